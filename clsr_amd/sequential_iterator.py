@@ -1,0 +1,309 @@
+"""Host-side batch builder for the CLSR step (numpy only).
+
+Mirror of the reference's ``reco_utils/recommender/deeprec/io/sequential_iterator.py``
+(``SequentialIterator`` ``:19-503`` and ``SASequentialIterator`` ``:506-732``):
+same TSV format, same time features, same left-aligned zero padding, same
+in-batch negative sampling driven by the global ``random`` module, so that for a
+given ``random.seed`` the produced feeds are bit-identical to the reference's
+(pinned by ``tests/golden/iterator_*.npz``, captured from the reference iterator).
+
+Differences by design:
+* feeds are keyed by field-name strings (``iterator.labels == "labels"`` ...)
+  instead of TF placeholders -- ``feed[iterator.users]`` keeps working;
+* the O(P*G*T) python loops of ``_convert_data`` (ref ``:588-634``) are replaced by
+  vectorised numpy scatter; only the negative-sampling draw (``random.randint``
+  rejection loop, ref ``:622-634``) stays a python loop because its RNG call
+  sequence is part of the observable behaviour.
+"""
+import random
+
+import numpy as np
+
+from clsr_amd.deeprec_utils import load_dict
+
+__all__ = ["BaseIterator", "SequentialIterator", "SASequentialIterator"]
+
+_FIELDS = (
+    "labels users items cates item_history item_cate_history mask time time_diff "
+    "time_from_first_action time_to_now"
+).split()
+
+
+class BaseIterator(object):
+    """4-method contract of the reference's ``io/iterator.py:9-24``."""
+
+    def parser_one_line(self, line):
+        raise NotImplementedError
+
+    def load_data_from_file(self, infile):
+        raise NotImplementedError
+
+    def _convert_data(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def gen_feed_dict(self, data_dict):
+        raise NotImplementedError
+
+
+class SequentialIterator(BaseIterator):
+    def __init__(self, hparams, graph=None, col_spliter="\t"):
+        """Load the three vocabularies and remember batch geometry (ref ``:20-70``).
+
+        ``graph`` is accepted and ignored (there is no TF graph).
+        """
+        self.col_spliter = col_spliter
+        self.userdict = load_dict(hparams.user_vocab)
+        self.itemdict = load_dict(hparams.item_vocab)
+        self.catedict = load_dict(hparams.cate_vocab)
+        self.max_seq_length = hparams.max_seq_length
+        self.batch_size = hparams.batch_size
+        self.iter_data = dict()
+        self.time_unit = hparams.time_unit
+        self.graph = graph
+        # feed keys (the reference exposes placeholders under these attribute names)
+        for name in _FIELDS:
+            setattr(self, name, name)
+
+    # ------------------------------------------------------------------ parsing
+    def parse_file(self, input_file):
+        """Parse every line of ``input_file`` (ref ``:72-88``)."""
+        with open(input_file, "r") as f:
+            lines = f.readlines()
+        return [self.parser_one_line(line) for line in lines if line]
+
+    def parser_one_line(self, line):
+        """One TSV line -> tuple of parsed fields (ref ``:90-163``).
+
+        ``label \\t user \\t item \\t cate \\t ts \\t item_hist(csv) \\t cate_hist(csv) \\t ts_hist(csv)``
+        """
+        words = line.strip().split(self.col_spliter)
+        label = int(words[0])
+        user_id = self.userdict.get(words[1], 0)
+        item_id = self.itemdict.get(words[2], 0)
+        item_cate = self.catedict.get(words[3], 0)
+        current_time = float(words[4])
+
+        item_hist, cate_hist = self.get_item_cate_history_sequence(
+            words[5].strip().split(","), words[6].strip().split(","), user_id
+        )
+        ts = np.asarray(self.get_time_history_sequence(words[7].strip().split(",")), dtype=np.float64)
+
+        time_range = 3600 * 24 * 1000 if self.time_unit == "ms" else 3600 * 24 / 1000
+
+        gaps = np.append(ts[1:] - ts[:-1], current_time - ts[-1]) / time_range
+        time_diff = np.log(np.maximum(gaps, 0.5))
+        since_first = np.append(ts[1:] - ts[0], current_time - ts[0]) / time_range
+        time_from_first_action = np.log(np.maximum(since_first, 0.5))
+        time_to_now = np.log(np.maximum((current_time - ts) / time_range, 0.5))
+
+        return (
+            label,
+            user_id,
+            item_id,
+            item_cate,
+            item_hist,
+            cate_hist,
+            current_time,
+            time_diff,
+            time_from_first_action,
+            time_to_now,
+        )
+
+    def get_item_cate_history_sequence(self, item_history_words, cate_history_words, user_id):
+        return (
+            self.get_item_history_sequence(item_history_words),
+            self.get_cate_history_sequence(cate_history_words),
+        )
+
+    def get_item_history_sequence(self, item_history_words):
+        d = self.itemdict
+        return [d.get(w, 0) for w in item_history_words]
+
+    def get_cate_history_sequence(self, cate_history_words):
+        d = self.catedict
+        return [d.get(w, 0) for w in cate_history_words]
+
+    def get_time_history_sequence(self, time_history_words):
+        return [float(w) for w in time_history_words]
+
+    # ------------------------------------------------------------------ batching
+    def load_data_from_file(self, infile, batch_num_ngs=0, min_seq_length=1):
+        """Generator of feed dicts, ``batch_size`` file lines each (ref ``:194-302``).
+
+        Parsed files are cached in ``self.iter_data``; when ``batch_num_ngs > 0`` the
+        cached list is shuffled in place with ``random.shuffle`` every call.  Yields
+        ``None`` for a training batch the reference drops (fewer than 5 lines).
+        """
+        if infile not in self.iter_data:
+            self.iter_data[infile] = self.parse_file(infile)
+        lines = self.iter_data[infile]
+        if batch_num_ngs > 0:
+            random.shuffle(lines)
+
+        chunk = []
+        for line in lines:
+            if not line:
+                continue
+            if len(line[4]) < min_seq_length:
+                continue
+            chunk.append(line)
+            if len(chunk) == self.batch_size:
+                feed = self.gen_feed_dict(self._convert_chunk(chunk, batch_num_ngs))
+                yield feed if feed else None
+                chunk = []
+        if chunk:
+            feed = self.gen_feed_dict(self._convert_chunk(chunk, batch_num_ngs))
+            yield feed if feed else None
+
+    def _convert_chunk(self, chunk, batch_num_ngs):
+        cols = list(zip(*chunk))
+        return self._convert_data(
+            list(cols[0]), list(cols[1]), list(cols[2]), list(cols[3]), list(cols[4]),
+            list(cols[5]), list(cols[6]), list(cols[7]), list(cols[8]), list(cols[9]),
+            batch_num_ngs,
+        )
+
+    _with_attn_labels = False
+
+    def _pad_histories(self, item_history_batch, item_cate_history_batch, time_diff_list,
+                       time_from_first_action_list, time_to_now_list):
+        """Most recent ``T`` actions, left-aligned, zero padded (ref ``:353-396, 588-610``)."""
+        n = len(item_history_batch)
+        T = self.max_seq_length
+        lens = np.fromiter((min(len(h), T) for h in item_history_batch), dtype=np.int64, count=n)
+        total = int(lens.sum())
+        rows = np.repeat(np.arange(n), lens)
+        cols = np.arange(total) - np.repeat(np.cumsum(lens) - lens, lens)
+
+        def scatter(seqs, dtype):
+            out = np.zeros((n, T), dtype=dtype)
+            if total:
+                flat = np.concatenate(
+                    [np.asarray(s[len(s) - l:], dtype=dtype) for s, l in zip(seqs, lens) if l > 0]
+                )
+                out[rows, cols] = flat
+            return out
+
+        item_hist = scatter(item_history_batch, np.int32)
+        cate_hist = scatter(item_cate_history_batch, np.int32)
+        tdiff = scatter(time_diff_list, np.float32)
+        tfirst = scatter(time_from_first_action_list, np.float32)
+        tnow = scatter(time_to_now_list, np.float32)
+        mask = np.zeros((n, T), dtype=np.float32)
+        mask[rows, cols] = 1.0
+        return lens, item_hist, cate_hist, mask, tdiff, tfirst, tnow
+
+    def _sample_negatives(self, item_list, batch_num_ngs):
+        """In-batch negative sampling with the reference's exact RNG call sequence
+        (``random.randint(0, n-1)``, reject draws whose item equals the positive;
+        ref ``:398-414, 612-634``).  Returns ``src[n, 1+ngs]``: for every output row,
+        the index of the batch line whose (item, cate) it carries.
+        """
+        n = len(item_list)
+        src = np.empty((n, batch_num_ngs + 1), dtype=np.int64)
+        randint = random.randint
+        hi = n - 1
+        for i in range(n):
+            pos = item_list[i]
+            src[i, 0] = i
+            count = 0
+            while count < batch_num_ngs:
+                j = randint(0, hi)
+                if item_list[j] == pos:
+                    continue
+                count += 1
+                src[i, count] = j
+        return src
+
+    def _convert_data(self, label_list, user_list, item_list, item_cate_list, item_history_batch,
+                      item_cate_history_batch, time_list, time_diff_list,
+                      time_from_first_action_list, time_to_now_list, batch_num_ngs):
+        """Lists of parsed fields -> dict of numpy arrays (ref ``:304-478``; SA variant ``:519-704``).
+
+        Training (``batch_num_ngs > 0``): every line becomes ``1 + batch_num_ngs`` rows
+        (positive first); batches with fewer than 5 lines are dropped (returns ``None``).
+        Evaluation: one row per line, ``users`` as float32 like the reference (``:462, 694``).
+        """
+        n = len(label_list)
+        if batch_num_ngs:
+            if n < 5:
+                return None
+        lens, item_hist, cate_hist, mask, tdiff, tfirst, tnow = self._pad_histories(
+            item_history_batch, item_cate_history_batch, time_diff_list,
+            time_from_first_action_list, time_to_now_list,
+        )
+        items = np.asarray(item_list, dtype=np.int32)
+        cates = np.asarray(item_cate_list, dtype=np.int32)
+        res = {}
+        if batch_num_ngs:
+            G = batch_num_ngs + 1
+            src = self._sample_negatives(item_list, batch_num_ngs)
+            flat_src = src.reshape(-1)
+            labels = np.zeros((n, G), dtype=np.float32)
+            labels[:, 0] = 1.0
+            res["labels"] = labels.reshape(-1, 1)
+            row_items = items[flat_src]
+            row_cates = cates[flat_src]
+            rep = np.repeat(np.arange(n), G)
+            if self._with_attn_labels:
+                res["attn_labels"] = self._attn_labels(cate_hist[rep], mask[rep], lens[rep], row_cates)
+            res["users"] = np.repeat(np.asarray(user_list, dtype=np.int32), G)
+            res["items"] = row_items
+            res["cates"] = row_cates
+            res["item_history"] = item_hist[rep]
+            res["item_cate_history"] = cate_hist[rep]
+            res["mask"] = mask[rep]
+            res["time"] = np.repeat(np.asarray(time_list, dtype=np.float32), G)
+            res["time_diff"] = tdiff[rep]
+            res["time_from_first_action"] = tfirst[rep]
+            res["time_to_now"] = tnow[rep]
+            return res
+
+        res["labels"] = np.asarray(label_list, dtype=np.float32).reshape(-1, 1)
+        if self._with_attn_labels:
+            res["attn_labels"] = self._attn_labels(cate_hist, mask, lens, cates)
+        res["users"] = np.asarray(user_list, dtype=np.float32)
+        res["items"] = items
+        res["cates"] = cates
+        res["item_history"] = item_hist
+        res["item_cate_history"] = cate_hist
+        res["mask"] = mask
+        res["time"] = np.asarray(time_list, dtype=np.float32)
+        res["time_diff"] = tdiff
+        res["time_from_first_action"] = tfirst
+        res["time_to_now"] = tnow
+        return res
+
+    @staticmethod
+    def _attn_labels(cate_hist, mask, lens, row_cates):
+        """Fraction of the (truncated) history whose category equals the row's target
+        category (ref ``:618, 629, 677-678``).  A zero-length history gives 0/0 = nan,
+        as in the reference."""
+        same = ((cate_hist == row_cates[:, None]) & (mask > 0)).sum(1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            frac = same / lens.astype(np.float64)
+        return frac.astype(np.float32).reshape(-1, 1)
+
+    def gen_feed_dict(self, data_dict):
+        """Map field names to arrays; empty dict for a dropped batch (ref ``:480-503``)."""
+        if not data_dict:
+            return dict()
+        return {getattr(self, name): data_dict[name] for name in _FIELDS}
+
+
+class SASequentialIterator(SequentialIterator):
+    """Adds ``attn_labels`` (ref ``:506-732``); the iterator CLSR is built with
+    (``examples/00_quick_start/sequential.py:88-91``)."""
+
+    _with_attn_labels = True
+
+    def __init__(self, hparams, graph=None, col_spliter="\t"):
+        super(SASequentialIterator, self).__init__(hparams, graph, col_spliter)
+        self.attn_labels = "attn_labels"
+
+    def gen_feed_dict(self, data_dict):
+        if not data_dict:
+            return dict()
+        feed = super(SASequentialIterator, self).gen_feed_dict(data_dict)
+        feed[self.attn_labels] = data_dict["attn_labels"]
+        return feed

@@ -1,0 +1,122 @@
+"""CPU tests: the host-side iterator / metrics / hparams against fixtures captured from the
+reference (scripts/make_golden.py)."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from clsr_amd.deeprec_utils import (
+    HParams, cal_mean_alpha_metric, cal_metric, cal_weighted_metric, prepare_hparams, roc_auc,
+)
+from clsr_amd.sequential_iterator import SASequentialIterator, SequentialIterator
+
+FIELDS = ("labels users items cates item_history item_cate_history mask time time_diff "
+          "time_from_first_action time_to_now").split()
+
+
+def _check_feed(feed, gold, b, with_attn):
+    names = FIELDS + (["attn_labels"] if with_attn else [])
+    for name in names:
+        exp = gold["b%d_%s" % (b, name)]
+        got = feed[name]
+        assert got.dtype == exp.dtype, (name, got.dtype, exp.dtype)
+        assert got.shape == exp.shape, (name, got.shape, exp.shape)
+        np.testing.assert_array_equal(got, exp, err_msg=name)
+
+
+@pytest.mark.parametrize("cls,tag", [(SASequentialIterator, "sa"), (SequentialIterator, "plain")])
+def test_iterator_matches_reference_feeds(golden_dir, golden_hparams, cls, tag):
+    d = os.path.join(golden_dir, "data")
+    it = cls(golden_hparams, None)
+    gold = np.load(os.path.join(golden_dir, "iterator_train_%s.npz" % tag))
+    random.seed(1234)
+    gen = it.load_data_from_file(os.path.join(d, "train_data"), batch_num_ngs=4, min_seq_length=1)
+    n = 0
+    for feed in gen:
+        if not feed:
+            continue
+        _check_feed(feed, gold, n, tag == "sa")
+        n += 1
+        if n == int(gold["n_batches"]):
+            break
+    assert n == int(gold["n_batches"])
+    gold = np.load(os.path.join(golden_dir, "iterator_eval_%s.npz" % tag))
+    n = 0
+    for feed in it.load_data_from_file(os.path.join(d, "valid_data"), batch_num_ngs=0):
+        _check_feed(feed, gold, n, tag == "sa")
+        n += 1
+    assert n == int(gold["n_batches"])
+
+
+def test_iterator_drops_small_training_batches(golden_dir, golden_hparams, tmp_path):
+    src = os.path.join(golden_dir, "data", "train_data")
+    small = tmp_path / "small"
+    with open(src) as f:
+        lines = f.readlines()[:67]  # 64 + 3 -> trailing batch of 3 (<5) is dropped
+    small.write_text("".join(lines))
+    it = SASequentialIterator(golden_hparams, None)
+    random.seed(0)
+    feeds = list(it.load_data_from_file(str(small), batch_num_ngs=4))
+    assert len(feeds) == 2 and feeds[1] is None
+    assert feeds[0]["labels"].shape == (64 * 5, 1)
+    # eval keeps the ragged tail and feeds users as float32 (reference quirk)
+    feeds = list(it.load_data_from_file(str(small), batch_num_ngs=0))
+    assert feeds[1]["labels"].shape == (3, 1) and feeds[1]["users"].dtype == np.float32
+
+
+def test_iterator_history_truncation_and_oov(golden_hparams, tmp_path):
+    hp = golden_hparams
+    it = SASequentialIterator(hp, None)
+    hist = ",".join("i%d" % i for i in range(25))
+    cats = ",".join("c1" for _ in range(25))
+    ts = ",".join(str(1511539200 + 100 * i) for i in range(25))
+    line = "\t".join(["1", "nobody", "not_an_item", "not_a_cate", str(1511539200 + 5000), hist, cats, ts])
+    parsed = it.parser_one_line(line)
+    assert parsed[1] == 0 and parsed[2] == 0 and parsed[3] == 0
+    res = it._convert_chunk([parsed], 0)
+    assert res["mask"].sum() == hp.max_seq_length  # most recent T kept
+    exp = [it.itemdict.get("i%d" % i, 0) for i in range(15, 25)]
+    np.testing.assert_array_equal(res["item_history"][0], exp)
+
+
+def test_metrics_match_reference_known_answers(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "metrics_golden.json")))
+    labels = np.asarray(g["labels"], dtype=np.float32)
+    preds = np.asarray(g["preds"], dtype=np.float32)
+    users = g["users"]
+    fl, fp = labels.reshape(-1).tolist(), preds.reshape(-1).tolist()
+    res = {}
+    res.update(cal_metric(fl, fp, ["auc", "logloss"]))
+    res.update(cal_metric(list(labels), list(preds), ["mean_mrr", "ndcg@2;4;6", "hit@2;4;6", "group_auc"]))
+    res.update(cal_weighted_metric(users, fp, fl, ["wauc", "whit@1;2"]))
+    res.update(cal_mean_alpha_metric(fp, fl))
+    for k, v in g["expected"].items():
+        assert abs(res[k] - v) < 1e-9, (k, res[k], v)
+
+
+def test_auc_matches_sklearn_with_ties():
+    from sklearn.metrics import roc_auc_score
+
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        y = rng.integers(0, 2, size=200)
+        s = np.round(rng.random(200), 1)  # many ties
+        assert abs(roc_auc(y, s) - roc_auc_score(y, s)) < 1e-12
+    with pytest.raises(ValueError):
+        roc_auc(np.ones(5), rng.random(5))
+
+
+def test_prepare_hparams_defaults_and_checks(golden_hparams):
+    hp = golden_hparams
+    assert isinstance(hp, HParams)
+    assert "min_seq_length" in hp and hp.min_seq_length == 1
+    assert hp.sequential_model == "time4lstm" and hp.contrastive_recent_k == 3
+    assert hp.max_grad_norm == 2 and hp.optimizer == "adam" and hp.enable_BN is True
+    hp.current_epoch = 3  # mutable like tf HParams
+    assert hp.current_epoch == 3
+    with pytest.raises(ValueError):
+        prepare_hparams(None, model_type="clsr", item_embedding_dim=32)
+    with pytest.raises(TypeError):
+        prepare_hparams(None, model_type="other", learning_rate=1)
