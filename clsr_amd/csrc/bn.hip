@@ -1,0 +1,199 @@
+// Batch-normalisation pieces of _fcn_net (gfx950).
+//
+// Reference: tf.layers.batch_normalization(momentum=0.95, epsilon=1e-4, training=is_train_stage)
+// at models/base_model.py:673-679 -- non-fused path for rank-2/3 inputs: moments over every axis
+// but the last (padded history positions included), biased variance for normalisation AND for
+// the moving average, moving <- 0.95*moving + 0.05*batch, inference uses the moving statistics.
+//
+// The forward normalise + ReLU is never materialised: pgemm writes the pre-BN linear output z
+// (and its per-block column sums), clsr_bn_finalize turns the sums into a per-feature affine
+// (scale, shift) and the NEXT consumer applies relu(z*scale + shift) while loading.
+// Backward:  dy = dh * (z*scale+shift > 0)      [clsr_bn_relu_bwd_reduce, + sums of dy, dy*xhat]
+//            dz = a1*dy + a2*z + a3              [clsr_bn_bwd_coef + clsr_bn_bwd_apply]
+// with a1 = gamma*invstd, a2 = -gamma*invstd^2*mean(dy*xhat), a3 = -gamma*invstd*mean(dy) - a2*mean.
+#include "common.h"
+
+// stats_partial: [nparts][2][C] doubles (column sums, column sums of squares).
+// outputs: scale, shift (always); mean, invstd (saved for backward); moving stats updated in place
+// when training.
+__global__ void bn_finalize_kernel(const double* __restrict__ stats_partial, int nparts, int C,
+                                   double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ moving_mean,
+                                   float* __restrict__ moving_var, float momentum, float eps,
+                                   int training, float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, var;
+  if (training) {
+    double s = 0.0, q = 0.0;
+    for (int p = 0; p < nparts; ++p) {
+      s += stats_partial[((long)p * 2 + 0) * C + c];
+      q += stats_partial[((long)p * 2 + 1) * C + c];
+    }
+    const double m = s / count;
+    double v = q / count - m * m;
+    if (v < 0.0) v = 0.0;
+    mean = (float)m;
+    var = (float)v;
+    moving_mean[c] = moving_mean[c] * momentum + mean * (1.0f - momentum);
+    moving_var[c] = moving_var[c] * momentum + var * (1.0f - momentum);
+  } else {
+    mean = moving_mean[c];
+    var = moving_var[c];
+  }
+  const float invstd = 1.0f / sqrtf(var + eps);
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - mean * sc;
+  if (mean_out) mean_out[c] = mean;
+  if (invstd_out) invstd_out[c] = invstd;
+}
+
+extern "C" int clsr_bn_finalize(const double* stats_partial, int nparts, int C, double count,
+                                const float* gamma, const float* beta, float* moving_mean,
+                                float* moving_var, float momentum, float eps, int training,
+                                float* scale, float* shift, float* mean_out, float* invstd_out,
+                                void* stream) {
+  CLSR_CHECK_ARG(gamma && beta && moving_mean && moving_var && scale && shift && C > 0);
+  CLSR_CHECK_ARG(!training || (stats_partial && nparts > 0 && count > 0));
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(clsr_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream,
+                     stats_partial, nparts, C, count, gamma, beta, moving_mean, moving_var, momentum,
+                     eps, training, scale, shift, mean_out, invstd_out);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// Thread layout for [M, C] column reductions: thread -> (ty, q) with q a fixed float4 column.
+#define COLRED_MAX_BLOCKS 512
+
+// dh (in) -> dy (out, in place): dy = dh * (z*scale + shift > 0)
+// partial[blockIdx.x][0][c] = sum dy ; partial[blockIdx.x][1][c] = sum dy * xhat,  xhat = (z-mean)*invstd
+__global__ void __launch_bounds__(256) bn_relu_bwd_reduce_kernel(
+    float* __restrict__ dh, const float* __restrict__ z, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+    int M, int C, double* __restrict__ partial) {
+  __shared__ double red[2][256][4];
+  const int QC = C >> 2;
+  const int rpb = 256 / QC;
+  const int ty = threadIdx.x / QC, q = threadIdx.x - ty * QC;
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (ty < rpb) {
+    const f32x4 sc = ld4(scale + 4 * q), sh = ld4(shift + 4 * q);
+    const f32x4 mu = ld4(mean + 4 * q), is = ld4(invstd + 4 * q);
+    for (long row = (long)blockIdx.x * rpb + ty; row < M; row += (long)gridDim.x * rpb) {
+      const long off = row * C + 4 * q;
+      const f32x4 zz = ld4(z + off);
+      f32x4 d = ld4(dh + off);
+      const f32x4 y = zz * sc + sh;
+      d.x = y.x > 0.f ? d.x : 0.f; d.y = y.y > 0.f ? d.y : 0.f;
+      d.z = y.z > 0.f ? d.z : 0.f; d.w = y.w > 0.f ? d.w : 0.f;
+      st4(dh + off, d);
+      const f32x4 xh = (zz - mu) * is;
+      s1[0] += d.x; s1[1] += d.y; s1[2] += d.z; s1[3] += d.w;
+      s2[0] += (double)d.x * xh.x; s2[1] += (double)d.y * xh.y;
+      s2[2] += (double)d.z * xh.z; s2[3] += (double)d.w * xh.w;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { red[0][threadIdx.x][r] = s1[r]; red[1][threadIdx.x][r] = s2[r]; }
+  __syncthreads();
+  if (threadIdx.x < QC) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double a = 0.0, b = 0.0;
+      for (int y = 0; y < rpb; ++y) { a += red[0][y * QC + threadIdx.x][r]; b += red[1][y * QC + threadIdx.x][r]; }
+      partial[((long)blockIdx.x * 2 + 0) * C + 4 * threadIdx.x + r] = a;
+      partial[((long)blockIdx.x * 2 + 1) * C + 4 * threadIdx.x + r] = b;
+    }
+  }
+}
+
+static int colred_blocks(int M, int C) {
+  const int rpb = 256 / (C / 4);
+  int b = clsr_cdiv(M, rpb * 4);
+  if (b > COLRED_MAX_BLOCKS) b = COLRED_MAX_BLOCKS;
+  if (b < 1) b = 1;
+  return b;
+}
+
+extern "C" int clsr_colred_parts(int M, int C) { return colred_blocks(M, C); }
+
+extern "C" int clsr_bn_relu_bwd_reduce(float* dh, const float* z, const float* scale,
+                                       const float* shift, const float* mean, const float* invstd,
+                                       int M, int C, double* partial, void* stream) {
+  CLSR_CHECK_ARG(dh && z && scale && shift && mean && invstd && partial && M > 0);
+  CLSR_CHECK_SUPPORTED(C % 4 == 0 && C >= 4 && C <= 1024);
+  hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(colred_blocks(M, C)), dim3(256), 0,
+                     (hipStream_t)stream, dh, z, scale, shift, mean, invstd, M, C, partial);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// coef[0..2][C] = a1, a2, a3 ; dgamma[c] (=|+=) sum dy*xhat ; dbeta[c] (=|+=) sum dy
+__global__ void bn_bwd_coef_kernel(const double* __restrict__ partial, int nparts, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ mean,
+                                   const float* __restrict__ invstd, float* __restrict__ coef,
+                                   float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                   int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int p = 0; p < nparts; ++p) {
+    s1 += partial[((long)p * 2 + 0) * C + c];
+    s2 += partial[((long)p * 2 + 1) * C + c];
+  }
+  const float g = gamma[c], is = invstd[c], mu = mean[c];
+  const float c1 = (float)(s1 / count), c2 = (float)(s2 / count);
+  const float a1 = g * is;
+  const float a2 = -g * is * is * c2;
+  coef[c] = a1;
+  coef[C + c] = a2;
+  coef[2 * C + c] = -a1 * c1 - a2 * mu;
+  if (accumulate) {
+    dgamma[c] += (float)s2;
+    dbeta[c] += (float)s1;
+  } else {
+    dgamma[c] = (float)s2;
+    dbeta[c] = (float)s1;
+  }
+}
+
+extern "C" int clsr_bn_bwd_coef(const double* partial, int nparts, int C, double count,
+                                const float* gamma, const float* mean, const float* invstd,
+                                float* coef, float* dgamma, float* dbeta, int accumulate,
+                                void* stream) {
+  CLSR_CHECK_ARG(partial && gamma && mean && invstd && coef && dgamma && dbeta && nparts > 0 && C > 0);
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(clsr_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream,
+                     partial, nparts, C, count, gamma, mean, invstd, coef, dgamma, dbeta, accumulate);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// dy (in place) -> dz = a1*dy + a2*z + a3
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(float* __restrict__ dy,
+                                                           const float* __restrict__ z,
+                                                           const float* __restrict__ coef, long M,
+                                                           int C) {
+  const int QC = C >> 2;
+  const long total = M * QC;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(e % QC);
+    const f32x4 a1 = ld4(coef + 4 * q), a2 = ld4(coef + C + 4 * q), a3 = ld4(coef + 2 * C + 4 * q);
+    const f32x4 d = ld4(dy + e * 4), zz = ld4(z + e * 4);
+    st4(dy + e * 4, a1 * d + a2 * zz + a3);
+  }
+}
+
+extern "C" int clsr_bn_bwd_apply(float* dy, const float* z, const float* coef, long M, int C,
+                                 void* stream) {
+  CLSR_CHECK_ARG(dy && z && coef && M > 0);
+  CLSR_CHECK_SUPPORTED(C % 4 == 0);
+  int blocks = clsr_cdiv(M * (C / 4), 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, z, coef,
+                     M, C);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}

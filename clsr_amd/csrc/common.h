@@ -1,0 +1,103 @@
+// Shared device/host helpers for the CLSR gfx950 kernels.
+// Target: MI355X (gfx950, CDNA4) only -- 64-wide wavefronts, fp32 MFMA 16x16x4.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CLSR_OK 0
+#define CLSR_EINVAL (-1)
+#define CLSR_ELAUNCH (-2)
+#define CLSR_EUNSUPPORTED (-3)
+
+void clsr_set_error(const char* fmt, ...);
+
+#define CLSR_CHECK_ARG(cond)                                                              \
+  do {                                                                                    \
+    if (!(cond)) {                                                                        \
+      clsr_set_error("%s:%d: invalid argument: %s", __FILE__, __LINE__, #cond);           \
+      return CLSR_EINVAL;                                                                 \
+    }                                                                                     \
+  } while (0)
+
+#define CLSR_CHECK_SUPPORTED(cond)                                                        \
+  do {                                                                                    \
+    if (!(cond)) {                                                                        \
+      clsr_set_error("%s:%d: unsupported shape: %s", __FILE__, __LINE__, #cond);          \
+      return CLSR_EUNSUPPORTED;                                                           \
+    }                                                                                     \
+  } while (0)
+
+#define CLSR_CHECK_LAUNCH()                                                               \
+  do {                                                                                    \
+    hipError_t e_ = hipGetLastError();                                                    \
+    if (e_ != hipSuccess) {                                                               \
+      clsr_set_error("%s:%d: kernel launch failed: %s", __FILE__, __LINE__,               \
+                     hipGetErrorString(e_));                                              \
+      return CLSR_ELAUNCH;                                                                \
+    }                                                                                     \
+  } while (0)
+
+#define CLSR_HIP(call)                                                                    \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      clsr_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call,                   \
+                     hipGetErrorString(e_));                                              \
+      return CLSR_ELAUNCH;                                                                \
+    }                                                                                     \
+  } while (0)
+
+static inline int clsr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+#ifdef __HIPCC__
+// ---- wave64 reductions -------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// sum over the 16 lanes that share (lane >> 4)
+__device__ __forceinline__ float row16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double row16_sum_d(double v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum over the 4 lanes {l, l^16, l^32, l^48} that share (lane & 15)
+__device__ __forceinline__ float col4_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// tanh via exp; accurate to ~1e-7 relative on the range that matters, saturates cleanly
+__device__ __forceinline__ float tanhf_(float x) {
+  float ax = fabsf(x);
+  float e = __expf(-2.0f * ax);
+  float t = (1.0f - e) / (1.0f + e);
+  return copysignf(t, x);
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+#define MFMA4(acc, a, b) (acc) = __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (acc), 0, 0, 0)
+#endif

@@ -1,0 +1,385 @@
+// Row-level heads of the CLSR step (gfx950): alpha-gate input/fusion, MLP output layers, the
+// group-softmax data loss, the contrastive loss; forward and backward.
+//
+// Reference: models/sequential/clsr.py:239-275 (concat_all, sigmoid alpha, user_embed fusion,
+// model_output), models/base_model.py:686-706 (w_nn_output/b_nn_output), base_model.py:215-235
+// (softmax data loss), clsr.py:46-71 (_compute_contrastive_loss).
+//
+// Rows b = h*G + g: the G rows of a history group share the history-level tensors
+// (final_state, att_fea_long, hist_mean, hist_recent); one wavefront owns one group so
+// history-level gradients are summed over the group in registers (no atomics).
+#include "common.h"
+
+// ------------------------------------------------------------------ alpha-gate input concat
+// out[b, :] = [fs[h] (nfs) | target[b] (D) | L[h] (D) | S[b] (D) | tnow_last[b] | 0 pad]   (ldo wide)
+__global__ void alpha_concat_kernel(const float* __restrict__ fs, int nfs, const float* __restrict__ target,
+                                    const float* __restrict__ L, const float* __restrict__ S,
+                                    const float* __restrict__ tnow, long tnow_stride, int tnow_col,
+                                    long B, int G, int D, float* __restrict__ out, int ldo) {
+  const long total = B * ldo;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long b = e / ldo;
+    const int c = (int)(e - b * ldo);
+    const long h = b / G;
+    float v = 0.f;
+    if (c < nfs) v = fs[h * nfs + c];
+    else if (c < nfs + D) v = target[b * D + (c - nfs)];
+    else if (c < nfs + 2 * D) v = L[h * D + (c - nfs - D)];
+    else if (c < nfs + 3 * D) v = S[b * D + (c - nfs - 2 * D)];
+    else if (c == nfs + 3 * D) v = tnow[b * tnow_stride + tnow_col];
+    out[e] = v;
+  }
+}
+
+extern "C" int clsr_alpha_concat(const float* fs, int nfs, const float* target, const float* L,
+                                 const float* S, const float* tnow, long tnow_stride, int tnow_col,
+                                 long B, int G, int D, float* out, int ldo, void* stream) {
+  CLSR_CHECK_ARG(target && L && S && tnow && out && B > 0 && G > 0 && (nfs == 0 || fs));
+  CLSR_CHECK_ARG(ldo >= nfs + 3 * D + 1);
+  int blocks = clsr_cdiv(B * ldo, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(alpha_concat_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, fs, nfs,
+                     target, L, S, tnow, tnow_stride, tnow_col, B, G, D, out, ldo);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// d(concat): dfs[h] += sum_g dA[b, 0:nfs]; dtarget[b] += dA[b, nfs:nfs+D]; dL[h] += sum_g ...; dS[b] += ...
+__global__ void __launch_bounds__(64) alpha_concat_bwd_kernel(const float* __restrict__ dA, int ldo, int nfs,
+                                                              long Hn, int G, int D,
+                                                              float* __restrict__ dfs,
+                                                              float* __restrict__ dtarget,
+                                                              float* __restrict__ dL,
+                                                              float* __restrict__ dS) {
+  const int lane = threadIdx.x;
+  for (long h = blockIdx.x; h < Hn; h += gridDim.x) {
+    for (int c = lane; c < nfs + 3 * D; c += 64) {
+      float acc = 0.f;
+      for (int gi = 0; gi < G; ++gi) {
+        const long b = h * G + gi;
+        const float v = dA[b * ldo + c];
+        if (c < nfs) acc += v;
+        else if (c < nfs + D) dtarget[b * D + (c - nfs)] += v;
+        else if (c < nfs + 2 * D) acc += v;
+        else dS[b * D + (c - nfs - 2 * D)] += v;
+      }
+      if (c < nfs) dfs[h * nfs + c] += acc;
+      else if (c >= nfs + D && c < nfs + 2 * D) dL[h * D + (c - nfs - D)] += acc;
+    }
+  }
+}
+
+extern "C" int clsr_alpha_concat_bwd(const float* dA, int ldo, int nfs, long Hn, int G, int D,
+                                     float* dfs, float* dtarget, float* dL, float* dS, void* stream) {
+  CLSR_CHECK_ARG(dA && dtarget && dL && dS && Hn > 0 && G > 0 && (nfs == 0 || dfs));
+  int blocks = Hn > 8192 ? 8192 : (int)Hn;
+  hipLaunchKernelGGL(alpha_concat_bwd_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, dA, ldo,
+                     nfs, Hn, G, D, dfs, dtarget, dL, dS);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// ------------------------------------------------------------------ MLP output layer
+// logit[b] = relu(z1[b,:]*scale + shift) . w_out + b_out
+__global__ void mlp_out_fwd_kernel(const float* __restrict__ z1, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, const float* __restrict__ w_out,
+                                   const float* __restrict__ b_out, long B, int C1,
+                                   float* __restrict__ logit) {
+  for (long b = (long)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (long)gridDim.x * blockDim.x) {
+    const float* zp = z1 + b * C1;
+    float s = b_out[0];
+    for (int c = 0; c < C1; c += 4) {
+      const f32x4 y = ld4(zp + c) * ld4(scale + c) + ld4(shift + c);
+      const f32x4 w = ld4(w_out + c);
+      s += fmaxf(y.x, 0.f) * w.x + fmaxf(y.y, 0.f) * w.y + fmaxf(y.z, 0.f) * w.z + fmaxf(y.w, 0.f) * w.w;
+    }
+    logit[b] = s;
+  }
+}
+
+extern "C" int clsr_mlp_out_fwd(const float* z1, const float* scale, const float* shift,
+                                const float* w_out, const float* b_out, long B, int C1, float* logit,
+                                void* stream) {
+  CLSR_CHECK_ARG(z1 && scale && shift && w_out && b_out && logit && B > 0);
+  CLSR_CHECK_SUPPORTED(C1 % 4 == 0);
+  int blocks = clsr_cdiv(B, 128);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(mlp_out_fwd_kernel, dim3(blocks), dim3(128), 0, (hipStream_t)stream, z1, scale, shift,
+                     w_out, b_out, B, C1, logit);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// dy1[b,c] = dlogit[b] * w_out[c] * (y1 > 0);  partial sums for BN backward and for d w_out / d b_out.
+// Thread layout (ty, q) as in bn.hip; bn_partial [nblocks][2][C1] doubles, w_partial [nblocks][C1+4] floats.
+__global__ void __launch_bounds__(256) mlp_out_bwd_kernel(
+    const float* __restrict__ dlogit, const float* __restrict__ z1, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ w_out, long B, int C1, float* __restrict__ dy1,
+    double* __restrict__ bn_partial, float* __restrict__ w_partial) {
+  __shared__ double red[2][256][4];
+  __shared__ float redw[256][4];
+  __shared__ float redb[256];
+  const int QC = C1 >> 2, rpb = 256 / QC;
+  const int ty = threadIdx.x / QC, q = threadIdx.x - ty * QC;
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  f32x4 sw = {0, 0, 0, 0};
+  float sb = 0.f;
+  if (ty < rpb) {
+    const f32x4 sc = ld4(scale + 4 * q), sh = ld4(shift + 4 * q), mu = ld4(mean + 4 * q);
+    const f32x4 is = ld4(invstd + 4 * q), wo = ld4(w_out + 4 * q);
+    for (long b = (long)blockIdx.x * rpb + ty; b < B; b += (long)gridDim.x * rpb) {
+      const float dl = dlogit[b];
+      const f32x4 zz = ld4(z1 + b * C1 + 4 * q);
+      const f32x4 y = zz * sc + sh;
+      f32x4 d = wo * dl;
+      d.x = y.x > 0.f ? d.x : 0.f; d.y = y.y > 0.f ? d.y : 0.f;
+      d.z = y.z > 0.f ? d.z : 0.f; d.w = y.w > 0.f ? d.w : 0.f;
+      st4(dy1 + b * C1 + 4 * q, d);
+      const f32x4 xh = (zz - mu) * is;
+      s1[0] += d.x; s1[1] += d.y; s1[2] += d.z; s1[3] += d.w;
+      s2[0] += (double)d.x * xh.x; s2[1] += (double)d.y * xh.y;
+      s2[2] += (double)d.z * xh.z; s2[3] += (double)d.w * xh.w;
+      sw.x += fmaxf(y.x, 0.f) * dl; sw.y += fmaxf(y.y, 0.f) * dl;
+      sw.z += fmaxf(y.z, 0.f) * dl; sw.w += fmaxf(y.w, 0.f) * dl;
+      if (q == 0) sb += dl;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { red[0][threadIdx.x][r] = s1[r]; red[1][threadIdx.x][r] = s2[r]; }
+  redw[threadIdx.x][0] = sw.x; redw[threadIdx.x][1] = sw.y; redw[threadIdx.x][2] = sw.z; redw[threadIdx.x][3] = sw.w;
+  redb[threadIdx.x] = sb;
+  __syncthreads();
+  if (threadIdx.x < QC) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double a = 0.0, b2 = 0.0;
+      float w = 0.f;
+      for (int y = 0; y < rpb; ++y) {
+        a += red[0][y * QC + threadIdx.x][r];
+        b2 += red[1][y * QC + threadIdx.x][r];
+        w += redw[y * QC + threadIdx.x][r];
+      }
+      bn_partial[((long)blockIdx.x * 2 + 0) * C1 + 4 * threadIdx.x + r] = a;
+      bn_partial[((long)blockIdx.x * 2 + 1) * C1 + 4 * threadIdx.x + r] = b2;
+      w_partial[(long)blockIdx.x * (C1 + 4) + 4 * threadIdx.x + r] = w;
+    }
+  }
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int y = 0; y < rpb; ++y) s += redb[y * QC];
+    w_partial[(long)blockIdx.x * (C1 + 4) + C1] = s;
+  }
+}
+
+static int mlp_bwd_blocks(long B, int C1) {
+  const int rpb = 256 / (C1 / 4);
+  long b = (B + rpb * 4 - 1) / (rpb * 4);
+  if (b > 512) b = 512;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+extern "C" int clsr_mlp_out_bwd_parts(long B, int C1) { return mlp_bwd_blocks(B, C1); }
+
+extern "C" int clsr_mlp_out_bwd(const float* dlogit, const float* z1, const float* scale,
+                                const float* shift, const float* mean, const float* invstd,
+                                const float* w_out, long B, int C1, float* dy1, double* bn_partial,
+                                float* w_partial, void* stream) {
+  CLSR_CHECK_ARG(dlogit && z1 && scale && shift && mean && invstd && w_out && dy1 && bn_partial && w_partial);
+  CLSR_CHECK_SUPPORTED(C1 % 4 == 0 && C1 >= 4 && C1 <= 1024 && B > 0);
+  hipLaunchKernelGGL(mlp_out_bwd_kernel, dim3(mlp_bwd_blocks(B, C1)), dim3(256), 0, (hipStream_t)stream,
+                     dlogit, z1, scale, shift, mean, invstd, w_out, B, C1, dy1, bn_partial, w_partial);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// ------------------------------------------------------------------ alpha fusion
+// alpha[b] = sigmoid(alpha_logit[b]) (or the manual constant);
+// mo[b, :] = [alpha*L[h] + (1-alpha)*S[b] | target[b]]
+__global__ void alpha_fuse_fwd_kernel(const float* __restrict__ alpha_logit, float manual_alpha,
+                                      const float* __restrict__ L, const float* __restrict__ S,
+                                      const float* __restrict__ target, long B, int G, int D,
+                                      float* __restrict__ alpha, float* __restrict__ mo) {
+  const long total = B * 2 * D;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long b = e / (2 * D);
+    const int c = (int)(e - b * 2 * D);
+    const float al = alpha_logit ? sigmoidf_(alpha_logit[b]) : manual_alpha;
+    if (c == 0 && alpha) alpha[b] = al;
+    float v;
+    if (c < D) v = al * L[(b / G) * D + c] + (1.0f - al) * S[b * D + c];
+    else v = target[b * D + (c - D)];
+    mo[e] = v;
+  }
+}
+
+extern "C" int clsr_alpha_fuse_fwd(const float* alpha_logit, float manual_alpha, const float* L,
+                                   const float* S, const float* target, long B, int G, int D,
+                                   float* alpha, float* mo, void* stream) {
+  CLSR_CHECK_ARG(L && S && target && mo && B > 0 && G > 0);
+  int blocks = clsr_cdiv(B * 2 * D, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(alpha_fuse_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, alpha_logit,
+                     manual_alpha, L, S, target, B, G, D, alpha, mo);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// backward: dmo[B, 2D] -> dalpha_logit[b], dL[h] += sum_g alpha*due, dS[b] += (1-alpha)*due,
+//           dtarget[b] += dmo[b, D:]
+__global__ void __launch_bounds__(64) alpha_fuse_bwd_kernel(
+    const float* __restrict__ dmo, const float* __restrict__ alpha, float manual_alpha,
+    const float* __restrict__ L, const float* __restrict__ S, long Hn, int G, int D,
+    float* __restrict__ dalpha_logit, float* __restrict__ dL, float* __restrict__ dS,
+    float* __restrict__ dtarget) {
+  const int lane = threadIdx.x;
+  for (long h = blockIdx.x; h < Hn; h += gridDim.x) {
+    for (int c0 = 0; c0 < D; c0 += 64) {  // D <= 64 -> one pass; larger D handled in column blocks
+      const int c = c0 + lane;
+      float accL = 0.f;
+      for (int gi = 0; gi < G; ++gi) {
+        const long b = h * G + gi;
+        const float al = alpha ? alpha[b] : manual_alpha;
+        float part = 0.f;
+        if (c < D) {
+          const float due = dmo[b * 2 * D + c];
+          part = due * (L[h * D + c] - S[b * D + c]);
+          accL += al * due;
+          dS[b * D + c] += (1.0f - al) * due;
+          dtarget[b * D + c] += dmo[b * 2 * D + D + c];
+        }
+        part = wave_sum(part);
+        if (dalpha_logit && lane == 0) {
+          const float da = part * al * (1.0f - al);
+          if (c0 == 0) dalpha_logit[b] = da; else dalpha_logit[b] += da;
+        }
+      }
+      if (c < D) dL[h * D + c] += accL;
+    }
+  }
+}
+
+extern "C" int clsr_alpha_fuse_bwd(const float* dmo, const float* alpha, float manual_alpha,
+                                   const float* L, const float* S, long Hn, int G, int D,
+                                   float* dalpha_logit, float* dL, float* dS, float* dtarget,
+                                   void* stream) {
+  CLSR_CHECK_ARG(dmo && L && S && dL && dS && dtarget && Hn > 0 && G > 0);
+  int blocks = Hn > 8192 ? 8192 : (int)Hn;
+  hipLaunchKernelGGL(alpha_fuse_bwd_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, dmo, alpha,
+                     manual_alpha, L, S, Hn, G, D, dalpha_logit, dL, dS, dtarget);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// ------------------------------------------------------------------ group-softmax data loss
+// loss = -(G/B) * sum_{b: label==1} log softmax_group(logit)[b]
+// dlogit[b] = (G/B) * (npos_group * softmax[b] - [label==1])
+__global__ void softmax_loss_kernel(const float* __restrict__ logit, const float* __restrict__ labels,
+                                    long P, int G, double* __restrict__ loss_out,
+                                    float* __restrict__ dlogit) {
+  const float scale = 1.0f / (float)P;  // G / B
+  float local = 0.f;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+    const float* lg = logit + p * G;
+    const float* lb = labels + p * G;
+    float mx = -INFINITY;
+    for (int g = 0; g < G; ++g) mx = fmaxf(mx, lg[g]);
+    float sum = 0.f;
+    for (int g = 0; g < G; ++g) sum += __expf(lg[g] - mx);
+    const float lse = mx + __logf(sum);
+    int npos = 0;
+    for (int g = 0; g < G; ++g)
+      if (lb[g] == 1.0f) { ++npos; local -= (lg[g] - lse); }
+    if (dlogit)
+      for (int g = 0; g < G; ++g) {
+        const float sm = __expf(lg[g] - lse);
+        dlogit[p * G + g] = scale * ((float)npos * sm - (lb[g] == 1.0f ? 1.0f : 0.0f));
+      }
+  }
+  local = wave_sum(local);
+  if ((threadIdx.x & 63) == 0 && local != 0.f) atomicAdd(loss_out, (double)local * scale);
+}
+
+extern "C" int clsr_softmax_loss(const float* logit, const float* labels, long P, int G,
+                                 double* loss_out, float* dlogit, void* stream) {
+  CLSR_CHECK_ARG(logit && labels && loss_out && P > 0 && G > 0);
+  int blocks = clsr_cdiv(P, 128);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(softmax_loss_kernel, dim3(blocks), dim3(128), 0, (hipStream_t)stream, logit, labels,
+                     P, G, loss_out, dlogit);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// ------------------------------------------------------------------ contrastive loss
+// mode 1 (triplet): four hinge terms on element-wise squared distances; mode 0 (bpr): four softplus
+// terms on dot products.  Every term is sum_b mask_b * term_b / sum_b mask_b, mask = len > threshold,
+// times `weight`.  denom = sum_b mask_b comes from the host (it only depends on the fed lengths).
+__device__ __forceinline__ float softplusf_(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
+
+__global__ void __launch_bounds__(64) contrastive_kernel(
+    const float* __restrict__ L, const float* __restrict__ S, const float* __restrict__ M,
+    const float* __restrict__ R, const int* __restrict__ seq_len, int len_stride, long Hn, int G, int D,
+    int threshold, int mode, float margin, float weight, const float* __restrict__ denom_ptr,
+    double* __restrict__ loss_out, float* __restrict__ dL, float* __restrict__ dS,
+    float* __restrict__ dM, float* __restrict__ dR) {
+  const int lane = threadIdx.x;
+  const float coef = weight / denom_ptr[0];
+  float loss_local = 0.f;
+  for (long h = blockIdx.x; h < Hn; h += gridDim.x) {
+    if (seq_len[h * len_stride] <= threshold) continue;
+    for (int c0 = 0; c0 < D; c0 += 64) {
+      const int c = c0 + lane;
+      const bool ok = c < D;
+      const float l = ok ? L[h * D + c] : 0.f, m = ok ? M[h * D + c] : 0.f, r = ok ? R[h * D + c] : 0.f;
+      float gl = 0.f, gm = 0.f, gr = 0.f;
+      for (int gi = 0; gi < G; ++gi) {
+        const long b = h * G + gi;
+        const float s = ok ? S[b * D + c] : 0.f;
+        float gs = 0.f;
+        if (mode == 1) {
+          if (ok) {
+            const float dLM = (l - m) * (l - m), dLR = (l - r) * (l - r);
+            const float dSM = (s - m) * (s - m), dSR = (s - r) * (s - r);
+            const float t1 = dLM - dLR + margin, t2 = dSR - dSM + margin;
+            const float t3 = dLM - dSM + margin, t4 = dSR - dLR + margin;
+            if (t1 > 0.f) { loss_local += t1; gl += 2.f * (r - m); gm -= 2.f * (l - m); gr += 2.f * (l - r); }
+            if (t2 > 0.f) { loss_local += t2; gs += 2.f * (m - r); gr -= 2.f * (s - r); gm += 2.f * (s - m); }
+            if (t3 > 0.f) { loss_local += t3; gl += 2.f * (l - m); gs -= 2.f * (s - m); gm += 2.f * (s - l); }
+            if (t4 > 0.f) { loss_local += t4; gs += 2.f * (s - r); gl -= 2.f * (l - r); gr += 2.f * (l - s); }
+          }
+        } else {
+          // softplus(sum L*(R-M)), softplus(sum S*(M-R)), softplus(sum M*(S-L)), softplus(sum R*(L-S))
+          const float a1 = wave_sum(l * (r - m)), a2 = wave_sum(s * (m - r));
+          const float a3 = wave_sum(m * (s - l)), a4 = wave_sum(r * (l - s));
+          if (c0 == 0 && lane == 0) loss_local += softplusf_(a1) + softplusf_(a2) + softplusf_(a3) + softplusf_(a4);
+          const float s1 = sigmoidf_(a1), s2 = sigmoidf_(a2), s3 = sigmoidf_(a3), s4 = sigmoidf_(a4);
+          gl += s1 * (r - m) - s3 * m + s4 * r;
+          gs += s2 * (m - r) + s3 * m - s4 * r;
+          gm += -s1 * l + s2 * s + s3 * (s - l);
+          gr += s1 * l - s2 * s + s4 * (l - s);
+        }
+        if (ok && dS) dS[b * D + c] += coef * gs;
+      }
+      if (ok && dL) { dL[h * D + c] += coef * gl; dM[h * D + c] += coef * gm; dR[h * D + c] += coef * gr; }
+    }
+  }
+  loss_local = wave_sum(loss_local);
+  if (lane == 0 && loss_local != 0.f) atomicAdd(loss_out, (double)loss_local * coef);
+}
+
+extern "C" int clsr_contrastive(const float* L, const float* S, const float* M, const float* R,
+                                const int* seq_len, int len_stride, long Hn, int G, int D, int threshold,
+                                int mode, float margin, float weight, const float* denom_ptr,
+                                double* loss_out, float* dL, float* dS, float* dM, float* dR,
+                                void* stream) {
+  CLSR_CHECK_ARG(L && S && M && R && seq_len && denom_ptr && loss_out && Hn > 0 && G > 0);
+  CLSR_CHECK_ARG((dL && dS && dM && dR) || (!dL && !dS && !dM && !dR));
+  CLSR_CHECK_SUPPORTED(mode == 1 || D <= 64);  // bpr dot products use one wave pass over D
+  int blocks = Hn > 4096 ? 4096 : (int)Hn;
+  hipLaunchKernelGGL(contrastive_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, L, S, M, R,
+                     seq_len, len_stride, Hn, G, D, threshold, mode, margin, weight, denom_ptr, loss_out,
+                     dL, dS, dM, dR);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}

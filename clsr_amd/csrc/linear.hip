@@ -1,0 +1,421 @@
+// Position-tiled fp32 MFMA linear layers (gfx950): forward / dX ("pgemm") and dW ("pgemm_dw").
+//
+// Replaces the reference's tf.tensordot / MatMul + BiasAdd sites on the CLSR path:
+//   models/base_model.py:664,704 (_fcn_net layers), models/sequential/clsr.py:363 (attention_mat),
+//   the input-side projections of GRUCell / Time4LSTMCell (rnn_cell_implement.py:207-231),
+// and their gradients.  Exact fp32: v_mfma_f32_16x16x4_f32 is bit-for-bit an fmaf chain.
+//
+// Orientation ("features x positions"): one MFMA tile is D[16 out-features][16 positions].
+//   A operand  = W^T tile from LDS   : lane (i = l&15, g = l>>4) holds Wt[o0 + i][kslot]
+//   B operand  = activations         : lane (j = l&15, g)        holds X[pos j][kslot]
+//   D          : lane (j, g) holds out features o0 + 4g + {0..3} of position j
+// The k-slot -> input-feature map is free as long as A and B agree, so MFMA #r of k-tile kt
+// uses feature 16*kt + 4g + r: every lane loads ONE float4 of its position's row per k-tile
+// and stores ONE float4 of outputs per out-tile -- the output layout of a layer is exactly
+// the input layout of the next one (16-byte vector global accesses, no LDS transposes).
+#include "common.h"
+
+struct PGemmArgs {
+  const float* X; int ldx;
+  int T; int G;                   // T>0: r = m / T, t = m % T; G>0: xrow = (r / G) * T + t else xrow = m
+  const float* Xmul; int ldmul;   // optional multiplier row r (needs T>0 or row-level positions)
+  const float* in_scale; const float* in_shift; int in_relu;  // optional per-input-feature affine (+relu)
+  const float* Wt; int Kp;        // packed transposed weights [16*ceil(N/16)][Kp], zero padded
+  const float* bias;
+  const float* addU; int ldu;     // optional += addU[xrow][n]
+  const float* addV; int ldv;     // optional += addV[r][n]
+  float* Y; int ldy; int accumulate;
+  double* stats;                  // optional per-block partial column sums [gridDim.x][2][N]
+  int M, K, N;
+};
+
+template <int OT, bool STATS>
+__global__ void __launch_bounds__(256) pgemm_kernel(PGemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int j = lane & 15, g = lane >> 4;
+  const int ntile_out = (a.N + 15) >> 4;
+  const int ot0 = blockIdx.y * OT;
+  const int otc = min(OT, ntile_out - ot0);
+  const int n0 = ot0 * 16;
+  const int KT = (a.K + 15) >> 4;
+  const int Kp = a.Kp;
+  {  // stage this block's W^T chunk: rows n0 .. n0 + 16*otc
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.Wt + (long)n0 * Kp);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds);
+    const int cnt = (16 * otc * Kp) >> 2;
+    for (int e = tid; e < cnt; e += 256) dst[e] = src[e];
+  }
+  __syncthreads();
+
+  double dsum[STATS ? OT : 1][4], dsq[STATS ? OT : 1][4];
+  if (STATS) {
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { dsum[ot][r] = 0.0; dsq[ot][r] = 0.0; }
+  }
+
+  const int ntiles = (a.M + 15) >> 4;
+  const float* ldsA = lds + (long)j * Kp + 4 * g;  // + ot*16*Kp + kt*16
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    const int m = tile * 16 + j;
+    const bool valid = m < a.M;
+    long xrow = m, r = m;
+    if (a.T > 0) {
+      r = m / a.T;
+      if (a.G > 0) xrow = (r / a.G) * a.T + (m - r * a.T);
+    }
+    const float* xp = a.X + xrow * a.ldx + 4 * g;
+    const float* mp = a.Xmul ? a.Xmul + r * a.ldmul + 4 * g : nullptr;
+
+    auto loadB = [&](int kt) -> f32x4 {
+      const int kcol = kt * 16 + 4 * g;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (valid && kcol < a.K) {
+        v = ld4(xp + kt * 16);
+        if (mp) v *= ld4(mp + kt * 16);
+        if (a.in_scale) {
+          v = v * ld4(a.in_scale + kcol) + ld4(a.in_shift + kcol);
+          if (a.in_relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          }
+        }
+      }
+      return v;
+    };
+
+    f32x4 acc[OT];
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) acc[ot] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 bnext = loadB(0);
+    for (int kt = 0; kt < KT; ++kt) {
+      const f32x4 b = bnext;
+      if (kt + 1 < KT) bnext = loadB(kt + 1);
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) {
+        if (ot < otc) {
+          const f32x4 w = ld4(ldsA + (long)ot * 16 * Kp + kt * 16);
+          MFMA4(acc[ot], w.x, b.x);
+          MFMA4(acc[ot], w.y, b.y);
+          MFMA4(acc[ot], w.z, b.z);
+          MFMA4(acc[ot], w.w, b.w);
+        }
+      }
+    }
+
+    if (valid) {
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) {
+        const int n = n0 + ot * 16 + 4 * g;
+        if (ot < otc && n < a.N) {
+          f32x4 v = acc[ot];
+          if (a.bias) v += ld4(a.bias + n);
+          if (a.addU) v += ld4(a.addU + xrow * a.ldu + n);
+          if (a.addV) v += ld4(a.addV + r * a.ldv + n);
+          float* yp = a.Y + (long)m * a.ldy + n;
+          if (a.accumulate) v += ld4(yp);
+          st4(yp, v);
+          if (STATS) {
+            dsum[ot][0] += v.x; dsq[ot][0] += (double)v.x * v.x;
+            dsum[ot][1] += v.y; dsq[ot][1] += (double)v.y * v.y;
+            dsum[ot][2] += v.z; dsq[ot][2] += (double)v.z * v.z;
+            dsum[ot][3] += v.w; dsq[ot][3] += (double)v.w * v.w;
+          }
+        }
+      }
+    }
+  }
+
+  if (STATS) {
+    __syncthreads();  // all waves are done with the weight tile; reuse LDS for the block reduction
+    double* red = reinterpret_cast<double*>(lds);  // [4 waves][2][OT*16]
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double s = row16_sum_d(dsum[ot][r]);
+        const double q = row16_sum_d(dsq[ot][r]);
+        if (j == 0) {
+          red[(wave * 2 + 0) * (OT * 16) + ot * 16 + 4 * g + r] = s;
+          red[(wave * 2 + 1) * (OT * 16) + ot * 16 + 4 * g + r] = q;
+        }
+      }
+    __syncthreads();
+    for (int e = tid; e < 2 * 16 * otc; e += 256) {
+      const int which = e / (16 * otc), c = e - which * 16 * otc;
+      const int n = n0 + c;
+      if (n < a.N) {
+        double s = 0.0;
+        for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * (OT * 16) + c];
+        a.stats[((long)blockIdx.x * 2 + which) * a.N + n] = s;
+      }
+    }
+  }
+}
+
+static int pgemm_grid_x(int M) {
+  int ntiles = clsr_cdiv(M, 16);
+  int gx = clsr_cdiv(ntiles, 4);
+  if (gx > 1024) gx = 1024;
+  if (gx < 1) gx = 1;
+  return gx;
+}
+
+extern "C" int clsr_pgemm_stats_parts(int M) { return pgemm_grid_x(M); }
+
+template <int OT>
+static int launch_pgemm(const PGemmArgs& a, hipStream_t stream) {
+  const int ntile_out = clsr_cdiv(a.N, 16);
+  dim3 grid(pgemm_grid_x(a.M), clsr_cdiv(ntile_out, OT));
+  size_t wbytes = (size_t)16 * OT * a.Kp * sizeof(float);
+  size_t sbytes = a.stats ? (size_t)4 * 2 * OT * 16 * sizeof(double) : 0;
+  size_t shmem = wbytes > sbytes ? wbytes : sbytes;
+  CLSR_CHECK_SUPPORTED(shmem <= 160 * 1024);
+  if (a.stats) {
+    if (shmem > 64 * 1024)
+      CLSR_HIP(hipFuncSetAttribute((const void*)pgemm_kernel<OT, true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL((pgemm_kernel<OT, true>), grid, dim3(256), shmem, stream, a);
+  } else {
+    if (shmem > 64 * 1024)
+      CLSR_HIP(hipFuncSetAttribute((const void*)pgemm_kernel<OT, false>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL((pgemm_kernel<OT, false>), grid, dim3(256), shmem, stream, a);
+  }
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// Y[m, :N] (=|+=) f(X)[xrow(m), :K] . W + bias + addU[xrow(m)] + addV[r(m)]
+//   f = optional (* Xmul[r(m)]) then optional (x*in_scale + in_shift, relu)
+// Wt is the packed transposed weight from clsr_pack_weight (row stride Kp).
+// stats (optional): per-block partial column sums / sums of squares of the stored values,
+//   [clsr_pgemm_stats_parts(M)][2][N] doubles, summed by clsr_bn_finalize.
+extern "C" int clsr_pgemm(const float* X, int ldx, int T, int G, const float* Xmul, int ldmul,
+                          const float* in_scale, const float* in_shift, int in_relu, const float* Wt,
+                          int Kp, const float* bias, const float* addU, int ldu, const float* addV,
+                          int ldv, float* Y, int ldy, int accumulate, double* stats, int M, int K,
+                          int N, void* stream) {
+  CLSR_CHECK_ARG(X && Wt && Y && M >= 0 && K > 0 && N > 0);
+  CLSR_CHECK_SUPPORTED(K % 4 == 0 && N % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && Kp % 4 == 0);
+  CLSR_CHECK_ARG(Kp >= 16 * clsr_cdiv(K, 16));
+  CLSR_CHECK_ARG(!(Xmul && ldmul % 4) && !(addU && ldu % 4) && !(addV && ldv % 4));
+  CLSR_CHECK_ARG(!(in_scale && !in_shift));
+  if (M == 0) return CLSR_OK;
+  PGemmArgs a;
+  a.X = X; a.ldx = ldx; a.T = T; a.G = G; a.Xmul = Xmul; a.ldmul = ldmul;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
+  a.Wt = Wt; a.Kp = Kp; a.bias = bias; a.addU = addU; a.ldu = ldu; a.addV = addV; a.ldv = ldv;
+  a.Y = Y; a.ldy = ldy; a.accumulate = accumulate; a.stats = stats; a.M = M; a.K = K; a.N = N;
+  const int nt = clsr_cdiv(N, 16);
+  hipStream_t s = (hipStream_t)stream;
+  if (nt <= 3) return launch_pgemm<3>(a, s);
+  if (nt <= 5) return launch_pgemm<5>(a, s);
+  if (nt <= 8) return launch_pgemm<8>(a, s);
+  const int waste5 = clsr_cdiv(nt, 5) * 5 - nt, waste8 = clsr_cdiv(nt, 8) * 8 - nt;
+  if (waste8 <= waste5) return launch_pgemm<8>(a, s);
+  return launch_pgemm<5>(a, s);
+}
+
+// ------------------------------------------------------------------------------------ packing
+// Wt[o][i] (o < 16*ceil(O/16), i < Ip) = s1 * A[o, i] + s2 * B[o, i], zero outside [O, I], where
+// A[o, i] = transposed ? src1[o*ld1 + i] : src1[i*ld1 + o]  (same for B).
+__global__ void pack_weight_kernel(const float* __restrict__ src1, int ld1, float s1,
+                                   const float* __restrict__ src2, int ld2, float s2, int transposed,
+                                   int O, int I, int Ip, int Opad, float* __restrict__ Wt) {
+  const int total = Opad * Ip;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int o = e / Ip, i = e - o * Ip;
+    float v = 0.f;
+    if (o < O && i < I) {
+      v = s1 * (transposed ? src1[(long)o * ld1 + i] : src1[(long)i * ld1 + o]);
+      if (src2) v += s2 * (transposed ? src2[(long)o * ld2 + i] : src2[(long)i * ld2 + o]);
+    }
+    Wt[e] = v;
+  }
+}
+
+extern "C" int clsr_pack_weight(const float* src1, int ld1, float s1, const float* src2, int ld2,
+                                float s2, int transposed, int O, int I, int Ip, float* Wt,
+                                void* stream) {
+  CLSR_CHECK_ARG(src1 && Wt && O > 0 && I > 0 && Ip >= I && Ip % 4 == 0);
+  const int Opad = 16 * clsr_cdiv(O, 16);
+  int blocks = clsr_cdiv((long)Opad * Ip, 256);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src1, ld1,
+                     s1, src2, ld2, s2, transposed, O, I, Ip, Opad, Wt);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// ------------------------------------------------------------------------------------ dW
+// dW[k, n] = sum_m f(X)[xrow(m), k] * dY[m, n];  db[n] = sum_m dY[m, n]
+// MFMA tile D[16 k][16 n] += A[16 k][4 m] . B[4 m][16 n]: the reduction (MFMA K) runs over
+// positions.  Every wave owns a full 80x80 (5x5 tile) accumulator chunk and a strided subset of
+// the positions; per-wave partial chunks go to `partial` and are summed deterministically by
+// clsr_dw_reduce (no float atomics on the weights).
+#define DW_T 5
+#define DW_CHUNK (DW_T * DW_T * 256 + DW_T * 16)
+
+struct DwArgs {
+  const float* X; int ldx; int T; int G; const float* Xmul; int ldmul;
+  const float* in_scale; const float* in_shift; int in_relu;
+  const float* dY; int ldy;
+  float* partial;
+  int M, K, N;
+};
+
+__global__ void __launch_bounds__(256) pgemm_dw_kernel(DwArgs a) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 15, g = lane >> 4;
+  const int k0 = blockIdx.y * (16 * DW_T), n0 = blockIdx.z * (16 * DW_T);
+  const int ktc = min(DW_T, ((a.K + 15) >> 4) - blockIdx.y * DW_T);
+  const int ntc = min(DW_T, ((a.N + 15) >> 4) - blockIdx.z * DW_T);
+  const int nw = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
+
+  float sc[DW_T], sh[DW_T];
+  bool kval[DW_T];
+#pragma unroll
+  for (int kt = 0; kt < DW_T; ++kt) {
+    const int k = k0 + kt * 16 + i;
+    kval[kt] = (kt < ktc) && (k < a.K);
+    sc[kt] = 1.f; sh[kt] = 0.f;
+    if (a.in_scale && kval[kt]) { sc[kt] = a.in_scale[k]; sh[kt] = a.in_shift[k]; }
+  }
+  f32x4 acc[DW_T][DW_T];
+#pragma unroll
+  for (int kt = 0; kt < DW_T; ++kt)
+#pragma unroll
+    for (int nt = 0; nt < DW_T; ++nt) acc[kt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum[DW_T];
+#pragma unroll
+  for (int nt = 0; nt < DW_T; ++nt) bsum[nt] = 0.f;
+
+  const int ngroups = (a.M + 15) >> 4;
+  for (int grp = gw; grp < ngroups; grp += nw) {
+    float av[4][DW_T], bv[4][DW_T];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int m = grp * 16 + 4 * s + g;
+      const bool valid = m < a.M;
+      long xrow = m, r = m;
+      if (a.T > 0) {
+        r = m / a.T;
+        if (a.G > 0) xrow = (r / a.G) * a.T + (m - r * a.T);
+      }
+#pragma unroll
+      for (int kt = 0; kt < DW_T; ++kt) {
+        float v = 0.f;
+        if (valid && kval[kt]) {
+          const int k = k0 + kt * 16 + i;
+          v = a.X[xrow * a.ldx + k];
+          if (a.Xmul) v *= a.Xmul[r * a.ldmul + k];
+          if (a.in_scale) {
+            v = v * sc[kt] + sh[kt];
+            if (a.in_relu) v = fmaxf(v, 0.f);
+          }
+        }
+        av[s][kt] = v;
+      }
+#pragma unroll
+      for (int nt = 0; nt < DW_T; ++nt) {
+        const int n = n0 + nt * 16 + i;
+        bv[s][nt] = (valid && nt < ntc && n < a.N) ? a.dY[(long)m * a.ldy + n] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int kt = 0; kt < DW_T; ++kt)
+        if (kt < ktc) {
+#pragma unroll
+          for (int nt = 0; nt < DW_T; ++nt)
+            if (nt < ntc) MFMA4(acc[kt][nt], av[s][kt], bv[s][nt]);
+        }
+#pragma unroll
+      for (int nt = 0; nt < DW_T; ++nt) bsum[nt] += bv[s][nt];
+    }
+  }
+
+  const long chunk = (long)blockIdx.y * gridDim.z + blockIdx.z;
+  float* out = a.partial + (chunk * nw + gw) * DW_CHUNK;
+#pragma unroll
+  for (int kt = 0; kt < DW_T; ++kt)
+#pragma unroll
+    for (int nt = 0; nt < DW_T; ++nt) {
+      float* t = out + (kt * DW_T + nt) * 256 + (4 * g) * 16 + i;
+      const f32x4 v = acc[kt][nt];
+      t[0] = v.x; t[16] = v.y; t[32] = v.z; t[48] = v.w;
+    }
+#pragma unroll
+  for (int nt = 0; nt < DW_T; ++nt) {
+    const float s = col4_sum(bsum[nt]);
+    if (g == 0) out[DW_T * DW_T * 256 + nt * 16 + i] = s;
+  }
+}
+
+// dW[k*ldw + n] (=|+=) scale * sum_p partial[...]; db[n] likewise (from K-chunk 0).
+__global__ void dw_reduce_kernel(const float* __restrict__ partial, int nw, int K, int N, int kchunks,
+                                 int nchunks, float scale, float* __restrict__ dW, int ldw,
+                                 float* __restrict__ db, int accumulate) {
+  const int total = K * N + (db ? N : 0);
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    if (e < K * N) {
+      const int k = e / N, n = e - k * N;
+      const int kc = k / (16 * DW_T), nc = n / (16 * DW_T);
+      const int kk = k - kc * 16 * DW_T, nn = n - nc * 16 * DW_T;
+      const long off = ((kk >> 4) * DW_T + (nn >> 4)) * 256 + (kk & 15) * 16 + (nn & 15);
+      const float* p = partial + ((long)(kc * nchunks + nc) * nw) * DW_CHUNK + off;
+      float s = 0.f;
+      for (int w = 0; w < nw; ++w) s += p[(long)w * DW_CHUNK];
+      s *= scale;
+      float* o = dW + (long)k * ldw + n;
+      *o = accumulate ? *o + s : s;
+    } else {
+      const int n = e - K * N;
+      const int nc = n / (16 * DW_T), nn = n - nc * 16 * DW_T;
+      const float* p = partial + ((long)(0 * nchunks + nc) * nw) * DW_CHUNK + DW_T * DW_T * 256 + nn;
+      float s = 0.f;
+      for (int w = 0; w < nw; ++w) s += p[(long)w * DW_CHUNK];
+      s *= scale;
+      db[n] = accumulate ? db[n] + s : s;
+    }
+  }
+}
+
+static int dw_grid_x(int M) {
+  int groups = clsr_cdiv(M, 16);
+  int gx = clsr_cdiv(groups, 4 * 8);  // >= 8 position groups per wave before adding waves
+  if (gx > 256) gx = 256;
+  if (gx < 1) gx = 1;
+  return gx;
+}
+
+// floats of workspace clsr_pgemm_dw needs
+extern "C" long clsr_pgemm_dw_workspace_floats(int M, int K, int N) {
+  const long chunks = (long)clsr_cdiv(K, 16 * DW_T) * clsr_cdiv(N, 16 * DW_T);
+  return chunks * dw_grid_x(M) * 4 * DW_CHUNK;
+}
+
+extern "C" int clsr_pgemm_dw(const float* X, int ldx, int T, int G, const float* Xmul, int ldmul,
+                             const float* in_scale, const float* in_shift, int in_relu,
+                             const float* dY, int ldy, int M, int K, int N, float scale, float* dW,
+                             int ldw, float* db, int accumulate, float* workspace, void* stream) {
+  CLSR_CHECK_ARG(X && dY && dW && workspace && M >= 0 && K > 0 && N > 0 && ldw >= N);
+  CLSR_CHECK_ARG(!(in_scale && !in_shift));
+  DwArgs a;
+  a.X = X; a.ldx = ldx; a.T = T; a.G = G; a.Xmul = Xmul; a.ldmul = ldmul;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
+  a.dY = dY; a.ldy = ldy; a.partial = workspace; a.M = M; a.K = K; a.N = N;
+  const int kch = clsr_cdiv(K, 16 * DW_T), nch = clsr_cdiv(N, 16 * DW_T);
+  const int gx = dw_grid_x(M);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(pgemm_dw_kernel, dim3(gx, kch, nch), dim3(256), 0, s, a);
+  CLSR_CHECK_LAUNCH();
+  const int total = K * N + (db ? N : 0);
+  hipLaunchKernelGGL(dw_reduce_kernel, dim3(clsr_cdiv(total, 256)), dim3(256), 0, s, workspace, gx * 4,
+                     K, N, kch, nch, scale, dW, ldw, db, accumulate);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}

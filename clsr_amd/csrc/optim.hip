@@ -1,0 +1,248 @@
+// Regularisers, per-tensor gradient clipping and Adam for the CLSR step (gfx950).
+//
+// Reference: models/base_model.py:118-159 (_l2_loss over "involved" embedding rows and every
+// non-embedding trainable), models/sequential/clsr.py:73-82 (_compute_discrepancy_loss),
+// base_model.py:281-297 (compute_gradients -> per-tensor tf.clip_by_norm -> apply_gradients),
+// base_model.py:263-264 tf.train.AdamOptimizer(lr): lr_t = lr*sqrt(1-b2^t)/(1-b1^t),
+// m <- b1 m + (1-b1) g, v <- b2 v + (1-b2) g^2, var <- var - lr_t m / (sqrt(v) + eps); for the
+// embedding tables (IndexedSlices) TF decays m, v over the WHOLE table and updates every row,
+// which is what the dense table sweep below does ("adam"); "lazyadam" (base_model.py:275-276)
+// touches flagged rows only.
+//
+// Dense parameters live in ONE flat fp32 buffer (param, grad, m, v) with a per-element tensor id
+// map, so the whole dense update is three launches regardless of the number of tensors.
+#include "common.h"
+
+// state[0]=step, [1]=beta1^t, [2]=beta2^t, [3]=lr_t   (doubles, device resident so graph replay works)
+__global__ void adam_tick_kernel(double* st, double lr, double b1, double b2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    st[0] += 1.0;
+    st[1] *= b1;
+    st[2] *= b2;
+    st[3] = lr * sqrt(1.0 - st[2]) / (1.0 - st[1]);
+  }
+}
+
+extern "C" int clsr_adam_tick(double* state, double lr, double beta1, double beta2, void* stream) {
+  CLSR_CHECK_ARG(state);
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, lr, beta1, beta2);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// One block per dense tensor: grad += l2 * param; sumsq[tensor] = ||grad||^2;
+// reg_loss += l2 * 0.5 * ||param||^2.
+__global__ void __launch_bounds__(256) dense_reg_norm_kernel(const float* __restrict__ param,
+                                                             float* __restrict__ grad,
+                                                             const int* __restrict__ seg_off, float l2,
+                                                             double* __restrict__ sumsq,
+                                                             double* __restrict__ reg_loss) {
+  __shared__ double red[2][4];
+  const int seg = blockIdx.x;
+  const int lo = seg_off[seg], hi = seg_off[seg + 1];
+  double ss = 0.0, pp = 0.0;
+  for (int e = lo + threadIdx.x; e < hi; e += 256) {
+    const float p = param[e];
+    const float g = grad[e] + l2 * p;
+    grad[e] = g;
+    ss += (double)g * g;
+    pp += (double)p * p;
+  }
+  ss = wave_sum_d(ss);
+  pp = wave_sum_d(pp);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ss; red[1][threadIdx.x >> 6] = pp; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sumsq[seg] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const double r = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    if (reg_loss) atomicAdd(reg_loss, 0.5 * (double)l2 * r);
+  }
+}
+
+extern "C" int clsr_dense_reg_norm(const float* param, float* grad, const int* seg_off, int nseg,
+                                   float l2, double* sumsq, double* reg_loss, void* stream) {
+  CLSR_CHECK_ARG(param && grad && seg_off && sumsq && nseg > 0);
+  hipLaunchKernelGGL(dense_reg_norm_kernel, dim3(nseg), dim3(256), 0, (hipStream_t)stream, param, grad,
+                     seg_off, l2, sumsq, reg_loss);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+__device__ __forceinline__ float clip_factor(double sumsq, float clip_norm) {
+  if (clip_norm <= 0.f) return 1.0f;
+  const float nrm = (float)sqrt(sumsq);
+  return clip_norm / fmaxf(nrm, clip_norm);
+}
+
+// Flat dense Adam: g = grad[e] * clip_factor(sumsq[seg_of[e]]); grad is zeroed for the next step.
+__global__ void __launch_bounds__(256) dense_adam_kernel(float* __restrict__ param, float* __restrict__ grad,
+                                                         float* __restrict__ m, float* __restrict__ v,
+                                                         const int* __restrict__ seg_of,
+                                                         const double* __restrict__ sumsq, float clip_norm,
+                                                         const double* __restrict__ adam_state, float b1,
+                                                         float b2, float eps, int n) {
+  const float lr_t = (float)adam_state[3];
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const float g = grad[e] * clip_factor(sumsq[seg_of[e]], clip_norm);
+    const float mm = b1 * m[e] + (1.0f - b1) * g;
+    const float vv = b2 * v[e] + (1.0f - b2) * g * g;
+    m[e] = mm;
+    v[e] = vv;
+    param[e] -= lr_t * mm / (sqrtf(vv) + eps);
+    grad[e] = 0.f;
+  }
+}
+
+extern "C" int clsr_dense_adam(float* param, float* grad, float* m, float* v, const int* seg_of,
+                               const double* sumsq, float clip_norm, const double* adam_state,
+                               float beta1, float beta2, float eps, int n, void* stream) {
+  CLSR_CHECK_ARG(param && grad && m && v && seg_of && sumsq && adam_state && n > 0);
+  int blocks = clsr_cdiv(n, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(dense_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, m, v,
+                     seg_of, sumsq, clip_norm, adam_state, beta1, beta2, eps, n);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// ---------------------------------------------------------------------------- embedding tables
+// count[0] = number of set flags (float, consumed by the discrepancy coefficient)
+__global__ void count_flags_kernel(const unsigned char* __restrict__ flags, long V, float* __restrict__ count) {
+  float local = 0.f;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < V; e += (long)gridDim.x * blockDim.x)
+    local += flags[e] ? 1.f : 0.f;
+  local = wave_sum(local);
+  if ((threadIdx.x & 63) == 0 && local != 0.f) atomicAdd(count, local);
+}
+
+extern "C" int clsr_count_flags(const unsigned char* flags, long V, float* count, void* stream) {
+  CLSR_CHECK_ARG(flags && count && V > 0);
+  int blocks = clsr_cdiv(V, 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(count_flags_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, flags, V, count);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// Pass A over the involved (flagged) rows of one table:
+//   g_reg = l2 * row + cd * (row - partner_row)        cd = disc_scale / (count * C)  (user tables)
+//   grad_table[row] += g_reg ; sumsq += ||g_reg||^2 ; reg_loss += l2/2 ||row||^2 ;
+//   disc_loss += disc_loss_scale * ||row - partner_row||^2 / (count * C)   (only when disc_loss != null)
+// These are the values of the reference's third IndexedSlices (the tf.unique "involved" lookup).
+__global__ void __launch_bounds__(256) table_reg_kernel(
+    const float* __restrict__ table, const float* __restrict__ partner,
+    const unsigned char* __restrict__ flags, long V, int C, float l2, float disc_scale,
+    float disc_loss_scale, const float* __restrict__ count, float* __restrict__ grad_table,
+    double* __restrict__ sumsq, double* __restrict__ reg_loss, double* __restrict__ disc_loss) {
+  const float cd = partner ? disc_scale / (count[0] * (float)C) : 0.f;
+  const float cl = (partner && disc_loss) ? disc_loss_scale / (count[0] * (float)C) : 0.f;
+  double ss = 0.0, rl = 0.0, dl = 0.0;
+  const long total = V * C;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long row = e / C;
+    if (!flags[row]) continue;
+    const float p = table[e];
+    float g = l2 * p;
+    if (partner) {
+      const float d = p - partner[e];
+      g += cd * d;
+      dl += (double)d * d;
+    }
+    grad_table[e] += g;
+    ss += (double)g * g;
+    rl += (double)p * p;
+  }
+  ss = wave_sum_d(ss); rl = wave_sum_d(rl); dl = wave_sum_d(dl);
+  if ((threadIdx.x & 63) == 0) {
+    if (ss != 0.0) atomicAdd(sumsq, ss);
+    if (reg_loss && rl != 0.0) atomicAdd(reg_loss, 0.5 * (double)l2 * rl);
+    if (disc_loss && dl != 0.0) atomicAdd(disc_loss, (double)cl * dl);
+  }
+}
+
+extern "C" int clsr_table_reg(const float* table, const float* partner, const unsigned char* flags,
+                              long V, int C, float l2, float disc_scale, float disc_loss_scale,
+                              const float* count, float* grad_table, double* sumsq, double* reg_loss,
+                              double* disc_loss, void* stream) {
+  CLSR_CHECK_ARG(table && flags && grad_table && sumsq && V > 0 && C > 0);
+  CLSR_CHECK_ARG(!partner || count);
+  int blocks = clsr_cdiv(V * C, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(table_reg_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, partner,
+                     flags, V, C, l2, disc_scale, disc_loss_scale, count, grad_table, sumsq, reg_loss,
+                     disc_loss);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// Pass B: Adam sweep of one table.  sumsq[0..nsum) are the squared norms of this table's
+// IndexedSlices pieces (lookup sites + involved rows); lazy != 0 restricts the update to rows whose
+// flag is set or that received gradient through a lookup (LazyAdam).  Clears grad rows and flags.
+__global__ void __launch_bounds__(256) table_adam_kernel(
+    float* __restrict__ table, float* __restrict__ grad_table, float* __restrict__ m,
+    float* __restrict__ v, unsigned char* __restrict__ flags, long V, int C,
+    const double* __restrict__ sumsq, int nsum, float clip_norm, const double* __restrict__ adam_state,
+    float b1, float b2, float eps, int lazy) {
+  double tot = 0.0;
+  for (int i = 0; i < nsum; ++i) tot += sumsq[i];
+  const float factor = clip_factor(tot, clip_norm);
+  const float lr_t = (float)adam_state[3];
+  const long total = V * C;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long row = e / C;
+    const float g = grad_table[e] * factor;
+    if (lazy && !flags[row]) continue;  // every row that got gradient is also flagged as involved
+    const float mm = b1 * m[e] + (1.0f - b1) * g;
+    const float vv = b2 * v[e] + (1.0f - b2) * g * g;
+    m[e] = mm;
+    v[e] = vv;
+    table[e] -= lr_t * mm / (sqrtf(vv) + eps);
+    grad_table[e] = 0.f;
+  }
+}
+
+__global__ void clear_bytes_kernel(unsigned char* p, long n) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) p[e] = 0;
+}
+
+extern "C" int clsr_table_adam(float* table, float* grad_table, float* m, float* v, unsigned char* flags,
+                               long V, int C, const double* sumsq, int nsum, float clip_norm,
+                               const double* adam_state, float beta1, float beta2, float eps, int lazy,
+                               void* stream) {
+  CLSR_CHECK_ARG(table && grad_table && m && v && flags && sumsq && adam_state && V > 0 && C > 0 && nsum > 0);
+  int blocks = clsr_cdiv(V * C, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(table_adam_kernel, dim3(blocks), dim3(256), 0, s, table, grad_table, m, v, flags, V, C,
+                     sumsq, nsum, clip_norm, adam_state, beta1, beta2, eps, lazy);
+  CLSR_CHECK_LAUNCH();
+  int cb = clsr_cdiv(V, 256);
+  if (cb > 1024) cb = 1024;
+  hipLaunchKernelGGL(clear_bytes_kernel, dim3(cb), dim3(256), 0, s, flags, V);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// p[0..n) = 0 (doubles)
+__global__ void zero_d_kernel(double* p, int n) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) p[e] = 0.0;
+}
+extern "C" int clsr_zero_doubles(double* p, int n, void* stream) {
+  CLSR_CHECK_ARG(p && n > 0);
+  hipLaunchKernelGGL(zero_d_kernel, dim3(clsr_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, n);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+__global__ void zero_f_kernel(float* p, long n) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) p[e] = 0.f;
+}
+extern "C" int clsr_zero_floats(float* p, long n, void* stream) {
+  CLSR_CHECK_ARG(p && n > 0);
+  int blocks = clsr_cdiv(n, 1024);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(zero_f_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, n);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}

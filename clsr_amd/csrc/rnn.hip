@@ -1,0 +1,559 @@
+// Recurrent encoders of CLSR as persistent per-wave kernels (gfx950): GRU and Time4LSTM,
+// forward and backward-through-time.
+//
+// Reference: tf.nn.rnn_cell.GRUCell under tensorflow.nn.dynamic_rnn at
+//   models/sequential/clsr.py:160-168 (short_term_intention, h0 = user_short_embedding),
+//   clsr.py:229-237 (causal2, zero h0), clsr.py:201-208 (sequential_model == 'gru'),
+// and Time4LSTMCell.call (models/sequential/rnn_cell_implement.py:129-298) at clsr.py:179-200.
+// dynamic_rnn semantics: steps t >= sequence_length copy the state through and emit zeros.
+//
+// Split of work: every input-side product (x.W_x, time-gate terms, biases) is hoisted out of the
+// time loop into one batched pgemm that produces Pin[h, t, :]; these kernels only run the
+// recurrence  state -> gates  with the hidden-to-hidden weights held in VGPRs as MFMA A
+// operands for the whole sequence.  One wavefront owns 16 histories; MFMA tile = D[16 hidden
+// features][16 histories]; the D layout of step t (lane (j,g): features 16*tile+4g+{0..3} of
+// history j) is exactly the B-operand layout of step t+1, so the state never leaves registers.
+// Hidden size n <= 48 (RNT = 3 feature tiles), n % 4 == 0.
+#include "common.h"
+
+#define RNT 3
+
+__device__ __forceinline__ f32x4 sig4(f32x4 v) {
+  return (f32x4){sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w)};
+}
+__device__ __forceinline__ f32x4 tanh4(f32x4 v) {
+  return (f32x4){tanhf_(v.x), tanhf_(v.y), tanhf_(v.z), tanhf_(v.w)};
+}
+__device__ __forceinline__ f32x4 sel4(bool c, f32x4 a, f32x4 b) { return c ? a : b; }
+#define Z4 ((f32x4){0.f, 0.f, 0.f, 0.f})
+
+// forward use: out[o] = sum_in W[in*ld + colbase + o] * state[in]
+__device__ __forceinline__ f32x4 load_w_fwd(const float* W, int ld, int colbase, int n, int ot, int kt,
+                                            int i, int g) {
+  f32x4 v = Z4;
+  const int o = 16 * ot + i;
+  if (o < n) {
+    const int in0 = 16 * kt + 4 * g;
+    if (in0 + 0 < n) v.x = W[(long)(in0 + 0) * ld + colbase + o];
+    if (in0 + 1 < n) v.y = W[(long)(in0 + 1) * ld + colbase + o];
+    if (in0 + 2 < n) v.z = W[(long)(in0 + 2) * ld + colbase + o];
+    if (in0 + 3 < n) v.w = W[(long)(in0 + 3) * ld + colbase + o];
+  }
+  return v;
+}
+// backward use: dstate[in] = sum_o W[in*ld + colbase + o] * dgate[o]
+__device__ __forceinline__ f32x4 load_w_bwd(const float* W, int ld, int colbase, int n, int ot, int kt,
+                                            int i, int g) {
+  const int in = 16 * ot + i, o0 = 16 * kt + 4 * g;
+  if (in < n && o0 < n) return ld4(W + (long)in * ld + colbase + o0);
+  return Z4;
+}
+
+template <int NO>
+__device__ __forceinline__ void matvec(f32x4 (&acc)[NO], const f32x4 (&w)[NO][RNT], const f32x4 (&b)[RNT]) {
+#pragma unroll
+  for (int kt = 0; kt < RNT; ++kt) {
+#pragma unroll
+    for (int ot = 0; ot < NO; ++ot) MFMA4(acc[ot], w[ot][kt].x, b[kt].x);
+#pragma unroll
+    for (int ot = 0; ot < NO; ++ot) MFMA4(acc[ot], w[ot][kt].y, b[kt].y);
+#pragma unroll
+    for (int ot = 0; ot < NO; ++ot) MFMA4(acc[ot], w[ot][kt].z, b[kt].z);
+#pragma unroll
+    for (int ot = 0; ot < NO; ++ot) MFMA4(acc[ot], w[ot][kt].w, b[kt].w);
+  }
+}
+
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ===================================================================================== GRU
+struct GruArgs {
+  const float* Pin; int ldp;           // [Hn, T, ldp]: r | u | c input-side pre-activations (+bias)
+  const float* Wgh; int ldg;           // [n, >=2n] hidden rows of gates/kernel
+  const float* Wch; int ldc;           // [n, >=n]  hidden rows of candidate/kernel
+  const float* h0; long h0_stride;     // optional initial state rows
+  const int* seq_len; int len_stride;
+  int Hn, T, n;
+  float* hT;                           // [Hn, n] final state
+  float* out_seq;                      // optional [Hn, T, n], zeros past len
+  float* hprev;                        // optional saves (training): [Hn, T, n]
+  float* gates;                        //                            [Hn, T, 3n] activated r | u | c
+  // backward
+  const float* dhT;                    // [Hn, n] grad wrt final state (may be null)
+  const float* dout_seq;               // optional [Hn, T, n]
+  float* dPin;                         // [Hn, T, 3n] (zeros past len)
+  float* dh0;                          // optional [Hn, n]
+};
+
+__global__ void __launch_bounds__(64) gru_fwd_kernel(GruArgs a) {
+  const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+  const int n = a.n, T = a.T;
+  const long h = (long)blockIdx.x * 16 + j;
+  const bool hvalid = h < a.Hn;
+  f32x4 wr[RNT][RNT], wu[RNT][RNT], wc[RNT][RNT];
+#pragma unroll
+  for (int ot = 0; ot < RNT; ++ot)
+#pragma unroll
+    for (int kt = 0; kt < RNT; ++kt) {
+      wr[ot][kt] = load_w_fwd(a.Wgh, a.ldg, 0, n, ot, kt, j, g);
+      wu[ot][kt] = load_w_fwd(a.Wgh, a.ldg, n, n, ot, kt, j, g);
+      wc[ot][kt] = load_w_fwd(a.Wch, a.ldc, 0, n, ot, kt, j, g);
+    }
+  bool cval[RNT];
+  f32x4 hs[RNT];
+#pragma unroll
+  for (int tl = 0; tl < RNT; ++tl) {
+    cval[tl] = hvalid && (16 * tl + 4 * g < n);
+    hs[tl] = (cval[tl] && a.h0) ? ld4(a.h0 + h * a.h0_stride + 16 * tl + 4 * g) : Z4;
+  }
+  const int len = hvalid ? min(a.seq_len[h * a.len_stride], T) : 0;
+  const int Tmax = wave_max_i(len);
+  const float* pin = a.Pin + (hvalid ? h : 0) * (long)T * a.ldp + 4 * g;
+  f32x4 pn[3][RNT];
+#pragma unroll
+  for (int gb = 0; gb < 3; ++gb)
+#pragma unroll
+    for (int tl = 0; tl < RNT; ++tl)
+      pn[gb][tl] = (cval[tl] && 0 < len) ? ld4(pin + gb * n + 16 * tl) : Z4;
+  for (int t = 0; t < Tmax; ++t) {
+    const bool live = t < len;
+    f32x4 accr[RNT], accu[RNT], accc[RNT];
+#pragma unroll
+    for (int tl = 0; tl < RNT; ++tl) { accr[tl] = pn[0][tl]; accu[tl] = pn[1][tl]; accc[tl] = pn[2][tl]; }
+    {  // prefetch next step's input projections
+      const bool nl = (t + 1) < len;
+#pragma unroll
+      for (int gb = 0; gb < 3; ++gb)
+#pragma unroll
+        for (int tl = 0; tl < RNT; ++tl)
+          pn[gb][tl] = (cval[tl] && nl) ? ld4(pin + (long)(t + 1) * a.ldp + gb * n + 16 * tl) : Z4;
+    }
+    matvec<RNT>(accr, wr, hs);
+    matvec<RNT>(accu, wu, hs);
+    f32x4 r[RNT], u[RNT], rh[RNT];
+#pragma unroll
+    for (int tl = 0; tl < RNT; ++tl) { r[tl] = sig4(accr[tl]); u[tl] = sig4(accu[tl]); rh[tl] = r[tl] * hs[tl]; }
+    matvec<RNT>(accc, wc, rh);
+#pragma unroll
+    for (int tl = 0; tl < RNT; ++tl) {
+      const f32x4 c = tanh4(accc[tl]);
+      const f32x4 hn = u[tl] * hs[tl] + (1.0f - u[tl]) * c;
+      if (live && cval[tl]) {
+        const long pos = h * T + t;
+        const int col = 16 * tl + 4 * g;
+        if (a.hprev) st4(a.hprev + pos * n + col, hs[tl]);
+        if (a.gates) {
+          float* gp = a.gates + pos * 3 * n + col;
+          st4(gp, r[tl]); st4(gp + n, u[tl]); st4(gp + 2 * n, c);
+        }
+        if (a.out_seq) st4(a.out_seq + pos * n + col, hn);
+      }
+      hs[tl] = sel4(live, hn, hs[tl]);
+    }
+  }
+#pragma unroll
+  for (int tl = 0; tl < RNT; ++tl)
+    if (cval[tl]) {
+      const int col = 16 * tl + 4 * g;
+      if (a.hT) st4(a.hT + h * n + col, hs[tl]);
+      if (a.out_seq)
+        for (int t = len; t < T; ++t) st4(a.out_seq + (h * T + t) * n + col, Z4);
+    }
+}
+
+__global__ void __launch_bounds__(64) gru_bwd_kernel(GruArgs a) {
+  const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+  const int n = a.n, T = a.T;
+  const long h = (long)blockIdx.x * 16 + j;
+  const bool hvalid = h < a.Hn;
+  // transposed operands: d(state in) = sum_o W[in][o] * dgate[o]
+  f32x4 wr[RNT][RNT], wu[RNT][RNT], wc[RNT][RNT];
+#pragma unroll
+  for (int ot = 0; ot < RNT; ++ot)
+#pragma unroll
+    for (int kt = 0; kt < RNT; ++kt) {
+      wr[ot][kt] = load_w_bwd(a.Wgh, a.ldg, 0, n, ot, kt, j, g);
+      wu[ot][kt] = load_w_bwd(a.Wgh, a.ldg, n, n, ot, kt, j, g);
+      wc[ot][kt] = load_w_bwd(a.Wch, a.ldc, 0, n, ot, kt, j, g);
+    }
+  bool cval[RNT];
+  f32x4 dh[RNT];
+#pragma unroll
+  for (int tl = 0; tl < RNT; ++tl) {
+    cval[tl] = hvalid && (16 * tl + 4 * g < n);
+    dh[tl] = (cval[tl] && a.dhT) ? ld4(a.dhT + h * n + 16 * tl + 4 * g) : Z4;
+  }
+  const int len = hvalid ? min(a.seq_len[h * a.len_stride], T) : 0;
+  const int Tmax = wave_max_i(len);
+  // zero dPin past len
+#pragma unroll
+  for (int tl = 0; tl < RNT; ++tl)
+    if (cval[tl])
+      for (int t = len; t < T; ++t) {
+        float* dp = a.dPin + (h * T + t) * 3 * n + 16 * tl + 4 * g;
+        st4(dp, Z4); st4(dp + n, Z4); st4(dp + 2 * n, Z4);
+      }
+  for (int t = Tmax - 1; t >= 0; --t) {
+    const bool live = t < len;
+    const long pos = h * T + t;
+    f32x4 r[RNT], u[RNT], c[RNT], hp[RNT], dcp[RNT], du[RNT], dhn[RNT];
+#pragma unroll
+    for (int tl = 0; tl < RNT; ++tl) {
+      const int col = 16 * tl + 4 * g;
+      const bool ok = live && cval[tl];
+      const float* gp = a.gates + pos * 3 * n + col;
+      r[tl] = ok ? ld4(gp) : Z4;
+      u[tl] = ok ? ld4(gp + n) : Z4;
+      c[tl] = ok ? ld4(gp + 2 * n) : Z4;
+      hp[tl] = ok ? ld4(a.hprev + pos * n + col) : Z4;
+      f32x4 d = dh[tl];
+      if (ok && a.dout_seq) d += ld4(a.dout_seq + pos * n + col);
+      d = sel4(ok, d, Z4);
+      du[tl] = d * (hp[tl] - c[tl]);
+      dcp[tl] = d * (1.0f - u[tl]) * (1.0f - c[tl] * c[tl]);
+      dhn[tl] = d * u[tl];
+    }
+    f32x4 drh[RNT] = {Z4, Z4, Z4};
+    matvec<RNT>(drh, wc, dcp);
+    f32x4 drp[RNT], dup[RNT];
+#pragma unroll
+    for (int tl = 0; tl < RNT; ++tl) {
+      drp[tl] = drh[tl] * hp[tl] * r[tl] * (1.0f - r[tl]);
+      dup[tl] = du[tl] * u[tl] * (1.0f - u[tl]);
+      dhn[tl] += drh[tl] * r[tl];
+    }
+    matvec<RNT>(dhn, wr, drp);
+    matvec<RNT>(dhn, wu, dup);
+#pragma unroll
+    for (int tl = 0; tl < RNT; ++tl) {
+      if (live && cval[tl]) {
+        float* dp = a.dPin + pos * 3 * n + 16 * tl + 4 * g;
+        st4(dp, drp[tl]); st4(dp + n, dup[tl]); st4(dp + 2 * n, dcp[tl]);
+      }
+      dh[tl] = sel4(live, dhn[tl], dh[tl]);
+    }
+  }
+  if (a.dh0) {
+#pragma unroll
+    for (int tl = 0; tl < RNT; ++tl)
+      if (cval[tl]) st4(a.dh0 + h * n + 16 * tl + 4 * g, dh[tl]);
+  }
+}
+
+static int check_rnn_shape(int Hn, int T, int n, int ld) {
+  CLSR_CHECK_ARG(Hn > 0 && T > 0);
+  CLSR_CHECK_SUPPORTED(n % 4 == 0 && n >= 4 && n <= 16 * RNT && ld % 4 == 0);
+  return CLSR_OK;
+}
+
+extern "C" int clsr_gru_fwd(const float* Pin, int ldp, const float* Wgh, int ldg, const float* Wch,
+                            int ldc, const float* h0, long h0_stride, const int* seq_len,
+                            int len_stride, int Hn, int T, int n, float* hT, float* out_seq,
+                            float* hprev, float* gates, void* stream) {
+  CLSR_CHECK_ARG(Pin && Wgh && Wch && seq_len);
+  int rc = check_rnn_shape(Hn, T, n, ldp);
+  if (rc) return rc;
+  CLSR_CHECK_SUPPORTED(h0_stride % 4 == 0);
+  GruArgs a = {};
+  a.Pin = Pin; a.ldp = ldp; a.Wgh = Wgh; a.ldg = ldg; a.Wch = Wch; a.ldc = ldc; a.h0 = h0;
+  a.h0_stride = h0_stride; a.seq_len = seq_len; a.len_stride = len_stride; a.Hn = Hn; a.T = T; a.n = n;
+  a.hT = hT; a.out_seq = out_seq; a.hprev = hprev; a.gates = gates;
+  hipLaunchKernelGGL(gru_fwd_kernel, dim3(clsr_cdiv(Hn, 16)), dim3(64), 0, (hipStream_t)stream, a);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+extern "C" int clsr_gru_bwd(const float* gates, const float* hprev, const float* Wgh, int ldg,
+                            const float* Wch, int ldc, const int* seq_len, int len_stride, int Hn,
+                            int T, int n, const float* dhT, const float* dout_seq, float* dPin,
+                            float* dh0, void* stream) {
+  CLSR_CHECK_ARG(gates && hprev && Wgh && Wch && seq_len && dPin);
+  int rc = check_rnn_shape(Hn, T, n, ldg);
+  if (rc) return rc;
+  CLSR_CHECK_SUPPORTED(ldc % 4 == 0 && ((uintptr_t)Wgh % 16) == 0 && ((uintptr_t)Wch % 16) == 0);
+  GruArgs a = {};
+  a.gates = const_cast<float*>(gates); a.hprev = const_cast<float*>(hprev);
+  a.Wgh = Wgh; a.ldg = ldg; a.Wch = Wch; a.ldc = ldc; a.seq_len = seq_len; a.len_stride = len_stride;
+  a.Hn = Hn; a.T = T; a.n = n; a.dhT = dhT; a.dout_seq = dout_seq; a.dPin = dPin; a.dh0 = dh0;
+  hipLaunchKernelGGL(gru_bwd_kernel, dim3(clsr_cdiv(Hn, 16)), dim3(64), 0, (hipStream_t)stream, a);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// ================================================================================ Time4LSTM
+// Pin blocks (each n wide): 0 i | 1 j | 2 f | 3 o (already holds Tn.Wo1 + Tl.Wo2) | 4 tns | 5 tls
+//   c' = sig(f + 1) * sig(tls) * c + sig(i) * sig(tns) * tanh(j) ;  m' = sig(o) * tanh(c')
+// saved (training): act[Hn,T,6n] = sig i | tanh j | sig(f+1) | sig o | sig tns | sig tls,
+//                   cst[Hn,T,n] = c', mprev[Hn,T,n] = m entering the step.
+struct T4Args {
+  const float* Pin; int ldp;
+  const float* Wm; int ldm;            // [n, >=4n] hidden rows of the lstm kernel (i|j|f|o columns)
+  const int* seq_len; int len_stride;
+  int Hn, T, n;
+  float* out_seq;                      // [Hn, T, n] (m, zeros past len)
+  float* act; float* cst; float* mprev;
+  const float* dout_seq;               // [Hn, T, n]
+  float* dPin;                         // [Hn, T, 6n]
+};
+
+__global__ void __launch_bounds__(64) t4lstm_fwd_kernel(T4Args a) {
+  const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+  const int n = a.n, T = a.T;
+  const long h = (long)blockIdx.x * 16 + j;
+  const bool hvalid = h < a.Hn;
+  f32x4 w[4][RNT][RNT];
+#pragma unroll
+  for (int gb = 0; gb < 4; ++gb)
+#pragma unroll
+    for (int ot = 0; ot < RNT; ++ot)
+#pragma unroll
+      for (int kt = 0; kt < RNT; ++kt) w[gb][ot][kt] = load_w_fwd(a.Wm, a.ldm, gb * n, n, ot, kt, j, g);
+  bool cval[RNT];
+  f32x4 cs[RNT], ms[RNT];
+#pragma unroll
+  for (int tl = 0; tl < RNT; ++tl) { cval[tl] = hvalid && (16 * tl + 4 * g < n); cs[tl] = Z4; ms[tl] = Z4; }
+  const int len = hvalid ? min(a.seq_len[h * a.len_stride], T) : 0;
+  const int Tmax = wave_max_i(len);
+  const float* pin = a.Pin + (hvalid ? h : 0) * (long)T * a.ldp + 4 * g;
+  f32x4 pn[6][RNT];
+#pragma unroll
+  for (int gb = 0; gb < 6; ++gb)
+#pragma unroll
+    for (int tl = 0; tl < RNT; ++tl) pn[gb][tl] = (cval[tl] && 0 < len) ? ld4(pin + gb * n + 16 * tl) : Z4;
+  for (int t = 0; t < Tmax; ++t) {
+    const bool live = t < len;
+    f32x4 acc[4][RNT], tns[RNT], tls[RNT];
+#pragma unroll
+    for (int tl = 0; tl < RNT; ++tl) {
+#pragma unroll
+      for (int gb = 0; gb < 4; ++gb) acc[gb][tl] = pn[gb][tl];
+      tns[tl] = pn[4][tl]; tls[tl] = pn[5][tl];
+    }
+    {
+      const bool nl = (t + 1) < len;
+#pragma unroll
+      for (int gb = 0; gb < 6; ++gb)
+#pragma unroll
+        for (int tl = 0; tl < RNT; ++tl)
+          pn[gb][tl] = (cval[tl] && nl) ? ld4(pin + (long)(t + 1) * a.ldp + gb * n + 16 * tl) : Z4;
+    }
+#pragma unroll
+    for (int gb = 0; gb < 4; ++gb) matvec<RNT>(acc[gb], w[gb], ms);
+#pragma unroll
+    for (int tl = 0; tl < RNT; ++tl) {
+      const f32x4 ig = sig4(acc[0][tl]), jg = tanh4(acc[1][tl]), fg = sig4(acc[2][tl] + 1.0f);
+      const f32x4 og = sig4(acc[3][tl]), tn = sig4(tns[tl]), tlg = sig4(tls[tl]);
+      const f32x4 cn = fg * tlg * cs[tl] + ig * tn * jg;
+      const f32x4 mn = og * tanh4(cn);
+      if (live && cval[tl]) {
+        const long pos = h * T + t;
+        const int col = 16 * tl + 4 * g;
+        st4(a.out_seq + pos * n + col, mn);
+        if (a.act) {
+          float* ap = a.act + pos * 6 * n + col;
+          st4(ap, ig); st4(ap + n, jg); st4(ap + 2 * n, fg); st4(ap + 3 * n, og);
+          st4(ap + 4 * n, tn); st4(ap + 5 * n, tlg);
+          st4(a.cst + pos * n + col, cn);
+          st4(a.mprev + pos * n + col, ms[tl]);
+        }
+      }
+      cs[tl] = sel4(live, cn, cs[tl]);
+      ms[tl] = sel4(live, mn, ms[tl]);
+    }
+  }
+#pragma unroll
+  for (int tl = 0; tl < RNT; ++tl)
+    if (cval[tl])
+      for (int t = len; t < T; ++t) st4(a.out_seq + (h * T + t) * n + 16 * tl + 4 * g, Z4);
+}
+
+__global__ void __launch_bounds__(64) t4lstm_bwd_kernel(T4Args a) {
+  const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+  const int n = a.n, T = a.T;
+  const long h = (long)blockIdx.x * 16 + j;
+  const bool hvalid = h < a.Hn;
+  f32x4 w[4][RNT][RNT];
+#pragma unroll
+  for (int gb = 0; gb < 4; ++gb)
+#pragma unroll
+    for (int ot = 0; ot < RNT; ++ot)
+#pragma unroll
+      for (int kt = 0; kt < RNT; ++kt) w[gb][ot][kt] = load_w_bwd(a.Wm, a.ldm, gb * n, n, ot, kt, j, g);
+  bool cval[RNT];
+  f32x4 dc[RNT], dm[RNT];
+#pragma unroll
+  for (int tl = 0; tl < RNT; ++tl) { cval[tl] = hvalid && (16 * tl + 4 * g < n); dc[tl] = Z4; dm[tl] = Z4; }
+  const int len = hvalid ? min(a.seq_len[h * a.len_stride], T) : 0;
+  const int Tmax = wave_max_i(len);
+#pragma unroll
+  for (int tl = 0; tl < RNT; ++tl)
+    if (cval[tl])
+      for (int t = len; t < T; ++t) {
+        float* dp = a.dPin + (h * T + t) * 6 * n + 16 * tl + 4 * g;
+#pragma unroll
+        for (int gb = 0; gb < 6; ++gb) st4(dp + gb * n, Z4);
+      }
+  for (int t = Tmax - 1; t >= 0; --t) {
+    const bool live = t < len;
+    const long pos = h * T + t;
+    f32x4 dg[4][RNT], dcn[RNT];
+#pragma unroll
+    for (int tl = 0; tl < RNT; ++tl) {
+      const int col = 16 * tl + 4 * g;
+      const bool ok = live && cval[tl];
+      const float* ap = a.act + pos * 6 * n + col;
+      const f32x4 ig = ok ? ld4(ap) : Z4, jg = ok ? ld4(ap + n) : Z4, fg = ok ? ld4(ap + 2 * n) : Z4;
+      const f32x4 og = ok ? ld4(ap + 3 * n) : Z4, tn = ok ? ld4(ap + 4 * n) : Z4, tlg = ok ? ld4(ap + 5 * n) : Z4;
+      const f32x4 cn = ok ? ld4(a.cst + pos * n + col) : Z4;
+      const f32x4 cp = (ok && t > 0) ? ld4(a.cst + (pos - 1) * n + col) : Z4;
+      f32x4 d = dm[tl];
+      if (ok) d += ld4(a.dout_seq + pos * n + col);
+      d = sel4(ok, d, Z4);
+      const f32x4 tc = tanh4(cn);
+      const f32x4 dcc = sel4(ok, dc[tl] + d * og * (1.0f - tc * tc), Z4);
+      dg[3][tl] = d * tc * og * (1.0f - og);                         // d o_pre
+      dg[2][tl] = dcc * tlg * cp * fg * (1.0f - fg);                 // d f_pre
+      dg[0][tl] = dcc * tn * jg * ig * (1.0f - ig);                  // d i_pre
+      dg[1][tl] = dcc * ig * tn * (1.0f - jg * jg);                  // d j_pre
+      const f32x4 dtn = dcc * ig * jg * tn * (1.0f - tn);            // d tns_pre
+      const f32x4 dtl = dcc * fg * cp * tlg * (1.0f - tlg);          // d tls_pre
+      dcn[tl] = dcc * fg * tlg;
+      if (ok) {
+        float* dp = a.dPin + pos * 6 * n + col;
+        st4(dp, dg[0][tl]); st4(dp + n, dg[1][tl]); st4(dp + 2 * n, dg[2][tl]); st4(dp + 3 * n, dg[3][tl]);
+        st4(dp + 4 * n, dtn); st4(dp + 5 * n, dtl);
+      }
+    }
+    f32x4 dmn[RNT] = {Z4, Z4, Z4};
+#pragma unroll
+    for (int gb = 0; gb < 4; ++gb) matvec<RNT>(dmn, w[gb], dg[gb]);
+#pragma unroll
+    for (int tl = 0; tl < RNT; ++tl) {
+      dc[tl] = sel4(live, dcn[tl], dc[tl]);
+      dm[tl] = sel4(live, dmn[tl], dm[tl]);
+    }
+  }
+}
+
+extern "C" int clsr_t4lstm_fwd(const float* Pin, int ldp, const float* Wm, int ldm, const int* seq_len,
+                               int len_stride, int Hn, int T, int n, float* out_seq, float* act,
+                               float* cst, float* mprev, void* stream) {
+  CLSR_CHECK_ARG(Pin && Wm && seq_len && out_seq);
+  CLSR_CHECK_ARG(!act || (cst && mprev));
+  int rc = check_rnn_shape(Hn, T, n, ldp);
+  if (rc) return rc;
+  T4Args a = {};
+  a.Pin = Pin; a.ldp = ldp; a.Wm = Wm; a.ldm = ldm; a.seq_len = seq_len; a.len_stride = len_stride;
+  a.Hn = Hn; a.T = T; a.n = n; a.out_seq = out_seq; a.act = act; a.cst = cst; a.mprev = mprev;
+  hipLaunchKernelGGL(t4lstm_fwd_kernel, dim3(clsr_cdiv(Hn, 16)), dim3(64), 0, (hipStream_t)stream, a);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+extern "C" int clsr_t4lstm_bwd(const float* act, const float* cst, const float* Wm, int ldm,
+                               const int* seq_len, int len_stride, int Hn, int T, int n,
+                               const float* dout_seq, float* dPin, void* stream) {
+  CLSR_CHECK_ARG(act && cst && Wm && seq_len && dout_seq && dPin);
+  int rc = check_rnn_shape(Hn, T, n, ldm);
+  if (rc) return rc;
+  CLSR_CHECK_SUPPORTED(((uintptr_t)Wm % 16) == 0);
+  T4Args a = {};
+  a.act = const_cast<float*>(act); a.cst = const_cast<float*>(cst); a.Wm = Wm; a.ldm = ldm;
+  a.seq_len = seq_len; a.len_stride = len_stride; a.Hn = Hn; a.T = T; a.n = n;
+  a.dout_seq = dout_seq; a.dPin = dPin;
+  hipLaunchKernelGGL(t4lstm_bwd_kernel, dim3(clsr_cdiv(Hn, 16)), dim3(64), 0, (hipStream_t)stream, a);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// ======================================================================= Time4LSTM time inputs
+// TT[h,t,:] = [tanh(t_now*w1 + b1) (n) | tanh(t_first*w2 + b2) (n)]
+// (rnn_cell_implement.py:200-205; inputs[:, -1] = time_to_now, inputs[:, -2] = time_from_first_action)
+__global__ void t4_time_inputs_fwd_kernel(const float* __restrict__ tnow, const float* __restrict__ tfirst,
+                                          long row_stride, const float* __restrict__ w1,
+                                          const float* __restrict__ b1, const float* __restrict__ w2,
+                                          const float* __restrict__ b2, long Hn, int T, int n,
+                                          float* __restrict__ TT) {
+  const long total = Hn * T * 2 * n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % (2 * n));
+    const long ht = e / (2 * n);
+    const int t = (int)(ht % T);
+    const long h = ht / T;
+    float v;
+    if (c < n) v = tanhf_(tnow[h * row_stride + t] * w1[c] + b1[c]);
+    else v = tanhf_(tfirst[h * row_stride + t] * w2[c - n] + b2[c - n]);
+    TT[e] = v;
+  }
+}
+
+extern "C" int clsr_t4_time_inputs_fwd(const float* tnow, const float* tfirst, long row_stride,
+                                       const float* w1, const float* b1, const float* w2,
+                                       const float* b2, long Hn, int T, int n, float* TT, void* stream) {
+  CLSR_CHECK_ARG(tnow && tfirst && w1 && b1 && w2 && b2 && TT && Hn > 0 && T > 0 && n > 0);
+  int blocks = clsr_cdiv(Hn * T * 2 * n, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(t4_time_inputs_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tnow,
+                     tfirst, row_stride, w1, b1, w2, b2, Hn, T, n, TT);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// dpre = dTT * (1 - TT^2); partial[blk][0][c] = sum dpre * time ; partial[blk][1][c] = sum dpre
+// (c < n: w1/b1 with time_to_now; c >= n: w2/b2 with time_from_first_action).  One column per
+// thread: block = (256 / C2) rows x C2 columns.
+__global__ void __launch_bounds__(256) t4_time_inputs_bwd_kernel(
+    const float* __restrict__ dTT, const float* __restrict__ TT, const float* __restrict__ tnow,
+    const float* __restrict__ tfirst, long row_stride, long Hn, int T, int n, float* __restrict__ partial) {
+  __shared__ float red[2][256];
+  const int C2 = 2 * n;
+  const int rpb = 256 / C2;
+  const int ty = threadIdx.x / C2, c = threadIdx.x - ty * C2;
+  float sw = 0.f, sb = 0.f;
+  if (ty < rpb) {
+    const float* tsrc = (c < n) ? tnow : tfirst;
+    const long M = Hn * T;
+    for (long row = (long)blockIdx.x * rpb + ty; row < M; row += (long)gridDim.x * rpb) {
+      const long h = row / T;
+      const int t = (int)(row - h * T);
+      const float y = TT[row * C2 + c];
+      const float d = dTT[row * C2 + c] * (1.0f - y * y);
+      sw += d * tsrc[h * row_stride + t];
+      sb += d;
+    }
+  }
+  red[0][threadIdx.x] = sw;
+  red[1][threadIdx.x] = sb;
+  __syncthreads();
+  if (threadIdx.x < C2) {
+    float a = 0.f, b = 0.f;
+    for (int y = 0; y < rpb; ++y) { a += red[0][y * C2 + threadIdx.x]; b += red[1][y * C2 + threadIdx.x]; }
+    partial[((long)blockIdx.x * 2 + 0) * C2 + threadIdx.x] = a;
+    partial[((long)blockIdx.x * 2 + 1) * C2 + threadIdx.x] = b;
+  }
+}
+
+static int t4_tbwd_blocks(long M, int n) {
+  const int rpb = 256 / (2 * n);
+  long b = (M + rpb * 8 - 1) / (rpb * 8);
+  if (b > 512) b = 512;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+extern "C" int clsr_t4_time_inputs_bwd_parts(long Hn, int T, int n) { return t4_tbwd_blocks(Hn * T, n); }
+
+// partial: [parts][2][2n] floats: row 0 = [d w1 | d w2], row 1 = [d b1 | d b2]
+extern "C" int clsr_t4_time_inputs_bwd(const float* dTT, const float* TT, const float* tnow,
+                                       const float* tfirst, long row_stride, long Hn, int T, int n,
+                                       float* partial, void* stream) {
+  CLSR_CHECK_ARG(dTT && TT && tnow && tfirst && partial && Hn > 0 && T > 0);
+  CLSR_CHECK_SUPPORTED(n > 0 && 2 * n <= 256);
+  hipLaunchKernelGGL(t4_time_inputs_bwd_kernel, dim3(t4_tbwd_blocks(Hn * T, n)), dim3(256), 0,
+                     (hipStream_t)stream, dTT, TT, tnow, tfirst, row_stride, Hn, T, n, partial);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}

@@ -1,0 +1,162 @@
+/* C ABI of libclsr_hip.so -- the MI355X (gfx950) kernels of the CLSR training / scoring step.
+ *
+ * The reference (tsinghua-fib-lab/CLSR) has no native code and no FFI: its hot path is the single
+ * sess.run() inside CLSRModel.train / eval_with_user / infer
+ * (reco_utils/recommender/deeprec/models/sequential/clsr.py:383-408,
+ *  sequential_base_model.py:294-352).  Every entry point below replaces the TF-1.15 ops that one
+ * part of that graph expands to; the reference lines are cited per function.  INTEGRATION.md shows
+ * the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - all pointers are DEVICE pointers into caller-owned buffers (no ownership transfer, no hidden
+ *    allocation); fp32 row-major unless stated; `stream` is a hipStream_t passed as void*;
+ *  - every call is asynchronous on `stream`, performs no host synchronisation and is re-entrant;
+ *  - return 0 on success, <0 on error (-1 invalid argument, -2 HIP launch failure, -3 unsupported
+ *    shape); clsr_last_error() returns the calling thread's last message; nothing throws or exits;
+ *  - "history-level" tensors have one row per history group; the G = 1 + train_num_ngs rows of a
+ *    training group (row b = h*G + g) share them.  Row-level index / feature arrays are read with a
+ *    row stride instead of being de-duplicated on the host (idx_row_stride = G*T, len_stride = G).
+ */
+#ifndef CLSR_HIP_H
+#define CLSR_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int clsr_version(void);
+int clsr_last_error(char* buf, size_t n);
+
+/* hipGraph capture of everything enqueued on `stream` between begin and end (one replay = one step) */
+int clsr_graph_begin(void* stream);
+int clsr_graph_end(void* stream, void** graph_exec_out);
+int clsr_graph_launch(void* graph_exec, void* stream);
+int clsr_graph_destroy(void* graph_exec);
+
+/* ---- embedding lookups: tf.nn.embedding_lookup at sequential_base_model.py:384-437, clsr.py:108-116;
+ *      history prologue (concat, hist_mean, hist_recent) clsr.py:145-150,157,173-177 */
+int clsr_gather_hist_fwd(const float* item_tbl, const float* cate_tbl, const int* item_idx,
+                         const int* cate_idx, long idx_row_stride, const int* seq_len, int len_stride,
+                         int Hn, int T, int Di, int Dc, int recent_k, float* hist, float* hist_mean,
+                         float* hist_recent, void* stream);
+int clsr_gather_hist_bwd(const float* dhist, const float* dmean, const float* drecent,
+                         const int* item_idx, const int* cate_idx, long idx_row_stride,
+                         const int* seq_len, int len_stride, int Hn, int T, int Di, int Dc, int recent_k,
+                         float* item_grad, float* cate_grad, double* sumsq, void* stream);
+int clsr_gather_rows(const float* tbl, const int* idx, long idx_stride, int N, int C, float* out,
+                     int ldo, int col0, void* stream);
+int clsr_scatter_add_rows(const float* src, int ld_src, int col0, const int* idx, long idx_stride, int N,
+                          int C, float* tbl_grad, double* sumsq, void* stream);
+/* "involved" id sets (tf.unique, sequential_base_model.py:409-433, clsr.py:118-127) as byte maps */
+int clsr_mark_rows(const int* idx, long nrows, int ncols, long row_stride, unsigned char* flags,
+                   void* stream);
+
+/* ---- linear layers: tf.tensordot / MatMul + BiasAdd (base_model.py:664,704; clsr.py:363;
+ *      rnn_cell_implement.py:207-231) and their gradients; fp32 MFMA */
+int clsr_pack_weight(const float* src1, int ld1, float s1, const float* src2, int ld2, float s2,
+                     int transposed, int O, int I, int Ip, float* Wt, void* stream);
+int clsr_pgemm_stats_parts(int M);
+int clsr_pgemm(const float* X, int ldx, int T, int G, const float* Xmul, int ldmul,
+               const float* in_scale, const float* in_shift, int in_relu, const float* Wt, int Kp,
+               const float* bias, const float* addU, int ldu, const float* addV, int ldv, float* Y,
+               int ldy, int accumulate, double* stats, int M, int K, int N, void* stream);
+long clsr_pgemm_dw_workspace_floats(int M, int K, int N);
+int clsr_pgemm_dw(const float* X, int ldx, int T, int G, const float* Xmul, int ldmul,
+                  const float* in_scale, const float* in_shift, int in_relu, const float* dY, int ldy,
+                  int M, int K, int N, float scale, float* dW, int ldw, float* db, int accumulate,
+                  float* workspace, void* stream);
+int clsr_reduce_parts(const float* partial, int nparts, int stride, int n, float scale, float* out,
+                      int accumulate, void* stream);
+
+/* ---- batch normalisation of _fcn_net: tf.layers.batch_normalization(momentum=0.95, eps=1e-4)
+ *      base_model.py:673-679 (non-fused: stats over all axes but the last, biased variance) */
+int clsr_bn_finalize(const double* stats_partial, int nparts, int C, double count, const float* gamma,
+                     const float* beta, float* moving_mean, float* moving_var, float momentum, float eps,
+                     int training, float* scale, float* shift, float* mean_out, float* invstd_out,
+                     void* stream);
+int clsr_colred_parts(int M, int C);
+int clsr_bn_relu_bwd_reduce(float* dh, const float* z, const float* scale, const float* shift,
+                            const float* mean, const float* invstd, int M, int C, double* partial,
+                            void* stream);
+int clsr_bn_bwd_coef(const double* partial, int nparts, int C, double count, const float* gamma,
+                     const float* mean, const float* invstd, float* coef, float* dgamma, float* dbeta,
+                     int accumulate, void* stream);
+int clsr_bn_bwd_apply(float* dy, const float* z, const float* coef, long M, int C, void* stream);
+
+/* ---- attention tail: score layer + padding mask + softmax over T + weighted sum, clsr.py:371-381 */
+int clsr_att_out_fwd(const float* z1, const float* scale1, const float* shift1, const float* w_out,
+                     const float* b_out, const int* seq_len, int len_stride, const float* keys, int Hn,
+                     int G, int T, int C1, int Dk, float* wts, float* out, void* stream);
+int clsr_att_out_bwd_parts(int Hn);
+int clsr_att_out_bwd(const float* dout, const float* wts, const float* z1, const float* scale1,
+                     const float* shift1, const float* mean1, const float* invstd1, const float* w_out,
+                     const int* seq_len, int len_stride, const float* keys, int Hn, int G, int T, int C1,
+                     int Dk, float* dy1, float* dkeys, double* bn_partial, float* w_partial, void* stream);
+
+/* ---- recurrent encoders under dynamic_rnn: GRUCell clsr.py:160-168,201-208,229-237;
+ *      Time4LSTMCell rnn_cell_implement.py:129-298 at clsr.py:179-200 */
+int clsr_gru_fwd(const float* Pin, int ldp, const float* Wgh, int ldg, const float* Wch, int ldc,
+                 const float* h0, long h0_stride, const int* seq_len, int len_stride, int Hn, int T,
+                 int n, float* hT, float* out_seq, float* hprev, float* gates, void* stream);
+int clsr_gru_bwd(const float* gates, const float* hprev, const float* Wgh, int ldg, const float* Wch,
+                 int ldc, const int* seq_len, int len_stride, int Hn, int T, int n, const float* dhT,
+                 const float* dout_seq, float* dPin, float* dh0, void* stream);
+int clsr_t4lstm_fwd(const float* Pin, int ldp, const float* Wm, int ldm, const int* seq_len,
+                    int len_stride, int Hn, int T, int n, float* out_seq, float* act, float* cst,
+                    float* mprev, void* stream);
+int clsr_t4lstm_bwd(const float* act, const float* cst, const float* Wm, int ldm, const int* seq_len,
+                    int len_stride, int Hn, int T, int n, const float* dout_seq, float* dPin,
+                    void* stream);
+int clsr_t4_time_inputs_fwd(const float* tnow, const float* tfirst, long row_stride, const float* w1,
+                            const float* b1, const float* w2, const float* b2, long Hn, int T, int n,
+                            float* TT, void* stream);
+int clsr_t4_time_inputs_bwd_parts(long Hn, int T, int n);
+int clsr_t4_time_inputs_bwd(const float* dTT, const float* TT, const float* tnow, const float* tfirst,
+                            long row_stride, long Hn, int T, int n, float* partial, void* stream);
+
+/* ---- heads: alpha gate + fusion clsr.py:239-275; MLP output layer base_model.py:686-706;
+ *      softmax data loss base_model.py:215-235; contrastive loss clsr.py:46-71 */
+int clsr_alpha_concat(const float* fs, int nfs, const float* target, const float* L, const float* S,
+                      const float* tnow, long tnow_stride, int tnow_col, long B, int G, int D, float* out,
+                      int ldo, void* stream);
+int clsr_alpha_concat_bwd(const float* dA, int ldo, int nfs, long Hn, int G, int D, float* dfs,
+                          float* dtarget, float* dL, float* dS, void* stream);
+int clsr_mlp_out_fwd(const float* z1, const float* scale, const float* shift, const float* w_out,
+                     const float* b_out, long B, int C1, float* logit, void* stream);
+int clsr_mlp_out_bwd_parts(long B, int C1);
+int clsr_mlp_out_bwd(const float* dlogit, const float* z1, const float* scale, const float* shift,
+                     const float* mean, const float* invstd, const float* w_out, long B, int C1,
+                     float* dy1, double* bn_partial, float* w_partial, void* stream);
+int clsr_alpha_fuse_fwd(const float* alpha_logit, float manual_alpha, const float* L, const float* S,
+                        const float* target, long B, int G, int D, float* alpha, float* mo, void* stream);
+int clsr_alpha_fuse_bwd(const float* dmo, const float* alpha, float manual_alpha, const float* L,
+                        const float* S, long Hn, int G, int D, float* dalpha_logit, float* dL, float* dS,
+                        float* dtarget, void* stream);
+int clsr_softmax_loss(const float* logit, const float* labels, long P, int G, double* loss_out,
+                      float* dlogit, void* stream);
+int clsr_contrastive(const float* L, const float* S, const float* M, const float* R, const int* seq_len,
+                     int len_stride, long Hn, int G, int D, int threshold, int mode, float margin,
+                     float weight, const float* denom_ptr, double* loss_out, float* dL, float* dS,
+                     float* dM, float* dR, void* stream);
+
+/* ---- regularisers, clip, Adam: base_model.py:118-159,249-297; clsr.py:73-82 */
+int clsr_adam_tick(double* state, double lr, double beta1, double beta2, void* stream);
+int clsr_dense_reg_norm(const float* param, float* grad, const int* seg_off, int nseg, float l2,
+                        double* sumsq, double* reg_loss, void* stream);
+int clsr_dense_adam(float* param, float* grad, float* m, float* v, const int* seg_of,
+                    const double* sumsq, float clip_norm, const double* adam_state, float beta1,
+                    float beta2, float eps, int n, void* stream);
+int clsr_count_flags(const unsigned char* flags, long V, float* count, void* stream);
+int clsr_table_reg(const float* table, const float* partner, const unsigned char* flags, long V, int C,
+                   float l2, float disc_scale, float disc_loss_scale, const float* count,
+                   float* grad_table, double* sumsq, double* reg_loss, double* disc_loss, void* stream);
+int clsr_table_adam(float* table, float* grad_table, float* m, float* v, unsigned char* flags, long V,
+                    int C, const double* sumsq, int nsum, float clip_norm, const double* adam_state,
+                    float beta1, float beta2, float eps, int lazy, void* stream);
+int clsr_zero_doubles(double* p, int n, void* stream);
+int clsr_zero_floats(float* p, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLSR_HIP_H */
