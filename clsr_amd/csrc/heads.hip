@@ -383,3 +383,163 @@ extern "C" int clsr_contrastive(const float* L, const float* S, const float* M, 
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
+
+// ------------------------------------------------------------------ small row/column movers
+// dst[n, dst_col0 + c] (=|+=) src[(n / row_div) * ld_src + src_col0 + c],  c < C
+__global__ void copy_cols_kernel(const float* __restrict__ src, int ld_src, int src_col0, int row_div,
+                                 long N, int C, float* __restrict__ dst, int ldd, int dst_col0,
+                                 int accumulate) {
+  const long total = N * C;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long n = e / C;
+    const int c = (int)(e - n * C);
+    const float v = src[(n / row_div) * ld_src + src_col0 + c];
+    float* d = dst + n * ldd + dst_col0 + c;
+    *d = accumulate ? *d + v : v;
+  }
+}
+
+extern "C" int clsr_copy_cols(const float* src, int ld_src, int src_col0, int row_div, long N, int C,
+                              float* dst, int ldd, int dst_col0, int accumulate, void* stream) {
+  CLSR_CHECK_ARG(src && dst && N > 0 && C > 0 && row_div > 0);
+  int blocks = clsr_cdiv(N * C, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld_src,
+                     src_col0, row_div, N, C, dst, ldd, dst_col0, accumulate);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// dst[h, dst_col0 + c] (=|+=) sum_{g<G} src[(h*G + g) * ld_src + src_col0 + c]
+__global__ void group_sum_cols_kernel(const float* __restrict__ src, int ld_src, int src_col0, int G,
+                                      long Hn, int C, float* __restrict__ dst, int ldd, int dst_col0,
+                                      int accumulate) {
+  const long total = Hn * C;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long h = e / C;
+    const int c = (int)(e - h * C);
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += src[(h * G + g) * ld_src + src_col0 + c];
+    float* d = dst + h * ldd + dst_col0 + c;
+    *d = accumulate ? *d + s : s;
+  }
+}
+
+extern "C" int clsr_group_sum_cols(const float* src, int ld_src, int src_col0, int G, long Hn, int C,
+                                   float* dst, int ldd, int dst_col0, int accumulate, void* stream) {
+  CLSR_CHECK_ARG(src && dst && Hn > 0 && C > 0 && G > 0);
+  int blocks = clsr_cdiv(Hn * C, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(group_sum_cols_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld_src,
+                     src_col0, G, Hn, C, dst, ldd, dst_col0, accumulate);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// out[e] = sa * a[e] + sb * b[e]
+__global__ void axpby_kernel(float* __restrict__ out, const float* __restrict__ a, float sa,
+                             const float* __restrict__ b, float sb, long n) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+    out[e] = sa * a[e] + (b ? sb * b[e] : 0.f);
+}
+
+extern "C" int clsr_axpby(float* out, const float* a, float sa, const float* b, float sb, long n,
+                          void* stream) {
+  CLSR_CHECK_ARG(out && a && n > 0);
+  int blocks = clsr_cdiv(n, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(axpby_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, a, sa, b, sb, n);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// ------------------------------------------------------------------ attention layer-0 backward helpers
+// z0[r,t,:] = U[h,t,:] + V[r,:] + (a[h,t,:] * q[r,:]) . Wp    (the re-associated first att_fcn layer)
+// (1) dU[h,t,:] = sum_g dz0[(h,g),t,:]   dV[r,:] = sum_t dz0[r,t,:]
+__global__ void __launch_bounds__(64) att_z0_bwd_reduce_kernel(const float* __restrict__ dz0, long Hn,
+                                                               int G, int T, int C,
+                                                               float* __restrict__ dU,
+                                                               float* __restrict__ dV) {
+  const int lane = threadIdx.x;
+  const int QC = C >> 2, tpar = 64 / QC, ts = lane / QC, q = lane - ts * QC;
+  __shared__ f32x4 red[64];
+  for (long h = blockIdx.x; h < Hn; h += gridDim.x) {
+    for (int gi = 0; gi < G; ++gi) {
+      const long r = h * G + gi;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (ts < tpar) {
+        for (int t = ts; t < T; t += tpar) {
+          const f32x4 d = ld4(dz0 + (r * T + t) * C + 4 * q);
+          acc += d;
+          if (dU) {
+            float* up = dU + (h * T + t) * C + 4 * q;
+            st4(up, gi == 0 ? d : ld4(up) + d);
+          }
+        }
+      }
+      red[lane] = acc;
+      __syncthreads();
+      if (ts == 0) {
+        for (int s = 1; s < tpar; ++s) acc += red[lane + s * QC];
+        st4(dV + r * C + 4 * q, acc);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+extern "C" int clsr_att_z0_bwd_reduce(const float* dz0, long Hn, int G, int T, int C, float* dU,
+                                      float* dV, void* stream) {
+  CLSR_CHECK_ARG(dz0 && dV && Hn > 0 && G > 0 && T > 0);
+  CLSR_CHECK_SUPPORTED(C % 4 == 0 && C <= 256);
+  int blocks = Hn > 8192 ? 8192 : (int)Hn;
+  hipLaunchKernelGGL(att_z0_bwd_reduce_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, dz0, Hn, G,
+                     T, C, dU, dV);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// (2) given daq = dz0 . Wp^T  [R*T, Q]:  da[h,t,:] = sum_g daq[(h,g),t,:] * q[(h,g),:]
+//                                        dq[r,:]   = sum_t daq[r,t,:] * a[h,t,:]
+__global__ void __launch_bounds__(64) att_prod_bwd_kernel(const float* __restrict__ daq,
+                                                          const float* __restrict__ a,
+                                                          const float* __restrict__ q, long Hn, int G,
+                                                          int T, int Q, float* __restrict__ da,
+                                                          float* __restrict__ dq) {
+  const int lane = threadIdx.x;
+  const int QQ = Q >> 2, tpar = 64 / QQ, ts = lane / QQ, qq = lane - ts * QQ;
+  __shared__ f32x4 red[64];
+  for (long h = blockIdx.x; h < Hn; h += gridDim.x) {
+    for (int gi = 0; gi < G; ++gi) {
+      const long r = h * G + gi;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (ts < tpar) {
+        const f32x4 qv = ld4(q + r * Q + 4 * qq);
+        for (int t = ts; t < T; t += tpar) {
+          const f32x4 d = ld4(daq + (r * T + t) * Q + 4 * qq);
+          acc += d * ld4(a + (h * T + t) * Q + 4 * qq);
+          float* ap = da + (h * T + t) * Q + 4 * qq;
+          st4(ap, gi == 0 ? d * qv : ld4(ap) + d * qv);
+        }
+      }
+      red[lane] = acc;
+      __syncthreads();
+      if (ts == 0) {
+        for (int s = 1; s < tpar; ++s) acc += red[lane + s * QQ];
+        st4(dq + r * Q + 4 * qq, acc);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+extern "C" int clsr_att_prod_bwd(const float* daq, const float* a, const float* q, long Hn, int G, int T,
+                                 int Q, float* da, float* dq, void* stream) {
+  CLSR_CHECK_ARG(daq && a && q && da && dq && Hn > 0 && G > 0 && T > 0);
+  CLSR_CHECK_SUPPORTED(Q % 4 == 0 && Q <= 256);
+  int blocks = Hn > 8192 ? 8192 : (int)Hn;
+  hipLaunchKernelGGL(att_prod_bwd_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, daq, a, q, Hn, G,
+                     T, Q, da, dq);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}

@@ -175,16 +175,16 @@ extern "C" int clsr_table_reg(const float* table, const float* partner, const un
   return CLSR_OK;
 }
 
-// Pass B: Adam sweep of one table.  sumsq[0..nsum) are the squared norms of this table's
+// Pass B: Adam sweep of one table.  sumsq[i * sumsq_stride], i < nsum, are the squared norms of this table's
 // IndexedSlices pieces (lookup sites + involved rows); lazy != 0 restricts the update to rows whose
 // flag is set or that received gradient through a lookup (LazyAdam).  Clears grad rows and flags.
 __global__ void __launch_bounds__(256) table_adam_kernel(
     float* __restrict__ table, float* __restrict__ grad_table, float* __restrict__ m,
     float* __restrict__ v, unsigned char* __restrict__ flags, long V, int C,
-    const double* __restrict__ sumsq, int nsum, float clip_norm, const double* __restrict__ adam_state,
-    float b1, float b2, float eps, int lazy) {
+    const double* __restrict__ sumsq, int sumsq_stride, int nsum, float clip_norm,
+    const double* __restrict__ adam_state, float b1, float b2, float eps, int lazy) {
   double tot = 0.0;
-  for (int i = 0; i < nsum; ++i) tot += sumsq[i];
+  for (int i = 0; i < nsum; ++i) tot += sumsq[(long)i * sumsq_stride];
   const float factor = clip_factor(tot, clip_norm);
   const float lr_t = (float)adam_state[3];
   const long total = V * C;
@@ -206,15 +206,15 @@ __global__ void clear_bytes_kernel(unsigned char* p, long n) {
 }
 
 extern "C" int clsr_table_adam(float* table, float* grad_table, float* m, float* v, unsigned char* flags,
-                               long V, int C, const double* sumsq, int nsum, float clip_norm,
-                               const double* adam_state, float beta1, float beta2, float eps, int lazy,
-                               void* stream) {
+                               long V, int C, const double* sumsq, int sumsq_stride, int nsum,
+                               float clip_norm, const double* adam_state, float beta1, float beta2,
+                               float eps, int lazy, void* stream) {
   CLSR_CHECK_ARG(table && grad_table && m && v && flags && sumsq && adam_state && V > 0 && C > 0 && nsum > 0);
   int blocks = clsr_cdiv(V * C, 256);
   if (blocks > 4096) blocks = 4096;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(table_adam_kernel, dim3(blocks), dim3(256), 0, s, table, grad_table, m, v, flags, V, C,
-                     sumsq, nsum, clip_norm, adam_state, beta1, beta2, eps, lazy);
+                     sumsq, sumsq_stride, nsum, clip_norm, adam_state, beta1, beta2, eps, lazy);
   CLSR_CHECK_LAUNCH();
   int cb = clsr_cdiv(V, 256);
   if (cb > 1024) cb = 1024;

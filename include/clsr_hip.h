@@ -139,6 +139,18 @@ int clsr_contrastive(const float* L, const float* S, const float* M, const float
                      float weight, const float* denom_ptr, double* loss_out, float* dL, float* dS,
                      float* dM, float* dR, void* stream);
 
+/* small movers + backward helpers of the re-associated first att_fcn layer
+ *   z0[r,t,:] = U[h,t,:] + V[r,:] + (a[h,t,:]*q[r,:]).Wp   ==  [a, q, a-q, a*q].W0 + b0  (clsr.py:368-370) */
+int clsr_copy_cols(const float* src, int ld_src, int src_col0, int row_div, long N, int C, float* dst,
+                   int ldd, int dst_col0, int accumulate, void* stream);
+int clsr_group_sum_cols(const float* src, int ld_src, int src_col0, int G, long Hn, int C, float* dst,
+                        int ldd, int dst_col0, int accumulate, void* stream);
+int clsr_axpby(float* out, const float* a, float sa, const float* b, float sb, long n, void* stream);
+int clsr_att_z0_bwd_reduce(const float* dz0, long Hn, int G, int T, int C, float* dU, float* dV,
+                           void* stream);
+int clsr_att_prod_bwd(const float* daq, const float* a, const float* q, long Hn, int G, int T, int Q,
+                      float* da, float* dq, void* stream);
+
 /* ---- regularisers, clip, Adam: base_model.py:118-159,249-297; clsr.py:73-82 */
 int clsr_adam_tick(double* state, double lr, double beta1, double beta2, void* stream);
 int clsr_dense_reg_norm(const float* param, float* grad, const int* seg_off, int nseg, float l2,
@@ -151,8 +163,8 @@ int clsr_table_reg(const float* table, const float* partner, const unsigned char
                    float l2, float disc_scale, float disc_loss_scale, const float* count,
                    float* grad_table, double* sumsq, double* reg_loss, double* disc_loss, void* stream);
 int clsr_table_adam(float* table, float* grad_table, float* m, float* v, unsigned char* flags, long V,
-                    int C, const double* sumsq, int nsum, float clip_norm, const double* adam_state,
-                    float beta1, float beta2, float eps, int lazy, void* stream);
+                    int C, const double* sumsq, int sumsq_stride, int nsum, float clip_norm,
+                    const double* adam_state, float beta1, float beta2, float eps, int lazy, void* stream);
 int clsr_zero_doubles(double* p, int n, void* stream);
 int clsr_zero_floats(float* p, long n, void* stream);
 

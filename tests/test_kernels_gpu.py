@@ -629,7 +629,7 @@ def test_table_reg_adam(lazy):
     close(ss[1:], (g_reg ** 2).sum().reshape(1), rtol=1e-5, name="reg sumsq")
     st = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device="cuda")
     call("clsr_adam_tick", st, 1e-3, 0.9, 0.999)
-    call("clsr_table_adam", dUL, dG, dm, dv, dfl, V, C, ss, 2, clip, st, 0.9, 0.999, 1e-8, lazy)
+    call("clsr_table_adam", dUL, dG, dm, dv, dfl, V, C, ss, 1, 2, clip, st, 0.9, 0.999, 1e-8, lazy)
     tot = float((G_l ** 2).sum() + (g_reg ** 2).sum())
     fac = clip / max(math.sqrt(tot), clip)
     gt = (G_l + g_reg) * fac
