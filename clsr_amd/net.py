@@ -1,0 +1,719 @@
+"""Device-side CLSR network: parameters, optimiser state and the training / scoring step,
+orchestrated from Python over the C ABI (every numeric operation is a HIP kernel in
+libclsr_hip.so; torch only owns the device memory and the stream).
+
+Mirrors what one ``sess.run`` of the reference executes
+(``CLSRModel.train`` models/sequential/clsr.py:383-408, ``eval_with_user``
+models/sequential/sequential_base_model.py:294-308):
+embedding gathers -> long-term attention, GRU / Time4LSTM / GRU encoders -> short-term
+attention -> alpha gate -> logit MLP -> losses -> gradients -> per-tensor clip -> Adam.
+
+History de-duplication.  In training the reference replicates every history
+``G = 1 + train_num_ngs`` times (io/sequential_iterator.py:588-610).  Everything that does not
+depend on the target item (gathers, long-term attention, the three RNNs, hist_mean/recent) is
+computed once per history group (``Hn = B / G`` rows) and shared by the G rows -- exact for the
+forward pass and for the summed gradients (BN statistics are identical because every history
+is replicated equally; dropout is 0).  The one observable difference: ``tf.clip_by_norm`` of
+the embedding IndexedSlices uses the norm of the G un-summed replica slices, here the norm of
+their sum is used; ``dedup_histories=False`` runs the reference's replicated computation.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from clsr_amd import ops
+from clsr_amd.ops import call, query
+from clsr_amd.params import CL, TABLES, UNUSED_TABLE, init_tensor, param_specs
+
+BN_MOMENTUM = 0.95
+BN_EPS = 1e-4
+F32 = torch.float32
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class _BN(object):
+    """One tf.layers.batch_normalization layer: trainables are views into the flat dense buffer."""
+
+    def __init__(self, net, scope, C):
+        dev = net.device
+        self.C = C
+        self.gamma, self.beta = net.P[scope + "gamma"], net.P[scope + "beta"]
+        self.dgamma, self.dbeta = net.Gd[scope + "gamma"], net.Gd[scope + "beta"]
+        self.moving_mean = torch.zeros(C, dtype=F32, device=dev)
+        self.moving_var = torch.ones(C, dtype=F32, device=dev)
+        self.scale = torch.empty(C, dtype=F32, device=dev)
+        self.shift = torch.empty(C, dtype=F32, device=dev)
+        self.mean = torch.empty(C, dtype=F32, device=dev)
+        self.invstd = torch.empty(C, dtype=F32, device=dev)
+        self.coef = torch.empty(3 * C, dtype=F32, device=dev)
+        self.scope = scope
+
+
+class CLSRNet(object):
+    def __init__(self, hp, dims, device="cuda:0", seed=None, dedup_histories=True):
+        self.hp = hp
+        self.dims = dict(dims)
+        self.device = torch.device(device)
+        self.dedup = bool(dedup_histories)
+        self._check_supported()
+        self.Di, self.Dc = hp.item_embedding_dim, hp.cate_embedding_dim
+        self.D = self.Di + self.Dc
+        self.Du, self.H = hp.user_embedding_dim, hp.hidden_size
+        self.A0, self.A1 = hp.att_fcn_layer_sizes
+        self.L0, self.L1 = hp.layer_sizes
+        self.G_train = hp.train_num_ngs + 1
+        self.lazy = 1 if hp.optimizer == "lazyadam" else 0
+        self._build_params(seed)
+        self._bufs = {}
+        self._zero_specs = OrderedDict()
+        self.packed = {}
+        self.adam_state = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device=self.device)
+        self.losses = torch.zeros(8, dtype=torch.float64, device=self.device)
+        self.sumsq_tab = torch.zeros(16, dtype=torch.float64, device=self.device)
+        self.ucount = torch.zeros(1, dtype=F32, device=self.device)
+        self.last_shape = None
+        self.capture_grads = False
+        self.captured = None
+
+    # ------------------------------------------------------------------ configuration guard
+    def _check_supported(self):
+        hp = self.hp
+        bad = []
+        if hp.sequential_model not in ("time4lstm", "gru"):
+            bad.append("sequential_model=%r (time4lstm | gru)" % hp.sequential_model)
+        if hp.enable_BN is not True:
+            bad.append("enable_BN must be True")
+        if list(hp.activation) != ["relu"] * len(hp.activation):
+            bad.append("activation must be relu")
+        if any(float(d) != 0.0 for d in hp.dropout) or float(hp.embedding_dropout) != 0.0 or hp.user_dropout:
+            bad.append("dropout must be 0")
+        if any(float(getattr(hp, k)) != 0.0 for k in ("embed_l1", "layer_l1", "cross_l1", "cross_l2")):
+            bad.append("l1 / cross regularisers must be 0")
+        if hp.loss != "softmax" or hp.method != "classification":
+            bad.append("loss must be softmax / method classification")
+        if hp.optimizer not in ("adam", "lazyadam"):
+            bad.append("optimizer must be adam or lazyadam")
+        if len(hp.att_fcn_layer_sizes) != 2 or len(hp.layer_sizes) != 2:
+            bad.append("att_fcn_layer_sizes / layer_sizes must have two layers")
+        if hp.contrastive_loss not in ("bpr", "triplet"):
+            bad.append("contrastive_loss must be bpr or triplet")
+        D = hp.item_embedding_dim + hp.cate_embedding_dim
+        if hp.hidden_size != D or hp.user_embedding_dim != D:
+            bad.append("hidden_size and user_embedding_dim must equal item+cate dims (alpha fusion, clsr.py:265)")
+        if bad:
+            raise NotImplementedError("CLSR HIP path does not support: " + "; ".join(bad))
+
+    # ------------------------------------------------------------------ parameters
+    def _build_params(self, seed):
+        hp, dev = self.hp, self.device
+        gen = torch.Generator()
+        if seed is None:
+            gen.seed()
+        else:
+            gen.manual_seed(int(seed))
+        specs = param_specs(self.dims, hp)
+        self.specs = specs
+        table_names = set(TABLES.values()) | {UNUSED_TABLE}
+        dense = [(n, s, k) for n, s, k in specs if n not in table_names]
+        sizes = [_pad4(int(np.prod(s))) for _, s, _ in dense]
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        self.n_dense = int(off[-1])
+        self.dense = torch.zeros(self.n_dense, dtype=F32, device=dev)
+        self.dense_grad = torch.zeros_like(self.dense)
+        self.dense_m = torch.zeros_like(self.dense)
+        self.dense_v = torch.zeros_like(self.dense)
+        self.seg_off = torch.tensor(off, dtype=torch.int32, device=dev)
+        self.seg_of = torch.tensor(np.repeat(np.arange(len(sizes)), sizes), dtype=torch.int32, device=dev)
+        self.dense_sumsq = torch.zeros(len(sizes), dtype=torch.float64, device=dev)
+        self.dense_names = [n for n, _, _ in dense]
+        self.P, self.Gd = OrderedDict(), OrderedDict()
+        host = torch.zeros(self.n_dense, dtype=F32)
+        self.tables, self.tab_grad, self.tab_m, self.tab_v, self.tab_flags = {}, {}, {}, {}, {}
+        it_dense = iter(zip(dense, off[:-1]))
+        for name, shape, kind in specs:
+            val = init_tensor(kind, tuple(shape), hp, gen)
+            if name in table_names:
+                t = val.to(dev)
+                self.P[name] = t
+                if name != UNUSED_TABLE:
+                    key = [k for k, v in TABLES.items() if v == name][0]
+                    self.tables[key] = t
+                    self.tab_grad[key] = torch.zeros_like(t)
+                    self.tab_m[key] = torch.zeros_like(t)
+                    self.tab_v[key] = torch.zeros_like(t)
+                    self.tab_flags[key] = torch.zeros(shape[0], dtype=torch.uint8, device=dev)
+            else:
+                (_, _, _), o = next(it_dense)
+                n = int(np.prod(shape))
+                host[o:o + n] = val.reshape(-1)
+                self.P[name] = self.dense[o:o + n].view(*shape)
+                self.Gd[name] = self.dense_grad[o:o + n].view(*shape)
+        self.dense.copy_(host)
+        # batch-norm layers
+        self.bn = {}
+        for name in self.dense_names:
+            if name.endswith("/gamma"):
+                scope = name[:-len("gamma")]
+                self.bn[scope] = _BN(self, scope, self.P[name].numel())
+
+    def state_dict(self):
+        """All variables under their TF names + BN moving stats + Adam slots (checkpoint payload)."""
+        sd = OrderedDict()
+        for name, t in self.P.items():
+            sd[name] = t.detach().cpu().clone()
+        for scope, bn in self.bn.items():
+            sd[scope + "moving_mean"] = bn.moving_mean.cpu().clone()
+            sd[scope + "moving_variance"] = bn.moving_var.cpu().clone()
+        sd["__adam__/dense_m"] = self.dense_m.cpu().clone()
+        sd["__adam__/dense_v"] = self.dense_v.cpu().clone()
+        for k in self.tables:
+            sd["__adam__/%s_m" % k] = self.tab_m[k].cpu().clone()
+            sd["__adam__/%s_v" % k] = self.tab_v[k].cpu().clone()
+        sd["__adam__/state"] = self.adam_state.cpu().clone()
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        for name, t in self.P.items():
+            if name in sd:
+                src = torch.as_tensor(np.asarray(sd[name]), dtype=F32)
+                if tuple(src.shape) != tuple(t.shape):
+                    raise ValueError("shape mismatch for %s: %s vs %s" % (name, tuple(src.shape), tuple(t.shape)))
+                t.copy_(src)
+            elif strict:
+                raise KeyError(name)
+        for scope, bn in self.bn.items():
+            if scope + "moving_mean" in sd:
+                bn.moving_mean.copy_(torch.as_tensor(np.asarray(sd[scope + "moving_mean"]), dtype=F32))
+                bn.moving_var.copy_(torch.as_tensor(np.asarray(sd[scope + "moving_variance"]), dtype=F32))
+            elif strict:
+                raise KeyError(scope + "moving_mean")
+        if "__adam__/dense_m" in sd:
+            self.dense_m.copy_(torch.as_tensor(sd["__adam__/dense_m"]))
+            self.dense_v.copy_(torch.as_tensor(sd["__adam__/dense_v"]))
+            for k in self.tables:
+                self.tab_m[k].copy_(torch.as_tensor(sd["__adam__/%s_m" % k]))
+                self.tab_v[k].copy_(torch.as_tensor(sd["__adam__/%s_v" % k]))
+            self.adam_state.copy_(torch.as_tensor(sd["__adam__/state"]))
+
+    # ------------------------------------------------------------------ buffers
+    def _buf(self, name, *shape, dtype=F32):
+        """Named persistent workspace tensor (allocated zeroed on first use, then reused)."""
+        key = (name,) + tuple(int(s) for s in shape) + (dtype,)
+        t = self._bufs.get(key)
+        if t is None:
+            t = torch.zeros(*[int(s) for s in shape], dtype=dtype, device=self.device)
+            self._bufs[key] = t
+        return t
+
+    def _pack(self, key, W, out_f, in_f, transposed=False, W2=None, s2=1.0, in_pad=None):
+        """Pack weight block W ([in, out] view) as the MFMA A operand (and cache under key)."""
+        Kp = ops.kp_for(in_pad or in_f)
+        opad = 16 * ((out_f + 15) // 16)
+        buf = self._buf("pack:" + key, opad * Kp)
+        call("clsr_pack_weight", W, W.stride(0), 1.0, W2, 0 if W2 is None else W2.stride(0), float(s2),
+             1 if transposed else 0, out_f, in_f, Kp, buf)
+        self.packed[key] = (buf, Kp)
+
+    def _pack_pair(self, key, W, K, N, K_pad=None):
+        """forward pack (K->N) and transposed pack (N->K) of the same [K, N] block."""
+        self._pack(key, W, N, K, in_pad=K_pad)
+        self._pack(key + "^T", W, K, N, transposed=True)
+
+    def _gemm(self, X, ldx, wkey, M, K, N, Y, ldy, bias=None, T=0, G=0, Xmul=None, ldmul=0, aff=None,
+              addU=None, ldu=0, addV=None, ldv=0, acc=0, stats=None):
+        Wt, Kp = self.packed[wkey]
+        sc, sh = (aff.scale, aff.shift) if aff is not None else (None, None)
+        call("clsr_pgemm", X, ldx, T, G, Xmul, ldmul, sc, sh, 1, Wt, Kp, bias, addU, ldu, addV, ldv, Y, ldy,
+             acc, stats, M, K, N)
+
+    def _dw(self, X, ldx, dY, ldy, M, K, N, dW, ldw, db=None, T=0, G=0, Xmul=None, ldmul=0, aff=None, acc=0):
+        need = query("clsr_pgemm_dw_workspace_floats", M, K, N)
+        ws = self._bufs.get("dw_ws")
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(max(need, 1 << 20), dtype=F32, device=self.device)
+            self._bufs["dw_ws"] = ws
+        sc, sh = (aff.scale, aff.shift) if aff is not None else (None, None)
+        call("clsr_pgemm_dw", X, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, ldy, M, K, N, 1.0, dW, ldw, db, acc, ws)
+
+    def _stats_buf(self, M, N):
+        parts = query("clsr_pgemm_stats_parts", M)
+        return self._buf("stats", 1024 * 2 * 256, dtype=torch.float64)[: parts * 2 * N], parts
+
+    def _bn_fwd(self, bn, stats, parts, count, training):
+        call("clsr_bn_finalize", stats, parts, bn.C, float(count), bn.gamma, bn.beta, bn.moving_mean,
+             bn.moving_var, BN_MOMENTUM, BN_EPS, 1 if training else 0, bn.scale, bn.shift, bn.mean, bn.invstd)
+
+    def _bn_bwd_from_partial(self, bn, part, parts, dy, z, M):
+        call("clsr_bn_bwd_coef", part, parts, bn.C, float(M), bn.gamma, bn.mean, bn.invstd, bn.coef,
+             bn.dgamma, bn.dbeta, 0)
+        call("clsr_bn_bwd_apply", dy, z, bn.coef, M, bn.C)
+
+    def _bn_relu_bwd(self, bn, dh, z, M):
+        parts = query("clsr_colred_parts", M, bn.C)
+        part = self._buf("colred", 2048 * 2 * 256, dtype=torch.float64)[: parts * 2 * bn.C]
+        call("clsr_bn_relu_bwd_reduce", dh, z, bn.scale, bn.shift, bn.mean, bn.invstd, M, bn.C, part)
+        self._bn_bwd_from_partial(bn, part, parts, dh, z, M)
+
+    # ------------------------------------------------------------------ weight packing (per step)
+    def _pack_all(self, training):
+        hp, P = self.hp, self.P
+        D, Du, H, A0, A1 = self.D, self.Du, self.H, self.A0, self.A1
+        for key, scope, Dk, Q in (("lt", CL + "long_term/attention_fcn/", D, Du),
+                                  ("st", CL + "short_term/attention_fcn/", H, Du + D)):
+            self._pack_pair(key + ".A", P[scope + "attention_mat"], Dk, Q)
+            W0 = P[scope + "att_fcn/nn_part/w_nn_layer0"]
+            self._pack(key + ".Wu", W0[0:Q], A0, Q, W2=W0[2 * Q:3 * Q], s2=1.0)
+            self._pack(key + ".Wv", W0[Q:2 * Q], A0, Q, W2=W0[2 * Q:3 * Q], s2=-1.0)
+            self._pack(key + ".Wp", W0[3 * Q:4 * Q], A0, Q)
+            self._pack(key + ".W1", P[scope + "att_fcn/nn_part/w_nn_layer1"], A1, A0)
+            if training:
+                self._pack(key + ".Wu^T", W0[0:Q], Q, A0, transposed=True, W2=W0[2 * Q:3 * Q], s2=1.0)
+                self._pack(key + ".Wv^T", W0[Q:2 * Q], Q, A0, transposed=True, W2=W0[2 * Q:3 * Q], s2=-1.0)
+                self._pack(key + ".Wp^T", W0[3 * Q:4 * Q], Q, A0, transposed=True)
+                self._pack(key + ".W1^T", P[scope + "att_fcn/nn_part/w_nn_layer1"], A0, A1, transposed=True)
+        pair = self._pack_pair if training else (lambda k, W, K, N, K_pad=None: self._pack(k, W, N, K, in_pad=K_pad))
+        for key, scope, n in self._gru_list():
+            pair(key + ".gx", P[scope + "gates/kernel"][0:D], D, 2 * n)
+            pair(key + ".cx", P[scope + "candidate/kernel"][0:D], D, n)
+        if hp.sequential_model == "time4lstm":
+            t = CL + "short_term/time4lstm/"
+            pair("t4.kx", P[t + "kernel"][0:D], D, 4 * H)
+            pair("t4.w1", P[t + "_time_kernel_w1"], D, H)
+            pair("t4.w2", P[t + "_time_kernel_w2"], D, H)
+            for nm in ("_o_kernel_t1", "_o_kernel_t2", "_time_kernel_t1", "_time_kernel_t2"):
+                pair("t4." + nm, P[t + nm], H, H)
+        if not hp.manual_alpha:
+            a = CL + "fcn_alpha/nn_part/"
+            pair("al.W0", P[a + "w_nn_layer0"], self.a_in, A0, K_pad=_pad4(self.a_in))
+            pair("al.W1", P[a + "w_nn_layer1"], A0, A1)
+        lg = "sequential/logit_fcn/nn_part/"
+        pair("lg.W0", P[lg + "w_nn_layer0"], 2 * D, self.L0)
+        pair("lg.W1", P[lg + "w_nn_layer1"], self.L0, self.L1)
+
+    def _gru_list(self):
+        hp = self.hp
+        out = []
+        if hp.interest_evolve:
+            out.append(("g1", CL + "short_term/short_term_intention/gru_cell/", self.Du))
+        if hp.sequential_model == "gru":
+            out.append(("gs", CL + "short_term/simple_gru/gru_cell/", self.H))
+        if (not hp.manual_alpha) and hp.predict_long_short:
+            out.append(("g2", CL + "causal2/causal2/gru_cell/", self.H))
+        return out
+
+    @property
+    def a_in(self):
+        hp = self.hp
+        return (self.H if hp.predict_long_short else 0) + 3 * self.D + 1
+
+    # ------------------------------------------------------------------ feed upload
+    def upload(self, feed, training):
+        """numpy feed (iterator layout) -> device tensors (+ per-batch scalars)."""
+        dev = self.device
+        mask = np.asarray(feed["mask"])
+        seq_len = mask.sum(1).astype(np.int32)
+        f = {}
+        f["users"] = torch.as_tensor(np.asarray(feed["users"]).astype(np.int32)).to(dev)
+        for k in ("items", "cates", "item_history", "item_cate_history"):
+            f[k] = torch.as_tensor(np.ascontiguousarray(feed[k], dtype=np.int32)).to(dev)
+        for k in ("time_from_first_action", "time_to_now"):
+            f[k] = torch.as_tensor(np.ascontiguousarray(feed[k], dtype=np.float32)).to(dev)
+        f["labels"] = torch.as_tensor(np.ascontiguousarray(feed["labels"], dtype=np.float32).reshape(-1)).to(dev)
+        f["seq_len"] = torch.as_tensor(seq_len).to(dev)
+        denom = float((seq_len > self.hp.contrastive_length_threshold).sum())
+        f["denom"] = torch.tensor([denom], dtype=F32, device=dev)
+        f["B"] = int(mask.shape[0])
+        f["T"] = int(mask.shape[1])
+        return f
+
+    # ------------------------------------------------------------------ attention block
+    def _att_fwd(self, key, scope, keys, q, Hn, G, T, Dk, Q, seq_len, len_stride, training):
+        P, A0, A1 = self.P, self.A0, self.A1
+        R = Hn * G
+        nn = scope + "att_fcn/nn_part/"
+        bn0, bn1 = self.bn[nn + "batch_normalization/"], self.bn[nn + "batch_normalization_1/"]
+        a = self._buf(key + ".a", Hn * T, Q)
+        U = self._buf(key + ".U", Hn * T, A0)
+        V = self._buf(key + ".V", R, A0)
+        z0 = self._buf(key + ".z0", R * T, A0)
+        z1 = self._buf(key + ".z1", R * T, A1)
+        wts = self._buf(key + ".wts", R, T)
+        out = self._buf(key + ".out", R, Dk)
+        self._gemm(keys, Dk, key + ".A", Hn * T, Dk, Q, a, Q)
+        self._gemm(a, Q, key + ".Wu", Hn * T, Q, A0, U, A0)
+        self._gemm(q, Q, key + ".Wv", R, Q, A0, V, A0, bias=P[nn + "b_nn_layer0"])
+        st, parts = self._stats_buf(R * T, A0) if training else (None, 0)
+        self._gemm(a, Q, key + ".Wp", R * T, Q, A0, z0, A0, T=T, G=G, Xmul=q, ldmul=Q, addU=U, ldu=A0,
+                   addV=V, ldv=A0, stats=st)
+        self._bn_fwd(bn0, st, parts, R * T, training)
+        st, parts = self._stats_buf(R * T, A1) if training else (None, 0)
+        self._gemm(z0, A0, key + ".W1", R * T, A0, A1, z1, A1, bias=P[nn + "b_nn_layer1"], aff=bn0, stats=st)
+        self._bn_fwd(bn1, st, parts, R * T, training)
+        call("clsr_att_out_fwd", z1, bn1.scale, bn1.shift, P[nn + "w_nn_output"], P[nn + "b_nn_output"],
+             seq_len, len_stride, keys, Hn, G, T, A1, Dk, wts, out)
+        return out
+
+    def _att_bwd(self, key, scope, dout, keys, q, dkeys, Hn, G, T, Dk, Q, seq_len, len_stride):
+        """Returns dq [R, Q]; accumulates into dkeys [Hn, T, Dk]; writes every dense gradient."""
+        P, Gd, A0, A1 = self.P, self.Gd, self.A0, self.A1
+        R = Hn * G
+        nn = scope + "att_fcn/nn_part/"
+        bn0, bn1 = self.bn[nn + "batch_normalization/"], self.bn[nn + "batch_normalization_1/"]
+        a, z0, z1 = (self._buf(key + s, *shp) for s, shp in
+                     ((".a", (Hn * T, Q)), (".z0", (R * T, A0)), (".z1", (R * T, A1))))
+        wts = self._buf(key + ".wts", R, T)
+        dz1 = self._buf(key + ".dz1", R * T, A1)
+        dz0 = self._buf(key + ".dz0", R * T, A0)
+        parts = query("clsr_att_out_bwd_parts", Hn)
+        bnp = self._buf("att.bnp", 2048 * 2 * 256, dtype=torch.float64)[: parts * 2 * A1]
+        wp = self._buf("att.wp", 2048 * (256 + 4))[: parts * (A1 + 4)]
+        call("clsr_att_out_bwd", dout, wts, z1, bn1.scale, bn1.shift, bn1.mean, bn1.invstd,
+             P[nn + "w_nn_output"], seq_len, len_stride, keys, Hn, G, T, A1, Dk, dz1, dkeys, bnp, wp)
+        call("clsr_reduce_parts", wp, parts, A1 + 4, A1, 1.0, Gd[nn + "w_nn_output"], 0)
+        call("clsr_reduce_parts", wp[A1:], parts, A1 + 4, 1, 1.0, Gd[nn + "b_nn_output"], 0)
+        self._bn_bwd_from_partial(bn1, bnp, parts, dz1, z1, R * T)
+        # layer 1: z1 = relu(bn0(z0)) . W1 + b1
+        self._dw(z0, A0, dz1, A1, R * T, A0, A1, Gd[nn + "w_nn_layer1"], A1, db=Gd[nn + "b_nn_layer1"], aff=bn0)
+        self._gemm(dz1, A1, key + ".W1^T", R * T, A1, A0, dz0, A0)
+        self._bn_relu_bwd(bn0, dz0, z0, R * T)
+        # layer 0 (re-associated): z0 = U[h,t] + V[r] + (a[h,t]*q[r]) . Wp
+        dW0 = Gd[nn + "w_nn_layer0"]
+        self._dw(a, Q, dz0, A0, R * T, Q, A0, dW0[3 * Q:4 * Q], A0, T=T, G=G, Xmul=q, ldmul=Q)
+        daq = self._buf(key + ".daq", R * T, Q)
+        self._gemm(dz0, A0, key + ".Wp^T", R * T, A0, Q, daq, Q)
+        da = self._buf(key + ".da", Hn * T, Q)
+        dq = self._buf(key + ".dq", R, Q)
+        call("clsr_att_prod_bwd", daq, a, q, Hn, G, T, Q, da, dq)
+        dV = self._buf(key + ".dV", R, A0)
+        if G == 1:
+            dU = dz0
+            call("clsr_att_z0_bwd_reduce", dz0, Hn, G, T, A0, None, dV)
+        else:
+            dU = self._buf(key + ".dU", Hn * T, A0)
+            call("clsr_att_z0_bwd_reduce", dz0, Hn, G, T, A0, dU, dV)
+        self._dw(a, Q, dU, A0, Hn * T, Q, A0, dW0[0:Q], A0)                        # d(W0a + W0d)
+        self._dw(q, Q, dV, A0, R, Q, A0, dW0[Q:2 * Q], A0, db=Gd[nn + "b_nn_layer0"])  # d(W0q - W0d)
+        call("clsr_axpby", dW0[2 * Q:3 * Q], dW0[0:Q], 1.0, dW0[Q:2 * Q], -1.0, Q * A0)
+        self._gemm(dU, A0, key + ".Wu^T", Hn * T, A0, Q, da, Q, acc=1)
+        self._gemm(dV, A0, key + ".Wv^T", R, A0, Q, dq, Q, acc=1)
+        self._dw(keys, Dk, da, Q, Hn * T, Dk, Q, Gd[scope + "attention_mat"], Q)
+        self._gemm(da, Q, key + ".A^T", Hn * T, Q, Dk, dkeys, Dk, acc=1)
+        return dq
+
+    # ------------------------------------------------------------------ MLP (alpha / logit)
+    def _mlp_fwd(self, key, nn, X, ldx, K0, sizes, B, training):
+        P = self.P
+        C0, C1 = sizes
+        bn0, bn1 = self.bn[nn + "batch_normalization/"], self.bn[nn + "batch_normalization_1/"]
+        z0, z1 = self._buf(key + ".z0", B, C0), self._buf(key + ".z1", B, C1)
+        logit = self._buf(key + ".logit", B)
+        st, parts = self._stats_buf(B, C0) if training else (None, 0)
+        self._gemm(X, ldx, key + ".W0", B, K0, C0, z0, C0, bias=P[nn + "b_nn_layer0"], stats=st)
+        self._bn_fwd(bn0, st, parts, B, training)
+        st, parts = self._stats_buf(B, C1) if training else (None, 0)
+        self._gemm(z0, C0, key + ".W1", B, C0, C1, z1, C1, bias=P[nn + "b_nn_layer1"], aff=bn0, stats=st)
+        self._bn_fwd(bn1, st, parts, B, training)
+        call("clsr_mlp_out_fwd", z1, bn1.scale, bn1.shift, P[nn + "w_nn_output"], P[nn + "b_nn_output"], B, C1, logit)
+        return logit
+
+    def _mlp_bwd(self, key, nn, dlogit, X, ldx, K0, K0_real, sizes, B):
+        """Returns dX [B, K0] (K0 = padded input width)."""
+        P, Gd = self.P, self.Gd
+        C0, C1 = sizes
+        bn0, bn1 = self.bn[nn + "batch_normalization/"], self.bn[nn + "batch_normalization_1/"]
+        z0, z1 = self._buf(key + ".z0", B, C0), self._buf(key + ".z1", B, C1)
+        dz1, dz0 = self._buf(key + ".dz1", B, C1), self._buf(key + ".dz0", B, C0)
+        parts = query("clsr_mlp_out_bwd_parts", B, C1)
+        bnp = self._buf("mlp.bnp", 512 * 2 * 256, dtype=torch.float64)[: parts * 2 * C1]
+        wp = self._buf("mlp.wp", 512 * (256 + 4))[: parts * (C1 + 4)]
+        call("clsr_mlp_out_bwd", dlogit, z1, bn1.scale, bn1.shift, bn1.mean, bn1.invstd, P[nn + "w_nn_output"],
+             B, C1, dz1, bnp, wp)
+        call("clsr_reduce_parts", wp, parts, C1 + 4, C1, 1.0, Gd[nn + "w_nn_output"], 0)
+        call("clsr_reduce_parts", wp[C1:], parts, C1 + 4, 1, 1.0, Gd[nn + "b_nn_output"], 0)
+        self._bn_bwd_from_partial(bn1, bnp, parts, dz1, z1, B)
+        self._dw(z0, C0, dz1, C1, B, C0, C1, Gd[nn + "w_nn_layer1"], C1, db=Gd[nn + "b_nn_layer1"], aff=bn0)
+        self._gemm(dz1, C1, key + ".W1^T", B, C1, C0, dz0, C0)
+        self._bn_relu_bwd(bn0, dz0, z0, B)
+        self._dw(X, ldx, dz0, C0, B, K0_real, C0, Gd[nn + "w_nn_layer0"], C0, db=Gd[nn + "b_nn_layer0"])
+        dX = self._buf(key + ".dX", B, K0)
+        self._gemm(dz0, C0, key + ".W0^T", B, C0, K0, dX, K0)
+        return dX
+
+    # ------------------------------------------------------------------ GRU helpers
+    def _gru_fwd(self, key, scope, n, hist, Hn, T, seq_len, ls, h0, training, want_seq=False):
+        P, D = self.P, self.D
+        Pin = self._buf(key + ".Pin", Hn * T, 3 * n)
+        self._gemm(hist, D, key + ".gx", Hn * T, D, 2 * n, Pin, 3 * n, bias=P[scope + "gates/bias"])
+        self._gemm(hist, D, key + ".cx", Hn * T, D, n, Pin[:, 2 * n:], 3 * n, bias=P[scope + "candidate/bias"])
+        hT = self._buf(key + ".hT", Hn, n)
+        seq = self._buf(key + ".seq", Hn, T, n) if want_seq else None
+        hprev = self._buf(key + ".hprev", Hn, T, n) if training else None
+        gates = self._buf(key + ".gates", Hn, T, 3 * n) if training else None
+        Wg, Wc = P[scope + "gates/kernel"], P[scope + "candidate/kernel"]
+        call("clsr_gru_fwd", Pin, 3 * n, Wg[D:], 2 * n, Wc[D:], n, h0, n if h0 is not None else 0, seq_len, ls,
+             Hn, T, n, hT, seq, hprev, gates)
+        return hT, seq
+
+    def _gru_bwd(self, key, scope, n, hist, dhist, Hn, T, seq_len, ls, dhT, dseq, dh0):
+        P, Gd, D = self.P, self.Gd, self.D
+        hprev, gates = self._buf(key + ".hprev", Hn, T, n), self._buf(key + ".gates", Hn, T, 3 * n)
+        dPin = self._buf(key + ".dPin", Hn * T, 3 * n)
+        Wg, Wc = P[scope + "gates/kernel"], P[scope + "candidate/kernel"]
+        dWg, dWc = Gd[scope + "gates/kernel"], Gd[scope + "candidate/kernel"]
+        call("clsr_gru_bwd", gates, hprev, Wg[D:], 2 * n, Wc[D:], n, seq_len, ls, Hn, T, n, dhT, dseq, dPin, dh0)
+        M = Hn * T
+        self._dw(hist, D, dPin, 3 * n, M, D, 2 * n, dWg[0:D], 2 * n, db=Gd[scope + "gates/bias"])
+        self._dw(hist, D, dPin[:, 2 * n:], 3 * n, M, D, n, dWc[0:D], n, db=Gd[scope + "candidate/bias"])
+        self._dw(hprev, n, dPin, 3 * n, M, n, 2 * n, dWg[D:], 2 * n)
+        self._dw(hprev, n, dPin[:, 2 * n:], 3 * n, M, n, n, dWc[D:], n, Xmul=gates, ldmul=3 * n)
+        self._gemm(dPin, 3 * n, key + ".gx^T", M, 2 * n, D, dhist, D, acc=1)
+        self._gemm(dPin[:, 2 * n:], 3 * n, key + ".cx^T", M, n, D, dhist, D, acc=1)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, f, training):
+        """Run the forward pass on an uploaded feed; returns dict of device tensors."""
+        hp, P = self.hp, self.P
+        B, T = f["B"], f["T"]
+        G = self.G_train if (training and self.dedup) else 1
+        if B % G:
+            raise ValueError("training feed rows (%d) must be a multiple of 1+train_num_ngs (%d)" % (B, G))
+        Hn = B // G
+        D, Du, H, Di, Dc = self.D, self.Du, self.H, self.Di, self.Dc
+        self.last_shape = (B, T, G, Hn)
+        self._pack_all(training)
+        seq_len, ls = f["seq_len"], G
+        # ---- gathers
+        hist = self._buf("hist", Hn, T, D)
+        hmean, hrec = self._buf("hist_mean", Hn, D), self._buf("hist_recent", Hn, D)
+        call("clsr_gather_hist_fwd", self.tables["item"], self.tables["cate"], f["item_history"],
+             f["item_cate_history"], G * T, seq_len, ls, Hn, T, Di, Dc, hp.contrastive_recent_k, hist, hmean, hrec)
+        target = self._buf("target", B, D)
+        call("clsr_gather_rows", self.tables["item"], f["items"], 1, B, Di, target, D, 0)
+        call("clsr_gather_rows", self.tables["cate"], f["cates"], 1, B, Dc, target, D, Di)
+        ulong, ushort = self._buf("u_long", Hn, Du), self._buf("u_short", Hn, Du)
+        call("clsr_gather_rows", self.tables["user_long"], f["users"], G, Hn, Du, ulong, Du, 0)
+        call("clsr_gather_rows", self.tables["user_short"], f["users"], G, Hn, Du, ushort, Du, 0)
+        # ---- long term
+        lt = CL + "long_term/attention_fcn/"
+        att_long = self._att_fwd("lt", lt, hist, ulong, Hn, 1, T, D, Du, seq_len, ls, training)
+        # ---- short term encoders
+        st = CL + "short_term/"
+        if hp.interest_evolve:
+            short_int, _ = self._gru_fwd("g1", st + "short_term_intention/gru_cell/", Du, hist, Hn, T, seq_len, ls,
+                                         ushort, training)
+        else:
+            short_int = ushort
+        if hp.sequential_model == "time4lstm":
+            t = st + "time4lstm/"
+            TT = self._buf("t4.TT", Hn * T, 2 * H)
+            call("clsr_t4_time_inputs_fwd", f["time_to_now"], f["time_from_first_action"], G * T,
+                 P[t + "_time_input_w1"], P[t + "_time_input_bias1"], P[t + "_time_input_w2"],
+                 P[t + "_time_input_bias2"], Hn, T, H, TT)
+            Pin = self._buf("t4.Pin", Hn * T, 6 * H)
+            M = Hn * T
+            self._gemm(hist, D, "t4.kx", M, D, 4 * H, Pin, 6 * H, bias=P[t + "bias"])
+            self._gemm(hist, D, "t4.w1", M, D, H, Pin[:, 4 * H:], 6 * H, bias=P[t + "_time_bias1"])
+            self._gemm(hist, D, "t4.w2", M, D, H, Pin[:, 5 * H:], 6 * H, bias=P[t + "_time_bias2"])
+            self._gemm(TT, 2 * H, "t4._o_kernel_t1", M, H, H, Pin[:, 3 * H:], 6 * H, acc=1)
+            self._gemm(TT[:, H:], 2 * H, "t4._o_kernel_t2", M, H, H, Pin[:, 3 * H:], 6 * H, acc=1)
+            self._gemm(TT, 2 * H, "t4._time_kernel_t1", M, H, H, Pin[:, 4 * H:], 6 * H, acc=1)
+            self._gemm(TT[:, H:], 2 * H, "t4._time_kernel_t2", M, H, H, Pin[:, 5 * H:], 6 * H, acc=1)
+            rnn_out = self._buf("rnn_out", Hn, T, H)
+            act = self._buf("t4.act", Hn, T, 6 * H) if training else None
+            cst = self._buf("t4.cst", Hn, T, H) if training else None
+            mprev = self._buf("t4.mprev", Hn, T, H) if training else None
+            call("clsr_t4lstm_fwd", Pin, 6 * H, P[t + "kernel"][D:], 4 * H, seq_len, ls, Hn, T, H, rnn_out, act,
+                 cst, mprev)
+        else:
+            _, rnn_out = self._gru_fwd("gs", st + "simple_gru/gru_cell/", H, hist, Hn, T, seq_len, ls, None,
+                                       training, want_seq=True)
+        # ---- short term attention: query = [short_term_intention | target]
+        Qs = Du + D
+        q = self._buf("st.q", B, Qs)
+        call("clsr_copy_cols", short_int, Du, 0, G, B, Du, q, Qs, 0, 0)
+        call("clsr_copy_cols", target, D, 0, 1, B, D, q, Qs, Du, 0)
+        att_short = self._att_fwd("st", st + "attention_fcn/", rnn_out, q, Hn, G, T, H, Qs, seq_len, ls, training)
+        # ---- alpha gate
+        alpha = self._buf("alpha", B)
+        mo = self._buf("model_output", B, 2 * D)
+        fs = None
+        if not hp.manual_alpha:
+            nfs = 0
+            if hp.predict_long_short:
+                fs, _ = self._gru_fwd("g2", CL + "causal2/causal2/gru_cell/", H, hist, Hn, T, seq_len, ls, None,
+                                      training)
+                nfs = H
+            ld = _pad4(self.a_in)
+            ain = self._buf("al.in", B, ld)
+            call("clsr_alpha_concat", fs, nfs, target, att_long, att_short, f["time_to_now"], T, T - 1, B, G, D,
+                 ain, ld)
+            al_logit = self._mlp_fwd("al", CL + "fcn_alpha/nn_part/", ain, ld, ld, (self.A0, self.A1), B, training)
+            call("clsr_alpha_fuse_fwd", al_logit, 0.0, att_long, att_short, target, B, G, D, alpha, mo)
+        else:
+            call("clsr_alpha_fuse_fwd", None, float(hp.manual_alpha_value), att_long, att_short, target, B, G, D,
+                 alpha, mo)
+        logit = self._mlp_fwd("lg", "sequential/logit_fcn/nn_part/", mo, 2 * D, 2 * D, (self.L0, self.L1), B, training)
+        return dict(logit=logit, alpha=alpha, att_fea_long=att_long, att_fea_short=att_short, hist_input=hist,
+                    hist_mean=hmean, hist_recent=hrec, target=target, u_long=ulong, u_short=ushort,
+                    short_intention=short_int, rnn_out=rnn_out, model_output=mo, causal_state=fs,
+                    w_long=self._buf("lt.wts", Hn, T), w_short=self._buf("st.wts", B, T), q_short=q)
+
+    # ------------------------------------------------------------------ training step
+    def train_step(self, f):
+        """forward + backward + clip + Adam on an uploaded feed.  Losses land in self.losses
+        (device doubles: data, regular, contrastive, discrepancy)."""
+        hp, P, Gd = self.hp, self.P, self.Gd
+        out = self.forward(f, True)
+        B, T, G, Hn = self.last_shape
+        D, Du, H, Di, Dc = self.D, self.Du, self.H, self.Di, self.Dc
+        seq_len, ls = f["seq_len"], G
+        call("clsr_zero_doubles", self.losses, 8)
+        call("clsr_zero_doubles", self.sumsq_tab, 16)
+        # gradient accumulators (zeroed every step)
+        zpool = self._buf("zero_pool", Hn * T * (D + H) + B * D * 2 + Hn * (3 * D + H + Du))
+        call("clsr_zero_floats", zpool, zpool.numel())
+        o = [0]
+
+        def take(*shape):
+            n = int(np.prod(shape))
+            t = zpool[o[0]:o[0] + n].view(*shape)
+            o[0] += n
+            return t
+        dhist, drnn = take(Hn, T, D), take(Hn, T, H)
+        dtarget, dS = take(B, D), take(B, D)
+        dL, dM, dR = take(Hn, D), take(Hn, D), take(Hn, D)
+        dfs, dsi = take(Hn, H), take(Hn, Du)
+        # involved-row flags (tf.unique id sets)
+        call("clsr_mark_rows", f["item_history"], Hn, T, G * T, self.tab_flags["item"])
+        call("clsr_mark_rows", f["items"], B, 1, 1, self.tab_flags["item"])
+        call("clsr_mark_rows", f["item_cate_history"], Hn, T, G * T, self.tab_flags["cate"])
+        call("clsr_mark_rows", f["cates"], B, 1, 1, self.tab_flags["cate"])
+        call("clsr_mark_rows", f["users"], Hn, 1, G, self.tab_flags["user_long"])
+        call("clsr_mark_rows", f["users"], Hn, 1, G, self.tab_flags["user_short"])
+        # ---- losses on the forward outputs
+        dlogit = self._buf("dlogit", B)
+        Gl = hp.train_num_ngs + 1
+        call("clsr_softmax_loss", out["logit"], f["labels"], B // Gl, Gl, self.losses[0:], dlogit)
+        call("clsr_contrastive", out["att_fea_long"], out["att_fea_short"], out["hist_mean"], out["hist_recent"],
+             seq_len, ls, Hn, G, D, int(hp.contrastive_length_threshold), 1 if hp.contrastive_loss == "triplet" else 0,
+             float(hp.triplet_margin), float(hp.contrastive_loss_weight), f["denom"], self.losses[2:], dL, dS, dM, dR)
+        # ---- logit MLP, fusion, alpha MLP
+        dmo = self._mlp_bwd("lg", "sequential/logit_fcn/nn_part/", dlogit, out["model_output"], 2 * D, 2 * D, 2 * D,
+                            (self.L0, self.L1), B)
+        if not hp.manual_alpha:
+            dal = self._buf("dalpha_logit", B)
+            call("clsr_alpha_fuse_bwd", dmo, out["alpha"], 0.0, out["att_fea_long"], out["att_fea_short"], Hn, G, D,
+                 dal, dL, dS, dtarget)
+            ld = _pad4(self.a_in)
+            dain = self._mlp_bwd("al", CL + "fcn_alpha/nn_part/", dal, self._buf("al.in", B, ld), ld, ld, self.a_in,
+                                 (self.A0, self.A1), B)
+            nfs = H if hp.predict_long_short else 0
+            call("clsr_alpha_concat_bwd", dain, ld, nfs, Hn, G, D, dfs if nfs else None, dtarget, dL, dS)
+        else:
+            call("clsr_alpha_fuse_bwd", dmo, None, float(hp.manual_alpha_value), out["att_fea_long"],
+                 out["att_fea_short"], Hn, G, D, None, dL, dS, dtarget)
+        # ---- short-term attention
+        st = CL + "short_term/"
+        Qs = Du + D
+        dq = self._att_bwd("st", st + "attention_fcn/", dS, out["rnn_out"], out["q_short"], drnn, Hn, G, T, H, Qs,
+                           seq_len, ls)
+        call("clsr_group_sum_cols", dq, Qs, 0, G, Hn, Du, dsi, Du, 0, 1)
+        call("clsr_copy_cols", dq, Qs, Du, 1, B, D, dtarget, D, 0, 1)
+        # ---- sequence encoders
+        M = Hn * T
+        if hp.sequential_model == "time4lstm":
+            t = st + "time4lstm/"
+            dPin = self._buf("t4.dPin", M, 6 * H)
+            call("clsr_t4lstm_bwd", self._buf("t4.act", Hn, T, 6 * H), self._buf("t4.cst", Hn, T, H),
+                 P[t + "kernel"][D:], 4 * H, seq_len, ls, Hn, T, H, drnn, dPin)
+            hist, TT = out["hist_input"], self._buf("t4.TT", M, 2 * H)
+            dK = Gd[t + "kernel"]
+            self._dw(hist, D, dPin, 6 * H, M, D, 4 * H, dK[0:D], 4 * H, db=Gd[t + "bias"])
+            self._dw(self._buf("t4.mprev", Hn, T, H), H, dPin, 6 * H, M, H, 4 * H, dK[D:], 4 * H)
+            self._dw(hist, D, dPin[:, 4 * H:], 6 * H, M, D, H, Gd[t + "_time_kernel_w1"], H, db=Gd[t + "_time_bias1"])
+            self._dw(hist, D, dPin[:, 5 * H:], 6 * H, M, D, H, Gd[t + "_time_kernel_w2"], H, db=Gd[t + "_time_bias2"])
+            self._dw(TT, 2 * H, dPin[:, 3 * H:], 6 * H, M, H, H, Gd[t + "_o_kernel_t1"], H)
+            self._dw(TT[:, H:], 2 * H, dPin[:, 3 * H:], 6 * H, M, H, H, Gd[t + "_o_kernel_t2"], H)
+            self._dw(TT, 2 * H, dPin[:, 4 * H:], 6 * H, M, H, H, Gd[t + "_time_kernel_t1"], H)
+            self._dw(TT[:, H:], 2 * H, dPin[:, 5 * H:], 6 * H, M, H, H, Gd[t + "_time_kernel_t2"], H)
+            self._gemm(dPin, 6 * H, "t4.kx^T", M, 4 * H, D, dhist, D, acc=1)
+            self._gemm(dPin[:, 4 * H:], 6 * H, "t4.w1^T", M, H, D, dhist, D, acc=1)
+            self._gemm(dPin[:, 5 * H:], 6 * H, "t4.w2^T", M, H, D, dhist, D, acc=1)
+            dTT = self._buf("t4.dTT", M, 2 * H)
+            self._gemm(dPin[:, 3 * H:], 6 * H, "t4._o_kernel_t1^T", M, H, H, dTT, 2 * H)
+            self._gemm(dPin[:, 4 * H:], 6 * H, "t4._time_kernel_t1^T", M, H, H, dTT, 2 * H, acc=1)
+            self._gemm(dPin[:, 3 * H:], 6 * H, "t4._o_kernel_t2^T", M, H, H, dTT[:, H:], 2 * H)
+            self._gemm(dPin[:, 5 * H:], 6 * H, "t4._time_kernel_t2^T", M, H, H, dTT[:, H:], 2 * H, acc=1)
+            parts = query("clsr_t4_time_inputs_bwd_parts", Hn, T, H)
+            tp = self._buf("t4.tpart", 512 * 4 * 128)[: parts * 4 * H]
+            call("clsr_t4_time_inputs_bwd", dTT, TT, f["time_to_now"], f["time_from_first_action"], G * T, Hn, T, H, tp)
+            for off_, nm in ((0, "_time_input_w1"), (H, "_time_input_w2"), (2 * H, "_time_input_bias1"),
+                             (3 * H, "_time_input_bias2")):
+                call("clsr_reduce_parts", tp[off_:], parts, 4 * H, H, 1.0, Gd[t + nm], 0)
+        else:
+            self._gru_bwd("gs", st + "simple_gru/gru_cell/", H, out["hist_input"], dhist, Hn, T, seq_len, ls, None,
+                          drnn, None)
+        dushort = self._buf("d_u_short", Hn, Du)
+        if hp.interest_evolve:
+            self._gru_bwd("g1", st + "short_term_intention/gru_cell/", Du, out["hist_input"], dhist, Hn, T, seq_len,
+                          ls, dsi, None, dushort)
+        else:
+            dushort = dsi
+        if (not hp.manual_alpha) and hp.predict_long_short:
+            self._gru_bwd("g2", CL + "causal2/causal2/gru_cell/", H, out["hist_input"], dhist, Hn, T, seq_len, ls,
+                          dfs, None, None)
+        # ---- long-term attention
+        dul = self._att_bwd("lt", CL + "long_term/attention_fcn/", dL, out["hist_input"], out["u_long"], dhist, Hn, 1,
+                            T, D, Du, seq_len, ls)
+        # ---- embedding gradients (IndexedSlices values -> dense grad tables + squared norms)
+        ss = self.sumsq_tab
+        call("clsr_gather_hist_bwd", dhist, dM, dR, f["item_history"], f["item_cate_history"], G * T, seq_len, ls,
+             Hn, T, Di, Dc, hp.contrastive_recent_k, self.tab_grad["item"], self.tab_grad["cate"], ss[0:])
+        call("clsr_scatter_add_rows", dtarget, D, 0, f["items"], 1, B, Di, self.tab_grad["item"], ss[2:])
+        call("clsr_scatter_add_rows", dtarget, D, Di, f["cates"], 1, B, Dc, self.tab_grad["cate"], ss[3:])
+        call("clsr_scatter_add_rows", dul, Du, 0, f["users"], G, Hn, Du, self.tab_grad["user_long"], ss[6:])
+        call("clsr_scatter_add_rows", dushort, Du, 0, f["users"], G, Hn, Du, self.tab_grad["user_short"], ss[7:])
+        self._apply_updates()
+        return out
+
+    def _apply_updates(self):
+        hp = self.hp
+        ss = self.sumsq_tab
+        Vu, Vi, Vc = self.dims["Vu"], self.dims["Vi"], self.dims["Vc"]
+        l2e, wd = float(hp.embed_l2), float(hp.discrepancy_loss_weight)
+        call("clsr_zero_floats", self.ucount, 1)
+        call("clsr_count_flags", self.tab_flags["user_long"], Vu, self.ucount)
+        tb, tg, fl = self.tables, self.tab_grad, self.tab_flags
+        call("clsr_table_reg", tb["item"], None, fl["item"], Vi, self.Di, l2e, 0.0, 0.0, None, tg["item"], ss[4:],
+             self.losses[1:], None)
+        call("clsr_table_reg", tb["cate"], None, fl["cate"], Vc, self.Dc, l2e, 0.0, 0.0, None, tg["cate"], ss[5:],
+             self.losses[1:], None)
+        call("clsr_table_reg", tb["user_long"], tb["user_short"], fl["user_long"], Vu, self.Du, l2e, -2.0 * wd, -wd,
+             self.ucount, tg["user_long"], ss[8:], self.losses[1:], self.losses[3:])
+        call("clsr_table_reg", tb["user_short"], tb["user_long"], fl["user_short"], Vu, self.Du, l2e, -2.0 * wd, 0.0,
+             self.ucount, tg["user_short"], ss[9:], self.losses[1:], None)
+        clip = float(hp.max_grad_norm) if hp.is_clip_norm else 0.0
+        call("clsr_dense_reg_norm", self.dense, self.dense_grad, self.seg_off, len(self.dense_names),
+             float(hp.layer_l2), self.dense_sumsq, self.losses[1:])
+        if self.capture_grads:  # test hook: pre-clip gradients (regularisers included) + squared norms
+            self.captured = dict(dense={n: g.detach().clone() for n, g in self.Gd.items()},
+                                 tables={k: g.detach().clone() for k, g in tg.items()},
+                                 dense_sumsq=self.dense_sumsq.clone(), table_sumsq=ss.clone())
+        call("clsr_adam_tick", self.adam_state, float(hp.learning_rate), 0.9, 0.999)
+        call("clsr_dense_adam", self.dense, self.dense_grad, self.dense_m, self.dense_v, self.seg_of,
+             self.dense_sumsq, clip, self.adam_state, 0.9, 0.999, 1e-8, self.n_dense)
+        for key, V, C, base, nsum in (("item", Vi, self.Di, 0, 3), ("cate", Vc, self.Dc, 1, 3),
+                                      ("user_long", Vu, self.Du, 6, 2), ("user_short", Vu, self.Du, 7, 2)):
+            call("clsr_table_adam", tb[key], tg[key], self.tab_m[key], self.tab_v[key], fl[key], V, C, ss[base:], 2,
+                 nsum, clip, self.adam_state, 0.9, 0.999, 1e-8, self.lazy)
+
+    def read_losses(self):
+        """Synchronising read of the step's loss terms -> dict of python floats."""
+        v = self.losses.cpu().tolist()
+        return dict(data_loss=v[0], regular_loss=v[1], contrastive_loss=v[2], discrepancy_loss=v[3],
+                    loss=v[0] + v[1] + v[2] + v[3])

@@ -481,7 +481,7 @@ def gradients(params, bn_state, feed, hp):
     out = forward(leaf, bn_state, feed, hp, True, new_bn, sites)
     ls = losses(leaf, out, feed, hp)
     ls["loss"].backward()
-    grads, norms = OrderedDict(), OrderedDict()
+    grads, norms, raw = OrderedDict(), OrderedDict(), OrderedDict()
     table_names = set(TABLES.values())
     for name, p in leaf.items():
         if name.endswith("/user_embedding"):
@@ -497,9 +497,11 @@ def gradients(params, bn_state, feed, hp):
         else:
             gr = p.grad
             norms[name] = float(gr.double().norm())
+        raw[name] = gr.detach().clone()
         if hp.is_clip_norm:
             gr = gr * _clip_factor(norms[name] ** 2, float(hp.max_grad_norm))
         grads[name] = gr.detach()
+    out["raw_grads"] = raw
     return {k: v.detach() for k, v in ls.items()}, grads, norms, new_bn, out
 
 
