@@ -55,6 +55,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so.7; it must be the first HIP runtime mapped into the process
+    # (same SONAME as /opt/rocm's) so that this library and torch share ONE runtime / device context.
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise ClsrLibraryError(
             "%s not found: build the gfx950 kernels first (python -m clsr_amd.build). "
