@@ -279,22 +279,29 @@ extern "C" int clsr_att_out_bwd(const float* dout, const float* wts, const float
   return CLSR_OK;
 }
 
-// out[e] (=|+=) scale * sum_p partial[p*stride + e]   (float partials; e < n)
-__global__ void reduce_parts_f_kernel(const float* __restrict__ partial, int nparts, int stride, int n,
-                                      float scale, float* __restrict__ out, int accumulate) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
+// out[e] (=|+=) scale * sum_p partial[p*stride + e]   (float partials; e < n).  One block per output
+// element: 256 threads stride over the partials, wave + LDS reduction.
+__global__ void __launch_bounds__(256) reduce_parts_f_kernel(const float* __restrict__ partial, int nparts,
+                                                             int stride, int n, float scale,
+                                                             float* __restrict__ out, int accumulate) {
+  __shared__ float red[4];
+  const int e = blockIdx.x;
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += partial[(long)p * stride + e];
-  s *= scale;
-  out[e] = accumulate ? out[e] + s : s;
+  for (int p = threadIdx.x; p < nparts; p += 256) s += partial[(long)p * stride + e];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s = ((red[0] + red[1]) + (red[2] + red[3])) * scale;
+    out[e] = accumulate ? out[e] + s : s;
+  }
 }
 
 extern "C" int clsr_reduce_parts(const float* partial, int nparts, int stride, int n, float scale,
                                  float* out, int accumulate, void* stream) {
   CLSR_CHECK_ARG(partial && out && nparts > 0 && n > 0 && stride >= n);
-  hipLaunchKernelGGL(reduce_parts_f_kernel, dim3(clsr_cdiv(n, 128)), dim3(128), 0,
-                     (hipStream_t)stream, partial, nparts, stride, n, scale, out, accumulate);
+  hipLaunchKernelGGL(reduce_parts_f_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, partial, nparts,
+                     stride, n, scale, out, accumulate);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }

@@ -267,6 +267,7 @@ struct DwArgs {
 };
 
 __global__ void __launch_bounds__(256) pgemm_dw_kernel(DwArgs a) {
+  __shared__ float red[2 * DW_CHUNK];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i = lane & 15, g = lane >> 4;
   const int k0 = blockIdx.y * (16 * DW_T), n0 = blockIdx.z * (16 * DW_T);
@@ -275,13 +276,14 @@ __global__ void __launch_bounds__(256) pgemm_dw_kernel(DwArgs a) {
   const int nw = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
 
   float sc[DW_T], sh[DW_T];
-  bool kval[DW_T];
+  bool kval[DW_T], nval[DW_T];
 #pragma unroll
   for (int kt = 0; kt < DW_T; ++kt) {
     const int k = k0 + kt * 16 + i;
     kval[kt] = (kt < ktc) && (k < a.K);
     sc[kt] = 1.f; sh[kt] = 0.f;
     if (a.in_scale && kval[kt]) { sc[kt] = a.in_scale[k]; sh[kt] = a.in_shift[k]; }
+    nval[kt] = (kt < ntc) && (n0 + kt * 16 + i < a.N);
   }
   f32x4 acc[DW_T][DW_T];
 #pragma unroll
@@ -293,12 +295,12 @@ __global__ void __launch_bounds__(256) pgemm_dw_kernel(DwArgs a) {
   for (int nt = 0; nt < DW_T; ++nt) bsum[nt] = 0.f;
 
   const int ngroups = (a.M + 15) >> 4;
-  for (int grp = gw; grp < ngroups; grp += nw) {
-    float av[4][DW_T], bv[4][DW_T];
+  float av[4][DW_T], bv[4][DW_T];
+  auto load_group = [&](int grp) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int m = grp * 16 + 4 * s + g;
-      const bool valid = m < a.M;
+      const bool valid = (grp < ngroups) && (m < a.M);
       long xrow = m, r = m;
       if (a.T > 0) {
         r = m / a.T;
@@ -319,11 +321,18 @@ __global__ void __launch_bounds__(256) pgemm_dw_kernel(DwArgs a) {
         av[s][kt] = v;
       }
 #pragma unroll
-      for (int nt = 0; nt < DW_T; ++nt) {
-        const int n = n0 + nt * 16 + i;
-        bv[s][nt] = (valid && nt < ntc && n < a.N) ? a.dY[(long)m * a.ldy + n] : 0.f;
-      }
+      for (int nt = 0; nt < DW_T; ++nt)
+        bv[s][nt] = (valid && nval[nt]) ? a.dY[(long)m * a.ldy + n0 + nt * 16 + i] : 0.f;
     }
+  };
+  load_group(gw);
+  for (int grp = gw; grp < ngroups; grp += nw) {
+    float ac[4][DW_T], bc[4][DW_T];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int t = 0; t < DW_T; ++t) { ac[s][t] = av[s][t]; bc[s][t] = bv[s][t]; }
+    load_group(grp + nw);  // prefetch the next position group behind this group's MFMAs
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -331,56 +340,89 @@ __global__ void __launch_bounds__(256) pgemm_dw_kernel(DwArgs a) {
         if (kt < ktc) {
 #pragma unroll
           for (int nt = 0; nt < DW_T; ++nt)
-            if (nt < ntc) MFMA4(acc[kt][nt], av[s][kt], bv[s][nt]);
+            if (nt < ntc) MFMA4(acc[kt][nt], ac[s][kt], bc[s][nt]);
         }
 #pragma unroll
-      for (int nt = 0; nt < DW_T; ++nt) bsum[nt] += bv[s][nt];
+      for (int nt = 0; nt < DW_T; ++nt) bsum[nt] += bc[s][nt];
     }
   }
+#pragma unroll
+  for (int nt = 0; nt < DW_T; ++nt) bsum[nt] = col4_sum(bsum[nt]);
 
-  const long chunk = (long)blockIdx.y * gridDim.z + blockIdx.z;
-  float* out = a.partial + (chunk * nw + gw) * DW_CHUNK;
+  // block-level reduction through LDS: waves 2,3 -> 0,1 ; wave 1 -> 0 ; wave 0 writes the partial
+  auto store_to = [&](float* dst) {
 #pragma unroll
-  for (int kt = 0; kt < DW_T; ++kt)
+    for (int kt = 0; kt < DW_T; ++kt)
 #pragma unroll
-    for (int nt = 0; nt < DW_T; ++nt) {
-      float* t = out + (kt * DW_T + nt) * 256 + (4 * g) * 16 + i;
-      const f32x4 v = acc[kt][nt];
-      t[0] = v.x; t[16] = v.y; t[32] = v.z; t[48] = v.w;
+      for (int nt = 0; nt < DW_T; ++nt) {
+        float* t = dst + (kt * DW_T + nt) * 256 + (4 * g) * 16 + i;
+        const f32x4 v = acc[kt][nt];
+        t[0] = v.x; t[16] = v.y; t[32] = v.z; t[48] = v.w;
+      }
+    if (g == 0) {
+#pragma unroll
+      for (int nt = 0; nt < DW_T; ++nt) dst[DW_T * DW_T * 256 + nt * 16 + i] = bsum[nt];
     }
+  };
+  auto add_from = [&](const float* src) {
 #pragma unroll
-  for (int nt = 0; nt < DW_T; ++nt) {
-    const float s = col4_sum(bsum[nt]);
-    if (g == 0) out[DW_T * DW_T * 256 + nt * 16 + i] = s;
+    for (int kt = 0; kt < DW_T; ++kt)
+#pragma unroll
+      for (int nt = 0; nt < DW_T; ++nt) {
+        const float* t = src + (kt * DW_T + nt) * 256 + (4 * g) * 16 + i;
+        acc[kt][nt] += (f32x4){t[0], t[16], t[32], t[48]};
+      }
+#pragma unroll
+    for (int nt = 0; nt < DW_T; ++nt) bsum[nt] += src[DW_T * DW_T * 256 + nt * 16 + i];
+  };
+  if (wave >= 2) store_to(red + (wave - 2) * DW_CHUNK);
+  __syncthreads();
+  if (wave < 2) add_from(red + wave * DW_CHUNK);
+  __syncthreads();
+  if (wave == 1) store_to(red);
+  __syncthreads();
+  if (wave == 0) {
+    add_from(red);
+    const long chunk = (long)blockIdx.y * gridDim.z + blockIdx.z;
+    store_to(a.partial + (chunk * gridDim.x + blockIdx.x) * DW_CHUNK);
   }
 }
 
 // dW[k*ldw + n] (=|+=) scale * sum_p partial[...]; db[n] likewise (from K-chunk 0).
-__global__ void dw_reduce_kernel(const float* __restrict__ partial, int nw, int K, int N, int kchunks,
-                                 int nchunks, float scale, float* __restrict__ dW, int ldw,
-                                 float* __restrict__ db, int accumulate) {
+// block = 64 output elements x 4 partial sub-ranges, combined through LDS.
+__global__ void __launch_bounds__(256) dw_reduce_kernel(const float* __restrict__ partial, int nparts, int K,
+                                                        int N, int kchunks, int nchunks, float scale,
+                                                        float* __restrict__ dW, int ldw,
+                                                        float* __restrict__ db, int accumulate) {
+  __shared__ float red[4][64];
   const int total = K * N + (db ? N : 0);
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int sub = threadIdx.x >> 6;
+  float s = 0.f;
+  float* o = nullptr;
+  if (e < total) {
+    const float* p;
     if (e < K * N) {
       const int k = e / N, n = e - k * N;
       const int kc = k / (16 * DW_T), nc = n / (16 * DW_T);
       const int kk = k - kc * 16 * DW_T, nn = n - nc * 16 * DW_T;
       const long off = ((kk >> 4) * DW_T + (nn >> 4)) * 256 + (kk & 15) * 16 + (nn & 15);
-      const float* p = partial + ((long)(kc * nchunks + nc) * nw) * DW_CHUNK + off;
-      float s = 0.f;
-      for (int w = 0; w < nw; ++w) s += p[(long)w * DW_CHUNK];
-      s *= scale;
-      float* o = dW + (long)k * ldw + n;
-      *o = accumulate ? *o + s : s;
+      p = partial + ((long)(kc * nchunks + nc) * nparts) * DW_CHUNK + off;
+      o = dW + (long)k * ldw + n;
     } else {
       const int n = e - K * N;
       const int nc = n / (16 * DW_T), nn = n - nc * 16 * DW_T;
-      const float* p = partial + ((long)(0 * nchunks + nc) * nw) * DW_CHUNK + DW_T * DW_T * 256 + nn;
-      float s = 0.f;
-      for (int w = 0; w < nw; ++w) s += p[(long)w * DW_CHUNK];
-      s *= scale;
-      db[n] = accumulate ? db[n] + s : s;
+      p = partial + ((long)nc * nparts) * DW_CHUNK + DW_T * DW_T * 256 + nn;
+      o = db + n;
     }
+    for (int w = sub; w < nparts; w += 4) s += p[(long)w * DW_CHUNK];
+  }
+  red[sub][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sub == 0 && e < total) {
+    s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    s *= scale;
+    *o = accumulate ? *o + s : s;
   }
 }
 
@@ -395,7 +437,7 @@ static int dw_grid_x(int M) {
 // floats of workspace clsr_pgemm_dw needs
 extern "C" long clsr_pgemm_dw_workspace_floats(int M, int K, int N) {
   const long chunks = (long)clsr_cdiv(K, 16 * DW_T) * clsr_cdiv(N, 16 * DW_T);
-  return chunks * dw_grid_x(M) * 4 * DW_CHUNK;
+  return chunks * dw_grid_x(M) * DW_CHUNK;
 }
 
 extern "C" int clsr_pgemm_dw(const float* X, int ldx, int T, int G, const float* Xmul, int ldmul,
@@ -414,8 +456,8 @@ extern "C" int clsr_pgemm_dw(const float* X, int ldx, int T, int G, const float*
   hipLaunchKernelGGL(pgemm_dw_kernel, dim3(gx, kch, nch), dim3(256), 0, s, a);
   CLSR_CHECK_LAUNCH();
   const int total = K * N + (db ? N : 0);
-  hipLaunchKernelGGL(dw_reduce_kernel, dim3(clsr_cdiv(total, 256)), dim3(256), 0, s, workspace, gx * 4,
-                     K, N, kch, nch, scale, dW, ldw, db, accumulate);
+  hipLaunchKernelGGL(dw_reduce_kernel, dim3(clsr_cdiv(total, 64)), dim3(256), 0, s, workspace, gx, K, N, kch,
+                     nch, scale, dW, ldw, db, accumulate);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
