@@ -87,6 +87,14 @@ __device__ __forceinline__ float col4_sum(float v) {
   return v;
 }
 
+// sum over a 256-thread block (result valid in thread 0); red = 4 doubles of LDS per value
+__device__ __forceinline__ double block256_sum_d(double v, double* red) {
+  v = wave_sum_d(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 // tanh via exp; accurate to ~1e-7 relative on the range that matters, saturates cleanly
 __device__ __forceinline__ float tanhf_(float x) {

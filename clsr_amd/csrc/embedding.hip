@@ -127,9 +127,10 @@ __global__ void __launch_bounds__(256) scatter_add_rows_kernel(
     local += v * v;
     atomicAdd(tbl_grad + (long)idx[(long)n * idx_stride] * C + c, v);
   }
-  if (sumsq) {
-    local = wave_sum(local);
-    if ((threadIdx.x & 63) == 0) atomicAdd(sumsq, (double)local);
+  if (sumsq) {  // one atomic per block (uniform branch: sumsq is a kernel argument)
+    __shared__ double red[4];
+    const double tot = block256_sum_d((double)local, red);
+    if (threadIdx.x == 0) atomicAdd(sumsq, tot);
   }
 }
 
@@ -138,8 +139,8 @@ extern "C" int clsr_scatter_add_rows(const float* src, int ld_src, int col0, con
                                      void* stream) {
   CLSR_CHECK_ARG(src && idx && tbl_grad && N >= 0 && C > 0);
   if (N == 0) return CLSR_OK;
-  int blocks = clsr_cdiv((long)N * C, 256);
-  if (blocks > 4096) blocks = 4096;
+  int blocks = clsr_cdiv((long)N * C, 256 * 4);
+  if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src,
                      ld_src, col0, idx, idx_stride, N, C, tbl_grad, sumsq);
   CLSR_CHECK_LAUNCH();
@@ -181,11 +182,12 @@ __global__ void __launch_bounds__(256) gather_hist_bwd_kernel(
     }
   }
   if (sumsq) {
-    s_item = wave_sum(s_item);
-    s_cate = wave_sum(s_cate);
-    if ((threadIdx.x & 63) == 0) {
-      atomicAdd(sumsq + 0, (double)s_item);
-      atomicAdd(sumsq + 1, (double)s_cate);
+    __shared__ double red[2][4];
+    const double ti = block256_sum_d((double)s_item, red[0]);
+    const double tc = block256_sum_d((double)s_cate, red[1]);
+    if (threadIdx.x == 0) {
+      atomicAdd(sumsq + 0, ti);
+      atomicAdd(sumsq + 1, tc);
     }
   }
 }
@@ -198,8 +200,8 @@ extern "C" int clsr_gather_hist_bwd(const float* dhist, const float* dmean, cons
   CLSR_CHECK_ARG(dhist && item_idx && cate_idx && seq_len && item_grad && cate_grad);
   CLSR_CHECK_ARG(Hn >= 0 && T > 0 && Di > 0 && Dc > 0);
   if (Hn == 0) return CLSR_OK;
-  int blocks = clsr_cdiv((long)Hn * T * (Di + Dc), 256);
-  if (blocks > 8192) blocks = 8192;
+  int blocks = clsr_cdiv((long)Hn * T * (Di + Dc), 256 * 4);
+  if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(gather_hist_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dhist,
                      dmean, drecent, item_idx, cate_idx, idx_row_stride, seq_len, len_stride, Hn, T,
                      Di, Dc, recent_k, item_grad, cate_grad, sumsq);

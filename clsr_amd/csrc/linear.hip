@@ -203,6 +203,8 @@ extern "C" int clsr_pgemm(const float* X, int ldx, int T, int G, const float* Xm
   CLSR_CHECK_ARG(Kp >= 16 * clsr_cdiv(K, 16));
   CLSR_CHECK_ARG(!(Xmul && ldmul % 4) && !(addU && ldu % 4) && !(addV && ldv % 4));
   CLSR_CHECK_ARG(!(in_scale && !in_shift));
+  CLSR_CHECK_SUPPORTED(!(Xmul && in_scale));
+  CLSR_CHECK_SUPPORTED(((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0 && ldx >= K && (!Xmul || ldmul >= K));
   if (M == 0) return CLSR_OK;
   PGemmArgs a;
   a.X = X; a.ldx = ldx; a.T = T; a.G = G; a.Xmul = Xmul; a.ldmul = ldmul;
@@ -266,25 +268,24 @@ struct DwArgs {
   int M, K, N;
 };
 
+// Block = 4 waves, 64 positions per iteration.  The X tile (prologue applied) and the dY tile are
+// staged through LDS with coalesced 16-byte global loads (register prefetch of the next tile runs
+// behind the MFMAs of the current one); each wave then reduces its own 16 positions:
+//   A operand (lane (i,g)) = Xs[16w + 4s + g][16kt + i],  B operand = Ys[16w + 4s + g][16nt + i].
+// Row stride 80 floats == 16 (mod 32) banks => the two row groups of a half-wave hit disjoint banks.
+#define DW_W (16 * DW_T)
+template <int MODE>  // 0 plain, 1 X*Xmul[r], 2 relu(X*in_scale + in_shift)
 __global__ void __launch_bounds__(256) pgemm_dw_kernel(DwArgs a) {
-  __shared__ float red[2 * DW_CHUNK];
+  __shared__ __attribute__((aligned(16))) float lds[64 * 2 * DW_W > 2 * DW_CHUNK ? 64 * 2 * DW_W : 2 * DW_CHUNK];
+  float* Xs = lds;
+  float* Ys = lds + 64 * DW_W;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i = lane & 15, g = lane >> 4;
-  const int k0 = blockIdx.y * (16 * DW_T), n0 = blockIdx.z * (16 * DW_T);
+  const int k0 = blockIdx.y * DW_W, n0 = blockIdx.z * DW_W;
   const int ktc = min(DW_T, ((a.K + 15) >> 4) - blockIdx.y * DW_T);
   const int ntc = min(DW_T, ((a.N + 15) >> 4) - blockIdx.z * DW_T);
-  const int nw = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
+  const int kmax4 = ((a.K + 3) & ~3) - 4, nmax4 = a.N - 4;
 
-  float sc[DW_T], sh[DW_T];
-  bool kval[DW_T], nval[DW_T];
-#pragma unroll
-  for (int kt = 0; kt < DW_T; ++kt) {
-    const int k = k0 + kt * 16 + i;
-    kval[kt] = (kt < ktc) && (k < a.K);
-    sc[kt] = 1.f; sh[kt] = 0.f;
-    if (a.in_scale && kval[kt]) { sc[kt] = a.in_scale[k]; sh[kt] = a.in_shift[k]; }
-    nval[kt] = (kt < ntc) && (n0 + kt * 16 + i < a.N);
-  }
   f32x4 acc[DW_T][DW_T];
 #pragma unroll
   for (int kt = 0; kt < DW_T; ++kt)
@@ -294,60 +295,99 @@ __global__ void __launch_bounds__(256) pgemm_dw_kernel(DwArgs a) {
 #pragma unroll
   for (int nt = 0; nt < DW_T; ++nt) bsum[nt] = 0.f;
 
-  const int ngroups = (a.M + 15) >> 4;
-  float av[4][DW_T], bv[4][DW_T];
-  auto load_group = [&](int grp) {
+  // staging assignment: 5 float4 of the X tile and 5 of the dY tile per thread (64 rows x 20 float4 each).
+  // Loads are unconditional (clamped addresses) and issued back to back; masks / prologue are applied
+  // when the registers are written to LDS, after the MFMAs of the previous tile.
+  constexpr int Q = DW_W / 4;       // float4 per tile row
+  constexpr int NLD = 64 * Q / 256; // loads per thread per tile
+  f32x4 xr[NLD], yr[NLD], mr[MODE == 1 ? NLD : 1];
+  unsigned vmask = 0;               // bit j: X piece valid, bit 8+j: dY piece valid
+  f32x4 scv[MODE == 2 ? NLD : 1], shv[MODE == 2 ? NLD : 1];
+  if (MODE == 2) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int m = grp * 16 + 4 * s + g;
-      const bool valid = (grp < ngroups) && (m < a.M);
+    for (int j = 0; j < NLD; ++j) {
+      const int idx = tid + 256 * j;
+      const int c4 = idx - (idx / Q) * Q;
+      int kcol = k0 + 4 * c4;
+      kcol = kcol <= kmax4 ? kcol : kmax4;
+      // K % 4 != 0 never happens together with an affine prologue (BN widths are multiples of 4)
+      scv[j] = ld4(a.in_scale + kcol);
+      shv[j] = ld4(a.in_shift + kcol);
+    }
+  }
+  const int ntiles = (a.M + 63) >> 6;
+  auto fetch = [&](int tile) {
+    vmask = 0;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int idx = tid + 256 * j;
+      const int row = idx / Q, c4 = idx - row * Q;
+      int m = tile * 64 + row;
+      const bool mv = (tile < ntiles) && (m < a.M);
+      m = m < a.M ? m : a.M - 1;
+      int kcol = k0 + 4 * c4, ncol = n0 + 4 * c4;
+      if (mv && kcol <= kmax4) vmask |= 1u << j;
+      if (mv && ncol <= nmax4) vmask |= 1u << (8 + j);
+      kcol = kcol <= kmax4 ? kcol : kmax4;
+      ncol = ncol <= nmax4 ? ncol : nmax4;
       long xrow = m, r = m;
       if (a.T > 0) {
-        r = m / a.T;
-        if (a.G > 0) xrow = (r / a.G) * a.T + (m - r * a.T);
+        const unsigned rr = (unsigned)m / (unsigned)a.T;
+        r = rr;
+        if (a.G > 0) xrow = (long)(rr / (unsigned)a.G) * a.T + (m - (int)rr * a.T);
       }
-#pragma unroll
-      for (int kt = 0; kt < DW_T; ++kt) {
-        float v = 0.f;
-        if (valid && kval[kt]) {
-          const int k = k0 + kt * 16 + i;
-          v = a.X[xrow * a.ldx + k];
-          if (a.Xmul) v *= a.Xmul[r * a.ldmul + k];
-          if (a.in_scale) {
-            v = v * sc[kt] + sh[kt];
-            if (a.in_relu) v = fmaxf(v, 0.f);
-          }
-        }
-        av[s][kt] = v;
-      }
-#pragma unroll
-      for (int nt = 0; nt < DW_T; ++nt)
-        bv[s][nt] = (valid && nval[nt]) ? a.dY[(long)m * a.ldy + n0 + nt * 16 + i] : 0.f;
+      xr[j] = ld4(a.X + xrow * a.ldx + kcol);
+      if (MODE == 1) mr[j] = ld4(a.Xmul + r * a.ldmul + kcol);
+      yr[j] = ld4(a.dY + (long)m * a.ldy + ncol);
     }
   };
-  load_group(gw);
-  for (int grp = gw; grp < ngroups; grp += nw) {
-    float ac[4][DW_T], bc[4][DW_T];
+  auto stage = [&]() {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int t = 0; t < DW_T; ++t) { ac[s][t] = av[s][t]; bc[s][t] = bv[s][t]; }
-    load_group(grp + nw);  // prefetch the next position group behind this group's MFMAs
+    for (int j = 0; j < NLD; ++j) {
+      const int idx = tid + 256 * j;
+      f32x4 xv = xr[j];
+      if (MODE == 1) xv *= mr[j];
+      if (MODE == 2) {
+        xv = xv * scv[j] + shv[j];
+        if (a.in_relu) { xv.x = fmaxf(xv.x, 0.f); xv.y = fmaxf(xv.y, 0.f); xv.z = fmaxf(xv.z, 0.f); xv.w = fmaxf(xv.w, 0.f); }
+      }
+      st4(Xs + 4 * idx, (vmask >> j) & 1u ? xv : z);
+      st4(Ys + 4 * idx, (vmask >> (8 + j)) & 1u ? yr[j] : z);
+    }
+  };
+
+  fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();  // previous tile fully consumed
+    stage();
+    __syncthreads();
+    fetch(tile + gridDim.x);  // global loads of the next tile fly behind the MFMAs below
+    const float* xw = Xs + (16 * wave + g) * DW_W + i;
+    const float* yw = Ys + (16 * wave + g) * DW_W + i;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
+      float av[DW_T], bv[DW_T];
+#pragma unroll
+      for (int t = 0; t < DW_T; ++t) {
+        av[t] = xw[(4 * s) * DW_W + 16 * t];
+        bv[t] = yw[(4 * s) * DW_W + 16 * t];
+      }
 #pragma unroll
       for (int kt = 0; kt < DW_T; ++kt)
         if (kt < ktc) {
 #pragma unroll
           for (int nt = 0; nt < DW_T; ++nt)
-            if (nt < ntc) MFMA4(acc[kt][nt], ac[s][kt], bc[s][nt]);
+            if (nt < ntc) MFMA4(acc[kt][nt], av[kt], bv[nt]);
         }
 #pragma unroll
-      for (int nt = 0; nt < DW_T; ++nt) bsum[nt] += bc[s][nt];
+      for (int nt = 0; nt < DW_T; ++nt) bsum[nt] += bv[nt];
     }
   }
 #pragma unroll
   for (int nt = 0; nt < DW_T; ++nt) bsum[nt] = col4_sum(bsum[nt]);
+  __syncthreads();  // staging buffers are dead from here on; reuse the LDS for the block reduction
+  float* red = lds;
 
   // block-level reduction through LDS: waves 2,3 -> 0,1 ; wave 1 -> 0 ; wave 0 writes the partial
   auto store_to = [&](float* dst) {
@@ -390,11 +430,11 @@ __global__ void __launch_bounds__(256) pgemm_dw_kernel(DwArgs a) {
 
 // dW[k*ldw + n] (=|+=) scale * sum_p partial[...]; db[n] likewise (from K-chunk 0).
 // block = 64 output elements x 4 partial sub-ranges, combined through LDS.
-__global__ void __launch_bounds__(256) dw_reduce_kernel(const float* __restrict__ partial, int nparts, int K,
+__global__ void __launch_bounds__(1024) dw_reduce_kernel(const float* __restrict__ partial, int nparts, int K,
                                                         int N, int kchunks, int nchunks, float scale,
                                                         float* __restrict__ dW, int ldw,
                                                         float* __restrict__ db, int accumulate) {
-  __shared__ float red[4][64];
+  __shared__ float red[16][64];
   const int total = K * N + (db ? N : 0);
   const int e = blockIdx.x * 64 + (threadIdx.x & 63);
   const int sub = threadIdx.x >> 6;
@@ -415,21 +455,23 @@ __global__ void __launch_bounds__(256) dw_reduce_kernel(const float* __restrict_
       p = partial + ((long)nc * nparts) * DW_CHUNK + DW_T * DW_T * 256 + nn;
       o = db + n;
     }
-    for (int w = sub; w < nparts; w += 4) s += p[(long)w * DW_CHUNK];
+    for (int w = sub; w < nparts; w += 16) s += p[(long)w * DW_CHUNK];
   }
   red[sub][threadIdx.x & 63] = s;
   __syncthreads();
   if (sub == 0 && e < total) {
-    s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += red[u][threadIdx.x];
     s *= scale;
     *o = accumulate ? *o + s : s;
   }
 }
 
 static int dw_grid_x(int M) {
-  int groups = clsr_cdiv(M, 16);
-  int gx = clsr_cdiv(groups, 4 * 8);  // >= 8 position groups per wave before adding waves
-  if (gx > 256) gx = 256;
+  int tiles = clsr_cdiv(M, 64);
+  int gx = clsr_cdiv(tiles, 4);  // >= 4 position tiles per block before adding blocks
+  if (gx > 512) gx = 512;
   if (gx < 1) gx = 1;
   return gx;
 }
@@ -446,6 +488,10 @@ extern "C" int clsr_pgemm_dw(const float* X, int ldx, int T, int G, const float*
                              int ldw, float* db, int accumulate, float* workspace, void* stream) {
   CLSR_CHECK_ARG(X && dY && dW && workspace && M >= 0 && K > 0 && N > 0 && ldw >= N);
   CLSR_CHECK_ARG(!(in_scale && !in_shift));
+  // 16-byte staging loads: rows must be float4 addressable up to roundup(K,4) / N
+  CLSR_CHECK_SUPPORTED(N % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= ((K + 3) & ~3) &&
+                       (!Xmul || (ldmul % 4 == 0 && ldmul >= ((K + 3) & ~3))) &&
+                       ((uintptr_t)X % 16) == 0 && ((uintptr_t)dY % 16) == 0);
   DwArgs a;
   a.X = X; a.ldx = ldx; a.T = T; a.G = G; a.Xmul = Xmul; a.ldmul = ldmul;
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
@@ -453,10 +499,13 @@ extern "C" int clsr_pgemm_dw(const float* X, int ldx, int T, int G, const float*
   const int kch = clsr_cdiv(K, 16 * DW_T), nch = clsr_cdiv(N, 16 * DW_T);
   const int gx = dw_grid_x(M);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(pgemm_dw_kernel, dim3(gx, kch, nch), dim3(256), 0, s, a);
+  CLSR_CHECK_SUPPORTED(!(Xmul && in_scale) && !(in_scale && K % 4));
+  if (Xmul) hipLaunchKernelGGL(pgemm_dw_kernel<1>, dim3(gx, kch, nch), dim3(256), 0, s, a);
+  else if (in_scale) hipLaunchKernelGGL(pgemm_dw_kernel<2>, dim3(gx, kch, nch), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(pgemm_dw_kernel<0>, dim3(gx, kch, nch), dim3(256), 0, s, a);
   CLSR_CHECK_LAUNCH();
   const int total = K * N + (db ? N : 0);
-  hipLaunchKernelGGL(dw_reduce_kernel, dim3(clsr_cdiv(total, 64)), dim3(256), 0, s, workspace, gx, K, N, kch,
+  hipLaunchKernelGGL(dw_reduce_kernel, dim3(clsr_cdiv(total, 64)), dim3(1024), 0, s, workspace, gx, K, N, kch,
                      nch, scale, dW, ldw, db, accumulate);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;

@@ -111,14 +111,15 @@ __global__ void count_flags_kernel(const unsigned char* __restrict__ flags, long
   float local = 0.f;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < V; e += (long)gridDim.x * blockDim.x)
     local += flags[e] ? 1.f : 0.f;
-  local = wave_sum(local);
-  if ((threadIdx.x & 63) == 0 && local != 0.f) atomicAdd(count, local);
+  __shared__ double red[4];
+  const double tot = block256_sum_d((double)local, red);
+  if (threadIdx.x == 0 && tot != 0.0) atomicAdd(count, (float)tot);
 }
 
 extern "C" int clsr_count_flags(const unsigned char* flags, long V, float* count, void* stream) {
   CLSR_CHECK_ARG(flags && count && V > 0);
-  int blocks = clsr_cdiv(V, 256);
-  if (blocks > 1024) blocks = 1024;
+  int blocks = clsr_cdiv(V, 256 * 16);
+  if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(count_flags_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, flags, V, count);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
@@ -152,8 +153,9 @@ __global__ void __launch_bounds__(256) table_reg_kernel(
     ss += (double)g * g;
     rl += (double)p * p;
   }
-  ss = wave_sum_d(ss); rl = wave_sum_d(rl); dl = wave_sum_d(dl);
-  if ((threadIdx.x & 63) == 0) {
+  __shared__ double red[3][4];
+  ss = block256_sum_d(ss, red[0]); rl = block256_sum_d(rl, red[1]); dl = block256_sum_d(dl, red[2]);
+  if (threadIdx.x == 0) {
     if (ss != 0.0) atomicAdd(sumsq, ss);
     if (reg_loss && rl != 0.0) atomicAdd(reg_loss, 0.5 * (double)l2 * rl);
     if (disc_loss && dl != 0.0) atomicAdd(disc_loss, (double)cl * dl);
@@ -166,8 +168,8 @@ extern "C" int clsr_table_reg(const float* table, const float* partner, const un
                               double* disc_loss, void* stream) {
   CLSR_CHECK_ARG(table && flags && grad_table && sumsq && V > 0 && C > 0);
   CLSR_CHECK_ARG(!partner || count);
-  int blocks = clsr_cdiv(V * C, 256);
-  if (blocks > 4096) blocks = 4096;
+  int blocks = clsr_cdiv(V * C, 256 * 8);
+  if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(table_reg_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, partner,
                      flags, V, C, l2, disc_scale, disc_loss_scale, count, grad_table, sumsq, reg_loss,
                      disc_loss);

@@ -15,6 +15,7 @@
 // history j) is exactly the B-operand layout of step t+1, so the state never leaves registers.
 // Hidden size n <= 48 (RNT = 3 feature tiles), n % 4 == 0.
 #include "common.h"
+#include "clsr_hip.h"
 
 #define RNT 3
 
@@ -89,10 +90,10 @@ struct GruArgs {
   float* dh0;                          // optional [Hn, n]
 };
 
-__global__ void __launch_bounds__(64) gru_fwd_kernel(GruArgs a) {
+__device__ __forceinline__ void gru_fwd_body(const GruArgs& a, const int bx) {
   const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
   const int n = a.n, T = a.T;
-  const long h = (long)blockIdx.x * 16 + j;
+  const long h = (long)bx * 16 + j;
   const bool hvalid = h < a.Hn;
   f32x4 wr[RNT][RNT], wu[RNT][RNT], wc[RNT][RNT];
 #pragma unroll
@@ -165,10 +166,10 @@ __global__ void __launch_bounds__(64) gru_fwd_kernel(GruArgs a) {
     }
 }
 
-__global__ void __launch_bounds__(64) gru_bwd_kernel(GruArgs a) {
+__device__ __forceinline__ void gru_bwd_body(const GruArgs& a, const int bx) {
   const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
   const int n = a.n, T = a.T;
-  const long h = (long)blockIdx.x * 16 + j;
+  const long h = (long)bx * 16 + j;
   const bool hvalid = h < a.Hn;
   // transposed operands: d(state in) = sum_o W[in][o] * dgate[o]
   f32x4 wr[RNT][RNT], wu[RNT][RNT], wc[RNT][RNT];
@@ -244,6 +245,9 @@ __global__ void __launch_bounds__(64) gru_bwd_kernel(GruArgs a) {
   }
 }
 
+__global__ void __launch_bounds__(64) gru_fwd_kernel(GruArgs a) { gru_fwd_body(a, blockIdx.x); }
+__global__ void __launch_bounds__(64) gru_bwd_kernel(GruArgs a) { gru_bwd_body(a, blockIdx.x); }
+
 static int check_rnn_shape(int Hn, int T, int n, int ld) {
   CLSR_CHECK_ARG(Hn > 0 && T > 0);
   CLSR_CHECK_SUPPORTED(n % 4 == 0 && n >= 4 && n <= 16 * RNT && ld % 4 == 0);
@@ -300,10 +304,10 @@ struct T4Args {
   float* dPin;                         // [Hn, T, 6n]
 };
 
-__global__ void __launch_bounds__(64) t4lstm_fwd_kernel(T4Args a) {
+__device__ __forceinline__ void t4lstm_fwd_body(const T4Args& a, const int bx) {
   const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
   const int n = a.n, T = a.T;
-  const long h = (long)blockIdx.x * 16 + j;
+  const long h = (long)bx * 16 + j;
   const bool hvalid = h < a.Hn;
   f32x4 w[4][RNT][RNT];
 #pragma unroll
@@ -371,10 +375,10 @@ __global__ void __launch_bounds__(64) t4lstm_fwd_kernel(T4Args a) {
       for (int t = len; t < T; ++t) st4(a.out_seq + (h * T + t) * n + 16 * tl + 4 * g, Z4);
 }
 
-__global__ void __launch_bounds__(64) t4lstm_bwd_kernel(T4Args a) {
+__device__ __forceinline__ void t4lstm_bwd_body(const T4Args& a, const int bx) {
   const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
   const int n = a.n, T = a.T;
-  const long h = (long)blockIdx.x * 16 + j;
+  const long h = (long)bx * 16 + j;
   const bool hvalid = h < a.Hn;
   f32x4 w[4][RNT][RNT];
 #pragma unroll
@@ -437,6 +441,33 @@ __global__ void __launch_bounds__(64) t4lstm_bwd_kernel(T4Args a) {
       dm[tl] = sel4(live, dmn[tl], dm[tl]);
     }
   }
+}
+
+__global__ void __launch_bounds__(64) t4lstm_fwd_kernel(T4Args a) { t4lstm_fwd_body(a, blockIdx.x); }
+__global__ void __launch_bounds__(64) t4lstm_bwd_kernel(T4Args a) { t4lstm_bwd_body(a, blockIdx.x); }
+
+// ------------------------------------------------------------------ fused multi-encoder launches
+// The CLSR step runs up to three independent recurrences over the same histories (GRU
+// short_term_intention, Time4LSTM / GRU short-term encoder, GRU causal2).  Each one only fills a
+// quarter of the chip (Hn/16 single-wave workgroups), so they are dispatched as ONE grid:
+// blockIdx.y selects the encoder, blockIdx.x the 16-history tile.
+#define RNN_MAX_GRU 3
+struct RnnMultiArgs {
+  GruArgs gru[RNN_MAX_GRU];
+  T4Args t4;
+  int ngru;
+  int has_t4;
+};
+
+__global__ void __launch_bounds__(64) rnn_multi_fwd_kernel(RnnMultiArgs a) {
+  const int which = blockIdx.y;
+  if (which < a.ngru) gru_fwd_body(a.gru[which], blockIdx.x);
+  else t4lstm_fwd_body(a.t4, blockIdx.x);
+}
+__global__ void __launch_bounds__(64) rnn_multi_bwd_kernel(RnnMultiArgs a) {
+  const int which = blockIdx.y;
+  if (which < a.ngru) gru_bwd_body(a.gru[which], blockIdx.x);
+  else t4lstm_bwd_body(a.t4, blockIdx.x);
 }
 
 extern "C" int clsr_t4lstm_fwd(const float* Pin, int ldp, const float* Wm, int ldm, const int* seq_len,
@@ -554,6 +585,64 @@ extern "C" int clsr_t4_time_inputs_bwd(const float* dTT, const float* TT, const 
   CLSR_CHECK_SUPPORTED(n > 0 && 2 * n <= 256);
   hipLaunchKernelGGL(t4_time_inputs_bwd_kernel, dim3(t4_tbwd_blocks(Hn * T, n)), dim3(256), 0,
                      (hipStream_t)stream, dTT, TT, tnow, tfirst, row_stride, Hn, T, n, partial);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// ---- C-ABI descriptors: clsr_gru_desc / clsr_t4_desc from include/clsr_hip.h
+extern "C" int clsr_sizeof_gru_desc(void) { return (int)sizeof(clsr_gru_desc); }
+extern "C" int clsr_sizeof_t4_desc(void) { return (int)sizeof(clsr_t4_desc); }
+
+static int fill_multi(RnnMultiArgs& m, const clsr_gru_desc* grus, int ngru, const clsr_t4_desc* t4,
+                      const int* seq_len, int len_stride, int Hn, int T, bool backward) {
+  CLSR_CHECK_ARG(seq_len && Hn > 0 && T > 0 && ngru >= 0 && ngru <= RNN_MAX_GRU && (ngru > 0 || t4));
+  CLSR_CHECK_ARG(ngru == 0 || grus);
+  m.ngru = ngru;
+  m.has_t4 = t4 ? 1 : 0;
+  for (int i = 0; i < ngru; ++i) {
+    const clsr_gru_desc& d = grus[i];
+    int rc = check_rnn_shape(Hn, T, d.n, backward ? d.ldg : d.ldp);
+    if (rc) return rc;
+    CLSR_CHECK_ARG(d.Wgh && d.Wch && (backward ? (d.gates && d.hprev && d.dPin) : (d.Pin != nullptr)));
+    GruArgs& a = m.gru[i];
+    a = GruArgs{};
+    a.Pin = d.Pin; a.ldp = d.ldp; a.Wgh = d.Wgh; a.ldg = d.ldg; a.Wch = d.Wch; a.ldc = d.ldc;
+    a.h0 = d.h0; a.h0_stride = d.h0_stride; a.seq_len = seq_len; a.len_stride = len_stride;
+    a.Hn = Hn; a.T = T; a.n = d.n; a.hT = d.hT; a.out_seq = d.out_seq; a.hprev = d.hprev; a.gates = d.gates;
+    a.dhT = d.dhT; a.dout_seq = d.dout_seq; a.dPin = d.dPin; a.dh0 = d.dh0;
+  }
+  if (t4) {
+    int rc = check_rnn_shape(Hn, T, t4->n, backward ? t4->ldm : t4->ldp);
+    if (rc) return rc;
+    CLSR_CHECK_ARG(t4->Wm && (backward ? (t4->act && t4->cst && t4->dout_seq && t4->dPin)
+                                       : (t4->Pin && t4->out_seq && (!t4->act || (t4->cst && t4->mprev)))));
+    T4Args& a = m.t4;
+    a = T4Args{};
+    a.Pin = t4->Pin; a.ldp = t4->ldp; a.Wm = t4->Wm; a.ldm = t4->ldm; a.seq_len = seq_len;
+    a.len_stride = len_stride; a.Hn = Hn; a.T = T; a.n = t4->n; a.out_seq = t4->out_seq; a.act = t4->act;
+    a.cst = t4->cst; a.mprev = t4->mprev; a.dout_seq = t4->dout_seq; a.dPin = t4->dPin;
+  }
+  return CLSR_OK;
+}
+
+extern "C" int clsr_rnn_fwd_multi(const clsr_gru_desc* grus, int ngru, const clsr_t4_desc* t4,
+                                  const int* seq_len, int len_stride, int Hn, int T, void* stream) {
+  RnnMultiArgs m;
+  int rc = fill_multi(m, grus, ngru, t4, seq_len, len_stride, Hn, T, false);
+  if (rc) return rc;
+  hipLaunchKernelGGL(rnn_multi_fwd_kernel, dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), dim3(64), 0,
+                     (hipStream_t)stream, m);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+extern "C" int clsr_rnn_bwd_multi(const clsr_gru_desc* grus, int ngru, const clsr_t4_desc* t4,
+                                  const int* seq_len, int len_stride, int Hn, int T, void* stream) {
+  RnnMultiArgs m;
+  int rc = fill_multi(m, grus, ngru, t4, seq_len, len_stride, Hn, T, true);
+  if (rc) return rc;
+  hipLaunchKernelGGL(rnn_multi_bwd_kernel, dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), dim3(64), 0,
+                     (hipStream_t)stream, m);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }

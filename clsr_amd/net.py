@@ -444,28 +444,39 @@ class CLSRNet(object):
         self._gemm(dz0, C0, key + ".W0^T", B, C0, K0, dX, K0)
         return dX
 
-    # ------------------------------------------------------------------ GRU helpers
-    def _gru_fwd(self, key, scope, n, hist, Hn, T, seq_len, ls, h0, training, want_seq=False):
+    # ------------------------------------------------------------------ recurrent encoders
+    def _gru_pin(self, key, scope, n, hist, Hn, T):
+        """Input-side projections of one GRU for every (history, step): Pin = x.[Wg_x | Wc_x] + bias."""
         P, D = self.P, self.D
         Pin = self._buf(key + ".Pin", Hn * T, 3 * n)
         self._gemm(hist, D, key + ".gx", Hn * T, D, 2 * n, Pin, 3 * n, bias=P[scope + "gates/bias"])
         self._gemm(hist, D, key + ".cx", Hn * T, D, n, Pin[:, 2 * n:], 3 * n, bias=P[scope + "candidate/bias"])
+        return Pin
+
+    def _gru_fwd_desc(self, key, scope, n, Pin, Hn, T, h0, training, want_seq=False):
+        P, D = self.P, self.D
         hT = self._buf(key + ".hT", Hn, n)
         seq = self._buf(key + ".seq", Hn, T, n) if want_seq else None
         hprev = self._buf(key + ".hprev", Hn, T, n) if training else None
         gates = self._buf(key + ".gates", Hn, T, 3 * n) if training else None
         Wg, Wc = P[scope + "gates/kernel"], P[scope + "candidate/kernel"]
-        call("clsr_gru_fwd", Pin, 3 * n, Wg[D:], 2 * n, Wc[D:], n, h0, n if h0 is not None else 0, seq_len, ls,
-             Hn, T, n, hT, seq, hprev, gates)
-        return hT, seq
+        d = ops.gru_desc(n, Pin=Pin, ldp=3 * n, Wgh=Wg[D:], ldg=2 * n, Wch=Wc[D:], ldc=n, h0=h0,
+                         h0_stride=n if h0 is not None else 0, hT=hT, out_seq=seq, hprev=hprev, gates=gates)
+        return d, hT, seq
 
-    def _gru_bwd(self, key, scope, n, hist, dhist, Hn, T, seq_len, ls, dhT, dseq, dh0):
-        P, Gd, D = self.P, self.Gd, self.D
+    def _gru_bwd_desc(self, key, scope, n, Hn, T, dhT, dseq, dh0):
+        P, D = self.P, self.D
+        Wg, Wc = P[scope + "gates/kernel"], P[scope + "candidate/kernel"]
+        return ops.gru_desc(n, Wgh=Wg[D:], ldg=2 * n, Wch=Wc[D:], ldc=n,
+                            hprev=self._buf(key + ".hprev", Hn, T, n), gates=self._buf(key + ".gates", Hn, T, 3 * n),
+                            dhT=dhT, dout_seq=dseq, dPin=self._buf(key + ".dPin", Hn * T, 3 * n), dh0=dh0)
+
+    def _gru_bwd_post(self, key, scope, n, hist, dhist, Hn, T):
+        """Weight gradients and d(hist) from the dPin written by the recurrence backward."""
+        Gd, D = self.Gd, self.D
         hprev, gates = self._buf(key + ".hprev", Hn, T, n), self._buf(key + ".gates", Hn, T, 3 * n)
         dPin = self._buf(key + ".dPin", Hn * T, 3 * n)
-        Wg, Wc = P[scope + "gates/kernel"], P[scope + "candidate/kernel"]
         dWg, dWc = Gd[scope + "gates/kernel"], Gd[scope + "candidate/kernel"]
-        call("clsr_gru_bwd", gates, hprev, Wg[D:], 2 * n, Wc[D:], n, seq_len, ls, Hn, T, n, dhT, dseq, dPin, dh0)
         M = Hn * T
         self._dw(hist, D, dPin, 3 * n, M, D, 2 * n, dWg[0:D], 2 * n, db=Gd[scope + "gates/bias"])
         self._dw(hist, D, dPin[:, 2 * n:], 3 * n, M, D, n, dWc[0:D], n, db=Gd[scope + "candidate/bias"])
@@ -501,21 +512,23 @@ class CLSRNet(object):
         # ---- long term
         lt = CL + "long_term/attention_fcn/"
         att_long = self._att_fwd("lt", lt, hist, ulong, Hn, 1, T, D, Du, seq_len, ls, training)
-        # ---- short term encoders
+        # ---- sequence encoders: input projections first, then ONE fused launch for all recurrences
         st = CL + "short_term/"
+        M = Hn * T
+        grus, t4d = [], None
+        short_int, rnn_out, fs = ushort, None, None
         if hp.interest_evolve:
-            short_int, _ = self._gru_fwd("g1", st + "short_term_intention/gru_cell/", Du, hist, Hn, T, seq_len, ls,
-                                         ushort, training)
-        else:
-            short_int = ushort
+            sc_ = st + "short_term_intention/gru_cell/"
+            d, short_int, _ = self._gru_fwd_desc("g1", sc_, Du, self._gru_pin("g1", sc_, Du, hist, Hn, T), Hn, T,
+                                                 ushort, training)
+            grus.append(d)
         if hp.sequential_model == "time4lstm":
             t = st + "time4lstm/"
-            TT = self._buf("t4.TT", Hn * T, 2 * H)
+            TT = self._buf("t4.TT", M, 2 * H)
             call("clsr_t4_time_inputs_fwd", f["time_to_now"], f["time_from_first_action"], G * T,
                  P[t + "_time_input_w1"], P[t + "_time_input_bias1"], P[t + "_time_input_w2"],
                  P[t + "_time_input_bias2"], Hn, T, H, TT)
-            Pin = self._buf("t4.Pin", Hn * T, 6 * H)
-            M = Hn * T
+            Pin = self._buf("t4.Pin", M, 6 * H)
             self._gemm(hist, D, "t4.kx", M, D, 4 * H, Pin, 6 * H, bias=P[t + "bias"])
             self._gemm(hist, D, "t4.w1", M, D, H, Pin[:, 4 * H:], 6 * H, bias=P[t + "_time_bias1"])
             self._gemm(hist, D, "t4.w2", M, D, H, Pin[:, 5 * H:], 6 * H, bias=P[t + "_time_bias2"])
@@ -524,14 +537,21 @@ class CLSRNet(object):
             self._gemm(TT, 2 * H, "t4._time_kernel_t1", M, H, H, Pin[:, 4 * H:], 6 * H, acc=1)
             self._gemm(TT[:, H:], 2 * H, "t4._time_kernel_t2", M, H, H, Pin[:, 5 * H:], 6 * H, acc=1)
             rnn_out = self._buf("rnn_out", Hn, T, H)
-            act = self._buf("t4.act", Hn, T, 6 * H) if training else None
-            cst = self._buf("t4.cst", Hn, T, H) if training else None
-            mprev = self._buf("t4.mprev", Hn, T, H) if training else None
-            call("clsr_t4lstm_fwd", Pin, 6 * H, P[t + "kernel"][D:], 4 * H, seq_len, ls, Hn, T, H, rnn_out, act,
-                 cst, mprev)
+            t4d = ops.t4_desc(H, Pin=Pin, ldp=6 * H, Wm=P[t + "kernel"][D:], ldm=4 * H, out_seq=rnn_out,
+                              act=self._buf("t4.act", Hn, T, 6 * H) if training else None,
+                              cst=self._buf("t4.cst", Hn, T, H) if training else None,
+                              mprev=self._buf("t4.mprev", Hn, T, H) if training else None)
         else:
-            _, rnn_out = self._gru_fwd("gs", st + "simple_gru/gru_cell/", H, hist, Hn, T, seq_len, ls, None,
-                                       training, want_seq=True)
+            sc_ = st + "simple_gru/gru_cell/"
+            d, _, rnn_out = self._gru_fwd_desc("gs", sc_, H, self._gru_pin("gs", sc_, H, hist, Hn, T), Hn, T, None,
+                                               training, want_seq=True)
+            grus.append(d)
+        if (not hp.manual_alpha) and hp.predict_long_short:
+            sc_ = CL + "causal2/causal2/gru_cell/"
+            d, fs, _ = self._gru_fwd_desc("g2", sc_, H, self._gru_pin("g2", sc_, H, hist, Hn, T), Hn, T, None,
+                                          training)
+            grus.append(d)
+        ops.rnn_multi("clsr_rnn_fwd_multi", grus, t4d, seq_len, ls, Hn, T)
         # ---- short term attention: query = [short_term_intention | target]
         Qs = Du + D
         q = self._buf("st.q", B, Qs)
@@ -541,13 +561,8 @@ class CLSRNet(object):
         # ---- alpha gate
         alpha = self._buf("alpha", B)
         mo = self._buf("model_output", B, 2 * D)
-        fs = None
         if not hp.manual_alpha:
-            nfs = 0
-            if hp.predict_long_short:
-                fs, _ = self._gru_fwd("g2", CL + "causal2/causal2/gru_cell/", H, hist, Hn, T, seq_len, ls, None,
-                                      training)
-                nfs = H
+            nfs = H if hp.predict_long_short else 0
             ld = _pad4(self.a_in)
             ain = self._buf("al.in", B, ld)
             call("clsr_alpha_concat", fs, nfs, target, att_long, att_short, f["time_to_now"], T, T - 1, B, G, D,
@@ -624,14 +639,26 @@ class CLSRNet(object):
                            seq_len, ls)
         call("clsr_group_sum_cols", dq, Qs, 0, G, Hn, Du, dsi, Du, 0, 1)
         call("clsr_copy_cols", dq, Qs, Du, 1, B, D, dtarget, D, 0, 1)
-        # ---- sequence encoders
+        # ---- sequence encoders: ONE fused backward-through-time launch, then the batched weight grads
         M = Hn * T
+        hist = out["hist_input"]
+        grus, t4d = [], None
+        dushort = dsi
+        if hp.interest_evolve:
+            dushort = self._buf("d_u_short", Hn, Du)
+            grus.append(self._gru_bwd_desc("g1", st + "short_term_intention/gru_cell/", Du, Hn, T, dsi, None, dushort))
         if hp.sequential_model == "time4lstm":
             t = st + "time4lstm/"
             dPin = self._buf("t4.dPin", M, 6 * H)
-            call("clsr_t4lstm_bwd", self._buf("t4.act", Hn, T, 6 * H), self._buf("t4.cst", Hn, T, H),
-                 P[t + "kernel"][D:], 4 * H, seq_len, ls, Hn, T, H, drnn, dPin)
-            hist, TT = out["hist_input"], self._buf("t4.TT", M, 2 * H)
+            t4d = ops.t4_desc(H, Wm=P[t + "kernel"][D:], ldm=4 * H, act=self._buf("t4.act", Hn, T, 6 * H),
+                              cst=self._buf("t4.cst", Hn, T, H), dout_seq=drnn, dPin=dPin)
+        else:
+            grus.append(self._gru_bwd_desc("gs", st + "simple_gru/gru_cell/", H, Hn, T, None, drnn, None))
+        if (not hp.manual_alpha) and hp.predict_long_short:
+            grus.append(self._gru_bwd_desc("g2", CL + "causal2/causal2/gru_cell/", H, Hn, T, dfs, None, None))
+        ops.rnn_multi("clsr_rnn_bwd_multi", grus, t4d, seq_len, ls, Hn, T)
+        if hp.sequential_model == "time4lstm":
+            TT = self._buf("t4.TT", M, 2 * H)
             dK = Gd[t + "kernel"]
             self._dw(hist, D, dPin, 6 * H, M, D, 4 * H, dK[0:D], 4 * H, db=Gd[t + "bias"])
             self._dw(self._buf("t4.mprev", Hn, T, H), H, dPin, 6 * H, M, H, 4 * H, dK[D:], 4 * H)
@@ -656,17 +683,11 @@ class CLSRNet(object):
                              (3 * H, "_time_input_bias2")):
                 call("clsr_reduce_parts", tp[off_:], parts, 4 * H, H, 1.0, Gd[t + nm], 0)
         else:
-            self._gru_bwd("gs", st + "simple_gru/gru_cell/", H, out["hist_input"], dhist, Hn, T, seq_len, ls, None,
-                          drnn, None)
-        dushort = self._buf("d_u_short", Hn, Du)
+            self._gru_bwd_post("gs", st + "simple_gru/gru_cell/", H, hist, dhist, Hn, T)
         if hp.interest_evolve:
-            self._gru_bwd("g1", st + "short_term_intention/gru_cell/", Du, out["hist_input"], dhist, Hn, T, seq_len,
-                          ls, dsi, None, dushort)
-        else:
-            dushort = dsi
+            self._gru_bwd_post("g1", st + "short_term_intention/gru_cell/", Du, hist, dhist, Hn, T)
         if (not hp.manual_alpha) and hp.predict_long_short:
-            self._gru_bwd("g2", CL + "causal2/causal2/gru_cell/", H, out["hist_input"], dhist, Hn, T, seq_len, ls,
-                          dfs, None, None)
+            self._gru_bwd_post("g2", CL + "causal2/causal2/gru_cell/", H, hist, dhist, Hn, T)
         # ---- long-term attention
         dul = self._att_bwd("lt", CL + "long_term/attention_fcn/", dL, out["hist_input"], out["u_long"], dhist, Hn, 1,
                             T, D, Du, seq_len, ls)

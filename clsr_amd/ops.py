@@ -73,6 +73,51 @@ def graph_destroy(graph_exec):
     _lib.check(_lib.load().clsr_graph_destroy(graph_exec), "clsr_graph_destroy")
 
 
+class GruDesc(ctypes.Structure):
+    """ctypes mirror of clsr_gru_desc (include/clsr_hip.h)."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("Pin", "Wgh", "Wch", "h0", "hT", "out_seq", "hprev", "gates",
+                                               "dhT", "dout_seq", "dPin", "dh0")] + \
+               [("h0_stride", ctypes.c_long), ("ldp", ctypes.c_int), ("ldg", ctypes.c_int), ("ldc", ctypes.c_int),
+                ("n", ctypes.c_int)]
+
+
+class T4Desc(ctypes.Structure):
+    """ctypes mirror of clsr_t4_desc (include/clsr_hip.h)."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("Pin", "Wm", "out_seq", "act", "cst", "mprev", "dout_seq", "dPin")] + \
+               [("ldp", ctypes.c_int), ("ldm", ctypes.c_int), ("n", ctypes.c_int), ("pad_", ctypes.c_int)]
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def gru_desc(n, Pin=None, ldp=0, Wgh=None, ldg=0, Wch=None, ldc=0, h0=None, h0_stride=0, hT=None, out_seq=None,
+             hprev=None, gates=None, dhT=None, dout_seq=None, dPin=None, dh0=None):
+    d = GruDesc()
+    for k, v in dict(Pin=Pin, Wgh=Wgh, Wch=Wch, h0=h0, hT=hT, out_seq=out_seq, hprev=hprev, gates=gates, dhT=dhT,
+                     dout_seq=dout_seq, dPin=dPin, dh0=dh0).items():
+        setattr(d, k, _ptr(v))
+    d.h0_stride, d.ldp, d.ldg, d.ldc, d.n = h0_stride, ldp, ldg, ldc, n
+    return d
+
+
+def t4_desc(n, Pin=None, ldp=0, Wm=None, ldm=0, out_seq=None, act=None, cst=None, mprev=None, dout_seq=None,
+            dPin=None):
+    d = T4Desc()
+    for k, v in dict(Pin=Pin, Wm=Wm, out_seq=out_seq, act=act, cst=cst, mprev=mprev, dout_seq=dout_seq,
+                     dPin=dPin).items():
+        setattr(d, k, _ptr(v))
+    d.ldp, d.ldm, d.n, d.pad_ = ldp, ldm, n, 0
+    return d
+
+
+def rnn_multi(name, grus, t4, seq_len, len_stride, Hn, T):
+    """clsr_rnn_fwd_multi / clsr_rnn_bwd_multi with python lists of descriptors."""
+    arr = (GruDesc * max(len(grus), 1))(*grus)
+    t4p = ctypes.addressof(t4) if t4 is not None else None
+    call(name, ctypes.addressof(arr) if grus else None, len(grus), t4p, seq_len, len_stride, Hn, T)
+
+
 def kp_for(K):
     """Row stride of a packed transposed weight for an input width K (see clsr_pack_weight)."""
     return 16 * ((K + 15) // 16) + 4

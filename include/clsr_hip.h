@@ -114,6 +114,28 @@ int clsr_t4_time_inputs_bwd_parts(long Hn, int T, int n);
 int clsr_t4_time_inputs_bwd(const float* dTT, const float* TT, const float* tnow, const float* tfirst,
                             long row_stride, long Hn, int T, int n, float* partial, void* stream);
 
+/* Fused launch of up to 3 GRUs + one Time4LSTM over the same histories (one grid, blockIdx.y = encoder).
+ * Forward reads Pin, the weights and h0 and writes hT/out_seq (+ hprev/gates | act/cst/mprev when non-null);
+ * backward reads the saved activations + dhT/dout_seq and writes dPin (+ dh0). */
+typedef struct clsr_gru_desc {
+  const float* Pin; const float* Wgh; const float* Wch; const float* h0;
+  float* hT; float* out_seq; float* hprev; float* gates;
+  const float* dhT; const float* dout_seq; float* dPin; float* dh0;
+  long h0_stride; int ldp; int ldg; int ldc; int n;
+} clsr_gru_desc;
+typedef struct clsr_t4_desc {
+  const float* Pin; const float* Wm;
+  float* out_seq; float* act; float* cst; float* mprev;
+  const float* dout_seq; float* dPin;
+  int ldp; int ldm; int n; int pad_;
+} clsr_t4_desc;
+int clsr_sizeof_gru_desc(void);
+int clsr_sizeof_t4_desc(void);
+int clsr_rnn_fwd_multi(const clsr_gru_desc* grus, int ngru, const clsr_t4_desc* t4, const int* seq_len,
+                       int len_stride, int Hn, int T, void* stream);
+int clsr_rnn_bwd_multi(const clsr_gru_desc* grus, int ngru, const clsr_t4_desc* t4, const int* seq_len,
+                       int len_stride, int Hn, int T, void* stream);
+
 /* ---- heads: alpha gate + fusion clsr.py:239-275; MLP output layer base_model.py:686-706;
  *      softmax data loss base_model.py:215-235; contrastive loss clsr.py:46-71 */
 int clsr_alpha_concat(const float* fs, int nfs, const float* target, const float* L, const float* S,
