@@ -1,0 +1,323 @@
+"""CLSRModel / SequentialBaseModel -- the reference's user-facing model API on top of the HIP step.
+
+Mirrors (same method names, arguments, return conventions, error behaviour):
+  reco_utils/recommender/deeprec/models/base_model.py            BaseModel      (:18-71, :381-410)
+  reco_utils/recommender/deeprec/models/sequential/sequential_base_model.py
+                                                                  SequentialBaseModel (:19-48, :111-352)
+  reco_utils/recommender/deeprec/models/sequential/clsr.py       CLSRModel      (:383-446)
+so that ``examples/00_quick_start/sequential.py``'s call sequence
+(``CLSRModel(hparams, SASequentialIterator, seed) -> fit -> load_model -> run_weighted_eval -> predict``)
+runs unchanged against this package (see examples/sequential.py).
+
+There is no TF session: ``self.sess`` is an opaque handle, ``train/eval_with_user/infer`` accept and
+ignore it.  One training step = one hipGraph replay of the kernels in libclsr_hip.so (captured per
+batch shape); feeds are copied into static device buffers first.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+from clsr_amd import ops
+from clsr_amd.deeprec_utils import cal_mean_alpha_metric, cal_metric, cal_weighted_metric, load_dict
+from clsr_amd.net import CLSRNet
+
+__all__ = ["BaseModel", "SequentialBaseModel", "CLSRModel", "latest_checkpoint"]
+
+_CKPT_INDEX = "checkpoint"
+
+
+def latest_checkpoint(model_dir):
+    """Path of the most recent checkpoint written under ``model_dir`` (``tf.train.latest_checkpoint``
+    stand-in used by the quick-start script, reference sequential.py:352,369); ``None`` if there is none."""
+    idx = os.path.join(model_dir, _CKPT_INDEX)
+    if not os.path.exists(idx):
+        return None
+    with open(idx) as f:
+        name = f.read().strip()
+    return name or None
+
+
+class _Session(object):
+    """Opaque stand-in for tf.Session (the reference passes ``self.sess`` around)."""
+
+    def close(self):
+        pass
+
+
+class BaseModel(object):
+    def __init__(self, hparams, iterator_creator, graph=None, seed=None):
+        """Build iterator, parameters, optimiser state (reference BaseModel.__init__ :18-71)."""
+        self.seed = seed
+        if seed is not None:
+            np.random.seed(seed)
+        self.graph = graph
+        self.iterator = iterator_creator(hparams, self.graph)
+        self.train_num_ngs = hparams.train_num_ngs if "train_num_ngs" in hparams else None
+        self.hparams = hparams
+        self.sess = _Session()
+        self._build_graph()
+
+    def _build_graph(self):
+        raise NotImplementedError
+
+    def load_model(self, model_path=None):
+        """Restore variables (+ BN moving stats, Adam slots); any failure raises IOError like the
+        reference (base_model.py:394-410)."""
+        act_path = self.hparams.load_saved_model
+        if model_path is not None:
+            act_path = model_path
+        try:
+            from safetensors.torch import load_file
+
+            path = act_path if str(act_path).endswith(".safetensors") else str(act_path) + ".safetensors"
+            sd = load_file(path)
+            self.net.load_state_dict(sd, strict=True)
+        except Exception:
+            raise IOError("Failed to find any matching files for {0}".format(act_path))
+
+    def save_model(self, save_path):
+        """Write all variables under their TF names (safetensors) and update the directory index."""
+        from safetensors.torch import save_file
+
+        path = str(save_path) + ".safetensors"
+        d = os.path.dirname(path)
+        if d:
+            os.makedirs(d, exist_ok=True)
+        save_file({k: v.contiguous() for k, v in self.net.state_dict().items()}, path)
+        with open(os.path.join(d, _CKPT_INDEX), "w") as f:
+            f.write(str(save_path))
+        return str(save_path)
+
+
+class SequentialBaseModel(BaseModel):
+    def __init__(self, hparams, iterator_creator, graph=None, seed=None, device="cuda:0", use_graph=True,
+                 dedup_histories=True):
+        """Reference ``SequentialBaseModel.__init__`` (:19-48): requires ``train_num_ngs``."""
+        self.hparams = hparams
+        self.need_sample = hparams.need_sample
+        self.train_num_ngs = hparams.train_num_ngs
+        if self.train_num_ngs is None:
+            raise ValueError("Please confirm the number of negative samples for each positive instance.")
+        self.min_seq_length = hparams.min_seq_length if "min_seq_length" in hparams else 1
+        self.hidden_size = hparams.hidden_size if "hidden_size" in hparams else None
+        self._device = device
+        self._use_graph = use_graph
+        self._dedup = dedup_histories
+        self._graphs = {}
+        self._static = {}
+        self.best_epoch = 0
+        super(SequentialBaseModel, self).__init__(hparams, iterator_creator, graph=graph, seed=seed)
+
+    # ------------------------------------------------------------------ construction
+    def _build_graph(self):
+        hp = self.hparams
+        self.keep_prob_train = 1 - np.array(hp.dropout)
+        self.keep_prob_test = np.ones_like(hp.dropout)
+        self.embedding_keep_prob_train = 1.0 - hp.embedding_dropout
+        self.embedding_keep_prob_test = 1.0
+        dims = dict(Vu=len(load_dict(hp.user_vocab)), Vi=len(load_dict(hp.item_vocab)),
+                    Vc=len(load_dict(hp.cate_vocab)))
+        self.user_vocab_length, self.item_vocab_length, self.cate_vocab_length = dims["Vu"], dims["Vi"], dims["Vc"]
+        self.net = CLSRNet(hp, dims, device=self._device, seed=self.seed, dedup_histories=self._dedup)
+
+    # ------------------------------------------------------------------ device feeds / graphs
+    def _to_arrays(self, feed_dict):
+        """Accept the iterator's feed (keys are the iterator attributes == field names)."""
+        it = self.iterator
+        return {name: feed_dict[getattr(it, name)] for name in
+                ("labels", "users", "items", "cates", "item_history", "item_cate_history", "mask",
+                 "time_from_first_action", "time_to_now")}
+
+    def _static_feed(self, feed, training):
+        """Copy a numpy feed into static device buffers keyed by (rows, T, mode)."""
+        net = self.net
+        fresh = net.upload(feed, training)
+        key = (fresh["B"], fresh["T"], bool(training))
+        st = self._static.get(key)
+        if st is None:
+            self._static[key] = fresh
+            return key, fresh, True
+        for k, v in fresh.items():
+            if isinstance(v, torch.Tensor):
+                st[k].copy_(v, non_blocking=True)
+        return key, st, False
+
+    def _train_step(self, feed):
+        net = self.net
+        key, f, _ = self._static_feed(feed, True)
+        if not self._use_graph:
+            net.train_step(f)
+            return
+        g = self._graphs.get(key)
+        if g is None:
+            if "stream" not in self._graphs:
+                self._graphs["stream"] = torch.cuda.Stream(device=net.device)
+            s = self._graphs["stream"]
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                net.train_step(f)               # eager: THIS is the step for this batch (also allocates
+                s.synchronize()                 # every workspace buffer the capture below will reference)
+                ops.graph_begin()
+                net.train_step(f)               # recorded only, nothing executes during capture
+                g = ops.graph_end()
+            torch.cuda.current_stream().wait_stream(s)
+            self._graphs[key] = g
+            return
+        s = self._graphs["stream"]
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            ops.graph_launch(g)
+        torch.cuda.current_stream().wait_stream(s)
+
+    # ------------------------------------------------------------------ per-step API
+    def train(self, sess, feed_dict):
+        """One optimisation step (reference CLSRModel.train, clsr.py:383-408).  Returns the same 8-list:
+        [update, extra_update_ops, loss, data_loss, regular_loss, contrastive_loss, discrepancy_loss, summary]."""
+        self._train_step(self._to_arrays(feed_dict))
+        ls = self.net.read_losses()
+        return [None, [], ls["loss"], ls["data_loss"], ls["regular_loss"], ls["contrastive_loss"],
+                ls["discrepancy_loss"], None]
+
+    def _score(self, feed_dict):
+        feed = self._to_arrays(feed_dict)
+        key, f, _ = self._static_feed(feed, False)
+        out = self.net.forward(f, False)
+        pred = torch.sigmoid(out["logit"]) if self.hparams.method == "classification" else out["logit"]
+        return feed, pred.detach().cpu().numpy().reshape(-1, 1), out
+
+    def eval(self, sess, feed_dict):
+        feed, pred, _ = self._score(feed_dict)
+        return pred, np.asarray(feed["labels"]).reshape(-1, 1)
+
+    def eval_with_user(self, sess, feed_dict):
+        """(users, pred [B,1], labels [B,1]) -- reference sequential_base_model.py:294-308."""
+        feed, pred, _ = self._score(feed_dict)
+        return (np.asarray(feed["users"]).astype(np.int32), pred, np.asarray(feed["labels"]).reshape(-1, 1))
+
+    def eval_with_user_and_alpha(self, sess, feed_dict):
+        feed, pred, out = self._score(feed_dict)
+        alpha = out["alpha"].detach().cpu().numpy().reshape(-1, 1)
+        return (np.asarray(feed["users"]).astype(np.int32), pred, np.asarray(feed["labels"]).reshape(-1, 1), alpha)
+
+    def infer(self, sess, feed_dict):
+        """[pred] -- reference base_model.py:381-392."""
+        return [self._score(feed_dict)[1]]
+
+    # ------------------------------------------------------------------ loops
+    def batch_train(self, file_iterator, train_sess):
+        """One epoch of mini-batches (reference clsr.py:410-446); returns the summed loss."""
+        step = 0
+        epoch_loss = 0
+        for batch_data_input in file_iterator:
+            if batch_data_input:
+                res = self.train(train_sess, batch_data_input)
+                (_, _, step_loss, step_data_loss, _, _, _, _) = res
+                epoch_loss += step_loss
+                step += 1
+                if step % self.hparams.show_step == 0:
+                    print("step {0:d} , total_loss: {1:.4f}, data_loss: {2:.4f}".format(step, step_loss,
+                                                                                       step_data_loss))
+        return epoch_loss
+
+    def fit(self, train_file, valid_file, valid_num_ngs, eval_metric="group_auc"):
+        """Train with per-epoch validation, early stopping and best-epoch checkpoints
+        (reference sequential_base_model.py:111-202)."""
+        if not self.need_sample and self.train_num_ngs < 1:
+            raise ValueError(
+                "Please specify a positive integer of negative numbers for training without sampling needed.")
+        if valid_num_ngs < 1:
+            raise ValueError("Please specify a positive integer of negative numbers for validation.")
+        if self.need_sample and self.train_num_ngs < 1:
+            self.train_num_ngs = 1
+        train_sess = self.sess
+        eval_info = list()
+        best_metric, self.best_epoch = 0, 0
+        for epoch in range(1, self.hparams.epochs + 1):
+            self.hparams.current_epoch = epoch
+            file_iterator = self.iterator.load_data_from_file(
+                train_file, min_seq_length=self.min_seq_length, batch_num_ngs=self.train_num_ngs)
+            self.batch_train(file_iterator, train_sess)
+            valid_res = self.run_weighted_eval(valid_file, valid_num_ngs)
+            print("eval valid at epoch {0}: {1}".format(
+                epoch, ",".join(["" + str(key) + ":" + str(value) for key, value in valid_res.items()])))
+            eval_info.append((epoch, valid_res))
+            progress = False
+            early_stop = self.hparams.EARLY_STOP
+            if valid_res[eval_metric] > best_metric:
+                best_metric = valid_res[eval_metric]
+                self.best_epoch = epoch
+                progress = True
+            else:
+                if early_stop > 0 and epoch - self.best_epoch >= early_stop:
+                    print("early stop at epoch {0}!".format(epoch))
+                    break
+            if self.hparams.save_model and self.hparams.MODEL_DIR:
+                if not os.path.exists(self.hparams.MODEL_DIR):
+                    os.makedirs(self.hparams.MODEL_DIR)
+                if progress:
+                    self.save_model(self.hparams.MODEL_DIR + "epoch_" + str(epoch))
+        print(eval_info)
+        print("best epoch: {0}".format(self.best_epoch))
+        return self
+
+    def run_eval(self, filename, num_ngs):
+        """auc/logloss + pairwise metrics over groups of ``num_ngs + 1`` lines
+        (reference sequential_base_model.py:204-236)."""
+        preds, labels = [], []
+        for batch_data_input in self.iterator.load_data_from_file(
+                filename, min_seq_length=self.min_seq_length, batch_num_ngs=0):
+            if batch_data_input:
+                step_pred, step_labels = self.eval(self.sess, batch_data_input)
+                preds.extend(np.reshape(step_pred, -1))
+                labels.extend(np.reshape(step_labels, -1))
+        return self._metrics(None, preds, labels, num_ngs + 1)
+
+    def _metrics(self, users, preds, labels, group):
+        res = cal_metric(labels, preds, self.hparams.metrics)
+        # the reference reshapes per batch (and silently needs batch_size % group == 0); accumulating
+        # first gives the identical grouping without that constraint
+        gp = np.reshape(np.asarray(preds), (-1, group))
+        gl = np.reshape(np.asarray(labels), (-1, group))
+        res.update(cal_metric(list(gl), list(gp), self.hparams.pairwise_metrics))
+        if users is not None:
+            res.update(cal_weighted_metric(users, preds, labels, self.hparams.weighted_metrics))
+        return res
+
+    def run_weighted_eval(self, filename, num_ngs, calc_mean_alpha=False, manual_alpha=False):
+        """run_eval + user-weighted metrics (wauc == the README's GAUC)
+        (reference sequential_base_model.py:244-292)."""
+        users, preds, labels, alphas = [], [], [], []
+        for batch_data_input in self.iterator.load_data_from_file(
+                filename, min_seq_length=self.min_seq_length, batch_num_ngs=0):
+            if batch_data_input:
+                if not calc_mean_alpha:
+                    step_user, step_pred, step_labels = self.eval_with_user(self.sess, batch_data_input)
+                else:
+                    step_user, step_pred, step_labels, step_alpha = self.eval_with_user_and_alpha(
+                        self.sess, batch_data_input)
+                    alphas.extend(np.reshape(step_alpha, -1))
+                users.extend(np.reshape(step_user, -1))
+                preds.extend(np.reshape(step_pred, -1))
+                labels.extend(np.reshape(step_labels, -1))
+        res = self._metrics(users, preds, labels, num_ngs + 1)
+        if calc_mean_alpha:
+            if manual_alpha:
+                alphas = alphas[0]
+            res.update(cal_mean_alpha_metric(alphas, labels))
+        return res
+
+    def predict(self, infile_name, outfile_name):
+        """One score per input line (reference sequential_base_model.py:326-347)."""
+        with open(outfile_name, "w") as wt:
+            for batch_data_input in self.iterator.load_data_from_file(infile_name, batch_num_ngs=0):
+                if batch_data_input:
+                    step_pred = np.reshape(self.infer(self.sess, batch_data_input), -1)
+                    wt.write("\n".join(map(str, step_pred)))
+                    wt.write("\n")
+        return self
+
+
+class CLSRModel(SequentialBaseModel):
+    """Reference ``CLSRModel`` (clsr.py).  All graph pieces live in :class:`clsr_amd.net.CLSRNet`."""
