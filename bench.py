@@ -111,7 +111,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--local-bn", action="store_true", help="(N>1) per-rank BN statistics")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="(N>1) global batch-norm statistics (single-device parity; eager, slower); default is "
+                         "per-rank statistics with averaged moving stats")
     args = ap.parse_args()
 
     import torch
@@ -143,7 +145,8 @@ def main():
     if world > 1:
         from clsr_amd.dp import DataParallel
 
-        stepper = DataParallel(net, dist, sync_bn=not args.local_bn)
+        stepper = DataParallel(net, dist, sync_bn=args.sync_bn)
+        stepper.prepare(f)
     else:
         stepper = None
 
@@ -244,7 +247,8 @@ def main():
                                                                         cfg["Vc"]),
                        "global_batch": world * P, "seq_len": T,
                        "parallelism": "dp%d" % world if world > 1 else "single",
-                       "hipgraph": not args.no_graph, "history_dedup": True},
+                       "hipgraph": not args.no_graph, "history_dedup": True,
+                       "batch_norm": ("sync" if args.sync_bn else "per-rank") if world > 1 else "single-device"},
             "rows_per_s": round(value * G, 1),
             "roofline": roof, "roofline_mfma": roof_mfma,
             "loss": float(host_losses[:4].sum()),

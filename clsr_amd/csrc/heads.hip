@@ -275,9 +275,8 @@ extern "C" int clsr_alpha_fuse_bwd(const float* dmo, const float* alpha, float m
 // loss = -(G/B) * sum_{b: label==1} log softmax_group(logit)[b]
 // dlogit[b] = (G/B) * (npos_group * softmax[b] - [label==1])
 __global__ void softmax_loss_kernel(const float* __restrict__ logit, const float* __restrict__ labels,
-                                    long P, int G, double* __restrict__ loss_out,
+                                    long P, int G, float scale, double* __restrict__ loss_out,
                                     float* __restrict__ dlogit) {
-  const float scale = 1.0f / (float)P;  // G / B
   float local = 0.f;
   for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
     const float* lg = logit + p * G;
@@ -300,13 +299,14 @@ __global__ void softmax_loss_kernel(const float* __restrict__ logit, const float
   if ((threadIdx.x & 63) == 0 && local != 0.f) atomicAdd(loss_out, (double)local * scale);
 }
 
-extern "C" int clsr_softmax_loss(const float* logit, const float* labels, long P, int G,
+// scale = 1 / (number of groups the mean runs over): 1/P single process, 1/(P * world) data parallel
+extern "C" int clsr_softmax_loss(const float* logit, const float* labels, long P, int G, float scale,
                                  double* loss_out, float* dlogit, void* stream) {
   CLSR_CHECK_ARG(logit && labels && loss_out && P > 0 && G > 0);
   int blocks = clsr_cdiv(P, 128);
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(softmax_loss_kernel, dim3(blocks), dim3(128), 0, (hipStream_t)stream, logit, labels,
-                     P, G, loss_out, dlogit);
+                     P, G, scale, loss_out, dlogit);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }

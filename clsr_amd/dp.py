@@ -1,0 +1,125 @@
+"""Single-node data parallelism for the CLSR step: one process per GPU, torch.distributed with the
+"nccl" backend (== RCCL over xGMI on ROCm).  The reference has no multi-device code at all
+(SURVEY.md section 5/8e); this is new surface.
+
+Per step every rank runs forward + backward on ITS shard of the global batch (whole groups of
+1 + train_num_ngs rows stay together), then ONE exchange step sums the gradient state:
+
+  dense_grad      flat fp32 buffer of the ~124 k dense parameters           (all-reduce SUM)
+  tab_grad_flat   dense gradient tables of the four embedding tables        (all-reduce SUM)
+                  -- at Taobao scale (21 MB) a dense all-reduce is simpler and as fast as a
+                  segmented sparse exchange; the sparse row exchange only pays for huge catalogues
+  tab_flags_flat  "involved row" byte maps (tf.unique id sets)               (all-reduce MAX == OR)
+  small           squared norms of the IndexedSlices pieces + loss numerators (all-reduce SUM)
+
+and every rank applies the identical clip + Adam update, so replicas never diverge.  Loss
+normalisers are global: the softmax data loss is scaled by 1/(P * world) and the contrastive
+denominator (rows longer than the threshold) is summed over ranks before the step.
+
+Batch-norm: ``sync_bn=True`` sums the per-feature partial statistics of every BN layer across ranks
+(forward sums and backward sums) so the result equals a single-device run on the global batch;
+``sync_bn=False`` ("local BN") keeps per-rank statistics (faster: no mid-step collectives, graph
+capturable) and averages the moving statistics once per step.
+"""
+import torch
+
+from clsr_amd import ops
+
+__all__ = ["DataParallel", "allreduce_step_buffers"]
+
+
+def allreduce_step_buffers(dist, dense_grad, tab_grad_flat, tab_flags_flat, small, group=None):
+    """The exchange step.  Works on CPU tensors (gloo) and GPU tensors (nccl/RCCL) alike."""
+    dist.all_reduce(dense_grad, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(tab_grad_flat, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(tab_flags_flat, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(small, op=dist.ReduceOp.SUM, group=group)
+
+
+def shard_feed(feed, rank, world, group_size):
+    """Contiguous block of whole groups for ``rank`` out of a global training feed (numpy arrays)."""
+    B = feed["labels"].shape[0]
+    if B % (group_size * world):
+        raise ValueError("global batch rows (%d) must be a multiple of group_size*world (%d)"
+                         % (B, group_size * world))
+    per = B // world
+    return {k: v[rank * per:(rank + 1) * per] for k, v in feed.items()}
+
+
+class DataParallel(object):
+    def __init__(self, net, dist, sync_bn=False, group=None):
+        self.net, self.dist, self.group = net, dist, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.sync_bn = bool(sync_bn)
+        net.dp_world = self.world
+        net.dp_stats_hook = self._sum_stats if self.sync_bn else None
+        # sumsq_tab (16) + losses (8) travel together
+        self.small = torch.zeros(24, dtype=torch.float64, device=net.device)
+        self._graphs = None
+        self.broadcast_parameters()
+
+    def broadcast_parameters(self):
+        """Replicas start from rank 0's variables (dense buffer, tables, BN moving stats, Adam slots)."""
+        net, dist = self.net, self.dist
+        tensors = [net.dense, net.dense_m, net.dense_v, net.adam_state]
+        tensors += list(net.tables.values()) + list(net.tab_m.values()) + list(net.tab_v.values())
+        for bn in net.bn.values():
+            tensors += [bn.moving_mean, bn.moving_var]
+        for t in tensors:
+            dist.broadcast(t, src=0, group=self.group)
+
+    def _sum_stats(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def prepare(self, f):
+        """Make the per-batch loss normalisers global (call once per uploaded feed)."""
+        self.dist.all_reduce(f["denom"], op=self.dist.ReduceOp.SUM, group=self.group)
+        return f
+
+    # ---- the three phases of a step
+    def _backward(self, f):
+        self.net.train_step(f, apply=False)
+
+    def _exchange(self):
+        net = self.net
+        self.small[:16].copy_(net.sumsq_tab)
+        self.small[16:].copy_(net.losses)
+        allreduce_step_buffers(self.dist, net.dense_grad, net.tab_grad_flat, net.tab_flags_flat, self.small,
+                               self.group)
+        net.sumsq_tab.copy_(self.small[:16])
+        net.losses.copy_(self.small[16:])
+        if not self.sync_bn:
+            # keep the (non-trainable) moving statistics identical on every replica
+            for bn in net.bn.values():
+                for t in (bn.moving_mean, bn.moving_var):
+                    self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+                    t.mul_(1.0 / self.world)
+
+    def _update(self):
+        self.net._apply_updates()
+
+    def train_step(self, f):
+        self._backward(f)
+        self._exchange()
+        self._update()
+
+    def capture(self, f):
+        """Two hipGraphs (backward | update) around the eager RCCL exchange; returns run().
+        With sync_bn the BN collectives sit inside the backward phase, so that phase stays eager."""
+        if self.sync_bn:
+            return lambda: self.train_step(f)
+        ops.graph_begin()
+        self._backward(f)
+        g1 = ops.graph_end()
+        ops.graph_begin()
+        self._update()
+        g2 = ops.graph_end()
+        self._graphs = (g1, g2)
+
+        def run():
+            ops.graph_launch(g1)
+            self._exchange()
+            ops.graph_launch(g2)
+
+        return run

@@ -77,6 +77,8 @@ class CLSRNet(object):
         self.sumsq_tab = torch.zeros(16, dtype=torch.float64, device=self.device)
         self.ucount = torch.zeros(1, dtype=F32, device=self.device)
         self.last_shape = None
+        self.dp_world = 1          # data-parallel world size (loss normalisers are global)
+        self.dp_stats_hook = None  # optional callable(tensor): sum BN partial statistics across ranks
         self.capture_grads = False
         self.captured = None
 
@@ -134,6 +136,16 @@ class CLSRNet(object):
         self.P, self.Gd = OrderedDict(), OrderedDict()
         host = torch.zeros(self.n_dense, dtype=F32)
         self.tables, self.tab_grad, self.tab_m, self.tab_v, self.tab_flags = {}, {}, {}, {}, {}
+        # gradient tables and involved-row flags live in ONE flat buffer each (one collective per kind)
+        tshape = {k: [tuple(sh) for n, sh, _ in specs if n == v][0] for k, v in TABLES.items()}
+        goff, foff = {}, {}
+        gtot = ftot = 0
+        for k, sh in tshape.items():
+            goff[k], foff[k] = gtot, ftot
+            gtot += _pad4(sh[0] * sh[1])
+            ftot += (sh[0] + 15) // 16 * 16
+        self.tab_grad_flat = torch.zeros(gtot, dtype=F32, device=dev)
+        self.tab_flags_flat = torch.zeros(ftot, dtype=torch.uint8, device=dev)
         it_dense = iter(zip(dense, off[:-1]))
         for name, shape, kind in specs:
             val = init_tensor(kind, tuple(shape), hp, gen)
@@ -143,10 +155,10 @@ class CLSRNet(object):
                 if name != UNUSED_TABLE:
                     key = [k for k, v in TABLES.items() if v == name][0]
                     self.tables[key] = t
-                    self.tab_grad[key] = torch.zeros_like(t)
+                    self.tab_grad[key] = self.tab_grad_flat[goff[key]:goff[key] + t.numel()].view_as(t)
                     self.tab_m[key] = torch.zeros_like(t)
                     self.tab_v[key] = torch.zeros_like(t)
-                    self.tab_flags[key] = torch.zeros(shape[0], dtype=torch.uint8, device=dev)
+                    self.tab_flags[key] = self.tab_flags_flat[foff[key]:foff[key] + shape[0]]
             else:
                 (_, _, _), o = next(it_dense)
                 n = int(np.prod(shape))
@@ -245,11 +257,18 @@ class CLSRNet(object):
         return self._buf("stats", 1024 * 2 * 256, dtype=torch.float64)[: parts * 2 * N], parts
 
     def _bn_fwd(self, bn, stats, parts, count, training):
+        if training and self.dp_stats_hook is not None:   # SyncBN: global batch statistics
+            self.dp_stats_hook(stats)
+            count = count * self.dp_world
         call("clsr_bn_finalize", stats, parts, bn.C, float(count), bn.gamma, bn.beta, bn.moving_mean,
              bn.moving_var, BN_MOMENTUM, BN_EPS, 1 if training else 0, bn.scale, bn.shift, bn.mean, bn.invstd)
 
     def _bn_bwd_from_partial(self, bn, part, parts, dy, z, M):
-        call("clsr_bn_bwd_coef", part, parts, bn.C, float(M), bn.gamma, bn.mean, bn.invstd, bn.coef,
+        count = M
+        if self.dp_stats_hook is not None:
+            self.dp_stats_hook(part)
+            count = M * self.dp_world
+        call("clsr_bn_bwd_coef", part, parts, bn.C, float(count), bn.gamma, bn.mean, bn.invstd, bn.coef,
              bn.dgamma, bn.dbeta, 0)
         call("clsr_bn_bwd_apply", dy, z, bn.coef, M, bn.C)
 
@@ -579,9 +598,10 @@ class CLSRNet(object):
                     w_long=self._buf("lt.wts", Hn, T), w_short=self._buf("st.wts", B, T), q_short=q)
 
     # ------------------------------------------------------------------ training step
-    def train_step(self, f):
-        """forward + backward + clip + Adam on an uploaded feed.  Losses land in self.losses
-        (device doubles: data, regular, contrastive, discrepancy)."""
+    def train_step(self, f, apply=True):
+        """forward + backward (+ clip + Adam when ``apply``) on an uploaded feed.  Losses land in
+        self.losses (device doubles: data, regular, contrastive, discrepancy).  Data-parallel runs call
+        with apply=False, all-reduce the gradient buffers, then call :meth:`_apply_updates`."""
         hp, P, Gd = self.hp, self.P, self.Gd
         out = self.forward(f, True)
         B, T, G, Hn = self.last_shape
@@ -613,7 +633,8 @@ class CLSRNet(object):
         # ---- losses on the forward outputs
         dlogit = self._buf("dlogit", B)
         Gl = hp.train_num_ngs + 1
-        call("clsr_softmax_loss", out["logit"], f["labels"], B // Gl, Gl, self.losses[0:], dlogit)
+        call("clsr_softmax_loss", out["logit"], f["labels"], B // Gl, Gl, 1.0 / ((B // Gl) * self.dp_world),
+             self.losses[0:], dlogit)
         call("clsr_contrastive", out["att_fea_long"], out["att_fea_short"], out["hist_mean"], out["hist_recent"],
              seq_len, ls, Hn, G, D, int(hp.contrastive_length_threshold), 1 if hp.contrastive_loss == "triplet" else 0,
              float(hp.triplet_margin), float(hp.contrastive_loss_weight), f["denom"], self.losses[2:], dL, dS, dM, dR)
@@ -699,7 +720,8 @@ class CLSRNet(object):
         call("clsr_scatter_add_rows", dtarget, D, Di, f["cates"], 1, B, Dc, self.tab_grad["cate"], ss[3:])
         call("clsr_scatter_add_rows", dul, Du, 0, f["users"], G, Hn, Du, self.tab_grad["user_long"], ss[6:])
         call("clsr_scatter_add_rows", dushort, Du, 0, f["users"], G, Hn, Du, self.tab_grad["user_short"], ss[7:])
-        self._apply_updates()
+        if apply:
+            self._apply_updates()
         return out
 
     def _apply_updates(self):

@@ -154,8 +154,8 @@ int clsr_alpha_fuse_fwd(const float* alpha_logit, float manual_alpha, const floa
 int clsr_alpha_fuse_bwd(const float* dmo, const float* alpha, float manual_alpha, const float* L,
                         const float* S, long Hn, int G, int D, float* dalpha_logit, float* dL, float* dS,
                         float* dtarget, void* stream);
-int clsr_softmax_loss(const float* logit, const float* labels, long P, int G, double* loss_out,
-                      float* dlogit, void* stream);
+int clsr_softmax_loss(const float* logit, const float* labels, long P, int G, float scale,
+                      double* loss_out, float* dlogit, void* stream);
 int clsr_contrastive(const float* L, const float* S, const float* M, const float* R, const int* seq_len,
                      int len_stride, long Hn, int G, int D, int threshold, int mode, float margin,
                      float weight, const float* denom_ptr, double* loss_out, float* dL, float* dS,

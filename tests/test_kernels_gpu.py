@@ -527,7 +527,7 @@ def test_softmax_loss():
     loss.backward()
     out = torch.zeros(1, dtype=torch.float64, device="cuda")
     dl = torch.empty(P * G, device="cuda")
-    call("clsr_softmax_loss", dev(logit.detach(), torch.float32), dev(labels, torch.float32), P, G, out, dl)
+    call("clsr_softmax_loss", dev(logit.detach(), torch.float32), dev(labels, torch.float32), P, G, 1.0 / P, out, dl)
     close(out, loss.detach().reshape(1), rtol=1e-5, name="data loss")
     close(dl, logit.grad, rtol=1e-4, atol=1e-7, name="dlogit")
 
