@@ -270,6 +270,11 @@ class CLSRNet(object):
             count = M * self.dp_world
         call("clsr_bn_bwd_coef", part, parts, bn.C, float(count), bn.gamma, bn.mean, bn.invstd, bn.coef,
              bn.dgamma, bn.dbeta, 0)
+        if self.dp_stats_hook is not None:
+            # the partial sums were already global: pre-divide so the gradient all-reduce (SUM) restores them
+            inv = 1.0 / self.dp_world
+            call("clsr_axpby", bn.dgamma, bn.dgamma, inv, None, 0.0, bn.C)
+            call("clsr_axpby", bn.dbeta, bn.dbeta, inv, None, 0.0, bn.C)
         call("clsr_bn_bwd_apply", dy, z, bn.coef, M, bn.C)
 
     def _bn_relu_bwd(self, bn, dh, z, M):
