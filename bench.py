@@ -213,7 +213,10 @@ def main():
         # bytes_gather_fwd(n) = n*(Di+Dc)*(s_t + s_a) + 2*n*4 per gathered history row
         gbytes = n_valid * D * (4 + 4) + 2 * n_valid * 4
         roof = dict(bound="hbm", kernel="gather_hist_fwd_kernel", achieved=round(gbytes / t_gather / 1e9, 1),
-                    peak=8000.0, unit="GB/s", frac=round(gbytes / t_gather / 8e12, 4), traffic=None,
+                    peak=8000.0, unit="GB/s", frac=round(gbytes / t_gather / 8e12, 4),
+                    # PMC pass committed in profiles/r01_gather_hist_fwd_pmc_hbm_traffic.csv (same shape): WRITE_SIZE
+                    # 33.4 MB + 2 x FETCH_SIZE 12.6 MB (gfx950 wide-load correction); reads of the 8 MB tables hit cache
+                    traffic=59.9e6, traffic_source="profiles/r01_gather_hist_fwd_pmc_hbm_traffic.csv",
                     bytes_per_launch=gbytes, us_per_launch=round(t_gather * 1e6, 2),
                     note="tables (%.1f MB) are L2/Infinity-Cache resident at this config; the HBM claim needs the "
                          "100M-item config" % ((cfg["Vi"] * cfg["Di"] + cfg["Vc"] * cfg["Dc"]) * 4 / 1e6))

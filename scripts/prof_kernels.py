@@ -56,6 +56,29 @@ def main():
         t = timeit(lambda: call("clsr_pgemm_dw", x, 40, 0, 0, None, 0, None, None, 0, dy, 120, Hn * T, 40, 80, 1.0,
                                 dWs, 80, None, 0, ws))
         print("dw hist^T dPin   205k x 40 x 80 : %8.1f us" % t)
+    if which in ("gather", "all"):
+        # embedding-history gather: Taobao-shaped (cache resident) and a 100M-item catalogue (HBM resident)
+        for name, Vi, Vc, Di, Dc in (("taobao", 64138, 4096, 32, 8), ("catalogue100m", 100_000_000, 10000, 96, 32)):
+            it = torch.empty(Vi, Di, device=dev)
+            ct = torch.empty(Vc, Dc, device=dev)
+            if name == "taobao":
+                it.normal_()
+                ct.normal_()
+            else:
+                it.zero_()   # 38 GB: touch every page once so the gather reads committed HBM
+                ct.normal_()
+            ii = torch.randint(1, Vi, (Hn, T), device=dev, dtype=torch.int32)
+            ci = torch.randint(1, Vc, (Hn, T), device=dev, dtype=torch.int32)
+            ln = torch.full((Hn,), T, device=dev, dtype=torch.int32)
+            D = Di + Dc
+            hist = torch.empty(Hn, T, D, device=dev)
+            hm, hr = torch.empty(Hn, D, device=dev), torch.empty(Hn, D, device=dev)
+            t = timeit(lambda: call("clsr_gather_hist_fwd", it, ct, ii, ci, T, ln, 1, Hn, T, Di, Dc, 3, hist, hm, hr),
+                       iters=20)
+            nbytes = Hn * T * (D * 8 + 8)
+            print("gather_hist_fwd %-14s rows %dB+%dB: %8.1f us  %.0f GB/s algorithmic (%.1f%% of 8 TB/s)" % (
+                name, Di * 4, Dc * 4, t, nbytes / t / 1e3, nbytes / t / 1e3 / 80))
+            del it, ct
     if which in ("pgemm", "all"):
         Wt, Kp = ops.pack_weight(W, 80, 80)
         U = torch.randn(Hn * T, 80, device=dev)
