@@ -14,6 +14,7 @@
 // and stores ONE float4 of outputs per out-tile -- the output layout of a layer is exactly
 // the input layout of the next one (16-byte vector global accesses, no LDS transposes).
 #include "common.h"
+#include "clsr_hip.h"
 
 struct PGemmArgs {
   const float* X; int ldx;
@@ -247,6 +248,28 @@ extern "C" int clsr_pack_weight(const float* src1, int ld1, float s1, const floa
   int blocks = clsr_cdiv((long)Opad * Ip, 256);
   hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src1, ld1,
                      s1, src2, ld2, s2, transposed, O, I, Ip, Opad, Wt);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+__global__ void __launch_bounds__(256) pack_batch_kernel(const clsr_pack_desc* __restrict__ descs) {
+  const clsr_pack_desc d = descs[blockIdx.y];
+  const int total = d.O * d.I;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int o = e / d.I, i = e - o * d.I;
+    float v = d.s1 * (d.transposed ? d.src1[(long)o * d.ld1 + i] : d.src1[(long)i * d.ld1 + o]);
+    if (d.src2) v += d.s2 * (d.transposed ? d.src2[(long)o * d.ld2 + i] : d.src2[(long)i * d.ld2 + o]);
+    d.dst[(long)(d.o0 + o) * d.Kp + d.i0 + i] = v;
+  }
+}
+
+extern "C" int clsr_sizeof_pack_desc(void) { return (int)sizeof(clsr_pack_desc); }
+
+extern "C" int clsr_pack_batch(const clsr_pack_desc* descs_device, int n, int max_elems, void* stream) {
+  CLSR_CHECK_ARG(descs_device && n > 0 && max_elems > 0);
+  int bx = clsr_cdiv(max_elems, 256);
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(pack_batch_kernel, dim3(bx, n), dim3(256), 0, (hipStream_t)stream, descs_device);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }

@@ -86,8 +86,9 @@ struct GruArgs {
   // backward
   const float* dhT;                    // [Hn, n] grad wrt final state (may be null)
   const float* dout_seq;               // optional [Hn, T, n]
-  float* dPin;                         // [Hn, T, 3n] (zeros past len)
+  float* dPin;                         // [Hn, T, lddp] (zeros past len); r | u | c blocks of n
   float* dh0;                          // optional [Hn, n]
+  int lddp;
 };
 
 __device__ __forceinline__ void gru_fwd_body(const GruArgs& a, const int bx) {
@@ -195,7 +196,7 @@ __device__ __forceinline__ void gru_bwd_body(const GruArgs& a, const int bx) {
   for (int tl = 0; tl < RNT; ++tl)
     if (cval[tl])
       for (int t = len; t < T; ++t) {
-        float* dp = a.dPin + (h * T + t) * 3 * n + 16 * tl + 4 * g;
+        float* dp = a.dPin + (h * T + t) * a.lddp + 16 * tl + 4 * g;
         st4(dp, Z4); st4(dp + n, Z4); st4(dp + 2 * n, Z4);
       }
   for (int t = Tmax - 1; t >= 0; --t) {
@@ -232,7 +233,7 @@ __device__ __forceinline__ void gru_bwd_body(const GruArgs& a, const int bx) {
 #pragma unroll
     for (int tl = 0; tl < RNT; ++tl) {
       if (live && cval[tl]) {
-        float* dp = a.dPin + pos * 3 * n + 16 * tl + 4 * g;
+        float* dp = a.dPin + pos * a.lddp + 16 * tl + 4 * g;
         st4(dp, drp[tl]); st4(dp + n, dup[tl]); st4(dp + 2 * n, dcp[tl]);
       }
       dh[tl] = sel4(live, dhn[tl], dh[tl]);
@@ -283,6 +284,7 @@ extern "C" int clsr_gru_bwd(const float* gates, const float* hprev, const float*
   a.gates = const_cast<float*>(gates); a.hprev = const_cast<float*>(hprev);
   a.Wgh = Wgh; a.ldg = ldg; a.Wch = Wch; a.ldc = ldc; a.seq_len = seq_len; a.len_stride = len_stride;
   a.Hn = Hn; a.T = T; a.n = n; a.dhT = dhT; a.dout_seq = dout_seq; a.dPin = dPin; a.dh0 = dh0;
+  a.lddp = 3 * n;
   hipLaunchKernelGGL(gru_bwd_kernel, dim3(clsr_cdiv(Hn, 16)), dim3(64), 0, (hipStream_t)stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
@@ -301,7 +303,8 @@ struct T4Args {
   float* out_seq;                      // [Hn, T, n] (m, zeros past len)
   float* act; float* cst; float* mprev;
   const float* dout_seq;               // [Hn, T, n]
-  float* dPin;                         // [Hn, T, 6n]
+  float* dPin;                         // [Hn, T, lddp]
+  int lddp;
 };
 
 __device__ __forceinline__ void t4lstm_fwd_body(const T4Args& a, const int bx) {
@@ -397,7 +400,7 @@ __device__ __forceinline__ void t4lstm_bwd_body(const T4Args& a, const int bx) {
   for (int tl = 0; tl < RNT; ++tl)
     if (cval[tl])
       for (int t = len; t < T; ++t) {
-        float* dp = a.dPin + (h * T + t) * 6 * n + 16 * tl + 4 * g;
+        float* dp = a.dPin + (h * T + t) * a.lddp + 16 * tl + 4 * g;
 #pragma unroll
         for (int gb = 0; gb < 6; ++gb) st4(dp + gb * n, Z4);
       }
@@ -427,7 +430,7 @@ __device__ __forceinline__ void t4lstm_bwd_body(const T4Args& a, const int bx) {
       const f32x4 dtl = dcc * fg * cp * tlg * (1.0f - tlg);          // d tls_pre
       dcn[tl] = dcc * fg * tlg;
       if (ok) {
-        float* dp = a.dPin + pos * 6 * n + col;
+        float* dp = a.dPin + pos * a.lddp + col;
         st4(dp, dg[0][tl]); st4(dp + n, dg[1][tl]); st4(dp + 2 * n, dg[2][tl]); st4(dp + 3 * n, dg[3][tl]);
         st4(dp + 4 * n, dtn); st4(dp + 5 * n, dtl);
       }
@@ -495,7 +498,7 @@ extern "C" int clsr_t4lstm_bwd(const float* act, const float* cst, const float* 
   T4Args a = {};
   a.act = const_cast<float*>(act); a.cst = const_cast<float*>(cst); a.Wm = Wm; a.ldm = ldm;
   a.seq_len = seq_len; a.len_stride = len_stride; a.Hn = Hn; a.T = T; a.n = n;
-  a.dout_seq = dout_seq; a.dPin = dPin;
+  a.dout_seq = dout_seq; a.dPin = dPin; a.lddp = 6 * n;
   hipLaunchKernelGGL(t4lstm_bwd_kernel, dim3(clsr_cdiv(Hn, 16)), dim3(64), 0, (hipStream_t)stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
@@ -610,6 +613,8 @@ static int fill_multi(RnnMultiArgs& m, const clsr_gru_desc* grus, int ngru, cons
     a.h0 = d.h0; a.h0_stride = d.h0_stride; a.seq_len = seq_len; a.len_stride = len_stride;
     a.Hn = Hn; a.T = T; a.n = d.n; a.hT = d.hT; a.out_seq = d.out_seq; a.hprev = d.hprev; a.gates = d.gates;
     a.dhT = d.dhT; a.dout_seq = d.dout_seq; a.dPin = d.dPin; a.dh0 = d.dh0;
+    a.lddp = d.lddp > 0 ? d.lddp : 3 * d.n;
+    CLSR_CHECK_SUPPORTED(a.lddp % 4 == 0);
   }
   if (t4) {
     int rc = check_rnn_shape(Hn, T, t4->n, backward ? t4->ldm : t4->ldp);
@@ -621,6 +626,8 @@ static int fill_multi(RnnMultiArgs& m, const clsr_gru_desc* grus, int ngru, cons
     a.Pin = t4->Pin; a.ldp = t4->ldp; a.Wm = t4->Wm; a.ldm = t4->ldm; a.seq_len = seq_len;
     a.len_stride = len_stride; a.Hn = Hn; a.T = T; a.n = t4->n; a.out_seq = t4->out_seq; a.act = t4->act;
     a.cst = t4->cst; a.mprev = t4->mprev; a.dout_seq = t4->dout_seq; a.dPin = t4->dPin;
+    a.lddp = t4->lddp > 0 ? t4->lddp : 6 * t4->n;
+    CLSR_CHECK_SUPPORTED(a.lddp % 4 == 0);
   }
   return CLSR_OK;
 }

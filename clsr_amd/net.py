@@ -72,6 +72,7 @@ class CLSRNet(object):
         self._bufs = {}
         self._zero_specs = OrderedDict()
         self.packed = {}
+        self._plans, self._plan_keep, self._cur_descs = {}, [], []
         self.adam_state = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device=self.device)
         self.losses = torch.zeros(8, dtype=torch.float64, device=self.device)
         self.sumsq_tab = torch.zeros(16, dtype=torch.float64, device=self.device)
@@ -222,14 +223,19 @@ class CLSRNet(object):
             self._bufs[key] = t
         return t
 
-    def _pack(self, key, W, out_f, in_f, transposed=False, W2=None, s2=1.0, in_pad=None):
-        """Pack weight block W ([in, out] view) as the MFMA A operand (and cache under key)."""
-        Kp = ops.kp_for(in_pad or in_f)
-        opad = 16 * ((out_f + 15) // 16)
-        buf = self._buf("pack:" + key, opad * Kp)
-        call("clsr_pack_weight", W, W.stride(0), 1.0, W2, 0 if W2 is None else W2.stride(0), float(s2),
-             1 if transposed else 0, out_f, in_f, Kp, buf)
+    def _pack(self, key, W, out_f, in_f, transposed=False, W2=None, s2=1.0, in_pad=None, o0=0, i0=0,
+              total=None):
+        """Plan one packed weight block: dst rows = out features, cols = in features (MFMA A operand
+        layout, row stride Kp).  ``W`` is an [in, out] view (``transposed``: an [out, in] view).  With
+        ``total=(out_total, in_total)`` the block is placed at (o0, i0) of an assembled matrix.  Nothing is
+        launched here: the descriptors are executed by ONE clsr_pack_batch launch per step."""
+        out_t, in_t = total if total is not None else (out_f, in_f)
+        Kp = ops.kp_for(in_pad or in_t)
+        opad = 16 * ((out_t + 15) // 16)
+        buf = self._buf("pack:" + key, opad * Kp)   # zero-initialised; padding is never written
         self.packed[key] = (buf, Kp)
+        self._cur_descs.append(ops.pack_desc(W, out_f, in_f, buf, Kp, transposed=transposed, o0=o0, i0=i0,
+                                             src2=W2, s2=s2))
 
     def _pack_pair(self, key, W, K, N, K_pad=None):
         """forward pack (K->N) and transposed pack (N->K) of the same [K, N] block."""
@@ -284,33 +290,78 @@ class CLSRNet(object):
         self._bn_bwd_from_partial(bn, part, parts, dh, z, M)
 
     # ------------------------------------------------------------------ weight packing (per step)
+    def _xw_blocks(self):
+        """Column layout of the fused history projection  hist . [all input-side weight blocks]:
+        list of (encoder key, kind, weight view [D, w], bias view, column offset, width)."""
+        P, D, H = self.P, self.D, self.H
+        out, off = [], 0
+        for key, scope, n in self._gru_list():
+            for kind, W, b, w in (("gx", P[scope + "gates/kernel"][0:D], P[scope + "gates/bias"], 2 * n),
+                                  ("cx", P[scope + "candidate/kernel"][0:D], P[scope + "candidate/bias"], n)):
+                out.append((key, kind, W, b, off, w))
+                off += w
+        if self.hp.sequential_model == "time4lstm":
+            t = CL + "short_term/time4lstm/"
+            for kind, W, b, w in (("kx", P[t + "kernel"][0:D], P[t + "bias"], 4 * H),
+                                  ("w1", P[t + "_time_kernel_w1"], P[t + "_time_bias1"], H),
+                                  ("w2", P[t + "_time_kernel_w2"], P[t + "_time_bias2"], H)):
+                out.append(("t4", kind, W, b, off, w))
+                off += w
+        return out, off
+
+    def _enc_off(self, key):
+        blocks, _ = self._xw_blocks()
+        return min(off for k, _, _, _, off, _ in blocks if k == key)
+
     def _pack_all(self, training):
+        """Fill every packed weight buffer of the step with one batched launch (the plan -- buffers +
+        device descriptor table -- is built on first use per mode)."""
+        plan = self._plans.get(bool(training))
+        if plan is None:
+            self._cur_descs = []
+            self._plan_weights(training)
+            plan = ops.pack_table(self._cur_descs, self.device)
+            self._plans[bool(training)] = plan
+            self._plan_keep.append(self._cur_descs)   # descriptors hold raw pointers of live tensors
+        tbl, n, max_elems = plan
+        call("clsr_pack_batch", tbl, n, max_elems)
+
+    def _plan_weights(self, training):
         hp, P = self.hp, self.P
         D, Du, H, A0, A1 = self.D, self.Du, self.H, self.A0, self.A1
         for key, scope, Dk, Q in (("lt", CL + "long_term/attention_fcn/", D, Du),
                                   ("st", CL + "short_term/attention_fcn/", H, Du + D)):
-            self._pack_pair(key + ".A", P[scope + "attention_mat"], Dk, Q)
             W0 = P[scope + "att_fcn/nn_part/w_nn_layer0"]
+            W1 = P[scope + "att_fcn/nn_part/w_nn_layer1"]
+            self._pack(key + ".A", P[scope + "attention_mat"], Q, Dk)
             self._pack(key + ".Wu", W0[0:Q], A0, Q, W2=W0[2 * Q:3 * Q], s2=1.0)
             self._pack(key + ".Wv", W0[Q:2 * Q], A0, Q, W2=W0[2 * Q:3 * Q], s2=-1.0)
             self._pack(key + ".Wp", W0[3 * Q:4 * Q], A0, Q)
-            self._pack(key + ".W1", P[scope + "att_fcn/nn_part/w_nn_layer1"], A1, A0)
+            self._pack(key + ".W1", W1, A1, A0)
             if training:
+                self._pack(key + ".A^T", P[scope + "attention_mat"], Dk, Q, transposed=True)
                 self._pack(key + ".Wu^T", W0[0:Q], Q, A0, transposed=True, W2=W0[2 * Q:3 * Q], s2=1.0)
                 self._pack(key + ".Wv^T", W0[Q:2 * Q], Q, A0, transposed=True, W2=W0[2 * Q:3 * Q], s2=-1.0)
                 self._pack(key + ".Wp^T", W0[3 * Q:4 * Q], Q, A0, transposed=True)
-                self._pack(key + ".W1^T", P[scope + "att_fcn/nn_part/w_nn_layer1"], A0, A1, transposed=True)
-        pair = self._pack_pair if training else (lambda k, W, K, N, K_pad=None: self._pack(k, W, N, K, in_pad=K_pad))
-        for key, scope, n in self._gru_list():
-            pair(key + ".gx", P[scope + "gates/kernel"][0:D], D, 2 * n)
-            pair(key + ".cx", P[scope + "candidate/kernel"][0:D], D, n)
+                self._pack(key + ".W1^T", W1, A0, A1, transposed=True)
+        # fused history projection: every input-side weight block of every encoder side by side
+        blocks, NX = self._xw_blocks()
+        self.NX = NX
+        bias = self._buf("xw.bias", NX)
+        for _, _, W, b, off, w in blocks:
+            self._pack("xw", W, w, D, o0=off, total=(NX, D))
+            self._cur_descs.append(ops.pack_desc(b, w, 1, bias, 1, ld1=1, o0=off))
+            if training:
+                self._pack("xw^T", W, D, w, transposed=True, i0=off, total=(D, NX))
         if hp.sequential_model == "time4lstm":
             t = CL + "short_term/time4lstm/"
-            pair("t4.kx", P[t + "kernel"][0:D], D, 4 * H)
-            pair("t4.w1", P[t + "_time_kernel_w1"], D, H)
-            pair("t4.w2", P[t + "_time_kernel_w2"], D, H)
-            for nm in ("_o_kernel_t1", "_o_kernel_t2", "_time_kernel_t1", "_time_kernel_t2"):
-                pair("t4." + nm, P[t + nm], H, H)
+            # [Tn | Tl] (2H) -> [o | tns | tls] (3H) block matrix of the four time kernels
+            for nm, o0, i0 in (("_o_kernel_t1", 0, 0), ("_o_kernel_t2", 0, H), ("_time_kernel_t1", H, 0),
+                               ("_time_kernel_t2", 2 * H, H)):
+                self._pack("t4.tw", P[t + nm], H, H, o0=o0, i0=i0, total=(3 * H, 2 * H))
+                if training:
+                    self._pack("t4.tw^T", P[t + nm], H, H, transposed=True, o0=i0, i0=o0, total=(2 * H, 3 * H))
+        pair = self._pack_pair if training else (lambda k, W, K, N, K_pad=None: self._pack(k, W, N, K, in_pad=K_pad))
         if not hp.manual_alpha:
             a = CL + "fcn_alpha/nn_part/"
             pair("al.W0", P[a + "w_nn_layer0"], self.a_in, A0, K_pad=_pad4(self.a_in))
@@ -318,6 +369,37 @@ class CLSRNet(object):
         lg = "sequential/logit_fcn/nn_part/"
         pair("lg.W0", P[lg + "w_nn_layer0"], 2 * D, self.L0)
         pair("lg.W1", P[lg + "w_nn_layer1"], self.L0, self.L1)
+
+    def _unpack_grads(self):
+        """Scatter the assembled gradient blocks (fused projection, time kernels) into the variables."""
+        plan = self._plans.get("unpack")
+        if plan is None:
+            Gd, D, H = self.Gd, self.D, self.H
+            blocks, NX = self._xw_blocks()
+            dXW, dxb = self._buf("xw.dW", D, NX), self._buf("xw.db", NX)
+            descs = []
+            gname = {"gx": ("gates/kernel", "gates/bias"), "cx": ("candidate/kernel", "candidate/bias")}
+            scopes = {k: sc for k, sc, _ in self._gru_list()}
+            t = CL + "short_term/time4lstm/"
+            tname = {"kx": ("kernel", "bias"), "w1": ("_time_kernel_w1", "_time_bias1"),
+                     "w2": ("_time_kernel_w2", "_time_bias2")}
+            for key, kind, W, b, off, w in blocks:
+                if key == "t4":
+                    gw, gb = Gd[t + tname[kind][0]], Gd[t + tname[kind][1]]
+                else:
+                    gw, gb = Gd[scopes[key] + gname[kind][0]], Gd[scopes[key] + gname[kind][1]]
+                descs.append(ops.pack_desc(dXW[:, off:], D, w, gw, gw.stride(0), ld1=NX, transposed=True))
+                descs.append(ops.pack_desc(dxb[off:], 1, w, gb, w, ld1=NX, transposed=True))
+            if self.hp.sequential_model == "time4lstm":
+                dTW = self._buf("t4.dTW", 2 * H, 3 * H)
+                for nm, r0, c0 in (("_o_kernel_t1", 0, 0), ("_o_kernel_t2", H, 0), ("_time_kernel_t1", 0, H),
+                                   ("_time_kernel_t2", H, 2 * H)):
+                    descs.append(ops.pack_desc(dTW[r0:, c0:], H, H, Gd[t + nm], H, ld1=3 * H, transposed=True))
+            plan = ops.pack_table(descs, self.device)
+            self._plans["unpack"] = plan
+            self._plan_keep.append(descs)
+        tbl, n, max_elems = plan
+        call("clsr_pack_batch", tbl, n, max_elems)
 
     def _gru_list(self):
         hp = self.hp
@@ -469,45 +551,34 @@ class CLSRNet(object):
         return dX
 
     # ------------------------------------------------------------------ recurrent encoders
-    def _gru_pin(self, key, scope, n, hist, Hn, T):
-        """Input-side projections of one GRU for every (history, step): Pin = x.[Wg_x | Wc_x] + bias."""
-        P, D = self.P, self.D
-        Pin = self._buf(key + ".Pin", Hn * T, 3 * n)
-        self._gemm(hist, D, key + ".gx", Hn * T, D, 2 * n, Pin, 3 * n, bias=P[scope + "gates/bias"])
-        self._gemm(hist, D, key + ".cx", Hn * T, D, n, Pin[:, 2 * n:], 3 * n, bias=P[scope + "candidate/bias"])
-        return Pin
-
-    def _gru_fwd_desc(self, key, scope, n, Pin, Hn, T, h0, training, want_seq=False):
+    def _gru_fwd_desc(self, key, scope, n, PinAll, Hn, T, h0, training, want_seq=False):
         P, D = self.P, self.D
         hT = self._buf(key + ".hT", Hn, n)
         seq = self._buf(key + ".seq", Hn, T, n) if want_seq else None
         hprev = self._buf(key + ".hprev", Hn, T, n) if training else None
         gates = self._buf(key + ".gates", Hn, T, 3 * n) if training else None
         Wg, Wc = P[scope + "gates/kernel"], P[scope + "candidate/kernel"]
-        d = ops.gru_desc(n, Pin=Pin, ldp=3 * n, Wgh=Wg[D:], ldg=2 * n, Wch=Wc[D:], ldc=n, h0=h0,
-                         h0_stride=n if h0 is not None else 0, hT=hT, out_seq=seq, hprev=hprev, gates=gates)
+        d = ops.gru_desc(n, Pin=PinAll[:, self._enc_off(key):], ldp=self.NX, Wgh=Wg[D:], ldg=2 * n, Wch=Wc[D:],
+                         ldc=n, h0=h0, h0_stride=n if h0 is not None else 0, hT=hT, out_seq=seq, hprev=hprev,
+                         gates=gates)
         return d, hT, seq
 
-    def _gru_bwd_desc(self, key, scope, n, Hn, T, dhT, dseq, dh0):
+    def _gru_bwd_desc(self, key, scope, n, dPinAll, Hn, T, dhT, dseq, dh0):
         P, D = self.P, self.D
         Wg, Wc = P[scope + "gates/kernel"], P[scope + "candidate/kernel"]
         return ops.gru_desc(n, Wgh=Wg[D:], ldg=2 * n, Wch=Wc[D:], ldc=n,
                             hprev=self._buf(key + ".hprev", Hn, T, n), gates=self._buf(key + ".gates", Hn, T, 3 * n),
-                            dhT=dhT, dout_seq=dseq, dPin=self._buf(key + ".dPin", Hn * T, 3 * n), dh0=dh0)
+                            dhT=dhT, dout_seq=dseq, dPin=dPinAll[:, self._enc_off(key):], lddp=self.NX, dh0=dh0)
 
-    def _gru_bwd_post(self, key, scope, n, hist, dhist, Hn, T):
-        """Weight gradients and d(hist) from the dPin written by the recurrence backward."""
-        Gd, D = self.Gd, self.D
+    def _gru_bwd_hidden(self, key, scope, n, dPinAll, Hn, T):
+        """Hidden-to-hidden weight gradients of one GRU from its slice of dPin."""
+        Gd, D, NX = self.Gd, self.D, self.NX
         hprev, gates = self._buf(key + ".hprev", Hn, T, n), self._buf(key + ".gates", Hn, T, 3 * n)
-        dPin = self._buf(key + ".dPin", Hn * T, 3 * n)
-        dWg, dWc = Gd[scope + "gates/kernel"], Gd[scope + "candidate/kernel"]
+        dP = dPinAll[:, self._enc_off(key):]
         M = Hn * T
-        self._dw(hist, D, dPin, 3 * n, M, D, 2 * n, dWg[0:D], 2 * n, db=Gd[scope + "gates/bias"])
-        self._dw(hist, D, dPin[:, 2 * n:], 3 * n, M, D, n, dWc[0:D], n, db=Gd[scope + "candidate/bias"])
-        self._dw(hprev, n, dPin, 3 * n, M, n, 2 * n, dWg[D:], 2 * n)
-        self._dw(hprev, n, dPin[:, 2 * n:], 3 * n, M, n, n, dWc[D:], n, Xmul=gates, ldmul=3 * n)
-        self._gemm(dPin, 3 * n, key + ".gx^T", M, 2 * n, D, dhist, D, acc=1)
-        self._gemm(dPin[:, 2 * n:], 3 * n, key + ".cx^T", M, n, D, dhist, D, acc=1)
+        self._dw(hprev, n, dP, NX, M, n, 2 * n, Gd[scope + "gates/kernel"][D:], 2 * n)
+        self._dw(hprev, n, dP[:, 2 * n:], NX, M, n, n, Gd[scope + "candidate/kernel"][D:], n, Xmul=gates,
+                 ldmul=3 * n)
 
     # ------------------------------------------------------------------ forward
     def forward(self, f, training):
@@ -536,14 +607,16 @@ class CLSRNet(object):
         # ---- long term
         lt = CL + "long_term/attention_fcn/"
         att_long = self._att_fwd("lt", lt, hist, ulong, Hn, 1, T, D, Du, seq_len, ls, training)
-        # ---- sequence encoders: input projections first, then ONE fused launch for all recurrences
+        # ---- sequence encoders: ONE fused input projection, then ONE fused launch for all recurrences
         st = CL + "short_term/"
         M = Hn * T
+        NX = self.NX
+        PinAll = self._buf("xw.Pin", M, NX)
+        self._gemm(hist, D, "xw", M, D, NX, PinAll, NX, bias=self._buf("xw.bias", NX))
         grus, t4d = [], None
         short_int, rnn_out, fs = ushort, None, None
         if hp.interest_evolve:
-            sc_ = st + "short_term_intention/gru_cell/"
-            d, short_int, _ = self._gru_fwd_desc("g1", sc_, Du, self._gru_pin("g1", sc_, Du, hist, Hn, T), Hn, T,
+            d, short_int, _ = self._gru_fwd_desc("g1", st + "short_term_intention/gru_cell/", Du, PinAll, Hn, T,
                                                  ushort, training)
             grus.append(d)
         if hp.sequential_model == "time4lstm":
@@ -552,28 +625,19 @@ class CLSRNet(object):
             call("clsr_t4_time_inputs_fwd", f["time_to_now"], f["time_from_first_action"], G * T,
                  P[t + "_time_input_w1"], P[t + "_time_input_bias1"], P[t + "_time_input_w2"],
                  P[t + "_time_input_bias2"], Hn, T, H, TT)
-            Pin = self._buf("t4.Pin", M, 6 * H)
-            self._gemm(hist, D, "t4.kx", M, D, 4 * H, Pin, 6 * H, bias=P[t + "bias"])
-            self._gemm(hist, D, "t4.w1", M, D, H, Pin[:, 4 * H:], 6 * H, bias=P[t + "_time_bias1"])
-            self._gemm(hist, D, "t4.w2", M, D, H, Pin[:, 5 * H:], 6 * H, bias=P[t + "_time_bias2"])
-            self._gemm(TT, 2 * H, "t4._o_kernel_t1", M, H, H, Pin[:, 3 * H:], 6 * H, acc=1)
-            self._gemm(TT[:, H:], 2 * H, "t4._o_kernel_t2", M, H, H, Pin[:, 3 * H:], 6 * H, acc=1)
-            self._gemm(TT, 2 * H, "t4._time_kernel_t1", M, H, H, Pin[:, 4 * H:], 6 * H, acc=1)
-            self._gemm(TT[:, H:], 2 * H, "t4._time_kernel_t2", M, H, H, Pin[:, 5 * H:], 6 * H, acc=1)
+            t4off = self._enc_off("t4")
+            self._gemm(TT, 2 * H, "t4.tw", M, 2 * H, 3 * H, PinAll[:, t4off + 3 * H:], NX, acc=1)
             rnn_out = self._buf("rnn_out", Hn, T, H)
-            t4d = ops.t4_desc(H, Pin=Pin, ldp=6 * H, Wm=P[t + "kernel"][D:], ldm=4 * H, out_seq=rnn_out,
+            t4d = ops.t4_desc(H, Pin=PinAll[:, t4off:], ldp=NX, Wm=P[t + "kernel"][D:], ldm=4 * H, out_seq=rnn_out,
                               act=self._buf("t4.act", Hn, T, 6 * H) if training else None,
                               cst=self._buf("t4.cst", Hn, T, H) if training else None,
                               mprev=self._buf("t4.mprev", Hn, T, H) if training else None)
         else:
-            sc_ = st + "simple_gru/gru_cell/"
-            d, _, rnn_out = self._gru_fwd_desc("gs", sc_, H, self._gru_pin("gs", sc_, H, hist, Hn, T), Hn, T, None,
-                                               training, want_seq=True)
+            d, _, rnn_out = self._gru_fwd_desc("gs", st + "simple_gru/gru_cell/", H, PinAll, Hn, T, None, training,
+                                               want_seq=True)
             grus.append(d)
         if (not hp.manual_alpha) and hp.predict_long_short:
-            sc_ = CL + "causal2/causal2/gru_cell/"
-            d, fs, _ = self._gru_fwd_desc("g2", sc_, H, self._gru_pin("g2", sc_, H, hist, Hn, T), Hn, T, None,
-                                          training)
+            d, fs, _ = self._gru_fwd_desc("g2", CL + "causal2/causal2/gru_cell/", H, PinAll, Hn, T, None, training)
             grus.append(d)
         ops.rnn_multi("clsr_rnn_fwd_multi", grus, t4d, seq_len, ls, Hn, T)
         # ---- short term attention: query = [short_term_intention | target]
@@ -667,41 +731,35 @@ class CLSRNet(object):
         call("clsr_copy_cols", dq, Qs, Du, 1, B, D, dtarget, D, 0, 1)
         # ---- sequence encoders: ONE fused backward-through-time launch, then the batched weight grads
         M = Hn * T
+        NX = self.NX
         hist = out["hist_input"]
+        dPinAll = self._buf("xw.dPin", M, NX)
         grus, t4d = [], None
         dushort = dsi
         if hp.interest_evolve:
             dushort = self._buf("d_u_short", Hn, Du)
-            grus.append(self._gru_bwd_desc("g1", st + "short_term_intention/gru_cell/", Du, Hn, T, dsi, None, dushort))
+            grus.append(self._gru_bwd_desc("g1", st + "short_term_intention/gru_cell/", Du, dPinAll, Hn, T, dsi, None,
+                                           dushort))
         if hp.sequential_model == "time4lstm":
             t = st + "time4lstm/"
-            dPin = self._buf("t4.dPin", M, 6 * H)
+            t4off = self._enc_off("t4")
             t4d = ops.t4_desc(H, Wm=P[t + "kernel"][D:], ldm=4 * H, act=self._buf("t4.act", Hn, T, 6 * H),
-                              cst=self._buf("t4.cst", Hn, T, H), dout_seq=drnn, dPin=dPin)
+                              cst=self._buf("t4.cst", Hn, T, H), dout_seq=drnn, dPin=dPinAll[:, t4off:], lddp=NX)
         else:
-            grus.append(self._gru_bwd_desc("gs", st + "simple_gru/gru_cell/", H, Hn, T, None, drnn, None))
+            grus.append(self._gru_bwd_desc("gs", st + "simple_gru/gru_cell/", H, dPinAll, Hn, T, None, drnn, None))
         if (not hp.manual_alpha) and hp.predict_long_short:
-            grus.append(self._gru_bwd_desc("g2", CL + "causal2/causal2/gru_cell/", H, Hn, T, dfs, None, None))
+            grus.append(self._gru_bwd_desc("g2", CL + "causal2/causal2/gru_cell/", H, dPinAll, Hn, T, dfs, None, None))
         ops.rnn_multi("clsr_rnn_bwd_multi", grus, t4d, seq_len, ls, Hn, T)
+        # input-side weights of every encoder in one reduction; d(hist) in one product
+        self._dw(hist, D, dPinAll, NX, M, D, NX, self._buf("xw.dW", D, NX), NX, db=self._buf("xw.db", NX))
+        self._gemm(dPinAll, NX, "xw^T", M, NX, D, dhist, D, acc=1)
         if hp.sequential_model == "time4lstm":
             TT = self._buf("t4.TT", M, 2 * H)
-            dK = Gd[t + "kernel"]
-            self._dw(hist, D, dPin, 6 * H, M, D, 4 * H, dK[0:D], 4 * H, db=Gd[t + "bias"])
-            self._dw(self._buf("t4.mprev", Hn, T, H), H, dPin, 6 * H, M, H, 4 * H, dK[D:], 4 * H)
-            self._dw(hist, D, dPin[:, 4 * H:], 6 * H, M, D, H, Gd[t + "_time_kernel_w1"], H, db=Gd[t + "_time_bias1"])
-            self._dw(hist, D, dPin[:, 5 * H:], 6 * H, M, D, H, Gd[t + "_time_kernel_w2"], H, db=Gd[t + "_time_bias2"])
-            self._dw(TT, 2 * H, dPin[:, 3 * H:], 6 * H, M, H, H, Gd[t + "_o_kernel_t1"], H)
-            self._dw(TT[:, H:], 2 * H, dPin[:, 3 * H:], 6 * H, M, H, H, Gd[t + "_o_kernel_t2"], H)
-            self._dw(TT, 2 * H, dPin[:, 4 * H:], 6 * H, M, H, H, Gd[t + "_time_kernel_t1"], H)
-            self._dw(TT[:, H:], 2 * H, dPin[:, 5 * H:], 6 * H, M, H, H, Gd[t + "_time_kernel_t2"], H)
-            self._gemm(dPin, 6 * H, "t4.kx^T", M, 4 * H, D, dhist, D, acc=1)
-            self._gemm(dPin[:, 4 * H:], 6 * H, "t4.w1^T", M, H, D, dhist, D, acc=1)
-            self._gemm(dPin[:, 5 * H:], 6 * H, "t4.w2^T", M, H, D, dhist, D, acc=1)
+            dPt = dPinAll[:, t4off:]
+            self._dw(self._buf("t4.mprev", Hn, T, H), H, dPt, NX, M, H, 4 * H, Gd[t + "kernel"][D:], 4 * H)
+            self._dw(TT, 2 * H, dPt[:, 3 * H:], NX, M, 2 * H, 3 * H, self._buf("t4.dTW", 2 * H, 3 * H), 3 * H)
             dTT = self._buf("t4.dTT", M, 2 * H)
-            self._gemm(dPin[:, 3 * H:], 6 * H, "t4._o_kernel_t1^T", M, H, H, dTT, 2 * H)
-            self._gemm(dPin[:, 4 * H:], 6 * H, "t4._time_kernel_t1^T", M, H, H, dTT, 2 * H, acc=1)
-            self._gemm(dPin[:, 3 * H:], 6 * H, "t4._o_kernel_t2^T", M, H, H, dTT[:, H:], 2 * H)
-            self._gemm(dPin[:, 5 * H:], 6 * H, "t4._time_kernel_t2^T", M, H, H, dTT[:, H:], 2 * H, acc=1)
+            self._gemm(dPt[:, 3 * H:], NX, "t4.tw^T", M, 3 * H, 2 * H, dTT, 2 * H)
             parts = query("clsr_t4_time_inputs_bwd_parts", Hn, T, H)
             tp = self._buf("t4.tpart", 512 * 4 * 128)[: parts * 4 * H]
             call("clsr_t4_time_inputs_bwd", dTT, TT, f["time_to_now"], f["time_from_first_action"], G * T, Hn, T, H, tp)
@@ -709,11 +767,12 @@ class CLSRNet(object):
                              (3 * H, "_time_input_bias2")):
                 call("clsr_reduce_parts", tp[off_:], parts, 4 * H, H, 1.0, Gd[t + nm], 0)
         else:
-            self._gru_bwd_post("gs", st + "simple_gru/gru_cell/", H, hist, dhist, Hn, T)
+            self._gru_bwd_hidden("gs", st + "simple_gru/gru_cell/", H, dPinAll, Hn, T)
         if hp.interest_evolve:
-            self._gru_bwd_post("g1", st + "short_term_intention/gru_cell/", Du, hist, dhist, Hn, T)
+            self._gru_bwd_hidden("g1", st + "short_term_intention/gru_cell/", Du, dPinAll, Hn, T)
         if (not hp.manual_alpha) and hp.predict_long_short:
-            self._gru_bwd_post("g2", CL + "causal2/causal2/gru_cell/", H, hist, dhist, Hn, T)
+            self._gru_bwd_hidden("g2", CL + "causal2/causal2/gru_cell/", H, dPinAll, Hn, T)
+        self._unpack_grads()
         # ---- long-term attention
         dul = self._att_bwd("lt", CL + "long_term/attention_fcn/", dL, out["hist_input"], out["u_long"], dhist, Hn, 1,
                             T, D, Du, seq_len, ls)

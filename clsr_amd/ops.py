@@ -78,13 +78,13 @@ class GruDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("Pin", "Wgh", "Wch", "h0", "hT", "out_seq", "hprev", "gates",
                                                "dhT", "dout_seq", "dPin", "dh0")] + \
                [("h0_stride", ctypes.c_long), ("ldp", ctypes.c_int), ("ldg", ctypes.c_int), ("ldc", ctypes.c_int),
-                ("n", ctypes.c_int)]
+                ("n", ctypes.c_int), ("lddp", ctypes.c_int), ("pad_", ctypes.c_int)]
 
 
 class T4Desc(ctypes.Structure):
     """ctypes mirror of clsr_t4_desc (include/clsr_hip.h)."""
     _fields_ = [(n, ctypes.c_void_p) for n in ("Pin", "Wm", "out_seq", "act", "cst", "mprev", "dout_seq", "dPin")] + \
-               [("ldp", ctypes.c_int), ("ldm", ctypes.c_int), ("n", ctypes.c_int), ("pad_", ctypes.c_int)]
+               [("ldp", ctypes.c_int), ("ldm", ctypes.c_int), ("n", ctypes.c_int), ("lddp", ctypes.c_int)]
 
 
 def _ptr(t):
@@ -92,22 +92,22 @@ def _ptr(t):
 
 
 def gru_desc(n, Pin=None, ldp=0, Wgh=None, ldg=0, Wch=None, ldc=0, h0=None, h0_stride=0, hT=None, out_seq=None,
-             hprev=None, gates=None, dhT=None, dout_seq=None, dPin=None, dh0=None):
+             hprev=None, gates=None, dhT=None, dout_seq=None, dPin=None, dh0=None, lddp=0):
     d = GruDesc()
     for k, v in dict(Pin=Pin, Wgh=Wgh, Wch=Wch, h0=h0, hT=hT, out_seq=out_seq, hprev=hprev, gates=gates, dhT=dhT,
                      dout_seq=dout_seq, dPin=dPin, dh0=dh0).items():
         setattr(d, k, _ptr(v))
-    d.h0_stride, d.ldp, d.ldg, d.ldc, d.n = h0_stride, ldp, ldg, ldc, n
+    d.h0_stride, d.ldp, d.ldg, d.ldc, d.n, d.lddp, d.pad_ = h0_stride, ldp, ldg, ldc, n, lddp, 0
     return d
 
 
 def t4_desc(n, Pin=None, ldp=0, Wm=None, ldm=0, out_seq=None, act=None, cst=None, mprev=None, dout_seq=None,
-            dPin=None):
+            dPin=None, lddp=0):
     d = T4Desc()
     for k, v in dict(Pin=Pin, Wm=Wm, out_seq=out_seq, act=act, cst=cst, mprev=mprev, dout_seq=dout_seq,
                      dPin=dPin).items():
         setattr(d, k, _ptr(v))
-    d.ldp, d.ldm, d.n, d.pad_ = ldp, ldm, n, 0
+    d.ldp, d.ldm, d.n, d.lddp = ldp, ldm, n, lddp
     return d
 
 
@@ -116,6 +116,33 @@ def rnn_multi(name, grus, t4, seq_len, len_stride, Hn, T):
     arr = (GruDesc * max(len(grus), 1))(*grus)
     t4p = ctypes.addressof(t4) if t4 is not None else None
     call(name, ctypes.addressof(arr) if grus else None, len(grus), t4p, seq_len, len_stride, Hn, T)
+
+
+class PackDesc(ctypes.Structure):
+    """ctypes mirror of clsr_pack_desc (include/clsr_hip.h)."""
+    _fields_ = [("src1", ctypes.c_void_p), ("src2", ctypes.c_void_p), ("dst", ctypes.c_void_p),
+                ("s1", ctypes.c_float), ("s2", ctypes.c_float)] + \
+               [(n, ctypes.c_int) for n in ("ld1", "ld2", "transposed", "O", "I", "Kp", "o0", "i0")]
+
+
+def pack_desc(src1, O, I, dst, Kp, ld1=None, transposed=False, o0=0, i0=0, src2=None, s1=1.0, s2=1.0, ld2=None):
+    d = PackDesc()
+    d.src1, d.src2, d.dst = src1.data_ptr(), _ptr(src2), dst.data_ptr()
+    d.s1, d.s2 = float(s1), float(s2)
+    d.ld1 = src1.stride(0) if ld1 is None else ld1
+    d.ld2 = (src2.stride(0) if src2 is not None else 0) if ld2 is None else ld2
+    d.transposed, d.O, d.I, d.Kp, d.o0, d.i0 = (1 if transposed else 0), O, I, Kp, o0, i0
+    return d
+
+
+def pack_table(descs, device):
+    """Upload a list of PackDesc to device memory; returns (tensor, n, max_elems)."""
+    import torch as _t
+
+    arr = (PackDesc * len(descs))(*descs)
+    raw = bytes(memoryview(arr))
+    t = _t.frombuffer(bytearray(raw), dtype=_t.uint8).to(device)
+    return t, len(descs), max(d.O * d.I for d in descs)
 
 
 def kp_for(K):

@@ -55,6 +55,17 @@ int clsr_mark_rows(const int* idx, long nrows, int ncols, long row_stride, unsig
  *      rnn_cell_implement.py:207-231) and their gradients; fp32 MFMA */
 int clsr_pack_weight(const float* src1, int ld1, float s1, const float* src2, int ld2, float s2,
                      int transposed, int O, int I, int Ip, float* Wt, void* stream);
+/* Batched block packer / strided block copier: descriptor i writes
+ *   dst[(o0+o)*Kp + i0+i] = s1*A(o,i) + s2*B(o,i),  o < O, i < I,  A(o,i) = transposed ? src1[o*ld1+i] : src1[i*ld1+o]
+ * (B likewise from src2, optional).  The descriptor table lives in DEVICE memory; one launch packs every weight
+ * block of the step (and, with transposed=1, scatters assembled gradient blocks back into the variables). */
+typedef struct clsr_pack_desc {
+  const float* src1; const float* src2; float* dst;
+  float s1; float s2;
+  int ld1; int ld2; int transposed; int O; int I; int Kp; int o0; int i0;
+} clsr_pack_desc;
+int clsr_sizeof_pack_desc(void);
+int clsr_pack_batch(const clsr_pack_desc* descs_device, int n, int max_elems, void* stream);
 int clsr_pgemm_stats_parts(int M);
 int clsr_pgemm(const float* X, int ldx, int T, int G, const float* Xmul, int ldmul,
                const float* in_scale, const float* in_shift, int in_relu, const float* Wt, int Kp,
@@ -121,13 +132,13 @@ typedef struct clsr_gru_desc {
   const float* Pin; const float* Wgh; const float* Wch; const float* h0;
   float* hT; float* out_seq; float* hprev; float* gates;
   const float* dhT; const float* dout_seq; float* dPin; float* dh0;
-  long h0_stride; int ldp; int ldg; int ldc; int n;
+  long h0_stride; int ldp; int ldg; int ldc; int n; int lddp; int pad_;
 } clsr_gru_desc;
 typedef struct clsr_t4_desc {
   const float* Pin; const float* Wm;
   float* out_seq; float* act; float* cst; float* mprev;
   const float* dout_seq; float* dPin;
-  int ldp; int ldm; int n; int pad_;
+  int ldp; int ldm; int n; int lddp;
 } clsr_t4_desc;
 int clsr_sizeof_gru_desc(void);
 int clsr_sizeof_t4_desc(void);
