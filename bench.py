@@ -128,10 +128,14 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dp = bool(os.environ.get("CLSR_FORCE_DP"))   # exercise the DP code path with a single rank
+    if world > 1 or force_dp:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     cfg = CONFIGS[args.config]
@@ -139,10 +143,12 @@ def main():
     hp = build_hparams(cfg, P)
     dims = dict(Vu=cfg["Vu"], Vi=cfg["Vi"], Vc=cfg["Vc"])
     net = CLSRNet(hp, dims, device="cuda:%d" % local_rank, seed=0)
+    if os.environ.get("CLSR_NO_OVERLAP"):
+        net.overlap = False
     log("net built")
     feed = synthetic_feed(P, T, cfg["Vu"], cfg["Vi"], cfg["Vc"], G=G, lengths=args.lengths, seed=20220425 + rank)
     f = net.upload(feed, True)
-    if world > 1:
+    if dist is not None:
         from clsr_amd.dp import DataParallel
 
         stepper = DataParallel(net, dist, sync_bn=args.sync_bn)

@@ -73,6 +73,11 @@ class CLSRNet(object):
         self._zero_specs = OrderedDict()
         self.packed = {}
         self._plans, self._plan_keep, self._cur_descs = {}, [], []
+        self._sort_bytes = {}
+        self._ws_tag = ""          # suffix of shared scratch buffers while a side-stream branch is recording
+        self._side = None
+        self._joins = []
+        self.overlap = True        # run the long-term attention chain on a side stream (fork / join)
         self.adam_state = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device=self.device)
         self.losses = torch.zeros(8, dtype=torch.float64, device=self.device)
         self.sumsq_tab = torch.zeros(16, dtype=torch.float64, device=self.device)
@@ -213,6 +218,51 @@ class CLSRNet(object):
                 self.tab_v[k].copy_(torch.as_tensor(sd["__adam__/%s_v" % k]))
             self.adam_state.copy_(torch.as_tensor(sd["__adam__/state"]))
 
+    # ------------------------------------------------------------------ stream fork / join
+    class _Branch(object):
+        """``with net._branch("@tag"):`` -- launches inside go to a side HIP stream that first waits for
+        everything enqueued so far on the current stream; scratch buffers get their own copies (tag).
+        ``net._join()`` makes the current stream wait for every finished branch.  Works eagerly and under
+        hipGraph capture (the event record / wait pairs become graph dependencies)."""
+
+        def __init__(self, net, tag):
+            self.net, self.tag = net, tag
+
+        def __enter__(self):
+            net = self.net
+            if not net.overlap:
+                return self
+            if net._side is None:
+                net._side = torch.cuda.Stream(device=net.device)
+            main = torch.cuda.current_stream()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            net._side.wait_event(ev)
+            self.old_tag, net._ws_tag = net._ws_tag, self.tag
+            self.ctx = torch.cuda.stream(net._side)
+            self.ctx.__enter__()
+            return self
+
+        def __exit__(self, *exc):
+            net = self.net
+            if not net.overlap:
+                return False
+            ev = torch.cuda.Event()
+            ev.record(net._side)
+            self.ctx.__exit__(*exc)
+            net._ws_tag = self.old_tag
+            net._joins.append(ev)
+            return False
+
+    def _branch(self, tag):
+        return CLSRNet._Branch(self, tag)
+
+    def _join(self):
+        main = torch.cuda.current_stream()
+        for ev in self._joins:
+            main.wait_event(ev)
+        self._joins = []
+
     # ------------------------------------------------------------------ buffers
     def _buf(self, name, *shape, dtype=F32):
         """Named persistent workspace tensor (allocated zeroed on first use, then reused)."""
@@ -251,16 +301,16 @@ class CLSRNet(object):
 
     def _dw(self, X, ldx, dY, ldy, M, K, N, dW, ldw, db=None, T=0, G=0, Xmul=None, ldmul=0, aff=None, acc=0):
         need = query("clsr_pgemm_dw_workspace_floats", M, K, N)
-        ws = self._bufs.get("dw_ws")
+        ws = self._bufs.get("dw_ws" + self._ws_tag)
         if ws is None or ws.numel() < need:
             ws = torch.empty(max(need, 1 << 20), dtype=F32, device=self.device)
-            self._bufs["dw_ws"] = ws
+            self._bufs["dw_ws" + self._ws_tag] = ws
         sc, sh = (aff.scale, aff.shift) if aff is not None else (None, None)
         call("clsr_pgemm_dw", X, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, ldy, M, K, N, 1.0, dW, ldw, db, acc, ws)
 
     def _stats_buf(self, M, N):
         parts = query("clsr_pgemm_stats_parts", M)
-        return self._buf("stats", 1024 * 2 * 256, dtype=torch.float64)[: parts * 2 * N], parts
+        return self._buf("stats" + self._ws_tag, 1024 * 2 * 256, dtype=torch.float64)[: parts * 2 * N], parts
 
     def _bn_fwd(self, bn, stats, parts, count, training):
         if training and self.dp_stats_hook is not None:   # SyncBN: global batch statistics
@@ -285,7 +335,7 @@ class CLSRNet(object):
 
     def _bn_relu_bwd(self, bn, dh, z, M):
         parts = query("clsr_colred_parts", M, bn.C)
-        part = self._buf("colred", 2048 * 2 * 256, dtype=torch.float64)[: parts * 2 * bn.C]
+        part = self._buf("colred" + self._ws_tag, 2048 * 2 * 256, dtype=torch.float64)[: parts * 2 * bn.C]
         call("clsr_bn_relu_bwd_reduce", dh, z, bn.scale, bn.shift, bn.mean, bn.invstd, M, bn.C, part)
         self._bn_bwd_from_partial(bn, part, parts, dh, z, M)
 
@@ -476,8 +526,8 @@ class CLSRNet(object):
         dz1 = self._buf(key + ".dz1", R * T, A1)
         dz0 = self._buf(key + ".dz0", R * T, A0)
         parts = query("clsr_att_out_bwd_parts", Hn)
-        bnp = self._buf("att.bnp", 2048 * 2 * 256, dtype=torch.float64)[: parts * 2 * A1]
-        wp = self._buf("att.wp", 2048 * (256 + 4))[: parts * (A1 + 4)]
+        bnp = self._buf("att.bnp" + self._ws_tag, 2048 * 2 * 256, dtype=torch.float64)[: parts * 2 * A1]
+        wp = self._buf("att.wp" + self._ws_tag, 2048 * (256 + 4))[: parts * (A1 + 4)]
         call("clsr_att_out_bwd", dout, wts, z1, bn1.scale, bn1.shift, bn1.mean, bn1.invstd,
              P[nn + "w_nn_output"], seq_len, len_stride, keys, Hn, G, T, A1, Dk, dz1, dkeys, bnp, wp)
         call("clsr_reduce_parts", wp, parts, A1 + 4, A1, 1.0, Gd[nn + "w_nn_output"], 0)
@@ -604,9 +654,10 @@ class CLSRNet(object):
         ulong, ushort = self._buf("u_long", Hn, Du), self._buf("u_short", Hn, Du)
         call("clsr_gather_rows", self.tables["user_long"], f["users"], G, Hn, Du, ulong, Du, 0)
         call("clsr_gather_rows", self.tables["user_short"], f["users"], G, Hn, Du, ushort, Du, 0)
-        # ---- long term
+        # ---- long term (independent of the encoders and of the short-term attention: side stream)
         lt = CL + "long_term/attention_fcn/"
-        att_long = self._att_fwd("lt", lt, hist, ulong, Hn, 1, T, D, Du, seq_len, ls, training)
+        with self._branch("@lt"):
+            att_long = self._att_fwd("lt", lt, hist, ulong, Hn, 1, T, D, Du, seq_len, ls, training)
         # ---- sequence encoders: ONE fused input projection, then ONE fused launch for all recurrences
         st = CL + "short_term/"
         M = Hn * T
@@ -647,6 +698,7 @@ class CLSRNet(object):
         call("clsr_copy_cols", target, D, 0, 1, B, D, q, Qs, Du, 0)
         att_short = self._att_fwd("st", st + "attention_fcn/", rnn_out, q, Hn, G, T, H, Qs, seq_len, ls, training)
         # ---- alpha gate
+        self._join()
         alpha = self._buf("alpha", B)
         mo = self._buf("model_output", B, 2 * D)
         if not hp.manual_alpha:
@@ -679,7 +731,7 @@ class CLSRNet(object):
         call("clsr_zero_doubles", self.losses, 8)
         call("clsr_zero_doubles", self.sumsq_tab, 16)
         # gradient accumulators (zeroed every step)
-        zpool = self._buf("zero_pool", Hn * T * (D + H) + B * D * 2 + Hn * (3 * D + H + Du))
+        zpool = self._buf("zero_pool", Hn * T * (2 * D + H) + B * D * 2 + Hn * (3 * D + H + Du))
         call("clsr_zero_floats", zpool, zpool.numel())
         o = [0]
 
@@ -688,7 +740,7 @@ class CLSRNet(object):
             t = zpool[o[0]:o[0] + n].view(*shape)
             o[0] += n
             return t
-        dhist, drnn = take(Hn, T, D), take(Hn, T, H)
+        dhist, drnn, dhist_lt = take(Hn, T, D), take(Hn, T, H), take(Hn, T, D)
         dtarget, dS = take(B, D), take(B, D)
         dL, dM, dR = take(Hn, D), take(Hn, D), take(Hn, D)
         dfs, dsi = take(Hn, H), take(Hn, Du)
@@ -722,6 +774,11 @@ class CLSRNet(object):
         else:
             call("clsr_alpha_fuse_bwd", dmo, None, float(hp.manual_alpha_value), out["att_fea_long"],
                  out["att_fea_short"], Hn, G, D, None, dL, dS, dtarget)
+        # ---- long-term attention backward: dL is final here; runs on the side stream underneath the
+        #      short-term attention / encoder backward (own scratch + own d(hist) accumulator)
+        with self._branch("@lt"):
+            dul = self._att_bwd("lt", CL + "long_term/attention_fcn/", dL, out["hist_input"], out["u_long"], dhist_lt,
+                                Hn, 1, T, D, Du, seq_len, ls)
         # ---- short-term attention
         st = CL + "short_term/"
         Qs = Du + D
@@ -773,11 +830,13 @@ class CLSRNet(object):
         if (not hp.manual_alpha) and hp.predict_long_short:
             self._gru_bwd_hidden("g2", CL + "causal2/causal2/gru_cell/", H, dPinAll, Hn, T)
         self._unpack_grads()
-        # ---- long-term attention
-        dul = self._att_bwd("lt", CL + "long_term/attention_fcn/", dL, out["hist_input"], out["u_long"], dhist, Hn, 1,
-                            T, D, Du, seq_len, ls)
+        # ---- join the long-term attention branch; its d(hist) contribution was accumulated separately
+        self._join()
+        call("clsr_axpby", dhist, dhist, 1.0, dhist_lt, 1.0, dhist.numel())
         # ---- embedding gradients (IndexedSlices values -> dense grad tables + squared norms)
         ss = self.sumsq_tab
+        # (sort + segmented sums -- _hist_grad_sorted -- measures the same as plain atomics at this size
+        #  because rocPRIM falls back to a 16-launch merge sort; it becomes the path for the sparse exchange)
         call("clsr_gather_hist_bwd", dhist, dM, dR, f["item_history"], f["item_cate_history"], G * T, seq_len, ls,
              Hn, T, Di, Dc, hp.contrastive_recent_k, self.tab_grad["item"], self.tab_grad["cate"], ss[0:])
         call("clsr_scatter_add_rows", dtarget, D, 0, f["items"], 1, B, Di, self.tab_grad["item"], ss[2:])
@@ -787,6 +846,24 @@ class CLSRNet(object):
         if apply:
             self._apply_updates()
         return out
+
+    def _hist_grad_sorted(self, f, dhist, dM, dR, Hn, T, G, seq_len, ls, ss):
+        """IndexedSlices of the history lookups -> dense gradient tables via sort + segmented sums."""
+        n = Hn * T
+        nbytes = self._sort_bytes.get(n)
+        if nbytes is None:
+            nbytes = self._sort_bytes[n] = max(query("clsr_sort_ids_workspace_bytes", n, self.dims["Vi"]),
+                                               query("clsr_sort_ids_workspace_bytes", n, self.dims["Vc"]))
+        ws = self._buf("sort.ws", nbytes, dtype=torch.uint8)
+        k = self.hp.contrastive_recent_k
+        for name, idx, V, col0, C, slot in (("item", f["item_history"], self.dims["Vi"], 0, self.Di, 0),
+                                            ("cate", f["item_cate_history"], self.dims["Vc"], self.Di, self.Dc, 1)):
+            keys = self._buf("sort.keys." + name, n, dtype=torch.int32)
+            perm = self._buf("sort.perm." + name, n, dtype=torch.int32)
+            call("clsr_sort_ids", idx, Hn, T, G * T, V, keys, perm, ws, nbytes)
+            for c0 in range(0, C, 64):   # column blocks of <= 64 floats; squared norms accumulate in the slot
+                call("clsr_gather_bwd_sorted", dhist, dM, dR, keys, perm, seq_len, ls, n, T, self.D, col0 + c0,
+                     min(64, C - c0), k, self.tab_grad[name], C, c0, ss[slot:])
 
     def _apply_updates(self):
         hp = self.hp

@@ -47,6 +47,14 @@ int clsr_gather_rows(const float* tbl, const int* idx, long idx_stride, int N, i
                      int ldo, int col0, void* stream);
 int clsr_scatter_add_rows(const float* src, int ld_src, int col0, const int* idx, long idx_stride, int N,
                           int C, float* tbl_grad, double* sumsq, void* stream);
+/* Sorted segmented reduction of the history-lookup gradient: radix sort (id, position) pairs on the device,
+ * then sum runs of equal ids in registers (dedup of IndexedSlices) */
+long clsr_sort_ids_workspace_bytes(long n, long vocab);
+int clsr_sort_ids(const int* ids, long nrows, int ncols, long row_stride, long vocab, int* keys_out,
+                  int* perm_out, void* workspace, long workspace_bytes, void* stream);
+int clsr_gather_bwd_sorted(const float* dhist, const float* dmean, const float* drecent, const int* keys,
+                           const int* perm, const int* seq_len, int len_stride, long n, int T, int D, int col0,
+                           int C, int recent_k, float* grad, int ldg, int gcol0, double* sumsq, void* stream);
 /* "involved" id sets (tf.unique, sequential_base_model.py:409-433, clsr.py:118-127) as byte maps */
 int clsr_mark_rows(const int* idx, long nrows, int ncols, long row_stride, unsigned char* flags,
                    void* stream);

@@ -110,6 +110,42 @@ def test_gather_scatter_rows_and_flags():
     assert float(cnt) == float(exp_f.sum())
 
 
+@pytest.mark.parametrize("Hn,T,Di,Dc,G,V", [(64, 50, 32, 8, 5, 40), (33, 10, 32, 8, 1, 5000), (16, 7, 96, 32, 2, 300)])
+def test_sorted_segmented_history_gradient(Hn, T, Di, Dc, G, V):
+    """sort (id, position) pairs + run-length sums == index_add of every slice (heavy duplicates: V small)."""
+    g = torch.Generator().manual_seed(Hn)
+    D, k = Di + Dc, 3
+    B = Hn * G
+    lens = torch.randint(1, T + 1, (Hn,), generator=g).repeat_interleave(G)
+    idx = torch.randint(0, V, (Hn, T), generator=g).repeat_interleave(G, 0).contiguous()
+    dh, dm, dr = rnd(g, Hn, T, D), rnd(g, Hn, D), rnd(g, Hn, D)
+    n = Hn * T
+    nbytes = query("clsr_sort_ids_workspace_bytes", n, V)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    keys = torch.empty(n, dtype=torch.int32, device="cuda")
+    perm = torch.empty(n, dtype=torch.int32, device="cuda")
+    d_idx = dev(idx, torch.int32)
+    call("clsr_sort_ids", d_idx, Hn, T, G * T, V, keys, perm, ws, nbytes)
+    flat = idx[::G].reshape(-1)
+    ks, pm = keys.cpu().long(), perm.cpu().long()
+    assert torch.equal(ks, torch.sort(flat)[0]) and torch.equal(flat[pm], ks)
+    grad = torch.zeros(V, Di, device="cuda")
+    ss = torch.zeros(1, dtype=torch.float64, device="cuda")
+    d_len = dev(lens, torch.int32)
+    for c0 in range(0, Di, 64):
+        call("clsr_gather_bwd_sorted", dev(dh, torch.float32), dev(dm, torch.float32), dev(dr, torch.float32), keys,
+             perm, d_len, G, n, T, D, c0, min(64, Di - c0), k, grad, Di, c0, ss)
+    lh = lens[::G]
+    m = (torch.arange(T)[None, :] < lh[:, None]).double()
+    pos = torch.flip(torch.cumsum(torch.flip(m, [1]), 1), [1])
+    rec = ((pos >= 1) & (pos <= k)).double()
+    gfull = dh + m[..., None] * (dm / m.sum(1, keepdim=True))[:, None, :] \
+        + rec[..., None] * (dr / rec.sum(1, keepdim=True))[:, None, :]
+    exp = torch.zeros(V, Di, dtype=torch.float64).index_add_(0, flat, gfull[..., :Di].reshape(-1, Di))
+    close(grad, exp, rtol=1e-4, atol=1e-4, name="sorted grad")
+    close(ss, (gfull[..., :Di] ** 2).sum().reshape(1), rtol=1e-5, name="sumsq")
+
+
 # ------------------------------------------------------------------------------- pgemm
 def _pgemm(X, W, bias=None, T=0, G=0, Xmul=None, in_scale=None, in_shift=None, relu=0, addU=None,
            addV=None, Y=None, accumulate=0, stats=False, M=None, ldx=None):
