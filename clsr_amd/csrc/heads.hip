@@ -456,32 +456,51 @@ extern "C" int clsr_axpby(float* out, const float* a, float sa, const float* b, 
 // ------------------------------------------------------------------ attention layer-0 backward helpers
 // z0[r,t,:] = U[h,t,:] + V[r,:] + (a[h,t,:] * q[r,:]) . Wp    (the re-associated first att_fcn layer)
 // (1) dU[h,t,:] = sum_g dz0[(h,g),t,:]   dV[r,:] = sum_t dz0[r,t,:]
+// One wave per history group; lane -> (t slot, 16-byte column chunk).  For every step the G rows of the
+// group are loaded back to back (independent loads), summed in registers for dU (ONE store per element,
+// no read-modify-write) and accumulated per row for dV.
+#define ATT_MAXG 8
+template <bool BIGG>
 __global__ void __launch_bounds__(64) att_z0_bwd_reduce_kernel(const float* __restrict__ dz0, long Hn,
                                                                int G, int T, int C,
                                                                float* __restrict__ dU,
                                                                float* __restrict__ dV) {
   const int lane = threadIdx.x;
   const int QC = C >> 2, tpar = 64 / QC, ts = lane / QC, q = lane - ts * QC;
-  __shared__ f32x4 red[64];
+  __shared__ f32x4 red[ATT_MAXG][64];
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   for (long h = blockIdx.x; h < Hn; h += gridDim.x) {
-    for (int gi = 0; gi < G; ++gi) {
-      const long r = h * G + gi;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int g0 = 0; g0 < G; g0 += ATT_MAXG) {   // groups larger than ATT_MAXG rows: several passes
+      const int gc = min(ATT_MAXG, G - g0);
+      f32x4 accv[ATT_MAXG];
+#pragma unroll
+      for (int g = 0; g < ATT_MAXG; ++g) accv[g] = z4;
       if (ts < tpar) {
         for (int t = ts; t < T; t += tpar) {
-          const f32x4 d = ld4(dz0 + (r * T + t) * C + 4 * q);
-          acc += d;
+          f32x4 d[ATT_MAXG];
+#pragma unroll
+          for (int g = 0; g < ATT_MAXG; ++g)
+            d[g] = g < gc ? ld4(dz0 + ((h * G + g0 + g) * T + t) * C + 4 * q) : z4;
+          f32x4 su = z4;
+#pragma unroll
+          for (int g = 0; g < ATT_MAXG; ++g) { su += d[g]; accv[g] += d[g]; }
           if (dU) {
             float* up = dU + (h * T + t) * C + 4 * q;
-            st4(up, gi == 0 ? d : ld4(up) + d);
+            st4(up, g0 == 0 ? su : ld4(up) + su);
           }
         }
       }
-      red[lane] = acc;
+#pragma unroll
+      for (int g = 0; g < ATT_MAXG; ++g) red[g][lane] = accv[g];
       __syncthreads();
       if (ts == 0) {
-        for (int s = 1; s < tpar; ++s) acc += red[lane + s * QC];
-        st4(dV + r * C + 4 * q, acc);
+#pragma unroll
+        for (int g = 0; g < ATT_MAXG; ++g)
+          if (g < gc) {
+            f32x4 v = accv[g];
+            for (int s2 = 1; s2 < tpar; ++s2) v += red[g][lane + s2 * QC];
+            st4(dV + (h * G + g0 + g) * C + 4 * q, v);
+          }
       }
       __syncthreads();
     }
@@ -493,14 +512,15 @@ extern "C" int clsr_att_z0_bwd_reduce(const float* dz0, long Hn, int G, int T, i
   CLSR_CHECK_ARG(dz0 && dV && Hn > 0 && G > 0 && T > 0);
   CLSR_CHECK_SUPPORTED(C % 4 == 0 && C <= 256);
   int blocks = Hn > 8192 ? 8192 : (int)Hn;
-  hipLaunchKernelGGL(att_z0_bwd_reduce_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, dz0, Hn, G,
-                     T, C, dU, dV);
+  hipLaunchKernelGGL(att_z0_bwd_reduce_kernel<false>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, dz0, Hn,
+                     G, T, C, dU, dV);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
 
 // (2) given daq = dz0 . Wp^T  [R*T, Q]:  da[h,t,:] = sum_g daq[(h,g),t,:] * q[(h,g),:]
 //                                        dq[r,:]   = sum_t daq[r,t,:] * a[h,t,:]
+// Same loop structure as (1): the G rows of a step are loaded together, da gets one store.
 __global__ void __launch_bounds__(64) att_prod_bwd_kernel(const float* __restrict__ daq,
                                                           const float* __restrict__ a,
                                                           const float* __restrict__ q, long Hn, int G,
@@ -508,25 +528,42 @@ __global__ void __launch_bounds__(64) att_prod_bwd_kernel(const float* __restric
                                                           float* __restrict__ dq) {
   const int lane = threadIdx.x;
   const int QQ = Q >> 2, tpar = 64 / QQ, ts = lane / QQ, qq = lane - ts * QQ;
-  __shared__ f32x4 red[64];
+  __shared__ f32x4 red[ATT_MAXG][64];
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   for (long h = blockIdx.x; h < Hn; h += gridDim.x) {
-    for (int gi = 0; gi < G; ++gi) {
-      const long r = h * G + gi;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int g0 = 0; g0 < G; g0 += ATT_MAXG) {
+      const int gc = min(ATT_MAXG, G - g0);
+      f32x4 accq[ATT_MAXG], qv[ATT_MAXG];
+#pragma unroll
+      for (int g = 0; g < ATT_MAXG; ++g) {
+        accq[g] = z4;
+        qv[g] = (g < gc && ts < tpar) ? ld4(q + (h * G + g0 + g) * Q + 4 * qq) : z4;
+      }
       if (ts < tpar) {
-        const f32x4 qv = ld4(q + r * Q + 4 * qq);
         for (int t = ts; t < T; t += tpar) {
-          const f32x4 d = ld4(daq + (r * T + t) * Q + 4 * qq);
-          acc += d * ld4(a + (h * T + t) * Q + 4 * qq);
+          const f32x4 av = ld4(a + (h * T + t) * Q + 4 * qq);
+          f32x4 d[ATT_MAXG];
+#pragma unroll
+          for (int g = 0; g < ATT_MAXG; ++g)
+            d[g] = g < gc ? ld4(daq + ((h * G + g0 + g) * T + t) * Q + 4 * qq) : z4;
+          f32x4 su = z4;
+#pragma unroll
+          for (int g = 0; g < ATT_MAXG; ++g) { su += d[g] * qv[g]; accq[g] += d[g] * av; }
           float* ap = da + (h * T + t) * Q + 4 * qq;
-          st4(ap, gi == 0 ? d * qv : ld4(ap) + d * qv);
+          st4(ap, g0 == 0 ? su : ld4(ap) + su);
         }
       }
-      red[lane] = acc;
+#pragma unroll
+      for (int g = 0; g < ATT_MAXG; ++g) red[g][lane] = accq[g];
       __syncthreads();
       if (ts == 0) {
-        for (int s = 1; s < tpar; ++s) acc += red[lane + s * QQ];
-        st4(dq + r * Q + 4 * qq, acc);
+#pragma unroll
+        for (int g = 0; g < ATT_MAXG; ++g)
+          if (g < gc) {
+            f32x4 v = accq[g];
+            for (int s2 = 1; s2 < tpar; ++s2) v += red[g][lane + s2 * QQ];
+            st4(dq + (h * G + g0 + g) * Q + 4 * qq, v);
+          }
       }
       __syncthreads();
     }

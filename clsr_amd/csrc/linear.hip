@@ -28,6 +28,9 @@ struct PGemmArgs {
   float* Y; int ldy; int accumulate;
   double* stats;                  // optional per-block partial column sums [gridDim.x][2][N]
   int M, K, N;
+  // optional BN+ReLU backward epilogue: v = (ez*e_scale + e_shift > 0) ? v : 0 and the column sums become
+  // (sum v, sum v * xhat) with xhat = (ez - e_mean) * e_invstd  (ez = pre-BN activation at [m, n])
+  const float* ez; int ldez; const float* e_scale; const float* e_shift; const float* e_mean; const float* e_invstd;
 };
 
 template <int OT, bool STATS>
@@ -117,12 +120,20 @@ __global__ void __launch_bounds__(256) pgemm_kernel(PGemmArgs a) {
           if (a.addV) v += ld4(a.addV + r * a.ldv + n);
           float* yp = a.Y + (long)m * a.ldy + n;
           if (a.accumulate) v += ld4(yp);
+          f32x4 w2 = v;  // second factor of the squared-sum accumulator
+          if (a.ez) {
+            const f32x4 zz = ld4(a.ez + (long)m * a.ldez + n);
+            const f32x4 y = zz * ld4(a.e_scale + n) + ld4(a.e_shift + n);
+            v.x = y.x > 0.f ? v.x : 0.f; v.y = y.y > 0.f ? v.y : 0.f;
+            v.z = y.z > 0.f ? v.z : 0.f; v.w = y.w > 0.f ? v.w : 0.f;
+            w2 = (zz - ld4(a.e_mean + n)) * ld4(a.e_invstd + n);
+          }
           st4(yp, v);
           if (STATS) {
-            dsum[ot][0] += v.x; dsq[ot][0] += (double)v.x * v.x;
-            dsum[ot][1] += v.y; dsq[ot][1] += (double)v.y * v.y;
-            dsum[ot][2] += v.z; dsq[ot][2] += (double)v.z * v.z;
-            dsum[ot][3] += v.w; dsq[ot][3] += (double)v.w * v.w;
+            dsum[ot][0] += v.x; dsq[ot][0] += (double)v.x * w2.x;
+            dsum[ot][1] += v.y; dsq[ot][1] += (double)v.y * w2.y;
+            dsum[ot][2] += v.z; dsq[ot][2] += (double)v.z * w2.z;
+            dsum[ot][3] += v.w; dsq[ot][3] += (double)v.w * w2.w;
           }
         }
       }
@@ -189,6 +200,25 @@ static int launch_pgemm(const PGemmArgs& a, hipStream_t stream) {
   return CLSR_OK;
 }
 
+static int pgemm_dispatch(const PGemmArgs& a, hipStream_t s);
+
+// dy[m, :N] = mask(dY_next[m, :K] . W^T) with mask = (z*scale + shift > 0)  -- the product that
+// back-propagates through a linear layer fused with the ReLU + batch-norm backward reduction of the
+// layer below: stats receives per-block partial (sum dy, sum dy*xhat) for clsr_bn_bwd_coef.
+extern "C" int clsr_pgemm_bnbwd(const float* X, int ldx, const float* Wt, int Kp, float* Y, int ldy,
+                                const float* z, int ldz, const float* scale, const float* shift,
+                                const float* mean, const float* invstd, double* stats, int M, int K, int N,
+                                void* stream) {
+  CLSR_CHECK_ARG(X && Wt && Y && z && scale && shift && mean && invstd && stats && M > 0 && K > 0 && N > 0);
+  CLSR_CHECK_SUPPORTED(K % 4 == 0 && N % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldz % 4 == 0 && Kp % 4 == 0);
+  CLSR_CHECK_ARG(Kp >= 16 * clsr_cdiv(K, 16));
+  PGemmArgs a = {};
+  a.X = X; a.ldx = ldx; a.Wt = Wt; a.Kp = Kp; a.Y = Y; a.ldy = ldy; a.stats = stats; a.M = M; a.K = K; a.N = N;
+  a.in_relu = 1;
+  a.ez = z; a.ldez = ldz; a.e_scale = scale; a.e_shift = shift; a.e_mean = mean; a.e_invstd = invstd;
+  return pgemm_dispatch(a, (hipStream_t)stream);
+}
+
 // Y[m, :N] (=|+=) f(X)[xrow(m), :K] . W + bias + addU[xrow(m)] + addV[r(m)]
 //   f = optional (* Xmul[r(m)]) then optional (x*in_scale + in_shift, relu)
 // Wt is the packed transposed weight from clsr_pack_weight (row stride Kp).
@@ -212,8 +242,12 @@ extern "C" int clsr_pgemm(const float* X, int ldx, int T, int G, const float* Xm
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
   a.Wt = Wt; a.Kp = Kp; a.bias = bias; a.addU = addU; a.ldu = ldu; a.addV = addV; a.ldv = ldv;
   a.Y = Y; a.ldy = ldy; a.accumulate = accumulate; a.stats = stats; a.M = M; a.K = K; a.N = N;
-  const int nt = clsr_cdiv(N, 16);
-  hipStream_t s = (hipStream_t)stream;
+  a.ez = nullptr; a.ldez = 0; a.e_scale = a.e_shift = a.e_mean = a.e_invstd = nullptr;
+  return pgemm_dispatch(a, (hipStream_t)stream);
+}
+
+static int pgemm_dispatch(const PGemmArgs& a, hipStream_t s) {
+  const int nt = clsr_cdiv(a.N, 16);
   if (nt <= 3) return launch_pgemm<3>(a, s);
   if (nt <= 5) return launch_pgemm<5>(a, s);
   if (nt <= 8) return launch_pgemm<8>(a, s);

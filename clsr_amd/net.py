@@ -333,6 +333,15 @@ class CLSRNet(object):
             call("clsr_axpby", bn.dbeta, bn.dbeta, inv, None, 0.0, bn.C)
         call("clsr_bn_bwd_apply", dy, z, bn.coef, M, bn.C)
 
+    def _gemm_bnbwd(self, dY, ldy_in, wkey, M, K, N, out, bn, z):
+        """out = relu-mask(dY . W^T) fused with the BN backward sums of layer ``bn`` (pre-BN activation z),
+        then the coefficient + apply pass: ``out`` ends up holding dz of that layer."""
+        Wt, Kp = self.packed[wkey]
+        parts = query("clsr_pgemm_stats_parts", M)
+        st = self._buf("stats" + self._ws_tag, 1024 * 2 * 256, dtype=torch.float64)[: parts * 2 * N]
+        call("clsr_pgemm_bnbwd", dY, ldy_in, Wt, Kp, out, N, z, N, bn.scale, bn.shift, bn.mean, bn.invstd, st, M, K, N)
+        self._bn_bwd_from_partial(bn, st, parts, out, z, M)
+
     def _bn_relu_bwd(self, bn, dh, z, M):
         parts = query("clsr_colred_parts", M, bn.C)
         part = self._buf("colred" + self._ws_tag, 2048 * 2 * 256, dtype=torch.float64)[: parts * 2 * bn.C]
@@ -535,8 +544,7 @@ class CLSRNet(object):
         self._bn_bwd_from_partial(bn1, bnp, parts, dz1, z1, R * T)
         # layer 1: z1 = relu(bn0(z0)) . W1 + b1
         self._dw(z0, A0, dz1, A1, R * T, A0, A1, Gd[nn + "w_nn_layer1"], A1, db=Gd[nn + "b_nn_layer1"], aff=bn0)
-        self._gemm(dz1, A1, key + ".W1^T", R * T, A1, A0, dz0, A0)
-        self._bn_relu_bwd(bn0, dz0, z0, R * T)
+        self._gemm_bnbwd(dz1, A1, key + ".W1^T", R * T, A1, A0, dz0, bn0, z0)
         # layer 0 (re-associated): z0 = U[h,t] + V[r] + (a[h,t]*q[r]) . Wp
         dW0 = Gd[nn + "w_nn_layer0"]
         self._dw(a, Q, dz0, A0, R * T, Q, A0, dW0[3 * Q:4 * Q], A0, T=T, G=G, Xmul=q, ldmul=Q)
@@ -593,8 +601,7 @@ class CLSRNet(object):
         call("clsr_reduce_parts", wp[C1:], parts, C1 + 4, 1, 1.0, Gd[nn + "b_nn_output"], 0)
         self._bn_bwd_from_partial(bn1, bnp, parts, dz1, z1, B)
         self._dw(z0, C0, dz1, C1, B, C0, C1, Gd[nn + "w_nn_layer1"], C1, db=Gd[nn + "b_nn_layer1"], aff=bn0)
-        self._gemm(dz1, C1, key + ".W1^T", B, C1, C0, dz0, C0)
-        self._bn_relu_bwd(bn0, dz0, z0, B)
+        self._gemm_bnbwd(dz1, C1, key + ".W1^T", B, C1, C0, dz0, bn0, z0)
         self._dw(X, ldx, dz0, C0, B, K0_real, C0, Gd[nn + "w_nn_layer0"], C0, db=Gd[nn + "b_nn_layer0"])
         dX = self._buf(key + ".dX", B, K0)
         self._gemm(dz0, C0, key + ".W0^T", B, C0, K0, dX, K0)

@@ -79,6 +79,10 @@ int clsr_pgemm(const float* X, int ldx, int T, int G, const float* Xmul, int ldm
                const float* in_scale, const float* in_shift, int in_relu, const float* Wt, int Kp,
                const float* bias, const float* addU, int ldu, const float* addV, int ldv, float* Y,
                int ldy, int accumulate, double* stats, int M, int K, int N, void* stream);
+/* back-propagating product fused with the ReLU + BN backward reduction of the layer below */
+int clsr_pgemm_bnbwd(const float* X, int ldx, const float* Wt, int Kp, float* Y, int ldy, const float* z,
+                     int ldz, const float* scale, const float* shift, const float* mean, const float* invstd,
+                     double* stats, int M, int K, int N, void* stream);
 long clsr_pgemm_dw_workspace_floats(int M, int K, int N);
 int clsr_pgemm_dw(const float* X, int ldx, int T, int G, const float* Xmul, int ldmul,
                   const float* in_scale, const float* in_shift, int in_relu, const float* dY, int ldy,
