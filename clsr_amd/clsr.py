@@ -25,6 +25,34 @@ from clsr_amd.net import CLSRNet
 
 __all__ = ["BaseModel", "SequentialBaseModel", "CLSRModel", "latest_checkpoint"]
 
+
+def _prefetch(gen, depth=3):
+    """Run a feed generator in a background thread, ``depth`` batches ahead of the consumer
+    (the numpy collate releases the GIL in its large copies, so it overlaps with the GPU step)."""
+    import queue
+    import threading
+
+    q = queue.Queue(maxsize=depth)
+    end = object()
+
+    def work():
+        try:
+            for item in gen:
+                q.put(item)
+            q.put(end)
+        except BaseException as e:  # surface iterator errors in the consumer
+            q.put(e)
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    while True:
+        item = q.get()
+        if item is end:
+            break
+        if isinstance(item, BaseException):
+            raise item
+        yield item
+
 _CKPT_INDEX = "checkpoint"
 
 
@@ -92,7 +120,7 @@ class BaseModel(object):
 
 
 class SequentialBaseModel(BaseModel):
-    def __init__(self, hparams, iterator_creator, graph=None, seed=None, device="cuda:0", use_graph=True,
+    def __init__(self, hparams, iterator_creator, graph=None, seed=None, device="cuda:0", use_graph=False,
                  dedup_histories=True):
         """Reference ``SequentialBaseModel.__init__`` (:19-48): requires ``train_num_ngs``."""
         self.hparams = hparams
@@ -107,6 +135,7 @@ class SequentialBaseModel(BaseModel):
         self._dedup = dedup_histories
         self._graphs = {}
         self._static = {}
+        self._stream = None
         self.best_epoch = 0
         super(SequentialBaseModel, self).__init__(hparams, iterator_creator, graph=graph, seed=seed)
 
@@ -131,61 +160,61 @@ class SequentialBaseModel(BaseModel):
                  "time_from_first_action", "time_to_now")}
 
     def _static_feed(self, feed, training):
-        """Copy a numpy feed into static device buffers keyed by (rows, T, mode)."""
-        net = self.net
-        fresh = net.upload(feed, training)
-        key = (fresh["B"], fresh["T"], bool(training))
+        """Copy a numpy feed into static device buffers keyed by (rows, T, mode) through persistent
+        pinned staging buffers (no per-step allocation)."""
+        mask = feed["mask"]
+        key = (int(mask.shape[0]), int(mask.shape[1]), bool(training))
         st = self._static.get(key)
         if st is None:
-            self._static[key] = fresh
-            return key, fresh, True
-        for k, v in fresh.items():
-            if isinstance(v, torch.Tensor):
-                st[k].copy_(v, non_blocking=True)
-        return key, st, False
+            st = self._static[key] = self.net.upload(feed, training)
+            return key, st, True
+        return key, self.net.upload(feed, training, into=st), False
+
+    def _stream_ctx(self):
+        """All device work of the model runs on one private HIP stream: launches on the legacy
+        default stream pay an implicit-synchronisation tax per kernel (measured 200 us vs 10 us)."""
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=self.net.device)
+        return torch.cuda.stream(self._stream)
 
     def _train_step(self, feed):
         net = self.net
-        key, f, _ = self._static_feed(feed, True)
-        if not self._use_graph:
-            net.train_step(f)
-            return
-        g = self._graphs.get(key)
-        if g is None:
-            if "stream" not in self._graphs:
-                self._graphs["stream"] = torch.cuda.Stream(device=net.device)
-            s = self._graphs["stream"]
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
+        with self._stream_ctx():
+            key, f, _ = self._static_feed(feed, True)
+            if not self._use_graph:
+                net.train_step(f)       # ~2 ms of host time for ~190 launches, hidden behind the GPU
+                return
+            # optional hipGraph replay (one graph per batch shape).  hipGraphLaunch costs ~6.7 ms of
+            # host time for this graph on ROCm 7.2, so it only pays when steps are enqueued back to back.
+            g = self._graphs.get(key)
+            if g is None:
                 net.train_step(f)               # eager: THIS is the step for this batch (also allocates
-                s.synchronize()                 # every workspace buffer the capture below will reference)
+                self._stream.synchronize()      # every workspace buffer the capture below will reference)
                 ops.graph_begin()
                 net.train_step(f)               # recorded only, nothing executes during capture
-                g = ops.graph_end()
-            torch.cuda.current_stream().wait_stream(s)
-            self._graphs[key] = g
-            return
-        s = self._graphs["stream"]
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
+                self._graphs[key] = ops.graph_end()
+                return
             ops.graph_launch(g)
-        torch.cuda.current_stream().wait_stream(s)
 
     # ------------------------------------------------------------------ per-step API
     def train(self, sess, feed_dict):
         """One optimisation step (reference CLSRModel.train, clsr.py:383-408).  Returns the same 8-list:
         [update, extra_update_ops, loss, data_loss, regular_loss, contrastive_loss, discrepancy_loss, summary]."""
         self._train_step(self._to_arrays(feed_dict))
-        ls = self.net.read_losses()
+        with self._stream_ctx():
+            ls = self.net.read_losses()
         return [None, [], ls["loss"], ls["data_loss"], ls["regular_loss"], ls["contrastive_loss"],
                 ls["discrepancy_loss"], None]
 
     def _score(self, feed_dict):
         feed = self._to_arrays(feed_dict)
-        key, f, _ = self._static_feed(feed, False)
-        out = self.net.forward(f, False)
-        pred = torch.sigmoid(out["logit"]) if self.hparams.method == "classification" else out["logit"]
-        return feed, pred.detach().cpu().numpy().reshape(-1, 1), out
+        with self._stream_ctx():
+            key, f, _ = self._static_feed(feed, False)
+            out = self.net.forward(f, False)
+            pred = torch.sigmoid(out["logit"]) if self.hparams.method == "classification" else out["logit"]
+            pred = pred.detach().cpu().numpy().reshape(-1, 1)
+            out = dict(out, alpha=out["alpha"].detach().cpu())
+        return feed, pred, out
 
     def eval(self, sess, feed_dict):
         feed, pred, _ = self._score(feed_dict)
@@ -198,7 +227,7 @@ class SequentialBaseModel(BaseModel):
 
     def eval_with_user_and_alpha(self, sess, feed_dict):
         feed, pred, out = self._score(feed_dict)
-        alpha = out["alpha"].detach().cpu().numpy().reshape(-1, 1)
+        alpha = out["alpha"].numpy().reshape(-1, 1)
         return (np.asarray(feed["users"]).astype(np.int32), pred, np.asarray(feed["labels"]).reshape(-1, 1), alpha)
 
     def infer(self, sess, feed_dict):
@@ -209,17 +238,21 @@ class SequentialBaseModel(BaseModel):
     def batch_train(self, file_iterator, train_sess):
         """One epoch of mini-batches (reference clsr.py:410-446); returns the summed loss."""
         step = 0
-        epoch_loss = 0
-        for batch_data_input in file_iterator:
+        net = self.net
+        with self._stream_ctx():
+            acc = torch.zeros(8, dtype=torch.float64, device=net.device)  # running loss sums stay on the device
+        for batch_data_input in _prefetch(file_iterator):
             if batch_data_input:
-                res = self.train(train_sess, batch_data_input)
-                (_, _, step_loss, step_data_loss, _, _, _, _) = res
-                epoch_loss += step_loss
-                step += 1
-                if step % self.hparams.show_step == 0:
-                    print("step {0:d} , total_loss: {1:.4f}, data_loss: {2:.4f}".format(step, step_loss,
-                                                                                       step_data_loss))
-        return epoch_loss
+                self._train_step(self._to_arrays(batch_data_input))     # no host sync per step
+                with self._stream_ctx():
+                    ops.call("clsr_add_doubles", acc, net.losses, 8)
+                    step += 1
+                    if step % self.hparams.show_step == 0:
+                        ls = net.read_losses()                          # synchronises (only when printing)
+                        print("step {0:d} , total_loss: {1:.4f}, data_loss: {2:.4f}".format(step, ls["loss"],
+                                                                                           ls["data_loss"]))
+        with self._stream_ctx():
+            return float(acc[:4].sum().item())
 
     def fit(self, train_file, valid_file, valid_num_ngs, eval_metric="group_auc"):
         """Train with per-epoch validation, early stopping and best-epoch checkpoints

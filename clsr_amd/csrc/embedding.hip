@@ -157,7 +157,12 @@ __global__ void __launch_bounds__(256) gather_hist_bwd_kernel(
     const int* __restrict__ cate_idx, long idx_row_stride, const int* __restrict__ seq_len,
     int len_stride, int Hn, int T, int Di, int Dc, int recent_k, float* __restrict__ item_grad,
     float* __restrict__ cate_grad, double* __restrict__ sumsq) {
+  // Row 0 (padding / out-of-vocabulary id) receives the gradient of EVERY padded step: its slices are
+  // first summed per block in LDS (ds_add_f32) and reach the table as one atomic per column per block.
+  extern __shared__ float row0_acc[];  // [D]
   const int D = Di + Dc;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) row0_acc[d] = 0.f;
+  __syncthreads();
   const long total = (long)Hn * T * D;
   float s_item = 0.f, s_cate = 0.f;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -175,10 +180,22 @@ __global__ void __launch_bounds__(256) gather_hist_bwd_kernel(
     }
     if (d < Di) {
       s_item += g * g;
-      atomicAdd(item_grad + (long)item_idx[(long)h * idx_row_stride + t] * Di + d, g);
+      const int id = item_idx[(long)h * idx_row_stride + t];
+      if (id == 0) atomicAdd(row0_acc + d, g);
+      else atomicAdd(item_grad + (long)id * Di + d, g);
     } else {
       s_cate += g * g;
-      atomicAdd(cate_grad + (long)cate_idx[(long)h * idx_row_stride + t] * Dc + (d - Di), g);
+      const int id = cate_idx[(long)h * idx_row_stride + t];
+      if (id == 0) atomicAdd(row0_acc + d, g);
+      else atomicAdd(cate_grad + (long)id * Dc + (d - Di), g);
+    }
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    const float v = row0_acc[d];
+    if (v != 0.f) {
+      if (d < Di) atomicAdd(item_grad + d, v);
+      else atomicAdd(cate_grad + (d - Di), v);
     }
   }
   if (sumsq) {
@@ -202,7 +219,8 @@ extern "C" int clsr_gather_hist_bwd(const float* dhist, const float* dmean, cons
   if (Hn == 0) return CLSR_OK;
   int blocks = clsr_cdiv((long)Hn * T * (Di + Dc), 256 * 4);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(gather_hist_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dhist,
+  hipLaunchKernelGGL(gather_hist_bwd_kernel, dim3(blocks), dim3(256), (Di + Dc) * sizeof(float),
+                     (hipStream_t)stream, dhist,
                      dmean, drecent, item_idx, cate_idx, idx_row_stride, seq_len, len_stride, Hn, T,
                      Di, Dc, recent_k, item_grad, cate_grad, sumsq);
   CLSR_CHECK_LAUNCH();

@@ -248,3 +248,36 @@ extern "C" int clsr_zero_floats(float* p, long n, void* stream) {
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
+
+// dst[i] += src[i] (doubles): running sums of the per-step loss terms kept on the device so that an
+// epoch loop does not have to synchronise after every step
+__global__ void add_d_kernel(double* dst, const double* src, int n) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) dst[e] += src[e];
+}
+extern "C" int clsr_add_doubles(double* dst, const double* src, int n, void* stream) {
+  CLSR_CHECK_ARG(dst && src && n > 0);
+  hipLaunchKernelGGL(add_d_kernel, dim3(clsr_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, dst, src, n);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// dst[0..n16) = src[0..n16) in 16-byte words.  ``src`` is PINNED HOST memory (hipHostMalloc: mapped into
+// the device address space), read by the kernel straight over PCIe: the feed upload becomes an ordinary
+// kernel launch on the step's stream (one launch for the whole feed instead of ten hipMemcpyAsync).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__global__ void stage_words_kernel(u32x4* __restrict__ dst, const u32x4* __restrict__ src, long n16) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n16; e += (long)gridDim.x * blockDim.x)
+    dst[e] = __builtin_nontemporal_load(src + e);
+}
+extern "C" int clsr_stage_feed(void* dst, const void* src_host, long nbytes, void* stream) {
+  CLSR_CHECK_ARG(dst && src_host && nbytes > 0 && nbytes % 16 == 0);
+  CLSR_CHECK_ARG(((uintptr_t)dst % 16) == 0 && ((uintptr_t)src_host % 16) == 0);
+  const long n16 = nbytes / 16;
+  int blocks = clsr_cdiv(n16, 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(stage_words_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (u32x4*)dst,
+                     (const u32x4*)src_host, n16);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}

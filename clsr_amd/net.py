@@ -477,24 +477,62 @@ class CLSRNet(object):
         return (self.H if hp.predict_long_short else 0) + 3 * self.D + 1
 
     # ------------------------------------------------------------------ feed upload
-    def upload(self, feed, training):
-        """numpy feed (iterator layout) -> device tensors (+ per-batch scalars)."""
-        dev = self.device
+    def host_arrays(self, feed):
+        """numpy feed (iterator layout) -> dict of contiguous numpy arrays with the device dtypes
+        (+ the per-batch scalars the kernels read from device memory)."""
         mask = np.asarray(feed["mask"])
         seq_len = mask.sum(1).astype(np.int32)
-        f = {}
-        f["users"] = torch.as_tensor(np.asarray(feed["users"]).astype(np.int32)).to(dev)
+        h = {"users": np.ascontiguousarray(np.asarray(feed["users"]), dtype=np.int32)}
         for k in ("items", "cates", "item_history", "item_cate_history"):
-            f[k] = torch.as_tensor(np.ascontiguousarray(feed[k], dtype=np.int32)).to(dev)
+            h[k] = np.ascontiguousarray(feed[k], dtype=np.int32)
         for k in ("time_from_first_action", "time_to_now"):
-            f[k] = torch.as_tensor(np.ascontiguousarray(feed[k], dtype=np.float32)).to(dev)
-        f["labels"] = torch.as_tensor(np.ascontiguousarray(feed["labels"], dtype=np.float32).reshape(-1)).to(dev)
-        f["seq_len"] = torch.as_tensor(seq_len).to(dev)
-        denom = float((seq_len > self.hp.contrastive_length_threshold).sum())
-        f["denom"] = torch.tensor([denom], dtype=F32, device=dev)
-        f["B"] = int(mask.shape[0])
-        f["T"] = int(mask.shape[1])
-        return f
+            h[k] = np.ascontiguousarray(feed[k], dtype=np.float32)
+        h["labels"] = np.ascontiguousarray(np.asarray(feed["labels"]).reshape(-1), dtype=np.float32)
+        h["seq_len"] = seq_len
+        h["denom"] = np.asarray([float((seq_len > self.hp.contrastive_length_threshold).sum())], dtype=np.float32)
+        return h, int(mask.shape[0]), int(mask.shape[1])
+
+    _STAGE_SLOTS = 3
+
+    def upload(self, feed, training, into=None):
+        """numpy feed -> device tensors (views into ONE device arena).  The arrays are packed into a
+        pinned host arena and pulled across PCIe by ``clsr_stage_feed`` -- an ordinary kernel launch on
+        the current stream, so the upload never blocks the host behind queued device work.  ``into``
+        (a dict returned by an earlier call for the same shape) re-uses the device arena and a ring of
+        pinned arenas: no allocation, and a pinned slot is only rewritten once the kernel that read it
+        has completed (event per slot)."""
+        h, B, T = self.host_arrays(feed)
+        if into is None:
+            lay, off = {}, 0
+            for k, arr in h.items():
+                lay[k] = (off, arr.nbytes)
+                off += (arr.nbytes + 15) // 16 * 16
+            dev = torch.empty(off, dtype=torch.uint8, device=self.device)
+            into = {"B": B, "T": T, "_lay": lay, "_nbytes": off, "_dev": dev, "_slot": 0,
+                    "_stage": [None] * self._STAGE_SLOTS}
+            for k, arr in h.items():
+                o, n = lay[k]
+                into[k] = dev[o:o + n].view(torch.from_numpy(arr).dtype).view(arr.shape)
+        assert into["B"] == B and into["T"] == T
+        slot = into["_slot"]
+        into["_slot"] = (slot + 1) % self._STAGE_SLOTS
+        if into["_stage"][slot] is None:
+            pin = torch.empty(into["_nbytes"], dtype=torch.uint8, pin_memory=True)
+            into["_stage"][slot] = [pin, None, pin.numpy()]
+        pin, ev, pin_np = into["_stage"][slot]
+        if ev is not None:
+            ev.synchronize()
+        for k, arr in h.items():
+            o, n = into["_lay"][k]
+            assert arr.nbytes == n
+            # plain single-threaded memcpy on purpose: a torch CPU copy_ wakes the whole OpenMP pool,
+            # whose spinning workers were measured to stall this thread's kernel launches for ~7 ms/step
+            np.copyto(pin_np[o:o + n], arr.reshape(-1).view(np.uint8))
+        call("clsr_stage_feed", into["_dev"], pin.data_ptr(), into["_nbytes"])
+        ev = torch.cuda.Event()
+        ev.record()
+        into["_stage"][slot][1] = ev
+        return into
 
     # ------------------------------------------------------------------ attention block
     def _att_fwd(self, key, scope, keys, q, Hn, G, T, Dk, Q, seq_len, len_stride, training):

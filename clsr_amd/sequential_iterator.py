@@ -10,10 +10,11 @@ given ``random.seed`` the produced feeds are bit-identical to the reference's
 Differences by design:
 * feeds are keyed by field-name strings (``iterator.labels == "labels"`` ...)
   instead of TF placeholders -- ``feed[iterator.users]`` keeps working;
-* the O(P*G*T) python loops of ``_convert_data`` (ref ``:588-634``) are replaced by
-  vectorised numpy scatter; only the negative-sampling draw (``random.randint``
-  rejection loop, ref ``:622-634``) stays a python loop because its RNG call
-  sequence is part of the observable behaviour.
+* the O(P*G*T) python loops of ``_convert_data`` (ref ``:588-634``) are replaced by a per-file
+  column store (every line padded once) + row gathers; the negative-sampling draws
+  (``random.randint`` rejection loop, ref ``:622-634``) replay the ``random`` module's
+  Mersenne-Twister stream in numpy, so the RNG call sequence -- part of the observable
+  behaviour -- is reproduced bit for bit.
 """
 import random
 
@@ -58,6 +59,8 @@ class SequentialIterator(BaseIterator):
         self.max_seq_length = hparams.max_seq_length
         self.batch_size = hparams.batch_size
         self.iter_data = dict()
+        self._columns = dict()
+        self._order = dict()
         self.time_unit = hparams.time_unit
         self.graph = graph
         # feed keys (the reference exposes placeholders under these attribute names)
@@ -133,27 +136,86 @@ class SequentialIterator(BaseIterator):
         Parsed files are cached in ``self.iter_data``; when ``batch_num_ngs > 0`` the
         cached list is shuffled in place with ``random.shuffle`` every call.  Yields
         ``None`` for a training batch the reference drops (fewer than 5 lines).
+
+        Fast path: the padded / truncated per-line arrays are built ONCE per file
+        (``self._columns``); a batch is then a row gather, and the in-batch negative
+        sampling replays the global ``random`` module's Mersenne-Twister stream in numpy
+        (bit-identical draws, see :func:`_sample_negatives`).
         """
         if infile not in self.iter_data:
             self.iter_data[infile] = self.parse_file(infile)
         lines = self.iter_data[infile]
+        cols = self._columns_of(infile, lines)
+        # the reference shuffles the cached list of parsed lines in place on every training pass
+        # (cumulative permutation); shuffling a persistent index list consumes the same random numbers
+        # and yields the same order without touching the column store
+        perm = self._order.setdefault(infile, list(range(len(lines))))
         if batch_num_ngs > 0:
-            random.shuffle(lines)
-
-        chunk = []
-        for line in lines:
-            if not line:
-                continue
-            if len(line[4]) < min_seq_length:
-                continue
-            chunk.append(line)
-            if len(chunk) == self.batch_size:
-                feed = self.gen_feed_dict(self._convert_chunk(chunk, batch_num_ngs))
-                yield feed if feed else None
-                chunk = []
-        if chunk:
-            feed = self.gen_feed_dict(self._convert_chunk(chunk, batch_num_ngs))
+            random.shuffle(perm)
+        order = np.asarray(perm, dtype=np.int64)
+        keep = order[cols["full_len"][order] >= min_seq_length]
+        for a in range(0, len(keep), self.batch_size):
+            sel = keep[a:a + self.batch_size]
+            feed = self.gen_feed_dict(self._convert_rows(cols, sel, batch_num_ngs))
             yield feed if feed else None
+
+    def _columns_of(self, infile, lines):
+        """Per-file column store: every parsed line padded once (most recent T actions, left aligned)."""
+        cols = self._columns.get(infile)
+        if cols is not None and cols["n"] == len(lines):
+            return cols
+        lens, item_hist, cate_hist, mask, tdiff, tfirst, tnow = self._pad_histories(
+            [l[4] for l in lines], [l[5] for l in lines], [l[7] for l in lines], [l[8] for l in lines],
+            [l[9] for l in lines])
+        cols = dict(
+            n=len(lines), lens=lens, full_len=np.fromiter((len(l[4]) for l in lines), np.int64,
+                                                                             len(lines)),
+            labels=np.asarray([l[0] for l in lines], dtype=np.float32),
+            users=np.asarray([l[1] for l in lines], dtype=np.int32),
+            items=np.asarray([l[2] for l in lines], dtype=np.int32),
+            cates=np.asarray([l[3] for l in lines], dtype=np.int32),
+            time=np.asarray([l[6] for l in lines], dtype=np.float32),
+            item_history=item_hist, item_cate_history=cate_hist, mask=mask, time_diff=tdiff,
+            time_from_first_action=tfirst, time_to_now=tnow)
+        self._columns[infile] = cols
+        return cols
+
+    def _convert_rows(self, cols, sel, batch_num_ngs):
+        """Same result as ``_convert_data`` on the selected lines, from the cached columns."""
+        n = len(sel)
+        if batch_num_ngs and n < 5:
+            return None
+        items, cates = cols["items"][sel], cols["cates"][sel]
+        res = {}
+        if batch_num_ngs:
+            G = batch_num_ngs + 1
+            src = self._sample_negatives(items.tolist(), batch_num_ngs)
+            flat = src.reshape(-1)
+            rows = np.repeat(sel, G)
+            labels = np.zeros((n, G), dtype=np.float32)
+            labels[:, 0] = 1.0
+            res["labels"] = labels.reshape(-1, 1)
+            row_cates = cates[flat]
+            if self._with_attn_labels:
+                res["attn_labels"] = self._attn_labels(cols["item_cate_history"][rows], cols["mask"][rows],
+                                                       cols["lens"][rows], row_cates)
+            res["users"] = cols["users"][rows]
+            res["items"] = items[flat]
+            res["cates"] = row_cates
+            res["time"] = cols["time"][rows]
+        else:
+            rows = sel
+            res["labels"] = cols["labels"][sel].reshape(-1, 1)
+            if self._with_attn_labels:
+                res["attn_labels"] = self._attn_labels(cols["item_cate_history"][rows], cols["mask"][rows],
+                                                       cols["lens"][rows], cates)
+            res["users"] = cols["users"][sel].astype(np.float32)
+            res["items"] = items
+            res["cates"] = cates
+            res["time"] = cols["time"][sel]
+        for k in ("item_history", "item_cate_history", "mask", "time_diff", "time_from_first_action", "time_to_now"):
+            res[k] = cols[k][rows]
+        return res
 
     def _convert_chunk(self, chunk, batch_num_ngs):
         cols = list(zip(*chunk))
@@ -201,11 +263,66 @@ class SequentialIterator(BaseIterator):
         """
         n = len(item_list)
         src = np.empty((n, batch_num_ngs + 1), dtype=np.int64)
+        src[:, 0] = np.arange(n)
+        # random.randint(0, n-1) == _randbelow(n): k = n.bit_length(); r = getrandbits(k) until r < n, and
+        # getrandbits(k <= 32) is one MT19937 32-bit output >> (32 - k).  Replay that stream with numpy's
+        # MT19937 seeded from the module's state, then put the advanced state back.
+        k = n.bit_length()
+        version, state, gauss = random.getstate()
+        if version != 3 or k > 32 or n < 2:
+            return self._sample_negatives_py(item_list, batch_num_ngs, src)
+        mt = np.random.MT19937()
+        mt.state = {"bit_generator": "MT19937", "state": {"key": np.asarray(state[:-1], dtype=np.uint32),
+                                                          "pos": int(state[-1])}}
+        need = n * batch_num_ngs
+        items = item_list
+        consumed = 0     # raw 32-bit outputs consumed from the stream so far
+        i, count = 0, 0
+        flat = np.empty(need, dtype=np.int64)
+        filled = 0
+        while filled < need:
+            block = max(4096, int((need - filled) * 1.3 * (1 << k) / n) + 64)
+            raw = mt.random_raw(block) >> np.uint64(32 - k)
+            ok = np.flatnonzero(raw < n)
+            cand = raw[ok].tolist()
+            raw_pos = ok.tolist()
+            used_upto = -1
+            for ci, j in enumerate(cand):
+                if items[j] == items[i]:
+                    used_upto = raw_pos[ci]
+                    continue
+                flat[filled] = j
+                filled += 1
+                count += 1
+                used_upto = raw_pos[ci]
+                if count == batch_num_ngs:
+                    count = 0
+                    i += 1
+                    if filled == need:
+                        break
+            consumed_in_block = used_upto + 1 if filled == need else block
+            if filled == need and consumed_in_block < block:
+                # rewind: rebuild the generator at the exact consumed position
+                mt2 = np.random.MT19937()
+                mt2.state = {"bit_generator": "MT19937", "state": {"key": np.asarray(state[:-1], dtype=np.uint32),
+                                                                   "pos": int(state[-1])}}
+                total = consumed + consumed_in_block
+                if total:
+                    mt2.random_raw(total)
+                mt = mt2
+            consumed += consumed_in_block
+        src[:, 1:] = flat.reshape(n, batch_num_ngs)
+        st = mt.state["state"]
+        random.setstate((3, tuple(int(x) for x in st["key"]) + (int(st["pos"]),), gauss))
+        return src
+
+    def _sample_negatives_py(self, item_list, batch_num_ngs, src):
+        """Plain-python fallback with the reference's literal loop (used for degenerate batch sizes)."""
+        n = len(item_list)
         randint = random.randint
         hi = n - 1
         for i in range(n):
             pos = item_list[i]
-            src[i, 0] = i
             count = 0
             while count < batch_num_ngs:
                 j = randint(0, hi)

@@ -211,7 +211,11 @@ int clsr_table_adam(float* table, float* grad_table, float* m, float* v, unsigne
                     int C, const double* sumsq, int sumsq_stride, int nsum, float clip_norm,
                     const double* adam_state, float beta1, float beta2, float eps, int lazy, void* stream);
 int clsr_zero_doubles(double* p, int n, void* stream);
+int clsr_add_doubles(double* dst, const double* src, int n, void* stream);
 int clsr_zero_floats(float* p, long n, void* stream);
+/* feed upload: device arena <- pinned host arena read by the kernel over PCIe (replaces the
+   feed_dict host->device copies of session.run, base_model.py:345-357) */
+int clsr_stage_feed(void* dst, const void* src_host, long nbytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -120,3 +120,25 @@ def test_prepare_hparams_defaults_and_checks(golden_hparams):
         prepare_hparams(None, model_type="clsr", item_embedding_dim=32)
     with pytest.raises(TypeError):
         prepare_hparams(None, model_type="other", learning_rate=1)
+
+
+@pytest.mark.parametrize("n,ngs", [(5, 4), (64, 4), (1000, 2), (4096, 4), (2, 1)])
+def test_vectorised_negative_sampling_replays_the_random_module(golden_hparams, n, ngs):
+    """numpy MT19937 replay == literal random.randint rejection loop: same draws AND same RNG state after."""
+    it = SASequentialIterator(golden_hparams, None)
+    rng = np.random.default_rng(n)
+    items = rng.integers(0, max(2, n // 3), size=n).tolist()   # many duplicates -> many rejections
+    if len(set(items)) < 2:
+        items[0] = 10 ** 6
+    for seed in (0, 1, 12345):
+        random.seed(seed)
+        random.random()  # move the stream off its initial position
+        src0 = np.empty((n, ngs + 1), dtype=np.int64)
+        src0[:, 0] = np.arange(n)
+        ref = it._sample_negatives_py(items, ngs, src0).copy()
+        st_ref = random.getstate()
+        random.seed(seed)
+        random.random()
+        got = it._sample_negatives(items, ngs)
+        assert np.array_equal(got, ref)
+        assert random.getstate() == st_ref
