@@ -152,18 +152,25 @@ class SequentialBaseModel(BaseModel):
         self.net = CLSRNet(hp, dims, device=self._device, seed=self.seed, dedup_histories=self._dedup)
 
     # ------------------------------------------------------------------ device feeds / graphs
-    def _to_arrays(self, feed_dict):
-        """Accept the iterator's feed (keys are the iterator attributes == field names)."""
+    def _to_arrays(self, feed_dict, training=False):
+        """Accept the iterator's feed (keys are the iterator attributes == field names).  A training
+        feed that carries the compact history-level arrays (sequential_iterator.LazyFeed) is passed on
+        in that form, so the (1 + train_num_ngs)-fold repeated histories are never built or uploaded."""
         it = self.iterator
+        compact = getattr(feed_dict, "compact", None) if training else None
+        if compact is not None:
+            arrays = {name: feed_dict[getattr(it, name)] for name in ("labels", "items", "cates")}
+            arrays.update(compact)
+            return arrays
         return {name: feed_dict[getattr(it, name)] for name in
                 ("labels", "users", "items", "cates", "item_history", "item_cate_history", "mask",
                  "time_from_first_action", "time_to_now")}
 
     def _static_feed(self, feed, training):
-        """Copy a numpy feed into static device buffers keyed by (rows, T, mode) through persistent
-        pinned staging buffers (no per-step allocation)."""
+        """Copy a numpy feed into static device buffers keyed by (rows, T, mode, layout) through
+        persistent pinned staging buffers (no per-step allocation)."""
         mask = feed["mask"]
-        key = (int(mask.shape[0]), int(mask.shape[1]), bool(training))
+        key = (int(mask.shape[0]), int(mask.shape[1]), bool(training), int(feed.get("hist_group", 0) or 0))
         st = self._static.get(key)
         if st is None:
             st = self._static[key] = self.net.upload(feed, training)
@@ -200,7 +207,7 @@ class SequentialBaseModel(BaseModel):
     def train(self, sess, feed_dict):
         """One optimisation step (reference CLSRModel.train, clsr.py:383-408).  Returns the same 8-list:
         [update, extra_update_ops, loss, data_loss, regular_loss, contrastive_loss, discrepancy_loss, summary]."""
-        self._train_step(self._to_arrays(feed_dict))
+        self._train_step(self._to_arrays(feed_dict, True))
         with self._stream_ctx():
             ls = self.net.read_losses()
         return [None, [], ls["loss"], ls["data_loss"], ls["regular_loss"], ls["contrastive_loss"],
@@ -243,7 +250,7 @@ class SequentialBaseModel(BaseModel):
             acc = torch.zeros(8, dtype=torch.float64, device=net.device)  # running loss sums stay on the device
         for batch_data_input in _prefetch(file_iterator):
             if batch_data_input:
-                self._train_step(self._to_arrays(batch_data_input))     # no host sync per step
+                self._train_step(self._to_arrays(batch_data_input, True))     # no host sync per step
                 with self._stream_ctx():
                     ops.call("clsr_add_doubles", acc, net.losses, 8)
                     step += 1

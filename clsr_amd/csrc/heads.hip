@@ -15,7 +15,7 @@
 __global__ void alpha_concat_kernel(const float* __restrict__ fs, int nfs, const float* __restrict__ target,
                                     const float* __restrict__ L, const float* __restrict__ S,
                                     const float* __restrict__ tnow, long tnow_stride, int tnow_col,
-                                    long B, int G, int D, float* __restrict__ out, int ldo) {
+                                    int tnow_group, long B, int G, int D, float* __restrict__ out, int ldo) {
   const long total = B * ldo;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const long b = e / ldo;
@@ -26,20 +26,20 @@ __global__ void alpha_concat_kernel(const float* __restrict__ fs, int nfs, const
     else if (c < nfs + D) v = target[b * D + (c - nfs)];
     else if (c < nfs + 2 * D) v = L[h * D + (c - nfs - D)];
     else if (c < nfs + 3 * D) v = S[b * D + (c - nfs - 2 * D)];
-    else if (c == nfs + 3 * D) v = tnow[b * tnow_stride + tnow_col];
+    else if (c == nfs + 3 * D) v = tnow[(b / tnow_group) * tnow_stride + tnow_col];
     out[e] = v;
   }
 }
 
 extern "C" int clsr_alpha_concat(const float* fs, int nfs, const float* target, const float* L,
                                  const float* S, const float* tnow, long tnow_stride, int tnow_col,
-                                 long B, int G, int D, float* out, int ldo, void* stream) {
-  CLSR_CHECK_ARG(target && L && S && tnow && out && B > 0 && G > 0 && (nfs == 0 || fs));
+                                 int tnow_group, long B, int G, int D, float* out, int ldo, void* stream) {
+  CLSR_CHECK_ARG(target && L && S && tnow && out && B > 0 && G > 0 && tnow_group > 0 && (nfs == 0 || fs));
   CLSR_CHECK_ARG(ldo >= nfs + 3 * D + 1);
   int blocks = clsr_cdiv(B * ldo, 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(alpha_concat_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, fs, nfs,
-                     target, L, S, tnow, tnow_stride, tnow_col, B, G, D, out, ldo);
+                     target, L, S, tnow, tnow_stride, tnow_col, tnow_group, B, G, D, out, ldo);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }

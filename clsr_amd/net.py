@@ -477,9 +477,19 @@ class CLSRNet(object):
         return (self.H if hp.predict_long_short else 0) + 3 * self.D + 1
 
     # ------------------------------------------------------------------ feed upload
-    def host_arrays(self, feed):
+    def host_arrays(self, feed, training=True):
         """numpy feed (iterator layout) -> dict of contiguous numpy arrays with the device dtypes
-        (+ the per-batch scalars the kernels read from device memory)."""
+        (+ the per-batch scalars the kernels read from device memory).
+
+        A COMPACT training feed (``hist_group`` = 1 + train_num_ngs present: users / histories / mask /
+        time arrays hold one row per positive line, see sequential_iterator.LazyFeed) is uploaded as is
+        when the step de-duplicates histories anyway; otherwise it is expanded to the row layout here."""
+        hg = int(feed.get("hist_group", 0) or 0)
+        hist_keys = ("users", "item_history", "item_cate_history", "mask", "time_from_first_action", "time_to_now")
+        compact = bool(hg) and training and self.dedup and hg == self.G_train
+        if hg and not compact:
+            feed = dict(feed, **{k: np.repeat(np.asarray(feed[k]), hg, axis=0) for k in hist_keys})
+            hg = 0
         mask = np.asarray(feed["mask"])
         seq_len = mask.sum(1).astype(np.int32)
         h = {"users": np.ascontiguousarray(np.asarray(feed["users"]), dtype=np.int32)}
@@ -489,8 +499,10 @@ class CLSRNet(object):
             h[k] = np.ascontiguousarray(feed[k], dtype=np.float32)
         h["labels"] = np.ascontiguousarray(np.asarray(feed["labels"]).reshape(-1), dtype=np.float32)
         h["seq_len"] = seq_len
-        h["denom"] = np.asarray([float((seq_len > self.hp.contrastive_length_threshold).sum())], dtype=np.float32)
-        return h, int(mask.shape[0]), int(mask.shape[1])
+        rep = hg if compact else 1
+        h["denom"] = np.asarray([float((seq_len > self.hp.contrastive_length_threshold).sum() * rep)],
+                                dtype=np.float32)
+        return h, int(mask.shape[0]) * rep, int(mask.shape[1]), compact
 
     _STAGE_SLOTS = 3
 
@@ -501,19 +513,19 @@ class CLSRNet(object):
         (a dict returned by an earlier call for the same shape) re-uses the device arena and a ring of
         pinned arenas: no allocation, and a pinned slot is only rewritten once the kernel that read it
         has completed (event per slot)."""
-        h, B, T = self.host_arrays(feed)
+        h, B, T, compact = self.host_arrays(feed, training)
         if into is None:
             lay, off = {}, 0
             for k, arr in h.items():
                 lay[k] = (off, arr.nbytes)
                 off += (arr.nbytes + 15) // 16 * 16
             dev = torch.empty(off, dtype=torch.uint8, device=self.device)
-            into = {"B": B, "T": T, "_lay": lay, "_nbytes": off, "_dev": dev, "_slot": 0,
+            into = {"B": B, "T": T, "compact": compact, "_lay": lay, "_nbytes": off, "_dev": dev, "_slot": 0,
                     "_stage": [None] * self._STAGE_SLOTS}
             for k, arr in h.items():
                 o, n = lay[k]
                 into[k] = dev[o:o + n].view(torch.from_numpy(arr).dtype).view(arr.shape)
-        assert into["B"] == B and into["T"] == T
+        assert into["B"] == B and into["T"] == T and into["compact"] == compact
         slot = into["_slot"]
         into["_slot"] = (slot + 1) % self._STAGE_SLOTS
         if into["_stage"][slot] is None:
@@ -687,18 +699,20 @@ class CLSRNet(object):
         D, Du, H, Di, Dc = self.D, self.Du, self.H, self.Di, self.Dc
         self.last_shape = (B, T, G, Hn)
         self._pack_all(training)
-        seq_len, ls = f["seq_len"], G
+        # rows between consecutive history groups in the uploaded history-level arrays
+        hs = 1 if f.get("compact") else G
+        seq_len, ls = f["seq_len"], hs
         # ---- gathers
         hist = self._buf("hist", Hn, T, D)
         hmean, hrec = self._buf("hist_mean", Hn, D), self._buf("hist_recent", Hn, D)
         call("clsr_gather_hist_fwd", self.tables["item"], self.tables["cate"], f["item_history"],
-             f["item_cate_history"], G * T, seq_len, ls, Hn, T, Di, Dc, hp.contrastive_recent_k, hist, hmean, hrec)
+             f["item_cate_history"], hs * T, seq_len, ls, Hn, T, Di, Dc, hp.contrastive_recent_k, hist, hmean, hrec)
         target = self._buf("target", B, D)
         call("clsr_gather_rows", self.tables["item"], f["items"], 1, B, Di, target, D, 0)
         call("clsr_gather_rows", self.tables["cate"], f["cates"], 1, B, Dc, target, D, Di)
         ulong, ushort = self._buf("u_long", Hn, Du), self._buf("u_short", Hn, Du)
-        call("clsr_gather_rows", self.tables["user_long"], f["users"], G, Hn, Du, ulong, Du, 0)
-        call("clsr_gather_rows", self.tables["user_short"], f["users"], G, Hn, Du, ushort, Du, 0)
+        call("clsr_gather_rows", self.tables["user_long"], f["users"], hs, Hn, Du, ulong, Du, 0)
+        call("clsr_gather_rows", self.tables["user_short"], f["users"], hs, Hn, Du, ushort, Du, 0)
         # ---- long term (independent of the encoders and of the short-term attention: side stream)
         lt = CL + "long_term/attention_fcn/"
         with self._branch("@lt"):
@@ -718,7 +732,7 @@ class CLSRNet(object):
         if hp.sequential_model == "time4lstm":
             t = st + "time4lstm/"
             TT = self._buf("t4.TT", M, 2 * H)
-            call("clsr_t4_time_inputs_fwd", f["time_to_now"], f["time_from_first_action"], G * T,
+            call("clsr_t4_time_inputs_fwd", f["time_to_now"], f["time_from_first_action"], hs * T,
                  P[t + "_time_input_w1"], P[t + "_time_input_bias1"], P[t + "_time_input_w2"],
                  P[t + "_time_input_bias2"], Hn, T, H, TT)
             t4off = self._enc_off("t4")
@@ -750,8 +764,8 @@ class CLSRNet(object):
             nfs = H if hp.predict_long_short else 0
             ld = _pad4(self.a_in)
             ain = self._buf("al.in", B, ld)
-            call("clsr_alpha_concat", fs, nfs, target, att_long, att_short, f["time_to_now"], T, T - 1, B, G, D,
-                 ain, ld)
+            call("clsr_alpha_concat", fs, nfs, target, att_long, att_short, f["time_to_now"], T, T - 1,
+                 G if f.get("compact") else 1, B, G, D, ain, ld)
             al_logit = self._mlp_fwd("al", CL + "fcn_alpha/nn_part/", ain, ld, ld, (self.A0, self.A1), B, training)
             call("clsr_alpha_fuse_fwd", al_logit, 0.0, att_long, att_short, target, B, G, D, alpha, mo)
         else:
@@ -772,7 +786,8 @@ class CLSRNet(object):
         out = self.forward(f, True)
         B, T, G, Hn = self.last_shape
         D, Du, H, Di, Dc = self.D, self.Du, self.H, self.Di, self.Dc
-        seq_len, ls = f["seq_len"], G
+        hs = 1 if f.get("compact") else G
+        seq_len, ls = f["seq_len"], hs
         call("clsr_zero_doubles", self.losses, 8)
         call("clsr_zero_doubles", self.sumsq_tab, 16)
         # gradient accumulators (zeroed every step)
@@ -790,12 +805,12 @@ class CLSRNet(object):
         dL, dM, dR = take(Hn, D), take(Hn, D), take(Hn, D)
         dfs, dsi = take(Hn, H), take(Hn, Du)
         # involved-row flags (tf.unique id sets)
-        call("clsr_mark_rows", f["item_history"], Hn, T, G * T, self.tab_flags["item"])
+        call("clsr_mark_rows", f["item_history"], Hn, T, hs * T, self.tab_flags["item"])
         call("clsr_mark_rows", f["items"], B, 1, 1, self.tab_flags["item"])
-        call("clsr_mark_rows", f["item_cate_history"], Hn, T, G * T, self.tab_flags["cate"])
+        call("clsr_mark_rows", f["item_cate_history"], Hn, T, hs * T, self.tab_flags["cate"])
         call("clsr_mark_rows", f["cates"], B, 1, 1, self.tab_flags["cate"])
-        call("clsr_mark_rows", f["users"], Hn, 1, G, self.tab_flags["user_long"])
-        call("clsr_mark_rows", f["users"], Hn, 1, G, self.tab_flags["user_short"])
+        call("clsr_mark_rows", f["users"], Hn, 1, hs, self.tab_flags["user_long"])
+        call("clsr_mark_rows", f["users"], Hn, 1, hs, self.tab_flags["user_short"])
         # ---- losses on the forward outputs
         dlogit = self._buf("dlogit", B)
         Gl = hp.train_num_ngs + 1
@@ -864,7 +879,7 @@ class CLSRNet(object):
             self._gemm(dPt[:, 3 * H:], NX, "t4.tw^T", M, 3 * H, 2 * H, dTT, 2 * H)
             parts = query("clsr_t4_time_inputs_bwd_parts", Hn, T, H)
             tp = self._buf("t4.tpart", 512 * 4 * 128)[: parts * 4 * H]
-            call("clsr_t4_time_inputs_bwd", dTT, TT, f["time_to_now"], f["time_from_first_action"], G * T, Hn, T, H, tp)
+            call("clsr_t4_time_inputs_bwd", dTT, TT, f["time_to_now"], f["time_from_first_action"], hs * T, Hn, T, H, tp)
             for off_, nm in ((0, "_time_input_w1"), (H, "_time_input_w2"), (2 * H, "_time_input_bias1"),
                              (3 * H, "_time_input_bias2")):
                 call("clsr_reduce_parts", tp[off_:], parts, 4 * H, H, 1.0, Gd[t + nm], 0)
@@ -882,12 +897,12 @@ class CLSRNet(object):
         ss = self.sumsq_tab
         # (sort + segmented sums -- _hist_grad_sorted -- measures the same as plain atomics at this size
         #  because rocPRIM falls back to a 16-launch merge sort; it becomes the path for the sparse exchange)
-        call("clsr_gather_hist_bwd", dhist, dM, dR, f["item_history"], f["item_cate_history"], G * T, seq_len, ls,
+        call("clsr_gather_hist_bwd", dhist, dM, dR, f["item_history"], f["item_cate_history"], hs * T, seq_len, ls,
              Hn, T, Di, Dc, hp.contrastive_recent_k, self.tab_grad["item"], self.tab_grad["cate"], ss[0:])
         call("clsr_scatter_add_rows", dtarget, D, 0, f["items"], 1, B, Di, self.tab_grad["item"], ss[2:])
         call("clsr_scatter_add_rows", dtarget, D, Di, f["cates"], 1, B, Dc, self.tab_grad["cate"], ss[3:])
-        call("clsr_scatter_add_rows", dul, Du, 0, f["users"], G, Hn, Du, self.tab_grad["user_long"], ss[6:])
-        call("clsr_scatter_add_rows", dushort, Du, 0, f["users"], G, Hn, Du, self.tab_grad["user_short"], ss[7:])
+        call("clsr_scatter_add_rows", dul, Du, 0, f["users"], hs, Hn, Du, self.tab_grad["user_long"], ss[6:])
+        call("clsr_scatter_add_rows", dushort, Du, 0, f["users"], hs, Hn, Du, self.tab_grad["user_short"], ss[7:])
         if apply:
             self._apply_updates()
         return out

@@ -30,6 +30,65 @@ _FIELDS = (
 ).split()
 
 
+class LazyFeed(dict):
+    """A feed dict whose big row-repeated arrays are built on first access.
+
+    A training batch repeats every line's padded history ``1 + batch_num_ngs`` times
+    (ref ``sequential_iterator.py:416-447``).  The CLSR device step only needs ONE copy per
+    line (``feed.compact``: history-level arrays + ``hist_group``), so the repeated arrays are
+    materialised only for a caller that actually reads them -- with exactly the values the
+    reference produces.  Any whole-dict access (iteration, ``len``, ``in``, ``keys``/``items``/
+    ``values``/``get``) materialises everything first, so this behaves like the plain dict.
+    """
+
+    def __init__(self, eager, thunks, compact):
+        dict.__init__(self, eager)
+        self._thunks = dict(thunks)
+        self.compact = compact
+
+    def __missing__(self, key):
+        th = self._thunks.pop(key, None)
+        if th is None:
+            raise KeyError(key)
+        val = th()
+        dict.__setitem__(self, key, val)
+        return val
+
+    def _force(self):
+        for k in list(self._thunks):
+            self[k]
+        return self
+
+    def __iter__(self):
+        return dict.__iter__(self._force())
+
+    def __len__(self):
+        return dict.__len__(self._force())
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._thunks
+
+    def keys(self):
+        return dict.keys(self._force())
+
+    def items(self):
+        return dict.items(self._force())
+
+    def values(self):
+        return dict.values(self._force())
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def __eq__(self, other):
+        return dict.__eq__(self._force(), other)
+
+    __hash__ = None
+
+    def __bool__(self):
+        return True
+
+
 class BaseIterator(object):
     """4-method contract of the reference's ``io/iterator.py:9-24``."""
 
@@ -196,7 +255,7 @@ class SequentialIterator(BaseIterator):
             labels[:, 0] = 1.0
             res["labels"] = labels.reshape(-1, 1)
             row_cates = cates[flat]
-            if self._with_attn_labels:
+            if self._with_attn_labels and not self.lazy_histories:
                 res["attn_labels"] = self._attn_labels(cols["item_cate_history"][rows], cols["mask"][rows],
                                                        cols["lens"][rows], row_cates)
             res["users"] = cols["users"][rows]
@@ -213,7 +272,17 @@ class SequentialIterator(BaseIterator):
             res["items"] = items
             res["cates"] = cates
             res["time"] = cols["time"][sel]
-        for k in ("item_history", "item_cate_history", "mask", "time_diff", "time_from_first_action", "time_to_now"):
+        big = ("item_history", "item_cate_history", "mask", "time_diff", "time_from_first_action", "time_to_now")
+        if batch_num_ngs and self.lazy_histories:
+            compact = {k: cols[k][sel] for k in big if k != "time_diff"}
+            compact["users"] = cols["users"][sel]
+            compact["hist_group"] = batch_num_ngs + 1
+            thunks = {k: (lambda k=k: cols[k][rows]) for k in big}
+            if self._with_attn_labels:
+                thunks["attn_labels"] = lambda: self._attn_labels(
+                    cols["item_cate_history"][rows], cols["mask"][rows], cols["lens"][rows], row_cates)
+            return LazyFeed(res, thunks, compact)
+        for k in big:
             res[k] = cols[k][rows]
         return res
 
@@ -226,6 +295,8 @@ class SequentialIterator(BaseIterator):
         )
 
     _with_attn_labels = False
+    #: training feeds defer the (1 + ngs)-fold repetition of the padded histories (see LazyFeed)
+    lazy_histories = True
 
     def _pad_histories(self, item_history_batch, item_cate_history_batch, time_diff_list,
                        time_from_first_action_list, time_to_now_list):
@@ -275,31 +346,30 @@ class SequentialIterator(BaseIterator):
         mt.state = {"bit_generator": "MT19937", "state": {"key": np.asarray(state[:-1], dtype=np.uint32),
                                                           "pos": int(state[-1])}}
         need = n * batch_num_ngs
-        items = item_list
+        items = np.asarray(item_list)
         consumed = 0     # raw 32-bit outputs consumed from the stream so far
-        i, count = 0, 0
         flat = np.empty(need, dtype=np.int64)
-        filled = 0
+        filled = 0       # output slot ``filled`` belongs to line ``filled // batch_num_ngs``
         while filled < need:
             block = max(4096, int((need - filled) * 1.3 * (1 << k) / n) + 64)
             raw = mt.random_raw(block) >> np.uint64(32 - k)
             ok = np.flatnonzero(raw < n)
-            cand = raw[ok].tolist()
-            raw_pos = ok.tolist()
-            used_upto = -1
-            for ci, j in enumerate(cand):
-                if items[j] == items[i]:
-                    used_upto = raw_pos[ci]
-                    continue
-                flat[filled] = j
-                filled += 1
-                count += 1
-                used_upto = raw_pos[ci]
-                if count == batch_num_ngs:
-                    count = 0
-                    i += 1
-                    if filled == need:
-                        break
+            cand = raw[ok].astype(np.int64)
+            p = 0        # candidates of this block consumed so far (accepted or rejected)
+            while p < len(cand) and filled < need:
+                m = min(len(cand) - p, need - filled)
+                c = cand[p:p + m]
+                owner = (filled + np.arange(m)) // batch_num_ngs
+                rej = items[c] == items[owner]
+                if rej.any():            # a draw that hit the positive's own item: skip it, re-align the rest
+                    m = int(np.argmax(rej))
+                    flat[filled:filled + m] = c[:m]
+                    p += m + 1
+                else:
+                    flat[filled:filled + m] = c
+                    p += m
+                filled += m
+            used_upto = int(ok[p - 1]) if p else -1
             consumed_in_block = used_upto + 1 if filled == need else block
             if filled == need and consumed_in_block < block:
                 # rewind: rebuild the generator at the exact consumed position
@@ -405,6 +475,12 @@ class SequentialIterator(BaseIterator):
         """Map field names to arrays; empty dict for a dropped batch (ref ``:480-503``)."""
         if not data_dict:
             return dict()
+        if isinstance(data_dict, LazyFeed):
+            eager = {getattr(self, n): dict.__getitem__(data_dict, n) for n in _FIELDS
+                     if dict.__contains__(data_dict, n)}
+            thunks = {getattr(self, n): (lambda n=n: data_dict[n]) for n in _FIELDS
+                      if not dict.__contains__(data_dict, n)}
+            return LazyFeed(eager, thunks, data_dict.compact)
         return {getattr(self, name): data_dict[name] for name in _FIELDS}
 
 
@@ -422,5 +498,8 @@ class SASequentialIterator(SequentialIterator):
         if not data_dict:
             return dict()
         feed = super(SASequentialIterator, self).gen_feed_dict(data_dict)
-        feed[self.attn_labels] = data_dict["attn_labels"]
+        if isinstance(feed, LazyFeed) and not dict.__contains__(data_dict, "attn_labels"):
+            feed._thunks[self.attn_labels] = lambda: data_dict["attn_labels"]
+        else:
+            feed[self.attn_labels] = data_dict["attn_labels"]
         return feed

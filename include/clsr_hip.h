@@ -162,8 +162,8 @@ int clsr_rnn_bwd_multi(const clsr_gru_desc* grus, int ngru, const clsr_t4_desc* 
 /* ---- heads: alpha gate + fusion clsr.py:239-275; MLP output layer base_model.py:686-706;
  *      softmax data loss base_model.py:215-235; contrastive loss clsr.py:46-71 */
 int clsr_alpha_concat(const float* fs, int nfs, const float* target, const float* L, const float* S,
-                      const float* tnow, long tnow_stride, int tnow_col, long B, int G, int D, float* out,
-                      int ldo, void* stream);
+                      const float* tnow, long tnow_stride, int tnow_col, int tnow_group, long B, int G,
+                      int D, float* out, int ldo, void* stream);
 int clsr_alpha_concat_bwd(const float* dA, int ldo, int nfs, long Hn, int G, int D, float* dfs,
                           float* dtarget, float* dL, float* dS, void* stream);
 int clsr_mlp_out_fwd(const float* z1, const float* scale, const float* shift, const float* w_out,

@@ -53,13 +53,13 @@ def main():
         pr = cProfile.Profile()
         pr.enable()
         for f in feeds[:4]:
-            model._train_step(model._to_arrays(f))
+            model._train_step(model._to_arrays(f, True))
         pr.disable()
         pstats.Stats(pr).sort_stats("tottime").print_stats(12)
     # host cost of enqueueing one step (no sync inside)
     td = time.perf_counter()
     for f in feeds:
-        model._train_step(model._to_arrays(f))
+        model._train_step(model._to_arrays(f, True))
     te = time.perf_counter()
     torch.cuda.synchronize()
     tf_ = time.perf_counter()

@@ -485,7 +485,7 @@ def test_alpha_concat_fuse_roundtrip():
     ld = 164
     out = torch.full((B, ld), 5.0, device="cuda")
     call("clsr_alpha_concat", dev(fs.detach(), f32), n, dev(target.detach(), f32), dev(L.detach(), f32),
-         dev(S.detach(), f32), dev(tnow, f32), T, T - 1, B, G, D, out, ld)
+         dev(S.detach(), f32), dev(tnow, f32), T, T - 1, 1, B, G, D, out, ld)
     exp = torch.cat([fs.repeat_interleave(G, 0), target, L.repeat_interleave(G, 0), S, tnow[:, -1:]], 1)
     close(out[:, :161], exp, name="concat")
     assert float(out[:, 161:].abs().max()) == 0

@@ -165,3 +165,37 @@ def test_three_steps_stay_on_the_oracle_trajectory(golden_dir, golden_hparams):
         net.train_step(net.upload(feed, True))
         gl = net.read_losses()
         assert abs(gl["loss"] - float(ls["loss"])) < 2e-3 * abs(float(ls["loss"])), (step, gl, ls)
+
+
+def _compact(feed, G):
+    """History-level form of a row-layout training feed (what sequential_iterator.LazyFeed.compact holds)."""
+    c = {k: feed[k] for k in ("labels", "items", "cates")}
+    for k in ("users", "item_history", "item_cate_history", "mask", "time_from_first_action", "time_to_now"):
+        assert np.array_equal(np.repeat(feed[k][::G], G, axis=0), feed[k])
+        c[k] = np.ascontiguousarray(feed[k][::G])
+    c["hist_group"] = G
+    return c
+
+
+@pytest.mark.parametrize("dedup", [True, False])
+def test_compact_feed_is_the_same_step(golden_dir, golden_hparams, dedup):
+    """A compact (history-level) training feed gives the same step as the (1+ngs)-fold repeated row
+    layout of the reference iterator: same logits, losses and updated variables (the embedding
+    gradients are atomic float sums, hence a tiny tolerance instead of bit equality)."""
+    hp = golden_hparams
+    feed = _feed(golden_dir, "iterator_train_sa.npz", b=1)
+    G = hp.train_num_ngs + 1
+    res = []
+    for fd in (feed, _compact(feed, G)):
+        _, net, _ = _setup(hp, dedup)
+        f = net.upload(fd, True)
+        assert bool(f["compact"]) == (dedup and "hist_group" in fd)
+        out = net.train_step(f)
+        torch.cuda.synchronize()
+        res.append((out["logit"].clone(), net.read_losses(), {k: v.clone() for k, v in net.state_dict().items()}))
+    (l0, ls0, sd0), (l1, ls1, sd1) = res
+    assert torch.equal(l0, l1)
+    for k in ls0:
+        assert abs(ls0[k] - ls1[k]) <= 1e-6 * max(1.0, abs(ls0[k])), k
+    for k in sd0:
+        _close(sd1[k], sd0[k], 1e-5, 1e-6, k)
