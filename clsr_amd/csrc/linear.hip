@@ -34,7 +34,7 @@ struct PGemmArgs {
 };
 
 template <int OT, bool STATS>
-__global__ void __launch_bounds__(256) pgemm_kernel(PGemmArgs a) {
+__global__ void __launch_bounds__(256) pgemm_generic_kernel(PGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int j = lane & 15, g = lane >> 4;
@@ -167,8 +167,243 @@ __global__ void __launch_bounds__(256) pgemm_kernel(PGemmArgs a) {
   }
 }
 
+// ---- specialised fast path ------------------------------------------------------------------------
+// Same math and the same lane layout as pgemm_generic_kernel, restructured so that the compiler can keep
+// loads in flight behind the MFMAs (the generic kernel's optional-feature branches force an s_waitcnt
+// after every load):
+//   * prologue / epilogue features are template parameters -- no branches inside the tile loop;
+//   * out-of-range rows / k-columns are handled with clamped addresses + selects, never with branches;
+//   * a wave owns 32 positions (two B operands): every LDS weight read feeds 8 MFMAs;
+//   * the activations of k-tile kt+1 are loaded while k-tile kt is multiplied;
+//   * XCD-aware tile order: workgroup b runs on XCD b % 8, and every XCD walks ONE contiguous range of
+//     position tiles, so the (1 + ngs) rows of a group that re-read the same history rows (xrow) hit in
+//     that XCD's L2.
+#define PRO_PLAIN 0
+#define PRO_MUL 1
+#define PRO_AFF 2
+#define EPI_NONE 0
+#define EPI_UV 1
+#define EPI_ACC 2
+#define EPI_EZ 4
+
+template <int OT, int PRO, int EPI, bool STATS>
+__global__ void __launch_bounds__(256) pgemm_fast_kernel(PGemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int j = lane & 15, g = lane >> 4;
+  const int ntile_out = (a.N + 15) >> 4;
+  const int ot0 = blockIdx.y * OT;
+  const int otc = min(OT, ntile_out - ot0);
+  const int n0 = ot0 * 16;
+  const int KT = (a.K + 15) >> 4;
+  const int Kp = a.Kp;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  {  // stage this block's W^T chunk (rows n0 .. n0 + 16*otc); missing out-tiles are zero-filled
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.Wt + (long)n0 * Kp);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds);
+    const int cnt = (16 * otc * Kp) >> 2, tot = (16 * OT * Kp) >> 2;
+    for (int e = tid; e < tot; e += 256) dst[e] = e < cnt ? src[e] : zero4;
+  }
+  __syncthreads();
+
+  f32x4 biasr[OT];
+  bool nok[OT];
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot) {
+    const int n = n0 + ot * 16 + 4 * g;
+    nok[ot] = n < a.N;
+    biasr[ot] = (a.bias && nok[ot]) ? ld4(a.bias + n) : zero4;
+  }
+  const float relu_lo = a.in_relu ? 0.f : -3.0e38f;
+
+  // column statistics: fp32 per-lane partials over at most STAT_FLUSH wave-tiles (32 values), then a
+  // 16-lane reduction added into per-wave DOUBLE accumulators in LDS (behind the weight chunk)
+  constexpr int STAT_FLUSH = 8;
+  float fsum[STATS ? OT : 1][4], fsq[STATS ? OT : 1][4];
+  double* red = reinterpret_cast<double*>(lds + (long)16 * OT * Kp);  // [4 waves][2][OT*16]
+  int pending = 0;
+  if (STATS) {
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { fsum[ot][r] = 0.f; fsq[ot][r] = 0.f; }
+    for (int e = tid; e < 4 * 2 * OT * 16; e += 256) red[e] = 0.0;
+    __syncthreads();
+  }
+  auto flush = [&]() {
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s_ = row16_sum(fsum[ot][r]);
+        const float q_ = row16_sum(fsq[ot][r]);
+        if (j == 0) {
+          red[(wave * 2 + 0) * (OT * 16) + ot * 16 + 4 * g + r] += (double)s_;
+          red[(wave * 2 + 1) * (OT * 16) + ot * 16 + 4 * g + r] += (double)q_;
+        }
+        fsum[ot][r] = 0.f;
+        fsq[ot][r] = 0.f;
+      }
+  };
+
+  const int ntiles = (a.M + 31) >> 5;
+  const int nb = gridDim.x;
+  const int nx = nb >= 8 ? 8 : 1;
+  const int xcd = blockIdx.x % nx, slot = blockIdx.x / nx;
+  const int nslots = (nb - xcd + nx - 1) / nx;
+  const int chunk = (ntiles + nx - 1) / nx;
+  const int t_end = min(ntiles, (xcd + 1) * chunk);
+  const float* ldsA = lds + (long)j * Kp + 4 * g;  // + ot*16*Kp + kt*16
+
+  for (int tile = xcd * chunk + slot * 4 + wave; tile < t_end; tile += nslots * 4) {
+    int mrow[2];
+    bool valid[2];
+    const float* xp[2];
+    const float* mp[2];
+    long xrow[2], rr[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int m = tile * 32 + s * 16 + j;
+      valid[s] = m < a.M;
+      const int mc = valid[s] ? m : a.M - 1;
+      mrow[s] = mc;
+      int r = mc, xr = mc;
+      if (a.T > 0) {
+        r = mc / a.T;
+        if (a.G > 0) xr = (r / a.G) * a.T + (mc - r * a.T);
+      }
+      xrow[s] = xr;
+      rr[s] = r;
+      xp[s] = a.X + (long)xr * a.ldx;
+      mp[s] = PRO == PRO_MUL ? a.Xmul + (long)r * a.ldmul : nullptr;
+    }
+
+    // raw loads of one k-tile (nothing consumes them here: the prologue arithmetic is applied one
+    // iteration later, so the loads stay in flight behind the MFMAs of the current k-tile)
+    struct Raw { f32x4 x0, x1, p0, p1; };
+    auto issue = [&](int kt) -> Raw {
+      const int kcol = kt * 16 + 4 * g;
+      const int kc = kcol < a.K ? kcol : 0;
+      Raw q;
+      q.x0 = ld4(xp[0] + kc);
+      q.x1 = ld4(xp[1] + kc);
+      if (PRO == PRO_MUL) { q.p0 = ld4(mp[0] + kc); q.p1 = ld4(mp[1] + kc); }
+      if (PRO == PRO_AFF) { q.p0 = ld4(a.in_scale + kc); q.p1 = ld4(a.in_shift + kc); }
+      return q;
+    };
+    auto finish = [&](const Raw& q, int kt, f32x4& b0, f32x4& b1) {
+      const bool ink = kt * 16 + 4 * g < a.K;
+      f32x4 v0 = q.x0, v1 = q.x1;
+      if (PRO == PRO_MUL) { v0 *= q.p0; v1 *= q.p1; }
+      if (PRO == PRO_AFF) {
+        v0 = v0 * q.p0 + q.p1;
+        v1 = v1 * q.p0 + q.p1;
+        v0.x = fmaxf(v0.x, relu_lo); v0.y = fmaxf(v0.y, relu_lo); v0.z = fmaxf(v0.z, relu_lo); v0.w = fmaxf(v0.w, relu_lo);
+        v1.x = fmaxf(v1.x, relu_lo); v1.y = fmaxf(v1.y, relu_lo); v1.z = fmaxf(v1.z, relu_lo); v1.w = fmaxf(v1.w, relu_lo);
+      }
+      b0 = ink ? v0 : zero4;
+      b1 = ink ? v1 : zero4;
+    };
+
+    Raw raw = issue(0);
+    // accumulators start from everything that is added to the product (bias, addU + addV, previous Y):
+    // these loads are in flight together with the first activation loads and need no extra registers
+    f32x4 acc[2][OT];
+    f32x4 ezr[(EPI & EPI_EZ) ? 2 : 1][(EPI & EPI_EZ) ? OT : 1];
+    {
+      constexpr bool UV = (EPI & EPI_UV) != 0, ACC = (EPI & EPI_ACC) != 0;
+      f32x4 tu[UV ? 2 : 1][UV ? OT : 1], tv[(UV || ACC) ? 2 : 1][(UV || ACC) ? OT : 1];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+          const int nc = nok[ot] ? n0 + ot * 16 + 4 * g : 0;
+          if (UV) { tu[s][ot] = ld4(a.addU + xrow[s] * a.ldu + nc); tv[s][ot] = ld4(a.addV + rr[s] * a.ldv + nc); }
+          if (ACC) tv[s][ot] = ld4(a.Y + (long)mrow[s] * a.ldy + nc);
+          if (EPI & EPI_EZ) ezr[s][ot] = ld4(a.ez + (long)mrow[s] * a.ldez + nc);
+        }
+      __builtin_amdgcn_sched_barrier(0);  // all of the loads above are issued before the first one is consumed
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+          f32x4 v = biasr[ot];
+          if (UV) v += tu[s][ot] + tv[s][ot];
+          if (ACC) v += tv[s][ot];
+          acc[s][ot] = v;
+        }
+    }
+
+    for (int kt = 0; kt < KT; ++kt) {
+      f32x4 b0, b1;
+      finish(raw, kt, b0, b1);
+      raw = issue(min(kt + 1, KT - 1));
+      __builtin_amdgcn_sched_barrier(0);  // keep the loads above ahead of the MFMA block
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) {
+        const f32x4 w = ld4(ldsA + (long)ot * 16 * Kp + kt * 16);
+        MFMA4(acc[0][ot], w.x, b0.x);
+        MFMA4(acc[1][ot], w.x, b1.x);
+        MFMA4(acc[0][ot], w.y, b0.y);
+        MFMA4(acc[1][ot], w.y, b1.y);
+        MFMA4(acc[0][ot], w.z, b0.z);
+        MFMA4(acc[1][ot], w.z, b1.z);
+        MFMA4(acc[0][ot], w.w, b0.w);
+        MFMA4(acc[1][ot], w.w, b1.w);
+      }
+    }
+
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) {
+        const int n = n0 + ot * 16 + 4 * g;
+        const int nc = nok[ot] ? n : 0;
+        const bool ok = valid[s] && nok[ot];
+        f32x4 v = acc[s][ot];
+        float* yp = a.Y + (long)mrow[s] * a.ldy + nc;
+        f32x4 w2 = v;  // second factor of the squared-sum accumulator
+        if (EPI & EPI_EZ) {
+          const f32x4 zz = ezr[s][ot];
+          const f32x4 y = zz * ld4(a.e_scale + nc) + ld4(a.e_shift + nc);
+          v.x = y.x > 0.f ? v.x : 0.f; v.y = y.y > 0.f ? v.y : 0.f;
+          v.z = y.z > 0.f ? v.z : 0.f; v.w = y.w > 0.f ? v.w : 0.f;
+          w2 = (zz - ld4(a.e_mean + nc)) * ld4(a.e_invstd + nc);
+        }
+        if (ok) st4(yp, v);
+        if (STATS) {
+          const f32x4 vm = ok ? v : zero4;
+          fsum[ot][0] += vm.x; fsq[ot][0] = fmaf(vm.x, w2.x, fsq[ot][0]);
+          fsum[ot][1] += vm.y; fsq[ot][1] = fmaf(vm.y, w2.y, fsq[ot][1]);
+          fsum[ot][2] += vm.z; fsq[ot][2] = fmaf(vm.z, w2.z, fsq[ot][2]);
+          fsum[ot][3] += vm.w; fsq[ot][3] = fmaf(vm.w, w2.w, fsq[ot][3]);
+        }
+      }
+    }
+    if (STATS && ++pending == STAT_FLUSH) {
+      flush();
+      pending = 0;
+    }
+  }
+
+  if (STATS) {
+    if (pending) flush();
+    __syncthreads();
+    for (int e = tid; e < 2 * 16 * otc; e += 256) {
+      const int which = e / (16 * otc), c = e - which * 16 * otc;
+      const int n = n0 + c;
+      if (n < a.N) {
+        double s = 0.0;
+        for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * (OT * 16) + c];
+        a.stats[((long)blockIdx.x * 2 + which) * a.N + n] = s;
+      }
+    }
+  }
+}
+
+
 static int pgemm_grid_x(int M) {
-  int ntiles = clsr_cdiv(M, 16);
+  int ntiles = clsr_cdiv(M, 32);
   int gx = clsr_cdiv(ntiles, 4);
   if (gx > 1024) gx = 1024;
   if (gx < 1) gx = 1;
@@ -177,27 +412,43 @@ static int pgemm_grid_x(int M) {
 
 extern "C" int clsr_pgemm_stats_parts(int M) { return pgemm_grid_x(M); }
 
+template <typename KernelT>
+static int launch_kernel(KernelT kernel, const PGemmArgs& a, dim3 grid, size_t shmem, hipStream_t stream) {
+  if (shmem > 64 * 1024)
+    CLSR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL(kernel, grid, dim3(256), shmem, stream, a);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
 template <int OT>
 static int launch_pgemm(const PGemmArgs& a, hipStream_t stream) {
   const int ntile_out = clsr_cdiv(a.N, 16);
   dim3 grid(pgemm_grid_x(a.M), clsr_cdiv(ntile_out, OT));
   size_t wbytes = (size_t)16 * OT * a.Kp * sizeof(float);
   size_t sbytes = a.stats ? (size_t)4 * 2 * OT * 16 * sizeof(double) : 0;
-  size_t shmem = wbytes > sbytes ? wbytes : sbytes;
+  size_t shmem = wbytes + sbytes;
   CLSR_CHECK_SUPPORTED(shmem <= 160 * 1024);
-  if (a.stats) {
-    if (shmem > 64 * 1024)
-      CLSR_HIP(hipFuncSetAttribute((const void*)pgemm_kernel<OT, true>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL((pgemm_kernel<OT, true>), grid, dim3(256), shmem, stream, a);
-  } else {
-    if (shmem > 64 * 1024)
-      CLSR_HIP(hipFuncSetAttribute((const void*)pgemm_kernel<OT, false>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL((pgemm_kernel<OT, false>), grid, dim3(256), shmem, stream, a);
-  }
-  CLSR_CHECK_LAUNCH();
-  return CLSR_OK;
+  const int pro = a.Xmul ? PRO_MUL : (a.in_scale ? PRO_AFF : PRO_PLAIN);
+  const int epi = ((a.addU && a.addV) ? EPI_UV : 0) | (a.accumulate ? EPI_ACC : 0) | (a.ez ? EPI_EZ : 0);
+  // (the 8-out-tile BN-backward variant would spill registers: it stays on the generic kernel)
+  const bool uv_ok = (a.addU != nullptr) == (a.addV != nullptr) && !(OT == 8 && epi == EPI_EZ);
+  const bool st = a.stats != nullptr;
+#define CLSR_FAST(P, E, S)                                                                          \
+  if (uv_ok && pro == (P) && epi == (E) && st == (S))                                               \
+    return launch_kernel(pgemm_fast_kernel<OT, P, E, S>, a, grid, shmem, stream);
+  CLSR_FAST(PRO_PLAIN, EPI_NONE, false)
+  CLSR_FAST(PRO_PLAIN, EPI_NONE, true)
+  CLSR_FAST(PRO_MUL, EPI_UV, false)
+  CLSR_FAST(PRO_MUL, EPI_UV, true)
+  CLSR_FAST(PRO_AFF, EPI_NONE, false)
+  CLSR_FAST(PRO_AFF, EPI_NONE, true)
+  CLSR_FAST(PRO_PLAIN, EPI_ACC, false)
+  if (OT < 8) { CLSR_FAST(PRO_PLAIN, EPI_EZ, true) }
+#undef CLSR_FAST
+  // any other combination of the optional features: generic kernel (same results, branchy)
+  if (st) return launch_kernel(pgemm_generic_kernel<OT, true>, a, grid, shmem, stream);
+  return launch_kernel(pgemm_generic_kernel<OT, false>, a, grid, shmem, stream);
 }
 
 static int pgemm_dispatch(const PGemmArgs& a, hipStream_t s);
