@@ -151,7 +151,8 @@ def main():
     if dist is not None:
         from clsr_amd.dp import DataParallel
 
-        stepper = DataParallel(net, dist, sync_bn=args.sync_bn)
+        stepper = DataParallel(net, dist, sync_bn=args.sync_bn,
+                               sparse_tables=os.environ.get("CLSR_SPARSE_TABLES", "auto"))
         stepper.prepare(f)
     else:
         stepper = None

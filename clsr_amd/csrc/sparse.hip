@@ -146,3 +146,158 @@ extern "C" int clsr_gather_bwd_sorted(const float* dhist, const float* dmean, co
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
+
+// =================================================================== touched-row exchange (multi-GPU)
+// The gradient of an embedding table lives in a dense table plus a byte map of the touched ("involved")
+// rows.  For the data-parallel exchange of a table whose touched rows are few compared with the vocabulary
+// (user tables at Taobao scale, every table of a 100M-item catalogue) a rank ships only (ids, rows):
+//   clsr_flags_compact : byte map -> ascending id list + count (bounded by cap)
+//   clsr_rows_pack     : rows[i, :] = table[ids[i], :]
+//   clsr_rows_unpack   : table[ids[i], :] (= 0 | += rows[i, :]) and flags[ids[i]] = 1
+// All three read the count from device memory, so the host never synchronises; every rank applies the
+// gathered lists in rank order, so the fp32 sums are bit-identical on all replicas.
+#define CMP_SEG 1024  // flags per wave
+
+// pass 1: wave w counts the non-zero flags of [w*CMP_SEG, (w+1)*CMP_SEG)
+__global__ void __launch_bounds__(256) flags_count_kernel(const unsigned char* __restrict__ flags, long V,
+                                                          long nseg, int* __restrict__ seg_count) {
+  const int lane = threadIdx.x & 63;
+  for (long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6); w < nseg; w += (long)gridDim.x * 4) {
+    const long base = w * CMP_SEG;
+    int c = 0;
+#pragma unroll 4
+    for (int i = 0; i < CMP_SEG / 64; ++i) {
+      const long v = base + i * 64 + lane;
+      const bool on = v < V && flags[v] != 0;
+      c += __popcll(__ballot(on));
+    }
+    if (lane == 0) seg_count[w] = c;
+  }
+}
+
+// exclusive scan of seg_count (one block; nseg <= a few 100k); total -> count_out[0] (clamped to cap),
+// count_out[1] = 1 if the list had to be truncated (never happens when cap is a true bound)
+__global__ void __launch_bounds__(1024) flags_scan_kernel(int* __restrict__ seg_count, long nseg, int cap,
+                                                          int* __restrict__ count_out) {
+  __shared__ int part[1024];
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (long b = 0; b < nseg; b += 1024) {
+    const long e = b + threadIdx.x;
+    const int v = e < nseg ? seg_count[e] : 0;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
+      const int add = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+      __syncthreads();
+      part[threadIdx.x] += add;
+      __syncthreads();
+    }
+    const int carry = carry_s;
+    if (e < nseg) seg_count[e] = carry + part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = carry + part[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int total = carry_s;
+    count_out[0] = total < cap ? total : cap;
+    count_out[1] = total > cap ? 1 : 0;
+  }
+}
+
+// pass 2: ids_out[offset(w) + rank within the wave segment] = v
+__global__ void __launch_bounds__(256) flags_write_kernel(const unsigned char* __restrict__ flags, long V,
+                                                          long nseg, const int* __restrict__ seg_offset,
+                                                          int cap, int* __restrict__ ids_out) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+  for (long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6); w < nseg; w += (long)gridDim.x * 4) {
+    const long base = w * CMP_SEG;
+    int pos = seg_offset[w];
+#pragma unroll 4
+    for (int i = 0; i < CMP_SEG / 64; ++i) {
+      const long v = base + i * 64 + lane;
+      const bool on = v < V && flags[v] != 0;
+      const unsigned long long m = __ballot(on);
+      const int p = pos + __popcll(m & lt);
+      if (on && p < cap) ids_out[p] = (int)v;
+      pos += __popcll(m);
+    }
+  }
+}
+
+extern "C" long clsr_flags_compact_workspace_bytes(long V) {
+  if (V <= 0) return 0;
+  return (long)(((V + CMP_SEG - 1) / CMP_SEG) * sizeof(int) + 256);
+}
+
+extern "C" int clsr_flags_compact(const unsigned char* flags, long V, int* ids_out, int cap, int* count_out,
+                                  void* workspace, long workspace_bytes, void* stream) {
+  CLSR_CHECK_ARG(flags && ids_out && count_out && workspace && V > 0 && cap > 0);
+  CLSR_CHECK_SUPPORTED(V < (1L << 31));
+  CLSR_CHECK_ARG(workspace_bytes >= clsr_flags_compact_workspace_bytes(V));
+  const long nseg = (V + CMP_SEG - 1) / CMP_SEG;
+  int* seg = (int*)workspace;
+  hipStream_t s = (hipStream_t)stream;
+  int blocks = clsr_cdiv(nseg, 4);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(flags_count_kernel, dim3(blocks), dim3(256), 0, s, flags, V, nseg, seg);
+  CLSR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(flags_scan_kernel, dim3(1), dim3(1024), 0, s, seg, nseg, cap, count_out);
+  CLSR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(flags_write_kernel, dim3(blocks), dim3(256), 0, s, flags, V, nseg, seg, cap, ids_out);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+__global__ void rows_pack_kernel(const float* __restrict__ table, const int* __restrict__ ids,
+                                 const int* __restrict__ count, int C, float* __restrict__ rows) {
+  const long total = (long)count[0] * C;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long i = e / C;
+    const int c = (int)(e - i * C);
+    rows[e] = table[(long)ids[i] * C + c];
+  }
+}
+
+extern "C" int clsr_rows_pack(const float* table, const int* ids, const int* count, int cap, int C,
+                              float* rows_out, void* stream) {
+  CLSR_CHECK_ARG(table && ids && count && rows_out && cap > 0 && C > 0);
+  int blocks = clsr_cdiv((long)cap * C, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(rows_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, ids, count, C,
+                     rows_out);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// mode 0: table rows = 0; mode 1: table rows += rows.  ids are unique within one list: no atomics.
+__global__ void rows_unpack_kernel(const int* __restrict__ ids, const float* __restrict__ rows,
+                                   const int* __restrict__ count, int C, int mode, float* __restrict__ table,
+                                   unsigned char* __restrict__ flags) {
+  const long total = (long)count[0] * C;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long i = e / C;
+    const int c = (int)(e - i * C);
+    const long v = ids[i];
+    if (mode == 0) {
+      table[v * C + c] = 0.f;
+    } else {
+      table[v * C + c] += rows[e];
+      if (c == 0 && flags) flags[v] = 1;
+    }
+  }
+}
+
+extern "C" int clsr_rows_unpack(const int* ids, const float* rows, const int* count, int cap, int C, int mode,
+                                float* table, unsigned char* flags, void* stream) {
+  CLSR_CHECK_ARG(ids && count && table && cap > 0 && C > 0 && (mode == 0 || (mode == 1 && rows)));
+  int blocks = clsr_cdiv((long)cap * C, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(rows_unpack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ids, rows, count, C,
+                     mode, table, flags);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}

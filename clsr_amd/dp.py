@@ -12,6 +12,13 @@ Per step every rank runs forward + backward on ITS shard of the global batch (wh
   tab_flags_flat  "involved row" byte maps (tf.unique id sets)               (all-reduce MAX == OR)
   small           squared norms of the IndexedSlices pieces + loss numerators (all-reduce SUM)
 
+Tables whose touched rows are few compared with the vocabulary are exchanged SPARSELY instead (the
+"segmented sparse reduce" of BASELINE.json:north_star): the byte map is compacted into an ascending id
+list, the listed rows are packed, (count, ids, rows) are all-gathered, and every rank adds the lists of
+all ranks in rank order into its cleared rows -- bit-identical sums on every replica, and the traffic is
+O(touched rows) instead of O(vocabulary).  ``sparse_tables="auto"`` picks per table and per batch shape
+(sparse when  rows_bound * world < vocabulary);  "all" / "none" force one path.
+
 and every rank applies the identical clip + Adam update, so replicas never diverge.  Loss
 normalisers are global: the softmax data loss is scaled by 1/(P * world) and the contrastive
 denominator (rows longer than the threshold) is summed over ranks before the step.
@@ -25,7 +32,7 @@ import torch
 
 from clsr_amd import ops
 
-__all__ = ["DataParallel", "allreduce_step_buffers"]
+__all__ = ["DataParallel", "allreduce_step_buffers", "allgather_row_lists", "touched_rows_bound"]
 
 
 def allreduce_step_buffers(dist, dense_grad, tab_grad_flat, tab_flags_flat, small, group=None):
@@ -34,6 +41,23 @@ def allreduce_step_buffers(dist, dense_grad, tab_grad_flat, tab_flags_flat, smal
     dist.all_reduce(tab_grad_flat, op=dist.ReduceOp.SUM, group=group)
     dist.all_reduce(tab_flags_flat, op=dist.ReduceOp.MAX, group=group)
     dist.all_reduce(small, op=dist.ReduceOp.SUM, group=group)
+
+
+def allgather_row_lists(dist, count, ids, rows, counts_all, ids_all, rows_all, group=None):
+    """All-gather one rank's (count[2], ids[cap], rows[cap, C]) into the [world, ...] buffers.  Works on
+    CPU tensors (gloo) and GPU tensors (nccl/RCCL); the lists are padded to ``cap`` so no host sync is
+    needed to learn the counts."""
+    world = counts_all.shape[0]
+    dist.all_gather([counts_all[r] for r in range(world)], count, group=group)
+    dist.all_gather([ids_all[r] for r in range(world)], ids, group=group)
+    dist.all_gather([rows_all[r] for r in range(world)], rows, group=group)
+
+
+def touched_rows_bound(table, shape, vocab):
+    """Upper bound on the rows of ``table`` one rank touches in a step of shape (B, T, G, Hn)."""
+    B, T, G, Hn = shape
+    bound = Hn if table.startswith("user") else Hn * T + B
+    return int(min(vocab, bound))
 
 
 def shard_feed(feed, rank, world, group_size):
@@ -47,8 +71,12 @@ def shard_feed(feed, rank, world, group_size):
 
 
 class DataParallel(object):
-    def __init__(self, net, dist, sync_bn=False, group=None):
+    def __init__(self, net, dist, sync_bn=False, group=None, sparse_tables="auto"):
+        if sparse_tables not in ("auto", "all", "none"):
+            raise ValueError("sparse_tables must be 'auto', 'all' or 'none'")
         self.net, self.dist, self.group = net, dist, group
+        self.sparse_tables = sparse_tables
+        self._sparse_bufs = {}
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.sync_bn = bool(sync_bn)
@@ -81,12 +109,57 @@ class DataParallel(object):
     def _backward(self, f):
         self.net.train_step(f, apply=False)
 
+    def _is_sparse(self, name):
+        if self.sparse_tables != "auto":
+            return self.sparse_tables == "all"
+        V = self.net.tables[name].shape[0]
+        return touched_rows_bound(name, self.net.last_shape, V) * self.world < V
+
+    def _exchange_rows(self, name):
+        """Sparse exchange of one embedding table's gradient (see the module docstring)."""
+        net, W = self.net, self.world
+        grad, flags = net.tab_grad[name], net.tab_flags[name]
+        V, C = grad.shape
+        cap = touched_rows_bound(name, net.last_shape, V)
+        key = (name, cap)
+        b = self._sparse_bufs.get(key)
+        if b is None:
+            dev, i32 = net.device, torch.int32
+            nws = ops.query("clsr_flags_compact_workspace_bytes", V)
+            b = self._sparse_bufs[key] = dict(
+                ws=torch.empty(nws, dtype=torch.uint8, device=dev), nws=nws,
+                count=torch.zeros(2, dtype=i32, device=dev), ids=torch.zeros(cap, dtype=i32, device=dev),
+                rows=torch.zeros(cap, C, device=dev), counts_all=torch.zeros(W, 2, dtype=i32, device=dev),
+                ids_all=torch.zeros(W, cap, dtype=i32, device=dev), rows_all=torch.zeros(W, cap, C, device=dev))
+        ops.call("clsr_flags_compact", flags, V, b["ids"], cap, b["count"], b["ws"], b["nws"])
+        ops.call("clsr_rows_pack", grad, b["ids"], b["count"], cap, C, b["rows"])
+        allgather_row_lists(self.dist, b["count"], b["ids"], b["rows"], b["counts_all"], b["ids_all"],
+                            b["rows_all"], self.group)
+        # own rows are cleared, then the lists of ALL ranks are added in rank order: the same fp32 sums,
+        # in the same order, on every replica
+        ops.call("clsr_rows_unpack", b["ids"], None, b["count"], cap, C, 0, grad, None)
+        for r in range(W):
+            ops.call("clsr_rows_unpack", b["ids_all"][r], b["rows_all"][r], b["counts_all"][r], cap, C, 1, grad,
+                     flags)
+
     def _exchange(self):
-        net = self.net
+        net, dist = self.net, self.dist
         self.small[:16].copy_(net.sumsq_tab)
         self.small[16:].copy_(net.losses)
-        allreduce_step_buffers(self.dist, net.dense_grad, net.tab_grad_flat, net.tab_flags_flat, self.small,
-                               self.group)
+        sparse = [n for n in net.tab_grad if self._is_sparse(n)]
+        self.last_sparse = sparse
+        if not sparse:
+            allreduce_step_buffers(dist, net.dense_grad, net.tab_grad_flat, net.tab_flags_flat, self.small,
+                                   self.group)
+        else:
+            dist.all_reduce(net.dense_grad, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(self.small, op=dist.ReduceOp.SUM, group=self.group)
+            for n in net.tab_grad:
+                if n in sparse:
+                    self._exchange_rows(n)
+                else:
+                    dist.all_reduce(net.tab_grad[n], op=dist.ReduceOp.SUM, group=self.group)
+                    dist.all_reduce(net.tab_flags[n], op=dist.ReduceOp.MAX, group=self.group)
         net.sumsq_tab.copy_(self.small[:16])
         net.losses.copy_(self.small[16:])
         if not self.sync_bn:

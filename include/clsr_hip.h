@@ -55,6 +55,17 @@ int clsr_sort_ids(const int* ids, long nrows, int ncols, long row_stride, long v
 int clsr_gather_bwd_sorted(const float* dhist, const float* dmean, const float* drecent, const int* keys,
                            const int* perm, const int* seq_len, int len_stride, long n, int T, int D, int col0,
                            int C, int recent_k, float* grad, int ldg, int gcol0, double* sumsq, void* stream);
+
+/* touched-row exchange for multi-GPU runs (new surface; the reference is single-device):
+ * byte map of involved rows -> ascending id list (count on the device, bounded by cap), pack / unpack of
+ * the listed rows of a dense gradient table.  mode 0 clears the rows, mode 1 adds rows and sets flags. */
+long clsr_flags_compact_workspace_bytes(long V);
+int clsr_flags_compact(const unsigned char* flags, long V, int* ids_out, int cap, int* count_out,
+                       void* workspace, long workspace_bytes, void* stream);
+int clsr_rows_pack(const float* table, const int* ids, const int* count, int cap, int C, float* rows_out,
+                   void* stream);
+int clsr_rows_unpack(const int* ids, const float* rows, const int* count, int cap, int C, int mode,
+                     float* table, unsigned char* flags, void* stream);
 /* "involved" id sets (tf.unique, sequential_base_model.py:409-433, clsr.py:118-127) as byte maps */
 int clsr_mark_rows(const int* idx, long nrows, int ncols, long row_stride, unsigned char* flags,
                    void* stream);

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from clsr_amd.dp import allreduce_step_buffers, shard_feed
+from clsr_amd.dp import allgather_row_lists, allreduce_step_buffers, shard_feed, touched_rows_bound
 
 
 def _free_port():
@@ -61,3 +61,53 @@ def test_shard_feed_keeps_groups_together():
         assert False
     except ValueError:
         pass
+
+
+def _rows_worker(rank, world, port, out):
+    """Sparse row exchange, host logic only: numpy stand-ins for the pack / unpack kernels."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    V, C, cap = 300, 8, 64
+    g = torch.Generator().manual_seed(7 + rank)
+    n = int(torch.randint(10, cap, (1,), generator=g))
+    touched = torch.sort(torch.randperm(V, generator=g)[:n]).values
+    grad = torch.zeros(V, C)
+    grad[touched] = torch.randn(n, C, generator=g)
+    # pack (what clsr_flags_compact + clsr_rows_pack produce)
+    count = torch.tensor([n, 0], dtype=torch.int32)
+    ids = torch.zeros(cap, dtype=torch.int32)
+    ids[:n] = touched.to(torch.int32)
+    rows = torch.zeros(cap, C)
+    rows[:n] = grad[touched]
+    counts_all = torch.zeros(world, 2, dtype=torch.int32)
+    ids_all = torch.zeros(world, cap, dtype=torch.int32)
+    rows_all = torch.zeros(world, cap, C)
+    allgather_row_lists(dist, count, ids, rows, counts_all, ids_all, rows_all)
+    # unpack in rank order (what clsr_rows_unpack does)
+    total = grad.clone()
+    total[touched] = 0
+    for r in range(world):
+        k = int(counts_all[r, 0])
+        total[ids_all[r, :k].long()] += rows_all[r, :k]
+    dense = grad.clone()
+    dist.all_reduce(dense)
+    lst = [torch.zeros_like(total) for _ in range(world)]
+    dist.all_gather(lst, total)
+    out[rank] = bool(torch.allclose(total, dense, atol=1e-6) and torch.equal(lst[0], lst[1]))
+    dist.destroy_process_group()
+
+
+def test_sparse_row_exchange_gloo_world2():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rows_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
+
+
+def test_touched_rows_bound():
+    shape = (20480, 50, 5, 4096)
+    assert touched_rows_bound("user_long", shape, 36915) == 4096
+    assert touched_rows_bound("item", shape, 64138) == 64138          # bound exceeds the vocabulary
+    assert touched_rows_bound("item", shape, 100_000_000) == 4096 * 50 + 20480

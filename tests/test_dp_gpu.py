@@ -29,13 +29,19 @@ class _HostStagedDist(object):
         self._d.all_reduce(c, op=op)
         t.copy_(c)
 
+    def all_gather(self, outs, t, group=None):
+        cs = [o.detach().cpu() for o in outs]
+        self._d.all_gather(cs, t.detach().cpu())
+        for o, c in zip(outs, cs):
+            o.copy_(c)
+
     def broadcast(self, t, src=0, group=None):
         c = t.detach().cpu()
         self._d.broadcast(c, src=src)
         t.copy_(c)
 
 
-def _worker(rank, world, port, hp, dims, feed, sd, out):
+def _worker(rank, world, port, hp, dims, feed, sd, sparse, out):
     import torch.distributed as dist
 
     from clsr_amd.dp import DataParallel, shard_feed
@@ -47,7 +53,7 @@ def _worker(rank, world, port, hp, dims, feed, sd, out):
     net = CLSRNet(hp, dims, device="cuda:0", seed=rank)  # different seeds: broadcast must fix that
     if rank == 0:
         net.load_state_dict(sd)
-    dp = DataParallel(net, _HostStagedDist(dist), sync_bn=True)
+    dp = DataParallel(net, _HostStagedDist(dist), sync_bn=True, sparse_tables=sparse)
     net.capture_grads = True
     f = dp.prepare(net.upload(shard_feed(feed, rank, world, hp.train_num_ngs + 1), True))
     dp.train_step(f)
@@ -57,11 +63,13 @@ def _worker(rank, world, port, hp, dims, feed, sd, out):
         out["grads"] = {k: v.cpu().numpy() for k, v in net.captured["dense"].items()}
         out["tgrads"] = {k: v.cpu().numpy() for k, v in net.captured["tables"].items()}
         out["losses"] = net.read_losses()
+        out["sparse"] = list(dp.last_sparse)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_match_single_process(golden_dir, golden_hparams):
+@pytest.mark.parametrize("sparse", ["none", "all", "auto"])
+def test_two_ranks_match_single_process(golden_dir, golden_hparams, sparse):
     import pickle
 
     import torch.multiprocessing as mp
@@ -91,7 +99,8 @@ def test_two_ranks_match_single_process(golden_dir, golden_hparams):
     ctx = mp.get_context("spawn")
     mgr = ctx.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, port, hp, dims, feed, sd, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, hp, dims, feed, sd, sparse, out), nprocs=2, join=True)
+    assert len(out["sparse"]) == {"none": 0, "all": 4}.get(sparse, len(out["sparse"]))
     for k in ("loss", "data_loss", "contrastive_loss", "regular_loss", "discrepancy_loss"):
         assert abs(out["losses"][k] - ref_losses[k]) < 1e-5 * max(1.0, abs(ref_losses[k])), (k, out["losses"], ref_losses)
     # gradients of the global batch (pre-clip, regularisers included) agree to fp32 accumulation noise

@@ -680,3 +680,41 @@ def test_table_reg_adam(lazy):
     close(dv, v2, rtol=1e-5, atol=1e-10, name="v")
     close(dUL, newp, rtol=1e-5, atol=1e-6, name="table")
     assert float(dG.abs().max()) == 0.0 and int(dfl.sum()) == 0
+
+
+@pytest.mark.parametrize("V,C,frac", [(1000, 8, 0.1), (70001, 32, 0.03), (5000, 40, 1.0), (64, 4, 0.0)])
+def test_touched_row_compaction_pack_unpack(V, C, frac):
+    """clsr_flags_compact / clsr_rows_pack / clsr_rows_unpack (touched-row exchange): bit exact."""
+    g = torch.Generator().manual_seed(V)
+    flags = (torch.rand(V, generator=g) < frac).to(torch.uint8)
+    table = torch.randn(V, C, generator=g)
+    exp_ids = torch.nonzero(flags).reshape(-1).to(torch.int32)
+    n = int(exp_ids.numel())
+    cap = max(n, 1) + 5
+    d_flags, d_table = flags.cuda(), table.cuda()
+    ids = torch.full((cap,), -7, dtype=torch.int32, device="cuda")
+    count = torch.zeros(2, dtype=torch.int32, device="cuda")
+    nws = ops.query("clsr_flags_compact_workspace_bytes", V)
+    ws = torch.empty(nws, dtype=torch.uint8, device="cuda")
+    call("clsr_flags_compact", d_flags, V, ids, cap, count, ws, nws)
+    assert count.tolist() == [n, 0]
+    assert torch.equal(ids[:n].cpu(), exp_ids) and bool((ids[n:] == -7).all())
+    rows = torch.zeros(cap, C, device="cuda")
+    call("clsr_rows_pack", d_table, ids, count, cap, C, rows)
+    assert torch.equal(rows[:n].cpu(), table[exp_ids.long()])
+    # truncation is reported, never written past cap
+    if n > 3:
+        small = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+        call("clsr_flags_compact", d_flags, V, small, n - 3, count, ws, nws)
+        assert count.tolist() == [n - 3, 1]
+        assert torch.equal(small[:n - 3].cpu(), exp_ids[:n - 3]) and bool((small[n - 3:] == -7).all())
+        call("clsr_flags_compact", d_flags, V, ids, cap, count, ws, nws)
+    # unpack: clear, then add twice -> 2 * rows on the touched rows, untouched rows unchanged
+    dst = d_table.clone()
+    f2 = torch.zeros(V, dtype=torch.uint8, device="cuda")
+    call("clsr_rows_unpack", ids, None, count, cap, C, 0, dst, None)
+    call("clsr_rows_unpack", ids, rows, count, cap, C, 1, dst, f2)
+    call("clsr_rows_unpack", ids, rows, count, cap, C, 1, dst, f2)
+    exp = table.clone()
+    exp[exp_ids.long()] *= 2
+    assert torch.equal(dst.cpu(), exp) and torch.equal(f2.cpu(), flags)
