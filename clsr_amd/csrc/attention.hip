@@ -138,143 +138,214 @@ extern "C" int clsr_att_out_fwd(const float* z1, const float* scale1, const floa
   return CLSR_OK;
 }
 
-// Backward.  One wave per history group h; loops over its G rows.
-// LDS (floats): dsl[T] | acc[T*Dk] | dol[Dk] | red[64*?]
-#define ATT_BWD_MAX_BLOCKS 2048
-__global__ void __launch_bounds__(64) att_out_bwd_kernel(AttOutArgs a) {
+// Backward, split by access pattern:
+//   att_score_bwd  (per history group, latency bound, tiny traffic): softmax backward -> d score ds[r, t],
+//                  dkeys[h, t, :] += sum_g w[g, t] * dout[g, :], partial sums of d b_out
+//   att_dy1_stats  (streaming over the R*T x C1 activations): with dy1 = ds * w_out * (y1 > 0), column sums
+//                  of dy1, dy1 * xhat1 (the BN-1 backward reduction) and relu(y1) * ds (d w_out) -- dy1 itself
+//                  is NOT written
+//   att_dy1_apply  (streaming): dz1 = a1 * dy1 + a2 * z1 + a3 recomputing dy1 from (z1, ds): the only pass
+//                  that writes an [R*T, C1] tensor.
+// Traffic per launch chain at R*T = 1M, C1 = 40: 2 reads of z1 + 1 write of dz1 (0.49 GB) instead of the
+// 0.82 GB of a materialised dy1 followed by a separate BN apply pass.
+#define ATT_BWD_MAX_BLOCKS 4096
+#define ATT_BWD_MAXG 8
+
+// One workgroup per history group, one wave per row of the group.
+// LDS (floats): dol[G][Dk] | wl[G][Tp] | pdb[G]
+template <int NCH>
+__global__ void __launch_bounds__(64 * ATT_BWD_MAXG) att_score_bwd_kernel(AttOutArgs a, float* __restrict__ ds_out,
+                                                                          float* __restrict__ b_partial) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int lane = threadIdx.x;
-  const int T = a.T, C1 = a.C1, Dk = a.Dk;
-  const int QC = C1 >> 2, tparC = 64 / QC, tsC = lane / QC, qC = lane - tsC * QC;
-  const int QD = Dk >> 2, tparD = 64 / QD, tsD = lane / QD, qD = lane - tsD * QD;
-  float* dsl = lds;                          // [T] d score
-  float* dol = dsl + ((T + 3) & ~3);         // [Dk] dout row
-  float* acc = dol + Dk;                     // [T*Dk] dkeys accumulator of this history
-  f32x4 sc = {0, 0, 0, 0}, sh = sc, wo = sc, mu = sc, is = sc;
-  if (tsC < tparC) {
-    sc = ld4(a.scale1 + 4 * qC); sh = ld4(a.shift1 + 4 * qC); wo = ld4(a.w_out + 4 * qC);
-    mu = ld4(a.mean1 + 4 * qC); is = ld4(a.invstd1 + 4 * qC);
-  }
-  f32x4 p_dy = {0, 0, 0, 0}, p_dyx = p_dy, p_dw = p_dy;  // column partial sums of this lane
+  const int tid = threadIdx.x, lane = tid & 63, gi = tid >> 6;
+  const int T = a.T, Dk = a.Dk, G = a.G;
+  const int Tp = (T + 3) & ~3;
+  const int QD = Dk >> 2;
+  float* dol = lds;                 // [G][Dk] dout rows
+  float* wl = dol + G * Dk;         // [G][Tp] softmax weights used by the dkeys sum
+  float* pdb = wl + G * Tp;
   float p_db = 0.f;
   for (long h = blockIdx.x; h < a.Hn; h += gridDim.x) {
     const int len = a.seq_len[h * a.len_stride];
     const float* kp = a.keys + h * T * Dk;
-    for (int e = lane; e < T * QD; e += 64) reinterpret_cast<f32x4*>(acc)[e] = (f32x4){0, 0, 0, 0};
-    for (int gi = 0; gi < a.G; ++gi) {
-      const long r = h * a.G + gi;
-      __syncthreads();
-      for (int d = lane; d < Dk; d += 64) dol[d] = a.dout[r * Dk + d];
-      __syncthreads();
-      // d weight_t = dout . keys[h,t,:]  (step layout), softmax backward
-      float w[ATT_MAXCH], dw[ATT_MAXCH];
-      float dotsum = 0.f;
+    const long r = h * G + gi;
+    __syncthreads();  // the previous group's dkeys pass is done with dol / wl
+    for (int d = lane; d < Dk; d += 64) dol[gi * Dk + d] = a.dout[r * Dk + d];
+    __syncthreads();
+    float w[NCH], dw[NCH];
+    float dotsum = 0.f;
 #pragma unroll
-      for (int c = 0; c < ATT_MAXCH; ++c) {
-        const int t = c * 64 + lane;
-        w[c] = 0.f; dw[c] = 0.f;
-        if (t < T && t < len) {
-          w[c] = a.wts[r * T + t];
-          const float* row = kp + (long)t * Dk;
-          float v = 0.f;
-          for (int q = 0; q < QD; ++q) v += dot4(ld4(row + 4 * q), ld4(dol + 4 * q));
-          dw[c] = v;
-          dotsum += w[c] * v;
-        }
+    for (int c = 0; c < NCH; ++c) {
+      const int t = c * 64 + lane;
+      w[c] = 0.f; dw[c] = 0.f;
+      if (t < T && t < len) {
+        w[c] = a.wts[r * T + t];
+        const float* row = kp + (long)t * Dk;
+        float v = 0.f;
+#pragma unroll 5
+        for (int q = 0; q < QD; ++q) v += dot4(ld4(row + 4 * q), ld4(dol + gi * Dk + 4 * q));
+        dw[c] = v;
+        dotsum += w[c] * v;
       }
-      dotsum = wave_sum(dotsum);
+    }
+    dotsum = wave_sum(dotsum);
 #pragma unroll
-      for (int c = 0; c < ATT_MAXCH; ++c) {
-        const int t = c * 64 + lane;
-        if (t < T) {
-          const float ds = (t < len) ? w[c] * (dw[c] - dotsum) : 0.f;
-          dsl[t] = ds;
-          p_db += ds;
-        }
-      }
-      __syncthreads();
-      // dkeys accumulation (column layout over Dk); for len == 0 the weights are the constant 1/T
-      if (tsD < tparD) {
-        const f32x4 dv = ld4(dol + 4 * qD);
-        const int tend = len > 0 ? len : T;
-        for (int t = tsD; t < tend; t += tparD) {
-          const float wt = len > 0 ? a.wts[r * T + t] : 1.0f / (float)T;
-          f32x4* ap = reinterpret_cast<f32x4*>(acc + t * Dk + 4 * qD);
-          *ap += dv * wt;
-        }
-      }
-      // dy1 = ds * w_out * (y1 > 0), column layout over C1; BN / w_out column sums
-      if (tsC < tparC) {
-        const float* zp = a.z1 + r * T * C1 + 4 * qC;
-        float* dp = a.dy1 + r * T * C1 + 4 * qC;
-        for (int t = tsC; t < T; t += tparC) {
-          const f32x4 zz = ld4(zp + (long)t * C1);
-          const f32x4 y = zz * sc + sh;
-          const float ds = dsl[t];
-          f32x4 d = wo * ds;
-          d.x = y.x > 0.f ? d.x : 0.f; d.y = y.y > 0.f ? d.y : 0.f;
-          d.z = y.z > 0.f ? d.z : 0.f; d.w = y.w > 0.f ? d.w : 0.f;
-          st4(dp + (long)t * C1, d);
-          p_dy += d;
-          p_dyx += d * ((zz - mu) * is);
-          p_dw += relu4(y) * ds;
-        }
+    for (int c = 0; c < NCH; ++c) {
+      const int t = c * 64 + lane;
+      if (t < T) {
+        const float ds = (t < len) ? w[c] * (dw[c] - dotsum) : 0.f;
+        ds_out[r * T + t] = ds;
+        wl[gi * Tp + t] = len > 0 ? w[c] : 1.0f / (float)T;  // len == 0: the weights are the constant 1/T
+        p_db += ds;
       }
     }
     __syncthreads();
-    // dkeys[h] += acc
+    // dkeys[h, t, :] += sum_g w[g, t] * dout[g, :]   (all waves of the group)
     float* dk = a.dkeys + h * T * Dk;
-    for (int e = lane; e < T * QD; e += 64) {
+    for (int e = tid; e < T * QD; e += 64 * G) {
+      const int t = e / QD, q = e - t * QD;
+      f32x4 sum = {0, 0, 0, 0};
+      for (int gg = 0; gg < G; ++gg) sum += ld4(dol + gg * Dk + 4 * q) * wl[gg * Tp + t];
       f32x4* gp = reinterpret_cast<f32x4*>(dk) + e;
-      *gp += reinterpret_cast<f32x4*>(acc)[e];
+      *gp += sum;
     }
-    __syncthreads();
-  }
-  // block partials: reduce the tslot copies through LDS (reuse acc region)
-  __syncthreads();
-  f32x4* red = reinterpret_cast<f32x4*>(acc);
-  red[lane] = p_dy; red[64 + lane] = p_dyx; red[128 + lane] = p_dw;
-  __syncthreads();
-  if (tsC == 0) {
-    for (int s = 1; s < tparC; ++s) {
-      p_dy += red[lane + s * QC]; p_dyx += red[64 + lane + s * QC]; p_dw += red[128 + lane + s * QC];
-    }
-    double* bp = a.bn_partial + (long)blockIdx.x * 2 * C1;
-    bp[4 * qC + 0] = p_dy.x; bp[4 * qC + 1] = p_dy.y; bp[4 * qC + 2] = p_dy.z; bp[4 * qC + 3] = p_dy.w;
-    bp[C1 + 4 * qC + 0] = p_dyx.x; bp[C1 + 4 * qC + 1] = p_dyx.y;
-    bp[C1 + 4 * qC + 2] = p_dyx.z; bp[C1 + 4 * qC + 3] = p_dyx.w;
-    st4(a.w_partial + (long)blockIdx.x * (C1 + 4) + 4 * qC, p_dw);
   }
   p_db = wave_sum(p_db);
-  if (lane == 0) a.w_partial[(long)blockIdx.x * (C1 + 4) + C1] = p_db;
+  if (lane == 0) pdb[gi] = p_db;
+  __syncthreads();
+  if (tid == 0) {
+    float s = 0.f;
+    for (int wv = 0; wv < G; ++wv) s += pdb[wv];
+    b_partial[blockIdx.x] = s;
+  }
 }
 
 static int att_bwd_blocks(int Hn) { return Hn > ATT_BWD_MAX_BLOCKS ? ATT_BWD_MAX_BLOCKS : Hn; }
-extern "C" int clsr_att_out_bwd_parts(int Hn) { return att_bwd_blocks(Hn); }
+extern "C" int clsr_att_score_bwd_parts(int Hn) { return att_bwd_blocks(Hn); }
 
-extern "C" int clsr_att_out_bwd(const float* dout, const float* wts, const float* z1,
-                                const float* scale1, const float* shift1, const float* mean1,
-                                const float* invstd1, const float* w_out, const int* seq_len,
-                                int len_stride, const float* keys, int Hn, int G, int T, int C1, int Dk,
-                                float* dy1, float* dkeys, double* bn_partial, float* w_partial,
-                                void* stream) {
-  CLSR_CHECK_ARG(dout && wts && z1 && scale1 && shift1 && mean1 && invstd1 && w_out && seq_len && keys);
-  CLSR_CHECK_ARG(dy1 && dkeys && bn_partial && w_partial && Hn > 0 && G > 0 && T > 0);
-  CLSR_CHECK_SUPPORTED(T <= 64 * ATT_MAXCH && C1 % 4 == 0 && Dk % 4 == 0 && C1 <= 256 && Dk <= 256);
+extern "C" int clsr_att_score_bwd(const float* dout, const float* wts, const int* seq_len, int len_stride,
+                                  const float* keys, int Hn, int G, int T, int Dk, float* ds, float* dkeys,
+                                  float* b_partial, void* stream) {
+  CLSR_CHECK_ARG(dout && wts && seq_len && keys && ds && dkeys && b_partial && Hn > 0 && G > 0 && T > 0);
+  CLSR_CHECK_SUPPORTED(T <= 64 * ATT_MAXCH && Dk % 4 == 0 && Dk <= 256 && G <= ATT_BWD_MAXG);
   AttOutArgs a = {};
-  a.z1 = z1; a.scale1 = scale1; a.shift1 = shift1; a.mean1 = mean1; a.invstd1 = invstd1;
-  a.w_out = w_out; a.seq_len = seq_len; a.len_stride = len_stride; a.keys = keys;
-  a.Hn = Hn; a.G = G; a.T = T; a.C1 = C1; a.Dk = Dk; a.wts = const_cast<float*>(wts);
-  a.dout = dout; a.dy1 = dy1; a.dkeys = dkeys; a.bn_partial = bn_partial; a.w_partial = w_partial;
-  size_t accf = (size_t)T * Dk;
-  if (accf < 192 * 4) accf = 192 * 4;
-  size_t shmem = (((size_t)T + 3) / 4 * 4 + Dk + accf) * sizeof(float);
-  CLSR_CHECK_SUPPORTED(shmem <= 160 * 1024);
-  if (shmem > 64 * 1024)
-    CLSR_HIP(hipFuncSetAttribute((const void*)att_out_bwd_kernel,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(att_out_bwd_kernel, dim3(att_bwd_blocks(Hn)), dim3(64), shmem,
-                     (hipStream_t)stream, a);
+  a.seq_len = seq_len; a.len_stride = len_stride; a.keys = keys;
+  a.Hn = Hn; a.G = G; a.T = T; a.Dk = Dk; a.wts = const_cast<float*>(wts);
+  a.dout = dout; a.dkeys = dkeys;
+  const size_t Tp = ((size_t)T + 3) / 4 * 4;
+  const size_t shmem = ((size_t)G * Dk + (size_t)G * Tp + ATT_BWD_MAXG) * sizeof(float);
+  CLSR_CHECK_SUPPORTED(shmem <= 64 * 1024);
+  const dim3 grid(att_bwd_blocks(Hn)), block(64 * G);
+  hipStream_t s = (hipStream_t)stream;
+  if (T <= 64) hipLaunchKernelGGL(att_score_bwd_kernel<1>, grid, block, shmem, s, a, ds, b_partial);
+  else if (T <= 128) hipLaunchKernelGGL(att_score_bwd_kernel<2>, grid, block, shmem, s, a, ds, b_partial);
+  else hipLaunchKernelGGL(att_score_bwd_kernel<4>, grid, block, shmem, s, a, ds, b_partial);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// column layout: thread (ty = tid / QC, q = tid % QC) owns the 16-byte column chunk q of rows ty, ty + rpb, ...
+#define DY1_MAX_BLOCKS 2048
+__device__ __forceinline__ f32x4 dy1_of(f32x4 zz, float ds, f32x4 sc, f32x4 sh, f32x4 wo) {
+  const f32x4 y = zz * sc + sh;
+  f32x4 d = wo * ds;
+  d.x = y.x > 0.f ? d.x : 0.f; d.y = y.y > 0.f ? d.y : 0.f;
+  d.z = y.z > 0.f ? d.z : 0.f; d.w = y.w > 0.f ? d.w : 0.f;
+  return d;
+}
+
+__global__ void __launch_bounds__(256) att_dy1_stats_kernel(
+    const float* __restrict__ z1, const float* __restrict__ ds, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ w_out, long M, int C, double* __restrict__ bn_partial,
+    float* __restrict__ w_partial) {
+  __shared__ f32x4 red[3][256];
+  const int QC = C >> 2;
+  const int rpb = 256 / QC;
+  const int ty = threadIdx.x / QC, q = threadIdx.x - ty * QC;
+  f32x4 s1 = {0, 0, 0, 0}, s2 = s1, s3 = s1;
+  if (ty < rpb) {
+    const f32x4 sc = ld4(scale + 4 * q), sh = ld4(shift + 4 * q), wo = ld4(w_out + 4 * q);
+    const f32x4 mu = ld4(mean + 4 * q), is = ld4(invstd + 4 * q);
+    // a block owns a contiguous range of rows: fp32 partial sums stay short (<= M / blocks / rpb terms)
+    const long per = (M + gridDim.x - 1) / gridDim.x;
+    const long lo = (long)blockIdx.x * per, hi = lo + per < M ? lo + per : M;
+    for (long row = lo + ty; row < hi; row += rpb) {
+      const f32x4 zz = ld4(z1 + row * C + 4 * q);
+      const float dsv = ds[row];
+      const f32x4 y = zz * sc + sh;
+      const f32x4 d = dy1_of(zz, dsv, sc, sh, wo);
+      s1 += d;
+      s2 += d * ((zz - mu) * is);
+      s3 += relu4(y) * dsv;
+    }
+  }
+  red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2; red[2][threadIdx.x] = s3;
+  __syncthreads();
+  if (threadIdx.x < QC) {
+    double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+    f32x4 a2 = {0, 0, 0, 0};
+    for (int y = 0; y < rpb; ++y) {
+      const f32x4 u = red[0][y * QC + threadIdx.x], v = red[1][y * QC + threadIdx.x];
+      a0[0] += u.x; a0[1] += u.y; a0[2] += u.z; a0[3] += u.w;
+      a1[0] += v.x; a1[1] += v.y; a1[2] += v.z; a1[3] += v.w;
+      a2 += red[2][y * QC + threadIdx.x];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      bn_partial[((long)blockIdx.x * 2 + 0) * C + 4 * threadIdx.x + r] = a0[r];
+      bn_partial[((long)blockIdx.x * 2 + 1) * C + 4 * threadIdx.x + r] = a1[r];
+    }
+    st4(w_partial + (long)blockIdx.x * C + 4 * threadIdx.x, a2);
+  }
+}
+
+static int dy1_blocks(long M, int C) {
+  const int rpb = 256 / (C / 4);
+  long b = (M + (long)rpb * 8 - 1) / ((long)rpb * 8);
+  if (b > DY1_MAX_BLOCKS) b = DY1_MAX_BLOCKS;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+extern "C" int clsr_att_dy1_parts(long M, int C1) { return dy1_blocks(M, C1); }
+
+extern "C" int clsr_att_dy1_stats(const float* z1, const float* ds, const float* scale1, const float* shift1,
+                                  const float* mean1, const float* invstd1, const float* w_out, long M, int C1,
+                                  double* bn_partial, float* w_partial, void* stream) {
+  CLSR_CHECK_ARG(z1 && ds && scale1 && shift1 && mean1 && invstd1 && w_out && bn_partial && w_partial && M > 0);
+  CLSR_CHECK_SUPPORTED(C1 % 4 == 0 && C1 >= 4 && C1 <= 1024);
+  hipLaunchKernelGGL(att_dy1_stats_kernel, dim3(dy1_blocks(M, C1)), dim3(256), 0, (hipStream_t)stream, z1, ds,
+                     scale1, shift1, mean1, invstd1, w_out, M, C1, bn_partial, w_partial);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// dz1 = a1 * dy1 + a2 * z1 + a3 with dy1 recomputed from (z1, ds); coef = [a1 | a2 | a3] from clsr_bn_bwd_coef
+__global__ void __launch_bounds__(256) att_dy1_apply_kernel(
+    const float* __restrict__ z1, const float* __restrict__ ds, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ w_out, const float* __restrict__ coef, long M,
+    int C, float* __restrict__ dz1) {
+  const int QC = C >> 2;
+  const long total = M * QC;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long row = e / QC;
+    const int q = (int)(e - row * QC);
+    const f32x4 a1 = ld4(coef + 4 * q), a2 = ld4(coef + C + 4 * q), a3 = ld4(coef + 2 * C + 4 * q);
+    const f32x4 zz = ld4(z1 + e * 4);
+    const f32x4 d = dy1_of(zz, ds[row], ld4(scale + 4 * q), ld4(shift + 4 * q), ld4(w_out + 4 * q));
+    st4(dz1 + e * 4, a1 * d + a2 * zz + a3);
+  }
+}
+
+extern "C" int clsr_att_dy1_apply(const float* z1, const float* ds, const float* scale1, const float* shift1,
+                                  const float* w_out, const float* coef, long M, int C1, float* dz1,
+                                  void* stream) {
+  CLSR_CHECK_ARG(z1 && ds && scale1 && shift1 && w_out && coef && dz1 && M > 0);
+  CLSR_CHECK_SUPPORTED(C1 % 4 == 0);
+  int blocks = clsr_cdiv(M * (C1 / 4), 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(att_dy1_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z1, ds, scale1,
+                     shift1, w_out, coef, M, C1, dz1);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }

@@ -10,9 +10,13 @@
 // Split of work: every input-side product (x.W_x, time-gate terms, biases) is hoisted out of the
 // time loop into one batched pgemm that produces Pin[h, t, :]; these kernels only run the
 // recurrence  state -> gates  with the hidden-to-hidden weights held in VGPRs as MFMA A
-// operands for the whole sequence.  One wavefront owns 16 histories; MFMA tile = D[16 hidden
-// features][16 histories]; the D layout of step t (lane (j,g): features 16*tile+4g+{0..3} of
-// history j) is exactly the B-operand layout of step t+1, so the state never leaves registers.
+// operands for the whole sequence.  One WORKGROUP of RNT waves owns 16 histories; MFMA tile =
+// D[16 hidden features][16 histories]; wave w owns feature tile w of every gate (its slice of the
+// weights, of the state and of every elementwise update).  The D layout of a step (lane (j,g):
+// features 16*tile+4g+{0..3} of history j) is exactly the B-operand layout of the next matvec, so
+// the only cross-wave traffic is one 16-byte LDS write + barrier + RNT 16-byte LDS reads per lane
+// whenever a full state vector is needed (GRU: r.h and h', Time4LSTM: m).  Compared with one wave
+// per 16 histories this divides the T-serial MFMA chain and the register footprint by RNT.
 // Hidden size n <= 48 (RNT = 3 feature tiles), n % 4 == 0.
 #include "common.h"
 #include "clsr_hip.h"
@@ -50,19 +54,23 @@ __device__ __forceinline__ f32x4 load_w_bwd(const float* W, int ld, int colbase,
   return Z4;
 }
 
-template <int NO>
-__device__ __forceinline__ void matvec(f32x4 (&acc)[NO], const f32x4 (&w)[NO][RNT], const f32x4 (&b)[RNT]) {
+// acc (one feature tile) += sum over all RNT k-tiles of W-tile . state
+__device__ __forceinline__ void mv1(f32x4& acc, const f32x4 (&w)[RNT], const f32x4 (&b)[RNT]) {
 #pragma unroll
   for (int kt = 0; kt < RNT; ++kt) {
-#pragma unroll
-    for (int ot = 0; ot < NO; ++ot) MFMA4(acc[ot], w[ot][kt].x, b[kt].x);
-#pragma unroll
-    for (int ot = 0; ot < NO; ++ot) MFMA4(acc[ot], w[ot][kt].y, b[kt].y);
-#pragma unroll
-    for (int ot = 0; ot < NO; ++ot) MFMA4(acc[ot], w[ot][kt].z, b[kt].z);
-#pragma unroll
-    for (int ot = 0; ot < NO; ++ot) MFMA4(acc[ot], w[ot][kt].w, b[kt].w);
+    MFMA4(acc, w[kt].x, b[kt].x);
+    MFMA4(acc, w[kt].y, b[kt].y);
+    MFMA4(acc, w[kt].z, b[kt].z);
+    MFMA4(acc, w[kt].w, b[kt].w);
   }
+}
+
+// publish this wave's tile of a vector and collect the full vector (RNT tiles) of the workgroup
+__device__ __forceinline__ void xchg(f32x4* buf, int w, int lane, f32x4 own, f32x4 (&full)[RNT]) {
+  buf[w * 64 + lane] = own;
+  __syncthreads();
+#pragma unroll
+  for (int kt = 0; kt < RNT; ++kt) full[kt] = buf[kt * 64 + lane];
 }
 
 __device__ __forceinline__ int wave_max_i(int v) {
@@ -91,163 +99,139 @@ struct GruArgs {
   int lddp;
 };
 
-__device__ __forceinline__ void gru_fwd_body(const GruArgs& a, const int bx) {
-  const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+// xb: LDS exchange area of the workgroup (f32x4 units): fwd uses [0, 2*RNT*64), bwd [0, 3*RNT*64)
+__device__ __forceinline__ void gru_fwd_body(const GruArgs& a, const int bx, f32x4* xb) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   const int n = a.n, T = a.T;
   const long h = (long)bx * 16 + j;
   const bool hvalid = h < a.Hn;
-  f32x4 wr[RNT][RNT], wu[RNT][RNT], wc[RNT][RNT];
+  f32x4 wr[RNT], wu[RNT], wc[RNT];
 #pragma unroll
-  for (int ot = 0; ot < RNT; ++ot)
-#pragma unroll
-    for (int kt = 0; kt < RNT; ++kt) {
-      wr[ot][kt] = load_w_fwd(a.Wgh, a.ldg, 0, n, ot, kt, j, g);
-      wu[ot][kt] = load_w_fwd(a.Wgh, a.ldg, n, n, ot, kt, j, g);
-      wc[ot][kt] = load_w_fwd(a.Wch, a.ldc, 0, n, ot, kt, j, g);
-    }
-  bool cval[RNT];
+  for (int kt = 0; kt < RNT; ++kt) {
+    wr[kt] = load_w_fwd(a.Wgh, a.ldg, 0, n, w, kt, j, g);
+    wu[kt] = load_w_fwd(a.Wgh, a.ldg, n, n, w, kt, j, g);
+    wc[kt] = load_w_fwd(a.Wch, a.ldc, 0, n, w, kt, j, g);
+  }
+  const int col = 16 * w + 4 * g;
+  const bool cval = hvalid && col < n;
   f32x4 hs[RNT];
 #pragma unroll
-  for (int tl = 0; tl < RNT; ++tl) {
-    cval[tl] = hvalid && (16 * tl + 4 * g < n);
-    hs[tl] = (cval[tl] && a.h0) ? ld4(a.h0 + h * a.h0_stride + 16 * tl + 4 * g) : Z4;
-  }
+  for (int kt = 0; kt < RNT; ++kt)
+    hs[kt] = (hvalid && 16 * kt + 4 * g < n && a.h0) ? ld4(a.h0 + h * a.h0_stride + 16 * kt + 4 * g) : Z4;
+  f32x4 hown = (cval && a.h0) ? ld4(a.h0 + h * a.h0_stride + col) : Z4;
   const int len = hvalid ? min(a.seq_len[h * a.len_stride], T) : 0;
   const int Tmax = wave_max_i(len);
-  const float* pin = a.Pin + (hvalid ? h : 0) * (long)T * a.ldp + 4 * g;
-  f32x4 pn[3][RNT];
+  const float* pin = a.Pin + (hvalid ? h : 0) * (long)T * a.ldp + col;
+  f32x4 pn[3];
 #pragma unroll
-  for (int gb = 0; gb < 3; ++gb)
-#pragma unroll
-    for (int tl = 0; tl < RNT; ++tl)
-      pn[gb][tl] = (cval[tl] && 0 < len) ? ld4(pin + gb * n + 16 * tl) : Z4;
+  for (int gb = 0; gb < 3; ++gb) pn[gb] = (cval && 0 < len) ? ld4(pin + gb * n) : Z4;
+  f32x4* bufA = xb;
+  f32x4* bufB = xb + RNT * 64;
   for (int t = 0; t < Tmax; ++t) {
     const bool live = t < len;
-    f32x4 accr[RNT], accu[RNT], accc[RNT];
-#pragma unroll
-    for (int tl = 0; tl < RNT; ++tl) { accr[tl] = pn[0][tl]; accu[tl] = pn[1][tl]; accc[tl] = pn[2][tl]; }
+    f32x4 accr = pn[0], accu = pn[1], accc = pn[2];
     {  // prefetch next step's input projections
       const bool nl = (t + 1) < len;
 #pragma unroll
-      for (int gb = 0; gb < 3; ++gb)
-#pragma unroll
-        for (int tl = 0; tl < RNT; ++tl)
-          pn[gb][tl] = (cval[tl] && nl) ? ld4(pin + (long)(t + 1) * a.ldp + gb * n + 16 * tl) : Z4;
+      for (int gb = 0; gb < 3; ++gb) pn[gb] = (cval && nl) ? ld4(pin + (long)(t + 1) * a.ldp + gb * n) : Z4;
     }
-    matvec<RNT>(accr, wr, hs);
-    matvec<RNT>(accu, wu, hs);
-    f32x4 r[RNT], u[RNT], rh[RNT];
-#pragma unroll
-    for (int tl = 0; tl < RNT; ++tl) { r[tl] = sig4(accr[tl]); u[tl] = sig4(accu[tl]); rh[tl] = r[tl] * hs[tl]; }
-    matvec<RNT>(accc, wc, rh);
-#pragma unroll
-    for (int tl = 0; tl < RNT; ++tl) {
-      const f32x4 c = tanh4(accc[tl]);
-      const f32x4 hn = u[tl] * hs[tl] + (1.0f - u[tl]) * c;
-      if (live && cval[tl]) {
-        const long pos = h * T + t;
-        const int col = 16 * tl + 4 * g;
-        if (a.hprev) st4(a.hprev + pos * n + col, hs[tl]);
-        if (a.gates) {
-          float* gp = a.gates + pos * 3 * n + col;
-          st4(gp, r[tl]); st4(gp + n, u[tl]); st4(gp + 2 * n, c);
-        }
-        if (a.out_seq) st4(a.out_seq + pos * n + col, hn);
+    mv1(accr, wr, hs);
+    mv1(accu, wu, hs);
+    const f32x4 r = sig4(accr), u = sig4(accu);
+    f32x4 rh[RNT];
+    xchg(bufA, w, lane, r * hown, rh);
+    mv1(accc, wc, rh);
+    const f32x4 c = tanh4(accc);
+    const f32x4 hn = u * hown + (1.0f - u) * c;
+    if (live && cval) {
+      const long pos = h * T + t;
+      if (a.hprev) st4(a.hprev + pos * n + col, hown);
+      if (a.gates) {
+        float* gp = a.gates + pos * 3 * n + col;
+        st4(gp, r); st4(gp + n, u); st4(gp + 2 * n, c);
       }
-      hs[tl] = sel4(live, hn, hs[tl]);
+      if (a.out_seq) st4(a.out_seq + pos * n + col, hn);
     }
+    hown = sel4(live, hn, hown);
+    xchg(bufB, w, lane, hown, hs);
   }
-#pragma unroll
-  for (int tl = 0; tl < RNT; ++tl)
-    if (cval[tl]) {
-      const int col = 16 * tl + 4 * g;
-      if (a.hT) st4(a.hT + h * n + col, hs[tl]);
-      if (a.out_seq)
-        for (int t = len; t < T; ++t) st4(a.out_seq + (h * T + t) * n + col, Z4);
-    }
+  if (cval) {
+    if (a.hT) st4(a.hT + h * n + col, hown);
+    if (a.out_seq)
+      for (int t = len; t < T; ++t) st4(a.out_seq + (h * T + t) * n + col, Z4);
+  }
 }
 
-__device__ __forceinline__ void gru_bwd_body(const GruArgs& a, const int bx) {
-  const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+__device__ __forceinline__ void gru_bwd_body(const GruArgs& a, const int bx, f32x4* xb) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   const int n = a.n, T = a.T;
   const long h = (long)bx * 16 + j;
   const bool hvalid = h < a.Hn;
-  // transposed operands: d(state in) = sum_o W[in][o] * dgate[o]
-  f32x4 wr[RNT][RNT], wu[RNT][RNT], wc[RNT][RNT];
+  // transposed operands: d(state in) = sum_o W[in][o] * dgate[o]; this wave owns in-tile w
+  f32x4 wr[RNT], wu[RNT], wc[RNT];
 #pragma unroll
-  for (int ot = 0; ot < RNT; ++ot)
-#pragma unroll
-    for (int kt = 0; kt < RNT; ++kt) {
-      wr[ot][kt] = load_w_bwd(a.Wgh, a.ldg, 0, n, ot, kt, j, g);
-      wu[ot][kt] = load_w_bwd(a.Wgh, a.ldg, n, n, ot, kt, j, g);
-      wc[ot][kt] = load_w_bwd(a.Wch, a.ldc, 0, n, ot, kt, j, g);
-    }
-  bool cval[RNT];
-  f32x4 dh[RNT];
-#pragma unroll
-  for (int tl = 0; tl < RNT; ++tl) {
-    cval[tl] = hvalid && (16 * tl + 4 * g < n);
-    dh[tl] = (cval[tl] && a.dhT) ? ld4(a.dhT + h * n + 16 * tl + 4 * g) : Z4;
+  for (int kt = 0; kt < RNT; ++kt) {
+    wr[kt] = load_w_bwd(a.Wgh, a.ldg, 0, n, w, kt, j, g);
+    wu[kt] = load_w_bwd(a.Wgh, a.ldg, n, n, w, kt, j, g);
+    wc[kt] = load_w_bwd(a.Wch, a.ldc, 0, n, w, kt, j, g);
   }
+  const int col = 16 * w + 4 * g;
+  const bool cval = hvalid && col < n;
+  f32x4 dh = (cval && a.dhT) ? ld4(a.dhT + h * n + col) : Z4;
   const int len = hvalid ? min(a.seq_len[h * a.len_stride], T) : 0;
   const int Tmax = wave_max_i(len);
-  // zero dPin past len
-#pragma unroll
-  for (int tl = 0; tl < RNT; ++tl)
-    if (cval[tl])
-      for (int t = len; t < T; ++t) {
-        float* dp = a.dPin + (h * T + t) * a.lddp + 16 * tl + 4 * g;
-        st4(dp, Z4); st4(dp + n, Z4); st4(dp + 2 * n, Z4);
-      }
+  if (cval)  // zero dPin past len
+    for (int t = len; t < T; ++t) {
+      float* dp = a.dPin + (h * T + t) * a.lddp + col;
+      st4(dp, Z4); st4(dp + n, Z4); st4(dp + 2 * n, Z4);
+    }
+  f32x4* bufA = xb;
+  f32x4* bufR = xb + RNT * 64;
+  f32x4* bufU = xb + 2 * RNT * 64;
   for (int t = Tmax - 1; t >= 0; --t) {
     const bool live = t < len;
+    const bool ok = live && cval;
     const long pos = h * T + t;
-    f32x4 r[RNT], u[RNT], c[RNT], hp[RNT], dcp[RNT], du[RNT], dhn[RNT];
+    const float* gp = a.gates + pos * 3 * n + col;
+    const f32x4 r = ok ? ld4(gp) : Z4, u = ok ? ld4(gp + n) : Z4, c = ok ? ld4(gp + 2 * n) : Z4;
+    const f32x4 hp = ok ? ld4(a.hprev + pos * n + col) : Z4;
+    f32x4 d = dh;
+    if (ok && a.dout_seq) d += ld4(a.dout_seq + pos * n + col);
+    d = sel4(ok, d, Z4);
+    const f32x4 du = d * (hp - c);
+    const f32x4 dcp = d * (1.0f - u) * (1.0f - c * c);
+    f32x4 dhn = d * u;
+    f32x4 full[RNT];
+    xchg(bufA, w, lane, dcp, full);
+    f32x4 drh = Z4;
+    mv1(drh, wc, full);
+    const f32x4 drp = drh * hp * r * (1.0f - r);
+    const f32x4 dup = du * u * (1.0f - u);
+    dhn += drh * r;
+    bufR[w * 64 + lane] = drp;
+    xchg(bufU, w, lane, dup, full);
+    mv1(dhn, wu, full);
 #pragma unroll
-    for (int tl = 0; tl < RNT; ++tl) {
-      const int col = 16 * tl + 4 * g;
-      const bool ok = live && cval[tl];
-      const float* gp = a.gates + pos * 3 * n + col;
-      r[tl] = ok ? ld4(gp) : Z4;
-      u[tl] = ok ? ld4(gp + n) : Z4;
-      c[tl] = ok ? ld4(gp + 2 * n) : Z4;
-      hp[tl] = ok ? ld4(a.hprev + pos * n + col) : Z4;
-      f32x4 d = dh[tl];
-      if (ok && a.dout_seq) d += ld4(a.dout_seq + pos * n + col);
-      d = sel4(ok, d, Z4);
-      du[tl] = d * (hp[tl] - c[tl]);
-      dcp[tl] = d * (1.0f - u[tl]) * (1.0f - c[tl] * c[tl]);
-      dhn[tl] = d * u[tl];
+    for (int kt = 0; kt < RNT; ++kt) full[kt] = bufR[kt * 64 + lane];
+    mv1(dhn, wr, full);
+    if (ok) {
+      float* dp = a.dPin + pos * a.lddp + col;
+      st4(dp, drp); st4(dp + n, dup); st4(dp + 2 * n, dcp);
     }
-    f32x4 drh[RNT] = {Z4, Z4, Z4};
-    matvec<RNT>(drh, wc, dcp);
-    f32x4 drp[RNT], dup[RNT];
-#pragma unroll
-    for (int tl = 0; tl < RNT; ++tl) {
-      drp[tl] = drh[tl] * hp[tl] * r[tl] * (1.0f - r[tl]);
-      dup[tl] = du[tl] * u[tl] * (1.0f - u[tl]);
-      dhn[tl] += drh[tl] * r[tl];
-    }
-    matvec<RNT>(dhn, wr, drp);
-    matvec<RNT>(dhn, wu, dup);
-#pragma unroll
-    for (int tl = 0; tl < RNT; ++tl) {
-      if (live && cval[tl]) {
-        float* dp = a.dPin + pos * a.lddp + 16 * tl + 4 * g;
-        st4(dp, drp[tl]); st4(dp + n, dup[tl]); st4(dp + 2 * n, dcp[tl]);
-      }
-      dh[tl] = sel4(live, dhn[tl], dh[tl]);
-    }
+    dh = sel4(live, dhn, dh);
   }
-  if (a.dh0) {
-#pragma unroll
-    for (int tl = 0; tl < RNT; ++tl)
-      if (cval[tl]) st4(a.dh0 + h * n + 16 * tl + 4 * g, dh[tl]);
-  }
+  if (a.dh0 && cval) st4(a.dh0 + h * n + col, dh);
 }
 
-__global__ void __launch_bounds__(64) gru_fwd_kernel(GruArgs a) { gru_fwd_body(a, blockIdx.x); }
-__global__ void __launch_bounds__(64) gru_bwd_kernel(GruArgs a) { gru_bwd_body(a, blockIdx.x); }
+#define RNN_XB (2 * 4 * RNT * 64)  // f32x4 units: the largest exchange area (Time4LSTM backward)
+__global__ void __launch_bounds__(64 * RNT) gru_fwd_kernel(GruArgs a) {
+  __shared__ f32x4 xb[RNN_XB];
+  gru_fwd_body(a, blockIdx.x, xb);
+}
+__global__ void __launch_bounds__(64 * RNT) gru_bwd_kernel(GruArgs a) {
+  __shared__ f32x4 xb[RNN_XB];
+  gru_bwd_body(a, blockIdx.x, xb);
+}
 
 static int check_rnn_shape(int Hn, int T, int n, int ld) {
   CLSR_CHECK_ARG(Hn > 0 && T > 0);
@@ -267,7 +251,7 @@ extern "C" int clsr_gru_fwd(const float* Pin, int ldp, const float* Wgh, int ldg
   a.Pin = Pin; a.ldp = ldp; a.Wgh = Wgh; a.ldg = ldg; a.Wch = Wch; a.ldc = ldc; a.h0 = h0;
   a.h0_stride = h0_stride; a.seq_len = seq_len; a.len_stride = len_stride; a.Hn = Hn; a.T = T; a.n = n;
   a.hT = hT; a.out_seq = out_seq; a.hprev = hprev; a.gates = gates;
-  hipLaunchKernelGGL(gru_fwd_kernel, dim3(clsr_cdiv(Hn, 16)), dim3(64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(gru_fwd_kernel, dim3(clsr_cdiv(Hn, 16)), dim3(64 * RNT), 0, (hipStream_t)stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
@@ -285,7 +269,7 @@ extern "C" int clsr_gru_bwd(const float* gates, const float* hprev, const float*
   a.Wgh = Wgh; a.ldg = ldg; a.Wch = Wch; a.ldc = ldc; a.seq_len = seq_len; a.len_stride = len_stride;
   a.Hn = Hn; a.T = T; a.n = n; a.dhT = dhT; a.dout_seq = dout_seq; a.dPin = dPin; a.dh0 = dh0;
   a.lddp = 3 * n;
-  hipLaunchKernelGGL(gru_bwd_kernel, dim3(clsr_cdiv(Hn, 16)), dim3(64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(gru_bwd_kernel, dim3(clsr_cdiv(Hn, 16)), dim3(64 * RNT), 0, (hipStream_t)stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
@@ -307,147 +291,151 @@ struct T4Args {
   int lddp;
 };
 
-__device__ __forceinline__ void t4lstm_fwd_body(const T4Args& a, const int bx) {
-  const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+__device__ __forceinline__ void t4lstm_fwd_body(const T4Args& a, const int bx, f32x4* xb) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   const int n = a.n, T = a.T;
   const long h = (long)bx * 16 + j;
   const bool hvalid = h < a.Hn;
-  f32x4 w[4][RNT][RNT];
+  f32x4 wm[4][RNT];
 #pragma unroll
   for (int gb = 0; gb < 4; ++gb)
 #pragma unroll
-    for (int ot = 0; ot < RNT; ++ot)
-#pragma unroll
-      for (int kt = 0; kt < RNT; ++kt) w[gb][ot][kt] = load_w_fwd(a.Wm, a.ldm, gb * n, n, ot, kt, j, g);
-  bool cval[RNT];
-  f32x4 cs[RNT], ms[RNT];
-#pragma unroll
-  for (int tl = 0; tl < RNT; ++tl) { cval[tl] = hvalid && (16 * tl + 4 * g < n); cs[tl] = Z4; ms[tl] = Z4; }
+    for (int kt = 0; kt < RNT; ++kt) wm[gb][kt] = load_w_fwd(a.Wm, a.ldm, gb * n, n, w, kt, j, g);
+  const int col = 16 * w + 4 * g;
+  const bool cval = hvalid && col < n;
+  f32x4 cs = Z4, mown = Z4, ms[RNT] = {Z4, Z4, Z4};
   const int len = hvalid ? min(a.seq_len[h * a.len_stride], T) : 0;
   const int Tmax = wave_max_i(len);
-  const float* pin = a.Pin + (hvalid ? h : 0) * (long)T * a.ldp + 4 * g;
-  f32x4 pn[6][RNT];
+  const float* pin = a.Pin + (hvalid ? h : 0) * (long)T * a.ldp + col;
+  f32x4 pn[6];
 #pragma unroll
-  for (int gb = 0; gb < 6; ++gb)
-#pragma unroll
-    for (int tl = 0; tl < RNT; ++tl) pn[gb][tl] = (cval[tl] && 0 < len) ? ld4(pin + gb * n + 16 * tl) : Z4;
+  for (int gb = 0; gb < 6; ++gb) pn[gb] = (cval && 0 < len) ? ld4(pin + gb * n) : Z4;
   for (int t = 0; t < Tmax; ++t) {
     const bool live = t < len;
-    f32x4 acc[4][RNT], tns[RNT], tls[RNT];
+    f32x4 acc[4];
 #pragma unroll
-    for (int tl = 0; tl < RNT; ++tl) {
-#pragma unroll
-      for (int gb = 0; gb < 4; ++gb) acc[gb][tl] = pn[gb][tl];
-      tns[tl] = pn[4][tl]; tls[tl] = pn[5][tl];
-    }
+    for (int gb = 0; gb < 4; ++gb) acc[gb] = pn[gb];
+    const f32x4 tns = pn[4], tls = pn[5];
     {
       const bool nl = (t + 1) < len;
 #pragma unroll
-      for (int gb = 0; gb < 6; ++gb)
-#pragma unroll
-        for (int tl = 0; tl < RNT; ++tl)
-          pn[gb][tl] = (cval[tl] && nl) ? ld4(pin + (long)(t + 1) * a.ldp + gb * n + 16 * tl) : Z4;
+      for (int gb = 0; gb < 6; ++gb) pn[gb] = (cval && nl) ? ld4(pin + (long)(t + 1) * a.ldp + gb * n) : Z4;
     }
 #pragma unroll
-    for (int gb = 0; gb < 4; ++gb) matvec<RNT>(acc[gb], w[gb], ms);
+    for (int kt = 0; kt < RNT; ++kt) {  // four independent accumulators interleaved
 #pragma unroll
-    for (int tl = 0; tl < RNT; ++tl) {
-      const f32x4 ig = sig4(acc[0][tl]), jg = tanh4(acc[1][tl]), fg = sig4(acc[2][tl] + 1.0f);
-      const f32x4 og = sig4(acc[3][tl]), tn = sig4(tns[tl]), tlg = sig4(tls[tl]);
-      const f32x4 cn = fg * tlg * cs[tl] + ig * tn * jg;
-      const f32x4 mn = og * tanh4(cn);
-      if (live && cval[tl]) {
-        const long pos = h * T + t;
-        const int col = 16 * tl + 4 * g;
-        st4(a.out_seq + pos * n + col, mn);
-        if (a.act) {
-          float* ap = a.act + pos * 6 * n + col;
-          st4(ap, ig); st4(ap + n, jg); st4(ap + 2 * n, fg); st4(ap + 3 * n, og);
-          st4(ap + 4 * n, tn); st4(ap + 5 * n, tlg);
-          st4(a.cst + pos * n + col, cn);
-          st4(a.mprev + pos * n + col, ms[tl]);
-        }
+      for (int gb = 0; gb < 4; ++gb) MFMA4(acc[gb], wm[gb][kt].x, ms[kt].x);
+#pragma unroll
+      for (int gb = 0; gb < 4; ++gb) MFMA4(acc[gb], wm[gb][kt].y, ms[kt].y);
+#pragma unroll
+      for (int gb = 0; gb < 4; ++gb) MFMA4(acc[gb], wm[gb][kt].z, ms[kt].z);
+#pragma unroll
+      for (int gb = 0; gb < 4; ++gb) MFMA4(acc[gb], wm[gb][kt].w, ms[kt].w);
+    }
+    const f32x4 ig = sig4(acc[0]), jg = tanh4(acc[1]), fg = sig4(acc[2] + 1.0f);
+    const f32x4 og = sig4(acc[3]), tn = sig4(tns), tlg = sig4(tls);
+    const f32x4 cn = fg * tlg * cs + ig * tn * jg;
+    const f32x4 mn = og * tanh4(cn);
+    if (live && cval) {
+      const long pos = h * T + t;
+      st4(a.out_seq + pos * n + col, mn);
+      if (a.act) {
+        float* ap = a.act + pos * 6 * n + col;
+        st4(ap, ig); st4(ap + n, jg); st4(ap + 2 * n, fg); st4(ap + 3 * n, og);
+        st4(ap + 4 * n, tn); st4(ap + 5 * n, tlg);
+        st4(a.cst + pos * n + col, cn);
+        st4(a.mprev + pos * n + col, mown);
       }
-      cs[tl] = sel4(live, cn, cs[tl]);
-      ms[tl] = sel4(live, mn, ms[tl]);
     }
+    cs = sel4(live, cn, cs);
+    mown = sel4(live, mn, mown);
+    xchg(xb + (t & 1) * RNT * 64, w, lane, mown, ms);  // double buffered: one barrier per step
   }
-#pragma unroll
-  for (int tl = 0; tl < RNT; ++tl)
-    if (cval[tl])
-      for (int t = len; t < T; ++t) st4(a.out_seq + (h * T + t) * n + 16 * tl + 4 * g, Z4);
+  if (cval)
+    for (int t = len; t < T; ++t) st4(a.out_seq + (h * T + t) * n + col, Z4);
 }
 
-__device__ __forceinline__ void t4lstm_bwd_body(const T4Args& a, const int bx) {
-  const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+__device__ __forceinline__ void t4lstm_bwd_body(const T4Args& a, const int bx, f32x4* xb) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   const int n = a.n, T = a.T;
   const long h = (long)bx * 16 + j;
   const bool hvalid = h < a.Hn;
-  f32x4 w[4][RNT][RNT];
+  f32x4 wm[4][RNT];
 #pragma unroll
   for (int gb = 0; gb < 4; ++gb)
 #pragma unroll
-    for (int ot = 0; ot < RNT; ++ot)
-#pragma unroll
-      for (int kt = 0; kt < RNT; ++kt) w[gb][ot][kt] = load_w_bwd(a.Wm, a.ldm, gb * n, n, ot, kt, j, g);
-  bool cval[RNT];
-  f32x4 dc[RNT], dm[RNT];
-#pragma unroll
-  for (int tl = 0; tl < RNT; ++tl) { cval[tl] = hvalid && (16 * tl + 4 * g < n); dc[tl] = Z4; dm[tl] = Z4; }
+    for (int kt = 0; kt < RNT; ++kt) wm[gb][kt] = load_w_bwd(a.Wm, a.ldm, gb * n, n, w, kt, j, g);
+  const int col = 16 * w + 4 * g;
+  const bool cval = hvalid && col < n;
+  f32x4 dc = Z4, dm = Z4;
   const int len = hvalid ? min(a.seq_len[h * a.len_stride], T) : 0;
   const int Tmax = wave_max_i(len);
+  if (cval)
+    for (int t = len; t < T; ++t) {
+      float* dp = a.dPin + (h * T + t) * a.lddp + col;
 #pragma unroll
-  for (int tl = 0; tl < RNT; ++tl)
-    if (cval[tl])
-      for (int t = len; t < T; ++t) {
-        float* dp = a.dPin + (h * T + t) * a.lddp + 16 * tl + 4 * g;
-#pragma unroll
-        for (int gb = 0; gb < 6; ++gb) st4(dp + gb * n, Z4);
-      }
+      for (int gb = 0; gb < 6; ++gb) st4(dp + gb * n, Z4);
+    }
   for (int t = Tmax - 1; t >= 0; --t) {
     const bool live = t < len;
+    const bool ok = live && cval;
     const long pos = h * T + t;
-    f32x4 dg[4][RNT], dcn[RNT];
+    const float* ap = a.act + pos * 6 * n + col;
+    const f32x4 ig = ok ? ld4(ap) : Z4, jg = ok ? ld4(ap + n) : Z4, fg = ok ? ld4(ap + 2 * n) : Z4;
+    const f32x4 og = ok ? ld4(ap + 3 * n) : Z4, tn = ok ? ld4(ap + 4 * n) : Z4, tlg = ok ? ld4(ap + 5 * n) : Z4;
+    const f32x4 cn = ok ? ld4(a.cst + pos * n + col) : Z4;
+    const f32x4 cp = (ok && t > 0) ? ld4(a.cst + (pos - 1) * n + col) : Z4;
+    f32x4 d = dm;
+    if (ok) d += ld4(a.dout_seq + pos * n + col);
+    d = sel4(ok, d, Z4);
+    const f32x4 tc = tanh4(cn);
+    const f32x4 dcc = sel4(ok, dc + d * og * (1.0f - tc * tc), Z4);
+    f32x4 dg[4];
+    dg[3] = d * tc * og * (1.0f - og);                         // d o_pre
+    dg[2] = dcc * tlg * cp * fg * (1.0f - fg);                 // d f_pre
+    dg[0] = dcc * tn * jg * ig * (1.0f - ig);                  // d i_pre
+    dg[1] = dcc * ig * tn * (1.0f - jg * jg);                  // d j_pre
+    const f32x4 dtn = dcc * ig * jg * tn * (1.0f - tn);        // d tns_pre
+    const f32x4 dtl = dcc * fg * cp * tlg * (1.0f - tlg);      // d tls_pre
+    const f32x4 dcn = dcc * fg * tlg;
+    if (ok) {
+      float* dp = a.dPin + pos * a.lddp + col;
+      st4(dp, dg[0]); st4(dp + n, dg[1]); st4(dp + 2 * n, dg[2]); st4(dp + 3 * n, dg[3]);
+      st4(dp + 4 * n, dtn); st4(dp + 5 * n, dtl);
+    }
+    // publish the four gate-gradient tiles (double buffered by step parity), one barrier, then
+    // d m_prev[own tile] = sum over gates and k-tiles
+    f32x4* buf = xb + (t & 1) * 4 * RNT * 64;
 #pragma unroll
-    for (int tl = 0; tl < RNT; ++tl) {
-      const int col = 16 * tl + 4 * g;
-      const bool ok = live && cval[tl];
-      const float* ap = a.act + pos * 6 * n + col;
-      const f32x4 ig = ok ? ld4(ap) : Z4, jg = ok ? ld4(ap + n) : Z4, fg = ok ? ld4(ap + 2 * n) : Z4;
-      const f32x4 og = ok ? ld4(ap + 3 * n) : Z4, tn = ok ? ld4(ap + 4 * n) : Z4, tlg = ok ? ld4(ap + 5 * n) : Z4;
-      const f32x4 cn = ok ? ld4(a.cst + pos * n + col) : Z4;
-      const f32x4 cp = (ok && t > 0) ? ld4(a.cst + (pos - 1) * n + col) : Z4;
-      f32x4 d = dm[tl];
-      if (ok) d += ld4(a.dout_seq + pos * n + col);
-      d = sel4(ok, d, Z4);
-      const f32x4 tc = tanh4(cn);
-      const f32x4 dcc = sel4(ok, dc[tl] + d * og * (1.0f - tc * tc), Z4);
-      dg[3][tl] = d * tc * og * (1.0f - og);                         // d o_pre
-      dg[2][tl] = dcc * tlg * cp * fg * (1.0f - fg);                 // d f_pre
-      dg[0][tl] = dcc * tn * jg * ig * (1.0f - ig);                  // d i_pre
-      dg[1][tl] = dcc * ig * tn * (1.0f - jg * jg);                  // d j_pre
-      const f32x4 dtn = dcc * ig * jg * tn * (1.0f - tn);            // d tns_pre
-      const f32x4 dtl = dcc * fg * cp * tlg * (1.0f - tlg);          // d tls_pre
-      dcn[tl] = dcc * fg * tlg;
-      if (ok) {
-        float* dp = a.dPin + pos * a.lddp + col;
-        st4(dp, dg[0][tl]); st4(dp + n, dg[1][tl]); st4(dp + 2 * n, dg[2][tl]); st4(dp + 3 * n, dg[3][tl]);
-        st4(dp + 4 * n, dtn); st4(dp + 5 * n, dtl);
+    for (int gb = 0; gb < 4; ++gb) buf[(gb * RNT + w) * 64 + lane] = dg[gb];
+    __syncthreads();
+    f32x4 dmn = Z4;
+#pragma unroll
+    for (int kt = 0; kt < RNT; ++kt) {
+      f32x4 bq[4];
+#pragma unroll
+      for (int gb = 0; gb < 4; ++gb) bq[gb] = buf[(gb * RNT + kt) * 64 + lane];
+#pragma unroll
+      for (int gb = 0; gb < 4; ++gb) {
+        MFMA4(dmn, wm[gb][kt].x, bq[gb].x);
+        MFMA4(dmn, wm[gb][kt].y, bq[gb].y);
+        MFMA4(dmn, wm[gb][kt].z, bq[gb].z);
+        MFMA4(dmn, wm[gb][kt].w, bq[gb].w);
       }
     }
-    f32x4 dmn[RNT] = {Z4, Z4, Z4};
-#pragma unroll
-    for (int gb = 0; gb < 4; ++gb) matvec<RNT>(dmn, w[gb], dg[gb]);
-#pragma unroll
-    for (int tl = 0; tl < RNT; ++tl) {
-      dc[tl] = sel4(live, dcn[tl], dc[tl]);
-      dm[tl] = sel4(live, dmn[tl], dm[tl]);
-    }
+    dc = sel4(live, dcn, dc);
+    dm = sel4(live, dmn, dm);
   }
 }
 
-__global__ void __launch_bounds__(64) t4lstm_fwd_kernel(T4Args a) { t4lstm_fwd_body(a, blockIdx.x); }
-__global__ void __launch_bounds__(64) t4lstm_bwd_kernel(T4Args a) { t4lstm_bwd_body(a, blockIdx.x); }
+__global__ void __launch_bounds__(64 * RNT) t4lstm_fwd_kernel(T4Args a) {
+  __shared__ f32x4 xb[RNN_XB];
+  t4lstm_fwd_body(a, blockIdx.x, xb);
+}
+__global__ void __launch_bounds__(64 * RNT) t4lstm_bwd_kernel(T4Args a) {
+  __shared__ f32x4 xb[RNN_XB];
+  t4lstm_bwd_body(a, blockIdx.x, xb);
+}
 
 // ------------------------------------------------------------------ fused multi-encoder launches
 // The CLSR step runs up to three independent recurrences over the same histories (GRU
@@ -462,15 +450,17 @@ struct RnnMultiArgs {
   int has_t4;
 };
 
-__global__ void __launch_bounds__(64) rnn_multi_fwd_kernel(RnnMultiArgs a) {
+__global__ void __launch_bounds__(64 * RNT) rnn_multi_fwd_kernel(RnnMultiArgs a) {
+  __shared__ f32x4 xb[RNN_XB];
   const int which = blockIdx.y;
-  if (which < a.ngru) gru_fwd_body(a.gru[which], blockIdx.x);
-  else t4lstm_fwd_body(a.t4, blockIdx.x);
+  if (which < a.ngru) gru_fwd_body(a.gru[which], blockIdx.x, xb);
+  else t4lstm_fwd_body(a.t4, blockIdx.x, xb);
 }
-__global__ void __launch_bounds__(64) rnn_multi_bwd_kernel(RnnMultiArgs a) {
+__global__ void __launch_bounds__(64 * RNT) rnn_multi_bwd_kernel(RnnMultiArgs a) {
+  __shared__ f32x4 xb[RNN_XB];
   const int which = blockIdx.y;
-  if (which < a.ngru) gru_bwd_body(a.gru[which], blockIdx.x);
-  else t4lstm_bwd_body(a.t4, blockIdx.x);
+  if (which < a.ngru) gru_bwd_body(a.gru[which], blockIdx.x, xb);
+  else t4lstm_bwd_body(a.t4, blockIdx.x, xb);
 }
 
 extern "C" int clsr_t4lstm_fwd(const float* Pin, int ldp, const float* Wm, int ldm, const int* seq_len,
@@ -483,7 +473,7 @@ extern "C" int clsr_t4lstm_fwd(const float* Pin, int ldp, const float* Wm, int l
   T4Args a = {};
   a.Pin = Pin; a.ldp = ldp; a.Wm = Wm; a.ldm = ldm; a.seq_len = seq_len; a.len_stride = len_stride;
   a.Hn = Hn; a.T = T; a.n = n; a.out_seq = out_seq; a.act = act; a.cst = cst; a.mprev = mprev;
-  hipLaunchKernelGGL(t4lstm_fwd_kernel, dim3(clsr_cdiv(Hn, 16)), dim3(64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(t4lstm_fwd_kernel, dim3(clsr_cdiv(Hn, 16)), dim3(64 * RNT), 0, (hipStream_t)stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
@@ -499,7 +489,7 @@ extern "C" int clsr_t4lstm_bwd(const float* act, const float* cst, const float* 
   a.act = const_cast<float*>(act); a.cst = const_cast<float*>(cst); a.Wm = Wm; a.ldm = ldm;
   a.seq_len = seq_len; a.len_stride = len_stride; a.Hn = Hn; a.T = T; a.n = n;
   a.dout_seq = dout_seq; a.dPin = dPin; a.lddp = 6 * n;
-  hipLaunchKernelGGL(t4lstm_bwd_kernel, dim3(clsr_cdiv(Hn, 16)), dim3(64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(t4lstm_bwd_kernel, dim3(clsr_cdiv(Hn, 16)), dim3(64 * RNT), 0, (hipStream_t)stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
@@ -637,7 +627,7 @@ extern "C" int clsr_rnn_fwd_multi(const clsr_gru_desc* grus, int ngru, const cls
   RnnMultiArgs m;
   int rc = fill_multi(m, grus, ngru, t4, seq_len, len_stride, Hn, T, false);
   if (rc) return rc;
-  hipLaunchKernelGGL(rnn_multi_fwd_kernel, dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), dim3(64), 0,
+  hipLaunchKernelGGL(rnn_multi_fwd_kernel, dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), dim3(64 * RNT), 0,
                      (hipStream_t)stream, m);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
@@ -648,7 +638,7 @@ extern "C" int clsr_rnn_bwd_multi(const clsr_gru_desc* grus, int ngru, const cls
   RnnMultiArgs m;
   int rc = fill_multi(m, grus, ngru, t4, seq_len, len_stride, Hn, T, true);
   if (rc) return rc;
-  hipLaunchKernelGGL(rnn_multi_bwd_kernel, dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), dim3(64), 0,
+  hipLaunchKernelGGL(rnn_multi_bwd_kernel, dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), dim3(64 * RNT), 0,
                      (hipStream_t)stream, m);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;

@@ -321,6 +321,10 @@ class CLSRNet(object):
              bn.moving_var, BN_MOMENTUM, BN_EPS, 1 if training else 0, bn.scale, bn.shift, bn.mean, bn.invstd)
 
     def _bn_bwd_from_partial(self, bn, part, parts, dy, z, M):
+        self._bn_bwd_coef(bn, part, parts, M)
+        call("clsr_bn_bwd_apply", dy, z, bn.coef, M, bn.C)
+
+    def _bn_bwd_coef(self, bn, part, parts, M):
         count = M
         if self.dp_stats_hook is not None:
             self.dp_stats_hook(part)
@@ -332,7 +336,6 @@ class CLSRNet(object):
             inv = 1.0 / self.dp_world
             call("clsr_axpby", bn.dgamma, bn.dgamma, inv, None, 0.0, bn.C)
             call("clsr_axpby", bn.dbeta, bn.dbeta, inv, None, 0.0, bn.C)
-        call("clsr_bn_bwd_apply", dy, z, bn.coef, M, bn.C)
 
     def _gemm_bnbwd(self, dY, ldy_in, wkey, M, K, N, out, bn, z):
         """out = relu-mask(dY . W^T) fused with the BN backward sums of layer ``bn`` (pre-BN activation z),
@@ -585,14 +588,22 @@ class CLSRNet(object):
         wts = self._buf(key + ".wts", R, T)
         dz1 = self._buf(key + ".dz1", R * T, A1)
         dz0 = self._buf(key + ".dz0", R * T, A0)
-        parts = query("clsr_att_out_bwd_parts", Hn)
+        # score / softmax backward per history group: d score, dkeys, d b_out
+        ds = self._buf(key + ".ds", R * T)
+        parts = query("clsr_att_score_bwd_parts", Hn)
+        bp = self._buf("att.bp" + self._ws_tag, 4096)[:parts]
+        call("clsr_att_score_bwd", dout, wts, seq_len, len_stride, keys, Hn, G, T, Dk, ds, dkeys, bp)
+        call("clsr_reduce_parts", bp, parts, 1, 1, 1.0, Gd[nn + "b_nn_output"], 0)
+        # dy1 = ds * w_out * relu'(bn1(z1)) is never materialised: one streaming pass for the BN-1 backward sums
+        # and d w_out, the coefficient kernel, one streaming pass that writes dz1
+        parts = query("clsr_att_dy1_parts", R * T, A1)
         bnp = self._buf("att.bnp" + self._ws_tag, 2048 * 2 * 256, dtype=torch.float64)[: parts * 2 * A1]
-        wp = self._buf("att.wp" + self._ws_tag, 2048 * (256 + 4))[: parts * (A1 + 4)]
-        call("clsr_att_out_bwd", dout, wts, z1, bn1.scale, bn1.shift, bn1.mean, bn1.invstd,
-             P[nn + "w_nn_output"], seq_len, len_stride, keys, Hn, G, T, A1, Dk, dz1, dkeys, bnp, wp)
-        call("clsr_reduce_parts", wp, parts, A1 + 4, A1, 1.0, Gd[nn + "w_nn_output"], 0)
-        call("clsr_reduce_parts", wp[A1:], parts, A1 + 4, 1, 1.0, Gd[nn + "b_nn_output"], 0)
-        self._bn_bwd_from_partial(bn1, bnp, parts, dz1, z1, R * T)
+        wp = self._buf("att.wp" + self._ws_tag, 2048 * 256)[: parts * A1]
+        call("clsr_att_dy1_stats", z1, ds, bn1.scale, bn1.shift, bn1.mean, bn1.invstd, P[nn + "w_nn_output"],
+             R * T, A1, bnp, wp)
+        call("clsr_reduce_parts", wp, parts, A1, A1, 1.0, Gd[nn + "w_nn_output"], 0)
+        self._bn_bwd_coef(bn1, bnp, parts, R * T)
+        call("clsr_att_dy1_apply", z1, ds, bn1.scale, bn1.shift, P[nn + "w_nn_output"], bn1.coef, R * T, A1, dz1)
         # layer 1: z1 = relu(bn0(z0)) . W1 + b1
         self._dw(z0, A0, dz1, A1, R * T, A0, A1, Gd[nn + "w_nn_layer1"], A1, db=Gd[nn + "b_nn_layer1"], aff=bn0)
         self._gemm_bnbwd(dz1, A1, key + ".W1^T", R * T, A1, A0, dz0, bn0, z0)
@@ -714,14 +725,6 @@ class CLSRNet(object):
         ulong, ushort = self._buf("u_long", Hn, Du), self._buf("u_short", Hn, Du)
         call("clsr_gather_rows", self.tables["user_long"], f["users"], hs, Hn, Du, ulong, Du, 0)
         call("clsr_gather_rows", self.tables["user_short"], f["users"], hs, Hn, Du, ushort, Du, 0)
-        # ---- long term (independent of the encoders and of the short-term attention: side stream)
-        lt = CL + "long_term/attention_fcn/"
-        with self._branch("@lt"):
-            att_long = self._att_fwd("lt", lt, hist, ulong, Hn, 1, T, D, Du, seq_len, ls, training)
-            if training and self.sorted_hist_grad:
-                # history ids sorted by row id for the backward's segmented sums: only the ids are needed, so
-                # the (launch-heavy) radix sort hides on the side stream underneath the recurrences
-                self._sort_hist_ids(f, Hn, T, hs)
         # ---- sequence encoders: ONE fused input projection, then ONE fused launch for all recurrences
         st = CL + "short_term/"
         M = Hn * T
@@ -754,6 +757,15 @@ class CLSRNet(object):
         if (not hp.manual_alpha) and hp.predict_long_short:
             d, fs, _ = self._gru_fwd_desc("g2", CL + "causal2/causal2/gru_cell/", H, PinAll, Hn, T, None, training)
             grus.append(d)
+        # ---- long term attention (independent of the encoders and of the short-term attention) on the side
+        #      stream, forked HERE: the T-serial recurrences below occupy only ~3 waves per CU, so the long-term
+        #      chain (and the id sort for the backward) runs underneath them instead of beside the big GEMMs
+        lt = CL + "long_term/attention_fcn/"
+        with self._branch("@lt"):
+            att_long = self._att_fwd("lt", lt, hist, ulong, Hn, 1, T, D, Du, seq_len, ls, training)
+            if training and self.sorted_hist_grad:
+                # history ids sorted by row id for the backward's segmented sums (launch-heavy radix sort)
+                self._sort_hist_ids(f, Hn, T, hs)
         ops.rnn_multi("clsr_rnn_fwd_multi", grus, t4d, seq_len, ls, Hn, T)
         # ---- short term attention: query = [short_term_intention | target]
         Qs = Du + D
@@ -839,11 +851,6 @@ class CLSRNet(object):
         else:
             call("clsr_alpha_fuse_bwd", dmo, None, float(hp.manual_alpha_value), out["att_fea_long"],
                  out["att_fea_short"], Hn, G, D, None, dL, dS, dtarget)
-        # ---- long-term attention backward: dL is final here; runs on the side stream underneath the
-        #      short-term attention / encoder backward (own scratch + own d(hist) accumulator)
-        with self._branch("@lt"):
-            dul = self._att_bwd("lt", CL + "long_term/attention_fcn/", dL, out["hist_input"], out["u_long"], dhist_lt,
-                                Hn, 1, T, D, Du, seq_len, ls)
         # ---- short-term attention
         st = CL + "short_term/"
         Qs = Du + D
@@ -871,6 +878,11 @@ class CLSRNet(object):
             grus.append(self._gru_bwd_desc("gs", st + "simple_gru/gru_cell/", H, dPinAll, Hn, T, None, drnn, None))
         if (not hp.manual_alpha) and hp.predict_long_short:
             grus.append(self._gru_bwd_desc("g2", CL + "causal2/causal2/gru_cell/", H, dPinAll, Hn, T, dfs, None, None))
+        # ---- long-term attention backward (dL has been final since the alpha gate): forked here so that it runs
+        #      on the side stream underneath the T-serial backward-through-time (own scratch + own d(hist))
+        with self._branch("@lt"):
+            dul = self._att_bwd("lt", CL + "long_term/attention_fcn/", dL, out["hist_input"], out["u_long"], dhist_lt,
+                                Hn, 1, T, D, Du, seq_len, ls)
         ops.rnn_multi("clsr_rnn_bwd_multi", grus, t4d, seq_len, ls, Hn, T)
         # input-side weights of every encoder in one reduction; d(hist) in one product
         self._dw(hist, D, dPinAll, NX, M, D, NX, self._buf("xw.dW", D, NX), NX, db=self._buf("xw.db", NX))

@@ -121,11 +121,19 @@ int clsr_bn_bwd_apply(float* dy, const float* z, const float* coef, long M, int 
 int clsr_att_out_fwd(const float* z1, const float* scale1, const float* shift1, const float* w_out,
                      const float* b_out, const int* seq_len, int len_stride, const float* keys, int Hn,
                      int G, int T, int C1, int Dk, float* wts, float* out, void* stream);
-int clsr_att_out_bwd_parts(int Hn);
-int clsr_att_out_bwd(const float* dout, const float* wts, const float* z1, const float* scale1,
-                     const float* shift1, const float* mean1, const float* invstd1, const float* w_out,
-                     const int* seq_len, int len_stride, const float* keys, int Hn, int G, int T, int C1,
-                     int Dk, float* dy1, float* dkeys, double* bn_partial, float* w_partial, void* stream);
+/* backward of the tail, split by access pattern: score/softmax backward per history group (d score ds[R*T],
+ * dkeys +=, partial sums of d b_out), then two streaming passes over z1 that never materialise dy1 =
+ * ds * w_out * relu'(y1): column sums for the BN-1 backward + d w_out, and dz1 = a1*dy1 + a2*z1 + a3. */
+int clsr_att_score_bwd_parts(int Hn);
+int clsr_att_score_bwd(const float* dout, const float* wts, const int* seq_len, int len_stride,
+                       const float* keys, int Hn, int G, int T, int Dk, float* ds, float* dkeys,
+                       float* b_partial, void* stream);
+int clsr_att_dy1_parts(long M, int C1);
+int clsr_att_dy1_stats(const float* z1, const float* ds, const float* scale1, const float* shift1,
+                       const float* mean1, const float* invstd1, const float* w_out, long M, int C1,
+                       double* bn_partial, float* w_partial, void* stream);
+int clsr_att_dy1_apply(const float* z1, const float* ds, const float* scale1, const float* shift1,
+                       const float* w_out, const float* coef, long M, int C1, float* dz1, void* stream);
 
 /* ---- recurrent encoders under dynamic_rnn: GRUCell clsr.py:160-168,201-208,229-237;
  *      Time4LSTMCell rnn_cell_implement.py:129-298 at clsr.py:179-200 */

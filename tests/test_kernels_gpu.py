@@ -322,25 +322,28 @@ def test_att_out_fwd_bwd(Hn, G, T, C1, Dk):
     call("clsr_att_out_fwd", d_z1, d_sc, d_sh, d_w, d_b, d_len, G, d_keys, Hn, G, T, C1, Dk, wts, o)
     close(wts, w, rtol=1e-4, atol=1e-6, name="weights")
     close(o, out, rtol=1e-4, atol=1e-5, name="out")
-    nparts = query("clsr_att_out_bwd_parts", Hn)
-    dy1 = torch.empty(R * T, C1, device="cuda")
+    # backward: score/softmax backward, then the two streaming passes (dy1 never materialised)
+    nparts = query("clsr_att_score_bwd_parts", Hn)
+    ds = torch.empty(R * T, device="cuda")
     dkeys = torch.zeros(Hn, T, Dk, device="cuda")
-    bnp = torch.zeros(nparts, 2, C1, dtype=torch.float64, device="cuda")
-    wp = torch.zeros(nparts, C1 + 4, device="cuda")
-    call("clsr_att_out_bwd", dev(up, torch.float32), wts, d_z1, d_sc, d_sh, d_mu, d_is, d_w, d_len, G, d_keys,
-         Hn, G, T, C1, Dk, dy1, dkeys, bnp, wp)
-    # dy1 is the gradient wrt the BN output y1 (relu mask applied)
-    y1 = (z1 * sc + sh)
-    dy_exp = z1.grad / sc  # z1 -> y1 is affine with slope sc
-    close(dy1, dy_exp, rtol=1e-4, atol=1e-5, name="dy1")
+    bp = torch.zeros(nparts, device="cuda")
+    call("clsr_att_score_bwd", dev(up, torch.float32), wts, d_len, G, d_keys, Hn, G, T, Dk, ds, dkeys, bp)
     close(dkeys, keys.grad, rtol=1e-4, atol=1e-5, name="dkeys")
+    close(bp.sum().reshape(1), b_out.grad, rtol=1e-4, atol=1e-4, name="db_out")
+    dy_exp = z1.grad / sc  # gradient wrt the BN output y1 (relu mask applied); z1 -> y1 has slope sc
+    np2 = query("clsr_att_dy1_parts", R * T, C1)
+    bnp = torch.zeros(np2, 2, C1, dtype=torch.float64, device="cuda")
+    wp = torch.zeros(np2, C1, device="cuda")
+    call("clsr_att_dy1_stats", d_z1, ds, d_sc, d_sh, d_mu, d_is, d_w, R * T, C1, bnp, wp)
     tot = bnp.sum(0).cpu()
     xhat = ((z1 - mu) * istd).detach()
     close(tot[0], dy_exp.sum(0), rtol=1e-4, atol=1e-4, name="sum dy")
     close(tot[1], (dy_exp * xhat).sum(0), rtol=1e-4, atol=1e-4, name="sum dy xhat")
-    wsum = wp.sum(0).cpu()
-    close(wsum[:C1], w_out.grad, rtol=1e-4, atol=1e-4, name="dw_out")
-    close(wsum[C1:C1 + 1], b_out.grad, rtol=1e-4, atol=1e-4, name="db_out")
+    close(wp.sum(0), w_out.grad, rtol=1e-4, atol=1e-4, name="dw_out")
+    coef = rnd(g, 3, C1)
+    dz1 = torch.empty(R * T, C1, device="cuda")
+    call("clsr_att_dy1_apply", d_z1, ds, d_sc, d_sh, d_w, dev(coef, torch.float32), R * T, C1, dz1)
+    close(dz1, coef[0] * dy_exp + coef[1] * z1.detach() + coef[2], rtol=1e-4, atol=1e-5, name="dz1")
 
 
 # ------------------------------------------------------------------------------- recurrent cells
