@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--lengths", default="full", choices=["full", "lognormal"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-catalogue", action="store_true",
+                    help="skip the HBM-resident (100M-item catalogue) measurement of the gather kernel")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--sync-bn", action="store_true",
                     help="(N>1) global batch-norm statistics (single-device parity; eager, slower); default is "
@@ -227,6 +229,33 @@ def main():
                     bytes_per_launch=gbytes, us_per_launch=round(t_gather * 1e6, 2),
                     note="tables (%.1f MB) are L2/Infinity-Cache resident at this config; the HBM claim needs the "
                          "100M-item config" % ((cfg["Vi"] * cfg["Di"] + cfg["Vc"] * cfg["Dc"]) * 4 / 1e6))
+        if world == 1 and not args.no_catalogue:
+            # same kernel on BASELINE configs[4]'s catalogue (100M items x 96 floats + 10k categories x 32, uniform
+            # ids: no cache reuse): the table is 38 GB, so every row read is an HBM read
+            big = CONFIGS["catalogue100m"]
+            try:
+                it = torch.empty(big["Vi"], big["Di"], device="cuda").zero_()   # touch every page once
+                ct = torch.randn(big["Vc"], big["Dc"], device="cuda")
+                ii = torch.randint(1, big["Vi"], (Hn, T), device="cuda", dtype=torch.int32)
+                ci = torch.randint(1, big["Vc"], (Hn, T), device="cuda", dtype=torch.int32)
+                ln = torch.full((Hn,), T, device="cuda", dtype=torch.int32)
+                Db = big["Di"] + big["Dc"]
+                hb = torch.empty(Hn, T, Db, device="cuda")
+                hmb, hrb = torch.empty(Hn, Db, device="cuda"), torch.empty(Hn, Db, device="cuda")
+                t_big = time_kernel(lambda: ops.call("clsr_gather_hist_fwd", it, ct, ii, ci, T, ln, 1, Hn, T,
+                                                     big["Di"], big["Dc"], 3, hb, hmb, hrb))
+                bbytes = Hn * T * (Db * 8 + 8)
+                roof["hbm_resident"] = dict(
+                    workload="BASELINE configs[4] catalogue: 100M items, rows 384 B + 128 B, uniform ids, "
+                             "4096 histories x 50 steps", bytes_per_launch=float(bbytes),
+                    us_per_launch=round(t_big * 1e6, 2), achieved=round(bbytes / t_big / 1e9, 1), peak=8000.0,
+                    unit="GB/s", frac=round(bbytes / t_big / 8e12, 4),
+                    traffic=204.4e6, traffic_source="profiles/r01_gather_hist_fwd_pmc_hbm_traffic.csv "
+                                                    "(WRITE_SIZE 106.5 MB + 2 x FETCH_SIZE 97.9 MB)")
+                del it, ct, hb
+                torch.cuda.empty_cache()
+            except RuntimeError as e:   # not enough free HBM on this device
+                roof["hbm_resident"] = {"skipped": str(e)[:120]}
         Qs, A0 = cfg["Du"] + D, 80
         a_s, q_s = net._buf("st.a", Hn * T, Qs), net._buf("st.q", B, Qs)
         U, V, z0 = net._buf("st.U", Hn * T, A0), net._buf("st.V", B, A0), net._buf("st.z0", B * T, A0)
@@ -238,7 +267,7 @@ def main():
 
         t_mm = time_kernel(z0_gemm)
         flops = 2.0 * B * T * Qs * A0
-        roof_mfma = dict(bound="mfma", kernel="pgemm_kernel<5,false> (short-term att layer 0)",
+        roof_mfma = dict(bound="mfma", kernel="pgemm_fast_kernel<5,MUL,UV,false> (short-term attention layer 0)",
                          achieved=round(flops / t_mm / 1e12, 2), peak=157.3, unit="TFLOP/s",
                          frac=round(flops / t_mm / 157.3e12, 4), us_per_launch=round(t_mm * 1e6, 2),
                          note="fp32-input MFMA (v_mfma_f32_16x16x4_f32); peak = dense fp32 matrix rate")

@@ -121,10 +121,13 @@ __device__ __forceinline__ void gru_fwd_body(const GruArgs& a, const int bx, f32
   f32x4 hown = (cval && a.h0) ? ld4(a.h0 + h * a.h0_stride + col) : Z4;
   const int len = hvalid ? min(a.seq_len[h * a.len_stride], T) : 0;
   const int Tmax = wave_max_i(len);
-  const float* pin = a.Pin + (hvalid ? h : 0) * (long)T * a.ldp + col;
+  // loads are UNCONDITIONAL (clamped addresses, select afterwards): a load under a branch makes the
+  // number of outstanding memory operations unknown to the compiler, which then drains the whole queue
+  // (s_waitcnt vmcnt(0)) right after issuing the prefetch -- one exposed HBM latency per time step
+  const float* pin = a.Pin + (hvalid ? h : 0) * (long)T * a.ldp + (cval ? col : 0);
   f32x4 pn[3];
 #pragma unroll
-  for (int gb = 0; gb < 3; ++gb) pn[gb] = (cval && 0 < len) ? ld4(pin + gb * n) : Z4;
+  for (int gb = 0; gb < 3; ++gb) pn[gb] = sel4(cval && 0 < len, ld4(pin + gb * n), Z4);
   f32x4* bufA = xb;
   f32x4* bufB = xb + RNT * 64;
   for (int t = 0; t < Tmax; ++t) {
@@ -132,8 +135,9 @@ __device__ __forceinline__ void gru_fwd_body(const GruArgs& a, const int bx, f32
     f32x4 accr = pn[0], accu = pn[1], accc = pn[2];
     {  // prefetch next step's input projections
       const bool nl = (t + 1) < len;
+      const long tn = t + 1 < T ? t + 1 : t;
 #pragma unroll
-      for (int gb = 0; gb < 3; ++gb) pn[gb] = (cval && nl) ? ld4(pin + (long)(t + 1) * a.ldp + gb * n) : Z4;
+      for (int gb = 0; gb < 3; ++gb) pn[gb] = sel4(cval && nl, ld4(pin + tn * a.ldp + gb * n), Z4);
     }
     mv1(accr, wr, hs);
     mv1(accu, wu, hs);
@@ -192,11 +196,13 @@ __device__ __forceinline__ void gru_bwd_body(const GruArgs& a, const int bx, f32
     const bool live = t < len;
     const bool ok = live && cval;
     const long pos = h * T + t;
-    const float* gp = a.gates + pos * 3 * n + col;
-    const f32x4 r = ok ? ld4(gp) : Z4, u = ok ? ld4(gp + n) : Z4, c = ok ? ld4(gp + 2 * n) : Z4;
-    const f32x4 hp = ok ? ld4(a.hprev + pos * n + col) : Z4;
+    const long posc = (hvalid ? h : 0) * T + t;   // always-valid addresses: unconditional loads, see gru_fwd_body
+    const int colc = cval ? col : 0;
+    const float* gp = a.gates + posc * 3 * n + colc;
+    const f32x4 r = sel4(ok, ld4(gp), Z4), u = sel4(ok, ld4(gp + n), Z4), c = sel4(ok, ld4(gp + 2 * n), Z4);
+    const f32x4 hp = sel4(ok, ld4(a.hprev + posc * n + colc), Z4);
     f32x4 d = dh;
-    if (ok && a.dout_seq) d += ld4(a.dout_seq + pos * n + col);
+    if (a.dout_seq) d += ld4(a.dout_seq + posc * n + colc);
     d = sel4(ok, d, Z4);
     const f32x4 du = d * (hp - c);
     const f32x4 dcp = d * (1.0f - u) * (1.0f - c * c);
@@ -306,10 +312,10 @@ __device__ __forceinline__ void t4lstm_fwd_body(const T4Args& a, const int bx, f
   f32x4 cs = Z4, mown = Z4, ms[RNT] = {Z4, Z4, Z4};
   const int len = hvalid ? min(a.seq_len[h * a.len_stride], T) : 0;
   const int Tmax = wave_max_i(len);
-  const float* pin = a.Pin + (hvalid ? h : 0) * (long)T * a.ldp + col;
+  const float* pin = a.Pin + (hvalid ? h : 0) * (long)T * a.ldp + (cval ? col : 0);
   f32x4 pn[6];
 #pragma unroll
-  for (int gb = 0; gb < 6; ++gb) pn[gb] = (cval && 0 < len) ? ld4(pin + gb * n) : Z4;
+  for (int gb = 0; gb < 6; ++gb) pn[gb] = sel4(cval && 0 < len, ld4(pin + gb * n), Z4);
   for (int t = 0; t < Tmax; ++t) {
     const bool live = t < len;
     f32x4 acc[4];
@@ -318,8 +324,9 @@ __device__ __forceinline__ void t4lstm_fwd_body(const T4Args& a, const int bx, f
     const f32x4 tns = pn[4], tls = pn[5];
     {
       const bool nl = (t + 1) < len;
+      const long tn = t + 1 < T ? t + 1 : t;
 #pragma unroll
-      for (int gb = 0; gb < 6; ++gb) pn[gb] = (cval && nl) ? ld4(pin + (long)(t + 1) * a.ldp + gb * n) : Z4;
+      for (int gb = 0; gb < 6; ++gb) pn[gb] = sel4(cval && nl, ld4(pin + tn * a.ldp + gb * n), Z4);
     }
 #pragma unroll
     for (int kt = 0; kt < RNT; ++kt) {  // four independent accumulators interleaved
@@ -380,13 +387,15 @@ __device__ __forceinline__ void t4lstm_bwd_body(const T4Args& a, const int bx, f
     const bool live = t < len;
     const bool ok = live && cval;
     const long pos = h * T + t;
-    const float* ap = a.act + pos * 6 * n + col;
-    const f32x4 ig = ok ? ld4(ap) : Z4, jg = ok ? ld4(ap + n) : Z4, fg = ok ? ld4(ap + 2 * n) : Z4;
-    const f32x4 og = ok ? ld4(ap + 3 * n) : Z4, tn = ok ? ld4(ap + 4 * n) : Z4, tlg = ok ? ld4(ap + 5 * n) : Z4;
-    const f32x4 cn = ok ? ld4(a.cst + pos * n + col) : Z4;
-    const f32x4 cp = (ok && t > 0) ? ld4(a.cst + (pos - 1) * n + col) : Z4;
-    f32x4 d = dm;
-    if (ok) d += ld4(a.dout_seq + pos * n + col);
+    const long posc = (hvalid ? h : 0) * T + t;   // always-valid addresses: unconditional loads, see gru_fwd_body
+    const int colc = cval ? col : 0;
+    const float* ap = a.act + posc * 6 * n + colc;
+    const f32x4 ig = sel4(ok, ld4(ap), Z4), jg = sel4(ok, ld4(ap + n), Z4), fg = sel4(ok, ld4(ap + 2 * n), Z4);
+    const f32x4 og = sel4(ok, ld4(ap + 3 * n), Z4), tn = sel4(ok, ld4(ap + 4 * n), Z4);
+    const f32x4 tlg = sel4(ok, ld4(ap + 5 * n), Z4);
+    const f32x4 cn = sel4(ok, ld4(a.cst + posc * n + colc), Z4);
+    const f32x4 cp = sel4(ok && t > 0, ld4(a.cst + (posc - (t > 0 ? 1 : 0)) * n + colc), Z4);
+    f32x4 d = dm + ld4(a.dout_seq + posc * n + colc);
     d = sel4(ok, d, Z4);
     const f32x4 tc = tanh4(cn);
     const f32x4 dcc = sel4(ok, dc + d * og * (1.0f - tc * tc), Z4);

@@ -32,6 +32,8 @@ def main():
     print("| kernel | calls | total ms | avg us | min us | max us | % |")
     print("|---|---|---|---|---|---|---|")
     for name, (n, tot, mn, mx) in sorted(stats.items(), key=lambda kv: -kv[1][1]):
+        if len(name) > 90:   # rocPRIM template instantiations
+            name = name[:87] + "..."
         print("| %s | %d | %.3f | %.2f | %.2f | %.2f | %.1f |" % (name, n, tot / 1e6, tot / n / 1e3, mn / 1e3, mx / 1e3,
                                                                 100.0 * tot / total))
     print("\ntotal kernel time %.3f ms over %d dispatches" % (total / 1e6, len(rows)))
