@@ -320,7 +320,7 @@ class SequentialBaseModel(BaseModel):
         # first gives the identical grouping without that constraint
         gp = np.reshape(np.asarray(preds), (-1, group))
         gl = np.reshape(np.asarray(labels), (-1, group))
-        res.update(cal_metric(list(gl), list(gp), self.hparams.pairwise_metrics))
+        res.update(cal_metric(gl, gp, self.hparams.pairwise_metrics))    # 2-D arrays: vectorised, same result
         if users is not None:
             res.update(cal_weighted_metric(users, preds, labels, self.hparams.weighted_metrics))
         return res

@@ -142,3 +142,23 @@ def test_vectorised_negative_sampling_replays_the_random_module(golden_hparams, 
         got = it._sample_negatives(items, ngs)
         assert np.array_equal(got, ref)
         assert random.getstate() == st_ref
+
+
+def test_grouped_metrics_vectorised_equals_per_group_loop():
+    """2-D (equal-size groups) fast path of cal_metric == the reference-shaped loop over groups, ties included."""
+    from clsr_amd.deeprec_utils import cal_metric
+
+    rng = np.random.default_rng(3)
+    metrics = ["mean_mrr", "ndcg@2;4;6", "hit@2;4;6"]
+    for n_groups, size in ((1, 5), (37, 5), (200, 100), (50, 3)):
+        preds = np.round(rng.random((n_groups, size)), 1)          # many ties
+        preds[0] = 0.5                                             # a fully tied group
+        labels = np.zeros((n_groups, size))
+        labels[:, 0] = 1
+        if n_groups > 2:
+            labels[2, 1] = 1                                       # two positives in one group
+        loop = cal_metric(list(labels), list(preds), metrics)
+        fast = cal_metric(labels, preds, metrics)
+        assert fast == loop and set(fast) == {"mean_mrr", "ndcg@2", "ndcg@4", "ndcg@6", "hit@2", "hit@4", "hit@6"}
+    # metrics without a vectorised form fall back to the loop
+    assert cal_metric(labels, preds, ["group_auc"]) == cal_metric(list(labels), list(preds), ["group_auc"])
