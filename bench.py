@@ -80,7 +80,8 @@ def cpu_baseline(cfg, seconds=15.0, P=256):
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = min(cores, 64)
     torch.set_num_threads(cores)
-    hp = build_hparams(cfg, P)
+    big = cfg["Vi"] >= 10_000_000   # catalogue configs: lazy Adam is mandatory, ids uniform
+    hp = build_hparams(cfg, P, **({"optimizer": "lazyadam"} if big else {}))
     dims = dict(Vu=cfg["Vu"], Vi=cfg["Vi"], Vc=cfg["Vc"])
     params = O.init_params(dims, hp, seed=0)
     bn, adam = O.init_bn_state(params), O.init_adam(params)
@@ -142,13 +143,15 @@ def main():
 
     cfg = CONFIGS[args.config]
     P, T, G = cfg["P"], cfg["T"], 5
-    hp = build_hparams(cfg, P)
+    big = cfg["Vi"] >= 10_000_000   # catalogue configs: lazy Adam is mandatory, ids uniform
+    hp = build_hparams(cfg, P, **({"optimizer": "lazyadam"} if big else {}))
     dims = dict(Vu=cfg["Vu"], Vi=cfg["Vi"], Vc=cfg["Vc"])
     net = CLSRNet(hp, dims, device="cuda:%d" % local_rank, seed=0)
     if os.environ.get("CLSR_NO_OVERLAP"):
         net.overlap = False
     log("net built")
-    feed = synthetic_feed(P, T, cfg["Vu"], cfg["Vi"], cfg["Vc"], G=G, lengths=args.lengths, seed=20220425 + rank)
+    feed = synthetic_feed(P, T, cfg["Vu"], cfg["Vi"], cfg["Vc"], G=G, lengths=args.lengths, seed=20220425 + rank,
+                          ids="uniform" if big else "zipf")
     f = net.upload(feed, True)
     if dist is not None:
         from clsr_amd.dp import DataParallel
@@ -225,11 +228,12 @@ def main():
                     peak=8000.0, unit="GB/s", frac=round(gbytes / t_gather / 8e12, 4),
                     # PMC pass committed in profiles/r01_gather_hist_fwd_pmc_hbm_traffic.csv (same shape): WRITE_SIZE
                     # 33.4 MB + 2 x FETCH_SIZE 12.6 MB (gfx950 wide-load correction); reads of the 8 MB tables hit cache
-                    traffic=59.9e6, traffic_source="profiles/r01_gather_hist_fwd_pmc_hbm_traffic.csv",
+                    traffic=204.4e6 if big else 59.9e6, traffic_source="profiles/r01_gather_hist_fwd_pmc_hbm_traffic.csv",
                     bytes_per_launch=gbytes, us_per_launch=round(t_gather * 1e6, 2),
-                    note="tables (%.1f MB) are L2/Infinity-Cache resident at this config; the HBM claim needs the "
-                         "100M-item config" % ((cfg["Vi"] * cfg["Di"] + cfg["Vc"] * cfg["Dc"]) * 4 / 1e6))
-        if world == 1 and not args.no_catalogue:
+                    note=("tables (%.1f MB) are L2/Infinity-Cache resident at this config; the HBM claim needs the "
+                          "100M-item config" % ((cfg["Vi"] * cfg["Di"] + cfg["Vc"] * cfg["Dc"]) * 4 / 1e6))
+                    if not big else "38 GB item table, uniform ids: every row read is an HBM read")
+        if world == 1 and not args.no_catalogue and not big:
             # same kernel on BASELINE configs[4]'s catalogue (100M items x 96 floats + 10k categories x 32, uniform
             # ids: no cache reuse): the table is 38 GB, so every row read is an HBM read
             big = CONFIGS["catalogue100m"]
@@ -279,11 +283,13 @@ def main():
             "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: Taobao-shaped CLSR train step, batch 4096 positives x5 rows "
+            "config": {"workload": "BASELINE configs[%s]: %s CLSR train step, batch 4096 positives x5 rows "
                                    "(B=20480), seq_len %d (%s lengths), Di/Dc/Du/H=%d/%d/%d/%d, Vu/Vi/Vc=%d/%d/%d, "
-                                   "time4lstm + triplet, dense Adam" % (T, args.lengths, cfg["Di"], cfg["Dc"],
-                                                                        cfg["Du"], cfg["H"], cfg["Vu"], cfg["Vi"],
-                                                                        cfg["Vc"]),
+                                   "time4lstm + triplet, %s" % (
+                                       {"taobao": "1", "kuaishou": "2", "catalogue100m": "4"}.get(args.config, "?"),
+                                       args.config, T, args.lengths, cfg["Di"], cfg["Dc"], cfg["Du"], cfg["H"],
+                                       cfg["Vu"], cfg["Vi"], cfg["Vc"],
+                                       "lazy Adam (row lists)" if big else "dense Adam"),
                        "global_batch": world * P, "seq_len": T,
                        "parallelism": "dp%d" % world if world > 1 else "single",
                        "hipgraph": not args.no_graph, "history_dedup": True,
@@ -292,7 +298,7 @@ def main():
             "roofline": roof, "roofline_mfma": roof_mfma,
             "loss": float(host_losses[:4].sum()),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not big:
             out["cpu_baseline"] = cpu_baseline(cfg, seconds=args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if dist is not None:

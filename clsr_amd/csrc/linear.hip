@@ -21,7 +21,8 @@ struct PGemmArgs {
   int T; int G;                   // T>0: r = m / T, t = m % T; G>0: xrow = (r / G) * T + t else xrow = m
   const float* Xmul; int ldmul;   // optional multiplier row r (needs T>0 or row-level positions)
   const float* in_scale; const float* in_shift; int in_relu;  // optional per-input-feature affine (+relu)
-  const float* Wt; int Kp;        // packed transposed weights [16*ceil(N/16)][Kp], zero padded
+  const float* Wt; int Kp;        // packed transposed weights [16*ceil(N/16)][ldw], zero padded; Kp = LDS row width
+  int ldw;                        // global row stride of Wt (== Kp unless the K range is processed in chunks)
   const float* bias;
   const float* addU; int ldu;     // optional += addU[xrow][n]
   const float* addV; int ldv;     // optional += addV[r][n]
@@ -45,10 +46,13 @@ __global__ void __launch_bounds__(256) pgemm_generic_kernel(PGemmArgs a) {
   const int KT = (a.K + 15) >> 4;
   const int Kp = a.Kp;
   {  // stage this block's W^T chunk: rows n0 .. n0 + 16*otc
-    const f32x4* src = reinterpret_cast<const f32x4*>(a.Wt + (long)n0 * Kp);
+    const float* src = a.Wt + (long)n0 * a.ldw;
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
-    const int cnt = (16 * otc * Kp) >> 2;
-    for (int e = tid; e < cnt; e += 256) dst[e] = src[e];
+    const int Kq = Kp >> 2, cnt = 16 * otc * Kq;
+    for (int e = tid; e < cnt; e += 256) {
+      const int row = e / Kq, c = e - row * Kq;
+      dst[e] = ld4(src + (long)row * a.ldw + 4 * c);
+    }
   }
   __syncthreads();
 
@@ -199,10 +203,13 @@ __global__ void __launch_bounds__(256) pgemm_fast_kernel(PGemmArgs a) {
   const int Kp = a.Kp;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   {  // stage this block's W^T chunk (rows n0 .. n0 + 16*otc); missing out-tiles are zero-filled
-    const f32x4* src = reinterpret_cast<const f32x4*>(a.Wt + (long)n0 * Kp);
+    const float* src = a.Wt + (long)n0 * a.ldw;
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
-    const int cnt = (16 * otc * Kp) >> 2, tot = (16 * OT * Kp) >> 2;
-    for (int e = tid; e < tot; e += 256) dst[e] = e < cnt ? src[e] : zero4;
+    const int Kq = Kp >> 2, cnt = 16 * otc * Kq, tot = 16 * OT * Kq;
+    for (int e = tid; e < tot; e += 256) {
+      const int row = e / Kq, c = e - row * Kq;
+      dst[e] = e < cnt ? ld4(src + (long)row * a.ldw + 4 * c) : zero4;
+    }
   }
   __syncthreads();
 
@@ -451,7 +458,7 @@ static int launch_pgemm(const PGemmArgs& a, hipStream_t stream) {
   return launch_kernel(pgemm_generic_kernel<OT, false>, a, grid, shmem, stream);
 }
 
-static int pgemm_dispatch(const PGemmArgs& a, hipStream_t s);
+static int pgemm_dispatch(const PGemmArgs& a, hipStream_t s);  // splits the K range when W^T does not fit in LDS
 
 // dy[m, :N] = mask(dY_next[m, :K] . W^T) with mask = (z*scale + shift > 0)  -- the product that
 // back-propagates through a linear layer fused with the ReLU + batch-norm backward reduction of the
@@ -464,7 +471,7 @@ extern "C" int clsr_pgemm_bnbwd(const float* X, int ldx, const float* Wt, int Kp
   CLSR_CHECK_SUPPORTED(K % 4 == 0 && N % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldz % 4 == 0 && Kp % 4 == 0);
   CLSR_CHECK_ARG(Kp >= 16 * clsr_cdiv(K, 16));
   PGemmArgs a = {};
-  a.X = X; a.ldx = ldx; a.Wt = Wt; a.Kp = Kp; a.Y = Y; a.ldy = ldy; a.stats = stats; a.M = M; a.K = K; a.N = N;
+  a.X = X; a.ldx = ldx; a.Wt = Wt; a.Kp = Kp; a.ldw = Kp; a.Y = Y; a.ldy = ldy; a.stats = stats; a.M = M; a.K = K; a.N = N;
   a.in_relu = 1;
   a.ez = z; a.ldez = ldz; a.e_scale = scale; a.e_shift = shift; a.e_mean = mean; a.e_invstd = invstd;
   return pgemm_dispatch(a, (hipStream_t)stream);
@@ -491,20 +498,54 @@ extern "C" int clsr_pgemm(const float* X, int ldx, int T, int G, const float* Xm
   PGemmArgs a;
   a.X = X; a.ldx = ldx; a.T = T; a.G = G; a.Xmul = Xmul; a.ldmul = ldmul;
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
-  a.Wt = Wt; a.Kp = Kp; a.bias = bias; a.addU = addU; a.ldu = ldu; a.addV = addV; a.ldv = ldv;
+  a.Wt = Wt; a.Kp = Kp; a.ldw = Kp; a.bias = bias; a.addU = addU; a.ldu = ldu; a.addV = addV; a.ldv = ldv;
   a.Y = Y; a.ldy = ldy; a.accumulate = accumulate; a.stats = stats; a.M = M; a.K = K; a.N = N;
   a.ez = nullptr; a.ldez = 0; a.e_scale = a.e_shift = a.e_mean = a.e_invstd = nullptr;
   return pgemm_dispatch(a, (hipStream_t)stream);
 }
 
-static int pgemm_dispatch(const PGemmArgs& a, hipStream_t s) {
-  const int nt = clsr_cdiv(a.N, 16);
-  if (nt <= 3) return launch_pgemm<3>(a, s);
-  if (nt <= 5) return launch_pgemm<5>(a, s);
-  if (nt <= 8) return launch_pgemm<8>(a, s);
+static int pgemm_out_tiles(int N) {
+  const int nt = clsr_cdiv(N, 16);
+  if (nt <= 3) return 3;
+  if (nt <= 5) return 5;
+  if (nt <= 8) return 8;
   const int waste5 = clsr_cdiv(nt, 5) * 5 - nt, waste8 = clsr_cdiv(nt, 8) * 8 - nt;
-  if (waste8 <= waste5) return launch_pgemm<8>(a, s);
-  return launch_pgemm<5>(a, s);
+  return waste8 <= waste5 ? 8 : 5;
+}
+
+static int pgemm_dispatch_one(const PGemmArgs& a, hipStream_t s) {
+  const int ot = pgemm_out_tiles(a.N);
+  if (ot == 3) return launch_pgemm<3>(a, s);
+  if (ot == 5) return launch_pgemm<5>(a, s);
+  return launch_pgemm<8>(a, s);
+}
+
+// W^T chunk of one workgroup = 16 * OT rows x Kp floats in LDS.  Wide inputs (K > ~290 for 8 out-tiles, the
+// 128-wide layer sizes of BASELINE configs[4]) are processed as a chain of launches over K ranges that
+// accumulate into Y: the first launch carries the bias / addU / addV terms, the last one the statistics and the
+// BN-backward epilogue (they need the final values).
+static int pgemm_dispatch(const PGemmArgs& a0, hipStream_t s) {
+  PGemmArgs a = a0;
+  if (a.ldw == 0) a.ldw = a.Kp;
+  const int ot = pgemm_out_tiles(a.N);
+  const size_t budget = 96 * 1024;  // bytes of LDS for the weight chunk: keeps at least one more workgroup per CU
+  const int kmax = (int)(budget / ((size_t)16 * ot * sizeof(float))) / 16 * 16;
+  if (a.Kp <= kmax) return pgemm_dispatch_one(a, s);
+  for (int k0 = 0; k0 < a.K; k0 += kmax) {
+    PGemmArgs c = a;
+    const bool first = k0 == 0, last = k0 + kmax >= a.K;
+    c.K = last ? a.K - k0 : kmax;
+    c.Kp = 16 * clsr_cdiv(c.K, 16);
+    c.X = a.X + k0;
+    c.Wt = a.Wt + k0;
+    if (a.Xmul) c.Xmul = a.Xmul + k0;
+    if (a.in_scale) { c.in_scale = a.in_scale + k0; c.in_shift = a.in_shift + k0; }
+    if (!first) { c.accumulate = 1; c.bias = nullptr; c.addU = nullptr; c.addV = nullptr; }
+    if (!last) { c.stats = nullptr; c.ez = nullptr; }
+    int rc = pgemm_dispatch_one(c, s);
+    if (rc) return rc;
+  }
+  return CLSR_OK;
 }
 
 // ------------------------------------------------------------------------------------ packing

@@ -225,6 +225,96 @@ extern "C" int clsr_table_adam(float* table, float* grad_table, float* m, float*
   return CLSR_OK;
 }
 
+// ---- row-list variants for huge vocabularies (100M-item catalogues): the same math as table_reg / lazy
+// table_adam, but driven by the compacted id list of the involved rows (clsr_flags_compact) instead of a sweep
+// over all V*C elements.  count[0] = number of listed rows (device memory).
+__global__ void __launch_bounds__(256) table_reg_rows_kernel(
+    const float* __restrict__ table, const float* __restrict__ partner, const int* __restrict__ ids,
+    const int* __restrict__ count, int C, float l2, float disc_scale, float disc_loss_scale,
+    const float* __restrict__ ucount, float* __restrict__ grad_table, double* __restrict__ sumsq,
+    double* __restrict__ reg_loss, double* __restrict__ disc_loss) {
+  const float cd = partner ? disc_scale / (ucount[0] * (float)C) : 0.f;
+  const float cl = (partner && disc_loss) ? disc_loss_scale / (ucount[0] * (float)C) : 0.f;
+  double ss = 0.0, rl = 0.0, dl = 0.0;
+  const long total = (long)count[0] * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C;
+    const long e = (long)ids[r] * C + (i - r * C);
+    const float p = table[e];
+    float g = l2 * p;
+    if (partner) {
+      const float d = p - partner[e];
+      g += cd * d;
+      dl += (double)d * d;
+    }
+    grad_table[e] += g;
+    ss += (double)g * g;
+    rl += (double)p * p;
+  }
+  __shared__ double red[3][4];
+  ss = block256_sum_d(ss, red[0]); rl = block256_sum_d(rl, red[1]); dl = block256_sum_d(dl, red[2]);
+  if (threadIdx.x == 0) {
+    if (ss != 0.0) atomicAdd(sumsq, ss);
+    if (reg_loss && rl != 0.0) atomicAdd(reg_loss, 0.5 * (double)l2 * rl);
+    if (disc_loss && dl != 0.0) atomicAdd(disc_loss, (double)cl * dl);
+  }
+}
+
+extern "C" int clsr_table_reg_rows(const float* table, const float* partner, const int* ids, const int* count,
+                                   int cap, int C, float l2, float disc_scale, float disc_loss_scale,
+                                   const float* ucount, float* grad_table, double* sumsq, double* reg_loss,
+                                   double* disc_loss, void* stream) {
+  CLSR_CHECK_ARG(table && ids && count && grad_table && sumsq && cap > 0 && C > 0);
+  CLSR_CHECK_ARG(!partner || ucount);
+  int blocks = clsr_cdiv((long)cap * C, 256 * 4);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(table_reg_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, partner, ids,
+                     count, C, l2, disc_scale, disc_loss_scale, ucount, grad_table, sumsq, reg_loss, disc_loss);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// LazyAdam over the listed rows; clears their gradient rows and flags.
+__global__ void __launch_bounds__(256) table_adam_rows_kernel(
+    float* __restrict__ table, float* __restrict__ grad_table, float* __restrict__ m, float* __restrict__ v,
+    unsigned char* __restrict__ flags, const int* __restrict__ ids, const int* __restrict__ count, int C,
+    const double* __restrict__ sumsq, int sumsq_stride, int nsum, float clip_norm,
+    const double* __restrict__ adam_state, float b1, float b2, float eps) {
+  double tot = 0.0;
+  for (int i = 0; i < nsum; ++i) tot += sumsq[(long)i * sumsq_stride];
+  const float factor = clip_factor(tot, clip_norm);
+  const float lr_t = (float)adam_state[3];
+  const long total = (long)count[0] * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C;
+    const int c = (int)(i - r * C);
+    const long row = ids[r];
+    const long e = row * C + c;
+    const float g = grad_table[e] * factor;
+    const float mm = b1 * m[e] + (1.0f - b1) * g;
+    const float vv = b2 * v[e] + (1.0f - b2) * g * g;
+    m[e] = mm;
+    v[e] = vv;
+    table[e] -= lr_t * mm / (sqrtf(vv) + eps);
+    grad_table[e] = 0.f;
+    if (c == 0) flags[row] = 0;
+  }
+}
+
+extern "C" int clsr_table_adam_rows(float* table, float* grad_table, float* m, float* v, unsigned char* flags,
+                                    const int* ids, const int* count, int cap, int C, const double* sumsq,
+                                    int sumsq_stride, int nsum, float clip_norm, const double* adam_state,
+                                    float beta1, float beta2, float eps, void* stream) {
+  CLSR_CHECK_ARG(table && grad_table && m && v && flags && ids && count && sumsq && adam_state && cap > 0 && C > 0);
+  CLSR_CHECK_ARG(nsum > 0);
+  int blocks = clsr_cdiv((long)cap * C, 256 * 4);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(table_adam_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, grad_table, m,
+                     v, flags, ids, count, C, sumsq, sumsq_stride, nsum, clip_norm, adam_state, beta1, beta2, eps);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
 // p[0..n) = 0 (doubles)
 __global__ void zero_d_kernel(double* p, int n) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;

@@ -17,11 +17,10 @@
 // the only cross-wave traffic is one 16-byte LDS write + barrier + RNT 16-byte LDS reads per lane
 // whenever a full state vector is needed (GRU: r.h and h', Time4LSTM: m).  Compared with one wave
 // per 16 histories this divides the T-serial MFMA chain and the register footprint by RNT.
-// Hidden size n <= 48 (RNT = 3 feature tiles), n % 4 == 0.
+// Hidden size n <= 48 runs with RNT = 3 feature tiles (3 waves), n <= 128 with 8 tiles (8 waves); n % 4 == 0.
 #include "common.h"
 #include "clsr_hip.h"
 
-#define RNT 3
 
 __device__ __forceinline__ f32x4 sig4(f32x4 v) {
   return (f32x4){sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w)};
@@ -55,6 +54,7 @@ __device__ __forceinline__ f32x4 load_w_bwd(const float* W, int ld, int colbase,
 }
 
 // acc (one feature tile) += sum over all RNT k-tiles of W-tile . state
+template <int RNT>
 __device__ __forceinline__ void mv1(f32x4& acc, const f32x4 (&w)[RNT], const f32x4 (&b)[RNT]) {
 #pragma unroll
   for (int kt = 0; kt < RNT; ++kt) {
@@ -66,6 +66,7 @@ __device__ __forceinline__ void mv1(f32x4& acc, const f32x4 (&w)[RNT], const f32
 }
 
 // publish this wave's tile of a vector and collect the full vector (RNT tiles) of the workgroup
+template <int RNT>
 __device__ __forceinline__ void xchg(f32x4* buf, int w, int lane, f32x4 own, f32x4 (&full)[RNT]) {
   buf[w * 64 + lane] = own;
   __syncthreads();
@@ -100,6 +101,7 @@ struct GruArgs {
 };
 
 // xb: LDS exchange area of the workgroup (f32x4 units): fwd uses [0, 2*RNT*64), bwd [0, 3*RNT*64)
+template <int RNT>
 __device__ __forceinline__ void gru_fwd_body(const GruArgs& a, const int bx, f32x4* xb) {
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   const int n = a.n, T = a.T;
@@ -166,6 +168,7 @@ __device__ __forceinline__ void gru_fwd_body(const GruArgs& a, const int bx, f32
   }
 }
 
+template <int RNT>
 __device__ __forceinline__ void gru_bwd_body(const GruArgs& a, const int bx, f32x4* xb) {
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   const int n = a.n, T = a.T;
@@ -229,19 +232,36 @@ __device__ __forceinline__ void gru_bwd_body(const GruArgs& a, const int bx, f32
   if (a.dh0 && cval) st4(a.dh0 + h * n + col, dh);
 }
 
-#define RNN_XB (2 * 4 * RNT * 64)  // f32x4 units: the largest exchange area (Time4LSTM backward)
+// dynamic LDS: the largest exchange area (Time4LSTM backward) is 2 * 4 * RNT * 64 float4
+static size_t rnn_lds_bytes(int rnt) { return (size_t)2 * 4 * rnt * 64 * sizeof(f32x4); }
+static int rnn_tiles(int n) { return n <= 48 ? 3 : 8; }
+
+// launch K<3> or K<8> by the widest hidden size of the launch
+#define RNN_LAUNCH(K, rnt, grid, stream, args)                                                           \
+  do {                                                                                                   \
+    const size_t lds_ = rnn_lds_bytes(rnt);                                                              \
+    if ((rnt) == 3) {                                                                                    \
+      hipLaunchKernelGGL(K<3>, grid, dim3(64 * 3), lds_, (hipStream_t)(stream), args);                   \
+    } else {                                                                                             \
+      CLSR_HIP(hipFuncSetAttribute((const void*)K<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
+      hipLaunchKernelGGL(K<8>, grid, dim3(64 * 8), lds_, (hipStream_t)(stream), args);                   \
+    }                                                                                                    \
+  } while (0)
+
+template <int RNT>
 __global__ void __launch_bounds__(64 * RNT) gru_fwd_kernel(GruArgs a) {
-  __shared__ f32x4 xb[RNN_XB];
-  gru_fwd_body(a, blockIdx.x, xb);
+  extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
+  gru_fwd_body<RNT>(a, blockIdx.x, xb);
 }
+template <int RNT>
 __global__ void __launch_bounds__(64 * RNT) gru_bwd_kernel(GruArgs a) {
-  __shared__ f32x4 xb[RNN_XB];
-  gru_bwd_body(a, blockIdx.x, xb);
+  extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
+  gru_bwd_body<RNT>(a, blockIdx.x, xb);
 }
 
 static int check_rnn_shape(int Hn, int T, int n, int ld) {
   CLSR_CHECK_ARG(Hn > 0 && T > 0);
-  CLSR_CHECK_SUPPORTED(n % 4 == 0 && n >= 4 && n <= 16 * RNT && ld % 4 == 0);
+  CLSR_CHECK_SUPPORTED(n % 4 == 0 && n >= 4 && n <= 128 && ld % 4 == 0);
   return CLSR_OK;
 }
 
@@ -257,7 +277,7 @@ extern "C" int clsr_gru_fwd(const float* Pin, int ldp, const float* Wgh, int ldg
   a.Pin = Pin; a.ldp = ldp; a.Wgh = Wgh; a.ldg = ldg; a.Wch = Wch; a.ldc = ldc; a.h0 = h0;
   a.h0_stride = h0_stride; a.seq_len = seq_len; a.len_stride = len_stride; a.Hn = Hn; a.T = T; a.n = n;
   a.hT = hT; a.out_seq = out_seq; a.hprev = hprev; a.gates = gates;
-  hipLaunchKernelGGL(gru_fwd_kernel, dim3(clsr_cdiv(Hn, 16)), dim3(64 * RNT), 0, (hipStream_t)stream, a);
+  RNN_LAUNCH(gru_fwd_kernel, rnn_tiles(n), dim3(clsr_cdiv(Hn, 16)), stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
@@ -275,7 +295,7 @@ extern "C" int clsr_gru_bwd(const float* gates, const float* hprev, const float*
   a.Wgh = Wgh; a.ldg = ldg; a.Wch = Wch; a.ldc = ldc; a.seq_len = seq_len; a.len_stride = len_stride;
   a.Hn = Hn; a.T = T; a.n = n; a.dhT = dhT; a.dout_seq = dout_seq; a.dPin = dPin; a.dh0 = dh0;
   a.lddp = 3 * n;
-  hipLaunchKernelGGL(gru_bwd_kernel, dim3(clsr_cdiv(Hn, 16)), dim3(64 * RNT), 0, (hipStream_t)stream, a);
+  RNN_LAUNCH(gru_bwd_kernel, rnn_tiles(n), dim3(clsr_cdiv(Hn, 16)), stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
@@ -297,6 +317,7 @@ struct T4Args {
   int lddp;
 };
 
+template <int RNT>
 __device__ __forceinline__ void t4lstm_fwd_body(const T4Args& a, const int bx, f32x4* xb) {
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   const int n = a.n, T = a.T;
@@ -309,7 +330,9 @@ __device__ __forceinline__ void t4lstm_fwd_body(const T4Args& a, const int bx, f
     for (int kt = 0; kt < RNT; ++kt) wm[gb][kt] = load_w_fwd(a.Wm, a.ldm, gb * n, n, w, kt, j, g);
   const int col = 16 * w + 4 * g;
   const bool cval = hvalid && col < n;
-  f32x4 cs = Z4, mown = Z4, ms[RNT] = {Z4, Z4, Z4};
+  f32x4 cs = Z4, mown = Z4, ms[RNT];
+#pragma unroll
+  for (int kt = 0; kt < RNT; ++kt) ms[kt] = Z4;
   const int len = hvalid ? min(a.seq_len[h * a.len_stride], T) : 0;
   const int Tmax = wave_max_i(len);
   const float* pin = a.Pin + (hvalid ? h : 0) * (long)T * a.ldp + (cval ? col : 0);
@@ -362,6 +385,7 @@ __device__ __forceinline__ void t4lstm_fwd_body(const T4Args& a, const int bx, f
     for (int t = len; t < T; ++t) st4(a.out_seq + (h * T + t) * n + col, Z4);
 }
 
+template <int RNT>
 __device__ __forceinline__ void t4lstm_bwd_body(const T4Args& a, const int bx, f32x4* xb) {
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   const int n = a.n, T = a.T;
@@ -437,13 +461,15 @@ __device__ __forceinline__ void t4lstm_bwd_body(const T4Args& a, const int bx, f
   }
 }
 
+template <int RNT>
 __global__ void __launch_bounds__(64 * RNT) t4lstm_fwd_kernel(T4Args a) {
-  __shared__ f32x4 xb[RNN_XB];
-  t4lstm_fwd_body(a, blockIdx.x, xb);
+  extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
+  t4lstm_fwd_body<RNT>(a, blockIdx.x, xb);
 }
+template <int RNT>
 __global__ void __launch_bounds__(64 * RNT) t4lstm_bwd_kernel(T4Args a) {
-  __shared__ f32x4 xb[RNN_XB];
-  t4lstm_bwd_body(a, blockIdx.x, xb);
+  extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
+  t4lstm_bwd_body<RNT>(a, blockIdx.x, xb);
 }
 
 // ------------------------------------------------------------------ fused multi-encoder launches
@@ -459,18 +485,21 @@ struct RnnMultiArgs {
   int has_t4;
 };
 
+template <int RNT>
 __global__ void __launch_bounds__(64 * RNT) rnn_multi_fwd_kernel(RnnMultiArgs a) {
-  __shared__ f32x4 xb[RNN_XB];
+  extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
   const int which = blockIdx.y;
-  if (which < a.ngru) gru_fwd_body(a.gru[which], blockIdx.x, xb);
-  else t4lstm_fwd_body(a.t4, blockIdx.x, xb);
+  if (which < a.ngru) gru_fwd_body<RNT>(a.gru[which], blockIdx.x, xb);
+  else t4lstm_fwd_body<RNT>(a.t4, blockIdx.x, xb);
 }
+template <int RNT>
 __global__ void __launch_bounds__(64 * RNT) rnn_multi_bwd_kernel(RnnMultiArgs a) {
-  __shared__ f32x4 xb[RNN_XB];
+  extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
   const int which = blockIdx.y;
-  if (which < a.ngru) gru_bwd_body(a.gru[which], blockIdx.x, xb);
-  else t4lstm_bwd_body(a.t4, blockIdx.x, xb);
+  if (which < a.ngru) gru_bwd_body<RNT>(a.gru[which], blockIdx.x, xb);
+  else t4lstm_bwd_body<RNT>(a.t4, blockIdx.x, xb);
 }
+
 
 extern "C" int clsr_t4lstm_fwd(const float* Pin, int ldp, const float* Wm, int ldm, const int* seq_len,
                                int len_stride, int Hn, int T, int n, float* out_seq, float* act,
@@ -482,7 +511,7 @@ extern "C" int clsr_t4lstm_fwd(const float* Pin, int ldp, const float* Wm, int l
   T4Args a = {};
   a.Pin = Pin; a.ldp = ldp; a.Wm = Wm; a.ldm = ldm; a.seq_len = seq_len; a.len_stride = len_stride;
   a.Hn = Hn; a.T = T; a.n = n; a.out_seq = out_seq; a.act = act; a.cst = cst; a.mprev = mprev;
-  hipLaunchKernelGGL(t4lstm_fwd_kernel, dim3(clsr_cdiv(Hn, 16)), dim3(64 * RNT), 0, (hipStream_t)stream, a);
+  RNN_LAUNCH(t4lstm_fwd_kernel, rnn_tiles(n), dim3(clsr_cdiv(Hn, 16)), stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
@@ -498,7 +527,7 @@ extern "C" int clsr_t4lstm_bwd(const float* act, const float* cst, const float* 
   a.act = const_cast<float*>(act); a.cst = const_cast<float*>(cst); a.Wm = Wm; a.ldm = ldm;
   a.seq_len = seq_len; a.len_stride = len_stride; a.Hn = Hn; a.T = T; a.n = n;
   a.dout_seq = dout_seq; a.dPin = dPin; a.lddp = 6 * n;
-  hipLaunchKernelGGL(t4lstm_bwd_kernel, dim3(clsr_cdiv(Hn, 16)), dim3(64 * RNT), 0, (hipStream_t)stream, a);
+  RNN_LAUNCH(t4lstm_bwd_kernel, rnn_tiles(n), dim3(clsr_cdiv(Hn, 16)), stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
@@ -631,13 +660,18 @@ static int fill_multi(RnnMultiArgs& m, const clsr_gru_desc* grus, int ngru, cons
   return CLSR_OK;
 }
 
+static int multi_tiles(const RnnMultiArgs& m) {
+  int n = m.has_t4 ? m.t4.n : 0;
+  for (int i = 0; i < m.ngru; ++i) n = m.gru[i].n > n ? m.gru[i].n : n;
+  return rnn_tiles(n);
+}
+
 extern "C" int clsr_rnn_fwd_multi(const clsr_gru_desc* grus, int ngru, const clsr_t4_desc* t4,
                                   const int* seq_len, int len_stride, int Hn, int T, void* stream) {
   RnnMultiArgs m;
   int rc = fill_multi(m, grus, ngru, t4, seq_len, len_stride, Hn, T, false);
   if (rc) return rc;
-  hipLaunchKernelGGL(rnn_multi_fwd_kernel, dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), dim3(64 * RNT), 0,
-                     (hipStream_t)stream, m);
+  RNN_LAUNCH(rnn_multi_fwd_kernel, multi_tiles(m), dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), stream, m);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
@@ -647,8 +681,7 @@ extern "C" int clsr_rnn_bwd_multi(const clsr_gru_desc* grus, int ngru, const cls
   RnnMultiArgs m;
   int rc = fill_multi(m, grus, ngru, t4, seq_len, len_stride, Hn, T, true);
   if (rc) return rc;
-  hipLaunchKernelGGL(rnn_multi_bwd_kernel, dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), dim3(64 * RNT), 0,
-                     (hipStream_t)stream, m);
+  RNN_LAUNCH(rnn_multi_bwd_kernel, multi_tiles(m), dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), stream, m);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }

@@ -120,7 +120,7 @@ class DataParallel(object):
         net, W = self.net, self.world
         grad, flags = net.tab_grad[name], net.tab_flags[name]
         V, C = grad.shape
-        cap = touched_rows_bound(name, net.last_shape, V)
+        cap = touched_rows_bound(name, net.last_shape, V)   # per rank: the flags are not merged yet
         key = (name, cap)
         b = self._sparse_bufs.get(key)
         if b is None:

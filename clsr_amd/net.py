@@ -155,9 +155,15 @@ class CLSRNet(object):
         self.tab_flags_flat = torch.zeros(ftot, dtype=torch.uint8, device=dev)
         it_dense = iter(zip(dense, off[:-1]))
         for name, shape, kind in specs:
-            val = init_tensor(kind, tuple(shape), hp, gen)
+            big = name in table_names and int(np.prod(shape)) > (1 << 27)
+            val = None if big else init_tensor(kind, tuple(shape), hp, gen)
             if name in table_names:
-                t = val.to(dev)
+                if big:   # 100M-item catalogues: initialise in place on the device (no 38 GB host copy)
+                    t = torch.empty(tuple(shape), dtype=F32, device=dev)
+                    v0 = float(hp.init_value)
+                    torch.nn.init.trunc_normal_(t, mean=0.0, std=v0, a=-2 * v0, b=2 * v0)
+                else:
+                    t = val.to(dev)
                 self.P[name] = t
                 if name != UNUSED_TABLE:
                     key = [k for k, v in TABLES.items() if v == name][0]
@@ -955,6 +961,28 @@ class CLSRNet(object):
                 call("clsr_gather_bwd_sorted", dhist, dM, dR, keys, perm, seq_len, ls, n, T, self.D, col0 + c0,
                      min(64, C - c0), k, self.tab_grad[name], C, c0, ss[slot:])
 
+    #: tables with more elements than this are regularised / lazily updated through the compacted list of
+    #: their involved rows instead of a sweep over all V*C elements (100M-item catalogues)
+    rowlist_min_elems = 1 << 26
+
+    def rows_bound(self, key):
+        """Upper bound on the rows of table ``key`` touched in the current step (all data-parallel ranks)."""
+        B, T, G, Hn = self.last_shape
+        V = self.tables[key].shape[0]
+        per_rank = Hn if key.startswith("user") else Hn * T + B
+        return int(min(V, per_rank * self.dp_world))
+
+    def _involved_list(self, key):
+        """(ids, count, cap): ascending ids of the flagged rows of table ``key``, count on the device."""
+        V = self.tables[key].shape[0]
+        cap = self.rows_bound(key)
+        nws = query("clsr_flags_compact_workspace_bytes", V)
+        ws = self._buf("rows.ws." + key, nws, dtype=torch.uint8)
+        ids = self._buf("rows.ids." + key, cap, dtype=torch.int32)
+        count = self._buf("rows.count." + key, 2, dtype=torch.int32)
+        call("clsr_flags_compact", self.tab_flags[key], V, ids, cap, count, ws, nws)
+        return ids, count, cap
+
     def _apply_updates(self):
         hp = self.hp
         ss = self.sumsq_tab
@@ -963,14 +991,21 @@ class CLSRNet(object):
         call("clsr_zero_floats", self.ucount, 1)
         call("clsr_count_flags", self.tab_flags["user_long"], Vu, self.ucount)
         tb, tg, fl = self.tables, self.tab_grad, self.tab_flags
-        call("clsr_table_reg", tb["item"], None, fl["item"], Vi, self.Di, l2e, 0.0, 0.0, None, tg["item"], ss[4:],
-             self.losses[1:], None)
-        call("clsr_table_reg", tb["cate"], None, fl["cate"], Vc, self.Dc, l2e, 0.0, 0.0, None, tg["cate"], ss[5:],
-             self.losses[1:], None)
-        call("clsr_table_reg", tb["user_long"], tb["user_short"], fl["user_long"], Vu, self.Du, l2e, -2.0 * wd, -wd,
-             self.ucount, tg["user_long"], ss[8:], self.losses[1:], self.losses[3:])
-        call("clsr_table_reg", tb["user_short"], tb["user_long"], fl["user_short"], Vu, self.Du, l2e, -2.0 * wd, 0.0,
-             self.ucount, tg["user_short"], ss[9:], self.losses[1:], None)
+        lists = {k: self._involved_list(k) for k, t in tb.items() if t.numel() > self.rowlist_min_elems}
+        for key, partner, slot, dscale, dloss_scale, dloss in (
+                ("item", None, 4, 0.0, 0.0, None), ("cate", None, 5, 0.0, 0.0, None),
+                ("user_long", "user_short", 8, -2.0 * wd, -wd, self.losses[3:]),
+                ("user_short", "user_long", 9, -2.0 * wd, 0.0, None)):
+            V, C = tb[key].shape
+            pt = tb[partner] if partner else None
+            uc = self.ucount if partner else None
+            if key in lists:
+                ids, count, cap = lists[key]
+                call("clsr_table_reg_rows", tb[key], pt, ids, count, cap, C, l2e, dscale, dloss_scale, uc, tg[key],
+                     ss[slot:], self.losses[1:], dloss)
+            else:
+                call("clsr_table_reg", tb[key], pt, fl[key], V, C, l2e, dscale, dloss_scale, uc, tg[key], ss[slot:],
+                     self.losses[1:], dloss)
         clip = float(hp.max_grad_norm) if hp.is_clip_norm else 0.0
         call("clsr_dense_reg_norm", self.dense, self.dense_grad, self.seg_off, len(self.dense_names),
              float(hp.layer_l2), self.dense_sumsq, self.losses[1:])
@@ -983,8 +1018,13 @@ class CLSRNet(object):
              self.dense_sumsq, clip, self.adam_state, 0.9, 0.999, 1e-8, self.n_dense)
         for key, V, C, base, nsum in (("item", Vi, self.Di, 0, 3), ("cate", Vc, self.Dc, 1, 3),
                                       ("user_long", Vu, self.Du, 6, 2), ("user_short", Vu, self.Du, 7, 2)):
-            call("clsr_table_adam", tb[key], tg[key], self.tab_m[key], self.tab_v[key], fl[key], V, C, ss[base:], 2,
-                 nsum, clip, self.adam_state, 0.9, 0.999, 1e-8, self.lazy)
+            if key in lists and self.lazy:
+                ids, count, cap = lists[key]
+                call("clsr_table_adam_rows", tb[key], tg[key], self.tab_m[key], self.tab_v[key], fl[key], ids, count,
+                     cap, C, ss[base:], 2, nsum, clip, self.adam_state, 0.9, 0.999, 1e-8)
+            else:
+                call("clsr_table_adam", tb[key], tg[key], self.tab_m[key], self.tab_v[key], fl[key], V, C, ss[base:],
+                     2, nsum, clip, self.adam_state, 0.9, 0.999, 1e-8, self.lazy)
 
     def read_losses(self):
         """Synchronising read of the step's loss terms -> dict of python floats."""

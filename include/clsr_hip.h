@@ -229,6 +229,14 @@ int clsr_table_reg(const float* table, const float* partner, const unsigned char
 int clsr_table_adam(float* table, float* grad_table, float* m, float* v, unsigned char* flags, long V,
                     int C, const double* sumsq, int sumsq_stride, int nsum, float clip_norm,
                     const double* adam_state, float beta1, float beta2, float eps, int lazy, void* stream);
+/* row-list variants for huge vocabularies: ids/count from clsr_flags_compact (involved rows) */
+int clsr_table_reg_rows(const float* table, const float* partner, const int* ids, const int* count, int cap,
+                        int C, float l2, float disc_scale, float disc_loss_scale, const float* ucount,
+                        float* grad_table, double* sumsq, double* reg_loss, double* disc_loss, void* stream);
+int clsr_table_adam_rows(float* table, float* grad_table, float* m, float* v, unsigned char* flags,
+                         const int* ids, const int* count, int cap, int C, const double* sumsq,
+                         int sumsq_stride, int nsum, float clip_norm, const double* adam_state, float beta1,
+                         float beta2, float eps, void* stream);
 int clsr_zero_doubles(double* p, int n, void* stream);
 int clsr_add_doubles(double* dst, const double* src, int n, void* stream);
 int clsr_zero_floats(float* p, long n, void* stream);

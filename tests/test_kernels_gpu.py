@@ -166,18 +166,20 @@ def _pgemm(X, W, bias=None, T=0, G=0, Xmul=None, in_scale=None, in_shift=None, r
 
 
 @pytest.mark.parametrize("M,K,N", [(1000, 80, 80), (333, 40, 40), (77, 164, 80), (515, 100, 64),
-                                   (260, 40, 240), (129, 80, 100), (50, 64, 4), (2000, 120, 120)])
+                                   (260, 40, 240), (129, 80, 100), (50, 64, 4), (2000, 120, 120),
+                                   (200, 516, 80), (300, 1536, 128), (90, 320, 80)])   # wide K: chunked launches
 def test_pgemm_plain_bias_stats(M, K, N):
     g = torch.Generator().manual_seed(M + K + N)
     X, W, b = rnd(g, M, K), rnd(g, K, N, scale=0.3), rnd(g, N)
     Y, st = _pgemm(X, W, b, stats=True)
     exp = X @ W + b
-    close(Y, exp, rtol=1e-5, atol=1e-5, name="Y")
+    tol = 1e-5 * max(1.0, (K / 100.0) ** 0.5)
+    close(Y, exp, rtol=1e-5, atol=tol, name="Y")
     tot = st.sum(0).cpu()
-    close(tot[0], exp.sum(0), rtol=1e-5, atol=1e-4, name="colsum")
-    close(tot[1], (exp ** 2).sum(0), rtol=1e-5, atol=1e-4, name="colsumsq")
+    close(tot[0], exp.sum(0), rtol=1e-5, atol=10 * tol, name="colsum")
+    close(tot[1], (exp ** 2).sum(0), rtol=1e-5, atol=10 * tol * max(1.0, K / 100.0), name="colsumsq")
     Y2, _ = _pgemm(X, W, None, Y=Y.clone(), accumulate=1)
-    close(Y2, 2 * exp - b, rtol=1e-5, atol=2e-5, name="accumulate")
+    close(Y2, 2 * exp - b, rtol=1e-5, atol=2 * tol, name="accumulate")
 
 
 def test_pgemm_rowmap_mul_affine_adds():
@@ -353,7 +355,8 @@ def _oracle():
 
 
 @pytest.mark.parametrize("Hn,T,n,use_h0,seq_out", [(37, 10, 40, True, False), (16, 50, 40, False, True),
-                                                   (5, 7, 40, True, True)])
+                                                   (5, 7, 40, True, True), (21, 9, 128, True, True),
+                                                   (4, 5, 64, False, False)])
 def test_gru_fwd_bwd(Hn, T, n, use_h0, seq_out):
     O = _oracle()
     g = torch.Generator().manual_seed(T + Hn)
@@ -407,11 +410,11 @@ def test_gru_fwd_bwd(Hn, T, n, use_h0, seq_out):
         close(dh0, h0.grad, rtol=2e-4, atol=2e-5, name="dh0")
 
 
-@pytest.mark.parametrize("Hn,T", [(37, 10), (16, 50)])
-def test_t4lstm_fwd_bwd(Hn, T):
+@pytest.mark.parametrize("Hn,T,n", [(37, 10, 40), (16, 50, 40), (19, 8, 128)])
+def test_t4lstm_fwd_bwd(Hn, T, n):
     O = _oracle()
     g = torch.Generator().manual_seed(T)
-    D = n = 40
+    D = 40
     x = rnd(g, Hn, T, D).float().double().requires_grad_(True)
     names = {"_time_input_w1": (n,), "_time_input_bias1": (n,), "_time_input_w2": (n,), "_time_input_bias2": (n,),
              "_time_kernel_w1": (D, n), "_time_kernel_t1": (n, n), "_time_bias1": (n,),

@@ -199,3 +199,31 @@ def test_compact_feed_is_the_same_step(golden_dir, golden_hparams, dedup):
         assert abs(ls0[k] - ls1[k]) <= 1e-6 * max(1.0, abs(ls0[k])), k
     for k in sd0:
         _close(sd1[k], sd0[k], 1e-5, 1e-6, k)
+
+
+def test_row_list_optimizer_path_equals_sweep(golden_dir, golden_hparams):
+    """lazyadam through the compacted involved-row lists (the path huge catalogues take) == the flag sweep."""
+    hp = _variant(golden_hparams, optimizer="lazyadam")
+    feed = _feed(golden_dir, "iterator_train_sa.npz", b=2)
+    res = []
+    for thresh in (1 << 26, 0):
+        _, net, _ = _setup(hp, True)
+        net.rowlist_min_elems = thresh
+        f = net.upload(feed, True)
+        for _ in range(2):
+            net.train_step(f)
+        torch.cuda.synchronize()
+        res.append((net.read_losses(), {k: v.clone() for k, v in net.state_dict().items()},
+                    {k: t.clone() for k, t in net.tab_flags.items()}, {k: t.clone() for k, t in net.tab_grad.items()}))
+    (ls0, sd0, fl0, tg0), (ls1, sd1, fl1, tg1) = res
+    for k in ls0:
+        assert abs(ls0[k] - ls1[k]) <= 1e-6 * max(1.0, abs(ls0[k])), (k, ls0[k], ls1[k])
+    # (dense biases in front of a batch-norm have a zero gradient: their Adam steps follow summation noise and
+    #  differ from run to run -- the optimiser paths under test only touch the embedding tables)
+    tabs = [k for k in sd0 if "embedding" in k]
+    assert len(tabs) >= 4
+    for k in tabs:
+        _close(sd1[k], sd0[k], 1e-5, 1e-7, k)
+    for k in fl0:   # both paths leave the flags and gradient tables cleared for the next step
+        assert int(fl1[k].sum()) == 0 and int(fl0[k].sum()) == 0
+        assert float(tg1[k].abs().max()) == 0.0 and float(tg0[k].abs().max()) == 0.0
