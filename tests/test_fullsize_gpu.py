@@ -107,7 +107,7 @@ def test_kuaishou_shape_runs_and_matches_oracle_on_a_slice():
                                            O.to_torch_feed(feed, dtype=torch.float64), hp)
     got = net.train_step(net.upload(feed, True))
     torch.cuda.synchronize()
-    assert float((got["logit"].cpu().double() - out["logit"].reshape(-1)).abs().max()) < 1e-3
+    assert float((got["logit"].cpu().double() - out["logit"].detach().reshape(-1)).abs().max()) < 1e-3
     gl = net.read_losses()
     assert abs(gl["loss"] - float(ls["loss"])) < 1e-4 * abs(float(ls["loss"]))
 
@@ -144,7 +144,7 @@ def test_catalogue_dims_match_oracle_on_a_slice():
                                                O.to_torch_feed(feed, dtype=torch.float64), hp)
     got = net.train_step(net.upload(feed, True))
     torch.cuda.synchronize()
-    assert float((got["logit"].cpu().double() - out["logit"].reshape(-1)).abs().max()) < 1e-3
+    assert float((got["logit"].cpu().double() - out["logit"].detach().reshape(-1)).abs().max()) < 1e-3
     gl = net.read_losses()
     for k in ("loss", "data_loss", "contrastive_loss", "regular_loss", "discrepancy_loss"):
         assert abs(gl[k] - float(ls[k])) <= 1e-4 * max(1e-3, abs(float(ls[k]))), (k, gl[k], float(ls[k]))
