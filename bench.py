@@ -175,7 +175,11 @@ def main():
             eager_step()
             stream.synchronize()
             log("eager step %d done" % i)
-        if args.no_graph:
+        # data-parallel runs stay eager: the RCCL watchdog thread of torch.distributed polls its events while a
+        # stream capture is open, which can invalidate the capture (hipErrorCapturedEvent, seen on the catalogue
+        # config); eager launches cost ~2 ms of host time per step and are hidden behind the device step
+        use_graph = not args.no_graph and (stepper is None or bool(os.environ.get("CLSR_DP_GRAPH")))
+        if not use_graph:
             run = eager_step
         elif stepper is None:
             ops.graph_begin()
@@ -184,7 +188,7 @@ def main():
             run = lambda: ops.graph_launch(graph)
         else:
             run = stepper.capture(f)
-        log("step captured" if not args.no_graph else "eager mode")
+        log("step captured" if use_graph else "eager mode")
         for _ in range(args.warmup):
             run()
         stream.synchronize()
@@ -279,20 +283,20 @@ def main():
     out = None
     if rank == 0:
         out = {
-            "metric": "train interactions/sec @ batch 4096 seq_len 50", "value": round(value, 1),
+            "metric": "train interactions/sec @ batch %d seq_len %d" % (P, T), "value": round(value, 1),
             "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[%s]: %s CLSR train step, batch 4096 positives x5 rows "
-                                   "(B=20480), seq_len %d (%s lengths), Di/Dc/Du/H=%d/%d/%d/%d, Vu/Vi/Vc=%d/%d/%d, "
+            "config": {"workload": "BASELINE configs[%s]: %s CLSR train step, batch %d positives x5 rows "
+                                   "(B=%d), seq_len %d (%s lengths), Di/Dc/Du/H=%d/%d/%d/%d, Vu/Vi/Vc=%d/%d/%d, "
                                    "time4lstm + triplet, %s" % (
                                        {"taobao": "1", "kuaishou": "2", "catalogue100m": "4"}.get(args.config, "?"),
-                                       args.config, T, args.lengths, cfg["Di"], cfg["Dc"], cfg["Du"], cfg["H"],
+                                       args.config, P, P * G, T, args.lengths, cfg["Di"], cfg["Dc"], cfg["Du"], cfg["H"],
                                        cfg["Vu"], cfg["Vi"], cfg["Vc"],
                                        "lazy Adam (row lists)" if big else "dense Adam"),
                        "global_batch": world * P, "seq_len": T,
                        "parallelism": "dp%d" % world if world > 1 else "single",
-                       "hipgraph": not args.no_graph, "history_dedup": True,
+                       "hipgraph": use_graph, "history_dedup": True,
                        "batch_norm": ("sync" if args.sync_bn else "per-rank") if world > 1 else "single-device"},
             "rows_per_s": round(value * G, 1),
             "roofline": roof, "roofline_mfma": roof_mfma,
