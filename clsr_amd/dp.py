@@ -92,8 +92,7 @@ class DataParallel(object):
         net, dist = self.net, self.dist
         tensors = [net.dense, net.dense_m, net.dense_v, net.adam_state]
         tensors += list(net.tables.values()) + list(net.tab_m.values()) + list(net.tab_v.values())
-        for bn in net.bn.values():
-            tensors += [bn.moving_mean, bn.moving_var]
+        tensors.append(net.bn_moving)
         for t in tensors:
             dist.broadcast(t, src=0, group=self.group)
 
@@ -154,20 +153,28 @@ class DataParallel(object):
         else:
             dist.all_reduce(net.dense_grad, op=dist.ReduceOp.SUM, group=self.group)
             dist.all_reduce(self.small, op=dist.ReduceOp.SUM, group=self.group)
-            for n in net.tab_grad:
-                if n in sparse:
-                    self._exchange_rows(n)
-                else:
-                    dist.all_reduce(net.tab_grad[n], op=dist.ReduceOp.SUM, group=self.group)
-                    dist.all_reduce(net.tab_flags[n], op=dist.ReduceOp.MAX, group=self.group)
+            # runs of consecutive dense tables share one collective per flat buffer (they are adjacent in it)
+            names, i = list(net.tab_grad), 0
+            while i < len(names):
+                if names[i] in sparse:
+                    self._exchange_rows(names[i])
+                    i += 1
+                    continue
+                j = i
+                while j + 1 < len(names) and names[j + 1] not in sparse:
+                    j += 1
+                V, C = net.tab_shape[names[j]]
+                g0, g1 = net.tab_goff[names[i]], net.tab_goff[names[j]] + V * C
+                f0, f1 = net.tab_foff[names[i]], net.tab_foff[names[j]] + V
+                dist.all_reduce(net.tab_grad_flat[g0:g1], op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(net.tab_flags_flat[f0:f1], op=dist.ReduceOp.MAX, group=self.group)
+                i = j + 1
         net.sumsq_tab.copy_(self.small[:16])
         net.losses.copy_(self.small[16:])
         if not self.sync_bn:
             # keep the (non-trainable) moving statistics identical on every replica
-            for bn in net.bn.values():
-                for t in (bn.moving_mean, bn.moving_var):
-                    self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-                    t.mul_(1.0 / self.world)
+            self.dist.all_reduce(net.bn_moving, op=self.dist.ReduceOp.SUM, group=self.group)
+            net.bn_moving.mul_(1.0 / self.world)
 
     def _update(self):
         self.net._apply_updates()

@@ -151,6 +151,7 @@ class CLSRNet(object):
             goff[k], foff[k] = gtot, ftot
             gtot += _pad4(sh[0] * sh[1])
             ftot += (sh[0] + 15) // 16 * 16
+        self.tab_goff, self.tab_foff, self.tab_shape = goff, foff, tshape   # layout of the two flat buffers
         self.tab_grad_flat = torch.zeros(gtot, dtype=F32, device=dev)
         self.tab_flags_flat = torch.zeros(ftot, dtype=torch.uint8, device=dev)
         it_dense = iter(zip(dense, off[:-1]))
@@ -185,6 +186,16 @@ class CLSRNet(object):
             if name.endswith("/gamma"):
                 scope = name[:-len("gamma")]
                 self.bn[scope] = _BN(self, scope, self.P[name].numel())
+        # moving statistics of all layers as views of ONE buffer (a single collective averages them across ranks)
+        tot = sum(2 * bn.C for bn in self.bn.values())
+        self.bn_moving = torch.zeros(tot, dtype=F32, device=dev)
+        o = 0
+        for bn in self.bn.values():
+            for attr in ("moving_mean", "moving_var"):
+                view = self.bn_moving[o:o + bn.C]
+                view.copy_(getattr(bn, attr))
+                setattr(bn, attr, view)
+                o += bn.C
 
     def state_dict(self):
         """All variables under their TF names + BN moving stats + Adam slots (checkpoint payload)."""
