@@ -149,6 +149,8 @@ def main():
     net = CLSRNet(hp, dims, device="cuda:%d" % local_rank, seed=0)
     if os.environ.get("CLSR_NO_OVERLAP"):
         net.overlap = False
+    if os.environ.get("CLSR_DW_EAGER"):
+        net.defer_dw = False
     log("net built")
     feed = synthetic_feed(P, T, cfg["Vu"], cfg["Vi"], cfg["Vc"], G=G, lengths=args.lengths, seed=20220425 + rank,
                           ids="uniform" if big else "zipf")

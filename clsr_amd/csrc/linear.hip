@@ -831,11 +831,10 @@ extern "C" long clsr_pgemm_dw_workspace_floats(int M, int K, int N) {
   return chunks * dw_grid_x(M) * DW_CHUNK;
 }
 
-extern "C" int clsr_pgemm_dw(const float* X, int ldx, int T, int G, const float* Xmul, int ldmul,
-                             const float* in_scale, const float* in_shift, int in_relu,
-                             const float* dY, int ldy, int M, int K, int N, float scale, float* dW,
-                             int ldw, float* db, int accumulate, float* workspace, void* stream) {
-  CLSR_CHECK_ARG(X && dY && dW && workspace && M >= 0 && K > 0 && N > 0 && ldw >= N);
+static int dw_launch_partial(const float* X, int ldx, int T, int G, const float* Xmul, int ldmul,
+                             const float* in_scale, const float* in_shift, int in_relu, const float* dY, int ldy,
+                             int M, int K, int N, float* workspace, hipStream_t s, int* gx_out) {
+  CLSR_CHECK_ARG(X && dY && workspace && M >= 0 && K > 0 && N > 0);
   CLSR_CHECK_ARG(!(in_scale && !in_shift));
   // 16-byte staging loads: rows must be float4 addressable up to roundup(K,4) / N
   CLSR_CHECK_SUPPORTED(N % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= ((K + 3) & ~3) &&
@@ -847,15 +846,92 @@ extern "C" int clsr_pgemm_dw(const float* X, int ldx, int T, int G, const float*
   a.dY = dY; a.ldy = ldy; a.partial = workspace; a.M = M; a.K = K; a.N = N;
   const int kch = clsr_cdiv(K, 16 * DW_T), nch = clsr_cdiv(N, 16 * DW_T);
   const int gx = dw_grid_x(M);
-  hipStream_t s = (hipStream_t)stream;
   CLSR_CHECK_SUPPORTED(!(Xmul && in_scale) && !(in_scale && K % 4));
   if (Xmul) hipLaunchKernelGGL(pgemm_dw_kernel<1>, dim3(gx, kch, nch), dim3(256), 0, s, a);
   else if (in_scale) hipLaunchKernelGGL(pgemm_dw_kernel<2>, dim3(gx, kch, nch), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(pgemm_dw_kernel<0>, dim3(gx, kch, nch), dim3(256), 0, s, a);
   CLSR_CHECK_LAUNCH();
+  *gx_out = gx;
+  return CLSR_OK;
+}
+
+extern "C" int clsr_pgemm_dw(const float* X, int ldx, int T, int G, const float* Xmul, int ldmul,
+                             const float* in_scale, const float* in_shift, int in_relu,
+                             const float* dY, int ldy, int M, int K, int N, float scale, float* dW,
+                             int ldw, float* db, int accumulate, float* workspace, void* stream) {
+  CLSR_CHECK_ARG(dW && ldw >= N);
+  hipStream_t s = (hipStream_t)stream;
+  int gx = 0;
+  int rc = dw_launch_partial(X, ldx, T, G, Xmul, ldmul, in_scale, in_shift, in_relu, dY, ldy, M, K, N, workspace, s,
+                             &gx);
+  if (rc) return rc;
+  const int kch = clsr_cdiv(K, 16 * DW_T), nch = clsr_cdiv(N, 16 * DW_T);
   const int total = K * N + (db ? N : 0);
   hipLaunchKernelGGL(dw_reduce_kernel, dim3(clsr_cdiv(total, 64)), dim3(1024), 0, s, workspace, gx, K, N, kch,
                      nch, scale, dW, ldw, db, accumulate);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// Deferred form: only the per-block partial chunks are produced (own workspace per call); the weight gradients
+// of a whole backward pass are then reduced by ONE clsr_dw_reduce_batch launch (blockIdx.y = descriptor) instead
+// of ~20 small dependent launches.  Returns the number of partials per chunk (for the descriptor).
+extern "C" int clsr_pgemm_dw_partial(const float* X, int ldx, int T, int G, const float* Xmul, int ldmul,
+                                     const float* in_scale, const float* in_shift, int in_relu,
+                                     const float* dY, int ldy, int M, int K, int N, float* workspace,
+                                     void* stream) {
+  int gx = 0;
+  return dw_launch_partial(X, ldx, T, G, Xmul, ldmul, in_scale, in_shift, in_relu, dY, ldy, M, K, N, workspace,
+                           (hipStream_t)stream, &gx);
+}
+
+extern "C" int clsr_pgemm_dw_parts(int M) { return dw_grid_x(M); }
+extern "C" int clsr_sizeof_dw_desc(void) { return (int)sizeof(clsr_dw_desc); }
+
+__global__ void __launch_bounds__(1024) dw_reduce_batch_kernel(const clsr_dw_desc* __restrict__ descs) {
+  __shared__ float red[16][64];
+  const clsr_dw_desc d = descs[blockIdx.y];
+  const int K = d.K, N = d.N;
+  const int total = K * N + (d.db ? N : 0);
+  if ((int)blockIdx.x * 64 >= total) return;   // block-uniform
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int sub = threadIdx.x >> 6;
+  const int kchunks = (K + 16 * DW_T - 1) / (16 * DW_T), nchunks = (N + 16 * DW_T - 1) / (16 * DW_T);
+  (void)kchunks;
+  float s = 0.f;
+  float* o = nullptr;
+  if (e < total) {
+    const float* p;
+    if (e < K * N) {
+      const int k = e / N, n = e - k * N;
+      const int kc = k / (16 * DW_T), nc = n / (16 * DW_T);
+      const int kk = k - kc * 16 * DW_T, nn = n - nc * 16 * DW_T;
+      const long off = ((kk >> 4) * DW_T + (nn >> 4)) * 256 + (kk & 15) * 16 + (nn & 15);
+      p = d.partial + ((long)(kc * nchunks + nc) * d.nparts) * DW_CHUNK + off;
+      o = d.dW + (long)k * d.ldw + n;
+    } else {
+      const int n = e - K * N;
+      const int nc = n / (16 * DW_T), nn = n - nc * 16 * DW_T;
+      p = d.partial + ((long)nc * d.nparts) * DW_CHUNK + DW_T * DW_T * 256 + nn;
+      o = d.db + n;
+    }
+    for (int w = sub; w < d.nparts; w += 16) s += p[(long)w * DW_CHUNK];
+  }
+  red[sub][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sub == 0 && e < total) {
+    s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += red[u][threadIdx.x];
+    s *= d.scale;
+    *o = d.accumulate ? *o + s : s;
+  }
+}
+
+extern "C" int clsr_dw_reduce_batch(const clsr_dw_desc* descs_device, int n, int max_outputs, void* stream) {
+  CLSR_CHECK_ARG(descs_device && n > 0 && max_outputs > 0);
+  hipLaunchKernelGGL(dw_reduce_batch_kernel, dim3(clsr_cdiv(max_outputs, 64), n), dim3(1024), 0,
+                     (hipStream_t)stream, descs_device);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }

@@ -77,6 +77,8 @@ class CLSRNet(object):
         self._ws_tag = ""          # suffix of shared scratch buffers while a side-stream branch is recording
         self._side = None
         self._joins = []
+        self._dw_pending, self._dw_tables, self._dw_after = {}, {}, {}
+        self.defer_dw = True       # one batched reduction of the weight-gradient partials per stream and step
         self.overlap = True        # run the long-term attention chain on a side stream (fork / join)
         self.sorted_hist_grad = True   # history-row gradients by sort + segmented sums (False: float atomics)
         self.adam_state = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device=self.device)
@@ -318,13 +320,32 @@ class CLSRNet(object):
              acc, stats, M, K, N)
 
     def _dw(self, X, ldx, dY, ldy, M, K, N, dW, ldw, db=None, T=0, G=0, Xmul=None, ldmul=0, aff=None, acc=0):
+        """Weight gradient dW = f(X)^T dY.  Deferred: this launches only the kernel that writes the per-block
+        partial chunks (into a workspace of its own); ``_dw_flush`` reduces every pending gradient of the current
+        stream in ONE launch."""
+        pend = self._dw_pending.setdefault(self._ws_tag, [])
         need = query("clsr_pgemm_dw_workspace_floats", M, K, N)
-        ws = self._bufs.get("dw_ws" + self._ws_tag)
-        if ws is None or ws.numel() < need:
-            ws = torch.empty(max(need, 1 << 20), dtype=F32, device=self.device)
-            self._bufs["dw_ws" + self._ws_tag] = ws
+        ws = self._buf("dw_ws%s.%d" % (self._ws_tag, len(pend)), max(need, 1))
         sc, sh = (aff.scale, aff.shift) if aff is not None else (None, None)
-        call("clsr_pgemm_dw", X, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, ldy, M, K, N, 1.0, dW, ldw, db, acc, ws)
+        call("clsr_pgemm_dw_partial", X, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, ldy, M, K, N, ws)
+        pend.append((ws.data_ptr(), dW.data_ptr(), db.data_ptr() if db is not None else 0, 1.0,
+                     query("clsr_pgemm_dw_parts", M), K, N, ldw, acc))
+        if not self.defer_dw:
+            self._dw_flush()
+
+    def _dw_flush(self):
+        """Reduce the partial chunks of every ``_dw`` issued on the current stream since the last flush, then
+        run the operations that were waiting for those gradients."""
+        tag = self._ws_tag
+        pend = self._dw_pending.pop(tag, [])
+        if pend:
+            sig = tuple(pend)
+            tab = self._dw_tables.get(sig)
+            if tab is None:   # descriptor table: built and uploaded once per shape signature
+                tab = self._dw_tables[sig] = ops.dw_table(sig, self.device)
+            call("clsr_dw_reduce_batch", tab[0], tab[1], tab[2])
+        for fn in self._dw_after.pop(tag, []):
+            fn()
 
     def _stats_buf(self, M, N):
         parts = query("clsr_pgemm_stats_parts", M)
@@ -641,7 +662,9 @@ class CLSRNet(object):
             call("clsr_att_z0_bwd_reduce", dz0, Hn, G, T, A0, dU, dV)
         self._dw(a, Q, dU, A0, Hn * T, Q, A0, dW0[0:Q], A0)                        # d(W0a + W0d)
         self._dw(q, Q, dV, A0, R, Q, A0, dW0[Q:2 * Q], A0, db=Gd[nn + "b_nn_layer0"])  # d(W0q - W0d)
-        call("clsr_axpby", dW0[2 * Q:3 * Q], dW0[0:Q], 1.0, dW0[Q:2 * Q], -1.0, Q * A0)
+        # d(W0d) = d(W0a+W0d) - d(W0q-W0d) block: needs the two reduced gradients above (runs at the flush)
+        self._dw_after.setdefault(self._ws_tag, []).append(
+            lambda: call("clsr_axpby", dW0[2 * Q:3 * Q], dW0[0:Q], 1.0, dW0[Q:2 * Q], -1.0, Q * A0))
         self._gemm(dU, A0, key + ".Wu^T", Hn * T, A0, Q, da, Q, acc=1)
         self._gemm(dV, A0, key + ".Wv^T", R, A0, Q, dq, Q, acc=1)
         self._dw(keys, Dk, da, Q, Hn * T, Dk, Q, Gd[scope + "attention_mat"], Q)
@@ -900,6 +923,7 @@ class CLSRNet(object):
         with self._branch("@lt"):
             dul = self._att_bwd("lt", CL + "long_term/attention_fcn/", dL, out["hist_input"], out["u_long"], dhist_lt,
                                 Hn, 1, T, D, Du, seq_len, ls)
+            self._dw_flush()
         ops.rnn_multi("clsr_rnn_bwd_multi", grus, t4d, seq_len, ls, Hn, T)
         # input-side weights of every encoder in one reduction; d(hist) in one product
         self._dw(hist, D, dPinAll, NX, M, D, NX, self._buf("xw.dW", D, NX), NX, db=self._buf("xw.db", NX))
@@ -923,6 +947,7 @@ class CLSRNet(object):
             self._gru_bwd_hidden("g1", st + "short_term_intention/gru_cell/", Du, dPinAll, Hn, T)
         if (not hp.manual_alpha) and hp.predict_long_short:
             self._gru_bwd_hidden("g2", CL + "causal2/causal2/gru_cell/", H, dPinAll, Hn, T)
+        self._dw_flush()          # one batched reduction of every weight gradient of the main stream
         self._unpack_grads()
         # ---- join the long-term attention branch; its d(hist) contribution was accumulated separately
         self._join()

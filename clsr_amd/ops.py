@@ -145,6 +145,27 @@ def pack_table(descs, device):
     return t, len(descs), max(d.O * d.I for d in descs)
 
 
+class DwDesc(ctypes.Structure):
+    """ctypes mirror of clsr_dw_desc (include/clsr_hip.h)."""
+    _fields_ = [("partial", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("db", ctypes.c_void_p),
+                ("scale", ctypes.c_float)] + \
+               [(n, ctypes.c_int) for n in ("nparts", "K", "N", "ldw", "accumulate")]
+
+
+def dw_table(sig, device):
+    """Upload dW-reduction descriptors (tuples partial, dW, db, scale, nparts, K, N, ldw, accumulate) to the
+    device; returns (tensor, n, max_outputs)."""
+    import torch as _t
+
+    assert ctypes.sizeof(DwDesc) == query("clsr_sizeof_dw_desc")
+    arr = (DwDesc * len(sig))()
+    for d, (partial, dW, db, scale, nparts, K, N, ldw, acc) in zip(arr, sig):
+        d.partial, d.dW, d.db, d.scale = partial, dW, db or None, scale
+        d.nparts, d.K, d.N, d.ldw, d.accumulate = nparts, K, N, ldw, acc
+    t = _t.frombuffer(bytearray(bytes(memoryview(arr))), dtype=_t.uint8).to(device)
+    return t, len(sig), max(s[5] * s[6] + (s[6] if s[2] else 0) for s in sig)
+
+
 def kp_for(K):
     """Row stride of a packed transposed weight for an input width K (see clsr_pack_weight)."""
     return 16 * ((K + 15) // 16) + 4

@@ -99,6 +99,19 @@ int clsr_pgemm_dw(const float* X, int ldx, int T, int G, const float* Xmul, int 
                   const float* in_scale, const float* in_shift, int in_relu, const float* dY, int ldy,
                   int M, int K, int N, float scale, float* dW, int ldw, float* db, int accumulate,
                   float* workspace, void* stream);
+/* deferred form: partial chunks only (own workspace per call), then ONE batched reduction of every weight
+ * gradient of the backward pass.  Descriptor table in DEVICE memory. */
+typedef struct clsr_dw_desc {
+  const float* partial; float* dW; float* db;
+  float scale;
+  int nparts; int K; int N; int ldw; int accumulate;
+} clsr_dw_desc;
+int clsr_sizeof_dw_desc(void);
+int clsr_pgemm_dw_parts(int M);
+int clsr_pgemm_dw_partial(const float* X, int ldx, int T, int G, const float* Xmul, int ldmul,
+                          const float* in_scale, const float* in_shift, int in_relu, const float* dY, int ldy,
+                          int M, int K, int N, float* workspace, void* stream);
+int clsr_dw_reduce_batch(const clsr_dw_desc* descs_device, int n, int max_outputs, void* stream);
 int clsr_reduce_parts(const float* partial, int nparts, int stride, int n, float scale, float* out,
                       int accumulate, void* stream);
 
