@@ -1,0 +1,239 @@
+// Multi-launch forms of the small kernels of the CLSR step (gfx950): several independent jobs per launch,
+// blockIdx.y = job, descriptors passed to the kernel BY VALUE (read from host memory at call time).
+// Same arithmetic as the single-job kernels in embedding.hip / attention.hip / optim.hip.
+#include "common.h"
+#include "clsr_hip.h"
+
+template <typename D>
+struct MultiArgs {
+  D d[CLSR_MULTI_MAX];
+};
+
+extern "C" int clsr_sizeof_multi_descs(int* mark, int* gather, int* rp, int* table) {
+  if (mark) *mark = (int)sizeof(clsr_mark_desc);
+  if (gather) *gather = (int)sizeof(clsr_gather_desc);
+  if (rp) *rp = (int)sizeof(clsr_rp_desc);
+  if (table) *table = (int)sizeof(clsr_table_desc);
+  return CLSR_OK;
+}
+
+// ---- involved-row flags (embedding.hip: mark_rows_kernel)
+__global__ void __launch_bounds__(256) mark_rows_multi_kernel(MultiArgs<clsr_mark_desc> a) {
+  const clsr_mark_desc d = a.d[blockIdx.y];
+  const long n = d.nrows * d.ncols;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const long r = e / d.ncols;
+    const int c = (int)(e - r * d.ncols);
+    d.flags[d.idx[r * d.row_stride + c]] = 1;
+  }
+}
+
+extern "C" int clsr_mark_rows_multi(const clsr_mark_desc* descs, int n, void* stream) {
+  CLSR_CHECK_ARG(descs && n > 0 && n <= CLSR_MULTI_MAX);
+  MultiArgs<clsr_mark_desc> a;
+  long mx = 1;
+  for (int i = 0; i < n; ++i) {
+    CLSR_CHECK_ARG(descs[i].idx && descs[i].flags && descs[i].nrows >= 0 && descs[i].ncols > 0);
+    a.d[i] = descs[i];
+    const long e = descs[i].nrows * descs[i].ncols;
+    mx = e > mx ? e : mx;
+  }
+  int blocks = clsr_cdiv(mx, 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(mark_rows_multi_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, a);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// ---- row gathers (embedding.hip: gather_rows_kernel)
+__global__ void __launch_bounds__(256) gather_rows_multi_kernel(MultiArgs<clsr_gather_desc> a) {
+  const clsr_gather_desc d = a.d[blockIdx.y];
+  const int QC = d.C >> 2;
+  const long total = (long)d.N * QC;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(e / QC), q = (int)(e - (long)n * QC);
+    const f32x4 v = ld4(d.table + (long)d.idx[(long)n * d.idx_stride] * d.C + 4 * q);
+    st4(d.out + (long)n * d.ldo + d.col0 + 4 * q, v);
+  }
+}
+
+extern "C" int clsr_gather_rows_multi(const clsr_gather_desc* descs, int n, void* stream) {
+  CLSR_CHECK_ARG(descs && n > 0 && n <= CLSR_MULTI_MAX);
+  MultiArgs<clsr_gather_desc> a;
+  long mx = 1;
+  for (int i = 0; i < n; ++i) {
+    const clsr_gather_desc& d = descs[i];
+    CLSR_CHECK_ARG(d.table && d.idx && d.out && d.N >= 0);
+    CLSR_CHECK_SUPPORTED(d.C % 4 == 0 && d.C > 0 && d.ldo % 4 == 0 && d.col0 % 4 == 0);
+    a.d[i] = d;
+    const long e = (long)d.N * (d.C / 4);
+    mx = e > mx ? e : mx;
+  }
+  int blocks = clsr_cdiv(mx, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gather_rows_multi_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, a);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// ---- out[e] (=|+=) scale * sum_p partial[p*stride + e]  (attention.hip: reduce_parts_f_kernel)
+__global__ void __launch_bounds__(256) reduce_parts_multi_kernel(MultiArgs<clsr_rp_desc> a) {
+  __shared__ float red[4];
+  const clsr_rp_desc d = a.d[blockIdx.y];
+  const int e = blockIdx.x;
+  if (e >= d.n) return;  // block-uniform
+  float s = 0.f;
+  for (int p = threadIdx.x; p < d.nparts; p += 256) s += d.partial[(long)p * d.stride + e];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s = ((red[0] + red[1]) + (red[2] + red[3])) * d.scale;
+    d.out[e] = d.accumulate ? d.out[e] + s : s;
+  }
+}
+
+extern "C" int clsr_reduce_parts_multi(const clsr_rp_desc* descs, int n, void* stream) {
+  CLSR_CHECK_ARG(descs && n > 0 && n <= CLSR_MULTI_MAX);
+  MultiArgs<clsr_rp_desc> a;
+  int mx = 1;
+  for (int i = 0; i < n; ++i) {
+    const clsr_rp_desc& d = descs[i];
+    CLSR_CHECK_ARG(d.partial && d.out && d.nparts > 0 && d.n > 0 && d.stride >= d.n);
+    a.d[i] = d;
+    mx = d.n > mx ? d.n : mx;
+  }
+  hipLaunchKernelGGL(reduce_parts_multi_kernel, dim3(mx, n), dim3(256), 0, (hipStream_t)stream, a);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// ---- regulariser pass over the involved rows of several tables (optim.hip: table_reg_kernel)
+struct TablesArgs {
+  clsr_table_desc t[4];
+  float l2;
+  const float* ucount;
+  double* reg_loss;
+  float clip_norm;
+  const double* adam_state;
+  float b1, b2, eps;
+  int lazy;
+};
+
+__global__ void __launch_bounds__(256) tables_reg_multi_kernel(TablesArgs a) {
+  const clsr_table_desc d = a.t[blockIdx.y];
+  const int C = d.C;
+  const float cd = d.partner ? d.disc_scale / (a.ucount[0] * (float)C) : 0.f;
+  const float cl = (d.partner && d.disc_loss) ? d.disc_loss_scale / (a.ucount[0] * (float)C) : 0.f;
+  double ss = 0.0, rl = 0.0, dl = 0.0;
+  const long total = d.V * C;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long row = e / C;
+    if (!d.flags[row]) continue;
+    const float p = d.table[e];
+    float g = a.l2 * p;
+    if (d.partner) {
+      const float df = p - d.partner[e];
+      g += cd * df;
+      dl += (double)df * df;
+    }
+    d.grad[e] += g;
+    ss += (double)g * g;
+    rl += (double)p * p;
+  }
+  __shared__ double red[3][4];
+  ss = block256_sum_d(ss, red[0]); rl = block256_sum_d(rl, red[1]); dl = block256_sum_d(dl, red[2]);
+  if (threadIdx.x == 0) {
+    if (ss != 0.0) atomicAdd(d.sumsq_reg, ss);
+    if (a.reg_loss && rl != 0.0) atomicAdd(a.reg_loss, 0.5 * (double)a.l2 * rl);
+    if (d.disc_loss && dl != 0.0) atomicAdd(d.disc_loss, (double)cl * dl);
+  }
+}
+
+static int fill_tables(TablesArgs& a, const clsr_table_desc* descs, int n, long* max_elems) {
+  CLSR_CHECK_ARG(descs && n > 0 && n <= 4);
+  long mx = 1;
+  for (int i = 0; i < n; ++i) {
+    const clsr_table_desc& d = descs[i];
+    CLSR_CHECK_ARG(d.table && d.grad && d.flags && d.V > 0 && d.C > 0);
+    a.t[i] = d;
+    mx = d.V * d.C > mx ? d.V * d.C : mx;
+  }
+  *max_elems = mx;
+  return CLSR_OK;
+}
+
+extern "C" int clsr_tables_reg_multi(const clsr_table_desc* descs, int n, float l2, const float* ucount,
+                                     double* reg_loss, void* stream) {
+  TablesArgs a = {};
+  long mx = 0;
+  int rc = fill_tables(a, descs, n, &mx);
+  if (rc) return rc;
+  for (int i = 0; i < n; ++i) CLSR_CHECK_ARG(descs[i].sumsq_reg && (!descs[i].partner || ucount));
+  a.l2 = l2; a.ucount = ucount; a.reg_loss = reg_loss;
+  int blocks = clsr_cdiv(mx, 256 * 8);
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(tables_reg_multi_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, a);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// ---- Adam sweep of several tables (optim.hip: table_adam_kernel); the flags are cleared by the same launch
+//      chain (second kernel: every element of the sweep has read its flag by then)
+__device__ __forceinline__ float clipf(double sumsq, float clip_norm) {
+  if (clip_norm <= 0.f) return 1.0f;
+  const float nrm = (float)sqrt(sumsq);
+  return clip_norm / fmaxf(nrm, clip_norm);
+}
+
+__global__ void __launch_bounds__(256) tables_adam_multi_kernel(TablesArgs a) {
+  const clsr_table_desc d = a.t[blockIdx.y];
+  double tot = 0.0;
+  for (int i = 0; i < d.nsum; ++i) tot += d.sumsq_adam[(long)i * d.sumsq_stride];
+  const float factor = clipf(tot, a.clip_norm);
+  const float lr_t = (float)a.adam_state[3];
+  const float b1 = a.b1, b2 = a.b2;
+  const long total = d.V * d.C;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long row = e / d.C;
+    if (a.lazy && !d.flags[row]) continue;  // every row that got gradient is also flagged as involved
+    const float g = d.grad[e] * factor;
+    const float mm = b1 * d.m[e] + (1.0f - b1) * g;
+    const float vv = b2 * d.v[e] + (1.0f - b2) * g * g;
+    d.m[e] = mm;
+    d.v[e] = vv;
+    d.table[e] -= lr_t * mm / (sqrtf(vv) + a.eps);
+    d.grad[e] = 0.f;
+  }
+}
+
+__global__ void __launch_bounds__(256) tables_clear_flags_kernel(TablesArgs a) {
+  const clsr_table_desc d = a.t[blockIdx.y];
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < d.V; e += (long)gridDim.x * blockDim.x) d.flags[e] = 0;
+}
+
+extern "C" int clsr_tables_adam_multi(const clsr_table_desc* descs, int n, float clip_norm,
+                                      const double* adam_state, float beta1, float beta2, float eps, int lazy,
+                                      void* stream) {
+  TablesArgs a = {};
+  long mx = 0;
+  int rc = fill_tables(a, descs, n, &mx);
+  if (rc) return rc;
+  CLSR_CHECK_ARG(adam_state);
+  long mxv = 1;
+  for (int i = 0; i < n; ++i) {
+    CLSR_CHECK_ARG(descs[i].m && descs[i].v && descs[i].sumsq_adam && descs[i].nsum > 0);
+    mxv = descs[i].V > mxv ? descs[i].V : mxv;
+  }
+  a.clip_norm = clip_norm; a.adam_state = adam_state; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.lazy = lazy;
+  int blocks = clsr_cdiv(mx, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(tables_adam_multi_kernel, dim3(blocks, n), dim3(256), 0, s, a);
+  CLSR_CHECK_LAUNCH();
+  int cb = clsr_cdiv(mxv, 256);
+  if (cb > 512) cb = 512;
+  hipLaunchKernelGGL(tables_clear_flags_kernel, dim3(cb, n), dim3(256), 0, s, a);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}

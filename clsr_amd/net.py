@@ -77,7 +77,7 @@ class CLSRNet(object):
         self._ws_tag = ""          # suffix of shared scratch buffers while a side-stream branch is recording
         self._side = None
         self._joins = []
-        self._dw_pending, self._dw_tables, self._dw_after = {}, {}, {}
+        self._dw_pending, self._dw_tables, self._dw_after, self._rp_pending = {}, {}, {}, {}
         self.defer_dw = True       # one batched reduction of the weight-gradient partials per stream and step
         self.overlap = True        # run the long-term attention chain on a side stream (fork / join)
         self.sorted_hist_grad = True   # history-row gradients by sort + segmented sums (False: float atomics)
@@ -333,6 +333,12 @@ class CLSRNet(object):
         if not self.defer_dw:
             self._dw_flush()
 
+    def _rp(self, partial, parts, stride, n, out):
+        """out[0:n] = sum over ``parts`` per-block partial rows (deferred to ``_dw_flush`` like the dW reductions;
+        the partial buffer must stay untouched until then)."""
+        self._rp_pending.setdefault(self._ws_tag, []).append(
+            (partial.data_ptr(), out.data_ptr(), 1.0, parts, stride, n, 0, 0))
+
     def _dw_flush(self):
         """Reduce the partial chunks of every ``_dw`` issued on the current stream since the last flush, then
         run the operations that were waiting for those gradients."""
@@ -344,6 +350,9 @@ class CLSRNet(object):
             if tab is None:   # descriptor table: built and uploaded once per shape signature
                 tab = self._dw_tables[sig] = ops.dw_table(sig, self.device)
             call("clsr_dw_reduce_batch", tab[0], tab[1], tab[2])
+        rp = self._rp_pending.pop(tag, [])
+        if rp:
+            ops.multi("clsr_reduce_parts_multi", ops.RpDesc, rp)
         for fn in self._dw_after.pop(tag, []):
             fn()
 
@@ -629,17 +638,17 @@ class CLSRNet(object):
         # score / softmax backward per history group: d score, dkeys, d b_out
         ds = self._buf(key + ".ds", R * T)
         parts = query("clsr_att_score_bwd_parts", Hn)
-        bp = self._buf("att.bp" + self._ws_tag, 4096)[:parts]
+        bp = self._buf("att.bp." + key, 4096)[:parts]                 # own buffers per attention: reduced at the flush
         call("clsr_att_score_bwd", dout, wts, seq_len, len_stride, keys, Hn, G, T, Dk, ds, dkeys, bp)
-        call("clsr_reduce_parts", bp, parts, 1, 1, 1.0, Gd[nn + "b_nn_output"], 0)
+        self._rp(bp, parts, 1, 1, Gd[nn + "b_nn_output"])
         # dy1 = ds * w_out * relu'(bn1(z1)) is never materialised: one streaming pass for the BN-1 backward sums
         # and d w_out, the coefficient kernel, one streaming pass that writes dz1
         parts = query("clsr_att_dy1_parts", R * T, A1)
         bnp = self._buf("att.bnp" + self._ws_tag, 2048 * 2 * 256, dtype=torch.float64)[: parts * 2 * A1]
-        wp = self._buf("att.wp" + self._ws_tag, 2048 * 256)[: parts * A1]
+        wp = self._buf("att.wp." + key, 2048 * 256)[: parts * A1]
         call("clsr_att_dy1_stats", z1, ds, bn1.scale, bn1.shift, bn1.mean, bn1.invstd, P[nn + "w_nn_output"],
              R * T, A1, bnp, wp)
-        call("clsr_reduce_parts", wp, parts, A1, A1, 1.0, Gd[nn + "w_nn_output"], 0)
+        self._rp(wp, parts, A1, A1, Gd[nn + "w_nn_output"])
         self._bn_bwd_coef(bn1, bnp, parts, R * T)
         call("clsr_att_dy1_apply", z1, ds, bn1.scale, bn1.shift, P[nn + "w_nn_output"], bn1.coef, R * T, A1, dz1)
         # layer 1: z1 = relu(bn0(z0)) . W1 + b1
@@ -696,11 +705,11 @@ class CLSRNet(object):
         dz1, dz0 = self._buf(key + ".dz1", B, C1), self._buf(key + ".dz0", B, C0)
         parts = query("clsr_mlp_out_bwd_parts", B, C1)
         bnp = self._buf("mlp.bnp", 512 * 2 * 256, dtype=torch.float64)[: parts * 2 * C1]
-        wp = self._buf("mlp.wp", 512 * (256 + 4))[: parts * (C1 + 4)]
+        wp = self._buf("mlp.wp." + key, 512 * (256 + 4))[: parts * (C1 + 4)]   # own buffer: reduced at the flush
         call("clsr_mlp_out_bwd", dlogit, z1, bn1.scale, bn1.shift, bn1.mean, bn1.invstd, P[nn + "w_nn_output"],
              B, C1, dz1, bnp, wp)
-        call("clsr_reduce_parts", wp, parts, C1 + 4, C1, 1.0, Gd[nn + "w_nn_output"], 0)
-        call("clsr_reduce_parts", wp[C1:], parts, C1 + 4, 1, 1.0, Gd[nn + "b_nn_output"], 0)
+        self._rp(wp, parts, C1 + 4, C1, Gd[nn + "w_nn_output"])
+        self._rp(wp[C1:], parts, C1 + 4, 1, Gd[nn + "b_nn_output"])
         self._bn_bwd_from_partial(bn1, bnp, parts, dz1, z1, B)
         self._dw(z0, C0, dz1, C1, B, C0, C1, Gd[nn + "w_nn_layer1"], C1, db=Gd[nn + "b_nn_layer1"], aff=bn0)
         self._gemm_bnbwd(dz1, C1, key + ".W1^T", B, C1, C0, dz0, bn0, z0)
@@ -760,11 +769,13 @@ class CLSRNet(object):
         call("clsr_gather_hist_fwd", self.tables["item"], self.tables["cate"], f["item_history"],
              f["item_cate_history"], hs * T, seq_len, ls, Hn, T, Di, Dc, hp.contrastive_recent_k, hist, hmean, hrec)
         target = self._buf("target", B, D)
-        call("clsr_gather_rows", self.tables["item"], f["items"], 1, B, Di, target, D, 0)
-        call("clsr_gather_rows", self.tables["cate"], f["cates"], 1, B, Dc, target, D, Di)
         ulong, ushort = self._buf("u_long", Hn, Du), self._buf("u_short", Hn, Du)
-        call("clsr_gather_rows", self.tables["user_long"], f["users"], hs, Hn, Du, ulong, Du, 0)
-        call("clsr_gather_rows", self.tables["user_short"], f["users"], hs, Hn, Du, ushort, Du, 0)
+        tb = self.tables
+        ops.multi("clsr_gather_rows_multi", ops.GatherDesc, [     # target = [item | cate], user_long, user_short
+            (tb["item"].data_ptr(), f["items"].data_ptr(), target.data_ptr(), 1, B, Di, D, 0),
+            (tb["cate"].data_ptr(), f["cates"].data_ptr(), target.data_ptr(), 1, B, Dc, D, Di),
+            (tb["user_long"].data_ptr(), f["users"].data_ptr(), ulong.data_ptr(), hs, Hn, Du, Du, 0),
+            (tb["user_short"].data_ptr(), f["users"].data_ptr(), ushort.data_ptr(), hs, Hn, Du, Du, 0)])
         # ---- sequence encoders: ONE fused input projection, then ONE fused launch for all recurrences
         st = CL + "short_term/"
         M = Hn * T
@@ -862,12 +873,14 @@ class CLSRNet(object):
         dL, dM, dR = take(Hn, D), take(Hn, D), take(Hn, D)
         dfs, dsi = take(Hn, H), take(Hn, Du)
         # involved-row flags (tf.unique id sets)
-        call("clsr_mark_rows", f["item_history"], Hn, T, hs * T, self.tab_flags["item"])
-        call("clsr_mark_rows", f["items"], B, 1, 1, self.tab_flags["item"])
-        call("clsr_mark_rows", f["item_cate_history"], Hn, T, hs * T, self.tab_flags["cate"])
-        call("clsr_mark_rows", f["cates"], B, 1, 1, self.tab_flags["cate"])
-        call("clsr_mark_rows", f["users"], Hn, 1, hs, self.tab_flags["user_long"])
-        call("clsr_mark_rows", f["users"], Hn, 1, hs, self.tab_flags["user_short"])
+        fl = self.tab_flags
+        ops.multi("clsr_mark_rows_multi", ops.MarkDesc, [
+            (f["item_history"].data_ptr(), fl["item"].data_ptr(), Hn, hs * T, T, 0),
+            (f["items"].data_ptr(), fl["item"].data_ptr(), B, 1, 1, 0),
+            (f["item_cate_history"].data_ptr(), fl["cate"].data_ptr(), Hn, hs * T, T, 0),
+            (f["cates"].data_ptr(), fl["cate"].data_ptr(), B, 1, 1, 0),
+            (f["users"].data_ptr(), fl["user_long"].data_ptr(), Hn, hs, 1, 0),
+            (f["users"].data_ptr(), fl["user_short"].data_ptr(), Hn, hs, 1, 0)])
         # ---- losses on the forward outputs
         dlogit = self._buf("dlogit", B)
         Gl = hp.train_num_ngs + 1
@@ -940,7 +953,7 @@ class CLSRNet(object):
             call("clsr_t4_time_inputs_bwd", dTT, TT, f["time_to_now"], f["time_from_first_action"], hs * T, Hn, T, H, tp)
             for off_, nm in ((0, "_time_input_w1"), (H, "_time_input_w2"), (2 * H, "_time_input_bias1"),
                              (3 * H, "_time_input_bias2")):
-                call("clsr_reduce_parts", tp[off_:], parts, 4 * H, H, 1.0, Gd[t + nm], 0)
+                self._rp(tp[off_:], parts, 4 * H, H, Gd[t + nm])
         else:
             self._gru_bwd_hidden("gs", st + "simple_gru/gru_cell/", H, dPinAll, Hn, T)
         if hp.interest_evolve:
@@ -1028,20 +1041,24 @@ class CLSRNet(object):
         call("clsr_count_flags", self.tab_flags["user_long"], Vu, self.ucount)
         tb, tg, fl = self.tables, self.tab_grad, self.tab_flags
         lists = {k: self._involved_list(k) for k, t in tb.items() if t.numel() > self.rowlist_min_elems}
-        for key, partner, slot, dscale, dloss_scale, dloss in (
-                ("item", None, 4, 0.0, 0.0, None), ("cate", None, 5, 0.0, 0.0, None),
-                ("user_long", "user_short", 8, -2.0 * wd, -wd, self.losses[3:]),
-                ("user_short", "user_long", 9, -2.0 * wd, 0.0, None)):
+        # (table, partner, reg-norm slot, discrepancy grad scale, discrepancy loss scale, loss slot, adam base, nsum)
+        spec = (("item", None, 4, 0.0, 0.0, None, 0, 3), ("cate", None, 5, 0.0, 0.0, None, 1, 3),
+                ("user_long", "user_short", 8, -2.0 * wd, -wd, self.losses[3:], 6, 2),
+                ("user_short", "user_long", 9, -2.0 * wd, 0.0, None, 7, 2))
+        sweep = []
+        for key, partner, slot, dscale, dloss_scale, dloss, base, nsum in spec:
             V, C = tb[key].shape
             pt = tb[partner] if partner else None
-            uc = self.ucount if partner else None
             if key in lists:
                 ids, count, cap = lists[key]
-                call("clsr_table_reg_rows", tb[key], pt, ids, count, cap, C, l2e, dscale, dloss_scale, uc, tg[key],
-                     ss[slot:], self.losses[1:], dloss)
-            else:
-                call("clsr_table_reg", tb[key], pt, fl[key], V, C, l2e, dscale, dloss_scale, uc, tg[key], ss[slot:],
-                     self.losses[1:], dloss)
+                call("clsr_table_reg_rows", tb[key], pt, ids, count, cap, C, l2e, dscale, dloss_scale,
+                     self.ucount if partner else None, tg[key], ss[slot:], self.losses[1:], dloss)
+            else:   # small tables: one launch sweeps all of them (blockIdx.y = table)
+                sweep.append((tb[key].data_ptr(), ops._ptr(pt), tg[key].data_ptr(), self.tab_m[key].data_ptr(),
+                              self.tab_v[key].data_ptr(), fl[key].data_ptr(), ss[slot:].data_ptr(), ops._ptr(dloss),
+                              ss[base:].data_ptr(), V, C, nsum, 2, dscale, dloss_scale, 0))
+        if sweep:
+            ops.multi("clsr_tables_reg_multi", ops.TableDesc, sweep, l2e, self.ucount, self.losses[1:])
         clip = float(hp.max_grad_norm) if hp.is_clip_norm else 0.0
         call("clsr_dense_reg_norm", self.dense, self.dense_grad, self.seg_off, len(self.dense_names),
              float(hp.layer_l2), self.dense_sumsq, self.losses[1:])
@@ -1052,15 +1069,22 @@ class CLSRNet(object):
         call("clsr_adam_tick", self.adam_state, float(hp.learning_rate), 0.9, 0.999)
         call("clsr_dense_adam", self.dense, self.dense_grad, self.dense_m, self.dense_v, self.seg_of,
              self.dense_sumsq, clip, self.adam_state, 0.9, 0.999, 1e-8, self.n_dense)
-        for key, V, C, base, nsum in (("item", Vi, self.Di, 0, 3), ("cate", Vc, self.Dc, 1, 3),
-                                      ("user_long", Vu, self.Du, 6, 2), ("user_short", Vu, self.Du, 7, 2)):
+        rest = []
+        for key, partner, slot, dscale, dloss_scale, dloss, base, nsum in spec:
+            V, C = tb[key].shape
             if key in lists and self.lazy:
                 ids, count, cap = lists[key]
                 call("clsr_table_adam_rows", tb[key], tg[key], self.tab_m[key], self.tab_v[key], fl[key], ids, count,
                      cap, C, ss[base:], 2, nsum, clip, self.adam_state, 0.9, 0.999, 1e-8)
-            else:
+            elif key in lists:   # huge table with the reference's dense Adam: the O(vocabulary) sweep is inherent
                 call("clsr_table_adam", tb[key], tg[key], self.tab_m[key], self.tab_v[key], fl[key], V, C, ss[base:],
                      2, nsum, clip, self.adam_state, 0.9, 0.999, 1e-8, self.lazy)
+            else:
+                rest.append(key)
+        if rest:
+            ops.multi("clsr_tables_adam_multi", ops.TableDesc, [r for r in sweep if r[0] in
+                                                                {tb[k].data_ptr() for k in rest}],
+                      clip, self.adam_state, 0.9, 0.999, 1e-8, self.lazy)
 
     def read_losses(self):
         """Synchronising read of the step's loss terms -> dict of python floats."""

@@ -166,6 +166,59 @@ def dw_table(sig, device):
     return t, len(sig), max(s[5] * s[6] + (s[6] if s[2] else 0) for s in sig)
 
 
+# ---- multi-launch descriptors (include/clsr_hip.h: clsr_mark_desc, clsr_gather_desc, clsr_rp_desc, clsr_table_desc)
+_P, _L, _I, _F = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float
+
+
+class MarkDesc(ctypes.Structure):
+    _fields_ = [("idx", _P), ("flags", _P), ("nrows", _L), ("row_stride", _L), ("ncols", _I), ("pad_", _I)]
+
+
+class GatherDesc(ctypes.Structure):
+    _fields_ = [("table", _P), ("idx", _P), ("out", _P), ("idx_stride", _L), ("N", _I), ("C", _I), ("ldo", _I),
+                ("col0", _I)]
+
+
+class RpDesc(ctypes.Structure):
+    _fields_ = [("partial", _P), ("out", _P), ("scale", _F), ("nparts", _I), ("stride", _I), ("n", _I),
+                ("accumulate", _I), ("pad_", _I)]
+
+
+class TableDesc(ctypes.Structure):
+    _fields_ = [("table", _P), ("partner", _P), ("grad", _P), ("m", _P), ("v", _P), ("flags", _P),
+                ("sumsq_reg", _P), ("disc_loss", _P), ("sumsq_adam", _P), ("V", _L), ("C", _I), ("nsum", _I),
+                ("sumsq_stride", _I), ("disc_scale", _F), ("disc_loss_scale", _F), ("pad_", _I)]
+
+
+_multi_checked = False
+
+
+def _check_multi_sizes():
+    global _multi_checked
+    if _multi_checked:
+        return
+    sz = [ctypes.c_int() for _ in range(4)]
+    _lib.load().clsr_sizeof_multi_descs(*[ctypes.byref(x) for x in sz])
+    got = [ctypes.sizeof(c) for c in (MarkDesc, GatherDesc, RpDesc, TableDesc)]
+    if got != [x.value for x in sz]:
+        raise RuntimeError("ctypes mirrors of the multi-launch descriptors are out of date: %r vs %r"
+                           % (got, [x.value for x in sz]))
+    _multi_checked = True
+
+
+def multi(name, cls, rows, *extra):
+    """Launch ``name`` (a clsr_*_multi entry point) on a list of descriptor field tuples (chunks of 16)."""
+    _check_multi_sizes()
+    lim = 4 if cls is TableDesc else 16
+    for i in range(0, len(rows), lim):
+        chunk = rows[i:i + lim]
+        arr = (cls * len(chunk))()
+        for d, row in zip(arr, chunk):
+            for (fname, _), val in zip(cls._fields_, row):
+                setattr(d, fname, val)
+        call(name, ctypes.addressof(arr), len(chunk), *extra)
+
+
 def kp_for(K):
     """Row stride of a packed transposed weight for an input width K (see clsr_pack_weight)."""
     return 16 * ((K + 15) // 16) + 4

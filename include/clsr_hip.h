@@ -257,6 +257,28 @@ int clsr_zero_floats(float* p, long n, void* stream);
    feed_dict host->device copies of session.run, base_model.py:345-357) */
 int clsr_stage_feed(void* dst, const void* src_host, long nbytes, void* stream);
 
+/* ---- multi-launch forms of the small kernels: up to CLSR_MULTI_MAX independent jobs in ONE launch
+ *      (blockIdx.y = job).  The descriptor array is read on the HOST and passed to the kernel by value, so these
+ *      calls are hipGraph-capturable like any other launch.  Every tiny dependent launch costs ~5 us of device
+ *      time on its own; the step had ~75 of them. */
+#define CLSR_MULTI_MAX 16
+typedef struct clsr_mark_desc { const int* idx; unsigned char* flags; long nrows; long row_stride; int ncols; int pad_; } clsr_mark_desc;
+typedef struct clsr_gather_desc { const float* table; const int* idx; float* out; long idx_stride; int N; int C; int ldo; int col0; } clsr_gather_desc;
+typedef struct clsr_rp_desc { const float* partial; float* out; float scale; int nparts; int stride; int n; int accumulate; int pad_; } clsr_rp_desc;
+typedef struct clsr_table_desc {
+  float* table; const float* partner; float* grad; float* m; float* v; unsigned char* flags;
+  double* sumsq_reg; double* disc_loss; const double* sumsq_adam;
+  long V; int C; int nsum; int sumsq_stride; float disc_scale; float disc_loss_scale; int pad_;
+} clsr_table_desc;
+int clsr_sizeof_multi_descs(int* mark, int* gather, int* rp, int* table);
+int clsr_mark_rows_multi(const clsr_mark_desc* descs_host, int n, void* stream);
+int clsr_gather_rows_multi(const clsr_gather_desc* descs_host, int n, void* stream);
+int clsr_reduce_parts_multi(const clsr_rp_desc* descs_host, int n, void* stream);
+int clsr_tables_reg_multi(const clsr_table_desc* descs_host, int n, float l2, const float* ucount,
+                          double* reg_loss, void* stream);
+int clsr_tables_adam_multi(const clsr_table_desc* descs_host, int n, float clip_norm, const double* adam_state,
+                           float beta1, float beta2, float eps, int lazy, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
