@@ -22,17 +22,18 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats_partial, int
                                    float* __restrict__ moving_var, float momentum, float eps,
                                    int training, float* __restrict__ scale, float* __restrict__ shift,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out) {
-  // one 64-thread block per feature; the partials are summed by the whole wave
+  // one 256-thread block per feature (on the critical path of every BN layer: ~1000 partials, 4 per thread)
+  __shared__ double red[2][4];
   const int c = blockIdx.x;
   float mean, var;
   if (training) {
     double s = 0.0, q = 0.0;
-    for (int p = threadIdx.x; p < nparts; p += 64) {
+    for (int p = threadIdx.x; p < nparts; p += 256) {
       s += stats_partial[((long)p * 2 + 0) * C + c];
       q += stats_partial[((long)p * 2 + 1) * C + c];
     }
-    s = wave_sum_d(s);
-    q = wave_sum_d(q);
+    s = block256_sum_d(s, red[0]);
+    q = block256_sum_d(q, red[1]);
     if (threadIdx.x != 0) return;
     const double m = s / count;
     double v = q / count - m * m;
@@ -61,7 +62,7 @@ extern "C" int clsr_bn_finalize(const double* stats_partial, int nparts, int C, 
                                 void* stream) {
   CLSR_CHECK_ARG(gamma && beta && moving_mean && moving_var && scale && shift && C > 0);
   CLSR_CHECK_ARG(!training || (stats_partial && nparts > 0 && count > 0));
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream,
                      stats_partial, nparts, C, count, gamma, beta, moving_mean, moving_var, momentum,
                      eps, training, scale, shift, mean_out, invstd_out);
   CLSR_CHECK_LAUNCH();
@@ -140,14 +141,15 @@ __global__ void bn_bwd_coef_kernel(const double* __restrict__ partial, int npart
                                    const float* __restrict__ invstd, float* __restrict__ coef,
                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
                                    int accumulate) {
-  const int c = blockIdx.x;  // one 64-thread block per feature
+  __shared__ double red[2][4];
+  const int c = blockIdx.x;  // one 256-thread block per feature
   double s1 = 0.0, s2 = 0.0;
-  for (int p = threadIdx.x; p < nparts; p += 64) {
+  for (int p = threadIdx.x; p < nparts; p += 256) {
     s1 += partial[((long)p * 2 + 0) * C + c];
     s2 += partial[((long)p * 2 + 1) * C + c];
   }
-  s1 = wave_sum_d(s1);
-  s2 = wave_sum_d(s2);
+  s1 = block256_sum_d(s1, red[0]);
+  s2 = block256_sum_d(s2, red[1]);
   if (threadIdx.x != 0) return;
   const float g = gamma[c], is = invstd[c], mu = mean[c];
   const float c1 = (float)(s1 / count), c2 = (float)(s2 / count);
@@ -170,7 +172,7 @@ extern "C" int clsr_bn_bwd_coef(const double* partial, int nparts, int C, double
                                 float* coef, float* dgamma, float* dbeta, int accumulate,
                                 void* stream) {
   CLSR_CHECK_ARG(partial && gamma && mean && invstd && coef && dgamma && dbeta && nparts > 0 && C > 0);
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream,
                      partial, nparts, C, count, gamma, mean, invstd, coef, dgamma, dbeta, accumulate);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
