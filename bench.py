@@ -242,18 +242,18 @@ def main():
         if world == 1 and not args.no_catalogue and not big:
             # same kernel on BASELINE configs[4]'s catalogue (100M items x 96 floats + 10k categories x 32, uniform
             # ids: no cache reuse): the table is 38 GB, so every row read is an HBM read
-            big = CONFIGS["catalogue100m"]
+            cat = CONFIGS["catalogue100m"]
             try:
-                it = torch.empty(big["Vi"], big["Di"], device="cuda").zero_()   # touch every page once
-                ct = torch.randn(big["Vc"], big["Dc"], device="cuda")
-                ii = torch.randint(1, big["Vi"], (Hn, T), device="cuda", dtype=torch.int32)
-                ci = torch.randint(1, big["Vc"], (Hn, T), device="cuda", dtype=torch.int32)
+                it = torch.empty(cat["Vi"], cat["Di"], device="cuda").zero_()   # touch every page once
+                ct = torch.randn(cat["Vc"], cat["Dc"], device="cuda")
+                ii = torch.randint(1, cat["Vi"], (Hn, T), device="cuda", dtype=torch.int32)
+                ci = torch.randint(1, cat["Vc"], (Hn, T), device="cuda", dtype=torch.int32)
                 ln = torch.full((Hn,), T, device="cuda", dtype=torch.int32)
-                Db = big["Di"] + big["Dc"]
+                Db = cat["Di"] + cat["Dc"]
                 hb = torch.empty(Hn, T, Db, device="cuda")
                 hmb, hrb = torch.empty(Hn, Db, device="cuda"), torch.empty(Hn, Db, device="cuda")
                 t_big = time_kernel(lambda: ops.call("clsr_gather_hist_fwd", it, ct, ii, ci, T, ln, 1, Hn, T,
-                                                     big["Di"], big["Dc"], 3, hb, hmb, hrb))
+                                                     cat["Di"], cat["Dc"], 3, hb, hmb, hrb))
                 bbytes = Hn * T * (Db * 8 + 8)
                 roof["hbm_resident"] = dict(
                     workload="BASELINE configs[4] catalogue: 100M items, rows 384 B + 128 B, uniform ids, "
