@@ -255,17 +255,23 @@ def main():
                 t_big = time_kernel(lambda: ops.call("clsr_gather_hist_fwd", it, ct, ii, ci, T, ln, 1, Hn, T,
                                                      cat["Di"], cat["Dc"], 3, hb, hmb, hrb))
                 bbytes = Hn * T * (Db * 8 + 8)
-                roof["hbm_resident"] = dict(
+                # the HBM claim is made on this measurement (at configs[1] the 8 MB of tables sit in the
+                # L2 / Infinity Cache); the cache-resident figure of the benchmarked config stays alongside
+                cache_resident = dict(roof)
+                roof = dict(
+                    bound="hbm", kernel="gather_hist_fwd_kernel",
                     workload="BASELINE configs[4] catalogue: 100M items, rows 384 B + 128 B, uniform ids, "
-                             "4096 histories x 50 steps", bytes_per_launch=float(bbytes),
-                    us_per_launch=round(t_big * 1e6, 2), achieved=round(bbytes / t_big / 1e9, 1), peak=8000.0,
-                    unit="GB/s", frac=round(bbytes / t_big / 8e12, 4),
+                             "4096 histories x 50 steps (38 GB table: every row read is an HBM read)",
+                    achieved=round(bbytes / t_big / 1e9, 1), peak=8000.0, unit="GB/s",
+                    frac=round(bbytes / t_big / 8e12, 4),
                     traffic=204.4e6, traffic_source="profiles/r01_gather_hist_fwd_pmc_hbm_traffic.csv "
-                                                    "(WRITE_SIZE 106.5 MB + 2 x FETCH_SIZE 97.9 MB)")
+                                                    "(WRITE_SIZE 106.5 MB + 2 x FETCH_SIZE 97.9 MB)",
+                    bytes_per_launch=float(bbytes), us_per_launch=round(t_big * 1e6, 2),
+                    cache_resident_at_benchmarked_config=cache_resident)
                 del it, ct, hb
                 torch.cuda.empty_cache()
             except RuntimeError as e:   # not enough free HBM on this device
-                roof["hbm_resident"] = {"skipped": str(e)[:120]}
+                roof["hbm_resident_skipped"] = str(e)[:120]
         Qs, A0 = cfg["Du"] + D, 80
         a_s, q_s = net._buf("st.a", Hn * T, Qs), net._buf("st.q", B, Qs)
         U, V, z0 = net._buf("st.U", Hn * T, A0), net._buf("st.V", B, A0), net._buf("st.z0", B * T, A0)
