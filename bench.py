@@ -233,8 +233,8 @@ def main():
         roof = dict(bound="hbm", kernel="gather_hist_fwd_kernel", achieved=round(gbytes / t_gather / 1e9, 1),
                     peak=8000.0, unit="GB/s", frac=round(gbytes / t_gather / 8e12, 4),
                     # PMC pass committed in profiles/r01_gather_hist_fwd_pmc_hbm_traffic.csv (same shape): WRITE_SIZE
-                    # 33.4 MB + 2 x FETCH_SIZE 12.6 MB (gfx950 wide-load correction); reads of the 8 MB tables hit cache
-                    traffic=204.4e6 if big else 59.9e6, traffic_source="profiles/r01_gather_hist_fwd_pmc_hbm_traffic.csv",
+                    # 33.3 MB + 2 x FETCH_SIZE 12.5 MB (gfx950 wide-load correction); reads of the 8 MB tables hit cache
+                    traffic=208.8e6 if big else 58.3e6, traffic_source="profiles/r01_gather_hist_fwd_pmc_hbm_traffic.csv",
                     bytes_per_launch=gbytes, us_per_launch=round(t_gather * 1e6, 2),
                     note=("tables (%.1f MB) are L2/Infinity-Cache resident at this config; the HBM claim needs the "
                           "100M-item config" % ((cfg["Vi"] * cfg["Di"] + cfg["Vc"] * cfg["Dc"]) * 4 / 1e6))
@@ -264,8 +264,8 @@ def main():
                              "4096 histories x 50 steps (38 GB table: every row read is an HBM read)",
                     achieved=round(bbytes / t_big / 1e9, 1), peak=8000.0, unit="GB/s",
                     frac=round(bbytes / t_big / 8e12, 4),
-                    traffic=204.4e6, traffic_source="profiles/r01_gather_hist_fwd_pmc_hbm_traffic.csv "
-                                                    "(WRITE_SIZE 106.5 MB + 2 x FETCH_SIZE 97.9 MB)",
+                    traffic=208.8e6, traffic_source="profiles/r01_gather_hist_fwd_pmc_hbm_traffic.csv "
+                                                    "(WRITE_SIZE 106.5 MB + 2 x FETCH_SIZE 51.1 MB)",
                     bytes_per_launch=float(bbytes), us_per_launch=round(t_big * 1e6, 2),
                     cache_resident_at_benchmarked_config=cache_resident)
                 del it, ct, hb
