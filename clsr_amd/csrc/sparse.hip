@@ -90,31 +90,42 @@ __global__ void __launch_bounds__(256) gather_bwd_sorted_kernel(
   }
   int cur = -1;
   float acc = 0.f, local = 0.f;
+  const float* dh_c = dhist + col0 + (cok ? c : 0);
+  const float* dm_c = dmean ? dmean + col0 + (cok ? c : 0) : nullptr;
+  const float* dr_c = drecent ? drecent + col0 + (cok ? c : 0) : nullptr;
 #pragma unroll
   for (int u = 0; u < EPL; ++u) {
-#pragma unroll 8
-    for (int q = 0; q < CP; ++q) {
-      const int key = __shfl(mk[u], q, CP);
-      const int pos = __shfl(mp[u], q, CP);
-      const int len = __shfl(ml[u], q, CP);
-      if (key < 0) continue;     // past the end of the array (uniform inside the group)
-      const int h = pos / T, t = pos - h * T;
-      float g = 0.f;
-      if (cok) {
-        g = dhist[(long)pos * D + col0 + c];
-        if (t < len) {
-          if (dmean) g += dmean[(long)h * D + col0 + c] / (float)len;
-          if (drecent && t >= len - recent_k)
-            g += drecent[(long)h * D + col0 + c] / (float)(len < recent_k ? len : recent_k);
-        }
+    // sub-chunks of 8 sorted entries: their (random-row) gradient reads are issued together, then the run
+    // accumulation walks them in order -- one exposed memory latency per 8 entries instead of per entry
+    constexpr int SUB = CP < 8 ? CP : 8;
+#pragma unroll
+    for (int q0 = 0; q0 < CP; q0 += SUB) {
+      int key[SUB];
+      float g[SUB];
+#pragma unroll
+      for (int k = 0; k < SUB; ++k) {
+        key[k] = __shfl(mk[u], q0 + k, CP);
+        const int pos = __shfl(mp[u], q0 + k, CP);
+        const int len = __shfl(ml[u], q0 + k, CP);
+        const int h = pos / T, t = pos - h * T;
+        float v = dh_c[(long)pos * D];
+        const bool in_len = t < len;
+        if (dm_c) v += in_len ? dm_c[(long)h * D] / (float)len : 0.f;
+        if (dr_c) v += (in_len && t >= len - recent_k) ? dr_c[(long)h * D] / (float)(len < recent_k ? len : recent_k)
+                                                       : 0.f;
+        g[k] = (cok && key[k] >= 0) ? v : 0.f;
       }
-      local += g * g;
-      if (key != cur) {
-        if (cur >= 0 && cok) atomicAdd(grad + (long)cur * ldg + gcol0 + c, acc);
-        cur = key;
-        acc = g;
-      } else {
-        acc += g;
+#pragma unroll
+      for (int k = 0; k < SUB; ++k) {
+        if (key[k] < 0) continue;     // past the end of the array (uniform inside the group)
+        local += g[k] * g[k];
+        if (key[k] != cur) {
+          if (cur >= 0 && cok) atomicAdd(grad + (long)cur * ldg + gcol0 + c, acc);
+          cur = key[k];
+          acc = g[k];
+        } else {
+          acc += g[k];
+        }
       }
     }
   }
