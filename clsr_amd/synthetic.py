@@ -113,7 +113,7 @@ def synthetic_feed(P, T, Vu, Vi, Vc, G=5, lengths="lognormal", ids="zipf", seed=
 
 
 def make_tsv_dataset(out_dir, n_users=200, n_items=1000, n_cates=20, n_train=600, n_valid=40,
-                     n_test=40, valid_ngs=4, test_ngs=9, max_hist=14, seed=SEED):
+                     n_test=40, valid_ngs=4, test_ngs=9, max_hist=14, seed=SEED, signal=False):
     """Write ``train_data / valid_data / test_data`` + vocab pickles under ``out_dir``.
 
     Train lines are positives only (negatives are sampled in-batch); valid/test hold one
@@ -121,6 +121,9 @@ def make_tsv_dataset(out_dir, n_users=200, n_items=1000, n_cates=20, n_train=600
     reference's offline negative sampling (``dataset/sequential_reviews.py:142-199``).
     A small fraction of tokens is left out of the vocabularies to exercise the
     id-0 (``default_*``) path.  Returns a dict of the file paths.
+
+    ``signal=True`` makes the task learnable (for end-to-end training tests): every user browses ONE
+    category, the positive target comes from that category and the offline negatives from other ones.
     """
     rng = np.random.default_rng(seed)
     os.makedirs(out_dir, exist_ok=True)
@@ -135,13 +138,22 @@ def make_tsv_dataset(out_dir, n_users=200, n_items=1000, n_cates=20, n_train=600
             ",".join(str(t) for t in hist_ts),
         ]) + "\n"
 
+    by_cate = [np.flatnonzero(item2cate == c) for c in range(n_cates)] if signal else None
+
     def sample_positive():
         u = int(rng.integers(0, n_users))
         n = int(rng.integers(1, max_hist + 1))
-        hist = rng.integers(0, n_items, size=n)
+        if signal:
+            pool = by_cate[u % n_cates]
+            if len(pool) < 2:
+                pool = np.arange(n_items)
+            hist = rng.choice(pool, size=n)
+            it = int(rng.choice(pool))
+        else:
+            hist = rng.integers(0, n_items, size=n)
+            it = int(rng.integers(0, n_items))
         gaps = rng.integers(1, 86400 * 3, size=n + 1)
         ts = base_ts + np.cumsum(gaps)
-        it = int(rng.integers(0, n_items))
         return u, it, int(ts[-1]), [int(h) for h in hist], [int(t) for t in ts[:-1]]
 
     paths = {k: os.path.join(out_dir, k) for k in ("train_data", "valid_data", "test_data")}
@@ -159,7 +171,7 @@ def make_tsv_dataset(out_dir, n_users=200, n_items=1000, n_cates=20, n_train=600
                 negs = set()
                 while len(negs) < ngs:
                     cand = int(rng.integers(0, n_items))
-                    if cand != it:
+                    if cand != it and not (signal and item2cate[cand] == item2cate[it]):
                         negs.add(cand)
                 for neg in sorted(negs):
                     f.write(one_line(0, u, neg, ts, h, hts))
