@@ -95,8 +95,8 @@ class CLSRNet(object):
     def _check_supported(self):
         hp = self.hp
         bad = []
-        if hp.sequential_model not in ("time4lstm", "gru"):
-            bad.append("sequential_model=%r (time4lstm | gru)" % hp.sequential_model)
+        if hp.sequential_model not in ("time4lstm", "gru", "lstm"):
+            bad.append("sequential_model=%r (time4lstm | gru | lstm)" % hp.sequential_model)
         if hp.enable_BN is not True:
             bad.append("enable_BN must be True")
         if list(hp.activation) != ["relu"] * len(hp.activation):
@@ -417,7 +417,29 @@ class CLSRNet(object):
                                   ("w2", P[t + "_time_kernel_w2"], P[t + "_time_bias2"], H)):
                 out.append(("t4", kind, W, b, off, w))
                 off += w
+        elif self.hp.sequential_model == "lstm":
+            # tf.nn.rnn_cell.LSTMCell (clsr.py:209-216) == the Time4LSTM recurrence with both time gates stuck
+            # open: constant pre-activations of +30 (sigmoid(30) == 1.0f) instead of learned time projections
+            g = CL + "short_term/simple_lstm/lstm_cell/"
+            zero_w = self._buf("lstm.const_w", D, H)
+            open_b = self._bufs.get("lstm.const_b")
+            if open_b is None:
+                open_b = self._bufs["lstm.const_b"] = torch.full((H,), 30.0, dtype=F32, device=self.device)
+            for kind, W, b, w in (("kx", P[g + "kernel"][0:D], P[g + "bias"], 4 * H),
+                                  ("const", zero_w, open_b, H), ("const", zero_w, open_b, H)):
+                out.append(("t4", kind, W, b, off, w))
+                off += w
         return out, off
+
+    @property
+    def _t4_scope(self):
+        """Variable scope of the LSTM-type short-term encoder (None for the GRU encoder)."""
+        sm = self.hp.sequential_model
+        if sm == "time4lstm":
+            return CL + "short_term/time4lstm/"
+        if sm == "lstm":
+            return CL + "short_term/simple_lstm/lstm_cell/"
+        return None
 
     def _enc_off(self, key):
         blocks, _ = self._xw_blocks()
@@ -490,10 +512,12 @@ class CLSRNet(object):
             descs = []
             gname = {"gx": ("gates/kernel", "gates/bias"), "cx": ("candidate/kernel", "candidate/bias")}
             scopes = {k: sc for k, sc, _ in self._gru_list()}
-            t = CL + "short_term/time4lstm/"
+            t = self._t4_scope
             tname = {"kx": ("kernel", "bias"), "w1": ("_time_kernel_w1", "_time_bias1"),
                      "w2": ("_time_kernel_w2", "_time_bias2")}
             for key, kind, W, b, off, w in blocks:
+                if kind == "const":
+                    continue              # the always-open time gates of the plain LSTM have no variables
                 if key == "t4":
                     gw, gb = Gd[t + tname[kind][0]], Gd[t + tname[kind][1]]
                 else:
@@ -788,14 +812,15 @@ class CLSRNet(object):
             d, short_int, _ = self._gru_fwd_desc("g1", st + "short_term_intention/gru_cell/", Du, PinAll, Hn, T,
                                                  ushort, training)
             grus.append(d)
-        if hp.sequential_model == "time4lstm":
-            t = st + "time4lstm/"
-            TT = self._buf("t4.TT", M, 2 * H)
-            call("clsr_t4_time_inputs_fwd", f["time_to_now"], f["time_from_first_action"], hs * T,
-                 P[t + "_time_input_w1"], P[t + "_time_input_bias1"], P[t + "_time_input_w2"],
-                 P[t + "_time_input_bias2"], Hn, T, H, TT)
+        if self._t4_scope is not None:
+            t = self._t4_scope
             t4off = self._enc_off("t4")
-            self._gemm(TT, 2 * H, "t4.tw", M, 2 * H, 3 * H, PinAll[:, t4off + 3 * H:], NX, acc=1)
+            if hp.sequential_model == "time4lstm":
+                TT = self._buf("t4.TT", M, 2 * H)
+                call("clsr_t4_time_inputs_fwd", f["time_to_now"], f["time_from_first_action"], hs * T,
+                     P[t + "_time_input_w1"], P[t + "_time_input_bias1"], P[t + "_time_input_w2"],
+                     P[t + "_time_input_bias2"], Hn, T, H, TT)
+                self._gemm(TT, 2 * H, "t4.tw", M, 2 * H, 3 * H, PinAll[:, t4off + 3 * H:], NX, acc=1)
             rnn_out = self._buf("rnn_out", Hn, T, H)
             t4d = ops.t4_desc(H, Pin=PinAll[:, t4off:], ldp=NX, Wm=P[t + "kernel"][D:], ldm=4 * H, out_seq=rnn_out,
                               act=self._buf("t4.act", Hn, T, 6 * H) if training else None,
@@ -922,8 +947,8 @@ class CLSRNet(object):
             dushort = self._buf("d_u_short", Hn, Du)
             grus.append(self._gru_bwd_desc("g1", st + "short_term_intention/gru_cell/", Du, dPinAll, Hn, T, dsi, None,
                                            dushort))
-        if hp.sequential_model == "time4lstm":
-            t = st + "time4lstm/"
+        if self._t4_scope is not None:
+            t = self._t4_scope
             t4off = self._enc_off("t4")
             t4d = ops.t4_desc(H, Wm=P[t + "kernel"][D:], ldm=4 * H, act=self._buf("t4.act", Hn, T, 6 * H),
                               cst=self._buf("t4.cst", Hn, T, H), dout_seq=drnn, dPin=dPinAll[:, t4off:], lddp=NX)
@@ -941,7 +966,10 @@ class CLSRNet(object):
         # input-side weights of every encoder in one reduction; d(hist) in one product
         self._dw(hist, D, dPinAll, NX, M, D, NX, self._buf("xw.dW", D, NX), NX, db=self._buf("xw.db", NX))
         self._gemm(dPinAll, NX, "xw^T", M, NX, D, dhist, D, acc=1)
-        if hp.sequential_model == "time4lstm":
+        if hp.sequential_model == "lstm":
+            self._dw(self._buf("t4.mprev", Hn, T, H), H, dPinAll[:, t4off:], NX, M, H, 4 * H, Gd[t + "kernel"][D:],
+                     4 * H)
+        elif hp.sequential_model == "time4lstm":
             TT = self._buf("t4.TT", M, 2 * H)
             dPt = dPinAll[:, t4off:]
             self._dw(self._buf("t4.mprev", Hn, T, H), H, dPt, NX, M, H, 4 * H, Gd[t + "kernel"][D:], 4 * H)

@@ -62,6 +62,7 @@ CONFIGS = [
     dict(sequential_model="gru", contrastive_loss="bpr"),
     dict(interest_evolve=False, predict_long_short=False),
     dict(manual_alpha=True, manual_alpha_value=0.3),
+    dict(sequential_model="lstm"),
 ]
 
 
