@@ -17,7 +17,8 @@ Tables whose touched rows are few compared with the vocabulary are exchanged SPA
 list, the listed rows are packed, (count, ids, rows) are all-gathered, and every rank adds the lists of
 all ranks in rank order into its cleared rows -- bit-identical sums on every replica, and the traffic is
 O(touched rows) instead of O(vocabulary).  ``sparse_tables="auto"`` picks per table and per batch shape
-(sparse when  rows_bound * world < vocabulary);  "all" / "none" force one path.
+(sparse when  4 * rows_bound * world < vocabulary: a dense table rides in the ONE flat all-reduce, a sparse one
+costs three collectives of its own, so it has to save real traffic);  "all" / "none" force one path.
 
 and every rank applies the identical clip + Adam update, so replicas never diverge.  Loss
 normalisers are global: the softmax data loss is scaled by 1/(P * world) and the contrastive
@@ -112,7 +113,7 @@ class DataParallel(object):
         if self.sparse_tables != "auto":
             return self.sparse_tables == "all"
         V = self.net.tables[name].shape[0]
-        return touched_rows_bound(name, self.net.last_shape, V) * self.world < V
+        return 4 * touched_rows_bound(name, self.net.last_shape, V) * self.world < V
 
     def _exchange_rows(self, name):
         """Sparse exchange of one embedding table's gradient (see the module docstring)."""
