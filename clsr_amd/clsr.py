@@ -121,8 +121,15 @@ class BaseModel(object):
 
 class SequentialBaseModel(BaseModel):
     def __init__(self, hparams, iterator_creator, graph=None, seed=None, device="cuda:0", use_graph=False,
-                 dedup_histories=True):
-        """Reference ``SequentialBaseModel.__init__`` (:19-48): requires ``train_num_ngs``."""
+                 dedup_histories=True, dist=None, sync_bn=False):
+        """Reference ``SequentialBaseModel.__init__`` (:19-48): requires ``train_num_ngs``.
+
+        ``dist`` (an initialised ``torch.distributed`` module, one process per GPU) turns ``train`` / ``fit``
+        into single-node data parallelism: every rank iterates the SAME global batches (same files, same
+        ``random`` seed -- the in-batch negative sampling runs over the global batch like in the reference),
+        trains on its contiguous share of the positives and exchanges gradients through
+        :class:`clsr_amd.dp.DataParallel`; ``hparams.batch_size`` is the GLOBAL batch.  Evaluation is
+        replicated (every rank scores the whole file and gets the same metrics)."""
         self.hparams = hparams
         self.need_sample = hparams.need_sample
         self.train_num_ngs = hparams.train_num_ngs
@@ -131,7 +138,8 @@ class SequentialBaseModel(BaseModel):
         self.min_seq_length = hparams.min_seq_length if "min_seq_length" in hparams else 1
         self.hidden_size = hparams.hidden_size if "hidden_size" in hparams else None
         self._device = device
-        self._use_graph = use_graph
+        self._dist, self._sync_bn, self._dp = dist, sync_bn, None
+        self._use_graph = use_graph and dist is None
         self._dedup = dedup_histories
         self._graphs = {}
         self._static = {}
@@ -187,6 +195,15 @@ class SequentialBaseModel(BaseModel):
     def _train_step(self, feed):
         net = self.net
         with self._stream_ctx():
+            if self._dist is not None:
+                from clsr_amd.dp import DataParallel, shard_feed
+
+                if self._dp is None:
+                    self._dp = DataParallel(net, self._dist, sync_bn=self._sync_bn)
+                feed = shard_feed(feed, self._dp.rank, self._dp.world, self.train_num_ngs + 1)
+                key, f, _ = self._static_feed(feed, True)
+                self._dp.train_step(self._dp.prepare(f))
+                return
             key, f, _ = self._static_feed(feed, True)
             if not self._use_graph:
                 net.train_step(f)       # ~2 ms of host time for ~190 launches, hidden behind the GPU

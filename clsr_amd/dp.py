@@ -61,8 +61,29 @@ def touched_rows_bound(table, shape, vocab):
     return int(min(vocab, bound))
 
 
+_HIST_KEYS = ("users", "item_history", "item_cate_history", "mask", "time_from_first_action", "time_to_now")
+
+
 def shard_feed(feed, rank, world, group_size):
-    """Contiguous block of whole groups for ``rank`` out of a global training feed (numpy arrays)."""
+    """Contiguous block of whole groups for ``rank`` out of a global training feed (numpy arrays): the row
+    layout of the reference iterator, or the compact layout (``hist_group``: history-level arrays hold one row
+    per positive).  A global batch whose number of positives is not a multiple of ``world`` is truncated (the
+    last partial batch of an epoch)."""
+    hg = int(feed.get("hist_group", 0) or 0)
+    if hg:
+        if hg != group_size:
+            raise ValueError("compact feed of group %d sharded with group size %d" % (hg, group_size))
+        n = feed["mask"].shape[0]
+        per = n // world
+        if per == 0:
+            raise ValueError("global batch of %d positives cannot feed %d ranks" % (n, world))
+        out = {"hist_group": hg}
+        for k, v in feed.items():
+            if k == "hist_group":
+                continue
+            step = 1 if k in _HIST_KEYS else hg
+            out[k] = v[rank * per * step:(rank + 1) * per * step]
+        return out
     B = feed["labels"].shape[0]
     if B % (group_size * world):
         raise ValueError("global batch rows (%d) must be a multiple of group_size*world (%d)"

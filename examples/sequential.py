@@ -63,7 +63,7 @@ def get_flags():
     return p.parse_args()
 
 
-def get_model(flags_obj, model_path, summary_path, user_vocab, item_vocab, cate_vocab, train_num_ngs):
+def get_model(flags_obj, model_path, summary_path, user_vocab, item_vocab, cate_vocab, train_num_ngs, dist=None):
     if flags_obj.dataset == "kuaishou":
         pairwise_metrics, weighted_metrics, max_seq_length, time_unit = ["mean_mrr", "ndcg@1;2"], ["wauc"], 250, "ms"
     else:
@@ -85,11 +85,34 @@ def get_model(flags_obj, model_path, summary_path, user_vocab, item_vocab, cate_
         item_vocab=item_vocab, cate_vocab=cate_vocab, need_sample=True, train_num_ngs=train_num_ngs,
         max_seq_length=max_seq_length, pairwise_metrics=pairwise_metrics, weighted_metrics=weighted_metrics,
         sequential_model=flags_obj.sequential_model, time_unit=time_unit)
-    return CLSRModel(hparams, SASequentialIterator, seed=None, device="cuda:%d" % flags_obj.gpu_id)
+    if dist is not None and dist.get_rank() != 0:
+        hparams.save_model = False      # replicas are identical: rank 0 writes the checkpoints
+    return CLSRModel(hparams, SASequentialIterator, seed=None, device="cuda:%d" % flags_obj.gpu_id, dist=dist)
+
+
+def init_data_parallel(flags_obj):
+    """One process per GPU (``python -m torch.distributed.run --nproc-per-node N examples/sequential.py ...``):
+    RCCL process group, this rank's GPU, and the SAME ``random`` stream on every rank (all ranks iterate the same
+    global batches of ``--batch_size`` positives and train on their share, see CLSRModel(dist=...))."""
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return None
+    import random
+
+    import torch
+    import torch.distributed as dist
+
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    flags_obj.gpu_id = local
+    random.seed(20220425)
+    return dist
 
 
 def main():
     flags_obj = get_flags()
+    dist = init_data_parallel(flags_obj)
     print("System version: {}".format(sys.version))
     print("start experiment")
     data_path = os.path.join(flags_obj.data_path, flags_obj.dataset)
@@ -108,7 +131,8 @@ def main():
                          "SURVEY.md section 8f) or pass --synthetic" % train_file)
     save_path = os.path.join(flags_obj.save_path, flags_obj.model, flags_obj.name)
     model_path, summary_path = os.path.join(save_path, "model/"), os.path.join(save_path, "summary/")
-    model = get_model(flags_obj, model_path, summary_path, user_vocab, item_vocab, cate_vocab, flags_obj.train_num_ngs)
+    model = get_model(flags_obj, model_path, summary_path, user_vocab, item_vocab, cate_vocab, flags_obj.train_num_ngs,
+                      dist=dist)
     if flags_obj.only_test:
         model.load_model(latest_checkpoint(model_path))
         print(model.run_weighted_eval(test_file, num_ngs=flags_obj.test_num_ngs))

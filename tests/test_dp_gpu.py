@@ -117,3 +117,69 @@ def test_two_ranks_match_single_process(golden_dir, golden_hparams, sparse):
     for k, v in ref_state.items():
         if k.endswith("moving_mean") or k.endswith("moving_variance"):
             np.testing.assert_allclose(out["state"][k], v.numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+def _model_worker(rank, world, port, hp, paths, sd, out):
+    import random
+
+    import torch.distributed as dist
+
+    from clsr_amd.clsr import CLSRModel
+    from clsr_amd.sequential_iterator import SASequentialIterator
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = CLSRModel(hp, SASequentialIterator, seed=rank, dist=_HostStagedDist(dist), sync_bn=True)
+    if rank == 0:
+        model.net.load_state_dict(sd)
+    random.seed(11)                      # same global batches (shuffle + negative sampling) on every rank
+    losses = []
+    for feed in model.iterator.load_data_from_file(paths, batch_num_ngs=hp.train_num_ngs):
+        if feed:
+            losses.append(model.train(model.sess, feed)[2])
+        if len(losses) == 4:
+            break
+    torch.cuda.synchronize()
+    out[rank] = dict(losses=losses, item=model.net.tables["item"].cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_model_train_with_two_ranks_matches_single_process(golden_dir, golden_hparams):
+    """CLSRModel(dist=...): two ranks that iterate the same global batches and train on their halves follow the
+    single-process run on the global batches (sync-BN): same loss per step, same embedding table afterwards.
+    (Four steps: over a whole epoch the two runs drift apart like any two fp32 runs with Adam -- parameters whose
+    gradient is analytically zero random-walk by +-lr per step on summation noise.)"""
+    import random
+
+    import torch.multiprocessing as mp
+
+    from clsr_amd.clsr import CLSRModel
+    from clsr_amd.sequential_iterator import SASequentialIterator
+
+    hp = copy.deepcopy(golden_hparams)
+    hp.batch_size = 16                   # global batch: 8 positives per rank
+    train = os.path.join(golden_dir, "data", "train_data")
+    single = CLSRModel(hp, SASequentialIterator, seed=0)
+    sd = {k: v.clone() for k, v in single.net.state_dict().items()}
+    random.seed(11)
+    ref_losses = []
+    for feed in single.iterator.load_data_from_file(train, batch_num_ngs=hp.train_num_ngs):
+        if feed:
+            ref_losses.append(single.train(single.sess, feed)[2])
+        if len(ref_losses) == 4:
+            break
+    torch.cuda.synchronize()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    mp.spawn(_model_worker, args=(2, port, hp, train, sd, out), nprocs=2, join=True)
+    assert len(out[0]["losses"]) == len(ref_losses) == 4
+    for a, b, c in zip(out[0]["losses"], out[1]["losses"], ref_losses):
+        assert abs(a - b) < 1e-12 and abs(a - c) < 1e-4 * max(1.0, abs(c)), (a, b, c)
+    np.testing.assert_allclose(out[0]["item"], single.net.tables["item"].cpu().numpy(), rtol=1e-3, atol=2e-6)
+    np.testing.assert_array_equal(out[0]["item"], out[1]["item"])      # replicas stay bit-identical
