@@ -111,3 +111,22 @@ def test_touched_rows_bound():
     assert touched_rows_bound("user_long", shape, 36915) == 4096
     assert touched_rows_bound("item", shape, 64138) == 64138          # bound exceeds the vocabulary
     assert touched_rows_bound("item", shape, 100_000_000) == 4096 * 50 + 20480
+
+
+def test_shard_feed_compact_layout():
+    """Compact (history-level) training feeds are sharded by positives; row-level arrays follow with G rows each."""
+    n, G, T = 10, 5, 4
+    feed = {"hist_group": G, "labels": np.arange(n * G).reshape(n * G, 1), "items": np.arange(n * G),
+            "cates": np.arange(n * G), "users": np.arange(n), "mask": np.ones((n, T)),
+            "item_history": np.arange(n * T).reshape(n, T), "item_cate_history": np.zeros((n, T)),
+            "time_from_first_action": np.zeros((n, T)), "time_to_now": np.zeros((n, T))}
+    parts = [shard_feed(feed, r, 3, G) for r in range(3)]      # 10 positives over 3 ranks: 3 each, 1 dropped
+    for r, p in enumerate(parts):
+        assert p["hist_group"] == G and p["users"].tolist() == [3 * r, 3 * r + 1, 3 * r + 2]
+        assert p["items"].tolist() == list(range(15 * r, 15 * r + 15)) and p["labels"].shape == (15, 1)
+        assert p["item_history"].shape == (3, T) and p["item_history"][0, 0] == 3 * r * T
+    try:
+        shard_feed(feed, 0, 2, G + 1)
+        raise AssertionError("group mismatch accepted")
+    except ValueError:
+        pass
