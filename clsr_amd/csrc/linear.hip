@@ -346,18 +346,18 @@ __global__ void __launch_bounds__(256) pgemm_fast_kernel(PGemmArgs a) {
       finish(raw, kt, b0, b1);
       raw = issue(min(kt + 1, KT - 1));
       __builtin_amdgcn_sched_barrier(0);  // keep the loads above ahead of the MFMA block
+      // all weight tiles of this k-tile first, then 2*OT independent accumulators per k-slot
+      f32x4 wt[OT];
 #pragma unroll
-      for (int ot = 0; ot < OT; ++ot) {
-        const f32x4 w = ld4(ldsA + (long)ot * 16 * Kp + kt * 16);
-        MFMA4(acc[0][ot], w.x, b0.x);
-        MFMA4(acc[1][ot], w.x, b1.x);
-        MFMA4(acc[0][ot], w.y, b0.y);
-        MFMA4(acc[1][ot], w.y, b1.y);
-        MFMA4(acc[0][ot], w.z, b0.z);
-        MFMA4(acc[1][ot], w.z, b1.z);
-        MFMA4(acc[0][ot], w.w, b0.w);
-        MFMA4(acc[1][ot], w.w, b1.w);
-      }
+      for (int ot = 0; ot < OT; ++ot) wt[ot] = ld4(ldsA + (long)ot * 16 * Kp + kt * 16);
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) { MFMA4(acc[0][ot], wt[ot].x, b0.x); MFMA4(acc[1][ot], wt[ot].x, b1.x); }
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) { MFMA4(acc[0][ot], wt[ot].y, b0.y); MFMA4(acc[1][ot], wt[ot].y, b1.y); }
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) { MFMA4(acc[0][ot], wt[ot].z, b0.z); MFMA4(acc[1][ot], wt[ot].z, b1.z); }
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) { MFMA4(acc[0][ot], wt[ot].w, b0.w); MFMA4(acc[1][ot], wt[ot].w, b1.w); }
     }
 
 #pragma unroll
