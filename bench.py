@@ -10,14 +10,20 @@ already resident in HBM, replayed as one hipGraph.  Rank 0 prints ONE JSON line:
 metric = train interactions/sec (interaction = one positive train line).
 
 N > 1: one process per GPU (torch.distributed, backend nccl == RCCL), weak scaling (every rank
-owns its own 4096-positive batch); gradients are summed with RCCL all-reduce between the
-backward graph and the update graph (see clsr_amd/dp.py).
+owns its own 4096-positive batch); the gradient exchange (dense all-reduce or sparse touched-row
+all-gather per table, see clsr_amd/dp.py) runs between backward and update; DP steps are launched eagerly.
 
 Extra objects on the line:
   roofline      the embedding-history gather (north-star kernel; HBM bound): algorithmic bytes per
-                launch / average launch duration measured here with HIP events.
+                launch / average launch duration measured here with HIP events, on the HBM-resident
+                100M-item catalogue table (N = 1); the cache-resident figure of the benchmarked config is
+                carried inside it.
   roofline_mfma the most expensive kernel of the step (short-term attention layer-0 fp32-MFMA GEMM).
   cpu_baseline  the CPU oracle (torch, all host cores) on a bounded sample of the same workload.
+
+Other workloads: --config kuaishou (configs[2]) | catalogue100m (configs[4], lazy Adam).
+Experiment switches (environment): CLSR_FORCE_DP=1 (DP code path with one rank), CLSR_SPARSE_TABLES=auto|all|none,
+CLSR_DP_GRAPH=1, CLSR_NO_OVERLAP=1 (no side stream), CLSR_DW_EAGER=1 (no batched dW reduction).
 """
 import argparse
 import json
