@@ -30,6 +30,55 @@ _FIELDS = (
 ).split()
 
 
+_NATIVE = [False, None]
+
+
+def _native_lib():
+    """libclsr_hip.so for the host-side MT19937 replay (clsr_host_mt_*), or None: the pure-python / numpy paths
+    below produce the same streams, only slower."""
+    if _NATIVE[0] is False:
+        try:
+            from clsr_amd import _lib
+
+            lib = _lib.load()
+            _NATIVE[1] = lib if hasattr(lib, "clsr_host_mt_shuffle") else None
+        except Exception:
+            _NATIVE[1] = None
+        _NATIVE[0] = True
+    return _NATIVE[1]
+
+
+def _mt_state():
+    """(key uint32[624], pos, gauss) of the global ``random`` module, or None if it is not a version-3 state."""
+    version, state, gauss = random.getstate()
+    if version != 3:
+        return None
+    return np.array(state[:-1], dtype=np.uint32), int(state[-1]), gauss
+
+
+def _mt_restore(key, pos, gauss):
+    random.setstate((3, tuple(key.tolist()) + (int(pos),), gauss))
+
+
+def shuffle_like_random(perm):
+    """In-place ``random.shuffle`` of the int64 array ``perm`` consuming exactly the random numbers the call on a
+    list would (native replay when the library is built: 1M entries in ~10 ms instead of ~0.7 s)."""
+    import ctypes
+
+    lib, st = _native_lib(), _mt_state()
+    if lib is not None and st is not None and perm.dtype == np.int64 and perm.flags.c_contiguous:
+        key, pos, gauss = st
+        cpos = ctypes.c_int(pos)
+        rc = lib.clsr_host_mt_shuffle(key.ctypes.data, ctypes.byref(cpos), perm.ctypes.data, len(perm))
+        if rc == 0:
+            _mt_restore(key, cpos.value, gauss)
+            return perm
+    lst = perm.tolist()
+    random.shuffle(lst)
+    perm[:] = lst
+    return perm
+
+
 class LazyFeed(dict):
     """A feed dict whose big row-repeated arrays are built on first access.
 
@@ -208,10 +257,12 @@ class SequentialIterator(BaseIterator):
         # the reference shuffles the cached list of parsed lines in place on every training pass
         # (cumulative permutation); shuffling a persistent index list consumes the same random numbers
         # and yields the same order without touching the column store
-        perm = self._order.setdefault(infile, list(range(len(lines))))
+        perm = self._order.get(infile)
+        if perm is None or len(perm) != len(lines):
+            perm = self._order[infile] = np.arange(len(lines), dtype=np.int64)
         if batch_num_ngs > 0:
-            random.shuffle(perm)
-        order = np.asarray(perm, dtype=np.int64)
+            shuffle_like_random(perm)
+        order = perm.copy()
         keep = order[cols["full_len"][order] >= min_seq_length]
         for a in range(0, len(keep), self.batch_size):
             sel = keep[a:a + self.batch_size]
@@ -334,6 +385,19 @@ class SequentialIterator(BaseIterator):
         """
         n = len(item_list)
         src = np.empty((n, batch_num_ngs + 1), dtype=np.int64)
+        lib, st = _native_lib(), _mt_state()
+        if lib is not None and st is not None and 2 <= n < (1 << 31):
+            import ctypes
+
+            key, pos, gauss = st
+            cpos = ctypes.c_int(pos)
+            items64 = np.ascontiguousarray(item_list, dtype=np.int64)
+            if len(np.unique(items64[:64])) > 1 or len(np.unique(items64)) > 1:   # the reference loops forever otherwise
+                rc = lib.clsr_host_mt_sample_negatives(key.ctypes.data, ctypes.byref(cpos), items64.ctypes.data, n,
+                                                       batch_num_ngs, src.ctypes.data)
+                if rc == 0:
+                    _mt_restore(key, cpos.value, gauss)
+                    return src
         src[:, 0] = np.arange(n)
         # random.randint(0, n-1) == _randbelow(n): k = n.bit_length(); r = getrandbits(k) until r < n, and
         # getrandbits(k <= 32) is one MT19937 32-bit output >> (32 - k).  Replay that stream with numpy's

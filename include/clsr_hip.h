@@ -279,6 +279,12 @@ int clsr_tables_reg_multi(const clsr_table_desc* descs_host, int n, float l2, co
 int clsr_tables_adam_multi(const clsr_table_desc* descs_host, int n, float clip_norm, const double* adam_state,
                            float beta1, float beta2, float eps, int lazy, void* stream);
 
+/* ---- host-side (no GPU) replay of CPython's random module for the input pipeline: continue the MT19937 stream of
+ *      random.getstate() through random.shuffle / the in-batch negative sampling of io/sequential_iterator.py:249-261,
+ *      612-634, bit-identically, and hand the advanced state back (key[624], *pos). */
+int clsr_host_mt_shuffle(unsigned* key, int* pos, long* perm, long n);
+int clsr_host_mt_sample_negatives(unsigned* key, int* pos, const long* items, long n, int ngs, long* src);
+
 #ifdef __cplusplus
 }
 #endif

@@ -162,3 +162,36 @@ def test_grouped_metrics_vectorised_equals_per_group_loop():
         assert fast == loop and set(fast) == {"mean_mrr", "ndcg@2", "ndcg@4", "ndcg@6", "hit@2", "hit@4", "hit@6"}
     # metrics without a vectorised form fall back to the loop
     assert cal_metric(labels, preds, ["group_auc"]) == cal_metric(list(labels), list(preds), ["group_auc"])
+
+
+def test_native_mt_replay_equals_python_random():
+    """clsr_host_mt_shuffle / clsr_host_mt_sample_negatives continue the `random` stream exactly like
+    random.shuffle / the literal randint loop (same results, same generator state afterwards)."""
+    import random
+
+    from clsr_amd import sequential_iterator as si
+
+    if si._native_lib() is None:
+        pytest.skip("libclsr_hip.so not built")
+    for n in (1, 2, 7, 1000, 4097, 70000):
+        random.seed(n)
+        lst = list(range(n))
+        random.shuffle(lst)
+        st_py = random.getstate()
+        random.seed(n)
+        perm = si.shuffle_like_random(np.arange(n, dtype=np.int64))
+        assert perm.tolist() == lst and random.getstate() == st_py
+    it = si.SequentialIterator.__new__(si.SequentialIterator)
+    rng = np.random.default_rng(1)
+    for n, V in ((5, 2), (37, 3), (4096, 50), (4097, 3000)):
+        items = rng.integers(0, V, n).tolist()
+        if len(set(items)) < 2:
+            items[0] = V + 1
+        random.seed(n)
+        a = it._sample_negatives(items, 4)
+        sa = random.getstate()
+        random.seed(n)
+        src = np.empty((n, 5), dtype=np.int64)
+        src[:, 0] = np.arange(n)
+        b = it._sample_negatives_py(items, 4, src)
+        assert np.array_equal(a, b) and sa == random.getstate()
