@@ -160,8 +160,34 @@ def test_grouped_metrics_vectorised_equals_per_group_loop():
         loop = cal_metric(list(labels), list(preds), metrics)
         fast = cal_metric(labels, preds, metrics)
         assert fast == loop and set(fast) == {"mean_mrr", "ndcg@2", "ndcg@4", "ndcg@6", "hit@2", "hit@4", "hit@6"}
+        both = metrics + ["group_auc"]
+        assert cal_metric(labels, preds, both) == cal_metric(list(labels), list(preds), both)
     # metrics without a vectorised form fall back to the loop
-    assert cal_metric(labels, preds, ["group_auc"]) == cal_metric(list(labels), list(preds), ["group_auc"])
+    assert cal_metric(labels, preds, ["mean_mrr", "acc"]) == cal_metric(list(labels), list(preds), ["mean_mrr", "acc"])
+
+
+def test_group_and_user_auc_vectorised_equal_the_per_group_roc_auc():
+    """_grouped_auc (rows of a 2-D array) and _segmented_auc (one lexsort over (user, score)) give bit-identical
+    values to roc_auc called group by group (ties averaged), and keep sklearn's single-class ValueError."""
+    from clsr_amd import deeprec_utils as du
+
+    rng = np.random.default_rng(11)
+    for g, n in ((1, 2), (300, 5), (40, 100), (11, 7)):
+        labels = np.zeros((g, n))
+        for i in range(g):
+            labels[i, rng.choice(n, int(rng.integers(1, min(3, n))), replace=False)] = 1
+        preds = np.round(rng.random((g, n)), 1 if n > 5 else 2)
+        want = np.array([du.roc_auc(l, p) for l, p in zip(labels, preds)])
+        assert np.array_equal(du._grouped_auc(labels, preds), want)
+        users = np.repeat(rng.permutation(g) // 3, n)              # a user owns up to three (non-adjacent) groups
+        vals, weight = du._segmented_auc(users, preds.reshape(-1), labels.reshape(-1))
+        groups, weight_loop = du._group_by_user(users, preds.reshape(-1), labels.reshape(-1))
+        assert np.array_equal(vals, np.array([du.roc_auc(l, p) for p, l in groups]))
+        assert np.array_equal(weight, weight_loop)
+    with pytest.raises(ValueError):
+        du.cal_weighted_metric([1, 1, 2, 2], [.1, .2, .3, .4], [1, 0, 1, 1], ["wauc"])
+    with pytest.raises(ValueError):
+        du.cal_metric(np.array([[1., 0.], [0., 0.]]), np.array([[.3, .2], [.1, .2]]), ["group_auc"])
 
 
 def test_native_mt_replay_equals_python_random():
