@@ -193,3 +193,57 @@ def make_tsv_dataset(out_dir, n_users=200, n_items=1000, n_cates=20, n_train=600
             pkl.dump(voc, f, protocol=2)
         paths[fname.split(".")[0]] = p
     return paths
+
+
+def make_raw_taobao_csv(path, n_users=1200, n_items=90, n_cates=12, events_per_user=34, seed=SEED):
+    """A synthetic ``UserBehavior.csv`` (no header: uid,iid,category,behavior,ts) with everything the Taobao
+    preprocessing has to cope with (reference ``dataset/sequential_reviews.py:955-982``): non-``pv`` behaviours,
+    repeated (user, item) pairs, a few items listed under two categories, timestamps outside the
+    2017-11-25 .. 2017-12-03 window, and enough users that the hard-coded 5 % user sample plus the 10-core filters
+    leave a usable log.  Deterministic for a given seed; returns the number of lines written."""
+    rng = np.random.default_rng(seed)
+    item2cate = rng.integers(1000, 1000 + n_cates, size=n_items)
+    two_cates = set(rng.choice(n_items, size=max(1, n_items // 15), replace=False).tolist())
+    t0, t1 = 1511600000, 1512300000            # well inside the window in any time zone
+    lines = []
+    for u in range(n_users):
+        n = int(rng.integers(events_per_user - 8, events_per_user + 9))
+        items = rng.integers(0, n_items, size=n)
+        ts = np.sort(rng.integers(t0, t1, size=n))
+        beh = rng.choice(["pv", "pv", "pv", "pv", "buy", "cart", "fav"], size=n)
+        for j in range(n):
+            it = int(items[j])
+            cate = int(item2cate[it])
+            if it in two_cates and rng.random() < 0.3:
+                cate += 500
+            t = int(ts[j])
+            if rng.random() < 0.03:
+                t = t0 - 40 * 86400 if rng.random() < 0.5 else t1 + 40 * 86400
+            lines.append("%d,%d,%d,%s,%d\n" % (100000 + u, 5000 + it, cate, beh[j], t))
+    order = rng.permutation(len(lines))         # the real file is not grouped by user
+    with open(path, "w") as f:
+        f.writelines(lines[i] for i in order)
+    return len(lines)
+
+
+def make_raw_kuaishou_csv(path, n_users=150, n_items=120, n_clusters=9, events_per_user=45, seed=SEED):
+    """A synthetic ``kuaishou.csv`` (header row; the columns the preprocessing reads are ``user_id, photo_id,
+    time_ms, effective_view, photo_kmeans_cluster_id`` -- reference ``dataset/sequential_reviews.py:999-1041``)
+    with negative feedback rows (``effective_view = 0``), repeated pairs and a two-day span in milliseconds."""
+    rng = np.random.default_rng(seed + 1)
+    cluster = rng.integers(0, n_clusters, size=n_items)
+    t0 = 1600000000000
+    rows = []
+    for u in range(n_users):
+        n = int(rng.integers(events_per_user - 10, events_per_user + 11))
+        items = rng.integers(0, n_items, size=n)
+        ts = np.sort(rng.integers(t0, t0 + 2 * 86400 * 1000, size=n))
+        eff = (rng.random(n) < 0.7).astype(int)
+        for j in range(n):
+            rows.append((7000 + u, 300000 + int(items[j]), int(ts[j]), int(eff[j]), int(cluster[items[j]]),
+                         int(rng.integers(0, 5))))
+    order = rng.permutation(len(rows))
+    with open(path, "w") as f:
+        f.write("user_id,photo_id,time_ms,effective_view,photo_kmeans_cluster_id,tab\n")
+        f.writelines("%d,%d,%d,%d,%d,%d\n" % rows[i] for i in order)
+    return len(rows)

@@ -59,6 +59,7 @@ def get_flags():
     p.add_argument("--contrastive_loss_weight", type=float, default=0.1)
     p.add_argument("--learning_rate", type=float, default=0.001)
     p.add_argument("--show_step", type=int, default=500)
+    p.add_argument("--sample_rate", type=float, default=1.0)
     p.add_argument("--synthetic", action="store_true", help="generate a 1k-item synthetic slice first")
     return p.parse_args()
 
@@ -127,8 +128,20 @@ def main():
                                           ("user_vocab.pkl", "item_vocab.pkl", "category_vocab.pkl"))
     output_file = os.path.join(data_path, "output.txt")
     if not os.path.exists(train_file):
-        raise SystemExit("%s not found: run the reference's data_preprocessing first (out of scope here, "
-                         "SURVEY.md section 8f) or pass --synthetic" % train_file)
+        # like the reference quick-start (:318-343): build the files from the raw behaviour log
+        from clsr_amd.sequential_reviews import data_preprocessing
+
+        reviews_file = os.path.join(data_path, {"taobao": "UserBehavior.csv", "kuaishou": "kuaishou.csv"}.get(
+            flags_obj.dataset, flags_obj.dataset + ".csv"))
+        if not os.path.exists(reviews_file):
+            raise SystemExit("neither %s nor the raw log %s exists (or pass --synthetic)" % (train_file, reviews_file))
+        if dist is None or dist.get_rank() == 0:
+            data_preprocessing(reviews_file, os.path.join(data_path, ""), train_file, valid_file, test_file,
+                               user_vocab, item_vocab, cate_vocab, sample_rate=flags_obj.sample_rate,
+                               valid_num_ngs=flags_obj.val_num_ngs, test_num_ngs=flags_obj.test_num_ngs,
+                               dataset=flags_obj.dataset)
+        if dist is not None:
+            dist.barrier()
     save_path = os.path.join(flags_obj.save_path, flags_obj.model, flags_obj.name)
     model_path, summary_path = os.path.join(save_path, "model/"), os.path.join(save_path, "summary/")
     model = get_model(flags_obj, model_path, summary_path, user_vocab, item_vocab, cate_vocab, flags_obj.train_num_ngs,
