@@ -1,0 +1,8 @@
+"""clsr_amd: the CLSR training / scoring step as hand-written gfx950 HIP kernels behind the reference's Python API."""
+import os
+
+# The step runs on four HIP streams (main, long-term-attention branch, small auxiliary kernels, weight-gradient
+# partial sums; clsr_amd/net.py).  ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, shared with
+# the runtime's own streams): with the default two of the four alias and the overlap is lost (4.80 vs 4.63 ms/step,
+# DESIGN.md section 3).  Read by the HIP runtime when it initialises, i.e. at the first device call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")

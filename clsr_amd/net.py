@@ -18,6 +18,7 @@ the embedding IndexedSlices uses the norm of the G un-summed replica slices, her
 their sum is used; ``dedup_histories=False`` runs the reference's replicated computation.
 """
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -75,7 +76,11 @@ class CLSRNet(object):
         self._plans, self._plan_keep, self._cur_descs = {}, [], []
         self._sort_bytes = {}
         self._ws_tag = ""          # suffix of shared scratch buffers while a side-stream branch is recording
-        self._side = None
+        self._side = {}
+        self.rnn_first = not os.environ.get("CLSR_BRANCH_FIRST")   # A/B switch (see forward)
+        self.dw_stream = not os.environ.get("CLSR_NO_DW_STREAM")   # A/B switch (see _dw)
+        self._dw_async = False
+        self.dw_streams = int(os.environ.get("CLSR_DW_STREAMS", "1"))
         self._joins = []
         self._dw_pending, self._dw_tables, self._dw_after, self._rp_pending = {}, {}, {}, {}
         self.defer_dw = True       # one batched reduction of the weight-gradient partials per stream and step
@@ -245,22 +250,27 @@ class CLSRNet(object):
         ``net._join()`` makes the current stream wait for every finished branch.  Works eagerly and under
         hipGraph capture (the event record / wait pairs become graph dependencies)."""
 
-        def __init__(self, net, tag):
-            self.net, self.tag = net, tag
+        def __init__(self, net, tag, after=None):
+            self.net, self.tag, self.after = net, tag, after
 
         def __enter__(self):
             net = self.net
             if not net.overlap:
                 return self
-            if net._side is None:
-                net._side = torch.cuda.Stream(device=net.device)
-            main = torch.cuda.current_stream()
-            ev = torch.cuda.Event()
-            ev.record(main)
-            net._side.wait_event(ev)
+            side = net._side.get(self.tag)
+            if side is None:
+                side = net._side[self.tag] = torch.cuda.Stream(device=net.device)
+            self.side = side
+            ev = self.after
+            if ev is None:
+                ev = torch.cuda.Event()
+                ev.record(ops.current_stream())
+            side.wait_event(ev)
             self.old_tag, net._ws_tag = net._ws_tag, self.tag
-            self.ctx = torch.cuda.stream(net._side)
+            self.ctx = torch.cuda.stream(side)
             self.ctx.__enter__()
+            self.scope = ops.stream_scope(side)
+            self.scope.__enter__()
             return self
 
         def __exit__(self, *exc):
@@ -268,17 +278,28 @@ class CLSRNet(object):
             if not net.overlap:
                 return False
             ev = torch.cuda.Event()
-            ev.record(net._side)
+            ev.record(self.side)
+            self.scope.__exit__(*exc)
             self.ctx.__exit__(*exc)
             net._ws_tag = self.old_tag
             net._joins.append(ev)
             return False
 
-    def _branch(self, tag):
-        return CLSRNet._Branch(self, tag)
+    def _branch(self, tag, after=None):
+        """``after``: an event already recorded on the current stream -- the branch then depends on the work up to
+        that point only, so the caller can enqueue main-stream work FIRST and the branch second (launch order
+        is what the device sees: a branch enqueued ahead of a long main-stream kernel delays that kernel)."""
+        return CLSRNet._Branch(self, tag, after)
+
+    def _fork_point(self):
+        if not self.overlap:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(ops.current_stream())
+        return ev
 
     def _join(self):
-        main = torch.cuda.current_stream()
+        main = ops.current_stream()
         for ev in self._joins:
             main.wait_event(ev)
         self._joins = []
@@ -327,7 +348,22 @@ class CLSRNet(object):
         need = query("clsr_pgemm_dw_workspace_floats", M, K, N)
         ws = self._buf("dw_ws%s.%d" % (self._ws_tag, len(pend)), max(need, 1))
         sc, sh = (aff.scale, aff.shift) if aff is not None else (None, None)
-        call("clsr_pgemm_dw_partial", X, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, ldy, M, K, N, ws)
+        if self.dw_stream and self.overlap and self._ws_tag == "":
+            # nothing on the main chain needs a weight gradient before the flush: the partial-sum kernels of the
+            # main stream go to a stream of their own (inputs are final at this point and stay untouched until the
+            # flush joins that stream), so they run beside the back-propagating GEMMs instead of between them.
+            # ONE such stream: main + @lt + @aux + @dw0 = 4 concurrently active streams; a fifth one was measured at
+            # 7.2 ms/step with GPU_MAX_HW_QUEUES=8 (hardware-queue oversubscription) -- do not add streams
+            name = "@dw%d" % (len(pend) % self.dw_streams)
+            side = self._side.get(name)
+            if side is None:
+                side = self._side[name] = torch.cuda.Stream(device=self.device)
+            side.wait_event(self._fork_point())
+            call("clsr_pgemm_dw_partial", X, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, ldy, M, K, N, ws,
+                 stream=side.cuda_stream)
+            self._dw_async = True
+        else:
+            call("clsr_pgemm_dw_partial", X, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, ldy, M, K, N, ws)
         pend.append((ws.data_ptr(), dW.data_ptr(), db.data_ptr() if db is not None else 0, 1.0,
                      query("clsr_pgemm_dw_parts", M), K, N, ldw, acc))
         if not self.defer_dw:
@@ -344,6 +380,14 @@ class CLSRNet(object):
         run the operations that were waiting for those gradients."""
         tag = self._ws_tag
         pend = self._dw_pending.pop(tag, [])
+        if tag == "" and self._dw_async:
+            for i in range(self.dw_streams):
+                side = self._side.get("@dw%d" % i)
+                if side is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    ops.current_stream().wait_event(ev)
+            self._dw_async = False
         if pend:
             sig = tuple(pend)
             tab = self._dw_tables.get(sig)
@@ -773,8 +817,14 @@ class CLSRNet(object):
                  ldmul=3 * n)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, f, training):
-        """Run the forward pass on an uploaded feed; returns dict of device tensors."""
+    def forward(self, f, training, after_attention=None):
+        """Run the forward pass on an uploaded feed; returns dict of device tensors.  ``after_attention(out)``
+        (training) is launched on a side stream as soon as both attention outputs exist, beside the alpha / logit
+        MLPs (the contrastive loss: it needs the interest vectors, not the logits)."""
+        with ops.stream_scope():
+            return self._forward(f, training, after_attention)
+
+    def _forward(self, f, training, after_attention):
         hp, P = self.hp, self.P
         B, T = f["B"], f["T"]
         G = self.G_train if (training and self.dedup) else 1
@@ -787,6 +837,11 @@ class CLSRNet(object):
         # rows between consecutive history groups in the uploaded history-level arrays
         hs = 1 if f.get("compact") else G
         seq_len, ls = f["seq_len"], hs
+        if training and self.sorted_hist_grad:
+            # history ids sorted by row id for the backward's segmented sums: ~35 tiny launches that depend on
+            # the feed only -> their own stream from the very start, underneath the gathers and projections
+            with self._branch("@aux"):      # NOT a stream of its own: see _dw (four streams in all)
+                self._sort_hist_ids(f, Hn, T, hs)
         # ---- gathers
         hist = self._buf("hist", Hn, T, D)
         hmean, hrec = self._buf("hist_mean", Hn, D), self._buf("hist_recent", Hn, D)
@@ -834,15 +889,18 @@ class CLSRNet(object):
             d, fs, _ = self._gru_fwd_desc("g2", CL + "causal2/causal2/gru_cell/", H, PinAll, Hn, T, None, training)
             grus.append(d)
         # ---- long term attention (independent of the encoders and of the short-term attention) on the side
-        #      stream, forked HERE: the T-serial recurrences below occupy only ~3 waves per CU, so the long-term
-        #      chain (and the id sort for the backward) runs underneath them instead of beside the big GEMMs
+        #      stream, forked HERE: the T-serial recurrences occupy only ~3 waves per CU, so the long-term chain
+        #      runs underneath them instead of beside the big GEMMs.  The recurrence is ENQUEUED FIRST: packets
+        #      reach the device in launch order, and with the branch's ~10 launches ahead of it the recurrence
+        #      started ~350 us late (profiles/r01_step_timeline_graph_before_after.txt)
         lt = CL + "long_term/attention_fcn/"
-        with self._branch("@lt"):
+        fork = self._fork_point()
+        if self.rnn_first:
+            ops.rnn_multi("clsr_rnn_fwd_multi", grus, t4d, seq_len, ls, Hn, T)
+        with self._branch("@lt", after=fork):
             att_long = self._att_fwd("lt", lt, hist, ulong, Hn, 1, T, D, Du, seq_len, ls, training)
-            if training and self.sorted_hist_grad:
-                # history ids sorted by row id for the backward's segmented sums (launch-heavy radix sort)
-                self._sort_hist_ids(f, Hn, T, hs)
-        ops.rnn_multi("clsr_rnn_fwd_multi", grus, t4d, seq_len, ls, Hn, T)
+        if not self.rnn_first:
+            ops.rnn_multi("clsr_rnn_fwd_multi", grus, t4d, seq_len, ls, Hn, T)
         # ---- short term attention: query = [short_term_intention | target]
         Qs = Du + D
         q = self._buf("st.q", B, Qs)
@@ -851,6 +909,10 @@ class CLSRNet(object):
         att_short = self._att_fwd("st", st + "attention_fcn/", rnn_out, q, Hn, G, T, H, Qs, seq_len, ls, training)
         # ---- alpha gate
         self._join()
+        if after_attention is not None:
+            with self._branch("@aux"):
+                after_attention(dict(att_fea_long=att_long, att_fea_short=att_short, hist_mean=hmean,
+                                     hist_recent=hrec))
         alpha = self._buf("alpha", B)
         mo = self._buf("model_output", B, 2 * D)
         if not hp.manual_alpha:
@@ -875,17 +937,35 @@ class CLSRNet(object):
         """forward + backward (+ clip + Adam when ``apply``) on an uploaded feed.  Losses land in
         self.losses (device doubles: data, regular, contrastive, discrepancy).  Data-parallel runs call
         with apply=False, all-reduce the gradient buffers, then call :meth:`_apply_updates`."""
+        with ops.stream_scope():
+            return self._train_step(f, apply)
+
+    def _train_step(self, f, apply):
         hp, P, Gd = self.hp, self.P, self.Gd
-        out = self.forward(f, True)
-        B, T, G, Hn = self.last_shape
+        B, T = f["B"], f["T"]
+        G = self.G_train if self.dedup else 1
+        if B % G:
+            raise ValueError("training feed rows (%d) must be a multiple of 1+train_num_ngs (%d)" % (B, G))
+        Hn = B // G
         D, Du, H, Di, Dc = self.D, self.Du, self.H, self.Di, self.Dc
         hs = 1 if f.get("compact") else G
         seq_len, ls = f["seq_len"], hs
-        call("clsr_zero_doubles", self.losses, 8)
-        call("clsr_zero_doubles", self.sumsq_tab, 16)
-        # gradient accumulators (zeroed every step)
+        # gradient accumulators (zeroed every step) and the involved-row flags depend on the feed only: zeroed /
+        # marked on a side stream underneath the forward's first kernels
         zpool = self._buf("zero_pool", Hn * T * (2 * D + H) + B * D * 2 + Hn * (3 * D + H + Du))
-        call("clsr_zero_floats", zpool, zpool.numel())
+        fl = self.tab_flags
+        with self._branch("@aux"):
+            call("clsr_zero_doubles", self.losses, 8)
+            call("clsr_zero_doubles", self.sumsq_tab, 16)
+            call("clsr_zero_floats", zpool, zpool.numel())
+            # involved-row flags (tf.unique id sets)
+            ops.multi("clsr_mark_rows_multi", ops.MarkDesc, [
+                (f["item_history"].data_ptr(), fl["item"].data_ptr(), Hn, hs * T, T, 0),
+                (f["items"].data_ptr(), fl["item"].data_ptr(), B, 1, 1, 0),
+                (f["item_cate_history"].data_ptr(), fl["cate"].data_ptr(), Hn, hs * T, T, 0),
+                (f["cates"].data_ptr(), fl["cate"].data_ptr(), B, 1, 1, 0),
+                (f["users"].data_ptr(), fl["user_long"].data_ptr(), Hn, hs, 1, 0),
+                (f["users"].data_ptr(), fl["user_short"].data_ptr(), Hn, hs, 1, 0)])
         o = [0]
 
         def take(*shape):
@@ -897,26 +977,24 @@ class CLSRNet(object):
         dtarget, dS = take(B, D), take(B, D)
         dL, dM, dR = take(Hn, D), take(Hn, D), take(Hn, D)
         dfs, dsi = take(Hn, H), take(Hn, Du)
-        # involved-row flags (tf.unique id sets)
-        fl = self.tab_flags
-        ops.multi("clsr_mark_rows_multi", ops.MarkDesc, [
-            (f["item_history"].data_ptr(), fl["item"].data_ptr(), Hn, hs * T, T, 0),
-            (f["items"].data_ptr(), fl["item"].data_ptr(), B, 1, 1, 0),
-            (f["item_cate_history"].data_ptr(), fl["cate"].data_ptr(), Hn, hs * T, T, 0),
-            (f["cates"].data_ptr(), fl["cate"].data_ptr(), B, 1, 1, 0),
-            (f["users"].data_ptr(), fl["user_long"].data_ptr(), Hn, hs, 1, 0),
-            (f["users"].data_ptr(), fl["user_short"].data_ptr(), Hn, hs, 1, 0)])
+
+        def contrastive(o_):
+            call("clsr_contrastive", o_["att_fea_long"], o_["att_fea_short"], o_["hist_mean"], o_["hist_recent"],
+                 seq_len, ls, Hn, G, D, int(hp.contrastive_length_threshold),
+                 1 if hp.contrastive_loss == "triplet" else 0, float(hp.triplet_margin),
+                 float(hp.contrastive_loss_weight), f["denom"], self.losses[2:], dL, dS, dM, dR)
+
+        out = self.forward(f, True, after_attention=contrastive)
+        assert self.last_shape == (B, T, G, Hn)
         # ---- losses on the forward outputs
         dlogit = self._buf("dlogit", B)
         Gl = hp.train_num_ngs + 1
         call("clsr_softmax_loss", out["logit"], f["labels"], B // Gl, Gl, 1.0 / ((B // Gl) * self.dp_world),
              self.losses[0:], dlogit)
-        call("clsr_contrastive", out["att_fea_long"], out["att_fea_short"], out["hist_mean"], out["hist_recent"],
-             seq_len, ls, Hn, G, D, int(hp.contrastive_length_threshold), 1 if hp.contrastive_loss == "triplet" else 0,
-             float(hp.triplet_margin), float(hp.contrastive_loss_weight), f["denom"], self.losses[2:], dL, dS, dM, dR)
         # ---- logit MLP, fusion, alpha MLP
         dmo = self._mlp_bwd("lg", "sequential/logit_fcn/nn_part/", dlogit, out["model_output"], 2 * D, 2 * D, 2 * D,
                             (self.L0, self.L1), B)
+        self._join()              # the contrastive branch: its dL / dS are accumulated into from here on
         if not hp.manual_alpha:
             dal = self._buf("dalpha_logit", B)
             call("clsr_alpha_fuse_bwd", dmo, out["alpha"], 0.0, out["att_fea_long"], out["att_fea_short"], Hn, G, D,
@@ -958,11 +1036,15 @@ class CLSRNet(object):
             grus.append(self._gru_bwd_desc("g2", CL + "causal2/causal2/gru_cell/", H, dPinAll, Hn, T, dfs, None, None))
         # ---- long-term attention backward (dL has been final since the alpha gate): forked here so that it runs
         #      on the side stream underneath the T-serial backward-through-time (own scratch + own d(hist))
-        with self._branch("@lt"):
+        fork = self._fork_point()
+        if self.rnn_first:
+            ops.rnn_multi("clsr_rnn_bwd_multi", grus, t4d, seq_len, ls, Hn, T)
+        with self._branch("@lt", after=fork):
             dul = self._att_bwd("lt", CL + "long_term/attention_fcn/", dL, out["hist_input"], out["u_long"], dhist_lt,
                                 Hn, 1, T, D, Du, seq_len, ls)
             self._dw_flush()
-        ops.rnn_multi("clsr_rnn_bwd_multi", grus, t4d, seq_len, ls, Hn, T)
+        if not self.rnn_first:
+            ops.rnn_multi("clsr_rnn_bwd_multi", grus, t4d, seq_len, ls, Hn, T)
         # input-side weights of every encoder in one reduction; d(hist) in one product
         self._dw(hist, D, dPinAll, NX, M, D, NX, self._buf("xw.dW", D, NX), NX, db=self._buf("xw.db", NX))
         self._gemm(dPinAll, NX, "xw^T", M, NX, D, dhist, D, acc=1)

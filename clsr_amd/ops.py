@@ -12,8 +12,38 @@ import torch
 from clsr_amd import _lib
 
 
+_scope = [None]   # raw stream of the innermost ``stream_scope`` (None: ask torch on every launch)
+_scope_obj = [None]
+
+
+def current_stream():
+    """torch's current stream object (cached by the innermost ``stream_scope``)."""
+    s = _scope_obj[0]
+    return s if s is not None else torch.cuda.current_stream()
+
+
 def stream_ptr():
-    return torch.cuda.current_stream().cuda_stream
+    s = _scope[0]
+    return s if s is not None else torch.cuda.current_stream().cuda_stream
+
+
+class stream_scope(object):
+    """``with stream_scope(stream=None):`` -- every ``call`` inside launches on ``stream`` (default: torch's current
+    stream, looked up ONCE instead of per launch: ``torch.cuda.current_stream()`` costs ~8 us, a step has ~190
+    launches).  Nests; code that switches torch's current stream inside a scope opens an inner scope."""
+
+    def __init__(self, stream=None):
+        self.stream = stream
+
+    def __enter__(self):
+        self.prev = (_scope[0], _scope_obj[0])
+        obj = self.stream if self.stream is not None else torch.cuda.current_stream()
+        _scope[0], _scope_obj[0] = obj.cuda_stream, obj
+        return self
+
+    def __exit__(self, *exc):
+        _scope[0], _scope_obj[0] = self.prev
+        return False
 
 
 def call(name, *args, stream=None):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Print the kernel timeline of ONE training step from a rocprofv3 rocpd database
-(rocprofv3 --kernel-trace -d DIR -o bench -- python bench.py --no-graph ...).
+(rocprofv3 --kernel-trace -d DIR -o bench -- python bench.py ...; eager is the default).
 
     python scripts/step_timeline.py gpurun_out/prof/bench_results.db [step_index_from_end=2]
 """
@@ -30,6 +30,21 @@ def main():
         busy += du
         print("%8.1f %7.1f us  %-46s grid %5d x%2d q%d" % ((st - t0) / 1e3, du / 1e3, nm, gx // wx, gy, q))
     print("step wall %.1f us, summed kernel time %.1f us" % ((rows[hi][1] - t0) / 1e3, busy / 1e3))
+    # device idle time: the union of the kernel intervals of all queues against the step wall
+    ivs = sorted((st, st + du) for _, st, du, *_ in rows[lo:hi])
+    covered, cur_s, cur_e, gaps = 0, ivs[0][0], ivs[0][1], []
+    for s, e in ivs[1:]:
+        if s > cur_e:
+            covered += cur_e - cur_s
+            gaps.append(s - cur_e)
+            cur_s, cur_e = s, e
+        else:
+            cur_e = max(cur_e, e)
+    covered += cur_e - cur_s
+    wall = rows[hi][1] - t0
+    print("device busy (any queue) %.1f us, idle %.1f us in %d gaps (median %.2f us, max %.1f us)" % (
+        covered / 1e3, (wall - covered) / 1e3, len(gaps) + 1, sorted(gaps)[len(gaps) // 2] / 1e3 if gaps else 0,
+        max(gaps) / 1e3 if gaps else 0))
 
 
 if __name__ == "__main__":
