@@ -282,7 +282,7 @@ class CLSRNet(object):
             self.scope.__exit__(*exc)
             self.ctx.__exit__(*exc)
             net._ws_tag = self.old_tag
-            net._joins.append(ev)
+            net._joins.append((self.tag, ev))
             return False
 
     def _branch(self, tag, after=None):
@@ -298,11 +298,16 @@ class CLSRNet(object):
         ev.record(ops.current_stream())
         return ev
 
-    def _join(self):
+    def _join(self, only=None):
+        """The current stream waits for the finished branches (all of them, or those of stream ``only``)."""
         main = ops.current_stream()
-        for ev in self._joins:
-            main.wait_event(ev)
-        self._joins = []
+        keep = []
+        for tag, ev in self._joins:
+            if only is None or tag == only:
+                main.wait_event(ev)
+            else:
+                keep.append((tag, ev))
+        self._joins = keep
 
     # ------------------------------------------------------------------ buffers
     def _buf(self, name, *shape, dtype=F32):
@@ -860,6 +865,14 @@ class CLSRNet(object):
         M = Hn * T
         NX = self.NX
         PinAll = self._buf("xw.Pin", M, NX)
+        if self._t4_scope is not None and hp.sequential_model == "time4lstm":
+            # tanh time features of the Time4LSTM gates depend on the feed only: on the (still idle) @lt stream
+            # beside the input projection instead of after it
+            t = self._t4_scope
+            with self._branch("@lt"):
+                call("clsr_t4_time_inputs_fwd", f["time_to_now"], f["time_from_first_action"], hs * T,
+                     P[t + "_time_input_w1"], P[t + "_time_input_bias1"], P[t + "_time_input_w2"],
+                     P[t + "_time_input_bias2"], Hn, T, H, self._buf("t4.TT", M, 2 * H))
         self._gemm(hist, D, "xw", M, D, NX, PinAll, NX, bias=self._buf("xw.bias", NX))
         grus, t4d = [], None
         short_int, rnn_out, fs = ushort, None, None
@@ -872,9 +885,7 @@ class CLSRNet(object):
             t4off = self._enc_off("t4")
             if hp.sequential_model == "time4lstm":
                 TT = self._buf("t4.TT", M, 2 * H)
-                call("clsr_t4_time_inputs_fwd", f["time_to_now"], f["time_from_first_action"], hs * T,
-                     P[t + "_time_input_w1"], P[t + "_time_input_bias1"], P[t + "_time_input_w2"],
-                     P[t + "_time_input_bias2"], Hn, T, H, TT)
+                self._join("@lt")     # the time features were computed beside the fused input projection
                 self._gemm(TT, 2 * H, "t4.tw", M, 2 * H, 3 * H, PinAll[:, t4off + 3 * H:], NX, acc=1)
             rnn_out = self._buf("rnn_out", Hn, T, H)
             t4d = ops.t4_desc(H, Pin=PinAll[:, t4off:], ldp=NX, Wm=P[t + "kernel"][D:], ldm=4 * H, out_seq=rnn_out,
