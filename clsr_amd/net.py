@@ -822,14 +822,14 @@ class CLSRNet(object):
                  ldmul=3 * n)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, f, training, after_attention=None):
+    def forward(self, f, training, after_attention=None, early_aux=None):
         """Run the forward pass on an uploaded feed; returns dict of device tensors.  ``after_attention(out)``
         (training) is launched on a side stream as soon as both attention outputs exist, beside the alpha / logit
         MLPs (the contrastive loss: it needs the interest vectors, not the logits)."""
         with ops.stream_scope():
-            return self._forward(f, training, after_attention)
+            return self._forward(f, training, after_attention, early_aux)
 
-    def _forward(self, f, training, after_attention):
+    def _forward(self, f, training, after_attention, early_aux):
         hp, P = self.hp, self.P
         B, T = f["B"], f["T"]
         G = self.G_train if (training and self.dedup) else 1
@@ -842,11 +842,7 @@ class CLSRNet(object):
         # rows between consecutive history groups in the uploaded history-level arrays
         hs = 1 if f.get("compact") else G
         seq_len, ls = f["seq_len"], hs
-        if training and self.sorted_hist_grad:
-            # history ids sorted by row id for the backward's segmented sums: ~35 tiny launches that depend on
-            # the feed only -> their own stream from the very start, underneath the gathers and projections
-            with self._branch("@aux"):      # NOT a stream of its own: see _dw (four streams in all)
-                self._sort_hist_ids(f, Hn, T, hs)
+        step_start = self._fork_point()
         # ---- gathers
         hist = self._buf("hist", Hn, T, D)
         hmean, hrec = self._buf("hist_mean", Hn, D), self._buf("hist_recent", Hn, D)
@@ -874,6 +870,18 @@ class CLSRNet(object):
                      P[t + "_time_input_w1"], P[t + "_time_input_bias1"], P[t + "_time_input_w2"],
                      P[t + "_time_input_bias2"], Hn, T, H, self._buf("t4.TT", M, 2 * H))
         self._gemm(hist, D, "xw", M, D, NX, PinAll, NX, bias=self._buf("xw.bias", NX))
+        if early_aux is not None or (training and self.sorted_hist_grad):
+            # work that depends on the feed only -- accumulator zeroing / row marks of the training step
+            # (``early_aux``) and the ~35 tiny launches that sort the history ids by row id for the backward's
+            # segmented sums -- on the @aux stream (NOT a stream of its own: see _dw, four streams in all), ordered
+            # after the START of the step but ENQUEUED here, behind the first big main-stream launches: when the
+            # host is the slower side (tracer, fit loop sharing the GIL with the iterator thread) the device
+            # executes in enqueue order and must not find 40 tiny launches ahead of the main chain
+            with self._branch("@aux", after=step_start):
+                if early_aux is not None:
+                    early_aux()
+                if training and self.sorted_hist_grad:
+                    self._sort_hist_ids(f, Hn, T, hs)
         grus, t4d = [], None
         short_int, rnn_out, fs = ushort, None, None
         if hp.interest_evolve:
@@ -965,7 +973,8 @@ class CLSRNet(object):
         # marked on a side stream underneath the forward's first kernels
         zpool = self._buf("zero_pool", Hn * T * (2 * D + H) + B * D * 2 + Hn * (3 * D + H + Du))
         fl = self.tab_flags
-        with self._branch("@aux"):
+
+        def zero_and_mark():
             call("clsr_zero_doubles", self.losses, 8)
             call("clsr_zero_doubles", self.sumsq_tab, 16)
             call("clsr_zero_floats", zpool, zpool.numel())
@@ -995,7 +1004,7 @@ class CLSRNet(object):
                  1 if hp.contrastive_loss == "triplet" else 0, float(hp.triplet_margin),
                  float(hp.contrastive_loss_weight), f["denom"], self.losses[2:], dL, dS, dM, dR)
 
-        out = self.forward(f, True, after_attention=contrastive)
+        out = self._forward(f, True, contrastive, zero_and_mark)
         assert self.last_shape == (B, T, G, Hn)
         # ---- losses on the forward outputs
         dlogit = self._buf("dlogit", B)
