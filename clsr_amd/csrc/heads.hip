@@ -521,11 +521,11 @@ extern "C" int clsr_att_z0_bwd_reduce(const float* dz0, long Hn, int G, int T, i
 // (2) given daq = dz0 . Wp^T  [R*T, Q]:  da[h,t,:] = sum_g daq[(h,g),t,:] * q[(h,g),:]
 //                                        dq[r,:]   = sum_t daq[r,t,:] * a[h,t,:]
 // Same loop structure as (1): the G rows of a step are loaded together, da gets one store.
-__global__ void __launch_bounds__(64) att_prod_bwd_kernel(const float* __restrict__ daq,
-                                                          const float* __restrict__ a,
-                                                          const float* __restrict__ q, long Hn, int G,
-                                                          int T, int Q, float* __restrict__ da,
-                                                          float* __restrict__ dq) {
+__global__ void __launch_bounds__(64) att_prod_bwd_kernel(const float* __restrict__ daq, int ldd,
+                                                          const float* __restrict__ a, int lda,
+                                                          const float* __restrict__ q, int ldq, long Hn, int G,
+                                                          int T, int Q, float* __restrict__ da, int ldda,
+                                                          float* __restrict__ dq, int lddq, int acc_dq) {
   const int lane = threadIdx.x;
   const int QQ = Q >> 2, tpar = 64 / QQ, ts = lane / QQ, qq = lane - ts * QQ;
   __shared__ f32x4 red[ATT_MAXG][64];
@@ -537,19 +537,19 @@ __global__ void __launch_bounds__(64) att_prod_bwd_kernel(const float* __restric
 #pragma unroll
       for (int g = 0; g < ATT_MAXG; ++g) {
         accq[g] = z4;
-        qv[g] = (g < gc && ts < tpar) ? ld4(q + (h * G + g0 + g) * Q + 4 * qq) : z4;
+        qv[g] = (g < gc && ts < tpar) ? ld4(q + (h * G + g0 + g) * ldq + 4 * qq) : z4;
       }
       if (ts < tpar) {
         for (int t = ts; t < T; t += tpar) {
-          const f32x4 av = ld4(a + (h * T + t) * Q + 4 * qq);
+          const f32x4 av = ld4(a + (h * T + t) * lda + 4 * qq);
           f32x4 d[ATT_MAXG];
 #pragma unroll
           for (int g = 0; g < ATT_MAXG; ++g)
-            d[g] = g < gc ? ld4(daq + ((h * G + g0 + g) * T + t) * Q + 4 * qq) : z4;
+            d[g] = g < gc ? ld4(daq + ((h * G + g0 + g) * T + t) * ldd + 4 * qq) : z4;
           f32x4 su = z4;
 #pragma unroll
           for (int g = 0; g < ATT_MAXG; ++g) { su += d[g] * qv[g]; accq[g] += d[g] * av; }
-          float* ap = da + (h * T + t) * Q + 4 * qq;
+          float* ap = da + (h * T + t) * ldda + 4 * qq;
           st4(ap, g0 == 0 ? su : ld4(ap) + su);
         }
       }
@@ -562,7 +562,8 @@ __global__ void __launch_bounds__(64) att_prod_bwd_kernel(const float* __restric
           if (g < gc) {
             f32x4 v = accq[g];
             for (int s2 = 1; s2 < tpar; ++s2) v += red[g][lane + s2 * QQ];
-            st4(dq + (h * G + g0 + g) * Q + 4 * qq, v);
+            float* qp = dq + (h * G + g0 + g) * lddq + 4 * qq;
+            st4(qp, acc_dq ? ld4(qp) + v : v);
           }
       }
       __syncthreads();
@@ -570,13 +571,21 @@ __global__ void __launch_bounds__(64) att_prod_bwd_kernel(const float* __restric
   }
 }
 
-extern "C" int clsr_att_prod_bwd(const float* daq, const float* a, const float* q, long Hn, int G, int T,
-                                 int Q, float* da, float* dq, void* stream) {
+extern "C" int clsr_att_prod_bwd_ld(const float* daq, int ldd, const float* a, int lda, const float* q, int ldq,
+                                    long Hn, int G, int T, int Q, float* da, int ldda, float* dq, int lddq,
+                                    int accumulate_dq, void* stream) {
   CLSR_CHECK_ARG(daq && a && q && da && dq && Hn > 0 && G > 0 && T > 0);
-  CLSR_CHECK_SUPPORTED(Q % 4 == 0 && Q <= 256);
+  CLSR_CHECK_SUPPORTED(Q % 4 == 0 && Q <= 256 && ldd % 4 == 0 && lda % 4 == 0 && ldq % 4 == 0 && ldda % 4 == 0 &&
+                       lddq % 4 == 0);
+  CLSR_CHECK_ARG(ldd >= Q && lda >= Q && ldq >= Q && ldda >= Q && lddq >= Q);
   int blocks = Hn > 8192 ? 8192 : (int)Hn;
-  hipLaunchKernelGGL(att_prod_bwd_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, daq, a, q, Hn, G,
-                     T, Q, da, dq);
+  hipLaunchKernelGGL(att_prod_bwd_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, daq, ldd, a, lda, q, ldq,
+                     Hn, G, T, Q, da, ldda, dq, lddq, accumulate_dq);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
+}
+
+extern "C" int clsr_att_prod_bwd(const float* daq, const float* a, const float* q, long Hn, int G, int T,
+                                 int Q, float* da, float* dq, void* stream) {
+  return clsr_att_prod_bwd_ld(daq, Q, a, Q, q, Q, Hn, G, T, Q, da, Q, dq, Q, 0, stream);
 }

@@ -80,6 +80,8 @@ class CLSRNet(object):
         self.rnn_first = not os.environ.get("CLSR_BRANCH_FIRST")   # A/B switch (see forward)
         self.dw_stream = not os.environ.get("CLSR_NO_DW_STREAM")   # A/B switch (see _dw)
         self._dw_async = False
+        self.split_query = not os.environ.get("CLSR_NO_SPLIT_QUERY")   # A/B switch (see _att_qh)
+        self.split_query_min = 64
         self.dw_streams = int(os.environ.get("CLSR_DW_STREAMS", "1"))
         self._joins = []
         self._dw_pending, self._dw_tables, self._dw_after, self._rp_pending = {}, {}, {}, {}
@@ -507,6 +509,15 @@ class CLSRNet(object):
         tbl, n, max_elems = plan
         call("clsr_pack_batch", tbl, n, max_elems)
 
+    def _att_qh(self, key):
+        """Leading query columns of attention ``key`` that are history-level.  The short-term query is
+        ``[short_term_intention[h] | target[r]]`` (clsr.py:219): its first Du columns do not depend on the candidate,
+        so their share of the product term ``(a*q).Wp`` is computed once per history (Hn*T positions) and folded
+        into U[h,t]; only the target half stays in the per-(row, step) GEMM (K = D instead of Du + D).  Pays off
+        when the layers are wide (BASELINE configs[4], Du = 128: 15.15 -> 14.36 ms/step); at Du = 40 the big GEMMs
+        are bound by their stores, not by K, and the five extra launches cost 1 % -- hence the width threshold."""
+        return self.Du if (key == "st" and self.split_query and self.Du >= self.split_query_min) else 0
+
     def _plan_weights(self, training):
         hp, P = self.hp, self.P
         D, Du, H, A0, A1 = self.D, self.Du, self.H, self.A0, self.A1
@@ -518,12 +529,19 @@ class CLSRNet(object):
             self._pack(key + ".Wu", W0[0:Q], A0, Q, W2=W0[2 * Q:3 * Q], s2=1.0)
             self._pack(key + ".Wv", W0[Q:2 * Q], A0, Q, W2=W0[2 * Q:3 * Q], s2=-1.0)
             self._pack(key + ".Wp", W0[3 * Q:4 * Q], A0, Q)
+            qh = self._att_qh(key)
+            if qh:   # product-term weights split into the history-level and the per-row query columns
+                self._pack(key + ".Wp1", W0[3 * Q:3 * Q + qh], A0, qh)
+                self._pack(key + ".Wp2", W0[3 * Q + qh:4 * Q], A0, Q - qh)
             self._pack(key + ".W1", W1, A1, A0)
             if training:
                 self._pack(key + ".A^T", P[scope + "attention_mat"], Dk, Q, transposed=True)
                 self._pack(key + ".Wu^T", W0[0:Q], Q, A0, transposed=True, W2=W0[2 * Q:3 * Q], s2=1.0)
                 self._pack(key + ".Wv^T", W0[Q:2 * Q], Q, A0, transposed=True, W2=W0[2 * Q:3 * Q], s2=-1.0)
                 self._pack(key + ".Wp^T", W0[3 * Q:4 * Q], Q, A0, transposed=True)
+                if qh:
+                    self._pack(key + ".Wp1^T", W0[3 * Q:3 * Q + qh], qh, A0, transposed=True)
+                    self._pack(key + ".Wp2^T", W0[3 * Q + qh:4 * Q], Q - qh, A0, transposed=True)
                 self._pack(key + ".W1^T", W1, A0, A1, transposed=True)
         # fused history projection: every input-side weight block of every encoder side by side
         blocks, NX = self._xw_blocks()
@@ -671,8 +689,9 @@ class CLSRNet(object):
         return into
 
     # ------------------------------------------------------------------ attention block
-    def _att_fwd(self, key, scope, keys, q, Hn, G, T, Dk, Q, seq_len, len_stride, training):
+    def _att_fwd(self, key, scope, keys, q, Hn, G, T, Dk, Q, seq_len, len_stride, training, q_hist=None):
         P, A0, A1 = self.P, self.A0, self.A1
+        qh = self._att_qh(key) if (q_hist is not None and G > 1) else 0
         R = Hn * G
         nn = scope + "att_fcn/nn_part/"
         bn0, bn1 = self.bn[nn + "batch_normalization/"], self.bn[nn + "batch_normalization_1/"]
@@ -687,8 +706,15 @@ class CLSRNet(object):
         self._gemm(a, Q, key + ".Wu", Hn * T, Q, A0, U, A0)
         self._gemm(q, Q, key + ".Wv", R, Q, A0, V, A0, bias=P[nn + "b_nn_layer0"])
         st, parts = self._stats_buf(R * T, A0) if training else (None, 0)
-        self._gemm(a, Q, key + ".Wp", R * T, Q, A0, z0, A0, T=T, G=G, Xmul=q, ldmul=Q, addU=U, ldu=A0,
-                   addV=V, ldv=A0, stats=st)
+        if qh:
+            # U[h,t] += (a[h,t,:qh] * q_hist[h]) . Wp[:qh]   (in place: every tile reads its own U before storing)
+            self._gemm(a, Q, key + ".Wp1", Hn * T, qh, A0, U, A0, T=T, G=1, Xmul=q_hist, ldmul=qh, addU=U, ldu=A0,
+                       addV=self._buf("att.zeroV", Hn, A0), ldv=A0)
+            self._gemm(a[:, qh:], Q, key + ".Wp2", R * T, Q - qh, A0, z0, A0, T=T, G=G, Xmul=q[:, qh:], ldmul=Q,
+                       addU=U, ldu=A0, addV=V, ldv=A0, stats=st)
+        else:
+            self._gemm(a, Q, key + ".Wp", R * T, Q, A0, z0, A0, T=T, G=G, Xmul=q, ldmul=Q, addU=U, ldu=A0,
+                       addV=V, ldv=A0, stats=st)
         self._bn_fwd(bn0, st, parts, R * T, training)
         st, parts = self._stats_buf(R * T, A1) if training else (None, 0)
         self._gemm(z0, A0, key + ".W1", R * T, A0, A1, z1, A1, bias=P[nn + "b_nn_layer1"], aff=bn0, stats=st)
@@ -697,9 +723,13 @@ class CLSRNet(object):
              seq_len, len_stride, keys, Hn, G, T, A1, Dk, wts, out)
         return out
 
-    def _att_bwd(self, key, scope, dout, keys, q, dkeys, Hn, G, T, Dk, Q, seq_len, len_stride):
-        """Returns dq [R, Q]; accumulates into dkeys [Hn, T, Dk]; writes every dense gradient."""
+    def _att_bwd(self, key, scope, dout, keys, q, dkeys, Hn, G, T, Dk, Q, seq_len, len_stride, q_hist=None,
+                 dq_hist=None):
+        """Returns dq [R, Q]; accumulates into dkeys [Hn, T, Dk]; writes every dense gradient.  With ``q_hist``
+        (see ``_att_qh``) the product-term gradient of the history-level query columns is ACCUMULATED into
+        ``dq_hist`` [Hn, qh] and dq[:, :qh] only holds the V-path share."""
         P, Gd, A0, A1 = self.P, self.Gd, self.A0, self.A1
+        qh = self._att_qh(key) if (q_hist is not None and G > 1) else 0
         R = Hn * G
         nn = scope + "att_fcn/nn_part/"
         bn0, bn1 = self.bn[nn + "batch_normalization/"], self.bn[nn + "batch_normalization_1/"]
@@ -729,26 +759,45 @@ class CLSRNet(object):
         self._gemm_bnbwd(dz1, A1, key + ".W1^T", R * T, A1, A0, dz0, bn0, z0)
         # layer 0 (re-associated): z0 = U[h,t] + V[r] + (a[h,t]*q[r]) . Wp
         dW0 = Gd[nn + "w_nn_layer0"]
-        self._dw(a, Q, dz0, A0, R * T, Q, A0, dW0[3 * Q:4 * Q], A0, T=T, G=G, Xmul=q, ldmul=Q)
-        daq = self._buf(key + ".daq", R * T, Q)
-        self._gemm(dz0, A0, key + ".Wp^T", R * T, A0, Q, daq, Q)
         da = self._buf(key + ".da", Hn * T, Q)
         dq = self._buf(key + ".dq", R, Q)
-        call("clsr_att_prod_bwd", daq, a, q, Hn, G, T, Q, da, dq)
         dV = self._buf(key + ".dV", R, A0)
-        if G == 1:
-            dU = dz0
-            call("clsr_att_z0_bwd_reduce", dz0, Hn, G, T, A0, None, dV)
-        else:
+        if qh:
+            Q2 = Q - qh
+            self._dw(a[:, qh:], Q, dz0, A0, R * T, Q2, A0, dW0[3 * Q + qh:4 * Q], A0, T=T, G=G, Xmul=q[:, qh:],
+                     ldmul=Q)
+            daq = self._buf(key + ".daq2", R * T, Q2)
+            self._gemm(dz0, A0, key + ".Wp2^T", R * T, A0, Q2, daq, Q2)
             dU = self._buf(key + ".dU", Hn * T, A0)
             call("clsr_att_z0_bwd_reduce", dz0, Hn, G, T, A0, dU, dV)
+            # dq = dV . Wv^T first (all Q columns), then the per-row product term is added to its target columns
+            self._gemm(dV, A0, key + ".Wv^T", R, A0, Q, dq, Q)
+            call("clsr_att_prod_bwd_ld", daq, Q2, a[:, qh:], Q, q[:, qh:], Q, Hn, G, T, Q2, da[:, qh:], Q,
+                 dq[:, qh:], Q, 1)
+            # history-level share of the product term: through dU = sum over the group's rows of dz0
+            self._dw(a, Q, dU, A0, Hn * T, qh, A0, dW0[3 * Q:3 * Q + qh], A0, T=T, G=1, Xmul=q_hist, ldmul=qh)
+            daq1 = self._buf(key + ".daq1", Hn * T, qh)
+            self._gemm(dU, A0, key + ".Wp1^T", Hn * T, A0, qh, daq1, qh)
+            call("clsr_att_prod_bwd_ld", daq1, qh, a, Q, q_hist, qh, Hn, 1, T, qh, da, Q, dq_hist, qh, 1)
+        else:
+            self._dw(a, Q, dz0, A0, R * T, Q, A0, dW0[3 * Q:4 * Q], A0, T=T, G=G, Xmul=q, ldmul=Q)
+            daq = self._buf(key + ".daq", R * T, Q)
+            self._gemm(dz0, A0, key + ".Wp^T", R * T, A0, Q, daq, Q)
+            call("clsr_att_prod_bwd", daq, a, q, Hn, G, T, Q, da, dq)
+            if G == 1:
+                dU = dz0
+                call("clsr_att_z0_bwd_reduce", dz0, Hn, G, T, A0, None, dV)
+            else:
+                dU = self._buf(key + ".dU", Hn * T, A0)
+                call("clsr_att_z0_bwd_reduce", dz0, Hn, G, T, A0, dU, dV)
         self._dw(a, Q, dU, A0, Hn * T, Q, A0, dW0[0:Q], A0)                        # d(W0a + W0d)
         self._dw(q, Q, dV, A0, R, Q, A0, dW0[Q:2 * Q], A0, db=Gd[nn + "b_nn_layer0"])  # d(W0q - W0d)
         # d(W0d) = d(W0a+W0d) - d(W0q-W0d) block: needs the two reduced gradients above (runs at the flush)
         self._dw_after.setdefault(self._ws_tag, []).append(
             lambda: call("clsr_axpby", dW0[2 * Q:3 * Q], dW0[0:Q], 1.0, dW0[Q:2 * Q], -1.0, Q * A0))
         self._gemm(dU, A0, key + ".Wu^T", Hn * T, A0, Q, da, Q, acc=1)
-        self._gemm(dV, A0, key + ".Wv^T", R, A0, Q, dq, Q, acc=1)
+        if not qh:
+            self._gemm(dV, A0, key + ".Wv^T", R, A0, Q, dq, Q, acc=1)
         self._dw(keys, Dk, da, Q, Hn * T, Dk, Q, Gd[scope + "attention_mat"], Q)
         self._gemm(da, Q, key + ".A^T", Hn * T, Q, Dk, dkeys, Dk, acc=1)
         return dq
@@ -925,7 +974,8 @@ class CLSRNet(object):
         q = self._buf("st.q", B, Qs)
         call("clsr_copy_cols", short_int, Du, 0, G, B, Du, q, Qs, 0, 0)
         call("clsr_copy_cols", target, D, 0, 1, B, D, q, Qs, Du, 0)
-        att_short = self._att_fwd("st", st + "attention_fcn/", rnn_out, q, Hn, G, T, H, Qs, seq_len, ls, training)
+        att_short = self._att_fwd("st", st + "attention_fcn/", rnn_out, q, Hn, G, T, H, Qs, seq_len, ls, training,
+                                  q_hist=short_int)
         # ---- alpha gate
         self._join()
         if after_attention is not None:
@@ -1031,7 +1081,7 @@ class CLSRNet(object):
         st = CL + "short_term/"
         Qs = Du + D
         dq = self._att_bwd("st", st + "attention_fcn/", dS, out["rnn_out"], out["q_short"], drnn, Hn, G, T, H, Qs,
-                           seq_len, ls)
+                           seq_len, ls, q_hist=out["short_intention"], dq_hist=dsi)
         call("clsr_group_sum_cols", dq, Qs, 0, G, Hn, Du, dsi, Du, 0, 1)
         call("clsr_copy_cols", dq, Qs, Du, 1, B, D, dtarget, D, 0, 1)
         # ---- sequence encoders: ONE fused backward-through-time launch, then the batched weight grads

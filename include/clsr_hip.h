@@ -227,6 +227,12 @@ int clsr_att_z0_bwd_reduce(const float* dz0, long Hn, int G, int T, int C, float
                            void* stream);
 int clsr_att_prod_bwd(const float* daq, const float* a, const float* q, long Hn, int G, int T, int Q,
                       float* da, float* dq, void* stream);
+/* the same on column blocks of wider tensors (leading dimensions) and with dq += instead of dq =: used when the
+ * history-level columns of the query (the short-term intention half of [h_T | target], clsr.py:219) are split
+ * off the per-row product term */
+int clsr_att_prod_bwd_ld(const float* daq, int ldd, const float* a, int lda, const float* q, int ldq, long Hn,
+                         int G, int T, int Q, float* da, int ldda, float* dq, int lddq, int accumulate_dq,
+                         void* stream);
 
 /* ---- regularisers, clip, Adam: base_model.py:118-159,249-297; clsr.py:73-82 */
 int clsr_adam_tick(double* state, double lr, double beta1, double beta2, void* stream);

@@ -354,6 +354,38 @@ def _oracle():
     return O
 
 
+@pytest.mark.parametrize("Hn,G,T,Q,col0,ld", [(19, 5, 10, 80, 0, 80), (7, 1, 50, 40, 0, 40), (11, 5, 13, 40, 40, 80),
+                                               (5, 9, 6, 128, 128, 256)])
+def test_att_prod_bwd_on_column_blocks(Hn, G, T, Q, col0, ld):
+    """Backward of the product feature a[h,t] * q[r]: da[h,t] = sum_g daq[r,t] * q[r], dq[r] = sum_t daq[r,t] * a[h,t]
+    (clsr.py:368-370) -- the plain entry point and the leading-dimension one on a column block [col0, col0+Q) of
+    wider a / q / da / dq tensors, overwriting and accumulating into dq."""
+    g = torch.Generator().manual_seed(Hn * 100 + Q)
+    R = Hn * G
+    a, q = rnd(g, Hn * T, ld), rnd(g, R, ld)
+    daq = rnd(g, R * T, Q)
+    ab, qb = a[:, col0:col0 + Q], q[:, col0:col0 + Q]
+    d4 = daq.view(Hn, G, T, Q)
+    da_exp = (d4 * qb.view(Hn, G, 1, Q)).sum(1).reshape(Hn * T, Q)
+    dq_exp = (d4 * ab.view(Hn, 1, T, Q)).sum(2).reshape(R, Q)
+    A, Qd, D = dev(a, torch.float32), dev(q, torch.float32), dev(daq, torch.float32)
+    for acc in (0, 1):
+        da = torch.full((Hn * T, ld), 7.0, device="cuda")
+        dq = torch.full((R, ld), 3.0, device="cuda")
+        call("clsr_att_prod_bwd_ld", D, Q, A[:, col0:], ld, Qd[:, col0:], ld, Hn, G, T, Q, da[:, col0:], ld,
+             dq[:, col0:], ld, acc)
+        close(da[:, col0:col0 + Q], da_exp, name="da")
+        close(dq[:, col0:col0 + Q], dq_exp + (3.0 if acc else 0.0), name="dq acc=%d" % acc)
+        if ld > Q:   # the other columns are untouched
+            other = [c for c in range(ld) if not col0 <= c < col0 + Q]
+            assert float((da[:, other] - 7.0).abs().max()) == 0 and float((dq[:, other] - 3.0).abs().max()) == 0
+    if ld == Q:
+        da, dq = torch.empty(Hn * T, Q, device="cuda"), torch.empty(R, Q, device="cuda")
+        call("clsr_att_prod_bwd", D, A, Qd, Hn, G, T, Q, da, dq)
+        close(da, da_exp, name="da plain")
+        close(dq, dq_exp, name="dq plain")
+
+
 @pytest.mark.parametrize("Hn,T,n,use_h0,seq_out", [(37, 10, 40, True, False), (16, 50, 40, False, True),
                                                    (5, 7, 40, True, True), (21, 9, 128, True, True),
                                                    (4, 5, 64, False, False)])

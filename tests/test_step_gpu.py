@@ -48,7 +48,10 @@ def _setup(hp, dedup, seed=3):
 
     dims = _dims(hp)
     params32 = O.init_params(dims, hp, seed=seed, scale_dense=8.0)
-    net = CLSRNet(hp, dims, device="cuda:0", seed=0, dedup_histories=dedup)
+    split = dedup == "split"     # de-duplicated histories + the history-level query columns split off the
+    net = CLSRNet(hp, dims, device="cuda:0", seed=0, dedup_histories=bool(dedup))   # product term at ANY width
+    if split:
+        net.split_query_min = 0
     sd = dict(params32)
     for k, v in O.init_bn_state(params32).items():
         sd[k] = v
@@ -66,7 +69,7 @@ CONFIGS = [
 ]
 
 
-@pytest.mark.parametrize("dedup", [True, False])
+@pytest.mark.parametrize("dedup", [True, False, "split"])
 @pytest.mark.parametrize("cfg", range(len(CONFIGS)))
 def test_train_step_matches_oracle(golden_dir, golden_hparams, cfg, dedup):
     hp = _variant(golden_hparams, **CONFIGS[cfg])
