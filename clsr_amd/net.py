@@ -142,7 +142,7 @@ class CLSRNet(object):
         off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
         self.n_dense = int(off[-1])
         self.dense = torch.zeros(self.n_dense, dtype=F32, device=dev)
-        self.dense_grad = torch.zeros_like(self.dense)
+        self.dense_grad = None     # a view of grad_flat (below): dense and table gradients travel in ONE collective
         self.dense_m = torch.zeros_like(self.dense)
         self.dense_v = torch.zeros_like(self.dense)
         self.seg_off = torch.tensor(off, dtype=torch.int32, device=dev)
@@ -161,7 +161,9 @@ class CLSRNet(object):
             gtot += _pad4(sh[0] * sh[1])
             ftot += (sh[0] + 15) // 16 * 16
         self.tab_goff, self.tab_foff, self.tab_shape = goff, foff, tshape   # layout of the two flat buffers
-        self.tab_grad_flat = torch.zeros(gtot, dtype=F32, device=dev)
+        self.grad_flat = torch.zeros(self.n_dense + gtot, dtype=F32, device=dev)   # [dense | tables]
+        self.dense_grad = self.grad_flat[:self.n_dense]
+        self.tab_grad_flat = self.grad_flat[self.n_dense:]
         self.tab_flags_flat = torch.zeros(ftot, dtype=torch.uint8, device=dev)
         it_dense = iter(zip(dense, off[:-1]))
         for name, shape, kind in specs:
