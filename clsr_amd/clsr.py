@@ -157,7 +157,10 @@ class SequentialBaseModel(BaseModel):
         dims = dict(Vu=len(load_dict(hp.user_vocab)), Vi=len(load_dict(hp.item_vocab)),
                     Vc=len(load_dict(hp.cate_vocab)))
         self.user_vocab_length, self.item_vocab_length, self.cate_vocab_length = dims["Vu"], dims["Vi"], dims["Vc"]
-        self.net = CLSRNet(hp, dims, device=self._device, seed=self.seed, dedup_histories=self._dedup)
+        self.net = self._make_net(hp, dims)
+
+    def _make_net(self, hp, dims):
+        return CLSRNet(hp, dims, device=self._device, seed=self.seed, dedup_histories=self._dedup)
 
     # ------------------------------------------------------------------ device feeds / graphs
     def _to_arrays(self, feed_dict, training=False):
@@ -237,7 +240,8 @@ class SequentialBaseModel(BaseModel):
             out = self.net.forward(f, False)
             pred = torch.sigmoid(out["logit"]) if self.hparams.method == "classification" else out["logit"]
             pred = pred.detach().cpu().numpy().reshape(-1, 1)
-            out = dict(out, alpha=out["alpha"].detach().cpu())
+            if "alpha" in out:
+                out = dict(out, alpha=out["alpha"].detach().cpu())
         return feed, pred, out
 
     def eval(self, sess, feed_dict):
@@ -378,3 +382,39 @@ class SequentialBaseModel(BaseModel):
 
 class CLSRModel(SequentialBaseModel):
     """Reference ``CLSRModel`` (clsr.py).  All graph pieces live in :class:`clsr_amd.net.CLSRNet`."""
+
+
+class _SiblingModel(SequentialBaseModel):
+    """A model of the reference that sits on the same ``SequentialBaseModel`` trunk as CLSR and is built from the same
+    kernels (:class:`clsr_amd.seqnet.SeqNet`).  ``train`` returns the base-class 5-list
+    ``[update, extra_update_ops, loss, data_loss, summary]`` (reference base_model.py:359-379)."""
+    kind = None
+
+    def _make_net(self, hp, dims):
+        from clsr_amd.seqnet import SeqNet
+
+        return SeqNet(hp, dims, kind=self.kind, device=self._device, seed=self.seed, dedup_histories=self._dedup)
+
+    def train(self, sess, feed_dict):
+        self._train_step(self._to_arrays(feed_dict, True))
+        with self._stream_ctx():
+            ls = self.net.read_losses()
+        return [None, [], ls["loss"], ls["data_loss"], None]
+
+
+class GRU4RecModel(_SiblingModel):
+    """Reference ``GRU4RecModel`` (models/sequential/gru4rec.py)."""
+    kind = "gru4rec"
+
+
+class DINModel(_SiblingModel):
+    """Reference ``DINModel`` (models/sequential/din.py)."""
+    kind = "din"
+
+
+class SLI_RECModel(_SiblingModel):
+    """Reference ``SLI_RECModel`` (models/sequential/sli_rec.py)."""
+    kind = "sli_rec"
+
+    def eval_with_user_and_alpha(self, sess, feed_dict):
+        return super(SLI_RECModel, self).eval_with_user_and_alpha(sess, feed_dict)

@@ -64,8 +64,9 @@ class CLSRNet(object):
         self._check_supported()
         self.Di, self.Dc = hp.item_embedding_dim, hp.cate_embedding_dim
         self.D = self.Di + self.Dc
+        self.enc_in = self.D       # leading columns of the history rows the recurrent encoders read
         self.Du, self.H = hp.user_embedding_dim, hp.hidden_size
-        self.A0, self.A1 = hp.att_fcn_layer_sizes
+        self.A0, self.A1 = hp.att_fcn_layer_sizes or (0, 0)    # (models without an attention MLP have none)
         self.L0, self.L1 = hp.layer_sizes
         self.G_train = hp.train_num_ngs + 1
         self.lazy = 1 if hp.optimizer == "lazyadam" else 0
@@ -127,6 +128,17 @@ class CLSRNet(object):
             raise NotImplementedError("CLSR HIP path does not support: " + "; ".join(bad))
 
     # ------------------------------------------------------------------ parameters
+    # The variable inventory, the trained embedding tables and the recurrent encoders are hooks so that the sibling
+    # models of the reference that share these kernels (clsr_amd/seqnet.py) reuse everything below.
+    def _param_specs(self):
+        return param_specs(self.dims, self.hp)
+
+    def _table_map(self):
+        return TABLES
+
+    def _unused_tables(self):
+        return (UNUSED_TABLE,)
+
     def _build_params(self, seed):
         hp, dev = self.hp, self.device
         gen = torch.Generator()
@@ -134,9 +146,10 @@ class CLSRNet(object):
             gen.seed()
         else:
             gen.manual_seed(int(seed))
-        specs = param_specs(self.dims, hp)
+        specs = self._param_specs()
         self.specs = specs
-        table_names = set(TABLES.values()) | {UNUSED_TABLE}
+        TABLES = self._table_map()
+        table_names = set(TABLES.values()) | set(self._unused_tables())
         dense = [(n, s, k) for n, s, k in specs if n not in table_names]
         sizes = [_pad4(int(np.prod(s))) for _, s, _ in dense]
         off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
@@ -177,7 +190,7 @@ class CLSRNet(object):
                 else:
                     t = val.to(dev)
                 self.P[name] = t
-                if name != UNUSED_TABLE:
+                if name not in self._unused_tables():
                     key = [k for k, v in TABLES.items() if v == name][0]
                     self.tables[key] = t
                     self.tab_grad[key] = self.tab_grad_flat[goff[key]:goff[key] + t.numel()].view_as(t)
@@ -456,24 +469,24 @@ class CLSRNet(object):
     def _xw_blocks(self):
         """Column layout of the fused history projection  hist . [all input-side weight blocks]:
         list of (encoder key, kind, weight view [D, w], bias view, column offset, width)."""
-        P, D, H = self.P, self.D, self.H
+        P, D, H = self.P, self.enc_in, self.H
         out, off = [], 0
         for key, scope, n in self._gru_list():
             for kind, W, b, w in (("gx", P[scope + "gates/kernel"][0:D], P[scope + "gates/bias"], 2 * n),
                                   ("cx", P[scope + "candidate/kernel"][0:D], P[scope + "candidate/bias"], n)):
                 out.append((key, kind, W, b, off, w))
                 off += w
-        if self.hp.sequential_model == "time4lstm":
-            t = CL + "short_term/time4lstm/"
+        if self._t4_kind == "time4lstm":
+            t = self._t4_scope
             for kind, W, b, w in (("kx", P[t + "kernel"][0:D], P[t + "bias"], 4 * H),
                                   ("w1", P[t + "_time_kernel_w1"], P[t + "_time_bias1"], H),
                                   ("w2", P[t + "_time_kernel_w2"], P[t + "_time_bias2"], H)):
                 out.append(("t4", kind, W, b, off, w))
                 off += w
-        elif self.hp.sequential_model == "lstm":
+        elif self._t4_kind == "lstm":
             # tf.nn.rnn_cell.LSTMCell (clsr.py:209-216) == the Time4LSTM recurrence with both time gates stuck
             # open: constant pre-activations of +30 (sigmoid(30) == 1.0f) instead of learned time projections
-            g = CL + "short_term/simple_lstm/lstm_cell/"
+            g = self._t4_scope
             zero_w = self._buf("lstm.const_w", D, H)
             open_b = self._bufs.get("lstm.const_b")
             if open_b is None:
@@ -485,12 +498,18 @@ class CLSRNet(object):
         return out, off
 
     @property
+    def _t4_kind(self):
+        """"time4lstm" | "lstm" | None: the LSTM-type encoder of the model, if any."""
+        sm = self.hp.sequential_model
+        return sm if sm in ("time4lstm", "lstm") else None
+
+    @property
     def _t4_scope(self):
         """Variable scope of the LSTM-type short-term encoder (None for the GRU encoder)."""
-        sm = self.hp.sequential_model
-        if sm == "time4lstm":
+        kind = self._t4_kind
+        if kind == "time4lstm":
             return CL + "short_term/time4lstm/"
-        if sm == "lstm":
+        if kind == "lstm":
             return CL + "short_term/simple_lstm/lstm_cell/"
         return None
 
@@ -523,45 +542,9 @@ class CLSRNet(object):
     def _plan_weights(self, training):
         hp, P = self.hp, self.P
         D, Du, H, A0, A1 = self.D, self.Du, self.H, self.A0, self.A1
-        for key, scope, Dk, Q in (("lt", CL + "long_term/attention_fcn/", D, Du),
-                                  ("st", CL + "short_term/attention_fcn/", H, Du + D)):
-            W0 = P[scope + "att_fcn/nn_part/w_nn_layer0"]
-            W1 = P[scope + "att_fcn/nn_part/w_nn_layer1"]
-            self._pack(key + ".A", P[scope + "attention_mat"], Q, Dk)
-            self._pack(key + ".Wu", W0[0:Q], A0, Q, W2=W0[2 * Q:3 * Q], s2=1.0)
-            self._pack(key + ".Wv", W0[Q:2 * Q], A0, Q, W2=W0[2 * Q:3 * Q], s2=-1.0)
-            self._pack(key + ".Wp", W0[3 * Q:4 * Q], A0, Q)
-            qh = self._att_qh(key)
-            if qh:   # product-term weights split into the history-level and the per-row query columns
-                self._pack(key + ".Wp1", W0[3 * Q:3 * Q + qh], A0, qh)
-                self._pack(key + ".Wp2", W0[3 * Q + qh:4 * Q], A0, Q - qh)
-            self._pack(key + ".W1", W1, A1, A0)
-            if training:
-                self._pack(key + ".A^T", P[scope + "attention_mat"], Dk, Q, transposed=True)
-                self._pack(key + ".Wu^T", W0[0:Q], Q, A0, transposed=True, W2=W0[2 * Q:3 * Q], s2=1.0)
-                self._pack(key + ".Wv^T", W0[Q:2 * Q], Q, A0, transposed=True, W2=W0[2 * Q:3 * Q], s2=-1.0)
-                self._pack(key + ".Wp^T", W0[3 * Q:4 * Q], Q, A0, transposed=True)
-                if qh:
-                    self._pack(key + ".Wp1^T", W0[3 * Q:3 * Q + qh], qh, A0, transposed=True)
-                    self._pack(key + ".Wp2^T", W0[3 * Q + qh:4 * Q], Q - qh, A0, transposed=True)
-                self._pack(key + ".W1^T", W1, A0, A1, transposed=True)
-        # fused history projection: every input-side weight block of every encoder side by side
-        blocks, NX = self._xw_blocks()
-        self.NX = NX
-        bias = self._buf("xw.bias", NX)
-        for _, _, W, b, off, w in blocks:
-            self._pack("xw", W, w, D, o0=off, total=(NX, D))
-            self._cur_descs.append(ops.pack_desc(b, w, 1, bias, 1, ld1=1, o0=off))
-            if training:
-                self._pack("xw^T", W, D, w, transposed=True, i0=off, total=(D, NX))
-        if hp.sequential_model == "time4lstm":
-            t = CL + "short_term/time4lstm/"
-            # [Tn | Tl] (2H) -> [o | tns | tls] (3H) block matrix of the four time kernels
-            for nm, o0, i0 in (("_o_kernel_t1", 0, 0), ("_o_kernel_t2", 0, H), ("_time_kernel_t1", H, 0),
-                               ("_time_kernel_t2", 2 * H, H)):
-                self._pack("t4.tw", P[t + nm], H, H, o0=o0, i0=i0, total=(3 * H, 2 * H))
-                if training:
-                    self._pack("t4.tw^T", P[t + nm], H, H, transposed=True, o0=i0, i0=o0, total=(2 * H, 3 * H))
+        self._plan_att("lt", CL + "long_term/attention_fcn/", D, Du, training)
+        self._plan_att("st", CL + "short_term/attention_fcn/", H, Du + D, training)
+        self._plan_encoders(training)
         pair = self._pack_pair if training else (lambda k, W, K, N, K_pad=None: self._pack(k, W, N, K, in_pad=K_pad))
         if not hp.manual_alpha:
             a = CL + "fcn_alpha/nn_part/"
@@ -571,11 +554,55 @@ class CLSRNet(object):
         pair("lg.W0", P[lg + "w_nn_layer0"], 2 * D, self.L0)
         pair("lg.W1", P[lg + "w_nn_layer1"], self.L0, self.L1)
 
+    def _plan_att(self, key, scope, Dk, Q, training):
+        """Packed weights of one ``_attention_fcn`` block (projection, re-associated first layer, second layer)."""
+        P, A0, A1 = self.P, self.A0, self.A1
+        W0 = P[scope + "att_fcn/nn_part/w_nn_layer0"]
+        W1 = P[scope + "att_fcn/nn_part/w_nn_layer1"]
+        self._pack(key + ".A", P[scope + "attention_mat"], Q, Dk)
+        self._pack(key + ".Wu", W0[0:Q], A0, Q, W2=W0[2 * Q:3 * Q], s2=1.0)
+        self._pack(key + ".Wv", W0[Q:2 * Q], A0, Q, W2=W0[2 * Q:3 * Q], s2=-1.0)
+        self._pack(key + ".Wp", W0[3 * Q:4 * Q], A0, Q)
+        qh = self._att_qh(key)
+        if qh:   # product-term weights split into the history-level and the per-row query columns
+            self._pack(key + ".Wp1", W0[3 * Q:3 * Q + qh], A0, qh)
+            self._pack(key + ".Wp2", W0[3 * Q + qh:4 * Q], A0, Q - qh)
+        self._pack(key + ".W1", W1, A1, A0)
+        if training:
+            self._pack(key + ".A^T", P[scope + "attention_mat"], Dk, Q, transposed=True)
+            self._pack(key + ".Wu^T", W0[0:Q], Q, A0, transposed=True, W2=W0[2 * Q:3 * Q], s2=1.0)
+            self._pack(key + ".Wv^T", W0[Q:2 * Q], Q, A0, transposed=True, W2=W0[2 * Q:3 * Q], s2=-1.0)
+            self._pack(key + ".Wp^T", W0[3 * Q:4 * Q], Q, A0, transposed=True)
+            if qh:
+                self._pack(key + ".Wp1^T", W0[3 * Q:3 * Q + qh], qh, A0, transposed=True)
+                self._pack(key + ".Wp2^T", W0[3 * Q + qh:4 * Q], Q - qh, A0, transposed=True)
+            self._pack(key + ".W1^T", W1, A0, A1, transposed=True)
+
+    def _plan_encoders(self, training):
+        """Fused history projection: every input-side weight block of every encoder side by side."""
+        hp, P, D, H = self.hp, self.P, self.enc_in, self.H
+        blocks, NX = self._xw_blocks()
+        self.NX = NX
+        bias = self._buf("xw.bias", NX)
+        for _, _, W, b, off, w in blocks:
+            self._pack("xw", W, w, D, o0=off, total=(NX, D))
+            self._cur_descs.append(ops.pack_desc(b, w, 1, bias, 1, ld1=1, o0=off))
+            if training:
+                self._pack("xw^T", W, D, w, transposed=True, i0=off, total=(D, NX))
+        if self._t4_kind == "time4lstm":
+            t = self._t4_scope
+            # [Tn | Tl] (2H) -> [o | tns | tls] (3H) block matrix of the four time kernels
+            for nm, o0, i0 in (("_o_kernel_t1", 0, 0), ("_o_kernel_t2", 0, H), ("_time_kernel_t1", H, 0),
+                               ("_time_kernel_t2", 2 * H, H)):
+                self._pack("t4.tw", P[t + nm], H, H, o0=o0, i0=i0, total=(3 * H, 2 * H))
+                if training:
+                    self._pack("t4.tw^T", P[t + nm], H, H, transposed=True, o0=i0, i0=o0, total=(2 * H, 3 * H))
+
     def _unpack_grads(self):
         """Scatter the assembled gradient blocks (fused projection, time kernels) into the variables."""
         plan = self._plans.get("unpack")
         if plan is None:
-            Gd, D, H = self.Gd, self.D, self.H
+            Gd, D, H = self.Gd, self.enc_in, self.H
             blocks, NX = self._xw_blocks()
             dXW, dxb = self._buf("xw.dW", D, NX), self._buf("xw.db", NX)
             descs = []
@@ -593,7 +620,7 @@ class CLSRNet(object):
                     gw, gb = Gd[scopes[key] + gname[kind][0]], Gd[scopes[key] + gname[kind][1]]
                 descs.append(ops.pack_desc(dXW[:, off:], D, w, gw, gw.stride(0), ld1=NX, transposed=True))
                 descs.append(ops.pack_desc(dxb[off:], 1, w, gb, w, ld1=NX, transposed=True))
-            if self.hp.sequential_model == "time4lstm":
+            if self._t4_kind == "time4lstm":
                 dTW = self._buf("t4.dTW", 2 * H, 3 * H)
                 for nm, r0, c0 in (("_o_kernel_t1", 0, 0), ("_o_kernel_t2", H, 0), ("_time_kernel_t1", 0, H),
                                    ("_time_kernel_t2", H, 2 * H)):
@@ -644,8 +671,8 @@ class CLSRNet(object):
         h["labels"] = np.ascontiguousarray(np.asarray(feed["labels"]).reshape(-1), dtype=np.float32)
         h["seq_len"] = seq_len
         rep = hg if compact else 1
-        h["denom"] = np.asarray([float((seq_len > self.hp.contrastive_length_threshold).sum() * rep)],
-                                dtype=np.float32)
+        thr = getattr(self.hp, "contrastive_length_threshold", None) or 0     # (unset for the sibling models)
+        h["denom"] = np.asarray([float((seq_len > thr).sum() * rep)], dtype=np.float32)
         return h, int(mask.shape[0]) * rep, int(mask.shape[1]), compact
 
     _STAGE_SLOTS = 3
@@ -844,7 +871,7 @@ class CLSRNet(object):
 
     # ------------------------------------------------------------------ recurrent encoders
     def _gru_fwd_desc(self, key, scope, n, PinAll, Hn, T, h0, training, want_seq=False):
-        P, D = self.P, self.D
+        P, D = self.P, self.enc_in
         hT = self._buf(key + ".hT", Hn, n)
         seq = self._buf(key + ".seq", Hn, T, n) if want_seq else None
         hprev = self._buf(key + ".hprev", Hn, T, n) if training else None
@@ -856,15 +883,34 @@ class CLSRNet(object):
         return d, hT, seq
 
     def _gru_bwd_desc(self, key, scope, n, dPinAll, Hn, T, dhT, dseq, dh0):
-        P, D = self.P, self.D
+        P, D = self.P, self.enc_in
         Wg, Wc = P[scope + "gates/kernel"], P[scope + "candidate/kernel"]
         return ops.gru_desc(n, Wgh=Wg[D:], ldg=2 * n, Wch=Wc[D:], ldc=n,
                             hprev=self._buf(key + ".hprev", Hn, T, n), gates=self._buf(key + ".gates", Hn, T, 3 * n),
                             dhT=dhT, dout_seq=dseq, dPin=dPinAll[:, self._enc_off(key):], lddp=self.NX, dh0=dh0)
 
+    def _t4_bwd_weights(self, f, dPinAll, Hn, T, hs):
+        """Hidden-to-hidden and time-feature weight gradients of the LSTM-type encoder from its slice of dPin."""
+        Gd, H, NX, E = self.Gd, self.H, self.NX, self.enc_in
+        t, M = self._t4_scope, Hn * T
+        dPt = dPinAll[:, self._enc_off("t4"):]
+        self._dw(self._buf("t4.mprev", Hn, T, H), H, dPt, NX, M, H, 4 * H, Gd[t + "kernel"][E:], 4 * H)
+        if self._t4_kind != "time4lstm":
+            return
+        TT = self._buf("t4.TT", M, 2 * H)
+        self._dw(TT, 2 * H, dPt[:, 3 * H:], NX, M, 2 * H, 3 * H, self._buf("t4.dTW", 2 * H, 3 * H), 3 * H)
+        dTT = self._buf("t4.dTT", M, 2 * H)
+        self._gemm(dPt[:, 3 * H:], NX, "t4.tw^T", M, 3 * H, 2 * H, dTT, 2 * H)
+        parts = query("clsr_t4_time_inputs_bwd_parts", Hn, T, H)
+        tp = self._buf("t4.tpart", 512 * 4 * 128)[: parts * 4 * H]
+        call("clsr_t4_time_inputs_bwd", dTT, TT, f["time_to_now"], f["time_from_first_action"], hs * T, Hn, T, H, tp)
+        for off_, nm in ((0, "_time_input_w1"), (H, "_time_input_w2"), (2 * H, "_time_input_bias1"),
+                         (3 * H, "_time_input_bias2")):
+            self._rp(tp[off_:], parts, 4 * H, H, Gd[t + nm])
+
     def _gru_bwd_hidden(self, key, scope, n, dPinAll, Hn, T):
         """Hidden-to-hidden weight gradients of one GRU from its slice of dPin."""
-        Gd, D, NX = self.Gd, self.D, self.NX
+        Gd, D, NX = self.Gd, self.enc_in, self.NX
         hprev, gates = self._buf(key + ".hprev", Hn, T, n), self._buf(key + ".gates", Hn, T, 3 * n)
         dP = dPinAll[:, self._enc_off(key):]
         M = Hn * T
@@ -1120,22 +1166,8 @@ class CLSRNet(object):
         # input-side weights of every encoder in one reduction; d(hist) in one product
         self._dw(hist, D, dPinAll, NX, M, D, NX, self._buf("xw.dW", D, NX), NX, db=self._buf("xw.db", NX))
         self._gemm(dPinAll, NX, "xw^T", M, NX, D, dhist, D, acc=1)
-        if hp.sequential_model == "lstm":
-            self._dw(self._buf("t4.mprev", Hn, T, H), H, dPinAll[:, t4off:], NX, M, H, 4 * H, Gd[t + "kernel"][D:],
-                     4 * H)
-        elif hp.sequential_model == "time4lstm":
-            TT = self._buf("t4.TT", M, 2 * H)
-            dPt = dPinAll[:, t4off:]
-            self._dw(self._buf("t4.mprev", Hn, T, H), H, dPt, NX, M, H, 4 * H, Gd[t + "kernel"][D:], 4 * H)
-            self._dw(TT, 2 * H, dPt[:, 3 * H:], NX, M, 2 * H, 3 * H, self._buf("t4.dTW", 2 * H, 3 * H), 3 * H)
-            dTT = self._buf("t4.dTT", M, 2 * H)
-            self._gemm(dPt[:, 3 * H:], NX, "t4.tw^T", M, 3 * H, 2 * H, dTT, 2 * H)
-            parts = query("clsr_t4_time_inputs_bwd_parts", Hn, T, H)
-            tp = self._buf("t4.tpart", 512 * 4 * 128)[: parts * 4 * H]
-            call("clsr_t4_time_inputs_bwd", dTT, TT, f["time_to_now"], f["time_from_first_action"], hs * T, Hn, T, H, tp)
-            for off_, nm in ((0, "_time_input_w1"), (H, "_time_input_w2"), (2 * H, "_time_input_bias1"),
-                             (3 * H, "_time_input_bias2")):
-                self._rp(tp[off_:], parts, 4 * H, H, Gd[t + nm])
+        if self._t4_kind is not None:
+            self._t4_bwd_weights(f, dPinAll, Hn, T, hs)
         else:
             self._gru_bwd_hidden("gs", st + "simple_gru/gru_cell/", H, dPinAll, Hn, T)
         if hp.interest_evolve:
@@ -1214,19 +1246,25 @@ class CLSRNet(object):
         call("clsr_flags_compact", self.tab_flags[key], V, ids, cap, count, ws, nws)
         return ids, count, cap
 
+    def _update_spec(self):
+        """(table, partner, reg-norm slot, discrepancy grad scale, discrepancy loss scale, loss slot, Adam clip-norm
+        base slot, number of norm slots) per trained embedding table."""
+        wd = float(self.hp.discrepancy_loss_weight)
+        return (("item", None, 4, 0.0, 0.0, None, 0, 3), ("cate", None, 5, 0.0, 0.0, None, 1, 3),
+                ("user_long", "user_short", 8, -2.0 * wd, -wd, self.losses[3:], 6, 2),
+                ("user_short", "user_long", 9, -2.0 * wd, 0.0, None, 7, 2))
+
     def _apply_updates(self):
         hp = self.hp
         ss = self.sumsq_tab
         Vu, Vi, Vc = self.dims["Vu"], self.dims["Vi"], self.dims["Vc"]
-        l2e, wd = float(hp.embed_l2), float(hp.discrepancy_loss_weight)
-        call("clsr_zero_floats", self.ucount, 1)
-        call("clsr_count_flags", self.tab_flags["user_long"], Vu, self.ucount)
+        l2e = float(hp.embed_l2)
         tb, tg, fl = self.tables, self.tab_grad, self.tab_flags
+        if "user_long" in tb:      # number of distinct users of the batch: the discrepancy loss is a mean over them
+            call("clsr_zero_floats", self.ucount, 1)
+            call("clsr_count_flags", fl["user_long"], Vu, self.ucount)
         lists = {k: self._involved_list(k) for k, t in tb.items() if t.numel() > self.rowlist_min_elems}
-        # (table, partner, reg-norm slot, discrepancy grad scale, discrepancy loss scale, loss slot, adam base, nsum)
-        spec = (("item", None, 4, 0.0, 0.0, None, 0, 3), ("cate", None, 5, 0.0, 0.0, None, 1, 3),
-                ("user_long", "user_short", 8, -2.0 * wd, -wd, self.losses[3:], 6, 2),
-                ("user_short", "user_long", 9, -2.0 * wd, 0.0, None, 7, 2))
+        spec = self._update_spec()
         sweep = []
         for key, partner, slot, dscale, dloss_scale, dloss, base, nsum in spec:
             V, C = tb[key].shape

@@ -133,3 +133,66 @@ def init_tensor(kind, shape, hp, gen):
     if kind == "one":
         return torch.ones(shape)
     return torch.zeros(shape)
+
+
+# ------------------------------------------------------------------------------------------ sibling models
+# The three models of the reference's quick-start that are built from the same pieces as CLSR
+# (examples/00_quick_start/sequential.py:94-205): they share the embedding layer and the logit MLP of
+# SequentialBaseModel (sequential_base_model.py:55-74,354-452) and differ in _build_seq_graph.
+SIB_TABLES = OrderedDict([("item", EMB + "item_embedding"), ("cate", EMB + "cate_embedding")])
+SIBLINGS = ("gru4rec", "din", "sli_rec")
+
+
+def sibling_kind(model_type):
+    """Canonical key for ``hparams.model_type`` (the reference's yaml files spell them GRU4Rec / DIN / sli_rec)."""
+    k = str(model_type).lower()
+    return k if k in SIBLINGS else None
+
+
+def sibling_scopes(kind):
+    """Variable scopes of the model-specific part (TF names; name_scope blocks do not show up in them)."""
+    if kind == "gru4rec":      # gru4rec.py:29-31,66-75: variable_scope("gru4rec"), dynamic_rnn(scope="gru")
+        return dict(gru="sequential/gru4rec/gru/gru_cell/")
+    if kind == "din":          # din.py:21-31 (name_scope only) + sli_rec.py:118 variable_scope("attention_fcn")
+        return dict(att="sequential/attention_fcn/")
+    if kind == "sli_rec":      # sli_rec.py:32-103
+        s = "sequential/sli_rec/"
+        return dict(asvd=s + "long_term_asvd/", t4=s + "rnn/time4lstm/", att=s + "attention_fcn/attention_fcn/",
+                    alpha=s + "fcn_alpha/")
+    raise ValueError("unknown sibling model %r" % (kind,))
+
+
+def sibling_specs(dims, hp, kind):
+    """Ordered (name, shape, init kind) of every variable of GRU4Rec / DIN / SLi-Rec."""
+    Vu, Vi, Vc = dims["Vu"], dims["Vi"], dims["Vc"]
+    Di, Dc, Du, H = hp.item_embedding_dim, hp.cate_embedding_dim, hp.user_embedding_dim, hp.hidden_size
+    D = Di + Dc
+    sc = sibling_scopes(kind)
+    specs = [(UNUSED_TABLE, (Vu, Du), "w"), (SIB_TABLES["item"], (Vi, Di), "w"), (SIB_TABLES["cate"], (Vc, Dc), "w")]
+    if kind == "gru4rec":
+        specs += gru_specs(sc["gru"], D, H)
+        out_dim = H + D
+    elif kind == "din":
+        att = list(hp.att_fcn_layer_sizes)
+        specs.append((sc["att"] + "attention_mat", (D, D), "w"))
+        specs += mlp_specs(sc["att"] + "att_fcn/", 4 * D, att)
+        out_dim = 3 * D
+    else:
+        att = list(hp.att_fcn_layer_sizes)
+        specs += [(sc["asvd"] + "attention_mat", (D, D), "w"), (sc["asvd"] + "query", (hp.attention_size,), "w")]
+        t = sc["t4"]      # Time4LSTM over the ITEM embedding only (sli_rec.py:43-57): input width Di
+        for n_ in ("_time_input_w1", "_time_input_bias1", "_time_input_w2", "_time_input_bias2"):
+            specs.append((t + n_, (H,), "glorot"))
+        specs += [(t + "_time_kernel_w1", (Di, H), "glorot"), (t + "_time_kernel_t1", (H, H), "glorot"),
+                  (t + "_time_bias1", (H,), "glorot"),
+                  (t + "_time_kernel_w2", (Di, H), "glorot"), (t + "_time_kernel_t2", (H, H), "glorot"),
+                  (t + "_time_bias2", (H,), "glorot"),
+                  (t + "_o_kernel_t1", (H, H), "glorot"), (t + "_o_kernel_t2", (H, H), "glorot"),
+                  (t + "kernel", (Di + H, 4 * H), "glorot"), (t + "bias", (4 * H,), "zero")]
+        specs.append((sc["att"] + "attention_mat", (H, D), "w"))
+        specs += mlp_specs(sc["att"] + "att_fcn/", 4 * D, att)
+        if not hp.manual_alpha:
+            specs += mlp_specs(sc["alpha"], 3 * D + 1, att)
+        out_dim = 2 * D
+    specs += mlp_specs("sequential/logit_fcn/", out_dim, list(hp.layer_sizes))
+    return specs

@@ -16,9 +16,9 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from clsr_amd.clsr import CLSRModel, latest_checkpoint  # noqa: E402
+from clsr_amd.clsr import CLSRModel, DINModel, GRU4RecModel, SLI_RECModel, latest_checkpoint  # noqa: E402
 from clsr_amd.deeprec_utils import prepare_hparams  # noqa: E402
-from clsr_amd.sequential_iterator import SASequentialIterator  # noqa: E402
+from clsr_amd.sequential_iterator import SASequentialIterator, SequentialIterator  # noqa: E402
 
 YAML = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "clsr_amd", "config", "clsr.yaml")
 
@@ -70,8 +70,26 @@ def get_model(flags_obj, model_path, summary_path, user_vocab, item_vocab, cate_
     else:
         pairwise_metrics, weighted_metrics = ["mean_mrr", "ndcg@2;4;6", "hit@2;4;6"], ["wauc"]
         max_seq_length, time_unit = (10 if flags_obj.synthetic else 50), "s"
+    device = "cuda:%d" % flags_obj.gpu_id
+    siblings = {"SLIREC": ("sli_rec.yaml", SLI_RECModel), "GRU4REC": ("gru4rec.yaml", GRU4RecModel),
+                "DIN": ("din.yaml", DINModel)}
+    if flags_obj.model in siblings:     # reference :94-119, :157-205: same flags, the model's own yaml
+        yaml_name, cls = siblings[flags_obj.model]
+        extra = dict(manual_alpha=flags_obj.manual_alpha, manual_alpha_value=flags_obj.manual_alpha_value) \
+            if flags_obj.model == "SLIREC" else {}
+        hparams = prepare_hparams(
+            os.path.join(os.path.dirname(YAML), yaml_name), embed_l2=flags_obj.embed_l2, layer_l2=flags_obj.layer_l2,
+            learning_rate=flags_obj.learning_rate, epochs=flags_obj.epochs, EARLY_STOP=flags_obj.early_stop,
+            batch_size=flags_obj.batch_size, show_step=flags_obj.show_step, MODEL_DIR=model_path,
+            SUMMARIES_DIR=summary_path, user_vocab=user_vocab, item_vocab=item_vocab, cate_vocab=cate_vocab,
+            need_sample=True, train_num_ngs=train_num_ngs, max_seq_length=max_seq_length,
+            pairwise_metrics=pairwise_metrics, weighted_metrics=weighted_metrics, time_unit=time_unit, **extra)
+        if dist is not None and dist.get_rank() != 0:
+            hparams.save_model = False
+        return cls(hparams, SequentialIterator, seed=None, device=device, dist=dist)
     if flags_obj.model != "CLSR":
-        raise SystemExit("only --model CLSR is in scope (see SURVEY.md section 2)")
+        raise SystemExit("--model must be CLSR, SLIREC, GRU4REC or DIN (the other quick-start models do not share "
+                         "this path's kernels; SURVEY.md section 2)")
     hparams = prepare_hparams(
         YAML, embed_l2=flags_obj.embed_l2, layer_l2=flags_obj.layer_l2,
         contrastive_loss=flags_obj.contrastive_loss, triplet_margin=flags_obj.triplet_margin,
@@ -88,7 +106,7 @@ def get_model(flags_obj, model_path, summary_path, user_vocab, item_vocab, cate_
         sequential_model=flags_obj.sequential_model, time_unit=time_unit)
     if dist is not None and dist.get_rank() != 0:
         hparams.save_model = False      # replicas are identical: rank 0 writes the checkpoints
-    return CLSRModel(hparams, SASequentialIterator, seed=None, device="cuda:%d" % flags_obj.gpu_id, dist=dist)
+    return CLSRModel(hparams, SASequentialIterator, seed=None, device=device, dist=dist)
 
 
 def init_data_parallel(flags_obj):

@@ -234,6 +234,21 @@ int clsr_att_prod_bwd_ld(const float* daq, int ldd, const float* a, int lda, con
                          int G, int T, int Q, float* da, int ldda, float* dq, int lddq, int accumulate_dq,
                          void* stream);
 
+/* ---- sibling models of the reference that run on the same kernels (clsr_amd/seqnet.py)
+ * SLi-Rec's long-term "A2SVD" attention, models/base_model.py:595-625 (_attention): logits = (x.A).query,
+ * softmax over ALL T steps (no mask: padded steps hold embedding row 0 and take part), out = sum_t w[t] x[t];
+ * att_inputs = x.A comes from clsr_pgemm.  Backward: d att_inputs (written), d inputs (accumulated), per-block
+ * partials of d query [clsr_asvd_att_bwd_parts(Hn)][D].
+ * DIN's masked history sum (models/sequential/din.py:27) = hist_mean * len: clsr_scale_rows_by_len. */
+int clsr_asvd_att_fwd(const float* att_inputs, const float* query, const float* inputs, long Hn, int T, int D,
+                      float* wts, float* out, void* stream);
+int clsr_asvd_att_bwd_parts(long Hn);
+int clsr_asvd_att_bwd(const float* dout, const float* wts, const float* att_inputs, const float* query,
+                      const float* inputs, long Hn, int T, int D, float* d_att_inputs, float* d_inputs,
+                      float* dquery_partial, void* stream);
+int clsr_scale_rows_by_len(const float* src, const int* seq_len, int len_stride, long Hn, int C, float* out,
+                           int accumulate, void* stream);
+
 /* ---- regularisers, clip, Adam: base_model.py:118-159,249-297; clsr.py:73-82 */
 int clsr_adam_tick(double* state, double lr, double beta1, double beta2, void* stream);
 int clsr_dense_reg_norm(const float* param, float* grad, const int* seg_off, int nseg, float l2,

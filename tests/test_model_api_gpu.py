@@ -103,3 +103,42 @@ def test_fit_learns_a_learnable_task(tmp_path):
     assert before["auc"] < 0.62, before
     assert after["auc"] > 0.85 and after["group_auc"] > 0.85 and after["mean_mrr"] > 2.0 * before["mean_mrr"], \
         (before, after)
+
+
+@pytest.mark.parametrize("cls_name,yaml_name", [("GRU4RecModel", "gru4rec.yaml"), ("DINModel", "din.yaml"),
+                                                ("SLI_RECModel", "sli_rec.yaml")])
+def test_sibling_models_fit_eval_predict_checkpoint(cls_name, yaml_name, tmp_path):
+    """The sibling models of the reference's quick-start through the same API: fit on a task with signal lifts the
+    ranking metrics, train() keeps the base-class 5-slot return, predict / checkpoint round trip work."""
+    import clsr_amd.clsr as M
+    from clsr_amd.clsr import latest_checkpoint
+    from clsr_amd.deeprec_utils import prepare_hparams
+    from clsr_amd.sequential_iterator import SequentialIterator
+    from clsr_amd.synthetic import make_tsv_dataset
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    paths = make_tsv_dataset(str(tmp_path / "data"), n_users=400, n_items=1500, n_cates=12, n_train=5000, n_valid=200,
+                             n_test=200, valid_ngs=4, test_ngs=9, max_hist=20, signal=True)
+    hp = prepare_hparams(os.path.join(root, "clsr_amd", "config", yaml_name), user_vocab=paths["user_vocab"],
+                         item_vocab=paths["item_vocab"], cate_vocab=paths["category_vocab"], max_seq_length=20,
+                         batch_size=500, train_num_ngs=4, time_unit="s", is_clip_norm=1, embed_l2=1e-6, layer_l2=1e-6,
+                         learning_rate=0.005, show_step=10 ** 9, save_model=True,
+                         MODEL_DIR=str(tmp_path / "model") + "/", SUMMARIES_DIR=None, write_tfevents=False, epochs=4,
+                         EARLY_STOP=10)
+    cls = getattr(M, cls_name)
+    model = cls(hp, SequentialIterator, seed=7)
+    feed = next(f for f in model.iterator.load_data_from_file(paths["train_data"], batch_num_ngs=4) if f)
+    res = model.train(model.sess, feed)
+    assert len(res) == 5 and res[0] is None and res[4] is None and res[2] >= res[3] > 0
+    before = model.run_eval(paths["test_data"], 9)
+    assert model.fit(paths["train_data"], paths["valid_data"], valid_num_ngs=4, eval_metric="group_auc") is model
+    after = model.run_eval(paths["test_data"], 9)
+    assert before["auc"] < 0.65 and after["auc"] > 0.8 and after["group_auc"] > 0.8, (before, after)
+    out = tmp_path / "pred.txt"
+    model.predict(paths["test_data"], str(out))
+    assert len(out.read_text().strip().split("\n")) == sum(1 for _ in open(paths["test_data"]))
+    ckpt = latest_checkpoint(hp.MODEL_DIR)
+    fresh = cls(hp, SequentialIterator, seed=123)
+    fresh.load_model(ckpt)
+    model.load_model(ckpt)
+    assert fresh.run_eval(paths["valid_data"], 4) == model.run_eval(paths["valid_data"], 4)
