@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="taobao")
     ap.add_argument("--lengths", default="full", choices=["full", "lognormal"])
+    ap.add_argument("--model", default="clsr", choices=["clsr", "gru4rec", "din", "sli_rec"],
+                    help="clsr = the BASELINE metric (default); the sibling models run the same step machinery "
+                         "(clsr_amd/seqnet.py) and report the same metric for comparison")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as ONE captured hipGraph instead of launching it eagerly (slower on "
                          "ROCm 7.2 once the step uses four streams: 5.15 vs 4.63 ms)")
@@ -157,7 +160,14 @@ def main():
     big = cfg["Vi"] >= 10_000_000   # catalogue configs: lazy Adam is mandatory, ids uniform
     hp = build_hparams(cfg, P, **({"optimizer": "lazyadam"} if big else {}))
     dims = dict(Vu=cfg["Vu"], Vi=cfg["Vi"], Vc=cfg["Vc"])
-    net = CLSRNet(hp, dims, device="cuda:%d" % local_rank, seed=0)
+    if args.model == "clsr":
+        net = CLSRNet(hp, dims, device="cuda:%d" % local_rank, seed=0)
+    else:
+        from clsr_amd.seqnet import SeqNet
+
+        hp = build_hparams(cfg, P, model_type=args.model, user_embedding_dim=16,
+                           attention_size=cfg["Di"] + cfg["Dc"], **({"optimizer": "lazyadam"} if big else {}))
+        net = SeqNet(hp, dims, kind=args.model, device="cuda:%d" % local_rank, seed=0)
     if os.environ.get("CLSR_NO_OVERLAP"):
         net.overlap = False
     if os.environ.get("CLSR_DW_EAGER"):
@@ -283,21 +293,23 @@ def main():
                 torch.cuda.empty_cache()
             except RuntimeError as e:   # not enough free HBM on this device
                 roof["hbm_resident_skipped"] = str(e)[:120]
-        Qs, A0 = cfg["Du"] + D, 80
-        a_s, q_s = net._buf("st.a", Hn * T, Qs), net._buf("st.q", B, Qs)
-        U, V, z0 = net._buf("st.U", Hn * T, A0), net._buf("st.V", B, A0), net._buf("st.z0", B * T, A0)
-        Wt, Kp = net.packed["st.Wp"]
+        roof_mfma = None
+        if args.model == "clsr":
+            Qs, A0 = cfg["Du"] + D, 80
+            a_s, q_s = net._buf("st.a", Hn * T, Qs), net._buf("st.q", B, Qs)
+            U, V, z0 = net._buf("st.U", Hn * T, A0), net._buf("st.V", B, A0), net._buf("st.z0", B * T, A0)
+            Wt, Kp = net.packed["st.Wp"]
 
-        def z0_gemm():
-            ops.call("clsr_pgemm", a_s, Qs, T, G, q_s, Qs, None, None, 1, Wt, Kp, None, U, A0, V, A0, z0, A0, 0,
-                     None, B * T, Qs, A0)
+            def z0_gemm():
+                ops.call("clsr_pgemm", a_s, Qs, T, G, q_s, Qs, None, None, 1, Wt, Kp, None, U, A0, V, A0, z0, A0, 0,
+                         None, B * T, Qs, A0)
 
-        t_mm = time_kernel(z0_gemm)
-        flops = 2.0 * B * T * Qs * A0
-        roof_mfma = dict(bound="mfma", kernel="pgemm_fast_kernel<5,MUL,UV,false> (short-term attention layer 0)",
-                         achieved=round(flops / t_mm / 1e12, 2), peak=157.3, unit="TFLOP/s",
-                         frac=round(flops / t_mm / 157.3e12, 4), us_per_launch=round(t_mm * 1e6, 2),
-                         note="fp32-input MFMA (v_mfma_f32_16x16x4_f32); peak = dense fp32 matrix rate")
+            t_mm = time_kernel(z0_gemm)
+            flops = 2.0 * B * T * Qs * A0
+            roof_mfma = dict(bound="mfma", kernel="pgemm_fast_kernel<5,MUL,UV,false> (short-term attention layer 0)",
+                             achieved=round(flops / t_mm / 1e12, 2), peak=157.3, unit="TFLOP/s",
+                             frac=round(flops / t_mm / 157.3e12, 4), us_per_launch=round(t_mm * 1e6, 2),
+                             note="fp32-input MFMA (v_mfma_f32_16x16x4_f32); peak = dense fp32 matrix rate")
 
     out = None
     if rank == 0:
@@ -306,12 +318,17 @@ def main():
             "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[%s]: %s CLSR train step, batch %d positives x5 rows "
+            "config": {"workload": "BASELINE configs[%s]: %s %s train step, batch %d positives x5 rows "
                                    "(B=%d), seq_len %d (%s lengths), Di/Dc/Du/H=%d/%d/%d/%d, Vu/Vi/Vc=%d/%d/%d, "
-                                   "time4lstm + triplet, %s" % (
+                                   "%s%s" % (
                                        {"taobao": "1", "kuaishou": "2", "catalogue100m": "4"}.get(args.config, "?"),
-                                       args.config, P, P * G, T, args.lengths, cfg["Di"], cfg["Dc"], cfg["Du"], cfg["H"],
+                                       args.config, {"clsr": "CLSR", "gru4rec": "GRU4Rec (sibling model)",
+                                                     "din": "DIN (sibling model)",
+                                                     "sli_rec": "SLi-Rec (sibling model)"}[args.model],
+                                       P, P * G, T, args.lengths, cfg["Di"], cfg["Dc"],
+                                       cfg["Du"] if args.model == "clsr" else 16, cfg["H"],
                                        cfg["Vu"], cfg["Vi"], cfg["Vc"],
+                                       "time4lstm + triplet, " if args.model == "clsr" else "",
                                        "lazy Adam (row lists)" if big else "dense Adam"),
                        "global_batch": world * P, "seq_len": T,
                        "parallelism": "dp%d" % world if world > 1 else "single",
@@ -321,7 +338,9 @@ def main():
             "roofline": roof, "roofline_mfma": roof_mfma,
             "loss": float(host_losses[:4].sum()),
         }
-        if world == 1 and not args.no_cpu_baseline and not big:
+        if roof_mfma is None:
+            del out["roofline_mfma"]
+        if world == 1 and not args.no_cpu_baseline and not big and args.model == "clsr":
             out["cpu_baseline"] = cpu_baseline(cfg, seconds=args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if dist is not None:
