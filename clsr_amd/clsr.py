@@ -412,6 +412,11 @@ class DINModel(_SiblingModel):
     kind = "din"
 
 
+class A2SVDModel(_SiblingModel):
+    """Reference ``A2SVDModel`` (models/sequential/asvd.py)."""
+    kind = "a2svd"
+
+
 class SLI_RECModel(_SiblingModel):
     """Reference ``SLI_RECModel`` (models/sequential/sli_rec.py)."""
     kind = "sli_rec"

@@ -140,7 +140,7 @@ def init_tensor(kind, shape, hp, gen):
 # (examples/00_quick_start/sequential.py:94-205): they share the embedding layer and the logit MLP of
 # SequentialBaseModel (sequential_base_model.py:55-74,354-452) and differ in _build_seq_graph.
 SIB_TABLES = OrderedDict([("item", EMB + "item_embedding"), ("cate", EMB + "cate_embedding")])
-SIBLINGS = ("gru4rec", "din", "sli_rec")
+SIBLINGS = ("gru4rec", "din", "sli_rec", "a2svd")
 
 
 def sibling_kind(model_type):
@@ -159,6 +159,8 @@ def sibling_scopes(kind):
         s = "sequential/sli_rec/"
         return dict(asvd=s + "long_term_asvd/", t4=s + "rnn/time4lstm/", att=s + "attention_fcn/attention_fcn/",
                     alpha=s + "fcn_alpha/")
+    if kind == "a2svd":        # asvd.py:31-38
+        return dict(asvd="sequential/a2svd/Attention_layer/")
     raise ValueError("unknown sibling model %r" % (kind,))
 
 
@@ -172,6 +174,9 @@ def sibling_specs(dims, hp, kind):
     if kind == "gru4rec":
         specs += gru_specs(sc["gru"], D, H)
         out_dim = H + D
+    elif kind == "a2svd":
+        specs += [(sc["asvd"] + "attention_mat", (D, D), "w"), (sc["asvd"] + "query", (hp.attention_size,), "w")]
+        out_dim = 2 * D
     elif kind == "din":
         att = list(hp.att_fcn_layer_sizes)
         specs.append((sc["att"] + "attention_mat", (D, D), "w"))

@@ -1,4 +1,4 @@
-"""GRU4Rec, DIN and SLi-Rec on the kernels of the CLSR step.
+"""GRU4Rec, DIN, SLi-Rec and A2SVD on the kernels of the CLSR step.
 
 The reference's quick-start trains these from the same script as CLSR (examples/00_quick_start/sequential.py:94-205);
 they sit on the same ``SequentialBaseModel`` trunk (embeddings + involved-row regulariser + logit MLP + softmax loss +
@@ -6,6 +6,7 @@ clip + Adam) and differ in ``_build_seq_graph``:
 
   GRU4RecModel   models/sequential/gru4rec.py:21-76     dynamic_rnn(GRUCell) final state ++ target
   DINModel       models/sequential/din.py:13-34          target ++ masked history sum ++ _attention_fcn(target, history)
+  A2SVDModel     models/sequential/asvd.py:13-45         A2SVD attention ++ target
   SLI_RECModel   models/sequential/sli_rec.py:25-147     A2SVD attention (unmasked), Time4LSTM over the item embedding,
                                                          _attention_fcn(target, rnn_outputs), alpha fusion
 
@@ -29,7 +30,7 @@ class SeqNet(CLSRNet):
     def __init__(self, hp, dims, kind=None, **kw):
         self.kind = sibling_kind(kind if kind is not None else hp.model_type)
         if self.kind is None:
-            raise ValueError("SeqNet builds gru4rec / din / sli_rec, got %r" % (kind or hp.model_type,))
+            raise ValueError("SeqNet builds gru4rec / din / sli_rec / a2svd, got %r" % (kind or hp.model_type,))
         self.sc = sibling_scopes(self.kind)
         super(SeqNet, self).__init__(hp, dims, **kw)
         if self.kind == "sli_rec":
@@ -54,8 +55,10 @@ class SeqNet(CLSRNet):
         if len(hp.layer_sizes) != 2:
             bad.append("layer_sizes must have two layers")
         D = hp.item_embedding_dim + hp.cate_embedding_dim
-        if self.kind != "gru4rec" and len(hp.att_fcn_layer_sizes or ()) != 2:
+        if self.kind in ("din", "sli_rec") and len(hp.att_fcn_layer_sizes or ()) != 2:
             bad.append("att_fcn_layer_sizes must have two layers")
+        if self.kind == "a2svd" and hp.attention_size != D:
+            bad.append("attention_size must equal item+cate dims (tensordot with query, base_model.py:622)")
         if self.kind == "sli_rec":
             if hp.hidden_size != D:
                 bad.append("hidden_size must equal item+cate dims (alpha fusion of att_fea1 and att_fea2, sli_rec.py:92)")
@@ -98,7 +101,7 @@ class SeqNet(CLSRNet):
     @property
     def out_dim(self):
         """Width of ``model_output`` (the logit MLP's input)."""
-        return {"gru4rec": self.H + self.D, "din": 3 * self.D, "sli_rec": 2 * self.D}[self.kind]
+        return {"gru4rec": self.H + self.D, "din": 3 * self.D, "sli_rec": 2 * self.D, "a2svd": 2 * self.D}[self.kind]
 
     def _plan_weights(self, training):
         hp, P, D, H = self.hp, self.P, self.D, self.H
@@ -112,7 +115,9 @@ class SeqNet(CLSRNet):
                 a = self.sc["alpha"] + "nn_part/"
                 pair("al.W0", P[a + "w_nn_layer0"], self.a_in, self.A0, K_pad=_pad4(self.a_in))
                 pair("al.W1", P[a + "w_nn_layer1"], self.A0, self.A1)
-        if self.kind != "din":
+        elif self.kind == "a2svd":
+            pair("asvd.A", P[self.sc["asvd"] + "attention_mat"], D, D)
+        if self.kind in ("gru4rec", "sli_rec"):
             self._plan_encoders(training)
         pair("lg.W0", P[LG + "w_nn_layer0"], self.out_dim, self.L0)
         pair("lg.W1", P[LG + "w_nn_layer1"], self.L0, self.L1)
@@ -164,6 +169,15 @@ class SeqNet(CLSRNet):
             call("clsr_copy_cols", hT, H, 0, G, B, H, mo, W, 0, 0)
             call("clsr_copy_cols", target, D, 0, 1, B, D, mo, W, H, 0)
             out["final_state"] = hT
+        elif kind == "a2svd":
+            ai = self._buf("asvd.ai", M, D)
+            self._gemm(hist, D, "asvd.A", M, D, D, ai, D)
+            aux()
+            w1, att1 = self._buf("asvd.wts", Hn, T), self._buf("asvd.out", Hn, D)
+            call("clsr_asvd_att_fwd", ai, P[sc["asvd"] + "query"], hist, Hn, T, D, w1, att1)
+            call("clsr_copy_cols", att1, D, 0, G, B, D, mo, W, 0, 0)
+            call("clsr_copy_cols", target, D, 0, 1, B, D, mo, W, D, 0)
+            out.update(asvd_output=att1, w_asvd=w1)
         elif kind == "din":
             hsum = self._buf("hist_sum", Hn, D)
             call("clsr_scale_rows_by_len", hmean, seq_len, ls, Hn, D, hsum, 0)
@@ -265,6 +279,11 @@ class SeqNet(CLSRNet):
             self._gru_bwd_hidden("gs", sc["gru"], H, dPinAll, Hn, T)
             self._dw_flush()
             self._unpack_grads()
+        elif kind == "a2svd":
+            call("clsr_group_sum_cols", dmo, W, 0, G, Hn, D, dL, D, 0, 1)
+            call("clsr_copy_cols", dmo, W, D, 1, B, D, dtarget, D, 0, 1)
+            self._asvd_bwd(dL, hist, dhist, Hn, T)
+            self._dw_flush()
         elif kind == "din":
             call("clsr_copy_cols", dmo, W, 0, 1, B, D, dtarget, D, 0, 1)
             dsum = self._buf("d_hist_sum", Hn, D)
@@ -299,16 +318,7 @@ class SeqNet(CLSRNet):
             self._dw(hist, D, dPinAll, NX, M, E, NX, self._buf("xw.dW", E, NX), NX, db=self._buf("xw.db", NX))
             self._gemm(dPinAll, NX, "xw^T", M, NX, E, dhist, D, acc=1)
             self._t4_bwd_weights(f, dPinAll, Hn, T, hs)
-            # A2SVD attention backward
-            ai, w1 = self._buf("asvd.ai", M, D), self._buf("asvd.wts", Hn, T)
-            dai = self._buf("asvd.dai", M, D)
-            parts = query("clsr_asvd_att_bwd_parts", Hn)
-            qp = self._buf("asvd.qpart", 1024 * 256)[: parts * D]
-            qname = sc["asvd"] + "query"
-            call("clsr_asvd_att_bwd", dL, w1, ai, P[qname], hist, Hn, T, D, dai, dhist, qp)
-            self._rp(qp, parts, D, D, Gd[qname])
-            self._dw(hist, D, dai, D, M, D, D, Gd[sc["asvd"] + "attention_mat"], D)
-            self._gemm(dai, D, "asvd.A^T", M, D, D, dhist, D, acc=1)
+            self._asvd_bwd(dL, hist, dhist, Hn, T)
             self._dw_flush()
             self._unpack_grads()
         self._join()
@@ -324,6 +334,19 @@ class SeqNet(CLSRNet):
         if apply:
             self._apply_updates()
         return out
+
+    def _asvd_bwd(self, dout, hist, dhist, Hn, T):
+        """Backward of the A2SVD attention: d query, d attention_mat, and its two contributions to d(hist)."""
+        P, Gd, D, M, sc = self.P, self.Gd, self.D, Hn * T, self.sc
+        ai, w1 = self._buf("asvd.ai", M, D), self._buf("asvd.wts", Hn, T)
+        dai = self._buf("asvd.dai", M, D)
+        parts = query("clsr_asvd_att_bwd_parts", Hn)
+        qp = self._buf("asvd.qpart", 1024 * 256)[: parts * D]
+        qname = sc["asvd"] + "query"
+        call("clsr_asvd_att_bwd", dout, w1, ai, P[qname], hist, Hn, T, D, dai, dhist, qp)
+        self._rp(qp, parts, D, D, Gd[qname])
+        self._dw(hist, D, dai, D, M, D, D, Gd[sc["asvd"] + "attention_mat"], D)
+        self._gemm(dai, D, "asvd.A^T", M, D, D, dhist, D, acc=1)
 
     def read_losses(self):
         v = self.losses.cpu().tolist()

@@ -5,6 +5,7 @@ torch-CPU restatement of ``_build_seq_graph`` of
 
   GRU4RecModel   models/sequential/gru4rec.py:21-76     dynamic_rnn(GRUCell) final state ++ target
   DINModel       models/sequential/din.py:13-34          target ++ masked history sum ++ _attention_fcn(target, history)
+  A2SVDModel     models/sequential/asvd.py:13-45         A2SVD attention (base_model.py:595-625) ++ target
   SLI_RECModel   models/sequential/sli_rec.py:25-147     A2SVD attention (base_model.py:595-625, UNMASKED softmax over
                                                          all T steps), Time4LSTM over [item emb, t_first, t_now],
                                                          _attention_fcn(target, rnn_outputs), alpha fusion
@@ -33,7 +34,7 @@ def param_specs(dims, hp, kind):
     Vu, Vi, Vc = dims["Vu"], dims["Vi"], dims["Vc"]
     Di, Dc, Du, H = hp.item_embedding_dim, hp.cate_embedding_dim, hp.user_embedding_dim, hp.hidden_size
     D = Di + Dc
-    att = list(hp.att_fcn_layer_sizes) if kind != "gru4rec" else None
+    att = list(hp.att_fcn_layer_sizes) if kind in ("din", "sli_rec") else None
     specs = [(EMB + "user_embedding", (Vu, Du), "w"), (EMB + "item_embedding", (Vi, Di), "w"),
              (EMB + "cate_embedding", (Vc, Dc), "w")]
 
@@ -44,6 +45,10 @@ def param_specs(dims, hp, kind):
     if kind == "gru4rec":
         specs += gru("sequential/gru4rec/gru/gru_cell/", D, H)
         out_dim = H + D
+    elif kind == "a2svd":
+        specs += [("sequential/a2svd/Attention_layer/attention_mat", (D, D), "w"),
+                  ("sequential/a2svd/Attention_layer/query", (hp.attention_size,), "w")]
+        out_dim = 2 * D
     elif kind == "din":
         specs.append(("sequential/attention_fcn/attention_mat", (D, D), "w"))
         specs += _mlp("sequential/attention_fcn/att_fcn/", 4 * D, att)
@@ -132,6 +137,11 @@ def forward(params, bn_state, feed, hp, kind, training, new_bn=None, sites=None)
                                  "sequential/gru4rec/gru/gru_cell/", params)
         model_output = torch.cat([final, target], 1)
         out["final_state"] = final
+    elif kind == "a2svd":
+        a_seq, w = asvd_attention(hist, "sequential/a2svd/Attention_layer/", params)
+        asvd_output = a_seq.sum(1)
+        model_output = torch.cat([asvd_output, target], 1)
+        out.update(asvd_output=asvd_output, w_asvd=w)
     elif kind == "din":
         hist_sum = (hist * real_mask.unsqueeze(-1)).sum(1)
         att_seq, w = C.attention_fcn(target, hist, mask, "sequential/attention_fcn/", params, bn_state, hp,

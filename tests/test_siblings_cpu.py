@@ -10,7 +10,7 @@ import torch
 
 from clsr_amd.params import sibling_kind, sibling_specs
 
-KINDS = {"gru4rec": "GRU4Rec", "din": "DIN", "sli_rec": "sli_rec"}
+KINDS = {"gru4rec": "GRU4Rec", "din": "DIN", "sli_rec": "sli_rec", "a2svd": "A2SVD"}
 
 
 def _hp(golden_hparams, kind, **kw):
@@ -33,7 +33,8 @@ def test_variable_inventory_matches_the_oracle(golden_hparams, kind):
     assert len(names) == len(set(names)) and names[0] == "sequential/embedding/user_embedding"
     expect = {"gru4rec": "sequential/gru4rec/gru/gru_cell/gates/kernel",
               "din": "sequential/attention_fcn/att_fcn/nn_part/w_nn_layer0",
-              "sli_rec": "sequential/sli_rec/attention_fcn/attention_fcn/attention_mat"}[kind]
+              "sli_rec": "sequential/sli_rec/attention_fcn/attention_fcn/attention_mat",
+              "a2svd": "sequential/a2svd/Attention_layer/query"}[kind]
     assert expect in names and "sequential/logit_fcn/nn_part/w_nn_output" in names
 
 
@@ -53,7 +54,7 @@ def test_oracle_graphs_train(golden_dir, golden_hparams, kind):
     bn, adam = O.init_bn_state(params), O.init_adam(params)
     new_p, new_bn, _, ls, grads, norms, out = O.train_step(params, bn, adam, 1, tf, hp, kind)
     assert all(np.isfinite(float(v)) for v in ls.values()) and float(ls["loss"]) > 0
-    if kind == "sli_rec":
+    if kind in ("sli_rec", "a2svd"):
         w = out["w_asvd"]
         assert torch.allclose(w.sum(1), torch.ones_like(w[:, 0])) and float(w[:, -1].min()) > 0   # padded steps too
     ls2 = O.gradients(new_p, new_bn, tf, hp, kind)[0]
