@@ -11,7 +11,7 @@ import re
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 HEADER = os.path.join(ROOT, "include", "clsr_hip.h")
-LIB_PATH = os.path.join(HERE, "libclsr_hip.so")
+LIB_PATH = os.environ.get("CLSR_LIB") or os.path.join(HERE, "libclsr_hip.so")   # CLSR_LIB: A/B builds of the kernels
 
 _CT = {
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
