@@ -83,6 +83,7 @@ class CLSRNet(object):
         self._dw_async = False
         self.split_query = not os.environ.get("CLSR_NO_SPLIT_QUERY")   # A/B switch (see _att_qh)
         self.split_query_min = 64
+        self.split_emb_grad = not os.environ.get("CLSR_SERIAL_EMB_GRAD")   # A/B switch (embedding gradient sites)
         self.dw_streams = int(os.environ.get("CLSR_DW_STREAMS", "1"))
         self._joins = []
         self._dw_pending, self._dw_tables, self._dw_after, self._rp_pending = {}, {}, {}, {}
@@ -272,7 +273,8 @@ class CLSRNet(object):
 
         def __enter__(self):
             net = self.net
-            if not net.overlap:
+            self.inline = (not net.overlap) or self.tag == "@main"     # "@main": stay on the current stream
+            if self.inline:
                 return self
             side = net._side.get(self.tag)
             if side is None:
@@ -292,7 +294,7 @@ class CLSRNet(object):
 
         def __exit__(self, *exc):
             net = self.net
-            if not net.overlap:
+            if self.inline:
                 return False
             ev = torch.cuda.Event()
             ev.record(self.side)
@@ -1182,15 +1184,28 @@ class CLSRNet(object):
         # ---- embedding gradients (IndexedSlices values -> dense grad tables + squared norms)
         ss = self.sumsq_tab
         if self.sorted_hist_grad:
-            # segmented sums over the ids sorted during the forward (119 us vs 350 us for float atomics)
-            self._hist_grad_sorted(dhist, dM, dR, Hn, T, seq_len, ls, ss)
+            # segmented sums over the ids sorted during the forward (119 us vs 350 us for float atomics).  The
+            # lookup sites are independent (distinct norm slots; the two sites of a table meet in fp32 atomics):
+            # category history + category targets, item / user row scatters and the item history run on three
+            # streams that are idle by now instead of one after the other
+            fork = self._fork_point()
+            with self._branch("@lt" if self.split_emb_grad else "@main", after=fork):
+                self._hist_grad_sorted(dhist, dM, dR, Hn, T, seq_len, ls, ss, only="cate")
+                call("clsr_scatter_add_rows", dtarget, D, Di, f["cates"], 1, B, Dc, self.tab_grad["cate"], ss[3:])
+            with self._branch("@aux" if self.split_emb_grad else "@main", after=fork):
+                call("clsr_scatter_add_rows", dtarget, D, 0, f["items"], 1, B, Di, self.tab_grad["item"], ss[2:])
+                call("clsr_scatter_add_rows", dul, Du, 0, f["users"], hs, Hn, Du, self.tab_grad["user_long"], ss[6:])
+                call("clsr_scatter_add_rows", dushort, Du, 0, f["users"], hs, Hn, Du, self.tab_grad["user_short"],
+                     ss[7:])
+            self._hist_grad_sorted(dhist, dM, dR, Hn, T, seq_len, ls, ss, only="item")
+            self._join()
         else:
             call("clsr_gather_hist_bwd", dhist, dM, dR, f["item_history"], f["item_cate_history"], hs * T, seq_len,
                  ls, Hn, T, Di, Dc, hp.contrastive_recent_k, self.tab_grad["item"], self.tab_grad["cate"], ss[0:])
-        call("clsr_scatter_add_rows", dtarget, D, 0, f["items"], 1, B, Di, self.tab_grad["item"], ss[2:])
-        call("clsr_scatter_add_rows", dtarget, D, Di, f["cates"], 1, B, Dc, self.tab_grad["cate"], ss[3:])
-        call("clsr_scatter_add_rows", dul, Du, 0, f["users"], hs, Hn, Du, self.tab_grad["user_long"], ss[6:])
-        call("clsr_scatter_add_rows", dushort, Du, 0, f["users"], hs, Hn, Du, self.tab_grad["user_short"], ss[7:])
+            call("clsr_scatter_add_rows", dtarget, D, 0, f["items"], 1, B, Di, self.tab_grad["item"], ss[2:])
+            call("clsr_scatter_add_rows", dtarget, D, Di, f["cates"], 1, B, Dc, self.tab_grad["cate"], ss[3:])
+            call("clsr_scatter_add_rows", dul, Du, 0, f["users"], hs, Hn, Du, self.tab_grad["user_long"], ss[6:])
+            call("clsr_scatter_add_rows", dushort, Du, 0, f["users"], hs, Hn, Du, self.tab_grad["user_short"], ss[7:])
         if apply:
             self._apply_updates()
         return out
@@ -1212,12 +1227,14 @@ class CLSRNet(object):
             perm = self._buf("sort.perm." + name, n, dtype=torch.int32)
             call("clsr_sort_ids", f[fkey], Hn, T, hs * T, V, keys, perm, ws, nbytes)
 
-    def _hist_grad_sorted(self, dhist, dM, dR, Hn, T, seq_len, ls, ss):
+    def _hist_grad_sorted(self, dhist, dM, dR, Hn, T, seq_len, ls, ss, only=None):
         """IndexedSlices of the history lookups -> dense gradient tables via segmented sums over the
-        sorted ids (no float atomics on hot rows; deterministic)."""
+        sorted ids (no float atomics on hot rows; deterministic).  ``only``: one table ("item" / "cate")."""
         n = Hn * T
         k = self.hp.contrastive_recent_k
         for name, _, V, col0, C, slot in self._sort_tables():
+            if only is not None and name != only:
+                continue
             keys = self._buf("sort.keys." + name, n, dtype=torch.int32)
             perm = self._buf("sort.perm." + name, n, dtype=torch.int32)
             for c0 in range(0, C, 64):   # column blocks of <= 64 floats; squared norms accumulate in the slot
@@ -1263,6 +1280,15 @@ class CLSRNet(object):
         if "user_long" in tb:      # number of distinct users of the batch: the discrepancy loss is a mean over them
             call("clsr_zero_floats", self.ucount, 1)
             call("clsr_count_flags", fl["user_long"], Vu, self.ucount)
+        clip = float(hp.max_grad_norm) if hp.is_clip_norm else 0.0
+        # dense variables (regulariser + norms, Adam clock, Adam) on the @aux stream beside the table regulariser
+        with self._branch("@main" if (self.capture_grads or not self.split_emb_grad) else "@aux"):
+            call("clsr_dense_reg_norm", self.dense, self.dense_grad, self.seg_off, len(self.dense_names),
+                 float(hp.layer_l2), self.dense_sumsq, self.losses[1:])
+            if not self.capture_grads:
+                call("clsr_adam_tick", self.adam_state, float(hp.learning_rate), 0.9, 0.999)
+                call("clsr_dense_adam", self.dense, self.dense_grad, self.dense_m, self.dense_v, self.seg_of,
+                     self.dense_sumsq, clip, self.adam_state, 0.9, 0.999, 1e-8, self.n_dense)
         lists = {k: self._involved_list(k) for k, t in tb.items() if t.numel() > self.rowlist_min_elems}
         spec = self._update_spec()
         sweep = []
@@ -1279,16 +1305,14 @@ class CLSRNet(object):
                               ss[base:].data_ptr(), V, C, nsum, 2, dscale, dloss_scale, 0))
         if sweep:
             ops.multi("clsr_tables_reg_multi", ops.TableDesc, sweep, l2e, self.ucount, self.losses[1:])
-        clip = float(hp.max_grad_norm) if hp.is_clip_norm else 0.0
-        call("clsr_dense_reg_norm", self.dense, self.dense_grad, self.seg_off, len(self.dense_names),
-             float(hp.layer_l2), self.dense_sumsq, self.losses[1:])
         if self.capture_grads:  # test hook: pre-clip gradients (regularisers included) + squared norms
             self.captured = dict(dense={n: g.detach().clone() for n, g in self.Gd.items()},
                                  tables={k: g.detach().clone() for k, g in tg.items()},
                                  dense_sumsq=self.dense_sumsq.clone(), table_sumsq=ss.clone())
-        call("clsr_adam_tick", self.adam_state, float(hp.learning_rate), 0.9, 0.999)
-        call("clsr_dense_adam", self.dense, self.dense_grad, self.dense_m, self.dense_v, self.seg_of,
-             self.dense_sumsq, clip, self.adam_state, 0.9, 0.999, 1e-8, self.n_dense)
+            call("clsr_adam_tick", self.adam_state, float(hp.learning_rate), 0.9, 0.999)
+            call("clsr_dense_adam", self.dense, self.dense_grad, self.dense_m, self.dense_v, self.seg_of,
+                 self.dense_sumsq, clip, self.adam_state, 0.9, 0.999, 1e-8, self.n_dense)
+        self._join()              # the Adam clock ticked on @aux: the table updates below read it
         rest = []
         for key, partner, slot, dscale, dloss_scale, dloss, base, nsum in spec:
             V, C = tb[key].shape
