@@ -231,6 +231,9 @@ extern "C" int clsr_table_adam(float* table, float* grad_table, float* m, float*
 // ---- row-list variants for huge vocabularies (100M-item catalogues): the same math as table_reg / lazy
 // table_adam, but driven by the compacted id list of the involved rows (clsr_flags_compact) instead of a sweep
 // over all V*C elements.  count[0] = number of listed rows (device memory).
+// VW = floats per lane and access (4 when C % 4 == 0: 16-byte pieces of the 128-512 B rows, 4x fewer dependent
+// id loads and address computations; random rows are HBM latency bound, so bytes in flight per lane matter)
+template <int VW>
 __global__ void __launch_bounds__(256) table_reg_rows_kernel(
     const float* __restrict__ table, const float* __restrict__ partner, const int* __restrict__ ids,
     const int* __restrict__ count, int C, float l2, float disc_scale, float disc_loss_scale,
@@ -239,20 +242,35 @@ __global__ void __launch_bounds__(256) table_reg_rows_kernel(
   const float cd = partner ? disc_scale / (ucount[0] * (float)C) : 0.f;
   const float cl = (partner && disc_loss) ? disc_loss_scale / (ucount[0] * (float)C) : 0.f;
   double ss = 0.0, rl = 0.0, dl = 0.0;
-  const long total = (long)count[0] * C;
+  const int QC = C / VW;
+  const long total = (long)count[0] * QC;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / C;
-    const long e = (long)ids[r] * C + (i - r * C);
-    const float p = table[e];
-    float g = l2 * p;
-    if (partner) {
-      const float d = p - partner[e];
-      g += cd * d;
-      dl += (double)d * d;
+    const long r = i / QC;
+    const long e = (long)ids[r] * C + (i - r * QC) * VW;
+    float p[VW], pp[VW], gt[VW];
+    if (VW == 4) {
+      *reinterpret_cast<f32x4*>(p) = ld4(table + e);
+      if (partner) *reinterpret_cast<f32x4*>(pp) = ld4(partner + e);
+      *reinterpret_cast<f32x4*>(gt) = ld4(grad_table + e);
+    } else {
+      p[0] = table[e];
+      if (partner) pp[0] = partner[e];
+      gt[0] = grad_table[e];
     }
-    grad_table[e] += g;
-    ss += (double)g * g;
-    rl += (double)p * p;
+#pragma unroll
+    for (int k = 0; k < VW; ++k) {
+      float g = l2 * p[k];
+      if (partner) {
+        const float d = p[k] - pp[k];
+        g += cd * d;
+        dl += (double)d * d;
+      }
+      gt[k] += g;
+      ss += (double)g * g;
+      rl += (double)p[k] * p[k];
+    }
+    if (VW == 4) st4(grad_table + e, *reinterpret_cast<f32x4*>(gt));
+    else grad_table[e] = gt[0];
   }
   __shared__ double red[3][4];
   ss = block256_sum_d(ss, red[0]); rl = block256_sum_d(rl, red[1]); dl = block256_sum_d(dl, red[2]);
@@ -269,15 +287,21 @@ extern "C" int clsr_table_reg_rows(const float* table, const float* partner, con
                                    double* disc_loss, void* stream) {
   CLSR_CHECK_ARG(table && ids && count && grad_table && sumsq && cap > 0 && C > 0);
   CLSR_CHECK_ARG(!partner || ucount);
-  int blocks = clsr_cdiv((long)cap * C, 256 * 4);
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(table_reg_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, partner, ids,
-                     count, C, l2, disc_scale, disc_loss_scale, ucount, grad_table, sumsq, reg_loss, disc_loss);
+  const bool vec = C % 4 == 0;
+  int blocks = clsr_cdiv((long)cap * C, 256 * 4 * (vec ? 2 : 1));
+  if (blocks > 2048) blocks = 2048;
+  if (vec)
+    hipLaunchKernelGGL(table_reg_rows_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, partner, ids,
+                       count, C, l2, disc_scale, disc_loss_scale, ucount, grad_table, sumsq, reg_loss, disc_loss);
+  else
+    hipLaunchKernelGGL(table_reg_rows_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, partner, ids,
+                       count, C, l2, disc_scale, disc_loss_scale, ucount, grad_table, sumsq, reg_loss, disc_loss);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
 
 // LazyAdam over the listed rows; clears their gradient rows and flags.
+template <int VW>
 __global__ void __launch_bounds__(256) table_adam_rows_kernel(
     float* __restrict__ table, float* __restrict__ grad_table, float* __restrict__ m, float* __restrict__ v,
     unsigned char* __restrict__ flags, const int* __restrict__ ids, const int* __restrict__ count, int C,
@@ -287,20 +311,41 @@ __global__ void __launch_bounds__(256) table_adam_rows_kernel(
   for (int i = 0; i < nsum; ++i) tot += sumsq[(long)i * sumsq_stride];
   const float factor = clip_factor(tot, clip_norm);
   const float lr_t = (float)adam_state[3];
-  const long total = (long)count[0] * C;
+  const int QC = C / VW;
+  const long total = (long)count[0] * QC;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / C;
-    const int c = (int)(i - r * C);
+    const long r = i / QC;
+    const int q = (int)(i - r * QC);
     const long row = ids[r];
-    const long e = row * C + c;
-    const float g = grad_table[e] * factor;
-    const float mm = b1 * m[e] + (1.0f - b1) * g;
-    const float vv = b2 * v[e] + (1.0f - b2) * g * g;
-    m[e] = mm;
-    v[e] = vv;
-    table[e] -= lr_t * mm / (sqrtf(vv) + eps);
-    grad_table[e] = 0.f;
-    if (c == 0) flags[row] = 0;
+    const long e = row * C + (long)q * VW;
+    float g[VW], mo[VW], vo[VW], po[VW];
+    if (VW == 4) {
+      *reinterpret_cast<f32x4*>(g) = ld4(grad_table + e);
+      *reinterpret_cast<f32x4*>(mo) = ld4(m + e);
+      *reinterpret_cast<f32x4*>(vo) = ld4(v + e);
+      *reinterpret_cast<f32x4*>(po) = ld4(table + e);
+    } else {
+      g[0] = grad_table[e]; mo[0] = m[e]; vo[0] = v[e]; po[0] = table[e];
+    }
+#pragma unroll
+    for (int k = 0; k < VW; ++k) {
+      const float gg = g[k] * factor;
+      const float mm = b1 * mo[k] + (1.0f - b1) * gg;
+      const float vv = b2 * vo[k] + (1.0f - b2) * gg * gg;
+      mo[k] = mm;
+      vo[k] = vv;
+      po[k] -= lr_t * mm / (sqrtf(vv) + eps);
+    }
+    if (VW == 4) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      st4(m + e, *reinterpret_cast<f32x4*>(mo));
+      st4(v + e, *reinterpret_cast<f32x4*>(vo));
+      st4(table + e, *reinterpret_cast<f32x4*>(po));
+      st4(grad_table + e, z);
+    } else {
+      m[e] = mo[0]; v[e] = vo[0]; table[e] = po[0]; grad_table[e] = 0.f;
+    }
+    if (q == 0) flags[row] = 0;
   }
 }
 
@@ -310,10 +355,15 @@ extern "C" int clsr_table_adam_rows(float* table, float* grad_table, float* m, f
                                     float beta1, float beta2, float eps, void* stream) {
   CLSR_CHECK_ARG(table && grad_table && m && v && flags && ids && count && sumsq && adam_state && cap > 0 && C > 0);
   CLSR_CHECK_ARG(nsum > 0);
-  int blocks = clsr_cdiv((long)cap * C, 256 * 4);
+  const bool vec = C % 4 == 0;
+  int blocks = clsr_cdiv((long)cap * C, 256 * 4 * (vec ? 2 : 1));
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(table_adam_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, grad_table, m,
-                     v, flags, ids, count, C, sumsq, sumsq_stride, nsum, clip_norm, adam_state, beta1, beta2, eps);
+  if (vec)
+    hipLaunchKernelGGL(table_adam_rows_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, grad_table,
+                       m, v, flags, ids, count, C, sumsq, sumsq_stride, nsum, clip_norm, adam_state, beta1, beta2, eps);
+  else
+    hipLaunchKernelGGL(table_adam_rows_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, grad_table,
+                       m, v, flags, ids, count, C, sumsq, sumsq_stride, nsum, clip_norm, adam_state, beta1, beta2, eps);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
