@@ -84,6 +84,8 @@ class CLSRNet(object):
         self.split_query = not os.environ.get("CLSR_NO_SPLIT_QUERY")   # A/B switch (see _att_qh)
         self.split_query_min = 64
         self.split_emb_grad = not os.environ.get("CLSR_SERIAL_EMB_GRAD")   # A/B switch (embedding gradient sites)
+        self.use_plans = not os.environ.get("CLSR_NO_PLAN")                # replay recorded launch sequences
+        self._step_plans = {}
         self.dw_streams = int(os.environ.get("CLSR_DW_STREAMS", "1"))
         self._joins = []
         self._dw_pending, self._dw_tables, self._dw_after, self._rp_pending = {}, {}, {}, {}
@@ -131,6 +133,39 @@ class CLSRNet(object):
     # ------------------------------------------------------------------ parameters
     # The variable inventory, the trained embedding tables and the recurrent encoders are hooks so that the sibling
     # models of the reference that share these kernels (clsr_amd/seqnet.py) reuse everything below.
+    # ------------------------------------------------------------------ launch plans
+    def _plan_key(self, what, f):
+        hp = self.hp
+        g = lambda k: getattr(hp, k, None)
+        return (what, id(f), ops.stream_ptr(), self.dp_world, self.overlap, self.defer_dw, self.sorted_hist_grad,
+                self.lazy, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("max_grad_norm"), g("is_clip_norm"),
+                g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
+                g("contrastive_length_threshold"), g("manual_alpha_value"))
+
+    def _planned(self, what, f, run):
+        """Run a step eagerly, or replay its recorded launch sequence (``ops.LaunchPlan``) when this exact step --
+        same uploaded feed object (its device arena is persistent), stream, scalars -- has run before.  The second
+        occurrence is the one recorded: the first one allocates workspaces and builds descriptor tables."""
+        if (not self.use_plans) or self.capture_grads or self.dp_stats_hook is not None or ops.recording():
+            return run()
+        key = self._plan_key(what, f)
+        ent = self._step_plans.get(key)
+        if ent is None:
+            self._step_plans[key] = [f, None]          # keeps f alive: id(f) cannot be recycled
+            return run()
+        if ent[1] is None:
+            plan = ops.record_begin()
+            try:
+                plan.result = run()
+            finally:
+                ops.record_end()
+            ent[1] = plan
+            ent.append(self.last_shape)
+            return plan.result
+        ops.replay(ent[1])
+        self.last_shape = ent[2]
+        return ent[1].result
+
     def _param_specs(self):
         return param_specs(self.dims, self.hp)
 
@@ -282,9 +317,8 @@ class CLSRNet(object):
             self.side = side
             ev = self.after
             if ev is None:
-                ev = torch.cuda.Event()
-                ev.record(ops.current_stream())
-            side.wait_event(ev)
+                ev = ops.event_record(ops.current_stream())
+            ops.stream_wait(side, ev)
             self.old_tag, net._ws_tag = net._ws_tag, self.tag
             self.ctx = torch.cuda.stream(side)
             self.ctx.__enter__()
@@ -296,8 +330,7 @@ class CLSRNet(object):
             net = self.net
             if self.inline:
                 return False
-            ev = torch.cuda.Event()
-            ev.record(self.side)
+            ev = ops.event_record(self.side)
             self.scope.__exit__(*exc)
             self.ctx.__exit__(*exc)
             net._ws_tag = self.old_tag
@@ -313,9 +346,7 @@ class CLSRNet(object):
     def _fork_point(self):
         if not self.overlap:
             return None
-        ev = torch.cuda.Event()
-        ev.record(ops.current_stream())
-        return ev
+        return ops.event_record(ops.current_stream())
 
     def _join(self, only=None):
         """The current stream waits for the finished branches (all of them, or those of stream ``only``)."""
@@ -323,7 +354,7 @@ class CLSRNet(object):
         keep = []
         for tag, ev in self._joins:
             if only is None or tag == only:
-                main.wait_event(ev)
+                ops.stream_wait(main, ev)
             else:
                 keep.append((tag, ev))
         self._joins = keep
@@ -382,7 +413,7 @@ class CLSRNet(object):
             side = self._side.get(name)
             if side is None:
                 side = self._side[name] = torch.cuda.Stream(device=self.device)
-            side.wait_event(self._fork_point())
+            ops.stream_wait(side, self._fork_point())
             call("clsr_pgemm_dw_partial", X, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, ldy, M, K, N, ws,
                  stream=side.cuda_stream)
             self._dw_async = True
@@ -408,9 +439,7 @@ class CLSRNet(object):
             for i in range(self.dw_streams):
                 side = self._side.get("@dw%d" % i)
                 if side is not None:
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    ops.current_stream().wait_event(ev)
+                    ops.stream_wait(ops.current_stream(), ops.event_record(side))
             self._dw_async = False
         if pend:
             sig = tuple(pend)
@@ -926,7 +955,9 @@ class CLSRNet(object):
         (training) is launched on a side stream as soon as both attention outputs exist, beside the alpha / logit
         MLPs (the contrastive loss: it needs the interest vectors, not the logits)."""
         with ops.stream_scope():
-            return self._forward(f, training, after_attention, early_aux)
+            if training or after_attention is not None or early_aux is not None:
+                return self._forward(f, training, after_attention, early_aux)
+            return self._planned(("fwd",), f, lambda: self._forward(f, False, None, None))
 
     def _forward(self, f, training, after_attention, early_aux):
         hp, P = self.hp, self.P
@@ -1057,7 +1088,7 @@ class CLSRNet(object):
         self.losses (device doubles: data, regular, contrastive, discrepancy).  Data-parallel runs call
         with apply=False, all-reduce the gradient buffers, then call :meth:`_apply_updates`."""
         with ops.stream_scope():
-            return self._train_step(f, apply)
+            return self._planned(("train", bool(apply)), f, lambda: self._train_step(f, apply))
 
     def _train_step(self, f, apply):
         hp, P, Gd = self.hp, self.P, self.Gd
