@@ -144,6 +144,7 @@ class SequentialBaseModel(BaseModel):
         self._graphs = {}
         self._static = {}
         self._stream = None
+        self._overlap_upload = not os.environ.get("CLSR_NO_OVERLAP_UPLOAD")
         self.best_epoch = 0
         super(SequentialBaseModel, self).__init__(hparams, iterator_creator, graph=graph, seed=seed)
 
@@ -177,16 +178,39 @@ class SequentialBaseModel(BaseModel):
                 ("labels", "users", "items", "cates", "item_history", "item_cate_history", "mask",
                  "time_from_first_action", "time_to_now")}
 
-    def _static_feed(self, feed, training):
+    def _static_feed(self, feed, training, lookahead=False):
         """Copy a numpy feed into static device buffers keyed by (rows, T, mode, layout) through
-        persistent pinned staging buffers (no per-step allocation)."""
+        persistent pinned staging buffers (no per-step allocation).
+
+        ``lookahead`` (training loop): two device arenas per shape are filled in turn, and the copy is issued on the
+        stream of the weight-gradient kernels, which is idle during the forward pass -- staged BEFORE the previous
+        step is launched, batch N+1 crosses PCIe underneath the forward pass of step N (a stream of its own would be
+        the fifth concurrently active one: 7 ms/step)."""
         mask = feed["mask"]
         key = (int(mask.shape[0]), int(mask.shape[1]), bool(training), int(feed.get("hist_group", 0) or 0))
-        st = self._static.get(key)
+        if not lookahead:
+            st = self._static.get(key)
+            if st is None:
+                st = self._static[key] = self.net.upload(feed, training)
+                return key, st, True
+            return key, self.net.upload(feed, training, into=st), False
+        side = self.net._side.get("@dw0")
+        if side is None:
+            side = self.net._side["@dw0"] = torch.cuda.Stream(device=self.net.device)
+        st = self._static.get(("2x",) + key)
         if st is None:
-            st = self._static[key] = self.net.upload(feed, training)
-            return key, st, True
-        return key, self.net.upload(feed, training, into=st), False
+            st = self._static[("2x",) + key] = [[None, None], 0]
+        i = st[1]
+        st[1] ^= 1
+        fresh = st[0][i] is None
+        st[0][i] = self.net.upload(feed, training, into=st[0][i], copy_stream=side)
+        return key, st[0][i], fresh
+
+    @staticmethod
+    def _mark_free(f):
+        ev = torch.cuda.Event()
+        ev.record()
+        f["_free"] = ev
 
     def _stream_ctx(self):
         """All device work of the model runs on one private HIP stream: launches on the legacy
@@ -195,21 +219,31 @@ class SequentialBaseModel(BaseModel):
             self._stream = torch.cuda.Stream(device=self.net.device)
         return torch.cuda.stream(self._stream)
 
-    def _train_step(self, feed):
-        net = self.net
+    def _stage(self, feed, lookahead=False):
+        """Host arrays of one training batch -> an uploaded (or uploading) device feed."""
         with self._stream_ctx():
             if self._dist is not None:
                 from clsr_amd.dp import DataParallel, shard_feed
 
                 if self._dp is None:
-                    self._dp = DataParallel(net, self._dist, sync_bn=self._sync_bn)
+                    self._dp = DataParallel(self.net, self._dist, sync_bn=self._sync_bn)
                 feed = shard_feed(feed, self._dp.rank, self._dp.world, self.train_num_ngs + 1)
-                key, f, _ = self._static_feed(feed, True)
+            key, f, _ = self._static_feed(feed, True, lookahead=lookahead and not self._use_graph)
+            return key, f
+
+    def _run_staged(self, key, f):
+        net = self.net
+        with self._stream_ctx():
+            ready = f.pop("_ready", None)
+            if ready is not None:
+                torch.cuda.current_stream().wait_event(ready)
+            if self._dist is not None:
                 self._dp.train_step(self._dp.prepare(f))
+                self._mark_free(f)
                 return
-            key, f, _ = self._static_feed(feed, True)
             if not self._use_graph:
-                net.train_step(f)       # ~2 ms of host time for ~190 launches, hidden behind the GPU
+                net.train_step(f)       # <1 ms of host time (replayed launch plan), hidden behind the GPU
+                self._mark_free(f)
                 return
             # optional hipGraph replay (one graph per batch shape).  hipGraphLaunch costs ~6.7 ms of
             # host time for this graph on ROCm 7.2, so it only pays when steps are enqueued back to back.
@@ -222,6 +256,9 @@ class SequentialBaseModel(BaseModel):
                 self._graphs[key] = ops.graph_end()
                 return
             ops.graph_launch(g)
+
+    def _train_step(self, feed):
+        self._run_staged(*self._stage(feed))
 
     # ------------------------------------------------------------------ per-step API
     def train(self, sess, feed_dict):
@@ -269,16 +306,27 @@ class SequentialBaseModel(BaseModel):
         net = self.net
         with self._stream_ctx():
             acc = torch.zeros(8, dtype=torch.float64, device=net.device)  # running loss sums stay on the device
+        def run(staged):
+            nonlocal step
+            self._run_staged(*staged)                                         # no host sync per step
+            with self._stream_ctx():
+                ops.call("clsr_add_doubles", acc, net.losses, 8)
+                step += 1
+                if step % self.hparams.show_step == 0:
+                    ls = net.read_losses()                              # synchronises (only when printing)
+                    print("step {0:d} , total_loss: {1:.4f}, data_loss: {2:.4f}".format(step, ls["loss"],
+                                                                                       ls["data_loss"]))
+
+        # one batch of lookahead: batch N+1 is staged (its PCIe copy enqueued) BEFORE step N is launched
+        pending = None
         for batch_data_input in _prefetch(file_iterator):
             if batch_data_input:
-                self._train_step(self._to_arrays(batch_data_input, True))     # no host sync per step
-                with self._stream_ctx():
-                    ops.call("clsr_add_doubles", acc, net.losses, 8)
-                    step += 1
-                    if step % self.hparams.show_step == 0:
-                        ls = net.read_losses()                          # synchronises (only when printing)
-                        print("step {0:d} , total_loss: {1:.4f}, data_loss: {2:.4f}".format(step, ls["loss"],
-                                                                                           ls["data_loss"]))
+                staged = self._stage(self._to_arrays(batch_data_input, True), lookahead=self._overlap_upload)
+                if pending is not None:
+                    run(pending)
+                pending = staged
+        if pending is not None:
+            run(pending)
         with self._stream_ctx():
             return float(acc[:4].sum().item())
 

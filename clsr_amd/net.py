@@ -708,13 +708,19 @@ class CLSRNet(object):
 
     _STAGE_SLOTS = 3
 
-    def upload(self, feed, training, into=None):
+    def upload(self, feed, training, into=None, copy_stream=None):
         """numpy feed -> device tensors (views into ONE device arena).  The arrays are packed into a
         pinned host arena and pulled across PCIe by ``clsr_stage_feed`` -- an ordinary kernel launch on
         the current stream, so the upload never blocks the host behind queued device work.  ``into``
         (a dict returned by an earlier call for the same shape) re-uses the device arena and a ring of
         pinned arenas: no allocation, and a pinned slot is only rewritten once the kernel that read it
-        has completed (event per slot)."""
+        has completed (event per slot).
+
+        ``copy_stream``: the transfer is issued there instead (one asynchronous 4 MB copy) and ``into["_ready"]``
+        holds its completion event: with TWO alternating device arenas and a caller that stages batch N+1 before it
+        launches step N (``SequentialBaseModel.batch_train``), the batch crosses PCIe while the previous step
+        computes.  The caller records ``into["_free"]`` (an event on the compute stream) after the last launch that
+        reads this arena; the copy waits for it."""
         h, B, T, compact = self.host_arrays(feed, training)
         if into is None:
             lay, off = {}, 0
@@ -742,9 +748,18 @@ class CLSRNet(object):
             # plain single-threaded memcpy on purpose: a torch CPU copy_ wakes the whole OpenMP pool,
             # whose spinning workers were measured to stall this thread's kernel launches for ~7 ms/step
             np.copyto(pin_np[o:o + n], arr.reshape(-1).view(np.uint8))
-        call("clsr_stage_feed", into["_dev"], pin.data_ptr(), into["_nbytes"])
-        ev = torch.cuda.Event()
-        ev.record()
+        if copy_stream is None:
+            call("clsr_stage_feed", into["_dev"], pin.data_ptr(), into["_nbytes"])
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            if into.get("_free") is not None:
+                copy_stream.wait_event(into["_free"])
+            with torch.cuda.stream(copy_stream):
+                into["_dev"].copy_(pin, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            into["_ready"] = ev      # the caller makes the compute stream wait for it right before the step
         into["_stage"][slot][1] = ev
         return into
 

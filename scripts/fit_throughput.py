@@ -17,6 +17,8 @@ from clsr_amd.synthetic import make_tsv_dataset  # noqa: E402
 
 
 def main():
+    if os.environ.get("CLSR_SWITCH"):
+        sys.setswitchinterval(float(os.environ["CLSR_SWITCH"]))
     d = "/tmp/clsr_fit_tsv"
     n_train = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
     paths = make_tsv_dataset(d, n_users=20000, n_items=60000, n_cates=4000, n_train=n_train, n_valid=64, n_test=64,
