@@ -260,6 +260,16 @@ def main():
                     note=("tables (%.1f MB) are L2/Infinity-Cache resident at this config; the HBM claim needs the "
                           "100M-item config" % ((cfg["Vi"] * cfg["Di"] + cfg["Vc"] * cfg["Dc"]) * 4 / 1e6))
                     if not big else "38 GB item table, uniform ids: every row read is an HBM read")
+        # the measured copy rate of this device next to the 8 TB/s datasheet figure (1 GiB device-to-device
+        # copy: 1 GiB read + 1 GiB written per launch)
+        try:
+            src_, dst_ = torch.empty(1 << 28, device="cuda"), torch.empty(1 << 28, device="cuda")
+            t_copy = time_kernel(lambda: dst_.copy_(src_), iters=10, warm=2)
+            roof["measured_copy_peak_GBps"] = round(2.0 * (1 << 30) / t_copy / 1e9, 1)
+            roof["frac_of_measured_copy_peak"] = round(roof["achieved"] / roof["measured_copy_peak_GBps"], 4)
+            del src_, dst_
+        except RuntimeError:
+            pass
         if world == 1 and not args.no_catalogue and not big:
             # same kernel on BASELINE configs[4]'s catalogue (100M items x 96 floats + 10k categories x 32, uniform
             # ids: no cache reuse): the table is 38 GB, so every row read is an HBM read
@@ -289,6 +299,9 @@ def main():
                                                     "(WRITE_SIZE 106.5 MB + 2 x FETCH_SIZE 51.1 MB)",
                     bytes_per_launch=float(bbytes), us_per_launch=round(t_big * 1e6, 2),
                     cache_resident_at_benchmarked_config=cache_resident)
+                if "measured_copy_peak_GBps" in cache_resident:
+                    roof["measured_copy_peak_GBps"] = cache_resident["measured_copy_peak_GBps"]
+                    roof["frac_of_measured_copy_peak"] = round(roof["achieved"] / roof["measured_copy_peak_GBps"], 4)
                 del it, ct, hb
                 torch.cuda.empty_cache()
             except RuntimeError as e:   # not enough free HBM on this device
@@ -333,7 +346,8 @@ def main():
                                        "lazy Adam (row lists)" if big else "dense Adam"),
                        "global_batch": world * P, "seq_len": T,
                        "parallelism": "dp%d" % world if world > 1 else "single",
-                       "hipgraph": use_graph, "history_dedup": True,
+                       "hipgraph": use_graph, "launch_plan": bool(getattr(net, "use_plans", False)) and not use_graph,
+                       "history_dedup": True,
                        "batch_norm": ("sync" if args.sync_bn else "per-rank") if world > 1 else "single-device"},
             "rows_per_s": round(value * G, 1),
             "roofline": roof, "roofline_mfma": roof_mfma,
