@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="taobao")
     ap.add_argument("--lengths", default="full", choices=["full", "lognormal"])
-    ap.add_argument("--model", default="clsr", choices=["clsr", "gru4rec", "din", "sli_rec", "a2svd"],
+    ap.add_argument("--model", default="clsr", choices=["clsr", "gru4rec", "din", "sli_rec", "a2svd", "dien"],
                     help="clsr = the BASELINE metric (default); the sibling models run the same step machinery "
                          "(clsr_amd/seqnet.py) and report the same metric for comparison")
     ap.add_argument("--graph", action="store_true",
@@ -338,7 +338,8 @@ def main():
                                        args.config, {"clsr": "CLSR", "gru4rec": "GRU4Rec (sibling model)",
                                                      "din": "DIN (sibling model)",
                                                      "sli_rec": "SLi-Rec (sibling model)",
-                                                     "a2svd": "A2SVD (sibling model)"}[args.model],
+                                                     "a2svd": "A2SVD (sibling model)",
+                                                     "dien": "DIEN (sibling model, relu)"}[args.model],
                                        P, P * G, T, args.lengths, cfg["Di"], cfg["Dc"],
                                        cfg["Du"] if args.model == "clsr" else 16, cfg["H"],
                                        cfg["Vu"], cfg["Vi"], cfg["Vc"],

@@ -465,6 +465,11 @@ class A2SVDModel(_SiblingModel):
     kind = "a2svd"
 
 
+class DIENModel(_SiblingModel):
+    """Reference ``DIENModel`` (models/sequential/dien.py)."""
+    kind = "dien"
+
+
 class SLI_RECModel(_SiblingModel):
     """Reference ``SLI_RECModel`` (models/sequential/sli_rec.py)."""
     kind = "sli_rec"

@@ -98,10 +98,17 @@ struct GruArgs {
   float* dPin;                         // [Hn, T, lddp] (zeros past len); r | u | c blocks of n
   float* dh0;                          // optional [Hn, n]
   int lddp;
+  // attentional update gate (DIEN's VecAttGRUCell, rnn_cell_implement.py:594-623): u <- (1 - att[s, t]) * u.
+  // The Hn sequences are then candidate ROWS: sequence s reads the input projections and the length of history
+  // s / in_div (the rows of a group share the first GRU's outputs, their attention scores differ)
+  const float* att;                    // optional [Hn, T]
+  float* datt;                         // backward: [Hn, T], accumulated with atomics (zeroed by the caller)
+  int in_div;
 };
 
 // xb: LDS exchange area of the workgroup (f32x4 units): fwd uses [0, 2*RNT*64), bwd [0, 3*RNT*64)
-template <int RNT>
+// ATT: the attentional-update-gate variant (own kernels below, so the plain GRU's code and registers are untouched)
+template <int RNT, bool ATT = false>
 __device__ __forceinline__ void gru_fwd_body(const GruArgs& a, const int bx, f32x4* xb) {
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   const int n = a.n, T = a.T;
@@ -121,25 +128,30 @@ __device__ __forceinline__ void gru_fwd_body(const GruArgs& a, const int bx, f32
   for (int kt = 0; kt < RNT; ++kt)
     hs[kt] = (hvalid && 16 * kt + 4 * g < n && a.h0) ? ld4(a.h0 + h * a.h0_stride + 16 * kt + 4 * g) : Z4;
   f32x4 hown = (cval && a.h0) ? ld4(a.h0 + h * a.h0_stride + col) : Z4;
-  const int len = hvalid ? min(a.seq_len[h * a.len_stride], T) : 0;
+  const long hin = ATT ? (hvalid ? h : 0) / a.in_div : (hvalid ? h : 0);   // history of this sequence
+  const int len = hvalid ? min(a.seq_len[hin * a.len_stride], T) : 0;
   const int Tmax = wave_max_i(len);
   // loads are UNCONDITIONAL (clamped addresses, select afterwards): a load under a branch makes the
   // number of outstanding memory operations unknown to the compiler, which then drains the whole queue
   // (s_waitcnt vmcnt(0)) right after issuing the prefetch -- one exposed HBM latency per time step
-  const float* pin = a.Pin + (hvalid ? h : 0) * (long)T * a.ldp + (cval ? col : 0);
+  const float* pin = a.Pin + hin * (long)T * a.ldp + (cval ? col : 0);
+  const float* attp = ATT ? a.att + (hvalid ? h : 0) * (long)T : nullptr;
   f32x4 pn[3];
 #pragma unroll
   for (int gb = 0; gb < 3; ++gb) pn[gb] = sel4(cval && 0 < len, ld4(pin + gb * n), Z4);
+  float an = ATT ? attp[0] : 0.f;
   f32x4* bufA = xb;
   f32x4* bufB = xb + RNT * 64;
   for (int t = 0; t < Tmax; ++t) {
     const bool live = t < len;
     f32x4 accr = pn[0], accu = pn[1], accc = pn[2];
+    const float keep = 1.0f - an;       // (1 - att_score) of this step; exactly 1 without attention
     {  // prefetch next step's input projections
       const bool nl = (t + 1) < len;
       const long tn = t + 1 < T ? t + 1 : t;
 #pragma unroll
       for (int gb = 0; gb < 3; ++gb) pn[gb] = sel4(cval && nl, ld4(pin + tn * a.ldp + gb * n), Z4);
+      if (ATT) an = attp[tn];
     }
     mv1(accr, wr, hs);
     mv1(accu, wu, hs);
@@ -148,7 +160,8 @@ __device__ __forceinline__ void gru_fwd_body(const GruArgs& a, const int bx, f32
     xchg(bufA, w, lane, r * hown, rh);
     mv1(accc, wc, rh);
     const f32x4 c = tanh4(accc);
-    const f32x4 hn = u * hown + (1.0f - u) * c;
+    const f32x4 ue = u * keep;
+    const f32x4 hn = ue * hown + (1.0f - ue) * c;
     if (live && cval) {
       const long pos = h * T + t;
       if (a.hprev) st4(a.hprev + pos * n + col, hown);
@@ -168,7 +181,7 @@ __device__ __forceinline__ void gru_fwd_body(const GruArgs& a, const int bx, f32
   }
 }
 
-template <int RNT>
+template <int RNT, bool ATT = false>
 __device__ __forceinline__ void gru_bwd_body(const GruArgs& a, const int bx, f32x4* xb) {
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   const int n = a.n, T = a.T;
@@ -185,8 +198,10 @@ __device__ __forceinline__ void gru_bwd_body(const GruArgs& a, const int bx, f32
   const int col = 16 * w + 4 * g;
   const bool cval = hvalid && col < n;
   f32x4 dh = (cval && a.dhT) ? ld4(a.dhT + h * n + col) : Z4;
-  const int len = hvalid ? min(a.seq_len[h * a.len_stride], T) : 0;
+  const long hin = ATT ? (hvalid ? h : 0) / a.in_div : (hvalid ? h : 0);
+  const int len = hvalid ? min(a.seq_len[hin * a.len_stride], T) : 0;
   const int Tmax = wave_max_i(len);
+  const float* attp = ATT ? a.att + (hvalid ? h : 0) * (long)T : nullptr;
   if (cval)  // zero dPin past len
     for (int t = len; t < T; ++t) {
       float* dp = a.dPin + (h * T + t) * a.lddp + col;
@@ -207,9 +222,18 @@ __device__ __forceinline__ void gru_bwd_body(const GruArgs& a, const int bx, f32
     f32x4 d = dh;
     if (a.dout_seq) d += ld4(a.dout_seq + posc * n + colc);
     d = sel4(ok, d, Z4);
-    const f32x4 du = d * (hp - c);
-    const f32x4 dcp = d * (1.0f - u) * (1.0f - c * c);
-    f32x4 dhn = d * u;
+    const float keep = ATT ? 1.0f - attp[t] : 1.0f;
+    const f32x4 ue = u * keep;                       // effective update gate (u itself is what was saved)
+    const f32x4 due = d * (hp - c);
+    const f32x4 du = due * keep;
+    const f32x4 dcp = d * (1.0f - ue) * (1.0f - c * c);
+    f32x4 dhn = d * ue;
+    if (ATT) {        // d att[s, t] = - sum over the features of u * d(ue): 4 lanes per sequence, RNT waves
+      float sa = -(u.x * due.x + u.y * due.y + u.z * due.z + u.w * due.w);
+      sa += __shfl_xor(sa, 16);
+      sa += __shfl_xor(sa, 32);
+      if (g == 0 && live && hvalid) atomicAdd(a.datt + h * (long)T + t, sa);
+    }
     f32x4 full[RNT];
     xchg(bufA, w, lane, dcp, full);
     f32x4 drh = Z4;
@@ -643,6 +667,8 @@ static int fill_multi(RnnMultiArgs& m, const clsr_gru_desc* grus, int ngru, cons
     a.dhT = d.dhT; a.dout_seq = d.dout_seq; a.dPin = d.dPin; a.dh0 = d.dh0;
     a.lddp = d.lddp > 0 ? d.lddp : 3 * d.n;
     CLSR_CHECK_SUPPORTED(a.lddp % 4 == 0);
+    a.att = d.att; a.datt = d.datt; a.in_div = d.in_div > 1 ? d.in_div : 1;
+    CLSR_CHECK_ARG(!(backward && d.att && !d.datt));
   }
   if (t4) {
     int rc = check_rnn_shape(Hn, T, t4->n, backward ? t4->ldm : t4->ldp);
@@ -660,6 +686,18 @@ static int fill_multi(RnnMultiArgs& m, const clsr_gru_desc* grus, int ngru, cons
   return CLSR_OK;
 }
 
+// the attentional GRU runs alone (its inputs depend on everything the other encoders produce): own kernels
+template <int RNT>
+__global__ void __launch_bounds__(64 * RNT) augru_fwd_kernel(GruArgs a) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
+  gru_fwd_body<RNT, true>(a, blockIdx.x, xb);
+}
+template <int RNT>
+__global__ void __launch_bounds__(64 * RNT) augru_bwd_kernel(GruArgs a) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
+  gru_bwd_body<RNT, true>(a, blockIdx.x, xb);
+}
+
 static int multi_tiles(const RnnMultiArgs& m) {
   int n = m.has_t4 ? m.t4.n : 0;
   for (int i = 0; i < m.ngru; ++i) n = m.gru[i].n > n ? m.gru[i].n : n;
@@ -671,6 +709,12 @@ extern "C" int clsr_rnn_fwd_multi(const clsr_gru_desc* grus, int ngru, const cls
   RnnMultiArgs m;
   int rc = fill_multi(m, grus, ngru, t4, seq_len, len_stride, Hn, T, false);
   if (rc) return rc;
+  if (ngru > 0 && grus[0].att) {
+    CLSR_CHECK_SUPPORTED(ngru == 1 && !t4);
+    RNN_LAUNCH(augru_fwd_kernel, rnn_tiles(m.gru[0].n), dim3(clsr_cdiv(Hn, 16)), stream, m.gru[0]);
+    CLSR_CHECK_LAUNCH();
+    return CLSR_OK;
+  }
   RNN_LAUNCH(rnn_multi_fwd_kernel, multi_tiles(m), dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), stream, m);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
@@ -681,6 +725,12 @@ extern "C" int clsr_rnn_bwd_multi(const clsr_gru_desc* grus, int ngru, const cls
   RnnMultiArgs m;
   int rc = fill_multi(m, grus, ngru, t4, seq_len, len_stride, Hn, T, true);
   if (rc) return rc;
+  if (ngru > 0 && grus[0].att) {
+    CLSR_CHECK_SUPPORTED(ngru == 1 && !t4);
+    RNN_LAUNCH(augru_bwd_kernel, rnn_tiles(m.gru[0].n), dim3(clsr_cdiv(Hn, 16)), stream, m.gru[0]);
+    CLSR_CHECK_LAUNCH();
+    return CLSR_OK;
+  }
   RNN_LAUNCH(rnn_multi_bwd_kernel, multi_tiles(m), dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), stream, m);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;

@@ -143,3 +143,63 @@ extern "C" int clsr_scale_rows_by_len(const float* src, const int* seq_len, int 
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
+
+// DIEN uses the attention WEIGHTS of _attention_fcn (return_alpha=True, dien.py:47), not its weighted sum: the
+// gradient arrives as d w[r, t].  Masked softmax backward  ds[t] = w[t] * (dw[t] - sum_t' w[t'] dw[t'])  for t < len,
+// 0 past it; per-block partial sums of ds (= d b_nn_output) like clsr_att_score_bwd.  One wave per row.
+__global__ void __launch_bounds__(64) softmax_weights_bwd_kernel(const float* __restrict__ dw,
+                                                                const float* __restrict__ wts,
+                                                                const int* __restrict__ seq_len, int len_stride,
+                                                                long R, int G, int T, float* __restrict__ ds,
+                                                                float* __restrict__ b_partial) {
+  const int lane = threadIdx.x;
+  float p_db = 0.f;
+  for (long r = blockIdx.x; r < R; r += gridDim.x) {
+    const int len = seq_len[(r / G) * len_stride];
+    float dot = 0.f;
+    for (int t = lane; t < T && t < len; t += 64) dot = fmaf(wts[r * T + t], dw[r * T + t], dot);
+    dot = wave_sum(dot);
+    for (int t = lane; t < T; t += 64) {
+      const float v = t < len ? wts[r * T + t] * (dw[r * T + t] - dot) : 0.f;
+      ds[r * T + t] = v;
+      p_db += v;
+    }
+  }
+  p_db = wave_sum(p_db);
+  if (lane == 0) b_partial[blockIdx.x] = p_db;
+}
+
+extern "C" int clsr_softmax_weights_bwd_parts(long R) { return R > 4096 ? 4096 : (R > 0 ? (int)R : 1); }
+
+extern "C" int clsr_softmax_weights_bwd(const float* dw, const float* wts, const int* seq_len, int len_stride,
+                                        long Hn, int G, int T, float* ds, float* b_partial, void* stream) {
+  CLSR_CHECK_ARG(dw && wts && seq_len && ds && b_partial && Hn > 0 && G > 0 && T > 0);
+  const long R = Hn * G;
+  hipLaunchKernelGGL(softmax_weights_bwd_kernel, dim3(clsr_softmax_weights_bwd_parts(R)), dim3(64), 0,
+                     (hipStream_t)stream, dw, wts, seq_len, len_stride, R, G, T, ds, b_partial);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// out[r, :] = a[r, :] * b[r / G, :]   (DIEN's target * hist_embedding_sum feature, dien.py:58); its backward is
+// clsr_att_prod_bwd_ld with T = 1
+__global__ void mul_rows_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int G,
+                                long R, int C, float* __restrict__ out, int ldo) {
+  const long total = R * C;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long r = e / C;
+    const int c = (int)(e - r * C);
+    out[r * ldo + c] = a[r * lda + c] * b[(r / G) * ldb + c];
+  }
+}
+
+extern "C" int clsr_mul_rows(const float* a, int lda, const float* b, int ldb, int G, long R, int C, float* out,
+                             int ldo, void* stream) {
+  CLSR_CHECK_ARG(a && b && out && G > 0 && R >= 0 && C > 0);
+  if (R == 0) return CLSR_OK;
+  int blocks = clsr_cdiv(R * C, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(mul_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, G, R, C, out, ldo);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}

@@ -799,7 +799,7 @@ class CLSRNet(object):
         return out
 
     def _att_bwd(self, key, scope, dout, keys, q, dkeys, Hn, G, T, Dk, Q, seq_len, len_stride, q_hist=None,
-                 dq_hist=None):
+                 dq_hist=None, dw_in=None):
         """Returns dq [R, Q]; accumulates into dkeys [Hn, T, Dk]; writes every dense gradient.  With ``q_hist``
         (see ``_att_qh``) the product-term gradient of the history-level query columns is ACCUMULATED into
         ``dq_hist`` [Hn, qh] and dq[:, :qh] only holds the V-path share."""
@@ -815,9 +815,15 @@ class CLSRNet(object):
         dz0 = self._buf(key + ".dz0", R * T, A0)
         # score / softmax backward per history group: d score, dkeys, d b_out
         ds = self._buf(key + ".ds", R * T)
-        parts = query("clsr_att_score_bwd_parts", Hn)
-        bp = self._buf("att.bp." + key, 4096)[:parts]                 # own buffers per attention: reduced at the flush
-        call("clsr_att_score_bwd", dout, wts, seq_len, len_stride, keys, Hn, G, T, Dk, ds, dkeys, bp)
+        if dw_in is not None:
+            # the caller consumed the attention WEIGHTS (not their weighted sum): the gradient arrives as d w[r, t]
+            parts = query("clsr_softmax_weights_bwd_parts", R)
+            bp = self._buf("att.bp." + key, 4096)[:parts]
+            call("clsr_softmax_weights_bwd", dw_in, wts, seq_len, len_stride, Hn, G, T, ds, bp)
+        else:
+            parts = query("clsr_att_score_bwd_parts", Hn)
+            bp = self._buf("att.bp." + key, 4096)[:parts]             # own buffers per attention: reduced at the flush
+            call("clsr_att_score_bwd", dout, wts, seq_len, len_stride, keys, Hn, G, T, Dk, ds, dkeys, bp)
         self._rp(bp, parts, 1, 1, Gd[nn + "b_nn_output"])
         # dy1 = ds * w_out * relu'(bn1(z1)) is never materialised: one streaming pass for the BN-1 backward sums
         # and d w_out, the coefficient kernel, one streaming pass that writes dz1

@@ -166,7 +166,8 @@ class GruDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("Pin", "Wgh", "Wch", "h0", "hT", "out_seq", "hprev", "gates",
                                                "dhT", "dout_seq", "dPin", "dh0")] + \
                [("h0_stride", ctypes.c_long), ("ldp", ctypes.c_int), ("ldg", ctypes.c_int), ("ldc", ctypes.c_int),
-                ("n", ctypes.c_int), ("lddp", ctypes.c_int), ("pad_", ctypes.c_int)]
+                ("n", ctypes.c_int), ("lddp", ctypes.c_int), ("in_div", ctypes.c_int),
+                ("att", ctypes.c_void_p), ("datt", ctypes.c_void_p)]
 
 
 class T4Desc(ctypes.Structure):
@@ -180,12 +181,13 @@ def _ptr(t):
 
 
 def gru_desc(n, Pin=None, ldp=0, Wgh=None, ldg=0, Wch=None, ldc=0, h0=None, h0_stride=0, hT=None, out_seq=None,
-             hprev=None, gates=None, dhT=None, dout_seq=None, dPin=None, dh0=None, lddp=0):
+             hprev=None, gates=None, dhT=None, dout_seq=None, dPin=None, dh0=None, lddp=0, att=None, datt=None,
+             in_div=1):
     d = GruDesc()
     for k, v in dict(Pin=Pin, Wgh=Wgh, Wch=Wch, h0=h0, hT=hT, out_seq=out_seq, hprev=hprev, gates=gates, dhT=dhT,
-                     dout_seq=dout_seq, dPin=dPin, dh0=dh0).items():
+                     dout_seq=dout_seq, dPin=dPin, dh0=dh0, att=att, datt=datt).items():
         setattr(d, k, _ptr(v))
-    d.h0_stride, d.ldp, d.ldg, d.ldc, d.n, d.lddp, d.pad_ = h0_stride, ldp, ldg, ldc, n, lddp, 0
+    d.h0_stride, d.ldp, d.ldg, d.ldc, d.n, d.lddp, d.in_div = h0_stride, ldp, ldg, ldc, n, lddp, in_div
     return d
 
 

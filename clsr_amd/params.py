@@ -140,7 +140,7 @@ def init_tensor(kind, shape, hp, gen):
 # (examples/00_quick_start/sequential.py:94-205): they share the embedding layer and the logit MLP of
 # SequentialBaseModel (sequential_base_model.py:55-74,354-452) and differ in _build_seq_graph.
 SIB_TABLES = OrderedDict([("item", EMB + "item_embedding"), ("cate", EMB + "cate_embedding")])
-SIBLINGS = ("gru4rec", "din", "sli_rec", "a2svd")
+SIBLINGS = ("gru4rec", "din", "sli_rec", "a2svd", "dien")
 
 
 def sibling_kind(model_type):
@@ -159,6 +159,9 @@ def sibling_scopes(kind):
         s = "sequential/sli_rec/"
         return dict(asvd=s + "long_term_asvd/", t4=s + "rnn/time4lstm/", att=s + "attention_fcn/attention_fcn/",
                     alpha=s + "fcn_alpha/")
+    if kind == "dien":         # dien.py:21-57 (name_scope only): dynamic_rnn scopes "gru1" / "gru2", sli_rec.py:118
+        return dict(gru1="sequential/gru1/gru_cell/", att="sequential/attention_fcn/",
+                    gru2="sequential/gru2/vec_att_gru_cell/")
     if kind == "a2svd":        # asvd.py:31-38
         return dict(asvd="sequential/a2svd/Attention_layer/")
     raise ValueError("unknown sibling model %r" % (kind,))
@@ -177,6 +180,13 @@ def sibling_specs(dims, hp, kind):
     elif kind == "a2svd":
         specs += [(sc["asvd"] + "attention_mat", (D, D), "w"), (sc["asvd"] + "query", (hp.attention_size,), "w")]
         out_dim = 2 * D
+    elif kind == "dien":
+        att = list(hp.att_fcn_layer_sizes)
+        specs += gru_specs(sc["gru1"], D, H)
+        specs.append((sc["att"] + "attention_mat", (H, D), "w"))
+        specs += mlp_specs(sc["att"] + "att_fcn/", 4 * D, att)
+        specs += gru_specs(sc["gru2"], H, H)
+        out_dim = 3 * D + H
     elif kind == "din":
         att = list(hp.att_fcn_layer_sizes)
         specs.append((sc["att"] + "attention_mat", (D, D), "w"))

@@ -1,4 +1,4 @@
-"""GRU4Rec, DIN, SLi-Rec and A2SVD on the kernels of the CLSR step.
+"""GRU4Rec, DIN, DIEN, SLi-Rec and A2SVD on the kernels of the CLSR step.
 
 The reference's quick-start trains these from the same script as CLSR (examples/00_quick_start/sequential.py:94-205);
 they sit on the same ``SequentialBaseModel`` trunk (embeddings + involved-row regulariser + logit MLP + softmax loss +
@@ -7,6 +7,8 @@ clip + Adam) and differ in ``_build_seq_graph``:
   GRU4RecModel   models/sequential/gru4rec.py:21-76     dynamic_rnn(GRUCell) final state ++ target
   DINModel       models/sequential/din.py:13-34          target ++ masked history sum ++ _attention_fcn(target, history)
   A2SVDModel     models/sequential/asvd.py:13-45         A2SVD attention ++ target
+  DIENModel      models/sequential/dien.py:13-64         GRU -> _attention_fcn WEIGHTS -> attentional GRU (one sequence
+                                                         per candidate row) final state, ++ target, history sum, product
   SLI_RECModel   models/sequential/sli_rec.py:25-147     A2SVD attention (unmasked), Time4LSTM over the item embedding,
                                                          _attention_fcn(target, rnn_outputs), alpha fusion
 
@@ -30,7 +32,7 @@ class SeqNet(CLSRNet):
     def __init__(self, hp, dims, kind=None, **kw):
         self.kind = sibling_kind(kind if kind is not None else hp.model_type)
         if self.kind is None:
-            raise ValueError("SeqNet builds gru4rec / din / sli_rec / a2svd, got %r" % (kind or hp.model_type,))
+            raise ValueError("SeqNet builds gru4rec / din / dien / sli_rec / a2svd, got %r" % (kind or hp.model_type,))
         self.sc = sibling_scopes(self.kind)
         super(SeqNet, self).__init__(hp, dims, **kw)
         if self.kind == "sli_rec":
@@ -55,7 +57,7 @@ class SeqNet(CLSRNet):
         if len(hp.layer_sizes) != 2:
             bad.append("layer_sizes must have two layers")
         D = hp.item_embedding_dim + hp.cate_embedding_dim
-        if self.kind in ("din", "sli_rec") and len(hp.att_fcn_layer_sizes or ()) != 2:
+        if self.kind in ("din", "sli_rec", "dien") and len(hp.att_fcn_layer_sizes or ()) != 2:
             bad.append("att_fcn_layer_sizes must have two layers")
         if self.kind == "a2svd" and hp.attention_size != D:
             bad.append("attention_size must equal item+cate dims (tensordot with query, base_model.py:622)")
@@ -84,7 +86,11 @@ class SeqNet(CLSRNet):
 
     # ------------------------------------------------------------------ encoders
     def _gru_list(self):
-        return [("gs", self.sc["gru"], self.H)] if self.kind == "gru4rec" else []
+        if self.kind == "gru4rec":
+            return [("gs", self.sc["gru"], self.H)]
+        if self.kind == "dien":
+            return [("gs", self.sc["gru1"], self.H)]
+        return []
 
     @property
     def _t4_kind(self):
@@ -101,7 +107,8 @@ class SeqNet(CLSRNet):
     @property
     def out_dim(self):
         """Width of ``model_output`` (the logit MLP's input)."""
-        return {"gru4rec": self.H + self.D, "din": 3 * self.D, "sli_rec": 2 * self.D, "a2svd": 2 * self.D}[self.kind]
+        return {"gru4rec": self.H + self.D, "din": 3 * self.D, "sli_rec": 2 * self.D, "a2svd": 2 * self.D,
+                "dien": 3 * self.D + self.H}[self.kind]
 
     def _plan_weights(self, training):
         hp, P, D, H = self.hp, self.P, self.D, self.H
@@ -117,7 +124,18 @@ class SeqNet(CLSRNet):
                 pair("al.W1", P[a + "w_nn_layer1"], self.A0, self.A1)
         elif self.kind == "a2svd":
             pair("asvd.A", P[self.sc["asvd"] + "attention_mat"], D, D)
-        if self.kind in ("gru4rec", "sli_rec"):
+        elif self.kind == "dien":
+            self._plan_att("st", self.sc["att"], H, D, training)
+            # input side of the attentional GRU: [gates (2H) | candidate (H)] over the first GRU's outputs
+            g2 = self.sc["gru2"]
+            bias = self._buf("a2.bias", 3 * H)
+            for W_, b_, off, w in ((P[g2 + "gates/kernel"][0:H], P[g2 + "gates/bias"], 0, 2 * H),
+                                   (P[g2 + "candidate/kernel"][0:H], P[g2 + "candidate/bias"], 2 * H, H)):
+                self._pack("a2.xw", W_, w, H, o0=off, total=(3 * H, H))
+                self._cur_descs.append(ops.pack_desc(b_, w, 1, bias, 1, ld1=1, o0=off))
+                if training:
+                    self._pack("a2.xw^T", W_, H, w, transposed=True, i0=off, total=(H, 3 * H))
+        if self.kind in ("gru4rec", "sli_rec", "dien"):
             self._plan_encoders(training)
         pair("lg.W0", P[LG + "w_nn_layer0"], self.out_dim, self.L0)
         pair("lg.W1", P[LG + "w_nn_layer1"], self.L0, self.L1)
@@ -169,6 +187,33 @@ class SeqNet(CLSRNet):
             call("clsr_copy_cols", hT, H, 0, G, B, H, mo, W, 0, 0)
             call("clsr_copy_cols", target, D, 0, 1, B, D, mo, W, H, 0)
             out["final_state"] = hT
+        elif kind == "dien":
+            NX = self.NX
+            PinAll = self._buf("xw.Pin", M, NX)
+            self._gemm(hist, D, "xw", M, E, NX, PinAll, NX, bias=self._buf("xw.bias", NX))
+            aux()
+            d1, _, rnn1 = self._gru_fwd_desc("gs", sc["gru1"], H, PinAll, Hn, T, None, training, want_seq=True)
+            ops.rnn_multi("clsr_rnn_fwd_multi", [d1], None, seq_len, ls, Hn, T)
+            hsum = self._buf("hist_sum", Hn, D)
+            call("clsr_scale_rows_by_len", hmean, seq_len, ls, Hn, D, hsum, 0)
+            # attention over the first GRU's outputs: only its WEIGHTS are used (return_alpha=True)
+            self._att_fwd("st", sc["att"], rnn1, target, Hn, G, T, H, D, seq_len, ls, training)
+            wts = self._buf("st.wts", B, T)
+            # attentional GRU: one sequence per candidate row, inputs shared by the rows of a history group
+            g2 = sc["gru2"]
+            Pin2 = self._buf("a2.Pin", M, 3 * H)
+            self._gemm(rnn1, H, "a2.xw", M, H, 3 * H, Pin2, 3 * H, bias=self._buf("a2.bias", 3 * H))
+            hT2 = self._buf("a2.hT", B, H)
+            d2 = ops.gru_desc(H, Pin=Pin2, ldp=3 * H, Wgh=P[g2 + "gates/kernel"][H:], ldg=2 * H,
+                              Wch=P[g2 + "candidate/kernel"][H:], ldc=H, hT=hT2,
+                              hprev=self._buf("a2.hprev", B, T, H) if training else None,
+                              gates=self._buf("a2.gates", B, T, 3 * H) if training else None, att=wts, in_div=G)
+            ops.rnn_multi("clsr_rnn_fwd_multi", [d2], None, seq_len, ls, B, T)
+            call("clsr_copy_cols", target, D, 0, 1, B, D, mo, W, 0, 0)
+            call("clsr_copy_cols", hT2, H, 0, 1, B, H, mo, W, D, 0)
+            call("clsr_copy_cols", hsum, D, 0, G, B, D, mo, W, D + H, 0)
+            call("clsr_mul_rows", target, D, hsum, D, G, B, D, mo[:, 2 * D + H:], W)
+            out.update(hist_sum=hsum, rnn_out=rnn1, w_att=wts, final_state=hT2)
         elif kind == "a2svd":
             ai = self._buf("asvd.ai", M, D)
             self._gemm(hist, D, "asvd.A", M, D, D, ai, D)
@@ -238,7 +283,7 @@ class SeqNet(CLSRNet):
         hs = 1 if f.get("compact") else G
         seq_len, ls = f["seq_len"], hs
         M, W = Hn * T, self.out_dim
-        zpool = self._buf("zero_pool", M * (D + H) + B * D * 3 + Hn * (3 * D + H))
+        zpool = self._buf("zero_pool", M * (D + H) + B * D * 3 + Hn * (3 * D + H) + B * T)
         fl = self.tab_flags
 
         def zero_and_mark():
@@ -260,6 +305,7 @@ class SeqNet(CLSRNet):
         dhist, drnn = take(Hn, T, D), take(Hn, T, H)
         dtarget, dS, datt = take(B, D), take(B, D), take(B, D)
         dL, dM, dR, dhT = take(Hn, D), take(Hn, D), take(Hn, D), take(Hn, H)
+        datt = take(B, T)
         out = self._forward(f, True, None, zero_and_mark)
         dlogit = self._buf("dlogit", B)
         Gl = hp.train_num_ngs + 1
@@ -277,6 +323,51 @@ class SeqNet(CLSRNet):
             self._dw(hist, D, dPinAll, NX, M, E, NX, self._buf("xw.dW", E, NX), NX, db=self._buf("xw.db", NX))
             self._gemm(dPinAll, NX, "xw^T", M, NX, E, dhist, D, acc=1)
             self._gru_bwd_hidden("gs", sc["gru"], H, dPinAll, Hn, T)
+            self._dw_flush()
+            self._unpack_grads()
+        elif kind == "dien":
+            NX = self.NX
+            g2 = sc["gru2"]
+            rnn1, wts, target, hsum = out["rnn_out"], out["w_att"], out["target"], out["hist_sum"]
+            call("clsr_copy_cols", dmo, W, 0, 1, B, D, dtarget, D, 0, 1)
+            dhT2 = self._buf("a2.dhT", B, H)
+            call("clsr_copy_cols", dmo, W, D, 1, B, H, dhT2, H, 0, 0)
+            dsum = self._buf("d_hist_sum", Hn, D)
+            call("clsr_group_sum_cols", dmo, W, D + H, G, Hn, D, dsum, D, 0, 0)
+            # product feature target * hist_sum: d target += dp * hist_sum[h], d hist_sum[h] += sum_g dp * target
+            dsum2 = self._buf("d_hist_sum2", Hn, D)
+            call("clsr_att_prod_bwd_ld", dmo[:, 2 * D + H:], W, hsum, D, target, D, Hn, G, 1, D, dsum2, D, dtarget, D, 1)
+            call("clsr_axpby", dsum, dsum, 1.0, dsum2, 1.0, Hn * D)
+            call("clsr_scale_rows_by_len", dsum, seq_len, ls, Hn, D, dM, 0)
+            # attentional GRU backward (row level): d att scores, d input projections per row
+            dPin2 = self._buf("a2.dPin", B * T, 3 * H)
+            hprev2, gates2 = self._buf("a2.hprev", B, T, H), self._buf("a2.gates", B, T, 3 * H)
+            d2 = ops.gru_desc(H, Wgh=P[g2 + "gates/kernel"][H:], ldg=2 * H, Wch=P[g2 + "candidate/kernel"][H:], ldc=H,
+                              hprev=hprev2, gates=gates2, dhT=dhT2, dPin=dPin2, lddp=3 * H, att=wts, datt=datt,
+                              in_div=G)
+            ops.rnn_multi("clsr_rnn_bwd_multi", [d2], None, seq_len, ls, B, T)
+            self._dw(hprev2, H, dPin2, 3 * H, B * T, H, 2 * H, Gd[g2 + "gates/kernel"][H:], 2 * H)
+            self._dw(hprev2, H, dPin2[:, 2 * H:], 3 * H, B * T, H, H, Gd[g2 + "candidate/kernel"][H:], H, Xmul=gates2,
+                     ldmul=3 * H)
+            if G > 1:       # the rows of a group share the inputs: sum their d(input projections)
+                dPin2h = self._buf("a2.dPinH", M, 3 * H)
+                call("clsr_att_z0_bwd_reduce", dPin2, Hn, G, T, 3 * H, dPin2h, self._buf("a2.dV", B, 3 * H))
+            else:
+                dPin2h = dPin2
+            self._dw(rnn1, H, dPin2h, 3 * H, M, H, 2 * H, Gd[g2 + "gates/kernel"][0:H], 2 * H,
+                     db=Gd[g2 + "gates/bias"])
+            self._dw(rnn1, H, dPin2h[:, 2 * H:], 3 * H, M, H, H, Gd[g2 + "candidate/kernel"][0:H], H,
+                     db=Gd[g2 + "candidate/bias"])
+            self._gemm(dPin2h, 3 * H, "a2.xw^T", M, 3 * H, H, drnn, H, acc=1)
+            # attention backward through its weights, then the first GRU
+            dq = self._att_bwd("st", sc["att"], None, rnn1, target, drnn, Hn, G, T, H, D, seq_len, ls, dw_in=datt)
+            call("clsr_copy_cols", dq, D, 0, 1, B, D, dtarget, D, 0, 1)
+            dPinAll = self._buf("xw.dPin", M, NX)
+            ops.rnn_multi("clsr_rnn_bwd_multi", [self._gru_bwd_desc("gs", sc["gru1"], H, dPinAll, Hn, T, None, drnn,
+                                                                     None)], None, seq_len, ls, Hn, T)
+            self._dw(hist, D, dPinAll, NX, M, E, NX, self._buf("xw.dW", E, NX), NX, db=self._buf("xw.db", NX))
+            self._gemm(dPinAll, NX, "xw^T", M, NX, E, dhist, D, acc=1)
+            self._gru_bwd_hidden("gs", sc["gru1"], H, dPinAll, Hn, T)
             self._dw_flush()
             self._unpack_grads()
         elif kind == "a2svd":

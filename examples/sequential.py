@@ -16,7 +16,8 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from clsr_amd.clsr import A2SVDModel, CLSRModel, DINModel, GRU4RecModel, SLI_RECModel, latest_checkpoint  # noqa: E402
+from clsr_amd.clsr import (A2SVDModel, CLSRModel, DIENModel, DINModel, GRU4RecModel, SLI_RECModel,  # noqa: E402
+                           latest_checkpoint)  # noqa: E402
 from clsr_amd.deeprec_utils import prepare_hparams  # noqa: E402
 from clsr_amd.sequential_iterator import SASequentialIterator, SequentialIterator  # noqa: E402
 
@@ -72,7 +73,7 @@ def get_model(flags_obj, model_path, summary_path, user_vocab, item_vocab, cate_
         max_seq_length, time_unit = (10 if flags_obj.synthetic else 50), "s"
     device = "cuda:%d" % flags_obj.gpu_id
     siblings = {"SLIREC": ("sli_rec.yaml", SLI_RECModel), "GRU4REC": ("gru4rec.yaml", GRU4RecModel),
-                "DIN": ("din.yaml", DINModel), "A2SVD": ("asvd.yaml", A2SVDModel)}
+                "DIN": ("din.yaml", DINModel), "A2SVD": ("asvd.yaml", A2SVDModel), "DIEN": ("dien.yaml", DIENModel)}
     if flags_obj.model in siblings:     # reference :94-119, :157-205: same flags, the model's own yaml
         yaml_name, cls = siblings[flags_obj.model]
         extra = dict(manual_alpha=flags_obj.manual_alpha, manual_alpha_value=flags_obj.manual_alpha_value) \
@@ -88,7 +89,7 @@ def get_model(flags_obj, model_path, summary_path, user_vocab, item_vocab, cate_
             hparams.save_model = False
         return cls(hparams, SequentialIterator, seed=None, device=device, dist=dist)
     if flags_obj.model != "CLSR":
-        raise SystemExit("--model must be CLSR, SLIREC, GRU4REC, DIN or A2SVD (the other quick-start models do not share "
+        raise SystemExit("--model must be CLSR, SLIREC, GRU4REC, DIN, DIEN or A2SVD (the other quick-start models do not share "
                          "this path's kernels; SURVEY.md section 2)")
     hparams = prepare_hparams(
         YAML, embed_l2=flags_obj.embed_l2, layer_l2=flags_obj.layer_l2,

@@ -176,7 +176,11 @@ typedef struct clsr_gru_desc {
   const float* Pin; const float* Wgh; const float* Wch; const float* h0;
   float* hT; float* out_seq; float* hprev; float* gates;
   const float* dhT; const float* dout_seq; float* dPin; float* dh0;
-  long h0_stride; int ldp; int ldg; int ldc; int n; int lddp; int pad_;
+  long h0_stride; int ldp; int ldg; int ldc; int n; int lddp; int in_div;
+  /* attentional update gate (DIEN, VecAttGRUCell rnn_cell_implement.py:594-623): u <- (1 - att[s, t]) * u with one
+   * sequence per candidate ROW; sequence s reads Pin / seq_len of history s / in_div.  datt [Hn, T] (backward) is
+   * accumulated with atomics: zero it first.  Both NULL / in_div <= 1: the plain GRU. */
+  const float* att; float* datt;
 } clsr_gru_desc;
 typedef struct clsr_t4_desc {
   const float* Pin; const float* Wm;
@@ -248,6 +252,15 @@ int clsr_asvd_att_bwd(const float* dout, const float* wts, const float* att_inpu
                       float* dquery_partial, void* stream);
 int clsr_scale_rows_by_len(const float* src, const int* seq_len, int len_stride, long Hn, int C, float* out,
                            int accumulate, void* stream);
+/* DIEN (models/sequential/dien.py:13-64): the gradient of _attention_fcn arrives through its WEIGHTS
+ * (return_alpha=True): masked softmax backward ds[r,t] from dw[r,t] + per-block partials of sum(ds);
+ * out[r,:] = a[r,:] * b[r / G,:] for the target * hist_embedding_sum feature (backward: clsr_att_prod_bwd_ld, T = 1).
+ * The attentional GRU itself is clsr_rnn_*_multi with clsr_gru_desc.att set. */
+int clsr_softmax_weights_bwd_parts(long R);
+int clsr_softmax_weights_bwd(const float* dw, const float* wts, const int* seq_len, int len_stride, long Hn, int G,
+                             int T, float* ds, float* b_partial, void* stream);
+int clsr_mul_rows(const float* a, int lda, const float* b, int ldb, int G, long R, int C, float* out, int ldo,
+                  void* stream);
 
 /* ---- regularisers, clip, Adam: base_model.py:118-159,249-297; clsr.py:73-82 */
 int clsr_adam_tick(double* state, double lr, double beta1, double beta2, void* stream);

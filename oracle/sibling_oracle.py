@@ -6,6 +6,8 @@ torch-CPU restatement of ``_build_seq_graph`` of
   GRU4RecModel   models/sequential/gru4rec.py:21-76     dynamic_rnn(GRUCell) final state ++ target
   DINModel       models/sequential/din.py:13-34          target ++ masked history sum ++ _attention_fcn(target, history)
   A2SVDModel     models/sequential/asvd.py:13-45         A2SVD attention (base_model.py:595-625) ++ target
+  DIENModel      models/sequential/dien.py:13-64         GRU, _attention_fcn weights, attentional GRU (VecAttGRUCell)
+                                                         final state ++ target ++ history sum ++ their product
   SLI_RECModel   models/sequential/sli_rec.py:25-147     A2SVD attention (base_model.py:595-625, UNMASKED softmax over
                                                          all T steps), Time4LSTM over [item emb, t_first, t_now],
                                                          _attention_fcn(target, rnn_outputs), alpha fusion
@@ -34,7 +36,7 @@ def param_specs(dims, hp, kind):
     Vu, Vi, Vc = dims["Vu"], dims["Vi"], dims["Vc"]
     Di, Dc, Du, H = hp.item_embedding_dim, hp.cate_embedding_dim, hp.user_embedding_dim, hp.hidden_size
     D = Di + Dc
-    att = list(hp.att_fcn_layer_sizes) if kind in ("din", "sli_rec") else None
+    att = list(hp.att_fcn_layer_sizes) if kind in ("din", "sli_rec", "dien") else None
     specs = [(EMB + "user_embedding", (Vu, Du), "w"), (EMB + "item_embedding", (Vi, Di), "w"),
              (EMB + "cate_embedding", (Vc, Dc), "w")]
 
@@ -45,6 +47,12 @@ def param_specs(dims, hp, kind):
     if kind == "gru4rec":
         specs += gru("sequential/gru4rec/gru/gru_cell/", D, H)
         out_dim = H + D
+    elif kind == "dien":
+        specs += gru("sequential/gru1/gru_cell/", D, H)
+        specs.append(("sequential/attention_fcn/attention_mat", (H, D), "w"))
+        specs += _mlp("sequential/attention_fcn/att_fcn/", 4 * D, list(hp.att_fcn_layer_sizes))
+        specs += gru("sequential/gru2/vec_att_gru_cell/", H, H)
+        out_dim = 3 * D + H
     elif kind == "a2svd":
         specs += [("sequential/a2svd/Attention_layer/attention_mat", (D, D), "w"),
                   ("sequential/a2svd/Attention_layer/query", (hp.attention_size,), "w")]
@@ -107,6 +115,22 @@ def asvd_attention(x, scope, params):
     return x * w.unsqueeze(-1), w
 
 
+def dynamic_augru(x, att, seq_len, scope, params, H):
+    """dynamic_rnn(VecAttGRUCell) (rnn_cell_implement.py:594-623, rnn_dien.py): a GRU whose update gate is scaled by
+    (1 - att_score) of the step; zero output / state copy-through past sequence_length."""
+    Wg, bg = params[scope + "gates/kernel"], params[scope + "gates/bias"]
+    Wc, bc = params[scope + "candidate/kernel"], params[scope + "candidate/bias"]
+    h = torch.zeros(x.shape[0], H, dtype=x.dtype)
+    for t in range(x.shape[1]):
+        ru = torch.sigmoid(torch.cat([x[:, t], h], -1) @ Wg + bg)
+        r, u = ru[:, :H], ru[:, H:]
+        c = torch.tanh(torch.cat([x[:, t], r * h], -1) @ Wc + bc)
+        u = (1.0 - att[:, t:t + 1]) * u
+        nh = u * h + (1 - u) * c
+        h = torch.where((t < seq_len).unsqueeze(-1), nh, h)
+    return h
+
+
 def forward(params, bn_state, feed, hp, kind, training, new_bn=None, sites=None):
     H = hp.hidden_size
     items, cates = feed["items"], feed["cates"]
@@ -137,6 +161,15 @@ def forward(params, bn_state, feed, hp, kind, training, new_bn=None, sites=None)
                                  "sequential/gru4rec/gru/gru_cell/", params)
         model_output = torch.cat([final, target], 1)
         out["final_state"] = final
+    elif kind == "dien":
+        hist_sum = (hist * real_mask.unsqueeze(-1)).sum(1)
+        rnn1, _ = C.dynamic_gru(hist, seq_len, torch.zeros(hist.shape[0], H, dtype=hist.dtype),
+                                "sequential/gru1/gru_cell/", params)
+        _, alphas = C.attention_fcn(target, rnn1, mask, "sequential/attention_fcn/", params, bn_state, hp, training,
+                                    new_bn)
+        final = dynamic_augru(rnn1, alphas, seq_len, "sequential/gru2/vec_att_gru_cell/", params, H)
+        model_output = torch.cat([target, final, hist_sum, target * hist_sum], 1)
+        out.update(hist_sum=hist_sum, rnn_out=rnn1, w_att=alphas, final_state=final)
     elif kind == "a2svd":
         a_seq, w = asvd_attention(hist, "sequential/a2svd/Attention_layer/", params)
         asvd_output = a_seq.sum(1)

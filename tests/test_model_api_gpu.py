@@ -106,7 +106,8 @@ def test_fit_learns_a_learnable_task(tmp_path):
 
 
 @pytest.mark.parametrize("cls_name,yaml_name", [("GRU4RecModel", "gru4rec.yaml"), ("DINModel", "din.yaml"),
-                                                ("SLI_RECModel", "sli_rec.yaml"), ("A2SVDModel", "asvd.yaml")])
+                                                ("SLI_RECModel", "sli_rec.yaml"), ("A2SVDModel", "asvd.yaml"),
+                                                ("DIENModel", "dien.yaml")])
 def test_sibling_models_fit_eval_predict_checkpoint(cls_name, yaml_name, tmp_path):
     """The sibling models of the reference's quick-start through the same API: fit on a task with signal lifts the
     ranking metrics, train() keeps the base-class 5-slot return, predict / checkpoint round trip work."""

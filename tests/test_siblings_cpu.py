@@ -10,7 +10,7 @@ import torch
 
 from clsr_amd.params import sibling_kind, sibling_specs
 
-KINDS = {"gru4rec": "GRU4Rec", "din": "DIN", "sli_rec": "sli_rec", "a2svd": "A2SVD"}
+KINDS = {"gru4rec": "GRU4Rec", "din": "DIN", "sli_rec": "sli_rec", "a2svd": "A2SVD", "dien": "DIEN"}
 
 
 def _hp(golden_hparams, kind, **kw):
@@ -34,7 +34,8 @@ def test_variable_inventory_matches_the_oracle(golden_hparams, kind):
     expect = {"gru4rec": "sequential/gru4rec/gru/gru_cell/gates/kernel",
               "din": "sequential/attention_fcn/att_fcn/nn_part/w_nn_layer0",
               "sli_rec": "sequential/sli_rec/attention_fcn/attention_fcn/attention_mat",
-              "a2svd": "sequential/a2svd/Attention_layer/query"}[kind]
+              "a2svd": "sequential/a2svd/Attention_layer/query",
+              "dien": "sequential/gru2/vec_att_gru_cell/candidate/kernel"}[kind]
     assert expect in names and "sequential/logit_fcn/nn_part/w_nn_output" in names
 
 

@@ -15,7 +15,7 @@ from clsr_amd.params import SIB_TABLES  # noqa: E402
 from clsr_amd.seqnet import SeqNet  # noqa: E402
 
 KINDS = {"gru4rec": dict(model_type="GRU4Rec"), "din": dict(model_type="DIN"), "sli_rec": dict(model_type="sli_rec"),
-         "a2svd": dict(model_type="A2SVD")}
+         "a2svd": dict(model_type="A2SVD"), "dien": dict(model_type="DIEN")}
 
 
 def _hp(golden_hparams, kind, **kw):
@@ -59,7 +59,7 @@ def _setup(hp, kind, dedup):
 
 
 @pytest.mark.parametrize("dedup", [True, False])
-@pytest.mark.parametrize("kind,extra", [("gru4rec", {}), ("din", {}), ("sli_rec", {}), ("a2svd", {}),
+@pytest.mark.parametrize("kind,extra", [("gru4rec", {}), ("din", {}), ("sli_rec", {}), ("a2svd", {}), ("dien", {}),
                                         ("sli_rec", dict(manual_alpha=True, manual_alpha_value=0.3))])
 def test_train_step_matches_oracle(golden_dir, golden_hparams, kind, extra, dedup):
     hp = _hp(golden_hparams, kind, **extra)
@@ -82,6 +82,11 @@ def test_train_step_matches_oracle(golden_dir, golden_hparams, kind, extra, dedu
         _close(got["att_fea2"], out["att_fea2"], 1e-4, 1e-5, "att_fea2")
         if not hp.manual_alpha:
             _close(got["alpha"], out["alpha"], 1e-4, 1e-5, "alpha")
+    if kind == "dien":
+        _close(got["rnn_out"], rep(out["rnn_out"]), 1e-4, 1e-5, "first GRU outputs")
+        _close(got["w_att"], out["w_att"], 1e-4, 1e-6, "attention weights")
+        _close(got["final_state"], out["final_state"], 1e-4, 1e-5, "attentional GRU final state")
+        _close(got["hist_sum"], rep(out["hist_sum"]), 1e-5, 1e-6, "hist_sum")
     if kind == "a2svd":
         _close(got["asvd_output"], rep(out["asvd_output"]), 1e-4, 1e-5, "asvd_output")
         _close(got["w_asvd"], rep(out["w_asvd"]), 1e-4, 1e-6, "A2SVD weights")
@@ -124,7 +129,7 @@ def test_train_step_matches_oracle(golden_dir, golden_hparams, kind, extra, dedu
     assert torch.equal(sd["sequential/embedding/user_embedding"].double(), params["sequential/embedding/user_embedding"])
 
 
-@pytest.mark.parametrize("kind", ["gru4rec", "din", "sli_rec", "a2svd"])
+@pytest.mark.parametrize("kind", ["gru4rec", "din", "sli_rec", "a2svd", "dien"])
 def test_eval_scores_match_oracle(golden_dir, golden_hparams, kind):
     hp = _hp(golden_hparams, kind)
     O, net, params = _setup(hp, kind, True)
