@@ -85,6 +85,7 @@ class CLSRNet(object):
         self.split_query_min = 64
         self.split_emb_grad = not os.environ.get("CLSR_SERIAL_EMB_GRAD")   # A/B switch (embedding gradient sites)
         self.use_plans = not os.environ.get("CLSR_NO_PLAN")                # replay recorded launch sequences
+        self.split_g2 = not os.environ.get("CLSR_NO_SPLIT_G2")             # A/B switch (causal GRU off the main launch)
         self._step_plans = {}
         self.dw_streams = int(os.environ.get("CLSR_DW_STREAMS", "1"))
         self._joins = []
@@ -303,8 +304,8 @@ class CLSRNet(object):
         ``net._join()`` makes the current stream wait for every finished branch.  Works eagerly and under
         hipGraph capture (the event record / wait pairs become graph dependencies)."""
 
-        def __init__(self, net, tag, after=None):
-            self.net, self.tag, self.after = net, tag, after
+        def __init__(self, net, tag, after=None, name=None):
+            self.net, self.tag, self.after, self.name = net, tag, after, name or tag
 
         def __enter__(self):
             net = self.net
@@ -334,14 +335,14 @@ class CLSRNet(object):
             self.scope.__exit__(*exc)
             self.ctx.__exit__(*exc)
             net._ws_tag = self.old_tag
-            net._joins.append((self.tag, ev))
+            net._joins.append((self.name, ev))
             return False
 
-    def _branch(self, tag, after=None):
+    def _branch(self, tag, after=None, name=None):
         """``after``: an event already recorded on the current stream -- the branch then depends on the work up to
         that point only, so the caller can enqueue main-stream work FIRST and the branch second (launch order
         is what the device sees: a branch enqueued ahead of a long main-stream kernel delays that kernel)."""
-        return CLSRNet._Branch(self, tag, after)
+        return CLSRNet._Branch(self, tag, after, name)     # name: what ``_join(only=...)`` refers to (default: tag)
 
     def _fork_point(self):
         if not self.overlap:
@@ -1055,9 +1056,13 @@ class CLSRNet(object):
             d, _, rnn_out = self._gru_fwd_desc("gs", st + "simple_gru/gru_cell/", H, PinAll, Hn, T, None, training,
                                                want_seq=True)
             grus.append(d)
+        g2_side = None
         if (not hp.manual_alpha) and hp.predict_long_short:
             d, fs, _ = self._gru_fwd_desc("g2", CL + "causal2/causal2/gru_cell/", H, PinAll, Hn, T, None, training)
-            grus.append(d)
+            if self.split_g2 and self.overlap and (grus or self._t4_scope is not None):
+                g2_side = d        # only the alpha gate needs this state: off the critical recurrence launch
+            else:
+                grus.append(d)
         # ---- long term attention (independent of the encoders and of the short-term attention) on the side
         #      stream, forked HERE: the T-serial recurrences occupy only ~3 waves per CU, so the long-term chain
         #      runs underneath them instead of beside the big GEMMs.  The recurrence is ENQUEUED FIRST: packets
@@ -1068,6 +1073,8 @@ class CLSRNet(object):
         if self.rnn_first:
             ops.rnn_multi("clsr_rnn_fwd_multi", grus, t4d, seq_len, ls, Hn, T)
         with self._branch("@lt", after=fork):
+            if g2_side is not None:
+                ops.rnn_multi("clsr_rnn_fwd_multi", [g2_side], None, seq_len, ls, Hn, T)
             att_long = self._att_fwd("lt", lt, hist, ulong, Hn, 1, T, D, Du, seq_len, ls, training)
         if not self.rnn_first:
             ops.rnn_multi("clsr_rnn_fwd_multi", grus, t4d, seq_len, ls, Hn, T)
