@@ -238,6 +238,18 @@ int clsr_att_prod_bwd_ld(const float* daq, int ldd, const float* a, int lda, con
                          int G, int T, int Q, float* da, int ldda, float* dq, int lddq, int accumulate_dq,
                          void* stream);
 
+/* ---- host side: tokenizer of the sequential TSV files (io/sequential_iterator.py:72-163, parse_file /
+ * parser_one_line).  Plain C++: vocabulary look-ups (dict.get(token, 0)) through a hash of the pickled dict's keys,
+ * numbers through strtol / strtod, histories flattened with per-line offsets; the time features and the padding
+ * are computed from these arrays in numpy.  clsr_host_tsv_count / _parse return 1 for anything irregular (short
+ * lines, ragged history columns, number syntax outside [0-9.+-eE]) -- the caller then uses the literal parser. */
+void* clsr_host_vocab_create(const char* blob, const long* offsets, const int* ids, long n);
+int clsr_host_vocab_destroy(void* vocab);
+int clsr_host_tsv_count(const char* buf, long nbytes, long* n_lines, long* n_tokens);
+int clsr_host_tsv_parse(const char* buf, long nbytes, const void* user_vocab, const void* item_vocab,
+                        const void* cate_vocab, int* labels, int* users, int* items, int* cates, double* cur_time,
+                        long* hist_off, int* hist_items, int* hist_cates, double* hist_ts);
+
 /* ---- sibling models of the reference that run on the same kernels (clsr_amd/seqnet.py)
  * SLi-Rec's long-term "A2SVD" attention, models/base_model.py:595-625 (_attention): logits = (x.A).query,
  * softmax over ALL T steps (no mask: padded steps hold embedding row 0 and take part), out = sum_t w[t] x[t];

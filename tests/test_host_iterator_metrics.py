@@ -221,3 +221,46 @@ def test_native_mt_replay_equals_python_random():
         src[:, 0] = np.arange(n)
         b = it._sample_negatives_py(items, 4, src)
         assert np.array_equal(a, b) and sa == random.getstate()
+
+
+def test_native_tsv_tokenizer_equals_the_literal_parser(golden_dir, golden_hparams, tmp_path):
+    """clsr_host_tsv_parse + the numpy time features == parse_file / parser_one_line + _columns_of, array for array
+    (both time units, histories longer than max_seq_length, unknown tokens); irregular files are left to the literal
+    parser; iter_data still answers len() and yields the reference-shaped tuples on demand."""
+    import copy
+
+    from clsr_amd import sequential_iterator as S
+
+    if S._native_lib() is None or not hasattr(S._native_lib(), "clsr_host_tsv_parse"):
+        pytest.skip("libclsr_hip.so not built")
+    d = os.path.join(golden_dir, "data")
+    for unit, T in (("s", 10), ("ms", 4)):
+        hp = copy.deepcopy(golden_hparams)
+        hp.time_unit, hp.max_seq_length = unit, T
+        it = SASequentialIterator(hp, None)
+        for name in ("train_data", "valid_data", "test_data"):
+            path = os.path.join(d, name)
+            got = it._parse_columns_native(path)
+            assert got is not None
+            want = it._columns_of("literal:" + name, it.parse_file(path))
+            assert set(got) == set(want)
+            for k, v in want.items():
+                if isinstance(v, np.ndarray):
+                    assert got[k].dtype == v.dtype and np.array_equal(got[k], v), (unit, name, k)
+                else:
+                    assert got[k] == v
+    it = SASequentialIterator(golden_hparams, None)
+    path = os.path.join(d, "train_data")
+    feeds = [f for f in it.load_data_from_file(path, batch_num_ngs=0) if f]
+    lines = it.iter_data[path]
+    assert len(lines) == sum(f["labels"].shape[0] for f in feeds)
+    assert lines._lines is None                       # nobody asked for the tuples: never parsed line by line
+    first = lines[0]
+    assert len(first) == 10 and first[0] in (0, 1) and lines._lines is not None
+    # irregular inputs: ragged history columns, a short line, a non-numeric timestamp -> the literal parser decides
+    good = open(path).readline()
+    w = good.rstrip("\n").split("\t")
+    for bad in ("\t".join(w[:5] + [w[5] + ",i1"] + w[6:]), "\t".join(w[:7]), "\t".join(w[:4] + ["abc"] + w[5:])):
+        p = tmp_path / "bad.tsv"
+        p.write_text(good + bad + "\n")
+        assert it._parse_columns_native(str(p)) is None
