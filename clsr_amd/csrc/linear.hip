@@ -377,7 +377,13 @@ __global__ void __launch_bounds__(256) pgemm_fast_kernel(PGemmArgs a) {
           v.z = y.z > 0.f ? v.z : 0.f; v.w = y.w > 0.f ? v.w : 0.f;
           w2 = (zz - ld4(a.e_mean + nc)) * ld4(a.e_invstd + nc);
         }
-        if (ok) st4(yp, v);
+        // the first attention layer's output (U + V + product epilogue: 65-330 MB, next read a kernel later) is
+        // stored non-temporally: streamed through the write-back L2 / Infinity Cache it costs this GEMM 15 %
+        // (213 -> 181 us alone) and evicts the history-level operands it re-reads.  Decided per variant at COMPILE
+        // time: a run-time flag around the two store flavours gave the gain back, and the other large outputs
+        // (dy0, daq, z1: read back by the very next kernel) lose with the same treatment -- all measured A/B
+        if (EPI & EPI_UV) { if (ok) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(yp)); }
+        else if (ok) st4(yp, v);
         if (STATS) {
           const f32x4 vm = ok ? v : zero4;
           fsum[ot][0] += vm.x; fsq[ot][0] = fmaf(vm.x, w2.x, fsq[ot][0]);
