@@ -183,3 +183,71 @@ def test_model_train_with_two_ranks_matches_single_process(golden_dir, golden_hp
         assert abs(a - b) < 1e-12 and abs(a - c) < 1e-4 * max(1.0, abs(c)), (a, b, c)
     np.testing.assert_allclose(out[0]["item"], single.net.tables["item"].cpu().numpy(), rtol=1e-3, atol=2e-6)
     np.testing.assert_array_equal(out[0]["item"], out[1]["item"])      # replicas stay bit-identical
+
+
+def _sibling_worker(rank, world, port, hp, dims, kind, feed, sd, out):
+    import torch.distributed as dist
+
+    from clsr_amd.dp import DataParallel, shard_feed
+    from clsr_amd.seqnet import SeqNet
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = SeqNet(hp, dims, kind=kind, device="cuda:0", seed=rank)
+    if rank == 0:
+        net.load_state_dict(sd)
+    dp = DataParallel(net, _HostStagedDist(dist), sync_bn=True, sparse_tables="auto")
+    net.capture_grads = True
+    dp.train_step(dp.prepare(net.upload(shard_feed(feed, rank, world, hp.train_num_ngs + 1), True)))
+    torch.cuda.synchronize()
+    if rank == 0:
+        out["grads"] = {k: v.cpu().numpy() for k, v in net.captured["dense"].items()}
+        out["tgrads"] = {k: v.cpu().numpy() for k, v in net.captured["tables"].items()}
+        out["losses"] = net.read_losses()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,model_type", [("sli_rec", "sli_rec"), ("dien", "DIEN")])
+def test_sibling_models_two_ranks_match_single_process(golden_dir, golden_hparams, kind, model_type):
+    """The sibling models go through the same DataParallel exchange (two trained tables instead of four)."""
+    import pickle
+
+    import torch.multiprocessing as mp
+
+    from clsr_amd.seqnet import SeqNet
+    from oracle import sibling_oracle as O
+
+    hp = copy.deepcopy(golden_hparams)
+    hp.model_type, hp.user_embedding_dim, hp.attention_size = model_type, 16, 40
+    dims = dict(Vu=len(pickle.load(open(hp.user_vocab, "rb"))), Vi=len(pickle.load(open(hp.item_vocab, "rb"))),
+                Vc=len(pickle.load(open(hp.cate_vocab, "rb"))))
+    g = np.load(os.path.join(golden_dir, "iterator_train_sa.npz"))
+    feed = {k[3:]: g[k] for k in g.files if k.startswith("b0_")}
+    params = O.init_params(dims, hp, kind, seed=5, scale_dense=8.0)
+    sd = dict(params)
+    sd.update(O.init_bn_state(params))
+    single = SeqNet(hp, dims, kind=kind, device="cuda:0", seed=0)
+    single.load_state_dict(sd)
+    single.capture_grads = True
+    single.train_step(single.upload(feed, True))
+    torch.cuda.synchronize()
+    ref_losses = single.read_losses()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    mp.spawn(_sibling_worker, args=(2, port, hp, dims, kind, feed, sd, out), nprocs=2, join=True)
+    for k in ("loss", "data_loss", "regular_loss"):
+        assert abs(out["losses"][k] - ref_losses[k]) < 1e-5 * max(1.0, abs(ref_losses[k])), (k, out["losses"], ref_losses)
+    ref_g = {k: v.cpu().numpy() for k, v in single.captured["dense"].items()}
+    floor = 4e-6 * max(float(np.abs(v).max()) for v in ref_g.values())
+    for k, v in ref_g.items():
+        d = np.abs(out["grads"][k] - v)
+        assert float(d.max()) <= 2e-3 * float(np.abs(v).max()) + floor, (k, float(d.max()), float(np.abs(v).max()))
+    for k, v in single.captured["tables"].items():
+        v = v.cpu().numpy()
+        assert float(np.abs(out["tgrads"][k] - v).max()) <= 2e-3 * float(np.abs(v).max()) + floor, k
