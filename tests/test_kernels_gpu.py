@@ -756,3 +756,114 @@ def test_touched_row_compaction_pack_unpack(V, C, frac):
     exp = table.clone()
     exp[exp_ids.long()] *= 2
     assert torch.equal(dst.cpu(), exp) and torch.equal(f2.cpu(), flags)
+
+
+# ------------------------------------------------------------------------------- sibling-model kernels
+@pytest.mark.parametrize("Hn,G,T,n", [(7, 5, 10, 40), (5, 1, 50, 40), (3, 4, 9, 128)])
+def test_attentional_gru_fwd_bwd(Hn, G, T, n):
+    """clsr_rnn_*_multi with clsr_gru_desc.att (DIEN's VecAttGRUCell): one sequence per candidate row reading the
+    input projections / length of its history (in_div = G), update gate scaled by 1 - att; backward incl. d att."""
+    from oracle import sibling_oracle as S
+
+    g = torch.Generator().manual_seed(T + Hn + n)
+    B, Hin = Hn * G, 24
+    x = rnd(g, Hn, T, Hin).requires_grad_(True)
+    Wg = (rnd(g, Hin + n, 2 * n) * 0.3).requires_grad_(True)
+    bg = (rnd(g, 2 * n) * 0.1 + 1).requires_grad_(True)
+    Wc = (rnd(g, Hin + n, n) * 0.3).requires_grad_(True)
+    bc = (rnd(g, n) * 0.1).requires_grad_(True)
+    att = torch.rand(B, T, generator=g, dtype=torch.float64).requires_grad_(True)
+    lens = torch.randint(1, T + 1, (Hn,), generator=g)
+    lens[0] = T
+    params = {"gates/kernel": Wg, "gates/bias": bg, "candidate/kernel": Wc, "candidate/bias": bc}
+    xr = x.repeat_interleave(G, 0)
+    hT = S.dynamic_augru(xr, att, lens.repeat_interleave(G), "", params, n)
+    up = rnd(g, B, n)
+    (hT * up).sum().backward()
+    f32 = torch.float32
+    Win = torch.cat([Wg[:Hin], Wc[:Hin]], 1).detach()
+    Pin = dev((x.detach().reshape(-1, Hin) @ Win + torch.cat([bg, bc]).detach()).float())     # history level
+    d_Wg, d_Wc, d_len, d_att = dev(Wg.detach(), f32), dev(Wc.detach(), f32), dev(lens, torch.int32), dev(att.detach(), f32)
+    hT_k = torch.empty(B, n, device="cuda")
+    hprev, gates = torch.zeros(B, T, n, device="cuda"), torch.zeros(B, T, 3 * n, device="cuda")
+    d = ops.gru_desc(n, Pin=Pin, ldp=3 * n, Wgh=d_Wg[Hin:], ldg=2 * n, Wch=d_Wc[Hin:], ldc=n, hT=hT_k, hprev=hprev,
+                     gates=gates, att=d_att, in_div=G)
+    ops.rnn_multi("clsr_rnn_fwd_multi", [d], None, d_len, 1, B, T)
+    close(hT_k, hT, rtol=1e-4, atol=2e-5, name="final state")
+    dPin = torch.full((B, T, 3 * n), 5.0, device="cuda")
+    datt = torch.zeros(B, T, device="cuda")
+    db = ops.gru_desc(n, Wgh=d_Wg[Hin:], ldg=2 * n, Wch=d_Wc[Hin:], ldc=n, hprev=hprev, gates=gates, dhT=dev(up, f32),
+                      dPin=dPin, lddp=3 * n, att=d_att, datt=datt, in_div=G)
+    ops.rnn_multi("clsr_rnn_bwd_multi", [db], None, d_len, 1, B, T)
+    close(datt, att.grad, rtol=2e-4, atol=2e-5, name="d att")
+    dP = dPin.double().cpu().reshape(Hn, G, T, 3 * n).sum(1).reshape(-1, 3 * n)      # rows of a group share the inputs
+    close(dP @ Win.T, x.grad.reshape(-1, Hin), rtol=2e-4, atol=2e-5, name="dx")
+    close(x.detach().reshape(-1, Hin).T @ dP[:, :2 * n], Wg.grad[:Hin], rtol=2e-4, atol=1e-4, name="dWg_x")
+    close(dP[:, 2 * n:].sum(0), bc.grad, rtol=2e-4, atol=1e-4, name="dbc")
+    dPr = dPin.double().cpu().reshape(-1, 3 * n)
+    hp = hprev.double().cpu().reshape(-1, n)
+    rh = (gates[..., :n] * hprev).double().cpu().reshape(-1, n)
+    close(hp.T @ dPr[:, :2 * n], Wg.grad[Hin:], rtol=2e-4, atol=1e-4, name="dWg_h")
+    close(rh.T @ dPr[:, 2 * n:], Wc.grad[Hin:], rtol=2e-4, atol=1e-4, name="dWc_h")
+
+
+@pytest.mark.parametrize("Hn,T,D", [(9, 10, 40), (4, 130, 40), (3, 7, 128)])
+def test_asvd_attention_fwd_bwd(Hn, T, D):
+    """A2SVD attention (base_model.py:595-625): unmasked softmax over T of (x.A).query, output sum_t w x."""
+    g = torch.Generator().manual_seed(Hn * T)
+    x = rnd(g, Hn, T, D).requires_grad_(True)
+    A = (rnd(g, D, D) * 0.2).requires_grad_(True)
+    q = (rnd(g, D) * 0.5).requires_grad_(True)
+    ai = x @ A
+    w = torch.softmax(ai @ q, -1)
+    out = (x * w.unsqueeze(-1)).sum(1)
+    up = rnd(g, Hn, D)
+    ai.retain_grad()
+    (out * up).sum().backward()
+    f32 = torch.float32
+    d_x, d_ai, d_q = dev(x.detach(), f32), dev(ai.detach(), f32), dev(q.detach(), f32)
+    wk, ok = torch.empty(Hn, T, device="cuda"), torch.empty(Hn, D, device="cuda")
+    call("clsr_asvd_att_fwd", d_ai, d_q, d_x, Hn, T, D, wk, ok)
+    close(wk, w, rtol=1e-4, atol=1e-6, name="weights")
+    close(ok, out, rtol=1e-4, atol=1e-5, name="output")
+    parts = query("clsr_asvd_att_bwd_parts", Hn)
+    dai = torch.empty(Hn * T, D, device="cuda")
+    dx = torch.full((Hn * T, D), 2.0, device="cuda")                # accumulated into
+    qp = torch.empty(parts, D, device="cuda")
+    call("clsr_asvd_att_bwd", dev(up, f32), wk, d_ai, d_q, d_x, Hn, T, D, dai, dx, qp)
+    close(dai.view(Hn, T, D), ai.grad, rtol=2e-4, atol=2e-6, name="d att_inputs")
+    close(qp.sum(0), q.grad, rtol=2e-4, atol=2e-5, name="d query")
+    direct = (w.detach().unsqueeze(-1) * up.unsqueeze(1))           # the x * w path; the x.A path goes through dai
+    close(dx.view(Hn, T, D) - 2.0, direct, rtol=2e-4, atol=2e-5, name="d x (direct part)")
+
+
+def test_weights_softmax_bwd_row_scaling_and_products():
+    g = torch.Generator().manual_seed(3)
+    Hn, G, T, D = 6, 5, 12, 40
+    R = Hn * G
+    lens = torch.randint(1, T + 1, (Hn,), generator=g)
+    lens[0] = T
+    score = rnd(g, R, T).requires_grad_(True)
+    mask = (torch.arange(T)[None, :] < lens.repeat_interleave(G)[:, None])
+    w = torch.softmax(torch.where(mask, score, torch.full_like(score, -4294967295.0)), -1)
+    dw = rnd(g, R, T)
+    (w * dw).sum().backward()
+    f32 = torch.float32
+    parts = query("clsr_softmax_weights_bwd_parts", R)
+    ds, bp = torch.empty(R, T, device="cuda"), torch.empty(parts, device="cuda")
+    call("clsr_softmax_weights_bwd", dev(dw, f32), dev(w.detach(), f32), dev(lens, torch.int32), 1, Hn, G, T, ds, bp)
+    close(ds, score.grad, rtol=2e-4, atol=2e-6, name="d score")
+    close(bp.sum(), score.grad.sum(), rtol=1e-3, atol=1e-5, name="d b_out partials")
+    # hist_sum = hist_mean * len (0 for an empty history), accumulate flag
+    m = rnd(g, Hn, D)
+    lens0 = lens.clone()
+    lens0[1] = 0
+    out = torch.full((Hn, D), 1.0, device="cuda")
+    call("clsr_scale_rows_by_len", dev(m, f32), dev(lens0, torch.int32), 1, Hn, D, out, 1)
+    close(out, 1.0 + m * lens0[:, None], name="scale rows (accumulate)")
+    # a[r] * b[r / G] into a column block of a wider output
+    a, b = rnd(g, R, D), rnd(g, Hn, D)
+    wide = torch.full((R, 3 * D), 9.0, device="cuda")
+    call("clsr_mul_rows", dev(a, f32), D, dev(b, f32), D, G, R, D, wide[:, D:], 3 * D)
+    close(wide[:, D:2 * D], a * b.repeat_interleave(G, 0), name="row products")
+    assert float((wide[:, :D] - 9.0).abs().max()) == 0 and float((wide[:, 2 * D:] - 9.0).abs().max()) == 0
