@@ -139,7 +139,8 @@ class CLSRNet(object):
         hp = self.hp
         g = lambda k: getattr(hp, k, None)
         return (what, id(f), ops.stream_ptr(), self.dp_world, self.overlap, self.defer_dw, self.sorted_hist_grad,
-                self.lazy, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("max_grad_norm"), g("is_clip_norm"),
+                self.lazy, self.rnn_first, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad,
+                self.split_g2, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
 
