@@ -17,7 +17,8 @@ Tables whose touched rows are few compared with the vocabulary are exchanged SPA
 list, the listed rows are packed, (count, ids, rows) are all-gathered, and every rank adds the lists of
 all ranks in rank order into its cleared rows -- bit-identical sums on every replica, and the traffic is
 O(touched rows) instead of O(vocabulary).  ``sparse_tables="auto"`` picks per table and per batch shape
-(sparse when  4 * rows_bound * world < vocabulary: a dense table rides in the ONE flat all-reduce, a sparse one
+(sparse when the table has at least 64 MB and  4 * rows_bound * world < vocabulary: a dense table rides in the ONE
+flat all-reduce, a sparse one
 costs three collectives of its own, so it has to save real traffic);  "all" / "none" force one path.
 
 and every rank applies the identical clip + Adam update, so replicas never diverge.  Loss
@@ -110,7 +111,8 @@ class DataParallel(object):
         net.dp_world = self.world
         net.dp_stats_hook = self._sum_stats if self.sync_bn else None
         # sumsq_tab (16) + losses (8) travel together
-        self.small = torch.zeros(24, dtype=torch.float64, device=net.device)
+        self.small = net.stats24       # the net's own 24 doubles: summed in place, no staging copies
+        self.sparse_min_bytes = 64 << 20   # "auto": tables below this size always go dense
         self._graphs = None
         self.broadcast_parameters()
 
@@ -138,7 +140,11 @@ class DataParallel(object):
     def _is_sparse(self, name):
         if self.sparse_tables != "auto":
             return self.sparse_tables == "all"
-        V = self.net.tables[name].shape[0]
+        V, C = self.net.tables[name].shape
+        if V * C * 4 < self.sparse_min_bytes:
+            # a small table rides in the one flat all-reduce for a few tens of microseconds; the sparse route costs
+            # ~25 small launches + three collectives per table (measured: +0.1 ms per 6 MB user table)
+            return False
         return 4 * touched_rows_bound(name, self.net.last_shape, V) * self.world < V
 
     def _exchange_rows(self, name):
@@ -170,13 +176,15 @@ class DataParallel(object):
 
     def _exchange(self):
         net, dist = self.net, self.dist
-        self.small[:16].copy_(net.sumsq_tab)
-        self.small[16:].copy_(net.losses)
         sparse = [n for n in net.tab_grad if self._is_sparse(n)]
         self.last_sparse = sparse
+        bn_done = False
         if not sparse:
+            # gradients (+ the moving BN statistics behind them in the same buffer, when they are per-rank)
+            flat = net.grad_flat if not self.sync_bn else net.grad_flat[:net.grad_flat.numel() - net.bn_moving.numel()]
             allreduce_step_buffers(dist, net.dense_grad, net.tab_grad_flat, net.tab_flags_flat, self.small,
-                                   self.group, grad_flat=getattr(net, "grad_flat", None))
+                                   self.group, grad_flat=flat)
+            bn_done = not self.sync_bn
         else:
             dist.all_reduce(net.dense_grad, op=dist.ReduceOp.SUM, group=self.group)
             dist.all_reduce(self.small, op=dist.ReduceOp.SUM, group=self.group)
@@ -196,11 +204,10 @@ class DataParallel(object):
                 dist.all_reduce(net.tab_grad_flat[g0:g1], op=dist.ReduceOp.SUM, group=self.group)
                 dist.all_reduce(net.tab_flags_flat[f0:f1], op=dist.ReduceOp.MAX, group=self.group)
                 i = j + 1
-        net.sumsq_tab.copy_(self.small[:16])
-        net.losses.copy_(self.small[16:])
         if not self.sync_bn:
-            # keep the (non-trainable) moving statistics identical on every replica
-            self.dist.all_reduce(net.bn_moving, op=self.dist.ReduceOp.SUM, group=self.group)
+            # keep the (non-trainable) moving statistics identical on every replica: their average
+            if not bn_done:
+                self.dist.all_reduce(net.bn_moving, op=self.dist.ReduceOp.SUM, group=self.group)
             net.bn_moving.mul_(1.0 / self.world)
 
     def _update(self):

@@ -94,8 +94,10 @@ class CLSRNet(object):
         self.overlap = True        # run the long-term attention chain on a side stream (fork / join)
         self.sorted_hist_grad = True   # history-row gradients by sort + segmented sums (False: float atomics)
         self.adam_state = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device=self.device)
-        self.losses = torch.zeros(8, dtype=torch.float64, device=self.device)
-        self.sumsq_tab = torch.zeros(16, dtype=torch.float64, device=self.device)
+        # squared norms of the IndexedSlices pieces (16) + loss numerators (8): ONE buffer, so that the data-parallel
+        # exchange sums them with one collective and no staging copies
+        self.stats24 = torch.zeros(24, dtype=torch.float64, device=self.device)
+        self.sumsq_tab, self.losses = self.stats24[:16], self.stats24[16:]
         self.ucount = torch.zeros(1, dtype=F32, device=self.device)
         self.last_shape = None
         self.dp_world = 1          # data-parallel world size (loss normalisers are global)
@@ -212,9 +214,13 @@ class CLSRNet(object):
             gtot += _pad4(sh[0] * sh[1])
             ftot += (sh[0] + 15) // 16 * 16
         self.tab_goff, self.tab_foff, self.tab_shape = goff, foff, tshape   # layout of the two flat buffers
-        self.grad_flat = torch.zeros(self.n_dense + gtot, dtype=F32, device=dev)   # [dense | tables]
+        # [dense gradients | table gradients | BN moving statistics]: with per-rank batch-norm the moving statistics
+        # are averaged over the replicas by the SAME all-reduce that sums the gradients (clsr_amd/dp.py)
+        n_bn = sum(2 * _pad4(int(np.prod(sh))) for n, sh, _ in dense if n.endswith("/gamma"))
+        self.grad_flat = torch.zeros(self.n_dense + gtot + n_bn, dtype=F32, device=dev)
         self.dense_grad = self.grad_flat[:self.n_dense]
-        self.tab_grad_flat = self.grad_flat[self.n_dense:]
+        self.tab_grad_flat = self.grad_flat[self.n_dense:self.n_dense + gtot]
+        self.bn_moving = self.grad_flat[self.n_dense + gtot:]
         self.tab_flags_flat = torch.zeros(ftot, dtype=torch.uint8, device=dev)
         it_dense = iter(zip(dense, off[:-1]))
         for name, shape, kind in specs:
@@ -249,15 +255,14 @@ class CLSRNet(object):
                 scope = name[:-len("gamma")]
                 self.bn[scope] = _BN(self, scope, self.P[name].numel())
         # moving statistics of all layers as views of ONE buffer (a single collective averages them across ranks)
-        tot = sum(2 * bn.C for bn in self.bn.values())
-        self.bn_moving = torch.zeros(tot, dtype=F32, device=dev)
         o = 0
         for bn in self.bn.values():
             for attr in ("moving_mean", "moving_var"):
                 view = self.bn_moving[o:o + bn.C]
                 view.copy_(getattr(bn, attr))
                 setattr(bn, attr, view)
-                o += bn.C
+                o += _pad4(bn.C)
+        assert o == self.bn_moving.numel()
 
     def state_dict(self):
         """All variables under their TF names + BN moving stats + Adam slots (checkpoint payload)."""
