@@ -174,9 +174,39 @@ class SequentialBaseModel(BaseModel):
             arrays = {name: feed_dict[getattr(it, name)] for name in ("labels", "items", "cates")}
             arrays.update(compact)
             return arrays
-        return {name: feed_dict[getattr(it, name)] for name in
-                ("labels", "users", "items", "cates", "item_history", "item_cate_history", "mask",
-                 "time_from_first_action", "time_to_now")}
+        arrays = {name: feed_dict[getattr(it, name)] for name in
+                  ("labels", "users", "items", "cates", "item_history", "item_cate_history", "mask",
+                   "time_from_first_action", "time_to_now")}
+        if not training and self._dedup:
+            g = self._shared_history_group(arrays)
+            if g > 1:
+                arrays["users_rows"] = np.asarray(arrays["users"])
+                # evaluation / test files hold 1 + num_ngs consecutive lines per positive with ONE history: gathers,
+                # recurrences and the long-term attention run once per group, like in training
+                for k in ("users", "item_history", "item_cate_history", "mask", "time_from_first_action",
+                          "time_to_now"):
+                    arrays[k] = np.ascontiguousarray(np.asarray(arrays[k])[::g])
+                arrays["hist_group"] = g
+        return arrays
+
+    @staticmethod
+    def _shared_history_group(arrays):
+        """Largest G such that the batch is made of runs of exactly G consecutive rows with identical user, history,
+        mask and time features (1: no sharing).  One vectorised comparison of neighbouring rows."""
+        ih = np.asarray(arrays["item_history"])
+        n = ih.shape[0]
+        if n < 2:
+            return 1
+        same = np.ones(n - 1, dtype=bool)
+        for k in ("item_history", "item_cate_history", "mask", "time_from_first_action", "time_to_now"):
+            a = np.asarray(arrays[k])
+            same &= (a[1:] == a[:-1]).all(axis=1)
+        u = np.asarray(arrays["users"]).reshape(-1)
+        same &= u[1:] == u[:-1]
+        starts = np.flatnonzero(np.concatenate(([True], ~same)))
+        runs = np.diff(np.concatenate((starts, [n])))
+        g = int(runs.min())
+        return g if g > 1 and n % g == 0 and bool(np.all(runs % g == 0)) else 1
 
     def _static_feed(self, feed, training, lookahead=False):
         """Copy a numpy feed into static device buffers keyed by (rows, T, mode, layout) through
@@ -288,12 +318,14 @@ class SequentialBaseModel(BaseModel):
     def eval_with_user(self, sess, feed_dict):
         """(users, pred [B,1], labels [B,1]) -- reference sequential_base_model.py:294-308."""
         feed, pred, _ = self._score(feed_dict)
-        return (np.asarray(feed["users"]).astype(np.int32), pred, np.asarray(feed["labels"]).reshape(-1, 1))
+        return (np.asarray(feed.get("users_rows", feed["users"])).astype(np.int32), pred,
+                np.asarray(feed["labels"]).reshape(-1, 1))
 
     def eval_with_user_and_alpha(self, sess, feed_dict):
         feed, pred, out = self._score(feed_dict)
         alpha = out["alpha"].numpy().reshape(-1, 1)
-        return (np.asarray(feed["users"]).astype(np.int32), pred, np.asarray(feed["labels"]).reshape(-1, 1), alpha)
+        return (np.asarray(feed.get("users_rows", feed["users"])).astype(np.int32), pred,
+                np.asarray(feed["labels"]).reshape(-1, 1), alpha)
 
     def infer(self, sess, feed_dict):
         """[pred] -- reference base_model.py:381-392."""

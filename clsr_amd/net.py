@@ -695,7 +695,9 @@ class CLSRNet(object):
         when the step de-duplicates histories anyway; otherwise it is expanded to the row layout here."""
         hg = int(feed.get("hist_group", 0) or 0)
         hist_keys = ("users", "item_history", "item_cate_history", "mask", "time_from_first_action", "time_to_now")
-        compact = bool(hg) and training and self.dedup and hg == self.G_train
+        # training: the group is the iterator's 1 + train_num_ngs; scoring: whatever run of consecutive rows with one
+        # history the caller found (an evaluation file holds 1 + num_ngs lines per positive, CLSRModel._to_arrays)
+        compact = bool(hg) and self.dedup and (hg == self.G_train if training else hg > 1)
         if hg and not compact:
             feed = dict(feed, **{k: np.repeat(np.asarray(feed[k]), hg, axis=0) for k in hist_keys})
             hg = 0
@@ -711,6 +713,7 @@ class CLSRNet(object):
         rep = hg if compact else 1
         thr = getattr(self.hp, "contrastive_length_threshold", None) or 0     # (unset for the sibling models)
         h["denom"] = np.asarray([float((seq_len > thr).sum() * rep)], dtype=np.float32)
+        self._last_group = hg if compact else 0
         return h, int(mask.shape[0]) * rep, int(mask.shape[1]), compact
 
     _STAGE_SLOTS = 3
@@ -735,12 +738,13 @@ class CLSRNet(object):
                 lay[k] = (off, arr.nbytes)
                 off += (arr.nbytes + 15) // 16 * 16
             dev = torch.empty(off, dtype=torch.uint8, device=self.device)
-            into = {"B": B, "T": T, "compact": compact, "_lay": lay, "_nbytes": off, "_dev": dev, "_slot": 0,
+            into = {"B": B, "T": T, "compact": compact, "G": self._last_group, "_lay": lay, "_nbytes": off,
+                    "_dev": dev, "_slot": 0,
                     "_stage": [None] * self._STAGE_SLOTS}
             for k, arr in h.items():
                 o, n = lay[k]
                 into[k] = dev[o:o + n].view(torch.from_numpy(arr).dtype).view(arr.shape)
-        assert into["B"] == B and into["T"] == T and into["compact"] == compact
+        assert into["B"] == B and into["T"] == T and into["compact"] == compact and into["G"] == self._last_group
         slot = into["_slot"]
         into["_slot"] = (slot + 1) % self._STAGE_SLOTS
         if into["_stage"][slot] is None:
@@ -990,7 +994,7 @@ class CLSRNet(object):
     def _forward(self, f, training, after_attention, early_aux):
         hp, P = self.hp, self.P
         B, T = f["B"], f["T"]
-        G = self.G_train if (training and self.dedup) else 1
+        G = self.G_train if (training and self.dedup) else ((f.get("G") or 1) if not training else 1)
         if B % G:
             raise ValueError("training feed rows (%d) must be a multiple of 1+train_num_ngs (%d)" % (B, G))
         Hn = B // G

@@ -144,7 +144,7 @@ class SeqNet(CLSRNet):
     def _forward(self, f, training, after_attention=None, early_aux=None):
         hp, P, kind, sc = self.hp, self.P, self.kind, self.sc
         B, T = f["B"], f["T"]
-        G = self.G_train if (training and self.dedup) else 1
+        G = self.G_train if (training and self.dedup) else ((f.get("G") or 1) if not training else 1)
         if B % G:
             raise ValueError("training feed rows (%d) must be a multiple of 1+train_num_ngs (%d)" % (B, G))
         Hn = B // G

@@ -143,3 +143,36 @@ def test_sibling_models_fit_eval_predict_checkpoint(cls_name, yaml_name, tmp_pat
     fresh.load_model(ckpt)
     model.load_model(ckpt)
     assert fresh.run_eval(paths["valid_data"], 4) == model.run_eval(paths["valid_data"], 4)
+
+
+def test_scoring_shares_the_history_work_of_a_group(golden_dir, golden_hparams):
+    """Evaluation files hold 1 + num_ngs consecutive lines per positive with one history: scoring detects the
+    groups and runs the history-level part once per group -- same predictions and metrics as row by row."""
+    import random
+
+    from clsr_amd.clsr import CLSRModel
+    from clsr_amd.sequential_iterator import SASequentialIterator
+
+    d = os.path.join(golden_dir, "data")
+    test = os.path.join(d, "test_data")
+    hp = copy.deepcopy(golden_hparams)
+    hp.batch_size = 60                      # a multiple of the 1 + 9 lines per positive
+    random.seed(3)
+    shared = CLSRModel(hp, SASequentialIterator, seed=5)
+    rowwise = CLSRModel(hp, SASequentialIterator, seed=5, dedup_histories=False)
+    rowwise.net.load_state_dict(shared.net.state_dict())
+    feed = next(iter(shared.iterator.load_data_from_file(test, batch_num_ngs=0)))
+    arrays = shared._to_arrays(feed)
+    assert arrays.get("hist_group") == 10 and arrays["item_history"].shape[0] * 10 == arrays["items"].shape[0]
+    assert "hist_group" not in rowwise._to_arrays(feed)
+    ua, pa, la = shared.eval_with_user(shared.sess, feed)
+    ub, pb, lb = rowwise.eval_with_user(rowwise.sess, feed)
+    assert np.array_equal(ua, ub) and np.array_equal(la, lb) and ua.shape[0] == 60
+    np.testing.assert_allclose(pa, pb, rtol=2e-5, atol=2e-6)
+    assert shared.run_weighted_eval(test, num_ngs=9) == rowwise.run_weighted_eval(test, num_ngs=9)
+    # a batch size that cuts groups apart: the detection falls back to row-by-row scoring
+    hp2 = copy.deepcopy(hp)
+    hp2.batch_size = 64
+    cut = CLSRModel(hp2, SASequentialIterator, seed=5)
+    cut.net.load_state_dict(shared.net.state_dict())
+    assert cut.run_weighted_eval(test, num_ngs=9) == shared.run_weighted_eval(test, num_ngs=9)
