@@ -31,47 +31,87 @@ __device__ __forceinline__ f32x4 tanh4(f32x4 v) {
 __device__ __forceinline__ f32x4 sel4(bool c, f32x4 a, f32x4 b) { return c ? a : b; }
 #define Z4 ((f32x4){0.f, 0.f, 0.f, 0.f})
 
+// Compact last k-tile.  The recurrent products run over k-tiles of 16 state features; lane (i, g) of a tile holds
+// the four features 4g..4g+3 of sequence i (the MFMA output layout, so a wave's result is the next step's operand
+// without a shuffle) and MFMA number c of the tile reduces over the features {4g + c}.  With n = 40 the last tile
+// holds 8 features (32..39) in the lanes g = 0, 1 and every one of its four MFMAs is half empty.  When the last tile
+// has <= 8 features it is therefore read back from the exchange buffer feature-major instead -- component x =
+// feature g, y = feature 4 + g of the tile, one scalar LDS read each -- and reduced by TWO full MFMAs: 10 instead of
+// 12 MFMAs per gate and step at n = 40 on the T-serial chain.
+template <int RNT>
+__device__ __forceinline__ bool last_tile_compact(int n) { return n - 16 * (RNT - 1) <= 8; }
+
 // forward use: out[o] = sum_in W[in*ld + colbase + o] * state[in]
 __device__ __forceinline__ f32x4 load_w_fwd(const float* W, int ld, int colbase, int n, int ot, int kt,
-                                            int i, int g) {
+                                            int i, int g, bool compact = false) {
   f32x4 v = Z4;
   const int o = 16 * ot + i;
   if (o < n) {
-    const int in0 = 16 * kt + 4 * g;
-    if (in0 + 0 < n) v.x = W[(long)(in0 + 0) * ld + colbase + o];
-    if (in0 + 1 < n) v.y = W[(long)(in0 + 1) * ld + colbase + o];
-    if (in0 + 2 < n) v.z = W[(long)(in0 + 2) * ld + colbase + o];
-    if (in0 + 3 < n) v.w = W[(long)(in0 + 3) * ld + colbase + o];
+    const int in0 = compact ? 16 * kt + g : 16 * kt + 4 * g;
+    const int st = compact ? 4 : 1;
+    if (in0 + 0 * st < n) v.x = W[(long)(in0 + 0 * st) * ld + colbase + o];
+    if (in0 + 1 * st < n) v.y = W[(long)(in0 + 1 * st) * ld + colbase + o];
+    if (!compact) {
+      if (in0 + 2 < n) v.z = W[(long)(in0 + 2) * ld + colbase + o];
+      if (in0 + 3 < n) v.w = W[(long)(in0 + 3) * ld + colbase + o];
+    }
   }
   return v;
 }
 // backward use: dstate[in] = sum_o W[in*ld + colbase + o] * dgate[o]
 __device__ __forceinline__ f32x4 load_w_bwd(const float* W, int ld, int colbase, int n, int ot, int kt,
-                                            int i, int g) {
-  const int in = 16 * ot + i, o0 = 16 * kt + 4 * g;
+                                            int i, int g, bool compact = false) {
+  const int in = 16 * ot + i;
+  if (compact) {
+    f32x4 v = Z4;
+    const int o0 = 16 * kt + g;
+    if (in < n && o0 < n) v.x = W[(long)in * ld + colbase + o0];
+    if (in < n && o0 + 4 < n) v.y = W[(long)in * ld + colbase + o0 + 4];
+    return v;
+  }
+  const int o0 = 16 * kt + 4 * g;
   if (in < n && o0 < n) return ld4(W + (long)in * ld + colbase + o0);
   return Z4;
 }
 
+// one k-tile of an exchange buffer as MFMA operand (tile = buf + kt * 64)
+__device__ __forceinline__ f32x4 read_tile(const f32x4* tile, int lane, bool compact) {
+  if (!compact) return tile[lane];
+  const float* f = (const float*)tile;
+  const int j = lane & 15, g = lane >> 4;
+  return (f32x4){f[4 * j + g], f[4 * (16 + j) + g], 0.f, 0.f};
+}
+
+// acc (one feature tile) += W-tile . state over one k-tile (two MFMAs for the compact last tile)
+__device__ __forceinline__ void mvt(f32x4& acc, const f32x4& w, const f32x4& b, bool two) {
+  MFMA4(acc, w.x, b.x);
+  MFMA4(acc, w.y, b.y);
+  if (!two) {
+    MFMA4(acc, w.z, b.z);
+    MFMA4(acc, w.w, b.w);
+  }
+}
+
 // acc (one feature tile) += sum over all RNT k-tiles of W-tile . state
 template <int RNT>
-__device__ __forceinline__ void mv1(f32x4& acc, const f32x4 (&w)[RNT], const f32x4 (&b)[RNT]) {
+__device__ __forceinline__ void mv1(f32x4& acc, const f32x4 (&w)[RNT], const f32x4 (&b)[RNT], bool cmp) {
 #pragma unroll
-  for (int kt = 0; kt < RNT; ++kt) {
-    MFMA4(acc, w[kt].x, b[kt].x);
-    MFMA4(acc, w[kt].y, b[kt].y);
-    MFMA4(acc, w[kt].z, b[kt].z);
-    MFMA4(acc, w[kt].w, b[kt].w);
-  }
+  for (int kt = 0; kt < RNT; ++kt) mvt(acc, w[kt], b[kt], kt == RNT - 1 && cmp);
+}
+
+// collect the full vector (RNT k-tiles) of the workgroup from an exchange buffer
+template <int RNT>
+__device__ __forceinline__ void collect(const f32x4* buf, int lane, bool cmp, f32x4 (&full)[RNT]) {
+#pragma unroll
+  for (int kt = 0; kt < RNT; ++kt) full[kt] = read_tile(buf + kt * 64, lane, kt == RNT - 1 && cmp);
 }
 
 // publish this wave's tile of a vector and collect the full vector (RNT tiles) of the workgroup
 template <int RNT>
-__device__ __forceinline__ void xchg(f32x4* buf, int w, int lane, f32x4 own, f32x4 (&full)[RNT]) {
+__device__ __forceinline__ void xchg(f32x4* buf, int w, int lane, f32x4 own, bool cmp, f32x4 (&full)[RNT]) {
   buf[w * 64 + lane] = own;
   __syncthreads();
-#pragma unroll
-  for (int kt = 0; kt < RNT; ++kt) full[kt] = buf[kt * 64 + lane];
+  collect<RNT>(buf, lane, cmp, full);
 }
 
 __device__ __forceinline__ int wave_max_i(int v) {
@@ -114,19 +154,30 @@ __device__ __forceinline__ void gru_fwd_body(const GruArgs& a, const int bx, f32
   const int n = a.n, T = a.T;
   const long h = (long)bx * 16 + j;
   const bool hvalid = h < a.Hn;
+  const bool cmp = last_tile_compact<RNT>(n);
   f32x4 wr[RNT], wu[RNT], wc[RNT];
 #pragma unroll
   for (int kt = 0; kt < RNT; ++kt) {
-    wr[kt] = load_w_fwd(a.Wgh, a.ldg, 0, n, w, kt, j, g);
-    wu[kt] = load_w_fwd(a.Wgh, a.ldg, n, n, w, kt, j, g);
-    wc[kt] = load_w_fwd(a.Wch, a.ldc, 0, n, w, kt, j, g);
+    const bool ck = kt == RNT - 1 && cmp;
+    wr[kt] = load_w_fwd(a.Wgh, a.ldg, 0, n, w, kt, j, g, ck);
+    wu[kt] = load_w_fwd(a.Wgh, a.ldg, n, n, w, kt, j, g, ck);
+    wc[kt] = load_w_fwd(a.Wch, a.ldc, 0, n, w, kt, j, g, ck);
   }
   const int col = 16 * w + 4 * g;
   const bool cval = hvalid && col < n;
   f32x4 hs[RNT];
 #pragma unroll
-  for (int kt = 0; kt < RNT; ++kt)
-    hs[kt] = (hvalid && 16 * kt + 4 * g < n && a.h0) ? ld4(a.h0 + h * a.h0_stride + 16 * kt + 4 * g) : Z4;
+  for (int kt = 0; kt < RNT; ++kt) {
+    hs[kt] = Z4;
+    if (!(hvalid && a.h0)) continue;
+    const float* hp0 = a.h0 + h * a.h0_stride + 16 * kt;
+    if (kt == RNT - 1 && cmp) {
+      if (16 * kt + g < n) hs[kt].x = hp0[g];
+      if (16 * kt + 4 + g < n) hs[kt].y = hp0[4 + g];
+    } else if (16 * kt + 4 * g < n) {
+      hs[kt] = ld4(hp0 + 4 * g);
+    }
+  }
   f32x4 hown = (cval && a.h0) ? ld4(a.h0 + h * a.h0_stride + col) : Z4;
   const long hin = ATT ? (hvalid ? h : 0) / a.in_div : (hvalid ? h : 0);   // history of this sequence
   const int len = hvalid ? min(a.seq_len[hin * a.len_stride], T) : 0;
@@ -153,12 +204,12 @@ __device__ __forceinline__ void gru_fwd_body(const GruArgs& a, const int bx, f32
       for (int gb = 0; gb < 3; ++gb) pn[gb] = sel4(cval && nl, ld4(pin + tn * a.ldp + gb * n), Z4);
       if (ATT) an = attp[tn];
     }
-    mv1(accr, wr, hs);
-    mv1(accu, wu, hs);
+    mv1(accr, wr, hs, cmp);
+    mv1(accu, wu, hs, cmp);
     const f32x4 r = sig4(accr), u = sig4(accu);
     f32x4 rh[RNT];
-    xchg(bufA, w, lane, r * hown, rh);
-    mv1(accc, wc, rh);
+    xchg(bufA, w, lane, r * hown, cmp, rh);
+    mv1(accc, wc, rh, cmp);
     const f32x4 c = tanh4(accc);
     const f32x4 ue = u * keep;
     const f32x4 hn = ue * hown + (1.0f - ue) * c;
@@ -172,7 +223,7 @@ __device__ __forceinline__ void gru_fwd_body(const GruArgs& a, const int bx, f32
       if (a.out_seq) st4(a.out_seq + pos * n + col, hn);
     }
     hown = sel4(live, hn, hown);
-    xchg(bufB, w, lane, hown, hs);
+    xchg(bufB, w, lane, hown, cmp, hs);
   }
   if (cval) {
     if (a.hT) st4(a.hT + h * n + col, hown);
@@ -188,12 +239,14 @@ __device__ __forceinline__ void gru_bwd_body(const GruArgs& a, const int bx, f32
   const long h = (long)bx * 16 + j;
   const bool hvalid = h < a.Hn;
   // transposed operands: d(state in) = sum_o W[in][o] * dgate[o]; this wave owns in-tile w
+  const bool cmp = last_tile_compact<RNT>(n);
   f32x4 wr[RNT], wu[RNT], wc[RNT];
 #pragma unroll
   for (int kt = 0; kt < RNT; ++kt) {
-    wr[kt] = load_w_bwd(a.Wgh, a.ldg, 0, n, w, kt, j, g);
-    wu[kt] = load_w_bwd(a.Wgh, a.ldg, n, n, w, kt, j, g);
-    wc[kt] = load_w_bwd(a.Wch, a.ldc, 0, n, w, kt, j, g);
+    const bool ck = kt == RNT - 1 && cmp;
+    wr[kt] = load_w_bwd(a.Wgh, a.ldg, 0, n, w, kt, j, g, ck);
+    wu[kt] = load_w_bwd(a.Wgh, a.ldg, n, n, w, kt, j, g, ck);
+    wc[kt] = load_w_bwd(a.Wch, a.ldc, 0, n, w, kt, j, g, ck);
   }
   const int col = 16 * w + 4 * g;
   const bool cval = hvalid && col < n;
@@ -235,18 +288,17 @@ __device__ __forceinline__ void gru_bwd_body(const GruArgs& a, const int bx, f32
       if (g == 0 && live && hvalid) atomicAdd(a.datt + h * (long)T + t, sa);
     }
     f32x4 full[RNT];
-    xchg(bufA, w, lane, dcp, full);
+    xchg(bufA, w, lane, dcp, cmp, full);
     f32x4 drh = Z4;
-    mv1(drh, wc, full);
+    mv1(drh, wc, full, cmp);
     const f32x4 drp = drh * hp * r * (1.0f - r);
     const f32x4 dup = du * u * (1.0f - u);
     dhn += drh * r;
     bufR[w * 64 + lane] = drp;
-    xchg(bufU, w, lane, dup, full);
-    mv1(dhn, wu, full);
-#pragma unroll
-    for (int kt = 0; kt < RNT; ++kt) full[kt] = bufR[kt * 64 + lane];
-    mv1(dhn, wr, full);
+    xchg(bufU, w, lane, dup, cmp, full);
+    mv1(dhn, wu, full, cmp);
+    collect<RNT>(bufR, lane, cmp, full);
+    mv1(dhn, wr, full, cmp);
     if (ok) {
       float* dp = a.dPin + pos * a.lddp + col;
       st4(dp, drp); st4(dp + n, dup); st4(dp + 2 * n, dcp);
@@ -347,11 +399,13 @@ __device__ __forceinline__ void t4lstm_fwd_body(const T4Args& a, const int bx, f
   const int n = a.n, T = a.T;
   const long h = (long)bx * 16 + j;
   const bool hvalid = h < a.Hn;
+  const bool cmp = last_tile_compact<RNT>(n);
   f32x4 wm[4][RNT];
 #pragma unroll
   for (int gb = 0; gb < 4; ++gb)
 #pragma unroll
-    for (int kt = 0; kt < RNT; ++kt) wm[gb][kt] = load_w_fwd(a.Wm, a.ldm, gb * n, n, w, kt, j, g);
+    for (int kt = 0; kt < RNT; ++kt)
+      wm[gb][kt] = load_w_fwd(a.Wm, a.ldm, gb * n, n, w, kt, j, g, kt == RNT - 1 && cmp);
   const int col = 16 * w + 4 * g;
   const bool cval = hvalid && col < n;
   f32x4 cs = Z4, mown = Z4, ms[RNT];
@@ -381,6 +435,7 @@ __device__ __forceinline__ void t4lstm_fwd_body(const T4Args& a, const int bx, f
       for (int gb = 0; gb < 4; ++gb) MFMA4(acc[gb], wm[gb][kt].x, ms[kt].x);
 #pragma unroll
       for (int gb = 0; gb < 4; ++gb) MFMA4(acc[gb], wm[gb][kt].y, ms[kt].y);
+      if (kt == RNT - 1 && cmp) continue;
 #pragma unroll
       for (int gb = 0; gb < 4; ++gb) MFMA4(acc[gb], wm[gb][kt].z, ms[kt].z);
 #pragma unroll
@@ -403,7 +458,7 @@ __device__ __forceinline__ void t4lstm_fwd_body(const T4Args& a, const int bx, f
     }
     cs = sel4(live, cn, cs);
     mown = sel4(live, mn, mown);
-    xchg(xb + (t & 1) * RNT * 64, w, lane, mown, ms);  // double buffered: one barrier per step
+    xchg(xb + (t & 1) * RNT * 64, w, lane, mown, cmp, ms);  // double buffered: one barrier per step
   }
   if (cval)
     for (int t = len; t < T; ++t) st4(a.out_seq + (h * T + t) * n + col, Z4);
@@ -415,11 +470,13 @@ __device__ __forceinline__ void t4lstm_bwd_body(const T4Args& a, const int bx, f
   const int n = a.n, T = a.T;
   const long h = (long)bx * 16 + j;
   const bool hvalid = h < a.Hn;
+  const bool cmp = last_tile_compact<RNT>(n);
   f32x4 wm[4][RNT];
 #pragma unroll
   for (int gb = 0; gb < 4; ++gb)
 #pragma unroll
-    for (int kt = 0; kt < RNT; ++kt) wm[gb][kt] = load_w_bwd(a.Wm, a.ldm, gb * n, n, w, kt, j, g);
+    for (int kt = 0; kt < RNT; ++kt)
+      wm[gb][kt] = load_w_bwd(a.Wm, a.ldm, gb * n, n, w, kt, j, g, kt == RNT - 1 && cmp);
   const int col = 16 * w + 4 * g;
   const bool cval = hvalid && col < n;
   f32x4 dc = Z4, dm = Z4;
@@ -471,14 +528,9 @@ __device__ __forceinline__ void t4lstm_bwd_body(const T4Args& a, const int bx, f
     for (int kt = 0; kt < RNT; ++kt) {
       f32x4 bq[4];
 #pragma unroll
-      for (int gb = 0; gb < 4; ++gb) bq[gb] = buf[(gb * RNT + kt) * 64 + lane];
+      for (int gb = 0; gb < 4; ++gb) bq[gb] = read_tile(buf + (gb * RNT + kt) * 64, lane, kt == RNT - 1 && cmp);
 #pragma unroll
-      for (int gb = 0; gb < 4; ++gb) {
-        MFMA4(dmn, wm[gb][kt].x, bq[gb].x);
-        MFMA4(dmn, wm[gb][kt].y, bq[gb].y);
-        MFMA4(dmn, wm[gb][kt].z, bq[gb].z);
-        MFMA4(dmn, wm[gb][kt].w, bq[gb].w);
-      }
+      for (int gb = 0; gb < 4; ++gb) mvt(dmn, wm[gb][kt], bq[gb], kt == RNT - 1 && cmp);
     }
     dc = sel4(live, dcn, dc);
     dm = sel4(live, dmn, dm);

@@ -105,8 +105,9 @@ def test_train_step_matches_oracle(golden_dir, golden_hparams, cfg, dedup):
     cap = net.captured
     raw = out["raw_grads"]
     # absolute floor: biases that feed a batch-norm (and the softmax-invariant output bias) have an
-    # exactly-zero gradient which fp32 accumulation returns as noise ~1e-7 of the layer's scale
-    floor = 1e-6 * max(float(raw[n].abs().max()) for n in net.dense_names)
+    # exactly-zero gradient which fp32 accumulation returns as noise of a few 1e-7 of the layer's scale (the sum
+    # of ~20 k row gradients that cancel analytically; its value moves with the summation order upstream)
+    floor = 4e-6 * max(float(raw[n].abs().max()) for n in net.dense_names)
     for i, name in enumerate(net.dense_names):
         scale = float(raw[name].abs().max()) + 1e-12
         _close(cap["dense"][name], raw[name], 2e-3, 2e-4 * scale + floor, "grad " + name)
