@@ -151,13 +151,14 @@ extern "C" int clsr_att_out_fwd(const float* z1, const float* scale1, const floa
 #define ATT_BWD_MAX_BLOCKS 4096
 #define ATT_BWD_MAXG 8
 
-// One workgroup per history group, one wave per row of the group.
-// LDS (floats): dol[G][Dk] | wl[G][Tp] | pdb[G]
+// One workgroup per history group, one wave per row of the group (groups of more than ATT_BWD_MAXG rows: the
+// waves take the rows round robin).
+// LDS (floats): dol[G][Dk] | wl[G][Tp] | pdb[waves]
 template <int NCH>
 __global__ void __launch_bounds__(64 * ATT_BWD_MAXG) att_score_bwd_kernel(AttOutArgs a, float* __restrict__ ds_out,
                                                                           float* __restrict__ b_partial) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, gi = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int T = a.T, Dk = a.Dk, G = a.G;
   const int Tp = (T + 3) & ~3;
   const int QD = Dk >> 2;
@@ -168,41 +169,44 @@ __global__ void __launch_bounds__(64 * ATT_BWD_MAXG) att_score_bwd_kernel(AttOut
   for (long h = blockIdx.x; h < a.Hn; h += gridDim.x) {
     const int len = a.seq_len[h * a.len_stride];
     const float* kp = a.keys + h * T * Dk;
-    const long r = h * G + gi;
     __syncthreads();  // the previous group's dkeys pass is done with dol / wl
-    for (int d = lane; d < Dk; d += 64) dol[gi * Dk + d] = a.dout[r * Dk + d];
+    for (int gi = wave; gi < G; gi += nw)
+      for (int d = lane; d < Dk; d += 64) dol[gi * Dk + d] = a.dout[(h * G + gi) * Dk + d];
     __syncthreads();
-    float w[NCH], dw[NCH];
-    float dotsum = 0.f;
+    for (int gi = wave; gi < G; gi += nw) {
+      const long r = h * G + gi;
+      float w[NCH], dw[NCH];
+      float dotsum = 0.f;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int t = c * 64 + lane;
-      w[c] = 0.f; dw[c] = 0.f;
-      if (t < T && t < len) {
-        w[c] = a.wts[r * T + t];
-        const float* row = kp + (long)t * Dk;
-        float v = 0.f;
+      for (int c = 0; c < NCH; ++c) {
+        const int t = c * 64 + lane;
+        w[c] = 0.f; dw[c] = 0.f;
+        if (t < T && t < len) {
+          w[c] = a.wts[r * T + t];
+          const float* row = kp + (long)t * Dk;
+          float v = 0.f;
 #pragma unroll 5
-        for (int q = 0; q < QD; ++q) v += dot4(ld4(row + 4 * q), ld4(dol + gi * Dk + 4 * q));
-        dw[c] = v;
-        dotsum += w[c] * v;
+          for (int q = 0; q < QD; ++q) v += dot4(ld4(row + 4 * q), ld4(dol + gi * Dk + 4 * q));
+          dw[c] = v;
+          dotsum += w[c] * v;
+        }
       }
-    }
-    dotsum = wave_sum(dotsum);
+      dotsum = wave_sum(dotsum);
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int t = c * 64 + lane;
-      if (t < T) {
-        const float ds = (t < len) ? w[c] * (dw[c] - dotsum) : 0.f;
-        ds_out[r * T + t] = ds;
-        wl[gi * Tp + t] = len > 0 ? w[c] : 1.0f / (float)T;  // len == 0: the weights are the constant 1/T
-        p_db += ds;
+      for (int c = 0; c < NCH; ++c) {
+        const int t = c * 64 + lane;
+        if (t < T) {
+          const float ds = (t < len) ? w[c] * (dw[c] - dotsum) : 0.f;
+          ds_out[r * T + t] = ds;
+          wl[gi * Tp + t] = len > 0 ? w[c] : 1.0f / (float)T;  // len == 0: the weights are the constant 1/T
+          p_db += ds;
+        }
       }
     }
     __syncthreads();
     // dkeys[h, t, :] += sum_g w[g, t] * dout[g, :]   (all waves of the group)
     float* dk = a.dkeys + h * T * Dk;
-    for (int e = tid; e < T * QD; e += 64 * G) {
+    for (int e = tid; e < T * QD; e += blockDim.x) {
       const int t = e / QD, q = e - t * QD;
       f32x4 sum = {0, 0, 0, 0};
       for (int gg = 0; gg < G; ++gg) sum += ld4(dol + gg * Dk + 4 * q) * wl[gg * Tp + t];
@@ -211,11 +215,11 @@ __global__ void __launch_bounds__(64 * ATT_BWD_MAXG) att_score_bwd_kernel(AttOut
     }
   }
   p_db = wave_sum(p_db);
-  if (lane == 0) pdb[gi] = p_db;
+  if (lane == 0) pdb[wave] = p_db;
   __syncthreads();
   if (tid == 0) {
     float s = 0.f;
-    for (int wv = 0; wv < G; ++wv) s += pdb[wv];
+    for (int wv = 0; wv < nw; ++wv) s += pdb[wv];
     b_partial[blockIdx.x] = s;
   }
 }
@@ -227,7 +231,7 @@ extern "C" int clsr_att_score_bwd(const float* dout, const float* wts, const int
                                   const float* keys, int Hn, int G, int T, int Dk, float* ds, float* dkeys,
                                   float* b_partial, void* stream) {
   CLSR_CHECK_ARG(dout && wts && seq_len && keys && ds && dkeys && b_partial && Hn > 0 && G > 0 && T > 0);
-  CLSR_CHECK_SUPPORTED(T <= 64 * ATT_MAXCH && Dk % 4 == 0 && Dk <= 256 && G <= ATT_BWD_MAXG);
+  CLSR_CHECK_SUPPORTED(T <= 64 * ATT_MAXCH && Dk % 4 == 0 && Dk <= 256);
   AttOutArgs a = {};
   a.seq_len = seq_len; a.len_stride = len_stride; a.keys = keys;
   a.Hn = Hn; a.G = G; a.T = T; a.Dk = Dk; a.wts = const_cast<float*>(wts);
@@ -235,7 +239,7 @@ extern "C" int clsr_att_score_bwd(const float* dout, const float* wts, const int
   const size_t Tp = ((size_t)T + 3) / 4 * 4;
   const size_t shmem = ((size_t)G * Dk + (size_t)G * Tp + ATT_BWD_MAXG) * sizeof(float);
   CLSR_CHECK_SUPPORTED(shmem <= 64 * 1024);
-  const dim3 grid(att_bwd_blocks(Hn)), block(64 * G);
+  const dim3 grid(att_bwd_blocks(Hn)), block(64 * (G < ATT_BWD_MAXG ? G : ATT_BWD_MAXG));
   hipStream_t s = (hipStream_t)stream;
   if (T <= 64) hipLaunchKernelGGL(att_score_bwd_kernel<1>, grid, block, shmem, s, a, ds, b_partial);
   else if (T <= 128) hipLaunchKernelGGL(att_score_bwd_kernel<2>, grid, block, shmem, s, a, ds, b_partial);

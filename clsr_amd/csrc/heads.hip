@@ -328,6 +328,47 @@ __global__ void __launch_bounds__(64) contrastive_kernel(
   float loss_local = 0.f;
   for (long h = blockIdx.x; h < Hn; h += gridDim.x) {
     if (seq_len[h * len_stride] <= threshold) continue;
+    if (mode != 1 && D > 64) {
+      // bpr on wide embeddings: the four dot products run over all of D before any gradient can be formed;
+      // the history-level vectors of up to 4 x 64 features stay in registers
+      float l[4], m[4], r[4], gl[4], gm[4], gr[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = 64 * k + lane;
+        const bool ok = c < D;
+        l[k] = ok ? L[h * D + c] : 0.f; m[k] = ok ? M[h * D + c] : 0.f; r[k] = ok ? R[h * D + c] : 0.f;
+        gl[k] = gm[k] = gr[k] = 0.f;
+      }
+      for (int gi = 0; gi < G; ++gi) {
+        const long b = h * G + gi;
+        float sv[4], p1 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = 64 * k + lane;
+          sv[k] = c < D ? S[b * D + c] : 0.f;
+          p1 += l[k] * (r[k] - m[k]); p2 += sv[k] * (m[k] - r[k]);
+          p3 += m[k] * (sv[k] - l[k]); p4 += r[k] * (l[k] - sv[k]);
+        }
+        const float a1 = wave_sum(p1), a2 = wave_sum(p2), a3 = wave_sum(p3), a4 = wave_sum(p4);
+        if (lane == 0) loss_local += softplusf_(a1) + softplusf_(a2) + softplusf_(a3) + softplusf_(a4);
+        const float s1 = sigmoidf_(a1), s2 = sigmoidf_(a2), s3 = sigmoidf_(a3), s4 = sigmoidf_(a4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = 64 * k + lane;
+          const float s = sv[k];
+          gl[k] += s1 * (r[k] - m[k]) - s3 * m[k] + s4 * r[k];
+          gm[k] += -s1 * l[k] + s2 * s + s3 * (s - l[k]);
+          gr[k] += s1 * l[k] - s2 * s + s4 * (l[k] - s);
+          if (c < D && dS) dS[b * D + c] += coef * (s2 * (m[k] - r[k]) + s3 * m[k] - s4 * r[k]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = 64 * k + lane;
+        if (c < D && dL) { dL[h * D + c] += coef * gl[k]; dM[h * D + c] += coef * gm[k]; dR[h * D + c] += coef * gr[k]; }
+      }
+      continue;
+    }
     for (int c0 = 0; c0 < D; c0 += 64) {
       const int c = c0 + lane;
       const bool ok = c < D;
@@ -375,7 +416,7 @@ extern "C" int clsr_contrastive(const float* L, const float* S, const float* M, 
                                 void* stream) {
   CLSR_CHECK_ARG(L && S && M && R && seq_len && denom_ptr && loss_out && Hn > 0 && G > 0);
   CLSR_CHECK_ARG((dL && dS && dM && dR) || (!dL && !dS && !dM && !dR));
-  CLSR_CHECK_SUPPORTED(mode == 1 || D <= 64);  // bpr dot products use one wave pass over D
+  CLSR_CHECK_SUPPORTED(mode == 1 || D <= 256);  // bpr keeps the history-level vectors in registers
   int blocks = Hn > 4096 ? 4096 : (int)Hn;
   hipLaunchKernelGGL(contrastive_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, L, S, M, R,
                      seq_len, len_stride, Hn, G, D, threshold, mode, margin, weight, denom_ptr, loss_out,

@@ -292,7 +292,8 @@ def test_bn_forward_backward(M, C):
 
 
 # ------------------------------------------------------------------------------- attention tail
-@pytest.mark.parametrize("Hn,G,T,C1,Dk", [(19, 5, 10, 40, 40), (7, 1, 50, 40, 40), (3, 2, 130, 40, 40)])
+@pytest.mark.parametrize("Hn,G,T,C1,Dk", [(19, 5, 10, 40, 40), (7, 1, 50, 40, 40), (3, 2, 130, 40, 40),
+                                             (5, 10, 10, 40, 40), (2, 21, 7, 12, 24)])
 def test_att_out_fwd_bwd(Hn, G, T, C1, Dk):
     g = torch.Generator().manual_seed(T)
     R = Hn * G
@@ -606,10 +607,10 @@ def test_softmax_loss():
     close(dl, logit.grad, rtol=1e-4, atol=1e-7, name="dlogit")
 
 
-@pytest.mark.parametrize("mode", [1, 0])
-def test_contrastive(mode):
+@pytest.mark.parametrize("mode,D", [(1, 40), (0, 40), (1, 128), (0, 128), (0, 200)])
+def test_contrastive(mode, D):
     g = torch.Generator().manual_seed(6 + mode)
-    Hn, G, D, thr = 40, 5, 40, 5
+    Hn, G, thr = 40, 5, 5
     B = Hn * G
     L, M, R = (rnd(g, Hn, D).requires_grad_(True) for _ in range(3))
     S = rnd(g, B, D).requires_grad_(True)
