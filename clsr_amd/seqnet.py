@@ -305,7 +305,7 @@ class SeqNet(CLSRNet):
         dhist, drnn = take(Hn, T, D), take(Hn, T, H)
         dtarget, dS, datt = take(B, D), take(B, D), take(B, D)
         dL, dM, dR, dhT = take(Hn, D), take(Hn, D), take(Hn, D), take(Hn, H)
-        datt = take(B, T)
+        dwts = take(B, T)      # DIEN: gradient w.r.t. the attention WEIGHTS (datt is d att_fea, [B, D])
         out = self._forward(f, True, None, zero_and_mark)
         dlogit = self._buf("dlogit", B)
         Gl = hp.train_num_ngs + 1
@@ -343,7 +343,7 @@ class SeqNet(CLSRNet):
             dPin2 = self._buf("a2.dPin", B * T, 3 * H)
             hprev2, gates2 = self._buf("a2.hprev", B, T, H), self._buf("a2.gates", B, T, 3 * H)
             d2 = ops.gru_desc(H, Wgh=P[g2 + "gates/kernel"][H:], ldg=2 * H, Wch=P[g2 + "candidate/kernel"][H:], ldc=H,
-                              hprev=hprev2, gates=gates2, dhT=dhT2, dPin=dPin2, lddp=3 * H, att=wts, datt=datt,
+                              hprev=hprev2, gates=gates2, dhT=dhT2, dPin=dPin2, lddp=3 * H, att=wts, datt=dwts,
                               in_div=G)
             ops.rnn_multi("clsr_rnn_bwd_multi", [d2], None, seq_len, ls, B, T)
             self._dw(hprev2, H, dPin2, 3 * H, B * T, H, 2 * H, Gd[g2 + "gates/kernel"][H:], 2 * H)
@@ -360,7 +360,7 @@ class SeqNet(CLSRNet):
                      db=Gd[g2 + "candidate/bias"])
             self._gemm(dPin2h, 3 * H, "a2.xw^T", M, 3 * H, H, drnn, H, acc=1)
             # attention backward through its weights, then the first GRU
-            dq = self._att_bwd("st", sc["att"], None, rnn1, target, drnn, Hn, G, T, H, D, seq_len, ls, dw_in=datt)
+            dq = self._att_bwd("st", sc["att"], None, rnn1, target, drnn, Hn, G, T, H, D, seq_len, ls, dw_in=dwts)
             call("clsr_copy_cols", dq, D, 0, 1, B, D, dtarget, D, 0, 1)
             dPinAll = self._buf("xw.dPin", M, NX)
             ops.rnn_multi("clsr_rnn_bwd_multi", [self._gru_bwd_desc("gs", sc["gru1"], H, dPinAll, Hn, T, None, drnn,

@@ -5,7 +5,7 @@ Random small shapes -- embedding width D (= Du = H), history length T, positives
 kind, MLP widths, losses, sequence-length patterns incl. length-1 histories and P = 1 -- one training step and one
 scoring pass each, compared with oracle/clsr_oracle.py: logits, the five loss terms, every dense gradient.
 
-    python scripts/fuzz_step.py [n_cases] [seed]
+    python scripts/fuzz_step.py [n_cases] [seed] [clsr,gru4rec,din,sli_rec,a2svd,dien]
 """
 import os
 import sys
@@ -19,8 +19,12 @@ sys.path.insert(0, ROOT)
 
 from bench import build_hparams  # noqa: E402
 from clsr_amd.net import CLSRNet  # noqa: E402
+from clsr_amd.seqnet import SeqNet  # noqa: E402
 from clsr_amd.synthetic import synthetic_feed  # noqa: E402
 from oracle import clsr_oracle as O  # noqa: E402
+from oracle import sibling_oracle as SO  # noqa: E402
+
+SIB_TYPES = {"gru4rec": "GRU4Rec", "din": "DIN", "sli_rec": "sli_rec", "a2svd": "A2SVD", "dien": "DIEN"}
 
 
 def close(got, exp, rtol, atol):
@@ -34,7 +38,7 @@ def close(got, exp, rtol, atol):
     return None
 
 
-def one_case(rng, idx):
+def one_case(rng, idx, kind="clsr"):
     D = int(rng.choice([8, 12, 16, 20, 24, 32, 40, 48, 52, 64, 96, 128]))
     Dc = int(rng.choice([4, 8])) if D > 8 else 4
     T = int(rng.choice([1, 2, 3, 5, 8, 10, 17, 50]))
@@ -55,15 +59,26 @@ def one_case(rng, idx):
         tok = os.environ["FUZZ_CASE"].split(",")
         D, Dc, T, P, G = (int(x) for x in tok[:5])
         over.update(sequential_model=tok[5], train_num_ngs=G - 1)
-    cfg = dict(T=T, Di=D - Dc, Dc=Dc, Du=D, H=D, Vu=50, Vi=200, Vc=12)
-    desc = "case %d: D=%d Dc=%d T=%d P=%d G=%d %s" % (idx, D, Dc, T, P, G, over)
+    if kind != "clsr":    # the siblings: free hidden / attention / user widths (reference sli_rec.yaml & co.)
+        over.update(model_type=SIB_TYPES[kind], user_embedding_dim=int(rng.choice([4, 16, 40])),
+                    attention_size=int(rng.choice([8, 20, 40])), hidden_size=int(rng.choice([8, 20, 40, 64])))
+        if kind == "sli_rec":
+            over["hidden_size"] = D      # alpha mixes the A2SVD feature (D wide) with the encoder feature (H wide)
+        if kind in ("sli_rec", "a2svd"):
+            over["attention_size"] = D   # the A2SVD query is contracted with the projected history (base_model.py:622)
+    cfg = dict(T=T, Di=D - Dc, Dc=Dc, Du=D, H=over.get("hidden_size", D), Vu=50, Vi=200, Vc=12)
+    desc = "case %d %s: D=%d Dc=%d T=%d P=%d G=%d %s" % (idx, kind, D, Dc, T, P, G, over)
     one_case.desc = desc
     hp = build_hparams(cfg, P, **over)
     dims = dict(Vu=cfg["Vu"], Vi=cfg["Vi"], Vc=cfg["Vc"])
     lengths = str(rng.choice(["full", "uniform", "lognormal"])) if T > 1 else "full"
+    feed_seed, short = int(rng.integers(1 << 30)), rng.random() < 0.5
+    only = os.environ.get("FUZZ_ONLY")   # "6,11": run these case numbers only (the random stream stays the same)
+    if only and str(idx) not in only.split(","):
+        return desc, None
     feed = synthetic_feed(P, T, dims["Vu"], dims["Vi"], dims["Vc"], G=G, lengths=lengths,
-                          ids="uniform", seed=int(rng.integers(1 << 30)))
-    if rng.random() < 0.5 and T > 1:     # force some length-1 histories
+                          ids="uniform", seed=feed_seed)
+    if short and T > 1:     # force some length-1 histories
         k = max(1, P // 3)
         rows = np.arange(k * G)
         for key in ("item_history", "item_cate_history", "mask", "time_diff", "time_from_first_action",
@@ -71,23 +86,29 @@ def one_case(rng, idx):
             feed[key][rows, 1:] = 0
     problems = []
     for dedup in (True, False):
-        params32 = O.init_params(dims, hp, seed=idx, scale_dense=8.0)
-        net = CLSRNet(hp, dims, device="cuda:0", seed=0, dedup_histories=dedup)
+        if kind == "clsr":
+            orc, extra = O, ()
+            params32 = O.init_params(dims, hp, seed=idx, scale_dense=8.0)
+            net = CLSRNet(hp, dims, device="cuda:0", seed=0, dedup_histories=dedup)
+        else:
+            orc, extra = SO, (kind,)
+            params32 = SO.init_params(dims, hp, kind, seed=idx, scale_dense=8.0)
+            net = SeqNet(hp, dims, kind=kind, device="cuda:0", seed=0, dedup_histories=dedup)
         sd = dict(params32)
-        sd.update(O.init_bn_state(params32))
+        sd.update(orc.init_bn_state(params32))
         net.load_state_dict(sd, strict=True)
         params = type(params32)((k, v.double()) for k, v in params32.items())
-        tf = O.to_torch_feed(feed, dtype=torch.float64)
-        bn = O.init_bn_state(params)
+        tf = orc.to_torch_feed(feed, dtype=torch.float64)
+        bn = orc.init_bn_state(params)
         # scoring (moving statistics)
-        ev = O.forward(params, bn, tf, hp, False)
+        ev = orc.forward(params, bn, tf, hp, *extra, False)
         got_ev = net.forward(net.upload(feed, False), False)
         torch.cuda.synchronize()
         e = close(got_ev["logit"], ev["logit"], 1e-4, 1e-4)
         if e:
             problems.append("dedup=%s eval logit: %s" % (dedup, e))
-        adam = O.init_adam(params)
-        _, _, _, ls, _, _, out = O.train_step(params, bn, adam, 1, tf, hp)
+        adam = orc.init_adam(params)
+        _, _, _, ls, _, _, out = orc.train_step(params, bn, adam, 1, tf, hp, *extra)
         net.capture_grads = True
         got = net.train_step(net.upload(feed, True))
         torch.cuda.synchronize()
@@ -95,7 +116,8 @@ def one_case(rng, idx):
         if e:
             problems.append("dedup=%s train logit: %s" % (dedup, e))
         gl = net.read_losses()
-        for k in ("loss", "data_loss", "regular_loss", "contrastive_loss", "discrepancy_loss"):
+        for k in ("loss", "data_loss", "regular_loss") + (("contrastive_loss", "discrepancy_loss")
+                                                            if kind == "clsr" else ()):
             e = close([gl[k]], [float(ls[k])], 1e-5, 1e-6)
             if e:
                 problems.append("dedup=%s %s: %s" % (dedup, k, e))
@@ -112,25 +134,33 @@ def one_case(rng, idx):
             if e:
                 problems.append("dedup=%s grad %s: %s" % (dedup, name, e))
                 if os.environ.get("FUZZ_TRACE"):
-                    print(name, "got", net.captured["dense"][name].reshape(-1)[:6].tolist(), "exp",
-                          raw[name].reshape(-1)[:6].tolist())
+                    gt, ex = net.captured["dense"][name].double().cpu(), raw[name].double().cpu()
+                    badm = (gt - ex).abs() > (2e-3 * ex.abs() + 2e-4 * scale + floor)
+                    idx_bad = badm.nonzero()
+                    print(name, tuple(ex.shape), "mismatches", int(badm.sum()), "first", idx_bad[:4].tolist(), "last",
+                          idx_bad[-2:].tolist())
+                    for ij in idx_bad[:4].tolist():
+                        print("   ", ij, "got", float(gt[tuple(ij)]), "exp", float(ex[tuple(ij)]))
     return desc, problems
 
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    kinds = sys.argv[3].split(",") if len(sys.argv) > 3 else ["clsr"]
     rng = np.random.default_rng(seed)
     bad = 0
     for i in range(n):
         try:
-            desc, problems = one_case(rng, i)
+            desc, problems = one_case(rng, i, kinds[i % len(kinds)])
         except Exception as exc:
             bad += 1
             print("CRASH " + getattr(one_case, "desc", "case %d" % i))
             print("    " + traceback.format_exc().strip().splitlines()[-1][:400])
             if os.environ.get("FUZZ_TRACE"):
                 traceback.print_exc()
+            continue
+        if problems is None:
             continue
         if problems:
             bad += 1

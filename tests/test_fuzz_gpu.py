@@ -1,0 +1,34 @@
+"""Random small shapes of the training / scoring step against the oracles (scripts/fuzz_step.py): widths that are
+not the golden 40, lengths 1..50, 1..64 positives, 2..10 rows per positive, all encoders and sibling models.  The
+seeds below include the cases that exposed real limits (groups of more than 8 rows in the attention backward, bpr on
+wide embeddings, DIN with D > T)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(n, seed, kinds):
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import fuzz_step
+
+    rng = np.random.default_rng(seed)
+    failures = []
+    for i in range(n):
+        desc, problems = fuzz_step.one_case(rng, i, kinds[i % len(kinds)])
+        if problems:
+            failures.append((desc, problems[:6]))
+    assert not failures, failures
+
+
+def test_clsr_random_shapes():
+    _run(16, 0, ["clsr"])
+
+
+def test_sibling_random_shapes():
+    _run(30, 7, ["gru4rec", "din", "sli_rec", "a2svd", "dien"])
