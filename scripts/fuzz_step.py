@@ -44,6 +44,9 @@ def one_case(rng, idx, kind="clsr"):
     T = int(rng.choice([1, 2, 3, 5, 8, 10, 17, 50]))
     P = int(rng.choice([1, 2, 3, 7, 16, 33, 64]))
     G = int(rng.choice([2, 3, 5, 10]))
+    if os.environ.get("FUZZ_LONG"):      # histories across the 64-step chunks of the attention kernels (slow oracle)
+        T = int(rng.choice([63, 64, 65, 100, 129, 250]))
+        P = int(rng.choice([2, 3, 5]))
     enc = str(rng.choice(["time4lstm", "gru", "lstm"]))
     over = dict(
         sequential_model=enc, train_num_ngs=G - 1,
@@ -59,6 +62,14 @@ def one_case(rng, idx, kind="clsr"):
         tok = os.environ["FUZZ_CASE"].split(",")
         D, Dc, T, P, G = (int(x) for x in tok[:5])
         over.update(sequential_model=tok[5], train_num_ngs=G - 1)
+    if kind == "clsr":
+        over.update(interest_evolve=bool(rng.random() < 0.7), predict_long_short=bool(rng.random() < 0.7),
+                    manual_alpha=bool(rng.random() < 0.25), manual_alpha_value=float(rng.choice([0.0, 0.3, 1.0])),
+                    embed_l2=float(rng.choice([0.0, 1e-6, 1e-3])), layer_l2=float(rng.choice([0.0, 1e-6, 1e-3])),
+                    discrepancy_loss_weight=float(rng.choice([0.0, 0.01, 0.5])),
+                    contrastive_loss_weight=float(rng.choice([0.0, 0.1, 1.0])),
+                    contrastive_margin=float(rng.choice([0.5, 1.0, 2.0])),
+                    max_grad_norm=float(rng.choice([0.01, 2.0])))
     if kind != "clsr":    # the siblings: free hidden / attention / user widths (reference sli_rec.yaml & co.)
         over.update(model_type=SIB_TYPES[kind], user_embedding_dim=int(rng.choice([4, 16, 40])),
                     attention_size=int(rng.choice([8, 20, 40])), hidden_size=int(rng.choice([8, 20, 40, 64])))
@@ -108,7 +119,7 @@ def one_case(rng, idx, kind="clsr"):
         if e:
             problems.append("dedup=%s eval logit: %s" % (dedup, e))
         adam = orc.init_adam(params)
-        _, _, _, ls, _, _, out = orc.train_step(params, bn, adam, 1, tf, hp, *extra)
+        new_p, new_bn, _, ls, grads, _, out = orc.train_step(params, bn, adam, 1, tf, hp, *extra)
         net.capture_grads = True
         got = net.train_step(net.upload(feed, True))
         torch.cuda.synchronize()
@@ -141,6 +152,20 @@ def one_case(rng, idx, kind="clsr"):
                           idx_bad[-2:].tolist())
                     for ij in idx_bad[:4].tolist():
                         print("   ", ij, "got", float(gt[tuple(ij)]), "exp", float(ex[tuple(ij)]))
+        # the applied update (clip + Adam, dense variables) and the batch-norm moving statistics
+        sd = net.state_dict()
+        for name in net.dense_names:
+            g_ = grads[name].double().reshape(-1)
+            sel = g_.abs() > 100 * floor      # Adam's first step is ~lr * sign(g): skip gradients at noise level
+            if int(sel.sum()):
+                e = close((sd[name].double().cpu().reshape(-1) - params[name].reshape(-1))[sel],
+                          (new_p[name].reshape(-1) - params[name].reshape(-1))[sel], 5e-3, 0.02 * hp.learning_rate)
+                if e:
+                    problems.append("dedup=%s adam update %s: %s" % (dedup, name, e))
+        for k, v in new_bn.items():
+            e = close(sd[k], v, 1e-4, 1e-6)
+            if e:
+                problems.append("dedup=%s %s: %s" % (dedup, k, e))
     return desc, problems
 
 
