@@ -32,3 +32,19 @@ def test_clsr_random_shapes():
 
 def test_sibling_random_shapes():
     _run(30, 7, ["gru4rec", "din", "sli_rec", "a2svd", "dien"])
+
+
+def test_model_api_random_batch_shapes(tmp_path):
+    """fit / run_weighted_eval / predict with random batch sizes, negatives per positive and file sizes (ragged last
+    batches, evaluation batches that cut groups apart): the product defaults (de-duplicated histories, compact feeds,
+    launch plans, look-ahead staging) against the plain row-by-row configuration."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import fuzz_model
+
+    rng = np.random.default_rng(0)
+    failures = []
+    for i in range(12):
+        desc, problems = fuzz_model.one_case(rng, i, str(tmp_path))
+        if problems:
+            failures.append((desc, problems[:6]))
+    assert not failures, failures
