@@ -130,8 +130,29 @@ class CLSRNet(object):
         D = hp.item_embedding_dim + hp.cate_embedding_dim
         if hp.hidden_size != D or hp.user_embedding_dim != D:
             bad.append("hidden_size and user_embedding_dim must equal item+cate dims (alpha fusion, clsr.py:265)")
+        bad += self._shape_limits(hp, rnn=True)
         if bad:
             raise NotImplementedError("CLSR HIP path does not support: " + "; ".join(bad))
+
+    @staticmethod
+    def _shape_limits(hp, rnn):
+        """Shape limits of the kernels (16-byte vector accesses, register-resident recurrent weights, 64-step
+        chunks of the attention softmax), reported here by name instead of as an 'unsupported shape' error code
+        of some launch in the middle of a step."""
+        bad = []
+        Di, Dc = int(hp.item_embedding_dim), int(hp.cate_embedding_dim)
+        if Di % 4 or Dc % 4 or Di <= 0 or Dc <= 0 or Di + Dc > 256:
+            bad.append("item / cate embedding dims must be positive multiples of 4, at most 256 together")
+        if rnn and (int(hp.hidden_size) % 4 or not 4 <= int(hp.hidden_size) <= 128):
+            bad.append("hidden_size must be a multiple of 4 in 4..128")
+        if int(hp.max_seq_length) > 256:
+            bad.append("max_seq_length must be at most 256")
+        widths = list(hp.layer_sizes) + list(getattr(hp, "att_fcn_layer_sizes", None) or [])
+        if any(int(w) % 4 or not 4 <= int(w) <= 1024 for w in widths):
+            bad.append("MLP layer widths must be multiples of 4 in 4..1024")
+        if any(int(w) > 256 for w in (getattr(hp, "att_fcn_layer_sizes", None) or [])):
+            bad.append("att_fcn_layer_sizes must be at most 256 wide")
+        return bad
 
     # ------------------------------------------------------------------ parameters
     # The variable inventory, the trained embedding tables and the recurrent encoders are hooks so that the sibling

@@ -66,6 +66,9 @@ class SeqNet(CLSRNet):
                 bad.append("hidden_size must equal item+cate dims (alpha fusion of att_fea1 and att_fea2, sli_rec.py:92)")
             if hp.attention_size != D:
                 bad.append("attention_size must equal item+cate dims (tensordot with query, base_model.py:622)")
+        bad += self._shape_limits(hp, rnn=self.kind in ("gru4rec", "sli_rec", "dien"))
+        if self.kind in ("a2svd", "sli_rec") and int(hp.attention_size) % 4:
+            bad.append("attention_size must be a multiple of 4")
         if bad:
             raise NotImplementedError("%s HIP path does not support: %s" % (self.kind, "; ".join(bad)))
 

@@ -62,6 +62,8 @@ def one_case(rng, idx, kind="clsr"):
         tok = os.environ["FUZZ_CASE"].split(",")
         D, Dc, T, P, G = (int(x) for x in tok[:5])
         over.update(sequential_model=tok[5], train_num_ngs=G - 1)
+        if len(tok) > 9:                 # ",a0,a1,l0,l1": pin the MLP widths too
+            over.update(att_fcn_layer_sizes=[int(tok[6]), int(tok[7])], layer_sizes=[int(tok[8]), int(tok[9])])
     if kind == "clsr":
         over.update(interest_evolve=bool(rng.random() < 0.7), predict_long_short=bool(rng.random() < 0.7),
                     manual_alpha=bool(rng.random() < 0.25), manual_alpha_value=float(rng.choice([0.0, 0.3, 1.0])),

@@ -61,3 +61,28 @@ def test_oracle_graphs_train(golden_dir, golden_hparams, kind):
     ls2 = O.gradients(new_p, new_bn, tf, hp, kind)[0]
     assert float(ls2["loss"]) < float(ls["loss"])
     assert "sequential/embedding/user_embedding" not in grads
+
+
+def test_shape_limits_are_reported_by_name(golden_hparams):
+    """Configurations outside the kernels' shape limits are refused when the net is built, with the limits named
+    (not as an 'unsupported shape' error code from a launch in the middle of the first step)."""
+    from clsr_amd.net import CLSRNet
+    from clsr_amd.seqnet import SeqNet
+
+    dims = dict(Vu=10, Vi=20, Vc=5)
+    for over, needle in ((dict(layer_sizes=[50, 25]), "MLP layer widths"),
+                         (dict(max_seq_length=300), "max_seq_length"),
+                         (dict(item_embedding_dim=30, cate_embedding_dim=10), "multiples of 4"),
+                         (dict(att_fcn_layer_sizes=[512, 40]), "att_fcn_layer_sizes")):
+        hp = copy.deepcopy(golden_hparams)
+        for k, v in over.items():
+            setattr(hp, k, v)
+        with pytest.raises(NotImplementedError, match=needle):
+            CLSRNet(hp, dims)
+        hp.model_type = "DIN"
+        with pytest.raises(NotImplementedError, match=needle):
+            SeqNet(hp, dims, kind="din")
+    hp = copy.deepcopy(golden_hparams)
+    hp.hidden_size, hp.model_type = 200, "GRU4Rec"
+    with pytest.raises(NotImplementedError, match="hidden_size"):
+        SeqNet(hp, dims, kind="gru4rec")
