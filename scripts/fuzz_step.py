@@ -140,12 +140,20 @@ def one_case(rng, idx, kind="clsr"):
             # decided by rounding noise -- gradients are not comparable there; values and losses are
             continue
         raw = out["raw_grads"]
+        raw32 = None
+        if os.environ.get("FUZZ_F32"):   # conditioning check: how far is a float32 run of the ORACLE from its float64 run?
+            p32 = type(params32)((k, v.float()) for k, v in params32.items())
+            raw32 = orc.train_step(p32, orc.init_bn_state(p32), orc.init_adam(p32), 1,
+                                   orc.to_torch_feed(feed, dtype=torch.float32), hp, *extra)[6]["raw_grads"]
         floor = 4e-6 * max(float(raw[n].abs().max()) for n in net.dense_names)
         for name in net.dense_names:
             scale = float(raw[name].abs().max()) + 1e-12
             e = close(net.captured["dense"][name], raw[name], 2e-3, 2e-4 * scale + floor)
             if e:
                 problems.append("dedup=%s grad %s: %s" % (dedup, name, e))
+                if raw32 is not None:
+                    problems.append("      float32 oracle vs float64 oracle: max abs err %.3e" %
+                                    float((raw32[name].double() - raw[name].double()).abs().max()))
                 if os.environ.get("FUZZ_TRACE"):
                     gt, ex = net.captured["dense"][name].double().cpu(), raw[name].double().cpu()
                     badm = (gt - ex).abs() > (2e-3 * ex.abs() + 2e-4 * scale + floor)

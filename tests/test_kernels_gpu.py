@@ -165,7 +165,7 @@ def _pgemm(X, W, bias=None, T=0, G=0, Xmul=None, in_scale=None, in_shift=None, r
     return Y, st
 
 
-@pytest.mark.parametrize("M,K,N", [(1000, 80, 80), (333, 40, 40), (77, 164, 80), (515, 100, 64),
+@pytest.mark.parametrize("M,K,N", [(1000, 80, 80), (333, 40, 40), (77, 164, 80), (515, 100, 64), (2304, 256, 256), (768, 256, 256),
                                    (260, 40, 240), (129, 80, 100), (50, 64, 4), (2000, 120, 120),
                                    (200, 516, 80), (300, 1536, 128), (90, 320, 80)])   # wide K: chunked launches
 def test_pgemm_plain_bias_stats(M, K, N):
@@ -211,7 +211,8 @@ def test_pgemm_rowmap_mul_affine_adds():
     assert float(out[:, :4].abs().max()) == 0 and float(out[:, 4 + K:].abs().max()) == 0
 
 
-@pytest.mark.parametrize("M,K,N", [(1000, 80, 80), (4097, 40, 120), (300, 164, 80), (64, 100, 64), (999, 80, 40)])
+@pytest.mark.parametrize("M,K,N", [(1000, 80, 80), (4097, 40, 120), (300, 164, 80), (64, 100, 64), (999, 80, 40),
+                                   (2304, 256, 256), (768, 256, 256)])
 def test_pgemm_dw(M, K, N):
     g = torch.Generator().manual_seed(M)
     X, dY = rnd(g, M, K), rnd(g, M, N)
@@ -250,7 +251,7 @@ def test_pgemm_dw_prologues():
 
 
 # ------------------------------------------------------------------------------- batch norm
-@pytest.mark.parametrize("M,C", [(1200, 80), (777, 40), (300, 100), (64, 64)])
+@pytest.mark.parametrize("M,C", [(1200, 80), (777, 40), (300, 100), (64, 64), (2304, 256)])
 def test_bn_forward_backward(M, C):
     g = torch.Generator().manual_seed(C)
     z = (rnd(g, M, C) * 1.5 + 0.3).float().double().requires_grad_(True)
@@ -293,7 +294,8 @@ def test_bn_forward_backward(M, C):
 
 # ------------------------------------------------------------------------------- attention tail
 @pytest.mark.parametrize("Hn,G,T,C1,Dk", [(19, 5, 10, 40, 40), (7, 1, 50, 40, 40), (3, 2, 130, 40, 40),
-                                             (5, 10, 10, 40, 40), (2, 21, 7, 12, 24)])
+                                             (5, 10, 10, 40, 40), (2, 21, 7, 12, 24), (3, 3, 256, 256, 40),
+                                             (9, 1, 256, 256, 128)])
 def test_att_out_fwd_bwd(Hn, G, T, C1, Dk):
     g = torch.Generator().manual_seed(T)
     R = Hn * G
