@@ -131,6 +131,8 @@ _TRAIN, _VALID, _TEST = 0, 1, 2
 def _global_time_split(ts, interval):
     """0 / 1 / 2 = train / valid / test: the last ``interval`` of the log is test, the one before it valid."""
     t = np.asarray([int(x) for x in ts], dtype=np.int64)
+    if t.size == 0:     # the reference indexes the last element of an empty sorted list here (sequential_reviews.py:722)
+        raise IndexError("list index out of range: no interaction survives the user sample and the 10-core filters")
     test_from = t.max() - interval
     valid_from = t.max() - 2 * interval
     return np.where(t < valid_from, _TRAIN, np.where(t < test_from, _VALID, _TEST))

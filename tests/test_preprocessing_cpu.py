@@ -73,3 +73,21 @@ def test_preprocessed_files_feed_the_iterator(tmp_path):
             assert np.all(lab.reshape(-1, g)[:, 0] == 1) and lab.sum() == lab.size // g
     with pytest.raises(ValueError):
         data_preprocessing("x", "", "a", "b", "c", "d", "e", "f", dataset="amazon")
+
+
+def test_log_that_does_not_survive_the_filters_raises_like_the_reference(tmp_path):
+    """A raw log too thin for the 5 % user sample + 10-core filters: the reference dies with IndexError when it
+    indexes the last touch time (sequential_reviews.py:722); same exception type here (scripts/fuzz_preprocessing.py)."""
+    import pytest
+
+    from clsr_amd.sequential_reviews import data_preprocessing
+    from clsr_amd.synthetic import make_raw_taobao_csv
+
+    raw = str(tmp_path / "UserBehavior.csv")
+    make_raw_taobao_csv(raw, seed=5, n_users=300, n_items=54, n_cates=21, events_per_user=12)
+    d = str(tmp_path) + "/"
+    random.seed(1)
+    np.random.seed(1)
+    with pytest.raises(IndexError):
+        data_preprocessing(raw, d, d + "tr", d + "va", d + "te", d + "u.pkl", d + "i.pkl", d + "c.pkl", sample_rate=0.3,
+                           valid_num_ngs=4, test_num_ngs=1, dataset="taobao", is_history_expanding=False)
