@@ -353,7 +353,14 @@ class SequentialBaseModel(BaseModel):
         pending = None
         for batch_data_input in _prefetch(file_iterator):
             if batch_data_input:
-                staged = self._stage(self._to_arrays(batch_data_input, True), lookahead=self._overlap_upload)
+                arrays = self._to_arrays(batch_data_input, True)
+                if self._dist is not None:
+                    # a last batch with fewer positives than ranks cannot be sharded: every rank sees the same
+                    # global batch and skips it alike
+                    n_pos = arrays["labels"].shape[0] // (self.train_num_ngs + 1)
+                    if n_pos < self._dist.get_world_size():
+                        continue
+                staged = self._stage(arrays, lookahead=self._overlap_upload)
                 if pending is not None:
                     run(pending)
                 pending = staged

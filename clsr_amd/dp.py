@@ -91,10 +91,11 @@ def shard_feed(feed, rank, world, group_size):
             out[k] = v[rank * per * step:(rank + 1) * per * step]
         return out
     B = feed["labels"].shape[0]
-    if B % (group_size * world):
-        raise ValueError("global batch rows (%d) must be a multiple of group_size*world (%d)"
-                         % (B, group_size * world))
-    per = B // world
+    if B % group_size:
+        raise ValueError("global batch rows (%d) must be a multiple of the group size (%d)" % (B, group_size))
+    per = (B // group_size // world) * group_size      # whole groups per rank; a remainder is dropped like above
+    if per == 0:
+        raise ValueError("global batch of %d positives cannot feed %d ranks" % (B // group_size, world))
     return {k: v[rank * per:(rank + 1) * per] for k, v in feed.items()}
 
 

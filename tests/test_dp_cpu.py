@@ -56,11 +56,17 @@ def test_shard_feed_keeps_groups_together():
     assert a["labels"].shape[0] == b["labels"].shape[0] == 20
     assert set(a["users"]) & set(b["users"]) == set()
     np.testing.assert_array_equal(np.concatenate([a["labels"], b["labels"]]), feed["labels"])
-    try:
-        shard_feed(feed, 0, 3, G)
-        assert False
-    except ValueError:
-        pass
+    # 8 positives over 3 ranks: two whole groups each, the remainder is dropped (last partial batch of an epoch),
+    # exactly like the compact layout
+    parts = [shard_feed(feed, r, 3, G) for r in range(3)]
+    assert [p["labels"].shape[0] for p in parts] == [10, 10, 10]
+    np.testing.assert_array_equal(np.concatenate([p["labels"] for p in parts]), feed["labels"][:30])
+    for bad_world, bad_g in ((9, G), (2, 3)):      # more ranks than positives; rows that are not whole groups
+        try:
+            shard_feed(feed, 0, bad_world, bad_g)
+            assert False
+        except ValueError:
+            pass
 
 
 def _rows_worker(rank, world, port, out):
