@@ -251,3 +251,47 @@ def test_sibling_models_two_ranks_match_single_process(golden_dir, golden_hparam
     for k, v in single.captured["tables"].items():
         v = v.cpu().numpy()
         assert float(np.abs(out["tgrads"][k] - v).max()) <= 2e-3 * float(np.abs(v).max()) + floor, k
+
+
+def _epoch_worker(rank, world, port, hp, train, dedup, out):
+    import random
+
+    import torch.distributed as dist
+
+    from clsr_amd.clsr import CLSRModel
+    from clsr_amd.sequential_iterator import SASequentialIterator
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = CLSRModel(hp, SASequentialIterator, seed=3, dist=_HostStagedDist(dist), sync_bn=True,
+                      dedup_histories=dedup)
+    random.seed(11)
+    it = model.iterator.load_data_from_file(train, batch_num_ngs=hp.train_num_ngs)
+    loss = model.batch_train(it, model.sess)
+    torch.cuda.synchronize()
+    out[rank] = dict(loss=float(loss), item=model.net.tables["item"].cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dedup", [True, False])
+def test_two_rank_epoch_with_ragged_end(golden_dir, golden_hparams, dedup):
+    """A whole data-parallel epoch whose batches do not divide by the ranks: 600 lines in batches of 85 positives
+    (odd: one positive per batch is dropped by the sharding, compact and row layout alike) and a last batch of 5;
+    then batches of 599, whose last batch of ONE positive cannot feed two ranks and is skipped on both."""
+    import torch.multiprocessing as mp
+
+    train = os.path.join(golden_dir, "data", "train_data")
+    for bs in (85, 599):
+        hp = copy.deepcopy(golden_hparams)
+        hp.batch_size = bs
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        ctx = mp.get_context("spawn")
+        out = ctx.Manager().dict()
+        mp.spawn(_epoch_worker, args=(2, port, hp, train, dedup, out), nprocs=2, join=True)
+        assert np.isfinite(out[0]["loss"]) and out[0]["loss"] == out[1]["loss"]
+        np.testing.assert_array_equal(out[0]["item"], out[1]["item"])      # replicas stay bit-identical
