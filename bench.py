@@ -6,20 +6,26 @@
 One "step" = one pass of the hot path (forward, losses, backward, per-tensor clip, Adam incl.
 the dense embedding-table sweeps, BN moving statistics) over one synthetic Taobao-shaped batch
 (BASELINE.json configs[1]: batch 4096 positives x (1+4) rows, seq_len 50, emb_dim 40), inputs
-already resident in HBM, replayed as one hipGraph.  Rank 0 prints ONE JSON line:
+already resident in HBM.  Rank 0 prints ONE JSON line:
 metric = train interactions/sec (interaction = one positive train line).
 
 N > 1: one process per GPU (torch.distributed, backend nccl == RCCL), weak scaling (every rank
-owns its own 4096-positive batch); the gradient exchange (dense all-reduce or sparse touched-row
-all-gather per table, see clsr_amd/dp.py) runs between backward and update; DP steps are launched eagerly.
+owns its own 4096-positive batch); `python bench.py --gpus N` re-executes itself under
+torch.distributed.run, and the same file is the per-rank program when the driver launches it that way.
+The gradient exchange (dense all-reduce or sparse touched-row exchange per table, see clsr_amd/dp.py)
+overlaps the tail of the backward pass; DP steps are launched eagerly.
 
 Extra objects on the line:
-  roofline      the embedding-history gather (north-star kernel; HBM bound): algorithmic bytes per
-                launch / average launch duration measured here with HIP events, on the HBM-resident
-                100M-item catalogue table (N = 1); the cache-resident figure of the benchmarked config is
-                carried inside it.
-  roofline_mfma the most expensive kernel of the step (short-term attention layer-0 fp32-MFMA GEMM).
-  cpu_baseline  the CPU oracle (torch, all host cores) on a bounded sample of the same workload.
+  roofline        the embedding-history gather (north-star kernel; HBM bound): algorithmic bytes per
+                  launch / average launch duration measured here with HIP events, on the HBM-resident
+                  100M-item catalogue table (N = 1); the cache-resident figure of the benchmarked config is
+                  carried inside it.
+  roofline_mfma   the most expensive kernel of the step (short-term attention layer-0 GEMM).
+  cpu_baseline    the CPU oracle (torch, all host cores) on a bounded sample of the same workload.
+  precision_modes step time of the other storage mode (fp32 = parity mode, bf16 = speed mode: bf16 storage of the
+                  attention activations + bf16 MFMA, fp32 accumulation / statistics / optimiser).
+  extra_workloads BASELINE configs[2] (kuaishou) and configs[4] (catalogue100m, single GPU), and the
+                  reference-exact clip mode (history replication, `--exact-clip` makes it the headline).
 
 Other workloads: --config kuaishou (configs[2]) | catalogue100m (configs[4], lazy Adam).
 Experiment switches (environment): CLSR_FORCE_DP=1 (DP code path with one rank), CLSR_SPARSE_TABLES=auto|all|none,
@@ -37,6 +43,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # four concurrently active str
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+CONFIG_INDEX = {"taobao": "1", "kuaishou": "2", "catalogue100m": "4"}
 
 
 def build_hparams(cfg, batch_size, **over):
@@ -78,9 +86,15 @@ def time_kernel(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def cpu_baseline(cfg, seconds=15.0, P=256):
+def cpu_baseline(cfg, seconds=25.0, P=None, warmup=1, steps=None):
     """The oracle (torch-CPU fp32 restatement of the reference graph, dense-Adam semantics) timed on
-    the host cores on a bounded sample of the same workload (P positives instead of 4096)."""
+    the host cores on the SAME workload (P = 4096 positives x5 rows, same synthetic batch as the GPU step).
+
+    Protocol (BASELINE.md section 2 / SURVEY 8d): 5 warm-ups + >= 20 timed steps.  One step of this size costs
+    tens of seconds on the host, so the DEFAULT run is bounded (task contract: a 10-30 s sample): ``warmup``
+    untimed steps, then timed steps until ``seconds`` have passed (at least one); ``--cpu-warmup 5 --cpu-steps 20``
+    runs the full protocol.  The oracle runs with its input-side RNN projections hoisted out of the T loop
+    (oracle.FAST_RNN: same math, one batched product per encoder instead of T small ones)."""
     import torch
     from oracle import clsr_oracle as O
     from clsr_amd.synthetic import synthetic_feed
@@ -88,26 +102,163 @@ def cpu_baseline(cfg, seconds=15.0, P=256):
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = min(cores, 64)
     torch.set_num_threads(cores)
+    P = P or cfg["P"]
     big = cfg["Vi"] >= 10_000_000   # catalogue configs: lazy Adam is mandatory, ids uniform
     hp = build_hparams(cfg, P, **({"optimizer": "lazyadam"} if big else {}))
     dims = dict(Vu=cfg["Vu"], Vi=cfg["Vi"], Vc=cfg["Vc"])
     params = O.init_params(dims, hp, seed=0)
     bn, adam = O.init_bn_state(params), O.init_adam(params)
     feed = O.to_torch_feed(synthetic_feed(P, cfg["T"], cfg["Vu"], cfg["Vi"], cfg["Vc"], lengths="full"))
-    tw = time.perf_counter()
-    O.train_step(params, bn, adam, 1, feed, hp)  # warm-up
-    log("cpu baseline warm-up step took %.1fs on %d threads" % (time.perf_counter() - tw, cores))
-    n, t0 = 0, time.perf_counter()
-    while True:
-        params, bn, adam, _, _, _, _ = O.train_step(params, bn, adam, n + 2, feed, hp)
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt > seconds or n >= 50:
-            break
+    O.FAST_RNN = True
+    try:
+        tw = time.perf_counter()
+        for i in range(warmup):
+            params, bn, adam, _, _, _, _ = O.train_step(params, bn, adam, i + 1, feed, hp)
+        log("cpu baseline: %d warm-up step(s) took %.1fs on %d threads" % (warmup, time.perf_counter() - tw, cores))
+        n, t0 = 0, time.perf_counter()
+        while True:
+            params, bn, adam, _, _, _, _ = O.train_step(params, bn, adam, warmup + n + 1, feed, hp)
+            n += 1
+            dt = time.perf_counter() - t0
+            if (steps is not None and n >= steps) or (steps is None and (dt > seconds or n >= 20)):
+                break
+    finally:
+        O.FAST_RNN = False
+    full = warmup >= 5 and n >= 20
     return dict(value=round(P * n / dt, 2), unit="interactions/s", cores=cores, kind="port",
-                sample="%d steps of batch %d positives x5 rows, seq_len %d, same tables (oracle/clsr_oracle.py, "
-                       "torch-CPU fp32, %d threads); the reference's TF-1.15 CPU path cannot run here"
-                       % (n, P, cfg["T"], cores))
+                ms_per_step=round(dt * 1e3 / n, 1),
+                sample="%d warm-up + %d timed steps of the benchmarked batch itself (%d positives x5 rows, seq_len %d, "
+                       "same tables; oracle/clsr_oracle.py, torch-CPU fp32, %d threads, input projections hoisted "
+                       "out of the T loop)%s; the reference's TF-1.15 CPU path cannot run here"
+                       % (warmup, n, P, cfg["T"], cores,
+                          "" if full else "; bounded sample (task contract: 10-30 s of CPU work) instead of the 5 + 20 "
+                                          "steps of BASELINE.md section 2, which take ~10 min: --cpu-warmup 5 --cpu-steps 20"))
+
+
+class Workload(object):
+    """One (config, model, precision, clip mode) training workload with its feed resident in HBM."""
+
+    def __init__(self, config, model="clsr", precision="fp32", dedup=True, lengths="full", rank=0, local_rank=0):
+        import torch
+        from clsr_amd.net import CLSRNet
+        from clsr_amd.synthetic import CONFIGS, synthetic_feed
+
+        self.name, self.model, self.precision, self.dedup = config, model, precision, dedup
+        cfg = self.cfg = CONFIGS[config]
+        self.P, self.T, self.G = cfg["P"], cfg["T"], 5
+        self.big = cfg["Vi"] >= 10_000_000   # catalogue configs: lazy Adam is mandatory (SURVEY 8d), ids uniform
+        big = self.big
+        dims = dict(Vu=cfg["Vu"], Vi=cfg["Vi"], Vc=cfg["Vc"])
+        dev = "cuda:%d" % local_rank
+        if model == "clsr":
+            self.hp = build_hparams(cfg, self.P, **({"optimizer": "lazyadam"} if big else {}))
+            self.net = CLSRNet(self.hp, dims, device=dev, seed=0, dedup_histories=dedup, precision=precision)
+        else:
+            from clsr_amd.seqnet import SeqNet
+
+            self.hp = build_hparams(cfg, self.P, model_type=model, user_embedding_dim=16,
+                                    attention_size=cfg["Di"] + cfg["Dc"], **({"optimizer": "lazyadam"} if big else {}))
+            self.net = SeqNet(self.hp, dims, kind=model, device=dev, seed=0)
+        if os.environ.get("CLSR_NO_OVERLAP"):
+            self.net.overlap = False
+        if os.environ.get("CLSR_DW_EAGER"):
+            self.net.defer_dw = False
+        self.feed = synthetic_feed(self.P, self.T, cfg["Vu"], cfg["Vi"], cfg["Vc"], G=self.G, lengths=lengths,
+                                   seed=20220425 + rank, ids="uniform" if big else "zipf")
+        self.f = self.net.upload(self.feed, True)
+        self.stepper = None
+        self.torch = torch
+
+    def describe(self):
+        cfg = self.cfg
+        return ("BASELINE configs[%s]: %s %s train step, batch %d positives x5 rows (B=%d), seq_len %d, "
+                "Di/Dc/Du/H=%d/%d/%d/%d, Vu/Vi/Vc=%d/%d/%d, %s%s" % (
+                    CONFIG_INDEX.get(self.name, "?"), self.name,
+                    {"clsr": "CLSR", "gru4rec": "GRU4Rec (sibling model)", "din": "DIN (sibling model)",
+                     "sli_rec": "SLi-Rec (sibling model)", "a2svd": "A2SVD (sibling model)",
+                     "dien": "DIEN (sibling model, relu)"}[self.model],
+                    self.P, self.P * self.G, self.T, cfg["Di"], cfg["Dc"], cfg["Du"] if self.model == "clsr" else 16,
+                    cfg["H"], cfg["Vu"], cfg["Vi"], cfg["Vc"],
+                    "time4lstm + triplet, " if self.model == "clsr" else "",
+                    "lazy Adam (row lists)" if self.big else "dense Adam"))
+
+    def step(self):
+        if self.stepper is None:
+            self.net.train_step(self.f)
+        else:
+            self.stepper.train_step(self.f)
+
+    def run(self, steps, warmup, dist=None, graph=False, host_losses=None):
+        """``warmup`` untimed steps, then exactly ``steps`` timed ones bracketed by barrier + device sync on both
+        sides; returns seconds (max over ranks)."""
+        from clsr_amd import ops
+        torch = self.torch
+
+        stream = torch.cuda.current_stream()
+        for i in range(2):
+            self.step()
+            stream.synchronize()
+        # data-parallel runs stay eager: the RCCL watchdog thread of torch.distributed polls its events while a
+        # stream capture is open, which can invalidate the capture (hipErrorCapturedEvent, seen on the catalogue
+        # config); eager launches cost ~1-2 ms of host time per step and are hidden behind the device step
+        self.use_graph = graph and (self.stepper is None or bool(os.environ.get("CLSR_DP_GRAPH")))
+        if not self.use_graph:
+            run = self.step
+        elif self.stepper is None:
+            ops.graph_begin()
+            self.net.train_step(self.f)
+            g = ops.graph_end()
+            run = lambda: ops.graph_launch(g)
+        else:
+            run = self.stepper.capture(self.f)
+        for _ in range(warmup):
+            run()
+        stream.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+            if host_losses is not None:
+                host_losses.copy_(self.net.losses, non_blocking=True)  # what CLSRModel.train() returns each step
+        stream.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax)
+        return dt
+
+    def free(self):
+        self.net = self.f = self.stepper = None
+        self.torch.cuda.empty_cache()
+
+
+def gather_roofline(net, f, cfg, G, feed, big):
+    """HIP-event timing of the history gather of ``net`` on its own tables (SURVEY 8d byte formula)."""
+    from clsr_amd import ops
+
+    T, Hn = cfg["T"], cfg["P"]
+    D = cfg["Di"] + cfg["Dc"]
+    hist = net._buf("hist", Hn, T, D)
+    hm, hr = net._buf("hist_mean", Hn, D), net._buf("hist_recent", Hn, D)
+
+    def gather():
+        ops.call("clsr_gather_hist_fwd", net.tables["item"], net.tables["cate"], f["item_history"],
+                 f["item_cate_history"], G * T, f["seq_len"], G, Hn, T, cfg["Di"], cfg["Dc"], 3, hist, hm, hr)
+
+    t_gather = time_kernel(gather)
+    lens = np.asarray(feed["mask"]).sum(1)[::G]
+    n_valid = float(lens.sum())
+    # SURVEY 8d: bytes_gather_fwd(n) = n*(Di+Dc)*(s_t + s_a) + 2*n*4 per gathered history row
+    gbytes = n_valid * D * (4 + 4) + 2 * n_valid * 4
+    return dict(bound="hbm", kernel="gather_hist_fwd_kernel", achieved=round(gbytes / t_gather / 1e9, 1),
+                peak=8000.0, unit="GB/s", frac=round(gbytes / t_gather / 8e12, 4),
+                bytes_per_launch=gbytes, us_per_launch=round(t_gather * 1e6, 2))
 
 
 def main():
@@ -120,29 +271,52 @@ def main():
     ap.add_argument("--model", default="clsr", choices=["clsr", "gru4rec", "din", "sli_rec", "a2svd", "dien"],
                     help="clsr = the BASELINE metric (default); the sibling models run the same step machinery "
                          "(clsr_amd/seqnet.py) and report the same metric for comparison")
+    ap.add_argument("--precision", default=os.environ.get("CLSR_PRECISION", "fp32"), choices=["fp32", "bf16"],
+                    help="fp32 = the reference's arithmetic (parity mode, headline); bf16 = speed mode: bf16 storage of "
+                         "the attention activations + bf16 MFMA with fp32 accumulation, statistics and optimiser")
+    ap.add_argument("--exact-clip", action="store_true",
+                    help="time the reference-exact clip mode (histories replicated like the reference iterator: "
+                         "tf.clip_by_norm sees the un-summed replica slices) instead of the de-duplicated step")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the step as ONE captured hipGraph instead of launching it eagerly (slower on "
-                         "ROCm 7.2 once the step uses four streams: 5.15 vs 4.63 ms)")
+                    help="replay the step as ONE captured hipGraph instead of launching it eagerly")
     ap.add_argument("--no-graph", action="store_true", help="(default now; kept for old command lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-catalogue", action="store_true",
-                    help="skip the HBM-resident (100M-item catalogue) measurement of the gather kernel")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--sync-bn", action="store_true",
-                    help="(N>1) global batch-norm statistics (single-device parity; eager, slower); default is "
-                         "per-rank statistics with averaged moving stats")
+                    help="skip the HBM-resident (100M-item catalogue) measurements (gather roofline + configs[4] step)")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra_workloads / precision_modes")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0)
+    ap.add_argument("--cpu-warmup", type=int, default=1)
+    ap.add_argument("--cpu-steps", type=int, default=None)
+    ap.add_argument("--local-bn", action="store_true",
+                    help="(N>1) per-rank batch-norm statistics with averaged moving stats (no mid-step collectives) "
+                         "instead of the default global statistics (single-device parity)")
+    ap.add_argument("--sync-bn", action="store_true", help="(default for N>1; kept for old command lines)")
     args = ap.parse_args()
 
     import torch
     from clsr_amd import ops
-    from clsr_amd.net import CLSRNet
-    from clsr_amd.synthetic import CONFIGS, synthetic_feed
+    from clsr_amd.synthetic import CONFIGS
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: re-exec under torch.distributed.run (one process per GPU, RCCL);
+        # rank 0 of that job prints the one JSON line
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit("--gpus %d: this node exposes %d GPU(s)" % (args.gpus, have))
+        import socket
+
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dist = None
     force_dp = bool(os.environ.get("CLSR_FORCE_DP"))   # exercise the DP code path with a single rank
@@ -154,84 +328,28 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    sync_bn = not args.local_bn
 
     cfg = CONFIGS[args.config]
-    P, T, G = cfg["P"], cfg["T"], 5
-    big = cfg["Vi"] >= 10_000_000   # catalogue configs: lazy Adam is mandatory, ids uniform
-    hp = build_hparams(cfg, P, **({"optimizer": "lazyadam"} if big else {}))
-    dims = dict(Vu=cfg["Vu"], Vi=cfg["Vi"], Vc=cfg["Vc"])
-    if args.model == "clsr":
-        net = CLSRNet(hp, dims, device="cuda:%d" % local_rank, seed=0)
-    else:
-        from clsr_amd.seqnet import SeqNet
-
-        hp = build_hparams(cfg, P, model_type=args.model, user_embedding_dim=16,
-                           attention_size=cfg["Di"] + cfg["Dc"], **({"optimizer": "lazyadam"} if big else {}))
-        net = SeqNet(hp, dims, kind=args.model, device="cuda:%d" % local_rank, seed=0)
-    if os.environ.get("CLSR_NO_OVERLAP"):
-        net.overlap = False
-    if os.environ.get("CLSR_DW_EAGER"):
-        net.defer_dw = False
+    wl = Workload(args.config, args.model, args.precision, dedup=not args.exact_clip, lengths=args.lengths, rank=rank,
+                  local_rank=local_rank)
+    net, f, feed = wl.net, wl.f, wl.feed
+    use_plans = bool(getattr(net, "use_plans", False))
+    P, T, G, big = wl.P, wl.T, wl.G, wl.big
     log("net built")
-    feed = synthetic_feed(P, T, cfg["Vu"], cfg["Vi"], cfg["Vc"], G=G, lengths=args.lengths, seed=20220425 + rank,
-                          ids="uniform" if big else "zipf")
-    f = net.upload(feed, True)
     if dist is not None:
         from clsr_amd.dp import DataParallel
 
-        stepper = DataParallel(net, dist, sync_bn=args.sync_bn,
-                               sparse_tables=os.environ.get("CLSR_SPARSE_TABLES", "auto"))
-        stepper.prepare(f)
-    else:
-        stepper = None
+        wl.stepper = DataParallel(net, dist, sync_bn=sync_bn, sparse_tables=os.environ.get("CLSR_SPARSE_TABLES", "auto"))
+        wl.stepper.prepare(f)
 
     stream = torch.cuda.Stream()
     host_losses = torch.zeros(8, dtype=torch.float64).pin_memory()
+    extra, modes = [], {}
     with torch.cuda.stream(stream):
-        def eager_step():
-            if stepper is None:
-                net.train_step(f)
-            else:
-                stepper.train_step(f)
-
-        for i in range(2):
-            eager_step()
-            stream.synchronize()
-            log("eager step %d done" % i)
-        # data-parallel runs stay eager: the RCCL watchdog thread of torch.distributed polls its events while a
-        # stream capture is open, which can invalidate the capture (hipErrorCapturedEvent, seen on the catalogue
-        # config); eager launches cost ~2 ms of host time per step and are hidden behind the device step
-        use_graph = args.graph and not args.no_graph and (stepper is None or bool(os.environ.get("CLSR_DP_GRAPH")))
-        if not use_graph:
-            run = eager_step
-        elif stepper is None:
-            ops.graph_begin()
-            net.train_step(f)
-            graph = ops.graph_end()
-            run = lambda: ops.graph_launch(graph)
-        else:
-            run = stepper.capture(f)
-        log("step captured" if use_graph else "eager mode")
-        for _ in range(args.warmup):
-            run()
-        stream.synchronize()
-        log("warmup done")
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run()
-            host_losses.copy_(net.losses, non_blocking=True)  # what CLSRModel.train() returns each step
-        stream.synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax)
+        dt = wl.run(args.steps, args.warmup, dist=dist, graph=args.graph and not args.no_graph,
+                    host_losses=host_losses)
+        use_graph = wl.use_graph
         ms = dt * 1e3 / args.steps
         value = world * P * args.steps / dt
         log("timed %d steps: %.3f ms/step" % (args.steps, ms))
@@ -239,125 +357,121 @@ def main():
         # ---- rooflines of two kernels, measured live with HIP events on this stream
         B, Hn = P * G, P
         D = cfg["Di"] + cfg["Dc"]
-        hist = net._buf("hist", Hn, T, D)
-        hm, hr = net._buf("hist_mean", Hn, D), net._buf("hist_recent", Hn, D)
-
-        def gather():
-            ops.call("clsr_gather_hist_fwd", net.tables["item"], net.tables["cate"], f["item_history"],
-                     f["item_cate_history"], G * T, f["seq_len"], G, Hn, T, cfg["Di"], cfg["Dc"], 3, hist, hm, hr)
-
-        t_gather = time_kernel(gather)
-        lens = np.asarray(feed["mask"]).sum(1)[::G]
-        n_valid = float(lens.sum())
-        # bytes_gather_fwd(n) = n*(Di+Dc)*(s_t + s_a) + 2*n*4 per gathered history row
-        gbytes = n_valid * D * (4 + 4) + 2 * n_valid * 4
-        roof = dict(bound="hbm", kernel="gather_hist_fwd_kernel", achieved=round(gbytes / t_gather / 1e9, 1),
-                    peak=8000.0, unit="GB/s", frac=round(gbytes / t_gather / 8e12, 4),
-                    # PMC pass committed in profiles/r01_gather_hist_fwd_pmc_hbm_traffic.csv (same shape): WRITE_SIZE
-                    # 33.3 MB + 2 x FETCH_SIZE 12.5 MB (gfx950 wide-load correction); reads of the 8 MB tables hit cache
-                    traffic=208.8e6 if big else 58.3e6, traffic_source="profiles/r01_gather_hist_fwd_pmc_hbm_traffic.csv",
-                    bytes_per_launch=gbytes, us_per_launch=round(t_gather * 1e6, 2),
+        roof = gather_roofline(net, f, cfg, G, feed, big)
+        # PMC pass committed in profiles/r01_gather_hist_fwd_pmc_hbm_traffic.csv (same shape): WRITE_SIZE
+        # 33.3 MB + 2 x FETCH_SIZE 12.5 MB (gfx950 wide-load correction); reads of the 8 MB tables hit cache
+        roof.update(traffic=208.8e6 if big else 58.3e6, traffic_source="profiles/r01_gather_hist_fwd_pmc_hbm_traffic.csv",
                     note=("tables (%.1f MB) are L2/Infinity-Cache resident at this config; the HBM claim needs the "
                           "100M-item config" % ((cfg["Vi"] * cfg["Di"] + cfg["Vc"] * cfg["Dc"]) * 4 / 1e6))
                     if not big else "38 GB item table, uniform ids: every row read is an HBM read")
         # the measured copy rate of this device next to the 8 TB/s datasheet figure (1 GiB device-to-device
         # copy: 1 GiB read + 1 GiB written per launch)
+        copy_peak = None
         try:
             src_, dst_ = torch.empty(1 << 28, device="cuda"), torch.empty(1 << 28, device="cuda")
             t_copy = time_kernel(lambda: dst_.copy_(src_), iters=10, warm=2)
-            roof["measured_copy_peak_GBps"] = round(2.0 * (1 << 30) / t_copy / 1e9, 1)
-            roof["frac_of_measured_copy_peak"] = round(roof["achieved"] / roof["measured_copy_peak_GBps"], 4)
+            copy_peak = round(2.0 * (1 << 30) / t_copy / 1e9, 1)
+            roof["measured_copy_peak_GBps"] = copy_peak
+            roof["frac_of_measured_copy_peak"] = round(roof["achieved"] / copy_peak, 4)
             del src_, dst_
         except RuntimeError:
             pass
-        if world == 1 and not args.no_catalogue and not big:
-            # same kernel on BASELINE configs[4]'s catalogue (100M items x 96 floats + 10k categories x 32, uniform
-            # ids: no cache reuse): the table is 38 GB, so every row read is an HBM read
-            cat = CONFIGS["catalogue100m"]
-            try:
-                it = torch.empty(cat["Vi"], cat["Di"], device="cuda").zero_()   # touch every page once
-                ct = torch.randn(cat["Vc"], cat["Dc"], device="cuda")
-                ii = torch.randint(1, cat["Vi"], (Hn, T), device="cuda", dtype=torch.int32)
-                ci = torch.randint(1, cat["Vc"], (Hn, T), device="cuda", dtype=torch.int32)
-                ln = torch.full((Hn,), T, device="cuda", dtype=torch.int32)
-                Db = cat["Di"] + cat["Dc"]
-                hb = torch.empty(Hn, T, Db, device="cuda")
-                hmb, hrb = torch.empty(Hn, Db, device="cuda"), torch.empty(Hn, Db, device="cuda")
-                t_big = time_kernel(lambda: ops.call("clsr_gather_hist_fwd", it, ct, ii, ci, T, ln, 1, Hn, T,
-                                                     cat["Di"], cat["Dc"], 3, hb, hmb, hrb))
-                bbytes = Hn * T * (Db * 8 + 8)
-                # the HBM claim is made on this measurement (at configs[1] the 8 MB of tables sit in the
-                # L2 / Infinity Cache); the cache-resident figure of the benchmarked config stays alongside
-                cache_resident = dict(roof)
-                roof = dict(
-                    bound="hbm", kernel="gather_hist_fwd_kernel",
-                    workload="BASELINE configs[4] catalogue: 100M items, rows 384 B + 128 B, uniform ids, "
-                             "4096 histories x 50 steps (38 GB table: every row read is an HBM read)",
-                    achieved=round(bbytes / t_big / 1e9, 1), peak=8000.0, unit="GB/s",
-                    frac=round(bbytes / t_big / 8e12, 4),
-                    traffic=208.8e6, traffic_source="profiles/r01_gather_hist_fwd_pmc_hbm_traffic.csv "
-                                                    "(WRITE_SIZE 106.5 MB + 2 x FETCH_SIZE 51.1 MB)",
-                    bytes_per_launch=float(bbytes), us_per_launch=round(t_big * 1e6, 2),
-                    cache_resident_at_benchmarked_config=cache_resident)
-                if "measured_copy_peak_GBps" in cache_resident:
-                    roof["measured_copy_peak_GBps"] = cache_resident["measured_copy_peak_GBps"]
-                    roof["frac_of_measured_copy_peak"] = round(roof["achieved"] / roof["measured_copy_peak_GBps"], 4)
-                del it, ct, hb
-                torch.cuda.empty_cache()
-            except RuntimeError as e:   # not enough free HBM on this device
-                roof["hbm_resident_skipped"] = str(e)[:120]
         roof_mfma = None
         if args.model == "clsr":
-            Qs, A0 = cfg["Du"] + D, 80
-            a_s, q_s = net._buf("st.a", Hn * T, Qs), net._buf("st.q", B, Qs)
-            U, V, z0 = net._buf("st.U", Hn * T, A0), net._buf("st.V", B, A0), net._buf("st.z0", B * T, A0)
-            Wt, Kp = net.packed["st.Wp"]
+            roof_mfma = net.bench_att_layer0(f, time_kernel)
 
-            def z0_gemm():
-                ops.call("clsr_pgemm", a_s, Qs, T, G, q_s, Qs, None, None, 1, Wt, Kp, None, U, A0, V, A0, z0, A0, 0,
-                         None, B * T, Qs, A0)
+        single = world == 1 and dist is None and args.model == "clsr" and args.config == "taobao"
+        if single and not args.no_extra:
+            # ---- the other precision mode of the same workload (named secondary object; `dtype` stays the headline's)
+            other = "bf16" if args.precision == "fp32" else "fp32"
+            try:
+                w2 = Workload(args.config, args.model, other, dedup=not args.exact_clip, lengths=args.lengths)
+                d2 = w2.run(max(10, args.steps // 2), 3)
+                n2 = max(10, args.steps // 2)
+                modes[other] = dict(ms_per_step=round(d2 * 1e3 / n2, 4), interactions_per_s=round(P * n2 / d2, 1),
+                                    layer0=w2.net.bench_att_layer0(w2.f, time_kernel),
+                                    note=w2.net.precision_note())
+                log("precision %s: %.3f ms/step" % (other, d2 * 1e3 / n2))
+                w2.free()
+            except NotImplementedError as e:
+                modes[other] = dict(skipped=str(e)[:200])
+            # ---- reference-exact clip mode (or, under --exact-clip, the de-duplicated default)
+            w3 = Workload(args.config, args.model, args.precision, dedup=args.exact_clip, lengths=args.lengths)
+            n3 = 5 if not args.exact_clip else 10
+            d3 = w3.run(n3, 2)
+            extra.append(dict(workload=w3.describe() + (", histories replicated x5 like the reference iterator "
+                                                         "(reference-exact tf.clip_by_norm of the embedding IndexedSlices)"
+                                                         if not args.exact_clip else ", histories de-duplicated"),
+                              history_dedup=bool(args.exact_clip), ms_per_step=round(d3 * 1e3 / n3, 4),
+                              interactions_per_s=round(P * n3 / d3, 1), steps=n3))
+            log("history_dedup=%s: %.3f ms/step" % (args.exact_clip, d3 * 1e3 / n3))
+            w3.free()
+            # ---- BASELINE configs[2]
+            w4 = Workload("kuaishou", "clsr", args.precision)
+            d4 = w4.run(10, 2)
+            extra.append(dict(workload=w4.describe(), ms_per_step=round(d4 * 100.0, 4),
+                              interactions_per_s=round(w4.P * 10 / d4, 1), steps=10))
+            log("kuaishou: %.3f ms/step" % (d4 * 100.0))
+            w4.free()
+        if world == 1 and dist is None and not args.no_catalogue and not big:
+            # BASELINE configs[4] on one GPU: 100M items x 96 floats (38 GB, uniform ids: no cache reuse, every row
+            # read is an HBM read) -- the HBM claim of the gather kernel is made HERE (at configs[1]
+            # the 8 MB of tables sit in the L2 / Infinity Cache), and the whole step is timed on the same net
+            wl.free()
+            net = f = None
+            try:
+                w5 = Workload("catalogue100m", "clsr", args.precision)
+                log("catalogue net built")
+                big_roof = gather_roofline(w5.net, w5.f, w5.cfg, w5.G, w5.feed, True)
+                cache_resident = dict(roof)
+                roof = dict(big_roof, workload="BASELINE configs[4] catalogue: 100M items, rows 384 B + 128 B, uniform "
+                                               "ids, 4096 histories x 50 steps (38 GB table: every row read is an HBM read)",
+                            traffic=208.8e6, traffic_source="profiles/r01_gather_hist_fwd_pmc_hbm_traffic.csv "
+                                                            "(WRITE_SIZE 106.5 MB + 2 x FETCH_SIZE 51.1 MB)",
+                            cache_resident_at_benchmarked_config=cache_resident)
+                if copy_peak:
+                    roof["measured_copy_peak_GBps"] = copy_peak
+                    roof["frac_of_measured_copy_peak"] = round(roof["achieved"] / copy_peak, 4)
+                if not args.no_extra:
+                    d5 = w5.run(5, 2)
+                    extra.append(dict(workload=w5.describe(), ms_per_step=round(d5 * 200.0, 4),
+                                      interactions_per_s=round(w5.P * 5 / d5, 1), steps=5))
+                    log("catalogue100m: %.3f ms/step" % (d5 * 200.0))
+                w5.free()
+            except RuntimeError as e:   # not enough free HBM on this device
+                roof["hbm_resident_skipped"] = str(e)[:120]
 
-            t_mm = time_kernel(z0_gemm)
-            flops = 2.0 * B * T * Qs * A0
-            roof_mfma = dict(bound="mfma", kernel="pgemm_fast_kernel<5,MUL,UV,false> (short-term attention layer 0)",
-                             achieved=round(flops / t_mm / 1e12, 2), peak=157.3, unit="TFLOP/s",
-                             frac=round(flops / t_mm / 157.3e12, 4), us_per_launch=round(t_mm * 1e6, 2),
-                             note="fp32-input MFMA (v_mfma_f32_16x16x4_f32); peak = dense fp32 matrix rate")
-
-    out = None
     if rank == 0:
         out = {
             "metric": "train interactions/sec @ batch %d seq_len %d" % (P, T), "value": round(value, 1),
             "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[%s]: %s %s train step, batch %d positives x5 rows "
-                                   "(B=%d), seq_len %d (%s lengths), Di/Dc/Du/H=%d/%d/%d/%d, Vu/Vi/Vc=%d/%d/%d, "
-                                   "%s%s" % (
-                                       {"taobao": "1", "kuaishou": "2", "catalogue100m": "4"}.get(args.config, "?"),
-                                       args.config, {"clsr": "CLSR", "gru4rec": "GRU4Rec (sibling model)",
-                                                     "din": "DIN (sibling model)",
-                                                     "sli_rec": "SLi-Rec (sibling model)",
-                                                     "a2svd": "A2SVD (sibling model)",
-                                                     "dien": "DIEN (sibling model, relu)"}[args.model],
-                                       P, P * G, T, args.lengths, cfg["Di"], cfg["Dc"],
-                                       cfg["Du"] if args.model == "clsr" else 16, cfg["H"],
-                                       cfg["Vu"], cfg["Vi"], cfg["Vc"],
-                                       "time4lstm + triplet, " if args.model == "clsr" else "",
-                                       "lazy Adam (row lists)" if big else "dense Adam"),
+            "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+            "config": {"workload": wl.describe() + " (%s lengths)" % args.lengths,
                        "global_batch": world * P, "seq_len": T,
                        "parallelism": "dp%d" % world if world > 1 else "single",
-                       "hipgraph": use_graph, "launch_plan": bool(getattr(net, "use_plans", False)) and not use_graph,
-                       "history_dedup": True,
-                       "batch_norm": ("sync" if args.sync_bn else "per-rank") if world > 1 else "single-device"},
+                       "hipgraph": use_graph, "launch_plan": use_plans and not use_graph,
+                       "history_dedup": not args.exact_clip,
+                       "history_dedup_note": "forward, losses and summed gradients are identical to the reference's "
+                                             "replicated computation; the one deviation is tf.clip_by_norm of the "
+                                             "item/cate embedding IndexedSlices (norm of the summed replica slices "
+                                             "instead of the un-summed ones), observable only while that clip is "
+                                             "active; --exact-clip / extra_workloads times the replicated step",
+                       "precision": args.precision,
+                       "batch_norm": ("sync" if sync_bn else "per-rank") if world > 1 else "single-device"},
             "rows_per_s": round(value * G, 1),
             "roofline": roof, "roofline_mfma": roof_mfma,
             "loss": float(host_losses[:4].sum()),
         }
         if roof_mfma is None:
             del out["roofline_mfma"]
+        if modes:
+            out["precision_modes"] = modes
+        if extra:
+            out["extra_workloads"] = extra
         if world == 1 and not args.no_cpu_baseline and not big and args.model == "clsr":
-            out["cpu_baseline"] = cpu_baseline(cfg, seconds=args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(cfg, seconds=args.cpu_seconds, warmup=args.cpu_warmup,
+                                               steps=args.cpu_steps)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -34,24 +34,50 @@ def _prefetch(gen, depth=3):
 
     q = queue.Queue(maxsize=depth)
     end = object()
+    stop = threading.Event()
+
+    def put(item):
+        """Blocking put that gives up when the consumer has gone away (returns False then)."""
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.05)
+                return True
+            except queue.Full:
+                pass
+        return False
 
     def work():
         try:
             for item in gen:
-                q.put(item)
-            q.put(end)
+                if not put(item):
+                    return
+            put(end)
         except BaseException as e:  # surface iterator errors in the consumer
-            q.put(e)
+            put(e)
 
     th = threading.Thread(target=work, daemon=True)
     th.start()
-    while True:
-        item = q.get()
-        if item is end:
-            break
-        if isinstance(item, BaseException):
-            raise item
-        yield item
+    try:
+        while True:
+            item = q.get()
+            if item is end:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+    finally:
+        # the consumer is done or raised mid-epoch (kernel error, unshardable batch): stop the worker instead of
+        # leaving it blocked on a full queue with batches alive and the global ``random`` stream advancing.  NOTE:
+        # the iterator shuffles / samples negatives from the process-global ``random`` module in this thread -- do
+        # not touch ``random`` from the main thread while an epoch is running, or the documented draw sequence of
+        # the reference is lost.
+        stop.set()
+        while True:
+            try:
+                q.get_nowait()
+            except queue.Empty:
+                break
+        th.join(timeout=5.0)
 
 _CKPT_INDEX = "checkpoint"
 
@@ -109,19 +135,30 @@ class BaseModel(object):
         """Write all variables under their TF names (safetensors) and update the directory index."""
         from safetensors.torch import save_file
 
-        path = str(save_path) + ".safetensors"
-        d = os.path.dirname(path)
-        if d:
-            os.makedirs(d, exist_ok=True)
-        save_file({k: v.contiguous() for k, v in self.net.state_dict().items()}, path)
-        with open(os.path.join(d, _CKPT_INDEX), "w") as f:
-            f.write(str(save_path))
+        dist = getattr(self, "_dist", None)
+        rank = 0
+        if dist is not None:
+            rank = self._dp.rank if getattr(self, "_dp", None) is not None else dist.get_rank()
+        if rank == 0:   # replicas are identical: ONE writer; temp file + rename, index last (no torn checkpoints)
+            path = str(save_path) + ".safetensors"
+            d = os.path.dirname(path)
+            if d:
+                os.makedirs(d, exist_ok=True)
+            tmp = path + ".tmp.%d" % os.getpid()
+            save_file({k: v.contiguous() for k, v in self.net.state_dict().items()}, tmp)
+            os.replace(tmp, path)
+            idx = os.path.join(d, _CKPT_INDEX)
+            with open(idx + ".tmp", "w") as f:
+                f.write(str(save_path))
+            os.replace(idx + ".tmp", idx)
+        if dist is not None:
+            dist.barrier()      # nobody reads the checkpoint before rank 0 has finished writing it
         return str(save_path)
 
 
 class SequentialBaseModel(BaseModel):
     def __init__(self, hparams, iterator_creator, graph=None, seed=None, device="cuda:0", use_graph=False,
-                 dedup_histories=True, dist=None, sync_bn=False):
+                 dedup_histories=True, dist=None, sync_bn=True, group=None, precision="fp32"):
         """Reference ``SequentialBaseModel.__init__`` (:19-48): requires ``train_num_ngs``.
 
         ``dist`` (an initialised ``torch.distributed`` module, one process per GPU) turns ``train`` / ``fit``
@@ -138,7 +175,9 @@ class SequentialBaseModel(BaseModel):
         self.min_seq_length = hparams.min_seq_length if "min_seq_length" in hparams else 1
         self.hidden_size = hparams.hidden_size if "hidden_size" in hparams else None
         self._device = device
-        self._dist, self._sync_bn, self._dp = dist, sync_bn, None
+        self._dist, self._sync_bn, self._dp, self._group = dist, sync_bn, None, group
+        self._precision = precision
+        self.dp_dropped_positives = self.dp_skipped_batches = 0
         self._use_graph = use_graph and dist is None
         self._dedup = dedup_histories
         self._graphs = {}
@@ -161,7 +200,8 @@ class SequentialBaseModel(BaseModel):
         self.net = self._make_net(hp, dims)
 
     def _make_net(self, hp, dims):
-        return CLSRNet(hp, dims, device=self._device, seed=self.seed, dedup_histories=self._dedup)
+        return CLSRNet(hp, dims, device=self._device, seed=self.seed, dedup_histories=self._dedup,
+                       precision=self._precision)
 
     # ------------------------------------------------------------------ device feeds / graphs
     def _to_arrays(self, feed_dict, training=False):
@@ -256,7 +296,7 @@ class SequentialBaseModel(BaseModel):
                 from clsr_amd.dp import DataParallel, shard_feed
 
                 if self._dp is None:
-                    self._dp = DataParallel(self.net, self._dist, sync_bn=self._sync_bn)
+                    self._dp = DataParallel(self.net, self._dist, sync_bn=self._sync_bn, group=self._group)
                 feed = shard_feed(feed, self._dp.rank, self._dp.world, self.train_num_ngs + 1)
             key, f, _ = self._static_feed(feed, True, lookahead=lookahead and not self._use_graph)
             return key, f
@@ -351,14 +391,17 @@ class SequentialBaseModel(BaseModel):
 
         # one batch of lookahead: batch N+1 is staged (its PCIe copy enqueued) BEFORE step N is launched
         pending = None
+        world = self._dp_world()
         for batch_data_input in _prefetch(file_iterator):
             if batch_data_input:
                 arrays = self._to_arrays(batch_data_input, True)
                 if self._dist is not None:
                     # a last batch with fewer positives than ranks cannot be sharded: every rank sees the same
-                    # global batch and skips it alike
+                    # global batch and skips it alike; a remainder (positives % world) is truncated by shard_feed
                     n_pos = arrays["labels"].shape[0] // (self.train_num_ngs + 1)
-                    if n_pos < self._dist.get_world_size():
+                    self.dp_dropped_positives += n_pos % world if n_pos >= world else n_pos
+                    if n_pos < world:
+                        self.dp_skipped_batches += 1
                         continue
                 staged = self._stage(arrays, lookahead=self._overlap_upload)
                 if pending is not None:
@@ -366,8 +409,19 @@ class SequentialBaseModel(BaseModel):
                 pending = staged
         if pending is not None:
             run(pending)
+        if self._dist is not None and self.dp_dropped_positives and self._dp is not None and self._dp.rank == 0:
+            print("data parallel: %d positives dropped so far (%d batches skipped): global batches are truncated to "
+                  "a multiple of %d ranks" % (self.dp_dropped_positives, self.dp_skipped_batches, world))
         with self._stream_ctx():
             return float(acc[:4].sum().item())
+
+    def _dp_world(self):
+        """Data-parallel world size of THIS model's process group (1 without ``dist``)."""
+        if self._dist is None:
+            return 1
+        if self._dp is not None:
+            return self._dp.world
+        return self._dist.get_world_size(self._group)
 
     def fit(self, train_file, valid_file, valid_num_ngs, eval_metric="group_auc"):
         """Train with per-epoch validation, early stopping and best-epoch checkpoints

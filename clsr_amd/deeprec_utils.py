@@ -405,6 +405,13 @@ def cal_metric(labels, preds, metrics):
         elif metric == "acc":
             pred = (np.asarray(preds) >= 0.5).astype(np.float64)
             res["acc"] = round(float(np.mean(pred == np.asarray(labels))), 4)
+        elif metric == "f1":
+            # sklearn.metrics.f1_score(labels, pred >= 0.5), binary: 2TP / (2TP + FP + FN); 0 when undefined
+            pred = np.asarray(preds).reshape(-1) >= 0.5
+            lab = np.asarray(labels).reshape(-1) == 1
+            tp = float(np.sum(pred & lab))
+            den = 2.0 * tp + float(np.sum(pred & ~lab)) + float(np.sum(~pred & lab))
+            res["f1"] = round(tp * 2.0 / den if den > 0 else 0.0, 4)
         elif metric == "mean_mrr":
             res["mean_mrr"] = round(
                 float(np.mean([mrr_score(l, p) for l, p in zip(labels, preds)])), 4

@@ -100,7 +100,7 @@ def shard_feed(feed, rank, world, group_size):
 
 
 class DataParallel(object):
-    def __init__(self, net, dist, sync_bn=False, group=None, sparse_tables="auto"):
+    def __init__(self, net, dist, sync_bn=True, group=None, sparse_tables="auto"):
         if sparse_tables not in ("auto", "all", "none"):
             raise ValueError("sparse_tables must be 'auto', 'all' or 'none'")
         self.net, self.dist, self.group = net, dist, group

@@ -56,11 +56,14 @@ class _BN(object):
 
 
 class CLSRNet(object):
-    def __init__(self, hp, dims, device="cuda:0", seed=None, dedup_histories=True):
+    def __init__(self, hp, dims, device="cuda:0", seed=None, dedup_histories=True, precision="fp32"):
         self.hp = hp
         self.dims = dict(dims)
         self.device = torch.device(device)
         self.dedup = bool(dedup_histories)
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.precision = precision
         self._check_supported()
         self.Di, self.Dc = hp.item_embedding_dim, hp.cate_embedding_dim
         self.D = self.Di + self.Dc
@@ -131,6 +134,8 @@ class CLSRNet(object):
         if hp.hidden_size != D or hp.user_embedding_dim != D:
             bad.append("hidden_size and user_embedding_dim must equal item+cate dims (alpha fusion, clsr.py:265)")
         bad += self._shape_limits(hp, rnn=True)
+        if self.precision == "bf16":
+            bad.append("precision bf16 (speed mode) is not built yet")
         if bad:
             raise NotImplementedError("CLSR HIP path does not support: " + "; ".join(bad))
 
@@ -1419,6 +1424,42 @@ class CLSRNet(object):
             ops.multi("clsr_tables_adam_multi", ops.TableDesc, [r for r in sweep if r[0] in
                                                                 {tb[k].data_ptr() for k in rest}],
                       clip, self.adam_state, 0.9, 0.999, 1e-8, self.lazy)
+
+    # ------------------------------------------------------------------ measurement hooks (bench.py)
+    def precision_note(self):
+        if self.precision == "fp32":
+            return "all tensors fp32, v_mfma_f32_16x16x4_f32 (bit-exact fp32 fmaf chains): the parity mode"
+        return ("attention-block activations at (row, step) level stored as bf16, GEMMs on v_mfma_f32_16x16x32_bf16 "
+                "with fp32 accumulation; batch-norm statistics, softmax, recurrences, losses, gradients of the "
+                "parameters and the optimiser stay fp32")
+
+    def bench_att_layer0(self, f, time_kernel):
+        """HIP-event timing of the most expensive GEMM of the step in isolation: the short-term attention's first
+        layer  z0 = U[h,t] + V[r] + (a[h,t] * q[r]) . Wp  over B*T positions (after at least one training step on
+        ``f``: buffers and packed weights exist)."""
+        B, T, G, Hn = self.last_shape
+        Qs, A0 = self.Du + self.D, self.A0
+        run = self._att_layer0_launcher("st", Hn, G, T, Qs)
+        t_mm = time_kernel(run)
+        flops = 2.0 * B * T * Qs * A0
+        bf = self.precision == "bf16"
+        peak = 2500.0 if bf else 157.3
+        return dict(bound="mfma", kernel=("hgemm_kernel<MUL,UV> (short-term attention layer 0, bf16 MFMA)" if bf else
+                                          "pgemm_fast_kernel<5,MUL,UV,false> (short-term attention layer 0)"),
+                    achieved=round(flops / t_mm / 1e12, 2), peak=peak, unit="TFLOP/s",
+                    frac=round(flops / t_mm / (peak * 1e12), 4), us_per_launch=round(t_mm * 1e6, 2),
+                    note=("bf16-input MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate; K = N = 80: the kernel is "
+                          "bound by its 164 MB bf16 output + operand reads, not by the matrix pipe" if bf else
+                          "fp32-input MFMA (v_mfma_f32_16x16x4_f32); peak = dense fp32 matrix rate"))
+
+    def _att_layer0_launcher(self, key, Hn, G, T, Q):
+        R, A0 = Hn * G, self.A0
+        a, q = self._buf(key + ".a", Hn * T, Q), self._buf(key + ".q", R, Q)
+        U, V = self._buf(key + ".U", Hn * T, A0), self._buf(key + ".V", R, A0)
+        z0 = self._buf(key + ".z0", R * T, A0)
+        Wt, Kp = self.packed[key + ".Wp"]
+        return lambda: call("clsr_pgemm", a, Q, T, G, q, Q, None, None, 1, Wt, Kp, None, U, A0, V, A0, z0, A0, 0,
+                            None, R * T, Q, A0)
 
     def read_losses(self):
         """Synchronising read of the step's loss terms -> dict of python floats."""

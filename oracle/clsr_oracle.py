@@ -235,15 +235,31 @@ def gru_cell(x, h, Wg, bg, Wc, bc):
     return u * h + (1 - u) * c
 
 
+#: bench.py's cpu_baseline leg sets this: the input-side products of the recurrent cells ([x, h] W = x W[:D] + h W[D:])
+#: are computed for all T steps in one batched product instead of T small ones.  Same math (fp32 rounding order of
+#: the two partial products differs); the parity tests run the literal per-step form above.
+FAST_RNN = False
+
+
 def dynamic_gru(x, seq_len, h0, scope, params):
     """dynamic_rnn(GRUCell): zero output and state copy-through for t >= sequence_length."""
-    B, T, _ = x.shape
+    B, T, D = x.shape
     Wg, bg = params[scope + "gates/kernel"], params[scope + "gates/bias"]
     Wc, bc = params[scope + "candidate/kernel"], params[scope + "candidate/bias"]
     h = h0
     outs = []
+    if FAST_RNN:
+        n = h0.shape[-1]
+        xg, xc = x @ Wg[:D] + bg, x @ Wc[:D] + bc
+        Wgh, Wch = Wg[D:], Wc[D:]
     for t in range(T):
-        nh = gru_cell(x[:, t], h, Wg, bg, Wc, bc)
+        if FAST_RNN:
+            ru = torch.sigmoid(xg[:, t] + h @ Wgh)
+            r, u = ru[..., :n], ru[..., n:]
+            c = torch.tanh(xc[:, t] + (r * h) @ Wch)
+            nh = u * h + (1 - u) * c
+        else:
+            nh = gru_cell(x[:, t], h, Wg, bg, Wc, bc)
         live = (t < seq_len).unsqueeze(-1)
         h = torch.where(live, nh, h)
         outs.append(torch.where(live, nh, torch.zeros_like(nh)))
@@ -255,19 +271,33 @@ def time4lstm(x, t_first, t_now, seq_len, scope, params, H):
     time_to_now ("time_now_score"), inputs[:, -2] is time_from_first_action ("time_last_score")
     because of the concat order at clsr.py:180-193."""
     p = lambda n: params[scope + n]
-    B, T, _ = x.shape
+    B, T, D = x.shape
     c = torch.zeros(B, H, dtype=x.dtype)
     m = torch.zeros(B, H, dtype=x.dtype)
     outs = []
+    if FAST_RNN:   # everything that does not depend on the recurrent state, for all steps at once
+        tn_all = torch.tanh(t_now.unsqueeze(-1) * p("_time_input_w1") + p("_time_input_bias1"))
+        tl_all = torch.tanh(t_first.unsqueeze(-1) * p("_time_input_w2") + p("_time_input_bias2"))
+        tns_all = x @ p("_time_kernel_w1") + tn_all @ p("_time_kernel_t1") + p("_time_bias1")
+        tls_all = x @ p("_time_kernel_w2") + tl_all @ p("_time_kernel_t2") + p("_time_bias2")
+        zx_all = x @ p("kernel")[:D] + p("bias")
+        zx_all = torch.cat([zx_all[..., :3 * H],
+                            zx_all[..., 3 * H:] + tn_all @ p("_o_kernel_t1") + tl_all @ p("_o_kernel_t2")], -1)
+        Wm = p("kernel")[D:]
     for t in range(T):
-        xt = x[:, t]
-        tn = torch.tanh(t_now[:, t:t + 1] * p("_time_input_w1") + p("_time_input_bias1"))
-        tl = torch.tanh(t_first[:, t:t + 1] * p("_time_input_w2") + p("_time_input_bias2"))
-        tns = xt @ p("_time_kernel_w1") + tn @ p("_time_kernel_t1") + p("_time_bias1")
-        tls = xt @ p("_time_kernel_w2") + tl @ p("_time_kernel_t2") + p("_time_bias2")
-        z = torch.cat([xt, m], -1) @ p("kernel") + p("bias")
-        i, j, f, o = z[:, :H], z[:, H:2 * H], z[:, 2 * H:3 * H], z[:, 3 * H:]
-        o = o + tn @ p("_o_kernel_t1") + tl @ p("_o_kernel_t2")
+        if FAST_RNN:
+            z = zx_all[:, t] + m @ Wm
+            i, j, f, o = z[:, :H], z[:, H:2 * H], z[:, 2 * H:3 * H], z[:, 3 * H:]
+            tns, tls = tns_all[:, t], tls_all[:, t]
+        else:
+            xt = x[:, t]
+            tn = torch.tanh(t_now[:, t:t + 1] * p("_time_input_w1") + p("_time_input_bias1"))
+            tl = torch.tanh(t_first[:, t:t + 1] * p("_time_input_w2") + p("_time_input_bias2"))
+            tns = xt @ p("_time_kernel_w1") + tn @ p("_time_kernel_t1") + p("_time_bias1")
+            tls = xt @ p("_time_kernel_w2") + tl @ p("_time_kernel_t2") + p("_time_bias2")
+            z = torch.cat([xt, m], -1) @ p("kernel") + p("bias")
+            i, j, f, o = z[:, :H], z[:, H:2 * H], z[:, 2 * H:3 * H], z[:, 3 * H:]
+            o = o + tn @ p("_o_kernel_t1") + tl @ p("_o_kernel_t2")
         nc = torch.sigmoid(f + 1.0) * torch.sigmoid(tls) * c + torch.sigmoid(i) * torch.sigmoid(tns) * torch.tanh(j)
         nm = torch.sigmoid(o) * torch.tanh(nc)
         live = (t < seq_len).unsqueeze(-1)

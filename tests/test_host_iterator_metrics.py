@@ -108,6 +108,19 @@ def test_auc_matches_sklearn_with_ties():
         roc_auc(np.ones(5), rng.random(5))
 
 
+def test_f1_matches_sklearn():
+    """cal_metric's "f1" (reference deeprec_utils.py:649-654: f1_score of the 0.5-thresholded predictions)."""
+    from sklearn.metrics import f1_score
+
+    from clsr_amd.deeprec_utils import cal_metric
+
+    rng = np.random.default_rng(4)
+    for _ in range(10):
+        y = rng.integers(0, 2, size=150).astype(np.float64)
+        s = rng.random(150)
+        assert cal_metric(list(y), list(s), ["f1"])["f1"] == round(f1_score(y, (s >= 0.5).astype(np.float64)), 4)
+
+
 def test_prepare_hparams_defaults_and_checks(golden_hparams):
     hp = golden_hparams
     assert isinstance(hp, HParams)

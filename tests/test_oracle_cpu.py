@@ -168,3 +168,27 @@ def test_losses_on_a_hand_checkable_batch(golden_hparams):
     assert abs(float(ls["contrastive_loss"]) - exp) < 1e-12
     assert abs(float(ls["loss"]) - sum(float(ls[k]) for k in ("data_loss", "regular_loss", "contrastive_loss",
                                                                "discrepancy_loss"))) < 1e-12
+
+
+def test_hoisted_rnn_projections_equal_the_literal_per_step_form(golden_hparams, golden_dir):
+    """bench.py's cpu_baseline leg runs the oracle with FAST_RNN (input-side products of the recurrent cells batched
+    over T): same forward values and gradients as the literal per-step form, in float64 to rounding."""
+    import os
+
+    hp = golden_hparams
+    g = np.load(os.path.join(golden_dir, "iterator_train_sa.npz"))
+    feed = O.to_torch_feed({k[3:]: g[k] for k in g.files if k.startswith("b0_")}, dtype=torch.float64)
+    dims = dict(Vu=int(feed["users"].max()) + 1, Vi=int(max(feed["items"].max(), feed["item_history"].max())) + 1,
+                Vc=int(max(feed["cates"].max(), feed["item_cate_history"].max())) + 1)
+    params = O.init_params(dims, hp, seed=5, dtype=torch.float64, scale_dense=8.0)
+    bn = O.init_bn_state(params)
+    ls0, g0, _, _, out0 = O.gradients(params, bn, feed, hp)
+    O.FAST_RNN = True
+    try:
+        ls1, g1, _, _, out1 = O.gradients(params, bn, feed, hp)
+    finally:
+        O.FAST_RNN = False
+    assert float((out0["logit"] - out1["logit"]).abs().max()) < 1e-12
+    assert abs(float(ls0["loss"]) - float(ls1["loss"])) < 1e-12
+    for k in g0:
+        assert float((g0[k] - g1[k]).abs().max()) < 1e-11, k
