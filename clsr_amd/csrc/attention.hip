@@ -15,7 +15,7 @@
 #define ATT_MAXCH 4
 
 struct AttOutArgs {
-  const float* z1; const float* scale1; const float* shift1; const float* mean1; const float* invstd1;
+  const void* z1; const float* scale1; const float* shift1; const float* mean1; const float* invstd1;
   const float* w_out; const float* b_out;
   const int* seq_len; int len_stride;
   const float* keys;
@@ -37,6 +37,7 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
 }
 
 // LDS (floats): sbuf[T*QC] | wl[T] | red[64*4]
+template <bool ZH>
 __global__ void __launch_bounds__(64) att_out_fwd_kernel(AttOutArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x;
@@ -55,9 +56,9 @@ __global__ void __launch_bounds__(64) att_out_fwd_kernel(AttOutArgs a) {
     const int len = a.seq_len[h * a.len_stride];
     // (1) partial scores in column layout
     if (tsC < tparC) {
-      const float* zp = a.z1 + r * T * C1 + 4 * qC;
+      const long zo = r * T * C1 + 4 * qC;
       for (int t = tsC; t < T; t += tparC) {
-        const f32x4 y = relu4(ld4(zp + (long)t * C1) * sc + sh);
+        const f32x4 y = relu4(load4e<ZH>(a.z1, zo + (long)t * C1) * sc + sh);
         sbuf[t * QC + qC] = dot4(y, wo);
       }
     }
@@ -118,10 +119,10 @@ static size_t att_fwd_lds(int T, int C1) {
   return ((size_t)((T * (C1 / 4) + 3) & ~3) + ((T + 3) & ~3) + 256) * sizeof(float);
 }
 
-extern "C" int clsr_att_out_fwd(const float* z1, const float* scale1, const float* shift1,
-                                const float* w_out, const float* b_out, const int* seq_len,
-                                int len_stride, const float* keys, int Hn, int G, int T, int C1, int Dk,
-                                float* wts, float* out, void* stream) {
+static int att_out_fwd_impl(const void* z1, int z1_bf16, const float* scale1, const float* shift1,
+                            const float* w_out, const float* b_out, const int* seq_len,
+                            int len_stride, const float* keys, int Hn, int G, int T, int C1, int Dk,
+                            float* wts, float* out, void* stream) {
   CLSR_CHECK_ARG(z1 && scale1 && shift1 && w_out && b_out && seq_len && keys && out);
   CLSR_CHECK_ARG(Hn >= 0 && G > 0 && T > 0);
   CLSR_CHECK_SUPPORTED(T <= 64 * ATT_MAXCH && C1 % 4 == 0 && Dk % 4 == 0 && C1 <= 256 && Dk <= 256);
@@ -132,10 +133,29 @@ extern "C" int clsr_att_out_fwd(const float* z1, const float* scale1, const floa
   a.Hn = Hn; a.G = G; a.T = T; a.C1 = C1; a.Dk = Dk; a.wts = wts; a.out = out;
   long R = (long)Hn * G;
   int blocks = R > 8192 ? 8192 : (int)R;
-  hipLaunchKernelGGL(att_out_fwd_kernel, dim3(blocks), dim3(64), att_fwd_lds(T, C1),
-                     (hipStream_t)stream, a);
+  if (z1_bf16)
+    hipLaunchKernelGGL(att_out_fwd_kernel<true>, dim3(blocks), dim3(64), att_fwd_lds(T, C1), (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(att_out_fwd_kernel<false>, dim3(blocks), dim3(64), att_fwd_lds(T, C1), (hipStream_t)stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
+}
+
+extern "C" int clsr_att_out_fwd(const float* z1, const float* scale1, const float* shift1,
+                                const float* w_out, const float* b_out, const int* seq_len,
+                                int len_stride, const float* keys, int Hn, int G, int T, int C1, int Dk,
+                                float* wts, float* out, void* stream) {
+  return att_out_fwd_impl(z1, 0, scale1, shift1, w_out, b_out, seq_len, len_stride, keys, Hn, G, T, C1, Dk, wts, out,
+                          stream);
+}
+
+// the same with z1 stored as bf16 (speed mode, csrc/hgemm.hip)
+extern "C" int clsr_att_out_fwd_h(const void* z1, const float* scale1, const float* shift1,
+                                  const float* w_out, const float* b_out, const int* seq_len,
+                                  int len_stride, const float* keys, int Hn, int G, int T, int C1, int Dk,
+                                  float* wts, float* out, void* stream) {
+  return att_out_fwd_impl(z1, 1, scale1, shift1, w_out, b_out, seq_len, len_stride, keys, Hn, G, T, C1, Dk, wts, out,
+                          stream);
 }
 
 // Backward, split by access pattern:
@@ -258,8 +278,9 @@ __device__ __forceinline__ f32x4 dy1_of(f32x4 zz, float ds, f32x4 sc, f32x4 sh, 
   return d;
 }
 
+template <bool ZH>
 __global__ void __launch_bounds__(256) att_dy1_stats_kernel(
-    const float* __restrict__ z1, const float* __restrict__ ds, const float* __restrict__ scale,
+    const void* __restrict__ z1, const float* __restrict__ ds, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ w_out, long M, int C, double* __restrict__ bn_partial,
     float* __restrict__ w_partial) {
@@ -275,7 +296,7 @@ __global__ void __launch_bounds__(256) att_dy1_stats_kernel(
     const long per = (M + gridDim.x - 1) / gridDim.x;
     const long lo = (long)blockIdx.x * per, hi = lo + per < M ? lo + per : M;
     for (long row = lo + ty; row < hi; row += rpb) {
-      const f32x4 zz = ld4(z1 + row * C + 4 * q);
+      const f32x4 zz = load4e<ZH>(z1, row * C + 4 * q);
       const float dsv = ds[row];
       const f32x4 y = zz * sc + sh;
       const f32x4 d = dy1_of(zz, dsv, sc, sh, wo);
@@ -313,15 +334,31 @@ static int dy1_blocks(long M, int C) {
 }
 extern "C" int clsr_att_dy1_parts(long M, int C1) { return dy1_blocks(M, C1); }
 
+static int att_dy1_stats_impl(const void* z1, int z1_bf16, const float* ds, const float* scale1, const float* shift1,
+                              const float* mean1, const float* invstd1, const float* w_out, long M, int C1,
+                              double* bn_partial, float* w_partial, void* stream) {
+  CLSR_CHECK_ARG(z1 && ds && scale1 && shift1 && mean1 && invstd1 && w_out && bn_partial && w_partial && M > 0);
+  CLSR_CHECK_SUPPORTED(C1 % 4 == 0 && C1 >= 4 && C1 <= 1024);
+  if (z1_bf16)
+    hipLaunchKernelGGL(att_dy1_stats_kernel<true>, dim3(dy1_blocks(M, C1)), dim3(256), 0, (hipStream_t)stream, z1, ds,
+                       scale1, shift1, mean1, invstd1, w_out, M, C1, bn_partial, w_partial);
+  else
+    hipLaunchKernelGGL(att_dy1_stats_kernel<false>, dim3(dy1_blocks(M, C1)), dim3(256), 0, (hipStream_t)stream, z1, ds,
+                       scale1, shift1, mean1, invstd1, w_out, M, C1, bn_partial, w_partial);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
 extern "C" int clsr_att_dy1_stats(const float* z1, const float* ds, const float* scale1, const float* shift1,
                                   const float* mean1, const float* invstd1, const float* w_out, long M, int C1,
                                   double* bn_partial, float* w_partial, void* stream) {
-  CLSR_CHECK_ARG(z1 && ds && scale1 && shift1 && mean1 && invstd1 && w_out && bn_partial && w_partial && M > 0);
-  CLSR_CHECK_SUPPORTED(C1 % 4 == 0 && C1 >= 4 && C1 <= 1024);
-  hipLaunchKernelGGL(att_dy1_stats_kernel, dim3(dy1_blocks(M, C1)), dim3(256), 0, (hipStream_t)stream, z1, ds,
-                     scale1, shift1, mean1, invstd1, w_out, M, C1, bn_partial, w_partial);
-  CLSR_CHECK_LAUNCH();
-  return CLSR_OK;
+  return att_dy1_stats_impl(z1, 0, ds, scale1, shift1, mean1, invstd1, w_out, M, C1, bn_partial, w_partial, stream);
+}
+
+extern "C" int clsr_att_dy1_stats_h(const void* z1, const float* ds, const float* scale1, const float* shift1,
+                                    const float* mean1, const float* invstd1, const float* w_out, long M, int C1,
+                                    double* bn_partial, float* w_partial, void* stream) {
+  return att_dy1_stats_impl(z1, 1, ds, scale1, shift1, mean1, invstd1, w_out, M, C1, bn_partial, w_partial, stream);
 }
 
 // dz1 = a1 * dy1 + a2 * z1 + a3 with dy1 recomputed from (z1, ds); coef = [a1 | a2 | a3] from clsr_bn_bwd_coef

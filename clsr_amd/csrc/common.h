@@ -109,5 +109,13 @@ __device__ __forceinline__ float tanhf_(float x) {
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// 4 consecutive elements of an fp32 or a bf16 (H) tensor as fp32 (element index idx: multiple of 4)
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+template <bool H>
+__device__ __forceinline__ f32x4 load4e(const void* base, long idx) {
+  if (H) return __builtin_convertvector(*reinterpret_cast<const bf16x4_t*>(reinterpret_cast<const __bf16*>(base) + idx), f32x4);
+  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx);
+}
+
 #define MFMA4(acc, a, b) (acc) = __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (acc), 0, 0, 0)
 #endif

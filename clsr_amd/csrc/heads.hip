@@ -501,8 +501,8 @@ extern "C" int clsr_axpby(float* out, const float* a, float sa, const float* b, 
 // group are loaded back to back (independent loads), summed in registers for dU (ONE store per element,
 // no read-modify-write) and accumulated per row for dV.
 #define ATT_MAXG 8
-template <bool BIGG>
-__global__ void __launch_bounds__(64) att_z0_bwd_reduce_kernel(const float* __restrict__ dz0, long Hn,
+template <bool BIGG, bool H>
+__global__ void __launch_bounds__(64) att_z0_bwd_reduce_kernel(const void* __restrict__ dz0, long Hn,
                                                                int G, int T, int C,
                                                                float* __restrict__ dU,
                                                                float* __restrict__ dV) {
@@ -521,7 +521,7 @@ __global__ void __launch_bounds__(64) att_z0_bwd_reduce_kernel(const float* __re
           f32x4 d[ATT_MAXG];
 #pragma unroll
           for (int g = 0; g < ATT_MAXG; ++g)
-            d[g] = g < gc ? ld4(dz0 + ((h * G + g0 + g) * T + t) * C + 4 * q) : z4;
+            d[g] = g < gc ? load4e<H>(dz0, ((h * G + g0 + g) * T + t) * C + 4 * q) : z4;
           f32x4 su = z4;
 #pragma unroll
           for (int g = 0; g < ATT_MAXG; ++g) { su += d[g]; accv[g] += d[g]; }
@@ -548,21 +548,36 @@ __global__ void __launch_bounds__(64) att_z0_bwd_reduce_kernel(const float* __re
   }
 }
 
-extern "C" int clsr_att_z0_bwd_reduce(const float* dz0, long Hn, int G, int T, int C, float* dU,
-                                      float* dV, void* stream) {
+static int att_z0_bwd_reduce_impl(const void* dz0, int bf16, long Hn, int G, int T, int C, float* dU, float* dV,
+                                  void* stream) {
   CLSR_CHECK_ARG(dz0 && dV && Hn > 0 && G > 0 && T > 0);
   CLSR_CHECK_SUPPORTED(C % 4 == 0 && C <= 256);
   int blocks = Hn > 8192 ? 8192 : (int)Hn;
-  hipLaunchKernelGGL(att_z0_bwd_reduce_kernel<false>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, dz0, Hn,
-                     G, T, C, dU, dV);
+  if (bf16)
+    hipLaunchKernelGGL((att_z0_bwd_reduce_kernel<false, true>), dim3(blocks), dim3(64), 0, (hipStream_t)stream, dz0,
+                       Hn, G, T, C, dU, dV);
+  else
+    hipLaunchKernelGGL((att_z0_bwd_reduce_kernel<false, false>), dim3(blocks), dim3(64), 0, (hipStream_t)stream, dz0,
+                       Hn, G, T, C, dU, dV);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
+}
+
+extern "C" int clsr_att_z0_bwd_reduce(const float* dz0, long Hn, int G, int T, int C, float* dU,
+                                      float* dV, void* stream) {
+  return att_z0_bwd_reduce_impl(dz0, 0, Hn, G, T, C, dU, dV, stream);
+}
+
+extern "C" int clsr_att_z0_bwd_reduce_h(const void* dz0, long Hn, int G, int T, int C, float* dU,
+                                        float* dV, void* stream) {
+  return att_z0_bwd_reduce_impl(dz0, 1, Hn, G, T, C, dU, dV, stream);
 }
 
 // (2) given daq = dz0 . Wp^T  [R*T, Q]:  da[h,t,:] = sum_g daq[(h,g),t,:] * q[(h,g),:]
 //                                        dq[r,:]   = sum_t daq[r,t,:] * a[h,t,:]
 // Same loop structure as (1): the G rows of a step are loaded together, da gets one store.
-__global__ void __launch_bounds__(64) att_prod_bwd_kernel(const float* __restrict__ daq, int ldd,
+template <bool H>
+__global__ void __launch_bounds__(64) att_prod_bwd_kernel(const void* __restrict__ daq, int ldd,
                                                           const float* __restrict__ a, int lda,
                                                           const float* __restrict__ q, int ldq, long Hn, int G,
                                                           int T, int Q, float* __restrict__ da, int ldda,
@@ -586,7 +601,7 @@ __global__ void __launch_bounds__(64) att_prod_bwd_kernel(const float* __restric
           f32x4 d[ATT_MAXG];
 #pragma unroll
           for (int g = 0; g < ATT_MAXG; ++g)
-            d[g] = g < gc ? ld4(daq + ((h * G + g0 + g) * T + t) * ldd + 4 * qq) : z4;
+            d[g] = g < gc ? load4e<H>(daq, ((h * G + g0 + g) * T + t) * ldd + 4 * qq) : z4;
           f32x4 su = z4;
 #pragma unroll
           for (int g = 0; g < ATT_MAXG; ++g) { su += d[g] * qv[g]; accq[g] += d[g] * av; }
@@ -612,18 +627,34 @@ __global__ void __launch_bounds__(64) att_prod_bwd_kernel(const float* __restric
   }
 }
 
-extern "C" int clsr_att_prod_bwd_ld(const float* daq, int ldd, const float* a, int lda, const float* q, int ldq,
-                                    long Hn, int G, int T, int Q, float* da, int ldda, float* dq, int lddq,
-                                    int accumulate_dq, void* stream) {
+static int att_prod_bwd_impl(const void* daq, int bf16, int ldd, const float* a, int lda, const float* q, int ldq,
+                             long Hn, int G, int T, int Q, float* da, int ldda, float* dq, int lddq,
+                             int accumulate_dq, void* stream) {
   CLSR_CHECK_ARG(daq && a && q && da && dq && Hn > 0 && G > 0 && T > 0);
   CLSR_CHECK_SUPPORTED(Q % 4 == 0 && Q <= 256 && ldd % 4 == 0 && lda % 4 == 0 && ldq % 4 == 0 && ldda % 4 == 0 &&
                        lddq % 4 == 0);
   CLSR_CHECK_ARG(ldd >= Q && lda >= Q && ldq >= Q && ldda >= Q && lddq >= Q);
   int blocks = Hn > 8192 ? 8192 : (int)Hn;
-  hipLaunchKernelGGL(att_prod_bwd_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, daq, ldd, a, lda, q, ldq,
-                     Hn, G, T, Q, da, ldda, dq, lddq, accumulate_dq);
+  if (bf16)
+    hipLaunchKernelGGL(att_prod_bwd_kernel<true>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, daq, ldd, a, lda, q,
+                       ldq, Hn, G, T, Q, da, ldda, dq, lddq, accumulate_dq);
+  else
+    hipLaunchKernelGGL(att_prod_bwd_kernel<false>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, daq, ldd, a, lda, q,
+                       ldq, Hn, G, T, Q, da, ldda, dq, lddq, accumulate_dq);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
+}
+
+extern "C" int clsr_att_prod_bwd_ld(const float* daq, int ldd, const float* a, int lda, const float* q, int ldq,
+                                    long Hn, int G, int T, int Q, float* da, int ldda, float* dq, int lddq,
+                                    int accumulate_dq, void* stream) {
+  return att_prod_bwd_impl(daq, 0, ldd, a, lda, q, ldq, Hn, G, T, Q, da, ldda, dq, lddq, accumulate_dq, stream);
+}
+
+extern "C" int clsr_att_prod_bwd_h(const void* daq, int ldd, const float* a, int lda, const float* q, int ldq,
+                                   long Hn, int G, int T, int Q, float* da, int ldda, float* dq, int lddq,
+                                   int accumulate_dq, void* stream) {
+  return att_prod_bwd_impl(daq, 1, ldd, a, lda, q, ldq, Hn, G, T, Q, da, ldda, dq, lddq, accumulate_dq, stream);
 }
 
 extern "C" int clsr_att_prod_bwd(const float* daq, const float* a, const float* q, long Hn, int G, int T,

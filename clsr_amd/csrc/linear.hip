@@ -620,9 +620,9 @@ extern "C" int clsr_pack_batch(const clsr_pack_desc* descs_device, int n, int ma
 #define DW_CHUNK (DW_T * DW_T * 256 + DW_T * 16)
 
 struct DwArgs {
-  const float* X; int ldx; int T; int G; const float* Xmul; int ldmul;
+  const void* X; int ldx; int T; int G; const float* Xmul; int ldmul;   // X / dY: fp32, or bf16 (XH / YH variants)
   const float* in_scale; const float* in_shift; int in_relu;
-  const float* dY; int ldy;
+  const void* dY; int ldy;
   float* partial;
   int M, K, N;
 };
@@ -633,7 +633,7 @@ struct DwArgs {
 //   A operand (lane (i,g)) = Xs[16w + 4s + g][16kt + i],  B operand = Ys[16w + 4s + g][16nt + i].
 // Row stride 80 floats == 16 (mod 32) banks => the two row groups of a half-wave hit disjoint banks.
 #define DW_W (16 * DW_T)
-template <int MODE>  // 0 plain, 1 X*Xmul[r], 2 relu(X*in_scale + in_shift)
+template <int MODE, bool XH = false, bool YH = false>  // 0 plain, 1 X*Xmul[r], 2 relu(X*in_scale + in_shift)
 __global__ void __launch_bounds__(256) pgemm_dw_kernel(DwArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[64 * 2 * DW_W > 2 * DW_CHUNK ? 64 * 2 * DW_W : 2 * DW_CHUNK];
   float* Xs = lds;
@@ -695,9 +695,9 @@ __global__ void __launch_bounds__(256) pgemm_dw_kernel(DwArgs a) {
         r = rr;
         if (a.G > 0) xrow = (long)(rr / (unsigned)a.G) * a.T + (m - (int)rr * a.T);
       }
-      xr[j] = ld4(a.X + xrow * a.ldx + kcol);
+      xr[j] = load4e<XH>(a.X, xrow * a.ldx + kcol);
       if (MODE == 1) mr[j] = ld4(a.Xmul + r * a.ldmul + kcol);
-      yr[j] = ld4(a.dY + (long)m * a.ldy + ncol);
+      yr[j] = load4e<YH>(a.dY, (long)m * a.ldy + ncol);
     }
   };
   auto stage = [&]() {
@@ -841,9 +841,10 @@ extern "C" long clsr_pgemm_dw_workspace_floats(int M, int K, int N) {
   return chunks * dw_grid_x(M) * DW_CHUNK;
 }
 
-static int dw_launch_partial(const float* X, int ldx, int T, int G, const float* Xmul, int ldmul,
-                             const float* in_scale, const float* in_shift, int in_relu, const float* dY, int ldy,
-                             int M, int K, int N, float* workspace, hipStream_t s, int* gx_out) {
+static int dw_launch_partial(const void* X, int ldx, int T, int G, const float* Xmul, int ldmul,
+                             const float* in_scale, const float* in_shift, int in_relu, const void* dY, int ldy,
+                             int M, int K, int N, float* workspace, hipStream_t s, int* gx_out, int x_bf16 = 0,
+                             int dy_bf16 = 0) {
   CLSR_CHECK_ARG(X && dY && workspace && M >= 0 && K > 0 && N > 0);
   CLSR_CHECK_ARG(!(in_scale && !in_shift));
   // 16-byte staging loads: rows must be float4 addressable up to roundup(K,4) / N
@@ -857,6 +858,16 @@ static int dw_launch_partial(const float* X, int ldx, int T, int G, const float*
   const int kch = clsr_cdiv(K, 16 * DW_T), nch = clsr_cdiv(N, 16 * DW_T);
   const int gx = dw_grid_x(M);
   CLSR_CHECK_SUPPORTED(!(Xmul && in_scale) && !(in_scale && K % 4));
+  if (x_bf16 || dy_bf16) {
+    // speed mode (csrc/hgemm.hip): bf16 activations / gradients, fp32 MFMA accumulation as in the fp32 mode.
+    // Built combinations: relu(bn(X bf16)) x dY bf16 (second attention layer), (X fp32 * Xmul) x dY bf16 (first layer)
+    CLSR_CHECK_SUPPORTED(dy_bf16 && ((x_bf16 && in_scale) || (!x_bf16 && Xmul)));
+    if (x_bf16) hipLaunchKernelGGL((pgemm_dw_kernel<2, true, true>), dim3(gx, kch, nch), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((pgemm_dw_kernel<1, false, true>), dim3(gx, kch, nch), dim3(256), 0, s, a);
+    CLSR_CHECK_LAUNCH();
+    *gx_out = gx;
+    return CLSR_OK;
+  }
   if (Xmul) hipLaunchKernelGGL(pgemm_dw_kernel<1>, dim3(gx, kch, nch), dim3(256), 0, s, a);
   else if (in_scale) hipLaunchKernelGGL(pgemm_dw_kernel<2>, dim3(gx, kch, nch), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(pgemm_dw_kernel<0>, dim3(gx, kch, nch), dim3(256), 0, s, a);
@@ -893,6 +904,16 @@ extern "C" int clsr_pgemm_dw_partial(const float* X, int ldx, int T, int G, cons
   int gx = 0;
   return dw_launch_partial(X, ldx, T, G, Xmul, ldmul, in_scale, in_shift, in_relu, dY, ldy, M, K, N, workspace,
                            (hipStream_t)stream, &gx);
+}
+
+// speed mode: X and / or dY stored as bf16 (see dw_launch_partial for the built combinations)
+extern "C" int clsr_pgemm_dw_partial_h(const void* X, int x_bf16, int ldx, int T, int G, const float* Xmul, int ldmul,
+                                       const float* in_scale, const float* in_shift, int in_relu,
+                                       const void* dY, int dy_bf16, int ldy, int M, int K, int N, float* workspace,
+                                       void* stream) {
+  int gx = 0;
+  return dw_launch_partial(X, ldx, T, G, Xmul, ldmul, in_scale, in_shift, in_relu, dY, ldy, M, K, N, workspace,
+                           (hipStream_t)stream, &gx, x_bf16, dy_bf16);
 }
 
 extern "C" int clsr_pgemm_dw_parts(int M) { return dw_grid_x(M); }

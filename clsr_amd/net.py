@@ -77,6 +77,9 @@ class CLSRNet(object):
         self._bufs = {}
         self._zero_specs = OrderedDict()
         self.packed = {}
+        self.packed_h = {}         # bf16 images of the weights the speed-mode attention kernels read (csrc/hgemm.hip)
+        self.bf16 = self.precision == "bf16"
+        self._cur_descs_h = []
         self._plans, self._plan_keep, self._cur_descs = {}, [], []
         self._sort_bytes = {}
         self._ws_tag = ""          # suffix of shared scratch buffers while a side-stream branch is recording
@@ -84,7 +87,8 @@ class CLSRNet(object):
         self.rnn_first = not os.environ.get("CLSR_BRANCH_FIRST")   # A/B switch (see forward)
         self.dw_stream = not os.environ.get("CLSR_NO_DW_STREAM")   # A/B switch (see _dw)
         self._dw_async = False
-        self.split_query = not os.environ.get("CLSR_NO_SPLIT_QUERY")   # A/B switch (see _att_qh)
+        # A/B switch (see _att_qh); the bf16 speed mode keeps the whole query in the per-(row, step) GEMM (K is cheap there)
+        self.split_query = not os.environ.get("CLSR_NO_SPLIT_QUERY") and self.precision != "bf16"
         self.split_query_min = 64
         self.split_emb_grad = not os.environ.get("CLSR_SERIAL_EMB_GRAD")   # A/B switch (embedding gradient sites)
         self.use_plans = not os.environ.get("CLSR_NO_PLAN")                # replay recorded launch sequences
@@ -134,8 +138,6 @@ class CLSRNet(object):
         if hp.hidden_size != D or hp.user_embedding_dim != D:
             bad.append("hidden_size and user_embedding_dim must equal item+cate dims (alpha fusion, clsr.py:265)")
         bad += self._shape_limits(hp, rnn=True)
-        if self.precision == "bf16":
-            bad.append("precision bf16 (speed mode) is not built yet")
         if bad:
             raise NotImplementedError("CLSR HIP path does not support: " + "; ".join(bad))
 
@@ -166,7 +168,7 @@ class CLSRNet(object):
     def _plan_key(self, what, f):
         hp = self.hp
         g = lambda k: getattr(hp, k, None)
-        return (what, id(f), ops.stream_ptr(), self.dp_world, self.overlap, self.defer_dw, self.sorted_hist_grad,
+        return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, self.overlap, self.defer_dw, self.sorted_hist_grad,
                 self.lazy, self.rnn_first, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad,
                 self.split_g2, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
@@ -416,6 +418,15 @@ class CLSRNet(object):
         self._cur_descs.append(ops.pack_desc(W, out_f, in_f, buf, Kp, transposed=transposed, o0=o0, i0=i0,
                                              src2=W2, s2=s2))
 
+    def _pack_h(self, key, W, out_f, in_f, transposed=False):
+        """bf16 image of one weight block for the speed-mode kernels (row-permuted pairs of MFMA tiles, row stride
+        ``clsr_hgemm_kp(in)``; executed by ONE clsr_pack_batch_bf16 launch per step)."""
+        Kp = query("clsr_hgemm_kp", in_f)
+        opad = 32 * ((out_f + 31) // 32)
+        buf = self._buf("packh:" + key, opad * Kp, dtype=torch.bfloat16)   # zero-initialised; padding is never written
+        self.packed_h[key] = (buf, Kp)
+        self._cur_descs_h.append(ops.pack_desc(W, out_f, in_f, buf, Kp, transposed=transposed))
+
     def _pack_pair(self, key, W, K, N, K_pad=None):
         """forward pack (K->N) and transposed pack (N->K) of the same [K, N] block."""
         self._pack(key, W, N, K, in_pad=K_pad)
@@ -428,7 +439,8 @@ class CLSRNet(object):
         call("clsr_pgemm", X, ldx, T, G, Xmul, ldmul, sc, sh, 1, Wt, Kp, bias, addU, ldu, addV, ldv, Y, ldy,
              acc, stats, M, K, N)
 
-    def _dw(self, X, ldx, dY, ldy, M, K, N, dW, ldw, db=None, T=0, G=0, Xmul=None, ldmul=0, aff=None, acc=0):
+    def _dw(self, X, ldx, dY, ldy, M, K, N, dW, ldw, db=None, T=0, G=0, Xmul=None, ldmul=0, aff=None, acc=0,
+            x_bf16=0, dy_bf16=0):
         """Weight gradient dW = f(X)^T dY.  Deferred: this launches only the kernel that writes the per-block
         partial chunks (into a workspace of its own); ``_dw_flush`` reduces every pending gradient of the current
         stream in ONE launch."""
@@ -447,9 +459,15 @@ class CLSRNet(object):
             if side is None:
                 side = self._side[name] = torch.cuda.Stream(device=self.device)
             ops.stream_wait(side, self._fork_point())
-            call("clsr_pgemm_dw_partial", X, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, ldy, M, K, N, ws,
-                 stream=side.cuda_stream)
+            if x_bf16 or dy_bf16:
+                call("clsr_pgemm_dw_partial_h", X, x_bf16, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, dy_bf16, ldy, M, K, N,
+                     ws, stream=side.cuda_stream)
+            else:
+                call("clsr_pgemm_dw_partial", X, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, ldy, M, K, N, ws,
+                     stream=side.cuda_stream)
             self._dw_async = True
+        elif x_bf16 or dy_bf16:
+            call("clsr_pgemm_dw_partial_h", X, x_bf16, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, dy_bf16, ldy, M, K, N, ws)
         else:
             call("clsr_pgemm_dw_partial", X, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, ldy, M, K, N, ws)
         pend.append((ws.data_ptr(), dW.data_ptr(), db.data_ptr() if db is not None else 0, 1.0,
@@ -586,13 +604,19 @@ class CLSRNet(object):
         device descriptor table -- is built on first use per mode)."""
         plan = self._plans.get(bool(training))
         if plan is None:
-            self._cur_descs = []
+            self._cur_descs, self._cur_descs_h = [], []
             self._plan_weights(training)
             plan = ops.pack_table(self._cur_descs, self.device)
             self._plans[bool(training)] = plan
             self._plan_keep.append(self._cur_descs)   # descriptors hold raw pointers of live tensors
+            if self._cur_descs_h:
+                self._plans[(bool(training), "bf16")] = ops.pack_table(self._cur_descs_h, self.device)
+                self._plan_keep.append(self._cur_descs_h)
         tbl, n, max_elems = plan
         call("clsr_pack_batch", tbl, n, max_elems)
+        plan_h = self._plans.get((bool(training), "bf16"))
+        if plan_h is not None:
+            call("clsr_pack_batch_bf16", plan_h[0], plan_h[1], plan_h[2])
 
     def _att_qh(self, key):
         """Leading query columns of attention ``key`` that are history-level.  The short-term query is
@@ -632,6 +656,12 @@ class CLSRNet(object):
             self._pack(key + ".Wp1", W0[3 * Q:3 * Q + qh], A0, qh)
             self._pack(key + ".Wp2", W0[3 * Q + qh:4 * Q], A0, Q - qh)
         self._pack(key + ".W1", W1, A1, A0)
+        if self.bf16:
+            self._pack_h(key + ".Wp", W0[3 * Q:4 * Q], A0, Q)
+            self._pack_h(key + ".W1", W1, A1, A0)
+            if training:
+                self._pack_h(key + ".Wp^T", W0[3 * Q:4 * Q], Q, A0, transposed=True)
+                self._pack_h(key + ".W1^T", W1, A0, A1, transposed=True)
         if training:
             self._pack(key + ".A^T", P[scope + "attention_mat"], Dk, Q, transposed=True)
             self._pack(key + ".Wu^T", W0[0:Q], Q, A0, transposed=True, W2=W0[2 * Q:3 * Q], s2=1.0)
@@ -810,13 +840,30 @@ class CLSRNet(object):
         a = self._buf(key + ".a", Hn * T, Q)
         U = self._buf(key + ".U", Hn * T, A0)
         V = self._buf(key + ".V", R, A0)
-        z0 = self._buf(key + ".z0", R * T, A0)
-        z1 = self._buf(key + ".z1", R * T, A1)
+        BF = torch.bfloat16
+        z0 = self._buf(key + ".z0", R * T, A0, dtype=BF if self.bf16 else F32)
+        z1 = self._buf(key + ".z1", R * T, A1, dtype=BF if self.bf16 else F32)
         wts = self._buf(key + ".wts", R, T)
         out = self._buf(key + ".out", R, Dk)
         self._gemm(keys, Dk, key + ".A", Hn * T, Dk, Q, a, Q)
         self._gemm(a, Q, key + ".Wu", Hn * T, Q, A0, U, A0)
         self._gemm(q, Q, key + ".Wv", R, Q, A0, V, A0, bias=P[nn + "b_nn_layer0"])
+        if self.bf16:
+            # speed mode: the two (row, step)-level layers on bf16 MFMA with bf16 storage (csrc/hgemm.hip)
+            M = R * T
+            parts = query("clsr_hgemm_stats_parts", M) if training else 0
+            sbuf = self._buf("stats" + self._ws_tag, 1024 * 2 * 256, dtype=torch.float64)
+            st = sbuf[: parts * 2 * A0] if training else None
+            Wt, Kp = self.packed_h[key + ".Wp"]
+            call("clsr_hgemm_mul_uv", a, Q, T, G, q, Q, Wt, Kp, U, A0, V, A0, z0, A0, st, M, Q, A0)
+            self._bn_fwd(bn0, st, parts, M, training)
+            st = sbuf[: parts * 2 * A1] if training else None
+            Wt, Kp = self.packed_h[key + ".W1"]
+            call("clsr_hgemm", z0, A0, bn0.scale, bn0.shift, 1, Wt, Kp, P[nn + "b_nn_layer1"], z1, A1, st, M, A0, A1)
+            self._bn_fwd(bn1, st, parts, M, training)
+            call("clsr_att_out_fwd_h", z1, bn1.scale, bn1.shift, P[nn + "w_nn_output"], P[nn + "b_nn_output"],
+                 seq_len, len_stride, keys, Hn, G, T, A1, Dk, wts, out)
+            return out
         st, parts = self._stats_buf(R * T, A0) if training else (None, 0)
         if qh:
             # U[h,t] += (a[h,t,:qh] * q_hist[h]) . Wp[:qh]   (in place: every tile reads its own U before storing)
@@ -845,11 +892,13 @@ class CLSRNet(object):
         R = Hn * G
         nn = scope + "att_fcn/nn_part/"
         bn0, bn1 = self.bn[nn + "batch_normalization/"], self.bn[nn + "batch_normalization_1/"]
-        a, z0, z1 = (self._buf(key + s, *shp) for s, shp in
-                     ((".a", (Hn * T, Q)), (".z0", (R * T, A0)), (".z1", (R * T, A1))))
+        BF = torch.bfloat16
+        AD = BF if self.bf16 else F32
+        a = self._buf(key + ".a", Hn * T, Q)
+        z0, z1 = self._buf(key + ".z0", R * T, A0, dtype=AD), self._buf(key + ".z1", R * T, A1, dtype=AD)
         wts = self._buf(key + ".wts", R, T)
-        dz1 = self._buf(key + ".dz1", R * T, A1)
-        dz0 = self._buf(key + ".dz0", R * T, A0)
+        dz1 = self._buf(key + ".dz1", R * T, A1, dtype=AD)
+        dz0 = self._buf(key + ".dz0", R * T, A0, dtype=AD)
         # score / softmax backward per history group: d score, dkeys, d b_out
         ds = self._buf(key + ".ds", R * T)
         if dw_in is not None:
@@ -867,19 +916,43 @@ class CLSRNet(object):
         parts = query("clsr_att_dy1_parts", R * T, A1)
         bnp = self._buf("att.bnp" + self._ws_tag, 2048 * 2 * 256, dtype=torch.float64)[: parts * 2 * A1]
         wp = self._buf("att.wp." + key, 2048 * 256)[: parts * A1]
-        call("clsr_att_dy1_stats", z1, ds, bn1.scale, bn1.shift, bn1.mean, bn1.invstd, P[nn + "w_nn_output"],
-             R * T, A1, bnp, wp)
+        call("clsr_att_dy1_stats_h" if self.bf16 else "clsr_att_dy1_stats", z1, ds, bn1.scale, bn1.shift, bn1.mean,
+             bn1.invstd, P[nn + "w_nn_output"], R * T, A1, bnp, wp)
         self._rp(wp, parts, A1, A1, Gd[nn + "w_nn_output"])
         self._bn_bwd_coef(bn1, bnp, parts, R * T)
+        dW0 = Gd[nn + "w_nn_layer0"]
+        da = self._buf(key + ".da", Hn * T, Q)
+        dq = self._buf(key + ".dq", R, Q)
+        dV = self._buf(key + ".dV", R, A0)
+        if self.bf16:
+            # speed mode: dz1 is recomputed from (z1, ds) in the prologue of the GEMM that back-propagates through the
+            # second layer; TWO passes over (z1, z0): the batch-norm sums of layer 0, then the finished dz0 (+ dz1 for the
+            # weight gradient) -- no separate dy1-apply / bn-apply sweeps (csrc/hgemm.hip: clsr_hgemm_att_l1_bwd)
+            M = R * T
+            Wt, Kp = self.packed_h[key + ".W1^T"]
+            parts = query("clsr_hgemm_stats_parts", M)
+            st = self._buf("stats" + self._ws_tag, 1024 * 2 * 256, dtype=torch.float64)[: parts * 2 * A0]
+            wo = P[nn + "w_nn_output"]
+            call("clsr_hgemm_att_l1_bwd", z1, A1, ds, bn1.scale, bn1.shift, wo, bn1.coef, Wt, Kp, z0, A0, bn0.scale,
+                 bn0.shift, bn0.mean, bn0.invstd, None, None, 0, None, 0, st, M, A1, A0)
+            self._bn_bwd_coef(bn0, st, parts, M)
+            call("clsr_hgemm_att_l1_bwd", z1, A1, ds, bn1.scale, bn1.shift, wo, bn1.coef, Wt, Kp, z0, A0, bn0.scale,
+                 bn0.shift, None, None, bn0.coef, dz1, A1, dz0, A0, None, M, A1, A0)
+            self._dw(z0, A0, dz1, A1, M, A0, A1, Gd[nn + "w_nn_layer1"], A1, db=Gd[nn + "b_nn_layer1"], aff=bn0,
+                     x_bf16=1, dy_bf16=1)
+            self._dw(a, Q, dz0, A0, M, Q, A0, dW0[3 * Q:4 * Q], A0, T=T, G=G, Xmul=q, ldmul=Q, dy_bf16=1)
+            daq = self._buf(key + ".daq", M, Q, dtype=BF)
+            Wt, Kp = self.packed_h[key + ".Wp^T"]
+            call("clsr_hgemm", dz0, A0, None, None, 0, Wt, Kp, None, daq, Q, None, M, A0, Q)
+            call("clsr_att_prod_bwd_h", daq, Q, a, Q, q, Q, Hn, G, T, Q, da, Q, dq, Q, 0)
+            dU = self._buf(key + ".dU", Hn * T, A0)
+            call("clsr_att_z0_bwd_reduce_h", dz0, Hn, G, T, A0, dU, dV)
+            return self._att_bwd_hist(key, scope, nn, a, q, keys, dkeys, dU, dV, da, dq, dW0, Hn, R, T, Dk, Q, 0)
         call("clsr_att_dy1_apply", z1, ds, bn1.scale, bn1.shift, P[nn + "w_nn_output"], bn1.coef, R * T, A1, dz1)
         # layer 1: z1 = relu(bn0(z0)) . W1 + b1
         self._dw(z0, A0, dz1, A1, R * T, A0, A1, Gd[nn + "w_nn_layer1"], A1, db=Gd[nn + "b_nn_layer1"], aff=bn0)
         self._gemm_bnbwd(dz1, A1, key + ".W1^T", R * T, A1, A0, dz0, bn0, z0)
         # layer 0 (re-associated): z0 = U[h,t] + V[r] + (a[h,t]*q[r]) . Wp
-        dW0 = Gd[nn + "w_nn_layer0"]
-        da = self._buf(key + ".da", Hn * T, Q)
-        dq = self._buf(key + ".dq", R, Q)
-        dV = self._buf(key + ".dV", R, A0)
         if qh:
             Q2 = Q - qh
             self._dw(a[:, qh:], Q, dz0, A0, R * T, Q2, A0, dW0[3 * Q + qh:4 * Q], A0, T=T, G=G, Xmul=q[:, qh:],
@@ -908,6 +981,12 @@ class CLSRNet(object):
             else:
                 dU = self._buf(key + ".dU", Hn * T, A0)
                 call("clsr_att_z0_bwd_reduce", dz0, Hn, G, T, A0, dU, dV)
+        return self._att_bwd_hist(key, scope, nn, a, q, keys, dkeys, dU, dV, da, dq, dW0, Hn, R, T, Dk, Q, qh)
+
+    def _att_bwd_hist(self, key, scope, nn, a, q, keys, dkeys, dU, dV, da, dq, dW0, Hn, R, T, Dk, Q, qh):
+        """History-level / row-level tail of the attention backward (fp32 in both precision modes): gradients of
+        the U / V projections, of the attention matrix, and d keys."""
+        Gd, A0 = self.Gd, self.A0
         self._dw(a, Q, dU, A0, Hn * T, Q, A0, dW0[0:Q], A0)                        # d(W0a + W0d)
         self._dw(q, Q, dV, A0, R, Q, A0, dW0[Q:2 * Q], A0, db=Gd[nn + "b_nn_layer0"])  # d(W0q - W0d)
         # d(W0d) = d(W0a+W0d) - d(W0q-W0d) block: needs the two reduced gradients above (runs at the flush)
@@ -1456,6 +1535,10 @@ class CLSRNet(object):
         R, A0 = Hn * G, self.A0
         a, q = self._buf(key + ".a", Hn * T, Q), self._buf(key + ".q", R, Q)
         U, V = self._buf(key + ".U", Hn * T, A0), self._buf(key + ".V", R, A0)
+        if self.bf16:
+            z0 = self._buf(key + ".z0", R * T, A0, dtype=torch.bfloat16)
+            Wt, Kp = self.packed_h[key + ".Wp"]
+            return lambda: call("clsr_hgemm_mul_uv", a, Q, T, G, q, Q, Wt, Kp, U, A0, V, A0, z0, A0, None, R * T, Q, A0)
         z0 = self._buf(key + ".z0", R * T, A0)
         Wt, Kp = self.packed[key + ".Wp"]
         return lambda: call("clsr_pgemm", a, Q, T, G, q, Q, None, None, 1, Wt, Kp, None, U, A0, V, A0, z0, A0, 0,

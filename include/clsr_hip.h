@@ -85,6 +85,44 @@ typedef struct clsr_pack_desc {
 } clsr_pack_desc;
 int clsr_sizeof_pack_desc(void);
 int clsr_pack_batch(const clsr_pack_desc* descs_device, int n, int max_elems, void* stream);
+/* ---- bf16 SPEED mode of the attention block (csrc/hgemm.hip; BASELINE.json configs[1] "bf16"): the (row, step)-level
+ *      activations of _attention_fcn (clsr.py:343-381, base_model.py:627-708) are stored as bf16 (void* arguments) and
+ *      multiplied on v_mfma_f32_16x16x32_bf16 with fp32 accumulation; statistics, biases and coefficients stay fp32.
+ *      Wt = bf16 image packed by clsr_pack_batch_bf16 (row stride Kp = clsr_hgemm_kp(K) bf16 elements, 32*ceil(N/32)
+ *      rows, zero-initialised by the caller). */
+int clsr_hgemm_stats_parts(int M);
+int clsr_hgemm_kp(int K);
+int clsr_pack_batch_bf16(const clsr_pack_desc* descs_device, int n, int max_elems, void* stream);
+int clsr_hgemm_mul_uv(const float* X, int ldx, int T, int G, const float* Xmul, int ldmul, const void* Wt,
+                      int Kp, const float* addU, int ldu, const float* addV, int ldv, void* Y, int ldy,
+                      double* stats, int M, int K, int N, void* stream);
+int clsr_hgemm(const void* X, int ldx, const float* in_scale, const float* in_shift, int in_relu,
+               const void* Wt, int Kp, const float* bias, void* Y, int ldy, double* stats, int M, int K,
+               int N, void* stream);
+int clsr_hgemm_att_l1_bwd(const void* z1, int ldz1, const float* ds, const float* scale1,
+                          const float* shift1, const float* w_out, const float* coef1, const void* Wt,
+                          int Kp, const void* z0, int ldz0, const float* scale0, const float* shift0,
+                          const float* mean0, const float* invstd0, const float* coef0, void* dz1,
+                          int lddz1, void* dz0, int lddz0, double* stats, int M, int C1, int C0,
+                          void* stream);
+int clsr_pgemm_dw_partial_h(const void* X, int x_bf16, int ldx, int T, int G, const float* Xmul, int ldmul,
+                            const float* in_scale, const float* in_shift, int in_relu,
+                            const void* dY, int dy_bf16, int ldy, int M, int K, int N, float* workspace,
+                            void* stream);
+int clsr_att_out_fwd_h(const void* z1, const float* scale1, const float* shift1,
+                       const float* w_out, const float* b_out, const int* seq_len,
+                       int len_stride, const float* keys, int Hn, int G, int T, int C1, int Dk,
+                       float* wts, float* out, void* stream);
+int clsr_att_dy1_stats_h(const void* z1, const float* ds, const float* scale1, const float* shift1,
+                         const float* mean1, const float* invstd1, const float* w_out, long M, int C1,
+                         double* bn_partial, float* w_partial, void* stream);
+int clsr_att_z0_bwd_reduce_h(const void* dz0, long Hn, int G, int T, int C, float* dU,
+                             float* dV, void* stream);
+int clsr_att_prod_bwd_h(const void* daq, int ldd, const float* a, int lda, const float* q, int ldq,
+                        long Hn, int G, int T, int Q, float* da, int ldda, float* dq, int lddq,
+                        int accumulate_dq, void* stream);
+int clsr_cvt_f32_to_bf16(const float* src, void* dst, long n, void* stream);
+int clsr_cvt_bf16_to_f32(const void* src, float* dst, long n, void* stream);
 int clsr_pgemm_stats_parts(int M);
 int clsr_pgemm(const float* X, int ldx, int T, int G, const float* Xmul, int ldmul,
                const float* in_scale, const float* in_shift, int in_relu, const float* Wt, int Kp,

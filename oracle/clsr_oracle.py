@@ -214,8 +214,42 @@ def fcn_net(x, sizes, scope, params, bn_state, hp, training, new_bn):
     return h @ params[scope + "nn_part/w_nn_output"] + params[scope + "nn_part/b_nn_output"]
 
 
+#: Emulation of the bf16 SPEED mode of the HIP attention block (clsr_amd/csrc/hgemm.hip, CLSRNet(precision="bf16")):
+#: the same graph with the (row, step)-level activations rounded to bfloat16 where that mode stores / multiplies
+#: them (straight-through for autograd).  Rounding a ReLU / batch-norm network's activations to 8 mantissa bits moves
+#: some of its gradients by 10-30 % on small batches (tests/test_bf16_gpu.py prints the table), so the bf16 mode is
+#: checked against THIS oracle tightly and against the exact one at the logit / loss bars only.
+BF16_ATTENTION = False
+
+
+def _ste_bf16(x):
+    return x + (x.to(torch.bfloat16).to(x.dtype) - x).detach()
+
+
+def _attention_fcn_bf16(query, keys, mask, scope, params, bn_state, hp, training, new_bn):
+    """``_attention_fcn`` as the speed mode evaluates it: first layer re-associated into
+    U[h,t] + V[r] + (a*q).Wp (fp32 U, V; bf16 product operands, bf16 z0), bf16 h0 / W1 / z1, everything else exact."""
+    nn = scope + "att_fcn/nn_part/"
+    a = keys @ params[scope + "attention_mat"]
+    q = query.unsqueeze(1).expand_as(a)
+    Q = a.shape[-1]
+    W0 = params[nn + "w_nn_layer0"]
+    Wu, Wv, Wp = W0[:Q] + W0[2 * Q:3 * Q], W0[Q:2 * Q] - W0[2 * Q:3 * Q], W0[3 * Q:]
+    r = _ste_bf16
+    z0 = r(r(a * q) @ r(Wp) + a @ Wu + q @ Wv + params[nn + "b_nn_layer0"])
+    h0 = r(_activate(batch_norm(z0, nn + "batch_normalization/", params, bn_state, training, new_bn), hp.activation[0]))
+    z1 = r(h0 @ r(params[nn + "w_nn_layer1"]) + params[nn + "b_nn_layer1"])
+    h1 = _activate(batch_norm(z1, nn + "batch_normalization_1/", params, bn_state, training, new_bn), hp.activation[1])
+    score = (h1 @ params[nn + "w_nn_output"] + params[nn + "b_nn_output"]).squeeze(-1)
+    score = torch.where(mask == 1, score, torch.full_like(score, MASK_PAD))
+    w = torch.softmax(score, dim=-1)
+    return keys * w.unsqueeze(-1), w
+
+
 def attention_fcn(query, keys, mask, scope, params, bn_state, hp, training, new_bn):
     """``_attention_fcn`` (clsr.py:343-381); returns keys * weights (caller sums over T)."""
+    if BF16_ATTENTION:
+        return _attention_fcn_bf16(query, keys, mask, scope, params, bn_state, hp, training, new_bn)
     att_inputs = keys @ params[scope + "attention_mat"]                       # [B,T,Q]
     q = query.unsqueeze(1).expand_as(att_inputs)
     feat = torch.cat([att_inputs, q, att_inputs - q, att_inputs * q], -1)    # [B,T,4Q]

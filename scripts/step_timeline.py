@@ -19,7 +19,7 @@ def main():
         "select s.kernel_name, d.start, d.end - d.start, d.grid_size_x, d.grid_size_y, d.workgroup_size_x, d.queue_id "
         "from %s d join %s s on d.kernel_id = s.id order by d.start" % (disp, sym)))
     # a step starts with the forward's pack_batch launch (two pack_batch launches per step)
-    idx = [i for i, r in enumerate(rows) if "pack_batch" in r[0]]
+    idx = [i for i, r in enumerate(rows) if "pack_batch_kernel" in r[0]]
     starts = idx[0::2]
     lo, hi = starts[-back - 1], starts[-back]
     t0 = rows[lo][1]
