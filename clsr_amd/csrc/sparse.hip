@@ -9,56 +9,172 @@
 // consecutive sorted entries, summing runs of equal ids in registers: one atomic per run per
 // group instead of one per slice.  The sorted order is also the per-rank input of the
 // segmented sparse row exchange for multi-GPU runs with catalogues too large for dense tables.
-#include <cstring>
-#include <rocprim/rocprim.hpp>
 #include "common.h"
+#include "clsr_hip.h"
 
-__global__ void prep_sort_kernel(const int* __restrict__ ids, long nrows, int ncols, long row_stride,
-                                 int* __restrict__ keys, int* __restrict__ vals) {
-  const long n = nrows * ncols;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-    const long r = e / ncols;
-    keys[e] = ids[r * row_stride + (e - r * ncols)];
-    vals[e] = (int)e;
+// ---- grouping (id, position) pairs by id: hand-written counting sort, three launches for ALL tables of a step
+// (blockIdx.y = table), no vendor library on the step:
+//   1. group_hist     every workgroup aggregates its chunk of ids in an LDS hash table (popular ids -- the Zipf head,
+//                     the padding row 0 -- meet in LDS, not in one L2 atomic), then adds one count per distinct id
+//   2. group_scan     exclusive scan of the bucket counters (one workgroup per table; counters -> cursors)
+//   3. group_scatter  the same LDS aggregation, one cursor claim per distinct id and workgroup, then every entry is
+//                     written to  base + its rank inside the workgroup's share
+// Bucket = id & (2^bits - 1) with bits <= GROUP_MAX_BITS: vocabularies up to 2^18 ids come out sorted by id;
+// larger ones (100M-item catalogue) come out grouped by bucket -- different ids of a bucket may interleave, which
+// the consumer (runs of EQUAL ids, one atomic per run) handles by construction.  The order inside a run of equal
+// ids is not defined (claims race); neither was the order of the run-sum atomics before.
+#define GROUP_MAX_BITS 18
+#define GROUP_CHUNK 2048          // ids per workgroup pass
+#define GROUP_HS 4096             // LDS hash slots (>= 2 x chunk: short probe sequences)
+#define GROUP_EPT (GROUP_CHUNK / 256)
+
+struct GroupArgs {
+  clsr_sortids_desc d[CLSR_SORTIDS_MAX];
+};
+
+__device__ __forceinline__ int group_slot(int bucket) { return (int)(((unsigned)bucket * 2654435761u) >> 20) & (GROUP_HS - 1); }
+
+// insert `bucket` into the LDS table; returns the slot, *rank = number of earlier arrivals with the same bucket
+__device__ __forceinline__ int group_insert(int* hkey, int* hcnt, int bucket, int* rank) {
+  int slot = group_slot(bucket);
+  while (true) {
+    const int prev = atomicCAS(&hkey[slot], -1, bucket);
+    if (prev == -1 || prev == bucket) break;
+    slot = (slot + 1) & (GROUP_HS - 1);
+  }
+  *rank = atomicAdd(&hcnt[slot], 1);
+  return slot;
+}
+
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) group_pass_kernel(GroupArgs a) {
+  __shared__ int hkey[GROUP_HS], hcnt[GROUP_HS];
+  const clsr_sortids_desc d = a.d[blockIdx.y];
+  const long n = d.nrows * d.ncols;
+  const int mask = (1 << d.bits) - 1;
+  for (long c0 = (long)blockIdx.x * GROUP_CHUNK; c0 < n; c0 += (long)gridDim.x * GROUP_CHUNK) {
+    for (int e = threadIdx.x; e < GROUP_HS; e += 256) { hkey[e] = -1; hcnt[e] = 0; }
+    __syncthreads();
+    int id[GROUP_EPT], slot[GROUP_EPT], rank[GROUP_EPT];
+#pragma unroll
+    for (int u = 0; u < GROUP_EPT; ++u) {
+      const long e = c0 + u * 256 + threadIdx.x;
+      id[u] = -1;
+      if (e < n) {
+        const long r = e / d.ncols;
+        id[u] = d.ids[r * d.row_stride + (e - r * d.ncols)];
+        slot[u] = group_insert(hkey, hcnt, id[u] & mask, &rank[u]);
+      }
+    }
+    __syncthreads();
+    // one global atomic per distinct bucket of the chunk: the histogram count, or the claim of that many
+    // consecutive output positions (the claimed base replaces the key's count in LDS)
+    for (int e = threadIdx.x; e < GROUP_HS; e += 256) {
+      if (hkey[e] >= 0) {
+        const int base = atomicAdd(&d.counts[hkey[e]], hcnt[e]);
+        if (SCATTER) hcnt[e] = base;
+      }
+    }
+    if (SCATTER) {
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < GROUP_EPT; ++u) {
+        if (id[u] >= 0) {
+          const int p = hcnt[slot[u]] + rank[u];
+          d.keys_out[p] = id[u];
+          d.perm_out[p] = (int)(c0 + u * 256 + threadIdx.x);
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 
-static size_t sort_temp_bytes(size_t n, int end_bit) {
-  size_t bytes = 0;
-  int* p = nullptr;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, p, p, p, p, n, 0, end_bit, (hipStream_t)0);
-  return (bytes + 255) & ~(size_t)255;
+// counts[b] -> number of entries in buckets < b  (exclusive scan, in place; one 1024-thread workgroup per table:
+// every thread sums a contiguous range, the workgroup scans the 1024 range sums, every thread writes its range back)
+__global__ void __launch_bounds__(1024) group_scan_kernel(GroupArgs a) {
+  __shared__ int part[1024];
+  const clsr_sortids_desc d = a.d[blockIdx.x];
+  const int nb = 1 << d.bits;
+  const int per = (nb + 1023) / 1024;
+  const int lo = threadIdx.x * per, hi = min(nb, lo + per);
+  int s = 0;
+  for (int b = lo; b < hi; ++b) s += d.counts[b];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int add = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+    __syncthreads();
+    part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  int run = part[threadIdx.x] - s;
+  for (int b = lo; b < hi; ++b) {
+    const int c = d.counts[b];
+    d.counts[b] = run;
+    run += c;
+  }
 }
 
-// bytes of workspace clsr_sort_ids needs for n = nrows*ncols pairs with ids < vocab
+extern "C" int clsr_sizeof_sortids_desc(void) { return (int)sizeof(clsr_sortids_desc); }
+
+// bucket bits used for a vocabulary (the caller provides (1 << bits) ZEROED int counters per table)
+extern "C" int clsr_sort_ids_bits(long vocab) {
+  int bits = 1;
+  while (bits < GROUP_MAX_BITS && (1L << bits) < vocab) ++bits;
+  return bits;
+}
+
+// keys_out / perm_out: the (id, position) pairs of ids[r*row_stride + c] (r < nrows, c < ncols; position = r*ncols + c)
+// grouped by id (ascending ids when vocab <= 2^18).  counts: (1 << bits) int counters per table, ZERO on entry
+// (they come back holding the end offset of every bucket).  Three launches whatever the number of tables.
+extern "C" int clsr_sort_ids_multi(const clsr_sortids_desc* descs, int n, void* stream) {
+  CLSR_CHECK_ARG(descs && n > 0 && n <= CLSR_SORTIDS_MAX);
+  GroupArgs a;
+  long mx = 1;
+  for (int i = 0; i < n; ++i) {
+    const clsr_sortids_desc& d = descs[i];
+    CLSR_CHECK_ARG(d.ids && d.keys_out && d.perm_out && d.counts && d.nrows > 0 && d.ncols > 0);
+    CLSR_CHECK_ARG(d.bits >= 1 && d.bits <= GROUP_MAX_BITS);
+    CLSR_CHECK_SUPPORTED(d.nrows * d.ncols < (1L << 31));
+    a.d[i] = d;
+    const long e = d.nrows * d.ncols;
+    mx = e > mx ? e : mx;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  int blocks = clsr_cdiv(mx, GROUP_CHUNK);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(group_pass_kernel<false>, dim3(blocks, n), dim3(256), 0, s, a);
+  CLSR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(group_scan_kernel, dim3(n), dim3(1024), 0, s, a);
+  CLSR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(group_pass_kernel<true>, dim3(blocks, n), dim3(256), 0, s, a);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// single-table form (workspace = the zeroed counters are NOT assumed: cleared here with one extra launch)
+__global__ void zero_ints_kernel(int* __restrict__ p, long n) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) p[e] = 0;
+}
+
 extern "C" long clsr_sort_ids_workspace_bytes(long n, long vocab) {
   if (n <= 0) return 0;
-  (void)vocab;  // a counting sort was tried: its per-key cursor atomics serialise on Zipf-head ids
-  return (long)(2 * ((size_t)n * sizeof(int) + 255) + sort_temp_bytes((size_t)n, 32) + 512);
+  return ((long)sizeof(int) << clsr_sort_ids_bits(vocab)) + 256;
 }
 
-// keys_out[p] = p-th smallest id of ids[r*row_stride + c] (r < nrows, c < ncols); perm_out[p] = r*ncols + c
 extern "C" int clsr_sort_ids(const int* ids, long nrows, int ncols, long row_stride, long vocab,
                              int* keys_out, int* perm_out, void* workspace, long workspace_bytes,
                              void* stream) {
   CLSR_CHECK_ARG(ids && keys_out && perm_out && workspace && nrows > 0 && ncols > 0 && vocab > 0);
-  const size_t n = (size_t)nrows * ncols;
-  CLSR_CHECK_ARG(workspace_bytes >= clsr_sort_ids_workspace_bytes((long)n, vocab));
-  char* ws = (char*)workspace;
-  int end_bit = 1;
-  while (end_bit < 32 && (1L << end_bit) < vocab) ++end_bit;
-  const size_t seg = (n * sizeof(int) + 255) & ~(size_t)255;
-  int* keys_in = (int*)ws;
-  int* vals_in = (int*)(ws + seg);
-  void* temp = ws + 2 * seg;
-  size_t temp_bytes = (size_t)workspace_bytes - 2 * seg;
-  hipStream_t s = (hipStream_t)stream;
-  int blocks = clsr_cdiv((long)n, 256);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(prep_sort_kernel, dim3(blocks), dim3(256), 0, s, ids, nrows, ncols, row_stride, keys_in, vals_in);
+  CLSR_CHECK_ARG(workspace_bytes >= clsr_sort_ids_workspace_bytes(nrows * ncols, vocab));
+  clsr_sortids_desc d;
+  d.ids = ids; d.keys_out = keys_out; d.perm_out = perm_out; d.counts = (int*)workspace;
+  d.nrows = nrows; d.row_stride = row_stride; d.ncols = ncols; d.bits = clsr_sort_ids_bits(vocab);
+  const long nb = 1L << d.bits;
+  hipLaunchKernelGGL(zero_ints_kernel, dim3(clsr_cdiv(nb, 256)), dim3(256), 0, (hipStream_t)stream, d.counts, nb);
   CLSR_CHECK_LAUNCH();
-  CLSR_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, perm_out, n, 0, end_bit, s));
-  return CLSR_OK;
+  return clsr_sort_ids_multi(&d, 1, stream);
 }
 
 // g[pos, :] = dhist[pos, col0:col0+C] + (t < len) dmean[h]/len + recent(t) drecent[h]/cnt   (pos = h*T + t)

@@ -1389,17 +1389,20 @@ class CLSRNet(object):
                 ("cate", "item_cate_history", self.dims["Vc"], self.Di, self.Dc, 1))
 
     def _sort_hist_ids(self, f, Hn, T, hs):
-        """(row id, position) pairs of both history lookups sorted by row id (rocPRIM radix sort)."""
+        """(row id, position) pairs of both history lookups grouped by row id: hand-written counting sort, one
+        zeroing launch + three launches for both tables together (csrc/sparse.hip: clsr_sort_ids_multi)."""
         n = Hn * T
-        nbytes = self._sort_bytes.get(n)
-        if nbytes is None:
-            nbytes = self._sort_bytes[n] = max(query("clsr_sort_ids_workspace_bytes", n, self.dims["Vi"]),
-                                               query("clsr_sort_ids_workspace_bytes", n, self.dims["Vc"]))
-        ws = self._buf("sort.ws", nbytes, dtype=torch.uint8)
-        for name, fkey, V, _, _, _ in self._sort_tables():
+        tabs = self._sort_tables()
+        bits = [query("clsr_sort_ids_bits", V) for _, _, V, _, _, _ in tabs]
+        counts = self._buf("sort.counts", sum(1 << b for b in bits), dtype=torch.int32)
+        call("clsr_zero_floats", counts.view(F32), counts.numel())
+        rows, o = [], 0
+        for (name, fkey, V, _, _, _), b in zip(tabs, bits):
             keys = self._buf("sort.keys." + name, n, dtype=torch.int32)
             perm = self._buf("sort.perm." + name, n, dtype=torch.int32)
-            call("clsr_sort_ids", f[fkey], Hn, T, hs * T, V, keys, perm, ws, nbytes)
+            rows.append((f[fkey].data_ptr(), keys.data_ptr(), perm.data_ptr(), counts[o:].data_ptr(), Hn, hs * T, T, b))
+            o += 1 << b
+        ops.sort_ids_multi(rows)
 
     def _hist_grad_sorted(self, dhist, dM, dR, Hn, T, seq_len, ls, ss, only=None):
         """IndexedSlices of the history lookups -> dense gradient tables via segmented sums over the

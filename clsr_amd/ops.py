@@ -281,6 +281,23 @@ class TableDesc(ctypes.Structure):
                 ("sumsq_stride", _I), ("disc_scale", _F), ("disc_loss_scale", _F), ("pad_", _I)]
 
 
+class SortIdsDesc(ctypes.Structure):
+    """ctypes mirror of clsr_sortids_desc (include/clsr_hip.h)."""
+    _fields_ = [("ids", _P), ("keys_out", _P), ("perm_out", _P), ("counts", _P), ("nrows", _L), ("row_stride", _L),
+                ("ncols", _I), ("bits", _I)]
+
+
+def sort_ids_multi(rows):
+    """clsr_sort_ids_multi on a list of (ids, keys_out, perm_out, counts, nrows, row_stride, ncols, bits) tuples."""
+    assert ctypes.sizeof(SortIdsDesc) == query("clsr_sizeof_sortids_desc")
+    arr = (SortIdsDesc * len(rows))()
+    keep_alive(arr)
+    for d, row in zip(arr, rows):
+        for (fname, _), val in zip(SortIdsDesc._fields_, row):
+            setattr(d, fname, val)
+    call("clsr_sort_ids_multi", ctypes.addressof(arr), len(rows))
+
+
 _multi_checked = False
 
 

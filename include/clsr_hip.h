@@ -47,8 +47,18 @@ int clsr_gather_rows(const float* tbl, const int* idx, long idx_stride, int N, i
                      int ldo, int col0, void* stream);
 int clsr_scatter_add_rows(const float* src, int ld_src, int col0, const int* idx, long idx_stride, int N,
                           int C, float* tbl_grad, double* sumsq, void* stream);
-/* Sorted segmented reduction of the history-lookup gradient: radix sort (id, position) pairs on the device,
- * then sum runs of equal ids in registers (dedup of IndexedSlices) */
+/* Sorted segmented reduction of the history-lookup gradient: (id, position) pairs grouped by id on the device with a
+ * hand-written counting sort (LDS-aggregated histogram, scan, scatter: three launches for all tables of a step), then
+ * runs of equal ids summed in registers (dedup of IndexedSlices).  Output: ascending ids when
+ * vocab <= 2^18, grouped by (id mod 2^18) beyond; order inside a run of equal ids undefined. */
+#define CLSR_SORTIDS_MAX 4
+typedef struct clsr_sortids_desc {
+  const int* ids; int* keys_out; int* perm_out; int* counts;   /* counts: (1 << bits) ints, ZERO on entry */
+  long nrows; long row_stride; int ncols; int bits;
+} clsr_sortids_desc;
+int clsr_sizeof_sortids_desc(void);
+int clsr_sort_ids_bits(long vocab);
+int clsr_sort_ids_multi(const clsr_sortids_desc* descs_host, int n, void* stream);
 long clsr_sort_ids_workspace_bytes(long n, long vocab);
 int clsr_sort_ids(const int* ids, long nrows, int ncols, long row_stride, long vocab, int* keys_out,
                   int* perm_out, void* workspace, long workspace_bytes, void* stream);

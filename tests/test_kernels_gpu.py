@@ -146,6 +146,33 @@ def test_sorted_segmented_history_gradient(Hn, T, Di, Dc, G, V):
     close(ss, (gfull[..., :Di] ** 2).sum().reshape(1), rtol=1e-5, name="sumsq")
 
 
+@pytest.mark.parametrize("Hn,T,V,zipf", [(4096, 50, 64138, True), (1024, 250, 292286, True), (4096, 50, 100_000_000, False),
+                                         (3, 1, 7, False)])
+def test_counting_sort_groups_ids_at_benchmark_sizes(Hn, T, V, zipf):
+    """clsr_sort_ids at the BASELINE shapes: a permutation, keys == ids[perm], ascending ids up to 2^18-id vocabularies
+    and grouped by (id mod 2^18) beyond (100M-item catalogue), Zipf-head duplicates included."""
+    g = torch.Generator().manual_seed(V % 1000)
+    n = Hn * T
+    if zipf:
+        ids = (torch.rand(n, generator=g).pow(6.0) * (V - 1)).long() + 1     # heavy head: thousands of copies of id 1
+        ids[::97] = 0                                                       # padding row
+    else:
+        ids = torch.randint(0, V, (n,), generator=g)
+    d_idx = dev(ids.reshape(Hn, T), torch.int32)
+    nbytes = query("clsr_sort_ids_workspace_bytes", n, V)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    keys = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    perm = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    call("clsr_sort_ids", d_idx, Hn, T, T, V, keys, perm, ws, nbytes)
+    ks, pm = keys.cpu().long(), perm.cpu().long()
+    assert torch.equal(torch.sort(pm)[0], torch.arange(n))
+    assert torch.equal(ids[pm], ks)
+    bucket = ks & ((1 << query("clsr_sort_ids_bits", V)) - 1)
+    assert bool((bucket[1:] >= bucket[:-1]).all())
+    if V <= (1 << 18):
+        assert torch.equal(ks, torch.sort(ids)[0])
+
+
 # ------------------------------------------------------------------------------- pgemm
 def _pgemm(X, W, bias=None, T=0, G=0, Xmul=None, in_scale=None, in_shift=None, relu=0, addU=None,
            addV=None, Y=None, accumulate=0, stats=False, M=None, ldx=None):
