@@ -205,3 +205,22 @@ extern "C" int clsr_bn_bwd_apply(float* dy, const float* z, const float* coef, l
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
+
+// out[e] = sum_p partial[p*n + e]  (e < n doubles): the per-block partial statistics of a batch-norm layer folded
+// into ONE row, so that a data-parallel run all-reduces 2*C doubles instead of parts*2*C (clsr_amd/dp.py, sync-BN)
+__global__ void __launch_bounds__(256) sum_parts_d_kernel(const double* __restrict__ partial, int nparts, int n,
+                                                          double* __restrict__ out) {
+  __shared__ double red[4];
+  const int e = blockIdx.x;
+  double s = 0.0;
+  for (int p = threadIdx.x; p < nparts; p += 256) s += partial[(long)p * n + e];
+  s = block256_sum_d(s, red);
+  if (threadIdx.x == 0) out[e] = s;
+}
+
+extern "C" int clsr_sum_parts_d(const double* partial, int nparts, int n, double* out, void* stream) {
+  CLSR_CHECK_ARG(partial && out && nparts > 0 && n > 0);
+  hipLaunchKernelGGL(sum_parts_d_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, partial, nparts, n, out);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}

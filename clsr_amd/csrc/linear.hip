@@ -13,6 +13,7 @@
 // uses feature 16*kt + 4g + r: every lane loads ONE float4 of its position's row per k-tile
 // and stores ONE float4 of outputs per out-tile -- the output layout of a layer is exactly
 // the input layout of the next one (16-byte vector global accesses, no LDS transposes).
+#include <stdlib.h>
 #include "common.h"
 #include "clsr_hip.h"
 
@@ -538,7 +539,11 @@ static int pgemm_dispatch(const PGemmArgs& a0, hipStream_t s) {
   if (a.ldw == 0) a.ldw = a.Kp;
   int ot = pgemm_out_tiles(a.N);
   if (ot == 8 && a.ez) ot = 5;
-  const size_t budget = 96 * 1024;  // bytes of LDS for the weight chunk: keeps at least one more workgroup per CU
+  // bytes of LDS for the weight chunk of one launch (A/B switch: CLSR_PGEMM_LDS_KB)
+  static const size_t budget = []() {
+    const char* e = getenv("CLSR_PGEMM_LDS_KB");
+    return (size_t)(e ? atoi(e) : 96) * 1024;
+  }();
   const int kmax = (int)(budget / ((size_t)16 * ot * sizeof(float))) / 16 * 16;
   if (a.Kp <= kmax) return pgemm_dispatch_one(a, s);
   for (int k0 = 0; k0 < a.K; k0 += kmax) {

@@ -100,7 +100,20 @@ def shard_feed(feed, rank, world, group_size):
 
 
 class DataParallel(object):
-    def __init__(self, net, dist, sync_bn=True, group=None, sparse_tables="auto"):
+    """Data-parallel stepper around a CLSRNet / SeqNet.
+
+    ``train_step`` = backward on this rank's shard with the exchange OVERLAPPED: the net reports, from inside the
+    step and on the stream where it happens, when a piece of the gradient state is final (``net.dp_hooks``), and that
+    piece's collective is issued right there with ``async_op=True`` -- RCCL's stream waits for exactly that stream's
+    work so far and the step's own streams keep going:
+      flags_ready   start of the step (row marks depend on the feed only)  -> byte-map all-reduce under the forward
+      dense_ready   after the batched weight-gradient reduction            -> 0.5 MB all-reduce under the embedding kernels
+      table_ready   per table, on the stream that finished it              -> category / user tables under the item kernel
+    ``_finish`` issues what is left (the item table, the 24 doubles of norms / loss numerators, per-rank BN moving
+    statistics), makes the compute stream wait for every collective, and the identical clip + Adam update follows.
+    Nets without hooks (or ``overlap=False``) run the same collectives back to back after the backward pass."""
+
+    def __init__(self, net, dist, sync_bn=True, group=None, sparse_tables="auto", overlap=True):
         if sparse_tables not in ("auto", "all", "none"):
             raise ValueError("sparse_tables must be 'auto', 'all' or 'none'")
         self.net, self.dist, self.group = net, dist, group
@@ -109,12 +122,16 @@ class DataParallel(object):
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.sync_bn = bool(sync_bn)
+        self.overlap = bool(overlap)
         net.dp_world = self.world
         net.dp_stats_hook = self._sum_stats if self.sync_bn else None
+        net.dp_hooks = self if self.overlap else None
         # sumsq_tab (16) + losses (8) travel together
         self.small = net.stats24       # the net's own 24 doubles: summed in place, no staging copies
         self.sparse_min_bytes = 64 << 20   # "auto": tables below this size always go dense
         self._graphs = None
+        self._works, self._done = [], set()
+        self.trace = None              # tests: list that receives (event, detail) tuples in issue order
         self.broadcast_parameters()
 
     def broadcast_parameters(self):
@@ -126,30 +143,80 @@ class DataParallel(object):
         for t in tensors:
             dist.broadcast(t, src=0, group=self.group)
 
-    def _sum_stats(self, t):
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+    # ---- collectives: issued on (ordered after) ``stream``, never waited for here
+    def _on(self, stream):
+        import contextlib
+
+        return torch.cuda.stream(stream) if (stream is not None and torch.cuda.is_available()) else contextlib.nullcontext()
+
+    def _allreduce(self, t, op, stream, what):
+        if self.trace is not None:
+            self.trace.append(("collective", what))
+        with self._on(stream):
+            w = self.dist.all_reduce(t, op=op, group=self.group, async_op=True)
+        self._works.append(w)
+
+    def _sum_stats(self, t, stream=None):
+        """SyncBN: the statistics are needed by the very next launch -- a blocking (stream-ordered) all-reduce."""
+        with self._on(stream):
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def prepare(self, f):
         """Make the per-batch loss normalisers global (call once per uploaded feed)."""
         self.dist.all_reduce(f["denom"], op=self.dist.ReduceOp.SUM, group=self.group)
         return f
 
-    # ---- the three phases of a step
-    def _backward(self, f):
-        self.net.train_step(f, apply=False)
-
     def _is_sparse(self, name):
         if self.sparse_tables != "auto":
             return self.sparse_tables == "all"
         V, C = self.net.tables[name].shape
         if V * C * 4 < self.sparse_min_bytes:
-            # a small table rides in the one flat all-reduce for a few tens of microseconds; the sparse route costs
-            # ~25 small launches + three collectives per table (measured: +0.1 ms per 6 MB user table)
+            # a small table rides in a dense all-reduce for a few tens of microseconds; the sparse route costs
+            # ~10 small launches + three collectives per table (measured: +0.1 ms per 6 MB user table)
             return False
         return 4 * touched_rows_bound(name, self.net.last_shape, V) * self.world < V
 
-    def _exchange_rows(self, name):
-        """Sparse exchange of one embedding table's gradient (see the module docstring)."""
+    # ---- hooks (called by the net from inside the step; ``stream`` = where the data became final)
+    def flags_ready(self, stream):
+        net = self.net
+        self._done.add("flags")
+        names = list(net.tab_grad)
+        sparse = [n for n in names if self._is_sparse(n)]
+        self.last_sparse = sparse
+        with self._on(stream):
+            for n in sparse:      # the list of THIS rank's touched rows, before any merging
+                self._compact_local(n)
+        # runs of consecutive dense tables share one collective (their byte maps are adjacent in the flat buffer)
+        i = 0
+        while i < len(names):
+            if names[i] in sparse:
+                i += 1
+                continue
+            j = i
+            while j + 1 < len(names) and names[j + 1] not in sparse:
+                j += 1
+            f0, f1 = net.tab_foff[names[i]], net.tab_foff[names[j]] + net.tab_shape[names[j]][0]
+            self._allreduce(net.tab_flags_flat[f0:f1], self.dist.ReduceOp.MAX, stream, "flags")
+            i = j + 1
+
+    def dense_ready(self, stream):
+        self._done.add("dense")
+        self._allreduce(self.net.dense_grad, self.dist.ReduceOp.SUM, stream, "dense")
+
+    def table_ready(self, stream, name):
+        net = self.net
+        if name in self._done or name not in net.tab_grad:
+            return
+        if "flags" not in self._done:          # a net that never reported its flags: exchange them first
+            self.flags_ready(stream)
+        self._done.add(name)
+        if name in self.last_sparse:
+            with self._on(stream):
+                self._exchange_rows(name)
+        else:
+            self._allreduce(net.tab_grad[name].view(-1), self.dist.ReduceOp.SUM, stream, "table:" + name)
+
+    def _compact_local(self, name):
         net, W = self.net, self.world
         grad, flags = net.tab_grad[name], net.tab_flags[name]
         V, C = grad.shape
@@ -164,65 +231,74 @@ class DataParallel(object):
                 count=torch.zeros(2, dtype=i32, device=dev), ids=torch.zeros(cap, dtype=i32, device=dev),
                 rows=torch.zeros(cap, C, device=dev), counts_all=torch.zeros(W, 2, dtype=i32, device=dev),
                 ids_all=torch.zeros(W, cap, dtype=i32, device=dev), rows_all=torch.zeros(W, cap, C, device=dev))
-        ops.call("clsr_flags_compact", flags, V, b["ids"], cap, b["count"], b["ws"], b["nws"])
-        ops.call("clsr_rows_pack", grad, b["ids"], b["count"], cap, C, b["rows"])
+        self._cur_sparse = getattr(self, "_cur_sparse", {})
+        self._cur_sparse[name] = (b, cap)
+        ops.call("clsr_flags_compact", flags, V, b["ids"], cap, b["count"], b["ws"], b["nws"],
+                 stream=torch.cuda.current_stream().cuda_stream)
+
+    def _exchange_rows(self, name):
+        """Sparse exchange of one embedding table's gradient (see the module docstring); runs on the current stream."""
+        net, W = self.net, self.world
+        grad, flags = net.tab_grad[name], net.tab_flags[name]
+        V, C = grad.shape
+        b, cap = self._cur_sparse[name]
+        if self.trace is not None:
+            self.trace.append(("collective", "rows:" + name))
+        s = torch.cuda.current_stream().cuda_stream
+        ops.call("clsr_rows_pack", grad, b["ids"], b["count"], cap, C, b["rows"], stream=s)
         allgather_row_lists(self.dist, b["count"], b["ids"], b["rows"], b["counts_all"], b["ids_all"],
                             b["rows_all"], self.group)
         # own rows are cleared, then the lists of ALL ranks are added in rank order: the same fp32 sums,
         # in the same order, on every replica
-        ops.call("clsr_rows_unpack", b["ids"], None, b["count"], cap, C, 0, grad, None)
+        ops.call("clsr_rows_unpack", b["ids"], None, b["count"], cap, C, 0, grad, None, stream=s)
         for r in range(W):
             ops.call("clsr_rows_unpack", b["ids_all"][r], b["rows_all"][r], b["counts_all"][r], cap, C, 1, grad,
-                     flags)
+                     flags, stream=s)
 
-    def _exchange(self):
+    # ---- the phases of a step
+    def _backward(self, f):
+        self._works, self._done = [], set()
+        self.net.train_step(f, apply=False)
+
+    def _finish(self):
+        """Everything that has not been exchanged yet, then the compute stream waits for all collectives."""
         net, dist = self.net, self.dist
-        sparse = [n for n in net.tab_grad if self._is_sparse(n)]
-        self.last_sparse = sparse
-        bn_done = False
-        if not sparse:
-            # gradients (+ the moving BN statistics behind them in the same buffer, when they are per-rank)
-            flat = net.grad_flat if not self.sync_bn else net.grad_flat[:net.grad_flat.numel() - net.bn_moving.numel()]
-            allreduce_step_buffers(dist, net.dense_grad, net.tab_grad_flat, net.tab_flags_flat, self.small,
-                                   self.group, grad_flat=flat)
-            bn_done = not self.sync_bn
-        else:
-            dist.all_reduce(net.dense_grad, op=dist.ReduceOp.SUM, group=self.group)
-            dist.all_reduce(self.small, op=dist.ReduceOp.SUM, group=self.group)
-            # runs of consecutive dense tables share one collective per flat buffer (they are adjacent in it)
-            names, i = list(net.tab_grad), 0
-            while i < len(names):
-                if names[i] in sparse:
-                    self._exchange_rows(names[i])
-                    i += 1
-                    continue
-                j = i
-                while j + 1 < len(names) and names[j + 1] not in sparse:
-                    j += 1
-                V, C = net.tab_shape[names[j]]
-                g0, g1 = net.tab_goff[names[i]], net.tab_goff[names[j]] + V * C
-                f0, f1 = net.tab_foff[names[i]], net.tab_foff[names[j]] + V
-                dist.all_reduce(net.tab_grad_flat[g0:g1], op=dist.ReduceOp.SUM, group=self.group)
-                dist.all_reduce(net.tab_flags_flat[f0:f1], op=dist.ReduceOp.MAX, group=self.group)
-                i = j + 1
+        if self.trace is not None:
+            self.trace.append(("finish", sorted(self._done)))
+        stream = ops.current_stream() if torch.cuda.is_available() else None
+        if "flags" not in self._done:
+            self.flags_ready(stream)
+        if "dense" not in self._done:
+            self.dense_ready(stream)
+        for name in net.tab_grad:
+            self.table_ready(stream, name)
+        self._allreduce(self.small, dist.ReduceOp.SUM, stream, "small")
         if not self.sync_bn:
             # keep the (non-trainable) moving statistics identical on every replica: their average
-            if not bn_done:
-                self.dist.all_reduce(net.bn_moving, op=self.dist.ReduceOp.SUM, group=self.group)
-            net.bn_moving.mul_(1.0 / self.world)
+            self._allreduce(net.bn_moving, dist.ReduceOp.SUM, stream, "bn_moving")
+        with self._on(stream):
+            for w in self._works:
+                w.wait()
+            if not self.sync_bn:
+                net.bn_moving.mul_(1.0 / self.world)
+        self._works = []
+
+    def _exchange(self):
+        self._finish()
 
     def _update(self):
         self.net._apply_updates()
 
     def train_step(self, f):
         self._backward(f)
-        self._exchange()
+        self._finish()
         self._update()
 
     def capture(self, f):
         """Two hipGraphs (backward | update) around the eager RCCL exchange; returns run().
-        With sync_bn the BN collectives sit inside the backward phase, so that phase stays eager."""
-        if self.sync_bn:
+        With sync_bn the BN collectives sit inside the backward phase, so that phase stays eager; the overlapped
+        exchange issues collectives from inside the backward phase too, so graphs need ``overlap=False``."""
+        if self.sync_bn or self.overlap:
             return lambda: self.train_step(f)
         ops.graph_begin()
         self._backward(f)

@@ -109,6 +109,10 @@ class CLSRNet(object):
         self.last_shape = None
         self.dp_world = 1          # data-parallel world size (loss normalisers are global)
         self.dp_stats_hook = None  # optional callable(tensor): sum BN partial statistics across ranks
+        # data-parallel exchange hooks (clsr_amd/dp.py): called (and recorded into launch plans) at the points of the
+        # step where a piece of the gradient state becomes final, so that its collective overlaps the rest of the
+        # backward pass: flags_ready() | dense_ready() | table_ready(name)
+        self.dp_hooks = None
         self.capture_grads = False
         self.captured = None
 
@@ -168,7 +172,8 @@ class CLSRNet(object):
     def _plan_key(self, what, f):
         hp = self.hp
         g = lambda k: getattr(hp, k, None)
-        return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, self.overlap, self.defer_dw, self.sorted_hist_grad,
+        return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook),
+                self.overlap, self.defer_dw, self.sorted_hist_grad,
                 self.lazy, self.rnn_first, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad,
                 self.split_g2, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
@@ -178,7 +183,7 @@ class CLSRNet(object):
         """Run a step eagerly, or replay its recorded launch sequence (``ops.LaunchPlan``) when this exact step --
         same uploaded feed object (its device arena is persistent), stream, scalars -- has run before.  The second
         occurrence is the one recorded: the first one allocates workspaces and builds descriptor tables."""
-        if (not self.use_plans) or self.capture_grads or self.dp_stats_hook is not None or ops.recording():
+        if (not self.use_plans) or self.capture_grads or ops.recording():
             return run()
         key = self._plan_key(what, f)
         ent = self._step_plans.get(key)
@@ -378,6 +383,14 @@ class CLSRNet(object):
         is what the device sees: a branch enqueued ahead of a long main-stream kernel delays that kernel)."""
         return CLSRNet._Branch(self, tag, after, name)     # name: what ``_join(only=...)`` refers to (default: tag)
 
+    def _dp_hook(self, name, *args):
+        """Tell the data-parallel exchange that a piece of the gradient state is final on the CURRENT stream (host
+        call, recorded into the launch plan like a kernel launch)."""
+        h = self.dp_hooks
+        if h is not None:
+            # the stream travels as an argument: a replayed plan does not re-enter the torch stream contexts
+            ops.host_call(getattr(h, name), ops.current_stream(), *args)
+
     def _fork_point(self):
         if not self.overlap:
             return None
@@ -510,10 +523,17 @@ class CLSRNet(object):
 
     def _bn_fwd(self, bn, stats, parts, count, training):
         if training and self.dp_stats_hook is not None:   # SyncBN: global batch statistics
-            self.dp_stats_hook(stats)
+            stats, parts = self._dp_sum_stats(stats, parts, bn.C)
             count = count * self.dp_world
         call("clsr_bn_finalize", stats, parts, bn.C, float(count), bn.gamma, bn.beta, bn.moving_mean,
              bn.moving_var, BN_MOMENTUM, BN_EPS, 1 if training else 0, bn.scale, bn.shift, bn.mean, bn.invstd)
+
+    def _dp_sum_stats(self, stats, parts, C):
+        """Sync-BN: fold the per-block partial sums into one row of 2*C doubles and sum THAT across the ranks."""
+        one = self._buf("dp.stats" + self._ws_tag, 2 * 1024, dtype=torch.float64)[: 2 * C]
+        call("clsr_sum_parts_d", stats, parts, 2 * C, one)
+        ops.host_call(self.dp_stats_hook, one, ops.current_stream())
+        return one, 1
 
     def _bn_bwd_from_partial(self, bn, part, parts, dy, z, M):
         self._bn_bwd_coef(bn, part, parts, M)
@@ -522,7 +542,7 @@ class CLSRNet(object):
     def _bn_bwd_coef(self, bn, part, parts, M):
         count = M
         if self.dp_stats_hook is not None:
-            self.dp_stats_hook(part)
+            part, parts = self._dp_sum_stats(part, parts, bn.C)
             count = M * self.dp_world
         call("clsr_bn_bwd_coef", part, parts, bn.C, float(count), bn.gamma, bn.mean, bn.invstd, bn.coef,
              bn.dgamma, bn.dbeta, 0)
@@ -1260,6 +1280,7 @@ class CLSRNet(object):
                 (f["cates"].data_ptr(), fl["cate"].data_ptr(), B, 1, 1, 0),
                 (f["users"].data_ptr(), fl["user_long"].data_ptr(), Hn, hs, 1, 0),
                 (f["users"].data_ptr(), fl["user_short"].data_ptr(), Hn, hs, 1, 0)])
+            self._dp_hook("flags_ready")      # involved-row byte maps are final: their exchange hides under the forward
         o = [0]
 
         def take(*shape):
@@ -1354,6 +1375,7 @@ class CLSRNet(object):
         self._unpack_grads()
         # ---- join the long-term attention branch; its d(hist) contribution was accumulated separately
         self._join()
+        self._dp_hook("dense_ready")          # every dense gradient is final: all-reduce under the embedding kernels
         call("clsr_axpby", dhist, dhist, 1.0, dhist_lt, 1.0, dhist.numel())
         # ---- embedding gradients (IndexedSlices values -> dense grad tables + squared norms)
         ss = self.sumsq_tab
@@ -1366,13 +1388,17 @@ class CLSRNet(object):
             with self._branch("@lt" if self.split_emb_grad else "@main", after=fork):
                 self._hist_grad_sorted(dhist, dM, dR, Hn, T, seq_len, ls, ss, only="cate")
                 call("clsr_scatter_add_rows", dtarget, D, Di, f["cates"], 1, B, Dc, self.tab_grad["cate"], ss[3:])
+                self._dp_hook("table_ready", "cate")
             with self._branch("@aux" if self.split_emb_grad else "@main", after=fork):
-                call("clsr_scatter_add_rows", dtarget, D, 0, f["items"], 1, B, Di, self.tab_grad["item"], ss[2:])
                 call("clsr_scatter_add_rows", dul, Du, 0, f["users"], hs, Hn, Du, self.tab_grad["user_long"], ss[6:])
                 call("clsr_scatter_add_rows", dushort, Du, 0, f["users"], hs, Hn, Du, self.tab_grad["user_short"],
                      ss[7:])
+                self._dp_hook("table_ready", "user_long")
+                self._dp_hook("table_ready", "user_short")
+                call("clsr_scatter_add_rows", dtarget, D, 0, f["items"], 1, B, Di, self.tab_grad["item"], ss[2:])
             self._hist_grad_sorted(dhist, dM, dR, Hn, T, seq_len, ls, ss, only="item")
             self._join()
+            self._dp_hook("table_ready", "item")
         else:
             call("clsr_gather_hist_bwd", dhist, dM, dR, f["item_history"], f["item_cate_history"], hs * T, seq_len,
                  ls, Hn, T, Di, Dc, hp.contrastive_recent_k, self.tab_grad["item"], self.tab_grad["cate"], ss[0:])
@@ -1380,6 +1406,8 @@ class CLSRNet(object):
             call("clsr_scatter_add_rows", dtarget, D, Di, f["cates"], 1, B, Dc, self.tab_grad["cate"], ss[3:])
             call("clsr_scatter_add_rows", dul, Du, 0, f["users"], hs, Hn, Du, self.tab_grad["user_long"], ss[6:])
             call("clsr_scatter_add_rows", dushort, Du, 0, f["users"], hs, Hn, Du, self.tab_grad["user_short"], ss[7:])
+            for k in ("cate", "user_long", "user_short", "item"):
+                self._dp_hook("table_ready", k)
         if apply:
             self._apply_updates()
         return out

@@ -102,6 +102,18 @@ def stream_wait(stream, ev):
         _rec[0].ops.append((stream.wait_event, (ev,)))
 
 
+def host_call(fn, *args):
+    """Run a host-side callback now and, while a launch plan is being recorded, make it part of the plan (the
+    data-parallel collectives issued from inside a step: clsr_amd/dp.py).  The callback must return None."""
+    rec, _rec[0] = _rec[0], None      # launches made by the callback itself belong to the callback, not to the plan
+    try:
+        fn(*args)
+    finally:
+        _rec[0] = rec
+    if rec is not None:
+        rec.ops.append((fn, args))
+
+
 def call(name, *args, stream=None):
     """Invoke an ``int clsr_*(..., void* stream)`` entry point; raises on a non-zero return."""
     lib = _lib.load()

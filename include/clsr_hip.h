@@ -165,6 +165,7 @@ int clsr_reduce_parts(const float* partial, int nparts, int stride, int n, float
 
 /* ---- batch normalisation of _fcn_net: tf.layers.batch_normalization(momentum=0.95, eps=1e-4)
  *      base_model.py:673-679 (non-fused: stats over all axes but the last, biased variance) */
+int clsr_sum_parts_d(const double* partial, int nparts, int n, double* out, void* stream);
 int clsr_bn_finalize(const double* stats_partial, int nparts, int C, double count, const float* gamma,
                      const float* beta, float* moving_mean, float* moving_var, float momentum, float eps,
                      int training, float* scale, float* shift, float* mean_out, float* invstd_out,

@@ -136,3 +136,113 @@ def test_shard_feed_compact_layout():
         raise AssertionError("group mismatch accepted")
     except ValueError:
         pass
+
+
+class _StubNet(object):
+    """What DataParallel touches of a net, on CPU tensors."""
+
+    def __init__(self):
+        self.device = torch.device("cpu")
+        shapes = dict(item=(50, 8), cate=(7, 4), user_long=(20, 8), user_short=(20, 8))
+        self.tab_shape = shapes
+        self.tab_goff, self.tab_foff, g, f = {}, {}, 0, 0
+        for k, (V, C) in shapes.items():
+            self.tab_goff[k], self.tab_foff[k] = g, f
+            g += V * C
+            f += (V + 15) // 16 * 16
+        self.grad_flat = torch.zeros(100 + g + 8)
+        self.dense_grad = self.grad_flat[:100]
+        self.tab_grad_flat = self.grad_flat[100:100 + g]
+        self.bn_moving = self.grad_flat[100 + g:]
+        self.tab_flags_flat = torch.zeros(f, dtype=torch.uint8)
+        self.tables = {k: torch.zeros(s) for k, s in shapes.items()}
+        self.tab_grad = {k: self.tab_grad_flat[self.tab_goff[k]:self.tab_goff[k] + s[0] * s[1]].view(s)
+                         for k, s in shapes.items()}
+        self.tab_flags = {k: self.tab_flags_flat[self.tab_foff[k]:self.tab_foff[k] + s[0]] for k, s in shapes.items()}
+        self.tab_m, self.tab_v = {}, {}
+        self.dense = self.dense_m = self.dense_v = torch.zeros(1)
+        self.adam_state = torch.zeros(4, dtype=torch.float64)
+        self.stats24 = torch.zeros(24, dtype=torch.float64)
+        self.last_shape = (10, 5, 5, 2)
+        self.dp_world, self.dp_stats_hook, self.dp_hooks = 1, None, None
+        self.updated = 0
+        self.script = []
+
+    def train_step(self, f, apply=True):
+        for name, args in self.script:             # the hooks a real step would fire, in the scripted order
+            getattr(self.dp_hooks, name)(None, *args)
+
+    def _apply_updates(self):
+        self.updated += 1
+
+
+class _LogDist(object):
+    class ReduceOp(object):
+        SUM, MAX = "sum", "max"
+
+    class _Work(object):
+        def __init__(self, log, tag):
+            self.log, self.tag = log, tag
+
+        def wait(self):
+            self.log.append(("wait", self.tag))
+
+    def __init__(self):
+        self.log = []
+
+    def get_world_size(self, group=None):
+        return 2
+
+    def get_rank(self, group=None):
+        return 1
+
+    def broadcast(self, t, src=0, group=None):
+        pass
+
+    def all_reduce(self, t, op=None, group=None, async_op=False):
+        self.log.append(("all_reduce", t.data_ptr(), t.numel(), op))
+        return self._Work(self.log, t.data_ptr()) if async_op else None
+
+
+def test_overlapped_exchange_bookkeeping_every_piece_exactly_once_and_waited_for():
+    """Host logic of DataParallel: whatever subset of hooks a step fires (all of them, some, none -- a net without
+    hooks), every piece of gradient state is all-reduced exactly once, flags go before the first table, the 24
+    doubles go last, and the update runs only after every collective has been waited for."""
+    from clsr_amd.dp import DataParallel
+
+    scripts = [
+        [("flags_ready", ()), ("dense_ready", ()), ("table_ready", ("cate",)), ("table_ready", ("user_long",)),
+         ("table_ready", ("user_short",)), ("table_ready", ("item",))],
+        [("dense_ready", ()), ("table_ready", ("cate",))],                    # flags never reported: forced before cate
+        [],                                                                   # a net without hooks
+        [("table_ready", ("item",)), ("table_ready", ("item",))],             # a duplicate report is ignored
+    ]
+    for script in scripts:
+        net, d = _StubNet(), _LogDist()
+        dp = DataParallel(net, d, sync_bn=True, sparse_tables="none")
+        assert net.dp_hooks is dp and net.dp_world == 2
+        net.script = script
+        dp.train_step({})
+        ar = [e for e in d.log if e[0] == "all_reduce"]
+        ptrs = [e[1] for e in ar]
+        last = list(net.tab_shape)[-1]                      # (the byte maps travel without the last table's padding)
+        expect = {net.dense_grad.data_ptr(): 100, net.stats24.data_ptr(): 24,
+                  net.tab_flags_flat.data_ptr(): net.tab_foff[last] + net.tab_shape[last][0]}
+        for k, (V, C) in net.tab_shape.items():
+            expect[net.tab_grad[k].data_ptr()] = V * C
+        assert sorted(ptrs) == sorted(expect), script          # every piece exactly once (sync BN: no moving stats)
+        assert all(expect[e[1]] == e[2] for e in ar)
+        first_table = min(i for i, e in enumerate(ar) if e[1] in {t.data_ptr() for t in net.tab_grad.values()})
+        assert ptrs.index(net.tab_flags_flat.data_ptr()) < first_table
+        assert ptrs[-1] == net.stats24.data_ptr()
+        waits = [e for e in d.log if e[0] == "wait"]
+        assert len(waits) == len(ar) and d.log.index(waits[0]) > d.log.index(ar[-1])
+        assert net.updated == 1
+    # per-rank batch-norm: the moving statistics are averaged as well
+    net, d = _StubNet(), _LogDist()
+    net.bn_moving += 2.0
+    dp = DataParallel(net, d, sync_bn=False, sparse_tables="none", overlap=False)
+    assert net.dp_hooks is None
+    dp.train_step({})
+    assert any(e[0] == "all_reduce" and e[1] == net.bn_moving.data_ptr() for e in d.log)
+    assert torch.allclose(net.bn_moving, torch.ones(8))       # (identity all-reduce) * 1 / world

@@ -1,5 +1,10 @@
-"""GPU test: two data-parallel ranks (sharing the one GPU of the test box, collectives staged
-through gloo on the host) with sync-BN reproduce the single-process step on the global batch."""
+"""GPU tests of the data-parallel step: two ranks with sync-BN reproduce the single-process step on the global batch.
+
+Two transports: ``nccl`` (RCCL, one GPU per rank -- runs when the box has at least two GPUs, skipped otherwise) and
+``staged`` (both ranks share the one GPU of the test box; every collective is staged through gloo on the host by
+``_HostStagedDist``, whose blocking device-to-host copy on the issuing stream gives the same "ordered after that
+stream's work so far" semantics RCCL has).  Plus: the order in which the overlapped exchange issues its collectives,
+checked against the state of the step's stream joins at issue time."""
 import copy
 import os
 import socket
@@ -24,10 +29,15 @@ class _HostStagedDist(object):
     def get_rank(self, group=None):
         return self._d.get_rank()
 
-    def all_reduce(self, t, op=None, group=None):
-        c = t.detach().cpu()
+    class _Done(object):
+        def wait(self):
+            pass
+
+    def all_reduce(self, t, op=None, group=None, async_op=False):
+        c = t.detach().cpu()             # blocking copy on the CURRENT stream: ordered after its work so far
         self._d.all_reduce(c, op=op)
         t.copy_(c)
+        return self._Done() if async_op else None
 
     def all_gather(self, outs, t, group=None):
         cs = [o.detach().cpu() for o in outs]
@@ -35,25 +45,47 @@ class _HostStagedDist(object):
         for o, c in zip(outs, cs):
             o.copy_(c)
 
+    def barrier(self):
+        self._d.barrier()
+
     def broadcast(self, t, src=0, group=None):
         c = t.detach().cpu()
         self._d.broadcast(c, src=src)
         t.copy_(c)
 
 
-def _worker(rank, world, port, hp, dims, feed, sd, sparse, out):
+def _transports():
+    return [pytest.param("staged"),
+            pytest.param("nccl", marks=pytest.mark.skipif(torch.cuda.device_count() < 2,
+                                                          reason="RCCL with two ranks needs two GPUs"))]
+
+
+def _init(transport, rank, world, port):
+    """-> (dist-like object for DataParallel / CLSRModel, device of this rank)"""
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if transport == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        return dist, "cuda:%d" % rank
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    return _HostStagedDist(dist), "cuda:0"
+
+
+def _worker(rank, world, port, hp, dims, feed, sd, sparse, out, transport="staged", overlap=True):
     import torch.distributed as dist
 
     from clsr_amd.dp import DataParallel, shard_feed
     from clsr_amd.net import CLSRNet
 
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    net = CLSRNet(hp, dims, device="cuda:0", seed=rank)  # different seeds: broadcast must fix that
+    d, dev = _init(transport, rank, world, port)
+    net = CLSRNet(hp, dims, device=dev, seed=rank)  # different seeds: broadcast must fix that
     if rank == 0:
         net.load_state_dict(sd)
-    dp = DataParallel(net, _HostStagedDist(dist), sync_bn=True, sparse_tables=sparse)
+    dp = DataParallel(net, d, sync_bn=True, sparse_tables=sparse, overlap=overlap)
     net.capture_grads = True
     f = dp.prepare(net.upload(shard_feed(feed, rank, world, hp.train_num_ngs + 1), True))
     dp.train_step(f)
@@ -68,8 +100,9 @@ def _worker(rank, world, port, hp, dims, feed, sd, sparse, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("sparse", ["none", "all", "auto"])
-def test_two_ranks_match_single_process(golden_dir, golden_hparams, sparse):
+@pytest.mark.parametrize("transport", _transports())
+@pytest.mark.parametrize("sparse,overlap", [("none", True), ("all", True), ("auto", True), ("none", False)])
+def test_two_ranks_match_single_process(golden_dir, golden_hparams, sparse, overlap, transport):
     import pickle
 
     import torch.multiprocessing as mp
@@ -99,7 +132,7 @@ def test_two_ranks_match_single_process(golden_dir, golden_hparams, sparse):
     ctx = mp.get_context("spawn")
     mgr = ctx.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, port, hp, dims, feed, sd, sparse, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, hp, dims, feed, sd, sparse, out, transport, overlap), nprocs=2, join=True)
     assert len(out["sparse"]) == {"none": 0, "all": 4}.get(sparse, len(out["sparse"]))
     for k in ("loss", "data_loss", "contrastive_loss", "regular_loss", "discrepancy_loss"):
         assert abs(out["losses"][k] - ref_losses[k]) < 1e-5 * max(1.0, abs(ref_losses[k])), (k, out["losses"], ref_losses)
@@ -119,7 +152,7 @@ def test_two_ranks_match_single_process(golden_dir, golden_hparams, sparse):
             np.testing.assert_allclose(out["state"][k], v.numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
 
 
-def _model_worker(rank, world, port, hp, paths, sd, out):
+def _model_worker(rank, world, port, hp, paths, sd, out, transport="staged"):
     import random
 
     import torch.distributed as dist
@@ -127,10 +160,8 @@ def _model_worker(rank, world, port, hp, paths, sd, out):
     from clsr_amd.clsr import CLSRModel
     from clsr_amd.sequential_iterator import SASequentialIterator
 
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    model = CLSRModel(hp, SASequentialIterator, seed=rank, dist=_HostStagedDist(dist), sync_bn=True)
+    d, dev = _init(transport, rank, world, port)
+    model = CLSRModel(hp, SASequentialIterator, seed=rank, dist=d, sync_bn=True, device=dev)
     if rank == 0:
         model.net.load_state_dict(sd)
     random.seed(11)                      # same global batches (shuffle + negative sampling) on every rank
@@ -146,7 +177,8 @@ def _model_worker(rank, world, port, hp, paths, sd, out):
     dist.destroy_process_group()
 
 
-def test_model_train_with_two_ranks_matches_single_process(golden_dir, golden_hparams):
+@pytest.mark.parametrize("transport", _transports())
+def test_model_train_with_two_ranks_matches_single_process(golden_dir, golden_hparams, transport):
     """CLSRModel(dist=...): two ranks that iterate the same global batches and train on their halves follow the
     single-process run on the global batches (sync-BN): same loss per step, same embedding table afterwards.
     (Four steps: over a whole epoch the two runs drift apart like any two fp32 runs with Adam -- parameters whose
@@ -177,7 +209,7 @@ def test_model_train_with_two_ranks_matches_single_process(golden_dir, golden_hp
     s.close()
     ctx = mp.get_context("spawn")
     out = ctx.Manager().dict()
-    mp.spawn(_model_worker, args=(2, port, hp, train, sd, out), nprocs=2, join=True)
+    mp.spawn(_model_worker, args=(2, port, hp, train, sd, out, transport), nprocs=2, join=True)
     assert len(out[0]["losses"]) == len(ref_losses) == 4
     for a, b, c in zip(out[0]["losses"], out[1]["losses"], ref_losses):
         assert abs(a - b) < 1e-12 and abs(a - c) < 1e-4 * max(1.0, abs(c)), (a, b, c)
@@ -295,3 +327,93 @@ def test_two_rank_epoch_with_ragged_end(golden_dir, golden_hparams, dedup):
         mp.spawn(_epoch_worker, args=(2, port, hp, train, dedup, out), nprocs=2, join=True)
         assert np.isfinite(out[0]["loss"]) and out[0]["loss"] == out[1]["loss"]
         np.testing.assert_array_equal(out[0]["item"], out[1]["item"])      # replicas stay bit-identical
+
+
+class _RecordingDist(object):
+    """Single-process torch.distributed look-alike (world 2 on paper): collectives are identities that record, at
+    ISSUE time, what the step's stream bookkeeping looked like."""
+
+    class ReduceOp(object):
+        SUM, MAX = "sum", "max"
+
+    class _Work(object):
+        def __init__(self, log):
+            self.log = log
+
+        def wait(self):
+            self.log.append(("wait", None))
+
+    def __init__(self):
+        self.log, self.net = [], None
+
+    def get_world_size(self, group=None):
+        return 2
+
+    def get_rank(self, group=None):
+        return 0
+
+    def broadcast(self, t, src=0, group=None):
+        pass
+
+    def all_reduce(self, t, op=None, group=None, async_op=False):
+        n = self.net
+        self.log.append(("all_reduce", t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream,
+                         [name for name, _ in n._joins], {k: len(v) for k, v in n._dw_pending.items() if v}))
+        return self._Work(self.log) if async_op else None
+
+    def all_gather(self, outs, t, group=None):
+        for o in outs:
+            o.copy_(t)
+
+
+@pytest.mark.parametrize("planned", [False, True])
+def test_overlapped_exchange_is_issued_after_the_joins_that_finish_its_data(golden_dir, golden_hparams, planned):
+    """Fails if a collective is enqueued before the stream joins / weight-gradient flush that make its buffer final:
+    the dense all-reduce must see NO unjoined branch and NO pending weight-gradient partials; every table all-reduce
+    is issued on the stream that ran the table's last kernel (item: the compute stream, after the final join); the
+    24 doubles and every wait come last.  Also under a replayed launch plan (the hooks are part of the plan)."""
+    import pickle
+
+    from clsr_amd.dp import DataParallel
+    from clsr_amd.net import CLSRNet
+
+    hp = copy.deepcopy(golden_hparams)
+    dims = dict(Vu=len(pickle.load(open(hp.user_vocab, "rb"))), Vi=len(pickle.load(open(hp.item_vocab, "rb"))),
+                Vc=len(pickle.load(open(hp.cate_vocab, "rb"))))
+    g = np.load(os.path.join(golden_dir, "iterator_train_sa.npz"))
+    feed = {k[3:]: g[k] for k in g.files if k.startswith("b0_")}
+    net = CLSRNet(hp, dims, device="cuda:0", seed=0)
+    d = _RecordingDist()
+    d.net = net
+    dp = DataParallel(net, d, sync_bn=False, sparse_tables="none")
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        f = net.upload(feed, True)
+        for _ in range(3 if planned else 1):     # third occurrence = replayed plan
+            d.log.clear()
+            dp.trace = []
+            dp.train_step(f)
+        torch.cuda.synchronize()
+    main = stream.cuda_stream
+    ar = [e for e in d.log if e[0] == "all_reduce"]
+    by_ptr = {e[1]: e for e in ar}
+    dense = by_ptr[net.dense_grad.data_ptr()]
+    if not planned:      # (a replayed plan does not rebuild the python-side bookkeeping the recorder looks at)
+        assert dense[4] == [] and dense[5] == {}, "dense all-reduce issued before the joins / the dW flush: %r" % (dense,)
+    assert dense[3] == main
+    flags = by_ptr[net.tab_flags_flat.data_ptr()]
+    assert d.log.index(flags) < d.log.index(dense), "the byte maps are exchanged from the start of the step"
+    assert flags[3] != main, "flags ride on the side stream that marked them"
+    item = by_ptr[net.tab_grad["item"].data_ptr()]
+    if not planned:
+        assert item[4] == [], "item table all-reduce issued before the final join"
+    assert item[3] == main
+    for k in ("cate", "user_long", "user_short"):
+        e = by_ptr[net.tab_grad[k].data_ptr()]
+        assert d.log.index(dense) < d.log.index(e) < d.log.index(item), k
+        assert e[3] != main, "table %s is exchanged from the side stream that finished it" % k
+    small = by_ptr[net.stats24.data_ptr()]
+    assert d.log.index(small) > d.log.index(item)
+    waits = [i for i, e in enumerate(d.log) if e[0] == "wait"]
+    assert len(waits) == len(ar) and min(waits) > max(d.log.index(e) for e in ar)
+    assert [w for w, _ in dp.trace if w == "finish"] == ["finish"]
