@@ -464,9 +464,53 @@ class SequentialBaseModel(BaseModel):
         print("best epoch: {0}".format(self.best_epoch))
         return self
 
+    # ------------------------------------------------------------------ evaluation on the device
+    def _device_eval(self, filename, num_ngs, weighted):
+        """Score ``filename`` and compute the metrics on the device (clsr_amd/device_metrics.py): no per-batch host
+        synchronisation, scores never leave HBM.  None when a requested metric has no device form (host path then)."""
+        from clsr_amd import device_metrics as DM
+
+        if os.environ.get("CLSR_HOST_METRICS") or not DM.supported(self.hparams, self.user_vocab_length):
+            return None
+        with self._stream_ctx():
+            acc = DM.DeviceScores(self.net.device)
+
+            def score(feeds):
+                feed = feeds[0] if len(feeds) == 1 else {
+                    k: (v if k == "hist_group" else np.concatenate([np.asarray(x[k]) for x in feeds], axis=0))
+                    for k, v in feeds[0].items()}
+                key, f, _ = self._static_feed(feed, False)
+                out = self.net.forward(f, False)
+                pred = torch.sigmoid(out["logit"]) if self.hparams.method == "classification" else out["logit"]
+                acc.append(pred, f["labels"], f["users_rows"] if "users_rows" in f else f["users"])
+
+            # the iterator's batches (hparams.batch_size LINES each) are scored several at a time: a forward pass is
+            # ~100 launches whatever its size, and nothing here waits for the device between batches
+            pend, rows, target = [], 0, int(os.environ.get("CLSR_EVAL_ROWS", "32768"))
+            for batch_data_input in self.iterator.load_data_from_file(
+                    filename, min_seq_length=self.min_seq_length, batch_num_ngs=0):
+                if not batch_data_input:
+                    continue
+                feed = self._to_arrays(batch_data_input)
+                if pend and (feed.get("hist_group", 0) != pend[0].get("hist_group", 0)
+                             or feed["mask"].shape[1] != pend[0]["mask"].shape[1]):
+                    score(pend)
+                    pend, rows = [], 0
+                pend.append(feed)
+                rows += int(np.asarray(feed["labels"]).shape[0])
+                if rows >= target:
+                    score(pend)
+                    pend, rows = [], 0
+            if pend:
+                score(pend)
+            return DM.compute(acc, self.hparams, num_ngs + 1, weighted)
+
     def run_eval(self, filename, num_ngs):
         """auc/logloss + pairwise metrics over groups of ``num_ngs + 1`` lines
         (reference sequential_base_model.py:204-236)."""
+        res = self._device_eval(filename, num_ngs, False)
+        if res is not None:
+            return res
         preds, labels = [], []
         for batch_data_input in self.iterator.load_data_from_file(
                 filename, min_seq_length=self.min_seq_length, batch_num_ngs=0):
@@ -490,6 +534,10 @@ class SequentialBaseModel(BaseModel):
     def run_weighted_eval(self, filename, num_ngs, calc_mean_alpha=False, manual_alpha=False):
         """run_eval + user-weighted metrics (wauc == the README's GAUC)
         (reference sequential_base_model.py:244-292)."""
+        if not calc_mean_alpha:
+            res = self._device_eval(filename, num_ngs, True)
+            if res is not None:
+                return res
         users, preds, labels, alphas = [], [], [], []
         for batch_data_input in self.iterator.load_data_from_file(
                 filename, min_seq_length=self.min_seq_length, batch_num_ngs=0):

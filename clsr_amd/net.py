@@ -785,6 +785,8 @@ class CLSRNet(object):
         for k in ("time_from_first_action", "time_to_now"):
             h[k] = np.ascontiguousarray(feed[k], dtype=np.float32)
         h["labels"] = np.ascontiguousarray(np.asarray(feed["labels"]).reshape(-1), dtype=np.float32)
+        if "users_rows" in feed:      # scoring feeds with shared histories: the user of every LINE (device metrics)
+            h["users_rows"] = np.ascontiguousarray(np.asarray(feed["users_rows"]).reshape(-1), dtype=np.int32)
         h["seq_len"] = seq_len
         rep = hg if compact else 1
         thr = getattr(self.hp, "contrastive_length_threshold", None) or 0     # (unset for the sibling models)

@@ -374,6 +374,19 @@ int clsr_tables_reg_multi(const clsr_table_desc* descs_host, int n, float l2, co
 int clsr_tables_adam_multi(const clsr_table_desc* descs_host, int n, float clip_norm, const double* adam_state,
                            float beta1, float beta2, float eps, int lazy, void* stream);
 
+/* ---- evaluation metrics on the device (csrc/metrics.hip): cal_metric / cal_weighted_metric of
+ *      deeprec_utils.py:554-821 as SequentialBaseModel.run_eval / run_weighted_eval use them
+ *      (sequential_base_model.py:204-292), by exact pair / rank COUNTING (no sort); accumulators are ADDED to (zero them
+ *      first).  Rank ties inside a group: the later line ranks first (stable ascending sort read backwards). */
+int clsr_eval_logloss(const float* pred, const float* labels, long N, double* out, void* stream);
+int clsr_eval_compact_pos(const float* pred, const float* labels, long N, float* pos_out, int* count, void* stream);
+int clsr_eval_auc_pairs(const float* pred, const float* labels, long N, const float* pos, const int* count,
+                        void* out_u64x3, void* stream);
+int clsr_eval_group_metrics(const float* pred, const float* labels, long n_groups, int G, const int* ks_host, int nk,
+                            int want_auc, double* out, int* err, void* stream);
+int clsr_eval_user_auc(const float* pred, const float* labels, const int* perm, const int* ends, int nb, long N,
+                       double* out, int* err, void* stream);
+
 /* ---- host-side (no GPU) replay of CPython's random module for the input pipeline: continue the MT19937 stream of
  *      random.getstate() through random.shuffle / the in-batch negative sampling of io/sequential_iterator.py:249-261,
  *      612-634, bit-identically, and hand the advanced state back (key[624], *pos). */
