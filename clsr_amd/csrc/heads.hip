@@ -12,22 +12,24 @@
 
 // ------------------------------------------------------------------ alpha-gate input concat
 // out[b, :] = [fs[h] (nfs) | target[b] (D) | L[h] (D) | S[b] (D) | tnow_last[b] | 0 pad]   (ldo wide)
-__global__ void alpha_concat_kernel(const float* __restrict__ fs, int nfs, const float* __restrict__ target,
-                                    const float* __restrict__ L, const float* __restrict__ S,
-                                    const float* __restrict__ tnow, long tnow_stride, int tnow_col,
-                                    int tnow_group, long B, int G, int D, float* __restrict__ out, int ldo) {
-  const long total = B * ldo;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const long b = e / ldo;
-    const int c = (int)(e - b * ldo);
-    const long h = b / G;
-    float v = 0.f;
-    if (c < nfs) v = fs[h * nfs + c];
-    else if (c < nfs + D) v = target[b * D + (c - nfs)];
-    else if (c < nfs + 2 * D) v = L[h * D + (c - nfs - D)];
-    else if (c < nfs + 3 * D) v = S[b * D + (c - nfs - 2 * D)];
-    else if (c == nfs + 3 * D) v = tnow[(b / tnow_group) * tnow_stride + tnow_col];
-    out[e] = v;
+// thread -> (row slot, 16-byte chunk); 32-bit indices (the element-wise form spent 70 us in 64-bit divisions)
+__global__ void __launch_bounds__(256) alpha_concat_kernel(
+    const float* __restrict__ fs, int nfs, const float* __restrict__ target, const float* __restrict__ L,
+    const float* __restrict__ S, const float* __restrict__ tnow, long tnow_stride, int tnow_col, int tnow_group, int B,
+    int G, int D, float* __restrict__ out, int ldo) {
+  const int QC = ldo >> 2, rpb = 256 / QC;
+  const int ty = threadIdx.x / QC, q = threadIdx.x - ty * QC;
+  if (ty >= rpb) return;
+  const int c = 4 * q;
+  for (int b = blockIdx.x * rpb + ty; b < B; b += gridDim.x * rpb) {
+    const int h = b / G;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c < nfs) v = ld4(fs + (long)h * nfs + c);
+    else if (c < nfs + D) v = ld4(target + (long)b * D + (c - nfs));
+    else if (c < nfs + 2 * D) v = ld4(L + (long)h * D + (c - nfs - D));
+    else if (c < nfs + 3 * D) v = ld4(S + (long)b * D + (c - nfs - 2 * D));
+    else if (c == nfs + 3 * D) v.x = tnow[(long)(b / tnow_group) * tnow_stride + tnow_col];
+    st4(out + (long)b * ldo + c, v);
   }
 }
 
@@ -36,10 +38,12 @@ extern "C" int clsr_alpha_concat(const float* fs, int nfs, const float* target, 
                                  int tnow_group, long B, int G, int D, float* out, int ldo, void* stream) {
   CLSR_CHECK_ARG(target && L && S && tnow && out && B > 0 && G > 0 && tnow_group > 0 && (nfs == 0 || fs));
   CLSR_CHECK_ARG(ldo >= nfs + 3 * D + 1);
-  int blocks = clsr_cdiv(B * ldo, 256);
+  CLSR_CHECK_SUPPORTED(nfs % 4 == 0 && D % 4 == 0 && ldo % 4 == 0 && ldo <= 1024 && B < (1L << 31));
+  const int rpb = 256 / (ldo / 4);
+  int blocks = clsr_cdiv(B, rpb * 2);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(alpha_concat_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, fs, nfs,
-                     target, L, S, tnow, tnow_stride, tnow_col, tnow_group, B, G, D, out, ldo);
+                     target, L, S, tnow, tnow_stride, tnow_col, tnow_group, (int)B, G, D, out, ldo);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }

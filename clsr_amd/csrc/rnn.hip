@@ -611,21 +611,26 @@ extern "C" int clsr_t4lstm_bwd(const float* act, const float* cst, const float* 
 // ======================================================================= Time4LSTM time inputs
 // TT[h,t,:] = [tanh(t_now*w1 + b1) (n) | tanh(t_first*w2 + b2) (n)]
 // (rnn_cell_implement.py:200-205; inputs[:, -1] = time_to_now, inputs[:, -2] = time_from_first_action)
-__global__ void t4_time_inputs_fwd_kernel(const float* __restrict__ tnow, const float* __restrict__ tfirst,
-                                          long row_stride, const float* __restrict__ w1,
-                                          const float* __restrict__ b1, const float* __restrict__ w2,
-                                          const float* __restrict__ b2, long Hn, int T, int n,
-                                          float* __restrict__ TT) {
-  const long total = Hn * T * 2 * n;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(e % (2 * n));
-    const long ht = e / (2 * n);
-    const int t = (int)(ht % T);
-    const long h = ht / T;
-    float v;
-    if (c < n) v = tanhf_(tnow[h * row_stride + t] * w1[c] + b1[c]);
-    else v = tanhf_(tfirst[h * row_stride + t] * w2[c - n] + b2[c - n]);
-    TT[e] = v;
+// thread -> (row slot, 16-byte column chunk): 32-bit index arithmetic, one division per row (the element-wise
+// form of this kernel spent its time in 64-bit divisions: 131 us for 16 M tanh; this one is bound by its 65 MB store)
+__global__ void __launch_bounds__(256) t4_time_inputs_fwd_kernel(
+    const float* __restrict__ tnow, const float* __restrict__ tfirst, long row_stride, const float* __restrict__ w1,
+    const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2, long Hn, int T, int n,
+    float* __restrict__ TT) {
+  const int QC = (2 * n) >> 2, rpb = 256 / QC;
+  const int ty = threadIdx.x / QC, q = threadIdx.x - ty * QC;
+  if (ty >= rpb) return;
+  const int c = 4 * q;
+  const bool first = c < n;
+  const f32x4 w = ld4(first ? w1 + c : w2 + (c - n)), b = ld4(first ? b1 + c : b2 + (c - n));
+  const float* tsrc = first ? tnow : tfirst;
+  const int M = (int)(Hn * T);
+  for (int row = blockIdx.x * rpb + ty; row < M; row += gridDim.x * rpb) {
+    const int h = row / T, t = row - h * T;
+    const float x = tsrc[(long)h * row_stride + t];
+    f32x4 v;
+    v.x = tanhf_(x * w.x + b.x); v.y = tanhf_(x * w.y + b.y); v.z = tanhf_(x * w.z + b.z); v.w = tanhf_(x * w.w + b.w);
+    st4(TT + (long)row * (2 * n) + c, v);
   }
 }
 
@@ -633,8 +638,9 @@ extern "C" int clsr_t4_time_inputs_fwd(const float* tnow, const float* tfirst, l
                                        const float* w1, const float* b1, const float* w2,
                                        const float* b2, long Hn, int T, int n, float* TT, void* stream) {
   CLSR_CHECK_ARG(tnow && tfirst && w1 && b1 && w2 && b2 && TT && Hn > 0 && T > 0 && n > 0);
-  int blocks = clsr_cdiv(Hn * T * 2 * n, 256);
-  if (blocks > 8192) blocks = 8192;
+  CLSR_CHECK_SUPPORTED(n % 4 == 0 && 2 * n <= 1024 && Hn * T < (1L << 31));
+  int blocks = clsr_cdiv(Hn * T, (256 / ((2 * n) / 4)) * 4);
+  if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(t4_time_inputs_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tnow,
                      tfirst, row_stride, w1, b1, w2, b2, Hn, T, n, TT);
   CLSR_CHECK_LAUNCH();
@@ -647,36 +653,36 @@ extern "C" int clsr_t4_time_inputs_fwd(const float* tnow, const float* tfirst, l
 __global__ void __launch_bounds__(256) t4_time_inputs_bwd_kernel(
     const float* __restrict__ dTT, const float* __restrict__ TT, const float* __restrict__ tnow,
     const float* __restrict__ tfirst, long row_stride, long Hn, int T, int n, float* __restrict__ partial) {
-  __shared__ float red[2][256];
-  const int C2 = 2 * n;
-  const int rpb = 256 / C2;
-  const int ty = threadIdx.x / C2, c = threadIdx.x - ty * C2;
-  float sw = 0.f, sb = 0.f;
+  __shared__ f32x4 red[2][256];
+  const int C2 = 2 * n, QC = C2 >> 2;
+  const int rpb = 256 / QC;
+  const int ty = threadIdx.x / QC, q = threadIdx.x - ty * QC;
+  f32x4 sw = {0.f, 0.f, 0.f, 0.f}, sb = sw;
   if (ty < rpb) {
+    const int c = 4 * q;
     const float* tsrc = (c < n) ? tnow : tfirst;
-    const long M = Hn * T;
-    for (long row = (long)blockIdx.x * rpb + ty; row < M; row += (long)gridDim.x * rpb) {
-      const long h = row / T;
-      const int t = (int)(row - h * T);
-      const float y = TT[row * C2 + c];
-      const float d = dTT[row * C2 + c] * (1.0f - y * y);
-      sw += d * tsrc[h * row_stride + t];
+    const int M = (int)(Hn * T);
+    for (int row = blockIdx.x * rpb + ty; row < M; row += gridDim.x * rpb) {
+      const int h = row / T, t = row - h * T;
+      const f32x4 y = ld4(TT + (long)row * C2 + c);
+      const f32x4 d = ld4(dTT + (long)row * C2 + c) * ((f32x4){1.f, 1.f, 1.f, 1.f} - y * y);
+      sw += d * tsrc[(long)h * row_stride + t];
       sb += d;
     }
   }
   red[0][threadIdx.x] = sw;
   red[1][threadIdx.x] = sb;
   __syncthreads();
-  if (threadIdx.x < C2) {
-    float a = 0.f, b = 0.f;
-    for (int y = 0; y < rpb; ++y) { a += red[0][y * C2 + threadIdx.x]; b += red[1][y * C2 + threadIdx.x]; }
-    partial[((long)blockIdx.x * 2 + 0) * C2 + threadIdx.x] = a;
-    partial[((long)blockIdx.x * 2 + 1) * C2 + threadIdx.x] = b;
+  if (threadIdx.x < QC) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    for (int y = 0; y < rpb; ++y) { a += red[0][y * QC + threadIdx.x]; b += red[1][y * QC + threadIdx.x]; }
+    st4(partial + ((long)blockIdx.x * 2 + 0) * C2 + 4 * threadIdx.x, a);
+    st4(partial + ((long)blockIdx.x * 2 + 1) * C2 + 4 * threadIdx.x, b);
   }
 }
 
 static int t4_tbwd_blocks(long M, int n) {
-  const int rpb = 256 / (2 * n);
+  const int rpb = 256 / ((2 * n) / 4);
   long b = (M + rpb * 8 - 1) / (rpb * 8);
   if (b > 512) b = 512;
   if (b < 1) b = 1;
@@ -689,7 +695,7 @@ extern "C" int clsr_t4_time_inputs_bwd(const float* dTT, const float* TT, const 
                                        const float* tfirst, long row_stride, long Hn, int T, int n,
                                        float* partial, void* stream) {
   CLSR_CHECK_ARG(dTT && TT && tnow && tfirst && partial && Hn > 0 && T > 0);
-  CLSR_CHECK_SUPPORTED(n > 0 && 2 * n <= 256);
+  CLSR_CHECK_SUPPORTED(n > 0 && n % 4 == 0 && 2 * n <= 1024 && Hn * T < (1L << 31));
   hipLaunchKernelGGL(t4_time_inputs_bwd_kernel, dim3(t4_tbwd_blocks(Hn * T, n)), dim3(256), 0,
                      (hipStream_t)stream, dTT, TT, tnow, tfirst, row_stride, Hn, T, n, partial);
   CLSR_CHECK_LAUNCH();

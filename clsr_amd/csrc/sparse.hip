@@ -90,29 +90,45 @@ __global__ void __launch_bounds__(256) group_pass_kernel(GroupArgs a) {
   }
 }
 
-// counts[b] -> number of entries in buckets < b  (exclusive scan, in place; one 1024-thread workgroup per table:
-// every thread sums a contiguous range, the workgroup scans the 1024 range sums, every thread writes its range back)
+// counts[b] -> number of entries in buckets < b  (exclusive scan, in place; one 1024-thread workgroup per table walks
+// the counters in coalesced tiles of 4096: 16-byte loads, wave scans by shuffles, one LDS exchange per tile)
 __global__ void __launch_bounds__(1024) group_scan_kernel(GroupArgs a) {
-  __shared__ int part[1024];
+  __shared__ int wtot[16];
+  __shared__ int carry_s;
   const clsr_sortids_desc d = a.d[blockIdx.x];
   const int nb = 1 << d.bits;
-  const int per = (nb + 1023) / 1024;
-  const int lo = threadIdx.x * per, hi = min(nb, lo + per);
-  int s = 0;
-  for (int b = lo; b < hi; ++b) s += d.counts[b];
-  part[threadIdx.x] = s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const int add = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+  for (int base = 0; base < nb; base += 4096) {
+    const int i = base + 4 * threadIdx.x;
+    int v[4] = {0, 0, 0, 0};
+    if (i + 3 < nb) {
+      const int4 q = *reinterpret_cast<const int4*>(d.counts + i);
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+      for (int k = 0; k < 4; ++k) if (i + k < nb) v[k] = d.counts[i + k];
+    }
+    const int mine = v[0] + v[1] + v[2] + v[3];
+    int inc = mine;                       // inclusive scan of the per-thread sums inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wtot[wave] = inc;
     __syncthreads();
-    part[threadIdx.x] += add;
+    int before = carry_s;
+    for (int w = 0; w < wave; ++w) before += wtot[w];
+    int run = before + inc - mine;
+    int o4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { o4[k] = run; run += v[k]; }
+    if (i + 3 < nb) *reinterpret_cast<int4*>(d.counts + i) = make_int4(o4[0], o4[1], o4[2], o4[3]);
+    else for (int k = 0; k < 4; ++k) if (i + k < nb) d.counts[i + k] = o4[k];
     __syncthreads();
-  }
-  int run = part[threadIdx.x] - s;
-  for (int b = lo; b < hi; ++b) {
-    const int c = d.counts[b];
-    d.counts[b] = run;
-    run += c;
+    if (threadIdx.x == 1023) carry_s = run;
+    __syncthreads();
   }
 }
 
