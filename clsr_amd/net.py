@@ -79,6 +79,7 @@ class CLSRNet(object):
         self.packed = {}
         self.packed_h = {}         # bf16 images of the weights the speed-mode attention kernels read (csrc/hgemm.hip)
         self.bf16 = self.precision == "bf16"
+        self.bf16_dw = not os.environ.get("CLSR_NO_HDW")        # A/B switch: weight gradients on the bf16 matrix pipe
         self._cur_descs_h = []
         self._plans, self._plan_keep, self._cur_descs = {}, [], []
         self._sort_bytes = {}
@@ -174,7 +175,7 @@ class CLSRNet(object):
         g = lambda k: getattr(hp, k, None)
         return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook),
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
-                self.lazy, self.rnn_first, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad,
+                self.lazy, self.rnn_first, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw,
                 self.split_g2, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
@@ -472,21 +473,26 @@ class CLSRNet(object):
             if side is None:
                 side = self._side[name] = torch.cuda.Stream(device=self.device)
             ops.stream_wait(side, self._fork_point())
-            if x_bf16 or dy_bf16:
-                call("clsr_pgemm_dw_partial_h", X, x_bf16, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, dy_bf16, ldy, M, K, N,
-                     ws, stream=side.cuda_stream)
-            else:
-                call("clsr_pgemm_dw_partial", X, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, ldy, M, K, N, ws,
-                     stream=side.cuda_stream)
+            self._dw_launch(X, x_bf16, ldx, T, G, Xmul, ldmul, sc, sh, dY, dy_bf16, ldy, M, K, N, ws, side.cuda_stream)
             self._dw_async = True
-        elif x_bf16 or dy_bf16:
-            call("clsr_pgemm_dw_partial_h", X, x_bf16, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, dy_bf16, ldy, M, K, N, ws)
         else:
-            call("clsr_pgemm_dw_partial", X, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, ldy, M, K, N, ws)
+            self._dw_launch(X, x_bf16, ldx, T, G, Xmul, ldmul, sc, sh, dY, dy_bf16, ldy, M, K, N, ws, None)
         pend.append((ws.data_ptr(), dW.data_ptr(), db.data_ptr() if db is not None else 0, 1.0,
                      query("clsr_pgemm_dw_parts", M), K, N, ldw, acc))
         if not self.defer_dw:
             self._dw_flush()
+
+    def _dw_launch(self, X, x_bf16, ldx, T, G, Xmul, ldmul, sc, sh, dY, dy_bf16, ldy, M, K, N, ws, stream):
+        """Partial-sum kernel of one weight gradient: the exact fp32-MFMA kernel, or -- speed mode -- the bf16-MFMA
+        one (csrc/hdw.hip: operands rounded to bf16 when staged, fp32 accumulation), same partial layout."""
+        if self.bf16 and self.bf16_dw:
+            call("clsr_hdw_partial", X, x_bf16, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, dy_bf16, ldy, M, K, N, ws,
+                 stream=stream)
+        elif x_bf16 or dy_bf16:
+            call("clsr_pgemm_dw_partial_h", X, x_bf16, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, dy_bf16, ldy, M, K, N, ws,
+                 stream=stream)
+        else:
+            call("clsr_pgemm_dw_partial", X, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, ldy, M, K, N, ws, stream=stream)
 
     def _rp(self, partial, parts, stride, n, out):
         """out[0:n] = sum over ``parts`` per-block partial rows (deferred to ``_dw_flush`` like the dW reductions;

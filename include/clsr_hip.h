@@ -119,6 +119,9 @@ int clsr_pgemm_dw_partial_h(const void* X, int x_bf16, int ldx, int T, int G, co
                             const float* in_scale, const float* in_shift, int in_relu,
                             const void* dY, int dy_bf16, int ldy, int M, int K, int N, float* workspace,
                             void* stream);
+int clsr_hdw_partial(const void* X, int x_bf16, int ldx, int T, int G, const float* Xmul, int ldmul,
+                     const float* in_scale, const float* in_shift, int in_relu, const void* dY,
+                     int dy_bf16, int ldy, int M, int K, int N, float* workspace, void* stream);
 int clsr_att_out_fwd_h(const void* z1, const float* scale1, const float* shift1,
                        const float* w_out, const float* b_out, const int* seq_len,
                        int len_stride, const float* keys, int Hn, int G, int T, int C1, int Dk,

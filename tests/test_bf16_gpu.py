@@ -176,6 +176,35 @@ def test_weight_gradient_kernels_with_bf16_operands():
     _close(db, dz1.double().sum(0), 2e-5, 5e-4, "db")
 
 
+@pytest.mark.parametrize("M,K,N", [(3200, 80, 80), (1000, 40, 480), (777, 80, 120), (130, 164, 80), (64, 80, 40)])
+def test_bf16_mfma_weight_gradient_kernel(M, K, N):
+    """clsr_hdw_partial (weight gradients on the bf16 matrix pipe) == float64 product of the bf16-ROUNDED operands:
+    plain fp32 operands, the X * Xmul[r] prologue with the (T, G) row map, relu(bn(X)) on bf16 X with bf16 dY."""
+    g = torch.Generator().manual_seed(M + K + N)
+    X = torch.randn(M, K, generator=g).to(DEV)
+    dY = torch.randn(M, N, generator=g).to(DEV)
+    dW, db = _dw_full(lambda ws: ops.call("clsr_hdw_partial", X, 0, K, 0, 0, None, 0, None, None, 1, dY, 0, N, M, K, N, ws),
+                      M, K, N, True)
+    _close(dW, _r(X).t() @ _r(dY), 1e-4, 2e-3, "dW plain")
+    _close(db, dY.double().sum(0), 1e-5, 1e-3, "db (exact fp32 column sums of the unrounded dY)")
+    if K % 4 == 0 and M % 10 == 0:
+        T, G = 10, 5 if (M // 10) % 5 == 0 else 1
+        R, Hn = M // T, M // T // G
+        a_, q_ = torch.randn(Hn * T, K, generator=g).to(DEV), torch.randn(R, K, generator=g).to(DEV)
+        dYh = dY.to(BF)
+        dW, _ = _dw_full(lambda ws: ops.call("clsr_hdw_partial", a_, 0, K, T, G, q_, K, None, None, 1, dYh, 1, N, M, K, N,
+                                             ws), M, K, N, False)
+        rows = torch.arange(M, device=DEV)
+        r, t = rows // T, rows % T
+        _close(dW, _r(a_[(r // G) * T + t] * q_[r]).t() @ dYh.double(), 1e-4, 2e-3, "dW (a * q)")
+    Xh, dYh = X.to(BF), dY.to(BF)
+    sc, sh = (torch.rand(K, generator=g) + 0.5).to(DEV), torch.randn(K, generator=g).to(DEV)
+    dW, db = _dw_full(lambda ws: ops.call("clsr_hdw_partial", Xh, 1, K, 0, 0, None, 0, sc, sh, 1, dYh, 1, N, M, K, N, ws),
+                      M, K, N, True)
+    _close(dW, _r(torch.relu(Xh.float() * sc + sh)).t() @ dYh.double(), 1e-4, 2e-3, "dW relu(bn(X))")
+    _close(db, dYh.double().sum(0), 1e-4, 2e-3, "db (bf16 dY)")
+
+
 @pytest.mark.parametrize("Hn,G,T", [(19, 5, 10), (33, 1, 50), (7, 5, 50)])
 def test_bf16_input_variants_equal_the_fp32_kernels_on_upcast_inputs(Hn, G, T):
     """att_out_fwd / att_dy1_stats / att_z0_bwd_reduce / att_prod_bwd with bf16 tensors == the fp32 kernels fed with
