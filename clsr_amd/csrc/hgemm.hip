@@ -57,8 +57,11 @@ __device__ __forceinline__ bf16x8 to_h(f32x8 v) { return __builtin_convertvector
 #define HMFMA(acc, a, b) (acc) = __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (acc), 0, 0, 0)
 
 // LDS: W [32*NP][Kp] bf16 | ptab [5][KTP] f32 (AFF / DY1) | etab [5][32*NP] f32 (EZ*) | red [4][2][32*NP] f64 (stats)
-template <int NP, int PRO, int EPI, bool STATS, int S>
-__global__ void __launch_bounds__(256) hgemm_kernel(HGemmArgs a) {
+// KTT > 0: the number of 32-wide k-tiles is KTT and ALL of a tile's operand loads are issued before the first MFMA (a
+// wave then has every byte of its tile in flight at once: these kernels are bound by memory latency x occupancy, not
+// by the matrix pipe); KTT == 0: any K, loads one k-tile ahead
+template <int NP, int PRO, int EPI, bool STATS, int S, int KTT>
+__global__ void __launch_bounds__(256, (PRO == HP_MUL && STATS) ? 2 : 3) hgemm_kernel(HGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int NT = 2 * NP, NR = 32 * NP;
   constexpr bool XF32 = PRO == HP_MUL || PRO == HP_F32;
@@ -129,7 +132,7 @@ __global__ void __launch_bounds__(256) hgemm_kernel(HGemmArgs a) {
   }
   const float relu_lo = a.in_relu ? 0.f : -3.0e38f;
 
-  constexpr int STAT_FLUSH = 8;
+  constexpr int STAT_FLUSH = 32 / S;   // fp32 per-lane partial sums of at most 32 values between flushes
   float fsum[ST ? NP : 1][8], fsq[ST ? NP : 1][8];
   int pending = 0;
   if (ST) {
@@ -232,7 +235,9 @@ __global__ void __launch_bounds__(256) hgemm_kernel(HGemmArgs a) {
       }
     };
 
-    Raw raw = issue(0);
+    Raw rawk[KTT > 0 ? KTT : 1];
+#pragma unroll
+    for (int kt = 0; kt < (KTT > 0 ? KTT : 1); ++kt) rawk[kt] = issue(kt);
     f32x4 acc[S][NT];
     bf16x8 ezr[EZ ? S : 1][EZ ? NP : 1];
     {
@@ -259,18 +264,34 @@ __global__ void __launch_bounds__(256) hgemm_kernel(HGemmArgs a) {
         }
     }
 
-    for (int kt = 0; kt < KT; ++kt) {
-      bf16x8 b[S];
-      finish(raw, kt, b);
-      raw = issue(min(kt + 1, KT - 1));
-      __builtin_amdgcn_sched_barrier(0);
-      bf16x8 wt[NT];
+    if (KTT > 0) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) wt[t] = ld8h(ldsA + (long)(16 * t) * Kp + kt * 32);
+      for (int kt = 0; kt < (KTT > 0 ? KTT : 1); ++kt) {
+        bf16x8 b[S];
+        finish(rawk[kt], kt, b);
+        bf16x8 wt[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t) wt[t] = ld8h(ldsA + (long)(16 * t) * Kp + kt * 32);
 #pragma unroll
-        for (int s = 0; s < S; ++s) HMFMA(acc[s][t], wt[t], b[s]);
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int s = 0; s < S; ++s) HMFMA(acc[s][t], wt[t], b[s]);
+      }
+    } else {
+      Raw raw = rawk[0];
+      for (int kt = 0; kt < KT; ++kt) {
+        bf16x8 b[S];
+        finish(raw, kt, b);
+        raw = issue(min(kt + 1, KT - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 wt[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wt[t] = ld8h(ldsA + (long)(16 * t) * Kp + kt * 32);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int s = 0; s < S; ++s) HMFMA(acc[s][t], wt[t], b[s]);
+      }
     }
 
 #pragma unroll
@@ -354,11 +375,18 @@ static int hgemm_launch(const HGemmArgs& a, hipStream_t stream) {
   if (EPI == HE_EZS || EPI == HE_EZA) shmem += (size_t)5 * 32 * NP * 4;
   if (STATS || EPI == HE_EZS) shmem += (size_t)4 * 2 * 32 * NP * 8;
   CLSR_CHECK_SUPPORTED(shmem <= 160 * 1024);
-  auto kernel = hgemm_kernel<NP, PRO, EPI, STATS, HG_S>;
-  if (shmem > 64 * 1024)
-    CLSR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   dim3 grid(hgemm_grid_x(a.M), clsr_cdiv(a.N, 32 * NP));
-  hipLaunchKernelGGL(kernel, grid, dim3(256), shmem, stream, a);
+#define HG_GO(KTTV)                                                                                                   \
+  do {                                                                                                                \
+    auto kernel = hgemm_kernel<NP, PRO, EPI, STATS, HG_S, KTTV>;                                                      \
+    if (shmem > 64 * 1024)                                                                                            \
+      CLSR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));     \
+    hipLaunchKernelGGL(kernel, grid, dim3(256), shmem, stream, a);                                                    \
+  } while (0)
+  if (KT == 2) HG_GO(2);
+  else if (KT == 3) HG_GO(3);
+  else HG_GO(0);
+#undef HG_GO
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
