@@ -523,15 +523,16 @@ __device__ __forceinline__ void t4lstm_bwd_body(const T4Args& a, const int bx, f
 #pragma unroll
     for (int gb = 0; gb < 4; ++gb) buf[(gb * RNT + w) * 64 + lane] = dg[gb];
     __syncthreads();
-    f32x4 dmn = Z4;
+    f32x4 dma = Z4, dmb = Z4;   // two accumulators: two independent MFMA chains instead of one of 4 * RNT * 4 links
 #pragma unroll
     for (int kt = 0; kt < RNT; ++kt) {
       f32x4 bq[4];
 #pragma unroll
       for (int gb = 0; gb < 4; ++gb) bq[gb] = read_tile(buf + (gb * RNT + kt) * 64, lane, kt == RNT - 1 && cmp);
 #pragma unroll
-      for (int gb = 0; gb < 4; ++gb) mvt(dmn, wm[gb][kt], bq[gb], kt == RNT - 1 && cmp);
+      for (int gb = 0; gb < 4; ++gb) mvt((gb & 1) ? dmb : dma, wm[gb][kt], bq[gb], kt == RNT - 1 && cmp);
     }
+    const f32x4 dmn = dma + dmb;
     dc = sel4(live, dcn, dc);
     dm = sel4(live, dmn, dm);
   }
