@@ -191,7 +191,9 @@ __global__ void __launch_bounds__(256) pgemm_generic_kernel(PGemmArgs a) {
 #define EPI_ACC 2
 #define EPI_EZ 4
 
-template <int OT, int PRO, int EPI, bool STATS>
+//   * KTT > 0 (K = 16*KTT exactly covered): ALL k-tiles of a wave-tile are loaded before its first MFMA -- the MFMA
+//     chain of a tile then runs back to back instead of waiting for one load latency per k-tile.
+template <int OT, int PRO, int EPI, bool STATS, int KTT = 0>
 __global__ void __launch_bounds__(256) pgemm_fast_kernel(PGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -313,7 +315,10 @@ __global__ void __launch_bounds__(256) pgemm_fast_kernel(PGemmArgs a) {
       b1 = ink ? v1 : zero4;
     };
 
-    Raw raw = issue(0);
+    Raw rawk[KTT > 0 ? KTT : 1];
+#pragma unroll
+    for (int kt = 0; kt < (KTT > 0 ? KTT : 1); ++kt) rawk[kt] = issue(kt);
+    Raw raw = rawk[0];
     // accumulators start from everything that is added to the product (bias, addU + addV, previous Y):
     // these loads are in flight together with the first activation loads and need no extra registers
     f32x4 acc[2][OT];
@@ -342,11 +347,7 @@ __global__ void __launch_bounds__(256) pgemm_fast_kernel(PGemmArgs a) {
         }
     }
 
-    for (int kt = 0; kt < KT; ++kt) {
-      f32x4 b0, b1;
-      finish(raw, kt, b0, b1);
-      raw = issue(min(kt + 1, KT - 1));
-      __builtin_amdgcn_sched_barrier(0);  // keep the loads above ahead of the MFMA block
+    auto mfma_block = [&](int kt, const f32x4& b0, const f32x4& b1) {
       // all weight tiles of this k-tile first, then 2*OT independent accumulators per k-slot
       f32x4 wt[OT];
 #pragma unroll
@@ -359,6 +360,22 @@ __global__ void __launch_bounds__(256) pgemm_fast_kernel(PGemmArgs a) {
       for (int ot = 0; ot < OT; ++ot) { MFMA4(acc[0][ot], wt[ot].z, b0.z); MFMA4(acc[1][ot], wt[ot].z, b1.z); }
 #pragma unroll
       for (int ot = 0; ot < OT; ++ot) { MFMA4(acc[0][ot], wt[ot].w, b0.w); MFMA4(acc[1][ot], wt[ot].w, b1.w); }
+    };
+    if (KTT > 0) {
+#pragma unroll
+      for (int kt = 0; kt < (KTT > 0 ? KTT : 1); ++kt) {
+        f32x4 b0, b1;
+        finish(rawk[kt], kt, b0, b1);
+        mfma_block(kt, b0, b1);
+      }
+    } else {
+      for (int kt = 0; kt < KT; ++kt) {
+        f32x4 b0, b1;
+        finish(raw, kt, b0, b1);
+        raw = issue(min(kt + 1, KT - 1));
+        __builtin_amdgcn_sched_barrier(0);  // keep the loads above ahead of the MFMA block
+        mfma_block(kt, b0, b1);
+      }
     }
 
 #pragma unroll
@@ -448,9 +465,15 @@ static int launch_pgemm(const PGemmArgs& a, hipStream_t stream) {
   // (the 8-out-tile BN-backward variant would spill registers: it stays on the generic kernel)
   const bool uv_ok = (a.addU != nullptr) == (a.addV != nullptr) && !(OT == 8 && epi == EPI_EZ);
   const bool st = a.stats != nullptr;
+  const int KTn = clsr_cdiv(a.K, 16);
+  const bool upfront = !getenv("CLSR_PGEMM_STREAM");   // A/B switch: loads one k-tile ahead instead of all up front
 #define CLSR_FAST(P, E, S)                                                                          \
-  if (uv_ok && pro == (P) && epi == (E) && st == (S))                                               \
-    return launch_kernel(pgemm_fast_kernel<OT, P, E, S>, a, grid, shmem, stream);
+  if (uv_ok && pro == (P) && epi == (E) && st == (S)) {                                             \
+    /* (the X * Xmul variant holds twice the operands: with everything in flight it drops to one wave per SIMD and loses) */ \
+    if (upfront && (P) != PRO_MUL && KTn == 5) return launch_kernel(pgemm_fast_kernel<OT, P, E, S, 5>, a, grid, shmem, stream); \
+    if (upfront && (P) != PRO_MUL && KTn == 3) return launch_kernel(pgemm_fast_kernel<OT, P, E, S, 3>, a, grid, shmem, stream); \
+    return launch_kernel(pgemm_fast_kernel<OT, P, E, S>, a, grid, shmem, stream);                   \
+  }
   CLSR_FAST(PRO_PLAIN, EPI_NONE, false)
   CLSR_FAST(PRO_PLAIN, EPI_NONE, true)
   CLSR_FAST(PRO_MUL, EPI_UV, false)
