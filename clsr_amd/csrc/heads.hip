@@ -481,6 +481,71 @@ extern "C" int clsr_group_sum_cols(const float* src, int ld_src, int src_col0, i
   return CLSR_OK;
 }
 
+// ---- short-term attention query (clsr.py:219): q[r] = [A[r / G, :Da] | B[r, :Db]] and its backward
+// dA[h] += sum_g dq[(h, g), :Da],  dB[r] += dq[r, Da:]  -- one launch each instead of two strided column movers
+__global__ void __launch_bounds__(256) query_concat_kernel(const float* __restrict__ A, int lda, int G,
+                                                           const float* __restrict__ B, int ldb, int R, int Da, int Db,
+                                                           float* __restrict__ out, int ldo) {
+  const int QC = (Da + Db) >> 2, rpb = 256 / QC;
+  const int ty = threadIdx.x / QC, q = threadIdx.x - ty * QC;
+  if (ty >= rpb) return;
+  const int c = 4 * q;
+  for (int r = blockIdx.x * rpb + ty; r < R; r += gridDim.x * rpb) {
+    const f32x4 v = c < Da ? ld4(A + (long)(r / G) * lda + c) : ld4(B + (long)r * ldb + (c - Da));
+    st4(out + (long)r * ldo + c, v);
+  }
+}
+
+extern "C" int clsr_query_concat(const float* A, int lda, int G, const float* B, int ldb, long R, int Da, int Db,
+                                 float* out, int ldo, void* stream) {
+  CLSR_CHECK_ARG(A && B && out && R > 0 && G > 0 && Da > 0 && Db > 0 && ldo >= Da + Db);
+  CLSR_CHECK_SUPPORTED(Da % 4 == 0 && Db % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldo % 4 == 0 && Da + Db <= 1024 &&
+                       R < (1L << 31));
+  const int rpb = 256 / ((Da + Db) / 4);
+  int blocks = clsr_cdiv(R, rpb * 2);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(query_concat_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, A, lda, G, B, ldb, (int)R, Da,
+                     Db, out, ldo);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+__global__ void __launch_bounds__(256) query_split_bwd_kernel(const float* __restrict__ dq, int ldq, int G, int Hn, int Da,
+                                                              int Db, float* __restrict__ dA, int ldda,
+                                                              float* __restrict__ dB, int lddb) {
+  const int QC = (Da + Db) >> 2, rpb = 256 / QC;
+  const int ty = threadIdx.x / QC, q = threadIdx.x - ty * QC;
+  if (ty >= rpb) return;
+  const int c = 4 * q;
+  for (int h = blockIdx.x * rpb + ty; h < Hn; h += gridDim.x * rpb) {
+    if (c < Da) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < G; ++g) s += ld4(dq + (long)(h * G + g) * ldq + c);
+      float* d = dA + (long)h * ldda + c;
+      st4(d, ld4(d) + s);
+    } else {
+      for (int g = 0; g < G; ++g) {
+        float* d = dB + (long)(h * G + g) * lddb + (c - Da);
+        st4(d, ld4(d) + ld4(dq + (long)(h * G + g) * ldq + c));
+      }
+    }
+  }
+}
+
+extern "C" int clsr_query_split_bwd(const float* dq, int ldq, int G, long Hn, int Da, int Db, float* dA, int ldda,
+                                    float* dB, int lddb, void* stream) {
+  CLSR_CHECK_ARG(dq && dA && dB && Hn > 0 && G > 0 && Da > 0 && Db > 0 && ldq >= Da + Db);
+  CLSR_CHECK_SUPPORTED(Da % 4 == 0 && Db % 4 == 0 && ldq % 4 == 0 && ldda % 4 == 0 && lddb % 4 == 0 && Da + Db <= 1024 &&
+                       Hn * G < (1L << 31));
+  const int rpb = 256 / ((Da + Db) / 4);
+  int blocks = clsr_cdiv(Hn, rpb);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(query_split_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dq, ldq, G, (int)Hn, Da, Db,
+                     dA, ldda, dB, lddb);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
 // out[e] = sa * a[e] + sb * b[e]
 __global__ void axpby_kernel(float* __restrict__ out, const float* __restrict__ a, float sa,
                              const float* __restrict__ b, float sb, long n) {

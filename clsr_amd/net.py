@@ -1224,8 +1224,7 @@ class CLSRNet(object):
         # ---- short term attention: query = [short_term_intention | target]
         Qs = Du + D
         q = self._buf("st.q", B, Qs)
-        call("clsr_copy_cols", short_int, Du, 0, G, B, Du, q, Qs, 0, 0)
-        call("clsr_copy_cols", target, D, 0, 1, B, D, q, Qs, Du, 0)
+        call("clsr_query_concat", short_int, Du, G, target, D, B, Du, D, q, Qs)
         att_short = self._att_fwd("st", st + "attention_fcn/", rnn_out, q, Hn, G, T, H, Qs, seq_len, ls, training,
                                   q_hist=short_int)
         # ---- alpha gate
@@ -1277,8 +1276,7 @@ class CLSRNet(object):
         fl = self.tab_flags
 
         def zero_and_mark():
-            call("clsr_zero_doubles", self.losses, 8)
-            call("clsr_zero_doubles", self.sumsq_tab, 16)
+            call("clsr_zero_doubles", self.stats24, 24)      # squared norms (16) + loss terms (8): one buffer
             call("clsr_zero_floats", zpool, zpool.numel())
             # involved-row flags (tf.unique id sets)
             ops.multi("clsr_mark_rows_multi", ops.MarkDesc, [
@@ -1335,8 +1333,7 @@ class CLSRNet(object):
         Qs = Du + D
         dq = self._att_bwd("st", st + "attention_fcn/", dS, out["rnn_out"], out["q_short"], drnn, Hn, G, T, H, Qs,
                            seq_len, ls, q_hist=out["short_intention"], dq_hist=dsi)
-        call("clsr_group_sum_cols", dq, Qs, 0, G, Hn, Du, dsi, Du, 0, 1)
-        call("clsr_copy_cols", dq, Qs, Du, 1, B, D, dtarget, D, 0, 1)
+        call("clsr_query_split_bwd", dq, Qs, G, Hn, Du, D, dsi, Du, dtarget, D)
         # ---- sequence encoders: ONE fused backward-through-time launch, then the batched weight grads
         M = Hn * T
         NX = self.NX

@@ -274,6 +274,10 @@ int clsr_contrastive(const float* L, const float* S, const float* M, const float
 
 /* small movers + backward helpers of the re-associated first att_fcn layer
  *   z0[r,t,:] = U[h,t,:] + V[r,:] + (a[h,t,:]*q[r,:]).Wp   ==  [a, q, a-q, a*q].W0 + b0  (clsr.py:368-370) */
+int clsr_query_concat(const float* A, int lda, int G, const float* B, int ldb, long R, int Da, int Db,
+                      float* out, int ldo, void* stream);
+int clsr_query_split_bwd(const float* dq, int ldq, int G, long Hn, int Da, int Db, float* dA, int ldda,
+                         float* dB, int lddb, void* stream);
 int clsr_copy_cols(const float* src, int ld_src, int src_col0, int row_div, long N, int C, float* dst,
                    int ldd, int dst_col0, int accumulate, void* stream);
 int clsr_group_sum_cols(const float* src, int ld_src, int src_col0, int G, long Hn, int C, float* dst,
