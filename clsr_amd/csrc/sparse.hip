@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(1024) flags_scan_kernel(int* __restrict__ seg_
 // pass 2: ids_out[offset(w) + rank within the wave segment] = v
 __global__ void __launch_bounds__(256) flags_write_kernel(const unsigned char* __restrict__ flags, long V,
                                                           long nseg, const int* __restrict__ seg_offset,
-                                                          int cap, int* __restrict__ ids_out) {
+                                                          int cap, int* __restrict__ ids_out, int id_offset = 0) {
   const int lane = threadIdx.x & 63;
   const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
   for (long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6); w < nseg; w += (long)gridDim.x * 4) {
@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(256) flags_write_kernel(const unsigned char* _
       const bool on = v < V && flags[v] != 0;
       const unsigned long long m = __ballot(on);
       const int p = pos + __popcll(m & lt);
-      if (on && p < cap) ids_out[p] = (int)v;
+      if (on && p < cap) ids_out[p] = (int)v + id_offset;
       pos += __popcll(m);
     }
   }
@@ -376,8 +376,8 @@ extern "C" long clsr_flags_compact_workspace_bytes(long V) {
   return (long)(((V + CMP_SEG - 1) / CMP_SEG) * sizeof(int) + 256);
 }
 
-extern "C" int clsr_flags_compact(const unsigned char* flags, long V, int* ids_out, int cap, int* count_out,
-                                  void* workspace, long workspace_bytes, void* stream) {
+static int flags_compact_impl(const unsigned char* flags, long V, int* ids_out, int cap, int* count_out,
+                              void* workspace, long workspace_bytes, int id_offset, void* stream) {
   CLSR_CHECK_ARG(flags && ids_out && count_out && workspace && V > 0 && cap > 0);
   CLSR_CHECK_SUPPORTED(V < (1L << 31));
   CLSR_CHECK_ARG(workspace_bytes >= clsr_flags_compact_workspace_bytes(V));
@@ -390,7 +390,43 @@ extern "C" int clsr_flags_compact(const unsigned char* flags, long V, int* ids_o
   CLSR_CHECK_LAUNCH();
   hipLaunchKernelGGL(flags_scan_kernel, dim3(1), dim3(1024), 0, s, seg, nseg, cap, count_out);
   CLSR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(flags_write_kernel, dim3(blocks), dim3(256), 0, s, flags, V, nseg, seg, cap, ids_out);
+  hipLaunchKernelGGL(flags_write_kernel, dim3(blocks), dim3(256), 0, s, flags, V, nseg, seg, cap, ids_out, id_offset);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+extern "C" int clsr_flags_compact(const unsigned char* flags, long V, int* ids_out, int cap, int* count_out,
+                                  void* workspace, long workspace_bytes, void* stream) {
+  return flags_compact_impl(flags, V, ids_out, cap, count_out, workspace, workspace_bytes, 0, stream);
+}
+
+// the same over the slice flags[0 .. V) of a larger byte map that starts at row id_offset: ids_out holds GLOBAL row ids
+// (owner-routed exchange: every rank compacts the range of rows it owns)
+extern "C" int clsr_flags_compact_off(const unsigned char* flags, long V, int id_offset, int* ids_out, int cap,
+                                      int* count_out, void* workspace, long workspace_bytes, void* stream) {
+  CLSR_CHECK_ARG(id_offset >= 0);
+  return flags_compact_impl(flags, V, ids_out, cap, count_out, workspace, workspace_bytes, id_offset, stream);
+}
+
+// offsets[o] = number of ids (ascending list of count[0] entries) below bounds[o], o <= W: the slices of a sorted id list
+// that fall into W contiguous ownership ranges
+__global__ void range_offsets_kernel(const int* __restrict__ ids, const int* __restrict__ count,
+                                     const int* __restrict__ bounds, int W, int* __restrict__ offsets) {
+  const int o = threadIdx.x;
+  if (o > W) return;
+  const int n = count[0], b = bounds[o];
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (ids[mid] < b) lo = mid + 1; else hi = mid;
+  }
+  offsets[o] = lo;
+}
+
+extern "C" int clsr_range_offsets(const int* ids, const int* count, const int* bounds, int W, int* offsets,
+                                  void* stream) {
+  CLSR_CHECK_ARG(ids && count && bounds && offsets && W > 0 && W < 1024);
+  hipLaunchKernelGGL(range_offsets_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ids, count, bounds, W, offsets);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }

@@ -113,9 +113,12 @@ class DataParallel(object):
     statistics), makes the compute stream wait for every collective, and the identical clip + Adam update follows.
     Nets without hooks (or ``overlap=False``) run the same collectives back to back after the backward pass."""
 
-    def __init__(self, net, dist, sync_bn=True, group=None, sparse_tables="auto", overlap=True):
+    def __init__(self, net, dist, sync_bn=True, group=None, sparse_tables="auto", overlap=True, sparse_mode="allgather"):
         if sparse_tables not in ("auto", "all", "none"):
             raise ValueError("sparse_tables must be 'auto', 'all' or 'none'")
+        if sparse_mode not in ("allgather", "owner"):
+            raise ValueError("sparse_mode must be 'allgather' or 'owner'")
+        self.sparse_mode = sparse_mode
         self.net, self.dist, self.group = net, dist, group
         self.sparse_tables = sparse_tables
         self._sparse_bufs = {}
@@ -236,8 +239,86 @@ class DataParallel(object):
         ops.call("clsr_flags_compact", flags, V, b["ids"], cap, b["count"], b["ws"], b["nws"],
                  stream=torch.cuda.current_stream().cuda_stream)
 
+    def _exchange_rows_owner(self, name):
+        """Owner-routed segmented sparse reduce: every rank OWNS a contiguous range of rows
+        [V*r/W, V*(r+1)/W).  (1) the local ascending (ids, rows) list is cut at the range bounds -- contiguous
+        slices, no permutation -- and routed to the owners with one all-to-all (each pair of GPUs uses its own xGMI
+        link); (2) the owner adds the W incoming slices into its range of the dense gradient table in rank order (ids
+        are unique inside a slice: no atomics, the same fp32 sums on every run); (3) it compacts the now globally
+        marked rows of its range and (4) the reduced lists are all-gathered and written into every replica.  Rows
+        touched by several ranks (popular items) cross the fabric once per toucher on the way in and ONCE on the way
+        out, instead of world times in the all-gather exchange; with uniform ids over a 100M-row table there is
+        almost nothing to merge and the all-gather exchange moves the same bytes in one hop less.
+        Costs two host synchronisations per table and step (slice sizes must be known to size the transfers)."""
+        net, W, r, dist = self.net, self.world, self.rank, self.dist
+        grad, flags = net.tab_grad[name], net.tab_flags[name]
+        V, C = grad.shape
+        b, cap = self._cur_sparse[name]
+        dev, i32 = net.device, torch.int32
+        if self.trace is not None:
+            self.trace.append(("collective", "owner-rows:" + name))
+        s = torch.cuda.current_stream().cuda_stream
+        bounds = b.get("bounds")
+        if bounds is None:
+            bounds = b["bounds"] = torch.tensor([V * o // W for o in range(W + 1)], dtype=i32, device=dev)
+            b["offs"] = torch.zeros(W + 1, dtype=i32, device=dev)
+            b["rcnt"] = torch.zeros(W, dtype=i32, device=dev)
+            b["cnt2"], b["cnt2_all"] = torch.zeros(2, dtype=i32, device=dev), torch.zeros(W, 2, dtype=i32, device=dev)
+        lo, hi = V * r // W, V * (r + 1) // W
+        ops.call("clsr_rows_pack", grad, b["ids"], b["count"], cap, C, b["rows"], stream=s)
+        ops.call("clsr_range_offsets", b["ids"], b["count"], bounds, W, b["offs"], stream=s)
+        scnt = b["offs"][1:] - b["offs"][:-1]
+        dist.all_to_all_single(b["rcnt"], scnt.contiguous(), group=self.group)
+        offs_h, rcnt_h = b["offs"].cpu().tolist(), b["rcnt"].cpu().tolist()          # host sync 1: slice sizes
+        ins = [offs_h[o + 1] - offs_h[o] for o in range(W)]
+        n_in = sum(rcnt_h)
+        ids_in = torch.empty(max(n_in, 1), dtype=i32, device=dev)
+        rows_in = torch.empty(max(n_in, 1), C, device=dev)
+        dist.all_to_all_single(ids_in[:n_in], b["ids"][:offs_h[W]], output_split_sizes=rcnt_h, input_split_sizes=ins,
+                               group=self.group)
+        dist.all_to_all_single(rows_in[:n_in], b["rows"][:offs_h[W]], output_split_sizes=rcnt_h, input_split_sizes=ins,
+                               group=self.group)
+        # local contributions are in flight / packed: clear them, then the owner sums the W slices in rank order
+        ops.call("clsr_rows_unpack", b["ids"], None, b["count"], cap, C, 0, grad, None, stream=s)
+        o0 = 0
+        for src in range(W):
+            if rcnt_h[src]:
+                ops.call("clsr_rows_unpack", ids_in[o0:], rows_in[o0:], b["rcnt"][src:], rcnt_h[src], C, 1, grad, flags,
+                         stream=s)
+            o0 += rcnt_h[src]
+        # the owner's reduced list: every marked row of its range (its own marks + what the slices marked)
+        cap2 = max(min(hi - lo, cap * W), 1)
+        key = ("own", name, cap2)
+        ob = self._sparse_bufs.get(key)
+        if ob is None:
+            nws = ops.query("clsr_flags_compact_workspace_bytes", hi - lo)
+            ob = self._sparse_bufs[key] = dict(ws=torch.empty(nws, dtype=torch.uint8, device=dev), nws=nws,
+                                               ids=torch.zeros(cap2, dtype=i32, device=dev),
+                                               rows=torch.zeros(cap2, C, device=dev))
+        ops.call("clsr_flags_compact_off", flags[lo:hi], hi - lo, lo, ob["ids"], cap2, b["cnt2"], ob["ws"], ob["nws"],
+                 stream=s)
+        ops.call("clsr_rows_pack", grad, ob["ids"], b["cnt2"], cap2, C, ob["rows"], stream=s)
+        dist.all_gather([b["cnt2_all"][o] for o in range(W)], b["cnt2"], group=self.group)
+        cnt2_h = b["cnt2_all"][:, 0].cpu().tolist()                                     # host sync 2: reduced sizes
+        mx = max(max(cnt2_h), 1)
+        ids_all = torch.empty(W, mx, dtype=i32, device=dev)
+        rows_all = torch.empty(W, mx, C, device=dev)
+        pad_i, pad_r = ob["ids"], ob["rows"]
+        if mx > cap2:                                                                   # (a peer owns more rows)
+            pad_i, pad_r = torch.zeros(mx, dtype=i32, device=dev), torch.zeros(mx, C, device=dev)
+            pad_i[:cap2].copy_(ob["ids"])
+            pad_r[:cap2].copy_(ob["rows"])
+        dist.all_gather([ids_all[o] for o in range(W)], pad_i[:mx], group=self.group)
+        dist.all_gather([rows_all[o] for o in range(W)], pad_r[:mx], group=self.group)
+        for o in range(W):
+            if o != r and cnt2_h[o]:      # (this rank's own range already holds the sums)
+                ops.call("clsr_rows_unpack", ids_all[o], rows_all[o], b["cnt2_all"][o], cnt2_h[o], C, 1, grad, flags,
+                         stream=s)
+
     def _exchange_rows(self, name):
         """Sparse exchange of one embedding table's gradient (see the module docstring); runs on the current stream."""
+        if self.sparse_mode == "owner" and self.world > 1:
+            return self._exchange_rows_owner(name)
         net, W = self.net, self.world
         grad, flags = net.tab_grad[name], net.tab_flags[name]
         V, C = grad.shape

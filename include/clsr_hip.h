@@ -72,6 +72,9 @@ int clsr_gather_bwd_sorted(const float* dhist, const float* dmean, const float* 
 long clsr_flags_compact_workspace_bytes(long V);
 int clsr_flags_compact(const unsigned char* flags, long V, int* ids_out, int cap, int* count_out,
                        void* workspace, long workspace_bytes, void* stream);
+int clsr_flags_compact_off(const unsigned char* flags, long V, int id_offset, int* ids_out, int cap,
+                           int* count_out, void* workspace, long workspace_bytes, void* stream);
+int clsr_range_offsets(const int* ids, const int* count, const int* bounds, int W, int* offsets, void* stream);
 int clsr_rows_pack(const float* table, const int* ids, const int* count, int cap, int C, float* rows_out,
                    void* stream);
 int clsr_rows_unpack(const int* ids, const float* rows, const int* count, int cap, int C, int mode,

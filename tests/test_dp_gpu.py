@@ -45,6 +45,11 @@ class _HostStagedDist(object):
         for o, c in zip(outs, cs):
             o.copy_(c)
 
+    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None, group=None):
+        co, ci = out.detach().cpu(), inp.detach().cpu().contiguous()
+        self._d.all_to_all_single(co, ci, output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes)
+        out.copy_(co)
+
     def barrier(self):
         self._d.barrier()
 
@@ -75,7 +80,7 @@ def _init(transport, rank, world, port):
     return _HostStagedDist(dist), "cuda:0"
 
 
-def _worker(rank, world, port, hp, dims, feed, sd, sparse, out, transport="staged", overlap=True):
+def _worker(rank, world, port, hp, dims, feed, sd, sparse, out, transport="staged", overlap=True, mode="allgather"):
     import torch.distributed as dist
 
     from clsr_amd.dp import DataParallel, shard_feed
@@ -85,7 +90,7 @@ def _worker(rank, world, port, hp, dims, feed, sd, sparse, out, transport="stage
     net = CLSRNet(hp, dims, device=dev, seed=rank)  # different seeds: broadcast must fix that
     if rank == 0:
         net.load_state_dict(sd)
-    dp = DataParallel(net, d, sync_bn=True, sparse_tables=sparse, overlap=overlap)
+    dp = DataParallel(net, d, sync_bn=True, sparse_tables=sparse, overlap=overlap, sparse_mode=mode)
     net.capture_grads = True
     f = dp.prepare(net.upload(shard_feed(feed, rank, world, hp.train_num_ngs + 1), True))
     dp.train_step(f)
@@ -101,8 +106,10 @@ def _worker(rank, world, port, hp, dims, feed, sd, sparse, out, transport="stage
 
 
 @pytest.mark.parametrize("transport", _transports())
-@pytest.mark.parametrize("sparse,overlap", [("none", True), ("all", True), ("auto", True), ("none", False)])
-def test_two_ranks_match_single_process(golden_dir, golden_hparams, sparse, overlap, transport):
+@pytest.mark.parametrize("sparse,overlap,mode", [("none", True, "allgather"), ("all", True, "allgather"),
+                                                 ("auto", True, "allgather"), ("none", False, "allgather"),
+                                                 ("all", True, "owner"), ("all", False, "owner")])
+def test_two_ranks_match_single_process(golden_dir, golden_hparams, sparse, overlap, mode, transport):
     import pickle
 
     import torch.multiprocessing as mp
@@ -132,7 +139,7 @@ def test_two_ranks_match_single_process(golden_dir, golden_hparams, sparse, over
     ctx = mp.get_context("spawn")
     mgr = ctx.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, port, hp, dims, feed, sd, sparse, out, transport, overlap), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, hp, dims, feed, sd, sparse, out, transport, overlap, mode), nprocs=2, join=True)
     assert len(out["sparse"]) == {"none": 0, "all": 4}.get(sparse, len(out["sparse"]))
     for k in ("loss", "data_loss", "contrastive_loss", "regular_loss", "discrepancy_loss"):
         assert abs(out["losses"][k] - ref_losses[k]) < 1e-5 * max(1.0, abs(ref_losses[k])), (k, out["losses"], ref_losses)
