@@ -28,6 +28,7 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 #define HE_UV 1    // Y = acc + addU[xrow] + addV[r]
 #define HE_EZS 2   // dy = (ez*sc + sh > 0) ? acc : 0; column sums of dy, dy*xhat ONLY (nothing stored)
 #define HE_EZA 3   // same mask, then Y = c1*dy + c2*ez + c3 (the complete BN backward)
+#define HE_F32 4   // fp32 Y (=|+=) acc   (back-propagating products whose operands and results stay fp32 tensors)
 
 struct HGemmArgs {
   const void* X; int ldx;
@@ -43,6 +44,7 @@ struct HGemmArgs {
   const __bf16* ez; int ldez;
   const float* ev[5];      // HE_EZS: scale, shift, mean, invstd | HE_EZA: scale, shift, coef (c1|c2|c3, stride N)
   __bf16* Y; int ldy;
+  float* Yf; int accumulate;   // HE_F32
   double* stats;
   int M, K, N;
 };
@@ -241,7 +243,8 @@ __global__ void __launch_bounds__(256, (PRO == HP_MUL && STATS) ? 2 : 3) hgemm_k
     f32x4 acc[S][NT];
     bf16x8 ezr[EZ ? S : 1][EZ ? NP : 1];
     {
-      f32x8 tu[EPI == HE_UV ? S : 1][EPI == HE_UV ? NP : 1], tv[EPI == HE_UV ? S : 1][EPI == HE_UV ? NP : 1];
+      constexpr bool INIT = EPI == HE_UV || EPI == HE_F32;
+      f32x8 tu[INIT ? S : 1][INIT ? NP : 1], tv[EPI == HE_UV ? S : 1][EPI == HE_UV ? NP : 1];
 #pragma unroll
       for (int s = 0; s < S; ++s)
 #pragma unroll
@@ -249,6 +252,10 @@ __global__ void __launch_bounds__(256, (PRO == HP_MUL && STATS) ? 2 : 3) hgemm_k
           if (EPI == HE_UV) {
             tu[s][p] = ld8f(a.addU + xrow[s] * a.ldu + ncl[p]);
             tv[s][p] = ld8f(a.addV + rr[s] * a.ldv + ncl[p]);
+          }
+          if (EPI == HE_F32) {
+            tu[s][p] = (f32x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (a.accumulate) tu[s][p] = ld8f(a.Yf + (long)mrow[s] * a.ldy + ncl[p]);
           }
           if (EZ) ezr[s][p] = ld8h(a.ez + (long)mrow[s] * a.ldez + ncl[p]);
         }
@@ -259,6 +266,7 @@ __global__ void __launch_bounds__(256, (PRO == HP_MUL && STATS) ? 2 : 3) hgemm_k
         for (int p = 0; p < NP; ++p) {
           f32x8 v = biasr[p];
           if (EPI == HE_UV) v = tu[s][p] + tv[s][p];
+          if (EPI == HE_F32) v = tu[s][p];
           acc[s][2 * p] = (f32x4){v[0], v[1], v[2], v[3]};
           acc[s][2 * p + 1] = (f32x4){v[4], v[5], v[6], v[7]};
         }
@@ -278,19 +286,28 @@ __global__ void __launch_bounds__(256, (PRO == HP_MUL && STATS) ? 2 : 3) hgemm_k
           for (int s = 0; s < S; ++s) HMFMA(acc[s][t], wt[t], b[s]);
       }
     } else {
-      Raw raw = rawk[0];
-      for (int kt = 0; kt < KT; ++kt) {
-        bf16x8 b[S];
-        finish(raw, kt, b);
-        raw = issue(min(kt + 1, KT - 1));
-        __builtin_amdgcn_sched_barrier(0);
-        bf16x8 wt[NT];
+      // any K: a ring of four k-tiles in flight (slot = kt % 4, refilled right after it is consumed)
+      Raw ring[4];
+      ring[0] = rawk[0];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) wt[t] = ld8h(ldsA + (long)(16 * t) * Kp + kt * 32);
+      for (int d = 1; d < 4; ++d) ring[d] = issue(min(d, KT - 1));
+      for (int kt0 = 0; kt0 < KT; kt0 += 4) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int d = 0; d < 4; ++d) {
+          const int kt = kt0 + d;
+          if (kt < KT) {
+            bf16x8 b[S];
+            finish(ring[d], kt, b);
+            ring[d] = issue(min(kt + 4, KT - 1));
+            bf16x8 wt[NT];
 #pragma unroll
-          for (int s = 0; s < S; ++s) HMFMA(acc[s][t], wt[t], b[s]);
+            for (int t = 0; t < NT; ++t) wt[t] = ld8h(ldsA + (long)(16 * t) * Kp + kt * 32);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+              for (int s = 0; s < S; ++s) HMFMA(acc[s][t], wt[t], b[s]);
+          }
+        }
       }
     }
 
@@ -323,7 +340,13 @@ __global__ void __launch_bounds__(256, (PRO == HP_MUL && STATS) ? 2 : 3) hgemm_k
           for (int e = 0; e < 8; ++e) v[e] = ok ? v[e] : 0.f;
           w2 = v;
         }
-        if (EPI != HE_EZS && ok) {
+        if (EPI == HE_F32) {
+          if (ok) {
+            float* yp = a.Yf + (long)mrow[s] * a.ldy + ncl[p];
+            st4(yp, lo);
+            st4(yp + 4, hi);
+          }
+        } else if (EPI != HE_EZS && ok) {
           bf16x8* yp = reinterpret_cast<bf16x8*>(a.Y + (long)mrow[s] * a.ldy + ncl[p]);
           if (EPI == HE_UV) __builtin_nontemporal_store(out, yp);
           else *yp = out;
@@ -471,6 +494,22 @@ extern "C" int clsr_hgemm_att_l1_bwd(const void* z1, int ldz1, const float* ds, 
   }
   a.ev[2] = coef0; a.Y = (__bf16*)dz0; a.ldy = lddz0; a.dx_out = dz1; a.lddx = lddz1;
   return hgemm_np<HP_DY1, HE_EZA, false>(a, s);
+}
+
+// Y[m, :N] (fp32, =|+=) X[m, :K] . W with fp32 X: the back-propagating products of the history-level / row-level layers
+// in speed mode (operands rounded to bf16 in registers, fp32 accumulation and storage) -- gradients only, the forward
+// values of those layers stay on the exact fp32 kernels
+extern "C" int clsr_hgemm_f32(const float* X, int ldx, const void* Wt, int Kp, float* Y, int ldy, int accumulate,
+                              int M, int K, int N, void* stream) {
+  CLSR_CHECK_ARG(X && Wt && Y && M >= 0 && K > 0 && N > 0 && ldx >= K && ldy >= N);
+  CLSR_CHECK_SUPPORTED(K % 8 == 0 && N % 8 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && Kp % 8 == 0 &&
+                       ((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0);
+  CLSR_CHECK_ARG(Kp >= 32 * clsr_cdiv(K, 32));
+  if (M == 0) return CLSR_OK;
+  HGemmArgs a = {};
+  a.X = X; a.ldx = ldx; a.Wt = (const __bf16*)Wt; a.Kp = Kp; a.Yf = Y; a.ldy = ldy; a.accumulate = accumulate;
+  a.M = M; a.K = K; a.N = N;
+  return hgemm_np<HP_F32, HE_F32, false>(a, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------ packing

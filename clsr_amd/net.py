@@ -80,6 +80,7 @@ class CLSRNet(object):
         self.packed_h = {}         # bf16 images of the weights the speed-mode attention kernels read (csrc/hgemm.hip)
         self.bf16 = self.precision == "bf16"
         self.bf16_dw = not os.environ.get("CLSR_NO_HDW")        # A/B switch: weight gradients on the bf16 matrix pipe
+        self.bf16_bwd = not os.environ.get("CLSR_NO_HBWD")      # A/B switch: back-propagating products likewise
         self._cur_descs_h = []
         self._plans, self._plan_keep, self._cur_descs = {}, [], []
         self._sort_bytes = {}
@@ -175,7 +176,7 @@ class CLSRNet(object):
         g = lambda k: getattr(hp, k, None)
         return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook),
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
-                self.lazy, self.rnn_first, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw,
+                self.lazy, self.rnn_first, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd,
                 self.split_g2, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
@@ -431,6 +432,13 @@ class CLSRNet(object):
         self.packed[key] = (buf, Kp)
         self._cur_descs.append(ops.pack_desc(W, out_f, in_f, buf, Kp, transposed=transposed, o0=o0, i0=i0,
                                              src2=W2, s2=s2))
+        if self.bf16 and self.bf16_bwd and key.endswith("^T") and out_t % 8 == 0 and in_t % 8 == 0:
+            # speed mode: the back-propagating products run on the bf16 matrix pipe too (csrc/hgemm.hip: clsr_hgemm_f32)
+            hKp = query("clsr_hgemm_kp", in_t)
+            hbuf = self._buf("packh:" + key, 32 * ((out_t + 31) // 32) * hKp, dtype=torch.bfloat16)
+            self.packed_h[key] = (hbuf, hKp)
+            self._cur_descs_h.append(ops.pack_desc(W, out_f, in_f, hbuf, hKp, transposed=transposed, o0=o0, i0=i0,
+                                                   src2=W2, s2=s2))
 
     def _pack_h(self, key, W, out_f, in_f, transposed=False):
         """bf16 image of one weight block for the speed-mode kernels (row-permuted pairs of MFMA tiles, row stride
@@ -448,6 +456,11 @@ class CLSRNet(object):
 
     def _gemm(self, X, ldx, wkey, M, K, N, Y, ldy, bias=None, T=0, G=0, Xmul=None, ldmul=0, aff=None,
               addU=None, ldu=0, addV=None, ldv=0, acc=0, stats=None):
+        if (self.bf16 and wkey in self.packed_h and wkey.endswith("^T") and bias is None and Xmul is None and aff is None
+                and addU is None and addV is None and stats is None and T == 0 and K % 8 == 0 and N % 8 == 0):
+            Wt, Kp = self.packed_h[wkey]
+            call("clsr_hgemm_f32", X, ldx, Wt, Kp, Y, ldy, acc, M, K, N)
+            return
         Wt, Kp = self.packed[wkey]
         sc, sh = (aff.scale, aff.shift) if aff is not None else (None, None)
         call("clsr_pgemm", X, ldx, T, G, Xmul, ldmul, sc, sh, 1, Wt, Kp, bias, addU, ldu, addV, ldv, Y, ldy,

@@ -112,6 +112,8 @@ int clsr_hgemm_mul_uv(const float* X, int ldx, int T, int G, const float* Xmul, 
 int clsr_hgemm(const void* X, int ldx, const float* in_scale, const float* in_shift, int in_relu,
                const void* Wt, int Kp, const float* bias, void* Y, int ldy, double* stats, int M, int K,
                int N, void* stream);
+int clsr_hgemm_f32(const float* X, int ldx, const void* Wt, int Kp, float* Y, int ldy, int accumulate,
+                   int M, int K, int N, void* stream);
 int clsr_hgemm_att_l1_bwd(const void* z1, int ldz1, const float* ds, const float* scale1,
                           const float* shift1, const float* w_out, const float* coef1, const void* Wt,
                           int Kp, const void* z0, int ldz0, const float* scale0, const float* shift0,

@@ -98,6 +98,23 @@ def test_hgemm_affine_relu_prologue(M, K, N, aff):
     _close(sq, (Y.double() ** 2).sum(0), 1e-5, 1e-3, "sums of squares")
 
 
+@pytest.mark.parametrize("M,K,N,ldx,acc", [(3000, 480, 40, 480, 1), (777, 120, 80, 480, 0), (1000, 80, 80, 80, 1),
+                                           (130, 264, 136, 264, 0), (50, 40, 40, 40, 1)])
+def test_hgemm_fp32_in_out_backward_product(M, K, N, ldx, acc):
+    """clsr_hgemm_f32: fp32 X (a column slice of a wider matrix), fp32 Y (=|+=), bf16 MFMA; any K (ring of k-tiles)."""
+    g = torch.Generator().manual_seed(M + K)
+    Xw = torch.randn(M, ldx, generator=g).to(DEV)
+    X = Xw[:, :K] if ldx == K else Xw[:, 8:8 + K]
+    W = (torch.randn(K, N, generator=g) * 0.2).to(DEV)
+    Wt, Kp, keep = _pack_h(W, N, K)
+    Y0 = torch.randn(M, N, generator=g).to(DEV)
+    Y = Y0.clone()
+    ops.call("clsr_hgemm_f32", X, ldx, Wt, Kp, Y, N, acc, M, K, N)
+    torch.cuda.synchronize()
+    exp = _r(X) @ _r(W) + (Y0.double() if acc else 0.0)
+    _close(Y, exp, 1e-4, 2e-3, "Y")
+
+
 @pytest.mark.parametrize("M,C1,C0", [(2000, 40, 80), (515, 40, 80), (300, 80, 136)])
 def test_hgemm_attention_layer1_backward(M, C1, C0):
     """dz1 recomputed from (z1, ds) -> dh0 = dz1 . W1^T -> ReLU / batch-norm backward of layer 0: the statistics
@@ -333,7 +350,7 @@ def test_bf16_train_step_against_oracle_and_fp32_mode(golden_dir, golden_hparams
         if float(raw[name].abs().max()) < floor:
             # analytically zero gradient (a bias under a batch-norm): the bf16 mode returns the sum of ~1e3..1e6 rounded
             # terms that cancel -- noise of a few 1e-4 of the step's largest gradient; held to 2e-3 of that scale
-            scale = 100.0 * floor     # 2e-2 * scale == 2e-3 of the largest dense gradient
+            scale = 100.0 * floor     # 3e-2 * scale == 3e-3 of the largest dense gradient
         rows.append((float((g_ - raw_e[name]).abs().max()) / scale, float((raw[name] - raw_e[name]).abs().max()) / scale,
                      name))
     rows.sort(reverse=True)
@@ -342,7 +359,9 @@ def test_bf16_train_step_against_oracle_and_fp32_mode(golden_dir, golden_hparams
               "oracles (fractions of the variable's largest gradient)" % (cfg, dedup))
         for e, gap, name in rows[:6]:
             print("   %.2e | %.2e  %s" % (e, gap, name))
-    bad = [(e, n) for e, _, n in rows if e > 2e-2]
+    # 3e-2: the noise-sensitive variables (large 'gap' column: sums of cancelling terms such as the GRU candidate bias)
+    # sit at 1.5-2.2e-2 once weight gradients and back-propagating products run on the bf16 matrix pipe as well
+    bad = [(e, n) for e, _, n in rows if e > 3e-2]
     assert not bad, bad
     sd = net.state_dict()
     for k, v in new_bn_e.items():
