@@ -29,7 +29,7 @@ Extra objects on the line:
 
 Other workloads: --config kuaishou (configs[2]) | catalogue100m (configs[4], lazy Adam).
 Experiment switches (environment): CLSR_FORCE_DP=1 (DP code path with one rank), CLSR_SPARSE_TABLES=auto|all|none,
-CLSR_DP_GRAPH=1, CLSR_NO_OVERLAP=1 (no side stream), CLSR_DW_EAGER=1 (no batched dW reduction).
+CLSR_SPARSE_MODE=allgather|owner, CLSR_DP_GRAPH=1, CLSR_NO_OVERLAP=1 (no side stream), CLSR_DW_EAGER=1 (no batched dW reduction).
 """
 import argparse
 import json
@@ -132,7 +132,7 @@ def cpu_baseline(cfg, seconds=25.0, P=None, warmup=1, steps=None):
                        "out of the T loop)%s; the reference's TF-1.15 CPU path cannot run here"
                        % (warmup, n, P, cfg["T"], cores,
                           "" if full else "; bounded sample (task contract: 10-30 s of CPU work) instead of the 5 + 20 "
-                                          "steps of BASELINE.md section 2, which take ~10 min: --cpu-warmup 5 --cpu-steps 20"))
+                                          "steps of BASELINE.md section 2, which take ~15 min: --cpu-warmup 5 --cpu-steps 20"))
 
 
 class Workload(object):
@@ -340,7 +340,8 @@ def main():
     if dist is not None:
         from clsr_amd.dp import DataParallel
 
-        wl.stepper = DataParallel(net, dist, sync_bn=sync_bn, sparse_tables=os.environ.get("CLSR_SPARSE_TABLES", "auto"))
+        wl.stepper = DataParallel(net, dist, sync_bn=sync_bn, sparse_tables=os.environ.get("CLSR_SPARSE_TABLES", "auto"),
+                                  sparse_mode=os.environ.get("CLSR_SPARSE_MODE", "allgather"))
         wl.stepper.prepare(f)
 
     stream = torch.cuda.Stream()
@@ -408,7 +409,7 @@ def main():
             w3.free()
             # ---- BASELINE configs[2]
             w4 = Workload("kuaishou", "clsr", args.precision)
-            d4 = w4.run(10, 2)
+            d4 = w4.run(10, 5)
             extra.append(dict(workload=w4.describe(), ms_per_step=round(d4 * 100.0, 4),
                               interactions_per_s=round(w4.P * 10 / d4, 1), steps=10))
             log("kuaishou: %.3f ms/step" % (d4 * 100.0))
