@@ -15,9 +15,7 @@
 #include "common.h"
 #include "clsr_hip.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x8 __attribute__((ext_vector_type(8)));
+#include "hmma.h"
 
 #define HP_BF 0    // X bf16, no prologue
 #define HP_MUL 1   // X fp32 * Xmul[r] fp32
@@ -48,15 +46,6 @@ struct HGemmArgs {
   double* stats;
   int M, K, N;
 };
-
-__device__ __forceinline__ f32x8 ld8f(const float* p) {
-  const f32x4 a = ld4(p), b = ld4(p + 4);
-  return (f32x8){a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-}
-__device__ __forceinline__ bf16x8 ld8h(const __bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
-__device__ __forceinline__ f32x8 to_f(bf16x8 v) { return __builtin_convertvector(v, f32x8); }
-__device__ __forceinline__ bf16x8 to_h(f32x8 v) { return __builtin_convertvector(v, bf16x8); }
-#define HMFMA(acc, a, b) (acc) = __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (acc), 0, 0, 0)
 
 // LDS: W [32*NP][Kp] bf16 | ptab [5][KTP] f32 (AFF / DY1) | etab [5][32*NP] f32 (EZ*) | red [4][2][32*NP] f64 (stats)
 // KTT > 0: the number of 32-wide k-tiles is KTT and ALL of a tile's operand loads are issued before the first MFMA (a

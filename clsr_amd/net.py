@@ -97,6 +97,8 @@ class CLSRNet(object):
         self.split_g2 = not os.environ.get("CLSR_NO_SPLIT_G2")             # A/B switch (causal GRU off the main launch)
         self._step_plans = {}
         self.dw_streams = int(os.environ.get("CLSR_DW_STREAMS", "1"))
+        self.fused_l0_bwd = not os.environ.get("CLSR_NO_FUSED_L0_BWD")   # A/B switch (speed mode, see _att_bwd)
+        self.fused_l0_wu = not os.environ.get("CLSR_NO_FUSED_L0_WU")   # A/B: dU . Wu^T inside that kernel as well (time-neutral, two launches fewer)
         self._joins = []
         self._dw_pending, self._dw_tables, self._dw_after, self._rp_pending = {}, {}, {}, {}
         self.defer_dw = True       # one batched reduction of the weight-gradient partials per stream and step
@@ -176,7 +178,7 @@ class CLSRNet(object):
         g = lambda k: getattr(hp, k, None)
         return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook),
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
-                self.lazy, self.rnn_first, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd,
+                self.lazy, self.rnn_first, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu,
                 self.split_g2, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
@@ -982,12 +984,20 @@ class CLSRNet(object):
             self._dw(z0, A0, dz1, A1, M, A0, A1, Gd[nn + "w_nn_layer1"], A1, db=Gd[nn + "b_nn_layer1"], aff=bn0,
                      x_bf16=1, dy_bf16=1)
             self._dw(a, Q, dz0, A0, M, Q, A0, dW0[3 * Q:4 * Q], A0, T=T, G=G, Xmul=q, ldmul=Q, dy_bf16=1)
-            daq = self._buf(key + ".daq", M, Q, dtype=BF)
             Wt, Kp = self.packed_h[key + ".Wp^T"]
-            call("clsr_hgemm", dz0, A0, None, None, 0, Wt, Kp, None, daq, Q, None, M, A0, Q)
-            call("clsr_att_prod_bwd_h", daq, Q, a, Q, q, Q, Hn, G, T, Q, da, Q, dq, Q, 0)
             dU = self._buf(key + ".dU", Hn * T, A0)
-            call("clsr_att_z0_bwd_reduce_h", dz0, Hn, G, T, A0, dU, dV)
+            if self.fused_l0_bwd and query("clsr_att_l0_bwd_h_supported", G, Q, A0):
+                # da, dq, dU, dV in one pass over dz0; daq = dz0 . Wp^T is never written (csrc/hattbwd.hip)
+                Wu, Kpu = self.packed_h[key + ".Wu^T"] if (self.bf16_bwd and self.fused_l0_wu) else (None, Kp)
+                assert Kpu == Kp
+                call("clsr_att_l0_bwd_h", dz0, A0, Wt, Wu, Kp, a, Q, q, Q, Hn, G, T, Q, A0, da, Q, dq, Q, dU, A0, dV, A0)
+                return self._att_bwd_hist(key, scope, nn, a, q, keys, dkeys, dU, dV, da, dq, dW0, Hn, R, T, Dk, Q, 0,
+                                          da_has_u=Wu is not None)
+            else:
+                daq = self._buf(key + ".daq", M, Q, dtype=BF)
+                call("clsr_hgemm", dz0, A0, None, None, 0, Wt, Kp, None, daq, Q, None, M, A0, Q)
+                call("clsr_att_prod_bwd_h", daq, Q, a, Q, q, Q, Hn, G, T, Q, da, Q, dq, Q, 0)
+                call("clsr_att_z0_bwd_reduce_h", dz0, Hn, G, T, A0, dU, dV)
             return self._att_bwd_hist(key, scope, nn, a, q, keys, dkeys, dU, dV, da, dq, dW0, Hn, R, T, Dk, Q, 0)
         call("clsr_att_dy1_apply", z1, ds, bn1.scale, bn1.shift, P[nn + "w_nn_output"], bn1.coef, R * T, A1, dz1)
         # layer 1: z1 = relu(bn0(z0)) . W1 + b1
@@ -1013,18 +1023,21 @@ class CLSRNet(object):
             call("clsr_att_prod_bwd_ld", daq1, qh, a, Q, q_hist, qh, Hn, 1, T, qh, da, Q, dq_hist, qh, 1)
         else:
             self._dw(a, Q, dz0, A0, R * T, Q, A0, dW0[3 * Q:4 * Q], A0, T=T, G=G, Xmul=q, ldmul=Q)
-            daq = self._buf(key + ".daq", R * T, Q)
-            self._gemm(dz0, A0, key + ".Wp^T", R * T, A0, Q, daq, Q)
-            call("clsr_att_prod_bwd", daq, a, q, Hn, G, T, Q, da, dq)
-            if G == 1:
-                dU = dz0
-                call("clsr_att_z0_bwd_reduce", dz0, Hn, G, T, A0, None, dV)
+            dU = dz0 if G == 1 else self._buf(key + ".dU", Hn * T, A0)
+            if self.fused_l0_bwd and query("clsr_att_l0_bwd_supported", G, Q, A0):
+                # da, dq, dU, dV in one pass over dz0 on the fp32 matrix pipe; daq = dz0 . Wp^T is never written
+                Wt, Kp = self.packed[key + ".Wp^T"]
+                call("clsr_att_l0_bwd", dz0, A0, Wt, Kp, a, Q, q, Q, Hn, G, T, Q, A0, da, Q, dq, Q,
+                     None if G == 1 else dU, A0, dV, A0)
             else:
-                dU = self._buf(key + ".dU", Hn * T, A0)
-                call("clsr_att_z0_bwd_reduce", dz0, Hn, G, T, A0, dU, dV)
+                daq = self._buf(key + ".daq", R * T, Q)
+                self._gemm(dz0, A0, key + ".Wp^T", R * T, A0, Q, daq, Q)
+                call("clsr_att_prod_bwd", daq, a, q, Hn, G, T, Q, da, dq)
+                call("clsr_att_z0_bwd_reduce", dz0, Hn, G, T, A0, None if G == 1 else dU, dV)
         return self._att_bwd_hist(key, scope, nn, a, q, keys, dkeys, dU, dV, da, dq, dW0, Hn, R, T, Dk, Q, qh)
 
-    def _att_bwd_hist(self, key, scope, nn, a, q, keys, dkeys, dU, dV, da, dq, dW0, Hn, R, T, Dk, Q, qh):
+    def _att_bwd_hist(self, key, scope, nn, a, q, keys, dkeys, dU, dV, da, dq, dW0, Hn, R, T, Dk, Q, qh,
+                      da_has_u=False):
         """History-level / row-level tail of the attention backward (fp32 in both precision modes): gradients of
         the U / V projections, of the attention matrix, and d keys."""
         Gd, A0 = self.Gd, self.A0
@@ -1033,7 +1046,8 @@ class CLSRNet(object):
         # d(W0d) = d(W0a+W0d) - d(W0q-W0d) block: needs the two reduced gradients above (runs at the flush)
         self._dw_after.setdefault(self._ws_tag, []).append(
             lambda: call("clsr_axpby", dW0[2 * Q:3 * Q], dW0[0:Q], 1.0, dW0[Q:2 * Q], -1.0, Q * A0))
-        self._gemm(dU, A0, key + ".Wu^T", Hn * T, A0, Q, da, Q, acc=1)
+        if not da_has_u:      # (speed mode: clsr_att_l0_bwd_h has already added dU . Wu^T)
+            self._gemm(dU, A0, key + ".Wu^T", Hn * T, A0, Q, da, Q, acc=1)
         if not qh:
             self._gemm(dV, A0, key + ".Wv^T", R, A0, Q, dq, Q, acc=1)
         self._dw(keys, Dk, da, Q, Hn * T, Dk, Q, Gd[scope + "attention_mat"], Q)

@@ -139,6 +139,22 @@ int clsr_att_z0_bwd_reduce_h(const void* dz0, long Hn, int G, int T, int C, floa
 int clsr_att_prod_bwd_h(const void* daq, int ldd, const float* a, int lda, const float* q, int ldq,
                         long Hn, int G, int T, int Q, float* da, int ldda, float* dq, int lddq,
                         int accumulate_dq, void* stream);
+/* All four reductions of the re-associated first attention layer's backward in ONE pass over dz0 (bf16 [R*T, A0]; csrc/hattbwd.hip):
+ *   da[h,t,:] = sum_g (dz0[(h,g),t,:] . Wp^T) * q[(h,g),:]     dq[r,:] = sum_t (dz0[r,t,:] . Wp^T) * a[h,t,:]
+ *   dU[h,t,:] = sum_g dz0[(h,g),t,:]                           dV[r,:] = sum_t dz0[r,t,:]
+ * (reference clsr.py:368-370 under tf.gradients).  Wt = packed bf16 image of Wp^T (clsr_pack_batch_bf16: Q rows, K = A0);
+ * Wu (optional) = packed image of Wu^T, same shape and row stride: da additionally receives dU . Wu^T.
+ * Replaces clsr_hgemm (daq) + clsr_att_prod_bwd_h + clsr_att_z0_bwd_reduce_h where clsr_att_l0_bwd_h_supported(G, Q, A0). */
+int clsr_att_l0_bwd_h_supported(int G, int Q, int A0);
+int clsr_att_l0_bwd_h(const void* dz0, int lddz, const void* Wt, const void* Wu, int Kp, const float* a, int lda,
+                      const float* q, int ldq, long Hn, int G, int T, int Q, int A0, float* da, int ldda,
+                      float* dq, int lddq, float* dU, int lddu, float* dV, int lddv, void* stream);
+/* The same four reductions in exact mode: dz0 and the packed Wp^T (clsr_pack_batch layout) fp32, fp32 matrix pipe; dU may
+ * be NULL (G == 1: dU is dz0).  Replaces clsr_pgemm (daq) + clsr_att_prod_bwd + clsr_att_z0_bwd_reduce. */
+int clsr_att_l0_bwd_supported(int G, int Q, int A0);
+int clsr_att_l0_bwd(const float* dz0, int lddz, const float* Wt, int Kp, const float* a, int lda,
+                    const float* q, int ldq, long Hn, int G, int T, int Q, int A0, float* da, int ldda,
+                    float* dq, int lddq, float* dU, int lddu, float* dV, int lddv, void* stream);
 int clsr_cvt_f32_to_bf16(const float* src, void* dst, long n, void* stream);
 int clsr_cvt_bf16_to_f32(const void* src, float* dst, long n, void* stream);
 int clsr_pgemm_stats_parts(int M);

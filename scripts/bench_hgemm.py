@@ -75,10 +75,13 @@ def main():
             print("%-62s %7.1f us  %.2f TB/s" % (name, t, mb / t))
         da, dq = torch.zeros(Hn * T, Q, device=dev), torch.zeros(R, Q, device=dev)
         t = timeit(lambda: call("clsr_att_prod_bwd_h", daq, Q, a, Q, q, Q, Hn, G, T, Q, da, Q, dq, Q, 0))
-        print("%-62s %7.1f us  %.2f TB/s" % ("att_prod_bwd (daq -> da, dq)   R 164 + 65", 229 / t * t, 229 / t))
+        print("%-62s %7.1f us  %.2f TB/s" % ("att_prod_bwd (daq -> da, dq)   R 164 + 65", t, 229 / t))
         dU, dV = torch.zeros(Hn * T, A0, device=dev), torch.zeros(R, A0, device=dev)
         t = timeit(lambda: call("clsr_att_z0_bwd_reduce_h", dz0, Hn, G, T, A0, dU, dV))
         print("%-62s %7.1f us  %.2f TB/s" % ("att_z0_bwd_reduce (dz0 -> dU, dV)  R 164, W 65", t, 229 / t))
+        t = timeit(lambda: call("clsr_att_l0_bwd_h", dz0, A0, WpT_h, WpT_h, KpT, a, Q, q, Q, Hn, G, T, Q, A0, da, Q, dq, Q, dU, A0, dV,
+                                A0))
+        print("%-62s %7.1f us  %.2f TB/s" % ("att_l0_bwd (dz0 -> da (+dU.Wu^T), dq, dU, dV)  R 164+65, W 131", t, 360 / t))
         wts, out = torch.zeros(R, T, device=dev), torch.zeros(R, 40, device=dev)
         keys = torch.randn(Hn, T, 40, device=dev)
         ln = torch.full((Hn,), T, dtype=torch.int32, device=dev)

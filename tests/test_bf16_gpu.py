@@ -157,6 +157,53 @@ def test_hgemm_attention_layer1_backward(M, C1, C0):
     _close(dz0, c1 * dy0 + c2 * z0.double() + c3, 2.0 ** -8, 2e-3, "dz0")
 
 
+@pytest.mark.parametrize("Hn,G,T,Q,A0", [(37, 5, 50, 80, 80), (64, 1, 50, 40, 80), (9, 8, 7, 96, 96), (6, 3, 17, 24, 40),
+                                         (1, 5, 1, 80, 80), (130, 2, 33, 48, 88)])
+def test_fused_layer0_backward_reductions(Hn, G, T, Q, A0):
+    """clsr_att_l0_bwd_h: da, dq, dU, dV from ONE pass over dz0 (bf16); daq = dz0 . Wp^T never stored.  Against float64 on
+    the bf16-rounded operands, and against the three-kernel path it replaces (which rounds daq to bf16)."""
+    assert ops.query("clsr_att_l0_bwd_h_supported", G, Q, A0) == 1
+    assert ops.query("clsr_att_l0_bwd_h_supported", 9, Q, A0) == 0 and ops.query("clsr_att_l0_bwd_h_supported", G, 128, A0) == 0
+    g = torch.Generator().manual_seed(Hn * 7 + T)
+    R, M = Hn * G, Hn * G * T
+    dz0 = (torch.randn(M, A0, generator=g) * 0.5).to(DEV).to(BF)
+    Wp = (torch.randn(Q, A0, generator=g) * 0.2).to(DEV)
+    a = torch.randn(Hn * T, Q, generator=g).to(DEV)
+    q = torch.randn(R, Q, generator=g).to(DEV)
+    Wt, Kp, keep = _pack_h(Wp, Q, A0, transposed=True)
+    Wu = (torch.randn(Q, A0, generator=g) * 0.2).to(DEV)
+    Wut, Kpu, keep_u = _pack_h(Wu, Q, A0, transposed=True)
+    assert Kpu == Kp
+    da = torch.full((Hn * T, Q), 7.0, device=DEV)
+    dq = torch.full((R, Q), 7.0, device=DEV)
+    dU = torch.full((Hn * T, A0), 7.0, device=DEV)
+    dV = torch.full((R, A0), 7.0, device=DEV)
+    ops.call("clsr_att_l0_bwd_h", dz0, A0, Wt, None, Kp, a, Q, q, Q, Hn, G, T, Q, A0, da, Q, dq, Q, dU, A0, dV, A0)
+    da_u = torch.full((Hn * T, Q), 7.0, device=DEV)       # the same with the U-path share added: da += dU . Wu^T
+    ops.call("clsr_att_l0_bwd_h", dz0, A0, Wt, Wut, Kp, a, Q, q, Q, Hn, G, T, Q, A0, da_u, Q, dq, Q, dU, A0, dV, A0)
+    torch.cuda.synchronize()
+    d = dz0.double().view(Hn, G, T, A0)
+    _close(da_u, da.double().view(Hn, T, Q) + d.sum(1) @ _r(Wu).t(), 1e-4, 2e-4, "da + dU.Wu^T")
+    daq = d @ _r(Wp).t()                                              # [Hn, G, T, Q]
+    a4, q4 = a.double().view(Hn, 1, T, Q), q.double().view(Hn, G, 1, Q)
+    _close(da, (daq * q4).sum(1), 1e-4, 1e-4, "da")
+    _close(dq, (daq * a4).sum(2), 1e-4, 2e-4, "dq")
+    _close(dU, d.sum(1), 1e-5, 1e-5, "dU")
+    _close(dV, d.sum(2), 1e-5, 1e-5, "dV")
+    # the path it replaces
+    daq_h = torch.zeros(M, Q, dtype=BF, device=DEV)
+    ops.call("clsr_hgemm", dz0, A0, None, None, 0, Wt, Kp, None, daq_h, Q, None, M, A0, Q)
+    da2, dq2 = torch.zeros_like(da), torch.zeros_like(dq)
+    dU2, dV2 = torch.zeros_like(dU), torch.zeros_like(dV)
+    ops.call("clsr_att_prod_bwd_h", daq_h, Q, a, Q, q, Q, Hn, G, T, Q, da2, Q, dq2, Q, 0)
+    ops.call("clsr_att_z0_bwd_reduce_h", dz0, Hn, G, T, A0, dU2, dV2)
+    torch.cuda.synchronize()
+    _close(da, da2, 2e-2, 2e-2 * float(da2.abs().max()), "da vs three-kernel path")
+    _close(dq, dq2, 2e-2, 2e-2 * float(dq2.abs().max()), "dq vs three-kernel path")
+    _close(dU, dU2, 1e-5, 1e-5, "dU vs three-kernel path")
+    _close(dV, dV2, 1e-5, 1e-5, "dV vs three-kernel path")
+
+
 def _dw_full(partial_call, M, K, N, with_bias):
     """run a deferred weight-gradient launch + the batched reduction; returns (dW, db)"""
     ws = torch.zeros(ops.query("clsr_pgemm_dw_workspace_floats", M, K, N), device=DEV)

@@ -897,3 +897,46 @@ def test_weights_softmax_bwd_row_scaling_and_products():
     call("clsr_mul_rows", dev(a, f32), D, dev(b, f32), D, G, R, D, wide[:, D:], 3 * D)
     close(wide[:, D:2 * D], a * b.repeat_interleave(G, 0), name="row products")
     assert float((wide[:, :D] - 9.0).abs().max()) == 0 and float((wide[:, 2 * D:] - 9.0).abs().max()) == 0
+
+
+@pytest.mark.parametrize("Hn,G,T,Q,A0", [(37, 5, 50, 80, 80), (64, 1, 50, 40, 80), (9, 8, 7, 44, 36), (6, 3, 17, 24, 40),
+                                         (1, 5, 1, 80, 80), (130, 2, 33, 48, 80)])
+def test_fused_layer0_backward_reductions_fp32(Hn, G, T, Q, A0):
+    """clsr_att_l0_bwd: da, dq, dU, dV of the re-associated first attention layer from one pass over dz0 on the fp32
+    matrix pipe (daq = dz0 . Wp^T never stored) == float64, and == the three kernels it replaces."""
+    assert query("clsr_att_l0_bwd_supported", G, Q, A0) == 1
+    assert query("clsr_att_l0_bwd_supported", 9, Q, A0) == 0 and query("clsr_att_l0_bwd_supported", G, 96, A0) == 0
+    g = torch.Generator().manual_seed(Hn * 7 + T)
+    R, M = Hn * G, Hn * G * T
+    dz0, Wp = rnd(g, M, A0, scale=0.5), rnd(g, Q, A0, scale=0.2)       # Wp: [Q, A0] block of the layer-0 weights
+    a, q = rnd(g, Hn * T, Q), rnd(g, R, Q)
+    Wt, Kp = ops.pack_weight(dev(Wp, torch.float32), Q, A0, transposed=True)   # rows = out features of dz0 . Wp^T
+    f = lambda t: dev(t, torch.float32)
+    da, dq = torch.full((Hn * T, Q), 7.0, device="cuda"), torch.full((R, Q), 7.0, device="cuda")
+    dU, dV = torch.full((Hn * T, A0), 7.0, device="cuda"), torch.full((R, A0), 7.0, device="cuda")
+    ddz0, da_, dq_ = f(dz0), f(a), f(q)
+    call("clsr_att_l0_bwd", ddz0, A0, Wt, Kp, da_, Q, dq_, Q, Hn, G, T, Q, A0, da, Q, dq, Q, dU, A0, dV, A0)
+    torch.cuda.synchronize()
+    d = dz0.double().view(Hn, G, T, A0)
+    daq = d @ Wp.double().t()
+    a4, q4 = a.double().view(Hn, 1, T, Q), q.double().view(Hn, G, 1, Q)
+    close(da, (daq * q4).sum(1).reshape(Hn * T, Q), rtol=1e-5, atol=2e-5, name="da")
+    close(dq, (daq * a4).sum(2).reshape(R, Q), rtol=1e-5, atol=1e-4, name="dq")
+    close(dU, d.sum(1).reshape(Hn * T, A0), rtol=1e-5, atol=1e-5, name="dU")
+    close(dV, d.sum(2).reshape(R, A0), rtol=1e-5, atol=2e-5, name="dV")
+    # dU = NULL (G == 1 callers alias dU with dz0): nothing else changes
+    da2, dq2, dV2 = torch.zeros_like(da), torch.zeros_like(dq), torch.zeros_like(dV)
+    call("clsr_att_l0_bwd", ddz0, A0, Wt, Kp, da_, Q, dq_, Q, Hn, G, T, Q, A0, da2, Q, dq2, Q, None, 0, dV2, A0)
+    torch.cuda.synchronize()
+    assert torch.equal(da2, da) and torch.equal(dq2, dq) and torch.equal(dV2, dV)
+    # the path it replaces
+    daq_d = torch.zeros(M, Q, device="cuda")
+    call("clsr_pgemm", ddz0, A0, 0, 0, None, 0, None, None, 0, Wt, Kp, None, None, 0, None, 0, daq_d, Q, 0, None, M, A0, Q)
+    da3, dq3, dU3, dV3 = torch.zeros_like(da), torch.zeros_like(dq), torch.zeros_like(dU), torch.zeros_like(dV)
+    call("clsr_att_prod_bwd", daq_d, da_, dq_, Hn, G, T, Q, da3, dq3)
+    call("clsr_att_z0_bwd_reduce", ddz0, Hn, G, T, A0, dU3, dV3)
+    torch.cuda.synchronize()
+    close(da, da3, rtol=1e-5, atol=2e-5, name="da vs three kernels")
+    close(dq, dq3, rtol=1e-5, atol=1e-4, name="dq vs three kernels")
+    close(dU, dU3, rtol=1e-6, atol=1e-6, name="dU vs three kernels")
+    close(dV, dV3, rtol=1e-5, atol=2e-5, name="dV vs three kernels")
