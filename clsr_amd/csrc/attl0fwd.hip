@@ -1,0 +1,262 @@
+// Re-associated first attention layer, exact (fp32) mode, one WAVE per history (gfx950):
+//   z0[r,t,:] = U[h,t,:] + V[r,:] + (a[h,t,:] * q[r,:]) . Wp      + per-feature sum / sum of squares for the batch-norm
+// (reference clsr.py:368-370 + base_model.py:664-673).  Same results as clsr_pgemm with the Xmul prologue and the
+// addU/addV epilogue; a different mapping onto the machine:
+//  * the MFMA operands are swapped (A = the (a*q) tile, rows = positions; B = weights), so a lane of the result
+//    D[16 positions][16 features] holds FOUR POSITIONS of ONE feature: the batch-norm column sums are plain per-lane
+//    accumulators (no cross-lane work per tile), U is added from registers, V[r, feature] is one LDS scalar;
+//  * the wave walks the 16-step tiles of ITS history and, inside a tile, the G rows of the group: a[h,t,:] and
+//    U[h,t,:] are loaded once per tile and re-used for the G rows (the position-tiled kernel re-reads them per row),
+//    q[r,:] and V[r,:] sit in LDS, and the only global memory instructions between two MFMA blocks are the stores;
+//  * v_mfma_f32_16x16x4_f32: MFMA #r of the 16-wide k-chunk kk uses feature 16kk + 4g + r, the A operand of a chunk is
+//    the float4 (a * q) of the lane's position, the B operand one ds_read_b128 of the packed weights.
+// ~1 VALU instruction per MFMA (3.3 in pgemm_fast_kernel).
+#include "common.h"
+#include "clsr_hip.h"
+
+#define AF_GMAX 8
+
+struct AttL0FwdArgs {
+  const float* a; int lda;      // [Hn*T, Q]
+  const float* q; int ldq;      // [R, Q]
+  const float* Wt; int Kp;      // packed Wp (clsr_pack_batch): row n = out feature, K = Q
+  const float* U; int ldu;      // [Hn*T, A0]
+  const float* V; int ldv;      // [R, A0]
+  float* z0; int ldz;           // [R*T, A0]
+  double* stats;                // [gridDim.x][2][A0] per-block partial sums, or NULL
+  long Hn;
+  int G, T, Q, A0;
+};
+
+// NZ = 16-feature tiles of A0 (outputs), NK = 16-wide chunks of Q (reduction)
+template <int NZ, int NK>
+__global__ void __launch_bounds__(256, 2) att_l0_fwd_kernel(AttL0FwdArgs s) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int ZP = 16 * NZ, QP = 16 * NK;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int j = lane & 15, g4 = lane >> 4;
+  const int Kp = s.Kp;
+  float* Wl = reinterpret_cast<float*>(lds_raw);
+  float* wl = Wl + (size_t)ZP * Kp + (size_t)wave * AF_GMAX * (QP + ZP);
+  float* qs = wl;                     // [G][QP]
+  float* vs = wl + AF_GMAX * QP;      // [G][ZP]
+  double* red = reinterpret_cast<double*>(Wl + (size_t)ZP * Kp + (size_t)4 * AF_GMAX * (QP + ZP));   // [4][2][ZP]
+  constexpr int TS = ZP + 4;   // row stride of the store-transposition tile: (4 g4 + e) * TS + 16 z + j hits 64 distinct banks
+  float* tb = reinterpret_cast<float*>(red + 4 * 2 * ZP) + (size_t)wave * 16 * TS;   // [16 positions][TS] per wave
+  {
+    const int Kq = Kp >> 2;
+    const int nrows = 16 * ((s.A0 + 15) >> 4);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int e = tid; e < ZP * Kq; e += 256) {
+      const int row = e / Kq, c = e - row * Kq;
+      reinterpret_cast<f32x4*>(Wl)[e] = row < nrows ? ld4(s.Wt + (long)row * Kp + 4 * c) : z;
+    }
+  }
+  __syncthreads();
+  const float* ldsB = Wl + (long)j * Kp + 4 * g4;   // + 16 z Kp + 16 kk
+
+  const int G = s.G, T = s.T;
+  const int NTT = (T + 15) >> 4;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  double d1[NZ], d2[NZ];
+#pragma unroll
+  for (int z = 0; z < NZ; ++z) { d1[z] = 0.0; d2[z] = 0.0; }
+  int ncl[NZ];
+  bool nok[NZ];
+#pragma unroll
+  for (int z = 0; z < NZ; ++z) {
+    nok[z] = 16 * z + j < s.A0;
+    ncl[z] = nok[z] ? 16 * z + j : 0;
+  }
+
+  for (long h = (long)blockIdx.x * 4 + wave; h < s.Hn; h += (long)gridDim.x * 4) {
+    for (int e = lane; e < G * QP; e += 64) {
+      const int g = e / QP, n = e - g * QP;
+      qs[e] = n < s.Q ? s.q[(h * G + g) * s.ldq + n] : 0.f;
+    }
+    for (int e = lane; e < G * ZP; e += 64) {
+      const int g = e / ZP, n = e - g * ZP;
+      vs[e] = n < s.A0 ? s.V[(h * G + g) * s.ldv + n] : 0.f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+
+    struct Tile { f32x4 a[NK]; f32x4 u[NZ]; };
+    auto load_tile = [&](int tt) -> Tile {
+      Tile r;
+      const int t0 = 16 * tt;
+      const float* ap = s.a + (h * T + min(t0 + j, T - 1)) * s.lda + 4 * g4;
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) r.a[kk] = ld4(ap + (16 * kk + 4 * g4 < s.Q ? 16 * kk : 0));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* up = s.U + (h * T + min(t0 + 4 * g4 + e, T - 1)) * s.ldu;
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) r.u[z][e] = up[ncl[z]];
+      }
+      return r;
+    };
+    float s1[NZ], s2[NZ];
+#pragma unroll
+    for (int z = 0; z < NZ; ++z) { s1[z] = 0.f; s2[z] = 0.f; }
+    // the next tile's operands are requested BEFORE this tile's stores: loads and stores retire through one in-order
+    // counter, so a load issued behind 100 stores would wait for their write acknowledgements
+    Tile nxt = load_tile(0);
+    for (int tt = 0; tt < NTT; ++tt) {
+      Tile cur = nxt;
+      if (tt + 1 < NTT) nxt = load_tile(tt + 1);
+      const int t0 = 16 * tt;
+      const bool fullT = t0 + 16 <= T;
+      const bool pv = t0 + j < T;
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) cur.a[kk] = (pv && 16 * kk + 4 * g4 < s.Q) ? cur.a[kk] : z4;
+      // make the tile's operands ARRIVE here: left pending, the counter pass puts a vmcnt(0) inside the g loop (it
+      // cannot tell the first iteration from the later ones), which then also waits for every store of the loop
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) asm volatile("" ::"v"(cur.a[kk]));
+#pragma unroll
+      for (int z = 0; z < NZ; ++z) asm volatile("" ::"v"(cur.u[z]));
+      for (int g = 0; g < G; ++g) {
+        // (opaque per iteration: keeps the compiler from parking the loop-invariant weight reads in ~70 VGPRs)
+        int woff = 0;
+        asm volatile("" : "+v"(woff));   // (an opaque OFFSET: an opaque pointer would lose its LDS address space -> flat loads)
+        const float* lb = ldsB + woff;
+        f32x4 x[NK];
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) x[kk] = cur.a[kk] * ld4(qs + g * QP + 16 * kk + 4 * g4);
+        f32x4 acc[NZ];
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) acc[z] = cur.u[z] + vs[g * ZP + 16 * z + j];
+        // weights of chunk kk + 1 are read from LDS while chunk kk is multiplied
+        f32x4 w[2][NZ];
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) w[0][z] = ld4(lb + (long)z * 16 * Kp);
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+          if (kk + 1 < NK) {
+#pragma unroll
+            for (int z = 0; z < NZ; ++z) w[(kk + 1) & 1][z] = ld4(lb + (long)z * 16 * Kp + 16 * (kk + 1));
+          }
+#pragma unroll
+          for (int z = 0; z < NZ; ++z) MFMA4(acc[z], x[kk].x, w[kk & 1][z].x);
+#pragma unroll
+          for (int z = 0; z < NZ; ++z) MFMA4(acc[z], x[kk].y, w[kk & 1][z].y);
+#pragma unroll
+          for (int z = 0; z < NZ; ++z) MFMA4(acc[z], x[kk].z, w[kk & 1][z].z);
+#pragma unroll
+          for (int z = 0; z < NZ; ++z) MFMA4(acc[z], x[kk].w, w[kk & 1][z].w);
+        }
+        // the result tile goes through LDS once so that every position's A0 floats leave as consecutive 16-byte stores
+        // (a lane holds 4 positions of one feature: stored directly that is 4 x NZ dword stores of 64-byte pieces)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int z = 0; z < NZ; ++z) tb[(4 * g4 + e) * TS + 16 * z + j] = acc[z][e];
+        if (s.stats) {
+          if (fullT) {
+#pragma unroll
+            for (int z = 0; z < NZ; ++z) {
+              s1[z] += (acc[z].x + acc[z].y) + (acc[z].z + acc[z].w);
+              s2[z] += (acc[z].x * acc[z].x + acc[z].y * acc[z].y) + (acc[z].z * acc[z].z + acc[z].w * acc[z].w);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const bool tv = t0 + 4 * g4 + e < T;
+#pragma unroll
+              for (int z = 0; z < NZ; ++z) {
+                const float v = tv ? acc[z][e] : 0.f;
+                s1[z] += v;
+                s2[z] = fmaf(v, v, s2[z]);
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        float* zrow = s.z0 + ((h * G + g) * T + t0) * s.ldz;
+        constexpr int C4 = ZP / 4;
+#pragma unroll
+        for (int i = 0; i < (16 * C4 + 63) / 64; ++i) {
+          const int idx = lane + 64 * i;
+          const int row = idx / C4, c4 = idx - row * C4;
+          if (idx < 16 * C4 && t0 + row < T && 4 * c4 < s.A0)
+            __builtin_nontemporal_store(ld4(tb + row * TS + 4 * c4), reinterpret_cast<f32x4*>(zrow + (long)row * s.ldz + 4 * c4));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    // at most 4 * NTT * G values per lane and feature since the last flush: fp32 partials -> double accumulators
+#pragma unroll
+    for (int z = 0; z < NZ; ++z) { d1[z] += (double)s1[z]; d2[z] += (double)s2[z]; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  if (s.stats) {
+#pragma unroll
+    for (int z = 0; z < NZ; ++z) {
+      double a1 = d1[z], a2 = d2[z];
+      a1 += __shfl_xor(a1, 16, 64); a1 += __shfl_xor(a1, 32, 64);
+      a2 += __shfl_xor(a2, 16, 64); a2 += __shfl_xor(a2, 32, 64);
+      if (g4 == 0) {
+        red[(wave * 2 + 0) * ZP + 16 * z + j] = a1;
+        red[(wave * 2 + 1) * ZP + 16 * z + j] = a2;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * ZP; e += 256) {
+      const int which = e / ZP, n = e - which * ZP;
+      if (n < s.A0) {
+        double t = 0.0;
+        for (int w = 0; w < 4; ++w) t += red[(w * 2 + which) * ZP + n];
+        s.stats[((long)blockIdx.x * 2 + which) * s.A0 + n] = t;
+      }
+    }
+  }
+}
+
+static int af_grid(long Hn) {
+  long gx = (Hn + 3) / 4;
+  return (int)(gx > 512 ? 512 : gx);
+}
+static int af_class(int n) { return n <= 48 ? 3 : 5; }
+
+// 1 when clsr_att_l0_fwd handles this shape (otherwise: clsr_pgemm with Xmul / addU / addV)
+extern "C" int clsr_att_l0_fwd_supported(int G, int Q, int A0) {
+  return G >= 1 && G <= AF_GMAX && Q >= 4 && Q <= 80 && A0 >= 4 && A0 <= 80 && Q % 4 == 0 && A0 % 4 == 0;
+}
+// number of per-block partial rows the statistics buffer receives: [parts][2][A0] doubles
+extern "C" int clsr_att_l0_fwd_stats_parts(long Hn) { return af_grid(Hn); }
+
+template <int NZ, int NK>
+static int att_l0_fwd_launch(const AttL0FwdArgs& a, hipStream_t stream) {
+  size_t shmem = (size_t)16 * NZ * a.Kp * 4 + (size_t)4 * AF_GMAX * (16 * NK + 16 * NZ) * 4 + (size_t)4 * 2 * 16 * NZ * 8 +
+                 (size_t)4 * 16 * (16 * NZ + 4) * 4;
+  auto kernel = att_l0_fwd_kernel<NZ, NK>;
+  if (shmem > 64 * 1024)
+    CLSR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL(kernel, dim3(af_grid(a.Hn)), dim3(256), shmem, stream, a);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+extern "C" int clsr_att_l0_fwd(const float* a, int lda, const float* q, int ldq, const float* Wt, int Kp,
+                               const float* U, int ldu, const float* V, int ldv, float* z0, int ldz, double* stats,
+                               long Hn, int G, int T, int Q, int A0, void* stream) {
+  CLSR_CHECK_ARG(a && q && Wt && U && V && z0 && Hn > 0 && T > 0);
+  CLSR_CHECK_SUPPORTED(clsr_att_l0_fwd_supported(G, Q, A0));
+  CLSR_CHECK_SUPPORTED(lda % 4 == 0 && Kp % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)Wt % 16) == 0);
+  CLSR_CHECK_ARG(lda >= Q && ldq >= Q && Kp >= 16 * clsr_cdiv(Q, 16) && ldu >= A0 && ldv >= A0 && ldz >= A0);
+  CLSR_CHECK_SUPPORTED(ldz % 4 == 0 && ((uintptr_t)z0 % 16) == 0);
+  AttL0FwdArgs s = {};
+  s.a = a; s.lda = lda; s.q = q; s.ldq = ldq; s.Wt = Wt; s.Kp = Kp; s.U = U; s.ldu = ldu; s.V = V; s.ldv = ldv;
+  s.z0 = z0; s.ldz = ldz; s.stats = stats; s.Hn = Hn; s.G = G; s.T = T; s.Q = Q; s.A0 = A0;
+  hipStream_t st = (hipStream_t)stream;
+  const int nz = af_class(A0), nk = af_class(Q);
+#define AF_GO(Z, K) if (nz == Z && nk == K) return att_l0_fwd_launch<Z, K>(s, st)
+  AF_GO(3, 3); AF_GO(3, 5); AF_GO(5, 3); AF_GO(5, 5);
+#undef AF_GO
+  return CLSR_OK;
+}

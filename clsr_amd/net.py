@@ -97,7 +97,8 @@ class CLSRNet(object):
         self.split_g2 = not os.environ.get("CLSR_NO_SPLIT_G2")             # A/B switch (causal GRU off the main launch)
         self._step_plans = {}
         self.dw_streams = int(os.environ.get("CLSR_DW_STREAMS", "1"))
-        self.fused_l0_bwd = not os.environ.get("CLSR_NO_FUSED_L0_BWD")   # A/B switch (speed mode, see _att_bwd)
+        self.fused_l0_bwd = not os.environ.get("CLSR_NO_FUSED_L0_BWD")   # A/B switch (see _att_bwd)
+        self.l0_fwd_wave = not os.environ.get("CLSR_NO_L0_FWD_WAVE")      # A/B switch (exact mode, see _att_fwd)
         self.fused_l0_wu = not os.environ.get("CLSR_NO_FUSED_L0_WU")   # A/B: dU . Wu^T inside that kernel as well (time-neutral, two launches fewer)
         self._joins = []
         self._dw_pending, self._dw_tables, self._dw_after, self._rp_pending = {}, {}, {}, {}
@@ -178,7 +179,7 @@ class CLSRNet(object):
         g = lambda k: getattr(hp, k, None)
         return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook),
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
-                self.lazy, self.rnn_first, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu,
+                self.lazy, self.rnn_first, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave,
                 self.split_g2, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
@@ -914,6 +915,13 @@ class CLSRNet(object):
                        addV=self._buf("att.zeroV", Hn, A0), ldv=A0)
             self._gemm(a[:, qh:], Q, key + ".Wp2", R * T, Q - qh, A0, z0, A0, T=T, G=G, Xmul=q[:, qh:], ldmul=Q,
                        addU=U, ldu=A0, addV=V, ldv=A0, stats=st)
+        elif self.l0_fwd_wave and query("clsr_att_l0_fwd_supported", G, Q, A0):
+            # one wave per history, a / U loaded once per group of rows (csrc/attl0fwd.hip)
+            parts = query("clsr_att_l0_fwd_stats_parts", Hn) if training else 0
+            st = (self._buf("stats" + self._ws_tag, 1024 * 2 * 256, dtype=torch.float64)[: parts * 2 * A0]
+                  if training else None)
+            Wt, Kp = self.packed[key + ".Wp"]
+            call("clsr_att_l0_fwd", a, Q, q, Q, Wt, Kp, U, A0, V, A0, z0, A0, st, Hn, G, T, Q, A0)
         else:
             self._gemm(a, Q, key + ".Wp", R * T, Q, A0, z0, A0, T=T, G=G, Xmul=q, ldmul=Q, addU=U, ldu=A0,
                        addV=V, ldv=A0, stats=st)
@@ -1587,6 +1595,8 @@ class CLSRNet(object):
         bf = self.precision == "bf16"
         peak = 2500.0 if bf else 157.3
         return dict(bound="mfma", kernel=("hgemm_kernel<MUL,UV> (short-term attention layer 0, bf16 MFMA)" if bf else
+                                          "att_l0_fwd_kernel<5,5> (short-term attention layer 0, one wave per history)"
+                                          if self._att_layer0_wave(G, Qs) else
                                           "pgemm_fast_kernel<5,MUL,UV,false> (short-term attention layer 0)"),
                     achieved=round(flops / t_mm / 1e12, 2), peak=peak, unit="TFLOP/s",
                     frac=round(flops / t_mm / (peak * 1e12), 4), us_per_launch=round(t_mm * 1e6, 2),
@@ -1604,8 +1614,13 @@ class CLSRNet(object):
             return lambda: call("clsr_hgemm_mul_uv", a, Q, T, G, q, Q, Wt, Kp, U, A0, V, A0, z0, A0, None, R * T, Q, A0)
         z0 = self._buf(key + ".z0", R * T, A0)
         Wt, Kp = self.packed[key + ".Wp"]
+        if self._att_layer0_wave(G, Q):
+            return lambda: call("clsr_att_l0_fwd", a, Q, q, Q, Wt, Kp, U, A0, V, A0, z0, A0, None, Hn, G, T, Q, A0)
         return lambda: call("clsr_pgemm", a, Q, T, G, q, Q, None, None, 1, Wt, Kp, None, U, A0, V, A0, z0, A0, 0,
                             None, R * T, Q, A0)
+
+    def _att_layer0_wave(self, G, Q):
+        return (not self.bf16) and self.l0_fwd_wave and bool(query("clsr_att_l0_fwd_supported", G, Q, self.A0))
 
     def read_losses(self):
         """Synchronising read of the step's loss terms -> dict of python floats."""

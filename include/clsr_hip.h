@@ -149,6 +149,15 @@ int clsr_att_l0_bwd_h_supported(int G, int Q, int A0);
 int clsr_att_l0_bwd_h(const void* dz0, int lddz, const void* Wt, const void* Wu, int Kp, const float* a, int lda,
                       const float* q, int ldq, long Hn, int G, int T, int Q, int A0, float* da, int ldda,
                       float* dq, int lddq, float* dU, int lddu, float* dV, int lddv, void* stream);
+/* Re-associated first attention layer, exact mode, one wave per history (csrc/attl0fwd.hip):
+ *   z0[r,t,:] = U[h,t,:] + V[r,:] + (a[h,t,:] * q[r,:]) . Wp,   stats = per-block partial column sums / sums of squares
+ *   [clsr_att_l0_fwd_stats_parts(Hn)][2][A0] doubles (NULL: none).  Wt = packed Wp (clsr_pack_batch: A0 rows, K = Q).
+ * Same results as clsr_pgemm(X = a, Xmul = q, addU = U, addV = V) (reference clsr.py:368-370, base_model.py:664-673). */
+int clsr_att_l0_fwd_supported(int G, int Q, int A0);
+int clsr_att_l0_fwd_stats_parts(long Hn);
+int clsr_att_l0_fwd(const float* a, int lda, const float* q, int ldq, const float* Wt, int Kp,
+                    const float* U, int ldu, const float* V, int ldv, float* z0, int ldz, double* stats,
+                    long Hn, int G, int T, int Q, int A0, void* stream);
 /* The same four reductions in exact mode: dz0 and the packed Wp^T (clsr_pack_batch layout) fp32, fp32 matrix pipe; dU may
  * be NULL (G == 1: dU is dz0).  Replaces clsr_pgemm (daq) + clsr_att_prod_bwd + clsr_att_z0_bwd_reduce. */
 int clsr_att_l0_bwd_supported(int G, int Q, int A0);

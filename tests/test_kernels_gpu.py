@@ -940,3 +940,40 @@ def test_fused_layer0_backward_reductions_fp32(Hn, G, T, Q, A0):
     close(dq, dq3, rtol=1e-5, atol=1e-4, name="dq vs three kernels")
     close(dU, dU3, rtol=1e-6, atol=1e-6, name="dU vs three kernels")
     close(dV, dV3, rtol=1e-5, atol=2e-5, name="dV vs three kernels")
+
+
+@pytest.mark.parametrize("Hn,G,T,Q,A0", [(37, 5, 50, 80, 80), (64, 1, 50, 40, 80), (9, 8, 7, 44, 36), (6, 3, 17, 24, 40),
+                                         (1, 5, 1, 80, 80), (2100, 2, 33, 48, 80)])
+def test_attention_layer0_forward_one_wave_per_history(Hn, G, T, Q, A0):
+    """clsr_att_l0_fwd: z0 = U[h,t] + V[r] + (a[h,t] * q[r]) . Wp with the batch-norm column sums == float64, and ==
+    clsr_pgemm with the Xmul prologue / addU + addV epilogue (the kernel it replaces)."""
+    assert query("clsr_att_l0_fwd_supported", G, Q, A0) == 1
+    assert query("clsr_att_l0_fwd_supported", 9, Q, A0) == 0 and query("clsr_att_l0_fwd_supported", G, 96, A0) == 0
+    g = torch.Generator().manual_seed(Hn * 3 + T)
+    R, M = Hn * G, Hn * G * T
+    a, q = rnd(g, Hn * T, Q), rnd(g, R, Q)
+    U, V, Wp = rnd(g, Hn * T, A0), rnd(g, R, A0), rnd(g, Q, A0, scale=0.2)
+    Wt, Kp = ops.pack_weight(dev(Wp, torch.float32), A0, Q)
+    f = lambda t: dev(t, torch.float32)
+    parts = query("clsr_att_l0_fwd_stats_parts", Hn)
+    st = torch.full((parts, 2, A0), 7.0, dtype=torch.float64, device="cuda")
+    z0 = torch.full((M, A0 + 4), 7.0, device="cuda")          # strided output
+    da, dq, dU, dV = f(a), f(q), f(U), f(V)
+    call("clsr_att_l0_fwd", da, Q, dq, Q, Wt, Kp, dU, A0, dV, A0, z0, A0 + 4, st, Hn, G, T, Q, A0)
+    torch.cuda.synchronize()
+    a4, q4 = a.view(Hn, 1, T, Q), q.view(Hn, G, 1, Q)
+    exp = ((a4 * q4) @ Wp + U.view(Hn, 1, T, A0) + V.view(Hn, G, 1, A0)).reshape(M, A0)
+    close(z0[:, :A0], exp, rtol=1e-5, atol=2e-5, name="z0")
+    assert float((z0[:, A0:] - 7.0).abs().max()) == 0
+    got = z0[:, :A0].double()
+    close(st.sum(0)[0], got.sum(0), rtol=1e-6, atol=1e-4, name="column sums")
+    close(st.sum(0)[1], (got * got).sum(0), rtol=1e-6, atol=1e-4, name="column sums of squares")
+    # no statistics (scoring)
+    z1 = torch.zeros(M, A0, device="cuda")
+    call("clsr_att_l0_fwd", da, Q, dq, Q, Wt, Kp, dU, A0, dV, A0, z1, A0, None, Hn, G, T, Q, A0)
+    # the position-tiled kernel
+    z2 = torch.zeros(M, A0, device="cuda")
+    call("clsr_pgemm", da, Q, T, G, dq, Q, None, None, 1, Wt, Kp, None, dU, A0, dV, A0, z2, A0, 0, None, M, Q, A0)
+    torch.cuda.synchronize()
+    assert torch.equal(z1, z0[:, :A0].contiguous())
+    close(z1, z2, rtol=1e-6, atol=2e-6, name="z0 vs clsr_pgemm")
