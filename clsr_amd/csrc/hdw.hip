@@ -43,17 +43,25 @@ __device__ __forceinline__ typename RawPiece<H>::type load_raw(const void* base,
 __device__ __forceinline__ f32x4 to_f32(f32x4 v) { return v; }
 __device__ __forceinline__ f32x4 to_f32(bf16x4v v) { return __builtin_convertvector(v, f32x4); }
 
+// (bx, gx) = this block's index / the number of blocks along the positions, (by, bz, gz) = its K / N chunk: blockIdx and
+// gridDim for a launch of its own, a job's share of the grid in a multi-job launch (hdw_multi_kernel)
+struct HdwLds {
+  __attribute__((aligned(16))) __bf16 Xs[HDW_W * HDW_LD];
+  __attribute__((aligned(16))) __bf16 Ys[HDW_W * HDW_LD];
+  __attribute__((aligned(16))) float aff[2][HDW_W];
+};
 template <int MODE, bool XH, bool YH>   // MODE 0 plain, 1 X * Xmul[r], 2 relu?(X * in_scale + in_shift)
-__global__ void __launch_bounds__(256, 3) hdw_kernel(HdwArgs a) {
-  __shared__ __attribute__((aligned(16))) __bf16 Xs[HDW_W * HDW_LD];
-  __shared__ __attribute__((aligned(16))) __bf16 Ys[HDW_W * HDW_LD];
-  __shared__ __attribute__((aligned(16))) float aff[2][HDW_W];
+__device__ __forceinline__ void hdw_body(const HdwArgs& a, HdwLds& L, const int bx, const int gx, const int by,
+                                         const int bz, const int gz) {
+  __bf16* Xs = L.Xs;
+  __bf16* Ys = L.Ys;
+  float (*aff)[HDW_W] = L.aff;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile ids / column chunks live in SGPRs
   const int j = lane & 15, g = lane >> 4;
-  const int k0 = blockIdx.y * HDW_W, n0 = blockIdx.z * HDW_W;
-  const int ktc = min(HDW_T, ((a.K + 15) >> 4) - blockIdx.y * HDW_T);
-  const int ntc = min(HDW_T, ((a.N + 15) >> 4) - blockIdx.z * HDW_T);
+  const int k0 = by * HDW_W, n0 = bz * HDW_W;
+  const int ktc = min(HDW_T, ((a.K + 15) >> 4) - by * HDW_T);
+  const int ntc = min(HDW_T, ((a.N + 15) >> 4) - bz * HDW_T);
   const int ntile = ktc * ntc;
   const int kmax4 = ((a.K + 3) & ~3) - 4, nmax4 = a.N - 4;
 
@@ -131,12 +139,12 @@ __global__ void __launch_bounds__(256, 3) hdw_kernel(HdwArgs a) {
     }
   };
 
-  fetch(blockIdx.x);
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  fetch(bx);
+  for (int tile = bx; tile < ntiles; tile += gx) {
     __syncthreads();   // previous stage fully consumed (and, first time, the affine table written)
     stage();
     __syncthreads();
-    fetch(tile + gridDim.x);   // the next stage's global loads fly behind the MFMAs below
+    fetch(tile + gx);   // the next stage's global loads fly behind the MFMAs below
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int mo = 32 * s + 8 * g;
@@ -152,8 +160,8 @@ __global__ void __launch_bounds__(256, 3) hdw_kernel(HdwArgs a) {
   }
 
   // partial chunk in pgemm_dw's layout: tile (kt, nt) element (k = 4g + r, n = j) at (kt*5 + nt)*256 + (4g + r)*16 + j
-  const long chunk = (long)blockIdx.y * gridDim.z + blockIdx.z;
-  float* dst = a.partial + (chunk * gridDim.x + blockIdx.x) * HDW_CHUNK;
+  const long chunk = (long)by * gz + bz;
+  float* dst = a.partial + (chunk * gx + bx) * HDW_CHUNK;
 #pragma unroll
   for (int u = 0; u < HDW_TPW; ++u) {
     if (tk[u] >= 0) {
@@ -167,6 +175,37 @@ __global__ void __launch_bounds__(256, 3) hdw_kernel(HdwArgs a) {
     f32x4 v = bsum[p];
     v.x = wave_sum(v.x); v.y = wave_sum(v.y); v.z = wave_sum(v.z); v.w = wave_sum(v.w);
     if (lane == 0) st4(dst + HDW_T * HDW_T * 256 + 4 * (wave + 4 * p), v);
+  }
+}
+
+template <int MODE, bool XH, bool YH>
+__global__ void __launch_bounds__(256, 3) hdw_kernel(HdwArgs a) {
+  __shared__ HdwLds L;
+  hdw_body<MODE, XH, YH>(a, L, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z, gridDim.z);
+}
+
+// Several weight gradients in ONE launch (see dw_multi_kernel in linear.hip): job j owns blocks [first[j], first[j+1]).
+#define HDWM_MAX 12
+struct HdwMultiArgs {
+  HdwArgs d[HDWM_MAX];
+  int first[HDWM_MAX + 1];
+  int gx[HDWM_MAX];
+  short nch[HDWM_MAX];
+  short key[HDWM_MAX];    // mode * 4 + 2 * x_bf16 + dy_bf16
+  int n;
+};
+__global__ void __launch_bounds__(256, 3) hdw_multi_kernel(HdwMultiArgs m) {
+  __shared__ HdwLds L;
+  int j = 0;
+  while (j + 1 < m.n && (int)blockIdx.x >= m.first[j + 1]) ++j;
+  const int local = blockIdx.x - m.first[j];
+  const int gx = m.gx[j], nch = m.nch[j];
+  const int bx = local % gx, c = local / gx;
+  const int by = c / nch, bz = c - by * nch;
+  switch (m.key[j]) {   // (the operand combinations of the encoders' weight gradients: fp32 activations and gradients)
+    case 0: hdw_body<0, false, false>(m.d[j], L, bx, gx, by, bz, nch); break;
+    case 4: hdw_body<1, false, false>(m.d[j], L, bx, gx, by, bz, nch); break;
+    default: hdw_body<2, false, false>(m.d[j], L, bx, gx, by, bz, nch); break;
   }
 }
 
@@ -214,6 +253,38 @@ extern "C" int clsr_hdw_partial(const void* X, int x_bf16, int ldx, int T, int G
       return CLSR_EUNSUPPORTED;
   }
 #undef HDW_LAUNCH
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// n weight-gradient partial products in one launch (fp32 X / dY only; same partial layout as clsr_hdw_partial)
+extern "C" int clsr_hdw_partial_multi(const clsr_dwjob* jobs, int n, void* stream) {
+  CLSR_CHECK_ARG(jobs && n > 0 && n <= HDWM_MAX);
+  HdwMultiArgs m;
+  m.n = n;
+  int total = 0;
+  for (int j = 0; j < n; ++j) {
+    const clsr_dwjob& q = jobs[j];
+    CLSR_CHECK_ARG(q.X && q.dY && q.workspace && q.M > 0 && q.K > 0 && q.N > 0 && !(q.in_scale && !q.in_shift));
+    CLSR_CHECK_SUPPORTED(!q.x_bf16 && !q.dy_bf16);
+    CLSR_CHECK_SUPPORTED(q.N % 4 == 0 && q.ldx % 4 == 0 && q.ldy % 4 == 0 && q.ldx >= ((q.K + 3) & ~3) &&
+                         (!q.Xmul || (q.ldmul % 4 == 0 && q.ldmul >= ((q.K + 3) & ~3))) &&
+                         ((uintptr_t)q.X % 16) == 0 && ((uintptr_t)q.dY % 16) == 0);
+    CLSR_CHECK_SUPPORTED(!(q.Xmul && q.in_scale) && !(q.in_scale && q.K % 4));
+    CLSR_CHECK_SUPPORTED(hdw_grid_x(q.M) == clsr_pgemm_dw_parts(q.M));
+    HdwArgs& a = m.d[j];
+    a.X = q.X; a.ldx = q.ldx; a.T = q.T; a.G = q.G; a.Xmul = q.Xmul; a.ldmul = q.ldmul;
+    a.in_scale = q.in_scale; a.in_shift = q.in_shift; a.in_relu = q.in_relu;
+    a.dY = q.dY; a.ldy = q.ldy; a.partial = q.workspace; a.M = q.M; a.K = q.K; a.N = q.N;
+    const int kch = clsr_cdiv(q.K, HDW_W), nch = clsr_cdiv(q.N, HDW_W);
+    m.first[j] = total;
+    m.gx[j] = hdw_grid_x(q.M);
+    m.nch[j] = (short)nch;
+    m.key[j] = (short)((q.Xmul ? 1 : (q.in_scale ? 2 : 0)) * 4);
+    total += m.gx[j] * kch * nch;
+  }
+  m.first[n] = total;
+  hipLaunchKernelGGL(hdw_multi_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, m);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }

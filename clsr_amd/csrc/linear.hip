@@ -661,16 +661,19 @@ struct DwArgs {
 //   A operand (lane (i,g)) = Xs[16w + 4s + g][16kt + i],  B operand = Ys[16w + 4s + g][16nt + i].
 // Row stride 80 floats == 16 (mod 32) banks => the two row groups of a half-wave hit disjoint banks.
 #define DW_W (16 * DW_T)
+// (bx, gx) = this block's index / the number of blocks along the positions, (by, bz, gz) = its K / N chunk: blockIdx and
+// gridDim for a launch of its own, a job's share of the grid in a multi-job launch (dw_multi_kernel)
+#define DW_LDS_FLOATS (64 * 2 * DW_W > 2 * DW_CHUNK ? 64 * 2 * DW_W : 2 * DW_CHUNK)
 template <int MODE, bool XH = false, bool YH = false>  // 0 plain, 1 X*Xmul[r], 2 relu(X*in_scale + in_shift)
-__global__ void __launch_bounds__(256) pgemm_dw_kernel(DwArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[64 * 2 * DW_W > 2 * DW_CHUNK ? 64 * 2 * DW_W : 2 * DW_CHUNK];
+__device__ __forceinline__ void dw_body(const DwArgs& a, float* lds, const int bx, const int gx, const int by,
+                                        const int bz, const int gz) {
   float* Xs = lds;
   float* Ys = lds + 64 * DW_W;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i = lane & 15, g = lane >> 4;
-  const int k0 = blockIdx.y * DW_W, n0 = blockIdx.z * DW_W;
-  const int ktc = min(DW_T, ((a.K + 15) >> 4) - blockIdx.y * DW_T);
-  const int ntc = min(DW_T, ((a.N + 15) >> 4) - blockIdx.z * DW_T);
+  const int k0 = by * DW_W, n0 = bz * DW_W;
+  const int ktc = min(DW_T, ((a.K + 15) >> 4) - by * DW_T);
+  const int ntc = min(DW_T, ((a.N + 15) >> 4) - bz * DW_T);
   const int kmax4 = ((a.K + 3) & ~3) - 4, nmax4 = a.N - 4;
 
   f32x4 acc[DW_T][DW_T];
@@ -744,12 +747,12 @@ __global__ void __launch_bounds__(256) pgemm_dw_kernel(DwArgs a) {
     }
   };
 
-  fetch(blockIdx.x);
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  fetch(bx);
+  for (int tile = bx; tile < ntiles; tile += gx) {
     __syncthreads();  // previous tile fully consumed
     stage();
     __syncthreads();
-    fetch(tile + gridDim.x);  // global loads of the next tile fly behind the MFMAs below
+    fetch(tile + gx);  // global loads of the next tile fly behind the MFMAs below
     const float* xw = Xs + (16 * wave + g) * DW_W + i;
     const float* yw = Ys + (16 * wave + g) * DW_W + i;
 #pragma unroll
@@ -810,9 +813,41 @@ __global__ void __launch_bounds__(256) pgemm_dw_kernel(DwArgs a) {
   __syncthreads();
   if (wave == 0) {
     add_from(red);
-    const long chunk = (long)blockIdx.y * gridDim.z + blockIdx.z;
-    store_to(a.partial + (chunk * gridDim.x + blockIdx.x) * DW_CHUNK);
+    const long chunk = (long)by * gz + bz;
+    store_to(a.partial + (chunk * gx + bx) * DW_CHUNK);
   }
+}
+
+template <int MODE, bool XH = false, bool YH = false>
+__global__ void __launch_bounds__(256) pgemm_dw_kernel(DwArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[DW_LDS_FLOATS];
+  dw_body<MODE, XH, YH>(a, lds, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z, gridDim.z);
+}
+
+// Several weight gradients in ONE launch: job j owns the blocks [first[j], first[j+1]) of the 1-D grid.  The hidden-to-
+// hidden / time-feature gradients of the sequence encoders are ~6 small products over the same Hn*T positions (30-100 us
+// each, latency bound at 512 blocks): one after the other they were 350 us at the end of the backward pass, side by side
+// they share the machine (and the slices of dPin they all read).
+#define DWM_MAX 12
+struct DwMultiArgs {
+  DwArgs d[DWM_MAX];
+  int first[DWM_MAX + 1];
+  int gx[DWM_MAX];
+  short nch[DWM_MAX];
+  short mode[DWM_MAX];
+  int n;
+};
+__global__ void __launch_bounds__(256) dw_multi_kernel(DwMultiArgs m) {
+  __shared__ __attribute__((aligned(16))) float lds[DW_LDS_FLOATS];
+  int j = 0;
+  while (j + 1 < m.n && (int)blockIdx.x >= m.first[j + 1]) ++j;
+  const int local = blockIdx.x - m.first[j];
+  const int gx = m.gx[j], nch = m.nch[j];
+  const int bx = local % gx, c = local / gx;
+  const int by = c / nch, bz = c - by * nch;
+  if (m.mode[j] == 0) dw_body<0>(m.d[j], lds, bx, gx, by, bz, nch);
+  else if (m.mode[j] == 1) dw_body<1>(m.d[j], lds, bx, gx, by, bz, nch);
+  else dw_body<2>(m.d[j], lds, bx, gx, by, bz, nch);
 }
 
 // dW[k*ldw + n] (=|+=) scale * sum_p partial[...]; db[n] likewise (from K-chunk 0).
@@ -901,6 +936,39 @@ static int dw_launch_partial(const void* X, int ldx, int T, int G, const float* 
   else hipLaunchKernelGGL(pgemm_dw_kernel<0>, dim3(gx, kch, nch), dim3(256), 0, s, a);
   CLSR_CHECK_LAUNCH();
   *gx_out = gx;
+  return CLSR_OK;
+}
+
+// n weight-gradient partial products in one launch (same partial layout per job as clsr_pgemm_dw_partial; fp32 operands)
+extern "C" int clsr_sizeof_dwjob(void) { return (int)sizeof(clsr_dwjob); }
+
+extern "C" int clsr_pgemm_dw_partial_multi(const clsr_dwjob* jobs, int n, void* stream) {
+  CLSR_CHECK_ARG(jobs && n > 0 && n <= DWM_MAX);
+  DwMultiArgs m;
+  m.n = n;
+  int total = 0;
+  for (int j = 0; j < n; ++j) {
+    const clsr_dwjob& q = jobs[j];
+    CLSR_CHECK_ARG(q.X && q.dY && q.workspace && q.M > 0 && q.K > 0 && q.N > 0 && !(q.in_scale && !q.in_shift));
+    CLSR_CHECK_SUPPORTED(!q.x_bf16 && !q.dy_bf16);
+    CLSR_CHECK_SUPPORTED(q.N % 4 == 0 && q.ldx % 4 == 0 && q.ldy % 4 == 0 && q.ldx >= ((q.K + 3) & ~3) &&
+                         (!q.Xmul || (q.ldmul % 4 == 0 && q.ldmul >= ((q.K + 3) & ~3))) &&
+                         ((uintptr_t)q.X % 16) == 0 && ((uintptr_t)q.dY % 16) == 0);
+    CLSR_CHECK_SUPPORTED(!(q.Xmul && q.in_scale) && !(q.in_scale && q.K % 4));
+    DwArgs& a = m.d[j];
+    a.X = q.X; a.ldx = q.ldx; a.T = q.T; a.G = q.G; a.Xmul = q.Xmul; a.ldmul = q.ldmul;
+    a.in_scale = q.in_scale; a.in_shift = q.in_shift; a.in_relu = q.in_relu;
+    a.dY = q.dY; a.ldy = q.ldy; a.partial = q.workspace; a.M = q.M; a.K = q.K; a.N = q.N;
+    const int kch = clsr_cdiv(q.K, 16 * DW_T), nch = clsr_cdiv(q.N, 16 * DW_T);
+    m.first[j] = total;
+    m.gx[j] = dw_grid_x(q.M);
+    m.nch[j] = (short)nch;
+    m.mode[j] = (short)(q.Xmul ? 1 : (q.in_scale ? 2 : 0));
+    total += m.gx[j] * kch * nch;
+  }
+  m.first[n] = total;
+  hipLaunchKernelGGL(dw_multi_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, m);
+  CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
 

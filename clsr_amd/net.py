@@ -18,6 +18,7 @@ the embedding IndexedSlices uses the norm of the G un-summed replica slices, her
 their sum is used; ``dedup_histories=False`` runs the reference's replicated computation.
 """
 import math
+import contextlib
 import os
 from collections import OrderedDict
 
@@ -98,6 +99,8 @@ class CLSRNet(object):
         self._step_plans = {}
         self.dw_streams = int(os.environ.get("CLSR_DW_STREAMS", "1"))
         self.fused_l0_bwd = not os.environ.get("CLSR_NO_FUSED_L0_BWD")   # A/B switch (see _att_bwd)
+        self.dw_batching = not os.environ.get("CLSR_NO_DW_BATCH")          # A/B switch (see _dw_batched)
+        self._dw_batch = None
         self.l0_fwd_wave = not os.environ.get("CLSR_NO_L0_FWD_WAVE")      # A/B switch (exact mode, see _att_fwd)
         self.fused_l0_wu = not os.environ.get("CLSR_NO_FUSED_L0_WU")   # A/B: dU . Wu^T inside that kernel as well (time-neutral, two launches fewer)
         self._joins = []
@@ -179,7 +182,7 @@ class CLSRNet(object):
         g = lambda k: getattr(hp, k, None)
         return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook),
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
-                self.lazy, self.rnn_first, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave,
+                self.lazy, self.rnn_first, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching,
                 self.split_g2, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
@@ -478,7 +481,12 @@ class CLSRNet(object):
         need = query("clsr_pgemm_dw_workspace_floats", M, K, N)
         ws = self._buf("dw_ws%s.%d" % (self._ws_tag, len(pend)), max(need, 1))
         sc, sh = (aff.scale, aff.shift) if aff is not None else (None, None)
-        if self.dw_stream and self.overlap and self._ws_tag == "":
+        if self._dw_batch is not None and not (x_bf16 or dy_bf16):
+            # inside _dw_batched(): the product joins the ONE multi-job launch issued when the block ends
+            ptr = lambda t: 0 if t is None else t.data_ptr()
+            self._dw_batch.append((ptr(X), ptr(Xmul), ptr(sc), ptr(sh), ptr(dY), ptr(ws), 0, ldx, T, G, ldmul, 1, 0,
+                                   ldy, M, K, N, 0))
+        elif self.dw_stream and self.overlap and self._ws_tag == "":
             # nothing on the main chain needs a weight gradient before the flush: the partial-sum kernels of the
             # main stream go to a stream of their own (inputs are final at this point and stay untouched until the
             # flush joins that stream), so they run beside the back-propagating GEMMs instead of between them.
@@ -497,6 +505,34 @@ class CLSRNet(object):
                      query("clsr_pgemm_dw_parts", M), K, N, ldw, acc))
         if not self.defer_dw:
             self._dw_flush()
+
+    @contextlib.contextmanager
+    def _dw_batched(self):
+        """Every ``_dw`` issued inside the block becomes a job of ONE launch (clsr_*_dw_partial_multi) that waits only
+        for what had been enqueued on the current stream when the block was ENTERED: the encoders' hidden-to-hidden /
+        time-feature / input-side weight gradients all read the finished dPin and forward activations.  One after the
+        other on the weight-gradient stream those ~7 products were the last 350 us of the backward pass."""
+        if not self.dw_batching or not self.defer_dw or self._dw_batch is not None:
+            yield
+            return
+        fork = self._fork_point()
+        self._dw_batch = []
+        try:
+            yield
+        finally:
+            jobs, self._dw_batch = self._dw_batch, None
+        if not jobs:
+            return
+        name = "clsr_hdw_partial_multi" if (self.bf16 and self.bf16_dw) else "clsr_pgemm_dw_partial_multi"
+        if self.dw_stream and self.overlap and self._ws_tag == "":
+            side = self._side.get("@dw0")
+            if side is None:
+                side = self._side["@dw0"] = torch.cuda.Stream(device=self.device)
+            ops.stream_wait(side, fork)
+            ops.dw_multi(name, jobs, stream=side.cuda_stream)
+            self._dw_async = True
+        else:
+            ops.dw_multi(name, jobs)
 
     def _dw_launch(self, X, x_bf16, ldx, T, G, Xmul, ldmul, sc, sh, dY, dy_bf16, ldy, M, K, N, ws, stream):
         """Partial-sum kernel of one weight gradient: the exact fp32-MFMA kernel, or -- speed mode -- the bf16-MFMA
@@ -1400,17 +1436,19 @@ class CLSRNet(object):
             self._dw_flush()
         if not self.rnn_first:
             ops.rnn_multi("clsr_rnn_bwd_multi", grus, t4d, seq_len, ls, Hn, T)
-        # input-side weights of every encoder in one reduction; d(hist) in one product
-        self._dw(hist, D, dPinAll, NX, M, D, NX, self._buf("xw.dW", D, NX), NX, db=self._buf("xw.db", NX))
-        self._gemm(dPinAll, NX, "xw^T", M, NX, D, dhist, D, acc=1)
-        if self._t4_kind is not None:
-            self._t4_bwd_weights(f, dPinAll, Hn, T, hs)
-        else:
-            self._gru_bwd_hidden("gs", st + "simple_gru/gru_cell/", H, dPinAll, Hn, T)
-        if hp.interest_evolve:
-            self._gru_bwd_hidden("g1", st + "short_term_intention/gru_cell/", Du, dPinAll, Hn, T)
-        if (not hp.manual_alpha) and hp.predict_long_short:
-            self._gru_bwd_hidden("g2", CL + "causal2/causal2/gru_cell/", H, dPinAll, Hn, T)
+        # input-side weights of every encoder in one reduction; d(hist) in one product; the hidden-side / time-feature
+        # weight gradients ride in the same multi-job launch as the input-side one (they all depend on dPin only)
+        with self._dw_batched():
+            self._dw(hist, D, dPinAll, NX, M, D, NX, self._buf("xw.dW", D, NX), NX, db=self._buf("xw.db", NX))
+            self._gemm(dPinAll, NX, "xw^T", M, NX, D, dhist, D, acc=1)
+            if self._t4_kind is not None:
+                self._t4_bwd_weights(f, dPinAll, Hn, T, hs)
+            else:
+                self._gru_bwd_hidden("gs", st + "simple_gru/gru_cell/", H, dPinAll, Hn, T)
+            if hp.interest_evolve:
+                self._gru_bwd_hidden("g1", st + "short_term_intention/gru_cell/", Du, dPinAll, Hn, T)
+            if (not hp.manual_alpha) and hp.predict_long_short:
+                self._gru_bwd_hidden("g2", CL + "causal2/causal2/gru_cell/", H, dPinAll, Hn, T)
         self._dw_flush()          # one batched reduction of every weight gradient of the main stream
         self._unpack_grads()
         # ---- join the long-term attention branch; its d(hist) contribution was accumulated separately

@@ -310,6 +310,29 @@ def sort_ids_multi(rows):
     call("clsr_sort_ids_multi", ctypes.addressof(arr), len(rows))
 
 
+class DwJob(ctypes.Structure):
+    """ctypes mirror of clsr_dwjob (include/clsr_hip.h)."""
+    _fields_ = [("X", _P), ("Xmul", _P), ("in_scale", _P), ("in_shift", _P), ("dY", _P), ("workspace", _P),
+                ("x_bf16", _I), ("ldx", _I), ("T", _I), ("G", _I), ("ldmul", _I), ("in_relu", _I), ("dy_bf16", _I),
+                ("ldy", _I), ("M", _I), ("K", _I), ("N", _I), ("pad_", _I)]
+
+
+DW_MULTI_MAX = 12
+
+
+def dw_multi(name, rows, stream=None):
+    """clsr_pgemm_dw_partial_multi / clsr_hdw_partial_multi on a list of DwJob field tuples (pointers as integers)."""
+    assert ctypes.sizeof(DwJob) == query("clsr_sizeof_dwjob")
+    for i in range(0, len(rows), DW_MULTI_MAX):
+        chunk = rows[i:i + DW_MULTI_MAX]
+        arr = (DwJob * len(chunk))()
+        keep_alive(arr)
+        for d, row in zip(arr, chunk):
+            for (fname, _), val in zip(DwJob._fields_, row):
+                setattr(d, fname, val)
+        call(name, ctypes.addressof(arr), len(chunk), stream=stream)
+
+
 _multi_checked = False
 
 

@@ -396,6 +396,15 @@ int clsr_stage_feed(void* dst, const void* src_host, long nbytes, void* stream);
 #define CLSR_MULTI_MAX 16
 typedef struct clsr_mark_desc { const int* idx; unsigned char* flags; long nrows; long row_stride; int ncols; int pad_; } clsr_mark_desc;
 typedef struct clsr_gather_desc { const float* table; const int* idx; float* out; long idx_stride; int N; int C; int ldo; int col0; } clsr_gather_desc;
+/* one weight-gradient product of a multi-job launch (clsr_pgemm_dw_partial_multi / clsr_hdw_partial_multi): the arguments
+ * of clsr_pgemm_dw_partial / clsr_hdw_partial */
+typedef struct clsr_dwjob {
+  const void* X; const float* Xmul; const float* in_scale; const float* in_shift; const void* dY; float* workspace;
+  int x_bf16; int ldx; int T; int G; int ldmul; int in_relu; int dy_bf16; int ldy; int M; int K; int N; int pad_;
+} clsr_dwjob;
+int clsr_sizeof_dwjob(void);
+int clsr_pgemm_dw_partial_multi(const clsr_dwjob* jobs_host, int n, void* stream);
+int clsr_hdw_partial_multi(const clsr_dwjob* jobs_host, int n, void* stream);
 typedef struct clsr_rp_desc { const float* partial; float* out; float scale; int nparts; int stride; int n; int accumulate; int pad_; } clsr_rp_desc;
 typedef struct clsr_table_desc {
   float* table; const float* partner; float* grad; float* m; float* v; unsigned char* flags;

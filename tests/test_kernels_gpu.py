@@ -977,3 +977,41 @@ def test_attention_layer0_forward_one_wave_per_history(Hn, G, T, Q, A0):
     torch.cuda.synchronize()
     assert torch.equal(z1, z0[:, :A0].contiguous())
     close(z1, z2, rtol=1e-6, atol=2e-6, name="z0 vs clsr_pgemm")
+
+
+@pytest.mark.parametrize("entry", ["clsr_pgemm_dw_partial_multi", "clsr_hdw_partial_multi"])
+def test_weight_gradient_multi_job_launch(entry):
+    """Several weight-gradient products in one launch == the same products launched one by one (same partial chunks):
+    plain, X * Xmul[r] and relu(X * scale + shift) jobs of different shapes, column slices of wider matrices."""
+    g = torch.Generator().manual_seed(11)
+    M = 3000
+    f = lambda t: dev(t, torch.float32)
+    Xw, dYw = f(rnd(g, M, 200)), f(rnd(g, M, 480))
+    mul = f(rnd(g, M, 120))
+    sc, sh = f(rnd(g, 80)), f(rnd(g, 80))
+    single = "clsr_hdw_partial" if "hdw" in entry else "clsr_pgemm_dw_partial"
+    #        X col0, K, dY col0, N, Xmul, affine
+    specs = [(0, 40, 0, 480, None, False), (40, 40, 0, 160, None, False), (80, 80, 160, 120, None, False),
+             (160, 40, 280, 80, None, False), (160, 40, 360, 40, mul, False), (80, 80, 400, 40, None, True),
+             (0, 36, 440, 24, None, False)]
+    jobs, ws_multi, ws_single = [], [], []
+    for x0, K, y0, N, xm, aff in specs:
+        need = query("clsr_pgemm_dw_workspace_floats", M, K, N)
+        wa, wb = torch.zeros(need, device="cuda"), torch.zeros(need, device="cuda")
+        ws_multi.append(wa)
+        ws_single.append(wb)
+        X, dY = Xw[:, x0:], dYw[:, y0:]
+        jobs.append((X.data_ptr(), xm.data_ptr() if xm is not None else 0, sc.data_ptr() if aff else 0,
+                     sh.data_ptr() if aff else 0, dY.data_ptr(), wa.data_ptr(), 0, 200, 0, 0, 120 if xm is not None else 0,
+                     1, 0, 480, M, K, N, 0))
+        if "hdw" in entry:
+            call(single, X, 0, 200, 0, 0, xm, 120 if xm is not None else 0, sc if aff else None, sh if aff else None, 1, dY,
+                 0, 480, M, K, N, wb)
+        else:
+            call(single, X, 200, 0, 0, xm, 120 if xm is not None else 0, sc if aff else None, sh if aff else None, 1, dY,
+                 480, M, K, N, wb)
+    ops.dw_multi(entry, jobs)
+    torch.cuda.synchronize()
+    for i, (wa, wb) in enumerate(zip(ws_multi, ws_single)):
+        assert torch.equal(wa, wb), "job %d differs from its single launch" % i
+    assert float(ws_multi[0].abs().max()) > 0
