@@ -33,6 +33,7 @@ struct PGemmArgs {
   // optional BN+ReLU backward epilogue: v = (ez*e_scale + e_shift > 0) ? v : 0 and the column sums become
   // (sum v, sum v * xhat) with xhat = (ez - e_mean) * e_invstd  (ez = pre-BN activation at [m, n])
   const float* ez; int ldez; const float* e_scale; const float* e_shift; const float* e_mean; const float* e_invstd;
+  int no_ring;                    // A/B switch (CLSR_PGEMM_NO_RING): wide-K plain products load one k-tile ahead only
 };
 
 template <int OT, bool STATS>
@@ -368,6 +369,27 @@ __global__ void __launch_bounds__(256) pgemm_fast_kernel(PGemmArgs a) {
         finish(rawk[kt], kt, b0, b1);
         mfma_block(kt, b0, b1);
       }
+    } else if (PRO == PRO_PLAIN && !a.no_ring) {
+      // any K, plain operand: a ring of four k-tiles in flight (slot = kt % 4, refilled right after it is consumed).
+      // With one tile ahead a wide-K product is a chain of K/16 exposed load latencies: the [20480, 200] input of the
+      // alpha-gate MLP (640 wave-tiles on 1024 SIMDs: nothing else to switch to) took 80 us for 0.65 GFLOP
+      Raw ring[4];
+      ring[0] = raw;
+#pragma unroll
+      for (int d = 1; d < 4; ++d) ring[d] = issue(min(d, KT - 1));
+      for (int kt0 = 0; kt0 < KT; kt0 += 4) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const int kt = kt0 + d;
+          if (kt < KT) {
+            f32x4 b0, b1;
+            finish(ring[d], kt, b0, b1);
+            ring[d] = issue(min(kt + 4, KT - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_block(kt, b0, b1);
+          }
+        }
+      }
     } else {
       for (int kt = 0; kt < KT; ++kt) {
         f32x4 b0, b1;
@@ -531,6 +553,7 @@ extern "C" int clsr_pgemm(const float* X, int ldx, int T, int G, const float* Xm
   a.Wt = Wt; a.Kp = Kp; a.ldw = Kp; a.bias = bias; a.addU = addU; a.ldu = ldu; a.addV = addV; a.ldv = ldv;
   a.Y = Y; a.ldy = ldy; a.accumulate = accumulate; a.stats = stats; a.M = M; a.K = K; a.N = N;
   a.ez = nullptr; a.ldez = 0; a.e_scale = a.e_shift = a.e_mean = a.e_invstd = nullptr;
+  a.no_ring = getenv("CLSR_PGEMM_NO_RING") ? 1 : 0;
   return pgemm_dispatch(a, (hipStream_t)stream);
 }
 
