@@ -100,7 +100,11 @@ class CLSRNet(object):
         self.dw_streams = int(os.environ.get("CLSR_DW_STREAMS", "1"))
         self.fused_l0_bwd = not os.environ.get("CLSR_NO_FUSED_L0_BWD")   # A/B switch (see _att_bwd)
         self.dw_batching = not os.environ.get("CLSR_NO_DW_BATCH")          # A/B switch (see _dw_batched)
+        # where the long-term attention backward forks: beside the short-term one (exact mode: -40 us) or underneath the
+        # backward-through-time launch (speed mode: the short-term backward is bandwidth bound there); CLSR_LT_BWD_EARLY=0|1
+        self.lt_bwd_early = (os.environ.get("CLSR_LT_BWD_EARLY", "1" if precision == "fp32" else "0") == "1")
         self._dw_batch = None
+        self._buf_allocs = 0
         self.l0_fwd_wave = not os.environ.get("CLSR_NO_L0_FWD_WAVE")      # A/B switch (exact mode, see _att_fwd)
         self.fused_l0_wu = not os.environ.get("CLSR_NO_FUSED_L0_WU")   # A/B: dU . Wu^T inside that kernel as well (time-neutral, two launches fewer)
         self._joins = []
@@ -182,7 +186,7 @@ class CLSRNet(object):
         g = lambda k: getattr(hp, k, None)
         return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook),
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
-                self.lazy, self.rnn_first, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching,
+                self.lazy, self.rnn_first, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early,
                 self.split_g2, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
@@ -423,6 +427,7 @@ class CLSRNet(object):
         if t is None:
             t = torch.zeros(*[int(s) for s in shape], dtype=dtype, device=self.device)
             self._bufs[key] = t
+            self._buf_allocs += 1     # (the zero fill is a kernel on the CURRENT stream: see _dw_batched)
         return t
 
     def _pack(self, key, W, out_f, in_f, transposed=False, W2=None, s2=1.0, in_pad=None, o0=0, i0=0,
@@ -516,6 +521,7 @@ class CLSRNet(object):
             yield
             return
         fork = self._fork_point()
+        allocs = self._buf_allocs
         self._dw_batch = []
         try:
             yield
@@ -523,6 +529,10 @@ class CLSRNet(object):
             jobs, self._dw_batch = self._dw_batch, None
         if not jobs:
             return
+        if self._buf_allocs != allocs:
+            # first occurrence of this shape: workspaces were allocated inside the block, and their zero fills sit on the
+            # current stream BEHIND the entry point -- this once the launch waits for everything enqueued so far
+            fork = self._fork_point()
         name = "clsr_hdw_partial_multi" if (self.bf16 and self.bf16_dw) else "clsr_pgemm_dw_partial_multi"
         if self.dw_stream and self.overlap and self._ws_tag == "":
             side = self._side.get("@dw0")
@@ -1399,6 +1409,13 @@ class CLSRNet(object):
         else:
             call("clsr_alpha_fuse_bwd", dmo, None, float(hp.manual_alpha_value), out["att_fea_long"],
                  out["att_fea_short"], Hn, G, D, None, dL, dS, dtarget)
+        dul = None
+        if self.lt_bwd_early:
+            # long-term attention backward (dL is final here) on the side stream from NOW, beside the short-term one
+            with self._branch("@lt", after=self._fork_point()):
+                dul = self._att_bwd("lt", CL + "long_term/attention_fcn/", dL, out["hist_input"], out["u_long"],
+                                    dhist_lt, Hn, 1, T, D, Du, seq_len, ls)
+                self._dw_flush()
         # ---- short-term attention
         st = CL + "short_term/"
         Qs = Du + D
@@ -1430,10 +1447,11 @@ class CLSRNet(object):
         fork = self._fork_point()
         if self.rnn_first:
             ops.rnn_multi("clsr_rnn_bwd_multi", grus, t4d, seq_len, ls, Hn, T)
-        with self._branch("@lt", after=fork):
-            dul = self._att_bwd("lt", CL + "long_term/attention_fcn/", dL, out["hist_input"], out["u_long"], dhist_lt,
-                                Hn, 1, T, D, Du, seq_len, ls)
-            self._dw_flush()
+        if dul is None:
+            with self._branch("@lt", after=fork):
+                dul = self._att_bwd("lt", CL + "long_term/attention_fcn/", dL, out["hist_input"], out["u_long"],
+                                    dhist_lt, Hn, 1, T, D, Du, seq_len, ls)
+                self._dw_flush()
         if not self.rnn_first:
             ops.rnn_multi("clsr_rnn_bwd_multi", grus, t4d, seq_len, ls, Hn, T)
         # input-side weights of every encoder in one reduction; d(hist) in one product; the hidden-side / time-feature

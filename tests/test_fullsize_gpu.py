@@ -151,7 +151,7 @@ def test_catalogue_dims_match_oracle_on_a_slice():
     gs = max(float(g.abs().max()) for n, g in grads.items() if n in net.captured["dense"])
     for name, g in net.captured["dense"].items():
         d = float((g.cpu().double() - grads[name].reshape(g.shape)).abs().max())
-        assert d <= 2e-3 * float(grads[name].abs().max()) + 2e-5 * gs, (name, d)
+        assert d <= 2e-3 * float(grads[name].abs().max()) + 1e-6 * gs, (name, d)
 
 
 def test_catalogue100m_full_size_step():

@@ -993,7 +993,8 @@ def test_weight_gradient_multi_job_launch(entry):
     #        X col0, K, dY col0, N, Xmul, affine
     specs = [(0, 40, 0, 480, None, False), (40, 40, 0, 160, None, False), (80, 80, 160, 120, None, False),
              (160, 40, 280, 80, None, False), (160, 40, 360, 40, mul, False), (80, 80, 400, 40, None, True),
-             (0, 36, 440, 24, None, False)]
+             (0, 36, 440, 24, None, False),
+             (0, 128, 0, 256, None, False), (64, 120, 100, 128, mul, False), (0, 200, 40, 440, None, False)]   # several K chunks
     jobs, ws_multi, ws_single = [], [], []
     for x0, K, y0, N, xm, aff in specs:
         need = query("clsr_pgemm_dw_workspace_floats", M, K, N)
