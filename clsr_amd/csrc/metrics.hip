@@ -19,7 +19,26 @@ typedef unsigned long long u64;
 
 __device__ __forceinline__ double clip_d(double p, double lo, double hi) { return p < lo ? lo : (p > hi ? hi : p); }
 
-// out[0] += sum over lines of -(y log p + (1 - y) log(1 - p)), p clipped to [1e-11, 1 - 1e-11] (cal_metric "logloss")
+// Order-independent accumulation of the per-block partial sums: double atomics add in whatever order the blocks
+// finish, and a metric that sits exactly on a 4-decimal rounding boundary (0.58125: small test files produce such
+// ratios) then rounds either way from run to run.  The partials are added as 64-bit FIXED-POINT integers instead
+// (integer addition commutes exactly); a one-block kernel converts the slots back to doubles.  The slots must be
+// zero on entry (the bit pattern of 0.0 is the integer 0) and hold the final sums on return.
+__device__ __forceinline__ void fx_add(double* slot, double v, double scale) {
+  atomicAdd(reinterpret_cast<u64*>(slot), (u64)__double2ll_rn(v * scale));
+}
+__global__ void fx_finalize_kernel(double* out, int n, double inv_scale) {
+  const int i = threadIdx.x;
+  if (i < n) out[i] = (double)(long long)reinterpret_cast<const u64*>(out)[i] * inv_scale;
+}
+static void fx_finalize(double* out, int n, double scale, hipStream_t s) {
+  hipLaunchKernelGGL(fx_finalize_kernel, dim3(1), dim3(64), 0, s, out, n, 1.0 / scale);
+}
+#define FX_LOGLOSS 67108864.0              // 2^26: the sum is at most 27 N (N < 2^31 lines)
+#define FX_GROUP 1073741824.0              // 2^30: sums of per-group values in [0, 1]
+#define FX_WAUC 1152921504606846976.0      // 2^60: the weighted sum is at most 1
+
+// out[0] = sum over lines of -(y log p + (1 - y) log(1 - p)), p clipped to [1e-11, 1 - 1e-11] (cal_metric "logloss")
 __global__ void __launch_bounds__(256) eval_logloss_kernel(const float* __restrict__ pred,
                                                            const float* __restrict__ labels, long N,
                                                            double* __restrict__ out) {
@@ -31,7 +50,7 @@ __global__ void __launch_bounds__(256) eval_logloss_kernel(const float* __restri
     s -= y * log(p) + (1.0 - y) * log(1.0 - p);
   }
   s = block256_sum_d(s, red);
-  if (threadIdx.x == 0) atomicAdd(out, s);
+  if (threadIdx.x == 0) fx_add(out, s, FX_LOGLOSS);
 }
 
 extern "C" int clsr_eval_logloss(const float* pred, const float* labels, long N, double* out, void* stream) {
@@ -39,6 +58,7 @@ extern "C" int clsr_eval_logloss(const float* pred, const float* labels, long N,
   int blocks = clsr_cdiv(N, 256 * 8);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(eval_logloss_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, labels, N, out);
+  fx_finalize(out, 1, FX_LOGLOSS, (hipStream_t)stream);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
@@ -213,7 +233,7 @@ __global__ void __launch_bounds__(256) eval_group_metrics_kernel(GroupMetricArgs
   }
   if (lane == 0) {
     for (int i = 0; i < 2 + 2 * a.nk; ++i)
-      if (acc[i] != 0.0) atomicAdd(a.out + i, acc[i]);
+      if (acc[i] != 0.0) fx_add(a.out + i, acc[i], FX_GROUP);
     if (bad) atomicAdd(a.err, bad);
   }
 }
@@ -230,6 +250,7 @@ extern "C" int clsr_eval_group_metrics(const float* pred, const float* labels, l
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(eval_group_metrics_kernel, dim3(blocks), dim3(256), (size_t)8 * G * sizeof(float),
                      (hipStream_t)stream, a);
+  fx_finalize(out, 2 + 2 * nk, FX_GROUP, (hipStream_t)stream);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
@@ -295,7 +316,7 @@ __global__ void __launch_bounds__(256) eval_user_auc_kernel(const float* __restr
     acc += ((double)n / (double)N) * (gtd + 0.5 * eqd) / ((double)npos * (double)nneg);
   }
   if (lane == 0) {
-    if (acc != 0.0) atomicAdd(out, acc);
+    if (acc != 0.0) fx_add(out, acc, FX_WAUC);
     if (bad) atomicAdd(err, bad);
   }
 }
@@ -307,6 +328,7 @@ extern "C" int clsr_eval_user_auc(const float* pred, const float* labels, const 
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(eval_user_auc_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, labels, perm, ends,
                      nb, N, out, err);
+  fx_finalize(out, 1, FX_WAUC, (hipStream_t)stream);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }

@@ -422,8 +422,9 @@ int clsr_tables_adam_multi(const clsr_table_desc* descs_host, int n, float clip_
 
 /* ---- evaluation metrics on the device (csrc/metrics.hip): cal_metric / cal_weighted_metric of
  *      deeprec_utils.py:554-821 as SequentialBaseModel.run_eval / run_weighted_eval use them
- *      (sequential_base_model.py:204-292), by exact pair / rank COUNTING (no sort); accumulators are ADDED to (zero them
- *      first).  Rank ties inside a group: the later line ranks first (stable ascending sort read backwards). */
+ *      (sequential_base_model.py:204-292), by exact pair / rank COUNTING (no sort).  The double accumulators (out) must be
+ *      ZERO on entry and hold the final sums on return: block partials are added as 64-bit fixed-point integers, so the
+ *      result does not depend on the order in which blocks finish (bit-identical from run to run).  Rank ties inside a group: the later line ranks first (stable ascending sort read backwards). */
 int clsr_eval_logloss(const float* pred, const float* labels, long N, double* out, void* stream);
 int clsr_eval_compact_pos(const float* pred, const float* labels, long N, float* pos_out, int* count, void* stream);
 int clsr_eval_auc_pairs(const float* pred, const float* labels, long N, const float* pos, const int* count,
