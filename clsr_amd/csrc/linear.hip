@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(256) pgemm_generic_kernel(PGemmArgs a) {
 
 //   * KTT > 0 (K = 16*KTT exactly covered): ALL k-tiles of a wave-tile are loaded before its first MFMA -- the MFMA
 //     chain of a tile then runs back to back instead of waiting for one load latency per k-tile.
-template <int OT, int PRO, int EPI, bool STATS, int KTT = 0>
+template <int OT, int PRO, int EPI, bool STATS, int KTT = 0, bool RING = false>
 __global__ void __launch_bounds__(256) pgemm_fast_kernel(PGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -369,8 +369,10 @@ __global__ void __launch_bounds__(256) pgemm_fast_kernel(PGemmArgs a) {
         finish(rawk[kt], kt, b0, b1);
         mfma_block(kt, b0, b1);
       }
-    } else if (PRO == PRO_PLAIN && !a.no_ring) {
-      // any K, plain operand: a ring of four k-tiles in flight (slot = kt % 4, refilled right after it is consumed).
+    } else if (RING) {
+      // any K, plain operand, FEW positions (a variant of its own: the ring costs 50-80 VGPRs, which the launches
+      // with many wave-tiles per SIMD would pay in occupancy -- the 100M-catalogue step got 8 % slower with it
+      // everywhere): a ring of four k-tiles in flight (slot = kt % 4, refilled right after it is consumed).
       // With one tile ahead a wide-K product is a chain of K/16 exposed load latencies: the [20480, 200] input of the
       // alpha-gate MLP (640 wave-tiles on 1024 SIMDs: nothing else to switch to) took 80 us for 0.65 GFLOP
       Raw ring[4];
@@ -489,11 +491,13 @@ static int launch_pgemm(const PGemmArgs& a, hipStream_t stream) {
   const bool st = a.stats != nullptr;
   const int KTn = clsr_cdiv(a.K, 16);
   const bool upfront = !getenv("CLSR_PGEMM_STREAM");   // A/B switch: loads one k-tile ahead instead of all up front
+  const bool ring = !a.no_ring && a.M <= 65536 && KTn > 5;   // few positions, wide K: latency bound (see the kernel)
 #define CLSR_FAST(P, E, S)                                                                          \
   if (uv_ok && pro == (P) && epi == (E) && st == (S)) {                                             \
     /* (the X * Xmul variant holds twice the operands: with everything in flight it drops to one wave per SIMD and loses) */ \
     if (upfront && (P) != PRO_MUL && KTn == 5) return launch_kernel(pgemm_fast_kernel<OT, P, E, S, 5>, a, grid, shmem, stream); \
     if (upfront && (P) != PRO_MUL && KTn == 3) return launch_kernel(pgemm_fast_kernel<OT, P, E, S, 3>, a, grid, shmem, stream); \
+    if ((P) == PRO_PLAIN && ring) return launch_kernel(pgemm_fast_kernel<OT, PRO_PLAIN, E, S, 0, true>, a, grid, shmem, stream); \
     return launch_kernel(pgemm_fast_kernel<OT, P, E, S>, a, grid, shmem, stream);                   \
   }
   CLSR_FAST(PRO_PLAIN, EPI_NONE, false)

@@ -56,6 +56,9 @@ class _BN(object):
         self.scope = scope
 
 
+_SIDE_STREAMS = {}     # device -> {tag: HIP stream}, see CLSRNet.__init__
+
+
 class CLSRNet(object):
     def __init__(self, hp, dims, device="cuda:0", seed=None, dedup_histories=True, precision="fp32"):
         self.hp = hp
@@ -86,7 +89,9 @@ class CLSRNet(object):
         self._plans, self._plan_keep, self._cur_descs = {}, [], []
         self._sort_bytes = {}
         self._ws_tag = ""          # suffix of shared scratch buffers while a side-stream branch is recording
-        self._side = {}
+        # side streams are shared by every net of the process on this device (one net steps at a time): a second net
+        # with four streams of its own puts eight hardware queues in play and its step takes 5.7 instead of 3.4 ms
+        self._side = _SIDE_STREAMS.setdefault(str(torch.device(device)), {})
         self.rnn_first = not os.environ.get("CLSR_BRANCH_FIRST")   # A/B switch (see forward)
         self.dw_stream = not os.environ.get("CLSR_NO_DW_STREAM")   # A/B switch (see _dw)
         self._dw_async = False
