@@ -359,9 +359,9 @@ def main():
         B, Hn = P * G, P
         D = cfg["Di"] + cfg["Dc"]
         roof = gather_roofline(net, f, cfg, G, feed, big)
-        # PMC pass committed in profiles/r01_gather_hist_fwd_pmc_hbm_traffic.csv (same shape): WRITE_SIZE
+        # PMC pass committed in profiles/r02_gather_hist_fwd_pmc_hbm_traffic.csv (same shape): WRITE_SIZE
         # 33.3 MB + 2 x FETCH_SIZE 12.5 MB (gfx950 wide-load correction); reads of the 8 MB tables hit cache
-        roof.update(traffic=208.8e6 if big else 58.3e6, traffic_source="profiles/r01_gather_hist_fwd_pmc_hbm_traffic.csv",
+        roof.update(traffic=208.8e6 if big else 58.3e6, traffic_source="profiles/r02_gather_hist_fwd_pmc_hbm_traffic.csv",
                     note=("tables (%.1f MB) are L2/Infinity-Cache resident at this config; the HBM claim needs the "
                           "100M-item config" % ((cfg["Vi"] * cfg["Di"] + cfg["Vc"] * cfg["Dc"]) * 4 / 1e6))
                     if not big else "38 GB item table, uniform ids: every row read is an HBM read")
@@ -427,7 +427,7 @@ def main():
                 cache_resident = dict(roof)
                 roof = dict(big_roof, workload="BASELINE configs[4] catalogue: 100M items, rows 384 B + 128 B, uniform "
                                                "ids, 4096 histories x 50 steps (38 GB table: every row read is an HBM read)",
-                            traffic=208.8e6, traffic_source="profiles/r01_gather_hist_fwd_pmc_hbm_traffic.csv "
+                            traffic=208.8e6, traffic_source="profiles/r02_gather_hist_fwd_pmc_hbm_traffic.csv "
                                                             "(WRITE_SIZE 106.5 MB + 2 x FETCH_SIZE 51.1 MB)",
                             cache_resident_at_benchmarked_config=cache_resident)
                 if copy_peak:
