@@ -202,9 +202,11 @@ __global__ void __launch_bounds__(256, 3) hdw_multi_kernel(HdwMultiArgs m) {
   const int gx = m.gx[j], nch = m.nch[j];
   const int bx = local % gx, c = local / gx;
   const int by = c / nch, bz = c - by * nch;
-  switch (m.key[j]) {   // (the operand combinations of the encoders' weight gradients: fp32 activations and gradients)
+  switch (m.key[j]) {   // (the operand combinations of the encoders' weight gradients: fp32 activations, fp32 or bf16 dY)
     case 0: hdw_body<0, false, false>(m.d[j], L, bx, gx, by, bz, nch); break;
+    case 1: hdw_body<0, false, true>(m.d[j], L, bx, gx, by, bz, nch); break;
     case 4: hdw_body<1, false, false>(m.d[j], L, bx, gx, by, bz, nch); break;
+    case 5: hdw_body<1, false, true>(m.d[j], L, bx, gx, by, bz, nch); break;
     default: hdw_body<2, false, false>(m.d[j], L, bx, gx, by, bz, nch); break;
   }
 }
@@ -257,7 +259,7 @@ extern "C" int clsr_hdw_partial(const void* X, int x_bf16, int ldx, int T, int G
   return CLSR_OK;
 }
 
-// n weight-gradient partial products in one launch (fp32 X / dY only; same partial layout as clsr_hdw_partial)
+// n weight-gradient partial products in one launch (fp32 X, fp32 or bf16 dY; same partial layout as clsr_hdw_partial)
 extern "C" int clsr_hdw_partial_multi(const clsr_dwjob* jobs, int n, void* stream) {
   CLSR_CHECK_ARG(jobs && n > 0 && n <= HDWM_MAX);
   HdwMultiArgs m;
@@ -266,10 +268,10 @@ extern "C" int clsr_hdw_partial_multi(const clsr_dwjob* jobs, int n, void* strea
   for (int j = 0; j < n; ++j) {
     const clsr_dwjob& q = jobs[j];
     CLSR_CHECK_ARG(q.X && q.dY && q.workspace && q.M > 0 && q.K > 0 && q.N > 0 && !(q.in_scale && !q.in_shift));
-    CLSR_CHECK_SUPPORTED(!q.x_bf16 && !q.dy_bf16);
+    CLSR_CHECK_SUPPORTED(!q.x_bf16 && !(q.dy_bf16 && q.in_scale));
     CLSR_CHECK_SUPPORTED(q.N % 4 == 0 && q.ldx % 4 == 0 && q.ldy % 4 == 0 && q.ldx >= ((q.K + 3) & ~3) &&
                          (!q.Xmul || (q.ldmul % 4 == 0 && q.ldmul >= ((q.K + 3) & ~3))) &&
-                         ((uintptr_t)q.X % 16) == 0 && ((uintptr_t)q.dY % 16) == 0);
+                         ((uintptr_t)q.X % 16) == 0 && ((uintptr_t)q.dY % 8) == 0);
     CLSR_CHECK_SUPPORTED(!(q.Xmul && q.in_scale) && !(q.in_scale && q.K % 4));
     CLSR_CHECK_SUPPORTED(hdw_grid_x(q.M) == clsr_pgemm_dw_parts(q.M));
     HdwArgs& a = m.d[j];
@@ -280,7 +282,7 @@ extern "C" int clsr_hdw_partial_multi(const clsr_dwjob* jobs, int n, void* strea
     m.first[j] = total;
     m.gx[j] = hdw_grid_x(q.M);
     m.nch[j] = (short)nch;
-    m.key[j] = (short)((q.Xmul ? 1 : (q.in_scale ? 2 : 0)) * 4);
+    m.key[j] = (short)((q.Xmul ? 1 : (q.in_scale ? 2 : 0)) * 4 + (q.dy_bf16 ? 1 : 0));
     total += m.gx[j] * kch * nch;
   }
   m.first[n] = total;

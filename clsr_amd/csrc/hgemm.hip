@@ -501,6 +501,20 @@ extern "C" int clsr_hgemm_f32(const float* X, int ldx, const void* Wt, int Kp, f
   return hgemm_np<HP_F32, HE_F32, false>(a, (hipStream_t)stream);
 }
 
+// The same with a bf16 X (gradients that the producing kernel already stored as bf16: dPin of the sequence encoders)
+extern "C" int clsr_hgemm_hf32(const void* X, int ldx, const void* Wt, int Kp, float* Y, int ldy, int accumulate,
+                               int M, int K, int N, void* stream) {
+  int rc = hgemm_check(X, Wt, Kp, M, K, N, ldx);
+  if (rc) return rc;
+  CLSR_CHECK_ARG(Y && ldy >= N);
+  CLSR_CHECK_SUPPORTED(ldy % 4 == 0 && ((uintptr_t)Y % 16) == 0);
+  if (M == 0) return CLSR_OK;
+  HGemmArgs a = {};
+  a.X = X; a.ldx = ldx; a.Wt = (const __bf16*)Wt; a.Kp = Kp; a.Yf = Y; a.ldy = ldy; a.accumulate = accumulate;
+  a.M = M; a.K = K; a.N = N;
+  return hgemm_np<HP_BF, HE_F32, false>(a, (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------------------------------ packing
 // bf16 image of the packed transposed weights for hgemm: row rho(o) of the image holds out-feature o with
 // rho = 32*(o/32) + 16*((o%8)/4) + 4*((o%32)/8) + (o%4)   (pairs of MFMA tiles, see the file header), row stride Kp

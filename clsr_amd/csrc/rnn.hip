@@ -121,6 +121,14 @@ __device__ __forceinline__ int wave_max_i(int v) {
 }
 
 // ===================================================================================== GRU
+// gradient-of-input-projection stores: fp32, or bf16 when the consumers (weight gradients, d(hist) product) run on the
+// bf16 matrix pipe anyway (speed mode: halves the 393 MB that the backward-through-time kernel writes and two kernels read)
+typedef __bf16 rnn_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_dpin(float* base, long off, f32x4 v, int h) {
+  if (h) *reinterpret_cast<rnn_bf16x4*>(reinterpret_cast<__bf16*>(base) + off) = __builtin_convertvector(v, rnn_bf16x4);
+  else st4(base + off, v);
+}
+
 struct GruArgs {
   const float* Pin; int ldp;           // [Hn, T, ldp]: r | u | c input-side pre-activations (+bias)
   const float* Wgh; int ldg;           // [n, >=2n] hidden rows of gates/kernel
@@ -136,6 +144,7 @@ struct GruArgs {
   const float* dhT;                    // [Hn, n] grad wrt final state (may be null)
   const float* dout_seq;               // optional [Hn, T, n]
   float* dPin;                         // [Hn, T, lddp] (zeros past len); r | u | c blocks of n
+  int dpin_bf16;                       // dPin is a bf16 tensor (lddp in elements): speed mode
   float* dh0;                          // optional [Hn, n]
   int lddp;
   // attentional update gate (DIEN's VecAttGRUCell, rnn_cell_implement.py:594-623): u <- (1 - att[s, t]) * u.
@@ -257,8 +266,8 @@ __device__ __forceinline__ void gru_bwd_body(const GruArgs& a, const int bx, f32
   const float* attp = ATT ? a.att + (hvalid ? h : 0) * (long)T : nullptr;
   if (cval)  // zero dPin past len
     for (int t = len; t < T; ++t) {
-      float* dp = a.dPin + (h * T + t) * a.lddp + col;
-      st4(dp, Z4); st4(dp + n, Z4); st4(dp + 2 * n, Z4);
+      const long dp = (h * T + t) * a.lddp + col;
+      st_dpin(a.dPin, dp, Z4, a.dpin_bf16); st_dpin(a.dPin, dp + n, Z4, a.dpin_bf16); st_dpin(a.dPin, dp + 2 * n, Z4, a.dpin_bf16);
     }
   f32x4* bufA = xb;
   f32x4* bufR = xb + RNT * 64;
@@ -300,8 +309,8 @@ __device__ __forceinline__ void gru_bwd_body(const GruArgs& a, const int bx, f32
     collect<RNT>(bufR, lane, cmp, full);
     mv1(dhn, wr, full, cmp);
     if (ok) {
-      float* dp = a.dPin + pos * a.lddp + col;
-      st4(dp, drp); st4(dp + n, dup); st4(dp + 2 * n, dcp);
+      const long dp = pos * a.lddp + col;
+      st_dpin(a.dPin, dp, drp, a.dpin_bf16); st_dpin(a.dPin, dp + n, dup, a.dpin_bf16); st_dpin(a.dPin, dp + 2 * n, dcp, a.dpin_bf16);
     }
     dh = sel4(live, dhn, dh);
   }
@@ -390,6 +399,7 @@ struct T4Args {
   float* act; float* cst; float* mprev;
   const float* dout_seq;               // [Hn, T, n]
   float* dPin;                         // [Hn, T, lddp]
+  int dpin_bf16;                       // dPin is a bf16 tensor (lddp in elements): speed mode
   int lddp;
 };
 
@@ -484,9 +494,9 @@ __device__ __forceinline__ void t4lstm_bwd_body(const T4Args& a, const int bx, f
   const int Tmax = wave_max_i(len);
   if (cval)
     for (int t = len; t < T; ++t) {
-      float* dp = a.dPin + (h * T + t) * a.lddp + col;
+      const long dp = (h * T + t) * a.lddp + col;
 #pragma unroll
-      for (int gb = 0; gb < 6; ++gb) st4(dp + gb * n, Z4);
+      for (int gb = 0; gb < 6; ++gb) st_dpin(a.dPin, dp + gb * n, Z4, a.dpin_bf16);
     }
   for (int t = Tmax - 1; t >= 0; --t) {
     const bool live = t < len;
@@ -513,9 +523,10 @@ __device__ __forceinline__ void t4lstm_bwd_body(const T4Args& a, const int bx, f
     const f32x4 dtl = dcc * fg * cp * tlg * (1.0f - tlg);      // d tls_pre
     const f32x4 dcn = dcc * fg * tlg;
     if (ok) {
-      float* dp = a.dPin + pos * a.lddp + col;
-      st4(dp, dg[0]); st4(dp + n, dg[1]); st4(dp + 2 * n, dg[2]); st4(dp + 3 * n, dg[3]);
-      st4(dp + 4 * n, dtn); st4(dp + 5 * n, dtl);
+      const long dp = pos * a.lddp + col;
+      st_dpin(a.dPin, dp, dg[0], a.dpin_bf16); st_dpin(a.dPin, dp + n, dg[1], a.dpin_bf16);
+      st_dpin(a.dPin, dp + 2 * n, dg[2], a.dpin_bf16); st_dpin(a.dPin, dp + 3 * n, dg[3], a.dpin_bf16);
+      st_dpin(a.dPin, dp + 4 * n, dtn, a.dpin_bf16); st_dpin(a.dPin, dp + 5 * n, dtl, a.dpin_bf16);
     }
     // publish the four gate-gradient tiles (double buffered by step parity), one barrier, then
     // d m_prev[own tile] = sum over gates and k-tiles
@@ -725,6 +736,7 @@ static int fill_multi(RnnMultiArgs& m, const clsr_gru_desc* grus, int ngru, cons
     a.Hn = Hn; a.T = T; a.n = d.n; a.hT = d.hT; a.out_seq = d.out_seq; a.hprev = d.hprev; a.gates = d.gates;
     a.dhT = d.dhT; a.dout_seq = d.dout_seq; a.dPin = d.dPin; a.dh0 = d.dh0;
     a.lddp = d.lddp > 0 ? d.lddp : 3 * d.n;
+    a.dpin_bf16 = d.dpin_bf16;
     CLSR_CHECK_SUPPORTED(a.lddp % 4 == 0);
     a.att = d.att; a.datt = d.datt; a.in_div = d.in_div > 1 ? d.in_div : 1;
     CLSR_CHECK_ARG(!(backward && d.att && !d.datt));
@@ -740,6 +752,7 @@ static int fill_multi(RnnMultiArgs& m, const clsr_gru_desc* grus, int ngru, cons
     a.len_stride = len_stride; a.Hn = Hn; a.T = T; a.n = t4->n; a.out_seq = t4->out_seq; a.act = t4->act;
     a.cst = t4->cst; a.mprev = t4->mprev; a.dout_seq = t4->dout_seq; a.dPin = t4->dPin;
     a.lddp = t4->lddp > 0 ? t4->lddp : 6 * t4->n;
+    a.dpin_bf16 = t4->dpin_bf16;
     CLSR_CHECK_SUPPORTED(a.lddp % 4 == 0);
   }
   return CLSR_OK;

@@ -105,6 +105,8 @@ class CLSRNet(object):
         self.dw_streams = int(os.environ.get("CLSR_DW_STREAMS", "1"))
         self.fused_l0_bwd = not os.environ.get("CLSR_NO_FUSED_L0_BWD")   # A/B switch (see _att_bwd)
         self.dw_batching = not os.environ.get("CLSR_NO_DW_BATCH")          # A/B switch (see _dw_batched)
+        self.dpin_h = (self.bf16 and self.bf16_dw and self.bf16_bwd and type(self) is CLSRNet
+                       and not os.environ.get("CLSR_NO_DPIN_BF16"))          # bf16 dPin (speed mode, CLSR graph only)
         # where the long-term attention backward forks: beside the short-term one (exact mode: -40 us) or underneath the
         # backward-through-time launch (speed mode: the short-term backward is bandwidth bound there); CLSR_LT_BWD_EARLY=0|1
         self.lt_bwd_early = (os.environ.get("CLSR_LT_BWD_EARLY", "1" if precision == "fp32" else "0") == "1")
@@ -191,7 +193,7 @@ class CLSRNet(object):
         g = lambda k: getattr(hp, k, None)
         return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook),
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
-                self.lazy, self.rnn_first, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early,
+                self.lazy, self.rnn_first, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h,
                 self.split_g2, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
@@ -475,7 +477,7 @@ class CLSRNet(object):
         if (self.bf16 and wkey in self.packed_h and wkey.endswith("^T") and bias is None and Xmul is None and aff is None
                 and addU is None and addV is None and stats is None and T == 0 and K % 8 == 0 and N % 8 == 0):
             Wt, Kp = self.packed_h[wkey]
-            call("clsr_hgemm_f32", X, ldx, Wt, Kp, Y, ldy, acc, M, K, N)
+            call("clsr_hgemm_hf32" if X.dtype == torch.bfloat16 else "clsr_hgemm_f32", X, ldx, Wt, Kp, Y, ldy, acc, M, K, N)
             return
         Wt, Kp = self.packed[wkey]
         sc, sh = (aff.scale, aff.shift) if aff is not None else (None, None)
@@ -491,11 +493,11 @@ class CLSRNet(object):
         need = query("clsr_pgemm_dw_workspace_floats", M, K, N)
         ws = self._buf("dw_ws%s.%d" % (self._ws_tag, len(pend)), max(need, 1))
         sc, sh = (aff.scale, aff.shift) if aff is not None else (None, None)
-        if self._dw_batch is not None and not (x_bf16 or dy_bf16):
+        if self._dw_batch is not None and not x_bf16 and not (dy_bf16 and not (self.bf16 and self.bf16_dw)):
             # inside _dw_batched(): the product joins the ONE multi-job launch issued when the block ends
             ptr = lambda t: 0 if t is None else t.data_ptr()
-            self._dw_batch.append((ptr(X), ptr(Xmul), ptr(sc), ptr(sh), ptr(dY), ptr(ws), 0, ldx, T, G, ldmul, 1, 0,
-                                   ldy, M, K, N, 0))
+            self._dw_batch.append((ptr(X), ptr(Xmul), ptr(sc), ptr(sh), ptr(dY), ptr(ws), 0, ldx, T, G, ldmul, 1,
+                                   int(dy_bf16), ldy, M, K, N, 0))
         elif self.dw_stream and self.overlap and self._ws_tag == "":
             # nothing on the main chain needs a weight gradient before the flush: the partial-sum kernels of the
             # main stream go to a stream of their own (inputs are final at this point and stay untouched until the
@@ -1176,11 +1178,12 @@ class CLSRNet(object):
         Gd, H, NX, E = self.Gd, self.H, self.NX, self.enc_in
         t, M = self._t4_scope, Hn * T
         dPt = dPinAll[:, self._enc_off("t4"):]
-        self._dw(self._buf("t4.mprev", Hn, T, H), H, dPt, NX, M, H, 4 * H, Gd[t + "kernel"][E:], 4 * H)
+        hb = int(dPinAll.dtype == torch.bfloat16)
+        self._dw(self._buf("t4.mprev", Hn, T, H), H, dPt, NX, M, H, 4 * H, Gd[t + "kernel"][E:], 4 * H, dy_bf16=hb)
         if self._t4_kind != "time4lstm":
             return
         TT = self._buf("t4.TT", M, 2 * H)
-        self._dw(TT, 2 * H, dPt[:, 3 * H:], NX, M, 2 * H, 3 * H, self._buf("t4.dTW", 2 * H, 3 * H), 3 * H)
+        self._dw(TT, 2 * H, dPt[:, 3 * H:], NX, M, 2 * H, 3 * H, self._buf("t4.dTW", 2 * H, 3 * H), 3 * H, dy_bf16=hb)
         dTT = self._buf("t4.dTT", M, 2 * H)
         self._gemm(dPt[:, 3 * H:], NX, "t4.tw^T", M, 3 * H, 2 * H, dTT, 2 * H)
         parts = query("clsr_t4_time_inputs_bwd_parts", Hn, T, H)
@@ -1196,9 +1199,10 @@ class CLSRNet(object):
         hprev, gates = self._buf(key + ".hprev", Hn, T, n), self._buf(key + ".gates", Hn, T, 3 * n)
         dP = dPinAll[:, self._enc_off(key):]
         M = Hn * T
-        self._dw(hprev, n, dP, NX, M, n, 2 * n, Gd[scope + "gates/kernel"][D:], 2 * n)
+        hb = int(dPinAll.dtype == torch.bfloat16)
+        self._dw(hprev, n, dP, NX, M, n, 2 * n, Gd[scope + "gates/kernel"][D:], 2 * n, dy_bf16=hb)
         self._dw(hprev, n, dP[:, 2 * n:], NX, M, n, n, Gd[scope + "candidate/kernel"][D:], n, Xmul=gates,
-                 ldmul=3 * n)
+                 ldmul=3 * n, dy_bf16=hb)
 
     # ------------------------------------------------------------------ forward
     def forward(self, f, training, after_attention=None, early_aux=None):
@@ -1431,7 +1435,11 @@ class CLSRNet(object):
         M = Hn * T
         NX = self.NX
         hist = out["hist_input"]
-        dPinAll = self._buf("xw.dPin", M, NX)
+        # speed mode: the gradients of the input projections leave the backward-through-time kernel as bf16 -- their
+        # consumers (input-side / hidden-side weight gradients, d(hist) = dPin . W^T) run on the bf16 matrix pipe anyway
+        dpin_h = (self.dpin_h and "xw^T" in self.packed_h and H % 8 == 0 and Du % 8 == 0 and D % 8 == 0
+                  and (self._t4_kind != "time4lstm" or "t4.tw^T" in self.packed_h))
+        dPinAll = self._buf("xw.dPin", M, NX, dtype=torch.bfloat16 if dpin_h else F32)
         grus, t4d = [], None
         dushort = dsi
         if hp.interest_evolve:
@@ -1462,7 +1470,8 @@ class CLSRNet(object):
         # input-side weights of every encoder in one reduction; d(hist) in one product; the hidden-side / time-feature
         # weight gradients ride in the same multi-job launch as the input-side one (they all depend on dPin only)
         with self._dw_batched():
-            self._dw(hist, D, dPinAll, NX, M, D, NX, self._buf("xw.dW", D, NX), NX, db=self._buf("xw.db", NX))
+            self._dw(hist, D, dPinAll, NX, M, D, NX, self._buf("xw.dW", D, NX), NX, db=self._buf("xw.db", NX),
+                     dy_bf16=int(dpin_h))
             self._gemm(dPinAll, NX, "xw^T", M, NX, D, dhist, D, acc=1)
             if self._t4_kind is not None:
                 self._t4_bwd_weights(f, dPinAll, Hn, T, hs)

@@ -179,13 +179,14 @@ class GruDesc(ctypes.Structure):
                                                "dhT", "dout_seq", "dPin", "dh0")] + \
                [("h0_stride", ctypes.c_long), ("ldp", ctypes.c_int), ("ldg", ctypes.c_int), ("ldc", ctypes.c_int),
                 ("n", ctypes.c_int), ("lddp", ctypes.c_int), ("in_div", ctypes.c_int),
-                ("att", ctypes.c_void_p), ("datt", ctypes.c_void_p)]
+                ("att", ctypes.c_void_p), ("datt", ctypes.c_void_p), ("dpin_bf16", ctypes.c_int), ("pad_", ctypes.c_int)]
 
 
 class T4Desc(ctypes.Structure):
     """ctypes mirror of clsr_t4_desc (include/clsr_hip.h)."""
     _fields_ = [(n, ctypes.c_void_p) for n in ("Pin", "Wm", "out_seq", "act", "cst", "mprev", "dout_seq", "dPin")] + \
-               [("ldp", ctypes.c_int), ("ldm", ctypes.c_int), ("n", ctypes.c_int), ("lddp", ctypes.c_int)]
+               [("ldp", ctypes.c_int), ("ldm", ctypes.c_int), ("n", ctypes.c_int), ("lddp", ctypes.c_int),
+                ("dpin_bf16", ctypes.c_int), ("pad_", ctypes.c_int)]
 
 
 def _ptr(t):
@@ -200,6 +201,7 @@ def gru_desc(n, Pin=None, ldp=0, Wgh=None, ldg=0, Wch=None, ldc=0, h0=None, h0_s
                      dout_seq=dout_seq, dPin=dPin, dh0=dh0, att=att, datt=datt).items():
         setattr(d, k, _ptr(v))
     d.h0_stride, d.ldp, d.ldg, d.ldc, d.n, d.lddp, d.in_div = h0_stride, ldp, ldg, ldc, n, lddp, in_div
+    d.dpin_bf16 = 1 if (dPin is not None and dPin.dtype == torch.bfloat16) else 0
     return d
 
 
@@ -210,6 +212,7 @@ def t4_desc(n, Pin=None, ldp=0, Wm=None, ldm=0, out_seq=None, act=None, cst=None
                      dPin=dPin).items():
         setattr(d, k, _ptr(v))
     d.ldp, d.ldm, d.n, d.lddp = ldp, ldm, n, lddp
+    d.dpin_bf16 = 1 if (dPin is not None and dPin.dtype == torch.bfloat16) else 0
     return d
 
 

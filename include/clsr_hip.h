@@ -164,6 +164,9 @@ int clsr_att_l0_bwd_supported(int G, int Q, int A0);
 int clsr_att_l0_bwd(const float* dz0, int lddz, const float* Wt, int Kp, const float* a, int lda,
                     const float* q, int ldq, long Hn, int G, int T, int Q, int A0, float* da, int ldda,
                     float* dq, int lddq, float* dU, int lddu, float* dV, int lddv, void* stream);
+/* Y[m, :N] (fp32, =|+=) X[m, :K] . W with a bf16 X (the fp32-X form is clsr_hgemm_f32) */
+int clsr_hgemm_hf32(const void* X, int ldx, const void* Wt, int Kp, float* Y, int ldy, int accumulate,
+                    int M, int K, int N, void* stream);
 int clsr_cvt_f32_to_bf16(const float* src, void* dst, long n, void* stream);
 int clsr_cvt_bf16_to_f32(const void* src, float* dst, long n, void* stream);
 int clsr_pgemm_stats_parts(int M);
@@ -263,12 +266,15 @@ typedef struct clsr_gru_desc {
    * sequence per candidate ROW; sequence s reads Pin / seq_len of history s / in_div.  datt [Hn, T] (backward) is
    * accumulated with atomics: zero it first.  Both NULL / in_div <= 1: the plain GRU. */
   const float* att; float* datt;
+  int dpin_bf16; int pad_;   /* dPin is a bf16 tensor (lddp in elements): clsr_rnn_bwd_multi stores the input-projection
+                              * gradients as bf16 for consumers that run on the bf16 matrix pipe (speed mode) */
 } clsr_gru_desc;
 typedef struct clsr_t4_desc {
   const float* Pin; const float* Wm;
   float* out_seq; float* act; float* cst; float* mprev;
   const float* dout_seq; float* dPin;
   int ldp; int ldm; int n; int lddp;
+  int dpin_bf16; int pad_;   /* as in clsr_gru_desc */
 } clsr_t4_desc;
 int clsr_sizeof_gru_desc(void);
 int clsr_sizeof_t4_desc(void);

@@ -113,6 +113,13 @@ def test_hgemm_fp32_in_out_backward_product(M, K, N, ldx, acc):
     torch.cuda.synchronize()
     exp = _r(X) @ _r(W) + (Y0.double() if acc else 0.0)
     _close(Y, exp, 1e-4, 2e-3, "Y")
+    # the same product from a bf16 X (gradients the producer already stored as bf16): identical results
+    Xh = Xw.to(BF)
+    Xs = Xh[:, :K] if ldx == K else Xh[:, 8:8 + K]
+    Y2 = Y0.clone()
+    ops.call("clsr_hgemm_hf32", Xs, ldx, Wt, Kp, Y2, N, acc, M, K, N)
+    torch.cuda.synchronize()
+    assert torch.equal(Y2, Y)
 
 
 @pytest.mark.parametrize("M,C1,C0", [(2000, 40, 80), (515, 40, 80), (300, 80, 136)])

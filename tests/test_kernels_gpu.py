@@ -1016,3 +1016,48 @@ def test_weight_gradient_multi_job_launch(entry):
     for i, (wa, wb) in enumerate(zip(ws_multi, ws_single)):
         assert torch.equal(wa, wb), "job %d differs from its single launch" % i
     assert float(ws_multi[0].abs().max()) > 0
+    if "hdw" in entry:      # bf16 dY (speed mode: dPin stored as bf16): plain and X * Xmul jobs
+        dYh = dYw.to(torch.bfloat16)
+        jobs, pairs = [], []
+        for x0, K, y0, N, xm, aff in specs:
+            if aff:
+                continue
+            need = query("clsr_pgemm_dw_workspace_floats", M, K, N)
+            wa, wb = torch.zeros(need, device="cuda"), torch.zeros(need, device="cuda")
+            pairs.append((wa, wb))
+            X, dY = Xw[:, x0:], dYh[:, y0:]
+            jobs.append((X.data_ptr(), xm.data_ptr() if xm is not None else 0, 0, 0, dY.data_ptr(), wa.data_ptr(), 0, 200, 0,
+                         0, 120 if xm is not None else 0, 1, 1, 480, M, K, N, 0))
+            call(single, X, 0, 200, 0, 0, xm, 120 if xm is not None else 0, None, None, 1, dY, 1, 480, M, K, N, wb)
+        ops.dw_multi(entry, jobs)
+        torch.cuda.synchronize()
+        for i, (wa, wb) in enumerate(pairs):
+            assert torch.equal(wa, wb), "bf16-dY job %d differs from its single launch" % i
+
+
+def test_rnn_backward_with_bf16_input_projection_gradients():
+    """clsr_rnn_bwd_multi with dPin as a bf16 tensor (speed mode): the same values as the fp32 run, rounded once when
+    stored -- GRU + Time4LSTM in one launch, ragged lengths (zeros past the length), column slices of one wide buffer."""
+    g = torch.Generator().manual_seed(21)
+    Hn, T, n = 37, 9, 40
+    NX = 3 * n + 6 * n
+    f = lambda t: dev(t, torch.float32)
+    lens = dev(torch.randint(1, T + 1, (Hn,), generator=g).int())
+    gates, hprev = f(torch.rand(Hn, T, 3 * n, generator=g)), f(rnd(g, Hn, T, n))
+    Wg, Wc = f(rnd(g, n, 2 * n, scale=0.3)), f(rnd(g, n, n, scale=0.3))
+    act, cst = f(torch.rand(Hn, T, 6 * n, generator=g)), f(rnd(g, Hn, T, n))
+    Wm = f(rnd(g, n, 4 * n, scale=0.3))
+    dseq, dhT = f(rnd(g, Hn, T, n)), f(rnd(g, Hn, n))
+    outs = []
+    for dt in (torch.float32, torch.bfloat16):
+        dP = torch.full((Hn * T, NX), 3.0, device="cuda", dtype=dt)
+        gd = ops.gru_desc(n, Wgh=Wg, ldg=2 * n, Wch=Wc, ldc=n, hprev=hprev, gates=gates, dhT=dhT, dout_seq=None,
+                          dPin=dP[:, :3 * n], lddp=NX)
+        td = ops.t4_desc(n, Wm=Wm, ldm=4 * n, act=act, cst=cst, dout_seq=dseq, dPin=dP[:, 3 * n:], lddp=NX)
+        ops.rnn_multi("clsr_rnn_bwd_multi", [gd], td, lens, 1, Hn, T)
+        torch.cuda.synchronize()
+        outs.append(dP)
+    assert float(outs[0].abs().max()) > 0
+    assert torch.equal(outs[1], outs[0].to(torch.bfloat16))
+    valid = (torch.arange(T, device="cuda")[None, :] < lens[:, None]).reshape(-1)
+    assert float(outs[1][~valid].abs().max()) == 0
