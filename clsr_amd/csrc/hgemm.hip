@@ -454,6 +454,211 @@ extern "C" int clsr_hgemm(const void* X, int ldx, const float* in_scale, const f
   return stats ? hgemm_np<HP_BF, HE_NONE, true>(a, s) : hgemm_np<HP_BF, HE_NONE, false>(a, s);
 }
 
+// ------------------------------------------------------------------------------------ layer 0, one wave per history
+// z0[r,t,:] (bf16) = U[h,t,:] + V[r,:] + (a[h,t,:] * q[r,:]) . Wp with the G rows of a history group handled by ONE
+// wave: it walks the history's 16-step tiles and, inside a tile, the rows of the group, so a[h,t,:] and U[h,t,:] are
+// loaded once per tile (the position-tiled kernel above re-reads them for every row: 1.3 GB through L2 at 1M
+// positions), q[r,:] and V[r,:] sit in LDS.  Same orientation, weights image and statistics as hgemm_kernel<MUL, UV>.
+#define HL0_GMAX 8
+struct HL0Args {
+  const float* a; int lda;
+  const float* q; int ldq;
+  const __bf16* Wt; int Kp;
+  const float* U; int ldu;
+  const float* V; int ldv;
+  __bf16* z0; int ldz;
+  double* stats;
+  long Hn;
+  int G, T, Q, A0;
+};
+
+template <int NP, int KT, bool STATS>
+__global__ void __launch_bounds__(256, 2) hgemm_l0g_kernel(HL0Args s) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int NT = 2 * NP, NR = 32 * NP, KTP = 32 * KT;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int j = lane & 15, g = lane >> 4;
+  const int Kp = s.Kp;
+  __bf16* Wl = reinterpret_cast<__bf16*>(lds_raw);
+  size_t off = ((size_t)NR * Kp * 2 + 15) & ~(size_t)15;
+  float* qs = reinterpret_cast<float*>(lds_raw + off) + (size_t)wave * HL0_GMAX * (KTP + NR);
+  float* vs = qs + HL0_GMAX * KTP;
+  off += (size_t)4 * HL0_GMAX * (KTP + NR) * 4;
+  double* red = reinterpret_cast<double*>(lds_raw + off);   // [4 waves][2][NR]
+  {
+    const int Kq = Kp >> 3;
+    const int nrows = 32 * ((s.A0 + 31) >> 5);
+    const bf16x8 z8 = {};
+    for (int e = tid; e < NR * Kq; e += 256) {
+      const int row = e / Kq, c = e - row * Kq;
+      reinterpret_cast<bf16x8*>(Wl)[e] = row < nrows ? ld8h(s.Wt + (long)row * Kp + 8 * c) : z8;
+    }
+    if (STATS) for (int e = tid; e < 4 * 2 * NR; e += 256) red[e] = 0.0;
+  }
+  __syncthreads();
+  const __bf16* ldsA = Wl + (long)j * Kp + 8 * g;
+  bool nok[NP];
+  int ncl[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    nok[p] = 32 * p + 8 * g < s.A0;
+    ncl[p] = nok[p] ? 32 * p + 8 * g : 0;
+  }
+  float fsum[STATS ? NP : 1][8], fsq[STATS ? NP : 1][8];
+  int pending = 0;
+  if (STATS) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { fsum[p][r] = 0.f; fsq[p][r] = 0.f; }
+  }
+  auto flush = [&]() {
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float s_ = row16_sum(fsum[p][r]);
+        const float q_ = row16_sum(fsq[p][r]);
+        if (j == 0) {
+          red[(wave * 2 + 0) * NR + 32 * p + 8 * g + r] += (double)s_;
+          red[(wave * 2 + 1) * NR + 32 * p + 8 * g + r] += (double)q_;
+        }
+        fsum[p][r] = 0.f;
+        fsq[p][r] = 0.f;
+      }
+  };
+  const int G = s.G, T = s.T, NTT = (T + 15) >> 4;
+  const bf16x8 z8 = {};
+
+  for (long h = (long)blockIdx.x * 4 + wave; h < s.Hn; h += (long)gridDim.x * 4) {
+    for (int e = lane; e < G * KTP; e += 64) {
+      const int gg = e / KTP, n = e - gg * KTP;
+      qs[e] = n < s.Q ? s.q[(h * G + gg) * s.ldq + n] : 0.f;
+    }
+    for (int e = lane; e < G * NR; e += 64) {
+      const int gg = e / NR, n = e - gg * NR;
+      vs[e] = n < s.A0 ? s.V[(h * G + gg) * s.ldv + n] : 0.f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int tt = 0; tt < NTT; ++tt) {
+      const int t = 16 * tt + j;
+      const bool valid = t < T;
+      const long xr = h * T + (valid ? t : T - 1);
+      f32x8 at[KT], ut[NP];     // (a next-tile prefetch of these 48 registers was measured: 91 -> 97 us, dropped)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) at[kt] = ld8f(s.a + xr * s.lda + (32 * kt + 8 * g < s.Q ? 32 * kt + 8 * g : 0));
+#pragma unroll
+      for (int p = 0; p < NP; ++p) ut[p] = ld8f(s.U + xr * s.ldu + ncl[p]);
+      // (arrive before the loop over the rows: see att_l0_fwd_kernel)
+#if defined(__HIP_DEVICE_COMPILE__)   // ("v" is an x86 vector-register constraint in the host pass)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) asm volatile("" ::"v"(at[kt]));
+#pragma unroll
+      for (int p = 0; p < NP; ++p) asm volatile("" ::"v"(ut[p]));
+#endif
+      for (int gg = 0; gg < G; ++gg) {
+        f32x4 acc[NT];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const f32x8 v = ut[p] + ld8f(vs + gg * NR + 32 * p + 8 * g);
+          acc[2 * p] = (f32x4){v[0], v[1], v[2], v[3]};
+          acc[2 * p + 1] = (f32x4){v[4], v[5], v[6], v[7]};
+        }
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          const bf16x8 b = 32 * kt + 8 * g < s.Q ? to_h(at[kt] * ld8f(qs + gg * KTP + 32 * kt + 8 * g)) : z8;
+#pragma unroll
+          for (int tl = 0; tl < NT; ++tl) HMFMA(acc[tl], ld8h(ldsA + (long)(16 * tl) * Kp + kt * 32), b);
+        }
+        const long m = (h * G + gg) * T + t;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const bool ok = valid && nok[p];
+          const f32x4 lo = acc[2 * p], hi = acc[2 * p + 1];
+          const f32x8 v0 = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          const bf16x8 out = to_h(v0);
+          if (ok) __builtin_nontemporal_store(out, reinterpret_cast<bf16x8*>(s.z0 + m * s.ldz + ncl[p]));
+          if (STATS) {
+            const f32x8 v = to_f(out);   // statistics of the STORED (rounded) values
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float x = ok ? v[e] : 0.f;
+              fsum[p][e] += x;
+              fsq[p][e] = fmaf(x, x, fsq[p][e]);
+            }
+          }
+        }
+        if (STATS && ++pending == 32) {
+          flush();
+          pending = 0;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (STATS) {
+    if (pending) flush();
+    __syncthreads();
+    for (int e = tid; e < 2 * NR; e += 256) {
+      const int which = e / NR, c = e - which * NR;
+      if (c < s.A0) {
+        double t = 0.0;
+        for (int w = 0; w < 4; ++w) t += red[(w * 2 + which) * NR + c];
+        s.stats[((long)blockIdx.x * 2 + which) * s.A0 + c] = t;
+      }
+    }
+  }
+}
+
+static int hl0_grid(long Hn) {
+  long gx = (Hn + 3) / 4;
+  return (int)(gx > 512 ? 512 : gx);
+}
+// 1 when clsr_hgemm_l0_group handles this shape (otherwise clsr_hgemm_mul_uv); only groups of several rows gain
+extern "C" int clsr_hgemm_l0_group_supported(int G, int Q, int A0) {
+  return G >= 2 && G <= HL0_GMAX && Q >= 8 && Q <= 96 && A0 >= 8 && A0 <= 96 && Q % 8 == 0 && A0 % 8 == 0;
+}
+extern "C" int clsr_hgemm_l0_group_stats_parts(long Hn) { return hl0_grid(Hn); }
+
+template <int NP, int KT>
+static int hl0_launch(const HL0Args& a, hipStream_t stream) {
+  size_t shmem = (((size_t)32 * NP * a.Kp * 2 + 15) & ~(size_t)15) + (size_t)4 * HL0_GMAX * (32 * KT + 32 * NP) * 4 +
+                 (size_t)4 * 2 * 32 * NP * 8;
+  dim3 grid(hl0_grid(a.Hn));
+  if (a.stats) {
+    auto kernel = hgemm_l0g_kernel<NP, KT, true>;
+    if (shmem > 64 * 1024) CLSR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(kernel, grid, dim3(256), shmem, stream, a);
+  } else {
+    auto kernel = hgemm_l0g_kernel<NP, KT, false>;
+    if (shmem > 64 * 1024) CLSR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(kernel, grid, dim3(256), shmem, stream, a);
+  }
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+extern "C" int clsr_hgemm_l0_group(const float* a, int lda, const float* q, int ldq, const void* Wt, int Kp,
+                                   const float* U, int ldu, const float* V, int ldv, void* z0, int ldz, double* stats,
+                                   long Hn, int G, int T, int Q, int A0, void* stream) {
+  CLSR_CHECK_ARG(a && q && Wt && U && V && z0 && Hn > 0 && T > 0);
+  CLSR_CHECK_SUPPORTED(clsr_hgemm_l0_group_supported(G, Q, A0));
+  CLSR_CHECK_SUPPORTED(lda % 4 == 0 && ldu % 4 == 0 && ldz % 8 == 0 && Kp % 8 == 0 && ((uintptr_t)a % 16) == 0 &&
+                       ((uintptr_t)U % 16) == 0 && ((uintptr_t)z0 % 16) == 0);
+  CLSR_CHECK_ARG(lda >= Q && ldq >= Q && Kp >= 32 * clsr_cdiv(Q, 32) && ldu >= A0 && ldv >= A0 && ldz >= A0);
+  HL0Args s = {};
+  s.a = a; s.lda = lda; s.q = q; s.ldq = ldq; s.Wt = (const __bf16*)Wt; s.Kp = Kp; s.U = U; s.ldu = ldu; s.V = V;
+  s.ldv = ldv; s.z0 = (__bf16*)z0; s.ldz = ldz; s.stats = stats; s.Hn = Hn; s.G = G; s.T = T; s.Q = Q; s.A0 = A0;
+  hipStream_t st = (hipStream_t)stream;
+  const int np = clsr_cdiv(A0, 32), kt = clsr_cdiv(Q, 32);
+#define HL0_GO(P, K) if (np == P && kt == K) return hl0_launch<P, K>(s, st)
+  HL0_GO(1, 1); HL0_GO(1, 2); HL0_GO(1, 3); HL0_GO(2, 1); HL0_GO(2, 2); HL0_GO(2, 3); HL0_GO(3, 1); HL0_GO(3, 2); HL0_GO(3, 3);
+#undef HL0_GO
+  return CLSR_OK;
+}
+
 // Backward through the second attention layer and the batch-norm + ReLU below it, the [M, C1] gradient dz1 never
 // round-tripping through memory:   x = dz1[m, :C1] = a1*dy1 + a2*z1 + a3  (BN-1 backward; dy1 = ds[m] * w_out where
 // relu(bn1(z1)) > 0, recomputed from z1 and the score gradient ds), dh0 = x . W1^T, dy0 = dh0 where relu(bn0(z0)) > 0.

@@ -952,8 +952,15 @@ class CLSRNet(object):
             sbuf = self._buf("stats" + self._ws_tag, 1024 * 2 * 256, dtype=torch.float64)
             st = sbuf[: parts * 2 * A0] if training else None
             Wt, Kp = self.packed_h[key + ".Wp"]
-            call("clsr_hgemm_mul_uv", a, Q, T, G, q, Q, Wt, Kp, U, A0, V, A0, z0, A0, st, M, Q, A0)
-            self._bn_fwd(bn0, st, parts, M, training)
+            if self.l0_fwd_wave and query("clsr_hgemm_l0_group_supported", G, Q, A0):
+                # one wave per history group: a / U loaded once per 16 steps and re-used for the G rows
+                p0 = query("clsr_hgemm_l0_group_stats_parts", Hn) if training else 0
+                call("clsr_hgemm_l0_group", a, Q, q, Q, Wt, Kp, U, A0, V, A0, z0, A0,
+                     sbuf[: p0 * 2 * A0] if training else None, Hn, G, T, Q, A0)
+                self._bn_fwd(bn0, sbuf[: p0 * 2 * A0] if training else None, p0, M, training)
+            else:
+                call("clsr_hgemm_mul_uv", a, Q, T, G, q, Q, Wt, Kp, U, A0, V, A0, z0, A0, st, M, Q, A0)
+                self._bn_fwd(bn0, st, parts, M, training)
             st = sbuf[: parts * 2 * A1] if training else None
             Wt, Kp = self.packed_h[key + ".W1"]
             call("clsr_hgemm", z0, A0, bn0.scale, bn0.shift, 1, Wt, Kp, P[nn + "b_nn_layer1"], z1, A1, st, M, A0, A1)
@@ -1664,7 +1671,9 @@ class CLSRNet(object):
         flops = 2.0 * B * T * Qs * A0
         bf = self.precision == "bf16"
         peak = 2500.0 if bf else 157.3
-        return dict(bound="mfma", kernel=("hgemm_kernel<MUL,UV> (short-term attention layer 0, bf16 MFMA)" if bf else
+        return dict(bound="mfma", kernel=(("hgemm_l0g_kernel (short-term attention layer 0, bf16 MFMA, one wave per history group)"
+                                           if self.l0_fwd_wave and query("clsr_hgemm_l0_group_supported", G, Qs, A0) else
+                                           "hgemm_kernel<MUL,UV> (short-term attention layer 0, bf16 MFMA)") if bf else
                                           "att_l0_fwd_kernel<5,5> (short-term attention layer 0, one wave per history)"
                                           if self._att_layer0_wave(G, Qs) else
                                           "pgemm_fast_kernel<5,MUL,UV,false> (short-term attention layer 0)"),
@@ -1681,6 +1690,8 @@ class CLSRNet(object):
         if self.bf16:
             z0 = self._buf(key + ".z0", R * T, A0, dtype=torch.bfloat16)
             Wt, Kp = self.packed_h[key + ".Wp"]
+            if self.l0_fwd_wave and query("clsr_hgemm_l0_group_supported", G, Q, A0):
+                return lambda: call("clsr_hgemm_l0_group", a, Q, q, Q, Wt, Kp, U, A0, V, A0, z0, A0, None, Hn, G, T, Q, A0)
             return lambda: call("clsr_hgemm_mul_uv", a, Q, T, G, q, Q, Wt, Kp, U, A0, V, A0, z0, A0, None, R * T, Q, A0)
         z0 = self._buf(key + ".z0", R * T, A0)
         Wt, Kp = self.packed[key + ".Wp"]

@@ -164,6 +164,13 @@ int clsr_att_l0_bwd_supported(int G, int Q, int A0);
 int clsr_att_l0_bwd(const float* dz0, int lddz, const float* Wt, int Kp, const float* a, int lda,
                     const float* q, int ldq, long Hn, int G, int T, int Q, int A0, float* da, int ldda,
                     float* dq, int lddq, float* dU, int lddu, float* dV, int lddv, void* stream);
+/* clsr_hgemm_mul_uv with one wave per history group (a, U read once per 16 steps of a history and re-used for its G
+ * rows; same packed bf16 weights image, same statistics layout with clsr_hgemm_l0_group_stats_parts(Hn) partial rows) */
+int clsr_hgemm_l0_group_supported(int G, int Q, int A0);
+int clsr_hgemm_l0_group_stats_parts(long Hn);
+int clsr_hgemm_l0_group(const float* a, int lda, const float* q, int ldq, const void* Wt, int Kp,
+                        const float* U, int ldu, const float* V, int ldv, void* z0, int ldz, double* stats,
+                        long Hn, int G, int T, int Q, int A0, void* stream);
 /* Y[m, :N] (fp32, =|+=) X[m, :K] . W with a bf16 X (the fp32-X form is clsr_hgemm_f32) */
 int clsr_hgemm_hf32(const void* X, int ldx, const void* Wt, int Kp, float* Y, int ldy, int accumulate,
                     int M, int K, int N, void* stream);

@@ -75,6 +75,36 @@ def test_hgemm_mul_uv(Hn, G, T, Q, N):
     _close(sq, (Yd * Yd).sum(0), 1e-5, 1e-3, "column sums of squares")
 
 
+@pytest.mark.parametrize("Hn,G,T,Q,N", [(37, 5, 10, 80, 80), (9, 3, 50, 40, 80), (5, 8, 17, 96, 72), (130, 2, 33, 24, 40)])
+def test_hgemm_layer0_one_wave_per_group(Hn, G, T, Q, N):
+    """clsr_hgemm_l0_group == clsr_hgemm_mul_uv (same packed weights, same rounding points): z0 bit for bit, the
+    batch-norm column sums to fp32 summation noise."""
+    assert ops.query("clsr_hgemm_l0_group_supported", G, Q, N) == 1 and ops.query("clsr_hgemm_l0_group_supported", 1, Q, N) == 0
+    g = torch.Generator().manual_seed(Hn + T)
+    R, M = Hn * G, Hn * G * T
+    a, q = torch.randn(Hn * T, Q, generator=g).to(DEV), torch.randn(R, Q, generator=g).to(DEV)
+    U, V = torch.randn(Hn * T, N, generator=g).to(DEV), torch.randn(R, N, generator=g).to(DEV)
+    W = (torch.randn(Q, N, generator=g) * 0.2).to(DEV)
+    Wt, Kp, keep = _pack_h(W, N, Q)
+    z_ref = torch.zeros(M, N, dtype=BF, device=DEV)
+    p_ref = ops.query("clsr_hgemm_stats_parts", M)
+    st_ref = torch.zeros(p_ref * 2 * N, dtype=torch.float64, device=DEV)
+    ops.call("clsr_hgemm_mul_uv", a, Q, T, G, q, Q, Wt, Kp, U, N, V, N, z_ref, N, st_ref, M, Q, N)
+    z = torch.full((M, N + 8), 3.0, dtype=BF, device=DEV)
+    parts = ops.query("clsr_hgemm_l0_group_stats_parts", Hn)
+    st = torch.full((parts * 2 * N,), 7.0, dtype=torch.float64, device=DEV)
+    ops.call("clsr_hgemm_l0_group", a, Q, q, Q, Wt, Kp, U, N, V, N, z, N + 8, st, Hn, G, T, Q, N)
+    z2 = torch.zeros(M, N, dtype=BF, device=DEV)
+    ops.call("clsr_hgemm_l0_group", a, Q, q, Q, Wt, Kp, U, N, V, N, z2, N, None, Hn, G, T, Q, N)
+    torch.cuda.synchronize()
+    assert torch.equal(z[:, :N], z_ref) and torch.equal(z2, z_ref)
+    assert float((z[:, N:].float() - 3.0).abs().max()) == 0
+    s1, s2 = _stats(st, parts, N)
+    r1, r2 = _stats(st_ref, p_ref, N)
+    _close(s1, r1, 1e-6, 1e-3, "column sums")
+    _close(s2, r2, 1e-6, 1e-3, "column sums of squares")
+
+
 @pytest.mark.parametrize("M,K,N,aff", [(1000, 80, 40, True), (333, 80, 80, False), (4097, 40, 80, True), (50, 136, 264, True)])
 def test_hgemm_affine_relu_prologue(M, K, N, aff):
     g = torch.Generator().manual_seed(2)
