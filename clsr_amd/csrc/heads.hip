@@ -421,7 +421,10 @@ extern "C" int clsr_contrastive(const float* L, const float* S, const float* M, 
   CLSR_CHECK_ARG(L && S && M && R && seq_len && denom_ptr && loss_out && Hn > 0 && G > 0);
   CLSR_CHECK_ARG((dL && dS && dM && dR) || (!dL && !dS && !dM && !dR));
   CLSR_CHECK_SUPPORTED(mode == 1 || D <= 256);  // bpr keeps the history-level vectors in registers
-  int blocks = Hn > 4096 ? 4096 : (int)Hn;
+  // a SMALL grid on purpose: this kernel runs on a side stream beside the first alpha-gate GEMM of the main chain; with
+  // 4096 one-wave blocks the dispatcher was busy issuing them and the GEMM's 160 workgroups (20 us alone) took 83 us
+  static const int cap = getenv("CLSR_CONTRASTIVE_BLOCKS") ? atoi(getenv("CLSR_CONTRASTIVE_BLOCKS")) : 1024;
+  int blocks = Hn > cap ? cap : (int)Hn;
   hipLaunchKernelGGL(contrastive_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, L, S, M, R,
                      seq_len, len_stride, Hn, G, D, threshold, mode, margin, weight, denom_ptr, loss_out,
                      dL, dS, dM, dR);
