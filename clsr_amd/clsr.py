@@ -286,8 +286,7 @@ class SequentialBaseModel(BaseModel):
         """All device work of the model runs on one private HIP stream: launches on the legacy
         default stream pay an implicit-synchronisation tax per kernel (measured 200 us vs 10 us)."""
         if self._stream is None:
-            # high priority: the dependent chain of a step runs here, the net's side streams fill in around it
-            self._stream = torch.cuda.Stream(device=self.net.device, priority=-1)
+            self._stream = torch.cuda.Stream(device=self.net.device)
         return torch.cuda.stream(self._stream)
 
     def _stage(self, feed, lookahead=False):
