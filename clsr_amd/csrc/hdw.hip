@@ -15,6 +15,7 @@
 // written in pgemm_dw's layout and summed by the same clsr_dw_reduce_batch launch.
 #include "common.h"
 #include "clsr_hip.h"
+#include <cstdlib>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
@@ -214,7 +215,8 @@ __global__ void __launch_bounds__(256, 3) hdw_multi_kernel(HdwMultiArgs m) {
 static int hdw_grid_x(int M) {
   int tiles = clsr_cdiv(M, 64);
   int gx = clsr_cdiv(tiles, 4);
-  if (gx > 512) gx = 512;
+  static const int cap = getenv("CLSR_DW_PARTS") ? atoi(getenv("CLSR_DW_PARTS")) : 384;   // blocks per chunk (512: 35 us more per speed-mode step in partial-sum traffic; 256: too few waves)
+  if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
   return gx;
 }

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include "common.h"
 #include "clsr_hip.h"
+#include <cstdlib>
 
 struct PGemmArgs {
   const float* X; int ldx;
@@ -920,7 +921,8 @@ __global__ void __launch_bounds__(1024) dw_reduce_kernel(const float* __restrict
 static int dw_grid_x(int M) {
   int tiles = clsr_cdiv(M, 64);
   int gx = clsr_cdiv(tiles, 4);  // >= 4 position tiles per block before adding blocks
-  if (gx > 512) gx = 512;
+  static const int cap = getenv("CLSR_DW_PARTS") ? atoi(getenv("CLSR_DW_PARTS")) : 384;   // blocks per chunk (512: 35 us more per speed-mode step in partial-sum traffic; 256: too few waves)
+  if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
   return gx;
 }
