@@ -1,0 +1,35 @@
+"""Isolated timing of the fused recurrence launches at configs[1] shapes.  usage: python scripts/bench_rnn.py"""
+import sys, torch
+sys.path.insert(0, "/root/repo")
+from clsr_amd import ops
+dev = "cuda:0"
+def timeit(fn, iters=10, warm=3):
+    s = torch.cuda.current_stream()
+    for _ in range(warm): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for _ in range(iters): fn()
+    e1.record(s); e1.synchronize()
+    return e0.elapsed_time(e1) * 1000 / iters
+st = torch.cuda.Stream()
+with torch.cuda.stream(st):
+    Hn, T, n = 4096, 50, 40
+    NX = 3 * n * 2 + 6 * n
+    lens = torch.full((Hn,), T, dtype=torch.int32, device=dev)
+    Pin = torch.randn(Hn * T, NX, device=dev) * 0.3
+    Wg, Wc, Wm = torch.randn(n, 2 * n, device=dev) * 0.2, torch.randn(n, n, device=dev) * 0.2, torch.randn(n, 4 * n, device=dev) * 0.2
+    def gru(off, train=True):
+        return ops.gru_desc(n, Pin=Pin[:, off:], ldp=NX, Wgh=Wg, ldg=2 * n, Wch=Wc, ldc=n,
+                            hT=torch.zeros(Hn, n, device=dev), hprev=torch.zeros(Hn, T, n, device=dev) if train else None,
+                            gates=torch.zeros(Hn, T, 3 * n, device=dev) if train else None)
+    def t4(train=True):
+        return ops.t4_desc(n, Pin=Pin[:, 6 * n:], ldp=NX, Wm=Wm, ldm=4 * n, out_seq=torch.zeros(Hn, T, n, device=dev),
+                           act=torch.zeros(Hn, T, 6 * n, device=dev) if train else None,
+                           cst=torch.zeros(Hn, T, n, device=dev) if train else None,
+                           mprev=torch.zeros(Hn, T, n, device=dev) if train else None)
+    g1, g2, t = gru(0), gru(3 * n), t4()
+    print("fwd  t4 only (training)     : %6.1f us" % timeit(lambda: ops.rnn_multi("clsr_rnn_fwd_multi", [], t, lens, 1, Hn, T)))
+    te = t4(False)
+    print("fwd  t4 only (scoring)      : %6.1f us" % timeit(lambda: ops.rnn_multi("clsr_rnn_fwd_multi", [], te, lens, 1, Hn, T)))
+    print("fwd  one gru (training)     : %6.1f us" % timeit(lambda: ops.rnn_multi("clsr_rnn_fwd_multi", [g1], None, lens, 1, Hn, T)))
+    print("fwd  gru + gru + t4         : %6.1f us" % timeit(lambda: ops.rnn_multi("clsr_rnn_fwd_multi", [g1, g2], t, lens, 1, Hn, T)))
