@@ -59,6 +59,8 @@ def main():
         rows = [
             ("z0 = U+V+(a*q).Wp + stats   W 164 MB, R 130 MB (L2 x5)", 294,
              lambda: call("clsr_hgemm_mul_uv", a, Q, T, G, q, Q, Wp_h, Kp, U, A0, V, A0, z0, A0, st, M, Q, A0)),
+            ("z0, one wave per history group W 164 MB, R 130 MB (L2 x1)", 294,
+             lambda: call("clsr_hgemm_l0_group", a, Q, q, Q, Wp_h, Kp, U, A0, V, A0, z0, A0, st, Hn, G, T, Q, A0)),
             ("z1 = relu(bn z0).W1 + stats  R 164, W 82", 246,
              lambda: call("clsr_hgemm", z0, A0, sc0, sh0, 1, W1_h, K1, sh1, z1, A1, st, M, A0, A1)),
             ("l1 bwd pass 1 (stats)        R 82 + 164", 246,

@@ -9,9 +9,9 @@ bash scripts/prof_step.sh ${tag}_fp32
 bash scripts/prof_step.sh ${tag}_bf16 --precision bf16
 cd /tmp && export TMPDIR=/tmp
 # rocprofv3 --kernel-trace --stats of the bench command itself (what the bench line's kernel durations must agree with)
-rm -rf /tmp/pb && rocprofv3 --kernel-trace --stats -d /tmp/pb -o bench -- python $root/bench.py --no-cpu-baseline --no-extra > /tmp/pb.log 2>&1
-grep "^{\"metric" /tmp/pb.log | tail -1 > $out/${tag}_bench_line_traced.json; tail -5 /tmp/pb.log
-f=$(find /tmp/pb -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/${tag}_bench_kernel_stats.csv; find /tmp/pb | head
+rm -rf /tmp/pb && rocprofv3 --kernel-trace --stats --output-format rocpd -d /tmp/pb -o bench -- python $root/bench.py --no-cpu-baseline > /tmp/pb.log 2>&1
+grep "^{\"metric" /tmp/pb.log | tail -1 > $out/${tag}_bench_line_traced.json
+f=$(find /tmp/pb -name "*.db" | head -1); [ -n "$f" ] && python $root/scripts/rocpd_stats.py $f > $out/${tag}_bench_kernel_stats.md
 # HBM traffic of the gather kernel: separate --pmc passes (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2)
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c && rocprofv3 --kernel-trace --pmc $c --kernel-include-regex gather_hist_fwd --output-format csv -d /tmp/pmc_$c -o g -- python $root/scripts/prof_kernels.py gather > /tmp/pmc_$c.log 2>&1
