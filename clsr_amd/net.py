@@ -105,6 +105,7 @@ class CLSRNet(object):
         self.dw_streams = int(os.environ.get("CLSR_DW_STREAMS", "1"))
         self.fused_l0_bwd = not os.environ.get("CLSR_NO_FUSED_L0_BWD")   # A/B switch (see _att_bwd)
         self.dw_batching = not os.environ.get("CLSR_NO_DW_BATCH")          # A/B switch (see _dw_batched)
+        self.flush_side = not os.environ.get("CLSR_NO_FLUSH_SIDE")          # A/B switch (dense path off the main stream)
         self.dpin_h = (self.bf16 and self.bf16_dw and self.bf16_bwd and type(self) is CLSRNet
                        and not os.environ.get("CLSR_NO_DPIN_BF16"))          # bf16 dPin (speed mode, CLSR graph only)
         # where the long-term attention backward forks: beside the short-term one (exact mode: -40 us) or underneath the
@@ -193,7 +194,7 @@ class CLSRNet(object):
         g = lambda k: getattr(hp, k, None)
         return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook),
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
-                self.lazy, self.rnn_first, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h,
+                self.lazy, self.rnn_first, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h, self.flush_side,
                 self.split_g2, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
@@ -415,12 +416,12 @@ class CLSRNet(object):
             return None
         return ops.event_record(ops.current_stream())
 
-    def _join(self, only=None):
-        """The current stream waits for the finished branches (all of them, or those of stream ``only``)."""
+    def _join(self, only=None, but=None):
+        """The current stream waits for the finished branches (all of them, those named ``only``, or all ``but`` one)."""
         main = ops.current_stream()
         keep = []
         for tag, ev in self._joins:
-            if only is None or tag == only:
+            if (only is None or tag == only) and tag != but:
                 ops.stream_wait(main, ev)
             else:
                 keep.append((tag, ev))
@@ -569,10 +570,10 @@ class CLSRNet(object):
         self._rp_pending.setdefault(self._ws_tag, []).append(
             (partial.data_ptr(), out.data_ptr(), 1.0, parts, stride, n, 0, 0))
 
-    def _dw_flush(self):
-        """Reduce the partial chunks of every ``_dw`` issued on the current stream since the last flush, then
-        run the operations that were waiting for those gradients."""
-        tag = self._ws_tag
+    def _dw_flush(self, tag=None):
+        """Reduce the partial chunks of every ``_dw`` issued under workspace tag ``tag`` (default: the current
+        stream's) since the last flush, then run the operations that were waiting for those gradients."""
+        tag = self._ws_tag if tag is None else tag
         pend = self._dw_pending.pop(tag, [])
         if tag == "" and self._dw_async:
             for i in range(self.dw_streams):
@@ -1488,11 +1489,17 @@ class CLSRNet(object):
                 self._gru_bwd_hidden("g1", st + "short_term_intention/gru_cell/", Du, dPinAll, Hn, T)
             if (not hp.manual_alpha) and hp.predict_long_short:
                 self._gru_bwd_hidden("g2", CL + "causal2/causal2/gru_cell/", H, dPinAll, Hn, T)
-        self._dw_flush()          # one batched reduction of every weight gradient of the main stream
-        self._unpack_grads()
         # ---- join the long-term attention branch; its d(hist) contribution was accumulated separately
         self._join()
-        self._dp_hook("dense_ready")          # every dense gradient is final: all-reduce under the embedding kernels
+        if self.flush_side and self.overlap and self.dw_stream:
+            # the dense path from here on (batched reduction of every weight gradient, unpacking, later the dense
+            # regulariser + Adam) does not meet the embedding path (gradient tables, table regulariser / Adam) again:
+            # it stays on the weight-gradient stream, where the last partial-sum kernel has just finished, and the main
+            # stream goes straight to the embedding gradients (the reduction used to sit between them: ~140 us)
+            with self._branch("@dw0", after=self._fork_point(), name="@dense"):
+                self._dense_grads_final()
+        else:
+            self._dense_grads_final()
         call("clsr_axpby", dhist, dhist, 1.0, dhist_lt, 1.0, dhist.numel())
         # ---- embedding gradients (IndexedSlices values -> dense grad tables + squared norms)
         ss = self.sumsq_tab
@@ -1514,7 +1521,7 @@ class CLSRNet(object):
                 self._dp_hook("table_ready", "user_short")
                 call("clsr_scatter_add_rows", dtarget, D, 0, f["items"], 1, B, Di, self.tab_grad["item"], ss[2:])
             self._hist_grad_sorted(dhist, dM, dR, Hn, T, seq_len, ls, ss, only="item")
-            self._join()
+            self._join(but="@dense")
             self._dp_hook("table_ready", "item")
         else:
             call("clsr_gather_hist_bwd", dhist, dM, dR, f["item_history"], f["item_cate_history"], hs * T, seq_len,
@@ -1527,7 +1534,16 @@ class CLSRNet(object):
                 self._dp_hook("table_ready", k)
         if apply:
             self._apply_updates()
+        elif self.dp_hooks is None:
+            self._join()              # callers that read the gradients themselves: everything back on this stream
         return out
+
+    def _dense_grads_final(self):
+        """One batched reduction of every weight gradient of the main stream (joins the weight-gradient stream),
+        the assembled blocks go back to their variables, and the data-parallel exchange is told."""
+        self._dw_flush(tag="")
+        self._unpack_grads()
+        self._dp_hook("dense_ready")          # every dense gradient is final: all-reduce under the embedding kernels
 
     def _sort_tables(self):
         return (("item", "item_history", self.dims["Vi"], 0, self.Di, 0),
@@ -1605,6 +1621,7 @@ class CLSRNet(object):
         clip = float(hp.max_grad_norm) if hp.is_clip_norm else 0.0
         # dense variables (regulariser + norms, Adam clock, Adam) on the @aux stream beside the table regulariser
         with self._branch("@main" if (self.capture_grads or not self.split_emb_grad) else "@aux"):
+            self._join(only="@dense")     # (the batched weight-gradient reduction, see _train_step)
             call("clsr_dense_reg_norm", self.dense, self.dense_grad, self.seg_off, len(self.dense_names),
                  float(hp.layer_l2), self.dense_sumsq, self.losses[1:])
             if not self.capture_grads:

@@ -407,17 +407,17 @@ def test_overlapped_exchange_is_issued_after_the_joins_that_finish_its_data(gold
     dense = by_ptr[net.dense_grad.data_ptr()]
     if not planned:      # (a replayed plan does not rebuild the python-side bookkeeping the recorder looks at)
         assert dense[4] == [] and dense[5] == {}, "dense all-reduce issued before the joins / the dW flush: %r" % (dense,)
-    assert dense[3] == main
+    assert dense[3] != main, "the dense path (batched reduction, all-reduce) runs on the weight-gradient stream"
     flags = by_ptr[net.tab_flags_flat.data_ptr()]
     assert d.log.index(flags) < d.log.index(dense), "the byte maps are exchanged from the start of the step"
     assert flags[3] != main, "flags ride on the side stream that marked them"
     item = by_ptr[net.tab_grad["item"].data_ptr()]
-    if not planned:
-        assert item[4] == [], "item table all-reduce issued before the final join"
+    if not planned:     # (the dense branch is independent of the tables: it is joined by the optimiser, not here)
+        assert item[4] in ([], ["@dense"]), "item table all-reduce issued before the final join"
     assert item[3] == main
     for k in ("cate", "user_long", "user_short"):
         e = by_ptr[net.tab_grad[k].data_ptr()]
-        assert d.log.index(dense) < d.log.index(e) < d.log.index(item), k
+        assert d.log.index(flags) < d.log.index(e) < d.log.index(item), k
         assert e[3] != main, "table %s is exchanged from the side stream that finished it" % k
     small = by_ptr[net.stats24.data_ptr()]
     assert d.log.index(small) > d.log.index(item)
