@@ -106,6 +106,7 @@ class CLSRNet(object):
         self.fused_l0_bwd = not os.environ.get("CLSR_NO_FUSED_L0_BWD")   # A/B switch (see _att_bwd)
         self.dw_batching = not os.environ.get("CLSR_NO_DW_BATCH")          # A/B switch (see _dw_batched)
         self.flush_side = not os.environ.get("CLSR_NO_FLUSH_SIDE")          # A/B switch (dense path off the main stream)
+        self.l1_bwd_2pass = not os.environ.get("CLSR_NO_L1_BWD_2PASS")      # A/B switch (exact mode, see _att_bwd)
         self.dpin_h = (self.bf16 and self.bf16_dw and self.bf16_bwd and type(self) is CLSRNet
                        and not os.environ.get("CLSR_NO_DPIN_BF16"))          # bf16 dPin (speed mode, CLSR graph only)
         # where the long-term attention backward forks: beside the short-term one (exact mode: -40 us) or underneath the
@@ -194,7 +195,7 @@ class CLSRNet(object):
         g = lambda k: getattr(hp, k, None)
         return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook),
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
-                self.lazy, self.rnn_first, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h, self.flush_side,
+                self.lazy, self.rnn_first, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h, self.flush_side, self.l1_bwd_2pass,
                 self.split_g2, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
@@ -1068,10 +1069,25 @@ class CLSRNet(object):
                 call("clsr_att_prod_bwd_h", daq, Q, a, Q, q, Q, Hn, G, T, Q, da, Q, dq, Q, 0)
                 call("clsr_att_z0_bwd_reduce_h", dz0, Hn, G, T, A0, dU, dV)
             return self._att_bwd_hist(key, scope, nn, a, q, keys, dkeys, dU, dV, da, dq, dW0, Hn, R, T, Dk, Q, 0)
-        call("clsr_att_dy1_apply", z1, ds, bn1.scale, bn1.shift, P[nn + "w_nn_output"], bn1.coef, R * T, A1, dz1)
-        # layer 1: z1 = relu(bn0(z0)) . W1 + b1
-        self._dw(z0, A0, dz1, A1, R * T, A0, A1, Gd[nn + "w_nn_layer1"], A1, db=Gd[nn + "b_nn_layer1"], aff=bn0)
-        self._gemm_bnbwd(dz1, A1, key + ".W1^T", R * T, A1, A0, dz0, bn0, z0)
+        if self.l1_bwd_2pass and query("clsr_att_l1_bwd_supported", A1, A0):
+            # two passes over (z1, z0) with dz1 recomputed in the GEMM prologue: the batch-norm sums of layer 0, then the
+            # finished dz0 (+ dz1 for the weight gradient) -- no dy1-apply / bn-apply sweeps (csrc/attl1bwd.hip)
+            M = R * T
+            Wt, Kp = self.packed[key + ".W1^T"]
+            parts = query("clsr_att_l1_bwd_stats_parts", M)
+            st = self._buf("stats" + self._ws_tag, 1024 * 2 * 256, dtype=torch.float64)[: parts * 2 * A0]
+            wo = P[nn + "w_nn_output"]
+            call("clsr_att_l1_bwd", z1, A1, ds, bn1.scale, bn1.shift, wo, bn1.coef, Wt, Kp, z0, A0, bn0.scale,
+                 bn0.shift, bn0.mean, bn0.invstd, None, None, 0, None, 0, st, M, A1, A0)
+            self._bn_bwd_coef(bn0, st, parts, M)
+            call("clsr_att_l1_bwd", z1, A1, ds, bn1.scale, bn1.shift, wo, bn1.coef, Wt, Kp, z0, A0, bn0.scale,
+                 bn0.shift, None, None, bn0.coef, dz1, A1, dz0, A0, None, M, A1, A0)
+            self._dw(z0, A0, dz1, A1, M, A0, A1, Gd[nn + "w_nn_layer1"], A1, db=Gd[nn + "b_nn_layer1"], aff=bn0)
+        else:
+            call("clsr_att_dy1_apply", z1, ds, bn1.scale, bn1.shift, P[nn + "w_nn_output"], bn1.coef, R * T, A1, dz1)
+            # layer 1: z1 = relu(bn0(z0)) . W1 + b1
+            self._dw(z0, A0, dz1, A1, R * T, A0, A1, Gd[nn + "w_nn_layer1"], A1, db=Gd[nn + "b_nn_layer1"], aff=bn0)
+            self._gemm_bnbwd(dz1, A1, key + ".W1^T", R * T, A1, A0, dz0, bn0, z0)
         # layer 0 (re-associated): z0 = U[h,t] + V[r] + (a[h,t]*q[r]) . Wp
         if qh:
             Q2 = Q - qh

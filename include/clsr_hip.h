@@ -149,6 +149,18 @@ int clsr_att_l0_bwd_h_supported(int G, int Q, int A0);
 int clsr_att_l0_bwd_h(const void* dz0, int lddz, const void* Wt, const void* Wu, int Kp, const float* a, int lda,
                       const float* q, int ldq, long Hn, int G, int T, int Q, int A0, float* da, int ldda,
                       float* dq, int lddq, float* dU, int lddu, float* dV, int lddv, void* stream);
+/* Exact-mode backward through the second attention layer + the batch-norm / ReLU below it in TWO passes over (z1, z0)
+ * (csrc/attl1bwd.hip; the fp32 twin of clsr_hgemm_att_l1_bwd, same arguments with fp32 tensors): dz1 is recomputed from
+ * (z1, ds) in the GEMM prologue; pass 1 (coef0 == NULL) writes the per-block BN-0 backward sums
+ * [clsr_att_l1_bwd_stats_parts(M)][2][C0]; pass 2 (coef0 given) writes dz0 and dz1.  Replaces clsr_att_dy1_apply +
+ * clsr_pgemm_bnbwd + clsr_bn_bwd_apply where clsr_att_l1_bwd_supported(C1, C0). */
+int clsr_att_l1_bwd_supported(int C1, int C0);
+int clsr_att_l1_bwd_stats_parts(int M);
+int clsr_att_l1_bwd(const float* z1, int ldz1, const float* ds, const float* scale1, const float* shift1,
+                    const float* w_out, const float* coef1, const float* Wt, int Kp, const float* z0, int ldz0,
+                    const float* scale0, const float* shift0, const float* mean0, const float* invstd0,
+                    const float* coef0, float* dz1, int lddz1, float* dz0, int lddz0, double* stats, int M,
+                    int C1, int C0, void* stream);
 /* Re-associated first attention layer, exact mode, one wave per history (csrc/attl0fwd.hip):
  *   z0[r,t,:] = U[h,t,:] + V[r,:] + (a[h,t,:] * q[r,:]) . Wp,   stats = per-block partial column sums / sums of squares
  *   [clsr_att_l0_fwd_stats_parts(Hn)][2][A0] doubles (NULL: none).  Wt = packed Wp (clsr_pack_batch: A0 rows, K = Q).

@@ -1061,3 +1061,58 @@ def test_rnn_backward_with_bf16_input_projection_gradients():
     assert torch.equal(outs[1], outs[0].to(torch.bfloat16))
     valid = (torch.arange(T, device="cuda")[None, :] < lens[:, None]).reshape(-1)
     assert float(outs[1][~valid].abs().max()) == 0
+
+
+@pytest.mark.parametrize("M,C1,C0", [(2000, 40, 80), (515, 40, 80), (300, 48, 128), (70, 12, 20), (4099, 40, 36)])
+def test_attention_layer1_backward_two_passes_fp32(M, C1, C0):
+    """clsr_att_l1_bwd: dz1 recomputed from (z1, ds) -> dh0 = dz1 . W1^T -> ReLU / batch-norm backward of layer 0: the
+    statistics pass and the apply pass == float64, and == the three kernels they replace (dy1-apply, GEMM with the
+    fused BN sums, bn-apply)."""
+    assert query("clsr_att_l1_bwd_supported", C1, C0) == 1 and query("clsr_att_l1_bwd_supported", 64, C0) == 0
+    g = torch.Generator().manual_seed(3)
+    f = lambda t: dev(t, torch.float32)
+    z1, z0, ds = rnd(g, M, C1), rnd(g, M, C0), rnd(g, M)
+    W1 = rnd(g, C0, C1, scale=0.3)                            # layer-1 weight [in = C0, out = C1]
+    sc1, sh1 = torch.rand(C1, generator=g, dtype=torch.float64) + 0.5, rnd(g, C1, scale=0.3)
+    wo, coef1 = rnd(g, C1), rnd(g, 3 * C1, scale=0.5)
+    sc0, sh0 = torch.rand(C0, generator=g, dtype=torch.float64) + 0.5, rnd(g, C0, scale=0.3)
+    mean0, inv0 = rnd(g, C0, scale=0.1), torch.rand(C0, generator=g, dtype=torch.float64) + 0.5
+    coef0 = rnd(g, 3 * C0, scale=0.5)
+    Wt, Kp = ops.pack_weight(dev(W1, torch.float32), C0, C1, transposed=True)   # dh0 = dz1 . W1^T: out = C0, in = C1
+    d = {k: f(v) for k, v in dict(z1=z1, z0=z0, ds=ds, sc1=sc1, sh1=sh1, wo=wo, coef1=coef1, sc0=sc0, sh0=sh0, mean0=mean0,
+                                  inv0=inv0, coef0=coef0).items()}
+    parts = query("clsr_att_l1_bwd_stats_parts", M)
+    st = torch.full((parts, 2, C0), 7.0, dtype=torch.float64, device="cuda")
+    call("clsr_att_l1_bwd", d["z1"], C1, d["ds"], d["sc1"], d["sh1"], d["wo"], d["coef1"], Wt, Kp, d["z0"], C0, d["sc0"],
+         d["sh0"], d["mean0"], d["inv0"], None, None, 0, None, 0, st, M, C1, C0)
+    dz1 = torch.full((M, C1), 7.0, device="cuda")
+    dz0 = torch.full((M, C0 + 4), 7.0, device="cuda")
+    call("clsr_att_l1_bwd", d["z1"], C1, d["ds"], d["sc1"], d["sh1"], d["wo"], d["coef1"], Wt, Kp, d["z0"], C0, d["sc0"],
+         d["sh0"], None, None, d["coef0"], dz1, C1, dz0, C0 + 4, None, M, C1, C0)
+    torch.cuda.synchronize()
+    y1 = z1 * sc1 + sh1
+    a1, a2, a3 = coef1[:C1], coef1[C1:2 * C1], coef1[2 * C1:]
+    x = torch.where(y1 > 0, (a1 * wo) * ds[:, None], torch.zeros_like(y1)) + a2 * z1 + a3
+    close(dz1, x, rtol=1e-5, atol=1e-5, name="dz1")
+    dh0 = x @ W1.t()
+    y0 = z0 * sc0 + sh0
+    dy0 = torch.where(y0 > 0, dh0, torch.zeros_like(dh0))
+    xhat = (z0 - mean0) * inv0
+    scale = float(dy0.abs().sum(0).max())
+    close(st.sum(0)[0], dy0.sum(0), rtol=1e-5, atol=1e-6 * scale, name="sum dy0")
+    close(st.sum(0)[1], (dy0 * xhat).sum(0), rtol=1e-5, atol=2e-6 * scale, name="sum dy0 * xhat0")
+    c1, c2, c3 = coef0[:C0], coef0[C0:2 * C0], coef0[2 * C0:]
+    close(dz0[:, :C0], c1 * dy0 + c2 * z0 + c3, rtol=1e-5, atol=2e-5, name="dz0")
+    assert float((dz0[:, C0:] - 7.0).abs().max()) == 0
+    # the path it replaces
+    dz1_b = torch.zeros(M, C1, device="cuda")
+    call("clsr_att_dy1_apply", d["z1"], d["ds"], d["sc1"], d["sh1"], d["wo"], d["coef1"], M, C1, dz1_b)
+    p2 = query("clsr_pgemm_stats_parts", M)
+    st2 = torch.zeros(p2, 2, C0, dtype=torch.float64, device="cuda")
+    dy0_b = torch.zeros(M, C0, device="cuda")
+    call("clsr_pgemm_bnbwd", dz1_b, C1, Wt, Kp, dy0_b, C0, d["z0"], C0, d["sc0"], d["sh0"], d["mean0"], d["inv0"], st2, M, C1, C0)
+    call("clsr_bn_bwd_apply", dy0_b, d["z0"], d["coef0"], M, C0)
+    torch.cuda.synchronize()
+    close(dz1, dz1_b, rtol=1e-6, atol=1e-6, name="dz1 vs dy1-apply kernel")
+    close(st.sum(0), st2.sum(0), rtol=1e-6, atol=1e-6 * scale, name="BN sums vs clsr_pgemm_bnbwd")
+    close(dz0[:, :C0], dy0_b, rtol=1e-5, atol=2e-5, name="dz0 vs GEMM + bn-apply kernels")
