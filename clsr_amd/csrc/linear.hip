@@ -692,7 +692,9 @@ struct DwArgs {
 // (bx, gx) = this block's index / the number of blocks along the positions, (by, bz, gz) = its K / N chunk: blockIdx and
 // gridDim for a launch of its own, a job's share of the grid in a multi-job launch (dw_multi_kernel)
 #define DW_LDS_FLOATS (64 * 2 * DW_W > 2 * DW_CHUNK ? 64 * 2 * DW_W : 2 * DW_CHUNK)
-template <int MODE, bool XH = false, bool YH = false>  // 0 plain, 1 X*Xmul[r], 2 relu(X*in_scale + in_shift)
+// KTC / NTC > 0: the chunk's tile counts are compile-time constants (single-chunk products of the common shapes): the
+// MFMA block then has no scalar compare + branch per tile and schedules as one straight run
+template <int MODE, bool XH = false, bool YH = false, int KTC = 0, int NTC = 0>  // 0 plain, 1 X*Xmul[r], 2 relu(X*in_scale + in_shift)
 __device__ __forceinline__ void dw_body(const DwArgs& a, float* lds, const int bx, const int gx, const int by,
                                         const int bz, const int gz) {
   float* Xs = lds;
@@ -700,8 +702,8 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, float* lds, const int b
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i = lane & 15, g = lane >> 4;
   const int k0 = by * DW_W, n0 = bz * DW_W;
-  const int ktc = min(DW_T, ((a.K + 15) >> 4) - by * DW_T);
-  const int ntc = min(DW_T, ((a.N + 15) >> 4) - bz * DW_T);
+  const int ktc = KTC ? KTC : min(DW_T, ((a.K + 15) >> 4) - by * DW_T);
+  const int ntc = NTC ? NTC : min(DW_T, ((a.N + 15) >> 4) - bz * DW_T);
   const int kmax4 = ((a.K + 3) & ~3) - 4, nmax4 = a.N - 4;
 
   f32x4 acc[DW_T][DW_T];
@@ -846,10 +848,10 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, float* lds, const int b
   }
 }
 
-template <int MODE, bool XH = false, bool YH = false>
+template <int MODE, bool XH = false, bool YH = false, int KTC = 0, int NTC = 0>
 __global__ void __launch_bounds__(256) pgemm_dw_kernel(DwArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[DW_LDS_FLOATS];
-  dw_body<MODE, XH, YH>(a, lds, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z, gridDim.z);
+  dw_body<MODE, XH, YH, KTC, NTC>(a, lds, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z, gridDim.z);
 }
 
 // Several weight gradients in ONE launch: job j owns the blocks [first[j], first[j+1]) of the 1-D grid.  The hidden-to-
@@ -960,6 +962,19 @@ static int dw_launch_partial(const void* X, int ldx, int T, int G, const float* 
     *gx_out = gx;
     return CLSR_OK;
   }
+  const int ktn = clsr_cdiv(K, 16), ntn = clsr_cdiv(N, 16);
+  const bool one = kch == 1 && nch == 1 && !getenv("CLSR_DW_GENERIC");
+#define DW_SPEC(MD, KT_, NT_)                                                                                          \
+  if (one && ktn == KT_ && ntn == NT_) {                                                                               \
+    hipLaunchKernelGGL((pgemm_dw_kernel<MD, false, false, KT_, NT_>), dim3(gx, 1, 1), dim3(256), 0, s, a);            \
+    CLSR_CHECK_LAUNCH();                                                                                               \
+    *gx_out = gx;                                                                                                      \
+    return CLSR_OK;                                                                                                    \
+  }
+  if (Xmul) { DW_SPEC(1, 5, 5) DW_SPEC(1, 3, 3) }
+  else if (in_scale) { DW_SPEC(2, 5, 3) DW_SPEC(2, 5, 5) }
+  else { DW_SPEC(0, 5, 5) DW_SPEC(0, 3, 5) DW_SPEC(0, 3, 3) DW_SPEC(0, 5, 3) }
+#undef DW_SPEC
   if (Xmul) hipLaunchKernelGGL(pgemm_dw_kernel<1>, dim3(gx, kch, nch), dim3(256), 0, s, a);
   else if (in_scale) hipLaunchKernelGGL(pgemm_dw_kernel<2>, dim3(gx, kch, nch), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(pgemm_dw_kernel<0>, dim3(gx, kch, nch), dim3(256), 0, s, a);

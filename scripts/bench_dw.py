@@ -54,6 +54,12 @@ def main():
         t0 = timeit(lambda: call("clsr_pgemm_dw_partial_h", a, 0, 80, 50, 5, q, 80, None, None, 1, dz0, 1, 80, M2, 80, 80, ws))
         t1 = timeit(lambda: call("clsr_hdw_partial", a, 0, 80, 50, 5, q, 80, None, None, 1, dz0, 1, 80, M2, 80, 80, ws))
         print("dWp (a*q fp32, dz0 bf16)    M=1M K=80 N=80: fp32 %.1f us  bf16-mfma %.1f us  (164 MB + L2)" % (t0, t1))
+        # the exact-mode (all fp32) forms of the same two products
+        z0f, dz1f, dz0f = z0.float(), dz1.float(), dz0.float()
+        t0 = timeit(lambda: call("clsr_pgemm_dw_partial", z0f, 80, 0, 0, None, 0, sc, sh, 1, dz1f, 40, M2, 80, 40, ws))
+        print("dW1 all fp32 (exact mode)   M=1M K=80 N=40: fp32 %.1f us  (492 MB, 6.5 GFLOP)" % t0)
+        t0 = timeit(lambda: call("clsr_pgemm_dw_partial", a, 80, 50, 5, q, 80, None, None, 1, dz0f, 80, M2, 80, 80, ws))
+        print("dWp all fp32 (exact mode)   M=1M K=80 N=80: fp32 %.1f us  (328 MB + L2, 13.1 GFLOP)" % t0)
         # projection GEMMs
         W = torch.randn(40, 480, device=dev) * 0.1
         Wt, Kp = ops.pack_weight(W, 480, 40)
