@@ -492,7 +492,9 @@ static int launch_pgemm(const PGemmArgs& a, hipStream_t stream) {
   const bool st = a.stats != nullptr;
   const int KTn = clsr_cdiv(a.K, 16);
   const bool upfront = !getenv("CLSR_PGEMM_STREAM");   // A/B switch: loads one k-tile ahead instead of all up front
-  const bool ring = !a.no_ring && a.M <= 65536 && KTn > 5;   // few positions, wide K: latency bound (see the kernel)
+  // few positions, wide K: latency bound (see the kernel); also the skinny d(hist) = dPin . W^T product (K = 480 -> 40
+  // columns: 30 k-tiles per wave-tile, 100 -> 132 VGPRs with the ring)
+  const bool ring = !a.no_ring && KTn > 5 && (a.M <= 65536 || (OT == 3 && KTn >= 16 && !getenv("CLSR_PGEMM_NO_RING_WIDE")));
 #define CLSR_FAST(P, E, S)                                                                          \
   if (uv_ok && pro == (P) && epi == (E) && st == (S)) {                                             \
     /* (the X * Xmul variant holds twice the operands: with everything in flight it drops to one wave per SIMD and loses) */ \
