@@ -56,7 +56,12 @@ __global__ void __launch_bounds__(256, 2) att_l0_fwd_kernel(AttL0FwdArgs s) {
   const float* ldsB = Wl + (long)j * Kp + 4 * g4;   // + 16 z Kp + 16 kk
 
   const int G = s.G, T = s.T;
-  const int NTT = (T + 15) >> 4;
+  // the ragged last tile of a history (T % 16 steps) is PACKED across the G rows of the group when they fit into one
+  // tile: T = 50, G = 5 -> 3 full tiles per row + one tile with the 5 x 2 left-over positions = 16 MFMA tiles per
+  // history instead of 20 (the matrix pipe is what this kernel waits for)
+  const int rem = T & 15;
+  const bool packed = rem > 0 && G * rem <= 16;
+  const int NTT = packed ? T >> 4 : (T + 15) >> 4;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   double d1[NZ], d2[NZ];
 #pragma unroll
@@ -99,12 +104,9 @@ __global__ void __launch_bounds__(256, 2) att_l0_fwd_kernel(AttL0FwdArgs s) {
     float s1[NZ], s2[NZ];
 #pragma unroll
     for (int z = 0; z < NZ; ++z) { s1[z] = 0.f; s2[z] = 0.f; }
-    // the next tile's operands are requested BEFORE this tile's stores: loads and stores retire through one in-order
-    // counter, so a load issued behind 100 stores would wait for their write acknowledgements
-    Tile nxt = load_tile(0);
+    // (a register prefetch of the next tile's operands was measured: no gain, 40 VGPRs)
     for (int tt = 0; tt < NTT; ++tt) {
-      Tile cur = nxt;
-      if (tt + 1 < NTT) nxt = load_tile(tt + 1);
+      Tile cur = load_tile(tt);
       const int t0 = 16 * tt;
       const bool fullT = t0 + 16 <= T;
       const bool pv = t0 + j < T;
@@ -186,6 +188,66 @@ __global__ void __launch_bounds__(256, 2) att_l0_fwd_kernel(AttL0FwdArgs s) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
       }
+    }
+    if (packed) {
+      const int np = G * rem, T0 = T - rem;
+      const bool pv = j < np;                         // A operand: lane j = packed position j = (row j / rem, step j % rem)
+      const int gi = pv ? j / rem : 0, ti = T0 + (pv ? j - gi * rem : 0);
+      f32x4 x[NK];
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) {
+        const int kc = 16 * kk + 4 * g4;
+        x[kk] = (pv && kc < s.Q) ? ld4(s.a + (h * T + ti) * s.lda + kc) * ld4(qs + gi * QP + kc) : z4;
+      }
+      f32x4 acc[NZ];
+      bool vp[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {                    // result layout: this lane's positions 4 g4 + e
+        const int p = 4 * g4 + e;
+        vp[e] = p < np;
+        const int gp = vp[e] ? p / rem : 0, tp = T0 + (vp[e] ? p - gp * rem : 0);
+        const float* up = s.U + (h * T + tp) * s.ldu;
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) acc[z][e] = up[ncl[z]] + vs[gp * ZP + 16 * z + j];
+      }
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) {
+        f32x4 w[NZ];
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) w[z] = ld4(ldsB + (long)z * 16 * Kp + 16 * kk);
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) MFMA4(acc[z], x[kk].x, w[z].x);
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) MFMA4(acc[z], x[kk].y, w[z].y);
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) MFMA4(acc[z], x[kk].z, w[z].z);
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) MFMA4(acc[z], x[kk].w, w[z].w);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) {
+          tb[(4 * g4 + e) * TS + 16 * z + j] = acc[z][e];
+          const float v = vp[e] ? acc[z][e] : 0.f;
+          s1[z] += v;
+          s2[z] = fmaf(v, v, s2[z]);
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      constexpr int C4t = ZP / 4;
+#pragma unroll
+      for (int i = 0; i < (16 * C4t + 63) / 64; ++i) {
+        const int idx = lane + 64 * i;
+        const int row = idx / C4t, c4 = idx - row * C4t;
+        if (idx < 16 * C4t && row < np && 4 * c4 < s.A0) {
+          const int gr = row / rem, tr = T0 + row - gr * rem;
+          __builtin_nontemporal_store(ld4(tb + row * TS + 4 * c4),
+                                      reinterpret_cast<f32x4*>(s.z0 + ((h * G + gr) * T + tr) * s.ldz + 4 * c4));
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
     }
     // at most 4 * NTT * G values per lane and feature since the last flush: fp32 partials -> double accumulators
 #pragma unroll

@@ -943,7 +943,8 @@ def test_fused_layer0_backward_reductions_fp32(Hn, G, T, Q, A0):
 
 
 @pytest.mark.parametrize("Hn,G,T,Q,A0", [(37, 5, 50, 80, 80), (64, 1, 50, 40, 80), (9, 8, 7, 44, 36), (6, 3, 17, 24, 40),
-                                         (1, 5, 1, 80, 80), (2100, 2, 33, 48, 80)])
+                                         (1, 5, 1, 80, 80), (2100, 2, 33, 48, 80), (11, 8, 18, 80, 80), (5, 4, 20, 40, 80),
+                                         (7, 5, 16, 80, 40), (3, 2, 8, 16, 16)])   # packed / unpacked ragged tiles
 def test_attention_layer0_forward_one_wave_per_history(Hn, G, T, Q, A0):
     """clsr_att_l0_fwd: z0 = U[h,t] + V[r] + (a[h,t] * q[r]) . Wp with the batch-norm column sums == float64, and ==
     clsr_pgemm with the Xmul prologue / addU + addV epilogue (the kernel it replaces)."""
