@@ -527,7 +527,10 @@ __global__ void __launch_bounds__(256, 2) hgemm_l0g_kernel(HL0Args s) {
         fsq[p][r] = 0.f;
       }
   };
-  const int G = s.G, T = s.T, NTT = (T + 15) >> 4;
+  // (the ragged last tile of a history is packed across the G rows when they fit into one tile: see att_l0_fwd_kernel)
+  const int G = s.G, T = s.T, rem = T & 15;
+  const bool packed = rem > 0 && G * rem <= 16;
+  const int NTT = packed ? T >> 4 : (T + 15) >> 4;
   const bf16x8 z8 = {};
 
   for (long h = (long)blockIdx.x * 4 + wave; h < s.Hn; h += (long)gridDim.x * 4) {
@@ -593,6 +596,48 @@ __global__ void __launch_bounds__(256, 2) hgemm_l0g_kernel(HL0Args s) {
           flush();
           pending = 0;
         }
+      }
+    }
+    if (packed) {   // lane j = packed position j = (row j / rem, step T - rem + j % rem): every operand is per lane
+      const int np = G * rem;
+      const bool valid = j < np;
+      const int gj = valid ? j / rem : 0, tj = T - rem + (valid ? j - gj * rem : 0);
+      const long xr = h * T + tj;
+      f32x4 acc[NT];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const f32x8 v = ld8f(s.U + xr * s.ldu + ncl[p]) + ld8f(vs + gj * NR + 32 * p + 8 * g);
+        acc[2 * p] = (f32x4){v[0], v[1], v[2], v[3]};
+        acc[2 * p + 1] = (f32x4){v[4], v[5], v[6], v[7]};
+      }
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const int kc = 32 * kt + 8 * g;
+        const bf16x8 b = (valid && kc < s.Q) ? to_h(ld8f(s.a + xr * s.lda + kc) * ld8f(qs + gj * KTP + kc)) : z8;
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) HMFMA(acc[tl], ld8h(ldsA + (long)(16 * tl) * Kp + kt * 32), b);
+      }
+      const long m = (h * G + gj) * T + tj;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const bool ok = valid && nok[p];
+        const f32x4 lo = acc[2 * p], hi = acc[2 * p + 1];
+        const f32x8 v0 = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const bf16x8 out = to_h(v0);
+        if (ok) __builtin_nontemporal_store(out, reinterpret_cast<bf16x8*>(s.z0 + m * s.ldz + ncl[p]));
+        if (STATS) {
+          const f32x8 v = to_f(out);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float x = ok ? v[e] : 0.f;
+            fsum[p][e] += x;
+            fsq[p][e] = fmaf(x, x, fsq[p][e]);
+          }
+        }
+      }
+      if (STATS && ++pending == 32) {
+        flush();
+        pending = 0;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");

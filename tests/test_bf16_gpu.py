@@ -75,7 +75,8 @@ def test_hgemm_mul_uv(Hn, G, T, Q, N):
     _close(sq, (Yd * Yd).sum(0), 1e-5, 1e-3, "column sums of squares")
 
 
-@pytest.mark.parametrize("Hn,G,T,Q,N", [(37, 5, 10, 80, 80), (9, 3, 50, 40, 80), (5, 8, 17, 96, 72), (130, 2, 33, 24, 40)])
+@pytest.mark.parametrize("Hn,G,T,Q,N", [(37, 5, 10, 80, 80), (9, 3, 50, 40, 80), (5, 8, 17, 96, 72), (130, 2, 33, 24, 40),
+                                        (41, 5, 50, 80, 80), (6, 8, 18, 80, 80), (7, 4, 16, 40, 40), (3, 2, 5, 16, 24)])
 def test_hgemm_layer0_one_wave_per_group(Hn, G, T, Q, N):
     """clsr_hgemm_l0_group == clsr_hgemm_mul_uv (same packed weights, same rounding points): z0 bit for bit, the
     batch-norm column sums to fp32 summation noise."""
