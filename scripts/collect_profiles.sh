@@ -21,4 +21,7 @@ done
 cd $root
 python scripts/bench_hgemm.py > $out/${tag}_hgemm_isolated.txt 2>&1
 python scripts/bench_dw.py > $out/${tag}_dw_isolated.txt 2>&1
+python scripts/bench_att_fp32.py > $out/${tag}_att_fp32_isolated.txt 2>&1
+python scripts/bench_rnn.py > $out/${tag}_rnn_isolated.txt 2>&1
+python scripts/bench_small_gemm.py > $out/${tag}_small_gemm_isolated.txt 2>&1
 ls -la $out | tail -20
