@@ -114,6 +114,7 @@ struct TablesArgs {
   float l2;
   const float* ucount;
   double* reg_loss;
+  float l1;
   float clip_norm;
   const double* adam_state;
   float b1, b2, eps;
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(256) tables_reg_multi_kernel(TablesArgs a) {
     const long row = e / C;
     if (!d.flags[row]) continue;
     const float p = d.table[e];
-    float g = a.l2 * p;
+    float g = a.l2 * p + a.l1 * (float)((p > 0.f) - (p < 0.f));
     if (d.partner) {
       const float df = p - d.partner[e];
       g += cd * df;
@@ -139,13 +140,13 @@ __global__ void __launch_bounds__(256) tables_reg_multi_kernel(TablesArgs a) {
     }
     d.grad[e] += g;
     ss += (double)g * g;
-    rl += (double)p * p;
+    rl += 0.5 * (double)a.l2 * p * p + (double)a.l1 * fabsf(p);
   }
   __shared__ double red[3][4];
   ss = block256_sum_d(ss, red[0]); rl = block256_sum_d(rl, red[1]); dl = block256_sum_d(dl, red[2]);
   if (threadIdx.x == 0) {
     if (ss != 0.0) atomicAdd(d.sumsq_reg, ss);
-    if (a.reg_loss && rl != 0.0) atomicAdd(a.reg_loss, 0.5 * (double)a.l2 * rl);
+    if (a.reg_loss && rl != 0.0) atomicAdd(a.reg_loss, rl);
     if (d.disc_loss && dl != 0.0) atomicAdd(d.disc_loss, (double)cl * dl);
   }
 }
@@ -163,14 +164,14 @@ static int fill_tables(TablesArgs& a, const clsr_table_desc* descs, int n, long*
   return CLSR_OK;
 }
 
-extern "C" int clsr_tables_reg_multi(const clsr_table_desc* descs, int n, float l2, const float* ucount,
+extern "C" int clsr_tables_reg_multi(const clsr_table_desc* descs, int n, float l2, float l1, const float* ucount,
                                      double* reg_loss, void* stream) {
   TablesArgs a = {};
   long mx = 0;
   int rc = fill_tables(a, descs, n, &mx);
   if (rc) return rc;
   for (int i = 0; i < n; ++i) CLSR_CHECK_ARG(descs[i].sumsq_reg && (!descs[i].partner || ucount));
-  a.l2 = l2; a.ucount = ucount; a.reg_loss = reg_loss;
+  a.l2 = l2; a.l1 = l1; a.ucount = ucount; a.reg_loss = reg_loss;
   int blocks = clsr_cdiv(mx, 256 * 8);
   if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(tables_reg_multi_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, a);

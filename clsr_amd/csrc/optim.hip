@@ -30,11 +30,11 @@ extern "C" int clsr_adam_tick(double* state, double lr, double beta1, double bet
   return CLSR_OK;
 }
 
-// One block per dense tensor: grad += l2 * param; sumsq[tensor] = ||grad||^2;
-// reg_loss += l2 * 0.5 * ||param||^2.
+// One block per dense tensor: grad += l2 * param + l1 * sign(param); sumsq[tensor] = ||grad||^2;
+// reg_loss += l2 * 0.5 * ||param||^2 + l1 * |param|_1   (base_model.py:118-147: _l2_loss / _l1_loss of the layer params)
 __global__ void __launch_bounds__(1024) dense_reg_norm_kernel(const float* __restrict__ param,
                                                              float* __restrict__ grad,
-                                                             const int* __restrict__ seg_off, float l2,
+                                                             const int* __restrict__ seg_off, float l2, float l1,
                                                              double* __restrict__ sumsq,
                                                              double* __restrict__ reg_loss) {
   // 1024 threads: the largest tensor (25.6 k elements) is 25 dependent iterations instead of 100; the 16 wave
@@ -45,10 +45,10 @@ __global__ void __launch_bounds__(1024) dense_reg_norm_kernel(const float* __res
   double ss = 0.0, pp = 0.0;
   for (int e = lo + threadIdx.x; e < hi; e += 1024) {
     const float p = param[e];
-    const float g = grad[e] + l2 * p;
+    const float g = grad[e] + l2 * p + l1 * (float)((p > 0.f) - (p < 0.f));
     grad[e] = g;
     ss += (double)g * g;
-    pp += (double)p * p;
+    pp += 0.5 * (double)l2 * p * p + (double)l1 * fabsf(p);
   }
   ss = wave_sum_d(ss);
   pp = wave_sum_d(pp);
@@ -58,15 +58,15 @@ __global__ void __launch_bounds__(1024) dense_reg_norm_kernel(const float* __res
     double a = 0.0, r = 0.0;
     for (int w = 0; w < 16; ++w) { a += red[0][w]; r += red[1][w]; }
     sumsq[seg] = a;
-    if (reg_loss) atomicAdd(reg_loss, 0.5 * (double)l2 * r);
+    if (reg_loss) atomicAdd(reg_loss, r);
   }
 }
 
 extern "C" int clsr_dense_reg_norm(const float* param, float* grad, const int* seg_off, int nseg,
-                                   float l2, double* sumsq, double* reg_loss, void* stream) {
+                                   float l2, float l1, double* sumsq, double* reg_loss, void* stream) {
   CLSR_CHECK_ARG(param && grad && seg_off && sumsq && nseg > 0);
   hipLaunchKernelGGL(dense_reg_norm_kernel, dim3(nseg), dim3(1024), 0, (hipStream_t)stream, param, grad,
-                     seg_off, l2, sumsq, reg_loss);
+                     seg_off, l2, l1, sumsq, reg_loss);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
@@ -135,7 +135,7 @@ extern "C" int clsr_count_flags(const unsigned char* flags, long V, float* count
 // These are the values of the reference's third IndexedSlices (the tf.unique "involved" lookup).
 __global__ void __launch_bounds__(256) table_reg_kernel(
     const float* __restrict__ table, const float* __restrict__ partner,
-    const unsigned char* __restrict__ flags, long V, int C, float l2, float disc_scale,
+    const unsigned char* __restrict__ flags, long V, int C, float l2, float l1, float disc_scale,
     float disc_loss_scale, const float* __restrict__ count, float* __restrict__ grad_table,
     double* __restrict__ sumsq, double* __restrict__ reg_loss, double* __restrict__ disc_loss) {
   const float cd = partner ? disc_scale / (count[0] * (float)C) : 0.f;
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(256) table_reg_kernel(
     const long row = e / C;
     if (!flags[row]) continue;
     const float p = table[e];
-    float g = l2 * p;
+    float g = l2 * p + l1 * (float)((p > 0.f) - (p < 0.f));
     if (partner) {
       const float d = p - partner[e];
       g += cd * d;
@@ -154,19 +154,19 @@ __global__ void __launch_bounds__(256) table_reg_kernel(
     }
     grad_table[e] += g;
     ss += (double)g * g;
-    rl += (double)p * p;
+    rl += 0.5 * (double)l2 * p * p + (double)l1 * fabsf(p);
   }
   __shared__ double red[3][4];
   ss = block256_sum_d(ss, red[0]); rl = block256_sum_d(rl, red[1]); dl = block256_sum_d(dl, red[2]);
   if (threadIdx.x == 0) {
     if (ss != 0.0) atomicAdd(sumsq, ss);
-    if (reg_loss && rl != 0.0) atomicAdd(reg_loss, 0.5 * (double)l2 * rl);
+    if (reg_loss && rl != 0.0) atomicAdd(reg_loss, rl);
     if (disc_loss && dl != 0.0) atomicAdd(disc_loss, (double)cl * dl);
   }
 }
 
 extern "C" int clsr_table_reg(const float* table, const float* partner, const unsigned char* flags,
-                              long V, int C, float l2, float disc_scale, float disc_loss_scale,
+                              long V, int C, float l2, float l1, float disc_scale, float disc_loss_scale,
                               const float* count, float* grad_table, double* sumsq, double* reg_loss,
                               double* disc_loss, void* stream) {
   CLSR_CHECK_ARG(table && flags && grad_table && sumsq && V > 0 && C > 0);
@@ -174,7 +174,7 @@ extern "C" int clsr_table_reg(const float* table, const float* partner, const un
   int blocks = clsr_cdiv(V * C, 256 * 8);
   if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(table_reg_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, partner,
-                     flags, V, C, l2, disc_scale, disc_loss_scale, count, grad_table, sumsq, reg_loss,
+                     flags, V, C, l2, l1, disc_scale, disc_loss_scale, count, grad_table, sumsq, reg_loss,
                      disc_loss);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
@@ -236,7 +236,7 @@ extern "C" int clsr_table_adam(float* table, float* grad_table, float* m, float*
 template <int VW>
 __global__ void __launch_bounds__(256) table_reg_rows_kernel(
     const float* __restrict__ table, const float* __restrict__ partner, const int* __restrict__ ids,
-    const int* __restrict__ count, int C, float l2, float disc_scale, float disc_loss_scale,
+    const int* __restrict__ count, int C, float l2, float l1, float disc_scale, float disc_loss_scale,
     const float* __restrict__ ucount, float* __restrict__ grad_table, double* __restrict__ sumsq,
     double* __restrict__ reg_loss, double* __restrict__ disc_loss) {
   const float cd = partner ? disc_scale / (ucount[0] * (float)C) : 0.f;
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(256) table_reg_rows_kernel(
     }
 #pragma unroll
     for (int k = 0; k < VW; ++k) {
-      float g = l2 * p[k];
+      float g = l2 * p[k] + l1 * (float)((p[k] > 0.f) - (p[k] < 0.f));
       if (partner) {
         const float d = p[k] - pp[k];
         g += cd * d;
@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(256) table_reg_rows_kernel(
       }
       gt[k] += g;
       ss += (double)g * g;
-      rl += (double)p[k] * p[k];
+      rl += 0.5 * (double)l2 * p[k] * p[k] + (double)l1 * fabsf(p[k]);
     }
     if (VW == 4) st4(grad_table + e, *reinterpret_cast<f32x4*>(gt));
     else grad_table[e] = gt[0];
@@ -276,13 +276,13 @@ __global__ void __launch_bounds__(256) table_reg_rows_kernel(
   ss = block256_sum_d(ss, red[0]); rl = block256_sum_d(rl, red[1]); dl = block256_sum_d(dl, red[2]);
   if (threadIdx.x == 0) {
     if (ss != 0.0) atomicAdd(sumsq, ss);
-    if (reg_loss && rl != 0.0) atomicAdd(reg_loss, 0.5 * (double)l2 * rl);
+    if (reg_loss && rl != 0.0) atomicAdd(reg_loss, rl);
     if (disc_loss && dl != 0.0) atomicAdd(disc_loss, (double)cl * dl);
   }
 }
 
 extern "C" int clsr_table_reg_rows(const float* table, const float* partner, const int* ids, const int* count,
-                                   int cap, int C, float l2, float disc_scale, float disc_loss_scale,
+                                   int cap, int C, float l2, float l1, float disc_scale, float disc_loss_scale,
                                    const float* ucount, float* grad_table, double* sumsq, double* reg_loss,
                                    double* disc_loss, void* stream) {
   CLSR_CHECK_ARG(table && ids && count && grad_table && sumsq && cap > 0 && C > 0);
@@ -292,10 +292,10 @@ extern "C" int clsr_table_reg_rows(const float* table, const float* partner, con
   if (blocks > 2048) blocks = 2048;
   if (vec)
     hipLaunchKernelGGL(table_reg_rows_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, partner, ids,
-                       count, C, l2, disc_scale, disc_loss_scale, ucount, grad_table, sumsq, reg_loss, disc_loss);
+                       count, C, l2, l1, disc_scale, disc_loss_scale, ucount, grad_table, sumsq, reg_loss, disc_loss);
   else
     hipLaunchKernelGGL(table_reg_rows_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, partner, ids,
-                       count, C, l2, disc_scale, disc_loss_scale, ucount, grad_table, sumsq, reg_loss, disc_loss);
+                       count, C, l2, l1, disc_scale, disc_loss_scale, ucount, grad_table, sumsq, reg_loss, disc_loss);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }

@@ -149,8 +149,8 @@ class CLSRNet(object):
             bad.append("activation must be relu")
         if any(float(d) != 0.0 for d in hp.dropout) or float(hp.embedding_dropout) != 0.0 or hp.user_dropout:
             bad.append("dropout must be 0")
-        if any(float(getattr(hp, k)) != 0.0 for k in ("embed_l1", "layer_l1", "cross_l1", "cross_l2")):
-            bad.append("l1 / cross regularisers must be 0")
+        if any(float(getattr(hp, k)) != 0.0 for k in ("cross_l1", "cross_l2")):
+            bad.append("cross regularisers must be 0 (no model of this family has cross-layer parameters)")
         if hp.loss != "softmax" or hp.method != "classification":
             bad.append("loss must be softmax / method classification")
         if hp.optimizer not in ("adam", "lazyadam"):
@@ -1629,7 +1629,7 @@ class CLSRNet(object):
         hp = self.hp
         ss = self.sumsq_tab
         Vu, Vi, Vc = self.dims["Vu"], self.dims["Vi"], self.dims["Vc"]
-        l2e = float(hp.embed_l2)
+        l2e, l1e = float(hp.embed_l2), float(hp.embed_l1)
         tb, tg, fl = self.tables, self.tab_grad, self.tab_flags
         if "user_long" in tb:      # number of distinct users of the batch: the discrepancy loss is a mean over them
             call("clsr_zero_floats", self.ucount, 1)
@@ -1639,7 +1639,7 @@ class CLSRNet(object):
         with self._branch("@main" if (self.capture_grads or not self.split_emb_grad) else "@aux"):
             self._join(only="@dense")     # (the batched weight-gradient reduction, see _train_step)
             call("clsr_dense_reg_norm", self.dense, self.dense_grad, self.seg_off, len(self.dense_names),
-                 float(hp.layer_l2), self.dense_sumsq, self.losses[1:])
+                 float(hp.layer_l2), float(hp.layer_l1), self.dense_sumsq, self.losses[1:])
             if not self.capture_grads:
                 call("clsr_adam_tick", self.adam_state, float(hp.learning_rate), 0.9, 0.999)
                 call("clsr_dense_adam", self.dense, self.dense_grad, self.dense_m, self.dense_v, self.seg_of,
@@ -1652,14 +1652,14 @@ class CLSRNet(object):
             pt = tb[partner] if partner else None
             if key in lists:
                 ids, count, cap = lists[key]
-                call("clsr_table_reg_rows", tb[key], pt, ids, count, cap, C, l2e, dscale, dloss_scale,
+                call("clsr_table_reg_rows", tb[key], pt, ids, count, cap, C, l2e, l1e, dscale, dloss_scale,
                      self.ucount if partner else None, tg[key], ss[slot:], self.losses[1:], dloss)
             else:   # small tables: one launch sweeps all of them (blockIdx.y = table)
                 sweep.append((tb[key].data_ptr(), ops._ptr(pt), tg[key].data_ptr(), self.tab_m[key].data_ptr(),
                               self.tab_v[key].data_ptr(), fl[key].data_ptr(), ss[slot:].data_ptr(), ops._ptr(dloss),
                               ss[base:].data_ptr(), V, C, nsum, 2, dscale, dloss_scale, 0))
         if sweep:
-            ops.multi("clsr_tables_reg_multi", ops.TableDesc, sweep, l2e, self.ucount, self.losses[1:])
+            ops.multi("clsr_tables_reg_multi", ops.TableDesc, sweep, l2e, l1e, self.ucount, self.losses[1:])
         if self.capture_grads:  # test hook: pre-clip gradients (regularisers included) + squared norms
             self.captured = dict(dense={n: g.detach().clone() for n, g in self.Gd.items()},
                                  tables={k: g.detach().clone() for k, g in tg.items()},

@@ -385,23 +385,25 @@ int clsr_softmax_weights_bwd(const float* dw, const float* wts, const int* seq_l
 int clsr_mul_rows(const float* a, int lda, const float* b, int ldb, int G, long R, int C, float* out, int ldo,
                   void* stream);
 
-/* ---- regularisers, clip, Adam: base_model.py:118-159,249-297; clsr.py:73-82 */
+/* ---- regularisers, clip, Adam: base_model.py:118-159,249-297; clsr.py:73-82.  l2 / l1: embed_l2 / embed_l1 for the
+ *      involved embedding rows, layer_l2 / layer_l1 for the dense variables (loss += l2/2 ||w||^2 + l1 |w|_1,
+ *      grad += l2 w + l1 sign(w)) */
 int clsr_adam_tick(double* state, double lr, double beta1, double beta2, void* stream);
-int clsr_dense_reg_norm(const float* param, float* grad, const int* seg_off, int nseg, float l2,
+int clsr_dense_reg_norm(const float* param, float* grad, const int* seg_off, int nseg, float l2, float l1,
                         double* sumsq, double* reg_loss, void* stream);
 int clsr_dense_adam(float* param, float* grad, float* m, float* v, const int* seg_of,
                     const double* sumsq, float clip_norm, const double* adam_state, float beta1,
                     float beta2, float eps, int n, void* stream);
 int clsr_count_flags(const unsigned char* flags, long V, float* count, void* stream);
 int clsr_table_reg(const float* table, const float* partner, const unsigned char* flags, long V, int C,
-                   float l2, float disc_scale, float disc_loss_scale, const float* count,
+                   float l2, float l1, float disc_scale, float disc_loss_scale, const float* count,
                    float* grad_table, double* sumsq, double* reg_loss, double* disc_loss, void* stream);
 int clsr_table_adam(float* table, float* grad_table, float* m, float* v, unsigned char* flags, long V,
                     int C, const double* sumsq, int sumsq_stride, int nsum, float clip_norm,
                     const double* adam_state, float beta1, float beta2, float eps, int lazy, void* stream);
 /* row-list variants for huge vocabularies: ids/count from clsr_flags_compact (involved rows) */
 int clsr_table_reg_rows(const float* table, const float* partner, const int* ids, const int* count, int cap,
-                        int C, float l2, float disc_scale, float disc_loss_scale, const float* ucount,
+                        int C, float l2, float l1, float disc_scale, float disc_loss_scale, const float* ucount,
                         float* grad_table, double* sumsq, double* reg_loss, double* disc_loss, void* stream);
 int clsr_table_adam_rows(float* table, float* grad_table, float* m, float* v, unsigned char* flags,
                          const int* ids, const int* count, int cap, int C, const double* sumsq,
@@ -440,7 +442,7 @@ int clsr_sizeof_multi_descs(int* mark, int* gather, int* rp, int* table);
 int clsr_mark_rows_multi(const clsr_mark_desc* descs_host, int n, void* stream);
 int clsr_gather_rows_multi(const clsr_gather_desc* descs_host, int n, void* stream);
 int clsr_reduce_parts_multi(const clsr_rp_desc* descs_host, int n, void* stream);
-int clsr_tables_reg_multi(const clsr_table_desc* descs_host, int n, float l2, const float* ucount,
+int clsr_tables_reg_multi(const clsr_table_desc* descs_host, int n, float l2, float l1, const float* ucount,
                           double* reg_loss, void* stream);
 int clsr_tables_adam_multi(const clsr_table_desc* descs_host, int n, float clip_norm, const double* adam_state,
                            float beta1, float beta2, float eps, int lazy, void* stream);

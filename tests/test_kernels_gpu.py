@@ -684,10 +684,10 @@ def test_dense_reg_clip_adam():
     dp, dg, dm, dv = dev(p, f32), dev(gr, f32), dev(m, f32), dev(v, f32)
     ss = torch.zeros(len(sizes), dtype=torch.float64, device="cuda")
     reg = torch.zeros(1, dtype=torch.float64, device="cuda")
-    l2, clip = 1e-3, 2.0
-    call("clsr_dense_reg_norm", dp, dg, dev(off), len(sizes), l2, ss, reg)
-    g2 = gr + l2 * p
-    close(reg, (0.5 * l2 * (p ** 2).sum()).reshape(1), rtol=1e-5, name="reg loss")
+    l2, l1, clip = 1e-3, 3e-4, 2.0
+    call("clsr_dense_reg_norm", dp, dg, dev(off), len(sizes), l2, l1, ss, reg)
+    g2 = gr + l2 * p + l1 * torch.sign(p)
+    close(reg, (0.5 * l2 * (p ** 2).sum() + l1 * p.abs().sum()).reshape(1), rtol=1e-5, name="reg loss")
     exp_ss = torch.stack([(g2[off[i]:off[i + 1]] ** 2).sum() for i in range(len(sizes))])
     close(ss, exp_ss, rtol=1e-5, name="sumsq")
     st = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device="cuda")
@@ -715,7 +715,7 @@ def test_table_reg_adam(lazy):
     flags = (torch.rand(V, generator=g) < 0.3)
     G_l = torch.where(flags[:, None], rnd(g, V, C) * 0.01, torch.zeros(V, C, dtype=torch.float64))
     m, v = rnd(g, V, C) * 0.01, rnd(g, V, C).abs() * 0.01
-    l2, wd, clip = 1e-3, 0.01, 0.05
+    l2, l1, wd, clip = 1e-3, 2e-4 * lazy, 0.01, 0.05
     f32 = torch.float32
     dUL, dUS, dG, dm, dv = dev(UL, f32), dev(US, f32), dev(G_l, f32), dev(m, f32), dev(v, f32)
     dfl = dev(flags.to(torch.uint8))
@@ -724,11 +724,11 @@ def test_table_reg_adam(lazy):
     ss = torch.tensor([float((G_l ** 2).sum()), 0.0], dtype=torch.float64, device="cuda")
     reg = torch.zeros(1, dtype=torch.float64, device="cuda")
     disc = torch.zeros(1, dtype=torch.float64, device="cuda")
-    call("clsr_table_reg", dUL, dUS, dfl, V, C, l2, -2 * wd, -wd, cnt, dG, ss[1:], reg, disc)
+    call("clsr_table_reg", dUL, dUS, dfl, V, C, l2, l1, -2 * wd, -wd, cnt, dG, ss[1:], reg, disc)
     nu = float(flags.sum())
     fm = flags[:, None].double()
-    g_reg = fm * (l2 * UL + (-2 * wd / (nu * C)) * (UL - US))
-    close(reg, (0.5 * l2 * (fm * UL ** 2).sum()).reshape(1), rtol=1e-5, name="reg")
+    g_reg = fm * (l2 * UL + l1 * torch.sign(UL) + (-2 * wd / (nu * C)) * (UL - US))
+    close(reg, (0.5 * l2 * (fm * UL ** 2).sum() + l1 * (fm * UL.abs()).sum()).reshape(1), rtol=1e-5, name="reg")
     close(disc, (-wd * (fm * (UL - US) ** 2).sum() / (nu * C)).reshape(1), rtol=1e-5, name="disc")
     close(ss[1:], (g_reg ** 2).sum().reshape(1), rtol=1e-5, name="reg sumsq")
     st = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device="cuda")

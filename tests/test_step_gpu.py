@@ -66,6 +66,7 @@ CONFIGS = [
     dict(interest_evolve=False, predict_long_short=False),
     dict(manual_alpha=True, manual_alpha_value=0.3),
     dict(sequential_model="lstm"),
+    dict(embed_l1=2e-5, layer_l1=3e-5, embed_l2=1e-4),     # L1 regularisers (base_model.py:134-147), off by default
 ]
 
 
