@@ -577,10 +577,11 @@ class CLSRNet(object):
         tag = self._ws_tag if tag is None else tag
         pend = self._dw_pending.pop(tag, [])
         if tag == "" and self._dw_async:
+            cur = ops.current_stream()
             for i in range(self.dw_streams):
                 side = self._side.get("@dw%d" % i)
-                if side is not None:
-                    ops.stream_wait(ops.current_stream(), ops.event_record(side))
+                if side is not None and side.cuda_stream != cur.cuda_stream:   # (a stream does not wait for itself:
+                    ops.stream_wait(cur, ops.event_record(side))              #  under hipGraph capture that crashed)
             self._dw_async = False
         if pend:
             sig = tuple(pend)

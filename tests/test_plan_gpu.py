@@ -82,3 +82,40 @@ def test_plan_is_not_reused_across_changed_scalars(golden_dir, golden_hparams):
     after = net.state_dict()["sequential/logit_fcn/nn_part/w_nn_output"]
     assert float((after - before).abs().max()) > 0.05      # an lr = 0.5 Adam step, not an lr = 1e-3 one
     assert len(net._step_plans) == 2
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_hipgraph_capture_of_the_step_equals_eager(golden_dir, golden_hparams, precision):
+    """The whole training step (four streams: fork / join through events, the dense path finishing on the weight-gradient
+    stream) captured as ONE hipGraph and replayed == the same steps launched eagerly (bench.py --graph)."""
+    from clsr_amd import ops
+
+    hp = copy.deepcopy(golden_hparams)
+    hp.learning_rate = 1e-5
+    feed = _feed(golden_dir, "iterator_train_sa.npz", 0)
+    res = []
+    for graph in (False, True):
+        net = CLSRNet(hp, _dims(hp), device="cuda:0", seed=3, precision=precision)
+        net.use_plans = False
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            f = net.upload(feed, True)
+            net.train_step(f)                      # buffers allocated, weights packed
+            stream.synchronize()
+            if graph:
+                ops.graph_begin()
+                net.train_step(f)
+                g = ops.graph_end()
+                run = lambda: ops.graph_launch(g)
+            else:
+                run = lambda: net.train_step(f)
+            for _ in range(3):
+                run()
+            stream.synchronize()
+        res.append((net.losses.clone().cpu(), {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}))
+    (la, sa), (lb, sb) = res
+    assert float((la - lb).abs().max()) <= 1e-6 * float(la.abs().max())
+    for k in sa:
+        if sa[k].dtype.is_floating_point:
+            d = float((sa[k].double() - sb[k].double()).abs().max())
+            assert d <= 1e-5 + 1e-3 * float(sa[k].abs().max()), (k, d)
