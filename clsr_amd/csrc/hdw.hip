@@ -212,17 +212,20 @@ __global__ void __launch_bounds__(256, 3) hdw_multi_kernel(HdwMultiArgs m) {
   }
 }
 
+static int hdw_grid_x(int M);
+// number of partial chunks per 80 x 80 block that clsr_hdw_partial(_multi) writes (the descriptor of the batched reduction)
+extern "C" int clsr_hdw_parts(int M) { return hdw_grid_x(M); }
 static int hdw_grid_x(int M) {
   int tiles = clsr_cdiv(M, 64);
   int gx = clsr_cdiv(tiles, 4);
-  static const int cap = getenv("CLSR_DW_PARTS") ? atoi(getenv("CLSR_DW_PARTS")) : 384;   // blocks per chunk (512: 35 us more per speed-mode step in partial-sum traffic; 256: too few waves)
+  static const int cap = getenv("CLSR_HDW_PARTS") ? atoi(getenv("CLSR_HDW_PARTS")) : 384;   // blocks per chunk (512: 35 us more per speed-mode step in partial-sum traffic; 256: too few waves)
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
   return gx;
 }
 
 // Same contract as clsr_pgemm_dw_partial (workspace floats = clsr_pgemm_dw_workspace_floats(M, K, N), partial count =
-// clsr_pgemm_dw_parts(M), reduced by clsr_dw_reduce_batch); X / dY are fp32 or bf16 (x_bf16 / dy_bf16).
+// clsr_hdw_parts(M) <= clsr_pgemm_dw_parts(M), reduced by clsr_dw_reduce_batch); X / dY are fp32 or bf16 (x_bf16 / dy_bf16).
 extern "C" int clsr_hdw_partial(const void* X, int x_bf16, int ldx, int T, int G, const float* Xmul, int ldmul,
                                 const float* in_scale, const float* in_shift, int in_relu, const void* dY,
                                 int dy_bf16, int ldy, int M, int K, int N, float* workspace, void* stream) {
@@ -232,7 +235,6 @@ extern "C" int clsr_hdw_partial(const void* X, int x_bf16, int ldx, int T, int G
                        (!Xmul || (ldmul % 4 == 0 && ldmul >= ((K + 3) & ~3))) &&
                        ((uintptr_t)X % 8) == 0 && ((uintptr_t)dY % 8) == 0);
   CLSR_CHECK_SUPPORTED(!(Xmul && in_scale) && !(in_scale && K % 4));
-  CLSR_CHECK_SUPPORTED(hdw_grid_x(M) == clsr_pgemm_dw_parts(M));
   HdwArgs a;
   a.X = X; a.ldx = ldx; a.T = T; a.G = G; a.Xmul = Xmul; a.ldmul = ldmul;
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
@@ -275,7 +277,6 @@ extern "C" int clsr_hdw_partial_multi(const clsr_dwjob* jobs, int n, void* strea
                          (!q.Xmul || (q.ldmul % 4 == 0 && q.ldmul >= ((q.K + 3) & ~3))) &&
                          ((uintptr_t)q.X % 16) == 0 && ((uintptr_t)q.dY % 8) == 0);
     CLSR_CHECK_SUPPORTED(!(q.Xmul && q.in_scale) && !(q.in_scale && q.K % 4));
-    CLSR_CHECK_SUPPORTED(hdw_grid_x(q.M) == clsr_pgemm_dw_parts(q.M));
     HdwArgs& a = m.d[j];
     a.X = q.X; a.ldx = q.ldx; a.T = q.T; a.G = q.G; a.Xmul = q.Xmul; a.ldmul = q.ldmul;
     a.in_scale = q.in_scale; a.in_shift = q.in_shift; a.in_relu = q.in_relu;

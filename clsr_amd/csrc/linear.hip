@@ -925,7 +925,7 @@ __global__ void __launch_bounds__(1024) dw_reduce_kernel(const float* __restrict
 static int dw_grid_x(int M) {
   int tiles = clsr_cdiv(M, 64);
   int gx = clsr_cdiv(tiles, 4);  // >= 4 position tiles per block before adding blocks
-  static const int cap = getenv("CLSR_DW_PARTS") ? atoi(getenv("CLSR_DW_PARTS")) : 384;   // blocks per chunk (512: 35 us more per speed-mode step in partial-sum traffic; 256: too few waves)
+  static const int cap = getenv("CLSR_DW_PARTS") ? atoi(getenv("CLSR_DW_PARTS")) : 512;   // blocks per chunk of the fp32-MFMA kernels (384: +40 us per exact-mode step; the bf16 kernels use 384, csrc/hdw.hip)
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
   return gx;

@@ -516,7 +516,7 @@ class CLSRNet(object):
         else:
             self._dw_launch(X, x_bf16, ldx, T, G, Xmul, ldmul, sc, sh, dY, dy_bf16, ldy, M, K, N, ws, None)
         pend.append((ws.data_ptr(), dW.data_ptr(), db.data_ptr() if db is not None else 0, 1.0,
-                     query("clsr_pgemm_dw_parts", M), K, N, ldw, acc))
+                     query("clsr_hdw_parts" if (self.bf16 and self.bf16_dw) else "clsr_pgemm_dw_parts", M), K, N, ldw, acc))
         if not self.defer_dw:
             self._dw_flush()
 

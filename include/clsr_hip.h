@@ -211,6 +211,7 @@ typedef struct clsr_dw_desc {
 } clsr_dw_desc;
 int clsr_sizeof_dw_desc(void);
 int clsr_pgemm_dw_parts(int M);
+int clsr_hdw_parts(int M);      /* partial chunks written by clsr_hdw_partial(_multi): <= clsr_pgemm_dw_parts(M), same workspace */
 int clsr_pgemm_dw_partial(const float* X, int ldx, int T, int G, const float* Xmul, int ldmul,
                           const float* in_scale, const float* in_shift, int in_relu, const float* dY, int ldy,
                           int M, int K, int N, float* workspace, void* stream);

@@ -242,12 +242,13 @@ def test_fused_layer0_backward_reductions(Hn, G, T, Q, A0):
     _close(dV, dV2, 1e-5, 1e-5, "dV vs three-kernel path")
 
 
-def _dw_full(partial_call, M, K, N, with_bias):
-    """run a deferred weight-gradient launch + the batched reduction; returns (dW, db)"""
+def _dw_full(partial_call, M, K, N, with_bias, parts="clsr_pgemm_dw_parts"):
+    """run a deferred weight-gradient launch + the batched reduction; returns (dW, db).  ``parts``: the query that tells
+    how many partial chunks the kernel wrote (clsr_hdw_parts for the bf16-MFMA kernel)"""
     ws = torch.zeros(ops.query("clsr_pgemm_dw_workspace_floats", M, K, N), device=DEV)
     partial_call(ws)
     dW, db = torch.zeros(K, N, device=DEV), torch.zeros(N, device=DEV)
-    sig = ((ws.data_ptr(), dW.data_ptr(), db.data_ptr() if with_bias else 0, 1.0, ops.query("clsr_pgemm_dw_parts", M), K,
+    sig = ((ws.data_ptr(), dW.data_ptr(), db.data_ptr() if with_bias else 0, 1.0, ops.query(parts, M), K,
             N, N, 0),)
     tab = ops.dw_table(sig, torch.device(DEV))
     ops.call("clsr_dw_reduce_batch", tab[0], tab[1], tab[2])
@@ -286,7 +287,7 @@ def test_bf16_mfma_weight_gradient_kernel(M, K, N):
     X = torch.randn(M, K, generator=g).to(DEV)
     dY = torch.randn(M, N, generator=g).to(DEV)
     dW, db = _dw_full(lambda ws: ops.call("clsr_hdw_partial", X, 0, K, 0, 0, None, 0, None, None, 1, dY, 0, N, M, K, N, ws),
-                      M, K, N, True)
+                      M, K, N, True, parts="clsr_hdw_parts")
     _close(dW, _r(X).t() @ _r(dY), 1e-4, 2e-3, "dW plain")
     _close(db, dY.double().sum(0), 1e-5, 1e-3, "db (exact fp32 column sums of the unrounded dY)")
     if K % 4 == 0 and M % 10 == 0:
@@ -295,14 +296,14 @@ def test_bf16_mfma_weight_gradient_kernel(M, K, N):
         a_, q_ = torch.randn(Hn * T, K, generator=g).to(DEV), torch.randn(R, K, generator=g).to(DEV)
         dYh = dY.to(BF)
         dW, _ = _dw_full(lambda ws: ops.call("clsr_hdw_partial", a_, 0, K, T, G, q_, K, None, None, 1, dYh, 1, N, M, K, N,
-                                             ws), M, K, N, False)
+                                             ws), M, K, N, False, parts="clsr_hdw_parts")
         rows = torch.arange(M, device=DEV)
         r, t = rows // T, rows % T
         _close(dW, _r(a_[(r // G) * T + t] * q_[r]).t() @ dYh.double(), 1e-4, 2e-3, "dW (a * q)")
     Xh, dYh = X.to(BF), dY.to(BF)
     sc, sh = (torch.rand(K, generator=g) + 0.5).to(DEV), torch.randn(K, generator=g).to(DEV)
     dW, db = _dw_full(lambda ws: ops.call("clsr_hdw_partial", Xh, 1, K, 0, 0, None, 0, sc, sh, 1, dYh, 1, N, M, K, N, ws),
-                      M, K, N, True)
+                      M, K, N, True, parts="clsr_hdw_parts")
     _close(dW, _r(torch.relu(Xh.float() * sc + sh)).t() @ dYh.double(), 1e-4, 2e-3, "dW relu(bn(X))")
     _close(db, dYh.double().sum(0), 1e-4, 2e-3, "db (bf16 dY)")
 
