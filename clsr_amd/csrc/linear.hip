@@ -1061,43 +1061,54 @@ extern "C" int clsr_pgemm_dw_partial_h(const void* X, int x_bf16, int ldx, int T
 extern "C" int clsr_pgemm_dw_parts(int M) { return dw_grid_x(M); }
 extern "C" int clsr_sizeof_dw_desc(void) { return (int)sizeof(clsr_dw_desc); }
 
+// Block = 64 consecutive floats of the partial layout (a quarter of one 16 x 16 tile: every wave load is one
+// contiguous 256-byte segment per partial) x 16 waves that split the partials; the tail blocks of a descriptor
+// sum its bias slots.  Work items beyond gridDim.x are picked up by a block-stride loop.
 __global__ void __launch_bounds__(1024) dw_reduce_batch_kernel(const clsr_dw_desc* __restrict__ descs) {
   __shared__ float red[16][64];
   const clsr_dw_desc d = descs[blockIdx.y];
   const int K = d.K, N = d.N;
-  const int total = K * N + (d.db ? N : 0);
-  if ((int)blockIdx.x * 64 >= total) return;   // block-uniform
-  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int sub = threadIdx.x >> 6;
-  const int kchunks = (K + 16 * DW_T - 1) / (16 * DW_T), nchunks = (N + 16 * DW_T - 1) / (16 * DW_T);
-  (void)kchunks;
-  float s = 0.f;
-  float* o = nullptr;
-  if (e < total) {
-    const float* p;
-    if (e < K * N) {
-      const int k = e / N, n = e - k * N;
-      const int kc = k / (16 * DW_T), nc = n / (16 * DW_T);
-      const int kk = k - kc * 16 * DW_T, nn = n - nc * 16 * DW_T;
-      const long off = ((kk >> 4) * DW_T + (nn >> 4)) * 256 + (kk & 15) * 16 + (nn & 15);
-      p = d.partial + ((long)(kc * nchunks + nc) * d.nparts) * DW_CHUNK + off;
-      o = d.dW + (long)k * d.ldw + n;
+  const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const int ktiles = (K + 15) >> 4, ntiles = (N + 15) >> 4;
+  const int nchunks = (N + 16 * DW_T - 1) / (16 * DW_T);
+  const int wq = ktiles * ntiles * 4;
+  const int items = wq + (d.db ? (N + 63) / 64 : 0);
+  for (int it = blockIdx.x; it < items; it += gridDim.x) {   // block-uniform
+    float s = 0.f;
+    float* o = nullptr;
+    const float* p = nullptr;
+    if (it < wq) {
+      const int tile = it >> 2, q = it & 3;
+      const int ktg = tile / ntiles, ntg = tile - ktg * ntiles;
+      const int kc = ktg / DW_T, kt = ktg - kc * DW_T, nc = ntg / DW_T, nt = ntg - nc * DW_T;
+      const int w = q * 64 + lane;
+      const int k = ktg * 16 + (w >> 4), n = ntg * 16 + (w & 15);
+      if (k < K && n < N) {
+        p = d.partial + ((long)(kc * nchunks + nc) * d.nparts) * DW_CHUNK + (kt * DW_T + nt) * 256 + w;
+        o = d.dW + (long)k * d.ldw + n;
+      }
     } else {
-      const int n = e - K * N;
-      const int nc = n / (16 * DW_T), nn = n - nc * 16 * DW_T;
-      p = d.partial + ((long)nc * d.nparts) * DW_CHUNK + DW_T * DW_T * 256 + nn;
-      o = d.db + n;
+      const int n = (it - wq) * 64 + lane;
+      if (n < N) {
+        const int nc = n / (16 * DW_T), nn = n - nc * 16 * DW_T;
+        p = d.partial + ((long)nc * d.nparts) * DW_CHUNK + DW_T * DW_T * 256 + nn;
+        o = d.db + n;
+      }
     }
-    for (int w = sub; w < d.nparts; w += 16) s += p[(long)w * DW_CHUNK];
-  }
-  red[sub][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (sub == 0 && e < total) {
-    s = 0.f;
+    if (p) {
+#pragma unroll 8
+      for (int w = sub; w < d.nparts; w += 16) s += p[(long)w * DW_CHUNK];
+    }
+    red[sub][lane] = s;
+    __syncthreads();
+    if (sub == 0 && o) {
+      s = 0.f;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) s += red[u][threadIdx.x];
-    s *= d.scale;
-    *o = d.accumulate ? *o + s : s;
+      for (int u = 0; u < 16; ++u) s += red[u][lane];
+      s *= d.scale;
+      *o = d.accumulate ? *o + s : s;
+    }
+    __syncthreads();
   }
 }
 

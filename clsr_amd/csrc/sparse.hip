@@ -195,6 +195,7 @@ extern "C" int clsr_sort_ids(const int* ids, long nrows, int ncols, long row_str
 
 // g[pos, :] = dhist[pos, col0:col0+C] + (t < len) dmean[h]/len + recent(t) drecent[h]/cnt   (pos = h*T + t)
 // grad[key*ldg + gcol0 + c] += sum of g over the run of equal keys; sumsq += sum g^2 (IndexedSlices norm)
+#define GBS_CHUNK(CP) ((CP) < 16 ? 16 : (CP))   // sorted entries per thread group
 template <int CP>
 __global__ void __launch_bounds__(256) gather_bwd_sorted_kernel(
     const float* __restrict__ dhist, const float* __restrict__ dmean, const float* __restrict__ drecent,
@@ -202,22 +203,31 @@ __global__ void __launch_bounds__(256) gather_bwd_sorted_kernel(
     int len_stride, long n, int T, int D, int col0, int C, int recent_k, float* __restrict__ grad, int ldg,
     int gcol0, double* __restrict__ sumsq) {
   __shared__ double red[4];
-  constexpr int GPB = 256 / CP;   // thread groups per block
-  constexpr int EPL = 64 / CP;    // chunk entries preloaded per lane
+  constexpr int GPB = 256 / CP;              // thread groups per block
+  constexpr int EPL = GBS_CHUNK(CP) / CP;    // chunk entries preloaded per lane
   const int c = threadIdx.x % CP;
   const long gid = (long)blockIdx.x * GPB + threadIdx.x / CP;
   const bool cok = c < C;
-  const long p0 = gid * 64;
-  // every lane preloads EPL entries of the chunk (coalesced), later broadcast inside the group
-  int mk[EPL], mp[EPL], ml[EPL];
+  const long p0 = gid * GBS_CHUNK(CP);
+  // every lane preloads EPL entries of the chunk (coalesced) and works out what only depends on the entry: the
+  // history row and the divisors of the mean / recent terms (0 = term absent); broadcast inside the group later.
+  // Short chunks (16 .. 64 sorted entries per thread group): the walk below is a serial chain per group, so the
+  // launch gets its parallelism from the number of groups (12 800 at 204 800 positions), not from long chunks.
+  int mk[EPL], mp[EPL], mh[EPL];
+  float ml[EPL], mr[EPL];
 #pragma unroll
   for (int u = 0; u < EPL; ++u) {
     const long p = p0 + u * CP + c;
-    mk[u] = -1; mp[u] = 0; ml[u] = 1;
+    mk[u] = -1; mp[u] = 0; mh[u] = 0; ml[u] = 0.f; mr[u] = 0.f;
     if (p < n) {
       mk[u] = keys[p];
-      mp[u] = perm[p];
-      ml[u] = seq_len[(long)(mp[u] / T) * len_stride];
+      const int pos = perm[p];
+      const int h = pos / T, t = pos - h * T;
+      const int len = seq_len[(long)h * len_stride];
+      const bool in_len = t < len;
+      mp[u] = pos; mh[u] = h;
+      ml[u] = in_len ? (float)len : 0.f;
+      mr[u] = (in_len && t >= len - recent_k) ? (float)(len < recent_k ? len : recent_k) : 0.f;
     }
   }
   int cur = -1;
@@ -238,13 +248,12 @@ __global__ void __launch_bounds__(256) gather_bwd_sorted_kernel(
       for (int k = 0; k < SUB; ++k) {
         key[k] = __shfl(mk[u], q0 + k, CP);
         const int pos = __shfl(mp[u], q0 + k, CP);
-        const int len = __shfl(ml[u], q0 + k, CP);
-        const int h = pos / T, t = pos - h * T;
+        const int h = __shfl(mh[u], q0 + k, CP);
+        const float flen = __shfl(ml[u], q0 + k, CP);
+        const float frec = __shfl(mr[u], q0 + k, CP);
         float v = dh_c[(long)pos * D];
-        const bool in_len = t < len;
-        if (dm_c) v += in_len ? dm_c[(long)h * D] / (float)len : 0.f;
-        if (dr_c) v += (in_len && t >= len - recent_k) ? dr_c[(long)h * D] / (float)(len < recent_k ? len : recent_k)
-                                                       : 0.f;
+        if (dm_c) v += flen > 0.f ? dm_c[(long)h * D] / flen : 0.f;
+        if (dr_c) v += frec > 0.f ? dr_c[(long)h * D] / frec : 0.f;
         g[k] = (cok && key[k] >= 0) ? v : 0.f;
       }
 #pragma unroll
@@ -275,7 +284,7 @@ extern "C" int clsr_gather_bwd_sorted(const float* dhist, const float* dmean, co
   CLSR_CHECK_ARG(dhist && keys && perm && seq_len && grad && n > 0 && T > 0 && D > 0 && C > 0);
   CLSR_CHECK_SUPPORTED(C <= 64);
   const int CP = C <= 8 ? 8 : (C <= 16 ? 16 : (C <= 32 ? 32 : 64));
-  const long groups = (n + 63) / 64;
+  const long groups = (n + GBS_CHUNK(CP) - 1) / GBS_CHUNK(CP);
   const int blocks = clsr_cdiv(groups, 256 / CP);
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_GBS(CPV)                                                                                     \

@@ -269,7 +269,9 @@ def dw_table(sig, device):
         d.partial, d.dW, d.db, d.scale = partial, dW, db or None, scale
         d.nparts, d.K, d.N, d.ldw, d.accumulate = nparts, K, N, ldw, acc
     t = _t.frombuffer(bytearray(bytes(memoryview(arr))), dtype=_t.uint8).to(device)
-    return t, len(sig), max(s[5] * s[6] + (s[6] if s[2] else 0) for s in sig)
+    # max_outputs / 64 = blocks per descriptor: one per quarter of a 16 x 16 tile (+ 64-wide bias slices)
+    cd = lambda a, b: -(-a // b)
+    return t, len(sig), 64 * max(cd(s[5], 16) * cd(s[6], 16) * 4 + (cd(s[6], 64) if s[2] else 0) for s in sig)
 
 
 # ---- multi-launch descriptors (include/clsr_hip.h: clsr_mark_desc, clsr_gather_desc, clsr_rp_desc, clsr_table_desc)

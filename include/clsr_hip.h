@@ -215,6 +215,8 @@ int clsr_hdw_parts(int M);      /* partial chunks written by clsr_hdw_partial(_m
 int clsr_pgemm_dw_partial(const float* X, int ldx, int T, int G, const float* Xmul, int ldmul,
                           const float* in_scale, const float* in_shift, int in_relu, const float* dY, int ldy,
                           int M, int K, int N, float* workspace, void* stream);
+/* max_outputs / 64 blocks per descriptor; one pass needs 64 * max(4 * ceil(K/16) * ceil(N/16) + ceil(N/64)) (a smaller
+ * value is correct too: blocks stride over the remaining work) */
 int clsr_dw_reduce_batch(const clsr_dw_desc* descs_device, int n, int max_outputs, void* stream);
 int clsr_reduce_parts(const float* partial, int nparts, int stride, int n, float scale, float* out,
                       int accumulate, void* stream);
