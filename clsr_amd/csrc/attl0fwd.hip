@@ -10,7 +10,8 @@
 //    q[r,:] and V[r,:] sit in LDS, and the only global memory instructions between two MFMA blocks are the stores;
 //  * v_mfma_f32_16x16x4_f32: MFMA #r of the 16-wide k-chunk kk uses feature 16kk + 4g + r, the A operand of a chunk is
 //    the float4 (a * q) of the lane's position, the B operand one ds_read_b128 of the packed weights.
-// ~1 VALU instruction per MFMA (3.3 in pgemm_fast_kernel).
+// ~1 VALU instruction per MFMA inside the row loop, 2.1 per MFMA over the whole launch (profiles/r02_att_pmc.md;
+// 3.4 in pgemm_fast_kernel); matrix pipe busy 63 % of the CU-busy time.
 #include "common.h"
 #include "clsr_hip.h"
 
