@@ -206,6 +206,77 @@ extern "C" int clsr_bn_bwd_apply(float* dy, const float* z, const float* coef, l
   return CLSR_OK;
 }
 
+// clsr_bn_bwd_coef + clsr_bn_bwd_apply in ONE launch for the small (row-level) layers: every block folds the partial
+// sums itself (nparts x 2C doubles out of L2, ~100 KB), keeps the 3C coefficients in LDS and applies them to its share
+// of dy; block 0 also writes coef / dgamma / dbeta.  One dispatch and one dependent-launch gap less per layer.
+__global__ void __launch_bounds__(1024) bn_bwd_coef_apply_kernel(const double* __restrict__ partial, int nparts, int C,
+                                                                 double count, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd,
+                                                                 float* __restrict__ coef, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, float* __restrict__ dy,
+                                                                 const float* __restrict__ z, long M) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bn_raw[];
+  const int W = 2 * C;                                       // sums per part row
+  const int NG = 1024 / W > 0 ? 1024 / W : 1;                // part groups folding side by side
+  double* sm = reinterpret_cast<double*>(bn_raw);            // [NG][2C]
+  float* cf = reinterpret_cast<float*>(sm + (size_t)NG * W); // [3][C]
+  for (int t = threadIdx.x; t < NG * W; t += 1024) {
+    const int pg = t / W, idx = t - pg * W;
+    const double* p = partial + idx;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int q = pg;
+    for (; q + 3 * NG < nparts; q += 4 * NG) {
+      s0 += p[(long)q * W];
+      s1 += p[(long)(q + NG) * W];
+      s2 += p[(long)(q + 2 * NG) * W];
+      s3 += p[(long)(q + 3 * NG) * W];
+    }
+    for (; q < nparts; q += NG) s0 += p[(long)q * W];
+    sm[t] = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 1024) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int pg = 0; pg < NG; ++pg) { s1 += sm[pg * W + c]; s2 += sm[pg * W + C + c]; }
+    const float g = gamma[c], is = invstd[c], mu = mean[c];
+    const float c1 = (float)(s1 / count), c2 = (float)(s2 / count);
+    const float a1 = g * is;
+    const float a2 = -g * is * is * c2;
+    const float a3 = -a1 * c1 - a2 * mu;
+    cf[c] = a1; cf[C + c] = a2; cf[2 * C + c] = a3;
+    if (blockIdx.x == 0) {
+      coef[c] = a1; coef[C + c] = a2; coef[2 * C + c] = a3;
+      dgamma[c] = (float)s2;
+      dbeta[c] = (float)s1;
+    }
+  }
+  __syncthreads();
+  const int QC = C >> 2;
+  const long total = M * QC;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(e % QC);
+    const f32x4 a1 = ld4(cf + 4 * q), a2 = ld4(cf + C + 4 * q), a3 = ld4(cf + 2 * C + 4 * q);
+    const f32x4 d = ld4(dy + e * 4), zz = ld4(z + e * 4);
+    st4(dy + e * 4, a1 * d + a2 * zz + a3);
+  }
+}
+
+extern "C" int clsr_bn_bwd_coef_apply(const double* partial, int nparts, int C, double count, const float* gamma,
+                                      const float* mean, const float* invstd, float* coef, float* dgamma,
+                                      float* dbeta, float* dy, const float* z, long M, void* stream) {
+  CLSR_CHECK_ARG(partial && gamma && mean && invstd && coef && dgamma && dbeta && dy && z && nparts > 0 && C > 0 && M > 0);
+  CLSR_CHECK_SUPPORTED(C % 4 == 0 && C <= 1024);
+  int blocks = clsr_cdiv(M * (C / 4), 1024 * 8);
+  if (blocks > 64) blocks = 64;
+  const int W = 2 * C, NG = 1024 / W > 0 ? 1024 / W : 1;
+  const size_t shmem = (size_t)NG * W * sizeof(double) + (size_t)3 * C * sizeof(float);
+  hipLaunchKernelGGL(bn_bwd_coef_apply_kernel, dim3(blocks), dim3(1024), shmem, (hipStream_t)stream, partial, nparts,
+                     C, count, gamma, mean, invstd, coef, dgamma, dbeta, dy, z, M);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
 // out[e] = sum_p partial[p*n + e]  (e < n doubles): the per-block partial statistics of a batch-norm layer folded
 // into ONE row, so that a data-parallel run all-reduces 2*C doubles instead of parts*2*C (clsr_amd/dp.py, sync-BN)
 __global__ void __launch_bounds__(256) sum_parts_d_kernel(const double* __restrict__ partial, int nparts, int n,

@@ -1077,6 +1077,7 @@ __global__ void __launch_bounds__(1024) dw_reduce_batch_kernel(const clsr_dw_des
     float s = 0.f;
     float* o = nullptr;
     const float* p = nullptr;
+    const float* p2 = nullptr;
     if (it < wq) {
       const int tile = it >> 2, q = it & 3;
       const int ktg = tile / ntiles, ntg = tile - ktg * ntiles;
@@ -1085,6 +1086,7 @@ __global__ void __launch_bounds__(1024) dw_reduce_batch_kernel(const clsr_dw_des
       const int k = ktg * 16 + (w >> 4), n = ntg * 16 + (w & 15);
       if (k < K && n < N) {
         p = d.partial + ((long)(kc * nchunks + nc) * d.nparts) * DW_CHUNK + (kt * DW_T + nt) * 256 + w;
+        if (d.partial2) p2 = d.partial2 + ((long)(kc * nchunks + nc) * d.nparts2) * DW_CHUNK + (kt * DW_T + nt) * 256 + w;
         o = d.dW + (long)k * d.ldw + n;
       }
     } else {
@@ -1098,6 +1100,13 @@ __global__ void __launch_bounds__(1024) dw_reduce_batch_kernel(const clsr_dw_des
     if (p) {
 #pragma unroll 8
       for (int w = sub; w < d.nparts; w += 16) s += p[(long)w * DW_CHUNK];
+      s *= d.scale;
+    }
+    if (p2) {
+      float s2 = 0.f;
+#pragma unroll 8
+      for (int w = sub; w < d.nparts2; w += 16) s2 += p2[(long)w * DW_CHUNK];
+      s += d.scale2 * s2;
     }
     red[sub][lane] = s;
     __syncthreads();
@@ -1105,7 +1114,6 @@ __global__ void __launch_bounds__(1024) dw_reduce_batch_kernel(const clsr_dw_des
       s = 0.f;
 #pragma unroll
       for (int u = 0; u < 16; ++u) s += red[u][lane];
-      s *= d.scale;
       *o = d.accumulate ? *o + s : s;
     }
     __syncthreads();

@@ -9,6 +9,8 @@ struct MultiArgs {
   D d[CLSR_MULTI_MAX];
 };
 
+extern "C" int clsr_sizeof_zero_desc(void) { return (int)sizeof(clsr_zero_desc); }
+extern "C" int clsr_sizeof_scatter_desc(void) { return (int)sizeof(clsr_scatter_desc); }
 extern "C" int clsr_sizeof_multi_descs(int* mark, int* gather, int* rp, int* table) {
   if (mark) *mark = (int)sizeof(clsr_mark_desc);
   if (gather) *gather = (int)sizeof(clsr_gather_desc);
@@ -41,6 +43,75 @@ extern "C" int clsr_mark_rows_multi(const clsr_mark_desc* descs, int n, void* st
   int blocks = clsr_cdiv(mx, 256);
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(mark_rows_multi_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, a);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// ---- zero fills: the per-step accumulators (norm / loss slots, gradient pool, sort counters, user counter) in ONE launch
+__global__ void __launch_bounds__(256) zero_multi_kernel(MultiArgs<clsr_zero_desc> a) {
+  const clsr_zero_desc d = a.d[blockIdx.y];
+  const long words = d.nbytes >> 2;
+  unsigned* w = reinterpret_cast<unsigned*>(d.p);
+  long head = ((16 - ((uintptr_t)d.p & 15)) & 15) >> 2;     // words up to the first 16-byte boundary
+  head = head < words ? head : words;
+  const long n16 = (words - head) >> 2;
+  uint4* v = reinterpret_cast<uint4*>(w + head);
+  const uint4 z = {0u, 0u, 0u, 0u};
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n16; e += (long)gridDim.x * blockDim.x) v[e] = z;
+  if (blockIdx.x == 0) {
+    for (long e = threadIdx.x; e < head; e += blockDim.x) w[e] = 0u;
+    for (long e = head + 4 * n16 + threadIdx.x; e < words; e += blockDim.x) w[e] = 0u;
+  }
+}
+
+extern "C" int clsr_zero_multi(const clsr_zero_desc* descs, int n, void* stream) {
+  CLSR_CHECK_ARG(descs && n > 0 && n <= CLSR_MULTI_MAX);
+  MultiArgs<clsr_zero_desc> a;
+  long mx = 1;
+  for (int i = 0; i < n; ++i) {
+    CLSR_CHECK_ARG(descs[i].p && descs[i].nbytes >= 0 && descs[i].nbytes % 4 == 0 && ((uintptr_t)descs[i].p % 4) == 0);
+    a.d[i] = descs[i];
+    mx = descs[i].nbytes > mx ? descs[i].nbytes : mx;
+  }
+  int blocks = clsr_cdiv(mx, 256 * 16 * 4);     // four 16-byte stores per thread
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(zero_multi_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, a);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// ---- row scatters of the embedding gradients (embedding.hip: scatter_add_rows_kernel), one job per lookup site
+__global__ void __launch_bounds__(256) scatter_add_rows_multi_kernel(MultiArgs<clsr_scatter_desc> a) {
+  __shared__ double red[4];
+  const clsr_scatter_desc d = a.d[blockIdx.y];
+  const long total = (long)d.N * d.C;
+  float local = 0.f;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(e / d.C), c = (int)(e - (long)n * d.C);
+    const float v = d.src[(long)n * d.ld_src + d.col0 + c];
+    local += v * v;
+    atomicAdd(d.tbl_grad + (long)d.idx[(long)n * d.idx_stride] * d.C + c, v);
+  }
+  if (d.sumsq) {   // block-uniform
+    const double tot = block256_sum_d((double)local, red);
+    if (threadIdx.x == 0 && tot != 0.0) atomicAdd(d.sumsq, tot);
+  }
+}
+
+extern "C" int clsr_scatter_add_rows_multi(const clsr_scatter_desc* descs, int n, void* stream) {
+  CLSR_CHECK_ARG(descs && n > 0 && n <= CLSR_MULTI_MAX);
+  MultiArgs<clsr_scatter_desc> a;
+  long mx = 1;
+  for (int i = 0; i < n; ++i) {
+    CLSR_CHECK_ARG(descs[i].src && descs[i].idx && descs[i].tbl_grad && descs[i].N >= 0 && descs[i].C > 0);
+    a.d[i] = descs[i];
+    const long e = (long)descs[i].N * descs[i].C;
+    mx = e > mx ? e : mx;
+  }
+  int blocks = clsr_cdiv(mx, 256 * 4);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(scatter_add_rows_multi_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }

@@ -36,7 +36,15 @@ __global__ void __launch_bounds__(1024) dense_reg_norm_kernel(const float* __res
                                                              float* __restrict__ grad,
                                                              const int* __restrict__ seg_off, float l2, float l1,
                                                              double* __restrict__ sumsq,
-                                                             double* __restrict__ reg_loss) {
+                                                             double* __restrict__ reg_loss,
+                                                             double* __restrict__ adam_state, double lr, double b1,
+                                                             double b2) {
+  if (adam_state && blockIdx.x == 0 && threadIdx.x == 0) {   // the Adam clock of this step (adam_tick_kernel) rides along
+    adam_state[0] += 1.0;
+    adam_state[1] *= b1;
+    adam_state[2] *= b2;
+    adam_state[3] = lr * sqrt(1.0 - adam_state[2]) / (1.0 - adam_state[1]);
+  }
   // 1024 threads: the largest tensor (25.6 k elements) is 25 dependent iterations instead of 100; the 16 wave
   // partials are combined in a fixed order (deterministic)
   __shared__ double red[2][16];
@@ -62,13 +70,19 @@ __global__ void __launch_bounds__(1024) dense_reg_norm_kernel(const float* __res
   }
 }
 
-extern "C" int clsr_dense_reg_norm(const float* param, float* grad, const int* seg_off, int nseg,
-                                   float l2, float l1, double* sumsq, double* reg_loss, void* stream) {
+extern "C" int clsr_dense_reg_norm_tick(const float* param, float* grad, const int* seg_off, int nseg,
+                                        float l2, float l1, double* sumsq, double* reg_loss, double* adam_state,
+                                        double lr, double beta1, double beta2, void* stream) {
   CLSR_CHECK_ARG(param && grad && seg_off && sumsq && nseg > 0);
   hipLaunchKernelGGL(dense_reg_norm_kernel, dim3(nseg), dim3(1024), 0, (hipStream_t)stream, param, grad,
-                     seg_off, l2, l1, sumsq, reg_loss);
+                     seg_off, l2, l1, sumsq, reg_loss, adam_state, lr, beta1, beta2);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
+}
+
+extern "C" int clsr_dense_reg_norm(const float* param, float* grad, const int* seg_off, int nseg,
+                                   float l2, float l1, double* sumsq, double* reg_loss, void* stream) {
+  return clsr_dense_reg_norm_tick(param, grad, seg_off, nseg, l2, l1, sumsq, reg_loss, nullptr, 0.0, 0.0, 0.0, stream);
 }
 
 __device__ __forceinline__ float clip_factor(double sumsq, float clip_norm) {

@@ -93,6 +93,8 @@ class CLSRNet(object):
         # with four streams of its own puts eight hardware queues in play and its step takes 5.7 instead of 3.4 ms
         self._side = _SIDE_STREAMS.setdefault(str(torch.device(device)), {})
         self.rnn_first = not os.environ.get("CLSR_BRANCH_FIRST")   # A/B switch (see forward)
+        self.dw_batch_late = not os.environ.get("CLSR_NO_DW_BATCH_LATE")   # A/B: merged launches of the attention / head weight gradients
+        self.bn_bwd_fused = not os.environ.get("CLSR_NO_BN_BWD_FUSED")   # A/B: coefficient + apply of the row-level batch-norm backward in one launch
         self.lt_att_first = bool(os.environ.get("CLSR_LT_ATT_FIRST"))   # A/B: long-term attention before the causal GRU on @lt (measured: +0.03 ms fp32, +0.04 ms bf16 -- the heavy GEMMs slow the main recurrence)
         self.dw_stream = not os.environ.get("CLSR_NO_DW_STREAM")   # A/B switch (see _dw)
         self._dw_async = False
@@ -129,6 +131,7 @@ class CLSRNet(object):
         self.sumsq_tab, self.losses = self.stats24[:16], self.stats24[16:]
         self.ucount = torch.zeros(1, dtype=F32, device=self.device)
         self.last_shape = None
+        self._counts_zeroed = self._ucount_zeroed = False
         self.dp_world = 1          # data-parallel world size (loss normalisers are global)
         self.dp_stats_hook = None  # optional callable(tensor): sum BN partial statistics across ranks
         # data-parallel exchange hooks (clsr_amd/dp.py): called (and recorded into launch plans) at the points of the
@@ -196,7 +199,7 @@ class CLSRNet(object):
         g = lambda k: getattr(hp, k, None)
         return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook),
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
-                self.lazy, self.rnn_first, self.lt_att_first, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h, self.flush_side, self.l1_bwd_2pass,
+                self.lazy, self.rnn_first, self.lt_att_first, self.dw_batch_late, self.bn_bwd_fused, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h, self.flush_side, self.l1_bwd_2pass,
                 self.split_g2, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
@@ -522,12 +525,12 @@ class CLSRNet(object):
             self._dw_flush()
 
     @contextlib.contextmanager
-    def _dw_batched(self):
+    def _dw_batched(self, late=False):
         """Every ``_dw`` issued inside the block becomes a job of ONE launch (clsr_*_dw_partial_multi) that waits only
         for what had been enqueued on the current stream when the block was ENTERED: the encoders' hidden-to-hidden /
         time-feature / input-side weight gradients all read the finished dPin and forward activations.  One after the
         other on the weight-gradient stream those ~7 products were the last 350 us of the backward pass."""
-        if not self.dw_batching or not self.defer_dw or self._dw_batch is not None:
+        if not self.dw_batching or not self.defer_dw or self._dw_batch is not None or (late and not self.dw_batch_late):
             yield
             return
         fork = self._fork_point()
@@ -539,9 +542,12 @@ class CLSRNet(object):
             jobs, self._dw_batch = self._dw_batch, None
         if not jobs:
             return
-        if self._buf_allocs != allocs:
-            # first occurrence of this shape: workspaces were allocated inside the block, and their zero fills sit on the
-            # current stream BEHIND the entry point -- this once the launch waits for everything enqueued so far
+        if late or self._buf_allocs != allocs:
+            # ``late``: the jobs' operands are produced INSIDE the block (small products of one backward stage whose
+            # launches are merged for the launch count, not for overlap): the launch waits for the block's end.
+            # Otherwise, first occurrence of this shape: workspaces were allocated inside the block, and their zero
+            # fills sit on the current stream BEHIND the entry point -- this once the launch waits for everything
+            # enqueued so far
             fork = self._fork_point()
         name = "clsr_hdw_partial_multi" if (self.bf16 and self.bf16_dw) else "clsr_pgemm_dw_partial_multi"
         if self.dw_stream and self.overlap and self._ws_tag == "":
@@ -615,6 +621,11 @@ class CLSRNet(object):
         return one, 1
 
     def _bn_bwd_from_partial(self, bn, part, parts, dy, z, M):
+        if self.dp_stats_hook is None and M * bn.C <= (1 << 23) and bn.C % 4 == 0 and self.bn_bwd_fused:
+            # row-level layers (alpha / logit MLPs): coefficients + apply in one launch
+            call("clsr_bn_bwd_coef_apply", part, parts, bn.C, float(M), bn.gamma, bn.mean, bn.invstd, bn.coef,
+                 bn.dgamma, bn.dbeta, dy, z, M)
+            return
         self._bn_bwd_coef(bn, part, parts, M)
         call("clsr_bn_bwd_apply", dy, z, bn.coef, M, bn.C)
 
@@ -1128,11 +1139,19 @@ class CLSRNet(object):
         """History-level / row-level tail of the attention backward (fp32 in both precision modes): gradients of
         the U / V projections, of the attention matrix, and d keys."""
         Gd, A0 = self.Gd, self.A0
-        self._dw(a, Q, dU, A0, Hn * T, Q, A0, dW0[0:Q], A0)                        # d(W0a + W0d)
-        self._dw(q, Q, dV, A0, R, Q, A0, dW0[Q:2 * Q], A0, db=Gd[nn + "b_nn_layer0"])  # d(W0q - W0d)
-        # d(W0d) = d(W0a+W0d) - d(W0q-W0d) block: needs the two reduced gradients above (runs at the flush)
-        self._dw_after.setdefault(self._ws_tag, []).append(
-            lambda: call("clsr_axpby", dW0[2 * Q:3 * Q], dW0[0:Q], 1.0, dW0[Q:2 * Q], -1.0, Q * A0))
+        # the two weight gradients that read the finished dU / dV leave as ONE two-job launch (operands final on entry:
+        # no waiting; merging the attention_mat product behind d(a) as well was measured at +0.05 ms per step)
+        with self._dw_batched():
+            self._dw(a, Q, dU, A0, Hn * T, Q, A0, dW0[0:Q], A0)                        # d(W0a + W0d)
+            self._dw(q, Q, dV, A0, R, Q, A0, dW0[Q:2 * Q], A0, db=Gd[nn + "b_nn_layer0"])  # d(W0q - W0d)
+        # d(W0d) = d(W0a+W0d) - d(W0q-W0d): a third reduction descriptor over the partial sums of the two products above
+        # (the batched reduction writes it in the same launch; it used to be an axpby launch behind the flush)
+        if self.defer_dw:
+            pend = self._dw_pending[self._ws_tag]
+            pa, pq = pend[-2], pend[-1]
+            pend.append((pa[0], dW0[2 * Q:3 * Q].data_ptr(), 0, 1.0, pa[4], Q, A0, A0, 0, pq[0], -1.0, pq[4]))
+        else:
+            call("clsr_axpby", dW0[2 * Q:3 * Q], dW0[0:Q], 1.0, dW0[Q:2 * Q], -1.0, Q * A0)
         if not da_has_u:      # (speed mode: clsr_att_l0_bwd_h has already added dU . Wu^T)
             self._gemm(dU, A0, key + ".Wu^T", Hn * T, A0, Q, da, Q, acc=1)
         if not qh:
@@ -1394,8 +1413,17 @@ class CLSRNet(object):
         fl = self.tab_flags
 
         def zero_and_mark():
-            call("clsr_zero_doubles", self.stats24, 24)      # squared norms (16) + loss terms (8): one buffer
-            call("clsr_zero_floats", zpool, zpool.numel())
+            # ONE zero-fill launch: squared norms (16) + loss terms (8), the gradient pool, the counters of the
+            # history-id sort and the distinct-user counter of the discrepancy loss
+            zr = [(self.stats24.data_ptr(), 24 * 8), (zpool.data_ptr(), zpool.numel() * 4)]
+            if self.sorted_hist_grad:
+                counts = self._sort_counts()[0]
+                zr.append((counts.data_ptr(), counts.numel() * 4))
+                self._counts_zeroed = True
+            if "user_long" in self.tables:
+                zr.append((self.ucount.data_ptr(), 4))
+                self._ucount_zeroed = True
+            ops.multi("clsr_zero_multi", ops.ZeroDesc, zr)
             # involved-row flags (tf.unique id sets)
             ops.multi("clsr_mark_rows_multi", ops.MarkDesc, [
                 (f["item_history"].data_ptr(), fl["item"].data_ptr(), Hn, hs * T, T, 0),
@@ -1430,17 +1458,19 @@ class CLSRNet(object):
         Gl = hp.train_num_ngs + 1
         call("clsr_softmax_loss", out["logit"], f["labels"], B // Gl, Gl, 1.0 / ((B // Gl) * self.dp_world),
              self.losses[0:], dlogit)
-        # ---- logit MLP, fusion, alpha MLP
-        dmo = self._mlp_bwd("lg", "sequential/logit_fcn/nn_part/", dlogit, out["model_output"], 2 * D, 2 * D, 2 * D,
-                            (self.L0, self.L1), B)
-        self._join()              # the contrastive branch: its dL / dS are accumulated into from here on
+        # ---- logit MLP, fusion, alpha MLP (their four small weight gradients: ONE multi-job launch at the end)
+        with self._dw_batched(late=True):
+            dmo = self._mlp_bwd("lg", "sequential/logit_fcn/nn_part/", dlogit, out["model_output"], 2 * D, 2 * D, 2 * D,
+                                (self.L0, self.L1), B)
+            self._join()              # the contrastive branch: its dL / dS are accumulated into from here on
+            if not hp.manual_alpha:
+                dal = self._buf("dalpha_logit", B)
+                call("clsr_alpha_fuse_bwd", dmo, out["alpha"], 0.0, out["att_fea_long"], out["att_fea_short"], Hn, G, D,
+                     dal, dL, dS, dtarget)
+                ld = _pad4(self.a_in)
+                dain = self._mlp_bwd("al", CL + "fcn_alpha/nn_part/", dal, self._buf("al.in", B, ld), ld, ld, self.a_in,
+                                     (self.A0, self.A1), B)
         if not hp.manual_alpha:
-            dal = self._buf("dalpha_logit", B)
-            call("clsr_alpha_fuse_bwd", dmo, out["alpha"], 0.0, out["att_fea_long"], out["att_fea_short"], Hn, G, D,
-                 dal, dL, dS, dtarget)
-            ld = _pad4(self.a_in)
-            dain = self._mlp_bwd("al", CL + "fcn_alpha/nn_part/", dal, self._buf("al.in", B, ld), ld, ld, self.a_in,
-                                 (self.A0, self.A1), B)
             nfs = H if hp.predict_long_short else 0
             call("clsr_alpha_concat_bwd", dain, ld, nfs, Hn, G, D, dfs if nfs else None, dtarget, dL, dS)
         else:
@@ -1534,12 +1564,14 @@ class CLSRNet(object):
                 call("clsr_scatter_add_rows", dtarget, D, Di, f["cates"], 1, B, Dc, self.tab_grad["cate"], ss[3:])
                 self._dp_hook("table_ready", "cate")
             with self._branch("@aux" if self.split_emb_grad else "@main", after=fork):
-                call("clsr_scatter_add_rows", dul, Du, 0, f["users"], hs, Hn, Du, self.tab_grad["user_long"], ss[6:])
-                call("clsr_scatter_add_rows", dushort, Du, 0, f["users"], hs, Hn, Du, self.tab_grad["user_short"],
-                     ss[7:])
+                # user rows (long / short table) and the target items' rows: ONE launch, blockIdx.y = lookup site
+                tg, dp_ = self.tab_grad, lambda t: t.data_ptr()
+                ops.multi("clsr_scatter_add_rows_multi", ops.ScatterDesc, [
+                    (dp_(dul), dp_(f["users"]), dp_(tg["user_long"]), dp_(ss[6:]), hs, Du, 0, Hn, Du),
+                    (dp_(dushort), dp_(f["users"]), dp_(tg["user_short"]), dp_(ss[7:]), hs, Du, 0, Hn, Du),
+                    (dp_(dtarget), dp_(f["items"]), dp_(tg["item"]), dp_(ss[2:]), 1, D, 0, B, Di)])
                 self._dp_hook("table_ready", "user_long")
                 self._dp_hook("table_ready", "user_short")
-                call("clsr_scatter_add_rows", dtarget, D, 0, f["items"], 1, B, Di, self.tab_grad["item"], ss[2:])
             self._hist_grad_sorted(dhist, dM, dR, Hn, T, seq_len, ls, ss, only="item")
             self._join(but="@dense")
             self._dp_hook("table_ready", "item")
@@ -1569,14 +1601,19 @@ class CLSRNet(object):
         return (("item", "item_history", self.dims["Vi"], 0, self.Di, 0),
                 ("cate", "item_cate_history", self.dims["Vc"], self.Di, self.Dc, 1))
 
+    def _sort_counts(self):
+        bits = [query("clsr_sort_ids_bits", V) for _, _, V, _, _, _ in self._sort_tables()]
+        return self._buf("sort.counts", sum(1 << b for b in bits), dtype=torch.int32), bits
+
     def _sort_hist_ids(self, f, Hn, T, hs):
         """(row id, position) pairs of both history lookups grouped by row id: hand-written counting sort, one
         zeroing launch + three launches for both tables together (csrc/sparse.hip: clsr_sort_ids_multi)."""
         n = Hn * T
         tabs = self._sort_tables()
-        bits = [query("clsr_sort_ids_bits", V) for _, _, V, _, _, _ in tabs]
-        counts = self._buf("sort.counts", sum(1 << b for b in bits), dtype=torch.int32)
-        call("clsr_zero_floats", counts.view(F32), counts.numel())
+        counts, bits = self._sort_counts()
+        if not self._counts_zeroed:      # (the training step clears them with its other accumulators)
+            call("clsr_zero_floats", counts.view(F32), counts.numel())
+        self._counts_zeroed = False
         rows, o = [], 0
         for (name, fkey, V, _, _, _), b in zip(tabs, bits):
             keys = self._buf("sort.keys." + name, n, dtype=torch.int32)
@@ -1636,16 +1673,19 @@ class CLSRNet(object):
         l2e, l1e = float(hp.embed_l2), float(hp.embed_l1)
         tb, tg, fl = self.tables, self.tab_grad, self.tab_flags
         if "user_long" in tb:      # number of distinct users of the batch: the discrepancy loss is a mean over them
-            call("clsr_zero_floats", self.ucount, 1)
+            if not self._ucount_zeroed:      # (the training step clears it with its other accumulators)
+                call("clsr_zero_floats", self.ucount, 1)
+            self._ucount_zeroed = False
             call("clsr_count_flags", fl["user_long"], Vu, self.ucount)
         clip = float(hp.max_grad_norm) if hp.is_clip_norm else 0.0
         # dense variables (regulariser + norms, Adam clock, Adam) on the @aux stream beside the table regulariser
         with self._branch("@main" if (self.capture_grads or not self.split_emb_grad) else "@aux"):
             self._join(only="@dense")     # (the batched weight-gradient reduction, see _train_step)
-            call("clsr_dense_reg_norm", self.dense, self.dense_grad, self.seg_off, len(self.dense_names),
-                 float(hp.layer_l2), float(hp.layer_l1), self.dense_sumsq, self.losses[1:])
+            # (the Adam clock of the step ticks in the same launch: every reader is ordered after it)
+            call("clsr_dense_reg_norm_tick", self.dense, self.dense_grad, self.seg_off, len(self.dense_names),
+                 float(hp.layer_l2), float(hp.layer_l1), self.dense_sumsq, self.losses[1:],
+                 None if self.capture_grads else self.adam_state, float(hp.learning_rate), 0.9, 0.999)
             if not self.capture_grads:
-                call("clsr_adam_tick", self.adam_state, float(hp.learning_rate), 0.9, 0.999)
                 call("clsr_dense_adam", self.dense, self.dense_grad, self.dense_m, self.dense_v, self.seg_of,
                      self.dense_sumsq, clip, self.adam_state, 0.9, 0.999, 1e-8, self.n_dense)
         lists = {k: self._involved_list(k) for k, t in tb.items() if t.numel() > self.rowlist_min_elems}

@@ -255,7 +255,8 @@ class DwDesc(ctypes.Structure):
     """ctypes mirror of clsr_dw_desc (include/clsr_hip.h)."""
     _fields_ = [("partial", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("db", ctypes.c_void_p),
                 ("scale", ctypes.c_float)] + \
-               [(n, ctypes.c_int) for n in ("nparts", "K", "N", "ldw", "accumulate")]
+               [(n, ctypes.c_int) for n in ("nparts", "K", "N", "ldw", "accumulate")] + \
+               [("partial2", ctypes.c_void_p), ("scale2", ctypes.c_float), ("nparts2", ctypes.c_int)]
 
 
 def dw_table(sig, device):
@@ -265,9 +266,12 @@ def dw_table(sig, device):
 
     assert ctypes.sizeof(DwDesc) == query("clsr_sizeof_dw_desc")
     arr = (DwDesc * len(sig))()
-    for d, (partial, dW, db, scale, nparts, K, N, ldw, acc) in zip(arr, sig):
+    for d, row in zip(arr, sig):
+        partial, dW, db, scale, nparts, K, N, ldw, acc = row[:9]
         d.partial, d.dW, d.db, d.scale = partial, dW, db or None, scale
         d.nparts, d.K, d.N, d.ldw, d.accumulate = nparts, K, N, ldw, acc
+        if len(row) > 9:      # + (partial2, scale2, nparts2): a second product summed into the same output
+            d.partial2, d.scale2, d.nparts2 = row[9], row[10], row[11]
     t = _t.frombuffer(bytearray(bytes(memoryview(arr))), dtype=_t.uint8).to(device)
     # max_outputs / 64 = blocks per descriptor: one per quarter of a 16 x 16 tile (+ 64-wide bias slices)
     cd = lambda a, b: -(-a // b)
@@ -280,6 +284,15 @@ _P, _L, _I, _F = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float
 
 class MarkDesc(ctypes.Structure):
     _fields_ = [("idx", _P), ("flags", _P), ("nrows", _L), ("row_stride", _L), ("ncols", _I), ("pad_", _I)]
+
+
+class ZeroDesc(ctypes.Structure):
+    _fields_ = [("p", _P), ("nbytes", _L)]
+
+
+class ScatterDesc(ctypes.Structure):
+    _fields_ = [("src", _P), ("idx", _P), ("tbl_grad", _P), ("sumsq", _P), ("idx_stride", _L), ("ld_src", _I),
+                ("col0", _I), ("N", _I), ("C", _I)]
 
 
 class GatherDesc(ctypes.Structure):
@@ -348,6 +361,8 @@ def _check_multi_sizes():
     sz = [ctypes.c_int() for _ in range(4)]
     _lib.load().clsr_sizeof_multi_descs(*[ctypes.byref(x) for x in sz])
     got = [ctypes.sizeof(c) for c in (MarkDesc, GatherDesc, RpDesc, TableDesc)]
+    got += [ctypes.sizeof(ZeroDesc), ctypes.sizeof(ScatterDesc)]
+    sz += [ctypes.c_int(query("clsr_sizeof_zero_desc")), ctypes.c_int(query("clsr_sizeof_scatter_desc"))]
     if got != [x.value for x in sz]:
         raise RuntimeError("ctypes mirrors of the multi-launch descriptors are out of date: %r vs %r"
                            % (got, [x.value for x in sz]))

@@ -208,6 +208,9 @@ typedef struct clsr_dw_desc {
   const float* partial; float* dW; float* db;
   float scale;
   int nparts; int K; int N; int ldw; int accumulate;
+  /* optional second product of the same K x N shape: dW = scale * sum(partial) + scale2 * sum(partial2)
+   * (the W0d block of the re-associated attention layer = d(W0a+W0d) - d(W0q-W0d), without a launch of its own) */
+  const float* partial2; float scale2; int nparts2;
 } clsr_dw_desc;
 int clsr_sizeof_dw_desc(void);
 int clsr_pgemm_dw_parts(int M);
@@ -236,6 +239,10 @@ int clsr_bn_bwd_coef(const double* partial, int nparts, int C, double count, con
                      const float* mean, const float* invstd, float* coef, float* dgamma, float* dbeta,
                      int accumulate, void* stream);
 int clsr_bn_bwd_apply(float* dy, const float* z, const float* coef, long M, int C, void* stream);
+/* clsr_bn_bwd_coef + clsr_bn_bwd_apply in one launch (row-level layers: every block folds the partial sums itself) */
+int clsr_bn_bwd_coef_apply(const double* partial, int nparts, int C, double count, const float* gamma,
+                           const float* mean, const float* invstd, float* coef, float* dgamma, float* dbeta,
+                           float* dy, const float* z, long M, void* stream);
 
 /* ---- attention tail: score layer + padding mask + softmax over T + weighted sum, clsr.py:371-381 */
 int clsr_att_out_fwd(const float* z1, const float* scale1, const float* shift1, const float* w_out,
@@ -394,6 +401,11 @@ int clsr_mul_rows(const float* a, int lda, const float* b, int ldb, int G, long 
 int clsr_adam_tick(double* state, double lr, double beta1, double beta2, void* stream);
 int clsr_dense_reg_norm(const float* param, float* grad, const int* seg_off, int nseg, float l2, float l1,
                         double* sumsq, double* reg_loss, void* stream);
+/* the same launch also advances the Adam clock (clsr_adam_tick) when adam_state != NULL: one dispatch less per step;
+ * every consumer of the clock is ordered after this launch */
+int clsr_dense_reg_norm_tick(const float* param, float* grad, const int* seg_off, int nseg, float l2, float l1,
+                             double* sumsq, double* reg_loss, double* adam_state, double lr, double beta1, double beta2,
+                             void* stream);
 int clsr_dense_adam(float* param, float* grad, float* m, float* v, const int* seg_of,
                     const double* sumsq, float clip_norm, const double* adam_state, float beta1,
                     float beta2, float eps, int n, void* stream);
@@ -441,6 +453,16 @@ typedef struct clsr_table_desc {
   double* sumsq_reg; double* disc_loss; const double* sumsq_adam;
   long V; int C; int nsum; int sumsq_stride; float disc_scale; float disc_loss_scale; int pad_;
 } clsr_table_desc;
+/* zero fills of several byte ranges (4-byte aligned, multiples of 4 bytes) in one launch */
+typedef struct clsr_zero_desc { void* p; long nbytes; } clsr_zero_desc;
+int clsr_sizeof_zero_desc(void);
+int clsr_zero_multi(const clsr_zero_desc* descs_host, int n, void* stream);
+/* clsr_scatter_add_rows for several lookup sites in one launch (sumsq may be NULL) */
+typedef struct clsr_scatter_desc {
+  const float* src; const int* idx; float* tbl_grad; double* sumsq; long idx_stride; int ld_src; int col0; int N; int C;
+} clsr_scatter_desc;
+int clsr_sizeof_scatter_desc(void);
+int clsr_scatter_add_rows_multi(const clsr_scatter_desc* descs_host, int n, void* stream);
 int clsr_sizeof_multi_descs(int* mark, int* gather, int* rp, int* table);
 int clsr_mark_rows_multi(const clsr_mark_desc* descs_host, int n, void* stream);
 int clsr_gather_rows_multi(const clsr_gather_desc* descs_host, int n, void* stream);

@@ -1117,3 +1117,110 @@ def test_attention_layer1_backward_two_passes_fp32(M, C1, C0):
     close(dz1, dz1_b, rtol=1e-6, atol=1e-6, name="dz1 vs dy1-apply kernel")
     close(st.sum(0), st2.sum(0), rtol=1e-6, atol=1e-6 * scale, name="BN sums vs clsr_pgemm_bnbwd")
     close(dz0[:, :C0], dy0_b, rtol=1e-5, atol=2e-5, name="dz0 vs GEMM + bn-apply kernels")
+
+
+# ------------------------------------------------------------------------------- merged small launches (round 2)
+def test_zero_multi_ranges():
+    """clsr_zero_multi clears exactly the given byte ranges (unaligned starts, odd word counts, empty range)."""
+    buf = torch.full((4099,), 7.0, device="cuda")
+    d8 = torch.full((24,), 3.0, dtype=torch.float64, device="cuda")
+    one = torch.full((3,), 5.0, device="cuda")
+    ops.multi("clsr_zero_multi", ops.ZeroDesc, [(buf[1:].data_ptr(), 4093 * 4), (d8.data_ptr(), 24 * 8),
+                                                (one[1:].data_ptr(), 4), (one.data_ptr(), 0)])
+    torch.cuda.synchronize()
+    b = buf.cpu()
+    assert float(b[0]) == 7.0 and float(b[1:4094].abs().max()) == 0.0 and bool((b[4094:] == 7.0).all())
+    assert float(d8.abs().max()) == 0.0
+    assert one.cpu().tolist() == [5.0, 0.0, 5.0]
+
+
+def test_scatter_add_rows_multi_matches_single_launches():
+    g = torch.Generator().manual_seed(21)
+    V, N, G = 301, 77, 3
+    sites = [(40, 0, 40, 40), (48, 8, 32, 32), (48, 40, 8, 8)]     # (ld_src, col0, C, table width)
+    idx = torch.randint(0, V, (N * G,), generator=g)
+    d_idx = dev(idx, torch.int32)
+    rows, exp, grads, sss = [], [], [], []
+    for ld, c0, C, _ in sites:
+        src = rnd(g, N, ld)
+        dsrc = dev(src, torch.float32)
+        grad = torch.zeros(V, C, device="cuda")
+        ss = torch.zeros(1, dtype=torch.float64, device="cuda")
+        rows.append((dsrc.data_ptr(), d_idx.data_ptr(), grad.data_ptr(), ss.data_ptr(), G, ld, c0, N, C))
+        exp.append((torch.zeros(V, C, dtype=torch.float64).index_add_(0, idx[::G], src[:, c0:c0 + C]),
+                    (src[:, c0:c0 + C] ** 2).sum().reshape(1)))
+        grads.append(grad)
+        sss.append(ss)
+        rows[-1] = rows[-1] + ()
+        exp[-1] = exp[-1] + (dsrc,)    # keep the device source alive until the launch
+    ops.multi("clsr_scatter_add_rows_multi", ops.ScatterDesc, rows)
+    for grad, ss, (e, es, _) in zip(grads, sss, exp):
+        close(grad, e, rtol=1e-4, atol=1e-5, name="scatter multi")
+        close(ss, es, name="scatter multi sumsq")
+
+
+@pytest.mark.parametrize("M,C,parts", [(20480, 100, 160), (333, 64, 7), (4096, 40, 1)])
+def test_bn_bwd_coef_apply_fused_equals_two_launches(M, C, parts):
+    g = torch.Generator().manual_seed(M)
+    f32 = torch.float32
+    part = dev(rnd(g, parts, 2, C))                     # float64 partial sums
+    gamma, mean, invstd = dev(rnd(g, C), f32), dev(rnd(g, C), f32), dev(rnd(g, C).abs() + 0.5, f32)
+    dy, z = rnd(g, M, C), rnd(g, M, C)
+    dy_a, dy_b, dz = dev(dy, f32), dev(dy, f32), dev(z, f32)
+    coef_a, coef_b = torch.empty(3, C, device="cuda"), torch.empty(3, C, device="cuda")
+    dg_a, db_a, dg_b, db_b = (torch.zeros(C, device="cuda") for _ in range(4))
+    call("clsr_bn_bwd_coef", part, parts, C, float(M), gamma, mean, invstd, coef_a, dg_a, db_a, 0)
+    call("clsr_bn_bwd_apply", dy_a, dz, coef_a, M, C)
+    call("clsr_bn_bwd_coef_apply", part, parts, C, float(M), gamma, mean, invstd, coef_b, dg_b, db_b, dy_b, dz, M)
+    close(coef_b, coef_a.double().cpu(), rtol=1e-6, atol=1e-7, name="coef")
+    close(dg_b, dg_a.double().cpu(), rtol=1e-6, atol=1e-7, name="dgamma")
+    close(db_b, db_a.double().cpu(), rtol=1e-6, atol=1e-7, name="dbeta")
+    close(dy_b, dy_a.double().cpu(), rtol=1e-5, atol=1e-6, name="dz")
+
+
+def test_dense_reg_norm_tick_advances_the_adam_clock():
+    g = torch.Generator().manual_seed(5)
+    sizes = [300, 7]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    n = int(off[-1])
+    p, gr = rnd(g, n), rnd(g, n)
+    f32 = torch.float32
+    dp_, dg_ = dev(p, f32), dev(gr, f32)
+    ss = torch.zeros(2, dtype=torch.float64, device="cuda")
+    st = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device="cuda")
+    call("clsr_dense_reg_norm_tick", dp_, dg_, dev(off), 2, 1e-3, 0.0, ss, None, st, 1e-3, 0.9, 0.999)
+    call("clsr_dense_reg_norm_tick", dp_, dg_, dev(off), 2, 0.0, 0.0, ss, None, st, 1e-3, 0.9, 0.999)
+    lr_t = 1e-3 * math.sqrt(1 - 0.999 ** 2) / (1 - 0.9 ** 2)
+    assert abs(float(st[3]) - lr_t) < 1e-12 and float(st[0]) == 2.0
+    g2 = gr + 1e-3 * p
+    close(ss, torch.stack([(g2[:300] ** 2).sum(), (g2[300:] ** 2).sum()]), rtol=1e-5, name="sumsq")
+    call("clsr_dense_reg_norm_tick", dp_, dg_, dev(off), 2, 0.0, 0.0, ss, None, None, 0.0, 0.0, 0.0)
+    assert float(st[0]) == 2.0
+
+
+@pytest.mark.parametrize("M1,M2,K,N", [(5000, 700, 80, 80), (300, 9000, 40, 96), (64, 64, 164, 36)])
+def test_dw_reduce_batch_two_products_into_one_block(M1, M2, K, N):
+    """A reduction descriptor with a second partial buffer: dW = X1^T dY1 - X2^T dY2 in the batched reduction itself
+    (the W0d block of the re-associated attention layer), next to ordinary descriptors of the same launch."""
+    g = torch.Generator().manual_seed(M1 + K)
+    f32 = torch.float32
+    X1, Y1, X2, Y2 = rnd(g, M1, K), rnd(g, M1, N), rnd(g, M2, K), rnd(g, M2, N)
+    d = [dev(t, f32) for t in (X1, Y1, X2, Y2)]
+    ws1 = torch.zeros(query("clsr_pgemm_dw_workspace_floats", M1, K, N), device="cuda")
+    ws2 = torch.zeros(query("clsr_pgemm_dw_workspace_floats", M2, K, N), device="cuda")
+    call("clsr_pgemm_dw_partial", d[0], K, 0, 0, None, 0, None, None, 1, d[1], N, M1, K, N, ws1)
+    call("clsr_pgemm_dw_partial", d[2], K, 0, 0, None, 0, None, None, 1, d[3], N, M2, K, N, ws2)
+    dW1, dW2, dWd = (torch.full((K, N), 9.0, device="cuda") for _ in range(3))
+    db1 = torch.zeros(N, device="cuda")
+    p1, p2 = query("clsr_pgemm_dw_parts", M1), query("clsr_pgemm_dw_parts", M2)
+    sig = ((ws1.data_ptr(), dW1.data_ptr(), db1.data_ptr(), 1.0, p1, K, N, N, 0),
+           (ws2.data_ptr(), dW2.data_ptr(), 0, 1.0, p2, K, N, N, 0),
+           (ws1.data_ptr(), dWd.data_ptr(), 0, 1.0, p1, K, N, N, 0, ws2.data_ptr(), -1.0, p2))
+    tab = ops.dw_table(sig, torch.device("cuda"))
+    call("clsr_dw_reduce_batch", tab[0], tab[1], tab[2])
+    e1, e2 = X1.T @ Y1, X2.T @ Y2
+    sc = float(max(e1.abs().max(), e2.abs().max()))
+    close(dW1, e1, rtol=1e-5, atol=2e-6 * sc, name="dW1")
+    close(db1, Y1.sum(0), rtol=1e-5, atol=2e-6 * sc, name="db1")
+    close(dW2, e2, rtol=1e-5, atol=2e-6 * sc, name="dW2")
+    close(dWd, e1 - e2, rtol=1e-5, atol=4e-6 * sc, name="dW1 - dW2")
