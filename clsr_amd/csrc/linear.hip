@@ -868,6 +868,7 @@ struct DwMultiArgs {
   short nch[DWM_MAX];
   short mode[DWM_MAX];
   int n;
+  int spec;    // 0: generic body only (CLSR_DW_GENERIC)
 };
 __global__ void __launch_bounds__(256) dw_multi_kernel(DwMultiArgs m) {
   __shared__ __attribute__((aligned(16))) float lds[DW_LDS_FLOATS];
@@ -877,9 +878,18 @@ __global__ void __launch_bounds__(256) dw_multi_kernel(DwMultiArgs m) {
   const int gx = m.gx[j], nch = m.nch[j];
   const int bx = local % gx, c = local / gx;
   const int by = c / nch, bz = c - by * nch;
-  if (m.mode[j] == 0) dw_body<0>(m.d[j], lds, bx, gx, by, bz, nch);
-  else if (m.mode[j] == 1) dw_body<1>(m.d[j], lds, bx, gx, by, bz, nch);
-  else dw_body<2>(m.d[j], lds, bx, gx, by, bz, nch);
+  // this block's tile counts (uniform): the plain products of the common widths (K = 40 -> 3 tiles, full 80-wide N
+  // chunks -> 5: the input-side / hidden-to-hidden gradients of the encoders) run the compile-time-count body
+  const int ktc = min(DW_T, ((m.d[j].K + 15) >> 4) - by * DW_T), ntc = min(DW_T, ((m.d[j].N + 15) >> 4) - bz * DW_T);
+  if (m.mode[j] == 0) {
+    if (m.spec && ktc == 3 && ntc == 5) dw_body<0, false, false, 3, 5>(m.d[j], lds, bx, gx, by, bz, nch);
+    else if (m.spec && ktc == 5 && ntc == 5) dw_body<0, false, false, 5, 5>(m.d[j], lds, bx, gx, by, bz, nch);
+    else if (m.spec > 1 && ktc == 5 && ntc == 3) dw_body<0, false, false, 5, 3>(m.d[j], lds, bx, gx, by, bz, nch);
+    else dw_body<0>(m.d[j], lds, bx, gx, by, bz, nch);
+  } else if (m.mode[j] == 1) {
+    if (m.spec > 1 && ktc == 3 && ntc == 3) dw_body<1, false, false, 3, 3>(m.d[j], lds, bx, gx, by, bz, nch);
+    else dw_body<1>(m.d[j], lds, bx, gx, by, bz, nch);
+  } else dw_body<2>(m.d[j], lds, bx, gx, by, bz, nch);
 }
 
 // dW[k*ldw + n] (=|+=) scale * sum_p partial[...]; db[n] likewise (from K-chunk 0).
@@ -1013,6 +1023,7 @@ extern "C" int clsr_pgemm_dw_partial_multi(const clsr_dwjob* jobs, int n, void* 
     total += m.gx[j] * kch * nch;
   }
   m.first[n] = total;
+  m.spec = getenv("CLSR_DW_GENERIC") ? 0 : (getenv("CLSR_DW_SPEC") ? atoi(getenv("CLSR_DW_SPEC")) : 2);
   hipLaunchKernelGGL(dw_multi_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, m);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
