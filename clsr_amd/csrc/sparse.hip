@@ -198,10 +198,10 @@ extern "C" int clsr_sort_ids(const int* ids, long nrows, int ncols, long row_str
 #define GBS_CHUNK(CP) ((CP) < 16 ? 16 : (CP))   // sorted entries per thread group
 template <int CP>
 __global__ void __launch_bounds__(256) gather_bwd_sorted_kernel(
-    const float* __restrict__ dhist, const float* __restrict__ dmean, const float* __restrict__ drecent,
-    const int* __restrict__ keys, const int* __restrict__ perm, const int* __restrict__ seq_len,
-    int len_stride, long n, int T, int D, int col0, int C, int recent_k, float* __restrict__ grad, int ldg,
-    int gcol0, double* __restrict__ sumsq) {
+    const float* __restrict__ dhist, const float* __restrict__ dhist2, const float* __restrict__ dmean,
+    const float* __restrict__ drecent, const int* __restrict__ keys, const int* __restrict__ perm,
+    const int* __restrict__ seq_len, int len_stride, long n, int T, int D, int col0, int C, int recent_k,
+    float* __restrict__ grad, int ldg, int gcol0, double* __restrict__ sumsq) {
   __shared__ double red[4];
   constexpr int GPB = 256 / CP;              // thread groups per block
   constexpr int EPL = GBS_CHUNK(CP) / CP;    // chunk entries preloaded per lane
@@ -233,6 +233,7 @@ __global__ void __launch_bounds__(256) gather_bwd_sorted_kernel(
   int cur = -1;
   float acc = 0.f, local = 0.f;
   const float* dh_c = dhist + col0 + (cok ? c : 0);
+  const float* dh2_c = dhist2 ? dhist2 + col0 + (cok ? c : 0) : nullptr;   // second addend of d(hist), same layout
   const float* dm_c = dmean ? dmean + col0 + (cok ? c : 0) : nullptr;
   const float* dr_c = drecent ? drecent + col0 + (cok ? c : 0) : nullptr;
 #pragma unroll
@@ -252,6 +253,7 @@ __global__ void __launch_bounds__(256) gather_bwd_sorted_kernel(
         const float flen = __shfl(ml[u], q0 + k, CP);
         const float frec = __shfl(mr[u], q0 + k, CP);
         float v = dh_c[(long)pos * D];
+        if (dh2_c) v += dh2_c[(long)pos * D];
         if (dm_c) v += flen > 0.f ? dm_c[(long)h * D] / flen : 0.f;
         if (dr_c) v += frec > 0.f ? dr_c[(long)h * D] / frec : 0.f;
         g[k] = (cok && key[k] >= 0) ? v : 0.f;
@@ -277,10 +279,10 @@ __global__ void __launch_bounds__(256) gather_bwd_sorted_kernel(
   }
 }
 
-extern "C" int clsr_gather_bwd_sorted(const float* dhist, const float* dmean, const float* drecent,
-                                      const int* keys, const int* perm, const int* seq_len, int len_stride,
-                                      long n, int T, int D, int col0, int C, int recent_k, float* grad,
-                                      int ldg, int gcol0, double* sumsq, void* stream) {
+extern "C" int clsr_gather_bwd_sorted2(const float* dhist, const float* dhist2, const float* dmean,
+                                       const float* drecent, const int* keys, const int* perm, const int* seq_len,
+                                       int len_stride, long n, int T, int D, int col0, int C, int recent_k,
+                                       float* grad, int ldg, int gcol0, double* sumsq, void* stream) {
   CLSR_CHECK_ARG(dhist && keys && perm && seq_len && grad && n > 0 && T > 0 && D > 0 && C > 0);
   CLSR_CHECK_SUPPORTED(C <= 64);
   const int CP = C <= 8 ? 8 : (C <= 16 ? 16 : (C <= 32 ? 32 : 64));
@@ -288,8 +290,8 @@ extern "C" int clsr_gather_bwd_sorted(const float* dhist, const float* dmean, co
   const int blocks = clsr_cdiv(groups, 256 / CP);
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_GBS(CPV)                                                                                     \
-  hipLaunchKernelGGL(gather_bwd_sorted_kernel<CPV>, dim3(blocks), dim3(256), 0, s, dhist, dmean, drecent,   \
-                     keys, perm, seq_len, len_stride, n, T, D, col0, C, recent_k, grad, ldg, gcol0, sumsq)
+  hipLaunchKernelGGL(gather_bwd_sorted_kernel<CPV>, dim3(blocks), dim3(256), 0, s, dhist, dhist2, dmean,    \
+                     drecent, keys, perm, seq_len, len_stride, n, T, D, col0, C, recent_k, grad, ldg, gcol0, sumsq)
   if (CP == 8) LAUNCH_GBS(8);
   else if (CP == 16) LAUNCH_GBS(16);
   else if (CP == 32) LAUNCH_GBS(32);
@@ -297,6 +299,14 @@ extern "C" int clsr_gather_bwd_sorted(const float* dhist, const float* dmean, co
 #undef LAUNCH_GBS
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
+}
+
+extern "C" int clsr_gather_bwd_sorted(const float* dhist, const float* dmean, const float* drecent,
+                                      const int* keys, const int* perm, const int* seq_len, int len_stride,
+                                      long n, int T, int D, int col0, int C, int recent_k, float* grad,
+                                      int ldg, int gcol0, double* sumsq, void* stream) {
+  return clsr_gather_bwd_sorted2(dhist, nullptr, dmean, drecent, keys, perm, seq_len, len_stride, n, T, D, col0, C,
+                                 recent_k, grad, ldg, gcol0, sumsq, stream);
 }
 
 // =================================================================== touched-row exchange (multi-GPU)

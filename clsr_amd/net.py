@@ -95,6 +95,7 @@ class CLSRNet(object):
         self.rnn_first = not os.environ.get("CLSR_BRANCH_FIRST")   # A/B switch (see forward)
         self.dw_batch_late = not os.environ.get("CLSR_NO_DW_BATCH_LATE")   # A/B: merged launches of the attention / head weight gradients
         self.bn_bwd_fused = not os.environ.get("CLSR_NO_BN_BWD_FUSED")   # A/B: coefficient + apply of the row-level batch-norm backward in one launch
+        self.hist_grad_two = not os.environ.get("CLSR_NO_HIST_GRAD_TWO")   # A/B: dhist + dhist_lt summed inside the segmented sums
         self.lt_att_first = bool(os.environ.get("CLSR_LT_ATT_FIRST"))   # A/B: long-term attention before the causal GRU on @lt (measured: +0.03 ms fp32, +0.04 ms bf16 -- the heavy GEMMs slow the main recurrence)
         self.dw_stream = not os.environ.get("CLSR_NO_DW_STREAM")   # A/B switch (see _dw)
         self._dw_async = False
@@ -199,7 +200,7 @@ class CLSRNet(object):
         g = lambda k: getattr(hp, k, None)
         return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook),
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
-                self.lazy, self.rnn_first, self.lt_att_first, self.dw_batch_late, self.bn_bwd_fused, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h, self.flush_side, self.l1_bwd_2pass,
+                self.lazy, self.rnn_first, self.lt_att_first, self.hist_grad_two, self.dw_batch_late, self.bn_bwd_fused, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h, self.flush_side, self.l1_bwd_2pass,
                 self.split_g2, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
@@ -1550,7 +1551,11 @@ class CLSRNet(object):
                 self._dense_grads_final()
         else:
             self._dense_grads_final()
-        call("clsr_axpby", dhist, dhist, 1.0, dhist_lt, 1.0, dhist.numel())
+        # d(hist) = dhist + dhist_lt (the long-term branch's share): the segmented sums add the two on the fly; the
+        # float-atomics path gets one tensor
+        if not (self.sorted_hist_grad and self.hist_grad_two):
+            call("clsr_axpby", dhist, dhist, 1.0, dhist_lt, 1.0, dhist.numel())
+            dhist_lt = None
         # ---- embedding gradients (IndexedSlices values -> dense grad tables + squared norms)
         ss = self.sumsq_tab
         if self.sorted_hist_grad:
@@ -1560,7 +1565,7 @@ class CLSRNet(object):
             # streams that are idle by now instead of one after the other
             fork = self._fork_point()
             with self._branch("@lt" if self.split_emb_grad else "@main", after=fork):
-                self._hist_grad_sorted(dhist, dM, dR, Hn, T, seq_len, ls, ss, only="cate")
+                self._hist_grad_sorted(dhist, dM, dR, Hn, T, seq_len, ls, ss, only="cate", dhist2=dhist_lt)
                 call("clsr_scatter_add_rows", dtarget, D, Di, f["cates"], 1, B, Dc, self.tab_grad["cate"], ss[3:])
                 self._dp_hook("table_ready", "cate")
             with self._branch("@aux" if self.split_emb_grad else "@main", after=fork):
@@ -1572,7 +1577,7 @@ class CLSRNet(object):
                     (dp_(dtarget), dp_(f["items"]), dp_(tg["item"]), dp_(ss[2:]), 1, D, 0, B, Di)])
                 self._dp_hook("table_ready", "user_long")
                 self._dp_hook("table_ready", "user_short")
-            self._hist_grad_sorted(dhist, dM, dR, Hn, T, seq_len, ls, ss, only="item")
+            self._hist_grad_sorted(dhist, dM, dR, Hn, T, seq_len, ls, ss, only="item", dhist2=dhist_lt)
             self._join(but="@dense")
             self._dp_hook("table_ready", "item")
         else:
@@ -1622,7 +1627,7 @@ class CLSRNet(object):
             o += 1 << b
         ops.sort_ids_multi(rows)
 
-    def _hist_grad_sorted(self, dhist, dM, dR, Hn, T, seq_len, ls, ss, only=None):
+    def _hist_grad_sorted(self, dhist, dM, dR, Hn, T, seq_len, ls, ss, only=None, dhist2=None):
         """IndexedSlices of the history lookups -> dense gradient tables via segmented sums over the
         sorted ids (no float atomics on hot rows; deterministic).  ``only``: one table ("item" / "cate")."""
         n = Hn * T
@@ -1633,7 +1638,7 @@ class CLSRNet(object):
             keys = self._buf("sort.keys." + name, n, dtype=torch.int32)
             perm = self._buf("sort.perm." + name, n, dtype=torch.int32)
             for c0 in range(0, C, 64):   # column blocks of <= 64 floats; squared norms accumulate in the slot
-                call("clsr_gather_bwd_sorted", dhist, dM, dR, keys, perm, seq_len, ls, n, T, self.D, col0 + c0,
+                call("clsr_gather_bwd_sorted2", dhist, dhist2, dM, dR, keys, perm, seq_len, ls, n, T, self.D, col0 + c0,
                      min(64, C - c0), k, self.tab_grad[name], C, c0, ss[slot:])
 
     #: tables with more elements than this are regularised / lazily updated through the compacted list of

@@ -62,6 +62,11 @@ int clsr_sort_ids_multi(const clsr_sortids_desc* descs_host, int n, void* stream
 long clsr_sort_ids_workspace_bytes(long n, long vocab);
 int clsr_sort_ids(const int* ids, long nrows, int ncols, long row_stride, long vocab, int* keys_out,
                   int* perm_out, void* workspace, long workspace_bytes, void* stream);
+/* ...sorted2: g = dhist + dhist2 (+ mean / recent terms): the long-term branch's share of d(hist) is added on the fly
+ * instead of by an axpby pass over both tensors (dhist2 may be NULL) */
+int clsr_gather_bwd_sorted2(const float* dhist, const float* dhist2, const float* dmean, const float* drecent,
+                            const int* keys, const int* perm, const int* seq_len, int len_stride, long n, int T, int D,
+                            int col0, int C, int recent_k, float* grad, int ldg, int gcol0, double* sumsq, void* stream);
 int clsr_gather_bwd_sorted(const float* dhist, const float* dmean, const float* drecent, const int* keys,
                            const int* perm, const int* seq_len, int len_stride, long n, int T, int D, int col0,
                            int C, int recent_k, float* grad, int ldg, int gcol0, double* sumsq, void* stream);
