@@ -91,7 +91,9 @@ __global__ void __launch_bounds__(256, 2) att_l0_fwd_kernel(AttL0FwdArgs s) {
     auto load_tile = [&](int tt) -> Tile {
       Tile r;
       const int t0 = 16 * tt;
-      const float* ap = s.a + (h * T + min(t0 + j, T - 1)) * s.lda + 4 * g4;
+      // (lanes whose 4 g4 offset is already past the row -- Q < 16 -- read the row start: their values are zeroed
+      // below, and an unclamped address ran up to 48 bytes past the END of the tensor at its last row)
+      const float* ap = s.a + (h * T + min(t0 + j, T - 1)) * s.lda + (4 * g4 < s.Q ? 4 * g4 : 0);
 #pragma unroll
       for (int kk = 0; kk < NK; ++kk) r.a[kk] = ld4(ap + (16 * kk + 4 * g4 < s.Q ? 16 * kk : 0));
 #pragma unroll

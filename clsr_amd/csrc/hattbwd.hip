@@ -107,7 +107,8 @@ __global__ void __launch_bounds__(256, 2) att_l0_bwd_kernel(AttL0BwdArgs s) {
     int itt = 0, ig = 0;   // issue cursor
     auto issue = [&]() -> Raw {
       const int tc = min(16 * itt + j, T - 1);
-      const __bf16* p = s.dz0 + ((h * G + ig) * T + tc) * s.lddz + 8 * g4;
+      // (offset clamped: for A0 < 32 the lanes past the row would read beyond the END of dz0 at its last row)
+      const __bf16* p = s.dz0 + ((h * G + ig) * T + tc) * s.lddz + (8 * g4 < s.A0 ? 8 * g4 : 0);
       Raw r;
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) r.x[kt] = ld8h(p + (32 * kt + 8 * g4 < s.A0 ? 32 * kt : 0));
@@ -300,7 +301,8 @@ __global__ void __launch_bounds__(256, 2) att_l0_bwd_f32_kernel(AttL0BwdArgsF s)
     int itt = 0, ig = 0;
     auto issue = [&]() -> Raw {
       const int tc = min(16 * itt + j, T - 1);
-      const float* p = s.dz0 + ((h * G + ig) * T + tc) * s.lddz + 4 * g4;
+      // (offset clamped: for A0 < 16 the lanes past the row would read beyond the END of dz0 at its last row)
+      const float* p = s.dz0 + ((h * G + ig) * T + tc) * s.lddz + (4 * g4 < s.A0 ? 4 * g4 : 0);
       Raw r;
 #pragma unroll
       for (int kk = 0; kk < NZ; ++kk) r.x[kk] = ld4(p + (16 * kk + 4 * g4 < s.A0 ? 16 * kk : 0));

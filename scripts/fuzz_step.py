@@ -72,6 +72,9 @@ def one_case(rng, idx, kind="clsr"):
                     contrastive_loss_weight=float(rng.choice([0.0, 0.1, 1.0])),
                     contrastive_margin=float(rng.choice([0.5, 1.0, 2.0])),
                     max_grad_norm=float(rng.choice([0.01, 2.0])))
+    if os.environ.get("FUZZ_OVERRIDE"):  # json dict applied on top of the drawn hyper-parameters (probing a failing case)
+        import json
+        over.update(json.loads(os.environ["FUZZ_OVERRIDE"]))
     if kind != "clsr":    # the siblings: free hidden / attention / user widths (reference sli_rec.yaml & co.)
         over.update(model_type=SIB_TYPES[kind], user_embedding_dim=int(rng.choice([4, 16, 40])),
                     attention_size=int(rng.choice([8, 20, 40])), hidden_size=int(rng.choice([8, 20, 40, 64])))
@@ -122,12 +125,61 @@ def one_case(rng, idx, kind="clsr"):
             problems.append("dedup=%s eval logit: %s" % (dedup, e))
         adam = orc.init_adam(params)
         new_p, new_bn, _, ls, grads, _, out = orc.train_step(params, bn, adam, 1, tf, hp, *extra)
+        if os.environ.get("FUZZ_WARM"):  # diagnosis: allocate every workspace in a throw-away pass first (a deviation
+            net.train_step(net.upload(feed, True), apply=False)   # that disappears is a first-step allocation race)
+            torch.cuda.synchronize()
         net.capture_grads = True
         got = net.train_step(net.upload(feed, True))
         torch.cuda.synchronize()
         e = close(got["logit"], out["logit"], 1e-4, 1e-4)
         if e:
             problems.append("dedup=%s train logit: %s" % (dedup, e))
+        if os.environ.get("FUZZ_DEBUG") and kind == "clsr":   # gradients of the INTERMEDIATE tensors against autograd
+            from collections import OrderedDict
+            leaf = OrderedDict((k, v.detach().clone().requires_grad_(not k.endswith("/user_embedding")))
+                               for k, v in params.items())
+            o2 = O.forward(leaf, bn, tf, hp, True, OrderedDict(), {})
+            keys = [k for k in ("att_fea_long", "att_fea_short", "short_intention", "causal_state", "target", "rnn_out",
+                                "hist_input") if k in o2 and getattr(o2[k], "requires_grad", False)]
+            for k in keys:
+                o2[k].retain_grad()
+            O.losses(leaf, o2, tf, hp)["loss"].backward()
+            B_, T_, G_, Hn_ = net.last_shape
+            D_, H_, Du_ = net.D, net.H, net.Du
+            zp = [v for k, v in net._bufs.items() if k[0] == "zero_pool"][-1].detach().double().cpu()
+            off = [0]
+
+            def take(*shape):
+                n = int(np.prod(shape))
+                t = zp[off[0]:off[0] + n].view(*shape)
+                off[0] += n
+                return t
+            dhist, drnn, dhist_lt = take(Hn_, T_, D_), take(Hn_, T_, H_), take(Hn_, T_, D_)
+            dtarget, dS = take(B_, D_), take(B_, D_)
+            dL, dM, dR = take(Hn_, D_), take(Hn_, D_), take(Hn_, D_)
+            dfs, dsi = take(Hn_, H_), take(Hn_, Du_)
+            for k in ("alpha", "att_fea_long", "att_fea_short", "model_output", "causal_state", "short_intention",
+                      "rnn_out", "logit", "w_long", "w_short"):
+                if k in got and k in o2 and got[k] is not None:
+                    g_, e_ = got[k].detach().double().cpu(), o2[k].detach().double()
+                    if g_.numel() != e_.numel() and e_.shape[0] == B_ and g_.shape[0] == Hn_:
+                        e_ = e_.reshape(Hn_, B_ // Hn_, *e_.shape[1:])[:, 0]
+                    if g_.numel() == e_.numel():
+                        print("    [debug dedup=%s] fwd %-16s max abs err %.3e  (max |exp| %.3e)" % (
+                            dedup, k, float((g_.reshape(-1) - e_.reshape(-1)).abs().max()), float(e_.abs().max())))
+            grp = lambda t: t.reshape(Hn_, B_ // Hn_, *t.shape[1:]).sum(1) if t.shape[0] == B_ and Hn_ != B_ else t
+            for nm, got_t, key in (("dS", dS, "att_fea_short"), ("dL", dL, "att_fea_long"), ("dsi", dsi, "short_intention"),
+                                   ("dfs", dfs, "causal_state"), ("dtarget", dtarget, "target"), ("drnn", drnn, "rnn_out")):
+                if key not in keys:
+                    continue
+                ex = o2[key].grad.double()
+                ex = ex if ex.shape == got_t.shape else grp(ex)
+                err = float((got_t - ex).abs().max())
+                print("    [debug dedup=%s] %-8s max abs err %.3e  (max |exp| %.3e)" % (dedup, nm, err, float(ex.abs().max())))
+                if os.environ.get("FUZZ_DEBUG") == "2":
+                    rows = (got_t - ex).abs().reshape(got_t.shape[0], -1).max(1)[0]
+                    print("        rows with err > 10%% of max:", (rows > 0.1 * rows.max()).nonzero().reshape(-1).tolist()[:40],
+                          "of", got_t.shape[0])
         gl = net.read_losses()
         for k in ("loss", "data_loss", "regular_loss") + (("contrastive_loss", "discrepancy_loss")
                                                             if kind == "clsr" else ()):
