@@ -124,7 +124,14 @@ extern "C" int clsr_dense_adam(float* param, float* grad, float* m, float* v, co
 
 // ---------------------------------------------------------------------------- embedding tables
 // count[0] = number of set flags (float, consumed by the discrepancy coefficient)
-__global__ void count_flags_kernel(const unsigned char* __restrict__ flags, long V, float* __restrict__ count) {
+__global__ void count_flags_kernel(const unsigned char* __restrict__ flags, long V, float* __restrict__ count,
+                                   double* __restrict__ adam_state, double lr, double b1, double b2) {
+  if (adam_state && blockIdx.x == 0 && threadIdx.x == 0) {   // the Adam clock of the step (adam_tick_kernel) rides along
+    adam_state[0] += 1.0;
+    adam_state[1] *= b1;
+    adam_state[2] *= b2;
+    adam_state[3] = lr * sqrt(1.0 - adam_state[2]) / (1.0 - adam_state[1]);
+  }
   float local = 0.f;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < V; e += (long)gridDim.x * blockDim.x)
     local += flags[e] ? 1.f : 0.f;
@@ -133,13 +140,19 @@ __global__ void count_flags_kernel(const unsigned char* __restrict__ flags, long
   if (threadIdx.x == 0 && tot != 0.0) atomicAdd(count, (float)tot);
 }
 
-extern "C" int clsr_count_flags(const unsigned char* flags, long V, float* count, void* stream) {
+extern "C" int clsr_count_flags_tick(const unsigned char* flags, long V, float* count, double* adam_state, double lr,
+                                     double beta1, double beta2, void* stream) {
   CLSR_CHECK_ARG(flags && count && V > 0);
   int blocks = clsr_cdiv(V, 256 * 16);
   if (blocks > 256) blocks = 256;
-  hipLaunchKernelGGL(count_flags_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, flags, V, count);
+  hipLaunchKernelGGL(count_flags_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, flags, V, count, adam_state,
+                     lr, beta1, beta2);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
+}
+
+extern "C" int clsr_count_flags(const unsigned char* flags, long V, float* count, void* stream) {
+  return clsr_count_flags_tick(flags, V, count, nullptr, 0.0, 0.0, 0.0, stream);
 }
 
 // Pass A over the involved (flagged) rows of one table:

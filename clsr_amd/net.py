@@ -96,6 +96,7 @@ class CLSRNet(object):
         self.dw_batch_late = not os.environ.get("CLSR_NO_DW_BATCH_LATE")   # A/B: merged launches of the attention / head weight gradients
         self.bn_bwd_fused = not os.environ.get("CLSR_NO_BN_BWD_FUSED")   # A/B: coefficient + apply of the row-level batch-norm backward in one launch
         self.hist_grad_two = not os.environ.get("CLSR_NO_HIST_GRAD_TWO")   # A/B: dhist + dhist_lt summed inside the segmented sums
+        self.tick_early = not os.environ.get("CLSR_NO_TICK_EARLY")   # A/B: Adam clock in the first launch of the update phase
         self.lt_att_first = bool(os.environ.get("CLSR_LT_ATT_FIRST"))   # A/B: long-term attention before the causal GRU on @lt (measured: +0.03 ms fp32, +0.04 ms bf16 -- the heavy GEMMs slow the main recurrence)
         self.dw_stream = not os.environ.get("CLSR_NO_DW_STREAM")   # A/B switch (see _dw)
         self._dw_async = False
@@ -200,7 +201,7 @@ class CLSRNet(object):
         g = lambda k: getattr(hp, k, None)
         return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook),
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
-                self.lazy, self.rnn_first, self.lt_att_first, self.hist_grad_two, self.dw_batch_late, self.bn_bwd_fused, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h, self.flush_side, self.l1_bwd_2pass,
+                self.lazy, self.rnn_first, self.lt_att_first, self.tick_early, self.hist_grad_two, self.dw_batch_late, self.bn_bwd_fused, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h, self.flush_side, self.l1_bwd_2pass,
                 self.split_g2, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
@@ -1681,7 +1682,16 @@ class CLSRNet(object):
             if not self._ucount_zeroed:      # (the training step clears it with its other accumulators)
                 call("clsr_zero_floats", self.ucount, 1)
             self._ucount_zeroed = False
-            call("clsr_count_flags", fl["user_long"], Vu, self.ucount)
+        # the Adam clock ticks in the FIRST launch of the update phase (with the user count when there is one): the table
+        # path and the dense path both only read it afterwards, so neither waits for the other (the clock used to tick
+        # on the dense path, and the table Adam launches waited for the whole weight-gradient reduction: 50 us)
+        tick_early = self.tick_early and not self.capture_grads
+        lr = float(hp.learning_rate)
+        if "user_long" in tb:
+            call("clsr_count_flags_tick", fl["user_long"], Vu, self.ucount, self.adam_state if tick_early else None, lr,
+                 0.9, 0.999)
+        elif tick_early:
+            call("clsr_adam_tick", self.adam_state, lr, 0.9, 0.999)
         clip = float(hp.max_grad_norm) if hp.is_clip_norm else 0.0
         # dense variables (regulariser + norms, Adam clock, Adam) on the @aux stream beside the table regulariser
         with self._branch("@main" if (self.capture_grads or not self.split_emb_grad) else "@aux"):
@@ -1689,7 +1699,7 @@ class CLSRNet(object):
             # (the Adam clock of the step ticks in the same launch: every reader is ordered after it)
             call("clsr_dense_reg_norm_tick", self.dense, self.dense_grad, self.seg_off, len(self.dense_names),
                  float(hp.layer_l2), float(hp.layer_l1), self.dense_sumsq, self.losses[1:],
-                 None if self.capture_grads else self.adam_state, float(hp.learning_rate), 0.9, 0.999)
+                 None if (self.capture_grads or tick_early) else self.adam_state, lr, 0.9, 0.999)
             if not self.capture_grads:
                 call("clsr_dense_adam", self.dense, self.dense_grad, self.dense_m, self.dense_v, self.seg_of,
                      self.dense_sumsq, clip, self.adam_state, 0.9, 0.999, 1e-8, self.n_dense)
@@ -1716,7 +1726,8 @@ class CLSRNet(object):
             call("clsr_adam_tick", self.adam_state, float(hp.learning_rate), 0.9, 0.999)
             call("clsr_dense_adam", self.dense, self.dense_grad, self.dense_m, self.dense_v, self.seg_of,
                  self.dense_sumsq, clip, self.adam_state, 0.9, 0.999, 1e-8, self.n_dense)
-        self._join()              # the Adam clock ticked on @aux: the table updates below read it
+        if not tick_early:
+            self._join()          # the Adam clock ticked on @aux: the table updates below read it
         rest = []
         for key, partner, slot, dscale, dloss_scale, dloss, base, nsum in spec:
             V, C = tb[key].shape
@@ -1733,6 +1744,8 @@ class CLSRNet(object):
             ops.multi("clsr_tables_adam_multi", ops.TableDesc, [r for r in sweep if r[0] in
                                                                 {tb[k].data_ptr() for k in rest}],
                       clip, self.adam_state, 0.9, 0.999, 1e-8, self.lazy)
+        if tick_early:
+            self._join()          # the dense path (@aux): the next step reads the updated variables on this stream
 
     # ------------------------------------------------------------------ measurement hooks (bench.py)
     def precision_note(self):

@@ -415,6 +415,10 @@ int clsr_dense_adam(float* param, float* grad, float* m, float* v, const int* se
                     const double* sumsq, float clip_norm, const double* adam_state, float beta1,
                     float beta2, float eps, int n, void* stream);
 int clsr_count_flags(const unsigned char* flags, long V, float* count, void* stream);
+/* ...and the Adam clock of the step in the same launch (adam_state may be NULL): the FIRST launch of the update phase,
+ * so that the table path (regulariser, Adam) and the dense path read the clock without waiting for each other */
+int clsr_count_flags_tick(const unsigned char* flags, long V, float* count, double* adam_state, double lr, double beta1,
+                          double beta2, void* stream);
 int clsr_table_reg(const float* table, const float* partner, const unsigned char* flags, long V, int C,
                    float l2, float l1, float disc_scale, float disc_loss_scale, const float* count,
                    float* grad_table, double* sumsq, double* reg_loss, double* disc_loss, void* stream);
