@@ -140,7 +140,7 @@ __global__ void bn_bwd_coef_kernel(const double* __restrict__ partial, int npart
                                    const float* __restrict__ gamma, const float* __restrict__ mean,
                                    const float* __restrict__ invstd, float* __restrict__ coef,
                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                   int accumulate) {
+                                   int accumulate, double grad_scale) {
   __shared__ double red[2][4];
   const int c = blockIdx.x;  // one 256-thread block per feature
   double s1 = 0.0, s2 = 0.0;
@@ -158,24 +158,34 @@ __global__ void bn_bwd_coef_kernel(const double* __restrict__ partial, int npart
   coef[c] = a1;
   coef[C + c] = a2;
   coef[2 * C + c] = -a1 * c1 - a2 * mu;
+  // grad_scale: data-parallel runs with synchronised statistics hold GLOBAL sums here and pre-divide by the world size,
+  // so that the gradient all-reduce (SUM over ranks) restores them
   if (accumulate) {
-    dgamma[c] += (float)s2;
-    dbeta[c] += (float)s1;
+    dgamma[c] += (float)(s2 * grad_scale);
+    dbeta[c] += (float)(s1 * grad_scale);
   } else {
-    dgamma[c] = (float)s2;
-    dbeta[c] = (float)s1;
+    dgamma[c] = (float)(s2 * grad_scale);
+    dbeta[c] = (float)(s1 * grad_scale);
   }
+}
+
+extern "C" int clsr_bn_bwd_coef_scaled(const double* partial, int nparts, int C, double count,
+                                       const float* gamma, const float* mean, const float* invstd,
+                                       float* coef, float* dgamma, float* dbeta, int accumulate,
+                                       double grad_scale, void* stream) {
+  CLSR_CHECK_ARG(partial && gamma && mean && invstd && coef && dgamma && dbeta && nparts > 0 && C > 0);
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream,
+                     partial, nparts, C, count, gamma, mean, invstd, coef, dgamma, dbeta, accumulate, grad_scale);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
 }
 
 extern "C" int clsr_bn_bwd_coef(const double* partial, int nparts, int C, double count,
                                 const float* gamma, const float* mean, const float* invstd,
                                 float* coef, float* dgamma, float* dbeta, int accumulate,
                                 void* stream) {
-  CLSR_CHECK_ARG(partial && gamma && mean && invstd && coef && dgamma && dbeta && nparts > 0 && C > 0);
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream,
-                     partial, nparts, C, count, gamma, mean, invstd, coef, dgamma, dbeta, accumulate);
-  CLSR_CHECK_LAUNCH();
-  return CLSR_OK;
+  return clsr_bn_bwd_coef_scaled(partial, nparts, C, count, gamma, mean, invstd, coef, dgamma, dbeta, accumulate, 1.0,
+                                 stream);
 }
 
 // dy (in place) -> dz = a1*dy + a2*z + a3

@@ -636,13 +636,10 @@ class CLSRNet(object):
         if self.dp_stats_hook is not None:
             part, parts = self._dp_sum_stats(part, parts, bn.C)
             count = M * self.dp_world
-        call("clsr_bn_bwd_coef", part, parts, bn.C, float(count), bn.gamma, bn.mean, bn.invstd, bn.coef,
-             bn.dgamma, bn.dbeta, 0)
-        if self.dp_stats_hook is not None:
-            # the partial sums were already global: pre-divide so the gradient all-reduce (SUM) restores them
-            inv = 1.0 / self.dp_world
-            call("clsr_axpby", bn.dgamma, bn.dgamma, inv, None, 0.0, bn.C)
-            call("clsr_axpby", bn.dbeta, bn.dbeta, inv, None, 0.0, bn.C)
+        # (synchronised statistics: the partial sums are already global -- dgamma / dbeta leave pre-divided by the world
+        # size so that the gradient all-reduce (SUM) restores them)
+        call("clsr_bn_bwd_coef_scaled", part, parts, bn.C, float(count), bn.gamma, bn.mean, bn.invstd, bn.coef,
+             bn.dgamma, bn.dbeta, 0, 1.0 / self.dp_world if self.dp_stats_hook is not None else 1.0)
 
     def _gemm_bnbwd(self, dY, ldy_in, wkey, M, K, N, out, bn, z):
         """out = relu-mask(dY . W^T) fused with the BN backward sums of layer ``bn`` (pre-BN activation z),

@@ -243,6 +243,10 @@ int clsr_bn_relu_bwd_reduce(float* dh, const float* z, const float* scale, const
 int clsr_bn_bwd_coef(const double* partial, int nparts, int C, double count, const float* gamma,
                      const float* mean, const float* invstd, float* coef, float* dgamma, float* dbeta,
                      int accumulate, void* stream);
+/* ...with dgamma / dbeta multiplied by grad_scale (data-parallel runs with synchronised statistics: 1 / world) */
+int clsr_bn_bwd_coef_scaled(const double* partial, int nparts, int C, double count, const float* gamma,
+                            const float* mean, const float* invstd, float* coef, float* dgamma, float* dbeta,
+                            int accumulate, double grad_scale, void* stream);
 int clsr_bn_bwd_apply(float* dy, const float* z, const float* coef, long M, int C, void* stream);
 /* clsr_bn_bwd_coef + clsr_bn_bwd_apply in one launch (row-level layers: every block folds the partial sums itself) */
 int clsr_bn_bwd_coef_apply(const double* partial, int nparts, int C, double count, const float* gamma,
