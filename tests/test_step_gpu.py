@@ -67,6 +67,7 @@ CONFIGS = [
     dict(manual_alpha=True, manual_alpha_value=0.3),
     dict(sequential_model="lstm"),
     dict(embed_l1=2e-5, layer_l1=3e-5, embed_l2=1e-4),     # L1 regularisers (base_model.py:134-147), off by default
+    dict(att_fcn_layer_sizes=[8, 12]),     # attention widths below one MFMA tile (masked lanes: clamped addresses)
 ]
 
 
