@@ -136,23 +136,28 @@ class BaseModel(object):
         from safetensors.torch import save_file
 
         dist = getattr(self, "_dist", None)
+        group = getattr(self, "_group", None)
         rank = 0
         if dist is not None:
-            rank = self._dp.rank if getattr(self, "_dp", None) is not None else dist.get_rank()
+            # rank WITHIN the model's own process group (a model may train on a sub-group, or several replica groups
+            # may exist side by side): exactly one writer per group, and only that group meets at the barrier
+            rank = self._dp.rank if getattr(self, "_dp", None) is not None else dist.get_rank(group)
         if rank == 0:   # replicas are identical: ONE writer; temp file + rename, index last (no torn checkpoints)
             path = str(save_path) + ".safetensors"
             d = os.path.dirname(path)
             if d:
                 os.makedirs(d, exist_ok=True)
-            tmp = path + ".tmp.%d" % os.getpid()
+            # unique per writer: two groups saving to the same path never share a temporary file
+            uniq = "%d.%d" % (os.getpid(), dist.get_rank() if dist is not None else 0)
+            tmp = path + ".tmp." + uniq
             save_file({k: v.contiguous() for k, v in self.net.state_dict().items()}, tmp)
             os.replace(tmp, path)
             idx = os.path.join(d, _CKPT_INDEX)
-            with open(idx + ".tmp", "w") as f:
+            with open(idx + ".tmp." + uniq, "w") as f:
                 f.write(str(save_path))
-            os.replace(idx + ".tmp", idx)
+            os.replace(idx + ".tmp." + uniq, idx)
         if dist is not None:
-            dist.barrier()      # nobody reads the checkpoint before rank 0 has finished writing it
+            dist.barrier(group=group)      # nobody reads the checkpoint before the group's writer has finished
         return str(save_path)
 
 
@@ -582,6 +587,10 @@ class _SiblingModel(SequentialBaseModel):
     def _make_net(self, hp, dims):
         from clsr_amd.seqnet import SeqNet
 
+        if self._precision != "fp32":
+            # (a silent fp32 run would be reported as a speed-mode result)
+            raise NotImplementedError("%s: precision=%r is not available for the sibling models -- only CLSRModel has "
+                                      "the bf16 speed mode" % (type(self).__name__, self._precision))
         return SeqNet(hp, dims, kind=self.kind, device=self._device, seed=self.seed, dedup_histories=self._dedup)
 
     def train(self, sess, feed_dict):

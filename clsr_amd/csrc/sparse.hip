@@ -5,7 +5,7 @@
 // sparse Adam first sums duplicate indices (unsorted_segment_sum).  Popular
 // items (Zipf head) and the padding row 0 appear thousands of times per batch, so scattering
 // every slice with atomics serialises on a few cache lines.  Here the (id, position) pairs are
-// radix-sorted by id on the device (rocPRIM device primitive) and each thread group walks 64
+// grouped by id on the device (the counting sort below) and each thread group walks 64
 // consecutive sorted entries, summing runs of equal ids in registers: one atomic per run per
 // group instead of one per slice.  The sorted order is also the per-rank input of the
 // segmented sparse row exchange for multi-GPU runs with catalogues too large for dense tables.

@@ -169,6 +169,15 @@ class CLSRNet(object):
         if hp.hidden_size != D or hp.user_embedding_dim != D:
             bad.append("hidden_size and user_embedding_dim must equal item+cate dims (alpha fusion, clsr.py:265)")
         bad += self._shape_limits(hp, rnn=True)
+        if self.precision == "bf16":
+            # the speed-mode kernels (csrc/hgemm.hip, hdw.hip, hattbwd.hip) move 8 bf16 values per 16-byte access: K, N
+            # and the leading dimensions of the attention block must be multiples of 8 -- said here, by name, instead of
+            # as an 'unsupported shape' code of some launch in the middle of a step
+            att = [int(w) for w in hp.att_fcn_layer_sizes]
+            qs = (int(hp.user_embedding_dim), int(hp.user_embedding_dim) + D)
+            if any(w % 8 for w in att) or any(q % 8 for q in qs) or int(hp.hidden_size) % 8:
+                bad.append("precision='bf16' needs att_fcn_layer_sizes %r, the attention query widths %r and hidden_size "
+                           "%d to be multiples of 8 (use precision='fp32')" % (att, qs, int(hp.hidden_size)))
         if bad:
             raise NotImplementedError("CLSR HIP path does not support: " + "; ".join(bad))
 
@@ -202,7 +211,7 @@ class CLSRNet(object):
         return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook),
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
                 self.lazy, self.rnn_first, self.lt_att_first, self.tick_early, self.hist_grad_two, self.dw_batch_late, self.bn_bwd_fused, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h, self.flush_side, self.l1_bwd_2pass,
-                self.split_g2, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("max_grad_norm"), g("is_clip_norm"),
+                self.split_g2, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
 
@@ -340,7 +349,21 @@ class CLSRNet(object):
         sd["__adam__/state"] = self.adam_state.cpu().clone()
         return sd
 
+    @staticmethod
+    def _alias_old_names(sd):
+        """Checkpoints written before round 3 named the Time4LSTM variables ``.../time4lstm/<var>``; TF puts the
+        variables of a plain ``RNNCell`` under the cell's own layer scope (``.../time4lstm/time4lstm_cell/<var>``,
+        reference cell rnn_cell_implement.py:46-128, call sites clsr.py:194-200 / sli_rec.py:43-57)."""
+        out = None
+        for k in list(sd.keys()):
+            if "/time4lstm/" in k and "/time4lstm/time4lstm_cell/" not in k:
+                if out is None:
+                    out = dict(sd)
+                out.setdefault(k.replace("/time4lstm/", "/time4lstm/time4lstm_cell/"), out.pop(k))
+        return sd if out is None else out
+
     def load_state_dict(self, sd, strict=True):
+        sd = self._alias_old_names(sd)
         for name, t in self.P.items():
             if name in sd:
                 src = torch.as_tensor(np.asarray(sd[name]), dtype=F32)
@@ -699,7 +722,7 @@ class CLSRNet(object):
         """Variable scope of the LSTM-type short-term encoder (None for the GRU encoder)."""
         kind = self._t4_kind
         if kind == "time4lstm":
-            return CL + "short_term/time4lstm/"
+            return CL + "short_term/time4lstm/time4lstm_cell/"
         if kind == "lstm":
             return CL + "short_term/simple_lstm/lstm_cell/"
         return None
@@ -1627,7 +1650,10 @@ class CLSRNet(object):
 
     def _hist_grad_sorted(self, dhist, dM, dR, Hn, T, seq_len, ls, ss, only=None, dhist2=None):
         """IndexedSlices of the history lookups -> dense gradient tables via segmented sums over the
-        sorted ids (no float atomics on hot rows; deterministic).  ``only``: one table ("item" / "cate")."""
+        sorted ids (no float atomics on hot rows).  ``only``: one table ("item" / "cate").  Not bit-reproducible from run
+        to run: the counting sort (csrc/sparse.hip) leaves the order INSIDE a run of equal ids to its cursor claims, and
+        the run is summed in that order -- the fp32 sums (and the squared norms that feed the clip factor) can differ in
+        the last bits, like the order of the per-run atomics always could."""
         n = Hn * T
         k = self.hp.contrastive_recent_k
         for name, _, V, col0, C, slot in self._sort_tables():

@@ -216,8 +216,21 @@ def t4_desc(n, Pin=None, ldp=0, Wm=None, ldm=0, out_seq=None, act=None, cst=None
     return d
 
 
+_rnn_descs_checked = False
+
+
+def _check_rnn_descs():
+    """The recurrence descriptors travel by address: a layout that differs from the C header would corrupt them silently."""
+    global _rnn_descs_checked
+    if not _rnn_descs_checked:
+        assert ctypes.sizeof(GruDesc) == query("clsr_sizeof_gru_desc"), "GruDesc does not match clsr_gru_desc"
+        assert ctypes.sizeof(T4Desc) == query("clsr_sizeof_t4_desc"), "T4Desc does not match clsr_t4_desc"
+        _rnn_descs_checked = True
+
+
 def rnn_multi(name, grus, t4, seq_len, len_stride, Hn, T):
     """clsr_rnn_fwd_multi / clsr_rnn_bwd_multi with python lists of descriptors."""
+    _check_rnn_descs()
     arr = (GruDesc * max(len(grus), 1))(*grus)
     t4p = ctypes.addressof(t4) if t4 is not None else None
     keep_alive(arr, t4, grus)

@@ -69,7 +69,7 @@ def param_specs(dims, hp):
         specs += gru_specs(st + "short_term_intention/gru_cell/", D, Du)
     sm = hp.sequential_model
     if sm == "time4lstm":
-        t = st + "time4lstm/"
+        t = st + "time4lstm/time4lstm_cell/"      # plain RNNCell: variables live under the layer's own scope (rnn_cell_implement.py:46, TF r1.15 RNNCell.__call__ -> Layer._set_scope)
         for n_ in ("_time_input_w1", "_time_input_bias1", "_time_input_w2", "_time_input_bias2"):
             specs.append((t + n_, (H,), "glorot"))
         specs += [(t + "_time_kernel_w1", (D, H), "glorot"), (t + "_time_kernel_t1", (H, H), "glorot"),
@@ -157,7 +157,7 @@ def sibling_scopes(kind):
         return dict(att="sequential/attention_fcn/")
     if kind == "sli_rec":      # sli_rec.py:32-103
         s = "sequential/sli_rec/"
-        return dict(asvd=s + "long_term_asvd/", t4=s + "rnn/time4lstm/", att=s + "attention_fcn/attention_fcn/",
+        return dict(asvd=s + "long_term_asvd/", t4=s + "rnn/time4lstm/time4lstm_cell/", att=s + "attention_fcn/attention_fcn/",
                     alpha=s + "fcn_alpha/")
     if kind == "dien":         # dien.py:21-57 (name_scope only): dynamic_rnn scopes "gru1" / "gru2", sli_rec.py:118
         return dict(gru1="sequential/gru1/gru_cell/", att="sequential/attention_fcn/",

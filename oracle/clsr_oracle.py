@@ -101,7 +101,7 @@ def param_specs(dims, hp):
                   (g + "candidate/kernel", (D + Du, Du), "glorot"), (g + "candidate/bias", (Du,), "zero")]
     sm = hp.sequential_model
     if sm == "time4lstm":
-        t = st + "time4lstm/"
+        t = st + "time4lstm/time4lstm_cell/"      # plain RNNCell: variables live under the layer's own scope (rnn_cell_implement.py:46, TF r1.15 RNNCell.__call__ -> Layer._set_scope)
         for n in ("_time_input_w1", "_time_input_bias1", "_time_input_w2", "_time_input_bias2"):
             specs.append((t + n, (H,), "glorot"))
         specs += [(t + "_time_kernel_w1", (D, H), "glorot"), (t + "_time_kernel_t1", (H, H), "glorot"),
@@ -438,7 +438,7 @@ def forward(params, bn_state, feed, hp, training, new_bn=None, sites=None):
     hist_recent = (hist_input * recent.unsqueeze(-1)).sum(1) / recent.sum(1, keepdim=True)
     if hp.sequential_model == "time4lstm":
         rnn_out = time4lstm(hist_input, feed["time_from_first_action"], feed["time_to_now"], seq_len,
-                            st + "time4lstm/", params, H)
+                            st + "time4lstm/time4lstm_cell/", params, H)
     elif hp.sequential_model == "gru":
         rnn_out, _ = dynamic_gru(hist_input, seq_len, torch.zeros(hist_input.shape[0], H, dtype=hist_input.dtype),
                                  st + "simple_gru/gru_cell/", params)

@@ -65,7 +65,7 @@ def param_specs(dims, hp, kind):
         s = "sequential/sli_rec/"
         specs += [(s + "long_term_asvd/attention_mat", (D, D), "w"),
                   (s + "long_term_asvd/query", (hp.attention_size,), "w")]
-        t = s + "rnn/time4lstm/"
+        t = s + "rnn/time4lstm/time4lstm_cell/"
         for n_ in ("_time_input_w1", "_time_input_bias1", "_time_input_w2", "_time_input_bias2"):
             specs.append((t + n_, (H,), "glorot"))
         specs += [(t + "_time_kernel_w1", (Di, H), "glorot"), (t + "_time_kernel_t1", (H, H), "glorot"),
@@ -187,7 +187,7 @@ def forward(params, bn_state, feed, hp, kind, training, new_bn=None, sites=None)
         a1_seq, w1 = asvd_attention(hist, s + "long_term_asvd/", params)
         att_fea1 = a1_seq.sum(1)
         rnn_out = C.time4lstm(item_hist, feed["time_from_first_action"], feed["time_to_now"], seq_len,
-                              s + "rnn/time4lstm/", params, H)
+                              s + "rnn/time4lstm/time4lstm_cell/", params, H)
         a2_seq, w2 = C.attention_fcn(target, rnn_out, mask, s + "attention_fcn/attention_fcn/", params, bn_state, hp,
                                      training, new_bn)
         att_fea2 = a2_seq.sum(1)

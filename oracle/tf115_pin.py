@@ -8,6 +8,12 @@ reference-captured batch (tests/golden/iterator_train_sa.npz) and dumps what the
 against that file when it exists and reports "parity unpinned" when it does not.  Only the .npz travels; nothing of
 the reference does.
 
+Round 3: the pin file is SELF-CONTAINED -- it carries the weights the TF run actually used (``before/<name>`` for every
+global variable right after the assignment) next to ``meta/variables`` (TF's own ``v.op.name`` list) and
+``meta/no_grad`` (trainables whose ``tf.gradients`` entry is None).  The tests load the weights FROM THE FILE and
+compare the two variable inventories first (``check_inventory``: any name present on one side only fails with both
+lists printed), so a naming difference can neither be skipped silently nor masquerade as an arithmetic mismatch.
+
 F2: every trainable variable is filled from ``numpy.random.RandomState(crc32(name) ^ seed)`` (the legacy generator:
 its ``randn`` stream is frozen across numpy versions), scaled by the variable's role -- so that the TF script and
 the tests build bit-identical float32 weights from nothing but (name, shape).
@@ -66,3 +72,30 @@ def feed_arrays(npz, batch=0):
     """The committed reference-captured batch as {iterator attribute name: array}."""
     pre = "b%d_" % batch
     return {k[len(pre):]: npz[k] for k in npz.files if k.startswith(pre)}
+
+
+def ref_names(ref, prefix):
+    """Names stored under ``prefix`` (e.g. "grad/") in a loaded pin file."""
+    return sorted(k[len(prefix):] for k in ref.files if k.startswith(prefix))
+
+
+def check_inventory(theirs, ours, what):
+    """Fail loudly -- with BOTH name lists -- when the reference graph and the restatement disagree on a variable
+    name.  (A silent skip of the odd one out is how a renamed variable would otherwise go unnoticed.)"""
+    theirs, ours = sorted(set(theirs)), sorted(set(ours))
+    only_t = [n for n in theirs if n not in set(ours)]
+    only_o = [n for n in ours if n not in set(theirs)]
+    if only_t or only_o:
+        raise AssertionError(
+            "%s: the variable inventories differ.\n  only in the TensorFlow reference (%d): %s\n  only in this repo (%d): %s"
+            "\n  -- all reference names: %s\n  -- all names of this repo: %s" % (
+                what, len(only_t), only_t, len(only_o), only_o, theirs, ours))
+
+
+def require_keys(ref, prefix, names, what, allow_missing=()):
+    """Every name must have ``prefix + name`` in the pin file (no silent skips), except ``allow_missing``."""
+    have = set(ref.files)
+    missing = [n for n in names if prefix + n not in have and n not in set(allow_missing)]
+    if missing:
+        raise AssertionError("%s: the pin file has no '%s<name>' entry for %s\n  -- entries it has: %s"
+                             % (what, prefix, missing, ref_names(ref, prefix)))

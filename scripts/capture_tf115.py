@@ -10,6 +10,8 @@ that turns "parity unpinned" into a pinned oracle: it imports the reference from
 tests/conftest.py::golden_hparams, assigns the deterministic weight set F2 (oracle/tf115_pin.py), feeds the
 committed reference-captured batch tests/golden/iterator_train_sa.npz[b0] and writes
 
+    meta/variables, meta/no_grad      TF's own names of the trainables; those whose tf.gradients entry is None
+    before/<variable>                 every global variable right after the F2 assignment (the tests load THESE weights)
     logit, alpha                      forward values of the training graph (is_train_stage = True)
     loss/{loss,data_loss,regular_loss,contrastive_loss,discrepancy_loss}
     grad/<variable>                   tf.gradients(loss, variable), IndexedSlices densified
@@ -59,9 +61,10 @@ def main():
         w = P.f2_weights([(n, v.shape.as_list()) for n, v in zip(names, tvars)])
         sess.run([tf.assign(v, w[n]) for n, v in zip(names, tvars)])
         grads = tf.gradients(model.loss, tvars)
-        dense_g, slice_norm = {}, {}
+        dense_g, slice_norm, no_grad = {}, {}, []
         for n, g in zip(names, grads):
             if g is None:
+                no_grad.append(n)
                 continue
             if isinstance(g, tf.IndexedSlices):
                 slice_norm[n] = tf.sqrt(tf.reduce_sum(tf.square(g.values)))
@@ -81,7 +84,10 @@ def main():
         return fd
 
     fd = feed_of(os.path.join(gold, "iterator_train_sa.npz"), True)
-    out = {"meta/tf_version": np.array(tf.__version__), "meta/variables": np.array(names)}
+    out = {"meta/tf_version": np.array(tf.__version__), "meta/variables": np.array(names),
+           "meta/no_grad": np.array(no_grad, dtype=str)}
+    for v, val in zip(gvars, sess.run(gvars)):                    # the weights this run really used (+ BN moving stats)
+        out["before/" + v.op.name] = val
     fetch = dict(logit=model.logit, alpha=model.alpha_output, loss=model.loss, data_loss=model.data_loss,
                  regular_loss=model.regular_loss, contrastive_loss=model.contrastive_loss,
                  discrepancy_loss=model.discrepancy_loss)

@@ -133,7 +133,7 @@ def test_variable_set_matches_the_reference_graph(golden_hparams):
     for must in ("sequential/embedding/item_embedding", "sequential/embedding/user_long_embedding",
                  "sequential/clsr/long_term/attention_fcn/attention_mat",
                  "sequential/clsr/short_term/short_term_intention/gru_cell/gates/kernel",
-                 "sequential/clsr/short_term/time4lstm/_time_kernel_t2",
+                 "sequential/clsr/short_term/time4lstm/time4lstm_cell/_time_kernel_t2",
                  "sequential/clsr/causal2/causal2/gru_cell/candidate/bias",
                  "sequential/clsr/fcn_alpha/nn_part/batch_normalization_1/gamma",
                  "sequential/logit_fcn/nn_part/w_nn_output"):
