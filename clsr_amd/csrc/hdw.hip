@@ -273,6 +273,7 @@ extern "C" int clsr_hdw_partial_multi(const clsr_dwjob* jobs, int n, void* strea
     const clsr_dwjob& q = jobs[j];
     CLSR_CHECK_ARG(q.X && q.dY && q.workspace && q.M > 0 && q.K > 0 && q.N > 0 && !(q.in_scale && !q.in_shift));
     CLSR_CHECK_SUPPORTED(!q.x_bf16 && !(q.dy_bf16 && q.in_scale));
+    CLSR_CHECK_SUPPORTED(q.rm_tc == 0 && q.pstride == 0 && q.pgx == 0);   // (time-range jobs: fp32 kernels only so far)
     CLSR_CHECK_SUPPORTED(q.N % 4 == 0 && q.ldx % 4 == 0 && q.ldy % 4 == 0 && q.ldx >= ((q.K + 3) & ~3) &&
                          (!q.Xmul || (q.ldmul % 4 == 0 && q.ldmul >= ((q.K + 3) & ~3))) &&
                          ((uintptr_t)q.X % 16) == 0 && ((uintptr_t)q.dY % 8) == 0);

@@ -35,7 +35,17 @@ struct PGemmArgs {
   // (sum v, sum v * xhat) with xhat = (ez - e_mean) * e_invstd  (ez = pre-BN activation at [m, n])
   const float* ez; int ldez; const float* e_scale; const float* e_shift; const float* e_mean; const float* e_invstd;
   int no_ring;                    // A/B switch (CLSR_PGEMM_NO_RING): wide-K plain products load one k-tile ahead only
+  // time-range form (clsr_pgemm_range): M = Hn * rm_tc virtual rows, virtual row v is the physical row
+  // (v / rm_tc) * rm_T + rm_t0 + v % rm_tc of X and of Y -- the steps [t0, t0 + tc) of every history of [Hn, T, .] tensors
+  int rm_tc, rm_T, rm_t0;
 };
+
+// virtual -> physical row of the time-range form (identity when rm_tc == 0)
+__device__ __forceinline__ int range_row(int v, int rm_tc, int rm_T, int rm_t0) {
+  if (rm_tc == 0) return v;
+  const int q = (int)((unsigned)v / (unsigned)rm_tc);
+  return q * rm_T + rm_t0 + (v - q * rm_tc);
+}
 
 template <int OT, bool STATS>
 __global__ void __launch_bounds__(256) pgemm_generic_kernel(PGemmArgs a) {
@@ -70,8 +80,9 @@ __global__ void __launch_bounds__(256) pgemm_generic_kernel(PGemmArgs a) {
   const int ntiles = (a.M + 15) >> 4;
   const float* ldsA = lds + (long)j * Kp + 4 * g;  // + ot*16*Kp + kt*16
   for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
-    const int m = tile * 16 + j;
-    const bool valid = m < a.M;
+    const int mv = tile * 16 + j;
+    const bool valid = mv < a.M;
+    const int m = range_row(valid ? mv : 0, a.rm_tc, a.rm_T, a.rm_t0);
     long xrow = m, r = m;
     if (a.T > 0) {
       r = m / a.T;
@@ -277,7 +288,7 @@ __global__ void __launch_bounds__(256) pgemm_fast_kernel(PGemmArgs a) {
     for (int s = 0; s < 2; ++s) {
       const int m = tile * 32 + s * 16 + j;
       valid[s] = m < a.M;
-      const int mc = valid[s] ? m : a.M - 1;
+      const int mc = range_row(valid[s] ? m : a.M - 1, a.rm_tc, a.rm_T, a.rm_t0);
       mrow[s] = mc;
       int r = mc, xr = mc;
       if (a.T > 0) {
@@ -561,6 +572,23 @@ extern "C" int clsr_pgemm(const float* X, int ldx, int T, int G, const float* Xm
   a.Y = Y; a.ldy = ldy; a.accumulate = accumulate; a.stats = stats; a.M = M; a.K = K; a.N = N;
   a.ez = nullptr; a.ldez = 0; a.e_scale = a.e_shift = a.e_mean = a.e_invstd = nullptr;
   a.no_ring = getenv("CLSR_PGEMM_NO_RING") ? 1 : 0;
+  a.rm_tc = a.rm_T = a.rm_t0 = 0;
+  return pgemm_dispatch(a, (hipStream_t)stream);
+}
+
+// Y[p, :N] (=|+=) X[p, :K] . W + bias  for the rows p = h * T + t, h < Hn, t0 <= t < t1 of [Hn, T, .] tensors: one
+// time range of a batched input projection / of the products that back-propagate dPin (see clsr_rnn_fwd_multi_range)
+extern "C" int clsr_pgemm_range(const float* X, int ldx, const float* Wt, int Kp, const float* bias, float* Y, int ldy,
+                                int accumulate, int Hn, int T, int t0, int t1, int K, int N, void* stream) {
+  CLSR_CHECK_ARG(X && Wt && Y && Hn > 0 && T > 0 && 0 <= t0 && t0 < t1 && t1 <= T && K > 0 && N > 0);
+  CLSR_CHECK_SUPPORTED(K % 4 == 0 && N % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && Kp % 4 == 0);
+  CLSR_CHECK_ARG(Kp >= 16 * clsr_cdiv(K, 16));
+  CLSR_CHECK_SUPPORTED(((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0 && ldx >= K && (long)Hn * T < (1L << 31));
+  PGemmArgs a = {};
+  a.X = X; a.ldx = ldx; a.Wt = Wt; a.Kp = Kp; a.ldw = Kp; a.bias = bias; a.Y = Y; a.ldy = ldy; a.accumulate = accumulate;
+  a.M = Hn * (t1 - t0); a.K = K; a.N = N;
+  a.no_ring = getenv("CLSR_PGEMM_NO_RING") ? 1 : 0;
+  if (t0 != 0 || t1 != T) { a.rm_tc = t1 - t0; a.rm_T = T; a.rm_t0 = t0; }
   return pgemm_dispatch(a, (hipStream_t)stream);
 }
 
@@ -683,6 +711,10 @@ struct DwArgs {
   const void* dY; int ldy;
   float* partial;
   int M, K, N;
+  // time-range form: M = Hn * rm_tc virtual rows -> physical rows of X and dY (see PGemmArgs); the launch writes the
+  // partials [poff, poff + gx) of the pstride partial slots that each (K, N) chunk of the workspace holds, so that
+  // the launches over the ranges of one product fill ONE workspace for ONE reduction
+  int rm_tc, rm_T, rm_t0, pstride, poff;
 };
 
 // Block = 4 waves, 64 positions per iteration.  The X tile (prologue applied) and the dY tile are
@@ -746,7 +778,7 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, float* lds, const int b
       const int row = idx / Q, c4 = idx - row * Q;
       int m = tile * 64 + row;
       const bool mv = (tile < ntiles) && (m < a.M);
-      m = m < a.M ? m : a.M - 1;
+      m = range_row(m < a.M ? m : a.M - 1, a.rm_tc, a.rm_T, a.rm_t0);
       int kcol = k0 + 4 * c4, ncol = n0 + 4 * c4;
       if (mv && kcol <= kmax4) vmask |= 1u << j;
       if (mv && ncol <= nmax4) vmask |= 1u << (8 + j);
@@ -846,7 +878,7 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, float* lds, const int b
   if (wave == 0) {
     add_from(red);
     const long chunk = (long)by * gz + bz;
-    store_to(a.partial + (chunk * gx + bx) * DW_CHUNK);
+    store_to(a.partial + (chunk * a.pstride + a.poff + bx) * DW_CHUNK);
   }
 }
 
@@ -963,6 +995,7 @@ static int dw_launch_partial(const void* X, int ldx, int T, int G, const float* 
   a.dY = dY; a.ldy = ldy; a.partial = workspace; a.M = M; a.K = K; a.N = N;
   const int kch = clsr_cdiv(K, 16 * DW_T), nch = clsr_cdiv(N, 16 * DW_T);
   const int gx = dw_grid_x(M);
+  a.rm_tc = a.rm_T = a.rm_t0 = 0; a.pstride = gx; a.poff = 0;
   CLSR_CHECK_SUPPORTED(!(Xmul && in_scale) && !(in_scale && K % 4));
   if (x_bf16 || dy_bf16) {
     // speed mode (csrc/hgemm.hip): bf16 activations / gradients, fp32 MFMA accumulation as in the fp32 mode.
@@ -1017,7 +1050,11 @@ extern "C" int clsr_pgemm_dw_partial_multi(const clsr_dwjob* jobs, int n, void* 
     a.dY = q.dY; a.ldy = q.ldy; a.partial = q.workspace; a.M = q.M; a.K = q.K; a.N = q.N;
     const int kch = clsr_cdiv(q.K, 16 * DW_T), nch = clsr_cdiv(q.N, 16 * DW_T);
     m.first[j] = total;
-    m.gx[j] = dw_grid_x(q.M);
+    m.gx[j] = q.pgx > 0 ? q.pgx : dw_grid_x(q.M);
+    CLSR_CHECK_ARG(q.rm_tc >= 0 && (q.rm_tc == 0 || (q.rm_T >= q.rm_t0 + q.rm_tc && q.rm_t0 >= 0 && q.M % q.rm_tc == 0 && !q.T)));
+    CLSR_CHECK_ARG(q.pstride == 0 || (q.poff >= 0 && q.poff + m.gx[j] <= q.pstride));
+    a.rm_tc = q.rm_tc; a.rm_T = q.rm_T; a.rm_t0 = q.rm_t0;
+    a.pstride = q.pstride > 0 ? q.pstride : m.gx[j]; a.poff = q.pstride > 0 ? q.poff : 0;
     m.nch[j] = (short)nch;
     m.mode[j] = (short)(q.Xmul ? 1 : (q.in_scale ? 2 : 0));
     total += m.gx[j] * kch * nch;

@@ -20,6 +20,7 @@
 // Hidden size n <= 48 runs with RNT = 3 feature tiles (3 waves), n <= 128 with 8 tiles (8 waves); n % 4 == 0.
 #include "common.h"
 #include "clsr_hip.h"
+#include "rnn_args.h"
 
 
 __device__ __forceinline__ f32x4 sig4(f32x4 v) {
@@ -129,32 +130,6 @@ __device__ __forceinline__ void st_dpin(float* base, long off, f32x4 v, int h) {
   else st4(base + off, v);
 }
 
-struct GruArgs {
-  const float* Pin; int ldp;           // [Hn, T, ldp]: r | u | c input-side pre-activations (+bias)
-  const float* Wgh; int ldg;           // [n, >=2n] hidden rows of gates/kernel
-  const float* Wch; int ldc;           // [n, >=n]  hidden rows of candidate/kernel
-  const float* h0; long h0_stride;     // optional initial state rows
-  const int* seq_len; int len_stride;
-  int Hn, T, n;
-  float* hT;                           // [Hn, n] final state
-  float* out_seq;                      // optional [Hn, T, n], zeros past len
-  float* hprev;                        // optional saves (training): [Hn, T, n]
-  float* gates;                        //                            [Hn, T, 3n] activated r | u | c
-  // backward
-  const float* dhT;                    // [Hn, n] grad wrt final state (may be null)
-  const float* dout_seq;               // optional [Hn, T, n]
-  float* dPin;                         // [Hn, T, lddp] (zeros past len); r | u | c blocks of n
-  int dpin_bf16;                       // dPin is a bf16 tensor (lddp in elements): speed mode
-  float* dh0;                          // optional [Hn, n]
-  int lddp;
-  // attentional update gate (DIEN's VecAttGRUCell, rnn_cell_implement.py:594-623): u <- (1 - att[s, t]) * u.
-  // The Hn sequences are then candidate ROWS: sequence s reads the input projections and the length of history
-  // s / in_div (the rows of a group share the first GRU's outputs, their attention scores differ)
-  const float* att;                    // optional [Hn, T]
-  float* datt;                         // backward: [Hn, T], accumulated with atomics (zeroed by the caller)
-  int in_div;
-};
-
 // xb: LDS exchange area of the workgroup (f32x4 units): fwd uses [0, 2*RNT*64), bwd [0, 3*RNT*64)
 // ATT: the attentional-update-gate variant (own kernels below, so the plain GRU's code and registers are untouched)
 template <int RNT, bool ATT = false>
@@ -196,13 +171,14 @@ __device__ __forceinline__ void gru_fwd_body(const GruArgs& a, const int bx, f32
   // (s_waitcnt vmcnt(0)) right after issuing the prefetch -- one exposed HBM latency per time step
   const float* pin = a.Pin + hin * (long)T * a.ldp + (cval ? col : 0);
   const float* attp = ATT ? a.att + (hvalid ? h : 0) * (long)T : nullptr;
+  const int t0 = a.t0, tend = min(Tmax, a.t1);
   f32x4 pn[3];
 #pragma unroll
-  for (int gb = 0; gb < 3; ++gb) pn[gb] = sel4(cval && 0 < len, ld4(pin + gb * n), Z4);
-  float an = ATT ? attp[0] : 0.f;
+  for (int gb = 0; gb < 3; ++gb) pn[gb] = sel4(cval && t0 < len, ld4(pin + (long)t0 * a.ldp + gb * n), Z4);
+  float an = ATT ? attp[t0] : 0.f;
   f32x4* bufA = xb;
   f32x4* bufB = xb + RNT * 64;
-  for (int t = 0; t < Tmax; ++t) {
+  for (int t = t0; t < tend; ++t) {
     const bool live = t < len;
     f32x4 accr = pn[0], accu = pn[1], accc = pn[2];
     const float keep = 1.0f - an;       // (1 - att_score) of this step; exactly 1 without attention
@@ -237,7 +213,7 @@ __device__ __forceinline__ void gru_fwd_body(const GruArgs& a, const int bx, f32
   if (cval) {
     if (a.hT) st4(a.hT + h * n + col, hown);
     if (a.out_seq)
-      for (int t = len; t < T; ++t) st4(a.out_seq + (h * T + t) * n + col, Z4);
+      for (int t = max(len, t0); t < a.t1; ++t) st4(a.out_seq + (h * T + t) * n + col, Z4);
   }
 }
 
@@ -265,14 +241,14 @@ __device__ __forceinline__ void gru_bwd_body(const GruArgs& a, const int bx, f32
   const int Tmax = wave_max_i(len);
   const float* attp = ATT ? a.att + (hvalid ? h : 0) * (long)T : nullptr;
   if (cval)  // zero dPin past len
-    for (int t = len; t < T; ++t) {
+    for (int t = max(len, a.t0); t < a.t1; ++t) {
       const long dp = (h * T + t) * a.lddp + col;
       st_dpin(a.dPin, dp, Z4, a.dpin_bf16); st_dpin(a.dPin, dp + n, Z4, a.dpin_bf16); st_dpin(a.dPin, dp + 2 * n, Z4, a.dpin_bf16);
     }
   f32x4* bufA = xb;
   f32x4* bufR = xb + RNT * 64;
   f32x4* bufU = xb + 2 * RNT * 64;
-  for (int t = Tmax - 1; t >= 0; --t) {
+  for (int t = min(Tmax, a.t1) - 1; t >= a.t0; --t) {
     const bool live = t < len;
     const bool ok = live && cval;
     const long pos = h * T + t;
@@ -361,7 +337,7 @@ extern "C" int clsr_gru_fwd(const float* Pin, int ldp, const float* Wgh, int ldg
   GruArgs a = {};
   a.Pin = Pin; a.ldp = ldp; a.Wgh = Wgh; a.ldg = ldg; a.Wch = Wch; a.ldc = ldc; a.h0 = h0;
   a.h0_stride = h0_stride; a.seq_len = seq_len; a.len_stride = len_stride; a.Hn = Hn; a.T = T; a.n = n;
-  a.hT = hT; a.out_seq = out_seq; a.hprev = hprev; a.gates = gates;
+  a.hT = hT; a.out_seq = out_seq; a.hprev = hprev; a.gates = gates; a.t0 = 0; a.t1 = T;
   RNN_LAUNCH(gru_fwd_kernel, rnn_tiles(n), dim3(clsr_cdiv(Hn, 16)), stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
@@ -379,7 +355,7 @@ extern "C" int clsr_gru_bwd(const float* gates, const float* hprev, const float*
   a.gates = const_cast<float*>(gates); a.hprev = const_cast<float*>(hprev);
   a.Wgh = Wgh; a.ldg = ldg; a.Wch = Wch; a.ldc = ldc; a.seq_len = seq_len; a.len_stride = len_stride;
   a.Hn = Hn; a.T = T; a.n = n; a.dhT = dhT; a.dout_seq = dout_seq; a.dPin = dPin; a.dh0 = dh0;
-  a.lddp = 3 * n;
+  a.lddp = 3 * n; a.t0 = 0; a.t1 = T;
   RNN_LAUNCH(gru_bwd_kernel, rnn_tiles(n), dim3(clsr_cdiv(Hn, 16)), stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
@@ -390,19 +366,6 @@ extern "C" int clsr_gru_bwd(const float* gates, const float* hprev, const float*
 //   c' = sig(f + 1) * sig(tls) * c + sig(i) * sig(tns) * tanh(j) ;  m' = sig(o) * tanh(c')
 // saved (training): act[Hn,T,6n] = sig i | tanh j | sig(f+1) | sig o | sig tns | sig tls,
 //                   cst[Hn,T,n] = c', mprev[Hn,T,n] = m entering the step.
-struct T4Args {
-  const float* Pin; int ldp;
-  const float* Wm; int ldm;            // [n, >=4n] hidden rows of the lstm kernel (i|j|f|o columns)
-  const int* seq_len; int len_stride;
-  int Hn, T, n;
-  float* out_seq;                      // [Hn, T, n] (m, zeros past len)
-  float* act; float* cst; float* mprev;
-  const float* dout_seq;               // [Hn, T, n]
-  float* dPin;                         // [Hn, T, lddp]
-  int dpin_bf16;                       // dPin is a bf16 tensor (lddp in elements): speed mode
-  int lddp;
-};
-
 template <int RNT>
 __device__ __forceinline__ void t4lstm_fwd_body(const T4Args& a, const int bx, f32x4* xb) {
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
@@ -420,14 +383,26 @@ __device__ __forceinline__ void t4lstm_fwd_body(const T4Args& a, const int bx, f
   const bool cval = hvalid && col < n;
   f32x4 cs = Z4, mown = Z4, ms[RNT];
 #pragma unroll
-  for (int kt = 0; kt < RNT; ++kt) ms[kt] = Z4;
+  for (int kt = 0; kt < RNT; ++kt) {
+    ms[kt] = Z4;
+    if (!(hvalid && a.st_in)) continue;
+    const float* mp0 = a.st_in + h * 2 * n + n + 16 * kt;      // m entering t0: the B operand of the first matvec
+    if (kt == RNT - 1 && cmp) {
+      if (16 * kt + g < n) ms[kt].x = mp0[g];
+      if (16 * kt + 4 + g < n) ms[kt].y = mp0[4 + g];
+    } else if (16 * kt + 4 * g < n) {
+      ms[kt] = ld4(mp0 + 4 * g);
+    }
+  }
+  if (cval && a.st_in) { cs = ld4(a.st_in + h * 2 * n + col); mown = ld4(a.st_in + h * 2 * n + n + col); }
   const int len = hvalid ? min(a.seq_len[h * a.len_stride], T) : 0;
   const int Tmax = wave_max_i(len);
+  const int t0 = a.t0, tend = min(Tmax, a.t1);
   const float* pin = a.Pin + (hvalid ? h : 0) * (long)T * a.ldp + (cval ? col : 0);
   f32x4 pn[6];
 #pragma unroll
-  for (int gb = 0; gb < 6; ++gb) pn[gb] = sel4(cval && 0 < len, ld4(pin + gb * n), Z4);
-  for (int t = 0; t < Tmax; ++t) {
+  for (int gb = 0; gb < 6; ++gb) pn[gb] = sel4(cval && t0 < len, ld4(pin + (long)t0 * a.ldp + gb * n), Z4);
+  for (int t = t0; t < tend; ++t) {
     const bool live = t < len;
     f32x4 acc[4];
 #pragma unroll
@@ -470,8 +445,10 @@ __device__ __forceinline__ void t4lstm_fwd_body(const T4Args& a, const int bx, f
     mown = sel4(live, mn, mown);
     xchg(xb + (t & 1) * RNT * 64, w, lane, mown, cmp, ms);  // double buffered: one barrier per step
   }
-  if (cval)
-    for (int t = len; t < T; ++t) st4(a.out_seq + (h * T + t) * n + col, Z4);
+  if (cval) {
+    for (int t = max(len, t0); t < a.t1; ++t) st4(a.out_seq + (h * T + t) * n + col, Z4);
+    if (a.st_out) { st4(a.st_out + h * 2 * n + col, cs); st4(a.st_out + h * 2 * n + n + col, mown); }
+  }
 }
 
 template <int RNT>
@@ -490,15 +467,16 @@ __device__ __forceinline__ void t4lstm_bwd_body(const T4Args& a, const int bx, f
   const int col = 16 * w + 4 * g;
   const bool cval = hvalid && col < n;
   f32x4 dc = Z4, dm = Z4;
+  if (cval && a.dst_in) { dc = ld4(a.dst_in + h * 2 * n + col); dm = ld4(a.dst_in + h * 2 * n + n + col); }
   const int len = hvalid ? min(a.seq_len[h * a.len_stride], T) : 0;
   const int Tmax = wave_max_i(len);
   if (cval)
-    for (int t = len; t < T; ++t) {
+    for (int t = max(len, a.t0); t < a.t1; ++t) {
       const long dp = (h * T + t) * a.lddp + col;
 #pragma unroll
       for (int gb = 0; gb < 6; ++gb) st_dpin(a.dPin, dp + gb * n, Z4, a.dpin_bf16);
     }
-  for (int t = Tmax - 1; t >= 0; --t) {
+  for (int t = min(Tmax, a.t1) - 1; t >= a.t0; --t) {
     const bool live = t < len;
     const bool ok = live && cval;
     const long pos = h * T + t;
@@ -547,6 +525,7 @@ __device__ __forceinline__ void t4lstm_bwd_body(const T4Args& a, const int bx, f
     dc = sel4(live, dcn, dc);
     dm = sel4(live, dmn, dm);
   }
+  if (cval && a.dst_out) { st4(a.dst_out + h * 2 * n + col, dc); st4(a.dst_out + h * 2 * n + n + col, dm); }
 }
 
 template <int RNT>
@@ -565,14 +544,6 @@ __global__ void __launch_bounds__(64 * RNT) t4lstm_bwd_kernel(T4Args a) {
 // short_term_intention, Time4LSTM / GRU short-term encoder, GRU causal2).  Each one only fills a
 // quarter of the chip (Hn/16 single-wave workgroups), so they are dispatched as ONE grid:
 // blockIdx.y selects the encoder, blockIdx.x the 16-history tile.
-#define RNN_MAX_GRU 3
-struct RnnMultiArgs {
-  GruArgs gru[RNN_MAX_GRU];
-  T4Args t4;
-  int ngru;
-  int has_t4;
-};
-
 template <int RNT>
 __global__ void __launch_bounds__(64 * RNT) rnn_multi_fwd_kernel(RnnMultiArgs a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
@@ -598,7 +569,7 @@ extern "C" int clsr_t4lstm_fwd(const float* Pin, int ldp, const float* Wm, int l
   if (rc) return rc;
   T4Args a = {};
   a.Pin = Pin; a.ldp = ldp; a.Wm = Wm; a.ldm = ldm; a.seq_len = seq_len; a.len_stride = len_stride;
-  a.Hn = Hn; a.T = T; a.n = n; a.out_seq = out_seq; a.act = act; a.cst = cst; a.mprev = mprev;
+  a.Hn = Hn; a.T = T; a.n = n; a.out_seq = out_seq; a.act = act; a.cst = cst; a.mprev = mprev; a.t0 = 0; a.t1 = T;
   RNN_LAUNCH(t4lstm_fwd_kernel, rnn_tiles(n), dim3(clsr_cdiv(Hn, 16)), stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
@@ -614,7 +585,7 @@ extern "C" int clsr_t4lstm_bwd(const float* act, const float* cst, const float* 
   T4Args a = {};
   a.act = const_cast<float*>(act); a.cst = const_cast<float*>(cst); a.Wm = Wm; a.ldm = ldm;
   a.seq_len = seq_len; a.len_stride = len_stride; a.Hn = Hn; a.T = T; a.n = n;
-  a.dout_seq = dout_seq; a.dPin = dPin; a.lddp = 6 * n;
+  a.dout_seq = dout_seq; a.dPin = dPin; a.lddp = 6 * n; a.t0 = 0; a.t1 = T;
   RNN_LAUNCH(t4lstm_bwd_kernel, rnn_tiles(n), dim3(clsr_cdiv(Hn, 16)), stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
@@ -664,7 +635,7 @@ extern "C" int clsr_t4_time_inputs_fwd(const float* tnow, const float* tfirst, l
 // thread: block = (256 / C2) rows x C2 columns.
 __global__ void __launch_bounds__(256) t4_time_inputs_bwd_kernel(
     const float* __restrict__ dTT, const float* __restrict__ TT, const float* __restrict__ tnow,
-    const float* __restrict__ tfirst, long row_stride, long Hn, int T, int n, float* __restrict__ partial) {
+    const float* __restrict__ tfirst, long row_stride, long Hn, int T, int n, float* __restrict__ partial, int t0, int tc) {
   __shared__ f32x4 red[2][256];
   const int C2 = 2 * n, QC = C2 >> 2;
   const int rpb = 256 / QC;
@@ -673,11 +644,12 @@ __global__ void __launch_bounds__(256) t4_time_inputs_bwd_kernel(
   if (ty < rpb) {
     const int c = 4 * q;
     const float* tsrc = (c < n) ? tnow : tfirst;
-    const int M = (int)(Hn * T);
-    for (int row = blockIdx.x * rpb + ty; row < M; row += gridDim.x * rpb) {
-      const int h = row / T, t = row - h * T;
-      const f32x4 y = ld4(TT + (long)row * C2 + c);
-      const f32x4 d = ld4(dTT + (long)row * C2 + c) * ((f32x4){1.f, 1.f, 1.f, 1.f} - y * y);
+    const int M = (int)(Hn * tc);     // the steps [t0, t0 + tc) of every history
+    for (int vrow = blockIdx.x * rpb + ty; vrow < M; vrow += gridDim.x * rpb) {
+      const int h = vrow / tc, t = t0 + vrow - h * tc;
+      const long row = (long)h * T + t;
+      const f32x4 y = ld4(TT + row * C2 + c);
+      const f32x4 d = ld4(dTT + row * C2 + c) * ((f32x4){1.f, 1.f, 1.f, 1.f} - y * y);
       sw += d * tsrc[(long)h * row_stride + t];
       sb += d;
     }
@@ -709,7 +681,19 @@ extern "C" int clsr_t4_time_inputs_bwd(const float* dTT, const float* TT, const 
   CLSR_CHECK_ARG(dTT && TT && tnow && tfirst && partial && Hn > 0 && T > 0);
   CLSR_CHECK_SUPPORTED(n > 0 && n % 4 == 0 && 2 * n <= 1024 && Hn * T < (1L << 31));
   hipLaunchKernelGGL(t4_time_inputs_bwd_kernel, dim3(t4_tbwd_blocks(Hn * T, n)), dim3(256), 0,
-                     (hipStream_t)stream, dTT, TT, tnow, tfirst, row_stride, Hn, T, n, partial);
+                     (hipStream_t)stream, dTT, TT, tnow, tfirst, row_stride, Hn, T, n, partial, 0, T);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// the same sums over the steps [t0, t1) only: clsr_t4_time_inputs_bwd_parts(Hn, t1 - t0, n) partial rows
+extern "C" int clsr_t4_time_inputs_bwd_range(const float* dTT, const float* TT, const float* tnow,
+                                             const float* tfirst, long row_stride, long Hn, int T, int t0, int t1, int n,
+                                             float* partial, void* stream) {
+  CLSR_CHECK_ARG(dTT && TT && tnow && tfirst && partial && Hn > 0 && T > 0 && 0 <= t0 && t0 < t1 && t1 <= T);
+  CLSR_CHECK_SUPPORTED(n > 0 && n % 4 == 0 && 2 * n <= 1024 && Hn * T < (1L << 31));
+  hipLaunchKernelGGL(t4_time_inputs_bwd_kernel, dim3(t4_tbwd_blocks(Hn * (t1 - t0), n)), dim3(256), 0,
+                     (hipStream_t)stream, dTT, TT, tnow, tfirst, row_stride, Hn, T, n, partial, t0, t1 - t0);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
@@ -719,8 +703,9 @@ extern "C" int clsr_sizeof_gru_desc(void) { return (int)sizeof(clsr_gru_desc); }
 extern "C" int clsr_sizeof_t4_desc(void) { return (int)sizeof(clsr_t4_desc); }
 
 static int fill_multi(RnnMultiArgs& m, const clsr_gru_desc* grus, int ngru, const clsr_t4_desc* t4,
-                      const int* seq_len, int len_stride, int Hn, int T, bool backward) {
+                      const int* seq_len, int len_stride, int Hn, int T, bool backward, int t0, int t1) {
   CLSR_CHECK_ARG(seq_len && Hn > 0 && T > 0 && ngru >= 0 && ngru <= RNN_MAX_GRU && (ngru > 0 || t4));
+  CLSR_CHECK_ARG(0 <= t0 && t0 < t1 && t1 <= T);
   CLSR_CHECK_ARG(ngru == 0 || grus);
   m.ngru = ngru;
   m.has_t4 = t4 ? 1 : 0;
@@ -739,6 +724,7 @@ static int fill_multi(RnnMultiArgs& m, const clsr_gru_desc* grus, int ngru, cons
     a.dpin_bf16 = d.dpin_bf16;
     CLSR_CHECK_SUPPORTED(a.lddp % 4 == 0);
     a.att = d.att; a.datt = d.datt; a.in_div = d.in_div > 1 ? d.in_div : 1;
+    a.t0 = t0; a.t1 = t1;
     CLSR_CHECK_ARG(!(backward && d.att && !d.datt));
   }
   if (t4) {
@@ -754,6 +740,8 @@ static int fill_multi(RnnMultiArgs& m, const clsr_gru_desc* grus, int ngru, cons
     a.lddp = t4->lddp > 0 ? t4->lddp : 6 * t4->n;
     a.dpin_bf16 = t4->dpin_bf16;
     CLSR_CHECK_SUPPORTED(a.lddp % 4 == 0);
+    a.t0 = t0; a.t1 = t1;
+    a.st_in = t4->st_in; a.st_out = t4->st_out; a.dst_in = t4->dst_in; a.dst_out = t4->dst_out;
   }
   return CLSR_OK;
 }
@@ -776,10 +764,12 @@ static int multi_tiles(const RnnMultiArgs& m) {
   return rnn_tiles(n);
 }
 
-extern "C" int clsr_rnn_fwd_multi(const clsr_gru_desc* grus, int ngru, const clsr_t4_desc* t4,
-                                  const int* seq_len, int len_stride, int Hn, int T, void* stream) {
+// the steps [t0, t1) of every recurrence of the launch (state carried through the descriptors: GRU h0 / hT, Time4LSTM
+// st_in / st_out)
+extern "C" int clsr_rnn_fwd_multi_range(const clsr_gru_desc* grus, int ngru, const clsr_t4_desc* t4,
+                                        const int* seq_len, int len_stride, int Hn, int T, int t0, int t1, void* stream) {
   RnnMultiArgs m;
-  int rc = fill_multi(m, grus, ngru, t4, seq_len, len_stride, Hn, T, false);
+  int rc = fill_multi(m, grus, ngru, t4, seq_len, len_stride, Hn, T, false, t0, t1);
   if (rc) return rc;
   if (ngru > 0 && grus[0].att) {
     CLSR_CHECK_SUPPORTED(ngru == 1 && !t4);
@@ -787,15 +777,22 @@ extern "C" int clsr_rnn_fwd_multi(const clsr_gru_desc* grus, int ngru, const cls
     CLSR_CHECK_LAUNCH();
     return CLSR_OK;
   }
+  if (rnn1_supported(m)) return rnn1_launch(m, Hn, false, (hipStream_t)stream);   // one wave per encoder (csrc/rnn1.hip)
   RNN_LAUNCH(rnn_multi_fwd_kernel, multi_tiles(m), dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), stream, m);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
 
-extern "C" int clsr_rnn_bwd_multi(const clsr_gru_desc* grus, int ngru, const clsr_t4_desc* t4,
+extern "C" int clsr_rnn_fwd_multi(const clsr_gru_desc* grus, int ngru, const clsr_t4_desc* t4,
                                   const int* seq_len, int len_stride, int Hn, int T, void* stream) {
+  return clsr_rnn_fwd_multi_range(grus, ngru, t4, seq_len, len_stride, Hn, T, 0, T, stream);
+}
+
+// backward through the steps [t0, t1), descending (gradients carried: GRU dhT / dh0, Time4LSTM dst_in / dst_out)
+extern "C" int clsr_rnn_bwd_multi_range(const clsr_gru_desc* grus, int ngru, const clsr_t4_desc* t4,
+                                        const int* seq_len, int len_stride, int Hn, int T, int t0, int t1, void* stream) {
   RnnMultiArgs m;
-  int rc = fill_multi(m, grus, ngru, t4, seq_len, len_stride, Hn, T, true);
+  int rc = fill_multi(m, grus, ngru, t4, seq_len, len_stride, Hn, T, true, t0, t1);
   if (rc) return rc;
   if (ngru > 0 && grus[0].att) {
     CLSR_CHECK_SUPPORTED(ngru == 1 && !t4);
@@ -803,7 +800,13 @@ extern "C" int clsr_rnn_bwd_multi(const clsr_gru_desc* grus, int ngru, const cls
     CLSR_CHECK_LAUNCH();
     return CLSR_OK;
   }
+  if (rnn1_supported(m)) return rnn1_launch(m, Hn, true, (hipStream_t)stream);
   RNN_LAUNCH(rnn_multi_bwd_kernel, multi_tiles(m), dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), stream, m);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
+}
+
+extern "C" int clsr_rnn_bwd_multi(const clsr_gru_desc* grus, int ngru, const clsr_t4_desc* t4,
+                                  const int* seq_len, int len_stride, int Hn, int T, void* stream) {
+  return clsr_rnn_bwd_multi_range(grus, ngru, t4, seq_len, len_stride, Hn, T, 0, T, stream);
 }

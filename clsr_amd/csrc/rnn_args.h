@@ -1,0 +1,66 @@
+// Argument blocks of the recurrence kernels (csrc/rnn.hip: RNT waves per 16 histories with an LDS exchange per state
+// vector; csrc/rnn1.hip: ONE wave per encoder and 16 histories, no exchange at all).
+#pragma once
+#include "common.h"
+
+struct GruArgs {
+  const float* Pin; int ldp;           // [Hn, T, ldp]: r | u | c input-side pre-activations (+bias)
+  const float* Wgh; int ldg;           // [n, >=2n] hidden rows of gates/kernel
+  const float* Wch; int ldc;           // [n, >=n]  hidden rows of candidate/kernel
+  const float* h0; long h0_stride;     // optional initial state rows
+  const int* seq_len; int len_stride;
+  int Hn, T, n;
+  float* hT;                           // [Hn, n] final state
+  float* out_seq;                      // optional [Hn, T, n], zeros past len
+  float* hprev;                        // optional saves (training): [Hn, T, n]
+  float* gates;                        //                            [Hn, T, 3n] activated r | u | c
+  // backward
+  const float* dhT;                    // [Hn, n] grad wrt final state (may be null)
+  const float* dout_seq;               // optional [Hn, T, n]
+  float* dPin;                         // [Hn, T, lddp] (zeros past len); r | u | c blocks of n
+  int dpin_bf16;                       // dPin is a bf16 tensor (lddp in elements): speed mode
+  float* dh0;                          // optional [Hn, n]
+  int lddp;
+  // attentional update gate (DIEN's VecAttGRUCell, rnn_cell_implement.py:594-623): u <- (1 - att[s, t]) * u.
+  // The Hn sequences are then candidate ROWS: sequence s reads the input projections and the length of history
+  // s / in_div (the rows of a group share the first GRU's outputs, their attention scores differ)
+  const float* att;                    // optional [Hn, T]
+  float* datt;                         // backward: [Hn, T], accumulated with atomics (zeroed by the caller)
+  int in_div;
+  // time range [t0, t1) of this launch (whole sequence: 0, T).  A recurrence may be run as a CHAIN of launches over
+  // consecutive ranges -- forward: h0 = the hT of the previous range; backward (descending ranges): dhT = the dh0 of
+  // the previous launch -- so that the producers / consumers of Pin / dPin work on one range while the recurrence is
+  // busy with the next (clsr_amd/net.py: CLSRNet.rnn_chunks)
+  int t0, t1;
+};
+
+
+struct T4Args {
+  const float* Pin; int ldp;
+  const float* Wm; int ldm;            // [n, >=4n] hidden rows of the lstm kernel (i|j|f|o columns)
+  const int* seq_len; int len_stride;
+  int Hn, T, n;
+  float* out_seq;                      // [Hn, T, n] (m, zeros past len)
+  float* act; float* cst; float* mprev;
+  const float* dout_seq;               // [Hn, T, n]
+  float* dPin;                         // [Hn, T, lddp]
+  int dpin_bf16;                       // dPin is a bf16 tensor (lddp in elements): speed mode
+  int lddp;
+  int t0, t1;                          // time range of this launch (see GruArgs)
+  const float* st_in; float* st_out;   // optional [Hn, 2n] carried state c | m entering t0 / leaving t1 (forward)
+  const float* dst_in; float* dst_out; // optional [Hn, 2n] carried gradients dc | dm entering t1 - 1 / leaving t0 (backward)
+};
+
+
+#define RNN_MAX_GRU 3
+struct RnnMultiArgs {
+  GruArgs gru[RNN_MAX_GRU];
+  T4Args t4;
+  int ngru;
+  int has_t4;
+};
+
+
+// csrc/rnn1.hip: 1 when every recurrence of the launch can run on the one-wave-per-encoder kernels
+bool rnn1_supported(const RnnMultiArgs& m);
+int rnn1_launch(const RnnMultiArgs& m, int Hn, bool backward, hipStream_t stream);

@@ -186,7 +186,8 @@ class T4Desc(ctypes.Structure):
     """ctypes mirror of clsr_t4_desc (include/clsr_hip.h)."""
     _fields_ = [(n, ctypes.c_void_p) for n in ("Pin", "Wm", "out_seq", "act", "cst", "mprev", "dout_seq", "dPin")] + \
                [("ldp", ctypes.c_int), ("ldm", ctypes.c_int), ("n", ctypes.c_int), ("lddp", ctypes.c_int),
-                ("dpin_bf16", ctypes.c_int), ("pad_", ctypes.c_int)]
+                ("dpin_bf16", ctypes.c_int), ("pad_", ctypes.c_int)] + \
+               [(n, ctypes.c_void_p) for n in ("st_in", "st_out", "dst_in", "dst_out")]
 
 
 def _ptr(t):
@@ -206,10 +207,10 @@ def gru_desc(n, Pin=None, ldp=0, Wgh=None, ldg=0, Wch=None, ldc=0, h0=None, h0_s
 
 
 def t4_desc(n, Pin=None, ldp=0, Wm=None, ldm=0, out_seq=None, act=None, cst=None, mprev=None, dout_seq=None,
-            dPin=None, lddp=0):
+            dPin=None, lddp=0, st_in=None, st_out=None, dst_in=None, dst_out=None):
     d = T4Desc()
     for k, v in dict(Pin=Pin, Wm=Wm, out_seq=out_seq, act=act, cst=cst, mprev=mprev, dout_seq=dout_seq,
-                     dPin=dPin).items():
+                     dPin=dPin, st_in=st_in, st_out=st_out, dst_in=dst_in, dst_out=dst_out).items():
         setattr(d, k, _ptr(v))
     d.ldp, d.ldm, d.n, d.lddp = ldp, ldm, n, lddp
     d.dpin_bf16 = 1 if (dPin is not None and dPin.dtype == torch.bfloat16) else 0
@@ -228,13 +229,18 @@ def _check_rnn_descs():
         _rnn_descs_checked = True
 
 
-def rnn_multi(name, grus, t4, seq_len, len_stride, Hn, T):
-    """clsr_rnn_fwd_multi / clsr_rnn_bwd_multi with python lists of descriptors."""
+def rnn_multi(name, grus, t4, seq_len, len_stride, Hn, T, t_range=None):
+    """clsr_rnn_fwd_multi / clsr_rnn_bwd_multi with python lists of descriptors; ``t_range=(t0, t1)``: the
+    ``*_range`` entry points (one time range of a recurrence that runs as a chain of launches)."""
     _check_rnn_descs()
     arr = (GruDesc * max(len(grus), 1))(*grus)
     t4p = ctypes.addressof(t4) if t4 is not None else None
     keep_alive(arr, t4, grus)
-    call(name, ctypes.addressof(arr) if grus else None, len(grus), t4p, seq_len, len_stride, Hn, T)
+    if t_range is None:
+        call(name, ctypes.addressof(arr) if grus else None, len(grus), t4p, seq_len, len_stride, Hn, T)
+    else:
+        call(name + "_range", ctypes.addressof(arr) if grus else None, len(grus), t4p, seq_len, len_stride, Hn, T,
+             int(t_range[0]), int(t_range[1]))
 
 
 class PackDesc(ctypes.Structure):
@@ -345,7 +351,8 @@ class DwJob(ctypes.Structure):
     """ctypes mirror of clsr_dwjob (include/clsr_hip.h)."""
     _fields_ = [("X", _P), ("Xmul", _P), ("in_scale", _P), ("in_shift", _P), ("dY", _P), ("workspace", _P),
                 ("x_bf16", _I), ("ldx", _I), ("T", _I), ("G", _I), ("ldmul", _I), ("in_relu", _I), ("dy_bf16", _I),
-                ("ldy", _I), ("M", _I), ("K", _I), ("N", _I), ("pad_", _I)]
+                ("ldy", _I), ("M", _I), ("K", _I), ("N", _I), ("pad_", _I),
+                ("rm_tc", _I), ("rm_T", _I), ("rm_t0", _I), ("pgx", _I), ("pstride", _I), ("poff", _I)]
 
 
 DW_MULTI_MAX = 12

@@ -194,6 +194,8 @@ int clsr_hgemm_hf32(const void* X, int ldx, const void* Wt, int Kp, float* Y, in
 int clsr_cvt_f32_to_bf16(const float* src, void* dst, long n, void* stream);
 int clsr_cvt_bf16_to_f32(const void* src, float* dst, long n, void* stream);
 int clsr_pgemm_stats_parts(int M);
+int clsr_pgemm_range(const float* X, int ldx, const float* Wt, int Kp, const float* bias, float* Y, int ldy,
+                     int accumulate, int Hn, int T, int t0, int t1, int K, int N, void* stream);
 int clsr_pgemm(const float* X, int ldx, int T, int G, const float* Xmul, int ldmul,
                const float* in_scale, const float* in_shift, int in_relu, const float* Wt, int Kp,
                const float* bias, const float* addU, int ldu, const float* addV, int ldv, float* Y,
@@ -291,6 +293,9 @@ int clsr_t4_time_inputs_fwd(const float* tnow, const float* tfirst, long row_str
 int clsr_t4_time_inputs_bwd_parts(long Hn, int T, int n);
 int clsr_t4_time_inputs_bwd(const float* dTT, const float* TT, const float* tnow, const float* tfirst,
                             long row_stride, long Hn, int T, int n, float* partial, void* stream);
+/* the same partial sums over the steps [t0, t1) only: clsr_t4_time_inputs_bwd_parts(Hn, t1 - t0, n) partial rows */
+int clsr_t4_time_inputs_bwd_range(const float* dTT, const float* TT, const float* tnow, const float* tfirst,
+                                  long row_stride, long Hn, int T, int t0, int t1, int n, float* partial, void* stream);
 
 /* Fused launch of up to 3 GRUs + one Time4LSTM over the same histories (one grid, blockIdx.y = encoder).
  * Forward reads Pin, the weights and h0 and writes hT/out_seq (+ hprev/gates | act/cst/mprev when non-null);
@@ -313,6 +318,10 @@ typedef struct clsr_t4_desc {
   const float* dout_seq; float* dPin;
   int ldp; int ldm; int n; int lddp;
   int dpin_bf16; int pad_;   /* as in clsr_gru_desc */
+  /* state carried between the launches of a recurrence that runs as a chain of time ranges (clsr_rnn_*_multi_range):
+   * [Hn, 2n] rows  c | m  entering t0 / leaving t1 (forward),  dc | dm  entering t1 - 1 / leaving t0 (backward).
+   * NULL: zeros in, nothing stored.  (The GRU carries its state through h0 / hT and dhT / dh0.) */
+  const float* st_in; float* st_out; const float* dst_in; float* dst_out;
 } clsr_t4_desc;
 int clsr_sizeof_gru_desc(void);
 int clsr_sizeof_t4_desc(void);
@@ -320,6 +329,16 @@ int clsr_rnn_fwd_multi(const clsr_gru_desc* grus, int ngru, const clsr_t4_desc* 
                        int len_stride, int Hn, int T, void* stream);
 int clsr_rnn_bwd_multi(const clsr_gru_desc* grus, int ngru, const clsr_t4_desc* t4, const int* seq_len,
                        int len_stride, int Hn, int T, void* stream);
+/* The same recurrences restricted to the steps [t0, t1) (backward: descending from t1 - 1 to t0).  dynamic_rnn
+ * (reference call sites clsr.py:161,194,202,210,230) is one T-step loop; run as a chain of ranges -- each launch starting
+ * from the state the previous one left -- the results are identical, and the batched input projections of range k + 1 /
+ * the weight gradients of range k - 1 run beside the recurrence of range k instead of before / after all of it. */
+/* 1 when the multi launches run recurrences of hidden size n on the one-wave-per-encoder kernels (csrc/rnn1.hip) */
+int clsr_rnn_one_wave(int n);
+int clsr_rnn_fwd_multi_range(const clsr_gru_desc* grus, int ngru, const clsr_t4_desc* t4, const int* seq_len,
+                             int len_stride, int Hn, int T, int t0, int t1, void* stream);
+int clsr_rnn_bwd_multi_range(const clsr_gru_desc* grus, int ngru, const clsr_t4_desc* t4, const int* seq_len,
+                             int len_stride, int Hn, int T, int t0, int t1, void* stream);
 
 /* ---- heads: alpha gate + fusion clsr.py:239-275; MLP output layer base_model.py:686-706;
  *      softmax data loss base_model.py:215-235; contrastive loss clsr.py:46-71 */
@@ -456,6 +475,12 @@ typedef struct clsr_gather_desc { const float* table; const int* idx; float* out
 typedef struct clsr_dwjob {
   const void* X; const float* Xmul; const float* in_scale; const float* in_shift; const void* dY; float* workspace;
   int x_bf16; int ldx; int T; int G; int ldmul; int in_relu; int dy_bf16; int ldy; int M; int K; int N; int pad_;
+  /* time-range form (all zero: the plain product).  M = Hn * rm_tc virtual rows: row v is the physical row
+   * (v / rm_tc) * rm_T + rm_t0 + v % rm_tc of X and dY (the steps [rm_t0, rm_t0 + rm_tc) of every history).  The job uses
+   * pgx blocks along the rows (0: clsr_pgemm_dw_parts(M)) and writes the partial slots [poff, poff + pgx) of the pstride
+   * slots per (K, N) chunk of its workspace: the launches over the ranges of one product fill one workspace, which ONE
+   * clsr_dw_reduce_batch descriptor with nparts = pstride then sums. */
+  int rm_tc; int rm_T; int rm_t0; int pgx; int pstride; int poff;
 } clsr_dwjob;
 int clsr_sizeof_dwjob(void);
 int clsr_pgemm_dw_partial_multi(const clsr_dwjob* jobs_host, int n, void* stream);

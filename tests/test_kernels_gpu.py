@@ -1224,3 +1224,201 @@ def test_dw_reduce_batch_two_products_into_one_block(M1, M2, K, N):
     close(db1, Y1.sum(0), rtol=1e-5, atol=2e-6 * sc, name="db1")
     close(dW2, e2, rtol=1e-5, atol=2e-6 * sc, name="dW2")
     close(dWd, e1 - e2, rtol=1e-5, atol=4e-6 * sc, name="dW1 - dW2")
+
+
+# ------------------------------------------------------------------------------- recurrences / products over time ranges
+def _ranges(T, n):
+    return [(k * T // n, (k + 1) * T // n) for k in range(n)]
+
+
+@pytest.mark.parametrize("one_wave", ["0", "1"])
+@pytest.mark.parametrize("Hn,T,n,nch", [(37, 10, 40, 5), (16, 50, 40, 5), (21, 9, 128, 2), (5, 23, 40, 4)])
+def test_recurrences_as_a_chain_of_time_ranges_equal_one_launch(Hn, T, n, nch, one_wave, monkeypatch):
+    """clsr_rnn_{fwd,bwd}_multi_range over consecutive ranges (state carried through h0 / hT, st_in / st_out, dhT / dh0,
+    dst_in / dst_out) == ONE launch over [0, T): every output bit for bit (same instruction sequence per step); on the
+    split kernels (csrc/rnn.hip) and on the opt-in one-wave-per-encoder kernels (csrc/rnn1.hip)."""
+    monkeypatch.setenv("CLSR_RNN1", one_wave)
+    g = torch.Generator().manual_seed(Hn + T)
+    f = lambda t: dev(t, torch.float32)
+    ldp = 3 * n + 6 * n
+    Pin = f(rnd(g, Hn * T, ldp))
+    Wgh, Wch, Wm = f(rnd(g, n, 2 * n) * 0.3), f(rnd(g, n, n) * 0.3), f(rnd(g, n, 4 * n) * 0.3)
+    h0 = f(rnd(g, Hn, n) * 0.5)
+    lens = torch.randint(1, T + 1, (Hn,), generator=g)
+    lens[0], lens[-1] = T, 1
+    d_len = dev(lens, torch.int32)
+    dhT, dseq_g, dseq_t = f(rnd(g, Hn, n)), f(rnd(g, Hn, T, n)), f(rnd(g, Hn, T, n))
+
+    def run(ranges):
+        z = lambda *s: torch.full(s, 3.0, device="cuda")
+        o = dict(hT=z(Hn, n), seq=z(Hn, T, n), hprev=torch.zeros(Hn, T, n, device="cuda"),
+                 gates=torch.zeros(Hn, T, 3 * n, device="cuda"), out=z(Hn, T, n), act=torch.zeros(Hn, T, 6 * n, device="cuda"),
+                 cst=torch.zeros(Hn, T, n, device="cuda"), mprev=torch.zeros(Hn, T, n, device="cuda"),
+                 dPin=z(Hn * T, ldp), dh0=z(Hn, n))
+        st, dst, dhc = torch.zeros(Hn, 2 * n, device="cuda"), torch.zeros(Hn, 2 * n, device="cuda"), torch.zeros(Hn, n, device="cuda")
+        for k, (t0, t1) in enumerate(ranges):
+            first, last = k == 0, k == len(ranges) - 1
+            gd = ops.gru_desc(n, Pin=Pin, ldp=ldp, Wgh=Wgh, ldg=2 * n, Wch=Wch, ldc=n, h0=h0 if first else o["hT"],
+                              h0_stride=n, hT=o["hT"], out_seq=o["seq"], hprev=o["hprev"], gates=o["gates"])
+            td = ops.t4_desc(n, Pin=Pin[:, 3 * n:], ldp=ldp, Wm=Wm, ldm=4 * n, out_seq=o["out"], act=o["act"], cst=o["cst"],
+                             mprev=o["mprev"], st_in=None if first else st, st_out=None if last else st)
+            ops.rnn_multi("clsr_rnn_fwd_multi", [gd], td, d_len, 1, Hn, T, t_range=(t0, t1))
+        for k, (t0, t1) in enumerate(reversed(ranges)):
+            first, last = k == 0, k == len(ranges) - 1
+            gd = ops.gru_desc(n, Wgh=Wgh, ldg=2 * n, Wch=Wch, ldc=n, hprev=o["hprev"], gates=o["gates"],
+                              dhT=dhT if first else dhc, dout_seq=dseq_g, dPin=o["dPin"], lddp=ldp,
+                              dh0=o["dh0"] if last else dhc)
+            td = ops.t4_desc(n, Wm=Wm, ldm=4 * n, act=o["act"], cst=o["cst"], dout_seq=dseq_t, dPin=o["dPin"][:, 3 * n:],
+                             lddp=ldp, dst_in=None if first else dst, dst_out=None if last else dst)
+            ops.rnn_multi("clsr_rnn_bwd_multi", [gd], td, d_len, 1, Hn, T, t_range=(t0, t1))
+        torch.cuda.synchronize()
+        return o
+
+    one, chain = run([(0, T)]), run(_ranges(T, nch))
+    for k in one:
+        assert torch.equal(one[k], chain[k]), k
+    assert float(one["dPin"].abs().max()) > 0 and float(one["out"].abs().max()) > 0
+
+
+@pytest.mark.parametrize("Hn,T,K,N,nch", [(37, 10, 40, 480, 5), (9, 50, 80, 120, 5), (5, 23, 480, 40, 4)])
+def test_product_over_time_ranges_equals_the_whole_product(Hn, T, K, N, nch):
+    """clsr_pgemm_range over the ranges of [Hn, T, .] tensors == clsr_pgemm over all rows (bias / accumulate forms)."""
+    g = torch.Generator().manual_seed(K + N)
+    f = lambda t: dev(t, torch.float32)
+    X, W, b = f(rnd(g, Hn * T, K + 4)), rnd(g, K, N), f(rnd(g, N))
+    Wt, Kp = ops.pack_weight(f(W), N, K)
+    Y0 = f(rnd(g, Hn * T, N + 8))
+    for acc, bias in ((0, b), (1, None)):
+        whole, parts = Y0.clone(), Y0.clone()
+        call("clsr_pgemm", X, K + 4, 0, 0, None, 0, None, None, 0, Wt, Kp, bias, None, 0, None, 0, whole, N + 8, acc, None,
+             Hn * T, K, N)
+        for t0, t1 in _ranges(T, nch):
+            call("clsr_pgemm_range", X, K + 4, Wt, Kp, bias, parts, N + 8, acc, Hn, T, t0, t1, K, N)
+        torch.cuda.synchronize()
+        assert torch.equal(whole, parts), (acc,)
+    exp = X[:, :K].double().cpu() @ W + b.double().cpu()
+    whole = torch.zeros(Hn * T, N, device="cuda")
+    for t0, t1 in _ranges(T, nch):
+        call("clsr_pgemm_range", X, K + 4, Wt, Kp, b, whole, N, 0, Hn, T, t0, t1, K, N)
+    close(whole, exp, rtol=2e-5, atol=2e-6 * K, name="Y")
+
+
+@pytest.mark.parametrize("Hn,T,nch", [(37, 10, 5), (64, 50, 5), (9, 23, 4)])
+def test_weight_gradients_over_time_ranges_fill_one_workspace(Hn, T, nch):
+    """Multi-job weight-gradient launches over time ranges (each writing its own partial slots of ONE workspace), summed by
+    one clsr_dw_reduce_batch descriptor == the products over all rows; plain and X * Xmul jobs; + the time-feature sums."""
+    g = torch.Generator().manual_seed(T)
+    f = lambda t: dev(t, torch.float32)
+    M = Hn * T
+    Xw, dYw, mul = f(rnd(g, M, 120)), f(rnd(g, M, 480)), f(rnd(g, M, 120))
+    specs = [(0, 40, 0, 480, None), (40, 40, 0, 160, None), (80, 40, 360, 40, mul), (0, 80, 160, 120, None)]
+    ranges = _ranges(T, nch)
+    tcmax = max(b - a for a, b in ranges)
+    pgx = query("clsr_pgemm_dw_parts", Hn * tcmax)
+    wss, outs, sig = [], [], []
+    for x0, K, y0, N, xm in specs:
+        ws = torch.full((nch * query("clsr_pgemm_dw_workspace_floats", Hn * tcmax, K, N),), 7.0, device="cuda")
+        dW, db = torch.zeros(K, N, device="cuda"), torch.zeros(N, device="cuda")
+        wss.append(ws)
+        outs.append((dW, db))
+        sig.append((ws.data_ptr(), dW.data_ptr(), db.data_ptr(), 1.0, nch * pgx, K, N, N, 0))
+    for k, (t0, t1) in enumerate(ranges):
+        tc = t1 - t0
+        jobs = [(Xw[:, x0:].data_ptr(), xm.data_ptr() if xm is not None else 0, 0, 0, dYw[:, y0:].data_ptr(), ws.data_ptr(),
+                 0, 120, 0, 0, 120 if xm is not None else 0, 1, 0, 480, Hn * tc, K, N, 0, tc, T, t0, pgx, nch * pgx, k * pgx)
+                for (x0, K, y0, N, xm), ws in zip(specs, wss)]
+        ops.dw_multi("clsr_pgemm_dw_partial_multi", jobs)
+    tab = ops.dw_table(tuple(sig), torch.device("cuda"))
+    call("clsr_dw_reduce_batch", tab[0], tab[1], tab[2])
+    torch.cuda.synchronize()
+    Xd, Yd, md = Xw.double().cpu(), dYw.double().cpu(), mul.double().cpu()
+    for (x0, K, y0, N, xm), (dW, db) in zip(specs, outs):
+        x = Xd[:, x0:x0 + K] * (md[:, :K] if xm is not None else 1.0)
+        close(dW, x.T @ Yd[:, y0:y0 + N], rtol=2e-4, atol=2e-4 * math.sqrt(M), name="dW")
+        close(db, Yd[:, y0:y0 + N].sum(0), rtol=2e-4, atol=2e-4 * math.sqrt(M), name="db")
+    # time-feature gradient sums over ranges == over all steps
+    n = 40
+    dTT, TT = f(rnd(g, M, 2 * n)), f(torch.tanh(rnd(g, M, 2 * n)))
+    tnow, tfirst = f(rnd(g, Hn, T)), f(rnd(g, Hn, T))
+    p_all = torch.zeros(query("clsr_t4_time_inputs_bwd_parts", Hn, T, n), 2, 2 * n, device="cuda")
+    call("clsr_t4_time_inputs_bwd", dTT, TT, tnow, tfirst, T, Hn, T, n, p_all)
+    tparts = [query("clsr_t4_time_inputs_bwd_parts", Hn, b - a, n) for a, b in ranges]
+    p_rng = torch.full((sum(tparts), 2, 2 * n), 5.0, device="cuda")
+    for k, (t0, t1) in enumerate(ranges):
+        call("clsr_t4_time_inputs_bwd_range", dTT, TT, tnow, tfirst, T, Hn, T, t0, t1, n, p_rng[sum(tparts[:k]):])
+    close(p_rng.sum(0), p_all.sum(0).double(), rtol=1e-4, atol=1e-4 * math.sqrt(M), name="time-feature sums")
+
+
+@pytest.mark.parametrize("Hn,T,n", [(37, 10, 40), (16, 50, 40), (21, 13, 36), (19, 9, 48), (18, 7, 44), (33, 6, 32),
+                                    (17, 11, 24), (5, 9, 16), (20, 5, 8)])
+def test_one_wave_per_encoder_recurrences_equal_the_split_kernels(Hn, T, n, monkeypatch):
+    """With CLSR_RNN1=1 clsr_rnn_{fwd,bwd}_multi runs hidden sizes <= 48 on the one-wave-per-encoder kernels
+    (csrc/rnn1.hip: all feature tiles in one wave, permuted compact last tile, raw buffer addressing); the single-encoder
+    entry points run the RNT-waves kernels of csrc/rnn.hip (LDS exchange per state vector).  Same arithmetic: every
+    output agrees to fp32 rounding of the differently associated sums -- two GRUs (with / without h0, with / without
+    sequence output) + a Time4LSTM in ONE launch, ragged lengths, histories that are not a multiple of 16.  Saved
+    activations are compared on LIVE steps only: the one-wave kernels also store (finite, never used) values for dead
+    steps inside a wave's common range."""
+    monkeypatch.setenv("CLSR_RNN1", "1")
+    assert query("clsr_rnn_one_wave", n) == 1
+    g = torch.Generator().manual_seed(Hn * 7 + n)
+    f = lambda t: dev(t, torch.float32)
+    ldp = 3 * n + 3 * n + 6 * n
+    Pin = f(rnd(g, Hn * T, ldp))
+    W = [(f(rnd(g, n, 2 * n) * 0.3), f(rnd(g, n, n) * 0.3)) for _ in range(2)]
+    Wm = f(rnd(g, n, 4 * n) * 0.3)
+    h0 = f(rnd(g, Hn, n) * 0.5)
+    lens = torch.randint(1, T + 1, (Hn,), generator=g)
+    lens[0], lens[-1] = T, 1
+    d_len = dev(lens, torch.int32)
+    dhT = [f(rnd(g, Hn, n)), f(rnd(g, Hn, n))]
+    dseq_g, dseq_t = f(rnd(g, Hn, T, n)), f(rnd(g, Hn, T, n))
+    z = lambda *s: torch.full(s, 3.0, device="cuda")
+
+    def bufs():
+        return dict(hT=[z(Hn, n), z(Hn, n)], seq=z(Hn, T, n), hprev=[torch.zeros(Hn, T, n, device="cuda") for _ in range(2)],
+                    gates=[torch.zeros(Hn, T, 3 * n, device="cuda") for _ in range(2)], out=z(Hn, T, n),
+                    act=torch.zeros(Hn, T, 6 * n, device="cuda"), cst=torch.zeros(Hn, T, n, device="cuda"),
+                    mprev=torch.zeros(Hn, T, n, device="cuda"), dPin=z(Hn * T, ldp), dh0=z(Hn, n))
+
+    A, B = bufs(), bufs()
+    # ---- one launch, one wave per encoder
+    g0 = ops.gru_desc(n, Pin=Pin, ldp=ldp, Wgh=W[0][0], ldg=2 * n, Wch=W[0][1], ldc=n, h0=h0, h0_stride=n, hT=A["hT"][0],
+                      hprev=A["hprev"][0], gates=A["gates"][0])
+    g1 = ops.gru_desc(n, Pin=Pin[:, 3 * n:], ldp=ldp, Wgh=W[1][0], ldg=2 * n, Wch=W[1][1], ldc=n, hT=A["hT"][1],
+                      out_seq=A["seq"], hprev=A["hprev"][1], gates=A["gates"][1])
+    td = ops.t4_desc(n, Pin=Pin[:, 6 * n:], ldp=ldp, Wm=Wm, ldm=4 * n, out_seq=A["out"], act=A["act"], cst=A["cst"],
+                     mprev=A["mprev"])
+    ops.rnn_multi("clsr_rnn_fwd_multi", [g0, g1], td, d_len, 1, Hn, T)
+    g0 = ops.gru_desc(n, Wgh=W[0][0], ldg=2 * n, Wch=W[0][1], ldc=n, hprev=A["hprev"][0], gates=A["gates"][0], dhT=dhT[0],
+                      dPin=A["dPin"], lddp=ldp, dh0=A["dh0"])
+    g1 = ops.gru_desc(n, Wgh=W[1][0], ldg=2 * n, Wch=W[1][1], ldc=n, hprev=A["hprev"][1], gates=A["gates"][1], dhT=dhT[1],
+                      dout_seq=dseq_g, dPin=A["dPin"][:, 3 * n:], lddp=ldp)
+    td = ops.t4_desc(n, Wm=Wm, ldm=4 * n, act=A["act"], cst=A["cst"], dout_seq=dseq_t, dPin=A["dPin"][:, 6 * n:], lddp=ldp)
+    ops.rnn_multi("clsr_rnn_bwd_multi", [g0, g1], td, d_len, 1, Hn, T)
+    # ---- the same encoders one by one through the single-encoder entry points (contiguous slices)
+    P0, P1, P2 = (Pin[:, :3 * n].contiguous(), Pin[:, 3 * n:6 * n].contiguous(), Pin[:, 6 * n:].contiguous())
+    call("clsr_gru_fwd", P0, 3 * n, W[0][0], 2 * n, W[0][1], n, h0, n, d_len, 1, Hn, T, n, B["hT"][0], None, B["hprev"][0],
+         B["gates"][0])
+    call("clsr_gru_fwd", P1, 3 * n, W[1][0], 2 * n, W[1][1], n, None, 0, d_len, 1, Hn, T, n, B["hT"][1], B["seq"],
+         B["hprev"][1], B["gates"][1])
+    call("clsr_t4lstm_fwd", P2, 6 * n, Wm, 4 * n, d_len, 1, Hn, T, n, B["out"], B["act"], B["cst"], B["mprev"])
+    dP0, dP1, dP2 = z(Hn * T, 3 * n), z(Hn * T, 3 * n), z(Hn * T, 6 * n)
+    call("clsr_gru_bwd", B["gates"][0], B["hprev"][0], W[0][0], 2 * n, W[0][1], n, d_len, 1, Hn, T, n, dhT[0], None, dP0,
+         B["dh0"])
+    call("clsr_gru_bwd", B["gates"][1], B["hprev"][1], W[1][0], 2 * n, W[1][1], n, d_len, 1, Hn, T, n, dhT[1], dseq_g, dP1,
+         None)
+    call("clsr_t4lstm_bwd", B["act"], B["cst"], Wm, 4 * n, d_len, 1, Hn, T, n, dseq_t, dP2)
+    torch.cuda.synchronize()
+    B["dPin"] = torch.cat([dP0, dP1, dP2], 1)
+    live = (torch.arange(T)[None, :] < lens[:, None]).cuda()[..., None]
+    for i in range(2):
+        close(A["hT"][i], B["hT"][i].double(), rtol=2e-5, atol=2e-6, name="hT[%d]" % i)
+        for k in ("hprev", "gates"):
+            close(A[k][i] * live, (B[k][i] * live).double(), rtol=2e-5, atol=2e-6, name="%s[%d]" % (k, i))
+    for k in ("act", "cst", "mprev"):
+        close(A[k] * live, (B[k] * live).double(), rtol=2e-5, atol=2e-6, name=k)
+    for k in ("seq", "out", "dh0"):
+        close(A[k], B[k].double(), rtol=2e-5, atol=2e-6, name=k)
+    close(A["dPin"], B["dPin"].double(), rtol=1e-4, atol=1e-5, name="dPin")
+    assert float(A["dPin"].abs().max()) > 0 and float(A["out"].abs().max()) > 0

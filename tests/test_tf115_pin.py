@@ -101,6 +101,26 @@ def fabricate_pin(path, hp, golden_dir, rename=None, drop=()):
     return path
 
 
+def _check_after(ref, after, lr, rtol, bn_rtol, bn_atol):
+    """Variables after ONE Adam step against the pin file.  Adam's first step is ~lr * g / (|g| + eps): where a gradient
+    is analytically zero (biases that feed a batch-norm, the softmax-invariant output bias) every implementation returns
+    its own fp32 summation noise and the step is +-lr times noise / (noise + 1e-8) -- arbitrary.  So the UPDATE
+    (after - before) is compared where the reference's own gradient is well above that noise, and merely bounded by the
+    step size elsewhere; batch-norm moving statistics (no optimiser) are compared directly."""
+    gnames = P.ref_names(ref, "grad/")
+    floor = 4e-6 * max(float(np.abs(ref["grad/" + n]).max()) for n in gnames if not n.startswith("sequential/embedding/"))
+    for name, v in after.items():
+        want = np.asarray(ref["after/" + name], dtype=np.float64)
+        got = np.asarray(v, dtype=np.float64)
+        if "grad/" + name not in ref.files:        # moving statistics, variables without a gradient
+            np.testing.assert_allclose(got, want, rtol=bn_rtol, atol=bn_atol, err_msg=name)
+            continue
+        before = np.asarray(ref["before/" + name], dtype=np.float64)
+        sel = np.abs(np.asarray(ref["grad/" + name], dtype=np.float64)) > 100 * floor
+        np.testing.assert_allclose((got - before)[sel], (want - before)[sel], rtol=rtol, atol=0.02 * lr, err_msg="adam update " + name)
+        assert float(np.abs(got - before).max()) <= 1.05 * lr, name     # |step 1| = lr * |g| / (|g| + eps') <= lr
+
+
 def check_oracle_against(pin_path, hp, golden_dir):
     """The oracle (CPU, float64) against a pin file: forward, losses, every gradient, slice norms, one Adam step,
     moving statistics, inference.  No key is optional."""
@@ -125,8 +145,7 @@ def check_oracle_against(pin_path, hp, golden_dir):
             np.testing.assert_allclose(norms[name], float(ref["slices_norm/" + name]), rtol=1e-4, err_msg=name)
     after = list(new_p.items()) + list(new_bn.items())
     P.require_keys(ref, "after/", [n for n, _ in after], "variables after one train step")
-    for name, v in after:
-        np.testing.assert_allclose(v.numpy(), ref["after/" + name], rtol=1e-4, atol=2e-5, err_msg=name)
+    _check_after(ref, {n: v.numpy() for n, v in after}, float(hp.learning_rate), rtol=5e-3, bn_rtol=1e-4, bn_atol=2e-5)
     np.testing.assert_allclose(pred.numpy().reshape(-1), ref["eval_pred"].reshape(-1), rtol=0, atol=1e-4)
 
 
@@ -151,8 +170,8 @@ def check_hip_against(pin_path, hp, golden_dir):
         np.testing.assert_allclose(gl[k], float(ref["loss/" + k]), rtol=1e-4, atol=1e-6, err_msg=k)
     after = {n: v for n, v in net.state_dict().items() if not n.startswith("__adam__/")}
     P.require_keys(ref, "after/", list(after), "variables after one train step (HIP net)")
-    for name, v in after.items():
-        np.testing.assert_allclose(v.numpy(), ref["after/" + name], rtol=1e-3, atol=5e-5, err_msg=name)
+    _check_after(ref, {n: v.numpy() for n, v in after.items()}, float(hp.learning_rate), rtol=5e-3, bn_rtol=1e-3,
+                 bn_atol=5e-5)
     feed_e = P.feed_arrays(np.load(os.path.join(golden_dir, "iterator_eval_sa.npz")))
     pred = torch.sigmoid(net.forward(net.upload(feed_e, False), False)["logit"]).cpu().numpy()
     np.testing.assert_allclose(pred.reshape(-1), ref["eval_pred"].reshape(-1), rtol=0, atol=1e-3)
