@@ -87,14 +87,16 @@ def time_kernel(fn, iters=20, warm=3):
 
 
 def cpu_baseline(cfg, seconds=25.0, P=None, warmup=1, steps=None):
-    """The oracle (torch-CPU fp32 restatement of the reference graph, dense-Adam semantics) timed on
-    the host cores on the SAME workload (P = 4096 positives x5 rows, same synthetic batch as the GPU step).
+    """The oracle (torch-CPU fp32 restatement of the reference graph, dense-Adam semantics) timed on the host cores.
 
-    Protocol (BASELINE.md section 2 / SURVEY 8d): 5 warm-ups + >= 20 timed steps.  One step of this size costs
-    tens of seconds on the host, so the DEFAULT run is bounded (task contract: a 10-30 s sample): ``warmup``
-    untimed steps, then timed steps until ``seconds`` have passed (at least one); ``--cpu-warmup 5 --cpu-steps 20``
-    runs the full protocol.  The oracle runs with its input-side RNN projections hoisted out of the T loop
-    (oracle.FAST_RNN: same math, one batched product per encoder instead of T small ones)."""
+    Protocol (BASELINE.md section 2 / SURVEY 8d): 5 warm-ups + >= 20 timed steps, median.  One step of the benchmarked
+    batch (4096 positives x5 rows) costs ~36 s on the host, so the DEFAULT run is bounded: the benchmarked batch itself,
+    ``warmup`` (1) untimed step, then THREE timed steps, MEDIAN step time (~2.5 min; a smaller batch is NOT representative:
+    1024 positives per step measured 64.8 interactions/s against 113 for the full batch -- the per-step costs of the 50
+    time steps do not shrink with the batch).  ``--cpu-warmup 5 --cpu-steps 20`` runs the full protocol (~15 min; that
+    run is committed as profiles/r03_cpu_baseline_full_protocol.json: 113.25 interactions/s, median 36.17 s/step).  The
+    oracle runs with its input-side RNN projections hoisted out of the T loop (oracle.FAST_RNN: same math, one batched
+    product per encoder instead of T small ones)."""
     import torch
     from oracle import clsr_oracle as O
     from clsr_amd.synthetic import synthetic_feed
@@ -110,29 +112,35 @@ def cpu_baseline(cfg, seconds=25.0, P=None, warmup=1, steps=None):
     bn, adam = O.init_bn_state(params), O.init_adam(params)
     feed = O.to_torch_feed(synthetic_feed(P, cfg["T"], cfg["Vu"], cfg["Vi"], cfg["Vc"], lengths="full"))
     O.FAST_RNN = True
+    times = []
     try:
         tw = time.perf_counter()
         for i in range(warmup):
             params, bn, adam, _, _, _, _ = O.train_step(params, bn, adam, i + 1, feed, hp)
         log("cpu baseline: %d warm-up step(s) took %.1fs on %d threads" % (warmup, time.perf_counter() - tw, cores))
-        n, t0 = 0, time.perf_counter()
+        t0 = time.perf_counter()
         while True:
-            params, bn, adam, _, _, _, _ = O.train_step(params, bn, adam, warmup + n + 1, feed, hp)
-            n += 1
-            dt = time.perf_counter() - t0
-            if (steps is not None and n >= steps) or (steps is None and (dt > seconds or n >= 20)):
+            t1 = time.perf_counter()
+            params, bn, adam, _, _, _, _ = O.train_step(params, bn, adam, warmup + len(times) + 1, feed, hp)
+            times.append(time.perf_counter() - t1)
+            n, dt = len(times), time.perf_counter() - t0
+            if (steps is not None and n >= steps) or (steps is None and ((n >= 3 and dt > seconds) or n >= 20)):
                 break
     finally:
         O.FAST_RNN = False
-    full = warmup >= 5 and n >= 20
-    return dict(value=round(P * n / dt, 2), unit="interactions/s", cores=cores, kind="port",
-                ms_per_step=round(dt * 1e3 / n, 1),
-                sample="%d warm-up + %d timed steps of the benchmarked batch itself (%d positives x5 rows, seq_len %d, "
-                       "same tables; oracle/clsr_oracle.py, torch-CPU fp32, %d threads, input projections hoisted "
-                       "out of the T loop)%s; the reference's TF-1.15 CPU path cannot run here"
-                       % (warmup, n, P, cfg["T"], cores,
-                          "" if full else "; bounded sample (task contract: 10-30 s of CPU work) instead of the 5 + 20 "
-                                          "steps of BASELINE.md section 2, which take ~15 min: --cpu-warmup 5 --cpu-steps 20"))
+    med = float(np.median(times))
+    full = warmup >= 5 and n >= 20 and P >= cfg["P"]
+    return dict(value=round(P / med, 2), unit="interactions/s", cores=cores, kind="port",
+                ms_per_step=round(med * 1e3, 1), timed_steps=n, positives_per_step=P,
+                step_ms_min_max=[round(min(times) * 1e3, 1), round(max(times) * 1e3, 1)],
+                sample="%d warm-up + %d timed steps, MEDIAN step time; each step = %d positives x5 rows of the benchmarked "
+                       "workload (seq_len %d, same tables, same row group; the GPU step holds %d positives); "
+                       "oracle/clsr_oracle.py, torch-CPU fp32, %d threads, input projections hoisted out of the T loop%s; "
+                       "the reference's TF-1.15 CPU path cannot run here"
+                       % (warmup, n, P, cfg["T"], cfg["P"], cores,
+                          "" if full else "; bounded sample instead of the 5 + 20 steps of BASELINE.md section 2 (~15 min: "
+                                          "--cpu-warmup 5 --cpu-steps 20; that run, 113.25 interactions/s: "
+                                          "profiles/r03_cpu_baseline_full_protocol.json)"))
 
 
 class Workload(object):
@@ -227,10 +235,12 @@ class Workload(object):
         if dist is not None:
             dist.barrier()
         dt = time.perf_counter() - t0
+        self.rank_seconds = [dt]
         if dist is not None:
-            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax)
+            every = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(dist.get_world_size())]
+            dist.all_gather(every, torch.tensor([dt], dtype=torch.float64, device="cuda"))
+            self.rank_seconds = [float(t) for t in every]
+            dt = max(self.rank_seconds)
         return dt
 
     def free(self):
@@ -287,11 +297,19 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--cpu-warmup", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=None)
+    ap.add_argument("--cpu-P", type=int, default=None, help="positives per CPU-baseline step (default: the benchmarked batch)")
+    ap.add_argument("--cpu-only", action="store_true", help="print only the cpu_baseline object (no GPU work)")
     ap.add_argument("--local-bn", action="store_true",
                     help="(N>1) per-rank batch-norm statistics with averaged moving stats (no mid-step collectives) "
                          "instead of the default global statistics (single-device parity)")
     ap.add_argument("--sync-bn", action="store_true", help="(default for N>1; kept for old command lines)")
     args = ap.parse_args()
+    if args.cpu_only:
+        from clsr_amd.synthetic import CONFIGS as _C
+
+        print(json.dumps(cpu_baseline(_C[args.config], seconds=args.cpu_seconds, warmup=args.cpu_warmup,
+                                      steps=args.cpu_steps, P=args.cpu_P)), flush=True)
+        return
 
     import torch
     from clsr_amd import ops
@@ -328,6 +346,13 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # proof that RCCL really connects the ranks the line claims: a sum of ones over the job
+        ones = torch.ones(1, device="cuda")
+        dist.all_reduce(ones)
+        torch.cuda.synchronize()
+        rccl_ranks = int(ones.item())
+        if rccl_ranks != world and not force_dp:
+            raise SystemExit("RCCL all-reduce of ones gave %d, WORLD_SIZE is %d" % (rccl_ranks, world))
     sync_bn = not args.local_bn
 
     cfg = CONFIGS[args.config]
@@ -371,9 +396,15 @@ def main():
         # copy: 1 GiB read + 1 GiB written per launch)
         copy_peak = None
         try:
-            src_, dst_ = torch.empty(1 << 28, device="cuda"), torch.empty(1 << 28, device="cuda")
-            t_copy = time_kernel(lambda: dst_.copy_(src_), iters=10, warm=2)
-            copy_peak = round(2.0 * (1 << 30) / t_copy / 1e9, 1)
+            from clsr_amd import ops as _ops
+
+            # the repo's own 16-byte copy kernel (csrc/optim.hip: clsr_copy_words, non-temporal, 4 words in flight per
+            # lane, one pass per lane) over 4 GiB -- past the 256 MiB Infinity Cache; swept in scripts/copy_sweep.py:
+            # 5.0-5.4 TB/s at 1 GiB, 6.1 TB/s at 4 GiB (a torch copy_ of 1 GiB: 5.2 TB/s, below the gather itself)
+            nb_ = 4 << 30
+            src_, dst_ = torch.empty(nb_ // 4, device="cuda"), torch.empty(nb_ // 4, device="cuda")
+            t_copy = time_kernel(lambda: _ops.call("clsr_copy_words", dst_, src_.data_ptr(), nb_), iters=10, warm=2)
+            copy_peak = round(2.0 * nb_ / t_copy / 1e9, 1)
             roof["measured_copy_peak_GBps"] = copy_peak
             roof["frac_of_measured_copy_peak"] = round(roof["achieved"] / copy_peak, 4)
             del src_, dst_
@@ -416,6 +447,15 @@ def main():
                               interactions_per_s=round(w4.P * 10 / d4, 1), steps=10))
             log("kuaishou: %.3f ms/step" % (d4 * 100.0))
             w4.free()
+            # ---- the same Taobao-shaped batch with realistic (log-normal) history lengths
+            other_len = "lognormal" if args.lengths == "full" else "full"
+            w6 = Workload(args.config, args.model, args.precision, dedup=not args.exact_clip, lengths=other_len)
+            d6 = w6.run(10, 3)
+            lens6 = np.asarray(w6.feed["mask"]).sum(1)[::w6.G]
+            extra.append(dict(workload=w6.describe() + " (%s lengths: mean %.1f of %d steps)" % (other_len, float(lens6.mean()), w6.T),
+                              ms_per_step=round(d6 * 100.0, 4), interactions_per_s=round(w6.P * 10 / d6, 1), steps=10))
+            log("%s lengths: %.3f ms/step" % (other_len, d6 * 100.0))
+            w6.free()
         if world == 1 and dist is None and not args.no_catalogue and not big:
             # BASELINE configs[4] on one GPU: 100M items x 96 floats (38 GB, uniform ids: no cache reuse, every row
             # read is an HBM read) -- the HBM claim of the gather kernel is made HERE (at configs[1]
@@ -466,6 +506,10 @@ def main():
             "roofline": roof, "roofline_mfma": roof_mfma,
             "loss": float(host_losses[:4].sum()),
         }
+        if dist is not None:
+            out["config"]["rccl_ranks"] = rccl_ranks
+            out["config"]["ms_per_step_by_rank"] = [round(t * 1e3 / args.steps, 4) for t in wl.rank_seconds]
+            out["config"]["sparse_tables"] = getattr(wl.stepper, "last_sparse", None)
         if roof_mfma is None:
             del out["roofline_mfma"]
         if modes:
@@ -474,7 +518,7 @@ def main():
             out["extra_workloads"] = extra
         if world == 1 and not args.no_cpu_baseline and not big and args.model == "clsr":
             out["cpu_baseline"] = cpu_baseline(cfg, seconds=args.cpu_seconds, warmup=args.cpu_warmup,
-                                               steps=args.cpu_steps)
+                                               steps=args.cpu_steps, P=args.cpu_P)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -199,7 +199,10 @@ __global__ void __launch_bounds__(256, OT <= 5 ? 2 : 1) att_l1_bwd_kernel(L1BwdA
           fsum[ot][3] += v.w; fsq[ot][3] = fmaf(v.w, w2.w, fsq[ot][3]);
         }
       }
-    if (!APPLY && ++pending == 8) {   // fp32 per-lane partials of at most 16 values between flushes
+#ifndef CLSR_STAT_FLUSH_N
+#define CLSR_STAT_FLUSH_N 8
+#endif
+    if (!APPLY && ++pending == CLSR_STAT_FLUSH_N) {   // fp32 per-lane partials of at most 16 values between flushes
       flush();
       pending = 0;
     }

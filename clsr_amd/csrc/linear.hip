@@ -241,7 +241,10 @@ __global__ void __launch_bounds__(256) pgemm_fast_kernel(PGemmArgs a) {
 
   // column statistics: fp32 per-lane partials over at most STAT_FLUSH wave-tiles (32 values), then a
   // 16-lane reduction added into per-wave DOUBLE accumulators in LDS (behind the weight chunk)
-  constexpr int STAT_FLUSH = 8;
+#ifndef CLSR_STAT_FLUSH_N
+#define CLSR_STAT_FLUSH_N 8      // (1: every partial goes straight into the double accumulators -- diagnosis builds)
+#endif
+  constexpr int STAT_FLUSH = CLSR_STAT_FLUSH_N;
   float fsum[STATS ? OT : 1][4], fsq[STATS ? OT : 1][4];
   double* red = reinterpret_cast<double*>(lds + (long)16 * OT * Kp);  // [4 waves][2][OT*16]
   int pending = 0;

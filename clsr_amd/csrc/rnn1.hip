@@ -41,7 +41,7 @@
 #endif
 typedef __bf16 r1_bf16x4 __attribute__((ext_vector_type(4)));
 
-// (R1_ABL_*: compile-time ablations for timing experiments -- scripts/r3_rnn1_ablate.sh; never defined in the product build)
+// (R1_ABL_*: compile-time ablations for timing experiments -- scripts/build_variant.sh; never defined in the product build)
 __device__ __forceinline__ f32x4 r1_sig4(f32x4 v) {
 #ifdef R1_ABL_NOACT
   return v * 0.25f + 0.5f;

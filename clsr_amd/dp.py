@@ -107,10 +107,15 @@ class DataParallel(object):
     piece's collective is issued right there with ``async_op=True`` -- RCCL's stream waits for exactly that stream's
     work so far and the step's own streams keep going:
       flags_ready   start of the step (row marks depend on the feed only)  -> byte-map all-reduce under the forward
-      dense_ready   after the batched weight-gradient reduction            -> 0.5 MB all-reduce under the embedding kernels
-      table_ready   per table, on the stream that finished it              -> category / user tables under the item kernel
-    ``_finish`` issues what is left (the item table, the 24 doubles of norms / loss numerators, per-rank BN moving
-    statistics), makes the compute stream wait for every collective, and the identical clip + Adam update follows.
+      table_ready   per table, on the stream that finished it              -> SPARSE tables: their row exchange starts there
+      dense_ready   after the batched weight-gradient reduction            -> noted (the stream it is final on)
+    ``_finish`` then issues, in THIS order: every run of adjacent dense gradient tables as ONE all-reduce (the compute
+    stream has joined the streams that produced them), the 0.5 MB of dense gradients (final ~100 us later, on the
+    weight-gradient stream: its collective is queued BEHIND the tables' so that the 20 MB of tables do not wait for
+    it -- collectives of a process group run in issue order), the 24 doubles of norms / loss numerators and, with
+    per-rank BN, the moving statistics; the compute stream waits for all of them and the identical clip + Adam update
+    follows.  Round 2 issued the dense all-reduce and every table's own all-reduce from the hooks: seven collectives at
+    the tail, the first of which (dense) held back the others (profiles/r03_dp_world1_timeline.txt).
     Nets without hooks (or ``overlap=False``) run the same collectives back to back after the backward pass."""
 
     def __init__(self, net, dist, sync_bn=True, group=None, sparse_tables="auto", overlap=True, sparse_mode="allgather"):
@@ -134,6 +139,8 @@ class DataParallel(object):
         self.sparse_min_bytes = 64 << 20   # "auto": tables below this size always go dense
         self._graphs = None
         self._works, self._done = [], set()
+        self._dense_stream = None
+        self.last_sparse = []
         self.trace = None              # tests: list that receives (event, detail) tuples in issue order
         self.broadcast_parameters()
 
@@ -203,8 +210,9 @@ class DataParallel(object):
             i = j + 1
 
     def dense_ready(self, stream):
-        self._done.add("dense")
-        self._allreduce(self.net.dense_grad, self.dist.ReduceOp.SUM, stream, "dense")
+        """The dense gradients are final on ``stream``; their all-reduce is issued by ``_finish`` behind the tables'."""
+        self._dense_stream = stream
+        self._done.add("dense-final")
 
     def table_ready(self, stream, name):
         net = self.net
@@ -212,12 +220,29 @@ class DataParallel(object):
             return
         if "flags" not in self._done:          # a net that never reported its flags: exchange them first
             self.flags_ready(stream)
-        self._done.add(name)
         if name in self.last_sparse:
+            self._done.add(name)
             with self._on(stream):
                 self._exchange_rows(name)
-        else:
-            self._allreduce(net.tab_grad[name].view(-1), self.dist.ReduceOp.SUM, stream, "table:" + name)
+        # (a dense table travels with its neighbours in ONE all-reduce issued by _finish)
+
+    def _dense_table_runs(self):
+        """[(first name, element offset, element count)] of the runs of ADJACENT dense tables in tab_grad_flat."""
+        net = self.net
+        names = list(net.tab_grad)
+        runs, i = [], 0
+        while i < len(names):
+            if names[i] in self.last_sparse:
+                i += 1
+                continue
+            j = i
+            while j + 1 < len(names) and names[j + 1] not in self.last_sparse:
+                j += 1
+            g0 = net.tab_goff[names[i]]
+            g1 = net.tab_goff[names[j]] + net.tab_shape[names[j]][0] * net.tab_shape[names[j]][1]
+            runs.append((names[i:j + 1], g0, g1 - g0))
+            i = j + 1
+        return runs
 
     def _compact_local(self, name):
         net, W = self.net, self.world
@@ -349,10 +374,16 @@ class DataParallel(object):
         stream = ops.current_stream() if torch.cuda.is_available() else None
         if "flags" not in self._done:
             self.flags_ready(stream)
-        if "dense" not in self._done:
-            self.dense_ready(stream)
-        for name in net.tab_grad:
+        for name in net.tab_grad:          # sparse tables that never reported
             self.table_ready(stream, name)
+        for names, g0, n in self._dense_table_runs():
+            if not all(k in self._done for k in names):
+                self._done.update(names)
+                self._allreduce(net.tab_grad_flat[g0:g0 + n], dist.ReduceOp.SUM, stream, "tables:" + "+".join(names))
+        if "dense" not in self._done:
+            self._done.add("dense")
+            ds = self._dense_stream if "dense-final" in self._done else stream
+            self._allreduce(net.dense_grad, dist.ReduceOp.SUM, ds, "dense")
         self._allreduce(self.small, dist.ReduceOp.SUM, stream, "small")
         if not self.sync_bn:
             # keep the (non-trainable) moving statistics identical on every replica: their average

@@ -102,7 +102,9 @@ class CLSRNet(object):
         self._dw_async = False
         # A/B switch (see _att_qh); the bf16 speed mode keeps the whole query in the per-(row, step) GEMM (K is cheap there)
         self.split_query = not os.environ.get("CLSR_NO_SPLIT_QUERY") and self.precision != "bf16"
-        self.split_query_min = 64
+        # history-level half of the short-term query folded into U (see _att_qh): pays off at every width once the per-row
+        # half runs on the one-wave-per-history kernels (round 3; the position-tiled kernels needed Du >= 64)
+        self.split_query_min = int(os.environ.get("CLSR_SPLIT_QUERY_MIN", "16"))
         self.split_emb_grad = not os.environ.get("CLSR_SERIAL_EMB_GRAD")   # A/B switch (embedding gradient sites)
         self.use_plans = not os.environ.get("CLSR_NO_PLAN")                # replay recorded launch sequences
         self.split_g2 = not os.environ.get("CLSR_NO_SPLIT_G2")             # A/B switch (causal GRU off the main launch)
@@ -1015,8 +1017,16 @@ class CLSRNet(object):
             # U[h,t] += (a[h,t,:qh] * q_hist[h]) . Wp[:qh]   (in place: every tile reads its own U before storing)
             self._gemm(a, Q, key + ".Wp1", Hn * T, qh, A0, U, A0, T=T, G=1, Xmul=q_hist, ldmul=qh, addU=U, ldu=A0,
                        addV=self._buf("att.zeroV", Hn, A0), ldv=A0)
-            self._gemm(a[:, qh:], Q, key + ".Wp2", R * T, Q - qh, A0, z0, A0, T=T, G=G, Xmul=q[:, qh:], ldmul=Q,
-                       addU=U, ldu=A0, addV=V, ldv=A0, stats=st)
+            if self.l0_fwd_wave and query("clsr_att_l0_fwd_supported", G, Q - qh, A0):
+                # the per-row half (target columns of the query) on the one-wave-per-history kernel: K = Q - qh
+                parts = query("clsr_att_l0_fwd_stats_parts", Hn) if training else 0
+                st = (self._buf("stats" + self._ws_tag, 1024 * 2 * 256, dtype=torch.float64)[: parts * 2 * A0]
+                      if training else None)
+                Wt, Kp = self.packed[key + ".Wp2"]
+                call("clsr_att_l0_fwd", a[:, qh:], Q, q[:, qh:], Q, Wt, Kp, U, A0, V, A0, z0, A0, st, Hn, G, T, Q - qh, A0)
+            else:
+                self._gemm(a[:, qh:], Q, key + ".Wp2", R * T, Q - qh, A0, z0, A0, T=T, G=G, Xmul=q[:, qh:], ldmul=Q,
+                           addU=U, ldu=A0, addV=V, ldv=A0, stats=st)
         elif self.l0_fwd_wave and query("clsr_att_l0_fwd_supported", G, Q, A0):
             # one wave per history, a / U loaded once per group of rows (csrc/attl0fwd.hip)
             parts = query("clsr_att_l0_fwd_stats_parts", Hn) if training else 0
@@ -1133,14 +1143,22 @@ class CLSRNet(object):
             Q2 = Q - qh
             self._dw(a[:, qh:], Q, dz0, A0, R * T, Q2, A0, dW0[3 * Q + qh:4 * Q], A0, T=T, G=G, Xmul=q[:, qh:],
                      ldmul=Q)
-            daq = self._buf(key + ".daq2", R * T, Q2)
-            self._gemm(dz0, A0, key + ".Wp2^T", R * T, A0, Q2, daq, Q2)
             dU = self._buf(key + ".dU", Hn * T, A0)
-            call("clsr_att_z0_bwd_reduce", dz0, Hn, G, T, A0, dU, dV)
-            # dq = dV . Wv^T first (all Q columns), then the per-row product term is added to its target columns
-            self._gemm(dV, A0, key + ".Wv^T", R, A0, Q, dq, Q)
-            call("clsr_att_prod_bwd_ld", daq, Q2, a[:, qh:], Q, q[:, qh:], Q, Hn, G, T, Q2, da[:, qh:], Q,
-                 dq[:, qh:], Q, 1)
+            if self.fused_l0_bwd and query("clsr_att_l0_bwd_supported", G, Q2, A0):
+                # per-row half in one pass over dz0 (csrc/hattbwd.hip): da / dq of the target columns, dU, dV; then the V
+                # path over ALL query columns is added (dq[:, :qh] was cleared with the step's accumulators)
+                Wt, Kp = self.packed[key + ".Wp2^T"]
+                call("clsr_att_l0_bwd", dz0, A0, Wt, Kp, a[:, qh:], Q, q[:, qh:], Q, Hn, G, T, Q2, A0, da[:, qh:], Q,
+                     dq[:, qh:], Q, dU, A0, dV, A0)
+                self._gemm(dV, A0, key + ".Wv^T", R, A0, Q, dq, Q, acc=1)
+            else:
+                daq = self._buf(key + ".daq2", R * T, Q2)
+                self._gemm(dz0, A0, key + ".Wp2^T", R * T, A0, Q2, daq, Q2)
+                call("clsr_att_z0_bwd_reduce", dz0, Hn, G, T, A0, dU, dV)
+                # dq = dV . Wv^T first (all Q columns), then the per-row product term is added to its target columns
+                self._gemm(dV, A0, key + ".Wv^T", R, A0, Q, dq, Q)
+                call("clsr_att_prod_bwd_ld", daq, Q2, a[:, qh:], Q, q[:, qh:], Q, Hn, G, T, Q2, da[:, qh:], Q,
+                     dq[:, qh:], Q, 1)
             # history-level share of the product term: through dU = sum over the group's rows of dz0
             self._dw(a, Q, dU, A0, Hn * T, qh, A0, dW0[3 * Q:3 * Q + qh], A0, T=T, G=1, Xmul=q_hist, ldmul=qh)
             daq1 = self._buf(key + ".daq1", Hn * T, qh)
@@ -1651,6 +1669,11 @@ class CLSRNet(object):
             if "user_long" in self.tables:
                 zr.append((self.ucount.data_ptr(), 4))
                 self._ucount_zeroed = True
+            if self._att_qh("st") and G > 1:
+                # split short-term query: the history-level columns of d(query) only receive the V path (an
+                # accumulating product): cleared here with the other accumulators
+                dq_st = self._buf("st.dq", B, Du + D)
+                zr.append((dq_st.data_ptr(), dq_st.numel() * 4))
             ops.multi("clsr_zero_multi", ops.ZeroDesc, zr)
             # involved-row flags (tf.unique id sets)
             ops.multi("clsr_mark_rows_multi", ops.MarkDesc, [

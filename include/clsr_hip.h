@@ -462,6 +462,8 @@ int clsr_zero_floats(float* p, long n, void* stream);
 /* feed upload: device arena <- pinned host arena read by the kernel over PCIe (replaces the
    feed_dict host->device copies of session.run, base_model.py:345-357) */
 int clsr_stage_feed(void* dst, const void* src_host, long nbytes, void* stream);
+/* measurement probe (bench.py): device-to-device copy in 16-byte words, non-temporal, 4 loads in flight per lane */
+int clsr_copy_words(void* dst, const void* src, long nbytes, void* stream);
 
 /* ---- multi-launch forms of the small kernels: up to CLSR_MULTI_MAX independent jobs in ONE launch
  *      (blockIdx.y = job).  The descriptor array is read on the HOST and passed to the kernel by value, so these

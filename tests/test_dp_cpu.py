@@ -206,14 +206,16 @@ class _LogDist(object):
 
 def test_overlapped_exchange_bookkeeping_every_piece_exactly_once_and_waited_for():
     """Host logic of DataParallel: whatever subset of hooks a step fires (all of them, some, none -- a net without
-    hooks), every piece of gradient state is all-reduced exactly once, flags go before the first table, the 24
-    doubles go last, and the update runs only after every collective has been waited for."""
+    hooks), every piece of gradient state is all-reduced exactly once: the byte maps first, the adjacent dense gradient
+    tables as ONE collective, the dense gradients BEHIND the tables (collectives of a group run in issue order and the
+    dense gradients are final last), the 24 doubles last; the update runs only after every collective has been waited
+    for."""
     from clsr_amd.dp import DataParallel
 
     scripts = [
         [("flags_ready", ()), ("dense_ready", ()), ("table_ready", ("cate",)), ("table_ready", ("user_long",)),
          ("table_ready", ("user_short",)), ("table_ready", ("item",))],
-        [("dense_ready", ()), ("table_ready", ("cate",))],                    # flags never reported: forced before cate
+        [("dense_ready", ()), ("table_ready", ("cate",))],                    # flags never reported: forced before the tables
         [],                                                                   # a net without hooks
         [("table_ready", ("item",)), ("table_ready", ("item",))],             # a duplicate report is ignored
     ]
@@ -227,17 +229,22 @@ def test_overlapped_exchange_bookkeeping_every_piece_exactly_once_and_waited_for
         ptrs = [e[1] for e in ar]
         last = list(net.tab_shape)[-1]                      # (the byte maps travel without the last table's padding)
         expect = {net.dense_grad.data_ptr(): 100, net.stats24.data_ptr(): 24,
-                  net.tab_flags_flat.data_ptr(): net.tab_foff[last] + net.tab_shape[last][0]}
-        for k, (V, C) in net.tab_shape.items():
-            expect[net.tab_grad[k].data_ptr()] = V * C
+                  net.tab_flags_flat.data_ptr(): net.tab_foff[last] + net.tab_shape[last][0],
+                  net.tab_grad_flat.data_ptr(): net.tab_grad_flat.numel()}       # the four tables: one collective
         assert sorted(ptrs) == sorted(expect), script          # every piece exactly once (sync BN: no moving stats)
         assert all(expect[e[1]] == e[2] for e in ar)
-        first_table = min(i for i, e in enumerate(ar) if e[1] in {t.data_ptr() for t in net.tab_grad.values()})
-        assert ptrs.index(net.tab_flags_flat.data_ptr()) < first_table
-        assert ptrs[-1] == net.stats24.data_ptr()
+        assert ptrs == [net.tab_flags_flat.data_ptr(), net.tab_grad_flat.data_ptr(), net.dense_grad.data_ptr(),
+                        net.stats24.data_ptr()], script
         waits = [e for e in d.log if e[0] == "wait"]
         assert len(waits) == len(ar) and d.log.index(waits[0]) > d.log.index(ar[-1])
         assert net.updated == 1
+    # a sparse table in the middle splits the dense tables into two runs, each one collective
+    net, d = _StubNet(), _LogDist()
+    dp = DataParallel(net, d, sync_bn=True, sparse_tables="none")
+    dp.last_sparse = ["cate"]
+    runs = dp._dense_table_runs()
+    assert [r[0] for r in runs] == [["item"], ["user_long", "user_short"]]
+    assert runs[0][1:] == (0, 50 * 8) and runs[1][1:] == (net.tab_goff["user_long"], 2 * 20 * 8)
     # per-rank batch-norm: the moving statistics are averaged as well
     net, d = _StubNet(), _LogDist()
     net.bn_moving += 2.0
