@@ -1,0 +1,329 @@
+// Fused tail of the backward pass through the sequence encoders of the default CLSR graph (gfx950, fp32 MFMA):
+// ONE pass over dPin [Hn*T, 480] -- the gradients of the fused input projection that the backward-through-time launch
+// leaves behind -- produces
+//   * the seven weight gradients that contract it over the positions (reference: tf.gradients through GRUCell /
+//     Time4LSTMCell.call, rnn_cell_implement.py:129-298, clsr.py:160-237):
+//       hist^T . dPin                     [40, 480]  every input-side kernel + the bias sums of all encoders
+//       hprev1^T . dPin[:, 0:80]          [40, 80]   short_term_intention gates/kernel, hidden rows
+//       (hprev1 * r1)^T . dPin[:, 80:120] [40, 40]   short_term_intention candidate/kernel, hidden rows
+//       hprev2^T . dPin[:, 120:200], (hprev2 * r2)^T . dPin[:, 200:240]          causal2
+//       mprev^T . dPin[:, 240:400]        [40, 160]  time4lstm kernel, hidden rows
+//       TT^T . dPin[:, 360:480]           [80, 120]  the four time kernels (block matrix o | tns | tls)
+//     (column layout of net.py's fused input projection: GRU blocks first -- short_term_intention, causal2 -- then
+//      the Time4LSTM block  kernel | time_kernel_w1 | time_kernel_w2)
+//   * d(hist) += dPin . W_x^T             [Hn*T, 40]  (the product that back-propagates into the history rows).
+// Round 2 ran these as a multi-job weight-gradient launch (7 168 blocks; every job stages its own slices of dPin: the
+// 393 MB are read ~2.1 times, the 33 MB of hist six times) beside a ring-buffered GEMM that reads dPin a third time:
+// 618 us + 279 us in the step, the last thing the update phase waits for.  Here a workgroup stages 16 positions of
+// dPin and of the seven left operands in LDS once; its four waves own DISJOINT sets of 16-column tiles of dPin (no cross-wave
+// reduction of the weight gradients), balanced by MFMA count (51 / 54 / 55 / 51 accumulator tiles); the d(hist) product
+// reads the same tile (K split over the waves, one LDS exchange per stage).  Specialised to the default widths
+// (D = Du = H = 40, three encoders); anything else keeps the generic kernels (clsr_enc_bwd_fused_supported).
+#include "common.h"
+#include "clsr_hip.h"
+
+// diagnosis builds (scripts/build_variant.sh): -DEB_ABL_NOMFMA (no matrix instructions), -DEB_ABL_NODH (no d(hist)),
+// -DEB_ABL_NOFETCH (operands of the first stage only)
+#ifdef EB_ABL_NOMFMA
+#define EB_MFMA(acc, a, b) (acc)[0] += (a) * (b)
+#else
+#define EB_MFMA(acc, a, b) MFMA4(acc, a, b)
+#endif
+#define EB_NX 480                 // columns of dPin
+#define EB_PS 484                 // LDS row stride of the dPin tile (484 % 64 = 36: rows land on different banks)
+#define EB_XW 368                 // left-operand tile: hist@0 | hp1@48 | hp1*r1@96 | mprev@144 | TT@192 (80) | hp2@272 | hp2*r2@320
+#define EB_XS 372
+#define EB_NPT 30                 // 16-column tiles of dPin
+#define EB_NXT 23                 // 16-column tiles of the left-operand tile
+#define EB_CHUNK (5 * 5 * 256 + 5 * 16)   // partial layout of clsr_dw_reduce_batch (csrc/linear.hip: DW_CHUNK)
+
+struct EncBwdArgs {
+  const float* dPin;              // [M, 480]
+  const float* hist;              // [M, 40]
+  const float* hp1; const float* g1;    // [M, 40], [M, 120] (r | u | c)
+  const float* mprev;             // [M, 40]
+  const float* TT;                // [M, 80]
+  const float* hp2; const float* g2;
+  const float* Wt; int Kp;        // packed W_x^T (clsr_pack_batch): 40 out rows, K = 480
+  float* dhist;                   // [M, 40], accumulated into
+  float* ws[7];                   // partial workspaces of the seven products, gridDim.x partial slots per chunk
+  long M;
+};
+
+// product p: rows = left-operand tile columns [x0, x0 + K), columns = dPin columns [c0, c0 + N)
+__device__ __host__ constexpr int eb_x0(int p) { return p == 0 ? 0 : p == 1 ? 48 : p == 2 ? 96 : p == 3 ? 144 : p == 4 ? 192 : p == 5 ? 272 : 320; }
+__device__ __host__ constexpr int eb_K(int p) { return p == 4 ? 80 : 40; }
+__device__ __host__ constexpr int eb_c0(int p) { return p == 0 ? 0 : p == 1 ? 0 : p == 2 ? 80 : p == 3 ? 240 : p == 4 ? 360 : p == 5 ? 120 : 200; }
+__device__ __host__ constexpr int eb_N(int p) { return p == 0 ? 480 : p == 1 ? 80 : p == 2 ? 40 : p == 3 ? 160 : p == 4 ? 120 : p == 5 ? 80 : 40; }
+// product that left-operand tile xt belongs to
+__device__ __host__ constexpr int eb_prod(int xt) { return xt < 3 ? 0 : xt < 6 ? 1 : xt < 9 ? 2 : xt < 12 ? 3 : xt < 17 ? 4 : xt < 20 ? 5 : 6; }
+// does (left tile xt, dPin tile pt) hold a wanted block?  (a tile that straddles a product's column range counts)
+__device__ __host__ constexpr bool eb_need(int xt, int pt) {
+  const int p = eb_prod(xt);
+  return 16 * pt + 16 > eb_c0(p) && 16 * pt < eb_c0(p) + eb_N(p);
+}
+// dPin tiles of wave w (weights: 6 accumulator tiles for most, 9 where two GRU products meet, 11 / 8 under the time
+// kernels): 51 / 54 / 55 / 51 accumulator tiles
+__device__ __host__ constexpr int eb_nt(int w) { return w == 0 ? 6 : 8; }
+__device__ __host__ constexpr int eb_tile(int w, int pi) {
+  constexpr int t[4][8] = {{22, 23, 24, 0, 1, 2, 0, 0}, {25, 26, 27, 3, 4, 5, 6, 8}, {28, 29, 7, 9, 10, 11, 13, 14},
+                           {12, 15, 16, 17, 18, 19, 20, 21}};
+  return t[w][pi];
+}
+__device__ __host__ constexpr int eb_count(int w) {
+  int n = 0;
+  for (int pi = 0; pi < eb_nt(w); ++pi)
+    for (int xt = 0; xt < EB_NXT; ++xt) n += eb_need(xt, eb_tile(w, pi)) ? 1 : 0;
+  return n;
+}
+__device__ __host__ constexpr bool eb_xused(int w, int xt) {
+  for (int pi = 0; pi < eb_nt(w); ++pi)
+    if (eb_need(xt, eb_tile(w, pi))) return true;
+  return false;
+}
+
+template <int W>
+__device__ __forceinline__ void eb_wave(const EncBwdArgs& a, float* Ps, float* Xs, const float* Wl, float* Dx,
+                                        f32x4 (&acc)[eb_count(W)], float (&bsum)[8], const int lane) {
+  constexpr int NP = eb_nt(W);
+  const int i = lane & 15, g = lane >> 4;
+  // ---- weight gradients: contraction over the 16 positions of the stage, 4 per MFMA
+#pragma unroll 1      // (unrolled, the operands of all four steps are read up front: +60 VGPRs and spills)
+  for (int s = 0; s < 4; ++s) {
+    float av[EB_NXT], bv[NP];
+#pragma unroll
+    for (int xt = 0; xt < EB_NXT; ++xt)
+      if (eb_xused(W, xt)) av[xt] = Xs[(4 * s + g) * EB_XS + 16 * xt + i];
+#pragma unroll
+    for (int pi = 0; pi < NP; ++pi) bv[pi] = Ps[(4 * s + g) * EB_PS + 16 * eb_tile(W, pi) + i];
+    int n = 0;
+#pragma unroll
+    for (int pi = 0; pi < NP; ++pi) {
+#pragma unroll
+      for (int xt = 0; xt < EB_NXT; ++xt)
+        if (eb_need(xt, eb_tile(W, pi))) { EB_MFMA(acc[n], av[xt], bv[pi]); ++n; }
+      bsum[pi] += bv[pi];
+    }
+  }
+#ifdef EB_ABL_NODH
+  return;
+#endif
+  // ---- d(hist)[16 pos, 40] partial over this wave's columns of dPin: D[16 features][16 positions]
+  f32x4 dh[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  // (an offset the compiler cannot see through, fresh every stage: the weight reads are loop invariant and would
+  //  otherwise be hoisted out of the stage loop into ~96 VGPRs -- an opaque POINTER would lose its LDS address space)
+  int woff = 0;
+  asm volatile("" : "+v"(woff));
+  const float* Wv = Wl + woff;
+#pragma unroll
+  for (int pi = 0; pi < NP; ++pi) {
+    const int kk = eb_tile(W, pi);
+    const f32x4 b = ld4(Ps + i * EB_PS + 16 * kk + 4 * g);          // lane (j = i, g): position j, columns 16 kk + 4 g ..
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const f32x4 w = ld4(Wv + (long)(16 * t + i) * a.Kp + 16 * kk + 4 * g);
+      EB_MFMA(dh[t], w.x, b.x); EB_MFMA(dh[t], w.y, b.y); EB_MFMA(dh[t], w.z, b.z); EB_MFMA(dh[t], w.w, b.w);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t) st4(Dx + ((W * 16 + i) * 48) + 16 * t + 4 * g, dh[t]);      // [wave][position][48]
+}
+
+// scatter one wave's accumulator tiles into the partial workspaces (layout of dw_body / clsr_dw_reduce_batch)
+template <int W>
+__device__ __forceinline__ void eb_store(const EncBwdArgs& a, const f32x4 (&acc)[eb_count(W)], const float (&bsum)[8],
+                                         const int lane, const int part, const int nparts) {
+  const int i = lane & 15, g = lane >> 4;
+  int n = 0;
+#pragma unroll
+  for (int pi = 0; pi < eb_nt(W); ++pi) {
+    const int pt = eb_tile(W, pi);
+#pragma unroll
+    for (int xt = 0; xt < EB_NXT; ++xt) {
+      if (!eb_need(xt, pt)) continue;
+      const int p = eb_prod(xt);
+      const int nl = 16 * pt + i - eb_c0(p);                       // column inside the product
+      const int kb = 16 * xt - eb_x0(p) + 4 * g;                   // first of the lane's four rows
+      if (nl >= 0 && nl < eb_N(p)) {
+        const int nc = nl / 80, nn = nl - nc * 80;
+        float* dst = a.ws[p] + ((long)nc * nparts + part) * EB_CHUNK + (nn >> 4) * 256 + (nn & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = kb + r;                                    // (one K chunk: K <= 80)
+          if (k < eb_K(p)) dst[((k >> 4) * 5) * 256 + (k & 15) * 16] = acc[n][r];
+        }
+      }
+      ++n;
+    }
+    // bias sums ride in the partial of the hist product: db[column] = sum over the positions
+    const float b = col4_sum(bsum[pi]);
+    if (g == 0) {
+      const int nl = 16 * pt + i, nc = nl / 80, nn = nl - nc * 80;
+      a.ws[0][((long)nc * nparts + part) * EB_CHUNK + 5 * 5 * 256 + nn] = b;
+    }
+  }
+}
+
+// Buffer resource over rows [row0, row0 + rows) of a row-major fp32 tensor: lanes whose byte offset falls outside read
+// zeros / have their store dropped, so the ragged last stage and the idle lanes of a staging pattern need no branches,
+// and the per-stage address arithmetic is scalar (the per-lane offsets are loop invariant).
+typedef __amdgpu_buffer_rsrc_t eb_rsrc_t;
+#define EB_OOB 0x80000000u
+__device__ __forceinline__ eb_rsrc_t eb_rsrc(const float* p, long row0, int rows, int stride) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p + row0 * stride), 0, (unsigned)(rows * stride * 4), 0x00020000);
+}
+__device__ __forceinline__ f32x4 eb_ld(eb_rsrc_t r, unsigned voff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+
+template <int W>
+__device__ __forceinline__ void eb_body(const EncBwdArgs& a, float* lds) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  float* Wl = lds;                                  // [48][Kp] packed W_x^T (rows >= 40: zero)
+  float* Ps = Wl + 48 * a.Kp;                       // [16][EB_PS]
+  float* Xs = Ps + 16 * EB_PS;                      // [16][EB_XS]
+  float* Dx = Xs + 16 * EB_XS;                      // [4 waves][16 positions][48]
+  const int lane = threadIdx.x & 63, tid = W * 64 + lane;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  {
+    const int Kq = a.Kp >> 2;
+    for (int e = tid; e < 48 * Kq; e += 256) {
+      const int row = e / Kq, c = e - row * Kq;
+      reinterpret_cast<f32x4*>(Wl)[e] = row < 40 ? ld4(a.Wt + (long)row * a.Kp + 4 * c) : z4;
+    }
+    for (int e = tid; e < 16 * EB_XS; e += 256) Xs[e] = 0.f;      // (padding columns of the left tile stay zero)
+  }
+  // Staging pattern of a thread: position row = tid / 16 of the stage, piece c = tid % 16 of that row --
+  //   dPin:  float4 c + 15 j (j = 0..7) of the row's 120, lanes c < 15;   every 40-wide operand: float4 c, lanes c < 10
+  // (byte offsets computed once; the stage's first row goes into the scalar buffer base)
+  const int row = tid >> 4, c = tid & 15;
+  const unsigned vP = c < 15 ? (unsigned)(row * EB_NX * 4 + c * 16) : EB_OOB;
+  const unsigned v40 = c < 10 ? (unsigned)(row * 160 + c * 16) : EB_OOB;
+  const unsigned v80 = c < 10 ? (unsigned)(row * 320 + c * 16) : EB_OOB;
+  const unsigned v120 = c < 10 ? (unsigned)(row * 480 + c * 16) : EB_OOB;
+  float* const pP = Ps + row * EB_PS + 4 * c;
+  float* const pX = Xs + row * EB_XS + 4 * c;
+  f32x4 pr[8], xh, x1, xm, xt0, xt1, x2, xr1, xr2, dr = z4;     // dr: the thread's float4 of the d(hist) rows of the stage
+  const long nst = (a.M + 15) >> 4;
+  auto fetch = [&](long st) {
+    const long m0 = st * 16;
+    const int rows = (int)min(16L, a.M - m0);
+    const eb_rsrc_t rP = eb_rsrc(a.dPin, m0, rows, EB_NX);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pr[j] = eb_ld(rP, vP + 240u * j);
+    xh = eb_ld(eb_rsrc(a.hist, m0, rows, 40), v40);
+    x1 = eb_ld(eb_rsrc(a.hp1, m0, rows, 40), v40);
+    xr1 = eb_ld(eb_rsrc(a.g1, m0, rows, 120), v120);
+    xm = eb_ld(eb_rsrc(a.mprev, m0, rows, 40), v40);
+    const eb_rsrc_t rT = eb_rsrc(a.TT, m0, rows, 80);
+    xt0 = eb_ld(rT, v80);
+    xt1 = eb_ld(rT, v80 + 160u);
+    x2 = eb_ld(eb_rsrc(a.hp2, m0, rows, 40), v40);
+    xr2 = eb_ld(eb_rsrc(a.g2, m0, rows, 120), v120);
+    dr = eb_ld(eb_rsrc(a.dhist, m0, rows, 40), v40);
+  };
+  auto stage = [&]() {     // (rows past the end of the batch were read as zeros)
+    if (c < 15) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) st4(pP + 60 * j, pr[j]);
+    }
+    if (c < 10) {
+      st4(pX, xh); st4(pX + 48, x1); st4(pX + 96, x1 * xr1); st4(pX + 144, xm);
+      st4(pX + 192, xt0); st4(pX + 232, xt1); st4(pX + 272, x2); st4(pX + 320, x2 * xr2);
+    }
+  };
+
+  constexpr int NA = eb_count(W);
+  f32x4 acc[NA];
+#pragma unroll
+  for (int n = 0; n < NA; ++n) acc[n] = z4;
+  float bsum[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) bsum[q] = 0.f;
+
+  long st = blockIdx.x;
+  if (st < nst) fetch(st);
+  f32x4 dprev = z4;                  // d(hist) rows of the PREVIOUS stage, stored one stage late (see below)
+  long st_prev = -1;
+  auto store_prev = [&]() {
+    if (st_prev >= 0)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dprev),
+                                             eb_rsrc(a.dhist, st_prev * 16, (int)min(16L, a.M - st_prev * 16), 40), v40, 0, 0);
+  };
+  for (; st < nst; st += gridDim.x) {
+    __syncthreads();                 // the previous stage's tiles / exchange area are free
+    stage();
+    const f32x4 dcur = dr;           // (fetched one stage ahead, like the operands)
+    __syncthreads();
+#ifdef EB_ABL_NOFETCH
+    if (st == blockIdx.x)
+#endif
+    if (st + gridDim.x < nst) fetch(st + gridDim.x);      // next stage's operands fly behind the MFMAs below
+    // the previous stage's d(hist) rows leave HERE, behind the loads: a store issued at the end of a stage would be
+    // the youngest memory operation when the next stage waits for its operands (one counter for loads and stores)
+    store_prev();
+    eb_wave<W>(a, Ps, Xs, Wl, Dx, acc, bsum, lane);
+#ifndef EB_ABL_NODH
+    __syncthreads();
+    // d(hist)[m0 + row, :] += sum of the four waves' partials: 16 rows x 10 float4
+    if (c < 10) {
+      const float* dx = Dx + row * 48 + 4 * c;
+      dprev = dcur + (ld4(dx) + ld4(dx + 16 * 48)) + (ld4(dx + 2 * 16 * 48) + ld4(dx + 3 * 16 * 48));
+    }
+    st_prev = st;
+#endif
+  }
+  store_prev();
+  const int part = blockIdx.x, nparts = gridDim.x;
+  eb_store<W>(a, acc, bsum, lane, part, nparts);
+}
+
+
+// every wave runs its own instance of the body: same staging code, its own column range and accumulators
+__global__ void __launch_bounds__(256) enc_bwd_fused_kernel(EncBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave == 0) eb_body<0>(a, lds);
+  else if (wave == 1) eb_body<1>(a, lds);
+  else if (wave == 2) eb_body<2>(a, lds);
+  else eb_body<3>(a, lds);
+}
+
+static_assert(eb_count(0) + eb_count(1) + eb_count(2) + eb_count(3) == 211, "every wanted block has an owner");
+static_assert(eb_count(0) <= 56 && eb_count(1) <= 56 && eb_count(2) <= 56 && eb_count(3) <= 56, "accumulator budget");
+
+static int eb_grid(long M) {
+  long st = (M + 15) / 16;
+  return (int)(st < 256 ? st : 256);
+}
+
+// partial slots per chunk that the launch fills in every workspace (== its grid size)
+extern "C" int clsr_enc_bwd_fused_parts(long M) { return eb_grid(M); }
+// floats of workspace of product p (0 hist | 1 hp1 | 2 hp1*r1 | 3 mprev | 4 TT | 5 hp2 | 6 hp2*r2)
+extern "C" long clsr_enc_bwd_fused_workspace_floats(long M, int p) {
+  if (p < 0 || p > 6) return 0;
+  return (long)clsr_cdiv(eb_N(p), 80) * eb_grid(M) * EB_CHUNK;
+}
+// 1 when the default-graph widths apply: D = n = 40, NX = 480 with the column layout of the header comment
+extern "C" int clsr_enc_bwd_fused_supported(int D, int n, int NX) { return D == 40 && n == 40 && NX == EB_NX; }
+
+extern "C" int clsr_enc_bwd_fused(const float* dPin, const float* hist, const float* hprev1, const float* gates1,
+                                  const float* mprev, const float* TT, const float* hprev2, const float* gates2,
+                                  const float* Wt, int Kp, float* dhist, float* ws_hist, float* ws_hp1, float* ws_hp1r,
+                                  float* ws_mprev, float* ws_tt, float* ws_hp2, float* ws_hp2r, long M, void* stream) {
+  CLSR_CHECK_ARG(dPin && hist && hprev1 && gates1 && mprev && TT && hprev2 && gates2 && Wt && dhist && M > 0);
+  CLSR_CHECK_ARG(ws_hist && ws_hp1 && ws_hp1r && ws_mprev && ws_tt && ws_hp2 && ws_hp2r);
+  CLSR_CHECK_ARG(Kp >= EB_NX && Kp % 4 == 0);
+  CLSR_CHECK_SUPPORTED(((uintptr_t)dPin % 16) == 0 && ((uintptr_t)hist % 16) == 0 && ((uintptr_t)dhist % 16) == 0 &&
+                       ((uintptr_t)Wt % 16) == 0);
+  EncBwdArgs a = {};
+  a.dPin = dPin; a.hist = hist; a.hp1 = hprev1; a.g1 = gates1; a.mprev = mprev; a.TT = TT; a.hp2 = hprev2; a.g2 = gates2;
+  a.Wt = Wt; a.Kp = Kp; a.dhist = dhist; a.M = M;
+  a.ws[0] = ws_hist; a.ws[1] = ws_hp1; a.ws[2] = ws_hp1r; a.ws[3] = ws_mprev; a.ws[4] = ws_tt; a.ws[5] = ws_hp2; a.ws[6] = ws_hp2r;
+  const size_t shmem = ((size_t)48 * Kp + 16 * EB_PS + 16 * EB_XS + 4 * 16 * 48) * sizeof(float);
+  CLSR_CHECK_SUPPORTED(shmem <= 160 * 1024);
+  CLSR_HIP(hipFuncSetAttribute((const void*)enc_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL(enc_bwd_fused_kernel, dim3(eb_grid(M)), dim3(256), shmem, (hipStream_t)stream, a);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}

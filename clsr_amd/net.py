@@ -125,6 +125,7 @@ class CLSRNet(object):
         # k + 1 (forward) and the weight gradients / d(hist) products of range k - 1 (backward) run beside the T-serial
         # recurrence of range k instead of before / after all of it (see _rnn_chunks_for); 1: one launch per pass.
         # Exact mode of the CLSR graph only so far (the bf16 weight-gradient kernels have no time-range form)
+        self.enc_bwd_fused = not os.environ.get("CLSR_NO_ENC_BWD_FUSED")   # A/B: one pass over dPin for the seven encoder-side weight gradients + d(hist) (csrc/encbwd.hip)
         self.rnn_chunks = int(os.environ.get("CLSR_RNN_CHUNKS", "1"))   # measured at configs[1]: 4.17-4.21 ms with 5 ranges, 4.11 with 3, against 3.91 with one launch (the projections throttle the chain, ~30 us start-up + ~15 us cross-stream signalling per range) -- kept as a switch
         self.l0_fwd_wave = not os.environ.get("CLSR_NO_L0_FWD_WAVE")      # A/B switch (exact mode, see _att_fwd)
         self.fused_l0_wu = not os.environ.get("CLSR_NO_FUSED_L0_WU")   # A/B: dU . Wu^T inside that kernel as well (time-neutral, two launches fewer)
@@ -218,7 +219,7 @@ class CLSRNet(object):
         return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook),
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
                 self.lazy, self.rnn_first, self.lt_att_first, self.tick_early, self.hist_grad_two, self.dw_batch_late, self.bn_bwd_fused, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h, self.flush_side, self.l1_bwd_2pass,
-                self.split_g2, self.rnn_chunks, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
+                self.split_g2, self.rnn_chunks, self.enc_bwd_fused, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
 
@@ -1391,6 +1392,58 @@ class CLSRNet(object):
                 ops.rnn_multi("clsr_rnn_fwd_multi", [d], None, seq_len, ls, Hn, T)
         return short_int, rnn_out, fs, att_long
 
+    def _enc_bwd_fused_ok(self, dpin_h):
+        """The default graph at the default widths: short_term_intention GRU + Time4LSTM + causal GRU, D = Du = H = 40,
+        fp32 dPin with the column layout csrc/encbwd.hip is written for."""
+        hp = self.hp
+        return (self.enc_bwd_fused and not dpin_h and not self.bf16 and type(self) is CLSRNet and self.defer_dw
+                and self._t4_kind == "time4lstm" and bool(hp.interest_evolve)
+                and (not hp.manual_alpha) and bool(hp.predict_long_short) and self.enc_in == self.D
+                and self.D == self.Du == self.H and bool(query("clsr_enc_bwd_fused_supported", self.D, self.H, self.NX))
+                and self._enc_off("g1") == 0 and self._enc_off("g2") == 3 * self.H and self._enc_off("t4") == 6 * self.H)
+
+    def _enc_bwd_fused(self, f, hist, dPinAll, dhist, Hn, T, hs):
+        """Seven encoder-side weight gradients + d(hist) from ONE pass over dPin (csrc/encbwd.hip) on the compute stream;
+        the time-feature chain (d TT, its tanh backward and parameter sums) runs beside it on the weight-gradient stream."""
+        Gd, D, H, NX, E = self.Gd, self.D, self.H, self.NX, self.enc_in
+        M = Hn * T
+        st, t = CL + "short_term/", self._t4_scope
+        g1, g2 = st + "short_term_intention/gru_cell/", CL + "causal2/causal2/gru_cell/"
+        parts = query("clsr_enc_bwd_fused_parts", M)
+        prods = [(self._buf("xw.dW", D, NX), NX, self._buf("xw.db", NX), D, NX),
+                 (Gd[g1 + "gates/kernel"][E:], 2 * H, None, H, 2 * H), (Gd[g1 + "candidate/kernel"][E:], H, None, H, H),
+                 (Gd[t + "kernel"][E:], 4 * H, None, H, 4 * H), (self._buf("t4.dTW", 2 * H, 3 * H), 3 * H, None, 2 * H, 3 * H),
+                 (Gd[g2 + "gates/kernel"][E:], 2 * H, None, H, 2 * H), (Gd[g2 + "candidate/kernel"][E:], H, None, H, H)]
+        pend = self._dw_pending.setdefault("", [])
+        wss = []
+        for i, (dW, ldw, db, K, N) in enumerate(prods):
+            ws = self._buf("encb.ws%d" % i, query("clsr_enc_bwd_fused_workspace_floats", M, i))
+            wss.append(ws)
+            pend.append((ws.data_ptr(), dW.data_ptr(), db.data_ptr() if db is not None else 0, 1.0, parts, K, N, ldw, 0))
+        # d TT = dPin[:, o | tns | tls] . tw^T FIRST, on the compute stream (~35 us alone; beside the fused kernel, whose
+        # workgroups fill every CU's LDS, it found no room and took 500 us); its tanh backward + parameter sums then
+        # run beside the fused kernel on the weight-gradient stream, which the dense reduction follows in stream order
+        dPt = dPinAll[:, self._enc_off("t4"):]
+        dTT = self._buf("t4.dTT", M, 2 * H)
+        TT = self._buf("t4.TT", M, 2 * H)
+        self._gemm(dPt[:, 3 * H:], NX, "t4.tw^T", M, 3 * H, 2 * H, dTT, 2 * H)
+        fork = self._fork_point()
+        Wt, Kp = self.packed["xw^T"]
+        call("clsr_enc_bwd_fused", dPinAll, hist, self._buf("g1.hprev", Hn, T, H), self._buf("g1.gates", Hn, T, 3 * H),
+             self._buf("t4.mprev", Hn, T, H), TT, self._buf("g2.hprev", Hn, T, H), self._buf("g2.gates", Hn, T, 3 * H),
+             Wt, Kp, dhist, *wss, M)
+        parts_t = query("clsr_t4_time_inputs_bwd_parts", Hn, T, H)
+        tp = self._buf("t4.tpart", 512 * 4 * 128)[: parts_t * 4 * H]
+        with self._branch("@dw0" if (self.dw_stream and self.overlap) else "@main", after=fork, name="@ttb"):
+            tag, self._ws_tag = self._ws_tag, ""      # (its reductions belong to the main flush)
+            try:
+                call("clsr_t4_time_inputs_bwd", dTT, TT, f["time_to_now"], f["time_from_first_action"], hs * T, Hn, T, H, tp)
+                for off_, nm in ((0, "_time_input_w1"), (H, "_time_input_w2"), (2 * H, "_time_input_bias1"),
+                                 (3 * H, "_time_input_bias2")):
+                    self._rp(tp[off_:], parts_t, 4 * H, H, Gd[t + nm])
+            finally:
+                self._ws_tag = tag
+
     def _encoders_bwd_chunked(self, f, chunks, hist, dhist, drnn, dsi, dfs, Hn, T, seq_len, ls, hs):
         """Backward-through-time as a chain of launches over ``chunks`` (descending); behind every range its weight
         gradients (ONE multi-job launch on @dw0) and its d(hist) / time-feature products (@aux) start at once.
@@ -1785,23 +1838,29 @@ class CLSRNet(object):
                     self._dw_flush()
             if not self.rnn_first:
                 ops.rnn_multi("clsr_rnn_bwd_multi", grus, t4d, seq_len, ls, Hn, T)
-            # input-side weights of every encoder in one reduction; d(hist) in one product; the hidden-side / time-feature
-            # weight gradients ride in the same multi-job launch as the input-side one (they all depend on dPin only)
-            with self._dw_batched():
-                self._dw(hist, D, dPinAll, NX, M, D, NX, self._buf("xw.dW", D, NX), NX, db=self._buf("xw.db", NX),
-                         dy_bf16=int(dpin_h))
-                self._gemm(dPinAll, NX, "xw^T", M, NX, D, dhist, D, acc=1)
-                if self._t4_kind is not None:
-                    self._t4_bwd_weights(f, dPinAll, Hn, T, hs)
-                else:
-                    self._gru_bwd_hidden("gs", st + "simple_gru/gru_cell/", H, dPinAll, Hn, T)
-                if hp.interest_evolve:
-                    self._gru_bwd_hidden("g1", st + "short_term_intention/gru_cell/", Du, dPinAll, Hn, T)
-                if (not hp.manual_alpha) and hp.predict_long_short:
-                    self._gru_bwd_hidden("g2", CL + "causal2/causal2/gru_cell/", H, dPinAll, Hn, T)
-        # ---- join the long-term attention branch; its d(hist) contribution was accumulated separately
-        self._join()
-        if self.flush_side and self.overlap and self.dw_stream:
+            if self._enc_bwd_fused_ok(dpin_h):
+                self._enc_bwd_fused(f, hist, dPinAll, dhist, Hn, T, hs)
+            else:
+              # input-side weights of every encoder in one reduction; d(hist) in one product; the hidden-side / time-feature
+              # weight gradients ride in the same multi-job launch as the input-side one (they all depend on dPin only)
+              with self._dw_batched():
+                  self._dw(hist, D, dPinAll, NX, M, D, NX, self._buf("xw.dW", D, NX), NX, db=self._buf("xw.db", NX),
+                           dy_bf16=int(dpin_h))
+                  self._gemm(dPinAll, NX, "xw^T", M, NX, D, dhist, D, acc=1)
+                  if self._t4_kind is not None:
+                      self._t4_bwd_weights(f, dPinAll, Hn, T, hs)
+                  else:
+                      self._gru_bwd_hidden("gs", st + "simple_gru/gru_cell/", H, dPinAll, Hn, T)
+                  if hp.interest_evolve:
+                      self._gru_bwd_hidden("g1", st + "short_term_intention/gru_cell/", Du, dPinAll, Hn, T)
+                  if (not hp.manual_alpha) and hp.predict_long_short:
+                      self._gru_bwd_hidden("g2", CL + "causal2/causal2/gru_cell/", H, dPinAll, Hn, T)
+        # ---- join the long-term attention branch; its d(hist) contribution was accumulated separately (the time-feature
+        #      chain of the fused encoder backward sits on the weight-gradient stream: the dense branch below follows it
+        #      in stream order, the compute stream has no business waiting for it)
+        side_dense = self.flush_side and self.overlap and self.dw_stream
+        self._join(but="@ttb" if side_dense else None)
+        if side_dense:
             # the dense path from here on (batched reduction of every weight gradient, unpacking, later the dense
             # regulariser + Adam) does not meet the embedding path (gradient tables, table regulariser / Adam) again:
             # it stays on the weight-gradient stream, where the last partial-sum kernel has just finished, and the main

@@ -1422,3 +1422,40 @@ def test_one_wave_per_encoder_recurrences_equal_the_split_kernels(Hn, T, n, monk
         close(A[k], B[k].double(), rtol=2e-5, atol=2e-6, name=k)
     close(A["dPin"], B["dPin"].double(), rtol=1e-4, atol=1e-5, name="dPin")
     assert float(A["dPin"].abs().max()) > 0 and float(A["out"].abs().max()) > 0
+
+
+@pytest.mark.parametrize("M", [16 * 300, 16 * 257 + 5, 37])
+def test_fused_encoder_backward_one_pass_over_dpin(M):
+    """clsr_enc_bwd_fused (csrc/encbwd.hip): the seven encoder-side weight gradients (+ bias sums) and d(hist) from one
+    pass over dPin == float64 products of the same operands, through the same partial layout + clsr_dw_reduce_batch
+    that the step uses."""
+    g = torch.Generator().manual_seed(M)
+    f = lambda t: dev(t, torch.float32)
+    n = 40
+    dPin, hist = f(rnd(g, M, 480)), f(rnd(g, M, n))
+    hp1, hp2, mp, TT = f(rnd(g, M, n)), f(rnd(g, M, n)), f(rnd(g, M, n)), f(torch.tanh(rnd(g, M, 2 * n)))
+    g1, g2 = f(torch.rand(M, 3 * n, generator=g, dtype=torch.float64)), f(torch.rand(M, 3 * n, generator=g, dtype=torch.float64))
+    Wx = rnd(g, n, 480) * 0.2                     # [in = hist feature, out = projection column]
+    Wt, Kp = ops.pack_weight(f(Wx), n, 480, transposed=True)      # rows = hist features, K = 480
+    dhist0 = f(rnd(g, M, n))
+    dhist = dhist0.clone()
+    parts = query("clsr_enc_bwd_fused_parts", M)
+    shapes = [(n, 480), (n, 80), (n, 40), (n, 160), (2 * n, 120), (n, 80), (n, 40)]
+    wss = [torch.full((query("clsr_enc_bwd_fused_workspace_floats", M, i),), 9.0, device="cuda") for i in range(7)]
+    outs = [torch.zeros(K, N, device="cuda") for K, N in shapes]
+    db = torch.zeros(480, device="cuda")
+    call("clsr_enc_bwd_fused", dPin, hist, hp1, g1, mp, TT, hp2, g2, Wt, Kp, dhist, *wss, M)
+    sig = tuple((ws.data_ptr(), o.data_ptr(), db.data_ptr() if i == 0 else 0, 1.0, parts, K, N, N, 0)
+                for i, (ws, o, (K, N)) in enumerate(zip(wss, outs, shapes)))
+    tab = ops.dw_table(sig, torch.device("cuda"))
+    call("clsr_dw_reduce_batch", tab[0], tab[1], tab[2])
+    torch.cuda.synchronize()
+    d = lambda t: t.double().cpu()
+    P = d(dPin)
+    exp = [d(hist).T @ P, d(hp1).T @ P[:, 0:80], (d(hp1) * d(g1)[:, :n]).T @ P[:, 80:120], d(mp).T @ P[:, 240:400],
+           d(TT).T @ P[:, 360:480], d(hp2).T @ P[:, 120:200], (d(hp2) * d(g2)[:, :n]).T @ P[:, 200:240]]
+    tol = 2e-5 * math.sqrt(M)
+    for i, (o, e) in enumerate(zip(outs, exp)):
+        close(o, e, rtol=2e-4, atol=tol, name="product %d" % i)
+    close(db, P.sum(0), rtol=2e-4, atol=tol, name="bias sums")
+    close(dhist, d(dhist0) + P @ Wx.T, rtol=2e-4, atol=2e-4, name="d(hist)")
