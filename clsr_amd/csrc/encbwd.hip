@@ -32,7 +32,9 @@
 #define EB_NX 480                 // columns of dPin
 #define EB_PS 484                 // LDS row stride of the dPin tile (484 % 64 = 36: rows land on different banks)
 #define EB_XW 368                 // left-operand tile: hist@0 | hp1@48 | hp1*r1@96 | mprev@144 | TT@192 (80) | hp2@272 | hp2*r2@320
-#define EB_XS 372
+#define EB_XS 400                // (400 % 64 = 16: the four position rows of a b32 read land on different banks)
+#define EB_WS 484                 // LDS row stride of W_x^T (like EB_PS: 16 rows x float4 without bank conflicts)
+#define EB_DS 52                  // row stride of the d(hist) exchange area
 #define EB_NPT 30                 // 16-column tiles of dPin
 #define EB_NXT 23                 // 16-column tiles of the left-operand tile
 #define EB_CHUNK (5 * 5 * 256 + 5 * 16)   // partial layout of clsr_dw_reduce_batch (csrc/linear.hip: DW_CHUNK)
@@ -70,6 +72,9 @@ __device__ __host__ constexpr int eb_tile(int w, int pi) {
                            {12, 15, 16, 17, 18, 19, 20, 21}};
   return t[w][pi];
 }
+// K split of the d(hist) product (12 MFMAs per tile): 8 / 7 / 7 / 8 tiles, so that every wave issues 300-304 MFMAs a stage
+__device__ __host__ constexpr int eb_dnt(int w) { return (w == 0 || w == 3) ? 8 : 7; }
+__device__ __host__ constexpr int eb_dtile(int w, int k) { return (w == 0 ? 0 : w == 1 ? 8 : w == 2 ? 15 : 22) + k; }
 __device__ __host__ constexpr int eb_count(int w) {
   int n = 0;
   for (int pi = 0; pi < eb_nt(w); ++pi)
@@ -87,15 +92,20 @@ __device__ __forceinline__ void eb_wave(const EncBwdArgs& a, float* Ps, float* X
                                         f32x4 (&acc)[eb_count(W)], float (&bsum)[8], const int lane) {
   constexpr int NP = eb_nt(W);
   const int i = lane & 15, g = lane >> 4;
-  // ---- weight gradients: contraction over the 16 positions of the stage, 4 per MFMA
-#pragma unroll 1      // (unrolled, the operands of all four steps are read up front: +60 VGPRs and spills)
-  for (int s = 0; s < 4; ++s) {
-    float av[EB_NXT], bv[NP];
+  // ---- weight gradients: contraction over the 16 positions of the stage, 4 per MFMA.  Software pipeline by hand: the
+  //      operands of step s + 1 are read from LDS BEFORE the MFMAs of step s issue (one wave per SIMD: nobody else hides
+  //      the LDS latency; fully unrolled, the compiler reads all four steps up front and spills)
+  float avA[EB_NXT], bvA[NP], avB[EB_NXT], bvB[NP];
+  auto load = [&](float (&av)[EB_NXT], float (&bv)[NP], const int s) {
+    const float* xs = Xs + (4 * s + g) * EB_XS + i;
+    const float* ps = Ps + (4 * s + g) * EB_PS + i;
 #pragma unroll
     for (int xt = 0; xt < EB_NXT; ++xt)
-      if (eb_xused(W, xt)) av[xt] = Xs[(4 * s + g) * EB_XS + 16 * xt + i];
+      if (eb_xused(W, xt)) av[xt] = xs[16 * xt];
 #pragma unroll
-    for (int pi = 0; pi < NP; ++pi) bv[pi] = Ps[(4 * s + g) * EB_PS + 16 * eb_tile(W, pi) + i];
+    for (int pi = 0; pi < NP; ++pi) bv[pi] = ps[16 * eb_tile(W, pi)];
+  };
+  auto mfmas = [&](const float (&av)[EB_NXT], const float (&bv)[NP]) {
     int n = 0;
 #pragma unroll
     for (int pi = 0; pi < NP; ++pi) {
@@ -104,29 +114,60 @@ __device__ __forceinline__ void eb_wave(const EncBwdArgs& a, float* Ps, float* X
         if (eb_need(xt, eb_tile(W, pi))) { EB_MFMA(acc[n], av[xt], bv[pi]); ++n; }
       bsum[pi] += bv[pi];
     }
-  }
-#ifdef EB_ABL_NODH
-  return;
-#endif
-  // ---- d(hist)[16 pos, 40] partial over this wave's columns of dPin: D[16 features][16 positions]
-  f32x4 dh[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  };
+  // d(hist) operands of dPin tile kk: lane (j = i, g) holds position j, columns 16 kk + 4 g .. + 3
   // (an offset the compiler cannot see through, fresh every stage: the weight reads are loop invariant and would
   //  otherwise be hoisted out of the stage loop into ~96 VGPRs -- an opaque POINTER would lose its LDS address space)
   int woff = 0;
   asm volatile("" : "+v"(woff));
-  const float* Wv = Wl + woff;
+  const float* Wv = Wl + woff + i * EB_WS + 4 * g;
+  const float* Pv = Ps + i * EB_PS + 4 * g;
+  struct DhOp { f32x4 b, w[3]; };
+  auto dload = [&](DhOp& o, const int k) {
+    const int kk = eb_dtile(W, k);
+    o.b = ld4(Pv + 16 * kk);
 #pragma unroll
-  for (int pi = 0; pi < NP; ++pi) {
-    const int kk = eb_tile(W, pi);
-    const f32x4 b = ld4(Ps + i * EB_PS + 16 * kk + 4 * g);          // lane (j = i, g): position j, columns 16 kk + 4 g ..
+    for (int t = 0; t < 3; ++t) o.w[t] = ld4(Wv + 16 * t * EB_WS + 16 * kk);
+  };
+  load(avA, bvA, 0);
+#pragma unroll 1
+  for (int s = 0; s < 4; s += 2) {
+    load(avB, bvB, s + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(avA, bvA);
+    __builtin_amdgcn_sched_barrier(0);
+    load(avA, bvA, s == 0 ? 2 : 3);          // (second trip: a harmless re-read, keeps the loop body branch free)
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(avB, bvB);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#ifdef EB_ABL_NODH
+  return;
+#endif
+  // ---- d(hist)[16 pos, 40] partial over this wave's K range of dPin columns: D[16 features][16 positions]; the same
+  //      hand pipeline, and the three accumulators take turns (a dependent MFMA would wait 8 cycles for its input)
+  f32x4 dh[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  DhOp oA, oB;
+  auto dmfma = [&](const DhOp& o) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const f32x4 w = ld4(Wv + (long)(16 * t + i) * a.Kp + 16 * kk + 4 * g);
-      EB_MFMA(dh[t], w.x, b.x); EB_MFMA(dh[t], w.y, b.y); EB_MFMA(dh[t], w.z, b.z); EB_MFMA(dh[t], w.w, b.w);
-    }
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) EB_MFMA(dh[t], o.w[t][r], o.b[r]);
+  };
+  dload(oA, 0);
+#pragma unroll
+  for (int k = 0; k < eb_dnt(W); k += 2) {
+    if (k + 1 < eb_dnt(W)) dload(oB, k + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    dmfma(oA);
+    __builtin_amdgcn_sched_barrier(0);
+    if (k + 2 < eb_dnt(W)) dload(oA, k + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (k + 1 < eb_dnt(W)) dmfma(oB);
+    __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
-  for (int t = 0; t < 3; ++t) st4(Dx + ((W * 16 + i) * 48) + 16 * t + 4 * g, dh[t]);      // [wave][position][48]
+  for (int t = 0; t < 3; ++t) st4(Dx + ((W * 16 + i) * EB_DS) + 16 * t + 4 * g, dh[t]);   // [wave][position][EB_DS]
 }
 
 // scatter one wave's accumulator tiles into the partial workspaces (layout of dw_body / clsr_dw_reduce_batch)
@@ -179,17 +220,16 @@ __device__ __forceinline__ f32x4 eb_ld(eb_rsrc_t r, unsigned voff) {
 template <int W>
 __device__ __forceinline__ void eb_body(const EncBwdArgs& a, float* lds) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  float* Wl = lds;                                  // [48][Kp] packed W_x^T (rows >= 40: zero)
-  float* Ps = Wl + 48 * a.Kp;                       // [16][EB_PS]
+  float* Wl = lds;                                  // [48][EB_WS] packed W_x^T (rows >= 40: zero)
+  float* Ps = Wl + 48 * EB_WS;                       // [16][EB_PS]
   float* Xs = Ps + 16 * EB_PS;                      // [16][EB_XS]
-  float* Dx = Xs + 16 * EB_XS;                      // [4 waves][16 positions][48]
+  float* Dx = Xs + 16 * EB_XS;                      // [4 waves][16 positions][EB_DS]
   const int lane = threadIdx.x & 63, tid = W * 64 + lane;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   {
-    const int Kq = a.Kp >> 2;
-    for (int e = tid; e < 48 * Kq; e += 256) {
-      const int row = e / Kq, c = e - row * Kq;
-      reinterpret_cast<f32x4*>(Wl)[e] = row < 40 ? ld4(a.Wt + (long)row * a.Kp + 4 * c) : z4;
+    for (int e = tid; e < 48 * (EB_WS / 4); e += 256) {
+      const int row = e / (EB_WS / 4), c = e - row * (EB_WS / 4);
+      st4(Wl + row * EB_WS + 4 * c, (row < 40 && c < EB_NX / 4) ? ld4(a.Wt + (long)row * a.Kp + 4 * c) : z4);
     }
     for (int e = tid; e < 16 * EB_XS; e += 256) Xs[e] = 0.f;      // (padding columns of the left tile stay zero)
   }
@@ -267,8 +307,8 @@ __device__ __forceinline__ void eb_body(const EncBwdArgs& a, float* lds) {
     __syncthreads();
     // d(hist)[m0 + row, :] += sum of the four waves' partials: 16 rows x 10 float4
     if (c < 10) {
-      const float* dx = Dx + row * 48 + 4 * c;
-      dprev = dcur + (ld4(dx) + ld4(dx + 16 * 48)) + (ld4(dx + 2 * 16 * 48) + ld4(dx + 3 * 16 * 48));
+      const float* dx = Dx + row * EB_DS + 4 * c;
+      dprev = dcur + (ld4(dx) + ld4(dx + 16 * EB_DS)) + (ld4(dx + 2 * 16 * EB_DS) + ld4(dx + 3 * 16 * EB_DS));
     }
     st_prev = st;
 #endif
@@ -320,7 +360,7 @@ extern "C" int clsr_enc_bwd_fused(const float* dPin, const float* hist, const fl
   a.dPin = dPin; a.hist = hist; a.hp1 = hprev1; a.g1 = gates1; a.mprev = mprev; a.TT = TT; a.hp2 = hprev2; a.g2 = gates2;
   a.Wt = Wt; a.Kp = Kp; a.dhist = dhist; a.M = M;
   a.ws[0] = ws_hist; a.ws[1] = ws_hp1; a.ws[2] = ws_hp1r; a.ws[3] = ws_mprev; a.ws[4] = ws_tt; a.ws[5] = ws_hp2; a.ws[6] = ws_hp2r;
-  const size_t shmem = ((size_t)48 * Kp + 16 * EB_PS + 16 * EB_XS + 4 * 16 * 48) * sizeof(float);
+  const size_t shmem = ((size_t)48 * EB_WS + 16 * EB_PS + 16 * EB_XS + 4 * 16 * EB_DS) * sizeof(float);
   CLSR_CHECK_SUPPORTED(shmem <= 160 * 1024);
   CLSR_HIP(hipFuncSetAttribute((const void*)enc_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   hipLaunchKernelGGL(enc_bwd_fused_kernel, dim3(eb_grid(M)), dim3(256), shmem, (hipStream_t)stream, a);

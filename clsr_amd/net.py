@@ -125,6 +125,7 @@ class CLSRNet(object):
         # k + 1 (forward) and the weight gradients / d(hist) products of range k - 1 (backward) run beside the T-serial
         # recurrence of range k instead of before / after all of it (see _rnn_chunks_for); 1: one launch per pass.
         # Exact mode of the CLSR graph only so far (the bf16 weight-gradient kernels have no time-range form)
+        self.early_scatter = not os.environ.get("CLSR_NO_EARLY_SCATTER")   # A/B: row scatters of the user / target lookups beside the encoder-backward tail instead of behind it
         self.enc_bwd_fused = not os.environ.get("CLSR_NO_ENC_BWD_FUSED")   # A/B: one pass over dPin for the seven encoder-side weight gradients + d(hist) (csrc/encbwd.hip)
         self.rnn_chunks = int(os.environ.get("CLSR_RNN_CHUNKS", "1"))   # measured at configs[1]: 4.17-4.21 ms with 5 ranges, 4.11 with 3, against 3.91 with one launch (the projections throttle the chain, ~30 us start-up + ~15 us cross-stream signalling per range) -- kept as a switch
         self.l0_fwd_wave = not os.environ.get("CLSR_NO_L0_FWD_WAVE")      # A/B switch (exact mode, see _att_fwd)
@@ -219,7 +220,7 @@ class CLSRNet(object):
         return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook),
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
                 self.lazy, self.rnn_first, self.lt_att_first, self.tick_early, self.hist_grad_two, self.dw_batch_late, self.bn_bwd_fused, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h, self.flush_side, self.l1_bwd_2pass,
-                self.split_g2, self.rnn_chunks, self.enc_bwd_fused, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
+                self.split_g2, self.rnn_chunks, self.enc_bwd_fused, self.early_scatter, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
 
@@ -454,16 +455,19 @@ class CLSRNet(object):
             return None
         return ops.event_record(ops.current_stream())
 
-    def _join(self, only=None, but=None):
-        """The current stream waits for the finished branches (all of them, those named ``only``, or all ``but`` one)."""
+    def _join(self, only=None, but=None, keep=False):
+        """The current stream waits for the finished branches (all of them, those named ``only``, or all ``but`` one).
+        ``keep``: the branches stay on the list -- another stream will join them again."""
         main = ops.current_stream()
-        keep = []
+        rest = []
         for tag, ev in self._joins:
             if (only is None or tag == only) and tag != but:
                 ops.stream_wait(main, ev)
+                if keep:
+                    rest.append((tag, ev))
             else:
-                keep.append((tag, ev))
-        self._joins = keep
+                rest.append((tag, ev))
+        self._joins = rest
 
     # ------------------------------------------------------------------ buffers
     def _buf(self, name, *shape, dtype=F32):
@@ -1443,6 +1447,7 @@ class CLSRNet(object):
                     self._rp(tp[off_:], parts_t, 4 * H, H, Gd[t + nm])
             finally:
                 self._ws_tag = tag
+        return fork
 
     def _encoders_bwd_chunked(self, f, chunks, hist, dhist, drnn, dsi, dfs, Hn, T, seq_len, ls, hs):
         """Backward-through-time as a chain of launches over ``chunks`` (descending); behind every range its weight
@@ -1798,6 +1803,7 @@ class CLSRNet(object):
         NX = self.NX
         hist = out["hist_input"]
         chunks = self._rnn_chunks_for(T)
+        scat_early = False
         if chunks is not None:
             if dul is None:
                 with self._branch("@lt", after=self._fork_point()):
@@ -1838,6 +1844,15 @@ class CLSRNet(object):
                     self._dw_flush()
             if not self.rnn_first:
                 ops.rnn_multi("clsr_rnn_bwd_multi", grus, t4d, seq_len, ls, Hn, T)
+            # the row scatters of the user / target-item / target-category lookups need nothing from the encoder tail
+            # below: they go to the side streams early instead of queueing behind it -- long-term user rows and target
+            # rows UNDER the backward-through-time launch (latency bound, leaves issue slots; beside the MFMA-saturated
+            # fused tail they ran 4x slower and the history-row sums waited for them), the short-term user rows (final
+            # only now) beside the small d TT product
+            scat_early = self.early_scatter and self.sorted_hist_grad and self.split_emb_grad and self.overlap
+            if scat_early:
+                self._scatter_rows_early(f, dul, None, dtarget, Hn, B, hs, fork)
+                self._scatter_rows_early(f, None, dushort, None, Hn, B, hs, self._fork_point())
             if self._enc_bwd_fused_ok(dpin_h):
                 self._enc_bwd_fused(f, hist, dPinAll, dhist, Hn, T, hs)
             else:
@@ -1884,17 +1899,12 @@ class CLSRNet(object):
             fork = self._fork_point()
             with self._branch("@lt" if self.split_emb_grad else "@main", after=fork):
                 self._hist_grad_sorted(dhist, dM, dR, Hn, T, seq_len, ls, ss, only="cate", dhist2=dhist_lt)
-                call("clsr_scatter_add_rows", dtarget, D, Di, f["cates"], 1, B, Dc, self.tab_grad["cate"], ss[3:])
+                if not scat_early:
+                    call("clsr_scatter_add_rows", dtarget, D, Di, f["cates"], 1, B, Dc, self.tab_grad["cate"], ss[3:])
                 self._dp_hook("table_ready", "cate")
-            with self._branch("@aux" if self.split_emb_grad else "@main", after=fork):
-                # user rows (long / short table) and the target items' rows: ONE launch, blockIdx.y = lookup site
-                tg, dp_ = self.tab_grad, lambda t: t.data_ptr()
-                ops.multi("clsr_scatter_add_rows_multi", ops.ScatterDesc, [
-                    (dp_(dul), dp_(f["users"]), dp_(tg["user_long"]), dp_(ss[6:]), hs, Du, 0, Hn, Du),
-                    (dp_(dushort), dp_(f["users"]), dp_(tg["user_short"]), dp_(ss[7:]), hs, Du, 0, Hn, Du),
-                    (dp_(dtarget), dp_(f["items"]), dp_(tg["item"]), dp_(ss[2:]), 1, D, 0, B, Di)])
-                self._dp_hook("table_ready", "user_long")
-                self._dp_hook("table_ready", "user_short")
+            if not scat_early:
+                with self._branch("@aux" if self.split_emb_grad else "@main", after=fork):
+                    self._scatter_user_item_rows(f, dul, dushort, dtarget, Hn, B, hs)
             self._hist_grad_sorted(dhist, dM, dR, Hn, T, seq_len, ls, ss, only="item", dhist2=dhist_lt)
             self._join(but="@dense")
             self._dp_hook("table_ready", "item")
@@ -1944,6 +1954,37 @@ class CLSRNet(object):
             rows.append((f[fkey].data_ptr(), keys.data_ptr(), perm.data_ptr(), counts[o:].data_ptr(), Hn, hs * T, T, b))
             o += 1 << b
         ops.sort_ids_multi(rows)
+
+    def _scatter_user_item_rows(self, f, dul, dushort, dtarget, Hn, B, hs):
+        """User rows (long / short table) and the target items' rows: ONE launch, blockIdx.y = lookup site (``None``:
+        that site is not part of this launch)."""
+        tg, ss, dp_ = self.tab_grad, self.sumsq_tab, lambda t: t.data_ptr()
+        D, Du, Di = self.D, self.Du, self.Di
+        sites = []
+        if dul is not None:
+            sites.append((dp_(dul), dp_(f["users"]), dp_(tg["user_long"]), dp_(ss[6:]), hs, Du, 0, Hn, Du))
+        if dushort is not None:
+            sites.append((dp_(dushort), dp_(f["users"]), dp_(tg["user_short"]), dp_(ss[7:]), hs, Du, 0, Hn, Du))
+        if dtarget is not None:
+            sites.append((dp_(dtarget), dp_(f["items"]), dp_(tg["item"]), dp_(ss[2:]), 1, D, 0, B, Di))
+        ops.multi("clsr_scatter_add_rows_multi", ops.ScatterDesc, sites)
+        if dul is not None:
+            self._dp_hook("table_ready", "user_long")
+        if dushort is not None:
+            self._dp_hook("table_ready", "user_short")
+
+    def _scatter_rows_early(self, f, dul, dushort, dtarget, Hn, B, hs, fork):
+        """Scatters that do not read d(hist), on the side streams behind ``fork`` (an event of the compute stream).  The
+        long-term user gradient is final on @lt, which the user launch joins and the category launch follows in stream
+        order."""
+        with self._branch("@aux", after=fork, name="@scat"):
+            if dul is not None:
+                self._join(only="@lt", keep=True)
+            self._scatter_user_item_rows(f, dul, dushort, dtarget, Hn, B, hs)
+        if dtarget is not None:
+            with self._branch("@lt", after=fork, name="@scat"):
+                call("clsr_scatter_add_rows", dtarget, self.D, self.Di, f["cates"], 1, B, self.Dc, self.tab_grad["cate"],
+                     self.sumsq_tab[3:])
 
     def _hist_grad_sorted(self, dhist, dM, dR, Hn, T, seq_len, ls, ss, only=None, dhist2=None):
         """IndexedSlices of the history lookups -> dense gradient tables via segmented sums over the
