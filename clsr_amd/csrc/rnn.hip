@@ -130,6 +130,35 @@ __device__ __forceinline__ void st_dpin(float* base, long off, f32x4 v, int h) {
   else st4(base + off, v);
 }
 
+// The same store WITHOUT a branch around it (backward-through-time loops): a raw buffer store whose per-lane byte offset
+// is out of range for the lanes that must not write.  A store under `if (ok)` makes the number of outstanding memory
+// operations unknown at the top of the next step; the compiler then drains the queue (s_waitcnt vmcnt(0)) before the
+// first use of the operands PREFETCHED for that step -- and waits for the stores' acknowledgements every step.
+// rs: resource over the block's 16 histories (base advanced per block: element offsets stay far below 2^31).
+typedef __amdgpu_buffer_rsrc_t rnn_rsrc_t;
+__device__ __forceinline__ rnn_rsrc_t rnn_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x80000000u, 0x00020000);
+}
+// resource over the 16 histories of block bx of an optional [Hn, T, row] tensor (null: every store is dropped)
+__device__ __forceinline__ rnn_rsrc_t rnn_rsrc_blk(const float* p, int bx, int T, int row) {
+  return __builtin_amdgcn_make_buffer_rsrc(p ? const_cast<float*>(p + (long)bx * 16 * T * row) : nullptr, 0,
+                                           p ? 0x80000000u : 0u, 0x00020000);
+}
+__device__ __forceinline__ void st4_b(rnn_rsrc_t rs, bool ok, unsigned off, f32x4 v) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, ok ? off * 4u : 0x80000000u, 0, 0);
+}
+__device__ __forceinline__ void st_dpin_b(rnn_rsrc_t rs, bool ok, unsigned off, f32x4 v, int h) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  if (h) {
+    const rnn_bf16x4 hv = __builtin_convertvector(v, rnn_bf16x4);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), rs, ok ? off * 2u : 0x80000000u, 0, 0);
+  } else {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, ok ? off * 4u : 0x80000000u, 0, 0);
+  }
+}
+
 // xb: LDS exchange area of the workgroup (f32x4 units): fwd uses [0, 2*RNT*64), bwd [0, 3*RNT*64)
 // ATT: the attentional-update-gate variant (own kernels below, so the plain GRU's code and registers are untouched)
 template <int RNT, bool ATT = false>
@@ -178,6 +207,8 @@ __device__ __forceinline__ void gru_fwd_body(const GruArgs& a, const int bx, f32
   float an = ATT ? attp[t0] : 0.f;
   f32x4* bufA = xb;
   f32x4* bufB = xb + RNT * 64;
+  const rnn_rsrc_t rhp = rnn_rsrc_blk(a.hprev, bx, T, n), rga = rnn_rsrc_blk(a.gates, bx, T, 3 * n);
+  const rnn_rsrc_t ros = rnn_rsrc_blk(a.out_seq, bx, T, n);
   for (int t = t0; t < tend; ++t) {
     const bool live = t < len;
     f32x4 accr = pn[0], accu = pn[1], accc = pn[2];
@@ -198,14 +229,12 @@ __device__ __forceinline__ void gru_fwd_body(const GruArgs& a, const int bx, f32
     const f32x4 c = tanh4(accc);
     const f32x4 ue = u * keep;
     const f32x4 hn = ue * hown + (1.0f - ue) * c;
-    if (live && cval) {
-      const long pos = h * T + t;
-      if (a.hprev) st4(a.hprev + pos * n + col, hown);
-      if (a.gates) {
-        float* gp = a.gates + pos * 3 * n + col;
-        st4(gp, r); st4(gp + n, u); st4(gp + 2 * n, c);
-      }
-      if (a.out_seq) st4(a.out_seq + pos * n + col, hn);
+    {  // branch-free stores (see st_dpin_b): the prefetched projections are waited for with an exact count
+      const bool ok = live && cval;
+      const unsigned pos = (unsigned)(j * T + t);
+      st4_b(rhp, ok, pos * n + col, hown);
+      st4_b(rga, ok, pos * 3 * n + col, r); st4_b(rga, ok, pos * 3 * n + n + col, u); st4_b(rga, ok, pos * 3 * n + 2 * n + col, c);
+      st4_b(ros, ok, pos * n + col, hn);
     }
     hown = sel4(live, hn, hown);
     xchg(bufB, w, lane, hown, cmp, hs);
@@ -248,19 +277,39 @@ __device__ __forceinline__ void gru_bwd_body(const GruArgs& a, const int bx, f32
   f32x4* bufA = xb;
   f32x4* bufR = xb + RNT * 64;
   f32x4* bufU = xb + 2 * RNT * 64;
-  for (int t = min(Tmax, a.t1) - 1; t >= a.t0; --t) {
+  // Saved activations of step t are fetched ONE STEP AHEAD (unconditional loads at clamped, always-valid addresses,
+  // masks applied at use); with them at the top of the step every step waited out an HBM round trip (SQ counters of the
+  // round-2 kernel: half of all wave cycles parked in s_waitcnt, profiles/r03_rnn_pmc.md)
+  const long hc = hvalid ? h : 0;
+  const int colc = cval ? col : 0;
+  const float* gbase = a.gates + hc * T * 3 * n + colc;
+  const float* hbase = a.hprev + hc * T * n + colc;
+  const float* dsbase = (a.dout_seq ? a.dout_seq : a.hprev) + hc * T * n + colc;   // (no dout_seq: loaded, not used)
+  const bool has_ds = a.dout_seq != nullptr;
+  const rnn_rsrc_t rdp = rnn_rsrc(a.dPin + (a.dpin_bf16 ? (long)bx * 16 * T * a.lddp / 2 : (long)bx * 16 * T * a.lddp));
+  struct In { f32x4 r, u, c, hp, ds; float at; };
+  auto fetch = [&](int t) {
+    t = max(t, 0);
+    In v;
+    const float* gp = gbase + (long)t * 3 * n;
+    v.r = ld4(gp); v.u = ld4(gp + n); v.c = ld4(gp + 2 * n);
+    v.hp = ld4(hbase + (long)t * n);
+    v.ds = ld4(dsbase + (long)t * n);
+    v.at = ATT ? attp[t] : 0.f;
+    return v;
+  };
+  const int tstart = min(Tmax, a.t1) - 1;
+  In cur = fetch(tstart);
+  for (int t = tstart; t >= a.t0; --t) {
+    const In nxt = fetch(t - 1);
     const bool live = t < len;
     const bool ok = live && cval;
-    const long pos = h * T + t;
-    const long posc = (hvalid ? h : 0) * T + t;   // always-valid addresses: unconditional loads, see gru_fwd_body
-    const int colc = cval ? col : 0;
-    const float* gp = a.gates + posc * 3 * n + colc;
-    const f32x4 r = sel4(ok, ld4(gp), Z4), u = sel4(ok, ld4(gp + n), Z4), c = sel4(ok, ld4(gp + 2 * n), Z4);
-    const f32x4 hp = sel4(ok, ld4(a.hprev + posc * n + colc), Z4);
+    const f32x4 r = sel4(ok, cur.r, Z4), u = sel4(ok, cur.u, Z4), c = sel4(ok, cur.c, Z4);
+    const f32x4 hp = sel4(ok, cur.hp, Z4);
     f32x4 d = dh;
-    if (a.dout_seq) d += ld4(a.dout_seq + posc * n + colc);
+    if (has_ds) d += cur.ds;
     d = sel4(ok, d, Z4);
-    const float keep = ATT ? 1.0f - attp[t] : 1.0f;
+    const float keep = ATT ? 1.0f - cur.at : 1.0f;
     const f32x4 ue = u * keep;                       // effective update gate (u itself is what was saved)
     const f32x4 due = d * (hp - c);
     const f32x4 du = due * keep;
@@ -284,11 +333,13 @@ __device__ __forceinline__ void gru_bwd_body(const GruArgs& a, const int bx, f32
     mv1(dhn, wu, full, cmp);
     collect<RNT>(bufR, lane, cmp, full);
     mv1(dhn, wr, full, cmp);
-    if (ok) {
-      const long dp = pos * a.lddp + col;
-      st_dpin(a.dPin, dp, drp, a.dpin_bf16); st_dpin(a.dPin, dp + n, dup, a.dpin_bf16); st_dpin(a.dPin, dp + 2 * n, dcp, a.dpin_bf16);
+    {
+      const unsigned dp = (unsigned)((j * T + t) * a.lddp + col);
+      st_dpin_b(rdp, ok, dp, drp, a.dpin_bf16); st_dpin_b(rdp, ok, dp + n, dup, a.dpin_bf16);
+      st_dpin_b(rdp, ok, dp + 2 * n, dcp, a.dpin_bf16);
     }
     dh = sel4(live, dhn, dh);
+    cur = nxt;
   }
   if (a.dh0 && cval) st4(a.dh0 + h * n + col, dh);
 }
@@ -402,6 +453,8 @@ __device__ __forceinline__ void t4lstm_fwd_body(const T4Args& a, const int bx, f
   f32x4 pn[6];
 #pragma unroll
   for (int gb = 0; gb < 6; ++gb) pn[gb] = sel4(cval && t0 < len, ld4(pin + (long)t0 * a.ldp + gb * n), Z4);
+  const rnn_rsrc_t ros = rnn_rsrc_blk(a.out_seq, bx, T, n), rac = rnn_rsrc_blk(a.act, bx, T, 6 * n);
+  const rnn_rsrc_t rcs = rnn_rsrc_blk(a.act ? a.cst : nullptr, bx, T, n), rmp = rnn_rsrc_blk(a.act ? a.mprev : nullptr, bx, T, n);
   for (int t = t0; t < tend; ++t) {
     const bool live = t < len;
     f32x4 acc[4];
@@ -430,16 +483,15 @@ __device__ __forceinline__ void t4lstm_fwd_body(const T4Args& a, const int bx, f
     const f32x4 og = sig4(acc[3]), tn = sig4(tns), tlg = sig4(tls);
     const f32x4 cn = fg * tlg * cs + ig * tn * jg;
     const f32x4 mn = og * tanh4(cn);
-    if (live && cval) {
-      const long pos = h * T + t;
-      st4(a.out_seq + pos * n + col, mn);
-      if (a.act) {
-        float* ap = a.act + pos * 6 * n + col;
-        st4(ap, ig); st4(ap + n, jg); st4(ap + 2 * n, fg); st4(ap + 3 * n, og);
-        st4(ap + 4 * n, tn); st4(ap + 5 * n, tlg);
-        st4(a.cst + pos * n + col, cn);
-        st4(a.mprev + pos * n + col, mown);
-      }
+    {  // branch-free stores (see st_dpin_b); scoring: the three training-only tensors are null resources
+      const bool ok = live && cval;
+      const unsigned pos = (unsigned)(j * T + t);
+      st4_b(ros, ok, pos * n + col, mn);
+      const unsigned ap = pos * 6 * n + col;
+      st4_b(rac, ok, ap, ig); st4_b(rac, ok, ap + n, jg); st4_b(rac, ok, ap + 2 * n, fg); st4_b(rac, ok, ap + 3 * n, og);
+      st4_b(rac, ok, ap + 4 * n, tn); st4_b(rac, ok, ap + 5 * n, tlg);
+      st4_b(rcs, ok, pos * n + col, cn);
+      st4_b(rmp, ok, pos * n + col, mown);
     }
     cs = sel4(live, cn, cs);
     mown = sel4(live, mn, mown);
@@ -476,19 +528,40 @@ __device__ __forceinline__ void t4lstm_bwd_body(const T4Args& a, const int bx, f
 #pragma unroll
       for (int gb = 0; gb < 6; ++gb) st_dpin(a.dPin, dp + gb * n, Z4, a.dpin_bf16);
     }
-  for (int t = min(Tmax, a.t1) - 1; t >= a.t0; --t) {
+  // saved activations one step ahead + branch-free dPin stores: see gru_bwd_body
+  const long hc = hvalid ? h : 0;
+  const int colc = cval ? col : 0;
+  const float* abase = a.act + hc * T * 6 * n + colc;
+  const float* cbase = a.cst + hc * T * n + colc;
+  const float* dsbase = a.dout_seq + hc * T * n + colc;
+  const rnn_rsrc_t rdp = rnn_rsrc(a.dPin + (a.dpin_bf16 ? (long)bx * 16 * T * a.lddp / 2 : (long)bx * 16 * T * a.lddp));
+  struct In { f32x4 ig, jg, fg, og, tn, tlg, cn, cp, ds; };
+  auto fetch = [&](int t) {
+    t = max(t, 0);
+    In v;
+    const float* ap = abase + (long)t * 6 * n;
+    v.ig = ld4(ap); v.jg = ld4(ap + n); v.fg = ld4(ap + 2 * n); v.og = ld4(ap + 3 * n); v.tn = ld4(ap + 4 * n);
+    v.tlg = ld4(ap + 5 * n);
+    v.cn = ld4(cbase + (long)t * n);
+    v.cp = ld4(cbase + (long)max(t - 1, 0) * n);
+    v.ds = ld4(dsbase + (long)t * n);
+    return v;
+  };
+  // (128-wide layers: 32 weight tiles per wave leave no room for a second operand set -- the look-ahead spilled)
+  constexpr bool PF = RNT <= 4;
+  const int tstart = min(Tmax, a.t1) - 1;
+  In cur = fetch(tstart), nxt = cur;
+  for (int t = tstart; t >= a.t0; --t) {
+    if (PF) nxt = fetch(t - 1);
+    else cur = fetch(t);
     const bool live = t < len;
     const bool ok = live && cval;
-    const long pos = h * T + t;
-    const long posc = (hvalid ? h : 0) * T + t;   // always-valid addresses: unconditional loads, see gru_fwd_body
-    const int colc = cval ? col : 0;
-    const float* ap = a.act + posc * 6 * n + colc;
-    const f32x4 ig = sel4(ok, ld4(ap), Z4), jg = sel4(ok, ld4(ap + n), Z4), fg = sel4(ok, ld4(ap + 2 * n), Z4);
-    const f32x4 og = sel4(ok, ld4(ap + 3 * n), Z4), tn = sel4(ok, ld4(ap + 4 * n), Z4);
-    const f32x4 tlg = sel4(ok, ld4(ap + 5 * n), Z4);
-    const f32x4 cn = sel4(ok, ld4(a.cst + posc * n + colc), Z4);
-    const f32x4 cp = sel4(ok && t > 0, ld4(a.cst + (posc - (t > 0 ? 1 : 0)) * n + colc), Z4);
-    f32x4 d = dm + ld4(a.dout_seq + posc * n + colc);
+    const f32x4 ig = sel4(ok, cur.ig, Z4), jg = sel4(ok, cur.jg, Z4), fg = sel4(ok, cur.fg, Z4);
+    const f32x4 og = sel4(ok, cur.og, Z4), tn = sel4(ok, cur.tn, Z4);
+    const f32x4 tlg = sel4(ok, cur.tlg, Z4);
+    const f32x4 cn = sel4(ok, cur.cn, Z4);
+    const f32x4 cp = sel4(ok && t > 0, cur.cp, Z4);
+    f32x4 d = dm + cur.ds;
     d = sel4(ok, d, Z4);
     const f32x4 tc = tanh4(cn);
     const f32x4 dcc = sel4(ok, dc + d * og * (1.0f - tc * tc), Z4);
@@ -500,11 +573,11 @@ __device__ __forceinline__ void t4lstm_bwd_body(const T4Args& a, const int bx, f
     const f32x4 dtn = dcc * ig * jg * tn * (1.0f - tn);        // d tns_pre
     const f32x4 dtl = dcc * fg * cp * tlg * (1.0f - tlg);      // d tls_pre
     const f32x4 dcn = dcc * fg * tlg;
-    if (ok) {
-      const long dp = pos * a.lddp + col;
-      st_dpin(a.dPin, dp, dg[0], a.dpin_bf16); st_dpin(a.dPin, dp + n, dg[1], a.dpin_bf16);
-      st_dpin(a.dPin, dp + 2 * n, dg[2], a.dpin_bf16); st_dpin(a.dPin, dp + 3 * n, dg[3], a.dpin_bf16);
-      st_dpin(a.dPin, dp + 4 * n, dtn, a.dpin_bf16); st_dpin(a.dPin, dp + 5 * n, dtl, a.dpin_bf16);
+    {
+      const unsigned dp = (unsigned)((j * T + t) * a.lddp + col);
+      st_dpin_b(rdp, ok, dp, dg[0], a.dpin_bf16); st_dpin_b(rdp, ok, dp + n, dg[1], a.dpin_bf16);
+      st_dpin_b(rdp, ok, dp + 2 * n, dg[2], a.dpin_bf16); st_dpin_b(rdp, ok, dp + 3 * n, dg[3], a.dpin_bf16);
+      st_dpin_b(rdp, ok, dp + 4 * n, dtn, a.dpin_bf16); st_dpin_b(rdp, ok, dp + 5 * n, dtl, a.dpin_bf16);
     }
     // publish the four gate-gradient tiles (double buffered by step parity), one barrier, then
     // d m_prev[own tile] = sum over gates and k-tiles
@@ -524,6 +597,7 @@ __device__ __forceinline__ void t4lstm_bwd_body(const T4Args& a, const int bx, f
     const f32x4 dmn = dma + dmb;
     dc = sel4(live, dcn, dc);
     dm = sel4(live, dmn, dm);
+    if (PF) cur = nxt;
   }
   if (cval && a.dst_out) { st4(a.dst_out + h * 2 * n + col, dc); st4(a.dst_out + h * 2 * n + n + col, dm); }
 }

@@ -460,8 +460,9 @@ class CLSRNet(object):
         ``keep``: the branches stay on the list -- another stream will join them again."""
         main = ops.current_stream()
         rest = []
+        but = but if isinstance(but, tuple) else (but,)
         for tag, ev in self._joins:
-            if (only is None or tag == only) and tag != but:
+            if (only is None or tag == only) and tag not in but:
                 ops.stream_wait(main, ev)
                 if keep:
                     rest.append((tag, ev))
@@ -1874,7 +1875,9 @@ class CLSRNet(object):
         #      chain of the fused encoder backward sits on the weight-gradient stream: the dense branch below follows it
         #      in stream order, the compute stream has no business waiting for it)
         side_dense = self.flush_side and self.overlap and self.dw_stream
-        self._join(but="@ttb" if side_dense else None)
+        # (nor for the early row scatters: nothing reads their tables before the update phase -- every wait is a barrier
+        #  packet in front of the history-row sums)
+        self._join(but=("@ttb", "@scat") if side_dense else ("@scat",))
         if side_dense:
             # the dense path from here on (batched reduction of every weight gradient, unpacking, later the dense
             # regulariser + Adam) does not meet the embedding path (gradient tables, table regulariser / Adam) again:

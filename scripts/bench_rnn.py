@@ -28,18 +28,22 @@ with torch.cuda.stream(st):
                            cst=torch.zeros(Hn, T, n, device=dev) if train else None,
                            mprev=torch.zeros(Hn, T, n, device=dev) if train else None)
     g1, g2, t = gru(0), gru(3 * n), t4()
-    only = sys.argv[1] if len(sys.argv) > 1 else None      # "t4" | "gru" | "all": ONE configuration (counter runs)
-    if only:
+    only = sys.argv[1] if len(sys.argv) > 1 else None      # "t4" | "gru" | "all" | "bwd": ONE configuration (counter runs)
+    if only and only != "bwd":
         fn = {"t4": lambda: ops.rnn_multi("clsr_rnn_fwd_multi", [], t, lens, 1, Hn, T),
               "gru": lambda: ops.rnn_multi("clsr_rnn_fwd_multi", [g1], None, lens, 1, Hn, T),
               "all": lambda: ops.rnn_multi("clsr_rnn_fwd_multi", [g1, g2], t, lens, 1, Hn, T)}[only]
         print("fwd  %-4s                    : %6.1f us" % (only, timeit(fn)))
         sys.exit(0)
-    print("fwd  t4 only (training)     : %6.1f us" % timeit(lambda: ops.rnn_multi("clsr_rnn_fwd_multi", [], t, lens, 1, Hn, T)))
+    if only != "bwd":
+      print("fwd  t4 only (training)     : %6.1f us" % timeit(lambda: ops.rnn_multi("clsr_rnn_fwd_multi", [], t, lens, 1, Hn, T)))
     te = t4(False)
-    print("fwd  t4 only (scoring)      : %6.1f us" % timeit(lambda: ops.rnn_multi("clsr_rnn_fwd_multi", [], te, lens, 1, Hn, T)))
-    print("fwd  one gru (training)     : %6.1f us" % timeit(lambda: ops.rnn_multi("clsr_rnn_fwd_multi", [g1], None, lens, 1, Hn, T)))
-    print("fwd  gru + gru + t4         : %6.1f us" % timeit(lambda: ops.rnn_multi("clsr_rnn_fwd_multi", [g1, g2], t, lens, 1, Hn, T)))
+    if only != "bwd":
+      print("fwd  t4 only (scoring)      : %6.1f us" % timeit(lambda: ops.rnn_multi("clsr_rnn_fwd_multi", [], te, lens, 1, Hn, T)))
+    if only != "bwd":
+      print("fwd  one gru (training)     : %6.1f us" % timeit(lambda: ops.rnn_multi("clsr_rnn_fwd_multi", [g1], None, lens, 1, Hn, T)))
+    if only != "bwd":
+      print("fwd  gru + gru + t4         : %6.1f us" % timeit(lambda: ops.rnn_multi("clsr_rnn_fwd_multi", [g1, g2], t, lens, 1, Hn, T)))
     # backward-through-time of the same three encoders (saved activations of the launch above)
     dP = torch.zeros(Hn * T, NX, device=dev)
     dseq, dh = torch.randn(Hn, T, n, device=dev) * 0.1, torch.randn(Hn, n, device=dev) * 0.1
@@ -49,6 +53,8 @@ with torch.cuda.stream(st):
     tb = ops.t4_desc(n, Wm=Wm, ldm=4 * n, act=torch.rand(Hn, T, 6 * n, device=dev), cst=torch.randn(Hn, T, n, device=dev) * 0.3,
                      dout_seq=dseq, dPin=dP[:, 6 * n:], lddp=NX)
     b1, b2 = gru_b(g1, 0), gru_b(g2, 3 * n)
-    print("bwd  t4 only                : %6.1f us" % timeit(lambda: ops.rnn_multi("clsr_rnn_bwd_multi", [], tb, lens, 1, Hn, T)))
-    print("bwd  one gru                : %6.1f us" % timeit(lambda: ops.rnn_multi("clsr_rnn_bwd_multi", [b1], None, lens, 1, Hn, T)))
+    if only != "bwd":
+      print("bwd  t4 only                : %6.1f us" % timeit(lambda: ops.rnn_multi("clsr_rnn_bwd_multi", [], tb, lens, 1, Hn, T)))
+    if only != "bwd":
+      print("bwd  one gru                : %6.1f us" % timeit(lambda: ops.rnn_multi("clsr_rnn_bwd_multi", [b1], None, lens, 1, Hn, T)))
     print("bwd  gru + gru + t4         : %6.1f us" % timeit(lambda: ops.rnn_multi("clsr_rnn_bwd_multi", [b1, b2], tb, lens, 1, Hn, T)))
