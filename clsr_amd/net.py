@@ -479,6 +479,14 @@ class CLSRNet(object):
             t = torch.zeros(*[int(s) for s in shape], dtype=dtype, device=self.device)
             self._bufs[key] = t
             self._buf_allocs += 1     # (the zero fill is a kernel on the CURRENT stream: see _dw_batched)
+            # ... and every side stream orders itself behind it: a branch forked BEFORE this point but enqueued after
+            # it could otherwise write the new buffer while the fill is still pending (first step of a net only; seen
+            # as a run-to-run difference of the time-input gradients, tests/test_fullsize_gpu.py)
+            if self._side:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                for side in self._side.values():
+                    side.wait_event(ev)
         return t
 
     def _pack(self, key, W, out_f, in_f, transposed=False, W2=None, s2=1.0, in_pad=None, o0=0, i0=0,
@@ -1431,14 +1439,16 @@ class CLSRNet(object):
         dPt = dPinAll[:, self._enc_off("t4"):]
         dTT = self._buf("t4.dTT", M, 2 * H)
         TT = self._buf("t4.TT", M, 2 * H)
+        # (every workspace of the side branch exists BEFORE the fork: a first-use allocation zero-fills on the compute
+        #  stream, and a fill enqueued behind the fork raced with the branch's writes in the first step of a net)
+        parts_t = query("clsr_t4_time_inputs_bwd_parts", Hn, T, H)
+        tp = self._buf("t4.tpart", 512 * 4 * 128)[: parts_t * 4 * H]
         self._gemm(dPt[:, 3 * H:], NX, "t4.tw^T", M, 3 * H, 2 * H, dTT, 2 * H)
         fork = self._fork_point()
         Wt, Kp = self.packed["xw^T"]
         call("clsr_enc_bwd_fused", dPinAll, hist, self._buf("g1.hprev", Hn, T, H), self._buf("g1.gates", Hn, T, 3 * H),
              self._buf("t4.mprev", Hn, T, H), TT, self._buf("g2.hprev", Hn, T, H), self._buf("g2.gates", Hn, T, 3 * H),
              Wt, Kp, dhist, *wss, M)
-        parts_t = query("clsr_t4_time_inputs_bwd_parts", Hn, T, H)
-        tp = self._buf("t4.tpart", 512 * 4 * 128)[: parts_t * 4 * H]
         with self._branch("@dw0" if (self.dw_stream and self.overlap) else "@main", after=fork, name="@ttb"):
             tag, self._ws_tag = self._ws_tag, ""      # (its reductions belong to the main flush)
             try:
