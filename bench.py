@@ -369,9 +369,12 @@ def main():
                                   sparse_mode=os.environ.get("CLSR_SPARSE_MODE", "allgather"))
         wl.stepper.prepare(f)
 
-    # (a HIGH-priority main stream gains 15-40 us per single-GPU step but costs the data-parallel step 2 ms -- 4.5 -> 6.6 ms
-    # with the RCCL collectives on it: equal priorities everywhere)
-    stream = torch.cuda.Stream()
+    # The step's compute stream outranks its side streams on a single GPU: the weight-gradient kernels beside it are
+    # MFMA-saturated and starve whatever shares a CU with them (r03: 3.72 -> 3.63 ms).  NOT under data parallelism: with
+    # the RCCL collectives queued behind a high-priority stream the step went from 4.5 to 6.6 ms (r02) -- equal
+    # priorities there.  CLSR_MAIN_PRIORITY overrides (0 = normal, -1 = high).
+    prio = int(os.environ.get("CLSR_MAIN_PRIORITY", "0" if wl.stepper is not None else "-1"))
+    stream = torch.cuda.Stream(priority=prio)
     host_losses = torch.zeros(8, dtype=torch.float64).pin_memory()
     extra, modes = [], {}
     with torch.cuda.stream(stream):

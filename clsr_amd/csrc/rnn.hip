@@ -618,6 +618,15 @@ __global__ void __launch_bounds__(64 * RNT) t4lstm_bwd_kernel(T4Args a) {
 // short_term_intention, Time4LSTM / GRU short-term encoder, GRU causal2).  Each one only fills a
 // quarter of the chip (Hn/16 single-wave workgroups), so they are dispatched as ONE grid:
 // blockIdx.y selects the encoder, blockIdx.x the 16-history tile.
+// Backward: the Time4LSTM chain is the longest of a launch (4 gate blocks + 2 time gates per step against the GRU's 3):
+// its waves issue ahead of the GRU waves that share their SIMDs (s_setprio), the GRUs fill the gaps -- 300 -> 242 us for
+// the three encoders alone (scripts/bench_rnn.py), ~10 us inside the step, where the saved activations come from HBM.
+// The forward launch measured 3-8 % SLOWER with it and keeps equal priorities.
+#ifdef RNN_NO_T4_PRIO
+#define RNN_T4_PRIO()
+#else
+#define RNN_T4_PRIO() __builtin_amdgcn_s_setprio(3)
+#endif
 template <int RNT>
 __global__ void __launch_bounds__(64 * RNT) rnn_multi_fwd_kernel(RnnMultiArgs a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
@@ -629,8 +638,9 @@ template <int RNT>
 __global__ void __launch_bounds__(64 * RNT) rnn_multi_bwd_kernel(RnnMultiArgs a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
   const int which = blockIdx.y;
-  if (which < a.ngru) gru_bwd_body<RNT>(a.gru[which], blockIdx.x, xb);
-  else t4lstm_bwd_body<RNT>(a.t4, blockIdx.x, xb);
+  if (which < a.ngru) { gru_bwd_body<RNT>(a.gru[which], blockIdx.x, xb); return; }
+  RNN_T4_PRIO();
+  t4lstm_bwd_body<RNT>(a.t4, blockIdx.x, xb);
 }
 
 

@@ -125,6 +125,9 @@ class CLSRNet(object):
         # k + 1 (forward) and the weight gradients / d(hist) products of range k - 1 (backward) run beside the T-serial
         # recurrence of range k instead of before / after all of it (see _rnn_chunks_for); 1: one launch per pass.
         # Exact mode of the CLSR graph only so far (the bf16 weight-gradient kernels have no time-range form)
+        # HIP stream priorities of the side streams (0 = normal; the callers' compute stream can be created with -1 = high)
+        self.side_priority = int(os.environ.get("CLSR_SIDE_PRIORITY", "0"))
+        self.dw_priority = int(os.environ.get("CLSR_DW_PRIORITY", "0"))
         self.early_scatter = not os.environ.get("CLSR_NO_EARLY_SCATTER")   # A/B: row scatters of the user / target lookups beside the encoder-backward tail instead of behind it
         self.enc_bwd_fused = not os.environ.get("CLSR_NO_ENC_BWD_FUSED")   # A/B: one pass over dPin for the seven encoder-side weight gradients + d(hist) (csrc/encbwd.hip)
         self.rnn_chunks = int(os.environ.get("CLSR_RNN_CHUNKS", "1"))   # measured at configs[1]: 4.17-4.21 ms with 5 ranges, 4.11 with 3, against 3.91 with one launch (the projections throttle the chain, ~30 us start-up + ~15 us cross-stream signalling per range) -- kept as a switch
@@ -412,7 +415,7 @@ class CLSRNet(object):
                 return self
             side = net._side.get(self.tag)
             if side is None:
-                side = net._side[self.tag] = torch.cuda.Stream(device=net.device)
+                side = net._side[self.tag] = torch.cuda.Stream(device=net.device, priority=net.side_priority)
             self.side = side
             ev = self.after
             if ev is None:
@@ -559,7 +562,7 @@ class CLSRNet(object):
             name = "@dw%d" % (len(pend) % self.dw_streams)
             side = self._side.get(name)
             if side is None:
-                side = self._side[name] = torch.cuda.Stream(device=self.device)
+                side = self._side[name] = torch.cuda.Stream(device=self.device, priority=self.side_priority)
             ops.stream_wait(side, self._fork_point())
             self._dw_launch(X, x_bf16, ldx, T, G, Xmul, ldmul, sc, sh, dY, dy_bf16, ldy, M, K, N, ws, side.cuda_stream)
             self._dw_async = True
@@ -599,7 +602,7 @@ class CLSRNet(object):
         if self.dw_stream and self.overlap and self._ws_tag == "":
             side = self._side.get("@dw0")
             if side is None:
-                side = self._side["@dw0"] = torch.cuda.Stream(device=self.device)
+                side = self._side["@dw0"] = torch.cuda.Stream(device=self.device, priority=self.dw_priority)
             ops.stream_wait(side, fork)
             ops.dw_multi(name, jobs, stream=side.cuda_stream)
             self._dw_async = True
