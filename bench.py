@@ -345,7 +345,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        pg_opts = None
+        if os.environ.get("CLSR_NCCL_HIGH_PRIORITY"):     # experiment: RCCL's internal stream at high priority
+            pg_opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=pg_opts)
         # proof that RCCL really connects the ranks the line claims: a sum of ones over the job
         ones = torch.ones(1, device="cuda")
         dist.all_reduce(ones)
@@ -369,11 +372,11 @@ def main():
                                   sparse_mode=os.environ.get("CLSR_SPARSE_MODE", "allgather"))
         wl.stepper.prepare(f)
 
-    # The step's compute stream outranks its side streams on a single GPU: the weight-gradient kernels beside it are
-    # MFMA-saturated and starve whatever shares a CU with them (r03: 3.72 -> 3.63 ms).  NOT under data parallelism: with
-    # the RCCL collectives queued behind a high-priority stream the step went from 4.5 to 6.6 ms (r02) -- equal
-    # priorities there.  CLSR_MAIN_PRIORITY overrides (0 = normal, -1 = high).
-    prio = int(os.environ.get("CLSR_MAIN_PRIORITY", "0" if wl.stepper is not None else "-1"))
+    # The step's compute stream outranks its side streams: the weight-gradient kernels beside it are MFMA-saturated and
+    # starve whatever shares a CU with them (r03: 3.72 -> 3.63 ms).  Safe under data parallelism only because the step
+    # keeps THREE streams of its own (net.stream_alias): with four, RCCL's stream was a fifth hardware queue and the
+    # step went from 4.0 to 6.6 ms.  CLSR_MAIN_PRIORITY overrides (0 = normal, -1 = high).
+    prio = int(os.environ.get("CLSR_MAIN_PRIORITY", "-1"))
     stream = torch.cuda.Stream(priority=prio)
     host_losses = torch.zeros(8, dtype=torch.float64).pin_memory()
     extra, modes = [], {}

@@ -291,10 +291,9 @@ class SequentialBaseModel(BaseModel):
         """All device work of the model runs on one private HIP stream: launches on the legacy
         default stream pay an implicit-synchronisation tax per kernel (measured 200 us vs 10 us)."""
         if self._stream is None:
-            # single GPU: the compute stream outranks the side streams of the step (their MFMA-saturated weight-gradient
-            # kernels starve whatever shares a CU with them); data parallel: equal priorities, or the RCCL collectives
-            # queue behind it (bench.py)
-            prio = int(os.environ.get("CLSR_MAIN_PRIORITY", "0" if self._dist is not None else "-1"))
+            # the compute stream outranks the side streams of the step (their MFMA-saturated weight-gradient kernels
+            # starve whatever shares a CU with them); see bench.py for the stream-count condition under data parallelism
+            prio = int(os.environ.get("CLSR_MAIN_PRIORITY", "-1"))
             self._stream = torch.cuda.Stream(device=self.net.device, priority=prio)
         return torch.cuda.stream(self._stream)
 

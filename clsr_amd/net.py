@@ -126,6 +126,11 @@ class CLSRNet(object):
         # recurrence of range k instead of before / after all of it (see _rnn_chunks_for); 1: one launch per pass.
         # Exact mode of the CLSR graph only so far (the bf16 weight-gradient kernels have no time-range form)
         # HIP stream priorities of the side streams (0 = normal; the callers' compute stream can be created with -1 = high)
+        # branch tag -> stream tag.  The @aux branches share the @lt stream: compute + @lt + @dw0 = three HIP streams, so
+        # that RCCL's stream is the FOURTH under data parallelism -- a fifth active queue (or a fourth next to a
+        # high-priority compute stream) cost 4.0 -> 6.6 ms per step (r03, CLSR_FORCE_DP=1); on a single GPU the fold
+        # measured 3.768 against 3.779 ms.  CLSR_FOLD_AUX=0: the round-2 layout with a stream of its own.
+        self.stream_alias = {} if os.environ.get("CLSR_FOLD_AUX") == "0" else {"@aux": "@lt"}
         self.side_priority = int(os.environ.get("CLSR_SIDE_PRIORITY", "0"))
         self.dw_priority = int(os.environ.get("CLSR_DW_PRIORITY", "0"))
         self.early_scatter = not os.environ.get("CLSR_NO_EARLY_SCATTER")   # A/B: row scatters of the user / target lookups beside the encoder-backward tail instead of behind it
@@ -413,9 +418,15 @@ class CLSRNet(object):
             self.inline = (not net.overlap) or self.tag == "@main"     # "@main": stay on the current stream
             if self.inline:
                 return self
-            side = net._side.get(self.tag)
+            stag = net.stream_alias.get(self.tag, self.tag)      # (scratch buffers keep the branch's own tag)
+            side = net._side.get(stag)
             if side is None:
-                side = net._side[self.tag] = torch.cuda.Stream(device=net.device, priority=net.side_priority)
+                side = net._side[stag] = torch.cuda.Stream(device=net.device, priority=net.side_priority)
+            if side.cuda_stream == ops.current_stream().cuda_stream:
+                # a branch onto the stream it is opened from (an @aux branch inside an @lt one, now that they share a
+                # stream): plain stream order -- a stream waiting for its own event crashes hipGraph capture
+                self.inline = True
+                return self
             self.side = side
             ev = self.after
             if ev is None:
@@ -436,7 +447,7 @@ class CLSRNet(object):
             self.scope.__exit__(*exc)
             self.ctx.__exit__(*exc)
             net._ws_tag = self.old_tag
-            net._joins.append((self.name, ev))
+            net._joins.append((self.name, ev, self.side.cuda_stream))
             return False
 
     def _branch(self, tag, after=None, name=None):
@@ -464,13 +475,14 @@ class CLSRNet(object):
         main = ops.current_stream()
         rest = []
         but = but if isinstance(but, tuple) else (but,)
-        for tag, ev in self._joins:
+        for tag, ev, sid in self._joins:
             if (only is None or tag == only) and tag not in but:
-                ops.stream_wait(main, ev)
+                if sid != main.cuda_stream:      # (work of this very stream is ordered already)
+                    ops.stream_wait(main, ev)
                 if keep:
-                    rest.append((tag, ev))
+                    rest.append((tag, ev, sid))
             else:
-                rest.append((tag, ev))
+                rest.append((tag, ev, sid))
         self._joins = rest
 
     # ------------------------------------------------------------------ buffers

@@ -365,7 +365,7 @@ class _RecordingDist(object):
     def all_reduce(self, t, op=None, group=None, async_op=False):
         n = self.net
         self.log.append(("all_reduce", t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream,
-                         [name for name, _ in n._joins], {k: len(v) for k, v in n._dw_pending.items() if v}))
+                         [j[0] for j in n._joins], {k: len(v) for k, v in n._dw_pending.items() if v}))
         return self._Work(self.log) if async_op else None
 
     def all_gather(self, outs, t, group=None):
