@@ -150,7 +150,7 @@ class CLSRNet(object):
         self.sumsq_tab, self.losses = self.stats24[:16], self.stats24[16:]
         self.ucount = torch.zeros(1, dtype=F32, device=self.device)
         self.last_shape = None
-        self._counts_zeroed = self._ucount_zeroed = False
+        self._counts_zeroed = self._ucount_zeroed = self._ticked = False
         self.dp_world = 1          # data-parallel world size (loss normalisers are global)
         self.dp_stats_hook = None  # optional callable(tensor): sum BN partial statistics across ranks
         # data-parallel exchange hooks (clsr_amd/dp.py): called (and recorded into launch plans) at the points of the
@@ -1431,8 +1431,8 @@ class CLSRNet(object):
                 and self._enc_off("g1") == 0 and self._enc_off("g2") == 3 * self.H and self._enc_off("t4") == 6 * self.H)
 
     def _enc_bwd_fused(self, f, hist, dPinAll, dhist, Hn, T, hs):
-        """Seven encoder-side weight gradients + d(hist) from ONE pass over dPin (csrc/encbwd.hip) on the compute stream;
-        the time-feature chain (d TT, its tanh backward and parameter sums) runs beside it on the weight-gradient stream."""
+        """Seven encoder-side weight gradients + d(hist) from ONE pass over dPin (csrc/encbwd.hip) on the compute stream,
+        behind the small time-feature chain (d TT, its tanh backward and parameter sums)."""
         Gd, D, H, NX, E = self.Gd, self.D, self.H, self.NX, self.enc_in
         M = Hn * T
         st, t = CL + "short_term/", self._t4_scope
@@ -1459,21 +1459,16 @@ class CLSRNet(object):
         parts_t = query("clsr_t4_time_inputs_bwd_parts", Hn, T, H)
         tp = self._buf("t4.tpart", 512 * 4 * 128)[: parts_t * 4 * H]
         self._gemm(dPt[:, 3 * H:], NX, "t4.tw^T", M, 3 * H, 2 * H, dTT, 2 * H)
-        fork = self._fork_point()
+        # ... and its tanh backward + parameter sums (27 us): beside the MFMA-saturated fused kernel they took 400 us and
+        # the batched reduction of ALL dense gradients waited for them
+        call("clsr_t4_time_inputs_bwd", dTT, TT, f["time_to_now"], f["time_from_first_action"], hs * T, Hn, T, H, tp)
+        for off_, nm in ((0, "_time_input_w1"), (H, "_time_input_w2"), (2 * H, "_time_input_bias1"),
+                         (3 * H, "_time_input_bias2")):
+            self._rp(tp[off_:], parts_t, 4 * H, H, Gd[t + nm])
         Wt, Kp = self.packed["xw^T"]
         call("clsr_enc_bwd_fused", dPinAll, hist, self._buf("g1.hprev", Hn, T, H), self._buf("g1.gates", Hn, T, 3 * H),
              self._buf("t4.mprev", Hn, T, H), TT, self._buf("g2.hprev", Hn, T, H), self._buf("g2.gates", Hn, T, 3 * H),
              Wt, Kp, dhist, *wss, M)
-        with self._branch("@dw0" if (self.dw_stream and self.overlap) else "@main", after=fork, name="@ttb"):
-            tag, self._ws_tag = self._ws_tag, ""      # (its reductions belong to the main flush)
-            try:
-                call("clsr_t4_time_inputs_bwd", dTT, TT, f["time_to_now"], f["time_from_first_action"], hs * T, Hn, T, H, tp)
-                for off_, nm in ((0, "_time_input_w1"), (H, "_time_input_w2"), (2 * H, "_time_input_bias1"),
-                                 (3 * H, "_time_input_bias2")):
-                    self._rp(tp[off_:], parts_t, 4 * H, H, Gd[t + nm])
-            finally:
-                self._ws_tag = tag
-        return fork
 
     def _encoders_bwd_chunked(self, f, chunks, hist, dhist, drnn, dsi, dfs, Hn, T, seq_len, ls, hs):
         """Backward-through-time as a chain of launches over ``chunks`` (descending); behind every range its weight
@@ -1768,6 +1763,14 @@ class CLSRNet(object):
                 (f["users"].data_ptr(), fl["user_long"].data_ptr(), Hn, hs, 1, 0),
                 (f["users"].data_ptr(), fl["user_short"].data_ptr(), Hn, hs, 1, 0)])
             self._dp_hook("flags_ready")      # involved-row byte maps are final: their exchange hides under the forward
+            if (apply and self.tick_early and not self.capture_grads and self.dp_hooks is None
+                    and "user_long" in self.tables):
+                # the distinct-user count of the discrepancy loss and the Adam clock need the marks only: HERE, under the
+                # forward, instead of as the first launch of the update phase (9 us + a stream hop in front of the table
+                # regulariser).  Not under data parallelism: the count is over the EXCHANGED byte map.
+                call("clsr_count_flags_tick", fl["user_long"], self.dims["Vu"], self.ucount, self.adam_state,
+                     float(hp.learning_rate), 0.9, 0.999)
+                self._ticked = True
         o = [0]
 
         def take(*shape):
@@ -1896,13 +1899,11 @@ class CLSRNet(object):
                       self._gru_bwd_hidden("g1", st + "short_term_intention/gru_cell/", Du, dPinAll, Hn, T)
                   if (not hp.manual_alpha) and hp.predict_long_short:
                       self._gru_bwd_hidden("g2", CL + "causal2/causal2/gru_cell/", H, dPinAll, Hn, T)
-        # ---- join the long-term attention branch; its d(hist) contribution was accumulated separately (the time-feature
-        #      chain of the fused encoder backward sits on the weight-gradient stream: the dense branch below follows it
-        #      in stream order, the compute stream has no business waiting for it)
+        # ---- join the long-term attention branch; its d(hist) contribution was accumulated separately (NOT the early row
+        #      scatters: nothing reads their tables before the update phase -- every wait is a barrier packet in front of
+        #      the history-row sums)
         side_dense = self.flush_side and self.overlap and self.dw_stream
-        # (nor for the early row scatters: nothing reads their tables before the update phase -- every wait is a barrier
-        #  packet in front of the history-row sums)
-        self._join(but=("@ttb", "@scat") if side_dense else ("@scat",))
+        self._join(but=("@scat",))
         if side_dense:
             # the dense path from here on (batched reduction of every weight gradient, unpacking, later the dense
             # regulariser + Adam) does not meet the embedding path (gradient tables, table regulariser / Adam) again:
@@ -2076,7 +2077,9 @@ class CLSRNet(object):
         # on the dense path, and the table Adam launches waited for the whole weight-gradient reduction: 50 us)
         tick_early = self.tick_early and not self.capture_grads
         lr = float(hp.learning_rate)
-        if "user_long" in tb:
+        if self._ticked:        # (count + clock went out with the row marks at the start of the step)
+            self._ticked = False
+        elif "user_long" in tb:
             call("clsr_count_flags_tick", fl["user_long"], Vu, self.ucount, self.adam_state if tick_early else None, lr,
                  0.9, 0.999)
         elif tick_early:
