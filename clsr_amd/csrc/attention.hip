@@ -39,6 +39,7 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
 // LDS (floats): sbuf[T*QC] | wl[T] | red[64*4]
 template <bool ZH>
 __global__ void __launch_bounds__(64) att_out_fwd_kernel(AttOutArgs a) {
+  CLSR_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x;
   const int T = a.T, C1 = a.C1, Dk = a.Dk;
@@ -177,6 +178,7 @@ extern "C" int clsr_att_out_fwd_h(const void* z1, const float* scale1, const flo
 template <int NCH>
 __global__ void __launch_bounds__(64 * ATT_BWD_MAXG) att_score_bwd_kernel(AttOutArgs a, float* __restrict__ ds_out,
                                                                           float* __restrict__ b_partial) {
+  CLSR_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int T = a.T, Dk = a.Dk, G = a.G;
@@ -284,6 +286,7 @@ __global__ void __launch_bounds__(256) att_dy1_stats_kernel(
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ w_out, long M, int C, double* __restrict__ bn_partial,
     float* __restrict__ w_partial) {
+  CLSR_CHAIN_PRIO();
   __shared__ f32x4 red[3][256];
   const int QC = C >> 2;
   const int rpb = 256 / QC;

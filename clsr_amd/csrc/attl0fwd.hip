@@ -32,6 +32,7 @@ struct AttL0FwdArgs {
 // NZ = 16-feature tiles of A0 (outputs), NK = 16-wide chunks of Q (reduction)
 template <int NZ, int NK>
 __global__ void __launch_bounds__(256, 2) att_l0_fwd_kernel(AttL0FwdArgs s) {
+  CLSR_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int ZP = 16 * NZ, QP = 16 * NK;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;

@@ -31,6 +31,7 @@ struct L1BwdArgs {
 
 template <int OT, int KC, bool APPLY>
 __global__ void __launch_bounds__(256, OT <= 5 ? 2 : 1) att_l1_bwd_kernel(L1BwdArgs a) {
+  CLSR_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NR = 16 * OT, KCP = 16 * KC;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;

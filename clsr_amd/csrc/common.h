@@ -117,5 +117,14 @@ __device__ __forceinline__ f32x4 load4e(const void* base, long idx) {
   return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx);
 }
 
+// Wave priority of the kernels on the step's dependency chain (everything except the weight-gradient partial-sum
+// kernels, which run beside it on their own stream): their waves issue ahead of the MFMA-saturated weight-gradient waves
+// that share their SIMDs.  In-step kernel times on the chain summed to 3.47 ms against 2.77 ms for the same kernels
+// running alone (profiles/r03_contention.md) -- issue arbitration, not occupancy, is what the side kernels take away.
+#ifdef CLSR_NO_CHAIN_PRIO
+#define CLSR_CHAIN_PRIO()
+#else
+#define CLSR_CHAIN_PRIO() __builtin_amdgcn_s_setprio(2)
+#endif
 #define MFMA4(acc, a, b) (acc) = __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (acc), 0, 0, 0)
 #endif

@@ -321,6 +321,7 @@ __device__ __forceinline__ void eb_body(const EncBwdArgs& a, float* lds) {
 
 // every wave runs its own instance of the body: same staging code, its own column range and accumulators
 __global__ void __launch_bounds__(256) enc_bwd_fused_kernel(EncBwdArgs a) {
+  CLSR_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wave == 0) eb_body<0>(a, lds);

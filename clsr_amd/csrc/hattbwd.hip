@@ -45,6 +45,7 @@ __device__ __forceinline__ int packed_row(int o) {
 // NF = 16-feature tiles of Q, NZ = 16-feature tiles of A0
 template <int NF, int NZ, bool WU>
 __global__ void __launch_bounds__(256, 2) att_l0_bwd_kernel(AttL0BwdArgs s) {
+  CLSR_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int KT = (NZ + 1) / 2;          // 32-wide k-tiles of A0
   constexpr int QP = 16 * NF, ZP = 16 * NZ;
@@ -256,6 +257,7 @@ struct AttL0BwdArgsF {
 
 template <int NF, int NZ>
 __global__ void __launch_bounds__(256, 2) att_l0_bwd_f32_kernel(AttL0BwdArgsF s) {
+  CLSR_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int QP = 16 * NF, ZP = 16 * NZ;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;

@@ -654,6 +654,7 @@ __global__ void __launch_bounds__(64) att_prod_bwd_kernel(const void* __restrict
                                                           const float* __restrict__ q, int ldq, long Hn, int G,
                                                           int T, int Q, float* __restrict__ da, int ldda,
                                                           float* __restrict__ dq, int lddq, int acc_dq) {
+  CLSR_CHAIN_PRIO();
   const int lane = threadIdx.x;
   const int QQ = Q >> 2, tpar = 64 / QQ, ts = lane / QQ, qq = lane - ts * QQ;
   __shared__ f32x4 red[ATT_MAXG][64];

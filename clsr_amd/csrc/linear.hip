@@ -208,6 +208,7 @@ __global__ void __launch_bounds__(256) pgemm_generic_kernel(PGemmArgs a) {
 //     chain of a tile then runs back to back instead of waiting for one load latency per k-tile.
 template <int OT, int PRO, int EPI, bool STATS, int KTT = 0, bool RING = false>
 __global__ void __launch_bounds__(256) pgemm_fast_kernel(PGemmArgs a) {
+  CLSR_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int j = lane & 15, g = lane >> 4;

@@ -630,6 +630,7 @@ __global__ void __launch_bounds__(64 * RNT) t4lstm_bwd_kernel(T4Args a) {
 template <int RNT>
 __global__ void __launch_bounds__(64 * RNT) rnn_multi_fwd_kernel(RnnMultiArgs a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
+  CLSR_CHAIN_PRIO();
   const int which = blockIdx.y;
   if (which < a.ngru) gru_fwd_body<RNT>(a.gru[which], blockIdx.x, xb);
   else t4lstm_fwd_body<RNT>(a.t4, blockIdx.x, xb);
@@ -637,6 +638,7 @@ __global__ void __launch_bounds__(64 * RNT) rnn_multi_fwd_kernel(RnnMultiArgs a)
 template <int RNT>
 __global__ void __launch_bounds__(64 * RNT) rnn_multi_bwd_kernel(RnnMultiArgs a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
+  CLSR_CHAIN_PRIO();
   const int which = blockIdx.y;
   if (which < a.ngru) { gru_bwd_body<RNT>(a.gru[which], blockIdx.x, xb); return; }
   RNN_T4_PRIO();

@@ -133,6 +133,7 @@ class CLSRNet(object):
         self.stream_alias = {} if os.environ.get("CLSR_FOLD_AUX") == "0" else {"@aux": "@lt"}
         self.side_priority = int(os.environ.get("CLSR_SIDE_PRIORITY", "0"))
         self.dw_priority = int(os.environ.get("CLSR_DW_PRIORITY", "0"))
+        self.sort_late = bool(os.environ.get("CLSR_SORT_LATE"))     # A/B: history-id sort beside the heads instead of at the start of the step (measured: no difference, 3.66 ms both)
         self.early_scatter = not os.environ.get("CLSR_NO_EARLY_SCATTER")   # A/B: row scatters of the user / target lookups beside the encoder-backward tail instead of behind it
         self.enc_bwd_fused = not os.environ.get("CLSR_NO_ENC_BWD_FUSED")   # A/B: one pass over dPin for the seven encoder-side weight gradients + d(hist) (csrc/encbwd.hip)
         self.rnn_chunks = int(os.environ.get("CLSR_RNN_CHUNKS", "1"))   # measured at configs[1]: 4.17-4.21 ms with 5 ranges, 4.11 with 3, against 3.91 with one launch (the projections throttle the chain, ~30 us start-up + ~15 us cross-stream signalling per range) -- kept as a switch
@@ -141,7 +142,7 @@ class CLSRNet(object):
         self._joins = []
         self._dw_pending, self._dw_tables, self._dw_after, self._rp_pending = {}, {}, {}, {}
         self.defer_dw = True       # one batched reduction of the weight-gradient partials per stream and step
-        self.overlap = True        # run the long-term attention chain on a side stream (fork / join)
+        self.overlap = not os.environ.get("CLSR_NO_OVERLAP")   # run the long-term attention chain etc. on side streams (fork / join); off: one stream, every kernel alone (diagnosis: contention-free kernel times)
         self.sorted_hist_grad = True   # history-row gradients by sort + segmented sums (False: float atomics)
         self.adam_state = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device=self.device)
         # squared norms of the IndexedSlices pieces (16) + loss numerators (8): ONE buffer, so that the data-parallel
@@ -228,7 +229,7 @@ class CLSRNet(object):
         return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook),
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
                 self.lazy, self.rnn_first, self.lt_att_first, self.tick_early, self.hist_grad_two, self.dw_batch_late, self.bn_bwd_fused, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h, self.flush_side, self.l1_bwd_2pass,
-                self.split_g2, self.rnn_chunks, self.enc_bwd_fused, self.early_scatter, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
+                self.split_g2, self.rnn_chunks, self.enc_bwd_fused, self.early_scatter, self.sort_late, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
 
@@ -1632,7 +1633,7 @@ class CLSRNet(object):
                 with self._branch("@aux", after=step_start):
                     if early_aux is not None:
                         early_aux()
-                    if training and self.sorted_hist_grad:
+                    if training and self.sorted_hist_grad and not self.sort_late:
                         self._sort_hist_ids(f, Hn, T, hs)
             grus, t4d = [], None
             short_int, rnn_out, fs = ushort, None, None
@@ -1695,6 +1696,12 @@ class CLSRNet(object):
             with self._branch("@aux"):
                 after_attention(dict(att_fea_long=att_long, att_fea_short=att_short, hist_mean=hmean,
                                      hist_recent=hrec))
+                if training and self.sorted_hist_grad and self.sort_late and chunks is None:
+                    # the ~35 tiny launches that sort the history ids for the backward's segmented sums need the feed
+                    # only and are read at the very end of the step: they run HERE, beside the row-level heads (~30
+                    # dependent 160-block launches, the device is idle), instead of beside the input projections at the
+                    # start of the step (opt-in, CLSR_SORT_LATE: the step time did not move)
+                    self._sort_hist_ids(f, Hn, T, hs)
         alpha = self._buf("alpha", B)
         mo = self._buf("model_output", B, 2 * D)
         if not hp.manual_alpha:
