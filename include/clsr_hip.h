@@ -473,14 +473,16 @@ int clsr_copy_words(void* dst, const void* src, long nbytes, void* stream);
 typedef struct clsr_mark_desc { const int* idx; unsigned char* flags; long nrows; long row_stride; int ncols; int pad_; } clsr_mark_desc;
 typedef struct clsr_gather_desc { const float* table; const int* idx; float* out; long idx_stride; int N; int C; int ldo; int col0; } clsr_gather_desc;
 /* ---- fused tail of the backward pass through the encoders of the default graph (csrc/encbwd.hip): from ONE pass over
- * dPin [M, 480] (M = Hn * T; columns: short_term_intention r,u | c, time4lstm i,j,f,o | tns | tls, causal2 r,u | c) the
- * partial sums of seven weight gradients -- hist^T dPin, hprev1^T dPin[:, 0:80], (hprev1 * r1)^T dPin[:, 80:120],
- * mprev^T dPin[:, 120:280], TT^T dPin[:, 240:360], hprev2^T dPin[:, 360:440], (hprev2 * r2)^T dPin[:, 440:480]; gates1 /
- * gates2 are the saved r | u | c activations [M, 120] -- and  dhist += dPin . W_x^T  (Wt: packed W_x^T, 40 rows, K = 480).
+ * dPin [M, 480] (M = Hn * T; columns as net.py lays out the fused input projection: short_term_intention r,u | c @0,
+ * causal2 r,u | c @120, time4lstm i,j,f,o | tns | tls @240) the partial sums of seven weight gradients -- hist^T dPin
+ * (+ the bias sums of all 480 columns), hprev1^T dPin[:, 0:80], (hprev1 * r1)^T dPin[:, 80:120], hprev2^T dPin[:, 120:200],
+ * (hprev2 * r2)^T dPin[:, 200:240], mprev^T dPin[:, 240:400], TT^T dPin[:, 360:480]; gates1 / gates2 are the saved
+ * r | u | c activations [M, 120] -- and  dhist += dPin . W_x^T  (Wt: packed W_x^T, 40 rows, K = 480).
  * Reference: the gradients of GRUCell / Time4LSTMCell.call under dynamic_rnn, clsr.py:160-237,
  * rnn_cell_implement.py:129-298.  Every workspace ws_* receives clsr_enc_bwd_fused_parts(M) partial slots per 80-column
  * chunk in the layout of clsr_pgemm_dw_partial (bias sums of dPin ride in ws_hist), for clsr_dw_reduce_batch.
- * Replaces clsr_pgemm_dw_partial_multi (seven jobs) + clsr_pgemm(dPin, W_x^T) at the default widths. */
+ * Replaces clsr_pgemm_dw_partial_multi (seven jobs) + clsr_pgemm(dPin, W_x^T) at the default widths (D = n = 40);
+ * clsr_enc_bwd_fused_supported says whether a shape is covered, everything else keeps those two. */
 int clsr_enc_bwd_fused_supported(int D, int n, int NX);
 int clsr_enc_bwd_fused_parts(long M);
 long clsr_enc_bwd_fused_workspace_floats(long M, int product);
