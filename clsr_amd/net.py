@@ -133,6 +133,8 @@ class CLSRNet(object):
         self.stream_alias = {} if os.environ.get("CLSR_FOLD_AUX") == "0" else {"@aux": "@lt"}
         self.side_priority = int(os.environ.get("CLSR_SIDE_PRIORITY", "0"))
         self.dw_priority = int(os.environ.get("CLSR_DW_PRIORITY", "0"))
+        self.late_attmat_dw = bool(os.environ.get("CLSR_LATE_ATTMAT_DW"))   # A/B: attention_mat weight gradient behind the encoder tail
+        self._late_dw = None
         self.sort_late = bool(os.environ.get("CLSR_SORT_LATE"))     # A/B: history-id sort beside the heads instead of at the start of the step (measured: no difference, 3.66 ms both)
         self.early_scatter = not os.environ.get("CLSR_NO_EARLY_SCATTER")   # A/B: row scatters of the user / target lookups beside the encoder-backward tail instead of behind it
         self.enc_bwd_fused = not os.environ.get("CLSR_NO_ENC_BWD_FUSED")   # A/B: one pass over dPin for the seven encoder-side weight gradients + d(hist) (csrc/encbwd.hip)
@@ -229,7 +231,7 @@ class CLSRNet(object):
         return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook),
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
                 self.lazy, self.rnn_first, self.lt_att_first, self.tick_early, self.hist_grad_two, self.dw_batch_late, self.bn_bwd_fused, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h, self.flush_side, self.l1_bwd_2pass,
-                self.split_g2, self.rnn_chunks, self.enc_bwd_fused, self.early_scatter, self.sort_late, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
+                self.split_g2, self.rnn_chunks, self.enc_bwd_fused, self.early_scatter, self.sort_late, self.late_attmat_dw, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
 
@@ -1231,7 +1233,14 @@ class CLSRNet(object):
             self._gemm(dU, A0, key + ".Wu^T", Hn * T, A0, Q, da, Q, acc=1)
         if not qh:
             self._gemm(dV, A0, key + ".Wv^T", R, A0, Q, dq, Q, acc=1)
-        self._dw(keys, Dk, da, Q, Hn * T, Dk, Q, Gd[scope + "attention_mat"], Q)
+        job = lambda: self._dw(keys, Dk, da, Q, Hn * T, Dk, Q, Gd[scope + "attention_mat"], Q)
+        if self.late_attmat_dw and key == "st" and self._ws_tag == "" and self._late_dw is not None:
+            # the last weight gradient of the short-term attention: queued behind the others on the weight-gradient
+            # stream it ran underneath the latency-bound backward-through-time launch (+60-70 us there); issued behind
+            # the encoder tail instead (operands stay untouched until the next step)
+            self._late_dw.append(job)
+        else:
+            job()
         self._gemm(da, Q, key + ".A^T", Hn * T, Q, Dk, dkeys, Dk, acc=1)
         return dq
 
@@ -1739,6 +1748,7 @@ class CLSRNet(object):
         D, Du, H, Di, Dc = self.D, self.Du, self.H, self.Di, self.Dc
         hs = 1 if f.get("compact") else G
         seq_len, ls = f["seq_len"], hs
+        self._late_dw = [] if self.late_attmat_dw else None
         # gradient accumulators (zeroed every step) and the involved-row flags depend on the feed only: zeroed /
         # marked on a side stream underneath the forward's first kernels
         zpool = self._buf("zero_pool", Hn * T * (2 * D + H) + B * D * 2 + Hn * (3 * D + H + Du))
@@ -1909,6 +1919,9 @@ class CLSRNet(object):
         # ---- join the long-term attention branch; its d(hist) contribution was accumulated separately (NOT the early row
         #      scatters: nothing reads their tables before the update phase -- every wait is a barrier packet in front of
         #      the history-row sums)
+        late, self._late_dw = self._late_dw, None
+        for job in late or ():
+            job()
         side_dense = self.flush_side and self.overlap and self.dw_stream
         self._join(but=("@scat",))
         if side_dense:
