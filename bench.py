@@ -375,8 +375,12 @@ def main():
     # The step's compute stream outranks its side streams: the weight-gradient kernels beside it are MFMA-saturated and
     # starve whatever shares a CU with them (r03: 3.72 -> 3.63 ms).  Safe under data parallelism only because the step
     # keeps THREE streams of its own (net.stream_alias): with four, RCCL's stream was a fifth hardware queue and the
-    # step went from 4.0 to 6.6 ms.  CLSR_MAIN_PRIORITY overrides (0 = normal, -1 = high).
-    prio = int(os.environ.get("CLSR_MAIN_PRIORITY", "-1"))
+    # step went from 4.0 to 6.6 ms.  With MORE than one rank the default stays at equal priorities: RCCL's kernels (a few
+    # persistent workgroups on a normal-priority stream) would have to find their CUs between the dispatches of a
+    # high-priority stream, and that has never run in this build environment -- the measured world-1 result (4.03 ms both
+    # ways) says nothing about it.  CLSR_MAIN_PRIORITY overrides (0 = normal, -1 = high).
+    multi_rank = wl.stepper is not None and world > 1
+    prio = int(os.environ.get("CLSR_MAIN_PRIORITY", "0" if multi_rank else "-1"))
     stream = torch.cuda.Stream(priority=prio)
     host_losses = torch.zeros(8, dtype=torch.float64).pin_memory()
     extra, modes = [], {}

@@ -293,7 +293,8 @@ class SequentialBaseModel(BaseModel):
         if self._stream is None:
             # the compute stream outranks the side streams of the step (their MFMA-saturated weight-gradient kernels
             # starve whatever shares a CU with them); see bench.py for the stream-count condition under data parallelism
-            prio = int(os.environ.get("CLSR_MAIN_PRIORITY", "-1"))
+            multi_rank = self._dist is not None and self._dist.get_world_size(self._group) > 1
+            prio = int(os.environ.get("CLSR_MAIN_PRIORITY", "0" if multi_rank else "-1"))   # (more than one rank: bench.py)
             self._stream = torch.cuda.Stream(device=self.net.device, priority=prio)
         return torch.cuda.stream(self._stream)
 
