@@ -610,6 +610,11 @@ static int pgemm_dispatch_one(const PGemmArgs& a, hipStream_t s) {
   // the BN-backward epilogue has no 8-out-tile fast variant (register spills): two column chunks of the
   // 5-tile one (blockIdx.y) beat the generic kernel (31 -> ~17 us for the 20 480 x 64 -> 100 logit layer)
   if (ot == 8 && a.ez) ot = 5;
+  // few positions (the row-level heads: 20 480 rows = 640 wave-tiles on 1 024 SIMDs): every wave owns ONE tile and its
+  // MFMA chain is the kernel's critical path -- three out-tiles per wave and more column chunks (blockIdx.y) instead of
+  // five or eight: 3.69 -> 3.65 ms per step (A/B switch CLSR_PGEMM_SMALLM_OT: 0 = off)
+  static const int small_ot = []() { const char* e = getenv("CLSR_PGEMM_SMALLM_OT"); return e ? atoi(e) : 3; }();
+  if (small_ot && a.M <= 32768 && ot > small_ot) ot = small_ot;
   if (ot == 3) return launch_pgemm<3>(a, s);
   if (ot == 5) return launch_pgemm<5>(a, s);
   return launch_pgemm<8>(a, s);

@@ -1,3 +1,3 @@
-bash scripts/prof_step.sh r3ks --config kuaishou > /dev/null 2>&1
-tail -2 gpurun_out/r3ks_timeline.txt
-head -24 gpurun_out/r3ks_stats.md | cut -c1-130
+python -m pytest tests/test_kernels_gpu.py tests/test_step_gpu.py tests/test_siblings_gpu.py tests/test_fullsize_gpu.py -q -x 2>&1 | tail -2
+bash scripts/prof_step.sh r3g > /dev/null 2>&1
+awk '$1>1100 && $1<1480' gpurun_out/r3g_timeline.txt | cut -c1-110
