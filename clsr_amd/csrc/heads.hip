@@ -315,6 +315,133 @@ extern "C" int clsr_softmax_loss(const float* logit, const float* labels, long P
   return CLSR_OK;
 }
 
+// ------------------------------------------------------------------ logit head: output layer + loss + its backward
+// The three row-local launches at the turn of the step -- clsr_mlp_out_fwd (logit), clsr_softmax_loss (loss, dlogit),
+// clsr_mlp_out_bwd (dy1, batch-norm sums, d w_out / d b_out) -- as ONE: a wave owns whole softmax groups (G consecutive
+// rows), lane c owns column c of z1 (C1 <= 64), the G logits are wave sums.  Each of the three was a ~5 us link of the
+// dependent chain of the heads.  Same partial layouts as clsr_mlp_out_bwd.
+#define MT_MAXG 8
+// wave64 sum on the DPP path (row_shr 1/2/4/8 = inclusive scan inside each row of 16, row_bcast 15 / 31 across the rows,
+// total in lane 63, read back as a scalar): ~12 VALU instructions instead of the six dependent ds_bpermute round trips
+// of __shfl_xor (20 of those per trip were this kernel's whole critical path)
+#define MT_DPP_STEP(x, ctrl, rm) \
+  (x) += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), (rm), 0xf, false))
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  MT_DPP_STEP(v, 0x111, 0xf);
+  MT_DPP_STEP(v, 0x112, 0xf);
+  MT_DPP_STEP(v, 0x114, 0xf);
+  MT_DPP_STEP(v, 0x118, 0xf);
+  MT_DPP_STEP(v, 0x142, 0xa);
+  MT_DPP_STEP(v, 0x143, 0xc);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__global__ void __launch_bounds__(256) mlp_tail_softmax_kernel(
+    const float* __restrict__ z1, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ w_out,
+    const float* __restrict__ b_out, const float* __restrict__ labels, long P, int G, int C1, float lscale,
+    double* __restrict__ loss_out, float* __restrict__ logit, float* __restrict__ dlogit_out, float* __restrict__ dy1,
+    double* __restrict__ bn_partial, float* __restrict__ w_partial) {
+  __shared__ double red[2][4][64];
+  __shared__ float redw[4][64];
+  __shared__ float redb[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool cv = lane < C1;
+  const int c = cv ? lane : 0;
+  const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c], wo = cv ? w_out[c] : 0.f, bo = b_out[0];
+  double s1 = 0.0, s2 = 0.0;
+  float sw = 0.f, sb = 0.f, local = 0.f;
+  // MT_NG groups per trip, every phase unrolled over all of them: the loads of 4 x G rows are in flight together and the
+  // 4 x G wave sums are independent chains (one group at a time, the kernel took 30 us: a serial chain of load -> sum)
+  constexpr int MT_NG = 4;
+  for (long p0 = ((long)blockIdx.x * 4 + wave) * MT_NG; p0 < P; p0 += (long)gridDim.x * 4 * MT_NG) {
+    float zz[MT_NG][MT_MAXG], lg[MT_NG][MT_MAXG], lb[MT_NG][MT_MAXG];
+#pragma unroll
+    for (int k = 0; k < MT_NG; ++k) {
+      const long p = min(p0 + k, P - 1);        // (a group past the end repeats the last one; masked below)
+#pragma unroll
+      for (int g = 0; g < MT_MAXG; ++g)
+        if (g < G) { zz[k][g] = z1[(p * G + g) * C1 + c]; lb[k][g] = labels[p * G + g]; }
+    }
+#pragma unroll
+    for (int k = 0; k < MT_NG; ++k)
+#pragma unroll
+      for (int g = 0; g < MT_MAXG; ++g)
+        if (g < G) lg[k][g] = wave_sum_dpp(fmaxf(zz[k][g] * sc + sh, 0.f) * wo) + bo;
+#pragma unroll
+    for (int k = 0; k < MT_NG; ++k) {
+      const long p = p0 + k;
+      const bool pv = p < P;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int g = 0; g < MT_MAXG; ++g)
+        if (g < G) mx = fmaxf(mx, lg[k][g]);
+      float sum = 0.f;
+#pragma unroll
+      for (int g = 0; g < MT_MAXG; ++g)
+        if (g < G) sum += __expf(lg[k][g] - mx);
+      const float lse = mx + __logf(sum);
+      int npos = 0;
+#pragma unroll
+      for (int g = 0; g < MT_MAXG; ++g)
+        if (g < G && lb[k][g] == 1.0f) { ++npos; if (pv) local -= (lg[k][g] - lse); }
+#pragma unroll
+      for (int g = 0; g < MT_MAXG; ++g)
+        if (g < G && pv) {
+          const long b = p * G + g;
+          const float sm = __expf(lg[k][g] - lse);
+          const float dl = lscale * ((float)npos * sm - (lb[k][g] == 1.0f ? 1.0f : 0.0f));
+          if (lane == 0) { logit[b] = lg[k][g]; if (dlogit_out) dlogit_out[b] = dl; }
+          const float y = zz[k][g] * sc + sh;
+          const float d = (cv && y > 0.f) ? wo * dl : 0.f;
+          if (cv) dy1[b * C1 + c] = d;
+          const float xh = (zz[k][g] - mu) * is;
+          s1 += d; s2 += (double)d * xh;
+          sw += fmaxf(y, 0.f) * dl;
+          sb += dl;
+        }
+    }
+  }
+  // ONE double atomic per workgroup for the loss (one per wave -- 1 024 on one address -- took 20 us)
+  __shared__ float redl[4];
+  red[0][wave][lane] = s1; red[1][wave][lane] = s2; redw[wave][lane] = sw;
+  if (lane == 0) { redb[wave] = sb; redl[wave] = local; }
+  __syncthreads();
+  if (threadIdx.x == 64) {
+    const float l = (redl[0] + redl[1]) + (redl[2] + redl[3]);
+    if (l != 0.f) atomicAdd(loss_out, (double)l * lscale);
+  }
+  if (threadIdx.x < C1) {
+    const int t = threadIdx.x;
+    bn_partial[((long)blockIdx.x * 2 + 0) * C1 + t] = (red[0][0][t] + red[0][1][t]) + (red[0][2][t] + red[0][3][t]);
+    bn_partial[((long)blockIdx.x * 2 + 1) * C1 + t] = (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]);
+    w_partial[(long)blockIdx.x * (C1 + 4) + t] = (redw[0][t] + redw[1][t]) + (redw[2][t] + redw[3][t]);
+  }
+  if (threadIdx.x == 0) w_partial[(long)blockIdx.x * (C1 + 4) + C1] = (redb[0] + redb[1]) + (redb[2] + redb[3]);
+}
+
+static int mlp_tail_blocks(long P) {
+  long b = (P + 15) / 16;          // four groups per wave and trip
+  static const int cap = []() { const char* e = getenv("CLSR_MLP_TAIL_BLOCKS"); return e ? atoi(e) : 256; }();
+  return (int)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+extern "C" int clsr_mlp_tail_softmax_supported(int G, int C1) { return G >= 1 && G <= MT_MAXG && C1 >= 4 && C1 <= 64; }
+extern "C" int clsr_mlp_tail_softmax_parts(long P) { return mlp_tail_blocks(P); }
+// reference: the output layer of _fcn_net (base_model.py:695-708), _compute_data_loss "softmax" (base_model.py:215-235)
+// and their gradients.  loss_out += -lscale * sum over the positives of log softmax_group(logit); dlogit_out optional.
+extern "C" int clsr_mlp_tail_softmax(const float* z1, const float* scale, const float* shift, const float* mean,
+                                     const float* invstd, const float* w_out, const float* b_out, const float* labels,
+                                     long P, int G, int C1, float lscale, double* loss_out, float* logit,
+                                     float* dlogit, float* dy1, double* bn_partial, float* w_partial, void* stream) {
+  CLSR_CHECK_ARG(z1 && scale && shift && mean && invstd && w_out && b_out && labels && loss_out && logit && dy1 &&
+                 bn_partial && w_partial && P > 0);
+  CLSR_CHECK_SUPPORTED(clsr_mlp_tail_softmax_supported(G, C1));
+  hipLaunchKernelGGL(mlp_tail_softmax_kernel, dim3(mlp_tail_blocks(P)), dim3(256), 0, (hipStream_t)stream, z1, scale,
+                     shift, mean, invstd, w_out, b_out, labels, P, G, C1, lscale, loss_out, logit, dlogit, dy1,
+                     bn_partial, w_partial);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
 // ------------------------------------------------------------------ contrastive loss
 // mode 1 (triplet): four hinge terms on element-wise squared distances; mode 0 (bpr): four softplus
 // terms on dot products.  Every term is sum_b mask_b * term_b / sum_b mask_b, mask = len > threshold,

@@ -133,6 +133,8 @@ class CLSRNet(object):
         self.stream_alias = {} if os.environ.get("CLSR_FOLD_AUX") == "0" else {"@aux": "@lt"}
         self.side_priority = int(os.environ.get("CLSR_SIDE_PRIORITY", "0"))
         self.dw_priority = int(os.environ.get("CLSR_DW_PRIORITY", "0"))
+        self.fused_logit_tail = not os.environ.get("CLSR_NO_FUSED_LOGIT_TAIL")   # A/B: output layer + softmax loss + their backward in one launch
+        self._defer_logit_out = False
         self.late_attmat_dw = bool(os.environ.get("CLSR_LATE_ATTMAT_DW"))   # A/B: attention_mat weight gradient behind the encoder tail
         self._late_dw = None
         self.sort_late = bool(os.environ.get("CLSR_SORT_LATE"))     # A/B: history-id sort beside the heads instead of at the start of the step (measured: no difference, 3.66 ms both)
@@ -231,7 +233,7 @@ class CLSRNet(object):
         return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook),
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
                 self.lazy, self.rnn_first, self.lt_att_first, self.tick_early, self.hist_grad_two, self.dw_batch_late, self.bn_bwd_fused, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h, self.flush_side, self.l1_bwd_2pass,
-                self.split_g2, self.rnn_chunks, self.enc_bwd_fused, self.early_scatter, self.sort_late, self.late_attmat_dw, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
+                self.split_g2, self.rnn_chunks, self.enc_bwd_fused, self.early_scatter, self.sort_late, self.late_attmat_dw, self.fused_logit_tail, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
 
@@ -1257,21 +1259,30 @@ class CLSRNet(object):
         st, parts = self._stats_buf(B, C1) if training else (None, 0)
         self._gemm(z0, C0, key + ".W1", B, C0, C1, z1, C1, bias=P[nn + "b_nn_layer1"], aff=bn0, stats=st)
         self._bn_fwd(bn1, st, parts, B, training)
-        call("clsr_mlp_out_fwd", z1, bn1.scale, bn1.shift, P[nn + "w_nn_output"], P[nn + "b_nn_output"], B, C1, logit)
+        if not (key == "lg" and self._defer_logit_out):   # (training step: the logits come out of clsr_mlp_tail_softmax)
+            call("clsr_mlp_out_fwd", z1, bn1.scale, bn1.shift, P[nn + "w_nn_output"], P[nn + "b_nn_output"], B, C1, logit)
         return logit
 
-    def _mlp_bwd(self, key, nn, dlogit, X, ldx, K0, K0_real, sizes, B):
-        """Returns dX [B, K0] (K0 = padded input width)."""
+    def _mlp_bwd(self, key, nn, dlogit, X, ldx, K0, K0_real, sizes, B, tail=None):
+        """Returns dX [B, K0] (K0 = padded input width).  ``tail = (labels, groups, rows per group, loss scale)``: the
+        output layer, the group-softmax loss and their backward run as ONE launch (the logits were not computed by the
+        forward: ``_defer_logit_out``)."""
         P, Gd = self.P, self.Gd
         C0, C1 = sizes
         bn0, bn1 = self.bn[nn + "batch_normalization/"], self.bn[nn + "batch_normalization_1/"]
         z0, z1 = self._buf(key + ".z0", B, C0), self._buf(key + ".z1", B, C1)
         dz1, dz0 = self._buf(key + ".dz1", B, C1), self._buf(key + ".dz0", B, C0)
-        parts = query("clsr_mlp_out_bwd_parts", B, C1)
+        parts = query("clsr_mlp_tail_softmax_parts", tail[1]) if tail else query("clsr_mlp_out_bwd_parts", B, C1)
         bnp = self._buf("mlp.bnp", 512 * 2 * 256, dtype=torch.float64)[: parts * 2 * C1]
         wp = self._buf("mlp.wp." + key, 512 * (256 + 4))[: parts * (C1 + 4)]   # own buffer: reduced at the flush
-        call("clsr_mlp_out_bwd", dlogit, z1, bn1.scale, bn1.shift, bn1.mean, bn1.invstd, P[nn + "w_nn_output"],
-             B, C1, dz1, bnp, wp)
+        if tail:
+            labels, ngroups, Gl, lscale = tail
+            call("clsr_mlp_tail_softmax", z1, bn1.scale, bn1.shift, bn1.mean, bn1.invstd, P[nn + "w_nn_output"],
+                 P[nn + "b_nn_output"], labels, ngroups, Gl, C1, lscale, self.losses[0:], self._buf(key + ".logit", B),
+                 dlogit, dz1, bnp, wp)
+        else:
+            call("clsr_mlp_out_bwd", dlogit, z1, bn1.scale, bn1.shift, bn1.mean, bn1.invstd, P[nn + "w_nn_output"],
+                 B, C1, dz1, bnp, wp)
         self._rp(wp, parts, C1 + 4, C1, Gd[nn + "w_nn_output"])
         self._rp(wp[C1:], parts, C1 + 4, 1, Gd[nn + "b_nn_output"])
         self._bn_bwd_from_partial(bn1, bnp, parts, dz1, z1, B)
@@ -1806,17 +1817,25 @@ class CLSRNet(object):
                  1 if hp.contrastive_loss == "triplet" else 0, float(hp.triplet_margin),
                  float(hp.contrastive_loss_weight), f["denom"], self.losses[2:], dL, dS, dM, dR)
 
-        out = self._forward(f, True, contrastive, zero_and_mark)
+        Gl = hp.train_num_ngs + 1
+        lscale = 1.0 / ((B // Gl) * self.dp_world)
+        # output layer of the logit MLP + data loss + their backward as ONE launch at the turn of the step
+        fused_tail = (self.fused_logit_tail and B % Gl == 0
+                      and bool(query("clsr_mlp_tail_softmax_supported", Gl, self.L1)))
+        self._defer_logit_out = fused_tail
+        try:
+            out = self._forward(f, True, contrastive, zero_and_mark)
+        finally:
+            self._defer_logit_out = False
         assert self.last_shape == (B, T, G, Hn)
         # ---- losses on the forward outputs
         dlogit = self._buf("dlogit", B)
-        Gl = hp.train_num_ngs + 1
-        call("clsr_softmax_loss", out["logit"], f["labels"], B // Gl, Gl, 1.0 / ((B // Gl) * self.dp_world),
-             self.losses[0:], dlogit)
+        if not fused_tail:
+            call("clsr_softmax_loss", out["logit"], f["labels"], B // Gl, Gl, lscale, self.losses[0:], dlogit)
         # ---- logit MLP, fusion, alpha MLP (their four small weight gradients: ONE multi-job launch at the end)
         with self._dw_batched(late=True):
             dmo = self._mlp_bwd("lg", "sequential/logit_fcn/nn_part/", dlogit, out["model_output"], 2 * D, 2 * D, 2 * D,
-                                (self.L0, self.L1), B)
+                                (self.L0, self.L1), B, tail=(f["labels"], B // Gl, Gl, lscale) if fused_tail else None)
             self._join()              # the contrastive branch: its dL / dS are accumulated into from here on
             if not hp.manual_alpha:
                 dal = self._buf("dalpha_logit", B)

@@ -358,6 +358,16 @@ int clsr_alpha_fuse_fwd(const float* alpha_logit, float manual_alpha, const floa
 int clsr_alpha_fuse_bwd(const float* dmo, const float* alpha, float manual_alpha, const float* L,
                         const float* S, long Hn, int G, int D, float* dalpha_logit, float* dL, float* dS,
                         float* dtarget, void* stream);
+/* output layer of the logit MLP + group-softmax loss + the backward of both in ONE launch (csrc/heads.hip): replaces
+ * clsr_mlp_out_fwd -> clsr_softmax_loss -> clsr_mlp_out_bwd of a training step (base_model.py:695-708, :215-235).  P
+ * groups of G consecutive rows, z1 [P*G, C1]; partial layouts of clsr_mlp_out_bwd with clsr_mlp_tail_softmax_parts(P)
+ * blocks; dlogit may be NULL. */
+int clsr_mlp_tail_softmax_supported(int G, int C1);
+int clsr_mlp_tail_softmax_parts(long P);
+int clsr_mlp_tail_softmax(const float* z1, const float* scale, const float* shift, const float* mean,
+                          const float* invstd, const float* w_out, const float* b_out, const float* labels,
+                          long P, int G, int C1, float lscale, double* loss_out, float* logit,
+                          float* dlogit, float* dy1, double* bn_partial, float* w_partial, void* stream);
 int clsr_softmax_loss(const float* logit, const float* labels, long P, int G, float scale,
                       double* loss_out, float* dlogit, void* stream);
 int clsr_contrastive(const float* L, const float* S, const float* M, const float* R, const int* seq_len,

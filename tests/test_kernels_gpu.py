@@ -1459,3 +1459,56 @@ def test_fused_encoder_backward_one_pass_over_dpin(M):
         close(o, e, rtol=2e-4, atol=tol, name="product %d" % i)
     close(db, P.sum(0), rtol=2e-4, atol=tol, name="bias sums")
     close(dhist, d(dhist0) + P @ Wx.T, rtol=2e-4, atol=2e-4, name="d(hist)")
+
+
+@pytest.mark.parametrize("P,G,C1", [(4096, 5, 64), (37, 3, 40), (5, 8, 4), (700, 1, 64)])
+def test_mlp_tail_softmax_equals_the_three_launches(P, G, C1):
+    """clsr_mlp_tail_softmax (output layer + group-softmax loss + their backward in one launch) == clsr_mlp_out_fwd ->
+    clsr_softmax_loss -> clsr_mlp_out_bwd, and the float64 restatement of the same chain."""
+    g = torch.Generator().manual_seed(P * 31 + G)
+    f32 = torch.float32
+    B = P * G
+    z = dev(rnd(g, B, C1), f32)
+    sc, sh = dev(rnd(g, C1).abs() + 0.5, f32), dev(rnd(g, C1, scale=0.3), f32)
+    mu, isd = dev(rnd(g, C1, scale=0.2), f32), dev(rnd(g, C1).abs() + 0.5, f32)
+    w, b = dev(rnd(g, C1, scale=0.5), f32), dev(rnd(g, 1), f32)
+    labels = torch.zeros(P, G)
+    labels[:, 0] = 1.0
+    if G > 2:
+        labels[::3, 2] = 1.0          # groups with two positives
+    labels = dev(labels.reshape(-1), f32)
+    lscale = 1.0 / P
+    # the three launches
+    logit0, dl0 = torch.zeros(B, device="cuda"), torch.zeros(B, device="cuda")
+    loss0 = torch.zeros(1, dtype=torch.float64, device="cuda")
+    call("clsr_mlp_out_fwd", z, sc, sh, w, b, B, C1, logit0)
+    call("clsr_softmax_loss", logit0, labels, P, G, lscale, loss0, dl0)
+    n0 = query("clsr_mlp_out_bwd_parts", B, C1)
+    dy0 = torch.zeros(B, C1, device="cuda")
+    bnp0 = torch.zeros(n0, 2, C1, dtype=torch.float64, device="cuda")
+    wp0 = torch.zeros(n0, C1 + 4, device="cuda")
+    call("clsr_mlp_out_bwd", dl0, z, sc, sh, mu, isd, w, B, C1, dy0, bnp0, wp0)
+    # one launch
+    assert query("clsr_mlp_tail_softmax_supported", G, C1)
+    n1 = query("clsr_mlp_tail_softmax_parts", P)
+    logit1, dl1 = torch.zeros(B, device="cuda"), torch.zeros(B, device="cuda")
+    loss1 = torch.zeros(1, dtype=torch.float64, device="cuda")
+    dy1 = torch.full((B, C1), 7.0, device="cuda")
+    bnp1 = torch.full((n1, 2, C1), 7.0, dtype=torch.float64, device="cuda")
+    wp1 = torch.full((n1, C1 + 4), 7.0, device="cuda")
+    call("clsr_mlp_tail_softmax", z, sc, sh, mu, isd, w, b, labels, P, G, C1, lscale, loss1, logit1, dl1, dy1, bnp1, wp1)
+    torch.cuda.synchronize()
+    close(logit1, logit0, rtol=1e-5, atol=1e-5, name="logit")
+    close(dl1, dl0, rtol=2e-5, atol=1e-7, name="dlogit")
+    close(loss1, loss0, rtol=1e-6, atol=1e-9, name="loss")
+    close(dy1, dy0, rtol=2e-5, atol=1e-7, name="dy1")
+    close(bnp1.sum(0), bnp0.sum(0), rtol=1e-5, atol=1e-6, name="bn sums")
+    close(wp1[:, :C1 + 1].sum(0), wp0[:, :C1 + 1].sum(0), rtol=2e-5, atol=2e-5, name="w_out / b_out sums")
+    # float64 restatement
+    zd, lab = z.double().cpu(), labels.double().cpu().reshape(P, G)
+    y = zd * sc.double().cpu() + sh.double().cpu()
+    lg = (y.clamp_min(0) * w.double().cpu()).sum(1) + b.double().cpu()
+    lsm = torch.log_softmax(lg.reshape(P, G), 1)
+    close(loss1, -(lsm * lab).sum().reshape(1) * lscale, rtol=1e-5, atol=1e-7, name="loss vs float64")
+    dlg = (lscale * (lab.sum(1, keepdim=True) * lsm.exp() - lab)).reshape(-1)
+    close(dy1, (dlg[:, None] * w.double().cpu()) * (y > 0), rtol=1e-4, atol=1e-6, name="dy1 vs float64")
