@@ -54,10 +54,26 @@ static inline int clsr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 #ifdef __HIPCC__
 // ---- wave64 reductions -------------------------------------------------------------
+// float sums / maxima run on the DPP path: row_shr 1/2/4/8 = inclusive scan inside each row of 16 lanes, row_bcast 15 /
+// 31 across the rows, total in lane 63, read back as a scalar (every lane gets it) -- ~12 VALU instructions instead of
+// six DEPENDENT ds_bpermute round trips (__shfl_xor), which were the critical path of the per-row softmax kernels.
+// -DCLSR_NO_DPP_REDUCE: the shuffle forms (A/B builds).
+#define CLSR_DPP_F(x, old, ctrl, rm) \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (old)), __builtin_bit_cast(int, (x)), (ctrl), (rm), 0xf, false))
 __device__ __forceinline__ float wave_sum(float v) {
+#ifdef CLSR_NO_DPP_REDUCE
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+#else
+  v += CLSR_DPP_F(v, 0.0f, 0x111, 0xf);
+  v += CLSR_DPP_F(v, 0.0f, 0x112, 0xf);
+  v += CLSR_DPP_F(v, 0.0f, 0x114, 0xf);
+  v += CLSR_DPP_F(v, 0.0f, 0x118, 0xf);
+  v += CLSR_DPP_F(v, 0.0f, 0x142, 0xa);
+  v += CLSR_DPP_F(v, 0.0f, 0x143, 0xc);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+#endif
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -65,15 +81,35 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
+#ifdef CLSR_NO_DPP_REDUCE
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
+#else
+  // (a lane without a source keeps its own value: max(v, v))
+  v = fmaxf(v, CLSR_DPP_F(v, v, 0x111, 0xf));
+  v = fmaxf(v, CLSR_DPP_F(v, v, 0x112, 0xf));
+  v = fmaxf(v, CLSR_DPP_F(v, v, 0x114, 0xf));
+  v = fmaxf(v, CLSR_DPP_F(v, v, 0x118, 0xf));
+  v = fmaxf(v, CLSR_DPP_F(v, v, 0x142, 0xa));
+  v = fmaxf(v, CLSR_DPP_F(v, v, 0x143, 0xc));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+#endif
 }
 // sum over the 16 lanes that share (lane >> 4)
 __device__ __forceinline__ float row16_sum(float v) {
+#ifdef CLSR_NO_DPP_REDUCE
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+#else
+  // butterfly inside a row of 16: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror -- every lane gets the total
+  v += CLSR_DPP_F(v, 0.0f, 0xB1, 0xf);
+  v += CLSR_DPP_F(v, 0.0f, 0x4E, 0xf);
+  v += CLSR_DPP_F(v, 0.0f, 0x141, 0xf);
+  v += CLSR_DPP_F(v, 0.0f, 0x140, 0xf);
+  return v;
+#endif
 }
 __device__ __forceinline__ double row16_sum_d(double v) {
 #pragma unroll

@@ -12,7 +12,8 @@ for f in "$@"; do
   b=$(basename $f .hip)
   /opt/rocm/bin/hipcc $FL $flags -c clsr_amd/csrc/$b.hip -o build/abl/${b}_$name.o
   objs=$(echo "$objs" | grep -v "/$b.o")
-  objs="$objs build/abl/${b}_$name.o"
+  objs="$objs
+"build/abl/${b}_$name.o; objs=$(printf "%b" "$objs")
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/abl/lib_$name.so $objs
 echo built build/abl/lib_$name.so
