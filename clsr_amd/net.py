@@ -478,16 +478,18 @@ class CLSRNet(object):
         """The current stream waits for the finished branches (all of them, those named ``only``, or all ``but`` one).
         ``keep``: the branches stay on the list -- another stream will join them again."""
         main = ops.current_stream()
-        rest = []
+        rest, last = [], {}
         but = but if isinstance(but, tuple) else (but,)
         for tag, ev, sid in self._joins:
             if (only is None or tag == only) and tag not in but:
                 if sid != main.cuda_stream:      # (work of this very stream is ordered already)
-                    ops.stream_wait(main, ev)
+                    last[sid] = ev               # branches that shared a stream: its LAST event covers the earlier ones
                 if keep:
                     rest.append((tag, ev, sid))
             else:
                 rest.append((tag, ev, sid))
+        for ev in last.values():                 # (every wait is a barrier packet of ~5 us in front of the next kernel)
+            ops.stream_wait(main, ev)
         self._joins = rest
 
     # ------------------------------------------------------------------ buffers

@@ -151,7 +151,10 @@ def test_catalogue_dims_match_oracle_on_a_slice():
     gs = max(float(g.abs().max()) for n, g in grads.items() if n in net.captured["dense"])
     for name, g in net.captured["dense"].items():
         d = float((g.cpu().double() - grads[name].reshape(g.shape)).abs().max())
-        assert d <= 2e-3 * float(grads[name].abs().max()) + 1e-6 * gs, (name, d)
+        # floor: 3e-6 of the gradient scale.  The biases in front of a batch-norm have an analytically ZERO gradient; what
+        # is compared there is the fp32 rounding of a sum of O(gs) terms -- 1e-6 * gs is ONE ulp of such a term (round 3:
+        # 1.49e-7 against a floor of 1.37e-7 after the reduction order inside the statistics kernels changed)
+        assert d <= 2e-3 * float(grads[name].abs().max()) + 3e-6 * gs, (name, d)
 
 
 def test_catalogue100m_full_size_step():
