@@ -21,6 +21,7 @@
 // (D = Du = H = 40, three encoders); anything else keeps the generic kernels (clsr_enc_bwd_fused_supported).
 #include "common.h"
 #include "clsr_hip.h"
+#include <utility>
 
 // diagnosis builds (scripts/build_variant.sh): -DEB_ABL_NOMFMA (no matrix instructions), -DEB_ABL_NODH (no d(hist)),
 // -DEB_ABL_NOFETCH (operands of the first stage only)
@@ -79,6 +80,15 @@ __device__ __host__ constexpr int eb_count(int w) {
   int n = 0;
   for (int pi = 0; pi < eb_nt(w); ++pi)
     for (int xt = 0; xt < EB_NXT; ++xt) n += eb_need(xt, eb_tile(w, pi)) ? 1 : 0;
+  return n;
+}
+__device__ __host__ constexpr int eb_acc(int w, int pi, int xt) {
+  int n = 0;
+  for (int p = 0; p < eb_nt(w); ++p)
+    for (int x = 0; x < EB_NXT; ++x) {
+      if (p == pi && x == xt) return n;
+      n += eb_need(x, eb_tile(w, p)) ? 1 : 0;
+    }
   return n;
 }
 __device__ __host__ constexpr bool eb_xused(int w, int xt) {
@@ -171,8 +181,9 @@ __device__ __forceinline__ void eb_wave(const EncBwdArgs& a, float* Ps, float* X
 }
 
 // scatter one wave's accumulator tiles into the partial workspaces (layout of dw_body / clsr_dw_reduce_batch)
-template <int W>
-__device__ __forceinline__ void eb_store(const EncBwdArgs& a, const f32x4 (&acc)[eb_count(W)], const float (&bsum)[8],
+// ACCB (speed-mode kernel): the bias sums are row 40 of the hist product -- a row of ones in the left operand tile
+template <int W, bool ACCB = false>
+__device__ __forceinline__ void eb_store(float* const (&ws)[7], const f32x4 (&acc)[eb_count(W)], const float (&bsum)[8],
                                          const int lane, const int part, const int nparts) {
   const int i = lane & 15, g = lane >> 4;
   int n = 0;
@@ -187,20 +198,26 @@ __device__ __forceinline__ void eb_store(const EncBwdArgs& a, const f32x4 (&acc)
       const int kb = 16 * xt - eb_x0(p) + 4 * g;                   // first of the lane's four rows
       if (nl >= 0 && nl < eb_N(p)) {
         const int nc = nl / 80, nn = nl - nc * 80;
-        float* dst = a.ws[p] + ((long)nc * nparts + part) * EB_CHUNK + (nn >> 4) * 256 + (nn & 15);
+        float* dst = ws[p] + ((long)nc * nparts + part) * EB_CHUNK + (nn >> 4) * 256 + (nn & 15);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int k = kb + r;                                    // (one K chunk: K <= 80)
           if (k < eb_K(p)) dst[((k >> 4) * 5) * 256 + (k & 15) * 16] = acc[n][r];
         }
       }
+      if (ACCB && xt == 2 && g == 2) {       // row 40 = 16 * 2 + 4 * 2 + 0 of the hist tiles: sum over the positions
+        const int nl0 = 16 * pt + i, nc = nl0 / 80, nn = nl0 - nc * 80;
+        ws[0][((long)nc * nparts + part) * EB_CHUNK + 5 * 5 * 256 + nn] = acc[n][0];
+      }
       ++n;
     }
-    // bias sums ride in the partial of the hist product: db[column] = sum over the positions
-    const float b = col4_sum(bsum[pi]);
-    if (g == 0) {
-      const int nl = 16 * pt + i, nc = nl / 80, nn = nl - nc * 80;
-      a.ws[0][((long)nc * nparts + part) * EB_CHUNK + 5 * 5 * 256 + nn] = b;
+    if (!ACCB) {
+      // bias sums ride in the partial of the hist product: db[column] = sum over the positions
+      const float b = col4_sum(bsum[pi]);
+      if (g == 0) {
+        const int nl = 16 * pt + i, nc = nl / 80, nn = nl - nc * 80;
+        ws[0][((long)nc * nparts + part) * EB_CHUNK + 5 * 5 * 256 + nn] = b;
+      }
     }
   }
 }
@@ -315,7 +332,7 @@ __device__ __forceinline__ void eb_body(const EncBwdArgs& a, float* lds) {
   }
   store_prev();
   const int part = blockIdx.x, nparts = gridDim.x;
-  eb_store<W>(a, acc, bsum, lane, part, nparts);
+  eb_store<W>(a.ws, acc, bsum, lane, part, nparts);
 }
 
 
@@ -328,6 +345,177 @@ __global__ void __launch_bounds__(256) enc_bwd_fused_kernel(EncBwdArgs a) {
   else if (wave == 1) eb_body<1>(a, lds);
   else if (wave == 2) eb_body<2>(a, lds);
   else eb_body<3>(a, lds);
+}
+
+// ------------------------------------------------------------------------------------ speed mode (bf16 matrix pipe)
+// The seven weight gradients of the same tail from the bf16 dPin that the speed mode's backward-through-time launch
+// writes, on v_mfma_f32_16x16x32_bf16 (contraction over 32 positions per instruction: A = left-operand tile
+// [16 features][32 positions], B = dPin tile [32 positions][16 columns]).  Same tile ownership, accumulators and partial
+// layout as the fp32 kernel; the operands are staged TRANSPOSED ([feature][position] bf16 -- the position is the fast
+// index across the lanes of a wave, so the 2-byte LDS writes are conflict free and a lane's 8 consecutive positions are
+// one ds_read_b128; csrc/hdw.hip) in stages of 64 positions; the left operands are fp32 in memory and rounded to bf16
+// on the way (hp * r is formed in fp32 first), products are exact, accumulation fp32.  The bias sums are a row of ones in
+// the hist tile.  d(hist) stays with clsr_hgemm_hf32 (its A operand is the ROW-major dPin tile: a second LDS image).
+// Replaces clsr_hdw_partial_multi (seven jobs, 5 376 blocks, each staging its own slices of dPin: 480 us in the step).
+typedef __bf16 ebh_bf16x8 __attribute__((ext_vector_type(8)));
+#define EBH_LD 72                 // bf16 per LDS row: 64 positions + 8 (rows 144 B apart: 16 rows x 16 B without conflicts)
+#define EBH_ST 64                 // positions per stage
+struct EncBwdHArgs {
+  const __bf16* dPin;             // [M, 480] bf16
+  const float* hist; const float* hp1; const float* g1; const float* mprev; const float* TT; const float* hp2;
+  const float* g2;
+  float* ws[7];
+  long M;
+};
+
+// MFMAs of one 32-position step, unrolled at COMPILE time (accumulator indices must be constants: a loop that the
+// optimiser does not fold sends the 220 accumulators to scratch memory)
+template <int W, int X, int PI>
+__device__ __forceinline__ void ebh_one(f32x4 (&acc)[eb_count(W)], const ebh_bf16x8& av, const ebh_bf16x8 (&bv)[eb_nt(W)]) {
+  if constexpr (eb_need(X, eb_tile(W, PI))) {
+    constexpr int n = eb_acc(W, PI, X);
+    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv[PI], acc[n], 0, 0, 0);
+  }
+}
+template <int W, int X, int... PI>
+__device__ __forceinline__ void ebh_row(f32x4 (&acc)[eb_count(W)], const ebh_bf16x8& av, const ebh_bf16x8 (&bv)[eb_nt(W)],
+                                        std::integer_sequence<int, PI...>) {
+  (ebh_one<W, X, PI>(acc, av, bv), ...);
+}
+template <int W, int X>
+__device__ __forceinline__ void ebh_x(f32x4 (&acc)[eb_count(W)], const ebh_bf16x8 (&bv)[eb_nt(W)], const __bf16* xs) {
+  if constexpr (eb_xused(W, X)) {
+    const ebh_bf16x8 av = *reinterpret_cast<const ebh_bf16x8*>(xs + 16 * X * EBH_LD);
+    ebh_row<W, X>(acc, av, bv, std::make_integer_sequence<int, eb_nt(W)>{});
+  }
+}
+template <int W, int... X>
+__device__ __forceinline__ void ebh_all(f32x4 (&acc)[eb_count(W)], const ebh_bf16x8 (&bv)[eb_nt(W)], const __bf16* xs,
+                                        std::integer_sequence<int, X...>) {
+  (ebh_x<W, X>(acc, bv, xs), ...);
+}
+
+template <int W>
+__device__ __forceinline__ void ebh_body(const EncBwdHArgs& a, __bf16* lds) {
+  __bf16* Ps = lds;                                  // [480][EBH_LD]
+  __bf16* Xs = Ps + EB_NX * EBH_LD;                  // [EB_XW][EBH_LD]: hist@0 (ones@40) | hp1@48 | hp1*r1@96 | mprev@144 | TT@192 | hp2@272 | hp2*r2@320
+  const int lane = threadIdx.x & 63, tid = W * 64 + lane;
+  const int i = lane & 15, g = lane >> 4;
+  for (int e = tid; e < EB_XW * EBH_LD; e += 256) Xs[e] = (__bf16)0.f;      // (padding rows stay zero)
+  // staging plan: lane = position of the stage; wave W takes the 16-byte pieces c = W + 4 q of every row
+  ebh_bf16x8 pr[15];
+  f32x4 xh[3], x1[3], xr1[3], xm[3], xt[5], x2[3], xr2[3];
+  bool valid = false;
+  const long nst = (a.M + EBH_ST - 1) / EBH_ST;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](long st) {
+    long m = st * EBH_ST + lane;
+    valid = m < a.M;
+    m = valid ? m : a.M - 1;
+    const __bf16* dp = a.dPin + m * EB_NX;
+#pragma unroll
+    for (int q = 0; q < 15; ++q) pr[q] = *reinterpret_cast<const ebh_bf16x8*>(dp + 8 * (W + 4 * q));
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int c = W + 4 * q < 10 ? W + 4 * q : 0;      // (pieces past the 40 columns: loaded, not written)
+      xh[q] = ld4(a.hist + m * 40 + 4 * c);
+      x1[q] = ld4(a.hp1 + m * 40 + 4 * c);
+      xr1[q] = ld4(a.g1 + m * 120 + 4 * c);
+      xm[q] = ld4(a.mprev + m * 40 + 4 * c);
+      x2[q] = ld4(a.hp2 + m * 40 + 4 * c);
+      xr2[q] = ld4(a.g2 + m * 120 + 4 * c);
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) xt[q] = ld4(a.TT + m * 80 + 4 * (W + 4 * q));
+  };
+  auto put4 = [&](int row0, f32x4 v) {      // four feature rows of this lane's position
+    typedef __bf16 h4 __attribute__((ext_vector_type(4)));
+    const h4 h = __builtin_convertvector(valid ? v : z4, h4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Xs[(row0 + e) * EBH_LD + lane] = h[e];
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int q = 0; q < 15; ++q) {
+      const int c0 = 8 * (W + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Ps[(c0 + e) * EBH_LD + lane] = valid ? pr[q][e] : (__bf16)0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int c = W + 4 * q;
+      if (c < 10) {
+        put4(4 * c, xh[q]); put4(48 + 4 * c, x1[q]); put4(96 + 4 * c, x1[q] * xr1[q]); put4(144 + 4 * c, xm[q]);
+        put4(272 + 4 * c, x2[q]); put4(320 + 4 * c, x2[q] * xr2[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) put4(192 + 4 * (W + 4 * q), xt[q]);
+    if (W == 0) Xs[40 * EBH_LD + lane] = (__bf16)(valid ? 1.f : 0.f);     // the row of ones: bias sums
+  };
+
+  constexpr int NA = eb_count(W), NP = eb_nt(W);
+  f32x4 acc[NA];
+#pragma unroll
+  for (int n = 0; n < NA; ++n) acc[n] = z4;
+
+  long st = blockIdx.x;
+  if (st < nst) fetch(st);
+  for (; st < nst; st += gridDim.x) {
+    __syncthreads();                 // the previous stage's tiles are free (first trip: the zero fill is complete)
+    stage();
+    __syncthreads();
+    if (st + gridDim.x < nst) fetch(st + gridDim.x);      // next stage's operands fly behind the MFMAs below
+#pragma unroll 1
+    for (int s = 0; s < EBH_ST / 32; ++s) {
+      const int mo = 32 * s + 8 * g;
+      // the wave's dPin tiles stay in registers for the step; the left-operand tiles pass through one at a time (all of
+      // them at once: 17 x 4 more registers on top of 220 accumulators and the 152 of the next stage's operands -- spills)
+      ebh_bf16x8 bv[NP];
+#pragma unroll
+      for (int pi = 0; pi < NP; ++pi) bv[pi] = *reinterpret_cast<const ebh_bf16x8*>(Ps + (16 * eb_tile(W, pi) + i) * EBH_LD + mo);
+      ebh_all<W>(acc, bv, Xs + i * EBH_LD + mo, std::make_integer_sequence<int, EB_NXT>{});
+    }
+  }
+  const float nob[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  eb_store<W, true>(a.ws, acc, nob, lane, blockIdx.x, gridDim.x);
+}
+
+__global__ void __launch_bounds__(256) enc_bwd_fused_h_kernel(EncBwdHArgs a) {
+  CLSR_CHAIN_PRIO();
+  extern __shared__ __attribute__((aligned(16))) __bf16 ldsh[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave == 0) ebh_body<0>(a, ldsh);
+  else if (wave == 1) ebh_body<1>(a, ldsh);
+  else if (wave == 2) ebh_body<2>(a, ldsh);
+  else ebh_body<3>(a, ldsh);
+}
+
+static int ebh_grid(long M) {
+  long st = (M + EBH_ST - 1) / EBH_ST;
+  return (int)(st < 256 ? st : 256);
+}
+extern "C" int clsr_enc_bwd_fused_h_parts(long M) { return ebh_grid(M); }
+extern "C" long clsr_enc_bwd_fused_h_workspace_floats(long M, int p) {
+  if (p < 0 || p > 6) return 0;
+  return (long)clsr_cdiv(eb_N(p), 80) * ebh_grid(M) * EB_CHUNK;
+}
+extern "C" int clsr_enc_bwd_fused_h(const void* dPin_bf16, const float* hist, const float* hprev1, const float* gates1,
+                                    const float* mprev, const float* TT, const float* hprev2, const float* gates2,
+                                    float* ws_hist, float* ws_hp1, float* ws_hp1r, float* ws_mprev, float* ws_tt,
+                                    float* ws_hp2, float* ws_hp2r, long M, void* stream) {
+  CLSR_CHECK_ARG(dPin_bf16 && hist && hprev1 && gates1 && mprev && TT && hprev2 && gates2 && M > 0);
+  CLSR_CHECK_ARG(ws_hist && ws_hp1 && ws_hp1r && ws_mprev && ws_tt && ws_hp2 && ws_hp2r);
+  CLSR_CHECK_SUPPORTED(((uintptr_t)dPin_bf16 % 16) == 0 && ((uintptr_t)hist % 16) == 0);
+  EncBwdHArgs a = {};
+  a.dPin = (const __bf16*)dPin_bf16; a.hist = hist; a.hp1 = hprev1; a.g1 = gates1; a.mprev = mprev; a.TT = TT;
+  a.hp2 = hprev2; a.g2 = gates2; a.M = M;
+  a.ws[0] = ws_hist; a.ws[1] = ws_hp1; a.ws[2] = ws_hp1r; a.ws[3] = ws_mprev; a.ws[4] = ws_tt; a.ws[5] = ws_hp2; a.ws[6] = ws_hp2r;
+  const size_t shmem = (size_t)(EB_NX + EB_XW) * EBH_LD * sizeof(__bf16);
+  CLSR_HIP(hipFuncSetAttribute((const void*)enc_bwd_fused_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL(enc_bwd_fused_h_kernel, dim3(ebh_grid(M)), dim3(256), shmem, (hipStream_t)stream, a);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
 }
 
 static_assert(eb_count(0) + eb_count(1) + eb_count(2) + eb_count(3) == 211, "every wanted block has an owner");

@@ -118,7 +118,9 @@ class CLSRNet(object):
                        and not os.environ.get("CLSR_NO_DPIN_BF16"))          # bf16 dPin (speed mode, CLSR graph only)
         # where the long-term attention backward forks: beside the short-term one (exact mode: -40 us) or underneath the
         # backward-through-time launch (speed mode: the short-term backward is bandwidth bound there); CLSR_LT_BWD_EARLY=0|1
-        self.lt_bwd_early = (os.environ.get("CLSR_LT_BWD_EARLY", "1" if precision == "fp32" else "0") == "1")
+        # (round 2: off in speed mode, +30 us there; with the fused encoder tail the long-term chain had become the LAST thing
+        #  to finish in that mode: early wins by 0.06 ms since round 3)
+        self.lt_bwd_early = os.environ.get("CLSR_LT_BWD_EARLY", "1") == "1"
         self._dw_batch = None
         self._buf_allocs = 0
         # the recurrences run as a CHAIN of launches over this many time ranges, so that the input projections of range
@@ -139,6 +141,7 @@ class CLSRNet(object):
         self._late_dw = None
         self.sort_late = bool(os.environ.get("CLSR_SORT_LATE"))     # A/B: history-id sort beside the heads instead of at the start of the step (measured: no difference, 3.66 ms both)
         self.early_scatter = not os.environ.get("CLSR_NO_EARLY_SCATTER")   # A/B: row scatters of the user / target lookups beside the encoder-backward tail instead of behind it
+        self.enc_bwd_fused_h = not os.environ.get("CLSR_NO_ENC_BWD_FUSED_H")   # A/B: the speed-mode (bf16 dPin) form of the fused encoder tail
         self.enc_bwd_fused = not os.environ.get("CLSR_NO_ENC_BWD_FUSED")   # A/B: one pass over dPin for the seven encoder-side weight gradients + d(hist) (csrc/encbwd.hip)
         self.rnn_chunks = int(os.environ.get("CLSR_RNN_CHUNKS", "1"))   # measured at configs[1]: 4.17-4.21 ms with 5 ranges, 4.11 with 3, against 3.91 with one launch (the projections throttle the chain, ~30 us start-up + ~15 us cross-stream signalling per range) -- kept as a switch
         self.l0_fwd_wave = not os.environ.get("CLSR_NO_L0_FWD_WAVE")      # A/B switch (exact mode, see _att_fwd)
@@ -233,7 +236,7 @@ class CLSRNet(object):
         return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook),
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
                 self.lazy, self.rnn_first, self.lt_att_first, self.tick_early, self.hist_grad_two, self.dw_batch_late, self.bn_bwd_fused, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h, self.flush_side, self.l1_bwd_2pass,
-                self.split_g2, self.rnn_chunks, self.enc_bwd_fused, self.early_scatter, self.sort_late, self.late_attmat_dw, self.fused_logit_tail, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
+                self.split_g2, self.rnn_chunks, self.enc_bwd_fused, self.enc_bwd_fused_h, self.early_scatter, self.sort_late, self.late_attmat_dw, self.fused_logit_tail, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
 
@@ -1326,10 +1329,18 @@ class CLSRNet(object):
             return
         TT = self._buf("t4.TT", M, 2 * H)
         self._dw(TT, 2 * H, dPt[:, 3 * H:], NX, M, 2 * H, 3 * H, self._buf("t4.dTW", 2 * H, 3 * H), 3 * H, dy_bf16=hb)
+        self._t4_time_chain_bwd(f, dPinAll, Hn, T, hs)
+
+    def _t4_time_chain_bwd(self, f, dPinAll, Hn, T, hs):
+        """d TT = dPin[:, o | tns | tls] . tw^T, its tanh backward and the sums for the four time-input vectors."""
+        Gd, H, NX = self.Gd, self.H, self.NX
+        t, M = self._t4_scope, Hn * T
+        dPt = dPinAll[:, self._enc_off("t4"):]
+        TT = self._buf("t4.TT", M, 2 * H)
         dTT = self._buf("t4.dTT", M, 2 * H)
-        self._gemm(dPt[:, 3 * H:], NX, "t4.tw^T", M, 3 * H, 2 * H, dTT, 2 * H)
         parts = query("clsr_t4_time_inputs_bwd_parts", Hn, T, H)
         tp = self._buf("t4.tpart", 512 * 4 * 128)[: parts * 4 * H]
+        self._gemm(dPt[:, 3 * H:], NX, "t4.tw^T", M, 3 * H, 2 * H, dTT, 2 * H)
         call("clsr_t4_time_inputs_bwd", dTT, TT, f["time_to_now"], f["time_from_first_action"], hs * T, Hn, T, H, tp)
         for off_, nm in ((0, "_time_input_w1"), (H, "_time_input_w2"), (2 * H, "_time_input_bias1"),
                          (3 * H, "_time_input_bias2")):
@@ -1447,7 +1458,9 @@ class CLSRNet(object):
         """The default graph at the default widths: short_term_intention GRU + Time4LSTM + causal GRU, D = Du = H = 40,
         fp32 dPin with the column layout csrc/encbwd.hip is written for."""
         hp = self.hp
-        return (self.enc_bwd_fused and not dpin_h and not self.bf16 and type(self) is CLSRNet and self.defer_dw
+        if self.bf16 and not (dpin_h and self.enc_bwd_fused_h):     # (speed mode: the bf16-dPin form of the kernel)
+            return False
+        return (self.enc_bwd_fused and (dpin_h if self.bf16 else not dpin_h) and type(self) is CLSRNet and self.defer_dw
                 and self._t4_kind == "time4lstm" and bool(hp.interest_evolve)
                 and (not hp.manual_alpha) and bool(hp.predict_long_short) and self.enc_in == self.D
                 and self.D == self.Du == self.H and bool(query("clsr_enc_bwd_fused_supported", self.D, self.H, self.NX))
@@ -1492,6 +1505,34 @@ class CLSRNet(object):
         call("clsr_enc_bwd_fused", dPinAll, hist, self._buf("g1.hprev", Hn, T, H), self._buf("g1.gates", Hn, T, 3 * H),
              self._buf("t4.mprev", Hn, T, H), TT, self._buf("g2.hprev", Hn, T, H), self._buf("g2.gates", Hn, T, 3 * H),
              Wt, Kp, dhist, *wss, M)
+
+    def _enc_bwd_fused_h(self, f, hist, dPinAll, dhist, Hn, T, hs):
+        """Speed mode: the seven encoder-side weight gradients from ONE pass over the bf16 dPin (clsr_enc_bwd_fused_h) on
+        the weight-gradient stream, beside d(hist) = dPin . W_x^T and the time-feature chain on the compute stream."""
+        Gd, D, H, NX, E = self.Gd, self.D, self.H, self.NX, self.enc_in
+        M = Hn * T
+        st, t = CL + "short_term/", self._t4_scope
+        g1, g2 = st + "short_term_intention/gru_cell/", CL + "causal2/causal2/gru_cell/"
+        parts = query("clsr_enc_bwd_fused_h_parts", M)
+        prods = [(self._buf("xw.dW", D, NX), NX, self._buf("xw.db", NX), D, NX),
+                 (Gd[g1 + "gates/kernel"][E:], 2 * H, None, H, 2 * H), (Gd[g1 + "candidate/kernel"][E:], H, None, H, H),
+                 (Gd[t + "kernel"][E:], 4 * H, None, H, 4 * H), (self._buf("t4.dTW", 2 * H, 3 * H), 3 * H, None, 2 * H, 3 * H),
+                 (Gd[g2 + "gates/kernel"][E:], 2 * H, None, H, 2 * H), (Gd[g2 + "candidate/kernel"][E:], H, None, H, H)]
+        pend = self._dw_pending.setdefault("", [])
+        wss = []
+        for i, (dW, ldw, db, K, N) in enumerate(prods):
+            ws = self._buf("encbh.ws%d" % i, query("clsr_enc_bwd_fused_h_workspace_floats", M, i))
+            wss.append(ws)
+            pend.append((ws.data_ptr(), dW.data_ptr(), db.data_ptr() if db is not None else 0, 1.0, parts, K, N, ldw, 0))
+        side = self.dw_stream and self.overlap
+        with self._branch("@dw0" if side else "@main", after=self._fork_point(), name="@encw"):
+            call("clsr_enc_bwd_fused_h", dPinAll, hist, self._buf("g1.hprev", Hn, T, H), self._buf("g1.gates", Hn, T, 3 * H),
+                 self._buf("t4.mprev", Hn, T, H), self._buf("t4.TT", M, 2 * H), self._buf("g2.hprev", Hn, T, H),
+                 self._buf("g2.gates", Hn, T, 3 * H), *wss, M)
+        if side:
+            self._dw_async = True       # (the flush waits for the weight-gradient stream)
+        self._gemm(dPinAll, NX, "xw^T", M, NX, D, dhist, D, acc=1)
+        self._t4_time_chain_bwd(f, dPinAll, Hn, T, hs)
 
     def _encoders_bwd_chunked(self, f, chunks, hist, dhist, drnn, dsi, dfs, Hn, T, seq_len, ls, hs):
         """Backward-through-time as a chain of launches over ``chunks`` (descending); behind every range its weight
@@ -1921,7 +1962,7 @@ class CLSRNet(object):
                 self._scatter_rows_early(f, dul, None, dtarget, Hn, B, hs, fork)
                 self._scatter_rows_early(f, None, dushort, None, Hn, B, hs, self._fork_point())
             if self._enc_bwd_fused_ok(dpin_h):
-                self._enc_bwd_fused(f, hist, dPinAll, dhist, Hn, T, hs)
+                (self._enc_bwd_fused_h if self.bf16 else self._enc_bwd_fused)(f, hist, dPinAll, dhist, Hn, T, hs)
             else:
               # input-side weights of every encoder in one reduction; d(hist) in one product; the hidden-side / time-feature
               # weight gradients ride in the same multi-job launch as the input-side one (they all depend on dPin only)
@@ -1944,7 +1985,7 @@ class CLSRNet(object):
         for job in late or ():
             job()
         side_dense = self.flush_side and self.overlap and self.dw_stream
-        self._join(but=("@scat",))
+        self._join(but=("@scat", "@encw") if side_dense else ("@scat",))
         if side_dense:
             # the dense path from here on (batched reduction of every weight gradient, unpacking, later the dense
             # regulariser + Adam) does not meet the embedding path (gradient tables, table regulariser / Adam) again:

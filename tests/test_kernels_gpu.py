@@ -1512,3 +1512,36 @@ def test_mlp_tail_softmax_equals_the_three_launches(P, G, C1):
     close(loss1, -(lsm * lab).sum().reshape(1) * lscale, rtol=1e-5, atol=1e-7, name="loss vs float64")
     dlg = (lscale * (lab.sum(1, keepdim=True) * lsm.exp() - lab)).reshape(-1)
     close(dy1, (dlg[:, None] * w.double().cpu()) * (y > 0), rtol=1e-4, atol=1e-6, name="dy1 vs float64")
+
+
+@pytest.mark.parametrize("M", [4800, 4117, 37])
+def test_fused_encoder_backward_speed_mode(M):
+    """clsr_enc_bwd_fused_h (csrc/encbwd.hip): the seven encoder-side weight gradients + bias sums from a bf16 dPin on the
+    bf16 matrix pipe == float64 products of the bf16-ROUNDED operands (products exact, accumulation fp32), through the
+    partial layout + clsr_dw_reduce_batch that the step uses."""
+    g = torch.Generator().manual_seed(M + 1)
+    f = lambda t: dev(t, torch.float32)
+    n = 40
+    dPin = dev(rnd(g, M, 480), torch.float32).to(torch.bfloat16)
+    hist, hp1, hp2, mp = f(rnd(g, M, n)), f(rnd(g, M, n)), f(rnd(g, M, n)), f(rnd(g, M, n))
+    TT = f(torch.tanh(rnd(g, M, 2 * n)))
+    g1, g2 = f(torch.rand(M, 3 * n, generator=g, dtype=torch.float64)), f(torch.rand(M, 3 * n, generator=g, dtype=torch.float64))
+    parts = query("clsr_enc_bwd_fused_h_parts", M)
+    shapes = [(n, 480), (n, 80), (n, 40), (n, 160), (2 * n, 120), (n, 80), (n, 40)]
+    wss = [torch.full((query("clsr_enc_bwd_fused_h_workspace_floats", M, i),), 9.0, device="cuda") for i in range(7)]
+    outs = [torch.zeros(K, N, device="cuda") for K, N in shapes]
+    db = torch.zeros(480, device="cuda")
+    call("clsr_enc_bwd_fused_h", dPin, hist, hp1, g1, mp, TT, hp2, g2, *wss, M)
+    sig = tuple((ws.data_ptr(), o.data_ptr(), db.data_ptr() if i == 0 else 0, 1.0, parts, K, N, N, 0)
+                for i, (ws, o, (K, N)) in enumerate(zip(wss, outs, shapes)))
+    tab = ops.dw_table(sig, torch.device("cuda"))
+    call("clsr_dw_reduce_batch", tab[0], tab[1], tab[2])
+    torch.cuda.synchronize()
+    r = lambda t: t.to(torch.bfloat16).double().cpu()          # what the kernel multiplies
+    P = dPin.double().cpu()
+    exp = [r(hist).T @ P, r(hp1).T @ P[:, 0:80], r(hp1 * g1[:, :n]).T @ P[:, 80:120], r(mp).T @ P[:, 240:400],
+           r(TT).T @ P[:, 360:480], r(hp2).T @ P[:, 120:200], r(hp2 * g2[:, :n]).T @ P[:, 200:240]]
+    tol = 2e-5 * math.sqrt(M)
+    for i, (o, e) in enumerate(zip(outs, exp)):
+        close(o, e, rtol=2e-4, atol=tol, name="product %d" % i)
+    close(db, P.sum(0), rtol=2e-4, atol=tol, name="bias sums")
