@@ -366,6 +366,8 @@ struct EncBwdHArgs {
   const float* g2;
   float* ws[7];
   long M;
+  const __bf16* Wh; int Kph;      // bf16 image of the packed W_x^T (clsr_pack_batch_bf16 row order) or NULL: no d(hist)
+  float* dhist;                   // [M, 40], accumulated into
 };
 
 // MFMAs of one 32-position step, unrolled at COMPILE time (accumulator indices must be constants: a loop that the
@@ -476,6 +478,44 @@ __device__ __forceinline__ void ebh_body(const EncBwdHArgs& a, __bf16* lds) {
       for (int pi = 0; pi < NP; ++pi) bv[pi] = *reinterpret_cast<const ebh_bf16x8*>(Ps + (16 * eb_tile(W, pi) + i) * EBH_LD + mo);
       ebh_all<W>(acc, bv, Xs + i * EBH_LD + mo, std::make_integer_sequence<int, EB_NXT>{});
     }
+    if (a.Wh) {
+      // d(hist)[pos, :] += dPin[pos, :] . W_x^T for the 16 positions 16 W .. 16 W + 15 of the stage: the contraction runs
+      // over the 480 COLUMNS here, so the A operand is the row-major dPin (lane (i, g): position i, columns 32 ks + 8 g ..:
+      // one 16-byte read of lines the staging loads have just brought in) and B the bf16 W_x^T image (38 KB: cache
+      // resident); no LDS.  Replaces the 230 us clsr_hgemm_hf32 launch on the compute stream.
+      const long m = st * EBH_ST + 16 * W + i;
+      const bool mv = m < a.M;
+      const __bf16* ap = a.dPin + (mv ? m : a.M - 1) * EB_NX + 8 * g;
+      const __bf16* bp[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int o = 16 * t + i;                                   // out feature (rows >= 40 of the image are zero)
+        const int rho = 32 * (o / 32) + 16 * ((o % 8) / 4) + 4 * ((o % 32) / 8) + (o % 4);
+        bp[t] = a.Wh + (long)rho * a.Kph + 8 * g;
+      }
+      f32x4 dh[3] = {z4, z4, z4};
+      const ebh_bf16x8 zh = {};
+      // (all 15 dPin pieces of the lane in flight at once, the weight pieces stream behind them: one wave per SIMD has
+      //  nobody else to hide a load latency per k-step)
+      ebh_bf16x8 av[EB_NX / 32];
+#pragma unroll
+      for (int ks = 0; ks < EB_NX / 32; ++ks) av[ks] = *reinterpret_cast<const ebh_bf16x8*>(ap + 32 * ks);
+#pragma unroll
+      for (int ks = 0; ks < EB_NX / 32; ++ks) {
+        const ebh_bf16x8 x = mv ? av[ks] : zh;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          dh[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, *reinterpret_cast<const ebh_bf16x8*>(bp[t] + 32 * ks), dh[t], 0, 0, 0);
+      }
+      // lane (j = i, g) holds features 16 t + i of the positions 4 g .. 4 g + 3 of the tile
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long mm = st * EBH_ST + 16 * W + 4 * g + r;
+          if (mm < a.M && 16 * t + i < 40) a.dhist[mm * 40 + 16 * t + i] += dh[t][r];
+        }
+    }
   }
   const float nob[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   eb_store<W, true>(a.ws, acc, nob, lane, blockIdx.x, gridDim.x);
@@ -503,13 +543,16 @@ extern "C" long clsr_enc_bwd_fused_h_workspace_floats(long M, int p) {
 extern "C" int clsr_enc_bwd_fused_h(const void* dPin_bf16, const float* hist, const float* hprev1, const float* gates1,
                                     const float* mprev, const float* TT, const float* hprev2, const float* gates2,
                                     float* ws_hist, float* ws_hp1, float* ws_hp1r, float* ws_mprev, float* ws_tt,
-                                    float* ws_hp2, float* ws_hp2r, long M, void* stream) {
+                                    float* ws_hp2, float* ws_hp2r, const void* Wt_bf16, int Kph, float* dhist, long M,
+                                    void* stream) {
   CLSR_CHECK_ARG(dPin_bf16 && hist && hprev1 && gates1 && mprev && TT && hprev2 && gates2 && M > 0);
+  CLSR_CHECK_ARG(!Wt_bf16 || (dhist && Kph >= EB_NX && Kph % 8 == 0));
   CLSR_CHECK_ARG(ws_hist && ws_hp1 && ws_hp1r && ws_mprev && ws_tt && ws_hp2 && ws_hp2r);
   CLSR_CHECK_SUPPORTED(((uintptr_t)dPin_bf16 % 16) == 0 && ((uintptr_t)hist % 16) == 0);
   EncBwdHArgs a = {};
   a.dPin = (const __bf16*)dPin_bf16; a.hist = hist; a.hp1 = hprev1; a.g1 = gates1; a.mprev = mprev; a.TT = TT;
   a.hp2 = hprev2; a.g2 = gates2; a.M = M;
+  a.Wh = (const __bf16*)Wt_bf16; a.Kph = Kph; a.dhist = dhist;
   a.ws[0] = ws_hist; a.ws[1] = ws_hp1; a.ws[2] = ws_hp1r; a.ws[3] = ws_mprev; a.ws[4] = ws_tt; a.ws[5] = ws_hp2; a.ws[6] = ws_hp2r;
   const size_t shmem = (size_t)(EB_NX + EB_XW) * EBH_LD * sizeof(__bf16);
   CLSR_HIP(hipFuncSetAttribute((const void*)enc_bwd_fused_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));

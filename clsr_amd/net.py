@@ -1524,11 +1524,14 @@ class CLSRNet(object):
             ws = self._buf("encbh.ws%d" % i, query("clsr_enc_bwd_fused_h_workspace_floats", M, i))
             wss.append(ws)
             pend.append((ws.data_ptr(), dW.data_ptr(), db.data_ptr() if db is not None else 0, 1.0, parts, K, N, ldw, 0))
+        # (the kernel can also accumulate d(hist) = dPin . W_x^T -- Wt_bf16 / dhist arguments, tested -- but that product
+        #  contracts over the COLUMNS: its operands come from global memory / L1, 100-150 us more in the kernel against the
+        #  230 us of the separate clsr_hgemm_hf32 launch that otherwise runs BESIDE it: 2.93 against 2.90 ms per step)
         side = self.dw_stream and self.overlap
         with self._branch("@dw0" if side else "@main", after=self._fork_point(), name="@encw"):
             call("clsr_enc_bwd_fused_h", dPinAll, hist, self._buf("g1.hprev", Hn, T, H), self._buf("g1.gates", Hn, T, 3 * H),
                  self._buf("t4.mprev", Hn, T, H), self._buf("t4.TT", M, 2 * H), self._buf("g2.hprev", Hn, T, H),
-                 self._buf("g2.gates", Hn, T, 3 * H), *wss, M)
+                 self._buf("g2.gates", Hn, T, 3 * H), *wss, None, 0, None, M)
         if side:
             self._dw_async = True       # (the flush waits for the weight-gradient stream)
         self._gemm(dPinAll, NX, "xw^T", M, NX, D, dhist, D, acc=1)

@@ -498,14 +498,15 @@ int clsr_enc_bwd_fused_parts(long M);
 long clsr_enc_bwd_fused_workspace_floats(long M, int product);
 /* speed mode: the seven weight gradients of the same tail from a bf16 dPin [M, 480] on the bf16 matrix pipe (left operands
  * fp32 in memory, rounded to bf16 when staged; fp32 accumulation; same column layout and partial layout;
- * clsr_enc_bwd_fused_h_parts(M) partial slots).  d(hist) is not part of it (clsr_hgemm_hf32).  Replaces the seven jobs of
- * clsr_hdw_partial_multi. */
+ * clsr_enc_bwd_fused_h_parts(M) partial slots).  With Wt_bf16 (the clsr_pack_batch_bf16 image of W_x^T, row stride Kph)
+ * it also accumulates dhist += dPin . W_x^T; NULL: weight gradients only.  Replaces the seven jobs of
+ * clsr_hdw_partial_multi (and clsr_hgemm_hf32 for d(hist)). */
 int clsr_enc_bwd_fused_h_parts(long M);
 long clsr_enc_bwd_fused_h_workspace_floats(long M, int product);
 int clsr_enc_bwd_fused_h(const void* dPin_bf16, const float* hist, const float* hprev1, const float* gates1,
                          const float* mprev, const float* TT, const float* hprev2, const float* gates2,
                          float* ws_hist, float* ws_hp1, float* ws_hp1r, float* ws_mprev, float* ws_tt,
-                         float* ws_hp2, float* ws_hp2r, long M, void* stream);
+                         float* ws_hp2, float* ws_hp2r, const void* Wt_bf16, int Kph, float* dhist, long M, void* stream);
 int clsr_enc_bwd_fused(const float* dPin, const float* hist, const float* hprev1, const float* gates1,
                        const float* mprev, const float* TT, const float* hprev2, const float* gates2,
                        const float* Wt, int Kp, float* dhist, float* ws_hist, float* ws_hp1, float* ws_hp1r,

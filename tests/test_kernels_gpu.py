@@ -1531,7 +1531,15 @@ def test_fused_encoder_backward_speed_mode(M):
     wss = [torch.full((query("clsr_enc_bwd_fused_h_workspace_floats", M, i),), 9.0, device="cuda") for i in range(7)]
     outs = [torch.zeros(K, N, device="cuda") for K, N in shapes]
     db = torch.zeros(480, device="cuda")
-    call("clsr_enc_bwd_fused_h", dPin, hist, hp1, g1, mp, TT, hp2, g2, *wss, M)
+    Wx = rnd(g, n, 480) * 0.2                     # [in = hist feature, out = projection column]
+    Wh = torch.zeros(64 * query("clsr_hgemm_kp", 480), dtype=torch.bfloat16, device="cuda")
+    Kph = query("clsr_hgemm_kp", 480)
+    Wxd = f(Wx)
+    tab_h = ops.pack_table([ops.pack_desc(Wxd, n, 480, Wh, Kph, transposed=True)], torch.device("cuda"))
+    call("clsr_pack_batch_bf16", tab_h[0], tab_h[1], tab_h[2])
+    dhist0 = f(rnd(g, M, n))
+    dhist = dhist0.clone()
+    call("clsr_enc_bwd_fused_h", dPin, hist, hp1, g1, mp, TT, hp2, g2, *wss, Wh, Kph, dhist, M)
     sig = tuple((ws.data_ptr(), o.data_ptr(), db.data_ptr() if i == 0 else 0, 1.0, parts, K, N, N, 0)
                 for i, (ws, o, (K, N)) in enumerate(zip(wss, outs, shapes)))
     tab = ops.dw_table(sig, torch.device("cuda"))
@@ -1545,3 +1553,4 @@ def test_fused_encoder_backward_speed_mode(M):
     for i, (o, e) in enumerate(zip(outs, exp)):
         close(o, e, rtol=2e-4, atol=tol, name="product %d" % i)
     close(db, P.sum(0), rtol=2e-4, atol=tol, name="bias sums")
+    close(dhist, dhist0.double().cpu() + P @ Wxd.to(torch.bfloat16).double().cpu().T, rtol=2e-4, atol=2e-4, name="d(hist)")
