@@ -220,7 +220,15 @@ def test_model_train_with_two_ranks_matches_single_process(golden_dir, golden_hp
     assert len(out[0]["losses"]) == len(ref_losses) == 4
     for a, b, c in zip(out[0]["losses"], out[1]["losses"], ref_losses):
         assert abs(a - b) < 1e-12 and abs(a - c) < 1e-4 * max(1.0, abs(c)), (a, b, c)
-    np.testing.assert_allclose(out[0]["item"], single.net.tables["item"].cpu().numpy(), rtol=1e-3, atol=2e-6)
+    # Adam divides by sqrt(v) + 1e-8: an element whose gradient is fp32 summation noise of ~1e-10 moves by a visible
+    # fraction of lr, with the sign of the noise -- and two ranks sum in a different order than one process.  A handful
+    # of such elements (seen: 2 of 31 808, off by 2.2e-5, one run in ~5) is not a defect; a real one (a lost shard, a
+    # wrong scale) moves EVERY touched element by ~lr per step.  So: tight tolerance for all but 0.1 % of the elements,
+    # and a bound of 5 % of lr * steps for those.
+    a, b = out[0]["item"], single.net.tables["item"].cpu().numpy()
+    bad = np.abs(a - b) > 2e-6 + 1e-3 * np.abs(b)
+    assert bad.mean() < 1e-3, "%d of %d elements differ" % (bad.sum(), bad.size)
+    assert float(np.abs(a - b).max()) < 0.05 * float(hp.learning_rate) * 4, float(np.abs(a - b).max())
     np.testing.assert_array_equal(out[0]["item"], out[1]["item"])      # replicas stay bit-identical
 
 
