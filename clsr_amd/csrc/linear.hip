@@ -507,6 +507,9 @@ static int launch_pgemm(const PGemmArgs& a, hipStream_t stream) {
   const bool st = a.stats != nullptr;
   const int KTn = clsr_cdiv(a.K, 16);
   const bool upfront = !getenv("CLSR_PGEMM_STREAM");   // A/B switch: loads one k-tile ahead instead of all up front
+  // K = 128 over many positions (the K-fused time-gate projection [hist | TT] of the Time4LSTM) with all eight k-tiles up
+  // front: measured 153 us against 123 us for the one-tile-ahead loop -- opt-in
+  const bool k8 = getenv("CLSR_PGEMM_K8") != nullptr;
   // few positions, wide K: latency bound (see the kernel); also the skinny d(hist) = dPin . W^T product (K = 480 -> 40
   // columns: 30 k-tiles per wave-tile, 100 -> 132 VGPRs with the ring)
   const bool ring = !a.no_ring && KTn > 5 && (a.M <= 65536 || (OT == 3 && KTn >= 16 && !getenv("CLSR_PGEMM_NO_RING_WIDE")));
@@ -515,6 +518,7 @@ static int launch_pgemm(const PGemmArgs& a, hipStream_t stream) {
     /* (the X * Xmul variant holds twice the operands: with everything in flight it drops to one wave per SIMD and loses) */ \
     if (upfront && (P) != PRO_MUL && KTn == 5) return launch_kernel(pgemm_fast_kernel<OT, P, E, S, 5>, a, grid, shmem, stream); \
     if (upfront && (P) != PRO_MUL && KTn == 3) return launch_kernel(pgemm_fast_kernel<OT, P, E, S, 3>, a, grid, shmem, stream); \
+    if (upfront && (P) == PRO_PLAIN && (E) == EPI_NONE && !(S) && KTn == 8 && k8) return launch_kernel(pgemm_fast_kernel<OT, PRO_PLAIN, EPI_NONE, false, 8>, a, grid, shmem, stream); \
     if ((P) == PRO_PLAIN && ring) return launch_kernel(pgemm_fast_kernel<OT, PRO_PLAIN, E, S, 0, true>, a, grid, shmem, stream); \
     return launch_kernel(pgemm_fast_kernel<OT, P, E, S>, a, grid, shmem, stream);                   \
   }
@@ -604,9 +608,19 @@ static int pgemm_out_tiles(int N) {
   const int waste5 = clsr_cdiv(nt, 5) * 5 - nt, waste8 = clsr_cdiv(nt, 8) * 8 - nt;
   return waste8 <= waste5 ? 8 : 5;
 }
+// narrow inputs (K <= 48: three k-tiles, all loaded up front): the five-tile variant keeps more waves in flight and wins
+// unless it wastes two or more out-tiles over the eight-tile one (360 columns: 166 us with eight tiles per workgroup)
+static int pgemm_out_tiles_k(int N, int K) {
+  const int nt = clsr_cdiv(N, 16);
+  if (nt > 8 && K <= 48 && !getenv("CLSR_PGEMM_NO_OT5")) {
+    const int waste5 = clsr_cdiv(nt, 5) * 5 - nt, waste8 = clsr_cdiv(nt, 8) * 8 - nt;
+    if (waste5 - waste8 <= 1) return 5;
+  }
+  return pgemm_out_tiles(N);
+}
 
 static int pgemm_dispatch_one(const PGemmArgs& a, hipStream_t s) {
-  int ot = pgemm_out_tiles(a.N);
+  int ot = pgemm_out_tiles_k(a.N, a.K);
   // the BN-backward epilogue has no 8-out-tile fast variant (register spills): two column chunks of the
   // 5-tile one (blockIdx.y) beat the generic kernel (31 -> ~17 us for the 20 480 x 64 -> 100 logit layer)
   if (ot == 8 && a.ez) ot = 5;
@@ -615,6 +629,8 @@ static int pgemm_dispatch_one(const PGemmArgs& a, hipStream_t s) {
   // five or eight: 3.69 -> 3.65 ms per step (A/B switch CLSR_PGEMM_SMALLM_OT: 0 = off)
   static const int small_ot = []() { const char* e = getenv("CLSR_PGEMM_SMALLM_OT"); return e ? atoi(e) : 3; }();
   if (small_ot && a.M <= 32768 && ot > small_ot) ot = small_ot;
+  static const int k128_ot = []() { const char* e = getenv("CLSR_PGEMM_K128_OT"); return e ? atoi(e) : 0; }();
+  if (k128_ot && a.K > 96 && a.K <= 128 && a.N <= 128 && ot > k128_ot) ot = k128_ot;     // (experiment switch)
   if (ot == 3) return launch_pgemm<3>(a, s);
   if (ot == 5) return launch_pgemm<5>(a, s);
   return launch_pgemm<8>(a, s);
@@ -627,7 +643,7 @@ static int pgemm_dispatch_one(const PGemmArgs& a, hipStream_t s) {
 static int pgemm_dispatch(const PGemmArgs& a0, hipStream_t s) {
   PGemmArgs a = a0;
   if (a.ldw == 0) a.ldw = a.Kp;
-  int ot = pgemm_out_tiles(a.N);
+  int ot = pgemm_out_tiles_k(a.N, a.K);
   if (ot == 8 && a.ez) ot = 5;
   // bytes of LDS for the weight chunk of one launch (A/B switch: CLSR_PGEMM_LDS_KB)
   static const size_t budget = []() {

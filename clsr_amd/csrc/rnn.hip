@@ -685,7 +685,7 @@ extern "C" int clsr_t4lstm_bwd(const float* act, const float* cst, const float* 
 __global__ void __launch_bounds__(256) t4_time_inputs_fwd_kernel(
     const float* __restrict__ tnow, const float* __restrict__ tfirst, long row_stride, const float* __restrict__ w1,
     const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2, long Hn, int T, int n,
-    float* __restrict__ TT) {
+    float* __restrict__ TT, const float* __restrict__ hist, int D, float* __restrict__ XT, int ldxt, int col0) {
   const int QC = (2 * n) >> 2, rpb = 256 / QC;
   const int ty = threadIdx.x / QC, q = threadIdx.x - ty * QC;
   if (ty >= rpb) return;
@@ -700,20 +700,32 @@ __global__ void __launch_bounds__(256) t4_time_inputs_fwd_kernel(
     f32x4 v;
     v.x = tanhf_(x * w.x + b.x); v.y = tanhf_(x * w.y + b.y); v.z = tanhf_(x * w.z + b.z); v.w = tanhf_(x * w.w + b.w);
     st4(TT + (long)row * (2 * n) + c, v);
+    if (XT) {   // second image [hist | pad | TT] of the row: the input of the K-fused time-gate projection (net.py)
+      st4(XT + (long)row * ldxt + col0 + c, v);
+      if (c < D) st4(XT + (long)row * ldxt + c, ld4(hist + (long)row * D + c));
+    }
   }
 }
 
-extern "C" int clsr_t4_time_inputs_fwd(const float* tnow, const float* tfirst, long row_stride,
-                                       const float* w1, const float* b1, const float* w2,
-                                       const float* b2, long Hn, int T, int n, float* TT, void* stream) {
+extern "C" int clsr_t4_time_inputs_fwd2(const float* tnow, const float* tfirst, long row_stride,
+                                        const float* w1, const float* b1, const float* w2,
+                                        const float* b2, long Hn, int T, int n, float* TT, const float* hist, int D,
+                                        float* XT, int ldxt, int col0, void* stream) {
   CLSR_CHECK_ARG(tnow && tfirst && w1 && b1 && w2 && b2 && TT && Hn > 0 && T > 0 && n > 0);
   CLSR_CHECK_SUPPORTED(n % 4 == 0 && 2 * n <= 1024 && Hn * T < (1L << 31));
+  CLSR_CHECK_ARG(!XT || (hist && D > 0 && D % 4 == 0 && D <= 2 * n && col0 >= D && col0 % 4 == 0 && ldxt >= col0 + 2 * n &&
+                        ldxt % 4 == 0));
   int blocks = clsr_cdiv(Hn * T, (256 / ((2 * n) / 4)) * 4);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(t4_time_inputs_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tnow,
-                     tfirst, row_stride, w1, b1, w2, b2, Hn, T, n, TT);
+                     tfirst, row_stride, w1, b1, w2, b2, Hn, T, n, TT, hist, D, XT, ldxt, col0);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
+}
+extern "C" int clsr_t4_time_inputs_fwd(const float* tnow, const float* tfirst, long row_stride,
+                                       const float* w1, const float* b1, const float* w2,
+                                       const float* b2, long Hn, int T, int n, float* TT, void* stream) {
+  return clsr_t4_time_inputs_fwd2(tnow, tfirst, row_stride, w1, b1, w2, b2, Hn, T, n, TT, nullptr, 0, nullptr, 0, 0, stream);
 }
 
 // dpre = dTT * (1 - TT^2); partial[blk][0][c] = sum dpre * time ; partial[blk][1][c] = sum dpre

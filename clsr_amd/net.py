@@ -135,6 +135,7 @@ class CLSRNet(object):
         self.stream_alias = {} if os.environ.get("CLSR_FOLD_AUX") == "0" else {"@aux": "@lt"}
         self.side_priority = int(os.environ.get("CLSR_SIDE_PRIORITY", "0"))
         self.dw_priority = int(os.environ.get("CLSR_DW_PRIORITY", "0"))
+        self.fuse_tt = not os.environ.get("CLSR_NO_FUSE_TT")   # A/B: time-gate blocks of the input projection as one product over [hist | TT]
         self.fused_logit_tail = not os.environ.get("CLSR_NO_FUSED_LOGIT_TAIL")   # A/B: output layer + softmax loss + their backward in one launch
         self._defer_logit_out = False
         self.late_attmat_dw = bool(os.environ.get("CLSR_LATE_ATTMAT_DW"))   # A/B: attention_mat weight gradient behind the encoder tail
@@ -236,7 +237,7 @@ class CLSRNet(object):
         return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook),
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
                 self.lazy, self.rnn_first, self.lt_att_first, self.tick_early, self.hist_grad_two, self.dw_batch_late, self.bn_bwd_fused, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h, self.flush_side, self.l1_bwd_2pass,
-                self.split_g2, self.rnn_chunks, self.enc_bwd_fused, self.enc_bwd_fused_h, self.early_scatter, self.sort_late, self.late_attmat_dw, self.fused_logit_tail, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
+                self.split_g2, self.rnn_chunks, self.enc_bwd_fused, self.enc_bwd_fused_h, self.early_scatter, self.sort_late, self.late_attmat_dw, self.fused_logit_tail, self.fuse_tt, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
 
@@ -869,6 +870,21 @@ class CLSRNet(object):
                 self._pack("t4.tw", P[t + nm], H, H, o0=o0, i0=i0, total=(3 * H, 2 * H))
                 if training:
                     self._pack("t4.tw^T", P[t + nm], H, H, transposed=True, o0=i0, i0=o0, total=(2 * H, 3 * H))
+            if self._fuse_tt_ok():
+                # K-fused projection of the three time-gate blocks [o | tns | tls]:  [hist | pad | TT] . [W_x ; 0 ; W_t]
+                Dp = 16 * ((D + 15) // 16)
+                for nm, o0, i0 in (("_o_kernel_t1", 0, 0), ("_o_kernel_t2", 0, H), ("_time_kernel_t1", H, 0),
+                                   ("_time_kernel_t2", 2 * H, H)):
+                    self._pack("xw.t", P[t + nm], H, H, o0=o0, i0=Dp + i0, total=(3 * H, Dp + 2 * H))
+                for o0, W in ((0, P[t + "kernel"][0:D][:, 3 * H:4 * H]), (H, P[t + "_time_kernel_w1"]),
+                              (2 * H, P[t + "_time_kernel_w2"])):
+                    self._pack("xw.t", W, H, D, o0=o0, i0=0, total=(3 * H, Dp + 2 * H))
+
+    def _fuse_tt_ok(self):
+        """One product [hist | TT] . [W_x ; W_t] for the three time-gate blocks of the Time4LSTM projection (the last 3H
+        columns of the fused input projection) instead of hist . W_x followed by an accumulating TT . W_t pass over them."""
+        return (self.fuse_tt and self._t4_kind == "time4lstm" and self.enc_in % 4 == 0
+                and self._enc_off("t4") + 6 * self.H == self._xw_blocks()[1])
 
     def _unpack_grads(self):
         """Scatter the assembled gradient blocks (fused projection, time kernels) into the variables."""
@@ -1684,11 +1700,19 @@ class CLSRNet(object):
                 # tanh time features of the Time4LSTM gates depend on the feed only: on the (still idle) @lt stream
                 # beside the input projection instead of after it
                 t = self._t4_scope
+                fuse_tt = self._fuse_tt_ok()
+                Dp = 16 * ((D + 15) // 16)
+                XT = self._buf("t4.XT", M, Dp + 2 * H) if fuse_tt else None
+                TTb = self._buf("t4.TT", M, 2 * H)
                 with self._branch("@lt"):
-                    call("clsr_t4_time_inputs_fwd", f["time_to_now"], f["time_from_first_action"], hs * T,
+                    call("clsr_t4_time_inputs_fwd2", f["time_to_now"], f["time_from_first_action"], hs * T,
                          P[t + "_time_input_w1"], P[t + "_time_input_bias1"], P[t + "_time_input_w2"],
-                         P[t + "_time_input_bias2"], Hn, T, H, self._buf("t4.TT", M, 2 * H))
-            self._gemm(hist, D, "xw", M, D, NX, PinAll, NX, bias=self._buf("xw.bias", NX))
+                         P[t + "_time_input_bias2"], Hn, T, H, TTb, hist if fuse_tt else None, D if fuse_tt else 0, XT,
+                         Dp + 2 * H if fuse_tt else 0, Dp if fuse_tt else 0)
+            else:
+                fuse_tt = False
+            # (with the K-fused time-gate product the first launch stops in front of those 3H columns)
+            self._gemm(hist, D, "xw", M, D, NX - 3 * H if fuse_tt else NX, PinAll, NX, bias=self._buf("xw.bias", NX))
             if early_aux is not None or (training and self.sorted_hist_grad):
                 # work that depends on the feed only -- accumulator zeroing / row marks of the training step
                 # (``early_aux``) and the ~35 tiny launches that sort the history ids by row id for the backward's
@@ -1713,7 +1737,13 @@ class CLSRNet(object):
                 if hp.sequential_model == "time4lstm":
                     TT = self._buf("t4.TT", M, 2 * H)
                     self._join("@lt")     # the time features were computed beside the fused input projection
-                    self._gemm(TT, 2 * H, "t4.tw", M, 2 * H, 3 * H, PinAll[:, t4off + 3 * H:], NX, acc=1)
+                    if fuse_tt:
+                        # ONE product over [hist | TT] (K = 48 + 80) writes the time-gate columns: the separate pass that
+                        # re-read and re-wrote them (hist . W_x first, += TT . W_t behind it: 112 us alone) is gone
+                        self._gemm(XT, Dp + 2 * H, "xw.t", M, Dp + 2 * H, 3 * H, PinAll[:, t4off + 3 * H:], NX,
+                                   bias=self._buf("xw.bias", NX)[t4off + 3 * H:])
+                    else:
+                        self._gemm(TT, 2 * H, "t4.tw", M, 2 * H, 3 * H, PinAll[:, t4off + 3 * H:], NX, acc=1)
                 rnn_out = self._buf("rnn_out", Hn, T, H)
                 t4d = ops.t4_desc(H, Pin=PinAll[:, t4off:], ldp=NX, Wm=P[t + "kernel"][D:], ldm=4 * H, out_seq=rnn_out,
                                   act=self._buf("t4.act", Hn, T, 6 * H) if training else None,

@@ -290,6 +290,13 @@ int clsr_t4lstm_bwd(const float* act, const float* cst, const float* Wm, int ldm
 int clsr_t4_time_inputs_fwd(const float* tnow, const float* tfirst, long row_stride, const float* w1,
                             const float* b1, const float* w2, const float* b2, long Hn, int T, int n,
                             float* TT, void* stream);
+/* the same, and (XT != NULL) a second image of every row:  XT[row, 0:D] = hist[row, :],  XT[row, col0:col0+2n] = TT[row, :]
+ * (row stride ldxt, the columns between stay as they are: zero) -- the input of ONE product for the three time-gate blocks
+ * of the Time4LSTM input projection, [hist | TT] . [W_x ; W_t] instead of hist . W_x followed by += TT . W_t
+ * (rnn_cell_implement.py:207-231). */
+int clsr_t4_time_inputs_fwd2(const float* tnow, const float* tfirst, long row_stride, const float* w1, const float* b1,
+                             const float* w2, const float* b2, long Hn, int T, int n, float* TT, const float* hist, int D,
+                             float* XT, int ldxt, int col0, void* stream);
 int clsr_t4_time_inputs_bwd_parts(long Hn, int T, int n);
 int clsr_t4_time_inputs_bwd(const float* dTT, const float* TT, const float* tnow, const float* tfirst,
                             long row_stride, long Hn, int T, int n, float* partial, void* stream);
