@@ -35,6 +35,7 @@ struct PGemmArgs {
   // (sum v, sum v * xhat) with xhat = (ez - e_mean) * e_invstd  (ez = pre-BN activation at [m, n])
   const float* ez; int ldez; const float* e_scale; const float* e_shift; const float* e_mean; const float* e_invstd;
   int no_ring;                    // A/B switch (CLSR_PGEMM_NO_RING): wide-K plain products load one k-tile ahead only
+  int no_compact;                 // A/B switch (CLSR_PGEMM_NO_COMPACT): four MFMAs for a last k-tile of 8 features
   // time-range form (clsr_pgemm_range): M = Hn * rm_tc virtual rows, virtual row v is the physical row
   // (v / rm_tc) * rm_T + rm_t0 + v % rm_tc of X and of Y -- the steps [t0, t0 + tc) of every history of [Hn, T, .] tensors
   int rm_tc, rm_T, rm_t0;
@@ -219,13 +220,30 @@ __global__ void __launch_bounds__(256) pgemm_fast_kernel(PGemmArgs a) {
   const int KT = (a.K + 15) >> 4;
   const int Kp = a.Kp;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // COMPACT LAST K-TILE (K % 16 == 8: the 40-wide inputs of this model).  The last k-tile holds 8 features in the lane
+  // groups g = 0, 1 and each of its four MFMAs is half empty.  Instead: lane groups 2, 3 take the features 2, 3 / 6, 7 of
+  // the tile (the float4 of groups 0, 1 again, components z, w) and the weight tile is staged with those columns moved to k' = 8, 9 / 12, 13
+  // -- then the components x, y of every lane cover all eight features and TWO MFMAs do the work of four: 10 instead
+  // of 12 MFMAs per out-tile and row at K = 40 (the z, w components meet zero weights and are not issued).
+  const bool cmp_last = (a.K & 15) == 8 && !a.no_compact;
+  const int kt_last = KT - 1;
   {  // stage this block's W^T chunk (rows n0 .. n0 + 16*otc); missing out-tiles are zero-filled
     const float* src = a.Wt + (long)n0 * a.ldw;
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
     const int Kq = Kp >> 2, cnt = 16 * otc * Kq, tot = 16 * OT * Kq;
     for (int e = tid; e < tot; e += 256) {
       const int row = e / Kq, c = e - row * Kq;
-      dst[e] = e < cnt ? ld4(src + (long)row * a.ldw + 4 * c) : zero4;
+      f32x4 v = zero4;
+      if (e < cnt) {
+        const int cl = c - 4 * kt_last;            // chunk inside the last k-tile (0..3) or outside it
+        if (cmp_last && cl >= 0 && cl < 4) {
+          const f32x4 s4 = ld4(src + (long)row * a.ldw + 4 * (4 * kt_last + (cl & 1)));
+          v = cl < 2 ? (f32x4){s4.x, s4.y, 0.f, 0.f} : (f32x4){s4.z, s4.w, 0.f, 0.f};
+        } else {
+          v = ld4(src + (long)row * a.ldw + 4 * c);
+        }
+      }
+      dst[e] = v;
     }
   }
   __syncthreads();
@@ -309,7 +327,8 @@ __global__ void __launch_bounds__(256) pgemm_fast_kernel(PGemmArgs a) {
     // iteration later, so the loads stay in flight behind the MFMAs of the current k-tile)
     struct Raw { f32x4 x0, x1, p0, p1; };
     auto issue = [&](int kt) -> Raw {
-      const int kcol = kt * 16 + 4 * g;
+      // (compact tile: lane groups 2, 3 re-read the float4 of groups 0, 1 and use its z, w components -- aligned, in range)
+      const int kcol = (cmp_last && kt == kt_last && g >= 2) ? kt * 16 + 4 * (g - 2) : kt * 16 + 4 * g;
       const int kc = kcol < a.K ? kcol : 0;
       Raw q;
       q.x0 = ld4(xp[0] + kc);
@@ -319,7 +338,7 @@ __global__ void __launch_bounds__(256) pgemm_fast_kernel(PGemmArgs a) {
       return q;
     };
     auto finish = [&](const Raw& q, int kt, f32x4& b0, f32x4& b1) {
-      const bool ink = kt * 16 + 4 * g < a.K;
+      const bool ink = (cmp_last && kt == kt_last) || kt * 16 + 4 * g < a.K;
       f32x4 v0 = q.x0, v1 = q.x1;
       if (PRO == PRO_MUL) { v0 *= q.p0; v1 *= q.p1; }
       if (PRO == PRO_AFF) {
@@ -330,6 +349,7 @@ __global__ void __launch_bounds__(256) pgemm_fast_kernel(PGemmArgs a) {
       }
       b0 = ink ? v0 : zero4;
       b1 = ink ? v1 : zero4;
+      if (cmp_last && kt == kt_last && g >= 2) { b0.x = b0.z; b0.y = b0.w; b1.x = b1.z; b1.y = b1.w; }
     };
 
     Raw rawk[KTT > 0 ? KTT : 1];
@@ -373,6 +393,7 @@ __global__ void __launch_bounds__(256) pgemm_fast_kernel(PGemmArgs a) {
       for (int ot = 0; ot < OT; ++ot) { MFMA4(acc[0][ot], wt[ot].x, b0.x); MFMA4(acc[1][ot], wt[ot].x, b1.x); }
 #pragma unroll
       for (int ot = 0; ot < OT; ++ot) { MFMA4(acc[0][ot], wt[ot].y, b0.y); MFMA4(acc[1][ot], wt[ot].y, b1.y); }
+      if (cmp_last && kt == kt_last) return;
 #pragma unroll
       for (int ot = 0; ot < OT; ++ot) { MFMA4(acc[0][ot], wt[ot].z, b0.z); MFMA4(acc[1][ot], wt[ot].z, b1.z); }
 #pragma unroll
@@ -580,6 +601,7 @@ extern "C" int clsr_pgemm(const float* X, int ldx, int T, int G, const float* Xm
   a.Y = Y; a.ldy = ldy; a.accumulate = accumulate; a.stats = stats; a.M = M; a.K = K; a.N = N;
   a.ez = nullptr; a.ldez = 0; a.e_scale = a.e_shift = a.e_mean = a.e_invstd = nullptr;
   a.no_ring = getenv("CLSR_PGEMM_NO_RING") ? 1 : 0;
+  a.no_compact = getenv("CLSR_PGEMM_NO_COMPACT") ? 1 : 0;
   a.rm_tc = a.rm_T = a.rm_t0 = 0;
   return pgemm_dispatch(a, (hipStream_t)stream);
 }
