@@ -142,6 +142,7 @@ class CLSRNet(object):
         self._late_dw = None
         self.sort_late = bool(os.environ.get("CLSR_SORT_LATE"))     # A/B: history-id sort beside the heads instead of at the start of the step (measured: no difference, 3.66 ms both)
         self.early_scatter = not os.environ.get("CLSR_NO_EARLY_SCATTER")   # A/B: row scatters of the user / target lookups beside the encoder-backward tail instead of behind it
+        self.dhist_side = not os.environ.get("CLSR_NO_DHIST_SIDE")      # A/B (speed mode): d(hist) product on the long-term stream (2.87 -> 2.84 ms)
         self.enc_bwd_fused_h = not os.environ.get("CLSR_NO_ENC_BWD_FUSED_H")   # A/B: the speed-mode (bf16 dPin) form of the fused encoder tail
         self.enc_bwd_fused = not os.environ.get("CLSR_NO_ENC_BWD_FUSED")   # A/B: one pass over dPin for the seven encoder-side weight gradients + d(hist) (csrc/encbwd.hip)
         self.rnn_chunks = int(os.environ.get("CLSR_RNN_CHUNKS", "1"))   # measured at configs[1]: 4.17-4.21 ms with 5 ranges, 4.11 with 3, against 3.91 with one launch (the projections throttle the chain, ~30 us start-up + ~15 us cross-stream signalling per range) -- kept as a switch
@@ -237,7 +238,7 @@ class CLSRNet(object):
         return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook),
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
                 self.lazy, self.rnn_first, self.lt_att_first, self.tick_early, self.hist_grad_two, self.dw_batch_late, self.bn_bwd_fused, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h, self.flush_side, self.l1_bwd_2pass,
-                self.split_g2, self.rnn_chunks, self.enc_bwd_fused, self.enc_bwd_fused_h, self.early_scatter, self.sort_late, self.late_attmat_dw, self.fused_logit_tail, self.fuse_tt, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
+                self.split_g2, self.rnn_chunks, self.enc_bwd_fused, self.enc_bwd_fused_h, self.dhist_side, self.early_scatter, self.sort_late, self.late_attmat_dw, self.fused_logit_tail, self.fuse_tt, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
 
@@ -1550,7 +1551,12 @@ class CLSRNet(object):
                  self._buf("g2.gates", Hn, T, 3 * H), *wss, None, 0, None, M)
         if side:
             self._dw_async = True       # (the flush waits for the weight-gradient stream)
-        self._gemm(dPinAll, NX, "xw^T", M, NX, D, dhist, D, acc=1)
+        if self.dhist_side and self.overlap:
+            # three ways: weight gradients on @dw0, d(hist) on the (by now idle) long-term stream, the time-feature chain here
+            with self._branch("@lt", after=self._fork_point(), name="@dhist"):
+                self._gemm(dPinAll, NX, "xw^T", M, NX, D, dhist, D, acc=1)
+        else:
+            self._gemm(dPinAll, NX, "xw^T", M, NX, D, dhist, D, acc=1)
         self._t4_time_chain_bwd(f, dPinAll, Hn, T, hs)
 
     def _encoders_bwd_chunked(self, f, chunks, hist, dhist, drnn, dsi, dfs, Hn, T, seq_len, ls, hs):
