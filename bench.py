@@ -281,7 +281,7 @@ def main():
     ap.add_argument("--model", default="clsr", choices=["clsr", "gru4rec", "din", "sli_rec", "a2svd", "dien"],
                     help="clsr = the BASELINE metric (default); the sibling models run the same step machinery "
                          "(clsr_amd/seqnet.py) and report the same metric for comparison")
-    ap.add_argument("--precision", default=os.environ.get("CLSR_PRECISION", "fp32"), choices=["fp32", "bf16"],
+    ap.add_argument("--precision", default=os.environ.get("CLSR_PRECISION", "fp32"), choices=["fp32", "fp32x3", "bf16"],
                     help="fp32 = the reference's arithmetic (parity mode, headline); bf16 = speed mode: bf16 storage of "
                          "the attention activations + bf16 MFMA with fp32 accumulation, statistics and optimiser")
     ap.add_argument("--exact-clip", action="store_true",

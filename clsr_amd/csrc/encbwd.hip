@@ -561,6 +561,214 @@ extern "C" int clsr_enc_bwd_fused_h(const void* dPin_bf16, const float* hist, co
   return CLSR_OK;
 }
 
+// ------------------------------------------------------------------------------------ "fp32x3" mode (split-bf16 products)
+// The seven weight gradients of the same tail from the fp32 dPin, as split-bf16 products on v_mfma_f32_16x16x32_bf16
+// (every value = bf16 hi + bf16 lo, product = lo*hi + hi*lo + hi*hi, fp32 accumulation; see csrc/dw3.hip): the fp32-MFMA
+// kernel above is bound by the matrix pipe (26 GFLOP at 0.46 of the fp32 peak = 320-350 us in the step, 6x its operand
+// traffic at the HBM rate); three bf16 MFMAs do the work of eight fp32 ones at 16x the rate.  Same tile ownership,
+// accumulators and partial layout as the other two kernels.  What differs is the LDS image: POSITION-major --
+// [32 positions][368 left-operand features | 480 dPin columns] bf16, one image for the hi parts and one for the lo
+// parts (2 x 54 KB) -- written with 8-byte stores by threads that walk the rows of the tensors linearly (every global
+// load instruction covers whole contiguous row segments; the position-fast mapping of the bf16 kernel above asks for 16
+// bytes out of 64 different rows per instruction), and read through ds_read_b64_tr_b16, the LDS transpose read of
+// gfx950: the 16 lanes of a group pass the addresses of a [4 positions][16 features] block and every lane receives
+// one feature's four positions -- two of them are an MFMA operand (k-slots = positions 4g..4g+3 and 16+4g..16+4g+3 of
+// the stage; A and B operands use the same map).  Row stride 1 696 B = 424 dwords = 40 mod 64: the eight rows a
+// half-wave reads land on disjoint bank groups.  The bias sums are a row of ones in the hist tile; d(hist) = dPin . W_x^T
+// stays a launch of its own (clsr_pgemm3) beside this one.
+#define EBX_ST 32
+#define EBX_ROW (EB_XW + EB_NX)            // bf16 per position row
+#define EBX_RB (EBX_ROW * 2)               // bytes per position row
+#define EBX_IMG (EBX_ST * EBX_RB)          // bytes per image
+struct EncBwdXArgs {
+  const float* dPin;              // [M, 480] fp32
+  const float* hist; const float* hp1; const float* g1; const float* mprev; const float* TT; const float* hp2;
+  const float* g2;
+  float* ws[7];
+  long M;
+};
+typedef short ebx_s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) unsigned char ebx_lds_t;
+// MFMA operand: features 16-wide block at byte offset ``off`` of the image rows, this lane's two transpose reads
+__device__ __forceinline__ ebh_bf16x8 ebx_tr2(ebx_lds_t* p) {
+  const ebx_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<__attribute__((address_space(3))) ebx_s16x4*>(p));
+  const ebx_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<__attribute__((address_space(3))) ebx_s16x4*>(p + 16 * EBX_RB));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  return __builtin_bit_cast(ebh_bf16x8, (s16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]});
+}
+// 4 fp32 -> 4 bf16 hi, 4 bf16 lo (two 8-byte words)
+__device__ __forceinline__ void ebx_split4(const f32x4& v, unsigned long long& hi, unsigned long long& lo) {
+  typedef __bf16 h2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  unsigned h[2], l[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const float a = v[2 * p], b = v[2 * p + 1];
+    const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){a, b}, h2));
+    const float ah = __builtin_bit_cast(float, hp << 16), bh = __builtin_bit_cast(float, hp & 0xffff0000u);
+    h[p] = hp;
+    l[p] = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){a - ah, b - bh}, h2));
+  }
+  hi = (unsigned long long)h[0] | ((unsigned long long)h[1] << 32);
+  lo = (unsigned long long)l[0] | ((unsigned long long)l[1] << 32);
+}
+
+// MFMAs of one stage, unrolled at compile time; dPin tiles OUTER (their operands: 8 registers at a time -- all of a wave's
+// tiles at once would be 64 on top of 220 accumulators and 100 registers of prefetched operands), the left-operand tiles
+// are re-read from LDS for every dPin tile that needs them (4 transpose reads per 3 MFMAs: far below the LDS rate)
+template <int W, int PI, int X>
+__device__ __forceinline__ void ebx_one(f32x4 (&acc)[eb_count(W)], const ebh_bf16x8& bvh, const ebh_bf16x8& bvl,
+                                        ebx_lds_t* xh, ebx_lds_t* xl) {
+  if constexpr (eb_need(X, eb_tile(W, PI))) {
+    constexpr int n = eb_acc(W, PI, X);
+    const ebh_bf16x8 avh = ebx_tr2(xh + 32 * X), avl = ebx_tr2(xl + 32 * X);
+    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(avl, bvh, acc[n], 0, 0, 0);
+    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(avh, bvl, acc[n], 0, 0, 0);
+    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(avh, bvh, acc[n], 0, 0, 0);
+  }
+}
+template <int W, int PI, int... X>
+__device__ __forceinline__ void ebx_col(f32x4 (&acc)[eb_count(W)], const ebh_bf16x8& bvh, const ebh_bf16x8& bvl,
+                                        ebx_lds_t* xh, ebx_lds_t* xl, std::integer_sequence<int, X...>) {
+  (ebx_one<W, PI, X>(acc, bvh, bvl, xh, xl), ...);
+}
+template <int W, int PI>
+__device__ __forceinline__ void ebx_p(f32x4 (&acc)[eb_count(W)], ebx_lds_t* th, ebx_lds_t* tl) {
+  // (an offset the compiler cannot see through: the left-operand reads of different dPin tiles must not be merged into
+  //  one set of 23 x 8 live registers)
+  int o = 0;
+  asm volatile("" : "+v"(o));
+  const ebh_bf16x8 bvh = ebx_tr2(th + o + (EB_XW + 16 * eb_tile(W, PI)) * 2), bvl = ebx_tr2(tl + o + (EB_XW + 16 * eb_tile(W, PI)) * 2);
+  ebx_col<W, PI>(acc, bvh, bvl, th + o, tl + o, std::make_integer_sequence<int, EB_NXT>{});
+}
+template <int W, int... PI>
+__device__ __forceinline__ void ebx_all(f32x4 (&acc)[eb_count(W)], ebx_lds_t* th, ebx_lds_t* tl, std::integer_sequence<int, PI...>) {
+  (ebx_p<W, PI>(acc, th, tl), ...);
+}
+
+template <int W>
+__device__ __forceinline__ void ebx_body(const EncBwdXArgs& a, unsigned char* lds) {
+  ebx_lds_t* const Lh = (ebx_lds_t*)lds;        // hi image, then the lo image (C-style cast: generic -> LDS address space)
+  const int lane = threadIdx.x & 63, tid = W * 64 + lane;
+  const int c16 = lane & 15, g = lane >> 4;
+  for (int e = tid; e < 2 * EBX_IMG / 16; e += 256) reinterpret_cast<f32x4*>(lds)[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // ---- staging plan (stage invariant)
+  //  dPin: thread = (position tid >> 3, pieces (tid & 7) + 8 q, q < 15): 8 lanes read 128 contiguous bytes of a row
+  //  left operands (40- / 80-wide rows without gaps: a stage's 32 rows are ONE contiguous block, read linearly, piece
+  //  lane + 64 i):  wave 0  hp1, r1 -> hp1, hp1 * r1 | wave 1  hp2, r2 | wave 2  hist, TT[0:320] | wave 3  mprev, TT[320:640]
+  constexpr int NPP = 15, NXP = 5;
+  const int posP = tid >> 3, subP = tid & 7;
+  int posX[NXP], colX[NXP], posT[NXP], colT[NXP];
+#pragma unroll
+  for (int i = 0; i < NXP; ++i) {
+    const int p = lane + 64 * i;
+    posX[i] = p / 10;
+    colX[i] = 4 * (p - posX[i] * 10);
+    const int pt = p + (W == 3 ? 320 : 0);
+    posT[i] = pt / 20;
+    colT[i] = 4 * (pt - posT[i] * 20);
+  }
+  f32x4 pr[NPP], xa[NXP], xb[NXP];
+  const long nst = (a.M + EBX_ST - 1) / EBX_ST;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](long st) {
+    const long m0 = st * EBX_ST;
+    const float* dp = a.dPin + min(m0 + posP, a.M - 1) * EB_NX + 4 * subP;
+#pragma unroll
+    for (int q = 0; q < NPP; ++q) pr[q] = ld4(dp + 32 * q);
+#pragma unroll
+    for (int i = 0; i < NXP; ++i) {
+      const long m = min(m0 + posX[i], a.M - 1), mt = min(m0 + posT[i], a.M - 1);
+      if (W == 0) { xa[i] = ld4(a.hp1 + m * 40 + colX[i]); xb[i] = ld4(a.g1 + m * 120 + colX[i]); }
+      if (W == 1) { xa[i] = ld4(a.hp2 + m * 40 + colX[i]); xb[i] = ld4(a.g2 + m * 120 + colX[i]); }
+      if (W == 2) { xa[i] = ld4(a.hist + m * 40 + colX[i]); xb[i] = ld4(a.TT + mt * 80 + colT[i]); }
+      if (W == 3) { xa[i] = ld4(a.mprev + m * 40 + colX[i]); xb[i] = ld4(a.TT + mt * 80 + colT[i]); }
+    }
+  };
+  auto put = [&](int pos, int feat, const f32x4& v, bool ok) {
+    unsigned long long hi, lo;
+    ebx_split4(ok ? v : z4, hi, lo);
+    ebx_lds_t* d = Lh + pos * EBX_RB + feat * 2;
+    *reinterpret_cast<__attribute__((address_space(3))) unsigned long long*>(d) = hi;
+    *reinterpret_cast<__attribute__((address_space(3))) unsigned long long*>(d + EBX_IMG) = lo;
+  };
+  auto stage = [&](long mbase) {
+    const bool okP = mbase + posP < a.M;
+#pragma unroll
+    for (int q = 0; q < NPP; ++q) put(posP, EB_XW + 4 * subP + 32 * q, pr[q], okP);
+#pragma unroll
+    for (int i = 0; i < NXP; ++i) {
+      const bool ok = mbase + posX[i] < a.M, okt = mbase + posT[i] < a.M;
+      if (W == 0) { put(posX[i], 48 + colX[i], xa[i], ok); put(posX[i], 96 + colX[i], xa[i] * xb[i], ok); }
+      if (W == 1) { put(posX[i], 272 + colX[i], xa[i], ok); put(posX[i], 320 + colX[i], xa[i] * xb[i], ok); }
+      if (W == 2) { put(posX[i], colX[i], xa[i], ok); put(posT[i], 192 + colT[i], xb[i], okt); }
+      if (W == 3) { put(posX[i], 144 + colX[i], xa[i], ok); put(posT[i], 192 + colT[i], xb[i], okt); }
+    }
+    if (W == 1 && lane < EBX_ST)      // the row of ones (feature 40 of the hist tile): bias sums; hi = 1, lo = 0
+      *reinterpret_cast<__attribute__((address_space(3))) unsigned short*>(Lh + lane * EBX_RB + 40 * 2) =
+          (mbase + lane < a.M) ? (unsigned short)0x3f80 : (unsigned short)0;
+  };
+
+  constexpr int NA = eb_count(W), NP = eb_nt(W);
+  f32x4 acc[NA];
+#pragma unroll
+  for (int n = 0; n < NA; ++n) acc[n] = z4;
+  // this lane's transpose-read base: row 4 g + (c16 >> 2), 8-byte column piece c16 & 3
+  ebx_lds_t* const th = Lh + (4 * g + (c16 >> 2)) * EBX_RB + (c16 & 3) * 8;
+  ebx_lds_t* const tl = th + EBX_IMG;
+
+  long st = blockIdx.x;
+  if (st < nst) fetch(st);
+  for (; st < nst; st += gridDim.x) {
+    __syncthreads();                 // the previous stage's image is free (first trip: the zero fill is complete)
+    stage(st * EBX_ST);
+    __syncthreads();
+    if (st + gridDim.x < nst) fetch(st + gridDim.x);      // next stage's operands fly behind the MFMAs below
+    ebx_all<W>(acc, th, tl, std::make_integer_sequence<int, NP>{});
+  }
+  const float nob[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  eb_store<W, true>(a.ws, acc, nob, lane, blockIdx.x, gridDim.x);
+}
+
+__global__ void __launch_bounds__(256) enc_bwd_fused_x3_kernel(EncBwdXArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsx[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave == 0) ebx_body<0>(a, ldsx);
+  else if (wave == 1) ebx_body<1>(a, ldsx);
+  else if (wave == 2) ebx_body<2>(a, ldsx);
+  else ebx_body<3>(a, ldsx);
+}
+
+static int ebx_grid(long M) {
+  long st = (M + EBX_ST - 1) / EBX_ST;
+  return (int)(st < 256 ? st : 256);
+}
+extern "C" int clsr_enc_bwd_fused_x3_parts(long M) { return ebx_grid(M); }
+extern "C" long clsr_enc_bwd_fused_x3_workspace_floats(long M, int p) {
+  if (p < 0 || p > 6) return 0;
+  return (long)clsr_cdiv(eb_N(p), 80) * ebx_grid(M) * EB_CHUNK;
+}
+// the seven weight gradients (+ bias sums) of clsr_enc_bwd_fused as split-bf16 products; d(hist) is NOT part of this launch
+extern "C" int clsr_enc_bwd_fused_x3(const float* dPin, const float* hist, const float* hprev1, const float* gates1,
+                                     const float* mprev, const float* TT, const float* hprev2, const float* gates2,
+                                     float* ws_hist, float* ws_hp1, float* ws_hp1r, float* ws_mprev, float* ws_tt,
+                                     float* ws_hp2, float* ws_hp2r, long M, void* stream) {
+  CLSR_CHECK_ARG(dPin && hist && hprev1 && gates1 && mprev && TT && hprev2 && gates2 && M > 0);
+  CLSR_CHECK_ARG(ws_hist && ws_hp1 && ws_hp1r && ws_mprev && ws_tt && ws_hp2 && ws_hp2r);
+  CLSR_CHECK_SUPPORTED(((uintptr_t)dPin % 16) == 0 && ((uintptr_t)hist % 16) == 0 && ((uintptr_t)hprev1 % 16) == 0 &&
+                       ((uintptr_t)gates1 % 16) == 0 && ((uintptr_t)mprev % 16) == 0 && ((uintptr_t)TT % 16) == 0 &&
+                       ((uintptr_t)hprev2 % 16) == 0 && ((uintptr_t)gates2 % 16) == 0);
+  EncBwdXArgs a = {};
+  a.dPin = dPin; a.hist = hist; a.hp1 = hprev1; a.g1 = gates1; a.mprev = mprev; a.TT = TT; a.hp2 = hprev2; a.g2 = gates2;
+  a.M = M;
+  a.ws[0] = ws_hist; a.ws[1] = ws_hp1; a.ws[2] = ws_hp1r; a.ws[3] = ws_mprev; a.ws[4] = ws_tt; a.ws[5] = ws_hp2; a.ws[6] = ws_hp2r;
+  const size_t shmem = (size_t)2 * EBX_IMG;
+  CLSR_HIP(hipFuncSetAttribute((const void*)enc_bwd_fused_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL(enc_bwd_fused_x3_kernel, dim3(ebx_grid(M)), dim3(256), shmem, (hipStream_t)stream, a);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
 static_assert(eb_count(0) + eb_count(1) + eb_count(2) + eb_count(3) == 211, "every wanted block has an owner");
 static_assert(eb_count(0) <= 56 && eb_count(1) <= 56 && eb_count(2) <= 56 && eb_count(3) <= 56, "accumulator budget");
 

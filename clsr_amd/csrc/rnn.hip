@@ -821,6 +821,8 @@ static int fill_multi(RnnMultiArgs& m, const clsr_gru_desc* grus, int ngru, cons
     a.lddp = d.lddp > 0 ? d.lddp : 3 * d.n;
     a.dpin_bf16 = d.dpin_bf16;
     CLSR_CHECK_SUPPORTED(a.lddp % 4 == 0);
+    // the branch-free stores address a block's 16 histories with 32-bit BYTE offsets into one buffer resource
+    CLSR_CHECK_SUPPORTED(16L * T * (a.lddp > 3 * d.n ? a.lddp : 3 * d.n) * 4 < 0x80000000L);
     a.att = d.att; a.datt = d.datt; a.in_div = d.in_div > 1 ? d.in_div : 1;
     a.t0 = t0; a.t1 = t1;
     CLSR_CHECK_ARG(!(backward && d.att && !d.datt));
@@ -838,6 +840,7 @@ static int fill_multi(RnnMultiArgs& m, const clsr_gru_desc* grus, int ngru, cons
     a.lddp = t4->lddp > 0 ? t4->lddp : 6 * t4->n;
     a.dpin_bf16 = t4->dpin_bf16;
     CLSR_CHECK_SUPPORTED(a.lddp % 4 == 0);
+    CLSR_CHECK_SUPPORTED(16L * T * (a.lddp > 6 * t4->n ? a.lddp : 6 * t4->n) * 4 < 0x80000000L);
     a.t0 = t0; a.t1 = t1;
     a.st_in = t4->st_in; a.st_out = t4->st_out; a.dst_in = t4->dst_in; a.dst_out = t4->dst_out;
   }

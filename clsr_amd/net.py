@@ -65,8 +65,8 @@ class CLSRNet(object):
         self.dims = dict(dims)
         self.device = torch.device(device)
         self.dedup = bool(dedup_histories)
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+        if precision not in ("fp32", "fp32x3", "bf16"):
+            raise ValueError("precision must be 'fp32', 'fp32x3' or 'bf16'")
         self.precision = precision
         self._check_supported()
         self.Di, self.Dc = hp.item_embedding_dim, hp.cate_embedding_dim
@@ -83,8 +83,18 @@ class CLSRNet(object):
         self.packed = {}
         self.packed_h = {}         # bf16 images of the weights the speed-mode attention kernels read (csrc/hgemm.hip)
         self.bf16 = self.precision == "bf16"
-        self.bf16_dw = not os.environ.get("CLSR_NO_HDW")        # A/B switch: weight gradients on the bf16 matrix pipe
-        self.bf16_bwd = not os.environ.get("CLSR_NO_HBWD")      # A/B switch: back-propagating products likewise
+        # "fp32x3": fp32 storage everywhere (tensors, layouts and launch structure of the exact mode); the MFMA-saturated
+        # products are taken as split-bf16 sums hi*hi + lo*hi + hi*lo on the bf16 matrix pipe (csrc/dw3.hip ...)
+        self.x3 = self.precision == "fp32x3"
+        # what runs as split products by default is what MEASURED faster (profiles/r04_split_bf16.md): the fused encoder tail
+        # (377 -> 174 us alone) and the skinny d(hist) = dPin . W_x^T product beside it (163 -> 134 us).  The generic
+        # weight-gradient kernel (csrc/dw3.hip) and the position-tiled products (csrc/gemm3.hip) are built and tested but
+        # stay opt-in: with their MFMA phase cut to 3/16 they are bound by memory latency, not by the pipe, and came out
+        # level or slower than the fp32-MFMA kernels whose long MFMA phases hide that latency (CLSR_X3_DW=1 /
+        # CLSR_X3_GEMM=all).
+        self.x3_dw = self.x3 and bool(os.environ.get("CLSR_X3_DW"))       # A/B: weight gradients (csrc/dw3.hip)
+        self.x3_gemm = self.x3 and os.environ.get("CLSR_X3_GEMM", "xw^T")  # "all" | comma-separated weight keys | ""
+        self.x3_enc = self.x3 and not os.environ.get("CLSR_NO_X3_ENC")    # A/B: fused encoder tail (csrc/encbwd.hip)
         self._cur_descs_h = []
         self._plans, self._plan_keep, self._cur_descs = {}, [], []
         self._sort_bytes = {}
@@ -560,7 +570,11 @@ class CLSRNet(object):
             return
         Wt, Kp = self.packed[wkey]
         sc, sh = (aff.scale, aff.shift) if aff is not None else (None, None)
-        call("clsr_pgemm", X, ldx, T, G, Xmul, ldmul, sc, sh, 1, Wt, Kp, bias, addU, ldu, addV, ldv, Y, ldy,
+        name = "clsr_pgemm"
+        if self._x3_site(wkey) and query("clsr_pgemm3_supported", int(Xmul is not None), int(aff is not None),
+                                  int(addU is not None), int(addV is not None), int(acc), int(stats is not None), M, K, N):
+            name = "clsr_pgemm3"
+        call(name, X, ldx, T, G, Xmul, ldmul, sc, sh, 1, Wt, Kp, bias, addU, ldu, addV, ldv, Y, ldy,
              acc, stats, M, K, N)
 
     def _dw(self, X, ldx, dY, ldy, M, K, N, dW, ldw, db=None, T=0, G=0, Xmul=None, ldmul=0, aff=None, acc=0,
@@ -593,7 +607,7 @@ class CLSRNet(object):
         else:
             self._dw_launch(X, x_bf16, ldx, T, G, Xmul, ldmul, sc, sh, dY, dy_bf16, ldy, M, K, N, ws, None)
         pend.append((ws.data_ptr(), dW.data_ptr(), db.data_ptr() if db is not None else 0, 1.0,
-                     query("clsr_hdw_parts" if (self.bf16 and self.bf16_dw) else "clsr_pgemm_dw_parts", M), K, N, ldw, acc))
+                     query(self._dw_parts_query(x_bf16 or dy_bf16), M), K, N, ldw, acc))
         if not self.defer_dw:
             self._dw_flush()
 
@@ -622,7 +636,8 @@ class CLSRNet(object):
             # fills sit on the current stream BEHIND the entry point -- this once the launch waits for everything
             # enqueued so far
             fork = self._fork_point()
-        name = "clsr_hdw_partial_multi" if (self.bf16 and self.bf16_dw) else "clsr_pgemm_dw_partial_multi"
+        name = ("clsr_hdw_partial_multi" if (self.bf16 and self.bf16_dw) else
+                "clsr_dw3_partial_multi" if self.x3_dw else "clsr_pgemm_dw_partial_multi")
         if self.dw_stream and self.overlap and self._ws_tag == "":
             side = self._side.get("@dw0")
             if side is None:
@@ -633,12 +648,27 @@ class CLSRNet(object):
         else:
             ops.dw_multi(name, jobs)
 
+    def _x3_site(self, wkey):
+        """does the product with the packed weights ``wkey`` run as a split-bf16 product (fp32x3 mode)?"""
+        sites = self.x3_gemm
+        if not sites:
+            return False
+        return sites == "all" or wkey in sites.split(",")
+
+    def _dw_parts_query(self, any_bf16=False):
+        """which query tells how many partial chunks the weight-gradient kernel of this mode writes"""
+        if self.bf16 and self.bf16_dw:
+            return "clsr_hdw_parts"
+        return "clsr_dw3_parts" if (self.x3_dw and not any_bf16) else "clsr_pgemm_dw_parts"
+
     def _dw_launch(self, X, x_bf16, ldx, T, G, Xmul, ldmul, sc, sh, dY, dy_bf16, ldy, M, K, N, ws, stream):
         """Partial-sum kernel of one weight gradient: the exact fp32-MFMA kernel, or -- speed mode -- the bf16-MFMA
         one (csrc/hdw.hip: operands rounded to bf16 when staged, fp32 accumulation), same partial layout."""
         if self.bf16 and self.bf16_dw:
             call("clsr_hdw_partial", X, x_bf16, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, dy_bf16, ldy, M, K, N, ws,
                  stream=stream)
+        elif self.x3_dw and not (x_bf16 or dy_bf16):
+            call("clsr_dw3_partial", X, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, ldy, M, K, N, ws, stream=stream)
         elif x_bf16 or dy_bf16:
             call("clsr_pgemm_dw_partial_h", X, x_bf16, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, dy_bf16, ldy, M, K, N, ws,
                  stream=stream)
@@ -718,7 +748,8 @@ class CLSRNet(object):
         Wt, Kp = self.packed[wkey]
         parts = query("clsr_pgemm_stats_parts", M)
         st = self._buf("stats" + self._ws_tag, 1024 * 2 * 256, dtype=torch.float64)[: parts * 2 * N]
-        call("clsr_pgemm_bnbwd", dY, ldy_in, Wt, Kp, out, N, z, N, bn.scale, bn.shift, bn.mean, bn.invstd, st, M, K, N)
+        call("clsr_pgemm3_bnbwd" if (self._x3_site(wkey) and query("clsr_pgemm3_bnbwd_supported", M, K, N)) else "clsr_pgemm_bnbwd", dY, ldy_in, Wt, Kp, out, N, z, N,
+             bn.scale, bn.shift, bn.mean, bn.invstd, st, M, K, N)
         self._bn_bwd_from_partial(bn, st, parts, out, z, M)
 
     def _bn_relu_bwd(self, bn, dh, z, M):
@@ -1523,6 +1554,40 @@ class CLSRNet(object):
              self._buf("t4.mprev", Hn, T, H), TT, self._buf("g2.hprev", Hn, T, H), self._buf("g2.gates", Hn, T, 3 * H),
              Wt, Kp, dhist, *wss, M)
 
+    def _enc_bwd_fused_x3(self, f, hist, dPinAll, dhist, Hn, T, hs):
+        """fp32x3 mode: the seven encoder-side weight gradients from ONE pass over the fp32 dPin as split-bf16 products
+        (clsr_enc_bwd_fused_x3) on the weight-gradient stream, beside d(hist) = dPin . W_x^T (long-term stream) and the
+        time-feature chain on the compute stream -- the launch structure of the speed mode's tail."""
+        Gd, D, H, NX, E = self.Gd, self.D, self.H, self.NX, self.enc_in
+        M = Hn * T
+        st, t = CL + "short_term/", self._t4_scope
+        g1, g2 = st + "short_term_intention/gru_cell/", CL + "causal2/causal2/gru_cell/"
+        parts = query("clsr_enc_bwd_fused_x3_parts", M)
+        prods = [(self._buf("xw.dW", D, NX), NX, self._buf("xw.db", NX), D, NX),
+                 (Gd[g1 + "gates/kernel"][E:], 2 * H, None, H, 2 * H), (Gd[g1 + "candidate/kernel"][E:], H, None, H, H),
+                 (Gd[t + "kernel"][E:], 4 * H, None, H, 4 * H), (self._buf("t4.dTW", 2 * H, 3 * H), 3 * H, None, 2 * H, 3 * H),
+                 (Gd[g2 + "gates/kernel"][E:], 2 * H, None, H, 2 * H), (Gd[g2 + "candidate/kernel"][E:], H, None, H, H)]
+        pend = self._dw_pending.setdefault("", [])
+        wss = []
+        for i, (dW, ldw, db, K, N) in enumerate(prods):
+            ws = self._buf("encbx.ws%d" % i, query("clsr_enc_bwd_fused_x3_workspace_floats", M, i))
+            wss.append(ws)
+            pend.append((ws.data_ptr(), dW.data_ptr(), db.data_ptr() if db is not None else 0, 1.0, parts, K, N, ldw, 0))
+        self._buf("t4.dTT", M, 2 * H)      # (workspaces of the branches exist before the fork: see _enc_bwd_fused)
+        side = self.dw_stream and self.overlap
+        with self._branch("@dw0" if side else "@main", after=self._fork_point(), name="@encw"):
+            call("clsr_enc_bwd_fused_x3", dPinAll, hist, self._buf("g1.hprev", Hn, T, H), self._buf("g1.gates", Hn, T, 3 * H),
+                 self._buf("t4.mprev", Hn, T, H), self._buf("t4.TT", M, 2 * H), self._buf("g2.hprev", Hn, T, H),
+                 self._buf("g2.gates", Hn, T, 3 * H), *wss, M)
+        if side:
+            self._dw_async = True       # (the flush waits for the weight-gradient stream)
+        if self.dhist_side and self.overlap:
+            with self._branch("@lt", after=self._fork_point(), name="@dhist"):
+                self._gemm(dPinAll, NX, "xw^T", M, NX, D, dhist, D, acc=1)
+        else:
+            self._gemm(dPinAll, NX, "xw^T", M, NX, D, dhist, D, acc=1)
+        self._t4_time_chain_bwd(f, dPinAll, Hn, T, hs)
+
     def _enc_bwd_fused_h(self, f, hist, dPinAll, dhist, Hn, T, hs):
         """Speed mode: the seven encoder-side weight gradients from ONE pass over the bf16 dPin (clsr_enc_bwd_fused_h) on
         the weight-gradient stream, beside d(hist) = dPin . W_x^T and the time-feature chain on the compute stream."""
@@ -2001,7 +2066,8 @@ class CLSRNet(object):
                 self._scatter_rows_early(f, dul, None, dtarget, Hn, B, hs, fork)
                 self._scatter_rows_early(f, None, dushort, None, Hn, B, hs, self._fork_point())
             if self._enc_bwd_fused_ok(dpin_h):
-                (self._enc_bwd_fused_h if self.bf16 else self._enc_bwd_fused)(f, hist, dPinAll, dhist, Hn, T, hs)
+                (self._enc_bwd_fused_h if self.bf16 else self._enc_bwd_fused_x3 if self.x3_enc else
+                 self._enc_bwd_fused)(f, hist, dPinAll, dhist, Hn, T, hs)
             else:
               # input-side weights of every encoder in one reduction; d(hist) in one product; the hidden-side / time-feature
               # weight gradients ride in the same multi-job launch as the input-side one (they all depend on dPin only)
@@ -2264,6 +2330,10 @@ class CLSRNet(object):
     def precision_note(self):
         if self.precision == "fp32":
             return "all tensors fp32, v_mfma_f32_16x16x4_f32 (bit-exact fp32 fmaf chains): the parity mode"
+        if self.precision == "fp32x3":
+            return ("all tensors fp32 (storage, statistics, recurrences, losses, optimiser exactly as in the parity mode); the "
+                    "MFMA-saturated products are split-bf16 sums hi*hi + lo*hi + hi*lo on v_mfma_f32_16x16x32_bf16 with fp32 "
+                    "accumulation (<= 2^-16 relative per product)")
         return ("attention-block activations at (row, step) level stored as bf16, GEMMs on v_mfma_f32_16x16x32_bf16 "
                 "with fp32 accumulation; batch-norm statistics, softmax, recurrences, losses, gradients of the "
                 "parameters and the optimiser stay fp32")

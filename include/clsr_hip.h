@@ -132,6 +132,31 @@ int clsr_pgemm_dw_partial_h(const void* X, int x_bf16, int ldx, int T, int G, co
 int clsr_hdw_partial(const void* X, int x_bf16, int ldx, int T, int G, const float* Xmul, int ldmul,
                      const float* in_scale, const float* in_shift, int in_relu, const void* dY,
                      int dy_bf16, int ldy, int M, int K, int N, float* workspace, void* stream);
+/* ---- "fp32x3" products (csrc/dw3.hip ...): fp32 operands in HBM, every value split into bf16 hi + bf16 lo in
+ *      registers, products taken as hi*hi + lo*hi + hi*lo on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (<= 2^-16
+ *      relative per product; CLSRNet(precision="fp32x3")).  Same contracts as the fp32-MFMA entry points they replace. */
+int clsr_dw3_parts(int M);      /* partial chunks written by clsr_dw3_partial(_multi): <= clsr_pgemm_dw_parts(M), same workspace */
+int clsr_dw3_partial(const float* X, int ldx, int T, int G, const float* Xmul, int ldmul,
+                     const float* in_scale, const float* in_shift, int in_relu, const float* dY, int ldy,
+                     int M, int K, int N, float* workspace, void* stream);
+int clsr_enc_bwd_fused_x3_parts(long M);
+long clsr_enc_bwd_fused_x3_workspace_floats(long M, int p);
+int clsr_enc_bwd_fused_x3(const float* dPin, const float* hist, const float* hprev1, const float* gates1,
+                          const float* mprev, const float* TT, const float* hprev2, const float* gates2,
+                          float* ws_hist, float* ws_hp1, float* ws_hp1r, float* ws_mprev, float* ws_tt,
+                          float* ws_hp2, float* ws_hp2r, long M, void* stream);
+int clsr_pgemm3_supported(int has_mul, int has_aff, int has_u, int has_v, int accumulate, int has_stats, int M, int K,
+                          int N);
+int clsr_pgemm3(const float* X, int ldx, int T, int G, const float* Xmul, int ldmul,
+                const float* in_scale, const float* in_shift, int in_relu, const float* Wt,
+                int Kp, const float* bias, const float* addU, int ldu, const float* addV,
+                int ldv, float* Y, int ldy, int accumulate, double* stats, int M, int K,
+                int N, void* stream);
+int clsr_pgemm3_bnbwd_supported(int M, int K, int N);
+int clsr_pgemm3_bnbwd(const float* X, int ldx, const float* Wt, int Kp, float* Y, int ldy,
+                      const float* z, int ldz, const float* scale, const float* shift,
+                      const float* mean, const float* invstd, double* stats, int M, int K, int N,
+                      void* stream);
 int clsr_att_out_fwd_h(const void* z1, const float* scale1, const float* shift1,
                        const float* w_out, const float* b_out, const int* seq_len,
                        int len_stride, const float* keys, int Hn, int G, int T, int C1, int Dk,
@@ -534,6 +559,7 @@ typedef struct clsr_dwjob {
 int clsr_sizeof_dwjob(void);
 int clsr_pgemm_dw_partial_multi(const clsr_dwjob* jobs_host, int n, void* stream);
 int clsr_hdw_partial_multi(const clsr_dwjob* jobs_host, int n, void* stream);
+int clsr_dw3_partial_multi(const clsr_dwjob* jobs_host, int n, void* stream);
 typedef struct clsr_rp_desc { const float* partial; float* out; float scale; int nparts; int stride; int n; int accumulate; int pad_; } clsr_rp_desc;
 typedef struct clsr_table_desc {
   float* table; const float* partner; float* grad; float* m; float* v; unsigned char* flags;

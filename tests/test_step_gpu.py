@@ -43,13 +43,13 @@ def _close(got, exp, rtol, atol, name):
     assert excess <= 0, "%s: max abs err %.3e, max |exp| %.3e" % (name, float(err.max()), float(exp.abs().max()))
 
 
-def _setup(hp, dedup, seed=3):
+def _setup(hp, dedup, seed=3, precision="fp32"):
     from oracle import clsr_oracle as O
 
     dims = _dims(hp)
     params32 = O.init_params(dims, hp, seed=seed, scale_dense=8.0)
     split = dedup == "split"     # de-duplicated histories + the history-level query columns split off the
-    net = CLSRNet(hp, dims, device="cuda:0", seed=0, dedup_histories=bool(dedup))   # product term at ANY width
+    net = CLSRNet(hp, dims, device="cuda:0", seed=0, dedup_histories=bool(dedup), precision=precision)   # product term at ANY width
     if split:
         net.split_query_min = 0
     sd = dict(params32)
@@ -71,11 +71,13 @@ CONFIGS = [
 ]
 
 
+# "fp32x3": fp32 storage, the MFMA-saturated products as split-bf16 sums (csrc/dw3.hip ...) -- held to the SAME tolerances
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
 @pytest.mark.parametrize("dedup", [True, False, "split"])
 @pytest.mark.parametrize("cfg", range(len(CONFIGS)))
-def test_train_step_matches_oracle(golden_dir, golden_hparams, cfg, dedup):
+def test_train_step_matches_oracle(golden_dir, golden_hparams, cfg, dedup, precision):
     hp = _variant(golden_hparams, **CONFIGS[cfg])
-    O, net, params = _setup(hp, dedup)
+    O, net, params = _setup(hp, dedup, precision=precision)
     feed = _feed(golden_dir, "iterator_train_sa.npz", b=cfg % 3)
     tf = O.to_torch_feed(feed, dtype=torch.float64)
     bn = O.init_bn_state(params)
