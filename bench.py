@@ -271,6 +271,100 @@ def gather_roofline(net, f, cfg, G, feed, big):
                 bytes_per_launch=gbytes, us_per_launch=round(t_gather * 1e6, 2))
 
 
+def embedding_rooflines(net, f, cfg, G, feed):
+    """HIP-event timing of the other HBM-bound embedding kernels on the net's own (HBM-resident) tables, with the byte
+    formulas of SURVEY 8d: the sorted segmented gradient of the history lookups (gather backward), the lazy-Adam row
+    update of the touched rows, and the bf16-table forms (bf16 tables + bf16 hist / d(hist)).  After at least one
+    training step on ``f`` (sorted id lists, involved-row lists and gradient buffers exist)."""
+    import torch
+
+    from clsr_amd import ops
+
+    out = {}
+    T, Hn = cfg["T"], cfg["P"]
+    Di, Dc = cfg["Di"], cfg["Dc"]
+    D, n = Di + Dc, cfg["P"] * cfg["T"]
+    lens = np.asarray(feed["mask"]).sum(1)[::G]
+    n_valid = float(lens.sum())
+    dev = net.device
+    # ---- gather backward: bytes_gather_bwd(n) = n*D*s_a (gradient read) + n*D*4 (fp32 row-gradient write) + 2*n*4
+    dhist = torch.randn(Hn * T, D, device=dev) * 1e-3
+    keys_i, perm_i = net._buf("sort.keys.item", n, dtype=torch.int32), net._buf("sort.perm.item", n, dtype=torch.int32)
+    keys_c, perm_c = net._buf("sort.keys.cate", n, dtype=torch.int32), net._buf("sort.perm.cate", n, dtype=torch.int32)
+    tg = net.tab_grad
+    blk = ops.query("clsr_gather_bwd_sorted_max_cols", D, 0, Di, Di, 0)
+
+    def bwd(name, d):
+        def run():
+            for c0 in range(0, Di, blk):
+                ops.call(name, d, None, None, None, keys_i, perm_i, f["seq_len"], G, n, T, D, c0, min(blk, Di - c0), 3,
+                         tg["item"], Di, c0, None)
+            ops.call(name, d, None, None, None, keys_c, perm_c, f["seq_len"], G, n, T, D, Di, Dc, 3, tg["cate"], Dc, 0, None)
+        return run
+
+    def clear_grads():      # the timed launches accumulate into the gradient tables: put the touched rows back to zero
+        tg["cate"].zero_()
+        tg["item"].index_fill_(0, keys_i.long(), 0.0)
+
+    for tag, name, d, sa in (("gather_bwd", "clsr_gather_bwd_sorted2", dhist, 4),
+                             ("gather_bwd_bf16_dhist", "clsr_gather_bwd_sorted2_h", dhist.to(torch.bfloat16), 2)):
+        t = time_kernel(bwd(name, d))
+        nbytes = n_valid * D * sa + n_valid * D * 4 + 2 * n_valid * 4
+        out[tag] = dict(bound="hbm", kernel="gather_bwd_sorted_kernel (item + category launches)",
+                        achieved=round(nbytes / t / 1e9, 1), peak=8000.0, unit="GB/s", frac=round(nbytes / t / 8e12, 4),
+                        bytes_per_launch=nbytes, us_per_launch=round(t * 1e6, 2),
+                        formula="n*D*%d (gradient read) + n*D*4 (fp32 row-gradient write) + 2*n*4" % sa)
+        clear_grads()
+    # ---- bf16 tables + bf16 hist: bytes_gather_fwd(n) = n*D*(2 + 2) + 2*n*4
+    try:
+        it_h, ct_h = net.tables["item"].to(torch.bfloat16), net.tables["cate"].to(torch.bfloat16)
+        hist_h = torch.empty(Hn * T, D, device=dev, dtype=torch.bfloat16)
+        hm, hr = net._buf("hist_mean", Hn, D), net._buf("hist_recent", Hn, D)
+        t = time_kernel(lambda: ops.call("clsr_gather_hist_fwd_h", it_h, ct_h, f["item_history"], f["item_cate_history"], G * T,
+                                         f["seq_len"], G, Hn, T, Di, Dc, 3, hist_h, 1, hm, hr))
+        nbytes = n_valid * D * (2 + 2) + 2 * n_valid * 4
+        out["gather_fwd_bf16_tables"] = dict(bound="hbm", kernel="gather_hist_fwd_h_kernel (bf16 tables, bf16 hist)",
+                                             achieved=round(nbytes / t / 1e9, 1), peak=8000.0, unit="GB/s",
+                                             frac=round(nbytes / t / 8e12, 4), bytes_per_launch=nbytes,
+                                             us_per_launch=round(t * 1e6, 2), formula="n*D*(2 + 2) + 2*n*4")
+    except RuntimeError as e:
+        out["gather_fwd_bf16_tables"] = dict(skipped=str(e)[:120])
+        it_h = None
+    # ---- lazy-Adam rows: touched_rows * Drow * (3 reads + 3 writes + gradient read + gradient clear) * 4
+    try:
+        tb, m, v, fl = net.tables["item"], net.tab_m["item"], net.tab_v["item"], net.tab_flags["item"]
+        fl.index_fill_(0, keys_i.long(), 1)      # (the step cleared its involved-row marks: the rows of this batch again)
+        ids, count, cap = net._involved_list("item")
+        nrows = int(count[0].item())
+        ss = torch.ones(1, dtype=torch.float64, device=dev)
+        state0 = net.adam_state.clone()
+        state0[3] = 0.0                          # learning rate 0: the timed launches leave the weights where they are
+
+        def adam():
+            ops.call("clsr_table_adam_rows", tb, tg["item"], m, v, fl, ids, count, cap, Di, ss, 1, 1, 2.0, state0,
+                     0.9, 0.999, 1e-8)
+
+        t = time_kernel(adam)
+        nbytes = float(nrows) * Di * 8 * 4
+        out["adam_rows"] = dict(bound="hbm", kernel="table_adam_rows_kernel<4,2> (item table, %d touched rows of %d B)"
+                                % (nrows, Di * 4), achieved=round(nbytes / t / 1e9, 1), peak=8000.0, unit="GB/s",
+                                frac=round(nbytes / t / 8e12, 4), bytes_per_launch=nbytes, us_per_launch=round(t * 1e6, 2),
+                                formula="touched_rows*Drow*(param, m, v read + write; gradient read + clear)*4")
+        if it_h is not None:
+            t = time_kernel(lambda: ops.call("clsr_table_adam_rows_h", it_h, tg["item"], m, v, fl, ids, count, cap, Di, ss, 1,
+                                             1, 2.0, state0, 0.9, 0.999, 1e-8))
+            nbytes = float(nrows) * Di * (6 * 4 + 2 * 2)
+            out["adam_rows_bf16_table"] = dict(bound="hbm", kernel="table_adam_rows_h_kernel<2> (bf16 item rows, fp32 moments)",
+                                               achieved=round(nbytes / t / 1e9, 1), peak=8000.0, unit="GB/s",
+                                               frac=round(nbytes / t / 8e12, 4), bytes_per_launch=nbytes,
+                                               us_per_launch=round(t * 1e6, 2),
+                                               formula="touched_rows*Drow*(m, v read + write, gradient read + clear: 6*4; "
+                                                       "bf16 parameter read + write: 2*2)")
+    except (RuntimeError, KeyError, AttributeError) as e:
+        out["adam_rows"] = dict(skipped="%s: %s" % (type(e).__name__, str(e)[:120]))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -485,6 +579,14 @@ def main():
                 if copy_peak:
                     roof["measured_copy_peak_GBps"] = copy_peak
                     roof["frac_of_measured_copy_peak"] = round(roof["achieved"] / copy_peak, 4)
+                try:
+                    w5.step()          # (sorted id lists / gradient buffers of the step exist)
+                    torch.cuda.synchronize()
+                    roof["more"] = embedding_rooflines(w5.net, w5.f, w5.cfg, w5.G, w5.feed)
+                    for k_, v_ in roof["more"].items():
+                        log("roofline %s: %s" % (k_, {kk: v_.get(kk) for kk in ("achieved", "frac", "us_per_launch", "skipped")}))
+                except RuntimeError as e:
+                    roof["more"] = dict(skipped=str(e)[:160])
                 if not args.no_extra:
                     d5 = w5.run(5, 2)
                     extra.append(dict(workload=w5.describe(), ms_per_step=round(d5 * 200.0, 4),

@@ -109,6 +109,122 @@ extern "C" int clsr_gather_hist_fwd(const float* item_tbl, const float* cate_tbl
   return CLSR_OK;
 }
 
+// ---- bf16 embedding tables ("bf16 tables + activations").  The same gather with 16-byte pieces
+// of EIGHT bf16 values: rows of 2 * D bytes (192 B + 64 B at the 100M-item catalogue), hist written as bf16 (a pure copy:
+// 26 000 algorithmic bytes per 50-step history at D = 128) or widened to fp32 for consumers that read fp32; the masked
+// mean / recent-k mean are accumulated in fp32 from the widened values, exactly what an fp32 gather of the widened
+// table would give.
+typedef __bf16 emb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float emb_f32x8 __attribute__((ext_vector_type(8)));
+template <int U, bool OUT_H>
+__global__ void __launch_bounds__(256) gather_hist_fwd_h_kernel(
+    const __bf16* __restrict__ item_tbl, const __bf16* __restrict__ cate_tbl,
+    const int* __restrict__ item_idx, const int* __restrict__ cate_idx, long idx_row_stride,
+    const int* __restrict__ seq_len, int len_stride, int Hn, int T, int Di, int Dc, int recent_k,
+    void* __restrict__ hist_v, float* __restrict__ hist_mean, float* __restrict__ hist_recent) {
+  __shared__ emb_f32x8 red[4][2][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int h = blockIdx.x * 4 + wave;
+  const int D = Di + Dc, QD = D >> 3, QI = Di >> 3;
+  const int tpar = 64 / QD;
+  const int tslot = lane / QD, q = lane - tslot * QD;
+  const bool active = (h < Hn) && (tslot < tpar);
+  const emb_f32x8 z8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  emb_f32x8 msum = z8, rsum = z8;
+  int len = 0;
+  if (active) {
+    len = seq_len[(long)h * len_stride];
+    const int* ii = item_idx + (long)h * idx_row_stride;
+    const int* ci = cate_idx + (long)h * idx_row_stride;
+    const int rlo = len - recent_k;
+    const bool is_item = q < QI;
+    const int* idx = is_item ? ii : ci;
+    const __bf16* tbl = is_item ? item_tbl + 8 * q : cate_tbl + 8 * (q - QI);
+    const long C = is_item ? Di : Dc;
+    for (int t0 = tslot; t0 < T; t0 += U * tpar) {
+      int id[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int t = t0 + u * tpar;
+        id[u] = idx[t < T ? t : tslot];
+      }
+      emb_bf16x8 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const emb_bf16x8*>(tbl + (long)id[u] * C);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int t = t0 + u * tpar;
+        if (t < T) {
+          const emb_f32x8 w = __builtin_convertvector(v[u], emb_f32x8);
+          const long o = ((long)h * T + t) * D + 8 * q;
+          if (OUT_H) {
+            *reinterpret_cast<emb_bf16x8*>(reinterpret_cast<__bf16*>(hist_v) + o) = v[u];
+          } else {
+            float* out = reinterpret_cast<float*>(hist_v) + o;
+            st4(out, (f32x4){w[0], w[1], w[2], w[3]});
+            st4(out + 4, (f32x4){w[4], w[5], w[6], w[7]});
+          }
+          if (t < len) {
+            msum += w;
+            if (t >= rlo) rsum += w;
+          }
+        }
+      }
+    }
+  }
+  red[wave][0][lane] = msum;
+  red[wave][1][lane] = rsum;
+  __syncthreads();
+  if (active && tslot == 0) {
+    for (int s = 1; s < tpar; ++s) {
+      msum += red[wave][0][lane + s * QD];
+      rsum += red[wave][1][lane + s * QD];
+    }
+    const float inv_len = 1.0f / (float)len;
+    const float inv_rec = 1.0f / (float)(len < recent_k ? len : recent_k);
+    float* pm = hist_mean + (long)h * D + 8 * q;
+    float* pr = hist_recent + (long)h * D + 8 * q;
+    st4(pm, (f32x4){msum[0], msum[1], msum[2], msum[3]} * inv_len);
+    st4(pm + 4, (f32x4){msum[4], msum[5], msum[6], msum[7]} * inv_len);
+    st4(pr, (f32x4){rsum[0], rsum[1], rsum[2], rsum[3]} * inv_rec);
+    st4(pr + 4, (f32x4){rsum[4], rsum[5], rsum[6], rsum[7]} * inv_rec);
+  }
+}
+
+// clsr_gather_hist_fwd with bf16 tables; hist is written as bf16 (hist_bf16 != 0) or fp32; Di, Dc multiples of 8
+extern "C" int clsr_gather_hist_fwd_h(const void* item_tbl, const void* cate_tbl, const int* item_idx,
+                                      const int* cate_idx, long idx_row_stride, const int* seq_len, int len_stride,
+                                      int Hn, int T, int Di, int Dc, int recent_k, void* hist, int hist_bf16,
+                                      float* hist_mean, float* hist_recent, void* stream) {
+  CLSR_CHECK_ARG(item_tbl && cate_tbl && item_idx && cate_idx && seq_len && hist && hist_mean && hist_recent);
+  CLSR_CHECK_ARG(Hn >= 0 && T > 0 && recent_k > 0);
+  CLSR_CHECK_SUPPORTED(Di % 8 == 0 && Dc % 8 == 0 && Di > 0 && Dc > 0 && (Di + Dc) <= 512);
+  CLSR_CHECK_SUPPORTED(((uintptr_t)item_tbl % 16) == 0 && ((uintptr_t)cate_tbl % 16) == 0 && ((uintptr_t)hist % 16) == 0);
+  if (Hn == 0) return CLSR_OK;
+  const int tpar = 64 / ((Di + Dc) / 8);
+  const int niter = clsr_cdiv(T, tpar > 0 ? tpar : 1);
+  const int per_chunk = clsr_cdiv(niter, clsr_cdiv(niter, 13));
+  const dim3 grid(clsr_cdiv(Hn, 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const __bf16* it = (const __bf16*)item_tbl;
+  const __bf16* ct = (const __bf16*)cate_tbl;
+#define CLSR_GATHER_H(U, OH)                                                                                     \
+  hipLaunchKernelGGL((gather_hist_fwd_h_kernel<U, OH>), grid, block, 0, s, it, ct, item_idx, cate_idx,           \
+                     idx_row_stride, seq_len, len_stride, Hn, T, Di, Dc, recent_k, hist, hist_mean, hist_recent)
+  if (hist_bf16) {
+    if (per_chunk <= 4) CLSR_GATHER_H(4, true);
+    else if (per_chunk <= 9) CLSR_GATHER_H(9, true);
+    else CLSR_GATHER_H(13, true);
+  } else {
+    if (per_chunk <= 4) CLSR_GATHER_H(4, false);
+    else if (per_chunk <= 9) CLSR_GATHER_H(9, false);
+    else CLSR_GATHER_H(13, false);
+  }
+#undef CLSR_GATHER_H
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
 // out[n, col0 : col0+C] = tbl[idx[n * idx_stride], :]   (C % 4 == 0)
 __global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restrict__ tbl,
                                                           const int* __restrict__ idx,

@@ -13,6 +13,7 @@
 // map, so the whole dense update is three launches regardless of the number of tensors.
 #include <stdlib.h>
 #include "common.h"
+#include <cstdlib>
 
 // state[0]=step, [1]=beta1^t, [2]=beta2^t, [3]=lr_t   (doubles, device resident so graph replay works)
 __global__ void adam_tick_kernel(double* st, double lr, double b1, double b2) {
@@ -329,7 +330,9 @@ extern "C" int clsr_table_reg_rows(const float* table, const float* partner, con
 }
 
 // LazyAdam over the listed rows; clears their gradient rows and flags.
-template <int VW>
+// UN pieces per lane and trip: their 4 * UN loads are issued before the first one is used (random 384-byte rows of a
+// 38 GB table: the update is bound by how many row reads are in flight; UN = 1 ran at 4.4-4.7 TB/s)
+template <int VW, int UN>
 __global__ void __launch_bounds__(256) table_adam_rows_kernel(
     float* __restrict__ table, float* __restrict__ grad_table, float* __restrict__ m, float* __restrict__ v,
     unsigned char* __restrict__ flags, const int* __restrict__ ids, const int* __restrict__ count, int C,
@@ -341,40 +344,138 @@ __global__ void __launch_bounds__(256) table_adam_rows_kernel(
   const float lr_t = (float)adam_state[3];
   const int QC = C / VW;
   const long total = (long)count[0] * QC;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / QC;
-    const int q = (int)(i - r * QC);
-    const long row = ids[r];
-    const long e = row * C + (long)q * VW;
-    float g[VW], mo[VW], vo[VW], po[VW];
-    if (VW == 4) {
-      *reinterpret_cast<f32x4*>(g) = ld4(grad_table + e);
-      *reinterpret_cast<f32x4*>(mo) = ld4(m + e);
-      *reinterpret_cast<f32x4*>(vo) = ld4(v + e);
-      *reinterpret_cast<f32x4*>(po) = ld4(table + e);
-    } else {
-      g[0] = grad_table[e]; mo[0] = m[e]; vo[0] = v[e]; po[0] = table[e];
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += stride * UN) {
+    long e[UN], row[UN];
+    int q[UN];
+    bool ok[UN];
+    float g[UN][VW], mo[UN][VW], vo[UN][VW], po[UN][VW];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const long i = i0 + u * stride;
+      ok[u] = i < total;
+      const long ic = ok[u] ? i : i0;
+      const long r = ic / QC;
+      q[u] = (int)(ic - r * QC);
+      row[u] = ids[r];
+      e[u] = row[u] * C + (long)q[u] * VW;
     }
 #pragma unroll
-    for (int k = 0; k < VW; ++k) {
-      const float gg = g[k] * factor;
-      const float mm = b1 * mo[k] + (1.0f - b1) * gg;
-      const float vv = b2 * vo[k] + (1.0f - b2) * gg * gg;
-      mo[k] = mm;
-      vo[k] = vv;
-      po[k] -= lr_t * mm / (sqrtf(vv) + eps);
+    for (int u = 0; u < UN; ++u) {
+      if (VW == 4) {
+        *reinterpret_cast<f32x4*>(g[u]) = ld4(grad_table + e[u]);
+        *reinterpret_cast<f32x4*>(mo[u]) = ld4(m + e[u]);
+        *reinterpret_cast<f32x4*>(vo[u]) = ld4(v + e[u]);
+        *reinterpret_cast<f32x4*>(po[u]) = ld4(table + e[u]);
+      } else {
+        g[u][0] = grad_table[e[u]]; mo[u][0] = m[e[u]]; vo[u][0] = v[e[u]]; po[u][0] = table[e[u]];
+      }
     }
-    if (VW == 4) {
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      st4(m + e, *reinterpret_cast<f32x4*>(mo));
-      st4(v + e, *reinterpret_cast<f32x4*>(vo));
-      st4(table + e, *reinterpret_cast<f32x4*>(po));
-      st4(grad_table + e, z);
-    } else {
-      m[e] = mo[0]; v[e] = vo[0]; table[e] = po[0]; grad_table[e] = 0.f;
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+#pragma unroll
+      for (int k = 0; k < VW; ++k) {
+        const float gg = g[u][k] * factor;
+        const float mm = b1 * mo[u][k] + (1.0f - b1) * gg;
+        const float vv = b2 * vo[u][k] + (1.0f - b2) * gg * gg;
+        mo[u][k] = mm;
+        vo[u][k] = vv;
+        po[u][k] -= lr_t * mm / (sqrtf(vv) + eps);
+      }
+      if (ok[u]) {
+        if (VW == 4) {
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          st4(m + e[u], *reinterpret_cast<f32x4*>(mo[u]));
+          st4(v + e[u], *reinterpret_cast<f32x4*>(vo[u]));
+          st4(table + e[u], *reinterpret_cast<f32x4*>(po[u]));
+          st4(grad_table + e[u], z);
+        } else {
+          m[e[u]] = mo[u][0]; v[e[u]] = vo[u][0]; table[e[u]] = po[u][0]; grad_table[e[u]] = 0.f;
+        }
+        if (q[u] == 0) flags[row[u]] = 0;
+      }
     }
-    if (q == 0) flags[row] = 0;
   }
+}
+
+// The same update for a table stored as bf16 (SURVEY 8d "bf16 tables"): the row is widened, updated in fp32 with fp32
+// moments and gradients, and rounded to nearest-even when written back (6 + 2 x 2 bytes per element instead of 8 x 4:
+// 28 against 32).  Without an fp32 master copy an update smaller than half a bf16 ulp of the weight (2^-9 relative) is
+// lost; the parity test pins exactly this arithmetic.
+template <int UN>
+__global__ void __launch_bounds__(256) table_adam_rows_h_kernel(
+    __bf16* __restrict__ table, float* __restrict__ grad_table, float* __restrict__ m, float* __restrict__ v,
+    unsigned char* __restrict__ flags, const int* __restrict__ ids, const int* __restrict__ count, int C,
+    const double* __restrict__ sumsq, int sumsq_stride, int nsum, float clip_norm,
+    const double* __restrict__ adam_state, float b1, float b2, float eps) {
+  double tot = 0.0;
+  for (int i = 0; i < nsum; ++i) tot += sumsq[(long)i * sumsq_stride];
+  const float factor = clip_factor(tot, clip_norm);
+  const float lr_t = (float)adam_state[3];
+  const int QC = C / 4;
+  const long total = (long)count[0] * QC;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += stride * UN) {
+    long e[UN], row[UN];
+    int q[UN];
+    bool ok[UN];
+    f32x4 g[UN], mo[UN], vo[UN];
+    bf16x4_t ph[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const long i = i0 + u * stride;
+      ok[u] = i < total;
+      const long ic = ok[u] ? i : i0;
+      const long r = ic / QC;
+      q[u] = (int)(ic - r * QC);
+      row[u] = ids[r];
+      e[u] = row[u] * C + (long)q[u] * 4;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      g[u] = ld4(grad_table + e[u]);
+      mo[u] = ld4(m + e[u]);
+      vo[u] = ld4(v + e[u]);
+      ph[u] = *reinterpret_cast<const bf16x4_t*>(table + e[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      f32x4 po = __builtin_convertvector(ph[u], f32x4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float gg = g[u][k] * factor;
+        const float mm = b1 * mo[u][k] + (1.0f - b1) * gg;
+        const float vv = b2 * vo[u][k] + (1.0f - b2) * gg * gg;
+        mo[u][k] = mm;
+        vo[u][k] = vv;
+        po[k] -= lr_t * mm / (sqrtf(vv) + eps);
+      }
+      if (ok[u]) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        st4(m + e[u], mo[u]);
+        st4(v + e[u], vo[u]);
+        *reinterpret_cast<bf16x4_t*>(table + e[u]) = __builtin_convertvector(po, bf16x4_t);
+        st4(grad_table + e[u], z);
+        if (q[u] == 0) flags[row[u]] = 0;
+      }
+    }
+  }
+}
+
+extern "C" int clsr_table_adam_rows_h(void* table_bf16, float* grad_table, float* m, float* v, unsigned char* flags,
+                                      const int* ids, const int* count, int cap, int C, const double* sumsq,
+                                      int sumsq_stride, int nsum, float clip_norm, const double* adam_state,
+                                      float beta1, float beta2, float eps, void* stream) {
+  CLSR_CHECK_ARG(table_bf16 && grad_table && m && v && flags && ids && count && sumsq && adam_state && cap > 0 && C > 0);
+  CLSR_CHECK_ARG(nsum > 0);
+  CLSR_CHECK_SUPPORTED(C % 4 == 0 && ((uintptr_t)table_bf16 % 8) == 0);
+  int blocks = clsr_cdiv((long)cap * C, 256 * 4 * 2);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(table_adam_rows_h_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (__bf16*)table_bf16,
+                     grad_table, m, v, flags, ids, count, C, sumsq, sumsq_stride, nsum, clip_norm, adam_state, beta1, beta2,
+                     eps);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
 }
 
 extern "C" int clsr_table_adam_rows(float* table, float* grad_table, float* m, float* v, unsigned char* flags,
@@ -385,12 +486,13 @@ extern "C" int clsr_table_adam_rows(float* table, float* grad_table, float* m, f
   CLSR_CHECK_ARG(nsum > 0);
   const bool vec = C % 4 == 0;
   int blocks = clsr_cdiv((long)cap * C, 256 * 4 * (vec ? 2 : 1));
-  if (blocks > 2048) blocks = 2048;
+  static const int cap_blocks = getenv("CLSR_ADAM_ROWS_BLOCKS") ? atoi(getenv("CLSR_ADAM_ROWS_BLOCKS")) : 4096;
+  if (blocks > cap_blocks) blocks = cap_blocks;
   if (vec)
-    hipLaunchKernelGGL(table_adam_rows_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, grad_table,
+    hipLaunchKernelGGL((table_adam_rows_kernel<4, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, grad_table,
                        m, v, flags, ids, count, C, sumsq, sumsq_stride, nsum, clip_norm, adam_state, beta1, beta2, eps);
   else
-    hipLaunchKernelGGL(table_adam_rows_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, grad_table,
+    hipLaunchKernelGGL((table_adam_rows_kernel<1, 1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, grad_table,
                        m, v, flags, ids, count, C, sumsq, sumsq_stride, nsum, clip_norm, adam_state, beta1, beta2, eps);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;

@@ -11,6 +11,7 @@
 // segmented sparse row exchange for multi-GPU runs with catalogues too large for dense tables.
 #include "common.h"
 #include "clsr_hip.h"
+#include <cstdlib>
 
 // ---- grouping (id, position) pairs by id: hand-written counting sort, three launches for ALL tables of a step
 // (blockIdx.y = table), no vendor library on the step:
@@ -195,17 +196,48 @@ extern "C" int clsr_sort_ids(const int* ids, long nrows, int ncols, long row_str
 
 // g[pos, :] = dhist[pos, col0:col0+C] + (t < len) dmean[h]/len + recent(t) drecent[h]/cnt   (pos = h*T + t)
 // grad[key*ldg + gcol0 + c] += sum of g over the run of equal keys; sumsq += sum g^2 (IndexedSlices norm)
+// VW = floats per lane (1 | 4).  VW = 4 (every offset a multiple of 4): a row slice is read as 16-byte pieces, CP lanes
+// cover 4 * CP columns -- 4x fewer lanes per entry and 4x the bytes per load, i.e. 16x the bytes in flight per wave.
+// The scalar form moved 211 MB in 308 us (0.09 of the HBM rate) over the three launches of the 100M-item catalogue's
+// 384 B + 128 B rows: one float per lane, eight reads in flight.  HD: dhist / dhist2 are bf16 tensors (bf16
+// activations -- n * D * 2 bytes of gradient read per row).
 #define GBS_CHUNK(CP) ((CP) < 16 ? 16 : (CP))   // sorted entries per thread group
-template <int CP>
+template <int VW, bool HD> struct GbsLoad;
+template <> struct GbsLoad<1, false> {
+  typedef float type;
+  static __device__ __forceinline__ float ld(const void* p, long off) { return reinterpret_cast<const float*>(p)[off]; }
+};
+template <> struct GbsLoad<4, false> {
+  typedef f32x4 type;
+  static __device__ __forceinline__ f32x4 ld(const void* p, long off) { return ld4(reinterpret_cast<const float*>(p) + off); }
+};
+template <> struct GbsLoad<1, true> {
+  typedef float type;
+  static __device__ __forceinline__ float ld(const void* p, long off) { return (float)reinterpret_cast<const __bf16*>(p)[off]; }
+};
+template <> struct GbsLoad<4, true> {
+  typedef f32x4 type;
+  static __device__ __forceinline__ f32x4 ld(const void* p, long off) { return load4e<true>(p, off); }
+};
+__device__ __forceinline__ float gbs_sq(float v) { return v * v; }
+__device__ __forceinline__ float gbs_sq(const f32x4& v) { return v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+__device__ __forceinline__ void gbs_atomic(float* p, float v) { atomicAdd(p, v); }
+__device__ __forceinline__ void gbs_atomic(float* p, const f32x4& v) {
+  atomicAdd(p, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
+}
+template <int CP, int VW, bool HD>
 __global__ void __launch_bounds__(256) gather_bwd_sorted_kernel(
-    const float* __restrict__ dhist, const float* __restrict__ dhist2, const float* __restrict__ dmean,
+    const void* __restrict__ dhist, const void* __restrict__ dhist2, const float* __restrict__ dmean,
     const float* __restrict__ drecent, const int* __restrict__ keys, const int* __restrict__ perm,
     const int* __restrict__ seq_len, int len_stride, long n, int T, int D, int col0, int C, int recent_k,
     float* __restrict__ grad, int ldg, int gcol0, double* __restrict__ sumsq) {
+  typedef typename GbsLoad<VW, HD>::type vec_t;
+  typedef GbsLoad<VW, false> LdF;
+  typedef GbsLoad<VW, HD> LdH;
   __shared__ double red[4];
   constexpr int GPB = 256 / CP;              // thread groups per block
   constexpr int EPL = GBS_CHUNK(CP) / CP;    // chunk entries preloaded per lane
-  const int c = threadIdx.x % CP;
+  const int c = (threadIdx.x % CP) * VW;     // first column of this lane
   const long gid = (long)blockIdx.x * GPB + threadIdx.x / CP;
   const bool cok = c < C;
   const long p0 = gid * GBS_CHUNK(CP);
@@ -217,7 +249,7 @@ __global__ void __launch_bounds__(256) gather_bwd_sorted_kernel(
   float ml[EPL], mr[EPL];
 #pragma unroll
   for (int u = 0; u < EPL; ++u) {
-    const long p = p0 + u * CP + c;
+    const long p = p0 + u * CP + threadIdx.x % CP;
     mk[u] = -1; mp[u] = 0; mh[u] = 0; ml[u] = 0.f; mr[u] = 0.f;
     if (p < n) {
       mk[u] = keys[p];
@@ -231,11 +263,9 @@ __global__ void __launch_bounds__(256) gather_bwd_sorted_kernel(
     }
   }
   int cur = -1;
-  float acc = 0.f, local = 0.f;
-  const float* dh_c = dhist + col0 + (cok ? c : 0);
-  const float* dh2_c = dhist2 ? dhist2 + col0 + (cok ? c : 0) : nullptr;   // second addend of d(hist), same layout
-  const float* dm_c = dmean ? dmean + col0 + (cok ? c : 0) : nullptr;
-  const float* dr_c = drecent ? drecent + col0 + (cok ? c : 0) : nullptr;
+  vec_t acc = vec_t(0.f);
+  float local = 0.f;
+  const long cc = col0 + (cok ? c : 0);      // this lane's column in the [., D] tensors
 #pragma unroll
   for (int u = 0; u < EPL; ++u) {
     // sub-chunks of 8 sorted entries: their (random-row) gradient reads are issued together, then the run
@@ -244,7 +274,7 @@ __global__ void __launch_bounds__(256) gather_bwd_sorted_kernel(
 #pragma unroll
     for (int q0 = 0; q0 < CP; q0 += SUB) {
       int key[SUB];
-      float g[SUB];
+      vec_t g[SUB];
 #pragma unroll
       for (int k = 0; k < SUB; ++k) {
         key[k] = __shfl(mk[u], q0 + k, CP);
@@ -252,18 +282,18 @@ __global__ void __launch_bounds__(256) gather_bwd_sorted_kernel(
         const int h = __shfl(mh[u], q0 + k, CP);
         const float flen = __shfl(ml[u], q0 + k, CP);
         const float frec = __shfl(mr[u], q0 + k, CP);
-        float v = dh_c[(long)pos * D];
-        if (dh2_c) v += dh2_c[(long)pos * D];
-        if (dm_c) v += flen > 0.f ? dm_c[(long)h * D] / flen : 0.f;
-        if (dr_c) v += frec > 0.f ? dr_c[(long)h * D] / frec : 0.f;
-        g[k] = (cok && key[k] >= 0) ? v : 0.f;
+        vec_t v = LdH::ld(dhist, (long)pos * D + cc);
+        if (dhist2) v += LdH::ld(dhist2, (long)pos * D + cc);
+        if (dmean) v += flen > 0.f ? LdF::ld(dmean, (long)h * D + cc) * (1.0f / flen) : vec_t(0.f);
+        if (drecent) v += frec > 0.f ? LdF::ld(drecent, (long)h * D + cc) * (1.0f / frec) : vec_t(0.f);
+        g[k] = (cok && key[k] >= 0) ? v : vec_t(0.f);
       }
 #pragma unroll
       for (int k = 0; k < SUB; ++k) {
         if (key[k] < 0) continue;     // past the end of the array (uniform inside the group)
-        local += g[k] * g[k];
+        local += gbs_sq(g[k]);
         if (key[k] != cur) {
-          if (cur >= 0 && cok) atomicAdd(grad + (long)cur * ldg + gcol0 + c, acc);
+          if (cur >= 0 && cok) gbs_atomic(grad + (long)cur * ldg + gcol0 + c, acc);
           cur = key[k];
           acc = g[k];
         } else {
@@ -272,33 +302,73 @@ __global__ void __launch_bounds__(256) gather_bwd_sorted_kernel(
       }
     }
   }
-  if (cur >= 0 && cok) atomicAdd(grad + (long)cur * ldg + gcol0 + c, acc);
+  if (cur >= 0 && cok) gbs_atomic(grad + (long)cur * ldg + gcol0 + c, acc);
   if (sumsq) {
     const double tot = block256_sum_d((double)local, red);
     if (threadIdx.x == 0 && tot != 0.0) atomicAdd(sumsq, tot);
   }
 }
 
+static int gbs_launch(const void* dhist, const void* dhist2, int bf16, const float* dmean, const float* drecent,
+                      const int* keys, const int* perm, const int* seq_len, int len_stride, long n, int T, int D,
+                      int col0, int C, int recent_k, float* grad, int ldg, int gcol0, double* sumsq, void* stream) {
+  CLSR_CHECK_ARG(dhist && keys && perm && seq_len && grad && n > 0 && T > 0 && D > 0 && C > 0);
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec = C % 4 == 0 && D % 4 == 0 && col0 % 4 == 0 && gcol0 % 4 == 0 && ldg % 4 == 0 &&
+                   ((uintptr_t)dhist % 16) == 0 && (!dhist2 || ((uintptr_t)dhist2 % 16) == 0) &&
+                   (!dmean || ((uintptr_t)dmean % 16) == 0) && (!drecent || ((uintptr_t)drecent % 16) == 0) &&
+                   ((uintptr_t)grad % 16) == 0 && !getenv("CLSR_GBS_SCALAR");
+#define LAUNCH_GBS(CPV, VWV)                                                                                   \
+  do {                                                                                                         \
+    const long groups = (n + GBS_CHUNK(CPV) - 1) / GBS_CHUNK(CPV);                                             \
+    const int blocks = clsr_cdiv(groups, 256 / (CPV));                                                         \
+    if (bf16)                                                                                                  \
+      hipLaunchKernelGGL((gather_bwd_sorted_kernel<CPV, VWV, true>), dim3(blocks), dim3(256), 0, s, dhist,     \
+                         dhist2, dmean, drecent, keys, perm, seq_len, len_stride, n, T, D, col0, C, recent_k,  \
+                         grad, ldg, gcol0, sumsq);                                                             \
+    else                                                                                                       \
+      hipLaunchKernelGGL((gather_bwd_sorted_kernel<CPV, VWV, false>), dim3(blocks), dim3(256), 0, s, dhist,    \
+                         dhist2, dmean, drecent, keys, perm, seq_len, len_stride, n, T, D, col0, C, recent_k,  \
+                         grad, ldg, gcol0, sumsq);                                                             \
+  } while (0)
+  if (vec) {
+    CLSR_CHECK_SUPPORTED(C <= 256);
+    const int q = C / 4;
+    if (q <= 8) LAUNCH_GBS(8, 4);
+    else if (q <= 16) LAUNCH_GBS(16, 4);
+    else if (q <= 32) LAUNCH_GBS(32, 4);
+    else LAUNCH_GBS(64, 4);
+  } else {
+    CLSR_CHECK_SUPPORTED(C <= 64 && !bf16);
+    if (C <= 8) LAUNCH_GBS(8, 1);
+    else if (C <= 16) LAUNCH_GBS(16, 1);
+    else if (C <= 32) LAUNCH_GBS(32, 1);
+    else LAUNCH_GBS(64, 1);
+  }
+#undef LAUNCH_GBS
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// widest column block one launch of clsr_gather_bwd_sorted2 takes for this layout (256 with 16-byte accesses, else 64)
+extern "C" int clsr_gather_bwd_sorted_max_cols(int D, int col0, int C, int ldg, int gcol0) {
+  return (C % 4 == 0 && D % 4 == 0 && col0 % 4 == 0 && gcol0 % 4 == 0 && ldg % 4 == 0 && !getenv("CLSR_GBS_SCALAR")) ? 256 : 64;
+}
+
 extern "C" int clsr_gather_bwd_sorted2(const float* dhist, const float* dhist2, const float* dmean,
                                        const float* drecent, const int* keys, const int* perm, const int* seq_len,
                                        int len_stride, long n, int T, int D, int col0, int C, int recent_k,
                                        float* grad, int ldg, int gcol0, double* sumsq, void* stream) {
-  CLSR_CHECK_ARG(dhist && keys && perm && seq_len && grad && n > 0 && T > 0 && D > 0 && C > 0);
-  CLSR_CHECK_SUPPORTED(C <= 64);
-  const int CP = C <= 8 ? 8 : (C <= 16 ? 16 : (C <= 32 ? 32 : 64));
-  const long groups = (n + GBS_CHUNK(CP) - 1) / GBS_CHUNK(CP);
-  const int blocks = clsr_cdiv(groups, 256 / CP);
-  hipStream_t s = (hipStream_t)stream;
-#define LAUNCH_GBS(CPV)                                                                                     \
-  hipLaunchKernelGGL(gather_bwd_sorted_kernel<CPV>, dim3(blocks), dim3(256), 0, s, dhist, dhist2, dmean,    \
-                     drecent, keys, perm, seq_len, len_stride, n, T, D, col0, C, recent_k, grad, ldg, gcol0, sumsq)
-  if (CP == 8) LAUNCH_GBS(8);
-  else if (CP == 16) LAUNCH_GBS(16);
-  else if (CP == 32) LAUNCH_GBS(32);
-  else LAUNCH_GBS(64);
-#undef LAUNCH_GBS
-  CLSR_CHECK_LAUNCH();
-  return CLSR_OK;
+  return gbs_launch(dhist, dhist2, 0, dmean, drecent, keys, perm, seq_len, len_stride, n, T, D, col0, C, recent_k, grad,
+                    ldg, gcol0, sumsq, stream);
+}
+// the same with d(hist) (and its optional second addend) stored as bf16; dmean / drecent stay fp32
+extern "C" int clsr_gather_bwd_sorted2_h(const void* dhist_bf16, const void* dhist2_bf16, const float* dmean,
+                                         const float* drecent, const int* keys, const int* perm, const int* seq_len,
+                                         int len_stride, long n, int T, int D, int col0, int C, int recent_k,
+                                         float* grad, int ldg, int gcol0, double* sumsq, void* stream) {
+  return gbs_launch(dhist_bf16, dhist2_bf16, 1, dmean, drecent, keys, perm, seq_len, len_stride, n, T, D, col0, C,
+                    recent_k, grad, ldg, gcol0, sumsq, stream);
 }
 
 extern "C" int clsr_gather_bwd_sorted(const float* dhist, const float* dmean, const float* drecent,

@@ -95,6 +95,8 @@ class CLSRNet(object):
         self.x3_dw = self.x3 and bool(os.environ.get("CLSR_X3_DW"))       # A/B: weight gradients (csrc/dw3.hip)
         self.x3_gemm = self.x3 and os.environ.get("CLSR_X3_GEMM", "xw^T")  # "all" | comma-separated weight keys | ""
         self.x3_enc = self.x3 and not os.environ.get("CLSR_NO_X3_ENC")    # A/B: fused encoder tail (csrc/encbwd.hip)
+        self.bf16_dw = not os.environ.get("CLSR_NO_HDW")        # A/B switch: weight gradients on the bf16 matrix pipe
+        self.bf16_bwd = not os.environ.get("CLSR_NO_HBWD")      # A/B switch: back-propagating products likewise
         self._cur_descs_h = []
         self._plans, self._plan_keep, self._cur_descs = {}, [], []
         self._sort_bytes = {}
@@ -2215,9 +2217,10 @@ class CLSRNet(object):
                 continue
             keys = self._buf("sort.keys." + name, n, dtype=torch.int32)
             perm = self._buf("sort.perm." + name, n, dtype=torch.int32)
-            for c0 in range(0, C, 64):   # column blocks of <= 64 floats; squared norms accumulate in the slot
+            blk = query("clsr_gather_bwd_sorted_max_cols", self.D, col0, C, C, 0)   # 256 with 16-byte accesses, else 64
+            for c0 in range(0, C, blk):   # column blocks; squared norms accumulate in the slot
                 call("clsr_gather_bwd_sorted2", dhist, dhist2, dM, dR, keys, perm, seq_len, ls, n, T, self.D, col0 + c0,
-                     min(64, C - c0), k, self.tab_grad[name], C, c0, ss[slot:])
+                     min(blk, C - c0), k, self.tab_grad[name], C, c0, ss[slot:])
 
     #: tables with more elements than this are regularised / lazily updated through the compacted list of
     #: their involved rows instead of a sweep over all V*C elements (100M-item catalogues)

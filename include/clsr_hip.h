@@ -39,6 +39,12 @@ int clsr_gather_hist_fwd(const float* item_tbl, const float* cate_tbl, const int
                          const int* cate_idx, long idx_row_stride, const int* seq_len, int len_stride,
                          int Hn, int T, int Di, int Dc, int recent_k, float* hist, float* hist_mean,
                          float* hist_recent, void* stream);
+/* bf16 embedding tables (16-byte pieces of eight values; Di, Dc multiples of 8); hist written as bf16 (hist_bf16) or
+ * widened to fp32; the masked means are accumulated in fp32 from the widened values */
+int clsr_gather_hist_fwd_h(const void* item_tbl, const void* cate_tbl, const int* item_idx,
+                           const int* cate_idx, long idx_row_stride, const int* seq_len, int len_stride,
+                           int Hn, int T, int Di, int Dc, int recent_k, void* hist, int hist_bf16,
+                           float* hist_mean, float* hist_recent, void* stream);
 int clsr_gather_hist_bwd(const float* dhist, const float* dmean, const float* drecent,
                          const int* item_idx, const int* cate_idx, long idx_row_stride,
                          const int* seq_len, int len_stride, int Hn, int T, int Di, int Dc, int recent_k,
@@ -67,6 +73,12 @@ int clsr_sort_ids(const int* ids, long nrows, int ncols, long row_stride, long v
 int clsr_gather_bwd_sorted2(const float* dhist, const float* dhist2, const float* dmean, const float* drecent,
                             const int* keys, const int* perm, const int* seq_len, int len_stride, long n, int T, int D,
                             int col0, int C, int recent_k, float* grad, int ldg, int gcol0, double* sumsq, void* stream);
+int clsr_gather_bwd_sorted_max_cols(int D, int col0, int C, int ldg, int gcol0);   /* widest column block per launch */
+/* d(hist) (and its optional second addend) as bf16 tensors */
+int clsr_gather_bwd_sorted2_h(const void* dhist_bf16, const void* dhist2_bf16, const float* dmean,
+                              const float* drecent, const int* keys, const int* perm, const int* seq_len,
+                              int len_stride, long n, int T, int D, int col0, int C, int recent_k,
+                              float* grad, int ldg, int gcol0, double* sumsq, void* stream);
 int clsr_gather_bwd_sorted(const float* dhist, const float* dmean, const float* drecent, const int* keys,
                            const int* perm, const int* seq_len, int len_stride, long n, int T, int D, int col0,
                            int C, int recent_k, float* grad, int ldg, int gcol0, double* sumsq, void* stream);
@@ -498,6 +510,11 @@ int clsr_table_adam_rows(float* table, float* grad_table, float* m, float* v, un
                          const int* ids, const int* count, int cap, int C, const double* sumsq,
                          int sumsq_stride, int nsum, float clip_norm, const double* adam_state, float beta1,
                          float beta2, float eps, void* stream);
+/* the same for a table stored as bf16: widened, updated in fp32 (fp32 moments / gradients), rounded to nearest-even */
+int clsr_table_adam_rows_h(void* table_bf16, float* grad_table, float* m, float* v, unsigned char* flags,
+                           const int* ids, const int* count, int cap, int C, const double* sumsq,
+                           int sumsq_stride, int nsum, float clip_norm, const double* adam_state,
+                           float beta1, float beta2, float eps, void* stream);
 int clsr_zero_doubles(double* p, int n, void* stream);
 int clsr_add_doubles(double* dst, const double* src, int n, void* stream);
 int clsr_zero_floats(float* p, long n, void* stream);
