@@ -1,0 +1,164 @@
+// Small-message all-reduce over peer-mapped buffers (gfx950, xGMI / same-device IPC) -- SURVEY 8(b)(ii): "communicators
+// are created by the host and passed in as opaque void* to the collective wrappers".
+//
+// Why: synchronised batch-norm (the statistics of tf.layers.batch_normalization, models/base_model.py:673-679,
+// must be those of the GLOBAL batch for single-device parity) needs 16 all-reduces of 2 C doubles (<= 2 KB) per step,
+// each in the middle of a dependent chain of kernels.  Through torch.distributed every one costs ~20 us of host call plus
+// two stream hops into and out of RCCL's stream, even with one rank (+6.6 % step time).  Here the sum is ONE
+// single-workgroup kernel on the issuing stream:
+//   1. push   every rank writes its n doubles into ITS slot of every peer's exchange buffer, fences, then publishes the
+//             sequence number of this all-reduce in its flag of every peer's buffer (release, system scope);
+//   2. wait   until the flags of all ranks in the OWN buffer have reached the sequence number (acquire);
+//   3. sum    the world slots of the own buffer in RANK ORDER (every rank computes the same fp64 sum: replicas stay
+//             bit-identical), in place.
+// Two slot sets alternate with the sequence number: a rank can be at most one all-reduce ahead of a peer (it cannot
+// finish all-reduce k + 1 before that peer has pushed k + 1, which the peer does after it has finished reading k).
+// The exchange buffers are fine-grained device allocations (no stale lines in a reader's L2) mapped into the peers by
+// hipIpc handles that the host exchanges once; the kernel gives up after ~2 s and raises the communicator's error flag
+// instead of hanging the device.
+#include "common.h"
+#include "clsr_hip.h"
+#include <string.h>
+
+#define P2P_MAXW 8            // ranks (one node)
+#define P2P_MAXN 256          // doubles per all-reduce
+
+struct P2PBuf {
+  double data[2][P2P_MAXW][P2P_MAXN];
+  unsigned long long flag[2][P2P_MAXW];
+  unsigned long long err;
+};
+
+struct P2PComm {
+  int rank, world;
+  P2PBuf* bufs[P2P_MAXW];     // own buffer at [rank], peers' mapped buffers elsewhere
+  unsigned long long seq;     // host-side count of issued all-reduces
+};
+
+struct P2PArgs {
+  P2PBuf* bufs[P2P_MAXW];
+  double* x;
+  int n, rank, world;
+  unsigned long long seq;
+};
+
+__global__ void __launch_bounds__(256) allreduce_small_kernel(P2PArgs a) {
+  const int tid = threadIdx.x;
+  const int slot = (int)(a.seq & 1ull);
+  P2PBuf* mine = a.bufs[a.rank];
+  if (tid < a.n) {
+    const double v = a.x[tid];
+    for (int p = 0; p < a.world; ++p)
+      __hip_atomic_store(&a.bufs[p]->data[slot][a.rank][tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid < a.world) {
+    __hip_atomic_store(&a.bufs[tid]->flag[slot][a.rank], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const long long t0 = wall_clock64();            // constant 100 MHz counter
+    while (__hip_atomic_load(&mine->flag[slot][tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
+      if (wall_clock64() - t0 > 200000000LL) {      // ~2 s: a peer never arrived
+        __hip_atomic_store(&mine->err, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid < a.n) {
+    double s = 0.0;
+    for (int r = 0; r < a.world; ++r)
+      s += __hip_atomic_load(&mine->data[slot][r][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    a.x[tid] = s;
+  }
+}
+
+extern "C" long clsr_comm_buffer_bytes(void) { return (long)sizeof(P2PBuf); }
+extern "C" int clsr_comm_max_doubles(void) { return P2P_MAXN; }
+extern "C" int clsr_comm_max_world(void) { return P2P_MAXW; }
+
+// fine-grained (uncached) device allocation of the exchange buffer, zeroed
+extern "C" int clsr_comm_alloc(void** buf_out) {
+  CLSR_CHECK_ARG(buf_out);
+  void* p = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&p, sizeof(P2PBuf), hipDeviceMallocUncached);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    e = hipExtMallocWithFlags(&p, sizeof(P2PBuf), hipDeviceMallocFinegrained);
+  }
+  if (e != hipSuccess) {
+    clsr_set_error("%s:%d: exchange buffer allocation failed: %s", __FILE__, __LINE__, hipGetErrorString(e));
+    return CLSR_ELAUNCH;
+  }
+  CLSR_HIP(hipMemset(p, 0, sizeof(P2PBuf)));
+  CLSR_HIP(hipDeviceSynchronize());
+  *buf_out = p;
+  return CLSR_OK;
+}
+extern "C" int clsr_comm_free(void* buf) {
+  if (buf) CLSR_HIP(hipFree(buf));
+  return CLSR_OK;
+}
+extern "C" int clsr_comm_ipc_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
+extern "C" int clsr_comm_ipc_handle(void* buf, void* handle_out) {
+  CLSR_CHECK_ARG(buf && handle_out);
+  hipIpcMemHandle_t h;
+  CLSR_HIP(hipIpcGetMemHandle(&h, buf));
+  memcpy(handle_out, &h, sizeof(h));
+  return CLSR_OK;
+}
+extern "C" int clsr_comm_ipc_open(const void* handle, void** peer_out) {
+  CLSR_CHECK_ARG(handle && peer_out);
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, sizeof(h));
+  void* p = nullptr;
+  CLSR_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+  *peer_out = p;
+  return CLSR_OK;
+}
+extern "C" int clsr_comm_ipc_close(void* peer) {
+  if (peer) CLSR_HIP(hipIpcCloseMemHandle(peer));
+  return CLSR_OK;
+}
+
+// bufs[r] = the exchange buffer of rank r as THIS process addresses it (own allocation at [rank], opened handles elsewhere)
+extern "C" int clsr_comm_create(int rank, int world, void* const* bufs, void** comm_out) {
+  CLSR_CHECK_ARG(bufs && comm_out && world >= 1 && world <= P2P_MAXW && rank >= 0 && rank < world);
+  P2PComm* c = new P2PComm();
+  c->rank = rank; c->world = world; c->seq = 0;
+  for (int r = 0; r < world; ++r) {
+    if (!bufs[r]) { delete c; clsr_set_error("%s:%d: exchange buffer of rank %d missing", __FILE__, __LINE__, r); return CLSR_EINVAL; }
+    c->bufs[r] = (P2PBuf*)bufs[r];
+  }
+  *comm_out = c;
+  return CLSR_OK;
+}
+extern "C" int clsr_comm_destroy(void* comm) {
+  delete (P2PComm*)comm;
+  return CLSR_OK;
+}
+// sequence number of the last all-reduce in which this rank gave up waiting for a peer (0: none); synchronises the device
+extern "C" long clsr_comm_error(void* comm) {
+  if (!comm) return -1;
+  P2PComm* c = (P2PComm*)comm;
+  unsigned long long e = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpy(&e, &c->bufs[c->rank]->err, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (long)e;
+}
+
+// data[0:n] <- sum over the ranks of data[0:n] (doubles, n <= 256), in place, asynchronous on ``stream``; every rank of
+// the communicator must issue the same sequence of calls
+extern "C" int clsr_allreduce_small(void* comm, double* data, int n, void* stream) {
+  CLSR_CHECK_ARG(comm && data && n > 0);
+  CLSR_CHECK_SUPPORTED(n <= P2P_MAXN);
+  P2PComm* c = (P2PComm*)comm;
+  P2PArgs a;
+  for (int r = 0; r < P2P_MAXW; ++r) a.bufs[r] = r < c->world ? c->bufs[r] : nullptr;
+  a.x = data; a.n = n; a.rank = c->rank; a.world = c->world;
+  a.seq = ++c->seq;
+  hipLaunchKernelGGL(allreduce_small_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}

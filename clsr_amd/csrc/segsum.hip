@@ -1,0 +1,528 @@
+// Deterministic gradients of the embedding lookups (gfx950): a STABLE radix sort of the (row id, slice) pairs of a
+// lookup site and a segmented sum over the sorted list that adds every row's total to the gradient table exactly once,
+// in a fixed order -- two runs of the same step give bit-identical gradient tables and clip norms.
+//
+// Reference semantics: the gradient of tf.nn.embedding_lookup (models/sequential/sequential_base_model.py:381-452,
+// models/sequential/clsr.py:103-135) is an IndexedSlices with one slice per looked-up id; tf.train.AdamOptimizer sums the
+// slices of equal ids (unsorted_segment_sum, models/base_model.py:263-276) and tf.clip_by_norm takes the norm of the
+// un-summed slices (base_model.py:290-296).  The counting sort of csrc/sparse.hip groups equal ids but leaves the order
+// inside a group to racing cursor claims, and its consumer combines partial sums with float atomics: the fp32 sums moved
+// in the last bits from run to run.
+//
+// Sort: least-significant-digit radix sort, 8-bit digits, ceil(bits / 8) passes; a pass = histogram, scan and scatter
+// launch for ALL tables of a step (blockIdx.y = table).  (Counting the next pass's digits inside the scatter, with global
+// integer atomics at the entries' destinations, saved a launch and cost 350 us: a popular id's entries all hit one counter.)  Stable: inside a workgroup's 2 048
+// entries the rank of an entry among the entries with its digit follows the index order (per-wave match masks by ballots,
+// per-segment counts scanned in segment order), workgroups are ordered by the scan.  Equal ids therefore stay in
+// slice order, and the whole result is a function of the input alone.
+//
+// Segmented sum (clsr_segsum_multi): thread groups walk chunks of the sorted list and sum runs of equal ids in
+// registers, in list order.  A run that lies inside one chunk is added to its row with a plain read-modify-write: no
+// other group holds that id (the list is fully sorted), and the caller guarantees that no other launch writes the table
+// meanwhile.  A run that crosses chunk borders leaves one partial per chunk in a workspace; a second launch adds the
+// partials of such a run IN CHUNK ORDER and writes the row once.  The squared norms of the slices leave as one partial
+// per workgroup and are added in workgroup order.  No float atomics anywhere.
+#include "common.h"
+#include "clsr_hip.h"
+#include <cstdlib>
+#include <type_traits>
+
+// ===================================================================================================== stable radix sort
+#define RS_EPB 2048                 // entries per workgroup
+#define RS_EPT (RS_EPB / 256)       // entries per thread
+#define RS_SEG (RS_EPT * 4)         // 64-entry segments per workgroup (round u, wave w) -> u * 4 + w
+
+struct RsTable {
+  const int* ids; long row_stride; int ncols;   // pass 0 source: ids[r * row_stride + c], position = r * ncols + c
+  int* k[2]; int* p[2];                         // ping-pong (key, position) buffers; the LAST pass writes k[1] / p[1] = outputs
+  int* hist;                                    // [2][256 * nblocks] digit counters of the current / next pass
+  long n; int nblocks; int passes; int first_dst;
+};
+struct RsArgs { RsTable t[CLSR_SORTIDS_MAX]; };
+
+__device__ __forceinline__ int rs_key(const RsTable& t, int pass, long e, int src) {
+  if (pass == 0) {
+    const long r = e / t.ncols;
+    return t.ids[r * t.row_stride + (e - r * t.ncols)];
+  }
+  return t.k[src][e];
+}
+
+// digit counts of a pass: hist[digit * nblocks + block]
+__global__ void __launch_bounds__(256) rs_hist_kernel(RsArgs a, int pass) {
+  __shared__ int h[256];
+  const RsTable& t = a.t[blockIdx.y];
+  if (pass >= t.passes || (int)blockIdx.x >= t.nblocks) return;
+  const int src = (t.first_dst + pass + 1) & 1;
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const long e0 = (long)blockIdx.x * RS_EPB;
+  const int shift = 8 * pass;
+#pragma unroll
+  for (int u = 0; u < RS_EPT; ++u) {
+    const long e = e0 + u * 256 + threadIdx.x;
+    if (e < t.n) atomicAdd(&h[(rs_key(t, pass, e, src) >> shift) & 255], 1);
+  }
+  __syncthreads();
+  t.hist[threadIdx.x * t.nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive scan of the 256 * nblocks counters of one table, in place (one workgroup per table; the loads of up to eight
+// 4096-counter tiles are in flight together: one memory latency per eight tiles instead of one per tile)
+__global__ void __launch_bounds__(1024) rs_scan_kernel(RsArgs a, int pass) {
+  __shared__ int wtot[16];
+  __shared__ int carry_s;
+  const RsTable& t = a.t[blockIdx.x];
+  if (pass >= t.passes) return;
+  int* c = t.hist;
+  const int nb = 256 * t.nblocks;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int base0 = 0; base0 < nb; base0 += 8 * 4096) {
+    int v[8][4];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = base0 + q * 4096 + 4 * threadIdx.x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[q][k] = i + k < nb ? c[i + k] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = base0 + q * 4096 + 4 * threadIdx.x;
+      if (base0 + q * 4096 >= nb) break;          // (uniform)
+      const int mine = v[q][0] + v[q][1] + v[q][2] + v[q][3];
+      int inc = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int x = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += x;
+      }
+      if (lane == 63) wtot[wave] = inc;
+      __syncthreads();
+      int before = carry_s;
+      for (int w = 0; w < wave; ++w) before += wtot[w];
+      int run = before + inc - mine;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (i + k < nb) c[i + k] = run;
+        run += v[q][k];
+      }
+      __syncthreads();
+      if (threadIdx.x == 1023) carry_s = run;
+      __syncthreads();
+    }
+  }
+}
+
+// one pass: entries of workgroup b go to offset[digit][b] + (stable rank among the workgroup's entries with that digit)
+__global__ void __launch_bounds__(256) rs_scatter_kernel(RsArgs a, int pass) {
+  __shared__ int segcnt[RS_SEG][256];
+  __shared__ int gbase[256];
+  const RsTable& t = a.t[blockIdx.y];
+  if (pass >= t.passes || (int)blockIdx.x >= t.nblocks) return;
+  const int src = (t.first_dst + pass + 1) & 1, dst = (t.first_dst + pass) & 1;
+  const int* hist = t.hist;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int e = threadIdx.x; e < RS_SEG * 256; e += 256) (&segcnt[0][0])[e] = 0;
+  gbase[threadIdx.x] = hist[threadIdx.x * t.nblocks + blockIdx.x];
+  __syncthreads();
+  const long e0 = (long)blockIdx.x * RS_EPB;
+  const int shift = 8 * pass;
+  int key[RS_EPT], pos[RS_EPT], rank[RS_EPT];
+#pragma unroll
+  for (int u = 0; u < RS_EPT; ++u) {
+    const long e = e0 + u * 256 + threadIdx.x;
+    const bool valid = e < t.n;
+    key[u] = valid ? rs_key(t, pass, e, src) : 0;
+    pos[u] = valid ? (pass == 0 ? (int)e : t.p[src][e]) : 0;
+    const int d = (key[u] >> shift) & 255;
+    // lanes of this wave with the same digit
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const unsigned long long bal = __ballot((d >> b) & 1);
+      peers &= ((d >> b) & 1) ? bal : ~bal;
+    }
+    const int r = __popcll(peers & ((1ull << lane) - 1ull));
+    rank[u] = valid ? r : -1;
+    if (valid && r == 0) segcnt[u * 4 + wave][d] = __popcll(peers);
+  }
+  __syncthreads();
+  {  // per digit: exclusive scan over the segments, in segment (= index) order
+    int run = 0;
+#pragma unroll
+    for (int s = 0; s < RS_SEG; ++s) {
+      const int c = segcnt[s][threadIdx.x];
+      segcnt[s][threadIdx.x] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < RS_EPT; ++u) {
+    if (rank[u] < 0) continue;
+    const int d = (key[u] >> shift) & 255;
+    const int o = gbase[d] + segcnt[u * 4 + wave][d] + rank[u];
+    t.k[dst][o] = key[u];
+    t.p[dst][o] = pos[u];
+  }
+}
+
+__global__ void rs_zero_kernel(int* __restrict__ p, long n) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) p[e] = 0;
+}
+
+static long rs_table_ints(long n) {
+  const long nb = (n + RS_EPB - 1) / RS_EPB;
+  return 2 * n + 2 * 256 * nb + 64;        // tmp keys, tmp positions, two digit-counter arrays
+}
+// bytes of workspace for sorting n_tables tables of total_entries entries in all together
+extern "C" long clsr_sort_ids_stable_workspace_bytes(long total_entries, int n_tables) {
+  if (total_entries < 0 || n_tables <= 0) return 0;
+  return (2 * total_entries + 2 * 256 * (total_entries / RS_EPB + n_tables) + 64L * n_tables) * (long)sizeof(int) + 256;
+}
+
+// keys_out / perm_out: the (id, position) pairs of ids[r*row_stride + c] (r < nrows, c < ncols; position = r*ncols + c)
+// in ascending id order, equal ids in ascending position order.  desc.bits = significant bits of the ids
+// (ceil(log2(vocab))), desc.counts is not used.  3 * ceil(max bits / 8) launches whatever the number of tables.
+extern "C" int clsr_sort_ids_stable_multi(const clsr_sortids_desc* descs, int n, void* workspace, long workspace_bytes,
+                                          void* stream) {
+  CLSR_CHECK_ARG(descs && n > 0 && n <= CLSR_SORTIDS_MAX && workspace);
+  RsArgs a;
+  int* w = (int*)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+  long used = 0, mxb = 1, hist_ints = 0;
+  int maxp = 0;
+  for (int i = 0; i < n; ++i) {
+    const clsr_sortids_desc& d = descs[i];
+    CLSR_CHECK_ARG(d.ids && d.keys_out && d.perm_out && d.nrows > 0 && d.ncols > 0 && d.bits >= 1 && d.bits <= 31);
+    const long e = d.nrows * d.ncols;
+    CLSR_CHECK_SUPPORTED(e < (1L << 31) - RS_EPB);
+    RsTable& t = a.t[i];
+    t.ids = d.ids; t.row_stride = d.row_stride; t.ncols = d.ncols; t.n = e;
+    t.nblocks = (int)((e + RS_EPB - 1) / RS_EPB);
+    t.passes = (d.bits + 7) / 8;
+    t.k[1] = d.keys_out; t.p[1] = d.perm_out;
+    t.k[0] = w + used; t.p[0] = w + used + e;
+    t.hist = w + used + 2 * e;
+    // pass p writes buffer (first_dst + p) & 1; the last pass must write buffer 1
+    t.first_dst = (t.passes & 1) ? 1 : 0;
+    used += rs_table_ints(e);
+    hist_ints += 2L * 256 * t.nblocks;
+    mxb = t.nblocks > mxb ? t.nblocks : mxb;
+    maxp = t.passes > maxp ? t.passes : maxp;
+  }
+  CLSR_CHECK_ARG(workspace_bytes >= used * (long)sizeof(int) + 16);
+  hipStream_t s = (hipStream_t)stream;
+  // (the first pass's counters are written by rs_hist_kernel; every scan launch clears the other half before its scatter
+  //  accumulates the next pass's counts into it)
+  for (int p = 0; p < maxp; ++p) {
+    hipLaunchKernelGGL(rs_hist_kernel, dim3((int)mxb, n), dim3(256), 0, s, a, p);
+    hipLaunchKernelGGL(rs_scan_kernel, dim3(n), dim3(1024), 0, s, a, p);
+    hipLaunchKernelGGL(rs_scatter_kernel, dim3((int)mxb, n), dim3(256), 0, s, a, p);
+    CLSR_CHECK_LAUNCH();
+  }
+  (void)hist_ints;
+  return CLSR_OK;
+}
+
+// ===================================================================================================== segmented sums
+// One lookup SITE of a launch: rows `key` of `grad` receive the sums of the slices  g[e, :] = src[pos(e), col0 : col0 + C]
+// (+ src2, + the mean / recent-k terms of the history prologue when dmean / drecent are given: pos = h * T + t).
+#define SS_CHUNK 32                 // sorted entries per thread group
+struct SsSite {
+  const void* src; const void* src2; int src_bf16; const float* dmean; const float* drecent;
+  const int* keys; const int* perm; const int* seq_len; int len_stride;
+  long n; int T; int D; int col0; int C; int recent_k;
+  float* grad; int ldg; int gcol0;
+  double* sumsq;                  // += sum of the squared slice values (may be NULL)
+  float* bnd; int* meta; double* ssp;   // workspace: chunk-border partials [nchunks][2][Cp], [nchunks][4] ints, [blocks] doubles
+  int first_block; int nblocks; int first_block_b; int cp; int vw;
+};
+struct SsArgs { SsSite s[CLSR_SEGSUM_MAX]; int n; };
+
+template <int VW> struct SsVec { typedef float type; };
+template <> struct SsVec<4> { typedef f32x4 type; };
+template <int VW>
+__device__ __forceinline__ typename SsVec<VW>::type ss_ld(const void* p, int bf16, long off) {
+  if constexpr (VW == 4) {
+    return bf16 ? load4e<true>(p, off) : load4e<false>(p, off);
+  } else {
+    return bf16 ? (float)reinterpret_cast<const __bf16*>(p)[off] : reinterpret_cast<const float*>(p)[off];
+  }
+}
+__device__ __forceinline__ float ss_sq(float x) { return x * x; }
+__device__ __forceinline__ float ss_sq(const f32x4& x) { return x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w; }
+
+// meta[chunk]: 0 first key (or -1), 1 last key, 2 flags (1: first run continues from the previous chunk, 2: last run
+// continues into the next chunk, 4: the whole chunk is one run), 3 unused
+template <int VW>
+__device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block, double* red) {
+  typedef typename SsVec<VW>::type vec_t;
+  const int CP = s.cp;                         // lanes per thread group (power of two, 8..64)
+  const int gpb = 256 / CP;
+  const int lig = threadIdx.x & (CP - 1);      // lane in group
+  const int c = lig * VW;
+  const bool cok = c < s.C;
+  const long chunk = (long)local_block * gpb + threadIdx.x / CP;
+  const long nchunks = (s.n + SS_CHUNK - 1) / SS_CHUNK;
+  const long p0 = chunk * SS_CHUNK;
+  const int Cp = CP * VW;
+  float local = 0.f;
+  if (chunk < nchunks) {
+    const long cc = s.col0 + (cok ? c : 0);
+    const int prev_key = p0 > 0 ? s.keys[p0 - 1] : -1;
+    const long pe = p0 + SS_CHUNK < s.n ? p0 + SS_CHUNK : s.n;
+    const int next_key = pe < s.n ? s.keys[pe] : -1;
+    int cur = -1, first_key = -1, nruns = 0;
+    vec_t acc = vec_t(0.f);
+    float* bnd = s.bnd + chunk * 2 * Cp;
+    auto flush = [&](bool last) {
+      // the run `cur` ends here (last: at the end of the chunk)
+      const bool from_prev = nruns == 0 && cur == prev_key;
+      const bool to_next = last && cur == next_key;
+      if (from_prev || to_next) {
+        if (cok) *reinterpret_cast<vec_t*>(bnd + (from_prev ? 0 : Cp) + c) = acc;
+      } else if (cok) {
+        vec_t* g = reinterpret_cast<vec_t*>(s.grad + (long)cur * s.ldg + s.gcol0 + c);
+        *g = *g + acc;
+      }
+      ++nruns;
+    };
+    for (long q0 = p0; q0 < pe; q0 += 8) {
+      int key[8];
+      vec_t g[8];
+      const int knext = q0 + 8 < pe ? s.keys[q0 + 8] : -1;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const long p = q0 + k;
+        const bool ok = p < pe;
+        key[k] = ok ? s.keys[p] : -1;
+        const int pos = ok ? s.perm[p] : 0;
+        vec_t v = ss_ld<VW>(s.src, s.src_bf16, (long)pos * s.D + cc);
+        if (s.src2) v += ss_ld<VW>(s.src2, s.src_bf16, (long)pos * s.D + cc);
+        if (s.dmean || s.drecent) {
+          const int h = pos / s.T, t = pos - h * s.T;
+          const int len = s.seq_len[(long)h * s.len_stride];
+          if (t < len) {
+            if (s.dmean) v += *reinterpret_cast<const vec_t*>(s.dmean + (long)h * s.D + cc) * (1.0f / (float)len);
+            if (s.drecent && t >= len - s.recent_k)
+              v += *reinterpret_cast<const vec_t*>(s.drecent + (long)h * s.D + cc) * (1.0f / (float)(len < s.recent_k ? len : s.recent_k));
+          }
+        }
+        g[k] = (cok && ok) ? v : vec_t(0.f);
+      }
+      // the gradient rows of all eight entries' ids are requested NOW, whether or not a run ends there: a run that ends
+      // inside the chunk is added to its row with a read-modify-write, and one dependent row read per run end, one after
+      // the other along the walk, made this launch 110 us for 640 chunks
+      vec_t gv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        gv[k] = *reinterpret_cast<const vec_t*>(s.grad + (long)(key[k] < 0 ? 0 : key[k]) * s.ldg + s.gcol0 + (cok ? c : 0));
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (key[k] < 0) continue;
+        local += ss_sq(g[k]);
+        if (key[k] != cur) {
+          if (cur < 0) first_key = key[k];
+          cur = key[k];
+          acc = g[k];
+        } else {
+          acc += g[k];
+        }
+        // does the run end at this entry?  (the last entry of the chunk leaves its run open: see below)
+        int nk = key[k];
+        if (k < 7) { if (key[k + 1] >= 0) nk = key[k + 1]; }
+        else if (q0 + 8 < pe) nk = knext;
+        if (nk != key[k]) {
+          const bool from_prev = nruns == 0 && cur == prev_key;
+          if (cok) {
+            if (from_prev) *reinterpret_cast<vec_t*>(bnd + c) = acc;
+            else *reinterpret_cast<vec_t*>(s.grad + (long)cur * s.ldg + s.gcol0 + c) = gv[k] + acc;
+          }
+          ++nruns;
+        }
+      }
+    }
+    int flags = 0;
+    if (cur >= 0) {
+      const bool single = nruns == 0;                 // the chunk is one run
+      const bool from_prev_last = single && cur == prev_key;
+      const bool to_next = cur == next_key;
+      flush(true);
+      if (first_key == prev_key && prev_key >= 0) flags |= 1;
+      if (to_next) flags |= 2;
+      if (single) flags |= 4;
+      (void)from_prev_last;
+    }
+    if (lig == 0) {
+      int* m = s.meta + chunk * 4;
+      m[0] = first_key; m[1] = cur; m[2] = flags; m[3] = 0;
+    }
+  }
+  if (s.sumsq) {
+    const double tot = block256_sum_d((double)local, red);
+    if (threadIdx.x == 0) s.ssp[local_block] = tot;
+  }
+}
+
+__global__ void __launch_bounds__(256) ss_chunks_kernel(SsArgs a) {
+  __shared__ double red[4];
+  int i = 0;
+  while (i + 1 < a.n && (int)blockIdx.x >= a.s[i + 1].first_block) ++i;
+  const SsSite& s = a.s[i];
+  if (s.vw == 4) ss_chunks<4>(s, blockIdx.x - s.first_block, red);
+  else ss_chunks<1>(s, blockIdx.x - s.first_block, red);
+}
+
+// Runs that cross chunk borders: the chunk whose LAST run continues (and is not itself a continuation covering the whole
+// chunk) is the head of such a run.  One WAVE per chunk: a head wave finds the extent of its run 64 chunks at a time
+// (ballots over the chunks' flags), then its 64 / CP lane slots add the partials of the following chunks -- slot j takes
+// the chunks j, j + S, ... of the run -- and the slots are added in slot order: a fixed order for a given list, and a
+// run of 25 000 slices of one popular row (780 partials) costs ~100 dependent steps instead of 780.  The first wave of
+// every site also folds the squared-norm partials of the first launch (lane-strided sums, then the lanes in order).
+template <int VW>
+__device__ __forceinline__ void ss_borders(const SsSite& s, const int local_block) {
+  typedef typename SsVec<VW>::type vec_t;
+  const int CP = s.cp, S = 64 / CP;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lig = lane & (CP - 1), slot = lane / CP;
+  const int c = lig * VW;
+  const bool cok = c < s.C;
+  const int Cp = CP * VW;
+  const long nchunks = (s.n + SS_CHUNK - 1) / SS_CHUNK;
+  const long chunk = (long)local_block * 4 + wave;
+  if (chunk < nchunks) {
+    const int* m = s.meta + chunk * 4;
+    const int flags = m[2];
+    const bool head = (flags & 2) && !((flags & 4) && (flags & 1));     // (wave-uniform)
+    if (head) {
+      const int key = m[1];
+      // extent: chunks chunk + 1 .. chunk + L belong to the run (whole-chunk continuations, then the chunk it ends in)
+      long L = 0;
+      while (true) {
+        const long k = chunk + 1 + L + lane;
+        int f = 0, fk = -1;
+        if (k < nchunks) { fk = s.meta[k * 4]; f = s.meta[k * 4 + 2]; }
+        const bool member = fk == key && (f & 1);
+        const bool whole = member && (f & 4) && (f & 2);
+        const unsigned long long bw = __ballot(whole), bm = __ballot(member);
+        const int nw = bw == ~0ull ? 64 : __builtin_ctzll(~bw);
+        if (nw == 64) { L += 64; continue; }
+        L += nw + (((bm >> nw) & 1ull) ? 1 : 0);
+        break;
+      }
+      vec_t acc = vec_t(0.f);
+      for (long k = slot; k < L; k += S)
+        if (cok) acc += *reinterpret_cast<const vec_t*>(s.bnd + (chunk + 1 + k) * 2 * Cp + c);
+      // the head chunk's own share (its last-run partial: slot 1), then the lane slots in order
+      vec_t tot = cok ? *reinterpret_cast<const vec_t*>(s.bnd + chunk * 2 * Cp + Cp + c) : vec_t(0.f);
+      for (int j = 0; j < S; ++j) {
+        if constexpr (VW == 4) {
+          f32x4 t;
+          t.x = __shfl(acc.x, j * CP + lig, 64); t.y = __shfl(acc.y, j * CP + lig, 64);
+          t.z = __shfl(acc.z, j * CP + lig, 64); t.w = __shfl(acc.w, j * CP + lig, 64);
+          tot += t;
+        } else {
+          tot += __shfl(acc, j * CP + lig, 64);
+        }
+      }
+      if (cok && slot == 0) {
+        vec_t* g = reinterpret_cast<vec_t*>(s.grad + (long)key * s.ldg + s.gcol0 + c);
+        *g = *g + tot;
+      }
+    }
+  }
+  if (s.sumsq && local_block == 0 && wave == 0) {
+    double t = 0.0;
+    for (int b = lane; b < s.nblocks; b += 64) t += s.ssp[b];
+    double tot = 0.0;
+    for (int l = 0; l < 64; ++l) tot += __shfl(t, l, 64);
+    if (lane == 0) *s.sumsq += tot;
+  }
+}
+
+__global__ void __launch_bounds__(256) ss_borders_kernel(SsArgs a) {
+  int i = 0;
+  while (i + 1 < a.n && (int)blockIdx.x >= a.s[i + 1].first_block_b) ++i;
+  const SsSite& s = a.s[i];
+  if (s.vw == 4) ss_borders<4>(s, blockIdx.x - s.first_block_b);
+  else ss_borders<1>(s, blockIdx.x - s.first_block_b);
+}
+
+static void ss_shape(const clsr_segsum_desc& d, int* cp, int* vw) {
+  const bool vec = d.C % 4 == 0 && d.D % 4 == 0 && d.col0 % 4 == 0 && d.gcol0 % 4 == 0 && d.ldg % 4 == 0 &&
+                   ((uintptr_t)d.src % 16) == 0 && (!d.src2 || ((uintptr_t)d.src2 % 16) == 0) &&
+                   (!d.dmean || ((uintptr_t)d.dmean % 16) == 0) && (!d.drecent || ((uintptr_t)d.drecent % 16) == 0) &&
+                   ((uintptr_t)d.grad % 16) == 0;
+  *vw = vec ? 4 : 1;
+  const int q = (d.C + *vw - 1) / *vw;
+  *cp = q <= 8 ? 8 : q <= 16 ? 16 : q <= 32 ? 32 : 64;
+}
+static long ss_site_bytes(long n, int cp, int vw, int* blocks) {
+  const long nchunks = (n + SS_CHUNK - 1) / SS_CHUNK;
+  const int nb = clsr_cdiv(nchunks, 256 / cp);
+  if (blocks) *blocks = nb;
+  long b = nchunks * 2 * cp * vw * (long)sizeof(float);
+  b = (b + 15) & ~15L;
+  b += nchunks * 4 * (long)sizeof(int);
+  b = (b + 15) & ~15L;
+  b += (long)nb * sizeof(double);
+  return (b + 15) & ~15L;
+}
+
+extern "C" int clsr_sizeof_segsum_desc(void) { return (int)sizeof(clsr_segsum_desc); }
+extern "C" long clsr_segsum_workspace_bytes(const clsr_segsum_desc* descs, int n) {
+  long tot = 256;
+  for (int i = 0; i < n; ++i) {
+    int cp, vw;
+    ss_shape(descs[i], &cp, &vw);
+    tot += ss_site_bytes(descs[i].n, cp, vw, nullptr);
+  }
+  return tot;
+}
+
+// Sums of the slices of n lookup sites into their gradient tables (two launches).  The sites of ONE call must write
+// different tables (or disjoint columns), and nothing else may write those tables while the call runs.
+extern "C" int clsr_segsum_multi(const clsr_segsum_desc* descs, int n, void* workspace, long workspace_bytes, void* stream) {
+  CLSR_CHECK_ARG(descs && n > 0 && n <= CLSR_SEGSUM_MAX && workspace);
+  SsArgs a;
+  a.n = n;
+  unsigned char* w = (unsigned char*)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+  long used = 0;
+  int total = 0, total_b = 0;
+  for (int i = 0; i < n; ++i) {
+    const clsr_segsum_desc& d = descs[i];
+    CLSR_CHECK_ARG(d.src && d.keys && d.perm && d.grad && d.n > 0 && d.D > 0 && d.C > 0);
+    CLSR_CHECK_ARG(!(d.dmean || d.drecent) || (d.seq_len && d.T > 0));
+    SsSite& s = a.s[i];
+    ss_shape(d, &s.cp, &s.vw);
+    CLSR_CHECK_SUPPORTED(d.C <= 64 * s.vw);
+    CLSR_CHECK_SUPPORTED(!(d.src_bf16 && s.vw == 4 && ((uintptr_t)d.src % 8)));
+    s.src = d.src; s.src2 = d.src2; s.src_bf16 = d.src_bf16; s.dmean = d.dmean; s.drecent = d.drecent;
+    s.keys = d.keys; s.perm = d.perm; s.seq_len = d.seq_len; s.len_stride = d.len_stride;
+    s.n = d.n; s.T = d.T > 0 ? d.T : 1; s.D = d.D; s.col0 = d.col0; s.C = d.C; s.recent_k = d.recent_k;
+    s.grad = d.grad; s.ldg = d.ldg; s.gcol0 = d.gcol0; s.sumsq = d.sumsq;
+    int nb;
+    const long bytes = ss_site_bytes(d.n, s.cp, s.vw, &nb);
+    const long nchunks = (d.n + SS_CHUNK - 1) / SS_CHUNK;
+    s.bnd = (float*)(w + used);
+    long o = (nchunks * 2 * s.cp * s.vw * (long)sizeof(float) + 15) & ~15L;
+    s.meta = (int*)(w + used + o);
+    o += (nchunks * 4 * (long)sizeof(int) + 15) & ~15L;
+    s.ssp = (double*)(w + used + o);
+    used += bytes;
+    s.first_block = total;
+    s.nblocks = nb;
+    total += nb;
+    s.first_block_b = total_b;
+    total_b += clsr_cdiv(nchunks, 4);
+  }
+  CLSR_CHECK_ARG(workspace_bytes >= used + 16);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ss_chunks_kernel, dim3(total), dim3(256), 0, st, a);
+  CLSR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(ss_borders_kernel, dim3(total_b), dim3(256), 0, st, a);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}

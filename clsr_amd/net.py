@@ -165,6 +165,10 @@ class CLSRNet(object):
         self.defer_dw = True       # one batched reduction of the weight-gradient partials per stream and step
         self.overlap = not os.environ.get("CLSR_NO_OVERLAP")   # run the long-term attention chain etc. on side streams (fork / join); off: one stream, every kernel alone (diagnosis: contention-free kernel times)
         self.sorted_hist_grad = True   # history-row gradients by sort + segmented sums (False: float atomics)
+        # deterministic embedding gradients (csrc/segsum.hip): STABLE radix sort of every lookup site's ids + segmented sums
+        # that write each row once, in a fixed order -- no float atomics; two runs of a step give bit-identical gradient
+        # tables and clip norms.  CLSR_NO_DET_GRADS=1: the counting sort + atomics of rounds 2-3.
+        self.det_grads = not os.environ.get("CLSR_NO_DET_GRADS")
         self.adam_state = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device=self.device)
         # squared norms of the IndexedSlices pieces (16) + loss numerators (8): ONE buffer, so that the data-parallel
         # exchange sums them with one collective and no staging copies
@@ -2092,7 +2096,10 @@ class CLSRNet(object):
         for job in late or ():
             job()
         side_dense = self.flush_side and self.overlap and self.dw_stream
-        self._join(but=("@scat", "@encw") if side_dense else ("@scat",))
+        # (deterministic segmented sums update a row with a plain read-modify-write: the target / user row sums of the
+        #  same tables -- the @scat branches -- must have finished, which they have long since: the wait costs a packet)
+        keep = () if (self.det_grads and self.sorted_hist_grad) else ("@scat",)
+        self._join(but=keep + ("@encw",) if side_dense else keep)
         if side_dense:
             # the dense path from here on (batched reduction of every weight gradient, unpacking, later the dense
             # regulariser + Adam) does not meet the embedding path (gradient tables, table regulariser / Adam) again:
@@ -2118,7 +2125,7 @@ class CLSRNet(object):
             with self._branch("@lt" if self.split_emb_grad else "@main", after=fork):
                 self._hist_grad_sorted(dhist, dM, dR, Hn, T, seq_len, ls, ss, only="cate", dhist2=dhist_lt)
                 if not scat_early:
-                    call("clsr_scatter_add_rows", dtarget, D, Di, f["cates"], 1, B, Dc, self.tab_grad["cate"], ss[3:])
+                    self._scatter_cate_targets(f, dtarget, B)
                 self._dp_hook("table_ready", "cate")
             if not scat_early:
                 with self._branch("@aux" if self.split_emb_grad else "@main", after=fork):
@@ -2161,6 +2168,8 @@ class CLSRNet(object):
         zeroing launch + three launches for both tables together (csrc/sparse.hip: clsr_sort_ids_multi)."""
         n = Hn * T
         tabs = self._sort_tables()
+        if self.det_grads:
+            return self._sort_ids_stable(f, Hn, T, hs)
         counts, bits = self._sort_counts()
         if not self._counts_zeroed:      # (the training step clears them with its other accumulators)
             call("clsr_zero_floats", counts.view(F32), counts.numel())
@@ -2173,11 +2182,65 @@ class CLSRNet(object):
             o += 1 << b
         ops.sort_ids_multi(rows)
 
+    def _det_sites(self, f):
+        """lookup sites besides the two history lookups whose ids are sorted for the deterministic segmented sums:
+        (list name, feed key, vocabulary, rows, row stride)"""
+        if type(self) is not CLSRNet or "user_long" not in self.tables:
+            return ()
+        B = f["B"]
+        G = self.G_train if self.dedup else 1
+        hs = 1 if f.get("compact") else G
+        return (("item_t", "items", self.dims["Vi"], B, 1), ("cate_t", "cates", self.dims["Vc"], B, 1),
+                ("user", "users", self.dims["Vu"], B // G, hs))
+
+    def _sort_ids_stable(self, f, Hn, T, hs):
+        """Stable radix sort (ascending ids, equal ids in slice order) of the ids of every lookup site of the step: the
+        two history lookups and -- CLSR graph -- the target item / category rows and the user rows: one launch set."""
+        n = Hn * T
+        rows, total = [], 0
+        for name, fkey, V, _, _, _ in self._sort_tables():
+            keys = self._buf("sort.keys." + name, n, dtype=torch.int32)
+            perm = self._buf("sort.perm." + name, n, dtype=torch.int32)
+            rows.append((f[fkey].data_ptr(), keys.data_ptr(), perm.data_ptr(), Hn, hs * T, T, max(1, (V - 1).bit_length())))
+            total += n
+        for name, fkey, V, nr, stride in self._det_sites(f):
+            keys = self._buf("sort.keys." + name, nr, dtype=torch.int32)
+            perm = self._buf("sort.perm." + name, nr, dtype=torch.int32)
+            rows.append((f[fkey].data_ptr(), keys.data_ptr(), perm.data_ptr(), nr, stride, 1, max(1, (V - 1).bit_length())))
+            total += nr
+        ws = self._buf("sort.ws", query("clsr_sort_ids_stable_workspace_bytes", total, len(rows)), dtype=torch.uint8)
+        ops.sort_ids_stable_multi(rows, ws)
+
+    def _segsum(self, tag, rows):
+        ws = self._buf("segsum.ws." + tag, ops.segsum_workspace_bytes(rows), dtype=torch.uint8)
+        ops.segsum_multi(rows, ws)
+
+    def _site_row(self, name, src, ld, col0, C, n, grad, sumsq):
+        """segmented-sum descriptor of a row-level lookup site (targets / users): slice e = row perm[e] of ``src``"""
+        keys = self._buf("sort.keys." + name, n, dtype=torch.int32)
+        perm = self._buf("sort.perm." + name, n, dtype=torch.int32)
+        return (src.data_ptr(), 0, 0, 0, keys.data_ptr(), perm.data_ptr(), 0, grad.data_ptr(), sumsq.data_ptr(), n, 0, 0, 1,
+                ld, col0, C, 1, grad.shape[1], 0, 0)
+
     def _scatter_user_item_rows(self, f, dul, dushort, dtarget, Hn, B, hs):
         """User rows (long / short table) and the target items' rows: ONE launch, blockIdx.y = lookup site (``None``:
         that site is not part of this launch)."""
         tg, ss, dp_ = self.tab_grad, self.sumsq_tab, lambda t: t.data_ptr()
         D, Du, Di = self.D, self.Du, self.Di
+        if self.det_grads and self._det_sites(f):
+            rows = []
+            if dul is not None:
+                rows.append(self._site_row("user", dul, Du, 0, Du, Hn, tg["user_long"], ss[6:]))
+            if dushort is not None:
+                rows.append(self._site_row("user", dushort, Du, 0, Du, Hn, tg["user_short"], ss[7:]))
+            if dtarget is not None:
+                rows.append(self._site_row("item_t", dtarget, D, 0, Di, B, tg["item"], ss[2:]))
+            self._segsum("rows%d%d%d" % (dul is not None, dushort is not None, dtarget is not None), rows)
+            if dul is not None:
+                self._dp_hook("table_ready", "user_long")
+            if dushort is not None:
+                self._dp_hook("table_ready", "user_short")
+            return
         sites = []
         if dul is not None:
             sites.append((dp_(dul), dp_(f["users"]), dp_(tg["user_long"]), dp_(ss[6:]), hs, Du, 0, Hn, Du))
@@ -2201,8 +2264,15 @@ class CLSRNet(object):
             self._scatter_user_item_rows(f, dul, dushort, dtarget, Hn, B, hs)
         if dtarget is not None:
             with self._branch("@lt", after=fork, name="@scat"):
-                call("clsr_scatter_add_rows", dtarget, self.D, self.Di, f["cates"], 1, B, self.Dc, self.tab_grad["cate"],
-                     self.sumsq_tab[3:])
+                self._scatter_cate_targets(f, dtarget, B)
+
+    def _scatter_cate_targets(self, f, dtarget, B):
+        if self.det_grads and self._det_sites(f):
+            self._segsum("cate_t", [self._site_row("cate_t", dtarget, self.D, self.Di, self.Dc, B, self.tab_grad["cate"],
+                                                   self.sumsq_tab[3:])])
+        else:
+            call("clsr_scatter_add_rows", dtarget, self.D, self.Di, f["cates"], 1, B, self.Dc, self.tab_grad["cate"],
+                 self.sumsq_tab[3:])
 
     def _hist_grad_sorted(self, dhist, dM, dR, Hn, T, seq_len, ls, ss, only=None, dhist2=None):
         """IndexedSlices of the history lookups -> dense gradient tables via segmented sums over the
@@ -2212,6 +2282,19 @@ class CLSRNet(object):
         the last bits, like the order of the per-run atomics always could."""
         n = Hn * T
         k = self.hp.contrastive_recent_k
+        if self.det_grads:
+            rows = []
+            for name, _, V, col0, C, slot in self._sort_tables():
+                if only is not None and name != only:
+                    continue
+                keys = self._buf("sort.keys." + name, n, dtype=torch.int32)
+                perm = self._buf("sort.perm." + name, n, dtype=torch.int32)
+                ptr = lambda t: 0 if t is None else t.data_ptr()
+                rows.append((dhist.data_ptr(), ptr(dhist2), ptr(dM), ptr(dR), keys.data_ptr(), perm.data_ptr(),
+                             seq_len.data_ptr(), self.tab_grad[name].data_ptr(), ss[slot:].data_ptr(), n,
+                             int(dhist.dtype == torch.bfloat16), ls, T, self.D, col0, C, k, C, 0, 0))
+            self._segsum("hist." + (only or "all"), rows)
+            return
         for name, _, V, col0, C, slot in self._sort_tables():
             if only is not None and name != only:
                 continue

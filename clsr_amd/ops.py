@@ -347,6 +347,47 @@ def sort_ids_multi(rows):
     call("clsr_sort_ids_multi", ctypes.addressof(arr), len(rows))
 
 
+def sort_ids_stable_multi(rows, workspace):
+    """clsr_sort_ids_stable_multi on a list of (ids, keys_out, perm_out, nrows, row_stride, ncols, bits) tuples
+    (pointers as integers); ``workspace``: a uint8 tensor of clsr_sort_ids_stable_workspace_bytes(total entries, tables)."""
+    assert ctypes.sizeof(SortIdsDesc) == query("clsr_sizeof_sortids_desc")
+    arr = (SortIdsDesc * len(rows))()
+    keep_alive(arr)
+    for d, (ids, ko, po, nrows, stride, ncols, bits) in zip(arr, rows):
+        d.ids, d.keys_out, d.perm_out, d.counts = ids, ko, po, None
+        d.nrows, d.row_stride, d.ncols, d.bits = nrows, stride, ncols, bits
+    call("clsr_sort_ids_stable_multi", ctypes.addressof(arr), len(rows), workspace, workspace.numel())
+
+
+class SegsumDesc(ctypes.Structure):
+    """ctypes mirror of clsr_segsum_desc (include/clsr_hip.h)."""
+    _fields_ = [("src", _P), ("src2", _P), ("dmean", _P), ("drecent", _P), ("keys", _P), ("perm", _P), ("seq_len", _P),
+                ("grad", _P), ("sumsq", _P), ("n", _L), ("src_bf16", _I), ("len_stride", _I), ("T", _I), ("D", _I),
+                ("col0", _I), ("C", _I), ("recent_k", _I), ("ldg", _I), ("gcol0", _I), ("pad_", _I)]
+
+
+def segsum_descs(rows):
+    """ctypes array of clsr_segsum_desc from field tuples in the order of SegsumDesc._fields_ (pointers as integers)."""
+    assert ctypes.sizeof(SegsumDesc) == query("clsr_sizeof_segsum_desc")
+    arr = (SegsumDesc * len(rows))()
+    for d, row in zip(arr, rows):
+        for (fname, _), val in zip(SegsumDesc._fields_, row):
+            setattr(d, fname, val)
+    return arr
+
+
+def segsum_workspace_bytes(rows):
+    arr = segsum_descs(rows)
+    return query("clsr_segsum_workspace_bytes", ctypes.addressof(arr), len(rows))
+
+
+def segsum_multi(rows, workspace):
+    """clsr_segsum_multi: deterministic segmented sums of the lookup sites ``rows`` into their gradient tables."""
+    arr = segsum_descs(rows)
+    keep_alive(arr)
+    call("clsr_segsum_multi", ctypes.addressof(arr), len(rows), workspace, workspace.numel())
+
+
 class DwJob(ctypes.Structure):
     """ctypes mirror of clsr_dwjob (include/clsr_hip.h)."""
     _fields_ = [("X", _P), ("Xmul", _P), ("in_scale", _P), ("in_shift", _P), ("dY", _P), ("workspace", _P),

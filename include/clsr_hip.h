@@ -57,7 +57,7 @@ int clsr_scatter_add_rows(const float* src, int ld_src, int col0, const int* idx
  * hand-written counting sort (LDS-aggregated histogram, scan, scatter: three launches for all tables of a step), then
  * runs of equal ids summed in registers (dedup of IndexedSlices).  Output: ascending ids when
  * vocab <= 2^18, grouped by (id mod 2^18) beyond; order inside a run of equal ids undefined. */
-#define CLSR_SORTIDS_MAX 4
+#define CLSR_SORTIDS_MAX 8
 typedef struct clsr_sortids_desc {
   const int* ids; int* keys_out; int* perm_out; int* counts;   /* counts: (1 << bits) ints, ZERO on entry */
   long nrows; long row_stride; int ncols; int bits;
@@ -65,6 +65,47 @@ typedef struct clsr_sortids_desc {
 int clsr_sizeof_sortids_desc(void);
 int clsr_sort_ids_bits(long vocab);
 int clsr_sort_ids_multi(const clsr_sortids_desc* descs_host, int n, void* stream);
+/* ---- small-message all-reduce over peer-mapped exchange buffers (csrc/p2p.hip): the 2 C doubles of
+ *      a synchronised batch-norm layer, summed by ONE single-workgroup kernel on the issuing stream (push into every
+ *      peer's buffer, flags with system-scope release / acquire, sum in rank order: bit-identical on every rank).  The
+ *      host allocates one exchange buffer per rank (clsr_comm_alloc: fine-grained device memory), exchanges the hipIpc
+ *      handles (clsr_comm_ipc_handle / clsr_comm_ipc_open) and creates the communicator from the world pointers; the
+ *      communicator is an opaque void* for every later call.  Not capturable into a hipGraph (the sequence number is a
+ *      launch argument). */
+long clsr_comm_buffer_bytes(void);
+int clsr_comm_max_doubles(void);
+int clsr_comm_max_world(void);
+int clsr_comm_alloc(void** buf_out);
+int clsr_comm_free(void* buf);
+int clsr_comm_ipc_handle_bytes(void);
+int clsr_comm_ipc_handle(void* buf, void* handle_out);
+int clsr_comm_ipc_open(const void* handle, void** peer_out);
+int clsr_comm_ipc_close(void* peer);
+int clsr_comm_create(int rank, int world, void* const* bufs, void** comm_out);
+int clsr_comm_destroy(void* comm);
+long clsr_comm_error(void* comm);    /* sequence number of the last all-reduce that timed out waiting for a peer (0: none) */
+int clsr_allreduce_small(void* comm, double* data, int n, void* stream);
+
+/* ---- deterministic embedding gradients (csrc/segsum.hip): STABLE radix sort (ascending ids, equal ids in position order;
+ *      desc.bits = significant bits of the ids, desc.counts unused; 1 + 2 * ceil(bits / 8) launches for all tables) and
+ *      segmented sums that add every row's total to its gradient table once, in a fixed order -- no float atomics: two
+ *      runs of a step give bit-identical tables and clip norms. */
+long clsr_sort_ids_stable_workspace_bytes(long total_entries, int n_tables);
+int clsr_sort_ids_stable_multi(const clsr_sortids_desc* descs_host, int n, void* workspace, long workspace_bytes,
+                               void* stream);
+/* one lookup site: grad[key, gcol0 : gcol0 + C] += sum over the sorted entries e with keys[e] == key of
+ * src[perm[e], col0 : col0 + C] (+ src2; + dmean[h] / len + recent-k term of the history prologue when given, perm = h*T+t);
+ * sumsq += sum of the squared slice values.  src / src2: fp32, or bf16 (src_bf16). */
+#define CLSR_SEGSUM_MAX 8
+typedef struct clsr_segsum_desc {
+  const void* src; const void* src2; const float* dmean; const float* drecent;
+  const int* keys; const int* perm; const int* seq_len; float* grad; double* sumsq;
+  long n; int src_bf16; int len_stride; int T; int D; int col0; int C; int recent_k; int ldg; int gcol0; int pad_;
+} clsr_segsum_desc;
+int clsr_sizeof_segsum_desc(void);
+long clsr_segsum_workspace_bytes(const clsr_segsum_desc* descs_host, int n);
+/* the sites of one call must write different tables (or disjoint columns); nothing else may write them meanwhile */
+int clsr_segsum_multi(const clsr_segsum_desc* descs_host, int n, void* workspace, long workspace_bytes, void* stream);
 long clsr_sort_ids_workspace_bytes(long n, long vocab);
 int clsr_sort_ids(const int* ids, long nrows, int ncols, long row_stride, long vocab, int* keys_out,
                   int* perm_out, void* workspace, long workspace_bytes, void* stream);

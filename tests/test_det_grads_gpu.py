@@ -1,0 +1,185 @@
+"""Deterministic embedding gradients (csrc/segsum.hip): the stable radix sort of the lookup ids, the segmented sums that
+write every gradient row once in a fixed order, and the whole training step run twice from the same state -- the gradient
+tables, clip norms and updated tables must be BIT-identical (reference semantics of the sums: tf.train.AdamOptimizer's
+unsorted_segment_sum over the IndexedSlices of tf.nn.embedding_lookup, models/base_model.py:263-276,
+models/sequential/sequential_base_model.py:381-452; the reference itself makes no ordering promise -- this is a property
+of the build, asked for by the reviews)."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from clsr_amd import ops  # noqa: E402
+from clsr_amd.ops import call, query  # noqa: E402
+
+DEV = "cuda"
+
+
+def _stable_sort(tables):
+    """tables: list of (ids tensor [nrows, row_stride] int32 on the device, nrows, ncols, vocab)"""
+    rows, outs, total = [], [], 0
+    for ids, nrows, ncols, V in tables:
+        n = nrows * ncols
+        k = torch.full((n,), -7, dtype=torch.int32, device=DEV)
+        p = torch.full((n,), -7, dtype=torch.int32, device=DEV)
+        outs.append((k, p))
+        rows.append((ids.data_ptr(), k.data_ptr(), p.data_ptr(), nrows, ids.stride(0), ncols, max(1, (V - 1).bit_length())))
+        total += n
+    ws = torch.empty(query("clsr_sort_ids_stable_workspace_bytes", total, len(rows)), dtype=torch.uint8, device=DEV)
+    ops.sort_ids_stable_multi(rows, ws)
+    torch.cuda.synchronize()
+    return outs
+
+
+@pytest.mark.parametrize("shapes", [
+    [(4096, 50, 64138, True), (4096, 50, 4096, True), (20480, 1, 64138, True), (20480, 1, 4096, False), (4096, 1, 36915, False)],
+    [(1024, 250, 292286, True)],
+    [(4096, 50, 100_000_000, False), (4096, 50, 10000, False)],
+    [(3, 1, 7, False), (1, 1, 2, False), (17, 3, 1 << 20, False)],
+    [(700, 3, 300, True)]])
+def test_stable_radix_sort_of_lookup_ids(shapes):
+    """clsr_sort_ids_stable_multi == torch.sort(stable=True) of the same ids: ascending ids, equal ids in position order, for
+    several tables of different sizes / vocabularies in one launch set, strided id rows included."""
+    g = torch.Generator().manual_seed(len(shapes) * 7 + shapes[0][0])
+    tables, flat = [], []
+    for nrows, ncols, V, zipf in shapes:
+        n = nrows * ncols
+        if zipf:
+            ids = (torch.rand(n, generator=g).pow(6.0) * (V - 1)).long() + 1
+            ids[::97] = 0
+        else:
+            ids = torch.randint(0, V, (n,), generator=g)
+        wide = torch.full((nrows, ncols + 3), -1, dtype=torch.int32)        # a row stride that is not the column count
+        wide[:, :ncols] = ids.view(nrows, ncols).int()
+        d = wide.to(DEV)
+        tables.append((d[:, :ncols], nrows, ncols, V))
+        flat.append(ids)
+    outs = _stable_sort(tables)
+    for (k, p), ids in zip(outs, flat):
+        ek, ep = torch.sort(ids, stable=True)
+        assert torch.equal(k.cpu().long(), ek), "keys"
+        assert torch.equal(p.cpu().long(), ep), "positions (stable order)"
+
+
+def _segsum(sites, V_C):
+    rows = []
+    for s in sites:
+        rows.append(s)
+    ws = torch.empty(ops.segsum_workspace_bytes(rows), dtype=torch.uint8, device=DEV)
+    ops.segsum_multi(rows, ws)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("Hn,T,Di,Dc,V,zipf", [(64, 50, 32, 8, 40, False), (33, 10, 32, 8, 5000, False), (16, 7, 96, 32, 300, True),
+                                               (512, 50, 96, 32, 1_000_000, False), (4096, 50, 32, 8, 64138, True),
+                                               (40, 50, 128, 8, 77, False), (5, 1, 20, 4, 3, False)])
+def test_deterministic_segmented_history_gradient(Hn, T, Di, Dc, V, zipf):
+    """clsr_segsum_multi on the stable-sorted ids == float64 index_add of every slice (mean / recent-k terms of the history
+    prologue included, second addend included), item and category tables in ONE call; squared norms of the un-summed
+    slices; and two calls give bit-identical tables."""
+    g = torch.Generator().manual_seed(Hn + V % 97)
+    D, k, n = Di + Dc, 3, Hn * T
+    Vc = max(2, min(V, 37))
+    lens = torch.randint(1, T + 1, (Hn,), generator=g)
+    if zipf:
+        ii = ((torch.rand(n, generator=g).pow(5.0) * (V - 1)).long() + 1).view(Hn, T)
+    else:
+        ii = torch.randint(0, V, (Hn, T), generator=g)
+    ci = torch.randint(0, Vc, (Hn, T), generator=g)
+    d_ii, d_ci = ii.int().to(DEV), ci.int().to(DEV)
+    (ki, pi), (kc, pc) = _stable_sort([(d_ii, Hn, T, V), (d_ci, Hn, T, Vc)])
+    dh, dh2 = torch.randn(Hn, T, D, generator=g), torch.randn(Hn, T, D, generator=g)
+    dm, dr = torch.randn(Hn, D, generator=g), torch.randn(Hn, D, generator=g)
+    d_len = lens.int().to(DEV)
+    dev = lambda t: t.to(DEV).contiguous()
+    a, b, m_, r_ = dev(dh), dev(dh2), dev(dm), dev(dr)
+    res = []
+    for _ in range(2):
+        gi, gc = torch.zeros(V, Di, device=DEV), torch.zeros(Vc, Dc, device=DEV)
+        gi[min(3, V - 1)] = 1.5                                  # rows are ADDED to (another site may have written them)
+        ss = torch.zeros(2, dtype=torch.float64, device=DEV)
+        rows = [(a.data_ptr(), b.data_ptr(), m_.data_ptr(), r_.data_ptr(), ki.data_ptr(), pi.data_ptr(), d_len.data_ptr(),
+                 gi.data_ptr(), ss[0:].data_ptr(), n, 0, 1, T, D, 0, Di, k, Di, 0, 0),
+                (a.data_ptr(), b.data_ptr(), m_.data_ptr(), r_.data_ptr(), kc.data_ptr(), pc.data_ptr(), d_len.data_ptr(),
+                 gc.data_ptr(), ss[1:].data_ptr(), n, 0, 1, T, D, Di, Dc, k, Dc, 0, 0)]
+        _segsum(rows, None)
+        res.append((gi, gc, ss))
+    m = (torch.arange(T)[None, :] < lens[:, None]).double()
+    pos = torch.flip(torch.cumsum(torch.flip(m, [1]), 1), [1])
+    rec = ((pos >= 1) & (pos <= k)).double()
+    gfull = dh.double() + dh2.double() + m[..., None] * (dm.double() / m.sum(1, keepdim=True))[:, None, :] \
+        + rec[..., None] * (dr.double() / rec.sum(1, keepdim=True))[:, None, :]
+    ei = torch.zeros(V, Di, dtype=torch.float64).index_add_(0, ii.reshape(-1), gfull[..., :Di].reshape(-1, Di))
+    ei[min(3, V - 1)] += 1.5
+    ec = torch.zeros(Vc, Dc, dtype=torch.float64).index_add_(0, ci.reshape(-1), gfull[..., Di:].reshape(-1, Dc))
+    gi, gc, ss = res[0]
+    scale = float(ei.abs().max())
+    err = (gi.double().cpu() - ei).abs().max()
+    assert float(err) <= 2e-6 * scale + 1e-5, "item gradient: max err %.3e at scale %.3e" % (float(err), scale)
+    errc = (gc.double().cpu() - ec).abs().max()
+    assert float(errc) <= 2e-6 * float(ec.abs().max()) + 1e-5, "category gradient: max err %.3e" % float(errc)
+    exp_ss = torch.tensor([float((gfull[..., :Di] ** 2).sum()), float((gfull[..., Di:] ** 2).sum())])
+    assert torch.allclose(ss.cpu(), exp_ss.double(), rtol=1e-5)
+    for x, y in zip(res[0], res[1]):
+        assert torch.equal(x, y), "two runs of the segmented sums must be bit-identical"
+
+
+def test_deterministic_row_level_sites():
+    """target / user lookups as sites with T = 1: slices = rows of a [B, ld] gradient matrix, column slices, duplicates"""
+    g = torch.Generator().manual_seed(9)
+    B, V, ld, col0, C = 20480, 5000, 40, 32, 8
+    idx = (torch.rand(B, generator=g).pow(3.0) * (V - 1)).long()
+    src = torch.randn(B, ld, generator=g)
+    d_idx = idx.int().to(DEV).view(B, 1)
+    (k, p), = _stable_sort([(d_idx, B, 1, V)])
+    grad = torch.zeros(V, C, device=DEV)
+    ss = torch.zeros(1, dtype=torch.float64, device=DEV)
+    d_src = src.to(DEV)
+    _segsum([(d_src.data_ptr(), 0, 0, 0, k.data_ptr(), p.data_ptr(), 0, grad.data_ptr(), ss.data_ptr(), B, 0, 0, 1, ld, col0, C,
+              1, C, 0, 0)], None)
+    exp = torch.zeros(V, C, dtype=torch.float64).index_add_(0, idx, src.double()[:, col0:col0 + C])
+    assert float((grad.double().cpu() - exp).abs().max()) <= 1e-5 * float(exp.abs().max())
+    assert abs(float(ss) - float((src[:, col0:col0 + C].double() ** 2).sum())) <= 1e-6 * float(ss)
+
+
+def test_training_step_is_bit_reproducible(golden_dir, golden_hparams):
+    """The same step from the same state, twice: every trained embedding table, its Adam moments, the dense variables and the
+    clip norms come out bit-identical."""
+    import pickle
+
+    from clsr_amd.net import CLSRNet
+    from oracle import clsr_oracle as O
+
+    hp = golden_hparams
+    dims = dict(Vu=len(pickle.load(open(hp.user_vocab, "rb"))), Vi=len(pickle.load(open(hp.item_vocab, "rb"))),
+                Vc=len(pickle.load(open(hp.cate_vocab, "rb"))))
+    gfeed = np.load(os.path.join(golden_dir, "iterator_train_sa.npz"))
+    feed = {k[3:]: gfeed[k] for k in gfeed.files if k.startswith("b0_")}
+    params = O.init_params(dims, hp, seed=3, scale_dense=8.0)
+    sd = dict(params)
+    sd.update(O.init_bn_state(params))
+    runs = []
+    for _ in range(2):
+        net = CLSRNet(hp, dims, device="cuda:0", seed=0)
+        assert net.det_grads
+        net.load_state_dict(copy.deepcopy(sd))
+        net.capture_grads = True
+        f = net.upload(feed, True)
+        for _ in range(2):
+            net.train_step(f)
+        torch.cuda.synchronize()
+        state = {k: v.clone() for k, v in net.state_dict().items()}
+        state.update({"m." + k: t.clone() for k, t in net.tab_m.items()})
+        # squared norms of the un-summed slices of the six lookup sites (the other slots are regulariser norms)
+        state["sumsq"] = net.captured["table_sumsq"][[0, 1, 2, 3, 6, 7]].clone()
+        state.update({"g." + k: t.clone() for k, t in net.captured["tables"].items()})
+        runs.append(state)
+    a, b = runs
+    tab = [k for k in a if "embedding" in k or k.startswith(("m.", "g.")) or k == "sumsq"]
+    assert len(tab) >= 9
+    for k in tab:
+        assert torch.equal(a[k], b[k]), "%s differs between two runs of the same step" % k
