@@ -292,28 +292,37 @@ def embedding_rooflines(net, f, cfg, G, feed):
     keys_i, perm_i = net._buf("sort.keys.item", n, dtype=torch.int32), net._buf("sort.perm.item", n, dtype=torch.int32)
     keys_c, perm_c = net._buf("sort.keys.cate", n, dtype=torch.int32), net._buf("sort.perm.cate", n, dtype=torch.int32)
     tg = net.tab_grad
-    blk = ops.query("clsr_gather_bwd_sorted_max_cols", D, 0, Di, Di, 0)
 
-    def bwd(name, d):
-        def run():
-            for c0 in range(0, Di, blk):
-                ops.call(name, d, None, None, None, keys_i, perm_i, f["seq_len"], G, n, T, D, c0, min(blk, Di - c0), 3,
-                         tg["item"], Di, c0, None)
-            ops.call(name, d, None, None, None, keys_c, perm_c, f["seq_len"], G, n, T, D, Di, Dc, 3, tg["cate"], Dc, 0, None)
-        return run
+    def site_rows(d):
+        bf = int(d.dtype == torch.bfloat16)
+        return [(d.data_ptr(), 0, 0, 0, keys_i.data_ptr(), perm_i.data_ptr(), f["seq_len"].data_ptr(), tg["item"].data_ptr(), 0,
+                 n, bf, G, T, D, 0, Di, 3, Di, 0, 0),
+                (d.data_ptr(), 0, 0, 0, keys_c.data_ptr(), perm_c.data_ptr(), f["seq_len"].data_ptr(), tg["cate"].data_ptr(), 0,
+                 n, bf, G, T, D, Di, Dc, 3, Dc, 0, 0)]
+
+    def bwd(d):
+        rows = site_rows(d)
+        ws = torch.empty(ops.segsum_workspace_bytes(rows), dtype=torch.uint8, device=dev)
+        return lambda: ops.segsum_multi(rows, ws)
 
     def clear_grads():      # the timed launches accumulate into the gradient tables: put the touched rows back to zero
         tg["cate"].zero_()
         tg["item"].index_fill_(0, keys_i.long(), 0.0)
 
-    for tag, name, d, sa in (("gather_bwd", "clsr_gather_bwd_sorted2", dhist, 4),
-                             ("gather_bwd_bf16_dhist", "clsr_gather_bwd_sorted2_h", dhist.to(torch.bfloat16), 2)):
-        t = time_kernel(bwd(name, d))
+    det = getattr(net, "det_grads", False)
+    for tag, d, sa in (("gather_bwd", dhist, 4), ("gather_bwd_bf16_dhist", dhist.to(torch.bfloat16), 2)):
+        if not det:
+            out[tag] = dict(skipped="CLSR_NO_DET_GRADS: the counting-sort + atomics path is not measured here")
+            continue
+        t = time_kernel(bwd(d))
         nbytes = n_valid * D * sa + n_valid * D * 4 + 2 * n_valid * 4
-        out[tag] = dict(bound="hbm", kernel="gather_bwd_sorted_kernel (item + category launches)",
+        out[tag] = dict(bound="hbm", kernel="ss_chunks_kernel + ss_borders_kernel (item and category sites in one call: "
+                                            "deterministic segmented sums, csrc/segsum.hip)",
                         achieved=round(nbytes / t / 1e9, 1), peak=8000.0, unit="GB/s", frac=round(nbytes / t / 8e12, 4),
                         bytes_per_launch=nbytes, us_per_launch=round(t * 1e6, 2),
-                        formula="n*D*%d (gradient read) + n*D*4 (fp32 row-gradient write) + 2*n*4" % sa)
+                        formula="n*D*%d (gradient read) + n*D*4 (fp32 row-gradient write) + 2*n*4" % sa,
+                        note="the rows are ADDED to (a table has two lookup sites): every row write is preceded by a row "
+                             "read that the formula does not count")
         clear_grads()
     # ---- bf16 tables + bf16 hist: bytes_gather_fwd(n) = n*D*(2 + 2) + 2*n*4
     try:

@@ -12,34 +12,44 @@
 //   3. sum    the world slots of the own buffer in RANK ORDER (every rank computes the same fp64 sum: replicas stay
 //             bit-identical), in place.
 // Two slot sets alternate with the sequence number: a rank can be at most one all-reduce ahead of a peer (it cannot
-// finish all-reduce k + 1 before that peer has pushed k + 1, which the peer does after it has finished reading k).
+// finish all-reduce k + 1 before that peer has pushed k + 1, which the peer does after it has finished reading k) -- as
+// long as the all-reduces of a sequence execute IN ORDER, which holds per HIP stream only: the step issues them from two
+// streams (main chain, long-term attention chain), and with one sequence for both a later all-reduce that ran first
+// had its flag overwritten by an earlier one that ran second (the peers then waited for a number that never came back).
+// Every stream therefore gets a CHANNEL of its own (slots, flags, sequence), assigned in order of first use -- the same
+// order on every rank, because every rank issues the same sequence of calls.
 // The exchange buffers are fine-grained device allocations (no stale lines in a reader's L2) mapped into the peers by
-// hipIpc handles that the host exchanges once; the kernel gives up after ~2 s and raises the communicator's error flag
+// hipIpc handles that the host exchanges once; the kernel gives up after a minute and raises the communicator's error flag
 // instead of hanging the device.
 #include "common.h"
 #include "clsr_hip.h"
 #include <string.h>
+#include <stdlib.h>
 
 #define P2P_MAXW 8            // ranks (one node)
 #define P2P_MAXN 256          // doubles per all-reduce
+#define P2P_NCH 4             // channels = streams that issue all-reduces
 
 struct P2PBuf {
-  double data[2][P2P_MAXW][P2P_MAXN];
-  unsigned long long flag[2][P2P_MAXW];
+  double data[P2P_NCH][2][P2P_MAXW][P2P_MAXN];
+  unsigned long long flag[P2P_NCH][2][P2P_MAXW];
   unsigned long long err;
 };
 
 struct P2PComm {
   int rank, world;
   P2PBuf* bufs[P2P_MAXW];     // own buffer at [rank], peers' mapped buffers elsewhere
-  unsigned long long seq;     // host-side count of issued all-reduces
+  unsigned long long seq[P2P_NCH];     // host-side count of issued all-reduces per channel
+  void* stream_of[P2P_NCH];            // channel -> the stream that owns it (assigned at first use)
+  int nch;
 };
 
 struct P2PArgs {
   P2PBuf* bufs[P2P_MAXW];
   double* x;
-  int n, rank, world;
+  int n, rank, world, ch;
   unsigned long long seq;
+  long long timeout_ticks;      // of the 100 MHz wall clock
 };
 
 __global__ void __launch_bounds__(256) allreduce_small_kernel(P2PArgs a) {
@@ -49,15 +59,15 @@ __global__ void __launch_bounds__(256) allreduce_small_kernel(P2PArgs a) {
   if (tid < a.n) {
     const double v = a.x[tid];
     for (int p = 0; p < a.world; ++p)
-      __hip_atomic_store(&a.bufs[p]->data[slot][a.rank][tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&a.bufs[p]->data[a.ch][slot][a.rank][tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __threadfence_system();
   __syncthreads();
   if (tid < a.world) {
-    __hip_atomic_store(&a.bufs[tid]->flag[slot][a.rank], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&a.bufs[tid]->flag[a.ch][slot][a.rank], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     const long long t0 = wall_clock64();            // constant 100 MHz counter
-    while (__hip_atomic_load(&mine->flag[slot][tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
-      if (wall_clock64() - t0 > 200000000LL) {      // ~2 s: a peer never arrived
+    while (__hip_atomic_load(&mine->flag[a.ch][slot][tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
+      if (wall_clock64() - t0 > a.timeout_ticks) {   // a peer never arrived
         __hip_atomic_store(&mine->err, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
@@ -69,7 +79,7 @@ __global__ void __launch_bounds__(256) allreduce_small_kernel(P2PArgs a) {
   if (tid < a.n) {
     double s = 0.0;
     for (int r = 0; r < a.world; ++r)
-      s += __hip_atomic_load(&mine->data[slot][r][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      s += __hip_atomic_load(&mine->data[a.ch][slot][r][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     a.x[tid] = s;
   }
 }
@@ -126,7 +136,8 @@ extern "C" int clsr_comm_ipc_close(void* peer) {
 extern "C" int clsr_comm_create(int rank, int world, void* const* bufs, void** comm_out) {
   CLSR_CHECK_ARG(bufs && comm_out && world >= 1 && world <= P2P_MAXW && rank >= 0 && rank < world);
   P2PComm* c = new P2PComm();
-  c->rank = rank; c->world = world; c->seq = 0;
+  c->rank = rank; c->world = world; c->nch = 0;
+  for (int i = 0; i < P2P_NCH; ++i) { c->seq[i] = 0; c->stream_of[i] = nullptr; }
   for (int r = 0; r < world; ++r) {
     if (!bufs[r]) { delete c; clsr_set_error("%s:%d: exchange buffer of rank %d missing", __FILE__, __LINE__, r); return CLSR_EINVAL; }
     c->bufs[r] = (P2PBuf*)bufs[r];
@@ -157,7 +168,18 @@ extern "C" int clsr_allreduce_small(void* comm, double* data, int n, void* strea
   P2PArgs a;
   for (int r = 0; r < P2P_MAXW; ++r) a.bufs[r] = r < c->world ? c->bufs[r] : nullptr;
   a.x = data; a.n = n; a.rank = c->rank; a.world = c->world;
-  a.seq = ++c->seq;
+  int ch = 0;
+  while (ch < c->nch && c->stream_of[ch] != stream) ++ch;
+  if (ch == c->nch) {
+    CLSR_CHECK_SUPPORTED(c->nch < P2P_NCH);      // more streams than channels
+    c->stream_of[c->nch++] = stream;
+  }
+  a.ch = ch;
+  a.seq = ++c->seq[ch];
+  // ranks of a job drift apart by whole seconds in the first steps (allocations, launch-plan recording): the wait is bounded
+  // only so that a peer that died cannot hang the device (CLSR_P2P_TIMEOUT_S, default 60)
+  static const long long ticks = (long long)(getenv("CLSR_P2P_TIMEOUT_S") ? atof(getenv("CLSR_P2P_TIMEOUT_S")) : 60.0) * 100000000LL;
+  a.timeout_ticks = ticks;
   hipLaunchKernelGGL(allreduce_small_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;

@@ -30,6 +30,8 @@ Batch-norm: ``sync_bn=True`` sums the per-feature partial statistics of every BN
 ``sync_bn=False`` ("local BN") keeps per-rank statistics (faster: no mid-step collectives, graph
 capturable) and averages the moving statistics once per step.
 """
+import os
+
 import torch
 
 from clsr_amd import ops
@@ -118,7 +120,8 @@ class DataParallel(object):
     the tail, the first of which (dense) held back the others (profiles/r03_dp_world1_timeline.txt).
     Nets without hooks (or ``overlap=False``) run the same collectives back to back after the backward pass."""
 
-    def __init__(self, net, dist, sync_bn=True, group=None, sparse_tables="auto", overlap=True, sparse_mode="allgather"):
+    def __init__(self, net, dist, sync_bn=True, group=None, sparse_tables="auto", overlap=True, sparse_mode="allgather",
+                 p2p_stats=True):
         if sparse_tables not in ("auto", "all", "none"):
             raise ValueError("sparse_tables must be 'auto', 'all' or 'none'")
         if sparse_mode not in ("allgather", "owner"):
@@ -133,6 +136,19 @@ class DataParallel(object):
         self.overlap = bool(overlap)
         net.dp_world = self.world
         net.dp_stats_hook = self._sum_stats if self.sync_bn else None
+        # sync-BN statistics through the peer-to-peer communicator (clsr_amd/p2p.py) when one can be set up: ONE kernel per
+        # all-reduce on the issuing stream instead of a torch.distributed call.  CLSR_P2P_STATS=0: always torch.distributed.
+        self.comm, self.stats_transport = None, "torch.distributed"
+        if self.sync_bn and p2p_stats and os.environ.get("CLSR_P2P_STATS", "1") != "0" and self.world <= 8 \
+                and torch.cuda.is_available() and str(net.device).startswith("cuda"):
+            try:
+                from clsr_amd import p2p
+                self.comm = p2p.from_process_group(self.rank, self.world, group)
+                net.dp_comm = self.comm.handle
+                self.stats_transport = "p2p"
+            except Exception as e:      # (no IPC between these devices / processes: the process group does it)
+                self.comm, net.dp_comm = None, None
+                self.stats_transport = "torch.distributed (p2p unavailable: %s)" % str(e)[:80]
         net.dp_hooks = self if self.overlap else None
         # sumsq_tab (16) + losses (8) travel together
         self.small = net.stats24       # the net's own 24 doubles: summed in place, no staging copies

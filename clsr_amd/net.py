@@ -109,7 +109,6 @@ class CLSRNet(object):
         self.bn_bwd_fused = not os.environ.get("CLSR_NO_BN_BWD_FUSED")   # A/B: coefficient + apply of the row-level batch-norm backward in one launch
         self.hist_grad_two = not os.environ.get("CLSR_NO_HIST_GRAD_TWO")   # A/B: dhist + dhist_lt summed inside the segmented sums
         self.tick_early = not os.environ.get("CLSR_NO_TICK_EARLY")   # A/B: Adam clock in the first launch of the update phase
-        self.lt_att_first = bool(os.environ.get("CLSR_LT_ATT_FIRST"))   # A/B: long-term attention before the causal GRU on @lt (measured: +0.03 ms fp32, +0.04 ms bf16 -- the heavy GEMMs slow the main recurrence)
         self.dw_stream = not os.environ.get("CLSR_NO_DW_STREAM")   # A/B switch (see _dw)
         self._dw_async = False
         # A/B switch (see _att_qh); the bf16 speed mode keeps the whole query in the per-(row, step) GEMM (K is cheap there)
@@ -135,10 +134,6 @@ class CLSRNet(object):
         self.lt_bwd_early = os.environ.get("CLSR_LT_BWD_EARLY", "1") == "1"
         self._dw_batch = None
         self._buf_allocs = 0
-        # the recurrences run as a CHAIN of launches over this many time ranges, so that the input projections of range
-        # k + 1 (forward) and the weight gradients / d(hist) products of range k - 1 (backward) run beside the T-serial
-        # recurrence of range k instead of before / after all of it (see _rnn_chunks_for); 1: one launch per pass.
-        # Exact mode of the CLSR graph only so far (the bf16 weight-gradient kernels have no time-range form)
         # HIP stream priorities of the side streams (0 = normal; the callers' compute stream can be created with -1 = high)
         # branch tag -> stream tag.  The @aux branches share the @lt stream: compute + @lt + @dw0 = three HIP streams, so
         # that RCCL's stream is the FOURTH under data parallelism -- a fifth active queue (or a fourth next to a
@@ -150,14 +145,10 @@ class CLSRNet(object):
         self.fuse_tt = not os.environ.get("CLSR_NO_FUSE_TT")   # A/B: time-gate blocks of the input projection as one product over [hist | TT]
         self.fused_logit_tail = not os.environ.get("CLSR_NO_FUSED_LOGIT_TAIL")   # A/B: output layer + softmax loss + their backward in one launch
         self._defer_logit_out = False
-        self.late_attmat_dw = bool(os.environ.get("CLSR_LATE_ATTMAT_DW"))   # A/B: attention_mat weight gradient behind the encoder tail
-        self._late_dw = None
-        self.sort_late = bool(os.environ.get("CLSR_SORT_LATE"))     # A/B: history-id sort beside the heads instead of at the start of the step (measured: no difference, 3.66 ms both)
         self.early_scatter = not os.environ.get("CLSR_NO_EARLY_SCATTER")   # A/B: row scatters of the user / target lookups beside the encoder-backward tail instead of behind it
         self.dhist_side = not os.environ.get("CLSR_NO_DHIST_SIDE")      # A/B (speed mode): d(hist) product on the long-term stream (2.87 -> 2.84 ms)
         self.enc_bwd_fused_h = not os.environ.get("CLSR_NO_ENC_BWD_FUSED_H")   # A/B: the speed-mode (bf16 dPin) form of the fused encoder tail
         self.enc_bwd_fused = not os.environ.get("CLSR_NO_ENC_BWD_FUSED")   # A/B: one pass over dPin for the seven encoder-side weight gradients + d(hist) (csrc/encbwd.hip)
-        self.rnn_chunks = int(os.environ.get("CLSR_RNN_CHUNKS", "1"))   # measured at configs[1]: 4.17-4.21 ms with 5 ranges, 4.11 with 3, against 3.91 with one launch (the projections throttle the chain, ~30 us start-up + ~15 us cross-stream signalling per range) -- kept as a switch
         self.l0_fwd_wave = not os.environ.get("CLSR_NO_L0_FWD_WAVE")      # A/B switch (exact mode, see _att_fwd)
         self.fused_l0_wu = not os.environ.get("CLSR_NO_FUSED_L0_WU")   # A/B: dU . Wu^T inside that kernel as well (time-neutral, two launches fewer)
         self._joins = []
@@ -179,6 +170,7 @@ class CLSRNet(object):
         self._counts_zeroed = self._ucount_zeroed = self._ticked = False
         self.dp_world = 1          # data-parallel world size (loss normalisers are global)
         self.dp_stats_hook = None  # optional callable(tensor): sum BN partial statistics across ranks
+        self.dp_comm = None        # optional communicator handle (clsr_amd/p2p.py): the same sum as ONE kernel on this stream
         # data-parallel exchange hooks (clsr_amd/dp.py): called (and recorded into launch plans) at the points of the
         # step where a piece of the gradient state becomes final, so that its collective overlaps the rest of the
         # backward pass: flags_ready() | dense_ready() | table_ready(name)
@@ -251,10 +243,10 @@ class CLSRNet(object):
     def _plan_key(self, what, f):
         hp = self.hp
         g = lambda k: getattr(hp, k, None)
-        return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook),
+        return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook), self.dp_comm,
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
-                self.lazy, self.rnn_first, self.lt_att_first, self.tick_early, self.hist_grad_two, self.dw_batch_late, self.bn_bwd_fused, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h, self.flush_side, self.l1_bwd_2pass,
-                self.split_g2, self.rnn_chunks, self.enc_bwd_fused, self.enc_bwd_fused_h, self.dhist_side, self.early_scatter, self.sort_late, self.late_attmat_dw, self.fused_logit_tail, self.fuse_tt, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
+                self.lazy, self.rnn_first, self.tick_early, self.hist_grad_two, self.dw_batch_late, self.bn_bwd_fused, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h, self.flush_side, self.l1_bwd_2pass,
+                self.split_g2, self.enc_bwd_fused, self.enc_bwd_fused_h, self.dhist_side, self.early_scatter, self.fused_logit_tail, self.fuse_tt, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
 
@@ -726,7 +718,12 @@ class CLSRNet(object):
         """Sync-BN: fold the per-block partial sums into one row of 2*C doubles and sum THAT across the ranks."""
         one = self._buf("dp.stats" + self._ws_tag, 2 * 1024, dtype=torch.float64)[: 2 * C]
         call("clsr_sum_parts_d", stats, parts, 2 * C, one)
-        ops.host_call(self.dp_stats_hook, one, ops.current_stream())
+        if self.dp_comm is not None and 2 * C <= 256:
+            # peer-to-peer sum over the mapped exchange buffers: a plain C-ABI launch on this stream (part of the launch
+            # plan like any other), no host callback, no hop into RCCL's stream
+            call("clsr_allreduce_small", self.dp_comm, one, 2 * C)
+        else:
+            ops.host_call(self.dp_stats_hook, one, ops.current_stream())
         return one, 1
 
     def _bn_bwd_from_partial(self, bn, part, parts, dy, z, M):
@@ -1294,14 +1291,7 @@ class CLSRNet(object):
             self._gemm(dU, A0, key + ".Wu^T", Hn * T, A0, Q, da, Q, acc=1)
         if not qh:
             self._gemm(dV, A0, key + ".Wv^T", R, A0, Q, dq, Q, acc=1)
-        job = lambda: self._dw(keys, Dk, da, Q, Hn * T, Dk, Q, Gd[scope + "attention_mat"], Q)
-        if self.late_attmat_dw and key == "st" and self._ws_tag == "" and self._late_dw is not None:
-            # the last weight gradient of the short-term attention: queued behind the others on the weight-gradient
-            # stream it ran underneath the latency-bound backward-through-time launch (+60-70 us there); issued behind
-            # the encoder tail instead (operands stay untouched until the next step)
-            self._late_dw.append(job)
-        else:
-            job()
+        self._dw(keys, Dk, da, Q, Hn * T, Dk, Q, Gd[scope + "attention_mat"], Q)
         self._gemm(da, Q, key + ".A^T", Hn * T, Q, Dk, dkeys, Dk, acc=1)
         return dq
 
@@ -1410,103 +1400,6 @@ class CLSRNet(object):
         self._dw(hprev, n, dP, NX, M, n, 2 * n, Gd[scope + "gates/kernel"][D:], 2 * n, dy_bf16=hb)
         self._dw(hprev, n, dP[:, 2 * n:], NX, M, n, n, Gd[scope + "candidate/kernel"][D:], n, Xmul=gates,
                  ldmul=3 * n, dy_bf16=hb)
-
-    # ------------------------------------------------------------------ recurrences as chains of time ranges
-    def _rnn_chunks_for(self, T):
-        """Time ranges [(t0, t1), ...] of the chained recurrence launches, or None for one launch per pass.
-
-        The T-serial recurrences keep ~2 waves per SIMD busy and leave the matrix pipe and HBM idle; the batched
-        products on either side of them are throughput bound.  Forward: the input projections of range k + 1 are
-        computed (weight-gradient stream) while the recurrences walk range k -- the recurrences start after a fifth of
-        the projection instead of after all of it.  Backward: the weight gradients and d(hist) of a range start as soon
-        as the backward-through-time launch of that range has written its dPin rows."""
-        n = self.rnn_chunks
-        if (n <= 1 or not self.overlap or self.bf16 or type(self) is not CLSRNet or not self.defer_dw
-                or not self.dw_stream or not self.rnn_first or T < 2 * n):
-            return None
-        return [(k * T // n, (k + 1) * T // n) for k in range(n)]
-
-    def _encoders_fwd_chunked(self, f, training, chunks, hist, ulong, ushort, Hn, T, seq_len, ls, hs, ev_in, aux):
-        """Fused input projection + recurrences + long-term attention of the forward pass with the recurrences chained
-        over ``chunks``.  Streams: projections of the ranges on @dw0 (idle in the forward pass), the main recurrences on
-        the current stream (range k waits for projection k), long-term attention and the causal GRU on @lt.
-        ``aux``: launches the feed-only side work on @aux (enqueued behind the first projection launches)."""
-        hp, P = self.hp, self.P
-        D, Du, H, NX = self.enc_in, self.Du, self.H, self.NX
-        M = Hn * T
-        st = CL + "short_term/"
-        PinAll = self._buf("xw.Pin", M, NX)
-        t4 = self._t4_scope
-        is_t4time = t4 is not None and hp.sequential_model == "time4lstm"
-        if is_t4time:
-            with self._branch("@lt", after=ev_in, name="@tt"):
-                call("clsr_t4_time_inputs_fwd", f["time_to_now"], f["time_from_first_action"], hs * T,
-                     P[t4 + "_time_input_w1"], P[t4 + "_time_input_bias1"], P[t4 + "_time_input_w2"],
-                     P[t4 + "_time_input_bias2"], Hn, T, H, self._buf("t4.TT", M, 2 * H))
-        Wx, Kpx = self.packed["xw"]
-        bias = self._buf("xw.bias", NX)
-        evs = []
-        with self._branch("@dw0", after=ev_in, name="@proj"):
-            for k, (t0, t1) in enumerate(chunks):
-                call("clsr_pgemm_range", hist, D, Wx, Kpx, bias, PinAll, NX, 0, Hn, T, t0, t1, D, NX)
-                if is_t4time:
-                    if k == 0:
-                        self._join("@tt")          # the time features (computed beside the first projection range)
-                    t4off = self._enc_off("t4")
-                    Wt, Kpt = self.packed["t4.tw"]
-                    call("clsr_pgemm_range", self._buf("t4.TT", M, 2 * H), 2 * H, Wt, Kpt, None,
-                         PinAll[:, t4off + 3 * H:], NX, 1, Hn, T, t0, t1, 2 * H, 3 * H)
-                evs.append(ops.event_record(ops.current_stream()))
-        aux()
-        # ---- descriptors: one set per range (only the carried-state pointers differ)
-        main_g, short_int, rnn_out, fs = [], ushort, None, None
-        if hp.interest_evolve:
-            main_g.append(("g1", st + "short_term_intention/gru_cell/", Du, ushort, False))
-        if t4 is None:
-            main_g.append(("gs", st + "simple_gru/gru_cell/", H, None, True))
-        n_ch = len(chunks)
-
-        def gru_descs(k):
-            out, hts, seqs = [], [], []
-            for key, scope, n, h0, want_seq in main_g:
-                d, hT, seq = self._gru_fwd_desc(key, scope, n, PinAll, Hn, T, h0 if k == 0 else self._buf(key + ".hT", Hn, n),
-                                                training, want_seq=want_seq)
-                out.append(d)
-                hts.append(hT)
-                seqs.append(seq)
-            return out, hts, seqs
-
-        t4st = self._buf("t4.state", Hn, 2 * H) if t4 is not None else None
-        if t4 is not None:
-            rnn_out = self._buf("rnn_out", Hn, T, H)
-        main = ops.current_stream()
-        for k, (t0, t1) in enumerate(chunks):
-            gd, hts, seqs = gru_descs(k)
-            t4d = None
-            if t4 is not None:
-                t4off = self._enc_off("t4")
-                t4d = ops.t4_desc(H, Pin=PinAll[:, t4off:], ldp=NX, Wm=P[t4 + "kernel"][D:], ldm=4 * H, out_seq=rnn_out,
-                                  act=self._buf("t4.act", Hn, T, 6 * H) if training else None,
-                                  cst=self._buf("t4.cst", Hn, T, H) if training else None,
-                                  mprev=self._buf("t4.mprev", Hn, T, H) if training else None,
-                                  st_in=t4st if k > 0 else None, st_out=t4st if k + 1 < n_ch else None)
-            ops.stream_wait(main, evs[k])
-            ops.rnn_multi("clsr_rnn_fwd_multi", gd, t4d, seq_len, ls, Hn, T, t_range=(t0, t1))
-        for (key, _, _, _, want_seq), hT, seq in zip(main_g, hts, seqs):
-            if key == "g1":
-                short_int = hT
-            if want_seq:
-                rnn_out = seq
-        # ---- long-term attention (needs the gathers only) and the causal GRU (needs every projection range; only the
-        #      alpha gate reads its state) on @lt
-        lt = CL + "long_term/attention_fcn/"
-        with self._branch("@lt", after=ev_in):
-            att_long = self._att_fwd("lt", lt, hist, ulong, Hn, 1, T, D, Du, seq_len, ls, training)
-            if (not hp.manual_alpha) and hp.predict_long_short:
-                d, fs, _ = self._gru_fwd_desc("g2", CL + "causal2/causal2/gru_cell/", H, PinAll, Hn, T, None, training)
-                ops.stream_wait(ops.current_stream(), evs[-1])
-                ops.rnn_multi("clsr_rnn_fwd_multi", [d], None, seq_len, ls, Hn, T)
-        return short_int, rnn_out, fs, att_long
 
     def _enc_bwd_fused_ok(self, dpin_h):
         """The default graph at the default widths: short_term_intention GRU + Time4LSTM + causal GRU, D = Du = H = 40,
@@ -1630,94 +1523,6 @@ class CLSRNet(object):
             self._gemm(dPinAll, NX, "xw^T", M, NX, D, dhist, D, acc=1)
         self._t4_time_chain_bwd(f, dPinAll, Hn, T, hs)
 
-    def _encoders_bwd_chunked(self, f, chunks, hist, dhist, drnn, dsi, dfs, Hn, T, seq_len, ls, hs):
-        """Backward-through-time as a chain of launches over ``chunks`` (descending); behind every range its weight
-        gradients (ONE multi-job launch on @dw0) and its d(hist) / time-feature products (@aux) start at once.
-        Returns d(user_short rows)."""
-        hp, P, Gd = self.hp, self.P, self.Gd
-        D, Du, H, NX, E = self.D, self.Du, self.H, self.NX, self.enc_in
-        M = Hn * T
-        st = CL + "short_term/"
-        t4 = self._t4_scope
-        is_t4time = self._t4_kind == "time4lstm"
-        dPinAll = self._buf("xw.dPin", M, NX)
-        n_ch = len(chunks)
-        tcmax = max(t1 - t0 for t0, t1 in chunks)
-        pgx = query("clsr_pgemm_dw_parts", Hn * tcmax)
-        # ---- recurrences: (key, scope, n, true dhT, dout_seq, true dh0)
-        grus = []
-        dushort = dsi
-        if hp.interest_evolve:
-            dushort = self._buf("d_u_short", Hn, Du)
-            grus.append(("g1", st + "short_term_intention/gru_cell/", Du, dsi, None, dushort))
-        if t4 is None:
-            grus.append(("gs", st + "simple_gru/gru_cell/", H, None, drnn, None))
-        if (not hp.manual_alpha) and hp.predict_long_short:
-            grus.append(("g2", CL + "causal2/causal2/gru_cell/", H, dfs, None, None))
-        # ---- weight-gradient products that read dPin: (X, ldx, Xmul, ldmul, dY, ldy, K, N, dW, ldw, db)
-        prods = [(hist, D, None, 0, dPinAll, NX, D, NX, self._buf("xw.dW", D, NX), NX, self._buf("xw.db", NX))]
-        if t4 is not None:
-            dPt = dPinAll[:, self._enc_off("t4"):]
-            prods.append((self._buf("t4.mprev", Hn, T, H), H, None, 0, dPt, NX, H, 4 * H, Gd[t4 + "kernel"][E:], 4 * H, None))
-            if is_t4time:
-                prods.append((self._buf("t4.TT", M, 2 * H), 2 * H, None, 0, dPt[:, 3 * H:], NX, 2 * H, 3 * H,
-                              self._buf("t4.dTW", 2 * H, 3 * H), 3 * H, None))
-        for key, scope, n, _, _, _ in grus:
-            hprev, gates = self._buf(key + ".hprev", Hn, T, n), self._buf(key + ".gates", Hn, T, 3 * n)
-            dP = dPinAll[:, self._enc_off(key):]
-            prods.append((hprev, n, None, 0, dP, NX, n, 2 * n, Gd[scope + "gates/kernel"][E:], 2 * n, None))
-            prods.append((hprev, n, gates, 3 * n, dP[:, 2 * n:], NX, n, n, Gd[scope + "candidate/kernel"][E:], n, None))
-        ptr = lambda t: 0 if t is None else t.data_ptr()
-        pend = self._dw_pending.setdefault("", [])
-        wss = []
-        for i, (X, ldx, Xm, ldm, dY, ldy, K, N, dW, ldw, db) in enumerate(prods):
-            need = n_ch * query("clsr_pgemm_dw_workspace_floats", Hn * tcmax, K, N)
-            ws = self._buf("dw_wsr.%d" % i, max(need, 1))
-            wss.append(ws)
-            pend.append((ws.data_ptr(), dW.data_ptr(), ptr(db), 1.0, n_ch * pgx, K, N, ldw, 0))
-        # ---- time-feature gradients: partial rows of all ranges side by side
-        if is_t4time:
-            tparts = [query("clsr_t4_time_inputs_bwd_parts", Hn, t1 - t0, H) for t0, t1 in chunks]
-            tp = self._buf("t4.tpart_r", sum(tparts) * 4 * H)
-            dTT = self._buf("t4.dTT", M, 2 * H)
-            TT = self._buf("t4.TT", M, 2 * H)
-        carry = {key: self._buf(key + ".dh_carry", Hn, n) for key, _, n, _, _, _ in grus}
-        t4c = self._buf("t4.dstate", Hn, 2 * H) if t4 is not None else None
-        Wxt, Kpxt = self.packed["xw^T"]
-        for idx, k in enumerate(reversed(range(n_ch))):
-            t0, t1 = chunks[k]
-            first, last = idx == 0, k == 0
-            gd = []
-            for key, scope, n, dhT, dseq, dh0 in grus:
-                gd.append(self._gru_bwd_desc(key, scope, n, dPinAll, Hn, T, dhT if first else carry[key], dseq,
-                                             dh0 if last else carry[key]))
-            t4d = None
-            if t4 is not None:
-                t4d = ops.t4_desc(H, Wm=P[t4 + "kernel"][D:], ldm=4 * H, act=self._buf("t4.act", Hn, T, 6 * H),
-                                  cst=self._buf("t4.cst", Hn, T, H), dout_seq=drnn, dPin=dPinAll[:, self._enc_off("t4"):],
-                                  lddp=NX, dst_in=None if first else t4c, dst_out=None if last else t4c)
-            ops.rnn_multi("clsr_rnn_bwd_multi", gd, t4d, seq_len, ls, Hn, T, t_range=(t0, t1))
-            ev = self._fork_point()
-            tc = t1 - t0
-            jobs = [(ptr(X), ptr(Xm), 0, 0, ptr(dY), ws.data_ptr(), 0, ldx, 0, 0, ldm, 1, 0, ldy, Hn * tc, K, N, 0,
-                     tc, T, t0, pgx, n_ch * pgx, k * pgx)
-                    for (X, ldx, Xm, ldm, dY, ldy, K, N, dW, ldw, db), ws in zip(prods, wss)]
-            with self._branch("@dw0", after=ev, name="@dwr"):
-                ops.dw_multi("clsr_pgemm_dw_partial_multi", jobs)
-            with self._branch("@aux", after=ev, name="@dhr"):
-                call("clsr_pgemm_range", dPinAll, NX, Wxt, Kpxt, None, dhist, D, 1, Hn, T, t0, t1, NX, D)
-                if is_t4time:
-                    Wt, Kpt = self.packed["t4.tw^T"]
-                    call("clsr_pgemm_range", dPt[:, 3 * H:], NX, Wt, Kpt, None, dTT, 2 * H, 0, Hn, T, t0, t1, 3 * H, 2 * H)
-                    call("clsr_t4_time_inputs_bwd_range", dTT, TT, f["time_to_now"], f["time_from_first_action"], hs * T,
-                         Hn, T, t0, t1, H, tp[sum(tparts[:k]) * 4 * H:])
-        self._dw_async = True      # the batched reduction joins the weight-gradient stream
-        if is_t4time:
-            for off_, nm in ((0, "_time_input_w1"), (H, "_time_input_w2"), (2 * H, "_time_input_bias1"),
-                             (3 * H, "_time_input_bias2")):
-                self._rp(tp[off_:], sum(tparts), 4 * H, H, Gd[t4 + nm])
-        return dushort
-
     # ------------------------------------------------------------------ forward
     def forward(self, f, training, after_attention=None, early_aux=None):
         """Run the forward pass on an uploaded feed; returns dict of device tensors.  ``after_attention(out)``
@@ -1759,104 +1564,89 @@ class CLSRNet(object):
         st = CL + "short_term/"
         M = Hn * T
         NX = self.NX
-        chunks = self._rnn_chunks_for(T)
-        if chunks is not None:
-            # recurrences as a chain of launches over time ranges, the projection of range k + 1 beside range k
-            def aux_work():
-                if early_aux is not None or (training and self.sorted_hist_grad):
-                    with self._branch("@aux", after=step_start):
-                        if early_aux is not None:
-                            early_aux()
-                        if training and self.sorted_hist_grad:
-                            self._sort_hist_ids(f, Hn, T, hs)
-            short_int, rnn_out, fs, att_long = self._encoders_fwd_chunked(
-                f, training, chunks, hist, ulong, ushort, Hn, T, seq_len, ls, hs, self._fork_point(), aux_work)
+        PinAll = self._buf("xw.Pin", M, NX)
+        if self._t4_scope is not None and hp.sequential_model == "time4lstm":
+            # tanh time features of the Time4LSTM gates depend on the feed only: on the (still idle) @lt stream
+            # beside the input projection instead of after it
+            t = self._t4_scope
+            fuse_tt = self._fuse_tt_ok()
+            Dp = 16 * ((D + 15) // 16)
+            XT = self._buf("t4.XT", M, Dp + 2 * H) if fuse_tt else None
+            TTb = self._buf("t4.TT", M, 2 * H)
+            with self._branch("@lt"):
+                call("clsr_t4_time_inputs_fwd2", f["time_to_now"], f["time_from_first_action"], hs * T,
+                     P[t + "_time_input_w1"], P[t + "_time_input_bias1"], P[t + "_time_input_w2"],
+                     P[t + "_time_input_bias2"], Hn, T, H, TTb, hist if fuse_tt else None, D if fuse_tt else 0, XT,
+                     Dp + 2 * H if fuse_tt else 0, Dp if fuse_tt else 0)
         else:
-            PinAll = self._buf("xw.Pin", M, NX)
-            if self._t4_scope is not None and hp.sequential_model == "time4lstm":
-                # tanh time features of the Time4LSTM gates depend on the feed only: on the (still idle) @lt stream
-                # beside the input projection instead of after it
-                t = self._t4_scope
-                fuse_tt = self._fuse_tt_ok()
-                Dp = 16 * ((D + 15) // 16)
-                XT = self._buf("t4.XT", M, Dp + 2 * H) if fuse_tt else None
-                TTb = self._buf("t4.TT", M, 2 * H)
-                with self._branch("@lt"):
-                    call("clsr_t4_time_inputs_fwd2", f["time_to_now"], f["time_from_first_action"], hs * T,
-                         P[t + "_time_input_w1"], P[t + "_time_input_bias1"], P[t + "_time_input_w2"],
-                         P[t + "_time_input_bias2"], Hn, T, H, TTb, hist if fuse_tt else None, D if fuse_tt else 0, XT,
-                         Dp + 2 * H if fuse_tt else 0, Dp if fuse_tt else 0)
-            else:
-                fuse_tt = False
-            # (with the K-fused time-gate product the first launch stops in front of those 3H columns)
-            self._gemm(hist, D, "xw", M, D, NX - 3 * H if fuse_tt else NX, PinAll, NX, bias=self._buf("xw.bias", NX))
-            if early_aux is not None or (training and self.sorted_hist_grad):
-                # work that depends on the feed only -- accumulator zeroing / row marks of the training step
-                # (``early_aux``) and the ~35 tiny launches that sort the history ids by row id for the backward's
-                # segmented sums -- on the @aux stream (NOT a stream of its own: see _dw, four streams in all), ordered
-                # after the START of the step but ENQUEUED here, behind the first big main-stream launches: when the
-                # host is the slower side (tracer, fit loop sharing the GIL with the iterator thread) the device
-                # executes in enqueue order and must not find 40 tiny launches ahead of the main chain
-                with self._branch("@aux", after=step_start):
-                    if early_aux is not None:
-                        early_aux()
-                    if training and self.sorted_hist_grad and not self.sort_late:
-                        self._sort_hist_ids(f, Hn, T, hs)
-            grus, t4d = [], None
-            short_int, rnn_out, fs = ushort, None, None
-            if hp.interest_evolve:
-                d, short_int, _ = self._gru_fwd_desc("g1", st + "short_term_intention/gru_cell/", Du, PinAll, Hn, T,
-                                                     ushort, training)
-                grus.append(d)
-            if self._t4_scope is not None:
-                t = self._t4_scope
-                t4off = self._enc_off("t4")
-                if hp.sequential_model == "time4lstm":
-                    TT = self._buf("t4.TT", M, 2 * H)
-                    self._join("@lt")     # the time features were computed beside the fused input projection
-                    if fuse_tt:
-                        # ONE product over [hist | TT] (K = 48 + 80) writes the time-gate columns: the separate pass that
-                        # re-read and re-wrote them (hist . W_x first, += TT . W_t behind it: 112 us alone) is gone
-                        self._gemm(XT, Dp + 2 * H, "xw.t", M, Dp + 2 * H, 3 * H, PinAll[:, t4off + 3 * H:], NX,
-                                   bias=self._buf("xw.bias", NX)[t4off + 3 * H:])
-                    else:
-                        self._gemm(TT, 2 * H, "t4.tw", M, 2 * H, 3 * H, PinAll[:, t4off + 3 * H:], NX, acc=1)
-                rnn_out = self._buf("rnn_out", Hn, T, H)
-                t4d = ops.t4_desc(H, Pin=PinAll[:, t4off:], ldp=NX, Wm=P[t + "kernel"][D:], ldm=4 * H, out_seq=rnn_out,
-                                  act=self._buf("t4.act", Hn, T, 6 * H) if training else None,
-                                  cst=self._buf("t4.cst", Hn, T, H) if training else None,
-                                  mprev=self._buf("t4.mprev", Hn, T, H) if training else None)
-            else:
-                d, _, rnn_out = self._gru_fwd_desc("gs", st + "simple_gru/gru_cell/", H, PinAll, Hn, T, None, training,
-                                                   want_seq=True)
-                grus.append(d)
-            g2_side = None
-            if (not hp.manual_alpha) and hp.predict_long_short:
-                d, fs, _ = self._gru_fwd_desc("g2", CL + "causal2/causal2/gru_cell/", H, PinAll, Hn, T, None, training)
-                if (self.split_g2 and self.overlap and (grus or self._t4_scope is not None)
-                        and not (H == Du and query("clsr_rnn_one_wave", H))):
-                    # only the alpha gate needs this state: off the critical recurrence launch -- unless the launch
-                    # gives every encoder a SIMD of its own (csrc/rnn1.hip): then it costs the others nothing
-                    g2_side = d
+            fuse_tt = False
+        # (with the K-fused time-gate product the first launch stops in front of those 3H columns)
+        self._gemm(hist, D, "xw", M, D, NX - 3 * H if fuse_tt else NX, PinAll, NX, bias=self._buf("xw.bias", NX))
+        if early_aux is not None or (training and self.sorted_hist_grad):
+            # work that depends on the feed only -- accumulator zeroing / row marks of the training step
+            # (``early_aux``) and the ~35 tiny launches that sort the history ids by row id for the backward's
+            # segmented sums -- on the @aux stream (NOT a stream of its own: see _dw, four streams in all), ordered
+            # after the START of the step but ENQUEUED here, behind the first big main-stream launches: when the
+            # host is the slower side (tracer, fit loop sharing the GIL with the iterator thread) the device
+            # executes in enqueue order and must not find 40 tiny launches ahead of the main chain
+            with self._branch("@aux", after=step_start):
+                if early_aux is not None:
+                    early_aux()
+                if training and self.sorted_hist_grad:
+                    self._sort_hist_ids(f, Hn, T, hs)
+        grus, t4d = [], None
+        short_int, rnn_out, fs = ushort, None, None
+        if hp.interest_evolve:
+            d, short_int, _ = self._gru_fwd_desc("g1", st + "short_term_intention/gru_cell/", Du, PinAll, Hn, T,
+                                                 ushort, training)
+            grus.append(d)
+        if self._t4_scope is not None:
+            t = self._t4_scope
+            t4off = self._enc_off("t4")
+            if hp.sequential_model == "time4lstm":
+                TT = self._buf("t4.TT", M, 2 * H)
+                self._join("@lt")     # the time features were computed beside the fused input projection
+                if fuse_tt:
+                    # ONE product over [hist | TT] (K = 48 + 80) writes the time-gate columns: the separate pass that
+                    # re-read and re-wrote them (hist . W_x first, += TT . W_t behind it: 112 us alone) is gone
+                    self._gemm(XT, Dp + 2 * H, "xw.t", M, Dp + 2 * H, 3 * H, PinAll[:, t4off + 3 * H:], NX,
+                               bias=self._buf("xw.bias", NX)[t4off + 3 * H:])
                 else:
-                    grus.append(d)
-            # ---- long term attention (independent of the encoders and of the short-term attention) on the side
-            #      stream, forked HERE: the T-serial recurrences occupy only ~3 waves per CU, so the long-term chain
-            #      runs underneath them instead of beside the big GEMMs.  The recurrence is ENQUEUED FIRST: packets
-            #      reach the device in launch order, and with the branch's ~10 launches ahead of it the recurrence
-            #      started ~350 us late (profiles/r01_step_timeline_graph_before_after.txt)
-            lt = CL + "long_term/attention_fcn/"
-            fork = self._fork_point()
-            if self.rnn_first:
-                ops.rnn_multi("clsr_rnn_fwd_multi", grus, t4d, seq_len, ls, Hn, T)
-            with self._branch("@lt", after=fork):
-                if g2_side is not None and not self.lt_att_first:
-                    ops.rnn_multi("clsr_rnn_fwd_multi", [g2_side], None, seq_len, ls, Hn, T)
-                att_long = self._att_fwd("lt", lt, hist, ulong, Hn, 1, T, D, Du, seq_len, ls, training)
-                if g2_side is not None and self.lt_att_first:
-                    ops.rnn_multi("clsr_rnn_fwd_multi", [g2_side], None, seq_len, ls, Hn, T)
-            if not self.rnn_first:
-                ops.rnn_multi("clsr_rnn_fwd_multi", grus, t4d, seq_len, ls, Hn, T)
+                    self._gemm(TT, 2 * H, "t4.tw", M, 2 * H, 3 * H, PinAll[:, t4off + 3 * H:], NX, acc=1)
+            rnn_out = self._buf("rnn_out", Hn, T, H)
+            t4d = ops.t4_desc(H, Pin=PinAll[:, t4off:], ldp=NX, Wm=P[t + "kernel"][D:], ldm=4 * H, out_seq=rnn_out,
+                              act=self._buf("t4.act", Hn, T, 6 * H) if training else None,
+                              cst=self._buf("t4.cst", Hn, T, H) if training else None,
+                              mprev=self._buf("t4.mprev", Hn, T, H) if training else None)
+        else:
+            d, _, rnn_out = self._gru_fwd_desc("gs", st + "simple_gru/gru_cell/", H, PinAll, Hn, T, None, training,
+                                               want_seq=True)
+            grus.append(d)
+        g2_side = None
+        if (not hp.manual_alpha) and hp.predict_long_short:
+            d, fs, _ = self._gru_fwd_desc("g2", CL + "causal2/causal2/gru_cell/", H, PinAll, Hn, T, None, training)
+            if (self.split_g2 and self.overlap and (grus or self._t4_scope is not None)
+                    and not (H == Du and query("clsr_rnn_one_wave", H))):
+                # only the alpha gate needs this state: off the critical recurrence launch -- unless the launch
+                # gives every encoder a SIMD of its own (csrc/rnn1.hip): then it costs the others nothing
+                g2_side = d
+            else:
+                grus.append(d)
+        # ---- long term attention (independent of the encoders and of the short-term attention) on the side
+        #      stream, forked HERE: the T-serial recurrences occupy only ~3 waves per CU, so the long-term chain
+        #      runs underneath them instead of beside the big GEMMs.  The recurrence is ENQUEUED FIRST: packets
+        #      reach the device in launch order, and with the branch's ~10 launches ahead of it the recurrence
+        #      started ~350 us late (profiles/r01_step_timeline_graph_before_after.txt)
+        lt = CL + "long_term/attention_fcn/"
+        fork = self._fork_point()
+        if self.rnn_first:
+            ops.rnn_multi("clsr_rnn_fwd_multi", grus, t4d, seq_len, ls, Hn, T)
+        with self._branch("@lt", after=fork):
+            if g2_side is not None:
+                ops.rnn_multi("clsr_rnn_fwd_multi", [g2_side], None, seq_len, ls, Hn, T)
+            att_long = self._att_fwd("lt", lt, hist, ulong, Hn, 1, T, D, Du, seq_len, ls, training)
+        if not self.rnn_first:
+            ops.rnn_multi("clsr_rnn_fwd_multi", grus, t4d, seq_len, ls, Hn, T)
         # ---- short term attention: query = [short_term_intention | target]
         Qs = Du + D
         q = self._buf("st.q", B, Qs)
@@ -1869,12 +1659,6 @@ class CLSRNet(object):
             with self._branch("@aux"):
                 after_attention(dict(att_fea_long=att_long, att_fea_short=att_short, hist_mean=hmean,
                                      hist_recent=hrec))
-                if training and self.sorted_hist_grad and self.sort_late and chunks is None:
-                    # the ~35 tiny launches that sort the history ids for the backward's segmented sums need the feed
-                    # only and are read at the very end of the step: they run HERE, beside the row-level heads (~30
-                    # dependent 160-block launches, the device is idle), instead of beside the input projections at the
-                    # start of the step (opt-in, CLSR_SORT_LATE: the step time did not move)
-                    self._sort_hist_ids(f, Hn, T, hs)
         alpha = self._buf("alpha", B)
         mo = self._buf("model_output", B, 2 * D)
         if not hp.manual_alpha:
@@ -1912,7 +1696,6 @@ class CLSRNet(object):
         D, Du, H, Di, Dc = self.D, self.Du, self.H, self.Di, self.Dc
         hs = 1 if f.get("compact") else G
         seq_len, ls = f["seq_len"], hs
-        self._late_dw = [] if self.late_attmat_dw else None
         # gradient accumulators (zeroed every step) and the involved-row flags depend on the feed only: zeroed /
         # marked on a side stream underneath the forward's first kernels
         zpool = self._buf("zero_pool", Hn * T * (2 * D + H) + B * D * 2 + Hn * (3 * D + H + Du))
@@ -2020,81 +1803,69 @@ class CLSRNet(object):
         M = Hn * T
         NX = self.NX
         hist = out["hist_input"]
-        chunks = self._rnn_chunks_for(T)
         scat_early = False
-        if chunks is not None:
-            if dul is None:
-                with self._branch("@lt", after=self._fork_point()):
-                    dul = self._att_bwd("lt", CL + "long_term/attention_fcn/", dL, out["hist_input"], out["u_long"],
-                                        dhist_lt, Hn, 1, T, D, Du, seq_len, ls)
-                    self._dw_flush()
-            dushort = self._encoders_bwd_chunked(f, chunks, hist, dhist, drnn, dsi, dfs, Hn, T, seq_len, ls, hs)
+        # speed mode: the gradients of the input projections leave the backward-through-time kernel as bf16 -- their
+        # consumers (input-side / hidden-side weight gradients, d(hist) = dPin . W^T) run on the bf16 matrix pipe anyway
+        dpin_h = (self.dpin_h and "xw^T" in self.packed_h and H % 8 == 0 and Du % 8 == 0 and D % 8 == 0
+                  and (self._t4_kind != "time4lstm" or "t4.tw^T" in self.packed_h))
+        dPinAll = self._buf("xw.dPin", M, NX, dtype=torch.bfloat16 if dpin_h else F32)
+        grus, t4d = [], None
+        dushort = dsi
+        if hp.interest_evolve:
+            dushort = self._buf("d_u_short", Hn, Du)
+            grus.append(self._gru_bwd_desc("g1", st + "short_term_intention/gru_cell/", Du, dPinAll, Hn, T, dsi, None,
+                                           dushort))
+        if self._t4_scope is not None:
+            t = self._t4_scope
+            t4off = self._enc_off("t4")
+            t4d = ops.t4_desc(H, Wm=P[t + "kernel"][D:], ldm=4 * H, act=self._buf("t4.act", Hn, T, 6 * H),
+                              cst=self._buf("t4.cst", Hn, T, H), dout_seq=drnn, dPin=dPinAll[:, t4off:], lddp=NX)
         else:
-            # speed mode: the gradients of the input projections leave the backward-through-time kernel as bf16 -- their
-            # consumers (input-side / hidden-side weight gradients, d(hist) = dPin . W^T) run on the bf16 matrix pipe anyway
-            dpin_h = (self.dpin_h and "xw^T" in self.packed_h and H % 8 == 0 and Du % 8 == 0 and D % 8 == 0
-                      and (self._t4_kind != "time4lstm" or "t4.tw^T" in self.packed_h))
-            dPinAll = self._buf("xw.dPin", M, NX, dtype=torch.bfloat16 if dpin_h else F32)
-            grus, t4d = [], None
-            dushort = dsi
-            if hp.interest_evolve:
-                dushort = self._buf("d_u_short", Hn, Du)
-                grus.append(self._gru_bwd_desc("g1", st + "short_term_intention/gru_cell/", Du, dPinAll, Hn, T, dsi, None,
-                                               dushort))
-            if self._t4_scope is not None:
-                t = self._t4_scope
-                t4off = self._enc_off("t4")
-                t4d = ops.t4_desc(H, Wm=P[t + "kernel"][D:], ldm=4 * H, act=self._buf("t4.act", Hn, T, 6 * H),
-                                  cst=self._buf("t4.cst", Hn, T, H), dout_seq=drnn, dPin=dPinAll[:, t4off:], lddp=NX)
-            else:
-                grus.append(self._gru_bwd_desc("gs", st + "simple_gru/gru_cell/", H, dPinAll, Hn, T, None, drnn, None))
-            if (not hp.manual_alpha) and hp.predict_long_short:
-                grus.append(self._gru_bwd_desc("g2", CL + "causal2/causal2/gru_cell/", H, dPinAll, Hn, T, dfs, None, None))
-            # ---- long-term attention backward (dL has been final since the alpha gate): forked here so that it runs
-            #      on the side stream underneath the T-serial backward-through-time (own scratch + own d(hist))
-            fork = self._fork_point()
-            if self.rnn_first:
-                ops.rnn_multi("clsr_rnn_bwd_multi", grus, t4d, seq_len, ls, Hn, T)
-            if dul is None:
-                with self._branch("@lt", after=fork):
-                    dul = self._att_bwd("lt", CL + "long_term/attention_fcn/", dL, out["hist_input"], out["u_long"],
-                                        dhist_lt, Hn, 1, T, D, Du, seq_len, ls)
-                    self._dw_flush()
-            if not self.rnn_first:
-                ops.rnn_multi("clsr_rnn_bwd_multi", grus, t4d, seq_len, ls, Hn, T)
-            # the row scatters of the user / target-item / target-category lookups need nothing from the encoder tail
-            # below: they go to the side streams early instead of queueing behind it -- long-term user rows and target
-            # rows UNDER the backward-through-time launch (latency bound, leaves issue slots; beside the MFMA-saturated
-            # fused tail they ran 4x slower and the history-row sums waited for them), the short-term user rows (final
-            # only now) beside the small d TT product
-            scat_early = self.early_scatter and self.sorted_hist_grad and self.split_emb_grad and self.overlap
-            if scat_early:
-                self._scatter_rows_early(f, dul, None, dtarget, Hn, B, hs, fork)
-                self._scatter_rows_early(f, None, dushort, None, Hn, B, hs, self._fork_point())
-            if self._enc_bwd_fused_ok(dpin_h):
-                (self._enc_bwd_fused_h if self.bf16 else self._enc_bwd_fused_x3 if self.x3_enc else
-                 self._enc_bwd_fused)(f, hist, dPinAll, dhist, Hn, T, hs)
-            else:
-              # input-side weights of every encoder in one reduction; d(hist) in one product; the hidden-side / time-feature
-              # weight gradients ride in the same multi-job launch as the input-side one (they all depend on dPin only)
-              with self._dw_batched():
-                  self._dw(hist, D, dPinAll, NX, M, D, NX, self._buf("xw.dW", D, NX), NX, db=self._buf("xw.db", NX),
-                           dy_bf16=int(dpin_h))
-                  self._gemm(dPinAll, NX, "xw^T", M, NX, D, dhist, D, acc=1)
-                  if self._t4_kind is not None:
-                      self._t4_bwd_weights(f, dPinAll, Hn, T, hs)
-                  else:
-                      self._gru_bwd_hidden("gs", st + "simple_gru/gru_cell/", H, dPinAll, Hn, T)
-                  if hp.interest_evolve:
-                      self._gru_bwd_hidden("g1", st + "short_term_intention/gru_cell/", Du, dPinAll, Hn, T)
-                  if (not hp.manual_alpha) and hp.predict_long_short:
-                      self._gru_bwd_hidden("g2", CL + "causal2/causal2/gru_cell/", H, dPinAll, Hn, T)
+            grus.append(self._gru_bwd_desc("gs", st + "simple_gru/gru_cell/", H, dPinAll, Hn, T, None, drnn, None))
+        if (not hp.manual_alpha) and hp.predict_long_short:
+            grus.append(self._gru_bwd_desc("g2", CL + "causal2/causal2/gru_cell/", H, dPinAll, Hn, T, dfs, None, None))
+        # ---- long-term attention backward (dL has been final since the alpha gate): forked here so that it runs
+        #      on the side stream underneath the T-serial backward-through-time (own scratch + own d(hist))
+        fork = self._fork_point()
+        if self.rnn_first:
+            ops.rnn_multi("clsr_rnn_bwd_multi", grus, t4d, seq_len, ls, Hn, T)
+        if dul is None:
+            with self._branch("@lt", after=fork):
+                dul = self._att_bwd("lt", CL + "long_term/attention_fcn/", dL, out["hist_input"], out["u_long"],
+                                    dhist_lt, Hn, 1, T, D, Du, seq_len, ls)
+                self._dw_flush()
+        if not self.rnn_first:
+            ops.rnn_multi("clsr_rnn_bwd_multi", grus, t4d, seq_len, ls, Hn, T)
+        # the row scatters of the user / target-item / target-category lookups need nothing from the encoder tail
+        # below: they go to the side streams early instead of queueing behind it -- long-term user rows and target
+        # rows UNDER the backward-through-time launch (latency bound, leaves issue slots; beside the MFMA-saturated
+        # fused tail they ran 4x slower and the history-row sums waited for them), the short-term user rows (final
+        # only now) beside the small d TT product
+        scat_early = self.early_scatter and self.sorted_hist_grad and self.split_emb_grad and self.overlap
+        if scat_early:
+            self._scatter_rows_early(f, dul, None, dtarget, Hn, B, hs, fork)
+            self._scatter_rows_early(f, None, dushort, None, Hn, B, hs, self._fork_point())
+        if self._enc_bwd_fused_ok(dpin_h):
+            (self._enc_bwd_fused_h if self.bf16 else self._enc_bwd_fused_x3 if self.x3_enc else
+             self._enc_bwd_fused)(f, hist, dPinAll, dhist, Hn, T, hs)
+        else:
+          # input-side weights of every encoder in one reduction; d(hist) in one product; the hidden-side / time-feature
+          # weight gradients ride in the same multi-job launch as the input-side one (they all depend on dPin only)
+          with self._dw_batched():
+              self._dw(hist, D, dPinAll, NX, M, D, NX, self._buf("xw.dW", D, NX), NX, db=self._buf("xw.db", NX),
+                       dy_bf16=int(dpin_h))
+              self._gemm(dPinAll, NX, "xw^T", M, NX, D, dhist, D, acc=1)
+              if self._t4_kind is not None:
+                  self._t4_bwd_weights(f, dPinAll, Hn, T, hs)
+              else:
+                  self._gru_bwd_hidden("gs", st + "simple_gru/gru_cell/", H, dPinAll, Hn, T)
+              if hp.interest_evolve:
+                  self._gru_bwd_hidden("g1", st + "short_term_intention/gru_cell/", Du, dPinAll, Hn, T)
+              if (not hp.manual_alpha) and hp.predict_long_short:
+                  self._gru_bwd_hidden("g2", CL + "causal2/causal2/gru_cell/", H, dPinAll, Hn, T)
         # ---- join the long-term attention branch; its d(hist) contribution was accumulated separately (NOT the early row
         #      scatters: nothing reads their tables before the update phase -- every wait is a barrier packet in front of
         #      the history-row sums)
-        late, self._late_dw = self._late_dw, None
-        for job in late or ():
-            job()
         side_dense = self.flush_side and self.overlap and self.dw_stream
         # (deterministic segmented sums update a row with a plain read-modify-write: the target / user row sums of the
         #  same tables -- the @scat branches -- must have finished, which they have long since: the wait costs a packet)

@@ -1,0 +1,80 @@
+"""Small-message all-reduce communicator over peer-mapped exchange buffers (csrc/p2p.hip).
+
+The synchronised batch-norm statistics of the data-parallel step (reference batch-norm:
+models/base_model.py:673-679) are 16 all-reduces of <= 2 KB per step, each needed by the very next launch of a
+dependent chain.  ``SmallComm`` sums them with ONE single-workgroup kernel on the issuing stream instead of a
+``torch.distributed`` call (host call + two stream hops into RCCL's stream, ~20 us each).  The communicator is created
+once: every rank allocates a fine-grained exchange buffer, the hipIpc handles travel through the process group
+(``all_gather_object``), every rank maps its peers' buffers.  Works between the GPUs of one node (xGMI peer access) and
+between processes that share one GPU (the test box)."""
+import ctypes
+
+import torch
+
+from clsr_amd import _lib, ops
+
+
+class SmallComm(object):
+    def __init__(self, rank, world, gather_objects):
+        """``gather_objects(obj) -> list of every rank's obj`` (torch.distributed.all_gather_object or equivalent)."""
+        lib = _lib.load()
+        self.rank, self.world = int(rank), int(world)
+        if self.world > lib.clsr_comm_max_world():
+            raise ValueError("SmallComm: at most %d ranks (one node)" % lib.clsr_comm_max_world())
+        self.max_doubles = lib.clsr_comm_max_doubles()
+        buf = ctypes.c_void_p()
+        _lib.check(lib.clsr_comm_alloc(ctypes.byref(buf)), "clsr_comm_alloc")
+        self._own = buf
+        nb = lib.clsr_comm_ipc_handle_bytes()
+        h = ctypes.create_string_buffer(nb)
+        _lib.check(lib.clsr_comm_ipc_handle(buf, h), "clsr_comm_ipc_handle")
+        handles = gather_objects(bytes(h.raw))
+        self._peers = []
+        ptrs = (ctypes.c_void_p * self.world)()
+        for r in range(self.world):
+            if r == self.rank:
+                ptrs[r] = buf
+                continue
+            p = ctypes.c_void_p()
+            hb = ctypes.create_string_buffer(handles[r], nb)
+            _lib.check(lib.clsr_comm_ipc_open(hb, ctypes.byref(p)), "clsr_comm_ipc_open (rank %d)" % r)
+            self._peers.append(p)
+            ptrs[r] = p
+        comm = ctypes.c_void_p()
+        _lib.check(lib.clsr_comm_create(self.rank, self.world, ptrs, ctypes.byref(comm)), "clsr_comm_create")
+        self.handle = comm.value          # (an integer address: what ops.call passes for a void*)
+        gather_objects(b"ready")          # nobody pushes before every rank has mapped every buffer
+
+    def all_reduce(self, t, n=None):
+        """in-place sum of the first ``n`` doubles of ``t`` over the ranks, asynchronous on the current stream"""
+        n = t.numel() if n is None else int(n)
+        assert t.dtype == torch.float64 and n <= self.max_doubles
+        ops.call("clsr_allreduce_small", self.handle, t, n)
+
+    def error(self):
+        """sequence number of the last all-reduce that gave up waiting for a peer (0: none); synchronises the device"""
+        return int(_lib.load().clsr_comm_error(ctypes.c_void_p(self.handle)))
+
+    def close(self):
+        lib = _lib.load()
+        if getattr(self, "handle", None):
+            lib.clsr_comm_destroy(ctypes.c_void_p(self.handle))
+            self.handle = None
+        for p in getattr(self, "_peers", []):
+            lib.clsr_comm_ipc_close(p)
+        self._peers = []
+        if getattr(self, "_own", None):
+            lib.clsr_comm_free(self._own)
+            self._own = None
+
+
+def from_process_group(rank, world, group=None):
+    """SmallComm whose handles travel through torch.distributed (any backend with all_gather_object)."""
+    import torch.distributed as dist
+
+    def gather(obj):
+        out = [None] * world
+        dist.all_gather_object(out, obj, group=group)
+        return out
+
+    return SmallComm(rank, world, gather)

@@ -1,7 +1,12 @@
 import os
 import sys
 
+
 import pytest
+
+# (a peer-to-peer all-reduce whose peer never arrives gives up after this many seconds instead of the default minute:
+#  a broken test must not sit on the GPU box; inherited by the spawned rank processes)
+os.environ.setdefault("CLSR_P2P_TIMEOUT_S", "10")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -144,8 +144,8 @@ def test_lazy_adam_rows_on_a_bf16_table(V, C, nrows):
     d_ulp = (th.view(torch.int16).int() - tf.to(BF).view(torch.int16).int()).abs()
     assert int(d_ulp.max()) <= 1 and float((d_ulp > 0).float().mean()) < 1e-3, \
         "bf16 rows = the fp32 update of the widened rows, rounded to nearest-even"
-    _close(mh, mf, 1e-6, 1e-12, "first moments")
-    _close(vh, vf, 1e-6, 1e-15, "second moments")
+    _close(mh, mf, 1e-6, 2e-9, "first moments")
+    _close(vh, vf, 1e-6, 1e-12, "second moments")
     assert torch.equal(gh, gf) and torch.equal(fh, ff)
     assert float(gh.abs().max()) == 0.0 and int(fh.sum()) == 0
     untouched = torch.ones(V, dtype=torch.bool, device=DEV)

@@ -1238,6 +1238,8 @@ def test_recurrences_as_a_chain_of_time_ranges_equal_one_launch(Hn, T, n, nch, o
     dst_in / dst_out) == ONE launch over [0, T): every output bit for bit (same instruction sequence per step); on the
     split kernels (csrc/rnn.hip) and on the opt-in one-wave-per-encoder kernels (csrc/rnn1.hip)."""
     monkeypatch.setenv("CLSR_RNN1", one_wave)
+    if one_wave == "1" and query("clsr_rnn_one_wave", 40) != 1:
+        pytest.skip("csrc/experimental/rnn1.hip is not part of the default build")
     g = torch.Generator().manual_seed(Hn + T)
     f = lambda t: dev(t, torch.float32)
     ldp = 3 * n + 6 * n
@@ -1360,7 +1362,8 @@ def test_one_wave_per_encoder_recurrences_equal_the_split_kernels(Hn, T, n, monk
     activations are compared on LIVE steps only: the one-wave kernels also store (finite, never used) values for dead
     steps inside a wave's common range."""
     monkeypatch.setenv("CLSR_RNN1", "1")
-    assert query("clsr_rnn_one_wave", n) == 1
+    if query("clsr_rnn_one_wave", n) != 1:
+        pytest.skip("csrc/experimental/rnn1.hip is not part of the default build (CLSR_EXPERIMENTAL=1 python -m clsr_amd.build)")
     g = torch.Generator().manual_seed(Hn * 7 + n)
     f = lambda t: dev(t, torch.float32)
     ldp = 3 * n + 3 * n + 6 * n
