@@ -146,7 +146,8 @@ def cpu_baseline(cfg, seconds=25.0, P=None, warmup=1, steps=None):
 class Workload(object):
     """One (config, model, precision, clip mode) training workload with its feed resident in HBM."""
 
-    def __init__(self, config, model="clsr", precision="fp32", dedup=True, lengths="full", rank=0, local_rank=0):
+    def __init__(self, config, model="clsr", precision="fp32", dedup=True, lengths="full", rank=0, local_rank=0,
+                 table_dtype="fp32"):
         import torch
         from clsr_amd.net import CLSRNet
         from clsr_amd.synthetic import CONFIGS, synthetic_feed
@@ -160,7 +161,8 @@ class Workload(object):
         dev = "cuda:%d" % local_rank
         if model == "clsr":
             self.hp = build_hparams(cfg, self.P, **({"optimizer": "lazyadam"} if big else {}))
-            self.net = CLSRNet(self.hp, dims, device=dev, seed=0, dedup_histories=dedup, precision=precision)
+            self.net = CLSRNet(self.hp, dims, device=dev, seed=0, dedup_histories=dedup, precision=precision,
+                               table_dtype=table_dtype)
         else:
             from clsr_amd.seqnet import SeqNet
 
@@ -631,6 +633,7 @@ def main():
             out["config"]["rccl_ranks"] = rccl_ranks
             out["config"]["ms_per_step_by_rank"] = [round(t * 1e3 / args.steps, 4) for t in wl.rank_seconds]
             out["config"]["sparse_tables"] = getattr(wl.stepper, "last_sparse", None)
+            out["config"]["sync_bn_statistics_through"] = getattr(wl.stepper, "stats_transport", None)
         if roof_mfma is None:
             del out["roofline_mfma"]
         if modes:

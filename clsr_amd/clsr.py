@@ -163,7 +163,7 @@ class BaseModel(object):
 
 class SequentialBaseModel(BaseModel):
     def __init__(self, hparams, iterator_creator, graph=None, seed=None, device="cuda:0", use_graph=False,
-                 dedup_histories=True, dist=None, sync_bn=True, group=None, precision="fp32"):
+                 dedup_histories=True, dist=None, sync_bn=True, group=None, precision="fp32", table_dtype="fp32"):
         """Reference ``SequentialBaseModel.__init__`` (:19-48): requires ``train_num_ngs``.
 
         ``dist`` (an initialised ``torch.distributed`` module, one process per GPU) turns ``train`` / ``fit``
@@ -182,6 +182,7 @@ class SequentialBaseModel(BaseModel):
         self._device = device
         self._dist, self._sync_bn, self._dp, self._group = dist, sync_bn, None, group
         self._precision = precision
+        self._table_dtype = table_dtype      # "bf16": embedding tables stored as bf16 (CLSRNet(table_dtype=...))
         self.dp_dropped_positives = self.dp_skipped_batches = 0
         self._use_graph = use_graph and dist is None
         self._dedup = dedup_histories
@@ -206,7 +207,7 @@ class SequentialBaseModel(BaseModel):
 
     def _make_net(self, hp, dims):
         return CLSRNet(hp, dims, device=self._device, seed=self.seed, dedup_histories=self._dedup,
-                       precision=self._precision)
+                       precision=self._precision, table_dtype=self._table_dtype)
 
     # ------------------------------------------------------------------ device feeds / graphs
     def _to_arrays(self, feed_dict, training=False):
@@ -595,6 +596,8 @@ class _SiblingModel(SequentialBaseModel):
             # (a silent fp32 run would be reported as a speed-mode result)
             raise NotImplementedError("%s: precision=%r is not available for the sibling models -- only CLSRModel has "
                                       "the bf16 speed mode" % (type(self).__name__, self._precision))
+        if self._table_dtype != "fp32":
+            raise NotImplementedError("%s: table_dtype=%r is available for CLSRModel only" % (type(self).__name__, self._table_dtype))
         return SeqNet(hp, dims, kind=self.kind, device=self._device, seed=self.seed, dedup_histories=self._dedup)
 
     def train(self, sess, feed_dict):

@@ -153,6 +153,21 @@ __device__ __forceinline__ f32x4 load4e(const void* base, long idx) {
   return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx);
 }
 
+// One element / four elements of an embedding table stored as fp32 or as bf16 (H): read widened to fp32, written rounded
+// to nearest-even (csrc/optim.hip, csrc/multi.hip: the bf16-table forms of the regulariser / Adam / row-gather kernels)
+template <bool H> __device__ __forceinline__ float tbl_ld(const void* p, long e) {
+  if (H) return (float)reinterpret_cast<const __bf16*>(p)[e];
+  return reinterpret_cast<const float*>(p)[e];
+}
+template <bool H> __device__ __forceinline__ void tbl_st(void* p, long e, float v) {
+  if (H) reinterpret_cast<__bf16*>(p)[e] = (__bf16)v;
+  else reinterpret_cast<float*>(p)[e] = v;
+}
+template <bool H> __device__ __forceinline__ void tbl_st4(void* p, long e, f32x4 v) {
+  if (H) *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(p) + e) = __builtin_convertvector(v, bf16x4_t);
+  else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p) + e) = v;
+}
+
 // Wave priority of the kernels on the step's dependency chain (everything except the weight-gradient partial-sum
 // kernels, which run beside it on their own stream): their waves issue ahead of the MFMA-saturated weight-gradient waves
 // that share their SIMDs.  In-step kernel times on the chain summed to 3.47 ms against 2.77 ms for the same kernels

@@ -117,18 +117,19 @@ extern "C" int clsr_scatter_add_rows_multi(const clsr_scatter_desc* descs, int n
 }
 
 // ---- row gathers (embedding.hip: gather_rows_kernel)
+template <bool H>
 __global__ void __launch_bounds__(256) gather_rows_multi_kernel(MultiArgs<clsr_gather_desc> a) {
   const clsr_gather_desc d = a.d[blockIdx.y];
   const int QC = d.C >> 2;
   const long total = (long)d.N * QC;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int n = (int)(e / QC), q = (int)(e - (long)n * QC);
-    const f32x4 v = ld4(d.table + (long)d.idx[(long)n * d.idx_stride] * d.C + 4 * q);
+    const f32x4 v = load4e<H>(d.table, (long)d.idx[(long)n * d.idx_stride] * d.C + 4 * q);
     st4(d.out + (long)n * d.ldo + d.col0 + 4 * q, v);
   }
 }
 
-extern "C" int clsr_gather_rows_multi(const clsr_gather_desc* descs, int n, void* stream) {
+static int gather_rows_multi_launch(const clsr_gather_desc* descs, int n, int bf16, void* stream) {
   CLSR_CHECK_ARG(descs && n > 0 && n <= CLSR_MULTI_MAX);
   MultiArgs<clsr_gather_desc> a;
   long mx = 1;
@@ -142,9 +143,17 @@ extern "C" int clsr_gather_rows_multi(const clsr_gather_desc* descs, int n, void
   }
   int blocks = clsr_cdiv(mx, 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(gather_rows_multi_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, a);
+  if (bf16) hipLaunchKernelGGL(gather_rows_multi_kernel<true>, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(gather_rows_multi_kernel<false>, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
+}
+extern "C" int clsr_gather_rows_multi(const clsr_gather_desc* descs, int n, void* stream) {
+  return gather_rows_multi_launch(descs, n, 0, stream);
+}
+// the tables of the descriptors are bf16 [V, C] (the pointer field is read as such); outputs fp32
+extern "C" int clsr_gather_rows_multi_h(const clsr_gather_desc* descs, int n, void* stream) {
+  return gather_rows_multi_launch(descs, n, 1, stream);
 }
 
 // ---- out[e] (=|+=) scale * sum_p partial[p*stride + e]  (attention.hip: reduce_parts_f_kernel)
@@ -192,6 +201,7 @@ struct TablesArgs {
   int lazy;
 };
 
+template <bool H>
 __global__ void __launch_bounds__(256) tables_reg_multi_kernel(TablesArgs a) {
   const clsr_table_desc d = a.t[blockIdx.y];
   const int C = d.C;
@@ -202,10 +212,10 @@ __global__ void __launch_bounds__(256) tables_reg_multi_kernel(TablesArgs a) {
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const long row = e / C;
     if (!d.flags[row]) continue;
-    const float p = d.table[e];
+    const float p = tbl_ld<H>(d.table, e);
     float g = a.l2 * p + a.l1 * (float)((p > 0.f) - (p < 0.f));
     if (d.partner) {
-      const float df = p - d.partner[e];
+      const float df = p - tbl_ld<H>(d.partner, e);
       g += cd * df;
       dl += (double)df * df;
     }
@@ -235,8 +245,8 @@ static int fill_tables(TablesArgs& a, const clsr_table_desc* descs, int n, long*
   return CLSR_OK;
 }
 
-extern "C" int clsr_tables_reg_multi(const clsr_table_desc* descs, int n, float l2, float l1, const float* ucount,
-                                     double* reg_loss, void* stream) {
+static int tables_reg_multi_launch(const clsr_table_desc* descs, int n, int bf16, float l2, float l1, const float* ucount,
+                                   double* reg_loss, void* stream) {
   TablesArgs a = {};
   long mx = 0;
   int rc = fill_tables(a, descs, n, &mx);
@@ -245,9 +255,19 @@ extern "C" int clsr_tables_reg_multi(const clsr_table_desc* descs, int n, float 
   a.l2 = l2; a.l1 = l1; a.ucount = ucount; a.reg_loss = reg_loss;
   int blocks = clsr_cdiv(mx, 256 * 8);
   if (blocks > 512) blocks = 512;
-  hipLaunchKernelGGL(tables_reg_multi_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, a);
+  if (bf16) hipLaunchKernelGGL(tables_reg_multi_kernel<true>, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(tables_reg_multi_kernel<false>, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
+}
+extern "C" int clsr_tables_reg_multi(const clsr_table_desc* descs, int n, float l2, float l1, const float* ucount,
+                                     double* reg_loss, void* stream) {
+  return tables_reg_multi_launch(descs, n, 0, l2, l1, ucount, reg_loss, stream);
+}
+// table / partner of every descriptor are bf16 [V, C]
+extern "C" int clsr_tables_reg_multi_h(const clsr_table_desc* descs, int n, float l2, float l1, const float* ucount,
+                                       double* reg_loss, void* stream) {
+  return tables_reg_multi_launch(descs, n, 1, l2, l1, ucount, reg_loss, stream);
 }
 
 // ---- Adam sweep of several tables (optim.hip: table_adam_kernel); the flags are cleared by the same launch
@@ -258,6 +278,7 @@ __device__ __forceinline__ float clipf(double sumsq, float clip_norm) {
   return clip_norm / fmaxf(nrm, clip_norm);
 }
 
+template <bool H>
 __global__ void __launch_bounds__(256) tables_adam_multi_kernel(TablesArgs a) {
   const clsr_table_desc d = a.t[blockIdx.y];
   double tot = 0.0;
@@ -274,7 +295,7 @@ __global__ void __launch_bounds__(256) tables_adam_multi_kernel(TablesArgs a) {
     const float vv = b2 * d.v[e] + (1.0f - b2) * g * g;
     d.m[e] = mm;
     d.v[e] = vv;
-    d.table[e] -= lr_t * mm / (sqrtf(vv) + a.eps);
+    tbl_st<H>(d.table, e, tbl_ld<H>(d.table, e) - lr_t * mm / (sqrtf(vv) + a.eps));
     d.grad[e] = 0.f;
   }
 }
@@ -284,9 +305,9 @@ __global__ void __launch_bounds__(256) tables_clear_flags_kernel(TablesArgs a) {
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < d.V; e += (long)gridDim.x * blockDim.x) d.flags[e] = 0;
 }
 
-extern "C" int clsr_tables_adam_multi(const clsr_table_desc* descs, int n, float clip_norm,
-                                      const double* adam_state, float beta1, float beta2, float eps, int lazy,
-                                      void* stream) {
+static int tables_adam_multi_launch(const clsr_table_desc* descs, int n, int bf16, float clip_norm,
+                                    const double* adam_state, float beta1, float beta2, float eps, int lazy,
+                                    void* stream) {
   TablesArgs a = {};
   long mx = 0;
   int rc = fill_tables(a, descs, n, &mx);
@@ -301,11 +322,23 @@ extern "C" int clsr_tables_adam_multi(const clsr_table_desc* descs, int n, float
   int blocks = clsr_cdiv(mx, 256);
   if (blocks > 2048) blocks = 2048;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(tables_adam_multi_kernel, dim3(blocks, n), dim3(256), 0, s, a);
+  if (bf16) hipLaunchKernelGGL(tables_adam_multi_kernel<true>, dim3(blocks, n), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(tables_adam_multi_kernel<false>, dim3(blocks, n), dim3(256), 0, s, a);
   CLSR_CHECK_LAUNCH();
   int cb = clsr_cdiv(mxv, 256);
   if (cb > 512) cb = 512;
   hipLaunchKernelGGL(tables_clear_flags_kernel, dim3(cb, n), dim3(256), 0, s, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
+}
+extern "C" int clsr_tables_adam_multi(const clsr_table_desc* descs, int n, float clip_norm,
+                                      const double* adam_state, float beta1, float beta2, float eps, int lazy,
+                                      void* stream) {
+  return tables_adam_multi_launch(descs, n, 0, clip_norm, adam_state, beta1, beta2, eps, lazy, stream);
+}
+// the tables of the descriptors are bf16 [V, C]: widened, updated in fp32, rounded to nearest-even
+extern "C" int clsr_tables_adam_multi_h(const clsr_table_desc* descs, int n, float clip_norm,
+                                        const double* adam_state, float beta1, float beta2, float eps, int lazy,
+                                        void* stream) {
+  return tables_adam_multi_launch(descs, n, 1, clip_norm, adam_state, beta1, beta2, eps, lazy, stream);
 }

@@ -162,8 +162,9 @@ extern "C" int clsr_count_flags(const unsigned char* flags, long V, float* count
 //   grad_table[row] += g_reg ; sumsq += ||g_reg||^2 ; reg_loss += l2/2 ||row||^2 ;
 //   disc_loss += disc_loss_scale * ||row - partner_row||^2 / (count * C)   (only when disc_loss != null)
 // These are the values of the reference's third IndexedSlices (the tf.unique "involved" lookup).
+template <bool H>
 __global__ void __launch_bounds__(256) table_reg_kernel(
-    const float* __restrict__ table, const float* __restrict__ partner,
+    const void* __restrict__ table, const void* __restrict__ partner,
     const unsigned char* __restrict__ flags, long V, int C, float l2, float l1, float disc_scale,
     float disc_loss_scale, const float* __restrict__ count, float* __restrict__ grad_table,
     double* __restrict__ sumsq, double* __restrict__ reg_loss, double* __restrict__ disc_loss) {
@@ -174,10 +175,10 @@ __global__ void __launch_bounds__(256) table_reg_kernel(
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const long row = e / C;
     if (!flags[row]) continue;
-    const float p = table[e];
+    const float p = tbl_ld<H>(table, e);
     float g = l2 * p + l1 * (float)((p > 0.f) - (p < 0.f));
     if (partner) {
-      const float d = p - partner[e];
+      const float d = p - tbl_ld<H>(partner, e);
       g += cd * d;
       dl += (double)d * d;
     }
@@ -194,26 +195,44 @@ __global__ void __launch_bounds__(256) table_reg_kernel(
   }
 }
 
-extern "C" int clsr_table_reg(const float* table, const float* partner, const unsigned char* flags,
-                              long V, int C, float l2, float l1, float disc_scale, float disc_loss_scale,
-                              const float* count, float* grad_table, double* sumsq, double* reg_loss,
-                              double* disc_loss, void* stream) {
+static int table_reg_launch(const void* table, const void* partner, int bf16, const unsigned char* flags, long V, int C,
+                            float l2, float l1, float disc_scale, float disc_loss_scale, const float* count,
+                            float* grad_table, double* sumsq, double* reg_loss, double* disc_loss, void* stream) {
   CLSR_CHECK_ARG(table && flags && grad_table && sumsq && V > 0 && C > 0);
   CLSR_CHECK_ARG(!partner || count);
   int blocks = clsr_cdiv(V * C, 256 * 8);
   if (blocks > 512) blocks = 512;
-  hipLaunchKernelGGL(table_reg_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, partner,
-                     flags, V, C, l2, l1, disc_scale, disc_loss_scale, count, grad_table, sumsq, reg_loss,
-                     disc_loss);
+  if (bf16)
+    hipLaunchKernelGGL(table_reg_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, partner, flags, V, C,
+                       l2, l1, disc_scale, disc_loss_scale, count, grad_table, sumsq, reg_loss, disc_loss);
+  else
+    hipLaunchKernelGGL(table_reg_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, partner, flags, V, C,
+                       l2, l1, disc_scale, disc_loss_scale, count, grad_table, sumsq, reg_loss, disc_loss);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
+}
+extern "C" int clsr_table_reg(const float* table, const float* partner, const unsigned char* flags,
+                              long V, int C, float l2, float l1, float disc_scale, float disc_loss_scale,
+                              const float* count, float* grad_table, double* sumsq, double* reg_loss,
+                              double* disc_loss, void* stream) {
+  return table_reg_launch(table, partner, 0, flags, V, C, l2, l1, disc_scale, disc_loss_scale, count, grad_table, sumsq,
+                          reg_loss, disc_loss, stream);
+}
+// bf16 tables (table / partner: bf16 [V, C]); gradients, norms and losses fp32 / fp64 as above
+extern "C" int clsr_table_reg_h(const void* table, const void* partner, const unsigned char* flags,
+                                long V, int C, float l2, float l1, float disc_scale, float disc_loss_scale,
+                                const float* count, float* grad_table, double* sumsq, double* reg_loss,
+                                double* disc_loss, void* stream) {
+  return table_reg_launch(table, partner, 1, flags, V, C, l2, l1, disc_scale, disc_loss_scale, count, grad_table, sumsq,
+                          reg_loss, disc_loss, stream);
 }
 
 // Pass B: Adam sweep of one table.  sumsq[i * sumsq_stride], i < nsum, are the squared norms of this table's
 // IndexedSlices pieces (lookup sites + involved rows); lazy != 0 restricts the update to rows whose
 // flag is set or that received gradient through a lookup (LazyAdam).  Clears grad rows and flags.
+template <bool H>
 __global__ void __launch_bounds__(256) table_adam_kernel(
-    float* __restrict__ table, float* __restrict__ grad_table, float* __restrict__ m,
+    void* __restrict__ table, float* __restrict__ grad_table, float* __restrict__ m,
     float* __restrict__ v, unsigned char* __restrict__ flags, long V, int C,
     const double* __restrict__ sumsq, int sumsq_stride, int nsum, float clip_norm,
     const double* __restrict__ adam_state, float b1, float b2, float eps, int lazy) {
@@ -230,7 +249,7 @@ __global__ void __launch_bounds__(256) table_adam_kernel(
     const float vv = b2 * v[e] + (1.0f - b2) * g * g;
     m[e] = mm;
     v[e] = vv;
-    table[e] -= lr_t * mm / (sqrtf(vv) + eps);
+    tbl_st<H>(table, e, tbl_ld<H>(table, e) - lr_t * mm / (sqrtf(vv) + eps));
     grad_table[e] = 0.f;
   }
 }
@@ -239,16 +258,19 @@ __global__ void clear_bytes_kernel(unsigned char* p, long n) {
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) p[e] = 0;
 }
 
-extern "C" int clsr_table_adam(float* table, float* grad_table, float* m, float* v, unsigned char* flags,
-                               long V, int C, const double* sumsq, int sumsq_stride, int nsum,
-                               float clip_norm, const double* adam_state, float beta1, float beta2,
-                               float eps, int lazy, void* stream) {
+static int table_adam_launch(void* table, int bf16, float* grad_table, float* m, float* v, unsigned char* flags, long V,
+                             int C, const double* sumsq, int sumsq_stride, int nsum, float clip_norm,
+                             const double* adam_state, float beta1, float beta2, float eps, int lazy, void* stream) {
   CLSR_CHECK_ARG(table && grad_table && m && v && flags && sumsq && adam_state && V > 0 && C > 0 && nsum > 0);
   int blocks = clsr_cdiv(V * C, 256);
   if (blocks > 4096) blocks = 4096;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(table_adam_kernel, dim3(blocks), dim3(256), 0, s, table, grad_table, m, v, flags, V, C,
-                     sumsq, sumsq_stride, nsum, clip_norm, adam_state, beta1, beta2, eps, lazy);
+  if (bf16)
+    hipLaunchKernelGGL(table_adam_kernel<true>, dim3(blocks), dim3(256), 0, s, table, grad_table, m, v, flags, V, C,
+                       sumsq, sumsq_stride, nsum, clip_norm, adam_state, beta1, beta2, eps, lazy);
+  else
+    hipLaunchKernelGGL(table_adam_kernel<false>, dim3(blocks), dim3(256), 0, s, table, grad_table, m, v, flags, V, C,
+                       sumsq, sumsq_stride, nsum, clip_norm, adam_state, beta1, beta2, eps, lazy);
   CLSR_CHECK_LAUNCH();
   int cb = clsr_cdiv(V, 256);
   if (cb > 1024) cb = 1024;
@@ -256,15 +278,30 @@ extern "C" int clsr_table_adam(float* table, float* grad_table, float* m, float*
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
+extern "C" int clsr_table_adam(float* table, float* grad_table, float* m, float* v, unsigned char* flags,
+                               long V, int C, const double* sumsq, int sumsq_stride, int nsum,
+                               float clip_norm, const double* adam_state, float beta1, float beta2,
+                               float eps, int lazy, void* stream) {
+  return table_adam_launch(table, 0, grad_table, m, v, flags, V, C, sumsq, sumsq_stride, nsum, clip_norm, adam_state, beta1,
+                           beta2, eps, lazy, stream);
+}
+// bf16 table: widened, updated in fp32 (fp32 moments / gradients), rounded to nearest-even
+extern "C" int clsr_table_adam_h(void* table_bf16, float* grad_table, float* m, float* v, unsigned char* flags,
+                                 long V, int C, const double* sumsq, int sumsq_stride, int nsum,
+                                 float clip_norm, const double* adam_state, float beta1, float beta2,
+                                 float eps, int lazy, void* stream) {
+  return table_adam_launch(table_bf16, 1, grad_table, m, v, flags, V, C, sumsq, sumsq_stride, nsum, clip_norm, adam_state,
+                           beta1, beta2, eps, lazy, stream);
+}
 
 // ---- row-list variants for huge vocabularies (100M-item catalogues): the same math as table_reg / lazy
 // table_adam, but driven by the compacted id list of the involved rows (clsr_flags_compact) instead of a sweep
 // over all V*C elements.  count[0] = number of listed rows (device memory).
 // VW = floats per lane and access (4 when C % 4 == 0: 16-byte pieces of the 128-512 B rows, 4x fewer dependent
 // id loads and address computations; random rows are HBM latency bound, so bytes in flight per lane matter)
-template <int VW>
+template <int VW, bool H>
 __global__ void __launch_bounds__(256) table_reg_rows_kernel(
-    const float* __restrict__ table, const float* __restrict__ partner, const int* __restrict__ ids,
+    const void* __restrict__ table, const void* __restrict__ partner, const int* __restrict__ ids,
     const int* __restrict__ count, int C, float l2, float l1, float disc_scale, float disc_loss_scale,
     const float* __restrict__ ucount, float* __restrict__ grad_table, double* __restrict__ sumsq,
     double* __restrict__ reg_loss, double* __restrict__ disc_loss) {
@@ -278,12 +315,12 @@ __global__ void __launch_bounds__(256) table_reg_rows_kernel(
     const long e = (long)ids[r] * C + (i - r * QC) * VW;
     float p[VW], pp[VW], gt[VW];
     if (VW == 4) {
-      *reinterpret_cast<f32x4*>(p) = ld4(table + e);
-      if (partner) *reinterpret_cast<f32x4*>(pp) = ld4(partner + e);
+      *reinterpret_cast<f32x4*>(p) = load4e<H>(table, e);
+      if (partner) *reinterpret_cast<f32x4*>(pp) = load4e<H>(partner, e);
       *reinterpret_cast<f32x4*>(gt) = ld4(grad_table + e);
     } else {
-      p[0] = table[e];
-      if (partner) pp[0] = partner[e];
+      p[0] = tbl_ld<H>(table, e);
+      if (partner) pp[0] = tbl_ld<H>(partner, e);
       gt[0] = grad_table[e];
     }
 #pragma unroll
@@ -310,23 +347,36 @@ __global__ void __launch_bounds__(256) table_reg_rows_kernel(
   }
 }
 
-extern "C" int clsr_table_reg_rows(const float* table, const float* partner, const int* ids, const int* count,
-                                   int cap, int C, float l2, float l1, float disc_scale, float disc_loss_scale,
-                                   const float* ucount, float* grad_table, double* sumsq, double* reg_loss,
-                                   double* disc_loss, void* stream) {
+static int table_reg_rows_launch(const void* table, const void* partner, int bf16, const int* ids, const int* count, int cap,
+                                 int C, float l2, float l1, float disc_scale, float disc_loss_scale, const float* ucount,
+                                 float* grad_table, double* sumsq, double* reg_loss, double* disc_loss, void* stream) {
   CLSR_CHECK_ARG(table && ids && count && grad_table && sumsq && cap > 0 && C > 0);
   CLSR_CHECK_ARG(!partner || ucount);
   const bool vec = C % 4 == 0;
   int blocks = clsr_cdiv((long)cap * C, 256 * 4 * (vec ? 2 : 1));
   if (blocks > 2048) blocks = 2048;
-  if (vec)
-    hipLaunchKernelGGL(table_reg_rows_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, partner, ids,
-                       count, C, l2, l1, disc_scale, disc_loss_scale, ucount, grad_table, sumsq, reg_loss, disc_loss);
-  else
-    hipLaunchKernelGGL(table_reg_rows_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, partner, ids,
-                       count, C, l2, l1, disc_scale, disc_loss_scale, ucount, grad_table, sumsq, reg_loss, disc_loss);
+#define TRR(VWV, HV)                                                                                                  \
+  hipLaunchKernelGGL((table_reg_rows_kernel<VWV, HV>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, partner, \
+                     ids, count, C, l2, l1, disc_scale, disc_loss_scale, ucount, grad_table, sumsq, reg_loss, disc_loss)
+  if (vec) { if (bf16) TRR(4, true); else TRR(4, false); }
+  else { if (bf16) TRR(1, true); else TRR(1, false); }
+#undef TRR
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
+}
+extern "C" int clsr_table_reg_rows(const float* table, const float* partner, const int* ids, const int* count,
+                                   int cap, int C, float l2, float l1, float disc_scale, float disc_loss_scale,
+                                   const float* ucount, float* grad_table, double* sumsq, double* reg_loss,
+                                   double* disc_loss, void* stream) {
+  return table_reg_rows_launch(table, partner, 0, ids, count, cap, C, l2, l1, disc_scale, disc_loss_scale, ucount, grad_table,
+                               sumsq, reg_loss, disc_loss, stream);
+}
+extern "C" int clsr_table_reg_rows_h(const void* table, const void* partner, const int* ids, const int* count,
+                                     int cap, int C, float l2, float l1, float disc_scale, float disc_loss_scale,
+                                     const float* ucount, float* grad_table, double* sumsq, double* reg_loss,
+                                     double* disc_loss, void* stream) {
+  return table_reg_rows_launch(table, partner, 1, ids, count, cap, C, l2, l1, disc_scale, disc_loss_scale, ucount, grad_table,
+                               sumsq, reg_loss, disc_loss, stream);
 }
 
 // LazyAdam over the listed rows; clears their gradient rows and flags.

@@ -60,7 +60,7 @@ _SIDE_STREAMS = {}     # device -> {tag: HIP stream}, see CLSRNet.__init__
 
 
 class CLSRNet(object):
-    def __init__(self, hp, dims, device="cuda:0", seed=None, dedup_histories=True, precision="fp32"):
+    def __init__(self, hp, dims, device="cuda:0", seed=None, dedup_histories=True, precision="fp32", table_dtype="fp32"):
         self.hp = hp
         self.dims = dict(dims)
         self.device = torch.device(device)
@@ -68,6 +68,17 @@ class CLSRNet(object):
         if precision not in ("fp32", "fp32x3", "bf16"):
             raise ValueError("precision must be 'fp32', 'fp32x3' or 'bf16'")
         self.precision = precision
+        # embedding tables stored as bf16 (SURVEY 8d configs 2, 3, 5 "bf16 tables"): the lookups widen the 2-byte rows, the
+        # gradients / Adam moments stay fp32, the (lazy-)Adam update widens a row, updates it in fp32 and writes it back
+        # rounded to nearest-even (no fp32 master copy: an update below half a bf16 ulp of the weight is lost)
+        if table_dtype not in ("fp32", "bf16"):
+            raise ValueError("table_dtype must be 'fp32' or 'bf16'")
+        self.table_bf16 = table_dtype == "bf16"
+        if self.table_bf16 and type(self) is not CLSRNet:
+            raise NotImplementedError("%s: bf16 embedding tables are available for CLSRNet only" % type(self).__name__)
+        if self.table_bf16 and (hp.item_embedding_dim % 8 or hp.cate_embedding_dim % 8 or hp.user_embedding_dim % 4):
+            raise NotImplementedError("table_dtype='bf16' needs item / cate embedding dims that are multiples of 8")
+        self._th = "_h" if self.table_bf16 else ""          # suffix of the table kernels' entry points
         self._check_supported()
         self.Di, self.Dc = hp.item_embedding_dim, hp.cate_embedding_dim
         self.D = self.Di + self.Dc
@@ -243,7 +254,7 @@ class CLSRNet(object):
     def _plan_key(self, what, f):
         hp = self.hp
         g = lambda k: getattr(hp, k, None)
-        return (what, id(f), ops.stream_ptr(), self.precision, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook), self.dp_comm,
+        return (what, id(f), ops.stream_ptr(), self.precision, self.table_bf16, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook), self.dp_comm,
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
                 self.lazy, self.rnn_first, self.tick_early, self.hist_grad_two, self.dw_batch_late, self.bn_bwd_fused, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h, self.flush_side, self.l1_bwd_2pass,
                 self.split_g2, self.enc_bwd_fused, self.enc_bwd_fused_h, self.dhist_side, self.early_scatter, self.fused_logit_tail, self.fuse_tt, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
@@ -340,10 +351,13 @@ class CLSRNet(object):
                 self.P[name] = t
                 if name not in self._unused_tables():
                     key = [k for k, v in TABLES.items() if v == name][0]
+                    if self.table_bf16:
+                        t = t.to(torch.bfloat16)
+                        self.P[name] = t
                     self.tables[key] = t
-                    self.tab_grad[key] = self.tab_grad_flat[goff[key]:goff[key] + t.numel()].view_as(t)
-                    self.tab_m[key] = torch.zeros_like(t)
-                    self.tab_v[key] = torch.zeros_like(t)
+                    self.tab_grad[key] = self.tab_grad_flat[goff[key]:goff[key] + t.numel()].view(t.shape)
+                    self.tab_m[key] = torch.zeros(t.shape, dtype=F32, device=dev)
+                    self.tab_v[key] = torch.zeros(t.shape, dtype=F32, device=dev)
                     self.tab_flags[key] = self.tab_flags_flat[foff[key]:foff[key] + shape[0]]
             else:
                 (_, _, _), o = next(it_dense)
@@ -372,7 +386,7 @@ class CLSRNet(object):
         """All variables under their TF names + BN moving stats + Adam slots (checkpoint payload)."""
         sd = OrderedDict()
         for name, t in self.P.items():
-            sd[name] = t.detach().cpu().clone()
+            sd[name] = t.detach().float().cpu().clone()      # (bf16 tables: widened -- the payload is always fp32)
         for scope, bn in self.bn.items():
             sd[scope + "moving_mean"] = bn.moving_mean.cpu().clone()
             sd[scope + "moving_variance"] = bn.moving_var.cpu().clone()
@@ -1550,12 +1564,16 @@ class CLSRNet(object):
         # ---- gathers
         hist = self._buf("hist", Hn, T, D)
         hmean, hrec = self._buf("hist_mean", Hn, D), self._buf("hist_recent", Hn, D)
-        call("clsr_gather_hist_fwd", self.tables["item"], self.tables["cate"], f["item_history"],
-             f["item_cate_history"], hs * T, seq_len, ls, Hn, T, Di, Dc, hp.contrastive_recent_k, hist, hmean, hrec)
+        if self.table_bf16:
+            call("clsr_gather_hist_fwd_h", self.tables["item"], self.tables["cate"], f["item_history"], f["item_cate_history"],
+                 hs * T, seq_len, ls, Hn, T, Di, Dc, hp.contrastive_recent_k, hist, 0, hmean, hrec)
+        else:
+            call("clsr_gather_hist_fwd", self.tables["item"], self.tables["cate"], f["item_history"],
+                 f["item_cate_history"], hs * T, seq_len, ls, Hn, T, Di, Dc, hp.contrastive_recent_k, hist, hmean, hrec)
         target = self._buf("target", B, D)
         ulong, ushort = self._buf("u_long", Hn, Du), self._buf("u_short", Hn, Du)
         tb = self.tables
-        ops.multi("clsr_gather_rows_multi", ops.GatherDesc, [     # target = [item | cate], user_long, user_short
+        ops.multi("clsr_gather_rows_multi" + self._th, ops.GatherDesc, [     # target = [item | cate], user_long, user_short
             (tb["item"].data_ptr(), f["items"].data_ptr(), target.data_ptr(), 1, B, Di, D, 0),
             (tb["cate"].data_ptr(), f["cates"].data_ptr(), target.data_ptr(), 1, B, Dc, D, Di),
             (tb["user_long"].data_ptr(), f["users"].data_ptr(), ulong.data_ptr(), hs, Hn, Du, Du, 0),
@@ -2147,14 +2165,14 @@ class CLSRNet(object):
             pt = tb[partner] if partner else None
             if key in lists:
                 ids, count, cap = lists[key]
-                call("clsr_table_reg_rows", tb[key], pt, ids, count, cap, C, l2e, l1e, dscale, dloss_scale,
+                call("clsr_table_reg_rows" + self._th, tb[key], pt, ids, count, cap, C, l2e, l1e, dscale, dloss_scale,
                      self.ucount if partner else None, tg[key], ss[slot:], self.losses[1:], dloss)
             else:   # small tables: one launch sweeps all of them (blockIdx.y = table)
                 sweep.append((tb[key].data_ptr(), ops._ptr(pt), tg[key].data_ptr(), self.tab_m[key].data_ptr(),
                               self.tab_v[key].data_ptr(), fl[key].data_ptr(), ss[slot:].data_ptr(), ops._ptr(dloss),
                               ss[base:].data_ptr(), V, C, nsum, 2, dscale, dloss_scale, 0))
         if sweep:
-            ops.multi("clsr_tables_reg_multi", ops.TableDesc, sweep, l2e, l1e, self.ucount, self.losses[1:])
+            ops.multi("clsr_tables_reg_multi" + self._th, ops.TableDesc, sweep, l2e, l1e, self.ucount, self.losses[1:])
         if self.capture_grads:  # test hook: pre-clip gradients (regularisers included) + squared norms
             self.captured = dict(dense={n: g.detach().clone() for n, g in self.Gd.items()},
                                  tables={k: g.detach().clone() for k, g in tg.items()},
@@ -2169,15 +2187,15 @@ class CLSRNet(object):
             V, C = tb[key].shape
             if key in lists and self.lazy:
                 ids, count, cap = lists[key]
-                call("clsr_table_adam_rows", tb[key], tg[key], self.tab_m[key], self.tab_v[key], fl[key], ids, count,
+                call("clsr_table_adam_rows" + self._th, tb[key], tg[key], self.tab_m[key], self.tab_v[key], fl[key], ids, count,
                      cap, C, ss[base:], 2, nsum, clip, self.adam_state, 0.9, 0.999, 1e-8)
             elif key in lists:   # huge table with the reference's dense Adam: the O(vocabulary) sweep is inherent
-                call("clsr_table_adam", tb[key], tg[key], self.tab_m[key], self.tab_v[key], fl[key], V, C, ss[base:],
+                call("clsr_table_adam" + self._th, tb[key], tg[key], self.tab_m[key], self.tab_v[key], fl[key], V, C, ss[base:],
                      2, nsum, clip, self.adam_state, 0.9, 0.999, 1e-8, self.lazy)
             else:
                 rest.append(key)
         if rest:
-            ops.multi("clsr_tables_adam_multi", ops.TableDesc, [r for r in sweep if r[0] in
+            ops.multi("clsr_tables_adam_multi" + self._th, ops.TableDesc, [r for r in sweep if r[0] in
                                                                 {tb[k].data_ptr() for k in rest}],
                       clip, self.adam_state, 0.9, 0.999, 1e-8, self.lazy)
         if tick_early:

@@ -540,13 +540,27 @@ int clsr_count_flags_tick(const unsigned char* flags, long V, float* count, doub
 int clsr_table_reg(const float* table, const float* partner, const unsigned char* flags, long V, int C,
                    float l2, float l1, float disc_scale, float disc_loss_scale, const float* count,
                    float* grad_table, double* sumsq, double* reg_loss, double* disc_loss, void* stream);
+/* bf16 embedding tables (table / partner: bf16 [V, C]; the `_h` forms of the table kernels: rows widened to fp32,
+ * gradients / moments / norms as in the fp32 forms, parameters written back rounded to nearest-even) */
+int clsr_table_reg_h(const void* table, const void* partner, const unsigned char* flags,
+                     long V, int C, float l2, float l1, float disc_scale, float disc_loss_scale,
+                     const float* count, float* grad_table, double* sumsq, double* reg_loss,
+                     double* disc_loss, void* stream);
 int clsr_table_adam(float* table, float* grad_table, float* m, float* v, unsigned char* flags, long V,
                     int C, const double* sumsq, int sumsq_stride, int nsum, float clip_norm,
                     const double* adam_state, float beta1, float beta2, float eps, int lazy, void* stream);
+int clsr_table_adam_h(void* table_bf16, float* grad_table, float* m, float* v, unsigned char* flags,
+                      long V, int C, const double* sumsq, int sumsq_stride, int nsum,
+                      float clip_norm, const double* adam_state, float beta1, float beta2,
+                      float eps, int lazy, void* stream);
 /* row-list variants for huge vocabularies: ids/count from clsr_flags_compact (involved rows) */
 int clsr_table_reg_rows(const float* table, const float* partner, const int* ids, const int* count, int cap,
                         int C, float l2, float l1, float disc_scale, float disc_loss_scale, const float* ucount,
                         float* grad_table, double* sumsq, double* reg_loss, double* disc_loss, void* stream);
+int clsr_table_reg_rows_h(const void* table, const void* partner, const int* ids, const int* count,
+                          int cap, int C, float l2, float l1, float disc_scale, float disc_loss_scale,
+                          const float* ucount, float* grad_table, double* sumsq, double* reg_loss,
+                          double* disc_loss, void* stream);
 int clsr_table_adam_rows(float* table, float* grad_table, float* m, float* v, unsigned char* flags,
                          const int* ids, const int* count, int cap, int C, const double* sumsq,
                          int sumsq_stride, int nsum, float clip_norm, const double* adam_state, float beta1,
@@ -637,11 +651,16 @@ int clsr_scatter_add_rows_multi(const clsr_scatter_desc* descs_host, int n, void
 int clsr_sizeof_multi_descs(int* mark, int* gather, int* rp, int* table);
 int clsr_mark_rows_multi(const clsr_mark_desc* descs_host, int n, void* stream);
 int clsr_gather_rows_multi(const clsr_gather_desc* descs_host, int n, void* stream);
+int clsr_gather_rows_multi_h(const clsr_gather_desc* descs_host, int n, void* stream);   /* bf16 tables, fp32 outputs */
 int clsr_reduce_parts_multi(const clsr_rp_desc* descs_host, int n, void* stream);
 int clsr_tables_reg_multi(const clsr_table_desc* descs_host, int n, float l2, float l1, const float* ucount,
                           double* reg_loss, void* stream);
+int clsr_tables_reg_multi_h(const clsr_table_desc* descs_host, int n, float l2, float l1, const float* ucount,
+                            double* reg_loss, void* stream);
 int clsr_tables_adam_multi(const clsr_table_desc* descs_host, int n, float clip_norm, const double* adam_state,
                            float beta1, float beta2, float eps, int lazy, void* stream);
+int clsr_tables_adam_multi_h(const clsr_table_desc* descs_host, int n, float clip_norm, const double* adam_state,
+                             float beta1, float beta2, float eps, int lazy, void* stream);
 
 /* ---- evaluation metrics on the device (csrc/metrics.hip): cal_metric / cal_weighted_metric of
  *      deeprec_utils.py:554-821 as SequentialBaseModel.run_eval / run_weighted_eval use them

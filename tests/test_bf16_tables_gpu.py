@@ -152,3 +152,71 @@ def test_lazy_adam_rows_on_a_bf16_table(V, C, nrows):
     untouched[ids.long()] = False
     assert torch.equal(th[untouched], tbl_h[untouched])
     assert not torch.equal(th[ids.long()], tbl_h[ids.long()])
+
+
+# ------------------------------------------------------------------------------- the whole step with bf16 tables
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("lazy", [False, True])
+def test_step_with_bf16_tables(golden_dir, golden_hparams, precision, lazy):
+    """CLSRNet(table_dtype="bf16"): the step on bf16 tables == the step of a net whose fp32 tables hold the SAME (bf16-
+    representable) values -- logits, losses and gradient tables bit for bit (the lookups return identical fp32 values and
+    everything behind them is deterministic) -- and its updated tables are that net's updated tables rounded to
+    nearest-even; against the float64 oracle on the rounded tables: logits at the exact-mode / speed-mode bars."""
+    import copy
+    import os
+    import pickle
+
+    import numpy as np
+
+    from clsr_amd.net import CLSRNet
+    from clsr_amd.params import TABLES
+    from oracle import clsr_oracle as O
+
+    hp = copy.deepcopy(golden_hparams)
+    hp.item_embedding_dim, hp.cate_embedding_dim = 32, 8
+    if lazy:
+        hp.optimizer = "lazyadam"
+    dims = dict(Vu=len(pickle.load(open(hp.user_vocab, "rb"))), Vi=len(pickle.load(open(hp.item_vocab, "rb"))),
+                Vc=len(pickle.load(open(hp.cate_vocab, "rb"))))
+    gf = np.load(os.path.join(golden_dir, "iterator_train_sa.npz"))
+    feed = {k[3:]: gf[k] for k in gf.files if k.startswith("b1_")}
+    params = O.init_params(dims, hp, seed=3, scale_dense=8.0)
+    for name in TABLES.values():                      # bf16-representable table values
+        params[name] = params[name].to(BF).float()
+    sd = dict(params)
+    sd.update(O.init_bn_state(params))
+    nets = {}
+    for td in ("bf16", "fp32"):
+        net = CLSRNet(hp, dims, device="cuda:0", seed=0, precision=precision, table_dtype=td)
+        net.load_state_dict(copy.deepcopy(sd))
+        net.capture_grads = True
+        out = net.train_step(net.upload(feed, True))
+        torch.cuda.synchronize()
+        nets[td] = (net, out["logit"].clone(), net.read_losses(), {k: v.clone() for k, v in net.captured["tables"].items()})
+    (nh, lh, lsh, gh), (nf, lf, lsf, gfp) = nets["bf16"], nets["fp32"]
+    assert nh.tables["item"].dtype == BF and nf.tables["item"].dtype == torch.float32
+    assert torch.equal(lh, lf), "same looked-up values -> identical logits"
+    for k in gh:
+        assert torch.equal(gh[k], gfp[k]), "gradient table %s" % k
+    for k in lsh:
+        assert abs(lsh[k] - lsf[k]) <= 1e-9 * max(1.0, abs(lsf[k])), k
+    changed = 0
+    for k in nh.tables:
+        a, b = nh.tables[k], nf.tables[k].to(BF)
+        d = (a.view(torch.int16).int() - b.view(torch.int16).int()).abs()
+        assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 1e-3, "updated table %s" % k
+        changed += int((nf.tables[k] != params[TABLES[k]].to("cuda")).sum())
+    assert changed > 0
+    # the checkpoint payload is fp32 and round-trips
+    sd2 = nh.state_dict()
+    assert all(v.dtype != BF for v in sd2.values())
+    n2 = CLSRNet(hp, dims, device="cuda:0", seed=1, precision=precision, table_dtype="bf16")
+    n2.load_state_dict(sd2)
+    for k in nh.tables:
+        assert torch.equal(n2.tables[k], nh.tables[k])
+    # against the oracle on the rounded tables
+    tf = O.to_torch_feed(feed, dtype=torch.float64)
+    p64 = type(params)((k, v.double()) for k, v in params.items())
+    _, _, _, ls, _, _, oout = O.train_step(p64, O.init_bn_state(p64), O.init_adam(p64), 1, tf, hp)
+    tol = 1e-4 if precision == "fp32" else 1e-3
+    _close(lh, oout["logit"].reshape(-1), tol, tol, "logit vs oracle")
