@@ -259,16 +259,22 @@ def gather_roofline(net, f, cfg, G, feed, big):
     hist = net._buf("hist", Hn, T, D)
     hm, hr = net._buf("hist_mean", Hn, D), net._buf("hist_recent", Hn, D)
 
+    tb16 = bool(getattr(net, "table_bf16", False))
+
     def gather():
-        ops.call("clsr_gather_hist_fwd", net.tables["item"], net.tables["cate"], f["item_history"],
-                 f["item_cate_history"], G * T, f["seq_len"], G, Hn, T, cfg["Di"], cfg["Dc"], 3, hist, hm, hr)
+        if tb16:
+            ops.call("clsr_gather_hist_fwd_h", net.tables["item"], net.tables["cate"], f["item_history"],
+                     f["item_cate_history"], G * T, f["seq_len"], G, Hn, T, cfg["Di"], cfg["Dc"], 3, hist, 0, hm, hr)
+        else:
+            ops.call("clsr_gather_hist_fwd", net.tables["item"], net.tables["cate"], f["item_history"],
+                     f["item_cate_history"], G * T, f["seq_len"], G, Hn, T, cfg["Di"], cfg["Dc"], 3, hist, hm, hr)
 
     t_gather = time_kernel(gather)
     lens = np.asarray(feed["mask"]).sum(1)[::G]
     n_valid = float(lens.sum())
     # bytes_gather_fwd(n) = n*(Di+Dc)*(s_t + s_a) + 2*n*4 per gathered history row
-    gbytes = n_valid * D * (4 + 4) + 2 * n_valid * 4
-    return dict(bound="hbm", kernel="gather_hist_fwd_kernel", achieved=round(gbytes / t_gather / 1e9, 1),
+    gbytes = n_valid * D * ((2 if tb16 else 4) + 4) + 2 * n_valid * 4
+    return dict(bound="hbm", kernel="gather_hist_fwd_h_kernel (bf16 tables, fp32 hist)" if tb16 else "gather_hist_fwd_kernel", achieved=round(gbytes / t_gather / 1e9, 1),
                 peak=8000.0, unit="GB/s", frac=round(gbytes / t_gather / 8e12, 4),
                 bytes_per_launch=gbytes, us_per_launch=round(t_gather * 1e6, 2))
 
@@ -291,16 +297,24 @@ def embedding_rooflines(net, f, cfg, G, feed):
     dev = net.device
     # ---- gather backward: bytes_gather_bwd(n) = n*D*s_a (gradient read) + n*D*4 (fp32 row-gradient write) + 2*n*4
     dhist = torch.randn(Hn * T, D, device=dev) * 1e-3
-    keys_i, perm_i = net._buf("sort.keys.item", n, dtype=torch.int32), net._buf("sort.perm.item", n, dtype=torch.int32)
-    keys_c, perm_c = net._buf("sort.keys.cate", n, dtype=torch.int32), net._buf("sort.perm.cate", n, dtype=torch.int32)
+    nk = n + (cfg["P"] * G if getattr(net, "det_grads", False) and net._det_merged(f) else 0)
+    keys_i, perm_i = net._buf("sort.keys.item", nk, dtype=torch.int32), net._buf("sort.perm.item", nk, dtype=torch.int32)
+    keys_c, perm_c = net._buf("sort.keys.cate", nk, dtype=torch.int32), net._buf("sort.perm.cate", nk, dtype=torch.int32)
     tg = net.tab_grad
+
+    B = cfg["P"] * G
+    dtarget = torch.randn(B, D, device=dev) * 1e-3
+    ne = keys_i.numel()                     # n history slices (+ B target rows when the net chains the two sites)
+    merged = ne > n
 
     def site_rows(d):
         bf = int(d.dtype == torch.bfloat16)
+        tail_i = (1, dtarget.data_ptr(), 0, n, D, 0) if merged else (0,)
+        tail_c = (1, dtarget.data_ptr(), 0, n, D, Di) if merged else (0,)
         return [(d.data_ptr(), 0, 0, 0, keys_i.data_ptr(), perm_i.data_ptr(), f["seq_len"].data_ptr(), tg["item"].data_ptr(), 0,
-                 n, bf, G, T, D, 0, Di, 3, Di, 0, 0),
+                 ne, bf, G, T, D, 0, Di, 3, Di, 0) + tail_i,
                 (d.data_ptr(), 0, 0, 0, keys_c.data_ptr(), perm_c.data_ptr(), f["seq_len"].data_ptr(), tg["cate"].data_ptr(), 0,
-                 n, bf, G, T, D, Di, Dc, 3, Dc, 0, 0)]
+                 ne, bf, G, T, D, Di, Dc, 3, Dc, 0) + tail_c]
 
     def bwd(d):
         rows = site_rows(d)
@@ -317,14 +331,15 @@ def embedding_rooflines(net, f, cfg, G, feed):
             out[tag] = dict(skipped="CLSR_NO_DET_GRADS: the counting-sort + atomics path is not measured here")
             continue
         t = time_kernel(bwd(d))
-        nbytes = n_valid * D * sa + n_valid * D * 4 + 2 * n_valid * 4
-        out[tag] = dict(bound="hbm", kernel="ss_chunks_kernel + ss_borders_kernel (item and category sites in one call: "
-                                            "deterministic segmented sums, csrc/segsum.hip)",
+        # (the target rows' B slices ride in the same lists: counted with the same formula, 4-byte values)
+        nbytes = n_valid * D * sa + n_valid * D * 4 + 2 * n_valid * 4 + (B * D * (4 + 4) + 2 * B * 4 if merged else 0)
+        out[tag] = dict(bound="hbm", kernel="ss_chunks_kernel + ss_borders_kernel (history + target slices of the item and the "
+                                            "category table in one call: deterministic segmented sums, every row stored once; "
+                                            "csrc/segsum.hip)",
                         achieved=round(nbytes / t / 1e9, 1), peak=8000.0, unit="GB/s", frac=round(nbytes / t / 8e12, 4),
                         bytes_per_launch=nbytes, us_per_launch=round(t * 1e6, 2),
                         formula="n*D*%d (gradient read) + n*D*4 (fp32 row-gradient write) + 2*n*4" % sa,
-                        note="the rows are ADDED to (a table has two lookup sites): every row write is preceded by a row "
-                             "read that the formula does not count")
+                        sites_merged=bool(merged))
         clear_grads()
     # ---- bf16 tables + bf16 hist: bytes_gather_fwd(n) = n*D*(2 + 2) + 2*n*4
     try:
@@ -389,6 +404,8 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("CLSR_PRECISION", "fp32"), choices=["fp32", "fp32x3", "bf16"],
                     help="fp32 = the reference's arithmetic (parity mode, headline); bf16 = speed mode: bf16 storage of "
                          "the attention activations + bf16 MFMA with fp32 accumulation, statistics and optimiser")
+    ap.add_argument("--table-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16: embedding tables stored as bf16 (SURVEY 8d 'bf16 tables'); gradients / Adam moments fp32")
     ap.add_argument("--exact-clip", action="store_true",
                     help="time the reference-exact clip mode (histories replicated like the reference iterator: "
                          "tf.clip_by_norm sees the un-summed replica slices) instead of the de-duplicated step")
@@ -465,7 +482,7 @@ def main():
 
     cfg = CONFIGS[args.config]
     wl = Workload(args.config, args.model, args.precision, dedup=not args.exact_clip, lengths=args.lengths, rank=rank,
-                  local_rank=local_rank)
+                  local_rank=local_rank, table_dtype=args.table_dtype)
     net, f, feed = wl.net, wl.f, wl.feed
     use_plans = bool(getattr(net, "use_plans", False))
     P, T, G, big = wl.P, wl.T, wl.G, wl.big
@@ -532,18 +549,24 @@ def main():
         single = world == 1 and dist is None and args.model == "clsr" and args.config == "taobao"
         if single and not args.no_extra:
             # ---- the other precision mode of the same workload (named secondary object; `dtype` stays the headline's)
-            other = "bf16" if args.precision == "fp32" else "fp32"
-            try:
-                w2 = Workload(args.config, args.model, other, dedup=not args.exact_clip, lengths=args.lengths)
-                d2 = w2.run(max(10, args.steps // 2), 3)
-                n2 = max(10, args.steps // 2)
-                modes[other] = dict(ms_per_step=round(d2 * 1e3 / n2, 4), interactions_per_s=round(P * n2 / d2, 1),
-                                    layer0=w2.net.bench_att_layer0(w2.f, time_kernel),
-                                    note=w2.net.precision_note())
-                log("precision %s: %.3f ms/step" % (other, d2 * 1e3 / n2))
-                w2.free()
-            except NotImplementedError as e:
-                modes[other] = dict(skipped=str(e)[:200])
+            for other, td in (("bf16", "fp32"), ("bf16", "bf16"), ("fp32x3", "fp32"), ("fp32", "fp32")):
+                if other == args.precision and td == args.table_dtype:
+                    continue
+                tag = other + ("+bf16_tables" if td == "bf16" else "")
+                try:
+                    w2 = Workload(args.config, args.model, other, dedup=not args.exact_clip, lengths=args.lengths,
+                                  table_dtype=td)
+                    d2 = w2.run(max(10, args.steps // 2), 3)
+                    n2 = max(10, args.steps // 2)
+                    modes[tag] = dict(ms_per_step=round(d2 * 1e3 / n2, 4), interactions_per_s=round(P * n2 / d2, 1),
+                                      note=w2.net.precision_note() + ("; embedding tables stored as bf16 (fp32 gradients and "
+                                                                      "Adam moments)" if td == "bf16" else ""))
+                    if td == "fp32" and other != "fp32x3":
+                        modes[tag]["layer0"] = w2.net.bench_att_layer0(w2.f, time_kernel)
+                    log("precision %s: %.3f ms/step" % (tag, d2 * 1e3 / n2))
+                    w2.free()
+                except NotImplementedError as e:
+                    modes[tag] = dict(skipped=str(e)[:200])
             # ---- reference-exact clip mode (or, under --exact-clip, the de-duplicated default)
             w3 = Workload(args.config, args.model, args.precision, dedup=args.exact_clip, lengths=args.lengths)
             n3 = 5 if not args.exact_clip else 10
@@ -612,7 +635,9 @@ def main():
             "metric": "train interactions/sec @ batch %d seq_len %d" % (P, T), "value": round(value, 1),
             "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+            "dtype": {"fp32": "f32", "fp32x3": "f32 storage, split-bf16 (bf16 x 3) products in the fused encoder tail",
+                      "bf16": "bf16"}[args.precision] + (" (bf16 embedding tables)" if args.table_dtype == "bf16" else ""),
+            "data": "synthetic",
             "config": {"workload": wl.describe() + " (%s lengths)" % args.lengths,
                        "global_batch": world * P, "seq_len": T,
                        "parallelism": "dp%d" % world if world > 1 else "single",
@@ -623,7 +648,7 @@ def main():
                                              "item/cate embedding IndexedSlices (norm of the summed replica slices "
                                              "instead of the un-summed ones), observable only while that clip is "
                                              "active; --exact-clip / extra_workloads times the replicated step",
-                       "precision": args.precision,
+                       "precision": args.precision, "table_dtype": args.table_dtype,
                        "batch_norm": ("sync" if sync_bn else "per-rank") if world > 1 else "single-device"},
             "rows_per_s": round(value * G, 1),
             "roofline": roof, "roofline_mfma": roof_mfma,

@@ -10,7 +10,7 @@
 // in the last bits from run to run.
 //
 // Sort: least-significant-digit radix sort, 8-bit digits, ceil(bits / 8) passes; a pass = histogram, scan and scatter
-// launch for ALL tables of a step (blockIdx.y = table).  (Counting the next pass's digits inside the scatter, with global
+// launch for ALL tables of a step (blockIdx.y = table); a table's list may chain two id sources (history lookup + target rows).  (Counting the next pass's digits inside the scatter, with global
 // integer atomics at the entries' destinations, saved a launch and cost 350 us: a popular id's entries all hit one counter.)  Stable: inside a workgroup's 2 048
 // entries the rank of an entry among the entries with its digit follows the index order (per-wave match masks by ballots,
 // per-segment counts scanned in segment order), workgroups are ordered by the scan.  Equal ids therefore stay in
@@ -34,6 +34,7 @@
 
 struct RsTable {
   const int* ids; long row_stride; int ncols;   // pass 0 source: ids[r * row_stride + c], position = r * ncols + c
+  const int* ids2; long row_stride2; long n1;   // ... and, for positions >= n1, ids2[(position - n1) * row_stride2]
   int* k[2]; int* p[2];                         // ping-pong (key, position) buffers; the LAST pass writes k[1] / p[1] = outputs
   int* hist;                                    // [2][256 * nblocks] digit counters of the current / next pass
   long n; int nblocks; int passes; int first_dst;
@@ -42,6 +43,7 @@ struct RsArgs { RsTable t[CLSR_SORTIDS_MAX]; };
 
 __device__ __forceinline__ int rs_key(const RsTable& t, int pass, long e, int src) {
   if (pass == 0) {
+    if (e >= t.n1) return t.ids2[(e - t.n1) * t.row_stride2];
     const long r = e / t.ncols;
     return t.ids[r * t.row_stride + (e - r * t.ncols)];
   }
@@ -196,10 +198,12 @@ extern "C" int clsr_sort_ids_stable_multi(const clsr_sortids_desc* descs, int n,
   for (int i = 0; i < n; ++i) {
     const clsr_sortids_desc& d = descs[i];
     CLSR_CHECK_ARG(d.ids && d.keys_out && d.perm_out && d.nrows > 0 && d.ncols > 0 && d.bits >= 1 && d.bits <= 31);
-    const long e = d.nrows * d.ncols;
+    CLSR_CHECK_ARG(d.nrows2 >= 0 && (d.nrows2 == 0 || d.ids2));
+    const long e = d.nrows * d.ncols + d.nrows2;
     CLSR_CHECK_SUPPORTED(e < (1L << 31) - RS_EPB);
     RsTable& t = a.t[i];
     t.ids = d.ids; t.row_stride = d.row_stride; t.ncols = d.ncols; t.n = e;
+    t.ids2 = d.ids2; t.row_stride2 = d.row_stride2; t.n1 = d.nrows * d.ncols;
     t.nblocks = (int)((e + RS_EPB - 1) / RS_EPB);
     t.passes = (d.bits + 7) / 8;
     t.k[1] = d.keys_out; t.p[1] = d.perm_out;
@@ -236,7 +240,9 @@ struct SsSite {
   long n; int T; int D; int col0; int C; int recent_k;
   float* grad; int ldg; int gcol0;
   double* sumsq;                  // += sum of the squared slice values (may be NULL)
-  float* bnd; int* meta; double* ssp;   // workspace: chunk-border partials [nchunks][2][Cp], [nchunks][4] ints, [blocks] doubles
+  int assign;                     // row totals are stored, not added
+  const float* src_b; double* sumsq_b; long n1; int ldb; int colb;   // second source (entries with perm >= n1), n1 = 0: none
+  float* bnd; int* meta; double* ssp;   // workspace: chunk-border partials [nchunks][2][Cp], [nchunks][4] ints, [blocks][2] doubles
   int first_block; int nblocks; int first_block_b; int cp; int vw;
 };
 struct SsArgs { SsSite s[CLSR_SEGSUM_MAX]; int n; };
@@ -268,7 +274,7 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
   const long nchunks = (s.n + SS_CHUNK - 1) / SS_CHUNK;
   const long p0 = chunk * SS_CHUNK;
   const int Cp = CP * VW;
-  float local = 0.f;
+  float local = 0.f, local_b = 0.f;
   if (chunk < nchunks) {
     const long cc = s.col0 + (cok ? c : 0);
     const int prev_key = p0 > 0 ? s.keys[p0 - 1] : -1;
@@ -285,12 +291,13 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
         if (cok) *reinterpret_cast<vec_t*>(bnd + (from_prev ? 0 : Cp) + c) = acc;
       } else if (cok) {
         vec_t* g = reinterpret_cast<vec_t*>(s.grad + (long)cur * s.ldg + s.gcol0 + c);
-        *g = *g + acc;
+        *g = s.assign ? acc : *g + acc;
       }
       ++nruns;
     };
     for (long q0 = p0; q0 < pe; q0 += 8) {
       int key[8];
+      bool sec[8];
       vec_t g[8];
       const int knext = q0 + 8 < pe ? s.keys[q0 + 8] : -1;
 #pragma unroll
@@ -299,9 +306,16 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
         const bool ok = p < pe;
         key[k] = ok ? s.keys[p] : -1;
         const int pos = ok ? s.perm[p] : 0;
-        vec_t v = ss_ld<VW>(s.src, s.src_bf16, (long)pos * s.D + cc);
-        if (s.src2) v += ss_ld<VW>(s.src2, s.src_bf16, (long)pos * s.D + cc);
-        if (s.dmean || s.drecent) {
+        const bool second = s.n1 > 0 && pos >= s.n1;          // (uniform inside the thread group)
+        sec[k] = second;
+        vec_t v;
+        if (second) {
+          v = *reinterpret_cast<const vec_t*>(s.src_b + (long)(pos - s.n1) * s.ldb + s.colb + (cok ? c : 0));
+        } else {
+          v = ss_ld<VW>(s.src, s.src_bf16, (long)pos * s.D + cc);
+          if (s.src2) v += ss_ld<VW>(s.src2, s.src_bf16, (long)pos * s.D + cc);
+        }
+        if (!second && (s.dmean || s.drecent)) {
           const int h = pos / s.T, t = pos - h * s.T;
           const int len = s.seq_len[(long)h * s.len_stride];
           if (t < len) {
@@ -315,14 +329,17 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
       // the gradient rows of all eight entries' ids are requested NOW, whether or not a run ends there: a run that ends
       // inside the chunk is added to its row with a read-modify-write, and one dependent row read per run end, one after
       // the other along the walk, made this launch 110 us for 640 chunks
+      // (assign: the rows are known to be zero and this call is their only writer -- no row read at all)
       vec_t gv[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k)
-        gv[k] = *reinterpret_cast<const vec_t*>(s.grad + (long)(key[k] < 0 ? 0 : key[k]) * s.ldg + s.gcol0 + (cok ? c : 0));
+        gv[k] = s.assign ? vec_t(0.f)
+                         : *reinterpret_cast<const vec_t*>(s.grad + (long)(key[k] < 0 ? 0 : key[k]) * s.ldg + s.gcol0 + (cok ? c : 0));
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         if (key[k] < 0) continue;
-        local += ss_sq(g[k]);
+        if (sec[k]) local_b += ss_sq(g[k]);
+        else local += ss_sq(g[k]);
         if (key[k] != cur) {
           if (cur < 0) first_key = key[k];
           cur = key[k];
@@ -362,7 +379,12 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
   }
   if (s.sumsq) {
     const double tot = block256_sum_d((double)local, red);
-    if (threadIdx.x == 0) s.ssp[local_block] = tot;
+    if (threadIdx.x == 0) s.ssp[2 * local_block] = tot;
+  }
+  if (s.sumsq_b) {
+    __syncthreads();
+    const double tot = block256_sum_d((double)local_b, red);
+    if (threadIdx.x == 0) s.ssp[2 * local_block + 1] = tot;
   }
 }
 
@@ -429,16 +451,19 @@ __device__ __forceinline__ void ss_borders(const SsSite& s, const int local_bloc
       }
       if (cok && slot == 0) {
         vec_t* g = reinterpret_cast<vec_t*>(s.grad + (long)key * s.ldg + s.gcol0 + c);
-        *g = *g + tot;
+        *g = s.assign ? tot : *g + tot;
       }
     }
   }
-  if (s.sumsq && local_block == 0 && wave == 0) {
-    double t = 0.0;
-    for (int b = lane; b < s.nblocks; b += 64) t += s.ssp[b];
-    double tot = 0.0;
-    for (int l = 0; l < 64; ++l) tot += __shfl(t, l, 64);
-    if (lane == 0) *s.sumsq += tot;
+  if (local_block == 0 && wave < 2) {        // wave 0: the first source's squared norms, wave 1: the second source's
+    double* dst = wave == 0 ? s.sumsq : s.sumsq_b;
+    if (dst) {
+      double t = 0.0;
+      for (int b = lane; b < s.nblocks; b += 64) t += s.ssp[2 * b + wave];
+      double tot = 0.0;
+      for (int l = 0; l < 64; ++l) tot += __shfl(t, l, 64);
+      if (lane == 0) *dst += tot;
+    }
   }
 }
 
@@ -467,7 +492,7 @@ static long ss_site_bytes(long n, int cp, int vw, int* blocks) {
   b = (b + 15) & ~15L;
   b += nchunks * 4 * (long)sizeof(int);
   b = (b + 15) & ~15L;
-  b += (long)nb * sizeof(double);
+  b += (long)nb * 2 * sizeof(double);
   return (b + 15) & ~15L;
 }
 
@@ -503,6 +528,9 @@ extern "C" int clsr_segsum_multi(const clsr_segsum_desc* descs, int n, void* wor
     s.keys = d.keys; s.perm = d.perm; s.seq_len = d.seq_len; s.len_stride = d.len_stride;
     s.n = d.n; s.T = d.T > 0 ? d.T : 1; s.D = d.D; s.col0 = d.col0; s.C = d.C; s.recent_k = d.recent_k;
     s.grad = d.grad; s.ldg = d.ldg; s.gcol0 = d.gcol0; s.sumsq = d.sumsq;
+    s.assign = d.assign; s.src_b = d.src_b; s.sumsq_b = d.sumsq_b; s.n1 = d.src_b ? d.n1 : 0; s.ldb = d.ldb; s.colb = d.colb;
+    CLSR_CHECK_ARG(!d.src_b || (d.n1 > 0 && d.ldb > 0));
+    CLSR_CHECK_SUPPORTED(!d.src_b || s.vw == 1 || (d.ldb % 4 == 0 && d.colb % 4 == 0 && ((uintptr_t)d.src_b % 16) == 0));
     int nb;
     const long bytes = ss_site_bytes(d.n, s.cp, s.vw, &nb);
     const long nchunks = (d.n + SS_CHUNK - 1) / SS_CHUNK;

@@ -1706,6 +1706,7 @@ class CLSRNet(object):
 
     def _train_step(self, f, apply):
         hp, P, Gd = self.hp, self.P, self.Gd
+        self._cur_feed = f
         B, T = f["B"], f["T"]
         G = self.G_train if self.dedup else 1
         if B % G:
@@ -1912,14 +1913,14 @@ class CLSRNet(object):
             # streams that are idle by now instead of one after the other
             fork = self._fork_point()
             with self._branch("@lt" if self.split_emb_grad else "@main", after=fork):
-                self._hist_grad_sorted(dhist, dM, dR, Hn, T, seq_len, ls, ss, only="cate", dhist2=dhist_lt)
+                self._hist_grad_sorted(dhist, dM, dR, Hn, T, seq_len, ls, ss, only="cate", dhist2=dhist_lt, dtarget=dtarget)
                 if not scat_early:
                     self._scatter_cate_targets(f, dtarget, B)
                 self._dp_hook("table_ready", "cate")
             if not scat_early:
                 with self._branch("@aux" if self.split_emb_grad else "@main", after=fork):
                     self._scatter_user_item_rows(f, dul, dushort, dtarget, Hn, B, hs)
-            self._hist_grad_sorted(dhist, dM, dR, Hn, T, seq_len, ls, ss, only="item", dhist2=dhist_lt)
+            self._hist_grad_sorted(dhist, dM, dR, Hn, T, seq_len, ls, ss, only="item", dhist2=dhist_lt, dtarget=dtarget)
             self._join(but="@dense")
             self._dp_hook("table_ready", "item")
         else:
@@ -1971,27 +1972,39 @@ class CLSRNet(object):
             o += 1 << b
         ops.sort_ids_multi(rows)
 
+    def _det_merged(self, f):
+        """CLSR graph: the target rows' ids ride behind the history lookup's ids in ONE sorted list per table (item,
+        category), so that the segmented sums write every gradient row exactly once -- stored, not added: no row read, no
+        second launch for the target site.  -> {table: (feed key of the target ids, rows)} or {}"""
+        if type(self) is not CLSRNet or "user_long" not in self.tables:
+            return {}
+        return {"item": ("items", f["B"]), "cate": ("cates", f["B"])}
+
     def _det_sites(self, f):
-        """lookup sites besides the two history lookups whose ids are sorted for the deterministic segmented sums:
-        (list name, feed key, vocabulary, rows, row stride)"""
+        """row-level lookup sites with a sorted list of their own: (list name, feed key, vocabulary, rows, row stride)"""
         if type(self) is not CLSRNet or "user_long" not in self.tables:
             return ()
-        B = f["B"]
         G = self.G_train if self.dedup else 1
         hs = 1 if f.get("compact") else G
-        return (("item_t", "items", self.dims["Vi"], B, 1), ("cate_t", "cates", self.dims["Vc"], B, 1),
-                ("user", "users", self.dims["Vu"], B // G, hs))
+        return (("user", "users", self.dims["Vu"], f["B"] // G, hs),)
 
     def _sort_ids_stable(self, f, Hn, T, hs):
         """Stable radix sort (ascending ids, equal ids in slice order) of the ids of every lookup site of the step: the
-        two history lookups and -- CLSR graph -- the target item / category rows and the user rows: one launch set."""
+        two history lookups (CLSR graph: each followed by the target rows' ids of the same table) and the user rows: one
+        launch set."""
         n = Hn * T
         rows, total = [], 0
+        merged = self._det_merged(f)
         for name, fkey, V, _, _, _ in self._sort_tables():
-            keys = self._buf("sort.keys." + name, n, dtype=torch.int32)
-            perm = self._buf("sort.perm." + name, n, dtype=torch.int32)
-            rows.append((f[fkey].data_ptr(), keys.data_ptr(), perm.data_ptr(), Hn, hs * T, T, max(1, (V - 1).bit_length())))
-            total += n
+            extra = merged.get(name)
+            ne = n + (extra[1] if extra else 0)
+            keys = self._buf("sort.keys." + name, ne, dtype=torch.int32)
+            perm = self._buf("sort.perm." + name, ne, dtype=torch.int32)
+            row = (f[fkey].data_ptr(), keys.data_ptr(), perm.data_ptr(), Hn, hs * T, T, max(1, (V - 1).bit_length()))
+            if extra:
+                row += (f[extra[0]].data_ptr(), extra[1], 1)
+            rows.append(row)
+            total += ne
         for name, fkey, V, nr, stride in self._det_sites(f):
             keys = self._buf("sort.keys." + name, nr, dtype=torch.int32)
             perm = self._buf("sort.perm." + name, nr, dtype=torch.int32)
@@ -2005,11 +2018,12 @@ class CLSRNet(object):
         ops.segsum_multi(rows, ws)
 
     def _site_row(self, name, src, ld, col0, C, n, grad, sumsq):
-        """segmented-sum descriptor of a row-level lookup site (targets / users): slice e = row perm[e] of ``src``"""
+        """segmented-sum descriptor of a row-level lookup site (users): slice e = row perm[e] of ``src``; the table has no
+        other lookup site, its gradient rows are zero: the totals are stored"""
         keys = self._buf("sort.keys." + name, n, dtype=torch.int32)
         perm = self._buf("sort.perm." + name, n, dtype=torch.int32)
         return (src.data_ptr(), 0, 0, 0, keys.data_ptr(), perm.data_ptr(), 0, grad.data_ptr(), sumsq.data_ptr(), n, 0, 0, 1,
-                ld, col0, C, 1, grad.shape[1], 0, 0)
+                ld, col0, C, 1, grad.shape[1], 0, 1)
 
     def _scatter_user_item_rows(self, f, dul, dushort, dtarget, Hn, B, hs):
         """User rows (long / short table) and the target items' rows: ONE launch, blockIdx.y = lookup site (``None``:
@@ -2022,9 +2036,9 @@ class CLSRNet(object):
                 rows.append(self._site_row("user", dul, Du, 0, Du, Hn, tg["user_long"], ss[6:]))
             if dushort is not None:
                 rows.append(self._site_row("user", dushort, Du, 0, Du, Hn, tg["user_short"], ss[7:]))
-            if dtarget is not None:
-                rows.append(self._site_row("item_t", dtarget, D, 0, Di, B, tg["item"], ss[2:]))
-            self._segsum("rows%d%d%d" % (dul is not None, dushort is not None, dtarget is not None), rows)
+            # (the target rows' sums are part of the history lookups' lists: _hist_grad_sorted)
+            if rows:
+                self._segsum("rows%d%d" % (dul is not None, dushort is not None), rows)
             if dul is not None:
                 self._dp_hook("table_ready", "user_long")
             if dushort is not None:
@@ -2056,14 +2070,13 @@ class CLSRNet(object):
                 self._scatter_cate_targets(f, dtarget, B)
 
     def _scatter_cate_targets(self, f, dtarget, B):
-        if self.det_grads and self._det_sites(f):
-            self._segsum("cate_t", [self._site_row("cate_t", dtarget, self.D, self.Di, self.Dc, B, self.tab_grad["cate"],
-                                                   self.sumsq_tab[3:])])
+        if self.det_grads and self._det_merged(f):
+            return          # (summed with the category history lookup: _hist_grad_sorted)
         else:
             call("clsr_scatter_add_rows", dtarget, self.D, self.Di, f["cates"], 1, B, self.Dc, self.tab_grad["cate"],
                  self.sumsq_tab[3:])
 
-    def _hist_grad_sorted(self, dhist, dM, dR, Hn, T, seq_len, ls, ss, only=None, dhist2=None):
+    def _hist_grad_sorted(self, dhist, dM, dR, Hn, T, seq_len, ls, ss, only=None, dhist2=None, dtarget=None):
         """IndexedSlices of the history lookups -> dense gradient tables via segmented sums over the
         sorted ids (no float atomics on hot rows).  ``only``: one table ("item" / "cate").  Not bit-reproducible from run
         to run: the counting sort (csrc/sparse.hip) leaves the order INSIDE a run of equal ids to its cursor claims, and
@@ -2073,15 +2086,22 @@ class CLSRNet(object):
         k = self.hp.contrastive_recent_k
         if self.det_grads:
             rows = []
+            merged = self._det_merged(self._cur_feed) if dtarget is not None else {}
             for name, _, V, col0, C, slot in self._sort_tables():
                 if only is not None and name != only:
                     continue
-                keys = self._buf("sort.keys." + name, n, dtype=torch.int32)
-                perm = self._buf("sort.perm." + name, n, dtype=torch.int32)
+                ne = n + (merged[name][1] if name in merged else 0)
+                keys = self._buf("sort.keys." + name, ne, dtype=torch.int32)
+                perm = self._buf("sort.perm." + name, ne, dtype=torch.int32)
                 ptr = lambda t: 0 if t is None else t.data_ptr()
-                rows.append((dhist.data_ptr(), ptr(dhist2), ptr(dM), ptr(dR), keys.data_ptr(), perm.data_ptr(),
-                             seq_len.data_ptr(), self.tab_grad[name].data_ptr(), ss[slot:].data_ptr(), n,
-                             int(dhist.dtype == torch.bfloat16), ls, T, self.D, col0, C, k, C, 0, 0))
+                row = (dhist.data_ptr(), ptr(dhist2), ptr(dM), ptr(dR), keys.data_ptr(), perm.data_ptr(),
+                       seq_len.data_ptr(), self.tab_grad[name].data_ptr(), ss[slot:].data_ptr(), ne,
+                       int(dhist.dtype == torch.bfloat16), ls, T, self.D, col0, C, k, C, 0)
+                if name in merged:
+                    # second source = the target rows' gradients [B, D] (same column slice), their squared norms in the
+                    # target site's slot (2 item, 3 category); every row is written once: stored
+                    row += (1, dtarget.data_ptr(), ss[slot + 2:].data_ptr(), n, self.D, col0)
+                rows.append(row)
             self._segsum("hist." + (only or "all"), rows)
             return
         for name, _, V, col0, C, slot in self._sort_tables():

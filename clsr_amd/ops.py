@@ -333,7 +333,7 @@ class TableDesc(ctypes.Structure):
 class SortIdsDesc(ctypes.Structure):
     """ctypes mirror of clsr_sortids_desc (include/clsr_hip.h)."""
     _fields_ = [("ids", _P), ("keys_out", _P), ("perm_out", _P), ("counts", _P), ("nrows", _L), ("row_stride", _L),
-                ("ncols", _I), ("bits", _I)]
+                ("ncols", _I), ("bits", _I), ("ids2", _P), ("nrows2", _L), ("row_stride2", _L)]
 
 
 def sort_ids_multi(rows):
@@ -348,14 +348,17 @@ def sort_ids_multi(rows):
 
 
 def sort_ids_stable_multi(rows, workspace):
-    """clsr_sort_ids_stable_multi on a list of (ids, keys_out, perm_out, nrows, row_stride, ncols, bits) tuples
-    (pointers as integers); ``workspace``: a uint8 tensor of clsr_sort_ids_stable_workspace_bytes(total entries, tables)."""
+    """clsr_sort_ids_stable_multi on a list of (ids, keys_out, perm_out, nrows, row_stride, ncols, bits[, ids2, nrows2,
+    row_stride2]) tuples (pointers as integers); ``workspace``: a uint8 tensor of
+    clsr_sort_ids_stable_workspace_bytes(total entries, tables)."""
     assert ctypes.sizeof(SortIdsDesc) == query("clsr_sizeof_sortids_desc")
     arr = (SortIdsDesc * len(rows))()
     keep_alive(arr)
-    for d, (ids, ko, po, nrows, stride, ncols, bits) in zip(arr, rows):
+    for d, row in zip(arr, rows):
+        ids, ko, po, nrows, stride, ncols, bits = row[:7]
         d.ids, d.keys_out, d.perm_out, d.counts = ids, ko, po, None
         d.nrows, d.row_stride, d.ncols, d.bits = nrows, stride, ncols, bits
+        d.ids2, d.nrows2, d.row_stride2 = row[7:10] if len(row) > 7 else (None, 0, 0)
     call("clsr_sort_ids_stable_multi", ctypes.addressof(arr), len(rows), workspace, workspace.numel())
 
 
@@ -363,14 +366,15 @@ class SegsumDesc(ctypes.Structure):
     """ctypes mirror of clsr_segsum_desc (include/clsr_hip.h)."""
     _fields_ = [("src", _P), ("src2", _P), ("dmean", _P), ("drecent", _P), ("keys", _P), ("perm", _P), ("seq_len", _P),
                 ("grad", _P), ("sumsq", _P), ("n", _L), ("src_bf16", _I), ("len_stride", _I), ("T", _I), ("D", _I),
-                ("col0", _I), ("C", _I), ("recent_k", _I), ("ldg", _I), ("gcol0", _I), ("pad_", _I)]
+                ("col0", _I), ("C", _I), ("recent_k", _I), ("ldg", _I), ("gcol0", _I), ("assign", _I),
+                ("src_b", _P), ("sumsq_b", _P), ("n1", _L), ("ldb", _I), ("colb", _I)]
 
 
 def segsum_descs(rows):
     """ctypes array of clsr_segsum_desc from field tuples in the order of SegsumDesc._fields_ (pointers as integers)."""
     assert ctypes.sizeof(SegsumDesc) == query("clsr_sizeof_segsum_desc")
     arr = (SegsumDesc * len(rows))()
-    for d, row in zip(arr, rows):
+    for d, row in zip(arr, rows):        # (short tuples: the trailing fields -- assign, second source -- stay zero)
         for (fname, _), val in zip(SegsumDesc._fields_, row):
             setattr(d, fname, val)
     return arr

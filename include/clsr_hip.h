@@ -61,6 +61,9 @@ int clsr_scatter_add_rows(const float* src, int ld_src, int col0, const int* idx
 typedef struct clsr_sortids_desc {
   const int* ids; int* keys_out; int* perm_out; int* counts;   /* counts: (1 << bits) ints, ZERO on entry */
   long nrows; long row_stride; int ncols; int bits;
+  /* clsr_sort_ids_stable_multi only: a SECOND id source appended to the first -- entries nrows*ncols + r (r < nrows2) are
+   * ids2[r * row_stride2] (the target rows' ids behind a history lookup's: one list per embedding table) */
+  const int* ids2; long nrows2; long row_stride2;
 } clsr_sortids_desc;
 int clsr_sizeof_sortids_desc(void);
 int clsr_sort_ids_bits(long vocab);
@@ -100,7 +103,13 @@ int clsr_sort_ids_stable_multi(const clsr_sortids_desc* descs_host, int n, void*
 typedef struct clsr_segsum_desc {
   const void* src; const void* src2; const float* dmean; const float* drecent;
   const int* keys; const int* perm; const int* seq_len; float* grad; double* sumsq;
-  long n; int src_bf16; int len_stride; int T; int D; int col0; int C; int recent_k; int ldg; int gcol0; int pad_;
+  long n; int src_bf16; int len_stride; int T; int D; int col0; int C; int recent_k; int ldg; int gcol0;
+  /* assign != 0: every row total is STORED (the rows are known to be zero and no other site writes the table: no row
+   * read).  Second source (n1 > 0): entries with perm >= n1 are rows of src_b -- slice = src_b[perm - n1, colb : colb + C]
+   * (fp32, row stride ldb), their squared norms go to sumsq_b: the target rows of a table's second lookup site in the
+   * same sorted list as the history lookup's (clsr_sortids_desc.ids2) */
+  int assign;
+  const float* src_b; double* sumsq_b; long n1; int ldb; int colb;
 } clsr_segsum_desc;
 int clsr_sizeof_segsum_desc(void);
 long clsr_segsum_workspace_bytes(const clsr_segsum_desc* descs_host, int n);

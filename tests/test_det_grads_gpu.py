@@ -20,14 +20,19 @@ DEV = "cuda"
 
 
 def _stable_sort(tables):
-    """tables: list of (ids tensor [nrows, row_stride] int32 on the device, nrows, ncols, vocab)"""
+    """tables: list of (ids tensor [nrows, row_stride] int32 on the device, nrows, ncols, vocab[, second id tensor [n2]])"""
     rows, outs, total = [], [], 0
-    for ids, nrows, ncols, V in tables:
-        n = nrows * ncols
+    for tab in tables:
+        ids, nrows, ncols, V = tab[:4]
+        ids2 = tab[4] if len(tab) > 4 else None
+        n = nrows * ncols + (ids2.numel() if ids2 is not None else 0)
         k = torch.full((n,), -7, dtype=torch.int32, device=DEV)
         p = torch.full((n,), -7, dtype=torch.int32, device=DEV)
         outs.append((k, p))
-        rows.append((ids.data_ptr(), k.data_ptr(), p.data_ptr(), nrows, ids.stride(0), ncols, max(1, (V - 1).bit_length())))
+        row = (ids.data_ptr(), k.data_ptr(), p.data_ptr(), nrows, ids.stride(0), ncols, max(1, (V - 1).bit_length()))
+        if ids2 is not None:
+            row += (ids2.data_ptr(), ids2.numel(), 1)
+        rows.append(row)
         total += n
     ws = torch.empty(query("clsr_sort_ids_stable_workspace_bytes", total, len(rows)), dtype=torch.uint8, device=DEV)
     ops.sort_ids_stable_multi(rows, ws)
@@ -144,6 +149,48 @@ def test_deterministic_row_level_sites():
     exp = torch.zeros(V, C, dtype=torch.float64).index_add_(0, idx, src.double()[:, col0:col0 + C])
     assert float((grad.double().cpu() - exp).abs().max()) <= 1e-5 * float(exp.abs().max())
     assert abs(float(ss) - float((src[:, col0:col0 + C].double() ** 2).sum())) <= 1e-6 * float(ss)
+
+
+@pytest.mark.parametrize("Hn,T,B,Di,Dc,V", [(64, 50, 320, 32, 8, 500), (4096, 50, 20480, 32, 8, 64138), (128, 50, 640, 96, 32, 1_000_000)])
+def test_history_and_target_sites_in_one_list_stored_once(Hn, T, B, Di, Dc, V):
+    """The CLSR step's form: the target rows' ids ride behind the history lookup's ids in ONE sorted list (second id source
+    of the sort), the segmented sums take the target rows' slices from a second gradient matrix, keep the two sites' squared
+    norms apart, and STORE every row total (assign: the rows start as zeros, garbage here to prove they are not read)."""
+    g = torch.Generator().manual_seed(B + V % 13)
+    D, k, n = Di + Dc, 3, Hn * T
+    lens = torch.randint(1, T + 1, (Hn,), generator=g)
+    ii = ((torch.rand(n, generator=g).pow(3.0) * (V - 1)).long()).view(Hn, T)
+    it = (torch.rand(B, generator=g).pow(3.0) * (V - 1)).long()
+    d_ii, d_it = ii.int().to(DEV), it.int().to(DEV)
+    (ks, ps), = _stable_sort([(d_ii, Hn, T, V, d_it)])
+    allids = torch.cat([ii.reshape(-1), it])
+    ek, ep = torch.sort(allids, stable=True)
+    assert torch.equal(ks.cpu().long(), ek) and torch.equal(ps.cpu().long(), ep)
+    dh = torch.randn(Hn, T, D, generator=g)
+    dm, dr = torch.randn(Hn, D, generator=g), torch.randn(Hn, D, generator=g)
+    dt = torch.randn(B, D, generator=g)
+    a, m_, r_, t_ = dh.to(DEV), dm.to(DEV), dr.to(DEV), dt.to(DEV)
+    d_len = lens.int().to(DEV)
+    grad = torch.full((V, Di), 777.0, device=DEV)          # (assign mode never reads the rows)
+    ss = torch.zeros(4, dtype=torch.float64, device=DEV)
+    rows = [(a.data_ptr(), 0, m_.data_ptr(), r_.data_ptr(), ks.data_ptr(), ps.data_ptr(), d_len.data_ptr(), grad.data_ptr(),
+             ss[0:].data_ptr(), n + B, 0, 1, T, D, 0, Di, k, Di, 0, 1, t_.data_ptr(), ss[2:].data_ptr(), n, D, 0)]
+    _segsum(rows, None)
+    m = (torch.arange(T)[None, :] < lens[:, None]).double()
+    pos = torch.flip(torch.cumsum(torch.flip(m, [1]), 1), [1])
+    rec = ((pos >= 1) & (pos <= k)).double()
+    gfull = dh.double() + m[..., None] * (dm.double() / m.sum(1, keepdim=True))[:, None, :] \
+        + rec[..., None] * (dr.double() / rec.sum(1, keepdim=True))[:, None, :]
+    exp = torch.zeros(V, Di, dtype=torch.float64).index_add_(0, ii.reshape(-1), gfull[..., :Di].reshape(-1, Di))
+    exp.index_add_(0, it, dt.double()[:, :Di])
+    touched = torch.zeros(V, dtype=torch.bool)
+    touched[allids] = True
+    got = grad.double().cpu()
+    assert float((got[touched] - exp[touched]).abs().max()) <= 2e-6 * float(exp.abs().max()) + 1e-5
+    assert bool((got[~touched] == 777.0).all()), "rows without a slice are not written"
+    assert abs(float(ss[0]) - float((gfull[..., :Di] ** 2).sum())) <= 1e-5 * float(ss[0])
+    assert abs(float(ss[2]) - float((dt.double()[:, :Di] ** 2).sum())) <= 1e-5 * float(ss[2])
+    assert float(ss[1]) == 0.0 and float(ss[3]) == 0.0
 
 
 def test_training_step_is_bit_reproducible(golden_dir, golden_hparams):
