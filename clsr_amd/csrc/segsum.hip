@@ -26,6 +26,7 @@
 #include "clsr_hip.h"
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 // ===================================================================================================== stable radix sort
 #define RS_EPB 2048                 // entries per workgroup
@@ -50,7 +51,7 @@ __device__ __forceinline__ int rs_key(const RsTable& t, int pass, long e, int sr
   return t.k[src][e];
 }
 
-// digit counts of a pass: hist[digit * nblocks + block]
+// digit counts of a pass: hist[block * 256 + digit]
 __global__ void __launch_bounds__(256) rs_hist_kernel(RsArgs a, int pass) {
   __shared__ int h[256];
   const RsTable& t = a.t[blockIdx.y];
@@ -66,53 +67,64 @@ __global__ void __launch_bounds__(256) rs_hist_kernel(RsArgs a, int pass) {
     if (e < t.n) atomicAdd(&h[(rs_key(t, pass, e, src) >> shift) & 255], 1);
   }
   __syncthreads();
-  t.hist[threadIdx.x * t.nblocks + blockIdx.x] = h[threadIdx.x];
+  t.hist[blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
 }
 
-// exclusive scan of the 256 * nblocks counters of one table, in place (one workgroup per table; the loads of up to eight
-// 4096-counter tiles are in flight together: one memory latency per eight tiles instead of one per tile)
+// exclusive scan of the 256 * nblocks counters of one table (block-major: hist[block * 256 + digit]) in digit-major
+// order, in place: offset[b][d] = sum of the totals of the digits below d + the counts of digit d in the blocks before b.
+// One workgroup of 1024 threads per table: thread (q, d) owns digit d of a quarter of the blocks; its counters are read
+// eight at a time (independent loads in flight), the 4 x 256 partial sums and the 256 digit totals are scanned in LDS,
+// and a second walk writes the running offsets.  (Tiled scans with barriers per tile, and per-digit wave scans, both
+// took 80-140 us per pass for 28 000 counters: chains of dependent trips to memory.)
 __global__ void __launch_bounds__(1024) rs_scan_kernel(RsArgs a, int pass) {
-  __shared__ int wtot[16];
-  __shared__ int carry_s;
+  __shared__ int psum[4][256], dbase[256];
   const RsTable& t = a.t[blockIdx.x];
   if (pass >= t.passes) return;
   int* c = t.hist;
-  const int nb = 256 * t.nblocks;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) carry_s = 0;
+  const int nbk = t.nblocks;
+  const int d = threadIdx.x & 255, q = threadIdx.x >> 8;
+  const int nbq = (nbk + 3) >> 2;
+  const int b0 = q * nbq, b1 = min(nbk, b0 + nbq);
+  int s = 0;
+  for (int b = b0; b < b1; b += 8) {
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = b + u < b1 ? c[(b + u) * 256 + d] : 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  psum[q][d] = s;
   __syncthreads();
-  for (int base0 = 0; base0 < nb; base0 += 8 * 4096) {
-    int v[8][4];
+  if (threadIdx.x < 64) {      // exclusive scan of the 256 digit totals: 4 per lane
+    const int lane = threadIdx.x;
+    int v[4], mine = 0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int i = base0 + q * 4096 + 4 * threadIdx.x;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[q][k] = i + k < nb ? c[i + k] : 0;
+    for (int k = 0; k < 4; ++k) {
+      const int dd = 4 * lane + k;
+      v[k] = psum[0][dd] + psum[1][dd] + psum[2][dd] + psum[3][dd];
+      mine += v[k];
     }
+    int inc = mine;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int i = base0 + q * 4096 + 4 * threadIdx.x;
-      if (base0 + q * 4096 >= nb) break;          // (uniform)
-      const int mine = v[q][0] + v[q][1] + v[q][2] + v[q][3];
-      int inc = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int x = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += x;
+    }
+    int run = inc - mine;
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int x = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += x;
-      }
-      if (lane == 63) wtot[wave] = inc;
-      __syncthreads();
-      int before = carry_s;
-      for (int w = 0; w < wave; ++w) before += wtot[w];
-      int run = before + inc - mine;
+    for (int k = 0; k < 4; ++k) { dbase[4 * lane + k] = run; run += v[k]; }
+  }
+  __syncthreads();
+  int run = dbase[d];
+  for (int qq = 0; qq < q; ++qq) run += psum[qq][d];
+  for (int b = b0; b < b1; b += 8) {
+    int v[8];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (i + k < nb) c[i + k] = run;
-        run += v[q][k];
-      }
-      __syncthreads();
-      if (threadIdx.x == 1023) carry_s = run;
-      __syncthreads();
+    for (int u = 0; u < 8; ++u) v[u] = b + u < b1 ? c[(b + u) * 256 + d] : 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (b + u < b1) c[(b + u) * 256 + d] = run;
+      run += v[u];
     }
   }
 }
@@ -127,7 +139,7 @@ __global__ void __launch_bounds__(256) rs_scatter_kernel(RsArgs a, int pass) {
   const int* hist = t.hist;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int e = threadIdx.x; e < RS_SEG * 256; e += 256) (&segcnt[0][0])[e] = 0;
-  gbase[threadIdx.x] = hist[threadIdx.x * t.nblocks + blockIdx.x];
+  gbase[threadIdx.x] = hist[blockIdx.x * 256 + threadIdx.x];
   __syncthreads();
   const long e0 = (long)blockIdx.x * RS_EPB;
   const int shift = 8 * pass;
@@ -233,7 +245,9 @@ extern "C" int clsr_sort_ids_stable_multi(const clsr_sortids_desc* descs, int n,
 // ===================================================================================================== segmented sums
 // One lookup SITE of a launch: rows `key` of `grad` receive the sums of the slices  g[e, :] = src[pos(e), col0 : col0 + C]
 // (+ src2, + the mean / recent-k terms of the history prologue when dmean / drecent are given: pos = h * T + t).
+#ifndef SS_CHUNK
 #define SS_CHUNK 32                 // sorted entries per thread group
+#endif
 struct SsSite {
   const void* src; const void* src2; int src_bf16; const float* dmean; const float* drecent;
   const int* keys; const int* perm; const int* seq_len; int len_stride;
@@ -434,9 +448,16 @@ __device__ __forceinline__ void ss_borders(const SsSite& s, const int local_bloc
         L += nw + (((bm >> nw) & 1ull) ? 1 : 0);
         break;
       }
-      vec_t acc = vec_t(0.f);
-      for (long k = slot; k < L; k += S)
-        if (cok) acc += *reinterpret_cast<const vec_t*>(s.bnd + (chunk + 1 + k) * 2 * Cp + c);
+      // (four partials of a slot in flight: the loop is a chain of dependent row reads otherwise; fixed association)
+      vec_t a4[4] = {vec_t(0.f), vec_t(0.f), vec_t(0.f), vec_t(0.f)};
+      for (long k = slot; k < L; k += 4 * S) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long ku = k + (long)u * S;
+          if (cok && ku < L) a4[u] += *reinterpret_cast<const vec_t*>(s.bnd + (chunk + 1 + ku) * 2 * Cp + c);
+        }
+      }
+      const vec_t acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
       // the head chunk's own share (its last-run partial: slot 1), then the lane slots in order
       vec_t tot = cok ? *reinterpret_cast<const vec_t*>(s.bnd + chunk * 2 * Cp + Cp + c) : vec_t(0.f);
       for (int j = 0; j < S; ++j) {

@@ -79,6 +79,66 @@ def main():
             print("gather_hist_fwd %-14s rows %dB+%dB: %8.1f us  %.0f GB/s algorithmic (%.1f%% of 8 TB/s)" % (
                 name, Di * 4, Dc * 4, t, nbytes / t / 1e3, nbytes / t / 1e3 / 80))
             del it, ct
+    if which == "embed":
+        # the other HBM-bound embedding kernels on the 100M-item catalogue (BASELINE configs[4]: rows 384 B + 128 B, uniform
+        # ids): deterministic segmented sums of the history + target slices (gather backward), lazy-Adam row update, and
+        # the bf16-table forms -- >= 22 launches each, for rocprofv3 --kernel-trace / --pmc (scripts/prof_embed.sh)
+        Vi, Vc, Di, Dc, B = 100_000_000, 10000, 96, 32, Hn * G
+        D, n = Di + Dc, Hn * T
+        gi, gc = torch.zeros(Vi, Di, device=dev), torch.zeros(Vc, Dc, device=dev)      # gradient tables (touches the pages)
+        ii = torch.randint(1, Vi, (Hn, T), device=dev, dtype=torch.int32)
+        ci = torch.randint(1, Vc, (Hn, T), device=dev, dtype=torch.int32)
+        it, ct = torch.randint(1, Vi, (B,), device=dev, dtype=torch.int32), torch.randint(1, Vc, (B,), device=dev, dtype=torch.int32)
+        ln = torch.full((Hn,), T, device=dev, dtype=torch.int32)
+        keys = [torch.empty(n + B, dtype=torch.int32, device=dev) for _ in range(2)]
+        perm = [torch.empty(n + B, dtype=torch.int32, device=dev) for _ in range(2)]
+        rows = [(ii.data_ptr(), keys[0].data_ptr(), perm[0].data_ptr(), Hn, T, T, 27, it.data_ptr(), B, 1),
+                (ci.data_ptr(), keys[1].data_ptr(), perm[1].data_ptr(), Hn, T, T, 14, ct.data_ptr(), B, 1)]
+        wss = torch.empty(query("clsr_sort_ids_stable_workspace_bytes", 2 * (n + B), 2), dtype=torch.uint8, device=dev)
+        t = timeit(lambda: ops.sort_ids_stable_multi(rows, wss), iters=5)
+        print("stable radix sort of 2 x %d ids (27 / 14 bits): %8.1f us" % (n + B, t))
+        dhist, dtarget = torch.randn(n, D, device=dev) * 1e-3, torch.randn(B, D, device=dev) * 1e-3
+        for tag, d, sa in (("fp32 d(hist)", dhist, 4), ("bf16 d(hist)", dhist.to(torch.bfloat16), 2)):
+            bf = int(d.dtype == torch.bfloat16)
+            sites = [(d.data_ptr(), 0, 0, 0, keys[0].data_ptr(), perm[0].data_ptr(), ln.data_ptr(), gi.data_ptr(), 0, n + B, bf,
+                      1, T, D, 0, Di, 3, Di, 0, 1, dtarget.data_ptr(), 0, n, D, 0),
+                     (d.data_ptr(), 0, 0, 0, keys[1].data_ptr(), perm[1].data_ptr(), ln.data_ptr(), gc.data_ptr(), 0, n + B, bf,
+                      1, T, D, Di, Dc, 3, Dc, 0, 1, dtarget.data_ptr(), 0, n, D, Di)]
+            which_sites = os.environ.get("EMBED_SITES", "both")
+            sites = sites[:1] if which_sites == "item" else sites[1:] if which_sites == "cate" else sites
+            wsg = torch.empty(ops.segsum_workspace_bytes(sites), dtype=torch.uint8, device=dev)
+            t = timeit(lambda: ops.segsum_multi(sites, wsg), iters=22)
+            nbytes = n * D * sa + n * D * 4 + 2 * n * 4 + B * D * 8 + 2 * B * 4
+            print("segmented sums (item + category, history + target slices, stored once), %s: %8.1f us  %.0f GB/s "
+                  "algorithmic (%.1f%% of 8 TB/s)" % (tag, t, nbytes / t / 1e3, nbytes / t / 1e3 / 80))
+        ids = torch.unique(keys[0].long()).int()
+        nrows = ids.numel()
+        count = torch.tensor([nrows, 0], dtype=torch.int32, device=dev)
+        tb = torch.zeros(Vi, Di, device=dev)
+        m_, v_ = torch.zeros(Vi, Di, device=dev), torch.zeros(Vi, Di, device=dev)
+        fl = torch.zeros(Vi, dtype=torch.uint8, device=dev)
+        ss = torch.ones(1, dtype=torch.float64, device=dev)
+        st = torch.tensor([1.0, 0.9, 0.999, 0.0], dtype=torch.float64, device=dev)
+        t = timeit(lambda: call("clsr_table_adam_rows", tb, gi, m_, v_, fl, ids, count, nrows, Di, ss, 1, 1, 2.0, st, 0.9, 0.999,
+                                1e-8), iters=22)
+        nbytes = nrows * Di * 8 * 4
+        print("lazy-Adam rows, %d rows of %d B (fp32 table): %8.1f us  %.0f GB/s (%.1f%% of 8 TB/s)" % (
+            nrows, Di * 4, t, nbytes / t / 1e3, nbytes / t / 1e3 / 80))
+        del m_, v_
+        tbh, cth = tb.to(torch.bfloat16), torch.zeros(Vc, Dc, device=dev, dtype=torch.bfloat16)
+        del tb
+        m_, v_ = torch.zeros(Vi, Di, device=dev), torch.zeros(Vi, Di, device=dev)
+        t = timeit(lambda: call("clsr_table_adam_rows_h", tbh, gi, m_, v_, fl, ids, count, nrows, Di, ss, 1, 1, 2.0, st, 0.9,
+                                0.999, 1e-8), iters=22)
+        nbytes = nrows * Di * (6 * 4 + 2 * 2)
+        print("lazy-Adam rows, bf16 table (fp32 moments)      : %8.1f us  %.0f GB/s (%.1f%% of 8 TB/s)" % (
+            t, nbytes / t / 1e3, nbytes / t / 1e3 / 80))
+        histh = torch.empty(Hn, T, D, device=dev, dtype=torch.bfloat16)
+        hm, hr = torch.empty(Hn, D, device=dev), torch.empty(Hn, D, device=dev)
+        t = timeit(lambda: call("clsr_gather_hist_fwd_h", tbh, cth, ii, ci, T, ln, 1, Hn, T, Di, Dc, 3, histh, 1, hm, hr), iters=22)
+        nbytes = n * (D * 4 + 8)
+        print("gather_hist_fwd_h (bf16 tables, bf16 hist)      : %8.1f us  %.0f GB/s (%.1f%% of 8 TB/s)" % (
+            t, nbytes / t / 1e3, nbytes / t / 1e3 / 80))
     if which in ("pgemm", "all"):
         Wt, Kp = ops.pack_weight(W, 80, 80)
         U = torch.randn(Hn * T, 80, device=dev)
