@@ -276,6 +276,18 @@ __device__ __forceinline__ float ss_sq(const f32x4& x) { return x.x * x.x + x.y 
 
 // meta[chunk]: 0 first key (or -1), 1 last key, 2 flags (1: first run continues from the previous chunk, 2: last run
 // continues into the next chunk, 4: the whole chunk is one run), 3 unused
+// eight consecutive ints a[q0 .. q0 + 7] (fill beyond ``pe``): two 16-byte loads when the batch is whole and aligned
+__device__ __forceinline__ void ss_ld8(const int* __restrict__ a, const long q0, const long pe, const int fill, int out[8]) {
+  if (q0 + 8 <= pe && ((reinterpret_cast<uintptr_t>(a + q0) & 15) == 0)) {
+    const int4 u = *reinterpret_cast<const int4*>(a + q0), w = *reinterpret_cast<const int4*>(a + q0 + 4);
+    out[0] = u.x; out[1] = u.y; out[2] = u.z; out[3] = u.w;
+    out[4] = w.x; out[5] = w.y; out[6] = w.z; out[7] = w.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out[k] = q0 + k < pe ? a[q0 + k] : fill;
+  }
+}
+
 template <int VW>
 __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block, double* red) {
   typedef typename SsVec<VW>::type vec_t;
@@ -309,17 +321,21 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
       }
       ++nruns;
     };
+    // keys / slice numbers of a batch of eight are fetched ONE BATCH AHEAD (two 16-byte loads each): the row reads of a
+    // batch depend on them, and with both fetched in the batch itself every batch paid two memory round trips in a row
+    int keyN[8], posN[8];
+    ss_ld8(s.keys, p0, pe, -1, keyN);
+    ss_ld8(s.perm, p0, pe, 0, posN);
     for (long q0 = p0; q0 < pe; q0 += 8) {
-      int key[8];
+      int key[8], posk[8];
       bool sec[8];
       vec_t g[8];
-      const int knext = q0 + 8 < pe ? s.keys[q0 + 8] : -1;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { key[k] = keyN[k]; posk[k] = posN[k]; }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const long p = q0 + k;
-        const bool ok = p < pe;
-        key[k] = ok ? s.keys[p] : -1;
-        const int pos = ok ? s.perm[p] : 0;
+        const bool ok = key[k] >= 0;
+        const int pos = posk[k];
         const bool second = s.n1 > 0 && pos >= s.n1;          // (uniform inside the thread group)
         sec[k] = second;
         vec_t v;
@@ -340,6 +356,14 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
         }
         g[k] = (cok && ok) ? v : vec_t(0.f);
       }
+      if (q0 + 8 < pe) {
+        ss_ld8(s.keys, q0 + 8, pe, -1, keyN);
+        ss_ld8(s.perm, q0 + 8, pe, 0, posN);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { keyN[k] = -1; posN[k] = 0; }
+      }
+      const int knext = keyN[0];
       // the gradient rows of all eight entries' ids are requested NOW, whether or not a run ends there: a run that ends
       // inside the chunk is added to its row with a read-modify-write, and one dependent row read per run end, one after
       // the other along the walk, made this launch 110 us for 640 chunks
