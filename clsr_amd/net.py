@@ -154,6 +154,10 @@ class CLSRNet(object):
         self.side_priority = int(os.environ.get("CLSR_SIDE_PRIORITY", "0"))
         self.dw_priority = int(os.environ.get("CLSR_DW_PRIORITY", "0"))
         self.fuse_tt = not os.environ.get("CLSR_NO_FUSE_TT")   # A/B: time-gate blocks of the input projection as one product over [hist | TT]
+        # the row-level heads (alpha gate, alpha / logit MLPs, loss, their backward) as two persistent launches with grid
+        # barriers for the batch-norm statistics (csrc/headsfused.hip) instead of a chain of 22 dependent launches
+        self.heads_fused = not os.environ.get("CLSR_NO_HEADS_FUSED")
+        self._heads_defer = False
         self.fused_logit_tail = not os.environ.get("CLSR_NO_FUSED_LOGIT_TAIL")   # A/B: output layer + softmax loss + their backward in one launch
         self._defer_logit_out = False
         self.early_scatter = not os.environ.get("CLSR_NO_EARLY_SCATTER")   # A/B: row scatters of the user / target lookups beside the encoder-backward tail instead of behind it
@@ -1679,7 +1683,10 @@ class CLSRNet(object):
                                      hist_recent=hrec))
         alpha = self._buf("alpha", B)
         mo = self._buf("model_output", B, 2 * D)
-        if not hp.manual_alpha:
+        if self._heads_defer:
+            # training step: everything from here to d(model_output) is the first clsr_heads_fused launch (_train_step)
+            logit = self._buf("lg.logit", B)
+        elif not hp.manual_alpha:
             nfs = H if hp.predict_long_short else 0
             ld = _pad4(self.a_in)
             ain = self._buf("al.in", B, ld)
@@ -1690,11 +1697,99 @@ class CLSRNet(object):
         else:
             call("clsr_alpha_fuse_fwd", None, float(hp.manual_alpha_value), att_long, att_short, target, B, G, D,
                  alpha, mo)
-        logit = self._mlp_fwd("lg", "sequential/logit_fcn/nn_part/", mo, 2 * D, 2 * D, (self.L0, self.L1), B, training)
+        if not self._heads_defer:
+            logit = self._mlp_fwd("lg", "sequential/logit_fcn/nn_part/", mo, 2 * D, 2 * D, (self.L0, self.L1), B, training)
         return dict(logit=logit, alpha=alpha, att_fea_long=att_long, att_fea_short=att_short, hist_input=hist,
                     hist_mean=hmean, hist_recent=hrec, target=target, u_long=ulong, u_short=ushort,
                     short_intention=short_int, rnn_out=rnn_out, model_output=mo, causal_state=fs,
                     w_long=self._buf("lt.wts", Hn, T), w_short=self._buf("st.wts", B, T), q_short=q)
+
+    def _heads_bwd_launches(self, f, out, B, G, Hn, Gl, lscale, fused_tail, dlogit, dtarget, dL, dS, dfs):
+        """Backward of the row-level heads as the chain of launches (any widths; synchronised batch-norm statistics)."""
+        hp, D, H = self.hp, self.D, self.H
+        with self._dw_batched(late=True):
+            dmo = self._mlp_bwd("lg", "sequential/logit_fcn/nn_part/", dlogit, out["model_output"], 2 * D, 2 * D, 2 * D,
+                                (self.L0, self.L1), B, tail=(f["labels"], B // Gl, Gl, lscale) if fused_tail else None)
+            self._join()              # the contrastive branch: its dL / dS are accumulated into from here on
+            if not hp.manual_alpha:
+                dal = self._buf("dalpha_logit", B)
+                call("clsr_alpha_fuse_bwd", dmo, out["alpha"], 0.0, out["att_fea_long"], out["att_fea_short"], Hn, G, D,
+                     dal, dL, dS, dtarget)
+                ld = _pad4(self.a_in)
+                dain = self._mlp_bwd("al", CL + "fcn_alpha/nn_part/", dal, self._buf("al.in", B, ld), ld, ld, self.a_in,
+                                     (self.A0, self.A1), B)
+        if not hp.manual_alpha:
+            nfs = H if hp.predict_long_short else 0
+            call("clsr_alpha_concat_bwd", dain, ld, nfs, Hn, G, D, dfs if nfs else None, dtarget, dL, dS)
+        else:
+            call("clsr_alpha_fuse_bwd", dmo, None, float(hp.manual_alpha_value), out["att_fea_long"],
+                 out["att_fea_short"], Hn, G, D, None, dL, dS, dtarget)
+
+    def _heads_fused_ok(self, B, G):
+        """The two-launch form of the heads: the reference's default widths, local batch-norm statistics, the fused
+        output-layer / softmax tail's conditions."""
+        hp = self.hp
+        return bool(self.heads_fused and type(self) is CLSRNet and not hp.manual_alpha and hp.predict_long_short
+                    and self.dp_stats_hook is None and self.fused_logit_tail and G == hp.train_num_ngs + 1
+                    and query("clsr_heads_fused_supported", B, G, self.D, self.H, self.a_in, self.A0, self.A1,
+                              self.L0, self.L1))
+
+    def _heads_ws(self):
+        return self._buf("heads.ws", (int(query("clsr_heads_fused_workspace_bytes")) + 3) // 4)
+
+    def _heads_fused_step(self, f, out, B, G, Hn, T, lscale, dlogit, dtarget, dL, dS, dfs):
+        """alpha gate -> alpha MLP -> fusion -> logit MLP -> softmax loss -> their backward: two persistent launches
+        (csrc/headsfused.hip) around the join with the contrastive branch, then the four dense layers' weight gradients in
+        the step's batched dW launch (they read the activations / dz tensors the two launches wrote)."""
+        P, Gd, D = self.P, self.Gd, self.D
+        al, lg = CL + "fcn_alpha/nn_part/", "sequential/logit_fcn/nn_part/"
+        A0, A1, L0, L1 = self.A0, self.A1, self.L0, self.L1
+        ld = _pad4(self.a_in)
+        parts = query("clsr_heads_fused_parts", B, G)
+        ws = self._heads_ws()
+        buf = self._buf
+        bns = [self.bn[al + "batch_normalization/"], self.bn[al + "batch_normalization_1/"],
+               self.bn[lg + "batch_normalization/"], self.bn[lg + "batch_normalization_1/"]]
+        wp_al = buf("mlp.wp.al", 512 * (256 + 4))[: parts * (A1 + 4)]
+        wp_lg = buf("mlp.wp.lg", 512 * (256 + 4))[: parts * (L1 + 4)]
+        ain, mo = buf("al.in", B, ld), out["model_output"]
+        z = {k: buf(k, B, n) for k, n in (("al.z0", A0), ("al.z1", A1), ("lg.z0", L0), ("lg.z1", L1), ("al.dz0", A0),
+                                          ("al.dz1", A1), ("lg.dz0", L0), ("lg.dz1", L1))}
+        pk = self.packed
+        d = ops.heads_desc(
+            fs=out["causal_state"], target=out["target"], att_long=out["att_fea_long"], att_short=out["att_fea_short"],
+            tnow=f["time_to_now"], labels=f["labels"], tnow_stride=T, tnow_col=T - 1,
+            tnow_group=G if f.get("compact") else 1, B=B, G=G, D=D, nfs=self.H, a_in=self.a_in, ld=ld, A0=A0, A1=A1,
+            L0=L0, L1=L1,
+            al_w0=pk["al.W0"][0], al_w1=pk["al.W1"][0], lg_w0=pk["lg.W0"][0], lg_w1=pk["lg.W1"][0],
+            al_w0T=pk["al.W0^T"][0], al_w1T=pk["al.W1^T"][0], lg_w0T=pk["lg.W0^T"][0], lg_w1T=pk["lg.W1^T"][0],
+            kp_al_w0=pk["al.W0"][1], kp_al_w1=pk["al.W1"][1], kp_lg_w0=pk["lg.W0"][1], kp_lg_w1=pk["lg.W1"][1],
+            kp_al_w0T=pk["al.W0^T"][1], kp_al_w1T=pk["al.W1^T"][1], kp_lg_w0T=pk["lg.W0^T"][1],
+            kp_lg_w1T=pk["lg.W1^T"][1],
+            al_b0=P[al + "b_nn_layer0"], al_b1=P[al + "b_nn_layer1"], al_wout=P[al + "w_nn_output"],
+            al_bout=P[al + "b_nn_output"], lg_b0=P[lg + "b_nn_layer0"], lg_b1=P[lg + "b_nn_layer1"],
+            lg_wout=P[lg + "w_nn_output"], lg_bout=P[lg + "b_nn_output"],
+            bn=[dict(gamma=b.gamma, beta=b.beta, moving_mean=b.moving_mean, moving_var=b.moving_var, scale=b.scale,
+                     shift=b.shift, mean=b.mean, invstd=b.invstd, coef=b.coef, dgamma=b.dgamma, dbeta=b.dbeta) for b in bns],
+            momentum=BN_MOMENTUM, eps=BN_EPS, lscale=lscale,
+            ain=ain, al_z0=z["al.z0"], al_z1=z["al.z1"], alpha=out["alpha"], mo=mo, lg_z0=z["lg.z0"], lg_z1=z["lg.z1"],
+            logit=out["logit"], dlogit=dlogit, loss=self.losses[0:],
+            lg_dz1=z["lg.dz1"], lg_dz0=z["lg.dz0"], dmo=buf("lg.dX", B, 2 * D), al_dz1=z["al.dz1"], al_dz0=z["al.dz0"],
+            lg_wp=wp_lg, al_wp=wp_al, dL=dL, dS=dS, dtarget=dtarget, dfs=dfs, workspace=ws, workspace_bytes=ws.numel() * 4)
+        with self._dw_batched(late=True):
+            ops.heads_fused(1, d)
+            self._rp(wp_lg, parts, L1 + 4, L1, Gd[lg + "w_nn_output"])
+            self._rp(wp_lg[L1:], parts, L1 + 4, 1, Gd[lg + "b_nn_output"])
+            self._dw(z["lg.z0"], L0, z["lg.dz1"], L1, B, L0, L1, Gd[lg + "w_nn_layer1"], L1, db=Gd[lg + "b_nn_layer1"],
+                     aff=bns[2])
+            self._dw(mo, 2 * D, z["lg.dz0"], L0, B, 2 * D, L0, Gd[lg + "w_nn_layer0"], L0, db=Gd[lg + "b_nn_layer0"])
+            self._join()              # the contrastive branch: the second launch adds to its dL / dS
+            ops.heads_fused(2, d)
+            self._rp(wp_al, parts, A1 + 4, A1, Gd[al + "w_nn_output"])
+            self._rp(wp_al[A1:], parts, A1 + 4, 1, Gd[al + "b_nn_output"])
+            self._dw(z["al.z0"], A0, z["al.dz1"], A1, B, A0, A1, Gd[al + "w_nn_layer1"], A1, db=Gd[al + "b_nn_layer1"],
+                     aff=bns[0])
+            self._dw(ain, ld, z["al.dz0"], A0, B, self.a_in, A0, Gd[al + "w_nn_layer0"], A0, db=Gd[al + "b_nn_layer0"])
 
     # ------------------------------------------------------------------ training step
     def train_step(self, f, apply=True):
@@ -1715,6 +1810,7 @@ class CLSRNet(object):
         D, Du, H, Di, Dc = self.D, self.Du, self.H, self.Di, self.Dc
         hs = 1 if f.get("compact") else G
         seq_len, ls = f["seq_len"], hs
+        heads_fused = self._heads_fused_ok(B, G)
         # gradient accumulators (zeroed every step) and the involved-row flags depend on the feed only: zeroed /
         # marked on a side stream underneath the forward's first kernels
         zpool = self._buf("zero_pool", Hn * T * (2 * D + H) + B * D * 2 + Hn * (3 * D + H + Du))
@@ -1731,6 +1827,8 @@ class CLSRNet(object):
             if "user_long" in self.tables:
                 zr.append((self.ucount.data_ptr(), 4))
                 self._ucount_zeroed = True
+            if heads_fused:
+                zr.append((self._heads_ws().data_ptr(), int(query("clsr_heads_fused_counter_bytes"))))
             if self._att_qh("st") and G > 1:
                 # split short-term query: the history-level columns of d(query) only receive the V path (an
                 # accumulating product): cleared here with the other accumulators
@@ -1778,33 +1876,22 @@ class CLSRNet(object):
         fused_tail = (self.fused_logit_tail and B % Gl == 0
                       and bool(query("clsr_mlp_tail_softmax_supported", Gl, self.L1)))
         self._defer_logit_out = fused_tail
+        self._heads_defer = heads_fused
         try:
             out = self._forward(f, True, contrastive, zero_and_mark)
         finally:
             self._defer_logit_out = False
+            self._heads_defer = False
         assert self.last_shape == (B, T, G, Hn)
         # ---- losses on the forward outputs
         dlogit = self._buf("dlogit", B)
         if not fused_tail:
             call("clsr_softmax_loss", out["logit"], f["labels"], B // Gl, Gl, lscale, self.losses[0:], dlogit)
         # ---- logit MLP, fusion, alpha MLP (their four small weight gradients: ONE multi-job launch at the end)
-        with self._dw_batched(late=True):
-            dmo = self._mlp_bwd("lg", "sequential/logit_fcn/nn_part/", dlogit, out["model_output"], 2 * D, 2 * D, 2 * D,
-                                (self.L0, self.L1), B, tail=(f["labels"], B // Gl, Gl, lscale) if fused_tail else None)
-            self._join()              # the contrastive branch: its dL / dS are accumulated into from here on
-            if not hp.manual_alpha:
-                dal = self._buf("dalpha_logit", B)
-                call("clsr_alpha_fuse_bwd", dmo, out["alpha"], 0.0, out["att_fea_long"], out["att_fea_short"], Hn, G, D,
-                     dal, dL, dS, dtarget)
-                ld = _pad4(self.a_in)
-                dain = self._mlp_bwd("al", CL + "fcn_alpha/nn_part/", dal, self._buf("al.in", B, ld), ld, ld, self.a_in,
-                                     (self.A0, self.A1), B)
-        if not hp.manual_alpha:
-            nfs = H if hp.predict_long_short else 0
-            call("clsr_alpha_concat_bwd", dain, ld, nfs, Hn, G, D, dfs if nfs else None, dtarget, dL, dS)
+        if heads_fused:
+            self._heads_fused_step(f, out, B, G, Hn, T, lscale, dlogit, dtarget, dL, dS, dfs)
         else:
-            call("clsr_alpha_fuse_bwd", dmo, None, float(hp.manual_alpha_value), out["att_fea_long"],
-                 out["att_fea_short"], Hn, G, D, None, dL, dS, dtarget)
+            self._heads_bwd_launches(f, out, B, G, Hn, Gl, lscale, fused_tail, dlogit, dtarget, dL, dS, dfs)
         dul = None
         if self.lt_bwd_early:
             # long-term attention backward (dL is final here) on the side stream from NOW, beside the short-term one

@@ -392,6 +392,47 @@ def segsum_multi(rows, workspace):
     call("clsr_segsum_multi", ctypes.addressof(arr), len(rows), workspace, workspace.numel())
 
 
+class BnPtrs(ctypes.Structure):
+    """ctypes mirror of clsr_bn_ptrs (include/clsr_hip.h)."""
+    _fields_ = [(n, _P) for n in ("gamma", "beta", "moving_mean", "moving_var", "scale", "shift", "mean", "invstd", "coef",
+                                  "dgamma", "dbeta")]
+
+
+class HeadsDesc(ctypes.Structure):
+    """ctypes mirror of clsr_heads_desc (include/clsr_hip.h)."""
+    _fields_ = ([(n, _P) for n in ("fs", "target", "att_long", "att_short", "tnow", "labels")]
+                + [("tnow_stride", _L), ("tnow_col", _I), ("tnow_group", _I), ("B", _L)]
+                + [(n, _I) for n in ("G", "D", "nfs", "a_in", "ld", "A0", "A1", "L0", "L1")]
+                + [(n, _P) for n in ("al_w0", "al_w1", "lg_w0", "lg_w1", "al_w0T", "al_w1T", "lg_w0T", "lg_w1T")]
+                + [(n, _I) for n in ("kp_al_w0", "kp_al_w1", "kp_lg_w0", "kp_lg_w1", "kp_al_w0T", "kp_al_w1T", "kp_lg_w0T",
+                                     "kp_lg_w1T")]
+                + [(n, _P) for n in ("al_b0", "al_b1", "al_wout", "al_bout", "lg_b0", "lg_b1", "lg_wout", "lg_bout")]
+                + [("bn", BnPtrs * 4), ("momentum", _F), ("eps", _F), ("lscale", _F), ("pad_", _I)]
+                + [(n, _P) for n in ("ain", "al_z0", "al_z1", "alpha", "mo", "lg_z0", "lg_z1", "logit", "dlogit", "loss",
+                                     "lg_dz1", "lg_dz0", "dmo", "al_dz1", "al_dz0", "lg_wp", "al_wp", "dL", "dS", "dtarget",
+                                     "dfs", "workspace")]
+                + [("workspace_bytes", _L)])
+
+
+def heads_desc(**kw):
+    """clsr_heads_desc from keyword values: tensors become their device pointers, ``bn`` is a list of four dicts."""
+    assert ctypes.sizeof(HeadsDesc) == query("clsr_sizeof_heads_desc")
+    d = HeadsDesc()
+    ptr = lambda v: v.data_ptr() if hasattr(v, "data_ptr") else (0 if v is None else v)
+    for i, layer in enumerate(kw.pop("bn")):
+        for name, v in layer.items():
+            setattr(d.bn[i], name, ptr(v))
+    for name, v in kw.items():
+        setattr(d, name, ptr(v))
+    return d
+
+
+def heads_fused(step, desc):
+    """clsr_heads_fused_step1 / _step2 on a HeadsDesc."""
+    keep_alive(desc)
+    call("clsr_heads_fused_step%d" % step, ctypes.addressof(desc))
+
+
 class DwJob(ctypes.Structure):
     """ctypes mirror of clsr_dwjob (include/clsr_hip.h)."""
     _fields_ = [("X", _P), ("Xmul", _P), ("in_scale", _P), ("in_shift", _P), ("dY", _P), ("workspace", _P),

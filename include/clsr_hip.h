@@ -115,6 +115,51 @@ int clsr_sizeof_segsum_desc(void);
 long clsr_segsum_workspace_bytes(const clsr_segsum_desc* descs_host, int n);
 /* the sites of one call must write different tables (or disjoint columns); nothing else may write them meanwhile */
 int clsr_segsum_multi(const clsr_segsum_desc* descs_host, int n, void* workspace, long workspace_bytes, void* stream);
+/* ---- the row-level heads of the CLSR training step as two persistent launches (csrc/headsfused.hip) -------------------
+ * Replaces, for the reference's default widths, the chain clsr_alpha_concat -> 2 x (clsr_pgemm + clsr_bn_finalize) ->
+ * clsr_mlp_out_fwd -> clsr_alpha_fuse_fwd -> 2 x (clsr_pgemm + clsr_bn_finalize) -> clsr_mlp_tail_softmax ->
+ * clsr_bn_bwd_coef_apply / clsr_pgemm_bnbwd / clsr_pgemm ... -> clsr_alpha_fuse_bwd -> ... -> clsr_alpha_concat_bwd
+ * (reference: models/sequential/clsr.py:239-275, models/base_model.py:653-708, 215-235 and their gradients): workgroups keep
+ * their rows in LDS through every layer and meet at grid barriers for the batch-norm statistics.  The weight gradients of
+ * the four dense layers are NOT computed here (the caller's batched clsr_pgemm_dw launch reads ain / al_z0 / mo / lg_z0 and
+ * the dz tensors written here); the output-layer gradients leave as [parts][C1 + 4] partial rows (clsr_mlp_out_bwd's
+ * layout, parts = clsr_heads_fused_parts).  bn[i]: alpha layer 0, alpha layer 1, logit layer 0, logit layer 1. */
+typedef struct clsr_bn_ptrs {
+  const float* gamma; const float* beta; float* moving_mean; float* moving_var;
+  float* scale; float* shift; float* mean; float* invstd; float* coef; float* dgamma; float* dbeta;
+} clsr_bn_ptrs;
+typedef struct clsr_heads_desc {
+  /* inputs: final state of the causal GRU [B/G, nfs], target embedding [B, D], long-term interest [B/G, D], short-term
+   * interest [B, D], time_to_now (row b / tnow_group, column tnow_col, row stride tnow_stride), labels [B] */
+  const float* fs; const float* target; const float* att_long; const float* att_short; const float* tnow; const float* labels;
+  long tnow_stride; int tnow_col; int tnow_group;
+  long B; int G; int D; int nfs; int a_in; int ld; int A0; int A1; int L0; int L1;
+  /* packed transposed weights (clsr_pack_batch layout, row strides kp_*): forward and transposed packs */
+  const float* al_w0; const float* al_w1; const float* lg_w0; const float* lg_w1;
+  const float* al_w0T; const float* al_w1T; const float* lg_w0T; const float* lg_w1T;
+  int kp_al_w0; int kp_al_w1; int kp_lg_w0; int kp_lg_w1; int kp_al_w0T; int kp_al_w1T; int kp_lg_w0T; int kp_lg_w1T;
+  const float* al_b0; const float* al_b1; const float* al_wout; const float* al_bout;
+  const float* lg_b0; const float* lg_b1; const float* lg_wout; const float* lg_bout;
+  clsr_bn_ptrs bn[4];
+  float momentum; float eps; float lscale; int pad_;
+  /* forward outputs */
+  float* ain; float* al_z0; float* al_z1; float* alpha; float* mo; float* lg_z0; float* lg_z1; float* logit;
+  float* dlogit;            /* optional */
+  double* loss;             /* += data loss */
+  /* backward outputs (dL / dS / dtarget / dfs are added to) */
+  float* lg_dz1; float* lg_dz0; float* dmo; float* al_dz1; float* al_dz0; float* lg_wp; float* al_wp;
+  float* dL; float* dS; float* dtarget; float* dfs;
+  void* workspace; long workspace_bytes;
+} clsr_heads_desc;
+int clsr_sizeof_heads_desc(void);
+int clsr_heads_fused_supported(long B, int G, int D, int nfs, int a_in, int A0, int A1, int L0, int L1);
+int clsr_heads_fused_parts(long B, int G);
+long clsr_heads_fused_workspace_bytes(void);
+long clsr_heads_fused_counter_bytes(void);   /* leading bytes of the workspace that must be zero before step1 */
+int clsr_heads_fused_error(const void* workspace);   /* synchronous; 1 = a grid barrier timed out (results invalid) */
+int clsr_heads_fused_step1(const clsr_heads_desc* d_host, void* stream);
+int clsr_heads_fused_step2(const clsr_heads_desc* d_host, void* stream);
+
 long clsr_sort_ids_workspace_bytes(long n, long vocab);
 int clsr_sort_ids(const int* ids, long nrows, int ncols, long row_stride, long vocab, int* keys_out,
                   int* perm_out, void* workspace, long workspace_bytes, void* stream);

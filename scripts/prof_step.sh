@@ -4,7 +4,7 @@
 tag=$1; shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_$tag
-rocprofv3 --kernel-trace --output-format rocpd -d /tmp/prof_$tag -o bench -- python $root/bench.py --no-cpu-baseline --no-catalogue --no-extra --steps 20 "$@" > /tmp/prof_$tag.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format rocpd -d /tmp/prof_$tag -o bench -- python $root/bench.py --no-cpu-baseline --no-catalogue --no-extra --steps 20 "$@" > /tmp/prof_$tag.log 2>&1
 grep -E "timed|Error|error" /tmp/prof_$tag.log | head -5
 cd $root
 f=$(find /tmp/prof_$tag -name "*.db" | head -1)
