@@ -270,9 +270,7 @@ class SequentialBaseModel(BaseModel):
                 st = self._static[key] = self.net.upload(feed, training)
                 return key, st, True
             return key, self.net.upload(feed, training, into=st), False
-        side = self.net._side.get("@dw0")
-        if side is None:
-            side = self.net._side["@dw0"] = torch.cuda.Stream(device=self.net.device)
+        side = self.net._side_stream("@dw0")
         st = self._static.get(("2x",) + key)
         if st is None:
             st = self._static[("2x",) + key] = [[None, None], 0]

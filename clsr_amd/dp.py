@@ -393,7 +393,7 @@ class DataParallel(object):
         for name in net.tab_grad:          # sparse tables that never reported
             self.table_ready(stream, name)
         for names, g0, n in self._dense_table_runs():
-            if not all(k in self._done for k in names):
+            if not all(k in self._done for k in names):     # (only a second _finish of the same step finds them done)
                 self._done.update(names)
                 self._allreduce(net.tab_grad_flat[g0:g0 + n], dist.ReduceOp.SUM, stream, "tables:" + "+".join(names))
         if "dense" not in self._done:

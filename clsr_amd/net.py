@@ -412,7 +412,10 @@ class CLSRNet(object):
             if "/time4lstm/" in k and "/time4lstm/time4lstm_cell/" not in k:
                 if out is None:
                     out = dict(sd)
-                out.setdefault(k.replace("/time4lstm/", "/time4lstm/time4lstm_cell/"), out.pop(k))
+                new = k.replace("/time4lstm/", "/time4lstm/time4lstm_cell/")
+                if new in out:
+                    raise ValueError("checkpoint holds both spellings of one variable: %s and %s" % (k, new))
+                out[new] = out.pop(k)
         return sd if out is None else out
 
     def load_state_dict(self, sd, strict=True):
@@ -457,7 +460,7 @@ class CLSRNet(object):
             stag = net.stream_alias.get(self.tag, self.tag)      # (scratch buffers keep the branch's own tag)
             side = net._side.get(stag)
             if side is None:
-                side = net._side[stag] = torch.cuda.Stream(device=net.device, priority=net.side_priority)
+                side = net._side_stream(stag)
             if side.cuda_stream == ops.current_stream().cuda_stream:
                 # a branch onto the stream it is opened from (an @aux branch inside an @lt one, now that they share a
                 # stream): plain stream order -- a stream waiting for its own event crashes hipGraph capture
@@ -522,6 +525,21 @@ class CLSRNet(object):
         for ev in last.values():                 # (every wait is a barrier packet of ~5 us in front of the next kernel)
             ops.stream_wait(main, ev)
         self._joins = rest
+
+    def _side_stream(self, tag):
+        """The side stream ``tag`` of this device, created on first use by whichever call site gets there first: the
+        weight-gradient streams (@dw*) with CLSR_DW_PRIORITY, every other one with CLSR_SIDE_PRIORITY.  A new stream
+        orders itself behind everything enqueued on the current stream so far -- the zero fills of workspaces allocated
+        before it existed included (``_buf`` makes the streams that exist at allocation time wait; a stream created later
+        in the same first step could still have written such a buffer ahead of its pending fill)."""
+        side = self._side.get(tag)
+        if side is None:
+            prio = self.dw_priority if tag.startswith("@dw") else self.side_priority
+            side = self._side[tag] = torch.cuda.Stream(device=self.device, priority=prio)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            side.wait_event(ev)
+        return side
 
     # ------------------------------------------------------------------ buffers
     def _buf(self, name, *shape, dtype=F32):
@@ -616,7 +634,7 @@ class CLSRNet(object):
             name = "@dw%d" % (len(pend) % self.dw_streams)
             side = self._side.get(name)
             if side is None:
-                side = self._side[name] = torch.cuda.Stream(device=self.device, priority=self.side_priority)
+                side = self._side_stream(name)
             ops.stream_wait(side, self._fork_point())
             self._dw_launch(X, x_bf16, ldx, T, G, Xmul, ldmul, sc, sh, dY, dy_bf16, ldy, M, K, N, ws, side.cuda_stream)
             self._dw_async = True
@@ -657,7 +675,7 @@ class CLSRNet(object):
         if self.dw_stream and self.overlap and self._ws_tag == "":
             side = self._side.get("@dw0")
             if side is None:
-                side = self._side["@dw0"] = torch.cuda.Stream(device=self.device, priority=self.dw_priority)
+                side = self._side_stream("@dw0")
             ops.stream_wait(side, fork)
             ops.dw_multi(name, jobs, stream=side.cuda_stream)
             self._dw_async = True

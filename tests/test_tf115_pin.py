@@ -279,3 +279,7 @@ def test_checkpoints_with_the_old_time4lstm_names_still_load():
                    "sequential/clsr/short_term/time4lstm/time4lstm_cell/bias": 3,
                    "sequential/embedding/item_embedding": 4}
     assert old["sequential/clsr/short_term/time4lstm/kernel"] == 1          # the caller's dict is left alone
+    both = dict(old)
+    both["sequential/clsr/short_term/time4lstm/time4lstm_cell/kernel"] = 9     # the same variable under both spellings
+    with pytest.raises(ValueError, match="both spellings"):
+        CLSRNet._alias_old_names(both)
