@@ -245,6 +245,9 @@ extern "C" int clsr_sort_ids_stable_multi(const clsr_sortids_desc* descs, int n,
 // ===================================================================================================== segmented sums
 // One lookup SITE of a launch: rows `key` of `grad` receive the sums of the slices  g[e, :] = src[pos(e), col0 : col0 + C]
 // (+ src2, + the mean / recent-k terms of the history prologue when dmean / drecent are given: pos = h * T + t).
+#ifndef SS_BU
+#define SS_BU 8          // partial rows of a lane slot in flight in the border combine (power of two)
+#endif
 #ifndef SS_CHUNK
 #define SS_CHUNK 32                 // sorted entries per thread group
 #endif
@@ -459,29 +462,53 @@ __device__ __forceinline__ void ss_borders(const SsSite& s, const int local_bloc
     if (head) {
       const int key = m[1];
       // extent: chunks chunk + 1 .. chunk + L belong to the run (whole-chunk continuations, then the chunk it ends in)
+      // (256 chunks per trip -- four 16-byte flag loads per lane in flight: the scan is a chain of dependent loads, and the
+      // run of the most popular item of a Zipf catalogue spans ~800 chunks)
       long L = 0;
-      while (true) {
-        const long k = chunk + 1 + L + lane;
-        int f = 0, fk = -1;
-        if (k < nchunks) { fk = s.meta[k * 4]; f = s.meta[k * 4 + 2]; }
-        const bool member = fk == key && (f & 1);
-        const bool whole = member && (f & 4) && (f & 2);
-        const unsigned long long bw = __ballot(whole), bm = __ballot(member);
-        const int nw = bw == ~0ull ? 64 : __builtin_ctzll(~bw);
-        if (nw == 64) { L += 64; continue; }
-        L += nw + (((bm >> nw) & 1ull) ? 1 : 0);
-        break;
-      }
-      // (four partials of a slot in flight: the loop is a chain of dependent row reads otherwise; fixed association)
-      vec_t a4[4] = {vec_t(0.f), vec_t(0.f), vec_t(0.f), vec_t(0.f)};
-      for (long k = slot; k < L; k += 4 * S) {
+      bool open = true;
+      while (open) {
+        int4 mk[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const long ku = k + (long)u * S;
-          if (cok && ku < L) a4[u] += *reinterpret_cast<const vec_t*>(s.bnd + (chunk + 1 + ku) * 2 * Cp + c);
+          const long k = chunk + 1 + L + 64 * u + lane;
+          mk[u] = k < nchunks ? *reinterpret_cast<const int4*>(s.meta + k * 4) : int4{-1, 0, 0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (!open) break;
+          const bool member = mk[u].x == key && (mk[u].z & 1);
+          const bool whole = member && (mk[u].z & 4) && (mk[u].z & 2);
+          const unsigned long long bw = __ballot(whole), bm = __ballot(member);
+          const int nw = bw == ~0ull ? 64 : __builtin_ctzll(~bw);
+          if (nw == 64) { L += 64; continue; }
+          L += nw + (((bm >> nw) & 1ull) ? 1 : 0);
+          open = false;
         }
       }
-      const vec_t acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+      // (SS_BU partials of a slot in flight: the loop is a chain of dependent row reads otherwise -- the longest run, the
+      // most popular item of a Zipf catalogue with ~800 partials, is what this launch waits for; fixed association)
+      vec_t aN[SS_BU];
+#pragma unroll
+      for (int u = 0; u < SS_BU; ++u) aN[u] = vec_t(0.f);
+      const int cs = cok ? c : 0;
+      for (long k = slot; k < L; k += SS_BU * S) {
+        // (unconditional loads from a clamped row, selected afterwards: with a branch per partial the loads left one at a
+        // time and the in-flight count made no difference)
+        vec_t pv[SS_BU];
+#pragma unroll
+        for (int u = 0; u < SS_BU; ++u) {
+          const long ku = k + (long)u * S;
+          pv[u] = *reinterpret_cast<const vec_t*>(s.bnd + (chunk + 1 + (ku < L ? ku : 0)) * 2 * Cp + cs);
+        }
+#pragma unroll
+        for (int u = 0; u < SS_BU; ++u)
+          if (cok && k + (long)u * S < L) aN[u] += pv[u];
+      }
+#pragma unroll
+      for (int w = 1; w < SS_BU; w *= 2)
+#pragma unroll
+        for (int u = 0; u + w < SS_BU; u += 2 * w) aN[u] += aN[u + w];
+      const vec_t acc = aN[0];
       // the head chunk's own share (its last-run partial: slot 1), then the lane slots in order
       vec_t tot = cok ? *reinterpret_cast<const vec_t*>(s.bnd + chunk * 2 * Cp + Cp + c) : vec_t(0.f);
       for (int j = 0; j < S; ++j) {

@@ -84,16 +84,22 @@ def main():
         # ids): deterministic segmented sums of the history + target slices (gather backward), lazy-Adam row update, and
         # the bf16-table forms -- >= 22 launches each, for rocprofv3 --kernel-trace / --pmc (scripts/prof_embed.sh)
         Vi, Vc, Di, Dc, B = 100_000_000, 10000, 96, 32, Hn * G
+        taobao = os.environ.get("EMBED_SHAPE") == "taobao"      # BASELINE configs[1]: small Zipf vocabularies, narrow rows
+        if taobao:
+            Vi, Vc, Di, Dc = 64138, 4096, 32, 8
         D, n = Di + Dc, Hn * T
         gi, gc = torch.zeros(Vi, Di, device=dev), torch.zeros(Vc, Dc, device=dev)      # gradient tables (touches the pages)
         ii = torch.randint(1, Vi, (Hn, T), device=dev, dtype=torch.int32)
         ci = torch.randint(1, Vc, (Hn, T), device=dev, dtype=torch.int32)
+        if taobao:
+            ii = (torch.rand(Hn, T, device=dev).pow(8.0) * (Vi - 2)).int() + 1
+            ci = (torch.rand(Hn, T, device=dev).pow(8.0) * (Vc - 2)).int() + 1
         it, ct = torch.randint(1, Vi, (B,), device=dev, dtype=torch.int32), torch.randint(1, Vc, (B,), device=dev, dtype=torch.int32)
         ln = torch.full((Hn,), T, device=dev, dtype=torch.int32)
         keys = [torch.empty(n + B, dtype=torch.int32, device=dev) for _ in range(2)]
         perm = [torch.empty(n + B, dtype=torch.int32, device=dev) for _ in range(2)]
-        rows = [(ii.data_ptr(), keys[0].data_ptr(), perm[0].data_ptr(), Hn, T, T, 27, it.data_ptr(), B, 1),
-                (ci.data_ptr(), keys[1].data_ptr(), perm[1].data_ptr(), Hn, T, T, 14, ct.data_ptr(), B, 1)]
+        rows = [(ii.data_ptr(), keys[0].data_ptr(), perm[0].data_ptr(), Hn, T, T, 17 if taobao else 27, it.data_ptr(), B, 1),
+                (ci.data_ptr(), keys[1].data_ptr(), perm[1].data_ptr(), Hn, T, T, 12 if taobao else 14, ct.data_ptr(), B, 1)]
         wss = torch.empty(query("clsr_sort_ids_stable_workspace_bytes", 2 * (n + B), 2), dtype=torch.uint8, device=dev)
         t = timeit(lambda: ops.sort_ids_stable_multi(rows, wss), iters=5)
         print("stable radix sort of 2 x %d ids (27 / 14 bits): %8.1f us" % (n + B, t))
@@ -111,6 +117,8 @@ def main():
             nbytes = n * D * sa + n * D * 4 + 2 * n * 4 + B * D * 8 + 2 * B * 4
             print("segmented sums (item + category, history + target slices, stored once), %s: %8.1f us  %.0f GB/s "
                   "algorithmic (%.1f%% of 8 TB/s)" % (tag, t, nbytes / t / 1e3, nbytes / t / 1e3 / 80))
+        if taobao:
+            return
         ids = torch.unique(keys[0].long()).int()
         nrows = ids.numel()
         count = torch.tensor([nrows, 0], dtype=torch.int32, device=dev)
