@@ -658,6 +658,118 @@ static int pgemm_dispatch_one(const PGemmArgs& a, hipStream_t s) {
   return launch_pgemm<8>(a, s);
 }
 
+// ------------------------------------------------------------------------------------ wide-K products
+// Y[m, :N] (=|+=) X[m, :K] . W (+ bias) for WIDE inputs (K >= 256, N <= 128: d(hist) = dPin . W_x^T at the 128-wide layer
+// sizes of BASELINE configs[4], K = 1 536).  pgemm_fast keeps the whole W^T chunk of a workgroup in LDS and ran such a
+// product as a chain of nine launches over K ranges, each re-reading and re-writing the output (4.7 ms of the 13.5 ms
+// catalogue step, profiles/r04_catalogue_step_timeline.txt).  Here the K loop is INSIDE the kernel: a workgroup owns 128
+// positions x all out-features (X is read once, Y written once), its four waves 64 positions x 64 features each
+// (16 accumulator tiles), and 32-wide K stages of W^T and X rows are double-buffered through LDS -- the loads of stage
+// s + 1 are in flight while stage s is multiplied, one barrier per stage.  Same orientation and k-slot map as above.
+#define PKL_ST 36                 // LDS row stride of a 32-wide stage (floats): 9 x 16 B, conflict-free operand reads
+struct PKLArgs { const float* X; int ldx; const float* Wt; int Kp; const float* bias; float* Y; int ldy; int accumulate; int M, K, N, opad; };
+
+__global__ void __launch_bounds__(256, 2) pgemm_kloop_kernel(PKLArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float pkl_lds[];
+  float (*Ws)[128 * PKL_ST] = reinterpret_cast<float (*)[128 * PKL_ST]>(pkl_lds);
+  float (*Xs)[128 * PKL_ST] = reinterpret_cast<float (*)[128 * PKL_ST]>(pkl_lds + 2 * 128 * PKL_ST);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+  const long p0 = (long)blockIdx.x * 128;
+  const int wp = (wave & 1) * 64, wo = (wave >> 1) * 64;      // this wave's positions / out-features inside the tile
+  // staging: thread -> (row = tid / 8 + 32 * q, 16-byte chunk tid % 8) of both operands
+  const int sr = tid >> 3, sc = (tid & 7) * 4;
+  f32x4 wv[4], xv[4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = sr + 32 * q;
+      const bool kin = k0 + sc < a.K;            // (K % 4 == 0: a chunk is inside or outside)
+      wv[q] = (kin && r < a.opad) ? ld4(a.Wt + (long)r * a.Kp + k0 + sc) : f32x4{0.f, 0.f, 0.f, 0.f};
+      xv[q] = (kin && p0 + r < a.M) ? ld4(a.X + (p0 + r) * a.ldx + k0 + sc) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto stash = [&](int b) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = sr + 32 * q;
+      st4(&Ws[b][r * PKL_ST + sc], wv[q]);
+      st4(&Xs[b][r * PKL_ST + sc], xv[q]);
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc[o][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nst = (a.K + 31) / 32;
+  const int not_ = min(4, (a.opad - wo + 15) / 16);      // out-tiles of this wave that exist (wave-uniform)
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int s = 0; s < nst; ++s) {
+    const int b = s & 1;
+    if (s + 1 < nst) fetch(32 * (s + 1));
+    if (not_ > 0) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        f32x4 wa[4], xb[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) wa[o] = ld4(&Ws[b][(wo + 16 * o + j) * PKL_ST + 16 * kt + 4 * g]);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) xb[p] = ld4(&Xs[b][(wp + 16 * p + j) * PKL_ST + 16 * kt + 4 * g]);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          if (o < not_) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+              MFMA4(acc[o][p], wa[o].x, xb[p].x);
+              MFMA4(acc[o][p], wa[o].y, xb[p].y);
+              MFMA4(acc[o][p], wa[o].z, xb[p].z);
+              MFMA4(acc[o][p], wa[o].w, xb[p].w);
+            }
+          }
+        }
+      }
+    }
+    if (s + 1 < nst) stash(b ^ 1);       // (buffer b ^ 1 was last read in stage s - 1: every wave is past that barrier)
+    __syncthreads();
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    const int f0 = wo + 16 * o + 4 * g;
+    if (o < not_ && f0 < a.N) {
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias) bv = f32x4{a.bias[f0], a.bias[f0 + 1], a.bias[f0 + 2], a.bias[f0 + 3]};
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const long m = p0 + wp + 16 * p + j;
+        if (m < a.M) {
+          float* y = a.Y + m * a.ldy + f0;
+          f32x4 v = acc[o][p] + bv;
+          if (a.accumulate) v += ld4(y);
+          st4(y, v);
+        }
+      }
+    }
+  }
+}
+
+static bool pgemm_kloop_ok(const PGemmArgs& a) {
+  static const bool off = getenv("CLSR_PGEMM_NO_KLOOP") != nullptr;
+  return !off && a.K >= 256 && a.N <= 128 && a.T == 0 && a.G == 0 && !a.Xmul && !a.in_scale && !a.addU && !a.addV && !a.stats &&
+         !a.ez && a.rm_tc == 0 && a.M >= 128 * 256;
+}
+static int launch_pgemm_kloop(const PGemmArgs& a, hipStream_t s) {
+  PKLArgs k;
+  k.X = a.X; k.ldx = a.ldx; k.Wt = a.Wt; k.Kp = a.ldw ? a.ldw : a.Kp; k.bias = a.bias; k.Y = a.Y; k.ldy = a.ldy;
+  k.accumulate = a.accumulate; k.M = a.M; k.K = a.K; k.N = a.N; k.opad = 16 * clsr_cdiv(a.N, 16);
+  const size_t shmem = (size_t)4 * 128 * PKL_ST * sizeof(float);
+  CLSR_HIP(hipFuncSetAttribute((const void*)pgemm_kloop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL(pgemm_kloop_kernel, dim3(clsr_cdiv(a.M, 128)), dim3(256), shmem, s, k);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
 // W^T chunk of one workgroup = 16 * OT rows x Kp floats in LDS.  Wide inputs (K > ~290 for 8 out-tiles, the
 // 128-wide layer sizes of BASELINE configs[4]) are processed as a chain of launches over K ranges that
 // accumulate into Y: the first launch carries the bias / addU / addV terms, the last one the statistics and the
@@ -674,6 +786,7 @@ static int pgemm_dispatch(const PGemmArgs& a0, hipStream_t s) {
   }();
   const int kmax = (int)(budget / ((size_t)16 * ot * sizeof(float))) / 16 * 16;
   if (a.Kp <= kmax) return pgemm_dispatch_one(a, s);
+  if (pgemm_kloop_ok(a)) return launch_pgemm_kloop(a, s);
   for (int k0 = 0; k0 < a.K; k0 += kmax) {
     PGemmArgs c = a;
     const bool first = k0 == 0, last = k0 + kmax >= a.K;

@@ -6,10 +6,10 @@ tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 re='ss_chunks|ss_borders|table_adam_rows|gather_hist_fwd_h'
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pe /tmp/pe_F /tmp/pe_W
-rocprofv3 --kernel-trace --kernel-include-regex "$re" --output-format csv -d /tmp/pe -o e -- python $root/scripts/prof_kernels.py embed > /tmp/pe.log 2>&1
+timeout 500 rocprofv3 --kernel-trace --kernel-include-regex "$re" --output-format csv -d /tmp/pe -o e -- python $root/scripts/prof_kernels.py embed > /tmp/pe.log 2>&1
 cp /tmp/pe.log $root/gpurun_out/${tag}_embed_isolated.txt
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "$re" --output-format csv -d /tmp/pe_${c:0:1} -o e -- python $root/scripts/prof_kernels.py embed > /tmp/pe_$c.log 2>&1
+  timeout 500 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "$re" --output-format csv -d /tmp/pe_${c:0:1} -o e -- python $root/scripts/prof_kernels.py embed > /tmp/pe_$c.log 2>&1
 done
 python - $(find /tmp/pe -name "*kernel_trace.csv" | head -1) $(find /tmp/pe_F -name "*counter_collection.csv" | head -1) $(find /tmp/pe_W -name "*counter_collection.csv" | head -1) > $root/gpurun_out/${tag}_embed_kernel_trace.md <<'PY'
 import csv, re, sys

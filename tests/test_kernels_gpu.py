@@ -209,6 +209,22 @@ def test_pgemm_plain_bias_stats(M, K, N):
     close(Y2, 2 * exp - b, rtol=1e-5, atol=2 * tol, name="accumulate")
 
 
+@pytest.mark.parametrize("M,K,N", [(32768, 1536, 128), (40000, 512, 96), (33000, 260, 40), (32768 + 77, 1000, 128)])
+def test_pgemm_wide_k_in_kernel_loop(M, K, N):
+    """Wide inputs on many positions (K >= 256, N <= 128, M >= 32 768: d(hist) = dPin . W_x^T of BASELINE configs[4]) take the
+    kernel that loops over K itself (pgemm_kloop_kernel) instead of a chain of launches over K ranges: plain product, bias,
+    accumulation, ragged last workgroup, K not a multiple of the 32-wide stage, a strided input."""
+    g = torch.Generator().manual_seed(M + K + N)
+    X, W, b = rnd(g, M, K + 8), rnd(g, K, N, scale=0.3), rnd(g, N)
+    Xs = X[:, :K]
+    exp = Xs @ W + b
+    tol = 1e-5 * max(1.0, (K / 100.0) ** 0.5)
+    Y, _ = _pgemm(X, W, b, M=M, ldx=K + 8)
+    close(Y, exp, rtol=1e-5, atol=tol, name="Y")
+    Y2, _ = _pgemm(X, W, None, Y=Y.clone(), accumulate=1, M=M, ldx=K + 8)
+    close(Y2, 2 * exp - b, rtol=2e-5, atol=4 * tol, name="accumulate")     # (two fp32 roundings of sums of ~1 500 products)
+
+
 def test_pgemm_rowmap_mul_affine_adds():
     g = torch.Generator().manual_seed(5)
     Hn, G, T, K, N = 13, 5, 10, 80, 80
