@@ -1,0 +1,196 @@
+// Weight gradients of WIDE layers: dW[k, n] = sum_m X[m, k] * dY[m, n], db[n] = sum_m dY[m, n]  (gfx950, fp32 MFMA).
+//
+// Reference: the gradients tf.gradients builds for the input-side and hidden-to-hidden kernels of GRUCell / Time4LSTMCell
+// (models/sequential/rnn_cell_implement.py:129-298, tf.nn.rnn_cell.GRUCell at clsr.py:160-168, 229-237) at the layer sizes
+// of BASELINE configs[4] (hidden 128, embedding 128: K, N in 128 .. 1 536 over M = 204 800 positions).
+//
+// Why a second dW kernel: pgemm_dw_kernel (csrc/linear.hip) gives every wave an 80 x 80 accumulator chunk of the output
+// -- the reference's default widths are 40 .. 80 -- and walks wider outputs as a grid of such chunks, every chunk
+// re-reading its X and dY columns: the 128 x 1 536 input-side gradient of the catalogue step read dPin twice and hist
+// twenty times, and the one multi-job launch of the encoders' weight gradients took 4.4 ms, the last third of the
+// 13 ms step (profiles/r04_catalogue_step_timeline.txt).  Here a workgroup owns a 128 x 128 output tile (its four waves
+// 64 x 64 each: 16 accumulator tiles) over a contiguous range of positions; 32-position stages of both operands are
+// double-buffered through LDS with the next stage's loads in flight behind the MFMAs, one barrier per stage.  X is read
+// N / 128 times, dY K / 128 times.  The position ranges' partial tiles go to a workspace [S][K][N] (+ [S][N] column sums)
+// and are added in range order by a second launch: no float atomics, bit-identical results run to run.
+//
+// MFMA tile D[16 k][16 n] += A[16 k][4 m] . B[4 m][16 n]: lane (i, g) supplies X[4s + g][k0 + i] and dY[4s + g][n0 + i]
+// for the four positions 4s .. 4s + 3 of MFMA step s; the row stride of the LDS stages is 144 floats (= 16 mod 32 banks:
+// the two position rows a half-wave reads sit in disjoint banks).
+#include "common.h"
+#include "clsr_hip.h"
+
+#define DWW_ST 144
+#define DWW_STAGE (32 * DWW_ST)
+
+struct DwwArgs {
+  const float* X; int ldx; const float* dY; int ldy; float* part; float* bpart; int M, K, N, mper, S;
+};
+
+__global__ void __launch_bounds__(256, 2) dw_wide_kernel(DwwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float dww_lds[];
+  float* Xs = dww_lds;                       // [2][32][DWW_ST]
+  float* Ys = dww_lds + 2 * DWW_STAGE;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
+  const int k0 = blockIdx.y * 128, n0 = blockIdx.z * 128;
+  const int wk = (wave & 1) * 64, wn = (wave >> 1) * 64;
+  const long m0 = (long)blockIdx.x * a.mper;
+  const long m1 = m0 + a.mper < a.M ? m0 + a.mper : a.M;
+  // staging: thread -> (position tid / 32 + 8 q, 16-byte chunk tid % 32) of both operands
+  const int sr = tid >> 5, sc = (tid & 31) * 4;
+  const bool kin = k0 + sc < a.K, nin = n0 + sc < a.N;       // (K % 4 == N % 4 == 0)
+  f32x4 xv[4], yv[4];
+  auto fetch = [&](long m) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long r = m + sr + 8 * q;
+      xv[q] = (kin && r < m1) ? ld4(a.X + r * a.ldx + k0 + sc) : f32x4{0.f, 0.f, 0.f, 0.f};
+      yv[q] = (nin && r < m1) ? ld4(a.dY + r * a.ldy + n0 + sc) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto stash = [&](int b) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      st4(Xs + b * DWW_STAGE + (sr + 8 * q) * DWW_ST + sc, xv[q]);
+      st4(Ys + b * DWW_STAGE + (sr + 8 * q) * DWW_ST + sc, yv[q]);
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[kt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool want_b = a.bpart && blockIdx.y == 0 && wk == 0;
+  const int nst = (int)((m1 - m0 + 31) / 32);
+  if (nst > 0) {
+    fetch(m0);
+    stash(0);
+  }
+  __syncthreads();
+  for (int s = 0; s < nst; ++s) {
+    const int b = s & 1;
+    if (s + 1 < nst) fetch(m0 + 32L * (s + 1));
+    const float* xs = Xs + b * DWW_STAGE + wk + i;
+    const float* ys = Ys + b * DWW_STAGE + wn + i;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      float xa[4], yb[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        xa[t] = xs[(4 * st + g) * DWW_ST + 16 * t];
+        yb[t] = ys[(4 * st + g) * DWW_ST + 16 * t];
+      }
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) MFMA4(acc[kt][nt], xa[kt], yb[nt]);
+      if (want_b) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bs[nt] += yb[nt];
+      }
+    }
+    if (s + 1 < nst) stash(b ^ 1);
+    __syncthreads();
+  }
+  // D lane (j = i, g): rows k = 16 kt + 4 g + {0..3}, column n = 16 nt + j
+  float* P = a.part + (long)blockIdx.x * a.K * a.N;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = n0 + wn + 16 * nt + i;
+      const int k = k0 + wk + 16 * kt + 4 * g;
+      if (n < a.N) {
+        if (k + 0 < a.K) P[(long)(k + 0) * a.N + n] = acc[kt][nt].x;
+        if (k + 1 < a.K) P[(long)(k + 1) * a.N + n] = acc[kt][nt].y;
+        if (k + 2 < a.K) P[(long)(k + 2) * a.N + n] = acc[kt][nt].z;
+        if (k + 3 < a.K) P[(long)(k + 3) * a.N + n] = acc[kt][nt].w;
+      }
+    }
+  }
+  if (want_b) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      float v = bs[nt];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int n = n0 + wn + 16 * nt + i;
+      if (g == 0 && n < a.N) a.bpart[(long)blockIdx.x * a.N + n] = v;
+    }
+  }
+}
+
+// dW[k, n] (=|+=) sum over the S position ranges of part[s][k][n], in range order; db likewise
+__global__ void __launch_bounds__(256) dw_wide_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart,
+                                                             int S, int K, int N, float* __restrict__ dW, int ldw,
+                                                             float* __restrict__ db, int accumulate) {
+  const long KN = (long)K * N;
+  const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e < KN) {
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int s = 0;
+    for (; s + 3 < S; s += 4) {
+      s0 += ld4(part + (long)s * KN + e);
+      s1 += ld4(part + (long)(s + 1) * KN + e);
+      s2 += ld4(part + (long)(s + 2) * KN + e);
+      s3 += ld4(part + (long)(s + 3) * KN + e);
+    }
+    for (; s < S; ++s) s0 += ld4(part + (long)s * KN + e);
+    f32x4 v = (s0 + s1) + (s2 + s3);
+    const long k = e / N;
+    const int n = (int)(e - k * N);
+    float* o = dW + k * ldw + n;
+    if (accumulate) { v.x += o[0]; v.y += o[1]; v.z += o[2]; v.w += o[3]; }
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;          // (views of the flat gradient buffer: no 16-byte alignment)
+  }
+  if (db && bpart && blockIdx.x == 0) {
+    for (int n = threadIdx.x; n < N; n += 256) {
+      float v = 0.f;
+      for (int s = 0; s < S; ++s) v += bpart[(long)s * N + n];
+      db[n] = accumulate ? db[n] + v : v;
+    }
+  }
+}
+
+static int dww_parts(long M, int K, int N) {
+  const int tiles = clsr_cdiv(K, 128) * clsr_cdiv(N, 128);
+  int S = 1024 / tiles;
+  if (S < 8) S = 8;
+  if (S > 128) S = 128;
+  const long per = (M + 31) / 32;          // stages
+  if (S > per) S = (int)per;
+  return S < 1 ? 1 : S;
+}
+extern "C" int clsr_pgemm_dw_wide_supported(long M, int K, int N) {
+  return M >= 32768 && M < (1L << 31) && K >= 96 && N >= 96 && K % 4 == 0 && N % 4 == 0 && (long)K * N < (1L << 28);
+}
+extern "C" int clsr_pgemm_dw_wide_parts(long M, int K, int N) { return dww_parts(M, K, N); }
+extern "C" long clsr_pgemm_dw_wide_workspace_floats(long M, int K, int N) {
+  return (long)dww_parts(M, K, N) * ((long)K * N + N);
+}
+
+// dW [K, N] (row stride ldw) and optionally db [N] from X [M, K] (row stride ldx) and dY [M, N] (row stride ldy): two
+// launches on ``stream`` (partial tiles, then their sum in range order).  accumulate != 0: added to dW / db.
+extern "C" int clsr_pgemm_dw_wide(const float* X, int ldx, const float* dY, int ldy, long M, int K, int N, float* workspace,
+                                  float* dW, int ldw, float* db, int accumulate, void* stream) {
+  CLSR_CHECK_ARG(X && dY && workspace && dW && ldx >= K && ldy >= N && ldw >= N);
+  CLSR_CHECK_SUPPORTED(clsr_pgemm_dw_wide_supported(M, K, N));
+  CLSR_CHECK_SUPPORTED(ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)dY % 16) == 0 &&
+                       ((uintptr_t)workspace % 16) == 0);
+  DwwArgs a;
+  a.X = X; a.ldx = ldx; a.dY = dY; a.ldy = ldy; a.M = (int)M; a.K = K; a.N = N;
+  a.S = dww_parts(M, K, N);
+  a.mper = (int)(((M + a.S - 1) / a.S + 31) / 32 * 32);
+  a.S = (int)((M + a.mper - 1) / a.mper);          // (ranges that exist after rounding the range length up to whole stages)
+  a.part = workspace;
+  a.bpart = db ? workspace + (long)dww_parts(M, K, N) * K * N : nullptr;
+  const size_t shmem = (size_t)4 * DWW_STAGE * sizeof(float);
+  CLSR_HIP(hipFuncSetAttribute((const void*)dw_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL(dw_wide_kernel, dim3(a.S, clsr_cdiv(K, 128), clsr_cdiv(N, 128)), dim3(256), shmem, (hipStream_t)stream, a);
+  CLSR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(dw_wide_reduce_kernel, dim3(clsr_cdiv((long)K * N / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                     a.part, a.bpart, a.S, K, N, dW, ldw, db, accumulate);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}

@@ -157,6 +157,9 @@ class CLSRNet(object):
         # the row-level heads (alpha gate, alpha / logit MLPs, loss, their backward) as two persistent launches with grid
         # barriers for the batch-norm statistics (csrc/headsfused.hip) instead of a chain of 22 dependent launches
         self.heads_fused = not os.environ.get("CLSR_NO_HEADS_FUSED")
+        # weight gradients of wide layers (K, N >= 96: BASELINE configs[4]) by the 128 x 128-tile kernel (csrc/dwwide.hip)
+        self.dw_wide = not os.environ.get("CLSR_NO_DW_WIDE")
+        self._dw_batch_wide = None
         self._heads_defer = False
         self.fused_logit_tail = not os.environ.get("CLSR_NO_FUSED_LOGIT_TAIL")   # A/B: output layer + softmax loss + their backward in one launch
         self._defer_logit_out = False
@@ -616,6 +619,9 @@ class CLSRNet(object):
         """Weight gradient dW = f(X)^T dY.  Deferred: this launches only the kernel that writes the per-block
         partial chunks (into a workspace of its own); ``_dw_flush`` reduces every pending gradient of the current
         stream in ONE launch."""
+        if (self.dw_wide and not x_bf16 and not dy_bf16 and Xmul is None and aff is None and T == 0 and G == 0
+                and not (self.bf16 and self.bf16_dw) and not self.x3_dw and query("clsr_pgemm_dw_wide_supported", M, K, N)):
+            return self._dw_wide(X, ldx, dY, ldy, M, K, N, dW, ldw, db, acc)
         pend = self._dw_pending.setdefault(self._ws_tag, [])
         need = query("clsr_pgemm_dw_workspace_floats", M, K, N)
         ws = self._buf("dw_ws%s.%d" % (self._ws_tag, len(pend)), max(need, 1))
@@ -645,6 +651,23 @@ class CLSRNet(object):
         if not self.defer_dw:
             self._dw_flush()
 
+    def _dw_wide(self, X, ldx, dY, ldy, M, K, N, dW, ldw, db, acc):
+        """Wide layer (K, N >= 96): partial tiles + their sum as two launches of csrc/dwwide.hip, on the weight-gradient
+        stream like the other products (inside ``_dw_batched``: behind the block's multi-job launch); the gradient is
+        complete when ``_dw_flush`` has joined that stream -- nothing is left for the batched reduction."""
+        key = "dww_ws%s.%d.%d.%d" % (self._ws_tag, K, N, dW.data_ptr() % 1000003)
+        ws = self._buf(key, query("clsr_pgemm_dw_wide_workspace_floats", M, K, N))
+        job = (X, ldx, dY, ldy, M, K, N, ws, dW, ldw, db, acc)
+        if self._dw_batch is not None:
+            self._dw_batch_wide.append(job)
+            return
+        side = None
+        if self.dw_stream and self.overlap and self._ws_tag == "":
+            side = self._side_stream("@dw0")
+            ops.stream_wait(side, self._fork_point())
+            self._dw_async = True
+        call("clsr_pgemm_dw_wide", *job, stream=side.cuda_stream if side is not None else None)
+
     @contextlib.contextmanager
     def _dw_batched(self, late=False):
         """Every ``_dw`` issued inside the block becomes a job of ONE launch (clsr_*_dw_partial_multi) that waits only
@@ -656,12 +679,13 @@ class CLSRNet(object):
             return
         fork = self._fork_point()
         allocs = self._buf_allocs
-        self._dw_batch = []
+        self._dw_batch, self._dw_batch_wide = [], []
         try:
             yield
         finally:
             jobs, self._dw_batch = self._dw_batch, None
-        if not jobs:
+            wide, self._dw_batch_wide = self._dw_batch_wide, None
+        if not jobs and not wide:
             return
         if late or self._buf_allocs != allocs:
             # ``late``: the jobs' operands are produced INSIDE the block (small products of one backward stage whose
@@ -677,10 +701,16 @@ class CLSRNet(object):
             if side is None:
                 side = self._side_stream("@dw0")
             ops.stream_wait(side, fork)
-            ops.dw_multi(name, jobs, stream=side.cuda_stream)
+            if jobs:
+                ops.dw_multi(name, jobs, stream=side.cuda_stream)
+            for job in wide:
+                call("clsr_pgemm_dw_wide", *job, stream=side.cuda_stream)
             self._dw_async = True
         else:
-            ops.dw_multi(name, jobs)
+            if jobs:
+                ops.dw_multi(name, jobs)
+            for job in wide:
+                call("clsr_pgemm_dw_wide", *job)
 
     def _x3_site(self, wkey):
         """does the product with the packed weights ``wkey`` run as a split-bf16 product (fp32x3 mode)?"""

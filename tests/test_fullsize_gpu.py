@@ -157,6 +157,39 @@ def test_catalogue_dims_match_oracle_on_a_slice():
         assert d <= 2e-3 * float(grads[name].abs().max()) + 3e-6 * gs, (name, d)
 
 
+def test_wide_layer_kernels_match_the_narrow_ones_at_catalogue_widths():
+    """The kernels that only engage at the 128-wide layer sizes on many positions -- the in-kernel K loop of the wide-K
+    products (pgemm_kloop_kernel) and the 128 x 128-tile weight gradients (csrc/dwwide.hip) -- against the chunked launches
+    they replace: one whole training step each way from the same state, BASELINE configs[4] widths, 1 024 x 50 positions."""
+    from clsr_amd.synthetic import synthetic_feed
+
+    cfg = dict(Vu=3000, Vi=20000, Vc=400, Di=96, Dc=32, Du=128, H=128, T=50, P=1024)
+    feed = synthetic_feed(cfg["P"], cfg["T"], cfg["Vu"], cfg["Vi"], cfg["Vc"], lengths="lognormal", seed=9)
+    res = []
+    sd = None
+    for wide in (True, False):
+        os.environ.pop("CLSR_PGEMM_NO_KLOOP", None)
+        hp, net = _net(cfg, cfg["P"], seed=3)
+        if sd is None:
+            sd = net.state_dict()
+        net.load_state_dict(sd)
+        net.dw_wide = wide
+        net.capture_grads = True
+        out = net.train_step(net.upload(feed, True))
+        torch.cuda.synchronize()
+        res.append((out["logit"].clone(), net.read_losses(), {k: v.clone() for k, v in net.captured["dense"].items()}))
+    (la, lossa, ga), (lb, lossb, gb) = res
+    assert float((la - lb).abs().max()) <= 1e-5
+    for k in lossa:
+        assert abs(lossa[k] - lossb[k]) <= 2e-6 * max(1.0, abs(lossb[k])), k
+    gs = max(float(g.abs().max()) for g in gb.values())
+    worst = 0.0
+    for name, g in gb.items():
+        d = float((ga[name] - g).abs().max())
+        worst = max(worst, d / (float(g.abs().max()) + 1e-30))
+        assert d <= 5e-4 * float(g.abs().max()) + 2e-5 * gs, (name, d, float(g.abs().max()))
+
+
 def test_catalogue100m_full_size_step():
     """BASELINE configs[4] on one GPU: 100M-item catalogue (38 GB table + gradient table + lazy-Adam slots),
     128-wide layers, lazy Adam through the involved-row lists.  Properties: finite losses, only rows that were

@@ -271,6 +271,38 @@ def test_pgemm_dw(M, K, N):
     close(dW, 1.5 * (X.T @ dY), rtol=2e-5, atol=3e-4, name="dW accumulate")
 
 
+@pytest.mark.parametrize("M,K,N,bias", [(40000, 128, 1536, True), (32768 + 5, 256, 384, False), (33000, 100, 96, True),
+                                         (70000, 128, 128, True)])
+def test_pgemm_dw_wide(M, K, N, bias):
+    """Weight gradients of wide layers (csrc/dwwide.hip: 128 x 128 output tiles over position ranges, partial tiles summed in
+    range order): against X^T dY in float64, strided operands, ragged position ranges / tiles, accumulation, and bit-identical
+    results of two runs."""
+    g = torch.Generator().manual_seed(M + K + N)
+    X, dY = rnd(g, M, K + 4), rnd(g, M, N + 8, scale=0.1)
+    dX, ddY = dev(X, torch.float32), dev(dY, torch.float32)
+    assert query("clsr_pgemm_dw_wide_supported", M, K, N) == 1
+    ws = torch.empty(query("clsr_pgemm_dw_wide_workspace_floats", M, K, N), device="cuda")
+    exp = X[:, :K].double().T @ dY[:, :N].double()
+    expb = dY[:, :N].double().sum(0)
+    outs = []
+    for _ in range(2):
+        dW = torch.full((K, N + 3), 7.0, device="cuda")
+        db = torch.full((N,), 7.0, device="cuda") if bias else None
+        call("clsr_pgemm_dw_wide", dX, K + 4, ddY, N + 8, M, K, N, ws, dW, N + 3, db, 0)
+        outs.append((dW.clone(), None if db is None else db.clone()))
+    tol = 3e-6 * float(exp.abs().max()) + 1e-5
+    close(outs[0][0][:, :N], exp, rtol=2e-5, atol=tol, name="dW")
+    assert float((outs[0][0][:, N:] - 7.0).abs().max()) == 0.0, "columns past N must stay untouched"
+    if bias:
+        close(outs[0][1], expb, rtol=2e-5, atol=3e-6 * float(expb.abs().max()) + 1e-5, name="db")
+        assert torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][0], outs[1][0]), "two runs must agree bit for bit"
+    dW2 = outs[0][0].clone()
+    call("clsr_pgemm_dw_wide", dX, K + 4, ddY, N + 8, M, K, N, ws, dW2, N + 3, None, 1)
+    close(dW2[:, :N], 2 * exp, rtol=2e-5, atol=2 * tol, name="accumulate")
+    assert query("clsr_pgemm_dw_wide_supported", 1000, K, N) == 0 and query("clsr_pgemm_dw_wide_supported", M, 80, N) == 0
+
+
 def test_pgemm_dw_prologues():
     g = torch.Generator().manual_seed(8)
     Hn, G, T, K, N = 11, 5, 10, 80, 80
