@@ -24,6 +24,7 @@
 #define DWW_STAGE (32 * DWW_ST)
 
 struct DwwArgs {
+  const float* Xmul; int ldmul;          // optional: X[m, k] * Xmul[m, k] (the candidate kernel of a GRU: r * h)
   const float* X; int ldx; const float* dY; int ldy; float* part; float* bpart; int M, K, N, mper, S;
 };
 
@@ -45,6 +46,7 @@ __global__ void __launch_bounds__(256, 2) dw_wide_kernel(DwwArgs a) {
     for (int q = 0; q < 4; ++q) {
       const long r = m + sr + 8 * q;
       xv[q] = (kin && r < m1) ? ld4(a.X + r * a.ldx + k0 + sc) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a.Xmul && kin && r < m1) xv[q] *= ld4(a.Xmul + r * a.ldmul + k0 + sc);
       yv[q] = (nin && r < m1) ? ld4(a.dY + r * a.ldy + n0 + sc) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
@@ -128,16 +130,16 @@ __global__ void __launch_bounds__(256) dw_wide_reduce_kernel(const float* __rest
   const long KN = (long)K * N;
   const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (e < KN) {
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    f32x4 sN[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sN[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     int s = 0;
-    for (; s + 3 < S; s += 4) {
-      s0 += ld4(part + (long)s * KN + e);
-      s1 += ld4(part + (long)(s + 1) * KN + e);
-      s2 += ld4(part + (long)(s + 2) * KN + e);
-      s3 += ld4(part + (long)(s + 3) * KN + e);
+    for (; s + 7 < S; s += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sN[u] += ld4(part + (long)(s + u) * KN + e);
     }
-    for (; s < S; ++s) s0 += ld4(part + (long)s * KN + e);
-    f32x4 v = (s0 + s1) + (s2 + s3);
+    for (; s < S; ++s) sN[0] += ld4(part + (long)s * KN + e);
+    f32x4 v = ((sN[0] + sN[1]) + (sN[2] + sN[3])) + ((sN[4] + sN[5]) + (sN[6] + sN[7]));
     const long k = e / N;
     const int n = (int)(e - k * N);
     float* o = dW + k * ldw + n;
@@ -155,7 +157,7 @@ __global__ void __launch_bounds__(256) dw_wide_reduce_kernel(const float* __rest
 
 static int dww_parts(long M, int K, int N) {
   const int tiles = clsr_cdiv(K, 128) * clsr_cdiv(N, 128);
-  int S = 1024 / tiles;
+  int S = 512 / tiles;        // (~512 workgroups: one round at two per CU; fewer partial tiles to add up afterwards)
   if (S < 8) S = 8;
   if (S > 128) S = 128;
   const long per = (M + 31) / 32;          // stages
@@ -170,15 +172,18 @@ extern "C" long clsr_pgemm_dw_wide_workspace_floats(long M, int K, int N) {
   return (long)dww_parts(M, K, N) * ((long)K * N + N);
 }
 
-// dW [K, N] (row stride ldw) and optionally db [N] from X [M, K] (row stride ldx) and dY [M, N] (row stride ldy): two
+// dW [K, N] (row stride ldw) and optionally db [N] from X [M, K] (row stride ldx; times Xmul [M, K] element-wise when
+// given) and dY [M, N] (row stride ldy): two
 // launches on ``stream`` (partial tiles, then their sum in range order).  accumulate != 0: added to dW / db.
-extern "C" int clsr_pgemm_dw_wide(const float* X, int ldx, const float* dY, int ldy, long M, int K, int N, float* workspace,
-                                  float* dW, int ldw, float* db, int accumulate, void* stream) {
+extern "C" int clsr_pgemm_dw_wide(const float* X, int ldx, const float* Xmul, int ldmul, const float* dY, int ldy, long M, int K,
+                                  int N, float* workspace, float* dW, int ldw, float* db, int accumulate, void* stream) {
   CLSR_CHECK_ARG(X && dY && workspace && dW && ldx >= K && ldy >= N && ldw >= N);
+  CLSR_CHECK_SUPPORTED(!Xmul || (ldmul >= K && ldmul % 4 == 0 && ((uintptr_t)Xmul % 16) == 0));
   CLSR_CHECK_SUPPORTED(clsr_pgemm_dw_wide_supported(M, K, N));
   CLSR_CHECK_SUPPORTED(ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)dY % 16) == 0 &&
                        ((uintptr_t)workspace % 16) == 0);
   DwwArgs a;
+  a.Xmul = Xmul; a.ldmul = ldmul;
   a.X = X; a.ldx = ldx; a.dY = dY; a.ldy = ldy; a.M = (int)M; a.K = K; a.N = N;
   a.S = dww_parts(M, K, N);
   a.mper = (int)(((M + a.S - 1) / a.S + 31) / 32 * 32);

@@ -161,6 +161,7 @@ class CLSRNet(object):
         self.dw_wide = not os.environ.get("CLSR_NO_DW_WIDE")
         self._dw_batch_wide = None
         self._heads_defer = False
+        self._early_lists = None
         self.fused_logit_tail = not os.environ.get("CLSR_NO_FUSED_LOGIT_TAIL")   # A/B: output layer + softmax loss + their backward in one launch
         self._defer_logit_out = False
         self.early_scatter = not os.environ.get("CLSR_NO_EARLY_SCATTER")   # A/B: row scatters of the user / target lookups beside the encoder-backward tail instead of behind it
@@ -619,9 +620,9 @@ class CLSRNet(object):
         """Weight gradient dW = f(X)^T dY.  Deferred: this launches only the kernel that writes the per-block
         partial chunks (into a workspace of its own); ``_dw_flush`` reduces every pending gradient of the current
         stream in ONE launch."""
-        if (self.dw_wide and not x_bf16 and not dy_bf16 and Xmul is None and aff is None and T == 0 and G == 0
+        if (self.dw_wide and not x_bf16 and not dy_bf16 and aff is None and T == 0 and G == 0
                 and not (self.bf16 and self.bf16_dw) and not self.x3_dw and query("clsr_pgemm_dw_wide_supported", M, K, N)):
-            return self._dw_wide(X, ldx, dY, ldy, M, K, N, dW, ldw, db, acc)
+            return self._dw_wide(X, ldx, Xmul, ldmul, dY, ldy, M, K, N, dW, ldw, db, acc)
         pend = self._dw_pending.setdefault(self._ws_tag, [])
         need = query("clsr_pgemm_dw_workspace_floats", M, K, N)
         ws = self._buf("dw_ws%s.%d" % (self._ws_tag, len(pend)), max(need, 1))
@@ -651,13 +652,13 @@ class CLSRNet(object):
         if not self.defer_dw:
             self._dw_flush()
 
-    def _dw_wide(self, X, ldx, dY, ldy, M, K, N, dW, ldw, db, acc):
+    def _dw_wide(self, X, ldx, Xmul, ldmul, dY, ldy, M, K, N, dW, ldw, db, acc):
         """Wide layer (K, N >= 96): partial tiles + their sum as two launches of csrc/dwwide.hip, on the weight-gradient
         stream like the other products (inside ``_dw_batched``: behind the block's multi-job launch); the gradient is
         complete when ``_dw_flush`` has joined that stream -- nothing is left for the batched reduction."""
         key = "dww_ws%s.%d.%d.%d" % (self._ws_tag, K, N, dW.data_ptr() % 1000003)
         ws = self._buf(key, query("clsr_pgemm_dw_wide_workspace_floats", M, K, N))
-        job = (X, ldx, dY, ldy, M, K, N, ws, dW, ldw, db, acc)
+        job = (X, ldx, Xmul, ldmul, dY, ldy, M, K, N, ws, dW, ldw, db, acc)
         if self._dw_batch is not None:
             self._dw_batch_wide.append(job)
             return
@@ -1900,6 +1901,12 @@ class CLSRNet(object):
                 call("clsr_count_flags_tick", fl["user_long"], self.dims["Vu"], self.ucount, self.adam_state,
                      float(hp.learning_rate), 0.9, 0.999)
                 self._ticked = True
+            if apply and self.dp_hooks is None:
+                # ... and so do the ascending lists of the touched rows of the big tables (lazy Adam): one single-workgroup
+                # scan over the 100M-row byte map of BASELINE configs[4] is 0.33 ms + 0.15 ms of list writing -- under the
+                # forward here, they were the first half millisecond of the update phase
+                self._early_lists = {k: self._involved_list(k) for k, t in self.tables.items()
+                                     if t.numel() > self.rowlist_min_elems}
         o = [0]
 
         def take(*shape):
@@ -2312,7 +2319,9 @@ class CLSRNet(object):
             if not self.capture_grads:
                 call("clsr_dense_adam", self.dense, self.dense_grad, self.dense_m, self.dense_v, self.seg_of,
                      self.dense_sumsq, clip, self.adam_state, 0.9, 0.999, 1e-8, self.n_dense)
-        lists = {k: self._involved_list(k) for k, t in tb.items() if t.numel() > self.rowlist_min_elems}
+        lists, self._early_lists = self._early_lists, None
+        if lists is None:
+            lists = {k: self._involved_list(k) for k, t in tb.items() if t.numel() > self.rowlist_min_elems}
         spec = self._update_spec()
         sweep = []
         for key, partner, slot, dscale, dloss_scale, dloss, base, nsum in spec:

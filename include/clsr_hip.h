@@ -116,14 +116,14 @@ long clsr_segsum_workspace_bytes(const clsr_segsum_desc* descs_host, int n);
 /* the sites of one call must write different tables (or disjoint columns); nothing else may write them meanwhile */
 int clsr_segsum_multi(const clsr_segsum_desc* descs_host, int n, void* workspace, long workspace_bytes, void* stream);
 /* Weight gradient of a WIDE layer (K, N >= 96 over M >= 32 768 positions: the 128-wide layer sizes of BASELINE configs[4]):
- * dW[k, n] (=|+=) sum_m X[m, k] * dY[m, n], db[n] (=|+=) sum_m dY[m, n] (db may be NULL); 128 x 128 output tiles over position
+ * dW[k, n] (=|+=) sum_m X[m, k] (* Xmul[m, k], optional) * dY[m, n], db[n] (=|+=) sum_m dY[m, n] (db may be NULL); 128 x 128 tiles over position
  * ranges, partial tiles summed in range order by a second launch (csrc/dwwide.hip; reference: the kernel gradients of
  * GRUCell / Time4LSTMCell, rnn_cell_implement.py:129-298).  workspace: clsr_pgemm_dw_wide_workspace_floats floats. */
 int clsr_pgemm_dw_wide_supported(long M, int K, int N);
 int clsr_pgemm_dw_wide_parts(long M, int K, int N);
 long clsr_pgemm_dw_wide_workspace_floats(long M, int K, int N);
-int clsr_pgemm_dw_wide(const float* X, int ldx, const float* dY, int ldy, long M, int K, int N, float* workspace,
-                       float* dW, int ldw, float* db, int accumulate, void* stream);
+int clsr_pgemm_dw_wide(const float* X, int ldx, const float* Xmul, int ldmul, const float* dY, int ldy, long M, int K, int N,
+                       float* workspace, float* dW, int ldw, float* db, int accumulate, void* stream);
 
 /* ---- the row-level heads of the CLSR training step as two persistent launches (csrc/headsfused.hip) -------------------
  * Replaces, for the reference's default widths, the chain clsr_alpha_concat -> 2 x (clsr_pgemm + clsr_bn_finalize) ->

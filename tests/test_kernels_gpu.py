@@ -288,7 +288,7 @@ def test_pgemm_dw_wide(M, K, N, bias):
     for _ in range(2):
         dW = torch.full((K, N + 3), 7.0, device="cuda")
         db = torch.full((N,), 7.0, device="cuda") if bias else None
-        call("clsr_pgemm_dw_wide", dX, K + 4, ddY, N + 8, M, K, N, ws, dW, N + 3, db, 0)
+        call("clsr_pgemm_dw_wide", dX, K + 4, None, 0, ddY, N + 8, M, K, N, ws, dW, N + 3, db, 0)
         outs.append((dW.clone(), None if db is None else db.clone()))
     tol = 3e-6 * float(exp.abs().max()) + 1e-5
     close(outs[0][0][:, :N], exp, rtol=2e-5, atol=tol, name="dW")
@@ -298,9 +298,15 @@ def test_pgemm_dw_wide(M, K, N, bias):
         assert torch.equal(outs[0][1], outs[1][1])
     assert torch.equal(outs[0][0], outs[1][0]), "two runs must agree bit for bit"
     dW2 = outs[0][0].clone()
-    call("clsr_pgemm_dw_wide", dX, K + 4, ddY, N + 8, M, K, N, ws, dW2, N + 3, None, 1)
+    call("clsr_pgemm_dw_wide", dX, K + 4, None, 0, ddY, N + 8, M, K, N, ws, dW2, N + 3, None, 1)
     close(dW2[:, :N], 2 * exp, rtol=2e-5, atol=2 * tol, name="accumulate")
     assert query("clsr_pgemm_dw_wide_supported", 1000, K, N) == 0 and query("clsr_pgemm_dw_wide_supported", M, 80, N) == 0
+    # element-wise multiplier on X (the candidate kernel of a GRU: (r * h)^T d(candidate))
+    Xm = rnd(g, M, K + 12)
+    dW3 = torch.zeros(K, N, device="cuda")
+    call("clsr_pgemm_dw_wide", dX, K + 4, dev(Xm, torch.float32), K + 12, ddY, N + 8, M, K, N, ws, dW3, N, None, 0)
+    exp3 = (X[:, :K].double() * Xm[:, :K].double()).T @ dY[:, :N].double()
+    close(dW3, exp3, rtol=2e-5, atol=3e-6 * float(exp3.abs().max()) + 1e-5, name="dW with multiplier")
 
 
 def test_pgemm_dw_prologues():
