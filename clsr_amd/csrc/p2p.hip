@@ -149,6 +149,18 @@ extern "C" int clsr_comm_destroy(void* comm) {
   delete (P2PComm*)comm;
   return CLSR_OK;
 }
+// Forget which stream owns which channel (the sequence numbers of the channels go on): the next all-reduces assign the
+// channels afresh in order of first use.  Every rank must call it at the same point of its call sequence (after a
+// self-test on temporary streams: a later stream that happens to reuse a destroyed stream's address on ONE rank only
+// would otherwise land on a different channel there).
+extern "C" int clsr_comm_reset_channels(void* comm) {
+  CLSR_CHECK_ARG(comm);
+  P2PComm* c = (P2PComm*)comm;
+  CLSR_HIP(hipDeviceSynchronize());
+  c->nch = 0;
+  for (int i = 0; i < P2P_NCH; ++i) c->stream_of[i] = nullptr;
+  return CLSR_OK;
+}
 // sequence number of the last all-reduce in which this rank gave up waiting for a peer (0: none); synchronises the device
 extern "C" long clsr_comm_error(void* comm) {
   if (!comm) return -1;

@@ -144,11 +144,28 @@ class DataParallel(object):
             try:
                 from clsr_amd import p2p
                 self.comm = p2p.from_process_group(self.rank, self.world, group)
+                # self-test before the step depends on it: sums of (rank + 1) * (i + 1) on two streams (two channels),
+                # checked on every rank
+                ok, why = self._p2p_self_test(), ""
+            except Exception as e:      # (no IPC between these devices / processes: the process group does it)
+                ok, why = False, str(e)[:80]
+            # ... and the verdict is agreed on by ALL ranks: one rank alone on the other transport would wait for
+            # collectives its peers never issue
+            votes = [None] * self.world
+            import torch.distributed as tdist      # (``dist`` may be a host-staged wrapper of the test rigs)
+            tdist.all_gather_object(votes, bool(ok), group=group)
+            if all(votes):
                 net.dp_comm = self.comm.handle
                 self.stats_transport = "p2p"
-            except Exception as e:      # (no IPC between these devices / processes: the process group does it)
+            else:
+                if self.comm is not None:
+                    try:
+                        self.comm.close()
+                    except Exception:
+                        pass
                 self.comm, net.dp_comm = None, None
-                self.stats_transport = "torch.distributed (p2p unavailable: %s)" % str(e)[:80]
+                self.stats_transport = "torch.distributed (p2p unavailable: %s)" % (
+                    why or "self-test failed on ranks %s" % [r for r, v in enumerate(votes) if not v])
         net.dp_hooks = self if self.overlap else None
         # sumsq_tab (16) + losses (8) travel together
         self.small = net.stats24       # the net's own 24 doubles: summed in place, no staging copies
@@ -381,6 +398,25 @@ class DataParallel(object):
     def _backward(self, f):
         self._works, self._done = [], set()
         self.net.train_step(f, apply=False)
+
+    def _p2p_self_test(self):
+        """Two small all-reduces on two streams through the communicator against the expected sums."""
+        dev = self.net.device
+        exp = float(sum(r + 1 for r in range(self.world)))
+        a = torch.arange(1, 65, dtype=torch.float64, device=dev) * (self.rank + 1)
+        b = torch.arange(1, 9, dtype=torch.float64, device=dev) * (self.rank + 1)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        self.comm.all_reduce(a, 64)
+        with torch.cuda.stream(side):
+            self.comm.all_reduce(b, 8)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.comm.reset_channels()      # (the step's streams take the channels in THEIR order of first use)
+        if self.comm.error() != 0:
+            return False
+        return bool(torch.equal(a, torch.arange(1, 65, dtype=torch.float64, device=dev) * exp)
+                    and torch.equal(b, torch.arange(1, 9, dtype=torch.float64, device=dev) * exp))
 
     def _finish(self):
         """Everything that has not been exchanged yet, then the compute stream waits for all collectives."""

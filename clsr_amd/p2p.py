@@ -51,6 +51,10 @@ class SmallComm(object):
         assert t.dtype == torch.float64 and n <= self.max_doubles
         ops.call("clsr_allreduce_small", self.handle, t, n)
 
+    def reset_channels(self):
+        """forget the stream -> channel assignment (every rank at the same point of its call sequence)"""
+        _lib.check(_lib.load().clsr_comm_reset_channels(ctypes.c_void_p(self.handle)), "clsr_comm_reset_channels")
+
     def error(self):
         """sequence number of the last all-reduce that gave up waiting for a peer (0: none); synchronises the device"""
         return int(_lib.load().clsr_comm_error(ctypes.c_void_p(self.handle)))

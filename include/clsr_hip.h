@@ -86,6 +86,7 @@ int clsr_comm_ipc_open(const void* handle, void** peer_out);
 int clsr_comm_ipc_close(void* peer);
 int clsr_comm_create(int rank, int world, void* const* bufs, void** comm_out);
 int clsr_comm_destroy(void* comm);
+int clsr_comm_reset_channels(void* comm);   /* forget the stream -> channel map (same point on every rank) */
 long clsr_comm_error(void* comm);    /* sequence number of the last all-reduce that timed out waiting for a peer (0: none) */
 int clsr_allreduce_small(void* comm, double* data, int n, void* stream);
 
