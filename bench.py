@@ -237,6 +237,8 @@ class Workload(object):
         if dist is not None:
             dist.barrier()
         dt = time.perf_counter() - t0
+        if self.net is not None and hasattr(self.net, "read_losses"):
+            self.net.read_losses()      # (raises if a grid barrier of the fused heads timed out: the numbers would be invalid)
         self.rank_seconds = [dt]
         if dist is not None:
             every = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(dist.get_world_size())]

@@ -824,14 +824,25 @@ static int hf_rows(long B, int G) {
   return (int)(gpb * G);
 }
 extern "C" int clsr_sizeof_heads_desc(void) { return (int)sizeof(clsr_heads_desc); }
-extern "C" int clsr_heads_fused_supported(long B, int G, int D, int nfs, int a_in, int A0, int A1, int L0, int L1) {
-  if (B <= 0 || G < 1 || G > HF_MAXG || B % G) return 0;
-  if (D != HF_D || nfs != HF_NFS || a_in != HF_AIN || A0 != HF_A0 || A1 != HF_A1 || L0 != HF_L0 || L1 != HF_L1) return 0;
-  return hf_rows(B, G) <= HF_RP;
-}
 extern "C" int clsr_heads_fused_parts(long B, int G) {
   const int R = hf_rows(B, G);
   return (int)((B + R - 1) / R);
+}
+// compute units of the current device: every workgroup of a launch needs a CU of its own for the whole launch (one
+// workgroup per CU by LDS footprint) -- on a partitioned device with fewer CUs the grid barriers would never complete
+static int hf_cu_count() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+extern "C" int clsr_heads_fused_supported(long B, int G, int D, int nfs, int a_in, int A0, int A1, int L0, int L1) {
+  if (B <= 0 || G < 1 || G > HF_MAXG || B % G) return 0;
+  if (D != HF_D || nfs != HF_NFS || a_in != HF_AIN || A0 != HF_A0 || A1 != HF_A1 || L0 != HF_L0 || L1 != HF_L1) return 0;
+  if (hf_rows(B, G) > HF_RP) return 0;
+  return clsr_heads_fused_parts(B, G) <= hf_cu_count();
 }
 extern "C" long clsr_heads_fused_workspace_bytes(void) {
   return (long)HF_CTR_BYTES + HF_PART_BYTES + HF_GPART_BYTES + HF_DBG_BYTES;   // (debug: phase stamps / barrier times of -DHF_TIMING builds)

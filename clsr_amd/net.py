@@ -2423,5 +2423,9 @@ class CLSRNet(object):
     def read_losses(self):
         """Synchronising read of the step's loss terms -> dict of python floats."""
         v = self.losses.cpu().tolist()
+        ws = self._bufs.get(("heads.ws", (int(query("clsr_heads_fused_workspace_bytes")) + 3) // 4, F32))
+        if ws is not None and query("clsr_heads_fused_error", ws.data_ptr()) != 0:
+            raise RuntimeError("clsr_heads_fused: a grid barrier timed out (the device could not hold every workgroup of the "
+                               "launch at once): the step's results are invalid; set CLSR_NO_HEADS_FUSED=1")
         return dict(data_loss=v[0], regular_loss=v[1], contrastive_loss=v[2], discrepancy_loss=v[3],
                     loss=v[0] + v[1] + v[2] + v[3])
