@@ -34,6 +34,7 @@
 // Widths are compile-time (the reference's clsr.yaml: D = 40, final-state width 40, att_fcn_layer_sizes [80, 40],
 // layer_sizes [100, 64]); clsr_heads_fused_supported() says no for anything else and the host keeps the multi-launch
 // path (also for synchronised batch-norm statistics across ranks, which need a collective between the layers).
+#include <stdlib.h>
 #include "common.h"
 #include "clsr_hip.h"
 
@@ -115,19 +116,35 @@ static_assert(sizeof(HfLds) <= 160 * 1024 && sizeof(HfLds2) <= 160 * 1024, "LDS 
 //   wait    until all groups are counted; every workgroup adds the <= 16 group rows in group order.
 // Two levels: 16 + 16 serialised counter updates instead of 256 on one address, 32 row reads per workgroup instead of 256;
 // the order of every addition is fixed by (workgroup index, group index): the same sums in every workgroup and every run.
+// Data-parallel runs with synchronised batch-norm statistics: the group rows of ALL ranks are summed.  Every
+// rank owns an exchange buffer (uncached device memory, mapped into its peers by hipIpc handles like csrc/p2p.hip's); the
+// last arrival of a group PUSHES the group row into the slot (stage, own rank, group) of every rank's buffer and counts
+// the group in every rank's counter of the stage; a workgroup waits until its own counter has reached
+// epoch * groups * world (the counters are never cleared: the epoch = number of steps so far lives in the communicator)
+// and adds world x groups rows in (rank, group) order -- the same sums, bit for bit, on every rank.
+#define HF_MAXW 8
+struct HfXchg {
+  unsigned long long top[HF_NSTAGE];
+  unsigned long long pad_[8];
+  double gpart[HF_NSTAGE][HF_MAXW][HF_NGRP][HF_ROW];
+};
+struct HfComm { int rank, world; unsigned long long epoch; HfXchg* x[HF_MAXW]; };
+struct HfPeers { HfXchg* x[HF_MAXW]; int rank, world; unsigned long long epoch; long long timeout_ticks; };
+
 struct HfSync {
   unsigned* gctr; unsigned* top; unsigned* err; double* part; double* gpart; int nb; int* flag;
+  const HfPeers* peers;
 #ifdef HF_TIMING
   long long* dbg; int dbg0;
 #endif
 };
-__device__ __forceinline__ HfSync hf_sync_init(void* workspace, int nb, int* flag, int dbg0) {
+__device__ __forceinline__ HfSync hf_sync_init(void* workspace, int nb, int* flag, int dbg0, const HfPeers* peers) {
   unsigned char* w = reinterpret_cast<unsigned char*>(workspace);
   HfSync S;
   S.gctr = reinterpret_cast<unsigned*>(w); S.top = S.gctr + 128; S.err = S.gctr + 192;
   S.part = reinterpret_cast<double*>(w + HF_CTR_BYTES);
   S.gpart = reinterpret_cast<double*>(w + HF_CTR_BYTES + HF_PART_BYTES);
-  S.nb = nb; S.flag = flag;
+  S.nb = nb; S.flag = flag; S.peers = peers;
 #ifdef HF_TIMING
   S.dbg = reinterpret_cast<long long*>(w + HF_CTR_BYTES + HF_PART_BYTES + HF_GPART_BYTES + 1024); S.dbg0 = dbg0;
 #endif
@@ -163,23 +180,47 @@ __device__ __forceinline__ void hf_arrive(const HfSync& S, int stage, int n2, bo
       double s = 0.0;
 #pragma unroll
       for (int k = 0; k < HF_GS; ++k) s += v[k];
-      hf_st(S.gpart + ((long)stage * HF_NGRP + grp) * HF_ROW + threadIdx.x, s);
+      if (S.peers->world > 1) {
+        for (int r = 0; r < S.peers->world; ++r)
+          __hip_atomic_store(&S.peers->x[r]->gpart[stage][S.peers->rank][grp][threadIdx.x], s, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {
+        hf_st(S.gpart + ((long)stage * HF_NGRP + grp) * HF_ROW + threadIdx.x, s);
+      }
     }
     HF_WAIT_STORES();
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(S.top + stage, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+      if (S.peers->world > 1) {
+        for (int r = 0; r < S.peers->world; ++r)
+          __hip_atomic_fetch_add(&S.peers->x[r]->top[stage], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {
+        __hip_atomic_fetch_add(S.top + stage, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 }
-// tot[0:n2] = the sums over all workgroups
+// tot[0:n2] = the sums over all workgroups (of all ranks)
 __device__ __forceinline__ void hf_wait(const HfSync& S, int stage, int n2, double* tot) {
   const int ngrp = (S.nb + HF_GS - 1) / HF_GS;
+  const int world = S.peers->world;
   if (threadIdx.x == 0) {
     // (bounded: a launch with more workgroups than the device can hold at once would otherwise hang it; two seconds of the
-    // 100 MHz wall clock, then the error word of the workspace is raised -- clsr_heads_fused_error)
+    // 100 MHz wall clock -- CLSR_P2P_TIMEOUT_S across ranks, which drift apart by seconds in their first steps -- then the
+    // error word of the workspace is raised: clsr_heads_fused_error)
     const long long t0 = wall_clock64();
-    while (__hip_atomic_load(S.top + stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ngrp) {
-      __builtin_amdgcn_s_sleep(1);
-      if (wall_clock64() - t0 > 200000000LL) { __hip_atomic_store(S.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    if (world > 1) {
+      const HfXchg* mine = S.peers->x[S.peers->rank];
+      const unsigned long long target = S.peers->epoch * (unsigned long long)(ngrp * world);
+      while (__hip_atomic_load(&mine->top[stage], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < target) {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > S.peers->timeout_ticks) { __hip_atomic_store(S.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+    } else {
+      while (__hip_atomic_load(S.top + stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ngrp) {
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > 200000000LL) { __hip_atomic_store(S.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
     }
 #ifdef HF_TIMING
     S.dbg[((S.dbg0 + stage) * 256 + blockIdx.x) * 2 + 1] = wall_clock64();
@@ -187,13 +228,25 @@ __device__ __forceinline__ void hf_wait(const HfSync& S, int stage, int n2, doub
   }
   __syncthreads();
   if ((int)threadIdx.x < n2) {
-    const double* p = S.gpart + (long)stage * HF_NGRP * HF_ROW + threadIdx.x;
-    double v[HF_NGRP];
-#pragma unroll
-    for (int g = 0; g < HF_NGRP; ++g) v[g] = g < ngrp ? hf_ld(p + (long)g * HF_ROW) : 0.0;
     double s = 0.0;
+    if (world > 1) {
+      const HfXchg* mine = S.peers->x[S.peers->rank];
+      for (int r = 0; r < world; ++r) {
+        double v[HF_NGRP];
 #pragma unroll
-    for (int g = 0; g < HF_NGRP; ++g) s += v[g];
+        for (int g = 0; g < HF_NGRP; ++g)
+          v[g] = g < ngrp ? __hip_atomic_load(&mine->gpart[stage][r][g][threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
+#pragma unroll
+        for (int g = 0; g < HF_NGRP; ++g) s += v[g];
+      }
+    } else {
+      const double* p = S.gpart + (long)stage * HF_NGRP * HF_ROW + threadIdx.x;
+      double v[HF_NGRP];
+#pragma unroll
+      for (int g = 0; g < HF_NGRP; ++g) v[g] = g < ngrp ? hf_ld(p + (long)g * HF_ROW) : 0.0;
+#pragma unroll
+      for (int g = 0; g < HF_NGRP; ++g) s += v[g];
+    }
     tot[threadIdx.x] = s;
   }
   __syncthreads();
@@ -337,7 +390,7 @@ __device__ __forceinline__ void hf_bn_finalize(const double* tot, int N, double 
   __syncthreads();
 }
 // backward sums -> dz = a1 * dy + a2 * z + a3 coefficients in LDS; workgroup 0 writes coef / dgamma / dbeta
-__device__ __forceinline__ void hf_bn_coef(const double* tot, int N, double count, const clsr_bn_ptrs& bn,
+__device__ __forceinline__ void hf_bn_coef(const double* tot, int N, double count, double gscale, const clsr_bn_ptrs& bn,
                                            const float (*o)[112], float (*cf)[112]) {
   const int c = threadIdx.x;
   if (c < 112) {
@@ -351,8 +404,9 @@ __device__ __forceinline__ void hf_bn_coef(const double* tot, int N, double coun
       a3 = -a1 * c1 - a2 * mu;
       if (blockIdx.x == 0) {
         bn.coef[c] = a1; bn.coef[N + c] = a2; bn.coef[2 * N + c] = a3;
-        bn.dgamma[c] = (float)s2;
-        bn.dbeta[c] = (float)s1;
+        // (global sums under synchronised statistics: pre-divided by the world size, the gradient all-reduce restores them)
+        bn.dgamma[c] = (float)(s2 * gscale);
+        bn.dbeta[c] = (float)(s1 * gscale);
       }
     }
     cf[0][c] = a1; cf[1][c] = a2; cf[2][c] = a3;
@@ -400,15 +454,16 @@ __device__ __forceinline__ void hf_act(float* act, const float* z, int ld, int N
 #define HF_NIT(n) (((n) + 255) / 256)
 
 // ============================================================================================== launch 1
-__global__ void __launch_bounds__(256, 1) heads_fused_k1(clsr_heads_desc a, int R, int nb) {
+__global__ void __launch_bounds__(256, 1) heads_fused_k1(clsr_heads_desc a, int R, int nb, HfPeers peers) {
   extern __shared__ __attribute__((aligned(16))) unsigned char hf_raw[];
   HfLds& L = *reinterpret_cast<HfLds*>(hf_raw);
   const int tid = threadIdx.x;
   const long row0 = (long)blockIdx.x * R;
   const int G = a.G;
   const int Rv = (int)((a.B - row0) < R ? (a.B - row0) : R);
-  const HfSync S = hf_sync_init(a.workspace, nb, L.flag, 0);
-  const double count = (double)a.B;
+  const HfSync S = hf_sync_init(a.workspace, nb, L.flag, 0, &peers);
+  const double count = (double)a.B * peers.world;      // (synchronised statistics: the rows of all ranks)
+  const double gscale = 1.0 / peers.world;
   long long* stamps = reinterpret_cast<long long*>(reinterpret_cast<unsigned char*>(a.workspace) + HF_CTR_BYTES + HF_PART_BYTES + HF_GPART_BYTES);
   (void)stamps;
   HF_STAMP(0);
@@ -609,7 +664,7 @@ __global__ void __launch_bounds__(256, 1) heads_fused_k1(clsr_heads_desc a, int 
   HF_STAMP(18);
 
   // ---- B1: dz of the second logit layer, back through W1
-  hf_bn_coef(L.tot, HF_L1, count, a.bn[3], L.bn[3], L.cf);
+  hf_bn_coef(L.tot, HF_L1, count, gscale, a.bn[3], L.bn[3], L.cf);
   hf_bn_apply(DY1, Z1L, HS_64, HF_L1, Rv, L.cf, a.lg_dz1, row0);
   __syncthreads();
   HF_STAMP(19);
@@ -624,7 +679,7 @@ __global__ void __launch_bounds__(256, 1) heads_fused_k1(clsr_heads_desc a, int 
   HF_STAMP(22);
 
   // ---- B2: dz of the first logit layer, d(model_output)
-  hf_bn_coef(L.tot, HF_L0, count, a.bn[2], L.bn[2], L.cf);
+  hf_bn_coef(L.tot, HF_L0, count, gscale, a.bn[2], L.bn[2], L.cf);
   hf_bn_apply(L.ACT, Z0L, HS_100, HF_L0, Rv, L.cf, a.lg_dz0, row0);
   __syncthreads();
   float* dmo = a.dmo;
@@ -636,15 +691,16 @@ __global__ void __launch_bounds__(256, 1) heads_fused_k1(clsr_heads_desc a, int 
 }
 
 // ============================================================================================== launch 2
-__global__ void __launch_bounds__(256, 1) heads_fused_k2(clsr_heads_desc a, int R, int nb) {
+__global__ void __launch_bounds__(256, 1) heads_fused_k2(clsr_heads_desc a, int R, int nb, HfPeers peers) {
   extern __shared__ __attribute__((aligned(16))) unsigned char hf_raw[];
   HfLds2& L = *reinterpret_cast<HfLds2*>(hf_raw);
   const int tid = threadIdx.x;
   const long row0 = (long)blockIdx.x * R;
   const int G = a.G;
   const int Rv = (int)((a.B - row0) < R ? (a.B - row0) : R);
-  const HfSync S = hf_sync_init(a.workspace, nb, L.flag, 0);
-  const double count = (double)a.B;
+  const HfSync S = hf_sync_init(a.workspace, nb, L.flag, 0, &peers);
+  const double count = (double)a.B * peers.world;      // (synchronised statistics: the rows of all ranks)
+  const double gscale = 1.0 / peers.world;
   long long* stamps = reinterpret_cast<long long*>(reinterpret_cast<unsigned char*>(a.workspace) + HF_CTR_BYTES + HF_PART_BYTES + HF_GPART_BYTES) + 64;
   (void)stamps;
   HF_STAMP(0);
@@ -758,7 +814,7 @@ __global__ void __launch_bounds__(256, 1) heads_fused_k2(clsr_heads_desc a, int 
   HF_STAMP(2);
 
   // ---- dz of the second alpha layer, back through W1
-  hf_bn_coef(L.tot, HF_A1, count, a.bn[1], L.bn[1], L.cf);
+  hf_bn_coef(L.tot, HF_A1, count, gscale, a.bn[1], L.bn[1], L.cf);
   hf_bn_apply(DY1, Z1A, HS_40, HF_A1, Rv, L.cf, a.al_dz1, row0);
   __syncthreads();
   HF_STAMP(3);
@@ -784,7 +840,7 @@ __global__ void __launch_bounds__(256, 1) heads_fused_k2(clsr_heads_desc a, int 
   HF_STAMP(6);
 
   // ---- dz of the first alpha layer, d(alpha-gate input), scattered to its sources together with the fusion's shares
-  hf_bn_coef(L.tot, HF_A0, count, a.bn[0], L.bn[0], L.cf);
+  hf_bn_coef(L.tot, HF_A0, count, gscale, a.bn[0], L.bn[0], L.cf);
   hf_bn_apply(L.DY0, L.Z0A, HS_80, HF_A0, Rv, L.cf, a.al_dz0, row0);
   __syncthreads();
   float* dain = DAIN;
@@ -877,6 +933,60 @@ static int hf_check(const clsr_heads_desc* d) {
   return CLSR_OK;
 }
 
+// ---- communicator for synchronised statistics across ranks (host creates it once; see HfXchg above)
+extern "C" long clsr_heads_comm_buffer_bytes(void) { return (long)sizeof(HfXchg); }
+extern "C" int clsr_heads_comm_max_world(void) { return HF_MAXW; }
+// uncached (fine-grained) device allocation of the exchange buffer, zeroed; freed by clsr_comm_free, shared by
+// clsr_comm_ipc_handle / clsr_comm_ipc_open / clsr_comm_ipc_close (csrc/p2p.hip: they are size-agnostic)
+extern "C" int clsr_heads_comm_alloc(void** buf_out) {
+  CLSR_CHECK_ARG(buf_out);
+  void* p = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&p, sizeof(HfXchg), hipDeviceMallocUncached);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    e = hipExtMallocWithFlags(&p, sizeof(HfXchg), hipDeviceMallocFinegrained);
+  }
+  if (e != hipSuccess) {
+    clsr_set_error("%s:%d: exchange buffer allocation failed: %s", __FILE__, __LINE__, hipGetErrorString(e));
+    return CLSR_ELAUNCH;
+  }
+  CLSR_HIP(hipMemset(p, 0, sizeof(HfXchg)));
+  CLSR_HIP(hipDeviceSynchronize());
+  *buf_out = p;
+  return CLSR_OK;
+}
+// bufs[r] = the exchange buffer of rank r as THIS process addresses it (own allocation at [rank], opened handles elsewhere)
+extern "C" int clsr_heads_comm_create(int rank, int world, void* const* bufs, void** comm_out) {
+  CLSR_CHECK_ARG(bufs && comm_out && world >= 1 && world <= HF_MAXW && rank >= 0 && rank < world);
+  HfComm* c = new HfComm();
+  c->rank = rank; c->world = world; c->epoch = 0;
+  for (int r = 0; r < HF_MAXW; ++r) c->x[r] = nullptr;
+  for (int r = 0; r < world; ++r) {
+    if (!bufs[r]) { delete c; clsr_set_error("%s:%d: exchange buffer of rank %d missing", __FILE__, __LINE__, r); return CLSR_EINVAL; }
+    c->x[r] = (HfXchg*)bufs[r];
+  }
+  *comm_out = c;
+  return CLSR_OK;
+}
+extern "C" int clsr_heads_comm_destroy(void* comm) {
+  delete (HfComm*)comm;
+  return CLSR_OK;
+}
+static HfPeers hf_peers(const clsr_heads_desc* d, bool new_step) {
+  HfPeers p;
+  for (int r = 0; r < HF_MAXW; ++r) p.x[r] = nullptr;
+  p.rank = 0; p.world = 1; p.epoch = 0;
+  static const long long ticks = (long long)(getenv("CLSR_P2P_TIMEOUT_S") ? atof(getenv("CLSR_P2P_TIMEOUT_S")) : 60.0) * 100000000LL;
+  p.timeout_ticks = ticks;
+  if (d->comm) {
+    HfComm* c = (HfComm*)d->comm;
+    if (new_step) ++c->epoch;          // (every rank issues the same sequence of step1 / step2 calls)
+    for (int r = 0; r < c->world; ++r) p.x[r] = c->x[r];
+    p.rank = c->rank; p.world = c->world; p.epoch = c->epoch;
+  }
+  return p;
+}
+
 // Launch 1.  The first clsr_heads_fused_counter_bytes() bytes of the workspace (the barrier counters) must be ZERO on
 // entry: the caller clears them once per step, before this launch (the step's zero-fill launch does).
 extern "C" int clsr_heads_fused_step1(const clsr_heads_desc* d, void* stream) {
@@ -885,7 +995,7 @@ extern "C" int clsr_heads_fused_step1(const clsr_heads_desc* d, void* stream) {
   const int R = hf_rows(d->B, d->G), nb = clsr_heads_fused_parts(d->B, d->G);
   const size_t shmem = sizeof(HfLds);
   CLSR_HIP(hipFuncSetAttribute((const void*)heads_fused_k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(heads_fused_k1, dim3(nb), dim3(256), shmem, (hipStream_t)stream, *d, R, nb);
+  hipLaunchKernelGGL(heads_fused_k1, dim3(nb), dim3(256), shmem, (hipStream_t)stream, *d, R, nb, hf_peers(d, true));
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
@@ -897,7 +1007,7 @@ extern "C" int clsr_heads_fused_step2(const clsr_heads_desc* d, void* stream) {
   const int R = hf_rows(d->B, d->G), nb = clsr_heads_fused_parts(d->B, d->G);
   const size_t shmem = sizeof(HfLds2);
   CLSR_HIP(hipFuncSetAttribute((const void*)heads_fused_k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(heads_fused_k2, dim3(nb), dim3(256), shmem, (hipStream_t)stream, *d, R, nb);
+  hipLaunchKernelGGL(heads_fused_k2, dim3(nb), dim3(256), shmem, (hipStream_t)stream, *d, R, nb, hf_peers(d, false));
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }

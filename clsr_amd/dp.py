@@ -139,6 +139,7 @@ class DataParallel(object):
         # sync-BN statistics through the peer-to-peer communicator (clsr_amd/p2p.py) when one can be set up: ONE kernel per
         # all-reduce on the issuing stream instead of a torch.distributed call.  CLSR_P2P_STATS=0: always torch.distributed.
         self.comm, self.stats_transport = None, "torch.distributed"
+        self.heads_comm = None
         if self.sync_bn and p2p_stats and os.environ.get("CLSR_P2P_STATS", "1") != "0" and self.world <= 8 \
                 and torch.cuda.is_available() and str(net.device).startswith("cuda"):
             try:
@@ -157,6 +158,22 @@ class DataParallel(object):
             if all(votes):
                 net.dp_comm = self.comm.handle
                 self.stats_transport = "p2p"
+                # the same primitives (IPC-mapped uncached buffers, system-scope atomics) carry the statistics of the fused
+                # heads launches: their group sums are pushed to every rank from inside the launches (csrc/headsfused.hip)
+                if os.environ.get("CLSR_HEADS_COMM", "1") != "0" and getattr(net, "heads_fused", False):
+                    try:
+                        self.heads_comm = p2p.heads_comm_from_process_group(self.rank, self.world, group)
+                        hok = True
+                    except Exception:
+                        self.heads_comm, hok = None, False
+                    hv = [None] * self.world
+                    tdist.all_gather_object(hv, bool(hok), group=group)
+                    if all(hv):
+                        net.heads_comm = self.heads_comm.handle
+                        self.stats_transport = "p2p + fused heads"
+                    elif self.heads_comm is not None:
+                        self.heads_comm.close()
+                        self.heads_comm = None
             else:
                 if self.comm is not None:
                     try:

@@ -162,6 +162,7 @@ class CLSRNet(object):
         self._dw_batch_wide = None
         self._heads_defer = False
         self._early_lists = None
+        self.heads_comm = None      # data-parallel runs: communicator of the fused heads (clsr_amd/p2p.py: HeadsComm)
         self.fused_logit_tail = not os.environ.get("CLSR_NO_FUSED_LOGIT_TAIL")   # A/B: output layer + softmax loss + their backward in one launch
         self._defer_logit_out = False
         self.early_scatter = not os.environ.get("CLSR_NO_EARLY_SCATTER")   # A/B: row scatters of the user / target lookups beside the encoder-backward tail instead of behind it
@@ -1779,7 +1780,8 @@ class CLSRNet(object):
         output-layer / softmax tail's conditions."""
         hp = self.hp
         return bool(self.heads_fused and type(self) is CLSRNet and not hp.manual_alpha and hp.predict_long_short
-                    and self.dp_stats_hook is None and self.fused_logit_tail and G == hp.train_num_ngs + 1
+                    and (self.dp_stats_hook is None or self.heads_comm is not None) and self.fused_logit_tail
+                    and G == hp.train_num_ngs + 1
                     and query("clsr_heads_fused_supported", B, G, self.D, self.H, self.a_in, self.A0, self.A1,
                               self.L0, self.L1))
 
@@ -1824,7 +1826,8 @@ class CLSRNet(object):
             ain=ain, al_z0=z["al.z0"], al_z1=z["al.z1"], alpha=out["alpha"], mo=mo, lg_z0=z["lg.z0"], lg_z1=z["lg.z1"],
             logit=out["logit"], dlogit=dlogit, loss=self.losses[0:],
             lg_dz1=z["lg.dz1"], lg_dz0=z["lg.dz0"], dmo=buf("lg.dX", B, 2 * D), al_dz1=z["al.dz1"], al_dz0=z["al.dz0"],
-            lg_wp=wp_lg, al_wp=wp_al, dL=dL, dS=dS, dtarget=dtarget, dfs=dfs, workspace=ws, workspace_bytes=ws.numel() * 4)
+            lg_wp=wp_lg, al_wp=wp_al, dL=dL, dS=dS, dtarget=dtarget, dfs=dfs, workspace=ws, workspace_bytes=ws.numel() * 4,
+            comm=(self.heads_comm or 0) if self.dp_stats_hook is not None else 0)
         with self._dw_batched(late=True):
             ops.heads_fused(1, d)
             self._rp(wp_lg, parts, L1 + 4, L1, Gd[lg + "w_nn_output"])

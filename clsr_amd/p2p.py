@@ -82,3 +82,60 @@ def from_process_group(rank, world, group=None):
         return out
 
     return SmallComm(rank, world, gather)
+
+
+class HeadsComm(object):
+    """Communicator of the fused heads launches (csrc/headsfused.hip) for synchronised batch-norm statistics across ranks:
+    every rank's exchange buffer mapped into every other rank; the workgroups of the launches push their group sums into
+    all of them.  Created like :class:`SmallComm` (handles through ``gather_objects``)."""
+
+    def __init__(self, rank, world, gather_objects):
+        lib = _lib.load()
+        self.rank, self.world = int(rank), int(world)
+        if self.world > lib.clsr_heads_comm_max_world():
+            raise ValueError("HeadsComm: at most %d ranks (one node)" % lib.clsr_heads_comm_max_world())
+        buf = ctypes.c_void_p()
+        _lib.check(lib.clsr_heads_comm_alloc(ctypes.byref(buf)), "clsr_heads_comm_alloc")
+        self._own = buf
+        nb = lib.clsr_comm_ipc_handle_bytes()
+        h = ctypes.create_string_buffer(nb)
+        _lib.check(lib.clsr_comm_ipc_handle(buf, h), "clsr_comm_ipc_handle")
+        handles = gather_objects(bytes(h.raw))
+        self._peers = []
+        ptrs = (ctypes.c_void_p * self.world)()
+        for r in range(self.world):
+            if r == self.rank:
+                ptrs[r] = buf
+                continue
+            p = ctypes.c_void_p()
+            hb = ctypes.create_string_buffer(handles[r], nb)
+            _lib.check(lib.clsr_comm_ipc_open(hb, ctypes.byref(p)), "clsr_comm_ipc_open (rank %d)" % r)
+            self._peers.append(p)
+            ptrs[r] = p
+        comm = ctypes.c_void_p()
+        _lib.check(lib.clsr_heads_comm_create(self.rank, self.world, ptrs, ctypes.byref(comm)), "clsr_heads_comm_create")
+        self.handle = comm.value
+        gather_objects(b"ready")          # nobody pushes before every rank has mapped every buffer
+
+    def close(self):
+        lib = _lib.load()
+        if getattr(self, "handle", None):
+            lib.clsr_heads_comm_destroy(ctypes.c_void_p(self.handle))
+            self.handle = None
+        for p in getattr(self, "_peers", []):
+            lib.clsr_comm_ipc_close(p)
+        self._peers = []
+        if getattr(self, "_own", None):
+            lib.clsr_comm_free(self._own)
+            self._own = None
+
+
+def heads_comm_from_process_group(rank, world, group=None):
+    import torch.distributed as dist
+
+    def gather(obj):
+        out = [None] * world
+        dist.all_gather_object(out, obj, group=group)
+        return out
+
+    return HeadsComm(rank, world, gather)

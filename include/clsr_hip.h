@@ -161,12 +161,23 @@ typedef struct clsr_heads_desc {
   float* lg_dz1; float* lg_dz0; float* dmo; float* al_dz1; float* al_dz0; float* lg_wp; float* al_wp;
   float* dL; float* dS; float* dtarget; float* dfs;
   void* workspace; long workspace_bytes;
+  /* data-parallel runs with synchronised batch-norm statistics: a communicator from clsr_heads_comm_create (every rank
+   * then issues the same sequence of step1 / step2 calls with the same B); NULL: the statistics of this process's rows */
+  void* comm;
 } clsr_heads_desc;
 int clsr_sizeof_heads_desc(void);
 int clsr_heads_fused_supported(long B, int G, int D, int nfs, int a_in, int A0, int A1, int L0, int L1);
 int clsr_heads_fused_parts(long B, int G);
 long clsr_heads_fused_workspace_bytes(void);
 long clsr_heads_fused_counter_bytes(void);   /* leading bytes of the workspace that must be zero before step1 */
+/* communicator for the cross-rank sums: every rank allocates an exchange buffer (clsr_heads_comm_alloc: uncached device
+ * memory; handles / mapping / freeing through clsr_comm_ipc_handle, clsr_comm_ipc_open, clsr_comm_ipc_close, clsr_comm_free)
+ * and passes all ranks' buffers as it addresses them */
+long clsr_heads_comm_buffer_bytes(void);
+int clsr_heads_comm_max_world(void);
+int clsr_heads_comm_alloc(void** buf_out);
+int clsr_heads_comm_create(int rank, int world, void* const* bufs, void** comm_out);
+int clsr_heads_comm_destroy(void* comm);
 int clsr_heads_fused_error(const void* workspace);   /* synchronous; 1 = a grid barrier timed out (results invalid) */
 int clsr_heads_fused_step1(const clsr_heads_desc* d_host, void* stream);
 int clsr_heads_fused_step2(const clsr_heads_desc* d_host, void* stream);
