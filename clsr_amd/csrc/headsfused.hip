@@ -35,6 +35,7 @@
 // layer_sizes [100, 64]); clsr_heads_fused_supported() says no for anything else and the host keeps the multi-launch
 // path (also for synchronised batch-norm statistics across ranks, which need a collective between the layers).
 #include <stdlib.h>
+#include <stdio.h>
 #include "common.h"
 #include "clsr_hip.h"
 
@@ -120,7 +121,8 @@ static_assert(sizeof(HfLds) <= 160 * 1024 && sizeof(HfLds2) <= 160 * 1024, "LDS 
 // rank owns an exchange buffer (uncached device memory, mapped into its peers by hipIpc handles like csrc/p2p.hip's); the
 // last arrival of a group PUSHES the group row into the slot (stage, own rank, group) of every rank's buffer and counts
 // the group in every rank's counter of the stage; a workgroup waits until its own counter has reached
-// epoch * groups * world (the counters are never cleared: the epoch = number of steps so far lives in the communicator)
+// the number of group rows pushed to it so far (the counters are never cleared: the running total -- groups x world per step,
+// batches of different sizes have different group counts -- lives in the communicator)
 // and adds world x groups rows in (rank, group) order -- the same sums, bit for bit, on every rank.
 #define HF_MAXW 8
 struct HfXchg {
@@ -128,8 +130,8 @@ struct HfXchg {
   unsigned long long pad_[8];
   double gpart[HF_NSTAGE][HF_MAXW][HF_NGRP][HF_ROW];
 };
-struct HfComm { int rank, world; unsigned long long epoch; HfXchg* x[HF_MAXW]; };
-struct HfPeers { HfXchg* x[HF_MAXW]; int rank, world; unsigned long long epoch; long long timeout_ticks; };
+struct HfComm { int rank, world; unsigned long long pushed; HfXchg* x[HF_MAXW]; };
+struct HfPeers { HfXchg* x[HF_MAXW]; int rank, world; unsigned long long target; long long timeout_ticks; };
 
 struct HfSync {
   unsigned* gctr; unsigned* top; unsigned* err; double* part; double* gpart; int nb; int* flag;
@@ -211,10 +213,15 @@ __device__ __forceinline__ void hf_wait(const HfSync& S, int stage, int n2, doub
     const long long t0 = wall_clock64();
     if (world > 1) {
       const HfXchg* mine = S.peers->x[S.peers->rank];
-      const unsigned long long target = S.peers->epoch * (unsigned long long)(ngrp * world);
+      const unsigned long long target = S.peers->target;
       while (__hip_atomic_load(&mine->top[stage], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < target) {
         __builtin_amdgcn_s_sleep(2);
-        if (wall_clock64() - t0 > S.peers->timeout_ticks) { __hip_atomic_store(S.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if (wall_clock64() - t0 > S.peers->timeout_ticks) {      // (err: 1 + stage; err[1], err[2]: counter seen / wanted)
+          __hip_atomic_store(S.err, 1u + (unsigned)stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          S.err[1] = (unsigned)__hip_atomic_load(&mine->top[stage], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          S.err[2] = (unsigned)target;
+          break;
+        }
       }
     } else {
       while (__hip_atomic_load(S.top + stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ngrp) {
@@ -907,9 +914,10 @@ extern "C" long clsr_heads_fused_counter_bytes(void) { return HF_CTR_BYTES; }
 // 1: a workgroup gave up waiting at a grid barrier in a launch since the counters were last cleared (results invalid)
 extern "C" int clsr_heads_fused_error(const void* workspace) {
   if (!workspace) return -1;
-  unsigned e = 0;
-  if (hipMemcpy(&e, reinterpret_cast<const unsigned*>(workspace) + 192, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  return (int)e;
+  unsigned e[3] = {0, 0, 0};
+  if (hipMemcpy(e, reinterpret_cast<const unsigned*>(workspace) + 192, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (e[0] && getenv("CLSR_HEADS_DEBUG")) fprintf(stderr, "[clsr_heads_fused] barrier timeout: stage %u, counter %u of %u\n", e[0] - 1, e[1], e[2]);
+  return (int)e[0];
 }
 
 static int hf_check(const clsr_heads_desc* d) {
@@ -959,7 +967,7 @@ extern "C" int clsr_heads_comm_alloc(void** buf_out) {
 extern "C" int clsr_heads_comm_create(int rank, int world, void* const* bufs, void** comm_out) {
   CLSR_CHECK_ARG(bufs && comm_out && world >= 1 && world <= HF_MAXW && rank >= 0 && rank < world);
   HfComm* c = new HfComm();
-  c->rank = rank; c->world = world; c->epoch = 0;
+  c->rank = rank; c->world = world; c->pushed = 0;
   for (int r = 0; r < HF_MAXW; ++r) c->x[r] = nullptr;
   for (int r = 0; r < world; ++r) {
     if (!bufs[r]) { delete c; clsr_set_error("%s:%d: exchange buffer of rank %d missing", __FILE__, __LINE__, r); return CLSR_EINVAL; }
@@ -972,17 +980,18 @@ extern "C" int clsr_heads_comm_destroy(void* comm) {
   delete (HfComm*)comm;
   return CLSR_OK;
 }
-static HfPeers hf_peers(const clsr_heads_desc* d, bool new_step) {
+static HfPeers hf_peers(const clsr_heads_desc* d, bool new_step, int nb) {
   HfPeers p;
   for (int r = 0; r < HF_MAXW; ++r) p.x[r] = nullptr;
-  p.rank = 0; p.world = 1; p.epoch = 0;
+  p.rank = 0; p.world = 1; p.target = 0;
   static const long long ticks = (long long)(getenv("CLSR_P2P_TIMEOUT_S") ? atof(getenv("CLSR_P2P_TIMEOUT_S")) : 60.0) * 100000000LL;
   p.timeout_ticks = ticks;
   if (d->comm) {
     HfComm* c = (HfComm*)d->comm;
-    if (new_step) ++c->epoch;          // (every rank issues the same sequence of step1 / step2 calls)
+    // (every rank issues the same sequence of step1 / step2 calls with the same B: the same totals everywhere)
+    if (new_step) c->pushed += (unsigned long long)((nb + HF_GS - 1) / HF_GS) * c->world;
     for (int r = 0; r < c->world; ++r) p.x[r] = c->x[r];
-    p.rank = c->rank; p.world = c->world; p.epoch = c->epoch;
+    p.rank = c->rank; p.world = c->world; p.target = c->pushed;
   }
   return p;
 }
@@ -995,7 +1004,7 @@ extern "C" int clsr_heads_fused_step1(const clsr_heads_desc* d, void* stream) {
   const int R = hf_rows(d->B, d->G), nb = clsr_heads_fused_parts(d->B, d->G);
   const size_t shmem = sizeof(HfLds);
   CLSR_HIP(hipFuncSetAttribute((const void*)heads_fused_k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(heads_fused_k1, dim3(nb), dim3(256), shmem, (hipStream_t)stream, *d, R, nb, hf_peers(d, true));
+  hipLaunchKernelGGL(heads_fused_k1, dim3(nb), dim3(256), shmem, (hipStream_t)stream, *d, R, nb, hf_peers(d, true, nb));
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
@@ -1007,7 +1016,7 @@ extern "C" int clsr_heads_fused_step2(const clsr_heads_desc* d, void* stream) {
   const int R = hf_rows(d->B, d->G), nb = clsr_heads_fused_parts(d->B, d->G);
   const size_t shmem = sizeof(HfLds2);
   CLSR_HIP(hipFuncSetAttribute((const void*)heads_fused_k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(heads_fused_k2, dim3(nb), dim3(256), shmem, (hipStream_t)stream, *d, R, nb, hf_peers(d, false));
+  hipLaunchKernelGGL(heads_fused_k2, dim3(nb), dim3(256), shmem, (hipStream_t)stream, *d, R, nb, hf_peers(d, false, nb));
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }

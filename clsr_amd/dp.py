@@ -160,7 +160,15 @@ class DataParallel(object):
                 self.stats_transport = "p2p"
                 # the same primitives (IPC-mapped uncached buffers, system-scope atomics) carry the statistics of the fused
                 # heads launches: their group sums are pushed to every rank from inside the launches (csrc/headsfused.hip)
-                if os.environ.get("CLSR_HEADS_COMM", "1") != "0" and getattr(net, "heads_fused", False):
+                # ... unless two ranks share ONE device (test rigs): each launch wants a compute unit per workgroup for its
+                # whole duration, and two of them waiting for each other cannot both be resident beyond 256 workgroups in all
+                # (CLSR_HEADS_COMM_SHARED=1: small batches on a shared device, tests/test_p2p_gpu.py)
+                props = torch.cuda.get_device_properties(net.device)
+                ident = "%s/%s" % (getattr(props, "uuid", None), getattr(props, "pci_bus_id", net.device))
+                idents = [None] * self.world
+                tdist.all_gather_object(idents, ident, group=group)
+                shared = len(set(idents)) < self.world and os.environ.get("CLSR_HEADS_COMM_SHARED") != "1"
+                if os.environ.get("CLSR_HEADS_COMM", "1") != "0" and getattr(net, "heads_fused", False) and not shared:
                     try:
                         self.heads_comm = p2p.heads_comm_from_process_group(self.rank, self.world, group)
                         hok = True

@@ -317,6 +317,7 @@ def _epoch_worker(rank, world, port, hp, train, dedup, out):
     it = model.iterator.load_data_from_file(train, batch_num_ngs=hp.train_num_ngs)
     loss = model.batch_train(it, model.sess)
     torch.cuda.synchronize()
+    model.net.read_losses()      # (raises if a grid barrier of the fused heads timed out)
     out[rank] = dict(loss=float(loss), item=model.net.tables["item"].cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()

@@ -76,6 +76,7 @@ def _dp_worker(rank, world, port, hp, dims, feed, sd, out, use_p2p, fused_heads=
     from clsr_amd.net import CLSRNet
     from test_dp_gpu import _init
 
+    os.environ["CLSR_HEADS_COMM_SHARED"] = "1"      # (two ranks on ONE device: fine at this batch, 2 x 8 workgroups)
     d, dev = _init("staged", rank, world, port)
     net = CLSRNet(hp, dims, device=dev, seed=rank)
     net.heads_fused = bool(fused_heads)
