@@ -424,6 +424,22 @@ class DataParallel(object):
         self._works, self._done = [], set()
         self.net.train_step(f, apply=False)
 
+    def close(self):
+        """Release the peer-to-peer communicators (mapped exchange buffers of the peers, own allocations).  Every rank calls
+        it at the same point, after its last step; the net goes back to the launch chain / the process group."""
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        self.net.dp_comm = None
+        self.net.heads_comm = None
+        for name in ("heads_comm", "comm"):
+            c = getattr(self, name, None)
+            if c is not None:
+                try:
+                    c.close()
+                finally:
+                    setattr(self, name, None)
+        self.stats_transport = "torch.distributed"
+
     def _p2p_self_test(self):
         """Two small all-reduces on two streams through the communicator against the expected sums."""
         dev = self.net.device

@@ -94,6 +94,9 @@ def _dp_worker(rank, world, port, hp, dims, feed, sd, out, use_p2p, fused_heads=
         out["losses"] = net.read_losses()       # (raises if a grid barrier of the fused heads timed out)
         out["fused"] = bool(net._heads_fused_ok(f["B"], hp.train_num_ngs + 1))
     dist.barrier()
+    dp.close()                      # (unmaps the peers' exchange buffers, frees the own ones)
+    assert dp.comm is None and net.dp_comm is None and net.heads_comm is None
+    dist.barrier()
     dist.destroy_process_group()
 
 
