@@ -1,6 +1,7 @@
 // Multi-launch forms of the small kernels of the CLSR step (gfx950): several independent jobs per launch,
 // blockIdx.y = job, descriptors passed to the kernel BY VALUE (read from host memory at call time).
 // Same arithmetic as the single-job kernels in embedding.hip / attention.hip / optim.hip.
+#include <stdlib.h>
 #include "common.h"
 #include "clsr_hip.h"
 
@@ -232,6 +233,73 @@ __global__ void __launch_bounds__(256) tables_reg_multi_kernel(TablesArgs a) {
   }
 }
 
+// The same sweep for tables whose rows are multiples of four values (all of the reference's): one 16-byte access per
+// thread and operand, 32-bit index arithmetic (the scalar form divides a 64-bit element index by C per element), and the
+// loads of four grid strides issued together from clamped addresses, selected by the row flags afterwards -- a load
+// behind `if (flag)` leaves only once the flag has arrived, one dependent round trip per element of the stride loop.
+// Measured at configs[1] (5 M values in four tables, on the tail of the step): 40 -> 36 us, the Adam sweep 32 -> 27 us --
+// both were closer to their traffic (~70 MB through the L2 / Infinity Cache) than to their latency chains.
+template <bool H>
+__global__ void __launch_bounds__(256) tables_reg_multi_v4_kernel(TablesArgs a) {
+  const clsr_table_desc d = a.t[blockIdx.y];
+  const unsigned QC = (unsigned)d.C >> 2, total = (unsigned)d.V * QC;
+  const float cd = d.partner ? d.disc_scale / (a.ucount[0] * (float)d.C) : 0.f;
+  const float cl = (d.partner && d.disc_loss) ? d.disc_loss_scale / (a.ucount[0] * (float)d.C) : 0.f;
+  double ss = 0.0, rl = 0.0, dl = 0.0;
+  const unsigned stride = gridDim.x * 256u;
+  for (unsigned q0 = blockIdx.x * 256u + threadIdx.x; q0 < total; q0 += 4u * stride) {
+    bool f[4];
+    f32x4 p[4], pp[4], g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned q = q0 + (unsigned)u * stride, qs = q < total ? q : 0u;
+      f[u] = q < total && d.flags[qs / QC];
+      p[u] = load4e<H>(d.table, 4L * qs);
+      pp[u] = d.partner ? load4e<H>(d.partner, 4L * qs) : f32x4{0.f, 0.f, 0.f, 0.f};
+      g[u] = ld4(d.grad + 4L * qs);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!f[u]) continue;
+      const unsigned q = q0 + (unsigned)u * stride;
+      f32x4 r;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float pv = p[u][c];
+        float gv = a.l2 * pv + a.l1 * (float)((pv > 0.f) - (pv < 0.f));
+        if (d.partner) {
+          const float df = pv - pp[u][c];
+          gv += cd * df;
+          dl += (double)df * df;
+        }
+        r[c] = g[u][c] + gv;
+        ss += (double)gv * gv;
+        rl += 0.5 * (double)a.l2 * pv * pv + (double)a.l1 * fabsf(pv);
+      }
+      st4(d.grad + 4L * q, r);
+    }
+  }
+  __shared__ double red[3][4];
+  ss = block256_sum_d(ss, red[0]); rl = block256_sum_d(rl, red[1]); dl = block256_sum_d(dl, red[2]);
+  if (threadIdx.x == 0) {
+    if (ss != 0.0) atomicAdd(d.sumsq_reg, ss);
+    if (a.reg_loss && rl != 0.0) atomicAdd(a.reg_loss, rl);
+    if (d.disc_loss && dl != 0.0) atomicAdd(d.disc_loss, (double)cl * dl);
+  }
+}
+// every table of the launch: rows of 4 k values, 16-byte aligned operands, fewer than 2^31 values
+static bool tables_v4_ok(const clsr_table_desc* descs, int n, bool with_moments) {
+  static const bool off = getenv("CLSR_TABLES_NO_V4") != nullptr;
+  if (off) return false;
+  for (int i = 0; i < n; ++i) {
+    const clsr_table_desc& d = descs[i];
+    if (d.C % 4 || d.V * d.C >= (1L << 31)) return false;
+    if (((uintptr_t)d.table | (uintptr_t)d.grad | (uintptr_t)d.partner) & 15) return false;
+    if (with_moments && (((uintptr_t)d.m | (uintptr_t)d.v) & 15)) return false;
+  }
+  return true;
+}
+
 static int fill_tables(TablesArgs& a, const clsr_table_desc* descs, int n, long* max_elems) {
   CLSR_CHECK_ARG(descs && n > 0 && n <= 4);
   long mx = 1;
@@ -255,7 +323,12 @@ static int tables_reg_multi_launch(const clsr_table_desc* descs, int n, int bf16
   a.l2 = l2; a.l1 = l1; a.ucount = ucount; a.reg_loss = reg_loss;
   int blocks = clsr_cdiv(mx, 256 * 8);
   if (blocks > 512) blocks = 512;
-  if (bf16) hipLaunchKernelGGL(tables_reg_multi_kernel<true>, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, a);
+  if (tables_v4_ok(descs, n, false)) {
+    blocks = clsr_cdiv(mx / 4, 256 * 4);
+    if (blocks > 1024) blocks = 1024;
+    if (bf16) hipLaunchKernelGGL(tables_reg_multi_v4_kernel<true>, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(tables_reg_multi_v4_kernel<false>, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, a);
+  } else if (bf16) hipLaunchKernelGGL(tables_reg_multi_kernel<true>, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(tables_reg_multi_kernel<false>, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
@@ -300,6 +373,46 @@ __global__ void __launch_bounds__(256) tables_adam_multi_kernel(TablesArgs a) {
   }
 }
 
+template <bool H>
+__global__ void __launch_bounds__(256) tables_adam_multi_v4_kernel(TablesArgs a) {
+  const clsr_table_desc d = a.t[blockIdx.y];
+  double tot = 0.0;
+  for (int i = 0; i < d.nsum; ++i) tot += d.sumsq_adam[(long)i * d.sumsq_stride];
+  const float factor = clipf(tot, a.clip_norm);
+  const float lr_t = (float)a.adam_state[3];
+  const float b1 = a.b1, b2 = a.b2;
+  const unsigned QC = (unsigned)d.C >> 2, total = (unsigned)d.V * QC;
+  const unsigned stride = gridDim.x * 256u;
+  for (unsigned q0 = blockIdx.x * 256u + threadIdx.x; q0 < total; q0 += 2u * stride) {
+    bool f[2];
+    f32x4 g[2], m[2], v[2], w[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const unsigned q = q0 + (unsigned)u * stride, qs = q < total ? q : 0u;
+      f[u] = q < total && (!a.lazy || d.flags[qs / QC]);
+      g[u] = ld4(d.grad + 4L * qs); m[u] = ld4(d.m + 4L * qs); v[u] = ld4(d.v + 4L * qs);
+      w[u] = load4e<H>(d.table, 4L * qs);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (!f[u]) continue;
+      const long e = 4L * (q0 + (unsigned)u * stride);
+      f32x4 mm, vv, ww;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float gc = g[u][c] * factor;
+        mm[c] = b1 * m[u][c] + (1.0f - b1) * gc;
+        vv[c] = b2 * v[u][c] + (1.0f - b2) * gc * gc;
+        ww[c] = w[u][c] - lr_t * mm[c] / (sqrtf(vv[c]) + a.eps);
+      }
+      st4(d.m + e, mm);
+      st4(d.v + e, vv);
+      tbl_st4<H>(d.table, e, ww);
+      st4(d.grad + e, f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) tables_clear_flags_kernel(TablesArgs a) {
   const clsr_table_desc d = a.t[blockIdx.y];
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < d.V; e += (long)gridDim.x * blockDim.x) d.flags[e] = 0;
@@ -322,7 +435,12 @@ static int tables_adam_multi_launch(const clsr_table_desc* descs, int n, int bf1
   int blocks = clsr_cdiv(mx, 256);
   if (blocks > 2048) blocks = 2048;
   hipStream_t s = (hipStream_t)stream;
-  if (bf16) hipLaunchKernelGGL(tables_adam_multi_kernel<true>, dim3(blocks, n), dim3(256), 0, s, a);
+  if (tables_v4_ok(descs, n, true)) {
+    blocks = clsr_cdiv(mx / 4, 256 * 2);
+    if (blocks > 2048) blocks = 2048;
+    if (bf16) hipLaunchKernelGGL(tables_adam_multi_v4_kernel<true>, dim3(blocks, n), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(tables_adam_multi_v4_kernel<false>, dim3(blocks, n), dim3(256), 0, s, a);
+  } else if (bf16) hipLaunchKernelGGL(tables_adam_multi_kernel<true>, dim3(blocks, n), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(tables_adam_multi_kernel<false>, dim3(blocks, n), dim3(256), 0, s, a);
   CLSR_CHECK_LAUNCH();
   int cb = clsr_cdiv(mxv, 256);
