@@ -996,6 +996,49 @@ static HfPeers hf_peers(const clsr_heads_desc* d, bool new_step, int nb) {
   return p;
 }
 
+// Start-up check of a communicator: a small launch that runs the SAME arrive / wait code as the heads launches through all
+// eight stages across the ranks (nblocks workgroups per rank, known contributions) and verifies the sums on the device.
+// ok_out (device int): 1 = every stage gave the expected sums on this rank, 0 = a sum was wrong or a wait timed out
+// (timeout_s, short: a rank that cannot see its peers' pushes must not hold the job for the production timeout).
+__global__ void __launch_bounds__(256) heads_comm_selftest_kernel(void* workspace, HfPeers peers, int nb, int* ok_out) {
+  __shared__ double tot[256];
+  __shared__ int flag[4];
+  const HfSync S = hf_sync_init(workspace, nb, flag, 0, &peers);
+  bool ok = true;
+  double ranks = 0.0;
+  for (int r = 0; r < peers.world; ++r) ranks += r + 1;
+  const double blocks = 0.5 * nb * (nb + 1.0);
+  for (int stage = 0; stage < HF_NSTAGE; ++stage) {
+    const int t = threadIdx.x;
+    // element i of a workgroup's row: (rank + 1) * (block + 1) * (i + 1 + stage)
+    hf_arrive(S, stage, 8, t < 4, t, (peers.rank + 1.0) * (blockIdx.x + 1.0) * (t + 1.0 + stage), t + 4,
+              (peers.rank + 1.0) * (blockIdx.x + 1.0) * (t + 5.0 + stage));
+    hf_wait(S, stage, 8, tot);
+    if (t < 8 && tot[t] != ranks * blocks * (t + 1.0 + stage)) ok = false;
+    __syncthreads();
+  }
+  if (!ok || __hip_atomic_load(S.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) atomicAnd(ok_out, 0);
+}
+extern "C" int clsr_heads_comm_self_test(void* comm, int nblocks, void* workspace, long workspace_bytes, int* ok_out,
+                                         float timeout_s, void* stream) {
+  CLSR_CHECK_ARG(comm && workspace && ok_out && nblocks >= 1 && nblocks <= HF_MAXBLK && timeout_s > 0.f);
+  CLSR_CHECK_ARG(workspace_bytes >= clsr_heads_fused_workspace_bytes() && ((uintptr_t)workspace & 15) == 0);
+  HfComm* c = (HfComm*)comm;
+  CLSR_HIP(hipMemsetAsync(workspace, 0, HF_CTR_BYTES, (hipStream_t)stream));
+  int one = 1;
+  CLSR_HIP(hipMemcpyAsync(ok_out, &one, sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream));
+  CLSR_HIP(hipStreamSynchronize((hipStream_t)stream));
+  HfPeers p;
+  for (int r = 0; r < HF_MAXW; ++r) p.x[r] = r < c->world ? c->x[r] : nullptr;
+  p.rank = c->rank; p.world = c->world;
+  c->pushed += (unsigned long long)((nblocks + HF_GS - 1) / HF_GS) * c->world;
+  p.target = c->pushed;
+  p.timeout_ticks = (long long)(timeout_s * 1e8f);
+  hipLaunchKernelGGL(heads_comm_selftest_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, workspace, p, nblocks, ok_out);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
 // Launch 1.  The first clsr_heads_fused_counter_bytes() bytes of the workspace (the barrier counters) must be ZERO on
 // entry: the caller clears them once per step, before this launch (the step's zero-fill launch does).
 extern "C" int clsr_heads_fused_step1(const clsr_heads_desc* d, void* stream) {

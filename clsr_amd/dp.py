@@ -171,7 +171,7 @@ class DataParallel(object):
                 if os.environ.get("CLSR_HEADS_COMM", "1") != "0" and getattr(net, "heads_fused", False) and not shared:
                     try:
                         self.heads_comm = p2p.heads_comm_from_process_group(self.rank, self.world, group)
-                        hok = True
+                        hok = self.heads_comm.self_test(net.device)
                     except Exception:
                         self.heads_comm, hok = None, False
                     hv = [None] * self.world

@@ -117,6 +117,18 @@ class HeadsComm(object):
         self.handle = comm.value
         gather_objects(b"ready")          # nobody pushes before every rank has mapped every buffer
 
+    def self_test(self, device, nblocks=48, timeout_s=5.0):
+        """Every rank at the same point: the arrive / wait protocol of the heads launches through all stages with known
+        contributions; True iff this rank saw the expected sums."""
+        import torch
+
+        nbytes = int(ops.query("clsr_heads_fused_workspace_bytes"))
+        ws = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        ok = torch.ones(1, dtype=torch.int32, device=device)
+        ops.call("clsr_heads_comm_self_test", self.handle, int(nblocks), ws, ws.numel() * 4, ok, float(timeout_s))
+        torch.cuda.synchronize(device)
+        return bool(int(ok.item()) == 1)
+
     def close(self):
         lib = _lib.load()
         if getattr(self, "handle", None):

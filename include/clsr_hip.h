@@ -178,6 +178,9 @@ int clsr_heads_comm_max_world(void);
 int clsr_heads_comm_alloc(void** buf_out);
 int clsr_heads_comm_create(int rank, int world, void* const* bufs, void** comm_out);
 int clsr_heads_comm_destroy(void* comm);
+/* start-up check: every rank calls it at the same point; *ok_out (device) = 1 iff all eight stages gave the expected sums */
+int clsr_heads_comm_self_test(void* comm, int nblocks, void* workspace, long workspace_bytes, int* ok_out, float timeout_s,
+                              void* stream);
 int clsr_heads_fused_error(const void* workspace);   /* synchronous; 1 = a grid barrier timed out (results invalid) */
 int clsr_heads_fused_step1(const clsr_heads_desc* d_host, void* stream);
 int clsr_heads_fused_step2(const clsr_heads_desc* d_host, void* stream);
