@@ -13,6 +13,16 @@
 // with a1 = gamma*invstd, a2 = -gamma*invstd^2*mean(dy*xhat), a3 = -gamma*invstd*mean(dy) - a2*mean.
 #include "common.h"
 
+// The two one-workgroup-per-feature reductions below are links of the step's dependent chain that run BESIDE the
+// MFMA-saturated kernels of the other streams (40-80 workgroups, a few loads and adds each): with equal priority their
+// waves queue for issue slots behind waves that hold the SIMD for 32 cycles per MFMA -- 28.6 us in the step for 5.7 us of
+// work alone (profiles/r04_step_timeline_fp32.txt).  -DCLSR_BN_NO_PRIO: the equal-priority form (A/B builds).
+#ifdef CLSR_BN_NO_PRIO
+#define BN_CHAIN_PRIO()
+#else
+#define BN_CHAIN_PRIO() __builtin_amdgcn_s_setprio(3)
+#endif
+
 // stats_partial: [nparts][2][C] doubles (column sums, column sums of squares).
 // outputs: scale, shift (always); mean, invstd (saved for backward); moving stats updated in place
 // when training.
@@ -23,6 +33,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats_partial, int
                                    int training, float* __restrict__ scale, float* __restrict__ shift,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out) {
   // one 256-thread block per feature (on the critical path of every BN layer: ~1000 partials, 4 per thread)
+  BN_CHAIN_PRIO();
   __shared__ double red[2][4];
   const int c = blockIdx.x;
   float mean, var;
@@ -141,6 +152,7 @@ __global__ void bn_bwd_coef_kernel(const double* __restrict__ partial, int npart
                                    const float* __restrict__ invstd, float* __restrict__ coef,
                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
                                    int accumulate, double grad_scale) {
+  BN_CHAIN_PRIO();
   __shared__ double red[2][4];
   const int c = blockIdx.x;  // one 256-thread block per feature
   double s1 = 0.0, s2 = 0.0;
