@@ -153,3 +153,41 @@ def test_no_barrier_timeout_after_the_steps_above():
         net.train_step(f)
     torch.cuda.synchronize()
     assert query("clsr_heads_fused_error", net._heads_ws().data_ptr()) == 0
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fused_heads_random_batches(seed):
+    """Random batches at the reference's widths -- positives 1 .. 400, rows per positive 2 .. 8, history length 3 .. 50,
+    bpr / triplet, ragged lengths: the two persistent launches against the launch chain (logits, alpha, losses, every
+    gradient) from the same state."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    from bench import build_hparams
+    from clsr_amd.net import CLSRNet
+    from clsr_amd.ops import query
+    from clsr_amd.synthetic import synthetic_feed
+
+    rng = np.random.default_rng(100 + seed)
+    P, G, T = int(rng.integers(1, 401)), int(rng.integers(2, 9)), int(rng.choice([3, 7, 20, 50]))
+    cfg = dict(Vu=500, Vi=3000, Vc=60, Di=32, Dc=8, Du=40, H=40, T=T, P=P)
+    feed = synthetic_feed(P, T, cfg["Vu"], cfg["Vi"], cfg["Vc"], G=G, lengths="lognormal", seed=seed)
+    hp = build_hparams(cfg, P, train_num_ngs=G - 1, contrastive_loss=str(rng.choice(["bpr", "triplet"])),
+                       contrastive_length_threshold=int(rng.integers(1, 6)))
+    dims = dict(Vu=cfg["Vu"], Vi=cfg["Vi"], Vc=cfg["Vc"])
+    nets = [CLSRNet(hp, dims, seed=seed), CLSRNet(hp, dims, seed=seed)]
+    nets[1].load_state_dict(nets[0].state_dict())
+    res = []
+    for net, fused in zip(nets, (True, False)):
+        net.heads_fused = fused
+        net.capture_grads = True
+        f = net.upload(feed, True)
+        assert net._heads_fused_ok(f["B"], G) == fused, (P, G, T)
+        out = net.train_step(f)
+        torch.cuda.synchronize()
+        res.append((dict(logit=out["logit"].clone(), alpha=out["alpha"].clone()), net.read_losses(),
+                    copy.deepcopy(net.captured)))
+        if fused:
+            assert query("clsr_heads_fused_error", net._heads_ws().data_ptr()) == 0
+    (a, la, ca), (b, lb, cb) = res
+    _compare(a, b, la, lb, ca, cb, rtol=5e-4)
