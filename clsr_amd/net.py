@@ -657,7 +657,7 @@ class CLSRNet(object):
         """Wide layer (K, N >= 96): partial tiles + their sum as two launches of csrc/dwwide.hip, on the weight-gradient
         stream like the other products (inside ``_dw_batched``: behind the block's multi-job launch); the gradient is
         complete when ``_dw_flush`` has joined that stream -- nothing is left for the batched reduction."""
-        key = "dww_ws%s.%d.%d.%d" % (self._ws_tag, K, N, dW.data_ptr() % 1000003)
+        key = "dww_ws%s.%d.%d.%x" % (self._ws_tag, K, N, dW.data_ptr())      # (one workspace per gradient: jobs of different streams never share)
         ws = self._buf(key, query("clsr_pgemm_dw_wide_workspace_floats", M, K, N))
         job = (X, ldx, Xmul, ldmul, dY, ldy, M, K, N, ws, dW, ldw, db, acc)
         if self._dw_batch is not None:
