@@ -14,16 +14,20 @@ import torch
 from clsr_amd import _lib, ops
 
 
-class SmallComm(object):
+class _PeerMapped(object):
+    """An exchange buffer per rank, every rank's buffer mapped into every other rank (hipIpc handles through
+    ``gather_objects``), and a communicator object of the C side built from the mapped addresses."""
+
+    _alloc, _create, _destroy, _max_world = None, None, None, None       # names of the C entry points (subclasses)
+
     def __init__(self, rank, world, gather_objects):
         """``gather_objects(obj) -> list of every rank's obj`` (torch.distributed.all_gather_object or equivalent)."""
         lib = _lib.load()
         self.rank, self.world = int(rank), int(world)
-        if self.world > lib.clsr_comm_max_world():
-            raise ValueError("SmallComm: at most %d ranks (one node)" % lib.clsr_comm_max_world())
-        self.max_doubles = lib.clsr_comm_max_doubles()
+        if self.world > getattr(lib, self._max_world)():
+            raise ValueError("%s: at most %d ranks (one node)" % (type(self).__name__, getattr(lib, self._max_world)()))
         buf = ctypes.c_void_p()
-        _lib.check(lib.clsr_comm_alloc(ctypes.byref(buf)), "clsr_comm_alloc")
+        _lib.check(getattr(lib, self._alloc)(ctypes.byref(buf)), self._alloc)
         self._own = buf
         nb = lib.clsr_comm_ipc_handle_bytes()
         h = ctypes.create_string_buffer(nb)
@@ -41,9 +45,31 @@ class SmallComm(object):
             self._peers.append(p)
             ptrs[r] = p
         comm = ctypes.c_void_p()
-        _lib.check(lib.clsr_comm_create(self.rank, self.world, ptrs, ctypes.byref(comm)), "clsr_comm_create")
+        _lib.check(getattr(lib, self._create)(self.rank, self.world, ptrs, ctypes.byref(comm)), self._create)
         self.handle = comm.value          # (an integer address: what ops.call passes for a void*)
         gather_objects(b"ready")          # nobody pushes before every rank has mapped every buffer
+
+    def close(self):
+        lib = _lib.load()
+        if getattr(self, "handle", None):
+            getattr(lib, self._destroy)(ctypes.c_void_p(self.handle))
+            self.handle = None
+        for p in getattr(self, "_peers", []):
+            lib.clsr_comm_ipc_close(p)
+        self._peers = []
+        if getattr(self, "_own", None):
+            lib.clsr_comm_free(self._own)
+            self._own = None
+
+
+class SmallComm(_PeerMapped):
+    """Communicator of clsr_allreduce_small (csrc/p2p.hip)."""
+
+    _alloc, _create, _destroy, _max_world = "clsr_comm_alloc", "clsr_comm_create", "clsr_comm_destroy", "clsr_comm_max_world"
+
+    def __init__(self, rank, world, gather_objects):
+        super().__init__(rank, world, gather_objects)
+        self.max_doubles = _lib.load().clsr_comm_max_doubles()
 
     def all_reduce(self, t, n=None):
         """in-place sum of the first ``n`` doubles of ``t`` over the ranks, asynchronous on the current stream"""
@@ -59,18 +85,6 @@ class SmallComm(object):
         """sequence number of the last all-reduce that gave up waiting for a peer (0: none); synchronises the device"""
         return int(_lib.load().clsr_comm_error(ctypes.c_void_p(self.handle)))
 
-    def close(self):
-        lib = _lib.load()
-        if getattr(self, "handle", None):
-            lib.clsr_comm_destroy(ctypes.c_void_p(self.handle))
-            self.handle = None
-        for p in getattr(self, "_peers", []):
-            lib.clsr_comm_ipc_close(p)
-        self._peers = []
-        if getattr(self, "_own", None):
-            lib.clsr_comm_free(self._own)
-            self._own = None
-
 
 def from_process_group(rank, world, group=None):
     """SmallComm whose handles travel through torch.distributed (any backend with all_gather_object)."""
@@ -84,62 +98,23 @@ def from_process_group(rank, world, group=None):
     return SmallComm(rank, world, gather)
 
 
-class HeadsComm(object):
+class HeadsComm(_PeerMapped):
     """Communicator of the fused heads launches (csrc/headsfused.hip) for synchronised batch-norm statistics across ranks:
     every rank's exchange buffer mapped into every other rank; the workgroups of the launches push their group sums into
-    all of them.  Created like :class:`SmallComm` (handles through ``gather_objects``)."""
+    all of them."""
 
-    def __init__(self, rank, world, gather_objects):
-        lib = _lib.load()
-        self.rank, self.world = int(rank), int(world)
-        if self.world > lib.clsr_heads_comm_max_world():
-            raise ValueError("HeadsComm: at most %d ranks (one node)" % lib.clsr_heads_comm_max_world())
-        buf = ctypes.c_void_p()
-        _lib.check(lib.clsr_heads_comm_alloc(ctypes.byref(buf)), "clsr_heads_comm_alloc")
-        self._own = buf
-        nb = lib.clsr_comm_ipc_handle_bytes()
-        h = ctypes.create_string_buffer(nb)
-        _lib.check(lib.clsr_comm_ipc_handle(buf, h), "clsr_comm_ipc_handle")
-        handles = gather_objects(bytes(h.raw))
-        self._peers = []
-        ptrs = (ctypes.c_void_p * self.world)()
-        for r in range(self.world):
-            if r == self.rank:
-                ptrs[r] = buf
-                continue
-            p = ctypes.c_void_p()
-            hb = ctypes.create_string_buffer(handles[r], nb)
-            _lib.check(lib.clsr_comm_ipc_open(hb, ctypes.byref(p)), "clsr_comm_ipc_open (rank %d)" % r)
-            self._peers.append(p)
-            ptrs[r] = p
-        comm = ctypes.c_void_p()
-        _lib.check(lib.clsr_heads_comm_create(self.rank, self.world, ptrs, ctypes.byref(comm)), "clsr_heads_comm_create")
-        self.handle = comm.value
-        gather_objects(b"ready")          # nobody pushes before every rank has mapped every buffer
+    _alloc, _create, _destroy, _max_world = ("clsr_heads_comm_alloc", "clsr_heads_comm_create", "clsr_heads_comm_destroy",
+                                             "clsr_heads_comm_max_world")
 
     def self_test(self, device, nblocks=48, timeout_s=5.0):
         """Every rank at the same point: the arrive / wait protocol of the heads launches through all stages with known
         contributions; True iff this rank saw the expected sums."""
-        import torch
-
         nbytes = int(ops.query("clsr_heads_fused_workspace_bytes"))
         ws = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=device)
         ok = torch.ones(1, dtype=torch.int32, device=device)
         ops.call("clsr_heads_comm_self_test", self.handle, int(nblocks), ws, ws.numel() * 4, ok, float(timeout_s))
         torch.cuda.synchronize(device)
         return bool(int(ok.item()) == 1)
-
-    def close(self):
-        lib = _lib.load()
-        if getattr(self, "handle", None):
-            lib.clsr_heads_comm_destroy(ctypes.c_void_p(self.handle))
-            self.handle = None
-        for p in getattr(self, "_peers", []):
-            lib.clsr_comm_ipc_close(p)
-        self._peers = []
-        if getattr(self, "_own", None):
-            lib.clsr_comm_free(self._own)
-            self._own = None
 
 
 def heads_comm_from_process_group(rank, world, group=None):
