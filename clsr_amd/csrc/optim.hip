@@ -55,17 +55,18 @@ __global__ void __launch_bounds__(1024) dense_reg_norm_kernel(const float* __res
   double ss = 0.0, pp = 0.0;
   // (eight strides of loads in flight from clamped addresses: the read-modify-write of one stride after the other was a
   // chain of dependent round trips -- 47 us for the 25.6 k-element tensor, one workgroup per CU; same per-thread order)
-  for (int e0 = lo + threadIdx.x; e0 < hi; e0 += 8 * 1024) {
+  const int BS = blockDim.x;
+  for (int e0 = lo + threadIdx.x; e0 < hi; e0 += 8 * BS) {
     float pv[8], gv[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int e = e0 + u * 1024, ec = e < hi ? e : lo;
+      const int e = e0 + u * BS, ec = e < hi ? e : lo;
       pv[u] = param[ec];
       gv[u] = grad[ec];
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int e = e0 + u * 1024;
+      const int e = e0 + u * BS;
       if (e < hi) {
         const float p = pv[u];
         const float g = gv[u] + l2 * p + l1 * (float)((p > 0.f) - (p < 0.f));
@@ -81,7 +82,7 @@ __global__ void __launch_bounds__(1024) dense_reg_norm_kernel(const float* __res
   __syncthreads();
   if (threadIdx.x == 0) {
     double a = 0.0, r = 0.0;
-    for (int w = 0; w < 16; ++w) { a += red[0][w]; r += red[1][w]; }
+    for (int w = 0; w < BS / 64; ++w) { a += red[0][w]; r += red[1][w]; }
     sumsq[seg] = a;
     if (reg_loss) atomicAdd(reg_loss, r);
   }
@@ -91,7 +92,10 @@ extern "C" int clsr_dense_reg_norm_tick(const float* param, float* grad, const i
                                         float l2, float l1, double* sumsq, double* reg_loss, double* adam_state,
                                         double lr, double beta1, double beta2, void* stream) {
   CLSR_CHECK_ARG(param && grad && seg_off && sumsq && nseg > 0);
-  hipLaunchKernelGGL(dense_reg_norm_kernel, dim3(nseg), dim3(1024), 0, (hipStream_t)stream, param, grad,
+  // (workgroups of 1 024 threads wait for a CU with sixteen free wave slots while the table sweeps of the other stream fill
+  // the chip: CLSR_DENSE_REG_THREADS picks the size, A/B)
+  static const int threads = []() { const char* e = getenv("CLSR_DENSE_REG_THREADS"); const int t = e ? atoi(e) : 256; return (t == 256 || t == 512 || t == 1024) ? t : 256; }();
+  hipLaunchKernelGGL(dense_reg_norm_kernel, dim3(nseg), dim3(threads), 0, (hipStream_t)stream, param, grad,
                      seg_off, l2, l1, sumsq, reg_loss, adam_state, lr, beta1, beta2);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
