@@ -392,6 +392,9 @@ __global__ void __launch_bounds__(256) tables_adam_multi_v4_kernel(TablesArgs a)
       f[u] = q < total && (!a.lazy || d.flags[qs / QC]);
       g[u] = ld4(d.grad + 4L * qs); m[u] = ld4(d.m + 4L * qs); v[u] = ld4(d.v + 4L * qs);
       w[u] = load4e<H>(d.table, 4L * qs);
+      // dense Adam does not read the row flags: the thread of a row's first chunk clears the row's flag here and the
+      // separate clearing launch is dropped (lazy Adam: every chunk of a row reads the flag first -- the second launch stays)
+      if (!a.lazy && q < total && q % QC == 0) d.flags[q / QC] = 0;
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -435,7 +438,8 @@ static int tables_adam_multi_launch(const clsr_table_desc* descs, int n, int bf1
   int blocks = clsr_cdiv(mx, 256);
   if (blocks > 2048) blocks = 2048;
   hipStream_t s = (hipStream_t)stream;
-  if (tables_v4_ok(descs, n, true)) {
+  const bool v4 = tables_v4_ok(descs, n, true);
+  if (v4) {
     blocks = clsr_cdiv(mx / 4, 256 * 2);
     if (blocks > 2048) blocks = 2048;
     if (bf16) hipLaunchKernelGGL(tables_adam_multi_v4_kernel<true>, dim3(blocks, n), dim3(256), 0, s, a);
@@ -443,6 +447,7 @@ static int tables_adam_multi_launch(const clsr_table_desc* descs, int n, int bf1
   } else if (bf16) hipLaunchKernelGGL(tables_adam_multi_kernel<true>, dim3(blocks, n), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(tables_adam_multi_kernel<false>, dim3(blocks, n), dim3(256), 0, s, a);
   CLSR_CHECK_LAUNCH();
+  if (v4 && !lazy) return CLSR_OK;          // (the sweep cleared the flags itself)
   int cb = clsr_cdiv(mxv, 256);
   if (cb > 512) cb = 512;
   hipLaunchKernelGGL(tables_clear_flags_kernel, dim3(cb, n), dim3(256), 0, s, a);
