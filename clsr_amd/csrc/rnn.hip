@@ -21,6 +21,7 @@
 #include "common.h"
 #include "clsr_hip.h"
 #include "rnn_args.h"
+#include "hmma.h"
 
 
 __device__ __forceinline__ f32x4 sig4(f32x4 v) {
@@ -348,27 +349,47 @@ __device__ __forceinline__ void gru_bwd_body(const GruArgs& a, const int bx, f32
 static size_t rnn_lds_bytes(int rnt) { return (size_t)2 * 4 * rnt * 64 * sizeof(f32x4); }
 static int rnn_tiles(int n) { return n <= 48 ? 3 : 8; }
 
-// launch K<3> or K<8> by the widest hidden size of the launch
-#define RNN_LAUNCH(K, rnt, grid, stream, args)                                                           \
+// launch K<3, X3> or K<8, X3> by the widest hidden size of the launch and the form of its hidden-to-hidden products
+#define RNN_LAUNCH1(K, RNT_, X3_, grid, stream, args)                                                    \
   do {                                                                                                   \
-    const size_t lds_ = rnn_lds_bytes(rnt);                                                              \
-    if ((rnt) == 3) {                                                                                    \
-      hipLaunchKernelGGL(K<3>, grid, dim3(64 * 3), lds_, (hipStream_t)(stream), args);                   \
-    } else {                                                                                             \
-      CLSR_HIP(hipFuncSetAttribute((const void*)K<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
-      hipLaunchKernelGGL(K<8>, grid, dim3(64 * 8), lds_, (hipStream_t)(stream), args);                   \
-    }                                                                                                    \
+    const size_t lds_ = rnn_lds_bytes(RNT_);                                                             \
+    if (lds_ > 48 * 1024)                                                                                \
+      CLSR_HIP(hipFuncSetAttribute((const void*)K<RNT_, X3_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
+    hipLaunchKernelGGL((K<RNT_, X3_>), grid, dim3(64 * RNT_), lds_, (hipStream_t)(stream), args);        \
+  } while (0)
+#define RNN_LAUNCH(K, rnt, x3, grid, stream, args)                                                       \
+  do {                                                                                                   \
+    if ((rnt) == 3) { if (x3) RNN_LAUNCH1(K, 3, true, grid, stream, args); else RNN_LAUNCH1(K, 3, false, grid, stream, args); } \
+    else { if (x3) RNN_LAUNCH1(K, 8, true, grid, stream, args); else RNN_LAUNCH1(K, 8, false, grid, stream, args); }            \
   } while (0)
 
-template <int RNT>
+// Form of the hidden-to-hidden products: 1 = fp32-input MFMA (bit-exact fp32), 2 = split-bf16 (see the *_x3 bodies).
+// Descriptors carry it (clsr_gru_desc.products / clsr_t4_desc.products); 0 = the process default: CLSR_RNN_PRODUCTS =
+// "fp32" | "x3", split-bf16 when unset.
+static bool rnn_default_x3() {
+  static const bool x3 = []() { const char* e = getenv("CLSR_RNN_PRODUCTS"); return !(e && e[0] == 'f'); }();
+  return x3;
+}
+static bool rnn_x3(int products) { return products == 0 ? rnn_default_x3() : products == 2; }
+
+// (the bodies are defined below the fp32 Time4LSTM ones)
+template <int RNT, bool ATT, bool FP> __device__ __forceinline__ void gru_fwd_x3(const GruArgs& a, const int bx, bf16x8* xb);
+template <int RNT, bool ATT> __device__ __forceinline__ void gru_bwd_x3(const GruArgs& a, const int bx, bf16x8* xb);
+template <int RNT, bool FP> __device__ __forceinline__ void t4lstm_fwd_x3(const T4Args& a, const int bx, bf16x8* xb);
+template <int RNT> __device__ __forceinline__ void t4lstm_bwd_x3(const T4Args& a, const int bx, bf16x8* xb);
+#define XB8(xb) reinterpret_cast<bf16x8*>(xb)
+
+template <int RNT, bool X3>
 __global__ void __launch_bounds__(64 * RNT) gru_fwd_kernel(GruArgs a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
-  gru_fwd_body<RNT>(a, blockIdx.x, xb);
+  if (X3) gru_fwd_x3<RNT, false, false>(a, blockIdx.x, XB8(xb));
+  else gru_fwd_body<RNT>(a, blockIdx.x, xb);
 }
-template <int RNT>
+template <int RNT, bool X3>
 __global__ void __launch_bounds__(64 * RNT) gru_bwd_kernel(GruArgs a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
-  gru_bwd_body<RNT>(a, blockIdx.x, xb);
+  if (X3) gru_bwd_x3<RNT, false>(a, blockIdx.x, XB8(xb));
+  else gru_bwd_body<RNT>(a, blockIdx.x, xb);
 }
 
 static int check_rnn_shape(int Hn, int T, int n, int ld) {
@@ -389,7 +410,7 @@ extern "C" int clsr_gru_fwd(const float* Pin, int ldp, const float* Wgh, int ldg
   a.Pin = Pin; a.ldp = ldp; a.Wgh = Wgh; a.ldg = ldg; a.Wch = Wch; a.ldc = ldc; a.h0 = h0;
   a.h0_stride = h0_stride; a.seq_len = seq_len; a.len_stride = len_stride; a.Hn = Hn; a.T = T; a.n = n;
   a.hT = hT; a.out_seq = out_seq; a.hprev = hprev; a.gates = gates; a.t0 = 0; a.t1 = T;
-  RNN_LAUNCH(gru_fwd_kernel, rnn_tiles(n), dim3(clsr_cdiv(Hn, 16)), stream, a);
+  RNN_LAUNCH(gru_fwd_kernel, rnn_tiles(n), rnn_default_x3(), dim3(clsr_cdiv(Hn, 16)), stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
@@ -407,7 +428,7 @@ extern "C" int clsr_gru_bwd(const float* gates, const float* hprev, const float*
   a.Wgh = Wgh; a.ldg = ldg; a.Wch = Wch; a.ldc = ldc; a.seq_len = seq_len; a.len_stride = len_stride;
   a.Hn = Hn; a.T = T; a.n = n; a.dhT = dhT; a.dout_seq = dout_seq; a.dPin = dPin; a.dh0 = dh0;
   a.lddp = 3 * n; a.t0 = 0; a.t1 = T;
-  RNN_LAUNCH(gru_bwd_kernel, rnn_tiles(n), dim3(clsr_cdiv(Hn, 16)), stream, a);
+  RNN_LAUNCH(gru_bwd_kernel, rnn_tiles(n), rnn_default_x3(), dim3(clsr_cdiv(Hn, 16)), stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
@@ -602,15 +623,589 @@ __device__ __forceinline__ void t4lstm_bwd_body(const T4Args& a, const int bx, f
   if (cval && a.dst_out) { st4(a.dst_out + h * 2 * n + col, dc); st4(a.dst_out + h * 2 * n + n + col, dm); }
 }
 
-template <int RNT>
+template <int RNT, bool X3>
 __global__ void __launch_bounds__(64 * RNT) t4lstm_fwd_kernel(T4Args a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
-  t4lstm_fwd_body<RNT>(a, blockIdx.x, xb);
+  if (X3) t4lstm_fwd_x3<RNT, false>(a, blockIdx.x, XB8(xb));
+  else t4lstm_fwd_body<RNT>(a, blockIdx.x, xb);
 }
-template <int RNT>
+template <int RNT, bool X3>
 __global__ void __launch_bounds__(64 * RNT) t4lstm_bwd_kernel(T4Args a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
-  t4lstm_bwd_body<RNT>(a, blockIdx.x, xb);
+  if (X3) t4lstm_bwd_x3<RNT>(a, blockIdx.x, XB8(xb));
+  else t4lstm_bwd_body<RNT>(a, blockIdx.x, xb);
+}
+
+
+// ============================================================ split-bf16 forms of the four bodies above
+// The hidden-to-hidden products of a step as  W.h ~ Whi.hhi + Whi.hlo + Wlo.hhi  on v_mfma_f32_16x16x32_bf16 (x = hi + lo,
+// hi = RNE_bf16(x), lo = RNE_bf16(x - hi): 16 significand bits, the dropped lo.lo term is 2^-18 relative), fp32
+// accumulation; everything else of a step (gates, state, saved activations, dPin) is the fp32 code of the bodies above.
+// Why: an fp32-input MFMA runs at the fp32 VECTOR rate and blocks its SIMD's issue port for 32 cycles -- the 40 MFMAs
+// of a Time4LSTM step (1 280 cycles) and the ~300 VALU instructions of its gates ran in SERIES, and two waves that share a
+// SIMD could not hide each other's stalls (profiles/r03_rnn_pmc.md).  The bf16 MFMA takes ~17 cycles, a K = 32 chunk per
+// instruction (6 per gate tile and step at n = 40 instead of 10 fp32 ones: 102 against 320 cycles) and co-issues with
+// VALU work of the same and of other waves (scripts/mfma_valu_overlap.hip).
+// Operand layouts of v_mfma_f32_16x16x32_bf16: A lane (i, g) = row i, k = 8g..8g+7; B lane (j, g) = column j (history),
+// k = 8g..8g+7; D lane (j, g) = rows 4g..4g+3 of column j.  A state / gate-gradient VECTOR of the workgroup's 16
+// histories lives in LDS in B-operand order -- [k chunk of 32][g][history j] x 8 bf16, hi image then lo image -- so
+// that collecting it is one conflict-free 16-byte read per chunk and image, and publishing an own f32x4 (4 consecutive
+// k of history j) is one 8-byte write per image.  Backward products concatenate their gate blocks along k
+// (Time4LSTM: k = gate * n + feature, 4n = 160 = exactly 5 chunks at n = 40; GRU: [d r_pre | d u_pre], 80 -> 3 chunks)
+// instead of padding every block to a multiple of 32.
+// Tile-major private image of the Time4LSTM's saved activations (clsr_t4_desc.act_tiled): [16-history tile][t][7 blocks:
+// sig i | tanh j | sig(f+1) | sig o | sig tns | sig tls | c'][feature tile w][lane] x f32x4 -- exactly the registers of the
+// wave that produced them.  In the [Hn, T, 6n] layout a wave's 16-byte store touches 16 different rows (64 separate
+// 64-byte pieces): the training forward of the Time4LSTM alone took 128 us, 71 us without its stores (ablation,
+// scripts/abl_rnn.sh).  Only the forward and the backward recurrence read / write these tensors.
+#define T4_TILED_ROW(RNT) (7 * (RNT) * 16)
+template <int KC> struct XA { bf16x8 hi[KC], lo[KC]; };   // weights of this wave's 16 output rows, KC chunks of k
+template <int KC> struct XB { bf16x8 hi[KC], lo[KC]; };   // a full vector of the 16 histories
+
+__device__ __forceinline__ void split8(f32x8 v, bf16x8& hi, bf16x8& lo) {
+  hi = to_h(v);
+  lo = to_h(v - to_f(hi));
+}
+
+// forward use: rows = outputs o = 16w + i of the block at colbase, k = input feature (W is [in][out]: strided reads, once)
+template <int KC>
+__device__ __forceinline__ void xa_load_fwd(XA<KC>& a, const float* W, int ld, int colbase, int n, int w, int lane) {
+  const int i = lane & 15, g = lane >> 4, o = 16 * w + i;
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    f32x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 32 * c + 8 * g + e;
+      v[e] = (o < n && k < n) ? W[(long)k * ld + colbase + o] : 0.f;
+    }
+    split8(v, a.hi[c], a.lo[c]);
+  }
+}
+// the same with an input width K != n (input-projection weights: k = embedding feature) and the bias of the block as row
+// k = K (the B operand carries a constant 1 there: the bias costs no register and no add)
+template <int KC>
+__device__ __forceinline__ void xa_load_fwd_k(XA<KC>& a, const float* W, int ld, int colbase, int n, int K, int w, int lane,
+                                              const float* bias) {
+  const int i = lane & 15, g = lane >> 4, o = 16 * w + i;
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    f32x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 32 * c + 8 * g + e;
+      v[e] = (o < n && k < K) ? W[(long)k * ld + colbase + o] : (o < n && k == K) ? bias[o] : 0.f;
+    }
+    split8(v, a.hi[c], a.lo[c]);
+  }
+}
+// backward use: rows = inputs in = 16w + i, k = the K consecutive columns of W's row from colbase on
+template <int KC>
+__device__ __forceinline__ void xa_load_bwd(XA<KC>& a, const float* W, int ld, int colbase, int K, int n, int w, int lane) {
+  const int i = lane & 15, g = lane >> 4, in = 16 * w + i;
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    const int k0 = 32 * c + 8 * g;
+    const float* p = W + (long)(in < n ? in : 0) * ld + colbase;
+    const f32x4 lo4 = (in < n && k0 < K) ? ld4(p + k0) : Z4;
+    const f32x4 hi4 = (in < n && k0 + 4 < K) ? ld4(p + k0 + 4) : Z4;
+    split8((f32x8){lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w}, a.hi[c], a.lo[c]);
+  }
+}
+
+// publish the 4 consecutive k = k0..k0+3 (k0 % 4 == 0) of history j
+template <int KC>
+__device__ __forceinline__ void xb_publish(bf16x8* buf, int k0, int j, bool ok, f32x4 v) {
+  const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+  const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+  const int slot = ((((k0 >> 5) * 4 + ((k0 & 31) >> 3)) * 16 + j) << 1) + ((k0 & 7) >> 2);   // 8-byte units
+  bf16x4* b4 = reinterpret_cast<bf16x4*>(buf);
+  if (ok) { b4[slot] = hi; b4[KC * 128 + slot] = lo; }
+}
+template <int KC>
+__device__ __forceinline__ void xb_collect(const bf16x8* buf, int lane, XB<KC>& v) {
+#pragma unroll
+  for (int c = 0; c < KC; ++c) { v.hi[c] = buf[c * 64 + lane]; v.lo[c] = buf[KC * 64 + c * 64 + lane]; }
+}
+// acc += A . B over the first kcu chunks, two accumulators (two independent MFMA chains)
+template <int KC>
+__device__ __forceinline__ void xmac2(f32x4& acc0, f32x4& acc1, const XA<KC>& a, const XB<KC>& b, int kcu) {
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    if (c < kcu) {     // (uniform; a `break` here keeps the loop rolled and the operand arrays in scratch)
+      f32x4& acc = (c & 1) ? acc1 : acc0;
+      HMFMA(acc, a.hi[c], b.lo[c]);
+      HMFMA(acc, a.lo[c], b.hi[c]);
+      HMFMA(acc, a.hi[c], b.hi[c]);
+    }
+  }
+}
+// the same with the vector read from LDS chunk by chunk (wide backward products: the whole vector would take as many
+// registers as the weights)
+template <int KC>
+__device__ __forceinline__ void xmac2_lds(f32x4& acc0, f32x4& acc1, const XA<KC>& a, const bf16x8* buf, int lane, int kcu) {
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    if (c < kcu) {
+      const bf16x8 bh = buf[c * 64 + lane], bl = buf[KC * 64 + c * 64 + lane];
+      f32x4& acc = (c & 1) ? acc1 : acc0;
+      HMFMA(acc, a.hi[c], bl);
+      HMFMA(acc, a.lo[c], bh);
+      HMFMA(acc, a.hi[c], bh);
+    }
+  }
+}
+__device__ __forceinline__ void xb_zero(bf16x8* xb, int n16) {
+  const f32x4 z = Z4;
+  for (int i = threadIdx.x; i < n16; i += blockDim.x) reinterpret_cast<f32x4*>(xb)[i] = z;
+  __syncthreads();
+}
+
+// ---- fused input projection (FP): the input-side pre-activations of a step, x_t . W_x + b, are computed IN the
+// recurrence from the history embeddings instead of being read from a [Hn, T, 3n | 6n] tensor that a batched GEMM wrote
+// (clsr_gru_desc.X / clsr_t4_desc.X).  The recurrences are HBM-bound (Time4LSTM training forward alone: 492 MB in 120 us;
+// neither its MFMAs nor its gate arithmetic show up in an ablation, its loads and stores each cost ~50 us,
+// scripts/abl_rnn.sh): the projection tensor was 1 920 of the 4 640 bytes a (history, step) moved through the forward
+// launch -- plus the same bytes written by the GEMM on the critical path in front of it.  x_t is read as fp32 in
+// B-operand order (lane (j, g): features 8g..8g+7 of chunk c of history j) one step ahead and split in registers; the
+// products of step t + 1 are issued between publishing the state of step t and the barrier that waits for the other
+// waves, where the wave would idle.  D % 8 == 0, D <= 32 KC.
+template <int KC>
+__device__ __forceinline__ void xload(f32x8 (&xr)[KC], const float* xrow, int D, int g) {
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    const int k0 = 32 * c + 8 * g;
+    xr[c] = ld8f(xrow + (k0 < D ? k0 : 0));     // (unconditional, clamped: masked in xsplit)
+  }
+}
+template <int KC>
+__device__ __forceinline__ void xsplit(const f32x8 (&xr)[KC], int D, int g, XB<KC>& xb) {
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    const int k0 = 32 * c + 8 * g;
+    f32x8 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    z[0] = k0 == D ? 1.0f : 0.f;               // the constant input that multiplies the bias row (xa_load_fwd_k)
+    split8(k0 < D ? xr[c] : z, xb.hi[c], xb.lo[c]);
+  }
+}
+
+template <int RNT, bool ATT = false, bool FP = false>
+__device__ __forceinline__ void gru_fwd_x3(const GruArgs& a, const int bx, bf16x8* xb) {
+  constexpr int KC = (RNT * 16 + 31) / 32;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const int n = a.n, T = a.T;
+  const int kcu = (n + 31) >> 5;
+  const long h = (long)bx * 16 + j;
+  const bool hvalid = h < a.Hn;
+  XA<KC> wr, wu, wc;
+  xa_load_fwd<KC>(wr, a.Wgh, a.ldg, 0, n, w, lane);
+  xa_load_fwd<KC>(wu, a.Wgh, a.ldg, n, n, w, lane);
+  xa_load_fwd<KC>(wc, a.Wch, a.ldc, 0, n, w, lane);
+  const int col = 16 * w + 4 * g;
+  const bool cval = hvalid && col < n;
+  f32x4 hown = (cval && a.h0) ? ld4(a.h0 + h * a.h0_stride + col) : Z4;
+  const long hin = ATT ? (hvalid ? h : 0) / a.in_div : (hvalid ? h : 0);
+  const int len = hvalid ? min(a.seq_len[hin * a.len_stride], T) : 0;
+  const int Tmax = wave_max_i(len);
+  const float* pin = FP ? nullptr : a.Pin + hin * (long)T * a.ldp + (cval ? col : 0);
+  const float* attp = ATT ? a.att + (hvalid ? h : 0) * (long)T : nullptr;
+  const int t0 = a.t0, tend = min(Tmax, a.t1);
+  // input side of a step: FP -- x . [Wgx | Wcx] + bias from the embeddings; else the projection tensor
+  const int Dx = a.Dx, kcx = (Dx + 32) >> 5;     // (+ the bias row)
+  XA<KC> pr, pu, pc;
+  f32x8 xr[KC];
+  const float* xrow = FP ? a.X + hin * (long)T * a.ldx : nullptr;
+  f32x4 pn[3];
+  if (FP) {
+    xa_load_fwd_k<KC>(pr, a.Wgx, a.ldg, 0, n, Dx, w, lane, a.bg);
+    xa_load_fwd_k<KC>(pu, a.Wgx, a.ldg, n, n, Dx, w, lane, a.bg + n);
+    xa_load_fwd_k<KC>(pc, a.Wcx, a.ldc, 0, n, Dx, w, lane, a.bc);
+    xload<KC>(xr, xrow + (long)t0 * a.ldx, Dx, g);
+  } else {
+#pragma unroll
+    for (int gb = 0; gb < 3; ++gb) pn[gb] = sel4(cval && t0 < len, ld4(pin + (long)t0 * a.ldp + gb * n), Z4);
+  }
+  auto project = [&](int tnext) {   // pn <- bias + x . W of the step whose embeddings sit in xr; then fetch step tnext
+    XB<KC> xv;
+    xsplit<KC>(xr, Dx, g, xv);
+    const long tn = tnext < T ? tnext : T - 1;
+    xload<KC>(xr, xrow + tn * a.ldx, Dx, g);
+    f32x4 q0 = Z4, q1 = Z4, q2 = Z4;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      if (c < kcx) {
+        HMFMA(q0, pr.hi[c], xv.lo[c]); HMFMA(q1, pu.hi[c], xv.lo[c]); HMFMA(q2, pc.hi[c], xv.lo[c]);
+        HMFMA(q0, pr.lo[c], xv.hi[c]); HMFMA(q1, pu.lo[c], xv.hi[c]); HMFMA(q2, pc.lo[c], xv.hi[c]);
+        HMFMA(q0, pr.hi[c], xv.hi[c]); HMFMA(q1, pu.hi[c], xv.hi[c]); HMFMA(q2, pc.hi[c], xv.hi[c]);
+      }
+    }
+    pn[0] = q0; pn[1] = q1; pn[2] = q2;
+  };
+  float an = ATT ? attp[t0] : 0.f;
+  bf16x8* bufA = xb;                   // r . h
+  bf16x8* bufB = xb + 2 * KC * 64;     // h
+  xb_zero(xb, 4 * KC * 64);
+  XB<KC> hs, rh;
+  xb_publish<KC>(bufB, col, j, true, hown);
+  if (FP) project(t0 + 1);
+  __syncthreads();
+  xb_collect<KC>(bufB, lane, hs);
+  const rnn_rsrc_t rhp = rnn_rsrc_blk(a.hprev, bx, T, n), rga = rnn_rsrc_blk(a.gates, bx, T, 3 * n);
+  const rnn_rsrc_t ros = rnn_rsrc_blk(a.out_seq, bx, T, n);
+  for (int t = t0; t < tend; ++t) {
+    const bool live = t < len;
+    f32x4 accr = pn[0], accu = pn[1], accc = pn[2], accc1 = Z4;
+    const float keep = 1.0f - an;
+    if (!FP) {
+      const bool nl = (t + 1) < len;
+      const long tn = t + 1 < T ? t + 1 : t;
+#pragma unroll
+      for (int gb = 0; gb < 3; ++gb) pn[gb] = sel4(cval && nl, ld4(pin + tn * a.ldp + gb * n), Z4);
+    }
+    if (ATT) an = attp[t + 1 < T ? t + 1 : t];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      if (c < kcu) {
+        HMFMA(accr, wr.hi[c], hs.lo[c]); HMFMA(accu, wu.hi[c], hs.lo[c]);
+        HMFMA(accr, wr.lo[c], hs.hi[c]); HMFMA(accu, wu.lo[c], hs.hi[c]);
+        HMFMA(accr, wr.hi[c], hs.hi[c]); HMFMA(accu, wu.hi[c], hs.hi[c]);
+      }
+    }
+    // (FP) the input-side products of step t + 1 right behind the recurrent ones: independent MFMAs for the matrix pipe while
+    // the VALU works on the gates -- between publish and barrier they sat on the critical path of EVERY wave (335 against
+    // 176 us in the step)
+    if (FP) project(t + 2);
+    const f32x4 r = sig4(accr), u = sig4(accu);
+    xb_publish<KC>(bufA, col, j, true, r * hown);
+    __syncthreads();
+    xb_collect<KC>(bufA, lane, rh);
+    xmac2<KC>(accc, accc1, wc, rh, kcu);
+    const f32x4 c = tanh4(accc + accc1);
+    const f32x4 ue = u * keep;
+    const f32x4 hn = ue * hown + (1.0f - ue) * c;
+    {
+      const bool ok = live && cval;
+      const unsigned pos = (unsigned)(j * T + t);
+      st4_b(rhp, ok, pos * n + col, hown);
+      st4_b(rga, ok, pos * 3 * n + col, r); st4_b(rga, ok, pos * 3 * n + n + col, u); st4_b(rga, ok, pos * 3 * n + 2 * n + col, c);
+      st4_b(ros, ok, pos * n + col, hn);
+    }
+    hown = sel4(live, hn, hown);
+    xb_publish<KC>(bufB, col, j, true, hown);
+    __syncthreads();
+    xb_collect<KC>(bufB, lane, hs);
+  }
+  if (cval) {
+    if (a.hT) st4(a.hT + h * n + col, hown);
+    if (a.out_seq)
+      for (int t = max(len, t0); t < a.t1; ++t) st4(a.out_seq + (h * T + t) * n + col, Z4);
+  }
+}
+
+template <int RNT, bool ATT = false>
+__device__ __forceinline__ void gru_bwd_x3(const GruArgs& a, const int bx, bf16x8* xb) {
+  constexpr int KC = (RNT * 16 + 31) / 32;     // d c_pre: k = feature
+  constexpr int KC2 = RNT;                     // [d r_pre | d u_pre]: k = gate * n + feature, 2n <= 32 RNT
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const int n = a.n, T = a.T;
+  const int kcu = (n + 31) >> 5, kcu2 = (2 * n + 31) >> 5;
+  const long h = (long)bx * 16 + j;
+  const bool hvalid = h < a.Hn;
+  XA<KC> wc;
+  XA<KC2> wg;
+  xa_load_bwd<KC>(wc, a.Wch, a.ldc, 0, n, n, w, lane);
+  xa_load_bwd<KC2>(wg, a.Wgh, a.ldg, 0, 2 * n, n, w, lane);
+  const int col = 16 * w + 4 * g;
+  const bool colv = col < n;
+  const bool cval = hvalid && colv;
+  f32x4 dh = (cval && a.dhT) ? ld4(a.dhT + h * n + col) : Z4;
+  const long hin = ATT ? (hvalid ? h : 0) / a.in_div : (hvalid ? h : 0);
+  const int len = hvalid ? min(a.seq_len[hin * a.len_stride], T) : 0;
+  const int Tmax = wave_max_i(len);
+  const float* attp = ATT ? a.att + (hvalid ? h : 0) * (long)T : nullptr;
+  if (cval)
+    for (int t = max(len, a.t0); t < a.t1; ++t) {
+      const long dp = (h * T + t) * a.lddp + col;
+      st_dpin(a.dPin, dp, Z4, a.dpin_bf16); st_dpin(a.dPin, dp + n, Z4, a.dpin_bf16); st_dpin(a.dPin, dp + 2 * n, Z4, a.dpin_bf16);
+    }
+  bf16x8* bufA = xb;
+  bf16x8* bufG = xb + 2 * KC * 64;
+  xb_zero(xb, 2 * KC * 64 + 2 * KC2 * 64);
+  const long hc = hvalid ? h : 0;
+  const int colc = cval ? col : 0;
+  const float* gbase = a.gates + hc * T * 3 * n + colc;
+  const float* hbase = a.hprev + hc * T * n + colc;
+  const float* dsbase = (a.dout_seq ? a.dout_seq : a.hprev) + hc * T * n + colc;
+  const bool has_ds = a.dout_seq != nullptr;
+  const rnn_rsrc_t rdp = rnn_rsrc(a.dPin + (a.dpin_bf16 ? (long)bx * 16 * T * a.lddp / 2 : (long)bx * 16 * T * a.lddp));
+  struct In { f32x4 r, u, c, hp, ds; float at; };
+  auto fetch = [&](int t) {
+    t = max(t, 0);
+    In v;
+    const float* gp = gbase + (long)t * 3 * n;
+    v.r = ld4(gp); v.u = ld4(gp + n); v.c = ld4(gp + 2 * n);
+    v.hp = ld4(hbase + (long)t * n);
+    v.ds = ld4(dsbase + (long)t * n);
+    v.at = ATT ? attp[t] : 0.f;
+    return v;
+  };
+  const int tstart = min(Tmax, a.t1) - 1;
+  In cur = fetch(tstart);
+  for (int t = tstart; t >= a.t0; --t) {
+    const In nxt = fetch(t - 1);
+    const bool live = t < len;
+    const bool ok = live && cval;
+    const f32x4 r = sel4(ok, cur.r, Z4), u = sel4(ok, cur.u, Z4), c = sel4(ok, cur.c, Z4);
+    const f32x4 hp = sel4(ok, cur.hp, Z4);
+    f32x4 d = dh;
+    if (has_ds) d += cur.ds;
+    d = sel4(ok, d, Z4);
+    const float keep = ATT ? 1.0f - cur.at : 1.0f;
+    const f32x4 ue = u * keep;
+    const f32x4 due = d * (hp - c);
+    const f32x4 du = due * keep;
+    const f32x4 dcp = d * (1.0f - ue) * (1.0f - c * c);
+    f32x4 dhn = d * ue;
+    if (ATT) {
+      float sa = -(u.x * due.x + u.y * due.y + u.z * due.z + u.w * due.w);
+      sa += __shfl_xor(sa, 16);
+      sa += __shfl_xor(sa, 32);
+      if (g == 0 && live && hvalid) atomicAdd(a.datt + h * (long)T + t, sa);
+    }
+    xb_publish<KC>(bufA, col, j, colv, dcp);
+    __syncthreads();
+    f32x4 drh = Z4, drh1 = Z4;
+    xmac2_lds<KC>(drh, drh1, wc, bufA, lane, kcu);
+    drh += drh1;
+    const f32x4 drp = drh * hp * r * (1.0f - r);
+    const f32x4 dup = du * u * (1.0f - u);
+    dhn += drh * r;
+    xb_publish<KC2>(bufG, col, j, colv, drp);
+    xb_publish<KC2>(bufG, n + col, j, colv, dup);
+    __syncthreads();
+    f32x4 dh1 = Z4;
+    xmac2_lds<KC2>(dhn, dh1, wg, bufG, lane, kcu2);
+    dhn += dh1;
+    {
+      const unsigned dp = (unsigned)((j * T + t) * a.lddp + col);
+      st_dpin_b(rdp, ok, dp, drp, a.dpin_bf16); st_dpin_b(rdp, ok, dp + n, dup, a.dpin_bf16);
+      st_dpin_b(rdp, ok, dp + 2 * n, dcp, a.dpin_bf16);
+    }
+    dh = sel4(live, dhn, dh);
+    cur = nxt;
+  }
+  if (a.dh0 && cval) st4(a.dh0 + h * n + col, dh);
+}
+
+// FP: blocks i | j | f from x . kernel[0:D] + bias in the kernel; Pin then holds only o | tns | tls (3n wide: the product
+// that also needs the time features, net.py "xw.t")
+template <int RNT, bool FP = false>
+__device__ __forceinline__ void t4lstm_fwd_x3(const T4Args& a, const int bx, bf16x8* xb) {
+  constexpr int KC = (RNT * 16 + 31) / 32;
+  constexpr int NP = FP ? 3 : 6;       // blocks read from Pin
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const int n = a.n, T = a.T;
+  const int kcu = (n + 31) >> 5;
+  const long h = (long)bx * 16 + j;
+  const bool hvalid = h < a.Hn;
+  XA<KC> wm[4];
+#pragma unroll
+  for (int gb = 0; gb < 4; ++gb) xa_load_fwd<KC>(wm[gb], a.Wm, a.ldm, gb * n, n, w, lane);
+  const int col = 16 * w + 4 * g;
+  const bool cval = hvalid && col < n;
+  f32x4 cs = Z4, mown = Z4;
+  if (cval && a.st_in) { cs = ld4(a.st_in + h * 2 * n + col); mown = ld4(a.st_in + h * 2 * n + n + col); }
+  const int len = hvalid ? min(a.seq_len[h * a.len_stride], T) : 0;
+  const int Tmax = wave_max_i(len);
+  const int t0 = a.t0, tend = min(Tmax, a.t1);
+  const float* pin = a.Pin + (hvalid ? h : 0) * (long)T * a.ldp + (cval ? col : 0);
+  f32x4 pn[NP];
+#pragma unroll
+  for (int gb = 0; gb < NP; ++gb) pn[gb] = sel4(cval && t0 < len, ld4(pin + (long)t0 * a.ldp + gb * n), Z4);
+  const int Dx = a.Dx, kcx = (Dx + 32) >> 5;     // (+ the bias row)
+  XA<KC> px[FP ? 3 : 1];
+  f32x4 qn[3] = {Z4, Z4, Z4};
+  f32x8 xr[KC];
+  const float* xrow = FP ? a.X + (hvalid ? h : 0) * (long)T * a.ldx : nullptr;
+  if (FP) {
+#pragma unroll
+    for (int gb = 0; gb < 3; ++gb) {
+      xa_load_fwd_k<KC>(px[gb], a.Wkx, a.ldm, gb * n, n, Dx, w, lane, a.bk + gb * n);
+    }
+    xload<KC>(xr, xrow + (long)t0 * a.ldx, Dx, g);
+  }
+  auto project = [&](int tnext) {
+    XB<KC> xv;
+    xsplit<KC>(xr, Dx, g, xv);
+    const long tn = tnext < T ? tnext : T - 1;
+    xload<KC>(xr, xrow + tn * a.ldx, Dx, g);
+    f32x4 q0 = Z4, q1 = Z4, q2 = Z4;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      if (c < kcx) {
+        HMFMA(q0, px[0].hi[c], xv.lo[c]); HMFMA(q1, px[FP ? 1 : 0].hi[c], xv.lo[c]); HMFMA(q2, px[FP ? 2 : 0].hi[c], xv.lo[c]);
+        HMFMA(q0, px[0].lo[c], xv.hi[c]); HMFMA(q1, px[FP ? 1 : 0].lo[c], xv.hi[c]); HMFMA(q2, px[FP ? 2 : 0].lo[c], xv.hi[c]);
+        HMFMA(q0, px[0].hi[c], xv.hi[c]); HMFMA(q1, px[FP ? 1 : 0].hi[c], xv.hi[c]); HMFMA(q2, px[FP ? 2 : 0].hi[c], xv.hi[c]);
+      }
+    }
+    qn[0] = q0; qn[1] = q1; qn[2] = q2;
+  };
+  xb_zero(xb, 4 * KC * 64);
+  XB<KC> ms;
+  xb_publish<KC>(xb + ((t0 + 1) & 1) * 2 * KC * 64, col, j, true, mown);
+  if (FP) project(t0 + 1);
+  __syncthreads();
+  xb_collect<KC>(xb + ((t0 + 1) & 1) * 2 * KC * 64, lane, ms);
+  const bool tiled = a.act_tiled != 0;
+  const rnn_rsrc_t ros = rnn_rsrc_blk(a.out_seq, bx, T, n), rac = rnn_rsrc_blk(a.act, bx, T, tiled ? T4_TILED_ROW(RNT) : 6 * n);
+  const rnn_rsrc_t rcs = rnn_rsrc_blk(a.act && !tiled ? a.cst : nullptr, bx, T, n), rmp = rnn_rsrc_blk(a.act ? a.mprev : nullptr, bx, T, n);
+  for (int t = t0; t < tend; ++t) {
+    const bool live = t < len;
+    f32x4 acc[4];
+    if (FP) { acc[0] = qn[0]; acc[1] = qn[1]; acc[2] = qn[2]; acc[3] = pn[0]; }
+    else {
+#pragma unroll
+      for (int gb = 0; gb < 4; ++gb) acc[gb] = pn[gb];
+    }
+    const f32x4 tns = pn[NP - 2], tls = pn[NP - 1];
+    {
+      const bool nl = (t + 1) < len;
+      const long tn = t + 1 < T ? t + 1 : t;
+#pragma unroll
+      for (int gb = 0; gb < NP; ++gb) pn[gb] = sel4(cval && nl, ld4(pin + tn * a.ldp + gb * n), Z4);
+    }
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      if (c < kcu) {
+#pragma unroll
+        for (int gb = 0; gb < 4; ++gb) HMFMA(acc[gb], wm[gb].hi[c], ms.lo[c]);
+#pragma unroll
+        for (int gb = 0; gb < 4; ++gb) HMFMA(acc[gb], wm[gb].lo[c], ms.hi[c]);
+#pragma unroll
+        for (int gb = 0; gb < 4; ++gb) HMFMA(acc[gb], wm[gb].hi[c], ms.hi[c]);
+      }
+    }
+    if (FP) project(t + 2);       // (behind the recurrent products, ahead of the gate arithmetic: see gru_fwd_x3)
+    const f32x4 ig = sig4(acc[0]), jg = tanh4(acc[1]), fg = sig4(acc[2] + 1.0f);
+    const f32x4 og = sig4(acc[3]), tn = sig4(tns), tlg = sig4(tls);
+    const f32x4 cn = fg * tlg * cs + ig * tn * jg;
+    const f32x4 mn = og * tanh4(cn);
+    {
+      const bool ok = live && cval;
+      const unsigned pos = (unsigned)(j * T + t);
+      st4_b(ros, ok, pos * n + col, mn);
+      if (tiled) {   // private tile-major image: every store is one contiguous KB of the wave (see T4_TILED_ROW)
+        const unsigned ap = (unsigned)(t * 7 * RNT + w) * 256u + lane * 4u, sb = RNT * 256u;
+        st4_b(rac, true, ap, ig); st4_b(rac, true, ap + sb, jg); st4_b(rac, true, ap + 2 * sb, fg); st4_b(rac, true, ap + 3 * sb, og);
+        st4_b(rac, true, ap + 4 * sb, tn); st4_b(rac, true, ap + 5 * sb, tlg); st4_b(rac, true, ap + 6 * sb, cn);
+      } else {
+        const unsigned ap = pos * 6 * n + col;
+        st4_b(rac, ok, ap, ig); st4_b(rac, ok, ap + n, jg); st4_b(rac, ok, ap + 2 * n, fg); st4_b(rac, ok, ap + 3 * n, og);
+        st4_b(rac, ok, ap + 4 * n, tn); st4_b(rac, ok, ap + 5 * n, tlg);
+        st4_b(rcs, ok, pos * n + col, cn);
+      }
+      st4_b(rmp, ok, pos * n + col, mown);
+    }
+    cs = sel4(live, cn, cs);
+    mown = sel4(live, mn, mown);
+    bf16x8* buf = xb + (t & 1) * 2 * KC * 64;     // double buffered: one barrier per step
+    xb_publish<KC>(buf, col, j, true, mown);
+    __syncthreads();
+    xb_collect<KC>(buf, lane, ms);
+  }
+  if (cval) {
+    for (int t = max(len, t0); t < a.t1; ++t) st4(a.out_seq + (h * T + t) * n + col, Z4);
+    if (a.st_out) { st4(a.st_out + h * 2 * n + col, cs); st4(a.st_out + h * 2 * n + n + col, mown); }
+  }
+}
+
+template <int RNT>
+__device__ __forceinline__ void t4lstm_bwd_x3(const T4Args& a, const int bx, bf16x8* xb) {
+  constexpr int KC4 = 2 * RNT;                 // k = gate * n + feature: 4n <= 64 RNT
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const int n = a.n, T = a.T;
+  const int kcu = (4 * n + 31) >> 5;
+  const long h = (long)bx * 16 + j;
+  const bool hvalid = h < a.Hn;
+  XA<KC4> wm;
+  xa_load_bwd<KC4>(wm, a.Wm, a.ldm, 0, 4 * n, n, w, lane);
+  const int col = 16 * w + 4 * g;
+  const bool colv = col < n;
+  const bool cval = hvalid && colv;
+  f32x4 dc = Z4, dm = Z4;
+  if (cval && a.dst_in) { dc = ld4(a.dst_in + h * 2 * n + col); dm = ld4(a.dst_in + h * 2 * n + n + col); }
+  const int len = hvalid ? min(a.seq_len[h * a.len_stride], T) : 0;
+  const int Tmax = wave_max_i(len);
+  if (cval)
+    for (int t = max(len, a.t0); t < a.t1; ++t) {
+      const long dp = (h * T + t) * a.lddp + col;
+#pragma unroll
+      for (int gb = 0; gb < 6; ++gb) st_dpin(a.dPin, dp + gb * n, Z4, a.dpin_bf16);
+    }
+  xb_zero(xb, 4 * KC4 * 64);
+  const long hc = hvalid ? h : 0;
+  const int colc = cval ? col : 0;
+  const bool tiled = a.act_tiled != 0;
+  const float* abase = tiled ? a.act + ((long)bx * T * 7 * RNT + w) * 256 + lane * 4 : a.act + hc * T * 6 * n + colc;
+  const float* cbase = tiled ? abase + 6 * RNT * 256 : a.cst + hc * T * n + colc;
+  const int sa = tiled ? 7 * RNT * 256 : 6 * n, sb = tiled ? RNT * 256 : n, sc = tiled ? 7 * RNT * 256 : n;
+  const float* dsbase = a.dout_seq + hc * T * n + colc;
+  const rnn_rsrc_t rdp = rnn_rsrc(a.dPin + (a.dpin_bf16 ? (long)bx * 16 * T * a.lddp / 2 : (long)bx * 16 * T * a.lddp));
+  struct In { f32x4 ig, jg, fg, og, tn, tlg, cn, cp, ds; };
+  auto fetch = [&](int t) {
+    t = max(t, 0);
+    In v;
+    const float* ap = abase + (long)t * sa;
+    v.ig = ld4(ap); v.jg = ld4(ap + sb); v.fg = ld4(ap + 2 * sb); v.og = ld4(ap + 3 * sb); v.tn = ld4(ap + 4 * sb);
+    v.tlg = ld4(ap + 5 * sb);
+    v.cn = ld4(cbase + (long)t * sc);
+    v.cp = ld4(cbase + (long)max(t - 1, 0) * sc);
+    v.ds = ld4(dsbase + (long)t * n);
+    return v;
+  };
+  constexpr bool PF = RNT <= 4;
+  const int tstart = min(Tmax, a.t1) - 1;
+  In cur = fetch(tstart), nxt = cur;
+  for (int t = tstart; t >= a.t0; --t) {
+    if (PF) nxt = fetch(t - 1);
+    else cur = fetch(t);
+    const bool live = t < len;
+    const bool ok = live && cval;
+    const f32x4 ig = sel4(ok, cur.ig, Z4), jg = sel4(ok, cur.jg, Z4), fg = sel4(ok, cur.fg, Z4);
+    const f32x4 og = sel4(ok, cur.og, Z4), tn = sel4(ok, cur.tn, Z4);
+    const f32x4 tlg = sel4(ok, cur.tlg, Z4);
+    const f32x4 cn = sel4(ok, cur.cn, Z4);
+    const f32x4 cp = sel4(ok && t > 0, cur.cp, Z4);
+    f32x4 d = dm + cur.ds;
+    d = sel4(ok, d, Z4);
+    const f32x4 tc = tanh4(cn);
+    const f32x4 dcc = sel4(ok, dc + d * og * (1.0f - tc * tc), Z4);
+    f32x4 dg[4];
+    dg[3] = d * tc * og * (1.0f - og);
+    dg[2] = dcc * tlg * cp * fg * (1.0f - fg);
+    dg[0] = dcc * tn * jg * ig * (1.0f - ig);
+    dg[1] = dcc * ig * tn * (1.0f - jg * jg);
+    const f32x4 dtn = dcc * ig * jg * tn * (1.0f - tn);
+    const f32x4 dtl = dcc * fg * cp * tlg * (1.0f - tlg);
+    const f32x4 dcn = dcc * fg * tlg;
+    {
+      const unsigned dp = (unsigned)((j * T + t) * a.lddp + col);
+      st_dpin_b(rdp, ok, dp, dg[0], a.dpin_bf16); st_dpin_b(rdp, ok, dp + n, dg[1], a.dpin_bf16);
+      st_dpin_b(rdp, ok, dp + 2 * n, dg[2], a.dpin_bf16); st_dpin_b(rdp, ok, dp + 3 * n, dg[3], a.dpin_bf16);
+      st_dpin_b(rdp, ok, dp + 4 * n, dtn, a.dpin_bf16); st_dpin_b(rdp, ok, dp + 5 * n, dtl, a.dpin_bf16);
+    }
+    bf16x8* buf = xb + (t & 1) * 2 * KC4 * 64;
+#pragma unroll
+    for (int gb = 0; gb < 4; ++gb) xb_publish<KC4>(buf, gb * n + col, j, colv, dg[gb]);
+    __syncthreads();
+    f32x4 dma = Z4, dmb = Z4;
+    xmac2_lds<KC4>(dma, dmb, wm, buf, lane, kcu);
+    const f32x4 dmn = dma + dmb;
+    dc = sel4(live, dcn, dc);
+    dm = sel4(live, dmn, dm);
+    if (PF) cur = nxt;
+  }
+  if (cval && a.dst_out) { st4(a.dst_out + h * 2 * n + col, dc); st4(a.dst_out + h * 2 * n + n + col, dm); }
 }
 
 // ------------------------------------------------------------------ fused multi-encoder launches
@@ -627,19 +1222,39 @@ __global__ void __launch_bounds__(64 * RNT) t4lstm_bwd_kernel(T4Args a) {
 #else
 #define RNN_T4_PRIO() __builtin_amdgcn_s_setprio(3)
 #endif
-template <int RNT>
+template <int RNT, bool X3>
 __global__ void __launch_bounds__(64 * RNT) rnn_multi_fwd_kernel(RnnMultiArgs a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
   CLSR_CHAIN_PRIO();
   const int which = blockIdx.y;
+  if (X3) {
+    if (which < a.ngru) gru_fwd_x3<RNT, false, false>(a.gru[which], blockIdx.x, XB8(xb));
+    else t4lstm_fwd_x3<RNT, false>(a.t4, blockIdx.x, XB8(xb));
+    return;
+  }
   if (which < a.ngru) gru_fwd_body<RNT>(a.gru[which], blockIdx.x, xb);
   else t4lstm_fwd_body<RNT>(a.t4, blockIdx.x, xb);
 }
-template <int RNT>
+// split-bf16 recurrences with the input projection fused (every encoder of the launch carries X)
+template <int RNT, bool X3>
+__global__ void __launch_bounds__(64 * RNT) rnn_multi_fwd_fp_kernel(RnnMultiArgs a) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
+  CLSR_CHAIN_PRIO();
+  const int which = blockIdx.y;
+  if (which < a.ngru) gru_fwd_x3<RNT, false, true>(a.gru[which], blockIdx.x, XB8(xb));
+  else t4lstm_fwd_x3<RNT, true>(a.t4, blockIdx.x, XB8(xb));
+}
+template <int RNT, bool X3>
 __global__ void __launch_bounds__(64 * RNT) rnn_multi_bwd_kernel(RnnMultiArgs a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
   CLSR_CHAIN_PRIO();
   const int which = blockIdx.y;
+  if (X3) {
+    if (which < a.ngru) { gru_bwd_x3<RNT, false>(a.gru[which], blockIdx.x, XB8(xb)); return; }
+    RNN_T4_PRIO();
+    t4lstm_bwd_x3<RNT>(a.t4, blockIdx.x, XB8(xb));
+    return;
+  }
   if (which < a.ngru) { gru_bwd_body<RNT>(a.gru[which], blockIdx.x, xb); return; }
   RNN_T4_PRIO();
   t4lstm_bwd_body<RNT>(a.t4, blockIdx.x, xb);
@@ -656,7 +1271,7 @@ extern "C" int clsr_t4lstm_fwd(const float* Pin, int ldp, const float* Wm, int l
   T4Args a = {};
   a.Pin = Pin; a.ldp = ldp; a.Wm = Wm; a.ldm = ldm; a.seq_len = seq_len; a.len_stride = len_stride;
   a.Hn = Hn; a.T = T; a.n = n; a.out_seq = out_seq; a.act = act; a.cst = cst; a.mprev = mprev; a.t0 = 0; a.t1 = T;
-  RNN_LAUNCH(t4lstm_fwd_kernel, rnn_tiles(n), dim3(clsr_cdiv(Hn, 16)), stream, a);
+  RNN_LAUNCH(t4lstm_fwd_kernel, rnn_tiles(n), rnn_default_x3(), dim3(clsr_cdiv(Hn, 16)), stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
@@ -672,7 +1287,7 @@ extern "C" int clsr_t4lstm_bwd(const float* act, const float* cst, const float* 
   a.act = const_cast<float*>(act); a.cst = const_cast<float*>(cst); a.Wm = Wm; a.ldm = ldm;
   a.seq_len = seq_len; a.len_stride = len_stride; a.Hn = Hn; a.T = T; a.n = n;
   a.dout_seq = dout_seq; a.dPin = dPin; a.lddp = 6 * n; a.t0 = 0; a.t1 = T;
-  RNN_LAUNCH(t4lstm_bwd_kernel, rnn_tiles(n), dim3(clsr_cdiv(Hn, 16)), stream, a);
+  RNN_LAUNCH(t4lstm_bwd_kernel, rnn_tiles(n), rnn_default_x3(), dim3(clsr_cdiv(Hn, 16)), stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
@@ -797,6 +1412,10 @@ extern "C" int clsr_t4_time_inputs_bwd_range(const float* dTT, const float* TT, 
 }
 
 // ---- C-ABI descriptors: clsr_gru_desc / clsr_t4_desc from include/clsr_hip.h
+// floats of the tile-major activation image of clsr_t4_desc.act_tiled (hidden size n decides the wave count of the launch)
+extern "C" long clsr_t4_act_tiled_floats(long Hn, int T, int n) {
+  return (long)clsr_cdiv(Hn, 16) * T * 7 * rnn_tiles(n) * 256;
+}
 extern "C" int clsr_sizeof_gru_desc(void) { return (int)sizeof(clsr_gru_desc); }
 extern "C" int clsr_sizeof_t4_desc(void) { return (int)sizeof(clsr_t4_desc); }
 
@@ -807,11 +1426,12 @@ static int fill_multi(RnnMultiArgs& m, const clsr_gru_desc* grus, int ngru, cons
   CLSR_CHECK_ARG(ngru == 0 || grus);
   m.ngru = ngru;
   m.has_t4 = t4 ? 1 : 0;
+  m.products = t4 ? t4->products : 0;
   for (int i = 0; i < ngru; ++i) {
     const clsr_gru_desc& d = grus[i];
     int rc = check_rnn_shape(Hn, T, d.n, backward ? d.ldg : d.ldp);
     if (rc) return rc;
-    CLSR_CHECK_ARG(d.Wgh && d.Wch && (backward ? (d.gates && d.hprev && d.dPin) : (d.Pin != nullptr)));
+    CLSR_CHECK_ARG(d.Wgh && d.Wch && (backward ? (d.gates && d.hprev && d.dPin) : (d.Pin != nullptr || d.X != nullptr)));
     GruArgs& a = m.gru[i];
     a = GruArgs{};
     a.Pin = d.Pin; a.ldp = d.ldp; a.Wgh = d.Wgh; a.ldg = d.ldg; a.Wch = d.Wch; a.ldc = d.ldc;
@@ -820,43 +1440,57 @@ static int fill_multi(RnnMultiArgs& m, const clsr_gru_desc* grus, int ngru, cons
     a.dhT = d.dhT; a.dout_seq = d.dout_seq; a.dPin = d.dPin; a.dh0 = d.dh0;
     a.lddp = d.lddp > 0 ? d.lddp : 3 * d.n;
     a.dpin_bf16 = d.dpin_bf16;
+    CLSR_CHECK_ARG(d.products >= 0 && d.products <= 2);
+    if (d.products) m.products = d.products;
     CLSR_CHECK_SUPPORTED(a.lddp % 4 == 0);
     // the branch-free stores address a block's 16 histories with 32-bit BYTE offsets into one buffer resource
     CLSR_CHECK_SUPPORTED(16L * T * (a.lddp > 3 * d.n ? a.lddp : 3 * d.n) * 4 < 0x80000000L);
     a.att = d.att; a.datt = d.datt; a.in_div = d.in_div > 1 ? d.in_div : 1;
+    a.X = d.X; a.ldx = d.ldx; a.Dx = d.Dx; a.Wgx = d.Wgx; a.Wcx = d.Wcx; a.bg = d.bg; a.bc = d.bc;
+    if (!backward && d.X) {
+      CLSR_CHECK_ARG(d.Wgx && d.Wcx && d.bg && d.bc && !d.att);
+      CLSR_CHECK_SUPPORTED(d.Dx > 0 && d.Dx % 8 == 0 && d.Dx < 64 && d.ldx % 4 == 0 && d.n <= 48 && ((uintptr_t)d.X % 16) == 0);
+    }
     a.t0 = t0; a.t1 = t1;
     CLSR_CHECK_ARG(!(backward && d.att && !d.datt));
   }
   if (t4) {
     int rc = check_rnn_shape(Hn, T, t4->n, backward ? t4->ldm : t4->ldp);
     if (rc) return rc;
-    CLSR_CHECK_ARG(t4->Wm && (backward ? (t4->act && t4->cst && t4->dout_seq && t4->dPin)
-                                       : (t4->Pin && t4->out_seq && (!t4->act || (t4->cst && t4->mprev)))));
+    CLSR_CHECK_ARG(t4->Wm && (backward ? (t4->act && (t4->cst || t4->act_tiled) && t4->dout_seq && t4->dPin)
+                                       : (t4->Pin && t4->out_seq && (!t4->act || ((t4->cst || t4->act_tiled) && t4->mprev)))));
     T4Args& a = m.t4;
     a = T4Args{};
     a.Pin = t4->Pin; a.ldp = t4->ldp; a.Wm = t4->Wm; a.ldm = t4->ldm; a.seq_len = seq_len;
     a.len_stride = len_stride; a.Hn = Hn; a.T = T; a.n = t4->n; a.out_seq = t4->out_seq; a.act = t4->act;
-    a.cst = t4->cst; a.mprev = t4->mprev; a.dout_seq = t4->dout_seq; a.dPin = t4->dPin;
+    a.cst = t4->cst; a.mprev = t4->mprev; a.act_tiled = t4->act_tiled; a.dout_seq = t4->dout_seq; a.dPin = t4->dPin;
     a.lddp = t4->lddp > 0 ? t4->lddp : 6 * t4->n;
     a.dpin_bf16 = t4->dpin_bf16;
     CLSR_CHECK_SUPPORTED(a.lddp % 4 == 0);
     CLSR_CHECK_SUPPORTED(16L * T * (a.lddp > 6 * t4->n ? a.lddp : 6 * t4->n) * 4 < 0x80000000L);
     a.t0 = t0; a.t1 = t1;
     a.st_in = t4->st_in; a.st_out = t4->st_out; a.dst_in = t4->dst_in; a.dst_out = t4->dst_out;
+    a.X = t4->X; a.ldx = t4->ldx; a.Dx = t4->Dx; a.Wkx = t4->Wkx; a.bk = t4->bk;
+    if (!backward && t4->X) {
+      CLSR_CHECK_ARG(t4->Wkx && t4->bk);
+      CLSR_CHECK_SUPPORTED(t4->Dx > 0 && t4->Dx % 8 == 0 && t4->Dx < 64 && t4->ldx % 4 == 0 && t4->n <= 48 && ((uintptr_t)t4->X % 16) == 0);
+    }
   }
   return CLSR_OK;
 }
 
 // the attentional GRU runs alone (its inputs depend on everything the other encoders produce): own kernels
-template <int RNT>
+template <int RNT, bool X3>
 __global__ void __launch_bounds__(64 * RNT) augru_fwd_kernel(GruArgs a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
-  gru_fwd_body<RNT, true>(a, blockIdx.x, xb);
+  if (X3) gru_fwd_x3<RNT, true, false>(a, blockIdx.x, XB8(xb));
+  else gru_fwd_body<RNT, true>(a, blockIdx.x, xb);
 }
-template <int RNT>
+template <int RNT, bool X3>
 __global__ void __launch_bounds__(64 * RNT) augru_bwd_kernel(GruArgs a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
-  gru_bwd_body<RNT, true>(a, blockIdx.x, xb);
+  if (X3) gru_bwd_x3<RNT, true>(a, blockIdx.x, XB8(xb));
+  else gru_bwd_body<RNT, true>(a, blockIdx.x, xb);
 }
 
 static int multi_tiles(const RnnMultiArgs& m) {
@@ -874,14 +1508,25 @@ extern "C" int clsr_rnn_fwd_multi_range(const clsr_gru_desc* grus, int ngru, con
   if (rc) return rc;
   if (ngru > 0 && grus[0].att) {
     CLSR_CHECK_SUPPORTED(ngru == 1 && !t4);
-    RNN_LAUNCH(augru_fwd_kernel, rnn_tiles(m.gru[0].n), dim3(clsr_cdiv(Hn, 16)), stream, m.gru[0]);
+    RNN_LAUNCH(augru_fwd_kernel, rnn_tiles(m.gru[0].n), rnn_x3(m.products), dim3(clsr_cdiv(Hn, 16)), stream, m.gru[0]);
     CLSR_CHECK_LAUNCH();
     return CLSR_OK;
   }
 #ifdef CLSR_WITH_RNN1     // (csrc/experimental/rnn1.hip: one wave per encoder -- measured slower, not in the default build)
   if (rnn1_supported(m)) return rnn1_launch(m, Hn, false, (hipStream_t)stream);
 #endif
-  RNN_LAUNCH(rnn_multi_fwd_kernel, multi_tiles(m), dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), stream, m);
+  {   // fused input projection: all encoders or none
+    int nfp = (t4 && t4->X) ? 1 : 0;
+    for (int i = 0; i < ngru; ++i) nfp += grus[i].X ? 1 : 0;
+    if (nfp) {
+      CLSR_CHECK_ARG(nfp == ngru + (t4 ? 1 : 0));
+      CLSR_CHECK_SUPPORTED(rnn_x3(m.products) && multi_tiles(m) == 3);
+      RNN_LAUNCH1(rnn_multi_fwd_fp_kernel, 3, true, dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), stream, m);
+      CLSR_CHECK_LAUNCH();
+      return CLSR_OK;
+    }
+  }
+  RNN_LAUNCH(rnn_multi_fwd_kernel, multi_tiles(m), rnn_x3(m.products), dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), stream, m);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
@@ -899,14 +1544,14 @@ extern "C" int clsr_rnn_bwd_multi_range(const clsr_gru_desc* grus, int ngru, con
   if (rc) return rc;
   if (ngru > 0 && grus[0].att) {
     CLSR_CHECK_SUPPORTED(ngru == 1 && !t4);
-    RNN_LAUNCH(augru_bwd_kernel, rnn_tiles(m.gru[0].n), dim3(clsr_cdiv(Hn, 16)), stream, m.gru[0]);
+    RNN_LAUNCH(augru_bwd_kernel, rnn_tiles(m.gru[0].n), rnn_x3(m.products), dim3(clsr_cdiv(Hn, 16)), stream, m.gru[0]);
     CLSR_CHECK_LAUNCH();
     return CLSR_OK;
   }
 #ifdef CLSR_WITH_RNN1
   if (rnn1_supported(m)) return rnn1_launch(m, Hn, true, (hipStream_t)stream);
 #endif
-  RNN_LAUNCH(rnn_multi_bwd_kernel, multi_tiles(m), dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), stream, m);
+  RNN_LAUNCH(rnn_multi_bwd_kernel, multi_tiles(m), rnn_x3(m.products), dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), stream, m);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }

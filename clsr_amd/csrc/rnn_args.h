@@ -32,6 +32,10 @@ struct GruArgs {
   // the previous launch -- so that the producers / consumers of Pin / dPin work on one range while the recurrence is
   // busy with the next (clsr_amd/net.py: CLSRNet.rnn_chunks)
   int t0, t1;
+  // fused input projection (split-bf16 forward only): Pin unused; x_t = X[hist, t, 0:Dx], weights = the x rows of the TF
+  // kernels (same leading dimensions as Wgh / Wch), biases [2n] / [n]
+  const float* X; int ldx; int Dx;
+  const float* Wgx; const float* Wcx; const float* bg; const float* bc;
 };
 
 
@@ -42,6 +46,7 @@ struct T4Args {
   int Hn, T, n;
   float* out_seq;                      // [Hn, T, n] (m, zeros past len)
   float* act; float* cst; float* mprev;
+  int act_tiled;                       // act is the tile-major private image (csrc/rnn.hip: T4_TILED_ROW), cst unused
   const float* dout_seq;               // [Hn, T, n]
   float* dPin;                         // [Hn, T, lddp]
   int dpin_bf16;                       // dPin is a bf16 tensor (lddp in elements): speed mode
@@ -49,6 +54,9 @@ struct T4Args {
   int t0, t1;                          // time range of this launch (see GruArgs)
   const float* st_in; float* st_out;   // optional [Hn, 2n] carried state c | m entering t0 / leaving t1 (forward)
   const float* dst_in; float* dst_out; // optional [Hn, 2n] carried gradients dc | dm entering t1 - 1 / leaving t0 (backward)
+  // fused input projection of the blocks i | j | f (split-bf16 forward only): Pin then holds o | tns | tls (ldp >= 3n)
+  const float* X; int ldx; int Dx;
+  const float* Wkx; const float* bk;   // x rows of the lstm kernel (leading dimension ldm), bias [4n]
 };
 
 
@@ -58,6 +66,7 @@ struct RnnMultiArgs {
   T4Args t4;
   int ngru;
   int has_t4;
+  int products;                        // 0 process default | 1 fp32-input MFMA | 2 split-bf16 (csrc/rnn.hip)
 };
 
 

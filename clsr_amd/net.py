@@ -153,6 +153,15 @@ class CLSRNet(object):
         self.stream_alias = {} if os.environ.get("CLSR_FOLD_AUX") == "0" else {"@aux": "@lt"}
         self.side_priority = int(os.environ.get("CLSR_SIDE_PRIORITY", "0"))
         self.dw_priority = int(os.environ.get("CLSR_DW_PRIORITY", "0"))
+        # Recurrences: hidden-to-hidden products as split-bf16 sums (csrc/rnn.hip, "x3") or fp32-input MFMAs ("fp32", bit-exact
+        # fp32); with x3 the input projections of the GRUs and of the Time4LSTM blocks i | j | f run INSIDE the recurrence
+        # launch from the history embeddings (no projection tensor, no GEMM in front of the T-serial chain), and the
+        # Time4LSTM keeps its saved activations in a private tile-major image.  CLSR_RNN_PRODUCTS=fp32 restores the exact form.
+        self.rnn_products = os.environ.get("CLSR_RNN_PRODUCTS", "x3")
+        if self.rnn_products not in ("x3", "fp32"):
+            raise ValueError("CLSR_RNN_PRODUCTS must be 'x3' or 'fp32'")
+        self.rnn_fused_proj = self.rnn_products == "x3" and not os.environ.get("CLSR_NO_RNN_FUSED_PROJ")
+        self.rnn_act_tiled = self.rnn_products == "x3" and not os.environ.get("CLSR_NO_RNN_ACT_TILED")
         self.fuse_tt = not os.environ.get("CLSR_NO_FUSE_TT")   # A/B: time-gate blocks of the input projection as one product over [hist | TT]
         # the row-level heads (alpha gate, alpha / logit MLPs, loss, their backward) as two persistent launches with grid
         # barriers for the batch-norm statistics (csrc/headsfused.hip) instead of a chain of 22 dependent launches
@@ -266,7 +275,7 @@ class CLSRNet(object):
         return (what, id(f), ops.stream_ptr(), self.precision, self.table_bf16, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook), self.dp_comm,
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
                 self.lazy, self.rnn_first, self.tick_early, self.hist_grad_two, self.dw_batch_late, self.bn_bwd_fused, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h, self.flush_side, self.l1_bwd_2pass,
-                self.split_g2, self.enc_bwd_fused, self.enc_bwd_fused_h, self.dhist_side, self.early_scatter, self.fused_logit_tail, self.fuse_tt, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
+                self.split_g2, self.rnn_products, self.rnn_fused_proj, self.rnn_act_tiled, self.enc_bwd_fused, self.enc_bwd_fused_h, self.dhist_side, self.early_scatter, self.fused_logit_tail, self.fuse_tt, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
 
@@ -1418,9 +1427,13 @@ class CLSRNet(object):
         hprev = self._buf(key + ".hprev", Hn, T, n) if training else None
         gates = self._buf(key + ".gates", Hn, T, 3 * n) if training else None
         Wg, Wc = P[scope + "gates/kernel"], P[scope + "candidate/kernel"]
+        fp = {}
+        if self._rnn_fp_on():      # input projection inside the recurrence: x = the history embeddings (Pin is not read)
+            fp = dict(X=self._buf("hist", Hn, T, D), ldx=D, Dx=D, Wgx=Wg, Wcx=Wc, bg=P[scope + "gates/bias"],
+                      bc=P[scope + "candidate/bias"])
         d = ops.gru_desc(n, Pin=PinAll[:, self._enc_off(key):], ldp=self.NX, Wgh=Wg[D:], ldg=2 * n, Wch=Wc[D:],
                          ldc=n, h0=h0, h0_stride=n if h0 is not None else 0, hT=hT, out_seq=seq, hprev=hprev,
-                         gates=gates)
+                         gates=gates, products=self.rnn_products, **fp)
         return d, hT, seq
 
     def _gru_bwd_desc(self, key, scope, n, dPinAll, Hn, T, dhT, dseq, dh0):
@@ -1428,7 +1441,28 @@ class CLSRNet(object):
         Wg, Wc = P[scope + "gates/kernel"], P[scope + "candidate/kernel"]
         return ops.gru_desc(n, Wgh=Wg[D:], ldg=2 * n, Wch=Wc[D:], ldc=n,
                             hprev=self._buf(key + ".hprev", Hn, T, n), gates=self._buf(key + ".gates", Hn, T, 3 * n),
-                            dhT=dhT, dout_seq=dseq, dPin=dPinAll[:, self._enc_off(key):], lddp=self.NX, dh0=dh0)
+                            dhT=dhT, dout_seq=dseq, dPin=dPinAll[:, self._enc_off(key):], lddp=self.NX, dh0=dh0,
+                            products=self.rnn_products)
+
+    def _rnn_fp_on(self):
+        """Input projections of the encoders inside the recurrence launch (csrc/rnn.hip, fused projection)?  Needs the
+        split-bf16 products, hidden sizes <= 48, an embedding width that leaves a spare k slot for the bias row, and --
+        with a Time4LSTM -- the K-fused time-gate product (it writes exactly the three blocks the kernel still reads)."""
+        D = self.enc_in
+        ok = (self.rnn_fused_proj and max(self.H, self.Du) <= 48 and D % 8 == 0 and D < 64
+              and self._t4_kind in (None, "time4lstm"))
+        if ok and self._t4_kind == "time4lstm":
+            ok = self._fuse_tt_ok()
+        return bool(ok)
+
+    def _t4_act(self, Hn, T, training):
+        """(act, cst, tiled) buffers of the LSTM-type encoder's saved activations."""
+        H = self.H
+        if not training:
+            return None, None, False
+        if self.rnn_act_tiled:
+            return self._buf("t4.act_tiled", query("clsr_t4_act_tiled_floats", Hn, T, H)), None, True
+        return self._buf("t4.act", Hn, T, 6 * H), self._buf("t4.cst", Hn, T, H), False
 
     def _t4_bwd_weights(self, f, dPinAll, Hn, T, hs):
         """Hidden-to-hidden and time-feature weight gradients of the LSTM-type encoder from its slice of dPin."""
@@ -1653,7 +1687,9 @@ class CLSRNet(object):
         else:
             fuse_tt = False
         # (with the K-fused time-gate product the first launch stops in front of those 3H columns)
-        self._gemm(hist, D, "xw", M, D, NX - 3 * H if fuse_tt else NX, PinAll, NX, bias=self._buf("xw.bias", NX))
+        rnn_fp = self._rnn_fp_on()
+        if not rnn_fp:      # (fused projection: the recurrences read the embeddings themselves)
+            self._gemm(hist, D, "xw", M, D, NX - 3 * H if fuse_tt else NX, PinAll, NX, bias=self._buf("xw.bias", NX))
         if early_aux is not None or (training and self.sorted_hist_grad):
             # work that depends on the feed only -- accumulator zeroing / row marks of the training step
             # (``early_aux``) and the ~35 tiny launches that sort the history ids by row id for the backward's
@@ -1686,10 +1722,11 @@ class CLSRNet(object):
                 else:
                     self._gemm(TT, 2 * H, "t4.tw", M, 2 * H, 3 * H, PinAll[:, t4off + 3 * H:], NX, acc=1)
             rnn_out = self._buf("rnn_out", Hn, T, H)
-            t4d = ops.t4_desc(H, Pin=PinAll[:, t4off:], ldp=NX, Wm=P[t + "kernel"][D:], ldm=4 * H, out_seq=rnn_out,
-                              act=self._buf("t4.act", Hn, T, 6 * H) if training else None,
-                              cst=self._buf("t4.cst", Hn, T, H) if training else None,
-                              mprev=self._buf("t4.mprev", Hn, T, H) if training else None)
+            act, cst, tiled = self._t4_act(Hn, T, training)
+            fp = dict(X=hist, ldx=D, Dx=D, Wkx=P[t + "kernel"], bk=P[t + "bias"]) if rnn_fp else {}
+            t4d = ops.t4_desc(H, Pin=PinAll[:, t4off + (3 * H if rnn_fp else 0):], ldp=NX, Wm=P[t + "kernel"][D:], ldm=4 * H,
+                              out_seq=rnn_out, act=act, cst=cst, act_tiled=tiled,
+                              mprev=self._buf("t4.mprev", Hn, T, H) if training else None, products=self.rnn_products, **fp)
         else:
             d, _, rnn_out = self._gru_fwd_desc("gs", st + "simple_gru/gru_cell/", H, PinAll, Hn, T, None, training,
                                                want_seq=True)
@@ -1982,8 +2019,9 @@ class CLSRNet(object):
         if self._t4_scope is not None:
             t = self._t4_scope
             t4off = self._enc_off("t4")
-            t4d = ops.t4_desc(H, Wm=P[t + "kernel"][D:], ldm=4 * H, act=self._buf("t4.act", Hn, T, 6 * H),
-                              cst=self._buf("t4.cst", Hn, T, H), dout_seq=drnn, dPin=dPinAll[:, t4off:], lddp=NX)
+            act, cst, tiled = self._t4_act(Hn, T, True)
+            t4d = ops.t4_desc(H, Wm=P[t + "kernel"][D:], ldm=4 * H, act=act, cst=cst, act_tiled=tiled, dout_seq=drnn,
+                              dPin=dPinAll[:, t4off:], lddp=NX, products=self.rnn_products)
         else:
             grus.append(self._gru_bwd_desc("gs", st + "simple_gru/gru_cell/", H, dPinAll, Hn, T, None, drnn, None))
         if (not hp.manual_alpha) and hp.predict_long_short:

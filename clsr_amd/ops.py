@@ -173,21 +173,28 @@ def graph_destroy(graph_exec):
     _lib.check(_lib.load().clsr_graph_destroy(graph_exec), "clsr_graph_destroy")
 
 
+# hidden-to-hidden products of the recurrences (clsr_gru_desc.products): process default / fp32-input MFMA / split-bf16
+RNN_PRODUCTS = {None: 0, "default": 0, "fp32": 1, "x3": 2}
+
+
 class GruDesc(ctypes.Structure):
     """ctypes mirror of clsr_gru_desc (include/clsr_hip.h)."""
     _fields_ = [(n, ctypes.c_void_p) for n in ("Pin", "Wgh", "Wch", "h0", "hT", "out_seq", "hprev", "gates",
                                                "dhT", "dout_seq", "dPin", "dh0")] + \
                [("h0_stride", ctypes.c_long), ("ldp", ctypes.c_int), ("ldg", ctypes.c_int), ("ldc", ctypes.c_int),
                 ("n", ctypes.c_int), ("lddp", ctypes.c_int), ("in_div", ctypes.c_int),
-                ("att", ctypes.c_void_p), ("datt", ctypes.c_void_p), ("dpin_bf16", ctypes.c_int), ("pad_", ctypes.c_int)]
+                ("att", ctypes.c_void_p), ("datt", ctypes.c_void_p), ("dpin_bf16", ctypes.c_int), ("products", ctypes.c_int)] + \
+               [(n, ctypes.c_void_p) for n in ("X", "Wgx", "Wcx", "bg", "bc")] + [("ldx", ctypes.c_int), ("Dx", ctypes.c_int)]
 
 
 class T4Desc(ctypes.Structure):
     """ctypes mirror of clsr_t4_desc (include/clsr_hip.h)."""
     _fields_ = [(n, ctypes.c_void_p) for n in ("Pin", "Wm", "out_seq", "act", "cst", "mprev", "dout_seq", "dPin")] + \
                [("ldp", ctypes.c_int), ("ldm", ctypes.c_int), ("n", ctypes.c_int), ("lddp", ctypes.c_int),
-                ("dpin_bf16", ctypes.c_int), ("pad_", ctypes.c_int)] + \
-               [(n, ctypes.c_void_p) for n in ("st_in", "st_out", "dst_in", "dst_out")]
+                ("dpin_bf16", ctypes.c_int), ("products", ctypes.c_int)] + \
+               [(n, ctypes.c_void_p) for n in ("st_in", "st_out", "dst_in", "dst_out")] + \
+               [("act_tiled", ctypes.c_int), ("pad_", ctypes.c_int)] + \
+               [(n, ctypes.c_void_p) for n in ("X", "Wkx", "bk")] + [("ldx", ctypes.c_int), ("Dx", ctypes.c_int)]
 
 
 def _ptr(t):
@@ -196,8 +203,10 @@ def _ptr(t):
 
 def gru_desc(n, Pin=None, ldp=0, Wgh=None, ldg=0, Wch=None, ldc=0, h0=None, h0_stride=0, hT=None, out_seq=None,
              hprev=None, gates=None, dhT=None, dout_seq=None, dPin=None, dh0=None, lddp=0, att=None, datt=None,
-             in_div=1):
+             in_div=1, products=0, X=None, ldx=0, Dx=0, Wgx=None, Wcx=None, bg=None, bc=None):
     d = GruDesc()
+    d.X, d.Wgx, d.Wcx, d.bg, d.bc, d.ldx, d.Dx = _ptr(X), _ptr(Wgx), _ptr(Wcx), _ptr(bg), _ptr(bc), ldx, Dx
+    d.products = RNN_PRODUCTS.get(products, products)
     for k, v in dict(Pin=Pin, Wgh=Wgh, Wch=Wch, h0=h0, hT=hT, out_seq=out_seq, hprev=hprev, gates=gates, dhT=dhT,
                      dout_seq=dout_seq, dPin=dPin, dh0=dh0, att=att, datt=datt).items():
         setattr(d, k, _ptr(v))
@@ -207,13 +216,17 @@ def gru_desc(n, Pin=None, ldp=0, Wgh=None, ldg=0, Wch=None, ldc=0, h0=None, h0_s
 
 
 def t4_desc(n, Pin=None, ldp=0, Wm=None, ldm=0, out_seq=None, act=None, cst=None, mprev=None, dout_seq=None,
-            dPin=None, lddp=0, st_in=None, st_out=None, dst_in=None, dst_out=None):
+            dPin=None, lddp=0, st_in=None, st_out=None, dst_in=None, dst_out=None, products=0, act_tiled=False,
+            X=None, ldx=0, Dx=0, Wkx=None, bk=None):
     d = T4Desc()
+    d.X, d.Wkx, d.bk, d.ldx, d.Dx = _ptr(X), _ptr(Wkx), _ptr(bk), ldx, Dx
+    d.products = RNN_PRODUCTS.get(products, products)
     for k, v in dict(Pin=Pin, Wm=Wm, out_seq=out_seq, act=act, cst=cst, mprev=mprev, dout_seq=dout_seq,
                      dPin=dPin, st_in=st_in, st_out=st_out, dst_in=dst_in, dst_out=dst_out).items():
         setattr(d, k, _ptr(v))
     d.ldp, d.ldm, d.n, d.lddp = ldp, ldm, n, lddp
     d.dpin_bf16 = 1 if (dPin is not None and dPin.dtype == torch.bfloat16) else 0
+    d.act_tiled = 1 if act_tiled else 0
     return d
 
 

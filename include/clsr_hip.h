@@ -473,20 +473,40 @@ typedef struct clsr_gru_desc {
    * sequence per candidate ROW; sequence s reads Pin / seq_len of history s / in_div.  datt [Hn, T] (backward) is
    * accumulated with atomics: zero it first.  Both NULL / in_div <= 1: the plain GRU. */
   const float* att; float* datt;
-  int dpin_bf16; int pad_;   /* dPin is a bf16 tensor (lddp in elements): clsr_rnn_bwd_multi stores the input-projection
+  int dpin_bf16;             /* dPin is a bf16 tensor (lddp in elements): clsr_rnn_bwd_multi stores the input-projection
                               * gradients as bf16 for consumers that run on the bf16 matrix pipe (speed mode) */
+  int products;              /* hidden-to-hidden products of the launch: 0 = process default (CLSR_RNN_PRODUCTS = fp32 | x3,
+                              * x3 when unset), 1 = fp32-input MFMA (bit-exact fp32), 2 = split-bf16: W.h as
+                              * Whi.hhi + Whi.hlo + Wlo.hhi on v_mfma_f32_16x16x32_bf16, fp32 accumulation (2^-17 relative).
+                              * One form per launch: the last non-zero value among its descriptors decides. */
+  /* Fused input projection (forward, split-bf16 launches, n <= 48, Dx % 8 == 0, Dx < 64; every encoder of the launch
+   * must carry it): X != NULL -- Pin is not read; the input side of step t is X[h, t, 0:Dx] . [Wgx | Wcx] + [bg | bc]
+   * computed in the recurrence (Wgx / Wcx: the x rows of gates/kernel and candidate/kernel, leading dimensions ldg / ldc;
+   * reference: GRUCell's single matmul over [inputs, state], clsr.py:160-168). */
+  const float* X; const float* Wgx; const float* Wcx; const float* bg; const float* bc;
+  int ldx; int Dx;
 } clsr_gru_desc;
 typedef struct clsr_t4_desc {
   const float* Pin; const float* Wm;
   float* out_seq; float* act; float* cst; float* mprev;
   const float* dout_seq; float* dPin;
   int ldp; int ldm; int n; int lddp;
-  int dpin_bf16; int pad_;   /* as in clsr_gru_desc */
+  int dpin_bf16; int products;   /* as in clsr_gru_desc */
   /* state carried between the launches of a recurrence that runs as a chain of time ranges (clsr_rnn_*_multi_range):
    * [Hn, 2n] rows  c | m  entering t0 / leaving t1 (forward),  dc | dm  entering t1 - 1 / leaving t0 (backward).
    * NULL: zeros in, nothing stored.  (The GRU carries its state through h0 / hT and dhT / dh0.) */
   const float* st_in; float* st_out; const float* dst_in; float* dst_out;
+  /* act_tiled != 0: `act` is a private tile-major image of clsr_t4_act_tiled_floats(Hn, T, n) floats that also holds the
+   * cell states (cst is ignored): written by the forward and read by the backward recurrence only, every access one
+   * contiguous KB per wave instead of 64 pieces of 16 rows.  Split-bf16 launches only (products = 2). */
+  int act_tiled; int pad_;
+  /* Fused input projection of the blocks i | j | f (as in clsr_gru_desc): X != NULL -- Pin holds only the blocks
+   * o | tns | tls (ldp >= 3n: the products that also take the time features); Wkx = the x rows of the lstm kernel
+   * (leading dimension ldm), bk = its bias [4n] (Time4LSTMCell.call, rnn_cell_implement.py:229-244). */
+  const float* X; const float* Wkx; const float* bk;
+  int ldx; int Dx;
 } clsr_t4_desc;
+long clsr_t4_act_tiled_floats(long Hn, int T, int n);
 int clsr_sizeof_gru_desc(void);
 int clsr_sizeof_t4_desc(void);
 int clsr_rnn_fwd_multi(const clsr_gru_desc* grus, int ngru, const clsr_t4_desc* t4, const int* seq_len,

@@ -1,5 +1,5 @@
 """Isolated timing of the fused recurrence launches at configs[1] shapes.  usage: python scripts/bench_rnn.py"""
-import sys, torch
+import os, sys, torch
 sys.path.insert(0, "/root/repo")
 from clsr_amd import ops
 dev = "cuda:0"
@@ -18,13 +18,22 @@ with torch.cuda.stream(st):
     lens = torch.full((Hn,), T, dtype=torch.int32, device=dev)
     Pin = torch.randn(Hn * T, NX, device=dev) * 0.3
     Wg, Wc, Wm = torch.randn(n, 2 * n, device=dev) * 0.2, torch.randn(n, n, device=dev) * 0.2, torch.randn(n, 4 * n, device=dev) * 0.2
+    FUSED = bool(os.environ.get("RNN_FUSED"))
+    X = torch.randn(Hn * T, 40, device=dev) * 0.5
+    Wgf, Wcf, Wkf = torch.randn(40 + n, 2 * n, device=dev) * 0.2, torch.randn(40 + n, n, device=dev) * 0.2, torch.randn(40 + n, 4 * n, device=dev) * 0.2
+    bgf, bcf, bkf = torch.zeros(2 * n, device=dev), torch.zeros(n, device=dev), torch.zeros(4 * n, device=dev)
+    P3 = torch.randn(Hn * T, 3 * n, device=dev) * 0.3
+    fg = dict(X=X, ldx=40, Dx=40, Wgx=Wgf, Wcx=Wcf, bg=bgf, bc=bcf) if FUSED else {}
+    ft = dict(X=X, ldx=40, Dx=40, Wkx=Wkf, bk=bkf) if FUSED else {}
     def gru(off, train=True):
-        return ops.gru_desc(n, Pin=Pin[:, off:], ldp=NX, Wgh=Wg, ldg=2 * n, Wch=Wc, ldc=n,
+        return ops.gru_desc(n, Pin=None if FUSED else Pin[:, off:], ldp=NX, Wgh=Wg, ldg=2 * n, Wch=Wc, ldc=n, **fg,
                             hT=torch.zeros(Hn, n, device=dev), hprev=torch.zeros(Hn, T, n, device=dev) if train else None,
                             gates=torch.zeros(Hn, T, 3 * n, device=dev) if train else None)
+    TILED = bool(os.environ.get("RNN_TILED"))
+    act_t = torch.zeros(ops.query("clsr_t4_act_tiled_floats", Hn, T, n), device=dev) if TILED else None
     def t4(train=True):
-        return ops.t4_desc(n, Pin=Pin[:, 6 * n:], ldp=NX, Wm=Wm, ldm=4 * n, out_seq=torch.zeros(Hn, T, n, device=dev),
-                           act=torch.zeros(Hn, T, 6 * n, device=dev) if train else None,
+        return ops.t4_desc(n, Pin=P3 if FUSED else Pin[:, 6 * n:], ldp=3 * n if FUSED else NX, **ft, Wm=Wm, ldm=4 * n, out_seq=torch.zeros(Hn, T, n, device=dev),
+                           act=(act_t if TILED else torch.zeros(Hn, T, 6 * n, device=dev)) if train else None, act_tiled=TILED and train,
                            cst=torch.zeros(Hn, T, n, device=dev) if train else None,
                            mprev=torch.zeros(Hn, T, n, device=dev) if train else None)
     g1, g2, t = gru(0), gru(3 * n), t4()
@@ -50,7 +59,7 @@ with torch.cuda.stream(st):
     def gru_b(d, off):
         hp = torch.rand(Hn, T, n, device=dev); ga = torch.rand(Hn, T, 3 * n, device=dev)
         return ops.gru_desc(n, Wgh=Wg, ldg=2 * n, Wch=Wc, ldc=n, hprev=hp, gates=ga, dhT=dh, dPin=dP[:, off:], lddp=NX)
-    tb = ops.t4_desc(n, Wm=Wm, ldm=4 * n, act=torch.rand(Hn, T, 6 * n, device=dev), cst=torch.randn(Hn, T, n, device=dev) * 0.3,
+    tb = ops.t4_desc(n, Wm=Wm, ldm=4 * n, act=torch.rand_like(act_t) if TILED else torch.rand(Hn, T, 6 * n, device=dev), act_tiled=TILED, cst=torch.randn(Hn, T, n, device=dev) * 0.3,
                      dout_seq=dseq, dPin=dP[:, 6 * n:], lddp=NX)
     b1, b2 = gru_b(g1, 0), gru_b(g2, 3 * n)
     if only != "bwd":
