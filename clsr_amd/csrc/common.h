@@ -50,6 +50,8 @@ void clsr_set_error(const char* fmt, ...);
     }                                                                                     \
   } while (0)
 
+long long clsr_p2p_timeout_ticks(void);   // csrc/p2p.hip: bounded waits of the peer-to-peer / grid-barrier kernels
+
 static inline int clsr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 #ifdef __HIPCC__

@@ -56,7 +56,8 @@
 #define HF_NGRP (HF_MAXBLK / HF_GS)
 #define HF_ROW 256               // doubles per partial row (2 x features <= 200)
 // workspace: counters | per-workgroup partial rows [stage][workgroup][256] | per-group rows [stage][group][256] | debug
-#define HF_CTR_BYTES 1024        // u32 gctr[8][16] at 0, u32 top[8] at 512, u32 err at 768
+#define HF_CTR_BYTES 1024        // u32 gctr[8][16] at 0, u32 top[8] at 512 (cleared by the step); the STICKY error words
+                                 // sit behind the partial sums, at the head of the debug area (hf_err_words)
 #define HF_PART_BYTES ((long)HF_NSTAGE * HF_MAXBLK * HF_ROW * 8)
 #define HF_GPART_BYTES ((long)HF_NSTAGE * HF_NGRP * HF_ROW * 8)
 #define HF_DBG_BYTES (1024 + 65536)
@@ -131,7 +132,7 @@ struct HfXchg {
   double gpart[HF_NSTAGE][HF_MAXW][HF_NGRP][HF_ROW];
 };
 struct HfComm { int rank, world; unsigned long long pushed; HfXchg* x[HF_MAXW]; };
-struct HfPeers { HfXchg* x[HF_MAXW]; int rank, world; unsigned long long target; long long timeout_ticks; };
+struct HfPeers { HfXchg* x[HF_MAXW]; int rank, world; unsigned long long target; long long timeout_ticks; double* abort_flag; };
 
 struct HfSync {
   unsigned* gctr; unsigned* top; unsigned* err; double* part; double* gpart; int nb; int* flag;
@@ -143,7 +144,8 @@ struct HfSync {
 __device__ __forceinline__ HfSync hf_sync_init(void* workspace, int nb, int* flag, int dbg0, const HfPeers* peers) {
   unsigned char* w = reinterpret_cast<unsigned char*>(workspace);
   HfSync S;
-  S.gctr = reinterpret_cast<unsigned*>(w); S.top = S.gctr + 128; S.err = S.gctr + 192;
+  S.gctr = reinterpret_cast<unsigned*>(w); S.top = S.gctr + 128;
+  S.err = reinterpret_cast<unsigned*>(w + HF_CTR_BYTES + HF_PART_BYTES + HF_GPART_BYTES);   // not in the range the step clears
   S.part = reinterpret_cast<double*>(w + HF_CTR_BYTES);
   S.gpart = reinterpret_cast<double*>(w + HF_CTR_BYTES + HF_PART_BYTES);
   S.nb = nb; S.flag = flag; S.peers = peers;
@@ -220,13 +222,18 @@ __device__ __forceinline__ void hf_wait(const HfSync& S, int stage, int n2, doub
           __hip_atomic_store(S.err, 1u + (unsigned)stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           S.err[1] = (unsigned)__hip_atomic_load(&mine->top[stage], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           S.err[2] = (unsigned)target;
+          if (S.peers->abort_flag) __hip_atomic_store(S.peers->abort_flag, 1.0 + stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
       }
     } else {
       while (__hip_atomic_load(S.top + stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ngrp) {
         __builtin_amdgcn_s_sleep(1);
-        if (wall_clock64() - t0 > 200000000LL) { __hip_atomic_store(S.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if (wall_clock64() - t0 > 200000000LL) {
+          __hip_atomic_store(S.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (S.peers->abort_flag) __hip_atomic_store(S.peers->abort_flag, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
       }
     }
 #ifdef HF_TIMING
@@ -911,11 +918,20 @@ extern "C" long clsr_heads_fused_workspace_bytes(void) {
   return (long)HF_CTR_BYTES + HF_PART_BYTES + HF_GPART_BYTES + HF_DBG_BYTES;   // (debug: phase stamps / barrier times of -DHF_TIMING builds)
 }
 extern "C" long clsr_heads_fused_counter_bytes(void) { return HF_CTR_BYTES; }
-// 1: a workgroup gave up waiting at a grid barrier in a launch since the counters were last cleared (results invalid)
+// != 0: a workgroup gave up waiting at a grid barrier in some launch since the error words were last cleared
+// (clsr_heads_fused_clear_error; the step's own zero fill does NOT reach them): the results of that step are invalid
+static const unsigned* hf_err_words(const void* workspace) {
+  return reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(workspace) + HF_CTR_BYTES + HF_PART_BYTES + HF_GPART_BYTES);
+}
+extern "C" int clsr_heads_fused_clear_error(void* workspace) {
+  CLSR_CHECK_ARG(workspace);
+  CLSR_HIP(hipMemset(const_cast<unsigned*>(hf_err_words(workspace)), 0, 3 * sizeof(unsigned)));
+  return CLSR_OK;
+}
 extern "C" int clsr_heads_fused_error(const void* workspace) {
   if (!workspace) return -1;
   unsigned e[3] = {0, 0, 0};
-  if (hipMemcpy(e, reinterpret_cast<const unsigned*>(workspace) + 192, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (hipMemcpy(e, hf_err_words(workspace), sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return -1;
   if (e[0] && getenv("CLSR_HEADS_DEBUG")) fprintf(stderr, "[clsr_heads_fused] barrier timeout: stage %u, counter %u of %u\n", e[0] - 1, e[1], e[2]);
   return (int)e[0];
 }
@@ -984,8 +1000,8 @@ static HfPeers hf_peers(const clsr_heads_desc* d, bool new_step, int nb) {
   HfPeers p;
   for (int r = 0; r < HF_MAXW; ++r) p.x[r] = nullptr;
   p.rank = 0; p.world = 1; p.target = 0;
-  static const long long ticks = (long long)(getenv("CLSR_P2P_TIMEOUT_S") ? atof(getenv("CLSR_P2P_TIMEOUT_S")) : 60.0) * 100000000LL;
-  p.timeout_ticks = ticks;
+  p.timeout_ticks = clsr_p2p_timeout_ticks();
+  p.abort_flag = d->abort_flag;
   if (d->comm) {
     HfComm* c = (HfComm*)d->comm;
     // (every rank issues the same sequence of step1 / step2 calls with the same B: the same totals everywhere)
@@ -1034,6 +1050,7 @@ extern "C" int clsr_heads_comm_self_test(void* comm, int nblocks, void* workspac
   c->pushed += (unsigned long long)((nblocks + HF_GS - 1) / HF_GS) * c->world;
   p.target = c->pushed;
   p.timeout_ticks = (long long)(timeout_s * 1e8f);
+  p.abort_flag = nullptr;
   hipLaunchKernelGGL(heads_comm_selftest_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, workspace, p, nblocks, ok_out);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;

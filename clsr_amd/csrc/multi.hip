@@ -357,6 +357,7 @@ __global__ void __launch_bounds__(256) tables_adam_multi_kernel(TablesArgs a) {
   double tot = 0.0;
   for (int i = 0; i < d.nsum; ++i) tot += d.sumsq_adam[(long)i * d.sumsq_stride];
   const float factor = clipf(tot, a.clip_norm);
+  if (a.adam_state[4] != 0.0) return;    // aborted step (csrc/p2p.hip, csrc/headsfused.hip): touch nothing
   const float lr_t = (float)a.adam_state[3];
   const float b1 = a.b1, b2 = a.b2;
   const long total = d.V * d.C;
@@ -379,6 +380,7 @@ __global__ void __launch_bounds__(256) tables_adam_multi_v4_kernel(TablesArgs a)
   double tot = 0.0;
   for (int i = 0; i < d.nsum; ++i) tot += d.sumsq_adam[(long)i * d.sumsq_stride];
   const float factor = clipf(tot, a.clip_norm);
+  if (a.adam_state[4] != 0.0) return;    // aborted step (csrc/p2p.hip, csrc/headsfused.hip): touch nothing
   const float lr_t = (float)a.adam_state[3];
   const float b1 = a.b1, b2 = a.b2;
   const unsigned QC = (unsigned)d.C >> 2, total = (unsigned)d.V * QC;

@@ -15,7 +15,8 @@
 #include "common.h"
 #include <cstdlib>
 
-// state[0]=step, [1]=beta1^t, [2]=beta2^t, [3]=lr_t   (doubles, device resident so graph replay works)
+// state[0]=step, [1]=beta1^t, [2]=beta2^t, [3]=lr_t, [4]=abort flag of the step   (doubles, device resident so graph
+// replay works; abort: raised by a collective / grid barrier that gave up -- csrc/p2p.hip -- the kernels below then return)
 __global__ void adam_tick_kernel(double* st, double lr, double b1, double b2) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     st[0] += 1.0;
@@ -119,6 +120,7 @@ __global__ void __launch_bounds__(256) dense_adam_kernel(float* __restrict__ par
                                                          const double* __restrict__ sumsq, float clip_norm,
                                                          const double* __restrict__ adam_state, float b1,
                                                          float b2, float eps, int n) {
+  if (adam_state[4] != 0.0) return;      // the step was aborted (a collective / grid barrier gave up): touch nothing
   const float lr_t = (float)adam_state[3];
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
     const float g = grad[e] * clip_factor(sumsq[seg_of[e]], clip_norm);
@@ -258,6 +260,7 @@ __global__ void __launch_bounds__(256) table_adam_kernel(
   double tot = 0.0;
   for (int i = 0; i < nsum; ++i) tot += sumsq[(long)i * sumsq_stride];
   const float factor = clip_factor(tot, clip_norm);
+  if (adam_state[4] != 0.0) return;      // the step was aborted (a collective / grid barrier gave up): touch nothing
   const float lr_t = (float)adam_state[3];
   const long total = V * C;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -410,6 +413,7 @@ __global__ void __launch_bounds__(256) table_adam_rows_kernel(
   double tot = 0.0;
   for (int i = 0; i < nsum; ++i) tot += sumsq[(long)i * sumsq_stride];
   const float factor = clip_factor(tot, clip_norm);
+  if (adam_state[4] != 0.0) return;      // the step was aborted (a collective / grid barrier gave up): touch nothing
   const float lr_t = (float)adam_state[3];
   const int QC = C / VW;
   const long total = (long)count[0] * QC;
@@ -480,6 +484,7 @@ __global__ void __launch_bounds__(256) table_adam_rows_h_kernel(
   double tot = 0.0;
   for (int i = 0; i < nsum; ++i) tot += sumsq[(long)i * sumsq_stride];
   const float factor = clip_factor(tot, clip_norm);
+  if (adam_state[4] != 0.0) return;      // the step was aborted (a collective / grid barrier gave up): touch nothing
   const float lr_t = (float)adam_state[3];
   const int QC = C / 4;
   const long total = (long)count[0] * QC;

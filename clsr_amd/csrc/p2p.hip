@@ -19,8 +19,14 @@
 // Every stream therefore gets a CHANNEL of its own (slots, flags, sequence), assigned in order of first use -- the same
 // order on every rank, because every rank issues the same sequence of calls.
 // The exchange buffers are fine-grained device allocations (no stale lines in a reader's L2) mapped into the peers by
-// hipIpc handles that the host exchanges once; the kernel gives up after a minute and raises the communicator's error flag
-// instead of hanging the device.
+// hipIpc handles that the host exchanges once.
+// A peer that never arrives must not hang the device: the wait is bounded (CLSR_P2P_TIMEOUT_S, default 10 s -- the ranks of a
+// step meet at the process-group collective that opens it, so inside a step they are milliseconds apart; only the first
+// steps drift by seconds).  A wait that gives up (1) raises the communicator's STICKY error word, (2) raises the step's
+// abort flag (clsr_comm_set_abort: adam_state[4] of the net -- every optimiser kernel returns without touching a
+// parameter or a moment while it is set) and (3) returns NaN instead of a partial sum, so that nothing downstream can mistake
+// the statistics for valid ones.  The host reports it at its next check (CLSRNet.check_abort: every loss read, every
+// data-parallel step one step late, before every checkpoint).
 #include "common.h"
 #include "clsr_hip.h"
 #include <string.h>
@@ -42,6 +48,7 @@ struct P2PComm {
   unsigned long long seq[P2P_NCH];     // host-side count of issued all-reduces per channel
   void* stream_of[P2P_NCH];            // channel -> the stream that owns it (assigned at first use)
   int nch;
+  double* abort_flag;                  // optional device double raised when a wait gives up (clsr_comm_set_abort)
 };
 
 struct P2PArgs {
@@ -50,10 +57,14 @@ struct P2PArgs {
   int n, rank, world, ch;
   unsigned long long seq;
   long long timeout_ticks;      // of the 100 MHz wall clock
+  double* abort_flag;
 };
 
 __global__ void __launch_bounds__(256) allreduce_small_kernel(P2PArgs a) {
+  __shared__ int gave_up;
   const int tid = threadIdx.x;
+  if (tid == 0) gave_up = 0;
+  __syncthreads();
   const int slot = (int)(a.seq & 1ull);
   P2PBuf* mine = a.bufs[a.rank];
   if (tid < a.n) {
@@ -69,6 +80,8 @@ __global__ void __launch_bounds__(256) allreduce_small_kernel(P2PArgs a) {
     while (__hip_atomic_load(&mine->flag[a.ch][slot][tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
       if (wall_clock64() - t0 > a.timeout_ticks) {   // a peer never arrived
         __hip_atomic_store(&mine->err, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (a.abort_flag) __hip_atomic_store(a.abort_flag, (double)a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gave_up = 1;
         break;
       }
       __builtin_amdgcn_s_sleep(8);
@@ -80,7 +93,7 @@ __global__ void __launch_bounds__(256) allreduce_small_kernel(P2PArgs a) {
     double s = 0.0;
     for (int r = 0; r < a.world; ++r)
       s += __hip_atomic_load(&mine->data[a.ch][slot][r][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    a.x[tid] = s;
+    a.x[tid] = gave_up ? __builtin_nan("") : s;     // never a partial sum that looks like statistics
   }
 }
 
@@ -136,7 +149,7 @@ extern "C" int clsr_comm_ipc_close(void* peer) {
 extern "C" int clsr_comm_create(int rank, int world, void* const* bufs, void** comm_out) {
   CLSR_CHECK_ARG(bufs && comm_out && world >= 1 && world <= P2P_MAXW && rank >= 0 && rank < world);
   P2PComm* c = new P2PComm();
-  c->rank = rank; c->world = world; c->nch = 0;
+  c->rank = rank; c->world = world; c->nch = 0; c->abort_flag = nullptr;
   for (int i = 0; i < P2P_NCH; ++i) { c->seq[i] = 0; c->stream_of[i] = nullptr; }
   for (int r = 0; r < world; ++r) {
     if (!bufs[r]) { delete c; clsr_set_error("%s:%d: exchange buffer of rank %d missing", __FILE__, __LINE__, r); return CLSR_EINVAL; }
@@ -160,6 +173,25 @@ extern "C" int clsr_comm_reset_channels(void* comm) {
   c->nch = 0;
   for (int i = 0; i < P2P_NCH; ++i) c->stream_of[i] = nullptr;
   return CLSR_OK;
+}
+// The step's abort flag: a device double (the net's adam_state[4]) that a wait which gives up sets to a non-zero value; NULL
+// detaches it.  The optimiser kernels of csrc/optim.hip / csrc/multi.hip do nothing while it is non-zero.
+extern "C" int clsr_comm_set_abort(void* comm, double* flag) {
+  CLSR_CHECK_ARG(comm);
+  ((P2PComm*)comm)->abort_flag = flag;
+  return CLSR_OK;
+}
+// bounded waits of the peer-to-peer kernels, in ticks of the 100 MHz wall clock: CLSR_P2P_TIMEOUT_S seconds (fractions
+// allowed, at least 10 ms), default 10 s
+long long clsr_p2p_timeout_ticks(void) {
+  static const long long ticks = []() {
+    const char* e = getenv("CLSR_P2P_TIMEOUT_S");
+    double sec = e ? atof(e) : 10.0;
+    if (!(sec >= 0.01)) sec = 0.01;
+    if (sec > 3600.0) sec = 3600.0;
+    return (long long)(sec * 1e8);
+  }();
+  return ticks;
 }
 // sequence number of the last all-reduce in which this rank gave up waiting for a peer (0: none); synchronises the device
 extern "C" long clsr_comm_error(void* comm) {
@@ -188,10 +220,8 @@ extern "C" int clsr_allreduce_small(void* comm, double* data, int n, void* strea
   }
   a.ch = ch;
   a.seq = ++c->seq[ch];
-  // ranks of a job drift apart by whole seconds in the first steps (allocations, launch-plan recording): the wait is bounded
-  // only so that a peer that died cannot hang the device (CLSR_P2P_TIMEOUT_S, default 60)
-  static const long long ticks = (long long)(getenv("CLSR_P2P_TIMEOUT_S") ? atof(getenv("CLSR_P2P_TIMEOUT_S")) : 60.0) * 100000000LL;
-  a.timeout_ticks = ticks;
+  a.timeout_ticks = clsr_p2p_timeout_ticks();
+  a.abort_flag = c->abort_flag;
   hipLaunchKernelGGL(allreduce_small_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;

@@ -410,7 +410,7 @@ extern "C" int clsr_gru_fwd(const float* Pin, int ldp, const float* Wgh, int ldg
   a.Pin = Pin; a.ldp = ldp; a.Wgh = Wgh; a.ldg = ldg; a.Wch = Wch; a.ldc = ldc; a.h0 = h0;
   a.h0_stride = h0_stride; a.seq_len = seq_len; a.len_stride = len_stride; a.Hn = Hn; a.T = T; a.n = n;
   a.hT = hT; a.out_seq = out_seq; a.hprev = hprev; a.gates = gates; a.t0 = 0; a.t1 = T;
-  RNN_LAUNCH(gru_fwd_kernel, rnn_tiles(n), rnn_default_x3(), dim3(clsr_cdiv(Hn, 16)), stream, a);
+  RNN_LAUNCH(gru_fwd_kernel, rnn_tiles(n), false /* the plain entry points: always the fp32 form */, dim3(clsr_cdiv(Hn, 16)), stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
@@ -428,7 +428,7 @@ extern "C" int clsr_gru_bwd(const float* gates, const float* hprev, const float*
   a.Wgh = Wgh; a.ldg = ldg; a.Wch = Wch; a.ldc = ldc; a.seq_len = seq_len; a.len_stride = len_stride;
   a.Hn = Hn; a.T = T; a.n = n; a.dhT = dhT; a.dout_seq = dout_seq; a.dPin = dPin; a.dh0 = dh0;
   a.lddp = 3 * n; a.t0 = 0; a.t1 = T;
-  RNN_LAUNCH(gru_bwd_kernel, rnn_tiles(n), rnn_default_x3(), dim3(clsr_cdiv(Hn, 16)), stream, a);
+  RNN_LAUNCH(gru_bwd_kernel, rnn_tiles(n), false /* the plain entry points: always the fp32 form */, dim3(clsr_cdiv(Hn, 16)), stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
@@ -1271,7 +1271,7 @@ extern "C" int clsr_t4lstm_fwd(const float* Pin, int ldp, const float* Wm, int l
   T4Args a = {};
   a.Pin = Pin; a.ldp = ldp; a.Wm = Wm; a.ldm = ldm; a.seq_len = seq_len; a.len_stride = len_stride;
   a.Hn = Hn; a.T = T; a.n = n; a.out_seq = out_seq; a.act = act; a.cst = cst; a.mprev = mprev; a.t0 = 0; a.t1 = T;
-  RNN_LAUNCH(t4lstm_fwd_kernel, rnn_tiles(n), rnn_default_x3(), dim3(clsr_cdiv(Hn, 16)), stream, a);
+  RNN_LAUNCH(t4lstm_fwd_kernel, rnn_tiles(n), false /* the plain entry points: always the fp32 form */, dim3(clsr_cdiv(Hn, 16)), stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
@@ -1287,7 +1287,7 @@ extern "C" int clsr_t4lstm_bwd(const float* act, const float* cst, const float* 
   a.act = const_cast<float*>(act); a.cst = const_cast<float*>(cst); a.Wm = Wm; a.ldm = ldm;
   a.seq_len = seq_len; a.len_stride = len_stride; a.Hn = Hn; a.T = T; a.n = n;
   a.dout_seq = dout_seq; a.dPin = dPin; a.lddp = 6 * n; a.t0 = 0; a.t1 = T;
-  RNN_LAUNCH(t4lstm_bwd_kernel, rnn_tiles(n), rnn_default_x3(), dim3(clsr_cdiv(Hn, 16)), stream, a);
+  RNN_LAUNCH(t4lstm_bwd_kernel, rnn_tiles(n), false /* the plain entry points: always the fp32 form */, dim3(clsr_cdiv(Hn, 16)), stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }

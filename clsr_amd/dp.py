@@ -135,6 +135,11 @@ class DataParallel(object):
         self.sync_bn = bool(sync_bn)
         self.overlap = bool(overlap)
         net.dp_world = self.world
+        # recorded launch plans keep raw communicator pointers: a new stepper on the same net must never replay the plans
+        # of an earlier one (a freed communicator's address can be handed out again)
+        net.dp_generation = getattr(net, "dp_generation", 0) + 1
+        if hasattr(net, "_step_plans"):
+            net._step_plans.clear()
         net.dp_stats_hook = self._sum_stats if self.sync_bn else None
         # sync-BN statistics through the peer-to-peer communicator (clsr_amd/p2p.py) when one can be set up: ONE kernel per
         # all-reduce on the issuing stream instead of a torch.distributed call.  CLSR_P2P_STATS=0: always torch.distributed.
@@ -157,6 +162,7 @@ class DataParallel(object):
             tdist.all_gather_object(votes, bool(ok), group=group)
             if all(votes):
                 net.dp_comm = self.comm.handle
+                self.comm.set_abort(net.adam_state[4:])     # a wait that gives up aborts the step (CLSRNet.check_abort)
                 self.stats_transport = "p2p"
                 # the same primitives (IPC-mapped uncached buffers, system-scope atomics) carry the statistics of the fused
                 # heads launches: their group sums are pushed to every rank from inside the launches (csrc/headsfused.hip)
@@ -200,6 +206,10 @@ class DataParallel(object):
         self._dense_stream = None
         self.last_sparse = []
         self.trace = None              # tests: list that receives (event, detail) tuples in issue order
+        # asynchronous copy of the step's abort flag (net.adam_state[4]), looked at one step late: no synchronisation
+        self._abort_host = None
+        if torch.cuda.is_available() and str(net.device).startswith("cuda") and hasattr(net, "adam_state"):
+            self._abort_host = torch.zeros(1, dtype=torch.float64).pin_memory()
         self.broadcast_parameters()
 
     def broadcast_parameters(self):
@@ -431,6 +441,9 @@ class DataParallel(object):
             torch.cuda.synchronize()
         self.net.dp_comm = None
         self.net.heads_comm = None
+        if hasattr(self.net, "_step_plans"):
+            self.net._step_plans.clear()       # (they hold the communicators' raw pointers)
+        self.net.dp_generation = getattr(self.net, "dp_generation", 0) + 1
         for name in ("heads_comm", "comm"):
             c = getattr(self, name, None)
             if c is not None:
@@ -495,9 +508,13 @@ class DataParallel(object):
         self.net._apply_updates()
 
     def train_step(self, f):
+        if self._abort_host is not None and float(self._abort_host[0]) != 0.0:
+            self.net.check_abort()         # (an earlier step gave up on the device: raises StepAborted)
         self._backward(f)
         self._finish()
         self._update()
+        if self._abort_host is not None:
+            self._abort_host.copy_(self.net.adam_state[4:5], non_blocking=True)
 
     def capture(self, f):
         """Two hipGraphs (backward | update) around the eager RCCL exchange; returns run().

@@ -59,6 +59,11 @@ class _BN(object):
 _SIDE_STREAMS = {}     # device -> {tag: HIP stream}, see CLSRNet.__init__
 
 
+class StepAborted(RuntimeError):
+    """A bounded wait inside a training step gave up (see CLSRNet.check_abort): the step's results are invalid and no
+    optimiser update has been applied since."""
+
+
 class CLSRNet(object):
     def __init__(self, hp, dims, device="cuda:0", seed=None, dedup_histories=True, precision="fp32", table_dtype="fp32"):
         self.hp = hp
@@ -189,7 +194,9 @@ class CLSRNet(object):
         # that write each row once, in a fixed order -- no float atomics; two runs of a step give bit-identical gradient
         # tables and clip norms.  CLSR_NO_DET_GRADS=1: the counting sort + atomics of rounds 2-3.
         self.det_grads = not os.environ.get("CLSR_NO_DET_GRADS")
-        self.adam_state = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device=self.device)
+        # step | beta1^t | beta2^t | lr_t | abort flag (raised on the device when a bounded wait of the step gives up: every
+        # optimiser kernel then returns without touching anything; reported by check_abort)
+        self.adam_state = torch.tensor([0.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0], dtype=torch.float64, device=self.device)
         # squared norms of the IndexedSlices pieces (16) + loss numerators (8): ONE buffer, so that the data-parallel
         # exchange sums them with one collective and no staging copies
         self.stats24 = torch.zeros(24, dtype=torch.float64, device=self.device)
@@ -272,7 +279,7 @@ class CLSRNet(object):
     def _plan_key(self, what, f):
         hp = self.hp
         g = lambda k: getattr(hp, k, None)
-        return (what, id(f), ops.stream_ptr(), self.precision, self.table_bf16, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook), self.dp_comm,
+        return (what, id(f), ops.stream_ptr(), self.precision, self.table_bf16, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook), self.dp_comm, self.heads_comm, getattr(self, "dp_generation", 0),
                 self.overlap, self.defer_dw, self.sorted_hist_grad,
                 self.lazy, self.rnn_first, self.tick_early, self.hist_grad_two, self.dw_batch_late, self.bn_bwd_fused, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h, self.flush_side, self.l1_bwd_2pass,
                 self.split_g2, self.rnn_products, self.rnn_fused_proj, self.rnn_act_tiled, self.enc_bwd_fused, self.enc_bwd_fused_h, self.dhist_side, self.early_scatter, self.fused_logit_tail, self.fuse_tt, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
@@ -413,7 +420,7 @@ class CLSRNet(object):
         for k in self.tables:
             sd["__adam__/%s_m" % k] = self.tab_m[k].cpu().clone()
             sd["__adam__/%s_v" % k] = self.tab_v[k].cpu().clone()
-        sd["__adam__/state"] = self.adam_state.cpu().clone()
+        sd["__adam__/state"] = self.adam_state[:4].cpu().clone()
         return sd
 
     @staticmethod
@@ -454,7 +461,7 @@ class CLSRNet(object):
             for k in self.tables:
                 self.tab_m[k].copy_(torch.as_tensor(sd["__adam__/%s_m" % k]))
                 self.tab_v[k].copy_(torch.as_tensor(sd["__adam__/%s_v" % k]))
-            self.adam_state.copy_(torch.as_tensor(sd["__adam__/state"]))
+            self.adam_state[:4].copy_(torch.as_tensor(sd["__adam__/state"])[:4])
 
     # ------------------------------------------------------------------ stream fork / join
     class _Branch(object):
@@ -1864,7 +1871,7 @@ class CLSRNet(object):
             logit=out["logit"], dlogit=dlogit, loss=self.losses[0:],
             lg_dz1=z["lg.dz1"], lg_dz0=z["lg.dz0"], dmo=buf("lg.dX", B, 2 * D), al_dz1=z["al.dz1"], al_dz0=z["al.dz0"],
             lg_wp=wp_lg, al_wp=wp_al, dL=dL, dS=dS, dtarget=dtarget, dfs=dfs, workspace=ws, workspace_bytes=ws.numel() * 4,
-            comm=(self.heads_comm or 0) if self.dp_stats_hook is not None else 0)
+            comm=(self.heads_comm or 0) if self.dp_stats_hook is not None else 0, abort_flag=self.adam_state[4:])
         with self._dw_batched(late=True):
             ops.heads_fused(1, d)
             self._rp(wp_lg, parts, L1 + 4, L1, Gd[lg + "w_nn_output"])
@@ -2461,12 +2468,35 @@ class CLSRNet(object):
     def _att_layer0_wave(self, G, Q):
         return (not self.bf16) and self.l0_fwd_wave and bool(query("clsr_att_l0_fwd_supported", G, Q, self.A0))
 
+    def check_abort(self, clear=False):
+        """Raise ``StepAborted`` if a bounded wait of some step since the last check gave up -- a grid barrier of the fused
+        heads launches (a launch wider than the device can hold at once, a peer rank that never pushed its statistics) or a
+        small all-reduce of the data-parallel step (csrc/p2p.hip).  The device raised adam_state[4] when it happened, and
+        every optimiser kernel since has returned without touching a parameter or a moment: the variables are those of the
+        last good step.  Synchronises the device (called with every loss read, before every checkpoint, at the end of an
+        epoch; the data-parallel stepper also looks at an asynchronous copy of the flag one step late)."""
+        flag = float(self.adam_state[4].item())
+        if flag == 0.0:
+            return
+        why = []
+        ws = self._bufs.get(("heads.ws", (int(query("clsr_heads_fused_workspace_bytes")) + 3) // 4, F32))
+        if ws is not None and query("clsr_heads_fused_error", ws.data_ptr()) != 0:
+            why.append("a grid barrier of the fused heads launches timed out (the device could not hold every workgroup of "
+                       "the launch at once, or a peer rank never pushed its statistics; CLSR_NO_HEADS_FUSED=1 runs the "
+                       "launch chain instead)")
+            if clear:
+                call("clsr_heads_fused_clear_error", ws)
+        comm = getattr(self, "dp_comm", None)
+        if comm and query("clsr_comm_error", comm) != 0:
+            why.append("a small all-reduce gave up waiting for a peer rank (CLSR_P2P_TIMEOUT_S)")
+        if clear:
+            self.adam_state[4] = 0.0
+        raise StepAborted("the training step was aborted on the device: %s; no update has been applied since"
+                          % ("; ".join(why) or "abort flag %g" % flag))
+
     def read_losses(self):
         """Synchronising read of the step's loss terms -> dict of python floats."""
         v = self.losses.cpu().tolist()
-        ws = self._bufs.get(("heads.ws", (int(query("clsr_heads_fused_workspace_bytes")) + 3) // 4, F32))
-        if ws is not None and query("clsr_heads_fused_error", ws.data_ptr()) != 0:
-            raise RuntimeError("clsr_heads_fused: a grid barrier timed out (the device could not hold every workgroup of the "
-                               "launch at once): the step's results are invalid; set CLSR_NO_HEADS_FUSED=1")
+        self.check_abort()
         return dict(data_loss=v[0], regular_loss=v[1], contrastive_loss=v[2], discrepancy_loss=v[3],
                     loss=v[0] + v[1] + v[2] + v[3])

@@ -424,7 +424,7 @@ class HeadsDesc(ctypes.Structure):
                 + [(n, _P) for n in ("ain", "al_z0", "al_z1", "alpha", "mo", "lg_z0", "lg_z1", "logit", "dlogit", "loss",
                                      "lg_dz1", "lg_dz0", "dmo", "al_dz1", "al_dz0", "lg_wp", "al_wp", "dL", "dS", "dtarget",
                                      "dfs", "workspace")]
-                + [("workspace_bytes", _L), ("comm", _P)])
+                + [("workspace_bytes", _L), ("comm", _P), ("abort_flag", _P)])
 
 
 def heads_desc(**kw):

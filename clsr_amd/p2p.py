@@ -21,33 +21,55 @@ class _PeerMapped(object):
     _alloc, _create, _destroy, _max_world = None, None, None, None       # names of the C entry points (subclasses)
 
     def __init__(self, rank, world, gather_objects):
-        """``gather_objects(obj) -> list of every rank's obj`` (torch.distributed.all_gather_object or equivalent)."""
+        """``gather_objects(obj) -> list of every rank's obj`` (torch.distributed.all_gather_object or equivalent).
+
+        Every rank runs the SAME sequence of gathers whatever fails locally (a rank that skipped one would pair its next
+        collective with a different one of its peers): stage 1 gathers (handle or None), stage 2 gathers (mapped-all or
+        the error text); the verdict of a stage is computed from the gathered list, so all ranks raise at the same stage --
+        after releasing whatever they had allocated or opened."""
         lib = _lib.load()
         self.rank, self.world = int(rank), int(world)
-        if self.world > getattr(lib, self._max_world)():
-            raise ValueError("%s: at most %d ranks (one node)" % (type(self).__name__, getattr(lib, self._max_world)()))
-        buf = ctypes.c_void_p()
-        _lib.check(getattr(lib, self._alloc)(ctypes.byref(buf)), self._alloc)
-        self._own = buf
+        self._own, self._peers, self.handle = None, [], None
         nb = lib.clsr_comm_ipc_handle_bytes()
-        h = ctypes.create_string_buffer(nb)
-        _lib.check(lib.clsr_comm_ipc_handle(buf, h), "clsr_comm_ipc_handle")
-        handles = gather_objects(bytes(h.raw))
-        self._peers = []
-        ptrs = (ctypes.c_void_p * self.world)()
-        for r in range(self.world):
-            if r == self.rank:
-                ptrs[r] = buf
-                continue
-            p = ctypes.c_void_p()
-            hb = ctypes.create_string_buffer(handles[r], nb)
-            _lib.check(lib.clsr_comm_ipc_open(hb, ctypes.byref(p)), "clsr_comm_ipc_open (rank %d)" % r)
-            self._peers.append(p)
-            ptrs[r] = p
-        comm = ctypes.c_void_p()
-        _lib.check(getattr(lib, self._create)(self.rank, self.world, ptrs, ctypes.byref(comm)), self._create)
-        self.handle = comm.value          # (an integer address: what ops.call passes for a void*)
-        gather_objects(b"ready")          # nobody pushes before every rank has mapped every buffer
+        mine, err = None, None
+        try:
+            if self.world > getattr(lib, self._max_world)():
+                raise ValueError("%s: at most %d ranks (one node)" % (type(self).__name__, getattr(lib, self._max_world)()))
+            buf = ctypes.c_void_p()
+            _lib.check(getattr(lib, self._alloc)(ctypes.byref(buf)), self._alloc)
+            self._own = buf
+            h = ctypes.create_string_buffer(nb)
+            _lib.check(lib.clsr_comm_ipc_handle(buf, h), "clsr_comm_ipc_handle")
+            mine = bytes(h.raw)
+        except Exception as e:      # noqa: BLE001 -- reported to every rank below
+            err = "rank %d: %s" % (self.rank, str(e)[:120])
+        handles = gather_objects(mine)                                   # ---- stage 1: every rank, always
+        if any(h is None for h in handles):
+            self.close()
+            raise RuntimeError("%s: exchange buffer / IPC handle failed on ranks %s%s" % (
+                type(self).__name__, [r for r, h in enumerate(handles) if h is None], (" (%s)" % err) if err else ""))
+        try:
+            ptrs = (ctypes.c_void_p * self.world)()
+            for r in range(self.world):
+                if r == self.rank:
+                    ptrs[r] = self._own
+                    continue
+                p = ctypes.c_void_p()
+                hb = ctypes.create_string_buffer(handles[r], nb)
+                _lib.check(lib.clsr_comm_ipc_open(hb, ctypes.byref(p)), "clsr_comm_ipc_open (rank %d)" % r)
+                self._peers.append(p)
+                ptrs[r] = p
+            comm = ctypes.c_void_p()
+            _lib.check(getattr(lib, self._create)(self.rank, self.world, ptrs, ctypes.byref(comm)), self._create)
+            self.handle = comm.value      # (an integer address: what ops.call passes for a void*)
+        except Exception as e:      # noqa: BLE001
+            err = "rank %d: %s" % (self.rank, str(e)[:120])
+        # ---- stage 2: nobody pushes before every rank has mapped every buffer -- and everybody learns if one could not
+        mapped = gather_objects(err or "ready")
+        bad = [m for m in mapped if m != "ready"]
+        if bad:
+            self.close()
+            raise RuntimeError("%s: mapping the peers' exchange buffers failed: %s" % (type(self).__name__, "; ".join(bad)))
 
     def close(self):
         lib = _lib.load()
@@ -76,6 +98,11 @@ class SmallComm(_PeerMapped):
         n = t.numel() if n is None else int(n)
         assert t.dtype == torch.float64 and n <= self.max_doubles
         ops.call("clsr_allreduce_small", self.handle, t, n)
+
+    def set_abort(self, flag):
+        """``flag``: a device double (view) that an all-reduce which gives up waiting raises; None detaches it"""
+        _lib.check(_lib.load().clsr_comm_set_abort(ctypes.c_void_p(self.handle), None if flag is None else ctypes.c_void_p(flag.data_ptr())),
+                   "clsr_comm_set_abort")
 
     def reset_channels(self):
         """forget the stream -> channel assignment (every rank at the same point of its call sequence)"""

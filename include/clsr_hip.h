@@ -87,6 +87,8 @@ int clsr_comm_ipc_close(void* peer);
 int clsr_comm_create(int rank, int world, void* const* bufs, void** comm_out);
 int clsr_comm_destroy(void* comm);
 int clsr_comm_reset_channels(void* comm);   /* forget the stream -> channel map (same point on every rank) */
+/* device double raised (non-zero) when an all-reduce of this communicator gives up waiting for a peer; NULL detaches */
+int clsr_comm_set_abort(void* comm, double* flag);
 long clsr_comm_error(void* comm);    /* sequence number of the last all-reduce that timed out waiting for a peer (0: none) */
 int clsr_allreduce_small(void* comm, double* data, int n, void* stream);
 
@@ -164,6 +166,10 @@ typedef struct clsr_heads_desc {
   /* data-parallel runs with synchronised batch-norm statistics: a communicator from clsr_heads_comm_create (every rank
    * then issues the same sequence of step1 / step2 calls with the same B); NULL: the statistics of this process's rows */
   void* comm;
+  /* the step's abort flag (a device double, the net's adam_state[4]; may be NULL): set non-zero when a grid barrier of a
+   * launch gives up (a launch wider than the device can hold at once, a peer rank that never pushed); while it is set the
+   * optimiser kernels leave parameters and moments untouched */
+  double* abort_flag;
 } clsr_heads_desc;
 int clsr_sizeof_heads_desc(void);
 int clsr_heads_fused_supported(long B, int G, int D, int nfs, int a_in, int A0, int A1, int L0, int L1);
@@ -181,7 +187,9 @@ int clsr_heads_comm_destroy(void* comm);
 /* start-up check: every rank calls it at the same point; *ok_out (device) = 1 iff all eight stages gave the expected sums */
 int clsr_heads_comm_self_test(void* comm, int nblocks, void* workspace, long workspace_bytes, int* ok_out, float timeout_s,
                               void* stream);
-int clsr_heads_fused_error(const void* workspace);   /* synchronous; 1 = a grid barrier timed out (results invalid) */
+int clsr_heads_fused_error(const void* workspace);   /* synchronous; != 0: a grid barrier timed out in some launch since the
+                                                       * sticky error words of the workspace were last cleared */
+int clsr_heads_fused_clear_error(void* workspace);
 int clsr_heads_fused_step1(const clsr_heads_desc* d_host, void* stream);
 int clsr_heads_fused_step2(const clsr_heads_desc* d_host, void* stream);
 
@@ -620,6 +628,9 @@ int clsr_mul_rows(const float* a, int lda, const float* b, int ldb, int G, long 
 /* ---- regularisers, clip, Adam: base_model.py:118-159,249-297; clsr.py:73-82.  l2 / l1: embed_l2 / embed_l1 for the
  *      involved embedding rows, layer_l2 / layer_l1 for the dense variables (loss += l2/2 ||w||^2 + l1 |w|_1,
  *      grad += l2 w + l1 sign(w)) */
+/* Adam state: FIVE device doubles  step | beta1^t | beta2^t | lr_t | abort.  abort != 0 (raised by clsr_allreduce_small /
+ * the fused heads launches when a bounded wait gives up, see clsr_comm_set_abort) makes every optimiser kernel below return
+ * without touching a parameter or a moment; the host clears it after reporting. */
 int clsr_adam_tick(double* state, double lr, double beta1, double beta2, void* stream);
 int clsr_dense_reg_norm(const float* param, float* grad, const int* seg_off, int nseg, float l2, float l1,
                         double* sumsq, double* reg_loss, void* stream);

@@ -470,11 +470,27 @@ def test_att_prod_bwd_on_column_blocks(Hn, G, T, Q, col0, ld):
         close(dq, dq_exp, name="dq plain")
 
 
+# The recurrences come in two forms (clsr_gru_desc.products, csrc/rnn.hip): "fp32" = fp32-input MFMAs, bit-exact fp32
+# products -- the tolerances below; "x3" = split-bf16 products (16 significand bits per operand, errors compound over the
+# steps) -- ten times those tolerances.  The plain entry points (clsr_gru_fwd ...) always run the fp32 form.
+FORMS = [("fp32", 1.0), ("x3", 10.0)]
+
+
+def _scaled_close(tf, exact=()):
+    """``close`` with both tolerances multiplied by the form's factor (tensors named in ``exact`` keep theirs)"""
+    def scaled(got, exp, rtol=2e-5, atol=2e-6, name=""):
+        f = 1.0 if name in exact else tf
+        close(got, exp, rtol=rtol * f, atol=atol * f, name=name)
+    return scaled
+
+
+@pytest.mark.parametrize("form,tf", FORMS)
 @pytest.mark.parametrize("Hn,T,n,use_h0,seq_out", [(37, 10, 40, True, False), (16, 50, 40, False, True),
                                                    (5, 7, 40, True, True), (21, 9, 128, True, True),
                                                    (4, 5, 64, False, False)])
-def test_gru_fwd_bwd(Hn, T, n, use_h0, seq_out):
+def test_gru_fwd_bwd(Hn, T, n, use_h0, seq_out, form, tf):
     O = _oracle()
+    close = _scaled_close(tf)
     g = torch.Generator().manual_seed(T + Hn)
     D = 40
     x = rnd(g, Hn, T, D).float().double().requires_grad_(True)
@@ -502,15 +518,26 @@ def test_gru_fwd_bwd(Hn, T, n, use_h0, seq_out):
     out_k = torch.full((Hn, T, n), 7.0, device="cuda") if seq_out else None
     hprev = torch.zeros(Hn, T, n, device="cuda")
     gates = torch.zeros(Hn, T, 3 * n, device="cuda")
-    call("clsr_gru_fwd", dev(Pin), 3 * n, d_Wg[D:], 2 * n, d_Wc[D:], n, None if h0 is None else dev(h0.detach(), f32),
-         n, d_len, 1, Hn, T, n, hT_k, out_k, hprev, gates)
+    h0d = None if h0 is None else dev(h0.detach(), f32)
+    if form == "fp32" and Hn % 2:      # (the plain entry point: always the fp32 form)
+        call("clsr_gru_fwd", dev(Pin), 3 * n, d_Wg[D:], 2 * n, d_Wc[D:], n, h0d, n, d_len, 1, Hn, T, n, hT_k, out_k, hprev, gates)
+    else:
+        ops.rnn_multi("clsr_rnn_fwd_multi", [ops.gru_desc(n, Pin=dev(Pin), ldp=3 * n, Wgh=d_Wg[D:], ldg=2 * n, Wch=d_Wc[D:],
+                                                          ldc=n, h0=h0d, h0_stride=n, hT=hT_k, out_seq=out_k, hprev=hprev,
+                                                          gates=gates, products=form)], None, d_len, 1, Hn, T)
     close(hT_k, hT, rtol=1e-4, atol=2e-5, name="hT")
     if seq_out:
         close(out_k, outs, rtol=1e-4, atol=2e-5, name="out_seq")
     dPin = torch.full((Hn, T, 3 * n), 5.0, device="cuda")
     dh0 = torch.empty(Hn, n, device="cuda")
-    call("clsr_gru_bwd", gates, hprev, d_Wg[D:], 2 * n, d_Wc[D:], n, d_len, 1, Hn, T, n, dev(up_T, f32),
-         dev(up_seq, f32) if seq_out else None, dPin, dh0)
+    if form == "fp32" and Hn % 2:
+        call("clsr_gru_bwd", gates, hprev, d_Wg[D:], 2 * n, d_Wc[D:], n, d_len, 1, Hn, T, n, dev(up_T, f32),
+             dev(up_seq, f32) if seq_out else None, dPin, dh0)
+    else:
+        ops.rnn_multi("clsr_rnn_bwd_multi", [ops.gru_desc(n, Wgh=d_Wg[D:], ldg=2 * n, Wch=d_Wc[D:], ldc=n, hprev=hprev,
+                                                          gates=gates, dhT=dev(up_T, f32),
+                                                          dout_seq=dev(up_seq, f32) if seq_out else None, dPin=dPin,
+                                                          lddp=3 * n, dh0=dh0, products=form)], None, d_len, 1, Hn, T)
     # check through the implied parameter / input gradients
     dP = dPin.double().cpu().reshape(-1, 3 * n)
     close(dP @ Win.T, x.grad.reshape(-1, D), rtol=2e-4, atol=2e-5, name="dx")
@@ -526,9 +553,11 @@ def test_gru_fwd_bwd(Hn, T, n, use_h0, seq_out):
         close(dh0, h0.grad, rtol=2e-4, atol=2e-5, name="dh0")
 
 
+@pytest.mark.parametrize("form,tf", FORMS)
 @pytest.mark.parametrize("Hn,T,n", [(37, 10, 40), (16, 50, 40), (19, 8, 128)])
-def test_t4lstm_fwd_bwd(Hn, T, n):
+def test_t4lstm_fwd_bwd(Hn, T, n, form, tf):
     O = _oracle()
+    close = _scaled_close(tf, exact=("TT",))
     g = torch.Generator().manual_seed(T)
     D = 40
     x = rnd(g, Hn, T, D).float().double().requires_grad_(True)
@@ -563,10 +592,23 @@ def test_t4lstm_fwd_bwd(Hn, T, n):
     act = torch.zeros(Hn, T, 6 * n, device="cuda")
     cst = torch.zeros(Hn, T, n, device="cuda")
     mprev = torch.zeros(Hn, T, n, device="cuda")
-    call("clsr_t4lstm_fwd", dev(Pin), 6 * n, d["kernel"][D:], 4 * n, d_len, 1, Hn, T, n, out_k, act, cst, mprev)
+    tiled = form == "x3" and Hn % 2 == 1        # (x3 only: the private tile-major image of the saved activations)
+    if tiled:
+        act, cst = torch.zeros(query("clsr_t4_act_tiled_floats", Hn, T, n), device="cuda"), None
+    if form == "fp32" and Hn % 2:               # (the plain entry points: always the fp32 form)
+        call("clsr_t4lstm_fwd", dev(Pin), 6 * n, d["kernel"][D:], 4 * n, d_len, 1, Hn, T, n, out_k, act, cst, mprev)
+    else:
+        ops.rnn_multi("clsr_rnn_fwd_multi", [], ops.t4_desc(n, Pin=dev(Pin), ldp=6 * n, Wm=d["kernel"][D:], ldm=4 * n,
+                                                            out_seq=out_k, act=act, cst=cst, mprev=mprev, products=form,
+                                                            act_tiled=tiled), d_len, 1, Hn, T)
     close(out_k, out, rtol=1e-4, atol=2e-5, name="rnn_out")
     dPin = torch.full((Hn, T, 6 * n), 9.0, device="cuda")
-    call("clsr_t4lstm_bwd", act, cst, d["kernel"][D:], 4 * n, d_len, 1, Hn, T, n, dev(up, f32), dPin)
+    if form == "fp32" and Hn % 2:
+        call("clsr_t4lstm_bwd", act, cst, d["kernel"][D:], 4 * n, d_len, 1, Hn, T, n, dev(up, f32), dPin)
+    else:
+        ops.rnn_multi("clsr_rnn_bwd_multi", [], ops.t4_desc(n, Wm=d["kernel"][D:], ldm=4 * n, act=act, cst=cst,
+                                                            dout_seq=dev(up, f32), dPin=dPin, lddp=6 * n, products=form,
+                                                            act_tiled=tiled), d_len, 1, Hn, T)
     dP = dPin.double().cpu().reshape(-1, 6 * n)
     xf = xd.reshape(-1, D)
     close(xf.T @ dP[:, :4 * n], P["kernel"].grad[:D], rtol=2e-4, atol=1e-4, name="dkernel_x")
@@ -744,7 +786,7 @@ def test_dense_reg_clip_adam():
     close(reg, (0.5 * l2 * (p ** 2).sum() + l1 * p.abs().sum()).reshape(1), rtol=1e-5, name="reg loss")
     exp_ss = torch.stack([(g2[off[i]:off[i + 1]] ** 2).sum() for i in range(len(sizes))])
     close(ss, exp_ss, rtol=1e-5, name="sumsq")
-    st = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device="cuda")
+    st = torch.tensor([0.0, 1.0, 1.0, 0.0, 0.0], dtype=torch.float64, device="cuda")
     call("clsr_adam_tick", st, 1e-3, 0.9, 0.999)
     call("clsr_adam_tick", st, 1e-3, 0.9, 0.999)
     lr_t = 1e-3 * math.sqrt(1 - 0.999 ** 2) / (1 - 0.9 ** 2)
@@ -785,7 +827,7 @@ def test_table_reg_adam(lazy):
     close(reg, (0.5 * l2 * (fm * UL ** 2).sum() + l1 * (fm * UL.abs()).sum()).reshape(1), rtol=1e-5, name="reg")
     close(disc, (-wd * (fm * (UL - US) ** 2).sum() / (nu * C)).reshape(1), rtol=1e-5, name="disc")
     close(ss[1:], (g_reg ** 2).sum().reshape(1), rtol=1e-5, name="reg sumsq")
-    st = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device="cuda")
+    st = torch.tensor([0.0, 1.0, 1.0, 0.0, 0.0], dtype=torch.float64, device="cuda")
     call("clsr_adam_tick", st, 1e-3, 0.9, 0.999)
     call("clsr_table_adam", dUL, dG, dm, dv, dfl, V, C, ss, 1, 2, clip, st, 0.9, 0.999, 1e-8, lazy)
     tot = float((G_l ** 2).sum() + (g_reg ** 2).sum())
@@ -843,11 +885,13 @@ def test_touched_row_compaction_pack_unpack(V, C, frac):
 
 
 # ------------------------------------------------------------------------------- sibling-model kernels
+@pytest.mark.parametrize("form,tf", FORMS)
 @pytest.mark.parametrize("Hn,G,T,n", [(7, 5, 10, 40), (5, 1, 50, 40), (3, 4, 9, 128)])
-def test_attentional_gru_fwd_bwd(Hn, G, T, n):
+def test_attentional_gru_fwd_bwd(Hn, G, T, n, form, tf):
     """clsr_rnn_*_multi with clsr_gru_desc.att (DIEN's VecAttGRUCell): one sequence per candidate row reading the
     input projections / length of its history (in_div = G), update gate scaled by 1 - att; backward incl. d att."""
     from oracle import sibling_oracle as S
+    close = _scaled_close(tf)
 
     g = torch.Generator().manual_seed(T + Hn + n)
     B, Hin = Hn * G, 24
@@ -871,13 +915,13 @@ def test_attentional_gru_fwd_bwd(Hn, G, T, n):
     hT_k = torch.empty(B, n, device="cuda")
     hprev, gates = torch.zeros(B, T, n, device="cuda"), torch.zeros(B, T, 3 * n, device="cuda")
     d = ops.gru_desc(n, Pin=Pin, ldp=3 * n, Wgh=d_Wg[Hin:], ldg=2 * n, Wch=d_Wc[Hin:], ldc=n, hT=hT_k, hprev=hprev,
-                     gates=gates, att=d_att, in_div=G)
+                     gates=gates, att=d_att, in_div=G, products=form)
     ops.rnn_multi("clsr_rnn_fwd_multi", [d], None, d_len, 1, B, T)
     close(hT_k, hT, rtol=1e-4, atol=2e-5, name="final state")
     dPin = torch.full((B, T, 3 * n), 5.0, device="cuda")
     datt = torch.zeros(B, T, device="cuda")
     db = ops.gru_desc(n, Wgh=d_Wg[Hin:], ldg=2 * n, Wch=d_Wc[Hin:], ldc=n, hprev=hprev, gates=gates, dhT=dev(up, f32),
-                      dPin=dPin, lddp=3 * n, att=d_att, datt=datt, in_div=G)
+                      dPin=dPin, lddp=3 * n, att=d_att, datt=datt, in_div=G, products=form)
     ops.rnn_multi("clsr_rnn_bwd_multi", [db], None, d_len, 1, B, T)
     close(datt, att.grad, rtol=2e-4, atol=2e-5, name="d att")
     dP = dPin.double().cpu().reshape(Hn, G, T, 3 * n).sum(1).reshape(-1, 3 * n)      # rows of a group share the inputs
@@ -1241,7 +1285,7 @@ def test_dense_reg_norm_tick_advances_the_adam_clock():
     f32 = torch.float32
     dp_, dg_ = dev(p, f32), dev(gr, f32)
     ss = torch.zeros(2, dtype=torch.float64, device="cuda")
-    st = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device="cuda")
+    st = torch.tensor([0.0, 1.0, 1.0, 0.0, 0.0], dtype=torch.float64, device="cuda")
     call("clsr_dense_reg_norm_tick", dp_, dg_, dev(off), 2, 1e-3, 0.0, ss, None, st, 1e-3, 0.9, 0.999)
     call("clsr_dense_reg_norm_tick", dp_, dg_, dev(off), 2, 0.0, 0.0, ss, None, st, 1e-3, 0.9, 0.999)
     lr_t = 1e-3 * math.sqrt(1 - 0.999 ** 2) / (1 - 0.9 ** 2)
