@@ -470,6 +470,12 @@ def main():
         os.execv(sys.executable, cmd)
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # CLSR_BENCH_TRANSPORT=staged (test rig: tests/test_bench_ranks_gpu.py): the ranks of the job share ONE device and their
+    # collectives are staged through the host (gloo) -- RCCL cannot connect two ranks on one GPU.  Everything else of the
+    # per-rank program (stepper, barriers, per-rank times, the JSON line) is the code the driver's N > 1 runs execute.
+    staged = os.environ.get("CLSR_BENCH_TRANSPORT") == "staged"
+    if staged:
+        local_rank = int(os.environ.get("CLSR_BENCH_DEVICE", "0"))
     torch.cuda.set_device(local_rank)
     dist = None
     force_dp = bool(os.environ.get("CLSR_FORCE_DP"))   # exercise the DP code path with a single rank
@@ -483,7 +489,13 @@ def main():
         pg_opts = None
         if os.environ.get("CLSR_NCCL_HIGH_PRIORITY"):     # experiment: RCCL's internal stream at high priority
             pg_opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=pg_opts)
+        if staged:
+            from clsr_amd.dp import HostStagedDist
+
+            dist.init_process_group("gloo")
+            dist = HostStagedDist(dist)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=pg_opts)
         # proof that RCCL really connects the ranks the line claims: a sum of ones over the job
         ones = torch.ones(1, device="cuda")
         dist.all_reduce(ones)

@@ -20,20 +20,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
          "-Wno-unused-result", "-I" + os.path.join(ROOT, "include")]
 
 
-# csrc/experimental/ holds kernels that were built, tested and MEASURED SLOWER than what the step uses (rnn1.hip: one wave per
-# recurrent encoder, 288 / 323 us against 225 / 320 us for the three encoders of configs[1]).  CLSR_EXPERIMENTAL=1 compiles
-# them in (-DCLSR_WITH_RNN1) for A/B runs and for their tests; the default library does not contain them.
-EXPERIMENTAL = bool(os.environ.get("CLSR_EXPERIMENTAL"))
-if EXPERIMENTAL:
-    FLAGS = FLAGS + ["-DCLSR_WITH_RNN1", "-I" + SRC_DIR]
-
-
 def _sources():
-    src = sorted(f for f in os.listdir(SRC_DIR) if f.endswith((".hip", ".cpp")))
-    if EXPERIMENTAL:
-        exp = os.path.join(SRC_DIR, "experimental")
-        src += sorted(os.path.join("experimental", f) for f in os.listdir(exp) if f.endswith(".hip"))
-    return src
+    return sorted(f for f in os.listdir(SRC_DIR) if f.endswith((".hip", ".cpp")))
 
 
 def _newer(a, b):

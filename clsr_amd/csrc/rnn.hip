@@ -1163,7 +1163,11 @@ __device__ __forceinline__ void t4lstm_bwd_x3(const T4Args& a, const int bx, bf1
     v.ds = ld4(dsbase + (long)t * n);
     return v;
   };
+#ifdef RNNX_NO_PF
+  constexpr bool PF = false;
+#else
   constexpr bool PF = RNT <= 4;
+#endif
   const int tstart = min(Tmax, a.t1) - 1;
   In cur = fetch(tstart), nxt = cur;
   for (int t = tstart; t >= a.t0; --t) {
@@ -1226,13 +1230,15 @@ template <int RNT, bool X3>
 __global__ void __launch_bounds__(64 * RNT) rnn_multi_fwd_kernel(RnnMultiArgs a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
   CLSR_CHAIN_PRIO();
-  const int which = blockIdx.y;
+  // the Time4LSTM first (y = 0): workgroups are dispatched in y-major order, and the longest chain of the launch must not
+  // be the one that waits for a free slot when the grid does not fit at once
+  const int which = a.has_t4 ? (int)blockIdx.y - 1 : (int)blockIdx.y;
   if (X3) {
-    if (which < a.ngru) gru_fwd_x3<RNT, false, false>(a.gru[which], blockIdx.x, XB8(xb));
+    if (which >= 0) gru_fwd_x3<RNT, false, false>(a.gru[which], blockIdx.x, XB8(xb));
     else t4lstm_fwd_x3<RNT, false>(a.t4, blockIdx.x, XB8(xb));
     return;
   }
-  if (which < a.ngru) gru_fwd_body<RNT>(a.gru[which], blockIdx.x, xb);
+  if (which >= 0) gru_fwd_body<RNT>(a.gru[which], blockIdx.x, xb);
   else t4lstm_fwd_body<RNT>(a.t4, blockIdx.x, xb);
 }
 // split-bf16 recurrences with the input projection fused (every encoder of the launch carries X)
@@ -1240,22 +1246,27 @@ template <int RNT, bool X3>
 __global__ void __launch_bounds__(64 * RNT) rnn_multi_fwd_fp_kernel(RnnMultiArgs a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
   CLSR_CHAIN_PRIO();
-  const int which = blockIdx.y;
-  if (which < a.ngru) gru_fwd_x3<RNT, false, true>(a.gru[which], blockIdx.x, XB8(xb));
+  const int which = a.has_t4 ? (int)blockIdx.y - 1 : (int)blockIdx.y;      // (the Time4LSTM first: see rnn_multi_fwd_kernel)
+  if (which >= 0) gru_fwd_x3<RNT, false, true>(a.gru[which], blockIdx.x, XB8(xb));
   else t4lstm_fwd_x3<RNT, true>(a.t4, blockIdx.x, XB8(xb));
 }
+#ifdef RNNX_WPE3
+#define RNN_WPE __attribute__((amdgpu_waves_per_eu(RNT == 3 ? 3 : 2)))
+#else
+#define RNN_WPE
+#endif
 template <int RNT, bool X3>
-__global__ void __launch_bounds__(64 * RNT) rnn_multi_bwd_kernel(RnnMultiArgs a) {
+__global__ void __launch_bounds__(64 * RNT) RNN_WPE rnn_multi_bwd_kernel(RnnMultiArgs a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
   CLSR_CHAIN_PRIO();
-  const int which = blockIdx.y;
+  const int which = a.has_t4 ? (int)blockIdx.y - 1 : (int)blockIdx.y;      // (the Time4LSTM first: see rnn_multi_fwd_kernel)
   if (X3) {
-    if (which < a.ngru) { gru_bwd_x3<RNT, false>(a.gru[which], blockIdx.x, XB8(xb)); return; }
+    if (which >= 0) { gru_bwd_x3<RNT, false>(a.gru[which], blockIdx.x, XB8(xb)); return; }
     RNN_T4_PRIO();
     t4lstm_bwd_x3<RNT>(a.t4, blockIdx.x, XB8(xb));
     return;
   }
-  if (which < a.ngru) { gru_bwd_body<RNT>(a.gru[which], blockIdx.x, xb); return; }
+  if (which >= 0) { gru_bwd_body<RNT>(a.gru[which], blockIdx.x, xb); return; }
   RNN_T4_PRIO();
   t4lstm_bwd_body<RNT>(a.t4, blockIdx.x, xb);
 }
@@ -1512,9 +1523,6 @@ extern "C" int clsr_rnn_fwd_multi_range(const clsr_gru_desc* grus, int ngru, con
     CLSR_CHECK_LAUNCH();
     return CLSR_OK;
   }
-#ifdef CLSR_WITH_RNN1     // (csrc/experimental/rnn1.hip: one wave per encoder -- measured slower, not in the default build)
-  if (rnn1_supported(m)) return rnn1_launch(m, Hn, false, (hipStream_t)stream);
-#endif
   {   // fused input projection: all encoders or none
     int nfp = (t4 && t4->X) ? 1 : 0;
     for (int i = 0; i < ngru; ++i) nfp += grus[i].X ? 1 : 0;
@@ -1548,9 +1556,6 @@ extern "C" int clsr_rnn_bwd_multi_range(const clsr_gru_desc* grus, int ngru, con
     CLSR_CHECK_LAUNCH();
     return CLSR_OK;
   }
-#ifdef CLSR_WITH_RNN1
-  if (rnn1_supported(m)) return rnn1_launch(m, Hn, true, (hipStream_t)stream);
-#endif
   RNN_LAUNCH(rnn_multi_bwd_kernel, multi_tiles(m), rnn_x3(m.products), dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), stream, m);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
@@ -1560,9 +1565,3 @@ extern "C" int clsr_rnn_bwd_multi(const clsr_gru_desc* grus, int ngru, const cls
                                   const int* seq_len, int len_stride, int Hn, int T, void* stream) {
   return clsr_rnn_bwd_multi_range(grus, ngru, t4, seq_len, len_stride, Hn, T, 0, T, stream);
 }
-
-#ifndef CLSR_WITH_RNN1
-// (1 when the multi launches run recurrences of hidden size n on the one-wave-per-encoder kernels: those live in
-//  csrc/experimental/rnn1.hip and are not part of the default build -- see build.py)
-extern "C" int clsr_rnn_one_wave(int n) { (void)n; return 0; }
-#endif

@@ -1,5 +1,5 @@
 // Argument blocks of the recurrence kernels (csrc/rnn.hip: RNT waves per 16 histories with an LDS exchange per state
-// vector; csrc/rnn1.hip: ONE wave per encoder and 16 histories, no exchange at all).
+// vector).
 #pragma once
 #include "common.h"
 
@@ -68,8 +68,3 @@ struct RnnMultiArgs {
   int has_t4;
   int products;                        // 0 process default | 1 fp32-input MFMA | 2 split-bf16 (csrc/rnn.hip)
 };
-
-
-// csrc/rnn1.hip: 1 when every recurrence of the launch can run on the one-wave-per-encoder kernels
-bool rnn1_supported(const RnnMultiArgs& m);
-int rnn1_launch(const RnnMultiArgs& m, int Hn, bool backward, hipStream_t stream);

@@ -36,7 +36,56 @@ import torch
 
 from clsr_amd import ops
 
-__all__ = ["DataParallel", "allreduce_step_buffers", "allgather_row_lists", "touched_rows_bound"]
+__all__ = ["DataParallel", "HostStagedDist", "allreduce_step_buffers", "allgather_row_lists", "touched_rows_bound"]
+
+
+class HostStagedDist(object):
+    """torch.distributed look-alike that stages GPU tensors through the host (a gloo process group): for rigs whose ranks
+    cannot run RCCL between them -- several ranks sharing ONE GPU (tests/test_dp_gpu.py, ``CLSR_BENCH_TRANSPORT=staged`` of
+    bench.py).  The blocking device-to-host copy on the issuing stream gives every collective the "ordered after that
+    stream's work so far" semantics RCCL has.  Not a production transport."""
+
+    def __init__(self, dist):
+        self._d = dist
+        self.ReduceOp = dist.ReduceOp
+
+    def get_world_size(self, group=None):
+        return self._d.get_world_size()
+
+    def get_rank(self, group=None):
+        return self._d.get_rank()
+
+    class _Done(object):
+        def wait(self):
+            pass
+
+    def all_reduce(self, t, op=None, group=None, async_op=False):
+        c = t.detach().cpu()             # blocking copy on the CURRENT stream: ordered after its work so far
+        self._d.all_reduce(c, op=op)
+        t.copy_(c)
+        return self._Done() if async_op else None
+
+    def all_gather(self, outs, t, group=None):
+        cs = [o.detach().cpu() for o in outs]
+        self._d.all_gather(cs, t.detach().cpu())
+        for o, c in zip(outs, cs):
+            o.copy_(c)
+
+    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None, group=None):
+        co, ci = out.detach().cpu(), inp.detach().cpu().contiguous()
+        self._d.all_to_all_single(co, ci, output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes)
+        out.copy_(co)
+
+    def barrier(self, group=None):
+        self._d.barrier()
+
+    def destroy_process_group(self):
+        self._d.destroy_process_group()
+
+    def broadcast(self, t, src=0, group=None):
+        c = t.detach().cpu()
+        self._d.broadcast(c, src=src)
+        t.copy_(c)
 
 
 def allreduce_step_buffers(dist, dense_grad, tab_grad_flat, tab_flags_flat, small, group=None, grad_flat=None):

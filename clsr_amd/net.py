@@ -1741,10 +1741,8 @@ class CLSRNet(object):
         g2_side = None
         if (not hp.manual_alpha) and hp.predict_long_short:
             d, fs, _ = self._gru_fwd_desc("g2", CL + "causal2/causal2/gru_cell/", H, PinAll, Hn, T, None, training)
-            if (self.split_g2 and self.overlap and (grus or self._t4_scope is not None)
-                    and not (H == Du and query("clsr_rnn_one_wave", H))):
-                # only the alpha gate needs this state: off the critical recurrence launch -- unless the launch
-                # gives every encoder a SIMD of its own (csrc/rnn1.hip): then it costs the others nothing
+            if self.split_g2 and self.overlap and (grus or self._t4_scope is not None):
+                # only the alpha gate needs this state: off the critical recurrence launch
                 g2_side = d
             else:
                 grus.append(d)

@@ -525,8 +525,6 @@ int clsr_rnn_bwd_multi(const clsr_gru_desc* grus, int ngru, const clsr_t4_desc* 
  * (reference call sites clsr.py:161,194,202,210,230) is one T-step loop; run as a chain of ranges -- each launch starting
  * from the state the previous one left -- the results are identical, and the batched input projections of range k + 1 /
  * the weight gradients of range k - 1 run beside the recurrence of range k instead of before / after all of it. */
-/* 1 when the multi launches run recurrences of hidden size n on the one-wave-per-encoder kernels (csrc/rnn1.hip) */
-int clsr_rnn_one_wave(int n);
 int clsr_rnn_fwd_multi_range(const clsr_gru_desc* grus, int ngru, const clsr_t4_desc* t4, const int* seq_len,
                              int len_stride, int Hn, int T, int t0, int t1, void* stream);
 int clsr_rnn_bwd_multi_range(const clsr_gru_desc* grus, int ngru, const clsr_t4_desc* t4, const int* seq_len,

@@ -126,7 +126,7 @@ def main():
         m_, v_ = torch.zeros(Vi, Di, device=dev), torch.zeros(Vi, Di, device=dev)
         fl = torch.zeros(Vi, dtype=torch.uint8, device=dev)
         ss = torch.ones(1, dtype=torch.float64, device=dev)
-        st = torch.tensor([1.0, 0.9, 0.999, 0.0], dtype=torch.float64, device=dev)
+        st = torch.tensor([1.0, 0.9, 0.999, 0.0, 0.0], dtype=torch.float64, device=dev)
         t = timeit(lambda: call("clsr_table_adam_rows", tb, gi, m_, v_, fl, ids, count, nrows, Di, ss, 1, 1, 2.0, st, 0.9, 0.999,
                                 1e-8), iters=22)
         nbytes = nrows * Di * 8 * 4

@@ -128,7 +128,7 @@ def test_lazy_adam_rows_on_a_bf16_table(V, C, nrows):
     flags = torch.zeros(V, dtype=torch.uint8, device=DEV)
     flags[ids.long()] = 1
     sumsq = torch.tensor([float((grad.double() ** 2).sum())], dtype=torch.float64, device=DEV)
-    state = torch.tensor([3.0, 0.9 ** 3, 0.999 ** 3, 1e-3 * (1 - 0.999 ** 3) ** 0.5 / (1 - 0.9 ** 3)],
+    state = torch.tensor([3.0, 0.9 ** 3, 0.999 ** 3, 1e-3 * (1 - 0.999 ** 3) ** 0.5 / (1 - 0.9 ** 3), 0.0],
                          dtype=torch.float64, device=DEV)
     res = []
     for h in (1, 0):

@@ -472,8 +472,8 @@ def test_att_prod_bwd_on_column_blocks(Hn, G, T, Q, col0, ld):
 
 # The recurrences come in two forms (clsr_gru_desc.products, csrc/rnn.hip): "fp32" = fp32-input MFMAs, bit-exact fp32
 # products -- the tolerances below; "x3" = split-bf16 products (16 significand bits per operand, errors compound over the
-# steps) -- ten times those tolerances.  The plain entry points (clsr_gru_fwd ...) always run the fp32 form.
-FORMS = [("fp32", 1.0), ("x3", 10.0)]
+# steps; relative to the float64 oracle on weights of scale 0.3) -- twenty times those tolerances.  The plain entry points (clsr_gru_fwd ...) always run the fp32 form.
+FORMS = [("fp32", 1.0), ("x3", 20.0)]
 
 
 def _scaled_close(tf, exact=()):
@@ -1329,15 +1329,12 @@ def _ranges(T, n):
     return [(k * T // n, (k + 1) * T // n) for k in range(n)]
 
 
-@pytest.mark.parametrize("one_wave", ["0", "1"])
+@pytest.mark.parametrize("form", ["fp32", "x3"])
 @pytest.mark.parametrize("Hn,T,n,nch", [(37, 10, 40, 5), (16, 50, 40, 5), (21, 9, 128, 2), (5, 23, 40, 4)])
-def test_recurrences_as_a_chain_of_time_ranges_equal_one_launch(Hn, T, n, nch, one_wave, monkeypatch):
+def test_recurrences_as_a_chain_of_time_ranges_equal_one_launch(Hn, T, n, nch, form):
     """clsr_rnn_{fwd,bwd}_multi_range over consecutive ranges (state carried through h0 / hT, st_in / st_out, dhT / dh0,
-    dst_in / dst_out) == ONE launch over [0, T): every output bit for bit (same instruction sequence per step); on the
-    split kernels (csrc/rnn.hip) and on the opt-in one-wave-per-encoder kernels (csrc/rnn1.hip)."""
-    monkeypatch.setenv("CLSR_RNN1", one_wave)
-    if one_wave == "1" and query("clsr_rnn_one_wave", 40) != 1:
-        pytest.skip("csrc/experimental/rnn1.hip is not part of the default build")
+    dst_in / dst_out) == ONE launch over [0, T): every output bit for bit (same instruction sequence per step), in both
+    forms of the hidden-to-hidden products."""
     g = torch.Generator().manual_seed(Hn + T)
     f = lambda t: dev(t, torch.float32)
     ldp = 3 * n + 6 * n
@@ -1359,17 +1356,17 @@ def test_recurrences_as_a_chain_of_time_ranges_equal_one_launch(Hn, T, n, nch, o
         for k, (t0, t1) in enumerate(ranges):
             first, last = k == 0, k == len(ranges) - 1
             gd = ops.gru_desc(n, Pin=Pin, ldp=ldp, Wgh=Wgh, ldg=2 * n, Wch=Wch, ldc=n, h0=h0 if first else o["hT"],
-                              h0_stride=n, hT=o["hT"], out_seq=o["seq"], hprev=o["hprev"], gates=o["gates"])
+                              h0_stride=n, hT=o["hT"], out_seq=o["seq"], hprev=o["hprev"], gates=o["gates"], products=form)
             td = ops.t4_desc(n, Pin=Pin[:, 3 * n:], ldp=ldp, Wm=Wm, ldm=4 * n, out_seq=o["out"], act=o["act"], cst=o["cst"],
-                             mprev=o["mprev"], st_in=None if first else st, st_out=None if last else st)
+                             mprev=o["mprev"], st_in=None if first else st, st_out=None if last else st, products=form)
             ops.rnn_multi("clsr_rnn_fwd_multi", [gd], td, d_len, 1, Hn, T, t_range=(t0, t1))
         for k, (t0, t1) in enumerate(reversed(ranges)):
             first, last = k == 0, k == len(ranges) - 1
             gd = ops.gru_desc(n, Wgh=Wgh, ldg=2 * n, Wch=Wch, ldc=n, hprev=o["hprev"], gates=o["gates"],
                               dhT=dhT if first else dhc, dout_seq=dseq_g, dPin=o["dPin"], lddp=ldp,
-                              dh0=o["dh0"] if last else dhc)
+                              dh0=o["dh0"] if last else dhc, products=form)
             td = ops.t4_desc(n, Wm=Wm, ldm=4 * n, act=o["act"], cst=o["cst"], dout_seq=dseq_t, dPin=o["dPin"][:, 3 * n:],
-                             lddp=ldp, dst_in=None if first else dst, dst_out=None if last else dst)
+                             lddp=ldp, dst_in=None if first else dst, dst_out=None if last else dst, products=form)
             ops.rnn_multi("clsr_rnn_bwd_multi", [gd], td, d_len, 1, Hn, T, t_range=(t0, t1))
         torch.cuda.synchronize()
         return o
@@ -1447,82 +1444,6 @@ def test_weight_gradients_over_time_ranges_fill_one_workspace(Hn, T, nch):
     for k, (t0, t1) in enumerate(ranges):
         call("clsr_t4_time_inputs_bwd_range", dTT, TT, tnow, tfirst, T, Hn, T, t0, t1, n, p_rng[sum(tparts[:k]):])
     close(p_rng.sum(0), p_all.sum(0).double(), rtol=1e-4, atol=1e-4 * math.sqrt(M), name="time-feature sums")
-
-
-@pytest.mark.parametrize("Hn,T,n", [(37, 10, 40), (16, 50, 40), (21, 13, 36), (19, 9, 48), (18, 7, 44), (33, 6, 32),
-                                    (17, 11, 24), (5, 9, 16), (20, 5, 8)])
-def test_one_wave_per_encoder_recurrences_equal_the_split_kernels(Hn, T, n, monkeypatch):
-    """With CLSR_RNN1=1 clsr_rnn_{fwd,bwd}_multi runs hidden sizes <= 48 on the one-wave-per-encoder kernels
-    (csrc/rnn1.hip: all feature tiles in one wave, permuted compact last tile, raw buffer addressing); the single-encoder
-    entry points run the RNT-waves kernels of csrc/rnn.hip (LDS exchange per state vector).  Same arithmetic: every
-    output agrees to fp32 rounding of the differently associated sums -- two GRUs (with / without h0, with / without
-    sequence output) + a Time4LSTM in ONE launch, ragged lengths, histories that are not a multiple of 16.  Saved
-    activations are compared on LIVE steps only: the one-wave kernels also store (finite, never used) values for dead
-    steps inside a wave's common range."""
-    monkeypatch.setenv("CLSR_RNN1", "1")
-    if query("clsr_rnn_one_wave", n) != 1:
-        pytest.skip("csrc/experimental/rnn1.hip is not part of the default build (CLSR_EXPERIMENTAL=1 python -m clsr_amd.build)")
-    g = torch.Generator().manual_seed(Hn * 7 + n)
-    f = lambda t: dev(t, torch.float32)
-    ldp = 3 * n + 3 * n + 6 * n
-    Pin = f(rnd(g, Hn * T, ldp))
-    W = [(f(rnd(g, n, 2 * n) * 0.3), f(rnd(g, n, n) * 0.3)) for _ in range(2)]
-    Wm = f(rnd(g, n, 4 * n) * 0.3)
-    h0 = f(rnd(g, Hn, n) * 0.5)
-    lens = torch.randint(1, T + 1, (Hn,), generator=g)
-    lens[0], lens[-1] = T, 1
-    d_len = dev(lens, torch.int32)
-    dhT = [f(rnd(g, Hn, n)), f(rnd(g, Hn, n))]
-    dseq_g, dseq_t = f(rnd(g, Hn, T, n)), f(rnd(g, Hn, T, n))
-    z = lambda *s: torch.full(s, 3.0, device="cuda")
-
-    def bufs():
-        return dict(hT=[z(Hn, n), z(Hn, n)], seq=z(Hn, T, n), hprev=[torch.zeros(Hn, T, n, device="cuda") for _ in range(2)],
-                    gates=[torch.zeros(Hn, T, 3 * n, device="cuda") for _ in range(2)], out=z(Hn, T, n),
-                    act=torch.zeros(Hn, T, 6 * n, device="cuda"), cst=torch.zeros(Hn, T, n, device="cuda"),
-                    mprev=torch.zeros(Hn, T, n, device="cuda"), dPin=z(Hn * T, ldp), dh0=z(Hn, n))
-
-    A, B = bufs(), bufs()
-    # ---- one launch, one wave per encoder
-    g0 = ops.gru_desc(n, Pin=Pin, ldp=ldp, Wgh=W[0][0], ldg=2 * n, Wch=W[0][1], ldc=n, h0=h0, h0_stride=n, hT=A["hT"][0],
-                      hprev=A["hprev"][0], gates=A["gates"][0])
-    g1 = ops.gru_desc(n, Pin=Pin[:, 3 * n:], ldp=ldp, Wgh=W[1][0], ldg=2 * n, Wch=W[1][1], ldc=n, hT=A["hT"][1],
-                      out_seq=A["seq"], hprev=A["hprev"][1], gates=A["gates"][1])
-    td = ops.t4_desc(n, Pin=Pin[:, 6 * n:], ldp=ldp, Wm=Wm, ldm=4 * n, out_seq=A["out"], act=A["act"], cst=A["cst"],
-                     mprev=A["mprev"])
-    ops.rnn_multi("clsr_rnn_fwd_multi", [g0, g1], td, d_len, 1, Hn, T)
-    g0 = ops.gru_desc(n, Wgh=W[0][0], ldg=2 * n, Wch=W[0][1], ldc=n, hprev=A["hprev"][0], gates=A["gates"][0], dhT=dhT[0],
-                      dPin=A["dPin"], lddp=ldp, dh0=A["dh0"])
-    g1 = ops.gru_desc(n, Wgh=W[1][0], ldg=2 * n, Wch=W[1][1], ldc=n, hprev=A["hprev"][1], gates=A["gates"][1], dhT=dhT[1],
-                      dout_seq=dseq_g, dPin=A["dPin"][:, 3 * n:], lddp=ldp)
-    td = ops.t4_desc(n, Wm=Wm, ldm=4 * n, act=A["act"], cst=A["cst"], dout_seq=dseq_t, dPin=A["dPin"][:, 6 * n:], lddp=ldp)
-    ops.rnn_multi("clsr_rnn_bwd_multi", [g0, g1], td, d_len, 1, Hn, T)
-    # ---- the same encoders one by one through the single-encoder entry points (contiguous slices)
-    P0, P1, P2 = (Pin[:, :3 * n].contiguous(), Pin[:, 3 * n:6 * n].contiguous(), Pin[:, 6 * n:].contiguous())
-    call("clsr_gru_fwd", P0, 3 * n, W[0][0], 2 * n, W[0][1], n, h0, n, d_len, 1, Hn, T, n, B["hT"][0], None, B["hprev"][0],
-         B["gates"][0])
-    call("clsr_gru_fwd", P1, 3 * n, W[1][0], 2 * n, W[1][1], n, None, 0, d_len, 1, Hn, T, n, B["hT"][1], B["seq"],
-         B["hprev"][1], B["gates"][1])
-    call("clsr_t4lstm_fwd", P2, 6 * n, Wm, 4 * n, d_len, 1, Hn, T, n, B["out"], B["act"], B["cst"], B["mprev"])
-    dP0, dP1, dP2 = z(Hn * T, 3 * n), z(Hn * T, 3 * n), z(Hn * T, 6 * n)
-    call("clsr_gru_bwd", B["gates"][0], B["hprev"][0], W[0][0], 2 * n, W[0][1], n, d_len, 1, Hn, T, n, dhT[0], None, dP0,
-         B["dh0"])
-    call("clsr_gru_bwd", B["gates"][1], B["hprev"][1], W[1][0], 2 * n, W[1][1], n, d_len, 1, Hn, T, n, dhT[1], dseq_g, dP1,
-         None)
-    call("clsr_t4lstm_bwd", B["act"], B["cst"], Wm, 4 * n, d_len, 1, Hn, T, n, dseq_t, dP2)
-    torch.cuda.synchronize()
-    B["dPin"] = torch.cat([dP0, dP1, dP2], 1)
-    live = (torch.arange(T)[None, :] < lens[:, None]).cuda()[..., None]
-    for i in range(2):
-        close(A["hT"][i], B["hT"][i].double(), rtol=2e-5, atol=2e-6, name="hT[%d]" % i)
-        for k in ("hprev", "gates"):
-            close(A[k][i] * live, (B[k][i] * live).double(), rtol=2e-5, atol=2e-6, name="%s[%d]" % (k, i))
-    for k in ("act", "cst", "mprev"):
-        close(A[k] * live, (B[k] * live).double(), rtol=2e-5, atol=2e-6, name=k)
-    for k in ("seq", "out", "dh0"):
-        close(A[k], B[k].double(), rtol=2e-5, atol=2e-6, name=k)
-    close(A["dPin"], B["dPin"].double(), rtol=1e-4, atol=1e-5, name="dPin")
-    assert float(A["dPin"].abs().max()) > 0 and float(A["out"].abs().max()) > 0
 
 
 @pytest.mark.parametrize("M", [16 * 300, 16 * 257 + 5, 37])

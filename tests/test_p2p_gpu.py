@@ -151,3 +151,64 @@ def test_sync_bn_through_the_p2p_communicator_equals_the_process_group(golden_di
             noise = "b_nn_layer" in k or ("b_nn_output" in k and "fcn_alpha" not in k)
             np.testing.assert_allclose(a[k], c[k], rtol=5e-4, atol=(2.0 if noise else 0.1) * 3 * float(hp.learning_rate),
                                        err_msg="fused heads: " + k)
+
+
+def _abort_worker(out):
+    """ONE process that plays rank 0 of a two-rank communicator whose peer never pushes: the all-reduce must give up after
+    CLSR_P2P_TIMEOUT_S, raise the sticky error word AND the abort flag, return NaN instead of a partial sum, and every
+    optimiser kernel must then leave parameters and moments alone until the host clears the flag."""
+    import ctypes
+
+    os.environ["CLSR_P2P_TIMEOUT_S"] = "0.05"        # (read once per process: set before the first call)
+    from clsr_amd import _lib, ops
+
+    torch.cuda.set_device(0)
+    lib = _lib.load()
+    bufs = (ctypes.c_void_p * 2)()
+    for r in range(2):
+        b = ctypes.c_void_p()
+        _lib.check(lib.clsr_comm_alloc(ctypes.byref(b)), "clsr_comm_alloc")
+        bufs[r] = b
+    comm = ctypes.c_void_p()
+    _lib.check(lib.clsr_comm_create(0, 2, bufs, ctypes.byref(comm)), "clsr_comm_create")
+    st = torch.tensor([0.0, 1.0, 1.0, 0.0, 0.0], dtype=torch.float64, device="cuda")      # Adam state: [4] = abort flag
+    _lib.check(lib.clsr_comm_set_abort(comm, ctypes.c_void_p(st[4:].data_ptr())), "clsr_comm_set_abort")
+    x = torch.arange(1, 9, dtype=torch.float64, device="cuda")
+    ops.call("clsr_allreduce_small", comm.value, x, 8)
+    torch.cuda.synchronize()
+    out["nan"] = bool(torch.isnan(x).all())
+    out["err"] = int(lib.clsr_comm_error(comm))
+    out["flag"] = float(st[4])
+    # an optimiser kernel under the raised flag: nothing moves
+    n = 1024
+    p, g = torch.randn(n, device="cuda"), torch.randn(n, device="cuda")
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    seg = torch.zeros(n, dtype=torch.int32, device="cuda")
+    sumsq = torch.ones(1, dtype=torch.float64, device="cuda")
+    ops.call("clsr_adam_tick", st, 1e-3, 0.9, 0.999)
+    p0 = p.clone()
+    ops.call("clsr_dense_adam", p, g, m, v, seg, sumsq, 0.0, st, 0.9, 0.999, 1e-8, n)
+    torch.cuda.synchronize()
+    out["frozen"] = bool(torch.equal(p, p0) and float(m.abs().max()) == 0.0 and float(v.abs().max()) == 0.0)
+    st[4] = 0.0                                       # the host clears the flag after reporting: updates resume
+    ops.call("clsr_dense_adam", p, g, m, v, seg, sumsq, 0.0, st, 0.9, 0.999, 1e-8, n)
+    torch.cuda.synchronize()
+    out["resumed"] = bool(not torch.equal(p, p0) and float(m.abs().max()) > 0.0)
+    lib.clsr_comm_destroy(comm)
+    for r in range(2):
+        lib.clsr_comm_free(bufs[r])
+
+
+def test_all_reduce_that_gives_up_aborts_the_step():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as man:
+        out = man.dict()
+        p = ctx.Process(target=_abort_worker, args=(out,))
+        p.start()
+        p.join(120)
+        assert p.exitcode == 0
+        assert out["nan"], "a timed-out all-reduce must not return a partial sum"
+        assert out["err"] == 1 and out["flag"] != 0.0
+        assert out["frozen"] and out["resumed"]
