@@ -61,7 +61,7 @@ class HostStagedDist(object):
 
     def all_reduce(self, t, op=None, group=None, async_op=False):
         c = t.detach().cpu()             # blocking copy on the CURRENT stream: ordered after its work so far
-        self._d.all_reduce(c, op=op)
+        self._d.all_reduce(c, op=self.ReduceOp.SUM if op is None else op)
         t.copy_(c)
         return self._Done() if async_op else None
 
