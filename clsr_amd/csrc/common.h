@@ -54,6 +54,11 @@ long long clsr_p2p_timeout_ticks(void);   // csrc/p2p.hip: bounded waits of the 
 
 static inline int clsr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Partial chunk of a weight gradient (csrc/linear.hip: pgemm_dw_kernel; summed by clsr_dw_reduce_batch): 5 x 5 tiles of
+// 16 x 16 (tile (kt, nt) at (kt * 5 + nt) * 256, element (k & 15) * 16 + (n & 15)) followed by 5 x 16 bias sums
+#define CLSR_DW_T 5
+#define CLSR_DW_CHUNK (CLSR_DW_T * CLSR_DW_T * 256 + CLSR_DW_T * 16)
+
 #ifdef __HIPCC__
 // ---- wave64 reductions -------------------------------------------------------------
 // float sums / maxima run on the DPP path: row_shr 1/2/4/8 = inclusive scan inside each row of 16 lanes, row_bcast 15 /

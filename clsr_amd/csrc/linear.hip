@@ -862,8 +862,8 @@ extern "C" int clsr_pack_batch(const clsr_pack_desc* descs_device, int n, int ma
 // positions.  Every wave owns a full 80x80 (5x5 tile) accumulator chunk and a strided subset of
 // the positions; per-wave partial chunks go to `partial` and are summed deterministically by
 // clsr_dw_reduce (no float atomics on the weights).
-#define DW_T 5
-#define DW_CHUNK (DW_T * DW_T * 256 + DW_T * 16)
+#define DW_T CLSR_DW_T
+#define DW_CHUNK CLSR_DW_CHUNK
 
 struct DwArgs {
   const void* X; int ldx; int T; int G; const float* Xmul; int ldmul;   // X / dY: fp32, or bf16 (XH / YH variants)

@@ -167,6 +167,12 @@ class CLSRNet(object):
             raise ValueError("CLSR_RNN_PRODUCTS must be 'x3' or 'fp32'")
         self.rnn_fused_proj = self.rnn_products == "x3" and not os.environ.get("CLSR_NO_RNN_FUSED_PROJ")
         self.rnn_act_tiled = self.rnn_products == "x3" and not os.environ.get("CLSR_NO_RNN_ACT_TILED")
+        # Attention-MLP backward (exact mode): "x3" = the two-pass layer-1 kernel and the one-pass layer-0 kernel as split-bf16
+        # products with the weight gradients dW1 / db1 / dWp accumulated inside them (csrc/attbwdx3.hip: no separate
+        # weight-gradient launches, no stored dz1); "fp32" = the fp32-MFMA kernels + clsr_pgemm_dw_partial beside them
+        self.att_bwd = os.environ.get("CLSR_ATT_BWD", "x3")
+        if self.att_bwd not in ("x3", "fp32"):
+            raise ValueError("CLSR_ATT_BWD must be 'x3' or 'fp32'")
         self.fuse_tt = not os.environ.get("CLSR_NO_FUSE_TT")   # A/B: time-gate blocks of the input projection as one product over [hist | TT]
         # the row-level heads (alpha gate, alpha / logit MLPs, loss, their backward) as two persistent launches with grid
         # barriers for the batch-norm statistics (csrc/headsfused.hip) instead of a chain of 22 dependent launches
@@ -757,6 +763,14 @@ class CLSRNet(object):
         else:
             call("clsr_pgemm_dw_partial", X, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, ldy, M, K, N, ws, stream=stream)
 
+    def _dw_fused(self, ws, parts, K, N, dW, ldw, db=None, acc=0):
+        """A weight gradient whose ``parts`` partial chunks were written by the back-propagating kernel itself
+        (csrc/attbwdx3.hip) on the CURRENT stream: only the entry of the batched reduction is left."""
+        self._dw_pending.setdefault(self._ws_tag, []).append(
+            (ws.data_ptr(), dW.data_ptr(), db.data_ptr() if db is not None else 0, 1.0, parts, K, N, ldw, acc))
+        if not self.defer_dw:
+            self._dw_flush()
+
     def _rp(self, partial, parts, stride, n, out):
         """out[0:n] = sum over ``parts`` per-block partial rows (deferred to ``_dw_flush`` like the dW reductions;
         the partial buffer must stay untouched until then)."""
@@ -1293,7 +1307,22 @@ class CLSRNet(object):
                 call("clsr_att_prod_bwd_h", daq, Q, a, Q, q, Q, Hn, G, T, Q, da, Q, dq, Q, 0)
                 call("clsr_att_z0_bwd_reduce_h", dz0, Hn, G, T, A0, dU, dV)
             return self._att_bwd_hist(key, scope, nn, a, q, keys, dkeys, dU, dV, da, dq, dW0, Hn, R, T, Dk, Q, 0)
-        if self.l1_bwd_2pass and query("clsr_att_l1_bwd_supported", A1, A0):
+        x3b = self.att_bwd == "x3"
+        if x3b and self.l1_bwd_2pass and query("clsr_att_l1_bwd_x3_supported", A1, A0):
+            # the same two passes as split-bf16 products; pass 2 also accumulates dW1 / db1 (dz1 is never stored)
+            M = R * T
+            Wt, Kp = self.packed[key + ".W1^T"]
+            parts = query("clsr_att_l1_bwd_x3_parts", M)
+            st = self._buf("stats" + self._ws_tag, 1024 * 2 * 256, dtype=torch.float64)[: parts * 2 * A0]
+            wo = P[nn + "w_nn_output"]
+            call("clsr_att_l1_bwd_x3", z1, A1, ds, bn1.scale, bn1.shift, wo, bn1.coef, Wt, Kp, z0, A0, bn0.scale,
+                 bn0.shift, bn0.mean, bn0.invstd, None, None, 0, None, st, M, A1, A0)
+            self._bn_bwd_coef(bn0, st, parts, M)
+            ws = self._buf(key + ".dw1x_ws", parts * query("clsr_dw_chunk_floats"))
+            call("clsr_att_l1_bwd_x3", z1, A1, ds, bn1.scale, bn1.shift, wo, bn1.coef, Wt, Kp, z0, A0, bn0.scale,
+                 bn0.shift, None, None, bn0.coef, dz0, A0, ws, None, M, A1, A0)
+            self._dw_fused(ws, parts, A0, A1, Gd[nn + "w_nn_layer1"], A1, db=Gd[nn + "b_nn_layer1"])
+        elif self.l1_bwd_2pass and query("clsr_att_l1_bwd_supported", A1, A0):
             # two passes over (z1, z0) with dz1 recomputed in the GEMM prologue: the batch-norm sums of layer 0, then the
             # finished dz0 (+ dz1 for the weight gradient) -- no dy1-apply / bn-apply sweeps (csrc/attl1bwd.hip)
             M = R * T
@@ -1315,10 +1344,21 @@ class CLSRNet(object):
         # layer 0 (re-associated): z0 = U[h,t] + V[r] + (a[h,t]*q[r]) . Wp
         if qh:
             Q2 = Q - qh
-            self._dw(a[:, qh:], Q, dz0, A0, R * T, Q2, A0, dW0[3 * Q + qh:4 * Q], A0, T=T, G=G, Xmul=q[:, qh:],
-                     ldmul=Q)
+            l0x3 = x3b and self.fused_l0_bwd and query("clsr_att_l0_bwd_x3_supported", G, Q2, A0)
+            if not l0x3:
+                self._dw(a[:, qh:], Q, dz0, A0, R * T, Q2, A0, dW0[3 * Q + qh:4 * Q], A0, T=T, G=G, Xmul=q[:, qh:],
+                         ldmul=Q)
             dU = self._buf(key + ".dU", Hn * T, A0)
-            if self.fused_l0_bwd and query("clsr_att_l0_bwd_supported", G, Q2, A0):
+            if l0x3:
+                # the same pass as split-bf16 products, with the partial sums of dWp[qh:] (csrc/attbwdx3.hip)
+                Wt, Kp = self.packed[key + ".Wp2^T"]
+                parts = query("clsr_att_l0_bwd_x3_parts", Hn)
+                ws = self._buf(key + ".dwpx_ws", parts * query("clsr_dw_chunk_floats"))
+                call("clsr_att_l0_bwd_x3", dz0, A0, Wt, Kp, a[:, qh:], Q, q[:, qh:], Q, Hn, G, T, Q2, A0, da[:, qh:], Q,
+                     dq[:, qh:], Q, dU, A0, dV, A0, ws)
+                self._dw_fused(ws, parts, Q2, A0, dW0[3 * Q + qh:4 * Q], A0)
+                self._gemm(dV, A0, key + ".Wv^T", R, A0, Q, dq, Q, acc=1)
+            elif self.fused_l0_bwd and query("clsr_att_l0_bwd_supported", G, Q2, A0):
                 # per-row half in one pass over dz0 (csrc/hattbwd.hip): da / dq of the target columns, dU, dV; then the V
                 # path over ALL query columns is added (dq[:, :qh] was cleared with the step's accumulators)
                 Wt, Kp = self.packed[key + ".Wp2^T"]
@@ -1339,9 +1379,18 @@ class CLSRNet(object):
             self._gemm(dU, A0, key + ".Wp1^T", Hn * T, A0, qh, daq1, qh)
             call("clsr_att_prod_bwd_ld", daq1, qh, a, Q, q_hist, qh, Hn, 1, T, qh, da, Q, dq_hist, qh, 1)
         else:
-            self._dw(a, Q, dz0, A0, R * T, Q, A0, dW0[3 * Q:4 * Q], A0, T=T, G=G, Xmul=q, ldmul=Q)
+            l0x3 = x3b and self.fused_l0_bwd and query("clsr_att_l0_bwd_x3_supported", G, Q, A0)
+            if not l0x3:
+                self._dw(a, Q, dz0, A0, R * T, Q, A0, dW0[3 * Q:4 * Q], A0, T=T, G=G, Xmul=q, ldmul=Q)
             dU = dz0 if G == 1 else self._buf(key + ".dU", Hn * T, A0)
-            if self.fused_l0_bwd and query("clsr_att_l0_bwd_supported", G, Q, A0):
+            if l0x3:
+                Wt, Kp = self.packed[key + ".Wp^T"]
+                parts = query("clsr_att_l0_bwd_x3_parts", Hn)
+                ws = self._buf(key + ".dwpx_ws", parts * query("clsr_dw_chunk_floats"))
+                call("clsr_att_l0_bwd_x3", dz0, A0, Wt, Kp, a, Q, q, Q, Hn, G, T, Q, A0, da, Q, dq, Q,
+                     None if G == 1 else dU, A0, dV, A0, ws)
+                self._dw_fused(ws, parts, Q, A0, dW0[3 * Q:4 * Q], A0)
+            elif self.fused_l0_bwd and query("clsr_att_l0_bwd_supported", G, Q, A0):
                 # da, dq, dU, dV in one pass over dz0 on the fp32 matrix pipe; daq = dz0 . Wp^T is never written
                 Wt, Kp = self.packed[key + ".Wp^T"]
                 call("clsr_att_l0_bwd", dz0, A0, Wt, Kp, a, Q, q, Q, Hn, G, T, Q, A0, da, Q, dq, Q,

@@ -346,6 +346,31 @@ int clsr_att_l0_bwd_supported(int G, int Q, int A0);
 int clsr_att_l0_bwd(const float* dz0, int lddz, const float* Wt, int Kp, const float* a, int lda,
                     const float* q, int ldq, long Hn, int G, int T, int Q, int A0, float* da, int ldda,
                     float* dq, int lddq, float* dU, int lddu, float* dV, int lddv, void* stream);
+/* The same pass over dz0 with every product as a split-bf16 product (x.y ~ xh.yh + xh.yl + xl.yh on the bf16 matrix pipe,
+ * fp32 accumulation: 2^-16 relative per term) AND the weight gradient of the product term folded in (csrc/attbwdx3.hip):
+ *   dWp[c, n] = sum_{r,t} a[h,t,c] q[r,c] dz0[r,t,n]   as clsr_att_l0_bwd_x3_parts(Hn) partial chunks in the layout of
+ * clsr_pgemm_dw_partial (summed by clsr_dw_reduce_batch with nparts = that count) -- the separate weight-gradient launch
+ * and its re-read of dz0 / a / q are gone (reference: tf.gradients through clsr.py:368-370). */
+int clsr_dw_chunk_floats(void);   /* floats per partial chunk of a weight gradient (5 x 5 tiles of 16 x 16 + 5 x 16 bias sums) */
+int clsr_att_l0_bwd_x3_supported(int G, int Q, int A0);
+int clsr_att_l0_bwd_x3_parts(long Hn);
+int clsr_att_l0_bwd_x3(const float* dz0, int lddz, const float* Wt, int Kp, const float* a, int lda,
+                       const float* q, int ldq, long Hn, int G, int T, int Q, int A0, float* da, int ldda,
+                       float* dq, int lddq, float* dU, int lddu, float* dV, int lddv, float* dwp_partial,
+                       void* stream);
+/* Second attention layer + the batch-norm / ReLU below it, backward, as split-bf16 products with the weight gradient of
+ * the layer folded into pass 2 (csrc/attbwdx3.hip; arguments as clsr_att_l1_bwd):
+ *   coef0 == NULL: pass 1, stats = [clsr_att_l1_bwd_x3_parts(M)][2][C0] partial sums of dy0 and dy0 * xhat0;
+ *   coef0 given:   pass 2, dz0 = c1*dy0 + c2*z0 + c3 and dw1_partial = clsr_att_l1_bwd_x3_parts(M) partial chunks (layout
+ *                  of clsr_pgemm_dw_partial, bias sums included) of dW1 = relu(bn0(z0))^T dz1, db1 = sum dz1 -- dz1 itself
+ *                  is not stored.  (reference: tf.gradients through _fcn_net, base_model.py:664-706) */
+int clsr_att_l1_bwd_x3_supported(int C1, int C0);
+int clsr_att_l1_bwd_x3_parts(int M);
+int clsr_att_l1_bwd_x3(const float* z1, int ldz1, const float* ds, const float* scale1, const float* shift1,
+                       const float* w_out, const float* coef1, const float* Wt, int Kp, const float* z0, int ldz0,
+                       const float* scale0, const float* shift0, const float* mean0, const float* invstd0,
+                       const float* coef0, float* dz0, int lddz0, float* dw1_partial, double* stats, int M, int C1,
+                       int C0, void* stream);
 /* clsr_hgemm_mul_uv with one wave per history group (a, U read once per 16 steps of a history and re-used for its G
  * rows; same packed bf16 weights image, same statistics layout with clsr_hgemm_l0_group_stats_parts(Hn) partial rows) */
 int clsr_hgemm_l0_group_supported(int G, int Q, int A0);
