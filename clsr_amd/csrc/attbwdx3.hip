@@ -27,8 +27,12 @@
 #ifndef X3_OCC
 #define X3_OCC 1
 #endif
-#ifndef X3_RING
-#define X3_RING 4
+// ablation switches (scripts/abl_att_l0x3.sh): 0 removes the piece from the layer-0 kernel
+#ifndef X3A_DW
+#define X3A_DW 1
+#endif
+#ifndef X3A_STORE
+#define X3A_STORE 1
 #endif
 
 __device__ __forceinline__ bf16x4 to_h4(f32x4 v) { return __builtin_convertvector(v, bf16x4); }
@@ -42,6 +46,33 @@ __device__ __forceinline__ void split8x(f32x8 v, bf16x8& hi, bf16x8& lo) {
   lo = to_h(v - to_f(hi));
 }
 __device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+
+typedef __amdgpu_buffer_rsrc_t x3_rsrc_t;
+#define X3_OOB 0x80000000u
+// keeps the scheduler from hoisting every tile's LDS reads / epilogue arithmetic to the top of the iteration (with 512
+// registers to fill it does, and then spills)
+#ifdef X3_NO_SCHED_FENCE
+#define X3_SCHED_FENCE()
+#else
+#define X3_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+__device__ __forceinline__ x3_rsrc_t x3_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, X3_OOB, 0x00020000);
+}
+// resource over exactly n bytes: any offset >= n (a skip marker, alone or summed with another one) is dropped / reads 0
+__device__ __forceinline__ x3_rsrc_t x3_rsrc_n(const void* p, unsigned nbytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, nbytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 x3_ld4(x3_rsrc_t rs, unsigned off, unsigned soff) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, soff, 0));
+}
+__device__ __forceinline__ float x3_ld1(x3_rsrc_t rs, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+}
+__device__ __forceinline__ void x3_st1(x3_rsrc_t rs, unsigned off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, off, 0, 0);
+}
 
 // ------------------------------------------------------------------------------------------------ layer 0
 //   z0[r,t,:] = U[h,t,:] + V[r,:] + (a[h,t,:] * q[r,:]) . Wp
@@ -70,7 +101,6 @@ __global__ void __launch_bounds__(256, X3_OCC) att_l0_bwd_x3_kernel(AttL0BwdArgs
   constexpr int KT = (NZ + 1) / 2;          // 32-wide k chunks of A0
   constexpr int QP = 16 * NF, ZP = 16 * NZ;
   constexpr int WS = 32 * KT + 8;           // bf16 row stride of the weight images (52 / 36 dwords: conflict-free 16-byte reads)
-  constexpr int RING = X3_RING;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int j = lane & 15, g4 = lane >> 4;
   __bf16* Wh = reinterpret_cast<__bf16*>(lds_raw);
@@ -94,9 +124,7 @@ __global__ void __launch_bounds__(256, X3_OCC) att_l0_bwd_x3_kernel(AttL0BwdArgs
   __syncthreads();
 
   // B operands: weights of query-feature tile f, lane (j, g4) reads row 16f + j, k = 32kt + 8g4 + {0..7}
-  int wrow[NF];
-#pragma unroll
-  for (int f = 0; f < NF; ++f) wrow[f] = (16 * f + j) * WS + 8 * g4;
+  const int wrow = j * WS + 8 * g4;          // + 16 f WS + 32 kt
   // identity blocks: feature tile z of dz0 lives in k chunk z/2, columns 16 (z&1) + j -> lane group 2 (z&1) + (j>>3), slot j&7
   bf16x8 sel[2];
 #pragma unroll
@@ -108,7 +136,24 @@ __global__ void __launch_bounds__(256, X3_OCC) att_l0_bwd_x3_kernel(AttL0BwdArgs
   const int NTT = (T + 15) >> 4;
   const int n_it = NTT * G;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const f32x8 z8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bf16x4 zh4 = {};
+  // Every global access of the main loop is a raw buffer access (resource = the rows of the wave's history, exact size):
+  // a lane that must not read / write gets an offset component of X3_SKIP -- out of range alone and in any sum of two -- so
+  // that no load or store sits under a branch (190 guarded stores cost ~740 exec-mask instructions per four iterations),
+  // and the address arithmetic is one 32-bit add per access.
+  constexpr unsigned X3_SKIP = 0x40000000u;
+  unsigned kofs[KT];                         // dz0: byte offset of the lane's 8 features of chunk kt
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) kofs[kt] = 32 * kt + 8 * g4 < s.A0 ? (32 * kt + 8 * g4) * 4u : X3_SKIP;   // (skipped: reads 0)
+  unsigned aofs[NF], dao[NF], duo[NZ];       // a (read, clamped), da / dU (written: skipped beyond the width)
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    aofs[f] = (16 * f + j < s.Q ? 16 * f + j : 0) * 4u;
+    dao[f] = 16 * f + j < s.Q ? (16 * f + j) * 4u : X3_SKIP;
+  }
+#pragma unroll
+  for (int z = 0; z < NZ; ++z) duo[z] = 16 * z + j < s.A0 ? (16 * z + j) * 4u : X3_SKIP;
 
   f32x4 accW[NF][NZ];
 #pragma unroll
@@ -126,28 +171,39 @@ __global__ void __launch_bounds__(256, X3_OCC) att_l0_bwd_x3_kernel(AttL0BwdArgs
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
 
+    const x3_rsrc_t rdz = x3_rsrc_n(s.dz0 + h * G * T * s.lddz, (unsigned)(G * T * s.lddz) * 4u);
+    const x3_rsrc_t ra = x3_rsrc_n(s.a + h * T * s.lda, (unsigned)(T * s.lda) * 4u);
+    const x3_rsrc_t rda = x3_rsrc_n(s.da + h * T * s.ldda, (unsigned)(T * s.ldda) * 4u);
+    const x3_rsrc_t rdu = x3_rsrc_n(s.dU ? s.dU + h * T * s.lddu : nullptr, s.dU ? (unsigned)(T * s.lddu) * 4u : 0u);
+
     // dz0 tiles of iteration i = (tt, g) in A-operand order: lane (position j, g4) holds features 32kt + 8g4 + {0..7}
     struct Raw { f32x8 x[KT]; };
     int itt = 0, ig = 0;
+    unsigned rowoff = (unsigned)(min(j, T - 1) * s.lddz) * 4u;          // lane's row of tile itt inside a [T, lddz] block
     auto issue = [&]() -> Raw {
-      const int tc = min(16 * itt + j, T - 1);
-      const float* p = s.dz0 + ((h * G + ig) * T + tc) * s.lddz;
+      const unsigned blk = (unsigned)(ig * T * s.lddz) * 4u;             // (uniform)
       Raw r;
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) r.x[kt] = ld8f(p + (32 * kt + 8 * g4 < s.A0 ? 32 * kt + 8 * g4 : 0));
-      if (++ig == G) { ig = 0; if (itt + 1 < NTT) ++itt; }   // clamps at the last tile (surplus loads are never used)
+      for (int kt = 0; kt < KT; ++kt) {
+        const f32x4 lo = x3_ld4(rdz, rowoff + kofs[kt], blk), hi = x3_ld4(rdz, rowoff + kofs[kt] + 16u, blk);
+        r.x[kt] = (f32x8){lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      }
+      if (++ig == G) {
+        ig = 0;
+        if (itt + 1 < NTT) { ++itt; rowoff = (unsigned)(min(16 * itt + j, T - 1) * s.lddz) * 4u; }   // (clamps at the last tile)
+      }
       return r;
     };
-    Raw ring[RING];
-#pragma unroll
-    for (int d = 0; d < RING; ++d) ring[d] = issue();
+    Raw ring[2];
+    ring[0] = issue();
+    ring[1] = issue();
 
     int ctt = 0, cg = 0;
     f32x4 at[NF], dacc[NF], uacc[NZ];
     bf16x4 sah[NF], sal[NF], sbh[NZ], sbl[NZ];     // first half of a pair: (a*q) and dz0 in feature-lane layout, hi / lo
-    for (int i0 = 0; i0 < n_it; i0 += RING) {
+    for (int i0 = 0; i0 < n_it; i0 += 2) {
 #pragma unroll
-      for (int d = 0; d < RING; ++d) {
+      for (int d = 0; d < 2; ++d) {
         const bool live = i0 + d < n_it;            // (uniform)
         bf16x4 cah[NF], cal[NF], cbh[NZ], cbl[NZ];
 #pragma unroll
@@ -156,27 +212,27 @@ __global__ void __launch_bounds__(256, X3_OCC) att_l0_bwd_x3_kernel(AttL0BwdArgs
         for (int z = 0; z < NZ; ++z) { cbh[z] = zh4; cbl[z] = zh4; }
         if (live) {
           const int t0 = 16 * ctt;
-          if (cg == 0) {
+          if (cg == 0) {   // new tile: a[h, t, :] in the result layout (4 positions of feature 16f + j), accumulators
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
-              const int n = 16 * f + j;
-              const int nc = n < s.Q ? n : 0;
+            for (int e = 0; e < 4; ++e) {
+              const unsigned ro = (unsigned)(min(t0 + 4 * g4 + e, T - 1) * s.lda) * 4u;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const int tc = min(t0 + 4 * g4 + e, T - 1);
-                at[f][e] = s.a[(h * T + tc) * s.lda + nc];
-              }
-              dacc[f] = z4;
+              for (int f = 0; f < NF; ++f) at[f][e] = x3_ld1(ra, ro + aofs[f]);
             }
+#pragma unroll
+            for (int f = 0; f < NF; ++f) dacc[f] = z4;
 #pragma unroll
             for (int z = 0; z < NZ; ++z) uacc[z] = z4;
           }
-          const bool pv = t0 + j < T;
+          // A operands (rows beyond T are duplicates of step T-1 -> zero them; features beyond A0 were not read: zeros)
           bf16x8 xh[KT], xl[KT];
+          if (t0 + 16 <= T) {
 #pragma unroll
-          for (int kt = 0; kt < KT; ++kt) {
-            const f32x8 z8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            split8x((pv && 32 * kt + 8 * g4 < s.A0) ? ring[d].x[kt] : z8, xh[kt], xl[kt]);
+            for (int kt = 0; kt < KT; ++kt) split8x(ring[d].x[kt], xh[kt], xl[kt]);
+          } else {
+            const bool pv = t0 + j < T;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) split8x(pv ? ring[d].x[kt] : z8, xh[kt], xl[kt]);
           }
           ring[d] = issue();
           // daq^T tiles: acc[f] = dz0 . Wp^T, 4 positions of query feature 16f + j
@@ -187,7 +243,10 @@ __global__ void __launch_bounds__(256, X3_OCC) att_l0_bwd_x3_kernel(AttL0BwdArgs
           for (int kt = 0; kt < KT; ++kt) {
             bf16x8 wh[NF], wlo[NF];
 #pragma unroll
-            for (int f = 0; f < NF; ++f) { wh[f] = ld8h(Wh + wrow[f] + 32 * kt); wlo[f] = ld8h(Wl + wrow[f] + 32 * kt); }
+            for (int f = 0; f < NF; ++f) {
+              wh[f] = ld8h(Wh + wrow + 16 * f * WS + 32 * kt);
+              wlo[f] = ld8h(Wl + wrow + 16 * f * WS + 32 * kt);
+            }
 #pragma unroll
             for (int f = 0; f < NF; ++f) HMFMA(acc[f], xh[kt], wlo[f]);
 #pragma unroll
@@ -206,6 +265,9 @@ __global__ void __launch_bounds__(256, X3_OCC) att_l0_bwd_x3_kernel(AttL0BwdArgs
             cbl[z] = to_h4(tl);
             dzt[z] = th + tl;
           }
+          // sums over the 16 positions of the tile: three adds inside a lane, then the four lane groups are summed by the
+          // fp32 matrix pipe (ones[16x4] . partial[4x16]); lane group g4 then owns feature tile 4c + g4 of the accumulators.
+          // (per-lane partial slots + ds_add_f32 instead measured 297 against 179 us for the kernel)
           float sq[NF], sv[NZ];
 #pragma unroll
           for (int f = 0; f < NF; ++f) {
@@ -236,30 +298,26 @@ __global__ void __launch_bounds__(256, X3_OCC) att_l0_bwd_x3_kernel(AttL0BwdArgs
               if (c + o < NZ) v = g4 == o ? sv[c + o] : v;
             if (c + g4 < NZ) dvs[cg * ZP + 16 * (c + g4) + j] += v;
           }
-          if (cg == G - 1) {
+          if (X3A_STORE && cg == G - 1) {   // tile finished: da, dU of its 16 steps
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int t = t0 + 4 * g4 + e;
-              if (t < T) {
+              const unsigned ra_ = t < T ? (unsigned)(t * s.ldda) * 4u : X3_SKIP;
+              const unsigned ru_ = t < T ? (unsigned)(t * s.lddu) * 4u : X3_SKIP;
 #pragma unroll
-                for (int f = 0; f < NF; ++f)
-                  if (16 * f + j < s.Q) s.da[(h * T + t) * s.ldda + 16 * f + j] = dacc[f][e];
-                if (s.dU) {
+              for (int f = 0; f < NF; ++f) x3_st1(rda, ra_ + dao[f], dacc[f][e]);
 #pragma unroll
-                  for (int z = 0; z < NZ; ++z)
-                    if (16 * z + j < s.A0) s.dU[(h * T + t) * s.lddu + 16 * z + j] = uacc[z][e];
-                }
-              }
+              for (int z = 0; z < NZ; ++z) x3_st1(rdu, ru_ + duo[z], uacc[z][e]);
             }
           }
           if (++cg == G) { cg = 0; ++ctt; }
         }
-        if ((d & 1) == 0) {
+        if (d == 0) {
 #pragma unroll
           for (int f = 0; f < NF; ++f) { sah[f] = cah[f]; sal[f] = cal[f]; }
 #pragma unroll
           for (int z = 0; z < NZ; ++z) { sbh[z] = cbh[z]; sbl[z] = cbl[z]; }
-        } else if (i0 + d - 1 < n_it) {
+        } else if (X3A_DW) {
           // weight gradient of the pair: k = the 8 positions a lane holds of its feature (4 of each iteration)
           bf16x8 bh[NZ], bl[NZ];
 #pragma unroll
@@ -404,25 +462,6 @@ struct L1BwdArgsX {
   double* stats;                 // pass 1: [gridDim.x][2][C0]
   int M, C1, C0;
 };
-
-typedef __amdgpu_buffer_rsrc_t x3_rsrc_t;
-#define X3_OOB 0x80000000u
-// keeps the scheduler from hoisting every tile's LDS reads / epilogue arithmetic to the top of the iteration (with 512
-// registers to fill it does, and then spills)
-#ifdef X3_NO_SCHED_FENCE
-#define X3_SCHED_FENCE()
-#else
-#define X3_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
-__device__ __forceinline__ x3_rsrc_t x3_rsrc(const void* p) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, X3_OOB, 0x00020000);
-}
-__device__ __forceinline__ float x3_ld1(x3_rsrc_t rs, unsigned off) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
-}
-__device__ __forceinline__ void x3_st1(x3_rsrc_t rs, unsigned off, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, off, 0, 0);
-}
 
 template <int OT, int NC, bool APPLY>
 __global__ void __launch_bounds__(256, 1) att_l1_bwd_x3_kernel(L1BwdArgsX a) {

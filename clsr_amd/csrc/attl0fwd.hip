@@ -14,6 +14,7 @@
 // 3.4 in pgemm_fast_kernel); matrix pipe busy 63 % of the CU-busy time.
 #include "common.h"
 #include "clsr_hip.h"
+#include "hmma.h"
 
 #define AF_GMAX 8
 
@@ -30,22 +31,52 @@ struct AttL0FwdArgs {
 };
 
 // NZ = 16-feature tiles of A0 (outputs), NK = 16-wide chunks of Q (reduction)
-template <int NZ, int NK>
+// X3: the product as split-bf16 sums (a*q)h.Wh + (a*q)h.Wl + (a*q)l.Wh on v_mfma_f32_16x16x32_bf16 (fp32 accumulators that
+// start from U + V: 2^-16 relative per product term).  The fp32 kernel is bound by the matrix pipe (100 fp32 MFMAs of 32
+// cycles per 16 x 80 tile, 0.57 of the fp32 matrix peak); with 30 bf16 MFMAs of ~17 cycles it is bound by its stores.  A
+// K = 32 chunk c takes the two 16-wide chunks 2c, 2c + 1 of the fp32 kernel side by side (k slot (g4, e) = feature
+// 32c + 16 (e >> 2) + 4 g4 + (e & 3): the loads of the A operand are the same float4 pairs), the bf16 hi / lo images of the
+// weights are laid out in LDS in that slot order.
+template <int NZ, int NK, bool X3>
 __global__ void __launch_bounds__(256, 2) att_l0_fwd_kernel(AttL0FwdArgs s) {
   CLSR_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int ZP = 16 * NZ, QP = 16 * NK;
+  constexpr int NC = (NK + 1) / 2, WS = 32 * NC + 8;      // X3: K = 32 chunks, bf16 row stride (conflict-free 16-byte reads)
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int j = lane & 15, g4 = lane >> 4;
   const int Kp = s.Kp;
   float* Wl = reinterpret_cast<float*>(lds_raw);
-  float* wl = Wl + (size_t)ZP * Kp + (size_t)wave * AF_GMAX * (QP + ZP);
+  __bf16* Wh = reinterpret_cast<__bf16*>(lds_raw);
+  __bf16* Wlo = Wh + ZP * WS;
+  const size_t wfloats = X3 ? (size_t)ZP * WS : (size_t)ZP * Kp;      // (2 images x ZP x WS bf16 = ZP x WS floats)
+  float* wl = Wl + wfloats + (size_t)wave * AF_GMAX * (QP + ZP);
   float* qs = wl;                     // [G][QP]
   float* vs = wl + AF_GMAX * QP;      // [G][ZP]
-  double* red = reinterpret_cast<double*>(Wl + (size_t)ZP * Kp + (size_t)4 * AF_GMAX * (QP + ZP));   // [4][2][ZP]
+  double* red = reinterpret_cast<double*>(Wl + wfloats + (size_t)4 * AF_GMAX * (QP + ZP));   // [4][2][ZP]
   constexpr int TS = ZP + 4;   // row stride of the store-transposition tile: (4 g4 + e) * TS + 16 z + j hits 64 distinct banks
   float* tb = reinterpret_cast<float*>(red + 4 * 2 * ZP) + (size_t)wave * 16 * TS;   // [16 positions][TS] per wave
-  {
+  if (X3) {
+    constexpr int C8 = WS / 8;
+    for (int e = tid; e < ZP * C8; e += 256) {
+      const int row = e / C8, k8 = e - row * C8;           // slots 8 k8 .. 8 k8 + 7 of the row: chunk c, lane group gg
+      const int c = k8 >> 2, gg = k8 & 3;
+      f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (row < s.A0 && c < NC) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int f0 = 32 * c + 16 * hf + 4 * gg;
+          if (f0 < s.Q) {                                   // (Q % 4 == 0)
+            const f32x4 w = ld4(s.Wt + (long)row * Kp + f0);
+            v[4 * hf] = w.x; v[4 * hf + 1] = w.y; v[4 * hf + 2] = w.z; v[4 * hf + 3] = w.w;
+          }
+        }
+      }
+      const bf16x8 hi = to_h(v);
+      reinterpret_cast<bf16x8*>(Wh)[e] = hi;
+      reinterpret_cast<bf16x8*>(Wlo)[e] = to_h(v - to_f(hi));
+    }
+  } else {
     const int Kq = Kp >> 2;
     const int nrows = 16 * ((s.A0 + 15) >> 4);
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -56,6 +87,52 @@ __global__ void __launch_bounds__(256, 2) att_l0_fwd_kernel(AttL0FwdArgs s) {
   }
   __syncthreads();
   const float* ldsB = Wl + (long)j * Kp + 4 * g4;   // + 16 z Kp + 16 kk
+  const int ldsH = j * WS + 8 * g4;                  // X3: + 16 z WS + 32 c
+  // acc[z] += x . W over all chunks (x[kk] = the (a * q) float4 of the lane's position for chunk kk)
+  auto mac = [&](f32x4 (&acc)[NZ], const f32x4 (&x)[NK], int woff) {
+    if (X3) {
+      const f32x4 z4_ = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const f32x4 lo4 = x[2 * c], hi4 = 2 * c + 1 < NK ? x[2 * c + 1 < NK ? 2 * c + 1 : 0] : z4_;
+        const f32x8 v = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+        const bf16x8 ah = to_h(v), al = to_h(v - to_f(ah));
+        bf16x8 wh[NZ], wlv[NZ];
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) {
+          wh[z] = ld8h(Wh + ldsH + woff + z * 16 * WS + 32 * c);
+          wlv[z] = ld8h(Wlo + ldsH + woff + z * 16 * WS + 32 * c);
+        }
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) HMFMA(acc[z], ah, wlv[z]);
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) HMFMA(acc[z], al, wh[z]);
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) HMFMA(acc[z], ah, wh[z]);
+      }
+    } else {
+      const float* lb = ldsB + woff;
+      // weights of chunk kk + 1 are read from LDS while chunk kk is multiplied
+      f32x4 w[2][NZ];
+#pragma unroll
+      for (int z = 0; z < NZ; ++z) w[0][z] = ld4(lb + (long)z * 16 * Kp);
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) {
+        if (kk + 1 < NK) {
+#pragma unroll
+          for (int z = 0; z < NZ; ++z) w[(kk + 1) & 1][z] = ld4(lb + (long)z * 16 * Kp + 16 * (kk + 1));
+        }
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) MFMA4(acc[z], x[kk].x, w[kk & 1][z].x);
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) MFMA4(acc[z], x[kk].y, w[kk & 1][z].y);
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) MFMA4(acc[z], x[kk].z, w[kk & 1][z].z);
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) MFMA4(acc[z], x[kk].w, w[kk & 1][z].w);
+      }
+    }
+  };
 
   const int G = s.G, T = s.T;
   // the ragged last tile of a history (T % 16 steps) is PACKED across the G rows of the group when they fit into one
@@ -126,32 +203,13 @@ __global__ void __launch_bounds__(256, 2) att_l0_fwd_kernel(AttL0FwdArgs s) {
         // (opaque per iteration: keeps the compiler from parking the loop-invariant weight reads in ~70 VGPRs)
         int woff = 0;
         asm volatile("" : "+v"(woff));   // (an opaque OFFSET: an opaque pointer would lose its LDS address space -> flat loads)
-        const float* lb = ldsB + woff;
         f32x4 x[NK];
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) x[kk] = cur.a[kk] * ld4(qs + g * QP + 16 * kk + 4 * g4);
         f32x4 acc[NZ];
 #pragma unroll
         for (int z = 0; z < NZ; ++z) acc[z] = cur.u[z] + vs[g * ZP + 16 * z + j];
-        // weights of chunk kk + 1 are read from LDS while chunk kk is multiplied
-        f32x4 w[2][NZ];
-#pragma unroll
-        for (int z = 0; z < NZ; ++z) w[0][z] = ld4(lb + (long)z * 16 * Kp);
-#pragma unroll
-        for (int kk = 0; kk < NK; ++kk) {
-          if (kk + 1 < NK) {
-#pragma unroll
-            for (int z = 0; z < NZ; ++z) w[(kk + 1) & 1][z] = ld4(lb + (long)z * 16 * Kp + 16 * (kk + 1));
-          }
-#pragma unroll
-          for (int z = 0; z < NZ; ++z) MFMA4(acc[z], x[kk].x, w[kk & 1][z].x);
-#pragma unroll
-          for (int z = 0; z < NZ; ++z) MFMA4(acc[z], x[kk].y, w[kk & 1][z].y);
-#pragma unroll
-          for (int z = 0; z < NZ; ++z) MFMA4(acc[z], x[kk].z, w[kk & 1][z].z);
-#pragma unroll
-          for (int z = 0; z < NZ; ++z) MFMA4(acc[z], x[kk].w, w[kk & 1][z].w);
-        }
+        mac(acc, x, woff);
         // the result tile goes through LDS once so that every position's A0 floats leave as consecutive 16-byte stores
         // (a lane holds 4 positions of one feature: stored directly that is 4 x NZ dword stores of 64-byte pieces)
 #pragma unroll
@@ -214,20 +272,7 @@ __global__ void __launch_bounds__(256, 2) att_l0_fwd_kernel(AttL0FwdArgs s) {
 #pragma unroll
         for (int z = 0; z < NZ; ++z) acc[z][e] = up[ncl[z]] + vs[gp * ZP + 16 * z + j];
       }
-#pragma unroll
-      for (int kk = 0; kk < NK; ++kk) {
-        f32x4 w[NZ];
-#pragma unroll
-        for (int z = 0; z < NZ; ++z) w[z] = ld4(ldsB + (long)z * 16 * Kp + 16 * kk);
-#pragma unroll
-        for (int z = 0; z < NZ; ++z) MFMA4(acc[z], x[kk].x, w[z].x);
-#pragma unroll
-        for (int z = 0; z < NZ; ++z) MFMA4(acc[z], x[kk].y, w[z].y);
-#pragma unroll
-        for (int z = 0; z < NZ; ++z) MFMA4(acc[z], x[kk].z, w[z].z);
-#pragma unroll
-        for (int z = 0; z < NZ; ++z) MFMA4(acc[z], x[kk].w, w[z].w);
-      }
+      mac(acc, x, 0);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -296,11 +341,12 @@ extern "C" int clsr_att_l0_fwd_supported(int G, int Q, int A0) {
 // number of per-block partial rows the statistics buffer receives: [parts][2][A0] doubles
 extern "C" int clsr_att_l0_fwd_stats_parts(long Hn) { return af_grid(Hn); }
 
-template <int NZ, int NK>
+template <int NZ, int NK, bool X3>
 static int att_l0_fwd_launch(const AttL0FwdArgs& a, hipStream_t stream) {
-  size_t shmem = (size_t)16 * NZ * a.Kp * 4 + (size_t)4 * AF_GMAX * (16 * NK + 16 * NZ) * 4 + (size_t)4 * 2 * 16 * NZ * 8 +
-                 (size_t)4 * 16 * (16 * NZ + 4) * 4;
-  auto kernel = att_l0_fwd_kernel<NZ, NK>;
+  constexpr int WS = 32 * ((NK + 1) / 2) + 8;
+  size_t shmem = (X3 ? (size_t)16 * NZ * WS * 4 : (size_t)16 * NZ * a.Kp * 4) + (size_t)4 * AF_GMAX * (16 * NK + 16 * NZ) * 4 +
+                 (size_t)4 * 2 * 16 * NZ * 8 + (size_t)4 * 16 * (16 * NZ + 4) * 4;
+  auto kernel = att_l0_fwd_kernel<NZ, NK, X3>;
   if (shmem > 64 * 1024)
     CLSR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   hipLaunchKernelGGL(kernel, dim3(af_grid(a.Hn)), dim3(256), shmem, stream, a);
@@ -308,9 +354,9 @@ static int att_l0_fwd_launch(const AttL0FwdArgs& a, hipStream_t stream) {
   return CLSR_OK;
 }
 
-extern "C" int clsr_att_l0_fwd(const float* a, int lda, const float* q, int ldq, const float* Wt, int Kp,
-                               const float* U, int ldu, const float* V, int ldv, float* z0, int ldz, double* stats,
-                               long Hn, int G, int T, int Q, int A0, void* stream) {
+static int att_l0_fwd_any(const float* a, int lda, const float* q, int ldq, const float* Wt, int Kp,
+                          const float* U, int ldu, const float* V, int ldv, float* z0, int ldz, double* stats,
+                          long Hn, int G, int T, int Q, int A0, bool x3, void* stream) {
   CLSR_CHECK_ARG(a && q && Wt && U && V && z0 && Hn > 0 && T > 0);
   CLSR_CHECK_SUPPORTED(clsr_att_l0_fwd_supported(G, Q, A0));
   CLSR_CHECK_SUPPORTED(lda % 4 == 0 && Kp % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)Wt % 16) == 0);
@@ -321,8 +367,20 @@ extern "C" int clsr_att_l0_fwd(const float* a, int lda, const float* q, int ldq,
   s.z0 = z0; s.ldz = ldz; s.stats = stats; s.Hn = Hn; s.G = G; s.T = T; s.Q = Q; s.A0 = A0;
   hipStream_t st = (hipStream_t)stream;
   const int nz = af_class(A0), nk = af_class(Q);
-#define AF_GO(Z, K) if (nz == Z && nk == K) return att_l0_fwd_launch<Z, K>(s, st)
+#define AF_GO(Z, K) if (nz == Z && nk == K) return x3 ? att_l0_fwd_launch<Z, K, true>(s, st) : att_l0_fwd_launch<Z, K, false>(s, st)
   AF_GO(3, 3); AF_GO(3, 5); AF_GO(5, 3); AF_GO(5, 5);
 #undef AF_GO
   return CLSR_OK;
+}
+
+extern "C" int clsr_att_l0_fwd(const float* a, int lda, const float* q, int ldq, const float* Wt, int Kp,
+                               const float* U, int ldu, const float* V, int ldv, float* z0, int ldz, double* stats,
+                               long Hn, int G, int T, int Q, int A0, void* stream) {
+  return att_l0_fwd_any(a, lda, q, ldq, Wt, Kp, U, ldu, V, ldv, z0, ldz, stats, Hn, G, T, Q, A0, false, stream);
+}
+// the same with the product as split-bf16 sums (see att_l0_fwd_kernel<.., X3>)
+extern "C" int clsr_att_l0_fwd_x3(const float* a, int lda, const float* q, int ldq, const float* Wt, int Kp,
+                                  const float* U, int ldu, const float* V, int ldv, float* z0, int ldz, double* stats,
+                                  long Hn, int G, int T, int Q, int A0, void* stream) {
+  return att_l0_fwd_any(a, lda, q, ldq, Wt, Kp, U, ldu, V, ldv, z0, ldz, stats, Hn, G, T, Q, A0, true, stream);
 }

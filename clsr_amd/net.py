@@ -108,9 +108,20 @@ class CLSRNet(object):
         # stay opt-in: with their MFMA phase cut to 3/16 they are bound by memory latency, not by the pipe, and came out
         # level or slower than the fp32-MFMA kernels whose long MFMA phases hide that latency (CLSR_X3_DW=1 /
         # CLSR_X3_GEMM=all).
+        # Round 5: the split products that measured faster are the default of precision="fp32" as well (recurrences,
+        # attention-MLP backward, fused encoder tail, d(hist) product): fp32 storage, 2^-16 relative per product term, the
+        # step tests hold their fp32 tolerances.  CLSR_EXACT_PRODUCTS=1 restores fp32-input MFMAs everywhere (bit-exact
+        # fp32 fma chains) for parity debugging; "fp32x3" additionally honours the opt-in sites below.
+        self.exact_products = bool(os.environ.get("CLSR_EXACT_PRODUCTS"))
+        x3d = self.precision in ("fp32", "fp32x3") and not self.exact_products
         self.x3_dw = self.x3 and bool(os.environ.get("CLSR_X3_DW"))       # A/B: weight gradients (csrc/dw3.hip)
-        self.x3_gemm = self.x3 and os.environ.get("CLSR_X3_GEMM", "xw^T")  # "all" | comma-separated weight keys | ""
-        self.x3_enc = self.x3 and not os.environ.get("CLSR_NO_X3_ENC")    # A/B: fused encoder tail (csrc/encbwd.hip)
+        self.x3_gemm = x3d and os.environ.get("CLSR_X3_GEMM", "xw^T")      # "all" | comma-separated weight keys | ""
+        self.x3_enc = x3d and not os.environ.get("CLSR_NO_X3_ENC")        # A/B: fused encoder tail (csrc/encbwd.hip)
+        self.att_hist_bwd_x3 = x3d and not os.environ.get("CLSR_NO_ATT_HIST_BWD_X3")   # A/B: history-level attention backward in one launch
+        self.att_hist_x3 = (x3d or self.precision == "bf16") and not self.exact_products and not os.environ.get("CLSR_NO_ATT_HIST_X3")  # A/B: history-level attention prologue in one launch (csrc/atthist.hip)
+        # (forward products that feed a batch-norm + ReLU stay at fp32 accuracy in the parity mode -- x6 pieces in the
+        # history-level kernel, the fp32-MFMA layer-0 kernel -- see csrc/atthist.hip; "fp32x3" takes the x3 forms)
+        self.att_fwd_x3 = (self.x3 or bool(os.environ.get("CLSR_ATT_FWD_X3"))) and not self.exact_products and not os.environ.get("CLSR_NO_ATT_FWD_X3")  # A/B: first attention layer, forward (csrc/attl0fwd.hip)
         self.bf16_dw = not os.environ.get("CLSR_NO_HDW")        # A/B switch: weight gradients on the bf16 matrix pipe
         self.bf16_bwd = not os.environ.get("CLSR_NO_HBWD")      # A/B switch: back-propagating products likewise
         self._cur_descs_h = []
@@ -162,7 +173,7 @@ class CLSRNet(object):
         # fp32); with x3 the input projections of the GRUs and of the Time4LSTM blocks i | j | f run INSIDE the recurrence
         # launch from the history embeddings (no projection tensor, no GEMM in front of the T-serial chain), and the
         # Time4LSTM keeps its saved activations in a private tile-major image.  CLSR_RNN_PRODUCTS=fp32 restores the exact form.
-        self.rnn_products = os.environ.get("CLSR_RNN_PRODUCTS", "x3")
+        self.rnn_products = os.environ.get("CLSR_RNN_PRODUCTS", "fp32" if self.exact_products else "x3")
         if self.rnn_products not in ("x3", "fp32"):
             raise ValueError("CLSR_RNN_PRODUCTS must be 'x3' or 'fp32'")
         self.rnn_fused_proj = self.rnn_products == "x3" and not os.environ.get("CLSR_NO_RNN_FUSED_PROJ")
@@ -170,7 +181,7 @@ class CLSRNet(object):
         # Attention-MLP backward (exact mode): "x3" = the two-pass layer-1 kernel and the one-pass layer-0 kernel as split-bf16
         # products with the weight gradients dW1 / db1 / dWp accumulated inside them (csrc/attbwdx3.hip: no separate
         # weight-gradient launches, no stored dz1); "fp32" = the fp32-MFMA kernels + clsr_pgemm_dw_partial beside them
-        self.att_bwd = os.environ.get("CLSR_ATT_BWD", "x3")
+        self.att_bwd = os.environ.get("CLSR_ATT_BWD", "fp32" if self.exact_products else "x3")
         if self.att_bwd not in ("x3", "fp32"):
             raise ValueError("CLSR_ATT_BWD must be 'x3' or 'fp32'")
         self.fuse_tt = not os.environ.get("CLSR_NO_FUSE_TT")   # A/B: time-gate blocks of the input projection as one product over [hist | TT]
@@ -1174,8 +1185,18 @@ class CLSRNet(object):
         z1 = self._buf(key + ".z1", R * T, A1, dtype=BF if self.bf16 else F32)
         wts = self._buf(key + ".wts", R, T)
         out = self._buf(key + ".out", R, Dk)
-        self._gemm(keys, Dk, key + ".A", Hn * T, Dk, Q, a, Q)
-        self._gemm(a, Q, key + ".Wu", Hn * T, Q, A0, U, A0)
+        hist_x3 = self.att_hist_x3 and bool(query("clsr_att_hist_fwd_x3_supported", Dk, Q, A0, qh))
+        if hist_x3:
+            # a = keys . A and U = a . Wu (+ the history-level share of the product term) in ONE pass over the keys
+            # (csrc/atthist.hip) instead of three position-tiled GEMM launches on the dependent chain
+            At, Kpa = self.packed[key + ".A"]
+            Wut, Kpu = self.packed[key + ".Wu"]
+            Wpt, Kpp = self.packed[key + ".Wp1"] if qh else (None, 0)
+            call("clsr_att_hist_fwd_x3", keys, Dk, At, Kpa, Wut, Kpu, Wpt, Kpp, q_hist if qh else None, qh, Hn, T, Dk, Q,
+                 A0, qh, 3 if self.precision == "fp32" else 2, a, Q, U, A0)
+        else:
+            self._gemm(keys, Dk, key + ".A", Hn * T, Dk, Q, a, Q)
+            self._gemm(a, Q, key + ".Wu", Hn * T, Q, A0, U, A0)
         self._gemm(q, Q, key + ".Wv", R, Q, A0, V, A0, bias=P[nn + "b_nn_layer0"])
         if self.bf16:
             # speed mode: the two (row, step)-level layers on bf16 MFMA with bf16 storage (csrc/hgemm.hip)
@@ -1203,15 +1224,16 @@ class CLSRNet(object):
         st, parts = self._stats_buf(R * T, A0) if training else (None, 0)
         if qh:
             # U[h,t] += (a[h,t,:qh] * q_hist[h]) . Wp[:qh]   (in place: every tile reads its own U before storing)
-            self._gemm(a, Q, key + ".Wp1", Hn * T, qh, A0, U, A0, T=T, G=1, Xmul=q_hist, ldmul=qh, addU=U, ldu=A0,
-                       addV=self._buf("att.zeroV", Hn, A0), ldv=A0)
+            if not hist_x3:
+                self._gemm(a, Q, key + ".Wp1", Hn * T, qh, A0, U, A0, T=T, G=1, Xmul=q_hist, ldmul=qh, addU=U, ldu=A0,
+                           addV=self._buf("att.zeroV", Hn, A0), ldv=A0)
             if self.l0_fwd_wave and query("clsr_att_l0_fwd_supported", G, Q - qh, A0):
                 # the per-row half (target columns of the query) on the one-wave-per-history kernel: K = Q - qh
                 parts = query("clsr_att_l0_fwd_stats_parts", Hn) if training else 0
                 st = (self._buf("stats" + self._ws_tag, 1024 * 2 * 256, dtype=torch.float64)[: parts * 2 * A0]
                       if training else None)
                 Wt, Kp = self.packed[key + ".Wp2"]
-                call("clsr_att_l0_fwd", a[:, qh:], Q, q[:, qh:], Q, Wt, Kp, U, A0, V, A0, z0, A0, st, Hn, G, T, Q - qh, A0)
+                call("clsr_att_l0_fwd_x3" if self.att_fwd_x3 else "clsr_att_l0_fwd", a[:, qh:], Q, q[:, qh:], Q, Wt, Kp, U, A0, V, A0, z0, A0, st, Hn, G, T, Q - qh, A0)
             else:
                 self._gemm(a[:, qh:], Q, key + ".Wp2", R * T, Q - qh, A0, z0, A0, T=T, G=G, Xmul=q[:, qh:], ldmul=Q,
                            addU=U, ldu=A0, addV=V, ldv=A0, stats=st)
@@ -1221,7 +1243,7 @@ class CLSRNet(object):
             st = (self._buf("stats" + self._ws_tag, 1024 * 2 * 256, dtype=torch.float64)[: parts * 2 * A0]
                   if training else None)
             Wt, Kp = self.packed[key + ".Wp"]
-            call("clsr_att_l0_fwd", a, Q, q, Q, Wt, Kp, U, A0, V, A0, z0, A0, st, Hn, G, T, Q, A0)
+            call("clsr_att_l0_fwd_x3" if self.att_fwd_x3 else "clsr_att_l0_fwd", a, Q, q, Q, Wt, Kp, U, A0, V, A0, z0, A0, st, Hn, G, T, Q, A0)
         else:
             self._gemm(a, Q, key + ".Wp", R * T, Q, A0, z0, A0, T=T, G=G, Xmul=q, ldmul=Q, addU=U, ldu=A0,
                        addV=V, ldv=A0, stats=st)
@@ -1375,9 +1397,10 @@ class CLSRNet(object):
                      dq[:, qh:], Q, 1)
             # history-level share of the product term: through dU = sum over the group's rows of dz0
             self._dw(a, Q, dU, A0, Hn * T, qh, A0, dW0[3 * Q:3 * Q + qh], A0, T=T, G=1, Xmul=q_hist, ldmul=qh)
-            daq1 = self._buf(key + ".daq1", Hn * T, qh)
-            self._gemm(dU, A0, key + ".Wp1^T", Hn * T, A0, qh, daq1, qh)
-            call("clsr_att_prod_bwd_ld", daq1, qh, a, Q, q_hist, qh, Hn, 1, T, qh, da, Q, dq_hist, qh, 1)
+            if not self._hist_bwd_x3(Dk, Q, qh):      # (else: inside the fused history-level kernel, _att_bwd_hist)
+                daq1 = self._buf(key + ".daq1", Hn * T, qh)
+                self._gemm(dU, A0, key + ".Wp1^T", Hn * T, A0, qh, daq1, qh)
+                call("clsr_att_prod_bwd_ld", daq1, qh, a, Q, q_hist, qh, Hn, 1, T, qh, da, Q, dq_hist, qh, 1)
         else:
             l0x3 = x3b and self.fused_l0_bwd and query("clsr_att_l0_bwd_x3_supported", G, Q, A0)
             if not l0x3:
@@ -1400,10 +1423,16 @@ class CLSRNet(object):
                 self._gemm(dz0, A0, key + ".Wp^T", R * T, A0, Q, daq, Q)
                 call("clsr_att_prod_bwd", daq, a, q, Hn, G, T, Q, da, dq)
                 call("clsr_att_z0_bwd_reduce", dz0, Hn, G, T, A0, None if G == 1 else dU, dV)
-        return self._att_bwd_hist(key, scope, nn, a, q, keys, dkeys, dU, dV, da, dq, dW0, Hn, R, T, Dk, Q, qh)
+        return self._att_bwd_hist(key, scope, nn, a, q, keys, dkeys, dU, dV, da, dq, dW0, Hn, R, T, Dk, Q, qh,
+                                  q_hist=q_hist, dq_hist=dq_hist)
+
+    def _hist_bwd_x3(self, Dk, Q, qh):
+        """history-level tail of the attention backward as ONE launch of split-bf16 products (csrc/atthist.hip)?"""
+        return (self.att_hist_bwd_x3 and not self.bf16
+                and bool(query("clsr_att_hist_bwd_x3_supported", Dk, Q, self.A0, qh)))
 
     def _att_bwd_hist(self, key, scope, nn, a, q, keys, dkeys, dU, dV, da, dq, dW0, Hn, R, T, Dk, Q, qh,
-                      da_has_u=False):
+                      da_has_u=False, q_hist=None, dq_hist=None):
         """History-level / row-level tail of the attention backward (fp32 in both precision modes): gradients of
         the U / V projections, of the attention matrix, and d keys."""
         Gd, A0 = self.Gd, self.A0
@@ -1420,12 +1449,21 @@ class CLSRNet(object):
             pend.append((pa[0], dW0[2 * Q:3 * Q].data_ptr(), 0, 1.0, pa[4], Q, A0, A0, 0, pq[0], -1.0, pq[4]))
         else:
             call("clsr_axpby", dW0[2 * Q:3 * Q], dW0[0:Q], 1.0, dW0[Q:2 * Q], -1.0, Q * A0)
-        if not da_has_u:      # (speed mode: clsr_att_l0_bwd_h has already added dU . Wu^T)
+        fused = not da_has_u and self._hist_bwd_x3(Dk, Q, qh)
+        if fused:
+            # da += dU . Wu^T (+ the history-level product term and its dq_hist), dkeys += da . A^T from one pass over dU
+            WuT, Kpu = self.packed[key + ".Wu^T"]
+            WpT, Kpp = self.packed[key + ".Wp1^T"] if qh else (None, 0)
+            AT, Kpa = self.packed[key + ".A^T"]
+            call("clsr_att_hist_bwd_x3", dU, A0, WuT, Kpu, WpT, Kpp, AT, Kpa, a, Q, q_hist if qh else None, qh, Hn, T, Dk,
+                 Q, A0, qh, da, Q, dq_hist if qh else None, qh, dkeys, Dk)
+        elif not da_has_u:      # (speed mode: clsr_att_l0_bwd_h has already added dU . Wu^T)
             self._gemm(dU, A0, key + ".Wu^T", Hn * T, A0, Q, da, Q, acc=1)
         if not qh:
             self._gemm(dV, A0, key + ".Wv^T", R, A0, Q, dq, Q, acc=1)
         self._dw(keys, Dk, da, Q, Hn * T, Dk, Q, Gd[scope + "attention_mat"], Q)
-        self._gemm(da, Q, key + ".A^T", Hn * T, Q, Dk, dkeys, Dk, acc=1)
+        if not fused:
+            self._gemm(da, Q, key + ".A^T", Hn * T, Q, Dk, dkeys, Dk, acc=1)
         return dq
 
     # ------------------------------------------------------------------ MLP (alpha / logit)
@@ -2508,7 +2546,7 @@ class CLSRNet(object):
         z0 = self._buf(key + ".z0", R * T, A0)
         Wt, Kp = self.packed[key + ".Wp"]
         if self._att_layer0_wave(G, Q):
-            return lambda: call("clsr_att_l0_fwd", a, Q, q, Q, Wt, Kp, U, A0, V, A0, z0, A0, None, Hn, G, T, Q, A0)
+            return lambda: call("clsr_att_l0_fwd_x3" if self.att_fwd_x3 else "clsr_att_l0_fwd", a, Q, q, Q, Wt, Kp, U, A0, V, A0, z0, A0, None, Hn, G, T, Q, A0)
         return lambda: call("clsr_pgemm", a, Q, T, G, q, Q, None, None, 1, Wt, Kp, None, U, A0, V, A0, z0, A0, 0,
                             None, R * T, Q, A0)
 

@@ -340,6 +340,31 @@ int clsr_att_l0_fwd_stats_parts(long Hn);
 int clsr_att_l0_fwd(const float* a, int lda, const float* q, int ldq, const float* Wt, int Kp,
                     const float* U, int ldu, const float* V, int ldv, float* z0, int ldz, double* stats,
                     long Hn, int G, int T, int Q, int A0, void* stream);
+/* History-level prologue of an attention block in one launch of split-bf16 products (csrc/atthist.hip):
+ *   a = keys . A (At = packed attention_mat: Q rows, K = Dk),  U = a . Wu (Wut: A0 rows, K = Q)
+ *   qh > 0: U += (a[:, :qh] * q_hist[h, :]) . Wp[:qh] (Wpt: A0 rows, K = qh; q_hist [Hn, qh]) -- the history-level share of
+ *   the product term of the short-term query.  Replaces clsr_pgemm x 3 (reference clsr.py:351-356, 368-370).
+ *   pieces = bf16 pieces per operand: 2 -> products of 2^-16 relative accuracy, 3 -> 2^-23 (the level of an fp32 fma chain:
+ *   the parity mode's forward; a 2^-16 perturbation of the pre-activations flips ReLU decisions on small batches). */
+int clsr_att_hist_fwd_x3_supported(int Dk, int Q, int A0, int qh);
+int clsr_att_hist_fwd_x3(const float* keys, int ldk, const float* At, int Kpa, const float* Wut, int Kpu,
+                         const float* Wpt, int Kpp, const float* q_hist, int ldqh, long Hn, int T, int Dk, int Q,
+                         int A0, int qh, int pieces, float* a, int lda, float* U, int ldu, void* stream);
+/* History-level tail of the attention backward in one launch (csrc/atthist.hip), from one pass over dU [Hn*T, A0]:
+ *   da = (columns >= qh: da as written by the layer-0 kernel | columns < qh: (dU . Wp[:qh]^T) * q_hist[h]) + dU . Wu^T
+ *   dq_hist[h] += sum_t (dU . Wp[:qh]^T) * a[h,t,:qh];   dkeys += da . A^T
+ * WuT / WpT / AT = packed transposed weights (rows = Q / qh / Dk, K = A0 / A0 / Q).  Replaces clsr_pgemm (daq1) +
+ * clsr_att_prod_bwd_ld + two accumulating clsr_pgemm (reference: tf.gradients through clsr.py:351-370). */
+int clsr_att_hist_bwd_x3_supported(int Dk, int Q, int A0, int qh);
+int clsr_att_hist_bwd_x3(const float* dU, int lddu, const float* WuT, int Kpu, const float* WpT, int Kpp,
+                         const float* AT, int Kpa, const float* a, int lda, const float* q_hist, int ldqh,
+                         long Hn, int T, int Dk, int Q, int A0, int qh, float* da, int ldda, float* dq_hist,
+                         int lddqh, float* dkeys, int lddk, void* stream);
+/* clsr_att_l0_fwd with the product term as split-bf16 sums on the bf16 matrix pipe (fp32 accumulators that start from
+ * U + V; 2^-16 relative per product term): bound by its stores instead of the fp32 matrix pipe */
+int clsr_att_l0_fwd_x3(const float* a, int lda, const float* q, int ldq, const float* Wt, int Kp,
+                       const float* U, int ldu, const float* V, int ldv, float* z0, int ldz, double* stats,
+                       long Hn, int G, int T, int Q, int A0, void* stream);
 /* The same four reductions in exact mode: dz0 and the packed Wp^T (clsr_pack_batch layout) fp32, fp32 matrix pipe; dU may
  * be NULL (G == 1: dU is dz0).  Replaces clsr_pgemm (daq) + clsr_att_prod_bwd + clsr_att_z0_bwd_reduce. */
 int clsr_att_l0_bwd_supported(int G, int Q, int A0);

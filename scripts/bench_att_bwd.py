@@ -1,7 +1,7 @@
 """Isolated timing of the attention-MLP backward kernels at configs[1] shapes: the fp32-MFMA kernels + their weight-gradient
 launches against the split-bf16 kernels with the weight gradients folded in (csrc/attbwdx3.hip).
 usage: python scripts/bench_att_bwd.py"""
-import sys, torch
+import os, sys, torch
 sys.path.insert(0, "/root/repo")
 from clsr_amd import ops
 from clsr_amd.ops import call, query
@@ -35,6 +35,10 @@ with torch.cuda.stream(st_):
     wsd = torch.zeros(query("clsr_pgemm_dw_workspace_floats", M, A0, A0), device=dev)
     da, dq = torch.zeros(Hn * T, Q, device=dev), torch.zeros(R, Q, device=dev)
     dU, dV = torch.zeros(Hn * T, A0, device=dev), torch.zeros(R, A0, device=dev)
+    if os.environ.get("ONLY_L0X3"):
+        t = timeit(lambda: call("clsr_att_l0_bwd_x3", dz0, A0, WtT, KpT, a, Q, q, Q, Hn, G, T, Q, A0, da, Q, dq, Q, dU, A0, dV, A0, ws))
+        print("x3    l0 (da, dq, dU, dV + dWp)  %-10s %6.1f us" % (os.environ["ONLY_L0X3"], t))
+        sys.exit(0)
     t = timeit(lambda: call("clsr_att_l1_bwd", z1, A1, ds, sc1, sh1, wo, c1, W1T, K1T, z0, A0, sc0, sh0, mu0, is0, None, None, 0, None, 0, st, M, A1, A0))
     print("fp32  l1 pass 1 (stats)               R 492 MB            %6.1f us  %5.2f TB/s" % (t, 492 / t))
     t = timeit(lambda: call("clsr_att_l1_bwd_x3", z1, A1, ds, sc1, sh1, wo, c1, W1T, K1T, z0, A0, sc0, sh0, mu0, is0, None, None, 0, None, st, M, A1, A0))
@@ -51,6 +55,28 @@ with torch.cuda.stream(st_):
     print("fp32  dWp = (a*q)^T dz0               R 328 MB + L2       %6.1f us  %5.2f TB/s" % (t2, 328 / t2))
     t = timeit(lambda: call("clsr_att_l0_bwd_x3", dz0, A0, WtT, KpT, a, Q, q, Q, Hn, G, T, Q, A0, da, Q, dq, Q, dU, A0, dV, A0, ws))
     print("x3    l0 (da, dq, dU, dV + dWp)       R 328 + 33, W 98 MB %6.1f us  %5.2f TB/s" % (t, 459 / t))
+    U, V = torch.randn(Hn * T, A0, device=dev), torch.randn(R, A0, device=dev)
+    Wf, Kf = ops.pack_weight(Wp, A0, Q)
+    for name in ("clsr_att_l0_fwd", "clsr_att_l0_fwd_x3"):
+        t = timeit(lambda: call(name, a, Q, q, Q, Wf, Kf, U, A0, V, A0, z0, A0, st, Hn, G, T, Q, A0))
+        print("%-20s z0 = U + V + (a*q).Wp + stats   W 328 MB     %6.1f us  %5.2f TB/s" % (name, t, 328 / t))
+    # history-level prologue of the short-term attention: keys [Hn*T, 40] -> a [.., 80], U [.., 80] (+ the qh = 40 product term)
+    Dk, Qs, qh = 40, 80, 40
+    keys = torch.randn(Hn * T, Dk, device=dev)
+    Am, Wu, Wp1 = torch.randn(Dk, Qs, device=dev) * 0.3, torch.randn(Qs, A0, device=dev) * 0.3, torch.randn(qh, A0, device=dev) * 0.3
+    qhist = torch.randn(Hn, qh, device=dev)
+    At, Kpa = ops.pack_weight(Am, Qs, Dk); Wut, Kpu = ops.pack_weight(Wu, A0, Qs); Wpt, Kpp = ops.pack_weight(Wp1, A0, qh)
+    a2, U2 = torch.zeros(Hn * T, Qs, device=dev), torch.zeros(Hn * T, A0, device=dev)
+    zV = torch.zeros(Hn, A0, device=dev)
+    def three():
+        call("clsr_pgemm", keys, Dk, 0, 0, None, 0, None, None, 1, At, Kpa, None, None, 0, None, 0, a2, Qs, 0, None, Hn * T, Dk, Qs)
+        call("clsr_pgemm", a2, Qs, 0, 0, None, 0, None, None, 1, Wut, Kpu, None, None, 0, None, 0, U2, A0, 0, None, Hn * T, Qs, A0)
+        call("clsr_pgemm", a2, Qs, T, 1, qhist, qh, None, None, 1, Wpt, Kpp, None, U2, A0, zV, A0, U2, A0, 0, None, Hn * T, qh, A0)
+    t = timeit(three)
+    print("fp32  history-level prologue, 3 clsr_pgemm launches   R 33 + W 131 MB  %6.1f us" % t)
+    for pc in (2, 3):
+        t = timeit(lambda: call("clsr_att_hist_fwd_x3", keys, Dk, At, Kpa, Wut, Kpu, Wpt, Kpp, qhist, qh, Hn, T, Dk, Qs, A0, qh, pc, a2, Qs, U2, A0))
+        print("x%d    history-level prologue, one launch              R 33 + W 131 MB  %6.1f us" % (3 * (pc - 1), t))
     # long-term attention shapes (G = 1, history level)
     Hn, G = 4096, 1
     R, M = Hn, Hn * T

@@ -162,3 +162,107 @@ def test_layer1_backward_x3_two_passes_with_weight_gradient(M, C1, C0):
          d["sh0"], None, None, d["coef0"], dz0b, ld0, wsb, None, M, C1, C0)
     torch.cuda.synchronize()
     assert torch.equal(dz0b[:, :C0], dz0[:, :C0])
+
+
+@pytest.mark.parametrize("Hn,G,T,Q,A0", [(37, 5, 50, 80, 80), (64, 1, 50, 40, 80), (9, 8, 7, 44, 36), (6, 3, 17, 24, 40),
+                                         (1, 5, 1, 80, 80), (2100, 2, 33, 48, 80), (11, 8, 18, 80, 80), (5, 4, 20, 40, 80),
+                                         (7, 5, 16, 80, 40), (3, 2, 8, 16, 16)])   # packed / unpacked ragged tiles
+def test_layer0_forward_x3(Hn, G, T, Q, A0):
+    """clsr_att_l0_fwd_x3: z0 = U[h,t] + V[r] + (a[h,t] * q[r]) . Wp with the product as split-bf16 sums: 2^-16 relative per
+    term against float64, statistics consistent with the stored z0, and close to the exact kernel."""
+    g = torch.Generator().manual_seed(Hn * 3 + T)
+    R, M = Hn * G, Hn * G * T
+    a, q = rnd(g, Hn * T, Q), rnd(g, R, Q)
+    U, V, Wp = rnd(g, Hn * T, A0), rnd(g, R, A0), rnd(g, Q, A0, scale=0.2)
+    Wt, Kp = ops.pack_weight(dev(Wp), A0, Q)
+    parts = query("clsr_att_l0_fwd_stats_parts", Hn)
+    st = torch.full((parts, 2, A0), 7.0, dtype=torch.float64, device="cuda")
+    z0 = torch.full((M, A0 + 4), 7.0, device="cuda")
+    da, dq, dU, dV = dev(a), dev(q), dev(U), dev(V)
+    call("clsr_att_l0_fwd_x3", da, Q, dq, Q, Wt, Kp, dU, A0, dV, A0, z0, A0 + 4, st, Hn, G, T, Q, A0)
+    torch.cuda.synchronize()
+    a4, q4 = da.double().cpu().view(Hn, 1, T, Q), dq.double().cpu().view(Hn, G, 1, Q)
+    exp = ((a4 * q4) @ dev(Wp).double().cpu() + dU.double().cpu().view(Hn, 1, T, A0)
+           + dV.double().cpu().view(Hn, G, 1, A0)).reshape(M, A0)
+    close(z0[:, :A0], exp, 5e-5, "z0")
+    assert float((z0[:, A0:] - 7.0).abs().max()) == 0
+    got = z0[:, :A0].double().cpu()
+    close(st.sum(0)[0], got.sum(0), 1e-5, "column sums")
+    close(st.sum(0)[1], (got * got).sum(0), 1e-5, "column sums of squares")
+    z1 = torch.zeros(M, A0, device="cuda")
+    call("clsr_att_l0_fwd", da, Q, dq, Q, Wt, Kp, dU, A0, dV, A0, z1, A0, None, Hn, G, T, Q, A0)
+    torch.cuda.synchronize()
+    close(z0[:, :A0], z1, 5e-5, "z0 vs the exact kernel")
+
+
+@pytest.mark.parametrize("Hn,T,Dk,Q,A0,qh", [(37, 50, 40, 80, 80, 40), (64, 50, 40, 40, 80, 0), (9, 7, 24, 44, 36, 0),
+                                             (5, 17, 8, 16, 16, 8), (2100, 5, 40, 80, 80, 40), (3, 50, 64, 48, 80, 24),
+                                             (2, 16, 32, 80, 40, 48)])
+@pytest.mark.parametrize("pieces", [2, 3])
+def test_history_level_prologue_x3(Hn, T, Dk, Q, A0, qh, pieces):
+    """clsr_att_hist_fwd_x3: a = keys . A, U = a . Wu + (a[:, :qh] * q_hist[h]) . Wp[:qh] in one launch of split-bf16
+    products == float64 (2^-16 relative per product term, two chained products)."""
+    assert query("clsr_att_hist_fwd_x3_supported", Dk, Q, A0, qh) == 1
+    assert query("clsr_att_hist_fwd_x3_supported", Dk, 96, A0, qh) == 0
+    g = torch.Generator().manual_seed(Hn + T + qh)
+    keys, A, Wu = rnd(g, Hn * T, Dk), rnd(g, Dk, Q, scale=0.3), rnd(g, Q, A0, scale=0.3)
+    Wp1, qhist = rnd(g, max(qh, 4), A0, scale=0.3), rnd(g, Hn, max(qh, 4))
+    At, Kpa = ops.pack_weight(dev(A), Q, Dk)
+    Wut, Kpu = ops.pack_weight(dev(Wu), A0, Q)
+    Wpt, Kpp = ops.pack_weight(dev(Wp1), A0, max(qh, 4))
+    dk, dqh = dev(keys), dev(qhist)
+    a = torch.full((Hn * T, Q + 4), 7.0, device="cuda")
+    U = torch.full((Hn * T, A0 + 4), 7.0, device="cuda")
+    call("clsr_att_hist_fwd_x3", dk, Dk, At, Kpa, Wut, Kpu, Wpt if qh else None, Kpp if qh else 0, dqh if qh else None,
+         max(qh, 4), Hn, T, Dk, Q, A0, qh, pieces, a, Q + 4, U, A0 + 4)
+    torch.cuda.synchronize()
+    ea = dk.double().cpu() @ dev(A).double().cpu()
+    eu = ea @ dev(Wu).double().cpu()
+    if qh:
+        qrep = dqh.double().cpu()[:, :qh].repeat_interleave(T, 0)
+        eu = eu + (ea[:, :qh] * qrep) @ dev(Wp1).double().cpu()[:qh]
+    close(a[:, :Q], ea, 5e-5 if pieces == 2 else 1e-6, "a")       # (3 pieces: 2^-23 per product term, fp32 accumulation)
+    close(U[:, :A0], eu, 1e-4 if pieces == 2 else 2e-6, "U")
+    assert float((a[:, Q:] - 7.0).abs().max()) == 0 and float((U[:, A0:] - 7.0).abs().max()) == 0
+
+
+@pytest.mark.parametrize("Hn,T,Dk,Q,A0,qh", [(37, 50, 40, 80, 80, 40), (64, 50, 40, 40, 80, 0), (9, 7, 24, 44, 40, 0),
+                                             (5, 17, 8, 16, 16, 8), (2100, 5, 40, 80, 80, 40), (3, 50, 48, 48, 96, 24),
+                                             (2, 16, 32, 80, 40, 48)])
+def test_history_level_backward_x3(Hn, T, Dk, Q, A0, qh):
+    """clsr_att_hist_bwd_x3: da = [(dU . Wp[:qh]^T) * q_hist | da] + dU . Wu^T, dq_hist += sum_t (dU . Wp[:qh]^T) * a,
+    dkeys += da . A^T in one launch == float64."""
+    assert query("clsr_att_hist_bwd_x3_supported", Dk, Q, A0, qh) == 1
+    g = torch.Generator().manual_seed(Hn + T + qh + 1)
+    M = Hn * T
+    dU, A, Wu = rnd(g, M, A0, scale=0.5), rnd(g, Dk, Q, scale=0.3), rnd(g, Q, A0, scale=0.3)
+    q4 = max(qh, 4)
+    Wp1, qhist, a = rnd(g, q4, A0, scale=0.3), rnd(g, Hn, q4), rnd(g, M, Q)
+    da0, dqh0, dk0 = rnd(g, M, Q), rnd(g, Hn, q4), rnd(g, M, Dk)
+    WuT, Kpu = ops.pack_weight(dev(Wu), Q, A0, transposed=True)
+    WpT, Kpp = ops.pack_weight(dev(Wp1), q4, A0, transposed=True)
+    AT, Kpa = ops.pack_weight(dev(A), Dk, Q, transposed=True)
+    d_dU, d_a, d_qh = dev(dU), dev(a), dev(qhist)
+    da = torch.full((M, Q + 4), 7.0, device="cuda")
+    da[:, :Q] = dev(da0)
+    if qh:
+        da[:, :qh] = float("nan")          # (columns < qh are written, never read)
+    dqh, dk = dev(dqh0).clone(), torch.full((M, Dk + 4), 7.0, device="cuda")
+    dk[:, :Dk] = dev(dk0)
+    call("clsr_att_hist_bwd_x3", d_dU, A0, WuT, Kpu, WpT if qh else None, Kpp if qh else 0, AT, Kpa, d_a, Q,
+         d_qh if qh else None, q4, Hn, T, Dk, Q, A0, qh, da, Q + 4, dqh if qh else None, q4, dk, Dk + 4)
+    torch.cuda.synchronize()
+    f = lambda t: dev(t).double().cpu()
+    r1 = f(dU) @ f(Wu).t()
+    eda = f(da0) + r1
+    if qh:
+        r2 = f(dU) @ f(Wp1)[:qh].t()
+        qrep = f(qhist)[:, :qh].repeat_interleave(T, 0)
+        eda[:, :qh] = r2 * qrep + r1[:, :qh]
+        edq = f(dqh0)[:, :qh] + (r2 * f(a)[:, :qh]).view(Hn, T, qh).sum(1)
+        close(dqh[:, :qh], edq, 1e-4, "dq_hist")
+        if q4 > qh:
+            assert torch.equal(dqh[:, qh:].cpu(), dev(dqh0)[:, qh:].cpu())
+    close(da[:, :Q], eda, 1e-4, "da")
+    close(dk[:, :Dk], f(dk0) + eda @ f(A).t(), 1e-4, "dkeys")
+    assert float((da[:, Q:] - 7.0).abs().max()) == 0 and float((dk[:, Dk:] - 7.0).abs().max()) == 0
