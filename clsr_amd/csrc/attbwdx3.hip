@@ -225,14 +225,20 @@ __global__ void __launch_bounds__(256, X3_OCC) att_l0_bwd_x3_kernel(AttL0BwdArgs
             for (int z = 0; z < NZ; ++z) uacc[z] = z4;
           }
           // A operands (rows beyond T are duplicates of step T-1 -> zero them; features beyond A0 were not read: zeros)
-          bf16x8 xh[KT], xl[KT];
-          if (t0 + 16 <= T) {
+          // (xr: the remainder x - xh - xl as a third piece, used by the transposing products only -- dU and dV are SUMS of
+          // dz0 that cancel analytically under the batch-norm (the bias gradient of the layer is exactly 0): two pieces
+          // left 2^-17 |dz0| sqrt(N) of noise there, scripts/fuzz_step.py case 4)
+          bf16x8 xh[KT], xl[KT], xr[KT];
+          {
+            const bool pv = t0 + j < T;      // (false only in a ragged last tile)
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) split8x(ring[d].x[kt], xh[kt], xl[kt]);
-          } else {
-            const bool pv = t0 + j < T;
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) split8x(pv ? ring[d].x[kt] : z8, xh[kt], xl[kt]);
+            for (int kt = 0; kt < KT; ++kt) {
+              f32x8 v = (t0 + 16 <= T || pv) ? ring[d].x[kt] : z8;
+              xh[kt] = to_h(v);
+              v -= to_f(xh[kt]);
+              xl[kt] = to_h(v);
+              xr[kt] = to_h(v - to_f(xl[kt]));
+            }
           }
           ring[d] = issue();
           // daq^T tiles: acc[f] = dz0 . Wp^T, 4 positions of query feature 16f + j
@@ -258,12 +264,13 @@ __global__ void __launch_bounds__(256, X3_OCC) att_l0_bwd_x3_kernel(AttL0BwdArgs
           f32x4 dzt[NZ];
 #pragma unroll
           for (int z = 0; z < NZ; ++z) {
-            f32x4 th = z4, tl = z4;
+            f32x4 th = z4, tl = z4, tr = z4;
             HMFMA(th, xh[z >> 1], sel[z & 1]);
             HMFMA(tl, xl[z >> 1], sel[z & 1]);
+            HMFMA(tr, xr[z >> 1], sel[z & 1]);
             cbh[z] = to_h4(th);
             cbl[z] = to_h4(tl);
-            dzt[z] = th + tl;
+            dzt[z] = th + (tl + tr);
           }
           // sums over the 16 positions of the tile: three adds inside a lane, then the four lane groups are summed by the
           // fp32 matrix pipe (ones[16x4] . partial[4x16]); lane group g4 then owns feature tile 4c + g4 of the accumulators.
@@ -543,7 +550,10 @@ __global__ void __launch_bounds__(256, 1) att_l1_bwd_x3_kernel(L1BwdArgsX a) {
     for (int ot = 0; ot < OT; ++ot) { fsum[ot] = 0.f; fsq[ot] = 0.f; dsum[ot] = 0.0; dsq[ot] = 0.0; }
   }
 
-  const x3_rsrc_t rz0 = x3_rsrc(a.z0), rdz = x3_rsrc(APPLY ? a.dz0 : nullptr);
+  // (exact sizes: a lane of a ragged last feature tile -- C0 % 16 != 0 -- addresses up to 15 floats past its row, at the
+  // last row past the END of the tensor; out of range it reads 0 / its store is dropped)
+  const x3_rsrc_t rz0 = x3_rsrc_n(a.z0, ((unsigned)(a.M - 1) * (unsigned)a.ldz0 + (unsigned)a.C0) * 4u);
+  const x3_rsrc_t rdz = x3_rsrc_n(APPLY ? a.dz0 : nullptr, APPLY ? ((unsigned)(a.M - 1) * (unsigned)a.lddz0 + (unsigned)a.C0) * 4u : 0u);
   const int ntiles = (a.M + 31) >> 5;
   struct RawT { f32x8 z1[2][KC]; f32x4 z0[2][OT]; float ds[2]; };
   auto fetch = [&](int tile) -> RawT {
@@ -578,7 +588,7 @@ __global__ void __launch_bounds__(256, 1) att_l1_bwd_x3_kernel(L1BwdArgsX a) {
     const RawT nxt = fetch(tile + tstride);      // (past the end: clamped / out-of-range loads, never used)
     const int m0 = tile * 32;
     // ---- prologue: dz1 of the lane's position (A operand: features 32c + 8g + {0..7}), split
-    bf16x8 dh[2][KC], dl[2][KC];
+    bf16x8 dh[2][KC], dl[2][KC], dr[APPLY ? 2 : 1][APPLY ? KC : 1];
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
       const int k0 = 32 * c + 8 * g;
@@ -592,7 +602,9 @@ __global__ void __launch_bounds__(256, 1) att_l1_bwd_x3_kernel(L1BwdArgsX a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] += y[e] > 0.f ? pp[e] * cur.ds[s] : 0.f;
         const bool pvalid = m0 + 16 * s + j < a.M;     // (features beyond C1: every table entry is 0 -> x = 0)
-        split8x(pvalid ? x : z8, dh[s][c], dl[s][c]);
+        const f32x8 xm = pvalid ? x : z8;
+        split8x(xm, dh[s][c], dl[s][c]);
+        if (APPLY) dr[s][c] = to_h(xm - to_f(dh[s][c]) - to_f(dl[s][c]));   // (third piece: the bias sums below)
       }
     }
     X3_SCHED_FENCE();
@@ -608,7 +620,11 @@ __global__ void __launch_bounds__(256, 1) att_l1_bwd_x3_kernel(L1BwdArgsX a) {
         HMFMA(tl1, dl[1][ct >> 1], sel[ct & 1]);
         bh[ct] = cat4(to_h4(th0), to_h4(th1));
         bl[ct] = cat4(to_h4(tl0), to_h4(tl1));
-        const f32x4 t = (th0 + tl0) + (th1 + tl1);
+        // (db1 = sum of dz1 cancels analytically under the batch-norm: its transposed image takes the third piece too)
+        f32x4 tr0 = z4, tr1 = z4;
+        HMFMA(tr0, dr[0][ct >> 1], sel[ct & 1]);
+        HMFMA(tr1, dr[1][ct >> 1], sel[ct & 1]);
+        const f32x4 t = (th0 + (tl0 + tr0)) + (th1 + (tl1 + tr1));
         bsum[ct] += (t.x + t.y) + (t.z + t.w);
       }
     }

@@ -291,7 +291,11 @@ __device__ __forceinline__ void ss_ld8(const int* __restrict__ a, const long q0,
   }
 }
 
-template <int VW>
+// LEAN: the site has no second gradient tensor and no mean / recent shares (src2, dmean, drecent all NULL) and its row totals
+// are stored (assign): four registers per entry in flight instead of twenty -- the kernel is bound by the number of row
+// reads it keeps in flight (profiles/r04_embed_kernel_trace.md: traffic = the algorithmic bytes at 3 TB/s), and with 240
+// VGPRs only two waves per SIMD were resident.
+template <int VW, bool LEAN>
 __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block, double* red) {
   typedef typename SsVec<VW>::type vec_t;
   const int CP = s.cp;                         // lanes per thread group (power of two, 8..64)
@@ -320,7 +324,7 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
         if (cok) *reinterpret_cast<vec_t*>(bnd + (from_prev ? 0 : Cp) + c) = acc;
       } else if (cok) {
         vec_t* g = reinterpret_cast<vec_t*>(s.grad + (long)cur * s.ldg + s.gcol0 + c);
-        *g = s.assign ? acc : *g + acc;
+        *g = (LEAN || s.assign) ? acc : *g + acc;
       }
       ++nruns;
     };
@@ -341,7 +345,7 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
       // 28 us for the bare rows
       vec_t rv[8], r2[8], mv[8], rc[8];
       int ln[8], tt[8];
-      const bool has_mr = s.dmean || s.drecent;          // (launch-uniform, like src2 / src_bf16)
+      const bool has_mr = !LEAN && (s.dmean || s.drecent);          // (launch-uniform, like src2 / src_bf16)
       const int cs = cok ? c : 0;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -357,26 +361,26 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
             rv[k] = *reinterpret_cast<const vec_t*>(s.src_b + (long)(pos - s.n1) * s.ldb + s.colb + cs);
           } else {
             rv[k] = ss_ld<VW>(s.src, 1, (long)pos * s.D + cc);
-            if (s.src2) rv[k] += ss_ld<VW>(s.src2, 1, (long)pos * s.D + cc);
+            if (!LEAN && s.src2) rv[k] += ss_ld<VW>(s.src2, 1, (long)pos * s.D + cc);
           }
         } else {
           const float* p = second ? s.src_b + (long)(pos - s.n1) * s.ldb + s.colb + cs
                                   : reinterpret_cast<const float*>(s.src) + (long)pos * s.D + cc;
           rv[k] = *reinterpret_cast<const vec_t*>(p);
-          if (s.src2) r2[k] = *reinterpret_cast<const vec_t*>(reinterpret_cast<const float*>(s.src2) + (long)pp * s.D + cc);
+          if (!LEAN && s.src2) r2[k] = *reinterpret_cast<const vec_t*>(reinterpret_cast<const float*>(s.src2) + (long)pp * s.D + cc);
         }
-        if (s.dmean) mv[k] = *reinterpret_cast<const vec_t*>(s.dmean + (long)h * s.D + cc);
-        if (s.drecent) rc[k] = *reinterpret_cast<const vec_t*>(s.drecent + (long)h * s.D + cc);
+        if (!LEAN && s.dmean) mv[k] = *reinterpret_cast<const vec_t*>(s.dmean + (long)h * s.D + cc);
+        if (!LEAN && s.drecent) rc[k] = *reinterpret_cast<const vec_t*>(s.drecent + (long)h * s.D + cc);
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         vec_t v = rv[k];
         if (!sec[k]) {
-          if (!s.src_bf16 && s.src2) v += r2[k];
+          if (!LEAN && !s.src_bf16 && s.src2) v += r2[k];
           const int len = ln[k];
           if (has_mr && tt[k] < len) {
-            if (s.dmean) v += mv[k] * (1.0f / (float)len);
-            if (s.drecent && tt[k] >= len - s.recent_k) v += rc[k] * (1.0f / (float)(len < s.recent_k ? len : s.recent_k));
+            if (!LEAN && s.dmean) v += mv[k] * (1.0f / (float)len);
+            if (!LEAN && s.drecent && tt[k] >= len - s.recent_k) v += rc[k] * (1.0f / (float)(len < s.recent_k ? len : s.recent_k));
           }
         }
         g[k] = (cok && key[k] >= 0) ? v : vec_t(0.f);
@@ -396,7 +400,7 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
       vec_t gv[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k)
-        gv[k] = s.assign ? vec_t(0.f)
+        gv[k] = (LEAN || s.assign) ? vec_t(0.f)
                          : *reinterpret_cast<const vec_t*>(s.grad + (long)(key[k] < 0 ? 0 : key[k]) * s.ldg + s.gcol0 + (cok ? c : 0));
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -456,8 +460,17 @@ __global__ void __launch_bounds__(256) ss_chunks_kernel(SsArgs a) {
   int i = 0;
   while (i + 1 < a.n && (int)blockIdx.x >= a.s[i + 1].first_block) ++i;
   const SsSite& s = a.s[i];
-  if (s.vw == 4) ss_chunks<4>(s, blockIdx.x - s.first_block, red);
-  else ss_chunks<1>(s, blockIdx.x - s.first_block, red);
+  if (s.vw == 4) ss_chunks<4, false>(s, blockIdx.x - s.first_block, red);
+  else ss_chunks<1, false>(s, blockIdx.x - s.first_block, red);
+}
+// every site of the launch is LEAN (see ss_chunks): half the registers, twice the resident waves
+__global__ void __launch_bounds__(256) ss_chunks_lean_kernel(SsArgs a) {
+  __shared__ double red[4];
+  int i = 0;
+  while (i + 1 < a.n && (int)blockIdx.x >= a.s[i + 1].first_block) ++i;
+  const SsSite& s = a.s[i];
+  if (s.vw == 4) ss_chunks<4, true>(s, blockIdx.x - s.first_block, red);
+  else ss_chunks<1, true>(s, blockIdx.x - s.first_block, red);
 }
 
 // Runs that cross chunk borders: the chunk whose LAST run continues (and is not itself a continuation covering the whole
@@ -642,7 +655,10 @@ extern "C" int clsr_segsum_multi(const clsr_segsum_desc* descs, int n, void* wor
   }
   CLSR_CHECK_ARG(workspace_bytes >= used + 16);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(ss_chunks_kernel, dim3(total), dim3(256), 0, st, a);
+  bool lean = true;
+  for (int i = 0; i < n; ++i) lean = lean && !descs[i].src2 && !descs[i].dmean && !descs[i].drecent && descs[i].assign;
+  if (lean) hipLaunchKernelGGL(ss_chunks_lean_kernel, dim3(total), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(ss_chunks_kernel, dim3(total), dim3(256), 0, st, a);
   CLSR_CHECK_LAUNCH();
   hipLaunchKernelGGL(ss_borders_kernel, dim3(total_b), dim3(256), 0, st, a);
   CLSR_CHECK_LAUNCH();

@@ -117,11 +117,14 @@ class CLSRNet(object):
         self.x3_dw = self.x3 and bool(os.environ.get("CLSR_X3_DW"))       # A/B: weight gradients (csrc/dw3.hip)
         self.x3_gemm = x3d and os.environ.get("CLSR_X3_GEMM", "xw^T")      # "all" | comma-separated weight keys | ""
         self.x3_enc = x3d and not os.environ.get("CLSR_NO_X3_ENC")        # A/B: fused encoder tail (csrc/encbwd.hip)
+        self.att_l1_fwd_x6 = x3d and not os.environ.get("CLSR_NO_ATT_L1_FWD_X6")   # A/B: second attention layer, forward (csrc/attl1fwd.hip)
         self.att_hist_bwd_x3 = x3d and not os.environ.get("CLSR_NO_ATT_HIST_BWD_X3")   # A/B: history-level attention backward in one launch
         self.att_hist_x3 = (x3d or self.precision == "bf16") and not self.exact_products and not os.environ.get("CLSR_NO_ATT_HIST_X3")  # A/B: history-level attention prologue in one launch (csrc/atthist.hip)
         # (forward products that feed a batch-norm + ReLU stay at fp32 accuracy in the parity mode -- x6 pieces in the
-        # history-level kernel, the fp32-MFMA layer-0 kernel -- see csrc/atthist.hip; "fp32x3" takes the x3 forms)
-        self.att_fwd_x3 = (self.x3 or bool(os.environ.get("CLSR_ATT_FWD_X3"))) and not self.exact_products and not os.environ.get("CLSR_NO_ATT_FWD_X3")  # A/B: first attention layer, forward (csrc/attl0fwd.hip)
+        # history-level kernel, the fp32-MFMA layer-0 kernel -- see csrc/atthist.hip; the x3 forms are opt-in:
+        # CLSR_ATT_FWD_X3=1, CLSR_ATT_HIST_PIECES=2)
+        self.att_fwd_x3 = bool(os.environ.get("CLSR_ATT_FWD_X3")) and not self.exact_products
+        self.att_hist_pieces = int(os.environ.get("CLSR_ATT_HIST_PIECES", "3"))  # A/B: first attention layer, forward (csrc/attl0fwd.hip)
         self.bf16_dw = not os.environ.get("CLSR_NO_HDW")        # A/B switch: weight gradients on the bf16 matrix pipe
         self.bf16_bwd = not os.environ.get("CLSR_NO_HBWD")      # A/B switch: back-propagating products likewise
         self._cur_descs_h = []
@@ -166,7 +169,7 @@ class CLSRNet(object):
         # that RCCL's stream is the FOURTH under data parallelism -- a fifth active queue (or a fourth next to a
         # high-priority compute stream) cost 4.0 -> 6.6 ms per step (r03, CLSR_FORCE_DP=1); on a single GPU the fold
         # measured 3.768 against 3.779 ms.  CLSR_FOLD_AUX=0: the round-2 layout with a stream of its own.
-        self.stream_alias = {} if os.environ.get("CLSR_FOLD_AUX") == "0" else {"@aux": "@lt"}
+        self.stream_alias = {} if os.environ.get("CLSR_FOLD_AUX") == "0" else {"@aux": os.environ.get("CLSR_AUX_ALIAS", "@lt")}
         self.side_priority = int(os.environ.get("CLSR_SIDE_PRIORITY", "0"))
         self.dw_priority = int(os.environ.get("CLSR_DW_PRIORITY", "0"))
         # Recurrences: hidden-to-hidden products as split-bf16 sums (csrc/rnn.hip, "x3") or fp32-input MFMAs ("fp32", bit-exact
@@ -1193,7 +1196,7 @@ class CLSRNet(object):
             Wut, Kpu = self.packed[key + ".Wu"]
             Wpt, Kpp = self.packed[key + ".Wp1"] if qh else (None, 0)
             call("clsr_att_hist_fwd_x3", keys, Dk, At, Kpa, Wut, Kpu, Wpt, Kpp, q_hist if qh else None, qh, Hn, T, Dk, Q,
-                 A0, qh, 3 if self.precision == "fp32" else 2, a, Q, U, A0)
+                 A0, qh, self.att_hist_pieces, a, Q, U, A0)
         else:
             self._gemm(keys, Dk, key + ".A", Hn * T, Dk, Q, a, Q)
             self._gemm(a, Q, key + ".Wu", Hn * T, Q, A0, U, A0)
@@ -1248,8 +1251,16 @@ class CLSRNet(object):
             self._gemm(a, Q, key + ".Wp", R * T, Q, A0, z0, A0, T=T, G=G, Xmul=q, ldmul=Q, addU=U, ldu=A0,
                        addV=V, ldv=A0, stats=st)
         self._bn_fwd(bn0, st, parts, R * T, training)
-        st, parts = self._stats_buf(R * T, A1) if training else (None, 0)
-        self._gemm(z0, A0, key + ".W1", R * T, A0, A1, z1, A1, bias=P[nn + "b_nn_layer1"], aff=bn0, stats=st)
+        if self.att_l1_fwd_x6 and query("clsr_att_l1_fwd_supported", A0, A1):
+            # z1 = relu(bn0(z0)) . W1 + b1 on the bf16 matrix pipe with three pieces per operand (csrc/attl1fwd.hip)
+            parts = query("clsr_att_l1_fwd_stats_parts", R * T) if training else 0
+            st = (self._buf("stats" + self._ws_tag, 1024 * 2 * 256, dtype=torch.float64)[: parts * 2 * A1]
+                  if training else None)
+            Wt, Kp = self.packed[key + ".W1"]
+            call("clsr_att_l1_fwd", z0, A0, bn0.scale, bn0.shift, Wt, Kp, P[nn + "b_nn_layer1"], z1, A1, st, R * T, A0, A1)
+        else:
+            st, parts = self._stats_buf(R * T, A1) if training else (None, 0)
+            self._gemm(z0, A0, key + ".W1", R * T, A0, A1, z1, A1, bias=P[nn + "b_nn_layer1"], aff=bn0, stats=st)
         self._bn_fwd(bn1, st, parts, R * T, training)
         call("clsr_att_out_fwd", z1, bn1.scale, bn1.shift, P[nn + "w_nn_output"], P[nn + "b_nn_output"],
              seq_len, len_stride, keys, Hn, G, T, A1, Dk, wts, out)

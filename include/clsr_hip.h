@@ -350,6 +350,14 @@ int clsr_att_hist_fwd_x3_supported(int Dk, int Q, int A0, int qh);
 int clsr_att_hist_fwd_x3(const float* keys, int ldk, const float* At, int Kpa, const float* Wut, int Kpu,
                          const float* Wpt, int Kpp, const float* q_hist, int ldqh, long Hn, int T, int Dk, int Q,
                          int A0, int qh, int pieces, float* a, int lda, float* U, int ldu, void* stream);
+/* Second attention layer, forward: z1 = relu(z0 * scale0 + shift0) . W1 + b1 with the product over three bf16 pieces per
+ * operand on the bf16 matrix pipe (2^-23 relative: the level of an fp32 fma chain), stats = per-block partial column sums /
+ * sums of squares of z1, [clsr_att_l1_fwd_stats_parts(M)][2][C1] doubles (NULL: none).  Wt = packed W1 (C1 rows, K = C0).
+ * Same results as clsr_pgemm with the affine + ReLU prologue (reference base_model.py:664-679). */
+int clsr_att_l1_fwd_supported(int C0, int C1);
+int clsr_att_l1_fwd_stats_parts(int M);
+int clsr_att_l1_fwd(const float* z0, int ldz0, const float* scale0, const float* shift0, const float* Wt, int Kp,
+                    const float* bias, float* z1, int ldz1, double* stats, int M, int C0, int C1, void* stream);
 /* History-level tail of the attention backward in one launch (csrc/atthist.hip), from one pass over dU [Hn*T, A0]:
  *   da = (columns >= qh: da as written by the layer-0 kernel | columns < qh: (dU . Wp[:qh]^T) * q_hist[h]) + dU . Wu^T
  *   dq_hist[h] += sum_t (dU . Wp[:qh]^T) * a[h,t,:qh];   dkeys += da . A^T

@@ -77,6 +77,12 @@ with torch.cuda.stream(st_):
     for pc in (2, 3):
         t = timeit(lambda: call("clsr_att_hist_fwd_x3", keys, Dk, At, Kpa, Wut, Kpu, Wpt, Kpp, qhist, qh, Hn, T, Dk, Qs, A0, qh, pc, a2, Qs, U2, A0))
         print("x%d    history-level prologue, one launch              R 33 + W 131 MB  %6.1f us" % (3 * (pc - 1), t))
+    W1f, K1f = ops.pack_weight(W1, A1, A0)
+    b1 = torch.randn(A1, device=dev)
+    t = timeit(lambda: call("clsr_pgemm", z0, A0, 0, 0, None, 0, sc0, sh0, 1, W1f, K1f, b1, None, 0, None, 0, z1, A1, 0, st, M, A0, A1))
+    print("fp32  l1 forward z1 = relu(bn z0).W1 + stats   R 328 + W 164 MB   %6.1f us  %5.2f TB/s" % (t, 492 / t))
+    t = timeit(lambda: call("clsr_att_l1_fwd", z0, A0, sc0, sh0, W1f, K1f, b1, z1, A1, st, M, A0, A1))
+    print("x6    l1 forward z1 = relu(bn z0).W1 + stats   R 328 + W 164 MB   %6.1f us  %5.2f TB/s" % (t, 492 / t))
     # long-term attention shapes (G = 1, history level)
     Hn, G = 4096, 1
     R, M = Hn, Hn * T

@@ -266,3 +266,32 @@ def test_history_level_backward_x3(Hn, T, Dk, Q, A0, qh):
     close(da[:, :Q], eda, 1e-4, "da")
     close(dk[:, :Dk], f(dk0) + eda @ f(A).t(), 1e-4, "dkeys")
     assert float((da[:, Q:] - 7.0).abs().max()) == 0 and float((dk[:, Dk:] - 7.0).abs().max()) == 0
+
+
+@pytest.mark.parametrize("M,C0,C1", [(2000, 80, 40), (515, 80, 40), (70, 16, 12), (4099, 40, 36), (40000, 80, 40),
+                                     (100, 48, 24), (33, 8, 4), (300, 96, 48)])
+def test_layer1_forward_three_pieces(M, C0, C1):
+    """clsr_att_l1_fwd: z1 = relu(bn0(z0)) . W1 + b1 over three bf16 pieces per operand == float64 at fp32 accuracy, with
+    the batch-norm sums of the stored z1."""
+    assert query("clsr_att_l1_fwd_supported", C0, C1) == 1 and query("clsr_att_l1_fwd_supported", 84, C1) == 0
+    g = torch.Generator().manual_seed(5 + M)
+    z0, W1, b1 = rnd(g, M, C0), rnd(g, C0, C1, scale=0.3), rnd(g, C1)
+    sc0, sh0 = torch.rand(C0, generator=g, dtype=torch.float64) + 0.5, rnd(g, C0, scale=0.3)
+    Wt, Kp = ops.pack_weight(dev(W1), C1, C0)
+    parts = query("clsr_att_l1_fwd_stats_parts", M)
+    st = torch.full((parts, 2, C1), 7.0, dtype=torch.float64, device="cuda")
+    z1 = torch.full((M, C1 + 4), 7.0, device="cuda")
+    d0, dsc, dsh, db = dev(z0), dev(sc0), dev(sh0), dev(b1)
+    call("clsr_att_l1_fwd", d0, C0, dsc, dsh, Wt, Kp, db, z1, C1 + 4, st, M, C0, C1)
+    torch.cuda.synchronize()
+    x1 = torch.clamp((d0 * dsc + dsh).double().cpu(), min=0)         # (the prologue in fp32, as the kernel takes it)
+    exp = x1 @ dev(W1).double().cpu() + db.double().cpu()
+    close(z1[:, :C1], exp, 2e-6, "z1")
+    assert float((z1[:, C1:] - 7.0).abs().max()) == 0
+    got = z1[:, :C1].double().cpu()
+    close(st.sum(0)[0], got.sum(0), 1e-6, "column sums")
+    close(st.sum(0)[1], (got * got).sum(0), 1e-6, "column sums of squares")
+    z1b = torch.zeros(M, C1, device="cuda")
+    call("clsr_att_l1_fwd", d0, C0, dsc, dsh, Wt, Kp, db, z1b, C1, None, M, C0, C1)
+    torch.cuda.synchronize()
+    assert torch.equal(z1b, z1[:, :C1].contiguous())
