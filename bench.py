@@ -567,9 +567,10 @@ def main():
             del src_, dst_
         except RuntimeError:
             pass
-        roof_mfma = None
+        roof_mfma, roof_bwd = None, None
         if args.model == "clsr":
             roof_mfma = net.bench_att_layer0(f, time_kernel)
+            roof_bwd = net.bench_att_l1_bwd(f, time_kernel) if hasattr(net, "bench_att_l1_bwd") else None
 
         single = world == 1 and dist is None and args.model == "clsr" and args.config == "taobao"
         if single and not args.no_extra:
@@ -687,6 +688,10 @@ def main():
             out["config"]["sync_bn_statistics_through"] = getattr(wl.stepper, "stats_transport", None)
         if roof_mfma is None:
             del out["roofline_mfma"]
+        if args.model == "clsr" and roof_bwd is not None:
+            out["roofline_att_bwd"] = roof_bwd
+        if args.model == "clsr":
+            out["config"]["products"] = net.precision_note()
         if modes:
             out["precision_modes"] = modes
         if extra:

@@ -251,6 +251,9 @@ extern "C" int clsr_sort_ids_stable_multi(const clsr_sortids_desc* descs, int n,
 #ifndef SS_CHUNK
 #define SS_CHUNK 32                 // sorted entries per thread group
 #endif
+#ifndef SS_WCH
+#define SS_WCH 1                    // chunks a wave of the border launch is responsible for (8: 20 us instead of 12 on the catalogue -- the category site has a head in most chunks and a wave walks its heads one after the other)
+#endif
 struct SsSite {
   const void* src; const void* src2; int src_bf16; const float* dmean; const float* drecent;
   const int* keys; const int* perm; const int* seq_len; int len_stride;
@@ -357,12 +360,14 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
         tt[k] = pp - h * s.T;
         ln[k] = has_mr ? s.seq_len[(long)h * s.len_stride] : 0;
         if (s.src_bf16) {
-          if (second) {
-            rv[k] = *reinterpret_cast<const vec_t*>(s.src_b + (long)(pos - s.n1) * s.ldb + s.colb + cs);
-          } else {
-            rv[k] = ss_ld<VW>(s.src, 1, (long)pos * s.D + cc);
-            if (!LEAN && s.src2) rv[k] += ss_ld<VW>(s.src2, 1, (long)pos * s.D + cc);
-          }
+          // (both sources unconditionally, from clamped rows, selected afterwards: under `if (second)` -- uniform in a thread
+          // group, not in a wave -- the eight loads of a batch left one branch at a time and the bf16 form of this launch,
+          // which moves 0.83 x the bytes, took 63 us against 56 us for fp32)
+          const vec_t vb = ss_ld<VW>(s.src, 1, (long)pp * s.D + cc);
+          const vec_t vs = s.n1 > 0 ? *reinterpret_cast<const vec_t*>(s.src_b + (long)(second ? pos - s.n1 : 0) * s.ldb + s.colb + cs)
+                                    : vec_t(0.f);
+          rv[k] = second ? vs : vb;
+          if (!LEAN && s.src2) r2[k] = second ? vec_t(0.f) : ss_ld<VW>(s.src2, 1, (long)pp * s.D + cc);
         } else {
           const float* p = second ? s.src_b + (long)(pos - s.n1) * s.ldb + s.colb + cs
                                   : reinterpret_cast<const float*>(s.src) + (long)pos * s.D + cc;
@@ -376,7 +381,7 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
       for (int k = 0; k < 8; ++k) {
         vec_t v = rv[k];
         if (!sec[k]) {
-          if (!LEAN && !s.src_bf16 && s.src2) v += r2[k];
+          if (!LEAN && s.src2) v += r2[k];
           const int len = ln[k];
           if (has_mr && tt[k] < len) {
             if (!LEAN && s.dmean) v += mv[k] * (1.0f / (float)len);
@@ -489,12 +494,21 @@ __device__ __forceinline__ void ss_borders(const SsSite& s, const int local_bloc
   const bool cok = c < s.C;
   const int Cp = CP * VW;
   const long nchunks = (s.n + SS_CHUNK - 1) / SS_CHUNK;
-  const long chunk = (long)local_block * 4 + wave;
-  if (chunk < nchunks) {
+  // a wave tests SS_WCH consecutive chunks at once (one lane each) and walks the heads among them: with one wave per chunk
+  // the launch cost 11.7 us on a catalogue with hardly any run across a border (1 760 workgroups that read one flag word)
+  const long cbase = ((long)local_block * 4 + wave) * SS_WCH;
+  unsigned long long heads = 0;
+  {
+    const long ck = cbase + lane;
+    int fl = 0;
+    if (lane < SS_WCH && ck < nchunks) fl = s.meta[ck * 4 + 2];
+    heads = __ballot((fl & 2) && !((fl & 4) && (fl & 1)));
+  }
+  while (heads) {
+    const long chunk = cbase + __builtin_ctzll(heads);
+    heads &= heads - 1;
     const int* m = s.meta + chunk * 4;
-    const int flags = m[2];
-    const bool head = (flags & 2) && !((flags & 4) && (flags & 1));     // (wave-uniform)
-    if (head) {
+    {
       const int key = m[1];
       // extent: chunks chunk + 1 .. chunk + L belong to the run (whole-chunk continuations, then the chunk it ends in)
       // (256 chunks per trip -- four 16-byte flag loads per lane in flight: the scan is a chain of dependent loads, and the
@@ -651,7 +665,7 @@ extern "C" int clsr_segsum_multi(const clsr_segsum_desc* descs, int n, void* wor
     s.nblocks = nb;
     total += nb;
     s.first_block_b = total_b;
-    total_b += clsr_cdiv(nchunks, 4);
+    total_b += clsr_cdiv(nchunks, 4 * SS_WCH);
   }
   CLSR_CHECK_ARG(workspace_bytes >= used + 16);
   hipStream_t st = (hipStream_t)stream;

@@ -149,6 +149,7 @@ class CLSRNet(object):
         self.split_emb_grad = not os.environ.get("CLSR_SERIAL_EMB_GRAD")   # A/B switch (embedding gradient sites)
         self.use_plans = not os.environ.get("CLSR_NO_PLAN")                # replay recorded launch sequences
         self.split_g2 = not os.environ.get("CLSR_NO_SPLIT_G2")             # A/B switch (causal GRU off the main launch)
+        self.g2_stream = os.environ.get("CLSR_G2_STREAM", "@lt")           # A/B: which side stream runs the causal GRU's forward
         self._step_plans = {}
         self.dw_streams = int(os.environ.get("CLSR_DW_STREAMS", "1"))
         self.fused_l0_bwd = not os.environ.get("CLSR_NO_FUSED_L0_BWD")   # A/B switch (see _att_bwd)
@@ -1853,8 +1854,14 @@ class CLSRNet(object):
         fork = self._fork_point()
         if self.rnn_first:
             ops.rnn_multi("clsr_rnn_fwd_multi", grus, t4d, seq_len, ls, Hn, T)
+        g2_tag = self.g2_stream if g2_side is not None else None
+        if g2_tag and g2_tag != "@lt":
+            # the causal GRU on the weight-gradient stream, idle in the forward pass: behind it on @lt the long-term attention
+            # finished ~70 us after the short-term one and the heads waited for it (profiles/r05_step_timeline_fp32.txt)
+            with self._branch(g2_tag, after=fork, name="@g2"):
+                ops.rnn_multi("clsr_rnn_fwd_multi", [g2_side], None, seq_len, ls, Hn, T)
         with self._branch("@lt", after=fork):
-            if g2_side is not None:
+            if g2_side is not None and g2_tag == "@lt":
                 ops.rnn_multi("clsr_rnn_fwd_multi", [g2_side], None, seq_len, ls, Hn, T)
             att_long = self._att_fwd("lt", lt, hist, ulong, Hn, 1, T, D, Du, seq_len, ls, training)
         if not self.rnn_first:
@@ -2511,8 +2518,14 @@ class CLSRNet(object):
 
     # ------------------------------------------------------------------ measurement hooks (bench.py)
     def precision_note(self):
+        if self.precision == "fp32" and self.exact_products:
+            return "all tensors fp32, v_mfma_f32_16x16x4_f32 (bit-exact fp32 fmaf chains) everywhere (CLSR_EXACT_PRODUCTS=1)"
         if self.precision == "fp32":
-            return "all tensors fp32, v_mfma_f32_16x16x4_f32 (bit-exact fp32 fmaf chains): the parity mode"
+            return ("all tensors fp32: the parity mode.  Forward products in front of a batch-norm + ReLU at fp32 accuracy "
+                    "(v_mfma_f32_16x16x4_f32, or three bf16 pieces per operand on v_mfma_f32_16x16x32_bf16: 2^-23 relative); the "
+                    "recurrences' hidden products, the attention-MLP backward with its folded weight gradients, the history-level "
+                    "attention backward and the fused encoder tail as split-bf16 sums hi*hi + hi*lo + lo*hi with fp32 accumulation "
+                    "(2^-16 relative per product term); CLSR_EXACT_PRODUCTS=1 restores fp32-input MFMAs everywhere")
         if self.precision == "fp32x3":
             return ("all tensors fp32 (storage, statistics, recurrences, losses, optimiser exactly as in the parity mode); the "
                     "MFMA-saturated products are split-bf16 sums hi*hi + lo*hi + hi*lo on v_mfma_f32_16x16x32_bf16 with fp32 "
@@ -2543,6 +2556,30 @@ class CLSRNet(object):
                     note=("bf16-input MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate; K = N = 80: the kernel is "
                           "bound by its 164 MB bf16 output + operand reads, not by the matrix pipe" if bf else
                           "fp32-input MFMA (v_mfma_f32_16x16x4_f32); peak = dense fp32 matrix rate"))
+
+    def bench_att_l1_bwd(self, f, time_kernel):
+        """HIP-event timing of the HBM-heaviest kernel of the backward pass in isolation: pass 2 of the second attention
+        layer's backward (short-term attention, B*T positions): reads z1 and z0, writes dz0, accumulates dW1 / db1."""
+        if self.bf16 or self.att_bwd != "x3" or not query("clsr_att_l1_bwd_x3_supported", self.A1, self.A0):
+            return None
+        B, T, G, Hn = self.last_shape
+        A0, A1, M = self.A0, self.A1, B * T
+        key, nn = "st", CL + "short_term/attention_fcn/att_fcn/nn_part/"
+        bn0, bn1 = self.bn[nn + "batch_normalization/"], self.bn[nn + "batch_normalization_1/"]
+        z0, z1 = self._buf(key + ".z0", M, A0), self._buf(key + ".z1", M, A1)
+        dz0, ds = self._buf(key + ".dz0", M, A0), self._buf(key + ".ds", M)
+        Wt, Kp = self.packed[key + ".W1^T"]
+        parts = query("clsr_att_l1_bwd_x3_parts", M)
+        ws = self._buf(key + ".dw1x_ws", parts * query("clsr_dw_chunk_floats"))
+        wo = self.P[nn + "w_nn_output"]
+        t = time_kernel(lambda: call("clsr_att_l1_bwd_x3", z1, A1, ds, bn1.scale, bn1.shift, wo, bn1.coef, Wt, Kp, z0, A0,
+                                     bn0.scale, bn0.shift, None, None, bn0.coef, dz0, A0, ws, None, M, A1, A0))
+        nbytes = float(M) * (A1 + 2 * A0 + 1) * 4
+        return dict(bound="hbm", kernel="att_l1_bwd_x3_kernel<5,3,true> (short-term attention, layer-1 backward pass 2: dz0 + the "
+                                        "partial sums of dW1 / db1 from one pass over z1, z0; split-bf16 products)",
+                    achieved=round(nbytes / t / 1e9, 1), peak=8000.0, unit="GB/s", frac=round(nbytes / t / 8e12, 4),
+                    bytes_per_launch=nbytes, us_per_launch=round(t * 1e6, 2),
+                    formula="M * (A1 + A0) * 4 read + M * A0 * 4 written + M * 4 (score gradient), M = B*T positions")
 
     def _att_layer0_launcher(self, key, Hn, G, T, Q):
         R, A0 = Hn * G, self.A0
