@@ -349,8 +349,8 @@ def embedding_rooflines(net, f, cfg, G, feed):
                         formula="n*W*%d (gradient read) + n*W*4 (fp32 row-gradient write) + 2*n*4 (+ the target rows' slices)"
                                 % sa, columns=W, sites_merged=bool(merged))
         if tag == "gather_bwd_item_and_category_one_stream":
-            out[tag].update(traffic=194.7e6, traffic_source="profiles/r04_embed_kernel_trace.md (48 dispatches, fp32 and bf16 "
-                                                            "d(hist) alternating: ss_chunks 190.9 MB + ss_borders 3.8 MB per launch)")
+            out[tag].update(traffic=203.7e6, traffic_source="profiles/r05_embed_kernel_trace.md, counters in KiB (48 dispatches, fp32 and bf16 "
+                                                            "d(hist) alternating: ss_chunks_lean 200.4 MB + ss_borders 3.8 MB per launch = WRITE_SIZE + 2 x FETCH_SIZE)")
         clear_grads()
     # ---- bf16 tables + bf16 hist: bytes_gather_fwd(n) = n*D*(2 + 2) + 2*n*4
     try:
@@ -387,7 +387,7 @@ def embedding_rooflines(net, f, cfg, G, feed):
                                 % (nrows, Di * 4), achieved=round(nbytes / t / 1e9, 1), peak=8000.0, unit="GB/s",
                                 frac=round(nbytes / t / 8e12, 4), bytes_per_launch=nbytes, us_per_launch=round(t * 1e6, 2),
                                 formula="touched_rows*Drow*(param, m, v read + write; gradient read + clear)*4",
-                                traffic=688.0e6, traffic_source="profiles/r04_embed_kernel_trace.md (24 dispatches, 225 012 rows: "
+                                traffic=704.5e6, traffic_source="profiles/r05_embed_kernel_trace.md, counters in KiB (24 dispatches, 225 012 rows: "
                                                                 "WRITE_SIZE 344.4 MB + 2 x FETCH_SIZE 171.8 MB; algorithmic 691 MB)")
         if it_h is not None:
             t = time_kernel(lambda: ops.call("clsr_table_adam_rows_h", it_h, tg["item"], m, v, fl, ids, count, cap, Di, ss, 1,
@@ -545,7 +545,7 @@ def main():
         roof = gather_roofline(net, f, cfg, G, feed, big)
         # PMC pass committed in profiles/r02_gather_hist_fwd_pmc_hbm_traffic.csv (same shape): WRITE_SIZE
         # 33.3 MB + 2 x FETCH_SIZE 12.5 MB (gfx950 wide-load correction); reads of the 8 MB tables hit cache
-        roof.update(traffic=208.8e6 if big else 58.3e6, traffic_source="profiles/r04_gather_pmc_{WRITE,FETCH}_SIZE.csv (first 22 dispatches: this config; last 22: the catalogue)",
+        roof.update(traffic=213.7e6 if big else 59.7e6, traffic_source="counters in KiB; profiles/r04_gather_pmc_{WRITE,FETCH}_SIZE.csv (first 22 dispatches: this config; last 22: the catalogue)",
                     note=("tables (%.1f MB) are L2/Infinity-Cache resident at this config; the HBM claim needs the "
                           "100M-item config" % ((cfg["Vi"] * cfg["Di"] + cfg["Vc"] * cfg["Dc"]) * 4 / 1e6))
                     if not big else "38 GB item table, uniform ids: every row read is an HBM read")
@@ -571,6 +571,7 @@ def main():
         if args.model == "clsr":
             roof_mfma = net.bench_att_layer0(f, time_kernel)
             roof_bwd = net.bench_att_l1_bwd(f, time_kernel) if hasattr(net, "bench_att_l1_bwd") else None
+        products_note = net.precision_note() if args.model == "clsr" else None
 
         single = world == 1 and dist is None and args.model == "clsr" and args.config == "taobao"
         if single and not args.no_extra:
@@ -633,7 +634,7 @@ def main():
                 cache_resident = dict(roof)
                 roof = dict(big_roof, workload="BASELINE configs[4] catalogue: 100M items, rows 384 B + 128 B, uniform "
                                                "ids, 4096 histories x 50 steps (38 GB table: every row read is an HBM read)",
-                            traffic=208.7e6, traffic_source="profiles/r04_gather_pmc_WRITE_SIZE.csv + r04_gather_pmc_FETCH_SIZE.csv, the 22 "
+                            traffic=213.7e6, traffic_source="counters in KiB; profiles/r04_gather_pmc_WRITE_SIZE.csv + r04_gather_pmc_FETCH_SIZE.csv, the 22 "
                                                             "catalogue dispatches (WRITE_SIZE 106.5 MB + 2 x FETCH_SIZE 51.1 MB; round 2 "
                                                             "measured the same: profiles/r02_gather_hist_fwd_pmc_hbm_traffic.csv)",
                             cache_resident_at_benchmarked_config=cache_resident)
@@ -690,8 +691,8 @@ def main():
             del out["roofline_mfma"]
         if args.model == "clsr" and roof_bwd is not None:
             out["roofline_att_bwd"] = roof_bwd
-        if args.model == "clsr":
-            out["config"]["products"] = net.precision_note()
+        if products_note:
+            out["config"]["products"] = products_note
         if modes:
             out["precision_modes"] = modes
         if extra:
