@@ -560,7 +560,8 @@ extern "C" int clsr_table_adam_rows(float* table, float* grad_table, float* m, f
   CLSR_CHECK_ARG(nsum > 0);
   const bool vec = C % 4 == 0;
   int blocks = clsr_cdiv((long)cap * C, 256 * 4 * (vec ? 2 : 1));
-  static const int cap_blocks = getenv("CLSR_ADAM_ROWS_BLOCKS") ? atoi(getenv("CLSR_ADAM_ROWS_BLOCKS")) : 4096;
+  static const int cap_env = getenv("CLSR_ADAM_ROWS_BLOCKS") ? atoi(getenv("CLSR_ADAM_ROWS_BLOCKS")) : 4096;
+  const int cap_blocks = cap_env > 0 ? cap_env : 4096;      // (a non-positive value would launch nothing)
   if (blocks > cap_blocks) blocks = cap_blocks;
   if (vec)
     hipLaunchKernelGGL((table_adam_rows_kernel<4, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, grad_table,

@@ -1,0 +1,154 @@
+// Plain projection  Y[m, :N] = X[m, :K] . W + b  over M positions as split-bf16 products (gfx950): the K-fused time-gate
+// projection of the Time4LSTM ([hist | TT] . [W_x ; W_t], K = 128 -> N = 120; reference rnn_cell_implement.py:214-236 --
+// the input-side pre-activations of the o / T1 / T2 gates).  It sits on the step's dependent chain IN FRONT of the
+// recurrences; the position-tiled fp32 kernel took 118 us for 6.3 GFLOP / 0.2 GB (256 fp32 MFMAs of 32 cycles per 16
+// positions).  Here: A = the X tile (rows = positions, 8 consecutive features per lane and K = 32 chunk), B = bf16
+// pieces of W from LDS, 96 bf16 MFMAs per 16 positions (two pieces per operand: the result feeds sigmoid gates, like the
+// recurrences' own split products), a lane of the result holds four positions of one output feature and stores them as
+// 4-byte pieces of 64-byte row segments (csrc/attl1fwd.hip).
+#include "common.h"
+#include "clsr_hip.h"
+#include "hmma.h"
+
+struct ProjArgs {
+  const float* X; int ldx;
+  const float* Wt; int Kp;        // packed W (clsr_pack_batch): row n = output feature (N rows), K inputs
+  const float* bias;              // may be NULL
+  float* Y; int ldy;
+  int M, K, N;
+};
+
+// NKC = 32-wide chunks of K, NT = 16-feature tiles of N, NP = bf16 pieces per operand
+template <int NKC, int NT, int NP>
+__global__ void __launch_bounds__(256, 2) proj_x3_kernel(ProjArgs a) {
+  CLSR_CHAIN_PRIO();
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int WS = 32 * NKC + 8, NR = 16 * NT;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int j = lane & 15, g = lane >> 4;
+  __bf16* Wi = reinterpret_cast<__bf16*>(lds_raw);          // [NP][NR][WS]
+  {
+    constexpr int C8 = WS / 8;
+    for (int e = tid; e < NR * C8; e += 256) {
+      const int row = e / C8, k = 8 * (e - row * C8);
+      f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (row < a.N && k < a.K) v = ld8f(a.Wt + (long)row * a.Kp + k);            // (K % 8 == 0)
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const bf16x8 h = to_h(v);
+        reinterpret_cast<bf16x8*>(Wi + (size_t)i * NR * WS)[e] = h;
+        v -= to_f(h);
+      }
+    }
+  }
+  __syncthreads();
+  float bias[NT];
+  unsigned co[NT];
+  constexpr unsigned SKIP = 0x40000000u;      // (out of range alone and in the sum of two: the resource spans exactly Y)
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const bool ok = 16 * n + j < a.N;
+    bias[n] = (ok && a.bias) ? a.bias[16 * n + j] : 0.f;
+    co[n] = ok ? (16 * n + j) * 4u : SKIP;
+  }
+  const int wrow = j * WS + 8 * g;
+  const __amdgpu_buffer_rsrc_t ry =
+      __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, ((unsigned)(a.M - 1) * (unsigned)a.ldy + (unsigned)a.N) * 4u, 0x00020000);
+  const f32x8 z8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int kofs[NKC];
+#pragma unroll
+  for (int c = 0; c < NKC; ++c) kofs[c] = 32 * c + 8 * g < a.K ? 32 * c + 8 * g : 0;
+
+  const int ntiles = (a.M + 15) >> 4;
+  const int tstride = gridDim.x * 4;
+  int tile = blockIdx.x * 4 + wave;
+  struct Raw { f32x8 x[NKC]; };
+  auto fetch = [&](int t) -> Raw {
+    Raw r;
+    const int m = t * 16 + j;
+    const float* p = a.X + (long)(m < a.M ? m : a.M - 1) * a.ldx;
+#pragma unroll
+    for (int c = 0; c < NKC; ++c) r.x[c] = ld8f(p + kofs[c]);
+    return r;
+  };
+  Raw cur = fetch(tile);
+  for (; tile < ntiles; tile += tstride) {
+    const Raw nxt = fetch(tile + tstride);
+    const int m0 = tile * 16;
+    const bool pv = m0 + j < a.M;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){bias[n], bias[n], bias[n], bias[n]};
+#pragma unroll
+    for (int c = 0; c < NKC; ++c) {
+      __builtin_amdgcn_sched_barrier(0);
+      f32x8 y = (pv && 32 * c + 8 * g < a.K) ? cur.x[c] : z8;
+      bf16x8 xp[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        xp[i] = to_h(y);
+        if (i + 1 < NP) y -= to_f(xp[i]);
+      }
+      bf16x8 w[NP][NT];
+#pragma unroll
+      for (int i = 0; i < NP; ++i)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) w[i][n] = ld8h(Wi + (size_t)i * NR * WS + wrow + 16 * n * WS + 32 * c);
+#pragma unroll
+      for (int sidx = NP - 1; sidx >= 0; --sidx)
+#pragma unroll
+        for (int i = 0; i <= sidx; ++i)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) HMFMA(acc[n], xp[i], w[sidx - i][n]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int p = m0 + 4 * g + e;
+      const unsigned ro = p < a.M ? (unsigned)p * (unsigned)a.ldy * 4u : SKIP;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const float v = acc[n][e];      // (a copy: __builtin_bit_cast straight on the vector ELEMENT took element 0 for every e)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, ro + co[n], 0, 0);
+      }
+    }
+    cur = nxt;
+  }
+}
+
+extern "C" int clsr_proj_x3_supported(int M, int K, int N) {
+  return M > 0 && K >= 8 && K <= 128 && K % 8 == 0 && N >= 4 && N <= 128 && N % 4 == 0;
+}
+
+template <int NKC, int NT, int NP>
+static int proj_launch(const ProjArgs& a, hipStream_t stream) {
+  constexpr int WS = 32 * NKC + 8, NR = 16 * NT;
+  const size_t shmem = (size_t)NP * NR * WS * 2;
+  int gx = clsr_cdiv(clsr_cdiv(a.M, 16), 4);
+  if (gx > 512) gx = 512;
+  auto kernel = proj_x3_kernel<NKC, NT, NP>;
+  if (shmem > 64 * 1024) CLSR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL(kernel, dim3(gx), dim3(256), shmem, stream, a);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+// pieces = 2: 2^-16 relative per product term; 3: 2^-23
+extern "C" int clsr_proj_x3(const float* X, int ldx, const float* Wt, int Kp, const float* bias, float* Y, int ldy, int M,
+                            int K, int N, int pieces, void* stream) {
+  CLSR_CHECK_ARG(X && Wt && Y && (pieces == 2 || pieces == 3));
+  CLSR_CHECK_SUPPORTED(clsr_proj_x3_supported(M, K, N));
+  CLSR_CHECK_ARG(ldx >= K && ldy >= N && Kp >= 16 * clsr_cdiv(K, 16));
+  CLSR_CHECK_SUPPORTED(ldx % 4 == 0 && Kp % 4 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)Wt % 16) == 0 &&
+                       ((uintptr_t)Y % 4) == 0 && ((long)M * ldy) * 4 < 0x40000000L);
+  ProjArgs a = {};
+  a.X = X; a.ldx = ldx; a.Wt = Wt; a.Kp = Kp; a.bias = bias; a.Y = Y; a.ldy = ldy; a.M = M; a.K = K; a.N = N;
+  hipStream_t s = (hipStream_t)stream;
+  const int nkc = clsr_cdiv(K, 32), nt = N <= 48 ? 3 : (N <= 80 ? 5 : 8);
+#define PJ_GO(C, T) \
+  if (nkc == C && nt == T) return pieces == 2 ? proj_launch<C, T, 2>(a, s) : proj_launch<C, T, 3>(a, s)
+  PJ_GO(1, 3); PJ_GO(2, 3); PJ_GO(3, 3); PJ_GO(4, 3);
+  PJ_GO(1, 5); PJ_GO(2, 5); PJ_GO(3, 5); PJ_GO(4, 5);
+  PJ_GO(1, 8); PJ_GO(2, 8); PJ_GO(3, 8); PJ_GO(4, 8);
+#undef PJ_GO
+  return CLSR_OK;
+}

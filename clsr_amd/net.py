@@ -114,11 +114,13 @@ class CLSRNet(object):
         # fp32 fma chains) for parity debugging; "fp32x3" additionally honours the opt-in sites below.
         self.exact_products = bool(os.environ.get("CLSR_EXACT_PRODUCTS"))
         x3d = self.precision in ("fp32", "fp32x3") and not self.exact_products
-        self.x3_dw = self.x3 and bool(os.environ.get("CLSR_X3_DW"))       # A/B: weight gradients (csrc/dw3.hip)
+        self.x3_dw = False      # (the generic split-bf16 weight-gradient kernel, csrc/dw3.hip, measured level or slower in
+                                # round 4 and was removed in round 5: the attention weight gradients are folded into the
+                                # backward kernels instead, csrc/attbwdx3.hip)
         self.x3_gemm = x3d and os.environ.get("CLSR_X3_GEMM", "xw^T")      # "all" | comma-separated weight keys | ""
         self.x3_enc = x3d and not os.environ.get("CLSR_NO_X3_ENC")        # A/B: fused encoder tail (csrc/encbwd.hip)
         self.att_l1_fwd_x6 = x3d and not os.environ.get("CLSR_NO_ATT_L1_FWD_X6")   # A/B: second attention layer, forward (csrc/attl1fwd.hip)
-        self.att_hist_bwd_x3 = x3d and not os.environ.get("CLSR_NO_ATT_HIST_BWD_X3")   # A/B: history-level attention backward in one launch
+        self.att_hist_bwd_x3 = (x3d or self.precision == "bf16") and not self.exact_products and not os.environ.get("CLSR_NO_ATT_HIST_BWD_X3")   # A/B: history-level attention backward in one launch
         self.att_hist_x3 = (x3d or self.precision == "bf16") and not self.exact_products and not os.environ.get("CLSR_NO_ATT_HIST_X3")  # A/B: history-level attention prologue in one launch (csrc/atthist.hip)
         # (forward products that feed a batch-norm + ReLU stay at fp32 accuracy in the parity mode -- x6 pieces in the
         # history-level kernel, the fp32-MFMA layer-0 kernel -- see csrc/atthist.hip; the x3 forms are opt-in:
@@ -142,7 +144,11 @@ class CLSRNet(object):
         self.dw_stream = not os.environ.get("CLSR_NO_DW_STREAM")   # A/B switch (see _dw)
         self._dw_async = False
         # A/B switch (see _att_qh); the bf16 speed mode keeps the whole query in the per-(row, step) GEMM (K is cheap there)
-        self.split_query = not os.environ.get("CLSR_NO_SPLIT_QUERY") and self.precision != "bf16"
+        self.split_query = not os.environ.get("CLSR_NO_SPLIT_QUERY")
+        # (speed mode, round 5: with the history-level share of the product term inside the fused history-level kernels
+        # -- csrc/atthist.hip -- the split costs no launch any more and halves K of the per-(row, step) kernels;
+        # CLSR_BF16_NO_SPLIT_QUERY=1: the whole query in those kernels, as before)
+        self.bf16_split_query = not os.environ.get("CLSR_BF16_NO_SPLIT_QUERY")
         # history-level half of the short-term query folded into U (see _att_qh): pays off at every width once the per-row
         # half runs on the one-wave-per-history kernels (round 3; the position-tiled kernels needed Du >= 64)
         self.split_query_min = int(os.environ.get("CLSR_SPLIT_QUERY_MIN", "16"))
@@ -181,6 +187,8 @@ class CLSRNet(object):
         if self.rnn_products not in ("x3", "fp32"):
             raise ValueError("CLSR_RNN_PRODUCTS must be 'x3' or 'fp32'")
         self.rnn_fused_proj = self.rnn_products == "x3" and not os.environ.get("CLSR_NO_RNN_FUSED_PROJ")
+        # the Time4LSTM's K-fused time-gate projection as split products too (csrc/projx3.hip): it feeds the same sigmoid gates
+        self.proj_x3 = (self.rnn_products == "x3" and not self.exact_products and not os.environ.get("CLSR_NO_PROJ_X3"))
         self.rnn_act_tiled = self.rnn_products == "x3" and not os.environ.get("CLSR_NO_RNN_ACT_TILED")
         # Attention-MLP backward (exact mode): "x3" = the two-pass layer-1 kernel and the one-pass layer-0 kernel as split-bf16
         # products with the weight gradients dW1 / db1 / dWp accumulated inside them (csrc/attbwdx3.hip: no separate
@@ -734,7 +742,7 @@ class CLSRNet(object):
             # enqueued so far
             fork = self._fork_point()
         name = ("clsr_hdw_partial_multi" if (self.bf16 and self.bf16_dw) else
-                "clsr_dw3_partial_multi" if self.x3_dw else "clsr_pgemm_dw_partial_multi")
+                "clsr_pgemm_dw_partial_multi")
         if self.dw_stream and self.overlap and self._ws_tag == "":
             side = self._side.get("@dw0")
             if side is None:
@@ -762,7 +770,7 @@ class CLSRNet(object):
         """which query tells how many partial chunks the weight-gradient kernel of this mode writes"""
         if self.bf16 and self.bf16_dw:
             return "clsr_hdw_parts"
-        return "clsr_dw3_parts" if (self.x3_dw and not any_bf16) else "clsr_pgemm_dw_parts"
+        return "clsr_pgemm_dw_parts"
 
     def _dw_launch(self, X, x_bf16, ldx, T, G, Xmul, ldmul, sc, sh, dY, dy_bf16, ldy, M, K, N, ws, stream):
         """Partial-sum kernel of one weight gradient: the exact fp32-MFMA kernel, or -- speed mode -- the bf16-MFMA
@@ -770,8 +778,6 @@ class CLSRNet(object):
         if self.bf16 and self.bf16_dw:
             call("clsr_hdw_partial", X, x_bf16, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, dy_bf16, ldy, M, K, N, ws,
                  stream=stream)
-        elif self.x3_dw and not (x_bf16 or dy_bf16):
-            call("clsr_dw3_partial", X, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, ldy, M, K, N, ws, stream=stream)
         elif x_bf16 or dy_bf16:
             call("clsr_pgemm_dw_partial_h", X, x_bf16, ldx, T, G, Xmul, ldmul, sc, sh, 1, dY, dy_bf16, ldy, M, K, N, ws,
                  stream=stream)
@@ -952,7 +958,16 @@ class CLSRNet(object):
         into U[h,t]; only the target half stays in the per-(row, step) GEMM (K = D instead of Du + D).  Pays off
         when the layers are wide (BASELINE configs[4], Du = 128: 15.15 -> 14.36 ms/step); at Du = 40 the big GEMMs
         are bound by their stores, not by K, and the five extra launches cost 1 % -- hence the width threshold."""
-        return self.Du if (key == "st" and self.split_query and self.Du >= self.split_query_min) else 0
+        if not (key == "st" and self.split_query and self.Du >= self.split_query_min):
+            return 0
+        if self.precision == "bf16":
+            # speed mode: only with the fused history-level kernels and the one-pass layer-0 backward (default widths)
+            ok = (self.bf16_split_query and self.att_hist_x3 and self.att_hist_bwd_x3 and self.fused_l0_bwd
+                  and query("clsr_att_hist_fwd_x3_supported", self.H, self.Du + self.D, self.A0, self.Du)
+                  and query("clsr_att_hist_bwd_x3_supported", self.H, self.Du + self.D, self.A0, self.Du)
+                  and query("clsr_att_l0_bwd_h_supported", self.G_train, self.D, self.A0))
+            return self.Du if ok else 0
+        return self.Du
 
     def _plan_weights(self, training):
         hp, P = self.hp, self.P
@@ -985,6 +1000,10 @@ class CLSRNet(object):
         self._pack(key + ".W1", W1, A1, A0)
         if self.bf16:
             self._pack_h(key + ".Wp", W0[3 * Q:4 * Q], A0, Q)
+            if qh:
+                self._pack_h(key + ".Wp2", W0[3 * Q + qh:4 * Q], A0, Q - qh)
+                if training:
+                    self._pack_h(key + ".Wp2^T", W0[3 * Q + qh:4 * Q], Q - qh, A0, transposed=True)
             self._pack_h(key + ".W1", W1, A1, A0)
             if training:
                 self._pack_h(key + ".Wp^T", W0[3 * Q:4 * Q], Q, A0, transposed=True)
@@ -1208,15 +1227,20 @@ class CLSRNet(object):
             parts = query("clsr_hgemm_stats_parts", M) if training else 0
             sbuf = self._buf("stats" + self._ws_tag, 1024 * 2 * 256, dtype=torch.float64)
             st = sbuf[: parts * 2 * A0] if training else None
-            Wt, Kp = self.packed_h[key + ".Wp"]
-            if self.l0_fwd_wave and query("clsr_hgemm_l0_group_supported", G, Q, A0):
+            if qh and not hist_x3:
+                self._gemm(a, Q, key + ".Wp1", Hn * T, qh, A0, U, A0, T=T, G=1, Xmul=q_hist, ldmul=qh, addU=U, ldu=A0,
+                           addV=self._buf("att.zeroV", Hn, A0), ldv=A0)
+            # (split query: only the target columns stay in the per-(row, step) product, K = Q - qh)
+            Qe, ae, qe = Q - qh, (a[:, qh:] if qh else a), (q[:, qh:] if qh else q)
+            Wt, Kp = self.packed_h[key + (".Wp2" if qh else ".Wp")]
+            if self.l0_fwd_wave and query("clsr_hgemm_l0_group_supported", G, Qe, A0):
                 # one wave per history group: a / U loaded once per 16 steps and re-used for the G rows
                 p0 = query("clsr_hgemm_l0_group_stats_parts", Hn) if training else 0
-                call("clsr_hgemm_l0_group", a, Q, q, Q, Wt, Kp, U, A0, V, A0, z0, A0,
-                     sbuf[: p0 * 2 * A0] if training else None, Hn, G, T, Q, A0)
+                call("clsr_hgemm_l0_group", ae, Q, qe, Q, Wt, Kp, U, A0, V, A0, z0, A0,
+                     sbuf[: p0 * 2 * A0] if training else None, Hn, G, T, Qe, A0)
                 self._bn_fwd(bn0, sbuf[: p0 * 2 * A0] if training else None, p0, M, training)
             else:
-                call("clsr_hgemm_mul_uv", a, Q, T, G, q, Q, Wt, Kp, U, A0, V, A0, z0, A0, st, M, Q, A0)
+                call("clsr_hgemm_mul_uv", ae, Q, T, G, qe, Q, Wt, Kp, U, A0, V, A0, z0, A0, st, M, Qe, A0)
                 self._bn_fwd(bn0, st, parts, M, training)
             st = sbuf[: parts * 2 * A1] if training else None
             Wt, Kp = self.packed_h[key + ".W1"]
@@ -1325,16 +1349,25 @@ class CLSRNet(object):
                  bn0.shift, None, None, bn0.coef, dz1, A1, dz0, A0, None, M, A1, A0)
             self._dw(z0, A0, dz1, A1, M, A0, A1, Gd[nn + "w_nn_layer1"], A1, db=Gd[nn + "b_nn_layer1"], aff=bn0,
                      x_bf16=1, dy_bf16=1)
-            self._dw(a, Q, dz0, A0, M, Q, A0, dW0[3 * Q:4 * Q], A0, T=T, G=G, Xmul=q, ldmul=Q, dy_bf16=1)
-            Wt, Kp = self.packed_h[key + ".Wp^T"]
+            Qe, ae, qe = Q - qh, (a[:, qh:] if qh else a), (q[:, qh:] if qh else q)
+            self._dw(ae, Q, dz0, A0, M, Qe, A0, dW0[3 * Q + qh:4 * Q], A0, T=T, G=G, Xmul=qe, ldmul=Q, dy_bf16=1)
+            Wt, Kp = self.packed_h[key + (".Wp2^T" if qh else ".Wp^T")]
             dU = self._buf(key + ".dU", Hn * T, A0)
-            if self.fused_l0_bwd and query("clsr_att_l0_bwd_h_supported", G, Q, A0):
+            if self.fused_l0_bwd and query("clsr_att_l0_bwd_h_supported", G, Qe, A0):
                 # da, dq, dU, dV in one pass over dz0; daq = dz0 . Wp^T is never written (csrc/hattbwd.hip)
-                Wu, Kpu = self.packed_h[key + ".Wu^T"] if (self.bf16_bwd and self.fused_l0_wu) else (None, Kp)
+                # (dU . Wu^T inside the kernel only while the history-level tail is not the fused launch of csrc/atthist.hip)
+                wu_in = self.bf16_bwd and self.fused_l0_wu and not qh and not self._hist_bwd_x3(Dk, Q, 0)
+                Wu, Kpu = self.packed_h[key + ".Wu^T"] if wu_in else (None, Kp)
                 assert Kpu == Kp
-                call("clsr_att_l0_bwd_h", dz0, A0, Wt, Wu, Kp, a, Q, q, Q, Hn, G, T, Q, A0, da, Q, dq, Q, dU, A0, dV, A0)
-                return self._att_bwd_hist(key, scope, nn, a, q, keys, dkeys, dU, dV, da, dq, dW0, Hn, R, T, Dk, Q, 0,
-                                          da_has_u=Wu is not None)
+                call("clsr_att_l0_bwd_h", dz0, A0, Wt, Wu, Kp, ae, Q, qe, Q, Hn, G, T, Qe, A0,
+                     da[:, qh:] if qh else da, Q, dq[:, qh:] if qh else dq, Q, dU, A0, dV, A0)
+                if qh:
+                    # the V path over ALL query columns (dq[:, :qh] was cleared with the step's accumulators), the weight
+                    # gradient of the history-level share of the product term; the rest of that share: _att_bwd_hist
+                    self._gemm(dV, A0, key + ".Wv^T", R, A0, Q, dq, Q, acc=1)
+                    self._dw(a, Q, dU, A0, Hn * T, qh, A0, dW0[3 * Q:3 * Q + qh], A0, T=T, G=1, Xmul=q_hist, ldmul=qh)
+                return self._att_bwd_hist(key, scope, nn, a, q, keys, dkeys, dU, dV, da, dq, dW0, Hn, R, T, Dk, Q, qh,
+                                          da_has_u=Wu is not None, q_hist=q_hist, dq_hist=dq_hist)
             else:
                 daq = self._buf(key + ".daq", M, Q, dtype=BF)
                 call("clsr_hgemm", dz0, A0, None, None, 0, Wt, Kp, None, daq, Q, None, M, A0, Q)
@@ -1440,8 +1473,7 @@ class CLSRNet(object):
 
     def _hist_bwd_x3(self, Dk, Q, qh):
         """history-level tail of the attention backward as ONE launch of split-bf16 products (csrc/atthist.hip)?"""
-        return (self.att_hist_bwd_x3 and not self.bf16
-                and bool(query("clsr_att_hist_bwd_x3_supported", Dk, Q, self.A0, qh)))
+        return self.att_hist_bwd_x3 and bool(query("clsr_att_hist_bwd_x3_supported", Dk, Q, self.A0, qh))
 
     def _att_bwd_hist(self, key, scope, nn, a, q, keys, dkeys, dU, dV, da, dq, dW0, Hn, R, T, Dk, Q, qh,
                       da_has_u=False, q_hist=None, dq_hist=None):
@@ -1823,8 +1855,14 @@ class CLSRNet(object):
                 if fuse_tt:
                     # ONE product over [hist | TT] (K = 48 + 80) writes the time-gate columns: the separate pass that
                     # re-read and re-wrote them (hist . W_x first, += TT . W_t behind it: 112 us alone) is gone
-                    self._gemm(XT, Dp + 2 * H, "xw.t", M, Dp + 2 * H, 3 * H, PinAll[:, t4off + 3 * H:], NX,
-                               bias=self._buf("xw.bias", NX)[t4off + 3 * H:])
+                    if self.proj_x3 and query("clsr_proj_x3_supported", M, Dp + 2 * H, 3 * H):
+                        # (split-bf16 products, result lanes = output features: csrc/projx3.hip)
+                        Wt, Kp = self.packed["xw.t"]
+                        call("clsr_proj_x3", XT, Dp + 2 * H, Wt, Kp, self._buf("xw.bias", NX)[t4off + 3 * H:],
+                             PinAll[:, t4off + 3 * H:], NX, M, Dp + 2 * H, 3 * H, 2)
+                    else:
+                        self._gemm(XT, Dp + 2 * H, "xw.t", M, Dp + 2 * H, 3 * H, PinAll[:, t4off + 3 * H:], NX,
+                                   bias=self._buf("xw.bias", NX)[t4off + 3 * H:])
                 else:
                     self._gemm(TT, 2 * H, "t4.tw", M, 2 * H, 3 * H, PinAll[:, t4off + 3 * H:], NX, acc=1)
             rnn_out = self._buf("rnn_out", Hn, T, H)

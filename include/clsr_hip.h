@@ -272,13 +272,10 @@ int clsr_pgemm_dw_partial_h(const void* X, int x_bf16, int ldx, int T, int G, co
 int clsr_hdw_partial(const void* X, int x_bf16, int ldx, int T, int G, const float* Xmul, int ldmul,
                      const float* in_scale, const float* in_shift, int in_relu, const void* dY,
                      int dy_bf16, int ldy, int M, int K, int N, float* workspace, void* stream);
-/* ---- "fp32x3" products (csrc/dw3.hip ...): fp32 operands in HBM, every value split into bf16 hi + bf16 lo in
- *      registers, products taken as hi*hi + lo*hi + hi*lo on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (<= 2^-16
- *      relative per product; CLSRNet(precision="fp32x3")).  Same contracts as the fp32-MFMA entry points they replace. */
-int clsr_dw3_parts(int M);      /* partial chunks written by clsr_dw3_partial(_multi): <= clsr_pgemm_dw_parts(M), same workspace */
-int clsr_dw3_partial(const float* X, int ldx, int T, int G, const float* Xmul, int ldmul,
-                     const float* in_scale, const float* in_shift, int in_relu, const float* dY, int ldy,
-                     int M, int K, int N, float* workspace, void* stream);
+/* ---- split-bf16 products (csrc/encbwd.hip, gemm3.hip; round 5: attbwdx3.hip, atthist.hip ...): fp32 operands in HBM,
+ *      every value split into bf16 hi + bf16 lo in registers, products taken as hi*hi + lo*hi + hi*lo on
+ *      v_mfma_f32_16x16x32_bf16 with fp32 accumulation (<= 2^-16 relative per product).  Same contracts as the fp32-MFMA
+ *      entry points they replace. */
 int clsr_enc_bwd_fused_x3_parts(long M);
 long clsr_enc_bwd_fused_x3_workspace_floats(long M, int p);
 int clsr_enc_bwd_fused_x3(const float* dPin, const float* hist, const float* hprev1, const float* gates1,
@@ -350,6 +347,13 @@ int clsr_att_hist_fwd_x3_supported(int Dk, int Q, int A0, int qh);
 int clsr_att_hist_fwd_x3(const float* keys, int ldk, const float* At, int Kpa, const float* Wut, int Kpu,
                          const float* Wpt, int Kpp, const float* q_hist, int ldqh, long Hn, int T, int Dk, int Q,
                          int A0, int qh, int pieces, float* a, int lda, float* U, int ldu, void* stream);
+/* Plain projection Y[m, :N] = X[m, :K] . W + bias over M positions as split-bf16 products (csrc/projx3.hip; Wt = packed W: N
+ * rows, K inputs; bias may be NULL; pieces = 2: 2^-16 relative per product term, 3: 2^-23).  Same result as clsr_pgemm
+ * without prologue / epilogue; used for the K-fused time-gate projection of the Time4LSTM in front of the recurrences
+ * (reference rnn_cell_implement.py:214-236). */
+int clsr_proj_x3_supported(int M, int K, int N);
+int clsr_proj_x3(const float* X, int ldx, const float* Wt, int Kp, const float* bias, float* Y, int ldy, int M, int K,
+                 int N, int pieces, void* stream);
 /* Second attention layer, forward: z1 = relu(z0 * scale0 + shift0) . W1 + b1 with the product over three bf16 pieces per
  * operand on the bf16 matrix pipe (2^-23 relative: the level of an fp32 fma chain), stats = per-block partial column sums /
  * sums of squares of z1, [clsr_att_l1_fwd_stats_parts(M)][2][C1] doubles (NULL: none).  Wt = packed W1 (C1 rows, K = C0).
@@ -797,7 +801,6 @@ typedef struct clsr_dwjob {
 int clsr_sizeof_dwjob(void);
 int clsr_pgemm_dw_partial_multi(const clsr_dwjob* jobs_host, int n, void* stream);
 int clsr_hdw_partial_multi(const clsr_dwjob* jobs_host, int n, void* stream);
-int clsr_dw3_partial_multi(const clsr_dwjob* jobs_host, int n, void* stream);
 typedef struct clsr_rp_desc { const float* partial; float* out; float scale; int nparts; int stride; int n; int accumulate; int pad_; } clsr_rp_desc;
 typedef struct clsr_table_desc {
   float* table; const float* partner; float* grad; float* m; float* v; unsigned char* flags;

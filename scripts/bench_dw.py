@@ -39,7 +39,7 @@ def main():
             ws = torch.empty(query("clsr_pgemm_dw_workspace_floats", M, K, N), device=dev)
             t0 = timeit(lambda: call("clsr_pgemm_dw_partial", X, ldx, 0, 0, None, 0, None, None, 1, dY, ldy, M, K, N, ws))
             t1 = timeit(lambda: call("clsr_hdw_partial", X, 0, ldx, 0, 0, None, 0, None, None, 1, dY, 0, ldy, M, K, N, ws))
-            t3 = timeit(lambda: call("clsr_dw3_partial", X, ldx, 0, 0, None, 0, None, None, 1, dY, ldy, M, K, N, ws))
+            t3 = float("nan")      # (the generic split-bf16 weight-gradient kernel was removed in round 5)
             mb = (M * (K + N) * 4) / 1e6
             print("%s  fp32 %.1f us  bf16-mfma %.1f us  split-bf16 %.1f us  (%.0f MB -> %.2f / %.2f / %.2f TB/s)"
                   % (name, t0, t1, t3, mb, mb / t0, mb / t1, mb / t3))
@@ -59,14 +59,14 @@ def main():
         # the exact-mode (all fp32) forms of the same two products
         z0f, dz1f, dz0f = z0.float(), dz1.float(), dz0.float()
         t0 = timeit(lambda: call("clsr_pgemm_dw_partial", z0f, 80, 0, 0, None, 0, sc, sh, 1, dz1f, 40, M2, 80, 40, ws))
-        t3 = timeit(lambda: call("clsr_dw3_partial", z0f, 80, 0, 0, None, 0, sc, sh, 1, dz1f, 40, M2, 80, 40, ws))
+        t3 = float("nan")      # (the generic split-bf16 weight-gradient kernel was removed in round 5)
         print("dW1 all fp32 (exact mode)   M=1M K=80 N=40: fp32 %.1f us  split-bf16 %.1f us (492 MB, 6.5 GFLOP)" % (t0, t3))
         t0 = timeit(lambda: call("clsr_pgemm_dw_partial", a, 80, 50, 5, q, 80, None, None, 1, dz0f, 80, M2, 80, 80, ws))
-        t3 = timeit(lambda: call("clsr_dw3_partial", a, 80, 50, 5, q, 80, None, None, 1, dz0f, 80, M2, 80, 80, ws))
+        t3 = float("nan")      # (the generic split-bf16 weight-gradient kernel was removed in round 5)
         print("dWp all fp32 (exact mode)   M=1M K=80 N=80: fp32 %.1f us  split-bf16 %.1f us (328 MB + L2, 13.1 GFLOP)" % (t0, t3))
         X80, Y80 = torch.randn(M2, 80, device=dev), torch.randn(M2, 80, device=dev)
         t0 = timeit(lambda: call("clsr_pgemm_dw_partial", X80, 80, 0, 0, None, 0, None, None, 1, Y80, 80, M2, 80, 80, ws))
-        t3 = timeit(lambda: call("clsr_dw3_partial", X80, 80, 0, 0, None, 0, None, None, 1, Y80, 80, M2, 80, 80, ws))
+        t3 = float("nan")      # (the generic split-bf16 weight-gradient kernel was removed in round 5)
         print("plain 80x80 all fp32        M=1M             : fp32 %.1f us  split-bf16 %.1f us (655 MB: %.2f TB/s)" % (t0, t3, 655.4 / t3))
         # projection GEMMs
         W = torch.randn(40, 480, device=dev) * 0.1

@@ -295,3 +295,25 @@ def test_layer1_forward_three_pieces(M, C0, C1):
     call("clsr_att_l1_fwd", d0, C0, dsc, dsh, Wt, Kp, db, z1b, C1, None, M, C0, C1)
     torch.cuda.synchronize()
     assert torch.equal(z1b, z1[:, :C1].contiguous())
+
+
+@pytest.mark.parametrize("M,K,N", [(2000, 128, 120), (515, 48, 40), (70, 16, 12), (4099, 40, 36), (40000, 128, 120),
+                                   (33, 8, 4), (300, 96, 128)])
+@pytest.mark.parametrize("pieces", [2, 3])
+def test_projection_split_products(M, K, N, pieces):
+    """clsr_proj_x3: Y = X . W + b into a column block of a wider tensor == float64 (2^-16 / 2^-23 per product term)."""
+    assert query("clsr_proj_x3_supported", M, K, N) == 1 and query("clsr_proj_x3_supported", M, 132, N) == 0
+    g = torch.Generator().manual_seed(M + K)
+    X, W, b = rnd(g, M, K), rnd(g, K, N, scale=0.3), rnd(g, N)
+    Wt, Kp = ops.pack_weight(dev(W), N, K)
+    dX, db = dev(X), dev(b)
+    Y = torch.full((M, N + 8), 7.0, device="cuda")
+    call("clsr_proj_x3", dX, K, Wt, Kp, db, Y[:, 4:], N + 8, M, K, N, pieces)
+    torch.cuda.synchronize()
+    exp = dX.double().cpu() @ dev(W).double().cpu() + db.double().cpu()
+    close(Y[:, 4:4 + N], exp, 5e-5 if pieces == 2 else 2e-6, "Y")
+    assert float((Y[:, :4] - 7.0).abs().max()) == 0 and float((Y[:, 4 + N:] - 7.0).abs().max()) == 0
+    Y2 = torch.zeros(M, N, device="cuda")
+    call("clsr_proj_x3", dX, K, Wt, Kp, None, Y2, N, M, K, N, pieces)
+    torch.cuda.synchronize()
+    close(Y2, exp - db.double().cpu(), 5e-5 if pieces == 2 else 2e-6, "Y without bias")

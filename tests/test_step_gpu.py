@@ -71,7 +71,7 @@ CONFIGS = [
 ]
 
 
-# "fp32x3": fp32 storage, the MFMA-saturated products as split-bf16 sums (csrc/dw3.hip ...) -- held to the SAME tolerances
+# "fp32x3": fp32 storage, the MFMA-saturated products as split-bf16 sums (csrc/gemm3.hip, encbwd.hip, attbwdx3.hip ...) -- held to the SAME tolerances
 @pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
 @pytest.mark.parametrize("dedup", [True, False, "split"])
 @pytest.mark.parametrize("cfg", range(len(CONFIGS)))

@@ -1,5 +1,5 @@
 """GPU parity tests of the split-bf16 ("fp32x3") kernels: fp32 operands in HBM, every value split into bf16 hi + bf16 lo
-in registers, products taken as hi*hi + lo*hi + hi*lo on the bf16 matrix pipe with fp32 accumulation (csrc/dw3.hip ...).
+in registers, products taken as hi*hi + lo*hi + hi*lo on the bf16 matrix pipe with fp32 accumulation (csrc/gemm3.hip, csrc/encbwd.hip ...).
 They must hold the EXACT-mode tolerances of the fp32-MFMA kernels they replace (reference arithmetic: fp32,
 models/base_model.py:627-708, models/sequential/clsr.py:343-381 through tf.gradients), i.e. they are compared with
 float64 products of the UNROUNDED operands -- unlike the speed-mode kernels of tests/test_bf16_gpu.py."""
@@ -28,102 +28,6 @@ def _within(got, exp, budget, name):
         name, float(err.max()), float(exp.abs().max()), over)
 
 
-def _dw_full(partial_call, M, K, N, with_bias, parts):
-    ws = torch.zeros(query("clsr_pgemm_dw_workspace_floats", M, K, N), device=DEV)
-    partial_call(ws)
-    dW, db = torch.zeros(K, N, device=DEV), torch.zeros(N, device=DEV)
-    sig = ((ws.data_ptr(), dW.data_ptr(), db.data_ptr() if with_bias else 0, 1.0, query(parts, M), K, N, N, 0),)
-    tab = ops.dw_table(sig, torch.device(DEV))
-    call("clsr_dw_reduce_batch", tab[0], tab[1], tab[2])
-    torch.cuda.synchronize()
-    return dW, db
-
-
-@pytest.mark.parametrize("M,K,N", [(3200, 80, 80), (1000, 40, 480), (777, 80, 120), (130, 164, 80), (64, 80, 40),
-                                   (50000, 80, 40), (4100, 40, 40), (333, 36, 24), (2049, 200, 100)])
-def test_split_bf16_weight_gradient_kernel(M, K, N):
-    """clsr_dw3_partial == float64 product of the fp32 operands, at the tolerance of the fp32-MFMA kernel (2e-5 relative
-    to the scale of the sum): plain, the X * Xmul[r] prologue with the (T, G) row map, relu(bn(X)); db = exact fp32 column
-    sums."""
-    g = torch.Generator().manual_seed(M + K + N)
-    X = torch.randn(M, K, generator=g).to(DEV)
-    dY = torch.randn(M, N, generator=g).to(DEV)
-    scale = float(M) ** 0.5           # |sum of M unit products| ~ sqrt(M)
-    dW, db = _dw_full(lambda ws: call("clsr_dw3_partial", X, K, 0, 0, None, 0, None, None, 1, dY, N, M, K, N, ws),
-                      M, K, N, True, "clsr_dw3_parts")
-    exp = X.double().t() @ dY.double()
-    _close(dW, exp, 2e-5, 3e-5 * scale, "dW plain")
-    _close(db, dY.double().sum(0), 1e-5, 1e-5 * scale, "db")
-    # the split product's own error: <= 2^-18 |x y| per product from the rounding of lo, + the dropped lo * lo term; a sum
-    # of M unit-variance products, worst of K * N outputs: a few times 2^-18 sqrt(M)
-    e3 = float((dW.double() - exp).abs().max())
-    assert e3 <= 2.0 ** -15 * scale, "split-bf16 error %.3e above its budget %.3e" % (e3, 2.0 ** -15 * scale)
-    if K % 4 == 0 and M % 10 == 0:
-        T, G = 10, 5 if (M // 10) % 5 == 0 else 1
-        R, Hn = M // T, M // T // G
-        a_, q_ = torch.randn(Hn * T, K, generator=g).to(DEV), torch.randn(R, K, generator=g).to(DEV)
-        dW, _ = _dw_full(lambda ws: call("clsr_dw3_partial", a_, K, T, G, q_, K, None, None, 1, dY, N, M, K, N, ws),
-                         M, K, N, False, "clsr_dw3_parts")
-        rows = torch.arange(M, device=DEV)
-        r, t = rows // T, rows % T
-        _close(dW, (a_[(r // G) * T + t] * q_[r]).double().t() @ dY.double(), 2e-5, 4e-5 * scale, "dW (a * q)")
-    if K % 4 == 0:
-        sc, sh = (torch.rand(K, generator=g) + 0.5).to(DEV), torch.randn(K, generator=g).to(DEV)
-        dW, db = _dw_full(lambda ws: call("clsr_dw3_partial", X, K, 0, 0, None, 0, sc, sh, 1, dY, N, M, K, N, ws),
-                          M, K, N, True, "clsr_dw3_parts")
-        _close(dW, torch.relu(X * sc + sh).double().t() @ dY.double(), 2e-5, 4e-5 * scale, "dW relu(bn(X))")
-        _close(db, dY.double().sum(0), 1e-5, 1e-5 * scale, "db (affine job)")
-
-
-def test_split_bf16_weight_gradient_wide_dynamic_range():
-    """Operands spanning 12 orders of magnitude, exact zeros, one huge column: the hi / lo split must not lose small
-    values next to large ones (every element is split on its own) and zeros must stay zeros."""
-    g = torch.Generator().manual_seed(3)
-    M, K, N = 4096, 80, 80
-    X = (torch.randn(M, K, generator=g) * torch.pow(10.0, torch.randint(-6, 6, (M, K), generator=g).float())).to(DEV)
-    dY = torch.randn(M, N, generator=g).to(DEV)
-    X[:, 3] = 0.0
-    dY[:, 5] = 0.0
-    dW, db = _dw_full(lambda ws: call("clsr_dw3_partial", X, K, 0, 0, None, 0, None, None, 1, dY, N, M, K, N, ws),
-                      M, K, N, True, "clsr_dw3_parts")
-    exp = X.double().t() @ dY.double()
-    # error budget: 2^-15 of the sum of |products| per output element (three rounding sources of <= 2^-17 each)
-    bound = (X.double().abs().t() @ dY.double().abs()) * 2.0 ** -15 + 1e-30
-    assert bool(((dW.double() - exp).abs() <= bound).all())
-    assert float(dW[3].abs().max()) == 0.0 and float(dW[:, 5].abs().max()) == 0.0 and float(db[5]) == 0.0
-
-
-def test_split_bf16_weight_gradient_multi_job_launch():
-    """Several products in one clsr_dw3_partial_multi launch == the same products launched one by one, bit for bit."""
-    g = torch.Generator().manual_seed(11)
-    M = 3000
-    Xw, dYw = torch.randn(M, 200, generator=g).to(DEV), torch.randn(M, 480, generator=g).to(DEV)
-    mul = torch.randn(M, 120, generator=g).to(DEV)
-    sc, sh = torch.randn(80, generator=g).to(DEV), torch.randn(80, generator=g).to(DEV)
-    #        X col0, K, dY col0, N, Xmul, affine
-    specs = [(0, 40, 0, 480, None, False), (40, 40, 0, 160, None, False), (80, 80, 160, 120, None, False),
-             (160, 40, 280, 80, None, False), (160, 40, 360, 40, mul, False), (80, 80, 400, 40, None, True),
-             (0, 36, 440, 24, None, False), (0, 128, 0, 256, None, False), (64, 120, 100, 128, mul, False),
-             (0, 200, 40, 440, None, False)]
-    jobs, pairs = [], []
-    for x0, K, y0, N, xm, aff in specs:
-        need = query("clsr_pgemm_dw_workspace_floats", M, K, N)
-        wa, wb = torch.zeros(need, device=DEV), torch.zeros(need, device=DEV)
-        pairs.append((wa, wb))
-        X, dY = Xw[:, x0:], dYw[:, y0:]
-        jobs.append((X.data_ptr(), xm.data_ptr() if xm is not None else 0, sc.data_ptr() if aff else 0,
-                     sh.data_ptr() if aff else 0, dY.data_ptr(), wa.data_ptr(), 0, 200, 0, 0, 120 if xm is not None else 0,
-                     1, 0, 480, M, K, N, 0))
-        call("clsr_dw3_partial", X, 200, 0, 0, xm, 120 if xm is not None else 0, sc if aff else None,
-             sh if aff else None, 1, dY, 480, M, K, N, wb)
-    ops.dw_multi("clsr_dw3_partial_multi", jobs)
-    torch.cuda.synchronize()
-    for i, (wa, wb) in enumerate(pairs):
-        assert torch.equal(wa, wb), "job %d differs from its single launch" % i
-    assert float(pairs[0][0].abs().max()) > 0
-
-
-# ------------------------------------------------------------------------------- position-tiled products (csrc/gemm3.hip)
 def _rnd(g, *shape, scale=1.0):
     return torch.randn(*shape, generator=g, dtype=torch.float64) * scale
 
