@@ -37,7 +37,7 @@ struct AttL0FwdArgs {
 // K = 32 chunk c takes the two 16-wide chunks 2c, 2c + 1 of the fp32 kernel side by side (k slot (g4, e) = feature
 // 32c + 16 (e >> 2) + 4 g4 + (e & 3): the loads of the A operand are the same float4 pairs), the bf16 hi / lo images of the
 // weights are laid out in LDS in that slot order.
-template <int NZ, int NK, bool X3>
+template <int NZ, int NK, int NP>      // NP = 0: fp32-input MFMAs; 2 / 3: bf16 pieces per operand (x3 / x6 products)
 __global__ void __launch_bounds__(256, 2) att_l0_fwd_kernel(AttL0FwdArgs s) {
   CLSR_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -48,8 +48,9 @@ __global__ void __launch_bounds__(256, 2) att_l0_fwd_kernel(AttL0FwdArgs s) {
   const int Kp = s.Kp;
   float* Wl = reinterpret_cast<float*>(lds_raw);
   __bf16* Wh = reinterpret_cast<__bf16*>(lds_raw);
-  __bf16* Wlo = Wh + ZP * WS;
-  const size_t wfloats = X3 ? (size_t)ZP * WS : (size_t)ZP * Kp;      // (2 images x ZP x WS bf16 = ZP x WS floats)
+  constexpr bool X3 = NP > 0;
+  constexpr int NPI = NP > 0 ? NP : 1;
+  const size_t wfloats = X3 ? (size_t)NP * ZP * WS / 2 : (size_t)ZP * Kp;      // (NP images x ZP x WS bf16)
   float* wl = Wl + wfloats + (size_t)wave * AF_GMAX * (QP + ZP);
   float* qs = wl;                     // [G][QP]
   float* vs = wl + AF_GMAX * QP;      // [G][ZP]
@@ -72,9 +73,12 @@ __global__ void __launch_bounds__(256, 2) att_l0_fwd_kernel(AttL0FwdArgs s) {
           }
         }
       }
-      const bf16x8 hi = to_h(v);
-      reinterpret_cast<bf16x8*>(Wh)[e] = hi;
-      reinterpret_cast<bf16x8*>(Wlo)[e] = to_h(v - to_f(hi));
+#pragma unroll
+      for (int i = 0; i < NPI; ++i) {
+        const bf16x8 h = to_h(v);
+        reinterpret_cast<bf16x8*>(Wh + (size_t)i * ZP * WS)[e] = h;
+        v -= to_f(h);
+      }
     }
   } else {
     const int Kq = Kp >> 2;
@@ -95,20 +99,25 @@ __global__ void __launch_bounds__(256, 2) att_l0_fwd_kernel(AttL0FwdArgs s) {
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const f32x4 lo4 = x[2 * c], hi4 = 2 * c + 1 < NK ? x[2 * c + 1 < NK ? 2 * c + 1 : 0] : z4_;
-        const f32x8 v = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
-        const bf16x8 ah = to_h(v), al = to_h(v - to_f(ah));
-        bf16x8 wh[NZ], wlv[NZ];
+        f32x8 v = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+        bf16x8 ap[NPI];
 #pragma unroll
-        for (int z = 0; z < NZ; ++z) {
-          wh[z] = ld8h(Wh + ldsH + woff + z * 16 * WS + 32 * c);
-          wlv[z] = ld8h(Wlo + ldsH + woff + z * 16 * WS + 32 * c);
+        for (int i = 0; i < NPI; ++i) {
+          ap[i] = to_h(v);
+          if (i + 1 < NPI) v -= to_f(ap[i]);
         }
+        bf16x8 w[NPI][NZ];
 #pragma unroll
-        for (int z = 0; z < NZ; ++z) HMFMA(acc[z], ah, wlv[z]);
+        for (int i = 0; i < NPI; ++i)
 #pragma unroll
-        for (int z = 0; z < NZ; ++z) HMFMA(acc[z], al, wh[z]);
+          for (int z = 0; z < NZ; ++z) w[i][z] = ld8h(Wh + (size_t)i * ZP * WS + ldsH + woff + z * 16 * WS + 32 * c);
+        // every piece product whose indices sum to <= NP - 1, smallest terms first
 #pragma unroll
-        for (int z = 0; z < NZ; ++z) HMFMA(acc[z], ah, wh[z]);
+        for (int sidx = NPI - 1; sidx >= 0; --sidx)
+#pragma unroll
+          for (int i = 0; i <= sidx; ++i)
+#pragma unroll
+            for (int z = 0; z < NZ; ++z) HMFMA(acc[z], ap[i], w[sidx - i][z]);
       }
     } else {
       const float* lb = ldsB + woff;
@@ -341,12 +350,12 @@ extern "C" int clsr_att_l0_fwd_supported(int G, int Q, int A0) {
 // number of per-block partial rows the statistics buffer receives: [parts][2][A0] doubles
 extern "C" int clsr_att_l0_fwd_stats_parts(long Hn) { return af_grid(Hn); }
 
-template <int NZ, int NK, bool X3>
+template <int NZ, int NK, int NP>
 static int att_l0_fwd_launch(const AttL0FwdArgs& a, hipStream_t stream) {
   constexpr int WS = 32 * ((NK + 1) / 2) + 8;
-  size_t shmem = (X3 ? (size_t)16 * NZ * WS * 4 : (size_t)16 * NZ * a.Kp * 4) + (size_t)4 * AF_GMAX * (16 * NK + 16 * NZ) * 4 +
+  size_t shmem = (NP ? (size_t)NP * 16 * NZ * WS * 2 : (size_t)16 * NZ * a.Kp * 4) + (size_t)4 * AF_GMAX * (16 * NK + 16 * NZ) * 4 +
                  (size_t)4 * 2 * 16 * NZ * 8 + (size_t)4 * 16 * (16 * NZ + 4) * 4;
-  auto kernel = att_l0_fwd_kernel<NZ, NK, X3>;
+  auto kernel = att_l0_fwd_kernel<NZ, NK, NP>;
   if (shmem > 64 * 1024)
     CLSR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   hipLaunchKernelGGL(kernel, dim3(af_grid(a.Hn)), dim3(256), shmem, stream, a);
@@ -356,7 +365,7 @@ static int att_l0_fwd_launch(const AttL0FwdArgs& a, hipStream_t stream) {
 
 static int att_l0_fwd_any(const float* a, int lda, const float* q, int ldq, const float* Wt, int Kp,
                           const float* U, int ldu, const float* V, int ldv, float* z0, int ldz, double* stats,
-                          long Hn, int G, int T, int Q, int A0, bool x3, void* stream) {
+                          long Hn, int G, int T, int Q, int A0, int pieces, void* stream) {
   CLSR_CHECK_ARG(a && q && Wt && U && V && z0 && Hn > 0 && T > 0);
   CLSR_CHECK_SUPPORTED(clsr_att_l0_fwd_supported(G, Q, A0));
   CLSR_CHECK_SUPPORTED(lda % 4 == 0 && Kp % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)Wt % 16) == 0);
@@ -367,7 +376,9 @@ static int att_l0_fwd_any(const float* a, int lda, const float* q, int ldq, cons
   s.z0 = z0; s.ldz = ldz; s.stats = stats; s.Hn = Hn; s.G = G; s.T = T; s.Q = Q; s.A0 = A0;
   hipStream_t st = (hipStream_t)stream;
   const int nz = af_class(A0), nk = af_class(Q);
-#define AF_GO(Z, K) if (nz == Z && nk == K) return x3 ? att_l0_fwd_launch<Z, K, true>(s, st) : att_l0_fwd_launch<Z, K, false>(s, st)
+#define AF_GO(Z, K) \
+  if (nz == Z && nk == K) \
+    return pieces == 3 ? att_l0_fwd_launch<Z, K, 3>(s, st) : pieces == 2 ? att_l0_fwd_launch<Z, K, 2>(s, st) : att_l0_fwd_launch<Z, K, 0>(s, st)
   AF_GO(3, 3); AF_GO(3, 5); AF_GO(5, 3); AF_GO(5, 5);
 #undef AF_GO
   return CLSR_OK;
@@ -376,11 +387,18 @@ static int att_l0_fwd_any(const float* a, int lda, const float* q, int ldq, cons
 extern "C" int clsr_att_l0_fwd(const float* a, int lda, const float* q, int ldq, const float* Wt, int Kp,
                                const float* U, int ldu, const float* V, int ldv, float* z0, int ldz, double* stats,
                                long Hn, int G, int T, int Q, int A0, void* stream) {
-  return att_l0_fwd_any(a, lda, q, ldq, Wt, Kp, U, ldu, V, ldv, z0, ldz, stats, Hn, G, T, Q, A0, false, stream);
+  return att_l0_fwd_any(a, lda, q, ldq, Wt, Kp, U, ldu, V, ldv, z0, ldz, stats, Hn, G, T, Q, A0, 0, stream);
 }
 // the same with the product as split-bf16 sums (see att_l0_fwd_kernel<.., X3>)
 extern "C" int clsr_att_l0_fwd_x3(const float* a, int lda, const float* q, int ldq, const float* Wt, int Kp,
                                   const float* U, int ldu, const float* V, int ldv, float* z0, int ldz, double* stats,
                                   long Hn, int G, int T, int Q, int A0, void* stream) {
-  return att_l0_fwd_any(a, lda, q, ldq, Wt, Kp, U, ldu, V, ldv, z0, ldz, stats, Hn, G, T, Q, A0, true, stream);
+  return att_l0_fwd_any(a, lda, q, ldq, Wt, Kp, U, ldu, V, ldv, z0, ldz, stats, Hn, G, T, Q, A0, 2, stream);
+}
+// ... over three bf16 pieces per operand (2^-23 relative: the level of the fp32 fma chain; 60 bf16 MFMAs of ~20 cycles per
+// 16 x 80 tile instead of 100 fp32 MFMAs of 32)
+extern "C" int clsr_att_l0_fwd_x6(const float* a, int lda, const float* q, int ldq, const float* Wt, int Kp,
+                                  const float* U, int ldu, const float* V, int ldv, float* z0, int ldz, double* stats,
+                                  long Hn, int G, int T, int Q, int A0, void* stream) {
+  return att_l0_fwd_any(a, lda, q, ldq, Wt, Kp, U, ldu, V, ldv, z0, ldz, stats, Hn, G, T, Q, A0, 3, stream);
 }

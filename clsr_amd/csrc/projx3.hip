@@ -139,16 +139,24 @@ extern "C" int clsr_proj_x3(const float* X, int ldx, const float* Wt, int Kp, co
   CLSR_CHECK_SUPPORTED(clsr_proj_x3_supported(M, K, N));
   CLSR_CHECK_ARG(ldx >= K && ldy >= N && Kp >= 16 * clsr_cdiv(K, 16));
   CLSR_CHECK_SUPPORTED(ldx % 4 == 0 && Kp % 4 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)Wt % 16) == 0 &&
-                       ((uintptr_t)Y % 4) == 0 && ((long)M * ldy) * 4 < 0x40000000L);
-  ProjArgs a = {};
-  a.X = X; a.ldx = ldx; a.Wt = Wt; a.Kp = Kp; a.bias = bias; a.Y = Y; a.ldy = ldy; a.M = M; a.K = K; a.N = N;
+                       ((uintptr_t)Y % 4) == 0 && (long)ldy * 4 * 16 < 0x40000000L);
   hipStream_t s = (hipStream_t)stream;
   const int nkc = clsr_cdiv(K, 32), nt = N <= 48 ? 3 : (N <= 80 ? 5 : 8);
+  // the kernel addresses Y through a buffer resource with 32-bit byte offsets below 2^30: row ranges of at most that size
+  // per launch (the history-replicated step projects 1M positions into a 480-column tensor: 1.97 GB)
+  const long rows_max = ((0x40000000L - 1) / ((long)ldy * 4)) & ~15L;
+  for (long m0 = 0; m0 < M; m0 += rows_max) {
+    ProjArgs a = {};
+    a.X = X + m0 * ldx; a.ldx = ldx; a.Wt = Wt; a.Kp = Kp; a.bias = bias; a.Y = Y + m0 * ldy; a.ldy = ldy;
+    a.M = (int)(M - m0 < rows_max ? M - m0 : rows_max); a.K = K; a.N = N;
+    int rc = CLSR_EUNSUPPORTED;
 #define PJ_GO(C, T) \
-  if (nkc == C && nt == T) return pieces == 2 ? proj_launch<C, T, 2>(a, s) : proj_launch<C, T, 3>(a, s)
-  PJ_GO(1, 3); PJ_GO(2, 3); PJ_GO(3, 3); PJ_GO(4, 3);
-  PJ_GO(1, 5); PJ_GO(2, 5); PJ_GO(3, 5); PJ_GO(4, 5);
-  PJ_GO(1, 8); PJ_GO(2, 8); PJ_GO(3, 8); PJ_GO(4, 8);
+    if (nkc == C && nt == T) rc = pieces == 2 ? proj_launch<C, T, 2>(a, s) : proj_launch<C, T, 3>(a, s)
+    PJ_GO(1, 3); PJ_GO(2, 3); PJ_GO(3, 3); PJ_GO(4, 3);
+    PJ_GO(1, 5); PJ_GO(2, 5); PJ_GO(3, 5); PJ_GO(4, 5);
+    PJ_GO(1, 8); PJ_GO(2, 8); PJ_GO(3, 8); PJ_GO(4, 8);
 #undef PJ_GO
+    if (rc != CLSR_OK) return rc;
+  }
   return CLSR_OK;
 }

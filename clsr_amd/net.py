@@ -126,6 +126,12 @@ class CLSRNet(object):
         # history-level kernel, the fp32-MFMA layer-0 kernel -- see csrc/atthist.hip; the x3 forms are opt-in:
         # CLSR_ATT_FWD_X3=1, CLSR_ATT_HIST_PIECES=2)
         self.att_fwd_x3 = bool(os.environ.get("CLSR_ATT_FWD_X3")) and not self.exact_products
+        # the per-(row, step) layer-0 product over three bf16 pieces per operand (fp32 accuracy, 60 bf16 MFMAs instead of 100
+        # fp32 ones per tile: csrc/attl0fwd.hip): 102 -> 90 us alone, nothing in the step (three interleaved A/B runs) --
+        # opt-in (CLSR_ATT_FWD_X6=1), the default stays the bit-exact fp32-MFMA form
+        self.att_fwd_x6 = x3d and bool(os.environ.get("CLSR_ATT_FWD_X6"))
+        self.att_l0_fwd_entry = ("clsr_att_l0_fwd_x3" if self.att_fwd_x3 else
+                                 "clsr_att_l0_fwd_x6" if self.att_fwd_x6 else "clsr_att_l0_fwd")
         self.att_hist_pieces = int(os.environ.get("CLSR_ATT_HIST_PIECES", "3"))  # A/B: first attention layer, forward (csrc/attl0fwd.hip)
         self.bf16_dw = not os.environ.get("CLSR_NO_HDW")        # A/B switch: weight gradients on the bf16 matrix pipe
         self.bf16_bwd = not os.environ.get("CLSR_NO_HBWD")      # A/B switch: back-propagating products likewise
@@ -1261,7 +1267,7 @@ class CLSRNet(object):
                 st = (self._buf("stats" + self._ws_tag, 1024 * 2 * 256, dtype=torch.float64)[: parts * 2 * A0]
                       if training else None)
                 Wt, Kp = self.packed[key + ".Wp2"]
-                call("clsr_att_l0_fwd_x3" if self.att_fwd_x3 else "clsr_att_l0_fwd", a[:, qh:], Q, q[:, qh:], Q, Wt, Kp, U, A0, V, A0, z0, A0, st, Hn, G, T, Q - qh, A0)
+                call(self.att_l0_fwd_entry, a[:, qh:], Q, q[:, qh:], Q, Wt, Kp, U, A0, V, A0, z0, A0, st, Hn, G, T, Q - qh, A0)
             else:
                 self._gemm(a[:, qh:], Q, key + ".Wp2", R * T, Q - qh, A0, z0, A0, T=T, G=G, Xmul=q[:, qh:], ldmul=Q,
                            addU=U, ldu=A0, addV=V, ldv=A0, stats=st)
@@ -1271,12 +1277,12 @@ class CLSRNet(object):
             st = (self._buf("stats" + self._ws_tag, 1024 * 2 * 256, dtype=torch.float64)[: parts * 2 * A0]
                   if training else None)
             Wt, Kp = self.packed[key + ".Wp"]
-            call("clsr_att_l0_fwd_x3" if self.att_fwd_x3 else "clsr_att_l0_fwd", a, Q, q, Q, Wt, Kp, U, A0, V, A0, z0, A0, st, Hn, G, T, Q, A0)
+            call(self.att_l0_fwd_entry, a, Q, q, Q, Wt, Kp, U, A0, V, A0, z0, A0, st, Hn, G, T, Q, A0)
         else:
             self._gemm(a, Q, key + ".Wp", R * T, Q, A0, z0, A0, T=T, G=G, Xmul=q, ldmul=Q, addU=U, ldu=A0,
                        addV=V, ldv=A0, stats=st)
         self._bn_fwd(bn0, st, parts, R * T, training)
-        if self.att_l1_fwd_x6 and query("clsr_att_l1_fwd_supported", A0, A1):
+        if self.att_l1_fwd_x6 and query("clsr_att_l1_fwd_supported", A0, A1) and R * T * A1 * 4 < (1 << 30):
             # z1 = relu(bn0(z0)) . W1 + b1 on the bf16 matrix pipe with three pieces per operand (csrc/attl1fwd.hip)
             parts = query("clsr_att_l1_fwd_stats_parts", R * T) if training else 0
             st = (self._buf("stats" + self._ws_tag, 1024 * 2 * 256, dtype=torch.float64)[: parts * 2 * A1]
@@ -1375,7 +1381,7 @@ class CLSRNet(object):
                 call("clsr_att_z0_bwd_reduce_h", dz0, Hn, G, T, A0, dU, dV)
             return self._att_bwd_hist(key, scope, nn, a, q, keys, dkeys, dU, dV, da, dq, dW0, Hn, R, T, Dk, Q, 0)
         x3b = self.att_bwd == "x3"
-        if x3b and self.l1_bwd_2pass and query("clsr_att_l1_bwd_x3_supported", A1, A0):
+        if x3b and self.l1_bwd_2pass and query("clsr_att_l1_bwd_x3_supported", A1, A0) and (R * T * A0 + 80) * 4 < (1 << 31) - 1:
             # the same two passes as split-bf16 products; pass 2 also accumulates dW1 / db1 (dz1 is never stored)
             M = R * T
             Wt, Kp = self.packed[key + ".W1^T"]
@@ -2632,7 +2638,7 @@ class CLSRNet(object):
         z0 = self._buf(key + ".z0", R * T, A0)
         Wt, Kp = self.packed[key + ".Wp"]
         if self._att_layer0_wave(G, Q):
-            return lambda: call("clsr_att_l0_fwd_x3" if self.att_fwd_x3 else "clsr_att_l0_fwd", a, Q, q, Q, Wt, Kp, U, A0, V, A0, z0, A0, None, Hn, G, T, Q, A0)
+            return lambda: call(self.att_l0_fwd_entry, a, Q, q, Q, Wt, Kp, U, A0, V, A0, z0, A0, None, Hn, G, T, Q, A0)
         return lambda: call("clsr_pgemm", a, Q, T, G, q, Q, None, None, 1, Wt, Kp, None, U, A0, V, A0, z0, A0, 0,
                             None, R * T, Q, A0)
 

@@ -377,6 +377,10 @@ int clsr_att_hist_bwd_x3(const float* dU, int lddu, const float* WuT, int Kpu, c
 int clsr_att_l0_fwd_x3(const float* a, int lda, const float* q, int ldq, const float* Wt, int Kp,
                        const float* U, int ldu, const float* V, int ldv, float* z0, int ldz, double* stats,
                        long Hn, int G, int T, int Q, int A0, void* stream);
+/* ... over three bf16 pieces per operand (2^-23 relative per product term: fp32 accuracy on the bf16 matrix pipe) */
+int clsr_att_l0_fwd_x6(const float* a, int lda, const float* q, int ldq, const float* Wt, int Kp,
+                       const float* U, int ldu, const float* V, int ldv, float* z0, int ldz, double* stats,
+                       long Hn, int G, int T, int Q, int A0, void* stream);
 /* The same four reductions in exact mode: dz0 and the packed Wp^T (clsr_pack_batch layout) fp32, fp32 matrix pipe; dU may
  * be NULL (G == 1: dU is dz0).  Replaces clsr_pgemm (daq) + clsr_att_prod_bwd + clsr_att_z0_bwd_reduce. */
 int clsr_att_l0_bwd_supported(int G, int Q, int A0);

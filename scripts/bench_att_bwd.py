@@ -57,7 +57,7 @@ with torch.cuda.stream(st_):
     print("x3    l0 (da, dq, dU, dV + dWp)       R 328 + 33, W 98 MB %6.1f us  %5.2f TB/s" % (t, 459 / t))
     U, V = torch.randn(Hn * T, A0, device=dev), torch.randn(R, A0, device=dev)
     Wf, Kf = ops.pack_weight(Wp, A0, Q)
-    for name in ("clsr_att_l0_fwd", "clsr_att_l0_fwd_x3"):
+    for name in ("clsr_att_l0_fwd", "clsr_att_l0_fwd_x3", "clsr_att_l0_fwd_x6"):
         t = timeit(lambda: call(name, a, Q, q, Q, Wf, Kf, U, A0, V, A0, z0, A0, st, Hn, G, T, Q, A0))
         print("%-20s z0 = U + V + (a*q).Wp + stats   W 328 MB     %6.1f us  %5.2f TB/s" % (name, t, 328 / t))
     # history-level prologue of the short-term attention: keys [Hn*T, 40] -> a [.., 80], U [.., 80] (+ the qh = 40 product term)
