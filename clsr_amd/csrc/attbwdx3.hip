@@ -24,6 +24,9 @@
 #include "hmma.h"
 
 #define X3_GMAX 8   // rows per history group (as AB_GMAX in hattbwd.hip)
+#ifndef X3_L1P1_OCC
+#define X3_L1P1_OCC 2
+#endif
 #ifndef X3_OCC
 #define X3_OCC 1
 #endif
@@ -471,7 +474,7 @@ struct L1BwdArgsX {
 };
 
 template <int OT, int NC, bool APPLY>
-__global__ void __launch_bounds__(256, 1) att_l1_bwd_x3_kernel(L1BwdArgsX a) {
+__global__ void __launch_bounds__(256, APPLY ? 1 : X3_L1P1_OCC) att_l1_bwd_x3_kernel(L1BwdArgsX a) {
   CLSR_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int KC = (NC + 1) / 2, KCP = 32 * KC, WS = KCP + 8, NR = 16 * OT;
@@ -521,8 +524,7 @@ __global__ void __launch_bounds__(256, 1) att_l1_bwd_x3_kernel(L1BwdArgsX a) {
       e4[ot] = nok[ot] ? a.ev[2][2 * a.C0 + nc] : 0.f;
     } else {
       e2[ot] = nok[ot] ? a.ev[2][nc] : 0.f;
-      e3[ot] = nok[ot] ? a.ev[3][nc] : 0.f;
-      e4[ot] = 0.f;
+      e3[ot] = 0.f; e4[ot] = 0.f;
     }
     wrow[ot] = n * WS + 8 * g;
   }
@@ -582,10 +584,14 @@ __global__ void __launch_bounds__(256, 1) att_l1_bwd_x3_kernel(L1BwdArgsX a) {
 
   const int tstride = gridDim.x * 4;
   int tile = blockIdx.x * 4 + wave;
+  // pass 2 (one 512-register wave per SIMD) keeps the next tile's loads in flight while it computes; pass 1 has no
+  // weight-gradient accumulators and runs two waves per SIMD without the register prefetch (X3_L1P1_OCC)
+  constexpr bool PF = APPLY || X3_L1P1_OCC < 2;
   RawT cur = fetch(tile);
   int pending = 0;
   for (; tile < ntiles; tile += tstride) {
-    const RawT nxt = fetch(tile + tstride);      // (past the end: clamped / out-of-range loads, never used)
+    RawT nxt;
+    if (PF) nxt = fetch(tile + tstride);      // (past the end: clamped / out-of-range loads, never used)
     const int m0 = tile * 32;
     // ---- prologue: dz1 of the lane's position (A operand: features 32c + 8g + {0..7}), split
     bf16x8 dh[2][KC], dl[2][KC], dr[APPLY ? 2 : 1][APPLY ? KC : 1];
@@ -669,7 +675,8 @@ __global__ void __launch_bounds__(256, 1) att_l1_bwd_x3_kernel(L1BwdArgsX a) {
           for (int e = 0; e < 4; ++e) x1[e] = pval[s][e] ? fmaxf(y[e], 0.f) : 0.f;
           split4(x1, xh[s], xl[s]);
         } else {
-          const f32x4 w2 = (zz - e2[ot]) * e3[ot];
+          // (sum of dy0 * (z0 - mean0): the factor invstd0 of xhat0 is applied to the finished sums)
+          const f32x4 w2 = zz - e2[ot];
           fsum[ot] += (v.x + v.y) + (v.z + v.w);
           fsq[ot] += (v.x * w2.x + v.y * w2.y) + (v.z * w2.z + v.w * w2.w);
         }
@@ -692,7 +699,8 @@ __global__ void __launch_bounds__(256, 1) att_l1_bwd_x3_kernel(L1BwdArgsX a) {
       }
       pending = 0;
     }
-    cur = nxt;
+    if (PF) cur = nxt;
+    else if (tile + tstride < ntiles) cur = fetch(tile + tstride);
   }
 
   __syncthreads();      // the weight images / tables are dead: the LDS becomes the reduction buffer
@@ -759,22 +767,25 @@ __global__ void __launch_bounds__(256, 1) att_l1_bwd_x3_kernel(L1BwdArgsX a) {
       if (c < a.C0) {
         double t = 0.0;
         for (int w = 0; w < 16; ++w) t += red[(w * 2 + which) * NR + c];
+        if (which == 1) t *= (double)a.ev[3][c];      // sum dy0 * xhat0 = invstd0 * sum dy0 * (z0 - mean0)
         a.stats[((long)blockIdx.x * 2 + which) * a.C0 + c] = t;
       }
     }
   }
 }
 
-static int l1x_grid(int M) {
+static int l1x_grid(int M, bool apply = true) {
   int gx = clsr_cdiv(clsr_cdiv(M, 32), 4);
-  if (gx > 256) gx = 256;      // one workgroup per CU
+  const int cap = apply ? 256 : 256 * X3_L1P1_OCC;      // one workgroup per CU (pass 1: X3_L1P1_OCC)
+  if (gx > cap) gx = cap;
   return gx < 1 ? 1 : gx;
 }
 
 extern "C" int clsr_att_l1_bwd_x3_supported(int C1, int C0) {
   return C1 >= 8 && C1 <= 48 && C0 >= 4 && C0 <= 80 && C1 % 8 == 0 && C0 % 4 == 0;
 }
-extern "C" int clsr_att_l1_bwd_x3_parts(int M) { return l1x_grid(M); }
+// partial rows of pass 1 (stats) / partial chunks of pass 2 (dw1_partial): sized for the larger of the two
+extern "C" int clsr_att_l1_bwd_x3_parts(int M) { return l1x_grid(M, false); }
 
 template <int OT, int NC>
 static int l1x_launch(const L1BwdArgsX& a, bool apply, hipStream_t stream) {
@@ -782,7 +793,7 @@ static int l1x_launch(const L1BwdArgsX& a, bool apply, hipStream_t stream) {
   size_t shmem = (size_t)2 * NR * WS * 2 + (size_t)5 * KCP * 4;
   const size_t red = apply ? ((size_t)2 * OT * NC * 256 + 4 * NC * 16) * 4 : (size_t)16 * 2 * NR * 8;
   if (shmem < red) shmem = red;
-  dim3 grid(l1x_grid(a.M));
+  dim3 grid(l1x_grid(a.M, apply));
   if (apply) {
     auto kernel = att_l1_bwd_x3_kernel<OT, NC, true>;
     if (shmem > 64 * 1024) CLSR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
