@@ -25,7 +25,7 @@
 
 #define X3_GMAX 8   // rows per history group (as AB_GMAX in hattbwd.hip)
 #ifndef X3_L1P1_OCC
-#define X3_L1P1_OCC 2
+#define X3_L1P1_OCC 1      // (2: two waves per SIMD without the register prefetch -- 115.7 vs 111.9 us alone, nothing in the step; pass 2 sizes its partial chunks with the same grid)
 #endif
 #ifndef X3_OCC
 #define X3_OCC 1

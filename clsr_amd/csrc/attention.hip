@@ -58,9 +58,20 @@ __global__ void __launch_bounds__(64) att_out_fwd_kernel(AttOutArgs a) {
     // (1) partial scores in column layout
     if (tsC < tparC) {
       const long zo = r * T * C1 + 4 * qC;
-      for (int t = tsC; t < T; t += tparC) {
-        const f32x4 y = relu4(load4e<ZH>(a.z1, zo + (long)t * C1) * sc + sh);
-        sbuf[t * QC + qC] = dot4(y, wo);
+      // (four row pieces in flight per lane: one load per trip made this launch a chain of ~T / tparC dependent round
+      // trips per row -- 64-82 us in the step for 164 MB)
+      for (int t0 = tsC; t0 < T; t0 += 4 * tparC) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = t0 + u * tparC;
+          v[u] = load4e<ZH>(a.z1, zo + (long)(t < T ? t : T - 1) * C1);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = t0 + u * tparC;
+          if (t < T) sbuf[t * QC + qC] = dot4(relu4(v[u] * sc + sh), wo);
+        }
       }
     }
     __syncthreads();
@@ -104,7 +115,19 @@ __global__ void __launch_bounds__(64) att_out_fwd_kernel(AttOutArgs a) {
     if (tsD < tparD) {
       const float* kp = a.keys + h * T * Dk + 4 * qD;
       const int tend = len > 0 ? len : T;
-      for (int t = tsD; t < tend; t += tparD) acc += ld4(kp + (long)t * Dk) * wl[t];
+      for (int t0 = tsD; t0 < tend; t0 += 4 * tparD) {
+        f32x4 kv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = t0 + u * tparD;
+          kv[u] = ld4(kp + (long)(t < tend ? t : tend - 1) * Dk);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = t0 + u * tparD;
+          if (t < tend) acc += kv[u] * wl[t];
+        }
+      }
     }
     red[lane] = acc;
     __syncthreads();
@@ -298,14 +321,29 @@ __global__ void __launch_bounds__(256) att_dy1_stats_kernel(
     // a block owns a contiguous range of rows: fp32 partial sums stay short (<= M / blocks / rpb terms)
     const long per = (M + gridDim.x - 1) / gridDim.x;
     const long lo = (long)blockIdx.x * per, hi = lo + per < M ? lo + per : M;
-    for (long row = lo + ty; row < hi; row += rpb) {
-      const f32x4 zz = load4e<ZH>(z1, row * C + 4 * q);
-      const float dsv = ds[row];
-      const f32x4 y = zz * sc + sh;
-      const f32x4 d = dy1_of(zz, dsv, sc, sh, wo);
-      s1 += d;
-      s2 += d * ((zz - mu) * is);
-      s3 += relu4(y) * dsv;
+    // (four rows in flight per thread, accumulated in row order: one load per trip left this streaming pass at 2.9 TB/s)
+    for (long row0 = lo + ty; row0 < hi; row0 += 4 * rpb) {
+      f32x4 zv[4];
+      float dv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long row = row0 + (long)u * rpb;
+        const long rc = row < hi ? row : hi - 1;
+        zv[u] = load4e<ZH>(z1, rc * C + 4 * q);
+        dv[u] = ds[rc];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (row0 + (long)u * rpb < hi) {
+          const f32x4 zz = zv[u];
+          const float dsv = dv[u];
+          const f32x4 y = zz * sc + sh;
+          const f32x4 d = dy1_of(zz, dsv, sc, sh, wo);
+          s1 += d;
+          s2 += d * ((zz - mu) * is);
+          s3 += relu4(y) * dsv;
+        }
+      }
     }
   }
   red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2; red[2][threadIdx.x] = s3;

@@ -83,6 +83,8 @@ with torch.cuda.stream(st_):
     print("fp32  l1 forward z1 = relu(bn z0).W1 + stats   R 328 + W 164 MB   %6.1f us  %5.2f TB/s" % (t, 492 / t))
     t = timeit(lambda: call("clsr_att_l1_fwd", z0, A0, sc0, sh0, W1f, K1f, b1, z1, A1, st, M, A0, A1))
     print("x6    l1 forward z1 = relu(bn z0).W1 + stats   R 328 + W 164 MB   %6.1f us  %5.2f TB/s" % (t, 492 / t))
+    if os.environ.get("ONLY_ST"):      # (counter runs: one shape per kernel)
+        torch.cuda.synchronize(); sys.exit(0)
     # long-term attention shapes (G = 1, history level)
     Hn, G = 4096, 1
     R, M = Hn, Hn * T
