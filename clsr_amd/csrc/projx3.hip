@@ -160,3 +160,188 @@ extern "C" int clsr_proj_x3(const float* X, int ldx, const float* Wt, int Kp, co
   }
   return CLSR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ encoder tail
+// Back-projections of the encoders' input-side gradients from ONE pass over dPin [M, NX] (gfx950, split-bf16 products):
+//   dhist[m, :D]  += dPin[m, :NX] . W_x^T                              (d of the history embeddings: every encoder's share)
+//   dTT[m, :2H]    = dPin[m, tcol0 : tcol0 + 3H] . W_t^T               (d of the Time4LSTM's tanh time features)
+// (reference: tf.gradients through the input side of GRUCell / Time4LSTMCell, rnn_cell_implement.py:214-236.)  They were two
+// position-tiled launches (clsr_pgemm3 134 us + clsr_pgemm 71 us alone) that each read the 393 MB of dPin beside the fused
+// weight-gradient kernel, which reads it a third time: the tail of the step is bound by those reads.  A = the dPin tile
+// (rows = positions; the K = 32 chunks of a row are loaded up front), B = bf16 pieces of W_x^T (all chunks) and of W_t^T
+// (the chunks that overlap the time-gate columns) from LDS; result lanes = output features (csrc/attl1fwd.hip).
+struct EncBackArgs {
+  const float* dPin; int ldp;
+  const float* WxT; int Kpx;      // packed W_x^T (clsr_pack_batch): row d = history feature (D rows), K = NX
+  const float* WtT; int Kpt;      // packed W_t^T: row n = time feature (2H rows), K = 3H
+  float* dhist; int ldh;
+  float* dTT; int ldt;
+  int M, NX, D, H2, H3, tcol0;
+};
+
+#define EB_TC 5      // K = 32 chunks the time-gate columns can overlap (3H <= 128 at any 8-aligned offset)
+
+template <int NKC, int ND, int NT>      // chunks of NX, tiles of D, tiles of 2H
+__global__ void __launch_bounds__(512, 1) enc_back_x3_kernel(EncBackArgs a) {
+  CLSR_CHAIN_PRIO();
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int WSX = 32 * NKC + 8, WST = 32 * EB_TC + 8, DR = 16 * ND, TR = 16 * NT;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int j = lane & 15, g = lane >> 4;
+  __bf16* Xi = reinterpret_cast<__bf16*>(lds_raw);        // [2][DR][WSX]
+  __bf16* Ti = Xi + 2 * DR * WSX;                         // [2][TR][WST]: column k of the image = dPin column 32 c0 + k
+  const int c0 = a.tcol0 >> 5;                            // first chunk that overlaps the time-gate columns
+  {
+    constexpr int C8 = WSX / 8;
+    for (int e = tid; e < DR * C8; e += 512) {
+      const int row = e / C8, k = 8 * (e - row * C8);
+      f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (row < a.D && k < a.NX) v = ld8f(a.WxT + (long)row * a.Kpx + k);          // (NX % 8 == 0)
+      const bf16x8 h = to_h(v);
+      reinterpret_cast<bf16x8*>(Xi)[e] = h;
+      reinterpret_cast<bf16x8*>(Xi + DR * WSX)[e] = to_h(v - to_f(h));
+    }
+    constexpr int T8 = WST / 8;
+    for (int e = tid; e < TR * T8; e += 512) {
+      const int row = e / T8, k = 8 * (e - row * T8);
+      const int kl = 32 * c0 + k - a.tcol0;               // column of W_t^T (tcol0 % 8 == 0: whole groups of 8)
+      f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (row < a.H2 && kl >= 0 && kl < a.H3) v = ld8f(a.WtT + (long)row * a.Kpt + kl);   // (3H % 8 == 0)
+      const bf16x8 h = to_h(v);
+      reinterpret_cast<bf16x8*>(Ti)[e] = h;
+      reinterpret_cast<bf16x8*>(Ti + TR * WST)[e] = to_h(v - to_f(h));
+    }
+  }
+  __syncthreads();
+  constexpr unsigned SKIP = 0x40000000u;
+  unsigned ho[ND], to_[NT];
+#pragma unroll
+  for (int n = 0; n < ND; ++n) ho[n] = 16 * n + j < a.D ? (16 * n + j) * 4u : SKIP;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) to_[n] = 16 * n + j < a.H2 ? (16 * n + j) * 4u : SKIP;
+  const int xrow = j * WSX + 8 * g, trow = j * WST + 8 * g;
+  const __amdgpu_buffer_rsrc_t rh =
+      __builtin_amdgcn_make_buffer_rsrc(a.dhist, 0, ((unsigned)(a.M - 1) * (unsigned)a.ldh + (unsigned)a.D) * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rt =
+      __builtin_amdgcn_make_buffer_rsrc(a.dTT, 0, ((unsigned)(a.M - 1) * (unsigned)a.ldt + (unsigned)a.H2) * 4u, 0x00020000);
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const f32x8 z8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int kofs[NKC];
+#pragma unroll
+  for (int c = 0; c < NKC; ++c) kofs[c] = 32 * c + 8 * g < a.NX ? 32 * c + 8 * g : 0;
+  const int c1 = min(NKC, (a.tcol0 + a.H3 + 31) >> 5);     // one past the last chunk with time-gate columns
+
+  const int ntiles = (a.M + 15) >> 4;
+  for (int tile = blockIdx.x * 8 + wave; tile < ntiles; tile += gridDim.x * 8) {
+    const int m0 = tile * 16;
+    const int m = m0 + j;
+    const bool pv = m < a.M;
+    const float* p = a.dPin + (long)(pv ? m : a.M - 1) * a.ldp;
+    f32x8 x[NKC];
+#pragma unroll
+    for (int c = 0; c < NKC; ++c) x[c] = ld8f(p + kofs[c]);
+    // d(hist) as it stands, in the result layout (4 positions of feature 16 n + j)
+    unsigned roh[4], rot[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int q = m0 + 4 * g + e;
+      roh[e] = q < a.M ? (unsigned)q * (unsigned)a.ldh * 4u : SKIP;
+      rot[e] = q < a.M ? (unsigned)q * (unsigned)a.ldt * 4u : SKIP;
+    }
+    f32x4 ah[ND], at[NT];
+#pragma unroll
+    for (int n = 0; n < ND; ++n)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        ah[n][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rh, roh[e] + ho[n], 0, 0));
+#pragma unroll
+    for (int n = 0; n < NT; ++n) at[n] = z4;
+#pragma unroll
+    for (int c = 0; c < NKC; ++c) {
+      __builtin_amdgcn_sched_barrier(0);
+      f32x8 y = (pv && 32 * c + 8 * g < a.NX) ? x[c] : z8;
+      const bf16x8 xh = to_h(y);
+      const bf16x8 xl = to_h(y - to_f(xh));
+      bf16x8 wh[ND], wl[ND];
+#pragma unroll
+      for (int n = 0; n < ND; ++n) {
+        wh[n] = ld8h(Xi + xrow + 16 * n * WSX + 32 * c);
+        wl[n] = ld8h(Xi + DR * WSX + xrow + 16 * n * WSX + 32 * c);
+      }
+#pragma unroll
+      for (int n = 0; n < ND; ++n) HMFMA(ah[n], xh, wl[n]);
+#pragma unroll
+      for (int n = 0; n < ND; ++n) HMFMA(ah[n], xl, wh[n]);
+#pragma unroll
+      for (int n = 0; n < ND; ++n) HMFMA(ah[n], xh, wh[n]);
+      if (c >= c0 && c < c1) {       // (uniform)
+        const int ct = c - c0;
+        bf16x8 th[NT], tl[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          th[n] = ld8h(Ti + trow + 16 * n * WST + 32 * ct);
+          tl[n] = ld8h(Ti + TR * WST + trow + 16 * n * WST + 32 * ct);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) HMFMA(at[n], xh, tl[n]);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) HMFMA(at[n], xl, th[n]);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) HMFMA(at[n], xh, th[n]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int n = 0; n < ND; ++n) {
+        const float v = ah[n][e];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rh, roh[e] + ho[n], 0, 0);
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const float v = at[n][e];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rt, rot[e] + to_[n], 0, 0);
+      }
+    }
+  }
+}
+
+extern "C" int clsr_enc_back_x3_supported(int M, int NX, int D, int H2, int H3, int tcol0) {
+  return M > 0 && NX >= 8 && NX <= 512 && NX % 8 == 0 && D >= 4 && D <= 48 && D % 4 == 0 && H2 >= 4 && H2 <= 80 &&
+         H2 % 4 == 0 && H3 >= 8 && H3 <= 128 && H3 % 8 == 0 && tcol0 >= 0 && tcol0 % 8 == 0 && tcol0 + H3 <= NX &&
+         ((tcol0 + H3 + 31) >> 5) - (tcol0 >> 5) <= EB_TC && (long)M * NX * 4 < 0x7fffffffL;
+}
+
+template <int NKC, int ND, int NT>
+static int enc_back_launch(const EncBackArgs& a, hipStream_t stream) {
+  constexpr int WSX = 32 * NKC + 8, WST = 32 * EB_TC + 8;
+  const size_t shmem = (size_t)2 * 16 * ND * WSX * 2 + (size_t)2 * 16 * NT * WST * 2;
+  int gx = clsr_cdiv(clsr_cdiv(a.M, 16), 8);
+  if (gx > 256) gx = 256;
+  auto kernel = enc_back_x3_kernel<NKC, ND, NT>;
+  if (shmem > 64 * 1024) CLSR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL(kernel, dim3(gx), dim3(512), shmem, stream, a);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+extern "C" int clsr_enc_back_x3(const float* dPin, int ldp, const float* WxT, int Kpx, const float* WtT, int Kpt, int tcol0,
+                                float* dhist, int ldh, float* dTT, int ldt, int M, int NX, int D, int H2, int H3,
+                                void* stream) {
+  CLSR_CHECK_ARG(dPin && WxT && WtT && dhist && dTT);
+  CLSR_CHECK_SUPPORTED(clsr_enc_back_x3_supported(M, NX, D, H2, H3, tcol0));
+  CLSR_CHECK_ARG(ldp >= NX && ldh >= D && ldt >= H2 && Kpx >= 16 * clsr_cdiv(NX, 16) && Kpt >= 16 * clsr_cdiv(H3, 16));
+  CLSR_CHECK_SUPPORTED(ldp % 4 == 0 && Kpx % 4 == 0 && Kpt % 4 == 0 && ((uintptr_t)dPin % 16) == 0 && ((uintptr_t)WxT % 16) == 0 &&
+                       ((uintptr_t)WtT % 16) == 0 && (long)M * ldh * 4 < 0x40000000L && (long)M * ldt * 4 < 0x40000000L);
+  EncBackArgs a = {};
+  a.dPin = dPin; a.ldp = ldp; a.WxT = WxT; a.Kpx = Kpx; a.WtT = WtT; a.Kpt = Kpt; a.dhist = dhist; a.ldh = ldh; a.dTT = dTT;
+  a.ldt = ldt; a.M = M; a.NX = NX; a.D = D; a.H2 = H2; a.H3 = H3; a.tcol0 = tcol0;
+  hipStream_t s = (hipStream_t)stream;
+  const int nkc = clsr_cdiv(NX, 32), nd = 3, nt = H2 <= 48 ? 3 : 5;
+#define EB_GO(C) \
+  if (nkc <= C) return nt == 3 ? enc_back_launch<C, 3, 3>(a, s) : enc_back_launch<C, 3, 5>(a, s)
+  EB_GO(4); EB_GO(8); EB_GO(12); EB_GO(15); EB_GO(16);
+#undef EB_GO
+  (void)nd;
+  return CLSR_OK;
+}

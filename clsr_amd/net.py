@@ -119,6 +119,7 @@ class CLSRNet(object):
                                 # backward kernels instead, csrc/attbwdx3.hip)
         self.x3_gemm = x3d and os.environ.get("CLSR_X3_GEMM", "xw^T")      # "all" | comma-separated weight keys | ""
         self.x3_enc = x3d and not os.environ.get("CLSR_NO_X3_ENC")        # A/B: fused encoder tail (csrc/encbwd.hip)
+        self.enc_back_x3 = x3d and not os.environ.get("CLSR_NO_ENC_BACK_X3")   # A/B: d(hist) and d TT from one pass over dPin (csrc/projx3.hip)
         self.att_l1_fwd_x6 = x3d and not os.environ.get("CLSR_NO_ATT_L1_FWD_X6")   # A/B: second attention layer, forward (csrc/attl1fwd.hip)
         self.att_hist_bwd_x3 = (x3d or self.precision == "bf16") and not self.exact_products and not os.environ.get("CLSR_NO_ATT_HIST_BWD_X3")   # A/B: history-level attention backward in one launch
         self.att_hist_x3 = (x3d or self.precision == "bf16") and not self.exact_products and not os.environ.get("CLSR_NO_ATT_HIST_X3")  # A/B: history-level attention prologue in one launch (csrc/atthist.hip)
@@ -1621,7 +1622,7 @@ class CLSRNet(object):
         self._dw(TT, 2 * H, dPt[:, 3 * H:], NX, M, 2 * H, 3 * H, self._buf("t4.dTW", 2 * H, 3 * H), 3 * H, dy_bf16=hb)
         self._t4_time_chain_bwd(f, dPinAll, Hn, T, hs)
 
-    def _t4_time_chain_bwd(self, f, dPinAll, Hn, T, hs):
+    def _t4_time_chain_bwd(self, f, dPinAll, Hn, T, hs, have_dtt=False):
         """d TT = dPin[:, o | tns | tls] . tw^T, its tanh backward and the sums for the four time-input vectors."""
         Gd, H, NX = self.Gd, self.H, self.NX
         t, M = self._t4_scope, Hn * T
@@ -1630,7 +1631,8 @@ class CLSRNet(object):
         dTT = self._buf("t4.dTT", M, 2 * H)
         parts = query("clsr_t4_time_inputs_bwd_parts", Hn, T, H)
         tp = self._buf("t4.tpart", 512 * 4 * 128)[: parts * 4 * H]
-        self._gemm(dPt[:, 3 * H:], NX, "t4.tw^T", M, 3 * H, 2 * H, dTT, 2 * H)
+        if not have_dtt:
+            self._gemm(dPt[:, 3 * H:], NX, "t4.tw^T", M, 3 * H, 2 * H, dTT, 2 * H)
         call("clsr_t4_time_inputs_bwd", dTT, TT, f["time_to_now"], f["time_from_first_action"], hs * T, Hn, T, H, tp)
         for off_, nm in ((0, "_time_input_w1"), (H, "_time_input_w2"), (2 * H, "_time_input_bias1"),
                          (3 * H, "_time_input_bias2")):
@@ -1726,6 +1728,16 @@ class CLSRNet(object):
                  self._buf("g2.gates", Hn, T, 3 * H), *wss, M)
         if side:
             self._dw_async = True       # (the flush waits for the weight-gradient stream)
+        tcol0 = self._enc_off("t4") + 3 * H
+        if (self.enc_back_x3 and "t4.tw^T" in self.packed
+                and query("clsr_enc_back_x3_supported", M, NX, D, 2 * H, 3 * H, tcol0)):
+            # d(hist) += dPin . W_x^T and d TT = dPin[:, o | tns | tls] . tw^T from ONE pass over dPin (csrc/projx3.hip)
+            Wx, Kpx = self.packed["xw^T"]
+            Wt, Kpt = self.packed["t4.tw^T"]
+            call("clsr_enc_back_x3", dPinAll, NX, Wx, Kpx, Wt, Kpt, tcol0, dhist, D, self._buf("t4.dTT", M, 2 * H), 2 * H,
+                 M, NX, D, 2 * H, 3 * H)
+            self._t4_time_chain_bwd(f, dPinAll, Hn, T, hs, have_dtt=True)
+            return
         if self.dhist_side and self.overlap:
             with self._branch("@lt", after=self._fork_point(), name="@dhist"):
                 self._gemm(dPinAll, NX, "xw^T", M, NX, D, dhist, D, acc=1)

@@ -354,6 +354,13 @@ int clsr_att_hist_fwd_x3(const float* keys, int ldk, const float* At, int Kpa, c
 int clsr_proj_x3_supported(int M, int K, int N);
 int clsr_proj_x3(const float* X, int ldx, const float* Wt, int Kp, const float* bias, float* Y, int ldy, int M, int K,
                  int N, int pieces, void* stream);
+/* Back-projections of the encoders' input-side gradients from ONE pass over dPin [M, NX] (split-bf16 products, csrc/projx3.hip):
+ *   dhist[m, :D] += dPin[m, :NX] . W_x^T;   dTT[m, :H2] = dPin[m, tcol0 : tcol0 + H3] . W_t^T
+ * WxT / WtT = packed transposed weights (D rows, K = NX / H2 rows, K = H3).  Replaces two clsr_pgemm(3) launches that each
+ * read dPin (reference: tf.gradients through the input side of the cells, rnn_cell_implement.py:214-236). */
+int clsr_enc_back_x3_supported(int M, int NX, int D, int H2, int H3, int tcol0);
+int clsr_enc_back_x3(const float* dPin, int ldp, const float* WxT, int Kpx, const float* WtT, int Kpt, int tcol0,
+                     float* dhist, int ldh, float* dTT, int ldt, int M, int NX, int D, int H2, int H3, void* stream);
 /* Second attention layer, forward: z1 = relu(z0 * scale0 + shift0) . W1 + b1 with the product over three bf16 pieces per
  * operand on the bf16 matrix pipe (2^-23 relative: the level of an fp32 fma chain), stats = per-block partial column sums /
  * sums of squares of z1, [clsr_att_l1_fwd_stats_parts(M)][2][C1] doubles (NULL: none).  Wt = packed W1 (C1 rows, K = C0).

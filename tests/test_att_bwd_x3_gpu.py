@@ -318,3 +318,26 @@ def test_projection_split_products(M, K, N, pieces):
     call("clsr_proj_x3", dX, K, Wt, Kp, None, Y2, N, M, K, N, pieces)
     torch.cuda.synchronize()
     close(Y2, exp - db.double().cpu(), 5e-5 if pieces == 2 else 2e-6, "Y without bias")
+
+
+@pytest.mark.parametrize("M,NX,D,H,tcol0", [(2000, 480, 40, 40, 360), (515, 480, 40, 40, 360), (70, 96, 8, 8, 40),
+                                             (4099, 144, 16, 16, 96), (40000, 480, 40, 40, 360), (33, 512, 48, 40, 392)])
+def test_encoder_tail_back_projections(M, NX, D, H, tcol0):
+    """clsr_enc_back_x3: dhist += dPin . Wx^T and dTT = dPin[:, tcol0 : tcol0 + 3H] . Wt^T from one pass == float64."""
+    H2, H3 = 2 * H, 3 * H
+    assert query("clsr_enc_back_x3_supported", M, NX, D, H2, H3, tcol0) == 1
+    g = torch.Generator().manual_seed(M + NX)
+    dPin, Wx, Wt = rnd(g, M, NX, scale=0.3), rnd(g, D, NX, scale=0.3), rnd(g, H2, H3, scale=0.3)     # Wx: [D, NX] = W_x as stored
+    dh0 = rnd(g, M, D)
+    WxT, Kpx = ops.pack_weight(dev(Wx), D, NX, transposed=True)      # dhist = dPin . W_x^T: out = D, in = NX
+    WtT, Kpt = ops.pack_weight(dev(Wt), H2, H3, transposed=True)
+    dP = dev(dPin)
+    dhist = torch.full((M, D + 4), 7.0, device="cuda")
+    dhist[:, :D] = dev(dh0)
+    dTT = torch.full((M, H2 + 4), 7.0, device="cuda")
+    call("clsr_enc_back_x3", dP, NX, WxT, Kpx, WtT, Kpt, tcol0, dhist, D + 4, dTT, H2 + 4, M, NX, D, H2, H3)
+    torch.cuda.synchronize()
+    f = lambda t: dev(t).double().cpu()
+    close(dhist[:, :D], f(dh0) + f(dPin) @ f(Wx).t(), 5e-5, "dhist")
+    close(dTT[:, :H2], f(dPin)[:, tcol0:tcol0 + H3] @ f(Wt).t(), 5e-5, "dTT")
+    assert float((dhist[:, D:] - 7.0).abs().max()) == 0 and float((dTT[:, H2:] - 7.0).abs().max()) == 0
