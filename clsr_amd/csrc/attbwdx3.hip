@@ -76,6 +76,55 @@ __device__ __forceinline__ float x3_ld1(x3_rsrc_t rs, unsigned off) {
 __device__ __forceinline__ void x3_st1(x3_rsrc_t rs, unsigned off, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, off, 0, 0);
 }
+// ---- storage type of the (row, step)-level tensors z1 / z0 / dz0: float (parity mode) or __bf16 (speed mode: half the
+// bytes; with NP = 1 -- ONE bf16 piece per operand -- the kernels below are the speed mode's chain kernels, replacing
+// csrc/hgemm.hip's position-tiled products + their separate weight-gradient launches).  Loads stay RAW in the prefetch
+// registers (a conversion at the load would wait for it).
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <typename ST> struct X3Raw8;
+template <> struct X3Raw8<float> { f32x4 lo, hi; };
+template <> struct X3Raw8<__bf16> { u32x4_t v; };
+__device__ __forceinline__ f32x8 x3_f8(const X3Raw8<float>& r) { return (f32x8){r.lo.x, r.lo.y, r.lo.z, r.lo.w, r.hi.x, r.hi.y, r.hi.z, r.hi.w}; }
+__device__ __forceinline__ f32x8 x3_f8(const X3Raw8<__bf16>& r) { return to_f(__builtin_bit_cast(bf16x8, r.v)); }
+template <typename ST> __device__ __forceinline__ X3Raw8<ST> x3_ld8raw(x3_rsrc_t rs, unsigned off, unsigned soff);
+template <> __device__ __forceinline__ X3Raw8<float> x3_ld8raw<float>(x3_rsrc_t rs, unsigned off, unsigned soff) {
+  X3Raw8<float> r;
+  r.lo = x3_ld4(rs, off, soff); r.hi = x3_ld4(rs, off + 16u, soff);
+  return r;
+}
+template <> __device__ __forceinline__ X3Raw8<__bf16> x3_ld8raw<__bf16>(x3_rsrc_t rs, unsigned off, unsigned soff) {
+  X3Raw8<__bf16> r;
+  r.v = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, off, soff, 0));
+  return r;
+}
+template <typename ST> __device__ __forceinline__ X3Raw8<ST> x3_ld8raw_g(const ST* p);
+template <> __device__ __forceinline__ X3Raw8<float> x3_ld8raw_g<float>(const float* p) {
+  X3Raw8<float> r;
+  r.lo = ld4(p); r.hi = ld4(p + 4);
+  return r;
+}
+template <> __device__ __forceinline__ X3Raw8<__bf16> x3_ld8raw_g<__bf16>(const __bf16* p) {
+  X3Raw8<__bf16> r;
+  r.v = *reinterpret_cast<const u32x4_t*>(p);
+  return r;
+}
+// one element: raw bits in a 32-bit register (bf16: zero-extended), converted at the use
+template <typename ST> __device__ __forceinline__ unsigned x3_ld1raw(x3_rsrc_t rs, unsigned off);
+template <> __device__ __forceinline__ unsigned x3_ld1raw<float>(x3_rsrc_t rs, unsigned off) {
+  return __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0);
+}
+template <> __device__ __forceinline__ unsigned x3_ld1raw<__bf16>(x3_rsrc_t rs, unsigned off) {
+  return (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, off, 0, 0);
+}
+template <typename ST> __device__ __forceinline__ float x3_f1(unsigned r);
+template <> __device__ __forceinline__ float x3_f1<float>(unsigned r) { return __builtin_bit_cast(float, r); }
+template <> __device__ __forceinline__ float x3_f1<__bf16>(unsigned r) { return __builtin_bit_cast(float, r << 16); }
+template <typename ST> __device__ __forceinline__ void x3_st1s(x3_rsrc_t rs, unsigned off, float v);
+template <> __device__ __forceinline__ void x3_st1s<float>(x3_rsrc_t rs, unsigned off, float v) { x3_st1(rs, off, v); }
+template <> __device__ __forceinline__ void x3_st1s<__bf16>(x3_rsrc_t rs, unsigned off, float v) {
+  const __bf16 h = (__bf16)v;      // (round to nearest even)
+  __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), rs, off, 0, 0);
+}
 
 // ------------------------------------------------------------------------------------------------ layer 0
 //   z0[r,t,:] = U[h,t,:] + V[r,:] + (a[h,t,:] * q[r,:]) . Wp
@@ -84,7 +133,7 @@ __device__ __forceinline__ void x3_st1(x3_rsrc_t rs, unsigned off, float v) {
 // One WAVE per history; iterations (16-step tile, row of the group) are processed in PAIRS so that the eight positions a
 // lane holds of its feature (4 of each iteration) fill one bf16x8 operand of the weight-gradient MFMAs.
 struct AttL0BwdArgsX {
-  const float* dz0; int lddz;
+  const void* dz0; int lddz;     // float or __bf16 (the kernel's ST)
   const float* Wt; int Kp;       // packed fp32 Wp^T (clsr_pack_batch): row c = query feature (natural order), K = A0
   const float* a; int lda;
   const float* q; int ldq;
@@ -97,8 +146,10 @@ struct AttL0BwdArgsX {
   int G, T, Q, A0;
 };
 
-template <int NF, int NZ>
+// NP = bf16 pieces per operand: 2 (hi + lo: the parity mode's x3 products) or 1 (speed mode); ST = storage type of dz0
+template <int NF, int NZ, int NP, typename ST>
 __global__ void __launch_bounds__(256, X3_OCC) att_l0_bwd_x3_kernel(AttL0BwdArgsX s) {
+  constexpr unsigned SB = sizeof(ST);
   CLSR_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int KT = (NZ + 1) / 2;          // 32-wide k chunks of A0
@@ -125,6 +176,7 @@ __global__ void __launch_bounds__(256, X3_OCC) att_l0_bwd_x3_kernel(AttL0BwdArgs
     }
   }
   __syncthreads();
+  const ST* dz0p = reinterpret_cast<const ST*>(s.dz0);
 
   // B operands: weights of query-feature tile f, lane (j, g4) reads row 16f + j, k = 32kt + 8g4 + {0..7}
   const int wrow = j * WS + 8 * g4;          // + 16 f WS + 32 kt
@@ -148,7 +200,7 @@ __global__ void __launch_bounds__(256, X3_OCC) att_l0_bwd_x3_kernel(AttL0BwdArgs
   constexpr unsigned X3_SKIP = 0x40000000u;
   unsigned kofs[KT];                         // dz0: byte offset of the lane's 8 features of chunk kt
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt) kofs[kt] = 32 * kt + 8 * g4 < s.A0 ? (32 * kt + 8 * g4) * 4u : X3_SKIP;   // (skipped: reads 0)
+  for (int kt = 0; kt < KT; ++kt) kofs[kt] = 32 * kt + 8 * g4 < s.A0 ? (32 * kt + 8 * g4) * SB : X3_SKIP;   // (skipped: reads 0)
   unsigned aofs[NF], dao[NF], duo[NZ];       // a (read, clamped), da / dU (written: skipped beyond the width)
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
@@ -174,26 +226,23 @@ __global__ void __launch_bounds__(256, X3_OCC) att_l0_bwd_x3_kernel(AttL0BwdArgs
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
 
-    const x3_rsrc_t rdz = x3_rsrc_n(s.dz0 + h * G * T * s.lddz, (unsigned)(G * T * s.lddz) * 4u);
+    const x3_rsrc_t rdz = x3_rsrc_n(dz0p + h * G * T * s.lddz, (unsigned)(G * T * s.lddz) * SB);
     const x3_rsrc_t ra = x3_rsrc_n(s.a + h * T * s.lda, (unsigned)(T * s.lda) * 4u);
     const x3_rsrc_t rda = x3_rsrc_n(s.da + h * T * s.ldda, (unsigned)(T * s.ldda) * 4u);
     const x3_rsrc_t rdu = x3_rsrc_n(s.dU ? s.dU + h * T * s.lddu : nullptr, s.dU ? (unsigned)(T * s.lddu) * 4u : 0u);
 
     // dz0 tiles of iteration i = (tt, g) in A-operand order: lane (position j, g4) holds features 32kt + 8g4 + {0..7}
-    struct Raw { f32x8 x[KT]; };
+    struct Raw { X3Raw8<ST> x[KT]; };
     int itt = 0, ig = 0;
-    unsigned rowoff = (unsigned)(min(j, T - 1) * s.lddz) * 4u;          // lane's row of tile itt inside a [T, lddz] block
+    unsigned rowoff = (unsigned)(min(j, T - 1) * s.lddz) * SB;          // lane's row of tile itt inside a [T, lddz] block
     auto issue = [&]() -> Raw {
-      const unsigned blk = (unsigned)(ig * T * s.lddz) * 4u;             // (uniform)
+      const unsigned blk = (unsigned)(ig * T * s.lddz) * SB;             // (uniform)
       Raw r;
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {
-        const f32x4 lo = x3_ld4(rdz, rowoff + kofs[kt], blk), hi = x3_ld4(rdz, rowoff + kofs[kt] + 16u, blk);
-        r.x[kt] = (f32x8){lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-      }
+      for (int kt = 0; kt < KT; ++kt) r.x[kt] = x3_ld8raw<ST>(rdz, rowoff + kofs[kt], blk);
       if (++ig == G) {
         ig = 0;
-        if (itt + 1 < NTT) { ++itt; rowoff = (unsigned)(min(16 * itt + j, T - 1) * s.lddz) * 4u; }   // (clamps at the last tile)
+        if (itt + 1 < NTT) { ++itt; rowoff = (unsigned)(min(16 * itt + j, T - 1) * s.lddz) * SB; }   // (clamps at the last tile)
       }
       return r;
     };
@@ -236,11 +285,13 @@ __global__ void __launch_bounds__(256, X3_OCC) att_l0_bwd_x3_kernel(AttL0BwdArgs
             const bool pv = t0 + j < T;      // (false only in a ragged last tile)
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
-              f32x8 v = (t0 + 16 <= T || pv) ? ring[d].x[kt] : z8;
+              f32x8 v = (t0 + 16 <= T || pv) ? x3_f8(ring[d].x[kt]) : z8;
               xh[kt] = to_h(v);
-              v -= to_f(xh[kt]);
-              xl[kt] = to_h(v);
-              xr[kt] = to_h(v - to_f(xl[kt]));
+              if constexpr (NP > 1) {
+                v -= to_f(xh[kt]);
+                xl[kt] = to_h(v);
+                xr[kt] = to_h(v - to_f(xl[kt]));
+              }
             }
           }
           ring[d] = issue();
@@ -254,12 +305,14 @@ __global__ void __launch_bounds__(256, X3_OCC) att_l0_bwd_x3_kernel(AttL0BwdArgs
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
               wh[f] = ld8h(Wh + wrow + 16 * f * WS + 32 * kt);
-              wlo[f] = ld8h(Wl + wrow + 16 * f * WS + 32 * kt);
+              if constexpr (NP > 1) wlo[f] = ld8h(Wl + wrow + 16 * f * WS + 32 * kt);
             }
+            if constexpr (NP > 1) {
 #pragma unroll
-            for (int f = 0; f < NF; ++f) HMFMA(acc[f], xh[kt], wlo[f]);
+              for (int f = 0; f < NF; ++f) HMFMA(acc[f], xh[kt], wlo[f]);
 #pragma unroll
-            for (int f = 0; f < NF; ++f) HMFMA(acc[f], xl[kt], wh[f]);
+              for (int f = 0; f < NF; ++f) HMFMA(acc[f], xl[kt], wh[f]);
+            }
 #pragma unroll
             for (int f = 0; f < NF; ++f) HMFMA(acc[f], xh[kt], wh[f]);
           }
@@ -267,13 +320,18 @@ __global__ void __launch_bounds__(256, X3_OCC) att_l0_bwd_x3_kernel(AttL0BwdArgs
           f32x4 dzt[NZ];
 #pragma unroll
           for (int z = 0; z < NZ; ++z) {
-            f32x4 th = z4, tl = z4, tr = z4;
+            f32x4 th = z4;
             HMFMA(th, xh[z >> 1], sel[z & 1]);
-            HMFMA(tl, xl[z >> 1], sel[z & 1]);
-            HMFMA(tr, xr[z >> 1], sel[z & 1]);
             cbh[z] = to_h4(th);
-            cbl[z] = to_h4(tl);
-            dzt[z] = th + (tl + tr);
+            if constexpr (NP > 1) {
+              f32x4 tl = z4, tr = z4;
+              HMFMA(tl, xl[z >> 1], sel[z & 1]);
+              HMFMA(tr, xr[z >> 1], sel[z & 1]);
+              cbl[z] = to_h4(tl);
+              dzt[z] = th + (tl + tr);
+            } else {
+              dzt[z] = th;      // (exact for a bf16 dz0)
+            }
           }
           // sums over the 16 positions of the tile: three adds inside a lane, then the four lane groups are summed by the
           // fp32 matrix pipe (ones[16x4] . partial[4x16]); lane group g4 then owns feature tile 4c + g4 of the accumulators.
@@ -285,7 +343,8 @@ __global__ void __launch_bounds__(256, X3_OCC) att_l0_bwd_x3_kernel(AttL0BwdArgs
             dacc[f] += acc[f] * qv;
             const f32x4 pr = acc[f] * at[f];
             sq[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, (pr.x + pr.y) + (pr.z + pr.w), z4, 0, 0, 0)[0];
-            split4(at[f] * qv, cah[f], cal[f]);
+            if constexpr (NP > 1) split4(at[f] * qv, cah[f], cal[f]);
+            else cah[f] = to_h4(at[f] * qv);
           }
 #pragma unroll
           for (int z = 0; z < NZ; ++z) {
@@ -335,10 +394,12 @@ __global__ void __launch_bounds__(256, X3_OCC) att_l0_bwd_x3_kernel(AttL0BwdArgs
 #pragma unroll
           for (int f = 0; f < NF; ++f) {
             const bf16x8 ah = cat4(sah[f], cah[f]), al = cat4(sal[f], cal[f]);
+            if constexpr (NP > 1) {
 #pragma unroll
-            for (int z = 0; z < NZ; ++z) HMFMA(accW[f][z], ah, bl[z]);
+              for (int z = 0; z < NZ; ++z) HMFMA(accW[f][z], ah, bl[z]);
 #pragma unroll
-            for (int z = 0; z < NZ; ++z) HMFMA(accW[f][z], al, bh[z]);
+              for (int z = 0; z < NZ; ++z) HMFMA(accW[f][z], al, bh[z]);
+            }
 #pragma unroll
             for (int z = 0; z < NZ; ++z) HMFMA(accW[f][z], ah, bh[z]);
           }
@@ -409,13 +470,13 @@ extern "C" int clsr_att_l0_bwd_x3_supported(int G, int Q, int A0) {
 }
 extern "C" int clsr_att_l0_bwd_x3_parts(long Hn) { return l0x_grid(Hn); }
 
-template <int NF, int NZ>
+template <int NF, int NZ, int NP, typename ST>
 static int att_l0_bwd_x3_launch(const AttL0BwdArgsX& a, hipStream_t stream) {
   constexpr int KT = (NZ + 1) / 2, WS = 32 * KT + 8;
   size_t shmem = (size_t)2 * 16 * NF * WS * 2 + (size_t)4 * X3_GMAX * (2 * 16 * NF + 16 * NZ) * 4;
   const size_t red = (size_t)2 * NF * NZ * 256 * 4;
   if (shmem < red) shmem = red;
-  auto kernel = att_l0_bwd_x3_kernel<NF, NZ>;
+  auto kernel = att_l0_bwd_x3_kernel<NF, NZ, NP, ST>;
   if (shmem > 64 * 1024)
     CLSR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   hipLaunchKernelGGL(kernel, dim3(l0x_grid(a.Hn)), dim3(256), shmem, stream, a);
@@ -423,13 +484,13 @@ static int att_l0_bwd_x3_launch(const AttL0BwdArgsX& a, hipStream_t stream) {
   return CLSR_OK;
 }
 
-extern "C" int clsr_att_l0_bwd_x3(const float* dz0, int lddz, const float* Wt, int Kp, const float* a, int lda,
-                                  const float* q, int ldq, long Hn, int G, int T, int Q, int A0, float* da, int ldda,
-                                  float* dq, int lddq, float* dU, int lddu, float* dV, int lddv, float* dwp_partial,
-                                  void* stream) {
+static int att_l0_bwd_x3_any(const void* dz0, bool half, int lddz, const float* Wt, int Kp, const float* a, int lda,
+                             const float* q, int ldq, long Hn, int G, int T, int Q, int A0, float* da, int ldda,
+                             float* dq, int lddq, float* dU, int lddu, float* dV, int lddv, float* dwp_partial,
+                             void* stream) {
   CLSR_CHECK_ARG(dz0 && Wt && a && q && da && dq && dV && dwp_partial && Hn > 0 && T > 0);
   CLSR_CHECK_SUPPORTED(clsr_att_l0_bwd_x3_supported(G, Q, A0));
-  CLSR_CHECK_SUPPORTED(lddz % 4 == 0 && Kp % 4 == 0 && ((uintptr_t)dz0 % 16) == 0 && ((uintptr_t)Wt % 16) == 0);
+  CLSR_CHECK_SUPPORTED(lddz % (half ? 8 : 4) == 0 && Kp % 4 == 0 && ((uintptr_t)dz0 % 16) == 0 && ((uintptr_t)Wt % 16) == 0);
   CLSR_CHECK_ARG(lddz >= A0 && Kp >= 16 * clsr_cdiv(A0, 16) && lda >= Q && ldq >= Q && ldda >= Q && lddq >= Q &&
                  (!dU || lddu >= A0) && lddv >= A0);
   AttL0BwdArgsX s = {};
@@ -438,10 +499,27 @@ extern "C" int clsr_att_l0_bwd_x3(const float* dz0, int lddz, const float* Wt, i
   s.Hn = Hn; s.G = G; s.T = T; s.Q = Q; s.A0 = A0;
   hipStream_t st = (hipStream_t)stream;
   const int nf = x3_tiles_class(Q), nz = x3_tiles_class(A0);
-#define X3_GO(F, Z) if (nf == F && nz == Z) return att_l0_bwd_x3_launch<F, Z>(s, st)
+#define X3_GO(F, Z) \
+  if (nf == F && nz == Z) return half ? att_l0_bwd_x3_launch<F, Z, 1, __bf16>(s, st) : att_l0_bwd_x3_launch<F, Z, 2, float>(s, st)
   X3_GO(3, 3); X3_GO(3, 5); X3_GO(5, 3); X3_GO(5, 5);
 #undef X3_GO
   return CLSR_OK;
+}
+
+extern "C" int clsr_att_l0_bwd_x3(const float* dz0, int lddz, const float* Wt, int Kp, const float* a, int lda,
+                                  const float* q, int ldq, long Hn, int G, int T, int Q, int A0, float* da, int ldda,
+                                  float* dq, int lddq, float* dU, int lddu, float* dV, int lddv, float* dwp_partial,
+                                  void* stream) {
+  return att_l0_bwd_x3_any(dz0, false, lddz, Wt, Kp, a, lda, q, ldq, Hn, G, T, Q, A0, da, ldda, dq, lddq, dU, lddu, dV,
+                           lddv, dwp_partial, stream);
+}
+// speed mode: dz0 stored as bf16 (uint16 bit patterns), ONE bf16 piece per operand (bf16-exact on the dz0 side)
+extern "C" int clsr_att_l0_bwd_x1_h(const void* dz0, int lddz, const float* Wt, int Kp, const float* a, int lda,
+                                    const float* q, int ldq, long Hn, int G, int T, int Q, int A0, float* da, int ldda,
+                                    float* dq, int lddq, float* dU, int lddu, float* dV, int lddv, float* dwp_partial,
+                                    void* stream) {
+  return att_l0_bwd_x3_any(dz0, true, lddz, Wt, Kp, a, lda, q, ldq, Hn, G, T, Q, A0, da, ldda, dq, lddq, dU, lddu, dV,
+                           lddv, dwp_partial, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ layer 1
@@ -461,21 +539,23 @@ extern "C" int clsr_att_l0_bwd_x3(const float* dz0, int lddz, const float* Wt, i
 // A wave owns tiles of 32 positions (two 16-position halves = one K = 32 chunk of the weight-gradient products); the loads
 // of its next tile are in flight while it computes (one 512-register wave per SIMD).
 struct L1BwdArgsX {
-  const float* z1; int ldz1;
+  const void* z1; int ldz1;      // z1 / z0 / dz0: float or __bf16 (the kernel's ST)
   const float* ds;
   const float* pv[4];            // scale1, shift1, w_out, coef1 (a1 | a2 | a3, stride C1)
   const float* Wt; int Kp;       // packed fp32 W1^T (clsr_pack_batch): row n = C0 feature, K = C1
-  const float* z0; int ldz0;
+  const void* z0; int ldz0;
   const float* ev[5];            // scale0, shift0, then mean0, invstd0 (pass 1) | coef0 c1|c2|c3 stride C0 (pass 2)
-  float* dz0; int lddz0;
+  void* dz0; int lddz0;
   float* dw1;                    // pass 2: [gridDim.x][CLSR_DW_CHUNK] partial chunks (tiles kt < OT, nt < NC, bias sums)
   double* stats;                 // pass 1: [gridDim.x][2][C0]
   int M, C1, C0;
 };
 
-template <int OT, int NC, bool APPLY>
+template <int OT, int NC, bool APPLY, int NP, typename ST>
 __global__ void __launch_bounds__(256, APPLY ? 1 : X3_L1P1_OCC) att_l1_bwd_x3_kernel(L1BwdArgsX a) {
   CLSR_CHAIN_PRIO();
+  constexpr unsigned SB = sizeof(ST);
+  const ST* z1p = reinterpret_cast<const ST*>(a.z1);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int KC = (NC + 1) / 2, KCP = 32 * KC, WS = KCP + 8, NR = 16 * OT;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -554,10 +634,10 @@ __global__ void __launch_bounds__(256, APPLY ? 1 : X3_L1P1_OCC) att_l1_bwd_x3_ke
 
   // (exact sizes: a lane of a ragged last feature tile -- C0 % 16 != 0 -- addresses up to 15 floats past its row, at the
   // last row past the END of the tensor; out of range it reads 0 / its store is dropped)
-  const x3_rsrc_t rz0 = x3_rsrc_n(a.z0, ((unsigned)(a.M - 1) * (unsigned)a.ldz0 + (unsigned)a.C0) * 4u);
-  const x3_rsrc_t rdz = x3_rsrc_n(APPLY ? a.dz0 : nullptr, APPLY ? ((unsigned)(a.M - 1) * (unsigned)a.lddz0 + (unsigned)a.C0) * 4u : 0u);
+  const x3_rsrc_t rz0 = x3_rsrc_n(a.z0, ((unsigned)(a.M - 1) * (unsigned)a.ldz0 + (unsigned)a.C0) * SB);
+  const x3_rsrc_t rdz = x3_rsrc_n(APPLY ? a.dz0 : nullptr, APPLY ? ((unsigned)(a.M - 1) * (unsigned)a.lddz0 + (unsigned)a.C0) * SB : 0u);
   const int ntiles = (a.M + 31) >> 5;
-  struct RawT { f32x8 z1[2][KC]; f32x4 z0[2][OT]; float ds[2]; };
+  struct RawT { X3Raw8<ST> z1[2][KC]; unsigned z0[2][OT][4]; float ds[2]; };
   auto fetch = [&](int tile) -> RawT {
     RawT r;
     const int m0 = tile * 32;
@@ -569,14 +649,14 @@ __global__ void __launch_bounds__(256, APPLY ? 1 : X3_L1P1_OCC) att_l1_bwd_x3_ke
 #pragma unroll
       for (int c = 0; c < KC; ++c) {
         const int k0 = 32 * c + 8 * g;
-        r.z1[s][c] = ld8f(a.z1 + mr * a.ldz1 + (k0 < a.C1 ? k0 : 0));
+        r.z1[s][c] = x3_ld8raw_g<ST>(z1p + mr * a.ldz1 + (k0 < a.C1 ? k0 : 0));
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int p = m0 + 16 * s + 4 * g + e;
-        const unsigned off = p < a.M ? ((unsigned)p * (unsigned)a.ldz0 + (unsigned)j) * 4u : X3_OOB;
+        const unsigned off = p < a.M ? ((unsigned)p * (unsigned)a.ldz0 + (unsigned)j) * SB : X3_OOB;
 #pragma unroll
-        for (int ot = 0; ot < OT; ++ot) r.z0[s][ot][e] = x3_ld1(rz0, off + 64u * ot);
+        for (int ot = 0; ot < OT; ++ot) r.z0[s][ot][e] = x3_ld1raw<ST>(rz0, off + 16u * SB * ot);
       }
     }
     return r;
@@ -594,7 +674,7 @@ __global__ void __launch_bounds__(256, APPLY ? 1 : X3_L1P1_OCC) att_l1_bwd_x3_ke
     if (PF) nxt = fetch(tile + tstride);      // (past the end: clamped / out-of-range loads, never used)
     const int m0 = tile * 32;
     // ---- prologue: dz1 of the lane's position (A operand: features 32c + 8g + {0..7}), split
-    bf16x8 dh[2][KC], dl[2][KC], dr[APPLY ? 2 : 1][APPLY ? KC : 1];
+    bf16x8 dh[2][KC], dl[2][KC], dr[APPLY ? 2 : 1][APPLY ? KC : 1];      // (dl, dr: NP > 1 only)
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
       const int k0 = 32 * c + 8 * g;
@@ -602,15 +682,19 @@ __global__ void __launch_bounds__(256, APPLY ? 1 : X3_L1P1_OCC) att_l1_bwd_x3_ke
       const f32x8 a2 = ld8f(ptab + 3 * KCP + k0), a3 = ld8f(ptab + 4 * KCP + k0);
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const f32x8 zz = cur.z1[s][c];
+        const f32x8 zz = x3_f8(cur.z1[s][c]);
         const f32x8 y = zz * sc + sh;
         f32x8 x = a2 * zz + a3;
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] += y[e] > 0.f ? pp[e] * cur.ds[s] : 0.f;
         const bool pvalid = m0 + 16 * s + j < a.M;     // (features beyond C1: every table entry is 0 -> x = 0)
         const f32x8 xm = pvalid ? x : z8;
-        split8x(xm, dh[s][c], dl[s][c]);
-        if (APPLY) dr[s][c] = to_h(xm - to_f(dh[s][c]) - to_f(dl[s][c]));   // (third piece: the bias sums below)
+        if constexpr (NP > 1) {
+          split8x(xm, dh[s][c], dl[s][c]);
+          if (APPLY) dr[s][c] = to_h(xm - to_f(dh[s][c]) - to_f(dl[s][c]));   // (third piece: the bias sums below)
+        } else {
+          dh[s][c] = to_h(xm);
+        }
       }
     }
     X3_SCHED_FENCE();
@@ -619,18 +703,22 @@ __global__ void __launch_bounds__(256, APPLY ? 1 : X3_L1P1_OCC) att_l1_bwd_x3_ke
     if (APPLY) {
 #pragma unroll
       for (int ct = 0; ct < NC; ++ct) {
-        f32x4 th0 = z4, tl0 = z4, th1 = z4, tl1 = z4;
+        f32x4 th0 = z4, th1 = z4;
         HMFMA(th0, dh[0][ct >> 1], sel[ct & 1]);
-        HMFMA(tl0, dl[0][ct >> 1], sel[ct & 1]);
         HMFMA(th1, dh[1][ct >> 1], sel[ct & 1]);
-        HMFMA(tl1, dl[1][ct >> 1], sel[ct & 1]);
         bh[ct] = cat4(to_h4(th0), to_h4(th1));
-        bl[ct] = cat4(to_h4(tl0), to_h4(tl1));
-        // (db1 = sum of dz1 cancels analytically under the batch-norm: its transposed image takes the third piece too)
-        f32x4 tr0 = z4, tr1 = z4;
-        HMFMA(tr0, dr[0][ct >> 1], sel[ct & 1]);
-        HMFMA(tr1, dr[1][ct >> 1], sel[ct & 1]);
-        const f32x4 t = (th0 + (tl0 + tr0)) + (th1 + (tl1 + tr1));
+        f32x4 t = th0 + th1;
+        if constexpr (NP > 1) {
+          f32x4 tl0 = z4, tl1 = z4;
+          HMFMA(tl0, dl[0][ct >> 1], sel[ct & 1]);
+          HMFMA(tl1, dl[1][ct >> 1], sel[ct & 1]);
+          bl[ct] = cat4(to_h4(tl0), to_h4(tl1));
+          // (db1 = sum of dz1 cancels analytically under the batch-norm: its transposed image takes the third piece too)
+          f32x4 tr0 = z4, tr1 = z4;
+          HMFMA(tr0, dr[0][ct >> 1], sel[ct & 1]);
+          HMFMA(tr1, dr[1][ct >> 1], sel[ct & 1]);
+          t = (th0 + (tl0 + tr0)) + (th1 + (tl1 + tr1));
+        }
         bsum[ct] += (t.x + t.y) + (t.z + t.w);
       }
     }
@@ -642,7 +730,7 @@ __global__ void __launch_bounds__(256, APPLY ? 1 : X3_L1P1_OCC) att_l1_bwd_x3_ke
       for (int e = 0; e < 4; ++e) {
         const int p = m0 + 16 * s + 4 * g + e;
         pval[s][e] = p < a.M;
-        soff[s][e] = pval[s][e] ? ((unsigned)p * (unsigned)a.lddz0 + (unsigned)j) * 4u : X3_OOB;
+        soff[s][e] = pval[s][e] ? ((unsigned)p * (unsigned)a.lddz0 + (unsigned)j) * SB : X3_OOB;
       }
     // ---- per C0 tile: dh0^T (4 positions of feature 16 ot + j for both halves), epilogue in the feature-lane layout,
     //      weight gradient of the tile (k = the 8 positions a lane holds of its feature, 4 of each half)
@@ -652,15 +740,19 @@ __global__ void __launch_bounds__(256, APPLY ? 1 : X3_L1P1_OCC) att_l1_bwd_x3_ke
       f32x4 acc0 = z4, acc1 = z4;
 #pragma unroll
       for (int c = 0; c < KC; ++c) {
-        const bf16x8 wh = ld8h(Wh + wrow[ot] + 32 * c), wl = ld8h(Wl + wrow[ot] + 32 * c);
-        HMFMA(acc0, dh[0][c], wl); HMFMA(acc1, dh[1][c], wl);
-        HMFMA(acc0, dl[0][c], wh); HMFMA(acc1, dl[1][c], wh);
+        const bf16x8 wh = ld8h(Wh + wrow[ot] + 32 * c);
+        if constexpr (NP > 1) {
+          const bf16x8 wl = ld8h(Wl + wrow[ot] + 32 * c);
+          HMFMA(acc0, dh[0][c], wl); HMFMA(acc1, dh[1][c], wl);
+          HMFMA(acc0, dl[0][c], wh); HMFMA(acc1, dl[1][c], wh);
+        }
         HMFMA(acc0, dh[0][c], wh); HMFMA(acc1, dh[1][c], wh);
       }
       bf16x4 xh[2], xl[2];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const f32x4 zz = cur.z0[s][ot];
+        const f32x4 zz = {x3_f1<ST>(cur.z0[s][ot][0]), x3_f1<ST>(cur.z0[s][ot][1]), x3_f1<ST>(cur.z0[s][ot][2]),
+                          x3_f1<ST>(cur.z0[s][ot][3])};
         const f32x4 y = zz * sc0[ot] + sh0[ot];
         const f32x4 ac = s ? acc1 : acc0;
         f32x4 v;
@@ -669,11 +761,12 @@ __global__ void __launch_bounds__(256, APPLY ? 1 : X3_L1P1_OCC) att_l1_bwd_x3_ke
         if (APPLY) {
           const f32x4 o = e2[ot] * v + e3[ot] * zz + e4[ot];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) x3_st1(rdz, nok[ot] ? soff[s][e] + 64u * ot : X3_OOB, o[e]);
+          for (int e = 0; e < 4; ++e) x3_st1s<ST>(rdz, nok[ot] ? soff[s][e] + 16u * SB * ot : X3_OOB, o[e]);
           f32x4 x1;
 #pragma unroll
           for (int e = 0; e < 4; ++e) x1[e] = pval[s][e] ? fmaxf(y[e], 0.f) : 0.f;
-          split4(x1, xh[s], xl[s]);
+          if constexpr (NP > 1) split4(x1, xh[s], xl[s]);
+          else xh[s] = to_h4(x1);
         } else {
           // (sum of dy0 * (z0 - mean0): the factor invstd0 of xhat0 is applied to the finished sums)
           const f32x4 w2 = zz - e2[ot];
@@ -682,11 +775,14 @@ __global__ void __launch_bounds__(256, APPLY ? 1 : X3_L1P1_OCC) att_l1_bwd_x3_ke
         }
       }
       if (APPLY) {
-        const bf16x8 ah = cat4(xh[0], xh[1]), al = cat4(xl[0], xl[1]);
+        const bf16x8 ah = cat4(xh[0], xh[1]);
+        if constexpr (NP > 1) {
+          const bf16x8 al = cat4(xl[0], xl[1]);
 #pragma unroll
-        for (int ct = 0; ct < NC; ++ct) HMFMA(accW[ot][ct], ah, bl[ct]);
+          for (int ct = 0; ct < NC; ++ct) HMFMA(accW[ot][ct], ah, bl[ct]);
 #pragma unroll
-        for (int ct = 0; ct < NC; ++ct) HMFMA(accW[ot][ct], al, bh[ct]);
+          for (int ct = 0; ct < NC; ++ct) HMFMA(accW[ot][ct], al, bh[ct]);
+        }
 #pragma unroll
         for (int ct = 0; ct < NC; ++ct) HMFMA(accW[ot][ct], ah, bh[ct]);
       }
@@ -787,7 +883,7 @@ extern "C" int clsr_att_l1_bwd_x3_supported(int C1, int C0) {
 // partial rows of pass 1 (stats) / partial chunks of pass 2 (dw1_partial): sized for the larger of the two
 extern "C" int clsr_att_l1_bwd_x3_parts(int M) { return l1x_grid(M, false); }
 
-template <int OT, int NC>
+template <int OT, int NC, int NP, typename ST>
 static int l1x_launch(const L1BwdArgsX& a, bool apply, hipStream_t stream) {
   constexpr int KC = (NC + 1) / 2, KCP = 32 * KC, WS = KCP + 8, NR = 16 * OT;
   size_t shmem = (size_t)2 * NR * WS * 2 + (size_t)5 * KCP * 4;
@@ -795,11 +891,11 @@ static int l1x_launch(const L1BwdArgsX& a, bool apply, hipStream_t stream) {
   if (shmem < red) shmem = red;
   dim3 grid(l1x_grid(a.M, apply));
   if (apply) {
-    auto kernel = att_l1_bwd_x3_kernel<OT, NC, true>;
+    auto kernel = att_l1_bwd_x3_kernel<OT, NC, true, NP, ST>;
     if (shmem > 64 * 1024) CLSR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL(kernel, grid, dim3(256), shmem, stream, a);
   } else {
-    auto kernel = att_l1_bwd_x3_kernel<OT, NC, false>;
+    auto kernel = att_l1_bwd_x3_kernel<OT, NC, false, NP, ST>;
     if (shmem > 64 * 1024) CLSR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL(kernel, grid, dim3(256), shmem, stream, a);
   }
@@ -808,17 +904,17 @@ static int l1x_launch(const L1BwdArgsX& a, bool apply, hipStream_t stream) {
 }
 
 // coef0 == NULL: pass 1 (stats);  coef0 given: pass 2 (dz0 + the partial chunks of dW1 / db1)
-extern "C" int clsr_att_l1_bwd_x3(const float* z1, int ldz1, const float* ds, const float* scale1, const float* shift1,
-                                  const float* w_out, const float* coef1, const float* Wt, int Kp, const float* z0,
-                                  int ldz0, const float* scale0, const float* shift0, const float* mean0,
-                                  const float* invstd0, const float* coef0, float* dz0, int lddz0, float* dw1_partial,
-                                  double* stats, int M, int C1, int C0, void* stream) {
+static int att_l1_bwd_x3_any(const void* z1, bool half, int ldz1, const float* ds, const float* scale1, const float* shift1,
+                             const float* w_out, const float* coef1, const float* Wt, int Kp, const void* z0,
+                             int ldz0, const float* scale0, const float* shift0, const float* mean0,
+                             const float* invstd0, const float* coef0, void* dz0, int lddz0, float* dw1_partial,
+                             double* stats, int M, int C1, int C0, void* stream) {
   CLSR_CHECK_ARG(z1 && ds && scale1 && shift1 && w_out && coef1 && Wt && z0 && scale0 && shift0 && M > 0);
   CLSR_CHECK_SUPPORTED(clsr_att_l1_bwd_x3_supported(C1, C0));
   CLSR_CHECK_ARG(coef0 ? (dz0 && lddz0 >= C0 && dw1_partial) : (mean0 && invstd0 && stats));
   CLSR_CHECK_ARG(ldz1 >= C1 && ldz0 >= C0 && Kp >= 16 * clsr_cdiv(C1, 16));
-  CLSR_CHECK_SUPPORTED(ldz1 % 4 == 0 && Kp % 4 == 0 && ((uintptr_t)z1 % 16) == 0 && ((uintptr_t)Wt % 16) == 0 &&
-                       ((uintptr_t)z0 % 4) == 0);
+  CLSR_CHECK_SUPPORTED(ldz1 % (half ? 8 : 4) == 0 && Kp % 4 == 0 && ((uintptr_t)z1 % 16) == 0 && ((uintptr_t)Wt % 16) == 0 &&
+                       ((uintptr_t)z0 % 4) == 0 && (!coef0 || ((uintptr_t)dz0 % 4) == 0));
   // 32-bit byte offsets into z0 / dz0 (raw buffer accesses; bit 31 marks a lane that must not touch memory)
   CLSR_CHECK_SUPPORTED(((long)M * ldz0 + 80) * 4 < 0x7fffffffL && (!coef0 || ((long)M * lddz0 + 80) * 4 < 0x7fffffffL));
   L1BwdArgsX a = {};
@@ -830,8 +926,27 @@ extern "C" int clsr_att_l1_bwd_x3(const float* z1, int ldz1, const float* ds, co
   else { a.ev[2] = mean0; a.ev[3] = invstd0; }
   hipStream_t s = (hipStream_t)stream;
   const int ot = x3_tiles_class(C0), nc = C1 <= 32 ? 2 : 3;
-#define L1X_GO(O, N) if (ot == O && nc == N) return l1x_launch<O, N>(a, apply, s)
+#define L1X_GO(O, N) \
+  if (ot == O && nc == N) return half ? l1x_launch<O, N, 1, __bf16>(a, apply, s) : l1x_launch<O, N, 2, float>(a, apply, s)
   L1X_GO(3, 2); L1X_GO(3, 3); L1X_GO(5, 2); L1X_GO(5, 3);
 #undef L1X_GO
   return CLSR_OK;
+}
+
+extern "C" int clsr_att_l1_bwd_x3(const float* z1, int ldz1, const float* ds, const float* scale1, const float* shift1,
+                                  const float* w_out, const float* coef1, const float* Wt, int Kp, const float* z0,
+                                  int ldz0, const float* scale0, const float* shift0, const float* mean0,
+                                  const float* invstd0, const float* coef0, float* dz0, int lddz0, float* dw1_partial,
+                                  double* stats, int M, int C1, int C0, void* stream) {
+  return att_l1_bwd_x3_any(z1, false, ldz1, ds, scale1, shift1, w_out, coef1, Wt, Kp, z0, ldz0, scale0, shift0, mean0,
+                           invstd0, coef0, dz0, lddz0, dw1_partial, stats, M, C1, C0, stream);
+}
+// speed mode: z1 / z0 / dz0 stored as bf16 (uint16 bit patterns), ONE bf16 piece per operand
+extern "C" int clsr_att_l1_bwd_x1_h(const void* z1, int ldz1, const float* ds, const float* scale1, const float* shift1,
+                                    const float* w_out, const float* coef1, const float* Wt, int Kp, const void* z0,
+                                    int ldz0, const float* scale0, const float* shift0, const float* mean0,
+                                    const float* invstd0, const float* coef0, void* dz0, int lddz0, float* dw1_partial,
+                                    double* stats, int M, int C1, int C0, void* stream) {
+  return att_l1_bwd_x3_any(z1, true, ldz1, ds, scale1, shift1, w_out, coef1, Wt, Kp, z0, ldz0, scale0, shift0, mean0,
+                           invstd0, coef0, dz0, lddz0, dw1_partial, stats, M, C1, C0, stream);
 }

@@ -24,7 +24,7 @@ struct AttL0FwdArgs {
   const float* Wt; int Kp;      // packed Wp (clsr_pack_batch): row n = out feature, K = Q
   const float* U; int ldu;      // [Hn*T, A0]
   const float* V; int ldv;      // [R, A0]
-  float* z0; int ldz;           // [R*T, A0]
+  void* z0; int ldz;            // [R*T, A0] float, or __bf16 (the kernel's ST: the speed mode's storage)
   double* stats;                // [gridDim.x][2][A0] per-block partial sums, or NULL
   long Hn;
   int G, T, Q, A0;
@@ -37,9 +37,20 @@ struct AttL0FwdArgs {
 // K = 32 chunk c takes the two 16-wide chunks 2c, 2c + 1 of the fp32 kernel side by side (k slot (g4, e) = feature
 // 32c + 16 (e >> 2) + 4 g4 + (e & 3): the loads of the A operand are the same float4 pairs), the bf16 hi / lo images of the
 // weights are laid out in LDS in that slot order.
-template <int NZ, int NK, int NP>      // NP = 0: fp32-input MFMAs; 2 / 3: bf16 pieces per operand (x3 / x6 products)
+// store one 16-position tile row piece: 4 floats, or 8 values rounded to bf16 (16 bytes either way)
+template <typename ST> __device__ __forceinline__ void af_store_piece(ST* dst, const float* src);
+template <> __device__ __forceinline__ void af_store_piece<float>(float* dst, const float* src) {
+  __builtin_nontemporal_store(ld4(src), reinterpret_cast<f32x4*>(dst));
+}
+template <> __device__ __forceinline__ void af_store_piece<__bf16>(__bf16* dst, const float* src) {
+  __builtin_nontemporal_store(to_h(ld8f(src)), reinterpret_cast<bf16x8*>(dst));
+}
+
+template <int NZ, int NK, int NP, typename ST>      // NP = 0: fp32-input MFMAs; 1 / 2 / 3: bf16 pieces per operand (speed mode / x3 / x6 products)
 __global__ void __launch_bounds__(256, 2) att_l0_fwd_kernel(AttL0FwdArgs s) {
   CLSR_CHAIN_PRIO();
+  constexpr int PW = sizeof(ST) == 2 ? 8 : 4;      // values per 16-byte store piece
+  ST* z0p = reinterpret_cast<ST*>(s.z0);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int ZP = 16 * NZ, QP = 16 * NK;
   constexpr int NC = (NK + 1) / 2, WS = 32 * NC + 8;      // X3: K = 32 chunks, bf16 row stride (conflict-free 16-byte reads)
@@ -247,14 +258,14 @@ __global__ void __launch_bounds__(256, 2) att_l0_fwd_kernel(AttL0FwdArgs s) {
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        float* zrow = s.z0 + ((h * G + g) * T + t0) * s.ldz;
-        constexpr int C4 = ZP / 4;
+        ST* zrow = z0p + ((h * G + g) * T + t0) * s.ldz;
+        constexpr int C4 = ZP / PW;
 #pragma unroll
         for (int i = 0; i < (16 * C4 + 63) / 64; ++i) {
           const int idx = lane + 64 * i;
           const int row = idx / C4, c4 = idx - row * C4;
-          if (idx < 16 * C4 && t0 + row < T && 4 * c4 < s.A0)
-            __builtin_nontemporal_store(ld4(tb + row * TS + 4 * c4), reinterpret_cast<f32x4*>(zrow + (long)row * s.ldz + 4 * c4));
+          if (idx < 16 * C4 && t0 + row < T && PW * c4 < s.A0)
+            af_store_piece<ST>(zrow + (long)row * s.ldz + PW * c4, tb + row * TS + PW * c4);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -293,15 +304,14 @@ __global__ void __launch_bounds__(256, 2) att_l0_fwd_kernel(AttL0FwdArgs s) {
         }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
-      constexpr int C4t = ZP / 4;
+      constexpr int C4t = ZP / PW;
 #pragma unroll
       for (int i = 0; i < (16 * C4t + 63) / 64; ++i) {
         const int idx = lane + 64 * i;
         const int row = idx / C4t, c4 = idx - row * C4t;
-        if (idx < 16 * C4t && row < np && 4 * c4 < s.A0) {
+        if (idx < 16 * C4t && row < np && PW * c4 < s.A0) {
           const int gr = row / rem, tr = T0 + row - gr * rem;
-          __builtin_nontemporal_store(ld4(tb + row * TS + 4 * c4),
-                                      reinterpret_cast<f32x4*>(s.z0 + ((h * G + gr) * T + tr) * s.ldz + 4 * c4));
+          af_store_piece<ST>(z0p + ((h * G + gr) * T + tr) * s.ldz + PW * c4, tb + row * TS + PW * c4);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -350,12 +360,12 @@ extern "C" int clsr_att_l0_fwd_supported(int G, int Q, int A0) {
 // number of per-block partial rows the statistics buffer receives: [parts][2][A0] doubles
 extern "C" int clsr_att_l0_fwd_stats_parts(long Hn) { return af_grid(Hn); }
 
-template <int NZ, int NK, int NP>
+template <int NZ, int NK, int NP, typename ST = float>
 static int att_l0_fwd_launch(const AttL0FwdArgs& a, hipStream_t stream) {
   constexpr int WS = 32 * ((NK + 1) / 2) + 8;
   size_t shmem = (NP ? (size_t)NP * 16 * NZ * WS * 2 : (size_t)16 * NZ * a.Kp * 4) + (size_t)4 * AF_GMAX * (16 * NK + 16 * NZ) * 4 +
                  (size_t)4 * 2 * 16 * NZ * 8 + (size_t)4 * 16 * (16 * NZ + 4) * 4;
-  auto kernel = att_l0_fwd_kernel<NZ, NK, NP>;
+  auto kernel = att_l0_fwd_kernel<NZ, NK, NP, ST>;
   if (shmem > 64 * 1024)
     CLSR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   hipLaunchKernelGGL(kernel, dim3(af_grid(a.Hn)), dim3(256), shmem, stream, a);
@@ -364,13 +374,13 @@ static int att_l0_fwd_launch(const AttL0FwdArgs& a, hipStream_t stream) {
 }
 
 static int att_l0_fwd_any(const float* a, int lda, const float* q, int ldq, const float* Wt, int Kp,
-                          const float* U, int ldu, const float* V, int ldv, float* z0, int ldz, double* stats,
+                          const float* U, int ldu, const float* V, int ldv, void* z0, int ldz, double* stats,
                           long Hn, int G, int T, int Q, int A0, int pieces, void* stream) {
   CLSR_CHECK_ARG(a && q && Wt && U && V && z0 && Hn > 0 && T > 0);
   CLSR_CHECK_SUPPORTED(clsr_att_l0_fwd_supported(G, Q, A0));
   CLSR_CHECK_SUPPORTED(lda % 4 == 0 && Kp % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)Wt % 16) == 0);
   CLSR_CHECK_ARG(lda >= Q && ldq >= Q && Kp >= 16 * clsr_cdiv(Q, 16) && ldu >= A0 && ldv >= A0 && ldz >= A0);
-  CLSR_CHECK_SUPPORTED(ldz % 4 == 0 && ((uintptr_t)z0 % 16) == 0);
+  CLSR_CHECK_SUPPORTED(ldz % (pieces == 1 ? 8 : 4) == 0 && ((uintptr_t)z0 % 16) == 0 && (pieces != 1 || A0 % 8 == 0));
   AttL0FwdArgs s = {};
   s.a = a; s.lda = lda; s.q = q; s.ldq = ldq; s.Wt = Wt; s.Kp = Kp; s.U = U; s.ldu = ldu; s.V = V; s.ldv = ldv;
   s.z0 = z0; s.ldz = ldz; s.stats = stats; s.Hn = Hn; s.G = G; s.T = T; s.Q = Q; s.A0 = A0;
@@ -378,7 +388,8 @@ static int att_l0_fwd_any(const float* a, int lda, const float* q, int ldq, cons
   const int nz = af_class(A0), nk = af_class(Q);
 #define AF_GO(Z, K) \
   if (nz == Z && nk == K) \
-    return pieces == 3 ? att_l0_fwd_launch<Z, K, 3>(s, st) : pieces == 2 ? att_l0_fwd_launch<Z, K, 2>(s, st) : att_l0_fwd_launch<Z, K, 0>(s, st)
+    return pieces == 3 ? att_l0_fwd_launch<Z, K, 3>(s, st) : pieces == 2 ? att_l0_fwd_launch<Z, K, 2>(s, st) \
+         : pieces == 1 ? att_l0_fwd_launch<Z, K, 1, __bf16>(s, st) : att_l0_fwd_launch<Z, K, 0>(s, st)
   AF_GO(3, 3); AF_GO(3, 5); AF_GO(5, 3); AF_GO(5, 5);
 #undef AF_GO
   return CLSR_OK;
@@ -401,4 +412,11 @@ extern "C" int clsr_att_l0_fwd_x6(const float* a, int lda, const float* q, int l
                                   const float* U, int ldu, const float* V, int ldv, float* z0, int ldz, double* stats,
                                   long Hn, int G, int T, int Q, int A0, void* stream) {
   return att_l0_fwd_any(a, lda, q, ldq, Wt, Kp, U, ldu, V, ldv, z0, ldz, stats, Hn, G, T, Q, A0, 3, stream);
+}
+// speed mode: ONE bf16 piece per operand (fp32 accumulation from U + V), z0 stored as bf16 (uint16 bit patterns, A0 % 8 == 0);
+// the batch-norm sums are taken from the fp32 accumulators
+extern "C" int clsr_att_l0_fwd_x1_h(const float* a, int lda, const float* q, int ldq, const float* Wt, int Kp,
+                                    const float* U, int ldu, const float* V, int ldv, void* z0, int ldz, double* stats,
+                                    long Hn, int G, int T, int Q, int A0, void* stream) {
+  return att_l0_fwd_any(a, lda, q, ldq, Wt, Kp, U, ldu, V, ldv, z0, ldz, stats, Hn, G, T, Q, A0, 1, stream);
 }

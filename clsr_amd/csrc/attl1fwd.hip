@@ -12,21 +12,38 @@
 #include "hmma.h"
 
 struct L1FwdArgs {
-  const float* z0; int ldz0;
+  const void* z0; int ldz0;       // z0 / z1: float, or __bf16 (the kernel's ST: the speed mode's storage)
   const float* scale0; const float* shift0;
   const float* Wt; int Kp;        // packed W1 (clsr_pack_batch): row n = z1 feature (C1 rows), K = C0
   const float* bias;
-  float* z1; int ldz1;
+  void* z1; int ldz1;
   double* stats;                  // [gridDim.x][2][C1] per-block partial sums (NULL: none)
   int M, C0, C1;
 };
 
 typedef __amdgpu_buffer_rsrc_t l1f_rsrc_t;
 
-// NKC = 32-wide chunks of C0, NT = 16-feature tiles of C1, NP = bf16 pieces per operand
-template <int NKC, int NT, int NP>
+template <typename ST> struct L1fRaw;
+template <> struct L1fRaw<float> { f32x8 v; };
+template <> struct L1fRaw<__bf16> { bf16x8 v; };
+__device__ __forceinline__ f32x8 l1f_f8(const L1fRaw<float>& r) { return r.v; }
+__device__ __forceinline__ f32x8 l1f_f8(const L1fRaw<__bf16>& r) { return to_f(r.v); }
+__device__ __forceinline__ L1fRaw<float> l1f_ld(const float* p) { L1fRaw<float> r; r.v = ld8f(p); return r; }
+__device__ __forceinline__ L1fRaw<__bf16> l1f_ld(const __bf16* p) { L1fRaw<__bf16> r; r.v = ld8h(p); return r; }
+__device__ __forceinline__ void l1f_st(float, l1f_rsrc_t rs, unsigned off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, off, 0, 0);
+}
+__device__ __forceinline__ void l1f_st(__bf16, l1f_rsrc_t rs, unsigned off, float v) {
+  const __bf16 h = (__bf16)v;
+  __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), rs, off, 0, 0);
+}
+
+// NKC = 32-wide chunks of C0, NT = 16-feature tiles of C1, NP = bf16 pieces per operand (3: parity mode; 1: speed mode)
+template <int NKC, int NT, int NP, typename ST>
 __global__ void __launch_bounds__(256, 2) att_l1_fwd_kernel(L1FwdArgs a) {
   CLSR_CHAIN_PRIO();
+  constexpr unsigned SB = sizeof(ST);
+  const ST* z0p = reinterpret_cast<const ST*>(a.z0);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int KCP = 32 * NKC, WS = KCP + 8, NR = 16 * NT;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -60,10 +77,10 @@ __global__ void __launch_bounds__(256, 2) att_l1_fwd_kernel(L1FwdArgs a) {
   for (int n = 0; n < NT; ++n) {
     const bool ok = 16 * n + j < a.C1;
     bias[n] = ok ? a.bias[16 * n + j] : 0.f;
-    co[n] = ok ? (16 * n + j) * 4u : SKIP;
+    co[n] = ok ? (16 * n + j) * SB : SKIP;
   }
   const int wrow = j * WS + 8 * g;
-  const l1f_rsrc_t rz1 = __builtin_amdgcn_make_buffer_rsrc(a.z1, 0, (unsigned)a.M * (unsigned)a.ldz1 * 4u, 0x00020000);
+  const l1f_rsrc_t rz1 = __builtin_amdgcn_make_buffer_rsrc(a.z1, 0, (unsigned)a.M * (unsigned)a.ldz1 * SB, 0x00020000);
   float s1[NT], s2[NT];
   double d1[NT], d2[NT];
 #pragma unroll
@@ -73,7 +90,7 @@ __global__ void __launch_bounds__(256, 2) att_l1_fwd_kernel(L1FwdArgs a) {
   const int ntiles = (a.M + 31) >> 5;
   const int tstride = gridDim.x * 4;
   int tile = blockIdx.x * 4 + wave;
-  struct Raw { f32x8 x[2][NKC]; };
+  struct Raw { L1fRaw<ST> x[2][NKC]; };
   auto fetch = [&](int t) -> Raw {
     Raw r;
 #pragma unroll
@@ -83,7 +100,7 @@ __global__ void __launch_bounds__(256, 2) att_l1_fwd_kernel(L1FwdArgs a) {
 #pragma unroll
       for (int c = 0; c < NKC; ++c) {
         const int k0 = 32 * c + 8 * g;
-        r.x[s][c] = ld8f(a.z0 + mr * a.ldz0 + (k0 < a.C0 ? k0 : 0));
+        r.x[s][c] = l1f_ld(z0p + mr * a.ldz0 + (k0 < a.C0 ? k0 : 0));
       }
     }
     return r;
@@ -106,7 +123,7 @@ __global__ void __launch_bounds__(256, 2) att_l1_fwd_kernel(L1FwdArgs a) {
       bf16x8 xp[2][NP];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        f32x8 y = cur.x[s][c] * sc + sh;
+        f32x8 y = l1f_f8(cur.x[s][c]) * sc + sh;
 #pragma unroll
         for (int e = 0; e < 8; ++e) y[e] = fmaxf(y[e], 0.f);
         if (m0 + 16 * s + j >= a.M) y = z8;
@@ -137,11 +154,11 @@ __global__ void __launch_bounds__(256, 2) att_l1_fwd_kernel(L1FwdArgs a) {
       for (int e = 0; e < 4; ++e) {
         const int p = m0 + 16 * s + 4 * g + e;
         const bool pv = p < a.M;
-        const unsigned ro = pv ? (unsigned)p * (unsigned)a.ldz1 * 4u : SKIP;
+        const unsigned ro = pv ? (unsigned)p * (unsigned)a.ldz1 * SB : SKIP;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const float v = acc[s][n][e];
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rz1, ro + co[n], 0, 0);
+          l1f_st(ST(), rz1, ro + co[n], v);
           const float vv = pv ? v : 0.f;
           s1[n] += vv;
           s2[n] = fmaf(vv, vv, s2[n]);
@@ -187,33 +204,43 @@ extern "C" int clsr_att_l1_fwd_supported(int C0, int C1) {
 }
 extern "C" int clsr_att_l1_fwd_stats_parts(int M) { return l1f_grid(M); }
 
-template <int NKC, int NT>
+template <int NKC, int NT, int NP, typename ST>
 static int l1f_launch(const L1FwdArgs& a, hipStream_t stream) {
-  constexpr int NP = 3, WS = 32 * NKC + 8, NR = 16 * NT;
+  constexpr int WS = 32 * NKC + 8, NR = 16 * NT;
   size_t shmem = (size_t)NP * NR * WS * 2 + (size_t)2 * 32 * NKC * 4;
   const size_t red = (size_t)16 * 2 * NR * 8;
   if (shmem < red) shmem = red;
-  auto kernel = att_l1_fwd_kernel<NKC, NT, NP>;
+  auto kernel = att_l1_fwd_kernel<NKC, NT, NP, ST>;
   if (shmem > 64 * 1024) CLSR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   hipLaunchKernelGGL(kernel, dim3(l1f_grid(a.M)), dim3(256), shmem, stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
 
-extern "C" int clsr_att_l1_fwd(const float* z0, int ldz0, const float* scale0, const float* shift0, const float* Wt, int Kp,
-                               const float* bias, float* z1, int ldz1, double* stats, int M, int C0, int C1, void* stream) {
+static int att_l1_fwd_any(const void* z0, bool half, int ldz0, const float* scale0, const float* shift0, const float* Wt, int Kp,
+                          const float* bias, void* z1, int ldz1, double* stats, int M, int C0, int C1, void* stream) {
   CLSR_CHECK_ARG(z0 && scale0 && shift0 && Wt && bias && z1 && M > 0);
   CLSR_CHECK_SUPPORTED(clsr_att_l1_fwd_supported(C0, C1));
   CLSR_CHECK_ARG(ldz0 >= C0 && ldz1 >= C1 && Kp >= 16 * clsr_cdiv(C0, 16));
-  CLSR_CHECK_SUPPORTED(ldz0 % 4 == 0 && Kp % 4 == 0 && ((uintptr_t)z0 % 16) == 0 && ((uintptr_t)Wt % 16) == 0 &&
+  CLSR_CHECK_SUPPORTED(ldz0 % (half ? 8 : 4) == 0 && Kp % 4 == 0 && ((uintptr_t)z0 % 16) == 0 && ((uintptr_t)Wt % 16) == 0 &&
                        ((uintptr_t)z1 % 4) == 0 && ((long)M * ldz1) * 4 < 0x40000000L);
   L1FwdArgs a = {};
   a.z0 = z0; a.ldz0 = ldz0; a.scale0 = scale0; a.shift0 = shift0; a.Wt = Wt; a.Kp = Kp; a.bias = bias; a.z1 = z1;
   a.ldz1 = ldz1; a.stats = stats; a.M = M; a.C0 = C0; a.C1 = C1;
   hipStream_t s = (hipStream_t)stream;
   const int nkc = clsr_cdiv(C0, 32), nt = C1 <= 32 ? 2 : 3;
-#define L1F_GO(K, N) if (nkc == K && nt == N) return l1f_launch<K, N>(a, s)
+#define L1F_GO(K, N) if (nkc == K && nt == N) return half ? l1f_launch<K, N, 1, __bf16>(a, s) : l1f_launch<K, N, 3, float>(a, s)
   L1F_GO(1, 2); L1F_GO(1, 3); L1F_GO(2, 2); L1F_GO(2, 3); L1F_GO(3, 2); L1F_GO(3, 3);
 #undef L1F_GO
   return CLSR_OK;
+}
+
+extern "C" int clsr_att_l1_fwd(const float* z0, int ldz0, const float* scale0, const float* shift0, const float* Wt, int Kp,
+                               const float* bias, float* z1, int ldz1, double* stats, int M, int C0, int C1, void* stream) {
+  return att_l1_fwd_any(z0, false, ldz0, scale0, shift0, Wt, Kp, bias, z1, ldz1, stats, M, C0, C1, stream);
+}
+// speed mode: z0 / z1 stored as bf16 (uint16 bit patterns), ONE bf16 piece per operand; batch-norm sums from the fp32 accumulators
+extern "C" int clsr_att_l1_fwd_x1_h(const void* z0, int ldz0, const float* scale0, const float* shift0, const float* Wt, int Kp,
+                                    const float* bias, void* z1, int ldz1, double* stats, int M, int C0, int C1, void* stream) {
+  return att_l1_fwd_any(z0, true, ldz0, scale0, shift0, Wt, Kp, bias, z1, ldz1, stats, M, C0, C1, stream);
 }

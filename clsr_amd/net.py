@@ -134,6 +134,11 @@ class CLSRNet(object):
         self.att_l0_fwd_entry = ("clsr_att_l0_fwd_x3" if self.att_fwd_x3 else
                                  "clsr_att_l0_fwd_x6" if self.att_fwd_x6 else "clsr_att_l0_fwd")
         self.att_hist_pieces = int(os.environ.get("CLSR_ATT_HIST_PIECES", "3"))  # A/B: first attention layer, forward (csrc/attl0fwd.hip)
+        # speed mode, round 5b: the (row, step)-level attention layers on the SAME chain kernels as the parity mode
+        # (csrc/attl0fwd.hip, attl1fwd.hip, attbwdx3.hip) with ONE bf16 piece per operand and bf16 storage of z0 / z1 / dz0:
+        # the weight gradients dW1 / db1 / dWp ride inside the backward kernels (no clsr_hdw launches over z0 / dz1 / dz0,
+        # no stored dz1).  CLSR_BF16_CHAIN=old: the position-tiled csrc/hgemm.hip kernels of rounds 2-4.
+        self.bf16_chain = self.precision == "bf16" and os.environ.get("CLSR_BF16_CHAIN", "x1") == "x1"
         self.bf16_dw = not os.environ.get("CLSR_NO_HDW")        # A/B switch: weight gradients on the bf16 matrix pipe
         self.bf16_bwd = not os.environ.get("CLSR_NO_HBWD")      # A/B switch: back-propagating products likewise
         self._cur_descs_h = []
@@ -1239,6 +1244,21 @@ class CLSRNet(object):
                            addV=self._buf("att.zeroV", Hn, A0), ldv=A0)
             # (split query: only the target columns stay in the per-(row, step) product, K = Q - qh)
             Qe, ae, qe = Q - qh, (a[:, qh:] if qh else a), (q[:, qh:] if qh else q)
+            if self._bf16_chain_ok(G, Qe):
+                # the parity mode's chain kernels with one bf16 piece per operand, z0 / z1 stored as bf16
+                Wt, Kp = self.packed[key + (".Wp2" if qh else ".Wp")]
+                p0 = query("clsr_att_l0_fwd_stats_parts", Hn) if training else 0
+                call("clsr_att_l0_fwd_x1_h", ae, Q, qe, Q, Wt, Kp, U, A0, V, A0, z0, A0,
+                     sbuf[: p0 * 2 * A0] if training else None, Hn, G, T, Qe, A0)
+                self._bn_fwd(bn0, sbuf[: p0 * 2 * A0] if training else None, p0, M, training)
+                p1 = query("clsr_att_l1_fwd_stats_parts", M) if training else 0
+                st = sbuf[: p1 * 2 * A1] if training else None
+                Wt, Kp = self.packed[key + ".W1"]
+                call("clsr_att_l1_fwd_x1_h", z0, A0, bn0.scale, bn0.shift, Wt, Kp, P[nn + "b_nn_layer1"], z1, A1, st, M, A0, A1)
+                self._bn_fwd(bn1, st, p1, M, training)
+                call("clsr_att_out_fwd_h", z1, bn1.scale, bn1.shift, P[nn + "w_nn_output"], P[nn + "b_nn_output"],
+                     seq_len, len_stride, keys, Hn, G, T, A1, Dk, wts, out)
+                return out
             Wt, Kp = self.packed_h[key + (".Wp2" if qh else ".Wp")]
             if self.l0_fwd_wave and query("clsr_hgemm_l0_group_supported", G, Qe, A0):
                 # one wave per history group: a / U loaded once per 16 steps and re-used for the G rows
@@ -1345,6 +1365,9 @@ class CLSRNet(object):
             # second layer; TWO passes over (z1, z0): the batch-norm sums of layer 0, then the finished dz0 (+ dz1 for the
             # weight gradient) -- no separate dy1-apply / bn-apply sweeps (csrc/hgemm.hip: clsr_hgemm_att_l1_bwd)
             M = R * T
+            if self._bf16_chain_ok(G, Q - qh):
+                return self._att_bwd_chain_h(key, scope, nn, bn0, bn1, a, q, keys, dkeys, z0, z1, dz0, ds, da, dq, dV, dW0,
+                                             Hn, G, R, T, Dk, Q, qh, q_hist, dq_hist)
             Wt, Kp = self.packed_h[key + ".W1^T"]
             parts = query("clsr_hgemm_stats_parts", M)
             st = self._buf("stats" + self._ws_tag, 1024 * 2 * 256, dtype=torch.float64)[: parts * 2 * A0]
@@ -1475,6 +1498,47 @@ class CLSRNet(object):
                 self._gemm(dz0, A0, key + ".Wp^T", R * T, A0, Q, daq, Q)
                 call("clsr_att_prod_bwd", daq, a, q, Hn, G, T, Q, da, dq)
                 call("clsr_att_z0_bwd_reduce", dz0, Hn, G, T, A0, None if G == 1 else dU, dV)
+        return self._att_bwd_hist(key, scope, nn, a, q, keys, dkeys, dU, dV, da, dq, dW0, Hn, R, T, Dk, Q, qh,
+                                  q_hist=q_hist, dq_hist=dq_hist)
+
+    def _bf16_chain_ok(self, G, Qe):
+        """speed mode on the parity mode's chain kernels (one bf16 piece per operand, bf16 z0 / z1 / dz0)?"""
+        A0, A1 = self.A0, self.A1
+        return bool(self.bf16_chain and A0 % 8 == 0 and A1 % 8 == 0 and self.l0_fwd_wave and self.fused_l0_bwd
+                    and query("clsr_att_l0_fwd_supported", G, Qe, A0) and query("clsr_att_l1_fwd_supported", A0, A1)
+                    and query("clsr_att_l1_bwd_x3_supported", A1, A0) and query("clsr_att_l0_bwd_x3_supported", G, Qe, A0))
+
+    def _att_bwd_chain_h(self, key, scope, nn, bn0, bn1, a, q, keys, dkeys, z0, z1, dz0, ds, da, dq, dV, dW0, Hn, G, R, T,
+                         Dk, Q, qh, q_hist, dq_hist):
+        """Speed-mode tail of ``_att_bwd`` behind the BN-1 coefficients: two passes over (z1, z0) -- the second one writes
+        dz0 (bf16) and the partial chunks of dW1 / db1 --, then ONE pass over dz0 for da, dq, dU, dV and dWp
+        (csrc/attbwdx3.hip with NP = 1, ST = bf16)."""
+        P, Gd, A0, A1 = self.P, self.Gd, self.A0, self.A1
+        M = R * T
+        Wt, Kp = self.packed[key + ".W1^T"]
+        parts = query("clsr_att_l1_bwd_x3_parts", M)
+        st = self._buf("stats" + self._ws_tag, 1024 * 2 * 256, dtype=torch.float64)[: parts * 2 * A0]
+        wo = P[nn + "w_nn_output"]
+        call("clsr_att_l1_bwd_x1_h", z1, A1, ds, bn1.scale, bn1.shift, wo, bn1.coef, Wt, Kp, z0, A0, bn0.scale,
+             bn0.shift, bn0.mean, bn0.invstd, None, None, 0, None, st, M, A1, A0)
+        self._bn_bwd_coef(bn0, st, parts, M)
+        ws = self._buf(key + ".dw1x_ws", parts * query("clsr_dw_chunk_floats"))
+        call("clsr_att_l1_bwd_x1_h", z1, A1, ds, bn1.scale, bn1.shift, wo, bn1.coef, Wt, Kp, z0, A0, bn0.scale,
+             bn0.shift, None, None, bn0.coef, dz0, A0, ws, None, M, A1, A0)
+        self._dw_fused(ws, parts, A0, A1, Gd[nn + "w_nn_layer1"], A1, db=Gd[nn + "b_nn_layer1"])
+        Qe, ae, qe = Q - qh, (a[:, qh:] if qh else a), (q[:, qh:] if qh else q)
+        dU = self._buf(key + ".dU", Hn * T, A0)
+        Wt, Kp = self.packed[key + (".Wp2^T" if qh else ".Wp^T")]
+        parts = query("clsr_att_l0_bwd_x3_parts", Hn)
+        ws = self._buf(key + ".dwpx_ws", parts * query("clsr_dw_chunk_floats"))
+        call("clsr_att_l0_bwd_x1_h", dz0, A0, Wt, Kp, ae, Q, qe, Q, Hn, G, T, Qe, A0, da[:, qh:] if qh else da, Q,
+             dq[:, qh:] if qh else dq, Q, dU, A0, dV, A0, ws)
+        self._dw_fused(ws, parts, Qe, A0, dW0[3 * Q + qh:4 * Q], A0)
+        if qh:
+            # the V path over ALL query columns (dq[:, :qh] was cleared with the step's accumulators), the weight
+            # gradient of the history-level share of the product term; the rest of that share: _att_bwd_hist
+            self._gemm(dV, A0, key + ".Wv^T", R, A0, Q, dq, Q, acc=1)
+            self._dw(a, Q, dU, A0, Hn * T, qh, A0, dW0[3 * Q:3 * Q + qh], A0, T=T, G=1, Xmul=q_hist, ldmul=qh)
         return self._att_bwd_hist(key, scope, nn, a, q, keys, dkeys, dU, dV, da, dq, dW0, Hn, R, T, Dk, Q, qh,
                                   q_hist=q_hist, dq_hist=dq_hist)
 
@@ -2601,6 +2665,14 @@ class CLSRNet(object):
         flops = 2.0 * B * T * Qs * A0
         bf = self.precision == "bf16"
         peak = 2500.0 if bf else 157.3
+        if bf and self._bf16_chain_ok(G, Qs):
+            nbytes = float(B) * T * A0 * 2 + float(Hn) * T * (Qs + A0) * 4 + float(B) * (Qs + A0) * 4
+            return dict(bound="hbm", kernel="att_l0_fwd_kernel<5,5,1,bf16> (short-term attention layer 0, one wave per history, one "
+                                            "bf16 piece per operand, bf16 z0)",
+                        achieved=round(nbytes / t_mm / 1e9, 1), peak=8000.0, unit="GB/s", frac=round(nbytes / t_mm / 8e12, 4),
+                        bytes_per_launch=nbytes, us_per_launch=round(t_mm * 1e6, 2),
+                        formula="B*T*A0*2 (bf16 z0 written) + Hn*T*(Q + A0)*4 (a, U read) + B*(Q + A0)*4 (q, V read)",
+                        mfma_tflops=round(flops / t_mm / 1e12, 2))
         return dict(bound="mfma", kernel=(("hgemm_l0g_kernel (short-term attention layer 0, bf16 MFMA, one wave per history group)"
                                            if self.l0_fwd_wave and query("clsr_hgemm_l0_group_supported", G, Qs, A0) else
                                            "hgemm_kernel<MUL,UV> (short-term attention layer 0, bf16 MFMA)") if bf else
@@ -2643,6 +2715,9 @@ class CLSRNet(object):
         U, V = self._buf(key + ".U", Hn * T, A0), self._buf(key + ".V", R, A0)
         if self.bf16:
             z0 = self._buf(key + ".z0", R * T, A0, dtype=torch.bfloat16)
+            if self._bf16_chain_ok(G, Q):
+                Wt, Kp = self.packed[key + ".Wp"]
+                return lambda: call("clsr_att_l0_fwd_x1_h", a, Q, q, Q, Wt, Kp, U, A0, V, A0, z0, A0, None, Hn, G, T, Q, A0)
             Wt, Kp = self.packed_h[key + ".Wp"]
             if self.l0_fwd_wave and query("clsr_hgemm_l0_group_supported", G, Q, A0):
                 return lambda: call("clsr_hgemm_l0_group", a, Q, q, Q, Wt, Kp, U, A0, V, A0, z0, A0, None, Hn, G, T, Q, A0)

@@ -419,6 +419,27 @@ int clsr_att_l1_bwd_x3(const float* z1, int ldz1, const float* ds, const float* 
                        const float* scale0, const float* shift0, const float* mean0, const float* invstd0,
                        const float* coef0, float* dz0, int lddz0, float* dw1_partial, double* stats, int M, int C1,
                        int C0, void* stream);
+/* Speed mode (precision = "bf16") on the SAME chain kernels: the (row, step)-level tensors z0 / z1 / dz0 stored as bf16
+ * (uint16 bit patterns, row strides in elements, % 8 == 0), ONE bf16 piece per operand on v_mfma_f32_16x16x32_bf16 with fp32
+ * accumulation, batch-norm sums from the fp32 accumulators, the weight gradients dW1 / db1 / dWp folded in as in the x3
+ * forms (fp32 partial chunks).  Replace clsr_hgemm_l0_group / clsr_hgemm / clsr_hgemm_att_l1_bwd / clsr_att_l0_bwd_h and
+ * their separate clsr_hdw launches.  History- and row-level operands (a, q, U, V, da, dq, dU, dV), the packed weights
+ * (clsr_pack_batch, fp32) and every statistic stay fp32.  Same arguments / *_supported / *_parts as the x3 / x6 entries.
+ * (reference: clsr.py:343-381, base_model.py:627-708 -- at bf16 product precision) */
+int clsr_att_l0_fwd_x1_h(const float* a, int lda, const float* q, int ldq, const float* Wt, int Kp,
+                         const float* U, int ldu, const float* V, int ldv, void* z0, int ldz, double* stats,
+                         long Hn, int G, int T, int Q, int A0, void* stream);
+int clsr_att_l1_fwd_x1_h(const void* z0, int ldz0, const float* scale0, const float* shift0, const float* Wt, int Kp,
+                         const float* bias, void* z1, int ldz1, double* stats, int M, int C0, int C1, void* stream);
+int clsr_att_l1_bwd_x1_h(const void* z1, int ldz1, const float* ds, const float* scale1, const float* shift1,
+                         const float* w_out, const float* coef1, const float* Wt, int Kp, const void* z0, int ldz0,
+                         const float* scale0, const float* shift0, const float* mean0, const float* invstd0,
+                         const float* coef0, void* dz0, int lddz0, float* dw1_partial, double* stats, int M, int C1,
+                         int C0, void* stream);
+int clsr_att_l0_bwd_x1_h(const void* dz0, int lddz, const float* Wt, int Kp, const float* a, int lda,
+                         const float* q, int ldq, long Hn, int G, int T, int Q, int A0, float* da, int ldda,
+                         float* dq, int lddq, float* dU, int lddu, float* dV, int lddv, float* dwp_partial,
+                         void* stream);
 /* clsr_hgemm_mul_uv with one wave per history group (a, U read once per 16 steps of a history and re-used for its G
  * rows; same packed bf16 weights image, same statistics layout with clsr_hgemm_l0_group_stats_parts(Hn) partial rows) */
 int clsr_hgemm_l0_group_supported(int G, int Q, int A0);

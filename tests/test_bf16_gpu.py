@@ -467,3 +467,31 @@ def test_bf16_eval_scores_match_oracle(golden_dir, golden_hparams):
     got = net.forward(net.upload(feed, False), False)
     torch.cuda.synchronize()
     _close(torch.sigmoid(got["logit"]), exp["pred"], 0.0, 1e-3, "pred")
+
+
+def test_bf16_chain_kernels_agree_with_the_position_tiled_kernels(golden_dir, golden_hparams, monkeypatch):
+    """The speed mode runs its (row, step)-level attention layers on the parity mode's chain kernels with one bf16 piece per
+    operand (net.bf16_chain, csrc/attbwdx3.hip ...); CLSR_BF16_CHAIN=old keeps the position-tiled csrc/hgemm.hip kernels +
+    separate weight-gradient launches.  Same roundings at the same places: logits and every dense gradient agree at the
+    level of bf16 noise."""
+    from oracle import clsr_oracle as O
+
+    hp = copy.deepcopy(golden_hparams)
+    dims = _dims(hp)
+    params32 = O.init_params(dims, hp, seed=3, scale_dense=8.0)
+    feed = _feed(golden_dir, "iterator_train_sa.npz", b=0)
+    res = {}
+    for chain in ("x1", "old"):
+        monkeypatch.setenv("CLSR_BF16_CHAIN", chain)
+        net = _net(hp, dims, params32, O, "bf16")
+        assert net.bf16_chain == (chain == "x1")
+        net.capture_grads = True
+        got = net.train_step(net.upload(feed, True))
+        torch.cuda.synchronize()
+        res[chain] = (got["logit"].double().cpu(), {k: v.double().cpu() for k, v in net.captured["dense"].items()})
+    _close(res["x1"][0], res["old"][0], 0.0, 2e-4, "logit (chain kernels vs position-tiled kernels)")
+    top = max(float(v.abs().max()) for v in res["old"][1].values())
+    for k, v in res["old"][1].items():
+        scale = max(float(v.abs().max()), 1e-3 * top)
+        err = float((res["x1"][1][k] - v).abs().max())
+        assert err <= 3e-2 * scale, (k, err, scale)
