@@ -230,6 +230,12 @@ __global__ void __launch_bounds__(256, 2) att_l0_fwd_kernel(AttL0FwdArgs s) {
 #pragma unroll
         for (int z = 0; z < NZ; ++z) acc[z] = cur.u[z] + vs[g * ZP + 16 * z + j];
         mac(acc, x, woff);
+        if constexpr (sizeof(ST) == 2) {
+          // bf16 storage: the batch-norm statistics are those of the STORED values (what the next layer and the backward
+          // pass read back), as in csrc/hgemm.hip and in the oracle's bf16 emulation
+#pragma unroll
+          for (int z = 0; z < NZ; ++z) acc[z] = __builtin_convertvector(__builtin_convertvector(acc[z], bf16x4), f32x4);
+        }
         // the result tile goes through LDS once so that every position's A0 floats leave as consecutive 16-byte stores
         // (a lane holds 4 positions of one feature: stored directly that is 4 x NZ dword stores of 64-byte pieces)
 #pragma unroll
@@ -293,6 +299,10 @@ __global__ void __launch_bounds__(256, 2) att_l0_fwd_kernel(AttL0FwdArgs s) {
         for (int z = 0; z < NZ; ++z) acc[z][e] = up[ncl[z]] + vs[gp * ZP + 16 * z + j];
       }
       mac(acc, x, 0);
+      if constexpr (sizeof(ST) == 2) {
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) acc[z] = __builtin_convertvector(__builtin_convertvector(acc[z], bf16x4), f32x4);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -414,7 +424,7 @@ extern "C" int clsr_att_l0_fwd_x6(const float* a, int lda, const float* q, int l
   return att_l0_fwd_any(a, lda, q, ldq, Wt, Kp, U, ldu, V, ldv, z0, ldz, stats, Hn, G, T, Q, A0, 3, stream);
 }
 // speed mode: ONE bf16 piece per operand (fp32 accumulation from U + V), z0 stored as bf16 (uint16 bit patterns, A0 % 8 == 0);
-// the batch-norm sums are taken from the fp32 accumulators
+// the batch-norm sums are those of the stored (rounded) values
 extern "C" int clsr_att_l0_fwd_x1_h(const float* a, int lda, const float* q, int ldq, const float* Wt, int Kp,
                                     const float* U, int ldu, const float* V, int ldv, void* z0, int ldz, double* stats,
                                     long Hn, int G, int T, int Q, int A0, void* stream) {

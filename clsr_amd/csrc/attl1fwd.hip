@@ -157,7 +157,8 @@ __global__ void __launch_bounds__(256, 2) att_l1_fwd_kernel(L1FwdArgs a) {
         const unsigned ro = pv ? (unsigned)p * (unsigned)a.ldz1 * SB : SKIP;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-          const float v = acc[s][n][e];
+          float v = acc[s][n][e];
+          if constexpr (sizeof(ST) == 2) v = (float)(__bf16)v;      // (bf16 storage: statistics of the STORED values)
           l1f_st(ST(), rz1, ro + co[n], v);
           const float vv = pv ? v : 0.f;
           s1[n] += vv;
@@ -239,7 +240,7 @@ extern "C" int clsr_att_l1_fwd(const float* z0, int ldz0, const float* scale0, c
                                const float* bias, float* z1, int ldz1, double* stats, int M, int C0, int C1, void* stream) {
   return att_l1_fwd_any(z0, false, ldz0, scale0, shift0, Wt, Kp, bias, z1, ldz1, stats, M, C0, C1, stream);
 }
-// speed mode: z0 / z1 stored as bf16 (uint16 bit patterns), ONE bf16 piece per operand; batch-norm sums from the fp32 accumulators
+// speed mode: z0 / z1 stored as bf16 (uint16 bit patterns), ONE bf16 piece per operand; batch-norm sums of the stored (rounded) values
 extern "C" int clsr_att_l1_fwd_x1_h(const void* z0, int ldz0, const float* scale0, const float* shift0, const float* Wt, int Kp,
                                     const float* bias, void* z1, int ldz1, double* stats, int M, int C0, int C1, void* stream) {
   return att_l1_fwd_any(z0, true, ldz0, scale0, shift0, Wt, Kp, bias, z1, ldz1, stats, M, C0, C1, stream);

@@ -27,12 +27,16 @@ __global__ void __launch_bounds__(256, 2) proj_x3_kernel(ProjArgs a) {
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int j = lane & 15, g = lane >> 4;
   __bf16* Wi = reinterpret_cast<__bf16*>(lds_raw);          // [NP][NR][WS]
+  // wide outputs (the fused input projection of 128-wide encoders, N = 1 536): blockIdx.y owns a block of NR output
+  // columns; X is re-read per block (L2 / Infinity Cache: 105 MB at configs[4]), every block writes its own columns
+  const int n0 = blockIdx.y * NR;
+  const int Nb = a.N - n0 < NR ? a.N - n0 : NR;
   {
     constexpr int C8 = WS / 8;
     for (int e = tid; e < NR * C8; e += 256) {
       const int row = e / C8, k = 8 * (e - row * C8);
       f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (row < a.N && k < a.K) v = ld8f(a.Wt + (long)row * a.Kp + k);            // (K % 8 == 0)
+      if (row < Nb && k < a.K) v = ld8f(a.Wt + (long)(n0 + row) * a.Kp + k);     // (K % 8 == 0)
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
         const bf16x8 h = to_h(v);
@@ -47,9 +51,9 @@ __global__ void __launch_bounds__(256, 2) proj_x3_kernel(ProjArgs a) {
   constexpr unsigned SKIP = 0x40000000u;      // (out of range alone and in the sum of two: the resource spans exactly Y)
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    const bool ok = 16 * n + j < a.N;
-    bias[n] = (ok && a.bias) ? a.bias[16 * n + j] : 0.f;
-    co[n] = ok ? (16 * n + j) * 4u : SKIP;
+    const bool ok = 16 * n + j < Nb;
+    bias[n] = (ok && a.bias) ? a.bias[n0 + 16 * n + j] : 0.f;
+    co[n] = ok ? (n0 + 16 * n + j) * 4u : SKIP;
   }
   const int wrow = j * WS + 8 * g;
   const __amdgpu_buffer_rsrc_t ry =
@@ -116,7 +120,7 @@ __global__ void __launch_bounds__(256, 2) proj_x3_kernel(ProjArgs a) {
 }
 
 extern "C" int clsr_proj_x3_supported(int M, int K, int N) {
-  return M > 0 && K >= 8 && K <= 128 && K % 8 == 0 && N >= 4 && N <= 128 && N % 4 == 0;
+  return M > 0 && K >= 8 && K <= 128 && K % 8 == 0 && N >= 4 && N <= 128 * 64 && N % 4 == 0;
 }
 
 template <int NKC, int NT, int NP>
@@ -127,7 +131,7 @@ static int proj_launch(const ProjArgs& a, hipStream_t stream) {
   if (gx > 512) gx = 512;
   auto kernel = proj_x3_kernel<NKC, NT, NP>;
   if (shmem > 64 * 1024) CLSR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(kernel, dim3(gx), dim3(256), shmem, stream, a);
+  hipLaunchKernelGGL(kernel, dim3(gx, clsr_cdiv(a.N, NR)), dim3(256), shmem, stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }

@@ -201,6 +201,9 @@ class CLSRNet(object):
         self.rnn_fused_proj = self.rnn_products == "x3" and not os.environ.get("CLSR_NO_RNN_FUSED_PROJ")
         # the Time4LSTM's K-fused time-gate projection as split products too (csrc/projx3.hip): it feeds the same sigmoid gates
         self.proj_x3 = (self.rnn_products == "x3" and not self.exact_products and not os.environ.get("CLSR_NO_PROJ_X3"))
+        # ... and the whole input projection when it is NOT fused into the recurrence launch (hidden sizes > 48: configs[4])
+        self.proj_x3_wide = self.proj_x3 and not os.environ.get("CLSR_NO_PROJ_X3_WIDE")
+        self.proj_wide_pieces = int(os.environ.get("CLSR_PROJ_WIDE_PIECES", "2" if self.precision == "bf16" else "3"))
         self.rnn_act_tiled = self.rnn_products == "x3" and not os.environ.get("CLSR_NO_RNN_ACT_TILED")
         # Attention-MLP backward (exact mode): "x3" = the two-pass layer-1 kernel and the one-pass layer-0 kernel as split-bf16
         # products with the weight gradients dW1 / db1 / dWp accumulated inside them (csrc/attbwdx3.hip: no separate
@@ -1909,7 +1912,17 @@ class CLSRNet(object):
         # (with the K-fused time-gate product the first launch stops in front of those 3H columns)
         rnn_fp = self._rnn_fp_on()
         if not rnn_fp:      # (fused projection: the recurrences read the embeddings themselves)
-            self._gemm(hist, D, "xw", M, D, NX - 3 * H if fuse_tt else NX, PinAll, NX, bias=self._buf("xw.bias", NX))
+            Nw = NX - 3 * H if fuse_tt else NX
+            if self.proj_x3_wide and D % 8 == 0 and query("clsr_proj_x3_supported", M, D, Nw):
+                # wide encoders (BASELINE configs[4]: 128 -> 1 536): the projection in front of the recurrences as split
+                # products with the operands in registers, 128 output columns per workgroup column (csrc/projx3.hip)
+                Wt, Kp = self.packed["xw"]
+                # (three pieces per operand in the parity mode: at K = 128 the 2^-16 perturbation of two pieces, carried through
+                # the recurrences into the short-term query, moved one attention gradient of tests/test_fullsize_gpu.py past
+                # its fp32 tolerance -- 6.0e-7 against 4.8e-7)
+                call("clsr_proj_x3", hist, D, Wt, Kp, self._buf("xw.bias", NX), PinAll, NX, M, D, Nw, self.proj_wide_pieces)
+            else:
+                self._gemm(hist, D, "xw", M, D, Nw, PinAll, NX, bias=self._buf("xw.bias", NX))
         if early_aux is not None or (training and self.sorted_hist_grad):
             # work that depends on the feed only -- accumulator zeroing / row marks of the training step
             # (``early_aux``) and the ~35 tiny launches that sort the history ids by row id for the backward's

@@ -299,7 +299,7 @@ def test_layer1_forward_three_pieces(M, C0, C1):
 
 
 @pytest.mark.parametrize("M,K,N", [(2000, 128, 120), (515, 48, 40), (70, 16, 12), (4099, 40, 36), (40000, 128, 120),
-                                   (33, 8, 4), (300, 96, 128)])
+                                   (33, 8, 4), (300, 96, 128), (1000, 128, 520), (300, 40, 260), (130, 128, 1536)])   # (N > 128: column blocks)
 @pytest.mark.parametrize("pieces", [2, 3])
 def test_projection_split_products(M, K, N, pieces):
     """clsr_proj_x3: Y = X . W + b into a column block of a wider tensor == float64 (2^-16 / 2^-23 per product term)."""

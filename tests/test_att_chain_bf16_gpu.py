@@ -62,8 +62,9 @@ def test_layer0_forward_one_piece_bf16_out(Hn, G, T, Q, A0):
     exp = (x @ r16(dev(Wp)) + dU.double().cpu().view(Hn, 1, T, A0) + dV.double().cpu().view(Hn, G, 1, A0)).reshape(M, A0)
     close(z0[:, :A0], exp, 1e-5, "z0", rtol=2.0 ** -8)
     assert float((z0[:, A0:].float() - 7.0).abs().max()) == 0
-    close(st.sum(0)[0], exp.sum(0), 1e-5, "column sums (of the fp32 accumulators)")
-    close(st.sum(0)[1], (exp * exp).sum(0), 1e-5, "column sums of squares")
+    got = z0[:, :A0].double().cpu()
+    close(st.sum(0)[0], got.sum(0), 1e-5, "column sums (of the stored values)")
+    close(st.sum(0)[1], (got * got).sum(0), 1e-5, "column sums of squares")
     z0b = torch.zeros(M, A0, dtype=BF, device="cuda")
     call("clsr_att_l0_fwd_x1_h", da, Q, dq, Q, Wt, Kp, dU, A0, dV, A0, z0b, A0, None, Hn, G, T, Q, A0)
     torch.cuda.synchronize()
@@ -89,8 +90,9 @@ def test_layer1_forward_one_piece_bf16(M, C0, C1):
     # (an element of the prologue within fp32 rounding of a bf16 tie may round the other way in the kernel: 2^-9 of ONE term)
     close(z1[:, :C1], exp, 1e-3, "z1", rtol=2.0 ** -8)
     assert float((z1[:, C1:].float() - 7.0).abs().max()) == 0
-    close(st.sum(0)[0], exp.sum(0), 1e-4, "column sums")
-    close(st.sum(0)[1], (exp * exp).sum(0), 1e-4, "column sums of squares")
+    got = z1[:, :C1].double().cpu()
+    close(st.sum(0)[0], got.sum(0), 1e-5, "column sums (of the stored values)")
+    close(st.sum(0)[1], (got * got).sum(0), 1e-5, "column sums of squares")
 
 
 @pytest.mark.parametrize("M,C1,C0", [(2000, 40, 80), (515, 40, 80), (300, 48, 80), (70, 16, 24), (4099, 40, 40),
@@ -112,7 +114,7 @@ def test_layer1_backward_one_piece_bf16(M, C1, C0):
             near = y.abs() < 1e-3
             if not bool(near.any()):
                 break
-            z[near] = z[near] * 1.0625 + 0.03125
+            z[near] = torch.where(z[near] == 0, torch.full_like(z[near], 0.5), z[near] * 1.125)
             z.copy_(z.float().to(BF).double())
     Wt, Kp = ops.pack_weight(dev(W1), C0, C1, transposed=True)
     d = {k: dev(v) for k, v in dict(ds=ds, sc1=sc1, sh1=sh1, wo=wo, coef1=coef1, sc0=sc0, sh0=sh0, mean0=mean0, inv0=inv0,
