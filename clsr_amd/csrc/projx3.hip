@@ -16,6 +16,7 @@ struct ProjArgs {
   const float* bias;              // may be NULL
   float* Y; int ldy;
   int M, K, N;
+  int acc;                        // != 0: Y += (a K slab of a wider product: K > 128 runs as slabs of 128 input features)
 };
 
 // NKC = 32-wide chunks of K, NT = 16-feature tiles of N, NP = bf16 pieces per operand
@@ -83,6 +84,17 @@ __global__ void __launch_bounds__(256, 2) proj_x3_kernel(ProjArgs a) {
     f32x4 acc[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[n] = (f32x4){bias[n], bias[n], bias[n], bias[n]};
+    f32x4 old[NT];                // accumulate: the tile's present values, in flight underneath the products
+    if (a.acc) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int p = m0 + 4 * g + e;
+        const unsigned ro = p < a.M ? (unsigned)p * (unsigned)a.ldy * 4u : SKIP;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          old[n][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, ro + co[n], 0, 0));
+      }
+    }
 #pragma unroll
     for (int c = 0; c < NKC; ++c) {
       __builtin_amdgcn_sched_barrier(0);
@@ -104,6 +116,10 @@ __global__ void __launch_bounds__(256, 2) proj_x3_kernel(ProjArgs a) {
         for (int i = 0; i <= sidx; ++i)
 #pragma unroll
           for (int n = 0; n < NT; ++n) HMFMA(acc[n], xp[i], w[sidx - i][n]);
+    }
+    if (a.acc) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n] += old[n];
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -137,8 +153,8 @@ static int proj_launch(const ProjArgs& a, hipStream_t stream) {
 }
 
 // pieces = 2: 2^-16 relative per product term; 3: 2^-23
-extern "C" int clsr_proj_x3(const float* X, int ldx, const float* Wt, int Kp, const float* bias, float* Y, int ldy, int M,
-                            int K, int N, int pieces, void* stream) {
+static int proj_x3_any(const float* X, int ldx, const float* Wt, int Kp, const float* bias, float* Y, int ldy, int M,
+                       int K, int N, int pieces, int accumulate, void* stream) {
   CLSR_CHECK_ARG(X && Wt && Y && (pieces == 2 || pieces == 3));
   CLSR_CHECK_SUPPORTED(clsr_proj_x3_supported(M, K, N));
   CLSR_CHECK_ARG(ldx >= K && ldy >= N && Kp >= 16 * clsr_cdiv(K, 16));
@@ -152,7 +168,7 @@ extern "C" int clsr_proj_x3(const float* X, int ldx, const float* Wt, int Kp, co
   for (long m0 = 0; m0 < M; m0 += rows_max) {
     ProjArgs a = {};
     a.X = X + m0 * ldx; a.ldx = ldx; a.Wt = Wt; a.Kp = Kp; a.bias = bias; a.Y = Y + m0 * ldy; a.ldy = ldy;
-    a.M = (int)(M - m0 < rows_max ? M - m0 : rows_max); a.K = K; a.N = N;
+    a.M = (int)(M - m0 < rows_max ? M - m0 : rows_max); a.K = K; a.N = N; a.acc = accumulate;
     int rc = CLSR_EUNSUPPORTED;
 #define PJ_GO(C, T) \
     if (nkc == C && nt == T) rc = pieces == 2 ? proj_launch<C, T, 2>(a, s) : proj_launch<C, T, 3>(a, s)
@@ -160,6 +176,26 @@ extern "C" int clsr_proj_x3(const float* X, int ldx, const float* Wt, int Kp, co
     PJ_GO(1, 5); PJ_GO(2, 5); PJ_GO(3, 5); PJ_GO(4, 5);
     PJ_GO(1, 8); PJ_GO(2, 8); PJ_GO(3, 8); PJ_GO(4, 8);
 #undef PJ_GO
+    if (rc != CLSR_OK) return rc;
+  }
+  return CLSR_OK;
+}
+
+extern "C" int clsr_proj_x3(const float* X, int ldx, const float* Wt, int Kp, const float* bias, float* Y, int ldy, int M,
+                            int K, int N, int pieces, void* stream) {
+  return proj_x3_any(X, ldx, Wt, Kp, bias, Y, ldy, M, K, N, pieces, 0, stream);
+}
+// K of any width (K % 8 == 0): slabs of 128 input features, the second and later ones accumulating into Y (launches on ONE
+// stream: each reads what the one before wrote).  Kp = row stride of the packed weights (>= K rounded up to 16).
+extern "C" int clsr_proj_x3_wide_supported(int M, int K, int N) {
+  return M > 0 && K >= 8 && K % 8 == 0 && N >= 4 && N <= 128 * 64 && N % 4 == 0;
+}
+extern "C" int clsr_proj_x3_wide(const float* X, int ldx, const float* Wt, int Kp, const float* bias, float* Y, int ldy, int M,
+                                 int K, int N, int pieces, void* stream) {
+  CLSR_CHECK_SUPPORTED(clsr_proj_x3_wide_supported(M, K, N));
+  for (int k0 = 0; k0 < K; k0 += 128) {
+    const int kw = K - k0 < 128 ? K - k0 : 128;
+    int rc = proj_x3_any(X + k0, ldx, Wt + k0, Kp, k0 ? nullptr : bias, Y, ldy, M, kw, N, pieces, k0 ? 1 : 0, stream);
     if (rc != CLSR_OK) return rc;
   }
   return CLSR_OK;

@@ -1955,6 +1955,12 @@ class CLSRNet(object):
                         Wt, Kp = self.packed["xw.t"]
                         call("clsr_proj_x3", XT, Dp + 2 * H, Wt, Kp, self._buf("xw.bias", NX)[t4off + 3 * H:],
                              PinAll[:, t4off + 3 * H:], NX, M, Dp + 2 * H, 3 * H, 2)
+                    elif self.proj_x3_wide and query("clsr_proj_x3_wide_supported", M, Dp + 2 * H, 3 * H):
+                        # (hidden 128: K = 384 as three slabs of 128, the later ones accumulating -- 3 x ~130 us against the
+                        # 0.99 ms of the position-tiled product, on the chain in front of the recurrences)
+                        Wt, Kp = self.packed["xw.t"]
+                        call("clsr_proj_x3_wide", XT, Dp + 2 * H, Wt, Kp, self._buf("xw.bias", NX)[t4off + 3 * H:],
+                             PinAll[:, t4off + 3 * H:], NX, M, Dp + 2 * H, 3 * H, self.proj_wide_pieces)
                     else:
                         self._gemm(XT, Dp + 2 * H, "xw.t", M, Dp + 2 * H, 3 * H, PinAll[:, t4off + 3 * H:], NX,
                                    bias=self._buf("xw.bias", NX)[t4off + 3 * H:])

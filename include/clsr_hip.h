@@ -354,6 +354,10 @@ int clsr_att_hist_fwd_x3(const float* keys, int ldk, const float* At, int Kpa, c
 int clsr_proj_x3_supported(int M, int K, int N);
 int clsr_proj_x3(const float* X, int ldx, const float* Wt, int Kp, const float* bias, float* Y, int ldy, int M, int K,
                  int N, int pieces, void* stream);
+/* ... for K of any width (K % 8 == 0): slabs of 128 input features, the later ones accumulating into Y on the same stream */
+int clsr_proj_x3_wide_supported(int M, int K, int N);
+int clsr_proj_x3_wide(const float* X, int ldx, const float* Wt, int Kp, const float* bias, float* Y, int ldy, int M,
+                      int K, int N, int pieces, void* stream);
 /* Back-projections of the encoders' input-side gradients from ONE pass over dPin [M, NX] (split-bf16 products, csrc/projx3.hip):
  *   dhist[m, :D] += dPin[m, :NX] . W_x^T;   dTT[m, :H2] = dPin[m, tcol0 : tcol0 + H3] . W_t^T
  * WxT / WtT = packed transposed weights (D rows, K = NX / H2 rows, K = H3).  Replaces two clsr_pgemm(3) launches that each

@@ -341,3 +341,20 @@ def test_encoder_tail_back_projections(M, NX, D, H, tcol0):
     close(dhist[:, :D], f(dh0) + f(dPin) @ f(Wx).t(), 5e-5, "dhist")
     close(dTT[:, :H2], f(dPin)[:, tcol0:tcol0 + H3] @ f(Wt).t(), 5e-5, "dTT")
     assert float((dhist[:, D:] - 7.0).abs().max()) == 0 and float((dTT[:, H2:] - 7.0).abs().max()) == 0
+
+
+@pytest.mark.parametrize("M,K,N", [(1000, 384, 384), (515, 136, 40), (70, 264, 132), (2000, 128, 120)])
+@pytest.mark.parametrize("pieces", [2, 3])
+def test_projection_wide_k_in_slabs(M, K, N, pieces):
+    """clsr_proj_x3_wide: K > 128 as slabs of 128 input features, the later slabs accumulating into Y == float64."""
+    assert query("clsr_proj_x3_wide_supported", M, K, N) == 1 and query("clsr_proj_x3_wide_supported", M, K + 4, N) == 0
+    g = torch.Generator().manual_seed(M + K)
+    X, W, b = rnd(g, M, K), rnd(g, K, N, scale=0.2), rnd(g, N)
+    Wt, Kp = ops.pack_weight(dev(W), N, K)
+    dX, db = dev(X), dev(b)
+    Y = torch.full((M, N + 8), 7.0, device="cuda")
+    call("clsr_proj_x3_wide", dX, K, Wt, Kp, db, Y[:, 4:], N + 8, M, K, N, pieces)
+    torch.cuda.synchronize()
+    exp = dX.double().cpu() @ dev(W).double().cpu() + db.double().cpu()
+    close(Y[:, 4:4 + N], exp, 5e-5 if pieces == 2 else 2e-6, "Y")
+    assert float((Y[:, :4] - 7.0).abs().max()) == 0 and float((Y[:, 4 + N:] - 7.0).abs().max()) == 0
