@@ -190,12 +190,13 @@ extern "C" int clsr_proj_x3(const float* X, int ldx, const float* Wt, int Kp, co
 extern "C" int clsr_proj_x3_wide_supported(int M, int K, int N) {
   return M > 0 && K >= 8 && K % 8 == 0 && N >= 4 && N <= 128 * 64 && N % 4 == 0;
 }
+// accumulate != 0: Y += X . W + b (the first slab accumulates as well)
 extern "C" int clsr_proj_x3_wide(const float* X, int ldx, const float* Wt, int Kp, const float* bias, float* Y, int ldy, int M,
-                                 int K, int N, int pieces, void* stream) {
+                                 int K, int N, int pieces, int accumulate, void* stream) {
   CLSR_CHECK_SUPPORTED(clsr_proj_x3_wide_supported(M, K, N));
   for (int k0 = 0; k0 < K; k0 += 128) {
     const int kw = K - k0 < 128 ? K - k0 : 128;
-    int rc = proj_x3_any(X + k0, ldx, Wt + k0, Kp, k0 ? nullptr : bias, Y, ldy, M, kw, N, pieces, k0 ? 1 : 0, stream);
+    int rc = proj_x3_any(X + k0, ldx, Wt + k0, Kp, k0 ? nullptr : bias, Y, ldy, M, kw, N, pieces, (k0 || accumulate) ? 1 : 0, stream);
     if (rc != CLSR_OK) return rc;
   }
   return CLSR_OK;

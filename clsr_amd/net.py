@@ -203,6 +203,7 @@ class CLSRNet(object):
         self.proj_x3 = (self.rnn_products == "x3" and not self.exact_products and not os.environ.get("CLSR_NO_PROJ_X3"))
         # ... and the whole input projection when it is NOT fused into the recurrence launch (hidden sizes > 48: configs[4])
         self.proj_x3_wide = self.proj_x3 and not os.environ.get("CLSR_NO_PROJ_X3_WIDE")
+        self.gemm_wide_x3 = self.proj_x3_wide and not os.environ.get("CLSR_NO_GEMM_WIDE_X3")   # A/B: every plain wide product
         self.proj_wide_pieces = int(os.environ.get("CLSR_PROJ_WIDE_PIECES", "2" if self.precision == "bf16" else "3"))
         self.rnn_act_tiled = self.rnn_products == "x3" and not os.environ.get("CLSR_NO_RNN_ACT_TILED")
         # Attention-MLP backward (exact mode): "x3" = the two-pass layer-1 kernel and the one-pass layer-0 kernel as split-bf16
@@ -668,6 +669,14 @@ class CLSRNet(object):
             call("clsr_hgemm_hf32" if X.dtype == torch.bfloat16 else "clsr_hgemm_f32", X, ldx, Wt, Kp, Y, ldy, acc, M, K, N)
             return
         Wt, Kp = self.packed[wkey]
+        if (self.gemm_wide_x3 and Xmul is None and aff is None and addU is None and addV is None and stats is None and T == 0
+                and M >= 32768 and (K > 80 or N > 80) and K <= 384 and K % 8 == 0 and ldx % 4 == 0
+                and query("clsr_proj_x3_wide_supported", M, K, N)):
+            # plain position-level products of WIDE layers (BASELINE configs[4]): operands in registers, 128 output columns
+            # per workgroup column, K in slabs of 128 (csrc/projx3.hip) -- the position-tiled fp32 kernel ran these at
+            # 0.3-0.4 of the fp32 matrix peak (profiles/r05_catalogue_pmc.md)
+            call("clsr_proj_x3_wide", X, ldx, Wt, Kp, bias, Y, ldy, M, K, N, self.proj_wide_pieces, int(acc))
+            return
         sc, sh = (aff.scale, aff.shift) if aff is not None else (None, None)
         name = "clsr_pgemm"
         if self._x3_site(wkey) and query("clsr_pgemm3_supported", int(Xmul is not None), int(aff is not None),
@@ -1960,7 +1969,7 @@ class CLSRNet(object):
                         # 0.99 ms of the position-tiled product, on the chain in front of the recurrences)
                         Wt, Kp = self.packed["xw.t"]
                         call("clsr_proj_x3_wide", XT, Dp + 2 * H, Wt, Kp, self._buf("xw.bias", NX)[t4off + 3 * H:],
-                             PinAll[:, t4off + 3 * H:], NX, M, Dp + 2 * H, 3 * H, self.proj_wide_pieces)
+                             PinAll[:, t4off + 3 * H:], NX, M, Dp + 2 * H, 3 * H, self.proj_wide_pieces, 0)
                     else:
                         self._gemm(XT, Dp + 2 * H, "xw.t", M, Dp + 2 * H, 3 * H, PinAll[:, t4off + 3 * H:], NX,
                                    bias=self._buf("xw.bias", NX)[t4off + 3 * H:])

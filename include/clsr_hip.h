@@ -354,10 +354,12 @@ int clsr_att_hist_fwd_x3(const float* keys, int ldk, const float* At, int Kpa, c
 int clsr_proj_x3_supported(int M, int K, int N);
 int clsr_proj_x3(const float* X, int ldx, const float* Wt, int Kp, const float* bias, float* Y, int ldy, int M, int K,
                  int N, int pieces, void* stream);
-/* ... for K of any width (K % 8 == 0): slabs of 128 input features, the later ones accumulating into Y on the same stream */
+/* ... for K of any width (K % 8 == 0): slabs of 128 input features, the later ones accumulating into Y on the same stream;
+ * accumulate != 0: Y += X . W + b.  The step routes every PLAIN position-level product of wide layers (K or N > 80:
+ * BASELINE configs[4]) through it -- three bf16 pieces per operand in the parity mode (2^-23 relative: fp32 level) */
 int clsr_proj_x3_wide_supported(int M, int K, int N);
 int clsr_proj_x3_wide(const float* X, int ldx, const float* Wt, int Kp, const float* bias, float* Y, int ldy, int M,
-                      int K, int N, int pieces, void* stream);
+                      int K, int N, int pieces, int accumulate, void* stream);
 /* Back-projections of the encoders' input-side gradients from ONE pass over dPin [M, NX] (split-bf16 products, csrc/projx3.hip):
  *   dhist[m, :D] += dPin[m, :NX] . W_x^T;   dTT[m, :H2] = dPin[m, tcol0 : tcol0 + H3] . W_t^T
  * WxT / WtT = packed transposed weights (D rows, K = NX / H2 rows, K = H3).  Replaces two clsr_pgemm(3) launches that each

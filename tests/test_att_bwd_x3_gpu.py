@@ -353,8 +353,12 @@ def test_projection_wide_k_in_slabs(M, K, N, pieces):
     Wt, Kp = ops.pack_weight(dev(W), N, K)
     dX, db = dev(X), dev(b)
     Y = torch.full((M, N + 8), 7.0, device="cuda")
-    call("clsr_proj_x3_wide", dX, K, Wt, Kp, db, Y[:, 4:], N + 8, M, K, N, pieces)
+    call("clsr_proj_x3_wide", dX, K, Wt, Kp, db, Y[:, 4:], N + 8, M, K, N, pieces, 0)
     torch.cuda.synchronize()
     exp = dX.double().cpu() @ dev(W).double().cpu() + db.double().cpu()
     close(Y[:, 4:4 + N], exp, 5e-5 if pieces == 2 else 2e-6, "Y")
+    assert float((Y[:, :4] - 7.0).abs().max()) == 0 and float((Y[:, 4 + N:] - 7.0).abs().max()) == 0
+    call("clsr_proj_x3_wide", dX, K, Wt, Kp, None, Y[:, 4:], N + 8, M, K, N, pieces, 1)       # Y += X . W
+    torch.cuda.synchronize()
+    close(Y[:, 4:4 + N], 2 * exp - db.double().cpu(), 5e-5 if pieces == 2 else 2e-6, "Y accumulated")
     assert float((Y[:, :4] - 7.0).abs().max()) == 0 and float((Y[:, 4 + N:] - 7.0).abs().max()) == 0
