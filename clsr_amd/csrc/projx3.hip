@@ -17,10 +17,16 @@ struct ProjArgs {
   float* Y; int ldy;
   int M, K, N;
   int acc;                        // != 0: Y += (a K slab of a wider product: K > 128 runs as slabs of 128 input features)
+  // TT form (clsr_proj_x3_tt): X is the history embeddings [M, D]; the columns [col0, col0 + 2n) of the product's input are the
+  // Time4LSTM's tanh time features, computed here from the two time scalars of the position (no [hist | TT] image in front
+  // of the product: the launch leaves the dependent chain that starts the recurrences)
+  const float* tnow; const float* tfirst; long row_stride; int T;
+  const float* w1; const float* b1; const float* w2; const float* b2;
+  int D, col0, n;
 };
 
 // NKC = 32-wide chunks of K, NT = 16-feature tiles of N, NP = bf16 pieces per operand
-template <int NKC, int NT, int NP>
+template <int NKC, int NT, int NP, bool TTF = false>
 __global__ void __launch_bounds__(256, 2) proj_x3_kernel(ProjArgs a) {
   CLSR_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -28,6 +34,16 @@ __global__ void __launch_bounds__(256, 2) proj_x3_kernel(ProjArgs a) {
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int j = lane & 15, g = lane >> 4;
   __bf16* Wi = reinterpret_cast<__bf16*>(lds_raw);          // [NP][NR][WS]
+  float* ttab = reinterpret_cast<float*>(lds_raw + (size_t)NP * NR * WS * 2);      // TTF: [2][32 NKC] weight / bias of a time-feature column
+  if (TTF) {
+    for (int e = tid; e < 32 * NKC; e += 256) {
+      const int k = e - a.col0;
+      float w = 0.f, b = 0.f;
+      if (k >= 0 && k < a.n) { w = a.w1[k]; b = a.b1[k]; }
+      else if (k >= a.n && k < 2 * a.n) { w = a.w2[k - a.n]; b = a.b2[k - a.n]; }
+      ttab[e] = w; ttab[32 * NKC + e] = b;
+    }
+  }
   // wide outputs (the fused input projection of 128-wide encoders, N = 1 536): blockIdx.y owns a block of NR output
   // columns; X is re-read per block (L2 / Infinity Cache: 105 MB at configs[4]), every block writes its own columns
   const int n0 = blockIdx.y * NR;
@@ -61,19 +77,31 @@ __global__ void __launch_bounds__(256, 2) proj_x3_kernel(ProjArgs a) {
       __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, ((unsigned)(a.M - 1) * (unsigned)a.ldy + (unsigned)a.N) * 4u, 0x00020000);
   const f32x8 z8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int kofs[NKC];
+  int kind[NKC];                // TTF: 0 = history columns (read), 1 = tanh(time_to_now ..), 2 = tanh(time_from_first ..), 3 = padding
 #pragma unroll
-  for (int c = 0; c < NKC; ++c) kofs[c] = 32 * c + 8 * g < a.K ? 32 * c + 8 * g : 0;
+  for (int c = 0; c < NKC; ++c) {
+    const int k0 = 32 * c + 8 * g;
+    kofs[c] = k0 < (TTF ? a.D : a.K) ? k0 : 0;
+    kind[c] = !TTF ? 0 : k0 < a.D ? 0 : (k0 >= a.col0 && k0 < a.col0 + a.n) ? 1 : (k0 >= a.col0 + a.n && k0 < a.col0 + 2 * a.n) ? 2 : 3;
+  }
 
   const int ntiles = (a.M + 15) >> 4;
   const int tstride = gridDim.x * 4;
   int tile = blockIdx.x * 4 + wave;
-  struct Raw { f32x8 x[NKC]; };
+  struct Raw { f32x8 x[NKC]; float tn, tf; };
   auto fetch = [&](int t) -> Raw {
     Raw r;
     const int m = t * 16 + j;
-    const float* p = a.X + (long)(m < a.M ? m : a.M - 1) * a.ldx;
+    const int mc = m < a.M ? m : a.M - 1;
+    const float* p = a.X + (long)mc * a.ldx;
 #pragma unroll
-    for (int c = 0; c < NKC; ++c) r.x[c] = ld8f(p + kofs[c]);
+    for (int c = 0; c < NKC; ++c)
+      if (!TTF || 32 * c < a.D) r.x[c] = ld8f(p + kofs[c]);        // (TTF: only the chunks that hold history columns; uniform)
+    if (TTF) {
+      const int h = mc / a.T, tt = mc - h * a.T;
+      r.tn = a.tnow[(long)h * a.row_stride + tt];
+      r.tf = a.tfirst[(long)h * a.row_stride + tt];
+    }
     return r;
   };
   Raw cur = fetch(tile);
@@ -99,6 +127,20 @@ __global__ void __launch_bounds__(256, 2) proj_x3_kernel(ProjArgs a) {
     for (int c = 0; c < NKC; ++c) {
       __builtin_amdgcn_sched_barrier(0);
       f32x8 y = (pv && 32 * c + 8 * g < a.K) ? cur.x[c] : z8;
+      if (TTF) {
+        // (same arithmetic as t4_time_inputs_fwd_kernel, csrc/rnn.hip, which still writes TT for the backward pass -- off the chain)
+        if (32 * c >= a.D) y = z8;
+        if (kind[c] != 0) {
+          const float x = kind[c] == 1 ? cur.tn : cur.tf;
+          const f32x8 w8 = ld8f(ttab + 32 * c + 8 * g), b8 = ld8f(ttab + 32 * NKC + 32 * c + 8 * g);
+          f32x8 v;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = tanhf_(x * w8[e] + b8[e]);
+          y = (pv && kind[c] != 3) ? v : z8;
+        } else if (!(pv && 32 * c + 8 * g < a.D)) {
+          y = z8;
+        }
+      }
       bf16x8 xp[NP];
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
@@ -139,13 +181,13 @@ extern "C" int clsr_proj_x3_supported(int M, int K, int N) {
   return M > 0 && K >= 8 && K <= 128 && K % 8 == 0 && N >= 4 && N <= 128 * 64 && N % 4 == 0;
 }
 
-template <int NKC, int NT, int NP>
+template <int NKC, int NT, int NP, bool TTF = false>
 static int proj_launch(const ProjArgs& a, hipStream_t stream) {
   constexpr int WS = 32 * NKC + 8, NR = 16 * NT;
-  const size_t shmem = (size_t)NP * NR * WS * 2;
+  const size_t shmem = (size_t)NP * NR * WS * 2 + (TTF ? (size_t)2 * 32 * NKC * 4 : 0);
   int gx = clsr_cdiv(clsr_cdiv(a.M, 16), 4);
   if (gx > 512) gx = 512;
-  auto kernel = proj_x3_kernel<NKC, NT, NP>;
+  auto kernel = proj_x3_kernel<NKC, NT, NP, TTF>;
   if (shmem > 64 * 1024) CLSR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   hipLaunchKernelGGL(kernel, dim3(gx, clsr_cdiv(a.N, NR)), dim3(256), shmem, stream, a);
   CLSR_CHECK_LAUNCH();
@@ -384,5 +426,44 @@ extern "C" int clsr_enc_back_x3(const float* dPin, int ldp, const float* WxT, in
   EB_GO(4); EB_GO(8); EB_GO(12); EB_GO(15); EB_GO(16);
 #undef EB_GO
   (void)nd;
+  return CLSR_OK;
+}
+
+// The Time4LSTM's time-gate projection without its [hist | TT] input image:  Y = [hist | 0 | tanh(t_now w1 + b1) | tanh(t_first w2 + b2)] . W + b
+// with the 2n time-feature columns computed in the prologue from the position's two time scalars (reference
+// rnn_cell_implement.py:200-236).  K = col0 + 2n <= 128, D % 8 == 0, col0 % 8 == 0, n % 8 == 0.
+extern "C" int clsr_proj_x3_tt_supported(int M, int D, int col0, int n, int N) {
+  return M > 0 && D >= 8 && D % 8 == 0 && col0 >= D && col0 % 8 == 0 && n >= 8 && n % 8 == 0 && col0 + 2 * n <= 128 &&
+         N >= 4 && N <= 128 && N % 4 == 0;
+}
+extern "C" int clsr_proj_x3_tt(const float* hist, int D, const float* tnow, const float* tfirst, long row_stride, int T,
+                               const float* w1, const float* b1, const float* w2, const float* b2, int n, int col0,
+                               const float* Wt, int Kp, const float* bias, float* Y, int ldy, int M, int N, int pieces,
+                               void* stream) {
+  CLSR_CHECK_ARG(hist && tnow && tfirst && w1 && b1 && w2 && b2 && Wt && Y && (pieces == 2 || pieces == 3) && T > 0);
+  CLSR_CHECK_SUPPORTED(clsr_proj_x3_tt_supported(M, D, col0, n, N));
+  const int K = col0 + 2 * n;
+  CLSR_CHECK_ARG(ldy >= N && Kp >= 16 * clsr_cdiv(K, 16));
+  CLSR_CHECK_SUPPORTED(Kp % 4 == 0 && ((uintptr_t)hist % 16) == 0 && ((uintptr_t)Wt % 16) == 0 && ((uintptr_t)Y % 4) == 0 &&
+                       (long)ldy * 4 * 16 < 0x40000000L);
+  hipStream_t s = (hipStream_t)stream;
+  const int nkc = clsr_cdiv(K, 32), nt = N <= 48 ? 3 : (N <= 80 ? 5 : 8);
+  const long rows_max = ((0x40000000L - 1) / ((long)ldy * 4)) / T * T;       // whole histories per launch (m -> (h, t) inside)
+  CLSR_CHECK_SUPPORTED(rows_max >= T);
+  for (long m0 = 0; m0 < M; m0 += rows_max) {
+    ProjArgs a = {};
+    a.X = hist + m0 * D; a.ldx = D; a.Wt = Wt; a.Kp = Kp; a.bias = bias; a.Y = Y + m0 * ldy; a.ldy = ldy;
+    a.M = (int)(M - m0 < rows_max ? M - m0 : rows_max); a.K = K; a.N = N; a.acc = 0;
+    a.tnow = tnow + (m0 / T) * row_stride; a.tfirst = tfirst + (m0 / T) * row_stride; a.row_stride = row_stride; a.T = T;
+    a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.D = D; a.col0 = col0; a.n = n;
+    int rc = CLSR_EUNSUPPORTED;
+#define PJT_GO(C, T_) \
+    if (nkc == C && nt == T_) rc = pieces == 2 ? proj_launch<C, T_, 2, true>(a, s) : proj_launch<C, T_, 3, true>(a, s)
+    PJT_GO(1, 3); PJT_GO(2, 3); PJT_GO(3, 3); PJT_GO(4, 3);
+    PJT_GO(1, 5); PJT_GO(2, 5); PJT_GO(3, 5); PJT_GO(4, 5);
+    PJT_GO(1, 8); PJT_GO(2, 8); PJT_GO(3, 8); PJT_GO(4, 8);
+#undef PJT_GO
+    if (rc != CLSR_OK) return rc;
+  }
   return CLSR_OK;
 }

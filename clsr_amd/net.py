@@ -202,6 +202,7 @@ class CLSRNet(object):
         # the Time4LSTM's K-fused time-gate projection as split products too (csrc/projx3.hip): it feeds the same sigmoid gates
         self.proj_x3 = (self.rnn_products == "x3" and not self.exact_products and not os.environ.get("CLSR_NO_PROJ_X3"))
         # ... and the whole input projection when it is NOT fused into the recurrence launch (hidden sizes > 48: configs[4])
+        self.proj_tt = self.proj_x3 and not os.environ.get("CLSR_NO_PROJ_TT")      # A/B: tanh time features in that kernel's prologue
         self.proj_x3_wide = self.proj_x3 and not os.environ.get("CLSR_NO_PROJ_X3_WIDE")
         self.gemm_wide_x3 = self.proj_x3_wide and not os.environ.get("CLSR_NO_GEMM_WIDE_X3")   # A/B: every plain wide product
         self.proj_wide_pieces = int(os.environ.get("CLSR_PROJ_WIDE_PIECES", "2" if self.precision == "bf16" else "3"))
@@ -1955,8 +1956,20 @@ class CLSRNet(object):
             t4off = self._enc_off("t4")
             if hp.sequential_model == "time4lstm":
                 TT = self._buf("t4.TT", M, 2 * H)
-                self._join("@lt")     # the time features were computed beside the fused input projection
-                if fuse_tt:
+                # the tanh time features INSIDE the projection's prologue (csrc/projx3.hip, clsr_proj_x3_tt): the launch no
+                # longer waits for the side kernel that writes TT / the [hist | TT] image (those are for the backward pass
+                # only now: joined with the long-term branch in front of the heads) -- one kernel + two stream hops off the
+                # chain that starts the recurrences
+                tt_fused = bool(fuse_tt and self.proj_tt and query("clsr_proj_x3_tt_supported", M, D, Dp, H, 3 * H))
+                if not tt_fused:
+                    self._join("@lt")     # the time features were computed beside the fused input projection
+                if tt_fused:
+                    Wt, Kp = self.packed["xw.t"]
+                    call("clsr_proj_x3_tt", hist, D, f["time_to_now"], f["time_from_first_action"], hs * T, T,
+                         P[t + "_time_input_w1"], P[t + "_time_input_bias1"], P[t + "_time_input_w2"],
+                         P[t + "_time_input_bias2"], H, Dp, Wt, Kp, self._buf("xw.bias", NX)[t4off + 3 * H:],
+                         PinAll[:, t4off + 3 * H:], NX, M, 3 * H, 2)
+                elif fuse_tt:
                     # ONE product over [hist | TT] (K = 48 + 80) writes the time-gate columns: the separate pass that
                     # re-read and re-wrote them (hist . W_x first, += TT . W_t behind it: 112 us alone) is gone
                     if self.proj_x3 and query("clsr_proj_x3_supported", M, Dp + 2 * H, 3 * H):

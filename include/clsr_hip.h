@@ -354,6 +354,15 @@ int clsr_att_hist_fwd_x3(const float* keys, int ldk, const float* At, int Kpa, c
 int clsr_proj_x3_supported(int M, int K, int N);
 int clsr_proj_x3(const float* X, int ldx, const float* Wt, int Kp, const float* bias, float* Y, int ldy, int M, int K,
                  int N, int pieces, void* stream);
+/* The Time4LSTM's time-gate projection WITHOUT its [hist | TT] input image: the 2n tanh time features of a position
+ * (clsr_t4_time_inputs_fwd's arithmetic: tanh(t_now w1 + b1) | tanh(t_first w2 + b2)) are computed in the product's
+ * prologue as columns [col0, col0 + 2n) of the input, columns [0, D) are the history embeddings, the rest zero.
+ * K = col0 + 2n <= 128.  (reference rnn_cell_implement.py:200-236) */
+int clsr_proj_x3_tt_supported(int M, int D, int col0, int n, int N);
+int clsr_proj_x3_tt(const float* hist, int D, const float* tnow, const float* tfirst, long row_stride, int T,
+                    const float* w1, const float* b1, const float* w2, const float* b2, int n, int col0,
+                    const float* Wt, int Kp, const float* bias, float* Y, int ldy, int M, int N, int pieces,
+                    void* stream);
 /* ... for K of any width (K % 8 == 0): slabs of 128 input features, the later ones accumulating into Y on the same stream;
  * accumulate != 0: Y += X . W + b.  The step routes every PLAIN position-level product of wide layers (K or N > 80:
  * BASELINE configs[4]) through it -- three bf16 pieces per operand in the parity mode (2^-23 relative: fp32 level) */

@@ -362,3 +362,33 @@ def test_projection_wide_k_in_slabs(M, K, N, pieces):
     torch.cuda.synchronize()
     close(Y[:, 4:4 + N], 2 * exp - db.double().cpu(), 5e-5 if pieces == 2 else 2e-6, "Y accumulated")
     assert float((Y[:, :4] - 7.0).abs().max()) == 0 and float((Y[:, 4 + N:] - 7.0).abs().max()) == 0
+
+
+@pytest.mark.parametrize("Hn,T,D,H", [(64, 50, 40, 40), (7, 13, 8, 8), (33, 250, 40, 40), (5, 7, 32, 24)])
+@pytest.mark.parametrize("pieces", [2, 3])
+def test_time_gate_projection_with_the_time_features_in_its_prologue(Hn, T, D, H, pieces):
+    """clsr_proj_x3_tt == clsr_t4_time_inputs_fwd2 (the [hist | 0 | TT] image) followed by clsr_proj_x3 on that image, and ==
+    float64 (reference rnn_cell_implement.py:200-236)."""
+    M, Dp, N = Hn * T, 16 * ((D + 15) // 16), 3 * H
+    K = Dp + 2 * H
+    assert query("clsr_proj_x3_tt_supported", M, D, Dp, H, N) == 1
+    g = torch.Generator().manual_seed(Hn + T)
+    hist, W, b = dev(rnd(g, M, D)), dev(rnd(g, K, N, scale=0.2)), dev(rnd(g, N))
+    W[D:Dp] = 0
+    tnow, tfirst = dev(torch.rand(Hn, T, generator=g, dtype=torch.float64) * 5), dev(torch.rand(Hn, T, generator=g, dtype=torch.float64) * 5)
+    w1, b1, w2, b2 = dev(rnd(g, H)), dev(rnd(g, H)), dev(rnd(g, H)), dev(rnd(g, H))
+    Wt, Kp = ops.pack_weight(W, N, K)
+    TT, XT = torch.zeros(M, 2 * H, device="cuda"), torch.zeros(M, K, device="cuda")
+    call("clsr_t4_time_inputs_fwd2", tnow, tfirst, T, w1, b1, w2, b2, Hn, T, H, TT, hist, D, XT, K, Dp)
+    Y0 = torch.full((M, N + 8), 7.0, device="cuda")
+    call("clsr_proj_x3", XT, K, Wt, Kp, b, Y0[:, 4:], N + 8, M, K, N, pieces)
+    Y1 = torch.full((M, N + 8), 7.0, device="cuda")
+    call("clsr_proj_x3_tt", hist, D, tnow, tfirst, T, T, w1, b1, w2, b2, H, Dp, Wt, Kp, b, Y1[:, 4:], N + 8, M, N, pieces)
+    torch.cuda.synchronize()
+    tol = 5e-5 if pieces == 2 else 2e-6
+    close(Y1[:, 4:4 + N], Y0[:, 4:4 + N], tol, "fused vs two launches")
+    assert float((Y1[:, :4] - 7.0).abs().max()) == 0 and float((Y1[:, 4 + N:] - 7.0).abs().max()) == 0
+    tn, tf = tnow.double().cpu().reshape(M, 1), tfirst.double().cpu().reshape(M, 1)
+    X = torch.cat([hist.double().cpu(), torch.zeros(M, Dp - D, dtype=torch.float64),
+                   torch.tanh(tn * w1.double().cpu() + b1.double().cpu()), torch.tanh(tf * w2.double().cpu() + b2.double().cpu())], 1)
+    close(Y1[:, 4:4 + N], X @ W.double().cpu() + b.double().cpu(), tol, "fused vs float64")
