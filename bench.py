@@ -590,6 +590,9 @@ def main():
                                                                       "Adam moments)" if td == "bf16" else ""))
                     if td == "fp32" and other != "fp32x3":
                         modes[tag]["layer0"] = w2.net.bench_att_layer0(w2.f, time_kernel)
+                        l1b = w2.net.bench_att_l1_bwd(w2.f, time_kernel)
+                        if l1b is not None:
+                            modes[tag]["layer1_bwd"] = l1b
                     log("precision %s: %.3f ms/step" % (tag, d2 * 1e3 / n2))
                     w2.free()
                 except NotImplementedError as e:

@@ -2691,8 +2691,11 @@ class CLSRNet(object):
             return ("all tensors fp32 (storage, statistics, recurrences, losses, optimiser exactly as in the parity mode); the "
                     "MFMA-saturated products are split-bf16 sums hi*hi + lo*hi + hi*lo on v_mfma_f32_16x16x32_bf16 with fp32 "
                     "accumulation (<= 2^-16 relative per product)")
-        return ("attention-block activations at (row, step) level stored as bf16, GEMMs on v_mfma_f32_16x16x32_bf16 "
-                "with fp32 accumulation; batch-norm statistics, softmax, recurrences, losses, gradients of the "
+        return ("attention-block activations at (row, step) level (z0, z1, dz0) stored as bf16, their products with ONE bf16 piece per "
+                "operand on v_mfma_f32_16x16x32_bf16 with fp32 accumulation"
+                + (" (the parity mode's chain kernels with the weight gradients folded in, csrc/attbwdx3.hip)" if self.bf16_chain
+                   else " (position-tiled csrc/hgemm.hip kernels, CLSR_BF16_CHAIN=old)")
+                + "; history- and row-level tensors, batch-norm statistics, softmax, recurrences, losses, gradients of the "
                 "parameters and the optimiser stay fp32")
 
     def bench_att_layer0(self, f, time_kernel):
@@ -2729,12 +2732,31 @@ class CLSRNet(object):
     def bench_att_l1_bwd(self, f, time_kernel):
         """HIP-event timing of the HBM-heaviest kernel of the backward pass in isolation: pass 2 of the second attention
         layer's backward (short-term attention, B*T positions): reads z1 and z0, writes dz0, accumulates dW1 / db1."""
-        if self.bf16 or self.att_bwd != "x3" or not query("clsr_att_l1_bwd_x3_supported", self.A1, self.A0):
-            return None
         B, T, G, Hn = self.last_shape
         A0, A1, M = self.A0, self.A1, B * T
         key, nn = "st", CL + "short_term/attention_fcn/att_fcn/nn_part/"
         bn0, bn1 = self.bn[nn + "batch_normalization/"], self.bn[nn + "batch_normalization_1/"]
+        if self.bf16:
+            if not self._bf16_chain_ok(G, self.D):
+                return None
+            BF = torch.bfloat16
+            z0, z1 = self._buf(key + ".z0", M, A0, dtype=BF), self._buf(key + ".z1", M, A1, dtype=BF)
+            dz0, ds = self._buf(key + ".dz0", M, A0, dtype=BF), self._buf(key + ".ds", M)
+            Wt, Kp = self.packed[key + ".W1^T"]
+            parts = query("clsr_att_l1_bwd_x3_parts", M)
+            ws = self._buf(key + ".dw1x_ws", parts * query("clsr_dw_chunk_floats"))
+            wo = self.P[nn + "w_nn_output"]
+            t = time_kernel(lambda: call("clsr_att_l1_bwd_x1_h", z1, A1, ds, bn1.scale, bn1.shift, wo, bn1.coef, Wt, Kp, z0, A0,
+                                         bn0.scale, bn0.shift, None, None, bn0.coef, dz0, A0, ws, None, M, A1, A0))
+            nbytes = float(M) * ((A1 + 2 * A0) * 2 + 4)
+            return dict(bound="hbm", kernel="att_l1_bwd_x3_kernel<5,3,true,1,bf16> (short-term attention, layer-1 backward pass 2: dz0 + "
+                                            "the partial sums of dW1 / db1 from one pass over the bf16 z1, z0; one bf16 piece per operand)",
+                        achieved=round(nbytes / t / 1e9, 1), peak=8000.0, unit="GB/s", frac=round(nbytes / t / 8e12, 4),
+                        bytes_per_launch=nbytes, us_per_launch=round(t * 1e6, 2),
+                        formula="M * (A1 + A0) * 2 read + M * A0 * 2 written + M * 4 (score gradient), M = B*T positions",
+                        note="one 512-register wave per SIMD: bound by instruction issue, not by HBM")
+        if self.att_bwd != "x3" or not query("clsr_att_l1_bwd_x3_supported", self.A1, self.A0):
+            return None
         z0, z1 = self._buf(key + ".z0", M, A0), self._buf(key + ".z1", M, A1)
         dz0, ds = self._buf(key + ".dz0", M, A0), self._buf(key + ".ds", M)
         Wt, Kp = self.packed[key + ".W1^T"]
