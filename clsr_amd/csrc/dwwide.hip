@@ -19,6 +19,7 @@
 // the two position rows a half-wave reads sit in disjoint banks).
 #include "common.h"
 #include "clsr_hip.h"
+#include "hmma.h"
 
 #define DWW_ST 144
 #define DWW_STAGE (32 * DWW_ST)
@@ -28,6 +29,12 @@ struct DwwArgs {
   const float* X; int ldx; const float* dY; int ldy; float* part; float* bpart; int M, K, N, mper, S;
 };
 
+// X3: the products as split-bf16 sums xh.yh + xh.yl + xl.yh on v_mfma_f32_16x16x32_bf16 (fp32 accumulation, 2^-16 relative per
+// term, like every other weight gradient of the parity mode's default): a 32-position stage is ONE K = 32 chunk -- a lane
+// gathers the eight positions 8g .. 8g + 7 of its feature from the LDS stage (the same 64 ds_read_b32 per wave and stage as
+// the fp32 form), splits them, and issues 48 bf16 MFMAs of ~16 cycles where the fp32 form issues 128 of 32: the fp32 kernel
+// ran the matrix pipe 70 % busy at 0.56 of its peak (profiles/r05_catalogue_pmc.md), this one is bound by its operand traffic.
+template <bool X3>
 __global__ void __launch_bounds__(256, 2) dw_wide_kernel(DwwArgs a) {
   extern __shared__ __attribute__((aligned(16))) float dww_lds[];
   float* Xs = dww_lds;                       // [2][32][DWW_ST]
@@ -75,6 +82,30 @@ __global__ void __launch_bounds__(256, 2) dw_wide_kernel(DwwArgs a) {
     if (s + 1 < nst) fetch(m0 + 32L * (s + 1));
     const float* xs = Xs + b * DWW_STAGE + wk + i;
     const float* ys = Ys + b * DWW_STAGE + wn + i;
+    if (X3) {
+      bf16x8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        f32x8 xv, yv8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xv[e] = xs[(8 * g + e) * DWW_ST + 16 * t];
+          yv8[e] = ys[(8 * g + e) * DWW_ST + 16 * t];
+        }
+        ah[t] = to_h(xv); al[t] = to_h(xv - to_f(ah[t]));
+        bh[t] = to_h(yv8); bl[t] = to_h(yv8 - to_f(bh[t]));
+        if (want_b) bs[t] += ((yv8[0] + yv8[1]) + (yv8[2] + yv8[3])) + ((yv8[4] + yv8[5]) + (yv8[6] + yv8[7]));
+      }
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) HMFMA(acc[kt][nt], ah[kt], bl[nt]);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) HMFMA(acc[kt][nt], al[kt], bh[nt]);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) HMFMA(acc[kt][nt], ah[kt], bh[nt]);
+      }
+    } else
 #pragma unroll
     for (int st = 0; st < 8; ++st) {
       float xa[4], yb[4];
@@ -175,8 +206,8 @@ extern "C" long clsr_pgemm_dw_wide_workspace_floats(long M, int K, int N) {
 // dW [K, N] (row stride ldw) and optionally db [N] from X [M, K] (row stride ldx; times Xmul [M, K] element-wise when
 // given) and dY [M, N] (row stride ldy): two
 // launches on ``stream`` (partial tiles, then their sum in range order).  accumulate != 0: added to dW / db.
-extern "C" int clsr_pgemm_dw_wide(const float* X, int ldx, const float* Xmul, int ldmul, const float* dY, int ldy, long M, int K,
-                                  int N, float* workspace, float* dW, int ldw, float* db, int accumulate, void* stream) {
+static int dw_wide_any(const float* X, int ldx, const float* Xmul, int ldmul, const float* dY, int ldy, long M, int K,
+                       int N, float* workspace, float* dW, int ldw, float* db, int accumulate, bool x3, void* stream) {
   CLSR_CHECK_ARG(X && dY && workspace && dW && ldx >= K && ldy >= N && ldw >= N);
   CLSR_CHECK_SUPPORTED(!Xmul || (ldmul >= K && ldmul % 4 == 0 && ((uintptr_t)Xmul % 16) == 0));
   CLSR_CHECK_SUPPORTED(clsr_pgemm_dw_wide_supported(M, K, N));
@@ -191,11 +222,27 @@ extern "C" int clsr_pgemm_dw_wide(const float* X, int ldx, const float* Xmul, in
   a.part = workspace;
   a.bpart = db ? workspace + (long)dww_parts(M, K, N) * K * N : nullptr;
   const size_t shmem = (size_t)4 * DWW_STAGE * sizeof(float);
-  CLSR_HIP(hipFuncSetAttribute((const void*)dw_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(dw_wide_kernel, dim3(a.S, clsr_cdiv(K, 128), clsr_cdiv(N, 128)), dim3(256), shmem, (hipStream_t)stream, a);
+  const dim3 grid(a.S, clsr_cdiv(K, 128), clsr_cdiv(N, 128));
+  if (!x3) {
+    CLSR_HIP(hipFuncSetAttribute((const void*)dw_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(dw_wide_kernel<false>, grid, dim3(256), shmem, (hipStream_t)stream, a);
+  } else {
+    CLSR_HIP(hipFuncSetAttribute((const void*)dw_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(dw_wide_kernel<true>, grid, dim3(256), shmem, (hipStream_t)stream, a);
+  }
   CLSR_CHECK_LAUNCH();
   hipLaunchKernelGGL(dw_wide_reduce_kernel, dim3(clsr_cdiv((long)K * N / 4, 256)), dim3(256), 0, (hipStream_t)stream,
                      a.part, a.bpart, a.S, K, N, dW, ldw, db, accumulate);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
+}
+
+extern "C" int clsr_pgemm_dw_wide(const float* X, int ldx, const float* Xmul, int ldmul, const float* dY, int ldy, long M, int K,
+                                  int N, float* workspace, float* dW, int ldw, float* db, int accumulate, void* stream) {
+  return dw_wide_any(X, ldx, Xmul, ldmul, dY, ldy, M, K, N, workspace, dW, ldw, db, accumulate, false, stream);
+}
+// the same with the products as split-bf16 sums (2^-16 relative per term; bias sums stay exact fp32 sums)
+extern "C" int clsr_pgemm_dw_wide_x3(const float* X, int ldx, const float* Xmul, int ldmul, const float* dY, int ldy, long M, int K,
+                                     int N, float* workspace, float* dW, int ldw, float* db, int accumulate, void* stream) {
+  return dw_wide_any(X, ldx, Xmul, ldmul, dY, ldy, M, K, N, workspace, dW, ldw, db, accumulate, true, stream);
 }

@@ -219,6 +219,10 @@ class CLSRNet(object):
         self.heads_fused = not os.environ.get("CLSR_NO_HEADS_FUSED")
         # weight gradients of wide layers (K, N >= 96: BASELINE configs[4]) by the 128 x 128-tile kernel (csrc/dwwide.hip)
         self.dw_wide = not os.environ.get("CLSR_NO_DW_WIDE")
+        # ... as split-bf16 products like the other weight gradients of the default modes (CLSR_DW_WIDE_FP32=1 / CLSR_EXACT_PRODUCTS=1:
+        # fp32-input MFMAs)
+        self.dw_wide_entry = ("clsr_pgemm_dw_wide" if (self.exact_products or os.environ.get("CLSR_DW_WIDE_FP32"))
+                              else "clsr_pgemm_dw_wide_x3")
         self._dw_batch_wide = None
         self._heads_defer = False
         self._early_lists = None
@@ -738,7 +742,7 @@ class CLSRNet(object):
             side = self._side_stream("@dw0")
             ops.stream_wait(side, self._fork_point())
             self._dw_async = True
-        call("clsr_pgemm_dw_wide", *job, stream=side.cuda_stream if side is not None else None)
+        call(self.dw_wide_entry, *job, stream=side.cuda_stream if side is not None else None)
 
     @contextlib.contextmanager
     def _dw_batched(self, late=False):
@@ -776,13 +780,13 @@ class CLSRNet(object):
             if jobs:
                 ops.dw_multi(name, jobs, stream=side.cuda_stream)
             for job in wide:
-                call("clsr_pgemm_dw_wide", *job, stream=side.cuda_stream)
+                call(self.dw_wide_entry, *job, stream=side.cuda_stream)
             self._dw_async = True
         else:
             if jobs:
                 ops.dw_multi(name, jobs)
             for job in wide:
-                call("clsr_pgemm_dw_wide", *job)
+                call(self.dw_wide_entry, *job)
 
     def _x3_site(self, wkey):
         """does the product with the packed weights ``wkey`` run as a split-bf16 product (fp32x3 mode)?"""
