@@ -52,23 +52,43 @@ __global__ void __launch_bounds__(64) att_out_fwd_kernel(AttOutArgs a) {
   if (tsC < tparC) { sc = ld4(a.scale1 + 4 * qC); sh = ld4(a.shift1 + 4 * qC); wo = ld4(a.w_out + 4 * qC); }
   const float b_out = a.b_out[0];
   const long R = (long)a.Hn * a.G;
+  // NU row pieces in flight per lane and trip (one load per trip made this launch a chain of ~T / tparC dependent round trips per
+  // row -- 64-82 us in the step for 164 MB).  Measured in round 5 (scripts: build_variant.sh -DATT_OUT_NU=9
+  // -DATT_OUT_EARLY_KEYS=1): with nine pieces ONE trip covers a row at T = 50 and the key rows of the weighted sum -- which do
+  // not depend on the scores -- can be requested before the scores are computed: the launch drops from 89 to 52 us, the step
+  // does not move (2.670 / 2.680 / 2.667 against 2.677 / 2.672 / 2.652 ms, same box): four pieces, keys behind the softmax stay.
+#ifndef ATT_OUT_NU
+#define ATT_OUT_NU 4
+#endif
+#ifndef ATT_OUT_EARLY_KEYS
+#define ATT_OUT_EARLY_KEYS 0
+#endif
+  constexpr int NU = ATT_OUT_NU;
   for (long r = blockIdx.x; r < R; r += gridDim.x) {
     const long h = r / a.G;
     const int len = a.seq_len[h * a.len_stride];
+    const float* kp = a.keys + h * T * Dk + 4 * qD;
+    const int tend = len > 0 ? len : T;
+    f32x4 kv[NU];
+    if (ATT_OUT_EARLY_KEYS && tsD < tparD) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int t = tsD + u * tparD;
+        kv[u] = ld4(kp + (long)(t < tend ? t : tend - 1) * Dk);
+      }
+    }
     // (1) partial scores in column layout
     if (tsC < tparC) {
       const long zo = r * T * C1 + 4 * qC;
-      // (four row pieces in flight per lane: one load per trip made this launch a chain of ~T / tparC dependent round
-      // trips per row -- 64-82 us in the step for 164 MB)
-      for (int t0 = tsC; t0 < T; t0 += 4 * tparC) {
-        f32x4 v[4];
+      for (int t0 = tsC; t0 < T; t0 += NU * tparC) {
+        f32x4 v[NU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NU; ++u) {
           const int t = t0 + u * tparC;
           v[u] = load4e<ZH>(a.z1, zo + (long)(t < T ? t : T - 1) * C1);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NU; ++u) {
           const int t = t0 + u * tparC;
           if (t < T) sbuf[t * QC + qC] = dot4(relu4(v[u] * sc + sh), wo);
         }
@@ -113,17 +133,16 @@ __global__ void __launch_bounds__(64) att_out_fwd_kernel(AttOutArgs a) {
     // (3) weighted sum of the keys in column layout
     f32x4 acc = {0, 0, 0, 0};
     if (tsD < tparD) {
-      const float* kp = a.keys + h * T * Dk + 4 * qD;
-      const int tend = len > 0 ? len : T;
-      for (int t0 = tsD; t0 < tend; t0 += 4 * tparD) {
-        f32x4 kv[4];
+      for (int t0 = tsD; t0 < tend; t0 += NU * tparD) {
+        if (!ATT_OUT_EARLY_KEYS || t0 != tsD) {       // (the first trip's rows were requested at the top)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int t = t0 + u * tparD;
-          kv[u] = ld4(kp + (long)(t < tend ? t : tend - 1) * Dk);
+          for (int u = 0; u < NU; ++u) {
+            const int t = t0 + u * tparD;
+            kv[u] = ld4(kp + (long)(t < tend ? t : tend - 1) * Dk);
+          }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NU; ++u) {
           const int t = t0 + u * tparD;
           if (t < tend) acc += kv[u] * wl[t];
         }
