@@ -313,10 +313,12 @@ def embedding_rooflines(net, f, cfg, G, feed):
         bf = int(d.dtype == torch.bfloat16)
         tail_i = (1, dtarget.data_ptr(), 0, n, D, 0) if merged else (0,)
         tail_c = (1, dtarget.data_ptr(), 0, n, D, Di) if merged else (0,)
+        wch = getattr(net, "border_wch", lambda V, n_: 0)      # (the hint the step passes: chunks per wave of the border launch)
+        pad = lambda t: t + (0,) * (6 - len(t))
         return [(d.data_ptr(), 0, 0, 0, keys_i.data_ptr(), perm_i.data_ptr(), f["seq_len"].data_ptr(), tg["item"].data_ptr(), 0,
-                 ne, bf, G, T, D, 0, Di, 3, Di, 0) + tail_i,
+                 ne, bf, G, T, D, 0, Di, 3, Di, 0) + pad(tail_i) + (wch(tg["item"].shape[0], ne), 0),
                 (d.data_ptr(), 0, 0, 0, keys_c.data_ptr(), perm_c.data_ptr(), f["seq_len"].data_ptr(), tg["cate"].data_ptr(), 0,
-                 ne, bf, G, T, D, Di, Dc, 3, Dc, 0) + tail_c]
+                 ne, bf, G, T, D, Di, Dc, 3, Dc, 0) + pad(tail_c) + (wch(tg["cate"].shape[0], ne), 0)]
 
     def bwd(d, only_item):
         rows = site_rows(d)[:1] if only_item else site_rows(d)
@@ -349,8 +351,12 @@ def embedding_rooflines(net, f, cfg, G, feed):
                         formula="n*W*%d (gradient read) + n*W*4 (fp32 row-gradient write) + 2*n*4 (+ the target rows' slices)"
                                 % sa, columns=W, sites_merged=bool(merged))
         if tag == "gather_bwd_item_and_category_one_stream":
-            out[tag].update(traffic=203.7e6, traffic_source="profiles/r05_embed_kernel_trace.md, counters in KiB (48 dispatches, fp32 and bf16 "
-                                                            "d(hist) alternating: ss_chunks_lean 200.4 MB + ss_borders 3.8 MB per launch = WRITE_SIZE + 2 x FETCH_SIZE)")
+            out[tag].update(traffic=204.1e6, traffic_source="profiles/r05g_embed_kernel_trace.md, counters in KiB (48 dispatches, fp32 and bf16 "
+                                                            "d(hist) alternating: ss_chunks_lean 200.4 MB + ss_borders 3.7 MB per launch = WRITE_SIZE + 2 x FETCH_SIZE)")
+        elif tag == "gather_bwd":
+            out[tag].update(traffic=165.3e6, traffic_source="profiles/r05g_item_embed_kernel_trace.md, counters in KiB (item site alone, 48 "
+                                                            "dispatches, fp32 and bf16 d(hist) alternating: ss_chunks_lean 165.1 MB + ss_borders 0.2 MB; "
+                                                            "the border launch tests 64 chunks per wave here: clsr_segsum_desc.border_wch)")
         clear_grads()
     # ---- bf16 tables + bf16 hist: bytes_gather_fwd(n) = n*D*(2 + 2) + 2*n*4
     try:

@@ -251,6 +251,9 @@ extern "C" int clsr_sort_ids_stable_multi(const clsr_sortids_desc* descs, int n,
 #ifndef SS_CHUNK
 #define SS_CHUNK 32                 // sorted entries per thread group
 #endif
+#ifndef SS_LEAN_B
+#define SS_LEAN_B 8                 // entries of a chunk in flight per thread group in the LEAN instantiation (8 or 16; SS_CHUNK % SS_LEAN_B == 0)
+#endif
 #ifndef SS_WCH
 #define SS_WCH 1                    // chunks a wave of the border launch is responsible for (8: 20 us instead of 12 on the catalogue -- the category site has a head in most chunks and a wave walks its heads one after the other)
 #endif
@@ -264,6 +267,7 @@ struct SsSite {
   const float* src_b; double* sumsq_b; long n1; int ldb; int colb;   // second source (entries with perm >= n1), n1 = 0: none
   float* bnd; int* meta; double* ssp;   // workspace: chunk-border partials [nchunks][2][Cp], [nchunks][4] ints, [blocks][2] doubles
   int first_block; int nblocks; int first_block_b; int cp; int vw;
+  int wch;                        // chunks per wave of the border launch (clsr_segsum_desc.border_wch)
 };
 struct SsArgs { SsSite s[CLSR_SEGSUM_MAX]; int n; };
 
@@ -298,7 +302,7 @@ __device__ __forceinline__ void ss_ld8(const int* __restrict__ a, const long q0,
 // are stored (assign): four registers per entry in flight instead of twenty -- the kernel is bound by the number of row
 // reads it keeps in flight (profiles/r04_embed_kernel_trace.md: traffic = the algorithmic bytes at 3 TB/s), and with 240
 // VGPRs only two waves per SIMD were resident.
-template <int VW, bool LEAN>
+template <int VW, bool LEAN, int SB = 8>
 __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block, double* red) {
   typedef typename SsVec<VW>::type vec_t;
   const int CP = s.cp;                         // lanes per thread group (power of two, 8..64)
@@ -333,25 +337,25 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
     };
     // keys / slice numbers of a batch of eight are fetched ONE BATCH AHEAD (two 16-byte loads each): the row reads of a
     // batch depend on them, and with both fetched in the batch itself every batch paid two memory round trips in a row
-    int keyN[8], posN[8];
-    ss_ld8(s.keys, p0, pe, -1, keyN);
-    ss_ld8(s.perm, p0, pe, 0, posN);
-    for (long q0 = p0; q0 < pe; q0 += 8) {
-      int key[8], posk[8];
-      bool sec[8];
-      vec_t g[8];
+    int keyN[SB], posN[SB];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { key[k] = keyN[k]; posk[k] = posN[k]; }
+    for (int b8 = 0; b8 < SB; b8 += 8) { ss_ld8(s.keys, p0 + b8, pe, -1, keyN + b8); ss_ld8(s.perm, p0 + b8, pe, 0, posN + b8); }
+    for (long q0 = p0; q0 < pe; q0 += SB) {
+      int key[SB], posk[SB];
+      bool sec[SB];
+      vec_t g[SB];
+#pragma unroll
+      for (int k = 0; k < SB; ++k) { key[k] = keyN[k]; posk[k] = posN[k]; }
       // every load of the batch is UNCONDITIONAL, from a selected / clamped address, and the shares are combined afterwards:
       // with a branch per source (second list, mean / recent shares behind the sequence length) the loads of the eight
       // entries left one branch at a time -- in the step (mean and recent shares present) this launch took 84 us against
       // 28 us for the bare rows
-      vec_t rv[8], r2[8], mv[8], rc[8];
-      int ln[8], tt[8];
+      vec_t rv[SB], r2[SB], mv[SB], rc[SB];
+      int ln[SB], tt[SB];
       const bool has_mr = !LEAN && (s.dmean || s.drecent);          // (launch-uniform, like src2 / src_bf16)
       const int cs = cok ? c : 0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < SB; ++k) {
         const int pos = posk[k];
         const bool second = s.n1 > 0 && pos >= s.n1;          // (uniform inside the thread group)
         sec[k] = second;
@@ -378,7 +382,7 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
         if (!LEAN && s.drecent) rc[k] = *reinterpret_cast<const vec_t*>(s.drecent + (long)h * s.D + cc);
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < SB; ++k) {
         vec_t v = rv[k];
         if (!sec[k]) {
           if (!LEAN && s.src2) v += r2[k];
@@ -390,25 +394,25 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
         }
         g[k] = (cok && key[k] >= 0) ? v : vec_t(0.f);
       }
-      if (q0 + 8 < pe) {
-        ss_ld8(s.keys, q0 + 8, pe, -1, keyN);
-        ss_ld8(s.perm, q0 + 8, pe, 0, posN);
+      if (q0 + SB < pe) {
+#pragma unroll
+        for (int b8 = 0; b8 < SB; b8 += 8) { ss_ld8(s.keys, q0 + SB + b8, pe, -1, keyN + b8); ss_ld8(s.perm, q0 + SB + b8, pe, 0, posN + b8); }
       } else {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { keyN[k] = -1; posN[k] = 0; }
+        for (int k = 0; k < SB; ++k) { keyN[k] = -1; posN[k] = 0; }
       }
       const int knext = keyN[0];
       // the gradient rows of all eight entries' ids are requested NOW, whether or not a run ends there: a run that ends
       // inside the chunk is added to its row with a read-modify-write, and one dependent row read per run end, one after
       // the other along the walk, made this launch 110 us for 640 chunks
       // (assign: the rows are known to be zero and this call is their only writer -- no row read at all)
-      vec_t gv[8];
+      vec_t gv[SB];
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
+      for (int k = 0; k < SB; ++k)
         gv[k] = (LEAN || s.assign) ? vec_t(0.f)
                          : *reinterpret_cast<const vec_t*>(s.grad + (long)(key[k] < 0 ? 0 : key[k]) * s.ldg + s.gcol0 + (cok ? c : 0));
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < SB; ++k) {
         if (key[k] < 0) continue;
         if (sec[k]) local_b += ss_sq(g[k]);
         else local += ss_sq(g[k]);
@@ -421,8 +425,8 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
         }
         // does the run end at this entry?  (the last entry of the chunk leaves its run open: see below)
         int nk = key[k];
-        if (k < 7) { if (key[k + 1] >= 0) nk = key[k + 1]; }
-        else if (q0 + 8 < pe) nk = knext;
+        if (k < SB - 1) { if (key[k + 1] >= 0) nk = key[k + 1]; }
+        else if (q0 + SB < pe) nk = knext;
         if (nk != key[k]) {
           const bool from_prev = nruns == 0 && cur == prev_key;
           if (cok) {
@@ -474,7 +478,7 @@ __global__ void __launch_bounds__(256) ss_chunks_lean_kernel(SsArgs a) {
   int i = 0;
   while (i + 1 < a.n && (int)blockIdx.x >= a.s[i + 1].first_block) ++i;
   const SsSite& s = a.s[i];
-  if (s.vw == 4) ss_chunks<4, true>(s, blockIdx.x - s.first_block, red);
+  if (s.vw == 4) ss_chunks<4, true, SS_LEAN_B>(s, blockIdx.x - s.first_block, red);
   else ss_chunks<1, true>(s, blockIdx.x - s.first_block, red);
 }
 
@@ -496,12 +500,13 @@ __device__ __forceinline__ void ss_borders(const SsSite& s, const int local_bloc
   const long nchunks = (s.n + SS_CHUNK - 1) / SS_CHUNK;
   // a wave tests SS_WCH consecutive chunks at once (one lane each) and walks the heads among them: with one wave per chunk
   // the launch cost 11.7 us on a catalogue with hardly any run across a border (1 760 workgroups that read one flag word)
-  const long cbase = ((long)local_block * 4 + wave) * SS_WCH;
+  const int WCH = s.wch;
+  const long cbase = ((long)local_block * 4 + wave) * WCH;
   unsigned long long heads = 0;
   {
     const long ck = cbase + lane;
     int fl = 0;
-    if (lane < SS_WCH && ck < nchunks) fl = s.meta[ck * 4 + 2];
+    if (lane < WCH && ck < nchunks) fl = s.meta[ck * 4 + 2];
     heads = __ballot((fl & 2) && !((fl & 4) && (fl & 1)));
   }
   while (heads) {
@@ -580,7 +585,17 @@ __device__ __forceinline__ void ss_borders(const SsSite& s, const int local_bloc
     double* dst = wave == 0 ? s.sumsq : s.sumsq_b;
     if (dst) {
       double t = 0.0;
-      for (int b = lane; b < s.nblocks; b += 64) t += s.ssp[2 * b + wave];
+      // (eight partials of a lane in flight; the same order of additions as one after the other)
+      for (int b0 = lane; b0 < s.nblocks; b0 += 64 * 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int b = b0 + 64 * u;
+          v[u] = b < s.nblocks ? s.ssp[2 * b + wave] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += v[u];
+      }
       double tot = 0.0;
       for (int l = 0; l < 64; ++l) tot += __shfl(t, l, 64);
       if (lane == 0) *dst += tot;
@@ -665,7 +680,8 @@ extern "C" int clsr_segsum_multi(const clsr_segsum_desc* descs, int n, void* wor
     s.nblocks = nb;
     total += nb;
     s.first_block_b = total_b;
-    total_b += clsr_cdiv(nchunks, 4 * SS_WCH);
+    s.wch = d.border_wch <= 0 ? SS_WCH : (d.border_wch > 64 ? 64 : d.border_wch);
+    total_b += clsr_cdiv(nchunks, 4 * s.wch);
   }
   CLSR_CHECK_ARG(workspace_bytes >= used + 16);
   hipStream_t st = (hipStream_t)stream;

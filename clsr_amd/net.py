@@ -2559,7 +2559,9 @@ class CLSRNet(object):
                     # second source = the target rows' gradients [B, D] (same column slice), their squared norms in the
                     # target site's slot (2 item, 3 category); every row is written once: stored
                     row += (1, dtarget.data_ptr(), ss[slot + 2:].data_ptr(), n, self.D, col0)
-                rows.append(row)
+                else:
+                    row += (0, 0, 0, 0, 0, 0)
+                rows.append(row + (self.border_wch(V, ne), 0))
             self._segsum("hist." + (only or "all"), rows)
             return
         for name, _, V, col0, C, slot in self._sort_tables():
@@ -2571,6 +2573,12 @@ class CLSRNet(object):
             for c0 in range(0, C, blk):   # column blocks; squared norms accumulate in the slot
                 call("clsr_gather_bwd_sorted2", dhist, dhist2, dM, dR, keys, perm, seq_len, ls, n, T, self.D, col0 + c0,
                      min(blk, C - c0), k, self.tab_grad[name], C, c0, ss[slot:])
+
+    @staticmethod
+    def border_wch(V, n):
+        """clsr_segsum_desc.border_wch: chunks per wave of the segmented sums' border launch -- 64 when the ids are spread
+        over a table much larger than the list (hardly any run crosses a chunk border), else 1 (see include/clsr_hip.h)."""
+        return 64 if V >= 32 * n else 1
 
     #: tables with more elements than this are regularised / lazily updated through the compacted list of
     #: their involved rows instead of a sweep over all V*C elements (100M-item catalogues)

@@ -380,7 +380,7 @@ class SegsumDesc(ctypes.Structure):
     _fields_ = [("src", _P), ("src2", _P), ("dmean", _P), ("drecent", _P), ("keys", _P), ("perm", _P), ("seq_len", _P),
                 ("grad", _P), ("sumsq", _P), ("n", _L), ("src_bf16", _I), ("len_stride", _I), ("T", _I), ("D", _I),
                 ("col0", _I), ("C", _I), ("recent_k", _I), ("ldg", _I), ("gcol0", _I), ("assign", _I),
-                ("src_b", _P), ("sumsq_b", _P), ("n1", _L), ("ldb", _I), ("colb", _I)]
+                ("src_b", _P), ("sumsq_b", _P), ("n1", _L), ("ldb", _I), ("colb", _I), ("border_wch", _I), ("pad_", _I)]
 
 
 def segsum_descs(rows):

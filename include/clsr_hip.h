@@ -113,6 +113,11 @@ typedef struct clsr_segsum_desc {
    * same sorted list as the history lookup's (clsr_sortids_desc.ids2) */
   int assign;
   const float* src_b; double* sumsq_b; long n1; int ldb; int colb;
+  /* chunks of 32 sorted entries one WAVE of the border launch tests (0 = 1; up to 64).  A hint: with ids spread over a table
+   * much larger than the list (100M-item catalogue) hardly any run crosses a chunk border and the border launch is 1 760
+   * workgroups that read one flag word each (12 of the launch pair's 45 us); with 64 it is 28 workgroups.  Lists with many
+   * long runs (Zipf ids, small tables) want 1: a wave walks its heads one after the other. */
+  int border_wch; int pad_;
 } clsr_segsum_desc;
 int clsr_sizeof_segsum_desc(void);
 long clsr_segsum_workspace_bytes(const clsr_segsum_desc* descs_host, int n);

@@ -104,12 +104,14 @@ def main():
         t = timeit(lambda: ops.sort_ids_stable_multi(rows, wss), iters=5)
         print("stable radix sort of 2 x %d ids (27 / 14 bits): %8.1f us" % (n + B, t))
         dhist, dtarget = torch.randn(n, D, device=dev) * 1e-3, torch.randn(B, D, device=dev) * 1e-3
+        from clsr_amd.net import CLSRNet
+        wch = (lambda V, n_: 0) if os.environ.get("EMBED_NO_WCH") else CLSRNet.border_wch      # the step's hint (border launch)
         for tag, d, sa in (("fp32 d(hist)", dhist, 4), ("bf16 d(hist)", dhist.to(torch.bfloat16), 2)):
             bf = int(d.dtype == torch.bfloat16)
             sites = [(d.data_ptr(), 0, 0, 0, keys[0].data_ptr(), perm[0].data_ptr(), ln.data_ptr(), gi.data_ptr(), 0, n + B, bf,
-                      1, T, D, 0, Di, 3, Di, 0, 1, dtarget.data_ptr(), 0, n, D, 0),
+                      1, T, D, 0, Di, 3, Di, 0, 1, dtarget.data_ptr(), 0, n, D, 0, wch(Vi, n + B), 0),
                      (d.data_ptr(), 0, 0, 0, keys[1].data_ptr(), perm[1].data_ptr(), ln.data_ptr(), gc.data_ptr(), 0, n + B, bf,
-                      1, T, D, Di, Dc, 3, Dc, 0, 1, dtarget.data_ptr(), 0, n, D, Di)]
+                      1, T, D, Di, Dc, 3, Dc, 0, 1, dtarget.data_ptr(), 0, n, D, Di, wch(Vc, n + B), 0)]
             which_sites = os.environ.get("EMBED_SITES", "both")
             sites = sites[:1] if which_sites == "item" else sites[1:] if which_sites == "cate" else sites
             wsg = torch.empty(ops.segsum_workspace_bytes(sites), dtype=torch.uint8, device=dev)
