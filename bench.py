@@ -354,9 +354,9 @@ def embedding_rooflines(net, f, cfg, G, feed):
             out[tag].update(traffic=204.1e6, traffic_source="profiles/r05g_embed_kernel_trace.md, counters in KiB (48 dispatches, fp32 and bf16 "
                                                             "d(hist) alternating: ss_chunks_lean 200.4 MB + ss_borders 3.7 MB per launch = WRITE_SIZE + 2 x FETCH_SIZE)")
         elif tag == "gather_bwd":
-            out[tag].update(traffic=165.3e6, traffic_source="profiles/r05g_item_embed_kernel_trace.md, counters in KiB (item site alone, 48 "
-                                                            "dispatches, fp32 and bf16 d(hist) alternating: ss_chunks_lean 165.1 MB + ss_borders 0.2 MB; "
-                                                            "the border launch tests 64 chunks per wave here: clsr_segsum_desc.border_wch)")
+            out[tag].update(traffic=165.3e6, traffic_source="profiles/r05g_item_embed_kernel_trace.md, counters in KiB (item site alone on independent "
+                                                            "uniform ids, 48 dispatches, fp32 and bf16 d(hist) alternating: ss_chunks_lean 165.1 MB + "
+                                                            "ss_borders 0.2 MB with 64 chunks per border wave; this feed's lists have a head in most chunks)")
         clear_grads()
     # ---- bf16 tables + bf16 hist: bytes_gather_fwd(n) = n*D*(2 + 2) + 2*n*4
     try:

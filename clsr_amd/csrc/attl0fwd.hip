@@ -47,7 +47,7 @@ template <> __device__ __forceinline__ void af_store_piece<__bf16>(__bf16* dst, 
 }
 
 template <int NZ, int NK, int NP, typename ST>      // NP = 0: fp32-input MFMAs; 1 / 2 / 3: bf16 pieces per operand (speed mode / x3 / x6 products)
-__global__ void __launch_bounds__(256, 2) att_l0_fwd_kernel(AttL0FwdArgs s) {
+__global__ void __launch_bounds__(256, (NK >= 8 && NP >= 2) ? 1 : 2) att_l0_fwd_kernel(AttL0FwdArgs s) {      // (K = 128 with two / three weight images: 110-151 KB of LDS, one workgroup per CU anyway)
   CLSR_CHAIN_PRIO();
   constexpr int PW = sizeof(ST) == 2 ? 8 : 4;      // values per 16-byte store piece
   ST* z0p = reinterpret_cast<ST*>(s.z0);
@@ -117,18 +117,18 @@ __global__ void __launch_bounds__(256, 2) att_l0_fwd_kernel(AttL0FwdArgs s) {
           ap[i] = to_h(v);
           if (i + 1 < NPI) v -= to_f(ap[i]);
         }
-        bf16x8 w[NPI][NZ];
+        // every piece product whose indices sum to <= NP - 1; ONE weight piece in registers at a time, the smaller x pieces
+        // first (all pieces of the five tiles at once were 60 VGPRs: the K = 128 instance spilled)
 #pragma unroll
-        for (int i = 0; i < NPI; ++i)
+        for (int wp = NPI - 1; wp >= 0; --wp) {
+          bf16x8 w[NZ];
 #pragma unroll
-          for (int z = 0; z < NZ; ++z) w[i][z] = ld8h(Wh + (size_t)i * ZP * WS + ldsH + woff + z * 16 * WS + 32 * c);
-        // every piece product whose indices sum to <= NP - 1, smallest terms first
+          for (int z = 0; z < NZ; ++z) w[z] = ld8h(Wh + (size_t)wp * ZP * WS + ldsH + woff + z * 16 * WS + 32 * c);
 #pragma unroll
-        for (int sidx = NPI - 1; sidx >= 0; --sidx)
+          for (int i = NPI - 1 - wp; i >= 0; --i)
 #pragma unroll
-          for (int i = 0; i <= sidx; ++i)
-#pragma unroll
-            for (int z = 0; z < NZ; ++z) HMFMA(acc[z], ap[i], w[sidx - i][z]);
+            for (int z = 0; z < NZ; ++z) HMFMA(acc[z], ap[i], w[z]);
+        }
       }
     } else {
       const float* lb = ldsB + woff;
@@ -361,11 +361,12 @@ static int af_grid(long Hn) {
   long gx = (Hn + 3) / 4;
   return (int)(gx > 512 ? 512 : gx);
 }
-static int af_class(int n) { return n <= 48 ? 3 : 5; }
+static int af_class(int n) { return n <= 48 ? 3 : (n <= 80 ? 5 : 8); }
 
 // 1 when clsr_att_l0_fwd handles this shape (otherwise: clsr_pgemm with Xmul / addU / addV)
 extern "C" int clsr_att_l0_fwd_supported(int G, int Q, int A0) {
-  return G >= 1 && G <= AF_GMAX && Q >= 4 && Q <= 80 && A0 >= 4 && A0 <= 80 && Q % 4 == 0 && A0 % 4 == 0;
+  // (Q up to 128: the per-row half of the short-term query of 128-wide layers, BASELINE configs[4])
+  return G >= 1 && G <= AF_GMAX && Q >= 4 && Q <= 128 && A0 >= 4 && A0 <= 80 && Q % 4 == 0 && A0 % 4 == 0;
 }
 // number of per-block partial rows the statistics buffer receives: [parts][2][A0] doubles
 extern "C" int clsr_att_l0_fwd_stats_parts(long Hn) { return af_grid(Hn); }
@@ -400,7 +401,7 @@ static int att_l0_fwd_any(const float* a, int lda, const float* q, int ldq, cons
   if (nz == Z && nk == K) \
     return pieces == 3 ? att_l0_fwd_launch<Z, K, 3>(s, st) : pieces == 2 ? att_l0_fwd_launch<Z, K, 2>(s, st) \
          : pieces == 1 ? att_l0_fwd_launch<Z, K, 1, __bf16>(s, st) : att_l0_fwd_launch<Z, K, 0>(s, st)
-  AF_GO(3, 3); AF_GO(3, 5); AF_GO(5, 3); AF_GO(5, 5);
+  AF_GO(3, 3); AF_GO(3, 5); AF_GO(5, 3); AF_GO(5, 5); AF_GO(3, 8); AF_GO(5, 8);
 #undef AF_GO
   return CLSR_OK;
 }

@@ -6,6 +6,7 @@
 // pieces of W from LDS, 96 bf16 MFMAs per 16 positions (two pieces per operand: the result feeds sigmoid gates, like the
 // recurrences' own split products), a lane of the result holds four positions of one output feature and stores them as
 // 4-byte pieces of 64-byte row segments (csrc/attl1fwd.hip).
+#include <stdlib.h>
 #include "common.h"
 #include "clsr_hip.h"
 #include "hmma.h"
@@ -26,17 +27,21 @@ struct ProjArgs {
 };
 
 // NKC = 32-wide chunks of K, NT = 16-feature tiles of N, NP = bf16 pieces per operand
+// Workgroups of 256 threads, or of 512 when the weight images leave room for only ONE workgroup per CU (three pieces of a
+// 128 x 128 block: 104 KB): eight waves then share the image -- two per SIMD instead of one, which is what hides the latency
+// of the X tile loads (one tile of prefetch) and of the stores.
 template <int NKC, int NT, int NP, bool TTF = false>
-__global__ void __launch_bounds__(256, 2) proj_x3_kernel(ProjArgs a) {
+__global__ void __launch_bounds__(512) proj_x3_kernel(ProjArgs a) {
   CLSR_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int WS = 32 * NKC + 8, NR = 16 * NT;
+  const int nthr = blockDim.x, nwv = nthr >> 6;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int j = lane & 15, g = lane >> 4;
   __bf16* Wi = reinterpret_cast<__bf16*>(lds_raw);          // [NP][NR][WS]
   float* ttab = reinterpret_cast<float*>(lds_raw + (size_t)NP * NR * WS * 2);      // TTF: [2][32 NKC] weight / bias of a time-feature column
   if (TTF) {
-    for (int e = tid; e < 32 * NKC; e += 256) {
+    for (int e = tid; e < 32 * NKC; e += nthr) {
       const int k = e - a.col0;
       float w = 0.f, b = 0.f;
       if (k >= 0 && k < a.n) { w = a.w1[k]; b = a.b1[k]; }
@@ -50,7 +55,7 @@ __global__ void __launch_bounds__(256, 2) proj_x3_kernel(ProjArgs a) {
   const int Nb = a.N - n0 < NR ? a.N - n0 : NR;
   {
     constexpr int C8 = WS / 8;
-    for (int e = tid; e < NR * C8; e += 256) {
+    for (int e = tid; e < NR * C8; e += nthr) {
       const int row = e / C8, k = 8 * (e - row * C8);
       f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (row < Nb && k < a.K) v = ld8f(a.Wt + (long)(n0 + row) * a.Kp + k);     // (K % 8 == 0)
@@ -86,8 +91,8 @@ __global__ void __launch_bounds__(256, 2) proj_x3_kernel(ProjArgs a) {
   }
 
   const int ntiles = (a.M + 15) >> 4;
-  const int tstride = gridDim.x * 4;
-  int tile = blockIdx.x * 4 + wave;
+  const int tstride = gridDim.x * nwv;
+  int tile = blockIdx.x * nwv + wave;
   struct Raw { f32x8 x[NKC]; float tn, tf; };
   auto fetch = [&](int t) -> Raw {
     Raw r;
@@ -147,17 +152,19 @@ __global__ void __launch_bounds__(256, 2) proj_x3_kernel(ProjArgs a) {
         xp[i] = to_h(y);
         if (i + 1 < NP) y -= to_f(xp[i]);
       }
-      bf16x8 w[NP][NT];
+      // one weight piece in registers at a time (all NP pieces of the eight tiles were 96 VGPRs: with the accumulate form's
+      // tile in flight the three-piece 128-column instance spilled); every piece product whose indices sum to <= NP - 1,
+      // the smaller x pieces first
 #pragma unroll
-      for (int i = 0; i < NP; ++i)
+      for (int wp = NP - 1; wp >= 0; --wp) {
+        bf16x8 w[NT];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) w[i][n] = ld8h(Wi + (size_t)i * NR * WS + wrow + 16 * n * WS + 32 * c);
+        for (int n = 0; n < NT; ++n) w[n] = ld8h(Wi + (size_t)wp * NR * WS + wrow + 16 * n * WS + 32 * c);
 #pragma unroll
-      for (int sidx = NP - 1; sidx >= 0; --sidx)
+        for (int i = NP - 1 - wp; i >= 0; --i)
 #pragma unroll
-        for (int i = 0; i <= sidx; ++i)
-#pragma unroll
-          for (int n = 0; n < NT; ++n) HMFMA(acc[n], xp[i], w[sidx - i][n]);
+          for (int n = 0; n < NT; ++n) HMFMA(acc[n], xp[i], w[n]);
+      }
     }
     if (a.acc) {
 #pragma unroll
@@ -185,11 +192,14 @@ template <int NKC, int NT, int NP, bool TTF = false>
 static int proj_launch(const ProjArgs& a, hipStream_t stream) {
   constexpr int WS = 32 * NKC + 8, NR = 16 * NT;
   const size_t shmem = (size_t)NP * NR * WS * 2 + (TTF ? (size_t)2 * 32 * NKC * 4 : 0);
-  int gx = clsr_cdiv(clsr_cdiv(a.M, 16), 4);
-  if (gx > 512) gx = 512;
+  static const bool wide_wg = getenv("CLSR_PROJ_WG256") == nullptr;      // (A/B)
+  const int threads = (shmem > 80 * 1024 && wide_wg) ? 512 : 256;         // (more than half of the CU's 160 KB: one workgroup per CU)
+  int gx = clsr_cdiv(clsr_cdiv(a.M, 16), threads / 64);
+  const int cap = threads == 512 ? 256 : 512;
+  if (gx > cap) gx = cap;
   auto kernel = proj_x3_kernel<NKC, NT, NP, TTF>;
   if (shmem > 64 * 1024) CLSR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(kernel, dim3(gx, clsr_cdiv(a.N, NR)), dim3(256), shmem, stream, a);
+  hipLaunchKernelGGL(kernel, dim3(gx, clsr_cdiv(a.N, NR)), dim3(threads), shmem, stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }

@@ -1305,7 +1305,7 @@ class CLSRNet(object):
                 st = (self._buf("stats" + self._ws_tag, 1024 * 2 * 256, dtype=torch.float64)[: parts * 2 * A0]
                       if training else None)
                 Wt, Kp = self.packed[key + ".Wp2"]
-                call(self.att_l0_fwd_entry, a[:, qh:], Q, q[:, qh:], Q, Wt, Kp, U, A0, V, A0, z0, A0, st, Hn, G, T, Q - qh, A0)
+                call(self._att_l0_fwd_entry_for(Q - qh), a[:, qh:], Q, q[:, qh:], Q, Wt, Kp, U, A0, V, A0, z0, A0, st, Hn, G, T, Q - qh, A0)
             else:
                 self._gemm(a[:, qh:], Q, key + ".Wp2", R * T, Q - qh, A0, z0, A0, T=T, G=G, Xmul=q[:, qh:], ldmul=Q,
                            addU=U, ldu=A0, addV=V, ldv=A0, stats=st)
@@ -1315,7 +1315,7 @@ class CLSRNet(object):
             st = (self._buf("stats" + self._ws_tag, 1024 * 2 * 256, dtype=torch.float64)[: parts * 2 * A0]
                   if training else None)
             Wt, Kp = self.packed[key + ".Wp"]
-            call(self.att_l0_fwd_entry, a, Q, q, Q, Wt, Kp, U, A0, V, A0, z0, A0, st, Hn, G, T, Q, A0)
+            call(self._att_l0_fwd_entry_for(Q), a, Q, q, Q, Wt, Kp, U, A0, V, A0, z0, A0, st, Hn, G, T, Q, A0)
         else:
             self._gemm(a, Q, key + ".Wp", R * T, Q, A0, z0, A0, T=T, G=G, Xmul=q, ldmul=Q, addU=U, ldu=A0,
                        addV=V, ldv=A0, stats=st)
@@ -1517,6 +1517,14 @@ class CLSRNet(object):
                 call("clsr_att_z0_bwd_reduce", dz0, Hn, G, T, A0, None if G == 1 else dU, dV)
         return self._att_bwd_hist(key, scope, nn, a, q, keys, dkeys, dU, dV, da, dq, dW0, Hn, R, T, Dk, Q, qh,
                                   q_hist=q_hist, dq_hist=dq_hist)
+
+    def _att_l0_fwd_entry_for(self, K):
+        """Layer-0 forward entry for a product term of K query columns: wide layers (K > 80: BASELINE configs[4]) take the
+        three-piece form (fp32 accuracy on the bf16 pipe: 120 bf16 MFMAs per 16 positions where the fp32-input form issues
+        160 of twice the cost) unless bit-exact fp32 products are asked for."""
+        if K > 80 and not self.exact_products and self.att_l0_fwd_entry == "clsr_att_l0_fwd":
+            return "clsr_att_l0_fwd_x6"
+        return self.att_l0_fwd_entry
 
     def _bf16_chain_ok(self, G, Qe):
         """speed mode on the parity mode's chain kernels (one bf16 piece per operand, bf16 z0 / z1 / dz0)?"""
@@ -2576,9 +2584,14 @@ class CLSRNet(object):
 
     @staticmethod
     def border_wch(V, n):
-        """clsr_segsum_desc.border_wch: chunks per wave of the segmented sums' border launch -- 64 when the ids are spread
-        over a table much larger than the list (hardly any run crosses a chunk border), else 1 (see include/clsr_hip.h)."""
-        return 64 if V >= 32 * n else 1
+        """clsr_segsum_desc.border_wch: chunks per wave of the segmented sums' border launch.  With ids drawn independently
+        from a table much larger than the list, hardly any run crosses a chunk border and 64 chunks per wave take the launch
+        from 11.7 to 4.6 us (scripts/prof_kernels.py embed: 45.5 -> 38.5 us for the launch pair).  The table size is no
+        evidence for that, though: the benchmark's catalogue feed (sliding windows over user sequences: most ids occur a few
+        times) has a head in most chunks, a wave walks its heads one after the other, and the same hint costs 14 us there
+        (bench.py: 44-46 -> 58-59 us).  Default therefore: one chunk per wave; CLSR_BORDER_WCH=n for feeds known to be run-free."""
+        e = os.environ.get("CLSR_BORDER_WCH")
+        return int(e) if e else 0
 
     #: tables with more elements than this are regularised / lazily updated through the compacted list of
     #: their involved rows instead of a sweep over all V*C elements (100M-item catalogues)

@@ -104,8 +104,7 @@ def main():
         t = timeit(lambda: ops.sort_ids_stable_multi(rows, wss), iters=5)
         print("stable radix sort of 2 x %d ids (27 / 14 bits): %8.1f us" % (n + B, t))
         dhist, dtarget = torch.randn(n, D, device=dev) * 1e-3, torch.randn(B, D, device=dev) * 1e-3
-        from clsr_amd.net import CLSRNet
-        wch = (lambda V, n_: 0) if os.environ.get("EMBED_NO_WCH") else CLSRNet.border_wch      # the step's hint (border launch)
+        wch = lambda V, n_: int(os.environ.get("EMBED_WCH", "0"))      # clsr_segsum_desc.border_wch (independent uniform ids here: 64 pays)
         for tag, d, sa in (("fp32 d(hist)", dhist, 4), ("bf16 d(hist)", dhist.to(torch.bfloat16), 2)):
             bf = int(d.dtype == torch.bfloat16)
             sites = [(d.data_ptr(), 0, 0, 0, keys[0].data_ptr(), perm[0].data_ptr(), ln.data_ptr(), gi.data_ptr(), 0, n + B, bf,

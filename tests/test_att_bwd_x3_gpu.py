@@ -166,7 +166,8 @@ def test_layer1_backward_x3_two_passes_with_weight_gradient(M, C1, C0):
 
 @pytest.mark.parametrize("Hn,G,T,Q,A0", [(37, 5, 50, 80, 80), (64, 1, 50, 40, 80), (9, 8, 7, 44, 36), (6, 3, 17, 24, 40),
                                          (1, 5, 1, 80, 80), (2100, 2, 33, 48, 80), (11, 8, 18, 80, 80), (5, 4, 20, 40, 80),
-                                         (7, 5, 16, 80, 40), (3, 2, 8, 16, 16)])   # packed / unpacked ragged tiles
+                                         (7, 5, 16, 80, 40), (3, 2, 8, 16, 16),   # packed / unpacked ragged tiles
+                                         (37, 5, 50, 128, 80), (9, 3, 17, 96, 40)])   # K up to 128: the wide layers of configs[4]
 @pytest.mark.parametrize("entry,tol", [("clsr_att_l0_fwd_x3", 5e-5), ("clsr_att_l0_fwd_x6", 2e-6)])
 def test_layer0_forward_x3(Hn, G, T, Q, A0, entry, tol):
     """clsr_att_l0_fwd_x3: z0 = U[h,t] + V[r] + (a[h,t] * q[r]) . Wp with the product as split-bf16 sums: 2^-16 relative per

@@ -1048,7 +1048,7 @@ def test_attention_layer0_forward_one_wave_per_history(Hn, G, T, Q, A0):
     """clsr_att_l0_fwd: z0 = U[h,t] + V[r] + (a[h,t] * q[r]) . Wp with the batch-norm column sums == float64, and ==
     clsr_pgemm with the Xmul prologue / addU + addV epilogue (the kernel it replaces)."""
     assert query("clsr_att_l0_fwd_supported", G, Q, A0) == 1
-    assert query("clsr_att_l0_fwd_supported", 9, Q, A0) == 0 and query("clsr_att_l0_fwd_supported", G, 96, A0) == 0
+    assert query("clsr_att_l0_fwd_supported", 9, Q, A0) == 0 and query("clsr_att_l0_fwd_supported", G, 132, A0) == 0
     g = torch.Generator().manual_seed(Hn * 3 + T)
     R, M = Hn * G, Hn * G * T
     a, q = rnd(g, Hn * T, Q), rnd(g, R, Q)
