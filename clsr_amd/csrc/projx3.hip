@@ -237,6 +237,167 @@ extern "C" int clsr_proj_x3(const float* X, int ldx, const float* Wt, int Kp, co
                             int K, int N, int pieces, void* stream) {
   return proj_x3_any(X, ldx, Wt, Kp, bias, Y, ldy, M, K, N, pieces, 0, stream);
 }
+// ---- K beyond 128 in ONE launch: the accumulators of a wave's position tiles stay in registers while the workgroup walks the
+// K slabs of 128 input features -- per slab: the X pieces of the wave's tiles are requested, the workgroup re-stages the
+// slab's weight block (bf16 pieces) in LDS between two barriers, then the products.  Against the chain of accumulating
+// launches (clsr_proj_x3 per slab) the output is written once instead of read and written per slab, and d(hist) = dPin . W_x^T
+// of the 128-wide encoders (K = 1 536: five K-range launches of clsr_pgemm3 before, each re-reading and re-writing the
+// 105 MB output and 0.9 GB of dPin) reads dPin once.  TPW position tiles per wave: a slab's weight staging (64 KB from L2 +
+// the splits) is shared by 8 x TPW tiles.
+template <int NT, int NP, int TPW>
+__global__ void __launch_bounds__(512) proj_x3_kloop_kernel(ProjArgs a) {
+  CLSR_CHAIN_PRIO();
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int NKC = 4, WS = 32 * NKC + 8, NR = 16 * NT, C8 = WS / 8;
+  const int nthr = blockDim.x, nwv = nthr >> 6;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int j = lane & 15, g = lane >> 4;
+  __bf16* Wi = reinterpret_cast<__bf16*>(lds_raw);          // [NP][NR][WS]
+  const int n0 = blockIdx.y * NR;
+  const int Nb = a.N - n0 < NR ? a.N - n0 : NR;
+  float bias[NT];
+  unsigned co[NT];
+  constexpr unsigned SKIP = 0x40000000u;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const bool ok = 16 * n + j < Nb;
+    bias[n] = (ok && a.bias) ? a.bias[n0 + 16 * n + j] : 0.f;
+    co[n] = ok ? (n0 + 16 * n + j) * 4u : SKIP;
+  }
+  const int wrow = j * WS + 8 * g;
+  const __amdgpu_buffer_rsrc_t ry =
+      __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, ((unsigned)(a.M - 1) * (unsigned)a.ldy + (unsigned)a.N) * 4u, 0x00020000);
+  const f32x8 z8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int ntiles = (a.M + 15) >> 4;
+  const int ngroups = (ntiles + nwv * TPW - 1) / (nwv * TPW);
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {      // (block-uniform: every wave meets every barrier)
+    const int tile0 = (grp * nwv + wave) * TPW;
+    f32x4 acc[TPW][NT];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[t][n] = (f32x4){bias[n], bias[n], bias[n], bias[n]};
+    for (int k0 = 0; k0 < a.K; k0 += 32 * NKC) {
+      // the X pieces of this slab: in flight underneath the weight staging
+      f32x8 xr[TPW][NKC];
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const int m = (tile0 + t) * 16 + j;
+        const float* p = a.X + (long)(m < a.M ? m : a.M - 1) * a.ldx;
+#pragma unroll
+        for (int c = 0; c < NKC; ++c) {
+          const int k = k0 + 32 * c + 8 * g;
+          xr[t][c] = ld8f(p + (k < a.K ? k : 0));
+        }
+      }
+      __syncthreads();       // the previous slab's products have read their weights
+      for (int e = tid; e < NR * C8; e += nthr) {
+        const int row = e / C8, k = 8 * (e - row * C8);
+        f32x8 v = z8;
+        if (row < Nb && k < 32 * NKC && k0 + k < a.K) v = ld8f(a.Wt + (long)(n0 + row) * a.Kp + k0 + k);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          const bf16x8 h = to_h(v);
+          reinterpret_cast<bf16x8*>(Wi + (size_t)i * NR * WS)[e] = h;
+          v -= to_f(h);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < NKC; ++c) {
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 xp[TPW][NP];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          const bool pv = (tile0 + t) * 16 + j < a.M;
+          f32x8 y = (pv && k0 + 32 * c + 8 * g < a.K) ? xr[t][c] : z8;
+#pragma unroll
+          for (int i = 0; i < NP; ++i) {
+            xp[t][i] = to_h(y);
+            if (i + 1 < NP) y -= to_f(xp[t][i]);
+          }
+        }
+#pragma unroll
+        for (int wp = NP - 1; wp >= 0; --wp) {
+          bf16x8 w[NT];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) w[n] = ld8h(Wi + (size_t)wp * NR * WS + wrow + 16 * n * WS + 32 * c);
+#pragma unroll
+          for (int i = NP - 1 - wp; i >= 0; --i)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+#pragma unroll
+              for (int n = 0; n < NT; ++n) HMFMA(acc[t][n], xp[t][i], w[n]);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int m0 = (tile0 + t) * 16;
+      unsigned ro[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int p = m0 + 4 * g + e;
+        ro[e] = p < a.M ? (unsigned)p * (unsigned)a.ldy * 4u : SKIP;
+      }
+      if (a.acc) {
+        f32x4 old[NT];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            old[n][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, ro[e] + co[n], 0, 0));
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[t][n] += old[n];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const float v = acc[t][n][e];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, ro[e] + co[n], 0, 0);
+        }
+    }
+  }
+}
+
+template <int NT, int NP>
+static int proj_kloop_launch(const ProjArgs& a, hipStream_t stream) {
+  constexpr int TPW = 2, WS = 32 * 4 + 8, NR = 16 * NT;
+  const size_t shmem = (size_t)NP * NR * WS * 2;
+  const int threads = 512;
+  int gx = clsr_cdiv(clsr_cdiv(a.M, 16), (threads / 64) * TPW);
+  const int cap = shmem > 80 * 1024 ? 256 : 512;
+  if (gx > cap) gx = cap;
+  auto kernel = proj_x3_kloop_kernel<NT, NP, TPW>;
+  if (shmem > 64 * 1024) CLSR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL(kernel, dim3(gx, clsr_cdiv(a.N, NR)), dim3(threads), shmem, stream, a);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+
+static int proj_x3_kloop(const float* X, int ldx, const float* Wt, int Kp, const float* bias, float* Y, int ldy, int M,
+                         int K, int N, int pieces, int accumulate, void* stream) {
+  CLSR_CHECK_ARG(X && Wt && Y && (pieces == 2 || pieces == 3));
+  CLSR_CHECK_ARG(ldx >= K && ldy >= N && Kp >= 16 * clsr_cdiv(K, 16));
+  CLSR_CHECK_SUPPORTED(ldx % 4 == 0 && Kp % 4 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)Wt % 16) == 0 &&
+                       ((uintptr_t)Y % 4) == 0 && (long)ldy * 4 * 16 < 0x40000000L);
+  hipStream_t s = (hipStream_t)stream;
+  const int nt = N <= 48 ? 3 : (N <= 80 ? 5 : 8);
+  const long rows_max = ((0x40000000L - 1) / ((long)ldy * 4)) & ~15L;
+  for (long m0 = 0; m0 < M; m0 += rows_max) {
+    ProjArgs a = {};
+    a.X = X + m0 * ldx; a.ldx = ldx; a.Wt = Wt; a.Kp = Kp; a.bias = bias; a.Y = Y + m0 * ldy; a.ldy = ldy;
+    a.M = (int)(M - m0 < rows_max ? M - m0 : rows_max); a.K = K; a.N = N; a.acc = accumulate;
+    int rc = CLSR_EUNSUPPORTED;
+#define PK_GO(T) if (nt == T) rc = pieces == 2 ? proj_kloop_launch<T, 2>(a, s) : proj_kloop_launch<T, 3>(a, s)
+    PK_GO(3); PK_GO(5); PK_GO(8);
+#undef PK_GO
+    if (rc != CLSR_OK) return rc;
+  }
+  return CLSR_OK;
+}
+
 // K of any width (K % 8 == 0): slabs of 128 input features, the second and later ones accumulating into Y (launches on ONE
 // stream: each reads what the one before wrote).  Kp = row stride of the packed weights (>= K rounded up to 16).
 extern "C" int clsr_proj_x3_wide_supported(int M, int K, int N) {
@@ -246,6 +407,8 @@ extern "C" int clsr_proj_x3_wide_supported(int M, int K, int N) {
 extern "C" int clsr_proj_x3_wide(const float* X, int ldx, const float* Wt, int Kp, const float* bias, float* Y, int ldy, int M,
                                  int K, int N, int pieces, int accumulate, void* stream) {
   CLSR_CHECK_SUPPORTED(clsr_proj_x3_wide_supported(M, K, N));
+  static const bool slabs = getenv("CLSR_PROJ_SLABS") != nullptr;      // (A/B: the chain of accumulating launches)
+  if (K > 128 && !slabs) return proj_x3_kloop(X, ldx, Wt, Kp, bias, Y, ldy, M, K, N, pieces, accumulate, stream);
   for (int k0 = 0; k0 < K; k0 += 128) {
     const int kw = K - k0 < 128 ? K - k0 : 128;
     int rc = proj_x3_any(X + k0, ldx, Wt + k0, Kp, k0 ? nullptr : bias, Y, ldy, M, kw, N, pieces, (k0 || accumulate) ? 1 : 0, stream);

@@ -675,7 +675,7 @@ class CLSRNet(object):
             return
         Wt, Kp = self.packed[wkey]
         if (self.gemm_wide_x3 and Xmul is None and aff is None and addU is None and addV is None and stats is None and T == 0
-                and M >= 32768 and (K > 80 or N > 80) and K <= 384 and K % 8 == 0 and ldx % 4 == 0
+                and M >= 32768 and (K > 80 or N > 80) and K <= 4096 and K % 8 == 0 and ldx % 4 == 0
                 and query("clsr_proj_x3_wide_supported", M, K, N)):
             # plain position-level products of WIDE layers (BASELINE configs[4]): operands in registers, 128 output columns
             # per workgroup column, K in slabs of 128 (csrc/projx3.hip) -- the position-tiled fp32 kernel ran these at

@@ -344,7 +344,7 @@ def test_encoder_tail_back_projections(M, NX, D, H, tcol0):
     assert float((dhist[:, D:] - 7.0).abs().max()) == 0 and float((dTT[:, H2:] - 7.0).abs().max()) == 0
 
 
-@pytest.mark.parametrize("M,K,N", [(1000, 384, 384), (515, 136, 40), (70, 264, 132), (2000, 128, 120)])
+@pytest.mark.parametrize("M,K,N", [(1000, 384, 384), (515, 136, 40), (70, 264, 132), (2000, 128, 120), (3000, 1536, 128), (33, 200, 8)])
 @pytest.mark.parametrize("pieces", [2, 3])
 def test_projection_wide_k_in_slabs(M, K, N, pieces):
     """clsr_proj_x3_wide: K > 128 as slabs of 128 input features, the later slabs accumulating into Y == float64."""
