@@ -372,7 +372,8 @@ int clsr_proj_x3_tt(const float* hist, int D, const float* tnow, const float* tf
                     const float* w1, const float* b1, const float* w2, const float* b2, int n, int col0,
                     const float* Wt, int Kp, const float* bias, float* Y, int ldy, int M, int N, int pieces,
                     void* stream);
-/* ... for K of any width (K % 8 == 0): slabs of 128 input features, the later ones accumulating into Y on the same stream;
+/* ... for K of any width (K % 8 == 0) in ONE launch: the accumulators of a wave's position tiles stay in registers while its
+ * workgroup re-stages the weight block of each 128-wide K slab in LDS (csrc/projx3.hip: proj_x3_kloop_kernel);
  * accumulate != 0: Y += X . W + b.  The step routes every PLAIN position-level product of wide layers (K or N > 80:
  * BASELINE configs[4]) through it -- three bf16 pieces per operand in the parity mode (2^-23 relative: fp32 level) */
 int clsr_proj_x3_wide_supported(int M, int K, int N);
