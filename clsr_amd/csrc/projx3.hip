@@ -225,8 +225,11 @@ static int proj_x3_any(const float* X, int ldx, const float* Wt, int Kp, const f
     a.X = X + m0 * ldx; a.ldx = ldx; a.Wt = Wt; a.Kp = Kp; a.bias = bias; a.Y = Y + m0 * ldy; a.ldy = ldy;
     a.M = (int)(M - m0 < rows_max ? M - m0 : rows_max); a.K = K; a.N = N; a.acc = accumulate;
     int rc = CLSR_EUNSUPPORTED;
-    static const bool no_nloop = getenv("CLSR_PROJ_NO_NLOOP") != nullptr;      // (A/B: one workgroup column per 128-column block)
-    if (N > 256 && !accumulate && !no_nloop) {
+    // (opt-in: measured SLOWER than one workgroup column per 128-column block at 128 -> 1 152 with three pieces -- 727 + 77 us
+    //  against 650 + 130 us, catalogue step 9.26-9.36 against 9.17-9.22 ms: one tile per wave and two barriers per column block
+    //  cost more than the eight extra reads / splits of X save)
+    static const bool nloop = getenv("CLSR_PROJ_NLOOP") != nullptr;
+    if (N > 256 && !accumulate && nloop) {
 #define PN_GO(C) if (nkc == C) rc = pieces == 2 ? proj_nloop_launch<C, 2>(a, s) : proj_nloop_launch<C, 3>(a, s)
       PN_GO(1); PN_GO(2); PN_GO(3); PN_GO(4);
 #undef PN_GO
