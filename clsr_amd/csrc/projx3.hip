@@ -204,9 +204,6 @@ static int proj_launch(const ProjArgs& a, hipStream_t stream) {
   return CLSR_OK;
 }
 
-template <int NKC, int NP>
-static int proj_nloop_launch(const ProjArgs& a, hipStream_t stream);      // (below)
-
 // pieces = 2: 2^-16 relative per product term; 3: 2^-23
 static int proj_x3_any(const float* X, int ldx, const float* Wt, int Kp, const float* bias, float* Y, int ldy, int M,
                        int K, int N, int pieces, int accumulate, void* stream) {
@@ -225,17 +222,6 @@ static int proj_x3_any(const float* X, int ldx, const float* Wt, int Kp, const f
     a.X = X + m0 * ldx; a.ldx = ldx; a.Wt = Wt; a.Kp = Kp; a.bias = bias; a.Y = Y + m0 * ldy; a.ldy = ldy;
     a.M = (int)(M - m0 < rows_max ? M - m0 : rows_max); a.K = K; a.N = N; a.acc = accumulate;
     int rc = CLSR_EUNSUPPORTED;
-    // (opt-in: measured SLOWER than one workgroup column per 128-column block at 128 -> 1 152 with three pieces -- 727 + 77 us
-    //  against 650 + 130 us, catalogue step 9.26-9.36 against 9.17-9.22 ms: one tile per wave and two barriers per column block
-    //  cost more than the eight extra reads / splits of X save)
-    static const bool nloop = getenv("CLSR_PROJ_NLOOP") != nullptr;
-    if (N > 256 && !accumulate && nloop) {
-#define PN_GO(C) if (nkc == C) rc = pieces == 2 ? proj_nloop_launch<C, 2>(a, s) : proj_nloop_launch<C, 3>(a, s)
-      PN_GO(1); PN_GO(2); PN_GO(3); PN_GO(4);
-#undef PN_GO
-      if (rc != CLSR_OK) return rc;
-      continue;
-    }
 #define PJ_GO(C, T) \
     if (nkc == C && nt == T) rc = pieces == 2 ? proj_launch<C, T, 2>(a, s) : proj_launch<C, T, 3>(a, s)
     PJ_GO(1, 3); PJ_GO(2, 3); PJ_GO(3, 3); PJ_GO(4, 3);
@@ -373,124 +359,6 @@ __global__ void __launch_bounds__(512) proj_x3_kloop_kernel(ProjArgs a) {
         }
     }
   }
-}
-
-// ---- N beyond 128 with K <= 128 in ONE pass over X: a wave splits its TPW position tiles into bf16 pieces ONCE and keeps them in
-// registers while the workgroup walks the 128-column blocks of the output (weight block re-staged in LDS per column block):
-// against one workgroup column per block (proj_x3_kernel, grid.y) X is read and split once instead of N / 128 times -- the
-// input projection of the 128-wide encoders (128 -> 1 152) sits on the chain in front of the recurrences.
-template <int NKC, int NP, int TPW>
-__global__ void __launch_bounds__(512) proj_x3_nloop_kernel(ProjArgs a) {
-  CLSR_CHAIN_PRIO();
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  constexpr int NT = 8, WS = 32 * NKC + 8, NR = 16 * NT, C8 = WS / 8;
-  const int nthr = blockDim.x, nwv = nthr >> 6;
-  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int j = lane & 15, g = lane >> 4;
-  __bf16* Wi = reinterpret_cast<__bf16*>(lds_raw);          // [NP][NR][WS]
-  constexpr unsigned SKIP = 0x40000000u;
-  const int wrow = j * WS + 8 * g;
-  const __amdgpu_buffer_rsrc_t ry =
-      __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, ((unsigned)(a.M - 1) * (unsigned)a.ldy + (unsigned)a.N) * 4u, 0x00020000);
-  const f32x8 z8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const int ntiles = (a.M + 15) >> 4;
-  const int ngroups = (ntiles + nwv * TPW - 1) / (nwv * TPW);
-  const int nblk = (a.N + NR - 1) / NR;
-  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {      // (block-uniform: every wave meets every barrier)
-    const int tile0 = (grp * nwv + wave) * TPW;
-    bf16x8 xp[TPW][NKC][NP];
-    unsigned ro[TPW][4];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      const int m = (tile0 + t) * 16 + j;
-      const bool pv = m < a.M;
-      const float* p = a.X + (long)(pv ? m : a.M - 1) * a.ldx;
-#pragma unroll
-      for (int c = 0; c < NKC; ++c) {
-        const int k = 32 * c + 8 * g;
-        f32x8 y = ld8f(p + (k < a.K ? k : 0));
-        if (!(pv && k < a.K)) y = z8;
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-          xp[t][c][i] = to_h(y);
-          if (i + 1 < NP) y -= to_f(xp[t][c][i]);
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int pp = (tile0 + t) * 16 + 4 * g + e;
-        ro[t][e] = pp < a.M ? (unsigned)pp * (unsigned)a.ldy * 4u : SKIP;
-      }
-    }
-    for (int nb = 0; nb < nblk; ++nb) {
-      const int n0 = nb * NR;
-      const int Nb = a.N - n0 < NR ? a.N - n0 : NR;
-      __syncthreads();       // the previous block's products have read their weights
-      for (int e = tid; e < NR * C8; e += nthr) {
-        const int row = e / C8, k = 8 * (e - row * C8);
-        f32x8 v = z8;
-        if (row < Nb && k < a.K) v = ld8f(a.Wt + (long)(n0 + row) * a.Kp + k);
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-          const bf16x8 h = to_h(v);
-          reinterpret_cast<bf16x8*>(Wi + (size_t)i * NR * WS)[e] = h;
-          v -= to_f(h);
-        }
-      }
-      __syncthreads();
-      f32x4 acc[TPW][NT];
-      unsigned co[NT];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const bool ok = 16 * n + j < Nb;
-        const float b = (ok && a.bias) ? a.bias[n0 + 16 * n + j] : 0.f;
-        co[n] = ok ? (n0 + 16 * n + j) * 4u : SKIP;
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t][n] = (f32x4){b, b, b, b};
-      }
-#pragma unroll
-      for (int c = 0; c < NKC; ++c) {
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int wp = NP - 1; wp >= 0; --wp) {
-          bf16x8 w[NT];
-#pragma unroll
-          for (int n = 0; n < NT; ++n) w[n] = ld8h(Wi + (size_t)wp * NR * WS + wrow + 16 * n * WS + 32 * c);
-#pragma unroll
-          for (int i = NP - 1 - wp; i >= 0; --i)
-#pragma unroll
-            for (int t = 0; t < TPW; ++t)
-#pragma unroll
-              for (int n = 0; n < NT; ++n) HMFMA(acc[t][n], xp[t][c][i], w[n]);
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < TPW; ++t)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int n = 0; n < NT; ++n) {
-            const float v = acc[t][n][e];
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, ro[t][e] + co[n], 0, 0);
-          }
-    }
-  }
-}
-
-template <int NKC, int NP>
-static int proj_nloop_launch(const ProjArgs& a, hipStream_t stream) {
-  constexpr int TPW = (NP == 3 && NKC == 4) ? 1 : 2;      // (three pieces of four chunks of two tiles: 96 VGPRs of pieces -- spills)
-  constexpr int WS = 32 * NKC + 8, NR = 128;
-  const size_t shmem = (size_t)NP * NR * WS * 2;
-  const int threads = 512;
-  int gx = clsr_cdiv(clsr_cdiv(a.M, 16), (threads / 64) * TPW);
-  const int cap = shmem > 80 * 1024 ? 256 : 512;
-  if (gx > cap) gx = cap;
-  auto kernel = proj_x3_nloop_kernel<NKC, NP, TPW>;
-  if (shmem > 64 * 1024) CLSR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(kernel, dim3(gx), dim3(threads), shmem, stream, a);
-  CLSR_CHECK_LAUNCH();
-  return CLSR_OK;
 }
 
 template <int NT, int NP>
