@@ -205,6 +205,7 @@ class CLSRNet(object):
         self.proj_tt = self.proj_x3 and not os.environ.get("CLSR_NO_PROJ_TT")      # A/B: tanh time features in that kernel's prologue
         self.proj_x3_wide = self.proj_x3 and not os.environ.get("CLSR_NO_PROJ_X3_WIDE")
         self.gemm_wide_x3 = self.proj_x3_wide and not os.environ.get("CLSR_NO_GEMM_WIDE_X3")   # A/B: every plain wide product
+        self.proj_bwd_pieces = int(os.environ.get("CLSR_PROJ_BWD_PIECES", "2"))
         self.proj_wide_pieces = int(os.environ.get("CLSR_PROJ_WIDE_PIECES", "2" if self.precision == "bf16" else "3"))
         self.rnn_act_tiled = self.rnn_products == "x3" and not os.environ.get("CLSR_NO_RNN_ACT_TILED")
         # Attention-MLP backward (exact mode): "x3" = the two-pass layer-1 kernel and the one-pass layer-0 kernel as split-bf16
@@ -680,7 +681,10 @@ class CLSRNet(object):
             # plain position-level products of WIDE layers (BASELINE configs[4]): operands in registers, 128 output columns
             # per workgroup column, K in slabs of 128 (csrc/projx3.hip) -- the position-tiled fp32 kernel ran these at
             # 0.3-0.4 of the fp32 matrix peak (profiles/r05_catalogue_pmc.md)
-            call("clsr_proj_x3_wide", X, ldx, Wt, Kp, bias, Y, ldy, M, K, N, self.proj_wide_pieces, int(acc))
+            # (back-propagating products -- transposed weights -- take two pieces like every other backward product of the
+            # default modes: half the MFMAs, two workgroups per CU instead of one; CLSR_PROJ_BWD_PIECES=3: as the forward ones)
+            pieces = self.proj_bwd_pieces if wkey.endswith("^T") else self.proj_wide_pieces
+            call("clsr_proj_x3_wide", X, ldx, Wt, Kp, bias, Y, ldy, M, K, N, pieces, int(acc))
             return
         sc, sh = (aff.scale, aff.shift) if aff is not None else (None, None)
         name = "clsr_pgemm"
