@@ -662,6 +662,13 @@ class CLSRNet(object):
         self.packed_h[key] = (buf, Kp)
         self._cur_descs_h.append(ops.pack_desc(W, out_f, in_f, buf, Kp, transposed=transposed))
 
+    @staticmethod
+    def _hgemm_fits(K, N):
+        """does the bf16 weight image of a K -> N product fit the LDS of csrc/hgemm.hip's position-tiled kernel?  (Not at
+        K = 1 536 -> 128, d(hist) of the 128-wide encoders: the speed mode then takes the fp32 route -- clsr_proj_x3_wide.)"""
+        np_ = 2 if N <= 64 else (3 if (N <= 96 or 128 < N <= 192) else 4)      # (hgemm_np, csrc/hgemm.hip)
+        return 32 * np_ * (32 * ((K + 31) // 32) + 8) * 2 <= 150 * 1024
+
     def _pack_pair(self, key, W, K, N, K_pad=None):
         """forward pack (K->N) and transposed pack (N->K) of the same [K, N] block."""
         self._pack(key, W, N, K, in_pad=K_pad)
@@ -670,13 +677,14 @@ class CLSRNet(object):
     def _gemm(self, X, ldx, wkey, M, K, N, Y, ldy, bias=None, T=0, G=0, Xmul=None, ldmul=0, aff=None,
               addU=None, ldu=0, addV=None, ldv=0, acc=0, stats=None):
         if (self.bf16 and wkey in self.packed_h and wkey.endswith("^T") and bias is None and Xmul is None and aff is None
-                and addU is None and addV is None and stats is None and T == 0 and K % 8 == 0 and N % 8 == 0):
+                and addU is None and addV is None and stats is None and T == 0 and K % 8 == 0 and N % 8 == 0
+                and self._hgemm_fits(K, N)):
             Wt, Kp = self.packed_h[wkey]
             call("clsr_hgemm_hf32" if X.dtype == torch.bfloat16 else "clsr_hgemm_f32", X, ldx, Wt, Kp, Y, ldy, acc, M, K, N)
             return
         Wt, Kp = self.packed[wkey]
         if (self.gemm_wide_x3 and Xmul is None and aff is None and addU is None and addV is None and stats is None and T == 0
-                and M >= 32768 and (K > 80 or N > 80) and K <= 4096 and K % 8 == 0 and ldx % 4 == 0
+                and X.dtype == F32 and Y.dtype == F32 and M >= 32768 and (K > 80 or N > 80) and K <= 4096 and K % 8 == 0 and ldx % 4 == 0
                 and query("clsr_proj_x3_wide_supported", M, K, N)):
             # plain position-level products of WIDE layers (BASELINE configs[4]): operands in registers, 128 output columns
             # per workgroup column, K in slabs of 128 (csrc/projx3.hip) -- the position-tiled fp32 kernel ran these at
@@ -2295,6 +2303,7 @@ class CLSRNet(object):
         # speed mode: the gradients of the input projections leave the backward-through-time kernel as bf16 -- their
         # consumers (input-side / hidden-side weight gradients, d(hist) = dPin . W^T) run on the bf16 matrix pipe anyway
         dpin_h = (self.dpin_h and "xw^T" in self.packed_h and H % 8 == 0 and Du % 8 == 0 and D % 8 == 0
+                  and self._hgemm_fits(NX, D)
                   and (self._t4_kind != "time4lstm" or "t4.tw^T" in self.packed_h))
         dPinAll = self._buf("xw.dPin", M, NX, dtype=torch.bfloat16 if dpin_h else F32)
         grus, t4d = [], None

@@ -224,3 +224,24 @@ def test_catalogue100m_full_size_step():
     assert float(net.tab_grad["item"][probe].abs().max()) == 0.0
     del net
     torch.cuda.empty_cache()
+
+
+def test_catalogue_dims_speed_mode_runs_and_agrees_with_the_parity_mode():
+    """128-wide layers (BASELINE configs[4] dims on a small vocabulary) in precision="bf16": the d(hist) product of this width
+    (K = 1 536) does not fit the position-tiled bf16 kernel's LDS image -- the step must take the fp32 route for it instead of
+    failing (it raised `unsupported shape` until round 5) -- and its logits stay within the speed mode's 2e-3 of the parity mode's."""
+    from clsr_amd.net import CLSRNet
+    from clsr_amd.synthetic import synthetic_feed
+
+    cfg = dict(Vu=3000, Vi=20000, Vc=400, Di=96, Dc=32, Du=128, H=128, T=50, P=512)
+    feed = synthetic_feed(cfg["P"], cfg["T"], cfg["Vu"], cfg["Vi"], cfg["Vc"], lengths="lognormal", seed=5)
+    hp, net = _net(cfg, cfg["P"], seed=3)
+    neth = CLSRNet(hp, dict(Vu=cfg["Vu"], Vi=cfg["Vi"], Vc=cfg["Vc"]), seed=3, precision="bf16")
+    neth.load_state_dict(net.state_dict())
+    out = net.train_step(net.upload(feed, True))
+    outh = neth.train_step(neth.upload(feed, True))
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(outh["logit"]).all())
+    assert float((out["logit"] - outh["logit"]).abs().max()) <= 2e-3
+    la, lb = net.read_losses(), neth.read_losses()
+    assert abs(la["loss"] - lb["loss"]) <= 1e-3 * max(1.0, abs(la["loss"]))
