@@ -152,6 +152,8 @@ class CLSRNet(object):
         self.dw_batch_late = not os.environ.get("CLSR_NO_DW_BATCH_LATE")   # A/B: merged launches of the attention / head weight gradients
         self.bn_bwd_fused = not os.environ.get("CLSR_NO_BN_BWD_FUSED")   # A/B: coefficient + apply of the row-level batch-norm backward in one launch
         self.hist_grad_two = not os.environ.get("CLSR_NO_HIST_GRAD_TWO")   # A/B: dhist + dhist_lt summed inside the segmented sums
+        self.dense_upd_dw = not os.environ.get("CLSR_DENSE_UPD_AUX")   # A/B: dense regulariser + Adam on the weight-gradient stream
+        self._dense_fork = None
         self.tick_early = not os.environ.get("CLSR_NO_TICK_EARLY")   # A/B: Adam clock in the first launch of the update phase
         self.dw_stream = not os.environ.get("CLSR_NO_DW_STREAM")   # A/B switch (see _dw)
         self._dw_async = False
@@ -2374,7 +2376,8 @@ class CLSRNet(object):
             # regulariser + Adam) does not meet the embedding path (gradient tables, table regulariser / Adam) again:
             # it stays on the weight-gradient stream, where the last partial-sum kernel has just finished, and the main
             # stream goes straight to the embedding gradients (the reduction used to sit between them: ~140 us)
-            with self._branch("@dw0", after=self._fork_point(), name="@dense"):
+            self._dense_fork = self._fork_point()
+            with self._branch("@dw0", after=self._dense_fork, name="@dense"):
                 self._dense_grads_final()
         else:
             self._dense_grads_final()
@@ -2413,6 +2416,7 @@ class CLSRNet(object):
                 self._dp_hook("table_ready", k)
         if apply:
             self._apply_updates()
+            self._dense_fork = None
         elif self.dp_hooks is None:
             self._join()              # callers that read the gradients themselves: everything back on this stream
         return out
@@ -2660,7 +2664,13 @@ class CLSRNet(object):
             call("clsr_adam_tick", self.adam_state, lr, 0.9, 0.999)
         clip = float(hp.max_grad_norm) if hp.is_clip_norm else 0.0
         # dense variables (regulariser + norms, Adam clock, Adam) on the @aux stream beside the table regulariser
-        with self._branch("@main" if (self.capture_grads or not self.split_emb_grad) else "@aux"):
+        # (single-GPU step with the dense path on the weight-gradient stream: the dense update STAYS on that stream, behind the
+        # batched reduction -- on @aux it started two stream hops, ~25 us, after the reduction had finished, and the dense
+        # Adam launch was the last kernel of the step; CLSR_DENSE_UPD_AUX=1: as before)
+        fork = getattr(self, "_dense_fork", None)
+        on_dw = (fork is not None and not self.capture_grads and self.split_emb_grad and self.dense_upd_dw)
+        with (self._branch("@dw0", after=fork, name="@denseupd") if on_dw else
+              self._branch("@main" if (self.capture_grads or not self.split_emb_grad) else "@aux")):
             self._join(only="@dense")     # (the batched weight-gradient reduction, see _train_step)
             # (the Adam clock of the step ticks in the same launch: every reader is ordered after it)
             call("clsr_dense_reg_norm_tick", self.dense, self.dense_grad, self.seg_off, len(self.dense_names),
