@@ -8,7 +8,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-re="dw_wide_kernel|pgemm_fast_kernel|pgemm3_kernel|pgemm_dw_kernel|rnn_multi_fwd|rnn_multi_bwd|dw_multi_kernel|pgemm_kloop|att_prod_bwd|dw_wide_reduce"
+re="dw_wide_kernel|pgemm_fast_kernel|pgemm3_kernel|pgemm_dw_kernel|rnn_multi_fwd|rnn_multi_bwd|dw_multi_kernel|pgemm_kloop|att_prod_bwd|dw_wide_reduce|proj_x3|att_l0_fwd_kernel"
 i=0
 files=""
 for set in "FETCH_SIZE" "WRITE_SIZE" \
