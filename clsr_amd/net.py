@@ -152,6 +152,7 @@ class CLSRNet(object):
         self.dw_batch_late = not os.environ.get("CLSR_NO_DW_BATCH_LATE")   # A/B: merged launches of the attention / head weight gradients
         self.bn_bwd_fused = not os.environ.get("CLSR_NO_BN_BWD_FUSED")   # A/B: coefficient + apply of the row-level batch-norm backward in one launch
         self.hist_grad_two = not os.environ.get("CLSR_NO_HIST_GRAD_TWO")   # A/B: dhist + dhist_lt summed inside the segmented sums
+        self.l0_bwd_halves = not os.environ.get("CLSR_NO_L0_BWD_HALVES")   # A/B: wide layer-0 backward as two launches of the x3 kernel over column halves
         self.dense_upd_dw = not os.environ.get("CLSR_DENSE_UPD_AUX")   # A/B: dense regulariser + Adam on the weight-gradient stream
         self._dense_fork = None
         self.tick_early = not os.environ.get("CLSR_NO_TICK_EARLY")   # A/B: Adam clock in the first launch of the update phase
@@ -1473,11 +1474,15 @@ class CLSRNet(object):
         if qh:
             Q2 = Q - qh
             l0x3 = x3b and self.fused_l0_bwd and query("clsr_att_l0_bwd_x3_supported", G, Q2, A0)
-            if not l0x3:
+            halves = (not l0x3) and x3b and self._l0_bwd_halves_ok(G, Q2)
+            if not (l0x3 or halves):
                 self._dw(a[:, qh:], Q, dz0, A0, R * T, Q2, A0, dW0[3 * Q + qh:4 * Q], A0, T=T, G=G, Xmul=q[:, qh:],
                          ldmul=Q)
             dU = self._buf(key + ".dU", Hn * T, A0)
-            if l0x3:
+            if halves:
+                self._att_l0_bwd_x3_halves(key, ".Wp2^T", dz0, a, q, da, dq, dU, dV, dW0, Hn, G, R, T, Q, qh, Q2)
+                self._gemm(dV, A0, key + ".Wv^T", R, A0, Q, dq, Q, acc=1)
+            elif l0x3:
                 # the same pass as split-bf16 products, with the partial sums of dWp[qh:] (csrc/attbwdx3.hip)
                 Wt, Kp = self.packed[key + ".Wp2^T"]
                 parts = query("clsr_att_l0_bwd_x3_parts", Hn)
@@ -1509,10 +1514,13 @@ class CLSRNet(object):
                 call("clsr_att_prod_bwd_ld", daq1, qh, a, Q, q_hist, qh, Hn, 1, T, qh, da, Q, dq_hist, qh, 1)
         else:
             l0x3 = x3b and self.fused_l0_bwd and query("clsr_att_l0_bwd_x3_supported", G, Q, A0)
-            if not l0x3:
+            halves = (not l0x3) and x3b and self._l0_bwd_halves_ok(G, Q)
+            if not (l0x3 or halves):
                 self._dw(a, Q, dz0, A0, R * T, Q, A0, dW0[3 * Q:4 * Q], A0, T=T, G=G, Xmul=q, ldmul=Q)
             dU = dz0 if G == 1 else self._buf(key + ".dU", Hn * T, A0)
-            if l0x3:
+            if halves:
+                self._att_l0_bwd_x3_halves(key, ".Wp^T", dz0, a, q, da, dq, None if G == 1 else dU, dV, dW0, Hn, G, R, T, Q, 0, Q)
+            elif l0x3:
                 Wt, Kp = self.packed[key + ".Wp^T"]
                 parts = query("clsr_att_l0_bwd_x3_parts", Hn)
                 ws = self._buf(key + ".dwpx_ws", parts * query("clsr_dw_chunk_floats"))
@@ -1531,6 +1539,29 @@ class CLSRNet(object):
                 call("clsr_att_z0_bwd_reduce", dz0, Hn, G, T, A0, None if G == 1 else dU, dV)
         return self._att_bwd_hist(key, scope, nn, a, q, keys, dkeys, dU, dV, da, dq, dW0, Hn, R, T, Dk, Q, qh,
                                   q_hist=q_hist, dq_hist=dq_hist)
+
+    def _l0_bwd_halves_ok(self, G, Qw):
+        """wide product term (80 < Qw <= 160 query columns: BASELINE configs[4]): the one-pass layer-0 backward with folded dWp
+        (csrc/attbwdx3.hip covers <= 80 columns) as TWO launches over the column halves?"""
+        return bool(self.l0_bwd_halves and self.fused_l0_bwd and Qw > 80 and Qw % 8 == 0 and Qw // 2 <= 80
+                    and query("clsr_att_l0_bwd_x3_supported", G, Qw // 2, self.A0))
+
+    def _att_l0_bwd_x3_halves(self, key, wkey, dz0, a, q, da, dq, dU, dV, dW0, Hn, G, R, T, Q, c_lo, Qw):
+        """Layer-0 backward of a product term of Qw query columns (a / q / da / dq columns [c_lo, c_lo + Qw)) as two launches of
+        clsr_att_l0_bwd_x3 over the column halves: each reads dz0 once and leaves da / dq and the partial sums of dWp of ITS
+        columns; dU / dV come from the first one.  Replaces, at 128 columns, the position-tiled chain daq = dz0 . Wp^T (written:
+        0.5 GB) -> clsr_att_prod_bwd -> clsr_att_z0_bwd_reduce + the separate weight-gradient launch over (a, q, dz0)."""
+        A0 = self.A0
+        Wt, Kp = self.packed[key + wkey]
+        parts = query("clsr_att_l0_bwd_x3_parts", Hn)
+        C = query("clsr_dw_chunk_floats")
+        Qh = Qw // 2
+        for i in (0, 1):
+            c0 = c_lo + i * Qh
+            ws = self._buf(key + ".dwpx_ws%d" % i, parts * C)
+            call("clsr_att_l0_bwd_x3", dz0, A0, Wt[i * Qh * Kp:], Kp, a[:, c0:], Q, q[:, c0:], Q, Hn, G, T, Qh, A0, da[:, c0:], Q,
+                 dq[:, c0:], Q, dU if i == 0 else None, A0, dV if i == 0 else self._buf(key + ".dV_scratch", R, A0), A0, ws)
+            self._dw_fused(ws, parts, Qh, A0, dW0[3 * Q + c0:3 * Q + c0 + Qh], A0)
 
     def _att_l0_fwd_entry_for(self, K):
         """Layer-0 forward entry for a product term of K query columns: wide layers (K > 80: BASELINE configs[4]) take the
