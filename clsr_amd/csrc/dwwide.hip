@@ -154,34 +154,68 @@ __global__ void __launch_bounds__(256, 2) dw_wide_kernel(DwwArgs a) {
   }
 }
 
-// dW[k, n] (=|+=) sum over the S position ranges of part[s][k][n], in range order; db likewise
+// dW[k, n] (=|+=) sum over the S position ranges of part[s][k][n]; db likewise.  A workgroup owns 16 consecutive output quads;
+// its 16 thread slices each add the ranges s = slice, slice + 16, ... (eight loads in flight), the slices are then combined in
+// slice order through LDS: a fixed order for given S -- bit-identical results run to run.  (Round 4: one thread per quad walked
+// all S ranges -- 16 workgroups for a 128 x 128 gradient, 200-320 us in the catalogue step's tail, as long as the product.)
 __global__ void __launch_bounds__(256) dw_wide_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart,
                                                              int S, int K, int N, float* __restrict__ dW, int ldw,
                                                              float* __restrict__ db, int accumulate) {
+  __shared__ f32x4 red[16][16];
   const long KN = (long)K * N;
-  const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const int ql = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long e = ((long)blockIdx.x * 16 + ql) * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   if (e < KN) {
-    f32x4 sN[8];
+    for (int s0 = sl; s0 < S; s0 += 16 * 8) {
+      f32x4 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) sN[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int s = 0;
-    for (; s + 7 < S; s += 8) {
+      for (int u = 0; u < 8; ++u) {
+        const int s = s0 + 16 * u;
+        v[u] = s < S ? ld4(part + (long)s * KN + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) sN[u] += ld4(part + (long)(s + u) * KN + e);
+      for (int u = 0; u < 8; ++u) acc += v[u];
     }
-    for (; s < S; ++s) sN[0] += ld4(part + (long)s * KN + e);
-    f32x4 v = ((sN[0] + sN[1]) + (sN[2] + sN[3])) + ((sN[4] + sN[5]) + (sN[6] + sN[7]));
+  }
+  red[sl][ql] = acc;
+  __syncthreads();
+  if (sl == 0 && e < KN) {
+    f32x4 v = red[0][ql];
+#pragma unroll
+    for (int u = 1; u < 16; ++u) v += red[u][ql];
     const long k = e / N;
     const int n = (int)(e - k * N);
     float* o = dW + k * ldw + n;
     if (accumulate) { v.x += o[0]; v.y += o[1]; v.z += o[2]; v.w += o[3]; }
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;          // (views of the flat gradient buffer: no 16-byte alignment)
   }
-  if (db && bpart && blockIdx.x == 0) {
-    for (int n = threadIdx.x; n < N; n += 256) {
-      float v = 0.f;
-      for (int s = 0; s < S; ++s) v += bpart[(long)s * N + n];
-      db[n] = accumulate ? db[n] + v : v;
+  // bias sums: the first ceil(N / 16) workgroups take 16 columns each, the same slice scheme (one thread per column walked all
+  // S ranges before: 280 us at S = 493)
+  if (db && bpart && (long)blockIdx.x * 16 < N) {
+    __syncthreads();
+    float* redb = reinterpret_cast<float*>(red);      // [16][16]
+    const int n = blockIdx.x * 16 + ql;
+    float v = 0.f;
+    if (n < N) {
+      for (int s0 = sl; s0 < S; s0 += 16 * 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int s_ = s0 + 16 * u;
+          t[u] = s_ < S ? bpart[(long)s_ * N + n] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+      }
+    }
+    redb[sl * 16 + ql] = v;
+    __syncthreads();
+    if (sl == 0 && n < N) {
+      float t = redb[ql];
+#pragma unroll
+      for (int u = 1; u < 16; ++u) t += redb[u * 16 + ql];
+      db[n] = accumulate ? db[n] + t : t;
     }
   }
 }
@@ -190,7 +224,9 @@ static int dww_parts(long M, int K, int N) {
   const int tiles = clsr_cdiv(K, 128) * clsr_cdiv(N, 128);
   int S = 512 / tiles;        // (~512 workgroups: one round at two per CU; fewer partial tiles to add up afterwards)
   if (S < 8) S = 8;
-  if (S > 128) S = 128;
+  // (capped at 128 until round 5: a one-tile gradient -- hidden-side kernels of the 128-wide encoders -- then ran 128 workgroups
+  //  of 50 stages each on 256 CUs, 200 us for 210 MB of operands, one after the other at the very end of the catalogue step)
+  if (S > 512) S = 512;
   const long per = (M + 31) / 32;          // stages
   if (S > per) S = (int)per;
   return S < 1 ? 1 : S;
@@ -231,7 +267,7 @@ static int dw_wide_any(const float* X, int ldx, const float* Xmul, int ldmul, co
     hipLaunchKernelGGL(dw_wide_kernel<true>, grid, dim3(256), shmem, (hipStream_t)stream, a);
   }
   CLSR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(dw_wide_reduce_kernel, dim3(clsr_cdiv((long)K * N / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(dw_wide_reduce_kernel, dim3(clsr_cdiv((long)K * N / 4, 16)), dim3(256), 0, (hipStream_t)stream,
                      a.part, a.bpart, a.S, K, N, dW, ldw, db, accumulate);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
