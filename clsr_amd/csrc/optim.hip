@@ -89,17 +89,31 @@ __global__ void __launch_bounds__(1024) dense_reg_norm_kernel(const float* __res
   }
 }
 
-extern "C" int clsr_dense_reg_norm_tick(const float* param, float* grad, const int* seg_off, int nseg,
-                                        float l2, float l1, double* sumsq, double* reg_loss, double* adam_state,
-                                        double lr, double beta1, double beta2, void* stream) {
+static int dense_reg_norm_any(const float* param, float* grad, const int* seg_off, int nseg,
+                              float l2, float l1, double* sumsq, double* reg_loss, double* adam_state,
+                              double lr, double beta1, double beta2, int threads_arg, void* stream) {
   CLSR_CHECK_ARG(param && grad && seg_off && sumsq && nseg > 0);
   // (workgroups of 1 024 threads wait for a CU with sixteen free wave slots while the table sweeps of the other stream fill
   // the chip: CLSR_DENSE_REG_THREADS picks the size, A/B)
   static const int threads = []() { const char* e = getenv("CLSR_DENSE_REG_THREADS"); const int t = e ? atoi(e) : 256; return (t == 256 || t == 512 || t == 1024) ? t : 256; }();
-  hipLaunchKernelGGL(dense_reg_norm_kernel, dim3(nseg), dim3(threads), 0, (hipStream_t)stream, param, grad,
+  const int th = (threads_arg == 256 || threads_arg == 512 || threads_arg == 1024) ? threads_arg : threads;
+  hipLaunchKernelGGL(dense_reg_norm_kernel, dim3(nseg), dim3(th), 0, (hipStream_t)stream, param, grad,
                      seg_off, l2, l1, sumsq, reg_loss, adam_state, lr, beta1, beta2);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
+}
+
+extern "C" int clsr_dense_reg_norm_tick(const float* param, float* grad, const int* seg_off, int nseg,
+                                        float l2, float l1, double* sumsq, double* reg_loss, double* adam_state,
+                                        double lr, double beta1, double beta2, void* stream) {
+  return dense_reg_norm_any(param, grad, seg_off, nseg, l2, l1, sumsq, reg_loss, adam_state, lr, beta1, beta2, 0, stream);
+}
+// ... with the workgroup size chosen by the caller (256 | 512 | 1024; 0: the default): one workgroup walks one tensor, and the
+// 128 x 1 536 kernels of 128-wide encoders are 768 elements per thread at 256 threads (109 us, the last kernel of that step)
+extern "C" int clsr_dense_reg_norm_tick_t(const float* param, float* grad, const int* seg_off, int nseg,
+                                          float l2, float l1, double* sumsq, double* reg_loss, double* adam_state,
+                                          double lr, double beta1, double beta2, int threads, void* stream) {
+  return dense_reg_norm_any(param, grad, seg_off, nseg, l2, l1, sumsq, reg_loss, adam_state, lr, beta1, beta2, threads, stream);
 }
 
 extern "C" int clsr_dense_reg_norm(const float* param, float* grad, const int* seg_off, int nseg,

@@ -393,6 +393,8 @@ class CLSRNet(object):
         self.dense_m = torch.zeros_like(self.dense)
         self.dense_v = torch.zeros_like(self.dense)
         self.seg_off = torch.tensor(off, dtype=torch.int32, device=dev)
+        # (dense regulariser: one workgroup per tensor -- 1 024 threads when a tensor is large: 128-wide encoders)
+        self.dense_reg_threads = 1024 if max(sizes) >= 65536 else 0
         self.seg_of = torch.tensor(np.repeat(np.arange(len(sizes)), sizes), dtype=torch.int32, device=dev)
         self.dense_sumsq = torch.zeros(len(sizes), dtype=torch.float64, device=dev)
         self.dense_names = [n for n, _, _ in dense]
@@ -2704,9 +2706,9 @@ class CLSRNet(object):
               self._branch("@main" if (self.capture_grads or not self.split_emb_grad) else "@aux")):
             self._join(only="@dense")     # (the batched weight-gradient reduction, see _train_step)
             # (the Adam clock of the step ticks in the same launch: every reader is ordered after it)
-            call("clsr_dense_reg_norm_tick", self.dense, self.dense_grad, self.seg_off, len(self.dense_names),
+            call("clsr_dense_reg_norm_tick_t", self.dense, self.dense_grad, self.seg_off, len(self.dense_names),
                  float(hp.layer_l2), float(hp.layer_l1), self.dense_sumsq, self.losses[1:],
-                 None if (self.capture_grads or tick_early) else self.adam_state, lr, 0.9, 0.999)
+                 None if (self.capture_grads or tick_early) else self.adam_state, lr, 0.9, 0.999, self.dense_reg_threads)
             if not self.capture_grads:
                 call("clsr_dense_adam", self.dense, self.dense_grad, self.dense_m, self.dense_v, self.seg_of,
                      self.dense_sumsq, clip, self.adam_state, 0.9, 0.999, 1e-8, self.n_dense)

@@ -756,6 +756,10 @@ int clsr_dense_reg_norm(const float* param, float* grad, const int* seg_off, int
 int clsr_dense_reg_norm_tick(const float* param, float* grad, const int* seg_off, int nseg, float l2, float l1,
                              double* sumsq, double* reg_loss, double* adam_state, double lr, double beta1, double beta2,
                              void* stream);
+/* ... with the workgroup size given (256 | 512 | 1024; 0 = default): one workgroup walks one tensor */
+int clsr_dense_reg_norm_tick_t(const float* param, float* grad, const int* seg_off, int nseg, float l2, float l1,
+                               double* sumsq, double* reg_loss, double* adam_state, double lr, double beta1, double beta2,
+                               int threads, void* stream);
 int clsr_dense_adam(float* param, float* grad, float* m, float* v, const int* seg_of,
                     const double* sumsq, float clip_norm, const double* adam_state, float beta1,
                     float beta2, float eps, int n, void* stream);
