@@ -643,7 +643,7 @@ def main():
                 cache_resident = dict(roof)
                 roof = dict(big_roof, workload="BASELINE configs[4] catalogue: 100M items, rows 384 B + 128 B, uniform "
                                                "ids, 4096 histories x 50 steps (38 GB table: every row read is an HBM read)",
-                            traffic=213.7e6, traffic_source="counters in KiB; profiles/r04_gather_pmc_WRITE_SIZE.csv + r04_gather_pmc_FETCH_SIZE.csv, the 22 "
+                            traffic=213.7e6, traffic_source="counters in KiB; profiles/r05t_gather_pmc_WRITE_SIZE.csv + r05t_gather_pmc_FETCH_SIZE.csv (round 4 measured the same: r04_gather_pmc_*.csv), the 22 "
                                                             "catalogue dispatches (WRITE_SIZE 106.5 MB + 2 x FETCH_SIZE 51.1 MB; round 2 "
                                                             "measured the same: profiles/r02_gather_hist_fwd_pmc_hbm_traffic.csv)",
                             cache_resident_at_benchmarked_config=cache_resident)
