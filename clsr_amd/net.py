@@ -2409,8 +2409,11 @@ class CLSRNet(object):
             # regulariser + Adam) does not meet the embedding path (gradient tables, table regulariser / Adam) again:
             # it stays on the weight-gradient stream, where the last partial-sum kernel has just finished, and the main
             # stream goes straight to the embedding gradients (the reduction used to sit between them: ~140 us)
-            self._dense_fork = self._fork_point()
-            with self._branch("@dw0", after=self._dense_fork, name="@dense"):
+            fork_dense = self._fork_point()
+            # (only the step that applies its own update right away keeps the dense update on this stream: under data
+            # parallelism the gradients are exchanged first, and the update must be ordered behind THAT, not behind this event)
+            self._dense_fork = fork_dense if (apply and self.dp_hooks is None) else None
+            with self._branch("@dw0", after=fork_dense, name="@dense"):
                 self._dense_grads_final()
         else:
             self._dense_grads_final()
