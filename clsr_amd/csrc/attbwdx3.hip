@@ -31,6 +31,11 @@
 #define X3_OCC 1
 #endif
 // ablation switches (scripts/abl_att_l0x3.sh): 0 removes the piece from the layer-0 kernel
+#ifndef X3_L0H_OCC2
+#define X3_L0H_OCC2 1      // two waves per SIMD for the one-piece bf16 instance of the layer-0 backward (256 registers, 11 spilled:
+                           // 128 -> 92 us alone, bf16 step 2.321 -> 2.308 ms; the layer-1 instances spill 44 / 126 registers at
+                           // that size and stay at one wave per SIMD)
+#endif
 #ifndef X3A_DW
 #define X3A_DW 1
 #endif
@@ -148,7 +153,7 @@ struct AttL0BwdArgsX {
 
 // NP = bf16 pieces per operand: 2 (hi + lo: the parity mode's x3 products) or 1 (speed mode); ST = storage type of dz0
 template <int NF, int NZ, int NP, typename ST>
-__global__ void __launch_bounds__(256, X3_OCC) att_l0_bwd_x3_kernel(AttL0BwdArgsX s) {
+__global__ void __launch_bounds__(256, (NP == 1 && X3_L0H_OCC2) ? 2 : X3_OCC) att_l0_bwd_x3_kernel(AttL0BwdArgsX s) {
   constexpr unsigned SB = sizeof(ST);
   CLSR_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -459,9 +464,10 @@ extern "C" int clsr_dw_chunk_floats(void) { return CLSR_DW_CHUNK; }
 
 static int x3_tiles_class(int n) { return n <= 48 ? 3 : 5; }
 
-static int l0x_grid(long Hn) {
+static int l0x_grid(long Hn, bool half = false) {
   long gx = (Hn + 3) / 4;
-  if (gx > 256) gx = 256;      // one workgroup per CU (512-register waves): a wave walks several histories
+  const long cap = (half && X3_L0H_OCC2) ? 512 : 256;      // one workgroup per CU (512-register waves; the bf16 instance: two)
+  if (gx > cap) gx = cap;                                    // -- a wave walks several histories
   return (int)gx;
 }
 
@@ -469,6 +475,7 @@ extern "C" int clsr_att_l0_bwd_x3_supported(int G, int Q, int A0) {
   return G >= 1 && G <= X3_GMAX && Q >= 4 && Q <= 80 && A0 >= 8 && A0 <= 80 && Q % 4 == 0 && A0 % 8 == 0;
 }
 extern "C" int clsr_att_l0_bwd_x3_parts(long Hn) { return l0x_grid(Hn); }
+extern "C" int clsr_att_l0_bwd_x1_h_parts(long Hn) { return l0x_grid(Hn, true); }
 
 template <int NF, int NZ, int NP, typename ST>
 static int att_l0_bwd_x3_launch(const AttL0BwdArgsX& a, hipStream_t stream) {
@@ -479,7 +486,7 @@ static int att_l0_bwd_x3_launch(const AttL0BwdArgsX& a, hipStream_t stream) {
   auto kernel = att_l0_bwd_x3_kernel<NF, NZ, NP, ST>;
   if (shmem > 64 * 1024)
     CLSR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(kernel, dim3(l0x_grid(a.Hn)), dim3(256), shmem, stream, a);
+  hipLaunchKernelGGL(kernel, dim3(l0x_grid(a.Hn, sizeof(ST) == 2)), dim3(256), shmem, stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }

@@ -1601,7 +1601,7 @@ class CLSRNet(object):
         Qe, ae, qe = Q - qh, (a[:, qh:] if qh else a), (q[:, qh:] if qh else q)
         dU = self._buf(key + ".dU", Hn * T, A0)
         Wt, Kp = self.packed[key + (".Wp2^T" if qh else ".Wp^T")]
-        parts = query("clsr_att_l0_bwd_x3_parts", Hn)
+        parts = query("clsr_att_l0_bwd_x1_h_parts", Hn)
         ws = self._buf(key + ".dwpx_ws", parts * query("clsr_dw_chunk_floats"))
         call("clsr_att_l0_bwd_x1_h", dz0, A0, Wt, Kp, ae, Q, qe, Q, Hn, G, T, Qe, A0, da[:, qh:] if qh else da, Q,
              dq[:, qh:] if qh else dq, Q, dU, A0, dV, A0, ws)

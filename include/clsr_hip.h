@@ -461,6 +461,7 @@ int clsr_att_l1_bwd_x1_h(const void* z1, int ldz1, const float* ds, const float*
                          const float* scale0, const float* shift0, const float* mean0, const float* invstd0,
                          const float* coef0, void* dz0, int lddz0, float* dw1_partial, double* stats, int M, int C1,
                          int C0, void* stream);
+int clsr_att_l0_bwd_x1_h_parts(long Hn);      /* partial chunks clsr_att_l0_bwd_x1_h writes (its workgroups run two per CU) */
 int clsr_att_l0_bwd_x1_h(const void* dz0, int lddz, const float* Wt, int Kp, const float* a, int lda,
                          const float* q, int ldq, long Hn, int G, int T, int Q, int A0, float* da, int ldda,
                          float* dq, int lddq, float* dU, int lddu, float* dV, int lddv, float* dwp_partial,

@@ -171,7 +171,7 @@ def test_layer0_backward_one_piece_bf16(Hn, G, T, Q, A0):
     Wt, Kp = ops.pack_weight(dev(Wp), Q, A0, transposed=True)
     da, dq = torch.full((Hn * T, Q), 7.0, device="cuda"), torch.full((R, Q), 7.0, device="cuda")
     dU, dV = torch.full((Hn * T, A0), 7.0, device="cuda"), torch.full((R, A0), 7.0, device="cuda")
-    parts = query("clsr_att_l0_bwd_x3_parts", Hn)
+    parts = query("clsr_att_l0_bwd_x1_h_parts", Hn)
     C = query("clsr_dw_chunk_floats")
     ws = torch.full((parts * C,), 7.0, device="cuda")
     ddz0, da_, dq_ = dev(dz0).to(BF), dev(a), dev(q)
