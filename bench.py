@@ -421,8 +421,10 @@ def main():
                     help="clsr = the BASELINE metric (default); the sibling models run the same step machinery "
                          "(clsr_amd/seqnet.py) and report the same metric for comparison")
     ap.add_argument("--precision", default=os.environ.get("CLSR_PRECISION", "fp32"), choices=["fp32", "fp32x3", "bf16"],
-                    help="fp32 = the reference's arithmetic (parity mode, headline); bf16 = speed mode: bf16 storage of "
-                         "the attention activations + bf16 MFMA with fp32 accumulation, statistics and optimiser")
+                    help="fp32 = the reference's arithmetic: every product at fp32 accuracy (parity mode, headline); fp32x3 = fp32 "
+                         "storage with two-piece split-bf16 products (2^-16 per term) in the recurrences / attention backward / "
+                         "encoder tail; bf16 = speed mode: bf16 storage of the attention activations + bf16 MFMA with fp32 "
+                         "accumulation, statistics and optimiser")
     ap.add_argument("--table-dtype", default="fp32", choices=["fp32", "bf16"],
                     help="bf16: embedding tables stored as bf16 (SURVEY 8d 'bf16 tables'); gradients / Adam moments fp32")
     ap.add_argument("--exact-clip", action="store_true",
@@ -672,7 +674,10 @@ def main():
             "metric": "train interactions/sec @ batch %d seq_len %d" % (P, T), "value": round(value, 1),
             "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "fp32x3": "f32 storage, split-bf16 (bf16 x 3) products in the fused encoder tail",
+            "dtype": {"fp32": "f32 (every product at fp32 accuracy: fp32-input MFMAs or three bf16 pieces per operand; the two-piece "
+                              "split-product step is precision_modes.fp32x3)",
+                      "fp32x3": "f32 storage, two-piece split-bf16 products (2^-16 per term) in the recurrences, the attention "
+                                "backward and the encoder tail -- NOT the reference's fp32 products (that step: --precision fp32)",
                       "bf16": "bf16"}[args.precision] + (" (bf16 embedding tables)" if args.table_dtype == "bf16" else ""),
             "data": "synthetic",
             "config": {"workload": wl.describe() + " (%s lengths)" % args.lengths,

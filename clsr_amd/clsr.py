@@ -421,7 +421,9 @@ class SequentialBaseModel(BaseModel):
             print("data parallel: %d positives dropped so far (%d batches skipped): global batches are truncated to "
                   "a multiple of %d ranks" % (self.dp_dropped_positives, self.dp_skipped_batches, world))
         with self._stream_ctx():
-            return float(acc[:4].sum().item())
+            total = float(acc[:4].sum().item())
+            net.check_abort()       # end of an epoch: an aborted step (bounded wait gave up) must not reach evaluation / checkpoints
+            return total
 
     def _dp_world(self):
         """Data-parallel world size of THIS model's process group (1 without ``dist``)."""

@@ -329,9 +329,12 @@ __device__ __forceinline__ float ah_ld1(ah_rsrc_t rs, unsigned off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
 }
 
-// NZC = 32-wide chunks of A0, NQ = tiles of Q, NH = tiles of qh (0: none), NK = tiles of Dk
-template <int NZC, int NQ, int NH, int NK>
-__global__ void __launch_bounds__(256, 2) att_hist_bwd_x3_kernel(AttHistBwdArgs s) {
+// NZC = 32-wide chunks of A0, NQ = tiles of Q, NH = tiles of qh (0: none), NK = tiles of Dk, NP = bf16 pieces per operand
+// (2: the "fp32x3" / speed modes; 3: fp32 accuracy, precision="fp32").  NTH threads: with three pieces the weight images
+// (110 KB at the default widths) leave room for ONE workgroup per CU -- eight waves share them instead of four (one wave
+// per SIMD took 277 us in the step where the two-piece form takes 130: the walk is latency bound, it needs the waves)
+template <int NZC, int NQ, int NH, int NK, int NP, int NTH>
+__global__ void __launch_bounds__(NTH, NTH == 512 ? 1 : 2) att_hist_bwd_x3_kernel(AttHistBwdArgs s) {
   CLSR_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int QP = 16 * NQ, HP = 16 * (NH ? NH : 1), KP = 16 * NK;
@@ -339,15 +342,12 @@ __global__ void __launch_bounds__(256, 2) att_hist_bwd_x3_kernel(AttHistBwdArgs 
   constexpr int NQC = (NQ + 1) / 2, WSQ = 32 * NQC + 8; // attention_mat^T image: permuted slots over the query features
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int j = lane & 15, g4 = lane >> 4;
-  __bf16* Uh = reinterpret_cast<__bf16*>(lds_raw);
-  __bf16* Ul = Uh + QP * WSZ;
-  __bf16* Ph = Ul + QP * WSZ;
-  __bf16* Pl = Ph + (NH ? HP * WSZ : 0);
-  __bf16* Ah = Pl + (NH ? HP * WSZ : 0);
-  __bf16* Al = Ah + KP * WSQ;
-  ah_stage<false, 2>(Uh, WSZ, QP, s.WuT, s.Kpu, s.Q, s.A0, tid, 256);      // (piece images are adjacent: Ul = Uh + QP * WSZ ...)
-  if (NH) ah_stage<false, 2>(Ph, WSZ, HP, s.WpT, s.Kpp, s.nqh, s.A0, tid, 256);
-  ah_stage<true, 2>(Ah, WSQ, KP, s.AT, s.Kpa, s.Dk, s.Q, tid, 256);
+  __bf16* Ui = reinterpret_cast<__bf16*>(lds_raw);        // [NP][QP][WSZ]
+  __bf16* Pi = Ui + NP * QP * WSZ;                        // [NP][HP][WSZ]
+  __bf16* Ai = Pi + (NH ? NP * HP * WSZ : 0);             // [NP][KP][WSQ]
+  ah_stage<false, NP>(Ui, WSZ, QP, s.WuT, s.Kpu, s.Q, s.A0, tid, NTH);
+  if (NH) ah_stage<false, NP>(Pi, WSZ, HP, s.WpT, s.Kpp, s.nqh, s.A0, tid, NTH);
+  ah_stage<true, NP>(Ai, WSQ, KP, s.AT, s.Kpa, s.Dk, s.Q, tid, NTH);
   __syncthreads();
 
   const int T = s.T, NTT = (T + 15) >> 4;
@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(256, 2) att_hist_bwd_x3_kernel(AttHistBwdArgs 
   for (int k = 0; k < NK; ++k) ko[k] = 16 * k + j < s.Dk ? (16 * k + j) * 4u : SKIP;
   const int urow = j * WSZ + 8 * g4, arow = j * WSQ + 8 * g4;
 
-  for (long h = (long)blockIdx.x * 4 + wave; h < s.Hn; h += (long)gridDim.x * 4) {
+  for (long h = (long)blockIdx.x * (NTH / 64) + wave; h < s.Hn; h += (long)gridDim.x * (NTH / 64)) {
     const float* up = s.dU + h * T * s.lddu;
     const ah_rsrc_t ra = ah_rsrc(s.a + h * T * s.lda, (unsigned)(T * s.lda) * 4u);
     const ah_rsrc_t rda = ah_rsrc(s.da + h * T * s.ldda, (unsigned)(T * s.ldda) * 4u);
@@ -389,13 +389,9 @@ __global__ void __launch_bounds__(256, 2) att_hist_bwd_x3_kernel(AttHistBwdArgs 
     for (int c = 0; c < NZC; ++c) uraw[c] = ld8f(up + (long)min(j, T - 1) * s.lddu + zofs[c]);
     for (int tt = 0; tt < NTT; ++tt) {
       const int t0 = 16 * tt;
-      bf16x8 uh[NZC], ul[NZC];
+      AhP8<NP> ux[NZC];
 #pragma unroll
-      for (int c = 0; c < NZC; ++c) {
-        const f32x8 v = (t0 + j < T && 32 * c + 8 * g4 < s.A0) ? uraw[c] : z8;
-        uh[c] = to_h(v);
-        ul[c] = to_h(v - to_f(uh[c]));
-      }
+      for (int c = 0; c < NZC; ++c) ux[c] = ah_split8<NP>((t0 + j < T && 32 * c + 8 * g4 < s.A0) ? uraw[c] : z8);
       {
         const long tn = min(t0 + 16 + j, T - 1);
 #pragma unroll
@@ -434,30 +430,12 @@ __global__ void __launch_bounds__(256, 2) att_hist_bwd_x3_kernel(AttHistBwdArgs 
 #pragma unroll
       for (int c = 0; c < NZC; ++c) {
         AH_FENCE();
-        bf16x8 wh[NQ], wl[NQ];
-#pragma unroll
-        for (int n = 0; n < NQ; ++n) { wh[n] = ld8h(Uh + urow + 16 * n * WSZ + 32 * c); wl[n] = ld8h(Ul + urow + 16 * n * WSZ + 32 * c); }
-#pragma unroll
-        for (int n = 0; n < NQ; ++n) HMFMA(r1[n], uh[c], wl[n]);
-#pragma unroll
-        for (int n = 0; n < NQ; ++n) HMFMA(r1[n], ul[c], wh[n]);
-#pragma unroll
-        for (int n = 0; n < NQ; ++n) HMFMA(r1[n], uh[c], wh[n]);
-        if (NH) {
-          bf16x8 ph[NH ? NH : 1], pl[NH ? NH : 1];
-#pragma unroll
-          for (int n = 0; n < NH; ++n) { ph[n] = ld8h(Ph + urow + 16 * n * WSZ + 32 * c); pl[n] = ld8h(Pl + urow + 16 * n * WSZ + 32 * c); }
-#pragma unroll
-          for (int n = 0; n < NH; ++n) HMFMA(r2[n], uh[c], pl[n]);
-#pragma unroll
-          for (int n = 0; n < NH; ++n) HMFMA(r2[n], ul[c], ph[n]);
-#pragma unroll
-          for (int n = 0; n < NH; ++n) HMFMA(r2[n], uh[c], ph[n]);
-        }
+        ah_mac<NP, NQ>(r1, ux[c], Ui, QP * WSZ, 16 * WSZ, urow + 32 * c);
+        if constexpr (NH > 0) ah_mac<NP, NH>(r2, ux[c], Pi, HP * WSZ, 16 * WSZ, urow + 32 * c);
       }
       AH_FENCE();
       // finish da, store it, split it, and bring it back to rows = positions for the last product
-      bf16x4 th[NQ], tl[NQ];
+      bf16x4 th[NP][NQ];
 #pragma unroll
       for (int n = 0; n < NQ; ++n) {
         f32x4 d = dold[n] + r1[n];
@@ -469,13 +447,13 @@ __global__ void __launch_bounds__(256, 2) att_hist_bwd_x3_kernel(AttHistBwdArgs 
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) ah_st1(rda, ro_da[e] + qo[n], d[e]);
-        const bf16x4 h4 = ah_h4(d);
-        const bf16x4 l4 = ah_h4(d - ah_f4(h4));
-        f32x4 dh = z4, dl = z4;
-        HMFMA(dh, ah_cat(h4, zh4), sel);
-        HMFMA(dl, ah_cat(l4, zh4), sel);
-        th[n] = ah_h4(dh);
-        tl[n] = ah_h4(dl);
+        const AhP4<NP> pc = ah_split4<NP>(d);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {                      // (products with the identity: exact for each bf16 piece)
+          f32x4 dt = z4;
+          HMFMA(dt, ah_cat(pc.p[i], zh4), sel);
+          th[i][n] = ah_h4(dt);
+        }
       }
       // dkeys += da . A^T: 4 positions of key feature 16k + j
       f32x4 dk[NK];
@@ -484,17 +462,10 @@ __global__ void __launch_bounds__(256, 2) att_hist_bwd_x3_kernel(AttHistBwdArgs 
 #pragma unroll
       for (int c = 0; c < NQC; ++c) {
         AH_FENCE();
-        const bf16x8 xh = ah_cat(th[2 * c], 2 * c + 1 < NQ ? th[2 * c + 1 < NQ ? 2 * c + 1 : 0] : zh4);
-        const bf16x8 xl = ah_cat(tl[2 * c], 2 * c + 1 < NQ ? tl[2 * c + 1 < NQ ? 2 * c + 1 : 0] : zh4);
-        bf16x8 wh[NK], wl[NK];
+        AhP8<NP> x;
 #pragma unroll
-        for (int k = 0; k < NK; ++k) { wh[k] = ld8h(Ah + arow + 16 * k * WSQ + 32 * c); wl[k] = ld8h(Al + arow + 16 * k * WSQ + 32 * c); }
-#pragma unroll
-        for (int k = 0; k < NK; ++k) HMFMA(dk[k], xh, wl[k]);
-#pragma unroll
-        for (int k = 0; k < NK; ++k) HMFMA(dk[k], xl, wh[k]);
-#pragma unroll
-        for (int k = 0; k < NK; ++k) HMFMA(dk[k], xh, wh[k]);
+        for (int i = 0; i < NP; ++i) x.p[i] = ah_cat(th[i][2 * c], 2 * c + 1 < NQ ? th[i][2 * c + 1 < NQ ? 2 * c + 1 : 0] : zh4);
+        ah_mac<NP, NK>(dk, x, Ai, KP * WSQ, 16 * WSQ, arow + 32 * c);
       }
 #pragma unroll
       for (int k = 0; k < NK; ++k)
@@ -516,25 +487,26 @@ extern "C" int clsr_att_hist_bwd_x3_supported(int Dk, int Q, int A0, int qh) {
          qh >= 0 && qh <= 48 && qh <= Q && qh % 4 == 0;
 }
 
-template <int NZC, int NQ, int NH, int NK>
+template <int NZC, int NQ, int NH, int NK, int NP>
 static int ahb_launch(const AttHistBwdArgs& a, hipStream_t stream) {
+  constexpr int NTH = NP > 2 ? 512 : 256;
   constexpr int QP = 16 * NQ, HP = 16 * (NH ? NH : 1), KP = 16 * NK, WSZ = 32 * NZC + 8, WSQ = 32 * ((NQ + 1) / 2) + 8;
-  const size_t shmem = (size_t)2 * 2 * (QP * WSZ + (NH ? HP * WSZ : 0) + KP * WSQ);
-  long gx = (a.Hn + 3) / 4;
-  if (gx > 512) gx = 512;
-  auto kernel = att_hist_bwd_x3_kernel<NZC, NQ, NH, NK>;
+  const size_t shmem = (size_t)NP * 2 * (QP * WSZ + (NH ? HP * WSZ : 0) + KP * WSQ);
+  long gx = (a.Hn + NTH / 64 - 1) / (NTH / 64);
+  if (gx > (NTH == 512 ? 256 : 512)) gx = NTH == 512 ? 256 : 512;
+  auto kernel = att_hist_bwd_x3_kernel<NZC, NQ, NH, NK, NP, NTH>;
   if (shmem > 64 * 1024)
     CLSR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(kernel, dim3((unsigned)gx), dim3(256), shmem, stream, a);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)gx), dim3(NTH), shmem, stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
 }
 
 extern "C" int clsr_att_hist_bwd_x3(const float* dU, int lddu, const float* WuT, int Kpu, const float* WpT, int Kpp,
                                     const float* AT, int Kpa, const float* a, int lda, const float* q_hist, int ldqh,
-                                    long Hn, int T, int Dk, int Q, int A0, int qh, float* da, int ldda, float* dq_hist,
-                                    int lddqh, float* dkeys, int lddk, void* stream) {
-  CLSR_CHECK_ARG(dU && WuT && AT && da && dkeys && Hn > 0 && T > 0);
+                                    long Hn, int T, int Dk, int Q, int A0, int qh, int pieces, float* da, int ldda,
+                                    float* dq_hist, int lddqh, float* dkeys, int lddk, void* stream) {
+  CLSR_CHECK_ARG(dU && WuT && AT && da && dkeys && Hn > 0 && T > 0 && (pieces == 2 || pieces == 3));
   CLSR_CHECK_SUPPORTED(clsr_att_hist_bwd_x3_supported(Dk, Q, A0, qh));
   CLSR_CHECK_ARG(qh == 0 || (WpT && a && q_hist && dq_hist && ldqh >= qh && lddqh >= qh && lda >= qh &&
                              Kpp >= 16 * clsr_cdiv(A0, 16)));
@@ -548,7 +520,8 @@ extern "C" int clsr_att_hist_bwd_x3(const float* dU, int lddu, const float* WuT,
   s.dkeys = dkeys; s.lddk = lddk; s.Hn = Hn; s.T = T; s.Dk = Dk; s.Q = Q; s.A0 = A0; s.nqh = qh;
   hipStream_t st = (hipStream_t)stream;
   const int nzc = clsr_cdiv(A0, 32), nq = ah_class(Q), nh = qh == 0 ? 0 : 3, nk = 3;
-#define AHB_GO(Z, Qn, H) if (nzc == Z && nq == Qn && nh == H) return ahb_launch<Z, Qn, H, 3>(s, st)
+#define AHB_GO(Z, Qn, H) \
+  if (nzc == Z && nq == Qn && nh == H) return pieces == 3 ? ahb_launch<Z, Qn, H, 3, 3>(s, st) : ahb_launch<Z, Qn, H, 3, 2>(s, st)
   AHB_GO(1, 3, 0); AHB_GO(2, 3, 0); AHB_GO(3, 3, 0); AHB_GO(1, 5, 0); AHB_GO(2, 5, 0); AHB_GO(3, 5, 0);
   AHB_GO(1, 3, 3); AHB_GO(2, 3, 3); AHB_GO(3, 3, 3); AHB_GO(1, 5, 3); AHB_GO(2, 5, 3); AHB_GO(3, 5, 3);
 #undef AHB_GO

@@ -18,7 +18,7 @@
 // state[0]=step, [1]=beta1^t, [2]=beta2^t, [3]=lr_t, [4]=abort flag of the step   (doubles, device resident so graph
 // replay works; abort: raised by a collective / grid barrier that gave up -- csrc/p2p.hip -- the kernels below then return)
 __global__ void adam_tick_kernel(double* st, double lr, double b1, double b2) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && st[4] == 0.0) {      // (an aborted step does not advance the Adam clock)
     st[0] += 1.0;
     st[1] *= b1;
     st[2] *= b2;
@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(1024) dense_reg_norm_kernel(const float* __res
                                                              double* __restrict__ reg_loss,
                                                              double* __restrict__ adam_state, double lr, double b1,
                                                              double b2) {
-  if (adam_state && blockIdx.x == 0 && threadIdx.x == 0) {   // the Adam clock of this step (adam_tick_kernel) rides along
+  if (adam_state && blockIdx.x == 0 && threadIdx.x == 0 && adam_state[4] == 0.0) {   // the Adam clock of this step (adam_tick_kernel) rides along; not in an aborted step
     adam_state[0] += 1.0;
     adam_state[1] *= b1;
     adam_state[2] *= b2;
@@ -163,7 +163,7 @@ extern "C" int clsr_dense_adam(float* param, float* grad, float* m, float* v, co
 // count[0] = number of set flags (float, consumed by the discrepancy coefficient)
 __global__ void count_flags_kernel(const unsigned char* __restrict__ flags, long V, float* __restrict__ count,
                                    double* __restrict__ adam_state, double lr, double b1, double b2) {
-  if (adam_state && blockIdx.x == 0 && threadIdx.x == 0) {   // the Adam clock of the step (adam_tick_kernel) rides along
+  if (adam_state && blockIdx.x == 0 && threadIdx.x == 0 && adam_state[4] == 0.0) {   // the Adam clock of the step (adam_tick_kernel) rides along; not in an aborted step
     adam_state[0] += 1.0;
     adam_state[1] *= b1;
     adam_state[2] *= b2;

@@ -20,13 +20,16 @@
 // order on every rank, because every rank issues the same sequence of calls.
 // The exchange buffers are fine-grained device allocations (no stale lines in a reader's L2) mapped into the peers by
 // hipIpc handles that the host exchanges once.
-// A peer that never arrives must not hang the device: the wait is bounded (CLSR_P2P_TIMEOUT_S, default 10 s -- the ranks of a
-// step meet at the process-group collective that opens it, so inside a step they are milliseconds apart; only the first
-// steps drift by seconds).  A wait that gives up (1) raises the communicator's STICKY error word, (2) raises the step's
+// A peer that never arrives must not hang the device: the wait is bounded (clsr_p2p_timeout_ticks below: CLSR_P2P_TIMEOUT_S
+// when set; otherwise 60 s while the job warms up -- the ranks' first steps drift apart by seconds -- and 10 s once the
+// stepper has armed the bound: the ranks of a step meet at the process-group collective that opens it, so inside a step they
+// are milliseconds apart).  A wait that gives up (1) raises the communicator's STICKY error word, (2) raises the step's
 // abort flag (clsr_comm_set_abort: adam_state[4] of the net -- every optimiser kernel returns without touching a
-// parameter or a moment while it is set) and (3) returns NaN instead of a partial sum, so that nothing downstream can mistake
-// the statistics for valid ones.  The host reports it at its next check (CLSRNet.check_abort: every loss read, every
-// data-parallel step one step late, before every checkpoint).
+// parameter or a moment and the Adam clock stops while it is set) and (3) returns NaN instead of a partial sum, so that
+// nothing downstream can mistake the statistics for valid ones.  The batch-norm moving statistics of that step ARE
+// poisoned by it: the host treats the net as invalid until a checkpoint is restored (CLSRNet.check_abort -- sticky; raised
+// at every loss read, by state_dict and so by every checkpoint, at the end of an epoch, and one step late by the
+// data-parallel stepper in train_step and in the run() of capture()).
 #include "common.h"
 #include "clsr_hip.h"
 #include <string.h>
@@ -181,18 +184,29 @@ extern "C" int clsr_comm_set_abort(void* comm, double* flag) {
   ((P2PComm*)comm)->abort_flag = flag;
   return CLSR_OK;
 }
-// bounded waits of the peer-to-peer kernels, in ticks of the 100 MHz wall clock: CLSR_P2P_TIMEOUT_S seconds (fractions
-// allowed, at least 10 ms), default 10 s
+// bounded waits of the peer-to-peer kernels, in ticks of the 100 MHz wall clock.  CLSR_P2P_TIMEOUT_S seconds (fractions
+// allowed, at least 10 ms) when the variable is set -- honoured from the first call.  Otherwise: 60 s while the job warms up
+// (the ranks' first steps drift apart by seconds: allocations, launch-plan recording, lazy module loads -- a slow first
+// step on one rank must WAIT, not abort the step), 10 s once the stepper has armed the bound after its first good steps
+// (clsr_p2p_arm_timeout, clsr_amd/dp.py).
+static int g_p2p_armed = 0;
+extern "C" int clsr_p2p_arm_timeout(int armed) {
+  __atomic_store_n(&g_p2p_armed, armed ? 1 : 0, __ATOMIC_RELAXED);
+  return CLSR_OK;
+}
 long long clsr_p2p_timeout_ticks(void) {
-  static const long long ticks = []() {
+  static const double fixed = []() {
     const char* e = getenv("CLSR_P2P_TIMEOUT_S");
-    double sec = e ? atof(e) : 10.0;
+    if (!e || !*e) return -1.0;
+    double sec = atof(e);
     if (!(sec >= 0.01)) sec = 0.01;
     if (sec > 3600.0) sec = 3600.0;
-    return (long long)(sec * 1e8);
+    return sec;
   }();
-  return ticks;
+  const double sec = fixed > 0.0 ? fixed : (__atomic_load_n(&g_p2p_armed, __ATOMIC_RELAXED) ? 10.0 : 60.0);
+  return (long long)(sec * 1e8);
 }
+extern "C" long clsr_p2p_timeout_ms(void) { return (long)(clsr_p2p_timeout_ticks() / 100000); }
 // sequence number of the last all-reduce in which this rank gave up waiting for a peer (0: none); synchronises the device
 extern "C" long clsr_comm_error(void* comm) {
   if (!comm) return -1;

@@ -256,7 +256,7 @@ class DataParallel(object):
         self.last_sparse = []
         self.trace = None              # tests: list that receives (event, detail) tuples in issue order
         # asynchronous copy of the step's abort flag (net.adam_state[4]), looked at one step late: no synchronisation
-        self._abort_host = None
+        self._abort_host, self._steps_done = None, 0
         if torch.cuda.is_available() and str(net.device).startswith("cuda") and hasattr(net, "adam_state"):
             self._abort_host = torch.zeros(1, dtype=torch.float64).pin_memory()
         self.broadcast_parameters()
@@ -556,14 +556,28 @@ class DataParallel(object):
     def _update(self):
         self.net._apply_updates()
 
-    def train_step(self, f):
+    ARM_AFTER_STEPS = 5     # good steps before the cross-rank waits take their production bound (csrc/p2p.hip)
+
+    def _abort_check(self):
+        """One step late, without a synchronisation: the asynchronous copy of the abort flag made after the previous step."""
         if self._abort_host is not None and float(self._abort_host[0]) != 0.0:
             self.net.check_abort()         # (an earlier step gave up on the device: raises StepAborted)
+
+    def _abort_poll(self):
+        if self._abort_host is not None:
+            self._abort_host.copy_(self.net.adam_state[4:5], non_blocking=True)
+        self._steps_done += 1
+        if self._steps_done == self.ARM_AFTER_STEPS and self.comm is not None:
+            # every rank counts the same steps: the warm-up bound (60 s: allocations, plan recording, lazy module loads
+            # make the first steps drift apart by seconds) gives way to the production bound on all of them alike
+            ops.query("clsr_p2p_arm_timeout", 1)
+
+    def train_step(self, f):
+        self._abort_check()
         self._backward(f)
         self._finish()
         self._update()
-        if self._abort_host is not None:
-            self._abort_host.copy_(self.net.adam_state[4:5], non_blocking=True)
+        self._abort_poll()
 
     def capture(self, f):
         """Two hipGraphs (backward | update) around the eager RCCL exchange; returns run().
@@ -580,8 +594,10 @@ class DataParallel(object):
         self._graphs = (g1, g2)
 
         def run():
+            self._abort_check()
             ops.graph_launch(g1)
             self._exchange()
             ops.graph_launch(g2)
+            self._abort_poll()
 
         return run

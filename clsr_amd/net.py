@@ -99,41 +99,42 @@ class CLSRNet(object):
         self.packed = {}
         self.packed_h = {}         # bf16 images of the weights the speed-mode attention kernels read (csrc/hgemm.hip)
         self.bf16 = self.precision == "bf16"
-        # "fp32x3": fp32 storage everywhere (tensors, layouts and launch structure of the exact mode); the MFMA-saturated
-        # products are taken as split-bf16 sums hi*hi + lo*hi + hi*lo on the bf16 matrix pipe (csrc/dw3.hip ...)
+        # Product arithmetic of the two fp32-storage modes ("Precision policy"):
+        #   "fp32"   -- the reference's arithmetic: EVERY product at fp32 accuracy, either on v_mfma_f32_16x16x4_f32 (bit-exact
+        #               fp32 fma chains) or as THREE bf16 pieces per operand on v_mfma_f32_16x16x32_bf16 (x = p0 + p1 + p2, the
+        #               six piece products whose indices sum to <= 2, fp32 accumulation: 2^-23 relative -- the level of an
+        #               fp32 product).  This is the parity mode and the benchmark's headline.
+        #   "fp32x3" -- fp32 storage, statistics, losses and optimiser as above; the recurrences' hidden products, the
+        #               attention-MLP backward with its folded weight gradients and the fused encoder tail as TWO-piece
+        #               split-bf16 sums hi*hi + hi*lo + lo*hi (2^-16 relative per product term: narrower than fp32; the step
+        #               tests hold their fp32 tolerances on the golden batches, but it is NOT the reference's arithmetic).
+        # (round 5 ran the two-piece forms under the name "fp32"; round 6 moved them back here.)
         self.x3 = self.precision == "fp32x3"
-        # what runs as split products by default is what MEASURED faster (profiles/r04_split_bf16.md): the fused encoder tail
-        # (377 -> 174 us alone) and the skinny d(hist) = dPin . W_x^T product beside it (163 -> 134 us).  The generic
-        # weight-gradient kernel (csrc/dw3.hip) and the position-tiled products (csrc/gemm3.hip) are built and tested but
-        # stay opt-in: with their MFMA phase cut to 3/16 they are bound by memory latency, not by the pipe, and came out
-        # level or slower than the fp32-MFMA kernels whose long MFMA phases hide that latency (CLSR_X3_DW=1 /
-        # CLSR_X3_GEMM=all).
-        # Round 5: the split products that measured faster are the default of precision="fp32" as well (recurrences,
-        # attention-MLP backward, fused encoder tail, d(hist) product): fp32 storage, 2^-16 relative per product term, the
-        # step tests hold their fp32 tolerances.  CLSR_EXACT_PRODUCTS=1 restores fp32-input MFMAs everywhere (bit-exact
-        # fp32 fma chains) for parity debugging; "fp32x3" additionally honours the opt-in sites below.
-        self.exact_products = bool(os.environ.get("CLSR_EXACT_PRODUCTS"))
-        x3d = self.precision in ("fp32", "fp32x3") and not self.exact_products
+        self.exact_products = self.precision == "fp32"      # no two-piece product anywhere
+        x3d = self.x3                                        # two-piece forms
+        x6d = self.precision in ("fp32", "fp32x3")           # three-piece forms (fp32 accuracy): both fp32-storage modes
         self.x3_dw = False      # (the generic split-bf16 weight-gradient kernel, csrc/dw3.hip, measured level or slower in
                                 # round 4 and was removed in round 5: the attention weight gradients are folded into the
                                 # backward kernels instead, csrc/attbwdx3.hip)
-        self.x3_gemm = x3d and os.environ.get("CLSR_X3_GEMM", "xw^T")      # "all" | comma-separated weight keys | ""
         self.x3_enc = x3d and not os.environ.get("CLSR_NO_X3_ENC")        # A/B: fused encoder tail (csrc/encbwd.hip)
         self.enc_back_x3 = x3d and not os.environ.get("CLSR_NO_ENC_BACK_X3")   # A/B: d(hist) and d TT from one pass over dPin (csrc/projx3.hip)
-        self.att_l1_fwd_x6 = x3d and not os.environ.get("CLSR_NO_ATT_L1_FWD_X6")   # A/B: second attention layer, forward (csrc/attl1fwd.hip)
-        self.att_hist_bwd_x3 = (x3d or self.precision == "bf16") and not self.exact_products and not os.environ.get("CLSR_NO_ATT_HIST_BWD_X3")   # A/B: history-level attention backward in one launch
-        self.att_hist_x3 = (x3d or self.precision == "bf16") and not self.exact_products and not os.environ.get("CLSR_NO_ATT_HIST_X3")  # A/B: history-level attention prologue in one launch (csrc/atthist.hip)
-        # (forward products that feed a batch-norm + ReLU stay at fp32 accuracy in the parity mode -- x6 pieces in the
-        # history-level kernel, the fp32-MFMA layer-0 kernel -- see csrc/atthist.hip; the x3 forms are opt-in:
-        # CLSR_ATT_FWD_X3=1, CLSR_ATT_HIST_PIECES=2)
-        self.att_fwd_x3 = bool(os.environ.get("CLSR_ATT_FWD_X3")) and not self.exact_products
+        self.att_l1_fwd_x6 = x6d and not os.environ.get("CLSR_NO_ATT_L1_FWD_X6")   # A/B: second attention layer, forward, three pieces (csrc/attl1fwd.hip)
+        # history-level attention backward in one launch (csrc/atthist.hip): two pieces in "fp32x3" / one-piece-compatible in
+        # the speed mode, THREE pieces in "fp32"
+        self.att_hist_bwd_x3 = not os.environ.get("CLSR_NO_ATT_HIST_BWD_X3")
+        self.att_hist_bwd_pieces = 3 if self.exact_products else 2
+        self.att_hist_x3 = not os.environ.get("CLSR_NO_ATT_HIST_X3")  # A/B: history-level attention prologue in one launch (csrc/atthist.hip)
+        # (forward products that feed a batch-norm + ReLU stay at fp32 accuracy in both fp32-storage modes -- three pieces in
+        # the history-level kernel, the fp32-MFMA layer-0 kernel -- see csrc/atthist.hip; the two-piece forms are opt-in
+        # under "fp32x3": CLSR_ATT_FWD_X3=1, CLSR_ATT_HIST_PIECES=2)
+        self.att_fwd_x3 = x3d and bool(os.environ.get("CLSR_ATT_FWD_X3"))
         # the per-(row, step) layer-0 product over three bf16 pieces per operand (fp32 accuracy, 60 bf16 MFMAs instead of 100
         # fp32 ones per tile: csrc/attl0fwd.hip): 102 -> 90 us alone, nothing in the step (three interleaved A/B runs) --
         # opt-in (CLSR_ATT_FWD_X6=1), the default stays the bit-exact fp32-MFMA form
-        self.att_fwd_x6 = x3d and bool(os.environ.get("CLSR_ATT_FWD_X6"))
+        self.att_fwd_x6 = x6d and bool(os.environ.get("CLSR_ATT_FWD_X6"))
         self.att_l0_fwd_entry = ("clsr_att_l0_fwd_x3" if self.att_fwd_x3 else
                                  "clsr_att_l0_fwd_x6" if self.att_fwd_x6 else "clsr_att_l0_fwd")
-        self.att_hist_pieces = int(os.environ.get("CLSR_ATT_HIST_PIECES", "3"))  # A/B: first attention layer, forward (csrc/attl0fwd.hip)
+        self.att_hist_pieces = int(os.environ.get("CLSR_ATT_HIST_PIECES", "3")) if x3d else 3  # A/B: first attention layer, forward (csrc/attl0fwd.hip)
         # speed mode, round 5b: the (row, step)-level attention layers on the SAME chain kernels as the parity mode
         # (csrc/attl0fwd.hip, attl1fwd.hip, attbwdx3.hip) with ONE bf16 piece per operand and bf16 storage of z0 / z1 / dz0:
         # the weight gradients dW1 / db1 / dWp ride inside the backward kernels (no clsr_hdw launches over z0 / dz1 / dz0,
@@ -198,23 +199,25 @@ class CLSRNet(object):
         # fp32); with x3 the input projections of the GRUs and of the Time4LSTM blocks i | j | f run INSIDE the recurrence
         # launch from the history embeddings (no projection tensor, no GEMM in front of the T-serial chain), and the
         # Time4LSTM keeps its saved activations in a private tile-major image.  CLSR_RNN_PRODUCTS=fp32 restores the exact form.
-        self.rnn_products = os.environ.get("CLSR_RNN_PRODUCTS", "fp32" if self.exact_products else "x3")
+        self.rnn_products = "fp32" if self.exact_products else os.environ.get("CLSR_RNN_PRODUCTS", "x3")
         if self.rnn_products not in ("x3", "fp32"):
             raise ValueError("CLSR_RNN_PRODUCTS must be 'x3' or 'fp32'")
         self.rnn_fused_proj = self.rnn_products == "x3" and not os.environ.get("CLSR_NO_RNN_FUSED_PROJ")
-        # the Time4LSTM's K-fused time-gate projection as split products too (csrc/projx3.hip): it feeds the same sigmoid gates
-        self.proj_x3 = (self.rnn_products == "x3" and not self.exact_products and not os.environ.get("CLSR_NO_PROJ_X3"))
+        # the Time4LSTM's K-fused time-gate projection as split products too (csrc/projx3.hip): three pieces in "fp32", two
+        # in the other modes (it feeds the same sigmoid gates as the recurrences' two-piece hidden products there)
+        self.proj_x3 = not os.environ.get("CLSR_NO_PROJ_X3")
+        self.proj_gate_pieces = 3 if self.exact_products else 2
         # ... and the whole input projection when it is NOT fused into the recurrence launch (hidden sizes > 48: configs[4])
         self.proj_tt = self.proj_x3 and not os.environ.get("CLSR_NO_PROJ_TT")      # A/B: tanh time features in that kernel's prologue
         self.proj_x3_wide = self.proj_x3 and not os.environ.get("CLSR_NO_PROJ_X3_WIDE")
         self.gemm_wide_x3 = self.proj_x3_wide and not os.environ.get("CLSR_NO_GEMM_WIDE_X3")   # A/B: every plain wide product
-        self.proj_bwd_pieces = int(os.environ.get("CLSR_PROJ_BWD_PIECES", "2"))
+        self.proj_bwd_pieces = 3 if self.exact_products else int(os.environ.get("CLSR_PROJ_BWD_PIECES", "2"))
         self.proj_wide_pieces = int(os.environ.get("CLSR_PROJ_WIDE_PIECES", "2" if self.precision == "bf16" else "3"))
         self.rnn_act_tiled = self.rnn_products == "x3" and not os.environ.get("CLSR_NO_RNN_ACT_TILED")
         # Attention-MLP backward (exact mode): "x3" = the two-pass layer-1 kernel and the one-pass layer-0 kernel as split-bf16
         # products with the weight gradients dW1 / db1 / dWp accumulated inside them (csrc/attbwdx3.hip: no separate
         # weight-gradient launches, no stored dz1); "fp32" = the fp32-MFMA kernels + clsr_pgemm_dw_partial beside them
-        self.att_bwd = os.environ.get("CLSR_ATT_BWD", "fp32" if self.exact_products else "x3")
+        self.att_bwd = "fp32" if self.exact_products else os.environ.get("CLSR_ATT_BWD", "x3")
         if self.att_bwd not in ("x3", "fp32"):
             raise ValueError("CLSR_ATT_BWD must be 'x3' or 'fp32'")
         self.fuse_tt = not os.environ.get("CLSR_NO_FUSE_TT")   # A/B: time-gate blocks of the input projection as one product over [hist | TT]
@@ -223,8 +226,8 @@ class CLSRNet(object):
         self.heads_fused = not os.environ.get("CLSR_NO_HEADS_FUSED")
         # weight gradients of wide layers (K, N >= 96: BASELINE configs[4]) by the 128 x 128-tile kernel (csrc/dwwide.hip)
         self.dw_wide = not os.environ.get("CLSR_NO_DW_WIDE")
-        # ... as split-bf16 products like the other weight gradients of the default modes (CLSR_DW_WIDE_FP32=1 / CLSR_EXACT_PRODUCTS=1:
-        # fp32-input MFMAs)
+        # ... as two-piece split-bf16 products like the other weight gradients outside "fp32" (CLSR_DW_WIDE_FP32=1 /
+        # precision="fp32": fp32-input MFMAs)
         self.dw_wide_entry = ("clsr_pgemm_dw_wide" if (self.exact_products or os.environ.get("CLSR_DW_WIDE_FP32"))
                               else "clsr_pgemm_dw_wide_x3")
         self._dw_batch_wide = None
@@ -267,6 +270,7 @@ class CLSRNet(object):
         self.dp_hooks = None
         self.capture_grads = False
         self.captured = None
+        self._aborted = None       # sticky reason of an aborted step (check_abort)
 
     # ------------------------------------------------------------------ configuration guard
     def _check_supported(self):
@@ -464,7 +468,9 @@ class CLSRNet(object):
         assert o == self.bn_moving.numel()
 
     def state_dict(self):
-        """All variables under their TF names + BN moving stats + Adam slots (checkpoint payload)."""
+        """All variables under their TF names + BN moving stats + Adam slots (checkpoint payload).  Raises ``StepAborted``
+        instead of handing out the state an aborted step left behind (check_abort)."""
+        self.check_abort()
         sd = OrderedDict()
         for name, t in self.P.items():
             sd[name] = t.detach().float().cpu().clone()      # (bf16 tables: widened -- the payload is always fp32)
@@ -518,6 +524,8 @@ class CLSRNet(object):
                 self.tab_m[k].copy_(torch.as_tensor(sd["__adam__/%s_m" % k]))
                 self.tab_v[k].copy_(torch.as_tensor(sd["__adam__/%s_v" % k]))
             self.adam_state[:4].copy_(torch.as_tensor(sd["__adam__/state"])[:4])
+            if self._aborted or float(self.adam_state[4].item()) != 0.0:
+                self._reset_after_abort()       # a full checkpoint is the recovery path of an aborted step
 
     # ------------------------------------------------------------------ stream fork / join
     class _Branch(object):
@@ -689,7 +697,7 @@ class CLSRNet(object):
             return
         Wt, Kp = self.packed[wkey]
         if (self.gemm_wide_x3 and Xmul is None and aff is None and addU is None and addV is None and stats is None and T == 0
-                and X.dtype == F32 and Y.dtype == F32 and M >= 32768 and (K > 80 or N > 80) and K <= 4096 and K % 8 == 0 and ldx % 4 == 0
+                and X.dtype == F32 and Y.dtype == F32 and M >= 32768 and (K >= 128 or N >= 128) and K <= 4096 and K % 8 == 0 and ldx % 4 == 0
                 and query("clsr_proj_x3_wide_supported", M, K, N)):
             # plain position-level products of WIDE layers (BASELINE configs[4]): operands in registers, 128 output columns
             # per workgroup column, K in slabs of 128 (csrc/projx3.hip) -- the position-tiled fp32 kernel ran these at
@@ -700,11 +708,7 @@ class CLSRNet(object):
             call("clsr_proj_x3_wide", X, ldx, Wt, Kp, bias, Y, ldy, M, K, N, pieces, int(acc))
             return
         sc, sh = (aff.scale, aff.shift) if aff is not None else (None, None)
-        name = "clsr_pgemm"
-        if self._x3_site(wkey) and query("clsr_pgemm3_supported", int(Xmul is not None), int(aff is not None),
-                                  int(addU is not None), int(addV is not None), int(acc), int(stats is not None), M, K, N):
-            name = "clsr_pgemm3"
-        call(name, X, ldx, T, G, Xmul, ldmul, sc, sh, 1, Wt, Kp, bias, addU, ldu, addV, ldv, Y, ldy,
+        call("clsr_pgemm", X, ldx, T, G, Xmul, ldmul, sc, sh, 1, Wt, Kp, bias, addU, ldu, addV, ldv, Y, ldy,
              acc, stats, M, K, N)
 
     def _dw(self, X, ldx, dY, ldy, M, K, N, dW, ldw, db=None, T=0, G=0, Xmul=None, ldmul=0, aff=None, acc=0,
@@ -804,13 +808,6 @@ class CLSRNet(object):
                 ops.dw_multi(name, jobs)
             for job in wide:
                 call(self.dw_wide_entry, *job)
-
-    def _x3_site(self, wkey):
-        """does the product with the packed weights ``wkey`` run as a split-bf16 product (fp32x3 mode)?"""
-        sites = self.x3_gemm
-        if not sites:
-            return False
-        return sites == "all" or wkey in sites.split(",")
 
     def _dw_parts_query(self, any_bf16=False):
         """which query tells how many partial chunks the weight-gradient kernel of this mode writes"""
@@ -916,7 +913,7 @@ class CLSRNet(object):
         Wt, Kp = self.packed[wkey]
         parts = query("clsr_pgemm_stats_parts", M)
         st = self._buf("stats" + self._ws_tag, 1024 * 2 * 256, dtype=torch.float64)[: parts * 2 * N]
-        call("clsr_pgemm3_bnbwd" if (self._x3_site(wkey) and query("clsr_pgemm3_bnbwd_supported", M, K, N)) else "clsr_pgemm_bnbwd", dY, ldy_in, Wt, Kp, out, N, z, N,
+        call("clsr_pgemm_bnbwd", dY, ldy_in, Wt, Kp, out, N, z, N,
              bn.scale, bn.shift, bn.mean, bn.invstd, st, M, K, N)
         self._bn_bwd_from_partial(bn, st, parts, out, z, M)
 
@@ -1643,7 +1640,7 @@ class CLSRNet(object):
             WpT, Kpp = self.packed[key + ".Wp1^T"] if qh else (None, 0)
             AT, Kpa = self.packed[key + ".A^T"]
             call("clsr_att_hist_bwd_x3", dU, A0, WuT, Kpu, WpT, Kpp, AT, Kpa, a, Q, q_hist if qh else None, qh, Hn, T, Dk,
-                 Q, A0, qh, da, Q, dq_hist if qh else None, qh, dkeys, Dk)
+                 Q, A0, qh, self.att_hist_bwd_pieces, da, Q, dq_hist if qh else None, qh, dkeys, Dk)
         elif not da_has_u:      # (speed mode: clsr_att_l0_bwd_h has already added dU . Wu^T)
             self._gemm(dU, A0, key + ".Wu^T", Hn * T, A0, Q, da, Q, acc=1)
         if not qh:
@@ -2027,7 +2024,7 @@ class CLSRNet(object):
                     call("clsr_proj_x3_tt", hist, D, f["time_to_now"], f["time_from_first_action"], hs * T, T,
                          P[t + "_time_input_w1"], P[t + "_time_input_bias1"], P[t + "_time_input_w2"],
                          P[t + "_time_input_bias2"], H, Dp, Wt, Kp, self._buf("xw.bias", NX)[t4off + 3 * H:],
-                         PinAll[:, t4off + 3 * H:], NX, M, 3 * H, 2)
+                         PinAll[:, t4off + 3 * H:], NX, M, 3 * H, self.proj_gate_pieces)
                 elif fuse_tt:
                     # ONE product over [hist | TT] (K = 48 + 80) writes the time-gate columns: the separate pass that
                     # re-read and re-wrote them (hist . W_x first, += TT . W_t behind it: 112 us alone) is gone
@@ -2035,7 +2032,7 @@ class CLSRNet(object):
                         # (split-bf16 products, result lanes = output features: csrc/projx3.hip)
                         Wt, Kp = self.packed["xw.t"]
                         call("clsr_proj_x3", XT, Dp + 2 * H, Wt, Kp, self._buf("xw.bias", NX)[t4off + 3 * H:],
-                             PinAll[:, t4off + 3 * H:], NX, M, Dp + 2 * H, 3 * H, 2)
+                             PinAll[:, t4off + 3 * H:], NX, M, Dp + 2 * H, 3 * H, self.proj_gate_pieces)
                     elif self.proj_x3_wide and query("clsr_proj_x3_wide_supported", M, Dp + 2 * H, 3 * H):
                         # (hidden 128: K = 384 as three slabs of 128, the later ones accumulating -- 3 x ~130 us against the
                         # 0.99 ms of the position-tiled product, on the chain in front of the recurrences)
@@ -2215,6 +2212,8 @@ class CLSRNet(object):
         """forward + backward (+ clip + Adam when ``apply``) on an uploaded feed.  Losses land in
         self.losses (device doubles: data, regular, contrastive, discrepancy).  Data-parallel runs call
         with apply=False, all-reduce the gradient buffers, then call :meth:`_apply_updates`."""
+        if self._aborted:
+            self.check_abort()      # sticky: an aborted net is restored from a checkpoint first
         with ops.stream_scope():
             return self._planned(("train", bool(apply)), f, lambda: self._train_step(f, apply))
 
@@ -2763,18 +2762,17 @@ class CLSRNet(object):
 
     # ------------------------------------------------------------------ measurement hooks (bench.py)
     def precision_note(self):
-        if self.precision == "fp32" and self.exact_products:
-            return "all tensors fp32, v_mfma_f32_16x16x4_f32 (bit-exact fp32 fmaf chains) everywhere (CLSR_EXACT_PRODUCTS=1)"
         if self.precision == "fp32":
-            return ("all tensors fp32: the parity mode.  Forward products in front of a batch-norm + ReLU at fp32 accuracy "
-                    "(v_mfma_f32_16x16x4_f32, or three bf16 pieces per operand on v_mfma_f32_16x16x32_bf16: 2^-23 relative); the "
-                    "recurrences' hidden products, the attention-MLP backward with its folded weight gradients, the history-level "
-                    "attention backward and the fused encoder tail as split-bf16 sums hi*hi + hi*lo + lo*hi with fp32 accumulation "
-                    "(2^-16 relative per product term); CLSR_EXACT_PRODUCTS=1 restores fp32-input MFMAs everywhere")
+            return ("all tensors fp32; EVERY product at fp32 accuracy: v_mfma_f32_16x16x4_f32 (bit-exact fp32 fma chains: recurrences, "
+                    "attention-MLP backward, layer-0 forward, heads, weight gradients) or three bf16 pieces per operand on "
+                    "v_mfma_f32_16x16x32_bf16 with fp32 accumulation (2^-23 relative: history-level attention forward / backward, "
+                    "layer-1 forward, the Time4LSTM time-gate projection, d(hist)); no two-piece (2^-16) product anywhere")
         if self.precision == "fp32x3":
-            return ("all tensors fp32 (storage, statistics, recurrences, losses, optimiser exactly as in the parity mode); the "
-                    "MFMA-saturated products are split-bf16 sums hi*hi + lo*hi + hi*lo on v_mfma_f32_16x16x32_bf16 with fp32 "
-                    "accumulation (<= 2^-16 relative per product)")
+            return ("all tensors fp32 (storage, statistics, losses, optimiser exactly as in the fp32 mode); forward products in front "
+                    "of a batch-norm + ReLU at fp32 accuracy; the recurrences' hidden products, the attention-MLP backward with its "
+                    "folded weight gradients, the history-level attention backward and the fused encoder tail as TWO-piece split-bf16 "
+                    "sums hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (2^-16 relative per product "
+                    "term: narrower than the reference's fp32 products)")
         return ("attention-block activations at (row, step) level (z0, z1, dz0) stored as bf16, their products with ONE bf16 piece per "
                 "operand on v_mfma_f32_16x16x32_bf16 with fp32 accumulation"
                 + (" (the parity mode's chain kernels with the weight gradients folded in, csrc/attbwdx3.hip)" if self.bf16_chain
@@ -2879,31 +2877,53 @@ class CLSRNet(object):
     def _att_layer0_wave(self, G, Q):
         return (not self.bf16) and self.l0_fwd_wave and bool(query("clsr_att_l0_fwd_supported", G, Q, self.A0))
 
-    def check_abort(self, clear=False):
-        """Raise ``StepAborted`` if a bounded wait of some step since the last check gave up -- a grid barrier of the fused
-        heads launches (a launch wider than the device can hold at once, a peer rank that never pushed its statistics) or a
-        small all-reduce of the data-parallel step (csrc/p2p.hip).  The device raised adam_state[4] when it happened, and
-        every optimiser kernel since has returned without touching a parameter or a moment: the variables are those of the
-        last good step.  Synchronises the device (called with every loss read, before every checkpoint, at the end of an
-        epoch; the data-parallel stepper also looks at an asynchronous copy of the flag one step late)."""
+    def check_abort(self):
+        """Raise ``StepAborted`` if a bounded wait of some step gave up -- a grid barrier of the fused heads launches (a
+        launch wider than the device can hold at once, a peer rank that never pushed its statistics) or a small all-reduce
+        of the data-parallel step (csrc/p2p.hip).  The device raised adam_state[4] when it happened; every optimiser kernel
+        since has returned without touching a parameter or a moment and the Adam clock has stopped.  That is NOT a state
+        to continue from: the batch-norm moving statistics of the aborted step were updated from invalid sums (the
+        peer-to-peer all-reduce returns NaN on purpose) and the gradient accumulators / involved-row marks were not cleared.
+        The condition is therefore STICKY: every later ``check_abort`` / ``state_dict`` / ``train_step`` raises again until
+        the net is restored with ``load_state_dict`` of a full checkpoint (variables + moving statistics + Adam slots),
+        which clears the flag and the accumulators.  Synchronises the device.  Callers: every loss read, ``state_dict``
+        (so: every checkpoint), the end of an epoch in ``fit``; the data-parallel stepper looks at an asynchronous copy
+        of the flag one step late, in ``train_step`` and in the ``run()`` of ``capture()``."""
         flag = float(self.adam_state[4].item())
-        if flag == 0.0:
+        if flag == 0.0 and not self._aborted:
             return
-        why = []
+        if not self._aborted:
+            why = []
+            ws = self._bufs.get(("heads.ws", (int(query("clsr_heads_fused_workspace_bytes")) + 3) // 4, F32))
+            if ws is not None and query("clsr_heads_fused_error", ws.data_ptr()) != 0:
+                why.append("a grid barrier of the fused heads launches timed out (the device could not hold every workgroup "
+                           "of the launch at once, or a peer rank never pushed its statistics; CLSR_NO_HEADS_FUSED=1 runs "
+                           "the launch chain instead)")
+            comm = getattr(self, "dp_comm", None)
+            if comm and query("clsr_comm_error", comm) != 0:
+                why.append("a small all-reduce gave up waiting for a peer rank (%.1f s: CLSR_P2P_TIMEOUT_S)"
+                           % (query("clsr_p2p_timeout_ms") * 1e-3))
+            self._aborted = "; ".join(why) or "abort flag %g" % flag
+        raise StepAborted("the training step was aborted on the device: %s; no update has been applied since, the moving "
+                          "statistics and gradient accumulators are invalid -- restore the last checkpoint "
+                          "(load_state_dict / load_model)" % self._aborted)
+
+    def _reset_after_abort(self):
+        """Part of ``load_state_dict`` of a full checkpoint: clear the device abort flag, the sticky error words and every
+        accumulator an aborted step left behind (gradient tables, involved-row marks, dense gradients, statistics)."""
         ws = self._bufs.get(("heads.ws", (int(query("clsr_heads_fused_workspace_bytes")) + 3) // 4, F32))
-        if ws is not None and query("clsr_heads_fused_error", ws.data_ptr()) != 0:
-            why.append("a grid barrier of the fused heads launches timed out (the device could not hold every workgroup of "
-                       "the launch at once, or a peer rank never pushed its statistics; CLSR_NO_HEADS_FUSED=1 runs the "
-                       "launch chain instead)")
-            if clear:
-                call("clsr_heads_fused_clear_error", ws)
-        comm = getattr(self, "dp_comm", None)
-        if comm and query("clsr_comm_error", comm) != 0:
-            why.append("a small all-reduce gave up waiting for a peer rank (CLSR_P2P_TIMEOUT_S)")
-        if clear:
-            self.adam_state[4] = 0.0
-        raise StepAborted("the training step was aborted on the device: %s; no update has been applied since"
-                          % ("; ".join(why) or "abort flag %g" % flag))
+        if ws is not None:
+            torch.cuda.synchronize(self.device)
+            query("clsr_heads_fused_clear_error", ws.data_ptr())      # (synchronous host-side entry point: no stream argument)
+        self.adam_state[4] = 0.0
+        for k in self.tables:
+            self.tab_grad[k].zero_()
+            self.tab_flags[k].zero_()
+        self.dense_grad.zero_()
+        self.stats24.zero_()
+        self.ucount.zero_()
+        self._counts_zeroed = self._ucount_zeroed = self._ticked = False
+        self._aborted = None
 
     def read_losses(self):
         """Synchronising read of the step's loss terms -> dict of python floats."""

@@ -90,6 +90,10 @@ int clsr_comm_reset_channels(void* comm);   /* forget the stream -> channel map 
 /* device double raised (non-zero) when an all-reduce of this communicator gives up waiting for a peer; NULL detaches */
 int clsr_comm_set_abort(void* comm, double* flag);
 long clsr_comm_error(void* comm);    /* sequence number of the last all-reduce that timed out waiting for a peer (0: none) */
+/* bound of the cross-rank waits (csrc/p2p.hip, csrc/headsfused.hip): CLSR_P2P_TIMEOUT_S when set; otherwise 60 s until the
+ * stepper arms the production bound (10 s) after its first good steps -- a slow FIRST step must wait, not abort */
+int clsr_p2p_arm_timeout(int armed);
+long clsr_p2p_timeout_ms(void);
 int clsr_allreduce_small(void* comm, double* data, int n, void* stream);
 
 /* ---- deterministic embedding gradients (csrc/segsum.hip): STABLE radix sort (ascending ids, equal ids in position order;
@@ -281,7 +285,7 @@ int clsr_pgemm_dw_partial_h(const void* X, int x_bf16, int ldx, int T, int G, co
 int clsr_hdw_partial(const void* X, int x_bf16, int ldx, int T, int G, const float* Xmul, int ldmul,
                      const float* in_scale, const float* in_shift, int in_relu, const void* dY,
                      int dy_bf16, int ldy, int M, int K, int N, float* workspace, void* stream);
-/* ---- split-bf16 products (csrc/encbwd.hip, gemm3.hip; round 5: attbwdx3.hip, atthist.hip ...): fp32 operands in HBM,
+/* ---- split-bf16 products (csrc/encbwd.hip; round 5: attbwdx3.hip, atthist.hip ...): fp32 operands in HBM,
  *      every value split into bf16 hi + bf16 lo in registers, products taken as hi*hi + lo*hi + hi*lo on
  *      v_mfma_f32_16x16x32_bf16 with fp32 accumulation (<= 2^-16 relative per product).  Same contracts as the fp32-MFMA
  *      entry points they replace. */
@@ -291,18 +295,6 @@ int clsr_enc_bwd_fused_x3(const float* dPin, const float* hist, const float* hpr
                           const float* mprev, const float* TT, const float* hprev2, const float* gates2,
                           float* ws_hist, float* ws_hp1, float* ws_hp1r, float* ws_mprev, float* ws_tt,
                           float* ws_hp2, float* ws_hp2r, long M, void* stream);
-int clsr_pgemm3_supported(int has_mul, int has_aff, int has_u, int has_v, int accumulate, int has_stats, int M, int K,
-                          int N);
-int clsr_pgemm3(const float* X, int ldx, int T, int G, const float* Xmul, int ldmul,
-                const float* in_scale, const float* in_shift, int in_relu, const float* Wt,
-                int Kp, const float* bias, const float* addU, int ldu, const float* addV,
-                int ldv, float* Y, int ldy, int accumulate, double* stats, int M, int K,
-                int N, void* stream);
-int clsr_pgemm3_bnbwd_supported(int M, int K, int N);
-int clsr_pgemm3_bnbwd(const float* X, int ldx, const float* Wt, int Kp, float* Y, int ldy,
-                      const float* z, int ldz, const float* scale, const float* shift,
-                      const float* mean, const float* invstd, double* stats, int M, int K, int N,
-                      void* stream);
 int clsr_att_out_fwd_h(const void* z1, const float* scale1, const float* shift1,
                        const float* w_out, const float* b_out, const int* seq_len,
                        int len_stride, const float* keys, int Hn, int G, int T, int C1, int Dk,
@@ -402,8 +394,8 @@ int clsr_att_l1_fwd(const float* z0, int ldz0, const float* scale0, const float*
 int clsr_att_hist_bwd_x3_supported(int Dk, int Q, int A0, int qh);
 int clsr_att_hist_bwd_x3(const float* dU, int lddu, const float* WuT, int Kpu, const float* WpT, int Kpp,
                          const float* AT, int Kpa, const float* a, int lda, const float* q_hist, int ldqh,
-                         long Hn, int T, int Dk, int Q, int A0, int qh, float* da, int ldda, float* dq_hist,
-                         int lddqh, float* dkeys, int lddk, void* stream);
+                         long Hn, int T, int Dk, int Q, int A0, int qh, int pieces, float* da, int ldda, float* dq_hist,
+                         int lddqh, float* dkeys, int lddk, void* stream);   /* pieces = 2 (2^-16 per term) | 3 (2^-23) */
 /* clsr_att_l0_fwd with the product term as split-bf16 sums on the bf16 matrix pipe (fp32 accumulators that start from
  * U + V; 2^-16 relative per product term): bound by its stores instead of the fp32 matrix pipe */
 int clsr_att_l0_fwd_x3(const float* a, int lda, const float* q, int ldq, const float* Wt, int Kp,

@@ -31,9 +31,9 @@ us = e0.elapsed_time(e1) * 100
 print("enc_bwd_fused_x3 (weight gradients only, split-bf16): %.1f us  (%.0f GB/s of the 0.49 GB it must read)" % (us, 0.49e3 / us * 1e3))
 W2 = r(n, 480)
 Wt2, Kp2 = ops.pack_weight(W2, n, 480, transposed=True)
-f3 = lambda: call("clsr_pgemm3", dPin, 480, 0, 0, None, 0, None, None, 0, Wt2, Kp2, None, None, 0, None, 0, dhist, n, 1, None, M, 480, n)
+f3 = lambda: call("clsr_proj_x3_wide", dPin, 480, Wt2, Kp2, None, dhist, n, M, 480, n, 3, 1)
 f1 = lambda: call("clsr_pgemm", dPin, 480, 0, 0, None, 0, None, None, 0, Wt2, Kp2, None, None, 0, None, 0, dhist, n, 1, None, M, 480, n)
-for name, fn_ in (("clsr_pgemm3", f3), ("clsr_pgemm", f1)):
+for name, fn_ in (("clsr_proj_x3_wide (three pieces)", f3), ("clsr_pgemm", f1)):
     for _ in range(3): fn_()
     e0.record()
     for _ in range(10): fn_()

@@ -24,6 +24,8 @@ from clsr_amd.synthetic import synthetic_feed  # noqa: E402
 from oracle import clsr_oracle as O  # noqa: E402
 from oracle import sibling_oracle as SO  # noqa: E402
 
+# fp32 = the reference's arithmetic (every product at fp32 accuracy); fp32x3 = two-piece split-bf16 products (FUZZ_PRECISION)
+PRECISION = os.environ.get("FUZZ_PRECISION", "fp32")
 SIB_TYPES = {"gru4rec": "GRU4Rec", "din": "DIN", "sli_rec": "sli_rec", "a2svd": "A2SVD", "dien": "DIEN"}
 
 
@@ -105,7 +107,7 @@ def one_case(rng, idx, kind="clsr"):
         if kind == "clsr":
             orc, extra = O, ()
             params32 = O.init_params(dims, hp, seed=idx, scale_dense=8.0)
-            net = CLSRNet(hp, dims, device="cuda:0", seed=0, dedup_histories=dedup)
+            net = CLSRNet(hp, dims, device="cuda:0", seed=0, dedup_histories=dedup, precision=PRECISION)
         else:
             orc, extra = SO, (kind,)
             params32 = SO.init_params(dims, hp, kind, seed=idx, scale_dense=8.0)

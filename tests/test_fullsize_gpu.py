@@ -21,21 +21,25 @@ def _hp(cfg, P, **over):
     return build_hparams(cfg, P, **over)
 
 
-def _net(cfg, P, dedup=True, seed=0, **over):
+def _net(cfg, P, dedup=True, seed=0, precision="fp32", **over):
     from clsr_amd.net import CLSRNet
 
     hp = _hp(cfg, P, **over)
-    return hp, CLSRNet(hp, dict(Vu=cfg["Vu"], Vi=cfg["Vi"], Vc=cfg["Vc"]), seed=seed, dedup_histories=dedup)
+    return hp, CLSRNet(hp, dict(Vu=cfg["Vu"], Vi=cfg["Vi"], Vc=cfg["Vc"]), seed=seed, dedup_histories=dedup,
+                       precision=precision)
 
 
-def test_taobao_full_size_properties():
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
+def test_taobao_full_size_properties(precision):
+    """(precision="fp32": the benchmark's headline arithmetic -- every product at fp32 accuracy -- at the benchmark's size: 1 M
+    positions; "fp32x3": the two-piece split products at the same size and tolerances)"""
     from clsr_amd.synthetic import CONFIGS, synthetic_feed
 
     cfg = CONFIGS["taobao"]
     P, T, G = cfg["P"], cfg["T"], 5
     feed = synthetic_feed(P, T, cfg["Vu"], cfg["Vi"], cfg["Vc"], G=G, lengths="lognormal")
-    hp, net = _net(cfg, P, dedup=True, seed=1)
-    _, ref = _net(cfg, P, dedup=False, seed=1)     # replicated (reference-shaped) computation
+    hp, net = _net(cfg, P, dedup=True, seed=1, precision=precision)
+    _, ref = _net(cfg, P, dedup=False, seed=1, precision=precision)     # replicated (reference-shaped) computation
     ref.load_state_dict(net.state_dict())
     f, fr = net.upload(feed, True), ref.upload(feed, True)
     net.capture_grads = ref.capture_grads = True

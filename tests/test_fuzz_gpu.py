@@ -13,10 +13,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(n, seed, kinds):
+def _run(n, seed, kinds, precision="fp32"):
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import fuzz_step
 
+    fuzz_step.PRECISION = precision
     rng = np.random.default_rng(seed)
     failures = []
     for i in range(n):
@@ -26,8 +27,11 @@ def _run(n, seed, kinds):
     assert not failures, failures
 
 
-def test_clsr_random_shapes():
-    _run(16, 0, ["clsr"])
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
+def test_clsr_random_shapes(precision):
+    """precision="fp32": every product at fp32 accuracy (the reference's arithmetic); "fp32x3": the two-piece split products,
+    held to the same tolerances."""
+    _run(16, 0, ["clsr"], precision)
 
 
 def test_sibling_random_shapes():

@@ -156,7 +156,7 @@ def test_sync_bn_through_the_p2p_communicator_equals_the_process_group(golden_di
 def _abort_worker(out):
     """ONE process that plays rank 0 of a two-rank communicator whose peer never pushes: the all-reduce must give up after
     CLSR_P2P_TIMEOUT_S, raise the sticky error word AND the abort flag, return NaN instead of a partial sum, and every
-    optimiser kernel must then leave parameters and moments alone until the host clears the flag."""
+    optimiser kernel must then leave parameters, moments and the Adam clock alone while the flag is up."""
     import ctypes
 
     os.environ["CLSR_P2P_TIMEOUT_S"] = "0.05"        # (read once per process: set before the first call)
@@ -189,8 +189,10 @@ def _abort_worker(out):
     p0 = p.clone()
     ops.call("clsr_dense_adam", p, g, m, v, seg, sumsq, 0.0, st, 0.9, 0.999, 1e-8, n)
     torch.cuda.synchronize()
-    out["frozen"] = bool(torch.equal(p, p0) and float(m.abs().max()) == 0.0 and float(v.abs().max()) == 0.0)
-    st[4] = 0.0                                       # the host clears the flag after reporting: updates resume
+    out["frozen"] = bool(torch.equal(p, p0) and float(m.abs().max()) == 0.0 and float(v.abs().max()) == 0.0
+                         and float(st[0]) == 0.0 and float(st[1]) == 1.0)      # (the clock too)
+    st[4] = 0.0                                       # flag down (CLSRNet: load_state_dict of a checkpoint): updates resume
+    ops.call("clsr_adam_tick", st, 1e-3, 0.9, 0.999)
     ops.call("clsr_dense_adam", p, g, m, v, seg, sumsq, 0.0, st, 0.9, 0.999, 1e-8, n)
     torch.cuda.synchronize()
     out["resumed"] = bool(not torch.equal(p, p0) and float(m.abs().max()) > 0.0)

@@ -71,7 +71,9 @@ CONFIGS = [
 ]
 
 
-# "fp32x3": fp32 storage, the MFMA-saturated products as split-bf16 sums (csrc/gemm3.hip, encbwd.hip, attbwdx3.hip ...) -- held to the SAME tolerances
+# "fp32": every product at fp32 accuracy (fp32-input MFMAs or three bf16 pieces per operand) -- the reference's arithmetic, the
+# benchmark's headline; "fp32x3": fp32 storage, the recurrences / attention backward / encoder tail as TWO-piece split-bf16 sums
+# (csrc/rnn.hip, attbwdx3.hip, encbwd.hip ...) -- held to the SAME tolerances
 @pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
 @pytest.mark.parametrize("dedup", [True, False, "split"])
 @pytest.mark.parametrize("cfg", range(len(CONFIGS)))
