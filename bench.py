@@ -322,7 +322,7 @@ def embedding_rooflines(net, f, cfg, G, feed):
 
     def bwd(d, only_item):
         rows = site_rows(d)[:1] if only_item else site_rows(d)
-        ws = torch.empty(ops.segsum_workspace_bytes(rows), dtype=torch.uint8, device=dev)
+        ws = torch.zeros(ops.segsum_workspace_bytes(rows), dtype=torch.uint8, device=dev)
         return lambda: ops.segsum_multi(rows, ws)
 
     def clear_grads():      # the timed launches wrote the gradient tables: put the touched rows back to zero

@@ -218,7 +218,7 @@ extern "C" int clsr_hdw_parts(int M) { return hdw_grid_x(M); }
 static int hdw_grid_x(int M) {
   int tiles = clsr_cdiv(M, 64);
   int gx = clsr_cdiv(tiles, 4);
-  static const int cap = getenv("CLSR_HDW_PARTS") ? atoi(getenv("CLSR_HDW_PARTS")) : 384;   // blocks per chunk (512: 35 us more per speed-mode step in partial-sum traffic; 256: too few waves)
+  constexpr int cap = 384;   // blocks per chunk (512: 35 us more per speed-mode step in partial-sum traffic; 256: too few waves)
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
   return gx;

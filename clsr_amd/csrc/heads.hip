@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(256) mlp_tail_softmax_kernel(
 
 static int mlp_tail_blocks(long P) {
   long b = (P + 15) / 16;          // four groups per wave and trip
-  static const int cap = []() { const char* e = getenv("CLSR_MLP_TAIL_BLOCKS"); return e ? atoi(e) : 256; }();
+  constexpr int cap = 256;
   return (int)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 extern "C" int clsr_mlp_tail_softmax_supported(int G, int C1) { return G >= 1 && G <= MT_MAXG && C1 >= 4 && C1 <= 64; }
@@ -550,7 +550,7 @@ extern "C" int clsr_contrastive(const float* L, const float* S, const float* M, 
   CLSR_CHECK_SUPPORTED(mode == 1 || D <= 256);  // bpr keeps the history-level vectors in registers
   // a SMALL grid on purpose: this kernel runs on a side stream beside the first alpha-gate GEMM of the main chain; with
   // 4096 one-wave blocks the dispatcher was busy issuing them and the GEMM's 160 workgroups (20 us alone) took 83 us
-  static const int cap = getenv("CLSR_CONTRASTIVE_BLOCKS") ? atoi(getenv("CLSR_CONTRASTIVE_BLOCKS")) : 1024;
+  constexpr int cap = 1024;
   int blocks = Hn > cap ? cap : (int)Hn;
   hipLaunchKernelGGL(contrastive_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, L, S, M, R,
                      seq_len, len_stride, Hn, G, D, threshold, mode, margin, weight, denom_ptr, loss_out,

@@ -527,13 +527,13 @@ static int launch_pgemm(const PGemmArgs& a, hipStream_t stream) {
   const bool uv_ok = (a.addU != nullptr) == (a.addV != nullptr) && !(OT == 8 && epi == EPI_EZ);
   const bool st = a.stats != nullptr;
   const int KTn = clsr_cdiv(a.K, 16);
-  const bool upfront = !getenv("CLSR_PGEMM_STREAM");   // A/B switch: loads one k-tile ahead instead of all up front
+  const bool upfront = true;   // (measured against loads one k-tile ahead: all up front wins)
   // K = 128 over many positions (the K-fused time-gate projection [hist | TT] of the Time4LSTM) with all eight k-tiles up
   // front: measured 153 us against 123 us for the one-tile-ahead loop -- opt-in
-  const bool k8 = getenv("CLSR_PGEMM_K8") != nullptr;
+  const bool k8 = false;
   // few positions, wide K: latency bound (see the kernel); also the skinny d(hist) = dPin . W^T product (K = 480 -> 40
   // columns: 30 k-tiles per wave-tile, 100 -> 132 VGPRs with the ring)
-  const bool ring = !a.no_ring && KTn > 5 && (a.M <= 65536 || (OT == 3 && KTn >= 16 && !getenv("CLSR_PGEMM_NO_RING_WIDE")));
+  const bool ring = !a.no_ring && KTn > 5 && (a.M <= 65536 || (OT == 3 && KTn >= 16));
 #define CLSR_FAST(P, E, S)                                                                          \
   if (uv_ok && pro == (P) && epi == (E) && st == (S)) {                                             \
     /* (the X * Xmul variant holds twice the operands: with everything in flight it drops to one wave per SIMD and loses) */ \
@@ -600,8 +600,8 @@ extern "C" int clsr_pgemm(const float* X, int ldx, int T, int G, const float* Xm
   a.Wt = Wt; a.Kp = Kp; a.ldw = Kp; a.bias = bias; a.addU = addU; a.ldu = ldu; a.addV = addV; a.ldv = ldv;
   a.Y = Y; a.ldy = ldy; a.accumulate = accumulate; a.stats = stats; a.M = M; a.K = K; a.N = N;
   a.ez = nullptr; a.ldez = 0; a.e_scale = a.e_shift = a.e_mean = a.e_invstd = nullptr;
-  a.no_ring = getenv("CLSR_PGEMM_NO_RING") ? 1 : 0;
-  a.no_compact = getenv("CLSR_PGEMM_NO_COMPACT") ? 1 : 0;
+  a.no_ring = 0;
+  a.no_compact = 0;
   a.rm_tc = a.rm_T = a.rm_t0 = 0;
   return pgemm_dispatch(a, (hipStream_t)stream);
 }
@@ -617,7 +617,7 @@ extern "C" int clsr_pgemm_range(const float* X, int ldx, const float* Wt, int Kp
   PGemmArgs a = {};
   a.X = X; a.ldx = ldx; a.Wt = Wt; a.Kp = Kp; a.ldw = Kp; a.bias = bias; a.Y = Y; a.ldy = ldy; a.accumulate = accumulate;
   a.M = Hn * (t1 - t0); a.K = K; a.N = N;
-  a.no_ring = getenv("CLSR_PGEMM_NO_RING") ? 1 : 0;
+  a.no_ring = 0;
   if (t0 != 0 || t1 != T) { a.rm_tc = t1 - t0; a.rm_T = T; a.rm_t0 = t0; }
   return pgemm_dispatch(a, (hipStream_t)stream);
 }
@@ -634,7 +634,7 @@ static int pgemm_out_tiles(int N) {
 // unless it wastes two or more out-tiles over the eight-tile one (360 columns: 166 us with eight tiles per workgroup)
 static int pgemm_out_tiles_k(int N, int K) {
   const int nt = clsr_cdiv(N, 16);
-  if (nt > 8 && K <= 48 && !getenv("CLSR_PGEMM_NO_OT5")) {
+  if (nt > 8 && K <= 48) {
     const int waste5 = clsr_cdiv(nt, 5) * 5 - nt, waste8 = clsr_cdiv(nt, 8) * 8 - nt;
     if (waste5 - waste8 <= 1) return 5;
   }
@@ -649,10 +649,8 @@ static int pgemm_dispatch_one(const PGemmArgs& a, hipStream_t s) {
   // few positions (the row-level heads: 20 480 rows = 640 wave-tiles on 1 024 SIMDs): every wave owns ONE tile and its
   // MFMA chain is the kernel's critical path -- three out-tiles per wave and more column chunks (blockIdx.y) instead of
   // five or eight: 3.69 -> 3.65 ms per step (A/B switch CLSR_PGEMM_SMALLM_OT: 0 = off)
-  static const int small_ot = []() { const char* e = getenv("CLSR_PGEMM_SMALLM_OT"); return e ? atoi(e) : 3; }();
+  constexpr int small_ot = 3;
   if (small_ot && a.M <= 32768 && ot > small_ot) ot = small_ot;
-  static const int k128_ot = []() { const char* e = getenv("CLSR_PGEMM_K128_OT"); return e ? atoi(e) : 0; }();
-  if (k128_ot && a.K > 96 && a.K <= 128 && a.N <= 128 && ot > k128_ot) ot = k128_ot;     // (experiment switch)
   if (ot == 3) return launch_pgemm<3>(a, s);
   if (ot == 5) return launch_pgemm<5>(a, s);
   return launch_pgemm<8>(a, s);
@@ -755,8 +753,7 @@ __global__ void __launch_bounds__(256, 2) pgemm_kloop_kernel(PKLArgs a) {
 }
 
 static bool pgemm_kloop_ok(const PGemmArgs& a) {
-  static const bool off = getenv("CLSR_PGEMM_NO_KLOOP") != nullptr;
-  return !off && a.K >= 256 && a.N <= 128 && a.T == 0 && a.G == 0 && !a.Xmul && !a.in_scale && !a.addU && !a.addV && !a.stats &&
+  return a.K >= 256 && a.N <= 128 && a.T == 0 && a.G == 0 && !a.Xmul && !a.in_scale && !a.addU && !a.addV && !a.stats &&
          !a.ez && a.rm_tc == 0 && a.M >= 128 * 256;
 }
 static int launch_pgemm_kloop(const PGemmArgs& a, hipStream_t s) {
@@ -780,10 +777,7 @@ static int pgemm_dispatch(const PGemmArgs& a0, hipStream_t s) {
   int ot = pgemm_out_tiles_k(a.N, a.K);
   if (ot == 8 && a.ez) ot = 5;
   // bytes of LDS for the weight chunk of one launch (A/B switch: CLSR_PGEMM_LDS_KB)
-  static const size_t budget = []() {
-    const char* e = getenv("CLSR_PGEMM_LDS_KB");
-    return (size_t)(e ? atoi(e) : 96) * 1024;
-  }();
+  constexpr size_t budget = (size_t)96 * 1024;
   const int kmax = (int)(budget / ((size_t)16 * ot * sizeof(float))) / 16 * 16;
   if (a.Kp <= kmax) return pgemm_dispatch_one(a, s);
   if (pgemm_kloop_ok(a)) return launch_pgemm_kloop(a, s);
@@ -1127,7 +1121,7 @@ __global__ void __launch_bounds__(1024) dw_reduce_kernel(const float* __restrict
 static int dw_grid_x(int M) {
   int tiles = clsr_cdiv(M, 64);
   int gx = clsr_cdiv(tiles, 4);  // >= 4 position tiles per block before adding blocks
-  static const int cap = getenv("CLSR_DW_PARTS") ? atoi(getenv("CLSR_DW_PARTS")) : 512;   // blocks per chunk of the fp32-MFMA kernels (384: +40 us per exact-mode step; the bf16 kernels use 384, csrc/hdw.hip)
+  constexpr int cap = 512;   // blocks per chunk of the fp32-MFMA kernels (384: +40 us per exact-mode step; the bf16 kernels use 384, csrc/hdw.hip)
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
   return gx;
@@ -1168,7 +1162,7 @@ static int dw_launch_partial(const void* X, int ldx, int T, int G, const float* 
     return CLSR_OK;
   }
   const int ktn = clsr_cdiv(K, 16), ntn = clsr_cdiv(N, 16);
-  const bool one = kch == 1 && nch == 1 && !getenv("CLSR_DW_GENERIC");
+  const bool one = kch == 1 && nch == 1;
 #define DW_SPEC(MD, KT_, NT_)                                                                                          \
   if (one && ktn == KT_ && ntn == NT_) {                                                                               \
     hipLaunchKernelGGL((pgemm_dw_kernel<MD, false, false, KT_, NT_>), dim3(gx, 1, 1), dim3(256), 0, s, a);            \
@@ -1220,7 +1214,7 @@ extern "C" int clsr_pgemm_dw_partial_multi(const clsr_dwjob* jobs, int n, void* 
     total += m.gx[j] * kch * nch;
   }
   m.first[n] = total;
-  m.spec = getenv("CLSR_DW_GENERIC") ? 0 : (getenv("CLSR_DW_SPEC") ? atoi(getenv("CLSR_DW_SPEC")) : 2);
+  m.spec = 2;
   hipLaunchKernelGGL(dw_multi_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, m);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;

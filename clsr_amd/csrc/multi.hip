@@ -289,8 +289,6 @@ __global__ void __launch_bounds__(256) tables_reg_multi_v4_kernel(TablesArgs a) 
 }
 // every table of the launch: rows of 4 k values, 16-byte aligned operands, fewer than 2^31 values
 static bool tables_v4_ok(const clsr_table_desc* descs, int n, bool with_moments) {
-  static const bool off = getenv("CLSR_TABLES_NO_V4") != nullptr;
-  if (off) return false;
   for (int i = 0; i < n; ++i) {
     const clsr_table_desc& d = descs[i];
     if (d.C % 4 || d.V * d.C >= (1L << 31)) return false;

@@ -95,7 +95,7 @@ static int dense_reg_norm_any(const float* param, float* grad, const int* seg_of
   CLSR_CHECK_ARG(param && grad && seg_off && sumsq && nseg > 0);
   // (workgroups of 1 024 threads wait for a CU with sixteen free wave slots while the table sweeps of the other stream fill
   // the chip: CLSR_DENSE_REG_THREADS picks the size, A/B)
-  static const int threads = []() { const char* e = getenv("CLSR_DENSE_REG_THREADS"); const int t = e ? atoi(e) : 256; return (t == 256 || t == 512 || t == 1024) ? t : 256; }();
+  constexpr int threads = 256;
   const int th = (threads_arg == 256 || threads_arg == 512 || threads_arg == 1024) ? threads_arg : threads;
   hipLaunchKernelGGL(dense_reg_norm_kernel, dim3(nseg), dim3(th), 0, (hipStream_t)stream, param, grad,
                      seg_off, l2, l1, sumsq, reg_loss, adam_state, lr, beta1, beta2);
@@ -574,8 +574,7 @@ extern "C" int clsr_table_adam_rows(float* table, float* grad_table, float* m, f
   CLSR_CHECK_ARG(nsum > 0);
   const bool vec = C % 4 == 0;
   int blocks = clsr_cdiv((long)cap * C, 256 * 4 * (vec ? 2 : 1));
-  static const int cap_env = getenv("CLSR_ADAM_ROWS_BLOCKS") ? atoi(getenv("CLSR_ADAM_ROWS_BLOCKS")) : 4096;
-  const int cap_blocks = cap_env > 0 ? cap_env : 4096;      // (a non-positive value would launch nothing)
+  constexpr int cap_blocks = 4096;
   if (blocks > cap_blocks) blocks = cap_blocks;
   if (vec)
     hipLaunchKernelGGL((table_adam_rows_kernel<4, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, grad_table,
@@ -668,9 +667,8 @@ extern "C" int clsr_copy_words(void* dst, const void* src, long nbytes, void* st
   CLSR_CHECK_ARG(((uintptr_t)dst % 16) == 0 && ((uintptr_t)src % 16) == 0);
   const long n16 = nbytes / 16;
   // (probe variants, for the record: CLSR_COPY_NT = 0 | 1, CLSR_COPY_U = 4 | 8, CLSR_COPY_BLOCKS)
-  static const int nt = getenv("CLSR_COPY_NT") ? atoi(getenv("CLSR_COPY_NT")) : 1;
-  static const int un = getenv("CLSR_COPY_U") ? atoi(getenv("CLSR_COPY_U")) : 4;
-  static const long cap = getenv("CLSR_COPY_BLOCKS") ? atol(getenv("CLSR_COPY_BLOCKS")) : (1L << 20);   // (swept: 2 Ki .. 1 Mi blocks, 64 MB .. 4 GB, plain / non-temporal, 4 / 8 in flight: scripts/copy_sweep.py)
+  constexpr int nt = 1, un = 4;
+  constexpr long cap = 1L << 20;   // (swept: 2 Ki .. 1 Mi blocks, 64 MB .. 4 GB, plain / non-temporal, 4 / 8 in flight: scripts/copy_sweep.py)
   long blocks = (n16 + 256L * un - 1) / (256L * un);
   if (blocks > cap) blocks = cap;
   hipStream_t st = (hipStream_t)stream;

@@ -192,8 +192,7 @@ template <int NKC, int NT, int NP, bool TTF = false>
 static int proj_launch(const ProjArgs& a, hipStream_t stream) {
   constexpr int WS = 32 * NKC + 8, NR = 16 * NT;
   const size_t shmem = (size_t)NP * NR * WS * 2 + (TTF ? (size_t)2 * 32 * NKC * 4 : 0);
-  static const bool wide_wg = getenv("CLSR_PROJ_WG256") == nullptr;      // (A/B)
-  const int threads = (shmem > 80 * 1024 && wide_wg) ? 512 : 256;         // (more than half of the CU's 160 KB: one workgroup per CU)
+  const int threads = shmem > 80 * 1024 ? 512 : 256;         // (more than half of the CU's 160 KB: one workgroup per CU)
   int gx = clsr_cdiv(clsr_cdiv(a.M, 16), threads / 64);
   const int cap = threads == 512 ? 256 : 512;
   if (gx > cap) gx = cap;
@@ -407,8 +406,7 @@ extern "C" int clsr_proj_x3_wide_supported(int M, int K, int N) {
 extern "C" int clsr_proj_x3_wide(const float* X, int ldx, const float* Wt, int Kp, const float* bias, float* Y, int ldy, int M,
                                  int K, int N, int pieces, int accumulate, void* stream) {
   CLSR_CHECK_SUPPORTED(clsr_proj_x3_wide_supported(M, K, N));
-  static const bool slabs = getenv("CLSR_PROJ_SLABS") != nullptr;      // (A/B: the chain of accumulating launches)
-  if (K > 128 && !slabs) return proj_x3_kloop(X, ldx, Wt, Kp, bias, Y, ldy, M, K, N, pieces, accumulate, stream);
+  if (K > 128) return proj_x3_kloop(X, ldx, Wt, Kp, bias, Y, ldy, M, K, N, pieces, accumulate, stream);
   for (int k0 = 0; k0 < K; k0 += 128) {
     const int kw = K - k0 < 128 ? K - k0 : 128;
     int rc = proj_x3_any(X + k0, ldx, Wt + k0, Kp, k0 ? nullptr : bias, Y, ldy, M, kw, N, pieces, (k0 || accumulate) ? 1 : 0, stream);

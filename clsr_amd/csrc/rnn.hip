@@ -367,8 +367,7 @@ static int rnn_tiles(int n) { return n <= 48 ? 3 : 8; }
 // Descriptors carry it (clsr_gru_desc.products / clsr_t4_desc.products); 0 = the process default: CLSR_RNN_PRODUCTS =
 // "fp32" | "x3", split-bf16 when unset.
 static bool rnn_default_x3() {
-  static const bool x3 = []() { const char* e = getenv("CLSR_RNN_PRODUCTS"); return !(e && e[0] == 'f'); }();
-  return x3;
+  return true;
 }
 static bool rnn_x3(int products) { return products == 0 ? rnn_default_x3() : products == 2; }
 

@@ -245,8 +245,29 @@ extern "C" int clsr_sort_ids_stable_multi(const clsr_sortids_desc* descs, int n,
 // ===================================================================================================== segmented sums
 // One lookup SITE of a launch: rows `key` of `grad` receive the sums of the slices  g[e, :] = src[pos(e), col0 : col0 + C]
 // (+ src2, + the mean / recent-k terms of the history prologue when dmean / drecent are given: pos = h * T + t).
+//
+// ONE launch (round 6; rounds 4-5: a chunk walk + a border launch).  Thread groups walk chunks of SS_CHUNK sorted entries
+// and sum runs of equal ids in registers, in list order; a run that lies inside one chunk is written to its row once.
+// Runs that cross a chunk border:
+//  * SHORT continuation -- the run ends within the first SS_E entries of the next chunk (decided from the sorted keys
+//    alone, the same answer on both sides of the border): the LEFT chunk keeps walking those entries, the right chunk skips
+//    them.  No partial, no communication; on lists whose ids repeat a few times (the benchmark's catalogue feed) this is every
+//    border.
+//  * LONG runs (popular ids of a Zipf list: the longest spans ~800 chunks): every chunk of the run leaves ONE partial in the
+//    workspace with device-coherent stores and then raises its ready word; the chunk in which the run ENDS (the tail) owns the
+//    row: its whole workgroup finds the run's extent from the key list, waits for the ready words of the EARLIER chunks
+//    (decoupled look-back: workgroups are dispatched in index order and a chunk only ever waits for lower-numbered ones, so
+//    the wait always ends), adds the partials in a fixed order and writes the row.  A ready word has exactly ONE reader -- the
+//    tail of the run its chunk feeds -- which clears it again: the workspace needs no clearing between launches and a replayed
+//    launch plan / hipGraph passes no counter.  (A launch-wide counter of finished workgroups -- the first version: epochs as
+//    ready values, the last workgroup folds the squared norms -- cost 8 us: ~900 device-scope atomics on one word at the end
+//    of a launch whose workgroups all finish together.)
+// The squared norms of the slices leave as one partial per workgroup and are added in workgroup order by a one-workgroup
+// launch behind the walk (only when a site asks for them).
+// The workspace must be ZERO when it is first used and must not be shared by two launches in flight.  No float atomics;
+// every addition has a fixed place in a fixed order: bit-identical runs.
 #ifndef SS_BU
-#define SS_BU 8          // partial rows of a lane slot in flight in the border combine (power of two)
+#define SS_BU 8          // partial rows of a lane slot in flight in the tail combine (power of two)
 #endif
 #ifndef SS_CHUNK
 #define SS_CHUNK 32                 // sorted entries per thread group
@@ -254,9 +275,8 @@ extern "C" int clsr_sort_ids_stable_multi(const clsr_sortids_desc* descs, int n,
 #ifndef SS_LEAN_B
 #define SS_LEAN_B 8                 // entries of a chunk in flight per thread group in the LEAN instantiation (8 or 16; SS_CHUNK % SS_LEAN_B == 0)
 #endif
-#ifndef SS_WCH
-#define SS_WCH 1                    // chunks a wave of the border launch is responsible for (8: 20 us instead of 12 on the catalogue -- the category site has a head in most chunks and a wave walks its heads one after the other)
-#endif
+#define SS_E 8                      // a continuation of at most this many entries is walked by the chunk the run comes from
+struct SsHdr { unsigned err; unsigned pad[3]; };
 struct SsSite {
   const void* src; const void* src2; int src_bf16; const float* dmean; const float* drecent;
   const int* keys; const int* perm; const int* seq_len; int len_stride;
@@ -266,10 +286,9 @@ struct SsSite {
   int assign;                     // row totals are stored, not added
   const float* src_b; double* sumsq_b; long n1; int ldb; int colb;   // second source (entries with perm >= n1), n1 = 0: none
   float* bnd; int* meta; double* ssp;   // workspace: chunk-border partials [nchunks][2][Cp], [nchunks][4] ints, [blocks][2] doubles
-  int first_block; int nblocks; int first_block_b; int cp; int vw;
-  int wch;                        // chunks per wave of the border launch (clsr_segsum_desc.border_wch)
+  int first_block; int nblocks; int cp; int vw;
 };
-struct SsArgs { SsSite s[CLSR_SEGSUM_MAX]; int n; };
+struct SsArgs { SsSite s[CLSR_SEGSUM_MAX]; int n; SsHdr* hdr; };
 
 template <int VW> struct SsVec { typedef float type; };
 template <> struct SsVec<4> { typedef f32x4 type; };
@@ -284,8 +303,27 @@ __device__ __forceinline__ typename SsVec<VW>::type ss_ld(const void* p, int bf1
 __device__ __forceinline__ float ss_sq(float x) { return x * x; }
 __device__ __forceinline__ float ss_sq(const f32x4& x) { return x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w; }
 
-// meta[chunk]: 0 first key (or -1), 1 last key, 2 flags (1: first run continues from the previous chunk, 2: last run
-// continues into the next chunk, 4: the whole chunk is one run), 3 unused
+// device-coherent accesses (write-through, L2-bypassing -- the pattern of csrc/headsfused.hip): only the few partial rows of
+// LONG runs and the per-workgroup squared norms travel this way; a release fence would write back an L2 full of gradient rows
+#define SS_WAIT_MEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+__device__ __forceinline__ void ss_cst(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ss_cst(float* p, const f32x4& v) { ss_cst(p, v.x); ss_cst(p + 1, v.y); ss_cst(p + 2, v.z); ss_cst(p + 3, v.w); }
+__device__ __forceinline__ void ss_csti(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ss_cldi(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <int VW> __device__ __forceinline__ typename SsVec<VW>::type ss_cld(const float* p) {
+  if constexpr (VW == 4) {
+    f32x4 v;
+    v.x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v.y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.z = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v.w = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+  } else {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// meta[chunk] (published by chunks whose LAST run goes on into the next chunk only): 0 first key, 1 last key, 2 flags (1: the
+// first run comes from the previous chunk, 2: the last run goes on into the next chunk, 4: the whole chunk is one run), 3 ready
+// (1 while the partial waits for its reader)
 // eight consecutive ints a[q0 .. q0 + 7] (fill beyond ``pe``): two 16-byte loads when the batch is whole and aligned
 __device__ __forceinline__ void ss_ld8(const int* __restrict__ a, const long q0, const long pe, const int fill, int out[8]) {
   if (q0 + 8 <= pe && ((reinterpret_cast<uintptr_t>(a + q0) & 15) == 0)) {
@@ -298,29 +336,71 @@ __device__ __forceinline__ void ss_ld8(const int* __restrict__ a, const long q0,
   }
 }
 
+// SB consecutive ints a[q0 .. q0 + SB - 1] (fill beyond ``pe``)
+template <int SB>
+__device__ __forceinline__ void ss_ldn(const int* __restrict__ a, const long q0, const long pe, const int fill, int (&out)[SB]) {
+  if constexpr (SB % 8 == 0) {
+#pragma unroll
+    for (int b8 = 0; b8 < SB; b8 += 8) ss_ld8(a, q0 + b8, pe, fill, out + b8);
+  } else {
+#pragma unroll
+    for (int k = 0; k < SB; ++k) out[k] = q0 + k < pe ? a[q0 + k] : fill;
+  }
+}
+
 // LEAN: the site has no second gradient tensor and no mean / recent shares (src2, dmean, drecent all NULL) and its row totals
 // are stored (assign): four registers per entry in flight instead of twenty -- the kernel is bound by the number of row
 // reads it keeps in flight (profiles/r04_embed_kernel_trace.md: traffic = the algorithmic bytes at 3 TB/s), and with 240
 // VGPRs only two waves per SIMD were resident.
 template <int VW, bool LEAN, int SB = 8>
-__device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block, double* red) {
+__device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block, double* red, int* sh, float* shf, SsHdr* hdr) {
   typedef typename SsVec<VW>::type vec_t;
+  // SB = 8: four batches cover the chunk, a short continuation (<= 8 entries) is one more batch -- on ~7 % of the chunks of the
+  // benchmark's catalogue feed; every wave is resident from the start, so the launch lasts as long as its LONGEST chain: five
+  // batches instead of four (42 us against the 36 us of a run-free walk).  SB = 9 (instantiable: the four batches have 36
+  // slots, the last four hold a continuation of <= 4 entries, EVERY chunk is four dependent batches) measured 52.7 us: 140
+  // VGPRs (three waves per SIMD), or 128 with 15 spilled, and unaligned key loads.
+  constexpr int NBATCH = SS_CHUNK / 8;
+  constexpr bool WIDE = SB * NBATCH > SS_CHUNK;
+  constexpr int E = WIDE ? SB * NBATCH - SS_CHUNK : SS_E;
+  static_assert(E <= SB && E <= SS_CHUNK, "a short continuation fits one batch");
   const int CP = s.cp;                         // lanes per thread group (power of two, 8..64)
   const int gpb = 256 / CP;
   const int lig = threadIdx.x & (CP - 1);      // lane in group
+  const int gi = threadIdx.x / CP;             // group in workgroup
   const int c = lig * VW;
   const bool cok = c < s.C;
-  const long chunk = (long)local_block * gpb + threadIdx.x / CP;
+  const long chunk = (long)local_block * gpb + gi;
   const long nchunks = (s.n + SS_CHUNK - 1) / SS_CHUNK;
   const long p0 = chunk * SS_CHUNK;
   const int Cp = CP * VW;
   float local = 0.f, local_b = 0.f;
+  int flags = 0, first_key = -1, cur = -1;
+  vec_t pfirst = vec_t(0.f);                   // this chunk's share of a run that comes from the previous chunk
   if (chunk < nchunks) {
     const long cc = s.col0 + (cok ? c : 0);
-    const int prev_key = p0 > 0 ? s.keys[p0 - 1] : -1;
     const long pe = p0 + SS_CHUNK < s.n ? p0 + SS_CHUNK : s.n;
-    const int next_key = pe < s.n ? s.keys[pe] : -1;
-    int cur = -1, first_key = -1, nruns = 0;
+    // the keys on both sides of the two borders: one round trip
+    const int kprev = p0 > 0 ? s.keys[p0 - 1] : -1;
+    const int kpe = p0 + E < s.n ? s.keys[p0 + E] : -2;          // (-2: no such entry)
+    const int klast = s.keys[pe - 1];
+    const int knx = pe < s.n ? s.keys[pe] : -1;
+    const int kne = pe + E < s.n ? s.keys[pe + E] : -2;
+    int keyN[SB], posN[SB];
+    ss_ldn<SB>(s.keys, p0, pe, -1, keyN);
+    ss_ldn<SB>(s.perm, p0, pe, 0, posN);
+    // a run over the border at p0 / pe that ends within SS_E entries behind it belongs to the chunk it comes from
+    const bool short_prev = kprev >= 0 && keyN[0] == kprev && kpe != kprev;
+    const bool short_next = knx >= 0 && klast == knx && kne != knx;
+    const int prev_key = short_prev ? -2 : kprev;      // (-2: never the key of an entry)
+    const int next_key = short_next ? -2 : knx;
+    const long pe_walk = WIDE ? p0 + (long)SB * NBATCH : (short_next ? pe + SB : pe);     // (not WIDE: one more batch for the continuation)
+    const long lim = short_next ? (pe + E < s.n ? pe + E : s.n) : pe;         // entries that may be read
+    if (short_prev) {
+#pragma unroll
+      for (int k = 0; k < E; ++k) if (keyN[k] == kprev) keyN[k] = -1;         // (a prefix: the list is sorted)
+    }
+    int nruns = 0;
     vec_t acc = vec_t(0.f);
     float* bnd = s.bnd + chunk * 2 * Cp;
     auto flush = [&](bool last) {
@@ -328,7 +408,8 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
       const bool from_prev = nruns == 0 && cur == prev_key;
       const bool to_next = last && cur == next_key;
       if (from_prev || to_next) {
-        if (cok) *reinterpret_cast<vec_t*>(bnd + (from_prev ? 0 : Cp) + c) = acc;
+        if (from_prev) pfirst = acc;
+        if (cok) ss_cst(bnd + (from_prev ? 0 : Cp) + c, acc);
       } else if (cok) {
         vec_t* g = reinterpret_cast<vec_t*>(s.grad + (long)cur * s.ldg + s.gcol0 + c);
         *g = (LEAN || s.assign) ? acc : *g + acc;
@@ -337,10 +418,7 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
     };
     // keys / slice numbers of a batch of eight are fetched ONE BATCH AHEAD (two 16-byte loads each): the row reads of a
     // batch depend on them, and with both fetched in the batch itself every batch paid two memory round trips in a row
-    int keyN[SB], posN[SB];
-#pragma unroll
-    for (int b8 = 0; b8 < SB; b8 += 8) { ss_ld8(s.keys, p0 + b8, pe, -1, keyN + b8); ss_ld8(s.perm, p0 + b8, pe, 0, posN + b8); }
-    for (long q0 = p0; q0 < pe; q0 += SB) {
+    for (long q0 = p0; q0 < pe_walk; q0 += SB) {
       int key[SB], posk[SB];
       bool sec[SB];
       vec_t g[SB];
@@ -394,9 +472,18 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
         }
         g[k] = (cok && key[k] >= 0) ? v : vec_t(0.f);
       }
-      if (q0 + SB < pe) {
+      if (q0 + SB < pe_walk) {
+        ss_ldn<SB>(s.keys, q0 + SB, lim, -1, keyN);
+        ss_ldn<SB>(s.perm, q0 + SB, lim, 0, posN);
+        if constexpr (WIDE) {
+          if (q0 + 2 * SB > pe) {          // slots behind the chunk: the entries of the run that crosses the border only
 #pragma unroll
-        for (int b8 = 0; b8 < SB; b8 += 8) { ss_ld8(s.keys, q0 + SB + b8, pe, -1, keyN + b8); ss_ld8(s.perm, q0 + SB + b8, pe, 0, posN + b8); }
+            for (int k = 0; k < SB; ++k) if (q0 + SB + k >= pe && keyN[k] != knx) keyN[k] = -1;
+          }
+        } else if (q0 + SB >= pe) {        // the continuation batch: the entries of the run that crosses the border only
+#pragma unroll
+          for (int k = 0; k < SB; ++k) if (keyN[k] != knx) keyN[k] = -1;
+        }
       } else {
 #pragma unroll
         for (int k = 0; k < SB; ++k) { keyN[k] = -1; posN[k] = 0; }
@@ -423,36 +510,85 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
         } else {
           acc += g[k];
         }
-        // does the run end at this entry?  (the last entry of the chunk leaves its run open: see below)
+        // does the run end at this entry?  (the last entry of the walk leaves its run open: see below)
         int nk = key[k];
         if (k < SB - 1) { if (key[k + 1] >= 0) nk = key[k + 1]; }
-        else if (q0 + SB < pe) nk = knext;
+        else if (q0 + SB < pe_walk && knext >= 0) nk = knext;
         if (nk != key[k]) {
           const bool from_prev = nruns == 0 && cur == prev_key;
+          if (from_prev) pfirst = acc;
           if (cok) {
-            if (from_prev) *reinterpret_cast<vec_t*>(bnd + c) = acc;
+            if (from_prev) ss_cst(bnd + c, acc);
             else *reinterpret_cast<vec_t*>(s.grad + (long)cur * s.ldg + s.gcol0 + c) = gv[k] + acc;
           }
           ++nruns;
         }
       }
     }
-    int flags = 0;
     if (cur >= 0) {
       const bool single = nruns == 0;                 // the chunk is one run
-      const bool from_prev_last = single && cur == prev_key;
       const bool to_next = cur == next_key;
       flush(true);
       if (first_key == prev_key && prev_key >= 0) flags |= 1;
       if (to_next) flags |= 2;
       if (single) flags |= 4;
-      (void)from_prev_last;
+      if (!(flags & 3)) flags = 0;                    // (no share of a long run: nothing to publish)
     }
-    if (lig == 0) {
-      int* m = s.meta + chunk * 4;
-      m[0] = first_key; m[1] = cur; m[2] = flags; m[3] = 0;
+    if (flags & 2) {                                  // a later chunk will read this chunk's partial
+      SS_WAIT_MEM();                                  // the partial rows of this wave have left
+      if (lig == 0) {
+        int* m = s.meta + chunk * 4;
+        ss_csti(m, first_key); ss_csti(m + 1, cur); ss_csti(m + 2, flags);
+      }
+      SS_WAIT_MEM();
+      if (lig == 0) ss_csti(s.meta + chunk * 4 + 3, 1);
     }
   }
+  // ---- the chunk in which a LONG run ends owns its row.  Extent of the run: the chunks before this one whose LAST entry
+  //      carries the key (read from the key list -- no communication); a run that started within the CP chunks before this
+  //      one is finished by the thread group itself (no barrier: the groups of a wave are in lockstep): its lanes wait for the
+  //      ready words of those chunks, then the partials are added in chunk order.  Longer runs: the whole workgroup (below).
+  const bool is_tail = chunk < nchunks && (flags & 1) && !((flags & 4) && (flags & 2));
+  bool deferred = false;
+  if (is_tail) {
+    const long cb = chunk - 1 - lig;
+    const bool member = cb >= 0 && s.keys[(cb + 1) * SS_CHUNK - 1] == first_key;
+    const unsigned long long bm = __ballot(member) >> ((threadIdx.x & 63) & ~(CP - 1));
+    const unsigned long long mine = CP == 64 ? bm : (bm & ((1ull << CP) - 1ull));
+    const int L = mine == (CP == 64 ? ~0ull : ((1ull << CP) - 1ull)) ? CP : __builtin_ctzll(~mine);
+    if (L >= CP) {
+      deferred = true;
+    } else {
+      // lane i < L waits for chunk - 1 - i (a LOWER-numbered chunk: its workgroup was dispatched before this one and waits
+      // for nothing this workgroup has to give; bounded all the same -- two seconds of the 100 MHz clock)
+      const long long t0 = wall_clock64();
+      if (lig < L) {
+        while (ss_cldi(s.meta + (chunk - 1 - lig) * 4 + 3) != 1) {
+          if (wall_clock64() - t0 > 200000000LL) { __hip_atomic_store(&hdr->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int cs = cok ? c : 0;
+      // head (chunk - L): the partial of its LAST run (slot 1); chunks in between: their only run (slot 0); then this chunk's
+      vec_t tot = ss_cld<VW>(s.bnd + (chunk - L) * 2 * Cp + Cp + cs);
+      for (int i0 = 1; i0 < L; i0 += 8) {
+        vec_t pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pv[u] = ss_cld<VW>(s.bnd + (chunk - L + (i0 + u < L ? i0 + u : L - 1)) * 2 * Cp + cs);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (i0 + u < L) tot += pv[u];
+      }
+      tot += pfirst;
+      if (cok) {
+        vec_t* g = reinterpret_cast<vec_t*>(s.grad + (long)first_key * s.ldg + s.gcol0 + c);
+        *g = (LEAN || s.assign) ? tot : *g + tot;
+      }
+      if (lig < L) ss_csti(s.meta + (chunk - 1 - lig) * 4 + 3, 0);      // (read: the words are clear again for the next launch)
+    }
+  }
+  if (lig == 0) { sh[2 * gi] = deferred ? flags : 0; sh[2 * gi + 1] = first_key; }
+  // ---- squared norms: one partial per workgroup and source, added in workgroup order by ss_fold_kernel
   if (s.sumsq) {
     const double tot = block256_sum_d((double)local, red);
     if (threadIdx.x == 0) s.ssp[2 * local_block] = tot;
@@ -462,153 +598,126 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
     const double tot = block256_sum_d((double)local_b, red);
     if (threadIdx.x == 0) s.ssp[2 * local_block + 1] = tot;
   }
+  if (!__syncthreads_or(deferred ? 1 : 0)) return;
+  // ---- tails of runs that span CP chunks or more (the popular ids of a Zipf list: up to ~800 chunks): the whole workgroup
+  //      adds the partials (slot j of 256 / CP takes the chunks j, j + S, ... of the run, SS_BU rows in flight; the slots are
+  //      added in order)
+  const int S = gpb;
+  for (int t = 0; t < gpb; ++t) {
+    const int fl = sh[2 * t];
+    if (!fl) continue;                                      // (uniform)
+    const long ck = (long)local_block * gpb + t;
+    const int key = sh[2 * t + 1];
+    // extent: chunks ck - L .. ck - 1 hold entries of the run -- their LAST entries carry the key (256 borders per trip)
+    long L = 0;
+    for (bool open = true; open;) {
+      const long cb = ck - 1 - L - threadIdx.x;             // this thread's chunk of the trip
+      const bool member = cb >= 0 && s.keys[(cb + 1) * SS_CHUNK - 1] == key;
+      // (first non-member of the trip, in thread order: ballots per wave, the waves in order through LDS)
+      const unsigned long long bm = __ballot(member);
+      const int nw = bm == ~0ull ? 64 : __builtin_ctzll(~bm);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) sh[2 * gpb + (threadIdx.x >> 6)] = nw;
+      __syncthreads();
+      int tot = 0;
+      bool all = true;
+      for (int w = 0; w < 4 && all; ++w) { const int x = sh[2 * gpb + w]; tot += x; all = x == 64; }
+      L += tot;
+      open = all;
+    }
+    // members i = 0 .. L - 1: chunk ck - L + i; the head (i = 0) left the partial of its LAST run (slot 1), the others the
+    // partial of their only run (slot 0); the tail's own share is still in the registers of its thread group
+    vec_t aN[SS_BU];
+#pragma unroll
+    for (int u = 0; u < SS_BU; ++u) aN[u] = vec_t(0.f);
+    const int cs = cok ? c : 0;
+    const long long t0 = wall_clock64();
+    for (long i0 = gi; i0 < L; i0 += (long)SS_BU * S) {
+      vec_t pv[SS_BU];
+#pragma unroll
+      for (int u = 0; u < SS_BU; ++u) {
+        const long i = i0 + (long)u * S;
+        const long cm = ck - L + (i < L ? i : L - 1);
+        while (ss_cldi(s.meta + cm * 4 + 3) != 1) {
+          if (wall_clock64() - t0 > 200000000LL) { __hip_atomic_store(&hdr->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        pv[u] = ss_cld<VW>(s.bnd + cm * 2 * Cp + (i == 0 ? Cp : 0) + cs);
+      }
+#pragma unroll
+      for (int u = 0; u < SS_BU; ++u)
+        if (cok && i0 + (long)u * S < L) aN[u] += pv[u];
+    }
+#pragma unroll
+    for (int w = 1; w < SS_BU; w *= 2)
+#pragma unroll
+      for (int u = 0; u + w < SS_BU; u += 2 * w) aN[u] += aN[u + w];
+    __syncthreads();                       // (every wait above has ended: the ready words can be cleared)
+    for (long i = threadIdx.x; i < L; i += 256) ss_csti(s.meta + (ck - L + i) * 4 + 3, 0);
+    if constexpr (VW == 4) {
+      shf[(gi * CP + lig) * 4 + 0] = aN[0].x; shf[(gi * CP + lig) * 4 + 1] = aN[0].y;
+      shf[(gi * CP + lig) * 4 + 2] = aN[0].z; shf[(gi * CP + lig) * 4 + 3] = aN[0].w;
+    } else {
+      shf[gi * CP + lig] = aN[0];
+    }
+    __syncthreads();
+    if (gi == t && cok) {                  // the tail's own thread group: the slots in order, then its own share
+      vec_t tot = vec_t(0.f);
+      for (int j = 0; j < S; ++j) {
+        if constexpr (VW == 4) tot += (f32x4){shf[(j * CP + lig) * 4], shf[(j * CP + lig) * 4 + 1], shf[(j * CP + lig) * 4 + 2], shf[(j * CP + lig) * 4 + 3]};
+        else tot += shf[j * CP + lig];
+      }
+      tot += pfirst;
+      vec_t* g = reinterpret_cast<vec_t*>(s.grad + (long)key * s.ldg + s.gcol0 + c);
+      *g = s.assign ? tot : *g + tot;
+    }
+  }
+}
+
+// squared norms of every site: the workgroup partials of the walk in workgroup order (lane-strided sums, then the lanes in
+// order -- a fixed order).  Block (site, source); launched only when a site wants its norms.
+__global__ void __launch_bounds__(64) ss_fold_kernel(SsArgs a) {
+  const SsSite& s = a.s[blockIdx.x >> 1];
+  const int which = blockIdx.x & 1, lane = threadIdx.x;
+  double* dst = which == 0 ? s.sumsq : s.sumsq_b;
+  if (!dst) return;
+  double t = 0.0;
+  // (eight partials of a lane in flight; the same order of additions as one after the other)
+  for (int b0 = lane; b0 < s.nblocks; b0 += 64 * 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = b0 + 64 * u;
+      v[u] = b < s.nblocks ? s.ssp[2 * b + which] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += v[u];
+  }
+  double tot = 0.0;
+  for (int l = 0; l < 64; ++l) tot += __shfl(t, l, 64);
+  if (lane == 0) *dst += tot;
 }
 
 __global__ void __launch_bounds__(256) ss_chunks_kernel(SsArgs a) {
   __shared__ double red[4];
+  __shared__ int sh[2 * 32 + 4];
+  __shared__ float shf[256 * 4];
   int i = 0;
   while (i + 1 < a.n && (int)blockIdx.x >= a.s[i + 1].first_block) ++i;
   const SsSite& s = a.s[i];
-  if (s.vw == 4) ss_chunks<4, false>(s, blockIdx.x - s.first_block, red);
-  else ss_chunks<1, false>(s, blockIdx.x - s.first_block, red);
+  if (s.vw == 4) ss_chunks<4, false>(s, blockIdx.x - s.first_block, red, sh, shf, a.hdr);
+  else ss_chunks<1, false>(s, blockIdx.x - s.first_block, red, sh, shf, a.hdr);
 }
 // every site of the launch is LEAN (see ss_chunks): half the registers, twice the resident waves
 __global__ void __launch_bounds__(256) ss_chunks_lean_kernel(SsArgs a) {
   __shared__ double red[4];
+  __shared__ int sh[2 * 32 + 4];
+  __shared__ float shf[256 * 4];
   int i = 0;
   while (i + 1 < a.n && (int)blockIdx.x >= a.s[i + 1].first_block) ++i;
   const SsSite& s = a.s[i];
-  if (s.vw == 4) ss_chunks<4, true, SS_LEAN_B>(s, blockIdx.x - s.first_block, red);
-  else ss_chunks<1, true>(s, blockIdx.x - s.first_block, red);
-}
-
-// Runs that cross chunk borders: the chunk whose LAST run continues (and is not itself a continuation covering the whole
-// chunk) is the head of such a run.  One WAVE per chunk: a head wave finds the extent of its run 64 chunks at a time
-// (ballots over the chunks' flags), then its 64 / CP lane slots add the partials of the following chunks -- slot j takes
-// the chunks j, j + S, ... of the run -- and the slots are added in slot order: a fixed order for a given list, and a
-// run of 25 000 slices of one popular row (780 partials) costs ~100 dependent steps instead of 780.  The first wave of
-// every site also folds the squared-norm partials of the first launch (lane-strided sums, then the lanes in order).
-template <int VW>
-__device__ __forceinline__ void ss_borders(const SsSite& s, const int local_block) {
-  typedef typename SsVec<VW>::type vec_t;
-  const int CP = s.cp, S = 64 / CP;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int lig = lane & (CP - 1), slot = lane / CP;
-  const int c = lig * VW;
-  const bool cok = c < s.C;
-  const int Cp = CP * VW;
-  const long nchunks = (s.n + SS_CHUNK - 1) / SS_CHUNK;
-  // a wave tests SS_WCH consecutive chunks at once (one lane each) and walks the heads among them: with one wave per chunk
-  // the launch cost 11.7 us on a catalogue with hardly any run across a border (1 760 workgroups that read one flag word)
-  const int WCH = s.wch;
-  const long cbase = ((long)local_block * 4 + wave) * WCH;
-  unsigned long long heads = 0;
-  {
-    const long ck = cbase + lane;
-    int fl = 0;
-    if (lane < WCH && ck < nchunks) fl = s.meta[ck * 4 + 2];
-    heads = __ballot((fl & 2) && !((fl & 4) && (fl & 1)));
-  }
-  while (heads) {
-    const long chunk = cbase + __builtin_ctzll(heads);
-    heads &= heads - 1;
-    const int* m = s.meta + chunk * 4;
-    {
-      const int key = m[1];
-      // extent: chunks chunk + 1 .. chunk + L belong to the run (whole-chunk continuations, then the chunk it ends in)
-      // (256 chunks per trip -- four 16-byte flag loads per lane in flight: the scan is a chain of dependent loads, and the
-      // run of the most popular item of a Zipf catalogue spans ~800 chunks)
-      long L = 0;
-      bool open = true;
-      while (open) {
-        int4 mk[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const long k = chunk + 1 + L + 64 * u + lane;
-          mk[u] = k < nchunks ? *reinterpret_cast<const int4*>(s.meta + k * 4) : int4{-1, 0, 0, 0};
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (!open) break;
-          const bool member = mk[u].x == key && (mk[u].z & 1);
-          const bool whole = member && (mk[u].z & 4) && (mk[u].z & 2);
-          const unsigned long long bw = __ballot(whole), bm = __ballot(member);
-          const int nw = bw == ~0ull ? 64 : __builtin_ctzll(~bw);
-          if (nw == 64) { L += 64; continue; }
-          L += nw + (((bm >> nw) & 1ull) ? 1 : 0);
-          open = false;
-        }
-      }
-      // (SS_BU partials of a slot in flight: the loop is a chain of dependent row reads otherwise -- the longest run, the
-      // most popular item of a Zipf catalogue with ~800 partials, is what this launch waits for; fixed association)
-      vec_t aN[SS_BU];
-#pragma unroll
-      for (int u = 0; u < SS_BU; ++u) aN[u] = vec_t(0.f);
-      const int cs = cok ? c : 0;
-      for (long k = slot; k < L; k += SS_BU * S) {
-        // (unconditional loads from a clamped row, selected afterwards: with a branch per partial the loads left one at a
-        // time and the in-flight count made no difference)
-        vec_t pv[SS_BU];
-#pragma unroll
-        for (int u = 0; u < SS_BU; ++u) {
-          const long ku = k + (long)u * S;
-          pv[u] = *reinterpret_cast<const vec_t*>(s.bnd + (chunk + 1 + (ku < L ? ku : 0)) * 2 * Cp + cs);
-        }
-#pragma unroll
-        for (int u = 0; u < SS_BU; ++u)
-          if (cok && k + (long)u * S < L) aN[u] += pv[u];
-      }
-#pragma unroll
-      for (int w = 1; w < SS_BU; w *= 2)
-#pragma unroll
-        for (int u = 0; u + w < SS_BU; u += 2 * w) aN[u] += aN[u + w];
-      const vec_t acc = aN[0];
-      // the head chunk's own share (its last-run partial: slot 1), then the lane slots in order
-      vec_t tot = cok ? *reinterpret_cast<const vec_t*>(s.bnd + chunk * 2 * Cp + Cp + c) : vec_t(0.f);
-      for (int j = 0; j < S; ++j) {
-        if constexpr (VW == 4) {
-          f32x4 t;
-          t.x = __shfl(acc.x, j * CP + lig, 64); t.y = __shfl(acc.y, j * CP + lig, 64);
-          t.z = __shfl(acc.z, j * CP + lig, 64); t.w = __shfl(acc.w, j * CP + lig, 64);
-          tot += t;
-        } else {
-          tot += __shfl(acc, j * CP + lig, 64);
-        }
-      }
-      if (cok && slot == 0) {
-        vec_t* g = reinterpret_cast<vec_t*>(s.grad + (long)key * s.ldg + s.gcol0 + c);
-        *g = s.assign ? tot : *g + tot;
-      }
-    }
-  }
-  if (local_block == 0 && wave < 2) {        // wave 0: the first source's squared norms, wave 1: the second source's
-    double* dst = wave == 0 ? s.sumsq : s.sumsq_b;
-    if (dst) {
-      double t = 0.0;
-      // (eight partials of a lane in flight; the same order of additions as one after the other)
-      for (int b0 = lane; b0 < s.nblocks; b0 += 64 * 8) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int b = b0 + 64 * u;
-          v[u] = b < s.nblocks ? s.ssp[2 * b + wave] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t += v[u];
-      }
-      double tot = 0.0;
-      for (int l = 0; l < 64; ++l) tot += __shfl(t, l, 64);
-      if (lane == 0) *dst += tot;
-    }
-  }
-}
-
-__global__ void __launch_bounds__(256) ss_borders_kernel(SsArgs a) {
-  int i = 0;
-  while (i + 1 < a.n && (int)blockIdx.x >= a.s[i + 1].first_block_b) ++i;
-  const SsSite& s = a.s[i];
-  if (s.vw == 4) ss_borders<4>(s, blockIdx.x - s.first_block_b);
-  else ss_borders<1>(s, blockIdx.x - s.first_block_b);
+  if (s.vw == 4) ss_chunks<4, true, SS_LEAN_B>(s, blockIdx.x - s.first_block, red, sh, shf, a.hdr);
+  else ss_chunks<1, true>(s, blockIdx.x - s.first_block, red, sh, shf, a.hdr);
 }
 
 static void ss_shape(const clsr_segsum_desc& d, int* cp, int* vw) {
@@ -634,7 +743,7 @@ static long ss_site_bytes(long n, int cp, int vw, int* blocks) {
 
 extern "C" int clsr_sizeof_segsum_desc(void) { return (int)sizeof(clsr_segsum_desc); }
 extern "C" long clsr_segsum_workspace_bytes(const clsr_segsum_desc* descs, int n) {
-  long tot = 256;
+  long tot = 256;      // (header: error word; alignment slack)
   for (int i = 0; i < n; ++i) {
     int cp, vw;
     ss_shape(descs[i], &cp, &vw);
@@ -642,16 +751,27 @@ extern "C" long clsr_segsum_workspace_bytes(const clsr_segsum_desc* descs, int n
   }
   return tot;
 }
+// != 0: a tail of some launch on this workspace gave up waiting for an earlier chunk's partial (never expected: see above);
+// synchronous
+extern "C" int clsr_segsum_error(const void* workspace) {
+  if (!workspace) return -1;
+  const unsigned char* w = (const unsigned char*)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+  SsHdr h;
+  if (hipMemcpy(&h, w, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int)h.err;
+}
 
-// Sums of the slices of n lookup sites into their gradient tables (two launches).  The sites of ONE call must write
-// different tables (or disjoint columns), and nothing else may write those tables while the call runs.
+// Sums of the slices of n lookup sites into their gradient tables (ONE launch).  The sites of one call must write
+// different tables (or disjoint columns), and nothing else may write those tables while the call runs.  ``workspace``: zero
+// when first used; not shared by launches in flight.
 extern "C" int clsr_segsum_multi(const clsr_segsum_desc* descs, int n, void* workspace, long workspace_bytes, void* stream) {
   CLSR_CHECK_ARG(descs && n > 0 && n <= CLSR_SEGSUM_MAX && workspace);
   SsArgs a;
   a.n = n;
   unsigned char* w = (unsigned char*)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
-  long used = 0;
-  int total = 0, total_b = 0;
+  a.hdr = (SsHdr*)w;
+  long used = 64;
+  int total = 0;
   for (int i = 0; i < n; ++i) {
     const clsr_segsum_desc& d = descs[i];
     CLSR_CHECK_ARG(d.src && d.keys && d.perm && d.grad && d.n > 0 && d.D > 0 && d.C > 0);
@@ -679,9 +799,6 @@ extern "C" int clsr_segsum_multi(const clsr_segsum_desc* descs, int n, void* wor
     s.first_block = total;
     s.nblocks = nb;
     total += nb;
-    s.first_block_b = total_b;
-    s.wch = d.border_wch <= 0 ? SS_WCH : (d.border_wch > 64 ? 64 : d.border_wch);
-    total_b += clsr_cdiv(nchunks, 4 * s.wch);
   }
   CLSR_CHECK_ARG(workspace_bytes >= used + 16);
   hipStream_t st = (hipStream_t)stream;
@@ -690,7 +807,11 @@ extern "C" int clsr_segsum_multi(const clsr_segsum_desc* descs, int n, void* wor
   if (lean) hipLaunchKernelGGL(ss_chunks_lean_kernel, dim3(total), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(ss_chunks_kernel, dim3(total), dim3(256), 0, st, a);
   CLSR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ss_borders_kernel, dim3(total_b), dim3(256), 0, st, a);
-  CLSR_CHECK_LAUNCH();
+  bool norms = false;
+  for (int i = 0; i < n; ++i) norms = norms || descs[i].sumsq || descs[i].sumsq_b;
+  if (norms) {
+    hipLaunchKernelGGL(ss_fold_kernel, dim3(2 * n), dim3(64), 0, st, a);
+    CLSR_CHECK_LAUNCH();
+  }
   return CLSR_OK;
 }

@@ -317,7 +317,7 @@ static int gbs_launch(const void* dhist, const void* dhist2, int bf16, const flo
   const bool vec = C % 4 == 0 && D % 4 == 0 && col0 % 4 == 0 && gcol0 % 4 == 0 && ldg % 4 == 0 &&
                    ((uintptr_t)dhist % 16) == 0 && (!dhist2 || ((uintptr_t)dhist2 % 16) == 0) &&
                    (!dmean || ((uintptr_t)dmean % 16) == 0) && (!drecent || ((uintptr_t)drecent % 16) == 0) &&
-                   ((uintptr_t)grad % 16) == 0 && !getenv("CLSR_GBS_SCALAR");
+                   ((uintptr_t)grad % 16) == 0;
 #define LAUNCH_GBS(CPV, VWV)                                                                                   \
   do {                                                                                                         \
     const long groups = (n + GBS_CHUNK(CPV) - 1) / GBS_CHUNK(CPV);                                             \
@@ -352,7 +352,7 @@ static int gbs_launch(const void* dhist, const void* dhist2, int bf16, const flo
 
 // widest column block one launch of clsr_gather_bwd_sorted2 takes for this layout (256 with 16-byte accesses, else 64)
 extern "C" int clsr_gather_bwd_sorted_max_cols(int D, int col0, int C, int ldg, int gcol0) {
-  return (C % 4 == 0 && D % 4 == 0 && col0 % 4 == 0 && gcol0 % 4 == 0 && ldg % 4 == 0 && !getenv("CLSR_GBS_SCALAR")) ? 256 : 64;
+  return (C % 4 == 0 && D % 4 == 0 && col0 % 4 == 0 && gcol0 % 4 == 0 && ldg % 4 == 0) ? 256 : 64;
 }
 
 extern "C" int clsr_gather_bwd_sorted2(const float* dhist, const float* dhist2, const float* dmean,

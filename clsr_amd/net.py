@@ -116,32 +116,32 @@ class CLSRNet(object):
         self.x3_dw = False      # (the generic split-bf16 weight-gradient kernel, csrc/dw3.hip, measured level or slower in
                                 # round 4 and was removed in round 5: the attention weight gradients are folded into the
                                 # backward kernels instead, csrc/attbwdx3.hip)
-        self.x3_enc = x3d and not os.environ.get("CLSR_NO_X3_ENC")        # A/B: fused encoder tail (csrc/encbwd.hip)
-        self.enc_back_x3 = x3d and not os.environ.get("CLSR_NO_ENC_BACK_X3")   # A/B: d(hist) and d TT from one pass over dPin (csrc/projx3.hip)
-        self.att_l1_fwd_x6 = x6d and not os.environ.get("CLSR_NO_ATT_L1_FWD_X6")   # A/B: second attention layer, forward, three pieces (csrc/attl1fwd.hip)
+        self.x3_enc = x3d and True        # A/B: fused encoder tail (csrc/encbwd.hip)
+        self.enc_back_x3 = x3d and True   # A/B: d(hist) and d TT from one pass over dPin (csrc/projx3.hip)
+        self.att_l1_fwd_x6 = x6d and True   # A/B: second attention layer, forward, three pieces (csrc/attl1fwd.hip)
         # history-level attention backward in one launch (csrc/atthist.hip): two pieces in "fp32x3" / one-piece-compatible in
         # the speed mode, THREE pieces in "fp32"
-        self.att_hist_bwd_x3 = not os.environ.get("CLSR_NO_ATT_HIST_BWD_X3")
+        self.att_hist_bwd_x3 = True
         self.att_hist_bwd_pieces = 3 if self.exact_products else 2
-        self.att_hist_x3 = not os.environ.get("CLSR_NO_ATT_HIST_X3")  # A/B: history-level attention prologue in one launch (csrc/atthist.hip)
+        self.att_hist_x3 = True  # A/B: history-level attention prologue in one launch (csrc/atthist.hip)
         # (forward products that feed a batch-norm + ReLU stay at fp32 accuracy in both fp32-storage modes -- three pieces in
         # the history-level kernel, the fp32-MFMA layer-0 kernel -- see csrc/atthist.hip; the two-piece forms are opt-in
         # under "fp32x3": CLSR_ATT_FWD_X3=1, CLSR_ATT_HIST_PIECES=2)
-        self.att_fwd_x3 = x3d and bool(os.environ.get("CLSR_ATT_FWD_X3"))
+        self.att_fwd_x3 = x3d and False
         # the per-(row, step) layer-0 product over three bf16 pieces per operand (fp32 accuracy, 60 bf16 MFMAs instead of 100
         # fp32 ones per tile: csrc/attl0fwd.hip): 102 -> 90 us alone, nothing in the step (three interleaved A/B runs) --
         # opt-in (CLSR_ATT_FWD_X6=1), the default stays the bit-exact fp32-MFMA form
-        self.att_fwd_x6 = x6d and bool(os.environ.get("CLSR_ATT_FWD_X6"))
+        self.att_fwd_x6 = x6d and False
         self.att_l0_fwd_entry = ("clsr_att_l0_fwd_x3" if self.att_fwd_x3 else
                                  "clsr_att_l0_fwd_x6" if self.att_fwd_x6 else "clsr_att_l0_fwd")
-        self.att_hist_pieces = int(os.environ.get("CLSR_ATT_HIST_PIECES", "3")) if x3d else 3  # A/B: first attention layer, forward (csrc/attl0fwd.hip)
+        self.att_hist_pieces = 3 if x3d else 3  # A/B: first attention layer, forward (csrc/attl0fwd.hip)
         # speed mode, round 5b: the (row, step)-level attention layers on the SAME chain kernels as the parity mode
         # (csrc/attl0fwd.hip, attl1fwd.hip, attbwdx3.hip) with ONE bf16 piece per operand and bf16 storage of z0 / z1 / dz0:
         # the weight gradients dW1 / db1 / dWp ride inside the backward kernels (no clsr_hdw launches over z0 / dz1 / dz0,
         # no stored dz1).  CLSR_BF16_CHAIN=old: the position-tiled csrc/hgemm.hip kernels of rounds 2-4.
         self.bf16_chain = self.precision == "bf16" and os.environ.get("CLSR_BF16_CHAIN", "x1") == "x1"
-        self.bf16_dw = not os.environ.get("CLSR_NO_HDW")        # A/B switch: weight gradients on the bf16 matrix pipe
-        self.bf16_bwd = not os.environ.get("CLSR_NO_HBWD")      # A/B switch: back-propagating products likewise
+        self.bf16_dw = True        # A/B switch: weight gradients on the bf16 matrix pipe
+        self.bf16_bwd = True      # A/B switch: back-propagating products likewise
         self._cur_descs_h = []
         self._plans, self._plan_keep, self._cur_descs = {}, [], []
         self._sort_bytes = {}
@@ -149,42 +149,42 @@ class CLSRNet(object):
         # side streams are shared by every net of the process on this device (one net steps at a time): a second net
         # with four streams of its own puts eight hardware queues in play and its step takes 5.7 instead of 3.4 ms
         self._side = _SIDE_STREAMS.setdefault(str(torch.device(device)), {})
-        self.rnn_first = not os.environ.get("CLSR_BRANCH_FIRST")   # A/B switch (see forward)
-        self.dw_batch_late = not os.environ.get("CLSR_NO_DW_BATCH_LATE")   # A/B: merged launches of the attention / head weight gradients
-        self.bn_bwd_fused = not os.environ.get("CLSR_NO_BN_BWD_FUSED")   # A/B: coefficient + apply of the row-level batch-norm backward in one launch
-        self.hist_grad_two = not os.environ.get("CLSR_NO_HIST_GRAD_TWO")   # A/B: dhist + dhist_lt summed inside the segmented sums
-        self.l0_bwd_halves = not os.environ.get("CLSR_NO_L0_BWD_HALVES")   # A/B: wide layer-0 backward as two launches of the x3 kernel over column halves
-        self.dense_upd_dw = not os.environ.get("CLSR_DENSE_UPD_AUX")   # A/B: dense regulariser + Adam on the weight-gradient stream
+        self.rnn_first = True   # A/B switch (see forward)
+        self.dw_batch_late = True   # A/B: merged launches of the attention / head weight gradients
+        self.bn_bwd_fused = True   # A/B: coefficient + apply of the row-level batch-norm backward in one launch
+        self.hist_grad_two = True   # A/B: dhist + dhist_lt summed inside the segmented sums
+        self.l0_bwd_halves = True   # A/B: wide layer-0 backward as two launches of the x3 kernel over column halves
+        self.dense_upd_dw = True   # A/B: dense regulariser + Adam on the weight-gradient stream
         self._dense_fork = None
-        self.tick_early = not os.environ.get("CLSR_NO_TICK_EARLY")   # A/B: Adam clock in the first launch of the update phase
-        self.dw_stream = not os.environ.get("CLSR_NO_DW_STREAM")   # A/B switch (see _dw)
+        self.tick_early = True   # A/B: Adam clock in the first launch of the update phase
+        self.dw_stream = True   # A/B switch (see _dw)
         self._dw_async = False
         # A/B switch (see _att_qh); the bf16 speed mode keeps the whole query in the per-(row, step) GEMM (K is cheap there)
-        self.split_query = not os.environ.get("CLSR_NO_SPLIT_QUERY")
+        self.split_query = True
         # (speed mode, round 5: with the history-level share of the product term inside the fused history-level kernels
         # -- csrc/atthist.hip -- the split costs no launch any more and halves K of the per-(row, step) kernels;
         # CLSR_BF16_NO_SPLIT_QUERY=1: the whole query in those kernels, as before)
-        self.bf16_split_query = not os.environ.get("CLSR_BF16_NO_SPLIT_QUERY")
+        self.bf16_split_query = True
         # history-level half of the short-term query folded into U (see _att_qh): pays off at every width once the per-row
         # half runs on the one-wave-per-history kernels (round 3; the position-tiled kernels needed Du >= 64)
-        self.split_query_min = int(os.environ.get("CLSR_SPLIT_QUERY_MIN", "16"))
-        self.split_emb_grad = not os.environ.get("CLSR_SERIAL_EMB_GRAD")   # A/B switch (embedding gradient sites)
+        self.split_query_min = 16
+        self.split_emb_grad = True   # A/B switch (embedding gradient sites)
         self.use_plans = not os.environ.get("CLSR_NO_PLAN")                # replay recorded launch sequences
-        self.split_g2 = not os.environ.get("CLSR_NO_SPLIT_G2")             # A/B switch (causal GRU off the main launch)
-        self.g2_stream = os.environ.get("CLSR_G2_STREAM", "@lt")           # A/B: which side stream runs the causal GRU's forward
+        self.split_g2 = True             # A/B switch (causal GRU off the main launch)
+        self.g2_stream = "@lt"           # A/B: which side stream runs the causal GRU's forward
         self._step_plans = {}
-        self.dw_streams = int(os.environ.get("CLSR_DW_STREAMS", "1"))
-        self.fused_l0_bwd = not os.environ.get("CLSR_NO_FUSED_L0_BWD")   # A/B switch (see _att_bwd)
-        self.dw_batching = not os.environ.get("CLSR_NO_DW_BATCH")          # A/B switch (see _dw_batched)
-        self.flush_side = not os.environ.get("CLSR_NO_FLUSH_SIDE")          # A/B switch (dense path off the main stream)
-        self.l1_bwd_2pass = not os.environ.get("CLSR_NO_L1_BWD_2PASS")      # A/B switch (exact mode, see _att_bwd)
+        self.dw_streams = 1
+        self.fused_l0_bwd = True   # A/B switch (see _att_bwd)
+        self.dw_batching = True          # A/B switch (see _dw_batched)
+        self.flush_side = True          # A/B switch (dense path off the main stream)
+        self.l1_bwd_2pass = True      # A/B switch (exact mode, see _att_bwd)
         self.dpin_h = (self.bf16 and self.bf16_dw and self.bf16_bwd and type(self) is CLSRNet
-                       and not os.environ.get("CLSR_NO_DPIN_BF16"))          # bf16 dPin (speed mode, CLSR graph only)
+                       and True)          # bf16 dPin (speed mode, CLSR graph only)
         # where the long-term attention backward forks: beside the short-term one (exact mode: -40 us) or underneath the
         # backward-through-time launch (speed mode: the short-term backward is bandwidth bound there); CLSR_LT_BWD_EARLY=0|1
         # (round 2: off in speed mode, +30 us there; with the fused encoder tail the long-term chain had become the LAST thing
         #  to finish in that mode: early wins by 0.06 ms since round 3)
-        self.lt_bwd_early = os.environ.get("CLSR_LT_BWD_EARLY", "1") == "1"
+        self.lt_bwd_early = True
         self._dw_batch = None
         self._buf_allocs = 0
         # HIP stream priorities of the side streams (0 = normal; the callers' compute stream can be created with -1 = high)
@@ -192,9 +192,9 @@ class CLSRNet(object):
         # that RCCL's stream is the FOURTH under data parallelism -- a fifth active queue (or a fourth next to a
         # high-priority compute stream) cost 4.0 -> 6.6 ms per step (r03, CLSR_FORCE_DP=1); on a single GPU the fold
         # measured 3.768 against 3.779 ms.  CLSR_FOLD_AUX=0: the round-2 layout with a stream of its own.
-        self.stream_alias = {} if os.environ.get("CLSR_FOLD_AUX") == "0" else {"@aux": os.environ.get("CLSR_AUX_ALIAS", "@lt")}
-        self.side_priority = int(os.environ.get("CLSR_SIDE_PRIORITY", "0"))
-        self.dw_priority = int(os.environ.get("CLSR_DW_PRIORITY", "0"))
+        self.stream_alias = {"@aux": "@lt"}
+        self.side_priority = 0
+        self.dw_priority = 0
         # Recurrences: hidden-to-hidden products as split-bf16 sums (csrc/rnn.hip, "x3") or fp32-input MFMAs ("fp32", bit-exact
         # fp32); with x3 the input projections of the GRUs and of the Time4LSTM blocks i | j | f run INSIDE the recurrence
         # launch from the history embeddings (no projection tensor, no GEMM in front of the T-serial chain), and the
@@ -202,46 +202,46 @@ class CLSRNet(object):
         self.rnn_products = "fp32" if self.exact_products else os.environ.get("CLSR_RNN_PRODUCTS", "x3")
         if self.rnn_products not in ("x3", "fp32"):
             raise ValueError("CLSR_RNN_PRODUCTS must be 'x3' or 'fp32'")
-        self.rnn_fused_proj = self.rnn_products == "x3" and not os.environ.get("CLSR_NO_RNN_FUSED_PROJ")
+        self.rnn_fused_proj = self.rnn_products == "x3" and True
         # the Time4LSTM's K-fused time-gate projection as split products too (csrc/projx3.hip): three pieces in "fp32", two
         # in the other modes (it feeds the same sigmoid gates as the recurrences' two-piece hidden products there)
-        self.proj_x3 = not os.environ.get("CLSR_NO_PROJ_X3")
+        self.proj_x3 = True
         self.proj_gate_pieces = 3 if self.exact_products else 2
         # ... and the whole input projection when it is NOT fused into the recurrence launch (hidden sizes > 48: configs[4])
-        self.proj_tt = self.proj_x3 and not os.environ.get("CLSR_NO_PROJ_TT")      # A/B: tanh time features in that kernel's prologue
-        self.proj_x3_wide = self.proj_x3 and not os.environ.get("CLSR_NO_PROJ_X3_WIDE")
-        self.gemm_wide_x3 = self.proj_x3_wide and not os.environ.get("CLSR_NO_GEMM_WIDE_X3")   # A/B: every plain wide product
-        self.proj_bwd_pieces = 3 if self.exact_products else int(os.environ.get("CLSR_PROJ_BWD_PIECES", "2"))
-        self.proj_wide_pieces = int(os.environ.get("CLSR_PROJ_WIDE_PIECES", "2" if self.precision == "bf16" else "3"))
-        self.rnn_act_tiled = self.rnn_products == "x3" and not os.environ.get("CLSR_NO_RNN_ACT_TILED")
+        self.proj_tt = self.proj_x3 and True      # A/B: tanh time features in that kernel's prologue
+        self.proj_x3_wide = self.proj_x3 and True
+        self.gemm_wide_x3 = self.proj_x3_wide and True   # A/B: every plain wide product
+        self.proj_bwd_pieces = 3 if self.exact_products else 2
+        self.proj_wide_pieces = (2 if self.precision == "bf16" else 3)
+        self.rnn_act_tiled = self.rnn_products == "x3" and True
         # Attention-MLP backward (exact mode): "x3" = the two-pass layer-1 kernel and the one-pass layer-0 kernel as split-bf16
         # products with the weight gradients dW1 / db1 / dWp accumulated inside them (csrc/attbwdx3.hip: no separate
         # weight-gradient launches, no stored dz1); "fp32" = the fp32-MFMA kernels + clsr_pgemm_dw_partial beside them
         self.att_bwd = "fp32" if self.exact_products else os.environ.get("CLSR_ATT_BWD", "x3")
         if self.att_bwd not in ("x3", "fp32"):
             raise ValueError("CLSR_ATT_BWD must be 'x3' or 'fp32'")
-        self.fuse_tt = not os.environ.get("CLSR_NO_FUSE_TT")   # A/B: time-gate blocks of the input projection as one product over [hist | TT]
+        self.fuse_tt = True   # A/B: time-gate blocks of the input projection as one product over [hist | TT]
         # the row-level heads (alpha gate, alpha / logit MLPs, loss, their backward) as two persistent launches with grid
         # barriers for the batch-norm statistics (csrc/headsfused.hip) instead of a chain of 22 dependent launches
         self.heads_fused = not os.environ.get("CLSR_NO_HEADS_FUSED")
         # weight gradients of wide layers (K, N >= 96: BASELINE configs[4]) by the 128 x 128-tile kernel (csrc/dwwide.hip)
-        self.dw_wide = not os.environ.get("CLSR_NO_DW_WIDE")
+        self.dw_wide = True
         # ... as two-piece split-bf16 products like the other weight gradients outside "fp32" (CLSR_DW_WIDE_FP32=1 /
         # precision="fp32": fp32-input MFMAs)
-        self.dw_wide_entry = ("clsr_pgemm_dw_wide" if (self.exact_products or os.environ.get("CLSR_DW_WIDE_FP32"))
+        self.dw_wide_entry = ("clsr_pgemm_dw_wide" if self.exact_products
                               else "clsr_pgemm_dw_wide_x3")
         self._dw_batch_wide = None
         self._heads_defer = False
         self._early_lists = None
         self.heads_comm = None      # data-parallel runs: communicator of the fused heads (clsr_amd/p2p.py: HeadsComm)
-        self.fused_logit_tail = not os.environ.get("CLSR_NO_FUSED_LOGIT_TAIL")   # A/B: output layer + softmax loss + their backward in one launch
+        self.fused_logit_tail = True   # A/B: output layer + softmax loss + their backward in one launch
         self._defer_logit_out = False
-        self.early_scatter = not os.environ.get("CLSR_NO_EARLY_SCATTER")   # A/B: row scatters of the user / target lookups beside the encoder-backward tail instead of behind it
-        self.dhist_side = not os.environ.get("CLSR_NO_DHIST_SIDE")      # A/B (speed mode): d(hist) product on the long-term stream (2.87 -> 2.84 ms)
-        self.enc_bwd_fused_h = not os.environ.get("CLSR_NO_ENC_BWD_FUSED_H")   # A/B: the speed-mode (bf16 dPin) form of the fused encoder tail
-        self.enc_bwd_fused = not os.environ.get("CLSR_NO_ENC_BWD_FUSED")   # A/B: one pass over dPin for the seven encoder-side weight gradients + d(hist) (csrc/encbwd.hip)
-        self.l0_fwd_wave = not os.environ.get("CLSR_NO_L0_FWD_WAVE")      # A/B switch (exact mode, see _att_fwd)
-        self.fused_l0_wu = not os.environ.get("CLSR_NO_FUSED_L0_WU")   # A/B: dU . Wu^T inside that kernel as well (time-neutral, two launches fewer)
+        self.early_scatter = True   # A/B: row scatters of the user / target lookups beside the encoder-backward tail instead of behind it
+        self.dhist_side = True      # A/B (speed mode): d(hist) product on the long-term stream (2.87 -> 2.84 ms)
+        self.enc_bwd_fused_h = True   # A/B: the speed-mode (bf16 dPin) form of the fused encoder tail
+        self.enc_bwd_fused = True   # A/B: one pass over dPin for the seven encoder-side weight gradients + d(hist) (csrc/encbwd.hip)
+        self.l0_fwd_wave = True      # A/B switch (exact mode, see _att_fwd)
+        self.fused_l0_wu = True   # A/B: dU . Wu^T inside that kernel as well (time-neutral, two launches fewer)
         self._joins = []
         self._dw_pending, self._dw_tables, self._dw_after, self._rp_pending = {}, {}, {}, {}
         self.defer_dw = True       # one batched reduction of the weight-gradient partials per stream and step
@@ -334,13 +334,24 @@ class CLSRNet(object):
     # The variable inventory, the trained embedding tables and the recurrent encoders are hooks so that the sibling
     # models of the reference that share these kernels (clsr_amd/seqnet.py) reuse everything below.
     # ------------------------------------------------------------------ launch plans
+    #: every mode switch that changes the recorded launch sequence: ONE tuple, so that flipping any of them on a live net (A/B
+    #: runs on the same feed, tests) records a new plan instead of silently replaying the old one
+    _SWITCHES = ("precision", "table_bf16", "exact_products", "overlap", "defer_dw", "sorted_hist_grad", "det_grads", "lazy",
+                 "rnn_first", "tick_early", "hist_grad_two", "dw_batch_late", "bn_bwd_fused", "dw_stream", "dw_streams",
+                 "split_query", "split_query_min", "bf16_split_query", "split_emb_grad", "bf16_chain", "bf16_dw", "bf16_bwd",
+                 "fused_l0_bwd", "fused_l0_wu", "l0_fwd_wave", "l0_bwd_halves", "dw_batching", "lt_bwd_early", "dpin_h", "flush_side",
+                 "l1_bwd_2pass", "split_g2", "g2_stream", "rnn_products", "rnn_fused_proj", "rnn_act_tiled", "att_bwd", "att_hist_x3",
+                 "att_hist_bwd_x3", "att_hist_bwd_pieces", "att_hist_pieces", "att_l1_fwd_x6", "att_fwd_x3", "att_fwd_x6",
+                 "att_l0_fwd_entry", "x3_enc", "enc_back_x3", "enc_bwd_fused", "enc_bwd_fused_h", "proj_x3", "proj_tt", "proj_x3_wide",
+                 "gemm_wide_x3", "proj_gate_pieces", "proj_bwd_pieces", "proj_wide_pieces", "dhist_side", "early_scatter",
+                 "fused_logit_tail", "fuse_tt", "heads_fused", "dense_upd_dw", "dw_wide", "dw_wide_entry", "rowlist_min_elems")
+
     def _plan_key(self, what, f):
         hp = self.hp
         g = lambda k: getattr(hp, k, None)
-        return (what, id(f), ops.stream_ptr(), self.precision, self.table_bf16, self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook), self.dp_comm, self.heads_comm, getattr(self, "dp_generation", 0),
-                self.overlap, self.defer_dw, self.sorted_hist_grad,
-                self.lazy, self.rnn_first, self.tick_early, self.hist_grad_two, self.dw_batch_late, self.bn_bwd_fused, self.dw_stream, self.split_query, self.split_query_min, self.split_emb_grad, self.bf16_dw, self.bf16_bwd, self.fused_l0_bwd, self.fused_l0_wu, self.l0_fwd_wave, self.dw_batching, self.lt_bwd_early, self.dpin_h, self.flush_side, self.l1_bwd_2pass,
-                self.split_g2, self.rnn_products, self.rnn_fused_proj, self.rnn_act_tiled, self.enc_bwd_fused, self.enc_bwd_fused_h, self.dhist_side, self.early_scatter, self.fused_logit_tail, self.fuse_tt, self.rowlist_min_elems, g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
+        return (what, id(f), ops.stream_ptr(), self.dp_world, id(self.dp_hooks), id(self.dp_stats_hook), self.dp_comm, self.heads_comm,
+                getattr(self, "dp_generation", 0)) + tuple(getattr(self, n, None) for n in self._SWITCHES) + (
+                g("learning_rate"), g("embed_l2"), g("layer_l2"), g("embed_l1"), g("layer_l1"), g("max_grad_norm"), g("is_clip_norm"),
                 g("discrepancy_loss_weight"), g("contrastive_loss_weight"), g("triplet_margin"),
                 g("contrastive_length_threshold"), g("manual_alpha_value"))
 
@@ -2621,7 +2632,7 @@ class CLSRNet(object):
                     row += (1, dtarget.data_ptr(), ss[slot + 2:].data_ptr(), n, self.D, col0)
                 else:
                     row += (0, 0, 0, 0, 0, 0)
-                rows.append(row + (self.border_wch(V, ne), 0))
+                rows.append(row + (0, 0))
             self._segsum("hist." + (only or "all"), rows)
             return
         for name, _, V, col0, C, slot in self._sort_tables():
@@ -2633,17 +2644,6 @@ class CLSRNet(object):
             for c0 in range(0, C, blk):   # column blocks; squared norms accumulate in the slot
                 call("clsr_gather_bwd_sorted2", dhist, dhist2, dM, dR, keys, perm, seq_len, ls, n, T, self.D, col0 + c0,
                      min(blk, C - c0), k, self.tab_grad[name], C, c0, ss[slot:])
-
-    @staticmethod
-    def border_wch(V, n):
-        """clsr_segsum_desc.border_wch: chunks per wave of the segmented sums' border launch.  With ids drawn independently
-        from a table much larger than the list, hardly any run crosses a chunk border and 64 chunks per wave take the launch
-        from 11.7 to 4.6 us (scripts/prof_kernels.py embed: 45.5 -> 38.5 us for the launch pair).  The table size is no
-        evidence for that, though: the benchmark's catalogue feed (sliding windows over user sequences: most ids occur a few
-        times) has a head in most chunks, a wave walks its heads one after the other, and the same hint costs 14 us there
-        (bench.py: 44-46 -> 58-59 us).  Default therefore: one chunk per wave; CLSR_BORDER_WCH=n for feeds known to be run-free."""
-        e = os.environ.get("CLSR_BORDER_WCH")
-        return int(e) if e else 0
 
     #: tables with more elements than this are regularised / lazily updated through the compacted list of
     #: their involved rows instead of a sweep over all V*C elements (100M-item catalogues)

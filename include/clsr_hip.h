@@ -117,15 +117,17 @@ typedef struct clsr_segsum_desc {
    * same sorted list as the history lookup's (clsr_sortids_desc.ids2) */
   int assign;
   const float* src_b; double* sumsq_b; long n1; int ldb; int colb;
-  /* chunks of 32 sorted entries one WAVE of the border launch tests (0 = 1; up to 64).  A hint: with ids spread over a table
-   * much larger than the list (100M-item catalogue) hardly any run crosses a chunk border and the border launch is 1 760
-   * workgroups that read one flag word each (12 of the launch pair's 45 us); with 64 it is 28 workgroups.  Lists with many
-   * long runs (Zipf ids, small tables) want 1: a wave walks its heads one after the other. */
+  /* (rounds 4-5: chunks per wave of the separate border launch; round 6 folded the borders into the one launch -- the field is
+   * ignored and stays for the layout of existing callers) */
   int border_wch; int pad_;
 } clsr_segsum_desc;
 int clsr_sizeof_segsum_desc(void);
 long clsr_segsum_workspace_bytes(const clsr_segsum_desc* descs_host, int n);
-/* the sites of one call must write different tables (or disjoint columns); nothing else may write them meanwhile */
+/* ONE launch.  The sites of one call must write different tables (or disjoint columns); nothing else may write them
+ * meanwhile.  workspace: ZERO when first used (it keeps a launch epoch and a finished-workgroup counter between launches: no
+ * clearing afterwards), not shared by two launches in flight.  clsr_segsum_error (synchronous): != 0 when a bounded wait
+ * for an earlier chunk's partial gave up -- never expected. */
+int clsr_segsum_error(const void* workspace);
 int clsr_segsum_multi(const clsr_segsum_desc* descs_host, int n, void* workspace, long workspace_bytes, void* stream);
 /* Weight gradient of a WIDE layer (K, N >= 96 over M >= 32 768 positions: the 128-wide layer sizes of BASELINE configs[4]):
  * dW[k, n] (=|+=) sum_m X[m, k] (* Xmul[m, k], optional) * dY[m, n], db[n] (=|+=) sum_m dY[m, n] (db may be NULL); 128 x 128 tiles over position

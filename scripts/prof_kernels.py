@@ -113,7 +113,7 @@ def main():
                       1, T, D, Di, Dc, 3, Dc, 0, 1, dtarget.data_ptr(), 0, n, D, Di, wch(Vc, n + B), 0)]
             which_sites = os.environ.get("EMBED_SITES", "both")
             sites = sites[:1] if which_sites == "item" else sites[1:] if which_sites == "cate" else sites
-            wsg = torch.empty(ops.segsum_workspace_bytes(sites), dtype=torch.uint8, device=dev)
+            wsg = torch.zeros(ops.segsum_workspace_bytes(sites), dtype=torch.uint8, device=dev)
             t = timeit(lambda: ops.segsum_multi(sites, wsg), iters=22)
             nbytes = n * D * sa + n * D * 4 + 2 * n * 4 + B * D * 8 + 2 * B * 4
             print("segmented sums (item + category, history + target slices, stored once), %s: %8.1f us  %.0f GB/s "

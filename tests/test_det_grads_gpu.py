@@ -74,9 +74,10 @@ def _segsum(sites, V_C):
     rows = []
     for s in sites:
         rows.append(s)
-    ws = torch.empty(ops.segsum_workspace_bytes(rows), dtype=torch.uint8, device=DEV)
+    ws = torch.zeros(ops.segsum_workspace_bytes(rows), dtype=torch.uint8, device=DEV)      # (zero when first used: launch epoch / counters)
     ops.segsum_multi(rows, ws)
     torch.cuda.synchronize()
+    assert ops.query("clsr_segsum_error", ws.data_ptr()) == 0, "a tail gave up waiting for an earlier chunk's partial"
 
 
 @pytest.mark.parametrize("Hn,T,Di,Dc,V,zipf", [(64, 50, 32, 8, 40, False), (33, 10, 32, 8, 5000, False), (16, 7, 96, 32, 300, True),
@@ -230,3 +231,44 @@ def test_training_step_is_bit_reproducible(golden_dir, golden_hparams):
     assert len(tab) >= 9
     for k in tab:
         assert torch.equal(a[k], b[k]), "%s differs between two runs of the same step" % k
+
+
+@pytest.mark.parametrize("n,V,C,power", [(225280, 64138, 32, 5.0), (100000, 7, 96, 1.0), (40000, 1, 8, 1.0), (70001, 3000, 40, 3.0),
+                                        (9, 2, 8, 1.0), (33, 1, 96, 1.0)])
+def test_long_runs_one_launch_and_a_workspace_that_is_never_cleared(n, V, C, power):
+    """Runs that span many chunks (one id for the whole list, seven ids, a Zipf head of ~800 chunks) are combined INSIDE the
+    one launch by the chunk in which they end (decoupled look-back over the earlier chunks' partials), short continuations are
+    walked by the chunk they come from; the workspace is zeroed once and then reused by launches on DIFFERENT lists (its ready
+    words are launch epochs): every launch == float64 index_add, the squared norms are right, the error word stays 0."""
+    g = torch.Generator().manual_seed(n + V)
+    ws = None
+    for rep in range(4):
+        idx = (torch.rand(n, generator=g).pow(power) * V).long().clamp_(max=V - 1)
+        src = torch.randn(n, C, generator=g)
+        d_idx = idx.int().to(DEV).view(n, 1)
+        (k, p), = _stable_sort([(d_idx, n, 1, V)])
+        assign = rep % 2
+        grad = torch.full((V, C), 0.25 if not assign else 777.0, device=DEV)
+        ss = torch.zeros(1, dtype=torch.float64, device=DEV)
+        d_src = src.to(DEV)
+        rows = [(d_src.data_ptr(), 0, 0, 0, k.data_ptr(), p.data_ptr(), 0, grad.data_ptr(), ss.data_ptr(), n, 0, 0, 1, C, 0, C, 1, C,
+                 0, assign)]
+        if ws is None:
+            ws = torch.zeros(ops.segsum_workspace_bytes(rows), dtype=torch.uint8, device=DEV)
+        ops.segsum_multi(rows, ws)
+        torch.cuda.synchronize()
+        assert ops.query("clsr_segsum_error", ws.data_ptr()) == 0
+        exp = torch.zeros(V, C, dtype=torch.float64).index_add_(0, idx, src.double())
+        touched = torch.zeros(V, dtype=torch.bool)
+        touched[idx] = True
+        got = grad.double().cpu()
+        base = 0.0 if assign else 0.25
+        err = float((got[touched] - exp[touched] - base).abs().max())
+        assert err <= 3e-6 * float(exp.abs().max()) + 1e-5, (rep, err)
+        assert bool((got[~touched] == (777.0 if assign else 0.25)).all())
+        assert abs(float(ss) - float((src.double() ** 2).sum())) <= 1e-6 * float(ss)
+        grad2 = torch.full((V, C), 0.25 if not assign else 777.0, device=DEV)
+        rows2 = [rows[0][:7] + (grad2.data_ptr(),) + rows[0][8:]]
+        ops.segsum_multi(rows2, ws)
+        torch.cuda.synchronize()
+        assert torch.equal(grad, grad2), "two launches on one list: bit-identical rows"
