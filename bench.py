@@ -252,33 +252,59 @@ class Workload(object):
         self.torch.cuda.empty_cache()
 
 
+NSETS = 3      # id sets the isolated kernel timings rotate through: the touched working set (>= 3 x 184 MB at the catalogue)
+               # exceeds the 256 MiB Infinity Cache, so that neither the timing nor FETCH_SIZE can be cache hits of the
+               # previous launch
+
+
+def rotating_id_sets(f, cfg, dev):
+    """NSETS (item_history, item_cate_history) pairs of the feed's shape: the feed's own ids, then fresh uniform draws."""
+    import torch
+
+    sets = [(f["item_history"], f["item_cate_history"])]
+    for j in range(1, NSETS):
+        g = torch.Generator(device=dev).manual_seed(977 + j)
+        ih = torch.randint(1, cfg["Vi"], tuple(f["item_history"].shape), generator=g, device=dev, dtype=torch.int32)
+        ch = torch.randint(1, cfg["Vc"], tuple(f["item_cate_history"].shape), generator=g, device=dev, dtype=torch.int32)
+        sets.append((ih, ch))
+    return sets
+
+
 def gather_roofline(net, f, cfg, G, feed, big):
-    """HIP-event timing of the history gather of ``net`` on its own tables (SURVEY 8d byte formula)."""
+    """HIP-event timing of the history gather of ``net`` on its own tables (SURVEY 8d byte formula), rotating through
+    NSETS id sets with an output tensor each."""
+    import torch
+
     from clsr_amd import ops
 
     T, Hn = cfg["T"], cfg["P"]
     D = cfg["Di"] + cfg["Dc"]
-    hist = net._buf("hist", Hn, T, D)
     hm, hr = net._buf("hist_mean", Hn, D), net._buf("hist_recent", Hn, D)
-
     tb16 = bool(getattr(net, "table_bf16", False))
+    sets = rotating_id_sets(f, cfg, net.device)
+    outs = [net._buf("hist", Hn, T, D)] + [torch.empty(Hn, T, D, device=net.device) for _ in range(NSETS - 1)]
+    turn = [0]
 
     def gather():
+        j = turn[0] % NSETS
+        turn[0] += 1
+        ih, ch = sets[j]
         if tb16:
-            ops.call("clsr_gather_hist_fwd_h", net.tables["item"], net.tables["cate"], f["item_history"],
-                     f["item_cate_history"], G * T, f["seq_len"], G, Hn, T, cfg["Di"], cfg["Dc"], 3, hist, 0, hm, hr)
+            ops.call("clsr_gather_hist_fwd_h", net.tables["item"], net.tables["cate"], ih, ch, G * T, f["seq_len"], G, Hn, T,
+                     cfg["Di"], cfg["Dc"], 3, outs[j], 0, hm, hr)
         else:
-            ops.call("clsr_gather_hist_fwd", net.tables["item"], net.tables["cate"], f["item_history"],
-                     f["item_cate_history"], G * T, f["seq_len"], G, Hn, T, cfg["Di"], cfg["Dc"], 3, hist, hm, hr)
+            ops.call("clsr_gather_hist_fwd", net.tables["item"], net.tables["cate"], ih, ch, G * T, f["seq_len"], G, Hn, T,
+                     cfg["Di"], cfg["Dc"], 3, outs[j], hm, hr)
 
-    t_gather = time_kernel(gather)
+    t_gather = time_kernel(gather, iters=21)
     lens = np.asarray(feed["mask"]).sum(1)[::G]
     n_valid = float(lens.sum())
     # SURVEY 8d: bytes_gather_fwd(n) = n*(Di+Dc)*(s_t + s_a) + 2*n*4 per gathered history row
     gbytes = n_valid * D * ((2 if tb16 else 4) + 4) + 2 * n_valid * 4
     return dict(bound="hbm", kernel="gather_hist_fwd_h_kernel (bf16 tables, fp32 hist)" if tb16 else "gather_hist_fwd_kernel", achieved=round(gbytes / t_gather / 1e9, 1),
                 peak=8000.0, unit="GB/s", frac=round(gbytes / t_gather / 8e12, 4),
-                bytes_per_launch=gbytes, us_per_launch=round(t_gather * 1e6, 2))
+                bytes_per_launch=gbytes, us_per_launch=round(t_gather * 1e6, 2),
+                id_sets_rotated=NSETS, working_set_bytes=NSETS * gbytes)
 
 
 def embedding_rooflines(net, f, cfg, G, feed):
@@ -298,73 +324,96 @@ def embedding_rooflines(net, f, cfg, G, feed):
     n_valid = float(lens.sum())
     dev = net.device
     # ---- gather backward: bytes_gather_bwd(n) = n*D*s_a (gradient read) + n*D*4 (fp32 row-gradient write) + 2*n*4
-    dhist = torch.randn(Hn * T, D, device=dev) * 1e-3
+    # NSETS rotating sorted lists (the step's own, then fresh draws with the same structure: n unique-ish history ids + the
+    # B target rows, P distinct ids x G) with a gradient tensor each: 3 x 175 MB touched per round > the Infinity Cache
     nk = n + (cfg["P"] * G if getattr(net, "det_grads", False) and net._det_merged(f) else 0)
-    keys_i, perm_i = net._buf("sort.keys.item", nk, dtype=torch.int32), net._buf("sort.perm.item", nk, dtype=torch.int32)
-    keys_c, perm_c = net._buf("sort.keys.cate", nk, dtype=torch.int32), net._buf("sort.perm.cate", nk, dtype=torch.int32)
     tg = net.tab_grad
-
     B = cfg["P"] * G
-    dtarget = torch.randn(B, D, device=dev) * 1e-3
-    ne = keys_i.numel()                     # n history slices (+ B target rows when the net chains the two sites)
+    ne = nk                                 # n history slices (+ B target rows when the net chains the two sites)
     merged = ne > n
+    lists = [dict(ki=net._buf("sort.keys.item", nk, dtype=torch.int32), pi=net._buf("sort.perm.item", nk, dtype=torch.int32),
+                  kc=net._buf("sort.keys.cate", nk, dtype=torch.int32), pc=net._buf("sort.perm.cate", nk, dtype=torch.int32))]
+    for j in range(1, NSETS):
+        g = torch.Generator(device=dev).manual_seed(4242 + j)
+        ent = {}
+        for tag_, V in (("i", cfg["Vi"]), ("c", cfg["Vc"])):
+            ids = torch.randint(1, V, (n,), generator=g, device=dev, dtype=torch.int64)
+            if merged:
+                tgt = torch.randint(1, V, (cfg["P"],), generator=g, device=dev, dtype=torch.int64)
+                ids = torch.cat([ids, tgt[torch.randint(0, cfg["P"], (B,), generator=g, device=dev)]])
+            k_, p_ = torch.sort(ids, stable=True)
+            ent["k" + tag_], ent["p" + tag_] = k_.int(), p_.int()
+        lists.append(ent)
+    dh32 = [torch.randn(Hn * T, D, device=dev) * 1e-3 for _ in range(NSETS)]
+    dh16 = [d.to(torch.bfloat16) for d in dh32]
+    dtarget = torch.randn(B, D, device=dev) * 1e-3
 
-    def site_rows(d):
+    def site_rows(d, L):
         bf = int(d.dtype == torch.bfloat16)
         tail_i = (1, dtarget.data_ptr(), 0, n, D, 0) if merged else (0,)
         tail_c = (1, dtarget.data_ptr(), 0, n, D, Di) if merged else (0,)
-        wch = getattr(net, "border_wch", lambda V, n_: 0)      # (the hint the step passes: chunks per wave of the border launch)
         pad = lambda t: t + (0,) * (6 - len(t))
-        return [(d.data_ptr(), 0, 0, 0, keys_i.data_ptr(), perm_i.data_ptr(), f["seq_len"].data_ptr(), tg["item"].data_ptr(), 0,
-                 ne, bf, G, T, D, 0, Di, 3, Di, 0) + pad(tail_i) + (wch(tg["item"].shape[0], ne), 0),
-                (d.data_ptr(), 0, 0, 0, keys_c.data_ptr(), perm_c.data_ptr(), f["seq_len"].data_ptr(), tg["cate"].data_ptr(), 0,
-                 ne, bf, G, T, D, Di, Dc, 3, Dc, 0) + pad(tail_c) + (wch(tg["cate"].shape[0], ne), 0)]
+        return [(d.data_ptr(), 0, 0, 0, L["ki"].data_ptr(), L["pi"].data_ptr(), f["seq_len"].data_ptr(), tg["item"].data_ptr(), 0,
+                 ne, bf, G, T, D, 0, Di, 3, Di, 0) + pad(tail_i) + (0, 0),
+                (d.data_ptr(), 0, 0, 0, L["kc"].data_ptr(), L["pc"].data_ptr(), f["seq_len"].data_ptr(), tg["cate"].data_ptr(), 0,
+                 ne, bf, G, T, D, Di, Dc, 3, Dc, 0) + pad(tail_c) + (0, 0)]
 
-    def bwd(d, only_item):
-        rows = site_rows(d)[:1] if only_item else site_rows(d)
-        ws = torch.zeros(ops.segsum_workspace_bytes(rows), dtype=torch.uint8, device=dev)
-        return lambda: ops.segsum_multi(rows, ws)
+    def bwd(ds, only_item):
+        jobs = []
+        for d, L in zip(ds, lists):
+            rows = site_rows(d, L)[:1] if only_item else site_rows(d, L)
+            jobs.append((rows, torch.zeros(ops.segsum_workspace_bytes(rows), dtype=torch.uint8, device=dev)))
+        turn = [0]
+
+        def run():
+            rows, ws = jobs[turn[0] % NSETS]
+            turn[0] += 1
+            ops.segsum_multi(rows, ws)
+        return run
 
     def clear_grads():      # the timed launches wrote the gradient tables: put the touched rows back to zero
         tg["cate"].zero_()
-        tg["item"].index_fill_(0, keys_i.long(), 0.0)
+        for L in lists:
+            tg["item"].index_fill_(0, L["ki"].long(), 0.0)
 
     det = getattr(net, "det_grads", False)
     # the HBM claim is about the ITEM table (38 GB, rows of Di * 4 bytes, uniform ids); the category table (1.3 MB) is cache
     # resident and its site runs beside the item site on another stream in the step -- timed here as a second entry
-    for tag, d, sa, only_item in (("gather_bwd", dhist, 4, True), ("gather_bwd_bf16_dhist", dhist.to(torch.bfloat16), 2, True),
-                                  ("gather_bwd_item_and_category_one_stream", dhist, 4, False)):
+    for tag, ds, sa, only_item in (("gather_bwd", dh32, 4, True), ("gather_bwd_bf16_dhist", dh16, 2, True),
+                                   ("gather_bwd_item_and_category_one_stream", dh32, 4, False)):
         if not det:
             out[tag] = dict(skipped="CLSR_NO_DET_GRADS: the counting-sort + atomics path is not measured here")
             continue
-        t = time_kernel(bwd(d, only_item))
+        t = time_kernel(bwd(ds, only_item), iters=21)
         W = Di if only_item else D
         # n slices of W values read (s_a bytes) and written once (fp32) + (key, slice) index pairs; the B target rows' slices
         # ride in the same list (fp32 read + fp32 write)
         nbytes = n_valid * W * sa + n_valid * W * 4 + 2 * n_valid * 4 + ((B * W * (4 + 4) + 2 * B * 4) if merged else 0)
         if not only_item:
             nbytes += 2 * n_valid * 4 + (2 * B * 4 if merged else 0)      # (the second site's index pairs)
-        out[tag] = dict(bound="hbm", kernel="ss_chunks_kernel + ss_borders_kernel (csrc/segsum.hip: deterministic segmented "
-                                            "sums, history + target slices of a table in one sorted list, every row stored once)",
+        out[tag] = dict(bound="hbm", kernel="ss_chunks_lean_kernel (csrc/segsum.hip: deterministic segmented sums in ONE launch, history "
+                                            "+ target slices of a table in one sorted list, every row stored once)",
                         achieved=round(nbytes / t / 1e9, 1), peak=8000.0, unit="GB/s", frac=round(nbytes / t / 8e12, 4),
-                        bytes_per_launch=nbytes, us_per_launch=round(t * 1e6, 2),
+                        bytes_per_launch=nbytes, us_per_launch=round(t * 1e6, 2), id_sets_rotated=NSETS,
                         formula="n*W*%d (gradient read) + n*W*4 (fp32 row-gradient write) + 2*n*4 (+ the target rows' slices)"
                                 % sa, columns=W, sites_merged=bool(merged))
-        if tag == "gather_bwd_item_and_category_one_stream":
-            out[tag].update(traffic=204.1e6, traffic_source="profiles/r05g_embed_kernel_trace.md, counters in KiB (48 dispatches, fp32 and bf16 "
-                                                            "d(hist) alternating: ss_chunks_lean 200.4 MB + ss_borders 3.7 MB per launch = WRITE_SIZE + 2 x FETCH_SIZE)")
-        elif tag == "gather_bwd":
-            out[tag].update(traffic=165.3e6, traffic_source="profiles/r05g_item_embed_kernel_trace.md, counters in KiB (item site alone on independent "
-                                                            "uniform ids, 48 dispatches, fp32 and bf16 d(hist) alternating: ss_chunks_lean 165.1 MB + "
-                                                            "ss_borders 0.2 MB with 64 chunks per border wave; this feed's lists have a head in most chunks)")
         clear_grads()
+    del dh32, dh16
     # ---- bf16 tables + bf16 hist: bytes_gather_fwd(n) = n*D*(2 + 2) + 2*n*4
     try:
         it_h, ct_h = net.tables["item"].to(torch.bfloat16), net.tables["cate"].to(torch.bfloat16)
-        hist_h = torch.empty(Hn * T, D, device=dev, dtype=torch.bfloat16)
+        sets = rotating_id_sets(f, cfg, dev)
+        hist_h = [torch.empty(Hn * T, D, device=dev, dtype=torch.bfloat16) for _ in range(NSETS)]
         hm, hr = net._buf("hist_mean", Hn, D), net._buf("hist_recent", Hn, D)
-        t = time_kernel(lambda: ops.call("clsr_gather_hist_fwd_h", it_h, ct_h, f["item_history"], f["item_cate_history"], G * T,
-                                         f["seq_len"], G, Hn, T, Di, Dc, 3, hist_h, 1, hm, hr))
+        turn = [0]
+
+        def fwd_h():
+            j = turn[0] % NSETS
+            turn[0] += 1
+            ops.call("clsr_gather_hist_fwd_h", it_h, ct_h, sets[j][0], sets[j][1], G * T, f["seq_len"], G, Hn, T, Di, Dc, 3,
+                     hist_h[j], 1, hm, hr)
+
+        t = time_kernel(fwd_h, iters=21)
         nbytes = n_valid * D * (2 + 2) + 2 * n_valid * 4
         out["gather_fwd_bf16_tables"] = dict(bound="hbm", kernel="gather_hist_fwd_h_kernel (bf16 tables, bf16 hist)",
                                              achieved=round(nbytes / t / 1e9, 1), peak=8000.0, unit="GB/s",
@@ -376,7 +425,7 @@ def embedding_rooflines(net, f, cfg, G, feed):
     # ---- lazy-Adam rows: touched_rows * Drow * (3 reads + 3 writes + gradient read + gradient clear) * 4
     try:
         tb, m, v, fl = net.tables["item"], net.tab_m["item"], net.tab_v["item"], net.tab_flags["item"]
-        fl.index_fill_(0, keys_i.long(), 1)      # (the step cleared its involved-row marks: the rows of this batch again)
+        fl.index_fill_(0, lists[0]["ki"].long(), 1)      # (the step cleared its involved-row marks: the rows of this batch again)
         ids, count, cap = net._involved_list("item")
         nrows = int(count[0].item())
         ss = torch.ones(1, dtype=torch.float64, device=dev)
@@ -393,6 +442,7 @@ def embedding_rooflines(net, f, cfg, G, feed):
                                 % (nrows, Di * 4), achieved=round(nbytes / t / 1e9, 1), peak=8000.0, unit="GB/s",
                                 frac=round(nbytes / t / 8e12, 4), bytes_per_launch=nbytes, us_per_launch=round(t * 1e6, 2),
                                 formula="touched_rows*Drow*(param, m, v read + write; gradient read + clear)*4",
+                                note="one launch touches 691 MB of rows: nothing of it survives in the 256 MiB Infinity Cache until the next",
                                 traffic=704.5e6, traffic_source="profiles/r05_embed_kernel_trace.md, counters in KiB (24 dispatches, 225 012 rows: "
                                                                 "WRITE_SIZE 344.4 MB + 2 x FETCH_SIZE 171.8 MB; algorithmic 691 MB)")
         if it_h is not None:

@@ -151,7 +151,8 @@ struct AttL0BwdArgsX {
   int G, T, Q, A0;
 };
 
-// NP = bf16 pieces per operand: 2 (hi + lo: the parity mode's x3 products) or 1 (speed mode); ST = storage type of dz0
+// NP = bf16 pieces per operand: 3 (precision="fp32": every piece product whose indices sum to <= 2 -- 2^-23 relative, the level
+// of an fp32 product), 2 (hi + lo, "fp32x3": 2^-16 per term) or 1 (speed mode); ST = storage type of dz0
 template <int NF, int NZ, int NP, typename ST>
 __global__ void __launch_bounds__(256, (NP == 1 && X3_L0H_OCC2) ? 2 : X3_OCC) att_l0_bwd_x3_kernel(AttL0BwdArgsX s) {
   constexpr unsigned SB = sizeof(ST);
@@ -162,9 +163,11 @@ __global__ void __launch_bounds__(256, (NP == 1 && X3_L0H_OCC2) ? 2 : X3_OCC) at
   constexpr int WS = 32 * KT + 8;           // bf16 row stride of the weight images (52 / 36 dwords: conflict-free 16-byte reads)
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int j = lane & 15, g4 = lane >> 4;
+  constexpr int NPW = NP > 2 ? 3 : 2;       // weight images in LDS
   __bf16* Wh = reinterpret_cast<__bf16*>(lds_raw);
   __bf16* Wl = Wh + QP * WS;
-  float* wl = reinterpret_cast<float*>(lds_raw + (size_t)2 * QP * WS * 2) + (size_t)wave * X3_GMAX * (2 * QP + ZP);
+  __bf16* Wr = Wl + QP * WS;                // (NP == 3 only)
+  float* wl = reinterpret_cast<float*>(lds_raw + (size_t)NPW * QP * WS * 2) + (size_t)wave * X3_GMAX * (2 * QP + ZP);
   float* qs = wl;                       // [G][QP] query rows of the group
   float* dqs = wl + X3_GMAX * QP;       // [G][QP] dq accumulators
   float* dvs = wl + 2 * X3_GMAX * QP;   // [G][ZP] dV accumulators
@@ -178,6 +181,7 @@ __global__ void __launch_bounds__(256, (NP == 1 && X3_L0H_OCC2) ? 2 : X3_OCC) at
       split8x(v, hi, lo);
       reinterpret_cast<bf16x8*>(Wh)[e] = hi;
       reinterpret_cast<bf16x8*>(Wl)[e] = lo;
+      if constexpr (NP > 2) reinterpret_cast<bf16x8*>(Wr)[e] = to_h(v - to_f(hi) - to_f(lo));
     }
   }
   __syncthreads();
@@ -258,15 +262,16 @@ __global__ void __launch_bounds__(256, (NP == 1 && X3_L0H_OCC2) ? 2 : X3_OCC) at
     int ctt = 0, cg = 0;
     f32x4 at[NF], dacc[NF], uacc[NZ];
     bf16x4 sah[NF], sal[NF], sbh[NZ], sbl[NZ];     // first half of a pair: (a*q) and dz0 in feature-lane layout, hi / lo
+    bf16x4 sar[NP > 2 ? NF : 1], sbr[NP > 2 ? NZ : 1];   // (third pieces)
     for (int i0 = 0; i0 < n_it; i0 += 2) {
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
         const bool live = i0 + d < n_it;            // (uniform)
-        bf16x4 cah[NF], cal[NF], cbh[NZ], cbl[NZ];
+        bf16x4 cah[NF], cal[NF], cbh[NZ], cbl[NZ], car[NP > 2 ? NF : 1], cbr[NP > 2 ? NZ : 1];
 #pragma unroll
-        for (int f = 0; f < NF; ++f) { cah[f] = zh4; cal[f] = zh4; }
+        for (int f = 0; f < NF; ++f) { cah[f] = zh4; cal[f] = zh4; if constexpr (NP > 2) car[f] = zh4; }
 #pragma unroll
-        for (int z = 0; z < NZ; ++z) { cbh[z] = zh4; cbl[z] = zh4; }
+        for (int z = 0; z < NZ; ++z) { cbh[z] = zh4; cbl[z] = zh4; if constexpr (NP > 2) cbr[z] = zh4; }
         if (live) {
           const int t0 = 16 * ctt;
           if (cg == 0) {   // new tile: a[h, t, :] in the result layout (4 positions of feature 16f + j), accumulators
@@ -312,6 +317,15 @@ __global__ void __launch_bounds__(256, (NP == 1 && X3_L0H_OCC2) ? 2 : X3_OCC) at
               wh[f] = ld8h(Wh + wrow + 16 * f * WS + 32 * kt);
               if constexpr (NP > 1) wlo[f] = ld8h(Wl + wrow + 16 * f * WS + 32 * kt);
             }
+            if constexpr (NP > 2) {       // the three products of index sum 2 first (smallest terms)
+#pragma unroll
+              for (int f = 0; f < NF; ++f) {
+                const bf16x8 wr = ld8h(Wr + wrow + 16 * f * WS + 32 * kt);
+                HMFMA(acc[f], xh[kt], wr);
+                HMFMA(acc[f], xl[kt], wlo[f]);
+                HMFMA(acc[f], xr[kt], wh[f]);
+              }
+            }
             if constexpr (NP > 1) {
 #pragma unroll
               for (int f = 0; f < NF; ++f) HMFMA(acc[f], xh[kt], wlo[f]);
@@ -333,6 +347,7 @@ __global__ void __launch_bounds__(256, (NP == 1 && X3_L0H_OCC2) ? 2 : X3_OCC) at
               HMFMA(tl, xl[z >> 1], sel[z & 1]);
               HMFMA(tr, xr[z >> 1], sel[z & 1]);
               cbl[z] = to_h4(tl);
+              if constexpr (NP > 2) cbr[z] = to_h4(tr);
               dzt[z] = th + (tl + tr);
             } else {
               dzt[z] = th;      // (exact for a bf16 dz0)
@@ -350,6 +365,7 @@ __global__ void __launch_bounds__(256, (NP == 1 && X3_L0H_OCC2) ? 2 : X3_OCC) at
             sq[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, (pr.x + pr.y) + (pr.z + pr.w), z4, 0, 0, 0)[0];
             if constexpr (NP > 1) split4(at[f] * qv, cah[f], cal[f]);
             else cah[f] = to_h4(at[f] * qv);
+            if constexpr (NP > 2) car[f] = to_h4(at[f] * qv - to_f4(cah[f]) - to_f4(cal[f]));
           }
 #pragma unroll
           for (int z = 0; z < NZ; ++z) {
@@ -388,9 +404,9 @@ __global__ void __launch_bounds__(256, (NP == 1 && X3_L0H_OCC2) ? 2 : X3_OCC) at
         }
         if (d == 0) {
 #pragma unroll
-          for (int f = 0; f < NF; ++f) { sah[f] = cah[f]; sal[f] = cal[f]; }
+          for (int f = 0; f < NF; ++f) { sah[f] = cah[f]; sal[f] = cal[f]; if constexpr (NP > 2) sar[f] = car[f]; }
 #pragma unroll
-          for (int z = 0; z < NZ; ++z) { sbh[z] = cbh[z]; sbl[z] = cbl[z]; }
+          for (int z = 0; z < NZ; ++z) { sbh[z] = cbh[z]; sbl[z] = cbl[z]; if constexpr (NP > 2) sbr[z] = cbr[z]; }
         } else if (X3A_DW) {
           // weight gradient of the pair: k = the 8 positions a lane holds of its feature (4 of each iteration)
           bf16x8 bh[NZ], bl[NZ];
@@ -399,6 +415,15 @@ __global__ void __launch_bounds__(256, (NP == 1 && X3_L0H_OCC2) ? 2 : X3_OCC) at
 #pragma unroll
           for (int f = 0; f < NF; ++f) {
             const bf16x8 ah = cat4(sah[f], cah[f]), al = cat4(sal[f], cal[f]);
+            if constexpr (NP > 2) {
+              const bf16x8 ar = cat4(sar[f], car[f]);
+#pragma unroll
+              for (int z = 0; z < NZ; ++z) {
+                HMFMA(accW[f][z], ah, cat4(sbr[z], cbr[z]));
+                HMFMA(accW[f][z], al, bl[z]);
+                HMFMA(accW[f][z], ar, bh[z]);
+              }
+            }
             if constexpr (NP > 1) {
 #pragma unroll
               for (int z = 0; z < NZ; ++z) HMFMA(accW[f][z], ah, bl[z]);
@@ -480,7 +505,7 @@ extern "C" int clsr_att_l0_bwd_x1_h_parts(long Hn) { return l0x_grid(Hn, true); 
 template <int NF, int NZ, int NP, typename ST>
 static int att_l0_bwd_x3_launch(const AttL0BwdArgsX& a, hipStream_t stream) {
   constexpr int KT = (NZ + 1) / 2, WS = 32 * KT + 8;
-  size_t shmem = (size_t)2 * 16 * NF * WS * 2 + (size_t)4 * X3_GMAX * (2 * 16 * NF + 16 * NZ) * 4;
+  size_t shmem = (size_t)(NP > 2 ? 3 : 2) * 16 * NF * WS * 2 + (size_t)4 * X3_GMAX * (2 * 16 * NF + 16 * NZ) * 4;
   const size_t red = (size_t)2 * NF * NZ * 256 * 4;
   if (shmem < red) shmem = red;
   auto kernel = att_l0_bwd_x3_kernel<NF, NZ, NP, ST>;
@@ -491,7 +516,7 @@ static int att_l0_bwd_x3_launch(const AttL0BwdArgsX& a, hipStream_t stream) {
   return CLSR_OK;
 }
 
-static int att_l0_bwd_x3_any(const void* dz0, bool half, int lddz, const float* Wt, int Kp, const float* a, int lda,
+static int att_l0_bwd_x3_any(const void* dz0, bool half, int pieces, int lddz, const float* Wt, int Kp, const float* a, int lda,
                              const float* q, int ldq, long Hn, int G, int T, int Q, int A0, float* da, int ldda,
                              float* dq, int lddq, float* dU, int lddu, float* dV, int lddv, float* dwp_partial,
                              void* stream) {
@@ -507,17 +532,26 @@ static int att_l0_bwd_x3_any(const void* dz0, bool half, int lddz, const float* 
   hipStream_t st = (hipStream_t)stream;
   const int nf = x3_tiles_class(Q), nz = x3_tiles_class(A0);
 #define X3_GO(F, Z) \
-  if (nf == F && nz == Z) return half ? att_l0_bwd_x3_launch<F, Z, 1, __bf16>(s, st) : att_l0_bwd_x3_launch<F, Z, 2, float>(s, st)
+  if (nf == F && nz == Z) return half ? att_l0_bwd_x3_launch<F, Z, 1, __bf16>(s, st) : pieces == 3 ? att_l0_bwd_x3_launch<F, Z, 3, float>(s, st) : att_l0_bwd_x3_launch<F, Z, 2, float>(s, st)
   X3_GO(3, 3); X3_GO(3, 5); X3_GO(5, 3); X3_GO(5, 5);
 #undef X3_GO
-  return CLSR_OK;
+  clsr_set_error("%s:%d: no instance for Q = %d, A0 = %d", __FILE__, __LINE__, Q, A0);
+  return CLSR_EUNSUPPORTED;
 }
 
 extern "C" int clsr_att_l0_bwd_x3(const float* dz0, int lddz, const float* Wt, int Kp, const float* a, int lda,
                                   const float* q, int ldq, long Hn, int G, int T, int Q, int A0, float* da, int ldda,
                                   float* dq, int lddq, float* dU, int lddu, float* dV, int lddv, float* dwp_partial,
                                   void* stream) {
-  return att_l0_bwd_x3_any(dz0, false, lddz, Wt, Kp, a, lda, q, ldq, Hn, G, T, Q, A0, da, ldda, dq, lddq, dU, lddu, dV,
+  return att_l0_bwd_x3_any(dz0, false, 2, lddz, Wt, Kp, a, lda, q, ldq, Hn, G, T, Q, A0, da, ldda, dq, lddq, dU, lddu, dV,
+                           lddv, dwp_partial, stream);
+}
+// the same with THREE bf16 pieces per operand (fp32 accuracy: precision="fp32")
+extern "C" int clsr_att_l0_bwd_x6(const float* dz0, int lddz, const float* Wt, int Kp, const float* a, int lda,
+                                  const float* q, int ldq, long Hn, int G, int T, int Q, int A0, float* da, int ldda,
+                                  float* dq, int lddq, float* dU, int lddu, float* dV, int lddv, float* dwp_partial,
+                                  void* stream) {
+  return att_l0_bwd_x3_any(dz0, false, 3, lddz, Wt, Kp, a, lda, q, ldq, Hn, G, T, Q, A0, da, ldda, dq, lddq, dU, lddu, dV,
                            lddv, dwp_partial, stream);
 }
 // speed mode: dz0 stored as bf16 (uint16 bit patterns), ONE bf16 piece per operand (bf16-exact on the dz0 side)
@@ -525,7 +559,7 @@ extern "C" int clsr_att_l0_bwd_x1_h(const void* dz0, int lddz, const float* Wt, 
                                     const float* q, int ldq, long Hn, int G, int T, int Q, int A0, float* da, int ldda,
                                     float* dq, int lddq, float* dU, int lddu, float* dV, int lddv, float* dwp_partial,
                                     void* stream) {
-  return att_l0_bwd_x3_any(dz0, true, lddz, Wt, Kp, a, lda, q, ldq, Hn, G, T, Q, A0, da, ldda, dq, lddq, dU, lddu, dV,
+  return att_l0_bwd_x3_any(dz0, true, 1, lddz, Wt, Kp, a, lda, q, ldq, Hn, G, T, Q, A0, da, ldda, dq, lddq, dU, lddu, dV,
                            lddv, dwp_partial, stream);
 }
 
@@ -567,9 +601,11 @@ __global__ void __launch_bounds__(256, APPLY ? 1 : X3_L1P1_OCC) att_l1_bwd_x3_ke
   constexpr int KC = (NC + 1) / 2, KCP = 32 * KC, WS = KCP + 8, NR = 16 * OT;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int j = lane & 15, g = lane >> 4;
+  constexpr int NPW = NP > 2 ? 3 : 2;       // weight images in LDS
   __bf16* Wh = reinterpret_cast<__bf16*>(lds_raw);
   __bf16* Wl = Wh + NR * WS;
-  float* ptab = reinterpret_cast<float*>(lds_raw + (size_t)2 * NR * WS * 2);   // [5][KCP]: sc1, sh1, p = a1 * w_out, a2, a3
+  __bf16* Wr = Wl + NR * WS;                // (NP == 3 only)
+  float* ptab = reinterpret_cast<float*>(lds_raw + (size_t)NPW * NR * WS * 2);   // [5][KCP]: sc1, sh1, p = a1 * w_out, a2, a3
   {
     constexpr int C8 = WS / 8;
     for (int e = tid; e < NR * C8; e += 256) {
@@ -580,6 +616,7 @@ __global__ void __launch_bounds__(256, APPLY ? 1 : X3_L1P1_OCC) att_l1_bwd_x3_ke
       split8x(v, hi, lo);
       reinterpret_cast<bf16x8*>(Wh)[e] = hi;
       reinterpret_cast<bf16x8*>(Wl)[e] = lo;
+      if constexpr (NP > 2) reinterpret_cast<bf16x8*>(Wr)[e] = to_h(v - to_f(hi) - to_f(lo));
     }
     for (int e = tid; e < 5 * KCP; e += 256) {
       const int which = e / KCP, k = e - which * KCP;
@@ -681,7 +718,8 @@ __global__ void __launch_bounds__(256, APPLY ? 1 : X3_L1P1_OCC) att_l1_bwd_x3_ke
     if (PF) nxt = fetch(tile + tstride);      // (past the end: clamped / out-of-range loads, never used)
     const int m0 = tile * 32;
     // ---- prologue: dz1 of the lane's position (A operand: features 32c + 8g + {0..7}), split
-    bf16x8 dh[2][KC], dl[2][KC], dr[APPLY ? 2 : 1][APPLY ? KC : 1];      // (dl, dr: NP > 1 only)
+    constexpr bool DR = APPLY || NP > 2;        // third piece: the bias sums of pass 2; every product with NP == 3
+    bf16x8 dh[2][KC], dl[2][KC], dr[DR ? 2 : 1][DR ? KC : 1];      // (dl, dr: NP > 1 only)
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
       const int k0 = 32 * c + 8 * g;
@@ -698,7 +736,7 @@ __global__ void __launch_bounds__(256, APPLY ? 1 : X3_L1P1_OCC) att_l1_bwd_x3_ke
         const f32x8 xm = pvalid ? x : z8;
         if constexpr (NP > 1) {
           split8x(xm, dh[s][c], dl[s][c]);
-          if (APPLY) dr[s][c] = to_h(xm - to_f(dh[s][c]) - to_f(dl[s][c]));   // (third piece: the bias sums below)
+          if (DR) dr[s][c] = to_h(xm - to_f(dh[s][c]) - to_f(dl[s][c]));   // (third piece: the bias sums below; NP == 3: every product)
         } else {
           dh[s][c] = to_h(xm);
         }
@@ -706,7 +744,7 @@ __global__ void __launch_bounds__(256, APPLY ? 1 : X3_L1P1_OCC) att_l1_bwd_x3_ke
     }
     X3_SCHED_FENCE();
     // ---- pass 2: dz1^T (feature-lane layout) through products with the identity: B operands of the weight gradient
-    bf16x8 bh[APPLY ? NC : 1], bl[APPLY ? NC : 1];
+    bf16x8 bh[APPLY ? NC : 1], bl[APPLY ? NC : 1], br[(APPLY && NP > 2) ? NC : 1];
     if (APPLY) {
 #pragma unroll
       for (int ct = 0; ct < NC; ++ct) {
@@ -724,6 +762,7 @@ __global__ void __launch_bounds__(256, APPLY ? 1 : X3_L1P1_OCC) att_l1_bwd_x3_ke
           f32x4 tr0 = z4, tr1 = z4;
           HMFMA(tr0, dr[0][ct >> 1], sel[ct & 1]);
           HMFMA(tr1, dr[1][ct >> 1], sel[ct & 1]);
+          if constexpr (NP > 2) br[ct] = cat4(to_h4(tr0), to_h4(tr1));
           t = (th0 + (tl0 + tr0)) + (th1 + (tl1 + tr1));
         }
         bsum[ct] += (t.x + t.y) + (t.z + t.w);
@@ -748,6 +787,12 @@ __global__ void __launch_bounds__(256, APPLY ? 1 : X3_L1P1_OCC) att_l1_bwd_x3_ke
 #pragma unroll
       for (int c = 0; c < KC; ++c) {
         const bf16x8 wh = ld8h(Wh + wrow[ot] + 32 * c);
+        if constexpr (NP > 2) {         // the three products of index sum 2 first (smallest terms)
+          const bf16x8 wl = ld8h(Wl + wrow[ot] + 32 * c), wr = ld8h(Wr + wrow[ot] + 32 * c);
+          HMFMA(acc0, dh[0][c], wr); HMFMA(acc1, dh[1][c], wr);
+          HMFMA(acc0, dl[0][c], wl); HMFMA(acc1, dl[1][c], wl);
+          HMFMA(acc0, dr[0][c], wh); HMFMA(acc1, dr[1][c], wh);
+        }
         if constexpr (NP > 1) {
           const bf16x8 wl = ld8h(Wl + wrow[ot] + 32 * c);
           HMFMA(acc0, dh[0][c], wl); HMFMA(acc1, dh[1][c], wl);
@@ -755,7 +800,7 @@ __global__ void __launch_bounds__(256, APPLY ? 1 : X3_L1P1_OCC) att_l1_bwd_x3_ke
         }
         HMFMA(acc0, dh[0][c], wh); HMFMA(acc1, dh[1][c], wh);
       }
-      bf16x4 xh[2], xl[2];
+      bf16x4 xh[2], xl[2], xr[2];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const f32x4 zz = {x3_f1<ST>(cur.z0[s][ot][0]), x3_f1<ST>(cur.z0[s][ot][1]), x3_f1<ST>(cur.z0[s][ot][2]),
@@ -774,6 +819,7 @@ __global__ void __launch_bounds__(256, APPLY ? 1 : X3_L1P1_OCC) att_l1_bwd_x3_ke
           for (int e = 0; e < 4; ++e) x1[e] = pval[s][e] ? fmaxf(y[e], 0.f) : 0.f;
           if constexpr (NP > 1) split4(x1, xh[s], xl[s]);
           else xh[s] = to_h4(x1);
+          if constexpr (NP > 2) xr[s] = to_h4(x1 - to_f4(xh[s]) - to_f4(xl[s]));
         } else {
           // (sum of dy0 * (z0 - mean0): the factor invstd0 of xhat0 is applied to the finished sums)
           const f32x4 w2 = zz - e2[ot];
@@ -783,6 +829,15 @@ __global__ void __launch_bounds__(256, APPLY ? 1 : X3_L1P1_OCC) att_l1_bwd_x3_ke
       }
       if (APPLY) {
         const bf16x8 ah = cat4(xh[0], xh[1]);
+        if constexpr (NP > 2) {
+          const bf16x8 al = cat4(xl[0], xl[1]), ar = cat4(xr[0], xr[1]);
+#pragma unroll
+          for (int ct = 0; ct < NC; ++ct) {
+            HMFMA(accW[ot][ct], ah, br[ct]);
+            HMFMA(accW[ot][ct], al, bl[ct]);
+            HMFMA(accW[ot][ct], ar, bh[ct]);
+          }
+        }
         if constexpr (NP > 1) {
           const bf16x8 al = cat4(xl[0], xl[1]);
 #pragma unroll
@@ -893,7 +948,7 @@ extern "C" int clsr_att_l1_bwd_x3_parts(int M) { return l1x_grid(M, false); }
 template <int OT, int NC, int NP, typename ST>
 static int l1x_launch(const L1BwdArgsX& a, bool apply, hipStream_t stream) {
   constexpr int KC = (NC + 1) / 2, KCP = 32 * KC, WS = KCP + 8, NR = 16 * OT;
-  size_t shmem = (size_t)2 * NR * WS * 2 + (size_t)5 * KCP * 4;
+  size_t shmem = (size_t)(NP > 2 ? 3 : 2) * NR * WS * 2 + (size_t)5 * KCP * 4;
   const size_t red = apply ? ((size_t)2 * OT * NC * 256 + 4 * NC * 16) * 4 : (size_t)16 * 2 * NR * 8;
   if (shmem < red) shmem = red;
   dim3 grid(l1x_grid(a.M, apply));
@@ -911,7 +966,7 @@ static int l1x_launch(const L1BwdArgsX& a, bool apply, hipStream_t stream) {
 }
 
 // coef0 == NULL: pass 1 (stats);  coef0 given: pass 2 (dz0 + the partial chunks of dW1 / db1)
-static int att_l1_bwd_x3_any(const void* z1, bool half, int ldz1, const float* ds, const float* scale1, const float* shift1,
+static int att_l1_bwd_x3_any(const void* z1, bool half, int pieces, int ldz1, const float* ds, const float* scale1, const float* shift1,
                              const float* w_out, const float* coef1, const float* Wt, int Kp, const void* z0,
                              int ldz0, const float* scale0, const float* shift0, const float* mean0,
                              const float* invstd0, const float* coef0, void* dz0, int lddz0, float* dw1_partial,
@@ -934,10 +989,11 @@ static int att_l1_bwd_x3_any(const void* z1, bool half, int ldz1, const float* d
   hipStream_t s = (hipStream_t)stream;
   const int ot = x3_tiles_class(C0), nc = C1 <= 32 ? 2 : 3;
 #define L1X_GO(O, N) \
-  if (ot == O && nc == N) return half ? l1x_launch<O, N, 1, __bf16>(a, apply, s) : l1x_launch<O, N, 2, float>(a, apply, s)
+  if (ot == O && nc == N) return half ? l1x_launch<O, N, 1, __bf16>(a, apply, s) : pieces == 3 ? l1x_launch<O, N, 3, float>(a, apply, s) : l1x_launch<O, N, 2, float>(a, apply, s)
   L1X_GO(3, 2); L1X_GO(3, 3); L1X_GO(5, 2); L1X_GO(5, 3);
 #undef L1X_GO
-  return CLSR_OK;
+  clsr_set_error("%s:%d: no instance for C1 = %d, C0 = %d", __FILE__, __LINE__, C1, C0);
+  return CLSR_EUNSUPPORTED;
 }
 
 extern "C" int clsr_att_l1_bwd_x3(const float* z1, int ldz1, const float* ds, const float* scale1, const float* shift1,
@@ -945,7 +1001,16 @@ extern "C" int clsr_att_l1_bwd_x3(const float* z1, int ldz1, const float* ds, co
                                   int ldz0, const float* scale0, const float* shift0, const float* mean0,
                                   const float* invstd0, const float* coef0, float* dz0, int lddz0, float* dw1_partial,
                                   double* stats, int M, int C1, int C0, void* stream) {
-  return att_l1_bwd_x3_any(z1, false, ldz1, ds, scale1, shift1, w_out, coef1, Wt, Kp, z0, ldz0, scale0, shift0, mean0,
+  return att_l1_bwd_x3_any(z1, false, 2, ldz1, ds, scale1, shift1, w_out, coef1, Wt, Kp, z0, ldz0, scale0, shift0, mean0,
+                           invstd0, coef0, dz0, lddz0, dw1_partial, stats, M, C1, C0, stream);
+}
+// the same with THREE bf16 pieces per operand (fp32 accuracy: precision="fp32")
+extern "C" int clsr_att_l1_bwd_x6(const float* z1, int ldz1, const float* ds, const float* scale1, const float* shift1,
+                                  const float* w_out, const float* coef1, const float* Wt, int Kp, const float* z0,
+                                  int ldz0, const float* scale0, const float* shift0, const float* mean0,
+                                  const float* invstd0, const float* coef0, float* dz0, int lddz0, float* dw1_partial,
+                                  double* stats, int M, int C1, int C0, void* stream) {
+  return att_l1_bwd_x3_any(z1, false, 3, ldz1, ds, scale1, shift1, w_out, coef1, Wt, Kp, z0, ldz0, scale0, shift0, mean0,
                            invstd0, coef0, dz0, lddz0, dw1_partial, stats, M, C1, C0, stream);
 }
 // speed mode: z1 / z0 / dz0 stored as bf16 (uint16 bit patterns), ONE bf16 piece per operand
@@ -954,6 +1019,6 @@ extern "C" int clsr_att_l1_bwd_x1_h(const void* z1, int ldz1, const float* ds, c
                                     int ldz0, const float* scale0, const float* shift0, const float* mean0,
                                     const float* invstd0, const float* coef0, void* dz0, int lddz0, float* dw1_partial,
                                     double* stats, int M, int C1, int C0, void* stream) {
-  return att_l1_bwd_x3_any(z1, true, ldz1, ds, scale1, shift1, w_out, coef1, Wt, Kp, z0, ldz0, scale0, shift0, mean0,
+  return att_l1_bwd_x3_any(z1, true, 1, ldz1, ds, scale1, shift1, w_out, coef1, Wt, Kp, z0, ldz0, scale0, shift0, mean0,
                            invstd0, coef0, dz0, lddz0, dw1_partial, stats, M, C1, C0, stream);
 }

@@ -298,7 +298,8 @@ extern "C" int clsr_att_hist_fwd_x3(const float* keys, int ldk, const float* At,
   AH_GO(1, 3, 3, 3); AH_GO(1, 3, 5, 3); AH_GO(1, 5, 3, 3); AH_GO(1, 5, 5, 3);
   AH_GO(2, 3, 3, 3); AH_GO(2, 3, 5, 3); AH_GO(2, 5, 3, 3); AH_GO(2, 5, 5, 3);
 #undef AH_GO
-  return CLSR_OK;
+  clsr_set_error("%s:%d: no instance for Dk = %d, Q = %d, A0 = %d, qh = %d", __FILE__, __LINE__, Dk, Q, A0, qh);
+  return CLSR_EUNSUPPORTED;
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -526,5 +527,6 @@ extern "C" int clsr_att_hist_bwd_x3(const float* dU, int lddu, const float* WuT,
   AHB_GO(1, 3, 3); AHB_GO(2, 3, 3); AHB_GO(3, 3, 3); AHB_GO(1, 5, 3); AHB_GO(2, 5, 3); AHB_GO(3, 5, 3);
 #undef AHB_GO
   (void)nk;
-  return CLSR_OK;
+  clsr_set_error("%s:%d: no instance for Q = %d, A0 = %d, qh = %d", __FILE__, __LINE__, Q, A0, qh);
+  return CLSR_EUNSUPPORTED;
 }

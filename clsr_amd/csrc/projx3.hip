@@ -597,7 +597,8 @@ extern "C" int clsr_enc_back_x3(const float* dPin, int ldp, const float* WxT, in
   EB_GO(4); EB_GO(8); EB_GO(12); EB_GO(15); EB_GO(16);
 #undef EB_GO
   (void)nd;
-  return CLSR_OK;
+  clsr_set_error("%s:%d: no instance for NX = %d", __FILE__, __LINE__, NX);
+  return CLSR_EUNSUPPORTED;
 }
 
 // The Time4LSTM's time-gate projection without its [hist | TT] input image:  Y = [hist | 0 | tanh(t_now w1 + b1) | tanh(t_first w2 + b2)] . W + b

@@ -217,9 +217,17 @@ class CLSRNet(object):
         # Attention-MLP backward (exact mode): "x3" = the two-pass layer-1 kernel and the one-pass layer-0 kernel as split-bf16
         # products with the weight gradients dW1 / db1 / dWp accumulated inside them (csrc/attbwdx3.hip: no separate
         # weight-gradient launches, no stored dz1); "fp32" = the fp32-MFMA kernels + clsr_pgemm_dw_partial beside them
-        self.att_bwd = "fp32" if self.exact_products else os.environ.get("CLSR_ATT_BWD", "x3")
-        if self.att_bwd not in ("x3", "fp32"):
-            raise ValueError("CLSR_ATT_BWD must be 'x3' or 'fp32'")
+        # precision="fp32": "x6" = the same kernels with THREE pieces per operand (fp32 accuracy; CLSR_ATT_BWD=fp32: the fp32-MFMA
+        # kernels + separate weight-gradient launches)
+        # ("x6l1": three pieces in the layer-1 kernel only, the layer-0 backward on fp32 MFMAs + its weight-gradient launch)
+        self.att_bwd = os.environ.get("CLSR_ATT_BWD", "x6l1" if self.exact_products else "x3")   # (x6l1: 3.19-3.22 ms, x6: 3.28-3.34 -- the three-piece layer-0 instance spills --, fp32: 3.32-3.34)
+        if self.att_bwd not in ("x6", "x6l1", "fp32") + (() if self.exact_products else ("x3",)):
+            raise ValueError("CLSR_ATT_BWD must be 'x6', 'x6l1' or 'fp32' (precision='fp32'), also 'x3' otherwise")
+        self.att_bwd_l0 = "fp32" if self.att_bwd == "x6l1" else self.att_bwd
+        if self.att_bwd == "x6l1":
+            self.att_bwd = "x6"
+        self._l1x = "clsr_att_l1_bwd_x6" if self.att_bwd == "x6" else "clsr_att_l1_bwd_x3"
+        self._l0x = "clsr_att_l0_bwd_x6" if self.att_bwd_l0 == "x6" else "clsr_att_l0_bwd_x3"
         self.fuse_tt = True   # A/B: time-gate blocks of the input projection as one product over [hist | TT]
         # the row-level heads (alpha gate, alpha / logit MLPs, loss, their backward) as two persistent launches with grid
         # barriers for the batch-norm statistics (csrc/headsfused.hip) instead of a chain of 22 dependent launches
@@ -340,7 +348,7 @@ class CLSRNet(object):
                  "rnn_first", "tick_early", "hist_grad_two", "dw_batch_late", "bn_bwd_fused", "dw_stream", "dw_streams",
                  "split_query", "split_query_min", "bf16_split_query", "split_emb_grad", "bf16_chain", "bf16_dw", "bf16_bwd",
                  "fused_l0_bwd", "fused_l0_wu", "l0_fwd_wave", "l0_bwd_halves", "dw_batching", "lt_bwd_early", "dpin_h", "flush_side",
-                 "l1_bwd_2pass", "split_g2", "g2_stream", "rnn_products", "rnn_fused_proj", "rnn_act_tiled", "att_bwd", "att_hist_x3",
+                 "l1_bwd_2pass", "split_g2", "g2_stream", "rnn_products", "rnn_fused_proj", "rnn_act_tiled", "att_bwd", "att_bwd_l0", "_l1x", "_l0x", "att_hist_x3",
                  "att_hist_bwd_x3", "att_hist_bwd_pieces", "att_hist_pieces", "att_l1_fwd_x6", "att_fwd_x3", "att_fwd_x6",
                  "att_l0_fwd_entry", "x3_enc", "enc_back_x3", "enc_bwd_fused", "enc_bwd_fused_h", "proj_x3", "proj_tt", "proj_x3_wide",
                  "gemm_wide_x3", "proj_gate_pieces", "proj_bwd_pieces", "proj_wide_pieces", "dhist_side", "early_scatter",
@@ -1446,7 +1454,7 @@ class CLSRNet(object):
                 call("clsr_att_prod_bwd_h", daq, Q, a, Q, q, Q, Hn, G, T, Q, da, Q, dq, Q, 0)
                 call("clsr_att_z0_bwd_reduce_h", dz0, Hn, G, T, A0, dU, dV)
             return self._att_bwd_hist(key, scope, nn, a, q, keys, dkeys, dU, dV, da, dq, dW0, Hn, R, T, Dk, Q, 0)
-        x3b = self.att_bwd == "x3"
+        x3b = self.att_bwd in ("x3", "x6")
         if x3b and self.l1_bwd_2pass and query("clsr_att_l1_bwd_x3_supported", A1, A0) and (R * T * A0 + 80) * 4 < (1 << 31) - 1:
             # the same two passes as split-bf16 products; pass 2 also accumulates dW1 / db1 (dz1 is never stored)
             M = R * T
@@ -1454,11 +1462,11 @@ class CLSRNet(object):
             parts = query("clsr_att_l1_bwd_x3_parts", M)
             st = self._buf("stats" + self._ws_tag, 1024 * 2 * 256, dtype=torch.float64)[: parts * 2 * A0]
             wo = P[nn + "w_nn_output"]
-            call("clsr_att_l1_bwd_x3", z1, A1, ds, bn1.scale, bn1.shift, wo, bn1.coef, Wt, Kp, z0, A0, bn0.scale,
+            call(self._l1x, z1, A1, ds, bn1.scale, bn1.shift, wo, bn1.coef, Wt, Kp, z0, A0, bn0.scale,
                  bn0.shift, bn0.mean, bn0.invstd, None, None, 0, None, st, M, A1, A0)
             self._bn_bwd_coef(bn0, st, parts, M)
             ws = self._buf(key + ".dw1x_ws", parts * query("clsr_dw_chunk_floats"))
-            call("clsr_att_l1_bwd_x3", z1, A1, ds, bn1.scale, bn1.shift, wo, bn1.coef, Wt, Kp, z0, A0, bn0.scale,
+            call(self._l1x, z1, A1, ds, bn1.scale, bn1.shift, wo, bn1.coef, Wt, Kp, z0, A0, bn0.scale,
                  bn0.shift, None, None, bn0.coef, dz0, A0, ws, None, M, A1, A0)
             self._dw_fused(ws, parts, A0, A1, Gd[nn + "w_nn_layer1"], A1, db=Gd[nn + "b_nn_layer1"])
         elif self.l1_bwd_2pass and query("clsr_att_l1_bwd_supported", A1, A0):
@@ -1481,6 +1489,7 @@ class CLSRNet(object):
             self._dw(z0, A0, dz1, A1, R * T, A0, A1, Gd[nn + "w_nn_layer1"], A1, db=Gd[nn + "b_nn_layer1"], aff=bn0)
             self._gemm_bnbwd(dz1, A1, key + ".W1^T", R * T, A1, A0, dz0, bn0, z0)
         # layer 0 (re-associated): z0 = U[h,t] + V[r] + (a[h,t]*q[r]) . Wp
+        x3b = self.att_bwd_l0 in ("x3", "x6")
         if qh:
             Q2 = Q - qh
             l0x3 = x3b and self.fused_l0_bwd and query("clsr_att_l0_bwd_x3_supported", G, Q2, A0)
@@ -1497,7 +1506,7 @@ class CLSRNet(object):
                 Wt, Kp = self.packed[key + ".Wp2^T"]
                 parts = query("clsr_att_l0_bwd_x3_parts", Hn)
                 ws = self._buf(key + ".dwpx_ws", parts * query("clsr_dw_chunk_floats"))
-                call("clsr_att_l0_bwd_x3", dz0, A0, Wt, Kp, a[:, qh:], Q, q[:, qh:], Q, Hn, G, T, Q2, A0, da[:, qh:], Q,
+                call(self._l0x, dz0, A0, Wt, Kp, a[:, qh:], Q, q[:, qh:], Q, Hn, G, T, Q2, A0, da[:, qh:], Q,
                      dq[:, qh:], Q, dU, A0, dV, A0, ws)
                 self._dw_fused(ws, parts, Q2, A0, dW0[3 * Q + qh:4 * Q], A0)
                 self._gemm(dV, A0, key + ".Wv^T", R, A0, Q, dq, Q, acc=1)
@@ -1534,7 +1543,7 @@ class CLSRNet(object):
                 Wt, Kp = self.packed[key + ".Wp^T"]
                 parts = query("clsr_att_l0_bwd_x3_parts", Hn)
                 ws = self._buf(key + ".dwpx_ws", parts * query("clsr_dw_chunk_floats"))
-                call("clsr_att_l0_bwd_x3", dz0, A0, Wt, Kp, a, Q, q, Q, Hn, G, T, Q, A0, da, Q, dq, Q,
+                call(self._l0x, dz0, A0, Wt, Kp, a, Q, q, Q, Hn, G, T, Q, A0, da, Q, dq, Q,
                      None if G == 1 else dU, A0, dV, A0, ws)
                 self._dw_fused(ws, parts, Q, A0, dW0[3 * Q:4 * Q], A0)
             elif self.fused_l0_bwd and query("clsr_att_l0_bwd_supported", G, Q, A0):
@@ -1569,7 +1578,7 @@ class CLSRNet(object):
         for i in (0, 1):
             c0 = c_lo + i * Qh
             ws = self._buf(key + ".dwpx_ws%d" % i, parts * C)
-            call("clsr_att_l0_bwd_x3", dz0, A0, Wt[i * Qh * Kp:], Kp, a[:, c0:], Q, q[:, c0:], Q, Hn, G, T, Qh, A0, da[:, c0:], Q,
+            call(self._l0x, dz0, A0, Wt[i * Qh * Kp:], Kp, a[:, c0:], Q, q[:, c0:], Q, Hn, G, T, Qh, A0, da[:, c0:], Q,
                  dq[:, c0:], Q, dU if i == 0 else None, A0, dV if i == 0 else self._buf(key + ".dV_scratch", R, A0), A0, ws)
             self._dw_fused(ws, parts, Qh, A0, dW0[3 * Q + c0:3 * Q + c0 + Qh], A0)
 
@@ -2764,9 +2773,10 @@ class CLSRNet(object):
     def precision_note(self):
         if self.precision == "fp32":
             return ("all tensors fp32; EVERY product at fp32 accuracy: v_mfma_f32_16x16x4_f32 (bit-exact fp32 fma chains: recurrences, "
-                    "attention-MLP backward, layer-0 forward, heads, weight gradients) or three bf16 pieces per operand on "
+                    "layer-0 forward, heads, encoder-side weight gradients) or three bf16 pieces per operand on "
                     "v_mfma_f32_16x16x32_bf16 with fp32 accumulation (2^-23 relative: history-level attention forward / backward, "
-                    "layer-1 forward, the Time4LSTM time-gate projection, d(hist)); no two-piece (2^-16) product anywhere")
+                    "layer-1 forward, the attention-MLP backward with its folded weight gradients%s, the Time4LSTM time-gate "
+                    "projection); no two-piece (2^-16) product anywhere" % ("" if self.att_bwd == "x6" else " [CLSR_ATT_BWD=fp32: fp32 MFMAs]"))
         if self.precision == "fp32x3":
             return ("all tensors fp32 (storage, statistics, losses, optimiser exactly as in the fp32 mode); forward products in front "
                     "of a batch-norm + ReLU at fp32 accuracy; the recurrences' hidden products, the attention-MLP backward with its "
@@ -2837,7 +2847,7 @@ class CLSRNet(object):
                         bytes_per_launch=nbytes, us_per_launch=round(t * 1e6, 2),
                         formula="M * (A1 + A0) * 2 read + M * A0 * 2 written + M * 4 (score gradient), M = B*T positions",
                         note="one 512-register wave per SIMD: bound by instruction issue, not by HBM")
-        if self.att_bwd != "x3" or not query("clsr_att_l1_bwd_x3_supported", self.A1, self.A0):
+        if self.att_bwd not in ("x3", "x6") or not query("clsr_att_l1_bwd_x3_supported", self.A1, self.A0):
             return None
         z0, z1 = self._buf(key + ".z0", M, A0), self._buf(key + ".z1", M, A1)
         dz0, ds = self._buf(key + ".dz0", M, A0), self._buf(key + ".ds", M)
@@ -2845,11 +2855,12 @@ class CLSRNet(object):
         parts = query("clsr_att_l1_bwd_x3_parts", M)
         ws = self._buf(key + ".dw1x_ws", parts * query("clsr_dw_chunk_floats"))
         wo = self.P[nn + "w_nn_output"]
-        t = time_kernel(lambda: call("clsr_att_l1_bwd_x3", z1, A1, ds, bn1.scale, bn1.shift, wo, bn1.coef, Wt, Kp, z0, A0,
+        t = time_kernel(lambda: call(self._l1x, z1, A1, ds, bn1.scale, bn1.shift, wo, bn1.coef, Wt, Kp, z0, A0,
                                      bn0.scale, bn0.shift, None, None, bn0.coef, dz0, A0, ws, None, M, A1, A0))
         nbytes = float(M) * (A1 + 2 * A0 + 1) * 4
-        return dict(bound="hbm", kernel="att_l1_bwd_x3_kernel<5,3,true> (short-term attention, layer-1 backward pass 2: dz0 + the "
-                                        "partial sums of dW1 / db1 from one pass over z1, z0; split-bf16 products)",
+        return dict(bound="hbm", kernel="att_l1_bwd_x3_kernel<5,3,true,%d> (short-term attention, layer-1 backward pass 2: dz0 + the "
+                                        "partial sums of dW1 / db1 from one pass over z1, z0; %s bf16 pieces per operand)"
+                                        % ((3, "three") if self.att_bwd == "x6" else (2, "two")),
                     achieved=round(nbytes / t / 1e9, 1), peak=8000.0, unit="GB/s", frac=round(nbytes / t / 8e12, 4),
                     bytes_per_launch=nbytes, us_per_launch=round(t * 1e6, 2),
                     formula="M * (A1 + A0) * 4 read + M * A0 * 4 written + M * 4 (score gradient), M = B*T positions")

@@ -438,6 +438,17 @@ int clsr_att_l1_bwd_x3(const float* z1, int ldz1, const float* ds, const float* 
                        const float* scale0, const float* shift0, const float* mean0, const float* invstd0,
                        const float* coef0, float* dz0, int lddz0, float* dw1_partial, double* stats, int M, int C1,
                        int C0, void* stream);
+/* ... with THREE bf16 pieces per operand (every piece product whose indices sum to <= 2: 2^-23 relative, the level of an fp32
+ * product -- precision="fp32"); same contracts */
+int clsr_att_l0_bwd_x6(const float* dz0, int lddz, const float* Wt, int Kp, const float* a, int lda,
+                       const float* q, int ldq, long Hn, int G, int T, int Q, int A0, float* da, int ldda,
+                       float* dq, int lddq, float* dU, int lddu, float* dV, int lddv, float* dwp_partial,
+                       void* stream);
+int clsr_att_l1_bwd_x6(const float* z1, int ldz1, const float* ds, const float* scale1, const float* shift1,
+                       const float* w_out, const float* coef1, const float* Wt, int Kp, const float* z0, int ldz0,
+                       const float* scale0, const float* shift0, const float* mean0, const float* invstd0,
+                       const float* coef0, float* dz0, int lddz0, float* dw1_partial, double* stats, int M, int C1,
+                       int C0, void* stream);
 /* Speed mode (precision = "bf16") on the SAME chain kernels: the (row, step)-level tensors z0 / z1 / dz0 stored as bf16
  * (uint16 bit patterns, row strides in elements, % 8 == 0), ONE bf16 piece per operand on v_mfma_f32_16x16x32_bf16 with fp32
  * accumulation, batch-norm sums from the fp32 accumulators, the weight gradients dW1 / db1 / dWp folded in as in the x3

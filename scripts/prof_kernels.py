@@ -67,14 +67,21 @@ def main():
             else:
                 it.zero_()   # 38 GB: touch every page once so the gather reads committed HBM
                 ct.normal_()
-            ii = torch.randint(1, Vi, (Hn, T), device=dev, dtype=torch.int32)
-            ci = torch.randint(1, Vc, (Hn, T), device=dev, dtype=torch.int32)
+            NS = 3      # id sets the launches rotate through (3 x 210 MB touched at the catalogue: past the 256 MiB Infinity Cache)
+            ii = [torch.randint(1, Vi, (Hn, T), device=dev, dtype=torch.int32) for _ in range(NS)]
+            ci = [torch.randint(1, Vc, (Hn, T), device=dev, dtype=torch.int32) for _ in range(NS)]
             ln = torch.full((Hn,), T, device=dev, dtype=torch.int32)
             D = Di + Dc
-            hist = torch.empty(Hn, T, D, device=dev)
+            hist = [torch.empty(Hn, T, D, device=dev) for _ in range(NS)]
             hm, hr = torch.empty(Hn, D, device=dev), torch.empty(Hn, D, device=dev)
-            t = timeit(lambda: call("clsr_gather_hist_fwd", it, ct, ii, ci, T, ln, 1, Hn, T, Di, Dc, 3, hist, hm, hr),
-                       iters=20)
+            turn = [0]
+
+            def gather():
+                j = turn[0] % NS
+                turn[0] += 1
+                call("clsr_gather_hist_fwd", it, ct, ii[j], ci[j], T, ln, 1, Hn, T, Di, Dc, 3, hist[j], hm, hr)
+
+            t = timeit(gather, iters=21)
             nbytes = Hn * T * (D * 8 + 8)
             print("gather_hist_fwd %-14s rows %dB+%dB: %8.1f us  %.0f GB/s algorithmic (%.1f%% of 8 TB/s)" % (
                 name, Di * 4, Dc * 4, t, nbytes / t / 1e3, nbytes / t / 1e3 / 80))
@@ -89,35 +96,53 @@ def main():
             Vi, Vc, Di, Dc = 64138, 4096, 32, 8
         D, n = Di + Dc, Hn * T
         gi, gc = torch.zeros(Vi, Di, device=dev), torch.zeros(Vc, Dc, device=dev)      # gradient tables (touches the pages)
-        ii = torch.randint(1, Vi, (Hn, T), device=dev, dtype=torch.int32)
-        ci = torch.randint(1, Vc, (Hn, T), device=dev, dtype=torch.int32)
-        if taobao:
-            ii = (torch.rand(Hn, T, device=dev).pow(8.0) * (Vi - 2)).int() + 1
-            ci = (torch.rand(Hn, T, device=dev).pow(8.0) * (Vc - 2)).int() + 1
-        it, ct = torch.randint(1, Vi, (B,), device=dev, dtype=torch.int32), torch.randint(1, Vc, (B,), device=dev, dtype=torch.int32)
+        NS = 3          # sorted lists + gradient tensors the launches rotate through (past the 256 MiB Infinity Cache)
         ln = torch.full((Hn,), T, device=dev, dtype=torch.int32)
-        keys = [torch.empty(n + B, dtype=torch.int32, device=dev) for _ in range(2)]
-        perm = [torch.empty(n + B, dtype=torch.int32, device=dev) for _ in range(2)]
-        rows = [(ii.data_ptr(), keys[0].data_ptr(), perm[0].data_ptr(), Hn, T, T, 17 if taobao else 27, it.data_ptr(), B, 1),
-                (ci.data_ptr(), keys[1].data_ptr(), perm[1].data_ptr(), Hn, T, T, 12 if taobao else 14, ct.data_ptr(), B, 1)]
-        wss = torch.empty(query("clsr_sort_ids_stable_workspace_bytes", 2 * (n + B), 2), dtype=torch.uint8, device=dev)
-        t = timeit(lambda: ops.sort_ids_stable_multi(rows, wss), iters=5)
-        print("stable radix sort of 2 x %d ids (27 / 14 bits): %8.1f us" % (n + B, t))
-        dhist, dtarget = torch.randn(n, D, device=dev) * 1e-3, torch.randn(B, D, device=dev) * 1e-3
-        wch = lambda V, n_: int(os.environ.get("EMBED_WCH", "0"))      # clsr_segsum_desc.border_wch (independent uniform ids here: 64 pays)
-        for tag, d, sa in (("fp32 d(hist)", dhist, 4), ("bf16 d(hist)", dhist.to(torch.bfloat16), 2)):
-            bf = int(d.dtype == torch.bfloat16)
-            sites = [(d.data_ptr(), 0, 0, 0, keys[0].data_ptr(), perm[0].data_ptr(), ln.data_ptr(), gi.data_ptr(), 0, n + B, bf,
-                      1, T, D, 0, Di, 3, Di, 0, 1, dtarget.data_ptr(), 0, n, D, 0, wch(Vi, n + B), 0),
-                     (d.data_ptr(), 0, 0, 0, keys[1].data_ptr(), perm[1].data_ptr(), ln.data_ptr(), gc.data_ptr(), 0, n + B, bf,
-                      1, T, D, Di, Dc, 3, Dc, 0, 1, dtarget.data_ptr(), 0, n, D, Di, wch(Vc, n + B), 0)]
-            which_sites = os.environ.get("EMBED_SITES", "both")
-            sites = sites[:1] if which_sites == "item" else sites[1:] if which_sites == "cate" else sites
-            wsg = torch.zeros(ops.segsum_workspace_bytes(sites), dtype=torch.uint8, device=dev)
-            t = timeit(lambda: ops.segsum_multi(sites, wsg), iters=22)
+        keys, perm, iis, cis = [], [], [], []
+        for j in range(NS):
+            ii = torch.randint(1, Vi, (Hn, T), device=dev, dtype=torch.int32)
+            ci = torch.randint(1, Vc, (Hn, T), device=dev, dtype=torch.int32)
+            if taobao:
+                ii = (torch.rand(Hn, T, device=dev).pow(8.0) * (Vi - 2)).int() + 1
+                ci = (torch.rand(Hn, T, device=dev).pow(8.0) * (Vc - 2)).int() + 1
+            it, ct = torch.randint(1, Vi, (B,), device=dev, dtype=torch.int32), torch.randint(1, Vc, (B,), device=dev, dtype=torch.int32)
+            k_ = [torch.empty(n + B, dtype=torch.int32, device=dev) for _ in range(2)]
+            p_ = [torch.empty(n + B, dtype=torch.int32, device=dev) for _ in range(2)]
+            rows = [(ii.data_ptr(), k_[0].data_ptr(), p_[0].data_ptr(), Hn, T, T, 17 if taobao else 27, it.data_ptr(), B, 1),
+                    (ci.data_ptr(), k_[1].data_ptr(), p_[1].data_ptr(), Hn, T, T, 12 if taobao else 14, ct.data_ptr(), B, 1)]
+            wss = torch.empty(query("clsr_sort_ids_stable_workspace_bytes", 2 * (n + B), 2), dtype=torch.uint8, device=dev)
+            t = timeit(lambda: ops.sort_ids_stable_multi(rows, wss), iters=5 if j == 0 else 1, warm=1)
+            if j == 0:
+                print("stable radix sort of 2 x %d ids (27 / 14 bits): %8.1f us" % (n + B, t))
+            keys.append(k_); perm.append(p_); iis.append(ii); cis.append(ci)
+        ii, ci = iis[0], cis[0]
+        dh32 = [torch.randn(n, D, device=dev) * 1e-3 for _ in range(NS)]
+        dtarget = torch.randn(B, D, device=dev) * 1e-3
+        for tag, ds, sa in (("fp32 d(hist)", dh32, 4), ("bf16 d(hist)", [d.to(torch.bfloat16) for d in dh32], 2)):
+            jobs = []
+            for j in range(NS):
+                d = ds[j]
+                bf = int(d.dtype == torch.bfloat16)
+                sites = [(d.data_ptr(), 0, 0, 0, keys[j][0].data_ptr(), perm[j][0].data_ptr(), ln.data_ptr(), gi.data_ptr(), 0, n + B, bf,
+                          1, T, D, 0, Di, 3, Di, 0, 1, dtarget.data_ptr(), 0, n, D, 0, 0, 0),
+                         (d.data_ptr(), 0, 0, 0, keys[j][1].data_ptr(), perm[j][1].data_ptr(), ln.data_ptr(), gc.data_ptr(), 0, n + B, bf,
+                          1, T, D, Di, Dc, 3, Dc, 0, 1, dtarget.data_ptr(), 0, n, D, Di, 0, 0)]
+                which_sites = os.environ.get("EMBED_SITES", "both")
+                sites = sites[:1] if which_sites == "item" else sites[1:] if which_sites == "cate" else sites
+                jobs.append((sites, torch.zeros(ops.segsum_workspace_bytes(sites), dtype=torch.uint8, device=dev)))
+            turn = [0]
+
+            def seg():
+                sites, wsg = jobs[turn[0] % NS]
+                turn[0] += 1
+                ops.segsum_multi(sites, wsg)
+
+            t = timeit(seg, iters=24)
             nbytes = n * D * sa + n * D * 4 + 2 * n * 4 + B * D * 8 + 2 * B * 4
-            print("segmented sums (item + category, history + target slices, stored once), %s: %8.1f us  %.0f GB/s "
+            print("segmented sums (item + category, history + target slices, stored once, ONE launch), %s: %8.1f us  %.0f GB/s "
                   "algorithmic (%.1f%% of 8 TB/s)" % (tag, t, nbytes / t / 1e3, nbytes / t / 1e3 / 80))
+        keys = keys[0]
+        del dh32
         if taobao:
             return
         ids = torch.unique(keys[0].long()).int()

@@ -383,10 +383,14 @@ def _net(hp, dims, params32, O, precision, dedup=True):
 CONFIGS = [dict(), dict(sequential_model="gru", contrastive_loss="bpr"), dict(manual_alpha=True, manual_alpha_value=0.3)]
 
 
+@pytest.mark.parametrize("chain", ["x1", "old"])
 @pytest.mark.parametrize("dedup", [True, False])
 @pytest.mark.parametrize("cfg", range(len(CONFIGS)))
-def test_bf16_train_step_against_oracle_and_fp32_mode(golden_dir, golden_hparams, cfg, dedup, capsys):
-    """(1) north_star bars against the EXACT oracle: logits within 1e-3, loss terms within 1e-4 relative;
+def test_bf16_train_step_against_oracle_and_fp32_mode(golden_dir, golden_hparams, cfg, dedup, chain, capsys):
+    """chain = "x1": the speed mode on the parity mode's chain kernels with one bf16 piece (the default); "old": the
+    position-tiled kernels of rounds 2-4 (csrc/hgemm.hip, hdw.hip, hattbwd.hip: what shapes outside the chain kernels'
+    limits fall back to, CLSR_BF16_CHAIN=old) run AS A STEP here so that they cannot rot.
+    (1) north_star bars against the EXACT oracle: logits within 1e-3, loss terms within 1e-4 relative;
     (2) everything -- forward values, every gradient, the BN statistics -- against the oracle that rounds the
     attention activations to bf16 at the same places (oracle.BF16_ATTENTION): percent-level agreement per variable.
     The gap between the two oracles (what bf16 storage itself does to the gradients of this small batch) is printed."""
@@ -409,6 +413,7 @@ def test_bf16_train_step_against_oracle_and_fp32_mode(golden_dir, golden_hparams
     finally:
         O.BF16_ATTENTION = False
     net = _net(hp, dims, params32, O, "bf16", dedup)
+    net.bf16_chain = chain == "x1"
     net.capture_grads = True
     got = net.train_step(net.upload(feed, True))
     torch.cuda.synchronize()
