@@ -345,49 +345,53 @@ __device__ __forceinline__ void gru_bwd_body(const GruArgs& a, const int bx, f32
   if (a.dh0 && cval) st4(a.dh0 + h * n + col, dh);
 }
 
-// dynamic LDS: the largest exchange area (Time4LSTM backward) is 2 * 4 * RNT * 64 float4
-static size_t rnn_lds_bytes(int rnt) { return (size_t)2 * 4 * rnt * 64 * sizeof(f32x4); }
+// dynamic LDS: the largest exchange area (Time4LSTM backward) is 2 * 4 * RNT * 64 float4 (three-piece products: 2 buffers x 3
+// piece images x 2 RNT chunks x 64 lanes x 16 bytes)
+static size_t rnn_lds_bytes(int rnt, int pc = 2) { return (size_t)2 * (pc > 2 ? 6 : 4) * rnt * 64 * sizeof(f32x4); }
 static int rnn_tiles(int n) { return n <= 48 ? 3 : 8; }
 
 // launch K<3, X3> or K<8, X3> by the widest hidden size of the launch and the form of its hidden-to-hidden products
 #define RNN_LAUNCH1(K, RNT_, X3_, grid, stream, args)                                                    \
   do {                                                                                                   \
-    const size_t lds_ = rnn_lds_bytes(RNT_);                                                             \
+    const size_t lds_ = rnn_lds_bytes(RNT_, X3_);                                                        \
     if (lds_ > 48 * 1024)                                                                                \
       CLSR_HIP(hipFuncSetAttribute((const void*)K<RNT_, X3_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
     hipLaunchKernelGGL((K<RNT_, X3_>), grid, dim3(64 * RNT_), lds_, (hipStream_t)(stream), args);        \
   } while (0)
 #define RNN_LAUNCH(K, rnt, x3, grid, stream, args)                                                       \
   do {                                                                                                   \
-    if ((rnt) == 3) { if (x3) RNN_LAUNCH1(K, 3, true, grid, stream, args); else RNN_LAUNCH1(K, 3, false, grid, stream, args); } \
-    else { if (x3) RNN_LAUNCH1(K, 8, true, grid, stream, args); else RNN_LAUNCH1(K, 8, false, grid, stream, args); }            \
+    if ((rnt) == 3) {                                                                                    \
+      if ((x3) == 3) RNN_LAUNCH1(K, 3, 3, grid, stream, args);                                           \
+      else if ((x3) == 2) RNN_LAUNCH1(K, 3, 2, grid, stream, args);                                      \
+      else RNN_LAUNCH1(K, 3, 0, grid, stream, args);                                                     \
+    } else { /* (wide encoders: the three-piece form is not instantiated -- fp32-input MFMAs, the same accuracy) */ \
+      if ((x3) == 2) RNN_LAUNCH1(K, 8, 2, grid, stream, args); else RNN_LAUNCH1(K, 8, 0, grid, stream, args); \
+    }                                                                                                    \
   } while (0)
 
-// Form of the hidden-to-hidden products: 1 = fp32-input MFMA (bit-exact fp32), 2 = split-bf16 (see the *_x3 bodies).
-// Descriptors carry it (clsr_gru_desc.products / clsr_t4_desc.products); 0 = the process default: CLSR_RNN_PRODUCTS =
-// "fp32" | "x3", split-bf16 when unset.
-static bool rnn_default_x3() {
-  return true;
-}
-static bool rnn_x3(int products) { return products == 0 ? rnn_default_x3() : products == 2; }
+// Form of the products of a recurrence: 1 = fp32-input MFMA (bit-exact fp32), 2 = two bf16 pieces per operand (2^-16 per
+// product term), 3 = three pieces (2^-23: fp32 accuracy; hidden sizes <= 48) -- see the *_x3 bodies.  Descriptors carry it
+// (clsr_gru_desc.products / clsr_t4_desc.products; 0 = two pieces).  -> pieces per operand, 0 = fp32-input MFMAs
+static int rnn_x3(int products) { return products == 1 ? 0 : products == 3 ? 3 : 2; }
 
 // (the bodies are defined below the fp32 Time4LSTM ones)
-template <int RNT, bool ATT, bool FP> __device__ __forceinline__ void gru_fwd_x3(const GruArgs& a, const int bx, bf16x8* xb);
-template <int RNT, bool ATT> __device__ __forceinline__ void gru_bwd_x3(const GruArgs& a, const int bx, bf16x8* xb);
-template <int RNT, bool FP> __device__ __forceinline__ void t4lstm_fwd_x3(const T4Args& a, const int bx, bf16x8* xb);
-template <int RNT> __device__ __forceinline__ void t4lstm_bwd_x3(const T4Args& a, const int bx, bf16x8* xb);
+template <int RNT, bool ATT, bool FP, int PC> __device__ __forceinline__ void gru_fwd_x3(const GruArgs& a, const int bx, bf16x8* xb);
+template <int RNT, bool ATT, int PC> __device__ __forceinline__ void gru_bwd_x3(const GruArgs& a, const int bx, bf16x8* xb);
+template <int RNT, bool FP, int PC> __device__ __forceinline__ void t4lstm_fwd_x3(const T4Args& a, const int bx, bf16x8* xb);
+template <int RNT, int PC> __device__ __forceinline__ void t4lstm_bwd_x3(const T4Args& a, const int bx, bf16x8* xb);
+#define XPC (X3 ? X3 : 2)      // (a valid piece count for the branch that is compiled out)
 #define XB8(xb) reinterpret_cast<bf16x8*>(xb)
 
-template <int RNT, bool X3>
+template <int RNT, int X3>
 __global__ void __launch_bounds__(64 * RNT) gru_fwd_kernel(GruArgs a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
-  if (X3) gru_fwd_x3<RNT, false, false>(a, blockIdx.x, XB8(xb));
+  if (X3) gru_fwd_x3<RNT, false, false, XPC>(a, blockIdx.x, XB8(xb));
   else gru_fwd_body<RNT>(a, blockIdx.x, xb);
 }
-template <int RNT, bool X3>
+template <int RNT, int X3>
 __global__ void __launch_bounds__(64 * RNT) gru_bwd_kernel(GruArgs a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
-  if (X3) gru_bwd_x3<RNT, false>(a, blockIdx.x, XB8(xb));
+  if (X3) gru_bwd_x3<RNT, false, XPC>(a, blockIdx.x, XB8(xb));
   else gru_bwd_body<RNT>(a, blockIdx.x, xb);
 }
 
@@ -622,16 +626,16 @@ __device__ __forceinline__ void t4lstm_bwd_body(const T4Args& a, const int bx, f
   if (cval && a.dst_out) { st4(a.dst_out + h * 2 * n + col, dc); st4(a.dst_out + h * 2 * n + n + col, dm); }
 }
 
-template <int RNT, bool X3>
+template <int RNT, int X3>
 __global__ void __launch_bounds__(64 * RNT) t4lstm_fwd_kernel(T4Args a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
-  if (X3) t4lstm_fwd_x3<RNT, false>(a, blockIdx.x, XB8(xb));
+  if (X3) t4lstm_fwd_x3<RNT, false, XPC>(a, blockIdx.x, XB8(xb));
   else t4lstm_fwd_body<RNT>(a, blockIdx.x, xb);
 }
-template <int RNT, bool X3>
+template <int RNT, int X3>
 __global__ void __launch_bounds__(64 * RNT) t4lstm_bwd_kernel(T4Args a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
-  if (X3) t4lstm_bwd_x3<RNT>(a, blockIdx.x, XB8(xb));
+  if (X3) t4lstm_bwd_x3<RNT, XPC>(a, blockIdx.x, XB8(xb));
   else t4lstm_bwd_body<RNT>(a, blockIdx.x, xb);
 }
 
@@ -658,17 +662,55 @@ __global__ void __launch_bounds__(64 * RNT) t4lstm_bwd_kernel(T4Args a) {
 // 64-byte pieces): the training forward of the Time4LSTM alone took 128 us, 71 us without its stores (ablation,
 // scripts/abl_rnn.sh).  Only the forward and the backward recurrence read / write these tensors.
 #define T4_TILED_ROW(RNT) (7 * (RNT) * 16)
-template <int KC> struct XA { bf16x8 hi[KC], lo[KC]; };   // weights of this wave's 16 output rows, KC chunks of k
-template <int KC> struct XB { bf16x8 hi[KC], lo[KC]; };   // a full vector of the 16 histories
+// PC = bf16 pieces per operand: x = p[0] + p[1] (+ p[2]), p[i] = RNE_bf16(x - p[0] - .. - p[i-1]).  A product takes every
+// piece pair whose indices sum to < PC, smallest terms first: PC = 2 -> hi.lo + lo.hi + hi.hi (2^-16 relative per term),
+// PC = 3 -> six products, 2^-23 (the level of an fp32 product: precision="fp32")
+// SPL: the THIRD piece of a weight operand lives in a per-lane LDS slot instead of registers (a lane reads back what it
+// wrote: no barrier).  The fused-projection forward with three pieces holds seven weight blocks per wave: 326 registers with
+// all pieces resident -- one wave per SIMD, the launch no longer fits the chip at once; 256 with 51 of them in scratch.
+template <int KC, int PC, bool SPL = false> struct XA {
+  bf16x8 p[SPL ? 2 : PC][KC];   // weights of this wave's 16 output rows, KC chunks of k
+  bf16x8* sp;                   // SPL: this lane's third pieces, chunk c at sp[c * 64]
+  __device__ __forceinline__ bf16x8 piece(int i, int c) const {
+    if constexpr (SPL) { if (i == 2) return sp[c * 64]; }
+    return p[i < (SPL ? 2 : PC) ? i : 0][c];
+  }
+};
+template <int KC, int PC> struct XB { bf16x8 p[PC][KC]; };   // a full vector of the 16 histories
 
-__device__ __forceinline__ void split8(f32x8 v, bf16x8& hi, bf16x8& lo) {
-  hi = to_h(v);
-  lo = to_h(v - to_f(hi));
+template <int KC, int PC>
+__device__ __forceinline__ void xsplit8(f32x8 v, bf16x8 (&p)[PC][KC], int c) {
+#pragma unroll
+  for (int i = 0; i < PC; ++i) {
+    p[i][c] = to_h(v);
+    if (i + 1 < PC) v -= to_f(p[i][c]);
+  }
+}
+template <int KC, int PC, bool SPL>
+__device__ __forceinline__ void xsplit8a(f32x8 v, XA<KC, PC, SPL>& a, int c) {
+  if constexpr (SPL) {
+    a.p[0][c] = to_h(v);
+    v -= to_f(a.p[0][c]);
+    a.p[1][c] = to_h(v);
+    a.sp[c * 64] = to_h(v - to_f(a.p[1][c]));
+  } else {
+    xsplit8<KC, PC>(v, a.p, c);
+  }
+}
+// acc[n] += A[n] . B over chunk c for N accumulators side by side (independent MFMA chains, issued interleaved)
+template <int N, int KC, int PC, bool SPL>
+__device__ __forceinline__ void xmn(f32x4 (&acc)[N], const XA<KC, PC, SPL> (&a)[N], const XB<KC, PC>& b, int c) {
+#pragma unroll
+  for (int sidx = PC - 1; sidx >= 0; --sidx)
+#pragma unroll
+    for (int i = 0; i <= sidx; ++i)
+#pragma unroll
+      for (int nn = 0; nn < N; ++nn) HMFMA(acc[nn], a[nn].piece(i, c), b.p[sidx - i][c]);
 }
 
 // forward use: rows = outputs o = 16w + i of the block at colbase, k = input feature (W is [in][out]: strided reads, once)
-template <int KC>
-__device__ __forceinline__ void xa_load_fwd(XA<KC>& a, const float* W, int ld, int colbase, int n, int w, int lane) {
+template <int KC, int PC, bool SPL>
+__device__ __forceinline__ void xa_load_fwd(XA<KC, PC, SPL>& a, const float* W, int ld, int colbase, int n, int w, int lane) {
   const int i = lane & 15, g = lane >> 4, o = 16 * w + i;
 #pragma unroll
   for (int c = 0; c < KC; ++c) {
@@ -678,13 +720,13 @@ __device__ __forceinline__ void xa_load_fwd(XA<KC>& a, const float* W, int ld, i
       const int k = 32 * c + 8 * g + e;
       v[e] = (o < n && k < n) ? W[(long)k * ld + colbase + o] : 0.f;
     }
-    split8(v, a.hi[c], a.lo[c]);
+    xsplit8a<KC, PC, SPL>(v, a, c);
   }
 }
 // the same with an input width K != n (input-projection weights: k = embedding feature) and the bias of the block as row
 // k = K (the B operand carries a constant 1 there: the bias costs no register and no add)
-template <int KC>
-__device__ __forceinline__ void xa_load_fwd_k(XA<KC>& a, const float* W, int ld, int colbase, int n, int K, int w, int lane,
+template <int KC, int PC, bool SPL>
+__device__ __forceinline__ void xa_load_fwd_k(XA<KC, PC, SPL>& a, const float* W, int ld, int colbase, int n, int K, int w, int lane,
                                               const float* bias) {
   const int i = lane & 15, g = lane >> 4, o = 16 * w + i;
 #pragma unroll
@@ -695,12 +737,12 @@ __device__ __forceinline__ void xa_load_fwd_k(XA<KC>& a, const float* W, int ld,
       const int k = 32 * c + 8 * g + e;
       v[e] = (o < n && k < K) ? W[(long)k * ld + colbase + o] : (o < n && k == K) ? bias[o] : 0.f;
     }
-    split8(v, a.hi[c], a.lo[c]);
+    xsplit8a<KC, PC, SPL>(v, a, c);
   }
 }
 // backward use: rows = inputs in = 16w + i, k = the K consecutive columns of W's row from colbase on
-template <int KC>
-__device__ __forceinline__ void xa_load_bwd(XA<KC>& a, const float* W, int ld, int colbase, int K, int n, int w, int lane) {
+template <int KC, int PC, bool SPL>
+__device__ __forceinline__ void xa_load_bwd(XA<KC, PC, SPL>& a, const float* W, int ld, int colbase, int K, int n, int w, int lane) {
   const int i = lane & 15, g = lane >> 4, in = 16 * w + i;
 #pragma unroll
   for (int c = 0; c < KC; ++c) {
@@ -708,49 +750,58 @@ __device__ __forceinline__ void xa_load_bwd(XA<KC>& a, const float* W, int ld, i
     const float* p = W + (long)(in < n ? in : 0) * ld + colbase;
     const f32x4 lo4 = (in < n && k0 < K) ? ld4(p + k0) : Z4;
     const f32x4 hi4 = (in < n && k0 + 4 < K) ? ld4(p + k0 + 4) : Z4;
-    split8((f32x8){lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w}, a.hi[c], a.lo[c]);
+    xsplit8a<KC, PC, SPL>((f32x8){lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w}, a, c);
   }
 }
 
-// publish the 4 consecutive k = k0..k0+3 (k0 % 4 == 0) of history j
-template <int KC>
+// publish the 4 consecutive k = k0..k0+3 (k0 % 4 == 0) of history j: one 8-byte write per piece image
+template <int KC, int PC>
 __device__ __forceinline__ void xb_publish(bf16x8* buf, int k0, int j, bool ok, f32x4 v) {
-  const bf16x4 hi = __builtin_convertvector(v, bf16x4);
-  const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
   const int slot = ((((k0 >> 5) * 4 + ((k0 & 31) >> 3)) * 16 + j) << 1) + ((k0 & 7) >> 2);   // 8-byte units
   bf16x4* b4 = reinterpret_cast<bf16x4*>(buf);
-  if (ok) { b4[slot] = hi; b4[KC * 128 + slot] = lo; }
-}
-template <int KC>
-__device__ __forceinline__ void xb_collect(const bf16x8* buf, int lane, XB<KC>& v) {
 #pragma unroll
-  for (int c = 0; c < KC; ++c) { v.hi[c] = buf[c * 64 + lane]; v.lo[c] = buf[KC * 64 + c * 64 + lane]; }
+  for (int i = 0; i < PC; ++i) {
+    const bf16x4 h = __builtin_convertvector(v, bf16x4);
+    if (ok) b4[i * KC * 128 + slot] = h;
+    if (i + 1 < PC) v -= __builtin_convertvector(h, f32x4);
+  }
+}
+template <int KC, int PC>
+__device__ __forceinline__ void xb_collect(const bf16x8* buf, int lane, XB<KC, PC>& v) {
+#pragma unroll
+  for (int i = 0; i < PC; ++i)
+#pragma unroll
+    for (int c = 0; c < KC; ++c) v.p[i][c] = buf[i * KC * 64 + c * 64 + lane];
 }
 // acc += A . B over the first kcu chunks, two accumulators (two independent MFMA chains)
-template <int KC>
-__device__ __forceinline__ void xmac2(f32x4& acc0, f32x4& acc1, const XA<KC>& a, const XB<KC>& b, int kcu) {
+template <int KC, int PC, bool SPL>
+__device__ __forceinline__ void xmac2(f32x4& acc0, f32x4& acc1, const XA<KC, PC, SPL>& a, const XB<KC, PC>& b, int kcu) {
 #pragma unroll
   for (int c = 0; c < KC; ++c) {
     if (c < kcu) {     // (uniform; a `break` here keeps the loop rolled and the operand arrays in scratch)
       f32x4& acc = (c & 1) ? acc1 : acc0;
-      HMFMA(acc, a.hi[c], b.lo[c]);
-      HMFMA(acc, a.lo[c], b.hi[c]);
-      HMFMA(acc, a.hi[c], b.hi[c]);
+#pragma unroll
+      for (int sidx = PC - 1; sidx >= 0; --sidx)
+#pragma unroll
+        for (int i = 0; i <= sidx; ++i) HMFMA(acc, a.piece(i, c), b.p[sidx - i][c]);
     }
   }
 }
 // the same with the vector read from LDS chunk by chunk (wide backward products: the whole vector would take as many
 // registers as the weights)
-template <int KC>
-__device__ __forceinline__ void xmac2_lds(f32x4& acc0, f32x4& acc1, const XA<KC>& a, const bf16x8* buf, int lane, int kcu) {
+template <int KC, int PC>
+__device__ __forceinline__ void xmac2_lds(f32x4& acc0, f32x4& acc1, const XA<KC, PC>& a, const bf16x8* buf, int lane, int kcu) {
 #pragma unroll
   for (int c = 0; c < KC; ++c) {
     if (c < kcu) {
-      const bf16x8 bh = buf[c * 64 + lane], bl = buf[KC * 64 + c * 64 + lane];
+      bf16x8 bp[PC];
+#pragma unroll
+      for (int i = 0; i < PC; ++i) bp[i] = buf[i * KC * 64 + c * 64 + lane];
       f32x4& acc = (c & 1) ? acc1 : acc0;
-      HMFMA(acc, a.hi[c], bl);
-      HMFMA(acc, a.lo[c], bh);
-      HMFMA(acc, a.hi[c], bh);
+#pragma unroll
+      for (int sidx = PC - 1; sidx >= 0; --sidx)
+#pragma unroll
+        for (int i = 0; i <= sidx; ++i) HMFMA(acc, a.p[i][c], bp[sidx - i]);
     }
   }
 }
@@ -777,18 +828,18 @@ __device__ __forceinline__ void xload(f32x8 (&xr)[KC], const float* xrow, int D,
     xr[c] = ld8f(xrow + (k0 < D ? k0 : 0));     // (unconditional, clamped: masked in xsplit)
   }
 }
-template <int KC>
-__device__ __forceinline__ void xsplit(const f32x8 (&xr)[KC], int D, int g, XB<KC>& xb) {
+template <int KC, int PC>
+__device__ __forceinline__ void xsplit(const f32x8 (&xr)[KC], int D, int g, XB<KC, PC>& xb) {
 #pragma unroll
   for (int c = 0; c < KC; ++c) {
     const int k0 = 32 * c + 8 * g;
     f32x8 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     z[0] = k0 == D ? 1.0f : 0.f;               // the constant input that multiplies the bias row (xa_load_fwd_k)
-    split8(k0 < D ? xr[c] : z, xb.hi[c], xb.lo[c]);
+    xsplit8<KC, PC>(k0 < D ? xr[c] : z, xb.p, c);
   }
 }
 
-template <int RNT, bool ATT = false, bool FP = false>
+template <int RNT, bool ATT, bool FP, int PC>
 __device__ __forceinline__ void gru_fwd_x3(const GruArgs& a, const int bx, bf16x8* xb) {
   constexpr int KC = (RNT * 16 + 31) / 32;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
@@ -796,10 +847,13 @@ __device__ __forceinline__ void gru_fwd_x3(const GruArgs& a, const int bx, bf16x
   const int kcu = (n + 31) >> 5;
   const long h = (long)bx * 16 + j;
   const bool hvalid = h < a.Hn;
-  XA<KC> wr, wu, wc;
-  xa_load_fwd<KC>(wr, a.Wgh, a.ldg, 0, n, w, lane);
-  xa_load_fwd<KC>(wu, a.Wgh, a.ldg, n, n, w, lane);
-  xa_load_fwd<KC>(wc, a.Wch, a.ldc, 0, n, w, lane);
+  constexpr bool SPL = FP && PC == 3;
+  bf16x8* const spill = xb + 2 * PC * KC * 64 + (size_t)w * 7 * KC * 64 + lane;      // (SPL: per-lane third pieces, 7 blocks per wave)
+  XA<KC, PC, SPL> wg[2], wc;       // gates r | u, candidate
+  wg[0].sp = spill; wg[1].sp = spill + KC * 64; wc.sp = spill + 2 * KC * 64;
+  xa_load_fwd(wg[0], a.Wgh, a.ldg, 0, n, w, lane);
+  xa_load_fwd(wg[1], a.Wgh, a.ldg, n, n, w, lane);
+  xa_load_fwd(wc, a.Wch, a.ldc, 0, n, w, lane);
   const int col = 16 * w + 4 * g;
   const bool cval = hvalid && col < n;
   f32x4 hown = (cval && a.h0) ? ld4(a.h0 + h * a.h0_stride + col) : Z4;
@@ -811,49 +865,45 @@ __device__ __forceinline__ void gru_fwd_x3(const GruArgs& a, const int bx, bf16x
   const int t0 = a.t0, tend = min(Tmax, a.t1);
   // input side of a step: FP -- x . [Wgx | Wcx] + bias from the embeddings; else the projection tensor
   const int Dx = a.Dx, kcx = (Dx + 32) >> 5;     // (+ the bias row)
-  XA<KC> pr, pu, pc;
+  XA<KC, PC, SPL> px[3];           // input side: r | u | c
+  px[0].sp = spill + 3 * KC * 64; px[1].sp = spill + 4 * KC * 64; px[2].sp = spill + 5 * KC * 64;
   f32x8 xr[KC];
   const float* xrow = FP ? a.X + hin * (long)T * a.ldx : nullptr;
   f32x4 pn[3];
   if (FP) {
-    xa_load_fwd_k<KC>(pr, a.Wgx, a.ldg, 0, n, Dx, w, lane, a.bg);
-    xa_load_fwd_k<KC>(pu, a.Wgx, a.ldg, n, n, Dx, w, lane, a.bg + n);
-    xa_load_fwd_k<KC>(pc, a.Wcx, a.ldc, 0, n, Dx, w, lane, a.bc);
+    xa_load_fwd_k(px[0], a.Wgx, a.ldg, 0, n, Dx, w, lane, a.bg);
+    xa_load_fwd_k(px[1], a.Wgx, a.ldg, n, n, Dx, w, lane, a.bg + n);
+    xa_load_fwd_k(px[2], a.Wcx, a.ldc, 0, n, Dx, w, lane, a.bc);
     xload<KC>(xr, xrow + (long)t0 * a.ldx, Dx, g);
   } else {
 #pragma unroll
     for (int gb = 0; gb < 3; ++gb) pn[gb] = sel4(cval && t0 < len, ld4(pin + (long)t0 * a.ldp + gb * n), Z4);
   }
   auto project = [&](int tnext) {   // pn <- bias + x . W of the step whose embeddings sit in xr; then fetch step tnext
-    XB<KC> xv;
-    xsplit<KC>(xr, Dx, g, xv);
+    XB<KC, PC> xv;
+    xsplit<KC, PC>(xr, Dx, g, xv);
     const long tn = tnext < T ? tnext : T - 1;
     xload<KC>(xr, xrow + tn * a.ldx, Dx, g);
-    f32x4 q0 = Z4, q1 = Z4, q2 = Z4;
+    f32x4 q[3] = {Z4, Z4, Z4};
 #pragma unroll
-    for (int c = 0; c < KC; ++c) {
-      if (c < kcx) {
-        HMFMA(q0, pr.hi[c], xv.lo[c]); HMFMA(q1, pu.hi[c], xv.lo[c]); HMFMA(q2, pc.hi[c], xv.lo[c]);
-        HMFMA(q0, pr.lo[c], xv.hi[c]); HMFMA(q1, pu.lo[c], xv.hi[c]); HMFMA(q2, pc.lo[c], xv.hi[c]);
-        HMFMA(q0, pr.hi[c], xv.hi[c]); HMFMA(q1, pu.hi[c], xv.hi[c]); HMFMA(q2, pc.hi[c], xv.hi[c]);
-      }
-    }
-    pn[0] = q0; pn[1] = q1; pn[2] = q2;
+    for (int c = 0; c < KC; ++c)
+      if (c < kcx) xmn(q, px, xv, c);
+    pn[0] = q[0]; pn[1] = q[1]; pn[2] = q[2];
   };
   float an = ATT ? attp[t0] : 0.f;
   bf16x8* bufA = xb;                   // r . h
-  bf16x8* bufB = xb + 2 * KC * 64;     // h
-  xb_zero(xb, 4 * KC * 64);
-  XB<KC> hs, rh;
-  xb_publish<KC>(bufB, col, j, true, hown);
+  bf16x8* bufB = xb + PC * KC * 64;     // h
+  xb_zero(xb, 2 * PC * KC * 64);
+  XB<KC, PC> hs, rh;
+  xb_publish<KC, PC>(bufB, col, j, true, hown);
   if (FP) project(t0 + 1);
   __syncthreads();
-  xb_collect<KC>(bufB, lane, hs);
+  xb_collect<KC, PC>(bufB, lane, hs);
   const rnn_rsrc_t rhp = rnn_rsrc_blk(a.hprev, bx, T, n), rga = rnn_rsrc_blk(a.gates, bx, T, 3 * n);
   const rnn_rsrc_t ros = rnn_rsrc_blk(a.out_seq, bx, T, n);
   for (int t = t0; t < tend; ++t) {
     const bool live = t < len;
-    f32x4 accr = pn[0], accu = pn[1], accc = pn[2], accc1 = Z4;
+    f32x4 accg[2] = {pn[0], pn[1]}, accc = pn[2], accc1 = Z4;
     const float keep = 1.0f - an;
     if (!FP) {
       const bool nl = (t + 1) < len;
@@ -863,22 +913,17 @@ __device__ __forceinline__ void gru_fwd_x3(const GruArgs& a, const int bx, bf16x
     }
     if (ATT) an = attp[t + 1 < T ? t + 1 : t];
 #pragma unroll
-    for (int c = 0; c < KC; ++c) {
-      if (c < kcu) {
-        HMFMA(accr, wr.hi[c], hs.lo[c]); HMFMA(accu, wu.hi[c], hs.lo[c]);
-        HMFMA(accr, wr.lo[c], hs.hi[c]); HMFMA(accu, wu.lo[c], hs.hi[c]);
-        HMFMA(accr, wr.hi[c], hs.hi[c]); HMFMA(accu, wu.hi[c], hs.hi[c]);
-      }
-    }
+    for (int c = 0; c < KC; ++c)
+      if (c < kcu) xmn(accg, wg, hs, c);
     // (FP) the input-side products of step t + 1 right behind the recurrent ones: independent MFMAs for the matrix pipe while
     // the VALU works on the gates -- between publish and barrier they sat on the critical path of EVERY wave (335 against
     // 176 us in the step)
     if (FP) project(t + 2);
-    const f32x4 r = sig4(accr), u = sig4(accu);
-    xb_publish<KC>(bufA, col, j, true, r * hown);
+    const f32x4 r = sig4(accg[0]), u = sig4(accg[1]);
+    xb_publish<KC, PC>(bufA, col, j, true, r * hown);
     __syncthreads();
-    xb_collect<KC>(bufA, lane, rh);
-    xmac2<KC>(accc, accc1, wc, rh, kcu);
+    xb_collect<KC, PC>(bufA, lane, rh);
+    xmac2(accc, accc1, wc, rh, kcu);
     const f32x4 c = tanh4(accc + accc1);
     const f32x4 ue = u * keep;
     const f32x4 hn = ue * hown + (1.0f - ue) * c;
@@ -890,9 +935,9 @@ __device__ __forceinline__ void gru_fwd_x3(const GruArgs& a, const int bx, bf16x
       st4_b(ros, ok, pos * n + col, hn);
     }
     hown = sel4(live, hn, hown);
-    xb_publish<KC>(bufB, col, j, true, hown);
+    xb_publish<KC, PC>(bufB, col, j, true, hown);
     __syncthreads();
-    xb_collect<KC>(bufB, lane, hs);
+    xb_collect<KC, PC>(bufB, lane, hs);
   }
   if (cval) {
     if (a.hT) st4(a.hT + h * n + col, hown);
@@ -901,7 +946,7 @@ __device__ __forceinline__ void gru_fwd_x3(const GruArgs& a, const int bx, bf16x
   }
 }
 
-template <int RNT, bool ATT = false>
+template <int RNT, bool ATT, int PC>
 __device__ __forceinline__ void gru_bwd_x3(const GruArgs& a, const int bx, bf16x8* xb) {
   constexpr int KC = (RNT * 16 + 31) / 32;     // d c_pre: k = feature
   constexpr int KC2 = RNT;                     // [d r_pre | d u_pre]: k = gate * n + feature, 2n <= 32 RNT
@@ -910,10 +955,10 @@ __device__ __forceinline__ void gru_bwd_x3(const GruArgs& a, const int bx, bf16x
   const int kcu = (n + 31) >> 5, kcu2 = (2 * n + 31) >> 5;
   const long h = (long)bx * 16 + j;
   const bool hvalid = h < a.Hn;
-  XA<KC> wc;
-  XA<KC2> wg;
-  xa_load_bwd<KC>(wc, a.Wch, a.ldc, 0, n, n, w, lane);
-  xa_load_bwd<KC2>(wg, a.Wgh, a.ldg, 0, 2 * n, n, w, lane);
+  XA<KC, PC> wc;
+  XA<KC2, PC> wg;
+  xa_load_bwd(wc, a.Wch, a.ldc, 0, n, n, w, lane);
+  xa_load_bwd(wg, a.Wgh, a.ldg, 0, 2 * n, n, w, lane);
   const int col = 16 * w + 4 * g;
   const bool colv = col < n;
   const bool cval = hvalid && colv;
@@ -928,8 +973,8 @@ __device__ __forceinline__ void gru_bwd_x3(const GruArgs& a, const int bx, bf16x
       st_dpin(a.dPin, dp, Z4, a.dpin_bf16); st_dpin(a.dPin, dp + n, Z4, a.dpin_bf16); st_dpin(a.dPin, dp + 2 * n, Z4, a.dpin_bf16);
     }
   bf16x8* bufA = xb;
-  bf16x8* bufG = xb + 2 * KC * 64;
-  xb_zero(xb, 2 * KC * 64 + 2 * KC2 * 64);
+  bf16x8* bufG = xb + PC * KC * 64;
+  xb_zero(xb, PC * KC * 64 + PC * KC2 * 64);
   const long hc = hvalid ? h : 0;
   const int colc = cval ? col : 0;
   const float* gbase = a.gates + hc * T * 3 * n + colc;
@@ -971,19 +1016,19 @@ __device__ __forceinline__ void gru_bwd_x3(const GruArgs& a, const int bx, bf16x
       sa += __shfl_xor(sa, 32);
       if (g == 0 && live && hvalid) atomicAdd(a.datt + h * (long)T + t, sa);
     }
-    xb_publish<KC>(bufA, col, j, colv, dcp);
+    xb_publish<KC, PC>(bufA, col, j, colv, dcp);
     __syncthreads();
     f32x4 drh = Z4, drh1 = Z4;
-    xmac2_lds<KC>(drh, drh1, wc, bufA, lane, kcu);
+    xmac2_lds<KC, PC>(drh, drh1, wc, bufA, lane, kcu);
     drh += drh1;
     const f32x4 drp = drh * hp * r * (1.0f - r);
     const f32x4 dup = du * u * (1.0f - u);
     dhn += drh * r;
-    xb_publish<KC2>(bufG, col, j, colv, drp);
-    xb_publish<KC2>(bufG, n + col, j, colv, dup);
+    xb_publish<KC2, PC>(bufG, col, j, colv, drp);
+    xb_publish<KC2, PC>(bufG, n + col, j, colv, dup);
     __syncthreads();
     f32x4 dh1 = Z4;
-    xmac2_lds<KC2>(dhn, dh1, wg, bufG, lane, kcu2);
+    xmac2_lds<KC2, PC>(dhn, dh1, wg, bufG, lane, kcu2);
     dhn += dh1;
     {
       const unsigned dp = (unsigned)((j * T + t) * a.lddp + col);
@@ -998,18 +1043,20 @@ __device__ __forceinline__ void gru_bwd_x3(const GruArgs& a, const int bx, bf16x
 
 // FP: blocks i | j | f from x . kernel[0:D] + bias in the kernel; Pin then holds only o | tns | tls (3n wide: the product
 // that also needs the time features, net.py "xw.t")
-template <int RNT, bool FP = false>
+template <int RNT, bool FP, int PC>
 __device__ __forceinline__ void t4lstm_fwd_x3(const T4Args& a, const int bx, bf16x8* xb) {
   constexpr int KC = (RNT * 16 + 31) / 32;
-  constexpr int NP = FP ? 3 : 6;       // blocks read from Pin
+  constexpr int NP = FP ? 3 : 6;       // blocks read from Pin (PC: bf16 pieces per operand)
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   const int n = a.n, T = a.T;
   const int kcu = (n + 31) >> 5;
   const long h = (long)bx * 16 + j;
   const bool hvalid = h < a.Hn;
-  XA<KC> wm[4];
+  constexpr bool SPL = FP && PC == 3;
+  bf16x8* const spill = xb + 2 * PC * KC * 64 + (size_t)w * 7 * KC * 64 + lane;      // (SPL: per-lane third pieces, 7 blocks per wave)
+  XA<KC, PC, SPL> wm[4];
 #pragma unroll
-  for (int gb = 0; gb < 4; ++gb) xa_load_fwd<KC>(wm[gb], a.Wm, a.ldm, gb * n, n, w, lane);
+  for (int gb = 0; gb < 4; ++gb) { wm[gb].sp = spill + gb * KC * 64; xa_load_fwd(wm[gb], a.Wm, a.ldm, gb * n, n, w, lane); }
   const int col = 16 * w + 4 * g;
   const bool cval = hvalid && col < n;
   f32x4 cs = Z4, mown = Z4;
@@ -1022,39 +1069,37 @@ __device__ __forceinline__ void t4lstm_fwd_x3(const T4Args& a, const int bx, bf1
 #pragma unroll
   for (int gb = 0; gb < NP; ++gb) pn[gb] = sel4(cval && t0 < len, ld4(pin + (long)t0 * a.ldp + gb * n), Z4);
   const int Dx = a.Dx, kcx = (Dx + 32) >> 5;     // (+ the bias row)
-  XA<KC> px[FP ? 3 : 1];
+  XA<KC, PC, SPL> px[FP ? 3 : 1];
   f32x4 qn[3] = {Z4, Z4, Z4};
   f32x8 xr[KC];
   const float* xrow = FP ? a.X + (hvalid ? h : 0) * (long)T * a.ldx : nullptr;
   if (FP) {
 #pragma unroll
     for (int gb = 0; gb < 3; ++gb) {
-      xa_load_fwd_k<KC>(px[gb], a.Wkx, a.ldm, gb * n, n, Dx, w, lane, a.bk + gb * n);
+      px[gb].sp = spill + (4 + gb) * KC * 64;
+      xa_load_fwd_k(px[gb], a.Wkx, a.ldm, gb * n, n, Dx, w, lane, a.bk + gb * n);
     }
     xload<KC>(xr, xrow + (long)t0 * a.ldx, Dx, g);
   }
   auto project = [&](int tnext) {
-    XB<KC> xv;
-    xsplit<KC>(xr, Dx, g, xv);
+    XB<KC, PC> xv;
+    xsplit<KC, PC>(xr, Dx, g, xv);
     const long tn = tnext < T ? tnext : T - 1;
     xload<KC>(xr, xrow + tn * a.ldx, Dx, g);
-    f32x4 q0 = Z4, q1 = Z4, q2 = Z4;
+    if constexpr (FP) {
+      f32x4 q[3] = {Z4, Z4, Z4};
 #pragma unroll
-    for (int c = 0; c < KC; ++c) {
-      if (c < kcx) {
-        HMFMA(q0, px[0].hi[c], xv.lo[c]); HMFMA(q1, px[FP ? 1 : 0].hi[c], xv.lo[c]); HMFMA(q2, px[FP ? 2 : 0].hi[c], xv.lo[c]);
-        HMFMA(q0, px[0].lo[c], xv.hi[c]); HMFMA(q1, px[FP ? 1 : 0].lo[c], xv.hi[c]); HMFMA(q2, px[FP ? 2 : 0].lo[c], xv.hi[c]);
-        HMFMA(q0, px[0].hi[c], xv.hi[c]); HMFMA(q1, px[FP ? 1 : 0].hi[c], xv.hi[c]); HMFMA(q2, px[FP ? 2 : 0].hi[c], xv.hi[c]);
-      }
+      for (int c = 0; c < KC; ++c)
+        if (c < kcx) xmn(q, px, xv, c);
+      qn[0] = q[0]; qn[1] = q[1]; qn[2] = q[2];
     }
-    qn[0] = q0; qn[1] = q1; qn[2] = q2;
   };
-  xb_zero(xb, 4 * KC * 64);
-  XB<KC> ms;
-  xb_publish<KC>(xb + ((t0 + 1) & 1) * 2 * KC * 64, col, j, true, mown);
+  xb_zero(xb, 2 * PC * KC * 64);
+  XB<KC, PC> ms;
+  xb_publish<KC, PC>(xb + ((t0 + 1) & 1) * PC * KC * 64, col, j, true, mown);
   if (FP) project(t0 + 1);
   __syncthreads();
-  xb_collect<KC>(xb + ((t0 + 1) & 1) * 2 * KC * 64, lane, ms);
+  xb_collect<KC, PC>(xb + ((t0 + 1) & 1) * PC * KC * 64, lane, ms);
   const bool tiled = a.act_tiled != 0;
   const rnn_rsrc_t ros = rnn_rsrc_blk(a.out_seq, bx, T, n), rac = rnn_rsrc_blk(a.act, bx, T, tiled ? T4_TILED_ROW(RNT) : 6 * n);
   const rnn_rsrc_t rcs = rnn_rsrc_blk(a.act && !tiled ? a.cst : nullptr, bx, T, n), rmp = rnn_rsrc_blk(a.act ? a.mprev : nullptr, bx, T, n);
@@ -1074,16 +1119,8 @@ __device__ __forceinline__ void t4lstm_fwd_x3(const T4Args& a, const int bx, bf1
       for (int gb = 0; gb < NP; ++gb) pn[gb] = sel4(cval && nl, ld4(pin + tn * a.ldp + gb * n), Z4);
     }
 #pragma unroll
-    for (int c = 0; c < KC; ++c) {
-      if (c < kcu) {
-#pragma unroll
-        for (int gb = 0; gb < 4; ++gb) HMFMA(acc[gb], wm[gb].hi[c], ms.lo[c]);
-#pragma unroll
-        for (int gb = 0; gb < 4; ++gb) HMFMA(acc[gb], wm[gb].lo[c], ms.hi[c]);
-#pragma unroll
-        for (int gb = 0; gb < 4; ++gb) HMFMA(acc[gb], wm[gb].hi[c], ms.hi[c]);
-      }
-    }
+    for (int c = 0; c < KC; ++c)
+      if (c < kcu) xmn(acc, wm, ms, c);
     if (FP) project(t + 2);       // (behind the recurrent products, ahead of the gate arithmetic: see gru_fwd_x3)
     const f32x4 ig = sig4(acc[0]), jg = tanh4(acc[1]), fg = sig4(acc[2] + 1.0f);
     const f32x4 og = sig4(acc[3]), tn = sig4(tns), tlg = sig4(tls);
@@ -1107,10 +1144,10 @@ __device__ __forceinline__ void t4lstm_fwd_x3(const T4Args& a, const int bx, bf1
     }
     cs = sel4(live, cn, cs);
     mown = sel4(live, mn, mown);
-    bf16x8* buf = xb + (t & 1) * 2 * KC * 64;     // double buffered: one barrier per step
-    xb_publish<KC>(buf, col, j, true, mown);
+    bf16x8* buf = xb + (t & 1) * PC * KC * 64;     // double buffered: one barrier per step
+    xb_publish<KC, PC>(buf, col, j, true, mown);
     __syncthreads();
-    xb_collect<KC>(buf, lane, ms);
+    xb_collect<KC, PC>(buf, lane, ms);
   }
   if (cval) {
     for (int t = max(len, t0); t < a.t1; ++t) st4(a.out_seq + (h * T + t) * n + col, Z4);
@@ -1118,7 +1155,7 @@ __device__ __forceinline__ void t4lstm_fwd_x3(const T4Args& a, const int bx, bf1
   }
 }
 
-template <int RNT>
+template <int RNT, int PC>
 __device__ __forceinline__ void t4lstm_bwd_x3(const T4Args& a, const int bx, bf16x8* xb) {
   constexpr int KC4 = 2 * RNT;                 // k = gate * n + feature: 4n <= 64 RNT
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
@@ -1126,8 +1163,8 @@ __device__ __forceinline__ void t4lstm_bwd_x3(const T4Args& a, const int bx, bf1
   const int kcu = (4 * n + 31) >> 5;
   const long h = (long)bx * 16 + j;
   const bool hvalid = h < a.Hn;
-  XA<KC4> wm;
-  xa_load_bwd<KC4>(wm, a.Wm, a.ldm, 0, 4 * n, n, w, lane);
+  XA<KC4, PC> wm;
+  xa_load_bwd(wm, a.Wm, a.ldm, 0, 4 * n, n, w, lane);
   const int col = 16 * w + 4 * g;
   const bool colv = col < n;
   const bool cval = hvalid && colv;
@@ -1141,7 +1178,7 @@ __device__ __forceinline__ void t4lstm_bwd_x3(const T4Args& a, const int bx, bf1
 #pragma unroll
       for (int gb = 0; gb < 6; ++gb) st_dpin(a.dPin, dp + gb * n, Z4, a.dpin_bf16);
     }
-  xb_zero(xb, 4 * KC4 * 64);
+  xb_zero(xb, 2 * PC * KC4 * 64);
   const long hc = hvalid ? h : 0;
   const int colc = cval ? col : 0;
   const bool tiled = a.act_tiled != 0;
@@ -1197,12 +1234,12 @@ __device__ __forceinline__ void t4lstm_bwd_x3(const T4Args& a, const int bx, bf1
       st_dpin_b(rdp, ok, dp + 2 * n, dg[2], a.dpin_bf16); st_dpin_b(rdp, ok, dp + 3 * n, dg[3], a.dpin_bf16);
       st_dpin_b(rdp, ok, dp + 4 * n, dtn, a.dpin_bf16); st_dpin_b(rdp, ok, dp + 5 * n, dtl, a.dpin_bf16);
     }
-    bf16x8* buf = xb + (t & 1) * 2 * KC4 * 64;
+    bf16x8* buf = xb + (t & 1) * PC * KC4 * 64;
 #pragma unroll
-    for (int gb = 0; gb < 4; ++gb) xb_publish<KC4>(buf, gb * n + col, j, colv, dg[gb]);
+    for (int gb = 0; gb < 4; ++gb) xb_publish<KC4, PC>(buf, gb * n + col, j, colv, dg[gb]);
     __syncthreads();
     f32x4 dma = Z4, dmb = Z4;
-    xmac2_lds<KC4>(dma, dmb, wm, buf, lane, kcu);
+    xmac2_lds<KC4, PC>(dma, dmb, wm, buf, lane, kcu);
     const f32x4 dmn = dma + dmb;
     dc = sel4(live, dcn, dc);
     dm = sel4(live, dmn, dm);
@@ -1225,7 +1262,7 @@ __device__ __forceinline__ void t4lstm_bwd_x3(const T4Args& a, const int bx, bf1
 #else
 #define RNN_T4_PRIO() __builtin_amdgcn_s_setprio(3)
 #endif
-template <int RNT, bool X3>
+template <int RNT, int X3>
 __global__ void __launch_bounds__(64 * RNT) rnn_multi_fwd_kernel(RnnMultiArgs a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
   CLSR_CHAIN_PRIO();
@@ -1233,36 +1270,36 @@ __global__ void __launch_bounds__(64 * RNT) rnn_multi_fwd_kernel(RnnMultiArgs a)
   // be the one that waits for a free slot when the grid does not fit at once
   const int which = a.has_t4 ? (int)blockIdx.y - 1 : (int)blockIdx.y;
   if (X3) {
-    if (which >= 0) gru_fwd_x3<RNT, false, false>(a.gru[which], blockIdx.x, XB8(xb));
-    else t4lstm_fwd_x3<RNT, false>(a.t4, blockIdx.x, XB8(xb));
+    if (which >= 0) gru_fwd_x3<RNT, false, false, XPC>(a.gru[which], blockIdx.x, XB8(xb));
+    else t4lstm_fwd_x3<RNT, false, XPC>(a.t4, blockIdx.x, XB8(xb));
     return;
   }
   if (which >= 0) gru_fwd_body<RNT>(a.gru[which], blockIdx.x, xb);
   else t4lstm_fwd_body<RNT>(a.t4, blockIdx.x, xb);
 }
 // split-bf16 recurrences with the input projection fused (every encoder of the launch carries X)
-template <int RNT, bool X3>
-__global__ void __launch_bounds__(64 * RNT) rnn_multi_fwd_fp_kernel(RnnMultiArgs a) {
+template <int RNT, int X3>
+__global__ void __launch_bounds__(64 * RNT, 2) rnn_multi_fwd_fp_kernel(RnnMultiArgs a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
   CLSR_CHAIN_PRIO();
   const int which = a.has_t4 ? (int)blockIdx.y - 1 : (int)blockIdx.y;      // (the Time4LSTM first: see rnn_multi_fwd_kernel)
-  if (which >= 0) gru_fwd_x3<RNT, false, true>(a.gru[which], blockIdx.x, XB8(xb));
-  else t4lstm_fwd_x3<RNT, true>(a.t4, blockIdx.x, XB8(xb));
+  if (which >= 0) gru_fwd_x3<RNT, false, true, XPC>(a.gru[which], blockIdx.x, XB8(xb));
+  else t4lstm_fwd_x3<RNT, true, XPC>(a.t4, blockIdx.x, XB8(xb));
 }
 #ifdef RNNX_WPE3
 #define RNN_WPE __attribute__((amdgpu_waves_per_eu(RNT == 3 ? 3 : 2)))
 #else
 #define RNN_WPE
 #endif
-template <int RNT, bool X3>
+template <int RNT, int X3>
 __global__ void __launch_bounds__(64 * RNT) RNN_WPE rnn_multi_bwd_kernel(RnnMultiArgs a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
   CLSR_CHAIN_PRIO();
   const int which = a.has_t4 ? (int)blockIdx.y - 1 : (int)blockIdx.y;      // (the Time4LSTM first: see rnn_multi_fwd_kernel)
   if (X3) {
-    if (which >= 0) { gru_bwd_x3<RNT, false>(a.gru[which], blockIdx.x, XB8(xb)); return; }
+    if (which >= 0) { gru_bwd_x3<RNT, false, XPC>(a.gru[which], blockIdx.x, XB8(xb)); return; }
     RNN_T4_PRIO();
-    t4lstm_bwd_x3<RNT>(a.t4, blockIdx.x, XB8(xb));
+    t4lstm_bwd_x3<RNT, XPC>(a.t4, blockIdx.x, XB8(xb));
     return;
   }
   if (which >= 0) { gru_bwd_body<RNT>(a.gru[which], blockIdx.x, xb); return; }
@@ -1450,7 +1487,7 @@ static int fill_multi(RnnMultiArgs& m, const clsr_gru_desc* grus, int ngru, cons
     a.dhT = d.dhT; a.dout_seq = d.dout_seq; a.dPin = d.dPin; a.dh0 = d.dh0;
     a.lddp = d.lddp > 0 ? d.lddp : 3 * d.n;
     a.dpin_bf16 = d.dpin_bf16;
-    CLSR_CHECK_ARG(d.products >= 0 && d.products <= 2);
+    CLSR_CHECK_ARG(d.products >= 0 && d.products <= 3);
     if (d.products) m.products = d.products;
     CLSR_CHECK_SUPPORTED(a.lddp % 4 == 0);
     // the branch-free stores address a block's 16 histories with 32-bit BYTE offsets into one buffer resource
@@ -1490,16 +1527,16 @@ static int fill_multi(RnnMultiArgs& m, const clsr_gru_desc* grus, int ngru, cons
 }
 
 // the attentional GRU runs alone (its inputs depend on everything the other encoders produce): own kernels
-template <int RNT, bool X3>
+template <int RNT, int X3>
 __global__ void __launch_bounds__(64 * RNT) augru_fwd_kernel(GruArgs a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
-  if (X3) gru_fwd_x3<RNT, true, false>(a, blockIdx.x, XB8(xb));
+  if (X3) gru_fwd_x3<RNT, true, false, XPC>(a, blockIdx.x, XB8(xb));
   else gru_fwd_body<RNT, true>(a, blockIdx.x, xb);
 }
-template <int RNT, bool X3>
+template <int RNT, int X3>
 __global__ void __launch_bounds__(64 * RNT) augru_bwd_kernel(GruArgs a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 xb[];
-  if (X3) gru_bwd_x3<RNT, true>(a, blockIdx.x, XB8(xb));
+  if (X3) gru_bwd_x3<RNT, true, XPC>(a, blockIdx.x, XB8(xb));
   else gru_bwd_body<RNT, true>(a, blockIdx.x, xb);
 }
 
@@ -1528,11 +1565,18 @@ extern "C" int clsr_rnn_fwd_multi_range(const clsr_gru_desc* grus, int ngru, con
     if (nfp) {
       CLSR_CHECK_ARG(nfp == ngru + (t4 ? 1 : 0));
       CLSR_CHECK_SUPPORTED(rnn_x3(m.products) && multi_tiles(m) == 3);
-      RNN_LAUNCH1(rnn_multi_fwd_fp_kernel, 3, true, dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), stream, m);
+      if (rnn_x3(m.products) == 3) {      // (+ the per-lane third pieces of the seven weight blocks of each of the three waves)
+        const size_t lds_ = (size_t)2 * 3 * 2 * 64 * 16 + (size_t)3 * 7 * 2 * 64 * 16;
+        CLSR_HIP(hipFuncSetAttribute((const void*)rnn_multi_fwd_fp_kernel<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
+        hipLaunchKernelGGL((rnn_multi_fwd_fp_kernel<3, 3>), dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), dim3(192), lds_, (hipStream_t)stream, m);
+      }
+      else RNN_LAUNCH1(rnn_multi_fwd_fp_kernel, 3, 2, dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), stream, m);
       CLSR_CHECK_LAUNCH();
       return CLSR_OK;
     }
   }
+  // (the tile-major activation image is written by the split-product bodies only)
+  CLSR_CHECK_SUPPORTED(!(t4 && t4->act_tiled) || (rnn_x3(m.products) != 0 && !(rnn_x3(m.products) == 3 && multi_tiles(m) != 3)));
   RNN_LAUNCH(rnn_multi_fwd_kernel, multi_tiles(m), rnn_x3(m.products), dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), stream, m);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
@@ -1555,6 +1599,7 @@ extern "C" int clsr_rnn_bwd_multi_range(const clsr_gru_desc* grus, int ngru, con
     CLSR_CHECK_LAUNCH();
     return CLSR_OK;
   }
+  CLSR_CHECK_SUPPORTED(!(t4 && t4->act_tiled) || (rnn_x3(m.products) != 0 && !(rnn_x3(m.products) == 3 && multi_tiles(m) != 3)));
   RNN_LAUNCH(rnn_multi_bwd_kernel, multi_tiles(m), rnn_x3(m.products), dim3(clsr_cdiv(Hn, 16), ngru + (t4 ? 1 : 0)), stream, m);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;

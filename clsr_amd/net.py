@@ -199,10 +199,14 @@ class CLSRNet(object):
         # fp32); with x3 the input projections of the GRUs and of the Time4LSTM blocks i | j | f run INSIDE the recurrence
         # launch from the history embeddings (no projection tensor, no GEMM in front of the T-serial chain), and the
         # Time4LSTM keeps its saved activations in a private tile-major image.  CLSR_RNN_PRODUCTS=fp32 restores the exact form.
-        self.rnn_products = "fp32" if self.exact_products else os.environ.get("CLSR_RNN_PRODUCTS", "x3")
-        if self.rnn_products not in ("x3", "fp32"):
-            raise ValueError("CLSR_RNN_PRODUCTS must be 'x3' or 'fp32'")
-        self.rnn_fused_proj = self.rnn_products == "x3" and True
+        # precision="fp32": "x6" = the same kernels with THREE pieces per operand (fp32 accuracy; wide encoders fall back to the
+        # fp32-input MFMAs inside the launch), "fp32" = fp32-input MFMAs everywhere
+        self.rnn_products = os.environ.get("CLSR_RNN_PRODUCTS", "x6" if self.exact_products else "x3")
+        if self.rnn_products not in ("x6", "fp32") + (() if self.exact_products else ("x3",)):
+            raise ValueError("CLSR_RNN_PRODUCTS must be 'x6' or 'fp32' (precision='fp32'), also 'x3' otherwise")
+        if self.rnn_products == "x6" and max(self.H, self.Du) > 48:
+            self.rnn_products = "fp32"      # (wide encoders: no three-piece instance -- fp32-input MFMAs, same accuracy)
+        self.rnn_fused_proj = self.rnn_products in ("x3", "x6") and not os.environ.get("CLSR_NO_RNN_FUSED_PROJ")
         # the Time4LSTM's K-fused time-gate projection as split products too (csrc/projx3.hip): three pieces in "fp32", two
         # in the other modes (it feeds the same sigmoid gates as the recurrences' two-piece hidden products there)
         self.proj_x3 = True
@@ -213,7 +217,7 @@ class CLSRNet(object):
         self.gemm_wide_x3 = self.proj_x3_wide and True   # A/B: every plain wide product
         self.proj_bwd_pieces = 3 if self.exact_products else 2
         self.proj_wide_pieces = (2 if self.precision == "bf16" else 3)
-        self.rnn_act_tiled = self.rnn_products == "x3" and True
+        self.rnn_act_tiled = self.rnn_products in ("x3", "x6")
         # Attention-MLP backward (exact mode): "x3" = the two-pass layer-1 kernel and the one-pass layer-0 kernel as split-bf16
         # products with the weight gradients dW1 / db1 / dWp accumulated inside them (csrc/attbwdx3.hip: no separate
         # weight-gradient launches, no stored dz1); "fp32" = the fp32-MFMA kernels + clsr_pgemm_dw_partial beside them

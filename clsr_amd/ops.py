@@ -174,7 +174,7 @@ def graph_destroy(graph_exec):
 
 
 # hidden-to-hidden products of the recurrences (clsr_gru_desc.products): process default / fp32-input MFMA / split-bf16
-RNN_PRODUCTS = {None: 0, "default": 0, "fp32": 1, "x3": 2}
+RNN_PRODUCTS = {None: 0, "default": 0, "fp32": 1, "x3": 2, "x6": 3}
 
 
 class GruDesc(ctypes.Structure):

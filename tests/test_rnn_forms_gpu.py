@@ -66,40 +66,45 @@ def _run(Hn, T, n, products, tiled=False, fused=False, seed=5, scale_w=0.15, D=4
     return dict(hT=hT, gru_seq=gout, hprev=hprev, gates=gates, t4_seq=tout, mprev=mprev, dPin=dP, dh0=dh0)
 
 
+@pytest.mark.parametrize("form,tol", [("x3", 2e-4), ("x6", 3e-6)])
 @pytest.mark.parametrize("Hn,T,n", [(37, 10, 40), (16, 50, 40), (19, 8, 128), (5, 7, 24)])
-def test_split_bf16_products_follow_the_fp32_form(Hn, T, n):
+def test_split_bf16_products_follow_the_fp32_form(Hn, T, n, form, tol):
     """Same inputs, both forms: every output of the forward and the backward launch within 2e-4 of the tensor's scale
-    (16 significand bits per operand, the dropped lo.lo term 2^-18; errors compound over the T steps)."""
-    a, b = _run(Hn, T, n, "fp32"), _run(Hn, T, n, "x3")
+    (x3: 16 significand bits per operand, the dropped lo.lo term 2^-18; errors compound over the T steps) / 3e-6 (x6: three
+    pieces per operand, the level of fp32 rounding itself; hidden sizes above 48 take the fp32-input MFMAs in the launch)."""
+    a, b = _run(Hn, T, n, "fp32"), _run(Hn, T, n, form)
     for k in a:
         scale = float(a[k].abs().max())
         assert scale > 0, k
         err = float((a[k] - b[k]).abs().max())
-        assert err <= 2e-4 * max(scale, 1.0), "%s: max abs difference %.3e at scale %.3e" % (k, err, scale)
+        assert err <= tol * max(scale, 1.0), "%s: max abs difference %.3e at scale %.3e" % (k, err, scale)
         # not the same arithmetic: a silent fall back to the fp32 form would make them identical
-    assert not torch.equal(a["hT"], b["hT"])
+    if not (form == "x6" and n > 48):
+        assert not torch.equal(a["hT"], b["hT"])
 
 
-@pytest.mark.parametrize("Hn,T,n", [(37, 10, 40), (16, 50, 40), (19, 8, 128)])
-def test_tile_major_activation_image_changes_no_bit(Hn, T, n):
-    a, b = _run(Hn, T, n, "x3", tiled=False), _run(Hn, T, n, "x3", tiled=True)
+@pytest.mark.parametrize("Hn,T,n,form", [(37, 10, 40, "x3"), (16, 50, 40, "x3"), (19, 8, 128, "x3"), (16, 50, 40, "x6")])
+def test_tile_major_activation_image_changes_no_bit(Hn, T, n, form):
+    a, b = _run(Hn, T, n, form, tiled=False), _run(Hn, T, n, form, tiled=True)
     for k in a:
         assert torch.equal(a[k], b[k]), k
 
 
-def test_runs_are_bit_identical():
-    a, b = _run(33, 12, 40, "x3", tiled=True), _run(33, 12, 40, "x3", tiled=True)
+@pytest.mark.parametrize("form", ["x3", "x6"])
+def test_runs_are_bit_identical(form):
+    a, b = _run(33, 12, 40, form, tiled=True), _run(33, 12, 40, form, tiled=True)
     for k in a:
         assert torch.equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("form,tol", [("x3", 2e-4), ("x6", 3e-6)])
 @pytest.mark.parametrize("Hn,T,n,D", [(37, 10, 40, 40), (16, 50, 40, 40), (21, 9, 48, 24), (5, 3, 16, 56)])
-def test_fused_input_projection_follows_the_gemm_in_front(Hn, T, n, D):
+def test_fused_input_projection_follows_the_gemm_in_front(Hn, T, n, D, form, tol):
     """x_t . W_x + b inside the recurrence (split-bf16, bias as an extra row of the product) against the fp32 GEMM that
     used to write the projection tensor: same bar as the split-bf16 products themselves."""
     a = _run(Hn, T, n, "fp32", D=D)
-    b = _run(Hn, T, n, "x3", fused=True, tiled=True, D=D)
+    b = _run(Hn, T, n, form, fused=True, tiled=True, D=D)
     for k in a:
         scale = float(a[k].abs().max())
         err = float((a[k] - b[k]).abs().max())
-        assert err <= 2e-4 * max(scale, 1.0), "%s: max abs difference %.3e at scale %.3e" % (k, err, scale)
+        assert err <= tol * max(scale, 1.0), "%s: max abs difference %.3e at scale %.3e" % (k, err, scale)
