@@ -616,42 +616,48 @@ __device__ __forceinline__ void ebx_split4(const f32x4& v, unsigned long long& h
 // MFMAs of one stage, unrolled at compile time; dPin tiles OUTER (their operands: 8 registers at a time -- all of a wave's
 // tiles at once would be 64 on top of 220 accumulators and 100 registers of prefetched operands), the left-operand tiles
 // are re-read from LDS for every dPin tile that needs them (4 transpose reads per 3 MFMAs: far below the LDS rate)
-template <int W, int PI, int X>
-__device__ __forceinline__ void ebx_one(f32x4 (&acc)[eb_count(W)], const ebh_bf16x8& bvh, const ebh_bf16x8& bvl,
-                                        ebx_lds_t* xh, ebx_lds_t* xl) {
+// NPC = bf16 pieces per operand: 2 (hi.lo + lo.hi + hi.hi: "fp32x3") or 3 (every piece pair whose indices sum to <= 2: fp32
+// accuracy, precision="fp32"; the third image makes 3 x 54 272 = 162 816 bytes of LDS: the CU's 160 KB less one KB)
+template <int W, int PI, int X, int NPC>
+__device__ __forceinline__ void ebx_one(f32x4 (&acc)[eb_count(W)], const ebh_bf16x8 (&bv)[NPC], ebx_lds_t* xh) {
   if constexpr (eb_need(X, eb_tile(W, PI))) {
     constexpr int n = eb_acc(W, PI, X);
-    const ebh_bf16x8 avh = ebx_tr2(xh + 32 * X), avl = ebx_tr2(xl + 32 * X);
-    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(avl, bvh, acc[n], 0, 0, 0);
-    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(avh, bvl, acc[n], 0, 0, 0);
-    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(avh, bvh, acc[n], 0, 0, 0);
+    ebh_bf16x8 av[NPC];
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) av[i] = ebx_tr2(xh + i * EBX_IMG + 32 * X);
+#pragma unroll
+    for (int sidx = NPC - 1; sidx >= 0; --sidx)
+#pragma unroll
+      for (int i = sidx; i >= 0; --i) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv[sidx - i], acc[n], 0, 0, 0);
   }
 }
-template <int W, int PI, int... X>
-__device__ __forceinline__ void ebx_col(f32x4 (&acc)[eb_count(W)], const ebh_bf16x8& bvh, const ebh_bf16x8& bvl,
-                                        ebx_lds_t* xh, ebx_lds_t* xl, std::integer_sequence<int, X...>) {
-  (ebx_one<W, PI, X>(acc, bvh, bvl, xh, xl), ...);
+template <int W, int PI, int NPC, int... X>
+__device__ __forceinline__ void ebx_col(f32x4 (&acc)[eb_count(W)], const ebh_bf16x8 (&bv)[NPC], ebx_lds_t* xh,
+                                        std::integer_sequence<int, X...>) {
+  (ebx_one<W, PI, X, NPC>(acc, bv, xh), ...);
 }
-template <int W, int PI>
-__device__ __forceinline__ void ebx_p(f32x4 (&acc)[eb_count(W)], ebx_lds_t* th, ebx_lds_t* tl) {
+template <int W, int PI, int NPC>
+__device__ __forceinline__ void ebx_p(f32x4 (&acc)[eb_count(W)], ebx_lds_t* th) {
   // (an offset the compiler cannot see through: the left-operand reads of different dPin tiles must not be merged into
   //  one set of 23 x 8 live registers)
   int o = 0;
   asm volatile("" : "+v"(o));
-  const ebh_bf16x8 bvh = ebx_tr2(th + o + (EB_XW + 16 * eb_tile(W, PI)) * 2), bvl = ebx_tr2(tl + o + (EB_XW + 16 * eb_tile(W, PI)) * 2);
-  ebx_col<W, PI>(acc, bvh, bvl, th + o, tl + o, std::make_integer_sequence<int, EB_NXT>{});
+  ebh_bf16x8 bv[NPC];
+#pragma unroll
+  for (int i = 0; i < NPC; ++i) bv[i] = ebx_tr2(th + o + i * EBX_IMG + (EB_XW + 16 * eb_tile(W, PI)) * 2);
+  ebx_col<W, PI, NPC>(acc, bv, th + o, std::make_integer_sequence<int, EB_NXT>{});
 }
-template <int W, int... PI>
-__device__ __forceinline__ void ebx_all(f32x4 (&acc)[eb_count(W)], ebx_lds_t* th, ebx_lds_t* tl, std::integer_sequence<int, PI...>) {
-  (ebx_p<W, PI>(acc, th, tl), ...);
+template <int W, int NPC, int... PI>
+__device__ __forceinline__ void ebx_all(f32x4 (&acc)[eb_count(W)], ebx_lds_t* th, std::integer_sequence<int, PI...>) {
+  (ebx_p<W, PI, NPC>(acc, th), ...);
 }
 
-template <int W>
+template <int W, int NPC>
 __device__ __forceinline__ void ebx_body(const EncBwdXArgs& a, unsigned char* lds) {
   ebx_lds_t* const Lh = (ebx_lds_t*)lds;        // hi image, then the lo image (C-style cast: generic -> LDS address space)
   const int lane = threadIdx.x & 63, tid = W * 64 + lane;
   const int c16 = lane & 15, g = lane >> 4;
-  for (int e = tid; e < 2 * EBX_IMG / 16; e += 256) reinterpret_cast<f32x4*>(lds)[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int e = tid; e < NPC * EBX_IMG / 16; e += 256) reinterpret_cast<f32x4*>(lds)[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // ---- staging plan (stage invariant)
   //  dPin: thread = (position tid >> 3, pieces (tid & 7) + 8 q, q < 15): 8 lanes read 128 contiguous bytes of a row
   //  left operands (40- / 80-wide rows without gaps: a stage's 32 rows are ONE contiguous block, read linearly, piece
@@ -687,10 +693,22 @@ __device__ __forceinline__ void ebx_body(const EncBwdXArgs& a, unsigned char* ld
   };
   auto put = [&](int pos, int feat, const f32x4& v, bool ok) {
     unsigned long long hi, lo;
-    ebx_split4(ok ? v : z4, hi, lo);
+    const f32x4 vv = ok ? v : z4;
+    ebx_split4(vv, hi, lo);
     ebx_lds_t* d = Lh + pos * EBX_RB + feat * 2;
     *reinterpret_cast<__attribute__((address_space(3))) unsigned long long*>(d) = hi;
     *reinterpret_cast<__attribute__((address_space(3))) unsigned long long*>(d + EBX_IMG) = lo;
+    if constexpr (NPC > 2) {      // third piece: what the first two leave
+      f32x4 r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned hb = (unsigned)((hi >> (16 * e)) & 0xffffull) << 16, lb = (unsigned)((lo >> (16 * e)) & 0xffffull) << 16;
+        r[e] = (vv[e] - __builtin_bit_cast(float, hb)) - __builtin_bit_cast(float, lb);
+      }
+      unsigned long long r3, dummy;
+      ebx_split4(r, r3, dummy);
+      *reinterpret_cast<__attribute__((address_space(3))) unsigned long long*>(d + 2 * EBX_IMG) = r3;
+    }
   };
   auto stage = [&](long mbase) {
     const bool okP = mbase + posP < a.M;
@@ -715,7 +733,6 @@ __device__ __forceinline__ void ebx_body(const EncBwdXArgs& a, unsigned char* ld
   for (int n = 0; n < NA; ++n) acc[n] = z4;
   // this lane's transpose-read base: row 4 g + (c16 >> 2), 8-byte column piece c16 & 3
   ebx_lds_t* const th = Lh + (4 * g + (c16 >> 2)) * EBX_RB + (c16 & 3) * 8;
-  ebx_lds_t* const tl = th + EBX_IMG;
 
   long st = blockIdx.x;
   if (st < nst) fetch(st);
@@ -724,19 +741,20 @@ __device__ __forceinline__ void ebx_body(const EncBwdXArgs& a, unsigned char* ld
     stage(st * EBX_ST);
     __syncthreads();
     if (st + gridDim.x < nst) fetch(st + gridDim.x);      // next stage's operands fly behind the MFMAs below
-    ebx_all<W>(acc, th, tl, std::make_integer_sequence<int, NP>{});
+    ebx_all<W, NPC>(acc, th, std::make_integer_sequence<int, NP>{});
   }
   const float nob[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   eb_store<W, true>(a.ws, acc, nob, lane, blockIdx.x, gridDim.x);
 }
 
+template <int NPC>
 __global__ void __launch_bounds__(256) enc_bwd_fused_x3_kernel(EncBwdXArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsx[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (wave == 0) ebx_body<0>(a, ldsx);
-  else if (wave == 1) ebx_body<1>(a, ldsx);
-  else if (wave == 2) ebx_body<2>(a, ldsx);
-  else ebx_body<3>(a, ldsx);
+  if (wave == 0) ebx_body<0, NPC>(a, ldsx);
+  else if (wave == 1) ebx_body<1, NPC>(a, ldsx);
+  else if (wave == 2) ebx_body<2, NPC>(a, ldsx);
+  else ebx_body<3, NPC>(a, ldsx);
 }
 
 static int ebx_grid(long M) {
@@ -749,10 +767,10 @@ extern "C" long clsr_enc_bwd_fused_x3_workspace_floats(long M, int p) {
   return (long)clsr_cdiv(eb_N(p), 80) * ebx_grid(M) * EB_CHUNK;
 }
 // the seven weight gradients (+ bias sums) of clsr_enc_bwd_fused as split-bf16 products; d(hist) is NOT part of this launch
-extern "C" int clsr_enc_bwd_fused_x3(const float* dPin, const float* hist, const float* hprev1, const float* gates1,
-                                     const float* mprev, const float* TT, const float* hprev2, const float* gates2,
-                                     float* ws_hist, float* ws_hp1, float* ws_hp1r, float* ws_mprev, float* ws_tt,
-                                     float* ws_hp2, float* ws_hp2r, long M, void* stream) {
+static int enc_bwd_fused_xn(int pieces, const float* dPin, const float* hist, const float* hprev1, const float* gates1,
+                            const float* mprev, const float* TT, const float* hprev2, const float* gates2,
+                            float* ws_hist, float* ws_hp1, float* ws_hp1r, float* ws_mprev, float* ws_tt,
+                            float* ws_hp2, float* ws_hp2r, long M, void* stream) {
   CLSR_CHECK_ARG(dPin && hist && hprev1 && gates1 && mprev && TT && hprev2 && gates2 && M > 0);
   CLSR_CHECK_ARG(ws_hist && ws_hp1 && ws_hp1r && ws_mprev && ws_tt && ws_hp2 && ws_hp2r);
   CLSR_CHECK_SUPPORTED(((uintptr_t)dPin % 16) == 0 && ((uintptr_t)hist % 16) == 0 && ((uintptr_t)hprev1 % 16) == 0 &&
@@ -762,11 +780,32 @@ extern "C" int clsr_enc_bwd_fused_x3(const float* dPin, const float* hist, const
   a.dPin = dPin; a.hist = hist; a.hp1 = hprev1; a.g1 = gates1; a.mprev = mprev; a.TT = TT; a.hp2 = hprev2; a.g2 = gates2;
   a.M = M;
   a.ws[0] = ws_hist; a.ws[1] = ws_hp1; a.ws[2] = ws_hp1r; a.ws[3] = ws_mprev; a.ws[4] = ws_tt; a.ws[5] = ws_hp2; a.ws[6] = ws_hp2r;
-  const size_t shmem = (size_t)2 * EBX_IMG;
-  CLSR_HIP(hipFuncSetAttribute((const void*)enc_bwd_fused_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(enc_bwd_fused_x3_kernel, dim3(ebx_grid(M)), dim3(256), shmem, (hipStream_t)stream, a);
+  const size_t shmem = (size_t)pieces * EBX_IMG;
+  CLSR_CHECK_SUPPORTED(shmem <= 160 * 1024);
+  if (pieces == 3) {
+    CLSR_HIP(hipFuncSetAttribute((const void*)enc_bwd_fused_x3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(enc_bwd_fused_x3_kernel<3>, dim3(ebx_grid(M)), dim3(256), shmem, (hipStream_t)stream, a);
+  } else {
+    CLSR_HIP(hipFuncSetAttribute((const void*)enc_bwd_fused_x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(enc_bwd_fused_x3_kernel<2>, dim3(ebx_grid(M)), dim3(256), shmem, (hipStream_t)stream, a);
+  }
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
+}
+extern "C" int clsr_enc_bwd_fused_x3(const float* dPin, const float* hist, const float* hprev1, const float* gates1,
+                                     const float* mprev, const float* TT, const float* hprev2, const float* gates2,
+                                     float* ws_hist, float* ws_hp1, float* ws_hp1r, float* ws_mprev, float* ws_tt,
+                                     float* ws_hp2, float* ws_hp2r, long M, void* stream) {
+  return enc_bwd_fused_xn(2, dPin, hist, hprev1, gates1, mprev, TT, hprev2, gates2, ws_hist, ws_hp1, ws_hp1r, ws_mprev, ws_tt,
+                          ws_hp2, ws_hp2r, M, stream);
+}
+// ... with THREE bf16 pieces per operand (fp32 accuracy: precision="fp32"); parts / workspaces as clsr_enc_bwd_fused_x3
+extern "C" int clsr_enc_bwd_fused_x6(const float* dPin, const float* hist, const float* hprev1, const float* gates1,
+                                     const float* mprev, const float* TT, const float* hprev2, const float* gates2,
+                                     float* ws_hist, float* ws_hp1, float* ws_hp1r, float* ws_mprev, float* ws_tt,
+                                     float* ws_hp2, float* ws_hp2r, long M, void* stream) {
+  return enc_bwd_fused_xn(3, dPin, hist, hprev1, gates1, mprev, TT, hprev2, gates2, ws_hist, ws_hp1, ws_hp1r, ws_mprev, ws_tt,
+                          ws_hp2, ws_hp2r, M, stream);
 }
 
 static_assert(eb_count(0) + eb_count(1) + eb_count(2) + eb_count(3) == 211, "every wanted block has an owner");

@@ -117,6 +117,11 @@ class CLSRNet(object):
                                 # round 4 and was removed in round 5: the attention weight gradients are folded into the
                                 # backward kernels instead, csrc/attbwdx3.hip)
         self.x3_enc = x3d and True        # A/B: fused encoder tail (csrc/encbwd.hip)
+        # precision="fp32": CLSR_ENC_BWD=x6 runs the same kernel with three pieces per operand (weight gradients on the
+        # weight-gradient stream, beside d(hist) as a three-piece product and the time-feature chain).  Measured and NOT the
+        # default: its three 54 KB piece images fill the CU's LDS, the launch takes 394 us and starves what runs beside it
+        # (3.09 against 3.03 ms per step with the fp32-MFMA kernel that also computes d(hist), alone on the compute stream)
+        self.enc_x6 = self.exact_products and os.environ.get("CLSR_ENC_BWD", "fp32") == "x6"
         self.enc_back_x3 = x3d and True   # A/B: d(hist) and d TT from one pass over dPin (csrc/projx3.hip)
         self.att_l1_fwd_x6 = x6d and True   # A/B: second attention layer, forward, three pieces (csrc/attl1fwd.hip)
         # history-level attention backward in one launch (csrc/atthist.hip): two pieces in "fp32x3" / one-piece-compatible in
@@ -354,7 +359,7 @@ class CLSRNet(object):
                  "fused_l0_bwd", "fused_l0_wu", "l0_fwd_wave", "l0_bwd_halves", "dw_batching", "lt_bwd_early", "dpin_h", "flush_side",
                  "l1_bwd_2pass", "split_g2", "g2_stream", "rnn_products", "rnn_fused_proj", "rnn_act_tiled", "att_bwd", "att_bwd_l0", "_l1x", "_l0x", "att_hist_x3",
                  "att_hist_bwd_x3", "att_hist_bwd_pieces", "att_hist_pieces", "att_l1_fwd_x6", "att_fwd_x3", "att_fwd_x6",
-                 "att_l0_fwd_entry", "x3_enc", "enc_back_x3", "enc_bwd_fused", "enc_bwd_fused_h", "proj_x3", "proj_tt", "proj_x3_wide",
+                 "att_l0_fwd_entry", "x3_enc", "enc_x6", "enc_back_x3", "enc_bwd_fused", "enc_bwd_fused_h", "proj_x3", "proj_tt", "proj_x3_wide",
                  "gemm_wide_x3", "proj_gate_pieces", "proj_bwd_pieces", "proj_wide_pieces", "dhist_side", "early_scatter",
                  "fused_logit_tail", "fuse_tt", "heads_fused", "dense_upd_dw", "dw_wide", "dw_wide_entry", "rowlist_min_elems")
 
@@ -1880,7 +1885,7 @@ class CLSRNet(object):
         self._buf("t4.dTT", M, 2 * H)      # (workspaces of the branches exist before the fork: see _enc_bwd_fused)
         side = self.dw_stream and self.overlap
         with self._branch("@dw0" if side else "@main", after=self._fork_point(), name="@encw"):
-            call("clsr_enc_bwd_fused_x3", dPinAll, hist, self._buf("g1.hprev", Hn, T, H), self._buf("g1.gates", Hn, T, 3 * H),
+            call("clsr_enc_bwd_fused_x6" if self.enc_x6 else "clsr_enc_bwd_fused_x3", dPinAll, hist, self._buf("g1.hprev", Hn, T, H), self._buf("g1.gates", Hn, T, 3 * H),
                  self._buf("t4.mprev", Hn, T, H), self._buf("t4.TT", M, 2 * H), self._buf("g2.hprev", Hn, T, H),
                  self._buf("g2.gates", Hn, T, 3 * H), *wss, M)
         if side:
@@ -2402,7 +2407,7 @@ class CLSRNet(object):
             self._scatter_rows_early(f, dul, None, dtarget, Hn, B, hs, fork)
             self._scatter_rows_early(f, None, dushort, None, Hn, B, hs, self._fork_point())
         if self._enc_bwd_fused_ok(dpin_h):
-            (self._enc_bwd_fused_h if self.bf16 else self._enc_bwd_fused_x3 if self.x3_enc else
+            (self._enc_bwd_fused_h if self.bf16 else self._enc_bwd_fused_x3 if (self.x3_enc or self.enc_x6) else
              self._enc_bwd_fused)(f, hist, dPinAll, dhist, Hn, T, hs)
         else:
           # input-side weights of every encoder in one reduction; d(hist) in one product; the hidden-side / time-feature

@@ -297,6 +297,11 @@ int clsr_enc_bwd_fused_x3(const float* dPin, const float* hist, const float* hpr
                           const float* mprev, const float* TT, const float* hprev2, const float* gates2,
                           float* ws_hist, float* ws_hp1, float* ws_hp1r, float* ws_mprev, float* ws_tt,
                           float* ws_hp2, float* ws_hp2r, long M, void* stream);
+/* ... with three bf16 pieces per operand (2^-23 relative: the level of an fp32 product) */
+int clsr_enc_bwd_fused_x6(const float* dPin, const float* hist, const float* hprev1, const float* gates1,
+                          const float* mprev, const float* TT, const float* hprev2, const float* gates2,
+                          float* ws_hist, float* ws_hp1, float* ws_hp1r, float* ws_mprev, float* ws_tt,
+                          float* ws_hp2, float* ws_hp2r, long M, void* stream);
 int clsr_att_out_fwd_h(const void* z1, const float* scale1, const float* shift1,
                        const float* w_out, const float* b_out, const int* seq_len,
                        int len_stride, const float* keys, int Hn, int G, int T, int C1, int Dk,

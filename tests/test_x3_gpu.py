@@ -37,8 +37,9 @@ def _f(t):
 
 
 # ------------------------------------------------------------------------------- fused encoder tail (csrc/encbwd.hip)
+@pytest.mark.parametrize("entry,rt,at", [("clsr_enc_bwd_fused_x3", 2e-4, 2e-5), ("clsr_enc_bwd_fused_x6", 2e-6, 4e-6)])
 @pytest.mark.parametrize("M", [4800, 4117, 37, 32, 204800])
-def test_split_bf16_fused_encoder_backward(M):
+def test_split_bf16_fused_encoder_backward(M, entry, rt, at):
     """clsr_enc_bwd_fused_x3: the seven encoder-side weight gradients + bias sums from one pass over the fp32 dPin as
     split-bf16 products == float64 products of the UNROUNDED operands at the tolerance of the fp32-MFMA kernel
     (tests/test_kernels_gpu.py::test_fused_encoder_backward_one_pass_over_dpin), through the partial layout +
@@ -54,7 +55,7 @@ def test_split_bf16_fused_encoder_backward(M):
     wss = [torch.full((query("clsr_enc_bwd_fused_x3_workspace_floats", M, i),), 9.0, device=DEV) for i in range(7)]
     outs = [torch.zeros(K, N, device=DEV) for K, N in shapes]
     db = torch.zeros(480, device=DEV)
-    call("clsr_enc_bwd_fused_x3", dPin, hist, hp1, g1, mp, TT, hp2, g2, *wss, M)
+    call(entry, dPin, hist, hp1, g1, mp, TT, hp2, g2, *wss, M)      # (x6: three pieces per operand, fp32 accuracy)
     sig = tuple((ws.data_ptr(), o.data_ptr(), db.data_ptr() if i == 0 else 0, 1.0, parts, K, N, N, 0)
                 for i, (ws, o, (K, N)) in enumerate(zip(wss, outs, shapes)))
     tab = ops.dw_table(sig, torch.device(DEV))
@@ -64,7 +65,7 @@ def test_split_bf16_fused_encoder_backward(M):
     P = d(dPin)
     exp = [d(hist).T @ P, d(hp1).T @ P[:, 0:80], (d(hp1) * d(g1)[:, :n]).T @ P[:, 80:120], d(mp).T @ P[:, 240:400],
            d(TT).T @ P[:, 360:480], d(hp2).T @ P[:, 120:200], (d(hp2) * d(g2)[:, :n]).T @ P[:, 200:240]]
-    tol = 2e-5 * M ** 0.5
+    tol = at * M ** 0.5      # (x6: what is left is the fp32 ACCUMULATION over M positions, not the products)
     for i, (o, e) in enumerate(zip(outs, exp)):
-        _close(o, e, 2e-4, tol, "product %d" % i)
-    _close(db, P.sum(0), 2e-4, tol, "bias sums")
+        _close(o, e, rt, tol, "product %d" % i)
+    _close(db, P.sum(0), rt, tol, "bias sums")
