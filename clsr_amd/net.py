@@ -229,14 +229,7 @@ class CLSRNet(object):
         # precision="fp32": "x6" = the same kernels with THREE pieces per operand (fp32 accuracy; CLSR_ATT_BWD=fp32: the fp32-MFMA
         # kernels + separate weight-gradient launches)
         # ("x6l1": three pieces in the layer-1 kernel only, the layer-0 backward on fp32 MFMAs + its weight-gradient launch)
-        self.att_bwd = os.environ.get("CLSR_ATT_BWD", "x6l1" if self.exact_products else "x3")   # (x6l1: 3.19-3.22 ms, x6: 3.28-3.34 -- the three-piece layer-0 instance spills --, fp32: 3.32-3.34)
-        if self.att_bwd not in ("x6", "x6l1", "fp32") + (() if self.exact_products else ("x3",)):
-            raise ValueError("CLSR_ATT_BWD must be 'x6', 'x6l1' or 'fp32' (precision='fp32'), also 'x3' otherwise")
-        self.att_bwd_l0 = "fp32" if self.att_bwd == "x6l1" else self.att_bwd
-        if self.att_bwd == "x6l1":
-            self.att_bwd = "x6"
-        self._l1x = "clsr_att_l1_bwd_x6" if self.att_bwd == "x6" else "clsr_att_l1_bwd_x3"
-        self._l0x = "clsr_att_l0_bwd_x6" if self.att_bwd_l0 == "x6" else "clsr_att_l0_bwd_x3"
+        self.set_att_bwd(os.environ.get("CLSR_ATT_BWD", "x6l1" if self.exact_products else "x3"))   # (x6l1: 3.19-3.22 ms, x6: 3.28-3.34 -- the three-piece layer-0 instance spills --, fp32: 3.32-3.34)
         self.fuse_tt = True   # A/B: time-gate blocks of the input projection as one product over [hist | TT]
         # the row-level heads (alpha gate, alpha / logit MLPs, loss, their backward) as two persistent launches with grid
         # barriers for the batch-norm statistics (csrc/headsfused.hip) instead of a chain of 22 dependent launches
@@ -288,6 +281,17 @@ class CLSRNet(object):
         self.capture_grads = False
         self.captured = None
         self._aborted = None       # sticky reason of an aborted step (check_abort)
+
+    def set_att_bwd(self, mode):
+        """Form of the attention-MLP backward: 'x3' (two bf16 pieces, not with precision='fp32'), 'x6' (three pieces, both
+        layers), 'x6l1' (three pieces in the layer-1 kernel, fp32-input MFMAs + a weight-gradient launch for layer 0) or
+        'fp32' (fp32-input MFMAs + separate weight-gradient launches)."""
+        if mode not in ("x6", "x6l1", "fp32") + (() if self.exact_products else ("x3",)):
+            raise ValueError("CLSR_ATT_BWD must be 'x6', 'x6l1' or 'fp32' (precision='fp32'), also 'x3' otherwise")
+        self.att_bwd_l0 = "fp32" if mode == "x6l1" else mode
+        self.att_bwd = "x6" if mode == "x6l1" else mode
+        self._l1x = "clsr_att_l1_bwd_x6" if self.att_bwd == "x6" else "clsr_att_l1_bwd_x3"
+        self._l0x = "clsr_att_l0_bwd_x6" if self.att_bwd_l0 == "x6" else "clsr_att_l0_bwd_x3"
 
     # ------------------------------------------------------------------ configuration guard
     def _check_supported(self):
