@@ -716,6 +716,15 @@ def main():
                                       interactions_per_s=round(w5.P * 5 / d5, 1), steps=5))
                     log("catalogue100m: %.3f ms/step" % (d5 * 200.0))
                 w5.free()
+                if not args.no_extra and args.precision == "fp32":
+                    # the same workload with the two-piece split products (what round 5 called "fp32": comparable with its 8.46 ms)
+                    w5b = Workload("catalogue100m", "clsr", "fp32x3")
+                    d5b = w5b.run(5, 2)
+                    extra.append(dict(workload=w5b.describe() + ", precision fp32x3 (two-piece split-bf16 products)",
+                                      precision="fp32x3", ms_per_step=round(d5b * 200.0, 4),
+                                      interactions_per_s=round(w5b.P * 5 / d5b, 1), steps=5))
+                    log("catalogue100m fp32x3: %.3f ms/step" % (d5b * 200.0))
+                    w5b.free()
             except RuntimeError as e:   # not enough free HBM on this device
                 roof["hbm_resident_skipped"] = str(e)[:120]
 
