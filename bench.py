@@ -397,6 +397,12 @@ def embedding_rooflines(net, f, cfg, G, feed):
                         bytes_per_launch=nbytes, us_per_launch=round(t * 1e6, 2), id_sets_rotated=NSETS,
                         formula="n*W*%d (gradient read) + n*W*4 (fp32 row-gradient write) + 2*n*4 (+ the target rows' slices)"
                                 % sa, columns=W, sites_merged=bool(merged))
+        if tag == "gather_bwd":
+            out[tag].update(traffic=160.9e6, traffic_source="profiles/r06_item_embed_kernel_trace.md, counters in KiB (52 dispatches of ss_chunks_lean_kernel over "
+                                                            "three rotating lists, fp32 and bf16 d(hist) alternating: WRITE_SIZE 86.4 MB + 2 x FETCH_SIZE 39.2 MB; kernel "
+                                                            "time avg 51.5 us)")
+        elif tag == "gather_bwd_item_and_category_one_stream":
+            out[tag].update(traffic=203.2e6, traffic_source="profiles/r06_embed_kernel_trace.md (52 dispatches, kernel time avg 72.7 us)")
         clear_grads()
     del dh32, dh16
     # ---- bf16 tables + bf16 hist: bytes_gather_fwd(n) = n*D*(2 + 2) + 2*n*4
@@ -443,8 +449,8 @@ def embedding_rooflines(net, f, cfg, G, feed):
                                 frac=round(nbytes / t / 8e12, 4), bytes_per_launch=nbytes, us_per_launch=round(t * 1e6, 2),
                                 formula="touched_rows*Drow*(param, m, v read + write; gradient read + clear)*4",
                                 note="one launch touches 691 MB of rows: nothing of it survives in the 256 MiB Infinity Cache until the next",
-                                traffic=704.5e6, traffic_source="profiles/r05_embed_kernel_trace.md, counters in KiB (24 dispatches, 225 012 rows: "
-                                                                "WRITE_SIZE 344.4 MB + 2 x FETCH_SIZE 171.8 MB; algorithmic 691 MB)")
+                                traffic=704.5e6, traffic_source="profiles/r06_item_embed_kernel_trace.md, counters in KiB (24 dispatches, 224 995 rows: "
+                                                                "WRITE_SIZE 352.7 MB + 2 x FETCH_SIZE 175.9 MB; algorithmic 691 MB)")
         if it_h is not None:
             t = time_kernel(lambda: ops.call("clsr_table_adam_rows_h", it_h, tg["item"], m, v, fl, ids, count, cap, Di, ss, 1,
                                              1, 2.0, state0, 0.9, 0.999, 1e-8))
@@ -603,7 +609,7 @@ def main():
         roof = gather_roofline(net, f, cfg, G, feed, big)
         # PMC pass committed in profiles/r02_gather_hist_fwd_pmc_hbm_traffic.csv (same shape): WRITE_SIZE
         # 33.3 MB + 2 x FETCH_SIZE 12.5 MB (gfx950 wide-load correction); reads of the 8 MB tables hit cache
-        roof.update(traffic=213.7e6 if big else 59.7e6, traffic_source="counters in KiB; profiles/r04_gather_pmc_{WRITE,FETCH}_SIZE.csv (first 22 dispatches: this config; last 22: the catalogue)",
+        roof.update(traffic=213.5e6 if big else 59.75e6, traffic_source="counters in KiB; profiles/r06_gather_pmc_{WRITE,FETCH}_SIZE.csv (rotating id sets; first 23 dispatches: this config; last 23: the catalogue)",
                     note=("tables (%.1f MB) are L2/Infinity-Cache resident at this config; the HBM claim needs the "
                           "100M-item config" % ((cfg["Vi"] * cfg["Di"] + cfg["Vc"] * cfg["Dc"]) * 4 / 1e6))
                     if not big else "38 GB item table, uniform ids: every row read is an HBM read")
@@ -695,9 +701,9 @@ def main():
                 cache_resident = dict(roof)
                 roof = dict(big_roof, workload="BASELINE configs[4] catalogue: 100M items, rows 384 B + 128 B, uniform "
                                                "ids, 4096 histories x 50 steps (38 GB table: every row read is an HBM read)",
-                            traffic=213.7e6, traffic_source="counters in KiB; profiles/r05t_gather_pmc_WRITE_SIZE.csv + r05t_gather_pmc_FETCH_SIZE.csv (round 4 measured the same: r04_gather_pmc_*.csv), the 22 "
-                                                            "catalogue dispatches (WRITE_SIZE 106.5 MB + 2 x FETCH_SIZE 51.1 MB; round 2 "
-                                                            "measured the same: profiles/r02_gather_hist_fwd_pmc_hbm_traffic.csv)",
+                            traffic=213.5e6, traffic_source="counters in KiB; profiles/r06_gather_pmc_WRITE_SIZE.csv + r06_gather_pmc_FETCH_SIZE.csv, the 23 catalogue "
+                                                            "dispatches over three rotating id sets (WRITE_SIZE 109.05 MB + 2 x FETCH_SIZE 52.25 MB = 1.01 x the "
+                                                            "algorithmic bytes; kernel trace of the same command: profiles/r06_gather_hist_fwd_kernel_trace.md, avg 41.2 us)",
                             cache_resident_at_benchmarked_config=cache_resident)
                 if copy_peak:
                     roof["measured_copy_peak_GBps"] = copy_peak

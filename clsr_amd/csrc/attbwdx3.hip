@@ -55,6 +55,12 @@ __device__ __forceinline__ void split8x(f32x8 v, bf16x8& hi, bf16x8& lo) {
 }
 __device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
 
+// K = 16 form (four positions per lane): the three-piece layer-0 instance takes its weight-gradient products per iteration
+// instead of pairing two iterations into a K = 32 operand -- the saved pieces of the pair's first half cost 32 registers that
+// instance does not have (92 B of scratch, 404 us in the step)
+typedef short x3_s16x4 __attribute__((ext_vector_type(4)));
+#define HMFMA16(acc, a, b) (acc) = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(x3_s16x4, (a)), __builtin_bit_cast(x3_s16x4, (b)), (acc), 0, 0, 0)
+
 typedef __amdgpu_buffer_rsrc_t x3_rsrc_t;
 #define X3_OOB 0x80000000u
 // keeps the scheduler from hoisting every tile's LDS reads / epilogue arithmetic to the top of the iteration (with 512
@@ -262,7 +268,6 @@ __global__ void __launch_bounds__(256, (NP == 1 && X3_L0H_OCC2) ? 2 : X3_OCC) at
     int ctt = 0, cg = 0;
     f32x4 at[NF], dacc[NF], uacc[NZ];
     bf16x4 sah[NF], sal[NF], sbh[NZ], sbl[NZ];     // first half of a pair: (a*q) and dz0 in feature-lane layout, hi / lo
-    bf16x4 sar[NP > 2 ? NF : 1], sbr[NP > 2 ? NZ : 1];   // (third pieces)
     for (int i0 = 0; i0 < n_it; i0 += 2) {
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
@@ -400,13 +405,30 @@ __global__ void __launch_bounds__(256, (NP == 1 && X3_L0H_OCC2) ? 2 : X3_OCC) at
               for (int z = 0; z < NZ; ++z) x3_st1(rdu, ru_ + duo[z], uacc[z][e]);
             }
           }
+          if constexpr (NP > 2) {
+            if (X3A_DW) {       // weight gradient of THIS iteration: k = the 4 positions a lane holds of its feature
+#pragma unroll
+              for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int z = 0; z < NZ; ++z) {
+                  HMFMA16(accW[f][z], cah[f], cbr[z]);
+                  HMFMA16(accW[f][z], cal[f], cbl[z]);
+                  HMFMA16(accW[f][z], car[f], cbh[z]);
+                  HMFMA16(accW[f][z], cah[f], cbl[z]);
+                  HMFMA16(accW[f][z], cal[f], cbh[z]);
+                  HMFMA16(accW[f][z], cah[f], cbh[z]);
+                }
+            }
+          }
           if (++cg == G) { cg = 0; ++ctt; }
         }
-        if (d == 0) {
+        if constexpr (NP > 2) {
+          // (no pairing: see HMFMA16)
+        } else if (d == 0) {
 #pragma unroll
-          for (int f = 0; f < NF; ++f) { sah[f] = cah[f]; sal[f] = cal[f]; if constexpr (NP > 2) sar[f] = car[f]; }
+          for (int f = 0; f < NF; ++f) { sah[f] = cah[f]; sal[f] = cal[f]; }
 #pragma unroll
-          for (int z = 0; z < NZ; ++z) { sbh[z] = cbh[z]; sbl[z] = cbl[z]; if constexpr (NP > 2) sbr[z] = cbr[z]; }
+          for (int z = 0; z < NZ; ++z) { sbh[z] = cbh[z]; sbl[z] = cbl[z]; }
         } else if (X3A_DW) {
           // weight gradient of the pair: k = the 8 positions a lane holds of its feature (4 of each iteration)
           bf16x8 bh[NZ], bl[NZ];
@@ -415,15 +437,6 @@ __global__ void __launch_bounds__(256, (NP == 1 && X3_L0H_OCC2) ? 2 : X3_OCC) at
 #pragma unroll
           for (int f = 0; f < NF; ++f) {
             const bf16x8 ah = cat4(sah[f], cah[f]), al = cat4(sal[f], cal[f]);
-            if constexpr (NP > 2) {
-              const bf16x8 ar = cat4(sar[f], car[f]);
-#pragma unroll
-              for (int z = 0; z < NZ; ++z) {
-                HMFMA(accW[f][z], ah, cat4(sbr[z], cbr[z]));
-                HMFMA(accW[f][z], al, bl[z]);
-                HMFMA(accW[f][z], ar, bh[z]);
-              }
-            }
             if constexpr (NP > 1) {
 #pragma unroll
               for (int z = 0; z < NZ; ++z) HMFMA(accW[f][z], ah, bl[z]);
