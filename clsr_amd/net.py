@@ -229,7 +229,7 @@ class CLSRNet(object):
         # precision="fp32": "x6" = the same kernels with THREE pieces per operand (fp32 accuracy; CLSR_ATT_BWD=fp32: the fp32-MFMA
         # kernels + separate weight-gradient launches)
         # ("x6l1": three pieces in the layer-1 kernel only, the layer-0 backward on fp32 MFMAs + its weight-gradient launch)
-        self.set_att_bwd(os.environ.get("CLSR_ATT_BWD", "x6l1" if self.exact_products else "x3"))   # (x6l1: 3.19-3.22 ms, x6: 3.28-3.34 -- the three-piece layer-0 instance spills --, fp32: 3.32-3.34)
+        self.set_att_bwd(os.environ.get("CLSR_ATT_BWD", "x6l1" if self.exact_products else "x3"))   # (before the three-piece recurrences: x6l1 3.19-3.22 ms, fp32 3.32-3.34; x6 with the per-iteration K = 16 weight-gradient products is level with x6l1: 3.05-3.08 both)
         self.fuse_tt = True   # A/B: time-gate blocks of the input projection as one product over [hist | TT]
         # the row-level heads (alpha gate, alpha / logit MLPs, loss, their backward) as two persistent launches with grid
         # barriers for the batch-norm statistics (csrc/headsfused.hip) instead of a chain of 22 dependent launches
