@@ -679,6 +679,13 @@ def main():
                               interactions_per_s=round(w4.P * 10 / d4, 1), steps=10))
             log("kuaishou: %.3f ms/step" % (d4 * 100.0))
             w4.free()
+            if args.precision == "fp32":      # (the two-piece split products: comparable with round 5's 3.655 ms)
+                w4b = Workload("kuaishou", "clsr", "fp32x3")
+                d4b = w4b.run(10, 5)
+                extra.append(dict(workload=w4b.describe() + ", precision fp32x3 (two-piece split-bf16 products)", precision="fp32x3",
+                                  ms_per_step=round(d4b * 100.0, 4), interactions_per_s=round(w4b.P * 10 / d4b, 1), steps=10))
+                log("kuaishou fp32x3: %.3f ms/step" % (d4b * 100.0))
+                w4b.free()
             # ---- the same Taobao-shaped batch with realistic (log-normal) history lengths
             other_len = "lognormal" if args.lengths == "full" else "full"
             w6 = Workload(args.config, args.model, args.precision, dedup=not args.exact_clip, lengths=other_len)
