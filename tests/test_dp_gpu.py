@@ -119,6 +119,62 @@ def test_two_ranks_match_single_process(golden_dir, golden_hparams, sparse, over
             np.testing.assert_allclose(out["state"][k], v.numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
 
 
+@pytest.mark.parametrize("mode", ["allgather", "owner"])
+def test_two_ranks_catalogue_dims_through_the_sparse_exchange(mode):
+    """BASELINE configs[4] layer sizes (item 96 + category 32 = 128 = user = hidden, lazy Adam, row lists) with EVERY table
+    exchanged as touched rows (sparse_tables="all": the path the 100M-item catalogue takes), two ranks on one device with
+    host-staged collectives, against the single-process step on the global batch (VERDICT r5 #3)."""
+    import sys
+
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import build_hparams
+    from clsr_amd.net import CLSRNet
+    from clsr_amd.synthetic import synthetic_feed
+    from oracle import clsr_oracle as O
+
+    cfg = dict(Vu=300, Vi=5000, Vc=40, Di=96, Dc=32, Du=128, H=128, T=20, P=32)
+    hp = build_hparams(cfg, cfg["P"], optimizer="lazyadam")
+    dims = dict(Vu=cfg["Vu"], Vi=cfg["Vi"], Vc=cfg["Vc"])
+    feed = synthetic_feed(cfg["P"], cfg["T"], cfg["Vu"], cfg["Vi"], cfg["Vc"], lengths="lognormal", seed=7)
+    params = O.init_params(dims, hp, seed=5, scale_dense=4.0)
+    sd = dict(params)
+    sd.update(O.init_bn_state(params))
+    single = CLSRNet(hp, dims, device="cuda:0", seed=0)
+    single.rowlist_min_elems = 0          # (row lists as at the catalogue, whatever the table size)
+    single.load_state_dict(sd)
+    single.capture_grads = True
+    single.train_step(single.upload(feed, True))
+    torch.cuda.synchronize()
+    ref_state, ref_losses = single.state_dict(), single.read_losses()
+
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, hp, dims, feed, sd, "all", out, "staged", True, mode), nprocs=2, join=True)
+    assert len(out["sparse"]) == 4
+    for k in ("loss", "data_loss", "contrastive_loss", "regular_loss", "discrepancy_loss"):
+        assert abs(out["losses"][k] - ref_losses[k]) < 1e-5 * max(1.0, abs(ref_losses[k])), (k, out["losses"], ref_losses)
+    ref_g = {k: v.cpu().numpy() for k, v in single.captured["dense"].items()}
+    floor = 3e-6 * max(float(np.abs(v).max()) for v in ref_g.values())
+    for k, v in ref_g.items():
+        d = np.abs(out["grads"][k] - v)
+        assert float(d.max()) <= 2e-3 * float(np.abs(v).max()) + floor, (k, float(d.max()), float(np.abs(v).max()))
+    for k, v in single.captured["tables"].items():
+        v = v.cpu().numpy()
+        d = np.abs(out["tgrads"][k] - v)
+        assert float(d.max()) <= 2e-3 * float(np.abs(v).max()) + floor, (k, float(d.max()))
+    # the updated tables (lazy Adam on the exchanged rows) and the moving statistics equal the single-process ones
+    for k, v in ref_state.items():
+        if k.endswith("moving_mean") or k.endswith("moving_variance") or k.endswith("_embedding"):
+            np.testing.assert_allclose(out["state"][k], v.numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
+
+
 def _model_worker(rank, world, port, hp, paths, sd, out, transport="staged"):
     import random
 
