@@ -43,6 +43,9 @@ struct P2PBuf {
   double data[P2P_NCH][2][P2P_MAXW][P2P_MAXN];
   unsigned long long flag[P2P_NCH][2][P2P_MAXW];
   unsigned long long err;
+  // fused sync-BN kernels (bn_sync_kernel): this rank's folded sums of a layer and the count of its blocks that have arrived
+  double stage[P2P_NCH][P2P_MAXN];
+  unsigned arrived[P2P_NCH];
 };
 
 struct P2PComm {
@@ -98,6 +101,156 @@ __global__ void __launch_bounds__(256) allreduce_small_kernel(P2PArgs a) {
       s += __hip_atomic_load(&mine->data[a.ch][slot][r][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     a.x[tid] = gave_up ? __builtin_nan("") : s;     // never a partial sum that looks like statistics
   }
+}
+
+// ---- synchronised batch-norm statistics of ONE layer in ONE launch (VERDICT r4/r5 #3c): block c folds the per-block partial
+// sums of feature c (as bn_finalize_kernel / bn_bwd_coef_kernel do), the LAST block of the rank to arrive pushes the 2 C folded
+// doubles to every peer (the protocol of allreduce_small_kernel: slot = seq & 1, flags with system-scope release / acquire,
+// sum in rank order -- bit-identical on every rank) and finishes the layer for all C features.  Replaces clsr_sum_parts_d +
+// clsr_allreduce_small + clsr_bn_finalize / clsr_bn_bwd_coef_scaled: 32 launches of the data-parallel step's chain.
+struct BnSyncArgs {
+  P2PArgs p;                      // (x unused)
+  const double* partial; int nparts; int C; double count;
+  int mode;                       // 0: forward finalize, 1: backward coefficients
+  const float* gamma; const float* beta; float* moving_mean; float* moving_var; float momentum, eps;
+  float* scale; float* shift; float* mean_out; float* invstd_out;           // mode 0
+  const float* mean; const float* invstd; float* coef; float* dgamma; float* dbeta; double grad_scale;   // mode 1
+};
+
+__global__ void __launch_bounds__(256) bn_sync_kernel(BnSyncArgs a) {
+  __shared__ double red[2][4];
+  __shared__ int last_s, gave_up;
+  __shared__ double tot[P2P_MAXN];
+  const int tid = threadIdx.x, c = blockIdx.x, C = a.C, n = 2 * C;
+  P2PBuf* mine = a.p.bufs[a.p.rank];
+  const int ch = a.p.ch;
+  double s = 0.0, q = 0.0;
+  for (int p = tid; p < a.nparts; p += 256) {
+    s += a.partial[((long)p * 2 + 0) * C + c];
+    q += a.partial[((long)p * 2 + 1) * C + c];
+  }
+  s = block256_sum_d(s, red[0]);
+  q = block256_sum_d(q, red[1]);
+  if (tid == 0) {
+    __hip_atomic_store(&mine->stage[ch][c], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&mine->stage[ch][C + c], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned old = __hip_atomic_fetch_add(&mine->arrived[ch], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_s = old == (unsigned)C - 1u;
+    gave_up = 0;
+  }
+  __syncthreads();
+  if (!last_s) return;
+  if (tid == 0) __hip_atomic_store(&mine->arrived[ch], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (the next layer of this channel)
+  const int slot = (int)(a.p.seq & 1ull);
+  double v = 0.0;
+  if (tid < n) v = __hip_atomic_load(&mine->stage[ch][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (a.p.world > 1) {
+    if (tid < n)
+      for (int p = 0; p < a.p.world; ++p)
+        __hip_atomic_store(&a.p.bufs[p]->data[ch][slot][a.p.rank][tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (tid < a.p.world) {
+      __hip_atomic_store(&a.p.bufs[tid]->flag[ch][slot][a.p.rank], a.p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      const long long t0 = wall_clock64();
+      while (__hip_atomic_load(&mine->flag[ch][slot][tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.p.seq) {
+        if (wall_clock64() - t0 > a.p.timeout_ticks) {   // a peer never arrived
+          __hip_atomic_store(&mine->err, a.p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (a.p.abort_flag) __hip_atomic_store(a.p.abort_flag, (double)a.p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          gave_up = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid < n) {
+      double t = 0.0;
+      for (int r = 0; r < a.p.world; ++r)
+        t += __hip_atomic_load(&mine->data[ch][slot][r][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      v = gave_up ? __builtin_nan("") : t;      // never a partial sum that looks like statistics
+    }
+  }
+  if (tid < n) tot[tid] = v;
+  __syncthreads();
+  if (tid >= C) return;
+  const double s1 = tot[tid], s2 = tot[C + tid];
+  if (a.mode == 0) {
+    const double m = s1 / a.count;
+    double var_d = s2 / a.count - m * m;
+    if (var_d < 0.0) var_d = 0.0;
+    const float mean = (float)m, var = (float)var_d;
+    a.moving_mean[tid] = a.moving_mean[tid] * a.momentum + mean * (1.0f - a.momentum);
+    a.moving_var[tid] = a.moving_var[tid] * a.momentum + var * (1.0f - a.momentum);
+    const float invstd = 1.0f / sqrtf(var + a.eps);
+    const float sc = a.gamma[tid] * invstd;
+    a.scale[tid] = sc;
+    a.shift[tid] = a.beta[tid] - mean * sc;
+    if (a.mean_out) a.mean_out[tid] = mean;
+    if (a.invstd_out) a.invstd_out[tid] = invstd;
+  } else {
+    const float g = a.gamma[tid], is = a.invstd[tid], mu = a.mean[tid];
+    const float c1 = (float)(s1 / a.count), c2 = (float)(s2 / a.count);
+    const float a1 = g * is;
+    const float a2 = -g * is * is * c2;
+    a.coef[tid] = a1;
+    a.coef[C + tid] = a2;
+    a.coef[2 * C + tid] = -a1 * c1 - a2 * mu;
+    a.dgamma[tid] = (float)(s2 * a.grad_scale);
+    a.dbeta[tid] = (float)(s1 * a.grad_scale);
+  }
+}
+
+long long clsr_p2p_timeout_ticks(void);
+static int bn_sync_fill(void* comm, void* stream, P2PArgs& a) {
+  P2PComm* c = (P2PComm*)comm;
+  for (int r = 0; r < P2P_MAXW; ++r) a.bufs[r] = r < c->world ? c->bufs[r] : nullptr;
+  a.x = nullptr; a.n = 0; a.rank = c->rank; a.world = c->world;
+  int ch = 0;
+  while (ch < c->nch && c->stream_of[ch] != stream) ++ch;
+  if (ch == c->nch) {
+    CLSR_CHECK_SUPPORTED(c->nch < P2P_NCH);      // more streams than channels
+    c->stream_of[c->nch++] = stream;
+  }
+  a.ch = ch;
+  a.seq = ++c->seq[ch];
+  a.timeout_ticks = clsr_p2p_timeout_ticks();
+  a.abort_flag = c->abort_flag;
+  return CLSR_OK;
+}
+// clsr_bn_finalize (training) with the statistics summed over the ranks of ``comm`` inside the launch; ``count`` = rows of ALL ranks
+extern "C" int clsr_bn_finalize_sync(void* comm, const double* stats_partial, int nparts, int C, double count,
+                                     const float* gamma, const float* beta, float* moving_mean, float* moving_var,
+                                     float momentum, float eps, float* scale, float* shift, float* mean_out,
+                                     float* invstd_out, void* stream) {
+  CLSR_CHECK_ARG(comm && stats_partial && gamma && beta && moving_mean && moving_var && scale && shift && nparts > 0 && count > 0);
+  CLSR_CHECK_SUPPORTED(C > 0 && 2 * C <= P2P_MAXN);
+  BnSyncArgs a = {};
+  int rc = bn_sync_fill(comm, stream, a.p);
+  if (rc) return rc;
+  a.partial = stats_partial; a.nparts = nparts; a.C = C; a.count = count; a.mode = 0;
+  a.gamma = gamma; a.beta = beta; a.moving_mean = moving_mean; a.moving_var = moving_var; a.momentum = momentum; a.eps = eps;
+  a.scale = scale; a.shift = shift; a.mean_out = mean_out; a.invstd_out = invstd_out;
+  hipLaunchKernelGGL(bn_sync_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, a);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
+}
+// clsr_bn_bwd_coef_scaled (no accumulate) with the backward sums summed over the ranks inside the launch
+extern "C" int clsr_bn_bwd_coef_sync(void* comm, const double* partial, int nparts, int C, double count, const float* gamma,
+                                     const float* mean, const float* invstd, float* coef, float* dgamma, float* dbeta,
+                                     double grad_scale, void* stream) {
+  CLSR_CHECK_ARG(comm && partial && gamma && mean && invstd && coef && dgamma && dbeta && nparts > 0 && count > 0);
+  CLSR_CHECK_SUPPORTED(C > 0 && 2 * C <= P2P_MAXN);
+  BnSyncArgs a = {};
+  int rc = bn_sync_fill(comm, stream, a.p);
+  if (rc) return rc;
+  a.partial = partial; a.nparts = nparts; a.C = C; a.count = count; a.mode = 1;
+  a.gamma = gamma; a.mean = mean; a.invstd = invstd; a.coef = coef; a.dgamma = dgamma; a.dbeta = dbeta; a.grad_scale = grad_scale;
+  hipLaunchKernelGGL(bn_sync_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, a);
+  CLSR_CHECK_LAUNCH();
+  return CLSR_OK;
 }
 
 extern "C" long clsr_comm_buffer_bytes(void) { return (long)sizeof(P2PBuf); }

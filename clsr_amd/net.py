@@ -274,6 +274,7 @@ class CLSRNet(object):
         self.dp_world = 1          # data-parallel world size (loss normalisers are global)
         self.dp_stats_hook = None  # optional callable(tensor): sum BN partial statistics across ranks
         self.dp_comm = None        # optional communicator handle (clsr_amd/p2p.py): the same sum as ONE kernel on this stream
+        self.bn_sync_fused = True  # ... fused with the fold of the partial sums and the layer's finalisation (round 6; False: three launches)
         # data-parallel exchange hooks (clsr_amd/dp.py): called (and recorded into launch plans) at the points of the
         # step where a piece of the gradient state becomes final, so that its collective overlaps the rest of the
         # backward pass: flags_ready() | dense_ready() | table_ready(name)
@@ -358,7 +359,7 @@ class CLSRNet(object):
     #: every mode switch that changes the recorded launch sequence: ONE tuple, so that flipping any of them on a live net (A/B
     #: runs on the same feed, tests) records a new plan instead of silently replaying the old one
     _SWITCHES = ("precision", "table_bf16", "exact_products", "overlap", "defer_dw", "sorted_hist_grad", "det_grads", "lazy",
-                 "rnn_first", "tick_early", "hist_grad_two", "dw_batch_late", "bn_bwd_fused", "dw_stream", "dw_streams",
+                 "rnn_first", "tick_early", "bn_sync_fused", "hist_grad_two", "dw_batch_late", "bn_bwd_fused", "dw_stream", "dw_streams",
                  "split_query", "split_query_min", "bf16_split_query", "split_emb_grad", "bf16_chain", "bf16_dw", "bf16_bwd",
                  "fused_l0_bwd", "fused_l0_wu", "l0_fwd_wave", "l0_bwd_halves", "dw_batching", "lt_bwd_early", "dpin_h", "flush_side",
                  "l1_bwd_2pass", "split_g2", "g2_stream", "rnn_products", "rnn_fused_proj", "rnn_act_tiled", "att_bwd", "att_bwd_l0", "_l1x", "_l0x", "att_hist_x3",
@@ -902,6 +903,11 @@ class CLSRNet(object):
         return self._buf("stats" + self._ws_tag, 1024 * 2 * 256, dtype=torch.float64)[: parts * 2 * N], parts
 
     def _bn_fwd(self, bn, stats, parts, count, training):
+        if training and self.dp_stats_hook is not None and self.dp_comm is not None and 2 * bn.C <= 256 and self.bn_sync_fused:
+            # SyncBN in ONE launch: partial sums folded, exchanged with the peers and finalised inside the kernel (csrc/p2p.hip)
+            call("clsr_bn_finalize_sync", self.dp_comm, stats, parts, bn.C, float(count * self.dp_world), bn.gamma, bn.beta,
+                 bn.moving_mean, bn.moving_var, BN_MOMENTUM, BN_EPS, bn.scale, bn.shift, bn.mean, bn.invstd)
+            return
         if training and self.dp_stats_hook is not None:   # SyncBN: global batch statistics
             stats, parts = self._dp_sum_stats(stats, parts, bn.C)
             count = count * self.dp_world
@@ -930,6 +936,10 @@ class CLSRNet(object):
         call("clsr_bn_bwd_apply", dy, z, bn.coef, M, bn.C)
 
     def _bn_bwd_coef(self, bn, part, parts, M):
+        if self.dp_stats_hook is not None and self.dp_comm is not None and 2 * bn.C <= 256 and self.bn_sync_fused:
+            call("clsr_bn_bwd_coef_sync", self.dp_comm, part, parts, bn.C, float(M * self.dp_world), bn.gamma, bn.mean, bn.invstd,
+                 bn.coef, bn.dgamma, bn.dbeta, 1.0 / self.dp_world)
+            return
         count = M
         if self.dp_stats_hook is not None:
             part, parts = self._dp_sum_stats(part, parts, bn.C)

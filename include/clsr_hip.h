@@ -95,6 +95,15 @@ long clsr_comm_error(void* comm);    /* sequence number of the last all-reduce t
 int clsr_p2p_arm_timeout(int armed);
 long clsr_p2p_timeout_ms(void);
 int clsr_allreduce_small(void* comm, double* data, int n, void* stream);
+/* synchronised batch-norm statistics of one layer in ONE launch: the per-block partial sums are folded per feature, the last block
+ * of the rank exchanges the 2 C sums with the peers of ``comm`` (the all-reduce above, inside the launch) and finishes the layer --
+ * clsr_bn_finalize (training; count = rows of all ranks) / clsr_bn_bwd_coef_scaled (no accumulate).  2 C <= clsr_comm_max_doubles. */
+int clsr_bn_finalize_sync(void* comm, const double* stats_partial, int nparts, int C, double count, const float* gamma,
+                          const float* beta, float* moving_mean, float* moving_var, float momentum, float eps, float* scale,
+                          float* shift, float* mean_out, float* invstd_out, void* stream);
+int clsr_bn_bwd_coef_sync(void* comm, const double* partial, int nparts, int C, double count, const float* gamma,
+                          const float* mean, const float* invstd, float* coef, float* dgamma, float* dbeta, double grad_scale,
+                          void* stream);
 
 /* ---- deterministic embedding gradients (csrc/segsum.hip): STABLE radix sort (ascending ids, equal ids in position order;
  *      desc.bits = significant bits of the ids, desc.counts unused; 1 + 2 * ceil(bits / 8) launches for all tables) and
