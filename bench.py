@@ -708,9 +708,6 @@ def main():
                             in_step_us=38.1, in_step_source="profiles/r06_cat_timeline.txt (rocprofv3 trace of the catalogue step: the gather "
                                                             "dispatch at t = 14.5 us, behind ~9.7 ms of other traffic since the previous step's gather)",
                             cache_resident_at_benchmarked_config=cache_resident)
-                if copy_peak:
-                    roof["measured_copy_peak_GBps"] = copy_peak
-                    roof["frac_of_measured_copy_peak"] = round(roof["achieved"] / copy_peak, 4)
                 try:
                     w5.step()          # (sorted id lists / gradient buffers of the step exist)
                     torch.cuda.synchronize()
@@ -754,8 +751,10 @@ def main():
             src_, dst_ = torch.empty(nb_ // 4, device="cuda"), torch.empty(nb_ // 4, device="cuda")
             t_copy = time_kernel(lambda: _ops.call("clsr_copy_words", dst_, src_.data_ptr(), nb_), iters=10, warm=2)
             copy_peak = round(2.0 * nb_ / t_copy / 1e9, 1)
-            roof["measured_copy_peak_GBps"] = copy_peak
-            roof["frac_of_measured_copy_peak"] = round(roof["achieved"] / copy_peak, 4)
+            for r_ in (roof, roof.get("cache_resident_at_benchmarked_config")):
+                if r_ is not None:
+                    r_["measured_copy_peak_GBps"] = copy_peak
+                    r_["frac_of_measured_copy_peak"] = round(r_["achieved"] / copy_peak, 4)
             del src_, dst_
         except RuntimeError:
             pass

@@ -276,6 +276,7 @@ extern "C" int clsr_sort_ids_stable_multi(const clsr_sortids_desc* descs, int n,
 #define SS_LEAN_B 8                 // entries of a chunk in flight per thread group in the LEAN instantiation (8 or 16; SS_CHUNK % SS_LEAN_B == 0)
 #endif
 #define SS_E 8                      // a continuation of at most this many entries is walked by the chunk the run comes from
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 struct SsHdr { unsigned err; unsigned pad[3]; };
 struct SsSite {
   const void* src; const void* src2; int src_bf16; const float* dmean; const float* drecent;
@@ -352,7 +353,11 @@ __device__ __forceinline__ void ss_ldn(const int* __restrict__ a, const long q0,
 // are stored (assign): four registers per entry in flight instead of twenty -- the kernel is bound by the number of row
 // reads it keeps in flight (profiles/r04_embed_kernel_trace.md: traffic = the algorithmic bytes at 3 TB/s), and with 240
 // VGPRs only two waves per SIMD were resident.
-template <int VW, bool LEAN, int SB = 8>
+// bf16 source rows whose slices start on 16-byte boundaries (launch-uniform): the PAIR instantiation of the lean walk
+__device__ __forceinline__ bool ss_pair16(const SsSite& s) {
+  return s.src_bf16 && (s.D & 7) == 0 && (s.col0 & 7) == 0 && (reinterpret_cast<uintptr_t>(s.src) & 15) == 0;
+}
+template <int VW, bool LEAN, int SB = 8, bool PAIR = false>
 __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block, double* red, int* sh, float* shf, SsHdr* hdr) {
   typedef typename SsVec<VW>::type vec_t;
   // SB = 8: four batches cover the chunk, a short continuation (<= 8 entries) is one more batch -- on ~7 % of the chunks of the
@@ -360,7 +365,7 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
   // batches instead of four (42 us against the 36 us of a run-free walk).  SB = 9 (instantiable: the four batches have 36
   // slots, the last four hold a continuation of <= 4 entries, EVERY chunk is four dependent batches) measured 52.7 us: 140
   // VGPRs (three waves per SIMD), or 128 with 15 spilled, and unaligned key loads.
-  constexpr int NBATCH = SS_CHUNK / 8;
+  constexpr int NBATCH = SS_CHUNK / (SB >= 16 ? SB : 8);
   constexpr bool WIDE = SB * NBATCH > SS_CHUNK;
   constexpr int E = WIDE ? SB * NBATCH - SS_CHUNK : SS_E;
   static_assert(E <= SB && E <= SS_CHUNK, "a short continuation fits one batch");
@@ -403,6 +408,7 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
     int nruns = 0;
     vec_t acc = vec_t(0.f);
     float* bnd = s.bnd + chunk * 2 * Cp;
+    constexpr bool pair16 = PAIR;       // (an instantiation of its own, chosen by ss_pair16: the fp32 walk keeps its code)
     auto flush = [&](bool last) {
       // the run `cur` ends here (last: at the end of the chunk)
       const bool from_prev = nruns == 0 && cur == prev_key;
@@ -432,6 +438,22 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
       int ln[SB], tt[SB];
       const bool has_mr = !LEAN && (s.dmean || s.drecent);          // (launch-uniform, like src2 / src_bf16)
       const int cs = cok ? c : 0;
+      if constexpr (pair16) {
+        // LEAN, bf16 source: ONE 16-byte load per entry whatever its source -- an fp32 slice of the second list, or the 16
+        // bytes that hold this lane's four bf16 values and its pair lane's (the same lines as 8-byte loads; the half is
+        // picked in the combine loop below).  The branch sits OUTSIDE the loop over the entries: inside it (the form below)
+        // the compiler converts each bf16 load where it is issued, behind an s_waitcnt vmcnt(0) -- the eight row reads of a
+        // batch left one round trip at a time, 62 us for the item site of configs[4] where the fp32 form takes 43
+#pragma unroll
+        for (int k = 0; k < SB; ++k) {
+          const int pos = posk[k];
+          const bool second = s.n1 > 0 && pos >= s.n1;
+          sec[k] = second; tt[k] = 0; ln[k] = 0;
+          const char* p = second ? reinterpret_cast<const char*>(s.src_b + (long)(pos - s.n1) * s.ldb + s.colb + cs)
+                                 : reinterpret_cast<const char*>(s.src) + ((((long)pos * s.D + cc) * 2) & ~15L);
+          if constexpr (VW == 4) rv[k] = *reinterpret_cast<const f32x4*>(p);
+        }
+      } else
 #pragma unroll
       for (int k = 0; k < SB; ++k) {
         const int pos = posk[k];
@@ -462,6 +484,15 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
 #pragma unroll
       for (int k = 0; k < SB; ++k) {
         vec_t v = rv[k];
+        if constexpr (VW == 4 && LEAN) {
+          if constexpr (pair16) {        // (selects, no branch: the raw 16 bytes of a bf16 row -> this lane's four values)
+            const u32x4_t raw = __builtin_bit_cast(u32x4_t, v);
+            const unsigned lo = (lig & 1) ? raw.z : raw.x, hi = (lig & 1) ? raw.w : raw.y;
+            const f32x4 vb = {__builtin_bit_cast(float, lo << 16), __builtin_bit_cast(float, lo & 0xffff0000u),
+                              __builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+            v = sec[k] ? v : vb;
+          }
+        }
         if (!sec[k]) {
           if (!LEAN && s.src2) v += r2[k];
           const int len = ln[k];
@@ -716,7 +747,8 @@ __global__ void __launch_bounds__(256) ss_chunks_lean_kernel(SsArgs a) {
   int i = 0;
   while (i + 1 < a.n && (int)blockIdx.x >= a.s[i + 1].first_block) ++i;
   const SsSite& s = a.s[i];
-  if (s.vw == 4) ss_chunks<4, true, SS_LEAN_B>(s, blockIdx.x - s.first_block, red, sh, shf, a.hdr);
+  if (s.vw == 4 && ss_pair16(s)) ss_chunks<4, true, SS_LEAN_B, true>(s, blockIdx.x - s.first_block, red, sh, shf, a.hdr);
+  else if (s.vw == 4) ss_chunks<4, true, SS_LEAN_B>(s, blockIdx.x - s.first_block, red, sh, shf, a.hdr);
   else ss_chunks<1, true>(s, blockIdx.x - s.first_block, red, sh, shf, a.hdr);
 }
 

@@ -439,7 +439,8 @@ def test_overlapped_exchange_is_issued_after_the_joins_that_finish_its_data(gold
     # the four dense gradient tables travel as ONE collective, issued on the compute stream after the final join; the
     # dense gradients follow it (issue order = execution order inside a process group) on the weight-gradient stream
     tabs = by_ptr[net.tab_grad_flat.data_ptr()]
-    assert tabs[2] == net.tab_grad_flat.numel()
+    last = list(net.tab_grad)[-1]       # (one run from the first table to the end of the last: the 256-byte padding between tables travels too)
+    assert tabs[2] == net.tab_goff[last] + net.tab_grad[last].numel()
     if not planned:     # (the dense branch is independent of the tables: it is joined by the optimiser, not here)
         assert tabs[4] in ([], ["@dense"]), "table all-reduce issued before the final join"
     assert tabs[3] == main
