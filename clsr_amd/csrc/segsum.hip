@@ -422,6 +422,119 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
       }
       ++nruns;
     };
+    if constexpr (LEAN && !WIDE && VW == 4) {
+      // ---- LEAN walk, software-pipelined: the row reads of batch b + 1 are in flight while batch b is summed (keys two batches
+      //      ahead).  With the loads of a batch issued only after the previous batch had been consumed, a chunk was a chain of
+      //      4-5 dependent row-read round trips: with every row read a cache hit and no row stores the launch still took 27 us
+      //      of its 43 (scripts/bench_segsum.py, -DSS_ABL_NOLOAD / -DSS_ABL_NOSTORE builds).
+      const int cs = cok ? c : 0;
+      // keys / slice numbers of the walk ([p0, p0 + SS_CHUNK + E)) staged in LDS once, in the round trip of the border keys
+      // above: the batches read them from there (no key registers held across the row reads: 162 registers -> three waves per
+      // SIMD with them, and the launch no longer fitted the chip at once)
+      __shared__ int kp_all[32 * (2 * (SS_CHUNK + SS_E))];
+      int* lk = kp_all + gi * (2 * (SS_CHUNK + SS_E));
+      int* lp = lk + SS_CHUNK + SS_E;
+      for (int e = lig; e < SS_CHUNK + SS_E; e += CP) {
+        const long q = p0 + e;
+        lk[e] = q < lim ? s.keys[q] : -1;
+        lp[e] = q < lim ? s.perm[q] : 0;
+      }
+      // (a thread group lies inside ONE wave: its LDS writes are visible to its own later reads once they have completed)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      auto fetch = [&](const long q0, int (&kk)[SB], int (&pp)[SB]) {
+        if (q0 < pe_walk) {
+          const int o = (int)(q0 - p0);
+#pragma unroll
+          for (int k = 0; k < SB; ++k) { kk[k] = lk[o + k]; pp[k] = lp[o + k]; }
+          if (q0 == p0 && short_prev) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) if (kk[k] == kprev) kk[k] = -1;       // (a prefix: the list is sorted)
+          }
+          if (q0 >= pe) {                    // the continuation batch: the entries of the run that crosses the border only
+#pragma unroll
+            for (int k = 0; k < SB; ++k) if (kk[k] != knx) kk[k] = -1;
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < SB; ++k) { kk[k] = -1; pp[k] = 0; }
+        }
+      };
+      auto issue = [&](const int (&pp)[SB], vec_t (&rv)[SB], unsigned& secm) {
+        secm = 0u;
+#pragma unroll
+        for (int k = 0; k < SB; ++k) {
+          const int pos = pp[k];
+          const bool second = s.n1 > 0 && pos >= s.n1;          // (uniform inside the thread group)
+          secm |= second ? 1u << k : 0u;
+          if constexpr (PAIR) {
+            // bf16 source: ONE 16-byte load per entry whatever its source -- an fp32 slice of the second list, or the 16 bytes
+            // that hold this lane's four bf16 values and its pair lane's (the half is picked when the batch is summed)
+            const char* p = second ? reinterpret_cast<const char*>(s.src_b + (long)(pos - s.n1) * s.ldb + s.colb + cs)
+                                   : reinterpret_cast<const char*>(s.src) + ((((long)pos * s.D + cc) * 2) & ~15L);
+            rv[k] = *reinterpret_cast<const f32x4*>(p);
+          } else {
+            const float* p = second ? s.src_b + (long)(pos - s.n1) * s.ldb + s.colb + cs
+                                    : reinterpret_cast<const float*>(s.src) + (long)pos * s.D + cc;
+            rv[k] = *reinterpret_cast<const vec_t*>(p);
+          }
+        }
+      };
+      auto consume = [&](const long q0, const unsigned secm, const vec_t (&rv)[SB]) {
+        int key[SB], pu[SB];
+        fetch(q0, key, pu);
+        const int knext = q0 + SB < pe_walk ? lk[(int)(q0 + SB - p0)] : -1;      // (the continuation batch starts with the run's key)
+#pragma unroll
+        for (int k = 0; k < SB; ++k) {
+          if (key[k] < 0) continue;
+          vec_t v = rv[k];
+          const bool second = (secm >> k) & 1u;
+          if constexpr (PAIR) {
+            const u32x4_t raw = __builtin_bit_cast(u32x4_t, v);
+            const unsigned lo = (lig & 1) ? raw.z : raw.x, hi = (lig & 1) ? raw.w : raw.y;
+            const f32x4 vb = {__builtin_bit_cast(float, lo << 16), __builtin_bit_cast(float, lo & 0xffff0000u),
+                              __builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+            v = second ? v : vb;
+          }
+          if (!cok) v = vec_t(0.f);
+          if (second) local_b += ss_sq(v);
+          else local += ss_sq(v);
+          if (key[k] != cur) {
+            if (cur < 0) first_key = key[k];
+            cur = key[k];
+            acc = v;
+          } else {
+            acc += v;
+          }
+          int nk = key[k];
+          if (k < SB - 1) { if (key[k + 1] >= 0) nk = key[k + 1]; }
+          else if (q0 + SB < pe_walk && knext >= 0) nk = knext;
+          if (nk != key[k]) {
+            const bool from_prev = nruns == 0 && cur == prev_key;
+            if (from_prev) pfirst = acc;
+            if (cok) {
+              if (from_prev) ss_cst(bnd + c, acc);
+              else *reinterpret_cast<vec_t*>(s.grad + (long)cur * s.ldg + s.gcol0 + c) = acc;
+            }
+            ++nruns;
+          }
+        }
+      };
+      int ku[SB], pp[SB];
+      vec_t rA[SB], rB[SB];
+      unsigned sA = 0u, sB = 0u;
+      fetch(p0, ku, pp);
+      issue(pp, rA, sA);
+      fetch(p0 + SB, ku, pp);
+      issue(pp, rB, sB);
+      for (long q0 = p0; q0 < pe_walk; q0 += 2 * SB) {
+        consume(q0, sA, rA);
+        if (q0 + 2 * SB < pe_walk) { fetch(q0 + 2 * SB, ku, pp); issue(pp, rA, sA); }
+        if (q0 + SB < pe_walk) consume(q0 + SB, sB, rB);
+        if (q0 + 3 * SB < pe_walk) { fetch(q0 + 3 * SB, ku, pp); issue(pp, rB, sB); }
+      }
+    } else
     // keys / slice numbers of a batch of eight are fetched ONE BATCH AHEAD (two 16-byte loads each): the row reads of a
     // batch depend on them, and with both fetched in the batch itself every batch paid two memory round trips in a row
     for (long q0 = p0; q0 < pe_walk; q0 += SB) {
@@ -740,7 +853,7 @@ __global__ void __launch_bounds__(256) ss_chunks_kernel(SsArgs a) {
   else ss_chunks<1, false>(s, blockIdx.x - s.first_block, red, sh, shf, a.hdr);
 }
 // every site of the launch is LEAN (see ss_chunks): half the registers, twice the resident waves
-__global__ void __launch_bounds__(256) ss_chunks_lean_kernel(SsArgs a) {
+__global__ void __launch_bounds__(256, 4) ss_chunks_lean_kernel(SsArgs a) {
   __shared__ double red[4];
   __shared__ int sh[2 * 32 + 4];
   __shared__ float shf[256 * 4];
