@@ -359,8 +359,19 @@ def embedding_rooflines(net, f, cfg, G, feed):
     dh16 = [d.to(torch.bfloat16) for d in dh32]
     dtarget = torch.randn(B, D, device=dev) * 1e-3
 
-    def site_rows(d, L):
+    # the step's own call of the item site while the contrastive loss is on: the long-term branch's d(hist) as a second
+    # gradient tensor and the mean / recent-k shares of the history prologue ride in the walk (the full instantiation,
+    # ss_chunks_kernel: 20 registers per entry in flight instead of 4)
+    dh_lt = torch.randn(Hn * T, D, device=dev) * 1e-3
+    dmean, drecent = torch.randn(Hn, D, device=dev) * 1e-3, torch.randn(Hn, D, device=dev) * 1e-3
+
+    def site_rows(d, L, full=False):
         bf = int(d.dtype == torch.bfloat16)
+        if full:
+            tail_i = (1, dtarget.data_ptr(), 0, n, D, 0) if merged else (0,)
+            pad = lambda t: t + (0,) * (6 - len(t))
+            return [(d.data_ptr(), dh_lt.data_ptr(), dmean.data_ptr(), drecent.data_ptr(), L["ki"].data_ptr(), L["pi"].data_ptr(),
+                     f["seq_len"].data_ptr(), tg["item"].data_ptr(), 0, ne, bf, G, T, D, 0, Di, 3, Di, 0) + pad(tail_i) + (0, 0)]
         tail_i = (1, dtarget.data_ptr(), 0, n, D, 0) if merged else (0,)
         tail_c = (1, dtarget.data_ptr(), 0, n, D, Di) if merged else (0,)
         pad = lambda t: t + (0,) * (6 - len(t))
@@ -372,7 +383,7 @@ def embedding_rooflines(net, f, cfg, G, feed):
     def bwd(ds, only_item):
         jobs = []
         for d, L in zip(ds, lists):
-            rows = site_rows(d, L)[:1] if only_item else site_rows(d, L)
+            rows = site_rows(d, L, True) if only_item == "full" else site_rows(d, L)[:1] if only_item else site_rows(d, L)
             jobs.append((rows, torch.zeros(ops.segsum_workspace_bytes(rows), dtype=torch.uint8, device=dev)))
         turn = [0]
 
@@ -391,7 +402,8 @@ def embedding_rooflines(net, f, cfg, G, feed):
     # the HBM claim is about the ITEM table (38 GB, rows of Di * 4 bytes, uniform ids); the category table (1.3 MB) is cache
     # resident and its site runs beside the item site on another stream in the step -- timed here as a second entry
     for tag, ds, sa, only_item in (("gather_bwd", dh32, 4, True), ("gather_bwd_bf16_dhist", dh16, 2, True),
-                                   ("gather_bwd_item_and_category_one_stream", dh32, 4, False)):
+                                   ("gather_bwd_item_and_category_one_stream", dh32, 4, False),
+                                   ("gather_bwd_step_form", dh32, 4, "full")):
         if not det:
             out[tag] = dict(skipped="CLSR_NO_DET_GRADS: the counting-sort + atomics path is not measured here")
             continue
@@ -402,6 +414,8 @@ def embedding_rooflines(net, f, cfg, G, feed):
         nbytes = n_valid * W * sa + n_valid * W * 4 + 2 * n_valid * 4 + ((B * W * (4 + 4) + 2 * B * 4) if merged else 0)
         if not only_item:
             nbytes += 2 * n_valid * 4 + (2 * B * 4 if merged else 0)      # (the second site's index pairs)
+        if only_item == "full":
+            nbytes += n_valid * W * 4 + 2 * Hn * W * 4                    # (second gradient tensor + the mean / recent rows)
         out[tag] = dict(bound="hbm", kernel="ss_chunks_lean_kernel (csrc/segsum.hip: deterministic segmented sums in ONE launch, history "
                                             "+ target slices of a table in one sorted list, every row stored once)",
                         achieved=round(nbytes / t / 1e9, 1), peak=8000.0, unit="GB/s", frac=round(nbytes / t / 8e12, 4),
@@ -412,6 +426,10 @@ def embedding_rooflines(net, f, cfg, G, feed):
             out[tag].update(traffic=160.9e6, traffic_source="profiles/r06_item_embed_kernel_trace.md, counters in KiB (52 dispatches of ss_chunks_lean_kernel over "
                                                             "three rotating lists, fp32 and bf16 d(hist) alternating: WRITE_SIZE 86.4 MB + 2 x FETCH_SIZE 39.2 MB; kernel "
                                                             "time avg 51.5 us)")
+        elif tag == "gather_bwd_step_form":
+            out[tag].update(kernel="ss_chunks_kernel (the full instantiation: what the item site of a training step with the contrastive "
+                                   "loss runs -- a second gradient tensor and the mean / recent-k shares added in the walk)",
+                            formula="n*W*4 (d(hist)) + n*W*4 (long-term d(hist)) + n*W*4 (row-gradient write) + 2*n*4 + 2*Hn*W*4")
         elif tag == "gather_bwd_item_and_category_one_stream":
             out[tag].update(traffic=203.2e6, traffic_source="profiles/r06_embed_kernel_trace.md (52 dispatches, kernel time avg 72.7 us)")
         clear_grads()

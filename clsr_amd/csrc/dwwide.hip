@@ -34,8 +34,12 @@ struct DwwArgs {
 // gathers the eight positions 8g .. 8g + 7 of its feature from the LDS stage (the same 64 ds_read_b32 per wave and stage as
 // the fp32 form), splits them, and issues 48 bf16 MFMAs of ~16 cycles where the fp32 form issues 128 of 32: the fp32 kernel
 // ran the matrix pipe 70 % busy at 0.56 of its peak (profiles/r05_catalogue_pmc.md), this one is bound by its operand traffic.
-template <bool X3>
+// NP = 0: fp32-input MFMAs; NP = 2: the two-piece sums above (precision="fp32x3"); NP = 3: three pieces per operand, the six products
+// whose piece indices sum to <= 2, smallest first (2^-23 relative per term: fp32 accuracy, the form of precision="fp32" -- 96 bf16
+// MFMAs of 16 cycles per stage and wave where the fp32-input form issues 128 of 32)
+template <int NP>
 __global__ void __launch_bounds__(256, 2) dw_wide_kernel(DwwArgs a) {
+  constexpr bool X3 = NP > 0;
   extern __shared__ __attribute__((aligned(16))) float dww_lds[];
   float* Xs = dww_lds;                       // [2][32][DWW_ST]
   float* Ys = dww_lds + 2 * DWW_STAGE;
@@ -83,7 +87,8 @@ __global__ void __launch_bounds__(256, 2) dw_wide_kernel(DwwArgs a) {
     const float* xs = Xs + b * DWW_STAGE + wk + i;
     const float* ys = Ys + b * DWW_STAGE + wn + i;
     if (X3) {
-      bf16x8 ah[4], al[4], bh[4], bl[4];
+      constexpr int PC = NP > 0 ? NP : 1;
+      bf16x8 ap[PC][4], bp[PC][4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         f32x8 xv, yv8;
@@ -92,18 +97,23 @@ __global__ void __launch_bounds__(256, 2) dw_wide_kernel(DwwArgs a) {
           xv[e] = xs[(8 * g + e) * DWW_ST + 16 * t];
           yv8[e] = ys[(8 * g + e) * DWW_ST + 16 * t];
         }
-        ah[t] = to_h(xv); al[t] = to_h(xv - to_f(ah[t]));
-        bh[t] = to_h(yv8); bl[t] = to_h(yv8 - to_f(bh[t]));
         if (want_b) bs[t] += ((yv8[0] + yv8[1]) + (yv8[2] + yv8[3])) + ((yv8[4] + yv8[5]) + (yv8[6] + yv8[7]));
+#pragma unroll
+        for (int q = 0; q < PC; ++q) {
+          ap[q][t] = to_h(xv);
+          bp[q][t] = to_h(yv8);
+          if (q + 1 < PC) { xv -= to_f(ap[q][t]); yv8 -= to_f(bp[q][t]); }
+        }
       }
+      // every product of pieces whose indices sum to <= PC - 1, the smallest terms first
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) HMFMA(acc[kt][nt], ah[kt], bl[nt]);
+        for (int sum = PC - 1; sum >= 0; --sum)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) HMFMA(acc[kt][nt], al[kt], bh[nt]);
+          for (int qa = sum; qa >= 0; --qa)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) HMFMA(acc[kt][nt], ah[kt], bh[nt]);
+            for (int nt = 0; nt < 4; ++nt) HMFMA(acc[kt][nt], ap[qa][kt], bp[sum - qa][nt]);
       }
     } else
 #pragma unroll
@@ -243,7 +253,7 @@ extern "C" long clsr_pgemm_dw_wide_workspace_floats(long M, int K, int N) {
 // given) and dY [M, N] (row stride ldy): two
 // launches on ``stream`` (partial tiles, then their sum in range order).  accumulate != 0: added to dW / db.
 static int dw_wide_any(const float* X, int ldx, const float* Xmul, int ldmul, const float* dY, int ldy, long M, int K,
-                       int N, float* workspace, float* dW, int ldw, float* db, int accumulate, bool x3, void* stream) {
+                       int N, float* workspace, float* dW, int ldw, float* db, int accumulate, int pieces, void* stream) {
   CLSR_CHECK_ARG(X && dY && workspace && dW && ldx >= K && ldy >= N && ldw >= N);
   CLSR_CHECK_SUPPORTED(!Xmul || (ldmul >= K && ldmul % 4 == 0 && ((uintptr_t)Xmul % 16) == 0));
   CLSR_CHECK_SUPPORTED(clsr_pgemm_dw_wide_supported(M, K, N));
@@ -259,12 +269,15 @@ static int dw_wide_any(const float* X, int ldx, const float* Xmul, int ldmul, co
   a.bpart = db ? workspace + (long)dww_parts(M, K, N) * K * N : nullptr;
   const size_t shmem = (size_t)4 * DWW_STAGE * sizeof(float);
   const dim3 grid(a.S, clsr_cdiv(K, 128), clsr_cdiv(N, 128));
-  if (!x3) {
-    CLSR_HIP(hipFuncSetAttribute((const void*)dw_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(dw_wide_kernel<false>, grid, dim3(256), shmem, (hipStream_t)stream, a);
+  if (pieces == 0) {
+    CLSR_HIP(hipFuncSetAttribute((const void*)dw_wide_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(dw_wide_kernel<0>, grid, dim3(256), shmem, (hipStream_t)stream, a);
+  } else if (pieces == 2) {
+    CLSR_HIP(hipFuncSetAttribute((const void*)dw_wide_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(dw_wide_kernel<2>, grid, dim3(256), shmem, (hipStream_t)stream, a);
   } else {
-    CLSR_HIP(hipFuncSetAttribute((const void*)dw_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(dw_wide_kernel<true>, grid, dim3(256), shmem, (hipStream_t)stream, a);
+    CLSR_HIP(hipFuncSetAttribute((const void*)dw_wide_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(dw_wide_kernel<3>, grid, dim3(256), shmem, (hipStream_t)stream, a);
   }
   CLSR_CHECK_LAUNCH();
   hipLaunchKernelGGL(dw_wide_reduce_kernel, dim3(clsr_cdiv((long)K * N / 4, 16)), dim3(256), 0, (hipStream_t)stream,
@@ -275,10 +288,15 @@ static int dw_wide_any(const float* X, int ldx, const float* Xmul, int ldmul, co
 
 extern "C" int clsr_pgemm_dw_wide(const float* X, int ldx, const float* Xmul, int ldmul, const float* dY, int ldy, long M, int K,
                                   int N, float* workspace, float* dW, int ldw, float* db, int accumulate, void* stream) {
-  return dw_wide_any(X, ldx, Xmul, ldmul, dY, ldy, M, K, N, workspace, dW, ldw, db, accumulate, false, stream);
+  return dw_wide_any(X, ldx, Xmul, ldmul, dY, ldy, M, K, N, workspace, dW, ldw, db, accumulate, 0, stream);
 }
 // the same with the products as split-bf16 sums (2^-16 relative per term; bias sums stay exact fp32 sums)
 extern "C" int clsr_pgemm_dw_wide_x3(const float* X, int ldx, const float* Xmul, int ldmul, const float* dY, int ldy, long M, int K,
                                      int N, float* workspace, float* dW, int ldw, float* db, int accumulate, void* stream) {
-  return dw_wide_any(X, ldx, Xmul, ldmul, dY, ldy, M, K, N, workspace, dW, ldw, db, accumulate, true, stream);
+  return dw_wide_any(X, ldx, Xmul, ldmul, dY, ldy, M, K, N, workspace, dW, ldw, db, accumulate, 2, stream);
+}
+// ... as three-piece sums (2^-23 relative per term: fp32 accuracy)
+extern "C" int clsr_pgemm_dw_wide_x6(const float* X, int ldx, const float* Xmul, int ldmul, const float* dY, int ldy, long M, int K,
+                                     int N, float* workspace, float* dW, int ldw, float* db, int accumulate, void* stream) {
+  return dw_wide_any(X, ldx, Xmul, ldmul, dY, ldy, M, K, N, workspace, dW, ldw, db, accumulate, 3, stream);
 }

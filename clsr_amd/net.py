@@ -236,10 +236,10 @@ class CLSRNet(object):
         self.heads_fused = not os.environ.get("CLSR_NO_HEADS_FUSED")
         # weight gradients of wide layers (K, N >= 96: BASELINE configs[4]) by the 128 x 128-tile kernel (csrc/dwwide.hip)
         self.dw_wide = True
-        # ... as two-piece split-bf16 products like the other weight gradients outside "fp32" (CLSR_DW_WIDE_FP32=1 /
-        # precision="fp32": fp32-input MFMAs)
-        self.dw_wide_entry = ("clsr_pgemm_dw_wide" if self.exact_products
-                              else "clsr_pgemm_dw_wide_x3")
+        # ... as two-piece split-bf16 products like the other weight gradients outside "fp32"; precision="fp32": three pieces
+        # per operand (fp32 accuracy; CLSR_DW_WIDE=fp32: fp32-input MFMAs)
+        self.dw_wide_entry = (("clsr_pgemm_dw_wide" if os.environ.get("CLSR_DW_WIDE", "x6") == "fp32" else "clsr_pgemm_dw_wide_x6")
+                              if self.exact_products else "clsr_pgemm_dw_wide_x3")
         self._dw_batch_wide = None
         self._heads_defer = False
         self._early_lists = None

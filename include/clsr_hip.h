@@ -151,6 +151,9 @@ int clsr_pgemm_dw_wide(const float* X, int ldx, const float* Xmul, int ldmul, co
  * the fp32 form runs the matrix pipe 70 % busy at 0.56 of its peak, profiles/r05_catalogue_pmc.md) */
 int clsr_pgemm_dw_wide_x3(const float* X, int ldx, const float* Xmul, int ldmul, const float* dY, int ldy, long M, int K,
                           int N, float* workspace, float* dW, int ldw, float* db, int accumulate, void* stream);
+/* ... as three-piece sums (2^-23 relative per term: the accuracy of an fp32 product; precision="fp32"). */
+int clsr_pgemm_dw_wide_x6(const float* X, int ldx, const float* Xmul, int ldmul, const float* dY, int ldy, long M, int K,
+                          int N, float* workspace, float* dW, int ldw, float* db, int accumulate, void* stream);
 
 /* ---- the row-level heads of the CLSR training step as two persistent launches (csrc/headsfused.hip) -------------------
  * Replaces, for the reference's default widths, the chain clsr_alpha_concat -> 2 x (clsr_pgemm + clsr_bn_finalize) ->

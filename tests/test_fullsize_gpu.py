@@ -171,27 +171,29 @@ def test_wide_layer_kernels_match_the_narrow_ones_at_catalogue_widths():
     feed = synthetic_feed(cfg["P"], cfg["T"], cfg["Vu"], cfg["Vi"], cfg["Vc"], lengths="lognormal", seed=9)
     res = []
     sd = None
-    for wide in (True, False):
+    for wide in (True, "clsr_pgemm_dw_wide", False):      # (default: three-piece products; CLSR_DW_WIDE=fp32; the narrow kernels)
         os.environ.pop("CLSR_PGEMM_NO_KLOOP", None)
         hp, net = _net(cfg, cfg["P"], seed=3)
         if sd is None:
             sd = net.state_dict()
         net.load_state_dict(sd)
-        net.dw_wide = wide
+        net.dw_wide = bool(wide)
+        if isinstance(wide, str):
+            assert net.dw_wide_entry == "clsr_pgemm_dw_wide_x6"
+            net.dw_wide_entry = wide
         net.capture_grads = True
         out = net.train_step(net.upload(feed, True))
         torch.cuda.synchronize()
         res.append((out["logit"].clone(), net.read_losses(), {k: v.clone() for k, v in net.captured["dense"].items()}))
-    (la, lossa, ga), (lb, lossb, gb) = res
-    assert float((la - lb).abs().max()) <= 1e-5
-    for k in lossa:
-        assert abs(lossa[k] - lossb[k]) <= 2e-6 * max(1.0, abs(lossb[k])), k
-    gs = max(float(g.abs().max()) for g in gb.values())
-    worst = 0.0
-    for name, g in gb.items():
-        d = float((ga[name] - g).abs().max())
-        worst = max(worst, d / (float(g.abs().max()) + 1e-30))
-        assert d <= 5e-4 * float(g.abs().max()) + 2e-5 * gs, (name, d, float(g.abs().max()))
+    lb, lossb, gb = res[-1]
+    for la, lossa, ga in res[:-1]:
+        assert float((la - lb).abs().max()) <= 1e-5
+        for k in lossa:
+            assert abs(lossa[k] - lossb[k]) <= 2e-6 * max(1.0, abs(lossb[k])), k
+        gs = max(float(g.abs().max()) for g in gb.values())
+        for name, g in gb.items():
+            d = float((ga[name] - g).abs().max())
+            assert d <= 5e-4 * float(g.abs().max()) + 2e-5 * gs, (name, d, float(g.abs().max()))
 
 
 def test_catalogue100m_full_size_step():

@@ -271,7 +271,7 @@ def test_pgemm_dw(M, K, N):
     close(dW, 1.5 * (X.T @ dY), rtol=2e-5, atol=3e-4, name="dW accumulate")
 
 
-@pytest.mark.parametrize("entry,rel", [("clsr_pgemm_dw_wide", 3e-6), ("clsr_pgemm_dw_wide_x3", 1e-4)])
+@pytest.mark.parametrize("entry,rel", [("clsr_pgemm_dw_wide", 3e-6), ("clsr_pgemm_dw_wide_x3", 1e-4), ("clsr_pgemm_dw_wide_x6", 4e-6)])
 @pytest.mark.parametrize("M,K,N,bias", [(40000, 128, 1536, True), (32768 + 5, 256, 384, False), (33000, 100, 96, True),
                                          (70000, 128, 128, True)])
 def test_pgemm_dw_wide(M, K, N, bias, entry, rel):
