@@ -423,15 +423,15 @@ def embedding_rooflines(net, f, cfg, G, feed):
                         formula="n*W*%d (gradient read) + n*W*4 (fp32 row-gradient write) + 2*n*4 (+ the target rows' slices)"
                                 % sa, columns=W, sites_merged=bool(merged))
         if tag == "gather_bwd":
-            out[tag].update(traffic=160.9e6, traffic_source="profiles/r06_item_embed_kernel_trace.md, counters in KiB (52 dispatches of ss_chunks_lean_kernel over "
-                                                            "three rotating lists, fp32 and bf16 d(hist) alternating: WRITE_SIZE 86.4 MB + 2 x FETCH_SIZE 39.2 MB; kernel "
-                                                            "time avg 51.5 us)")
+            out[tag].update(traffic=167.7e6, traffic_source="profiles/r06_item_embed_kernel_trace.md, counters in KiB (52 dispatches of ss_chunks_lean_kernel over "
+                                                            "three rotating lists, fp32 and bf16 d(hist) alternating: WRITE_SIZE 89.1 MB + 2 x FETCH_SIZE 39.3 MB; kernel "
+                                                            "time avg 39.4 us)")
         elif tag == "gather_bwd_step_form":
             out[tag].update(kernel="ss_chunks_kernel (the full instantiation: what the item site of a training step with the contrastive "
                                    "loss runs -- a second gradient tensor and the mean / recent-k shares added in the walk)",
                             formula="n*W*4 (d(hist)) + n*W*4 (long-term d(hist)) + n*W*4 (row-gradient write) + 2*n*4 + 2*Hn*W*4")
         elif tag == "gather_bwd_item_and_category_one_stream":
-            out[tag].update(traffic=203.2e6, traffic_source="profiles/r06_embed_kernel_trace.md (52 dispatches, kernel time avg 72.7 us)")
+            out[tag].update(traffic=209.5e6, traffic_source="profiles/r06_embed_kernel_trace.md (52 dispatches, counters in KiB, kernel time avg 56.1 us)")
         clear_grads()
     del dh32, dh16
     # ---- bf16 tables + bf16 hist: bytes_gather_fwd(n) = n*D*(2 + 2) + 2*n*4

@@ -183,6 +183,7 @@ class DataParallel(object):
         self.rank = dist.get_rank(group)
         self.sync_bn = bool(sync_bn)
         self.overlap = bool(overlap)
+        self.coalesce = True        # dense gradients + dense gradient tables in one collective (False: one each)
         net.dp_world = self.world
         # recorded launch plans keep raw communicator pointers: a new stepper on the same net must never replay the plans
         # of an earlier one (a freed communicator's address can be handed out again)
@@ -531,7 +532,26 @@ class DataParallel(object):
             self.flags_ready(stream)
         for name in net.tab_grad:          # sparse tables that never reported
             self.table_ready(stream, name)
-        for names, g0, n in self._dense_table_runs():
+        runs = self._dense_table_runs()
+        flat = getattr(net, "grad_flat", None)
+        bn_done = False
+        if (self.coalesce and flat is not None and len(runs) == 1 and runs[0][1] == 0 and "dense" not in self._done
+                and not any(k in self._done for k in runs[0][0]) and net.dense_grad.data_ptr() == flat.data_ptr()):
+            # every table is dense (BASELINE configs[1]-[3]): [dense gradients | gradient tables (| moving statistics of a
+            # per-rank batch-norm)] are ONE range of the flat gradient buffer and travel in ONE collective -- all of them are
+            # issued here, behind the backward pass, whatever their order: every collective costs a launch and the ring's
+            # latency whatever its size (world 1, CLSR_FORCE_DP: three stream hand-overs fewer at the end of the step)
+            names, g0, n = runs[0]
+            t0 = (net.tab_grad_flat.data_ptr() - flat.data_ptr()) // flat.element_size()
+            end = flat.numel() if not self.sync_bn else t0 + g0 + n
+            ds = self._dense_stream if "dense-final" in self._done else None
+            if ds is not None and stream is not None and ds is not stream:
+                stream.wait_stream(ds)                  # (the dense gradients became final on the weight-gradient stream)
+            self._done.update(names)
+            self._done.add("dense")
+            bn_done = not self.sync_bn
+            self._allreduce(flat[:end], dist.ReduceOp.SUM, stream, "dense+tables:" + "+".join(names))
+        for names, g0, n in runs:
             if not all(k in self._done for k in names):     # (only a second _finish of the same step finds them done)
                 self._done.update(names)
                 self._allreduce(net.tab_grad_flat[g0:g0 + n], dist.ReduceOp.SUM, stream, "tables:" + "+".join(names))
@@ -539,8 +559,15 @@ class DataParallel(object):
             self._done.add("dense")
             ds = self._dense_stream if "dense-final" in self._done else stream
             self._allreduce(net.dense_grad, dist.ReduceOp.SUM, ds, "dense")
-        self._allreduce(self.small, dist.ReduceOp.SUM, stream, "small")
-        if not self.sync_bn:
+        if self.comm is not None and self.small.numel() <= 64:
+            # the 24 doubles through the peer-mapped buffers (one small launch on the compute stream, no process-group call)
+            if self.trace is not None:
+                self.trace.append(("collective", "small (p2p)"))
+            with self._on(stream):
+                self.comm.all_reduce(self.small, self.small.numel())
+        else:
+            self._allreduce(self.small, dist.ReduceOp.SUM, stream, "small")
+        if not self.sync_bn and not bn_done:
             # keep the (non-trainable) moving statistics identical on every replica: their average
             self._allreduce(net.bn_moving, dist.ReduceOp.SUM, stream, "bn_moving")
         with self._on(stream):

@@ -220,21 +220,31 @@ def test_overlapped_exchange_bookkeeping_every_piece_exactly_once_and_waited_for
         [("table_ready", ("item",)), ("table_ready", ("item",))],             # a duplicate report is ignored
     ]
     for script in scripts:
+      for coalesce in (True, False):
         net, d = _StubNet(), _LogDist()
         dp = DataParallel(net, d, sync_bn=True, sparse_tables="none")
+        dp.coalesce = coalesce
         assert net.dp_hooks is dp and net.dp_world == 2
         net.script = script
         dp.train_step({})
         ar = [e for e in d.log if e[0] == "all_reduce"]
         ptrs = [e[1] for e in ar]
         last = list(net.tab_shape)[-1]                      # (the byte maps travel without the last table's padding)
-        expect = {net.dense_grad.data_ptr(): 100, net.stats24.data_ptr(): 24,
-                  net.tab_flags_flat.data_ptr(): net.tab_foff[last] + net.tab_shape[last][0],
-                  net.tab_grad_flat.data_ptr(): net.tab_grad_flat.numel()}       # the four tables: one collective
+        if coalesce:
+            # every table dense: [dense gradients | gradient tables] of the flat buffer in ONE collective (not the moving
+            # statistics behind them: sync BN)
+            expect = {net.grad_flat.data_ptr(): 100 + net.tab_grad_flat.numel(), net.stats24.data_ptr(): 24,
+                      net.tab_flags_flat.data_ptr(): net.tab_foff[last] + net.tab_shape[last][0]}
+            order = [net.tab_flags_flat.data_ptr(), net.grad_flat.data_ptr(), net.stats24.data_ptr()]
+        else:
+            expect = {net.dense_grad.data_ptr(): 100, net.stats24.data_ptr(): 24,
+                      net.tab_flags_flat.data_ptr(): net.tab_foff[last] + net.tab_shape[last][0],
+                      net.tab_grad_flat.data_ptr(): net.tab_grad_flat.numel()}       # the four tables: one collective
+            order = [net.tab_flags_flat.data_ptr(), net.tab_grad_flat.data_ptr(), net.dense_grad.data_ptr(),
+                     net.stats24.data_ptr()]
         assert sorted(ptrs) == sorted(expect), script          # every piece exactly once (sync BN: no moving stats)
         assert all(expect[e[1]] == e[2] for e in ar)
-        assert ptrs == [net.tab_flags_flat.data_ptr(), net.tab_grad_flat.data_ptr(), net.dense_grad.data_ptr(),
-                        net.stats24.data_ptr()], script
+        assert ptrs == order, script
         waits = [e for e in d.log if e[0] == "wait"]
         assert len(waits) == len(ar) and d.log.index(waits[0]) > d.log.index(ar[-1])
         assert net.updated == 1
@@ -251,5 +261,14 @@ def test_overlapped_exchange_bookkeeping_every_piece_exactly_once_and_waited_for
     dp = DataParallel(net, d, sync_bn=False, sparse_tables="none", overlap=False)
     assert net.dp_hooks is None
     dp.train_step({})
-    assert any(e[0] == "all_reduce" and e[1] == net.bn_moving.data_ptr() for e in d.log)
+    # (the whole flat buffer in one collective: dense gradients, gradient tables, moving statistics)
+    assert any(e[0] == "all_reduce" and e[1] == net.grad_flat.data_ptr() and e[2] == net.grad_flat.numel() for e in d.log)
+    assert not any(e[0] == "all_reduce" and e[1] == net.bn_moving.data_ptr() for e in d.log)
     assert torch.allclose(net.bn_moving, torch.ones(8))       # (identity all-reduce) * 1 / world
+    net, d = _StubNet(), _LogDist()
+    net.bn_moving += 2.0
+    dp = DataParallel(net, d, sync_bn=False, sparse_tables="none", overlap=False)
+    dp.coalesce = False
+    dp.train_step({})
+    assert any(e[0] == "all_reduce" and e[1] == net.bn_moving.data_ptr() for e in d.log)
+    assert torch.allclose(net.bn_moving, torch.ones(8))

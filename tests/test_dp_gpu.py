@@ -398,8 +398,9 @@ class _RecordingDist(object):
             o.copy_(t)
 
 
+@pytest.mark.parametrize("coalesce", [True, False])
 @pytest.mark.parametrize("planned", [False, True])
-def test_overlapped_exchange_is_issued_after_the_joins_that_finish_its_data(golden_dir, golden_hparams, planned):
+def test_overlapped_exchange_is_issued_after_the_joins_that_finish_its_data(golden_dir, golden_hparams, planned, coalesce):
     """Fails if a collective is enqueued before the stream joins / weight-gradient flush that make its buffer final:
     the dense all-reduce must see NO unjoined branch and NO pending weight-gradient partials and rides on the
     weight-gradient stream; the gradient tables go as one collective from the compute stream after the final join; the
@@ -418,6 +419,7 @@ def test_overlapped_exchange_is_issued_after_the_joins_that_finish_its_data(gold
     d = _RecordingDist()
     d.net = net
     dp = DataParallel(net, d, sync_bn=False, sparse_tables="none")
+    dp.coalesce = coalesce
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         f = net.upload(feed, True)
@@ -429,6 +431,23 @@ def test_overlapped_exchange_is_issued_after_the_joins_that_finish_its_data(gold
     main = stream.cuda_stream
     ar = [e for e in d.log if e[0] == "all_reduce"]
     by_ptr = {e[1]: e for e in ar}
+    if coalesce:
+        # every table dense: [dense gradients | gradient tables | moving statistics (per-rank batch-norm)] = the whole flat
+        # buffer in ONE collective on the compute stream, after the final join and behind a wait for the weight-gradient
+        # stream (where the dense gradients became final); the byte maps before it, the 24 doubles after it
+        assert net.dense_grad.data_ptr() == net.grad_flat.data_ptr()
+        one = by_ptr[net.grad_flat.data_ptr()]
+        assert one[2] == net.grad_flat.numel() and one[3] == main
+        assert net.tab_grad_flat.data_ptr() not in by_ptr and net.bn_moving.data_ptr() not in by_ptr
+        if not planned:
+            assert one[4] in ([], ["@dense"]) and one[5] == {}, "issued before the joins / the dW flush: %r" % (one,)
+        flags = by_ptr[net.tab_flags_flat.data_ptr()]
+        assert d.log.index(flags) < d.log.index(one) and flags[3] != main
+        small = by_ptr[net.stats24.data_ptr()]
+        assert d.log.index(small) > d.log.index(one)
+        waits = [i for i, e in enumerate(d.log) if e[0] == "wait"]
+        assert len(waits) == len(ar) == 3 and min(waits) > max(d.log.index(e) for e in ar)
+        return
     dense = by_ptr[net.dense_grad.data_ptr()]
     if not planned:      # (a replayed plan does not rebuild the python-side bookkeeping the recorder looks at)
         assert dense[4] in ([], ["@dense"]) and dense[5] == {}, "dense all-reduce issued before the joins / the dW flush: %r" % (dense,)
