@@ -364,14 +364,16 @@ def embedding_rooflines(net, f, cfg, G, feed):
     # ss_chunks_kernel: 20 registers per entry in flight instead of 4)
     dh_lt = torch.randn(Hn * T, D, device=dev) * 1e-3
     dmean, drecent = torch.randn(Hn, D, device=dev) * 1e-3, torch.randn(Hn, D, device=dev) * 1e-3
+    ss_full = torch.zeros(4, dtype=torch.float64, device=dev)
 
     def site_rows(d, L, full=False):
         bf = int(d.dtype == torch.bfloat16)
         if full:
             tail_i = (1, dtarget.data_ptr(), 0, n, D, 0) if merged else (0,)
             pad = lambda t: t + (0,) * (6 - len(t))
+            tail_i = (1, dtarget.data_ptr(), ss_full[2:].data_ptr(), n, D, 0) if merged else (0,)      # (with the two squared norms)
             return [(d.data_ptr(), dh_lt.data_ptr(), dmean.data_ptr(), drecent.data_ptr(), L["ki"].data_ptr(), L["pi"].data_ptr(),
-                     f["seq_len"].data_ptr(), tg["item"].data_ptr(), 0, ne, bf, G, T, D, 0, Di, 3, Di, 0) + pad(tail_i) + (0, 0)]
+                     f["seq_len"].data_ptr(), tg["item"].data_ptr(), ss_full.data_ptr(), ne, bf, G, T, D, 0, Di, 3, Di, 0) + pad(tail_i) + (0, 0)]
         tail_i = (1, dtarget.data_ptr(), 0, n, D, 0) if merged else (0,)
         tail_c = (1, dtarget.data_ptr(), 0, n, D, Di) if merged else (0,)
         pad = lambda t: t + (0,) * (6 - len(t))
@@ -428,7 +430,8 @@ def embedding_rooflines(net, f, cfg, G, feed):
                                                             "time avg 39.4 us)")
         elif tag == "gather_bwd_step_form":
             out[tag].update(kernel="ss_chunks_kernel (the full instantiation: what the item site of a training step with the contrastive "
-                                   "loss runs -- a second gradient tensor and the mean / recent-k shares added in the walk)",
+                                   "loss runs -- a second gradient tensor and the mean / recent-k shares added in the walk, the squared norms of both "
+                                   "sites folded by ss_fold_kernel behind it)",
                             formula="n*W*4 (d(hist)) + n*W*4 (long-term d(hist)) + n*W*4 (row-gradient write) + 2*n*4 + 2*Hn*W*4")
         elif tag == "gather_bwd_item_and_category_one_stream":
             out[tag].update(traffic=209.5e6, traffic_source="profiles/r06_embed_kernel_trace.md (52 dispatches, counters in KiB, kernel time avg 56.1 us)")
