@@ -391,9 +391,14 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
     const int klast = s.keys[pe - 1];
     const int knx = pe < s.n ? s.keys[pe] : -1;
     const int kne = pe + E < s.n ? s.keys[pe + E] : -2;
+    constexpr bool PIPED = LEAN && SB * (SS_CHUNK / (SB >= 16 ? SB : 8)) <= SS_CHUNK && VW == 4;    // (the pipelined walk below)
     int keyN[SB], posN[SB];
-    ss_ldn<SB>(s.keys, p0, pe, -1, keyN);
-    ss_ldn<SB>(s.perm, p0, pe, 0, posN);
+    if constexpr (PIPED) {
+      keyN[0] = s.keys[p0];                      // (the walk takes its keys / slice numbers from LDS)
+    } else {
+      ss_ldn<SB>(s.keys, p0, pe, -1, keyN);
+      ss_ldn<SB>(s.perm, p0, pe, 0, posN);
+    }
     // a run over the border at p0 / pe that ends within SS_E entries behind it belongs to the chunk it comes from
     const bool short_prev = kprev >= 0 && keyN[0] == kprev && kpe != kprev;
     const bool short_next = knx >= 0 && klast == knx && kne != knx;
@@ -401,9 +406,11 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
     const int next_key = short_next ? -2 : knx;
     const long pe_walk = WIDE ? p0 + (long)SB * NBATCH : (short_next ? pe + SB : pe);     // (not WIDE: one more batch for the continuation)
     const long lim = short_next ? (pe + E < s.n ? pe + E : s.n) : pe;         // entries that may be read
-    if (short_prev) {
+    if constexpr (!PIPED) {
+      if (short_prev) {
 #pragma unroll
-      for (int k = 0; k < E; ++k) if (keyN[k] == kprev) keyN[k] = -1;         // (a prefix: the list is sorted)
+        for (int k = 0; k < E; ++k) if (keyN[k] == kprev) keyN[k] = -1;         // (a prefix: the list is sorted)
+      }
     }
     int nruns = 0;
     vec_t acc = vec_t(0.f);
@@ -422,7 +429,7 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
       }
       ++nruns;
     };
-    if constexpr (LEAN && !WIDE && VW == 4) {
+    if constexpr (PIPED) {
       // ---- LEAN walk, software-pipelined: the row reads of batch b + 1 are in flight while batch b is summed (keys two batches
       //      ahead).  With the loads of a batch issued only after the previous batch had been consumed, a chunk was a chain of
       //      4-5 dependent row-read round trips: with every row read a cache hit and no row stores the launch still took 27 us
@@ -434,10 +441,12 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
       __shared__ int kp_all[32 * (2 * (SS_CHUNK + SS_E))];
       int* lk = kp_all + gi * (2 * (SS_CHUNK + SS_E));
       int* lp = lk + SS_CHUNK + SS_E;
+      // (every entry that exists: which of those behind the chunk may be READ -- ``lim`` -- hangs on the border keys above; with
+      //  the bound applied when a batch is fetched these loads leave together with those, not one round trip behind them)
       for (int e = lig; e < SS_CHUNK + SS_E; e += CP) {
         const long q = p0 + e;
-        lk[e] = q < lim ? s.keys[q] : -1;
-        lp[e] = q < lim ? s.perm[q] : 0;
+        lk[e] = q < s.n ? s.keys[q] : -1;
+        lp[e] = q < s.n ? s.perm[q] : 0;
       }
       // (a thread group lies inside ONE wave: its LDS writes are visible to its own later reads once they have completed)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -447,7 +456,11 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
         if (q0 < pe_walk) {
           const int o = (int)(q0 - p0);
 #pragma unroll
-          for (int k = 0; k < SB; ++k) { kk[k] = lk[o + k]; pp[k] = lp[o + k]; }
+          for (int k = 0; k < SB; ++k) {
+            const bool in = q0 + k < lim;
+            kk[k] = in ? lk[o + k] : -1;
+            pp[k] = in ? lp[o + k] : 0;
+          }
           if (q0 == p0 && short_prev) {
 #pragma unroll
             for (int k = 0; k < E; ++k) if (kk[k] == kprev) kk[k] = -1;       // (a prefix: the list is sorted)
@@ -484,7 +497,7 @@ __device__ __forceinline__ void ss_chunks(const SsSite& s, const int local_block
       auto consume = [&](const long q0, const unsigned secm, const vec_t (&rv)[SB]) {
         int key[SB], pu[SB];
         fetch(q0, key, pu);
-        const int knext = q0 + SB < pe_walk ? lk[(int)(q0 + SB - p0)] : -1;      // (the continuation batch starts with the run's key)
+        const int knext = (q0 + SB < pe_walk && q0 + SB < lim) ? lk[(int)(q0 + SB - p0)] : -1;      // (the continuation batch starts with the run's key)
 #pragma unroll
         for (int k = 0; k < SB; ++k) {
           if (key[k] < 0) continue;
