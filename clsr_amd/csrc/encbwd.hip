@@ -51,6 +51,10 @@ struct EncBwdArgs {
   float* dhist;                   // [M, 40], accumulated into
   float* ws[7];                   // partial workspaces of the seven products, gridDim.x partial slots per chunk
   long M;
+  // optional (clsr_enc_bwd_fused_fold): what the segmented sums of the history lookups would otherwise add per sorted entry --
+  // the long-term branch's d(hist) and the mean / recent-k shares of the history prologue -- is added to d(hist) HERE, where
+  // its rows are read and written anyway; the sums then run in their lean form (csrc/segsum.hip)
+  const float* dhist2; const float* dmean; const float* drecent; const int* seq_len; int len_stride, T, recent_k;
 };
 
 // product p: rows = left-operand tile columns [x0, x0 + K), columns = dPin columns [c0, c0 + N)
@@ -261,6 +265,9 @@ __device__ __forceinline__ void eb_body(const EncBwdArgs& a, float* lds) {
   float* const pP = Ps + row * EB_PS + 4 * c;
   float* const pX = Xs + row * EB_XS + 4 * c;
   f32x4 pr[8], xh, x1, xm, xt0, xt1, x2, xr1, xr2, dr = z4;     // dr: the thread's float4 of the d(hist) rows of the stage
+  f32x4 d2 = z4, smv = z4, src_ = z4;                           // (fold form: second d(hist), mean / recent rows of the history)
+  int slen = 0, stt = 0;
+  const bool fold = a.dhist2 != nullptr;
   const long nst = (a.M + 15) >> 4;
   auto fetch = [&](long st) {
     const long m0 = st * 16;
@@ -278,6 +285,30 @@ __device__ __forceinline__ void eb_body(const EncBwdArgs& a, float* lds) {
     x2 = eb_ld(eb_rsrc(a.hp2, m0, rows, 40), v40);
     xr2 = eb_ld(eb_rsrc(a.g2, m0, rows, 120), v120);
     dr = eb_ld(eb_rsrc(a.dhist, m0, rows, 40), v40);
+    if (fold) {
+      d2 = eb_ld(eb_rsrc(a.dhist2, m0, rows, 40), v40);
+      const long m = m0 + row < a.M ? m0 + row : a.M - 1;
+      const int h = (int)(m / a.T);
+      stt = (int)(m - (long)h * a.T);
+      slen = a.seq_len[(long)h * a.len_stride];
+      if (c < 10) {
+        if (a.dmean) smv = ld4(a.dmean + (long)h * 40 + 4 * c);
+        if (a.drecent) src_ = ld4(a.drecent + (long)h * 40 + 4 * c);
+      }
+    }
+  };
+  // d(hist) of the thread's piece as the segmented sums would have formed it (reference: clsr.py:145-150,157,173-177: the
+  // masked mean / recent-k mean of the history embeddings back-propagate 1 / len resp. 1 / min(len, k) of their gradient)
+  auto folded = [&]() {
+    f32x4 v = dr;
+    if (fold) {
+      v += d2;
+      if (stt < slen) {
+        if (a.dmean) v += smv * (1.0f / (float)slen);
+        if (a.drecent && stt >= slen - a.recent_k) v += src_ * (1.0f / (float)(slen < a.recent_k ? slen : a.recent_k));
+      }
+    }
+    return v;
   };
   auto stage = [&]() {     // (rows past the end of the batch were read as zeros)
     if (c < 15) {
@@ -310,7 +341,7 @@ __device__ __forceinline__ void eb_body(const EncBwdArgs& a, float* lds) {
   for (; st < nst; st += gridDim.x) {
     __syncthreads();                 // the previous stage's tiles / exchange area are free
     stage();
-    const f32x4 dcur = dr;           // (fetched one stage ahead, like the operands)
+    const f32x4 dcur = folded();     // (fetched one stage ahead, like the operands)
     __syncthreads();
 #ifdef EB_ABL_NOFETCH
     if (st == blockIdx.x)
@@ -826,7 +857,8 @@ extern "C" long clsr_enc_bwd_fused_workspace_floats(long M, int p) {
 // 1 when the default-graph widths apply: D = n = 40, NX = 480 with the column layout of the header comment
 extern "C" int clsr_enc_bwd_fused_supported(int D, int n, int NX) { return D == 40 && n == 40 && NX == EB_NX; }
 
-extern "C" int clsr_enc_bwd_fused(const float* dPin, const float* hist, const float* hprev1, const float* gates1,
+static int enc_bwd_fused_any(const float* dhist2, const float* dmean, const float* drecent, const int* seq_len, int len_stride, int T,
+                             int recent_k, const float* dPin, const float* hist, const float* hprev1, const float* gates1,
                                   const float* mprev, const float* TT, const float* hprev2, const float* gates2,
                                   const float* Wt, int Kp, float* dhist, float* ws_hist, float* ws_hp1, float* ws_hp1r,
                                   float* ws_mprev, float* ws_tt, float* ws_hp2, float* ws_hp2r, long M, void* stream) {
@@ -838,6 +870,7 @@ extern "C" int clsr_enc_bwd_fused(const float* dPin, const float* hist, const fl
   EncBwdArgs a = {};
   a.dPin = dPin; a.hist = hist; a.hp1 = hprev1; a.g1 = gates1; a.mprev = mprev; a.TT = TT; a.hp2 = hprev2; a.g2 = gates2;
   a.Wt = Wt; a.Kp = Kp; a.dhist = dhist; a.M = M;
+  a.dhist2 = dhist2; a.dmean = dmean; a.drecent = drecent; a.seq_len = seq_len; a.len_stride = len_stride; a.T = T; a.recent_k = recent_k;
   a.ws[0] = ws_hist; a.ws[1] = ws_hp1; a.ws[2] = ws_hp1r; a.ws[3] = ws_mprev; a.ws[4] = ws_tt; a.ws[5] = ws_hp2; a.ws[6] = ws_hp2r;
   const size_t shmem = ((size_t)48 * EB_WS + 16 * EB_PS + 16 * EB_XS + 4 * 16 * EB_DS) * sizeof(float);
   CLSR_CHECK_SUPPORTED(shmem <= 160 * 1024);
@@ -845,4 +878,25 @@ extern "C" int clsr_enc_bwd_fused(const float* dPin, const float* hist, const fl
   hipLaunchKernelGGL(enc_bwd_fused_kernel, dim3(eb_grid(M)), dim3(256), shmem, (hipStream_t)stream, a);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
+}
+extern "C" int clsr_enc_bwd_fused(const float* dPin, const float* hist, const float* hprev1, const float* gates1,
+                                  const float* mprev, const float* TT, const float* hprev2, const float* gates2,
+                                  const float* Wt, int Kp, float* dhist, float* ws_hist, float* ws_hp1, float* ws_hp1r,
+                                  float* ws_mprev, float* ws_tt, float* ws_hp2, float* ws_hp2r, long M, void* stream) {
+  return enc_bwd_fused_any(nullptr, nullptr, nullptr, nullptr, 0, 1, 1, dPin, hist, hprev1, gates1, mprev, TT, hprev2, gates2, Wt, Kp, dhist,
+                           ws_hist, ws_hp1, ws_hp1r, ws_mprev, ws_tt, ws_hp2, ws_hp2r, M, stream);
+}
+// ... with d(hist)[m, :] += dhist2[m, :] + the mean / recent-k shares of row m = (history h, step t) of [Hn, T] positions:
+// dmean[h, :] / len_h when t < len_h, drecent[h, :] / min(len_h, recent_k) when len_h - recent_k <= t < len_h (dmean / drecent
+// may be NULL; len_h = seq_len[h * len_stride]) -- the terms the segmented sums of the history lookups otherwise add per entry
+extern "C" int clsr_enc_bwd_fused_fold(const float* dPin, const float* hist, const float* hprev1, const float* gates1,
+                                       const float* mprev, const float* TT, const float* hprev2, const float* gates2,
+                                       const float* Wt, int Kp, float* dhist, const float* dhist2, const float* dmean,
+                                       const float* drecent, const int* seq_len, int len_stride, int T, int recent_k,
+                                       float* ws_hist, float* ws_hp1, float* ws_hp1r, float* ws_mprev, float* ws_tt, float* ws_hp2,
+                                       float* ws_hp2r, long M, void* stream) {
+  CLSR_CHECK_ARG(dhist2 && seq_len && T > 0 && recent_k > 0 && M % T == 0);
+  CLSR_CHECK_SUPPORTED(((uintptr_t)dhist2 % 16) == 0 && ((uintptr_t)dmean % 16) == 0 && ((uintptr_t)drecent % 16) == 0);
+  return enc_bwd_fused_any(dhist2, dmean, drecent, seq_len, len_stride, T, recent_k, dPin, hist, hprev1, gates1, mprev, TT, hprev2, gates2,
+                           Wt, Kp, dhist, ws_hist, ws_hp1, ws_hp1r, ws_mprev, ws_tt, ws_hp2, ws_hp2r, M, stream);
 }

@@ -250,6 +250,9 @@ class CLSRNet(object):
         self.dhist_side = True      # A/B (speed mode): d(hist) product on the long-term stream (2.87 -> 2.84 ms)
         self.enc_bwd_fused_h = True   # A/B: the speed-mode (bf16 dPin) form of the fused encoder tail
         self.enc_bwd_fused = True   # A/B: one pass over dPin for the seven encoder-side weight gradients + d(hist) (csrc/encbwd.hip)
+        # ... which also adds the long-term d(hist) and the history prologue's shares, so that the segmented sums run lean
+        self.fold_hist_shares = not os.environ.get("CLSR_NO_FOLD_SHARES")
+        self._fold_args, self._folded = None, False
         self.l0_fwd_wave = True      # A/B switch (exact mode, see _att_fwd)
         self.fused_l0_wu = True   # A/B: dU . Wu^T inside that kernel as well (time-neutral, two launches fewer)
         self._joins = []
@@ -364,7 +367,7 @@ class CLSRNet(object):
                  "fused_l0_bwd", "fused_l0_wu", "l0_fwd_wave", "l0_bwd_halves", "dw_batching", "lt_bwd_early", "dpin_h", "flush_side",
                  "l1_bwd_2pass", "split_g2", "g2_stream", "rnn_products", "rnn_fused_proj", "rnn_act_tiled", "att_bwd", "att_bwd_l0", "_l1x", "_l0x", "att_hist_x3",
                  "att_hist_bwd_x3", "att_hist_bwd_pieces", "att_hist_pieces", "att_l1_fwd_x6", "att_fwd_x3", "att_fwd_x6",
-                 "att_l0_fwd_entry", "x3_enc", "enc_x6", "enc_back_x3", "enc_bwd_fused", "enc_bwd_fused_h", "proj_x3", "proj_tt", "proj_x3_wide",
+                 "att_l0_fwd_entry", "x3_enc", "enc_x6", "enc_back_x3", "enc_bwd_fused", "enc_bwd_fused_h", "fold_hist_shares", "proj_x3", "proj_tt", "proj_x3_wide",
                  "gemm_wide_x3", "proj_gate_pieces", "proj_bwd_pieces", "proj_wide_pieces", "dhist_side", "early_scatter",
                  "fused_logit_tail", "fuse_tt", "heads_fused", "dense_upd_dw", "dw_wide", "dw_wide_entry", "rowlist_min_elems")
 
@@ -1877,6 +1880,19 @@ class CLSRNet(object):
                          (3 * H, "_time_input_bias2")):
             self._rp(tp[off_:], parts_t, 4 * H, H, Gd[t + nm])
         Wt, Kp = self.packed["xw^T"]
+        fold = self._fold_args if self.fold_hist_shares else None
+        if fold is not None:
+            # d(hist) += the long-term branch's d(hist) + the mean / recent-k shares of the history prologue INSIDE this launch
+            # (it reads and writes every d(hist) row anyway): the segmented sums of the item / category sites then run in
+            # their lean, software-pipelined form (csrc/segsum.hip) -- they are what the table update at the end of the step
+            # waits for
+            dhist_lt, dM, dR, seq_len, ls = fold
+            self._join(only="@lt")          # (the long-term attention backward wrote dhist_lt on its branch, long ago)
+            call("clsr_enc_bwd_fused_fold", dPinAll, hist, self._buf("g1.hprev", Hn, T, H), self._buf("g1.gates", Hn, T, 3 * H),
+                 self._buf("t4.mprev", Hn, T, H), TT, self._buf("g2.hprev", Hn, T, H), self._buf("g2.gates", Hn, T, 3 * H),
+                 Wt, Kp, dhist, dhist_lt, dM, dR, seq_len, ls, T, int(self.hp.contrastive_recent_k), *wss, M)
+            self._folded = True
+            return
         call("clsr_enc_bwd_fused", dPinAll, hist, self._buf("g1.hprev", Hn, T, H), self._buf("g1.gates", Hn, T, 3 * H),
              self._buf("t4.mprev", Hn, T, H), TT, self._buf("g2.hprev", Hn, T, H), self._buf("g2.gates", Hn, T, 3 * H),
              Wt, Kp, dhist, *wss, M)
@@ -2424,6 +2440,9 @@ class CLSRNet(object):
         if scat_early:
             self._scatter_rows_early(f, dul, None, dtarget, Hn, B, hs, fork)
             self._scatter_rows_early(f, None, dushort, None, Hn, B, hs, self._fork_point())
+        self._folded = False
+        self._fold_args = ((dhist_lt, dM, dR, seq_len, ls) if (self.sorted_hist_grad and self.det_grads and self.hist_grad_two
+                                                              and dhist.dtype == F32) else None)
         if self._enc_bwd_fused_ok(dpin_h):
             (self._enc_bwd_fused_h if self.bf16 else self._enc_bwd_fused_x3 if (self.x3_enc or self.enc_x6) else
              self._enc_bwd_fused)(f, hist, dPinAll, dhist, Hn, T, hs)
@@ -2465,7 +2484,9 @@ class CLSRNet(object):
             self._dense_grads_final()
         # d(hist) = dhist + dhist_lt (the long-term branch's share): the segmented sums add the two on the fly; the
         # float-atomics path gets one tensor
-        if not (self.sorted_hist_grad and self.hist_grad_two):
+        if self._folded:       # (the fused encoder tail added the long-term share and the prologue's shares to d(hist))
+            dhist_lt = dM = dR = None
+        elif not (self.sorted_hist_grad and self.hist_grad_two):
             call("clsr_axpby", dhist, dhist, 1.0, dhist_lt, 1.0, dhist.numel())
             dhist_lt = None
         # ---- embedding gradients (IndexedSlices values -> dense grad tables + squared norms)

@@ -869,6 +869,16 @@ int clsr_enc_bwd_fused(const float* dPin, const float* hist, const float* hprev1
                        const float* mprev, const float* TT, const float* hprev2, const float* gates2,
                        const float* Wt, int Kp, float* dhist, float* ws_hist, float* ws_hp1, float* ws_hp1r,
                        float* ws_mprev, float* ws_tt, float* ws_hp2, float* ws_hp2r, long M, void* stream);
+/* ... and d(hist)[m, :] += dhist2[m, :] + the shares of the history prologue (clsr.py:145-150,157,173-177) of row m = (h, t):
+ * dmean[h, :] / len_h when t < len_h, drecent[h, :] / min(len_h, recent_k) when len_h - recent_k <= t < len_h (dmean, drecent
+ * may be NULL; len_h = seq_len[h * len_stride], M = Hn * T) -- the terms the segmented sums of the history lookups
+ * (clsr_segsum_multi: src2, dmean, drecent) otherwise add per sorted entry; with them folded in here those run lean. */
+int clsr_enc_bwd_fused_fold(const float* dPin, const float* hist, const float* hprev1, const float* gates1,
+                            const float* mprev, const float* TT, const float* hprev2, const float* gates2,
+                            const float* Wt, int Kp, float* dhist, const float* dhist2, const float* dmean,
+                            const float* drecent, const int* seq_len, int len_stride, int T, int recent_k,
+                            float* ws_hist, float* ws_hp1, float* ws_hp1r, float* ws_mprev, float* ws_tt, float* ws_hp2,
+                            float* ws_hp2r, long M, void* stream);
 
 /* one weight-gradient product of a multi-job launch (clsr_pgemm_dw_partial_multi / clsr_hdw_partial_multi): the arguments
  * of clsr_pgemm_dw_partial / clsr_hdw_partial */

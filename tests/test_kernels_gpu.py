@@ -1447,8 +1447,9 @@ def test_weight_gradients_over_time_ranges_fill_one_workspace(Hn, T, nch):
     close(p_rng.sum(0), p_all.sum(0).double(), rtol=1e-4, atol=1e-4 * math.sqrt(M), name="time-feature sums")
 
 
+@pytest.mark.parametrize("fold", [False, True])
 @pytest.mark.parametrize("M", [16 * 300, 16 * 257 + 5, 37])
-def test_fused_encoder_backward_one_pass_over_dpin(M):
+def test_fused_encoder_backward_one_pass_over_dpin(M, fold):
     """clsr_enc_bwd_fused (csrc/encbwd.hip): the seven encoder-side weight gradients (+ bias sums) and d(hist) from one
     pass over dPin == float64 products of the same operands, through the same partial layout + clsr_dw_reduce_batch
     that the step uses."""
@@ -1467,7 +1468,27 @@ def test_fused_encoder_backward_one_pass_over_dpin(M):
     wss = [torch.full((query("clsr_enc_bwd_fused_workspace_floats", M, i),), 9.0, device="cuda") for i in range(7)]
     outs = [torch.zeros(K, N, device="cuda") for K, N in shapes]
     db = torch.zeros(480, device="cuda")
-    call("clsr_enc_bwd_fused", dPin, hist, hp1, g1, mp, TT, hp2, g2, Wt, Kp, dhist, *wss, M)
+    extra = 0.0
+    if fold:
+        # clsr_enc_bwd_fused_fold: + a second d(hist) tensor + the mean / recent-k shares of the history prologue per (h, t) row
+        T, k = (37 if M == 37 else 16), 3
+        if M % T:
+            pytest.skip("M is not whole histories")
+        Hn = M // T
+        d2, dm, dr = f(rnd(g, M, n)), f(rnd(g, Hn, n)), f(rnd(g, Hn, n))
+        lens = torch.randint(0, T + 1, (Hn,), generator=g)
+        seq_len = torch.zeros(Hn * 2, dtype=torch.int32)
+        seq_len[::2] = lens.int()                       # (len_stride 2)
+        call("clsr_enc_bwd_fused_fold", dPin, hist, hp1, g1, mp, TT, hp2, g2, Wt, Kp, dhist, d2, dm, dr, seq_len.cuda(), 2, T, k,
+             *wss, M)
+        t = torch.arange(T)[None, :]
+        L = lens[:, None].double()
+        m_ = (t < lens[:, None]).double()
+        r_ = ((t < lens[:, None]) & (t >= lens[:, None] - k)).double()
+        extra = (d2.double().cpu().view(Hn, T, n) + (m_ / L.clamp(min=1))[..., None] * dm.double().cpu()[:, None, :]
+                 + (r_ / torch.minimum(L, torch.tensor(float(k))).clamp(min=1))[..., None] * dr.double().cpu()[:, None, :]).view(M, n)
+    else:
+        call("clsr_enc_bwd_fused", dPin, hist, hp1, g1, mp, TT, hp2, g2, Wt, Kp, dhist, *wss, M)
     sig = tuple((ws.data_ptr(), o.data_ptr(), db.data_ptr() if i == 0 else 0, 1.0, parts, K, N, N, 0)
                 for i, (ws, o, (K, N)) in enumerate(zip(wss, outs, shapes)))
     tab = ops.dw_table(sig, torch.device("cuda"))
@@ -1481,7 +1502,7 @@ def test_fused_encoder_backward_one_pass_over_dpin(M):
     for i, (o, e) in enumerate(zip(outs, exp)):
         close(o, e, rtol=2e-4, atol=tol, name="product %d" % i)
     close(db, P.sum(0), rtol=2e-4, atol=tol, name="bias sums")
-    close(dhist, d(dhist0) + P @ Wx.T, rtol=2e-4, atol=2e-4, name="d(hist)")
+    close(dhist, d(dhist0) + P @ Wx.T + extra, rtol=2e-4, atol=2e-4, name="d(hist)")
 
 
 @pytest.mark.parametrize("P,G,C1", [(4096, 5, 64), (37, 3, 40), (5, 8, 4), (700, 1, 64)])
