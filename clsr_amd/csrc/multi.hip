@@ -241,6 +241,9 @@ __global__ void __launch_bounds__(256) tables_reg_multi_kernel(TablesArgs a) {
 // both were closer to their traffic (~70 MB through the L2 / Infinity Cache) than to their latency chains.
 template <bool H>
 __global__ void __launch_bounds__(256) tables_reg_multi_v4_kernel(TablesArgs a) {
+  // (memory-bound sweep that may run BESIDE the fused encoder tail -- the early update of the user tables: without a wave
+  //  priority above that kernel's it only got the issue slots the MFMA chain left over, 329 us for 25 us of work)
+  __builtin_amdgcn_s_setprio(3);
   const clsr_table_desc d = a.t[blockIdx.y];
   const unsigned QC = (unsigned)d.C >> 2, total = (unsigned)d.V * QC;
   const float cd = d.partner ? d.disc_scale / (a.ucount[0] * (float)d.C) : 0.f;
@@ -279,9 +282,11 @@ __global__ void __launch_bounds__(256) tables_reg_multi_v4_kernel(TablesArgs a) 
       st4(d.grad + 4L * q, r);
     }
   }
-  __shared__ double red[3][4];
-  ss = block256_sum_d(ss, red[0]); rl = block256_sum_d(rl, red[1]); dl = block256_sum_d(dl, red[2]);
-  if (threadIdx.x == 0) {
+  // NO LDS: a workgroup of the fused encoder tail (csrc/encbwd.hip) owns a CU's whole LDS, and a launch that asks for as much
+  // as 96 bytes of it waits for that kernel to end -- the early update of the user tables ran 330 us beside it.  One atomic
+  // per wave instead of one per workgroup (the sums were unordered across workgroups already).
+  ss = wave_sum_d(ss); rl = wave_sum_d(rl); dl = wave_sum_d(dl);
+  if ((threadIdx.x & 63) == 0) {
     if (ss != 0.0) atomicAdd(d.sumsq_reg, ss);
     if (a.reg_loss && rl != 0.0) atomicAdd(a.reg_loss, rl);
     if (d.disc_loss && dl != 0.0) atomicAdd(d.disc_loss, (double)cl * dl);
@@ -374,6 +379,7 @@ __global__ void __launch_bounds__(256) tables_adam_multi_kernel(TablesArgs a) {
 
 template <bool H>
 __global__ void __launch_bounds__(256) tables_adam_multi_v4_kernel(TablesArgs a) {
+  __builtin_amdgcn_s_setprio(3);
   const clsr_table_desc d = a.t[blockIdx.y];
   double tot = 0.0;
   for (int i = 0; i < d.nsum; ++i) tot += d.sumsq_adam[(long)i * d.sumsq_stride];

@@ -253,6 +253,8 @@ class CLSRNet(object):
         # ... which also adds the long-term d(hist) and the history prologue's shares, so that the segmented sums run lean
         self.fold_hist_shares = not os.environ.get("CLSR_NO_FOLD_SHARES")
         self._fold_args, self._folded = None, False
+        self.early_user_update = not os.environ.get("CLSR_NO_EARLY_USER_UPDATE")   # user tables: regulariser + Adam behind their row scatters
+        self._updated_early = set()
         self.l0_fwd_wave = True      # A/B switch (exact mode, see _att_fwd)
         self.fused_l0_wu = True   # A/B: dU . Wu^T inside that kernel as well (time-neutral, two launches fewer)
         self._joins = []
@@ -367,7 +369,7 @@ class CLSRNet(object):
                  "fused_l0_bwd", "fused_l0_wu", "l0_fwd_wave", "l0_bwd_halves", "dw_batching", "lt_bwd_early", "dpin_h", "flush_side",
                  "l1_bwd_2pass", "split_g2", "g2_stream", "rnn_products", "rnn_fused_proj", "rnn_act_tiled", "att_bwd", "att_bwd_l0", "_l1x", "_l0x", "att_hist_x3",
                  "att_hist_bwd_x3", "att_hist_bwd_pieces", "att_hist_pieces", "att_l1_fwd_x6", "att_fwd_x3", "att_fwd_x6",
-                 "att_l0_fwd_entry", "x3_enc", "enc_x6", "enc_back_x3", "enc_bwd_fused", "enc_bwd_fused_h", "fold_hist_shares", "proj_x3", "proj_tt", "proj_x3_wide",
+                 "att_l0_fwd_entry", "x3_enc", "enc_x6", "enc_back_x3", "enc_bwd_fused", "enc_bwd_fused_h", "fold_hist_shares", "early_user_update", "proj_x3", "proj_tt", "proj_x3_wide",
                  "gemm_wide_x3", "proj_gate_pieces", "proj_bwd_pieces", "proj_wide_pieces", "dhist_side", "early_scatter",
                  "fused_logit_tail", "fuse_tt", "heads_fused", "dense_upd_dw", "dw_wide", "dw_wide_entry", "rowlist_min_elems")
 
@@ -2440,6 +2442,12 @@ class CLSRNet(object):
         if scat_early:
             self._scatter_rows_early(f, dul, None, dtarget, Hn, B, hs, fork)
             self._scatter_rows_early(f, None, dushort, None, Hn, B, hs, self._fork_point())
+            if (self.early_user_update and apply and self._ticked and self.dp_hooks is None and not self.capture_grads
+                    and "user_long" in self.tables):
+                # (same stream as the two scatters: ordered behind them; a branch name of its own -- only the end of the update
+                #  phase waits for it)
+                with self._branch("@aux", after=self._fork_point(), name="@uupd"):
+                    self._update_user_tables_early()
         self._folded = False
         self._fold_args = ((dhist_lt, dM, dR, seq_len, ls) if (self.sorted_hist_grad and self.det_grads and self.hist_grad_two
                                                               and dhist.dtype == F32) else None)
@@ -2468,7 +2476,7 @@ class CLSRNet(object):
         # (deterministic segmented sums update a row with a plain read-modify-write: the target / user row sums of the
         #  same tables -- the @scat branches -- must have finished, which they have long since: the wait costs a packet)
         keep = () if (self.det_grads and self.sorted_hist_grad) else ("@scat",)
-        self._join(but=keep + ("@encw",) if side_dense else keep)
+        self._join(but=keep + ("@encw", "@uupd") if side_dense else keep + ("@uupd",))
         if side_dense:
             # the dense path from here on (batched reduction of every weight gradient, unpacking, later the dense
             # regulariser + Adam) does not meet the embedding path (gradient tables, table regulariser / Adam) again:
@@ -2506,7 +2514,7 @@ class CLSRNet(object):
                 with self._branch("@aux" if self.split_emb_grad else "@main", after=fork):
                     self._scatter_user_item_rows(f, dul, dushort, dtarget, Hn, B, hs)
             self._hist_grad_sorted(dhist, dM, dR, Hn, T, seq_len, ls, ss, only="item", dhist2=dhist_lt, dtarget=dtarget)
-            self._join(but="@dense")
+            self._join(but=("@dense", "@uupd"))
             self._dp_hook("table_ready", "item")
         else:
             call("clsr_gather_hist_bwd", dhist, dM, dR, f["item_history"], f["item_cate_history"], hs * T, seq_len,
@@ -2732,6 +2740,31 @@ class CLSRNet(object):
                 ("user_long", "user_short", 8, -2.0 * wd, -wd, self.losses[3:], 6, 2),
                 ("user_short", "user_long", 9, -2.0 * wd, 0.0, None, 7, 2))
 
+    def _sweep_row(self, key, partner, slot, dscale, dloss_scale, dloss, base, nsum):
+        tb, ss = self.tables, self.sumsq_tab
+        V, C = tb[key].shape
+        pt = tb[partner] if partner else None
+        return (tb[key].data_ptr(), ops._ptr(pt), self.tab_grad[key].data_ptr(), self.tab_m[key].data_ptr(),
+                self.tab_v[key].data_ptr(), self.tab_flags[key].data_ptr(), ss[slot:].data_ptr(), ops._ptr(dloss),
+                ss[base:].data_ptr(), V, C, nsum, 2, dscale, dloss_scale, 0)
+
+    def _update_user_tables_early(self):
+        """Regulariser (+ discrepancy term) and Adam of the two user tables as soon as their gradients are final -- the row
+        scatters of the long- and short-term user gradients, long before the end of the backward pass -- instead of in the sweep
+        over all four tables that the step ends with (tf.clip_by_norm is per variable, base_model.py:290-296: a table's update
+        needs its own norms only).  60 % of the values of that sweep at BASELINE configs[1]; what stays at the end of the step
+        is the item and category tables, whose gradients the history-row sums finish last."""
+        hp, tb = self.hp, self.tables
+        spec = [sp for sp in self._update_spec() if sp[0] in ("user_long", "user_short")]
+        if len(spec) != 2 or any(tb[sp[0]].numel() > self.rowlist_min_elems for sp in spec):
+            return
+        rows = [self._sweep_row(*sp) for sp in spec]
+        clip = float(hp.max_grad_norm) if hp.is_clip_norm else 0.0
+        ops.multi("clsr_tables_reg_multi" + self._th, ops.TableDesc, rows, float(hp.embed_l2), float(hp.embed_l1), self.ucount,
+                  self.losses[1:])
+        ops.multi("clsr_tables_adam_multi" + self._th, ops.TableDesc, rows, clip, self.adam_state, 0.9, 0.999, 1e-8, self.lazy)
+        self._updated_early = {sp[0] for sp in spec}
+
     def _apply_updates(self):
         hp = self.hp
         ss = self.sumsq_tab
@@ -2774,7 +2807,8 @@ class CLSRNet(object):
         lists, self._early_lists = self._early_lists, None
         if lists is None:
             lists = {k: self._involved_list(k) for k, t in tb.items() if t.numel() > self.rowlist_min_elems}
-        spec = self._update_spec()
+        done_early, self._updated_early = self._updated_early, set()
+        spec = [sp for sp in self._update_spec() if sp[0] not in done_early]
         sweep = []
         for key, partner, slot, dscale, dloss_scale, dloss, base, nsum in spec:
             V, C = tb[key].shape

@@ -39,6 +39,7 @@ VARIANTS = [
     ("fp32", dict(rnn_products="fp32", rnn_fused_proj=False, rnn_act_tiled=False)),   # CLSR_RNN_PRODUCTS=fp32
     ("fp32", dict(rnn_fused_proj=False)),                # CLSR_NO_RNN_FUSED_PROJ=1: projection GEMM in front of the recurrences
     ("fp32", dict(enc_x6=True)),                         # CLSR_ENC_BWD=x6
+    ("fp32", dict(early_user_update=False)),             # CLSR_NO_EARLY_USER_UPDATE=1: all four tables updated by the sweep at the end of the step
     ("fp32", dict(fold_hist_shares=False)),              # CLSR_NO_FOLD_SHARES=1: long-term d(hist) + prologue shares added by the segmented sums
     ("fp32", dict(heads_fused=False)),                   # CLSR_NO_HEADS_FUSED=1: the launch chain of the row-level heads
     ("fp32", dict(overlap=False)),                       # CLSR_NO_OVERLAP=1: one stream
