@@ -726,8 +726,8 @@ def main():
                             traffic=213.5e6, traffic_source="counters in KiB; profiles/r06_gather_pmc_WRITE_SIZE.csv + r06_gather_pmc_FETCH_SIZE.csv, the 23 catalogue "
                                                             "dispatches over three rotating id sets (WRITE_SIZE 109.05 MB + 2 x FETCH_SIZE 52.25 MB = 1.01 x the "
                                                             "algorithmic bytes; kernel trace of the same command: profiles/r06_gather_hist_fwd_kernel_trace.md, avg 40.9 us)",
-                            in_step_us=35.4, in_step_source="profiles/r06_cat_timeline.txt (rocprofv3 trace of the catalogue step: the gather "
-                                                            "dispatch at t = 13.9 us, behind ~9.5 ms of other traffic since the previous step's gather)",
+                            in_step_us=36.4, in_step_source="profiles/r06_cat_timeline.txt (rocprofv3 trace of the catalogue step: the gather "
+                                                            "dispatch at t = 13.4 us, behind ~9.4 ms of other traffic since the previous step's gather)",
                             cache_resident_at_benchmarked_config=cache_resident)
                 try:
                     w5.step()          # (sorted id lists / gradient buffers of the step exist)
