@@ -23,6 +23,27 @@
 #define BN_CHAIN_PRIO() __builtin_amdgcn_s_setprio(3)
 #endif
 
+// column c of the [nparts][2][C] partial sums, over the partials: one wave, four partial rows per lane in flight, the lanes'
+// sums combined by a wave shuffle reduction (a fixed order: deterministic)
+__device__ __forceinline__ void bn_wave_sums(const double* __restrict__ partial, int nparts, int C, int c, double& s0,
+                                             double& s1) {
+  double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int p0 = threadIdx.x; p0 < nparts; p0 += 4 * 64) {
+    double x[4], y[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + 64 * u, pc = p < nparts ? p : 0;
+      x[u] = partial[((long)pc * 2 + 0) * C + c];
+      y[u] = partial[((long)pc * 2 + 1) * C + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (p0 + 64 * u < nparts) { a[u] += x[u]; b[u] += y[u]; }
+  }
+  s0 = wave_sum_d((a[0] + a[1]) + (a[2] + a[3]));
+  s1 = wave_sum_d((b[0] + b[1]) + (b[2] + b[3]));
+}
+
 // stats_partial: [nparts][2][C] doubles (column sums, column sums of squares).
 // outputs: scale, shift (always); mean, invstd (saved for backward); moving stats updated in place
 // when training.
@@ -32,19 +53,16 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats_partial, int
                                    float* __restrict__ moving_var, float momentum, float eps,
                                    int training, float* __restrict__ scale, float* __restrict__ shift,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out) {
-  // one 256-thread block per feature (on the critical path of every BN layer: ~1000 partials, 4 per thread)
+  // ONE WAVE per feature and NO LDS (on the critical path of every BN layer: ~1000 partials, 16 per lane, four loads in
+  // flight per sum): the launches run beside kernels whose workgroups own their CU's whole LDS (weight images of the
+  // attention kernels, the fused encoder tail) -- a workgroup that asks for 64 bytes of LDS waits for one of THOSE to end
+  // (40-49 us in the step for two of the eight launches of the chain, profiles/r06_fp32_timeline.txt)
   BN_CHAIN_PRIO();
-  __shared__ double red[2][4];
   const int c = blockIdx.x;
   float mean, var;
   if (training) {
     double s = 0.0, q = 0.0;
-    for (int p = threadIdx.x; p < nparts; p += 256) {
-      s += stats_partial[((long)p * 2 + 0) * C + c];
-      q += stats_partial[((long)p * 2 + 1) * C + c];
-    }
-    s = block256_sum_d(s, red[0]);
-    q = block256_sum_d(q, red[1]);
+    bn_wave_sums(stats_partial, nparts, C, c, s, q);
     if (threadIdx.x != 0) return;
     const double m = s / count;
     double v = q / count - m * m;
@@ -73,7 +91,7 @@ extern "C" int clsr_bn_finalize(const double* stats_partial, int nparts, int C, 
                                 void* stream) {
   CLSR_CHECK_ARG(gamma && beta && moving_mean && moving_var && scale && shift && C > 0);
   CLSR_CHECK_ARG(!training || (stats_partial && nparts > 0 && count > 0));
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream,
                      stats_partial, nparts, C, count, gamma, beta, moving_mean, moving_var, momentum,
                      eps, training, scale, shift, mean_out, invstd_out);
   CLSR_CHECK_LAUNCH();
@@ -153,15 +171,9 @@ __global__ void bn_bwd_coef_kernel(const double* __restrict__ partial, int npart
                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
                                    int accumulate, double grad_scale) {
   BN_CHAIN_PRIO();
-  __shared__ double red[2][4];
-  const int c = blockIdx.x;  // one 256-thread block per feature
+  const int c = blockIdx.x;  // one wave per feature, no LDS (see bn_finalize_kernel)
   double s1 = 0.0, s2 = 0.0;
-  for (int p = threadIdx.x; p < nparts; p += 256) {
-    s1 += partial[((long)p * 2 + 0) * C + c];
-    s2 += partial[((long)p * 2 + 1) * C + c];
-  }
-  s1 = block256_sum_d(s1, red[0]);
-  s2 = block256_sum_d(s2, red[1]);
+  bn_wave_sums(partial, nparts, C, c, s1, s2);
   if (threadIdx.x != 0) return;
   const float g = gamma[c], is = invstd[c], mu = mean[c];
   const float c1 = (float)(s1 / count), c2 = (float)(s2 / count);
@@ -186,7 +198,7 @@ extern "C" int clsr_bn_bwd_coef_scaled(const double* partial, int nparts, int C,
                                        float* coef, float* dgamma, float* dbeta, int accumulate,
                                        double grad_scale, void* stream) {
   CLSR_CHECK_ARG(partial && gamma && mean && invstd && coef && dgamma && dbeta && nparts > 0 && C > 0);
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream,
                      partial, nparts, C, count, gamma, mean, invstd, coef, dgamma, dbeta, accumulate, grad_scale);
   CLSR_CHECK_LAUNCH();
   return CLSR_OK;
